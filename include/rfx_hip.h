@@ -1,0 +1,244 @@
+/*
+ * rfx_hip.h -- flat device-level C ABI of librfx.so (gfx950 only).
+ *
+ * Everything below this line of the stack is raw pointers + sizes: no obj_p, no torch types, no C++.
+ * Every pointer named d_* is a DEVICE pointer (HBM of the context's GPU); everything else is host memory.
+ * All calls are asynchronous on the context's HIP stream unless the doc says "(syncs)".
+ * Every function returns RFX_OK (0) or a negative RFX_E* code; rfx_hip_last_error() has the text.
+ *
+ * Which reference loop each entry point replaces (paths relative to the RayforceDB tree):
+ *   rfx_hip_filter_aggr ..... core/cmp.c:35-68 + core/logic.c:34-86 + core/ops.c:254-273 (ops_where)
+ *                             + core/rayforce.c:1036-1158 (at_ids gather) + core/math.c:37-44,1785-2045 folds,
+ *                             i.e. the whole `select {aggs} from t where p` pipeline of core/query.c:607-654
+ *   rfx_hip_cmp_mask ........ ray_{eq,ne,lt,gt,le,ge} -> cmp_map, core/cmp.c:335-697 (B8 byte mask result)
+ *   rfx_hip_mask_logic ...... and_op_partial / or_op_partial, core/logic.c:34-86
+ *   rfx_hip_where_* ......... ray_where -> ops_where, core/items.c:1366-1372, core/ops.c:254-273
+ *   rfx_hip_gather .......... at_ids / at_ids_partial, core/rayforce.c:1036-1158
+ *   rfx_hip_scope_i64 ....... index_scope_i64, core/index.c:376-435
+ *   rfx_hip_group_* ......... index_group_i64_scoped (core/index.c:2002-2092), index_group_distribute
+ *                             (core/index.c:1777-1911, core/hash.c:35-148) and AGGR_ITER/AGGR_COLLECT with
+ *                             aggr_{sum,min,max,count,avg,first}_partial (core/aggr.c:73-181,441-560,1078-2063)
+ */
+#ifndef RFX_HIP_H
+#define RFX_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes ---- */
+enum {
+    RFX_OK = 0,
+    RFX_ENODEV = -1,  /* no gfx950 device / HIP runtime unusable */
+    RFX_EINVAL = -2,  /* bad argument (type, op, count, alignment) */
+    RFX_ENOMEM = -3,  /* device allocation failed */
+    RFX_EHIP = -4,    /* a HIP call failed; see rfx_hip_last_error() */
+    RFX_ELIMIT = -5,  /* descriptor exceeds RFX_MAX_* */
+    RFX_ESTATE = -6   /* call sequence error (e.g. where_emit without where_begin) */
+};
+
+/* ---- element types: same numbers as the reference's vector type codes (include/rfx_abi.h) ---- */
+enum { RFX_B8 = 1, RFX_I64 = 5, RFX_F64 = 10 };
+
+/* ---- comparison operators: ray_eq .. ray_ge (core/cmp.c:692-697), scalar rules core/ops.h:76-123 ---- */
+enum { RFX_EQ = 0, RFX_NE = 1, RFX_LT = 2, RFX_GT = 3, RFX_LE = 4, RFX_GE = 5 };
+
+/* ---- how several predicates combine: ray_and / ray_or (core/logic.c:262-264) ---- */
+enum { RFX_AND = 0, RFX_OR = 1 };
+
+/* ---- aggregates ---- */
+enum {
+    RFX_AGG_SUM = 0,   /* ray_sum: null-skipping fold (scalar) / null-sticky (grouped)  */
+    RFX_AGG_MIN = 1,   /* ray_min                                                        */
+    RFX_AGG_MAX = 2,   /* ray_max                                                        */
+    RFX_AGG_COUNT = 3, /* ray_count: counts every selected row, nulls included           */
+    RFX_AGG_AVG = 4,   /* ray_avg: sum / count_non_null as f64                           */
+    RFX_AGG_FIRST = 5  /* ray_first / aggr_first: value at the first selected row        */
+};
+
+#define RFX_MAX_PREDS 8
+#define RFX_MAX_AGGS 8
+#define RFX_MAX_COLS 8 /* distinct columns one fused launch may read */
+
+/* One comparison `col OP rhs`.  rhs is an atom (d_rhs_col == NULL, value in rhs_i / rhs_f according to
+ * rhs_type) or a second column of the same length (d_rhs_col != NULL).  i64 (x) f64 promotes the i64 side
+ * to f64 with null -> NaN exactly as core/cmp.c:197-198 + core/ops.h:250 do. */
+typedef struct rfx_pred {
+    const void *d_col;
+    const void *d_rhs_col;
+    int32_t col_type; /* RFX_I64 | RFX_F64 */
+    int32_t rhs_type; /* RFX_I64 | RFX_F64 */
+    int32_t op;       /* RFX_EQ .. RFX_GE  */
+    int32_t _pad;
+    union {
+        int64_t rhs_i;
+        double rhs_f;
+    };
+} rfx_pred_t;
+
+typedef struct rfx_agg {
+    const void *d_col; /* may be NULL for RFX_AGG_COUNT */
+    int32_t col_type;  /* RFX_I64 | RFX_F64 */
+    int32_t kind;      /* RFX_AGG_*         */
+} rfx_agg_t;
+
+/* Mergeable partial state of ONE scalar aggregate over ONE row range (one GPU).  64 bytes.  Partials from
+ * several row ranges merge field-wise (isum wrap-add, fsum add, cnt add, ext min/max by kind) -- this is the
+ * payload of the multi-GPU exchange.  rfx_agg_finalize() turns a merged partial into the reference's answer. */
+typedef struct rfx_partial {
+    int64_t isum; /* SUM/AVG over i64: wrapping sum of non-null values                         */
+    double fsum;  /* SUM/AVG over f64 (and AVG over i64 keeps isum): sum of non-NaN values      */
+    int64_t cnt;  /* SUM/AVG/MIN/MAX: number of non-null values; COUNT: number of selected rows */
+    int64_t ext;  /* MIN/MAX: extremum (f64 as raw bits); FIRST: value bits; valid iff cnt > 0  */
+    int64_t pos;  /* FIRST: global row id of the first selected row (INT64_MAX if none)         */
+    int64_t _rsv[3];
+} rfx_partial_t;
+
+/* Final scalar value of an aggregate, typed like the reference's result atom. */
+typedef struct rfx_value {
+    int32_t type; /* RFX_I64 | RFX_F64 */
+    int32_t is_null;
+    union {
+        int64_t i;
+        double f;
+    };
+} rfx_value_t;
+
+typedef struct rfx_ctx rfx_ctx_t; /* opaque: device ordinal, stream, scratch workspace */
+
+/* ---- context / device ---- */
+int rfx_hip_device_count(void);
+const char *rfx_hip_last_error(void);
+const char *rfx_hip_version(void);
+/* stream == NULL: the context creates and owns a non-blocking stream.  Otherwise `stream` is a hipStream_t
+ * owned by the caller (e.g. torch.cuda.current_stream().cuda_stream cast to a pointer). */
+int rfx_hip_ctx_create(int device, void *stream, rfx_ctx_t **out);
+int rfx_hip_ctx_destroy(rfx_ctx_t *ctx);
+int rfx_hip_ctx_sync(rfx_ctx_t *ctx);                 /* (syncs) */
+int rfx_hip_ctx_set_stream(rfx_ctx_t *ctx, void *stream);
+/* Tuning knobs for the streaming kernels (0 = keep default). */
+int rfx_hip_ctx_tune(rfx_ctx_t *ctx, int blocks_per_cu, int flags);
+
+/* ---- plain device memory for C hosts (Python hosts pass torch-owned pointers instead) ---- */
+int rfx_hip_malloc(rfx_ctx_t *ctx, void **d_ptr, size_t bytes);
+int rfx_hip_free(rfx_ctx_t *ctx, void *d_ptr);
+int rfx_hip_h2d(rfx_ctx_t *ctx, void *d_dst, const void *src, size_t bytes); /* (syncs) */
+int rfx_hip_d2h(rfx_ctx_t *ctx, void *dst, const void *d_src, size_t bytes); /* (syncs) */
+int rfx_hip_memset(rfx_ctx_t *ctx, void *d_dst, int byte, size_t bytes);
+
+/* ---- timing on the context's stream (bench.py measures kernels with these HIP events) ---- */
+int rfx_hip_timer_start(rfx_ctx_t *ctx);
+int rfx_hip_timer_stop(rfx_ctx_t *ctx, float *ms); /* (syncs) */
+
+/* ---- synthetic columns: counter-based splitmix64, element r = mix(seed + (r+1)*0x9E3779B97F4A7C15) ----
+ * i64: value % modulus (modulus > 0);  f64: (value >> 11) * 2^-53 in [0,1).  row0 = global id of d_out[0]. */
+int rfx_hip_gen_i64(rfx_ctx_t *ctx, int64_t *d_out, int64_t n, uint64_t seed, int64_t row0, uint64_t modulus);
+int rfx_hip_gen_f64(rfx_ctx_t *ctx, double *d_out, int64_t n, uint64_t seed, int64_t row0);
+
+/* ---- K1/K5: fused filter -> scalar aggregates (one pass over each distinct column) ----
+ * d_out receives nagg + 1 partials: [0..nagg) one per aggregate, [nagg].cnt = number of selected rows.
+ * npred == 0 selects every row.  row0 = global row id of local row 0 (only FIRST uses it). */
+int rfx_hip_filter_aggr(rfx_ctx_t *ctx, const rfx_pred_t *preds, int npred, int logic, const rfx_agg_t *aggs,
+                        int nagg, int64_t nrows, int64_t row0, rfx_partial_t *d_out);
+/* Host-side helpers (pure C, no device work). */
+void rfx_partial_merge(int kind, int col_type, rfx_partial_t *into, const rfx_partial_t *from);
+void rfx_partial_identity(rfx_partial_t *p);
+/* `grouped` = 0: scalar rules of core/math.c (sum skips nulls, empty min/max -> null, avg none -> NaN). */
+int rfx_agg_finalize(int kind, int col_type, const rfx_partial_t *p, rfx_value_t *out);
+/* Convenience: run + copy back + finalize.  (syncs) */
+int rfx_hip_filter_aggr_host(rfx_ctx_t *ctx, const rfx_pred_t *preds, int npred, int logic, const rfx_agg_t *aggs,
+                             int nagg, int64_t nrows, rfx_value_t *values, int64_t *selected);
+
+/* ---- K2: byte masks (API parity with the reference's materialised B8 results) ---- */
+int rfx_hip_cmp_mask(rfx_ctx_t *ctx, const rfx_pred_t *pred, int64_t nrows, int8_t *d_mask);
+/* acc[i] = acc[i] && next[i]  (RFX_AND) / || (RFX_OR); next may be NULL with `scalar` used instead. */
+int rfx_hip_mask_logic(rfx_ctx_t *ctx, int logic, int8_t *d_acc, const int8_t *d_next, int scalar, int64_t nrows);
+
+/* ---- K3: ordered stream compaction ----
+ * where_begin evaluates either the fused predicates (d_mask == NULL) or a byte mask (npred == 0), records a
+ * 1-bit-per-row selection bitmap in the context and returns the number of selected rows.  (syncs)
+ * where_emit then writes the ascending global row ids  row0 + i  of the selected rows into d_ids[0..count). */
+int rfx_hip_where_begin(rfx_ctx_t *ctx, const rfx_pred_t *preds, int npred, int logic, const int8_t *d_mask,
+                        int64_t nrows, int64_t *count);
+int rfx_hip_where_emit(rfx_ctx_t *ctx, int64_t row0, int64_t *d_ids);
+
+/* ---- K4: gather of 8-byte elements: d_out[i] = d_col[d_ids[i]] ---- */
+int rfx_hip_gather(rfx_ctx_t *ctx, const void *d_col, const int64_t *d_ids, int64_t m, void *d_out);
+
+/* ---- K6: key scope (min / max of an i64 column, optionally only over rows passing the predicates) ----
+ * (syncs)  *count = rows seen; min/max undefined when *count == 0. */
+int rfx_hip_scope_i64(rfx_ctx_t *ctx, const int64_t *d_key, const rfx_pred_t *preds, int npred, int logic,
+                      int64_t nrows, int64_t *min, int64_t *max, int64_t *count);
+
+/* ---- K7/K8/K10: dense group-by over [kmin, kmin + range) ----
+ * Table layout (device, caller-visible so that several GPUs can all-reduce them):
+ *   d_first[range]            i64  global row id of the first selected row with that key, INT64_MAX if none (MIN-merge)
+ *   d_acc[a][range]           8-byte accumulators of aggregate a; per kind:
+ *        SUM   i64: wrap sum (SUM-merge) ; f64: IEEE sum, NaN sticky (SUM-merge)
+ *        MIN/MAX  : order-preserving u64 image of the value, see rfx_hip.h notes in DESIGN.md (MIN/MAX-merge)
+ *        COUNT    : i64 rows (SUM-merge)
+ *        AVG      : f64 sum of non-null values cast to f64 (SUM-merge) ; d_cnt[a] holds the non-null count
+ *   d_cnt[a][range]           i64 non-null count (AVG) / null count (SUM over i64: null-sticky flag) (SUM-merge)
+ */
+typedef struct rfx_group_tables {
+    int64_t kmin;
+    int64_t range;
+    int32_t nagg;
+    int32_t _pad;
+    int64_t *d_first;
+    void *d_acc[RFX_MAX_AGGS];
+    int64_t *d_cnt[RFX_MAX_AGGS];
+} rfx_group_tables_t;
+
+/* Bytes a caller must provide for one table set (all arrays are `range` * 8 bytes; this returns how many). */
+int rfx_hip_group_table_arrays(const rfx_agg_t *aggs, int nagg, int *n_arrays);
+/* Set every table to its identity. */
+int rfx_hip_group_tables_init(rfx_ctx_t *ctx, const rfx_agg_t *aggs, const rfx_group_tables_t *t);
+/* One pass over (key, predicate columns, aggregate columns): scatter-aggregate local rows [0,nrows). */
+int rfx_hip_group_dense_accumulate(rfx_ctx_t *ctx, const int64_t *d_key, const rfx_pred_t *preds, int npred,
+                                   int logic, const rfx_agg_t *aggs, int64_t nrows, int64_t row0,
+                                   const rfx_group_tables_t *t);
+/* Rank occupied slots by first row (first-occurrence order, core/index.c:2037-2055).  total_rows = global
+ * number of rows the row ids in d_first range over.  Returns the group count.  (syncs) */
+int rfx_hip_group_rank(rfx_ctx_t *ctx, const rfx_group_tables_t *t, int64_t total_rows, int64_t *ngroups);
+/* Emit, in group order: keys, first row ids, and one result column per aggregate (8-byte elements typed as the
+ * reference types them: sum keeps the input type, avg -> f64, count -> i64, min/max keep the input type).
+ * Any of d_keys / d_first_ids / d_results[a] may be NULL to skip it. */
+int rfx_hip_group_emit(rfx_ctx_t *ctx, const rfx_agg_t *aggs, const rfx_group_tables_t *t, int64_t *d_keys,
+                       int64_t *d_first_ids, void *const *d_results);
+
+/* ---- K9: sparse keys (range > rows): open-addressed table, same table/merge contract keyed by slot ---- */
+typedef struct rfx_hash_tables {
+    int64_t capacity; /* power of two */
+    int32_t nagg;
+    int32_t _pad;
+    int64_t *d_keys;  /* [capacity], empty = RFX_NULL_I64 (as the reference, core/hash.c:35-56) */
+    int64_t *d_first;
+    void *d_acc[RFX_MAX_AGGS];
+    int64_t *d_cnt[RFX_MAX_AGGS];
+} rfx_hash_tables_t;
+int rfx_hip_hash_tables_init(rfx_ctx_t *ctx, const rfx_agg_t *aggs, const rfx_hash_tables_t *t);
+int rfx_hip_group_hash_accumulate(rfx_ctx_t *ctx, const int64_t *d_key, const rfx_pred_t *preds, int npred, int logic,
+                                  const rfx_agg_t *aggs, int64_t nrows, int64_t row0, const rfx_hash_tables_t *t);
+/* Merge another GPU's table (same capacity) into ours: re-inserts its occupied slots. */
+int rfx_hip_hash_tables_merge(rfx_ctx_t *ctx, const rfx_agg_t *aggs, const rfx_hash_tables_t *into,
+                              const rfx_hash_tables_t *from);
+int rfx_hip_hash_rank(rfx_ctx_t *ctx, const rfx_hash_tables_t *t, int64_t total_rows, int64_t *ngroups);
+int rfx_hip_hash_emit(rfx_ctx_t *ctx, const rfx_agg_t *aggs, const rfx_hash_tables_t *t, int64_t *d_keys,
+                      int64_t *d_first_ids, void *const *d_results);
+
+/* ---- per-row group ids (INDEX_TYPE_IDS payload, core/index.c:2069-2089) -- only when a caller wants it ---- */
+int rfx_hip_group_ids_dense(rfx_ctx_t *ctx, const int64_t *d_key, int64_t nrows, const rfx_group_tables_t *t,
+                            int64_t *d_gids);
+
+/* ---- hash primitives pinned against the reference (core/hash.c:530-542, core/hash.h:86-97) ---- */
+int rfx_hip_hash_fnv1a_i64(rfx_ctx_t *ctx, const int64_t *d_in, int64_t n, uint64_t *d_out);
+int rfx_hip_hash_mix_u64(rfx_ctx_t *ctx, const uint64_t *d_in, int64_t n, uint64_t seed_or_prev, uint64_t *d_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RFX_HIP_H */

@@ -1,0 +1,248 @@
+"""oracle/rfo.py -- numpy front-end of the CPU restatement (oracle/librfo.so).
+
+*** TEST INFRASTRUCTURE ONLY ***  Imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg --
+never by rayforce_amd.  It composes the C restatement in the reference's own pass order:
+
+    where:  predicate -> B8 mask (cmp_map) -> and/or in place (logic_map) -> ops_where -> ascending ids
+    no by:  every aggregated column is GATHERED through the ids (filter_collect / at_ids) and the copy is folded
+            (ray_sum_partial's TYPE_MAPFILTER arm, core/math.c:1874-1890)
+    by:     index_scope_i64 -> dense first-occurrence index (range <= rows) or open-addressed hash -> AGGR_ITER partials
+            -> AGGR_COLLECT, group key column = key[filter[first_ids]] (core/query.c:63-75)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+NULL_I64 = np.int64(-(2**63))
+OPS = {"==": 0, "!=": 1, "<": 2, ">": 3, "<=": 4, ">=": 5}
+_I64, _F64 = 5, 10
+
+
+def build() -> str:
+    path = os.path.join(_HERE, "librfo.so")
+    subprocess.run(["make", "-s", "-C", _HERE, "oracle"], check=True)
+    return path
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        path = os.path.join(_HERE, "librfo.so")
+        if not os.path.exists(path):
+            build()
+        _lib = C.CDLL(path)
+        p, i64, f64 = C.c_void_p, C.c_int64, C.c_double
+        sig = {
+            "rfo_set_threads": (None, [C.c_int]), "rfo_get_threads": (C.c_int, []),
+            "rfo_pool_split_by_mem": (i64, [i64, i64, i64]), "rfo_pool_chunk_aligned": (i64, [i64, i64, i64]),
+            "rfo_gen_i64": (None, [p, i64, C.c_uint64, i64, C.c_uint64]), "rfo_gen_f64": (None, [p, i64, C.c_uint64, i64]),
+            "rfo_cmp": (C.c_int, [C.c_int, C.c_int, p, C.c_int, C.c_int, p, C.c_int, i64, p]),
+            "rfo_logic": (None, [C.c_int, p, p, C.c_int, i64]),
+            "rfo_where": (i64, [p, i64, p]), "rfo_at_ids": (None, [p, p, i64, p]),
+            "rfo_sum_i64": (i64, [p, i64]), "rfo_sum_f64": (f64, [p, i64]),
+            "rfo_min_i64": (i64, [p, i64]), "rfo_max_i64": (i64, [p, i64]),
+            "rfo_min_f64": (f64, [p, i64]), "rfo_max_f64": (f64, [p, i64]),
+            "rfo_cnt_i64": (i64, [p, i64]), "rfo_cnt_f64": (i64, [p, i64]),
+            "rfo_avg_i64": (f64, [p, i64]), "rfo_avg_f64": (f64, [p, i64]),
+            "rfo_scope_i64": (None, [p, p, i64, C.POINTER(i64), C.POINTER(i64)]),
+            "rfo_group_dense": (i64, [p, p, i64, i64, i64, p, p, p]),
+            "rfo_group_sparse": (i64, [p, p, i64, p, p]),
+            "rfo_hash_fnv1a": (C.c_uint64, [i64]), "rfo_hash_index_u64": (C.c_uint64, [C.c_uint64, C.c_uint64]),
+            "rfo_aggr_first": (None, [p, p, p, i64, p]),
+        }
+        for fn in ("sum", "min", "max", "count", "avg"):
+            for t in ("i64", "f64"):
+                sig[f"rfo_aggr_{fn}_{t}"] = (None, [p, p, p, i64, i64, p])
+        for name, (res, args) in sig.items():
+            f = getattr(_lib, name)
+            f.restype, f.argtypes = res, args
+    return _lib
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _col(a) -> np.ndarray:
+    a = np.ascontiguousarray(a)
+    if a.dtype not in (np.int64, np.float64):
+        raise TypeError(f"unsupported dtype {a.dtype}")
+    return a
+
+
+def _t(a) -> str:
+    return "i64" if a.dtype == np.int64 else "f64"
+
+
+def set_threads(n: int) -> None:
+    lib().rfo_set_threads(int(n))
+
+
+def gen_i64(n, seed, modulus, row0=0):
+    out = np.empty(n, np.int64)
+    lib().rfo_gen_i64(_ptr(out), n, seed, row0, modulus)
+    return out
+
+
+def gen_f64(n, seed, row0=0):
+    out = np.empty(n, np.float64)
+    lib().rfo_gen_f64(_ptr(out), n, seed, row0)
+    return out
+
+
+# ---------------------------------------------------------------- operators (names of the reference)
+def cmp(op: str, lhs, rhs) -> np.ndarray:
+    """ray_eq..ray_ge: vector (x) atom | atom (x) vector | vector (x) vector -> B8 mask."""
+    def prep(x):
+        if isinstance(x, np.ndarray):
+            return _col(x), 0
+        if x is None:
+            return np.array([NULL_I64], np.int64), 1
+        if isinstance(x, (int, np.integer)):
+            return np.array([x], np.int64), 1
+        return np.array([x], np.float64), 1
+    l, la = prep(lhs)
+    r, ra = prep(rhs)
+    n = len(l) if not la else (len(r) if not ra else 1)
+    if not la and not ra and len(l) != len(r):
+        raise ValueError("length")
+    out = np.empty(n, np.int8)
+    rc = lib().rfo_cmp(OPS[op], _I64 if l.dtype == np.int64 else _F64, _ptr(l), la, _I64 if r.dtype == np.int64 else _F64, _ptr(r), ra, n, _ptr(out))
+    if rc:
+        raise TypeError("type")
+    return out
+
+
+def and_(*masks):
+    acc = np.array(masks[0], np.int8, copy=True)
+    for m in masks[1:]:
+        m = np.ascontiguousarray(m, np.int8)
+        lib().rfo_logic(0, _ptr(acc), _ptr(m), 0, len(acc))
+    return acc
+
+
+def or_(*masks):
+    acc = np.array(masks[0], np.int8, copy=True)
+    for m in masks[1:]:
+        m = np.ascontiguousarray(m, np.int8)
+        lib().rfo_logic(1, _ptr(acc), _ptr(m), 0, len(acc))
+    return acc
+
+
+def where(mask) -> np.ndarray:
+    mask = np.ascontiguousarray(mask, np.int8)
+    n = lib().rfo_where(_ptr(mask), len(mask), None)
+    ids = np.empty(n, np.int64)
+    lib().rfo_where(_ptr(mask), len(mask), _ptr(ids))
+    return ids
+
+
+def at_ids(col, ids):
+    col = _col(col)
+    out = np.empty(len(ids), col.dtype)
+    lib().rfo_at_ids(_ptr(col), _ptr(np.ascontiguousarray(ids, np.int64)), len(ids), _ptr(out))
+    return out
+
+
+def fold(fn: str, col):
+    """Scalar ray_sum / ray_min / ray_max / ray_avg / ray_count of a materialised column.  None = null."""
+    col = _col(col)
+    t, n, L = _t(col), len(col), lib()
+    if fn == "count":
+        return n  # ops_count: length, nulls included (core/misc.c:43-60)
+    if fn == "first":
+        if n == 0:
+            return None if t == "i64" else float("nan")
+        v = col[0]
+        return (None if v == NULL_I64 else int(v)) if t == "i64" else float(v)
+    r = getattr(L, f"rfo_{fn}_{t}")(_ptr(col), n)
+    if fn == "avg" or t == "f64":
+        return float(r)
+    return None if r == NULL_I64 else int(r)
+
+
+def mask_of(where_spec, table) -> np.ndarray:
+    head = where_spec[0]
+    if head in OPS:
+        _, lhs, rhs = where_spec
+        lhs = table[lhs] if isinstance(lhs, str) else lhs
+        rhs = table[rhs] if isinstance(rhs, str) else rhs
+        return cmp(head, lhs, rhs)
+    subs = [mask_of(w, table) for w in where_spec[1:]]
+    return and_(*subs) if head == "and" else or_(*subs)
+
+
+def group_index(key, filter_ids=None):
+    """index_group_i64: returns (gids per selected row, first positions, groups, dense?)."""
+    key = _col(key)
+    L = lib()
+    idx = None if filter_ids is None else np.ascontiguousarray(filter_ids, np.int64)
+    n = len(key) if idx is None else len(idx)
+    if n == 0:
+        return np.empty(0, np.int64), np.empty(0, np.int64), 0, True
+    mn, mx = C.c_int64(), C.c_int64()
+    L.rfo_scope_i64(_ptr(key), _ptr(idx), n, C.byref(mn), C.byref(mx))
+    rng = mx.value - mn.value + 1
+    gids = np.empty(n, np.int64)
+    firsts = np.empty(n, np.int64)
+    if 0 < rng <= n and mn.value != int(NULL_I64):
+        hk = np.empty(rng, np.int64)
+        g = L.rfo_group_dense(_ptr(key), _ptr(idx), n, mn.value, rng, _ptr(hk), _ptr(firsts), _ptr(gids))
+        return gids, firsts[:g].copy(), g, True
+    g = L.rfo_group_sparse(_ptr(key), _ptr(idx), n, _ptr(gids), _ptr(firsts))
+    return gids, firsts[:g].copy(), g, False
+
+
+def aggr(fn: str, col, gids, filter_ids, groups):
+    col = _col(col)
+    t = _t(col)
+    idx = None if filter_ids is None else np.ascontiguousarray(filter_ids, np.int64)
+    out = np.empty(groups, np.float64 if (fn == "avg" or (t == "f64" and fn != "count")) else np.int64)
+    getattr(lib(), f"rfo_aggr_{fn}_{t}")(_ptr(col), _ptr(gids), _ptr(idx), len(gids), groups, _ptr(out))
+    return out
+
+
+def select(query: dict) -> dict:
+    """Same contract as rayforce_amd.Engine.select, numpy in / numpy out."""
+    table = query["from"]
+    where_spec, by = query.get("where"), query.get("by")
+    outs = [(k, v) for k, v in query.items() if k not in ("from", "where", "by", "take")]
+    ids = None
+    if where_spec is not None:
+        ids = where(mask_of(where_spec, table))
+    if by is not None:
+        key = table[by]
+        gids, firsts, groups, _ = group_index(key, ids)
+        pos = firsts if ids is None else ids[firsts]
+        res = {by: _col(key)[pos] if groups else np.empty(0, np.int64)}
+        for name, (fn, col) in outs:
+            if fn == "first":
+                c = _col(table[col])
+                res[name] = c[pos] if groups else np.empty(0, c.dtype)
+            else:
+                c = table[col] if col is not None else key
+                res[name] = aggr(fn, c, gids, ids, groups)
+        return res
+    if outs:
+        res = {}
+        for name, (fn, col) in outs:
+            c = _col(table[col]) if col is not None else _col(next(iter(table.values())))
+            if ids is not None:
+                c = at_ids(c, ids)
+            v = fold(fn, c)
+            f64 = fn == "avg" or (fn != "count" and c.dtype == np.float64)
+            if v is None:
+                v = float("nan") if f64 else NULL_I64
+            res[name] = np.array([v], np.float64 if f64 else np.int64)
+        return res
+    if ids is None:
+        return dict(table)
+    return {name: at_ids(col, ids) for name, col in table.items()}

@@ -1,0 +1,148 @@
+"""ctypes binding of librfx.so -- declarations mirror include/rfx_hip.h one to one."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+RFX_OK = 0
+RFX_B8, RFX_I64, RFX_F64 = 1, 5, 10
+RFX_EQ, RFX_NE, RFX_LT, RFX_GT, RFX_LE, RFX_GE = range(6)
+RFX_AND, RFX_OR = 0, 1
+RFX_AGG_SUM, RFX_AGG_MIN, RFX_AGG_MAX, RFX_AGG_COUNT, RFX_AGG_AVG, RFX_AGG_FIRST = range(6)
+RFX_MAX_PREDS = RFX_MAX_AGGS = RFX_MAX_COLS = 8
+NULL_I64 = -(2**63)
+INF_I64 = 2**63 - 1
+
+OPS = {"==": RFX_EQ, "!=": RFX_NE, "<": RFX_LT, ">": RFX_GT, "<=": RFX_LE, ">=": RFX_GE}
+AGGS = {"sum": RFX_AGG_SUM, "min": RFX_AGG_MIN, "max": RFX_AGG_MAX, "count": RFX_AGG_COUNT, "avg": RFX_AGG_AVG,
+        "first": RFX_AGG_FIRST}
+
+
+class RfxError(RuntimeError):
+    pass
+
+
+class _RhsUnion(C.Union):
+    _fields_ = [("rhs_i", C.c_int64), ("rhs_f", C.c_double)]
+
+
+class Pred(C.Structure):
+    _anonymous_ = ("u",)
+    _fields_ = [("d_col", C.c_void_p), ("d_rhs_col", C.c_void_p), ("col_type", C.c_int32), ("rhs_type", C.c_int32),
+                ("op", C.c_int32), ("_pad", C.c_int32), ("u", _RhsUnion)]
+
+
+class Agg(C.Structure):
+    _fields_ = [("d_col", C.c_void_p), ("col_type", C.c_int32), ("kind", C.c_int32)]
+
+
+class Partial(C.Structure):
+    _fields_ = [("isum", C.c_int64), ("fsum", C.c_double), ("cnt", C.c_int64), ("ext", C.c_int64), ("pos", C.c_int64),
+                ("_rsv", C.c_int64 * 3)]
+
+
+class _ValUnion(C.Union):
+    _fields_ = [("i", C.c_int64), ("f", C.c_double)]
+
+
+class Value(C.Structure):
+    _anonymous_ = ("u",)
+    _fields_ = [("type", C.c_int32), ("is_null", C.c_int32), ("u", _ValUnion)]
+
+
+class GroupTables(C.Structure):
+    _fields_ = [("kmin", C.c_int64), ("range", C.c_int64), ("nagg", C.c_int32), ("_pad", C.c_int32),
+                ("d_first", C.c_void_p), ("d_acc", C.c_void_p * RFX_MAX_AGGS), ("d_cnt", C.c_void_p * RFX_MAX_AGGS)]
+
+
+class HashTables(C.Structure):
+    _fields_ = [("capacity", C.c_int64), ("nagg", C.c_int32), ("_pad", C.c_int32), ("d_keys", C.c_void_p),
+                ("d_first", C.c_void_p), ("d_acc", C.c_void_p * RFX_MAX_AGGS), ("d_cnt", C.c_void_p * RFX_MAX_AGGS)]
+
+
+assert C.sizeof(Pred) == 40 and C.sizeof(Agg) == 16 and C.sizeof(Partial) == 64 and C.sizeof(Value) == 16
+
+_P = C.POINTER
+_ctx = C.c_void_p
+
+# name -> (restype, argtypes).  EVERY symbol include/rfx_hip.h declares is listed here; the CPU test-suite checks
+# that the built library exports all of them.
+PROTOTYPES = {
+    "rfx_hip_device_count": (C.c_int, []),
+    "rfx_hip_last_error": (C.c_char_p, []),
+    "rfx_hip_version": (C.c_char_p, []),
+    "rfx_hip_ctx_create": (C.c_int, [C.c_int, C.c_void_p, _P(_ctx)]),
+    "rfx_hip_ctx_destroy": (C.c_int, [_ctx]),
+    "rfx_hip_ctx_sync": (C.c_int, [_ctx]),
+    "rfx_hip_ctx_set_stream": (C.c_int, [_ctx, C.c_void_p]),
+    "rfx_hip_ctx_tune": (C.c_int, [_ctx, C.c_int, C.c_int]),
+    "rfx_hip_malloc": (C.c_int, [_ctx, _P(C.c_void_p), C.c_size_t]),
+    "rfx_hip_free": (C.c_int, [_ctx, C.c_void_p]),
+    "rfx_hip_h2d": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "rfx_hip_d2h": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "rfx_hip_memset": (C.c_int, [_ctx, C.c_void_p, C.c_int, C.c_size_t]),
+    "rfx_hip_timer_start": (C.c_int, [_ctx]),
+    "rfx_hip_timer_stop": (C.c_int, [_ctx, _P(C.c_float)]),
+    "rfx_hip_gen_i64": (C.c_int, [_ctx, C.c_void_p, C.c_int64, C.c_uint64, C.c_int64, C.c_uint64]),
+    "rfx_hip_gen_f64": (C.c_int, [_ctx, C.c_void_p, C.c_int64, C.c_uint64, C.c_int64]),
+    "rfx_hip_filter_aggr": (C.c_int, [_ctx, _P(Pred), C.c_int, C.c_int, _P(Agg), C.c_int, C.c_int64, C.c_int64, C.c_void_p]),
+    "rfx_partial_merge": (None, [C.c_int, C.c_int, _P(Partial), _P(Partial)]),
+    "rfx_partial_identity": (None, [_P(Partial)]),
+    "rfx_agg_finalize": (C.c_int, [C.c_int, C.c_int, _P(Partial), _P(Value)]),
+    "rfx_hip_filter_aggr_host": (C.c_int, [_ctx, _P(Pred), C.c_int, C.c_int, _P(Agg), C.c_int, C.c_int64, _P(Value), _P(C.c_int64)]),
+    "rfx_hip_cmp_mask": (C.c_int, [_ctx, _P(Pred), C.c_int64, C.c_void_p]),
+    "rfx_hip_mask_logic": (C.c_int, [_ctx, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int64]),
+    "rfx_hip_where_begin": (C.c_int, [_ctx, _P(Pred), C.c_int, C.c_int, C.c_void_p, C.c_int64, _P(C.c_int64)]),
+    "rfx_hip_where_emit": (C.c_int, [_ctx, C.c_int64, C.c_void_p]),
+    "rfx_hip_gather": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "rfx_hip_scope_i64": (C.c_int, [_ctx, C.c_void_p, _P(Pred), C.c_int, C.c_int, C.c_int64, _P(C.c_int64), _P(C.c_int64), _P(C.c_int64)]),
+    "rfx_hip_group_table_arrays": (C.c_int, [_P(Agg), C.c_int, _P(C.c_int)]),
+    "rfx_hip_group_tables_init": (C.c_int, [_ctx, _P(Agg), _P(GroupTables)]),
+    "rfx_hip_group_dense_accumulate": (C.c_int, [_ctx, C.c_void_p, _P(Pred), C.c_int, C.c_int, _P(Agg), C.c_int64, C.c_int64, _P(GroupTables)]),
+    "rfx_hip_group_rank": (C.c_int, [_ctx, _P(GroupTables), C.c_int64, _P(C.c_int64)]),
+    "rfx_hip_group_emit": (C.c_int, [_ctx, _P(Agg), _P(GroupTables), C.c_void_p, C.c_void_p, _P(C.c_void_p)]),
+    "rfx_hip_hash_tables_init": (C.c_int, [_ctx, _P(Agg), _P(HashTables)]),
+    "rfx_hip_group_hash_accumulate": (C.c_int, [_ctx, C.c_void_p, _P(Pred), C.c_int, C.c_int, _P(Agg), C.c_int64, C.c_int64, _P(HashTables)]),
+    "rfx_hip_hash_tables_merge": (C.c_int, [_ctx, _P(Agg), _P(HashTables), _P(HashTables)]),
+    "rfx_hip_hash_rank": (C.c_int, [_ctx, _P(HashTables), C.c_int64, _P(C.c_int64)]),
+    "rfx_hip_hash_emit": (C.c_int, [_ctx, _P(Agg), _P(HashTables), C.c_void_p, C.c_void_p, _P(C.c_void_p)]),
+    "rfx_hip_group_ids_dense": (C.c_int, [_ctx, C.c_void_p, C.c_int64, _P(GroupTables), C.c_void_p]),
+    "rfx_hip_hash_fnv1a_i64": (C.c_int, [_ctx, C.c_void_p, C.c_int64, C.c_void_p]),
+    "rfx_hip_hash_mix_u64": (C.c_int, [_ctx, C.c_void_p, C.c_int64, C.c_uint64, C.c_void_p]),
+}
+
+_LIB = None
+
+
+def lib_path() -> str:
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "librfx.so")
+
+
+def load_library() -> C.CDLL:
+    """Load librfx.so or raise -- there is deliberately no fallback implementation."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = lib_path()
+    if not os.path.exists(path):
+        raise RfxError(f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                       f"(or `make -C rayforce_amd/csrc -j`). The MI355X path has no CPU fallback.")
+    try:
+        lib = C.CDLL(path, mode=C.RTLD_GLOBAL)
+    except OSError as e:  # e.g. libamdhip64 missing
+        raise RfxError(f"cannot load {path}: {e}") from e
+    for name, (res, args) in PROTOTYPES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise RfxError(f"{path} does not export {name} (stale build?)") from e
+        fn.restype = res
+        fn.argtypes = args
+    _LIB = lib
+    return lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != RFX_OK:
+        msg = load_library().rfx_hip_last_error().decode(errors="replace")
+        raise RfxError(f"{what or 'librfx'} failed with code {rc}: {msg}")

@@ -1,0 +1,179 @@
+// rfx_common.hpp -- internal (not part of the C ABI): context layout, launch plan, device-side scalar rules.
+// gfx950 / wave64 only.  The scalar rules restate core/ops.h:63-197 of the reference (cited per function).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include "../../include/rfx_hip.h"
+
+#define RFX_WAVE 64
+#define RFX_BLOCK 256 /* 4 waves: one per SIMD of a CU */
+#define RFX_NULL_I64_D ((int64_t)0x8000000000000000LL)
+#define RFX_INF_I64_D ((int64_t)0x7FFFFFFFFFFFFFFFLL)
+#define RFX_NAN_BITS 0x7FF8000000000000ULL
+#define RFX_PINF_BITS 0x7FF0000000000000ULL
+
+typedef unsigned long long u64;
+typedef long long i64;
+
+void rfx_set_error(const char *fmt, ...);
+
+#define RFX_HIP_CHECK(expr)                                                                       \
+    do {                                                                                          \
+        hipError_t _e = (expr);                                                                   \
+        if (_e != hipSuccess) {                                                                   \
+            rfx_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e));   \
+            return (_e == hipErrorOutOfMemory) ? RFX_ENOMEM : RFX_EHIP;                           \
+        }                                                                                         \
+    } while (0)
+
+#define RFX_REQUIRE(cond, code, msg)                      \
+    do {                                                  \
+        if (!(cond)) {                                    \
+            rfx_set_error("%s: %s", __func__, msg);       \
+            return (code);                                \
+        }                                                 \
+    } while (0)
+
+struct rfx_ctx {
+    int device;
+    hipStream_t stream;
+    bool own_stream;
+    int num_cus;
+    int blocks_per_cu; // streaming-kernel grid = num_cus * blocks_per_cu
+    int flags;
+    hipEvent_t ev0, ev1;
+    // scratch: per-block partials of the fused reductions
+    void *d_ws;
+    size_t ws_bytes;
+    // pinned host staging for small read-backs
+    void *h_pin;
+    size_t pin_bytes;
+    // ordered-compaction state (where_begin -> where_emit, group rank -> emit)
+    u64 *d_bitmap;      // 1 bit per row
+    size_t bitmap_cap;  // in 64-bit words
+    i64 *d_blksum;      // per 2048-row block: popcount, then exclusive prefix
+    size_t blksum_cap;  // entries
+    i64 where_n;        // rows covered by the bitmap
+    i64 where_count;    // selected rows
+    i64 rank_rows;      // group rank: total rows of the bitmap
+    i64 rank_groups;
+    i64 *d_gid;         // group rank: slot -> group id (or -1)
+    size_t gid_cap;
+};
+
+int rfx_ws_reserve(rfx_ctx *ctx, size_t bytes);
+int rfx_bitmap_reserve(rfx_ctx *ctx, i64 nrows);
+int rfx_gid_reserve(rfx_ctx *ctx, i64 slots);
+static inline int rfx_grid(const rfx_ctx *ctx) { return ctx->num_cus * ctx->blocks_per_cu; }
+
+// ------------------------------------------------------------------------------------------------
+// Launch plan: what one fused pass reads and computes.  Passed to kernels by value (kernarg segment).
+// ------------------------------------------------------------------------------------------------
+struct PlanPred {
+    int col;      // index into Plan::cols
+    int rhs_col;  // -1: atom in rhs_bits ; else index into Plan::cols
+    int op;       // RFX_EQ..RFX_GE
+    int dom_f64;  // 1: compare as f64 (core/cmp.c: mt = f64), 0: as i64
+    int lhs_cvt;  // 1: column is i64 but domain is f64 -> i64_to_f64 (null -> NaN), core/ops.h:250
+    int rhs_cvt;  // same for a vector rhs
+    u64 rhs_bits; // atom, already promoted to the comparison domain on the host
+};
+struct PlanAgg {
+    int col;  // index into Plan::cols (-1 for COUNT without a column)
+    int f64;  // column element type is f64
+    int kind; // RFX_AGG_* ; -1 = unused slot
+    int _pad;
+};
+struct Plan {
+    int ncols, npred, nagg, logic;
+    const u64 *cols[RFX_MAX_COLS];
+    PlanPred preds[RFX_MAX_PREDS];
+    PlanAgg aggs[RFX_MAX_AGGS];
+    i64 nrows;
+    i64 row0;
+};
+
+// Build a Plan from the public descriptors (dedupes columns, promotes atoms).  Returns RFX_OK or an error.
+int rfx_plan_build(Plan *P, const rfx_pred_t *preds, int npred, int logic, const rfx_agg_t *aggs, int nagg,
+                   const void *extra_col, int *extra_idx, i64 nrows, i64 row0);
+
+// ------------------------------------------------------------------------------------------------
+// Device-side scalar rules
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double rfx_as_f64(u64 b) { return __longlong_as_double((i64)b); }
+__device__ __forceinline__ u64 rfx_as_u64(double d) { return (u64)__double_as_longlong(d); }
+
+// ISNANF64 -- bit-pattern test, core/ops.h:63-70
+__device__ __forceinline__ bool rfx_isnan_bits(u64 u) {
+    return (u & 0x7FF0000000000000ULL) == 0x7FF0000000000000ULL && (u & 0x000FFFFFFFFFFFFFULL) != 0;
+}
+// i64_to_f64 -- core/ops.h:250 : null -> NaN
+__device__ __forceinline__ u64 rfx_i64_to_f64_bits(u64 x) {
+    return ((i64)x == RFX_NULL_I64_D) ? RFX_NAN_BITS : rfx_as_u64((double)(i64)x);
+}
+
+// {EQ,NE,LT,GT,LE,GE}I64 -- core/ops.h:80,88,96,104,112,120 : plain signed compares, no null test
+__device__ __forceinline__ bool rfx_cmp_i64(int op, i64 x, i64 y) {
+    switch (op) {
+        case RFX_EQ: return x == y;
+        case RFX_NE: return x != y;
+        case RFX_LT: return x < y;
+        case RFX_GT: return x > y;
+        case RFX_LE: return x <= y;
+        default: return x >= y;
+    }
+}
+// {EQ,NE,LT,GT,LE,GE}F64 -- core/ops.h:81,89,97,105,113,121 : NaN is the smallest value, NaN == NaN
+__device__ __forceinline__ bool rfx_ltf64(u64 xb, u64 yb) {
+    bool xn = rfx_isnan_bits(xb), yn = rfx_isnan_bits(yb);
+    return xn ? !yn : (yn ? false : rfx_as_f64(xb) < rfx_as_f64(yb));
+}
+__device__ __forceinline__ bool rfx_gtf64(u64 xb, u64 yb) {
+    bool xn = rfx_isnan_bits(xb), yn = rfx_isnan_bits(yb);
+    return yn ? !xn : (xn ? false : rfx_as_f64(xb) > rfx_as_f64(yb));
+}
+__device__ __forceinline__ bool rfx_eqf64(u64 xb, u64 yb) {
+    bool xn = rfx_isnan_bits(xb), yn = rfx_isnan_bits(yb);
+    return xn ? yn : (yn ? false : rfx_as_f64(xb) == rfx_as_f64(yb));
+}
+__device__ __forceinline__ bool rfx_cmp_f64(int op, u64 x, u64 y) {
+    switch (op) {
+        case RFX_EQ: return rfx_eqf64(x, y);
+        case RFX_NE: return !rfx_eqf64(x, y);
+        case RFX_LT: return rfx_ltf64(x, y);
+        case RFX_GT: return rfx_gtf64(x, y);
+        case RFX_LE: return !rfx_gtf64(x, y);
+        default: return !rfx_ltf64(x, y);
+    }
+}
+
+// Order-preserving image of a non-NaN f64 in signed-i64 order (so integer min/max == IEEE min/max, with
+// -0.0 < +0.0 as a deterministic tie-break the reference leaves to summation order).
+__device__ __host__ __forceinline__ i64 rfx_f64_to_ord(u64 b) { return (i64)(b ^ (((i64)b >> 63) & 0x7FFFFFFFFFFFFFFFULL)); }
+__device__ __host__ __forceinline__ u64 rfx_ord_to_f64(i64 o) { return (u64)(o ^ ((o >> 63) & 0x7FFFFFFFFFFFFFFFLL)); }
+
+// splitmix64 output for counter value `state`
+__device__ __host__ __forceinline__ u64 rfx_splitmix_mix(u64 z) {
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+
+// 64-bit wave shuffles
+__device__ __forceinline__ u64 rfx_shfl_xor_u64(u64 v, int m) {
+    unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
+    lo = __shfl_xor(lo, m, 64);
+    hi = __shfl_xor(hi, m, 64);
+    return ((u64)hi << 32) | lo;
+}
+
+// 16-byte streaming load of two consecutive 8-byte elements
+struct __attribute__((aligned(16))) u64x2 { u64 x, y; };
+__device__ __forceinline__ u64x2 rfx_ld2(const u64 *p) {
+    typedef u64 v2 __attribute__((ext_vector_type(2)));
+    v2 t = __builtin_nontemporal_load((const v2 *)p);
+    u64x2 r; r.x = t.x; r.y = t.y;
+    return r;
+}

@@ -1,0 +1,290 @@
+// rfx_ctx.hip -- context, device memory, timers, synthetic-column generator, plan builder.
+#include "rfx_common.hpp"
+#include <stdarg.h>
+#include <stdlib.h>
+
+static thread_local char g_err[512] = "";
+
+void rfx_set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char *rfx_hip_last_error(void) { return g_err; }
+extern "C" const char *rfx_hip_version(void) { return "rfx-hip 0.1 (gfx950)"; }
+
+extern "C" int rfx_hip_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" int rfx_hip_ctx_create(int device, void *stream, rfx_ctx_t **out) {
+    RFX_REQUIRE(out != NULL, RFX_EINVAL, "out is NULL");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        rfx_set_error("no HIP device visible (hipGetDeviceCount failed or returned 0) -- the MI355X path has no CPU fallback");
+        return RFX_ENODEV;
+    }
+    RFX_REQUIRE(device >= 0 && device < n, RFX_EINVAL, "device ordinal out of range");
+    RFX_HIP_CHECK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    RFX_HIP_CHECK(hipGetDeviceProperties(&prop, device));
+    rfx_ctx *c = (rfx_ctx *)calloc(1, sizeof(rfx_ctx));
+    RFX_REQUIRE(c != NULL, RFX_ENOMEM, "host calloc failed");
+    c->device = device;
+    c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    c->blocks_per_cu = 2; // tools/probe_hw: 2 workgroups per CU streams fastest (7.0 TB/s)
+    if (stream) {
+        c->stream = (hipStream_t)stream;
+        c->own_stream = false;
+    } else {
+        RFX_HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        c->own_stream = true;
+    }
+    RFX_HIP_CHECK(hipEventCreate(&c->ev0));
+    RFX_HIP_CHECK(hipEventCreate(&c->ev1));
+    c->pin_bytes = 1 << 16;
+    RFX_HIP_CHECK(hipHostMalloc(&c->h_pin, c->pin_bytes, hipHostMallocDefault));
+    int rc = rfx_ws_reserve(c, 4u << 20);
+    if (rc != RFX_OK) return rc;
+    *out = c;
+    return RFX_OK;
+}
+
+extern "C" int rfx_hip_ctx_destroy(rfx_ctx_t *c) {
+    if (!c) return RFX_OK;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    if (c->d_ws) (void)hipFree(c->d_ws);
+    if (c->d_bitmap) (void)hipFree(c->d_bitmap);
+    if (c->d_blksum) (void)hipFree(c->d_blksum);
+    if (c->d_gid) (void)hipFree(c->d_gid);
+    if (c->h_pin) (void)hipHostFree(c->h_pin);
+    (void)hipEventDestroy(c->ev0);
+    (void)hipEventDestroy(c->ev1);
+    if (c->own_stream) (void)hipStreamDestroy(c->stream);
+    free(c);
+    return RFX_OK;
+}
+
+extern "C" int rfx_hip_ctx_sync(rfx_ctx_t *c) {
+    RFX_REQUIRE(c, RFX_EINVAL, "ctx is NULL");
+    RFX_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return RFX_OK;
+}
+
+extern "C" int rfx_hip_ctx_set_stream(rfx_ctx_t *c, void *stream) {
+    RFX_REQUIRE(c, RFX_EINVAL, "ctx is NULL");
+    RFX_REQUIRE(stream, RFX_EINVAL, "stream is NULL");
+    if (c->own_stream) {
+        (void)hipStreamSynchronize(c->stream);
+        (void)hipStreamDestroy(c->stream);
+        c->own_stream = false;
+    }
+    c->stream = (hipStream_t)stream;
+    return RFX_OK;
+}
+
+extern "C" int rfx_hip_ctx_tune(rfx_ctx_t *c, int blocks_per_cu, int flags) {
+    RFX_REQUIRE(c, RFX_EINVAL, "ctx is NULL");
+    if (blocks_per_cu > 0) {
+        RFX_REQUIRE(blocks_per_cu <= 64, RFX_EINVAL, "blocks_per_cu > 64");
+        c->blocks_per_cu = blocks_per_cu;
+    }
+    c->flags = flags;
+    return RFX_OK;
+}
+
+int rfx_ws_reserve(rfx_ctx *c, size_t bytes) {
+    if (c->ws_bytes >= bytes) return RFX_OK;
+    RFX_HIP_CHECK(hipStreamSynchronize(c->stream));
+    if (c->d_ws) RFX_HIP_CHECK(hipFree(c->d_ws));
+    c->d_ws = NULL;
+    c->ws_bytes = 0;
+    RFX_HIP_CHECK(hipMalloc(&c->d_ws, bytes));
+    c->ws_bytes = bytes;
+    return RFX_OK;
+}
+
+int rfx_bitmap_reserve(rfx_ctx *c, i64 nrows) {
+    size_t words = (size_t)((nrows + 63) / 64) + 64;
+    size_t blocks = (size_t)((nrows + 2047) / 2048) + 2;
+    if (c->bitmap_cap < words) {
+        RFX_HIP_CHECK(hipStreamSynchronize(c->stream));
+        if (c->d_bitmap) RFX_HIP_CHECK(hipFree(c->d_bitmap));
+        c->d_bitmap = NULL;
+        c->bitmap_cap = 0;
+        RFX_HIP_CHECK(hipMalloc((void **)&c->d_bitmap, words * 8));
+        c->bitmap_cap = words;
+    }
+    if (c->blksum_cap < blocks) {
+        RFX_HIP_CHECK(hipStreamSynchronize(c->stream));
+        if (c->d_blksum) RFX_HIP_CHECK(hipFree(c->d_blksum));
+        c->d_blksum = NULL;
+        c->blksum_cap = 0;
+        RFX_HIP_CHECK(hipMalloc((void **)&c->d_blksum, blocks * 8));
+        c->blksum_cap = blocks;
+    }
+    return RFX_OK;
+}
+
+int rfx_gid_reserve(rfx_ctx *c, i64 slots) {
+    if (c->gid_cap >= (size_t)slots) return RFX_OK;
+    RFX_HIP_CHECK(hipStreamSynchronize(c->stream));
+    if (c->d_gid) RFX_HIP_CHECK(hipFree(c->d_gid));
+    c->d_gid = NULL;
+    c->gid_cap = 0;
+    RFX_HIP_CHECK(hipMalloc((void **)&c->d_gid, (size_t)slots * 8));
+    c->gid_cap = (size_t)slots;
+    return RFX_OK;
+}
+
+// ---- plain memory ----
+extern "C" int rfx_hip_malloc(rfx_ctx_t *c, void **d_ptr, size_t bytes) {
+    RFX_REQUIRE(c && d_ptr, RFX_EINVAL, "NULL argument");
+    RFX_HIP_CHECK(hipSetDevice(c->device));
+    RFX_HIP_CHECK(hipMalloc(d_ptr, bytes ? bytes : 8));
+    return RFX_OK;
+}
+extern "C" int rfx_hip_free(rfx_ctx_t *c, void *d_ptr) {
+    RFX_REQUIRE(c, RFX_EINVAL, "ctx is NULL");
+    if (d_ptr) RFX_HIP_CHECK(hipFree(d_ptr));
+    return RFX_OK;
+}
+extern "C" int rfx_hip_h2d(rfx_ctx_t *c, void *d_dst, const void *src, size_t bytes) {
+    RFX_REQUIRE(c, RFX_EINVAL, "ctx is NULL");
+    if (!bytes) return RFX_OK;
+    RFX_HIP_CHECK(hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+    RFX_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return RFX_OK;
+}
+extern "C" int rfx_hip_d2h(rfx_ctx_t *c, void *dst, const void *d_src, size_t bytes) {
+    RFX_REQUIRE(c, RFX_EINVAL, "ctx is NULL");
+    if (!bytes) return RFX_OK;
+    RFX_HIP_CHECK(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, c->stream));
+    RFX_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return RFX_OK;
+}
+extern "C" int rfx_hip_memset(rfx_ctx_t *c, void *d_dst, int byte, size_t bytes) {
+    RFX_REQUIRE(c, RFX_EINVAL, "ctx is NULL");
+    if (!bytes) return RFX_OK;
+    RFX_HIP_CHECK(hipMemsetAsync(d_dst, byte, bytes, c->stream));
+    return RFX_OK;
+}
+
+// ---- timers ----
+extern "C" int rfx_hip_timer_start(rfx_ctx_t *c) {
+    RFX_REQUIRE(c, RFX_EINVAL, "ctx is NULL");
+    RFX_HIP_CHECK(hipEventRecord(c->ev0, c->stream));
+    return RFX_OK;
+}
+extern "C" int rfx_hip_timer_stop(rfx_ctx_t *c, float *ms) {
+    RFX_REQUIRE(c && ms, RFX_EINVAL, "NULL argument");
+    RFX_HIP_CHECK(hipEventRecord(c->ev1, c->stream));
+    RFX_HIP_CHECK(hipEventSynchronize(c->ev1));
+    RFX_HIP_CHECK(hipEventElapsedTime(ms, c->ev0, c->ev1));
+    return RFX_OK;
+}
+
+// ---- generator ----
+__global__ __launch_bounds__(RFX_BLOCK) void k_gen_i64(i64 *out, i64 n, u64 seed, i64 row0, u64 mod) {
+    for (i64 i = blockIdx.x * (i64)RFX_BLOCK + threadIdx.x; i < n; i += (i64)gridDim.x * RFX_BLOCK)
+        out[i] = (i64)(rfx_splitmix_mix(seed + (u64)(row0 + i + 1) * 0x9E3779B97F4A7C15ULL) % mod);
+}
+__global__ __launch_bounds__(RFX_BLOCK) void k_gen_f64(double *out, i64 n, u64 seed, i64 row0) {
+    for (i64 i = blockIdx.x * (i64)RFX_BLOCK + threadIdx.x; i < n; i += (i64)gridDim.x * RFX_BLOCK)
+        out[i] = (double)(rfx_splitmix_mix(seed + (u64)(row0 + i + 1) * 0x9E3779B97F4A7C15ULL) >> 11) * 0x1.0p-53;
+}
+extern "C" int rfx_hip_gen_i64(rfx_ctx_t *c, int64_t *d_out, int64_t n, uint64_t seed, int64_t row0, uint64_t modulus) {
+    RFX_REQUIRE(c && (d_out || n == 0), RFX_EINVAL, "NULL argument");
+    RFX_REQUIRE(modulus > 0, RFX_EINVAL, "modulus must be > 0");
+    if (n <= 0) return RFX_OK;
+    hipLaunchKernelGGL(k_gen_i64, dim3(rfx_grid(c)), dim3(RFX_BLOCK), 0, c->stream, (i64 *)d_out, (i64)n, (u64)seed, (i64)row0, (u64)modulus);
+    RFX_HIP_CHECK(hipGetLastError());
+    return RFX_OK;
+}
+extern "C" int rfx_hip_gen_f64(rfx_ctx_t *c, double *d_out, int64_t n, uint64_t seed, int64_t row0) {
+    RFX_REQUIRE(c && (d_out || n == 0), RFX_EINVAL, "NULL argument");
+    if (n <= 0) return RFX_OK;
+    hipLaunchKernelGGL(k_gen_f64, dim3(rfx_grid(c)), dim3(RFX_BLOCK), 0, c->stream, d_out, (i64)n, (u64)seed, (i64)row0);
+    RFX_HIP_CHECK(hipGetLastError());
+    return RFX_OK;
+}
+
+// ---- plan builder ----
+static int plan_col(Plan *P, const void *p) {
+    for (int i = 0; i < P->ncols; i++)
+        if ((const void *)P->cols[i] == p) return i;
+    if (P->ncols >= RFX_MAX_COLS) return -1;
+    P->cols[P->ncols] = (const u64 *)p;
+    return P->ncols++;
+}
+
+static inline u64 host_f64_bits(double d) { u64 b; memcpy(&b, &d, 8); return b; }
+
+int rfx_plan_build(Plan *P, const rfx_pred_t *preds, int npred, int logic, const rfx_agg_t *aggs, int nagg,
+                   const void *extra_col, int *extra_idx, i64 nrows, i64 row0) {
+    memset(P, 0, sizeof(*P));
+    RFX_REQUIRE(npred >= 0 && npred <= RFX_MAX_PREDS, RFX_ELIMIT, "too many predicates");
+    RFX_REQUIRE(nagg >= 0 && nagg <= RFX_MAX_AGGS, RFX_ELIMIT, "too many aggregates");
+    RFX_REQUIRE(logic == RFX_AND || logic == RFX_OR, RFX_EINVAL, "logic must be RFX_AND or RFX_OR");
+    RFX_REQUIRE(nrows >= 0, RFX_EINVAL, "nrows < 0");
+    RFX_REQUIRE(npred == 0 || preds, RFX_EINVAL, "preds is NULL");
+    RFX_REQUIRE(nagg == 0 || aggs, RFX_EINVAL, "aggs is NULL");
+    P->npred = npred;
+    P->nagg = nagg;
+    P->logic = logic;
+    P->nrows = nrows;
+    P->row0 = row0;
+    if (extra_col) {
+        int ci = plan_col(P, extra_col);
+        RFX_REQUIRE(ci >= 0, RFX_ELIMIT, "too many distinct columns");
+        if (extra_idx) *extra_idx = ci;
+    }
+    for (int i = 0; i < npred; i++) {
+        const rfx_pred_t *p = &preds[i];
+        PlanPred *q = &P->preds[i];
+        RFX_REQUIRE(p->d_col != NULL, RFX_EINVAL, "predicate column is NULL");
+        RFX_REQUIRE(p->col_type == RFX_I64 || p->col_type == RFX_F64, RFX_EINVAL, "predicate column type must be i64 or f64");
+        RFX_REQUIRE(p->rhs_type == RFX_I64 || p->rhs_type == RFX_F64, RFX_EINVAL, "predicate rhs type must be i64 or f64");
+        RFX_REQUIRE(p->op >= RFX_EQ && p->op <= RFX_GE, RFX_EINVAL, "bad comparison operator");
+        q->col = plan_col(P, p->d_col);
+        RFX_REQUIRE(q->col >= 0, RFX_ELIMIT, "too many distinct columns");
+        q->op = p->op;
+        q->dom_f64 = (p->col_type == RFX_F64 || p->rhs_type == RFX_F64);
+        q->lhs_cvt = q->dom_f64 && p->col_type == RFX_I64;
+        if (p->d_rhs_col) {
+            q->rhs_col = plan_col(P, p->d_rhs_col);
+            RFX_REQUIRE(q->rhs_col >= 0, RFX_ELIMIT, "too many distinct columns");
+            q->rhs_cvt = q->dom_f64 && p->rhs_type == RFX_I64;
+            q->rhs_bits = 0;
+        } else {
+            q->rhs_col = -1;
+            q->rhs_cvt = 0;
+            if (!q->dom_f64) q->rhs_bits = (u64)p->rhs_i;
+            else if (p->rhs_type == RFX_F64) q->rhs_bits = host_f64_bits(p->rhs_f);
+            else q->rhs_bits = (p->rhs_i == RFX_NULL_I64_D) ? RFX_NAN_BITS : host_f64_bits((double)p->rhs_i); // i64_to_f64, core/ops.h:250
+        }
+    }
+    for (int i = 0; i < RFX_MAX_AGGS; i++) P->aggs[i].kind = -1;
+    for (int i = 0; i < nagg; i++) {
+        const rfx_agg_t *a = &aggs[i];
+        PlanAgg *q = &P->aggs[i];
+        RFX_REQUIRE(a->kind >= RFX_AGG_SUM && a->kind <= RFX_AGG_FIRST, RFX_EINVAL, "bad aggregate kind");
+        q->kind = a->kind;
+        if (a->kind == RFX_AGG_COUNT) {
+            q->col = -1;
+            q->f64 = 0;
+        } else {
+            RFX_REQUIRE(a->d_col != NULL, RFX_EINVAL, "aggregate column is NULL");
+            RFX_REQUIRE(a->col_type == RFX_I64 || a->col_type == RFX_F64, RFX_EINVAL, "aggregate column type must be i64 or f64");
+            q->col = plan_col(P, a->d_col);
+            RFX_REQUIRE(q->col >= 0, RFX_ELIMIT, "too many distinct columns");
+            q->f64 = (a->col_type == RFX_F64);
+        }
+    }
+    return RFX_OK;
+}

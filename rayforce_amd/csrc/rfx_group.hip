@@ -1,0 +1,416 @@
+// rfx_group.hip -- dense group-by: K7 first-occurrence table, K8 first-occurrence ranking, K10 fused scatter-aggregate.
+//
+// Reference: index_group_i64_scoped (core/index.c:2002-2092) builds group ids with a SEQUENTIAL first-occurrence loop
+// over all rows and AGGR_ITER/AGGR_COLLECT (core/aggr.c:73-181) scatter into per-thread arrays of `groups` entries.
+// Here one fused pass reads key + predicate + value columns once and scatters into tables indexed by  key - kmin :
+//   d_first[slot]  = min global row id           (atomic min)      -> group ORDER = ascending first row
+//   d_acc[a][slot] = running aggregate           (atomic add/min/max on 8-byte cells)
+// Tables that fit the LDS budget are privatised per workgroup in LDS (ds_* atomics run at HBM streaming rate:
+// tools/probe_hw measured 400+ G rows/s against 23 G rows/s for device-scope atomics) and merged into the global
+// tables once per workgroup.  Larger ranges use the radix-partitioned path (rfx_group_part.hip) or, as the
+// always-correct fallback in this file, direct device-scope atomics.
+// The rank step reuses `where`'s bitmap machinery: mark bit first[slot] in a 1-bit-per-row bitmap, prefix-popcount
+// it, and the rank of a slot's first row IS its group id (first-occurrence order, bit-exact with the reference).
+#include "rfx_group_common.hpp"
+
+int rfx_group_part_accumulate(rfx_ctx *c, const Plan &P, int key_idx, const rfx_group_tables_t *t); // rfx_group_part.hip
+
+struct GroupArgs {
+    i64 kmin;
+    i64 range;
+    int key_idx; // column index of the key inside Plan::cols
+    int nagg;
+    u64 *first;
+    u64 *acc[RFX_MAX_AGGS];
+    u64 *cnt[RFX_MAX_AGGS];
+};
+
+// ---- K7 + K10, one pass.  LDS = true: tables privatised in dynamic LDS, merged at the end. ----
+template <int NC, bool LDS>
+__global__ __launch_bounds__(RFX_BLOCK) void k_group_dense(const Plan P, const GroupArgs G) {
+    constexpr int U = (NC <= 2) ? 4 : (NC <= 4 ? 2 : 1);
+    constexpr int E = 2 * U;
+    constexpr int TILE = RFX_BLOCK * E;
+    constexpr int JSTRIDE = RFX_BLOCK * 2;
+    extern __shared__ __attribute__((aligned(16))) u64 smem[];
+    const int tid = threadIdx.x;
+    const i64 range = G.range;
+
+    // LDS layout: [first | acc0 | (cnt0) | acc1 | ...] each `range` cells
+    if (LDS) {
+        for (i64 i = tid; i < range; i += RFX_BLOCK) smem[i] = (u64)RFX_INF_I64_D;
+        int arr = 1;
+        for (int a = 0; a < G.nagg; a++) {
+            const PlanAgg ag = P.aggs[a];
+            u64 id = acc_identity(ag.kind, ag.f64);
+            for (i64 i = tid; i < range; i += RFX_BLOCK) smem[(i64)arr * range + i] = id;
+            arr++;
+            if (agg_has_cnt(ag.kind, ag.f64)) {
+                for (i64 i = tid; i < range; i += RFX_BLOCK) smem[(i64)arr * range + i] = 0;
+                arr++;
+            }
+        }
+        __syncthreads();
+    }
+
+    const i64 nfull = P.nrows / TILE;
+    const i64 ntiles = nfull + ((nfull * TILE < P.nrows) ? 1 : 0);
+    for (i64 t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const i64 base = t * TILE + tid * 2;
+        u64 v[NC][E];
+        unsigned valid;
+        if (t < nfull) {
+            valid = (1u << E) - 1u;
+#pragma unroll
+            for (int c = 0; c < NC; c++) {
+                const u64 *p = P.cols[c] + base;
+#pragma unroll
+                for (int j = 0; j < U; j++) {
+                    u64x2 q = rfx_ld2(p + (i64)j * JSTRIDE);
+                    v[c][2 * j] = q.x;
+                    v[c][2 * j + 1] = q.y;
+                }
+            }
+        } else {
+            valid = 0;
+#pragma unroll
+            for (int e = 0; e < E; e++) {
+                i64 row = base + (i64)(e >> 1) * JSTRIDE + (e & 1);
+                bool in = row < P.nrows;
+                valid |= (unsigned)in << e;
+#pragma unroll
+                for (int c = 0; c < NC; c++) v[c][e] = in ? P.cols[c][row] : 0ULL;
+            }
+        }
+        const unsigned m = eval_preds<NC, E>(P, v, valid);
+        if (m == 0) continue;
+        u64 key[E];
+        sel_col<NC, E>(key, v, G.key_idx);
+        // first-occurrence table
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+            if (!((m >> e) & 1u)) continue;
+            const u64 slot = key[e] - (u64)G.kmin;
+            if (slot >= (u64)range) continue; // outside the agreed scope (cannot happen when scope came from these rows)
+            const u64 row = (u64)(P.row0 + base + (i64)(e >> 1) * JSTRIDE + (e & 1));
+            if (LDS) {
+                if (row < smem[slot]) atomicMin((unsigned long long *)&smem[slot], (unsigned long long)row);
+            } else {
+                // plain pre-check: a stale (larger) value only costs a redundant atomic, never a wrong minimum
+                if (row < G.first[slot]) atomicMin((unsigned long long *)&G.first[slot], (unsigned long long)row);
+            }
+        }
+        int arr = 1;
+        for (int a = 0; a < G.nagg; a++) {
+            const PlanAgg ag = P.aggs[a];
+            const bool hc = agg_has_cnt(ag.kind, ag.f64);
+            u64 x[E];
+            if (ag.col >= 0) sel_col<NC, E>(x, v, ag.col);
+#pragma unroll
+            for (int e = 0; e < E; e++) {
+                if (!((m >> e) & 1u)) continue;
+                const u64 slot = key[e] - (u64)G.kmin;
+                if (slot >= (u64)range) continue;
+                if (LDS) group_apply(&smem[(i64)arr * range + slot], &smem[(i64)(arr + 1) * range + slot], ag.kind, ag.f64, x[e]);
+                else group_apply(&G.acc[a][slot], G.cnt[a] ? &G.cnt[a][slot] : (u64 *)0, ag.kind, ag.f64, x[e]);
+            }
+            arr += hc ? 2 : 1;
+        }
+    }
+
+    if (LDS) {
+        __syncthreads();
+        for (i64 i = tid; i < range; i += RFX_BLOCK) {
+            const u64 f = smem[i];
+            if (f == (u64)RFX_INF_I64_D) continue; // slot untouched by this workgroup
+            if (f < G.first[i]) atomicMin((unsigned long long *)&G.first[i], (unsigned long long)f);
+            int arr = 1;
+            for (int a = 0; a < G.nagg; a++) {
+                const PlanAgg ag = P.aggs[a];
+                const bool hc = agg_has_cnt(ag.kind, ag.f64);
+                group_merge_cell(&G.acc[a][i], hc ? &G.cnt[a][i] : (u64 *)0, ag.kind, ag.f64, smem[(i64)arr * range + i],
+                                 hc ? smem[(i64)(arr + 1) * range + i] : 0ULL);
+                arr += hc ? 2 : 1;
+            }
+        }
+    }
+}
+
+// ---- table init ----
+__global__ __launch_bounds__(RFX_BLOCK) void k_fill_u64(u64 *p, i64 n, u64 val) {
+    for (i64 i = blockIdx.x * (i64)RFX_BLOCK + threadIdx.x; i < n; i += (i64)gridDim.x * RFX_BLOCK) p[i] = val;
+}
+int rfx_fill_u64(rfx_ctx *c, void *p, i64 n, u64 val) {
+    if (n <= 0 || !p) return RFX_OK;
+    i64 blocks = (n + RFX_BLOCK - 1) / RFX_BLOCK;
+    int grid = rfx_grid(c) * 4;
+    if (blocks < grid) grid = (int)blocks;
+    hipLaunchKernelGGL(k_fill_u64, dim3(grid), dim3(RFX_BLOCK), 0, c->stream, (u64 *)p, n, val);
+    RFX_HIP_CHECK(hipGetLastError());
+    return RFX_OK;
+}
+
+extern "C" int rfx_hip_group_table_arrays(const rfx_agg_t *aggs, int nagg, int *n_arrays) {
+    if (!n_arrays || nagg < 0 || nagg > RFX_MAX_AGGS || (nagg && !aggs)) return RFX_EINVAL;
+    int n = 1;
+    for (int a = 0; a < nagg; a++) n += 1 + (agg_has_cnt(aggs[a].kind, aggs[a].col_type == RFX_F64) ? 1 : 0);
+    *n_arrays = n;
+    return RFX_OK;
+}
+
+static int check_tables(const rfx_agg_t *aggs, const rfx_group_tables_t *t) {
+    RFX_REQUIRE(t && t->d_first, RFX_EINVAL, "tables / d_first is NULL");
+    RFX_REQUIRE(t->range > 0, RFX_EINVAL, "range must be > 0");
+    RFX_REQUIRE(t->nagg >= 0 && t->nagg <= RFX_MAX_AGGS, RFX_ELIMIT, "too many aggregates");
+    for (int a = 0; a < t->nagg; a++) {
+        RFX_REQUIRE(t->d_acc[a] != NULL, RFX_EINVAL, "d_acc[a] is NULL");
+        if (agg_has_cnt(aggs[a].kind, aggs[a].col_type == RFX_F64)) RFX_REQUIRE(t->d_cnt[a] != NULL, RFX_EINVAL, "d_cnt[a] is NULL for SUM(i64)/AVG");
+    }
+    return RFX_OK;
+}
+
+extern "C" int rfx_hip_group_tables_init(rfx_ctx_t *c, const rfx_agg_t *aggs, const rfx_group_tables_t *t) {
+    RFX_REQUIRE(c, RFX_EINVAL, "ctx is NULL");
+    int rc = check_tables(aggs, t);
+    if (rc != RFX_OK) return rc;
+    rc = rfx_fill_u64(c, t->d_first, t->range, (u64)RFX_INF_I64_D);
+    if (rc != RFX_OK) return rc;
+    for (int a = 0; a < t->nagg; a++) {
+        rc = rfx_fill_u64(c, t->d_acc[a], t->range, acc_identity(aggs[a].kind, aggs[a].col_type == RFX_F64));
+        if (rc != RFX_OK) return rc;
+        if (t->d_cnt[a]) {
+            rc = rfx_fill_u64(c, t->d_cnt[a], t->range, 0);
+            if (rc != RFX_OK) return rc;
+        }
+    }
+    return RFX_OK;
+}
+
+#define RFX_LDS_GROUP_BYTES (64 * 1024) /* per workgroup: two workgroups per CU keep streaming at full rate */
+
+template <int NC>
+static void launch_group(rfx_ctx *c, const Plan &P, const GroupArgs &G, int grid, size_t lds_bytes) {
+    if (lds_bytes) hipLaunchKernelGGL((k_group_dense<NC, true>), dim3(grid), dim3(RFX_BLOCK), lds_bytes, c->stream, P, G);
+    else hipLaunchKernelGGL((k_group_dense<NC, false>), dim3(grid), dim3(RFX_BLOCK), 0, c->stream, P, G);
+}
+
+extern "C" int rfx_hip_group_dense_accumulate(rfx_ctx_t *c, const int64_t *d_key, const rfx_pred_t *preds, int npred,
+                                              int logic, const rfx_agg_t *aggs, int64_t nrows, int64_t row0,
+                                              const rfx_group_tables_t *t) {
+    RFX_REQUIRE(c && d_key, RFX_EINVAL, "NULL argument");
+    int rc = check_tables(aggs, t);
+    if (rc != RFX_OK) return rc;
+    if (nrows == 0) return RFX_OK;
+    Plan P;
+    int key_idx = 0;
+    rc = rfx_plan_build(&P, preds, npred, logic, aggs, t->nagg, d_key, &key_idx, nrows, row0);
+    if (rc != RFX_OK) return rc;
+    GroupArgs G;
+    memset(&G, 0, sizeof(G));
+    G.kmin = t->kmin;
+    G.range = t->range;
+    G.key_idx = key_idx;
+    G.nagg = t->nagg;
+    G.first = (u64 *)t->d_first;
+    int narr = 1;
+    for (int a = 0; a < t->nagg; a++) {
+        G.acc[a] = (u64 *)t->d_acc[a];
+        G.cnt[a] = (u64 *)t->d_cnt[a];
+        narr += 1 + (agg_has_cnt(aggs[a].kind, aggs[a].col_type == RFX_F64) ? 1 : 0);
+    }
+    size_t lds_bytes = (size_t)narr * (size_t)t->range * 8;
+    const bool use_lds = lds_bytes <= RFX_LDS_GROUP_BYTES && !(c->flags & 1);
+    if (!use_lds && !(c->flags & 2)) {
+        rc = rfx_group_part_accumulate(c, P, key_idx, t);
+        if (rc != RFX_ESTATE) return rc; // RFX_ESTATE = "partitioned path not applicable", fall through to atomics
+    }
+    if (!use_lds) lds_bytes = 0;
+    int grid = rfx_grid(c);
+    switch (P.ncols) {
+        case 1: launch_group<1>(c, P, G, grid, lds_bytes); break;
+        case 2: launch_group<2>(c, P, G, grid, lds_bytes); break;
+        case 3: launch_group<3>(c, P, G, grid, lds_bytes); break;
+        case 4: launch_group<4>(c, P, G, grid, lds_bytes); break;
+        case 5: launch_group<5>(c, P, G, grid, lds_bytes); break;
+        case 6: launch_group<6>(c, P, G, grid, lds_bytes); break;
+        case 7: launch_group<7>(c, P, G, grid, lds_bytes); break;
+        default: launch_group<8>(c, P, G, grid, lds_bytes); break;
+    }
+    RFX_HIP_CHECK(hipGetLastError());
+    return RFX_OK;
+}
+
+// ---------------- K8: rank occupied slots by first row ----------------
+__device__ __forceinline__ void bitpos(u64 row, u64 *word, unsigned *bit) {
+    const u64 g = row >> 7;
+    const unsigned r = (unsigned)(row & 127);
+    *word = g * 2 + (r & 1);
+    *bit = r >> 1;
+}
+
+__global__ __launch_bounds__(RFX_BLOCK) void k_mark_first(const u64 *__restrict__ first, i64 slots, i64 row_base, u64 *__restrict__ bitmap) {
+    for (i64 i = blockIdx.x * (i64)RFX_BLOCK + threadIdx.x; i < slots; i += (i64)gridDim.x * RFX_BLOCK) {
+        const u64 f = first[i];
+        if (f == (u64)RFX_INF_I64_D) continue;
+        u64 w;
+        unsigned b;
+        bitpos(f - (u64)row_base, &w, &b);
+        atomicOr((unsigned long long *)&bitmap[w], 1ULL << b);
+    }
+}
+
+__global__ __launch_bounds__(RFX_BLOCK) void k_bitmap_counts(const u64 *__restrict__ bitmap, i64 nchunks, i64 *__restrict__ cnt) {
+    for (i64 q = blockIdx.x * (i64)RFX_BLOCK + threadIdx.x; q < nchunks; q += (i64)gridDim.x * RFX_BLOCK) {
+        const u64 *w = bitmap + q * 8;
+        int s = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) s += __popcll(w[i]);
+        cnt[q] = s;
+    }
+}
+
+__global__ __launch_bounds__(RFX_BLOCK) void k_slot_gid(const u64 *__restrict__ first, i64 slots, i64 row_base, const u64 *__restrict__ bitmap,
+                                                      const i64 *__restrict__ chunk_off, i64 *__restrict__ gid) {
+    for (i64 i = blockIdx.x * (i64)RFX_BLOCK + threadIdx.x; i < slots; i += (i64)gridDim.x * RFX_BLOCK) {
+        const u64 f = first[i];
+        if (f == (u64)RFX_INF_I64_D) {
+            gid[i] = -1;
+            continue;
+        }
+        const u64 row = f - (u64)row_base;
+        const u64 q = row >> 9;
+        const unsigned within = (unsigned)(row & 511);
+        const unsigned g = within >> 7, r = within & 127, lane = r >> 1, par = r & 1;
+        const u64 *w = bitmap + q * 8;
+        i64 rank = chunk_off[q];
+        for (unsigned gg = 0; gg < g; gg++) rank += __popcll(w[2 * gg]) + __popcll(w[2 * gg + 1]);
+        const u64 below = lane ? (~0ULL >> (64 - lane)) : 0ULL;
+        rank += __popcll(w[2 * g] & below) + __popcll(w[2 * g + 1] & below);
+        if (par) rank += (i64)((w[2 * g] >> lane) & 1ULL);
+        gid[i] = rank;
+    }
+}
+
+// shared by the dense and the hashed tables
+int rfx_rank_slots(rfx_ctx *c, const u64 *d_first, i64 slots, i64 row_base, i64 total_rows, i64 *ngroups) {
+    RFX_REQUIRE(total_rows >= 0, RFX_EINVAL, "total_rows < 0");
+    const i64 nchunks = (total_rows + RFX_CHUNK - 1) / RFX_CHUNK;
+    int rc = rfx_bitmap_reserve(c, nchunks * RFX_CHUNK);
+    if (rc != RFX_OK) return rc;
+    if (c->blksum_cap < (size_t)nchunks + 2) {
+        RFX_HIP_CHECK(hipStreamSynchronize(c->stream));
+        if (c->d_blksum) RFX_HIP_CHECK(hipFree(c->d_blksum));
+        c->d_blksum = NULL;
+        c->blksum_cap = 0;
+        RFX_HIP_CHECK(hipMalloc((void **)&c->d_blksum, ((size_t)nchunks + 2) * 8));
+        c->blksum_cap = (size_t)nchunks + 2;
+    }
+    rc = rfx_gid_reserve(c, slots);
+    if (rc != RFX_OK) return rc;
+    c->where_n = -1; // the bitmap no longer describes a `where`
+    *ngroups = 0;
+    if (nchunks == 0 || slots == 0) {
+        c->rank_groups = 0;
+        return RFX_OK;
+    }
+    RFX_HIP_CHECK(hipMemsetAsync(c->d_bitmap, 0, (size_t)nchunks * 64, c->stream));
+    i64 sb = (slots + RFX_BLOCK - 1) / RFX_BLOCK;
+    int sgrid = rfx_grid(c) * 4;
+    if (sb < sgrid) sgrid = (int)sb;
+    hipLaunchKernelGGL(k_mark_first, dim3(sgrid), dim3(RFX_BLOCK), 0, c->stream, d_first, slots, row_base, c->d_bitmap);
+    i64 cb = (nchunks + RFX_BLOCK - 1) / RFX_BLOCK;
+    int cgrid = rfx_grid(c) * 4;
+    if (cb < cgrid) cgrid = (int)cb;
+    hipLaunchKernelGGL(k_bitmap_counts, dim3(cgrid), dim3(RFX_BLOCK), 0, c->stream, (const u64 *)c->d_bitmap, nchunks, c->d_blksum);
+    RFX_HIP_CHECK(hipGetLastError());
+    i64 *d_total = c->d_blksum + nchunks;
+    rc = rfx_scan_counts(c, c->d_blksum, nchunks, d_total);
+    if (rc != RFX_OK) return rc;
+    hipLaunchKernelGGL(k_slot_gid, dim3(sgrid), dim3(RFX_BLOCK), 0, c->stream, d_first, slots, row_base, (const u64 *)c->d_bitmap,
+                       (const i64 *)c->d_blksum, c->d_gid);
+    RFX_HIP_CHECK(hipGetLastError());
+    i64 *h = (i64 *)c->h_pin;
+    RFX_HIP_CHECK(hipMemcpyAsync(h, d_total, 8, hipMemcpyDeviceToHost, c->stream));
+    RFX_HIP_CHECK(hipStreamSynchronize(c->stream));
+    c->rank_groups = h[0];
+    *ngroups = h[0];
+    return RFX_OK;
+}
+
+extern "C" int rfx_hip_group_rank(rfx_ctx_t *c, const rfx_group_tables_t *t, int64_t total_rows, int64_t *ngroups) {
+    RFX_REQUIRE(c && t && ngroups, RFX_EINVAL, "NULL argument");
+    RFX_REQUIRE(t->d_first && t->range > 0, RFX_EINVAL, "bad tables");
+    return rfx_rank_slots(c, (const u64 *)t->d_first, t->range, 0, total_rows, (i64 *)ngroups);
+}
+
+// ---------------- emit in group order ----------------
+__global__ __launch_bounds__(RFX_BLOCK) void k_group_emit(const EmitArgs A, const i64 *__restrict__ gid) {
+    for (i64 i = blockIdx.x * (i64)RFX_BLOCK + threadIdx.x; i < A.slots; i += (i64)gridDim.x * RFX_BLOCK) {
+        const i64 g = gid[i];
+        if (g < 0) continue;
+        if (A.out_keys) A.out_keys[g] = A.keys ? (i64)A.keys[i] : A.kmin + i;
+        const u64 f = A.first[i];
+        if (A.out_first) A.out_first[g] = (i64)f;
+        for (int a = 0; a < A.nagg; a++) {
+            if (!A.out[a]) continue;
+            if (A.kinds[a] == RFX_AGG_FIRST) A.out[a][g] = A.col[a] ? A.col[a][(i64)f - A.row0] : 0ULL;
+            else A.out[a][g] = group_final(A.kinds[a], A.f64s[a], A.acc[a][i], A.cnt[a] ? A.cnt[a][i] : 0ULL);
+        }
+    }
+}
+
+int rfx_emit_slots(rfx_ctx *c, const EmitArgs &A) {
+    if (A.slots <= 0 || c->rank_groups == 0) return RFX_OK;
+    i64 sb = (A.slots + RFX_BLOCK - 1) / RFX_BLOCK;
+    int sgrid = rfx_grid(c) * 4;
+    if (sb < sgrid) sgrid = (int)sb;
+    hipLaunchKernelGGL(k_group_emit, dim3(sgrid), dim3(RFX_BLOCK), 0, c->stream, A, (const i64 *)c->d_gid);
+    RFX_HIP_CHECK(hipGetLastError());
+    return RFX_OK;
+}
+
+extern "C" int rfx_hip_group_emit(rfx_ctx_t *c, const rfx_agg_t *aggs, const rfx_group_tables_t *t, int64_t *d_keys,
+                                  int64_t *d_first_ids, void *const *d_results) {
+    RFX_REQUIRE(c, RFX_EINVAL, "ctx is NULL");
+    int rc = check_tables(aggs, t);
+    if (rc != RFX_OK) return rc;
+    RFX_REQUIRE(c->gid_cap >= (size_t)t->range, RFX_ESTATE, "group_emit without group_rank");
+    EmitArgs A;
+    memset(&A, 0, sizeof(A));
+    A.kmin = t->kmin;
+    A.slots = t->range;
+    A.nagg = t->nagg;
+    A.first = (const u64 *)t->d_first;
+    A.out_keys = (i64 *)d_keys;
+    A.out_first = (i64 *)d_first_ids;
+    for (int a = 0; a < t->nagg; a++) {
+        A.kinds[a] = aggs[a].kind;
+        A.f64s[a] = aggs[a].col_type == RFX_F64;
+        A.acc[a] = (const u64 *)t->d_acc[a];
+        A.cnt[a] = (const u64 *)t->d_cnt[a];
+        A.col[a] = (const u64 *)aggs[a].d_col;
+        A.out[a] = d_results ? (u64 *)d_results[a] : NULL;
+    }
+    return rfx_emit_slots(c, A);
+}
+
+// ---------------- per-row group ids (INDEX_TYPE_IDS payload) ----------------
+__global__ __launch_bounds__(RFX_BLOCK) void k_group_ids(const i64 *__restrict__ key, i64 n, i64 kmin, i64 range, const i64 *__restrict__ gid,
+                                                       i64 *__restrict__ out) {
+    for (i64 i = blockIdx.x * (i64)RFX_BLOCK + threadIdx.x; i < n; i += (i64)gridDim.x * RFX_BLOCK) {
+        u64 s = (u64)key[i] - (u64)kmin;
+        out[i] = (s < (u64)range) ? gid[s] : -1;
+    }
+}
+
+extern "C" int rfx_hip_group_ids_dense(rfx_ctx_t *c, const int64_t *d_key, int64_t nrows, const rfx_group_tables_t *t,
+                                       int64_t *d_gids) {
+    RFX_REQUIRE(c && t, RFX_EINVAL, "NULL argument");
+    if (nrows <= 0) return RFX_OK;
+    RFX_REQUIRE(d_key && d_gids, RFX_EINVAL, "NULL argument");
+    RFX_REQUIRE(c->gid_cap >= (size_t)t->range, RFX_ESTATE, "group_ids without group_rank");
+    hipLaunchKernelGGL(k_group_ids, dim3(rfx_grid(c) * 4), dim3(RFX_BLOCK), 0, c->stream, (const i64 *)d_key, (i64)nrows, t->kmin, t->range,
+                       (const i64 *)c->d_gid, (i64 *)d_gids);
+    RFX_HIP_CHECK(hipGetLastError());
+    return RFX_OK;
+}

@@ -1,0 +1,123 @@
+// rfx_group_common.hpp -- internal: cell rules shared by the dense (rfx_group.hip), partitioned
+// (rfx_group_part.hip) and hashed (rfx_hash.hip) group-by paths.
+#pragma once
+#include "rfx_scalar_kernel.hpp"
+
+#define RFX_CHUNK 512
+int rfx_scan_counts(rfx_ctx *c, i64 *d_cnt, i64 n, i64 *d_total);
+int rfx_rank_slots(rfx_ctx *c, const u64 *d_first, i64 slots, i64 row_base, i64 total_rows, i64 *ngroups);
+int rfx_fill_u64(rfx_ctx *c, void *p, i64 n, u64 val);
+
+// identity element of an accumulator cell
+__device__ __host__ __forceinline__ u64 acc_identity(int kind, int f64) {
+    (void)f64;
+    if (kind == RFX_AGG_MIN) return (u64)RFX_INF_I64_D;
+    if (kind == RFX_AGG_MAX) return (u64)RFX_NULL_I64_D;
+    return 0ULL; // SUM/AVG/COUNT/FIRST: 0 (== +0.0)
+}
+__host__ __device__ __forceinline__ bool agg_has_cnt(int kind, int f64) {
+    return kind == RFX_AGG_AVG || (kind == RFX_AGG_SUM && !f64);
+}
+
+// Apply one selected row to the tables.  Works on LDS or global cells (the compiler resolves the address space).
+// Grouped rules (core/aggr.c): sum is null-STICKY (ADDI64/ADDF64, :1088-1092) -> i64: count nulls aside, f64: IEEE NaN
+// propagates by itself; min/max skip nulls (:1152-1315); count counts every row (:1317-1453); avg casts to f64
+// and skips nulls (:1455-1540).
+template <typename P64>
+__device__ __forceinline__ void group_apply(P64 acc, P64 cnt, int kind, int f64, u64 x) {
+    switch (kind) {
+        case RFX_AGG_SUM:
+            if (f64) unsafeAtomicAdd((double *)acc, rfx_as_f64(x));
+            else if ((i64)x == RFX_NULL_I64_D) atomicAdd((unsigned long long *)cnt, 1ULL);
+            else atomicAdd((unsigned long long *)acc, (unsigned long long)x);
+            break;
+        case RFX_AGG_AVG:
+            if (f64 ? !rfx_isnan_bits(x) : ((i64)x != RFX_NULL_I64_D)) {
+                unsafeAtomicAdd((double *)acc, f64 ? rfx_as_f64(x) : (double)(i64)x);
+                atomicAdd((unsigned long long *)cnt, 1ULL);
+            }
+            break;
+        case RFX_AGG_MIN:
+            if (f64 ? !rfx_isnan_bits(x) : ((i64)x != RFX_NULL_I64_D)) atomicMin((long long *)acc, f64 ? rfx_f64_to_ord(x) : (i64)x);
+            break;
+        case RFX_AGG_MAX:
+            if (f64 ? !rfx_isnan_bits(x) : ((i64)x != RFX_NULL_I64_D)) atomicMax((long long *)acc, f64 ? rfx_f64_to_ord(x) : (i64)x);
+            break;
+        case RFX_AGG_COUNT:
+            atomicAdd((unsigned long long *)acc, 1ULL);
+            break;
+        default: // FIRST is resolved at emit time from d_first
+            break;
+    }
+}
+
+// Merge one LDS cell into the global tables.
+__device__ __forceinline__ void group_merge_cell(u64 *gacc, u64 *gcnt, int kind, int f64, u64 a, u64 c) {
+    switch (kind) {
+        case RFX_AGG_SUM:
+            if (f64) { if (a != 0ULL) unsafeAtomicAdd((double *)gacc, rfx_as_f64(a)); }
+            else {
+                if (a) atomicAdd((unsigned long long *)gacc, (unsigned long long)a);
+                if (c) atomicAdd((unsigned long long *)gcnt, (unsigned long long)c);
+            }
+            break;
+        case RFX_AGG_AVG:
+            if (c) {
+                unsafeAtomicAdd((double *)gacc, rfx_as_f64(a));
+                atomicAdd((unsigned long long *)gcnt, (unsigned long long)c);
+            }
+            break;
+        case RFX_AGG_MIN:
+            if ((i64)a != RFX_INF_I64_D) atomicMin((long long *)gacc, (i64)a);
+            break;
+        case RFX_AGG_MAX:
+            if ((i64)a != RFX_NULL_I64_D) atomicMax((long long *)gacc, (i64)a);
+            break;
+        case RFX_AGG_COUNT:
+            if (a) atomicAdd((unsigned long long *)gacc, (unsigned long long)a);
+            break;
+        default:
+            break;
+    }
+}
+
+struct EmitArgs {
+    i64 kmin;
+    i64 slots;
+    int nagg;
+    int kinds[RFX_MAX_AGGS];
+    int f64s[RFX_MAX_AGGS];
+    const u64 *first;
+    const u64 *keys; // hashed tables: explicit key per slot ; dense: NULL (key = kmin + slot)
+    const u64 *acc[RFX_MAX_AGGS];
+    const u64 *cnt[RFX_MAX_AGGS];
+    const u64 *col[RFX_MAX_AGGS]; // FIRST: source column (local rows), may be NULL
+    i64 row0;                     // FIRST: global id of col[0]
+    i64 *out_keys;
+    i64 *out_first;
+    u64 *out[RFX_MAX_AGGS];
+};
+
+// Final grouped value of one cell -- core/aggr.c rules, see DESIGN.md "NULL semantics".
+__device__ __forceinline__ u64 group_final(int kind, int f64, u64 a, u64 c) {
+    switch (kind) {
+        case RFX_AGG_SUM:
+            if (f64) return rfx_isnan_bits(a) ? RFX_NAN_BITS : a;
+            return c ? (u64)RFX_NULL_I64_D : a; // any null input poisons the group (ADDI64, core/ops.h:154)
+        case RFX_AGG_AVG:
+            return c ? rfx_as_u64(rfx_as_f64(a) / (double)(i64)c) : RFX_NAN_BITS; // core/aggr.c:2060
+        case RFX_AGG_MIN:
+            if (f64) return ((i64)a == RFX_INF_I64_D) ? RFX_PINF_BITS : rfx_ord_to_f64((i64)a); // all-null group -> +inf (core/aggr.c:1250)
+            return a;                                                                             // all-null group -> INF_I64 (core/aggr.c:1246)
+        case RFX_AGG_MAX:
+            if (f64) return ((i64)a == RFX_NULL_I64_D) ? RFX_NAN_BITS : rfx_ord_to_f64((i64)a); // all-null group -> null
+            return a;
+        case RFX_AGG_COUNT:
+            return a;
+        default:
+            return a;
+    }
+}
+
+
+int rfx_emit_slots(rfx_ctx *c, const EmitArgs &A);

@@ -1,0 +1,313 @@
+// rfx_hash.hip -- K9 sparse-key group-by (range > rows) and the reference's hash primitives.
+//
+// Reference: index_group_i64_unscoped -> index_group_distribute (core/index.c:1959-1977, 1777-1911) builds one
+// open-addressed table per CPU chunk (ht_oa_create / ht_oa_tab_next_with, core/hash.c:35-148: prime size >= len/0.75,
+// linear probing, empty slot = NULL_I64, fnv1a hash) and merges them sequentially; the group ORDER of that merge is
+// implementation-defined.  Here: ONE device-wide open-addressed table (power-of-two capacity, linear
+// probing, empty = NULL_I64 as in the reference, 64-bit CAS insert, hash = hash_index_u64 of core/hash.h:86-97), cells
+// indexed by slot exactly like the dense tables, so first-row tracking, ranking and emit are shared with the dense
+// path and the group order is FIRST OCCURRENCE (what the reference itself produces when it runs on one thread).
+// A NULL_I64 key cannot be stored as a key (it is the empty marker); it gets the dedicated slot `capacity`
+// (the reference's own table would open a fresh group for every such row -- see DESIGN.md "deliberate deviations").
+#include "rfx_group_common.hpp"
+
+#define RFX_U64_HASH_SEED 0x9ddfea08eb382d69ULL /* core/hash.h:35 */
+
+// hash_index_u64 -- core/hash.h:86-97
+__device__ __host__ __forceinline__ u64 rfx_hash_index_u64(u64 h, u64 k) {
+    const u64 s = RFX_U64_HASH_SEED;
+    u64 a = (h ^ k) * s;
+    a ^= (a >> 47);
+    u64 b = (((k << 31) | (k >> 33)) ^ a) * s;
+    b ^= (b >> 47);
+    b *= s;
+    return b;
+}
+// hash_fnv1a -- core/hash.c:530-542
+__device__ __host__ __forceinline__ u64 rfx_hash_fnv1a(u64 key) {
+    u64 h = 14695981039346656037ULL;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        h ^= (key >> (i * 8)) & 0xff;
+        h *= 1099511628211ULL;
+    }
+    return h;
+}
+
+struct HashArgs {
+    i64 capacity;
+    int key_idx;
+    int nagg;
+    u64 *keys;
+    u64 *first;
+    u64 *acc[RFX_MAX_AGGS];
+    u64 *cnt[RFX_MAX_AGGS];
+};
+
+// find-or-insert; returns the slot.  Bounded probing: the table is never allowed to fill (capacity >= 2 * distinct).
+__device__ __forceinline__ i64 hash_slot(u64 *keys, i64 capacity, u64 key) {
+    if ((i64)key == RFX_NULL_I64_D) return capacity;
+    const u64 mask = (u64)capacity - 1;
+    u64 s = rfx_hash_index_u64(RFX_U64_HASH_SEED, key) & mask;
+    for (i64 probe = 0; probe < capacity; probe++) {
+        u64 k = keys[s];
+        if (k == key) return (i64)s;
+        if ((i64)k == RFX_NULL_I64_D) {
+            u64 old = atomicCAS((unsigned long long *)&keys[s], (unsigned long long)RFX_NULL_I64_D, (unsigned long long)key);
+            if ((i64)old == RFX_NULL_I64_D || old == key) return (i64)s;
+        }
+        s = (s + 1) & mask;
+    }
+    return -1; // table full
+}
+
+template <int NC>
+__global__ __launch_bounds__(RFX_BLOCK) void k_group_hash(const Plan P, const HashArgs H, int *__restrict__ overflow) {
+    constexpr int U = (NC <= 2) ? 2 : 1;
+    constexpr int E = 2 * U;
+    constexpr int TILE = RFX_BLOCK * E;
+    constexpr int JSTRIDE = RFX_BLOCK * 2;
+    const int tid = threadIdx.x;
+    const i64 ntiles = (P.nrows + TILE - 1) / TILE;
+    for (i64 t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const i64 base = t * TILE + tid * 2;
+        u64 v[NC][E];
+        unsigned valid = 0;
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+            i64 row = base + (i64)(e >> 1) * JSTRIDE + (e & 1);
+            bool in = row < P.nrows;
+            valid |= (unsigned)in << e;
+#pragma unroll
+            for (int c = 0; c < NC; c++) v[c][e] = in ? P.cols[c][row] : 0ULL;
+        }
+        const unsigned m = eval_preds<NC, E>(P, v, valid);
+        if (m == 0) continue;
+        u64 key[E];
+        sel_col<NC, E>(key, v, H.key_idx);
+        i64 slot[E];
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+            slot[e] = -1;
+            if (!((m >> e) & 1u)) continue;
+            slot[e] = hash_slot(H.keys, H.capacity, key[e]);
+            if (slot[e] < 0) {
+                atomicExch(overflow, 1);
+                continue;
+            }
+            const u64 row = (u64)(P.row0 + base + (i64)(e >> 1) * JSTRIDE + (e & 1));
+            if (row < H.first[slot[e]]) atomicMin((unsigned long long *)&H.first[slot[e]], (unsigned long long)row);
+        }
+        for (int a = 0; a < H.nagg; a++) {
+            const PlanAgg ag = P.aggs[a];
+            u64 x[E];
+            if (ag.col >= 0) sel_col<NC, E>(x, v, ag.col);
+#pragma unroll
+            for (int e = 0; e < E; e++) {
+                if (slot[e] < 0) continue;
+                group_apply(&H.acc[a][slot[e]], H.cnt[a] ? &H.cnt[a][slot[e]] : (u64 *)0, ag.kind, ag.f64, x[e]);
+            }
+        }
+    }
+}
+
+struct MergeArgs {
+    i64 capacity;
+    int nagg;
+    int kinds[RFX_MAX_AGGS];
+    int f64s[RFX_MAX_AGGS];
+    u64 *keys;
+    u64 *first;
+    u64 *acc[RFX_MAX_AGGS];
+    u64 *cnt[RFX_MAX_AGGS];
+    const u64 *fkeys;
+    const u64 *ffirst;
+    const u64 *facc[RFX_MAX_AGGS];
+    const u64 *fcnt[RFX_MAX_AGGS];
+};
+
+__global__ __launch_bounds__(RFX_BLOCK) void k_hash_merge(const MergeArgs M, int *__restrict__ overflow) {
+    for (i64 i = blockIdx.x * (i64)RFX_BLOCK + threadIdx.x; i <= M.capacity; i += (i64)gridDim.x * RFX_BLOCK) {
+        const u64 f = M.ffirst[i];
+        if (f == (u64)RFX_INF_I64_D) continue;
+        const u64 key = (i == M.capacity) ? (u64)RFX_NULL_I64_D : M.fkeys[i];
+        const i64 s = hash_slot(M.keys, M.capacity, key);
+        if (s < 0) {
+            atomicExch(overflow, 1);
+            continue;
+        }
+        if (f < M.first[s]) atomicMin((unsigned long long *)&M.first[s], (unsigned long long)f);
+        for (int a = 0; a < M.nagg; a++)
+            group_merge_cell(&M.acc[a][s], M.cnt[a] ? &M.cnt[a][s] : (u64 *)0, M.kinds[a], M.f64s[a], M.facc[a][i], M.fcnt[a] ? M.fcnt[a][i] : 0ULL);
+    }
+}
+
+static int check_hash(const rfx_agg_t *aggs, const rfx_hash_tables_t *t) {
+    RFX_REQUIRE(t && t->d_keys && t->d_first, RFX_EINVAL, "hash tables / d_keys / d_first is NULL");
+    RFX_REQUIRE(t->capacity >= 2 && (t->capacity & (t->capacity - 1)) == 0, RFX_EINVAL, "capacity must be a power of two >= 2");
+    RFX_REQUIRE(t->nagg >= 0 && t->nagg <= RFX_MAX_AGGS, RFX_ELIMIT, "too many aggregates");
+    for (int a = 0; a < t->nagg; a++) {
+        RFX_REQUIRE(t->d_acc[a] != NULL, RFX_EINVAL, "d_acc[a] is NULL");
+        if (agg_has_cnt(aggs[a].kind, aggs[a].col_type == RFX_F64)) RFX_REQUIRE(t->d_cnt[a] != NULL, RFX_EINVAL, "d_cnt[a] is NULL for SUM(i64)/AVG");
+    }
+    return RFX_OK;
+}
+
+// every array of a hash table set has capacity + 1 cells (the extra one is the NULL-key group)
+extern "C" int rfx_hip_hash_tables_init(rfx_ctx_t *c, const rfx_agg_t *aggs, const rfx_hash_tables_t *t) {
+    RFX_REQUIRE(c, RFX_EINVAL, "ctx is NULL");
+    int rc = check_hash(aggs, t);
+    if (rc != RFX_OK) return rc;
+    const i64 n = t->capacity + 1;
+    if ((rc = rfx_fill_u64(c, t->d_keys, n, (u64)RFX_NULL_I64_D)) != RFX_OK) return rc;
+    if ((rc = rfx_fill_u64(c, t->d_first, n, (u64)RFX_INF_I64_D)) != RFX_OK) return rc;
+    for (int a = 0; a < t->nagg; a++) {
+        if ((rc = rfx_fill_u64(c, t->d_acc[a], n, acc_identity(aggs[a].kind, aggs[a].col_type == RFX_F64))) != RFX_OK) return rc;
+        if (t->d_cnt[a] && (rc = rfx_fill_u64(c, t->d_cnt[a], n, 0)) != RFX_OK) return rc;
+    }
+    return RFX_OK;
+}
+
+static int read_overflow(rfx_ctx *c, int *d_flag, const char *what) {
+    int *h = (int *)c->h_pin;
+    RFX_HIP_CHECK(hipMemcpyAsync(h, d_flag, 4, hipMemcpyDeviceToHost, c->stream));
+    RFX_HIP_CHECK(hipStreamSynchronize(c->stream));
+    if (h[0]) {
+        rfx_set_error("%s: hash table full (capacity must be >= 2x the number of distinct keys)", what);
+        return RFX_ELIMIT;
+    }
+    return RFX_OK;
+}
+
+template <int NC>
+static void launch_hash(rfx_ctx *c, const Plan &P, const HashArgs &H, int grid, int *flag) {
+    hipLaunchKernelGGL((k_group_hash<NC>), dim3(grid), dim3(RFX_BLOCK), 0, c->stream, P, H, flag);
+}
+
+extern "C" int rfx_hip_group_hash_accumulate(rfx_ctx_t *c, const int64_t *d_key, const rfx_pred_t *preds, int npred, int logic,
+                                             const rfx_agg_t *aggs, int64_t nrows, int64_t row0, const rfx_hash_tables_t *t) {
+    RFX_REQUIRE(c && d_key, RFX_EINVAL, "NULL argument");
+    int rc = check_hash(aggs, t);
+    if (rc != RFX_OK) return rc;
+    if (nrows == 0) return RFX_OK;
+    Plan P;
+    int key_idx = 0;
+    rc = rfx_plan_build(&P, preds, npred, logic, aggs, t->nagg, d_key, &key_idx, nrows, row0);
+    if (rc != RFX_OK) return rc;
+    HashArgs H;
+    memset(&H, 0, sizeof(H));
+    H.capacity = t->capacity;
+    H.key_idx = key_idx;
+    H.nagg = t->nagg;
+    H.keys = (u64 *)t->d_keys;
+    H.first = (u64 *)t->d_first;
+    for (int a = 0; a < t->nagg; a++) {
+        H.acc[a] = (u64 *)t->d_acc[a];
+        H.cnt[a] = (u64 *)t->d_cnt[a];
+    }
+    rc = rfx_ws_reserve(c, 256);
+    if (rc != RFX_OK) return rc;
+    int *flag = (int *)c->d_ws;
+    RFX_HIP_CHECK(hipMemsetAsync(flag, 0, 4, c->stream));
+    int grid = rfx_grid(c) * 4;
+    switch (P.ncols) {
+        case 1: launch_hash<1>(c, P, H, grid, flag); break;
+        case 2: launch_hash<2>(c, P, H, grid, flag); break;
+        case 3: launch_hash<3>(c, P, H, grid, flag); break;
+        case 4: launch_hash<4>(c, P, H, grid, flag); break;
+        case 5: launch_hash<5>(c, P, H, grid, flag); break;
+        case 6: launch_hash<6>(c, P, H, grid, flag); break;
+        case 7: launch_hash<7>(c, P, H, grid, flag); break;
+        default: launch_hash<8>(c, P, H, grid, flag); break;
+    }
+    RFX_HIP_CHECK(hipGetLastError());
+    return read_overflow(c, flag, "group_hash_accumulate");
+}
+
+extern "C" int rfx_hip_hash_tables_merge(rfx_ctx_t *c, const rfx_agg_t *aggs, const rfx_hash_tables_t *into,
+                                         const rfx_hash_tables_t *from) {
+    RFX_REQUIRE(c, RFX_EINVAL, "ctx is NULL");
+    int rc = check_hash(aggs, into);
+    if (rc != RFX_OK) return rc;
+    rc = check_hash(aggs, from);
+    if (rc != RFX_OK) return rc;
+    RFX_REQUIRE(into->capacity == from->capacity && into->nagg == from->nagg, RFX_EINVAL, "tables differ in shape");
+    MergeArgs M;
+    memset(&M, 0, sizeof(M));
+    M.capacity = into->capacity;
+    M.nagg = into->nagg;
+    M.keys = (u64 *)into->d_keys;
+    M.first = (u64 *)into->d_first;
+    M.fkeys = (const u64 *)from->d_keys;
+    M.ffirst = (const u64 *)from->d_first;
+    for (int a = 0; a < into->nagg; a++) {
+        M.kinds[a] = aggs[a].kind;
+        M.f64s[a] = aggs[a].col_type == RFX_F64;
+        M.acc[a] = (u64 *)into->d_acc[a];
+        M.cnt[a] = (u64 *)into->d_cnt[a];
+        M.facc[a] = (const u64 *)from->d_acc[a];
+        M.fcnt[a] = (const u64 *)from->d_cnt[a];
+    }
+    rc = rfx_ws_reserve(c, 256);
+    if (rc != RFX_OK) return rc;
+    int *flag = (int *)c->d_ws;
+    RFX_HIP_CHECK(hipMemsetAsync(flag, 0, 4, c->stream));
+    hipLaunchKernelGGL(k_hash_merge, dim3(rfx_grid(c) * 4), dim3(RFX_BLOCK), 0, c->stream, M, flag);
+    RFX_HIP_CHECK(hipGetLastError());
+    return read_overflow(c, flag, "hash_tables_merge");
+}
+
+extern "C" int rfx_hip_hash_rank(rfx_ctx_t *c, const rfx_hash_tables_t *t, int64_t total_rows, int64_t *ngroups) {
+    RFX_REQUIRE(c && t && ngroups, RFX_EINVAL, "NULL argument");
+    RFX_REQUIRE(t->d_first && t->capacity > 0, RFX_EINVAL, "bad tables");
+    return rfx_rank_slots(c, (const u64 *)t->d_first, t->capacity + 1, 0, total_rows, (i64 *)ngroups);
+}
+
+extern "C" int rfx_hip_hash_emit(rfx_ctx_t *c, const rfx_agg_t *aggs, const rfx_hash_tables_t *t, int64_t *d_keys,
+                                 int64_t *d_first_ids, void *const *d_results) {
+    RFX_REQUIRE(c, RFX_EINVAL, "ctx is NULL");
+    int rc = check_hash(aggs, t);
+    if (rc != RFX_OK) return rc;
+    RFX_REQUIRE(c->gid_cap >= (size_t)t->capacity + 1, RFX_ESTATE, "hash_emit without hash_rank");
+    EmitArgs A;
+    memset(&A, 0, sizeof(A));
+    A.slots = t->capacity + 1;
+    A.nagg = t->nagg;
+    A.first = (const u64 *)t->d_first;
+    A.keys = (const u64 *)t->d_keys;
+    A.out_keys = (i64 *)d_keys;
+    A.out_first = (i64 *)d_first_ids;
+    for (int a = 0; a < t->nagg; a++) {
+        A.kinds[a] = aggs[a].kind;
+        A.f64s[a] = aggs[a].col_type == RFX_F64;
+        A.acc[a] = (const u64 *)t->d_acc[a];
+        A.cnt[a] = (const u64 *)t->d_cnt[a];
+        A.col[a] = (const u64 *)aggs[a].d_col;
+        A.out[a] = d_results ? (u64 *)d_results[a] : NULL;
+    }
+    return rfx_emit_slots(c, A);
+}
+
+// ---------------- hash primitives (pinned against the compiled reference in tests/golden) ----------------
+__global__ __launch_bounds__(RFX_BLOCK) void k_fnv1a(const u64 *__restrict__ in, i64 n, u64 *__restrict__ out) {
+    for (i64 i = blockIdx.x * (i64)RFX_BLOCK + threadIdx.x; i < n; i += (i64)gridDim.x * RFX_BLOCK) out[i] = rfx_hash_fnv1a(in[i]);
+}
+__global__ __launch_bounds__(RFX_BLOCK) void k_mix(const u64 *__restrict__ in, i64 n, u64 h, u64 *__restrict__ out) {
+    for (i64 i = blockIdx.x * (i64)RFX_BLOCK + threadIdx.x; i < n; i += (i64)gridDim.x * RFX_BLOCK) out[i] = rfx_hash_index_u64(h, in[i]);
+}
+extern "C" int rfx_hip_hash_fnv1a_i64(rfx_ctx_t *c, const int64_t *d_in, int64_t n, uint64_t *d_out) {
+    RFX_REQUIRE(c, RFX_EINVAL, "ctx is NULL");
+    if (n <= 0) return RFX_OK;
+    RFX_REQUIRE(d_in && d_out, RFX_EINVAL, "NULL argument");
+    hipLaunchKernelGGL(k_fnv1a, dim3(rfx_grid(c)), dim3(RFX_BLOCK), 0, c->stream, (const u64 *)d_in, (i64)n, (u64 *)d_out);
+    RFX_HIP_CHECK(hipGetLastError());
+    return RFX_OK;
+}
+extern "C" int rfx_hip_hash_mix_u64(rfx_ctx_t *c, const uint64_t *d_in, int64_t n, uint64_t h, uint64_t *d_out) {
+    RFX_REQUIRE(c, RFX_EINVAL, "ctx is NULL");
+    if (n <= 0) return RFX_OK;
+    RFX_REQUIRE(d_in && d_out, RFX_EINVAL, "NULL argument");
+    hipLaunchKernelGGL(k_mix, dim3(rfx_grid(c)), dim3(RFX_BLOCK), 0, c->stream, (const u64 *)d_in, (i64)n, (u64)h, (u64 *)d_out);
+    RFX_HIP_CHECK(hipGetLastError());
+    return RFX_OK;
+}

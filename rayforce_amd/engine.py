@@ -1,0 +1,479 @@
+"""Host-side mirror of the reference's operator surface for the select / where / by path, over HBM-resident columns.
+
+Names follow RayforceDB (core/env.c:135-225): ``eq ne lt gt le ge`` (-> B8 byte masks), ``and_ / or_``, ``where``,
+``at_ids`` (gather), ``sum min max avg count first`` and ``select`` with ``where:`` / ``by:`` clauses
+(core/query.c:607-654).  Columns are 1-D ``torch.int64`` / ``torch.float64`` CUDA tensors; torch only owns the memory
+and the stream -- all compute goes through librfx.so (hand-written HIP).  No CPU fallback exists.
+
+Predicates are tuples ``(op, lhs, rhs)`` with op in ``== != < > <= >=``, lhs a column (tensor or table column name) and
+rhs a Python int/float atom or another column; ``("and", p1, p2, ...)`` / ``("or", p1, ...)`` combine them flatly
+(nested trees are evaluated through materialised masks, like the reference does).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Dict, List, Optional, Sequence, Tuple, Union
+
+import torch
+
+from . import _lib as L
+from ._lib import RfxError
+
+Column = torch.Tensor
+PredSpec = tuple
+
+
+def _ctype_of(t: torch.Tensor) -> int:
+    if t.dtype == torch.int64:
+        return L.RFX_I64
+    if t.dtype == torch.float64:
+        return L.RFX_F64
+    raise RfxError(f"unsupported column dtype {t.dtype} (the path handles i64 and f64 columns)")
+
+
+class Engine:
+    """One GPU, one HIP stream, one librfx context."""
+
+    def __init__(self, device: Union[int, torch.device, None] = None):
+        self.lib = L.load_library()
+        if not torch.cuda.is_available():
+            raise RfxError("no GPU visible to torch: the MI355X engine has no CPU fallback")
+        if device is None:
+            device = torch.cuda.current_device()
+        self.device = torch.device("cuda", device if isinstance(device, int) else device.index)
+        torch.cuda.set_device(self.device)
+        self._ctx = C.c_void_p()
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        L.check(self.lib.rfx_hip_ctx_create(self.device.index, C.c_void_p(stream), C.byref(self._ctx)), "ctx_create")
+        self._keep: List[torch.Tensor] = []
+
+    def close(self) -> None:
+        if self._ctx:
+            self.lib.rfx_hip_ctx_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ plumbing
+    def sync(self) -> None:
+        L.check(self.lib.rfx_hip_ctx_sync(self._ctx), "sync")
+
+    def tune(self, blocks_per_cu: int = 0, flags: int = 0) -> None:
+        L.check(self.lib.rfx_hip_ctx_tune(self._ctx, blocks_per_cu, flags), "tune")
+
+    def timer_start(self) -> None:
+        L.check(self.lib.rfx_hip_timer_start(self._ctx), "timer_start")
+
+    def timer_stop(self) -> float:
+        ms = C.c_float()
+        L.check(self.lib.rfx_hip_timer_stop(self._ctx, C.byref(ms)), "timer_stop")
+        return float(ms.value)
+
+    def empty(self, n: int, dtype=torch.int64) -> torch.Tensor:
+        return torch.empty(int(n), dtype=dtype, device=self.device)
+
+    def column(self, host_array) -> torch.Tensor:
+        """Upload a numpy int64/float64 array (host -> HBM over PCIe; not part of any timed region)."""
+        t = torch.as_tensor(host_array)
+        if t.dtype not in (torch.int64, torch.float64, torch.int8, torch.bool):
+            raise RfxError(f"unsupported dtype {t.dtype}")
+        if t.dtype == torch.bool:
+            t = t.to(torch.int8)
+        return t.contiguous().to(self.device)
+
+    def gen_i64(self, n: int, seed: int, modulus: int, row0: int = 0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        out = self.empty(n, torch.int64) if out is None else out
+        L.check(self.lib.rfx_hip_gen_i64(self._ctx, out.data_ptr(), n, seed, row0, modulus), "gen_i64")
+        return out
+
+    def gen_f64(self, n: int, seed: int, row0: int = 0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        out = self.empty(n, torch.float64) if out is None else out
+        L.check(self.lib.rfx_hip_gen_f64(self._ctx, out.data_ptr(), n, seed, row0), "gen_f64")
+        return out
+
+    # ------------------------------------------------------------------ descriptors
+    def _check_col(self, t: torch.Tensor, n: Optional[int] = None) -> torch.Tensor:
+        if not isinstance(t, torch.Tensor) or t.dim() != 1 or not t.is_contiguous():
+            raise RfxError("columns must be contiguous 1-D tensors")
+        if t.device != self.device:
+            raise RfxError(f"column lives on {t.device}, engine on {self.device}")
+        if n is not None and t.numel() != n:
+            raise RfxError("length mismatch")  # reference: err_length (core/cmp.c:633-640)
+        return t
+
+    def _flatten(self, where, table) -> Tuple[int, List[tuple]]:
+        """Return (logic, [simple predicates]) or raise NotFlat for nested trees."""
+        if where is None:
+            return L.RFX_AND, []
+        head = where[0]
+        if head in L.OPS:
+            return L.RFX_AND, [where]
+        if head in ("and", "or"):
+            subs = list(where[1:])
+            if all(s[0] in L.OPS for s in subs):
+                return (L.RFX_AND if head == "and" else L.RFX_OR), subs
+            raise _NotFlat()
+        raise RfxError(f"unknown predicate head {head!r}")
+
+    def _resolve(self, x, table):
+        if isinstance(x, str):
+            if table is None or x not in table:
+                raise RfxError(f"unknown column {x!r}")
+            return table[x]
+        return x
+
+    def _preds(self, preds: Sequence[tuple], table, n: Optional[int]):
+        if len(preds) > L.RFX_MAX_PREDS:
+            raise RfxError("too many predicates for one fused pass")
+        arr = (L.Pred * max(1, len(preds)))()
+        for i, (op, lhs, rhs) in enumerate(preds):
+            lhs = self._check_col(self._resolve(lhs, table), n)
+            n = lhs.numel() if n is None else n
+            p = arr[i]
+            p.d_col = lhs.data_ptr()
+            p.col_type = _ctype_of(lhs)
+            p.op = L.OPS[op]
+            rhs = self._resolve(rhs, table) if isinstance(rhs, str) else rhs
+            if isinstance(rhs, torch.Tensor):
+                rhs = self._check_col(rhs, n)
+                p.d_rhs_col = rhs.data_ptr()
+                p.rhs_type = _ctype_of(rhs)
+                self._keep.append(rhs)
+            elif isinstance(rhs, bool):
+                raise RfxError("boolean atoms are not comparable on this path")
+            elif isinstance(rhs, int):
+                p.d_rhs_col = None
+                p.rhs_type = L.RFX_I64
+                p.rhs_i = rhs
+            elif isinstance(rhs, float):
+                p.d_rhs_col = None
+                p.rhs_type = L.RFX_F64
+                p.rhs_f = rhs
+            elif rhs is None:  # null atom compares as 0Nl
+                p.d_rhs_col = None
+                p.rhs_type = L.RFX_I64
+                p.rhs_i = L.NULL_I64
+            else:
+                raise RfxError(f"unsupported rhs {type(rhs)}")
+            self._keep.append(lhs)
+        return arr, n
+
+    def _aggs(self, aggs: Sequence[Tuple[str, Optional[torch.Tensor]]], table, n: Optional[int]):
+        if len(aggs) > L.RFX_MAX_AGGS:
+            raise RfxError("too many aggregates for one fused pass")
+        arr = (L.Agg * max(1, len(aggs)))()
+        for i, (fn, col) in enumerate(aggs):
+            a = arr[i]
+            a.kind = L.AGGS[fn]
+            col = self._resolve(col, table) if col is not None else None
+            if col is None:
+                if fn != "count":
+                    raise RfxError(f"{fn} needs a column")
+                a.d_col = None
+                a.col_type = L.RFX_I64
+            else:
+                col = self._check_col(col, n)
+                n = col.numel() if n is None else n
+                a.d_col = col.data_ptr()
+                a.col_type = _ctype_of(col)
+                self._keep.append(col)
+        return arr, n
+
+    @staticmethod
+    def _value(v: L.Value):
+        if v.type == L.RFX_F64:
+            return float("nan") if v.is_null else float(v.f)
+        return None if v.is_null else int(v.i)
+
+    # ------------------------------------------------------------------ K1/K5: fused filter -> aggregates
+    def filter_aggr_partials(self, aggs, where=None, table=None, nrows: Optional[int] = None, row0: int = 0,
+                             out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Device-resident partials ((nagg+1) x 64 bytes as a uint8 tensor) -- the multi-GPU exchange payload."""
+        self._keep.clear()
+        logic, flat = self._flatten(where, table)
+        parr, n = self._preds(flat, table, nrows)
+        aarr, n = self._aggs(aggs, table, n)
+        if n is None:
+            raise RfxError("cannot infer the row count (count without column and without predicate needs nrows=)")
+        out = torch.empty((len(aggs) + 1) * 64, dtype=torch.uint8, device=self.device) if out is None else out
+        L.check(self.lib.rfx_hip_filter_aggr(self._ctx, parr, len(flat), logic, aarr, len(aggs), n, row0, out.data_ptr()),
+                "filter_aggr")
+        return out
+
+    def filter_aggr(self, aggs, where=None, table=None, nrows: Optional[int] = None):
+        """``select {aggs} from t where p`` without ``by:`` -> ([values], selected_rows).  (syncs)"""
+        try:
+            logic, flat = self._flatten(where, table)
+        except _NotFlat:
+            return self._filter_aggr_via_ids(aggs, where, table)
+        self._keep.clear()
+        parr, n = self._preds(flat, table, nrows)
+        aarr, n = self._aggs(aggs, table, n)
+        if n is None:
+            raise RfxError("cannot infer the row count")
+        vals = (L.Value * max(1, len(aggs)))()
+        sel = C.c_int64()
+        L.check(self.lib.rfx_hip_filter_aggr_host(self._ctx, parr, len(flat), logic, aarr, len(aggs), n, vals, C.byref(sel)),
+                "filter_aggr")
+        return [self._value(vals[i]) for i in range(len(aggs))], int(sel.value)
+
+    def _filter_aggr_via_ids(self, aggs, where, table):
+        # nested boolean tree: masks -> where -> gather -> plain folds (the reference's own plan, on the GPU)
+        ids = self.where(where, table)
+        gathered = []
+        for fn, col in aggs:
+            col = self._resolve(col, table) if col is not None else None
+            gathered.append((fn, self.at_ids(col, ids) if col is not None else None))
+        vals, _ = self.filter_aggr(gathered, None, None, nrows=int(ids.numel()))
+        return vals, int(ids.numel())
+
+    # scalar verbs of the reference (core/math.c:2388-2526, core/misc.c:43-60)
+    def sum(self, col, where=None, table=None):
+        return self.filter_aggr([("sum", col)], where, table)[0][0]
+
+    def min(self, col, where=None, table=None):
+        return self.filter_aggr([("min", col)], where, table)[0][0]
+
+    def max(self, col, where=None, table=None):
+        return self.filter_aggr([("max", col)], where, table)[0][0]
+
+    def avg(self, col, where=None, table=None):
+        return self.filter_aggr([("avg", col)], where, table)[0][0]
+
+    def count(self, col, where=None, table=None):
+        return self.filter_aggr([("count", col)], where, table)[0][0]
+
+    def first(self, col, where=None, table=None):
+        return self.filter_aggr([("first", col)], where, table)[0][0]
+
+    # ------------------------------------------------------------------ K2: masks
+    def cmp(self, op: str, lhs, rhs, table=None) -> torch.Tensor:
+        """ray_eq .. ray_ge on a column: B8 byte mask (int8 tensor of 0/1)."""
+        self._keep.clear()
+        parr, n = self._preds([(op, lhs, rhs)], table, None)
+        out = torch.empty(n, dtype=torch.int8, device=self.device)
+        L.check(self.lib.rfx_hip_cmp_mask(self._ctx, parr, n, out.data_ptr()), "cmp_mask")
+        return out
+
+    def eq(self, a, b): return self.cmp("==", a, b)
+    def ne(self, a, b): return self.cmp("!=", a, b)
+    def lt(self, a, b): return self.cmp("<", a, b)
+    def gt(self, a, b): return self.cmp(">", a, b)
+    def le(self, a, b): return self.cmp("<=", a, b)
+    def ge(self, a, b): return self.cmp(">=", a, b)
+
+    def _logic(self, logic: int, masks) -> torch.Tensor:
+        if not masks:
+            raise RfxError("and/or need at least one argument")
+        acc = masks[0].clone()
+        for m in masks[1:]:
+            if isinstance(m, (bool, int)):
+                L.check(self.lib.rfx_hip_mask_logic(self._ctx, logic, acc.data_ptr(), None, int(bool(m)), acc.numel()), "mask_logic")
+                continue
+            if m.numel() != acc.numel():
+                raise RfxError("length mismatch")  # reference: err_type on unequal lengths (core/logic.c:122-126)
+            L.check(self.lib.rfx_hip_mask_logic(self._ctx, logic, acc.data_ptr(), m.data_ptr(), 0, acc.numel()), "mask_logic")
+        return acc
+
+    def and_(self, *masks) -> torch.Tensor:
+        return self._logic(L.RFX_AND, masks)
+
+    def or_(self, *masks) -> torch.Tensor:
+        return self._logic(L.RFX_OR, masks)
+
+    def mask_of(self, where, table=None) -> torch.Tensor:
+        """Materialise any predicate tree as a byte mask (the reference's evaluation order, on the GPU)."""
+        head = where[0]
+        if head in L.OPS:
+            return self.cmp(head, where[1], where[2], table)
+        subs = [self.mask_of(w, table) for w in where[1:]]
+        return self.and_(*subs) if head == "and" else self.or_(*subs)
+
+    # ------------------------------------------------------------------ K3: where
+    def where(self, where, table=None, row0: int = 0) -> torch.Tensor:
+        """Ascending row ids of the selected rows.  `where` = int8/bool mask tensor or a predicate tree.  (syncs)"""
+        cnt = C.c_int64()
+        if isinstance(where, torch.Tensor):
+            mask = self._check_col(where.view(torch.int8) if where.dtype == torch.bool else where)
+            if mask.dtype != torch.int8:
+                raise RfxError("where expects a B8 mask")  # reference: err_type (core/items.c:1395)
+            L.check(self.lib.rfx_hip_where_begin(self._ctx, None, 0, L.RFX_AND, mask.data_ptr(), mask.numel(), C.byref(cnt)), "where_begin")
+        else:
+            try:
+                logic, flat = self._flatten(where, table)
+            except _NotFlat:
+                return self.where(self.mask_of(where, table), row0=row0)
+            self._keep.clear()
+            parr, n = self._preds(flat, table, None)
+            L.check(self.lib.rfx_hip_where_begin(self._ctx, parr, len(flat), logic, None, n, C.byref(cnt)), "where_begin")
+        out = torch.empty(int(cnt.value), dtype=torch.int64, device=self.device)
+        L.check(self.lib.rfx_hip_where_emit(self._ctx, row0, out.data_ptr()), "where_emit")
+        return out
+
+    # ------------------------------------------------------------------ K4: gather
+    def at_ids(self, col: torch.Tensor, ids: torch.Tensor) -> torch.Tensor:
+        self._check_col(col)
+        self._check_col(ids)
+        if ids.dtype != torch.int64:
+            raise RfxError("ids must be i64")
+        _ctype_of(col)
+        out = torch.empty(ids.numel(), dtype=col.dtype, device=self.device)
+        L.check(self.lib.rfx_hip_gather(self._ctx, col.data_ptr(), ids.data_ptr(), ids.numel(), out.data_ptr()), "gather")
+        return out
+
+    # ------------------------------------------------------------------ K6: scope
+    def scope(self, key: torch.Tensor, where=None, table=None) -> Tuple[int, int, int]:
+        """index_scope_i64: (min, max, rows_seen).  (syncs)"""
+        self._check_col(key)
+        if key.dtype != torch.int64:
+            raise RfxError("group key must be i64 on this path")
+        logic, flat = self._flatten(where, table)
+        self._keep.clear()
+        parr, n = self._preds(flat, table, key.numel())
+        mn, mx, cnt = C.c_int64(), C.c_int64(), C.c_int64()
+        L.check(self.lib.rfx_hip_scope_i64(self._ctx, key.data_ptr(), parr, len(flat), logic, key.numel(), C.byref(mn), C.byref(mx),
+                                           C.byref(cnt)), "scope_i64")
+        return int(mn.value), int(mx.value), int(cnt.value)
+
+    # ------------------------------------------------------------------ K7/K8/K10 dense group-by, K9 hashed
+    def group_tables(self, aggs_arr, nagg: int, kmin: int, rng: int, hashed: bool = False):
+        """Allocate one table set.  Returns (struct, backing tensor [n_arrays, cells])."""
+        n_arr = C.c_int()
+        L.check(self.lib.rfx_hip_group_table_arrays(aggs_arr, nagg, C.byref(n_arr)), "group_table_arrays")
+        cells = rng + 1 if hashed else rng
+        total = n_arr.value + (1 if hashed else 0)
+        store = torch.empty((total, cells), dtype=torch.int64, device=self.device)
+        t = L.HashTables() if hashed else L.GroupTables()
+        k = 0
+        if hashed:
+            t.capacity = rng
+            t.d_keys = store[k].data_ptr(); k += 1
+        else:
+            t.kmin, t.range = kmin, rng
+        t.nagg = nagg
+        t.d_first = store[k].data_ptr(); k += 1
+        layout = [("first", None)]
+        for a in range(nagg):
+            t.d_acc[a] = store[k].data_ptr(); k += 1
+            layout.append(("acc", a))
+            kind, f64 = aggs_arr[a].kind, aggs_arr[a].col_type == L.RFX_F64
+            if kind == L.RFX_AGG_AVG or (kind == L.RFX_AGG_SUM and not f64):
+                t.d_cnt[a] = store[k].data_ptr(); k += 1
+                layout.append(("cnt", a))
+            else:
+                t.d_cnt[a] = None
+        return t, store, layout
+
+    def group_by(self, key, aggs, where=None, table=None, total_rows: Optional[int] = None, row0: int = 0, _collective=None):
+        """``select {aggs} from t [where p] by key`` -> dict(keys=, first=, results=[...], groups=n) of device tensors.
+
+        Group order is first occurrence.  `_collective(store, layout, aggs_arr, hashed)` -- if given -- is called
+        between the local scatter pass and the ranking step so that several GPUs can merge their tables.  (syncs)
+        """
+        key = self._check_col(self._resolve(key, table))
+        if key.dtype != torch.int64:
+            raise RfxError("group key must be i64 on this path (f64 keys group on their bit pattern: view as int64)")
+        n = key.numel()
+        try:
+            logic, flat = self._flatten(where, table)
+        except _NotFlat:
+            raise RfxError("nested boolean trees are not fused with `by:`; pass ids via where() + at_ids()")
+        kmin, kmax, seen = self.scope(key, where, table)
+        if _collective is not None:
+            kmin, kmax, seen = _collective("scope", (kmin, kmax, seen))
+        self._keep.clear()
+        parr, _ = self._preds(flat, table, n)
+        aarr, _ = self._aggs(aggs, table, n)
+        nagg = len(aggs)
+        total_rows = n if total_rows is None else total_rows
+        out_dtypes = []
+        for fn, col in aggs:
+            col = self._resolve(col, table) if col is not None else None
+            if fn in ("avg",):
+                out_dtypes.append(torch.float64)
+            elif fn == "count":
+                out_dtypes.append(torch.int64)
+            else:
+                out_dtypes.append(col.dtype)
+        if seen == 0:
+            return dict(groups=0, keys=self.empty(0), first=self.empty(0), results=[self.empty(0, d) for d in out_dtypes])
+        rng = kmax - kmin + 1
+        # index_group_i64_scoped: dense "perfect hash" iff range <= rows (core/index.c:2013); else open addressing
+        dense = 0 < rng <= max(seen, 1) and kmin != L.NULL_I64
+        ng = C.c_int64()
+        if dense:
+            t, store, layout = self.group_tables(aarr, nagg, kmin, rng)
+            L.check(self.lib.rfx_hip_group_tables_init(self._ctx, aarr, C.byref(t)), "group_tables_init")
+            L.check(self.lib.rfx_hip_group_dense_accumulate(self._ctx, key.data_ptr(), parr, len(flat), logic, aarr, n, row0, C.byref(t)),
+                    "group_dense_accumulate")
+            if _collective is not None:
+                _collective("tables", (store, layout, aarr, False))
+            L.check(self.lib.rfx_hip_group_rank(self._ctx, C.byref(t), total_rows, C.byref(ng)), "group_rank")
+        else:
+            cap = 1 << max(4, math.ceil(math.log2(max(2 * seen, 16))))
+            t, store, layout = self.group_tables(aarr, nagg, 0, cap, hashed=True)
+            L.check(self.lib.rfx_hip_hash_tables_init(self._ctx, aarr, C.byref(t)), "hash_tables_init")
+            L.check(self.lib.rfx_hip_group_hash_accumulate(self._ctx, key.data_ptr(), parr, len(flat), logic, aarr, n, row0, C.byref(t)),
+                    "group_hash_accumulate")
+            if _collective is not None:
+                _collective("hash_tables", (self, t, store, layout, aarr))
+            L.check(self.lib.rfx_hip_hash_rank(self._ctx, C.byref(t), total_rows, C.byref(ng)), "hash_rank")
+        g = int(ng.value)
+        keys = self.empty(g)
+        first = self.empty(g)
+        results = [self.empty(g, d) for d in out_dtypes]
+        ptrs = (C.c_void_p * max(1, nagg))(*[r.data_ptr() for r in results])
+        if dense:
+            L.check(self.lib.rfx_hip_group_emit(self._ctx, aarr, C.byref(t), keys.data_ptr(), first.data_ptr(), ptrs), "group_emit")
+        else:
+            L.check(self.lib.rfx_hip_hash_emit(self._ctx, aarr, C.byref(t), keys.data_ptr(), first.data_ptr(), ptrs), "hash_emit")
+        self.sync()
+        return dict(groups=g, keys=keys, first=first, results=results, dense=dense)
+
+    # ------------------------------------------------------------------ the select surface (core/query.c:607-654)
+    def select(self, query: Dict) -> Dict[str, torch.Tensor]:
+        """``(select {name: (fn col) ... from: t where: p by: k})`` with t a dict of equally long columns.
+
+        Keys ``from`` (required), ``where``, ``by`` (column name) are clauses; every other key is an output column
+        given as ``(fn, colname)``.  Without aggregates the filtered (and ungrouped) columns are returned, like
+        select_collect_fields (core/query.c:474-557).  Result: dict name -> device tensor, group key first.
+        """
+        if "from" not in query:
+            raise RfxError("'select' expects 'from' param")  # core/query.c:281
+        table = query["from"]
+        where, by = query.get("where"), query.get("by")
+        outs = [(k, v) for k, v in query.items() if k not in ("from", "where", "by", "take")]
+        lens = {int(c.numel()) for c in table.values()}
+        if len(lens) > 1:
+            raise RfxError("table columns differ in length")
+        n = lens.pop() if lens else 0
+        if by is not None:
+            aggs = [(fn, col) for _, (fn, col) in outs]
+            r = self.group_by(by, aggs, where, table)
+            res = {by if isinstance(by, str) else "by": r["keys"]}
+            for (name, _), col in zip(outs, r["results"]):
+                res[name] = col
+            return res
+        if outs:
+            aggs = [(fn, col) for _, (fn, col) in outs]
+            vals, _ = self.filter_aggr(aggs, where, table, nrows=n)
+            res = {}
+            for (name, (fn, col)), v in zip(outs, vals):
+                f64 = fn == "avg" or (col is not None and fn != "count" and table[col].dtype == torch.float64)
+                if v is None:
+                    v = float("nan") if f64 else L.NULL_I64
+                res[name] = torch.tensor([v], dtype=torch.float64 if f64 else torch.int64, device=self.device)
+            return res
+        if where is None:
+            return dict(table)
+        ids = self.where(where, table)
+        return {name: self.at_ids(col, ids) for name, col in table.items()}
+
+
+class _NotFlat(Exception):
+    pass
