@@ -113,8 +113,10 @@ typedef struct rfx_ctx rfx_ctx_t; /* opaque: device ordinal, stream, scratch wor
 int rfx_hip_device_count(void);
 const char *rfx_hip_last_error(void);
 const char *rfx_hip_version(void);
-/* stream == NULL: the context creates and owns a non-blocking stream.  Otherwise `stream` is a hipStream_t
- * owned by the caller (e.g. torch.cuda.current_stream().cuda_stream cast to a pointer). */
+/* stream == NULL: the context creates and owns a non-blocking stream.  stream == RFX_STREAM_LEGACY: the device's
+ * legacy default (null) stream -- what torch.cuda.current_stream().cuda_stream == 0 means.  Otherwise `stream` is a
+ * hipStream_t owned by the caller. */
+#define RFX_STREAM_LEGACY ((void *)(uintptr_t)1)
 int rfx_hip_ctx_create(int device, void *stream, rfx_ctx_t **out);
 int rfx_hip_ctx_destroy(rfx_ctx_t *ctx);
 int rfx_hip_ctx_sync(rfx_ctx_t *ctx);                 /* (syncs) */

@@ -38,7 +38,7 @@ extern "C" int rfx_hip_ctx_create(int device, void *stream, rfx_ctx_t **out) {
     c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     c->blocks_per_cu = 2; // tools/probe_hw: 2 workgroups per CU streams fastest (7.0 TB/s)
     if (stream) {
-        c->stream = (hipStream_t)stream;
+        c->stream = (stream == RFX_STREAM_LEGACY) ? (hipStream_t)0 : (hipStream_t)stream;
         c->own_stream = false;
     } else {
         RFX_HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
@@ -84,7 +84,7 @@ extern "C" int rfx_hip_ctx_set_stream(rfx_ctx_t *c, void *stream) {
         (void)hipStreamDestroy(c->stream);
         c->own_stream = false;
     }
-    c->stream = (hipStream_t)stream;
+    c->stream = (stream == RFX_STREAM_LEGACY) ? (hipStream_t)0 : (hipStream_t)stream;
     return RFX_OK;
 }
 
@@ -247,7 +247,7 @@ int rfx_plan_build(Plan *P, const rfx_pred_t *preds, int npred, int logic, const
     for (int i = 0; i < npred; i++) {
         const rfx_pred_t *p = &preds[i];
         PlanPred *q = &P->preds[i];
-        RFX_REQUIRE(p->d_col != NULL, RFX_EINVAL, "predicate column is NULL");
+        RFX_REQUIRE(p->d_col != NULL || nrows == 0, RFX_EINVAL, "predicate column is NULL");
         RFX_REQUIRE(p->col_type == RFX_I64 || p->col_type == RFX_F64, RFX_EINVAL, "predicate column type must be i64 or f64");
         RFX_REQUIRE(p->rhs_type == RFX_I64 || p->rhs_type == RFX_F64, RFX_EINVAL, "predicate rhs type must be i64 or f64");
         RFX_REQUIRE(p->op >= RFX_EQ && p->op <= RFX_GE, RFX_EINVAL, "bad comparison operator");
@@ -279,7 +279,7 @@ int rfx_plan_build(Plan *P, const rfx_pred_t *preds, int npred, int logic, const
             q->col = -1;
             q->f64 = 0;
         } else {
-            RFX_REQUIRE(a->d_col != NULL, RFX_EINVAL, "aggregate column is NULL");
+            RFX_REQUIRE(a->d_col != NULL || nrows == 0, RFX_EINVAL, "aggregate column is NULL");
             RFX_REQUIRE(a->col_type == RFX_I64 || a->col_type == RFX_F64, RFX_EINVAL, "aggregate column type must be i64 or f64");
             q->col = plan_col(P, a->d_col);
             RFX_REQUIRE(q->col >= 0, RFX_ELIMIT, "too many distinct columns");

@@ -223,7 +223,6 @@ static void launch_sel_bitmap(rfx_ctx *c, const Plan &P, int grid) {
 extern "C" int rfx_hip_where_begin(rfx_ctx_t *c, const rfx_pred_t *preds, int npred, int logic, const int8_t *d_mask,
                                    int64_t nrows, int64_t *count) {
     RFX_REQUIRE(c && count, RFX_EINVAL, "NULL argument");
-    RFX_REQUIRE((d_mask != NULL) != (npred > 0), RFX_EINVAL, "give either predicates or a byte mask");
     RFX_REQUIRE(nrows >= 0, RFX_EINVAL, "nrows < 0");
     c->where_n = -1;
     *count = 0;
@@ -232,6 +231,7 @@ extern "C" int rfx_hip_where_begin(rfx_ctx_t *c, const rfx_pred_t *preds, int np
         c->where_count = 0;
         return RFX_OK;
     }
+    RFX_REQUIRE((d_mask != NULL) != (npred > 0), RFX_EINVAL, "give either predicates or a byte mask");
     int rc = rfx_bitmap_reserve(c, ((nrows + RFX_CHUNK - 1) / RFX_CHUNK) * RFX_CHUNK);
     if (rc != RFX_OK) return rc;
     // blksum is sized per 2048 rows by rfx_bitmap_reserve; we need one entry per 512 rows (+1 for the total)

@@ -44,7 +44,8 @@ class Engine:
         self.device = torch.device("cuda", device if isinstance(device, int) else device.index)
         torch.cuda.set_device(self.device)
         self._ctx = C.c_void_p()
-        stream = torch.cuda.current_stream(self.device).cuda_stream
+        # run on torch's current stream so that tensor ops and librfx kernels are ordered without extra syncs
+        stream = torch.cuda.current_stream(self.device).cuda_stream or 1  # 0 = legacy default stream -> RFX_STREAM_LEGACY
         L.check(self.lib.rfx_hip_ctx_create(self.device.index, C.c_void_p(stream), C.byref(self._ctx)), "ctx_create")
         self._keep: List[torch.Tensor] = []
 

@@ -1,0 +1,265 @@
+"""GPU parity: every HIP entry point against the CPU oracle on the same seeded inputs (bit-exact for integer / index /
+key-order output, <= 1e-9 relative for f64 sums and averages -- the tolerance BASELINE.json's north_star states).
+
+All calls go through the C ABI of librfx.so (rayforce_amd.engine is a ctypes host).  The oracle (oracle/rfo.py) is the
+checker only."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import rfo
+
+pytestmark = pytest.mark.gpu
+
+NULL = -(2**63)
+RTOL = 1e-9
+
+
+def dev(eng, table):
+    return {k: eng.column(v) for k, v in table.items()}
+
+
+def same_f64(a, b, rtol=RTOL):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    assert a.shape == b.shape
+    nan_a, nan_b = np.isnan(a), np.isnan(b)
+    assert np.array_equal(nan_a, nan_b), "NaN pattern differs"
+    ok = ~nan_a
+    if ok.any():
+        inf = np.isinf(a[ok]) | np.isinf(b[ok])
+        assert np.array_equal(a[ok][inf], b[ok][inf])
+        fin = ~inf
+        scale = np.maximum(np.abs(b[ok][fin]), 1e-300)
+        assert np.all(np.abs(a[ok][fin] - b[ok][fin]) <= rtol * scale), float(np.max(np.abs(a[ok][fin] - b[ok][fin]) / scale))
+
+
+def check_select(eng, host, q):
+    got = eng.select({"from": dev(eng, host), **q})
+    want = rfo.select({"from": host, **q})
+    assert list(got.keys()) == list(want.keys())
+    for name in want:
+        g = got[name].cpu().numpy()
+        w = want[name]
+        assert g.dtype == w.dtype, (name, g.dtype, w.dtype)
+        if w.dtype == np.float64:
+            same_f64(g, w)
+        else:
+            assert np.array_equal(g, w), name
+    return got
+
+
+def table(n, seed=0, keys=1000, nulls=False):
+    t = {
+        "k": rfo.gen_i64(n, 4 + seed, keys),
+        "a": rfo.gen_i64(n, 2 + seed, 1_000_000),
+        "v": rfo.gen_f64(n, 5 + seed),
+        "w": rfo.gen_f64(n, 6 + seed) - 0.5,
+    }
+    if nulls and n:
+        r = rfo.gen_i64(n, 99 + seed, 100)
+        t["a"][r == 0] = NULL
+        t["v"][r == 1] = np.nan
+        t["w"][r == 2] = np.nan
+    return t
+
+
+# ---------------------------------------------------------------- generator
+@pytest.mark.parametrize("n,row0", [(0, 0), (1, 0), (1000, 7), (100_003, 12345)])
+def test_generator_matches_oracle(eng, n, row0):
+    assert np.array_equal(eng.gen_i64(n, 2, 1_000_000, row0).cpu().numpy(), rfo.gen_i64(n, 2, 1_000_000, row0))
+    assert np.array_equal(eng.gen_f64(n, 5, row0).cpu().numpy(), rfo.gen_f64(n, 5, row0))
+
+
+# ---------------------------------------------------------------- K1/K5 fused filter -> aggregates
+SIZES = [0, 1, 2, 63, 64, 511, 512, 513, 2047, 2048, 4097, 25_001, 100_003, 1_000_003]
+
+
+@pytest.mark.parametrize("n", SIZES)
+def test_filter_sum_i64_bit_exact(eng, n):
+    host = table(n)
+    check_select(eng, host, {"where": ("<", "a", 100_000), "s": ("sum", "a"), "c": ("count", "a")})
+
+
+@pytest.mark.parametrize("n", SIZES)
+@pytest.mark.parametrize("nulls", [False, True])
+def test_all_scalar_aggregates(eng, n, nulls):
+    host = table(n, nulls=nulls)
+    q = {"where": ("<", "a", 500_000), "s": ("sum", "a"), "f": ("sum", "v"), "mn": ("min", "a"), "mx": ("max", "a"),
+         "fm": ("min", "w"), "fx": ("max", "w"), "av": ("avg", "v"), "ai": ("avg", "a")}
+    check_select(eng, host, q)
+    check_select(eng, host, {"c": ("count", "v"), "s": ("sum", "w"), "first": ("first", "a")})
+
+
+@pytest.mark.parametrize("op", ["==", "!=", "<", ">", "<=", ">="])
+@pytest.mark.parametrize("kind", ["i64_i64", "i64_f64", "f64_f64", "f64_i64", "vec_vec", "vec_vec_mixed"])
+def test_comparison_matrix(eng, op, kind):
+    n = 10_007
+    host = table(n, nulls=True)
+    host["b"] = rfo.gen_i64(n, 77, 1_000_000)
+    lhs, rhs = {"i64_i64": ("a", 500_000), "i64_f64": ("a", 499_999.5), "f64_f64": ("v", 0.5), "f64_i64": ("w", 0),
+                "vec_vec": ("a", "b"), "vec_vec_mixed": ("a", "v")}[kind]
+    d = dev(eng, host)
+    mask = eng.cmp(op, d[lhs], d[rhs] if isinstance(rhs, str) else rhs).cpu().numpy()
+    want = rfo.cmp(op, host[lhs], host[rhs] if isinstance(rhs, str) else rhs)
+    assert np.array_equal(mask, want)
+    check_select(eng, host, {"where": (op, lhs, rhs), "c": ("count", "a"), "s": ("sum", "a")})
+
+
+def test_null_and_nan_ordering(eng):
+    # core/ops.h:96-121 : 0Nl < anything ; NaN is the smallest f64 ; NaN == NaN ; -0.0 == 0.0
+    a = np.array([1, NULL, 3, NULL, -5], np.int64)
+    f = np.array([0.0, -0.0, np.nan, 1.5, -np.inf], np.float64)
+    host = {"a": a, "f": f}
+    d = dev(eng, host)
+    for op in ["==", "!=", "<", ">", "<=", ">="]:
+        for rhs in (2, NULL, 0):
+            assert np.array_equal(eng.cmp(op, d["a"], rhs).cpu().numpy(), rfo.cmp(op, a, rhs)), (op, rhs)
+        for rhs in (0.0, -0.0, float("nan"), 1.5):
+            assert np.array_equal(eng.cmp(op, d["f"], rhs).cpu().numpy(), rfo.cmp(op, f, rhs)), (op, rhs)
+    assert eng.cmp("<", d["a"], 2).cpu().tolist() == [1, 1, 0, 1, 1]
+
+
+def test_multi_predicate_and_or(eng):
+    host = table(200_003, nulls=True)
+    w3 = ("and", ("<", "v", 0.316228), (">", "w", 0.183772), ("!=", "a", 250_000))
+    check_select(eng, host, {"where": w3, "av": ("avg", "w"), "mn": ("min", "w"), "mx": ("max", "w"), "c": ("count", "w")})
+    wo = ("or", ("<", "a", 1000), (">", "v", 0.999), ("==", "k", 7))
+    check_select(eng, host, {"where": wo, "s": ("sum", "a"), "c": ("count", "a")})
+    nested = ("and", ("or", ("<", "a", 1000), (">", "v", 0.9)), ("!=", "k", 3))
+    check_select(eng, host, {"where": nested, "s": ("sum", "a"), "f": ("sum", "v")})
+
+
+def test_empty_selection_rules(eng):
+    # tests/lang.c:2508,2535,4070 : empty sum = 0, empty min/max = null, avg = NaN
+    host = table(5000)
+    got = check_select(eng, host, {"where": ("<", "a", -1), "s": ("sum", "a"), "f": ("sum", "v"), "mn": ("min", "a"), "mx": ("max", "v"),
+                                   "av": ("avg", "a"), "c": ("count", "a")})
+    assert int(got["s"][0]) == 0 and int(got["c"][0]) == 0 and int(got["mn"][0]) == NULL
+    assert math.isnan(float(got["mx"][0])) and math.isnan(float(got["av"][0]))
+
+
+def test_i64_sum_wraps(eng):
+    a = np.full(1000, 2**62, np.int64)
+    got = eng.select({"from": dev(eng, {"a": a}), "s": ("sum", "a")})
+    assert int(got["s"][0]) == int(np.sum(a.astype(np.uint64)).astype(np.int64))
+    assert int(got["s"][0]) == int(rfo.select({"from": {"a": a}, "s": ("sum", "a")})["s"][0])
+
+
+# ---------------------------------------------------------------- K2 masks, K3 where, K4 gather
+@pytest.mark.parametrize("n", [0, 1, 7, 8, 9, 511, 512, 513, 25_001, 1_000_003])
+def test_where_ids_bit_exact(eng, n):
+    host = table(n)
+    d = dev(eng, host)
+    for spec in [("<", "a", 100_000), ("<", "a", 10), (">=", "a", 0), ("and", ("<", "a", 500_000), (">", "v", 0.5))]:
+        want = rfo.where(rfo.mask_of(spec, host))
+        got = eng.where(spec, d)
+        assert got.dtype == torch.int64 and np.array_equal(got.cpu().numpy(), want), spec
+        got_m = eng.where(eng.mask_of(spec, d))
+        assert np.array_equal(got_m.cpu().numpy(), want), spec
+    if n:
+        assert np.array_equal(eng.where(("<", "a", 100_000), d, row0=10**12).cpu().numpy(), rfo.where(rfo.mask_of(("<", "a", 100_000), host)) + 10**12)
+
+
+def test_where_across_parallel_threshold(eng):
+    # tests/lang.c:2893-2897 crosses POOL_SPLIT_THRESHOLD (16 384) at 25 001 rows
+    n = 25_001
+    a = np.arange(n, dtype=np.int64)
+    d = {"a": eng.column(a)}
+    got = eng.where(("and", (">=", "a", 5), ("<", "a", 20_000)), d)
+    assert np.array_equal(got.cpu().numpy(), np.arange(5, 20_000, dtype=np.int64))
+
+
+def test_mask_logic_and_gather(eng):
+    n = 100_003
+    host = table(n)
+    d = dev(eng, host)
+    m1, m2 = eng.lt(d["a"], 500_000), eng.gt(d["v"], 0.25)
+    assert np.array_equal(eng.and_(m1, m2).cpu().numpy(), rfo.and_(rfo.cmp("<", host["a"], 500_000), rfo.cmp(">", host["v"], 0.25)))
+    assert np.array_equal(eng.or_(m1, m2).cpu().numpy(), rfo.or_(rfo.cmp("<", host["a"], 500_000), rfo.cmp(">", host["v"], 0.25)))
+    ids = eng.where(m1)
+    assert np.array_equal(eng.at_ids(d["v"], ids).cpu().numpy(), rfo.at_ids(host["v"], ids.cpu().numpy()))
+    assert np.array_equal(eng.at_ids(d["a"], ids).cpu().numpy(), host["a"][ids.cpu().numpy()])
+    # select without aggregates = filter_collect of every column (core/filter.c:51-165)
+    check_select(eng, host, {"where": ("<", "a", 1000)})
+
+
+# ---------------------------------------------------------------- group-by
+GSIZES = [1, 2, 513, 25_001, 300_007]
+
+
+@pytest.mark.parametrize("n", GSIZES)
+@pytest.mark.parametrize("keys", [1, 7, 1000, 20_000])
+def test_group_by_dense_order_and_aggregates(eng, n, keys):
+    host = table(n, keys=keys)
+    q = {"by": "k", "s": ("sum", "v"), "si": ("sum", "a"), "c": ("count", "a"), "mn": ("min", "a"), "mx": ("max", "w"), "av": ("avg", "v"),
+         "ai": ("avg", "a")}
+    check_select(eng, host, q)
+
+
+@pytest.mark.parametrize("n", [1000, 200_003])
+def test_group_by_with_where_and_nulls(eng, n):
+    host = table(n, keys=300, nulls=True)
+    q = {"where": ("and", ("<", "a", 700_000), (">", "v", 0.1)), "by": "k", "s": ("sum", "v"), "si": ("sum", "a"), "c": ("count", "v"),
+         "mn": ("min", "w"), "mx": ("max", "a"), "av": ("avg", "w"), "fi": ("first", "a")}
+    check_select(eng, host, q)
+
+
+def test_group_null_semantics_golden(eng):
+    # SURVEY 0.6 (oracle-verified): grouped sum PROPAGATES null, scalar sum skips it; grouped min of an all-null group is
+    # INF, max is null; count counts nulls; avg divides by the non-null count.
+    k = np.array([1, 1, 2, 3, 3], np.int64)
+    v = np.array([1, NULL, 5, NULL, NULL], np.int64)
+    f = np.array([1.0, np.nan, 5.0, np.nan, np.nan])
+    host = {"k": k, "v": v, "f": f}
+    got = check_select(eng, host, {"by": "k", "s": ("sum", "v"), "fs": ("sum", "f"), "mn": ("min", "v"), "mx": ("max", "v"), "fmn": ("min", "f"),
+                                   "fmx": ("max", "f"), "c": ("count", "v"), "av": ("avg", "v")})
+    assert got["k"].tolist() == [1, 2, 3]
+    assert got["s"].tolist() == [NULL, 5, NULL]
+    assert got["mn"].tolist() == [1, 5, 2**63 - 1] and got["mx"].tolist() == [1, 5, NULL]
+    assert got["c"].tolist() == [2, 1, 2]
+    assert got["fmn"].cpu().numpy()[2] == np.inf and np.isnan(got["fmx"].cpu().numpy()[2])
+    assert int(eng.select({"from": dev(eng, host), "s": ("sum", "v")})["s"][0]) == 6
+
+
+def test_group_first_occurrence_order(eng):
+    # keys [3 1 3 2 1 3] -> groups 3, 1, 2
+    host = {"k": np.array([3, 1, 3, 2, 1, 3], np.int64), "v": np.arange(6, dtype=np.float64)}
+    got = check_select(eng, host, {"by": "k", "s": ("sum", "v")})
+    assert got["k"].tolist() == [3, 1, 2] and got["s"].tolist() == [7.0, 5.0, 3.0]
+
+
+def test_group_by_large_range_paths(eng):
+    # range 1e6 > LDS table budget -> partitioned / device-atomic path; IDS vs SHIFT boundary (524 288) on both sides
+    n = 2_000_003
+    for keys in (524_288, 524_289, 1_000_000):
+        host = table(n, keys=keys)
+        check_select(eng, host, {"by": "k", "s": ("sum", "v"), "c": ("count", "v")})
+        check_select(eng, host, {"where": ("<", "a", 100_000), "by": "k", "s": ("sum", "v"), "mx": ("max", "a")})
+
+
+def test_group_by_sparse_keys_hash_path(eng):
+    # range > rows -> open-addressed path (core/index.c:1959-1977).  Order contract there is key -> aggregate map only
+    # when the reference runs multi-threaded; single-threaded (what the oracle restates) it is first occurrence.
+    n = 50_000
+    host = table(n, keys=1000)
+    host["k"] = host["k"] * 1_000_003 - 77  # spread 1000 distinct keys over a huge range
+    got = check_select(eng, host, {"by": "k", "s": ("sum", "v"), "c": ("count", "a"), "mx": ("max", "a")})
+    assert len(got["k"]) == 1000
+    host["k"][::5] = rfo.gen_i64(n, 123, 2**62)[::5]  # many distinct keys
+    check_select(eng, host, {"where": (">", "v", 0.5), "by": "k", "s": ("sum", "a")})
+
+
+def test_hash_primitives_pinned(eng):
+    import ctypes as C
+    from rayforce_amd import _lib as L
+    x = rfo.gen_i64(4096, 11, 2**62) - 2**61
+    d = eng.column(x)
+    out = eng.empty(len(x))
+    L.check(eng.lib.rfx_hip_hash_fnv1a_i64(eng._ctx, d.data_ptr(), len(x), out.data_ptr()))
+    want = np.array([rfo.lib().rfo_hash_fnv1a(int(v)) for v in x], np.uint64)
+    assert np.array_equal(out.cpu().numpy().view(np.uint64), want)
+    L.check(eng.lib.rfx_hip_hash_mix_u64(eng._ctx, d.data_ptr(), len(x), 0x9ddfea08eb382d69, out.data_ptr()))
+    want = np.array([rfo.lib().rfo_hash_index_u64(0x9ddfea08eb382d69, int(v) & (2**64 - 1)) for v in x], np.uint64)
+    assert np.array_equal(out.cpu().numpy().view(np.uint64), want)
