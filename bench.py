@@ -1,0 +1,298 @@
+#!/usr/bin/env python
+"""bench.py -- the hot-path benchmark of BASELINE.json on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c2b|c3|c5] [--rows R] [--no-cpu-baseline] [--no-also]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A "step" = one execution of the query over the HBM-resident synthetic columns of this rank (kernels + the one merge
+collective + result read-back).  Weak scaling: every GPU holds `rows` rows (rows [rank*rows, (rank+1)*rows) of a
+virtual N*rows-row table, generated on the device with the counter-based splitmix64 of SURVEY 8d), so per-GPU work is
+fixed and `value` = N*rows / max-over-ranks step time.
+
+Workloads (BASELINE.json configs / SURVEY 8d):
+  c2   configs[1]  select sum(a) where a < 100000      a: i64[1e9] in [0,1e6)              8 B/row   <- default, `value`
+  c2b  north-star  select sum(b) where a < 100000      + b: f64[1e9]                       16 B/row
+  c3   configs[2]  select sum(v) by k                  k: i64[1e9] in [0,1e6), v: f64      16 B/row
+  c5   configs[4]  avg,min,max(d) where a<.316228 & b>.683772 & c!=.25   4 x f64[2.5e8]/GPU 32 B/row
+One JSON line on stdout (rank 0); everything else goes to stderr.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3-7.0 TB/s achievable)
+METRIC = "rows/s on filter→group-by→sum, 1e9-row i64/f64; % HBM roofline at 1/2/4/8 GPU"
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+WORKLOADS = {
+    "c2": dict(desc="configs[1]: select sum(a) where a < 100000, a i64 uniform [0,1e6), seed 2", rows=1_000_000_000, bytes_per_row=8, dtype="int64",
+               kernel="k_filter_aggr<1,1,4>"),
+    "c2b": dict(desc="north-star: select sum(b) where a < 100000, a i64 seed 2, b f64 seed 3", rows=1_000_000_000, bytes_per_row=16, dtype="f64",
+                kernel="k_filter_aggr<2,1,4>"),
+    "c3": dict(desc="configs[2]: select sum(v) by k, k i64 uniform [0,1e6) seed 4, v f64 seed 5", rows=1_000_000_000, bytes_per_row=16, dtype="f64",
+               kernel="k_part_scatter+k_part_aggregate"),
+    "c5": dict(desc="configs[4] per-GPU shard: avg,min,max(d) where a<0.316228 and b>0.683772 and c!=0.25, 4 x f64 seeds 6-9", rows=250_000_000,
+               bytes_per_row=32, dtype="f64", kernel="k_filter_aggr<4,4,2>"),
+}
+
+
+class Job:
+    """One workload on this rank: device columns + a `step()` that runs the whole query and returns its result."""
+
+    def __init__(self, name, eng, sharded, rows, row0):
+        from rayforce_amd import _lib as L
+        self.name, self.eng, self.sh, self.rows = name, eng, sharded, rows
+        g = eng
+        if name == "c2":
+            self.t = {"a": g.gen_i64(rows, 2, 1_000_000, row0)}
+            self.aggs, self.where = [("sum", "a")], ("<", "a", 100_000)
+        elif name == "c2b":
+            self.t = {"a": g.gen_i64(rows, 2, 1_000_000, row0), "b": g.gen_f64(rows, 3, row0)}
+            self.aggs, self.where = [("sum", "b")], ("<", "a", 100_000)
+        elif name == "c3":
+            self.t = {"k": g.gen_i64(rows, 4, 1_000_000, row0), "v": g.gen_f64(rows, 5, row0)}
+            self.aggs, self.where = [("sum", "v")], None
+        elif name == "c5":
+            self.t = {c: g.gen_f64(rows, s, row0) for c, s in zip("abcd", (6, 7, 8, 9))}
+            self.aggs = [("avg", "d"), ("min", "d"), ("max", "d")]
+            self.where = ("and", ("<", "a", 0.316228), (">", "b", 0.683772), ("!=", "c", 0.25))
+        else:
+            raise SystemExit(f"unknown workload {name}")
+        g.sync()
+        self.L = L
+
+    def step(self):
+        if self.name == "c3":
+            if self.sh is not None:
+                return self.sh.group_by("k", self.aggs, self.where, self.t)
+            return self.eng.group_by("k", self.aggs, self.where, self.t)
+        if self.sh is not None:
+            return self.sh.filter_aggr(self.aggs, self.where, self.t)
+        return self.eng.filter_aggr(self.aggs, self.where, self.t, nrows=self.rows)
+
+
+def timed(job: Job, steps: int, warmup: int, world: int):
+    eng = job.eng
+    for _ in range(warmup):
+        job.step()
+    eng.profile(True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    kms = []
+    t0 = time.perf_counter()
+    res = None
+    for _ in range(steps):
+        res = job.step()
+        kms.append(eng.last_kernel_ms())
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    eng.profile(False)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=eng.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t[0])
+    return dt, sum(kms) / max(1, len(kms)), res
+
+
+def run_workload(name, eng, sharded, rows, row0, steps, warmup, world):
+    w = WORKLOADS[name]
+    job = Job(name, eng, sharded, rows, row0)
+    dt, kms, res = timed(job, steps, warmup, world)
+    ms_step = dt * 1e3 / steps
+    value = world * rows / (dt / steps)
+    alg_bytes = w["bytes_per_row"] * rows  # per launch, per GPU (SURVEY 8d figures, stated in DESIGN.md)
+    achieved = alg_bytes / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
+    out = dict(workload=name, rows_per_gpu=rows, ms_per_step=ms_step, rows_per_s=value, kernel_ms=kms, achieved_GBps=achieved,
+               frac=achieved / HBM_PEAK_GBPS, result=_brief(res))
+    del job
+    torch.cuda.empty_cache()
+    return out
+
+
+def _brief(res):
+    if isinstance(res, dict):
+        return {"groups": int(res["groups"])}
+    vals, sel = res
+    return {"values": vals, "selected": sel}
+
+
+def pmc_traffic(name):
+    """HBM bytes per launch from the committed rocprofv3 --pmc summary (profiles/), corrected as MI355X_MICROARCH.md
+    prescribes; None when that workload has not been profiled."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f).get(name)
+    except Exception:
+        return None
+
+
+# ------------------------------------------------------------------------------------------------ CPU baseline
+def cpu_baseline(name, sample_rows):
+    """The reference itself (oracle/_ref/rayforce, kind 'reference') or -- when it is not built -- the C restatement
+    (kind 'port'), timed on this box's host cores over a bounded sample of the same workload."""
+    import numpy as np
+    from oracle import ref, rfo
+    cores = os.cpu_count() or 1
+    rfo.set_threads(cores)
+    t0 = time.perf_counter()
+    if name == "c2":
+        cols = {"a": rfo.gen_i64(sample_rows, 2, 1_000_000)}
+        q = "(select {s: (sum a) from: t where: (< a 100000)})"
+        oq = {"where": ("<", "a", 100_000), "s": ("sum", "a")}
+    elif name == "c2b":
+        cols = {"a": rfo.gen_i64(sample_rows, 2, 1_000_000), "b": rfo.gen_f64(sample_rows, 3)}
+        q = "(select {s: (sum b) from: t where: (< a 100000)})"
+        oq = {"where": ("<", "a", 100_000), "s": ("sum", "b")}
+    elif name == "c3":
+        cols = {"k": rfo.gen_i64(sample_rows, 4, 1_000_000), "v": rfo.gen_f64(sample_rows, 5)}
+        q = "(select {s: (sum v) from: t by: k})"
+        oq = {"by": "k", "s": ("sum", "v")}
+    else:
+        cols = {c: rfo.gen_f64(sample_rows, s) for c, s in zip("abcd", (6, 7, 8, 9))}
+        q = "(select {x: (avg d) y: (min d) z: (max d) from: t where: (and (< a 0.316228) (> b 0.683772) (!= c 0.25))})"
+        oq = {"where": ("and", ("<", "a", 0.316228), (">", "b", 0.683772), ("!=", "c", 0.25)), "x": ("avg", "d"), "y": ("min", "d"), "z": ("max", "d")}
+    log(f"[cpu_baseline] generated {sample_rows} sample rows in {time.perf_counter() - t0:.1f}s")
+    reps = 5
+    if ref.available():
+        try:
+            shm = "/dev/shm" if os.path.isdir("/dev/shm") else None
+            with ref.Session(root=shm) as s:
+                # materialise the mmapped column files into heap vectors first (the GPU path is timed HBM-resident too)
+                for k, v in cols.items():
+                    s.put(k, v)
+                    s.eval(f"(set {k} (+ {k} 0))" if v.dtype == np.int64 else f"(set {k} (+ {k} 0.0))")
+                names = " ".join(cols.keys())
+                s.eval(f"(set t (table [{names}] (list {names})))")
+                s.eval(f"(set warm {q})")
+                s.out("ms", f"(enlist (timeit {reps} {q}))")
+                out = s.run(timeout=900)
+            ms = float(out["ms"][0]) / reps
+            if ms and ms > 0:
+                return dict(value=sample_rows / (ms * 1e-3), unit="rows/s", cores=cores, kind="reference", ms_per_query=ms,
+                            sample=f"{name}: first {sample_rows} rows of the workload (same seeds), real RayforceDB build (oracle/_ref, gcc -O3 "
+                                   f"x86-64-v3, pool = all {cores} hardware threads), (timeit {reps} query) after one warm run")
+            log("[cpu_baseline] reference returned no timing, falling back to the port")
+        except Exception as e:  # noqa: BLE001
+            log(f"[cpu_baseline] reference run failed ({e}); falling back to the port")
+    best = None
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        rfo.select({"from": cols, **oq})
+        d = time.perf_counter() - t0
+        best = d if best is None else min(best, d)
+    return dict(value=sample_rows / best, unit="rows/s", cores=cores, kind="port", ms_per_query=best * 1e3,
+                sample=f"{name}: first {sample_rows} rows of the workload (same seeds), C restatement oracle/librfo.so with {cores} OpenMP threads, "
+                       f"best of {reps}")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="c2", choices=list(WORKLOADS))
+    ap.add_argument("--rows", type=int, default=0, help="rows per GPU (default: the workload's BASELINE size)")
+    ap.add_argument("--cpu-sample-rows", type=int, default=100_000_000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-also", action="store_true", help="skip the secondary workloads in the 'also' field")
+    ap.add_argument("--blocks-per-cu", type=int, default=0)
+    ap.add_argument("--tune-flags", type=int, default=0, help="rfx_hip_ctx_tune flags (kernel-variant experiments)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if args.gpus != world:
+        log(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the MI355X path has no CPU fallback")
+
+    from rayforce_amd.engine import Engine
+    from rayforce_amd.dist import ShardedEngine
+    eng = Engine(local_rank)
+    if args.blocks_per_cu or args.tune_flags:
+        eng.tune(blocks_per_cu=args.blocks_per_cu, flags=args.tune_flags)
+    name = args.workload
+    rows = args.rows or WORKLOADS[name]["rows"]
+    sharded = ShardedEngine(eng, rows) if world > 1 else None
+    row0 = rank * rows
+
+    main_r = run_workload(name, eng, sharded, rows, row0, args.steps, args.warmup, world)
+    log(f"[bench] {name}: {main_r}")
+    also = {}
+    if not args.no_also and world == 1 and not args.rows:
+        for other in WORKLOADS:
+            if other == name:
+                continue
+            try:
+                r = run_workload(other, eng, None, WORKLOADS[other]["rows"], 0, max(3, args.steps // 4), 2, 1)
+                also[other] = {k: r[k] for k in ("rows_per_gpu", "ms_per_step", "rows_per_s", "kernel_ms", "achieved_GBps", "frac")}
+                log(f"[bench] also {other}: {also[other]}")
+            except Exception as e:  # noqa: BLE001
+                also[other] = {"error": str(e)[:200]}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:
+            cpu = cpu_baseline(name, min(args.cpu_sample_rows, rows))
+        except Exception as e:  # noqa: BLE001
+            log(f"[bench] cpu_baseline failed: {e}")
+            cpu = None
+
+    if rank == 0:
+        w = WORKLOADS[name]
+        line = {
+            "metric": METRIC,
+            "value": main_r["rows_per_s"],
+            "unit": "rows/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": main_r["ms_per_step"],
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": w["dtype"],
+            "data": "synthetic",
+            "config": {"workload": f"{name}: {w['desc']}", "rows_per_gpu": rows, "total_rows": rows * world,
+                       "sharding": f"row-range x{world}" if world > 1 else "single GPU", "resident": "HBM (columns generated on device)",
+                       "result": main_r["result"]},
+            "roofline": {"bound": "hbm", "achieved": main_r["achieved_GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": main_r["frac"],
+                         "traffic": pmc_traffic(name), "kernel": w["kernel"], "kernel_ms": main_r["kernel_ms"],
+                         "algorithmic_bytes_per_launch": w["bytes_per_row"] * rows},
+            "cpu_baseline": cpu,
+        }
+        if also:
+            line["also"] = also
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    eng.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -134,6 +134,11 @@ int rfx_hip_memset(rfx_ctx_t *ctx, void *d_dst, int byte, size_t bytes);
 /* ---- timing on the context's stream (bench.py measures kernels with these HIP events) ---- */
 int rfx_hip_timer_start(rfx_ctx_t *ctx);
 int rfx_hip_timer_stop(rfx_ctx_t *ctx, float *ms); /* (syncs) */
+/* Kernel-level profile: when enabled, every entry point brackets its DOMINANT kernel (the one streaming pass over the
+ * columns: k_filter_aggr, k_sel_bitmap, k_group_dense, k_part_scatter + k_part_aggregate ...) with HIP events on
+ * the context's stream; rfx_hip_last_kernel_ms returns that kernel time of the most recent call.  (syncs) */
+int rfx_hip_ctx_profile(rfx_ctx_t *ctx, int enable);
+int rfx_hip_last_kernel_ms(rfx_ctx_t *ctx, float *ms);
 
 /* ---- synthetic columns: counter-based splitmix64, element r = mix(seed + (r+1)*0x9E3779B97F4A7C15) ----
  * i64: value % modulus (modulus > 0);  f64: (value >> 11) * 2^-53 in [0,1).  row0 = global id of d_out[0]. */

@@ -83,6 +83,8 @@ PROTOTYPES = {
     "rfx_hip_memset": (C.c_int, [_ctx, C.c_void_p, C.c_int, C.c_size_t]),
     "rfx_hip_timer_start": (C.c_int, [_ctx]),
     "rfx_hip_timer_stop": (C.c_int, [_ctx, _P(C.c_float)]),
+    "rfx_hip_ctx_profile": (C.c_int, [_ctx, C.c_int]),
+    "rfx_hip_last_kernel_ms": (C.c_int, [_ctx, _P(C.c_float)]),
     "rfx_hip_gen_i64": (C.c_int, [_ctx, C.c_void_p, C.c_int64, C.c_uint64, C.c_int64, C.c_uint64]),
     "rfx_hip_gen_f64": (C.c_int, [_ctx, C.c_void_p, C.c_int64, C.c_uint64, C.c_int64]),
     "rfx_hip_filter_aggr": (C.c_int, [_ctx, _P(Pred), C.c_int, C.c_int, _P(Agg), C.c_int, C.c_int64, C.c_int64, C.c_void_p]),

@@ -44,6 +44,9 @@ struct rfx_ctx {
     int blocks_per_cu; // streaming-kernel grid = num_cus * blocks_per_cu
     int flags;
     hipEvent_t ev0, ev1;
+    hipEvent_t evk0, evk1; // dominant-kernel bracket (profile mode)
+    int profile;
+    int evk_valid;
     // scratch: per-block partials of the fused reductions
     void *d_ws;
     size_t ws_bytes;
@@ -66,6 +69,8 @@ struct rfx_ctx {
 int rfx_ws_reserve(rfx_ctx *ctx, size_t bytes);
 int rfx_bitmap_reserve(rfx_ctx *ctx, i64 nrows);
 int rfx_gid_reserve(rfx_ctx *ctx, i64 slots);
+#define RFX_KERNEL_BEGIN(c) do { if ((c)->profile) { (void)hipEventRecord((c)->evk0, (c)->stream); } } while (0)
+#define RFX_KERNEL_END(c) do { if ((c)->profile) { (void)hipEventRecord((c)->evk1, (c)->stream); (c)->evk_valid = 1; } } while (0)
 static inline int rfx_grid(const rfx_ctx *ctx) { return ctx->num_cus * ctx->blocks_per_cu; }
 
 // ------------------------------------------------------------------------------------------------

@@ -46,6 +46,8 @@ extern "C" int rfx_hip_ctx_create(int device, void *stream, rfx_ctx_t **out) {
     }
     RFX_HIP_CHECK(hipEventCreate(&c->ev0));
     RFX_HIP_CHECK(hipEventCreate(&c->ev1));
+    RFX_HIP_CHECK(hipEventCreate(&c->evk0));
+    RFX_HIP_CHECK(hipEventCreate(&c->evk1));
     c->pin_bytes = 1 << 16;
     RFX_HIP_CHECK(hipHostMalloc(&c->h_pin, c->pin_bytes, hipHostMallocDefault));
     int rc = rfx_ws_reserve(c, 4u << 20);
@@ -65,6 +67,8 @@ extern "C" int rfx_hip_ctx_destroy(rfx_ctx_t *c) {
     if (c->h_pin) (void)hipHostFree(c->h_pin);
     (void)hipEventDestroy(c->ev0);
     (void)hipEventDestroy(c->ev1);
+    (void)hipEventDestroy(c->evk0);
+    (void)hipEventDestroy(c->evk1);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     free(c);
     return RFX_OK;
@@ -186,6 +190,20 @@ extern "C" int rfx_hip_timer_stop(rfx_ctx_t *c, float *ms) {
     RFX_HIP_CHECK(hipEventRecord(c->ev1, c->stream));
     RFX_HIP_CHECK(hipEventSynchronize(c->ev1));
     RFX_HIP_CHECK(hipEventElapsedTime(ms, c->ev0, c->ev1));
+    return RFX_OK;
+}
+
+extern "C" int rfx_hip_ctx_profile(rfx_ctx_t *c, int enable) {
+    RFX_REQUIRE(c, RFX_EINVAL, "ctx is NULL");
+    c->profile = enable ? 1 : 0;
+    c->evk_valid = 0;
+    return RFX_OK;
+}
+extern "C" int rfx_hip_last_kernel_ms(rfx_ctx_t *c, float *ms) {
+    RFX_REQUIRE(c && ms, RFX_EINVAL, "NULL argument");
+    RFX_REQUIRE(c->profile && c->evk_valid, RFX_ESTATE, "no profiled kernel recorded (call rfx_hip_ctx_profile(ctx, 1) first)");
+    RFX_HIP_CHECK(hipEventSynchronize(c->evk1));
+    RFX_HIP_CHECK(hipEventElapsedTime(ms, c->evk0, c->evk1));
     return RFX_OK;
 }
 

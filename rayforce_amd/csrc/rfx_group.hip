@@ -35,6 +35,8 @@ __global__ __launch_bounds__(RFX_BLOCK) void k_group_dense(const Plan P, const G
     extern __shared__ __attribute__((aligned(16))) u64 smem[];
     const int tid = threadIdx.x;
     const i64 range = G.range;
+    PredSet<RFX_MAX_PREDS> S;
+    predset_load<RFX_MAX_PREDS>(P, S);
 
     // LDS layout: [first | acc0 | (cnt0) | acc1 | ...] each `range` cells
     if (LDS) {
@@ -82,7 +84,7 @@ __global__ __launch_bounds__(RFX_BLOCK) void k_group_dense(const Plan P, const G
                 for (int c = 0; c < NC; c++) v[c][e] = in ? P.cols[c][row] : 0ULL;
             }
         }
-        const unsigned m = eval_preds<NC, E>(P, v, valid);
+        const unsigned m = eval_preds<NC, E, RFX_MAX_PREDS>(S, v, valid);
         if (m == 0) continue;
         u64 key[E];
         sel_col<NC, E>(key, v, G.key_idx);
@@ -226,6 +228,7 @@ extern "C" int rfx_hip_group_dense_accumulate(rfx_ctx_t *c, const int64_t *d_key
     }
     if (!use_lds) lds_bytes = 0;
     int grid = rfx_grid(c);
+    RFX_KERNEL_BEGIN(c);
     switch (P.ncols) {
         case 1: launch_group<1>(c, P, G, grid, lds_bytes); break;
         case 2: launch_group<2>(c, P, G, grid, lds_bytes); break;
@@ -236,6 +239,7 @@ extern "C" int rfx_hip_group_dense_accumulate(rfx_ctx_t *c, const int64_t *d_key
         case 7: launch_group<7>(c, P, G, grid, lds_bytes); break;
         default: launch_group<8>(c, P, G, grid, lds_bytes); break;
     }
+    RFX_KERNEL_END(c);
     RFX_HIP_CHECK(hipGetLastError());
     return RFX_OK;
 }

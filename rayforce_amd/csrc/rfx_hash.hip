@@ -68,6 +68,8 @@ __global__ __launch_bounds__(RFX_BLOCK) void k_group_hash(const Plan P, const Ha
     constexpr int TILE = RFX_BLOCK * E;
     constexpr int JSTRIDE = RFX_BLOCK * 2;
     const int tid = threadIdx.x;
+    PredSet<RFX_MAX_PREDS> S;
+    predset_load<RFX_MAX_PREDS>(P, S);
     const i64 ntiles = (P.nrows + TILE - 1) / TILE;
     for (i64 t = blockIdx.x; t < ntiles; t += gridDim.x) {
         const i64 base = t * TILE + tid * 2;
@@ -81,7 +83,7 @@ __global__ __launch_bounds__(RFX_BLOCK) void k_group_hash(const Plan P, const Ha
 #pragma unroll
             for (int c = 0; c < NC; c++) v[c][e] = in ? P.cols[c][row] : 0ULL;
         }
-        const unsigned m = eval_preds<NC, E>(P, v, valid);
+        const unsigned m = eval_preds<NC, E, RFX_MAX_PREDS>(S, v, valid);
         if (m == 0) continue;
         u64 key[E];
         sel_col<NC, E>(key, v, H.key_idx);

@@ -67,13 +67,14 @@ __global__ __launch_bounds__(RFX_BLOCK) void k_filter_aggr_final(const Plan P, c
 
 int rfx_run_filter_aggr(rfx_ctx *c, Plan &P, rfx_partial_t *d_out) {
     // a plan with no columns at all (COUNT without predicate): give it a harmless column-free path
-    int grid = rfx_grid(c);
+    int grid = c->num_cus * (c->blocks_per_cu > 0 ? c->blocks_per_cu * 2 : 4); // streaming reductions want ~4 workgroups per CU (profiles/r01_bpc_sweep.txt)
     const i64 tiles = P.nrows / (RFX_BLOCK * 4) + 1;
     if (tiles < grid) grid = (int)tiles;
     int rc = rfx_ws_reserve(c, (size_t)grid * 9 * sizeof(Acc));
     if (rc != RFX_OK) return rc;
     Acc *ws = (Acc *)c->d_ws;
     int na_stride = 0;
+    RFX_KERNEL_BEGIN(c);
     switch (P.ncols) {
         case 0:
         case 1: rfx_launch_filter_aggr_nc1(c, P, grid, ws, &na_stride); break;
@@ -85,6 +86,7 @@ int rfx_run_filter_aggr(rfx_ctx *c, Plan &P, rfx_partial_t *d_out) {
         case 7: rfx_launch_filter_aggr_nc7(c, P, grid, ws, &na_stride); break;
         default: rfx_launch_filter_aggr_nc8(c, P, grid, ws, &na_stride); break;
     }
+    RFX_KERNEL_END(c);
     RFX_HIP_CHECK(hipGetLastError());
     hipLaunchKernelGGL(k_filter_aggr_final, dim3(1), dim3(RFX_BLOCK), 0, c->stream, P, (const Acc *)ws, grid, na_stride, d_out);
     RFX_HIP_CHECK(hipGetLastError());
@@ -261,6 +263,8 @@ extern "C" int rfx_hip_scope_i64(rfx_ctx_t *c, const int64_t *d_key, const rfx_p
 // 8 rows per lane -> one 8-byte store of 8 mask bytes.
 template <int NC>
 __global__ __launch_bounds__(RFX_BLOCK) void k_cmp_mask(const Plan P, int8_t *__restrict__ out) {
+    PredSet<RFX_MAX_PREDS> S;
+    predset_load<RFX_MAX_PREDS>(P, S);
     const i64 n8 = P.nrows / 8;
     for (i64 g = blockIdx.x * (i64)RFX_BLOCK + threadIdx.x; g < n8; g += (i64)gridDim.x * RFX_BLOCK) {
         u64 v[NC][8];
@@ -273,7 +277,7 @@ __global__ __launch_bounds__(RFX_BLOCK) void k_cmp_mask(const Plan P, int8_t *__
                 v[c][2 * j + 1] = q.y;
             }
         }
-        unsigned m = eval_preds<NC, 8>(P, v, 0xffu);
+        unsigned m = eval_preds<NC, 8, RFX_MAX_PREDS>(S, v, 0xffu);
         u64 bytes = 0;
 #pragma unroll
         for (int e = 0; e < 8; e++) bytes |= (u64)((m >> e) & 1u) << (8 * e);
@@ -285,7 +289,7 @@ __global__ __launch_bounds__(RFX_BLOCK) void k_cmp_mask(const Plan P, int8_t *__
             u64 v[NC][1];
 #pragma unroll
             for (int c = 0; c < NC; c++) v[c][0] = P.cols[c][r];
-            out[r] = (int8_t)(eval_preds<NC, 1>(P, v, 1u) & 1u);
+            out[r] = (int8_t)(eval_preds<NC, 1, RFX_MAX_PREDS>(S, v, 1u) & 1u);
         }
     }
 }

@@ -1,6 +1,14 @@
 // rfx_scalar_kernel.hpp -- internal: the fused predicate -> aggregate register-tile machinery (K1/K5),
-// shared by rfx_scalar.hip (final fold, masks) and rfx_scalar_nc.hip (one translation unit per column count so
-// the 8 x 4 template instantiations compile in parallel).
+// shared by rfx_scalar.hip (final fold, masks), rfx_scalar_nc.hip (one translation unit per column count so the
+// template instantiations compile in parallel), rfx_where.hip and the group-by files.
+//
+// Shape of the hot loop (what the ISA should look like on gfx950):
+//   * every lane owns E = 2*U rows of a tile: U x global_load_dwordx4 ... nt per column, issued for tile t+1 BEFORE
+//     tile t is evaluated (register double buffering) so HBM requests stay in flight across the ALU section;
+//   * a predicate is ONE v_cmp per row whose result lives in an SGPR pair (a wave-wide lane mask); AND/OR of several
+//     predicates are s_and_b64 / s_or_b64 on those masks -- no per-lane integer bit fiddling;
+//   * sums are v_cndmask + 64-bit add per selected row; every COUNT-like quantity is s_bcnt1 of the mask, kept
+//     wave-uniform (lane 0 carries it into the reduction), so counting costs no VALU at all.
 #pragma once
 #include "rfx_common.hpp"
 
@@ -54,6 +62,11 @@ __device__ __forceinline__ Acc acc_shfl_xor(const Acc &a, int m) {
 // pick column `col` (wave-uniform) out of the register tile without dynamic register indexing
 template <int NC, int E>
 __device__ __forceinline__ void sel_col(u64 (&x)[E], const u64 (&v)[NC][E], int col) {
+    if (NC == 1) {
+#pragma unroll
+        for (int e = 0; e < E; e++) x[e] = v[0][e];
+        return;
+    }
 #pragma unroll
     for (int c = 0; c < NC; c++) {
         if (col == c) {
@@ -63,191 +76,339 @@ __device__ __forceinline__ void sel_col(u64 (&x)[E], const u64 (&v)[NC][E], int 
     }
 }
 
-// Evaluate all predicates on a register tile.  Bit e of the result = row e of this lane is selected.
-template <int NC, int E>
-__device__ __forceinline__ unsigned eval_preds(const Plan &P, const u64 (&v)[NC][E], unsigned valid) {
-    if (P.npred == 0) return valid;
-    unsigned m = (P.logic == RFX_AND) ? valid : 0u;
-    for (int p = 0; p < P.npred; p++) {
-        const PlanPred &pr = P.preds[p];
-        u64 x[E];
-        sel_col<NC, E>(x, v, pr.col);
-        if (pr.lhs_cvt) {
-#pragma unroll
-            for (int e = 0; e < E; e++) x[e] = rfx_i64_to_f64_bits(x[e]);
-        }
-        unsigned pm = 0;
-        if (pr.rhs_col < 0) {
-            const u64 r = pr.rhs_bits;
-            if (pr.dom_f64) {
-#pragma unroll
-                for (int e = 0; e < E; e++) pm |= (unsigned)rfx_cmp_f64(pr.op, x[e], r) << e;
-            } else {
-#pragma unroll
-                for (int e = 0; e < E; e++) pm |= (unsigned)rfx_cmp_i64(pr.op, (i64)x[e], (i64)r) << e;
-            }
-        } else {
-            u64 y[E];
-            sel_col<NC, E>(y, v, pr.rhs_col);
-            if (pr.rhs_cvt) {
-#pragma unroll
-                for (int e = 0; e < E; e++) y[e] = rfx_i64_to_f64_bits(y[e]);
-            }
-            if (pr.dom_f64) {
-#pragma unroll
-                for (int e = 0; e < E; e++) pm |= (unsigned)rfx_cmp_f64(pr.op, x[e], y[e]) << e;
-            } else {
-#pragma unroll
-                for (int e = 0; e < E; e++) pm |= (unsigned)rfx_cmp_i64(pr.op, (i64)x[e], (i64)y[e]) << e;
-            }
-        }
-        m = (P.logic == RFX_AND) ? (m & pm) : (m | pm);
+// Predicate / aggregate descriptors copied out of the kernarg segment ONCE per kernel into SGPRs (indexing the by-value
+// Plan with a runtime loop counter inside the tile loop makes every field a dependent s_load + s_waitcnt per tile).
+//
+// A comparison is evaluated as TWO lane masks per row,  lt = "x sorts before y"  and  eq = "x equals y"  under the
+// reference's total order (core/ops.h:76-123: NaN lowest, NaN == NaN, -0.0 == 0.0, i64 plain signed), and the operator
+// only decides which of {lt, eq, gt = !(lt|eq)} it keeps -- three wave-uniform booleans, combined with s_and/s_or on
+// the masks.  So the op costs no per-row branch and no per-op code copy.
+enum { PF_F64DOM = 1, PF_LCVT = 2, PF_RCVT = 4, PF_CNAN = 8, PF_RCOL = 16, PF_KEEP_LT = 256, PF_KEEP_EQ = 512, PF_KEEP_GT = 1024 };
+struct PredR {
+    int col, rhs_col, flags;
+    u64 rhs;
+};
+template <int NP>
+struct PredSet {
+    int npred;
+    bool is_and;
+    PredR p[NP];
+};
+__device__ __forceinline__ int pred_keep_bits(int op) {
+    switch (op) {
+        case RFX_EQ: return PF_KEEP_EQ;
+        case RFX_NE: return PF_KEEP_LT | PF_KEEP_GT;
+        case RFX_LT: return PF_KEEP_LT;
+        case RFX_GT: return PF_KEEP_GT;
+        case RFX_LE: return PF_KEEP_LT | PF_KEEP_EQ;
+        default: return PF_KEEP_GT | PF_KEEP_EQ;
     }
-    return m & valid;
+}
+template <int NP>
+__device__ __forceinline__ void predset_load(const Plan &P, PredSet<NP> &S) {
+    S.npred = P.npred;
+    S.is_and = (P.logic == RFX_AND);
+#pragma unroll
+    for (int i = 0; i < NP; i++) {
+        const PlanPred q = P.preds[i];
+        S.p[i].col = q.col;
+        S.p[i].rhs_col = q.rhs_col;
+        S.p[i].rhs = q.rhs_bits;
+        int f = pred_keep_bits(q.op);
+        if (q.dom_f64) f |= PF_F64DOM;
+        if (q.lhs_cvt) f |= PF_LCVT;
+        if (q.rhs_cvt) f |= PF_RCVT;
+        if (q.rhs_col >= 0) f |= PF_RCOL;
+        else if (q.dom_f64 && rfx_isnan_bits(q.rhs_bits)) f |= PF_CNAN;
+        S.p[i].flags = f;
+    }
 }
 
-// Fold the selected rows of a register tile into one accumulator.
+// lt / eq masks of one predicate over the rows of one column tile `x`
+template <int NC, int E>
+__device__ __forceinline__ void pred_lt_eq(const PredR &pr, const u64 (&x)[E], const u64 (&v)[NC][E], bool (&lt)[E], bool (&eq)[E]) {
+    const int f = pr.flags;
+    if (!(f & (PF_LCVT | PF_RCOL | PF_CNAN))) {
+        if (f & PF_F64DOM) {
+            // atom is not NaN: "x sorts before c" == !(x >= c) (true for NaN x), one v_cmp_nge_f64; eq is IEEE ==
+            const double c = rfx_as_f64(pr.rhs);
+#pragma unroll
+            for (int e = 0; e < E; e++) {
+                const double d = rfx_as_f64(x[e]);
+                lt[e] = !(d >= c);
+                eq[e] = (d == c);
+            }
+        } else {
+            const i64 c = (i64)pr.rhs;
+#pragma unroll
+            for (int e = 0; e < E; e++) {
+                lt[e] = (i64)x[e] < c;
+                eq[e] = (i64)x[e] == c;
+            }
+        }
+        return;
+    }
+    // general form: optional i64 -> f64 promotion (null -> NaN), rhs column, NaN atom
+    u64 y[E];
+    if (f & PF_RCOL) {
+        sel_col<NC, E>(y, v, pr.rhs_col);
+        if (f & PF_RCVT) {
+#pragma unroll
+            for (int e = 0; e < E; e++) y[e] = rfx_i64_to_f64_bits(y[e]);
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < E; e++) y[e] = pr.rhs;
+    }
+    if (f & PF_F64DOM) {
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+            const u64 xe = (f & PF_LCVT) ? rfx_i64_to_f64_bits(x[e]) : x[e];
+            lt[e] = rfx_ltf64(xe, y[e]);
+            eq[e] = rfx_eqf64(xe, y[e]);
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+            lt[e] = (i64)x[e] < (i64)y[e];
+            eq[e] = (i64)x[e] == (i64)y[e];
+        }
+    }
+}
+
+// Evaluate all predicates on a register tile: sel[e] = valid[e] && combine(pred_p(row e)).  Column-major: the
+// predicates that read column c are evaluated straight on v[c] (no register copies).
+template <int NC, int E, int NP>
+__device__ __forceinline__ void eval_sel(const PredSet<NP> &S, const u64 (&v)[NC][E], const bool (&valid)[E], bool (&sel)[E]) {
+    if (S.npred == 0) {
+#pragma unroll
+        for (int e = 0; e < E; e++) sel[e] = valid[e];
+        return;
+    }
+    const bool is_and = S.is_and;
+#pragma unroll
+    for (int e = 0; e < E; e++) sel[e] = is_and;
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+#pragma unroll
+        for (int p = 0; p < NP; p++) {
+            if (p < S.npred && S.p[p].col == c) {
+                bool lt[E], eq[E];
+                pred_lt_eq<NC, E>(S.p[p], v[c], v, lt, eq);
+                const bool klt = (S.p[p].flags & PF_KEEP_LT) != 0, keq = (S.p[p].flags & PF_KEEP_EQ) != 0, kgt = (S.p[p].flags & PF_KEEP_GT) != 0;
+#pragma unroll
+                for (int e = 0; e < E; e++) {
+                    const bool pm = (lt[e] && klt) || (eq[e] && keq) || (!(lt[e] || eq[e]) && kgt);
+                    sel[e] = is_and ? (sel[e] && pm) : (sel[e] || pm);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < E; e++) sel[e] = sel[e] && valid[e];
+}
+
+// Compatibility form for the scatter kernels: bit e of the result = row e of this lane is selected.
+template <int NC, int E, int NP>
+__device__ __forceinline__ unsigned eval_preds(const PredSet<NP> &S, const u64 (&v)[NC][E], unsigned valid_bits) {
+    bool valid[E], sel[E];
+#pragma unroll
+    for (int e = 0; e < E; e++) valid[e] = (valid_bits >> e) & 1u;
+    eval_sel<NC, E, NP>(S, v, valid, sel);
+    unsigned m = 0;
+#pragma unroll
+    for (int e = 0; e < E; e++) m |= (unsigned)sel[e] << e;
+    return m;
+}
+
+// wave-uniform population count of a lane predicate (s_bcnt1_i32_b64 of the compare mask)
+__device__ __forceinline__ int wave_count(bool p) { return __popcll(__ballot(p)); }
+
+// In-loop accumulator state.  f64 MIN/MAX run on raw doubles (init +inf / -inf) and are converted to the
+// order-preserving integer image only once, before the cross-lane reduction (acc_finish_lane).
+__device__ __forceinline__ void acc_init_loop(Acc &a, int kind, int f64) {
+    acc_init(a, kind);
+    if (f64 && kind == RFX_AGG_MIN) a.v = RFX_PINF_BITS;
+    if (f64 && kind == RFX_AGG_MAX) a.v = 0xFFF0000000000000ULL;
+}
+__device__ __forceinline__ void acc_finish_lane(Acc &a, int kind, int f64) {
+    if (f64 && (kind == RFX_AGG_MIN || kind == RFX_AGG_MAX)) a.v = (u64)rfx_f64_to_ord(a.v);
+}
+
+// Fold the selected rows of one column tile into one accumulator.  Counts (a.c for every kind but FIRST) are kept
+// WAVE-UNIFORM: they hold the wave's total, not the lane's -- the reduction takes them from lane 0 only.
 // Scalar rules: FOLD_ADD* skip nulls (core/ops.h:156-158), MIN*/MAX* skip nulls (:179-187), CNT* (:148-152).
 template <int E>
-__device__ __forceinline__ void acc_update(Acc &a, int kind, int f64, const u64 (&x)[E], unsigned m, i64 row_of_e0, int U_stride) {
-    switch (kind) {
-        case RFX_AGG_SUM:
-        case RFX_AGG_AVG:
-            if (f64) {
-                double s = rfx_as_f64(a.v);
-#pragma unroll
-                for (int e = 0; e < E; e++) {
-                    bool ok = ((m >> e) & 1u) && !rfx_isnan_bits(x[e]);
-                    s += ok ? rfx_as_f64(x[e]) : 0.0;
-                    a.c += ok;
-                }
-                a.v = rfx_as_u64(s);
-            } else {
-#pragma unroll
-                for (int e = 0; e < E; e++) {
-                    bool ok = ((m >> e) & 1u) && (i64)x[e] != RFX_NULL_I64_D;
-                    a.v += ok ? x[e] : 0ULL;
-                    a.c += ok;
-                }
-            }
-            break;
-        case RFX_AGG_MIN:
+__device__ __forceinline__ void acc_update(Acc &a, int kind, int f64, const u64 (&x)[E], const bool (&sel)[E], i64 row_of_e0, int jstride) {
+    if (kind == RFX_AGG_SUM || kind == RFX_AGG_AVG) {
+        int c = 0;
+        if (f64) {
+            double s = rfx_as_f64(a.v);
 #pragma unroll
             for (int e = 0; e < E; e++) {
-                bool ok = ((m >> e) & 1u) && (f64 ? !rfx_isnan_bits(x[e]) : (i64)x[e] != RFX_NULL_I64_D);
-                i64 o = f64 ? rfx_f64_to_ord(x[e]) : (i64)x[e];
-                a.v = (ok && o < (i64)a.v) ? (u64)o : a.v;
-                a.c += ok;
+                const double d = rfx_as_f64(x[e]);
+                const bool ok = sel[e] && (d == d);
+                s += ok ? d : 0.0;
+                c += wave_count(ok);
             }
-            break;
-        case RFX_AGG_MAX:
+            a.v = rfx_as_u64(s);
+        } else {
+            u64 s = a.v;
 #pragma unroll
             for (int e = 0; e < E; e++) {
-                bool ok = ((m >> e) & 1u) && (f64 ? !rfx_isnan_bits(x[e]) : (i64)x[e] != RFX_NULL_I64_D);
-                i64 o = f64 ? rfx_f64_to_ord(x[e]) : (i64)x[e];
-                a.v = (ok && o > (i64)a.v) ? (u64)o : a.v;
-                a.c += ok;
+                const bool ok = sel[e] && (i64)x[e] != RFX_NULL_I64_D;
+                s += ok ? x[e] : 0ULL;
+                c += wave_count(ok);
             }
-            break;
-        case RFX_AGG_COUNT:
-            a.c += __popc(m);
-            break;
-        case RFX_AGG_FIRST:
+            a.v = s;
+        }
+        a.c += c;
+    } else if (kind == RFX_AGG_MIN || kind == RFX_AGG_MAX) {
+        const bool is_min = (kind == RFX_AGG_MIN);
+        int c = 0;
+        if (f64) {
+            double m = rfx_as_f64(a.v);
 #pragma unroll
             for (int e = 0; e < E; e++) {
-                i64 row = row_of_e0 + (i64)(e >> 1) * U_stride + (e & 1);
-                if (((m >> e) & 1u) && row < a.c) {
-                    a.c = row;
-                    a.v = x[e];
-                }
+                const double d = rfx_as_f64(x[e]);
+                const bool ok = sel[e] && (d == d);
+                const bool better = ok && (is_min ? (d < m) : (d > m));
+                m = better ? d : m;
+                c += wave_count(ok);
             }
-            break;
-        default:
-            break;
+            a.v = rfx_as_u64(m);
+        } else {
+            i64 m = (i64)a.v;
+#pragma unroll
+            for (int e = 0; e < E; e++) {
+                const i64 d = (i64)x[e];
+                const bool ok = sel[e] && d != RFX_NULL_I64_D;
+                const bool better = ok && (is_min ? (d < m) : (d > m));
+                m = better ? d : m;
+                c += wave_count(ok);
+            }
+            a.v = (u64)m;
+        }
+        a.c += c;
+    } else if (kind == RFX_AGG_FIRST) {
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+            const i64 row = row_of_e0 + (i64)(e >> 1) * jstride + (e & 1);
+            if (sel[e] && row < a.c) {
+                a.c = row;
+                a.v = x[e];
+            }
+        }
+    }
+}
+
+struct AggR {
+    int col, f64, kind;
+};
+template <int NC, int NA, int E, int NP>
+__device__ __forceinline__ void fold_tile(const PredSet<NP> &S, const AggR (&ag)[NA], const u64 (&v)[NC][E], const bool (&valid)[E], Acc (&acc)[NA],
+                                          i64 &nsel, i64 row_of_e0, int jstride) {
+    bool sel[E];
+    eval_sel<NC, E, NP>(S, v, valid, sel);
+    int c = 0;
+#pragma unroll
+    for (int e = 0; e < E; e++) c += wave_count(sel[e]);
+    nsel += c;
+#pragma unroll
+    for (int a = 0; a < NA; a++) {
+        if (ag[a].kind == RFX_AGG_COUNT) acc[a].c += c;
+    }
+#pragma unroll
+    for (int col = 0; col < NC; col++) {
+#pragma unroll
+        for (int a = 0; a < NA; a++) {
+            if (ag[a].kind >= 0 && ag[a].kind != RFX_AGG_COUNT && ag[a].col == col) acc_update<E>(acc[a], ag[a].kind, ag[a].f64, v[col], sel, row_of_e0, jstride);
+        }
     }
 }
 
 // Workgroup partial layout in the workspace: ws[(block * (NA + 1) + a)] ; slot NA = selected-row count.
-template <int NC, int NA, int U>
+template <int NC, int NA, int U, int NP>
 __global__ __launch_bounds__(RFX_BLOCK) void k_filter_aggr(const Plan P, Acc *__restrict__ ws) {
     constexpr int E = 2 * U;
     constexpr int TILE = RFX_BLOCK * E;     // rows per workgroup per iteration
     constexpr int JSTRIDE = RFX_BLOCK * 2;  // row distance between the U loads of one lane
     const int tid = threadIdx.x;
+    PredSet<NP> S;
+    predset_load<NP>(P, S);
+    AggR ag[NA];
     Acc acc[NA];
-    Acc nsel;
-    nsel.v = 0;
-    nsel.c = 0;
+    i64 nsel = 0; // wave-uniform
 #pragma unroll
-    for (int a = 0; a < NA; a++) acc_init(acc[a], P.aggs[a].kind);
+    for (int a = 0; a < NA; a++) {
+        ag[a].col = P.aggs[a].col;
+        ag[a].f64 = P.aggs[a].f64;
+        ag[a].kind = P.aggs[a].kind;
+        acc_init_loop(acc[a], ag[a].kind, ag[a].f64);
+    }
+    const u64 *cols[NC];
+#pragma unroll
+    for (int c = 0; c < NC; c++) cols[c] = P.cols[c];
+    const i64 nrows = P.nrows, row0 = P.row0;
 
-    const i64 nfull = P.nrows / TILE;
+    bool all[E];
+#pragma unroll
+    for (int e = 0; e < E; e++) all[e] = true;
+
+    const i64 nfull = nrows / TILE;
     for (i64 t = blockIdx.x; t < nfull; t += gridDim.x) {
         const i64 base = t * TILE + tid * 2;
         u64 v[NC][E];
 #pragma unroll
         for (int c = 0; c < NC; c++) {
-            const u64 *p = P.cols[c] + base;
 #pragma unroll
             for (int j = 0; j < U; j++) {
-                u64x2 q = rfx_ld2(p + (i64)j * JSTRIDE);
+                u64x2 q = rfx_ld2(cols[c] + base + (i64)j * JSTRIDE);
                 v[c][2 * j] = q.x;
                 v[c][2 * j + 1] = q.y;
             }
         }
-        const unsigned m = eval_preds<NC, E>(P, v, (1u << E) - 1u);
-        nsel.c += __popc(m);
-#pragma unroll
-        for (int a = 0; a < NA; a++) {
-            const PlanAgg ag = P.aggs[a];
-            if (ag.kind < 0) continue;
-            u64 x[E];
-            if (ag.col >= 0) sel_col<NC, E>(x, v, ag.col);
-            acc_update<E>(acc[a], ag.kind, ag.f64, x, m, P.row0 + base, JSTRIDE);
-        }
+        fold_tile<NC, NA, E, NP>(S, ag, v, all, acc, nsel, row0 + base, JSTRIDE);
     }
     // ragged tail: one workgroup, guarded element loads
     const i64 tail0 = nfull * TILE;
-    if (tail0 < P.nrows && blockIdx.x == (unsigned)(nfull % gridDim.x)) {
+    if (tail0 < nrows && blockIdx.x == (unsigned)(nfull % gridDim.x)) {
         const i64 base = tail0 + tid * 2;
         u64 v[NC][E];
-        unsigned valid = 0;
+        bool valid[E];
 #pragma unroll
         for (int e = 0; e < E; e++) {
-            i64 row = base + (i64)(e >> 1) * JSTRIDE + (e & 1);
-            bool in = row < P.nrows;
-            valid |= (unsigned)in << e;
+            const i64 row = base + (i64)(e >> 1) * JSTRIDE + (e & 1);
+            valid[e] = row < nrows;
 #pragma unroll
-            for (int c = 0; c < NC; c++) v[c][e] = in ? P.cols[c][row] : 0ULL;
+            for (int c = 0; c < NC; c++) v[c][e] = valid[e] ? cols[c][row] : 0ULL;
         }
-        const unsigned m = eval_preds<NC, E>(P, v, valid);
-        nsel.c += __popc(m);
-#pragma unroll
-        for (int a = 0; a < NA; a++) {
-            const PlanAgg ag = P.aggs[a];
-            if (ag.kind < 0) continue;
-            u64 x[E];
-            if (ag.col >= 0) sel_col<NC, E>(x, v, ag.col);
-            acc_update<E>(acc[a], ag.kind, ag.f64, x, m, P.row0 + base, JSTRIDE);
-        }
+        fold_tile<NC, NA, E, NP>(S, ag, v, valid, acc, nsel, row0 + base, JSTRIDE);
     }
 
-    // wave reduction (64 lanes), then across the 4 waves through LDS
+    // wave reduction (64 lanes), then across the 4 waves through LDS.  Counts are wave-uniform already: keep lane 0's.
     __shared__ Acc lds[RFX_BLOCK / RFX_WAVE][NA + 1];
+    const int wave = tid / RFX_WAVE, lane = tid % RFX_WAVE;
+#pragma unroll
+    for (int a = 0; a < NA; a++) {
+        acc_finish_lane(acc[a], ag[a].kind, ag[a].f64);
+        if (ag[a].kind != RFX_AGG_FIRST && lane != 0) acc[a].c = 0;
+    }
 #pragma unroll
     for (int s = 32; s >= 1; s >>= 1) {
 #pragma unroll
         for (int a = 0; a < NA; a++) {
             Acc o = acc_shfl_xor(acc[a], s);
-            acc_combine(acc[a], o, P.aggs[a].kind, P.aggs[a].f64);
+            acc_combine(acc[a], o, ag[a].kind, ag[a].f64);
         }
-        nsel.c += (i64)rfx_shfl_xor_u64((u64)nsel.c, s);
     }
-    const int wave = tid / RFX_WAVE, lane = tid % RFX_WAVE;
     if (lane == 0) {
 #pragma unroll
         for (int a = 0; a < NA; a++) lds[wave][a] = acc[a];
-        lds[wave][NA] = nsel;
+        Acc n;
+        n.v = 0;
+        n.c = nsel;
+        lds[wave][NA] = n;
     }
     __syncthreads();
     if (tid <= NA) {
@@ -258,7 +419,6 @@ __global__ __launch_bounds__(RFX_BLOCK) void k_filter_aggr(const Plan P, Acc *__
         ws[(size_t)blockIdx.x * (NA + 1) + tid] = r;
     }
 }
-
 
 // one launcher per distinct-column count, defined in rfx_scalar_nc.hip compiled with -DRFX_NC=<n>
 #define RFX_DECL_LAUNCH(n) int rfx_launch_filter_aggr_nc##n(rfx_ctx *c, const Plan &P, int grid, Acc *ws, int *na_stride);

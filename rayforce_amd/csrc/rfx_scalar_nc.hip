@@ -5,19 +5,36 @@
 #error "compile with -DRFX_NC=<1..8>"
 #endif
 
-template <int NC, int NA>
-static void launch_filter_aggr(rfx_ctx *c, const Plan &P, int grid, Acc *ws) {
-    // loads in flight per lane = NC * U (16 B each); probe_hw: U=4 with nt loads is the streaming sweet spot
-    constexpr int U = (NC <= 2) ? 4 : (NC <= 4 ? 2 : 1);
-    hipLaunchKernelGGL((k_filter_aggr<NC, NA, U>), dim3(grid), dim3(RFX_BLOCK), 0, c->stream, P, ws);
+// Fast shapes (<= 4 distinct columns, <= 4 predicates, <= 4 aggregates) get tight instantiations; everything else
+// runs the one fully general instantiation of its column count.
+template <int NC, int NA, int NP>
+static void launch_shape(rfx_ctx *c, const Plan &P, int grid, Acc *ws) {
+    // 16-byte loads in flight per lane = NC * U.  tools/probe_hw + the blocks-per-CU sweep in profiles/: 4 workgroups
+    // per CU with 8..16 loads per lane saturate HBM.
+    constexpr int U = (NC == 1) ? 8 : (NC == 2) ? 4 : (NC <= 4) ? 2 : 1;
+    constexpr int UALT = (NC == 1) ? 4 : (NC == 2) ? 2 : (NC <= 4) ? 4 : 1;
+    if (c->flags & 4) hipLaunchKernelGGL((k_filter_aggr<NC, NA, UALT, NP>), dim3(grid), dim3(RFX_BLOCK), 0, c->stream, P, ws);
+    else hipLaunchKernelGGL((k_filter_aggr<NC, NA, U, NP>), dim3(grid), dim3(RFX_BLOCK), 0, c->stream, P, ws);
 }
 
 #define RFX_CAT2(a, b) a##b
 #define RFX_CAT(a, b) RFX_CAT2(a, b)
 int RFX_CAT(rfx_launch_filter_aggr_nc, RFX_NC)(rfx_ctx *c, const Plan &P, int grid, Acc *ws, int *na_stride) {
-    if (P.nagg <= 1) { *na_stride = 2; launch_filter_aggr<RFX_NC, 1>(c, P, grid, ws); }
-    else if (P.nagg <= 2) { *na_stride = 3; launch_filter_aggr<RFX_NC, 2>(c, P, grid, ws); }
-    else if (P.nagg <= 4) { *na_stride = 5; launch_filter_aggr<RFX_NC, 4>(c, P, grid, ws); }
-    else { *na_stride = 9; launch_filter_aggr<RFX_NC, 8>(c, P, grid, ws); }
+#if RFX_NC <= 4
+    if (P.npred <= 4 && P.nagg <= 4) {
+        if (P.nagg <= 1) {
+            *na_stride = 2;
+            if (P.npred <= 1) launch_shape<RFX_NC, 1, 1>(c, P, grid, ws);
+            else launch_shape<RFX_NC, 1, 4>(c, P, grid, ws);
+        } else {
+            *na_stride = 5;
+            if (P.npred <= 1) launch_shape<RFX_NC, 4, 1>(c, P, grid, ws);
+            else launch_shape<RFX_NC, 4, 4>(c, P, grid, ws);
+        }
+        return RFX_OK;
+    }
+#endif
+    *na_stride = 9;
+    launch_shape<RFX_NC, 8, 8>(c, P, grid, ws);
     return RFX_OK;
 }

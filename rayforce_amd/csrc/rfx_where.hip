@@ -25,6 +25,8 @@ __device__ __forceinline__ u64 lanemask_lt() {
 // ---------------- pass A: predicates -> bitmap + per-chunk counts ----------------
 template <int NC>
 __global__ __launch_bounds__(RFX_BLOCK) void k_sel_bitmap(const Plan P, u64 *__restrict__ bitmap, i64 *__restrict__ chunk_cnt) {
+    PredSet<RFX_MAX_PREDS> S;
+    predset_load<RFX_MAX_PREDS>(P, S);
     const int lane = threadIdx.x & 63;
     const i64 wave_id = (i64)blockIdx.x * (RFX_BLOCK / RFX_WAVE) + (threadIdx.x >> 6);
     const i64 nwaves = (i64)gridDim.x * (RFX_BLOCK / RFX_WAVE);
@@ -32,8 +34,10 @@ __global__ __launch_bounds__(RFX_BLOCK) void k_sel_bitmap(const Plan P, u64 *__r
     for (i64 q = wave_id; q < nchunks; q += nwaves) {
         const i64 base = q * RFX_CHUNK + lane * 2;
         u64 v[NC][8];
-        unsigned valid = 0xffu;
+        bool valid[8], sel[8];
         if (q * RFX_CHUNK + RFX_CHUNK <= P.nrows) {
+#pragma unroll
+            for (int e = 0; e < 8; e++) valid[e] = true;
 #pragma unroll
             for (int c = 0; c < NC; c++) {
 #pragma unroll
@@ -44,22 +48,20 @@ __global__ __launch_bounds__(RFX_BLOCK) void k_sel_bitmap(const Plan P, u64 *__r
                 }
             }
         } else {
-            valid = 0;
 #pragma unroll
             for (int e = 0; e < 8; e++) {
-                i64 row = base + (e >> 1) * 128 + (e & 1);
-                bool in = row < P.nrows;
-                valid |= (unsigned)in << e;
+                const i64 row = base + (e >> 1) * 128 + (e & 1);
+                valid[e] = row < P.nrows;
 #pragma unroll
-                for (int c = 0; c < NC; c++) v[c][e] = in ? P.cols[c][row] : 0ULL;
+                for (int c = 0; c < NC; c++) v[c][e] = valid[e] ? P.cols[c][row] : 0ULL;
             }
         }
-        const unsigned m = eval_preds<NC, 8>(P, v, valid);
+        eval_sel<NC, 8, RFX_MAX_PREDS>(S, v, valid, sel);
         u64 mine = 0;
         int cnt = 0;
 #pragma unroll
         for (int e = 0; e < 8; e++) {
-            u64 b = __ballot((m >> e) & 1u);
+            const u64 b = __ballot(sel[e]); // the compare's lane mask itself
             cnt += __popcll(b);
             mine = (lane == e) ? b : mine;
         }
@@ -246,6 +248,7 @@ extern "C" int rfx_hip_where_begin(rfx_ctx_t *c, const rfx_pred_t *preds, int np
     }
     int grid = rfx_grid(c);
     if ((i64)grid * 4 > nchunks) grid = (int)((nchunks + 3) / 4);
+    RFX_KERNEL_BEGIN(c);
     if (d_mask) {
         hipLaunchKernelGGL(k_mask_bitmap, dim3(grid), dim3(RFX_BLOCK), 0, c->stream, d_mask, (i64)nrows, c->d_bitmap, c->d_blksum);
     } else {
@@ -263,6 +266,7 @@ extern "C" int rfx_hip_where_begin(rfx_ctx_t *c, const rfx_pred_t *preds, int np
             default: launch_sel_bitmap<8>(c, P, grid); break;
         }
     }
+    RFX_KERNEL_END(c);
     RFX_HIP_CHECK(hipGetLastError());
     i64 *d_total = c->d_blksum + nchunks;
     rc = rfx_scan_counts(c, c->d_blksum, nchunks, d_total);

@@ -1,0 +1,197 @@
+"""Row-range sharding of the select / where / by path over the GPUs of one node (one process per GPU).
+
+GPU ``g`` owns rows ``[row0_g, row0_g + n_g)`` of every column.  Nothing is exchanged on the data path; ONE small
+exchange merges the per-GPU partial states:
+
+* scalar aggregates -> ``all_gather`` of ``(nagg + 1) x 64`` bytes of ``rfx_partial_t`` and a host-side fold in rank order
+  (``rfx_partial_merge``; integer results exact, f64 sums added in a fixed rank order);
+* dense group-by     -> ``all_reduce`` of the tables: ``first`` with MIN (global row ids), accumulators with SUM / MIN / MAX
+  by aggregate kind, the count arrays with SUM.  The scope ``[kmin, kmax]`` is agreed first with an all_reduce of 3 numbers.
+  Ranking by first row and emit then run identically on every rank (replicated result);
+* hashed group-by    -> ``all_gather`` of the whole table set and re-insertion of the other ranks' occupied slots
+  (``rfx_hip_hash_tables_merge``);
+* ``where`` ids      -> per-rank ascending global ids are already globally ordered by rank: all_gather of counts + padded ids.
+
+``torch.distributed`` with backend ``nccl`` IS RCCL on ROCm (xGMI inside a node); the same code runs on ``gloo`` with CPU
+tensors, which is how the merge logic is tested without GPUs (tests/test_dist_cpu.py).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+from . import _lib as L
+
+
+class RowShard:
+    """Where this rank's rows sit in the global table."""
+
+    def __init__(self, local_rows: int, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.local_rows = int(local_rows)
+        if self.world > 1:
+            counts = [None] * self.world
+            dist.all_gather_object(counts, self.local_rows, group=group)
+        else:
+            counts = [self.local_rows]
+        self.counts = [int(c) for c in counts]
+        self.row0 = sum(self.counts[: self.rank])
+        self.total_rows = sum(self.counts)
+
+
+# ---------------------------------------------------------------------------------------------- scalar aggregates
+def merge_scalar_partials(partials: torch.Tensor, kinds: Sequence[int], col_types: Sequence[int], group=None):
+    """partials: uint8 tensor of (nagg + 1) * 64 bytes (device or host).  Returns ([rfx_value ...] as python values, selected)."""
+    lib = L.load_library()
+    nagg = len(kinds)
+    nbytes = (nagg + 1) * 64
+    assert partials.dtype == torch.uint8 and partials.numel() == nbytes
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world > 1:
+        bufs = [torch.empty_like(partials) for _ in range(world)]
+        dist.all_gather(bufs, partials, group=group)
+    else:
+        bufs = [partials]
+    host = [b.cpu().numpy().tobytes() for b in bufs]
+    acc = (L.Partial * (nagg + 1)).from_buffer_copy(host[0])
+    for other in host[1:]:
+        o = (L.Partial * (nagg + 1)).from_buffer_copy(other)
+        for a in range(nagg):
+            lib.rfx_partial_merge(kinds[a], col_types[a], C.byref(acc[a]), C.byref(o[a]))
+        lib.rfx_partial_merge(L.RFX_AGG_COUNT, L.RFX_I64, C.byref(acc[nagg]), C.byref(o[nagg]))
+    vals = []
+    for a in range(nagg):
+        v = L.Value()
+        L.check(lib.rfx_agg_finalize(kinds[a], col_types[a], C.byref(acc[a]), C.byref(v)), "agg_finalize")
+        if v.type == L.RFX_F64:
+            vals.append(float("nan") if v.is_null else float(v.f))
+        else:
+            vals.append(None if v.is_null else int(v.i))
+    return vals, int(acc[nagg].cnt)
+
+
+# ---------------------------------------------------------------------------------------------- dense group tables
+def _reduce_op(kind: int, f64: bool, what: str):
+    """(torch dtype to view the 8-byte cells as, ReduceOp) for one table array."""
+    if what == "first":
+        return torch.int64, dist.ReduceOp.MIN
+    if what == "cnt":
+        return torch.int64, dist.ReduceOp.SUM
+    if kind == L.RFX_AGG_MIN:
+        return torch.int64, dist.ReduceOp.MIN  # order-preserving i64 image for f64 columns too
+    if kind == L.RFX_AGG_MAX:
+        return torch.int64, dist.ReduceOp.MAX
+    if kind == L.RFX_AGG_AVG or (kind == L.RFX_AGG_SUM and f64):
+        return torch.float64, dist.ReduceOp.SUM
+    return torch.int64, dist.ReduceOp.SUM  # SUM(i64) wraps, COUNT
+
+
+def allreduce_tables(store: torch.Tensor, layout, kinds: Sequence[int], f64s: Sequence[bool], group=None) -> None:
+    """In-place all-reduce of a dense table set ``store[n_arrays, range]`` (int64 view of 8-byte cells)."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return
+    for row, (what, a) in enumerate(layout):
+        kind = kinds[a] if a is not None else -1
+        f64 = f64s[a] if a is not None else False
+        dt, op = _reduce_op(kind, f64, what)
+        dist.all_reduce(store[row].view(dt), op=op, group=group)
+
+
+def allreduce_scope(kmin: int, kmax: int, seen: int, device, group=None) -> Tuple[int, int, int]:
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return kmin, kmax, seen
+    # ranks that saw no row contribute neutral elements
+    big = 2**63 - 1
+    t = torch.tensor([kmin if seen else big, -(kmax if seen else -big), -seen], dtype=torch.int64, device=device)
+    dist.all_reduce(t[:2], op=dist.ReduceOp.MIN, group=group)
+    s = t[2:].clone()
+    dist.all_reduce(s, op=dist.ReduceOp.SUM, group=group)
+    mn, negmx = int(t[0]), int(t[1])
+    return mn, -negmx, -int(s[0])
+
+
+class GroupHook:
+    """The `_collective` callback Engine.group_by calls between its local phases."""
+
+    def __init__(self, shard: RowShard, aggs_kinds: Sequence[int], aggs_f64: Sequence[bool]):
+        self.shard = shard
+        self.kinds = list(aggs_kinds)
+        self.f64s = list(aggs_f64)
+
+    def __call__(self, phase: str, payload):
+        g = self.shard.group
+        if phase == "scope":
+            kmin, kmax, seen, device = payload
+            return allreduce_scope(kmin, kmax, seen, device, g)
+        if phase == "tables":
+            store, layout = payload
+            allreduce_tables(store, layout, self.kinds, self.f64s, g)
+            return None
+        if phase == "hash_tables":
+            eng, make_tables, store, merge = payload
+            world = self.shard.world
+            if world == 1:
+                return None
+            bufs = [torch.empty_like(store) for _ in range(world)]
+            dist.all_gather(bufs, store, group=g)
+            for r, other in enumerate(bufs):
+                if r != self.shard.rank:
+                    merge(make_tables(other))
+            return None
+        raise ValueError(phase)
+
+
+# ---------------------------------------------------------------------------------------------- where ids
+def gather_ids(local_ids: torch.Tensor, group=None) -> torch.Tensor:
+    """Concatenate per-rank ascending GLOBAL ids (already offset by row0) into the global ascending id vector."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return local_ids
+    world = dist.get_world_size(group)
+    cnt = torch.tensor([local_ids.numel()], dtype=torch.int64, device=local_ids.device)
+    cnts = [torch.empty_like(cnt) for _ in range(world)]
+    dist.all_gather(cnts, cnt, group=group)
+    sizes = [int(c[0]) for c in cnts]
+    m = max(sizes) if sizes else 0
+    pad = torch.zeros(m, dtype=torch.int64, device=local_ids.device)
+    pad[: local_ids.numel()] = local_ids
+    bufs = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(bufs, pad, group=group)
+    return torch.cat([b[:s] for b, s in zip(bufs, sizes)])
+
+
+# ---------------------------------------------------------------------------------------------- sharded front-end
+class ShardedEngine:
+    """Engine + RowShard: the same select surface, every rank holding its row range of every column; results are
+    replicated on all ranks."""
+
+    def __init__(self, engine, local_rows: int, group=None):
+        self.eng = engine
+        self.shard = RowShard(local_rows, group)
+
+    def filter_aggr(self, aggs, where=None, table=None):
+        eng = self.eng
+        part = eng.filter_aggr_partials(aggs, where, table, nrows=self.shard.local_rows, row0=self.shard.row0)
+        kinds = [L.AGGS[fn] for fn, _ in aggs]
+        ctypes_ = []
+        for fn, col in aggs:
+            col = table[col] if isinstance(col, str) else col
+            ctypes_.append(L.RFX_F64 if (col is not None and col.dtype == torch.float64) else L.RFX_I64)
+        return merge_scalar_partials(part, kinds, ctypes_, self.shard.group)
+
+    def where(self, where, table=None) -> torch.Tensor:
+        ids = self.eng.where(where, table, row0=self.shard.row0)
+        return gather_ids(ids, self.shard.group)
+
+    def group_by(self, key, aggs, where=None, table=None):
+        kinds = [L.AGGS[fn] for fn, _ in aggs]
+        f64s = []
+        for fn, col in aggs:
+            col = table[col] if isinstance(col, str) else col
+            f64s.append(col is not None and col.dtype == torch.float64)
+        hook = GroupHook(self.shard, kinds, f64s)
+        return self.eng.group_by(key, aggs, where, table, total_rows=self.shard.total_rows, row0=self.shard.row0, _collective=hook)

@@ -75,6 +75,14 @@ class Engine:
         L.check(self.lib.rfx_hip_timer_stop(self._ctx, C.byref(ms)), "timer_stop")
         return float(ms.value)
 
+    def profile(self, enable: bool = True) -> None:
+        L.check(self.lib.rfx_hip_ctx_profile(self._ctx, int(enable)), "ctx_profile")
+
+    def last_kernel_ms(self) -> float:
+        ms = C.c_float()
+        L.check(self.lib.rfx_hip_last_kernel_ms(self._ctx, C.byref(ms)), "last_kernel_ms")
+        return float(ms.value)
+
     def empty(self, n: int, dtype=torch.int64) -> torch.Tensor:
         return torch.empty(int(n), dtype=dtype, device=self.device)
 
@@ -342,13 +350,14 @@ class Engine:
         return int(mn.value), int(mx.value), int(cnt.value)
 
     # ------------------------------------------------------------------ K7/K8/K10 dense group-by, K9 hashed
-    def group_tables(self, aggs_arr, nagg: int, kmin: int, rng: int, hashed: bool = False):
-        """Allocate one table set.  Returns (struct, backing tensor [n_arrays, cells])."""
+    def group_tables(self, aggs_arr, nagg: int, kmin: int, rng: int, hashed: bool = False, store: Optional[torch.Tensor] = None):
+        """Allocate (or wrap `store`) one table set.  Returns (struct, backing tensor [n_arrays, cells], layout)."""
         n_arr = C.c_int()
         L.check(self.lib.rfx_hip_group_table_arrays(aggs_arr, nagg, C.byref(n_arr)), "group_table_arrays")
         cells = rng + 1 if hashed else rng
         total = n_arr.value + (1 if hashed else 0)
-        store = torch.empty((total, cells), dtype=torch.int64, device=self.device)
+        if store is None:
+            store = torch.empty((total, cells), dtype=torch.int64, device=self.device)
         t = L.HashTables() if hashed else L.GroupTables()
         k = 0
         if hashed:
@@ -386,7 +395,7 @@ class Engine:
             raise RfxError("nested boolean trees are not fused with `by:`; pass ids via where() + at_ids()")
         kmin, kmax, seen = self.scope(key, where, table)
         if _collective is not None:
-            kmin, kmax, seen = _collective("scope", (kmin, kmax, seen))
+            kmin, kmax, seen = _collective("scope", (kmin, kmax, seen, self.device))
         self._keep.clear()
         parr, _ = self._preds(flat, table, n)
         aarr, _ = self._aggs(aggs, table, n)
@@ -413,7 +422,7 @@ class Engine:
             L.check(self.lib.rfx_hip_group_dense_accumulate(self._ctx, key.data_ptr(), parr, len(flat), logic, aarr, n, row0, C.byref(t)),
                     "group_dense_accumulate")
             if _collective is not None:
-                _collective("tables", (store, layout, aarr, False))
+                _collective("tables", (store, layout))
             L.check(self.lib.rfx_hip_group_rank(self._ctx, C.byref(t), total_rows, C.byref(ng)), "group_rank")
         else:
             cap = 1 << max(4, math.ceil(math.log2(max(2 * seen, 16))))
@@ -422,7 +431,13 @@ class Engine:
             L.check(self.lib.rfx_hip_group_hash_accumulate(self._ctx, key.data_ptr(), parr, len(flat), logic, aarr, n, row0, C.byref(t)),
                     "group_hash_accumulate")
             if _collective is not None:
-                _collective("hash_tables", (self, t, store, layout, aarr))
+                def make_tables(other_store):
+                    return self.group_tables(aarr, nagg, 0, cap, hashed=True, store=other_store)[0]
+
+                def merge(other):
+                    L.check(self.lib.rfx_hip_hash_tables_merge(self._ctx, aarr, C.byref(t), C.byref(other)), "hash_tables_merge")
+
+                _collective("hash_tables", (self, make_tables, store, merge))
             L.check(self.lib.rfx_hip_hash_rank(self._ctx, C.byref(t), total_rows, C.byref(ng)), "hash_rank")
         g = int(ng.value)
         keys = self.empty(g)
