@@ -64,11 +64,14 @@ struct rfx_ctx {
     i64 rank_groups;
     i64 *d_gid;         // group rank: slot -> group id (or -1)
     size_t gid_cap;
+    void *d_part;       // partitioned group-by: offsets + record planes (grow-only)
+    size_t part_bytes;
 };
 
 int rfx_ws_reserve(rfx_ctx *ctx, size_t bytes);
 int rfx_bitmap_reserve(rfx_ctx *ctx, i64 nrows);
 int rfx_gid_reserve(rfx_ctx *ctx, i64 slots);
+int rfx_part_reserve(rfx_ctx *ctx, size_t bytes);
 #define RFX_KERNEL_BEGIN(c) do { if ((c)->profile) { (void)hipEventRecord((c)->evk0, (c)->stream); } } while (0)
 #define RFX_KERNEL_END(c) do { if ((c)->profile) { (void)hipEventRecord((c)->evk1, (c)->stream); (c)->evk_valid = 1; } } while (0)
 static inline int rfx_grid(const rfx_ctx *ctx) { return ctx->num_cus * ctx->blocks_per_cu; }

@@ -64,6 +64,7 @@ extern "C" int rfx_hip_ctx_destroy(rfx_ctx_t *c) {
     if (c->d_bitmap) (void)hipFree(c->d_bitmap);
     if (c->d_blksum) (void)hipFree(c->d_blksum);
     if (c->d_gid) (void)hipFree(c->d_gid);
+    if (c->d_part) (void)hipFree(c->d_part);
     if (c->h_pin) (void)hipHostFree(c->h_pin);
     (void)hipEventDestroy(c->ev0);
     (void)hipEventDestroy(c->ev1);
@@ -143,6 +144,17 @@ int rfx_gid_reserve(rfx_ctx *c, i64 slots) {
     c->gid_cap = 0;
     RFX_HIP_CHECK(hipMalloc((void **)&c->d_gid, (size_t)slots * 8));
     c->gid_cap = (size_t)slots;
+    return RFX_OK;
+}
+
+int rfx_part_reserve(rfx_ctx *c, size_t bytes) {
+    if (c->part_bytes >= bytes) return RFX_OK;
+    RFX_HIP_CHECK(hipStreamSynchronize(c->stream));
+    if (c->d_part) RFX_HIP_CHECK(hipFree(c->d_part));
+    c->d_part = NULL;
+    c->part_bytes = 0;
+    RFX_HIP_CHECK(hipMalloc(&c->d_part, bytes));
+    c->part_bytes = bytes;
     return RFX_OK;
 }
 

@@ -1,8 +1,423 @@
-// rfx_group_part.hip -- radix-partitioned dense group-by for ranges whose tables do not fit one workgroup's LDS.
-// (placeholder until the partitioned kernels land: reports "not applicable" so the caller uses device atomics)
-#include "rfx_scalar_kernel.hpp"
+// rfx_group_part.hip -- radix-partitioned dense group-by for key ranges whose tables do not fit one workgroup's LDS
+// (e.g. BASELINE config C3: 1e9 rows, 1e6 distinct i64 keys, sum(f64)).
+//
+// Why: tools/probe_hw measured device-scope f64/u64 atomics into an 8 MB table at 23 G rows/s (12 G rows/s with the
+// first-row atomicMin on top) -- 20-40x off the 16 B/row HBM roofline -- while LDS-privatised tables run at the HBM
+// streaming rate (400+ G rows/s).  So rows are first routed to the workgroup that owns their key range:
+//
+//   pass 0  k_part_hist      read key (+ predicate columns): per-(workgroup, partition) row counts          8 B/row read
+//           k_part_offsets   column-wise exclusive scan -> exact output offset of every (workgroup, partition)
+//   pass 1  k_part_scatter   read key + value columns, build records {local_row:32 | local_slot:32} + values,
+//                            sort each 2048-row tile by partition in LDS, write runs to the partition's region
+//                            (coalesced, no atomics, no overflow: offsets are exact)                16 B/row read + 16 B/row write
+//   pass 2  k_part_aggregate each partition (a contiguous record range) is streamed by SPLIT workgroups that
+//                            aggregate into LDS tables (ds_add_f64 / ds_min_u64 ...) and merge them into the global
+//                            tables once                                                              16 B/row read
+// partition p = (key - kmin) >> lb owns slots [p << lb, (p+1) << lb): the per-partition LDS table covers them exactly.
+// The global tables, the first-row ranking and the emit are those of rfx_group.hip, so results (group order included)
+// are identical to the LDS-direct and atomic paths.
+#include "rfx_group_common.hpp"
 
+#define PART_TILE_ROWS 2048 /* rows per workgroup per tile: 256 lanes x 8 rows */
+#define PART_MAX 1024       /* max partitions */
+#define PART_LDS_BYTES (64 * 1024)
+#define PART_AGG_THREADS 512
+
+struct PartArgs {
+    i64 kmin, range;
+    int lb;      // log2(slots per partition)
+    int nparts;  // partitions
+    int key_idx;
+    int nv;                    // value planes carried in the records
+    int vcol[RFX_MAX_AGGS];    // plane j carries Plan::cols[vcol[j]]
+    int agg_plane[RFX_MAX_AGGS]; // aggregate a reads plane agg_plane[a] (-1: none, COUNT / FIRST)
+    int narr;                  // table arrays per slot (first + acc + cnt ...)
+    int split;                 // workgroups per partition in pass 2
+    u64 *offsets;              // [nwg][nparts] : counts, then exclusive offsets
+    u64 *part_start;           // [nparts + 1]
+    u64 *recs;                 // plane 0 = headers, planes 1..nv = values ; each plane `cap` entries
+    i64 cap;
+    u64 *first;
+    u64 *acc[RFX_MAX_AGGS];
+    u64 *cnt[RFX_MAX_AGGS];
+};
+
+// Shared tile front-end of pass 0 and pass 1: 8 rows per lane as four 16-byte loads per column.
+template <int NC>
+__device__ __forceinline__ unsigned part_load_eval(const Plan &P, const PredSet<RFX_MAX_PREDS> &S, i64 tile, u64 (&v)[NC][8]) {
+    const i64 base = tile * PART_TILE_ROWS + threadIdx.x * 2;
+    unsigned valid = 0xffu;
+    if ((tile + 1) * PART_TILE_ROWS <= P.nrows) {
+#pragma unroll
+        for (int c = 0; c < NC; c++) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                u64x2 q = rfx_ld2(P.cols[c] + base + (i64)j * (RFX_BLOCK * 2));
+                v[c][2 * j] = q.x;
+                v[c][2 * j + 1] = q.y;
+            }
+        }
+    } else {
+        valid = 0;
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const i64 row = base + (i64)(e >> 1) * (RFX_BLOCK * 2) + (e & 1);
+            const bool in = row < P.nrows;
+            valid |= (unsigned)in << e;
+#pragma unroll
+            for (int c = 0; c < NC; c++) v[c][e] = in ? P.cols[c][row] : 0ULL;
+        }
+    }
+    return eval_preds<NC, 8, RFX_MAX_PREDS>(S, v, valid);
+}
+
+// ---- pass 0: per-(workgroup, partition) counts ----
+template <int NC>
+__global__ __launch_bounds__(RFX_BLOCK) void k_part_hist(const Plan P, const PartArgs A) {
+    __shared__ unsigned hist[PART_MAX];
+    PredSet<RFX_MAX_PREDS> S;
+    predset_load<RFX_MAX_PREDS>(P, S);
+    for (int i = threadIdx.x; i < A.nparts; i += RFX_BLOCK) hist[i] = 0;
+    __syncthreads();
+    const i64 ntiles = (P.nrows + PART_TILE_ROWS - 1) / PART_TILE_ROWS;
+    for (i64 t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        u64 v[NC][8];
+        const unsigned m = part_load_eval<NC>(P, S, t, v);
+        u64 key[8];
+        sel_col<NC, 8>(key, v, A.key_idx);
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const u64 slot = key[e] - (u64)A.kmin;
+            if (((m >> e) & 1u) && slot < (u64)A.range) atomicAdd(&hist[slot >> A.lb], 1u);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < A.nparts; i += RFX_BLOCK) A.offsets[(size_t)blockIdx.x * A.nparts + i] = hist[i];
+}
+
+// ---- offsets: offsets[w][p] = part_start[p] + sum_{w' < w} counts[w'][p] ----
+__global__ __launch_bounds__(RFX_BLOCK) void k_part_colscan(const PartArgs A, int nwg) {
+    const int p = blockIdx.x * RFX_BLOCK + threadIdx.x;
+    if (p >= A.nparts) return;
+    u64 run = 0;
+    for (int w = 0; w < nwg; w++) {
+        const size_t i = (size_t)w * A.nparts + p;
+        const u64 c = A.offsets[i];
+        A.offsets[i] = run;
+        run += c;
+    }
+    A.part_start[p] = run; // column total, scanned by k_part_startscan
+}
+__global__ __launch_bounds__(PART_MAX) void k_part_startscan(const PartArgs A) {
+    __shared__ u64 tmp[PART_MAX + 1];
+    const int p = threadIdx.x;
+    tmp[p] = (p < A.nparts) ? A.part_start[p] : 0;
+    __syncthreads();
+    // Hillis-Steele inclusive scan over <= 1024 entries
+    for (int s = 1; s < PART_MAX; s <<= 1) {
+        u64 add = (p >= s) ? tmp[p - s] : 0;
+        __syncthreads();
+        tmp[p] += add;
+        __syncthreads();
+    }
+    if (p < A.nparts) A.part_start[p + 1] = tmp[p];
+    if (p == 0) A.part_start[0] = 0;
+}
+
+// ---- pass 1: scatter records, tile sorted by partition in LDS ----
+template <int NC, int NV>
+__global__ __launch_bounds__(RFX_BLOCK) void k_part_scatter(const Plan P, const PartArgs A) {
+    __shared__ unsigned thist[PART_MAX]; // per tile: count, then exclusive tile offset
+    __shared__ u64 cursor[PART_MAX];     // running global output position of (this workgroup, partition)
+    __shared__ u64 stag[(1 + NV) * PART_TILE_ROWS];
+    __shared__ unsigned short stag_p[PART_TILE_ROWS];
+    __shared__ unsigned scan_w[RFX_BLOCK / RFX_WAVE];
+    __shared__ unsigned tile_total;
+    PredSet<RFX_MAX_PREDS> S;
+    predset_load<RFX_MAX_PREDS>(P, S);
+    const int tid = threadIdx.x;
+    for (int i = tid; i < A.nparts; i += RFX_BLOCK) cursor[i] = A.part_start[i] + A.offsets[(size_t)blockIdx.x * A.nparts + i];
+    const i64 ntiles = (P.nrows + PART_TILE_ROWS - 1) / PART_TILE_ROWS;
+    for (i64 t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        for (int i = tid; i < A.nparts; i += RFX_BLOCK) thist[i] = 0;
+        __syncthreads();
+        u64 v[NC][8];
+        const unsigned m0 = part_load_eval<NC>(P, S, t, v);
+        u64 key[8];
+        sel_col<NC, 8>(key, v, A.key_idx);
+        unsigned m = 0, part[8], rank[8];
+        const i64 base = t * PART_TILE_ROWS + tid * 2;
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const u64 slot = key[e] - (u64)A.kmin;
+            part[e] = 0;
+            rank[e] = 0;
+            if (((m0 >> e) & 1u) && slot < (u64)A.range) {
+                m |= 1u << e;
+                part[e] = (unsigned)(slot >> A.lb);
+                rank[e] = atomicAdd(&thist[part[e]], 1u);
+            }
+        }
+        __syncthreads();
+        // exclusive scan of thist over nparts (<= 1024): 4 entries per lane
+        {
+            unsigned x[4], s = 0;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int idx = tid * 4 + i;
+                x[i] = (idx < A.nparts) ? thist[idx] : 0;
+                s += x[i];
+            }
+            unsigned inc = s;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                unsigned o = __shfl_up(inc, d, 64);
+                if ((tid & 63) >= d) inc += o;
+            }
+            if ((tid & 63) == 63) scan_w[tid >> 6] = inc;
+            __syncthreads();
+            unsigned wbase = 0;
+            for (int w = 0; w < (tid >> 6); w++) wbase += scan_w[w];
+            unsigned ex = wbase + inc - s;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int idx = tid * 4 + i;
+                if (idx < A.nparts) thist[idx] = ex;
+                ex += x[i];
+            }
+            if (tid == RFX_BLOCK - 1) tile_total = ex;
+        }
+        __syncthreads();
+        // stage the records in partition order
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            if (!((m >> e) & 1u)) continue;
+            const unsigned idx = thist[part[e]] + rank[e];
+            const u64 slot = key[e] - (u64)A.kmin;
+            const u64 lrow = (u64)(base + (i64)(e >> 1) * (RFX_BLOCK * 2) + (e & 1));
+            stag[idx] = (lrow << 32) | (slot & ((1ULL << A.lb) - 1));
+            stag_p[idx] = (unsigned short)part[e];
+        }
+#pragma unroll
+        for (int j = 0; j < NV; j++) {
+            u64 x[8];
+            sel_col<NC, 8>(x, v, A.vcol[j]);
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                if ((m >> e) & 1u) stag[(1 + j) * PART_TILE_ROWS + thist[part[e]] + rank[e]] = x[e];
+            }
+        }
+        __syncthreads();
+        // write out: consecutive staged records of one partition go to consecutive global positions
+        const unsigned total = tile_total;
+        for (unsigned i = tid; i < total; i += RFX_BLOCK) {
+            const unsigned p = stag_p[i];
+            const u64 dst = cursor[p] + (i - thist[p]);
+            if (NV == 1) {
+                // array-of-structures: one 16-byte store per record {header, value}
+                u64x2 r;
+                r.x = stag[i];
+                r.y = stag[PART_TILE_ROWS + i];
+                *(u64x2 *)(A.recs + 2 * dst) = r;
+            } else {
+                A.recs[dst] = stag[i];
+#pragma unroll
+                for (int j = 0; j < NV; j++) A.recs[(size_t)(1 + j) * A.cap + dst] = stag[(1 + j) * PART_TILE_ROWS + i];
+            }
+        }
+        __syncthreads();
+        // advance the cursors by this tile's counts (count of p = next offset - this offset)
+        for (int i = tid; i < A.nparts; i += RFX_BLOCK) {
+            const unsigned nxt = (i + 1 < A.nparts) ? thist[i + 1] : total;
+            cursor[i] += nxt - thist[i];
+        }
+        __syncthreads();
+    }
+}
+
+// ---- pass 2: per-partition LDS aggregation ----
+template <int NV>
+__global__ __launch_bounds__(PART_AGG_THREADS) void k_part_aggregate(const Plan P, const PartArgs A) {
+    extern __shared__ __attribute__((aligned(16))) u64 smem[];
+    const int tid = threadIdx.x;
+    const int p = blockIdx.x / A.split, s = blockIdx.x % A.split;
+    const i64 local = 1LL << A.lb;
+    // descriptors into registers once (static indices only inside the record loop)
+    int kind[RFX_MAX_AGGS], f64[RFX_MAX_AGGS], plane[RFX_MAX_AGGS], arr_of[RFX_MAX_AGGS];
+    {
+        int arr = 1;
+#pragma unroll
+        for (int a = 0; a < RFX_MAX_AGGS; a++) {
+            kind[a] = (a < P.nagg) ? P.aggs[a].kind : -1;
+            f64[a] = (a < P.nagg) ? P.aggs[a].f64 : 0;
+            plane[a] = (a < P.nagg) ? A.agg_plane[a] : -1;
+            arr_of[a] = arr;
+            if (kind[a] >= 0) arr += agg_has_cnt(kind[a], f64[a]) ? 2 : 1;
+        }
+    }
+    // LDS layout: [first | acc0 | (cnt0) | acc1 ...] each `local` cells
+    for (i64 i = tid; i < local; i += PART_AGG_THREADS) smem[i] = (u64)RFX_INF_I64_D;
+#pragma unroll
+    for (int a = 0; a < RFX_MAX_AGGS; a++) {
+        if (kind[a] < 0) continue;
+        const u64 id = acc_identity(kind[a], f64[a]);
+        for (i64 i = tid; i < local; i += PART_AGG_THREADS) smem[(i64)arr_of[a] * local + i] = id;
+        if (agg_has_cnt(kind[a], f64[a])) {
+            for (i64 i = tid; i < local; i += PART_AGG_THREADS) smem[(i64)(arr_of[a] + 1) * local + i] = 0;
+        }
+    }
+    __syncthreads();
+    const u64 beg = A.part_start[p], end = A.part_start[p + 1];
+    const u64 len = end - beg;
+    const u64 per = (len + A.split - 1) / A.split;
+    const u64 b0 = beg + per * s;
+    const u64 b1 = (b0 + per < end) ? (b0 + per) : end;
+    const u64 row0 = (u64)P.row0;
+    const u64 *__restrict__ recs = A.recs;
+    const size_t cap = (size_t)A.cap;
+    constexpr int RU = 4; // records in flight per lane
+    for (u64 i0 = b0; i0 < b1; i0 += (u64)PART_AGG_THREADS * RU) {
+        u64 h[RU], val[RU][NV > 0 ? NV : 1];
+        bool in[RU];
+#pragma unroll
+        for (int r = 0; r < RU; r++) {
+            const u64 i = i0 + (u64)r * PART_AGG_THREADS + tid;
+            in[r] = i < b1;
+            h[r] = 0;
+            if (!in[r]) continue;
+            if (NV == 1) {
+                typedef u64 v2 __attribute__((ext_vector_type(2)));
+                const v2 q = __builtin_nontemporal_load((const v2 *)(recs + 2 * i));
+                h[r] = q.x;
+                val[r][0] = q.y;
+            } else {
+                h[r] = __builtin_nontemporal_load(&recs[i]);
+#pragma unroll
+                for (int j = 0; j < NV; j++) val[r][j] = __builtin_nontemporal_load(&recs[(size_t)(1 + j) * cap + i]);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < RU; r++) {
+            if (!in[r]) continue;
+            const u64 slot = h[r] & 0xffffffffULL;
+            const u64 row = row0 + (h[r] >> 32);
+            if (row < smem[slot]) atomicMin((unsigned long long *)&smem[slot], (unsigned long long)row);
+#pragma unroll
+            for (int a = 0; a < RFX_MAX_AGGS; a++) {
+                if (kind[a] < 0) continue;
+                u64 x = 0;
+#pragma unroll
+                for (int j = 0; j < NV; j++)
+                    if (plane[a] == j) x = val[r][j];
+                group_apply(&smem[(i64)arr_of[a] * local + slot], &smem[(i64)(arr_of[a] + 1) * local + slot], kind[a], f64[a], x);
+            }
+        }
+    }
+    __syncthreads();
+    // merge into the global tables (several workgroups may share a partition: atomics)
+    const i64 gbase = (i64)p << A.lb;
+    for (i64 i = tid; i < local; i += PART_AGG_THREADS) {
+        const u64 f = smem[i];
+        if (f == (u64)RFX_INF_I64_D) continue;
+        const i64 g = gbase + i;
+        if (g >= A.range) continue;
+        if (f < A.first[g]) atomicMin((unsigned long long *)&A.first[g], (unsigned long long)f);
+#pragma unroll
+        for (int a = 0; a < RFX_MAX_AGGS; a++) {
+            if (kind[a] < 0) continue;
+            const bool hc = agg_has_cnt(kind[a], f64[a]);
+            group_merge_cell(&A.acc[a][g], hc ? &A.cnt[a][g] : (u64 *)0, kind[a], f64[a], smem[(i64)arr_of[a] * local + i],
+                             hc ? smem[(i64)(arr_of[a] + 1) * local + i] : 0ULL);
+        }
+    }
+}
+
+template <int NC>
+static int launch_part(rfx_ctx *c, const Plan &P, const PartArgs &A, int nwg) {
+    hipLaunchKernelGGL((k_part_hist<NC>), dim3(nwg), dim3(RFX_BLOCK), 0, c->stream, P, A);
+    hipLaunchKernelGGL(k_part_colscan, dim3((A.nparts + RFX_BLOCK - 1) / RFX_BLOCK), dim3(RFX_BLOCK), 0, c->stream, A, nwg);
+    hipLaunchKernelGGL(k_part_startscan, dim3(1), dim3(PART_MAX), 0, c->stream, A);
+    switch (A.nv) {
+        case 0: hipLaunchKernelGGL((k_part_scatter<NC, 0>), dim3(nwg), dim3(RFX_BLOCK), 0, c->stream, P, A); break;
+        case 1: hipLaunchKernelGGL((k_part_scatter<NC, 1>), dim3(nwg), dim3(RFX_BLOCK), 0, c->stream, P, A); break;
+        case 2: hipLaunchKernelGGL((k_part_scatter<NC, 2>), dim3(nwg), dim3(RFX_BLOCK), 0, c->stream, P, A); break;
+        default: hipLaunchKernelGGL((k_part_scatter<NC, 3>), dim3(nwg), dim3(RFX_BLOCK), 0, c->stream, P, A); break;
+    }
+    return RFX_OK;
+}
+
+// Returns RFX_ESTATE when this path does not apply (caller falls back to device-scope atomics).
 int rfx_group_part_accumulate(rfx_ctx *c, const Plan &P, int key_idx, const rfx_group_tables_t *t) {
-    (void)c; (void)P; (void)key_idx; (void)t;
-    return RFX_ESTATE;
+    if (P.nrows >= (1LL << 32) || P.nrows < (1 << 16)) return RFX_ESTATE; // 32-bit local rows; tiny inputs are not worth 4 passes
+    PartArgs A;
+    memset(&A, 0, sizeof(A));
+    int narr = 1;
+    A.nv = 0;
+    for (int a = 0; a < P.nagg; a++) {
+        const PlanAgg ag = P.aggs[a];
+        narr += 1 + (agg_has_cnt(ag.kind, ag.f64) ? 1 : 0);
+        A.agg_plane[a] = -1;
+        if (ag.kind == RFX_AGG_COUNT || ag.kind == RFX_AGG_FIRST || ag.col < 0) continue;
+        int j = 0;
+        for (; j < A.nv; j++)
+            if (A.vcol[j] == ag.col) break;
+        if (j == A.nv) {
+            if (A.nv >= 3) return RFX_ESTATE; // records carry at most 3 value planes
+            A.vcol[A.nv++] = ag.col;
+        }
+        A.agg_plane[a] = j;
+    }
+    // slots per partition: largest power of two whose tables fit the LDS budget
+    int lb = 0;
+    while ((1LL << (lb + 1)) * narr * 8 <= PART_LDS_BYTES) lb++;
+    if (lb < 8) return RFX_ESTATE;
+    const i64 nparts = (t->range + (1LL << lb) - 1) >> lb;
+    if (nparts > PART_MAX || nparts < 2) return RFX_ESTATE;
+    const int nwg = c->num_cus * ((c->flags & 8) ? 2 : 3); // ~48 KB LDS per workgroup: three fit a CU
+    A.kmin = t->kmin;
+    A.range = t->range;
+    A.lb = lb;
+    A.nparts = (int)nparts;
+    A.key_idx = key_idx;
+    A.narr = narr;
+    // enough workgroups in pass 2 to fill the chip (two 512-thread workgroups per CU)
+    A.split = (int)((2 * c->num_cus + nparts - 1) / nparts);
+    if (A.split < 1) A.split = 1;
+    A.cap = ((P.nrows + 63) / 64) * 64;
+    const size_t off_bytes = (size_t)nwg * nparts * 8;
+    const size_t start_bytes = (size_t)(nparts + 2) * 8;
+    const size_t rec_bytes = (size_t)(1 + A.nv) * A.cap * 8;
+    const size_t need = ((off_bytes + 255) & ~(size_t)255) + ((start_bytes + 255) & ~(size_t)255) + rec_bytes;
+    int rc = rfx_part_reserve(c, need);
+    if (rc != RFX_OK) return rc;
+    char *w = (char *)c->d_part;
+    A.offsets = (u64 *)w;
+    w += (off_bytes + 255) & ~(size_t)255;
+    A.part_start = (u64 *)w;
+    w += (start_bytes + 255) & ~(size_t)255;
+    A.recs = (u64 *)w;
+    A.first = (u64 *)t->d_first;
+    for (int a = 0; a < t->nagg; a++) {
+        A.acc[a] = (u64 *)t->d_acc[a];
+        A.cnt[a] = (u64 *)t->d_cnt[a];
+    }
+    RFX_KERNEL_BEGIN(c);
+    switch (P.ncols) {
+        case 1: launch_part<1>(c, P, A, nwg); break;
+        case 2: launch_part<2>(c, P, A, nwg); break;
+        case 3: launch_part<3>(c, P, A, nwg); break;
+        case 4: launch_part<4>(c, P, A, nwg); break;
+        default: return RFX_ESTATE;
+    }
+    const size_t lds = (size_t)narr * (1ULL << lb) * 8;
+    const int grid2 = (int)(nparts * A.split);
+    switch (A.nv) {
+        case 0: hipLaunchKernelGGL((k_part_aggregate<0>), dim3(grid2), dim3(PART_AGG_THREADS), lds, c->stream, P, A); break;
+        case 1: hipLaunchKernelGGL((k_part_aggregate<1>), dim3(grid2), dim3(PART_AGG_THREADS), lds, c->stream, P, A); break;
+        case 2: hipLaunchKernelGGL((k_part_aggregate<2>), dim3(grid2), dim3(PART_AGG_THREADS), lds, c->stream, P, A); break;
+        default: hipLaunchKernelGGL((k_part_aggregate<3>), dim3(grid2), dim3(PART_AGG_THREADS), lds, c->stream, P, A); break;
+    }
+    RFX_KERNEL_END(c);
+    RFX_HIP_CHECK(hipGetLastError());
+    return RFX_OK;
 }

@@ -65,9 +65,12 @@ __global__ __launch_bounds__(RFX_BLOCK) void k_filter_aggr_final(const Plan P, c
     }
 }
 
+// streaming reductions want ~4 workgroups per CU (profiles/r01_bpc_sweep.txt)
+static inline int rfx_scalar_grid(const rfx_ctx *c) { return c->num_cus * (c->blocks_per_cu > 0 ? c->blocks_per_cu * 2 : 4); }
+
 int rfx_run_filter_aggr(rfx_ctx *c, Plan &P, rfx_partial_t *d_out) {
     // a plan with no columns at all (COUNT without predicate): give it a harmless column-free path
-    int grid = c->num_cus * (c->blocks_per_cu > 0 ? c->blocks_per_cu * 2 : 4); // streaming reductions want ~4 workgroups per CU (profiles/r01_bpc_sweep.txt)
+    int grid = rfx_scalar_grid(c);
     const i64 tiles = P.nrows / (RFX_BLOCK * 4) + 1;
     if (tiles < grid) grid = (int)tiles;
     int rc = rfx_ws_reserve(c, (size_t)grid * 9 * sizeof(Acc));
@@ -220,9 +223,9 @@ extern "C" int rfx_hip_filter_aggr_host(rfx_ctx_t *c, const rfx_pred_t *preds, i
     RFX_REQUIRE(nagg >= 0 && nagg <= RFX_MAX_AGGS, RFX_ELIMIT, "too many aggregates");
     size_t bytes = sizeof(rfx_partial_t) * (size_t)(nagg + 1);
     // device staging for the partials lives behind the block partials in the workspace
-    int rc = rfx_ws_reserve(c, (size_t)rfx_grid(c) * 9 * sizeof(Acc) + bytes + 256);
+    int rc = rfx_ws_reserve(c, (size_t)rfx_scalar_grid(c) * 9 * sizeof(Acc) + bytes + 256);
     if (rc != RFX_OK) return rc;
-    rfx_partial_t *d_out = (rfx_partial_t *)((char *)c->d_ws + (((size_t)rfx_grid(c) * 9 * sizeof(Acc) + 255) & ~(size_t)255));
+    rfx_partial_t *d_out = (rfx_partial_t *)((char *)c->d_ws + (((size_t)rfx_scalar_grid(c) * 9 * sizeof(Acc) + 255) & ~(size_t)255));
     rc = rfx_hip_filter_aggr(c, preds, npred, logic, aggs, nagg, nrows, 0, d_out);
     if (rc != RFX_OK) return rc;
     rfx_partial_t *h = (rfx_partial_t *)c->h_pin;
