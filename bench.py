@@ -172,26 +172,29 @@ def cpu_baseline(name, sample_rows):
     log(f"[cpu_baseline] generated {sample_rows} sample rows in {time.perf_counter() - t0:.1f}s")
     reps = 5
     if ref.available():
-        try:
-            shm = "/dev/shm" if os.path.isdir("/dev/shm") else None
-            with ref.Session(root=shm) as s:
-                # materialise the mmapped column files into heap vectors first (the GPU path is timed HBM-resident too)
-                for k, v in cols.items():
-                    s.put(k, v)
-                    s.eval(f"(set {k} (+ {k} 0))" if v.dtype == np.int64 else f"(set {k} (+ {k} 0.0))")
-                names = " ".join(cols.keys())
-                s.eval(f"(set t (table [{names}] (list {names})))")
-                s.eval(f"(set warm {q})")
-                s.out("ms", f"(enlist (timeit {reps} {q}))")
-                out = s.run(timeout=900)
-            ms = float(out["ms"][0]) / reps
-            if ms and ms > 0:
-                return dict(value=sample_rows / (ms * 1e-3), unit="rows/s", cores=cores, kind="reference", ms_per_query=ms,
-                            sample=f"{name}: first {sample_rows} rows of the workload (same seeds), real RayforceDB build (oracle/_ref, gcc -O3 "
-                                   f"x86-64-v3, pool = all {cores} hardware threads), (timeit {reps} query) after one warm run")
-            log("[cpu_baseline] reference returned no timing, falling back to the port")
-        except Exception as e:  # noqa: BLE001
-            log(f"[cpu_baseline] reference run failed ({e}); falling back to the port")
+        shm = "/dev/shm" if os.path.isdir("/dev/shm") else None
+        # the reference sizes its pool to all cores (core/runtime.c:141-145); its page-aligned chunking can overshoot and
+        # crash when the pool is large relative to the input, so fall back to smaller pools and report what was used
+        for threads in [cores] + [t for t in (128, 64, 32, 16, 8) if t < cores]:
+            try:
+                with ref.Session(root=shm) as s:
+                    # materialise the mmapped column files into heap vectors first (the GPU path is timed HBM-resident too)
+                    for k, v in cols.items():
+                        s.put(k, v)
+                        s.eval(f"(set {k} (+ {k} 0))" if v.dtype == np.int64 else f"(set {k} (+ {k} 0.0))")
+                    names = " ".join(cols.keys())
+                    s.eval(f"(set t (table [{names}] (list {names})))")
+                    s.eval(f"(set warm {q})")
+                    s.out("ms", f"(enlist (timeit {reps} {q}))")
+                    out = s.run(threads=threads, timeout=900)
+                ms = float(out["ms"][0]) / reps
+                if ms > 0:
+                    return dict(value=sample_rows / (ms * 1e-3), unit="rows/s", cores=threads, kind="reference", ms_per_query=ms,
+                                sample=f"{name}: first {sample_rows} rows of the workload (same seeds), real RayforceDB build (oracle/_ref, gcc -O3 "
+                                       f"x86-64-v3, -c {threads} of {cores} hardware threads), (timeit {reps} query) after one warm run")
+            except Exception as e:  # noqa: BLE001
+                log(f"[cpu_baseline] reference run with {threads} threads failed ({str(e)[:120]}); trying a smaller pool")
+        log("[cpu_baseline] reference unusable here, falling back to the port")
     best = None
     for _ in range(reps):
         t0 = time.perf_counter()

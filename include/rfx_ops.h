@@ -1,0 +1,105 @@
+/*
+ * rfx_ops.h -- operator-level C ABI of librfx.so: the drop-in boundary for RayforceDB's select / where / by path.
+ *
+ * Every entry point has one of the reference's three operator shapes (core/ops.h:202-204)
+ *
+ *     obj_p f(obj_p)            unary_f          obj_p f(obj_p, obj_p)     binary_f          obj_p f(obj_p *, i64_t)   vary_f
+ *
+ * over the reference's 16-byte object header (include/rfx_abi.h), follows its ownership rule -- arguments are BORROWED,
+ * the result is OWNED by the caller (core/eval.c:741-742,764-766,793-794) -- and reports errors by returning an object
+ * of type TYPE_ERR obtained from the host's ray_err() (core/rayforce.h:292), never by longjmp / exit.  So a function
+ * here can be bound with the reference's own plugin loader, unchanged:
+ *
+ *     (set gsel (loadfn "librfx.so" "rfx_select" 1))        ;; core/dynlib.c:153-216  dlopen(RTLD_NOW|RTLD_GLOBAL) + dlsym
+ *     (gsel {s: (sum v) from: t where: (< a 100000) by: k})
+ *
+ * or linked in place of the reference's objects (Makefile:54-61 CORE_OBJECTS).  INTEGRATION.md shows both.
+ *
+ *   entry point            replaces (reference)                                  shape
+ *   ---------------------  ----------------------------------------------------  -------
+ *   rfx_select             ray_select            core/query.c:607-654            unary_f   (whole select dict)
+ *   rfx_eq .. rfx_ge       ray_eq .. ray_ge      core/cmp.c:692-697              binary_f  -> B8 mask vector
+ *   rfx_and, rfx_or        ray_and, ray_or       core/logic.c:262-264            vary_f    (over EVALUATED B8 masks: a loadfn
+ *                                                                                           plugin is not a special form)
+ *   rfx_where              ray_where             core/items.c:1366-1397          unary_f   -> ascending I64 row ids
+ *   rfx_sum rfx_avg        ray_sum ray_avg       core/math.c:2388,2445-2526      unary_f   vector | MAPFILTER(val, ids)
+ *   rfx_min rfx_max        ray_min ray_max       core/math.c:2428-2429           unary_f
+ *   rfx_count rfx_first    ray_count ray_first   core/misc.c:43-60, core/items.c unary_f
+ *   rfx_at                 at_ids via ray_at     core/rayforce.c:1100-1158       binary_f  (column, I64 ids) -> gathered column
+ *
+ * Everything below runs on the MI355X through the flat ABI of rfx_hip.h.  There is NO CPU implementation behind these
+ * entry points: queries whose shape the GPU path does not cover are handed back to the host's own ray_* function when
+ * the library runs as a plugin (the host exports them, rayforce.syms), and return an error object otherwise.
+ *
+ * Data residency: columns are host objects.  The first query that touches a column uploads it to HBM (PCIe) and keeps
+ * it in a residency cache keyed by (payload pointer, length, type) and guarded by a sampled checksum; later queries
+ * run HBM-resident.  rfx_pin / rfx_unpin / rfx_cache_clear make that explicit.
+ */
+#ifndef RFX_OPS_H
+#define RFX_OPS_H
+
+#include "rfx_abi.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- host binding ------------------------------------------------------------------------------------------------
+ * The shim needs the host's constructors (vector, table, i64, f64, b8, drop_obj, clone_obj, eval, ray_err,
+ * symbols_intern, str_from_symbol: all in the reference's dynamic export list, rayforce.syms).  As a plugin it finds
+ * them with dlsym(RTLD_DEFAULT) on first use.  Without a host process (tests, bench, the GPU box) it falls back to the
+ * minimal object allocator in rfx_host.c.  Returns 1 = reference host bound, 0 = standalone host, <0 = error. */
+int rfx_host_bind(void);
+/* GPU ordinal used by the operator layer (default 0 or $RFX_DEVICE).  Call before the first operator. */
+int rfx_ops_set_device(int device);
+const char *rfx_ops_last_error(void);
+
+/* ---- the operator surface ---------------------------------------------------------------------------------------- */
+rfx_obj_p rfx_select(rfx_obj_p dict);
+
+rfx_obj_p rfx_eq(rfx_obj_p x, rfx_obj_p y);
+rfx_obj_p rfx_ne(rfx_obj_p x, rfx_obj_p y);
+rfx_obj_p rfx_lt(rfx_obj_p x, rfx_obj_p y);
+rfx_obj_p rfx_gt(rfx_obj_p x, rfx_obj_p y);
+rfx_obj_p rfx_le(rfx_obj_p x, rfx_obj_p y);
+rfx_obj_p rfx_ge(rfx_obj_p x, rfx_obj_p y);
+
+rfx_obj_p rfx_and(rfx_obj_p *x, int64_t n);
+rfx_obj_p rfx_or(rfx_obj_p *x, int64_t n);
+rfx_obj_p rfx_where(rfx_obj_p mask);
+rfx_obj_p rfx_at(rfx_obj_p col, rfx_obj_p ids);
+
+rfx_obj_p rfx_sum(rfx_obj_p x);
+rfx_obj_p rfx_avg(rfx_obj_p x);
+rfx_obj_p rfx_min(rfx_obj_p x);
+rfx_obj_p rfx_max(rfx_obj_p x);
+rfx_obj_p rfx_count(rfx_obj_p x);
+rfx_obj_p rfx_first(rfx_obj_p x);
+
+/* ---- residency ---------------------------------------------------------------------------------------------------- */
+rfx_obj_p rfx_pin(rfx_obj_p table_or_column);   /* unary_f: upload + keep resident; returns a clone of its argument */
+rfx_obj_p rfx_unpin(rfx_obj_p table_or_column); /* unary_f: drop the device copies */
+void rfx_cache_clear(void);
+int64_t rfx_cache_bytes(void);
+/* statistics of the most recent rfx_select: 1 = ran on the GPU path, 0 = delegated to the host's ray_select */
+int rfx_last_select_on_gpu(void);
+
+/* ---- standalone host (rfx_host.c): just enough object model to build queries without the reference ---------------- */
+rfx_obj_p rfx_host_vector(int8_t type, int64_t len);
+rfx_obj_p rfx_host_i64(int64_t v);
+rfx_obj_p rfx_host_f64(double v);
+rfx_obj_p rfx_host_symbol(const char *name);             /* symbol atom */
+rfx_obj_p rfx_host_list(int64_t len);                    /* LIST of `len` null slots; fill with RFX_AS_LIST */
+rfx_obj_p rfx_host_table(rfx_obj_p keys, rfx_obj_p vals); /* takes ownership of both */
+rfx_obj_p rfx_host_dict(rfx_obj_p keys, rfx_obj_p vals);
+rfx_obj_p rfx_host_fn(const char *name);                 /* function object for "sum" "<" "and" ... bound to rfx_* */
+rfx_obj_p rfx_host_clone(rfx_obj_p o);
+void rfx_host_drop(rfx_obj_p o);
+int64_t rfx_host_intern(const char *s, int64_t len);
+const char *rfx_host_symbol_name(int64_t id);
+const char *rfx_host_error_text(rfx_obj_p err);          /* message of an error object made by the standalone host */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RFX_OPS_H */

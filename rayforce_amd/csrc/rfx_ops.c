@@ -1,0 +1,627 @@
+/*
+ * rfx_ops.c -- the drop-in operator layer (host code stays in C, as in the reference): obj_p-shaped entry points that
+ * plan a RayforceDB select / where / by query onto the flat HIP ABI (rfx_hip.h).
+ *
+ *   rfx_select walks the select dictionary the way ray_select does (core/query.c:243-654): `from:` is evaluated through
+ *   the host's eval, `where:` is an expression LIST whose head is a function object (the parser already substituted the
+ *   built-in for the symbol, core/parse.c:771-772), `by:` is a column symbol, every other key is an output mapping
+ *   `(aggr col)`.  Supported shapes run as <= 4 kernel launches on HBM-resident columns; anything else goes back to
+ *   the host's own ray_select (plugin mode) -- never to a CPU re-implementation of ours.
+ */
+#define _GNU_SOURCE
+#include <dlfcn.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "rfx_abi.h"
+#include "rfx_hip.h"
+#include "rfx_ops.h"
+
+typedef rfx_obj_p obj_p;
+
+/* rfx_host.c */
+obj_p rfx_host_null(void);
+obj_p rfx_host_b8(int8_t v);
+obj_p rfx_host_err(const char *msg);
+obj_p rfx_host_eval(obj_p o);
+
+/* ------------------------------------------------------------------------------------------------ host binding */
+static struct {
+    int bound; /* 0 = not yet, 1 = reference host, 2 = standalone */
+    obj_p (*vector)(int8_t, int64_t);
+    obj_p (*table)(obj_p, obj_p);
+    obj_p (*i64)(int64_t);
+    obj_p (*f64)(double);
+    void (*drop)(obj_p);
+    obj_p (*clone)(obj_p);
+    obj_p (*eval)(obj_p);
+    obj_p (*err)(const char *);
+    int64_t (*intern)(const char *, int64_t);
+    const char *(*symname)(int64_t);
+    obj_p null_obj;
+    /* the host's own built-ins, for recognising function objects inside parsed expressions and for delegation */
+    void *f[16];
+} H;
+enum { F_SUM, F_AVG, F_MIN, F_MAX, F_COUNT, F_FIRST, F_EQ, F_NE, F_LT, F_GT, F_LE, F_GE, F_AND, F_OR, F_SELECT, F_N };
+static const char *HOST_FN[F_N] = {"ray_sum", "ray_avg", "ray_min", "ray_max", "ray_count", "ray_first", "ray_eq", "ray_ne",
+                                   "ray_lt",  "ray_gt",  "ray_le",  "ray_ge",  "ray_and",   "ray_or",    "ray_select"};
+static void *OUR_FN[F_N];
+static char g_err[512];
+static int g_last_gpu = 0;
+
+const char *rfx_ops_last_error(void) { return g_err; }
+int rfx_last_select_on_gpu(void) { return g_last_gpu; }
+
+int rfx_host_bind(void) {
+    if (H.bound) return H.bound == 1;
+    OUR_FN[F_SUM] = (void *)rfx_sum; OUR_FN[F_AVG] = (void *)rfx_avg; OUR_FN[F_MIN] = (void *)rfx_min; OUR_FN[F_MAX] = (void *)rfx_max;
+    OUR_FN[F_COUNT] = (void *)rfx_count; OUR_FN[F_FIRST] = (void *)rfx_first; OUR_FN[F_EQ] = (void *)rfx_eq; OUR_FN[F_NE] = (void *)rfx_ne;
+    OUR_FN[F_LT] = (void *)rfx_lt; OUR_FN[F_GT] = (void *)rfx_gt; OUR_FN[F_LE] = (void *)rfx_le; OUR_FN[F_GE] = (void *)rfx_ge;
+    OUR_FN[F_AND] = (void *)rfx_and; OUR_FN[F_OR] = (void *)rfx_or; OUR_FN[F_SELECT] = (void *)rfx_select;
+    void *v = dlsym(RTLD_DEFAULT, "vector"), *t = dlsym(RTLD_DEFAULT, "table"), *e = dlsym(RTLD_DEFAULT, "eval");
+    void *rs = dlsym(RTLD_DEFAULT, "ray_select"), *nu = dlsym(RTLD_DEFAULT, "__NULL_OBJ");
+    if (v && t && e && rs && nu && !getenv("RFX_FORCE_STANDALONE")) {
+        H.vector = (obj_p(*)(int8_t, int64_t))v;
+        H.table = (obj_p(*)(obj_p, obj_p))t;
+        H.eval = (obj_p(*)(obj_p))e;
+        H.i64 = (obj_p(*)(int64_t))dlsym(RTLD_DEFAULT, "i64");
+        H.f64 = (obj_p(*)(double))dlsym(RTLD_DEFAULT, "f64");
+        H.drop = (void (*)(obj_p))dlsym(RTLD_DEFAULT, "drop_obj");
+        H.clone = (obj_p(*)(obj_p))dlsym(RTLD_DEFAULT, "clone_obj");
+        H.err = (obj_p(*)(const char *))dlsym(RTLD_DEFAULT, "ray_err");
+        H.intern = (int64_t(*)(const char *, int64_t))dlsym(RTLD_DEFAULT, "symbols_intern");
+        H.symname = (const char *(*)(int64_t))dlsym(RTLD_DEFAULT, "str_from_symbol");
+        H.null_obj = (obj_p)nu;
+        for (int i = 0; i < F_N; i++) H.f[i] = dlsym(RTLD_DEFAULT, HOST_FN[i]);
+        if (H.i64 && H.f64 && H.drop && H.clone && H.err && H.intern && H.symname) {
+            H.bound = 1;
+            return 1;
+        }
+    }
+    H.vector = rfx_host_vector;
+    H.table = rfx_host_table;
+    H.i64 = rfx_host_i64;
+    H.f64 = rfx_host_f64;
+    H.drop = rfx_host_drop;
+    H.clone = rfx_host_clone;
+    H.eval = rfx_host_eval;
+    H.err = rfx_host_err;
+    H.intern = rfx_host_intern;
+    H.symname = rfx_host_symbol_name;
+    H.null_obj = rfx_host_null();
+    memset(H.f, 0, sizeof(H.f));
+    H.bound = 2;
+    return 0;
+}
+
+obj_p rfx_host_fn(const char *name) {
+    static const struct { const char *n; int f; int type; int attrs; } T[] = {
+        {"sum", F_SUM, RFX_TYPE_UNARY, RFX_FN_AGGR}, {"avg", F_AVG, RFX_TYPE_UNARY, RFX_FN_AGGR}, {"min", F_MIN, RFX_TYPE_UNARY, RFX_FN_AGGR},
+        {"max", F_MAX, RFX_TYPE_UNARY, RFX_FN_AGGR}, {"count", F_COUNT, RFX_TYPE_UNARY, RFX_FN_AGGR}, {"first", F_FIRST, RFX_TYPE_UNARY, RFX_FN_AGGR},
+        {"==", F_EQ, RFX_TYPE_BINARY, RFX_FN_ATOMIC}, {"!=", F_NE, RFX_TYPE_BINARY, RFX_FN_ATOMIC}, {"<", F_LT, RFX_TYPE_BINARY, RFX_FN_ATOMIC},
+        {">", F_GT, RFX_TYPE_BINARY, RFX_FN_ATOMIC}, {"<=", F_LE, RFX_TYPE_BINARY, RFX_FN_ATOMIC}, {">=", F_GE, RFX_TYPE_BINARY, RFX_FN_ATOMIC},
+        {"and", F_AND, RFX_TYPE_VARY, RFX_FN_SPECIAL_FORM}, {"or", F_OR, RFX_TYPE_VARY, RFX_FN_SPECIAL_FORM}, {"select", F_SELECT, RFX_TYPE_UNARY, 0}};
+    rfx_host_bind();
+    for (size_t i = 0; i < sizeof(T) / sizeof(T[0]); i++)
+        if (strcmp(T[i].n, name) == 0) {
+            obj_p o = rfx_host_i64((int64_t)(intptr_t)OUR_FN[T[i].f]);
+            o->type = (int8_t)T[i].type; /* function objects carry the POSITIVE type code (core/env.c:66-74) */
+            o->attrs = (uint8_t)T[i].attrs;
+            return o;
+        }
+    return NULL;
+}
+
+static obj_p fail(const char *msg) {
+    rfx_host_bind();
+    snprintf(g_err, sizeof(g_err), "%s", msg);
+    return H.err(msg);
+}
+static obj_p fail_hip(const char *what) {
+    char b[600];
+    snprintf(b, sizeof(b), "%s: %s", what, rfx_hip_last_error());
+    return fail(b);
+}
+
+/* which built-in does this function object denote? -1 if none */
+static int fn_id(obj_p o) {
+    if (!o || (o->type != RFX_TYPE_UNARY && o->type != RFX_TYPE_BINARY && o->type != RFX_TYPE_VARY)) return -1;
+    void *p = (void *)(intptr_t)o->i64;
+    for (int i = 0; i < F_N; i++)
+        if (p == OUR_FN[i] || (H.f[i] && p == H.f[i])) return i;
+    return -1;
+}
+
+/* ------------------------------------------------------------------------------------------------ device + residency */
+static rfx_ctx_t *g_ctx;
+static int g_device = -1;
+int rfx_ops_set_device(int device) {
+    if (g_ctx) return RFX_ESTATE;
+    g_device = device;
+    return RFX_OK;
+}
+static int ensure_ctx(void) {
+    if (g_ctx) return RFX_OK;
+    if (g_device < 0) {
+        const char *e = getenv("RFX_DEVICE");
+        g_device = e ? atoi(e) : 0;
+    }
+    return rfx_hip_ctx_create(g_device, NULL, &g_ctx);
+}
+
+typedef struct {
+    const void *host;
+    int64_t len;
+    int type;
+    uint64_t stamp;
+    void *dev;
+    size_t bytes;
+    int pinned;
+    uint64_t tick;
+} resident_t;
+static resident_t *g_res;
+static int g_nres, g_capres;
+static uint64_t g_tick;
+static size_t g_res_bytes;
+
+static uint64_t stamp_of(const void *p, int64_t len, int esz) {
+    /* sampled checksum: 64 probes across the payload catch in-place rewrites of a cached column (not every single-cell
+     * update: mutate-in-place callers should rfx_unpin / rfx_cache_clear) */
+    uint64_t h = 1469598103934665603ULL ^ (uint64_t)len;
+    if (len <= 0) return h;
+    const unsigned char *b = (const unsigned char *)p;
+    int64_t step = len / 64 + 1;
+    for (int64_t i = 0; i < len; i += step) {
+        uint64_t v = 0;
+        memcpy(&v, b + (size_t)i * esz, (size_t)(esz < 8 ? esz : 8));
+        h = (h ^ v) * 1099511628211ULL;
+    }
+    uint64_t v = 0;
+    memcpy(&v, b + (size_t)(len - 1) * esz, (size_t)(esz < 8 ? esz : 8));
+    return (h ^ v) * 1099511628211ULL;
+}
+static void res_free(int i) {
+    if (g_res[i].dev) rfx_hip_free(g_ctx, g_res[i].dev);
+    g_res_bytes -= g_res[i].bytes;
+    g_res[i] = g_res[--g_nres];
+}
+void rfx_cache_clear(void) {
+    while (g_nres) res_free(g_nres - 1);
+}
+int64_t rfx_cache_bytes(void) { return (int64_t)g_res_bytes; }
+
+static size_t cache_budget(void) {
+    const char *e = getenv("RFX_CACHE_BYTES");
+    return e ? (size_t)strtoull(e, NULL, 10) : (size_t)200 << 30; /* of the 288 GB of HBM3E */
+}
+
+/* device pointer of a host vector's payload (uploading it if needed) */
+static int resident(obj_p col, int pin, const void **dev) {
+    int esz = (col->type == RFX_TYPE_B8) ? 1 : 8;
+    const void *host = RFX_AS_RAW(col);
+    uint64_t st = stamp_of(host, col->len, esz);
+    for (int i = 0; i < g_nres; i++)
+        if (g_res[i].host == host && g_res[i].len == col->len && g_res[i].type == col->type) {
+            if (g_res[i].stamp == st) {
+                g_res[i].tick = ++g_tick;
+                g_res[i].pinned |= pin;
+                *dev = g_res[i].dev;
+                return RFX_OK;
+            }
+            res_free(i); /* stale */
+            break;
+        }
+    size_t bytes = (size_t)col->len * esz;
+    while (g_nres && g_res_bytes + bytes > cache_budget()) {
+        int victim = -1;
+        for (int i = 0; i < g_nres; i++)
+            if (!g_res[i].pinned && (victim < 0 || g_res[i].tick < g_res[victim].tick)) victim = i;
+        if (victim < 0) break;
+        res_free(victim);
+    }
+    void *d = NULL;
+    int rc = rfx_hip_malloc(g_ctx, &d, bytes ? bytes : 8);
+    if (rc != RFX_OK) return rc;
+    rc = rfx_hip_h2d(g_ctx, d, host, bytes);
+    if (rc != RFX_OK) { rfx_hip_free(g_ctx, d); return rc; }
+    if (g_nres == g_capres) {
+        g_capres = g_capres ? g_capres * 2 : 32;
+        g_res = (resident_t *)realloc(g_res, sizeof(resident_t) * (size_t)g_capres);
+    }
+    g_res[g_nres++] = (resident_t){host, col->len, col->type, st, d, bytes, pin, ++g_tick};
+    g_res_bytes += bytes;
+    *dev = d;
+    return RFX_OK;
+}
+
+static int col_ctype(obj_p c) {
+    switch (c->type) {
+        case RFX_TYPE_I64: case RFX_TYPE_TIMESTAMP: case RFX_TYPE_SYMBOL: return RFX_I64; /* 8-byte integer payloads */
+        case RFX_TYPE_F64: return RFX_F64;
+        default: return 0;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------ table access */
+static obj_p table_col(obj_p tab, int64_t sym) {
+    obj_p names = RFX_AS_LIST(tab)[0], cols = RFX_AS_LIST(tab)[1];
+    for (int64_t i = 0; i < names->len; i++)
+        if (RFX_AS_I64(names)[i] == sym) return RFX_AS_LIST(cols)[i];
+    return NULL;
+}
+static obj_p dict_get(obj_p d, const char *key) {
+    int64_t id = H.intern(key, (int64_t)strlen(key));
+    obj_p keys = RFX_AS_LIST(d)[0], vals = RFX_AS_LIST(d)[1];
+    for (int64_t i = 0; i < keys->len; i++)
+        if (RFX_AS_I64(keys)[i] == id) return RFX_AS_LIST(vals)[i];
+    return NULL;
+}
+
+/* ------------------------------------------------------------------------------------------------ planning */
+typedef struct {
+    rfx_pred_t preds[RFX_MAX_PREDS];
+    int npred, logic;
+} wplan_t;
+
+/* one comparison `(op colsym atom|colsym)` -> descriptor; 0 ok, -1 unsupported shape */
+static int plan_cmp(obj_p tab, obj_p e, rfx_pred_t *p) {
+    if (e->type != RFX_TYPE_LIST || e->len != 3) return -1;
+    int f = fn_id(RFX_AS_LIST(e)[0]);
+    if (f < F_EQ || f > F_GE) return -1;
+    obj_p l = RFX_AS_LIST(e)[1], r = RFX_AS_LIST(e)[2];
+    if (l->type != -RFX_TYPE_SYMBOL) return -1;
+    obj_p lc = table_col(tab, l->i64);
+    if (!lc || !col_ctype(lc)) return -1;
+    memset(p, 0, sizeof(*p));
+    p->op = f - F_EQ; /* F_EQ..F_GE are in RFX_EQ..RFX_GE order */
+    p->col_type = col_ctype(lc);
+    const void *d;
+    if (resident(lc, 0, &d) != RFX_OK) return -2;
+    p->d_col = d;
+    if (r->type == -RFX_TYPE_I64) { p->rhs_type = RFX_I64; p->rhs_i = r->i64; }
+    else if (r->type == -RFX_TYPE_F64) { p->rhs_type = RFX_F64; p->rhs_f = r->f64; }
+    else if (r->type == -RFX_TYPE_SYMBOL) {
+        obj_p rc = table_col(tab, r->i64);
+        if (!rc || !col_ctype(rc) || rc->len != lc->len) return -1;
+        if (resident(rc, 0, &d) != RFX_OK) return -2;
+        p->d_rhs_col = d;
+        p->rhs_type = col_ctype(rc);
+    } else return -1;
+    return 0;
+}
+/* where: a comparison, or a flat (and ...) / (or ...) of comparisons */
+static int plan_where(obj_p tab, obj_p w, wplan_t *wp) {
+    wp->npred = 0;
+    wp->logic = RFX_AND;
+    if (!w) return 0;
+    if (w->type != RFX_TYPE_LIST || w->len < 1) return -1;
+    int f = fn_id(RFX_AS_LIST(w)[0]);
+    if (f == F_AND || f == F_OR) {
+        if (w->len - 1 > RFX_MAX_PREDS || w->len < 2) return -1;
+        wp->logic = (f == F_AND) ? RFX_AND : RFX_OR;
+        for (int64_t i = 1; i < w->len; i++) {
+            int rc = plan_cmp(tab, RFX_AS_LIST(w)[i], &wp->preds[wp->npred]);
+            if (rc) return rc;
+            wp->npred++;
+        }
+        return 0;
+    }
+    int rc = plan_cmp(tab, w, &wp->preds[0]);
+    if (rc) return rc;
+    wp->npred = 1;
+    return 0;
+}
+
+static obj_p value_atom(const rfx_value_t *v) { return v->type == RFX_F64 ? H.f64(v->f) : H.i64(v->i); }
+static obj_p one_row(const rfx_value_t *v) {
+    obj_p c = H.vector(v->type == RFX_F64 ? RFX_TYPE_F64 : RFX_TYPE_I64, 1);
+    RFX_AS_I64(c)[0] = v->i;
+    return c;
+}
+
+static obj_p delegate_select(obj_p dict, const char *why) {
+    g_last_gpu = 0;
+    if (H.bound == 1 && H.f[F_SELECT]) return ((rfx_unary_f)H.f[F_SELECT])(dict);
+    char b[300];
+    snprintf(b, sizeof(b), "rfx_select: query shape not covered by the MI355X path (%s) and no host ray_select to delegate to", why);
+    return fail(b);
+}
+
+/* ------------------------------------------------------------------------------------------------ select */
+rfx_obj_p rfx_select(rfx_obj_p dict) {
+    rfx_host_bind();
+    if (!dict || dict->type != RFX_TYPE_DICT || RFX_AS_LIST(dict)[0]->type != RFX_TYPE_SYMBOL) return fail("select: expected a dict");
+    obj_p from = dict_get(dict, "from");
+    if (!from) return fail("'select' expects 'from' param"); /* core/query.c:281 */
+    if (dict_get(dict, "take")) return delegate_select(dict, "take:");
+    obj_p tab = H.eval(from);
+    if (!tab || tab->type == RFX_TYPE_ERR) return tab;
+    obj_p res = NULL;
+    const char *why = NULL;
+    obj_p where = dict_get(dict, "where"), by = dict_get(dict, "by");
+    obj_p dkeys = RFX_AS_LIST(dict)[0], dvals = RFX_AS_LIST(dict)[1];
+    int64_t s_from = H.intern("from", 4), s_where = H.intern("where", 5), s_by = H.intern("by", 2);
+    if (tab->type != RFX_TYPE_TABLE) { why = "from: is not a table"; goto out; }
+    if (ensure_ctx() != RFX_OK) { res = fail_hip("no usable MI355X"); goto done; }
+    {
+        obj_p tcols = RFX_AS_LIST(tab)[1];
+        int64_t nrows = tcols->len ? RFX_AS_LIST(tcols)[0]->len : 0;
+        wplan_t wp;
+        int rc = plan_where(tab, where, &wp);
+        if (rc == -2) { res = fail_hip("column upload"); goto done; }
+        if (rc) { why = "where: shape"; goto out; }
+        /* output mappings */
+        rfx_agg_t aggs[RFX_MAX_AGGS];
+        int64_t names[RFX_MAX_AGGS];
+        int outtype[RFX_MAX_AGGS];
+        int nagg = 0;
+        for (int64_t i = 0; i < dkeys->len; i++) {
+            int64_t k = RFX_AS_I64(dkeys)[i];
+            if (k == s_from || k == s_where || k == s_by) continue;
+            obj_p e = RFX_AS_LIST(dvals)[i];
+            if (nagg >= RFX_MAX_AGGS || e->type != RFX_TYPE_LIST || e->len != 2) { why = "mapping shape"; goto out; }
+            int f = fn_id(RFX_AS_LIST(e)[0]);
+            obj_p a = RFX_AS_LIST(e)[1];
+            if (f < F_SUM || f > F_FIRST || a->type != -RFX_TYPE_SYMBOL) { why = "mapping is not (aggr column)"; goto out; }
+            obj_p c = table_col(tab, a->i64);
+            if (!c || !col_ctype(c) || c->type == RFX_TYPE_SYMBOL) { why = "aggregate column type"; goto out; }
+            const void *d;
+            if (resident(c, 0, &d) != RFX_OK) { res = fail_hip("column upload"); goto done; }
+            static const int KIND[] = {RFX_AGG_SUM, RFX_AGG_AVG, RFX_AGG_MIN, RFX_AGG_MAX, RFX_AGG_COUNT, RFX_AGG_FIRST};
+            aggs[nagg].d_col = d;
+            aggs[nagg].col_type = col_ctype(c);
+            aggs[nagg].kind = KIND[f - F_SUM];
+            outtype[nagg] = (f == F_AVG) ? RFX_TYPE_F64 : (f == F_COUNT) ? RFX_TYPE_I64 : c->type;
+            names[nagg++] = k;
+        }
+        if (by) {
+            if (by->type != -RFX_TYPE_SYMBOL) { why = "by: is not a single column"; goto out; }
+            obj_p kc = table_col(tab, by->i64);
+            if (!kc || kc->type != RFX_TYPE_I64) { why = "by: key is not an i64 column"; goto out; }
+            const void *dk;
+            if (resident(kc, 0, &dk) != RFX_OK) { res = fail_hip("column upload"); goto done; }
+            int64_t kmin, kmax, seen;
+            if (rfx_hip_scope_i64(g_ctx, (const int64_t *)dk, wp.preds, wp.npred, wp.logic, nrows, &kmin, &kmax, &seen) != RFX_OK) { res = fail_hip("scope"); goto done; }
+            int64_t groups = 0;
+            obj_p okeys = NULL, ocols[RFX_MAX_AGGS] = {0};
+            if (seen > 0) {
+                /* dense "perfect hash" iff range <= rows (core/index.c:2013), like the reference; else open addressing */
+                uint64_t range = (uint64_t)kmax - (uint64_t)kmin + 1;
+                int dense = range != 0 && range <= (uint64_t)seen && kmin != RFX_NULL_I64;
+                int narr = 0;
+                rfx_hip_group_table_arrays(aggs, nagg, &narr);
+                int64_t cells = dense ? (int64_t)range : 0;
+                int64_t cap = 16;
+                if (!dense) {
+                    while (cap < 2 * seen) cap <<= 1;
+                    cells = cap + 1;
+                    narr += 1;
+                }
+                void *store = NULL;
+                if (rfx_hip_malloc(g_ctx, &store, (size_t)narr * (size_t)cells * 8) != RFX_OK) { res = fail_hip("group tables"); goto done; }
+                int64_t *base = (int64_t *)store;
+                int k = 0, ok = 1;
+                rfx_group_tables_t gt;
+                rfx_hash_tables_t ht;
+                memset(&gt, 0, sizeof(gt));
+                memset(&ht, 0, sizeof(ht));
+                if (dense) { gt.kmin = kmin; gt.range = (int64_t)range; gt.nagg = nagg; gt.d_first = base + (k++) * cells; }
+                else { ht.capacity = cap; ht.nagg = nagg; ht.d_keys = base + (k++) * cells; ht.d_first = base + (k++) * cells; }
+                for (int a = 0; a < nagg; a++) {
+                    void *acc = base + (k++) * cells;
+                    int hc = aggs[a].kind == RFX_AGG_AVG || (aggs[a].kind == RFX_AGG_SUM && aggs[a].col_type == RFX_I64);
+                    int64_t *cnt = hc ? base + (k++) * cells : NULL;
+                    if (dense) { gt.d_acc[a] = acc; gt.d_cnt[a] = cnt; } else { ht.d_acc[a] = acc; ht.d_cnt[a] = cnt; }
+                }
+                if (dense) {
+                    ok = rfx_hip_group_tables_init(g_ctx, aggs, &gt) == RFX_OK &&
+                         rfx_hip_group_dense_accumulate(g_ctx, (const int64_t *)dk, wp.preds, wp.npred, wp.logic, aggs, nrows, 0, &gt) == RFX_OK &&
+                         rfx_hip_group_rank(g_ctx, &gt, nrows, &groups) == RFX_OK;
+                } else {
+                    ok = rfx_hip_hash_tables_init(g_ctx, aggs, &ht) == RFX_OK &&
+                         rfx_hip_group_hash_accumulate(g_ctx, (const int64_t *)dk, wp.preds, wp.npred, wp.logic, aggs, nrows, 0, &ht) == RFX_OK &&
+                         rfx_hip_hash_rank(g_ctx, &ht, nrows, &groups) == RFX_OK;
+                }
+                void *dout = NULL;
+                if (ok && groups > 0) ok = rfx_hip_malloc(g_ctx, &dout, (size_t)(nagg + 1) * (size_t)groups * 8) == RFX_OK;
+                if (ok && groups > 0) {
+                    void *ptrs[RFX_MAX_AGGS];
+                    for (int a = 0; a < nagg; a++) ptrs[a] = (int64_t *)dout + (size_t)(a + 1) * groups;
+                    ok = (dense ? rfx_hip_group_emit(g_ctx, aggs, &gt, (int64_t *)dout, NULL, ptrs) : rfx_hip_hash_emit(g_ctx, aggs, &ht, (int64_t *)dout, NULL, ptrs)) == RFX_OK;
+                    okeys = H.vector(RFX_TYPE_I64, groups);
+                    if (ok) ok = rfx_hip_d2h(g_ctx, RFX_AS_RAW(okeys), dout, (size_t)groups * 8) == RFX_OK;
+                    for (int a = 0; a < nagg && ok; a++) {
+                        ocols[a] = H.vector((int8_t)outtype[a], groups);
+                        ok = rfx_hip_d2h(g_ctx, RFX_AS_RAW(ocols[a]), ptrs[a], (size_t)groups * 8) == RFX_OK;
+                    }
+                }
+                if (dout) rfx_hip_free(g_ctx, dout);
+                rfx_hip_free(g_ctx, store);
+                if (!ok) {
+                    if (okeys) H.drop(okeys);
+                    for (int a = 0; a < nagg; a++) if (ocols[a]) H.drop(ocols[a]);
+                    res = fail_hip("group-by");
+                    goto done;
+                }
+            }
+            if (!okeys) okeys = H.vector(RFX_TYPE_I64, 0);
+            obj_p rk = H.vector(RFX_TYPE_SYMBOL, nagg + 1), rv = H.vector(RFX_TYPE_LIST, nagg + 1);
+            RFX_AS_I64(rk)[0] = by->i64;
+            RFX_AS_LIST(rv)[0] = okeys;
+            for (int a = 0; a < nagg; a++) {
+                RFX_AS_I64(rk)[a + 1] = names[a];
+                RFX_AS_LIST(rv)[a + 1] = ocols[a] ? ocols[a] : H.vector((int8_t)outtype[a], 0);
+            }
+            res = H.table(rk, rv);
+            g_last_gpu = 1;
+            goto done;
+        }
+        if (nagg == 0) { why = "projection without aggregates"; goto out; }
+        rfx_value_t vals[RFX_MAX_AGGS];
+        int64_t selected = 0;
+        if (rfx_hip_filter_aggr_host(g_ctx, wp.preds, wp.npred, wp.logic, aggs, nagg, nrows, vals, &selected) != RFX_OK) { res = fail_hip("filter_aggr"); goto done; }
+        obj_p rk = H.vector(RFX_TYPE_SYMBOL, nagg), rv = H.vector(RFX_TYPE_LIST, nagg);
+        for (int a = 0; a < nagg; a++) {
+            RFX_AS_I64(rk)[a] = names[a];
+            RFX_AS_LIST(rv)[a] = one_row(&vals[a]);
+        }
+        res = H.table(rk, rv);
+        g_last_gpu = 1;
+        goto done;
+    }
+out:
+    res = delegate_select(dict, why ? why : "unsupported");
+done:
+    H.drop(tab);
+    return res;
+}
+
+/* ------------------------------------------------------------------------------------------------ single operators */
+static obj_p cmp_op(int op, obj_p x, obj_p y) {
+    rfx_host_bind();
+    if (!x || !y) return fail("cmp: null argument");
+    if (!(x->type > 0 && col_ctype(x) && (y->type == -RFX_TYPE_I64 || y->type == -RFX_TYPE_F64 || (y->type > 0 && col_ctype(y))))) {
+        if (H.bound == 1 && H.f[F_EQ + op]) return ((rfx_binary_f)H.f[F_EQ + op])(x, y);
+        return fail("cmp: only i64/f64 column (x) atom|column runs on the MI355X path");
+    }
+    if (y->type > 0 && y->len != x->len) return fail("length"); /* err_length, core/cmp.c:633-640 */
+    if (ensure_ctx() != RFX_OK) return fail_hip("no usable MI355X");
+    rfx_pred_t p;
+    memset(&p, 0, sizeof(p));
+    const void *d;
+    if (resident(x, 0, &d) != RFX_OK) return fail_hip("column upload");
+    p.d_col = d;
+    p.col_type = col_ctype(x);
+    p.op = op;
+    if (y->type == -RFX_TYPE_I64) { p.rhs_type = RFX_I64; p.rhs_i = y->i64; }
+    else if (y->type == -RFX_TYPE_F64) { p.rhs_type = RFX_F64; p.rhs_f = y->f64; }
+    else {
+        if (resident(y, 0, &d) != RFX_OK) return fail_hip("column upload");
+        p.d_rhs_col = d;
+        p.rhs_type = col_ctype(y);
+    }
+    void *dm = NULL;
+    if (rfx_hip_malloc(g_ctx, &dm, (size_t)x->len + 8) != RFX_OK) return fail_hip("mask");
+    obj_p out = H.vector(RFX_TYPE_B8, x->len);
+    int ok = rfx_hip_cmp_mask(g_ctx, &p, x->len, (int8_t *)dm) == RFX_OK && rfx_hip_d2h(g_ctx, RFX_AS_RAW(out), dm, (size_t)x->len) == RFX_OK;
+    rfx_hip_free(g_ctx, dm);
+    if (!ok) { H.drop(out); return fail_hip("cmp_mask"); }
+    return out;
+}
+rfx_obj_p rfx_eq(rfx_obj_p x, rfx_obj_p y) { return cmp_op(RFX_EQ, x, y); }
+rfx_obj_p rfx_ne(rfx_obj_p x, rfx_obj_p y) { return cmp_op(RFX_NE, x, y); }
+rfx_obj_p rfx_lt(rfx_obj_p x, rfx_obj_p y) { return cmp_op(RFX_LT, x, y); }
+rfx_obj_p rfx_gt(rfx_obj_p x, rfx_obj_p y) { return cmp_op(RFX_GT, x, y); }
+rfx_obj_p rfx_le(rfx_obj_p x, rfx_obj_p y) { return cmp_op(RFX_LE, x, y); }
+rfx_obj_p rfx_ge(rfx_obj_p x, rfx_obj_p y) { return cmp_op(RFX_GE, x, y); }
+
+static obj_p logic_op(int logic, obj_p *x, int64_t n) {
+    rfx_host_bind();
+    if (n == 0) return rfx_host_b8(0); /* logic_map: (and) -> false, core/logic.c:96-97 */
+    for (int64_t i = 0; i < n; i++)
+        if (!x[i] || x[i]->type != RFX_TYPE_B8 || x[i]->len != x[0]->len) return fail("and/or: expected B8 masks of one length");
+    if (ensure_ctx() != RFX_OK) return fail_hip("no usable MI355X");
+    int64_t len = x[0]->len;
+    void *acc = NULL, *nxt = NULL;
+    if (rfx_hip_malloc(g_ctx, &acc, (size_t)len + 8) != RFX_OK || rfx_hip_malloc(g_ctx, &nxt, (size_t)len + 8) != RFX_OK) return fail_hip("mask");
+    int ok = rfx_hip_h2d(g_ctx, acc, RFX_AS_RAW(x[0]), (size_t)len) == RFX_OK;
+    for (int64_t i = 1; i < n && ok; i++)
+        ok = rfx_hip_h2d(g_ctx, nxt, RFX_AS_RAW(x[i]), (size_t)len) == RFX_OK && rfx_hip_mask_logic(g_ctx, logic, (int8_t *)acc, (const int8_t *)nxt, 0, len) == RFX_OK;
+    obj_p out = H.vector(RFX_TYPE_B8, len);
+    ok = ok && rfx_hip_d2h(g_ctx, RFX_AS_RAW(out), acc, (size_t)len) == RFX_OK;
+    rfx_hip_free(g_ctx, acc);
+    rfx_hip_free(g_ctx, nxt);
+    if (!ok) { H.drop(out); return fail_hip("mask_logic"); }
+    return out;
+}
+rfx_obj_p rfx_and(rfx_obj_p *x, int64_t n) { return logic_op(RFX_AND, x, n); }
+rfx_obj_p rfx_or(rfx_obj_p *x, int64_t n) { return logic_op(RFX_OR, x, n); }
+
+rfx_obj_p rfx_where(rfx_obj_p mask) {
+    rfx_host_bind();
+    if (!mask || mask->type != RFX_TYPE_B8) return fail("where: expected a B8 mask"); /* err_type, core/items.c:1395 */
+    if (ensure_ctx() != RFX_OK) return fail_hip("no usable MI355X");
+    const void *dm;
+    if (resident(mask, 0, &dm) != RFX_OK) return fail_hip("mask upload");
+    int64_t count = 0;
+    if (rfx_hip_where_begin(g_ctx, NULL, 0, RFX_AND, (const int8_t *)dm, mask->len, &count) != RFX_OK) return fail_hip("where");
+    obj_p out = H.vector(RFX_TYPE_I64, count);
+    void *di = NULL;
+    int ok = 1;
+    if (count > 0) {
+        ok = rfx_hip_malloc(g_ctx, &di, (size_t)count * 8) == RFX_OK && rfx_hip_where_emit(g_ctx, 0, (int64_t *)di) == RFX_OK &&
+             rfx_hip_d2h(g_ctx, RFX_AS_RAW(out), di, (size_t)count * 8) == RFX_OK;
+        if (di) rfx_hip_free(g_ctx, di);
+    }
+    if (!ok) { H.drop(out); return fail_hip("where"); }
+    return out;
+}
+
+rfx_obj_p rfx_at(rfx_obj_p col, rfx_obj_p ids) {
+    rfx_host_bind();
+    if (!col || !ids || !col_ctype(col) || ids->type != RFX_TYPE_I64) return fail("at: expected (i64|f64 column, I64 ids)");
+    if (ensure_ctx() != RFX_OK) return fail_hip("no usable MI355X");
+    const void *dc, *di;
+    if (resident(col, 0, &dc) != RFX_OK || resident(ids, 0, &di) != RFX_OK) return fail_hip("upload");
+    obj_p out = H.vector(col->type, ids->len);
+    void *dout = NULL;
+    int ok = rfx_hip_malloc(g_ctx, &dout, (size_t)ids->len * 8 + 8) == RFX_OK && rfx_hip_gather(g_ctx, dc, (const int64_t *)di, ids->len, dout) == RFX_OK &&
+             rfx_hip_d2h(g_ctx, RFX_AS_RAW(out), dout, (size_t)ids->len * 8) == RFX_OK;
+    if (dout) rfx_hip_free(g_ctx, dout);
+    if (!ok) { H.drop(out); return fail_hip("gather"); }
+    return out;
+}
+
+/* scalar aggregates of a vector or of a lazy MAPFILTER (val, ids) pair (core/filter.c:29-49, core/math.c:1874-1890) */
+static obj_p fold_op(int f, int kind, obj_p x) {
+    rfx_host_bind();
+    if (!x) return fail("aggregate: null argument");
+    if (x->type == RFX_TYPE_MAPFILTER) {
+        obj_p g = rfx_at(RFX_AS_LIST(x)[0], RFX_AS_LIST(x)[1]);
+        if (g->type == RFX_TYPE_ERR) return g;
+        obj_p r = fold_op(f, kind, g);
+        H.drop(g);
+        return r;
+    }
+    if (!(x->type > 0 && col_ctype(x) && x->type != RFX_TYPE_SYMBOL)) {
+        if (H.bound == 1 && H.f[f]) return ((rfx_unary_f)H.f[f])(x);
+        return fail("aggregate: only i64/f64 vectors run on the MI355X path");
+    }
+    if (ensure_ctx() != RFX_OK) return fail_hip("no usable MI355X");
+    const void *d;
+    if (resident(x, 0, &d) != RFX_OK) return fail_hip("column upload");
+    rfx_agg_t a = {d, col_ctype(x), kind};
+    rfx_value_t v;
+    if (rfx_hip_filter_aggr_host(g_ctx, NULL, 0, RFX_AND, &a, 1, x->len, &v, NULL) != RFX_OK) return fail_hip("filter_aggr");
+    return value_atom(&v);
+}
+rfx_obj_p rfx_sum(rfx_obj_p x) { return fold_op(F_SUM, RFX_AGG_SUM, x); }
+rfx_obj_p rfx_avg(rfx_obj_p x) { return fold_op(F_AVG, RFX_AGG_AVG, x); }
+rfx_obj_p rfx_min(rfx_obj_p x) { return fold_op(F_MIN, RFX_AGG_MIN, x); }
+rfx_obj_p rfx_max(rfx_obj_p x) { return fold_op(F_MAX, RFX_AGG_MAX, x); }
+rfx_obj_p rfx_count(rfx_obj_p x) { return fold_op(F_COUNT, RFX_AGG_COUNT, x); }
+rfx_obj_p rfx_first(rfx_obj_p x) { return fold_op(F_FIRST, RFX_AGG_FIRST, x); }
+
+/* ------------------------------------------------------------------------------------------------ residency verbs */
+static obj_p pin_op(obj_p x, int pin) {
+    rfx_host_bind();
+    if (!x) return fail("pin: null argument");
+    if (ensure_ctx() != RFX_OK) return fail_hip("no usable MI355X");
+    obj_p cols = (x->type == RFX_TYPE_TABLE) ? RFX_AS_LIST(x)[1] : NULL;
+    int64_t n = cols ? cols->len : 1;
+    for (int64_t i = 0; i < n; i++) {
+        obj_p c = cols ? RFX_AS_LIST(cols)[i] : x;
+        if (!(c->type > 0 && (col_ctype(c) || c->type == RFX_TYPE_B8))) continue;
+        if (pin) {
+            const void *d;
+            if (resident(c, 1, &d) != RFX_OK) return fail_hip("pin");
+        } else {
+            for (int j = 0; j < g_nres; j++)
+                if (g_res[j].host == RFX_AS_RAW(c)) { res_free(j); break; }
+        }
+    }
+    return H.clone(x);
+}
+rfx_obj_p rfx_pin(rfx_obj_p x) { return pin_op(x, 1); }
+rfx_obj_p rfx_unpin(rfx_obj_p x) { return pin_op(x, 0); }

@@ -1,0 +1,132 @@
+"""Operator-level C ABI (include/rfx_ops.h) driven through obj_p arguments laid out like RayforceDB objects, by the
+standalone host object model (no reference process).  Checker: the CPU oracle."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oracle import rfo
+from rayforce_amd import hostobj as H
+
+pytestmark = pytest.mark.gpu
+NULL = -(2**63)
+
+
+@pytest.fixture(scope="module")
+def ops(built):
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    l = H.lib()
+    assert l.rfx_host_bind() == 0  # standalone host inside the python process
+    yield l
+    l.rfx_cache_clear()
+
+
+def host_table(n, keys=1000, seed=0):
+    return {"k": rfo.gen_i64(n, 4 + seed, keys), "a": rfo.gen_i64(n, 2 + seed, 1_000_000), "v": rfo.gen_f64(n, 5 + seed)}
+
+
+def run_select(ops, host, query):
+    tab = H.table(host)
+    d = H.select_dict(query, tab)
+    r = ops.rfx_select(d)
+    assert r, "null result"
+    if H.is_error(r):
+        msg = H.error_text(r)
+        ops.rfx_host_drop(r)
+        ops.rfx_host_drop(d)
+        ops.rfx_host_drop(tab)
+        raise RuntimeError(msg)
+    out = H.table_to_numpy(r)
+    for o in (r, d, tab):
+        ops.rfx_host_drop(o)
+    return out
+
+
+def check(got, want):
+    assert list(got) == list(want)
+    for name in want:
+        g, w = got[name], want[name]
+        assert g.dtype == w.dtype, name
+        if w.dtype == np.float64:
+            assert np.array_equal(np.isnan(g), np.isnan(w))
+            ok = ~np.isnan(w)
+            assert np.allclose(g[ok], w[ok], rtol=1e-9, atol=0), name
+        else:
+            assert np.array_equal(g, w), name
+
+
+@pytest.mark.parametrize("n", [1000, 300_007])
+def test_select_where_aggregates(ops, n):
+    host = host_table(n)
+    q = {"s": ("sum", "a"), "f": ("sum", "v"), "c": ("count", "v"), "m": ("max", "a"), "x": ("avg", "v")}
+    got = run_select(ops, host, {**q, "where": ("<", "a", 100_000)})
+    assert ops.rfx_last_select_on_gpu() == 1
+    check(got, rfo.select({"from": host, **q, "where": ("<", "a", 100_000)}))
+    w3 = ("and", ("<", "a", 500_000), (">", "v", 0.25), ("!=", "k", 7))
+    check(run_select(ops, host, {**q, "where": w3}), rfo.select({"from": host, **q, "where": w3}))
+
+
+@pytest.mark.parametrize("keys", [10, 1000, 250_000])
+def test_select_by(ops, keys):
+    host = host_table(400_003, keys=keys)
+    q = {"s": ("sum", "v"), "c": ("count", "a"), "mn": ("min", "a"), "av": ("avg", "v")}
+    check(run_select(ops, host, {**q, "by": "k"}), rfo.select({"from": host, **q, "by": "k"}))
+    check(run_select(ops, host, {**q, "by": "k", "where": (">", "v", 0.5)}), rfo.select({"from": host, **q, "by": "k", "where": (">", "v", 0.5)}))
+
+
+def test_select_by_sparse_keys(ops):
+    host = host_table(50_000, keys=500)
+    host["k"] = host["k"] * 999_983 + 5
+    q = {"s": ("sum", "v"), "c": ("count", "a")}
+    check(run_select(ops, host, {**q, "by": "k"}), rfo.select({"from": host, **q, "by": "k"}))
+
+
+def test_unsupported_shape_fails_loudly_without_host(ops):
+    host = host_table(100)
+    with pytest.raises(RuntimeError, match="not covered by the MI355X path"):
+        run_select(ops, host, {"where": ("<", "a", 10)})  # projection without aggregates: the reference host would take it
+    assert ops.rfx_last_select_on_gpu() == 0
+
+
+def test_missing_from(ops):
+    d = ops.rfx_host_dict(H.symbols(["s"]), H.list_of([H.expr(("sum", "v"))]))
+    r = ops.rfx_select(d)
+    assert H.is_error(r) and "from" in H.error_text(r)
+    ops.rfx_host_drop(r)
+    ops.rfx_host_drop(d)
+
+
+def test_single_operators(ops):
+    n = 100_003
+    host = host_table(n)
+    a, v = H.vector(host["a"]), H.vector(host["v"])
+    m1 = ops.rfx_lt(a, H.atom(500_000))
+    m2 = ops.rfx_gt(v, H.atom(0.25))
+    assert np.array_equal(H.to_numpy(m1), rfo.cmp("<", host["a"], 500_000))
+    both = ops.rfx_and((C.c_void_p * 2)(m1, m2), 2)
+    want = rfo.and_(rfo.cmp("<", host["a"], 500_000), rfo.cmp(">", host["v"], 0.25))
+    assert np.array_equal(H.to_numpy(both), want)
+    ids = ops.rfx_where(both)
+    assert np.array_equal(H.to_numpy(ids), rfo.where(want))
+    g = ops.rfx_at(v, ids)
+    assert np.array_equal(H.to_numpy(g), host["v"][rfo.where(want)])
+    s = ops.rfx_sum(a)
+    assert H.header(s).type == -H.T_I64 and C.c_int64.from_address(s + 8).value == int(host["a"].sum())
+    mx = ops.rfx_max(v)
+    assert H.header(mx).type == -H.T_F64 and C.c_double.from_address(mx + 8).value == host["v"].max()
+    for o in (a, v, m1, m2, both, ids, g, s, mx):
+        ops.rfx_host_drop(o)
+
+
+def test_residency_cache(ops):
+    ops.rfx_cache_clear()
+    host = host_table(200_000)
+    tab = H.table(host)
+    p = ops.rfx_pin(tab)
+    assert ops.rfx_cache_bytes() == 3 * 200_000 * 8
+    u = ops.rfx_unpin(tab)
+    assert ops.rfx_cache_bytes() == 0
+    for o in (p, u, tab):
+        ops.rfx_host_drop(o)
