@@ -1,0 +1,183 @@
+#!/usr/bin/env python
+"""Capture golden vectors from the REAL reference (oracle/_ref/rayforce, compiled from /root/reference by
+`make -C oracle ref`).  Run in the build container only:
+
+    python tests/golden/make_golden.py            # rewrites tests/golden/ref_golden.npz + ref_golden.json
+
+Inputs are described by (generator, seed, size) or stored explicitly (the null / NaN / -0.0 special vectors), outputs are
+what the reference answered.  The fixture is DATA (inputs + expected outputs); no reference source text is stored.
+Queries go through the reference's own Rayfall surface (select / where / and / or / sum ... ), i.e. through exactly the
+functions SURVEY 8a lists.  Pool size is pinned (-c 8) except where noted: the reference crashes with large pools on
+small inputs, and its sparse-key group ORDER is only defined single-threaded (-c 1).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle import ref, rfo  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+NULL = -(2**63)
+OPS = ["==", "!=", "<", ">", "<=", ">="]
+
+
+def gen_table(n, seed, keys, nulls):
+    t = {"k": rfo.gen_i64(n, 4 + seed, keys), "a": rfo.gen_i64(n, 2 + seed, 1_000_000), "v": rfo.gen_f64(n, 5 + seed),
+         "w": rfo.gen_f64(n, 6 + seed) - 0.5}
+    if nulls and n:
+        r = rfo.gen_i64(n, 99 + seed, 100)
+        t["a"][r == 0] = NULL
+        t["v"][r == 1] = np.nan
+        t["w"][r == 2] = np.nan
+    return t
+
+
+def rf_where(w):
+    """python predicate tuple -> Rayfall text"""
+    if w[0] in ("and", "or"):
+        return "(" + w[0] + " " + " ".join(rf_where(x) for x in w[1:]) + ")"
+    op, l, r = w
+    if isinstance(r, float):
+        r = repr(r)
+    return f"({op} {l} {r})"
+
+
+def main():
+    assert ref.build(), "reference not buildable here"
+    arrays, cases = {}, []
+
+    # ---- 1. comparison truth tables on special values (mirrors the intent of tests/lang.c:3378-3605) ----
+    si = np.array([0, 1, -1, NULL, 2**63 - 1, 5, -5, NULL], np.int64)
+    sf = np.array([0.0, -0.0, np.nan, 1.5, -1.5, np.inf, -np.inf, np.nan], np.float64)
+    arrays["special_i64"], arrays["special_f64"] = si, sf
+    with ref.Session() as s:
+        s.put("si", si)
+        s.put("sf", sf)
+        names = []
+        for oi, op in enumerate(OPS):
+            for tag, expr in [("ii", f"({op} si 1)"), ("in", f"({op} si 0Nl)"), ("if", f"({op} si 0.5)"), ("ff", f"({op} sf 0.0)"),
+                              ("fn", f"({op} sf 0Nf)"), ("fi", f"({op} sf 1)"), ("vv_ii", f"({op} si (reverse si))"),
+                              ("vv_ff", f"({op} sf (reverse sf))"), ("vv_if", f"({op} si sf)"), ("vv_fi", f"({op} sf si)")]:
+                nm = f"cmp_{oi}_{tag}"
+                s.out(nm, f"(as 'I64 {expr})")
+                names.append(nm)
+        r = s.run(threads=8)
+    for nm in names:
+        arrays[nm] = r[nm].astype(np.int8)
+    cases.append({"kind": "cmp_special", "ops": OPS, "tags": ["ii", "in", "if", "ff", "fn", "fi", "vv_ii", "vv_ff", "vv_if", "vv_fi"]})
+
+    # ---- 2. scalar aggregates, where ids, masks on seeded tables ----
+    # n = 32 769 and 70 003 are chosen so that index_scope_i64's unguarded page-aligned chunking (core/index.c:412-420 with
+    # core/pool.c:495-507) does not overshoot the column with 8 executors: at e.g. 25 001 rows the reference reads out of bounds,
+    # gets a garbage key range and silently takes its sparse path (DESIGN.md "reference defects").
+    specs = [dict(n=0, seed=0, keys=10, nulls=False), dict(n=1, seed=1, keys=10, nulls=False), dict(n=1000, seed=2, keys=50, nulls=True),
+             dict(n=32_769, seed=3, keys=1000, nulls=True), dict(n=70_003, seed=4, keys=20_000, nulls=False)]
+    wheres = [None, ("<", "a", 100000), ("and", ("<", "a", 500000), (">", "v", 0.25), ("!=", "k", 7)), ("or", ("<", "a", 1000), (">", "w", 0.45)),
+              ("<", "a", -5)]
+    for ti, sp in enumerate(specs):
+        t = gen_table(**sp)
+        if sp["n"] == 0:
+            continue  # the reference cannot read empty column files; empty inputs are covered by the empty-selection cases
+        for wi, w in enumerate(wheres):
+            with ref.Session() as s:
+                s.table("t", t)
+                wtxt = f" where: {rf_where(w)}" if w else ""
+                s.eval(f"(set r (select {{si: (sum a) sf: (sum v) mni: (min a) mxi: (max a) mnf: (min w) mxf: (max w) avf: (avg v) avi: (avg a) "
+                       f"c: (count a) from: t{wtxt}}}))")
+                outs = ["si", "sf", "mni", "mxi", "mnf", "mxf", "avf", "avi", "c"]
+                for o in outs:
+                    s.out(o, f"(at r '{o})")
+                if w:
+                    s.out("ids", f"(where {rf_where(w)})".replace(" a ", " (at t 'a) ").replace(" v ", " (at t 'v) ").replace(" w ", " (at t 'w) ")
+                          .replace(" k ", " (at t 'k) "))
+                r = s.run(threads=8)
+            for o in outs + (["ids"] if w else []):
+                arrays[f"scalar_{ti}_{wi}_{o}"] = r[o]
+        cases.append({"kind": "scalar", "table": sp, "index": ti, "wheres": [list(map(_j, [w])) [0] for w in wheres]})
+
+    # ---- 3. dense group-by (first-occurrence order) ----
+    gwheres = [None, ("and", ("<", "a", 700000), (">", "v", 0.1))]
+    for ti, sp in enumerate(specs):
+        if sp["n"] == 0:
+            continue
+        t = gen_table(**sp)
+        for wi, w in enumerate(gwheres):
+            with ref.Session() as s:
+                s.table("t", t)
+                wtxt = f" where: {rf_where(w)}" if w else ""
+                s.eval(f"(set r (select {{sf: (sum v) si: (sum a) c: (count v) mni: (min a) mxf: (max w) avf: (avg v) avi: (avg a) fi: (first a) "
+                       f"from: t{wtxt} by: k}}))")
+                outs = ["k", "sf", "si", "c", "mni", "mxf", "avf", "avi", "fi"]
+                for o in outs:
+                    s.out(o, f"(at r '{o})")
+                r = s.run(threads=8)
+            for o in outs:
+                arrays[f"group_{ti}_{wi}_{o}"] = r[o]
+        cases.append({"kind": "group", "table": sp, "index": ti, "wheres": [_j(w) for w in gwheres]})
+
+    # ---- 4. sparse keys (range > rows): single-threaded reference => first-occurrence order is defined ----
+    t = gen_table(20_011, 9, 400, True)
+    t["k"] = t["k"] * 1_000_003 - 77
+    with ref.Session() as s:
+        s.table("t", t)
+        s.eval("(set r (select {sf: (sum v) c: (count a) mxi: (max a) from: t by: k}))")
+        for o in ["k", "sf", "c", "mxi"]:
+            s.out(o, f"(at r '{o})")
+        r = s.run(threads=1)
+    for o in ["k", "sf", "c", "mxi"]:
+        arrays[f"sparse_{o}"] = r[o]
+    cases.append({"kind": "sparse", "table": dict(n=20_011, seed=9, keys=400, nulls=True), "mul": 1_000_003, "add": -77})
+
+    # ---- 5. null-semantics known answers (verified against the reference here) ----
+    k = np.array([1, 1, 2, 3, 3], np.int64)
+    v = np.array([1, NULL, 5, NULL, NULL], np.int64)
+    f = np.array([1.0, np.nan, 5.0, np.nan, np.nan])
+    arrays.update(nullsem_k=k, nullsem_v=v, nullsem_f=f)
+    with ref.Session() as s:
+        s.table("t", {"k": k, "v": v, "f": f})
+        s.eval("(set r (select {s: (sum v) fs: (sum f) mn: (min v) mx: (max v) fmn: (min f) fmx: (max f) c: (count v) av: (avg v) from: t by: k}))")
+        for o in ["k", "s", "fs", "mn", "mx", "fmn", "fmx", "c", "av"]:
+            s.out(o, f"(at r '{o})")
+        s.out("scalar_sum", "(enlist (sum v))")
+        r = s.run(threads=8)
+    for o in ["k", "s", "fs", "mn", "mx", "fmn", "fmx", "c", "av", "scalar_sum"]:
+        arrays[f"nullsem_out_{o}"] = r[o]
+    cases.append({"kind": "nullsem"})
+
+    # ---- 6. hash primitives, straight from the compiled reference library ----
+    lib = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "librayforce_ref.so"))
+    lib.hash_fnv1a.restype = C.c_uint64
+    lib.hash_fnv1a.argtypes = [C.c_int64, C.c_void_p]
+    hk = np.concatenate([np.array([0, 1, -1, NULL, 2**63 - 1, 42], np.int64), rfo.gen_i64(250, 11, 2**62) - 2**61])
+    arrays["hash_keys"] = hk
+    arrays["hash_fnv1a"] = np.array([lib.hash_fnv1a(int(x), None) for x in hk], np.uint64)
+    try:
+        lib.hash_index_u64.restype = C.c_uint64
+        lib.hash_index_u64.argtypes = [C.c_uint64, C.c_uint64]
+        arrays["hash_index_u64"] = np.array([lib.hash_index_u64(0x9ddfea08eb382d69, int(x) & (2**64 - 1)) for x in hk], np.uint64)
+    except AttributeError:
+        pass  # `inline` in core/hash.h: not emitted as a symbol by this build
+    cases.append({"kind": "hash"})
+
+    np.savez_compressed(os.path.join(HERE, "ref_golden.npz"), **arrays)
+    with open(os.path.join(HERE, "ref_golden.json"), "w") as fjs:
+        json.dump({"generator": "tests/golden/make_golden.py", "reference": "RayforceDB/rayforce @ /root/reference (2026-01-09), oracle/_ref build",
+                   "cases": cases}, fjs, indent=1)
+    print(f"wrote {len(arrays)} arrays, {sum(a.nbytes for a in arrays.values())} bytes raw")
+
+
+def _j(w):
+    if w is None:
+        return None
+    return [_j(x) if isinstance(x, tuple) else x for x in w]
+
+
+if __name__ == "__main__":
+    main()

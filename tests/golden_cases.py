@@ -1,0 +1,103 @@
+"""Iterate the golden fixture captured from the compiled reference (tests/golden/make_golden.py): each case yields the
+inputs (regenerated from seeds, or stored explicitly) and the reference's answers."""
+import json
+import os
+
+import numpy as np
+
+from oracle import rfo
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+NULL = -(2**63)
+_npz = np.load(os.path.join(HERE, "golden", "ref_golden.npz"))
+_meta = json.load(open(os.path.join(HERE, "golden", "ref_golden.json")))
+OPS = ["==", "!=", "<", ">", "<=", ">="]
+
+
+def arr(name):
+    return _npz[name]
+
+
+def has(name):
+    return name in _npz.files
+
+
+def gen_table(n, seed, keys, nulls):
+    t = {"k": rfo.gen_i64(n, 4 + seed, keys), "a": rfo.gen_i64(n, 2 + seed, 1_000_000), "v": rfo.gen_f64(n, 5 + seed),
+         "w": rfo.gen_f64(n, 6 + seed) - 0.5}
+    if nulls and n:
+        r = rfo.gen_i64(n, 99 + seed, 100)
+        t["a"][r == 0] = NULL
+        t["v"][r == 1] = np.nan
+        t["w"][r == 2] = np.nan
+    return t
+
+
+def _tup(w):
+    if w is None:
+        return None
+    return tuple(_tup(x) if isinstance(x, list) else x for x in w)
+
+
+def cmp_special_cases():
+    si, sf = arr("special_i64"), arr("special_f64")
+    rhs = {"ii": (si, 1), "in": (si, None), "if": (si, 0.5), "ff": (sf, 0.0), "fn": (sf, float("nan")), "fi": (sf, 1),
+           "vv_ii": (si, si[::-1].copy()), "vv_ff": (sf, sf[::-1].copy()), "vv_if": (si, sf), "vv_fi": (sf, si)}
+    for oi, op in enumerate(OPS):
+        for tag, (l, r) in rhs.items():
+            yield op, tag, l, r, arr(f"cmp_{oi}_{tag}")
+
+
+SCALAR_Q = {"si": ("sum", "a"), "sf": ("sum", "v"), "mni": ("min", "a"), "mxi": ("max", "a"), "mnf": ("min", "w"), "mxf": ("max", "w"),
+            "avf": ("avg", "v"), "avi": ("avg", "a"), "c": ("count", "a")}
+GROUP_Q = {"sf": ("sum", "v"), "si": ("sum", "a"), "c": ("count", "v"), "mni": ("min", "a"), "mxf": ("max", "w"), "avf": ("avg", "v"),
+           "avi": ("avg", "a"), "fi": ("first", "a")}
+
+
+def scalar_cases():
+    for c in _meta["cases"]:
+        if c["kind"] != "scalar":
+            continue
+        t = gen_table(**c["table"])
+        for wi, w in enumerate(c["wheres"]):
+            want = {o: arr(f"scalar_{c['index']}_{wi}_{o}") for o in SCALAR_Q}
+            ids = arr(f"scalar_{c['index']}_{wi}_ids") if has(f"scalar_{c['index']}_{wi}_ids") else None
+            yield f"t{c['index']}w{wi}", t, _tup(w), want, ids
+
+
+def group_cases():
+    for c in _meta["cases"]:
+        if c["kind"] != "group":
+            continue
+        t = gen_table(**c["table"])
+        for wi, w in enumerate(c["wheres"]):
+            want = {o: arr(f"group_{c['index']}_{wi}_{o}") for o in ["k"] + list(GROUP_Q)}
+            yield f"t{c['index']}w{wi}", t, _tup(w), want
+
+
+def sparse_case():
+    c = [c for c in _meta["cases"] if c["kind"] == "sparse"][0]
+    t = gen_table(**c["table"])
+    t["k"] = t["k"] * c["mul"] + c["add"]
+    return t, {o: arr(f"sparse_{o}") for o in ["k", "sf", "c", "mxi"]}
+
+
+def nullsem_case():
+    t = {"k": arr("nullsem_k"), "v": arr("nullsem_v"), "f": arr("nullsem_f")}
+    want = {o: arr(f"nullsem_out_{o}") for o in ["k", "s", "fs", "mn", "mx", "fmn", "fmx", "c", "av"]}
+    return t, want, int(arr("nullsem_out_scalar_sum")[0])
+
+
+def same(got, want, name=""):
+    got, want = np.asarray(got), np.asarray(want)
+    assert got.shape == want.shape, (name, got.shape, want.shape)
+    if want.dtype == np.float64:
+        got = got.astype(np.float64)
+        assert np.array_equal(np.isnan(got), np.isnan(want)), name
+        ok = ~np.isnan(want)
+        inf = np.isinf(want[ok])
+        assert np.array_equal(got[ok][inf], want[ok][inf]), name
+        g, w = got[ok][~inf], want[ok][~inf]
+        assert np.all(np.abs(g - w) <= 1e-9 * np.maximum(np.abs(w), 1e-300)), name
+    else:
+        assert np.array_equal(got.astype(want.dtype), want), name

@@ -1,0 +1,111 @@
+"""Pin the CPU oracle (oracle/rfo_core.c) against the golden vectors captured from the compiled reference and against
+known answers of the reference's own test-suite.  Runs without a GPU."""
+import numpy as np
+import pytest
+
+import golden_cases as G
+from oracle import rfo
+
+NULL = -(2**63)
+
+
+@pytest.fixture(autouse=True, scope="module")
+def threads():
+    rfo.set_threads(8)  # the pool size the goldens were captured with (chunking fixes the f64 summation order)
+
+
+def test_cmp_truth_tables_on_special_values():
+    n = 0
+    for op, tag, l, r, want in G.cmp_special_cases():
+        got = rfo.cmp(op, l, r)
+        assert np.array_equal(got, want), (op, tag)
+        n += 1
+    assert n == 60
+
+
+def test_scalar_aggregates_and_where_ids():
+    seen = 0
+    for name, t, w, want, ids in G.scalar_cases():
+        q = {"from": t, **G.SCALAR_Q}
+        if w is not None:
+            q["where"] = w
+        got = rfo.select(q)
+        for o in want:
+            G.same(got[o], want[o], f"{name}.{o}")
+        if ids is not None:
+            assert np.array_equal(rfo.where(rfo.mask_of(w, t)), ids), name
+        seen += 1
+    assert seen >= 20
+
+
+def test_group_by_dense_first_occurrence_order():
+    seen = 0
+    for name, t, w, want in G.group_cases():
+        q = {"from": t, "by": "k", **G.GROUP_Q}
+        if w is not None:
+            q["where"] = w
+        got = rfo.select(q)
+        assert np.array_equal(got["k"], want["k"]), f"{name}: group keys / order"
+        for o in G.GROUP_Q:
+            G.same(got[o], want[o], f"{name}.{o}")
+        seen += 1
+    assert seen >= 8
+
+
+def test_group_by_sparse_keys():
+    t, want = G.sparse_case()
+    rfo.set_threads(1)
+    got = rfo.select({"from": t, "by": "k", "sf": ("sum", "v"), "c": ("count", "a"), "mxi": ("max", "a")})
+    rfo.set_threads(8)
+    for o in want:
+        G.same(got[o], want[o], o)
+
+
+def test_null_semantics():
+    t, want, scalar_sum = G.nullsem_case()
+    got = rfo.select({"from": t, "by": "k", "s": ("sum", "v"), "fs": ("sum", "f"), "mn": ("min", "v"), "mx": ("max", "v"), "fmn": ("min", "f"),
+                      "fmx": ("max", "f"), "c": ("count", "v"), "av": ("avg", "v")})
+    for o in want:
+        G.same(got[o], want[o], o)
+    assert got["s"].tolist() == [NULL, 5, NULL] and got["mn"].tolist() == [1, 5, 2**63 - 1] and got["mx"].tolist() == [1, 5, NULL]
+    assert rfo.fold("sum", t["v"]) == scalar_sum == 6
+
+
+def test_hash_primitives():
+    keys = G.arr("hash_keys")
+    assert np.array_equal(np.array([rfo.lib().rfo_hash_fnv1a(int(k)) for k in keys], np.uint64), G.arr("hash_fnv1a"))
+    if G.has("hash_index_u64"):
+        got = np.array([rfo.lib().rfo_hash_index_u64(0x9ddfea08eb382d69, int(k) & (2**64 - 1)) for k in keys], np.uint64)
+        assert np.array_equal(got, G.arr("hash_index_u64"))
+
+
+# ---- known answers transcribed (as data) from the reference's own tests ----
+def test_reference_known_answers():
+    # tests/lang.c:2457-2543, 4067-4099: scalar aggregates with nulls
+    assert rfo.fold("sum", np.array([1, NULL, 5], np.int64)) == 6
+    assert rfo.fold("sum", np.array([], np.int64)) == 0
+    assert rfo.fold("min", np.array([], np.int64)) is None and rfo.fold("max", np.array([NULL, NULL], np.int64)) is None
+    assert rfo.fold("min", np.array([3, NULL, 1], np.int64)) == 1 and rfo.fold("max", np.array([3, NULL, 1], np.int64)) == 3
+    assert rfo.fold("avg", np.array([1, NULL, 5], np.int64)) == 3.0
+    assert np.isnan(rfo.fold("avg", np.array([], np.float64)))
+    assert rfo.fold("sum", np.array([1.5, np.nan, 2.5])) == 4.0
+    # SURVEY 0.7 (oracle-verified): (< [1 0Nl 3] 2) -> [true true false]
+    assert rfo.cmp("<", np.array([1, NULL, 3], np.int64), 2).tolist() == [1, 1, 0]
+    # tests/lang.c:2893-2897: where + and across the 16 384-row parallel threshold
+    a = np.arange(25_001, dtype=np.int64)
+    ids = rfo.where(rfo.and_(rfo.cmp(">=", a, 5), rfo.cmp("<", a, 20_000)))
+    assert np.array_equal(ids, np.arange(5, 20_000))
+    # keys [3 1 3 2 1 3] -> groups 3, 1, 2
+    got = rfo.select({"from": {"k": np.array([3, 1, 3, 2, 1, 3], np.int64), "v": np.arange(6.0)}, "by": "k", "s": ("sum", "v")})
+    assert got["k"].tolist() == [3, 1, 2] and got["s"].tolist() == [7.0, 5.0, 3.0]
+    # tests/lang.c:2885-2887: select ... by with an empty filter result -> 0 rows
+    got = rfo.select({"from": {"k": np.array([1, 2], np.int64), "v": np.array([1.0, 2.0])}, "where": ("<", "k", 0), "by": "k", "s": ("sum", "v")})
+    assert len(got["k"]) == 0 and len(got["s"]) == 0
+
+
+def test_pool_chunking_policy():
+    # core/pool.c:450-507
+    L = rfo.lib()
+    assert L.rfo_pool_split_by_mem(16383, 0, 8) == 1 and L.rfo_pool_split_by_mem(16384, 0, 8) == 8
+    assert L.rfo_pool_split_by_mem(10**7, 10**6, 8) == 8 and L.rfo_pool_split_by_mem(10**7, 10**7, 8) == 1  # 64 MB budget
+    assert L.rfo_pool_chunk_aligned(25001, 8, 8) == 3584 and L.rfo_pool_chunk_aligned(100, 1, 8) == 100
