@@ -40,13 +40,13 @@ def log(*a):
 
 WORKLOADS = {
     "c2": dict(desc="configs[1]: select sum(a) where a < 100000, a i64 uniform [0,1e6), seed 2", rows=1_000_000_000, bytes_per_row=8, dtype="int64",
-               kernel="k_filter_aggr<1,1,4>"),
+               kernel="k_filter_aggr<1,1,8,1>"),
     "c2b": dict(desc="north-star: select sum(b) where a < 100000, a i64 seed 2, b f64 seed 3", rows=1_000_000_000, bytes_per_row=16, dtype="f64",
-                kernel="k_filter_aggr<2,1,4>"),
+                kernel="k_filter_aggr<2,1,4,1>"),
     "c3": dict(desc="configs[2]: select sum(v) by k, k i64 uniform [0,1e6) seed 4, v f64 seed 5", rows=1_000_000_000, bytes_per_row=16, dtype="f64",
-               kernel="k_part_scatter+k_part_aggregate"),
+               kernel="k_part_hist+k_part_scatter+k_part_aggregate"),
     "c5": dict(desc="configs[4] per-GPU shard: avg,min,max(d) where a<0.316228 and b>0.683772 and c!=0.25, 4 x f64 seeds 6-9", rows=250_000_000,
-               bytes_per_row=32, dtype="f64", kernel="k_filter_aggr<4,4,2>"),
+               bytes_per_row=32, dtype="f64", kernel="k_filter_aggr<4,4,2,4>"),
 }
 
 

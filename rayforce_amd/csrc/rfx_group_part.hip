@@ -333,8 +333,41 @@ __global__ __launch_bounds__(PART_AGG_THREADS) void k_part_aggregate(const Plan 
 }
 
 template <int NC>
+static void launch_hist(rfx_ctx *c, const Plan &Ph, const PartArgs &Ah, int nwg) {
+    hipLaunchKernelGGL((k_part_hist<NC>), dim3(nwg), dim3(RFX_BLOCK), 0, c->stream, Ph, Ah);
+}
+
+template <int NC>
 static int launch_part(rfx_ctx *c, const Plan &P, const PartArgs &A, int nwg) {
-    hipLaunchKernelGGL((k_part_hist<NC>), dim3(nwg), dim3(RFX_BLOCK), 0, c->stream, P, A);
+    // pass 0 reads only the key and the predicate columns: a reduced plan without the value columns
+    Plan Ph = P;
+    PartArgs Ah = A;
+    int map[RFX_MAX_COLS], nh = 0;
+    for (int i = 0; i < RFX_MAX_COLS; i++) map[i] = -1;
+    auto use = [&](int col) {
+        if (col >= 0 && map[col] < 0) {
+            map[col] = nh;
+            Ph.cols[nh++] = P.cols[col];
+        }
+    };
+    use(A.key_idx);
+    for (int i = 0; i < P.npred; i++) {
+        use(P.preds[i].col);
+        use(P.preds[i].rhs_col);
+    }
+    for (int i = 0; i < P.npred; i++) {
+        Ph.preds[i].col = map[P.preds[i].col];
+        if (P.preds[i].rhs_col >= 0) Ph.preds[i].rhs_col = map[P.preds[i].rhs_col];
+    }
+    Ph.ncols = nh;
+    Ph.nagg = 0;
+    Ah.key_idx = map[A.key_idx];
+    switch (nh) {
+        case 1: launch_hist<1>(c, Ph, Ah, nwg); break;
+        case 2: launch_hist<2>(c, Ph, Ah, nwg); break;
+        case 3: launch_hist<3>(c, Ph, Ah, nwg); break;
+        default: launch_hist<4>(c, Ph, Ah, nwg); break;
+    }
     hipLaunchKernelGGL(k_part_colscan, dim3((A.nparts + RFX_BLOCK - 1) / RFX_BLOCK), dim3(RFX_BLOCK), 0, c->stream, A, nwg);
     hipLaunchKernelGGL(k_part_startscan, dim3(1), dim3(PART_MAX), 0, c->stream, A);
     switch (A.nv) {

@@ -220,6 +220,12 @@ class Engine:
             logic, flat = self._flatten(where, table)
         except _NotFlat:
             return self._filter_aggr_via_ids(aggs, where, table)
+        if len(aggs) > L.RFX_MAX_AGGS:  # more outputs than one fused pass carries: several passes, same selection
+            vals, sel = [], 0
+            for i in range(0, len(aggs), L.RFX_MAX_AGGS):
+                v, sel = self.filter_aggr(aggs[i:i + L.RFX_MAX_AGGS], where, table, nrows)
+                vals += v
+            return vals, sel
         self._keep.clear()
         parr, n = self._preds(flat, table, nrows)
         aarr, n = self._aggs(aggs, table, n)

@@ -1,0 +1,55 @@
+#!/usr/bin/env python
+"""Copy the rocprofv3 summaries a `gpurun -- bash tools/profile_round.sh <tag>` call left in gpurun_out/prof_<tag>/ into the
+tracked profiles/ directory and derive profiles/pmc_traffic.json (HBM bytes per launch of each workload's dominant
+kernel(s)), applying the corrections of MI355X_MICROARCH.md "HBM":  FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950
+FETCH_SIZE counts a wide coalesced streaming read at exactly 1/2 (128-byte requests tallied as 64 B) -> x2;
+WRITE_SIZE calibrates 1:1 (k_gen_* writes exactly n*8 bytes and reads 7 812 500 KiB per 1e9 rows in these runs).
+"""
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
+dst = os.path.join(ROOT, "profiles")
+os.makedirs(dst, exist_ok=True)
+DOMINANT = {"c2": ["k_filter_aggr<"], "c2b": ["k_filter_aggr<"], "c5": ["k_filter_aggr<"],
+            "c3": ["k_part_hist", "k_part_scatter", "k_part_aggregate"]}
+
+
+def read_pmc(path):
+    out = {}
+    if not os.path.exists(path):
+        return out
+    for line in open(path):
+        if line.startswith("#") or not line.strip():
+            continue
+        val, n, name = line.rstrip("\n").split("\t")
+        out[name] = (float(val), int(n))
+    return out
+
+
+traffic, detail = {}, {}
+for w, pats in DOMINANT.items():
+    for suffix in ("kernel_stats.csv", "pmc_FETCH_SIZE.txt", "pmc_WRITE_SIZE.txt"):
+        f = os.path.join(src, f"{w}_{suffix}")
+        if os.path.exists(f):
+            shutil.copy(f, os.path.join(dst, f"{tag}_{w}_{suffix}"))
+    fe, wr = read_pmc(os.path.join(src, f"{w}_pmc_FETCH_SIZE.txt")), read_pmc(os.path.join(src, f"{w}_pmc_WRITE_SIZE.txt"))
+    if not fe:
+        continue
+    tot, parts = 0.0, {}
+    for name, (v, _) in fe.items():
+        if any(p in name for p in pats):
+            rd = v * 1024 * 2
+            wv = wr.get(name, (0.0, 0))[0] * 1024
+            parts[name.split("(")[0].replace("void ", "")] = {"read_bytes": rd, "write_bytes": wv}
+            tot += rd + wv
+    traffic[w] = tot
+    detail[w] = parts
+json.dump(traffic, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
+json.dump({"tag": tag, "corrections": "FETCH_SIZE KiB x1024 x2 (gfx950 streaming-read undercount), WRITE_SIZE KiB x1024", "per_kernel": detail},
+          open(os.path.join(dst, f"{tag}_pmc_detail.json"), "w"), indent=1)
+print(json.dumps(traffic, indent=1))
