@@ -215,6 +215,7 @@ def main():
     ap.add_argument("--rows", type=int, default=0, help="rows per GPU (default: the workload's BASELINE size)")
     ap.add_argument("--cpu-sample-rows", type=int, default=100_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sharded", action="store_true", help="use the row-sharded driver (collectives) even with one rank")
     ap.add_argument("--no-also", action="store_true", help="skip the secondary workloads in the 'also' field")
     ap.add_argument("--blocks-per-cu", type=int, default=0)
     ap.add_argument("--tune-flags", type=int, default=0, help="rfx_hip_ctx_tune flags (kernel-variant experiments)")
@@ -240,7 +241,11 @@ def main():
         eng.tune(blocks_per_cu=args.blocks_per_cu, flags=args.tune_flags)
     name = args.workload
     rows = args.rows or WORKLOADS[name]["rows"]
-    sharded = ShardedEngine(eng, rows) if world > 1 else None
+    if args.sharded and world == 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
+    sharded = ShardedEngine(eng, rows) if (world > 1 or args.sharded) else None
     row0 = rank * rows
 
     main_r = run_workload(name, eng, sharded, rows, row0, args.steps, args.warmup, world)
@@ -291,7 +296,7 @@ def main():
         if also:
             line["also"] = also
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
     eng.close()

@@ -263,3 +263,25 @@ def test_hash_primitives_pinned(eng):
     L.check(eng.lib.rfx_hip_hash_mix_u64(eng._ctx, d.data_ptr(), len(x), 0x9ddfea08eb382d69, out.data_ptr()))
     want = np.array([rfo.lib().rfo_hash_index_u64(0x9ddfea08eb382d69, int(v) & (2**64 - 1)) for v in x], np.uint64)
     assert np.array_equal(out.cpu().numpy().view(np.uint64), want)
+
+
+# ---------------------------------------------------------------- row-sharded driver on one rank (collectives are no-ops)
+def test_sharded_engine_single_rank(eng):
+    from rayforce_amd.dist import ShardedEngine
+    n = 150_001
+    host = table(n, keys=3000, nulls=True)
+    d = dev(eng, host)
+    sh = ShardedEngine(eng, n)
+    assert sh.shard.row0 == 0 and sh.shard.total_rows == n
+    aggs = [("sum", "a"), ("avg", "v"), ("min", "w"), ("max", "a"), ("count", "a")]
+    vals, sel = sh.filter_aggr(aggs, ("<", "a", 400_000), d)
+    want = rfo.select({"from": host, "where": ("<", "a", 400_000), **{f"o{i}": a for i, a in enumerate(aggs)}})
+    for i, v in enumerate(vals):
+        w = want[f"o{i}"][0]
+        assert (abs(v - w) <= RTOL * abs(w)) if isinstance(v, float) else v == int(w)
+    assert sel == int(rfo.mask_of(("<", "a", 400_000), host).sum())
+    r = sh.group_by("k", [("sum", "v"), ("count", "a")], None, d)
+    w = rfo.select({"from": host, "by": "k", "s": ("sum", "v"), "c": ("count", "a")})
+    assert np.array_equal(r["keys"].cpu().numpy(), w["k"]) and np.array_equal(r["results"][1].cpu().numpy(), w["c"])
+    same_f64(r["results"][0].cpu().numpy(), w["s"])
+    assert np.array_equal(sh.where(("<", "a", 1000), d).cpu().numpy(), rfo.where(rfo.mask_of(("<", "a", 1000), host)))
