@@ -1,0 +1,86 @@
+"""BASELINE.json's full sizes (1e9 rows) through size-independent properties -- the oracle would take minutes there.
+
+  * partition of unity: aggregates over `p` and over `not p` add up to the aggregate over everything (i64 exact);
+  * `where` ids: ascending, exactly `count` of them, every gathered value satisfies the predicate, none missed;
+  * group-by: counts add up to N, sums add up to the column sum, keys distinct, first ids strictly ascending
+    (= first-occurrence order) and key[first[g]] == keys[g]; partitioned and atomic paths agree bit-exactly on
+    integer outputs.
+Columns are generated on the device with the same counter-based generator the oracle has (checked at small n)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+N = 1_000_000_000
+
+
+@pytest.fixture(scope="module")
+def big(eng):
+    free, _ = torch.cuda.mem_get_info()
+    if free < 60 * 2**30:
+        pytest.skip("needs ~60 GB of free HBM")
+    t = {"a": eng.gen_i64(N, 2, 1_000_000), "k": eng.gen_i64(N, 4, 1_000_000), "v": eng.gen_f64(N, 5)}
+    eng.sync()
+    yield t
+    del t
+    torch.cuda.empty_cache()
+
+
+def test_c2_filter_sum_partition_of_unity(eng, big):
+    aggs = [("sum", "a"), ("count", "a"), ("min", "a"), ("max", "a")]
+    (s_all, c_all, mn_all, mx_all), sel_all = eng.filter_aggr(aggs, None, big)
+    (s_lo, c_lo, mn_lo, mx_lo), sel_lo = eng.filter_aggr(aggs, ("<", "a", 100_000), big)
+    (s_hi, c_hi, mn_hi, mx_hi), sel_hi = eng.filter_aggr(aggs, (">=", "a", 100_000), big)
+    assert sel_all == c_all == N and sel_lo + sel_hi == N and c_lo == sel_lo
+    assert s_lo + s_hi == s_all  # exact integer arithmetic
+    assert mn_all == min(mn_lo, mn_hi) == 0 and mx_all == max(mx_lo, mx_hi) == 999_999 and mx_lo == 99_999 and mn_hi == 100_000
+    assert abs(sel_lo / N - 0.1) < 1e-4  # uniform [0, 1e6): 10 % selectivity
+    # f64 column, multi-predicate (the C5 shape) -- partition by the first predicate
+    w = ("and", ("<", "v", 0.316228), (">=", "a", 500_000))
+    (fs, fc), _ = eng.filter_aggr([("sum", "v"), ("count", "v")], w, big)
+    (gs, gc), _ = eng.filter_aggr([("sum", "v"), ("count", "v")], ("and", (">=", "v", 0.316228), (">=", "a", 500_000)), big)
+    (ts, tc), _ = eng.filter_aggr([("sum", "v"), ("count", "v")], (">=", "a", 500_000), big)
+    assert fc + gc == tc and abs((fs + gs) - ts) <= 1e-9 * ts
+
+
+def test_where_ids_full_size(eng, big):
+    ids = eng.where(("<", "a", 1000), big)  # 0.1 % selectivity -> ~1e6 ids
+    (cnt,), _ = eng.filter_aggr([("count", "a")], ("<", "a", 1000), big)
+    assert ids.numel() == cnt
+    assert bool((ids[1:] > ids[:-1]).all()) and int(ids[0]) >= 0 and int(ids[-1]) < N
+    got = eng.at_ids(big["a"], ids)
+    assert bool((got < 1000).all())
+    (s,), _ = eng.filter_aggr([("sum", "a")], ("<", "a", 1000), big)
+    assert int(got.sum()) == s
+    # 10 % selectivity: 1e8 ids (0.8 GB), same checks on the count / order / sum
+    ids = eng.where(("<", "a", 100_000), big)
+    (cnt, s), _ = eng.filter_aggr([("count", "a"), ("sum", "a")], ("<", "a", 100_000), big)
+    assert ids.numel() == cnt and bool((ids[1:] > ids[:-1]).all())
+    assert int(eng.at_ids(big["a"], ids).sum()) == s
+
+
+def test_c3_group_by_full_size(eng, big):
+    r = eng.group_by("k", [("sum", "v"), ("count", "v"), ("max", "a")], None, big)
+    g = r["groups"]
+    assert g == 1_000_000  # every key of [0, 1e6) occurs in 1e9 uniform draws
+    keys, first, (sums, counts, maxa) = r["keys"], r["first"], r["results"]
+    assert int(counts.sum()) == N
+    (tot,), _ = eng.filter_aggr([("sum", "v")], None, big)
+    assert abs(float(sums.sum()) - tot) <= 1e-9 * tot
+    assert int(torch.unique(keys).numel()) == g
+    assert bool((first[1:] > first[:-1]).all())  # group order == first-occurrence order
+    assert torch.equal(eng.at_ids(big["k"], first), keys)  # the key at each group's first row is that group's key
+    assert int(maxa.max()) == 999_999
+    # the same query through device-scope atomics (tune flag 2 disables the partitioned path): integer outputs identical
+    eng.tune(flags=2)
+    try:
+        r2 = eng.group_by("k", [("sum", "v"), ("count", "v"), ("max", "a")], None, big)
+    finally:
+        eng.tune(flags=0)
+    assert torch.equal(r2["keys"], keys) and torch.equal(r2["first"], first)
+    assert torch.equal(r2["results"][1], counts) and torch.equal(r2["results"][2], maxa)
+    assert torch.allclose(r2["results"][0], sums, rtol=1e-9, atol=0)
+    # with a filter: groups are the keys that survive, counts add up to the selected rows
+    r3 = eng.group_by("k", [("count", "v")], ("<", "a", 100_000), big)
+    (sel,), _ = eng.filter_aggr([("count", "a")], ("<", "a", 100_000), big)
+    assert int(r3["results"][0].sum()) == sel and bool((r3["first"][1:] > r3["first"][:-1]).all())
