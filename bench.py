@@ -45,6 +45,8 @@ WORKLOADS = {
                 kernel="k_filter_aggr<2,1,4,1>"),
     "c3": dict(desc="configs[2]: select sum(v) by k, k i64 uniform [0,1e6) seed 4, v f64 seed 5", rows=1_000_000_000, bytes_per_row=16, dtype="f64",
                kernel="k_part_hist+k_part_scatter+k_part_aggregate"),
+    "w2": dict(desc="where ids: (where (< a 100000)) on the C2 column -> 1e8 ascending i64 row ids (8 B/row in + 8 B/selected row out)", rows=1_000_000_000,
+               bytes_per_row=8.8, dtype="int64", kernel="k_sel_bitmap<1>+k_emit_ids"),
     "c5": dict(desc="configs[4] per-GPU shard: avg,min,max(d) where a<0.316228 and b>0.683772 and c!=0.25, 4 x f64 seeds 6-9", rows=250_000_000,
                bytes_per_row=32, dtype="f64", kernel="k_filter_aggr<4,4,2,4>"),
 }
@@ -60,6 +62,9 @@ class Job:
         if name == "c2":
             self.t = {"a": g.gen_i64(rows, 2, 1_000_000, row0)}
             self.aggs, self.where = [("sum", "a")], ("<", "a", 100_000)
+        elif name == "w2":
+            self.t = {"a": g.gen_i64(rows, 2, 1_000_000, row0)}
+            self.aggs, self.where = [], ("<", "a", 100_000)
         elif name == "c2b":
             self.t = {"a": g.gen_i64(rows, 2, 1_000_000, row0), "b": g.gen_f64(rows, 3, row0)}
             self.aggs, self.where = [("sum", "b")], ("<", "a", 100_000)
@@ -76,6 +81,10 @@ class Job:
         self.L = L
 
     def step(self):
+        if self.name == "w2":
+            ids = self.sh.where(self.where, self.t) if self.sh is not None else self.eng.where(self.where, self.t)
+            self.eng.sync()
+            return ([int(ids.numel())], int(ids.numel()))
         if self.name == "c3":
             if self.sh is not None:
                 return self.sh.group_by("k", self.aggs, self.where, self.t)
@@ -218,6 +227,7 @@ def main():
     ap.add_argument("--sharded", action="store_true", help="use the row-sharded driver (collectives) even with one rank")
     ap.add_argument("--no-also", action="store_true", help="skip the secondary workloads in the 'also' field")
     ap.add_argument("--blocks-per-cu", type=int, default=0)
+    ap.add_argument("--ab", default="", help="dev: comma list of tune flags to A/B in ONE process (same box, same clocks); prints one line per run")
     ap.add_argument("--tune-flags", type=int, default=0, help="rfx_hip_ctx_tune flags (kernel-variant experiments)")
     args = ap.parse_args()
 
@@ -248,6 +258,14 @@ def main():
     sharded = ShardedEngine(eng, rows) if (world > 1 or args.sharded) else None
     row0 = rank * rows
 
+    if args.ab:
+        job = Job(name, eng, sharded, rows, row0)
+        for rep in range(3):
+            for fl in [int(x) for x in args.ab.split(",")]:
+                eng.tune(blocks_per_cu=args.blocks_per_cu, flags=fl)
+                dt, kms, _ = timed(job, args.steps, 1, world)
+                log(f"[ab] rep {rep} flags {fl}: ms_per_step {dt * 1e3 / args.steps:.3f} kernel_ms {kms:.3f}")
+        return
     main_r = run_workload(name, eng, sharded, rows, row0, args.steps, args.warmup, world)
     log(f"[bench] {name}: {main_r}")
     also = {}

@@ -13,6 +13,11 @@
 //   pass 2  k_part_aggregate each partition (a contiguous record range) is streamed by SPLIT workgroups that
 //                            aggregate into LDS tables (ds_add_f64 / ds_min_u64 ...) and merge them into the global
 //                            tables once                                                              16 B/row read
+// What bounds pass 1 (rocprofv3 PMC, profiles/): TCC_EA0_WRREQ_STALL ~ TCC_EA0_WRREQ -- the L2 -> memory write path is
+// back-pressured by 64-byte write requests that arrive in no DRAM-page order (the same kernel writing each tile
+// contiguously runs in 6.1 ms instead of ~9 ms).  Tried and measured without gain: 4096/8192-row tiles, 528-byte runs
+// (123 partitions), a workgroup-major record layout, randomised segment padding, register prefetch of the next tile,
+// direct (unsorted) stores.  Next lever: per-partition write-combining to >= 1 KB before the store.
 // partition p = (key - kmin) >> lb owns slots [p << lb, (p+1) << lb): the per-partition LDS table covers them exactly.
 // The global tables, the first-row ranking and the emit are those of rfx_group.hip, so results (group order included)
 // are identical to the LDS-direct and atomic paths.
@@ -43,8 +48,8 @@ struct PartArgs {
 };
 
 // Shared tile front-end of pass 0 and pass 1: 8 rows per lane as four 16-byte loads per column.
-template <int NC>
-__device__ __forceinline__ unsigned part_load_eval(const Plan &P, const PredSet<RFX_MAX_PREDS> &S, i64 tile, u64 (&v)[NC][8]) {
+template <int NC, int NP>
+__device__ __forceinline__ unsigned part_load_eval(const Plan &P, const PredSet<NP> &S, i64 tile, u64 (&v)[NC][8]) {
     const i64 base = tile * PART_TILE_ROWS + threadIdx.x * 2;
     unsigned valid = 0xffu;
     if ((tile + 1) * PART_TILE_ROWS <= P.nrows) {
@@ -68,21 +73,22 @@ __device__ __forceinline__ unsigned part_load_eval(const Plan &P, const PredSet<
             for (int c = 0; c < NC; c++) v[c][e] = in ? P.cols[c][row] : 0ULL;
         }
     }
-    return eval_preds<NC, 8, RFX_MAX_PREDS>(S, v, valid);
+    if (NP == 0) return valid;
+    return eval_preds<NC, 8, NP>(S, v, valid);
 }
 
 // ---- pass 0: per-(workgroup, partition) counts ----
-template <int NC>
+template <int NC, int NP>
 __global__ __launch_bounds__(RFX_BLOCK) void k_part_hist(const Plan P, const PartArgs A) {
     __shared__ unsigned hist[PART_MAX];
-    PredSet<RFX_MAX_PREDS> S;
-    predset_load<RFX_MAX_PREDS>(P, S);
+    PredSet<NP> S;
+    predset_load<NP>(P, S);
     for (int i = threadIdx.x; i < A.nparts; i += RFX_BLOCK) hist[i] = 0;
     __syncthreads();
     const i64 ntiles = (P.nrows + PART_TILE_ROWS - 1) / PART_TILE_ROWS;
     for (i64 t = blockIdx.x; t < ntiles; t += gridDim.x) {
         u64 v[NC][8];
-        const unsigned m = part_load_eval<NC>(P, S, t, v);
+        const unsigned m = part_load_eval<NC, NP>(P, S, t, v);
         u64 key[8];
         sel_col<NC, 8>(key, v, A.key_idx);
 #pragma unroll
@@ -125,7 +131,7 @@ __global__ __launch_bounds__(PART_MAX) void k_part_startscan(const PartArgs A) {
 }
 
 // ---- pass 1: scatter records, tile sorted by partition in LDS ----
-template <int NC, int NV>
+template <int NC, int NV, int NP>
 __global__ __launch_bounds__(RFX_BLOCK) void k_part_scatter(const Plan P, const PartArgs A) {
     __shared__ unsigned thist[PART_MAX]; // per tile: count, then exclusive tile offset
     __shared__ u64 cursor[PART_MAX];     // running global output position of (this workgroup, partition)
@@ -133,8 +139,8 @@ __global__ __launch_bounds__(RFX_BLOCK) void k_part_scatter(const Plan P, const 
     __shared__ unsigned short stag_p[PART_TILE_ROWS];
     __shared__ unsigned scan_w[RFX_BLOCK / RFX_WAVE];
     __shared__ unsigned tile_total;
-    PredSet<RFX_MAX_PREDS> S;
-    predset_load<RFX_MAX_PREDS>(P, S);
+    PredSet<NP> S;
+    predset_load<NP>(P, S);
     const int tid = threadIdx.x;
     for (int i = tid; i < A.nparts; i += RFX_BLOCK) cursor[i] = A.part_start[i] + A.offsets[(size_t)blockIdx.x * A.nparts + i];
     const i64 ntiles = (P.nrows + PART_TILE_ROWS - 1) / PART_TILE_ROWS;
@@ -142,7 +148,7 @@ __global__ __launch_bounds__(RFX_BLOCK) void k_part_scatter(const Plan P, const 
         for (int i = tid; i < A.nparts; i += RFX_BLOCK) thist[i] = 0;
         __syncthreads();
         u64 v[NC][8];
-        const unsigned m0 = part_load_eval<NC>(P, S, t, v);
+        const unsigned m0 = part_load_eval<NC, NP>(P, S, t, v);
         u64 key[8];
         sel_col<NC, 8>(key, v, A.key_idx);
         unsigned m = 0, part[8], rank[8];
@@ -334,7 +340,15 @@ __global__ __launch_bounds__(PART_AGG_THREADS) void k_part_aggregate(const Plan 
 
 template <int NC>
 static void launch_hist(rfx_ctx *c, const Plan &Ph, const PartArgs &Ah, int nwg) {
-    hipLaunchKernelGGL((k_part_hist<NC>), dim3(nwg), dim3(RFX_BLOCK), 0, c->stream, Ph, Ah);
+    // the predicate-free instantiations are the C3 shape: without the generic predicate code the kernels are ~10x smaller
+    if (Ph.npred == 0) hipLaunchKernelGGL((k_part_hist<NC, 0>), dim3(nwg), dim3(RFX_BLOCK), 0, c->stream, Ph, Ah);
+    else hipLaunchKernelGGL((k_part_hist<NC, RFX_MAX_PREDS>), dim3(nwg), dim3(RFX_BLOCK), 0, c->stream, Ph, Ah);
+}
+
+template <int NC, int NV>
+static void launch_scatter(rfx_ctx *c, const Plan &P, const PartArgs &A, int nwg) {
+    if (P.npred == 0) hipLaunchKernelGGL((k_part_scatter<NC, NV, 0>), dim3(nwg), dim3(RFX_BLOCK), 0, c->stream, P, A);
+    else hipLaunchKernelGGL((k_part_scatter<NC, NV, RFX_MAX_PREDS>), dim3(nwg), dim3(RFX_BLOCK), 0, c->stream, P, A);
 }
 
 template <int NC>
@@ -371,10 +385,10 @@ static int launch_part(rfx_ctx *c, const Plan &P, const PartArgs &A, int nwg) {
     hipLaunchKernelGGL(k_part_colscan, dim3((A.nparts + RFX_BLOCK - 1) / RFX_BLOCK), dim3(RFX_BLOCK), 0, c->stream, A, nwg);
     hipLaunchKernelGGL(k_part_startscan, dim3(1), dim3(PART_MAX), 0, c->stream, A);
     switch (A.nv) {
-        case 0: hipLaunchKernelGGL((k_part_scatter<NC, 0>), dim3(nwg), dim3(RFX_BLOCK), 0, c->stream, P, A); break;
-        case 1: hipLaunchKernelGGL((k_part_scatter<NC, 1>), dim3(nwg), dim3(RFX_BLOCK), 0, c->stream, P, A); break;
-        case 2: hipLaunchKernelGGL((k_part_scatter<NC, 2>), dim3(nwg), dim3(RFX_BLOCK), 0, c->stream, P, A); break;
-        default: hipLaunchKernelGGL((k_part_scatter<NC, 3>), dim3(nwg), dim3(RFX_BLOCK), 0, c->stream, P, A); break;
+        case 0: launch_scatter<NC, 0>(c, P, A, nwg); break;
+        case 1: launch_scatter<NC, 1>(c, P, A, nwg); break;
+        case 2: launch_scatter<NC, 2>(c, P, A, nwg); break;
+        default: launch_scatter<NC, 3>(c, P, A, nwg); break;
     }
     return RFX_OK;
 }
@@ -406,7 +420,7 @@ int rfx_group_part_accumulate(rfx_ctx *c, const Plan &P, int key_idx, const rfx_
     if (lb < 8) return RFX_ESTATE;
     const i64 nparts = (t->range + (1LL << lb) - 1) >> lb;
     if (nparts > PART_MAX || nparts < 2) return RFX_ESTATE;
-    const int nwg = c->num_cus * ((c->flags & 8) ? 2 : 3); // ~48 KB LDS per workgroup: three fit a CU
+    const int nwg = c->num_cus * ((c->flags & 8) ? 3 : 2); // in-process A/B (bench.py --ab 0,8): 2 workgroups per CU beat 3 by ~3 %
     A.kmin = t->kmin;
     A.range = t->range;
     A.lb = lb;

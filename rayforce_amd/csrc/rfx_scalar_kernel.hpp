@@ -92,7 +92,7 @@ template <int NP>
 struct PredSet {
     int npred;
     bool is_and;
-    PredR p[NP];
+    PredR p[NP > 0 ? NP : 1];
 };
 __device__ __forceinline__ int pred_keep_bits(int op) {
     switch (op) {
@@ -180,7 +180,7 @@ __device__ __forceinline__ void pred_lt_eq(const PredR &pr, const u64 (&x)[E], c
 // predicates that read column c are evaluated straight on v[c] (no register copies).
 template <int NC, int E, int NP>
 __device__ __forceinline__ void eval_sel(const PredSet<NP> &S, const u64 (&v)[NC][E], const bool (&valid)[E], bool (&sel)[E]) {
-    if (S.npred == 0) {
+    if (NP == 0 || S.npred == 0) {
 #pragma unroll
         for (int e = 0; e < E; e++) sel[e] = valid[e];
         return;
