@@ -47,6 +47,10 @@ WORKLOADS = {
                kernel="k_part_hist+k_part_scatter+k_part_aggregate"),
     "w2": dict(desc="where ids: (where (< a 100000)) on the C2 column -> 1e8 ascending i64 row ids (8 B/row in + 8 B/selected row out)", rows=1_000_000_000,
                bytes_per_row=8.8, dtype="int64", kernel="k_sel_bitmap<1>+k_emit_ids"),
+    "m2": dict(desc="B8 mask: (< a 100000) materialised as the reference's byte mask (8 B/row in + 1 B/row out)", rows=1_000_000_000, bytes_per_row=9,
+               dtype="int64", kernel="k_cmp_mask<1>"),
+    "g2": dict(desc="gather: (at b ids) for the 1e8 ids of w2 (8 B id + 8 B random read + 8 B write per id)", rows=1_000_000_000, bytes_per_row=2.4,
+               dtype="f64", kernel="k_gather8"),
     "c5": dict(desc="configs[4] per-GPU shard: avg,min,max(d) where a<0.316228 and b>0.683772 and c!=0.25, 4 x f64 seeds 6-9", rows=250_000_000,
                bytes_per_row=32, dtype="f64", kernel="k_filter_aggr<4,4,2,4>"),
 }
@@ -62,9 +66,13 @@ class Job:
         if name == "c2":
             self.t = {"a": g.gen_i64(rows, 2, 1_000_000, row0)}
             self.aggs, self.where = [("sum", "a")], ("<", "a", 100_000)
-        elif name == "w2":
+        elif name in ("w2", "m2"):
             self.t = {"a": g.gen_i64(rows, 2, 1_000_000, row0)}
             self.aggs, self.where = [], ("<", "a", 100_000)
+        elif name == "g2":
+            self.t = {"a": g.gen_i64(rows, 2, 1_000_000, row0), "b": g.gen_f64(rows, 3, row0)}
+            self.aggs, self.where = [], ("<", "a", 100_000)
+            self.ids = g.where(self.where, self.t)
         elif name == "c2b":
             self.t = {"a": g.gen_i64(rows, 2, 1_000_000, row0), "b": g.gen_f64(rows, 3, row0)}
             self.aggs, self.where = [("sum", "b")], ("<", "a", 100_000)
@@ -81,6 +89,16 @@ class Job:
         self.L = L
 
     def step(self):
+        if self.name == "m2":
+            self.eng.timer_start()
+            m = self.eng.cmp("<", self.t["a"], 100_000)
+            self.kms = self.eng.timer_stop()
+            return ([int(m.numel())], int(m.numel()))
+        if self.name == "g2":
+            self.eng.timer_start()
+            out = self.eng.at_ids(self.t["b"], self.ids)
+            self.kms = self.eng.timer_stop()
+            return ([int(out.numel())], int(out.numel()))
         if self.name == "w2":
             ids = self.sh.where(self.where, self.t) if self.sh is not None else self.eng.where(self.where, self.t)
             self.eng.sync()
@@ -107,7 +125,7 @@ def timed(job: Job, steps: int, warmup: int, world: int):
     res = None
     for _ in range(steps):
         res = job.step()
-        kms.append(eng.last_kernel_ms())
+        kms.append(job.kms if job.name in ("m2", "g2") else eng.last_kernel_ms())
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -261,10 +279,12 @@ def main():
     if args.ab:
         job = Job(name, eng, sharded, rows, row0)
         for rep in range(3):
-            for fl in [int(x) for x in args.ab.split(",")]:
-                eng.tune(blocks_per_cu=args.blocks_per_cu, flags=fl)
+            for item in args.ab.split(","):
+                fl, _, bpc = item.partition(":")
+                eng.tune(blocks_per_cu=int(bpc or args.blocks_per_cu or 2), flags=int(fl))
                 dt, kms, _ = timed(job, args.steps, 1, world)
-                log(f"[ab] rep {rep} flags {fl}: ms_per_step {dt * 1e3 / args.steps:.3f} kernel_ms {kms:.3f}")
+                log(f"[ab] rep {rep} flags:bpc {item}: ms_per_step {dt * 1e3 / args.steps:.3f} kernel_ms {kms:.3f} "
+                    f"GB/s {WORKLOADS[name]['bytes_per_row'] * rows / kms / 1e6:.0f}")
         return
     main_r = run_workload(name, eng, sharded, rows, row0, args.steps, args.warmup, world)
     log(f"[bench] {name}: {main_r}")

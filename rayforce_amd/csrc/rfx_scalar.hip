@@ -65,12 +65,19 @@ __global__ __launch_bounds__(RFX_BLOCK) void k_filter_aggr_final(const Plan P, c
     }
 }
 
-// streaming reductions want ~4 workgroups per CU (profiles/r01_bpc_sweep.txt)
-static inline int rfx_scalar_grid(const rfx_ctx *c) { return c->num_cus * (c->blocks_per_cu > 0 ? c->blocks_per_cu * 2 : 4); }
+// Workgroups per CU of the fused reduction, by distinct-column count (in-process sweep, bench.py --ab): the lighter the
+// ALU work per byte, the fewer waves it takes to keep HBM busy -- 1 column: 4, 2 columns: 2, 3+ columns (more predicates /
+// aggregates per row): 6.  blocks_per_cu (rfx_hip_ctx_tune) scales it: 2 = as measured.
+static inline int rfx_scalar_wg_per_cu(int ncols) { return ncols <= 1 ? 4 : (ncols == 2 ? 2 : 6); }
+static inline int rfx_scalar_grid_for(const rfx_ctx *c, int ncols) {
+    int per = rfx_scalar_wg_per_cu(ncols) * (c->blocks_per_cu > 0 ? c->blocks_per_cu : 2) / 2;
+    return c->num_cus * (per < 1 ? 1 : per);
+}
+static inline int rfx_scalar_grid(const rfx_ctx *c) { return c->num_cus * 6 * ((c->blocks_per_cu > 2 ? c->blocks_per_cu : 2) / 2); } // upper bound, for workspace sizing
 
 int rfx_run_filter_aggr(rfx_ctx *c, Plan &P, rfx_partial_t *d_out) {
     // a plan with no columns at all (COUNT without predicate): give it a harmless column-free path
-    int grid = rfx_scalar_grid(c);
+    int grid = rfx_scalar_grid_for(c, P.ncols);
     const i64 tiles = P.nrows / (RFX_BLOCK * 4) + 1;
     if (tiles < grid) grid = (int)tiles;
     int rc = rfx_ws_reserve(c, (size_t)grid * 9 * sizeof(Acc));
@@ -263,32 +270,39 @@ extern "C" int rfx_hip_scope_i64(rfx_ctx_t *c, const int64_t *d_key, const rfx_p
 }
 
 // ---------------- K2: byte masks ----------------
-// 8 rows per lane -> one 8-byte store of 8 mask bytes.
+// A wave owns 512 consecutive rows per step: lane l loads rows 2l, 2l+1 of each 128-row group (one 16-byte load per
+// group and column, 1 KB contiguous per wave instruction) and stores their two mask bytes as one 16-bit store
+// (128 B contiguous per wave instruction).
 template <int NC>
 __global__ __launch_bounds__(RFX_BLOCK) void k_cmp_mask(const Plan P, int8_t *__restrict__ out) {
     PredSet<RFX_MAX_PREDS> S;
     predset_load<RFX_MAX_PREDS>(P, S);
-    const i64 n8 = P.nrows / 8;
-    for (i64 g = blockIdx.x * (i64)RFX_BLOCK + threadIdx.x; g < n8; g += (i64)gridDim.x * RFX_BLOCK) {
+    const int lane = threadIdx.x & 63;
+    const i64 wave_id = (i64)blockIdx.x * (RFX_BLOCK / RFX_WAVE) + (threadIdx.x >> 6);
+    const i64 nwaves = (i64)gridDim.x * (RFX_BLOCK / RFX_WAVE);
+    const i64 nfull = P.nrows / 512;
+    for (i64 q = wave_id; q < nfull; q += nwaves) {
+        const i64 base = q * 512 + lane * 2;
         u64 v[NC][8];
 #pragma unroll
         for (int c = 0; c < NC; c++) {
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                u64x2 q = rfx_ld2(P.cols[c] + g * 8 + j * 2);
-                v[c][2 * j] = q.x;
-                v[c][2 * j + 1] = q.y;
+                u64x2 t = rfx_ld2(P.cols[c] + base + j * 128);
+                v[c][2 * j] = t.x;
+                v[c][2 * j + 1] = t.y;
             }
         }
-        unsigned m = eval_preds<NC, 8, RFX_MAX_PREDS>(S, v, 0xffu);
-        u64 bytes = 0;
+        const unsigned m = eval_preds<NC, 8, RFX_MAX_PREDS>(S, v, 0xffu);
 #pragma unroll
-        for (int e = 0; e < 8; e++) bytes |= (u64)((m >> e) & 1u) << (8 * e);
-        *(u64 *)(out + g * 8) = bytes;
+        for (int j = 0; j < 4; j++) {
+            const unsigned short two = (unsigned short)(((m >> (2 * j)) & 1u) | (((m >> (2 * j + 1)) & 1u) << 8));
+            *(unsigned short *)(out + base + j * 128) = two;
+        }
     }
     // tail rows
     if (blockIdx.x == 0) {
-        for (i64 r = n8 * 8 + threadIdx.x; r < P.nrows; r += RFX_BLOCK) {
+        for (i64 r = nfull * 512 + threadIdx.x; r < P.nrows; r += RFX_BLOCK) {
             u64 v[NC][1];
 #pragma unroll
             for (int c = 0; c < NC; c++) v[c][0] = P.cols[c][r];
@@ -304,7 +318,7 @@ extern "C" int rfx_hip_cmp_mask(rfx_ctx_t *c, const rfx_pred_t *pred, int64_t nr
     Plan P;
     int rc = rfx_plan_build(&P, pred, 1, RFX_AND, NULL, 0, NULL, NULL, nrows, 0);
     if (rc != RFX_OK) return rc;
-    int grid = rfx_grid(c);
+    int grid = c->num_cus * 8;
     if (P.ncols == 1) hipLaunchKernelGGL((k_cmp_mask<1>), dim3(grid), dim3(RFX_BLOCK), 0, c->stream, P, d_mask);
     else hipLaunchKernelGGL((k_cmp_mask<2>), dim3(grid), dim3(RFX_BLOCK), 0, c->stream, P, d_mask);
     RFX_HIP_CHECK(hipGetLastError());

@@ -9,12 +9,10 @@
 // runs the one fully general instantiation of its column count.
 template <int NC, int NA, int NP>
 static void launch_shape(rfx_ctx *c, const Plan &P, int grid, Acc *ws) {
-    // 16-byte loads in flight per lane = NC * U.  tools/probe_hw + the blocks-per-CU sweep in profiles/: 4 workgroups
-    // per CU with 8..16 loads per lane saturate HBM.
-    constexpr int U = (NC == 1) ? 8 : (NC == 2) ? 4 : (NC <= 4) ? 2 : 1;
-    constexpr int UALT = (NC == 1) ? 4 : (NC == 2) ? 2 : (NC <= 4) ? 4 : 1;
-    if (c->flags & 4) hipLaunchKernelGGL((k_filter_aggr<NC, NA, UALT, NP>), dim3(grid), dim3(RFX_BLOCK), 0, c->stream, P, ws);
-    else hipLaunchKernelGGL((k_filter_aggr<NC, NA, U, NP>), dim3(grid), dim3(RFX_BLOCK), 0, c->stream, P, ws);
+    // 16-byte loads in flight per lane = NC * U.  In-process sweep on MI355X (bench.py --ab): U = 4 wins
+    // for 1..4 columns (C2 6.77, C2b 6.92, C5 6.10 TB/s); the matching workgroups-per-CU choice is rfx_scalar_grid().
+    constexpr int U = (NC <= 4) ? 4 : (NC <= 6) ? 2 : 1;
+    hipLaunchKernelGGL((k_filter_aggr<NC, NA, U, NP>), dim3(grid), dim3(RFX_BLOCK), 0, c->stream, P, ws);
 }
 
 #define RFX_CAT2(a, b) a##b

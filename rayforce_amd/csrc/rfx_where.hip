@@ -23,50 +23,65 @@ __device__ __forceinline__ u64 lanemask_lt() {
 }
 
 // ---------------- pass A: predicates -> bitmap + per-chunk counts ----------------
-template <int NC>
+template <int NC, int NP>
+__device__ __forceinline__ void sel_chunk_load(const Plan &P, i64 q, int lane, u64 (&v)[NC][8], bool (&valid)[8]) {
+    const i64 base = q * RFX_CHUNK + lane * 2;
+    if (q * RFX_CHUNK + RFX_CHUNK <= P.nrows) {
+#pragma unroll
+        for (int e = 0; e < 8; e++) valid[e] = true;
+#pragma unroll
+        for (int c = 0; c < NC; c++) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                u64x2 t = rfx_ld2(P.cols[c] + base + j * 128);
+                v[c][2 * j] = t.x;
+                v[c][2 * j + 1] = t.y;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const i64 row = base + (e >> 1) * 128 + (e & 1);
+            valid[e] = row < P.nrows;
+#pragma unroll
+            for (int c = 0; c < NC; c++) v[c][e] = valid[e] ? P.cols[c][row] : 0ULL;
+        }
+    }
+}
+template <int NC, int NP>
+__device__ __forceinline__ void sel_chunk_store(const PredSet<NP> &S, i64 q, int lane, const u64 (&v)[NC][8], const bool (&valid)[8],
+                                                u64 *__restrict__ bitmap, i64 *__restrict__ chunk_cnt) {
+    bool sel[8];
+    eval_sel<NC, 8, NP>(S, v, valid, sel);
+    u64 mine = 0;
+    int cnt = 0;
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        const u64 b = __ballot(sel[e]); // the compare's lane mask itself
+        cnt += __popcll(b);
+        mine = (lane == e) ? b : mine;
+    }
+    if (lane < 8) bitmap[q * 8 + lane] = mine;
+    if (lane == 0) chunk_cnt[q] = cnt;
+}
+
+template <int NC, int NP>
 __global__ __launch_bounds__(RFX_BLOCK) void k_sel_bitmap(const Plan P, u64 *__restrict__ bitmap, i64 *__restrict__ chunk_cnt) {
-    PredSet<RFX_MAX_PREDS> S;
-    predset_load<RFX_MAX_PREDS>(P, S);
+    PredSet<NP> S;
+    predset_load<NP>(P, S);
     const int lane = threadIdx.x & 63;
     const i64 wave_id = (i64)blockIdx.x * (RFX_BLOCK / RFX_WAVE) + (threadIdx.x >> 6);
     const i64 nwaves = (i64)gridDim.x * (RFX_BLOCK / RFX_WAVE);
     const i64 nchunks = (P.nrows + RFX_CHUNK - 1) / RFX_CHUNK;
-    for (i64 q = wave_id; q < nchunks; q += nwaves) {
-        const i64 base = q * RFX_CHUNK + lane * 2;
-        u64 v[NC][8];
-        bool valid[8], sel[8];
-        if (q * RFX_CHUNK + RFX_CHUNK <= P.nrows) {
-#pragma unroll
-            for (int e = 0; e < 8; e++) valid[e] = true;
-#pragma unroll
-            for (int c = 0; c < NC; c++) {
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    u64x2 t = rfx_ld2(P.cols[c] + base + j * 128);
-                    v[c][2 * j] = t.x;
-                    v[c][2 * j + 1] = t.y;
-                }
-            }
-        } else {
-#pragma unroll
-            for (int e = 0; e < 8; e++) {
-                const i64 row = base + (e >> 1) * 128 + (e & 1);
-                valid[e] = row < P.nrows;
-#pragma unroll
-                for (int c = 0; c < NC; c++) v[c][e] = valid[e] ? P.cols[c][row] : 0ULL;
-            }
-        }
-        eval_sel<NC, 8, RFX_MAX_PREDS>(S, v, valid, sel);
-        u64 mine = 0;
-        int cnt = 0;
-#pragma unroll
-        for (int e = 0; e < 8; e++) {
-            const u64 b = __ballot(sel[e]); // the compare's lane mask itself
-            cnt += __popcll(b);
-            mine = (lane == e) ? b : mine;
-        }
-        if (lane < 8) bitmap[q * 8 + lane] = mine;
-        if (lane == 0) chunk_cnt[q] = cnt;
+    // two 512-row chunks per wave step: 8 x 16-byte loads per lane per column in flight
+    for (i64 q = wave_id; q < nchunks; q += 2 * nwaves) {
+        const i64 q2 = q + nwaves;
+        u64 v0[NC][8], v1[NC][8];
+        bool ok0[8], ok1[8];
+        sel_chunk_load<NC, NP>(P, q, lane, v0, ok0);
+        if (q2 < nchunks) sel_chunk_load<NC, NP>(P, q2, lane, v1, ok1);
+        sel_chunk_store<NC, NP>(S, q, lane, v0, ok0, bitmap, chunk_cnt);
+        if (q2 < nchunks) sel_chunk_store<NC, NP>(S, q2, lane, v1, ok1, bitmap, chunk_cnt);
     }
 }
 
@@ -219,7 +234,9 @@ __global__ __launch_bounds__(RFX_BLOCK) void k_emit_ids(const u64 *__restrict__ 
 
 template <int NC>
 static void launch_sel_bitmap(rfx_ctx *c, const Plan &P, int grid) {
-    hipLaunchKernelGGL((k_sel_bitmap<NC>), dim3(grid), dim3(RFX_BLOCK), 0, c->stream, P, c->d_bitmap, c->d_blksum);
+    if (P.npred <= 1) hipLaunchKernelGGL((k_sel_bitmap<NC, 1>), dim3(grid), dim3(RFX_BLOCK), 0, c->stream, P, c->d_bitmap, c->d_blksum);
+    else if (P.npred <= 4) hipLaunchKernelGGL((k_sel_bitmap<NC, 4>), dim3(grid), dim3(RFX_BLOCK), 0, c->stream, P, c->d_bitmap, c->d_blksum);
+    else hipLaunchKernelGGL((k_sel_bitmap<NC, RFX_MAX_PREDS>), dim3(grid), dim3(RFX_BLOCK), 0, c->stream, P, c->d_bitmap, c->d_blksum);
 }
 
 extern "C" int rfx_hip_where_begin(rfx_ctx_t *c, const rfx_pred_t *preds, int npred, int logic, const int8_t *d_mask,
@@ -246,7 +263,7 @@ extern "C" int rfx_hip_where_begin(rfx_ctx_t *c, const rfx_pred_t *preds, int np
         RFX_HIP_CHECK(hipMalloc((void **)&c->d_blksum, ((size_t)nchunks + 2) * 8));
         c->blksum_cap = (size_t)nchunks + 2;
     }
-    int grid = rfx_grid(c);
+    int grid = c->num_cus * ((c->flags & 512) ? 8 : 4);
     if ((i64)grid * 4 > nchunks) grid = (int)((nchunks + 3) / 4);
     RFX_KERNEL_BEGIN(c);
     if (d_mask) {
@@ -286,7 +303,7 @@ extern "C" int rfx_hip_where_emit(rfx_ctx_t *c, int64_t row0, int64_t *d_ids) {
     if (c->where_count == 0) return RFX_OK;
     RFX_REQUIRE(d_ids, RFX_EINVAL, "d_ids is NULL");
     const i64 nchunks = (c->where_n + RFX_CHUNK - 1) / RFX_CHUNK;
-    int grid = rfx_grid(c) * 2;
+    int grid = c->num_cus * ((c->flags & 1024) ? 32 : 16);
     if ((i64)grid * 4 > nchunks) grid = (int)((nchunks + 3) / 4);
     hipLaunchKernelGGL(k_emit_ids, dim3(grid), dim3(RFX_BLOCK), 0, c->stream, (const u64 *)c->d_bitmap, (const i64 *)c->d_blksum, c->where_n,
                        (i64)row0, (i64 *)d_ids);
