@@ -66,6 +66,12 @@ struct rfx_ctx {
     size_t gid_cap;
     void *d_part;       // partitioned group-by: offsets + record planes (grow-only)
     size_t part_bytes;
+    // scope + low-bit histogram computed together by rfx_hip_scope_i64 and consumed by the next group_dense_accumulate
+    u64 *d_pc_counts;   // [pc_nwg][256]
+    int pc_valid, pc_npred, pc_logic, pc_nwg;
+    const void *pc_key;
+    i64 pc_nrows;
+    u64 pc_sig[RFX_MAX_PREDS][6];
 };
 
 int rfx_ws_reserve(rfx_ctx *ctx, size_t bytes);

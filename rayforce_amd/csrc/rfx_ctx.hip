@@ -65,6 +65,7 @@ extern "C" int rfx_hip_ctx_destroy(rfx_ctx_t *c) {
     if (c->d_blksum) (void)hipFree(c->d_blksum);
     if (c->d_gid) (void)hipFree(c->d_gid);
     if (c->d_part) (void)hipFree(c->d_part);
+    if (c->d_pc_counts) (void)hipFree(c->d_pc_counts);
     if (c->h_pin) (void)hipHostFree(c->h_pin);
     (void)hipEventDestroy(c->ev0);
     (void)hipEventDestroy(c->ev1);

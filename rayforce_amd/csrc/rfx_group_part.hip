@@ -38,6 +38,7 @@ struct PartArgs {
     int agg_plane[RFX_MAX_AGGS]; // aggregate a reads plane agg_plane[a] (-1: none, COUNT / FIRST)
     int narr;                  // table arrays per slot (first + acc + cnt ...)
     int split;                 // workgroups per partition in pass 2
+    int lowbit;                // 1: partition = key & 255 (known before the scope is), local slot = (key - kmin) >> 8
     u64 *offsets;              // [nwg][nparts] : counts, then exclusive offsets
     u64 *part_start;           // [nparts + 1]
     u64 *recs;                 // plane 0 = headers, planes 1..nv = values ; each plane `cap` entries
@@ -101,6 +102,138 @@ __global__ __launch_bounds__(RFX_BLOCK) void k_part_hist(const Plan P, const Par
     for (int i = threadIdx.x; i < A.nparts; i += RFX_BLOCK) A.offsets[(size_t)blockIdx.x * A.nparts + i] = hist[i];
 }
 
+// ---- pass 0 fused with the key scope (index_scope_i64, core/index.c:376-435) ----
+// Partitioning on the key's LOW 8 bits needs no kmin, so the histogram can be taken in the same streaming read that finds
+// min / max: one 8 B/row pass instead of two.  Per workgroup: counts[256] + {min, max, selected, null keys}.
+struct ScopePart {
+    i64 mn, mx, sel, nulls;
+};
+template <int NC, int NP>
+__global__ __launch_bounds__(RFX_BLOCK) void k_part_scope_hist(const Plan P, int key_idx, u64 *__restrict__ counts, ScopePart *__restrict__ parts) {
+    __shared__ unsigned hist[256];
+    __shared__ ScopePart red[RFX_BLOCK / RFX_WAVE];
+    PredSet<NP> S;
+    predset_load<NP>(P, S);
+    hist[threadIdx.x] = 0; // RFX_BLOCK == 256
+    __syncthreads();
+    i64 mn = RFX_INF_I64_D, mx = RFX_NULL_I64_D, sel = 0, nulls = 0;
+    const i64 ntiles = (P.nrows + PART_TILE_ROWS - 1) / PART_TILE_ROWS;
+    for (i64 t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        u64 v[NC][8];
+        const unsigned m = part_load_eval<NC, NP>(P, S, t, v);
+        u64 key[8];
+        sel_col<NC, 8>(key, v, key_idx);
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            if (!((m >> e) & 1u)) continue;
+            const i64 k = (i64)key[e];
+            atomicAdd(&hist[key[e] & 255ULL], 1u);
+            sel++;
+            if (k == RFX_NULL_I64_D) nulls++;
+            else {
+                mn = k < mn ? k : mn;
+                mx = k > mx ? k : mx;
+            }
+        }
+    }
+    for (int s = 32; s >= 1; s >>= 1) {
+        const i64 omn = (i64)rfx_shfl_xor_u64((u64)mn, s), omx = (i64)rfx_shfl_xor_u64((u64)mx, s);
+        mn = omn < mn ? omn : mn;
+        mx = omx > mx ? omx : mx;
+        sel += (i64)rfx_shfl_xor_u64((u64)sel, s);
+        nulls += (i64)rfx_shfl_xor_u64((u64)nulls, s);
+    }
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ScopePart{mn, mx, sel, nulls};
+    __syncthreads();
+    counts[(size_t)blockIdx.x * 256 + threadIdx.x] = hist[threadIdx.x];
+    if (threadIdx.x == 0) {
+        ScopePart r = red[0];
+        for (int w = 1; w < RFX_BLOCK / RFX_WAVE; w++) {
+            r.mn = red[w].mn < r.mn ? red[w].mn : r.mn;
+            r.mx = red[w].mx > r.mx ? red[w].mx : r.mx;
+            r.sel += red[w].sel;
+            r.nulls += red[w].nulls;
+        }
+        parts[blockIdx.x] = r;
+    }
+}
+
+template <int NC>
+static void launch_scope_hist(rfx_ctx *c, const Plan &P, int key_idx, int nwg, ScopePart *parts) {
+    if (P.npred == 0) hipLaunchKernelGGL((k_part_scope_hist<NC, 0>), dim3(nwg), dim3(RFX_BLOCK), 0, c->stream, P, key_idx, c->d_pc_counts, parts);
+    else hipLaunchKernelGGL((k_part_scope_hist<NC, RFX_MAX_PREDS>), dim3(nwg), dim3(RFX_BLOCK), 0, c->stream, P, key_idx, c->d_pc_counts, parts);
+}
+
+static inline int part_nwg(const rfx_ctx *c) { return c->num_cus * ((c->flags & 8) ? 3 : 2); } // in-process A/B: 2 per CU beat 3 by ~3 %
+
+// predicate signature (column POINTERS, not plan indices: the scope plan and the accumulate plan order columns differently)
+static void plan_pred_sig(const Plan &P, u64 (*sig)[6]) {
+    for (int i = 0; i < P.npred; i++) {
+        const PlanPred &q = P.preds[i];
+        sig[i][0] = (u64)(uintptr_t)P.cols[q.col];
+        sig[i][1] = q.rhs_col >= 0 ? (u64)(uintptr_t)P.cols[q.rhs_col] : 0;
+        sig[i][2] = (u64)q.op;
+        sig[i][3] = (u64)(q.dom_f64 | (q.lhs_cvt << 1) | (q.rhs_cvt << 2));
+        sig[i][4] = q.rhs_bits;
+        sig[i][5] = 0;
+    }
+}
+
+// Called by rfx_hip_scope_i64 for inputs the partitioned path will take.  RFX_ESTATE = not applicable.
+int rfx_part_scope_hist(rfx_ctx *c, const int64_t *d_key, const rfx_pred_t *preds, int npred, int logic, i64 nrows, i64 *kmin, i64 *kmax,
+                        i64 *seen) {
+    c->pc_valid = 0;
+    if ((c->flags & 2) || (c->flags & 128) || nrows >= (1LL << 32) || nrows < (1 << 16)) return RFX_ESTATE;
+    Plan P;
+    int key_idx = 0;
+    int rc = rfx_plan_build(&P, preds, npred, logic, NULL, 0, d_key, &key_idx, nrows, 0);
+    if (rc != RFX_OK) return rc;
+    if (P.ncols > 4) return RFX_ESTATE;
+    const int nwg = part_nwg(c);
+    if (!c->d_pc_counts) RFX_HIP_CHECK(hipMalloc((void **)&c->d_pc_counts, (size_t)1024 * 3 * 256 * 8));
+    rc = rfx_ws_reserve(c, (size_t)nwg * sizeof(ScopePart));
+    if (rc != RFX_OK) return rc;
+    ScopePart *d_parts = (ScopePart *)c->d_ws;
+    RFX_KERNEL_BEGIN(c);
+    switch (P.ncols) {
+        case 1: launch_scope_hist<1>(c, P, key_idx, nwg, d_parts); break;
+        case 2: launch_scope_hist<2>(c, P, key_idx, nwg, d_parts); break;
+        case 3: launch_scope_hist<3>(c, P, key_idx, nwg, d_parts); break;
+        default: launch_scope_hist<4>(c, P, key_idx, nwg, d_parts); break;
+    }
+    RFX_KERNEL_END(c);
+    RFX_HIP_CHECK(hipGetLastError());
+    static_assert(sizeof(ScopePart) == 32, "ScopePart layout");
+    RFX_REQUIRE((size_t)nwg * sizeof(ScopePart) <= c->pin_bytes, RFX_ELIMIT, "pinned staging too small");
+    ScopePart *h = (ScopePart *)c->h_pin;
+    RFX_HIP_CHECK(hipMemcpyAsync(h, d_parts, (size_t)nwg * sizeof(ScopePart), hipMemcpyDeviceToHost, c->stream));
+    RFX_HIP_CHECK(hipStreamSynchronize(c->stream));
+    i64 mn = RFX_INF_I64_D, mx = RFX_NULL_I64_D, sel = 0, nulls = 0;
+    for (int w = 0; w < nwg; w++) {
+        mn = h[w].mn < mn ? h[w].mn : mn;
+        mx = h[w].mx > mx ? h[w].mx : mx;
+        sel += h[w].sel;
+        nulls += h[w].nulls;
+    }
+    *seen = sel;
+    if (nulls > 0) { // a null key is the value INT64_MIN for index_scope_i64
+        mn = RFX_NULL_I64_D;
+        if (nulls == sel) mx = RFX_NULL_I64_D;
+    }
+    *kmin = mn;
+    *kmax = mx;
+    if (sel > 0 && nulls == 0) {
+        c->pc_valid = 1;
+        c->pc_key = d_key;
+        c->pc_nrows = nrows;
+        c->pc_npred = npred;
+        c->pc_logic = logic;
+        c->pc_nwg = nwg;
+        plan_pred_sig(P, c->pc_sig);
+    }
+    return RFX_OK;
+}
+
 // ---- offsets: offsets[w][p] = part_start[p] + sum_{w' < w} counts[w'][p] ----
 __global__ __launch_bounds__(RFX_BLOCK) void k_part_colscan(const PartArgs A, int nwg) {
     const int p = blockIdx.x * RFX_BLOCK + threadIdx.x;
@@ -160,7 +293,7 @@ __global__ __launch_bounds__(RFX_BLOCK) void k_part_scatter(const Plan P, const 
             rank[e] = 0;
             if (((m0 >> e) & 1u) && slot < (u64)A.range) {
                 m |= 1u << e;
-                part[e] = (unsigned)(slot >> A.lb);
+                part[e] = A.lowbit ? (unsigned)(key[e] & 255ULL) : (unsigned)(slot >> A.lb);
                 rank[e] = atomicAdd(&thist[part[e]], 1u);
             }
         }
@@ -201,7 +334,7 @@ __global__ __launch_bounds__(RFX_BLOCK) void k_part_scatter(const Plan P, const 
             const unsigned idx = thist[part[e]] + rank[e];
             const u64 slot = key[e] - (u64)A.kmin;
             const u64 lrow = (u64)(base + (i64)(e >> 1) * (RFX_BLOCK * 2) + (e & 1));
-            stag[idx] = (lrow << 32) | (slot & ((1ULL << A.lb) - 1));
+            stag[idx] = (lrow << 32) | (A.lowbit ? (slot >> 8) : (slot & ((1ULL << A.lb) - 1)));
             stag_p[idx] = (unsigned short)part[e];
         }
 #pragma unroll
@@ -325,7 +458,7 @@ __global__ __launch_bounds__(PART_AGG_THREADS) void k_part_aggregate(const Plan 
     for (i64 i = tid; i < local; i += PART_AGG_THREADS) {
         const u64 f = smem[i];
         if (f == (u64)RFX_INF_I64_D) continue;
-        const i64 g = gbase + i;
+        const i64 g = A.lowbit ? ((i << 8) | (i64)(((u64)p - (u64)A.kmin) & 255ULL)) : (gbase + i);
         if (g >= A.range) continue;
         if (f < A.first[g]) atomicMin((unsigned long long *)&A.first[g], (unsigned long long)f);
 #pragma unroll
@@ -376,11 +509,13 @@ static int launch_part(rfx_ctx *c, const Plan &P, const PartArgs &A, int nwg) {
     Ph.ncols = nh;
     Ph.nagg = 0;
     Ah.key_idx = map[A.key_idx];
-    switch (nh) {
-        case 1: launch_hist<1>(c, Ph, Ah, nwg); break;
-        case 2: launch_hist<2>(c, Ph, Ah, nwg); break;
-        case 3: launch_hist<3>(c, Ph, Ah, nwg); break;
-        default: launch_hist<4>(c, Ph, Ah, nwg); break;
+    if (!A.lowbit) {
+        switch (nh) {
+            case 1: launch_hist<1>(c, Ph, Ah, nwg); break;
+            case 2: launch_hist<2>(c, Ph, Ah, nwg); break;
+            case 3: launch_hist<3>(c, Ph, Ah, nwg); break;
+            default: launch_hist<4>(c, Ph, Ah, nwg); break;
+        }
     }
     hipLaunchKernelGGL(k_part_colscan, dim3((A.nparts + RFX_BLOCK - 1) / RFX_BLOCK), dim3(RFX_BLOCK), 0, c->stream, A, nwg);
     hipLaunchKernelGGL(k_part_startscan, dim3(1), dim3(PART_MAX), 0, c->stream, A);
@@ -414,13 +549,32 @@ int rfx_group_part_accumulate(rfx_ctx *c, const Plan &P, int key_idx, const rfx_
         }
         A.agg_plane[a] = j;
     }
-    // slots per partition: largest power of two whose tables fit the LDS budget
-    int lb = 0;
-    while ((1LL << (lb + 1)) * narr * 8 <= PART_LDS_BYTES) lb++;
-    if (lb < 8) return RFX_ESTATE;
-    const i64 nparts = (t->range + (1LL << lb) - 1) >> lb;
-    if (nparts > PART_MAX || nparts < 2) return RFX_ESTATE;
-    const int nwg = c->num_cus * ((c->flags & 8) ? 3 : 2); // in-process A/B (bench.py --ab 0,8): 2 workgroups per CU beat 3 by ~3 %
+    const int nwg = part_nwg(c);
+    // Did rfx_hip_scope_i64 just leave the low-bit histogram of exactly these rows?  Then pass 0 is already done.
+    int lowbit = 0, lb = 0;
+    if (c->pc_valid && c->pc_key == (const void *)P.cols[key_idx] && c->pc_nrows == P.nrows && c->pc_npred == P.npred && c->pc_logic == P.logic &&
+        c->pc_nwg == nwg && t->range > 256) {
+        u64 sig[RFX_MAX_PREDS][6];
+        plan_pred_sig(P, sig);
+        lowbit = (P.npred == 0) || memcmp(sig, c->pc_sig, sizeof(u64) * 6 * (size_t)P.npred) == 0;
+        if (lowbit) {
+            const i64 per = (t->range + 255) >> 8; // slots per partition: those congruent to one residue mod 256
+            while ((1LL << lb) < per) lb++;
+            if ((1LL << lb) * narr * 8 > PART_LDS_BYTES) lowbit = 0;
+        }
+    }
+    c->pc_valid = 0; // consumed (or stale) either way
+    i64 nparts;
+    if (lowbit) nparts = 256;
+    else {
+        // slots per partition: largest power of two whose tables fit the LDS budget
+        lb = 0;
+        while ((1LL << (lb + 1)) * narr * 8 <= PART_LDS_BYTES) lb++;
+        if (lb < 8) return RFX_ESTATE;
+        nparts = (t->range + (1LL << lb) - 1) >> lb;
+        if (nparts > PART_MAX || nparts < 2) return RFX_ESTATE;
+    }
+    A.lowbit = lowbit;
     A.kmin = t->kmin;
     A.range = t->range;
     A.lb = lb;
@@ -443,6 +597,7 @@ int rfx_group_part_accumulate(rfx_ctx *c, const Plan &P, int key_idx, const rfx_
     A.part_start = (u64 *)w;
     w += (start_bytes + 255) & ~(size_t)255;
     A.recs = (u64 *)w;
+    if (lowbit) A.offsets = c->d_pc_counts; // [nwg][256] counts from the fused scope pass, scanned in place below
     A.first = (u64 *)t->d_first;
     for (int a = 0; a < t->nagg; a++) {
         A.acc[a] = (u64 *)t->d_acc[a];

@@ -247,9 +247,16 @@ extern "C" int rfx_hip_filter_aggr_host(rfx_ctx_t *c, const rfx_pred_t *preds, i
 }
 
 // ---------------- K6: key scope ----------------
+int rfx_part_scope_hist(rfx_ctx *c, const int64_t *d_key, const rfx_pred_t *preds, int npred, int logic, i64 nrows, i64 *kmin, i64 *kmax,
+                        i64 *seen); // rfx_group_part.hip
 extern "C" int rfx_hip_scope_i64(rfx_ctx_t *c, const int64_t *d_key, const rfx_pred_t *preds, int npred, int logic,
                                  int64_t nrows, int64_t *min, int64_t *max, int64_t *count) {
     RFX_REQUIRE(c && d_key && min && max && count, RFX_EINVAL, "NULL argument");
+    {
+        // large inputs: one pass that also leaves the partition histogram for the group-by that usually follows
+        int prc = rfx_part_scope_hist(c, d_key, preds, npred, logic, nrows, (i64 *)min, (i64 *)max, (i64 *)count);
+        if (prc != RFX_ESTATE) return prc;
+    }
     rfx_agg_t aggs[2] = {{d_key, RFX_I64, RFX_AGG_MIN}, {d_key, RFX_I64, RFX_AGG_MAX}};
     rfx_value_t v[2];
     int64_t sel = 0;
