@@ -143,6 +143,8 @@ def run_workload(name, eng, sharded, rows, row0, steps, warmup, world):
     job = Job(name, eng, sharded, rows, row0)
     dt, kms, res = timed(job, steps, warmup, world)
     ms_step = dt * 1e3 / steps
+    if name == "c3":
+        kms = ms_step  # several dependent kernels (scope+hist, scatter, aggregate, rank, emit): price the whole query
     value = world * rows / (dt / steps)
     alg_bytes = w["bytes_per_row"] * rows  # per launch, per GPU (SURVEY 8d figures, stated in DESIGN.md)
     achieved = alg_bytes / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
@@ -307,6 +309,15 @@ def main():
         except Exception as e:  # noqa: BLE001
             log(f"[bench] cpu_baseline failed: {e}")
             cpu = None
+        # the reference's CPU path beside the secondary workloads too (smaller samples: the whole run stays within minutes)
+        for other in also:
+            if other in ("c2b", "c3", "c5") and "error" not in also[other]:
+                try:
+                    cb = cpu_baseline(other, min(20_000_000, WORKLOADS[other]["rows"]))
+                    also[other]["cpu_baseline"] = {k: cb[k] for k in ("value", "unit", "cores", "kind", "ms_per_query")}
+                    also[other]["cpu_baseline"]["sample_rows"] = min(20_000_000, WORKLOADS[other]["rows"])
+                except Exception as e:  # noqa: BLE001
+                    log(f"[bench] cpu_baseline({other}) failed: {e}")
 
     if rank == 0:
         w = WORKLOADS[name]

@@ -121,7 +121,14 @@ int rfx_hip_ctx_create(int device, void *stream, rfx_ctx_t **out);
 int rfx_hip_ctx_destroy(rfx_ctx_t *ctx);
 int rfx_hip_ctx_sync(rfx_ctx_t *ctx);                 /* (syncs) */
 int rfx_hip_ctx_set_stream(rfx_ctx_t *ctx, void *stream);
-/* Tuning knobs for the streaming kernels (0 = keep default). */
+/* Tuning / path-selection knobs (tests use them to force every code path; 0 = defaults).
+ * blocks_per_cu scales the workgroups-per-CU choice of the streaming kernels (2 = as tuned). */
+enum {
+    RFX_TUNE_NO_LDS_TABLES = 1,   /* dense group-by: never privatise tables in LDS */
+    RFX_TUNE_NO_PARTITION = 2,    /* dense group-by: never take the radix-partitioned path (device-scope atomics instead) */
+    RFX_TUNE_PART_3WG = 8,        /* partitioned path: 3 scatter workgroups per CU instead of 2 */
+    RFX_TUNE_NO_FUSED_SCOPE = 128 /* rfx_hip_scope_i64: plain min/max pass, no partition histogram side product */
+};
 int rfx_hip_ctx_tune(rfx_ctx_t *ctx, int blocks_per_cu, int flags);
 
 /* ---- plain device memory for C hosts (Python hosts pass torch-owned pointers instead) ---- */

@@ -221,8 +221,8 @@ extern "C" int rfx_hip_group_dense_accumulate(rfx_ctx_t *c, const int64_t *d_key
         narr += 1 + (agg_has_cnt(aggs[a].kind, aggs[a].col_type == RFX_F64) ? 1 : 0);
     }
     size_t lds_bytes = (size_t)narr * (size_t)t->range * 8;
-    const bool use_lds = lds_bytes <= RFX_LDS_GROUP_BYTES && !(c->flags & 1);
-    if (!use_lds && !(c->flags & 2)) {
+    const bool use_lds = lds_bytes <= RFX_LDS_GROUP_BYTES && !(c->flags & RFX_TUNE_NO_LDS_TABLES);
+    if (!use_lds && !(c->flags & RFX_TUNE_NO_PARTITION)) {
         rc = rfx_group_part_accumulate(c, P, key_idx, t);
         if (rc != RFX_ESTATE) return rc; // RFX_ESTATE = "partitioned path not applicable", fall through to atomics
     }

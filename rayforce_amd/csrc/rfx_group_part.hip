@@ -164,7 +164,7 @@ static void launch_scope_hist(rfx_ctx *c, const Plan &P, int key_idx, int nwg, S
     else hipLaunchKernelGGL((k_part_scope_hist<NC, RFX_MAX_PREDS>), dim3(nwg), dim3(RFX_BLOCK), 0, c->stream, P, key_idx, c->d_pc_counts, parts);
 }
 
-static inline int part_nwg(const rfx_ctx *c) { return c->num_cus * ((c->flags & 8) ? 3 : 2); } // in-process A/B: 2 per CU beat 3 by ~3 %
+static inline int part_nwg(const rfx_ctx *c) { return c->num_cus * ((c->flags & RFX_TUNE_PART_3WG) ? 3 : 2); } // in-process A/B: 2 per CU beat 3 by ~3 %
 
 // predicate signature (column POINTERS, not plan indices: the scope plan and the accumulate plan order columns differently)
 static void plan_pred_sig(const Plan &P, u64 (*sig)[6]) {
@@ -183,7 +183,7 @@ static void plan_pred_sig(const Plan &P, u64 (*sig)[6]) {
 int rfx_part_scope_hist(rfx_ctx *c, const int64_t *d_key, const rfx_pred_t *preds, int npred, int logic, i64 nrows, i64 *kmin, i64 *kmax,
                         i64 *seen) {
     c->pc_valid = 0;
-    if ((c->flags & 2) || (c->flags & 128) || nrows >= (1LL << 32) || nrows < (1 << 16)) return RFX_ESTATE;
+    if ((c->flags & (RFX_TUNE_NO_PARTITION | RFX_TUNE_NO_FUSED_SCOPE)) || nrows >= (1LL << 32) || nrows < (1 << 16)) return RFX_ESTATE;
     Plan P;
     int key_idx = 0;
     int rc = rfx_plan_build(&P, preds, npred, logic, NULL, 0, d_key, &key_idx, nrows, 0);

@@ -47,7 +47,7 @@ enum { F_SUM, F_AVG, F_MIN, F_MAX, F_COUNT, F_FIRST, F_EQ, F_NE, F_LT, F_GT, F_L
 static const char *HOST_FN[F_N] = {"ray_sum", "ray_avg", "ray_min", "ray_max", "ray_count", "ray_first", "ray_eq", "ray_ne",
                                    "ray_lt",  "ray_gt",  "ray_le",  "ray_ge",  "ray_and",   "ray_or",    "ray_select"};
 static void *OUR_FN[F_N];
-static char g_err[512];
+static char g_err[640];
 static int g_last_gpu = 0;
 
 const char *rfx_ops_last_error(void) { return g_err; }

@@ -263,7 +263,7 @@ extern "C" int rfx_hip_where_begin(rfx_ctx_t *c, const rfx_pred_t *preds, int np
         RFX_HIP_CHECK(hipMalloc((void **)&c->d_blksum, ((size_t)nchunks + 2) * 8));
         c->blksum_cap = (size_t)nchunks + 2;
     }
-    int grid = c->num_cus * ((c->flags & 512) ? 8 : 4);
+    int grid = c->num_cus * 4;
     if ((i64)grid * 4 > nchunks) grid = (int)((nchunks + 3) / 4);
     RFX_KERNEL_BEGIN(c);
     if (d_mask) {
@@ -303,7 +303,7 @@ extern "C" int rfx_hip_where_emit(rfx_ctx_t *c, int64_t row0, int64_t *d_ids) {
     if (c->where_count == 0) return RFX_OK;
     RFX_REQUIRE(d_ids, RFX_EINVAL, "d_ids is NULL");
     const i64 nchunks = (c->where_n + RFX_CHUNK - 1) / RFX_CHUNK;
-    int grid = c->num_cus * ((c->flags & 1024) ? 32 : 16);
+    int grid = c->num_cus * 16;
     if ((i64)grid * 4 > nchunks) grid = (int)((nchunks + 3) / 4);
     hipLaunchKernelGGL(k_emit_ids, dim3(grid), dim3(RFX_BLOCK), 0, c->stream, (const u64 *)c->d_bitmap, (const i64 *)c->d_blksum, c->where_n,
                        (i64)row0, (i64 *)d_ids);

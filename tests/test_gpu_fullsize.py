@@ -72,7 +72,7 @@ def test_c3_group_by_full_size(eng, big):
     assert torch.equal(eng.at_ids(big["k"], first), keys)  # the key at each group's first row is that group's key
     assert int(maxa.max()) == 999_999
     # the same query through device-scope atomics (tune flag 2 disables the partitioned path): integer outputs identical
-    eng.tune(flags=2)
+    eng.tune(flags=2)  # RFX_TUNE_NO_PARTITION
     try:
         r2 = eng.group_by("k", [("sum", "v"), ("count", "v"), ("max", "a")], None, big)
     finally:

@@ -285,3 +285,17 @@ def test_sharded_engine_single_rank(eng):
     assert np.array_equal(r["keys"].cpu().numpy(), w["k"]) and np.array_equal(r["results"][1].cpu().numpy(), w["c"])
     same_f64(r["results"][0].cpu().numpy(), w["s"])
     assert np.array_equal(sh.where(("<", "a", 1000), d).cpu().numpy(), rfo.where(rfo.mask_of(("<", "a", 1000), host)))
+
+
+@pytest.mark.parametrize("flags", [0, 1, 2, 3, 8, 128])
+def test_group_by_every_code_path_agrees(eng, flags):
+    """RFX_TUNE_* force the LDS-table / partitioned (fused and unfused scope) / device-atomic paths: same answers."""
+    n = 400_003
+    try:
+        eng.tune(flags=flags)
+        for keys in (900, 60_000, 300_000):
+            host = table(n, keys=keys, nulls=True)
+            check_select(eng, host, {"by": "k", "s": ("sum", "v"), "si": ("sum", "a"), "c": ("count", "a"), "mx": ("max", "w"), "av": ("avg", "a")})
+            check_select(eng, host, {"where": ("<", "a", 300_000), "by": "k", "s": ("sum", "v"), "mn": ("min", "a")})
+    finally:
+        eng.tune(flags=0)
