@@ -126,7 +126,8 @@ int rfx_hip_ctx_set_stream(rfx_ctx_t *ctx, void *stream);
 enum {
     RFX_TUNE_NO_LDS_TABLES = 1,   /* dense group-by: never privatise tables in LDS */
     RFX_TUNE_NO_PARTITION = 2,    /* dense group-by: never take the radix-partitioned path (device-scope atomics instead) */
-    RFX_TUNE_PART_3WG = 8,        /* partitioned path: 3 scatter workgroups per CU instead of 2 */
+    RFX_TUNE_PART_3WG = 8,
+    RFX_TUNE_NO_WRITE_COMBINE = 16, /* partitioned path: plain sorted-tile scatter instead of 128-byte write combining */        /* partitioned path: 3 scatter workgroups per CU instead of 2 */
     RFX_TUNE_NO_FUSED_SCOPE = 128 /* rfx_hip_scope_i64: plain min/max pass, no partition histogram side product */
 };
 int rfx_hip_ctx_tune(rfx_ctx_t *ctx, int blocks_per_cu, int flags);

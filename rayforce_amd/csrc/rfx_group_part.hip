@@ -27,6 +27,9 @@
 #define PART_MAX 1024       /* max partitions */
 #define PART_LDS_BYTES (64 * 1024)
 #define PART_AGG_THREADS 512
+#define WC_B 8 /* write-combining scatter: records per store group = 128 bytes */
+#define WC_MAXP 256
+#define WC_SENTINEL 0xFFFFFFFFFFFFFFFFULL
 
 struct PartArgs {
     i64 kmin, range;
@@ -38,6 +41,7 @@ struct PartArgs {
     int agg_plane[RFX_MAX_AGGS]; // aggregate a reads plane agg_plane[a] (-1: none, COUNT / FIRST)
     int narr;                  // table arrays per slot (first + acc + cnt ...)
     int split;                 // workgroups per partition in pass 2
+    int wc;                    // 1: write-combining scatter (regions padded to 8 records, sentinel records possible)
     int lowbit;                // 1: partition = key & 255 (known before the scope is), local slot = (key - kmin) >> 8
     u64 *offsets;              // [nwg][nparts] : counts, then exclusive offsets
     u64 *part_start;           // [nparts + 1]
@@ -241,7 +245,8 @@ __global__ __launch_bounds__(RFX_BLOCK) void k_part_colscan(const PartArgs A, in
     u64 run = 0;
     for (int w = 0; w < nwg; w++) {
         const size_t i = (size_t)w * A.nparts + p;
-        const u64 c = A.offsets[i];
+        u64 c = A.offsets[i];
+        if (A.wc) c = (c + WC_B - 1) / WC_B * WC_B; // every (workgroup, partition) region is whole 128-byte groups
         A.offsets[i] = run;
         run += c;
     }
@@ -374,6 +379,128 @@ __global__ __launch_bounds__(RFX_BLOCK) void k_part_scatter(const Plan P, const 
     }
 }
 
+// ---- pass 1, write-combining form (one value plane, <= 256 partitions: the C3 shape) ----
+// rocprofv3 PMC A/B with IDENTICAL instruction streams (profiles/): the sorted-tile scatter above
+// spends 11.7 ms where the same kernel storing each tile contiguously spends 6.3 ms.  The difference is entirely in the
+// L2: a partition's run of ~8 records starts at an arbitrary 16-byte offset, so 64-byte sectors are completed by two
+// different store instructions (or evicted half-written): TCC_WRITE 354 M vs 250 M requests, 91 M of the 370 M fabric
+// writes are 32-byte partials, TCC_EA0_WRREQ_STALL 346 M vs 135 M cycles.
+// Here each (workgroup, partition) keeps its last < 8 records in an LDS carry buffer and only ever stores whole,
+// 128-byte aligned groups of 8 records; the tail is flushed once at the end, padded with sentinel records
+// (slot field 0xFFFFFFFF) that pass 2 skips.  Every (workgroup, partition) region is padded to a multiple of 8 records.
+template <int NC, int NP>
+__global__ __launch_bounds__(RFX_BLOCK) void k_part_scatter_wc(const Plan P, const PartArgs A) {
+    __shared__ unsigned thist[WC_MAXP];   // per tile: count, then exclusive tile offset
+    __shared__ unsigned tcnt[WC_MAXP];    // per tile: count
+    __shared__ unsigned pre[WC_MAXP];     // records carried over from earlier tiles (< WC_B)
+    __shared__ unsigned pfl[WC_MAXP];     // records of (carry ++ tile) that leave for global memory now (multiple of WC_B)
+    __shared__ u64 cursor[WC_MAXP];       // next global record index of (this workgroup, partition), multiple of WC_B
+    __shared__ u64x2 carry[WC_MAXP][WC_B];
+    __shared__ u64x2 stag[PART_TILE_ROWS];
+    __shared__ unsigned short stag_p[PART_TILE_ROWS];
+    __shared__ unsigned scan_w[RFX_BLOCK / RFX_WAVE];
+    __shared__ unsigned tile_total;
+    PredSet<NP> S;
+    predset_load<NP>(P, S);
+    const int tid = threadIdx.x;
+    const int np = A.nparts;
+    u64x2 *__restrict__ recs = (u64x2 *)A.recs;
+    if (tid < np) {
+        cursor[tid] = A.part_start[tid] + A.offsets[(size_t)blockIdx.x * np + tid];
+        pre[tid] = 0;
+    }
+    const int vc = A.vcol[0];
+    const i64 ntiles = (P.nrows + PART_TILE_ROWS - 1) / PART_TILE_ROWS;
+    for (i64 t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        if (tid < np) thist[tid] = 0;
+        __syncthreads();
+        u64 v[NC][8];
+        const unsigned m0 = part_load_eval<NC, NP>(P, S, t, v);
+        u64 key[8], val[8];
+        sel_col<NC, 8>(key, v, A.key_idx);
+        sel_col<NC, 8>(val, v, vc);
+        unsigned m = 0, part[8], rank[8];
+        const i64 base = t * PART_TILE_ROWS + tid * 2;
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const u64 slot = key[e] - (u64)A.kmin;
+            part[e] = 0;
+            rank[e] = 0;
+            if (((m0 >> e) & 1u) && slot < (u64)A.range) {
+                m |= 1u << e;
+                part[e] = A.lowbit ? (unsigned)(key[e] & 255ULL) : (unsigned)(slot >> A.lb);
+                rank[e] = atomicAdd(&thist[part[e]], 1u);
+            }
+        }
+        __syncthreads();
+        // one lane per partition: exclusive scan of the tile counts + the flush decision
+        {
+            const unsigned x = (tid < np) ? thist[tid] : 0;
+            unsigned inc = x;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                unsigned o = __shfl_up(inc, d, 64);
+                if ((tid & 63) >= d) inc += o;
+            }
+            if ((tid & 63) == 63) scan_w[tid >> 6] = inc;
+            __syncthreads();
+            unsigned wbase = 0;
+            for (int w = 0; w < (tid >> 6); w++) wbase += scan_w[w];
+            if (tid < np) {
+                thist[tid] = wbase + inc - x;
+                tcnt[tid] = x;
+                pfl[tid] = ((pre[tid] + x) / WC_B) * WC_B;
+            }
+            if (tid == RFX_BLOCK - 1) tile_total = wbase + inc;
+        }
+        __syncthreads();
+        // stage this tile's records in partition order
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            if (!((m >> e) & 1u)) continue;
+            const unsigned idx = thist[part[e]] + rank[e];
+            const u64 slot = key[e] - (u64)A.kmin;
+            const u64 lrow = (u64)(base + (i64)(e >> 1) * (RFX_BLOCK * 2) + (e & 1));
+            u64x2 r;
+            r.x = (lrow << 32) | (A.lowbit ? (slot >> 8) : (slot & ((1ULL << A.lb) - 1)));
+            r.y = val[e];
+            stag[idx] = r;
+            stag_p[idx] = (unsigned short)part[e];
+        }
+        // old carry -> global for the partitions that flush (positions 0 .. pre-1 of their sequence)
+        for (int idx = tid; idx < np * WC_B; idx += RFX_BLOCK) {
+            const int p = idx / WC_B, j = idx % WC_B;
+            if ((unsigned)j < pre[p] && pfl[p] > 0) recs[cursor[p] + j] = carry[p][j];
+        }
+        __syncthreads();
+        // new records: the first (pfl - pre) of a partition complete the 128-byte groups, the rest is the new carry
+        const unsigned total = tile_total;
+        for (unsigned i = tid; i < total; i += RFX_BLOCK) {
+            const unsigned p = stag_p[i];
+            const unsigned pos = pre[p] + (i - thist[p]);
+            if (pos < pfl[p]) recs[cursor[p] + pos] = stag[i];
+            else carry[p][pos - pfl[p]] = stag[i];
+        }
+        __syncthreads();
+        if (tid < np) {
+            const unsigned tot = pre[tid] + tcnt[tid];
+            cursor[tid] += pfl[tid];
+            pre[tid] = tot - pfl[tid];
+        }
+        __syncthreads();
+    }
+    // tails: one padded 128-byte group per partition that still carries records
+    for (int idx = tid; idx < np * WC_B; idx += RFX_BLOCK) {
+        const int p = idx / WC_B, j = idx % WC_B;
+        if (pre[p] > 0) {
+            u64x2 r;
+            r.x = WC_SENTINEL;
+            r.y = 0;
+            recs[cursor[p] + j] = ((unsigned)j < pre[p]) ? carry[p][j] : r;
+        }
+    }
+}
+
 // ---- pass 2: per-partition LDS aggregation ----
 template <int NV>
 __global__ __launch_bounds__(PART_AGG_THREADS) void k_part_aggregate(const Plan P, const PartArgs A) {
@@ -437,7 +564,7 @@ __global__ __launch_bounds__(PART_AGG_THREADS) void k_part_aggregate(const Plan 
         }
 #pragma unroll
         for (int r = 0; r < RU; r++) {
-            if (!in[r]) continue;
+            if (!in[r] || (unsigned)h[r] == 0xffffffffu) continue; // padding of the write-combining scatter
             const u64 slot = h[r] & 0xffffffffULL;
             const u64 row = row0 + (h[r] >> 32);
             if (row < smem[slot]) atomicMin((unsigned long long *)&smem[slot], (unsigned long long)row);
@@ -521,7 +648,12 @@ static int launch_part(rfx_ctx *c, const Plan &P, const PartArgs &A, int nwg) {
     hipLaunchKernelGGL(k_part_startscan, dim3(1), dim3(PART_MAX), 0, c->stream, A);
     switch (A.nv) {
         case 0: launch_scatter<NC, 0>(c, P, A, nwg); break;
-        case 1: launch_scatter<NC, 1>(c, P, A, nwg); break;
+        case 1:
+            if (A.wc) {
+                if (P.npred == 0) hipLaunchKernelGGL((k_part_scatter_wc<NC, 0>), dim3(nwg), dim3(RFX_BLOCK), 0, c->stream, P, A);
+                else hipLaunchKernelGGL((k_part_scatter_wc<NC, RFX_MAX_PREDS>), dim3(nwg), dim3(RFX_BLOCK), 0, c->stream, P, A);
+            } else launch_scatter<NC, 1>(c, P, A, nwg);
+            break;
         case 2: launch_scatter<NC, 2>(c, P, A, nwg); break;
         default: launch_scatter<NC, 3>(c, P, A, nwg); break;
     }
@@ -584,7 +716,8 @@ int rfx_group_part_accumulate(rfx_ctx *c, const Plan &P, int key_idx, const rfx_
     // enough workgroups in pass 2 to fill the chip (two 512-thread workgroups per CU)
     A.split = (int)((2 * c->num_cus + nparts - 1) / nparts);
     if (A.split < 1) A.split = 1;
-    A.cap = ((P.nrows + 63) / 64) * 64;
+    A.wc = (A.nv == 1 && nparts <= WC_MAXP && !(c->flags & RFX_TUNE_NO_WRITE_COMBINE)) ? 1 : 0;
+    A.cap = ((P.nrows + 63) / 64) * 64 + (A.wc ? (i64)nwg * nparts * WC_B : 0);
     const size_t off_bytes = (size_t)nwg * nparts * 8;
     const size_t start_bytes = (size_t)(nparts + 2) * 8;
     const size_t rec_bytes = (size_t)(1 + A.nv) * A.cap * 8;
