@@ -127,6 +127,7 @@ enum {
     RFX_TUNE_NO_LDS_TABLES = 1,   /* dense group-by: never privatise tables in LDS */
     RFX_TUNE_NO_PARTITION = 2,    /* dense group-by: never take the radix-partitioned path (device-scope atomics instead) */
     RFX_TUNE_PART_3WG = 8,
+    RFX_TUNE_DIRECT_WC = 32,      /* partitioned path, one value plane: register-direct write combining instead of the tile-sorted form */
     RFX_TUNE_NO_WRITE_COMBINE = 16, /* partitioned path: plain sorted-tile scatter instead of 128-byte write combining */        /* partitioned path: 3 scatter workgroups per CU instead of 2 */
     RFX_TUNE_NO_FUSED_SCOPE = 128 /* rfx_hip_scope_i64: plain min/max pass, no partition histogram side product */
 };
