@@ -313,6 +313,62 @@ static int plan_where(obj_p tab, obj_p w, wplan_t *wp) {
     return 0;
 }
 
+
+/* ---- nested boolean trees: evaluated the way the reference does (mask per comparison, and/or in place, where), but on
+ * the GPU: core/cmp.c -> K2 rfx_hip_cmp_mask, core/logic.c -> rfx_hip_mask_logic, core/ops.c:254 -> K3 ---- */
+static int mask_of_expr(obj_p tab, obj_p e, int64_t nrows, int8_t **out) {
+    *out = NULL;
+    if (!e || e->type != RFX_TYPE_LIST || e->len < 2) return -1;
+    int f = fn_id(RFX_AS_LIST(e)[0]);
+    void *m = NULL;
+    if (f >= F_EQ && f <= F_GE) {
+        rfx_pred_t p;
+        int rc = plan_cmp(tab, e, &p);
+        if (rc) return rc;
+        if (rfx_hip_malloc(g_ctx, &m, (size_t)nrows + 16) != RFX_OK) return -2;
+        if (rfx_hip_cmp_mask(g_ctx, &p, nrows, (int8_t *)m) != RFX_OK) { rfx_hip_free(g_ctx, m); return -2; }
+        *out = (int8_t *)m;
+        return 0;
+    }
+    if (f != F_AND && f != F_OR) return -1;
+    int8_t *acc = NULL;
+    for (int64_t i = 1; i < e->len; i++) {
+        int8_t *sub = NULL;
+        int rc = mask_of_expr(tab, RFX_AS_LIST(e)[i], nrows, &sub);
+        if (rc) { if (acc) rfx_hip_free(g_ctx, acc); return rc; }
+        if (!acc) acc = sub;
+        else {
+            rc = rfx_hip_mask_logic(g_ctx, f == F_AND ? RFX_AND : RFX_OR, acc, sub, 0, nrows);
+            rfx_hip_free(g_ctx, sub);
+            if (rc != RFX_OK) { rfx_hip_free(g_ctx, acc); return -2; }
+        }
+    }
+    *out = acc;
+    return 0;
+}
+
+/* selection of `where` as ascending device row ids (flat predicates fused, nested trees through masks) */
+static int where_ids(obj_p tab, obj_p where, const wplan_t *wp, int flat, int64_t nrows, int64_t **d_ids, int64_t *count) {
+    *d_ids = NULL;
+    *count = 0;
+    int8_t *mask = NULL;
+    int rc;
+    if (flat) rc = rfx_hip_where_begin(g_ctx, wp->preds, wp->npred, wp->logic, NULL, nrows, count) == RFX_OK ? 0 : -2;
+    else {
+        rc = mask_of_expr(tab, where, nrows, &mask);
+        if (rc == 0) rc = rfx_hip_where_begin(g_ctx, NULL, 0, RFX_AND, mask, nrows, count) == RFX_OK ? 0 : -2;
+    }
+    if (rc == 0 && *count > 0) {
+        void *d = NULL;
+        if (rfx_hip_malloc(g_ctx, &d, (size_t)*count * 8) != RFX_OK || rfx_hip_where_emit(g_ctx, 0, (int64_t *)d) != RFX_OK) {
+            if (d) rfx_hip_free(g_ctx, d);
+            rc = -2;
+        } else *d_ids = (int64_t *)d;
+    }
+    if (mask) rfx_hip_free(g_ctx, mask);
+    return rc;
+}
+
 static obj_p value_atom(const rfx_value_t *v) { return v->type == RFX_F64 ? H.f64(v->f) : H.i64(v->i); }
 static obj_p one_row(const rfx_value_t *v) {
     obj_p c = H.vector(v->type == RFX_F64 ? RFX_TYPE_F64 : RFX_TYPE_I64, 1);
@@ -348,9 +404,17 @@ rfx_obj_p rfx_select(rfx_obj_p dict) {
         obj_p tcols = RFX_AS_LIST(tab)[1];
         int64_t nrows = tcols->len ? RFX_AS_LIST(tcols)[0]->len : 0;
         wplan_t wp;
+        int flat = 1;
+        int64_t *d_ids = NULL, nsel = 0;
+        void *tmp[RFX_MAX_AGGS + 2];
+        int ntmp = 0;
         int rc = plan_where(tab, where, &wp);
         if (rc == -2) { res = fail_hip("column upload"); goto done; }
-        if (rc) { why = "where: shape"; goto out; }
+        if (rc) { /* not one comparison / one flat and|or: a nested tree, evaluated through masks */
+            flat = 0;
+            wp.npred = 0;
+            wp.logic = RFX_AND;
+        }
         /* output mappings */
         rfx_agg_t aggs[RFX_MAX_AGGS];
         int64_t names[RFX_MAX_AGGS];
@@ -375,12 +439,73 @@ rfx_obj_p rfx_select(rfx_obj_p dict) {
             outtype[nagg] = (f == F_AVG) ? RFX_TYPE_F64 : (f == F_COUNT) ? RFX_TYPE_I64 : c->type;
             names[nagg++] = k;
         }
+        obj_p kc = NULL;
+        const void *dk = NULL;
         if (by) {
             if (by->type != -RFX_TYPE_SYMBOL) { why = "by: is not a single column"; goto out; }
-            obj_p kc = table_col(tab, by->i64);
+            kc = table_col(tab, by->i64);
             if (!kc || kc->type != RFX_TYPE_I64) { why = "by: key is not an i64 column"; goto out; }
-            const void *dk;
             if (resident(kc, 0, &dk) != RFX_OK) { res = fail_hip("column upload"); goto done; }
+        }
+        if (!by && nagg == 0) {
+            /* projection: filter_collect of every column (core/filter.c:51-165): where -> ids -> gather */
+            if (!where) { res = H.clone(tab); g_last_gpu = 1; goto done; }
+            for (int64_t i = 0; i < tcols->len; i++)
+                if (!col_ctype(RFX_AS_LIST(tcols)[i])) { why = "projection of a non-8-byte column"; goto out; }
+            rc = where_ids(tab, where, &wp, flat, nrows, &d_ids, &nsel);
+            if (rc == -1) { why = "where: shape"; goto out; }
+            if (rc) { res = fail_hip("where"); goto done; }
+            obj_p rv = H.vector(RFX_TYPE_LIST, tcols->len);
+            void *dg = NULL;
+            int ok = nsel == 0 || rfx_hip_malloc(g_ctx, &dg, (size_t)nsel * 8) == RFX_OK;
+            for (int64_t i = 0; i < tcols->len && ok; i++) {
+                obj_p c = RFX_AS_LIST(tcols)[i];
+                obj_p o = H.vector(c->type, nsel);
+                RFX_AS_LIST(rv)[i] = o;
+                const void *dc;
+                if (nsel == 0) continue;
+                ok = resident(c, 0, &dc) == RFX_OK && rfx_hip_gather(g_ctx, dc, d_ids, nsel, dg) == RFX_OK &&
+                     rfx_hip_d2h(g_ctx, RFX_AS_RAW(o), dg, (size_t)nsel * 8) == RFX_OK;
+            }
+            if (dg) rfx_hip_free(g_ctx, dg);
+            if (d_ids) rfx_hip_free(g_ctx, d_ids);
+            if (!ok) { H.drop(rv); res = fail_hip("projection"); goto done; }
+            res = H.table(H.clone(RFX_AS_LIST(tab)[0]), rv);
+            g_last_gpu = 1;
+            goto done;
+        }
+        if (!flat) {
+            /* nested tree + aggregates: the reference's own plan (filter_collect then fold / group) on gathered columns */
+            rc = where_ids(tab, where, &wp, 0, nrows, &d_ids, &nsel);
+            if (rc == -1) { why = "where: shape"; goto out; }
+            if (rc) { res = fail_hip("where"); goto done; }
+            int ok = 1;
+            const void *seen_src[RFX_MAX_AGGS + 1];
+            void *seen_dst[RFX_MAX_AGGS + 1];
+            int nseen = 0;
+            for (int a = 0; a <= nagg && ok; a++) {
+                const void **slot = (a < nagg) ? &aggs[a].d_col : &dk;
+                if (a == nagg && !by) break;
+                if (!*slot) continue;
+                int j = 0;
+                for (; j < nseen; j++)
+                    if (seen_src[j] == *slot) break;
+                if (j == nseen) {
+                    void *g = NULL;
+                    ok = rfx_hip_malloc(g_ctx, &g, (size_t)(nsel ? nsel : 1) * 8) == RFX_OK &&
+                         (nsel == 0 || rfx_hip_gather(g_ctx, *slot, d_ids, nsel, g) == RFX_OK);
+                    if (g) tmp[ntmp++] = g;
+                    seen_src[nseen] = *slot;
+                    seen_dst[nseen++] = g;
+                }
+                if (ok) *slot = seen_dst[j];
+            }
+            if (d_ids) rfx_hip_free(g_ctx, d_ids);
+            d_ids = NULL;
+            if (!ok) { for (int i = 0; i < ntmp; i++) rfx_hip_free(g_ctx, tmp[i]); res = fail_hip("gather"); goto done; }
+            nrows = nsel;
+        }
+        if (by) {
             int64_t kmin, kmax, seen;
             if (rfx_hip_scope_i64(g_ctx, (const int64_t *)dk, wp.preds, wp.npred, wp.logic, nrows, &kmin, &kmax, &seen) != RFX_OK) { res = fail_hip("scope"); goto done; }
             int64_t groups = 0;
@@ -453,14 +578,18 @@ rfx_obj_p rfx_select(rfx_obj_p dict) {
                 RFX_AS_I64(rk)[a + 1] = names[a];
                 RFX_AS_LIST(rv)[a + 1] = ocols[a] ? ocols[a] : H.vector((int8_t)outtype[a], 0);
             }
+            for (int i = 0; i < ntmp; i++) rfx_hip_free(g_ctx, tmp[i]);
             res = H.table(rk, rv);
             g_last_gpu = 1;
             goto done;
         }
-        if (nagg == 0) { why = "projection without aggregates"; goto out; }
         rfx_value_t vals[RFX_MAX_AGGS];
         int64_t selected = 0;
-        if (rfx_hip_filter_aggr_host(g_ctx, wp.preds, wp.npred, wp.logic, aggs, nagg, nrows, vals, &selected) != RFX_OK) { res = fail_hip("filter_aggr"); goto done; }
+        {
+            int frc = rfx_hip_filter_aggr_host(g_ctx, wp.preds, wp.npred, wp.logic, aggs, nagg, nrows, vals, &selected);
+            for (int i = 0; i < ntmp; i++) rfx_hip_free(g_ctx, tmp[i]);
+            if (frc != RFX_OK) { res = fail_hip("filter_aggr"); goto done; }
+        }
         obj_p rk = H.vector(RFX_TYPE_SYMBOL, nagg), rv = H.vector(RFX_TYPE_LIST, nagg);
         for (int a = 0; a < nagg; a++) {
             RFX_AS_I64(rk)[a] = names[a];

@@ -37,9 +37,18 @@ def test_plugin_inside_the_real_reference(built):
             for o in outs:
                 s.out(f"g_{name}_{o}", f"(at g_{name} '{o})")
                 s.out(f"r_{name}_{o}", f"(at r_{name} '{o})")
-        # a shape the GPU path does not cover is handed back to the host's own ray_select by the plugin
+        # projection (filter_collect) and a nested boolean tree run on the GPU too ...
         s.eval("(set g_proj (gsel {from: t where: (< a 1000)}))")
         s.out("g_proj_a", "(at g_proj 'a)")
+        s.eval("(set g_nest (gsel {s: (sum a) from: t where: (and (or (< a 1000) (> v 0.9)) (!= k 3))}))")
+        s.eval("(set r_nest (select {s: (sum a) from: t where: (and (or (< a 1000) (> v 0.9)) (!= k 3))}))")
+        s.out("g_nest_s", "(at g_nest 's)")
+        s.out("r_nest_s", "(at r_nest 's)")
+        # ... and a shape the GPU path does not cover (f64 group key) is handed back to the host's own ray_select by the plugin
+        s.eval("(set g_del (gsel {c: (count a) from: t by: v}))")
+        s.eval("(set r_del (select {c: (count a) from: t by: v}))")
+        s.out("g_del_n", "(enlist (count (at g_del 'c)))")
+        s.out("r_del_n", "(enlist (count (at r_del 'c)))")
         # -c 8: the reference's page-aligned chunking (core/pool.c:495-507) overshoots small inputs when the pool is large
         # (it segfaults on this 300k-row table with 64+ executors, with or without the plugin) -- keep its pool small here
         res = s.run(threads=8)
@@ -52,3 +61,5 @@ def test_plugin_inside_the_real_reference(built):
             else:
                 assert np.array_equal(g, r), (name, o)
     assert np.array_equal(res["g_proj_a"], cols["a"][cols["a"] < 1000])
+    assert np.array_equal(res["g_nest_s"], res["r_nest_s"])
+    assert np.array_equal(res["g_del_n"], res["r_del_n"])

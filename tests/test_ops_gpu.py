@@ -83,10 +83,23 @@ def test_select_by_sparse_keys(ops):
     check(run_select(ops, host, {**q, "by": "k"}), rfo.select({"from": host, **q, "by": "k"}))
 
 
+def test_nested_tree_and_projection(ops):
+    host = host_table(200_003)
+    nested = ("and", ("or", ("<", "a", 1000), (">", "v", 0.9)), ("!=", "k", 3))
+    q = {"s": ("sum", "a"), "f": ("sum", "v"), "c": ("count", "a"), "fi": ("first", "a")}
+    check(run_select(ops, host, {**q, "where": nested}), rfo.select({"from": host, **q, "where": nested}))
+    assert ops.rfx_last_select_on_gpu() == 1
+    check(run_select(ops, host, {**q, "where": nested, "by": "k"}), rfo.select({"from": host, **q, "where": nested, "by": "k"}))
+    # projection = filter_collect of every column (core/filter.c:51-165), flat and nested predicates
+    check(run_select(ops, host, {"where": ("<", "a", 1000)}), rfo.select({"from": host, "where": ("<", "a", 1000)}))
+    check(run_select(ops, host, {"where": nested}), rfo.select({"from": host, "where": nested}))
+    check(run_select(ops, host, {"where": ("<", "a", -1)}), rfo.select({"from": host, "where": ("<", "a", -1)}))
+
+
 def test_unsupported_shape_fails_loudly_without_host(ops):
     host = host_table(100)
     with pytest.raises(RuntimeError, match="not covered by the MI355X path"):
-        run_select(ops, host, {"where": ("<", "a", 10)})  # projection without aggregates: the reference host would take it
+        run_select(ops, host, {"s": ("sum", "a"), "by": "v"})  # f64 group key: the reference host would take it
     assert ops.rfx_last_select_on_gpu() == 0
 
 
