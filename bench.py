@@ -132,7 +132,7 @@ def timed(job: Job, steps: int, warmup: int, world: int):
     dt = time.perf_counter() - t0
     eng.profile(False)
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=eng.device)
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else eng.device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t[0])
     return dt, sum(kms) / max(1, len(kms)), res
@@ -257,8 +257,14 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        backend = os.environ.get("RFX_BENCH_BACKEND", "nccl")  # "gloo" + RFX_BENCH_SAME_DEVICE=1: dry-run N ranks on ONE GPU
+        if os.environ.get("RFX_BENCH_SAME_DEVICE"):
+            local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     if args.gpus != world:
         log(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE")
     if not torch.cuda.is_available():

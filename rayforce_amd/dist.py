@@ -26,6 +26,32 @@ import torch.distributed as dist
 from . import _lib as L
 
 
+def _gloo(group=None) -> bool:
+    return dist.is_initialized() and dist.get_backend(group) == "gloo"
+
+
+def _all_reduce(t: torch.Tensor, op, group=None) -> None:
+    """all_reduce in place; under gloo a device tensor takes a host round trip (test mode: ranks sharing one GPU)."""
+    if _gloo(group) and t.is_cuda:
+        h = t.cpu()
+        dist.all_reduce(h, op=op, group=group)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=op, group=group)
+
+
+def _all_gather(t: torch.Tensor, group=None):
+    world = dist.get_world_size(group)
+    if _gloo(group) and t.is_cuda:
+        h = t.cpu()
+        bufs = [torch.empty_like(h) for _ in range(world)]
+        dist.all_gather(bufs, h, group=group)
+        return [b.to(t.device) for b in bufs]
+    bufs = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(bufs, t, group=group)
+    return bufs
+
+
 class RowShard:
     """Where this rank's rows sit in the global table."""
 
@@ -53,8 +79,7 @@ def merge_scalar_partials(partials: torch.Tensor, kinds: Sequence[int], col_type
     assert partials.dtype == torch.uint8 and partials.numel() == nbytes
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     if world > 1:
-        bufs = [torch.empty_like(partials) for _ in range(world)]
-        dist.all_gather(bufs, partials, group=group)
+        bufs = _all_gather(partials, group)
     else:
         bufs = [partials]
     host = [b.cpu().numpy().tobytes() for b in bufs]
@@ -99,7 +124,7 @@ def allreduce_tables(store: torch.Tensor, layout, kinds: Sequence[int], f64s: Se
         kind = kinds[a] if a is not None else -1
         f64 = f64s[a] if a is not None else False
         dt, op = _reduce_op(kind, f64, what)
-        dist.all_reduce(store[row].view(dt), op=op, group=group)
+        _all_reduce(store[row].view(dt), op, group)
 
 
 def allreduce_scope(kmin: int, kmax: int, seen: int, device, group=None) -> Tuple[int, int, int]:
@@ -108,9 +133,11 @@ def allreduce_scope(kmin: int, kmax: int, seen: int, device, group=None) -> Tupl
     # ranks that saw no row contribute neutral elements
     big = 2**63 - 1
     t = torch.tensor([kmin if seen else big, -(kmax if seen else -big), -seen], dtype=torch.int64, device=device)
-    dist.all_reduce(t[:2], op=dist.ReduceOp.MIN, group=group)
+    mm = t[:2].clone()
+    _all_reduce(mm, dist.ReduceOp.MIN, group)
+    t[:2] = mm
     s = t[2:].clone()
-    dist.all_reduce(s, op=dist.ReduceOp.SUM, group=group)
+    _all_reduce(s, dist.ReduceOp.SUM, group)
     mn, negmx = int(t[0]), int(t[1])
     return mn, -negmx, -int(s[0])
 
@@ -137,8 +164,7 @@ class GroupHook:
             world = self.shard.world
             if world == 1:
                 return None
-            bufs = [torch.empty_like(store) for _ in range(world)]
-            dist.all_gather(bufs, store, group=g)
+            bufs = _all_gather(store, g)
             for r, other in enumerate(bufs):
                 if r != self.shard.rank:
                     merge(make_tables(other))
@@ -153,14 +179,12 @@ def gather_ids(local_ids: torch.Tensor, group=None) -> torch.Tensor:
         return local_ids
     world = dist.get_world_size(group)
     cnt = torch.tensor([local_ids.numel()], dtype=torch.int64, device=local_ids.device)
-    cnts = [torch.empty_like(cnt) for _ in range(world)]
-    dist.all_gather(cnts, cnt, group=group)
+    cnts = _all_gather(cnt, group)
     sizes = [int(c[0]) for c in cnts]
     m = max(sizes) if sizes else 0
     pad = torch.zeros(m, dtype=torch.int64, device=local_ids.device)
     pad[: local_ids.numel()] = local_ids
-    bufs = [torch.empty_like(pad) for _ in range(world)]
-    dist.all_gather(bufs, pad, group=group)
+    bufs = _all_gather(pad, group)
     return torch.cat([b[:s] for b, s in zip(bufs, sizes)])
 
 
