@@ -15,6 +15,7 @@
  *   rfx_hip_where_* ......... ray_where -> ops_where, core/items.c:1366-1372, core/ops.c:254-273
  *   rfx_hip_gather .......... at_ids / at_ids_partial, core/rayforce.c:1036-1158
  *   rfx_hip_scope_i64 ....... index_scope_i64, core/index.c:376-435
+ *   rfx_composite_* ......... index_group_list_perfect, core/index.c:2238-2424 (several `by:` columns -> one dense key)
  *   rfx_hip_group_* ......... index_group_i64_scoped (core/index.c:2002-2092), index_group_distribute
  *                             (core/index.c:1777-1911, core/hash.c:35-148) and AGGR_ITER/AGGR_COLLECT with
  *                             aggr_{sum,min,max,count,avg,first}_partial (core/aggr.c:73-181,441-560,1078-2063)
@@ -62,6 +63,7 @@ enum {
 #define RFX_MAX_PREDS 8
 #define RFX_MAX_AGGS 8
 #define RFX_MAX_COLS 8 /* distinct columns one fused launch may read */
+#define RFX_MAX_KEYS 8 /* `by:` columns folded into one composite key */
 
 /* One comparison `col OP rhs`.  rhs is an atom (d_rhs_col == NULL, value in rhs_i / rhs_f according to
  * rhs_type) or a second column of the same length (d_rhs_col != NULL).  i64 (x) f64 promotes the i64 side
@@ -126,9 +128,9 @@ int rfx_hip_ctx_set_stream(rfx_ctx_t *ctx, void *stream);
 enum {
     RFX_TUNE_NO_LDS_TABLES = 1,   /* dense group-by: never privatise tables in LDS */
     RFX_TUNE_NO_PARTITION = 2,    /* dense group-by: never take the radix-partitioned path (device-scope atomics instead) */
-    RFX_TUNE_PART_3WG = 8,
-    RFX_TUNE_DIRECT_WC = 32,      /* partitioned path, one value plane: register-direct write combining instead of the tile-sorted form */
-    RFX_TUNE_NO_WRITE_COMBINE = 16, /* partitioned path: plain sorted-tile scatter instead of 128-byte write combining */        /* partitioned path: 3 scatter workgroups per CU instead of 2 */
+    RFX_TUNE_PART_3WG = 8,          /* partitioned path: 3 scatter workgroups per CU instead of 2 */
+    RFX_TUNE_NO_WRITE_COMBINE = 16, /* partitioned path: plain sorted-tile scatter instead of 128-byte write combining */
+    RFX_TUNE_DIRECT_WC = 32,        /* partitioned path, one value plane: register-direct write combining instead of the tile-sorted form */
     RFX_TUNE_NO_FUSED_SCOPE = 128 /* rfx_hip_scope_i64: plain min/max pass, no partition histogram side product */
 };
 int rfx_hip_ctx_tune(rfx_ctx_t *ctx, int blocks_per_cu, int flags);
@@ -249,6 +251,22 @@ int rfx_hip_hash_emit(rfx_ctx_t *ctx, const rfx_agg_t *aggs, const rfx_hash_tabl
 /* ---- per-row group ids (INDEX_TYPE_IDS payload, core/index.c:2069-2089) -- only when a caller wants it ---- */
 int rfx_hip_group_ids_dense(rfx_ctx_t *ctx, const int64_t *d_key, int64_t nrows, const rfx_group_tables_t *t,
                             int64_t *d_gids);
+
+/* ---- several `by:` columns: composite ("perfect hash") key, index_group_list_perfect, core/index.c:2308-2424 ----
+ * rfx_composite_plan (host, no device work): from the per-column scopes [mins[i], maxs[i]] compute the multipliers
+ * mult_0 = 1, mult_i = mult_{i-1} * range_{i-1} and the composite maximum, with the reference's overflow tests
+ * (:2364-2383).  RFX_ELIMIT when the product of ranges does not fit a signed 64-bit integer (the reference then takes its
+ * row-hash path, which this library does not cover) -- a null key (INT64_MIN) always ends up there.
+ * rfx_hip_composite_key: d_out[r] = sum_i (d_cols[i][r] - mins[i]) * mults[i]  for every local row (:2238-2305).  Rows a
+ * later predicate rejects get a meaningless value; the group kernels never look at it.  Group the result with the forced
+ * scope {kmin = 0, range = total_max + 1} (dense when range <= selected rows, else hashed), exactly as :2421 does.
+ * rfx_hip_composite_decode: d_out[g] = min + (d_comp[g] / mult) % range  -- key column i of the result from the emitted
+ * composite keys (equals the reference's key_i[first_row[g]], core/query.c:110-135). */
+int rfx_composite_plan(const int64_t *mins, const int64_t *maxs, int nkeys, int64_t *mults, int64_t *total_max);
+int rfx_hip_composite_key(rfx_ctx_t *ctx, const void *const *d_cols, const int64_t *mins, const int64_t *mults, int nkeys,
+                          int64_t nrows, int64_t *d_out);
+int rfx_hip_composite_decode(rfx_ctx_t *ctx, const int64_t *d_comp, int64_t n, int64_t min, int64_t mult, int64_t range,
+                             int64_t *d_out);
 
 /* ---- hash primitives pinned against the reference (core/hash.c:530-542, core/hash.h:86-97) ---- */
 int rfx_hip_hash_fnv1a_i64(rfx_ctx_t *ctx, const int64_t *d_in, int64_t n, uint64_t *d_out);

@@ -39,6 +39,9 @@ void rfo_scope_i64(const int64_t *values, const int64_t *indices, int64_t len, i
 int64_t rfo_group_dense(const int64_t *values, const int64_t *indices, int64_t len, int64_t min, int64_t range, int64_t *hk,
                         int64_t *firsts, int64_t *gids);
 int64_t rfo_group_sparse(const int64_t *values, const int64_t *indices, int64_t len, int64_t *gids, int64_t *firsts);
+int rfo_composite_plan(const int64_t *mins, const int64_t *maxs, int ncols, int64_t *mults, int64_t *total_max);
+void rfo_composite_key(const int64_t *const *cols, const int64_t *mins, const int64_t *mults, int ncols, const int64_t *indices,
+                       int64_t len, int64_t *out);
 uint64_t rfo_hash_fnv1a(int64_t key);
 uint64_t rfo_hash_index_u64(uint64_t h, uint64_t k);
 

@@ -57,6 +57,8 @@ def lib() -> C.CDLL:
             "rfo_group_sparse": (i64, [p, p, i64, p, p]),
             "rfo_hash_fnv1a": (C.c_uint64, [i64]), "rfo_hash_index_u64": (C.c_uint64, [C.c_uint64, C.c_uint64]),
             "rfo_aggr_first": (None, [p, p, p, i64, p]),
+            "rfo_composite_plan": (C.c_int, [p, p, C.c_int, p, C.POINTER(i64)]),
+            "rfo_composite_key": (None, [p, p, p, C.c_int, p, i64, p]),
         }
         for fn in ("sum", "min", "max", "count", "avg"):
             for t in ("i64", "f64"):
@@ -180,8 +182,40 @@ def mask_of(where_spec, table) -> np.ndarray:
     return and_(*subs) if head == "and" else or_(*subs)
 
 
-def group_index(key, filter_ids=None):
-    """index_group_i64: returns (gids per selected row, first positions, groups, dense?)."""
+class NotPerfect(Exception):
+    """index_group_list_perfect returned NULL_OBJ: the reference takes its row-hash path (not restated)."""
+
+
+def composite_key(keys, filter_ids=None):
+    """index_group_list_perfect (core/index.c:2308-2424): (composite key per SELECTED row, total_max, mins, mults)."""
+    L = lib()
+    cols = [_col(k) for k in keys]
+    idx = None if filter_ids is None else np.ascontiguousarray(filter_ids, np.int64)
+    n = len(cols[0]) if idx is None else len(idx)
+    if n == 0:
+        return np.empty(0, np.int64), -1, [], []
+    mins, maxs = [], []
+    for c in cols:
+        if c.dtype != np.int64:
+            raise NotPerfect("non-integer key column")
+        mn, mx = C.c_int64(), C.c_int64()
+        L.rfo_scope_i64(_ptr(c), _ptr(idx), n, C.byref(mn), C.byref(mx))
+        mins.append(mn.value)
+        maxs.append(mx.value)
+    k = len(cols)
+    amin, amax, amul = (C.c_int64 * k)(*mins), (C.c_int64 * k)(*maxs), (C.c_int64 * k)()
+    tmax = C.c_int64()
+    if not L.rfo_composite_plan(amin, amax, k, amul, C.byref(tmax)):
+        raise NotPerfect("key ranges overflow the composite key")
+    out = np.empty(n, np.int64)
+    ptrs = (C.c_void_p * k)(*[c.ctypes.data for c in cols])
+    L.rfo_composite_key(ptrs, amin, amul, k, _ptr(idx), n, _ptr(out))
+    return out, tmax.value, mins, list(amul)
+
+
+def group_index(key, filter_ids=None, scope=None):
+    """index_group_i64: returns (gids per selected row, first positions, groups, dense?).  `scope=(min, max)` forces the
+    key scope instead of scanning for it (index_group_i64_scoped called by index_group_list_perfect)."""
     key = _col(key)
     L = lib()
     idx = None if filter_ids is None else np.ascontiguousarray(filter_ids, np.int64)
@@ -189,7 +223,10 @@ def group_index(key, filter_ids=None):
     if n == 0:
         return np.empty(0, np.int64), np.empty(0, np.int64), 0, True
     mn, mx = C.c_int64(), C.c_int64()
-    L.rfo_scope_i64(_ptr(key), _ptr(idx), n, C.byref(mn), C.byref(mx))
+    if scope is None:
+        L.rfo_scope_i64(_ptr(key), _ptr(idx), n, C.byref(mn), C.byref(mx))
+    else:
+        mn.value, mx.value = scope
     rng = mx.value - mn.value + 1
     gids = np.empty(n, np.int64)
     firsts = np.empty(n, np.int64)
@@ -219,10 +256,23 @@ def select(query: dict) -> dict:
     if where_spec is not None:
         ids = where(mask_of(where_spec, table))
     if by is not None:
-        key = table[by]
-        gids, firsts, groups, _ = group_index(key, ids)
-        pos = firsts if ids is None else ids[firsts]
-        res = {by: _col(key)[pos] if groups else np.empty(0, np.int64)}
+        if isinstance(by, dict):  # by: {name: col ...} -- several key columns (index_group_list, core/query.c:93-135)
+            names, srcs = list(by.keys()), [table[c] for c in by.values()]
+            if len(srcs) == 1:
+                key = srcs[0]
+                gids, firsts, groups, _ = group_index(key, ids)
+            else:
+                comp, tmax, _, _ = composite_key(srcs, ids)
+                key = srcs[0]
+                # the composite column is already restricted to the selected rows: no filter below this line
+                gids, firsts, groups, _ = group_index(comp, None, scope=(0, tmax))
+            pos = firsts if ids is None else ids[firsts]
+            res = {nm: (_col(c)[pos] if groups else np.empty(0, np.int64)) for nm, c in zip(names, srcs)}
+        else:
+            key = table[by]
+            gids, firsts, groups, _ = group_index(key, ids)
+            pos = firsts if ids is None else ids[firsts]
+            res = {by: _col(key)[pos] if groups else np.empty(0, np.int64)}
         for name, (fn, col) in outs:
             if fn == "first":
                 c = _col(table[col])

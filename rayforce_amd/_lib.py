@@ -9,7 +9,7 @@ RFX_B8, RFX_I64, RFX_F64 = 1, 5, 10
 RFX_EQ, RFX_NE, RFX_LT, RFX_GT, RFX_LE, RFX_GE = range(6)
 RFX_AND, RFX_OR = 0, 1
 RFX_AGG_SUM, RFX_AGG_MIN, RFX_AGG_MAX, RFX_AGG_COUNT, RFX_AGG_AVG, RFX_AGG_FIRST = range(6)
-RFX_MAX_PREDS = RFX_MAX_AGGS = RFX_MAX_COLS = 8
+RFX_MAX_PREDS = RFX_MAX_AGGS = RFX_MAX_COLS = RFX_MAX_KEYS = 8
 NULL_I64 = -(2**63)
 INF_I64 = 2**63 - 1
 
@@ -111,6 +111,9 @@ PROTOTYPES = {
     "rfx_hip_group_ids_dense": (C.c_int, [_ctx, C.c_void_p, C.c_int64, _P(GroupTables), C.c_void_p]),
     "rfx_hip_hash_fnv1a_i64": (C.c_int, [_ctx, C.c_void_p, C.c_int64, C.c_void_p]),
     "rfx_hip_hash_mix_u64": (C.c_int, [_ctx, C.c_void_p, C.c_int64, C.c_uint64, C.c_void_p]),
+    "rfx_composite_plan": (C.c_int, [C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "rfx_hip_composite_key": (C.c_int, [_ctx, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_int, C.c_int64, C.c_void_p]),
+    "rfx_hip_composite_decode": (C.c_int, [_ctx, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_void_p]),
 }
 
 _LIB = None

@@ -1,0 +1,140 @@
+// rfx_multikey.hip -- several `by:` columns folded into ONE dense i64 key.
+//
+// Reference: index_group_list_perfect (core/index.c:2308-2424).  When the product of the per-column key ranges fits a signed
+// 64-bit integer, every row gets the composite key  sum_c (col_c[row] - min_c) * mult_c  (mult_0 = 1, mult_c = mult_{c-1} *
+// range_{c-1}) and the single-key index (index_group_i64_scoped with the forced scope {0, max}) does the grouping; the
+// result's key columns are the source columns at the groups' first rows (core/query.c:93-135).
+//
+// Here: rfx_composite_plan is the host-side multiplier / overflow logic (:2364-2383), k_composite_key the one streaming
+// pass that writes the composite column (NK x 8 B/row in, 8 B/row out; the reference materialises the same column, :2386),
+// k_composite_decode turns the emitted composite keys back into one key column (groups elements; replaces the reference's
+// at_ids gather over first rows, which on several GPUs would need rows another rank owns).
+#include "rfx_common.hpp"
+
+struct KeyParts {
+    int n;
+    const u64 *col[RFX_MAX_KEYS];
+    u64 min[RFX_MAX_KEYS];
+    u64 mult[RFX_MAX_KEYS];
+};
+
+extern "C" int rfx_composite_plan(const int64_t *mins, const int64_t *maxs, int nkeys, int64_t *mults, int64_t *total_max) {
+    RFX_REQUIRE(mins && maxs && mults && total_max, RFX_EINVAL, "NULL argument");
+    RFX_REQUIRE(nkeys >= 1 && nkeys <= RFX_MAX_KEYS, RFX_ELIMIT, "1..RFX_MAX_KEYS key columns");
+    u64 product = 1, smax = 0;
+    for (int i = 0; i < nkeys; i++) {
+        const i64 range = (i64)((u64)maxs[i] - (u64)mins[i] + 1u);
+        // a null key (INT64_MIN) makes the range wrap: the reference gives up on the perfect path there (row-hash path)
+        if (range <= 0 || product > (u64)INT64_MAX / (u64)range) {
+            rfx_set_error("rfx_composite_plan: key ranges overflow a 64-bit composite key (column %d)", i);
+            return RFX_ELIMIT;
+        }
+        mults[i] = (i64)product;
+        product *= (u64)range;
+        const u64 delta = (u64)(maxs[i] - mins[i]) * (u64)mults[i];
+        if (smax > (u64)INT64_MAX - delta) {
+            rfx_set_error("rfx_composite_plan: composite key maximum overflows (column %d)", i);
+            return RFX_ELIMIT;
+        }
+        smax += delta;
+    }
+    *total_max = (i64)smax;
+    return RFX_OK;
+}
+
+// A wave owns 512 consecutive rows per step (as k_cmp_mask): lane l takes rows 2l, 2l+1 of each 128-row group -- one
+// 16-byte load per key column and group (1 KB contiguous per wave instruction) and one 16-byte store of the two composites.
+template <int NK>
+__global__ __launch_bounds__(RFX_BLOCK) void k_composite_key(const KeyParts K, i64 nrows, u64 *__restrict__ out) {
+    u64 mn[NK], mu[NK];
+#pragma unroll
+    for (int c = 0; c < NK; c++) {
+        mn[c] = K.min[c];
+        mu[c] = K.mult[c];
+    }
+    const int lane = threadIdx.x & 63;
+    const i64 wave_id = (i64)blockIdx.x * (RFX_BLOCK / RFX_WAVE) + (threadIdx.x >> 6);
+    const i64 nwaves = (i64)gridDim.x * (RFX_BLOCK / RFX_WAVE);
+    const i64 nfull = nrows / 512;
+    for (i64 q = wave_id; q < nfull; q += nwaves) {
+        const i64 base = q * 512 + lane * 2;
+        u64 k[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) k[e] = 0;
+#pragma unroll
+        for (int c = 0; c < NK; c++) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const u64x2 t = rfx_ld2(K.col[c] + base + j * 128);
+                k[2 * j] += (t.x - mn[c]) * mu[c];
+                k[2 * j + 1] += (t.y - mn[c]) * mu[c];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            u64x2 o;
+            o.x = k[2 * j];
+            o.y = k[2 * j + 1];
+            *(u64x2 *)(out + base + j * 128) = o;
+        }
+    }
+    if (blockIdx.x == 0) {
+        for (i64 r = nfull * 512 + threadIdx.x; r < nrows; r += RFX_BLOCK) {
+            u64 k = 0;
+#pragma unroll
+            for (int c = 0; c < NK; c++) k += (K.col[c][r] - mn[c]) * mu[c];
+            out[r] = k;
+        }
+    }
+}
+
+extern "C" int rfx_hip_composite_key(rfx_ctx_t *c, const void *const *d_cols, const int64_t *mins, const int64_t *mults, int nkeys,
+                                     int64_t nrows, int64_t *d_out) {
+    RFX_REQUIRE(c && d_cols && mins && mults, RFX_EINVAL, "NULL argument");
+    RFX_REQUIRE(nkeys >= 1 && nkeys <= RFX_MAX_KEYS, RFX_ELIMIT, "1..RFX_MAX_KEYS key columns");
+    if (nrows <= 0) return RFX_OK;
+    RFX_REQUIRE(d_out && ((uintptr_t)d_out & 15) == 0, RFX_EINVAL, "output must be a 16-byte aligned device buffer");
+    KeyParts K;
+    memset(&K, 0, sizeof(K));
+    K.n = nkeys;
+    for (int i = 0; i < nkeys; i++) {
+        RFX_REQUIRE(d_cols[i] && ((uintptr_t)d_cols[i] & 15) == 0, RFX_EINVAL, "key columns must be 16-byte aligned device buffers");
+        K.col[i] = (const u64 *)d_cols[i];
+        K.min[i] = (u64)mins[i];
+        K.mult[i] = (u64)mults[i];
+    }
+    const int grid = c->num_cus * 8;
+    RFX_KERNEL_BEGIN(c);
+#define RFX_CK(N) case N: hipLaunchKernelGGL((k_composite_key<N>), dim3(grid), dim3(RFX_BLOCK), 0, c->stream, K, (i64)nrows, (u64 *)d_out); break
+    switch (nkeys) {
+        RFX_CK(1);
+        RFX_CK(2);
+        RFX_CK(3);
+        RFX_CK(4);
+        RFX_CK(5);
+        RFX_CK(6);
+        RFX_CK(7);
+        default: RFX_CK(8);
+    }
+#undef RFX_CK
+    RFX_KERNEL_END(c);
+    RFX_HIP_CHECK(hipGetLastError());
+    return RFX_OK;
+}
+
+__global__ __launch_bounds__(RFX_BLOCK) void k_composite_decode(const u64 *__restrict__ comp, i64 n, u64 mn, u64 mult, u64 range, u64 *__restrict__ out) {
+    for (i64 i = blockIdx.x * (i64)RFX_BLOCK + threadIdx.x; i < n; i += (i64)gridDim.x * RFX_BLOCK) out[i] = mn + (comp[i] / mult) % range;
+}
+
+extern "C" int rfx_hip_composite_decode(rfx_ctx_t *c, const int64_t *d_comp, int64_t n, int64_t min, int64_t mult, int64_t range, int64_t *d_out) {
+    RFX_REQUIRE(c, RFX_EINVAL, "ctx is NULL");
+    if (n <= 0) return RFX_OK;
+    RFX_REQUIRE(d_comp && d_out, RFX_EINVAL, "NULL argument");
+    RFX_REQUIRE(mult >= 1 && range >= 1, RFX_EINVAL, "multiplier and range must be positive");
+    i64 blocks = (n + RFX_BLOCK - 1) / RFX_BLOCK;
+    int grid = rfx_grid(c);
+    if (blocks < grid) grid = (int)blocks;
+    hipLaunchKernelGGL(k_composite_decode, dim3(grid), dim3(RFX_BLOCK), 0, c->stream, (const u64 *)d_comp, (i64)n, (u64)min, (u64)mult, (u64)range, (u64 *)d_out);
+    RFX_HIP_CHECK(hipGetLastError());
+    return RFX_OK;
+}

@@ -406,7 +406,7 @@ rfx_obj_p rfx_select(rfx_obj_p dict) {
         wplan_t wp;
         int flat = 1;
         int64_t *d_ids = NULL, nsel = 0;
-        void *tmp[RFX_MAX_AGGS + 2];
+        void *tmp[RFX_MAX_AGGS + 4];
         int ntmp = 0;
         int rc = plan_where(tab, where, &wp);
         if (rc == -2) { res = fail_hip("column upload"); goto done; }
@@ -439,13 +439,43 @@ rfx_obj_p rfx_select(rfx_obj_p dict) {
             outtype[nagg] = (f == F_AVG) ? RFX_TYPE_F64 : (f == F_COUNT) ? RFX_TYPE_I64 : c->type;
             names[nagg++] = k;
         }
-        obj_p kc = NULL;
+        /* by: a column symbol, or a dict {name: column ...} (get_gkeys / get_gvals, core/query.c:165-240).  Several key
+         * columns fold into one composite key (index_group_list_perfect, core/index.c:2308-2424). */
+        obj_p kcs[RFX_MAX_KEYS] = {0};
+        const void *dks[RFX_MAX_KEYS] = {0};
+        int64_t knames[RFX_MAX_KEYS];
+        int nkeys = 0;
         const void *dk = NULL;
+        int64_t kmins[RFX_MAX_KEYS], kmaxs[RFX_MAX_KEYS], kmults[RFX_MAX_KEYS], comp_max = 0;
         if (by) {
-            if (by->type != -RFX_TYPE_SYMBOL) { why = "by: is not a single column"; goto out; }
-            kc = table_col(tab, by->i64);
-            if (!kc || kc->type != RFX_TYPE_I64) { why = "by: key is not an i64 column"; goto out; }
-            if (resident(kc, 0, &dk) != RFX_OK) { res = fail_hip("column upload"); goto done; }
+            if (by->type == -RFX_TYPE_SYMBOL) {
+                knames[0] = by->i64;
+                kcs[nkeys++] = table_col(tab, by->i64);
+            } else if (by->type == RFX_TYPE_DICT && RFX_AS_LIST(by)[0]->type == RFX_TYPE_SYMBOL) {
+                obj_p bk = RFX_AS_LIST(by)[0], bv = RFX_AS_LIST(by)[1];
+                if (bk->len < 1 || bk->len > RFX_MAX_KEYS || bv->len != bk->len) { why = "by: dict shape"; goto out; }
+                for (int64_t i = 0; i < bk->len; i++) {
+                    int64_t sym;
+                    if (bv->type == RFX_TYPE_SYMBOL) sym = RFX_AS_I64(bv)[i];
+                    else if (bv->type == RFX_TYPE_LIST && RFX_AS_LIST(bv)[i]->type == -RFX_TYPE_SYMBOL) sym = RFX_AS_LIST(bv)[i]->i64;
+                    else { why = "by: key is an expression"; goto out; }
+                    knames[nkeys] = RFX_AS_I64(bk)[i];
+                    kcs[nkeys++] = table_col(tab, sym);
+                }
+            } else { why = "by: is neither a column nor a dict of columns"; goto out; }
+            for (int i = 0; i < nkeys; i++) {
+                /* index_group's 8-byte integer arms: I64 / SYMBOL / TIMESTAMP group on the raw i64 (core/index.c:2183-2186) */
+                if (!kcs[i] || !(kcs[i]->type == RFX_TYPE_I64 || kcs[i]->type == RFX_TYPE_SYMBOL || kcs[i]->type == RFX_TYPE_TIMESTAMP)) {
+                    why = "by: key is not an 8-byte integer column";
+                    goto out;
+                }
+                if (resident(kcs[i], 0, &dks[i]) != RFX_OK) { res = fail_hip("column upload"); goto done; }
+            }
+            /* where: + several keys: the reference's own result is defective (its composite index drops the filter, so key
+             * columns and aggregates are taken from the wrong rows -- DESIGN.md "reference defects"); leave that to the host
+             * so that this entry point never answers differently from ray_select. */
+            if (nkeys > 1 && where) { why = "where: with several by: columns"; goto out; }
+            dk = dks[0];
         }
         if (!by && nagg == 0) {
             /* projection: filter_collect of every column (core/filter.c:51-165): where -> ids -> gather */
@@ -507,9 +537,27 @@ rfx_obj_p rfx_select(rfx_obj_p dict) {
         }
         if (by) {
             int64_t kmin, kmax, seen;
+            if (nkeys > 1) {
+                int64_t cnt = 0;
+                for (int i = 0; i < nkeys; i++)
+                    if (rfx_hip_scope_i64(g_ctx, (const int64_t *)dks[i], NULL, 0, RFX_AND, nrows, &kmins[i], &kmaxs[i], &cnt) != RFX_OK) { res = fail_hip("scope"); goto done; }
+                if (cnt > 0) {
+                    if (rfx_composite_plan(kmins, kmaxs, nkeys, kmults, &comp_max) != RFX_OK) { why = "by: key ranges overflow the composite key (row-hash path)"; goto out; }
+                    void *comp = NULL;
+                    if (rfx_hip_malloc(g_ctx, &comp, (size_t)nrows * 8) != RFX_OK) { res = fail_hip("composite key"); goto done; }
+                    tmp[ntmp++] = comp;
+                    if (rfx_hip_composite_key(g_ctx, dks, kmins, kmults, nkeys, nrows, (int64_t *)comp) != RFX_OK) {
+                        for (int i = 0; i < ntmp; i++) rfx_hip_free(g_ctx, tmp[i]);
+                        res = fail_hip("composite key");
+                        goto done;
+                    }
+                    dk = comp;
+                }
+            }
             if (rfx_hip_scope_i64(g_ctx, (const int64_t *)dk, wp.preds, wp.npred, wp.logic, nrows, &kmin, &kmax, &seen) != RFX_OK) { res = fail_hip("scope"); goto done; }
+            if (nkeys > 1 && seen > 0) { kmin = 0; kmax = comp_max; } /* forced scope, core/index.c:2421 */
             int64_t groups = 0;
-            obj_p okeys = NULL, ocols[RFX_MAX_AGGS] = {0};
+            obj_p okeys = NULL, ocols[RFX_MAX_AGGS] = {0}, okcols[RFX_MAX_KEYS] = {0};
             if (seen > 0) {
                 /* dense "perfect hash" iff range <= rows (core/index.c:2013), like the reference; else open addressing */
                 uint64_t range = (uint64_t)kmax - (uint64_t)kmin + 1;
@@ -554,8 +602,20 @@ rfx_obj_p rfx_select(rfx_obj_p dict) {
                     void *ptrs[RFX_MAX_AGGS];
                     for (int a = 0; a < nagg; a++) ptrs[a] = (int64_t *)dout + (size_t)(a + 1) * groups;
                     ok = (dense ? rfx_hip_group_emit(g_ctx, aggs, &gt, (int64_t *)dout, NULL, ptrs) : rfx_hip_hash_emit(g_ctx, aggs, &ht, (int64_t *)dout, NULL, ptrs)) == RFX_OK;
-                    okeys = H.vector(RFX_TYPE_I64, groups);
-                    if (ok) ok = rfx_hip_d2h(g_ctx, RFX_AS_RAW(okeys), dout, (size_t)groups * 8) == RFX_OK;
+                    if (nkeys == 1) {
+                        okeys = H.vector(kcs[0]->type, groups);
+                        if (ok) ok = rfx_hip_d2h(g_ctx, RFX_AS_RAW(okeys), dout, (size_t)groups * 8) == RFX_OK;
+                    } else {
+                        /* key column i = min_i + (composite / mult_i) % range_i  (= key_i[first row], core/query.c:110-135) */
+                        void *dec = NULL;
+                        ok = ok && rfx_hip_malloc(g_ctx, &dec, (size_t)groups * 8) == RFX_OK;
+                        for (int i = 0; i < nkeys && ok; i++) {
+                            okcols[i] = H.vector(kcs[i]->type, groups);
+                            ok = rfx_hip_composite_decode(g_ctx, (const int64_t *)dout, groups, kmins[i], kmults[i], kmaxs[i] - kmins[i] + 1, (int64_t *)dec) == RFX_OK &&
+                                 rfx_hip_d2h(g_ctx, RFX_AS_RAW(okcols[i]), dec, (size_t)groups * 8) == RFX_OK;
+                        }
+                        if (dec) rfx_hip_free(g_ctx, dec);
+                    }
                     for (int a = 0; a < nagg && ok; a++) {
                         ocols[a] = H.vector((int8_t)outtype[a], groups);
                         ok = rfx_hip_d2h(g_ctx, RFX_AS_RAW(ocols[a]), ptrs[a], (size_t)groups * 8) == RFX_OK;
@@ -565,18 +625,22 @@ rfx_obj_p rfx_select(rfx_obj_p dict) {
                 rfx_hip_free(g_ctx, store);
                 if (!ok) {
                     if (okeys) H.drop(okeys);
+                    for (int i = 0; i < nkeys; i++) if (okcols[i]) H.drop(okcols[i]);
                     for (int a = 0; a < nagg; a++) if (ocols[a]) H.drop(ocols[a]);
+                    for (int i = 0; i < ntmp; i++) rfx_hip_free(g_ctx, tmp[i]);
                     res = fail_hip("group-by");
                     goto done;
                 }
             }
-            if (!okeys) okeys = H.vector(RFX_TYPE_I64, 0);
-            obj_p rk = H.vector(RFX_TYPE_SYMBOL, nagg + 1), rv = H.vector(RFX_TYPE_LIST, nagg + 1);
-            RFX_AS_I64(rk)[0] = by->i64;
-            RFX_AS_LIST(rv)[0] = okeys;
+            if (nkeys == 1) okcols[0] = okeys ? okeys : H.vector(kcs[0]->type, 0);
+            obj_p rk = H.vector(RFX_TYPE_SYMBOL, nagg + nkeys), rv = H.vector(RFX_TYPE_LIST, nagg + nkeys);
+            for (int i = 0; i < nkeys; i++) {
+                RFX_AS_I64(rk)[i] = knames[i];
+                RFX_AS_LIST(rv)[i] = okcols[i] ? okcols[i] : H.vector(kcs[i]->type, 0);
+            }
             for (int a = 0; a < nagg; a++) {
-                RFX_AS_I64(rk)[a + 1] = names[a];
-                RFX_AS_LIST(rv)[a + 1] = ocols[a] ? ocols[a] : H.vector((int8_t)outtype[a], 0);
+                RFX_AS_I64(rk)[a + nkeys] = names[a];
+                RFX_AS_LIST(rv)[a + nkeys] = ocols[a] ? ocols[a] : H.vector((int8_t)outtype[a], 0);
             }
             for (int i = 0; i < ntmp; i++) rfx_hip_free(g_ctx, tmp[i]);
             res = H.table(rk, rv);

@@ -391,7 +391,16 @@ class Engine:
         Group order is first occurrence.  `_collective(store, layout, aggs_arr, hashed)` -- if given -- is called
         between the local scatter pass and the ranking step so that several GPUs can merge their tables.  (syncs)
         """
-        key = self._check_col(self._resolve(key, table))
+        multi = None
+        if isinstance(key, (list, tuple)) and len(key) == 1:
+            key = key[0]
+        if isinstance(key, (list, tuple)):
+            # several key columns -> one composite dense key (index_group_list_perfect, core/index.c:2308-2424)
+            kcols = [self._check_col(self._resolve(k, table)) for k in key]
+            comp, tmax, seen, multi = self._composite(kcols, where, table, _collective)
+            key = comp
+        else:
+            key = self._check_col(self._resolve(key, table))
         if key.dtype != torch.int64:
             raise RfxError("group key must be i64 on this path (f64 keys group on their bit pattern: view as int64)")
         n = key.numel()
@@ -399,9 +408,14 @@ class Engine:
             logic, flat = self._flatten(where, table)
         except _NotFlat:
             raise RfxError("nested boolean trees are not fused with `by:`; pass ids via where() + at_ids()")
-        kmin, kmax, seen = self.scope(key, where, table)
-        if _collective is not None:
-            kmin, kmax, seen = _collective("scope", (kmin, kmax, seen, self.device))
+        if multi is None:
+            kmin, kmax, seen = self.scope(key, where, table)
+            if _collective is not None:
+                kmin, kmax, seen = _collective("scope", (kmin, kmax, seen, self.device))
+        else:
+            if seen:
+                self.scope(key, where, table)  # leaves the partition histogram of the composite column for the accumulate pass
+            kmin, kmax = 0, tmax  # forced scope, core/index.c:2421
         self._keep.clear()
         parr, _ = self._preds(flat, table, n)
         aarr, _ = self._aggs(aggs, table, n)
@@ -417,7 +431,10 @@ class Engine:
             else:
                 out_dtypes.append(col.dtype)
         if seen == 0:
-            return dict(groups=0, keys=self.empty(0), first=self.empty(0), results=[self.empty(0, d) for d in out_dtypes])
+            r = dict(groups=0, keys=self.empty(0), first=self.empty(0), results=[self.empty(0, d) for d in out_dtypes])
+            if multi is not None:
+                r["key_columns"] = [self.empty(0) for _ in multi[0]]
+            return r
         rng = kmax - kmin + 1
         # index_group_i64_scoped: dense "perfect hash" iff range <= rows (core/index.c:2013); else open addressing
         dense = 0 < rng <= max(seen, 1) and kmin != L.NULL_I64
@@ -454,8 +471,41 @@ class Engine:
             L.check(self.lib.rfx_hip_group_emit(self._ctx, aarr, C.byref(t), keys.data_ptr(), first.data_ptr(), ptrs), "group_emit")
         else:
             L.check(self.lib.rfx_hip_hash_emit(self._ctx, aarr, C.byref(t), keys.data_ptr(), first.data_ptr(), ptrs), "hash_emit")
+        r = dict(groups=g, keys=keys, first=first, results=results, dense=dense)
+        if multi is not None:
+            mins, mults, ranges = multi
+            r["key_columns"] = []
+            for mn, mu, rg in zip(mins, mults, ranges):
+                kc = self.empty(g)
+                L.check(self.lib.rfx_hip_composite_decode(self._ctx, keys.data_ptr(), g, mn, mu, rg, kc.data_ptr()), "composite_decode")
+                r["key_columns"].append(kc)
         self.sync()
-        return dict(groups=g, keys=keys, first=first, results=results, dense=dense)
+        return r
+
+    def _composite(self, kcols, where, table, _collective):
+        """Scopes of every key column (through the predicates), the reference's multiplier plan, and the composite column."""
+        if len(kcols) > L.RFX_MAX_KEYS:
+            raise RfxError(f"at most {L.RFX_MAX_KEYS} key columns")
+        n = kcols[0].numel()
+        mins, maxs, seen = [], [], 0
+        for kc in kcols:
+            if kc.dtype != torch.int64 or kc.numel() != n:
+                raise RfxError("key columns must be equally long i64 columns on this path")
+            mn, mx, seen = self.scope(kc, where, table)
+            if _collective is not None:
+                mn, mx, seen = _collective("scope", (mn, mx, seen, self.device))
+            mins.append(mn)
+            maxs.append(mx)
+        k = len(kcols)
+        if seen == 0:
+            return self.empty(n), -1, 0, ([0] * k, [1] * k, [1] * k)
+        amin, amax, amul = (C.c_int64 * k)(*mins), (C.c_int64 * k)(*maxs), (C.c_int64 * k)()
+        tmax = C.c_int64()
+        L.check(self.lib.rfx_composite_plan(amin, amax, k, amul, C.byref(tmax)), "composite_plan")
+        comp = self.empty(n)
+        ptrs = (C.c_void_p * k)(*[kc.data_ptr() for kc in kcols])
+        L.check(self.lib.rfx_hip_composite_key(self._ctx, ptrs, amin, amul, k, n, comp.data_ptr()), "composite_key")
+        return comp, int(tmax.value), seen, (mins, list(amul), [mx - mn + 1 for mn, mx in zip(mins, maxs)])
 
     # ------------------------------------------------------------------ the select surface (core/query.c:607-654)
     def select(self, query: Dict) -> Dict[str, torch.Tensor]:
@@ -476,8 +526,12 @@ class Engine:
         n = lens.pop() if lens else 0
         if by is not None:
             aggs = [(fn, col) for _, (fn, col) in outs]
-            r = self.group_by(by, aggs, where, table)
-            res = {by if isinstance(by, str) else "by": r["keys"]}
+            if isinstance(by, dict):  # by: {name: column ...}
+                r = self.group_by(list(by.values()), aggs, where, table)
+                res = dict(zip(by.keys(), r["key_columns"])) if len(by) > 1 else {next(iter(by)): r["keys"]}
+            else:
+                r = self.group_by(by, aggs, where, table)
+                res = {by if isinstance(by, str) else "by": r["keys"]}
             for (name, _), col in zip(outs, r["results"]):
                 res[name] = col
             return res

@@ -132,7 +132,10 @@ def select_dict(query: Dict, tab: int) -> int:
     keys, vals = [], []
     for k, v in query.items():
         keys.append(k)
-        vals.append(atom(v) if k == "by" else expr(v))
+        if k == "by" and isinstance(v, dict):  # by: {name: column ...} -> DICT of SYMBOL keys, LIST of symbol atoms
+            vals.append(lib().rfx_host_dict(symbols(list(v.keys())), list_of([atom(c) for c in v.values()])))
+        else:
+            vals.append(atom(v) if k == "by" else expr(v))
     keys.append("from")
     vals.append(lib().rfx_host_clone(tab))
     return lib().rfx_host_dict(symbols(keys), list_of(vals))

@@ -135,6 +135,26 @@ def main():
         arrays[f"sparse_{o}"] = r[o]
     cases.append({"kind": "sparse", "table": dict(n=20_011, seed=9, keys=400, nulls=True), "mul": 1_000_003, "add": -77})
 
+    # ---- 4b. several `by:` columns (index_group_list_perfect, core/index.c:2308-2424): H2O Q2 shape, no `where:` ----
+    # (with `where:` the reference's result is defective -- DESIGN.md "reference defects" -- and is not captured)
+    for mi, (n, seed, mods, offs, thr) in enumerate([(32_769, 21, (7, 13), (0, 100), 8), (70_003, 22, (100, 100, 5), (-50, 1000, 3), 8),
+                                                     (20_011, 23, (3000, 4000), (0, 0), 1)]):  # last: composite range > rows -> sparse arm, -c 1
+        t = {f"k{j + 1}": rfo.gen_i64(n, seed + 10 * j, m) + o for j, (m, o) in enumerate(zip(mods, offs))}
+        t["v"] = rfo.gen_f64(n, seed + 5)
+        t["a"] = rfo.gen_i64(n, seed + 6, 1_000_000)
+        names = [f"k{j + 1}" for j in range(len(mods))]
+        with ref.Session() as s:
+            s.table("t", t)
+            bytxt = " ".join(f"{nm}: {nm}" for nm in names)
+            s.eval(f"(set r (select {{sf: (sum v) c: (count a) mxi: (max a) avf: (avg v) from: t by: {{{bytxt}}}}}))")
+            outs = names + ["sf", "c", "mxi", "avf"]
+            for o in outs:
+                s.out(o, f"(at r '{o})")
+            r = s.run(threads=thr)
+        for o in outs:
+            arrays[f"multikey_{mi}_{o}"] = r[o]
+        cases.append({"kind": "multikey", "index": mi, "n": n, "seed": seed, "mods": list(mods), "offs": list(offs)})
+
     # ---- 5. null-semantics known answers (verified against the reference here) ----
     k = np.array([1, 1, 2, 3, 3], np.int64)
     v = np.array([1, NULL, 5, NULL, NULL], np.int64)

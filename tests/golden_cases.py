@@ -82,6 +82,22 @@ def sparse_case():
     return t, {o: arr(f"sparse_{o}") for o in ["k", "sf", "c", "mxi"]}
 
 
+MULTIKEY_Q = {"sf": ("sum", "v"), "c": ("count", "a"), "mxi": ("max", "a"), "avf": ("avg", "v")}
+
+
+def multikey_cases():
+    """Several `by:` columns, no `where:` (H2O Q2 shape).  Yields (id, table, key names, wanted columns)."""
+    for c in _meta["cases"]:
+        if c["kind"] != "multikey":
+            continue
+        n, seed = c["n"], c["seed"]
+        t = {f"k{j + 1}": rfo.gen_i64(n, seed + 10 * j, m) + o for j, (m, o) in enumerate(zip(c["mods"], c["offs"]))}
+        t["v"] = rfo.gen_f64(n, seed + 5)
+        t["a"] = rfo.gen_i64(n, seed + 6, 1_000_000)
+        names = [f"k{j + 1}" for j in range(len(c["mods"]))]
+        yield f"m{c['index']}", t, names, {o: arr(f"multikey_{c['index']}_{o}") for o in names + list(MULTIKEY_Q)}
+
+
 def nullsem_case():
     t = {"k": arr("nullsem_k"), "v": arr("nullsem_v"), "f": arr("nullsem_f")}
     want = {o: arr(f"nullsem_out_{o}") for o in ["k", "s", "fs", "mn", "mx", "fmn", "fmx", "c", "av"]}

@@ -18,6 +18,10 @@ QUERIES = [
     ("q3", "{s: (sum v) c: (count a) m: (max a) from: t by: k}", ["k", "s", "c", "m"]),
     ("q4", "{s: (sum v) from: t where: (> v 0.5) by: k}", ["k", "s"]),
     ("q5", "{s: (sum v) from: t where: (< a 1000)}", ["s"]),
+    # several by: columns -> composite key on the GPU (H2O Q2 shape); one-entry dict renames the key column
+    ("q6", "{s: (sum v) c: (count a) from: t by: {k1: k1 k2: k2}}", ["k1", "k2", "s", "c"]),
+    ("q7", "{m: (max a) f: (first v) from: t by: {x: k2 y: k1 z: k3}}", ["x", "y", "z", "m", "f"]),
+    ("q8", "{s: (sum v) from: t where: (< a 500000) by: {g: k}}", ["g", "s"]),
 ]
 
 
@@ -27,7 +31,8 @@ def test_plugin_inside_the_real_reference(built):
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     n = 300_007
-    cols = {"k": rfo.gen_i64(n, 4, 5000), "a": rfo.gen_i64(n, 2, 1_000_000), "v": rfo.gen_f64(n, 5)}
+    cols = {"k": rfo.gen_i64(n, 4, 5000), "a": rfo.gen_i64(n, 2, 1_000_000), "v": rfo.gen_f64(n, 5),
+            "k1": rfo.gen_i64(n, 14, 7), "k2": rfo.gen_i64(n, 15, 11) + 100, "k3": rfo.gen_i64(n, 16, 50) - 25}
     with ref.Session() as s:
         s.table("t", cols)
         s.eval(f'(set gsel (loadfn "{LIB}" "rfx_select" 1))')

@@ -44,6 +44,15 @@ def test_group_by_order_and_aggregates(eng):
             G.same(got[o].cpu().numpy(), want[o], f"{name}.{o}")
 
 
+@pytest.mark.parametrize("case", list(G.multikey_cases()), ids=lambda c: c[0])
+def test_group_by_several_keys(eng, case):
+    _, t, names, want = case
+    got = eng.select({"from": {k: eng.column(v) for k, v in t.items()}, "by": {nm: nm for nm in names}, **G.MULTIKEY_Q})
+    assert list(got.keys()) == list(want.keys())
+    for o in want:
+        G.same(got[o].cpu().numpy(), want[o], o)
+
+
 def test_group_by_sparse_keys(eng):
     t, want = G.sparse_case()
     got = eng.select({"from": dev(eng, t), "by": "k", "sf": ("sum", "v"), "c": ("count", "a"), "mxi": ("max", "a")})

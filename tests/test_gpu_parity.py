@@ -299,3 +299,47 @@ def test_group_by_every_code_path_agrees(eng, flags):
             check_select(eng, host, {"where": ("<", "a", 300_000), "by": "k", "s": ("sum", "v"), "mn": ("min", "a")})
     finally:
         eng.tune(flags=0)
+
+
+# ---------------------------------------------------------------- several `by:` columns (composite key)
+def mk_table(n, mods, offs, seed=31):
+    t = {f"k{j + 1}": rfo.gen_i64(n, seed + 10 * j, m) + o for j, (m, o) in enumerate(zip(mods, offs))}
+    t.update(v=rfo.gen_f64(n, seed + 5), a=rfo.gen_i64(n, seed + 6, 1_000_000))
+    return t
+
+
+@pytest.mark.parametrize("n,mods,offs", [(1, (3, 3), (0, 0)), (1000, (7, 13), (0, 100)), (300_007, (100, 100), (-5, 10**12)),
+                                         (300_007, (40, 30, 20, 4), (0, 1, 2, 3)), (700_001, (1000, 1000), (0, 0)),
+                                         (50_000, (3000, 4000), (0, 0))])
+def test_group_by_several_keys(eng, n, mods, offs):
+    """Dense composite (LDS tables / partitioned / atomics by range) and the sparse arm (range > rows).  Without `where:`
+    this is pinned by the golden multikey cases; with `where:` the oracle restates the evident intent (filter, then group)
+    because the reference's own result for that combination is defective."""
+    host = mk_table(n, mods, offs)
+    by = {f"g{j}": f"k{j + 1}" for j in range(len(mods))}
+    check_select(eng, host, {"by": by, "s": ("sum", "v"), "c": ("count", "a"), "mx": ("max", "a"), "av": ("avg", "v")})
+    check_select(eng, host, {"where": ("and", ("<", "a", 400_000), (">", "v", 0.125)), "by": by, "s": ("sum", "v"), "f": ("first", "a")})
+    check_select(eng, host, {"where": ("<", "a", -1), "by": by, "s": ("sum", "v")})  # nothing selected
+
+
+def test_group_by_several_keys_overflow_is_refused(eng):
+    """Product of ranges beyond i64 (a null key always is): the reference leaves its perfect path; this library says so."""
+    from rayforce_amd._lib import RfxError
+    host = mk_table(1000, (10, 10), (0, 0))
+    host["k2"][7] = NULL
+    with pytest.raises(RfxError, match="overflow"):
+        eng.select({"from": dev(eng, host), "by": {"x": "k1", "y": "k2"}, "s": ("sum", "v")})
+    # one key through the dict spelling is the plain single-key path (null key -> hashed), core/index.c:2741-2742
+    check_select(eng, host, {"by": {"y": "k2"}, "s": ("sum", "v")})
+
+
+def test_sharded_several_keys_single_rank(eng):
+    from rayforce_amd.dist import ShardedEngine
+    n = 200_003
+    host = mk_table(n, (50, 60), (5, -5))
+    sh = ShardedEngine(eng, n)
+    r = sh.group_by(["k1", "k2"], [("sum", "v"), ("count", "a")], ("<", "a", 600_000), dev(eng, host))
+    w = rfo.select({"from": host, "where": ("<", "a", 600_000), "by": {"k1": "k1", "k2": "k2"}, "s": ("sum", "v"), "c": ("count", "a")})
+    assert np.array_equal(r["key_columns"][0].cpu().numpy(), w["k1"]) and np.array_equal(r["key_columns"][1].cpu().numpy(), w["k2"])
+    assert np.array_equal(r["results"][1].cpu().numpy(), w["c"])
+    same_f64(r["results"][0].cpu().numpy(), w["s"])

@@ -61,6 +61,34 @@ def test_group_by_sparse_keys():
         G.same(got[o], want[o], o)
 
 
+@pytest.mark.parametrize("case", list(G.multikey_cases()), ids=lambda c: c[0])
+def test_group_by_several_keys(case):
+    """by: {k1: k1 k2: k2 ...} -- composite-key path of index_group_list_perfect, dense and sparse arms."""
+    _, t, names, want = case
+    rfo.set_threads(1 if case[0] == "m2" else 8)
+    got = rfo.select({"from": t, "by": {nm: nm for nm in names}, **G.MULTIKEY_Q})
+    rfo.set_threads(8)
+    assert list(got.keys()) == list(want.keys())
+    for o in want:
+        G.same(got[o], want[o], o)
+
+
+def test_composite_plan_overflow_rules():
+    """core/index.c:2364-2383: the perfect path is abandoned when the product of ranges leaves i64 -- a null key always does."""
+    n = 1000
+    t = {"k1": rfo.gen_i64(n, 1, 10), "k2": rfo.gen_i64(n, 2, 10)}
+    comp, tmax, mins, mults = rfo.composite_key([t["k1"], t["k2"]])
+    assert tmax == 99 and mults == [1, 10] and comp.min() >= 0 and comp.max() <= 99
+    t["k2"][5] = -(2**63)
+    with pytest.raises(rfo.NotPerfect):
+        rfo.composite_key([t["k1"], t["k2"]])
+    big = [rfo.gen_i64(n, 3 + i, 2**40) for i in range(2)]
+    for b in big:
+        b[0], b[1] = 0, 2**40 - 1
+    with pytest.raises(rfo.NotPerfect):
+        rfo.composite_key(big)
+
+
 def test_null_semantics():
     t, want, scalar_sum = G.nullsem_case()
     got = rfo.select({"from": t, "by": "k", "s": ("sum", "v"), "fs": ("sum", "f"), "mn": ("min", "v"), "mx": ("max", "v"), "fmn": ("min", "f"),
