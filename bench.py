@@ -13,6 +13,9 @@ Workloads (BASELINE.json configs / SURVEY 8d):
   c2   configs[1]  select sum(a) where a < 100000      a: i64[1e9] in [0,1e6)              8 B/row   <- default, `value`
   c2b  north-star  select sum(b) where a < 100000      + b: f64[1e9]                       16 B/row
   c3   configs[2]  select sum(v) by k                  k: i64[1e9] in [0,1e6), v: f64      16 B/row
+  c1   configs[0]  (sum v)                             v: f64[1e7]                         8 B/row   (plumbing case)
+  c3w  metric      select sum(v) by k where a < 100000 k, v as c3 + a as c2                24 B/row
+  q2   8f-1        select sum(v) by {id1, id2}         id1, id2: i64[1e9] in [0,100), v    24 B/row
   c5   configs[4]  avg,min,max(d) where a<.316228 & b>.683772 & c!=.25   4 x f64[2.5e8]/GPU 32 B/row
 One JSON line on stdout (rank 0); everything else goes to stderr.
 """
@@ -39,12 +42,18 @@ def log(*a):
 
 
 WORKLOADS = {
+    "c1": dict(desc="configs[0]: (sum v), v f64[1e7] uniform [0,1), seed 1 -- the reference's `make bench` plumbing case, here on the GPU", rows=10_000_000,
+               bytes_per_row=8, dtype="f64", kernel="k_filter_aggr<1,1,4,0>"),
     "c2": dict(desc="configs[1]: select sum(a) where a < 100000, a i64 uniform [0,1e6), seed 2", rows=1_000_000_000, bytes_per_row=8, dtype="int64",
                kernel="k_filter_aggr<1,1,8,1>"),
     "c2b": dict(desc="north-star: select sum(b) where a < 100000, a i64 seed 2, b f64 seed 3", rows=1_000_000_000, bytes_per_row=16, dtype="f64",
                 kernel="k_filter_aggr<2,1,4,1>"),
     "c3": dict(desc="configs[2]: select sum(v) by k, k i64 uniform [0,1e6) seed 4, v f64 seed 5", rows=1_000_000_000, bytes_per_row=16, dtype="f64",
                kernel="k_part_hist+k_part_scatter+k_part_aggregate"),
+    "c3w": dict(desc="metric shape filter->group-by->sum: select sum(v) by k where a < 100000 (10 %), k/v as C3, a as C2", rows=1_000_000_000,
+                bytes_per_row=24, dtype="f64", kernel="k_part_scope_hist+k_part_scatter+k_part_aggregate"),
+    "q2": dict(desc="several by: columns (H2O Q2 shape): select sum(v) by {id1, id2}, id1/id2 i64 uniform [0,100) seeds 10/11, v f64 seed 5", rows=1_000_000_000,
+               bytes_per_row=24, dtype="f64", kernel="k_composite_key+k_group_dense"),
     "w2": dict(desc="where ids: (where (< a 100000)) on the C2 column -> 1e8 ascending i64 row ids (8 B/row in + 8 B/selected row out)", rows=1_000_000_000,
                bytes_per_row=8.8, dtype="int64", kernel="k_sel_bitmap<1>+k_emit_ids"),
     "m2": dict(desc="B8 mask: (< a 100000) materialised as the reference's byte mask (8 B/row in + 1 B/row out)", rows=1_000_000_000, bytes_per_row=9,
@@ -63,9 +72,19 @@ class Job:
         from rayforce_amd import _lib as L
         self.name, self.eng, self.sh, self.rows = name, eng, sharded, rows
         g = eng
+        self.key = "k"
         if name == "c2":
             self.t = {"a": g.gen_i64(rows, 2, 1_000_000, row0)}
             self.aggs, self.where = [("sum", "a")], ("<", "a", 100_000)
+        elif name == "c1":
+            self.t = {"v": g.gen_f64(rows, 1, row0)}
+            self.aggs, self.where = [("sum", "v")], None
+        elif name == "c3w":
+            self.t = {"k": g.gen_i64(rows, 4, 1_000_000, row0), "v": g.gen_f64(rows, 5, row0), "a": g.gen_i64(rows, 2, 1_000_000, row0)}
+            self.aggs, self.where = [("sum", "v")], ("<", "a", 100_000)
+        elif name == "q2":
+            self.t = {"id1": g.gen_i64(rows, 10, 100, row0), "id2": g.gen_i64(rows, 11, 100, row0), "v": g.gen_f64(rows, 5, row0)}
+            self.aggs, self.where, self.key = [("sum", "v")], None, ["id1", "id2"]
         elif name in ("w2", "m2"):
             self.t = {"a": g.gen_i64(rows, 2, 1_000_000, row0)}
             self.aggs, self.where = [], ("<", "a", 100_000)
@@ -103,10 +122,10 @@ class Job:
             ids = self.sh.where(self.where, self.t) if self.sh is not None else self.eng.where(self.where, self.t)
             self.eng.sync()
             return ([int(ids.numel())], int(ids.numel()))
-        if self.name == "c3":
+        if self.name in ("c3", "c3w", "q2"):
             if self.sh is not None:
-                return self.sh.group_by("k", self.aggs, self.where, self.t)
-            return self.eng.group_by("k", self.aggs, self.where, self.t)
+                return self.sh.group_by(self.key, self.aggs, self.where, self.t)
+            return self.eng.group_by(self.key, self.aggs, self.where, self.t)
         if self.sh is not None:
             return self.sh.filter_aggr(self.aggs, self.where, self.t)
         return self.eng.filter_aggr(self.aggs, self.where, self.t, nrows=self.rows)
@@ -143,7 +162,7 @@ def run_workload(name, eng, sharded, rows, row0, steps, warmup, world):
     job = Job(name, eng, sharded, rows, row0)
     dt, kms, res = timed(job, steps, warmup, world)
     ms_step = dt * 1e3 / steps
-    if name in ("c3", "w2"):
+    if name in ("c3", "c3w", "q2", "w2"):
         kms = ms_step  # several dependent kernels (scope+hist, scatter, aggregate, rank, emit): price the whole query
     value = world * rows / (dt / steps)
     alg_bytes = w["bytes_per_row"] * rows  # per launch, per GPU (SURVEY 8d figures, stated in DESIGN.md)
@@ -186,6 +205,18 @@ def cpu_baseline(name, sample_rows):
         cols = {"a": rfo.gen_i64(sample_rows, 2, 1_000_000)}
         q = "(select {s: (sum a) from: t where: (< a 100000)})"
         oq = {"where": ("<", "a", 100_000), "s": ("sum", "a")}
+    elif name == "c1":
+        cols = {"v": rfo.gen_f64(sample_rows, 1)}
+        q = "(sum v)"
+        oq = {"s": ("sum", "v")}
+    elif name == "c3w":
+        cols = {"k": rfo.gen_i64(sample_rows, 4, 1_000_000), "v": rfo.gen_f64(sample_rows, 5), "a": rfo.gen_i64(sample_rows, 2, 1_000_000)}
+        q = "(select {s: (sum v) from: t where: (< a 100000) by: k})"
+        oq = {"where": ("<", "a", 100_000), "by": "k", "s": ("sum", "v")}
+    elif name == "q2":
+        cols = {"id1": rfo.gen_i64(sample_rows, 10, 100), "id2": rfo.gen_i64(sample_rows, 11, 100), "v": rfo.gen_f64(sample_rows, 5)}
+        q = "(select {s: (sum v) from: t by: {id1: id1 id2: id2}})"
+        oq = {"by": {"id1": "id1", "id2": "id2"}, "s": ("sum", "v")}
     elif name == "c2b":
         cols = {"a": rfo.gen_i64(sample_rows, 2, 1_000_000), "b": rfo.gen_f64(sample_rows, 3)}
         q = "(select {s: (sum b) from: t where: (< a 100000)})"
@@ -317,7 +348,7 @@ def main():
             cpu = None
         # the reference's CPU path beside the secondary workloads too (smaller samples: the whole run stays within minutes)
         for other in also:
-            if other in ("c2b", "c3", "c5") and "error" not in also[other]:
+            if other in ("c1", "c2b", "c3", "c3w", "q2", "c5") and "error" not in also[other]:
                 try:
                     cb = cpu_baseline(other, min(20_000_000, WORKLOADS[other]["rows"]))
                     also[other]["cpu_baseline"] = {k: cb[k] for k in ("value", "unit", "cores", "kind", "ms_per_query")}

@@ -128,10 +128,13 @@ int rfx_hip_ctx_set_stream(rfx_ctx_t *ctx, void *stream);
 enum {
     RFX_TUNE_NO_LDS_TABLES = 1,   /* dense group-by: never privatise tables in LDS */
     RFX_TUNE_NO_PARTITION = 2,    /* dense group-by: never take the radix-partitioned path (device-scope atomics instead) */
+    RFX_TUNE_NO_BIG_LDS = 4,        /* dense group-by: LDS tables only up to 64 KB (no 1024-thread / 160 KB variant) */
     RFX_TUNE_PART_3WG = 8,          /* partitioned path: 3 scatter workgroups per CU instead of 2 */
     RFX_TUNE_NO_WRITE_COMBINE = 16, /* partitioned path: plain sorted-tile scatter instead of 128-byte write combining */
     RFX_TUNE_DIRECT_WC = 32,        /* partitioned path, one value plane: register-direct write combining instead of the tile-sorted form */
-    RFX_TUNE_NO_FUSED_SCOPE = 128 /* rfx_hip_scope_i64: plain min/max pass, no partition histogram side product */
+    RFX_TUNE_FUSED_KEYS = 64,       /* several key columns: always fold them on the fly, never materialise the composite column */
+    RFX_TUNE_NO_FUSED_SCOPE = 128,  /* rfx_hip_scope_i64: plain min/max pass, no partition histogram side product */
+    RFX_TUNE_NO_SEL_COMPACT = 256   /* partitioned path under a filter: never compact the selected rows first */
 };
 int rfx_hip_ctx_tune(rfx_ctx_t *ctx, int blocks_per_cu, int flags);
 
@@ -267,6 +270,13 @@ int rfx_hip_composite_key(rfx_ctx_t *ctx, const void *const *d_cols, const int64
                           int64_t nrows, int64_t *d_out);
 int rfx_hip_composite_decode(rfx_ctx_t *ctx, const int64_t *d_comp, int64_t n, int64_t min, int64_t mult, int64_t range,
                              int64_t *d_out);
+/* Dense scatter-aggregate keyed by several columns: the same contract as rfx_hip_group_dense_accumulate with
+ * slot = sum_i (d_keys[i][row] - mins[i]) * mults[i]  and tables over {kmin = 0, range = total_max + 1}.  Where the tables
+ * fit LDS the keys are folded on the fly (no composite column is written); otherwise the composite column is materialised
+ * in context-owned scratch (as the reference does) and the single-key paths run on it. */
+int rfx_hip_group_dense_accumulate_keys(rfx_ctx_t *ctx, const void *const *d_keys, const int64_t *mins, const int64_t *mults,
+                                        int nkeys, const rfx_pred_t *preds, int npred, int logic, const rfx_agg_t *aggs,
+                                        int64_t nrows, int64_t row0, const rfx_group_tables_t *t);
 
 /* ---- hash primitives pinned against the reference (core/hash.c:530-542, core/hash.h:86-97) ---- */
 int rfx_hip_hash_fnv1a_i64(rfx_ctx_t *ctx, const int64_t *d_in, int64_t n, uint64_t *d_out);

@@ -113,6 +113,8 @@ PROTOTYPES = {
     "rfx_hip_hash_mix_u64": (C.c_int, [_ctx, C.c_void_p, C.c_int64, C.c_uint64, C.c_void_p]),
     "rfx_composite_plan": (C.c_int, [C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "rfx_hip_composite_key": (C.c_int, [_ctx, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_int, C.c_int64, C.c_void_p]),
+    "rfx_hip_group_dense_accumulate_keys": (C.c_int, [_ctx, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_int, _P(Pred),
+                                                      C.c_int, C.c_int, _P(Agg), C.c_int64, C.c_int64, _P(GroupTables)]),
     "rfx_hip_composite_decode": (C.c_int, [_ctx, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_void_p]),
 }
 

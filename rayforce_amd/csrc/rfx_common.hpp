@@ -66,11 +66,16 @@ struct rfx_ctx {
     size_t gid_cap;
     void *d_part;       // partitioned group-by: offsets + record planes (grow-only)
     size_t part_bytes;
+    void *d_comp;       // materialised composite key column of a multi-key group-by (grow-only)
+    size_t comp_bytes;
+    void *d_sel;        // compacted (key, values, row ids) of a selectively filtered partitioned group-by (grow-only)
+    size_t sel_bytes;
     // scope + low-bit histogram computed together by rfx_hip_scope_i64 and consumed by the next group_dense_accumulate
     u64 *d_pc_counts;   // [pc_nwg][256]
     int pc_valid, pc_npred, pc_logic, pc_nwg;
     const void *pc_key;
     i64 pc_nrows;
+    i64 pc_seen;        // rows that passed the predicates in that scope pass
     u64 pc_sig[RFX_MAX_PREDS][6];
 };
 
@@ -78,6 +83,9 @@ int rfx_ws_reserve(rfx_ctx *ctx, size_t bytes);
 int rfx_bitmap_reserve(rfx_ctx *ctx, i64 nrows);
 int rfx_gid_reserve(rfx_ctx *ctx, i64 slots);
 int rfx_part_reserve(rfx_ctx *ctx, size_t bytes);
+int rfx_comp_reserve(rfx_ctx *ctx, size_t bytes);
+int rfx_sel_reserve(rfx_ctx *ctx, size_t bytes);
+int rfx_plan_add_col(struct Plan *P, const void *col); // index of `col` in P->cols (added if new), -1 when full
 #define RFX_KERNEL_BEGIN(c) do { if ((c)->profile) { (void)hipEventRecord((c)->evk0, (c)->stream); } } while (0)
 #define RFX_KERNEL_END(c) do { if ((c)->profile) { (void)hipEventRecord((c)->evk1, (c)->stream); (c)->evk_valid = 1; } } while (0)
 static inline int rfx_grid(const rfx_ctx *ctx) { return ctx->num_cus * ctx->blocks_per_cu; }

@@ -65,6 +65,8 @@ extern "C" int rfx_hip_ctx_destroy(rfx_ctx_t *c) {
     if (c->d_blksum) (void)hipFree(c->d_blksum);
     if (c->d_gid) (void)hipFree(c->d_gid);
     if (c->d_part) (void)hipFree(c->d_part);
+    if (c->d_comp) (void)hipFree(c->d_comp);
+    if (c->d_sel) (void)hipFree(c->d_sel);
     if (c->d_pc_counts) (void)hipFree(c->d_pc_counts);
     if (c->h_pin) (void)hipHostFree(c->h_pin);
     (void)hipEventDestroy(c->ev0);
@@ -156,6 +158,28 @@ int rfx_part_reserve(rfx_ctx *c, size_t bytes) {
     c->part_bytes = 0;
     RFX_HIP_CHECK(hipMalloc(&c->d_part, bytes));
     c->part_bytes = bytes;
+    return RFX_OK;
+}
+
+int rfx_sel_reserve(rfx_ctx *c, size_t bytes) {
+    if (c->sel_bytes >= bytes) return RFX_OK;
+    RFX_HIP_CHECK(hipStreamSynchronize(c->stream));
+    if (c->d_sel) RFX_HIP_CHECK(hipFree(c->d_sel));
+    c->d_sel = NULL;
+    c->sel_bytes = 0;
+    RFX_HIP_CHECK(hipMalloc(&c->d_sel, bytes));
+    c->sel_bytes = bytes;
+    return RFX_OK;
+}
+
+int rfx_comp_reserve(rfx_ctx *c, size_t bytes) {
+    if (c->comp_bytes >= bytes) return RFX_OK;
+    RFX_HIP_CHECK(hipStreamSynchronize(c->stream));
+    if (c->d_comp) RFX_HIP_CHECK(hipFree(c->d_comp));
+    c->d_comp = NULL;
+    c->comp_bytes = 0;
+    RFX_HIP_CHECK(hipMalloc(&c->d_comp, bytes));
+    c->comp_bytes = bytes;
     return RFX_OK;
 }
 
@@ -253,6 +277,8 @@ static int plan_col(Plan *P, const void *p) {
     P->cols[P->ncols] = (const u64 *)p;
     return P->ncols++;
 }
+
+int rfx_plan_add_col(Plan *P, const void *col) { return plan_col(P, col); }
 
 static inline u64 host_f64_bits(double d) { u64 b; memcpy(&b, &d, 8); return b; }
 

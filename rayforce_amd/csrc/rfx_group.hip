@@ -20,18 +20,24 @@ struct GroupArgs {
     i64 range;
     int key_idx; // column index of the key inside Plan::cols
     int nagg;
+    // several key columns folded on the fly (index_group_list_perfect_partial, core/index.c:2238-2305): nkeys >= 2,
+    // slot = sum_i (col[kidx[i]] - kmn[i]) * kmul[i]; kmin is 0 then
+    int nkeys;
+    int kidx[RFX_MAX_KEYS];
+    u64 kmn[RFX_MAX_KEYS];
+    u64 kmul[RFX_MAX_KEYS];
     u64 *first;
     u64 *acc[RFX_MAX_AGGS];
     u64 *cnt[RFX_MAX_AGGS];
 };
 
 // ---- K7 + K10, one pass.  LDS = true: tables privatised in dynamic LDS, merged at the end. ----
-template <int NC, bool LDS>
-__global__ __launch_bounds__(RFX_BLOCK) void k_group_dense(const Plan P, const GroupArgs G) {
+template <int NC, bool LDS, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_group_dense(const Plan P, const GroupArgs G) {
     constexpr int U = (NC <= 2) ? 4 : (NC <= 4 ? 2 : 1);
     constexpr int E = 2 * U;
-    constexpr int TILE = RFX_BLOCK * E;
-    constexpr int JSTRIDE = RFX_BLOCK * 2;
+    constexpr int TILE = BLOCK * E;
+    constexpr int JSTRIDE = BLOCK * 2;
     extern __shared__ __attribute__((aligned(16))) u64 smem[];
     const int tid = threadIdx.x;
     const i64 range = G.range;
@@ -40,15 +46,15 @@ __global__ __launch_bounds__(RFX_BLOCK) void k_group_dense(const Plan P, const G
 
     // LDS layout: [first | acc0 | (cnt0) | acc1 | ...] each `range` cells
     if (LDS) {
-        for (i64 i = tid; i < range; i += RFX_BLOCK) smem[i] = (u64)RFX_INF_I64_D;
+        for (i64 i = tid; i < range; i += BLOCK) smem[i] = (u64)RFX_INF_I64_D;
         int arr = 1;
         for (int a = 0; a < G.nagg; a++) {
             const PlanAgg ag = P.aggs[a];
             u64 id = acc_identity(ag.kind, ag.f64);
-            for (i64 i = tid; i < range; i += RFX_BLOCK) smem[(i64)arr * range + i] = id;
+            for (i64 i = tid; i < range; i += BLOCK) smem[(i64)arr * range + i] = id;
             arr++;
             if (agg_has_cnt(ag.kind, ag.f64)) {
-                for (i64 i = tid; i < range; i += RFX_BLOCK) smem[(i64)arr * range + i] = 0;
+                for (i64 i = tid; i < range; i += BLOCK) smem[(i64)arr * range + i] = 0;
                 arr++;
             }
         }
@@ -86,13 +92,27 @@ __global__ __launch_bounds__(RFX_BLOCK) void k_group_dense(const Plan P, const G
         }
         const unsigned m = eval_preds<NC, E, RFX_MAX_PREDS>(S, v, valid);
         if (m == 0) continue;
-        u64 key[E];
-        sel_col<NC, E>(key, v, G.key_idx);
+        u64 key[E]; // slot in the dense table
+        if (G.nkeys <= 1) {
+            sel_col<NC, E>(key, v, G.key_idx);
+#pragma unroll
+            for (int e = 0; e < E; e++) key[e] -= (u64)G.kmin;
+        } else {
+#pragma unroll
+            for (int e = 0; e < E; e++) key[e] = 0;
+            for (int i = 0; i < G.nkeys; i++) {
+                u64 x[E];
+                sel_col<NC, E>(x, v, G.kidx[i]);
+                const u64 mn = G.kmn[i], mu = G.kmul[i];
+#pragma unroll
+                for (int e = 0; e < E; e++) key[e] += (x[e] - mn) * mu;
+            }
+        }
         // first-occurrence table
 #pragma unroll
         for (int e = 0; e < E; e++) {
             if (!((m >> e) & 1u)) continue;
-            const u64 slot = key[e] - (u64)G.kmin;
+            const u64 slot = key[e];
             if (slot >= (u64)range) continue; // outside the agreed scope (cannot happen when scope came from these rows)
             const u64 row = (u64)(P.row0 + base + (i64)(e >> 1) * JSTRIDE + (e & 1));
             if (LDS) {
@@ -111,7 +131,7 @@ __global__ __launch_bounds__(RFX_BLOCK) void k_group_dense(const Plan P, const G
 #pragma unroll
             for (int e = 0; e < E; e++) {
                 if (!((m >> e) & 1u)) continue;
-                const u64 slot = key[e] - (u64)G.kmin;
+                const u64 slot = key[e];
                 if (slot >= (u64)range) continue;
                 if (LDS) group_apply(&smem[(i64)arr * range + slot], &smem[(i64)(arr + 1) * range + slot], ag.kind, ag.f64, x[e]);
                 else group_apply(&G.acc[a][slot], G.cnt[a] ? &G.cnt[a][slot] : (u64 *)0, ag.kind, ag.f64, x[e]);
@@ -122,7 +142,7 @@ __global__ __launch_bounds__(RFX_BLOCK) void k_group_dense(const Plan P, const G
 
     if (LDS) {
         __syncthreads();
-        for (i64 i = tid; i < range; i += RFX_BLOCK) {
+        for (i64 i = tid; i < range; i += BLOCK) {
             const u64 f = smem[i];
             if (f == (u64)RFX_INF_I64_D) continue; // slot untouched by this workgroup
             if (f < G.first[i]) atomicMin((unsigned long long *)&G.first[i], (unsigned long long)f);
@@ -188,12 +208,66 @@ extern "C" int rfx_hip_group_tables_init(rfx_ctx_t *c, const rfx_agg_t *aggs, co
     return RFX_OK;
 }
 
-#define RFX_LDS_GROUP_BYTES (64 * 1024) /* per workgroup: two workgroups per CU keep streaming at full rate */
+#define RFX_LDS_GROUP_BYTES (64 * 1024)      /* per 256-thread workgroup: two workgroups per CU keep streaming at full rate */
+#define RFX_LDS_GROUP_BIG_BYTES (160 * 1024) /* one 1024-thread workgroup per CU owning the whole LDS (mid-range key counts) */
 
 template <int NC>
-static void launch_group(rfx_ctx *c, const Plan &P, const GroupArgs &G, int grid, size_t lds_bytes) {
-    if (lds_bytes) hipLaunchKernelGGL((k_group_dense<NC, true>), dim3(grid), dim3(RFX_BLOCK), lds_bytes, c->stream, P, G);
-    else hipLaunchKernelGGL((k_group_dense<NC, false>), dim3(grid), dim3(RFX_BLOCK), 0, c->stream, P, G);
+static int launch_group(rfx_ctx *c, const Plan &P, const GroupArgs &G, int grid, size_t lds_bytes) {
+    if (lds_bytes > RFX_LDS_GROUP_BYTES) {
+        static bool attr_set = false; // per template instance: dynamic LDS above 64 KB must be opted into once
+        if (!attr_set) {
+            RFX_HIP_CHECK(hipFuncSetAttribute((const void *)k_group_dense<NC, true, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, RFX_LDS_GROUP_BIG_BYTES));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL((k_group_dense<NC, true, 1024>), dim3(c->num_cus), dim3(1024), lds_bytes, c->stream, P, G);
+    } else if (lds_bytes) hipLaunchKernelGGL((k_group_dense<NC, true, RFX_BLOCK>), dim3(grid), dim3(RFX_BLOCK), lds_bytes, c->stream, P, G);
+    else hipLaunchKernelGGL((k_group_dense<NC, false, RFX_BLOCK>), dim3(grid), dim3(RFX_BLOCK), 0, c->stream, P, G);
+    return RFX_OK;
+}
+
+static int group_dense_run(rfx_ctx_t *c, Plan &P, GroupArgs &G, const rfx_agg_t *aggs, const rfx_group_tables_t *t, bool allow_part, bool *need_materialise) {
+    G.kmin = t->kmin;
+    G.range = t->range;
+    G.nagg = t->nagg;
+    G.first = (u64 *)t->d_first;
+    int narr = 1;
+    for (int a = 0; a < t->nagg; a++) {
+        G.acc[a] = (u64 *)t->d_acc[a];
+        G.cnt[a] = (u64 *)t->d_cnt[a];
+        narr += 1 + (agg_has_cnt(aggs[a].kind, aggs[a].col_type == RFX_F64) ? 1 : 0);
+    }
+    size_t lds_bytes = (size_t)narr * (size_t)t->range * 8;
+    const size_t lds_cap = (c->flags & RFX_TUNE_NO_BIG_LDS) ? RFX_LDS_GROUP_BYTES : RFX_LDS_GROUP_BIG_BYTES;
+    const bool use_lds = lds_bytes <= lds_cap && !(c->flags & RFX_TUNE_NO_LDS_TABLES);
+    if (need_materialise) {
+        // several keys: fold them on the fly only where the LDS tables make the pass stream; the big-range paths
+        // (partitioned, device atomics) want the one materialised key column the reference builds too
+        *need_materialise = !use_lds && !(c->flags & RFX_TUNE_FUSED_KEYS);
+        if (*need_materialise) return RFX_OK;
+    }
+    int rc;
+    if (!use_lds && allow_part && !(c->flags & RFX_TUNE_NO_PARTITION)) {
+        rc = rfx_group_part_accumulate(c, P, G.key_idx, t);
+        if (rc != RFX_ESTATE) return rc; // RFX_ESTATE = "partitioned path not applicable", fall through to atomics
+    }
+    if (!use_lds) lds_bytes = 0;
+    int grid = rfx_grid(c);
+    rc = RFX_OK;
+    RFX_KERNEL_BEGIN(c);
+    switch (P.ncols) {
+        case 1: rc = launch_group<1>(c, P, G, grid, lds_bytes); break;
+        case 2: rc = launch_group<2>(c, P, G, grid, lds_bytes); break;
+        case 3: rc = launch_group<3>(c, P, G, grid, lds_bytes); break;
+        case 4: rc = launch_group<4>(c, P, G, grid, lds_bytes); break;
+        case 5: rc = launch_group<5>(c, P, G, grid, lds_bytes); break;
+        case 6: rc = launch_group<6>(c, P, G, grid, lds_bytes); break;
+        case 7: rc = launch_group<7>(c, P, G, grid, lds_bytes); break;
+        default: rc = launch_group<8>(c, P, G, grid, lds_bytes); break;
+    }
+    RFX_KERNEL_END(c);
+    if (rc != RFX_OK) return rc;
+    RFX_HIP_CHECK(hipGetLastError());
+    return RFX_OK;
 }
 
 extern "C" int rfx_hip_group_dense_accumulate(rfx_ctx_t *c, const int64_t *d_key, const rfx_pred_t *preds, int npred,
@@ -209,39 +283,48 @@ extern "C" int rfx_hip_group_dense_accumulate(rfx_ctx_t *c, const int64_t *d_key
     if (rc != RFX_OK) return rc;
     GroupArgs G;
     memset(&G, 0, sizeof(G));
-    G.kmin = t->kmin;
-    G.range = t->range;
     G.key_idx = key_idx;
-    G.nagg = t->nagg;
-    G.first = (u64 *)t->d_first;
-    int narr = 1;
-    for (int a = 0; a < t->nagg; a++) {
-        G.acc[a] = (u64 *)t->d_acc[a];
-        G.cnt[a] = (u64 *)t->d_cnt[a];
-        narr += 1 + (agg_has_cnt(aggs[a].kind, aggs[a].col_type == RFX_F64) ? 1 : 0);
+    G.nkeys = 1;
+    return group_dense_run(c, P, G, aggs, t, true, NULL);
+}
+
+// Several key columns.  t->kmin must be 0 and t->range the composite range (rfx_composite_plan).
+extern "C" int rfx_hip_group_dense_accumulate_keys(rfx_ctx_t *c, const void *const *d_keys, const int64_t *mins, const int64_t *mults,
+                                                   int nkeys, const rfx_pred_t *preds, int npred, int logic, const rfx_agg_t *aggs,
+                                                   int64_t nrows, int64_t row0, const rfx_group_tables_t *t) {
+    RFX_REQUIRE(c && d_keys && mins && mults, RFX_EINVAL, "NULL argument");
+    RFX_REQUIRE(nkeys >= 1 && nkeys <= RFX_MAX_KEYS, RFX_ELIMIT, "1..RFX_MAX_KEYS key columns");
+    int rc = check_tables(aggs, t);
+    if (rc != RFX_OK) return rc;
+    RFX_REQUIRE(t->kmin == 0, RFX_EINVAL, "composite tables start at key 0");
+    if (nrows == 0) return RFX_OK;
+    for (int i = 0; i < nkeys; i++) RFX_REQUIRE(d_keys[i] != NULL, RFX_EINVAL, "key column is NULL");
+    Plan P;
+    int k0 = 0;
+    rc = rfx_plan_build(&P, preds, npred, logic, aggs, t->nagg, d_keys[0], &k0, nrows, row0);
+    if (rc != RFX_OK) return rc;
+    GroupArgs G;
+    memset(&G, 0, sizeof(G));
+    G.key_idx = k0;
+    G.nkeys = nkeys;
+    bool fits = true;
+    for (int i = 0; i < nkeys; i++) {
+        G.kidx[i] = (i == 0) ? k0 : rfx_plan_add_col(&P, d_keys[i]);
+        if (G.kidx[i] < 0) fits = false; // more than RFX_MAX_COLS distinct columns in one pass
+        G.kmn[i] = (u64)mins[i];
+        G.kmul[i] = (u64)mults[i];
     }
-    size_t lds_bytes = (size_t)narr * (size_t)t->range * 8;
-    const bool use_lds = lds_bytes <= RFX_LDS_GROUP_BYTES && !(c->flags & RFX_TUNE_NO_LDS_TABLES);
-    if (!use_lds && !(c->flags & RFX_TUNE_NO_PARTITION)) {
-        rc = rfx_group_part_accumulate(c, P, key_idx, t);
-        if (rc != RFX_ESTATE) return rc; // RFX_ESTATE = "partitioned path not applicable", fall through to atomics
+    bool materialise = !fits;
+    if (fits) {
+        rc = group_dense_run(c, P, G, aggs, t, false, &materialise);
+        if (rc != RFX_OK || !materialise) return rc;
     }
-    if (!use_lds) lds_bytes = 0;
-    int grid = rfx_grid(c);
-    RFX_KERNEL_BEGIN(c);
-    switch (P.ncols) {
-        case 1: launch_group<1>(c, P, G, grid, lds_bytes); break;
-        case 2: launch_group<2>(c, P, G, grid, lds_bytes); break;
-        case 3: launch_group<3>(c, P, G, grid, lds_bytes); break;
-        case 4: launch_group<4>(c, P, G, grid, lds_bytes); break;
-        case 5: launch_group<5>(c, P, G, grid, lds_bytes); break;
-        case 6: launch_group<6>(c, P, G, grid, lds_bytes); break;
-        case 7: launch_group<7>(c, P, G, grid, lds_bytes); break;
-        default: launch_group<8>(c, P, G, grid, lds_bytes); break;
-    }
-    RFX_KERNEL_END(c);
-    RFX_HIP_CHECK(hipGetLastError());
-    return RFX_OK;
+    // one composite column (as the reference, core/index.c:2386-2418), then the single-key machinery
+    rc = rfx_comp_reserve(c, (size_t)nrows * 8);
+    if (rc != RFX_OK) return rc;
+    rc = rfx_hip_composite_key(c, d_keys, mins, mults, nkeys, nrows, (int64_t *)c->d_comp);
+    if (rc != RFX_OK) return rc;
+    return rfx_hip_group_dense_accumulate(c, (const int64_t *)c->d_comp, preds, npred, logic, aggs, nrows, row0, t);
 }
 
 // ---------------- K8: rank occupied slots by first row ----------------

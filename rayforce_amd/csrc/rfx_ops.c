@@ -538,24 +538,29 @@ rfx_obj_p rfx_select(rfx_obj_p dict) {
         if (by) {
             int64_t kmin, kmax, seen;
             if (nkeys > 1) {
-                int64_t cnt = 0;
+                /* scopes of every key column, then the reference's multiplier plan (core/index.c:2340-2383); no where: here */
+                seen = 0;
                 for (int i = 0; i < nkeys; i++)
-                    if (rfx_hip_scope_i64(g_ctx, (const int64_t *)dks[i], NULL, 0, RFX_AND, nrows, &kmins[i], &kmaxs[i], &cnt) != RFX_OK) { res = fail_hip("scope"); goto done; }
-                if (cnt > 0) {
+                    if (rfx_hip_scope_i64(g_ctx, (const int64_t *)dks[i], NULL, 0, RFX_AND, nrows, &kmins[i], &kmaxs[i], &seen) != RFX_OK) { res = fail_hip("scope"); goto done; }
+                kmin = 0;
+                kmax = -1;
+                if (seen > 0) {
                     if (rfx_composite_plan(kmins, kmaxs, nkeys, kmults, &comp_max) != RFX_OK) { why = "by: key ranges overflow the composite key (row-hash path)"; goto out; }
-                    void *comp = NULL;
-                    if (rfx_hip_malloc(g_ctx, &comp, (size_t)nrows * 8) != RFX_OK) { res = fail_hip("composite key"); goto done; }
-                    tmp[ntmp++] = comp;
-                    if (rfx_hip_composite_key(g_ctx, dks, kmins, kmults, nkeys, nrows, (int64_t *)comp) != RFX_OK) {
-                        for (int i = 0; i < ntmp; i++) rfx_hip_free(g_ctx, tmp[i]);
-                        res = fail_hip("composite key");
-                        goto done;
+                    kmax = comp_max; /* forced scope {0, max}, core/index.c:2421 */
+                    if ((uint64_t)comp_max + 1 > (uint64_t)seen) {
+                        /* sparse composite: the hashed path keys on the materialised column */
+                        void *comp = NULL;
+                        if (rfx_hip_malloc(g_ctx, &comp, (size_t)nrows * 8) != RFX_OK) { res = fail_hip("composite key"); goto done; }
+                        tmp[ntmp++] = comp;
+                        if (rfx_hip_composite_key(g_ctx, dks, kmins, kmults, nkeys, nrows, (int64_t *)comp) != RFX_OK) {
+                            for (int i = 0; i < ntmp; i++) rfx_hip_free(g_ctx, tmp[i]);
+                            res = fail_hip("composite key");
+                            goto done;
+                        }
+                        dk = comp;
                     }
-                    dk = comp;
                 }
-            }
-            if (rfx_hip_scope_i64(g_ctx, (const int64_t *)dk, wp.preds, wp.npred, wp.logic, nrows, &kmin, &kmax, &seen) != RFX_OK) { res = fail_hip("scope"); goto done; }
-            if (nkeys > 1 && seen > 0) { kmin = 0; kmax = comp_max; } /* forced scope, core/index.c:2421 */
+            } else if (rfx_hip_scope_i64(g_ctx, (const int64_t *)dk, wp.preds, wp.npred, wp.logic, nrows, &kmin, &kmax, &seen) != RFX_OK) { res = fail_hip("scope"); goto done; }
             int64_t groups = 0;
             obj_p okeys = NULL, ocols[RFX_MAX_AGGS] = {0}, okcols[RFX_MAX_KEYS] = {0};
             if (seen > 0) {
@@ -589,7 +594,8 @@ rfx_obj_p rfx_select(rfx_obj_p dict) {
                 }
                 if (dense) {
                     ok = rfx_hip_group_tables_init(g_ctx, aggs, &gt) == RFX_OK &&
-                         rfx_hip_group_dense_accumulate(g_ctx, (const int64_t *)dk, wp.preds, wp.npred, wp.logic, aggs, nrows, 0, &gt) == RFX_OK &&
+                         (nkeys > 1 ? rfx_hip_group_dense_accumulate_keys(g_ctx, dks, kmins, kmults, nkeys, wp.preds, wp.npred, wp.logic, aggs, nrows, 0, &gt)
+                                    : rfx_hip_group_dense_accumulate(g_ctx, (const int64_t *)dk, wp.preds, wp.npred, wp.logic, aggs, nrows, 0, &gt)) == RFX_OK &&
                          rfx_hip_group_rank(g_ctx, &gt, nrows, &groups) == RFX_OK;
                 } else {
                     ok = rfx_hip_hash_tables_init(g_ctx, aggs, &ht) == RFX_OK &&

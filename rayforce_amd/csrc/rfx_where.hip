@@ -239,18 +239,7 @@ static void launch_sel_bitmap(rfx_ctx *c, const Plan &P, int grid) {
     else hipLaunchKernelGGL((k_sel_bitmap<NC, RFX_MAX_PREDS>), dim3(grid), dim3(RFX_BLOCK), 0, c->stream, P, c->d_bitmap, c->d_blksum);
 }
 
-extern "C" int rfx_hip_where_begin(rfx_ctx_t *c, const rfx_pred_t *preds, int npred, int logic, const int8_t *d_mask,
-                                   int64_t nrows, int64_t *count) {
-    RFX_REQUIRE(c && count, RFX_EINVAL, "NULL argument");
-    RFX_REQUIRE(nrows >= 0, RFX_EINVAL, "nrows < 0");
-    c->where_n = -1;
-    *count = 0;
-    if (nrows == 0) {
-        c->where_n = 0;
-        c->where_count = 0;
-        return RFX_OK;
-    }
-    RFX_REQUIRE((d_mask != NULL) != (npred > 0), RFX_EINVAL, "give either predicates or a byte mask");
+static int where_reserve(rfx_ctx *c, i64 nrows) {
     int rc = rfx_bitmap_reserve(c, ((nrows + RFX_CHUNK - 1) / RFX_CHUNK) * RFX_CHUNK);
     if (rc != RFX_OK) return rc;
     // blksum is sized per 2048 rows by rfx_bitmap_reserve; we need one entry per 512 rows (+1 for the total)
@@ -263,37 +252,173 @@ extern "C" int rfx_hip_where_begin(rfx_ctx_t *c, const rfx_pred_t *preds, int np
         RFX_HIP_CHECK(hipMalloc((void **)&c->d_blksum, ((size_t)nchunks + 2) * 8));
         c->blksum_cap = (size_t)nchunks + 2;
     }
+    return RFX_OK;
+}
+
+// P must hold only the predicate columns (every column of P is loaded).
+static void where_launch_bitmap(rfx_ctx *c, const Plan &P) {
+    const i64 nchunks = (P.nrows + RFX_CHUNK - 1) / RFX_CHUNK;
     int grid = c->num_cus * 4;
     if ((i64)grid * 4 > nchunks) grid = (int)((nchunks + 3) / 4);
+    switch (P.ncols) {
+        case 1: launch_sel_bitmap<1>(c, P, grid); break;
+        case 2: launch_sel_bitmap<2>(c, P, grid); break;
+        case 3: launch_sel_bitmap<3>(c, P, grid); break;
+        case 4: launch_sel_bitmap<4>(c, P, grid); break;
+        case 5: launch_sel_bitmap<5>(c, P, grid); break;
+        case 6: launch_sel_bitmap<6>(c, P, grid); break;
+        case 7: launch_sel_bitmap<7>(c, P, grid); break;
+        default: launch_sel_bitmap<8>(c, P, grid); break;
+    }
+}
+
+static int where_scan_total(rfx_ctx *c, i64 nrows, i64 *count) {
+    const i64 nchunks = (nrows + RFX_CHUNK - 1) / RFX_CHUNK;
+    i64 *d_total = c->d_blksum + nchunks;
+    int rc = rfx_scan_counts(c, c->d_blksum, nchunks, d_total);
+    if (rc != RFX_OK) return rc;
+    i64 *h = (i64 *)c->h_pin;
+    RFX_HIP_CHECK(hipMemcpyAsync(h, d_total, 8, hipMemcpyDeviceToHost, c->stream));
+    RFX_HIP_CHECK(hipStreamSynchronize(c->stream));
+    *count = h[0];
+    return RFX_OK;
+}
+
+// Internal (partitioned group-by under a selective filter): the predicates of `Pfull` -> selection bitmap + scanned
+// per-chunk offsets in the context, *count = selected rows.  Invalidates a pending where_begin.  (syncs)
+int rfx_where_bitmap_of_plan(rfx_ctx *c, const Plan &Pfull, i64 *count) {
+    c->where_n = -1;
+    int rc = where_reserve(c, Pfull.nrows);
+    if (rc != RFX_OK) return rc;
+    Plan Ph = Pfull; // keep only the columns the predicates read
+    int map[RFX_MAX_COLS], nh = 0;
+    for (int i = 0; i < RFX_MAX_COLS; i++) map[i] = -1;
+    for (int i = 0; i < Pfull.npred; i++) {
+        const int cs[2] = {Pfull.preds[i].col, Pfull.preds[i].rhs_col};
+        for (int j = 0; j < 2; j++)
+            if (cs[j] >= 0 && map[cs[j]] < 0) {
+                map[cs[j]] = nh;
+                Ph.cols[nh++] = Pfull.cols[cs[j]];
+            }
+    }
+    for (int i = 0; i < Pfull.npred; i++) {
+        Ph.preds[i].col = map[Pfull.preds[i].col];
+        if (Pfull.preds[i].rhs_col >= 0) Ph.preds[i].rhs_col = map[Pfull.preds[i].rhs_col];
+    }
+    Ph.ncols = nh;
+    Ph.nagg = 0;
+    where_launch_bitmap(c, Ph);
+    RFX_HIP_CHECK(hipGetLastError());
+    return where_scan_total(c, Pfull.nrows, count);
+}
+
+// Ordered compaction of whole columns by the context's bitmap: dst[c][r] = src[c][row] for the r-th selected row, and
+// rows32[r] = row (local).  A lane fetches its 16-byte row pair only when one of the two rows is selected.
+struct CompactArgs {
+    const u64 *src[4];
+    u64 *dst[4];
+    unsigned *rows32;
+};
+template <int NCOL>
+__global__ __launch_bounds__(RFX_BLOCK) void k_compact_cols(const u64 *__restrict__ bitmap, const i64 *__restrict__ chunk_off, i64 nrows,
+                                                          const CompactArgs A) {
+    const int lane = threadIdx.x & 63;
+    const i64 wave_id = (i64)blockIdx.x * (RFX_BLOCK / RFX_WAVE) + (threadIdx.x >> 6);
+    const i64 nwaves = (i64)gridDim.x * (RFX_BLOCK / RFX_WAVE);
+    const i64 nchunks = (nrows + RFX_CHUNK - 1) / RFX_CHUNK;
+    const u64 below = lanemask_lt();
+    for (i64 q = wave_id; q < nchunks; q += nwaves) {
+        i64 pos = chunk_off[q];
+        const u64 *w = bitmap + q * 8;
+        u64 ws[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) ws[i] = w[i];
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            const u64 w0 = ws[2 * g], w1 = ws[2 * g + 1];
+            if ((w0 | w1) == 0) continue;
+            const unsigned s0 = (unsigned)(w0 >> lane) & 1u, s1 = (unsigned)(w1 >> lane) & 1u;
+            const i64 r = pos + __popcll(w0 & below) + __popcll(w1 & below);
+            const i64 row = q * RFX_CHUNK + g * 128 + lane * 2;
+            if (s0 | s1) {
+                const bool pair_ok = row + 1 < nrows;
+#pragma unroll
+                for (int c = 0; c < NCOL; c++) {
+                    u64 x, y = 0;
+                    if (pair_ok) {
+                        const u64x2 t = rfx_ld2(A.src[c] + row);
+                        x = t.x;
+                        y = t.y;
+                    } else x = A.src[c][row];
+                    if (s0) A.dst[c][r] = x;
+                    if (s1) A.dst[c][r + s0] = y;
+                }
+                if (s0) A.rows32[r] = (unsigned)row;
+                if (s1) A.rows32[r + s0] = (unsigned)(row + 1);
+            }
+            pos += __popcll(w0) + __popcll(w1);
+        }
+    }
+}
+
+int rfx_where_compact_cols(rfx_ctx *c, i64 nrows, const u64 *const *src, u64 *const *dst, int ncol, unsigned *d_rows32) {
+    RFX_REQUIRE(ncol >= 1 && ncol <= 4, RFX_ELIMIT, "1..4 columns");
+    CompactArgs A;
+    memset(&A, 0, sizeof(A));
+    for (int i = 0; i < ncol; i++) {
+        A.src[i] = src[i];
+        A.dst[i] = dst[i];
+    }
+    A.rows32 = d_rows32;
+    const i64 nchunks = (nrows + RFX_CHUNK - 1) / RFX_CHUNK;
+    int grid = c->num_cus * 16;
+    if ((i64)grid * 4 > nchunks) grid = (int)((nchunks + 3) / 4);
+    const u64 *bm = (const u64 *)c->d_bitmap;
+    const i64 *off = (const i64 *)c->d_blksum;
+    switch (ncol) {
+        case 1: hipLaunchKernelGGL((k_compact_cols<1>), dim3(grid), dim3(RFX_BLOCK), 0, c->stream, bm, off, nrows, A); break;
+        case 2: hipLaunchKernelGGL((k_compact_cols<2>), dim3(grid), dim3(RFX_BLOCK), 0, c->stream, bm, off, nrows, A); break;
+        case 3: hipLaunchKernelGGL((k_compact_cols<3>), dim3(grid), dim3(RFX_BLOCK), 0, c->stream, bm, off, nrows, A); break;
+        default: hipLaunchKernelGGL((k_compact_cols<4>), dim3(grid), dim3(RFX_BLOCK), 0, c->stream, bm, off, nrows, A); break;
+    }
+    RFX_HIP_CHECK(hipGetLastError());
+    return RFX_OK;
+}
+
+extern "C" int rfx_hip_where_begin(rfx_ctx_t *c, const rfx_pred_t *preds, int npred, int logic, const int8_t *d_mask,
+                                   int64_t nrows, int64_t *count) {
+    RFX_REQUIRE(c && count, RFX_EINVAL, "NULL argument");
+    RFX_REQUIRE(nrows >= 0, RFX_EINVAL, "nrows < 0");
+    c->where_n = -1;
+    *count = 0;
+    if (nrows == 0) {
+        c->where_n = 0;
+        c->where_count = 0;
+        return RFX_OK;
+    }
+    RFX_REQUIRE((d_mask != NULL) != (npred > 0), RFX_EINVAL, "give either predicates or a byte mask");
+    int rc = where_reserve(c, nrows);
+    if (rc != RFX_OK) return rc;
+    const i64 nchunks = (nrows + RFX_CHUNK - 1) / RFX_CHUNK;
     RFX_KERNEL_BEGIN(c);
     if (d_mask) {
+        int grid = c->num_cus * 4;
+        if ((i64)grid * 4 > nchunks) grid = (int)((nchunks + 3) / 4);
         hipLaunchKernelGGL(k_mask_bitmap, dim3(grid), dim3(RFX_BLOCK), 0, c->stream, d_mask, (i64)nrows, c->d_bitmap, c->d_blksum);
     } else {
         Plan P;
         rc = rfx_plan_build(&P, preds, npred, logic, NULL, 0, NULL, NULL, nrows, 0);
         if (rc != RFX_OK) return rc;
-        switch (P.ncols) {
-            case 1: launch_sel_bitmap<1>(c, P, grid); break;
-            case 2: launch_sel_bitmap<2>(c, P, grid); break;
-            case 3: launch_sel_bitmap<3>(c, P, grid); break;
-            case 4: launch_sel_bitmap<4>(c, P, grid); break;
-            case 5: launch_sel_bitmap<5>(c, P, grid); break;
-            case 6: launch_sel_bitmap<6>(c, P, grid); break;
-            case 7: launch_sel_bitmap<7>(c, P, grid); break;
-            default: launch_sel_bitmap<8>(c, P, grid); break;
-        }
+        where_launch_bitmap(c, P);
     }
     RFX_KERNEL_END(c);
     RFX_HIP_CHECK(hipGetLastError());
-    i64 *d_total = c->d_blksum + nchunks;
-    rc = rfx_scan_counts(c, c->d_blksum, nchunks, d_total);
+    i64 total = 0;
+    rc = where_scan_total(c, nrows, &total);
     if (rc != RFX_OK) return rc;
-    i64 *h = (i64 *)c->h_pin;
-    RFX_HIP_CHECK(hipMemcpyAsync(h, d_total, 8, hipMemcpyDeviceToHost, c->stream));
-    RFX_HIP_CHECK(hipStreamSynchronize(c->stream));
     c->where_n = nrows;
-    c->where_count = h[0];
-    *count = h[0];
+    c->where_count = total;
+    *count = total;
     return RFX_OK;
 }
 

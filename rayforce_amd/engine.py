@@ -397,8 +397,8 @@ class Engine:
         if isinstance(key, (list, tuple)):
             # several key columns -> one composite dense key (index_group_list_perfect, core/index.c:2308-2424)
             kcols = [self._check_col(self._resolve(k, table)) for k in key]
-            comp, tmax, seen, multi = self._composite(kcols, where, table, _collective)
-            key = comp
+            tmax, seen, multi = self._composite_plan(kcols, where, table, _collective)
+            key = kcols[0]
         else:
             key = self._check_col(self._resolve(key, table))
         if key.dtype != torch.int64:
@@ -413,8 +413,6 @@ class Engine:
             if _collective is not None:
                 kmin, kmax, seen = _collective("scope", (kmin, kmax, seen, self.device))
         else:
-            if seen:
-                self.scope(key, where, table)  # leaves the partition histogram of the composite column for the accumulate pass
             kmin, kmax = 0, tmax  # forced scope, core/index.c:2421
         self._keep.clear()
         parr, _ = self._preds(flat, table, n)
@@ -442,12 +440,24 @@ class Engine:
         if dense:
             t, store, layout = self.group_tables(aarr, nagg, kmin, rng)
             L.check(self.lib.rfx_hip_group_tables_init(self._ctx, aarr, C.byref(t)), "group_tables_init")
-            L.check(self.lib.rfx_hip_group_dense_accumulate(self._ctx, key.data_ptr(), parr, len(flat), logic, aarr, n, row0, C.byref(t)),
-                    "group_dense_accumulate")
+            if multi is None:
+                L.check(self.lib.rfx_hip_group_dense_accumulate(self._ctx, key.data_ptr(), parr, len(flat), logic, aarr, n, row0, C.byref(t)),
+                        "group_dense_accumulate")
+            else:
+                k = len(kcols)
+                ptrs = (C.c_void_p * k)(*[kc.data_ptr() for kc in kcols])
+                L.check(self.lib.rfx_hip_group_dense_accumulate_keys(self._ctx, ptrs, (C.c_int64 * k)(*multi[0]), (C.c_int64 * k)(*multi[1]), k, parr,
+                                                                     len(flat), logic, aarr, n, row0, C.byref(t)), "group_dense_accumulate_keys")
             if _collective is not None:
                 _collective("tables", (store, layout))
             L.check(self.lib.rfx_hip_group_rank(self._ctx, C.byref(t), total_rows, C.byref(ng)), "group_rank")
         else:
+            if multi is not None:  # sparse composite: the hashed path keys on the materialised column (core/index.c:2421 -> :2092)
+                k = len(kcols)
+                key = self.empty(n)
+                ptrs = (C.c_void_p * k)(*[kc.data_ptr() for kc in kcols])
+                L.check(self.lib.rfx_hip_composite_key(self._ctx, ptrs, (C.c_int64 * k)(*multi[0]), (C.c_int64 * k)(*multi[1]), k, n, key.data_ptr()),
+                        "composite_key")
             cap = 1 << max(4, math.ceil(math.log2(max(2 * seen, 16))))
             t, store, layout = self.group_tables(aarr, nagg, 0, cap, hashed=True)
             L.check(self.lib.rfx_hip_hash_tables_init(self._ctx, aarr, C.byref(t)), "hash_tables_init")
@@ -482,8 +492,9 @@ class Engine:
         self.sync()
         return r
 
-    def _composite(self, kcols, where, table, _collective):
-        """Scopes of every key column (through the predicates), the reference's multiplier plan, and the composite column."""
+    def _composite_plan(self, kcols, where, table, _collective):
+        """Scopes of every key column (through the predicates) and the reference's multiplier plan (core/index.c:2340-2383).
+        Returns (composite max, rows seen, (mins, mults, ranges))."""
         if len(kcols) > L.RFX_MAX_KEYS:
             raise RfxError(f"at most {L.RFX_MAX_KEYS} key columns")
         n = kcols[0].numel()
@@ -498,14 +509,11 @@ class Engine:
             maxs.append(mx)
         k = len(kcols)
         if seen == 0:
-            return self.empty(n), -1, 0, ([0] * k, [1] * k, [1] * k)
+            return -1, 0, ([0] * k, [1] * k, [1] * k)
         amin, amax, amul = (C.c_int64 * k)(*mins), (C.c_int64 * k)(*maxs), (C.c_int64 * k)()
         tmax = C.c_int64()
         L.check(self.lib.rfx_composite_plan(amin, amax, k, amul, C.byref(tmax)), "composite_plan")
-        comp = self.empty(n)
-        ptrs = (C.c_void_p * k)(*[kc.data_ptr() for kc in kcols])
-        L.check(self.lib.rfx_hip_composite_key(self._ctx, ptrs, amin, amul, k, n, comp.data_ptr()), "composite_key")
-        return comp, int(tmax.value), seen, (mins, list(amul), [mx - mn + 1 for mn, mx in zip(mins, maxs)])
+        return int(tmax.value), seen, (mins, list(amul), [mx - mn + 1 for mn, mx in zip(mins, maxs)])
 
     # ------------------------------------------------------------------ the select surface (core/query.c:607-654)
     def select(self, query: Dict) -> Dict[str, torch.Tensor]:

@@ -287,16 +287,35 @@ def test_sharded_engine_single_rank(eng):
     assert np.array_equal(sh.where(("<", "a", 1000), d).cpu().numpy(), rfo.where(rfo.mask_of(("<", "a", 1000), host)))
 
 
-@pytest.mark.parametrize("flags", [0, 1, 2, 3, 8, 16, 32, 128, 144, 160])
+@pytest.mark.parametrize("flags", [0, 1, 2, 3, 4, 6, 8, 16, 32, 128, 144, 160, 256, 384])
 def test_group_by_every_code_path_agrees(eng, flags):
     """RFX_TUNE_* force the LDS-table / partitioned (fused and unfused scope) / device-atomic paths: same answers."""
     n = 400_003
     try:
         eng.tune(flags=flags)
-        for keys in (900, 60_000, 300_000):
+        for keys in (900, 2000, 60_000, 300_000):  # 64 KB LDS tables / 160 KB LDS tables / partitioned / partitioned
             host = table(n, keys=keys, nulls=True)
             check_select(eng, host, {"by": "k", "s": ("sum", "v"), "si": ("sum", "a"), "c": ("count", "a"), "mx": ("max", "w"), "av": ("avg", "a")})
             check_select(eng, host, {"where": ("<", "a", 300_000), "by": "k", "s": ("sum", "v"), "mn": ("min", "a")})
+    finally:
+        eng.tune(flags=0)
+
+
+@pytest.mark.parametrize("flags", [0, 128, 256])
+@pytest.mark.parametrize("thr", [1_000, 100_000, 480_000, 520_000, 990_000])
+def test_filtered_partitioned_group_by(eng, flags, thr):
+    """Partitioned path under a filter: <= 50 % selected -> compact (bitmap, ordered compaction of key / value planes / row
+    ids) then the unfiltered pipeline with `first` translated back (1..3 value planes; with and without the fused scope count;
+    288 k survivors = fewer tiles than workgroups); above 50 % the write-combining scatter with predicates; tiny selections
+    fall back to device atomics."""
+    n = 600_011
+    host = table(n, keys=200_000, nulls=True)
+    try:
+        eng.tune(flags=flags)
+        w = ("<", "a", thr)
+        check_select(eng, host, {"where": w, "by": "k", "s": ("sum", "v")})
+        check_select(eng, host, {"where": w, "by": "k", "s": ("sum", "v"), "mn": ("min", "a"), "c": ("count", "a")})
+        check_select(eng, host, {"where": ("and", w, (">", "v", 0.2)), "by": "k", "s": ("sum", "v"), "mx": ("max", "a"), "av": ("avg", "w"), "f": ("first", "a")})
     finally:
         eng.tune(flags=0)
 
@@ -320,6 +339,21 @@ def test_group_by_several_keys(eng, n, mods, offs):
     check_select(eng, host, {"by": by, "s": ("sum", "v"), "c": ("count", "a"), "mx": ("max", "a"), "av": ("avg", "v")})
     check_select(eng, host, {"where": ("and", ("<", "a", 400_000), (">", "v", 0.125)), "by": by, "s": ("sum", "v"), "f": ("first", "a")})
     check_select(eng, host, {"where": ("<", "a", -1), "by": by, "s": ("sum", "v")})  # nothing selected
+
+
+@pytest.mark.parametrize("flags", [0, 1, 4, 64, 66])
+def test_group_by_several_keys_every_path(eng, flags):
+    """Keys folded on the fly in the LDS-table kernels (small / 160 KB) vs the materialised composite column feeding the
+    partitioned path vs on-the-fly into device atomics (64+2): same answers."""
+    try:
+        eng.tune(flags=flags)
+        for mods in ((20, 30), (60, 50), (300, 400)):
+            host = mk_table(400_003, mods, (3, -7))
+            by = {"x": "k1", "y": "k2"}
+            check_select(eng, host, {"by": by, "s": ("sum", "v"), "c": ("count", "a"), "mn": ("min", "a")})
+            check_select(eng, host, {"where": (">", "v", 0.3), "by": by, "s": ("sum", "v")})
+    finally:
+        eng.tune(flags=0)
 
 
 def test_group_by_several_keys_overflow_is_refused(eng):
