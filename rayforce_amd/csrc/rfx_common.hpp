@@ -73,6 +73,7 @@ struct rfx_ctx {
     // scope + low-bit histogram computed together by rfx_hip_scope_i64 and consumed by the next group_dense_accumulate
     u64 *d_pc_counts;   // [pc_nwg][256]
     int pc_valid, pc_npred, pc_logic, pc_nwg;
+    int pc_bitmap;      // that scope pass also left the selection in d_bitmap
     const void *pc_key;
     i64 pc_nrows;
     i64 pc_seen;        // rows that passed the predicates in that scope pass

@@ -114,7 +114,7 @@ struct ScopePart {
     i64 mn, mx, sel, nulls;
 };
 template <int NC, int NP>
-__global__ __launch_bounds__(RFX_BLOCK) void k_part_scope_hist(const Plan P, int key_idx, u64 *__restrict__ counts, ScopePart *__restrict__ parts) {
+__global__ __launch_bounds__(RFX_BLOCK) void k_part_scope_hist(const Plan P, int key_idx, u64 *__restrict__ counts, ScopePart *__restrict__ parts, u64 *__restrict__ bitmap) {
     __shared__ unsigned hist[256];
     __shared__ ScopePart red[RFX_BLOCK / RFX_WAVE];
     PredSet<NP> S;
@@ -126,6 +126,22 @@ __global__ __launch_bounds__(RFX_BLOCK) void k_part_scope_hist(const Plan P, int
     for (i64 t = blockIdx.x; t < ntiles; t += gridDim.x) {
         u64 v[NC][8];
         const unsigned m = part_load_eval<NC, NP>(P, S, t, v);
+        if (NP > 0 && bitmap) {
+            // the selection as `where`'s bitmap ("pair-split 128": word 2g = even rows of the 128-row group g, word 2g+1 = odd
+            // rows): a wave's rows of load j ARE one such group, so the two ballots are its two words.  A selective filter
+            // then compacts by this bitmap instead of evaluating the predicates a second time.
+            const i64 g0 = t * (PART_TILE_ROWS / 128) + (threadIdx.x >> 6);
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const u64 b0 = __ballot((m >> (2 * j)) & 1u), b1 = __ballot((m >> (2 * j + 1)) & 1u);
+                if ((threadIdx.x & 63) == 0) {
+                    u64x2 w;
+                    w.x = b0;
+                    w.y = b1;
+                    *(u64x2 *)(bitmap + 2 * (g0 + j * 4)) = w;
+                }
+            }
+        }
         u64 key[8];
         sel_col<NC, 8>(key, v, key_idx);
 #pragma unroll
@@ -164,9 +180,9 @@ __global__ __launch_bounds__(RFX_BLOCK) void k_part_scope_hist(const Plan P, int
 }
 
 template <int NC>
-static void launch_scope_hist(rfx_ctx *c, const Plan &P, int key_idx, int nwg, ScopePart *parts) {
-    if (P.npred == 0) hipLaunchKernelGGL((k_part_scope_hist<NC, 0>), dim3(nwg), dim3(RFX_BLOCK), 0, c->stream, P, key_idx, c->d_pc_counts, parts);
-    else hipLaunchKernelGGL((k_part_scope_hist<NC, RFX_MAX_PREDS>), dim3(nwg), dim3(RFX_BLOCK), 0, c->stream, P, key_idx, c->d_pc_counts, parts);
+static void launch_scope_hist(rfx_ctx *c, const Plan &P, int key_idx, int nwg, ScopePart *parts, u64 *bitmap) {
+    if (P.npred == 0) hipLaunchKernelGGL((k_part_scope_hist<NC, 0>), dim3(nwg), dim3(RFX_BLOCK), 0, c->stream, P, key_idx, c->d_pc_counts, parts, (u64 *)0);
+    else hipLaunchKernelGGL((k_part_scope_hist<NC, RFX_MAX_PREDS>), dim3(nwg), dim3(RFX_BLOCK), 0, c->stream, P, key_idx, c->d_pc_counts, parts, bitmap);
 }
 
 static inline int part_nwg(const rfx_ctx *c) { return c->num_cus * ((c->flags & RFX_TUNE_PART_3WG) ? 3 : 2); } // in-process A/B: 2 per CU beat 3 by ~3 %
@@ -199,12 +215,20 @@ int rfx_part_scope_hist(rfx_ctx *c, const int64_t *d_key, const rfx_pred_t *pred
     rc = rfx_ws_reserve(c, (size_t)nwg * sizeof(ScopePart));
     if (rc != RFX_OK) return rc;
     ScopePart *d_parts = (ScopePart *)c->d_ws;
+    u64 *bitmap = NULL;
+    c->pc_bitmap = 0;
+    if (P.npred > 0) { // the selection bitmap as a side product (whole 2048-row tiles are written)
+        rc = rfx_bitmap_reserve(c, ((nrows + PART_TILE_ROWS - 1) / PART_TILE_ROWS) * PART_TILE_ROWS);
+        if (rc != RFX_OK) return rc;
+        c->where_n = -1; // a pending where_begin / where_emit pair loses its bitmap
+        bitmap = c->d_bitmap;
+    }
     RFX_KERNEL_BEGIN(c);
     switch (P.ncols) {
-        case 1: launch_scope_hist<1>(c, P, key_idx, nwg, d_parts); break;
-        case 2: launch_scope_hist<2>(c, P, key_idx, nwg, d_parts); break;
-        case 3: launch_scope_hist<3>(c, P, key_idx, nwg, d_parts); break;
-        default: launch_scope_hist<4>(c, P, key_idx, nwg, d_parts); break;
+        case 1: launch_scope_hist<1>(c, P, key_idx, nwg, d_parts, bitmap); break;
+        case 2: launch_scope_hist<2>(c, P, key_idx, nwg, d_parts, bitmap); break;
+        case 3: launch_scope_hist<3>(c, P, key_idx, nwg, d_parts, bitmap); break;
+        default: launch_scope_hist<4>(c, P, key_idx, nwg, d_parts, bitmap); break;
     }
     RFX_KERNEL_END(c);
     RFX_HIP_CHECK(hipGetLastError());
@@ -229,6 +253,7 @@ int rfx_part_scope_hist(rfx_ctx *c, const int64_t *d_key, const rfx_pred_t *pred
     *kmax = mx;
     if (sel > 0 && nulls == 0) {
         c->pc_valid = 1;
+        c->pc_bitmap = bitmap != NULL;
         c->pc_seen = sel;
         c->pc_key = d_key;
         c->pc_nrows = nrows;
@@ -807,6 +832,7 @@ static int launch_part(rfx_ctx *c, const Plan &P, const PartArgs &A, int nwg) {
 //   4. first[slot] = min(first[slot], row0 + rows32[scratch_first[slot]]): compaction is order preserving, so the smallest
 //      compacted position is the first occurrence (the reference does the same through its filter ids, core/query.c:65-72).
 int rfx_where_bitmap_of_plan(rfx_ctx *c, const Plan &Pfull, i64 *count);
+int rfx_where_counts_of_bitmap(rfx_ctx *c, i64 nrows, i64 *count);
 int rfx_where_compact_cols(rfx_ctx *c, i64 nrows, const u64 *const *src, u64 *const *dst, int ncol, unsigned *d_rows32);
 
 __global__ __launch_bounds__(RFX_BLOCK) void k_first_translate(const u64 *__restrict__ tmp, i64 range, const unsigned *__restrict__ rows32, i64 row0,
@@ -823,9 +849,10 @@ int rfx_group_part_accumulate(rfx_ctx *c, const Plan &P, int key_idx, const rfx_
 
 // RFX_OK: done.  RFX_ESTATE: the partitioned path does not apply (caller uses device atomics).  1: not selective after
 // all, continue with the filtered write-combining scatter.
-static int part_accumulate_selective(rfx_ctx *c, const Plan &P, int key_idx, const rfx_group_tables_t *t, const PartArgs &A) {
+static int part_accumulate_selective(rfx_ctx *c, const Plan &P, int key_idx, const rfx_group_tables_t *t, const PartArgs &A, bool have_bitmap) {
     i64 nsel = 0;
-    int rc = rfx_where_bitmap_of_plan(c, P, &nsel);
+    // the fused scope pass has just left this very selection as a bitmap: count and scan it; else evaluate the predicates
+    int rc = have_bitmap ? rfx_where_counts_of_bitmap(c, P.nrows, &nsel) : rfx_where_bitmap_of_plan(c, P, &nsel);
     if (rc != RFX_OK) return rc;
     if (nsel * 2 > P.nrows) return 1;
     if (nsel < (1 << 16)) return RFX_ESTATE;
@@ -899,9 +926,14 @@ int rfx_group_part_accumulate(rfx_ctx *c, const Plan &P, int key_idx, const rfx_
     }
     if (P.npred > 0 && A.nv >= 1 && !(c->flags & RFX_TUNE_NO_SEL_COMPACT)) {
         // rows that passed the predicates, if the fused scope pass has just counted exactly this selection
-        const bool known = c->pc_valid && c->pc_key == (const void *)P.cols[key_idx] && c->pc_nrows == P.nrows && c->pc_npred == P.npred;
+        bool known = c->pc_valid && c->pc_key == (const void *)P.cols[key_idx] && c->pc_nrows == P.nrows && c->pc_npred == P.npred && c->pc_logic == P.logic;
+        if (known) {
+            u64 sig[RFX_MAX_PREDS][6];
+            plan_pred_sig(P, sig);
+            known = memcmp(sig, c->pc_sig, sizeof(u64) * 6 * (size_t)P.npred) == 0;
+        }
         if (!known || c->pc_seen * 2 <= P.nrows) {
-            const int rc2 = part_accumulate_selective(c, P, key_idx, t, A);
+            const int rc2 = part_accumulate_selective(c, P, key_idx, t, A, known && c->pc_bitmap);
             if (rc2 != 1) {
                 c->pc_valid = 0;
                 return rc2;

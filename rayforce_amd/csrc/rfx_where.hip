@@ -312,6 +312,29 @@ int rfx_where_bitmap_of_plan(rfx_ctx *c, const Plan &Pfull, i64 *count) {
     return where_scan_total(c, Pfull.nrows, count);
 }
 
+// Internal: a selection bitmap is already in the context (written by the fused scope pass): per-chunk counts + scan.  (syncs)
+__global__ __launch_bounds__(RFX_BLOCK) void k_chunk_counts(const u64 *__restrict__ bitmap, i64 nchunks, i64 *__restrict__ cnt) {
+    for (i64 q = blockIdx.x * (i64)RFX_BLOCK + threadIdx.x; q < nchunks; q += (i64)gridDim.x * RFX_BLOCK) {
+        const u64 *w = bitmap + q * 8;
+        int s = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) s += __popcll(w[i]);
+        cnt[q] = s;
+    }
+}
+int rfx_where_counts_of_bitmap(rfx_ctx *c, i64 nrows, i64 *count) {
+    c->where_n = -1;
+    int rc = where_reserve(c, nrows);
+    if (rc != RFX_OK) return rc;
+    const i64 nchunks = (nrows + RFX_CHUNK - 1) / RFX_CHUNK;
+    i64 cb = (nchunks + RFX_BLOCK - 1) / RFX_BLOCK;
+    int grid = rfx_grid(c) * 4;
+    if (cb < grid) grid = (int)cb;
+    hipLaunchKernelGGL(k_chunk_counts, dim3(grid), dim3(RFX_BLOCK), 0, c->stream, (const u64 *)c->d_bitmap, nchunks, c->d_blksum);
+    RFX_HIP_CHECK(hipGetLastError());
+    return where_scan_total(c, nrows, count);
+}
+
 // Ordered compaction of whole columns by the context's bitmap: dst[c][r] = src[c][row] for the r-th selected row, and
 // rows32[r] = row (local).  A lane fetches its 16-byte row pair only when one of the two rows is selected.
 struct CompactArgs {
