@@ -37,8 +37,11 @@ HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3-7.0 TB/s
 METRIC = "rows/s on filter→group-by→sum, 1e9-row i64/f64; % HBM roofline at 1/2/4/8 GPU"
 
 
+_T0 = time.perf_counter()
+
+
 def log(*a):
-    print(*a, file=sys.stderr, flush=True)
+    print(f"[{time.perf_counter() - _T0:7.1f}s]", *a, file=sys.stderr, flush=True)
 
 
 WORKLOADS = {
@@ -193,7 +196,7 @@ def pmc_traffic(name):
 
 
 # ------------------------------------------------------------------------------------------------ CPU baseline
-def cpu_baseline(name, sample_rows):
+def cpu_baseline(name, sample_rows, timeout=120):
     """The reference itself (oracle/_ref/rayforce, kind 'reference') or -- when it is not built -- the C restatement
     (kind 'port'), timed on this box's host cores over a bounded sample of the same workload."""
     import numpy as np
@@ -246,7 +249,8 @@ def cpu_baseline(name, sample_rows):
                     s.eval(f"(set t (table [{names}] (list {names})))")
                     s.eval(f"(set warm {q})")
                     s.out("ms", f"(enlist (timeit {reps} {q}))")
-                    out = s.run(threads=threads, timeout=900)
+                    # the reference occasionally hangs in its pool with very wide pools (seen: group-by, 256 executors): bound every attempt
+                    out = s.run(threads=threads, timeout=timeout)
                 ms = float(out["ms"][0]) / reps
                 if ms > 0:
                     return dict(value=sample_rows / (ms * 1e-3), unit="rows/s", cores=threads, kind="reference", ms_per_query=ms,
@@ -347,10 +351,14 @@ def main():
             log(f"[bench] cpu_baseline failed: {e}")
             cpu = None
         # the reference's CPU path beside the secondary workloads too (smaller samples: the whole run stays within minutes)
+        t_cpu = time.perf_counter()
         for other in also:
             if other in ("c1", "c2b", "c3", "c3w", "q2", "c5") and "error" not in also[other]:
+                if time.perf_counter() - t_cpu > 150:  # keep the default run within minutes
+                    log(f"[bench] cpu_baseline({other}) skipped: time budget for the secondary baselines used up")
+                    continue
                 try:
-                    cb = cpu_baseline(other, min(20_000_000, WORKLOADS[other]["rows"]))
+                    cb = cpu_baseline(other, min(20_000_000, WORKLOADS[other]["rows"]), timeout=45)
                     also[other]["cpu_baseline"] = {k: cb[k] for k in ("value", "unit", "cores", "kind", "ms_per_query")}
                     also[other]["cpu_baseline"]["sample_rows"] = min(20_000_000, WORKLOADS[other]["rows"])
                 except Exception as e:  # noqa: BLE001
