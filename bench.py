@@ -16,6 +16,7 @@ Workloads (BASELINE.json configs / SURVEY 8d):
   c1   configs[0]  (sum v)                             v: f64[1e7]                         8 B/row   (plumbing case)
   c3w  metric      select sum(v) by k where a < 100000 k, v as c3 + a as c2                24 B/row
   q2   8f-1        select sum(v) by {id1, id2}         id1, id2: i64[1e9] in [0,100), v    24 B/row
+  x6   8f-3        select sum(p*d) where q<24 and .05<=d<=.07   p, d: f64[1e9], q: i64[1e9]   24 B/row (TPC-H Q6 shape)
   c5   configs[4]  avg,min,max(d) where a<.316228 & b>.683772 & c!=.25   4 x f64[2.5e8]/GPU 32 B/row
 One JSON line on stdout (rank 0); everything else goes to stderr.
 """
@@ -57,6 +58,8 @@ WORKLOADS = {
                 bytes_per_row=24, dtype="f64", kernel="k_part_scope_hist+k_part_scatter+k_part_aggregate"),
     "q2": dict(desc="several by: columns (H2O Q2 shape): select sum(v) by {id1, id2}, id1/id2 i64 uniform [0,100) seeds 10/11, v f64 seed 5", rows=1_000_000_000,
                bytes_per_row=24, dtype="f64", kernel="k_composite_key+k_group_dense"),
+    "x6": dict(desc="expression aggregate (TPC-H Q6 shape): select sum(p * d) where q < 24 and d >= 0.05 and d <= 0.07; p f64 seed 12, d f64 seed 13 "
+                    "scaled to [0,0.1), q i64 uniform [0,50) seed 14", rows=1_000_000_000, bytes_per_row=24, dtype="f64", kernel="k_filter_aggr<3,4,4,4,4>"),
     "w2": dict(desc="where ids: (where (< a 100000)) on the C2 column -> 1e8 ascending i64 row ids (8 B/row in + 8 B/selected row out)", rows=1_000_000_000,
                bytes_per_row=8.8, dtype="int64", kernel="k_sel_bitmap<1>+k_emit_ids"),
     "m2": dict(desc="B8 mask: (< a 100000) materialised as the reference's byte mask (8 B/row in + 1 B/row out)", rows=1_000_000_000, bytes_per_row=9,
@@ -85,6 +88,12 @@ class Job:
         elif name == "c3w":
             self.t = {"k": g.gen_i64(rows, 4, 1_000_000, row0), "v": g.gen_f64(rows, 5, row0), "a": g.gen_i64(rows, 2, 1_000_000, row0)}
             self.aggs, self.where = [("sum", "v")], ("<", "a", 100_000)
+        elif name == "x6":
+            d = g.gen_f64(rows, 13, row0)
+            d.mul_(0.1)  # plumbing: scale the synthetic discount column once, outside every timed region
+            self.t = {"p": g.gen_f64(rows, 12, row0), "d": d, "q": g.gen_i64(rows, 14, 50, row0)}
+            self.aggs = [("sum", ("*", "p", "d"))]
+            self.where = ("and", ("<", "q", 24), (">=", "d", 0.05), ("<=", "d", 0.07))
         elif name == "q2":
             self.t = {"id1": g.gen_i64(rows, 10, 100, row0), "id2": g.gen_i64(rows, 11, 100, row0), "v": g.gen_f64(rows, 5, row0)}
             self.aggs, self.where, self.key = [("sum", "v")], None, ["id1", "id2"]
@@ -216,6 +225,10 @@ def cpu_baseline(name, sample_rows, timeout=120):
         cols = {"k": rfo.gen_i64(sample_rows, 4, 1_000_000), "v": rfo.gen_f64(sample_rows, 5), "a": rfo.gen_i64(sample_rows, 2, 1_000_000)}
         q = "(select {s: (sum v) from: t where: (< a 100000) by: k})"
         oq = {"where": ("<", "a", 100_000), "by": "k", "s": ("sum", "v")}
+    elif name == "x6":
+        cols = {"p": rfo.gen_f64(sample_rows, 12), "d": rfo.gen_f64(sample_rows, 13) * 0.1, "q": rfo.gen_i64(sample_rows, 14, 50)}
+        q = "(select {s: (sum (* p d)) from: t where: (and (< q 24) (>= d 0.05) (<= d 0.07))})"
+        oq = {"where": ("and", ("<", "q", 24), (">=", "d", 0.05), ("<=", "d", 0.07)), "s": ("sum", ("*", "p", "d"))}
     elif name == "q2":
         cols = {"id1": rfo.gen_i64(sample_rows, 10, 100), "id2": rfo.gen_i64(sample_rows, 11, 100), "v": rfo.gen_f64(sample_rows, 5)}
         q = "(select {s: (sum v) from: t by: {id1: id1 id2: id2}})"
@@ -353,7 +366,7 @@ def main():
         # the reference's CPU path beside the secondary workloads too (smaller samples: the whole run stays within minutes)
         t_cpu = time.perf_counter()
         for other in also:
-            if other in ("c1", "c2b", "c3", "c3w", "q2", "c5") and "error" not in also[other]:
+            if other in ("c1", "c2b", "c3", "c3w", "q2", "x6", "c5") and "error" not in also[other]:
                 if time.perf_counter() - t_cpu > 150:  # keep the default run within minutes
                     log(f"[bench] cpu_baseline({other}) skipped: time budget for the secondary baselines used up")
                     continue

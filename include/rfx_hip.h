@@ -64,6 +64,7 @@ enum {
 #define RFX_MAX_AGGS 8
 #define RFX_MAX_COLS 8 /* distinct columns one fused launch may read */
 #define RFX_MAX_KEYS 8 /* `by:` columns folded into one composite key */
+#define RFX_MAX_EXPRS 4 /* distinct element-wise expressions one launch may evaluate */
 
 /* One comparison `col OP rhs`.  rhs is an atom (d_rhs_col == NULL, value in rhs_i / rhs_f according to
  * rhs_type) or a second column of the same length (d_rhs_col != NULL).  i64 (x) f64 promotes the i64 side
@@ -81,11 +82,29 @@ typedef struct rfx_pred {
     };
 } rfx_pred_t;
 
+/* Element-wise arithmetic feeding an aggregate: input = lhs OP rhs with the reference's scalar rules
+ * (ADD/SUB/MUL{I64,F64}, FDIV{I64,F64}: core/ops.h:153-174 -- null in -> null out, i64 wraps, i64 (x) f64 promotes the
+ * i64 side with null -> NaN, `div` by zero -> NaN; result type f64 unless both sides are i64 and OP is not FDIV). */
+enum { RFX_X_NONE = 0, RFX_X_ADD = 1, RFX_X_SUB = 2, RFX_X_MUL = 3, RFX_X_FDIV = 4 };
+enum { RFX_XF_SWAP = 1 }; /* operands swapped: input = rhs OP column (for `(- 2 a)`, `(div 1 a)`) */
+
 typedef struct rfx_agg {
     const void *d_col; /* may be NULL for RFX_AGG_COUNT */
     int32_t col_type;  /* RFX_I64 | RFX_F64 */
     int32_t kind;      /* RFX_AGG_*         */
+    /* optional expression: all zero = the aggregate reads d_col itself */
+    int32_t xop;             /* RFX_X_*                                                            */
+    int32_t xflags;          /* RFX_XF_*                                                           */
+    const void *d_xrhs_col;  /* second operand: a column of the same length, or NULL for the atom  */
+    int32_t xrhs_type;       /* RFX_I64 | RFX_F64                                                  */
+    int32_t _pad;
+    union {
+        int64_t xrhs_i;
+        double xrhs_f;
+    };
 } rfx_agg_t;
+/* Element type the aggregate folds (= the column's type, or the expression's result type).  Pure host helper. */
+int rfx_agg_input_type(const rfx_agg_t *a);
 
 /* Mergeable partial state of ONE scalar aggregate over ONE row range (one GPU).  64 bytes.  Partials from
  * several row ranges merge field-wise (isum wrap-add, fsum add, cnt add, ext min/max by kind) -- this is the

@@ -57,6 +57,8 @@ def lib() -> C.CDLL:
             "rfo_group_sparse": (i64, [p, p, i64, p, p]),
             "rfo_hash_fnv1a": (C.c_uint64, [i64]), "rfo_hash_index_u64": (C.c_uint64, [C.c_uint64, C.c_uint64]),
             "rfo_aggr_first": (None, [p, p, p, i64, p]),
+            "rfo_binop": (C.c_int, [C.c_int, C.c_int, p, C.c_int, C.c_int, p, C.c_int, i64, p]),
+            "rfo_aggr_fold": (None, [C.c_int, C.c_int, p, p, i64, i64, p]),
             "rfo_composite_plan": (C.c_int, [p, p, C.c_int, p, C.POINTER(i64)]),
             "rfo_composite_key": (None, [p, p, p, C.c_int, p, i64, p]),
         }
@@ -213,6 +215,44 @@ def composite_key(keys, filter_ids=None):
     return out, tmax.value, mins, list(amul)
 
 
+XOPS = {"+": 1, "-": 2, "*": 3, "div": 4}
+
+
+def binop(op: str, lhs, rhs) -> np.ndarray:
+    """ray_add / ray_sub / ray_mul / ray_fdiv over i64 / f64 vectors and atoms (one side must be a vector)."""
+    def prep(x):
+        if isinstance(x, np.ndarray):
+            a = _col(x)
+            return a, 0, (10 if a.dtype == np.float64 else 5)
+        if isinstance(x, float):
+            return np.array([x], np.float64), 1, 10
+        return np.array([int(x)], np.int64), 1, 5
+    la, l_atom, lt = prep(lhs)
+    ra, r_atom, rt = prep(rhs)
+    n = len(la) if not l_atom else len(ra)
+    out_f64 = op == "div" or lt == 10 or rt == 10
+    out = np.empty(n, np.float64 if out_f64 else np.int64)
+    lib().rfo_binop(XOPS[op], lt, _ptr(la), l_atom, rt, _ptr(ra), r_atom, n, _ptr(out))
+    return out
+
+
+def eval_arg(arg, table):
+    """An aggregate's argument: a column name, or (op, lhs, rhs) with operands column names / atoms."""
+    if isinstance(arg, tuple):
+        op, l, r = arg
+        return binop(op, table[l] if isinstance(l, str) else l, table[r] if isinstance(r, str) else r)
+    return table[arg]
+
+
+def aggr_fold(fn: str, vals, gids, groups):
+    """Expression argument under `by:`: per-group vectors folded with the scalar rules (rfo_aggr_fold)."""
+    vals = _col(vals)
+    out = np.empty(groups, np.float64 if (fn == "avg" or vals.dtype == np.float64) else np.int64)
+    lib().rfo_aggr_fold({"sum": 0, "min": 1, "max": 2, "avg": 3}[fn], 10 if vals.dtype == np.float64 else 5, _ptr(vals),
+                        _ptr(np.ascontiguousarray(gids, np.int64)), len(gids), groups, _ptr(out))
+    return out
+
+
 def group_index(key, filter_ids=None, scope=None):
     """index_group_i64: returns (gids per selected row, first positions, groups, dense?).  `scope=(min, max)` forces the
     key scope instead of scanning for it (index_group_i64_scoped called by index_group_list_perfect)."""
@@ -274,7 +314,12 @@ def select(query: dict) -> dict:
             pos = firsts if ids is None else ids[firsts]
             res = {by: _col(key)[pos] if groups else np.empty(0, np.int64)}
         for name, (fn, col) in outs:
-            if fn == "first":
+            if isinstance(col, tuple):  # expression argument: scalar rules group by group
+                if fn in ("count", "first"):
+                    raise ValueError(f"({fn} expr) under by: is not restated")
+                vals = eval_arg(col, table)
+                res[name] = aggr_fold(fn, vals if ids is None else at_ids(vals, ids), gids, groups)
+            elif fn == "first":
                 c = _col(table[col])
                 res[name] = c[pos] if groups else np.empty(0, c.dtype)
             else:
@@ -284,7 +329,7 @@ def select(query: dict) -> dict:
     if outs:
         res = {}
         for name, (fn, col) in outs:
-            c = _col(table[col]) if col is not None else _col(next(iter(table.values())))
+            c = _col(eval_arg(col, table)) if col is not None else _col(next(iter(table.values())))
             if ids is not None:
                 c = at_ids(c, ids)
             v = fold(fn, c)

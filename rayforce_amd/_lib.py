@@ -10,6 +10,7 @@ RFX_EQ, RFX_NE, RFX_LT, RFX_GT, RFX_LE, RFX_GE = range(6)
 RFX_AND, RFX_OR = 0, 1
 RFX_AGG_SUM, RFX_AGG_MIN, RFX_AGG_MAX, RFX_AGG_COUNT, RFX_AGG_AVG, RFX_AGG_FIRST = range(6)
 RFX_MAX_PREDS = RFX_MAX_AGGS = RFX_MAX_COLS = RFX_MAX_KEYS = 8
+RFX_MAX_EXPRS = 4
 NULL_I64 = -(2**63)
 INF_I64 = 2**63 - 1
 
@@ -32,8 +33,26 @@ class Pred(C.Structure):
                 ("op", C.c_int32), ("_pad", C.c_int32), ("u", _RhsUnion)]
 
 
+class _XRhsUnion(C.Union):
+    _fields_ = [("xrhs_i", C.c_int64), ("xrhs_f", C.c_double)]
+
+
 class Agg(C.Structure):
-    _fields_ = [("d_col", C.c_void_p), ("col_type", C.c_int32), ("kind", C.c_int32)]
+    """rfx_agg_t: the aggregate's column plus the optional element-wise expression feeding it (include/rfx_hip.h)."""
+    _anonymous_ = ("xu",)
+    _fields_ = [("d_col", C.c_void_p), ("col_type", C.c_int32), ("kind", C.c_int32), ("xop", C.c_int32), ("xflags", C.c_int32),
+                ("d_xrhs_col", C.c_void_p), ("xrhs_type", C.c_int32), ("_pad", C.c_int32), ("xu", _XRhsUnion)]
+
+
+XOPS = {"+": 1, "-": 2, "*": 3, "div": 4}
+RFX_XF_SWAP = 1
+
+
+def agg_input_type(a: "Agg") -> int:
+    """rfx_agg_input_type: the element type the aggregate folds."""
+    if a.xop == 0:
+        return a.col_type
+    return RFX_F64 if (a.xop == 4 or a.col_type == RFX_F64 or a.xrhs_type == RFX_F64) else RFX_I64
 
 
 class Partial(C.Structure):
@@ -60,7 +79,7 @@ class HashTables(C.Structure):
                 ("d_first", C.c_void_p), ("d_acc", C.c_void_p * RFX_MAX_AGGS), ("d_cnt", C.c_void_p * RFX_MAX_AGGS)]
 
 
-assert C.sizeof(Pred) == 40 and C.sizeof(Agg) == 16 and C.sizeof(Partial) == 64 and C.sizeof(Value) == 16
+assert C.sizeof(Pred) == 40 and C.sizeof(Agg) == 48 and C.sizeof(Partial) == 64 and C.sizeof(Value) == 16
 
 _P = C.POINTER
 _ctx = C.c_void_p
@@ -111,6 +130,7 @@ PROTOTYPES = {
     "rfx_hip_group_ids_dense": (C.c_int, [_ctx, C.c_void_p, C.c_int64, _P(GroupTables), C.c_void_p]),
     "rfx_hip_hash_fnv1a_i64": (C.c_int, [_ctx, C.c_void_p, C.c_int64, C.c_void_p]),
     "rfx_hip_hash_mix_u64": (C.c_int, [_ctx, C.c_void_p, C.c_int64, C.c_uint64, C.c_void_p]),
+    "rfx_agg_input_type": (C.c_int, [_P(Agg)]),
     "rfx_composite_plan": (C.c_int, [C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "rfx_hip_composite_key": (C.c_int, [_ctx, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_int, C.c_int64, C.c_void_p]),
     "rfx_hip_group_dense_accumulate_keys": (C.c_int, [_ctx, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_int, _P(Pred),

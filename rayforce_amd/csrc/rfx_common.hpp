@@ -68,6 +68,8 @@ struct rfx_ctx {
     size_t part_bytes;
     void *d_comp;       // materialised composite key column of a multi-key group-by (grow-only)
     size_t comp_bytes;
+    void *d_expr;       // materialised expression columns (grow-only)
+    size_t expr_bytes;
     void *d_sel;        // compacted (key, values, row ids) of a selectively filtered partitioned group-by (grow-only)
     size_t sel_bytes;
     // scope + low-bit histogram computed together by rfx_hip_scope_i64 and consumed by the next group_dense_accumulate
@@ -85,6 +87,7 @@ int rfx_bitmap_reserve(rfx_ctx *ctx, i64 nrows);
 int rfx_gid_reserve(rfx_ctx *ctx, i64 slots);
 int rfx_part_reserve(rfx_ctx *ctx, size_t bytes);
 int rfx_comp_reserve(rfx_ctx *ctx, size_t bytes);
+int rfx_expr_reserve(rfx_ctx *ctx, size_t bytes);
 int rfx_sel_reserve(rfx_ctx *ctx, size_t bytes);
 int rfx_plan_add_col(struct Plan *P, const void *col); // index of `col` in P->cols (added if new), -1 when full
 #define RFX_KERNEL_BEGIN(c) do { if ((c)->profile) { (void)hipEventRecord((c)->evk0, (c)->stream); } } while (0)
@@ -103,11 +106,21 @@ struct PlanPred {
     int rhs_cvt;  // same for a vector rhs
     u64 rhs_bits; // atom, already promoted to the comparison domain on the host
 };
+#define RFX_XCOL 64 /* PlanAgg::col >= RFX_XCOL: the aggregate folds expression Plan::xs[col - RFX_XCOL] */
 struct PlanAgg {
-    int col;  // index into Plan::cols (-1 for COUNT without a column)
-    int f64;  // column element type is f64
-    int kind; // RFX_AGG_* ; -1 = unused slot
-    int _pad;
+    int col;      // index into Plan::cols (-1 for COUNT without a column), or RFX_XCOL + expression index
+    int f64;      // folded element type is f64 (column type, or the expression's result type)
+    int kind;     // RFX_AGG_* ; -1 = unused slot
+    int skipnull; // grouped: fold with the SCALAR rules (nulls skipped, all-null group -> null) -- what the reference does
+                  // when the aggregate's argument is an expression (per-group vectors folded one by one)
+};
+// One element-wise expression  out = l OP r  (SURVEY 8f-3).  Operands: a plan column or an atom (col < 0).
+struct PlanExpr {
+    int op;             // RFX_X_ADD .. RFX_X_FDIV
+    int out_f64;        // result type
+    int l_col, r_col;   // index into Plan::cols, or -1: atom
+    int l_f64, r_f64;   // operand element types
+    u64 l_atom, r_atom; // atom bits in the operand's own type
 };
 struct Plan {
     int ncols, npred, nagg, logic;
@@ -116,7 +129,12 @@ struct Plan {
     PlanAgg aggs[RFX_MAX_AGGS];
     i64 nrows;
     i64 row0;
+    int nx, _pad;
+    PlanExpr xs[RFX_MAX_EXPRS];
 };
+// Evaluate every expression into context scratch and rewrite the plan to read the results as plain columns (nx = 0):
+// for the kernels that do not fold expressions on the fly (partitioned and hashed group-by).
+int rfx_plan_materialise_exprs(rfx_ctx *c, Plan *P);
 
 // Build a Plan from the public descriptors (dedupes columns, promotes atoms).  Returns RFX_OK or an error.
 int rfx_plan_build(Plan *P, const rfx_pred_t *preds, int npred, int logic, const rfx_agg_t *aggs, int nagg,
@@ -135,6 +153,29 @@ __device__ __forceinline__ bool rfx_isnan_bits(u64 u) {
 // i64_to_f64 -- core/ops.h:250 : null -> NaN
 __device__ __forceinline__ u64 rfx_i64_to_f64_bits(u64 x) {
     return ((i64)x == RFX_NULL_I64_D) ? RFX_NAN_BITS : rfx_as_u64((double)(i64)x);
+}
+
+// ADD/SUB/MUL{I64,F64}, FDIV{I64,F64} -- core/ops.h:153-174, with the binop type promotion of core/math.c (i64 (x) f64 ->
+// f64 through i64_to_f64).  lx / rx are the operands' raw bits in their own types.
+__device__ __forceinline__ u64 rfx_expr_eval(int op, int out_f64, int l_f64, int r_f64, u64 lx, u64 rx) {
+    if (!out_f64) { // i64 (x) i64, op in {ADD, SUB, MUL}: null in -> null out, two's-complement wrap
+        if ((i64)lx == RFX_NULL_I64_D || (i64)rx == RFX_NULL_I64_D) return (u64)RFX_NULL_I64_D;
+        return op == RFX_X_ADD ? lx + rx : (op == RFX_X_SUB ? lx - rx : lx * rx);
+    }
+    const u64 lb = l_f64 ? lx : rfx_i64_to_f64_bits(lx), rb = r_f64 ? rx : rfx_i64_to_f64_bits(rx);
+    if (rfx_isnan_bits(lb) || rfx_isnan_bits(rb)) return RFX_NAN_BITS;
+    const double a = rfx_as_f64(lb), b = rfx_as_f64(rb);
+    double r;
+    switch (op) {
+        case RFX_X_ADD: r = a + b; break;
+        case RFX_X_SUB: r = a - b; break;
+        case RFX_X_MUL: r = a * b; break;
+        default:
+            if (b == 0.0) return RFX_NAN_BITS; // FDIV*: zero divisor -> null
+            r = a / b;
+            break;
+    }
+    return rfx_as_u64(r);
 }
 
 // {EQ,NE,LT,GT,LE,GE}I64 -- core/ops.h:80,88,96,104,112,120 : plain signed compares, no null test

@@ -67,6 +67,7 @@ extern "C" int rfx_hip_ctx_destroy(rfx_ctx_t *c) {
     if (c->d_part) (void)hipFree(c->d_part);
     if (c->d_comp) (void)hipFree(c->d_comp);
     if (c->d_sel) (void)hipFree(c->d_sel);
+    if (c->d_expr) (void)hipFree(c->d_expr);
     if (c->d_pc_counts) (void)hipFree(c->d_pc_counts);
     if (c->h_pin) (void)hipHostFree(c->h_pin);
     (void)hipEventDestroy(c->ev0);
@@ -161,6 +162,17 @@ int rfx_part_reserve(rfx_ctx *c, size_t bytes) {
     return RFX_OK;
 }
 
+int rfx_expr_reserve(rfx_ctx *c, size_t bytes) {
+    if (c->expr_bytes >= bytes) return RFX_OK;
+    RFX_HIP_CHECK(hipStreamSynchronize(c->stream));
+    if (c->d_expr) RFX_HIP_CHECK(hipFree(c->d_expr));
+    c->d_expr = NULL;
+    c->expr_bytes = 0;
+    RFX_HIP_CHECK(hipMalloc(&c->d_expr, bytes));
+    c->expr_bytes = bytes;
+    return RFX_OK;
+}
+
 int rfx_sel_reserve(rfx_ctx *c, size_t bytes) {
     if (c->sel_bytes >= bytes) return RFX_OK;
     RFX_HIP_CHECK(hipStreamSynchronize(c->stream));
@@ -180,6 +192,56 @@ int rfx_comp_reserve(rfx_ctx *c, size_t bytes) {
     c->comp_bytes = 0;
     RFX_HIP_CHECK(hipMalloc(&c->d_comp, bytes));
     c->comp_bytes = bytes;
+    return RFX_OK;
+}
+
+// ---- expressions as plain columns (for the kernels that do not fold them on the fly) ----
+struct DeriveArgs {
+    PlanExpr x;
+    const u64 *l, *r;
+    u64 *out;
+};
+__global__ __launch_bounds__(RFX_BLOCK) void k_derive(const DeriveArgs A, i64 nrows) {
+    const PlanExpr x = A.x;
+    const i64 npairs = nrows / 2;
+    for (i64 i = blockIdx.x * (i64)RFX_BLOCK + threadIdx.x; i < npairs; i += (i64)gridDim.x * RFX_BLOCK) {
+        u64x2 l, r, o;
+        if (A.l) l = rfx_ld2(A.l + 2 * i);
+        else l.x = l.y = x.l_atom;
+        if (A.r) r = rfx_ld2(A.r + 2 * i);
+        else r.x = r.y = x.r_atom;
+        o.x = rfx_expr_eval(x.op, x.out_f64, x.l_f64, x.r_f64, l.x, r.x);
+        o.y = rfx_expr_eval(x.op, x.out_f64, x.l_f64, x.r_f64, l.y, r.y);
+        *(u64x2 *)(A.out + 2 * i) = o;
+    }
+    if ((nrows & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+        const i64 i = nrows - 1;
+        A.out[i] = rfx_expr_eval(x.op, x.out_f64, x.l_f64, x.r_f64, A.l ? A.l[i] : x.l_atom, A.r ? A.r[i] : x.r_atom);
+    }
+}
+
+int rfx_plan_materialise_exprs(rfx_ctx *c, Plan *P) {
+    if (P->nx == 0) return RFX_OK;
+    RFX_REQUIRE(P->ncols + P->nx <= RFX_MAX_COLS, RFX_ELIMIT, "too many distinct columns once the expressions are materialised");
+    const size_t col_bytes = (((size_t)P->nrows * 8) + 255) & ~(size_t)255;
+    int rc = rfx_expr_reserve(c, col_bytes * (size_t)P->nx);
+    if (rc != RFX_OK) return rc;
+    int newcol[RFX_MAX_EXPRS];
+    for (int i = 0; i < P->nx; i++) {
+        DeriveArgs A;
+        A.x = P->xs[i];
+        A.l = A.x.l_col >= 0 ? P->cols[A.x.l_col] : NULL;
+        A.r = A.x.r_col >= 0 ? P->cols[A.x.r_col] : NULL;
+        A.out = (u64 *)((char *)c->d_expr + col_bytes * (size_t)i);
+        hipLaunchKernelGGL(k_derive, dim3(c->num_cus * 8), dim3(RFX_BLOCK), 0, c->stream, A, P->nrows);
+        RFX_HIP_CHECK(hipGetLastError());
+        newcol[i] = P->ncols + i;
+    }
+    for (int i = 0; i < P->nx; i++) P->cols[P->ncols + i] = (const u64 *)((char *)c->d_expr + col_bytes * (size_t)i);
+    P->ncols += P->nx;
+    for (int a = 0; a < P->nagg; a++)
+        if (P->aggs[a].col >= RFX_XCOL) P->aggs[a].col = newcol[P->aggs[a].col - RFX_XCOL];
+    P->nx = 0;
     return RFX_OK;
 }
 
@@ -332,15 +394,53 @@ int rfx_plan_build(Plan *P, const rfx_pred_t *preds, int npred, int logic, const
         PlanAgg *q = &P->aggs[i];
         RFX_REQUIRE(a->kind >= RFX_AGG_SUM && a->kind <= RFX_AGG_FIRST, RFX_EINVAL, "bad aggregate kind");
         q->kind = a->kind;
+        q->skipnull = 0;
         if (a->kind == RFX_AGG_COUNT) {
+            // (count expr) is not the reference's count of the expression's rows when grouped (it answers the number of
+            // groups, a quirk of its lazy-argument collection): not reproduced, refused instead
+            RFX_REQUIRE(a->xop == RFX_X_NONE, RFX_EINVAL, "count of an expression is not supported");
             q->col = -1;
             q->f64 = 0;
         } else {
             RFX_REQUIRE(a->d_col != NULL || nrows == 0, RFX_EINVAL, "aggregate column is NULL");
             RFX_REQUIRE(a->col_type == RFX_I64 || a->col_type == RFX_F64, RFX_EINVAL, "aggregate column type must be i64 or f64");
-            q->col = plan_col(P, a->d_col);
-            RFX_REQUIRE(q->col >= 0, RFX_ELIMIT, "too many distinct columns");
-            q->f64 = (a->col_type == RFX_F64);
+            const int ci = plan_col(P, a->d_col);
+            RFX_REQUIRE(ci >= 0, RFX_ELIMIT, "too many distinct columns");
+            if (a->xop == RFX_X_NONE) {
+                q->col = ci;
+                q->f64 = (a->col_type == RFX_F64);
+            } else {
+                RFX_REQUIRE(a->xop >= RFX_X_ADD && a->xop <= RFX_X_FDIV, RFX_EINVAL, "bad expression operator");
+                RFX_REQUIRE(a->xrhs_type == RFX_I64 || a->xrhs_type == RFX_F64, RFX_EINVAL, "expression operand type must be i64 or f64");
+                RFX_REQUIRE(a->kind != RFX_AGG_FIRST, RFX_EINVAL, "first of an expression is not supported");
+                PlanExpr x;
+                memset(&x, 0, sizeof(x));
+                x.op = a->xop;
+                int oc = -1;
+                if (a->d_xrhs_col) {
+                    oc = plan_col(P, a->d_xrhs_col);
+                    RFX_REQUIRE(oc >= 0, RFX_ELIMIT, "too many distinct columns");
+                }
+                const u64 atom = (a->xrhs_type == RFX_F64) ? host_f64_bits(a->xrhs_f) : (u64)a->xrhs_i;
+                const bool swap = (a->xflags & RFX_XF_SWAP) != 0;
+                x.l_col = swap ? oc : ci;
+                x.r_col = swap ? ci : oc;
+                x.l_f64 = swap ? (a->xrhs_type == RFX_F64) : (a->col_type == RFX_F64);
+                x.r_f64 = swap ? (a->col_type == RFX_F64) : (a->xrhs_type == RFX_F64);
+                x.l_atom = (swap && oc < 0) ? atom : 0;
+                x.r_atom = (!swap && oc < 0) ? atom : 0;
+                x.out_f64 = (rfx_agg_input_type(a) == RFX_F64);
+                int xi = 0;
+                for (; xi < P->nx; xi++)
+                    if (memcmp(&P->xs[xi], &x, sizeof(x)) == 0) break;
+                if (xi == P->nx) {
+                    RFX_REQUIRE(P->nx < RFX_MAX_EXPRS, RFX_ELIMIT, "too many distinct expressions");
+                    P->xs[P->nx++] = x;
+                }
+                q->col = RFX_XCOL + xi;
+                q->f64 = x.out_f64;
+                q->skipnull = 1;
+            }
         }
     }
     return RFX_OK;

@@ -127,14 +127,15 @@ __global__ __launch_bounds__(BLOCK) void k_group_dense(const Plan P, const Group
             const PlanAgg ag = P.aggs[a];
             const bool hc = agg_has_cnt(ag.kind, ag.f64);
             u64 x[E];
-            if (ag.col >= 0) sel_col<NC, E>(x, v, ag.col);
+            if (ag.col >= RFX_XCOL) expr_input<NC, E>(x, v, P.xs[ag.col - RFX_XCOL]); // expression folded on the fly
+            else if (ag.col >= 0) sel_col<NC, E>(x, v, ag.col);
 #pragma unroll
             for (int e = 0; e < E; e++) {
                 if (!((m >> e) & 1u)) continue;
                 const u64 slot = key[e];
                 if (slot >= (u64)range) continue;
-                if (LDS) group_apply(&smem[(i64)arr * range + slot], &smem[(i64)(arr + 1) * range + slot], ag.kind, ag.f64, x[e]);
-                else group_apply(&G.acc[a][slot], G.cnt[a] ? &G.cnt[a][slot] : (u64 *)0, ag.kind, ag.f64, x[e]);
+                if (LDS) group_apply(&smem[(i64)arr * range + slot], &smem[(i64)(arr + 1) * range + slot], ag.kind, ag.f64, x[e], ag.skipnull);
+                else group_apply(&G.acc[a][slot], G.cnt[a] ? &G.cnt[a][slot] : (u64 *)0, ag.kind, ag.f64, x[e], ag.skipnull);
             }
             arr += hc ? 2 : 1;
         }
@@ -175,7 +176,7 @@ int rfx_fill_u64(rfx_ctx *c, void *p, i64 n, u64 val) {
 extern "C" int rfx_hip_group_table_arrays(const rfx_agg_t *aggs, int nagg, int *n_arrays) {
     if (!n_arrays || nagg < 0 || nagg > RFX_MAX_AGGS || (nagg && !aggs)) return RFX_EINVAL;
     int n = 1;
-    for (int a = 0; a < nagg; a++) n += 1 + (agg_has_cnt(aggs[a].kind, aggs[a].col_type == RFX_F64) ? 1 : 0);
+    for (int a = 0; a < nagg; a++) n += 1 + (agg_has_cnt(aggs[a].kind, rfx_agg_input_type(&aggs[a]) == RFX_F64) ? 1 : 0);
     *n_arrays = n;
     return RFX_OK;
 }
@@ -186,7 +187,7 @@ static int check_tables(const rfx_agg_t *aggs, const rfx_group_tables_t *t) {
     RFX_REQUIRE(t->nagg >= 0 && t->nagg <= RFX_MAX_AGGS, RFX_ELIMIT, "too many aggregates");
     for (int a = 0; a < t->nagg; a++) {
         RFX_REQUIRE(t->d_acc[a] != NULL, RFX_EINVAL, "d_acc[a] is NULL");
-        if (agg_has_cnt(aggs[a].kind, aggs[a].col_type == RFX_F64)) RFX_REQUIRE(t->d_cnt[a] != NULL, RFX_EINVAL, "d_cnt[a] is NULL for SUM(i64)/AVG");
+        if (agg_has_cnt(aggs[a].kind, rfx_agg_input_type(&aggs[a]) == RFX_F64)) RFX_REQUIRE(t->d_cnt[a] != NULL, RFX_EINVAL, "d_cnt[a] is NULL for SUM(i64)/AVG");
     }
     return RFX_OK;
 }
@@ -198,7 +199,7 @@ extern "C" int rfx_hip_group_tables_init(rfx_ctx_t *c, const rfx_agg_t *aggs, co
     rc = rfx_fill_u64(c, t->d_first, t->range, (u64)RFX_INF_I64_D);
     if (rc != RFX_OK) return rc;
     for (int a = 0; a < t->nagg; a++) {
-        rc = rfx_fill_u64(c, t->d_acc[a], t->range, acc_identity(aggs[a].kind, aggs[a].col_type == RFX_F64));
+        rc = rfx_fill_u64(c, t->d_acc[a], t->range, acc_identity(aggs[a].kind, rfx_agg_input_type(&aggs[a]) == RFX_F64));
         if (rc != RFX_OK) return rc;
         if (t->d_cnt[a]) {
             rc = rfx_fill_u64(c, t->d_cnt[a], t->range, 0);
@@ -225,6 +226,20 @@ static int launch_group(rfx_ctx *c, const Plan &P, const GroupArgs &G, int grid,
     return RFX_OK;
 }
 
+// halves of a table set: aggregates [0, h) and [h, nagg) over the same `first` array
+static int split_tables(const rfx_group_tables_t *t, rfx_group_tables_t *t1, rfx_group_tables_t *t2) {
+    const int h = t->nagg / 2;
+    *t1 = *t;
+    *t2 = *t;
+    t1->nagg = h;
+    t2->nagg = t->nagg - h;
+    for (int a = 0; a < t2->nagg; a++) {
+        t2->d_acc[a] = t->d_acc[h + a];
+        t2->d_cnt[a] = t->d_cnt[h + a];
+    }
+    return h;
+}
+
 static int group_dense_run(rfx_ctx_t *c, Plan &P, GroupArgs &G, const rfx_agg_t *aggs, const rfx_group_tables_t *t, bool allow_part, bool *need_materialise) {
     G.kmin = t->kmin;
     G.range = t->range;
@@ -234,7 +249,7 @@ static int group_dense_run(rfx_ctx_t *c, Plan &P, GroupArgs &G, const rfx_agg_t 
     for (int a = 0; a < t->nagg; a++) {
         G.acc[a] = (u64 *)t->d_acc[a];
         G.cnt[a] = (u64 *)t->d_cnt[a];
-        narr += 1 + (agg_has_cnt(aggs[a].kind, aggs[a].col_type == RFX_F64) ? 1 : 0);
+        narr += 1 + (agg_has_cnt(aggs[a].kind, rfx_agg_input_type(&aggs[a]) == RFX_F64) ? 1 : 0);
     }
     size_t lds_bytes = (size_t)narr * (size_t)t->range * 8;
     const size_t lds_cap = (c->flags & RFX_TUNE_NO_BIG_LDS) ? RFX_LDS_GROUP_BYTES : RFX_LDS_GROUP_BIG_BYTES;
@@ -280,6 +295,13 @@ extern "C" int rfx_hip_group_dense_accumulate(rfx_ctx_t *c, const int64_t *d_key
     Plan P;
     int key_idx = 0;
     rc = rfx_plan_build(&P, preds, npred, logic, aggs, t->nagg, d_key, &key_idx, nrows, row0);
+    if (rc == RFX_ELIMIT && t->nagg > 1) { // too many columns / expressions for one launch: two passes over the same tables
+        rfx_group_tables_t t1, t2;
+        const int h = split_tables(t, &t1, &t2);
+        rc = rfx_hip_group_dense_accumulate(c, d_key, preds, npred, logic, aggs, nrows, row0, &t1);
+        if (rc != RFX_OK) return rc;
+        return rfx_hip_group_dense_accumulate(c, d_key, preds, npred, logic, aggs + h, nrows, row0, &t2);
+    }
     if (rc != RFX_OK) return rc;
     GroupArgs G;
     memset(&G, 0, sizeof(G));
@@ -302,6 +324,13 @@ extern "C" int rfx_hip_group_dense_accumulate_keys(rfx_ctx_t *c, const void *con
     Plan P;
     int k0 = 0;
     rc = rfx_plan_build(&P, preds, npred, logic, aggs, t->nagg, d_keys[0], &k0, nrows, row0);
+    if (rc == RFX_ELIMIT && t->nagg > 1) {
+        rfx_group_tables_t t1, t2;
+        const int h = split_tables(t, &t1, &t2);
+        rc = rfx_hip_group_dense_accumulate_keys(c, d_keys, mins, mults, nkeys, preds, npred, logic, aggs, nrows, row0, &t1);
+        if (rc != RFX_OK) return rc;
+        return rfx_hip_group_dense_accumulate_keys(c, d_keys, mins, mults, nkeys, preds, npred, logic, aggs + h, nrows, row0, &t2);
+    }
     if (rc != RFX_OK) return rc;
     GroupArgs G;
     memset(&G, 0, sizeof(G));
@@ -441,7 +470,7 @@ __global__ __launch_bounds__(RFX_BLOCK) void k_group_emit(const EmitArgs A, cons
         for (int a = 0; a < A.nagg; a++) {
             if (!A.out[a]) continue;
             if (A.kinds[a] == RFX_AGG_FIRST) A.out[a][g] = A.col[a] ? A.col[a][(i64)f - A.row0] : 0ULL;
-            else A.out[a][g] = group_final(A.kinds[a], A.f64s[a], A.acc[a][i], A.cnt[a] ? A.cnt[a][i] : 0ULL);
+            else A.out[a][g] = group_final(A.kinds[a], A.f64s[a], A.acc[a][i], A.cnt[a] ? A.cnt[a][i] : 0ULL, A.skips[a]);
         }
     }
 }
@@ -472,7 +501,8 @@ extern "C" int rfx_hip_group_emit(rfx_ctx_t *c, const rfx_agg_t *aggs, const rfx
     A.out_first = (i64 *)d_first_ids;
     for (int a = 0; a < t->nagg; a++) {
         A.kinds[a] = aggs[a].kind;
-        A.f64s[a] = aggs[a].col_type == RFX_F64;
+        A.f64s[a] = rfx_agg_input_type(&aggs[a]) == RFX_F64;
+        A.skips[a] = aggs[a].xop != RFX_X_NONE;
         A.acc[a] = (const u64 *)t->d_acc[a];
         A.cnt[a] = (const u64 *)t->d_cnt[a];
         A.col[a] = (const u64 *)aggs[a].d_col;

@@ -23,11 +23,15 @@ __host__ __device__ __forceinline__ bool agg_has_cnt(int kind, int f64) {
 // Grouped rules (core/aggr.c): sum is null-STICKY (ADDI64/ADDF64, :1088-1092) -> i64: count nulls aside, f64: IEEE NaN
 // propagates by itself; min/max skip nulls (:1152-1315); count counts every row (:1317-1453); avg casts to f64
 // and skips nulls (:1455-1540).
+// skip = 1: the aggregate's argument is an expression, which the reference folds group by group with its SCALAR rules
+// (FOLD_ADD* skip nulls, core/ops.h:156-158): an f64 sum then skips NaN instead of letting it poison the group.
 template <typename P64>
-__device__ __forceinline__ void group_apply(P64 acc, P64 cnt, int kind, int f64, u64 x) {
+__device__ __forceinline__ void group_apply(P64 acc, P64 cnt, int kind, int f64, u64 x, int skip = 0) {
     switch (kind) {
         case RFX_AGG_SUM:
-            if (f64) unsafeAtomicAdd((double *)acc, rfx_as_f64(x));
+            if (f64) {
+                if (!skip || !rfx_isnan_bits(x)) unsafeAtomicAdd((double *)acc, rfx_as_f64(x));
+            }
             else if ((i64)x == RFX_NULL_I64_D) atomicAdd((unsigned long long *)cnt, 1ULL);
             else atomicAdd((unsigned long long *)acc, (unsigned long long)x);
             break;
@@ -87,6 +91,7 @@ struct EmitArgs {
     int nagg;
     int kinds[RFX_MAX_AGGS];
     int f64s[RFX_MAX_AGGS];
+    int skips[RFX_MAX_AGGS]; // scalar (null-skipping) finalisation: expression aggregates
     const u64 *first;
     const u64 *keys; // hashed tables: explicit key per slot ; dense: NULL (key = kmin + slot)
     const u64 *acc[RFX_MAX_AGGS];
@@ -99,7 +104,19 @@ struct EmitArgs {
 };
 
 // Final grouped value of one cell -- core/aggr.c rules, see DESIGN.md "NULL semantics".
-__device__ __forceinline__ u64 group_final(int kind, int f64, u64 a, u64 c) {
+__device__ __forceinline__ u64 group_final(int kind, int f64, u64 a, u64 c, int skip = 0) {
+    if (skip) { // scalar rules per group (core/math.c folds): sum of no value = 0, min / max of no value = null
+        switch (kind) {
+            case RFX_AGG_SUM: return a;
+            case RFX_AGG_MIN:
+                if ((i64)a == RFX_INF_I64_D) return f64 ? RFX_NAN_BITS : (u64)RFX_NULL_I64_D;
+                return f64 ? rfx_ord_to_f64((i64)a) : a;
+            case RFX_AGG_MAX:
+                if ((i64)a == RFX_NULL_I64_D) return f64 ? RFX_NAN_BITS : a;
+                return f64 ? rfx_ord_to_f64((i64)a) : a;
+            default: break; // AVG: same rule either way
+        }
+    }
     switch (kind) {
         case RFX_AGG_SUM:
             if (f64) return rfx_isnan_bits(a) ? RFX_NAN_BITS : a;

@@ -650,13 +650,14 @@ __global__ __launch_bounds__(PART_AGG_THREADS) void k_part_aggregate(const Plan 
     const int p = blockIdx.x / A.split, s = blockIdx.x % A.split;
     const i64 local = 1LL << A.lb;
     // descriptors into registers once (static indices only inside the record loop)
-    int kind[RFX_MAX_AGGS], f64[RFX_MAX_AGGS], plane[RFX_MAX_AGGS], arr_of[RFX_MAX_AGGS];
+    int kind[RFX_MAX_AGGS], f64[RFX_MAX_AGGS], plane[RFX_MAX_AGGS], arr_of[RFX_MAX_AGGS], skip[RFX_MAX_AGGS];
     {
         int arr = 1;
 #pragma unroll
         for (int a = 0; a < RFX_MAX_AGGS; a++) {
             kind[a] = (a < P.nagg) ? P.aggs[a].kind : -1;
             f64[a] = (a < P.nagg) ? P.aggs[a].f64 : 0;
+            skip[a] = (a < P.nagg) ? P.aggs[a].skipnull : 0;
             plane[a] = (a < P.nagg) ? A.agg_plane[a] : -1;
             arr_of[a] = arr;
             if (kind[a] >= 0) arr += agg_has_cnt(kind[a], f64[a]) ? 2 : 1;
@@ -724,7 +725,7 @@ __global__ __launch_bounds__(PART_AGG_THREADS) void k_part_aggregate(const Plan 
 #pragma unroll
                 for (int j = 0; j < NV; j++)
                     if (plane[a] == j) x = val[r][j];
-                group_apply(&smem[(i64)arr_of[a] * local + slot], &smem[(i64)(arr_of[a] + 1) * local + slot], kind[a], f64[a], x);
+                group_apply(&smem[(i64)arr_of[a] * local + slot], &smem[(i64)(arr_of[a] + 1) * local + slot], kind[a], f64[a], x, skip[a]);
             }
         }
     }
@@ -906,6 +907,15 @@ static int part_accumulate_selective(rfx_ctx *c, const Plan &P, int key_idx, con
 // Returns RFX_ESTATE when this path does not apply (caller falls back to device-scope atomics).
 int rfx_group_part_accumulate(rfx_ctx *c, const Plan &P, int key_idx, const rfx_group_tables_t *t) {
     if (P.nrows >= (1LL << 32) || P.nrows < (1 << 16)) return RFX_ESTATE; // 32-bit local rows; tiny inputs are not worth 4 passes
+    if (P.nx > 0) {
+        // expression aggregates: the records carry plain values, so evaluate the expressions into scratch columns first
+        // (what the reference does for every query, core/math.c binop_map) and partition those
+        if (P.ncols + P.nx > RFX_MAX_COLS) return RFX_ESTATE;
+        Plan Pm = P;
+        const int rc = rfx_plan_materialise_exprs(c, &Pm);
+        if (rc != RFX_OK) return rc;
+        return rfx_group_part_accumulate(c, Pm, key_idx, t);
+    }
     PartArgs A;
     memset(&A, 0, sizeof(A));
     int narr = 1;

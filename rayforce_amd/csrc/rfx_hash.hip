@@ -103,11 +103,12 @@ __global__ __launch_bounds__(RFX_BLOCK) void k_group_hash(const Plan P, const Ha
         for (int a = 0; a < H.nagg; a++) {
             const PlanAgg ag = P.aggs[a];
             u64 x[E];
-            if (ag.col >= 0) sel_col<NC, E>(x, v, ag.col);
+            if (ag.col >= RFX_XCOL) expr_input<NC, E>(x, v, P.xs[ag.col - RFX_XCOL]);
+            else if (ag.col >= 0) sel_col<NC, E>(x, v, ag.col);
 #pragma unroll
             for (int e = 0; e < E; e++) {
                 if (slot[e] < 0) continue;
-                group_apply(&H.acc[a][slot[e]], H.cnt[a] ? &H.cnt[a][slot[e]] : (u64 *)0, ag.kind, ag.f64, x[e]);
+                group_apply(&H.acc[a][slot[e]], H.cnt[a] ? &H.cnt[a][slot[e]] : (u64 *)0, ag.kind, ag.f64, x[e], ag.skipnull);
             }
         }
     }
@@ -150,7 +151,7 @@ static int check_hash(const rfx_agg_t *aggs, const rfx_hash_tables_t *t) {
     RFX_REQUIRE(t->nagg >= 0 && t->nagg <= RFX_MAX_AGGS, RFX_ELIMIT, "too many aggregates");
     for (int a = 0; a < t->nagg; a++) {
         RFX_REQUIRE(t->d_acc[a] != NULL, RFX_EINVAL, "d_acc[a] is NULL");
-        if (agg_has_cnt(aggs[a].kind, aggs[a].col_type == RFX_F64)) RFX_REQUIRE(t->d_cnt[a] != NULL, RFX_EINVAL, "d_cnt[a] is NULL for SUM(i64)/AVG");
+        if (agg_has_cnt(aggs[a].kind, rfx_agg_input_type(&aggs[a]) == RFX_F64)) RFX_REQUIRE(t->d_cnt[a] != NULL, RFX_EINVAL, "d_cnt[a] is NULL for SUM(i64)/AVG");
     }
     return RFX_OK;
 }
@@ -164,7 +165,7 @@ extern "C" int rfx_hip_hash_tables_init(rfx_ctx_t *c, const rfx_agg_t *aggs, con
     if ((rc = rfx_fill_u64(c, t->d_keys, n, (u64)RFX_NULL_I64_D)) != RFX_OK) return rc;
     if ((rc = rfx_fill_u64(c, t->d_first, n, (u64)RFX_INF_I64_D)) != RFX_OK) return rc;
     for (int a = 0; a < t->nagg; a++) {
-        if ((rc = rfx_fill_u64(c, t->d_acc[a], n, acc_identity(aggs[a].kind, aggs[a].col_type == RFX_F64))) != RFX_OK) return rc;
+        if ((rc = rfx_fill_u64(c, t->d_acc[a], n, acc_identity(aggs[a].kind, rfx_agg_input_type(&aggs[a]) == RFX_F64))) != RFX_OK) return rc;
         if (t->d_cnt[a] && (rc = rfx_fill_u64(c, t->d_cnt[a], n, 0)) != RFX_OK) return rc;
     }
     return RFX_OK;
@@ -195,6 +196,19 @@ extern "C" int rfx_hip_group_hash_accumulate(rfx_ctx_t *c, const int64_t *d_key,
     Plan P;
     int key_idx = 0;
     rc = rfx_plan_build(&P, preds, npred, logic, aggs, t->nagg, d_key, &key_idx, nrows, row0);
+    if (rc == RFX_ELIMIT && t->nagg > 1) { // too many columns / expressions for one launch: two passes, same keys and slots
+        const int h = t->nagg / 2;
+        rfx_hash_tables_t t1 = *t, t2 = *t;
+        t1.nagg = h;
+        t2.nagg = t->nagg - h;
+        for (int a = 0; a < t2.nagg; a++) {
+            t2.d_acc[a] = t->d_acc[h + a];
+            t2.d_cnt[a] = t->d_cnt[h + a];
+        }
+        rc = rfx_hip_group_hash_accumulate(c, d_key, preds, npred, logic, aggs, nrows, row0, &t1);
+        if (rc != RFX_OK) return rc;
+        return rfx_hip_group_hash_accumulate(c, d_key, preds, npred, logic, aggs + h, nrows, row0, &t2);
+    }
     if (rc != RFX_OK) return rc;
     HashArgs H;
     memset(&H, 0, sizeof(H));
@@ -244,7 +258,7 @@ extern "C" int rfx_hip_hash_tables_merge(rfx_ctx_t *c, const rfx_agg_t *aggs, co
     M.ffirst = (const u64 *)from->d_first;
     for (int a = 0; a < into->nagg; a++) {
         M.kinds[a] = aggs[a].kind;
-        M.f64s[a] = aggs[a].col_type == RFX_F64;
+        M.f64s[a] = rfx_agg_input_type(&aggs[a]) == RFX_F64;
         M.acc[a] = (u64 *)into->d_acc[a];
         M.cnt[a] = (u64 *)into->d_cnt[a];
         M.facc[a] = (const u64 *)from->d_acc[a];
@@ -281,7 +295,8 @@ extern "C" int rfx_hip_hash_emit(rfx_ctx_t *c, const rfx_agg_t *aggs, const rfx_
     A.out_first = (i64 *)d_first_ids;
     for (int a = 0; a < t->nagg; a++) {
         A.kinds[a] = aggs[a].kind;
-        A.f64s[a] = aggs[a].col_type == RFX_F64;
+        A.f64s[a] = rfx_agg_input_type(&aggs[a]) == RFX_F64;
+        A.skips[a] = aggs[a].xop != RFX_X_NONE;
         A.acc[a] = (const u64 *)t->d_acc[a];
         A.cnt[a] = (const u64 *)t->d_cnt[a];
         A.col[a] = (const u64 *)aggs[a].d_col;

@@ -41,11 +41,17 @@ static struct {
     const char *(*symname)(int64_t);
     obj_p null_obj;
     /* the host's own built-ins, for recognising function objects inside parsed expressions and for delegation */
-    void *f[16];
+    void *f[32];
 } H;
-enum { F_SUM, F_AVG, F_MIN, F_MAX, F_COUNT, F_FIRST, F_EQ, F_NE, F_LT, F_GT, F_LE, F_GE, F_AND, F_OR, F_SELECT, F_N };
-static const char *HOST_FN[F_N] = {"ray_sum", "ray_avg", "ray_min", "ray_max", "ray_count", "ray_first", "ray_eq", "ray_ne",
-                                   "ray_lt",  "ray_gt",  "ray_le",  "ray_ge",  "ray_and",   "ray_or",    "ray_select"};
+enum { F_SUM, F_AVG, F_MIN, F_MAX, F_COUNT, F_FIRST, F_EQ, F_NE, F_LT, F_GT, F_LE, F_GE, F_AND, F_OR, F_SELECT, F_ADD, F_SUB, F_MUL, F_FDIV, F_N };
+static const char *HOST_FN[F_N] = {"ray_sum", "ray_avg", "ray_min", "ray_max", "ray_count", "ray_first", "ray_eq",  "ray_ne",  "ray_lt",  "ray_gt",
+                                   "ray_le",  "ray_ge",  "ray_and", "ray_or",  "ray_select", "ray_add",  "ray_sub", "ray_mul", "ray_fdiv"};
+/* + - * div are recognised inside aggregate arguments only; as stand-alone operators they are the host's.  The
+ * standalone object model still needs distinct function objects for them: these stubs are never called by this library. */
+static obj_p x_stub_add(obj_p a, obj_p b) { (void)a; (void)b; return NULL; }
+static obj_p x_stub_sub(obj_p a, obj_p b) { (void)a; (void)b; return NULL; }
+static obj_p x_stub_mul(obj_p a, obj_p b) { (void)a; (void)b; return NULL; }
+static obj_p x_stub_fdiv(obj_p a, obj_p b) { (void)a; (void)b; return NULL; }
 static void *OUR_FN[F_N];
 static char g_err[640];
 static int g_last_gpu = 0;
@@ -59,6 +65,7 @@ int rfx_host_bind(void) {
     OUR_FN[F_COUNT] = (void *)rfx_count; OUR_FN[F_FIRST] = (void *)rfx_first; OUR_FN[F_EQ] = (void *)rfx_eq; OUR_FN[F_NE] = (void *)rfx_ne;
     OUR_FN[F_LT] = (void *)rfx_lt; OUR_FN[F_GT] = (void *)rfx_gt; OUR_FN[F_LE] = (void *)rfx_le; OUR_FN[F_GE] = (void *)rfx_ge;
     OUR_FN[F_AND] = (void *)rfx_and; OUR_FN[F_OR] = (void *)rfx_or; OUR_FN[F_SELECT] = (void *)rfx_select;
+    OUR_FN[F_ADD] = (void *)x_stub_add; OUR_FN[F_SUB] = (void *)x_stub_sub; OUR_FN[F_MUL] = (void *)x_stub_mul; OUR_FN[F_FDIV] = (void *)x_stub_fdiv;
     void *v = dlsym(RTLD_DEFAULT, "vector"), *t = dlsym(RTLD_DEFAULT, "table"), *e = dlsym(RTLD_DEFAULT, "eval");
     void *rs = dlsym(RTLD_DEFAULT, "ray_select"), *nu = dlsym(RTLD_DEFAULT, "__NULL_OBJ");
     if (v && t && e && rs && nu && !getenv("RFX_FORCE_STANDALONE")) {
@@ -101,7 +108,9 @@ obj_p rfx_host_fn(const char *name) {
         {"max", F_MAX, RFX_TYPE_UNARY, RFX_FN_AGGR}, {"count", F_COUNT, RFX_TYPE_UNARY, RFX_FN_AGGR}, {"first", F_FIRST, RFX_TYPE_UNARY, RFX_FN_AGGR},
         {"==", F_EQ, RFX_TYPE_BINARY, RFX_FN_ATOMIC}, {"!=", F_NE, RFX_TYPE_BINARY, RFX_FN_ATOMIC}, {"<", F_LT, RFX_TYPE_BINARY, RFX_FN_ATOMIC},
         {">", F_GT, RFX_TYPE_BINARY, RFX_FN_ATOMIC}, {"<=", F_LE, RFX_TYPE_BINARY, RFX_FN_ATOMIC}, {">=", F_GE, RFX_TYPE_BINARY, RFX_FN_ATOMIC},
-        {"and", F_AND, RFX_TYPE_VARY, RFX_FN_SPECIAL_FORM}, {"or", F_OR, RFX_TYPE_VARY, RFX_FN_SPECIAL_FORM}, {"select", F_SELECT, RFX_TYPE_UNARY, 0}};
+        {"and", F_AND, RFX_TYPE_VARY, RFX_FN_SPECIAL_FORM}, {"or", F_OR, RFX_TYPE_VARY, RFX_FN_SPECIAL_FORM}, {"select", F_SELECT, RFX_TYPE_UNARY, 0},
+        {"+", F_ADD, RFX_TYPE_BINARY, RFX_FN_ATOMIC}, {"-", F_SUB, RFX_TYPE_BINARY, RFX_FN_ATOMIC}, {"*", F_MUL, RFX_TYPE_BINARY, RFX_FN_ATOMIC},
+        {"div", F_FDIV, RFX_TYPE_BINARY, RFX_FN_ATOMIC}};
     rfx_host_bind();
     for (size_t i = 0; i < sizeof(T) / sizeof(T[0]); i++)
         if (strcmp(T[i].n, name) == 0) {
@@ -406,7 +415,7 @@ rfx_obj_p rfx_select(rfx_obj_p dict) {
         wplan_t wp;
         int flat = 1;
         int64_t *d_ids = NULL, nsel = 0;
-        void *tmp[RFX_MAX_AGGS + 4];
+        void *tmp[2 * RFX_MAX_AGGS + 4];
         int ntmp = 0;
         int rc = plan_where(tab, where, &wp);
         if (rc == -2) { res = fail_hip("column upload"); goto done; }
@@ -427,15 +436,51 @@ rfx_obj_p rfx_select(rfx_obj_p dict) {
             if (nagg >= RFX_MAX_AGGS || e->type != RFX_TYPE_LIST || e->len != 2) { why = "mapping shape"; goto out; }
             int f = fn_id(RFX_AS_LIST(e)[0]);
             obj_p a = RFX_AS_LIST(e)[1];
-            if (f < F_SUM || f > F_FIRST || a->type != -RFX_TYPE_SYMBOL) { why = "mapping is not (aggr column)"; goto out; }
+            static const int KIND[] = {RFX_AGG_SUM, RFX_AGG_AVG, RFX_AGG_MIN, RFX_AGG_MAX, RFX_AGG_COUNT, RFX_AGG_FIRST};
+            if (f < F_SUM || f > F_FIRST) { why = "mapping is not (aggr ...)"; goto out; }
+            memset(&aggs[nagg], 0, sizeof(aggs[nagg]));
+            aggs[nagg].kind = KIND[f - F_SUM];
+            if (a->type == RFX_TYPE_LIST && a->len == 3) {
+                /* (aggr (op x y)), op in + - * div, x / y a column or an i64 / f64 atom: folded on the device */
+                int xf = fn_id(RFX_AS_LIST(a)[0]);
+                obj_p xo[2] = {RFX_AS_LIST(a)[1], RFX_AS_LIST(a)[2]}, xc[2] = {NULL, NULL};
+                if (xf < F_ADD || xf > F_FDIV || f == F_COUNT || f == F_FIRST) { why = "mapping argument is not (+|-|*|div x y) under sum/avg/min/max"; goto out; }
+                for (int j = 0; j < 2; j++) {
+                    if (xo[j]->type == -RFX_TYPE_SYMBOL) {
+                        xc[j] = table_col(tab, xo[j]->i64);
+                        if (!xc[j] || !(xc[j]->type == RFX_TYPE_I64 || xc[j]->type == RFX_TYPE_F64)) { why = "expression operand column type"; goto out; }
+                    } else if (xo[j]->type != -RFX_TYPE_I64 && xo[j]->type != -RFX_TYPE_F64) { why = "expression operand is neither a column nor an i64/f64 atom"; goto out; }
+                }
+                if (!xc[0] && !xc[1]) { why = "expression without a column"; goto out; }
+                const int ci = xc[0] ? 0 : 1, oi = 1 - ci; /* ci: the operand stored as the aggregate's column */
+                const void *d;
+                if (resident(xc[ci], 0, &d) != RFX_OK) { res = fail_hip("column upload"); goto done; }
+                aggs[nagg].d_col = d;
+                aggs[nagg].col_type = col_ctype(xc[ci]);
+                aggs[nagg].xop = RFX_X_ADD + (xf - F_ADD);
+                aggs[nagg].xflags = (ci == 1) ? RFX_XF_SWAP : 0;
+                if (xc[oi]) {
+                    if (resident(xc[oi], 0, &d) != RFX_OK) { res = fail_hip("column upload"); goto done; }
+                    aggs[nagg].d_xrhs_col = d;
+                    aggs[nagg].xrhs_type = col_ctype(xc[oi]);
+                } else if (xo[oi]->type == -RFX_TYPE_F64) {
+                    aggs[nagg].xrhs_type = RFX_F64;
+                    aggs[nagg].xrhs_f = xo[oi]->f64;
+                } else {
+                    aggs[nagg].xrhs_type = RFX_I64;
+                    aggs[nagg].xrhs_i = xo[oi]->i64;
+                }
+                outtype[nagg] = (f == F_AVG || rfx_agg_input_type(&aggs[nagg]) == RFX_F64) ? RFX_TYPE_F64 : RFX_TYPE_I64;
+                names[nagg++] = k;
+                continue;
+            }
+            if (a->type != -RFX_TYPE_SYMBOL) { why = "mapping is not (aggr column)"; goto out; }
             obj_p c = table_col(tab, a->i64);
             if (!c || !col_ctype(c) || c->type == RFX_TYPE_SYMBOL) { why = "aggregate column type"; goto out; }
             const void *d;
             if (resident(c, 0, &d) != RFX_OK) { res = fail_hip("column upload"); goto done; }
-            static const int KIND[] = {RFX_AGG_SUM, RFX_AGG_AVG, RFX_AGG_MIN, RFX_AGG_MAX, RFX_AGG_COUNT, RFX_AGG_FIRST};
             aggs[nagg].d_col = d;
             aggs[nagg].col_type = col_ctype(c);
-            aggs[nagg].kind = KIND[f - F_SUM];
             outtype[nagg] = (f == F_AVG) ? RFX_TYPE_F64 : (f == F_COUNT) ? RFX_TYPE_I64 : c->type;
             names[nagg++] = k;
         }
@@ -510,12 +555,13 @@ rfx_obj_p rfx_select(rfx_obj_p dict) {
             if (rc == -1) { why = "where: shape"; goto out; }
             if (rc) { res = fail_hip("where"); goto done; }
             int ok = 1;
-            const void *seen_src[RFX_MAX_AGGS + 1];
-            void *seen_dst[RFX_MAX_AGGS + 1];
+            const void *seen_src[2 * RFX_MAX_AGGS + 1];
+            void *seen_dst[2 * RFX_MAX_AGGS + 1];
             int nseen = 0;
-            for (int a = 0; a <= nagg && ok; a++) {
-                const void **slot = (a < nagg) ? &aggs[a].d_col : &dk;
-                if (a == nagg && !by) break;
+            for (int a = 0; a <= 2 * nagg && ok; a++) {
+                /* every device column the aggregates read (argument and second expression operand), then the key */
+                const void **slot = (a < nagg) ? &aggs[a].d_col : (a < 2 * nagg) ? &aggs[a - nagg].d_xrhs_col : &dk;
+                if (a == 2 * nagg && !by) break;
                 if (!*slot) continue;
                 int j = 0;
                 for (; j < nseen; j++)
@@ -588,7 +634,7 @@ rfx_obj_p rfx_select(rfx_obj_p dict) {
                 else { ht.capacity = cap; ht.nagg = nagg; ht.d_keys = base + (k++) * cells; ht.d_first = base + (k++) * cells; }
                 for (int a = 0; a < nagg; a++) {
                     void *acc = base + (k++) * cells;
-                    int hc = aggs[a].kind == RFX_AGG_AVG || (aggs[a].kind == RFX_AGG_SUM && aggs[a].col_type == RFX_I64);
+                    int hc = aggs[a].kind == RFX_AGG_AVG || (aggs[a].kind == RFX_AGG_SUM && rfx_agg_input_type(&aggs[a]) == RFX_I64);
                     int64_t *cnt = hc ? base + (k++) * cells : NULL;
                     if (dense) { gt.d_acc[a] = acc; gt.d_cnt[a] = cnt; } else { ht.d_acc[a] = acc; ht.d_cnt[a] = cnt; }
                 }
@@ -790,7 +836,11 @@ static obj_p fold_op(int f, int kind, obj_p x) {
     if (ensure_ctx() != RFX_OK) return fail_hip("no usable MI355X");
     const void *d;
     if (resident(x, 0, &d) != RFX_OK) return fail_hip("column upload");
-    rfx_agg_t a = {d, col_ctype(x), kind};
+    rfx_agg_t a;
+    memset(&a, 0, sizeof(a));
+    a.d_col = d;
+    a.col_type = col_ctype(x);
+    a.kind = kind;
     rfx_value_t v;
     if (rfx_hip_filter_aggr_host(g_ctx, NULL, 0, RFX_AND, &a, 1, x->len, &v, NULL) != RFX_OK) return fail_hip("filter_aggr");
     return value_atom(&v);

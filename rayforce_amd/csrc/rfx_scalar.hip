@@ -108,6 +108,15 @@ extern "C" int rfx_hip_filter_aggr(rfx_ctx_t *c, const rfx_pred_t *preds, int np
     RFX_REQUIRE(c && d_out, RFX_EINVAL, "NULL argument");
     Plan P;
     int rc = rfx_plan_build(&P, preds, npred, logic, aggs, nagg, NULL, NULL, nrows, row0);
+    if (rc == RFX_ELIMIT && nagg > 1) {
+        // more distinct columns / expressions than one launch carries: two passes over the same selection.  The first
+        // writes partials [0, h) plus its count into slot h, which the second overwrites with partial h (its own count
+        // lands in slot nagg).
+        const int h = nagg / 2;
+        rc = rfx_hip_filter_aggr(c, preds, npred, logic, aggs, h, nrows, row0, d_out);
+        if (rc != RFX_OK) return rc;
+        return rfx_hip_filter_aggr(c, preds, npred, logic, aggs + h, nagg - h, nrows, row0, d_out + h);
+    }
     if (rc != RFX_OK) return rc;
     if (P.ncols == 0) {
         // nothing to read: COUNT(s) over all rows.  Use a 1-element dummy so the kernel shape stays uniform.
@@ -127,6 +136,11 @@ extern "C" int rfx_hip_filter_aggr(rfx_ctx_t *c, const rfx_pred_t *preds, int np
         return RFX_OK;
     }
     return rfx_run_filter_aggr(c, P, d_out);
+}
+
+extern "C" int rfx_agg_input_type(const rfx_agg_t *a) {
+    if (!a || a->xop == RFX_X_NONE) return a ? a->col_type : RFX_I64;
+    return (a->xop == RFX_X_FDIV || a->col_type == RFX_F64 || a->xrhs_type == RFX_F64) ? RFX_F64 : RFX_I64;
 }
 
 // ---------------- host-side partial algebra ----------------
@@ -239,7 +253,7 @@ extern "C" int rfx_hip_filter_aggr_host(rfx_ctx_t *c, const rfx_pred_t *preds, i
     RFX_HIP_CHECK(hipMemcpyAsync(h, d_out, bytes, hipMemcpyDeviceToHost, c->stream));
     RFX_HIP_CHECK(hipStreamSynchronize(c->stream));
     for (int a = 0; a < nagg; a++) {
-        rc = rfx_agg_finalize(aggs[a].kind, aggs[a].col_type, &h[a], &values[a]);
+        rc = rfx_agg_finalize(aggs[a].kind, rfx_agg_input_type(&aggs[a]), &h[a], &values[a]);
         if (rc != RFX_OK) return rc;
     }
     if (selected) *selected = h[nagg].cnt;

@@ -76,6 +76,25 @@ __device__ __forceinline__ void sel_col(u64 (&x)[E], const u64 (&v)[NC][E], int 
     }
 }
 
+// The input of an expression aggregate, computed from the register tile: no temporary column exists.
+template <int NC, int E>
+__device__ __forceinline__ void expr_input(u64 (&x)[E], const u64 (&v)[NC][E], const PlanExpr &X) {
+    u64 l[E], r[E];
+    if (X.l_col >= 0) sel_col<NC, E>(l, v, X.l_col);
+    else {
+#pragma unroll
+        for (int e = 0; e < E; e++) l[e] = X.l_atom;
+    }
+    if (X.r_col >= 0) sel_col<NC, E>(r, v, X.r_col);
+    else {
+#pragma unroll
+        for (int e = 0; e < E; e++) r[e] = X.r_atom;
+    }
+#pragma unroll
+    for (int e = 0; e < E; e++) x[e] = rfx_expr_eval(X.op, X.out_f64, X.l_f64, X.r_f64, l[e], r[e]);
+}
+
+
 // Predicate / aggregate descriptors copied out of the kernarg segment ONCE per kernel into SGPRs (indexing the by-value
 // Plan with a runtime loop counter inside the tile loop makes every field a dependent s_load + s_waitcnt per tile).
 //
@@ -305,9 +324,9 @@ __device__ __forceinline__ void acc_update(Acc &a, int kind, int f64, const u64 
 struct AggR {
     int col, f64, kind;
 };
-template <int NC, int NA, int E, int NP>
+template <int NC, int NA, int E, int NP, int NX = 0>
 __device__ __forceinline__ void fold_tile(const PredSet<NP> &S, const AggR (&ag)[NA], const u64 (&v)[NC][E], const bool (&valid)[E], Acc (&acc)[NA],
-                                          i64 &nsel, i64 row_of_e0, int jstride) {
+                                          i64 &nsel, i64 row_of_e0, int jstride, const PlanExpr *xs = nullptr) {
     bool sel[E];
     eval_sel<NC, E, NP>(S, v, valid, sel);
     int c = 0;
@@ -325,10 +344,26 @@ __device__ __forceinline__ void fold_tile(const PredSet<NP> &S, const AggR (&ag)
             if (ag[a].kind >= 0 && ag[a].kind != RFX_AGG_COUNT && ag[a].col == col) acc_update<E>(acc[a], ag[a].kind, ag[a].f64, v[col], sel, row_of_e0, jstride);
         }
     }
+    if (NX > 0) {
+#pragma unroll
+        for (int i = 0; i < NX; i++) {
+            bool used = false;
+#pragma unroll
+            for (int a = 0; a < NA; a++) used |= (ag[a].kind >= 0 && ag[a].col == RFX_XCOL + i);
+            if (!used) continue; // wave-uniform
+            u64 x[E];
+            expr_input<NC, E>(x, v, xs[i]);
+#pragma unroll
+            for (int a = 0; a < NA; a++) {
+                if (ag[a].kind >= 0 && ag[a].kind != RFX_AGG_COUNT && ag[a].col == RFX_XCOL + i)
+                    acc_update<E>(acc[a], ag[a].kind, ag[a].f64, x, sel, row_of_e0, jstride);
+            }
+        }
+    }
 }
 
 // Workgroup partial layout in the workspace: ws[(block * (NA + 1) + a)] ; slot NA = selected-row count.
-template <int NC, int NA, int U, int NP>
+template <int NC, int NA, int U, int NP, int NX = 0>
 __global__ __launch_bounds__(RFX_BLOCK) void k_filter_aggr(const Plan P, Acc *__restrict__ ws) {
     constexpr int E = 2 * U;
     constexpr int TILE = RFX_BLOCK * E;     // rows per workgroup per iteration
@@ -350,6 +385,9 @@ __global__ __launch_bounds__(RFX_BLOCK) void k_filter_aggr(const Plan P, Acc *__
 #pragma unroll
     for (int c = 0; c < NC; c++) cols[c] = P.cols[c];
     const i64 nrows = P.nrows, row0 = P.row0;
+    PlanExpr xs[NX > 0 ? NX : 1]; // expression descriptors, hoisted like the others (static indices only)
+#pragma unroll
+    for (int i = 0; i < (NX > 0 ? NX : 1); i++) xs[i] = P.xs[i];
 
     bool all[E];
 #pragma unroll
@@ -368,7 +406,7 @@ __global__ __launch_bounds__(RFX_BLOCK) void k_filter_aggr(const Plan P, Acc *__
                 v[c][2 * j + 1] = q.y;
             }
         }
-        fold_tile<NC, NA, E, NP>(S, ag, v, all, acc, nsel, row0 + base, JSTRIDE);
+        fold_tile<NC, NA, E, NP, NX>(S, ag, v, all, acc, nsel, row0 + base, JSTRIDE, xs);
     }
     // ragged tail: one workgroup, guarded element loads
     const i64 tail0 = nfull * TILE;
@@ -383,7 +421,7 @@ __global__ __launch_bounds__(RFX_BLOCK) void k_filter_aggr(const Plan P, Acc *__
 #pragma unroll
             for (int c = 0; c < NC; c++) v[c][e] = valid[e] ? cols[c][row] : 0ULL;
         }
-        fold_tile<NC, NA, E, NP>(S, ag, v, valid, acc, nsel, row0 + base, JSTRIDE);
+        fold_tile<NC, NA, E, NP, NX>(S, ag, v, valid, acc, nsel, row0 + base, JSTRIDE, xs);
     }
 
     // wave reduction (64 lanes), then across the 4 waves through LDS.  Counts are wave-uniform already: keep lane 0's.

@@ -201,10 +201,7 @@ class ShardedEngine:
         eng = self.eng
         part = eng.filter_aggr_partials(aggs, where, table, nrows=self.shard.local_rows, row0=self.shard.row0)
         kinds = [L.AGGS[fn] for fn, _ in aggs]
-        ctypes_ = []
-        for fn, col in aggs:
-            col = table[col] if isinstance(col, str) else col
-            ctypes_.append(L.RFX_F64 if (col is not None and col.dtype == torch.float64) else L.RFX_I64)
+        ctypes_ = [L.RFX_F64 if (col is not None and eng._arg_f64(col, table)) else L.RFX_I64 for fn, col in aggs]
         return merge_scalar_partials(part, kinds, ctypes_, self.shard.group)
 
     def where(self, where, table=None) -> torch.Tensor:
@@ -213,9 +210,6 @@ class ShardedEngine:
 
     def group_by(self, key, aggs, where=None, table=None):
         kinds = [L.AGGS[fn] for fn, _ in aggs]
-        f64s = []
-        for fn, col in aggs:
-            col = table[col] if isinstance(col, str) else col
-            f64s.append(col is not None and col.dtype == torch.float64)
+        f64s = [col is not None and self.eng._arg_f64(col, table) for fn, col in aggs]
         hook = GroupHook(self.shard, kinds, f64s)
         return self.eng.group_by(key, aggs, where, table, total_rows=self.shard.total_rows, row0=self.shard.row0, _collective=hook)

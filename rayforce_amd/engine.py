@@ -179,6 +179,9 @@ class Engine:
         for i, (fn, col) in enumerate(aggs):
             a = arr[i]
             a.kind = L.AGGS[fn]
+            if isinstance(col, tuple):
+                n = self._agg_expr(a, fn, col, table, n)
+                continue
             col = self._resolve(col, table) if col is not None else None
             if col is None:
                 if fn != "count":
@@ -192,6 +195,61 @@ class Engine:
                 a.col_type = _ctype_of(col)
                 self._keep.append(col)
         return arr, n
+
+    def _agg_expr(self, a, fn: str, expr, table, n):
+        """``(fn (op lhs rhs))``: lhs / rhs are columns or atoms, at least one a column."""
+        if len(expr) != 3 or expr[0] not in L.XOPS:
+            raise RfxError(f"unsupported expression {expr!r}: (op lhs rhs) with op in + - * div")
+        op, lhs, rhs = expr
+        l = self._resolve(lhs, table) if isinstance(lhs, (str, torch.Tensor)) else lhs
+        r = self._resolve(rhs, table) if isinstance(rhs, (str, torch.Tensor)) else rhs
+        lcol, rcol = isinstance(l, torch.Tensor), isinstance(r, torch.Tensor)
+        if not (lcol or rcol):
+            raise RfxError("an expression needs at least one column operand")
+        a.xop = L.XOPS[op]
+        col, other, swap = (l, r, False) if lcol else (r, l, True)
+        col = self._check_col(col, n)
+        n = col.numel() if n is None else n
+        a.d_col, a.col_type = col.data_ptr(), _ctype_of(col)
+        a.xflags = L.RFX_XF_SWAP if swap else 0
+        self._keep.append(col)
+        if isinstance(other, torch.Tensor):
+            other = self._check_col(other, n)
+            a.d_xrhs_col, a.xrhs_type = other.data_ptr(), _ctype_of(other)
+            self._keep.append(other)
+        elif isinstance(other, float):
+            a.d_xrhs_col, a.xrhs_type, a.xrhs_f = None, L.RFX_F64, other
+        else:
+            a.d_xrhs_col, a.xrhs_type, a.xrhs_i = None, L.RFX_I64, L.NULL_I64 if other is None else int(other)
+        return n
+
+    @staticmethod
+    def _agg_chunks(aggs):
+        """Split an output list into launches: <= RFX_MAX_AGGS aggregates, <= RFX_MAX_EXPRS expressions and a handful of
+        distinct argument columns each (predicate and key columns need plan slots too)."""
+        chunks, cur, nx, cols = [], [], 0, set()
+        for fn, col in aggs:
+            ops = [x for x in col[1:] if isinstance(x, (str, torch.Tensor))] if isinstance(col, tuple) else ([col] if col is not None else [])
+            ids = {x if isinstance(x, str) else x.data_ptr() for x in ops}
+            x = 1 if isinstance(col, tuple) else 0
+            if cur and (len(cur) >= L.RFX_MAX_AGGS or nx + x > L.RFX_MAX_EXPRS or len(cols | ids) > 4):
+                chunks.append(cur)
+                cur, nx, cols = [], 0, set()
+            cur.append((fn, col))
+            nx += x
+            cols |= ids
+        if cur:
+            chunks.append(cur)
+        return chunks or [[]]
+
+    def _arg_f64(self, col, table) -> bool:
+        """Element type of an aggregate's argument: a column, or (op lhs rhs) with the reference's promotion."""
+        if isinstance(col, tuple):
+            def f(x):
+                x = self._resolve(x, table) if isinstance(x, (str, torch.Tensor)) else x
+                return x.dtype == torch.float64 if isinstance(x, torch.Tensor) else isinstance(x, float)
+            return col[0] == "div" or f(col[1]) or f(col[2])
+        return self._resolve(col, table).dtype == torch.float64
 
     @staticmethod
     def _value(v: L.Value):
@@ -220,10 +278,11 @@ class Engine:
             logic, flat = self._flatten(where, table)
         except _NotFlat:
             return self._filter_aggr_via_ids(aggs, where, table)
-        if len(aggs) > L.RFX_MAX_AGGS:  # more outputs than one fused pass carries: several passes, same selection
+        chunks = self._agg_chunks(aggs)
+        if len(chunks) > 1:  # more outputs than one fused pass carries: several passes, same selection
             vals, sel = [], 0
-            for i in range(0, len(aggs), L.RFX_MAX_AGGS):
-                v, sel = self.filter_aggr(aggs[i:i + L.RFX_MAX_AGGS], where, table, nrows)
+            for ch in chunks:
+                v, sel = self.filter_aggr(ch, where, table, nrows)
                 vals += v
             return vals, sel
         self._keep.clear()
@@ -241,7 +300,14 @@ class Engine:
         # nested boolean tree: masks -> where -> gather -> plain folds (the reference's own plan, on the GPU)
         ids = self.where(where, table)
         gathered = []
+        def pick(x):
+            x = self._resolve(x, table) if isinstance(x, (str, torch.Tensor)) else x
+            return self.at_ids(x, ids) if isinstance(x, torch.Tensor) else x
+
         for fn, col in aggs:
+            if isinstance(col, tuple):
+                gathered.append((fn, (col[0], pick(col[1]), pick(col[2]))))
+                continue
             col = self._resolve(col, table) if col is not None else None
             gathered.append((fn, self.at_ids(col, ids) if col is not None else None))
         vals, _ = self.filter_aggr(gathered, None, None, nrows=int(ids.numel()))
@@ -377,7 +443,7 @@ class Engine:
         for a in range(nagg):
             t.d_acc[a] = store[k].data_ptr(); k += 1
             layout.append(("acc", a))
-            kind, f64 = aggs_arr[a].kind, aggs_arr[a].col_type == L.RFX_F64
+            kind, f64 = aggs_arr[a].kind, L.agg_input_type(aggs_arr[a]) == L.RFX_F64
             if kind == L.RFX_AGG_AVG or (kind == L.RFX_AGG_SUM and not f64):
                 t.d_cnt[a] = store[k].data_ptr(); k += 1
                 layout.append(("cnt", a))
@@ -391,6 +457,16 @@ class Engine:
         Group order is first occurrence.  `_collective(store, layout, aggs_arr, hashed)` -- if given -- is called
         between the local scatter pass and the ranking step so that several GPUs can merge their tables.  (syncs)
         """
+        chunks = self._agg_chunks(aggs)
+        if len(chunks) > 1:  # more outputs than one table set carries: several passes (same groups, same order)
+            r = None
+            for ch in chunks:
+                part = self.group_by(key, ch, where, table, total_rows, row0, _collective)
+                if r is None:
+                    r = part
+                else:
+                    r["results"] += part["results"]
+            return r
         multi = None
         if isinstance(key, (list, tuple)) and len(key) == 1:
             key = key[0]
@@ -420,14 +496,13 @@ class Engine:
         nagg = len(aggs)
         total_rows = n if total_rows is None else total_rows
         out_dtypes = []
-        for fn, col in aggs:
-            col = self._resolve(col, table) if col is not None else None
+        for i, (fn, col) in enumerate(aggs):
             if fn in ("avg",):
                 out_dtypes.append(torch.float64)
             elif fn == "count":
                 out_dtypes.append(torch.int64)
             else:
-                out_dtypes.append(col.dtype)
+                out_dtypes.append(torch.float64 if L.agg_input_type(aarr[i]) == L.RFX_F64 else torch.int64)
         if seen == 0:
             r = dict(groups=0, keys=self.empty(0), first=self.empty(0), results=[self.empty(0, d) for d in out_dtypes])
             if multi is not None:
@@ -548,7 +623,7 @@ class Engine:
             vals, _ = self.filter_aggr(aggs, where, table, nrows=n)
             res = {}
             for (name, (fn, col)), v in zip(outs, vals):
-                f64 = fn == "avg" or (col is not None and fn != "count" and table[col].dtype == torch.float64)
+                f64 = fn == "avg" or (col is not None and fn != "count" and self._arg_f64(col, table))
                 if v is None:
                     v = float("nan") if f64 else L.NULL_I64
                 res[name] = torch.tensor([v], dtype=torch.float64 if f64 else torch.int64, device=self.device)

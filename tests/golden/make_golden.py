@@ -155,6 +155,46 @@ def main():
             arrays[f"multikey_{mi}_{o}"] = r[o]
         cases.append({"kind": "multikey", "index": mi, "n": n, "seed": seed, "mods": list(mods), "offs": list(offs)})
 
+    # ---- 4c. element-wise arithmetic: truth tables on special values, then aggregates over expressions ----
+    xi = np.array([0, 1, -1, NULL, 2**63 - 1, 5, -5, 7], np.int64)
+    xj = np.array([3, 0, -2, 4, NULL, -3, 3, -7], np.int64)
+    xf = np.array([0.0, -0.0, np.nan, 1.5, -1.5, np.inf, -np.inf, 2.5], np.float64)
+    xg = np.array([2.0, 0.0, 1.0, np.nan, -0.5, 3.0, -2.0, 0.75], np.float64)
+    arrays.update(x_i=xi, x_j=xj, x_f=xf, x_g=xg)
+    XTAGS = {"ii": "({op} xi xj)", "if": "({op} xi xg)", "fi": "({op} xf xj)", "ff": "({op} xf xg)", "ia": "({op} xi 3)", "ai": "({op} 3 xj)",
+             "iaf": "({op} xi 2.5)", "fa": "({op} xf 2)", "faf": "({op} xf -1.5)", "afi": "({op} 2.5 xj)", "iz": "({op} xi 0)", "fz": "({op} xf 0.0)"}
+    XOPS = ["+", "-", "*", "div"]
+    with ref.Session() as s:
+        for nm, a in (("xi", xi), ("xj", xj), ("xf", xf), ("xg", xg)):
+            s.put(nm, a)
+        for oi, op in enumerate(XOPS):
+            for tag, e in XTAGS.items():
+                s.out(f"binop_{oi}_{tag}", e.format(op=op))
+        r = s.run(threads=8)
+    for k, v in r.items():
+        if k.startswith("binop_"):
+            arrays[k] = v
+    cases.append({"kind": "binop", "ops": XOPS, "tags": list(XTAGS)})
+    XQ = {"s1": "(sum (* a v))", "s2": "(sum (* a b))", "s3": "(sum (+ v w))", "av": "(avg (- a b))", "mx": "(max (* v w))", "mn": "(min (- 100 a))",
+          "s4": "(sum (div a b))", "s5": "(sum (* v 2.0))", "mn2": "(min (* w b))"}
+    for xi_, (n, seed, keys) in enumerate([(32_769, 41, 50), (70_003, 42, 3000)]):
+        t = gen_table(n, seed, keys, True)
+        t["b"] = rfo.gen_i64(n, seed + 7, 9) - 1
+        t["b"][rfo.gen_i64(n, seed + 8, 40) == 0] = NULL
+        for wi, w in enumerate([None, ("<", "b", 5)]):
+            for bi, by in enumerate(["", " by: k"]):
+                with ref.Session() as s:
+                    s.table("t", t)
+                    wtxt = f" where: {rf_where(w)}" if w else ""
+                    s.eval("(set r (select {" + " ".join(f"{k}: {q}" for k, q in XQ.items()) + f" from: t{wtxt}{by}}}))")
+                    outs = list(XQ) + (["k"] if by else [])
+                    for o in outs:
+                        s.out(o, f"(at r '{o})")
+                    r = s.run(threads=8)
+                for o in outs:
+                    arrays[f"xagg_{xi_}_{wi}_{bi}_{o}"] = r[o]
+        cases.append({"kind": "xagg", "index": xi_, "n": n, "seed": seed, "keys": keys})
+
     # ---- 5. null-semantics known answers (verified against the reference here) ----
     k = np.array([1, 1, 2, 3, 3], np.int64)
     v = np.array([1, NULL, 5, NULL, NULL], np.int64)

@@ -98,6 +98,36 @@ def multikey_cases():
         yield f"m{c['index']}", t, names, {o: arr(f"multikey_{c['index']}_{o}") for o in names + list(MULTIKEY_Q)}
 
 
+XTAGS = {"ii": ("x_i", "x_j"), "if": ("x_i", "x_g"), "fi": ("x_f", "x_j"), "ff": ("x_f", "x_g"), "ia": ("x_i", 3), "ai": (3, "x_j"), "iaf": ("x_i", 2.5),
+         "fa": ("x_f", 2), "faf": ("x_f", -1.5), "afi": (2.5, "x_j"), "iz": ("x_i", 0), "fz": ("x_f", 0.0)}
+XQ = {"s1": ("sum", ("*", "a", "v")), "s2": ("sum", ("*", "a", "b")), "s3": ("sum", ("+", "v", "w")), "av": ("avg", ("-", "a", "b")),
+      "mx": ("max", ("*", "v", "w")), "mn": ("min", ("-", 100, "a")), "s4": ("sum", ("div", "a", "b")), "s5": ("sum", ("*", "v", 2.0)),
+      "mn2": ("min", ("*", "w", "b"))}
+
+
+def binop_cases():
+    """Element-wise + - * div truth tables on special values: yields (op, tag, lhs, rhs, reference result)."""
+    c = [c for c in _meta["cases"] if c["kind"] == "binop"][0]
+    for oi, op in enumerate(c["ops"]):
+        for tag in c["tags"]:
+            l, r = XTAGS[tag]
+            yield op, tag, (arr(l) if isinstance(l, str) else l), (arr(r) if isinstance(r, str) else r), arr(f"binop_{oi}_{tag}")
+
+
+def xagg_cases():
+    """Aggregates over expressions, scalar and grouped, with and without where:.  Yields (id, table, where, by, wanted)."""
+    for c in _meta["cases"]:
+        if c["kind"] != "xagg":
+            continue
+        t = gen_table(c["n"], c["seed"], c["keys"], True)
+        t["b"] = rfo.gen_i64(c["n"], c["seed"] + 7, 9) - 1
+        t["b"][rfo.gen_i64(c["n"], c["seed"] + 8, 40) == 0] = NULL
+        for wi, w in enumerate([None, ("<", "b", 5)]):
+            for bi, by in enumerate([None, "k"]):
+                names = list(XQ) + (["k"] if by else [])
+                yield f"x{c['index']}w{wi}b{bi}", t, w, by, {o: arr(f"xagg_{c['index']}_{wi}_{bi}_{o}") for o in names}
+
+
 def nullsem_case():
     t = {"k": arr("nullsem_k"), "v": arr("nullsem_v"), "f": arr("nullsem_f")}
     want = {o: arr(f"nullsem_out_{o}") for o in ["k", "s", "fs", "mn", "mx", "fmn", "fmx", "c", "av"]}

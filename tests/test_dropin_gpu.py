@@ -22,6 +22,10 @@ QUERIES = [
     ("q6", "{s: (sum v) c: (count a) from: t by: {k1: k1 k2: k2}}", ["k1", "k2", "s", "c"]),
     ("q7", "{m: (max a) f: (first v) from: t by: {x: k2 y: k1 z: k3}}", ["x", "y", "z", "m", "f"]),
     ("q8", "{s: (sum v) from: t where: (< a 500000) by: {g: k}}", ["g", "s"]),
+    # aggregates over element-wise expressions (TPC-H Q6 / Q1 shapes), scalar and grouped
+    ("q9", "{rev: (sum (* v a)) m: (max (- 100 a)) av: (avg (div a k2)) from: t where: (and (< a 500000) (> v 0.05))}", ["rev", "m", "av"]),
+    ("q10", "{s: (sum (* v 2.0)) d: (sum (- a k3)) mn: (min (* v a)) from: t by: k1}", ["k1", "s", "d", "mn"]),
+    ("q11", "{s: (sum (+ v a)) from: t where: (> v 0.5) by: k}", ["k", "s"]),
 ]
 
 

@@ -1,6 +1,6 @@
 """Randomised (fixed-seed) select / where / by shapes against the CPU oracle: sizes around every tile / chunk / threshold
 boundary, key counts that land on each group-by path (64 KB LDS tables, 160 KB LDS tables, partitioned, compaction-first,
-device atomics, hashed), 0-3 predicates of any selectivity, 1-5 aggregates, nulls / NaNs, one or two key columns."""
+device atomics, hashed), 0-3 predicates of any selectivity, 1-5 aggregates (some over element-wise expressions), nulls / NaNs, one or two key columns."""
 import numpy as np
 import pytest
 
@@ -48,7 +48,12 @@ def make_case(rng):
     q = {}
     for i in range(int(rng.integers(1, 6))):
         fn = str(rng.choice(FNS))
-        q[f"o{i}"] = (fn, str(rng.choice(["a", "v", "w"])))
+        arg = str(rng.choice(["a", "v", "w"]))
+        if fn not in ("count", "first") and rng.random() < 0.3:  # element-wise expression as the aggregate's argument
+            other = [str(rng.choice(["a", "v", "w", "j"])), int(rng.integers(-3, 4)), float(rng.choice([0.5, -2.0, 0.0]))][int(rng.integers(0, 3))]
+            ops = (arg, other) if rng.random() < 0.7 else (other, arg)
+            arg = (str(rng.choice(["+", "-", "*", "div"])), *ops)
+        q[f"o{i}"] = (fn, arg)
     if where is not None:
         q["where"] = where
     mode = rng.random()

@@ -53,6 +53,20 @@ def test_group_by_several_keys(eng, case):
         G.same(got[o].cpu().numpy(), want[o], o)
 
 
+@pytest.mark.parametrize("case", list(G.xagg_cases()), ids=lambda c: c[0])
+def test_aggregates_over_expressions(eng, case):
+    """(sum (* a v)) & co: folded on the fly in the scalar and LDS-table kernels, materialised for the partitioned path."""
+    _, t, w, by, want = case
+    q = {"from": {k: eng.column(v) for k, v in t.items()}, **G.XQ}
+    if w:
+        q["where"] = w
+    if by:
+        q["by"] = by
+    got = eng.select(q)
+    for o in want:
+        G.same(got[o].cpu().numpy(), want[o], o)
+
+
 def test_group_by_sparse_keys(eng):
     t, want = G.sparse_case()
     got = eng.select({"from": dev(eng, t), "by": "k", "sf": ("sum", "v"), "c": ("count", "a"), "mxi": ("max", "a")})

@@ -377,3 +377,59 @@ def test_sharded_several_keys_single_rank(eng):
     assert np.array_equal(r["key_columns"][0].cpu().numpy(), w["k1"]) and np.array_equal(r["key_columns"][1].cpu().numpy(), w["k2"])
     assert np.array_equal(r["results"][1].cpu().numpy(), w["c"])
     same_f64(r["results"][0].cpu().numpy(), w["s"])
+
+
+# ---------------------------------------------------------------- element-wise arithmetic feeding aggregates (SURVEY 8f-3)
+def test_expression_special_values(eng):
+    """+ - * div on nulls / NaN / +-inf / -0.0 / zero divisors / wrap-around, every type shape: sum, min and max of the
+    expression over ONE selected row at a time reproduce the element-wise truth table (bit-exact for i64; f64 `div` by an atom
+    may differ by 1 ulp from the reference build, which multiplies by the reciprocal)."""
+    import golden_cases as G
+    for op, tag, l, r, want in G.binop_cases():
+        n = len(want)
+        t = {"row": np.arange(n, dtype=np.int64)}
+        lhs = "l" if isinstance(l, np.ndarray) else l
+        rhs = "r" if isinstance(r, np.ndarray) else r
+        if isinstance(l, np.ndarray):
+            t["l"] = l
+        if isinstance(r, np.ndarray):
+            t["r"] = r
+        d = dev(eng, t)
+        for i in range(n):
+            got = eng.select({"from": d, "where": ("==", "row", i), "mx": ("max", (op, lhs, rhs)), "s": ("sum", (op, lhs, rhs))})
+            w = want[i]
+            if want.dtype == np.float64:
+                g = float(got["mx"][0])
+                if np.isnan(w):
+                    assert np.isnan(g) and float(got["s"][0]) == 0.0, (op, tag, i)
+                else:
+                    assert g == w or abs(g - w) <= 2.3e-16 * abs(w), (op, tag, i, g, w)
+            else:
+                assert int(got["mx"][0]) == int(w), (op, tag, i)
+                assert int(got["s"][0]) == (0 if int(w) == NULL else int(w)), (op, tag, i)
+
+
+@pytest.mark.parametrize("n", [1, 1000, 300_007])
+@pytest.mark.parametrize("keys", [7, 3000, 150_000])
+def test_expression_aggregates(eng, n, keys):
+    host = table(n, keys=keys, nulls=True)
+    host["b"] = rfo.gen_i64(n, 77, 9) - 1
+    q = {"s1": ("sum", ("*", "a", "v")), "s2": ("sum", ("*", "a", "b")), "av": ("avg", ("-", "a", "b")), "mx": ("max", ("*", "v", "w")),
+         "mn": ("min", ("-", 100, "a")), "s4": ("sum", ("div", "a", "b")), "s5": ("sum", ("+", "v", 2))}
+    check_select(eng, host, q)
+    check_select(eng, host, {**q, "where": ("and", ("<", "b", 5), (">", "v", 0.1))})
+    check_select(eng, host, {**q, "where": ("or", ("<", "b", 1), ("and", (">", "v", 0.5), ("!=", "k", 3)))})  # nested tree
+    check_select(eng, host, {**q, "by": "k"})
+    check_select(eng, host, {**q, "by": "k", "where": ("<", "b", 5)})
+    check_select(eng, host, {"plain": ("sum", "v"), "x": ("sum", ("*", "v", "w")), "c": ("count", "a"), "by": "k"})  # mixed plain / expression
+
+
+def test_expression_aggregates_refusals(eng):
+    from rayforce_amd._lib import RfxError
+    d = dev(eng, table(100))
+    with pytest.raises(RfxError, match="count of an expression"):
+        eng.select({"from": d, "c": ("count", ("*", "a", "v"))})
+    with pytest.raises(RfxError, match="first of an expression"):
+        eng.select({"from": d, "f": ("first", ("*", "a", "v")), "by": "k"})
+    with pytest.raises(RfxError, match="unsupported expression"):
+        eng.select({"from": d, "s": ("sum", ("/", "a", "k"))})

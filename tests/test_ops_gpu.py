@@ -102,6 +102,23 @@ def test_select_by_several_keys(ops):
         run_select(ops, host, {**q, "by": {"a1": "k1", "a2": "k2"}})
 
 
+def test_select_expression_aggregates(ops):
+    """(sum (* a v)) & co through the operator ABI: scalar, grouped (LDS tables and partitioned), flat and nested where."""
+    host = host_table(300_007, keys=4000)
+    host["b"] = rfo.gen_i64(300_007, 9, 9) - 1
+    q = {"s1": ("sum", ("*", "a", "v")), "s2": ("sum", ("*", "a", "b")), "av": ("avg", ("-", "a", "b")), "mn": ("min", ("-", 100, "a")),
+         "s4": ("sum", ("div", "a", "b")), "mx": ("max", ("*", "v", 2.5)), "plain": ("sum", "v")}
+    nested = ("and", ("or", ("<", "a", 1000), (">", "v", 0.9)), ("!=", "k", 3))
+    for extra in ({}, {"where": ("<", "b", 5)}, {"where": nested}, {"by": "k"}, {"by": "k", "where": ("<", "b", 5)}, {"by": "k", "where": nested}):
+        check(run_select(ops, host, {**q, **extra}), rfo.select({"from": host, **q, **extra}))
+        assert ops.rfx_last_select_on_gpu() == 1
+    host2 = host_table(300_007, keys=200_000)
+    q2 = {"s": ("sum", ("*", "a", "v")), "m": ("max", ("+", "v", "a"))}
+    check(run_select(ops, host2, {**q2, "by": "k"}), rfo.select({"from": host2, **q2, "by": "k"}))
+    with pytest.raises(RuntimeError, match="not covered by the MI355X path"):
+        run_select(ops, host, {"c": ("count", ("*", "a", "v"))})
+
+
 def test_nested_tree_and_projection(ops):
     host = host_table(200_003)
     nested = ("and", ("or", ("<", "a", 1000), (">", "v", 0.9)), ("!=", "k", 3))

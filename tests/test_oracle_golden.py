@@ -89,6 +89,35 @@ def test_composite_plan_overflow_rules():
         rfo.composite_key(big)
 
 
+def test_binop_truth_tables():
+    """+ - * div over i64 / f64 vectors and atoms incl. nulls, NaN, +-inf, -0.0, zero divisors, wrap-around: bit for bit."""
+    n = 0
+    for op, tag, l, r, want in G.binop_cases():
+        got = rfo.binop(op, l, r)
+        assert got.dtype == want.dtype, (op, tag)
+        if want.dtype == np.float64:
+            assert np.array_equal(np.isnan(got), np.isnan(want)), (op, tag)
+            ok = ~np.isnan(want)
+            assert np.array_equal(got[ok].view(np.uint64), want[ok].view(np.uint64)), (op, tag, got, want)
+        else:
+            assert np.array_equal(got, want), (op, tag, got, want)
+        n += 1
+    assert n == 48
+
+
+@pytest.mark.parametrize("case", list(G.xagg_cases()), ids=lambda c: c[0])
+def test_aggregates_over_expressions(case):
+    _, t, w, by, want = case
+    q = {"from": t, **G.XQ}
+    if w:
+        q["where"] = w
+    if by:
+        q["by"] = by
+    got = rfo.select(q)
+    for o in want:
+        G.same(got[o], want[o], o)
+
+
 def test_null_semantics():
     t, want, scalar_sum = G.nullsem_case()
     got = rfo.select({"from": t, "by": "k", "s": ("sum", "v"), "fs": ("sum", "f"), "mn": ("min", "v"), "mx": ("max", "v"), "fmn": ("min", "f"),
