@@ -68,16 +68,17 @@ __global__ __launch_bounds__(RFX_BLOCK) void k_filter_aggr_final(const Plan P, c
 // Workgroups per CU of the fused reduction, by distinct-column count (in-process sweep, bench.py --ab): the lighter the
 // ALU work per byte, the fewer waves it takes to keep HBM busy -- 1 column: 4, 2 columns: 2, 3+ columns (more predicates /
 // aggregates per row): 6.  blocks_per_cu (rfx_hip_ctx_tune) scales it: 2 = as measured.
-static inline int rfx_scalar_wg_per_cu(int ncols) { return ncols <= 1 ? 4 : (ncols == 2 ? 2 : 6); }
-static inline int rfx_scalar_grid_for(const rfx_ctx *c, int ncols) {
-    int per = rfx_scalar_wg_per_cu(ncols) * (c->blocks_per_cu > 0 ? c->blocks_per_cu : 2) / 2;
+// Expression aggregates add ALU work per row: 16 (x6, 3 columns: 4.91 ms at 6, 4.34 at 12, 4.17 at 24).
+static inline int rfx_scalar_wg_per_cu(int ncols, int nx) { return nx > 0 ? 16 : (ncols <= 1 ? 4 : (ncols == 2 ? 2 : 6)); }
+static inline int rfx_scalar_grid_for(const rfx_ctx *c, int ncols, int nx) {
+    int per = rfx_scalar_wg_per_cu(ncols, nx) * (c->blocks_per_cu > 0 ? c->blocks_per_cu : 2) / 2;
     return c->num_cus * (per < 1 ? 1 : per);
 }
-static inline int rfx_scalar_grid(const rfx_ctx *c) { return c->num_cus * 6 * ((c->blocks_per_cu > 2 ? c->blocks_per_cu : 2) / 2); } // upper bound, for workspace sizing
+static inline int rfx_scalar_grid(const rfx_ctx *c) { return c->num_cus * 16 * ((c->blocks_per_cu > 2 ? c->blocks_per_cu : 2) / 2); } // upper bound, for workspace sizing
 
 int rfx_run_filter_aggr(rfx_ctx *c, Plan &P, rfx_partial_t *d_out) {
     // a plan with no columns at all (COUNT without predicate): give it a harmless column-free path
-    int grid = rfx_scalar_grid_for(c, P.ncols);
+    int grid = rfx_scalar_grid_for(c, P.ncols, P.nx);
     const i64 tiles = P.nrows / (RFX_BLOCK * 4) + 1;
     if (tiles < grid) grid = (int)tiles;
     int rc = rfx_ws_reserve(c, (size_t)grid * 9 * sizeof(Acc));

@@ -22,7 +22,8 @@ int RFX_CAT(rfx_launch_filter_aggr_nc, RFX_NC)(rfx_ctx *c, const Plan &P, int gr
 #if RFX_NC <= 4
         if (P.npred <= 4 && P.nagg <= 4) {
             *na_stride = 5;
-            launch_shape<RFX_NC, 4, 4, RFX_MAX_EXPRS>(c, P, grid, ws);
+            if (P.nx == 1) launch_shape<RFX_NC, 4, 4, 1>(c, P, grid, ws); // the common one-expression query (TPC-H Q6 shape)
+            else launch_shape<RFX_NC, 4, 4, RFX_MAX_EXPRS>(c, P, grid, ws);
             return RFX_OK;
         }
 #endif

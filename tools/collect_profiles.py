@@ -15,7 +15,7 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
 dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
-DOMINANT = {"c2": ["k_filter_aggr<"], "c2b": ["k_filter_aggr<"], "c5": ["k_filter_aggr<"],
+DOMINANT = {"c2": ["k_filter_aggr<"], "c2b": ["k_filter_aggr<"], "c5": ["k_filter_aggr<"], "x6": ["k_filter_aggr<"],
             "c3": ["k_part_scope_hist", "k_part_hist", "k_part_scatter", "k_part_aggregate", "k_part_colscan", "k_mark_first", "k_group_emit", "k_slot_gid",
                    "k_bitmap_counts", "k_fill_u64"],
             "c3w": ["k_part_scope_hist", "k_chunk_counts", "k_compact_cols", "k_part_hist", "k_part_scatter", "k_part_aggregate", "k_part_colscan", "k_first_translate",
