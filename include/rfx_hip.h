@@ -164,6 +164,15 @@ int rfx_hip_h2d(rfx_ctx_t *ctx, void *d_dst, const void *src, size_t bytes); /* 
 int rfx_hip_d2h(rfx_ctx_t *ctx, void *dst, const void *d_src, size_t bytes); /* (syncs) */
 int rfx_hip_memset(rfx_ctx_t *ctx, void *d_dst, int byte, size_t bytes);
 
+/* Host-to-device at link speed from ANY host memory (heap vector, mmapped column file): chunks are staged through pinned
+ * buffers by worker threads while the previous chunk is in flight.  (syncs) */
+int rfx_hip_h2d_pipelined(rfx_ctx_t *ctx, void *d_dst, const void *src, size_t bytes);
+/* RayforceDB column files (16-byte header {mmod 0xfd, order, type, attrs, rc, len} + raw payload, core/binary.c:263-311):
+ * rfx_column_file_stat reads type (the reference's vector type code) and length -- host only, no device needed;
+ * rfx_hip_column_file_load maps the file and moves its nrows 8-byte elements into d_dst with the pipelined path.  (syncs) */
+int rfx_column_file_stat(const char *path, int32_t *type, int64_t *len);
+int rfx_hip_column_file_load(rfx_ctx_t *ctx, const char *path, void *d_dst, int64_t nrows);
+
 /* ---- timing on the context's stream (bench.py measures kernels with these HIP events) ---- */
 int rfx_hip_timer_start(rfx_ctx_t *ctx);
 int rfx_hip_timer_stop(rfx_ctx_t *ctx, float *ms); /* (syncs) */

@@ -68,6 +68,8 @@ struct rfx_ctx {
     size_t part_bytes;
     void *d_comp;       // materialised composite key column of a multi-key group-by (grow-only)
     size_t comp_bytes;
+    void *io_stage[4];  // pinned staging buffers of the pipelined host-to-device path (rfx_io.hip), created on first use
+    hipEvent_t io_done[4];
     void *d_expr;       // materialised expression columns (grow-only)
     size_t expr_bytes;
     void *d_sel;        // compacted (key, values, row ids) of a selectively filtered partitioned group-by (grow-only)
@@ -88,6 +90,7 @@ int rfx_gid_reserve(rfx_ctx *ctx, i64 slots);
 int rfx_part_reserve(rfx_ctx *ctx, size_t bytes);
 int rfx_comp_reserve(rfx_ctx *ctx, size_t bytes);
 int rfx_expr_reserve(rfx_ctx *ctx, size_t bytes);
+void rfx_io_release(rfx_ctx *ctx);
 int rfx_sel_reserve(rfx_ctx *ctx, size_t bytes);
 int rfx_plan_add_col(struct Plan *P, const void *col); // index of `col` in P->cols (added if new), -1 when full
 #define RFX_KERNEL_BEGIN(c) do { if ((c)->profile) { (void)hipEventRecord((c)->evk0, (c)->stream); } } while (0)

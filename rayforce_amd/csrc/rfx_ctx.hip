@@ -68,6 +68,7 @@ extern "C" int rfx_hip_ctx_destroy(rfx_ctx_t *c) {
     if (c->d_comp) (void)hipFree(c->d_comp);
     if (c->d_sel) (void)hipFree(c->d_sel);
     if (c->d_expr) (void)hipFree(c->d_expr);
+    rfx_io_release(c);
     if (c->d_pc_counts) (void)hipFree(c->d_pc_counts);
     if (c->h_pin) (void)hipHostFree(c->h_pin);
     (void)hipEventDestroy(c->ev0);

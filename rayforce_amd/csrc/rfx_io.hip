@@ -1,0 +1,171 @@
+// rfx_io.hip -- getting host / on-disk columns into HBM fast: the caller side of the hot path.
+//
+// Reference: a column file is a 16-byte header {mmod = 0xfd, order, type, attrs, rc, len:i64} followed by the raw
+// little-endian payload (core/binary.c:263-311 writes it, core/unary.c:48-136 mmaps it); a splayed table is a directory of
+// such files plus `.d`, the serialised symbol vector of the column names (core/io.c:1194-1364).  The reference never copies:
+// `get` maps the file and the evaluator reads the mapping.  A GPU has to move the bytes once; what matters is that this one
+// move runs at PCIe speed rather than at the speed of a pageable memcpy:
+//
+//   rfx_hip_h2d_pipelined   source = ANY host memory (heap vector, mmapped file).  The range is cut into chunks; worker
+//                           threads copy chunk i+1 into one of four pinned staging buffers (touching mmapped pages, i.e. doing
+//                           the file I/O) while the DMA engine moves chunk i from another -- staging copy and transfer overlap,
+//                           and the DMA only ever sees pinned memory.
+//   rfx_hip_column_file_load  mmap + the above.  rfx_column_file_stat reads the header only (no device needed).
+//
+// rfx_ops.c's residency cache uploads through rfx_hip_h2d_pipelined, so a reference process that `get`s a 1e9-row column
+// pays the transfer once at link speed and keeps the column in HBM afterwards.
+#include <fcntl.h>
+#include <pthread.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+#include "rfx_common.hpp"
+
+#define IO_CHUNK ((size_t)32 << 20) /* staging buffer size */
+#define IO_NBUF 4
+#define IO_THREADS 16 /* staging-copy threads: first-touch faults on an mmapped file are what they parallelise */
+
+struct CopyJob {
+    char *dst;
+    const char *src;
+    size_t bytes;
+};
+static void *copy_worker(void *p) {
+    CopyJob *j = (CopyJob *)p;
+    memcpy(j->dst, j->src, j->bytes);
+    return NULL;
+}
+// memcpy split over IO_THREADS threads (the staging copy is what touches the source pages)
+static void parallel_copy(char *dst, const char *src, size_t bytes) {
+    if (bytes < ((size_t)4 << 20)) {
+        memcpy(dst, src, bytes);
+        return;
+    }
+    pthread_t th[IO_THREADS];
+    bool started[IO_THREADS];
+    CopyJob job[IO_THREADS];
+    const size_t per = (((bytes + IO_THREADS - 1) / IO_THREADS) + 4095) & ~(size_t)4095;
+    int n = 0;
+    for (size_t off = 0; off < bytes; off += per, n++) {
+        job[n].dst = dst + off;
+        job[n].src = src + off;
+        job[n].bytes = (bytes - off < per) ? bytes - off : per;
+        started[n] = pthread_create(&th[n], NULL, copy_worker, &job[n]) == 0;
+        if (!started[n]) memcpy(job[n].dst, job[n].src, job[n].bytes); // no thread to be had: copy here
+    }
+    for (int i = 0; i < n; i++)
+        if (started[i]) pthread_join(th[i], NULL);
+}
+
+extern "C" int rfx_hip_h2d_pipelined(rfx_ctx_t *c, void *d_dst, const void *src, size_t bytes) {
+    RFX_REQUIRE(c, RFX_EINVAL, "ctx is NULL");
+    if (!bytes) return RFX_OK;
+    RFX_REQUIRE(d_dst && src, RFX_EINVAL, "NULL argument");
+    if (bytes < IO_CHUNK) return rfx_hip_h2d(c, d_dst, src, bytes);
+    if (!c->io_stage[0]) {
+        for (int i = 0; i < IO_NBUF; i++) {
+            RFX_HIP_CHECK(hipHostMalloc(&c->io_stage[i], IO_CHUNK, hipHostMallocDefault));
+            RFX_HIP_CHECK(hipEventCreateWithFlags(&c->io_done[i], hipEventDisableTiming));
+        }
+    }
+    size_t off = 0;
+    int k = 0;
+    bool used[IO_NBUF] = {false, false, false, false};
+    while (off < bytes) {
+        const size_t n = (bytes - off < IO_CHUNK) ? bytes - off : IO_CHUNK;
+        const int b = k % IO_NBUF;
+        if (used[b]) RFX_HIP_CHECK(hipEventSynchronize(c->io_done[b])); // its previous transfer has left the buffer
+        parallel_copy((char *)c->io_stage[b], (const char *)src + off, n);
+        RFX_HIP_CHECK(hipMemcpyAsync((char *)d_dst + off, c->io_stage[b], n, hipMemcpyHostToDevice, c->stream));
+        RFX_HIP_CHECK(hipEventRecord(c->io_done[b], c->stream));
+        used[b] = true;
+        off += n;
+        k++;
+    }
+    RFX_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return RFX_OK;
+}
+
+void rfx_io_release(rfx_ctx *c) {
+    for (int i = 0; i < IO_NBUF; i++) {
+        if (c->io_stage[i]) {
+            (void)hipHostFree(c->io_stage[i]);
+            (void)hipEventDestroy(c->io_done[i]);
+            c->io_stage[i] = NULL;
+        }
+    }
+}
+
+// ---- column files (core/binary.c:263-311) ----
+struct ColHeader {
+    uint8_t mmod, order;
+    int8_t type;
+    uint8_t attrs;
+    uint32_t rc;
+    int64_t len;
+};
+static_assert(sizeof(ColHeader) == 16, "column file header");
+
+static int elem_size(int type) {
+    switch (type) {
+        case 5:  /* I64 */
+        case 6:  /* SYMBOL (ids) */
+        case 9:  /* TIMESTAMP */
+        case 10: /* F64 */
+            return 8;
+        default: return 0;
+    }
+}
+
+extern "C" int rfx_column_file_stat(const char *path, int32_t *type, int64_t *len) {
+    RFX_REQUIRE(path && type && len, RFX_EINVAL, "NULL argument");
+    int fd = open(path, O_RDONLY);
+    if (fd < 0) {
+        rfx_set_error("rfx_column_file_stat: cannot open %s", path);
+        return RFX_EINVAL;
+    }
+    ColHeader h;
+    struct stat st;
+    const bool ok = read(fd, &h, sizeof(h)) == (ssize_t)sizeof(h) && fstat(fd, &st) == 0;
+    close(fd);
+    if (!ok || h.mmod != 0xfd) {
+        rfx_set_error("rfx_column_file_stat: %s is not a RayforceDB column file (16-byte header with mmod 0xfd expected)", path);
+        return RFX_EINVAL;
+    }
+    const int es = elem_size(h.type);
+    if (!es) {
+        rfx_set_error("rfx_column_file_stat: %s holds type %d; only 8-byte columns (i64 / symbol ids / timestamp / f64) are on this path", path, (int)h.type);
+        return RFX_EINVAL;
+    }
+    if (h.len < 0 || (int64_t)st.st_size < 16 + h.len * es) {
+        rfx_set_error("rfx_column_file_stat: %s is truncated (%lld rows declared)", path, (long long)h.len);
+        return RFX_EINVAL;
+    }
+    *type = h.type;
+    *len = h.len;
+    return RFX_OK;
+}
+
+extern "C" int rfx_hip_column_file_load(rfx_ctx_t *c, const char *path, void *d_dst, int64_t nrows) {
+    RFX_REQUIRE(c && path, RFX_EINVAL, "NULL argument");
+    int32_t type;
+    int64_t len;
+    int rc = rfx_column_file_stat(path, &type, &len);
+    if (rc != RFX_OK) return rc;
+    RFX_REQUIRE(nrows == len, RFX_EINVAL, "nrows does not match the file's length");
+    if (len == 0) return RFX_OK;
+    RFX_REQUIRE(d_dst != NULL, RFX_EINVAL, "d_dst is NULL");
+    int fd = open(path, O_RDONLY);
+    RFX_REQUIRE(fd >= 0, RFX_EINVAL, "cannot open the column file");
+    const size_t bytes = 16 + (size_t)len * 8;
+    void *m = mmap(NULL, bytes, PROT_READ, MAP_PRIVATE, fd, 0);
+    close(fd);
+    if (m == MAP_FAILED) {
+        rfx_set_error("rfx_hip_column_file_load: mmap of %s failed", path);
+        return RFX_EINVAL;
+    }
+    (void)madvise(m, bytes, MADV_SEQUENTIAL);
+    rc = rfx_hip_h2d_pipelined(c, d_dst, (const char *)m + 16, (size_t)len * 8);
+    munmap(m, bytes);
+    return rc;
+}

@@ -232,7 +232,7 @@ static int resident(obj_p col, int pin, const void **dev) {
     void *d = NULL;
     int rc = rfx_hip_malloc(g_ctx, &d, bytes ? bytes : 8);
     if (rc != RFX_OK) return rc;
-    rc = rfx_hip_h2d(g_ctx, d, host, bytes);
+    rc = rfx_hip_h2d_pipelined(g_ctx, d, host, bytes); /* heap vector or mmapped column file alike: staged through pinned buffers */
     if (rc != RFX_OK) { rfx_hip_free(g_ctx, d); return rc; }
     if (g_nres == g_capres) {
         g_capres = g_capres ? g_capres * 2 : 32;

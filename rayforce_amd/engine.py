@@ -95,6 +95,41 @@ class Engine:
             t = t.to(torch.int8)
         return t.contiguous().to(self.device)
 
+    # ------------------------------------------------------------------ on-disk columns
+    _FILE_DTYPES = {5: torch.int64, 6: torch.int64, 9: torch.int64, 10: torch.float64}  # i64, symbol ids, timestamp, f64
+
+    def load_column(self, path: str) -> torch.Tensor:
+        """A RayforceDB column file (core/binary.c:263-311) -> device column, moved with the pipelined pinned-staging path."""
+        t, n = C.c_int32(), C.c_int64()
+        L.check(self.lib.rfx_column_file_stat(path.encode(), C.byref(t), C.byref(n)), "column_file_stat")
+        out = torch.empty(n.value, dtype=self._FILE_DTYPES[t.value], device=self.device)
+        L.check(self.lib.rfx_hip_column_file_load(self._ctx, path.encode(), out.data_ptr(), n.value), "column_file_load")
+        return out
+
+    def load_splayed(self, directory: str, columns: Optional[Sequence[str]] = None) -> Dict[str, torch.Tensor]:
+        """A splayed table (core/io.c:1194-1364): `<dir>/.d` is the serialised symbol vector of the column names, every
+        column is its own file.  Loads the 8-byte columns (all, or the ones asked for) into HBM."""
+        import os
+        raw = open(os.path.join(directory, ".d"), "rb").read()
+        # serialised object: 16-byte IPC header (magic fa de fa ce, version, payload size), then type, attrs, len:i64, strings
+        if len(raw) < 26 or raw[:4] != bytes.fromhex("fadeface") or raw[16] != 6:
+            raise RfxError(f"{directory}/.d is not a serialised symbol vector")
+        cnt = int.from_bytes(raw[18:26], "little")
+        names = [b.decode() for b in raw[26:].split(b"\0")[:cnt]]
+        want = list(columns) if columns is not None else names
+        missing = [c for c in want if c not in names]
+        if missing:
+            raise RfxError(f"no such column(s) in {directory}: {missing}")
+        return {c: self.load_column(os.path.join(directory, c)) for c in want}
+
+    def upload(self, host_array) -> torch.Tensor:
+        """Host numpy array (i64 / f64) -> device column through the pipelined path (what rfx_ops.c's residency cache uses)."""
+        import numpy as np
+        a = np.ascontiguousarray(host_array)
+        out = torch.empty(a.shape[0], dtype=torch.float64 if a.dtype == np.float64 else torch.int64, device=self.device)
+        L.check(self.lib.rfx_hip_h2d_pipelined(self._ctx, out.data_ptr(), a.ctypes.data, a.nbytes), "h2d_pipelined")
+        return out
+
     def gen_i64(self, n: int, seed: int, modulus: int, row0: int = 0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         out = self.empty(n, torch.int64) if out is None else out
         L.check(self.lib.rfx_hip_gen_i64(self._ctx, out.data_ptr(), n, seed, row0, modulus), "gen_i64")

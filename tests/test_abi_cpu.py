@@ -121,3 +121,17 @@ def test_partial_algebra_on_host(built):
     q.ext, q.cnt = bits(-2.5), 1
     lib.rfx_partial_merge(L.RFX_AGG_MIN, L.RFX_F64, C.byref(p), C.byref(q))
     assert p.ext == bits(-2.5)
+
+
+def test_column_file_header_is_read_without_a_device(built, tmp_path):
+    """rfx_column_file_stat is host-only: the 16-byte header of core/binary.c:263-311."""
+    from oracle import ref
+    from rayforce_amd import _lib as L
+    lib = L.load_library()
+    p = str(tmp_path / "col")
+    ref.write_col(p, np.arange(12345, dtype=np.float64))
+    t, n = C.c_int32(), C.c_int64()
+    assert lib.rfx_column_file_stat(p.encode(), C.byref(t), C.byref(n)) == 0 and t.value == 10 and n.value == 12345
+    (tmp_path / "junk").write_bytes(b"x" * 40)
+    assert lib.rfx_column_file_stat(str(tmp_path / "junk").encode(), C.byref(t), C.byref(n)) == -2
+    assert b"not a RayforceDB column file" in lib.rfx_hip_last_error()
