@@ -49,39 +49,40 @@ __device__ __forceinline__ void sel_chunk_load(const Plan &P, i64 q, int lane, u
     }
 }
 template <int NC, int NP>
-__device__ __forceinline__ void sel_chunk_store(const PredSet<NP> &S, i64 q, int lane, const u64 (&v)[NC][8], const bool (&valid)[8],
-                                                u64 *__restrict__ bitmap, i64 *__restrict__ chunk_cnt) {
+__device__ __forceinline__ u64 sel_chunk_words(const PredSet<NP> &S, int lane, int lane_off, const u64 (&v)[NC][8], const bool (&valid)[8], u64 mine) {
     bool sel[8];
     eval_sel<NC, 8, NP>(S, v, valid, sel);
-    u64 mine = 0;
-    int cnt = 0;
 #pragma unroll
     for (int e = 0; e < 8; e++) {
         const u64 b = __ballot(sel[e]); // the compare's lane mask itself
-        cnt += __popcll(b);
-        mine = (lane == e) ? b : mine;
+        mine = (lane == e + lane_off) ? b : mine;
     }
-    if (lane < 8) bitmap[q * 8 + lane] = mine;
-    if (lane == 0) chunk_cnt[q] = cnt;
+    return mine;
 }
 
+// A wave step = TWO ADJACENT 512-row chunks: 8 x 16-byte loads per lane per column in flight, and the 16 bitmap words of
+// the pair leave as ONE aligned 128-byte store (lanes 0..15).  Writing the chunks' 64 bytes separately, plus an 8-byte
+// count each, meant two partial cache lines per chunk (read-modify-write at the memory side): 1.5 ms for the 8 GB pass
+// against 1.2 ms for the same read in K1.  The per-chunk counts come from k_chunk_counts over the bitmap afterwards.
 template <int NC, int NP>
 __global__ __launch_bounds__(RFX_BLOCK) void k_sel_bitmap(const Plan P, u64 *__restrict__ bitmap, i64 *__restrict__ chunk_cnt) {
+    (void)chunk_cnt;
     PredSet<NP> S;
     predset_load<NP>(P, S);
     const int lane = threadIdx.x & 63;
     const i64 wave_id = (i64)blockIdx.x * (RFX_BLOCK / RFX_WAVE) + (threadIdx.x >> 6);
     const i64 nwaves = (i64)gridDim.x * (RFX_BLOCK / RFX_WAVE);
     const i64 nchunks = (P.nrows + RFX_CHUNK - 1) / RFX_CHUNK;
-    // two 512-row chunks per wave step: 8 x 16-byte loads per lane per column in flight
-    for (i64 q = wave_id; q < nchunks; q += 2 * nwaves) {
-        const i64 q2 = q + nwaves;
+    const i64 npairs = (nchunks + 1) / 2;
+    for (i64 p = wave_id; p < npairs; p += nwaves) {
+        const i64 q = 2 * p, q2 = q + 1;
         u64 v0[NC][8], v1[NC][8];
         bool ok0[8], ok1[8];
         sel_chunk_load<NC, NP>(P, q, lane, v0, ok0);
         if (q2 < nchunks) sel_chunk_load<NC, NP>(P, q2, lane, v1, ok1);
-        sel_chunk_store<NC, NP>(S, q, lane, v0, ok0, bitmap, chunk_cnt);
-        if (q2 < nchunks) sel_chunk_store<NC, NP>(S, q2, lane, v1, ok1, bitmap, chunk_cnt);
+        u64 mine = sel_chunk_words<NC, NP>(S, lane, 0, v0, ok0, 0ULL);
+        if (q2 < nchunks) mine = sel_chunk_words<NC, NP>(S, lane, 8, v1, ok1, mine);
+        if (lane < 16) bitmap[q * 8 + lane] = mine; // the bitmap is sized in whole pairs; an absent second chunk stores zeros
     }
 }
 
@@ -232,6 +233,52 @@ __global__ __launch_bounds__(RFX_BLOCK) void k_emit_ids(const u64 *__restrict__ 
     }
 }
 
+// Write-combining form of pass B.  k_emit_ids stores each 128-row group's ids as two masked store instructions of ~6 active
+// lanes at 10 % selectivity: every store is a partial cache line (0.81 ms for 0.8 GB of ids).  Here a wave owns a CONTIGUOUS
+// range of chunks, so its output is one contiguous run: ids go through a 256-entry wave-private LDS ring and leave as whole,
+// 512-byte-aligned 64-id stores (the first flush is short to reach alignment, the last one drains the ring).  Wave-private:
+// no workgroup barrier, waves may run out of chunks independently.
+#define EMIT_RING 256
+__global__ __launch_bounds__(RFX_BLOCK) void k_emit_ids_wc(const u64 *__restrict__ bitmap, const i64 *__restrict__ chunk_off, i64 nrows, i64 row0,
+                                                         i64 *__restrict__ out) {
+    __shared__ i64 ring[RFX_BLOCK / RFX_WAVE][EMIT_RING];
+    const int lane = threadIdx.x & 63;
+    i64 *R = ring[threadIdx.x >> 6];
+    const i64 wave_id = (i64)blockIdx.x * (RFX_BLOCK / RFX_WAVE) + (threadIdx.x >> 6);
+    const i64 nwaves = (i64)gridDim.x * (RFX_BLOCK / RFX_WAVE);
+    const i64 nchunks = (nrows + RFX_CHUNK - 1) / RFX_CHUNK;
+    const i64 per = (nchunks + nwaves - 1) / nwaves;
+    const i64 q0 = wave_id * per, q1 = (q0 + per < nchunks) ? q0 + per : nchunks;
+    if (q0 >= q1) return;
+    const u64 below = lanemask_lt();
+    i64 gpos = chunk_off[q0]; // global output index of the ring's head
+    unsigned head = 0, fill = 0;
+    for (i64 q = q0; q < q1; q++) {
+        const u64 *w = bitmap + q * 8;
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            const u64 w0 = w[2 * g], w1 = w[2 * g + 1];
+            if ((w0 | w1) == 0) continue;
+            const unsigned s0 = (unsigned)(w0 >> lane) & 1u, s1 = (unsigned)(w1 >> lane) & 1u;
+            const unsigned r = head + fill + (unsigned)(__popcll(w0 & below) + __popcll(w1 & below));
+            const i64 row = row0 + q * RFX_CHUNK + g * 128 + lane * 2;
+            if (s0) R[r & (EMIT_RING - 1)] = row;
+            if (s1) R[(r + s0) & (EMIT_RING - 1)] = row + 1;
+            fill += (unsigned)(__popcll(w0) + __popcll(w1));
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the wave's ring writes have landed before other lanes read them
+            while (fill >= 64) {
+                const unsigned k = 64 - (unsigned)(gpos & 63); // short first flush, then whole aligned 64-id lines
+                if ((unsigned)lane < k) out[gpos + lane] = R[(head + lane) & (EMIT_RING - 1)];
+                gpos += k;
+                head += k;
+                fill -= k;
+            }
+            asm volatile("" ::: "memory");
+        }
+    }
+    if ((unsigned)lane < fill) out[gpos + lane] = R[(head + lane) & (EMIT_RING - 1)];
+}
+
 template <int NC>
 static void launch_sel_bitmap(rfx_ctx *c, const Plan &P, int grid) {
     if (P.npred <= 1) hipLaunchKernelGGL((k_sel_bitmap<NC, 1>), dim3(grid), dim3(RFX_BLOCK), 0, c->stream, P, c->d_bitmap, c->d_blksum);
@@ -272,8 +319,25 @@ static void where_launch_bitmap(rfx_ctx *c, const Plan &P) {
     }
 }
 
-static int where_scan_total(rfx_ctx *c, i64 nrows, i64 *count) {
+// per-chunk popcounts of the selection bitmap (full-line stores; the bitmap pass itself writes no counts)
+__global__ __launch_bounds__(RFX_BLOCK) void k_chunk_counts(const u64 *__restrict__ bitmap, i64 nchunks, i64 *__restrict__ cnt) {
+    for (i64 q = blockIdx.x * (i64)RFX_BLOCK + threadIdx.x; q < nchunks; q += (i64)gridDim.x * RFX_BLOCK) {
+        const u64 *w = bitmap + q * 8;
+        int s = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) s += __popcll(w[i]);
+        cnt[q] = s;
+    }
+}
+static int where_scan_total(rfx_ctx *c, i64 nrows, i64 *count, bool counts_from_bitmap) {
     const i64 nchunks = (nrows + RFX_CHUNK - 1) / RFX_CHUNK;
+    if (counts_from_bitmap) {
+        i64 cb = (nchunks + RFX_BLOCK - 1) / RFX_BLOCK;
+        int grid = rfx_grid(c) * 4;
+        if (cb < grid) grid = (int)cb;
+        hipLaunchKernelGGL(k_chunk_counts, dim3(grid), dim3(RFX_BLOCK), 0, c->stream, (const u64 *)c->d_bitmap, nchunks, c->d_blksum);
+        RFX_HIP_CHECK(hipGetLastError());
+    }
     i64 *d_total = c->d_blksum + nchunks;
     int rc = rfx_scan_counts(c, c->d_blksum, nchunks, d_total);
     if (rc != RFX_OK) return rc;
@@ -309,30 +373,15 @@ int rfx_where_bitmap_of_plan(rfx_ctx *c, const Plan &Pfull, i64 *count) {
     Ph.nagg = 0;
     where_launch_bitmap(c, Ph);
     RFX_HIP_CHECK(hipGetLastError());
-    return where_scan_total(c, Pfull.nrows, count);
+    return where_scan_total(c, Pfull.nrows, count, true);
 }
 
 // Internal: a selection bitmap is already in the context (written by the fused scope pass): per-chunk counts + scan.  (syncs)
-__global__ __launch_bounds__(RFX_BLOCK) void k_chunk_counts(const u64 *__restrict__ bitmap, i64 nchunks, i64 *__restrict__ cnt) {
-    for (i64 q = blockIdx.x * (i64)RFX_BLOCK + threadIdx.x; q < nchunks; q += (i64)gridDim.x * RFX_BLOCK) {
-        const u64 *w = bitmap + q * 8;
-        int s = 0;
-#pragma unroll
-        for (int i = 0; i < 8; i++) s += __popcll(w[i]);
-        cnt[q] = s;
-    }
-}
 int rfx_where_counts_of_bitmap(rfx_ctx *c, i64 nrows, i64 *count) {
     c->where_n = -1;
     int rc = where_reserve(c, nrows);
     if (rc != RFX_OK) return rc;
-    const i64 nchunks = (nrows + RFX_CHUNK - 1) / RFX_CHUNK;
-    i64 cb = (nchunks + RFX_BLOCK - 1) / RFX_BLOCK;
-    int grid = rfx_grid(c) * 4;
-    if (cb < grid) grid = (int)cb;
-    hipLaunchKernelGGL(k_chunk_counts, dim3(grid), dim3(RFX_BLOCK), 0, c->stream, (const u64 *)c->d_bitmap, nchunks, c->d_blksum);
-    RFX_HIP_CHECK(hipGetLastError());
-    return where_scan_total(c, nrows, count);
+    return where_scan_total(c, nrows, count, true);
 }
 
 // Ordered compaction of whole columns by the context's bitmap: dst[c][r] = src[c][row] for the r-th selected row, and
@@ -437,7 +486,7 @@ extern "C" int rfx_hip_where_begin(rfx_ctx_t *c, const rfx_pred_t *preds, int np
     RFX_KERNEL_END(c);
     RFX_HIP_CHECK(hipGetLastError());
     i64 total = 0;
-    rc = where_scan_total(c, nrows, &total);
+    rc = where_scan_total(c, nrows, &total, d_mask == NULL);
     if (rc != RFX_OK) return rc;
     c->where_n = nrows;
     c->where_count = total;
@@ -453,8 +502,12 @@ extern "C" int rfx_hip_where_emit(rfx_ctx_t *c, int64_t row0, int64_t *d_ids) {
     const i64 nchunks = (c->where_n + RFX_CHUNK - 1) / RFX_CHUNK;
     int grid = c->num_cus * 16;
     if ((i64)grid * 4 > nchunks) grid = (int)((nchunks + 3) / 4);
-    hipLaunchKernelGGL(k_emit_ids, dim3(grid), dim3(RFX_BLOCK), 0, c->stream, (const u64 *)c->d_bitmap, (const i64 *)c->d_blksum, c->where_n,
-                       (i64)row0, (i64 *)d_ids);
+    if (c->flags & RFX_TUNE_NO_EMIT_WC)
+        hipLaunchKernelGGL(k_emit_ids, dim3(grid), dim3(RFX_BLOCK), 0, c->stream, (const u64 *)c->d_bitmap, (const i64 *)c->d_blksum, c->where_n,
+                           (i64)row0, (i64 *)d_ids);
+    else
+        hipLaunchKernelGGL(k_emit_ids_wc, dim3(grid), dim3(RFX_BLOCK), 0, c->stream, (const u64 *)c->d_bitmap, (const i64 *)c->d_blksum, c->where_n,
+                           (i64)row0, (i64 *)d_ids);
     RFX_HIP_CHECK(hipGetLastError());
     return RFX_OK;
 }
