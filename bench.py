@@ -16,6 +16,7 @@ Workloads (BASELINE.json configs / SURVEY 8d):
   c1   configs[0]  (sum v)                             v: f64[1e7]                         8 B/row   (plumbing case)
   c3w  metric      select sum(v) by k where a < 100000 k, v as c3 + a as c2                24 B/row
   q2   8f-1        select sum(v) by {id1, id2}         id1, id2: i64[1e9] in [0,100), v    24 B/row
+  k9   a10         select sum(v) by k, sparse keys (range > rows: open-addressing path)          16 B/row
   x6   8f-3        select sum(p*d) where q<24 and .05<=d<=.07   p, d: f64[1e9], q: i64[1e9]   24 B/row (TPC-H Q6 shape)
   c5   configs[4]  avg,min,max(d) where a<.316228 & b>.683772 & c!=.25   4 x f64[2.5e8]/GPU 32 B/row
 One JSON line on stdout (rank 0); everything else goes to stderr.
@@ -60,6 +61,8 @@ WORKLOADS = {
                bytes_per_row=24, dtype="f64", kernel="k_composite_key+k_group_dense"),
     "x6": dict(desc="expression aggregate (TPC-H Q6 shape): select sum(p * d) where q < 24 and d >= 0.05 and d <= 0.07; p f64 seed 12, d f64 seed 13 "
                     "scaled to [0,0.1), q i64 uniform [0,50) seed 14", rows=1_000_000_000, bytes_per_row=24, dtype="f64", kernel="k_filter_aggr<3,4,4,4,4>"),
+    "k9": dict(desc="sparse keys (range > rows -> the reference's open-addressing path): select sum(v) by k, k = 1000003 * (i64 uniform [0,1e6) seed 4) - 77, "
+                    "v f64 seed 5", rows=1_000_000_000, bytes_per_row=16, dtype="f64", kernel="k_group_hash"),
     "w2": dict(desc="where ids: (where (< a 100000)) on the C2 column -> 1e8 ascending i64 row ids (8 B/row in + 8 B/selected row out)", rows=1_000_000_000,
                bytes_per_row=8.8, dtype="int64", kernel="k_sel_bitmap<1>+k_emit_ids"),
     "m2": dict(desc="B8 mask: (< a 100000) materialised as the reference's byte mask (8 B/row in + 1 B/row out)", rows=1_000_000_000, bytes_per_row=9,
@@ -94,6 +97,11 @@ class Job:
             self.t = {"p": g.gen_f64(rows, 12, row0), "d": d, "q": g.gen_i64(rows, 14, 50, row0)}
             self.aggs = [("sum", ("*", "p", "d"))]
             self.where = ("and", ("<", "q", 24), (">=", "d", 0.05), ("<=", "d", 0.07))
+        elif name == "k9":
+            k = g.gen_i64(rows, 4, 1_000_000, row0)
+            k.mul_(1_000_003).sub_(77)  # plumbing: spread the keys once, outside every timed region
+            self.t = {"k": k, "v": g.gen_f64(rows, 5, row0)}
+            self.aggs, self.where = [("sum", "v")], None
         elif name == "q2":
             self.t = {"id1": g.gen_i64(rows, 10, 100, row0), "id2": g.gen_i64(rows, 11, 100, row0), "v": g.gen_f64(rows, 5, row0)}
             self.aggs, self.where, self.key = [("sum", "v")], None, ["id1", "id2"]
@@ -134,7 +142,7 @@ class Job:
             ids = self.sh.where(self.where, self.t) if self.sh is not None else self.eng.where(self.where, self.t)
             self.eng.sync()
             return ([int(ids.numel())], int(ids.numel()))
-        if self.name in ("c3", "c3w", "q2"):
+        if self.name in ("c3", "c3w", "q2", "k9"):
             if self.sh is not None:
                 return self.sh.group_by(self.key, self.aggs, self.where, self.t)
             return self.eng.group_by(self.key, self.aggs, self.where, self.t)
@@ -174,7 +182,7 @@ def run_workload(name, eng, sharded, rows, row0, steps, warmup, world):
     job = Job(name, eng, sharded, rows, row0)
     dt, kms, res = timed(job, steps, warmup, world)
     ms_step = dt * 1e3 / steps
-    if name in ("c3", "c3w", "q2", "w2"):
+    if name in ("c3", "c3w", "q2", "k9", "w2"):
         kms = ms_step  # several dependent kernels (scope+hist, scatter, aggregate, rank, emit): price the whole query
     value = world * rows / (dt / steps)
     alg_bytes = w["bytes_per_row"] * rows  # per launch, per GPU (SURVEY 8d figures, stated in DESIGN.md)
@@ -229,6 +237,10 @@ def cpu_baseline(name, sample_rows, timeout=120):
         cols = {"p": rfo.gen_f64(sample_rows, 12), "d": rfo.gen_f64(sample_rows, 13) * 0.1, "q": rfo.gen_i64(sample_rows, 14, 50)}
         q = "(select {s: (sum (* p d)) from: t where: (and (< q 24) (>= d 0.05) (<= d 0.07))})"
         oq = {"where": ("and", ("<", "q", 24), (">=", "d", 0.05), ("<=", "d", 0.07)), "s": ("sum", ("*", "p", "d"))}
+    elif name == "k9":
+        cols = {"k": rfo.gen_i64(sample_rows, 4, 1_000_000) * 1_000_003 - 77, "v": rfo.gen_f64(sample_rows, 5)}
+        q = "(select {s: (sum v) from: t by: k})"
+        oq = {"by": "k", "s": ("sum", "v")}
     elif name == "q2":
         cols = {"id1": rfo.gen_i64(sample_rows, 10, 100), "id2": rfo.gen_i64(sample_rows, 11, 100), "v": rfo.gen_f64(sample_rows, 5)}
         q = "(select {s: (sum v) from: t by: {id1: id1 id2: id2}})"
@@ -366,7 +378,7 @@ def main():
         # the reference's CPU path beside the secondary workloads too (smaller samples: the whole run stays within minutes)
         t_cpu = time.perf_counter()
         for other in also:
-            if other in ("c1", "c2b", "c3", "c3w", "q2", "x6", "c5") and "error" not in also[other]:
+            if other in ("c1", "c2b", "c3", "c3w", "q2", "x6", "k9", "c5") and "error" not in also[other]:
                 if time.perf_counter() - t_cpu > 150:  # keep the default run within minutes
                     log(f"[bench] cpu_baseline({other}) skipped: time budget for the secondary baselines used up")
                     continue

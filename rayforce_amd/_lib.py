@@ -5,6 +5,7 @@ import ctypes as C
 import os
 
 RFX_OK = 0
+RFX_ELIMIT = -5
 RFX_B8, RFX_I64, RFX_F64 = 1, 5, 10
 RFX_EQ, RFX_NE, RFX_LT, RFX_GT, RFX_LE, RFX_GE = range(6)
 RFX_AND, RFX_OR = 0, 1

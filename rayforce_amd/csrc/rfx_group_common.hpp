@@ -7,6 +7,52 @@
 int rfx_scan_counts(rfx_ctx *c, i64 *d_cnt, i64 n, i64 *d_total);
 int rfx_rank_slots(rfx_ctx *c, const u64 *d_first, i64 slots, i64 row_base, i64 total_rows, i64 *ngroups);
 int rfx_fill_u64(rfx_ctx *c, void *p, i64 n, u64 val);
+// partitioned form of the sparse-key (hashed) group-by, rfx_group_part.hip.  RFX_ESTATE: not applicable.
+int rfx_group_part_hash_accumulate(rfx_ctx *c, const struct Plan &P, int key_idx, const struct HashArgs &H, int *d_overflow);
+
+#define RFX_U64_HASH_SEED 0x9ddfea08eb382d69ULL /* core/hash.h:35 */
+
+// hash_index_u64 -- core/hash.h:86-97
+__device__ __host__ __forceinline__ u64 rfx_hash_index_u64(u64 h, u64 k) {
+    const u64 s = RFX_U64_HASH_SEED;
+    u64 a = (h ^ k) * s;
+    a ^= (a >> 47);
+    u64 b = (((k << 31) | (k >> 33)) ^ a) * s;
+    b ^= (b >> 47);
+    b *= s;
+    return b;
+}
+
+struct HashArgs {
+    i64 capacity;
+    int key_idx;
+    int nagg;
+    u64 *keys;
+    u64 *first;
+    u64 *acc[RFX_MAX_AGGS];
+    u64 *cnt[RFX_MAX_AGGS];
+};
+
+// find-or-insert in the device-wide open-addressed table; returns the slot, or -1 when RFX_HASH_MAX_PROBES consecutive
+// slots are taken by other keys (the caller reports "table full": capacity is meant to be >= 2x the distinct keys, where
+// runs of that length do not occur).
+#define RFX_HASH_MAX_PROBES 2048
+__device__ __forceinline__ i64 hash_slot(u64 *keys, i64 capacity, u64 key) {
+    if ((i64)key == RFX_NULL_I64_D) return capacity;
+    const u64 mask = (u64)capacity - 1;
+    u64 s = rfx_hash_index_u64(RFX_U64_HASH_SEED, key) & mask;
+    const i64 bound = capacity < RFX_HASH_MAX_PROBES ? capacity : RFX_HASH_MAX_PROBES;
+    for (i64 probe = 0; probe < bound; probe++) {
+        u64 k = keys[s];
+        if (k == key) return (i64)s;
+        if ((i64)k == RFX_NULL_I64_D) {
+            u64 old = atomicCAS((unsigned long long *)&keys[s], (unsigned long long)RFX_NULL_I64_D, (unsigned long long)key);
+            if ((i64)old == RFX_NULL_I64_D || old == key) return (i64)s;
+        }
+        s = (s + 1) & mask;
+    }
+    return -1; // table (locally) full
+}
 
 // identity element of an accumulator cell
 __device__ __host__ __forceinline__ u64 acc_identity(int kind, int f64) {

@@ -43,6 +43,7 @@ struct PartArgs {
     int split;                 // workgroups per partition in pass 2
     int wc;                    // > 0: write-combining scatter, value = records per 128-byte store group (regions padded to it,
                                //      sentinel records possible); with 2-3 value planes records are 32-byte {hdr, v0, v1, v2}
+    int hashed;                // 1: sparse keys -- partition = top 8 bits of hash_index_u64(key); records carry the KEY as plane 0
     int lowbit;                // 1: partition = key & 255 (known before the scope is), local slot = (key - kmin) >> 8
     u64 *offsets;              // [nwg][nparts] : counts, then exclusive offsets
     u64 *part_start;           // [nparts + 1]
@@ -52,6 +53,13 @@ struct PartArgs {
     u64 *acc[RFX_MAX_AGGS];
     u64 *cnt[RFX_MAX_AGGS];
 };
+
+// Which partition a selected row goes to, and whether it takes part at all.
+__device__ __forceinline__ bool part_row_ok(const PartArgs &A, u64 slot) { return A.hashed || slot < (u64)A.range; }
+__device__ __forceinline__ unsigned part_of(const PartArgs &A, u64 key, u64 slot) {
+    if (A.hashed) return (unsigned)(rfx_hash_index_u64(RFX_U64_HASH_SEED, key) >> 56);
+    return A.lowbit ? (unsigned)(key & 255ULL) : (unsigned)(slot >> A.lb);
+}
 
 // Shared tile front-end of pass 0 and pass 1: 8 rows per lane as four 16-byte loads per column.
 template <int NC, int NP>
@@ -100,7 +108,7 @@ __global__ __launch_bounds__(RFX_BLOCK) void k_part_hist(const Plan P, const Par
 #pragma unroll
         for (int e = 0; e < 8; e++) {
             const u64 slot = key[e] - (u64)A.kmin;
-            if (((m >> e) & 1u) && slot < (u64)A.range) atomicAdd(&hist[slot >> A.lb], 1u);
+            if (((m >> e) & 1u) && part_row_ok(A, slot)) atomicAdd(&hist[part_of(A, key[e], slot)], 1u);
         }
     }
     __syncthreads();
@@ -323,9 +331,9 @@ __global__ __launch_bounds__(RFX_BLOCK) void k_part_scatter(const Plan P, const 
             const u64 slot = key[e] - (u64)A.kmin;
             part[e] = 0;
             rank[e] = 0;
-            if (((m0 >> e) & 1u) && slot < (u64)A.range) {
+            if (((m0 >> e) & 1u) && part_row_ok(A, slot)) {
                 m |= 1u << e;
-                part[e] = A.lowbit ? (unsigned)(key[e] & 255ULL) : (unsigned)(slot >> A.lb);
+                part[e] = part_of(A, key[e], slot);
                 rank[e] = atomicAdd(&thist[part[e]], 1u);
             }
         }
@@ -454,9 +462,9 @@ __global__ __launch_bounds__(RFX_BLOCK) void k_part_scatter_wc(const Plan P, con
             const u64 slot = key[e] - (u64)A.kmin;
             part[e] = 0;
             rank[e] = 0;
-            if (((m0 >> e) & 1u) && slot < (u64)A.range) {
+            if (((m0 >> e) & 1u) && part_row_ok(A, slot)) {
                 m |= 1u << e;
-                part[e] = A.lowbit ? (unsigned)(key[e] & 255ULL) : (unsigned)(slot >> A.lb);
+                part[e] = part_of(A, key[e], slot);
                 rank[e] = atomicAdd(&thist[part[e]], 1u);
             }
         }
@@ -567,9 +575,9 @@ __global__ __launch_bounds__(RFX_BLOCK) void k_part_scatter_dwc(const Plan P, co
             const u64 slot = key[e] - (u64)A.kmin;
             part[e] = 0;
             rank[e] = 0;
-            if (((m0 >> e) & 1u) && slot < (u64)A.range) {
+            if (((m0 >> e) & 1u) && part_row_ok(A, slot)) {
                 m |= 1u << e;
-                part[e] = A.lowbit ? (unsigned)(key[e] & 255ULL) : (unsigned)(slot >> A.lb);
+                part[e] = part_of(A, key[e], slot);
                 rank[e] = atomicAdd(&cnt[part[e]], 1u);
             }
         }
@@ -823,6 +831,136 @@ static int launch_part(rfx_ctx *c, const Plan &P, const PartArgs &A, int nwg) {
     return RFX_OK;
 }
 
+// ---- sparse keys: per-partition LDS hash tables in front of the device-wide one (K9, partitioned form) ----
+// range > rows: the reference switches to open addressing (index_group_i64_unscoped, core/index.c:1959-1977).  One
+// device-wide CAS table takes ~21 G rows/s whatever its size (memory-side atomics, section 3 of DESIGN.md): 48 ms per 1e9
+// rows.  Same cure as for the dense path: partition -- here by the TOP 8 bits of hash_index_u64(key), records carry the key
+// as value plane 0 -- then one workgroup per partition aggregates its records in an LDS open-addressed table
+// {key, first, acc..} (ds_cmpst_rtn_b64 insert, ds atomics) and merges every occupied entry into the device-wide table
+// once: the global atomics drop from one per row to one per (partition, distinct key).  A key that finds no free LDS entry
+// within PH_PROBES steps (more distinct keys in the partition than the table holds) is applied to the device-wide table
+// directly; the null key (its bit pattern is the empty marker) always is.
+#define PH_THREADS 1024
+#define PH_PROBES 48
+struct PartHashArgs {
+    HashArgs H;       // the device-wide table
+    unsigned lcap;    // LDS table entries
+    int narr;         // 8-byte arrays per entry besides key and first (acc + cnt per aggregate)
+    int *overflow;    // device-wide table full
+};
+template <int NVT>
+__global__ __launch_bounds__(PH_THREADS) void k_part_hash_aggregate(const Plan P, const PartArgs A, const PartHashArgs X) {
+    extern __shared__ __attribute__((aligned(16))) u64 smem[];
+    const int tid = threadIdx.x;
+    const int p = blockIdx.x;
+    const unsigned C = X.lcap;
+    u64 *lkey = smem;                              // [C]
+    u64 *larr = smem + C;                          // [narr][C]
+    unsigned *lfirst = (unsigned *)(smem + (size_t)(1 + X.narr) * C); // [C] local row of the first occurrence
+    int kind[RFX_MAX_AGGS], f64[RFX_MAX_AGGS], plane[RFX_MAX_AGGS], arr_of[RFX_MAX_AGGS], skip[RFX_MAX_AGGS];
+    {
+        int arr = 0;
+#pragma unroll
+        for (int a = 0; a < RFX_MAX_AGGS; a++) {
+            kind[a] = (a < P.nagg) ? P.aggs[a].kind : -1;
+            f64[a] = (a < P.nagg) ? P.aggs[a].f64 : 0;
+            skip[a] = (a < P.nagg) ? P.aggs[a].skipnull : 0;
+            plane[a] = (a < P.nagg) ? A.agg_plane[a] : -1;
+            arr_of[a] = arr;
+            if (kind[a] >= 0) arr += agg_has_cnt(kind[a], f64[a]) ? 2 : 1;
+        }
+    }
+    for (unsigned i = tid; i < C; i += PH_THREADS) {
+        lkey[i] = (u64)RFX_NULL_I64_D;
+        lfirst[i] = 0xffffffffu;
+    }
+#pragma unroll
+    for (int a = 0; a < RFX_MAX_AGGS; a++) {
+        if (kind[a] < 0) continue;
+        const u64 id = acc_identity(kind[a], f64[a]);
+        for (unsigned i = tid; i < C; i += PH_THREADS) larr[(size_t)arr_of[a] * C + i] = id;
+        if (agg_has_cnt(kind[a], f64[a]))
+            for (unsigned i = tid; i < C; i += PH_THREADS) larr[(size_t)(arr_of[a] + 1) * C + i] = 0;
+    }
+    __syncthreads();
+    const u64 beg = A.part_start[p], end = A.part_start[p + 1];
+    const u64 row0 = (u64)P.row0;
+    const u64 *__restrict__ recs = A.recs;
+    constexpr int RSU = (NVT == 1) ? 2 : 4;
+    for (u64 i = beg + tid; i < end; i += PH_THREADS) {
+        typedef u64 v2 __attribute__((ext_vector_type(2)));
+        const v2 q0 = __builtin_nontemporal_load((const v2 *)(recs + RSU * i));
+        const u64 h = q0.x, key = q0.y;
+        if ((unsigned)h == 0xffffffffu && (h >> 32) == 0xffffffffu) continue; // padding of the write-combining scatter
+        u64 val[2] = {0, 0};
+        if (NVT > 1) {
+            const v2 q1 = __builtin_nontemporal_load((const v2 *)(recs + RSU * i + 2));
+            val[0] = q1.x;
+            val[1] = q1.y;
+        }
+        const unsigned lrow = (unsigned)(h >> 32);
+        // find-or-insert in the LDS table
+        int idx = -1;
+        if ((i64)key != RFX_NULL_I64_D) {
+            const u64 hh = rfx_hash_index_u64(RFX_U64_HASH_SEED, key);
+            unsigned s = (unsigned)((((hh >> 16) & 0xffffffffULL) * (u64)C) >> 32); // bits 16..47: independent of the partition bits
+            for (int probe = 0; probe < PH_PROBES; probe++) {
+                const u64 k = lkey[s];
+                if (k == key) { idx = (int)s; break; }
+                if ((i64)k == RFX_NULL_I64_D) {
+                    const u64 old = atomicCAS((unsigned long long *)&lkey[s], (unsigned long long)RFX_NULL_I64_D, (unsigned long long)key);
+                    if ((i64)old == RFX_NULL_I64_D || old == key) { idx = (int)s; break; }
+                }
+                s = (s + 1 == C) ? 0 : s + 1;
+            }
+        }
+        if (idx >= 0) {
+            atomicMin(&lfirst[idx], lrow);
+#pragma unroll
+            for (int a = 0; a < RFX_MAX_AGGS; a++) {
+                if (kind[a] < 0) continue;
+                const u64 x = (plane[a] == 1) ? val[0] : ((plane[a] == 2) ? val[1] : 0ULL);
+                group_apply(&larr[(size_t)arr_of[a] * C + idx], &larr[(size_t)(arr_of[a] + 1) * C + idx], kind[a], f64[a], x, skip[a]);
+            }
+        } else {
+            // no room in LDS for this key (or the null key): straight to the device-wide table
+            const i64 g = hash_slot(X.H.keys, X.H.capacity, key);
+            if (g < 0) {
+                atomicExch(X.overflow, 1);
+                continue;
+            }
+            const u64 row = row0 + lrow;
+            if (row < X.H.first[g]) atomicMin((unsigned long long *)&X.H.first[g], (unsigned long long)row);
+#pragma unroll
+            for (int a = 0; a < RFX_MAX_AGGS; a++) {
+                if (kind[a] < 0) continue;
+                const u64 x = (plane[a] == 1) ? val[0] : ((plane[a] == 2) ? val[1] : 0ULL);
+                group_apply(&X.H.acc[a][g], X.H.cnt[a] ? &X.H.cnt[a][g] : (u64 *)0, kind[a], f64[a], x, skip[a]);
+            }
+        }
+    }
+    __syncthreads();
+    // merge the partition's groups into the device-wide table: one insert per distinct key
+    for (unsigned i = tid; i < C; i += PH_THREADS) {
+        const u64 key = lkey[i];
+        if ((i64)key == RFX_NULL_I64_D) continue;
+        const i64 g = hash_slot(X.H.keys, X.H.capacity, key);
+        if (g < 0) {
+            atomicExch(X.overflow, 1);
+            continue;
+        }
+        const u64 row = row0 + lfirst[i];
+        if (row < X.H.first[g]) atomicMin((unsigned long long *)&X.H.first[g], (unsigned long long)row);
+#pragma unroll
+        for (int a = 0; a < RFX_MAX_AGGS; a++) {
+            if (kind[a] < 0) continue;
+            const bool hc = agg_has_cnt(kind[a], f64[a]);
+            group_merge_cell(&X.H.acc[a][g], hc ? &X.H.cnt[a][g] : (u64 *)0, kind[a], f64[a], larr[(size_t)arr_of[a] * C + i],
+                             hc ? larr[(size_t)(arr_of[a] + 1) * C + i] : 0ULL);
+        }
+    }
+}
+
 // ---- selective filters: compact first, partition what is left ----
 // The scatter pays its LDS phases per 2048-row tile whether 2048 or 200 rows survive the predicates (C3 under a 10 %
 // filter: 11.8 ms in the scatter alone, slower than unfiltered; storing the survivors directly as 16-byte records is
@@ -1023,6 +1161,95 @@ int rfx_group_part_accumulate(rfx_ctx *c, const Plan &P, int key_idx, const rfx_
         case 2: hipLaunchKernelGGL((k_part_aggregate<2>), dim3(grid2), dim3(PART_AGG_THREADS), lds, c->stream, P, A); break;
         default: hipLaunchKernelGGL((k_part_aggregate<3>), dim3(grid2), dim3(PART_AGG_THREADS), lds, c->stream, P, A); break;
     }
+    RFX_KERNEL_END(c);
+    RFX_HIP_CHECK(hipGetLastError());
+    return RFX_OK;
+}
+
+// Sparse-key form.  RFX_ESTATE: not applicable (tiny input, too many value planes) -- the caller runs the direct kernel.
+int rfx_group_part_hash_accumulate(rfx_ctx *c, const Plan &P0, int key_idx, const HashArgs &H, int *d_overflow) {
+    if (P0.nrows >= (1LL << 32) || P0.nrows < (1 << 16) || (c->flags & RFX_TUNE_NO_PARTITION)) return RFX_ESTATE;
+    Plan P = P0;
+    if (P.nx > 0) { // expression aggregates: the records carry plain values
+        if (P.ncols + P.nx > RFX_MAX_COLS) return RFX_ESTATE;
+        const int rc = rfx_plan_materialise_exprs(c, &P);
+        if (rc != RFX_OK) return rc;
+    }
+    PartArgs A;
+    memset(&A, 0, sizeof(A));
+    A.hashed = 1;
+    A.nv = 1;
+    A.vcol[0] = key_idx; // plane 0 of every record is the key itself
+    int narr = 0;
+    for (int a = 0; a < P.nagg; a++) {
+        const PlanAgg ag = P.aggs[a];
+        narr += 1 + (agg_has_cnt(ag.kind, ag.f64) ? 1 : 0);
+        A.agg_plane[a] = -1;
+        if (ag.kind == RFX_AGG_COUNT || ag.kind == RFX_AGG_FIRST || ag.col < 0) continue;
+        int j = 1;
+        for (; j < A.nv; j++)
+            if (A.vcol[j] == ag.col) break;
+        if (j == A.nv) {
+            if (A.nv >= 3) return RFX_ESTATE; // records carry the key and at most 2 value planes
+            A.vcol[A.nv++] = ag.col;
+        }
+        A.agg_plane[a] = j;
+    }
+    const int nwg = part_nwg(c);
+    A.kmin = 0;
+    A.range = 0;
+    A.lb = 0;
+    A.nparts = 256;
+    A.key_idx = key_idx;
+    A.narr = narr;
+    A.split = 1;
+    A.wc = (A.nv == 1) ? 8 : 4;
+    const int rsu = (A.nv == 1) ? 2 : 4;
+    A.cap = ((P.nrows + 63) / 64) * 64 + (i64)nwg * A.nparts * A.wc;
+    const size_t off_bytes = (size_t)nwg * A.nparts * 8;
+    const size_t start_bytes = (size_t)(A.nparts + 2) * 8;
+    const size_t rec_bytes = (size_t)rsu * A.cap * 8;
+    const size_t need = ((off_bytes + 255) & ~(size_t)255) + ((start_bytes + 255) & ~(size_t)255) + rec_bytes;
+    int rc = rfx_part_reserve(c, need);
+    if (rc != RFX_OK) return rc;
+    char *w = (char *)c->d_part;
+    A.offsets = (u64 *)w;
+    w += (off_bytes + 255) & ~(size_t)255;
+    A.part_start = (u64 *)w;
+    w += (start_bytes + 255) & ~(size_t)255;
+    A.recs = (u64 *)w;
+    c->pc_valid = 0;
+    RFX_KERNEL_BEGIN(c);
+    switch (P.ncols) {
+        case 1: launch_part<1>(c, P, A, nwg); break;
+        case 2: launch_part<2>(c, P, A, nwg); break;
+        case 3: launch_part<3>(c, P, A, nwg); break;
+        case 4: launch_part<4>(c, P, A, nwg); break;
+        default: return RFX_ESTATE;
+    }
+    PartHashArgs X;
+    X.H = H;
+    X.narr = narr;
+    X.overflow = d_overflow;
+    // LDS entry = key 8 B + narr x 8 B + first 4 B; take what fits 150 KB (one 1024-thread workgroup per CU)
+    const size_t entry = 8 + (size_t)narr * 8 + 4;
+    X.lcap = (unsigned)(((size_t)150 * 1024) / entry) & ~63u;
+    const size_t lds = (((size_t)X.lcap * (8 + (size_t)narr * 8)) + (size_t)X.lcap * 4 + 15) & ~(size_t)15;
+    static bool attr_set[3] = {false, false, false};
+#define RFX_PH(N)                                                                                                                              \
+    case N:                                                                                                                                    \
+        if (!attr_set[N - 1]) {                                                                                                                \
+            RFX_HIP_CHECK(hipFuncSetAttribute((const void *)k_part_hash_aggregate<N>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+            attr_set[N - 1] = true;                                                                                                            \
+        }                                                                                                                                      \
+        hipLaunchKernelGGL((k_part_hash_aggregate<N>), dim3(A.nparts), dim3(PH_THREADS), lds, c->stream, P, A, X);                             \
+        break
+    switch (A.nv) {
+        RFX_PH(1);
+        RFX_PH(2);
+        default: RFX_PH(3);
+    }
+#undef RFX_PH
     RFX_KERNEL_END(c);
     RFX_HIP_CHECK(hipGetLastError());
     return RFX_OK;

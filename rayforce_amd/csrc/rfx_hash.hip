@@ -11,18 +11,6 @@
 // (the reference's own table would open a fresh group for every such row -- see DESIGN.md "deliberate deviations").
 #include "rfx_group_common.hpp"
 
-#define RFX_U64_HASH_SEED 0x9ddfea08eb382d69ULL /* core/hash.h:35 */
-
-// hash_index_u64 -- core/hash.h:86-97
-__device__ __host__ __forceinline__ u64 rfx_hash_index_u64(u64 h, u64 k) {
-    const u64 s = RFX_U64_HASH_SEED;
-    u64 a = (h ^ k) * s;
-    a ^= (a >> 47);
-    u64 b = (((k << 31) | (k >> 33)) ^ a) * s;
-    b ^= (b >> 47);
-    b *= s;
-    return b;
-}
 // hash_fnv1a -- core/hash.c:530-542
 __device__ __host__ __forceinline__ u64 rfx_hash_fnv1a(u64 key) {
     u64 h = 14695981039346656037ULL;
@@ -34,32 +22,6 @@ __device__ __host__ __forceinline__ u64 rfx_hash_fnv1a(u64 key) {
     return h;
 }
 
-struct HashArgs {
-    i64 capacity;
-    int key_idx;
-    int nagg;
-    u64 *keys;
-    u64 *first;
-    u64 *acc[RFX_MAX_AGGS];
-    u64 *cnt[RFX_MAX_AGGS];
-};
-
-// find-or-insert; returns the slot.  Bounded probing: the table is never allowed to fill (capacity >= 2 * distinct).
-__device__ __forceinline__ i64 hash_slot(u64 *keys, i64 capacity, u64 key) {
-    if ((i64)key == RFX_NULL_I64_D) return capacity;
-    const u64 mask = (u64)capacity - 1;
-    u64 s = rfx_hash_index_u64(RFX_U64_HASH_SEED, key) & mask;
-    for (i64 probe = 0; probe < capacity; probe++) {
-        u64 k = keys[s];
-        if (k == key) return (i64)s;
-        if ((i64)k == RFX_NULL_I64_D) {
-            u64 old = atomicCAS((unsigned long long *)&keys[s], (unsigned long long)RFX_NULL_I64_D, (unsigned long long)key);
-            if ((i64)old == RFX_NULL_I64_D || old == key) return (i64)s;
-        }
-        s = (s + 1) & mask;
-    }
-    return -1; // table full
-}
 
 template <int NC>
 __global__ __launch_bounds__(RFX_BLOCK) void k_group_hash(const Plan P, const HashArgs H, int *__restrict__ overflow) {
@@ -72,6 +34,7 @@ __global__ __launch_bounds__(RFX_BLOCK) void k_group_hash(const Plan P, const Ha
     predset_load<RFX_MAX_PREDS>(P, S);
     const i64 ntiles = (P.nrows + TILE - 1) / TILE;
     for (i64 t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        if (*(volatile int *)overflow) return; // another workgroup has found the table full: the caller will grow it and retry
         const i64 base = t * TILE + tid * 2;
         u64 v[NC][E];
         unsigned valid = 0;
@@ -225,6 +188,10 @@ extern "C" int rfx_hip_group_hash_accumulate(rfx_ctx_t *c, const int64_t *d_key,
     if (rc != RFX_OK) return rc;
     int *flag = (int *)c->d_ws;
     RFX_HIP_CHECK(hipMemsetAsync(flag, 0, 4, c->stream));
+    // large inputs: partition by hash, aggregate every partition in an LDS table, merge once (rfx_group_part.hip)
+    rc = rfx_group_part_hash_accumulate(c, P, key_idx, H, flag);
+    if (rc == RFX_OK) return read_overflow(c, flag, "group_hash_accumulate");
+    if (rc != RFX_ESTATE) return rc;
     int grid = rfx_grid(c) * 4;
     switch (P.ncols) {
         case 1: launch_hash<1>(c, P, H, grid, flag); break;

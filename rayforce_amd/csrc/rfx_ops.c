@@ -616,12 +616,16 @@ rfx_obj_p rfx_select(rfx_obj_p dict) {
                 int narr = 0;
                 rfx_hip_group_table_arrays(aggs, nagg, &narr);
                 int64_t cells = dense ? (int64_t)range : 0;
-                int64_t cap = 16;
+                int64_t cap = 16, cap_max = 16;
                 if (!dense) {
-                    while (cap < 2 * seen) cap <<= 1;
-                    cells = cap + 1;
+                    /* the reference sizes its table by the row count (ht_oa_create(len)); distinct keys are usually far fewer:
+                     * start at 4 M slots and grow x16 whenever the table reports full */
+                    while (cap_max < 2 * seen) cap_max <<= 1;
+                    cap = cap_max < (1 << 22) ? cap_max : (1 << 22);
                     narr += 1;
                 }
+            grow:
+                if (!dense) cells = cap + 1;
                 void *store = NULL;
                 if (rfx_hip_malloc(g_ctx, &store, (size_t)narr * (size_t)cells * 8) != RFX_OK) { res = fail_hip("group tables"); goto done; }
                 int64_t *base = (int64_t *)store;
@@ -644,9 +648,15 @@ rfx_obj_p rfx_select(rfx_obj_p dict) {
                                     : rfx_hip_group_dense_accumulate(g_ctx, (const int64_t *)dk, wp.preds, wp.npred, wp.logic, aggs, nrows, 0, &gt)) == RFX_OK &&
                          rfx_hip_group_rank(g_ctx, &gt, nrows, &groups) == RFX_OK;
                 } else {
+                    int arc = RFX_EINVAL;
                     ok = rfx_hip_hash_tables_init(g_ctx, aggs, &ht) == RFX_OK &&
-                         rfx_hip_group_hash_accumulate(g_ctx, (const int64_t *)dk, wp.preds, wp.npred, wp.logic, aggs, nrows, 0, &ht) == RFX_OK &&
+                         (arc = rfx_hip_group_hash_accumulate(g_ctx, (const int64_t *)dk, wp.preds, wp.npred, wp.logic, aggs, nrows, 0, &ht)) == RFX_OK &&
                          rfx_hip_hash_rank(g_ctx, &ht, nrows, &groups) == RFX_OK;
+                    if (!ok && arc == RFX_ELIMIT && cap < cap_max) { /* table full: grow and run again */
+                        rfx_hip_free(g_ctx, store);
+                        cap = (cap << 4) < cap_max ? (cap << 4) : cap_max;
+                        goto grow;
+                    }
                 }
                 void *dout = NULL;
                 if (ok && groups > 0) ok = rfx_hip_malloc(g_ctx, &dout, (size_t)(nagg + 1) * (size_t)groups * 8) == RFX_OK;

@@ -159,6 +159,12 @@ class GroupHook:
             store, layout = payload
             allreduce_tables(store, layout, self.kinds, self.f64s, g)
             return None
+        if phase == "flag":  # logical OR of a per-rank flag
+            if self.shard.world == 1:
+                return payload
+            t = torch.tensor([int(payload)], dtype=torch.int64, device="cpu" if _gloo(g) else torch.device("cuda", torch.cuda.current_device()))
+            _all_reduce(t, dist.ReduceOp.MAX, g)
+            return int(t[0])
         if phase == "hash_tables":
             eng, make_tables, store, merge = payload
             world = self.shard.world

@@ -568,11 +568,24 @@ class Engine:
                 ptrs = (C.c_void_p * k)(*[kc.data_ptr() for kc in kcols])
                 L.check(self.lib.rfx_hip_composite_key(self._ctx, ptrs, (C.c_int64 * k)(*multi[0]), (C.c_int64 * k)(*multi[1]), k, n, key.data_ptr()),
                         "composite_key")
-            cap = 1 << max(4, math.ceil(math.log2(max(2 * seen, 16))))
-            t, store, layout = self.group_tables(aarr, nagg, 0, cap, hashed=True)
-            L.check(self.lib.rfx_hip_hash_tables_init(self._ctx, aarr, C.byref(t)), "hash_tables_init")
-            L.check(self.lib.rfx_hip_group_hash_accumulate(self._ctx, key.data_ptr(), parr, len(flat), logic, aarr, n, row0, C.byref(t)),
-                    "group_hash_accumulate")
+            # capacity: the reference sizes its table by the row count (ht_oa_create(len), core/index.c:1805); the distinct keys
+            # are usually far fewer, so start at 4 M slots (>= 2 M distinct keys) and grow x16 whenever the table reports full
+            cap_max = 1 << max(4, math.ceil(math.log2(max(2 * seen, 16))))
+            cap = min(cap_max, 1 << 22)
+            while True:
+                t, store, layout = self.group_tables(aarr, nagg, 0, cap, hashed=True)
+                L.check(self.lib.rfx_hip_hash_tables_init(self._ctx, aarr, C.byref(t)), "hash_tables_init")
+                rc = self.lib.rfx_hip_group_hash_accumulate(self._ctx, key.data_ptr(), parr, len(flat), logic, aarr, n, row0, C.byref(t))
+                full = rc == L.RFX_ELIMIT
+                if _collective is not None:
+                    full = bool(_collective("flag", int(full)))  # every rank grows together: merged tables share one capacity
+                if not full:
+                    L.check(rc, "group_hash_accumulate")
+                    break
+                if cap >= cap_max:
+                    L.check(rc, "group_hash_accumulate")
+                del t, store
+                cap = min(cap_max, cap << 4)
             if _collective is not None:
                 def make_tables(other_store):
                     return self.group_tables(aarr, nagg, 0, cap, hashed=True, store=other_store)[0]

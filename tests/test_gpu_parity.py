@@ -251,6 +251,37 @@ def test_group_by_sparse_keys_hash_path(eng):
     check_select(eng, host, {"where": (">", "v", 0.5), "by": "k", "s": ("sum", "a")})
 
 
+@pytest.mark.parametrize("flags", [0, 2])
+def test_sparse_keys_partitioned_hash_path(eng, flags):
+    """range > rows on inputs large enough for the partitioned form (hash partition -> LDS tables -> one merge) and, with
+    RFX_TUNE_NO_PARTITION, the direct device-wide table: few keys (everything lives in LDS), ~LDS-capacity keys per partition,
+    far more (LDS overflow -> direct updates; device-wide table grows x16), null keys, predicates, 0..2 value planes."""
+    n = 400_003
+    try:
+        eng.tune(flags=flags)
+        for distinct in (5, 3000, 200_000, 399_000):
+            host = table(n, keys=distinct, nulls=True)
+            host["k"] = host["k"] * 1_000_003 - 77_777
+            check_select(eng, host, {"by": "k", "s": ("sum", "v"), "c": ("count", "a")})
+            check_select(eng, host, {"by": "k", "mx": ("max", "a"), "av": ("avg", "w"), "f": ("first", "v")})
+            check_select(eng, host, {"where": ("<", "a", 400_000), "by": "k", "s": ("sum", ("*", "v", "a")), "c": ("count", "a")})
+            check_select(eng, host, {"by": "k", "c": ("count", "a")})
+        # null keys: ONE group here (dedicated slot), where the reference opens a group per null row (DESIGN.md deviation 3)
+        host = table(n, keys=3000)
+        host["k"] = host["k"] * 1_000_003 - 77_777
+        nul = rfo.gen_i64(n, 321, 97) == 0
+        host["k"][nul] = NULL
+        got = eng.select({"from": dev(eng, host), "by": "k", "c": ("count", "a"), "s": ("sum", "v")})
+        gk = got["k"].cpu().numpy()
+        assert (gk == NULL).sum() == 1 and len(gk) == len(np.unique(host["k"]))
+        i = int(np.nonzero(gk == NULL)[0][0])
+        assert int(got["c"][i]) == int(nul.sum()) and abs(float(got["s"][i]) - host["v"][nul].sum()) <= 1e-9 * host["v"][nul].sum()
+        first_rows = {k: r for r, k in reversed(list(enumerate(host["k"].tolist())))}
+        assert [first_rows[k] for k in gk.tolist()] == sorted(first_rows.values())  # first-occurrence order, null group included
+    finally:
+        eng.tune(flags=0)
+
+
 def test_hash_primitives_pinned(eng):
     import ctypes as C
     from rayforce_amd import _lib as L
