@@ -47,6 +47,11 @@ def _all_gather(t: torch.Tensor, group=None):
         bufs = [torch.empty_like(h) for _ in range(world)]
         dist.all_gather(bufs, h, group=group)
         return [b.to(t.device) for b in bufs]
+    if not _gloo(group):
+        # one contiguous receive buffer: a single collective and, for small payloads read back by the host, a single copy
+        out = torch.empty((world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+        dist.all_gather_into_tensor(out, t.contiguous(), group=group)
+        return list(out.unbind(0))
     bufs = [torch.empty_like(t) for _ in range(world)]
     dist.all_gather(bufs, t, group=group)
     return bufs
@@ -80,9 +85,14 @@ def merge_scalar_partials(partials: torch.Tensor, kinds: Sequence[int], col_type
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     if world > 1:
         bufs = _all_gather(partials, group)
+        base = bufs[0]._base if bufs[0]._base is not None else None
+        if base is not None and base.numel() == world * nbytes:  # rows of one receive buffer: one device-to-host copy
+            whole = base.cpu().numpy().tobytes()
+            host = [whole[r * nbytes:(r + 1) * nbytes] for r in range(world)]
+        else:
+            host = [b.cpu().numpy().tobytes() for b in bufs]
     else:
-        bufs = [partials]
-    host = [b.cpu().numpy().tobytes() for b in bufs]
+        host = [partials.cpu().numpy().tobytes()]
     acc = (L.Partial * (nagg + 1)).from_buffer_copy(host[0])
     for other in host[1:]:
         o = (L.Partial * (nagg + 1)).from_buffer_copy(other)
