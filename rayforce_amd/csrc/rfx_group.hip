@@ -226,9 +226,9 @@ static int launch_group(rfx_ctx *c, const Plan &P, const GroupArgs &G, int grid,
     return RFX_OK;
 }
 
-// halves of a table set: aggregates [0, h) and [h, nagg) over the same `first` array
-static int split_tables(const rfx_group_tables_t *t, rfx_group_tables_t *t1, rfx_group_tables_t *t2) {
-    const int h = t->nagg / 2;
+// two parts of a table set: aggregates [0, h) and [h, nagg) over the same `first` array (h <= 0: halves)
+static int split_tables(const rfx_group_tables_t *t, rfx_group_tables_t *t1, rfx_group_tables_t *t2, int h = 0) {
+    if (h <= 0) h = t->nagg / 2;
     *t1 = *t;
     *t2 = *t;
     t1->nagg = h;
@@ -238,6 +238,29 @@ static int split_tables(const rfx_group_tables_t *t, rfx_group_tables_t *t1, rfx
         t2->d_cnt[a] = t->d_cnt[h + a];
     }
     return h;
+}
+
+// Mid-range key counts with several aggregates: the whole table set does not fit LDS (so the query would take the
+// partitioned path: 29 ms per 1e9 rows with three value planes) but every aggregate alone does.  Then one streaming LDS
+// pass per group of aggregates -- each re-reads the key column, 2.5-3.7 ms -- is several times cheaper.  Returns how many
+// leading aggregates the first pass takes, 0 when no split is called for.
+static int lds_pass_split(const rfx_ctx *c, const rfx_agg_t *aggs, const rfx_group_tables_t *t) {
+    if (t->nagg < 2 || (c->flags & (RFX_TUNE_NO_LDS_TABLES | RFX_TUNE_NO_LDS_SPLIT))) return 0;
+    const size_t cap = (c->flags & RFX_TUNE_NO_BIG_LDS) ? RFX_LDS_GROUP_BYTES : RFX_LDS_GROUP_BIG_BYTES;
+    const size_t cell = (size_t)t->range * 8;
+    size_t total = cell, run = cell;
+    int h = 0;
+    bool open = true;
+    for (int a = 0; a < t->nagg; a++) {
+        const size_t mine = cell * (1 + (agg_has_cnt(aggs[a].kind, rfx_agg_input_type(&aggs[a]) == RFX_F64) ? 1 : 0));
+        if (cell + mine > cap) return 0; // this aggregate alone does not fit
+        total += mine;
+        if (open && run + mine <= cap) {
+            run += mine;
+            h = a + 1;
+        } else open = false;
+    }
+    return (total > cap && h >= 1 && h < t->nagg) ? h : 0;
 }
 
 static int group_dense_run(rfx_ctx_t *c, Plan &P, GroupArgs &G, const rfx_agg_t *aggs, const rfx_group_tables_t *t, bool allow_part, bool *need_materialise) {
@@ -294,10 +317,11 @@ extern "C" int rfx_hip_group_dense_accumulate(rfx_ctx_t *c, const int64_t *d_key
     if (nrows == 0) return RFX_OK;
     Plan P;
     int key_idx = 0;
-    rc = rfx_plan_build(&P, preds, npred, logic, aggs, t->nagg, d_key, &key_idx, nrows, row0);
-    if (rc == RFX_ELIMIT && t->nagg > 1) { // too many columns / expressions for one launch: two passes over the same tables
+    const int hs = lds_pass_split(c, aggs, t);
+    rc = hs ? RFX_ELIMIT : rfx_plan_build(&P, preds, npred, logic, aggs, t->nagg, d_key, &key_idx, nrows, row0);
+    if (rc == RFX_ELIMIT && t->nagg > 1) { // too many columns / expressions for one launch, or tables that fit LDS only in parts
         rfx_group_tables_t t1, t2;
-        const int h = split_tables(t, &t1, &t2);
+        const int h = split_tables(t, &t1, &t2, hs);
         rc = rfx_hip_group_dense_accumulate(c, d_key, preds, npred, logic, aggs, nrows, row0, &t1);
         if (rc != RFX_OK) return rc;
         return rfx_hip_group_dense_accumulate(c, d_key, preds, npred, logic, aggs + h, nrows, row0, &t2);
@@ -323,10 +347,11 @@ extern "C" int rfx_hip_group_dense_accumulate_keys(rfx_ctx_t *c, const void *con
     for (int i = 0; i < nkeys; i++) RFX_REQUIRE(d_keys[i] != NULL, RFX_EINVAL, "key column is NULL");
     Plan P;
     int k0 = 0;
-    rc = rfx_plan_build(&P, preds, npred, logic, aggs, t->nagg, d_keys[0], &k0, nrows, row0);
+    const int hs = lds_pass_split(c, aggs, t);
+    rc = hs ? RFX_ELIMIT : rfx_plan_build(&P, preds, npred, logic, aggs, t->nagg, d_keys[0], &k0, nrows, row0);
     if (rc == RFX_ELIMIT && t->nagg > 1) {
         rfx_group_tables_t t1, t2;
-        const int h = split_tables(t, &t1, &t2);
+        const int h = split_tables(t, &t1, &t2, hs);
         rc = rfx_hip_group_dense_accumulate_keys(c, d_keys, mins, mults, nkeys, preds, npred, logic, aggs, nrows, row0, &t1);
         if (rc != RFX_OK) return rc;
         return rfx_hip_group_dense_accumulate_keys(c, d_keys, mins, mults, nkeys, preds, npred, logic, aggs + h, nrows, row0, &t2);

@@ -318,13 +318,13 @@ def test_sharded_engine_single_rank(eng):
     assert np.array_equal(sh.where(("<", "a", 1000), d).cpu().numpy(), rfo.where(rfo.mask_of(("<", "a", 1000), host)))
 
 
-@pytest.mark.parametrize("flags", [0, 1, 2, 3, 4, 6, 8, 16, 32, 128, 144, 160, 256, 384])
+@pytest.mark.parametrize("flags", [0, 1, 2, 3, 4, 6, 8, 16, 32, 128, 144, 160, 256, 384, 1024, 1028])
 def test_group_by_every_code_path_agrees(eng, flags):
     """RFX_TUNE_* force the LDS-table / partitioned (fused and unfused scope) / device-atomic paths: same answers."""
     n = 400_003
     try:
         eng.tune(flags=flags)
-        for keys in (900, 2000, 60_000, 300_000):  # 64 KB LDS tables / 160 KB LDS tables / partitioned / partitioned
+        for keys in (900, 2000, 7000, 60_000, 300_000):  # 64 KB LDS / 160 KB LDS / LDS in several passes / partitioned / partitioned
             host = table(n, keys=keys, nulls=True)
             check_select(eng, host, {"by": "k", "s": ("sum", "v"), "si": ("sum", "a"), "c": ("count", "a"), "mx": ("max", "w"), "av": ("avg", "a")})
             check_select(eng, host, {"where": ("<", "a", 300_000), "by": "k", "s": ("sum", "v"), "mn": ("min", "a")})
