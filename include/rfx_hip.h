@@ -153,6 +153,7 @@ enum {
     RFX_TUNE_DIRECT_WC = 32,        /* partitioned path, one value plane: register-direct write combining instead of the tile-sorted form */
     RFX_TUNE_FUSED_KEYS = 64,       /* several key columns: always fold them on the fly, never materialise the composite column */
     RFX_TUNE_NO_FUSED_SCOPE = 128,  /* rfx_hip_scope_i64: plain min/max pass, no partition histogram side product */
+    RFX_TUNE_NO_SOA_WC = 2048,      /* partitioned path, 2-3 value planes: 32-byte register-direct records instead of tile-sorted planes */
     RFX_TUNE_NO_LDS_SPLIT = 1024,   /* dense group-by: never split the aggregates into several LDS-table passes */
     RFX_TUNE_NO_EMIT_WC = 512,      /* where: plain masked id stores instead of the LDS-ring write-combining emit */
     RFX_TUNE_NO_SEL_COMPACT = 256   /* partitioned path under a filter: never compact the selected rows first */

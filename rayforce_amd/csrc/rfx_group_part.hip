@@ -43,6 +43,8 @@ struct PartArgs {
     int split;                 // workgroups per partition in pass 2
     int wc;                    // > 0: write-combining scatter, value = records per 128-byte store group (regions padded to it,
                                //      sentinel records possible); with 2-3 value planes records are 32-byte {hdr, v0, v1, v2}
+    int soa;                   // 1: write-combined STRUCTURE-OF-ARRAYS records: plane 0 = headers, planes 1..nv = values, `cap` apart,
+                               //    every (workgroup, partition) region padded to 8 records (k_part_scatter_soa)
     int hashed;                // 1: sparse keys -- partition = top 8 bits of hash_index_u64(key); records carry the KEY as plane 0
     int lowbit;                // 1: partition = key & 255 (known before the scope is), local slot = (key - kmin) >> 8
     u64 *offsets;              // [nwg][nparts] : counts, then exclusive offsets
@@ -650,6 +652,135 @@ __global__ __launch_bounds__(RFX_BLOCK) void k_part_scatter_dwc(const Plan P, co
     }
 }
 
+// ---- pass 1, tile-sorted write-combining form for SEVERAL value planes (structure of arrays) ----
+// Two or three value planes made the records 32 bytes and the scatter register-direct (k_part_scatter_dwc): every record a
+// 32-byte store of its own, 20 ms per 1e9 rows.  Here the tile is sorted by partition once (as in k_part_scatter_wc), then
+// each PLANE -- headers, then every value plane -- goes through the same 16 KB staging buffer and leaves as whole aligned
+// 64-byte groups of 8 x 8 bytes, with an 8-record LDS carry per (partition, plane) between tiles.  LDS 26 KB + 16 KB per
+// plane: two workgroups per CU with two value planes.
+template <int NC, int NV, int NP>
+__global__ __launch_bounds__(RFX_BLOCK) void k_part_scatter_soa(const Plan P, const PartArgs A) {
+    constexpr int NPL = 1 + NV;
+    __shared__ unsigned thist[WC_MAXP];   // per tile: count, then exclusive tile offset
+    __shared__ unsigned tcnt[WC_MAXP];
+    __shared__ unsigned pre[WC_MAXP];     // records carried over from earlier tiles (< WC_B)
+    __shared__ unsigned pfl[WC_MAXP];     // records of (carry ++ tile) that leave now (multiple of WC_B)
+    __shared__ u64 cursor[WC_MAXP];       // next record index of (this workgroup, partition), multiple of WC_B
+    __shared__ u64 carry[NPL][WC_MAXP][WC_B];
+    __shared__ u64 stag[PART_TILE_ROWS];
+    __shared__ unsigned short stag_p[PART_TILE_ROWS];
+    __shared__ unsigned scan_w[RFX_BLOCK / RFX_WAVE];
+    __shared__ unsigned tile_total;
+    PredSet<NP> S;
+    predset_load<NP>(P, S);
+    const int tid = threadIdx.x;
+    const int np = A.nparts;
+    u64 *__restrict__ recs = A.recs;
+    const size_t cap = (size_t)A.cap;
+    if (tid < np) {
+        cursor[tid] = A.part_start[tid] + A.offsets[(size_t)blockIdx.x * np + tid];
+        pre[tid] = 0;
+    }
+    __syncthreads();
+    const i64 ntiles = (P.nrows + PART_TILE_ROWS - 1) / PART_TILE_ROWS;
+    for (i64 t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        if (tid < np) thist[tid] = 0;
+        __syncthreads();
+        u64 v[NC][8];
+        const unsigned m0 = part_load_eval<NC, NP>(P, S, t, v);
+        u64 key[8];
+        sel_col<NC, 8>(key, v, A.key_idx);
+        unsigned m = 0, part[8], rank[8];
+        const i64 base = t * PART_TILE_ROWS + tid * 2;
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const u64 slot = key[e] - (u64)A.kmin;
+            part[e] = 0;
+            rank[e] = 0;
+            if (((m0 >> e) & 1u) && part_row_ok(A, slot)) {
+                m |= 1u << e;
+                part[e] = part_of(A, key[e], slot);
+                rank[e] = atomicAdd(&thist[part[e]], 1u);
+            }
+        }
+        __syncthreads();
+        {
+            const unsigned x = (tid < np) ? thist[tid] : 0;
+            unsigned inc = x;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                unsigned o = __shfl_up(inc, d, 64);
+                if ((tid & 63) >= d) inc += o;
+            }
+            if ((tid & 63) == 63) scan_w[tid >> 6] = inc;
+            __syncthreads();
+            unsigned wbase = 0;
+            for (int w = 0; w < (tid >> 6); w++) wbase += scan_w[w];
+            if (tid < np) {
+                thist[tid] = wbase + inc - x;
+                tcnt[tid] = x;
+                pfl[tid] = ((pre[tid] + x) / WC_B) * WC_B;
+            }
+            if (tid == RFX_BLOCK - 1) tile_total = wbase + inc;
+        }
+        __syncthreads();
+        const unsigned total = tile_total;
+#pragma unroll
+        for (int pl = 0; pl < NPL; pl++) {
+            // this plane's values of the tile, in partition order
+            u64 x[8];
+            if (pl == 0) {
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    const u64 slot = key[e] - (u64)A.kmin;
+                    const u64 lrow = (u64)(base + (i64)(e >> 1) * (RFX_BLOCK * 2) + (e & 1));
+                    x[e] = (lrow << 32) | (A.lowbit ? (slot >> 8) : (slot & ((1ULL << A.lb) - 1)));
+                }
+            } else sel_col<NC, 8>(x, v, A.vcol[pl - 1]);
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                if (!((m >> e) & 1u)) continue;
+                const unsigned idx = thist[part[e]] + rank[e];
+                stag[idx] = x[e];
+                if (pl == 0) stag_p[idx] = (unsigned short)part[e];
+            }
+            u64 *__restrict__ out = recs + (size_t)pl * cap;
+            // old carry -> global for the partitions that complete a group now
+            for (int idx = tid; idx < np * WC_B; idx += RFX_BLOCK) {
+                const int p = idx / WC_B, j = idx % WC_B;
+                if ((unsigned)j < pre[p] && pfl[p] > 0) out[cursor[p] + j] = carry[pl][p][j];
+            }
+            __syncthreads();
+            for (unsigned i = tid; i < total; i += RFX_BLOCK) {
+                const unsigned p = stag_p[i];
+                const unsigned pos = pre[p] + (i - thist[p]);
+                if (pos < pfl[p]) out[cursor[p] + pos] = stag[i];
+                else carry[pl][p][pos - pfl[p]] = stag[i];
+            }
+            __syncthreads();
+        }
+        if (tid < np) {
+            const unsigned tot = pre[tid] + tcnt[tid];
+            cursor[tid] += pfl[tid];
+            pre[tid] = tot - pfl[tid];
+        }
+        __syncthreads();
+    }
+    // tails: one padded group per partition that still carries records (sentinel headers; the value planes' padding is never read)
+    for (int idx = tid; idx < np * WC_B; idx += RFX_BLOCK) {
+        const int p = idx / WC_B, j = idx % WC_B;
+        if (pre[p] > 0) {
+#pragma unroll
+            for (int pl = 0; pl < NPL; pl++) recs[(size_t)pl * cap + cursor[p] + j] = ((unsigned)j < pre[p]) ? carry[pl][p][j] : (pl == 0 ? WC_SENTINEL : 0ULL);
+        }
+    }
+}
+template <int NC, int NV>
+static void launch_scatter_soa(rfx_ctx *c, const Plan &P, const PartArgs &A, int nwg) {
+    if (P.npred == 0) hipLaunchKernelGGL((k_part_scatter_soa<NC, NV, 0>), dim3(nwg), dim3(RFX_BLOCK), 0, c->stream, P, A);
+    else hipLaunchKernelGGL((k_part_scatter_soa<NC, NV, RFX_MAX_PREDS>), dim3(nwg), dim3(RFX_BLOCK), 0, c->stream, P, A);
+}
+
 // ---- pass 2: per-partition LDS aggregation ----
 template <int NV>
 __global__ __launch_bounds__(PART_AGG_THREADS) void k_part_aggregate(const Plan P, const PartArgs A) {
@@ -706,7 +837,7 @@ __global__ __launch_bounds__(PART_AGG_THREADS) void k_part_aggregate(const Plan 
                 const v2 q = __builtin_nontemporal_load((const v2 *)(recs + 2 * i));
                 h[r] = q.x;
                 val[r][0] = q.y;
-            } else if (NV > 1 && A.wc) {
+            } else if (NV > 1 && A.wc && !A.soa) {
                 typedef u64 v2 __attribute__((ext_vector_type(2)));
                 const v2 q0 = __builtin_nontemporal_load((const v2 *)(recs + 4 * i));
                 const v2 q1 = __builtin_nontemporal_load((const v2 *)(recs + 4 * i + 2));
@@ -820,11 +951,13 @@ static int launch_part(rfx_ctx *c, const Plan &P, const PartArgs &A, int nwg) {
             else launch_scatter<NC, 1>(c, P, A, nwg);
             break;
         case 2:
-            if (A.wc) launch_scatter_dwc<NC, 2>(c, P, A, nwg);
+            if (A.soa) launch_scatter_soa<NC, 2>(c, P, A, nwg);
+            else if (A.wc) launch_scatter_dwc<NC, 2>(c, P, A, nwg);
             else launch_scatter<NC, 2>(c, P, A, nwg);
             break;
         default:
-            if (A.wc) launch_scatter_dwc<NC, 3>(c, P, A, nwg);
+            if (A.soa) launch_scatter_soa<NC, 3>(c, P, A, nwg);
+            else if (A.wc) launch_scatter_dwc<NC, 3>(c, P, A, nwg);
             else launch_scatter<NC, 3>(c, P, A, nwg);
             break;
     }
@@ -887,16 +1020,26 @@ __global__ __launch_bounds__(PH_THREADS) void k_part_hash_aggregate(const Plan P
     const u64 row0 = (u64)P.row0;
     const u64 *__restrict__ recs = A.recs;
     constexpr int RSU = (NVT == 1) ? 2 : 4;
+    const size_t cap = (size_t)A.cap;
     for (u64 i = beg + tid; i < end; i += PH_THREADS) {
         typedef u64 v2 __attribute__((ext_vector_type(2)));
-        const v2 q0 = __builtin_nontemporal_load((const v2 *)(recs + RSU * i));
-        const u64 h = q0.x, key = q0.y;
-        if ((unsigned)h == 0xffffffffu && (h >> 32) == 0xffffffffu) continue; // padding of the write-combining scatter
-        u64 val[2] = {0, 0};
-        if (NVT > 1) {
-            const v2 q1 = __builtin_nontemporal_load((const v2 *)(recs + RSU * i + 2));
-            val[0] = q1.x;
-            val[1] = q1.y;
+        u64 h, key, val[2] = {0, 0};
+        if (A.soa) { // planes: headers, keys, values
+            h = __builtin_nontemporal_load(&recs[i]);
+            if (h == WC_SENTINEL) continue;
+            key = __builtin_nontemporal_load(&recs[cap + i]);
+            if (NVT > 1) val[0] = __builtin_nontemporal_load(&recs[2 * cap + i]);
+            if (NVT > 2) val[1] = __builtin_nontemporal_load(&recs[3 * cap + i]);
+        } else {
+            const v2 q0 = __builtin_nontemporal_load((const v2 *)(recs + RSU * i));
+            h = q0.x;
+            key = q0.y;
+            if (h == WC_SENTINEL) continue; // padding of the write-combining scatter
+            if (NVT > 1) {
+                const v2 q1 = __builtin_nontemporal_load((const v2 *)(recs + RSU * i + 2));
+                val[0] = q1.x;
+                val[1] = q1.y;
+            }
         }
         const unsigned lrow = (unsigned)(h >> 32);
         // find-or-insert in the LDS table
@@ -1124,8 +1267,10 @@ int rfx_group_part_accumulate(rfx_ctx *c, const Plan &P, int key_idx, const rfx_
     A.split = (int)((2 * c->num_cus + nparts - 1) / nparts);
     if (A.split < 1) A.split = 1;
     const bool wc_ok = A.nv >= 1 && A.nv <= 3 && nparts <= WC_MAXP && !(c->flags & RFX_TUNE_NO_WRITE_COMBINE);
-    A.wc = wc_ok ? ((A.nv == 1) ? 8 : 4) : 0;
-    const int rsu = A.wc ? ((A.nv == 1) ? 2 : 4) : (1 + A.nv); // u64 per record (array-of-structures when write-combining)
+    // in-process A/B: two planes 35.6 -> 31.7 ms (K9), three planes 29 -> 38 ms (90 KB of LDS: one workgroup per CU) -- so two only
+    A.soa = wc_ok && A.nv == 2 && !(c->flags & RFX_TUNE_NO_SOA_WC);
+    A.wc = wc_ok ? ((A.nv == 1 || A.soa) ? 8 : 4) : 0;
+    const int rsu = (A.wc && !A.soa) ? ((A.nv == 1) ? 2 : 4) : (1 + A.nv); // u64 per record: AoS when write-combining 16/32-byte records, else planes
     A.cap = ((P.nrows + 63) / 64) * 64 + (A.wc ? (i64)nwg * nparts * A.wc : 0);
     const size_t off_bytes = (size_t)nwg * nparts * 8;
     const size_t start_bytes = (size_t)(nparts + 2) * 8;
@@ -1203,8 +1348,9 @@ int rfx_group_part_hash_accumulate(rfx_ctx *c, const Plan &P0, int key_idx, cons
     A.key_idx = key_idx;
     A.narr = narr;
     A.split = 1;
-    A.wc = (A.nv == 1) ? 8 : 4;
-    const int rsu = (A.nv == 1) ? 2 : 4;
+    A.soa = A.nv == 2 && !(c->flags & RFX_TUNE_NO_SOA_WC);
+    A.wc = (A.nv == 1 || A.soa) ? 8 : 4;
+    const int rsu = A.soa ? (1 + A.nv) : ((A.nv == 1) ? 2 : 4);
     A.cap = ((P.nrows + 63) / 64) * 64 + (i64)nwg * A.nparts * A.wc;
     const size_t off_bytes = (size_t)nwg * A.nparts * 8;
     const size_t start_bytes = (size_t)(A.nparts + 2) * 8;

@@ -251,7 +251,7 @@ def test_group_by_sparse_keys_hash_path(eng):
     check_select(eng, host, {"where": (">", "v", 0.5), "by": "k", "s": ("sum", "a")})
 
 
-@pytest.mark.parametrize("flags", [0, 2])
+@pytest.mark.parametrize("flags", [0, 2, 2048])
 def test_sparse_keys_partitioned_hash_path(eng, flags):
     """range > rows on inputs large enough for the partitioned form (hash partition -> LDS tables -> one merge) and, with
     RFX_TUNE_NO_PARTITION, the direct device-wide table: few keys (everything lives in LDS), ~LDS-capacity keys per partition,
@@ -318,7 +318,7 @@ def test_sharded_engine_single_rank(eng):
     assert np.array_equal(sh.where(("<", "a", 1000), d).cpu().numpy(), rfo.where(rfo.mask_of(("<", "a", 1000), host)))
 
 
-@pytest.mark.parametrize("flags", [0, 1, 2, 3, 4, 6, 8, 16, 32, 128, 144, 160, 256, 384, 1024, 1028])
+@pytest.mark.parametrize("flags", [0, 1, 2, 3, 4, 6, 8, 16, 32, 128, 144, 160, 256, 384, 1024, 1028, 2048, 2064])
 def test_group_by_every_code_path_agrees(eng, flags):
     """RFX_TUNE_* force the LDS-table / partitioned (fused and unfused scope) / device-atomic paths: same answers."""
     n = 400_003
@@ -332,7 +332,7 @@ def test_group_by_every_code_path_agrees(eng, flags):
         eng.tune(flags=0)
 
 
-@pytest.mark.parametrize("flags", [0, 128, 256])
+@pytest.mark.parametrize("flags", [0, 128, 256, 2048])
 @pytest.mark.parametrize("thr", [1_000, 100_000, 480_000, 520_000, 990_000])
 def test_filtered_partitioned_group_by(eng, flags, thr):
     """Partitioned path under a filter: <= 50 % selected -> compact (bitmap, ordered compaction of key / value planes / row
