@@ -51,6 +51,9 @@ WORKLOADS = {
                bytes_per_row=8, dtype="f64", kernel="k_filter_aggr<1,1,4,0>"),
     "c2": dict(desc="configs[1]: select sum(a) where a < 100000, a i64 uniform [0,1e6), seed 2", rows=1_000_000_000, bytes_per_row=8, dtype="int64",
                kernel="k_filter_aggr<1,1,8,1>"),
+    "c2_1pct": dict(desc="C2 at 1 % selectivity (a < 10000) -- SURVEY 8d asks for 1 / 10 / 50 %", rows=1_000_000_000, bytes_per_row=8, dtype="int64",
+                    kernel="k_filter_aggr<1,1,8,1>"),
+    "c2_50pct": dict(desc="C2 at 50 % selectivity (a < 500000)", rows=1_000_000_000, bytes_per_row=8, dtype="int64", kernel="k_filter_aggr<1,1,8,1>"),
     "c2b": dict(desc="north-star: select sum(b) where a < 100000, a i64 seed 2, b f64 seed 3", rows=1_000_000_000, bytes_per_row=16, dtype="f64",
                 kernel="k_filter_aggr<2,1,4,1>"),
     "c3": dict(desc="configs[2]: select sum(v) by k, k i64 uniform [0,1e6) seed 4, v f64 seed 5", rows=1_000_000_000, bytes_per_row=16, dtype="f64",
@@ -82,9 +85,9 @@ class Job:
         self.name, self.eng, self.sh, self.rows = name, eng, sharded, rows
         g = eng
         self.key = "k"
-        if name == "c2":
+        if name in ("c2", "c2_1pct", "c2_50pct"):
             self.t = {"a": g.gen_i64(rows, 2, 1_000_000, row0)}
-            self.aggs, self.where = [("sum", "a")], ("<", "a", 100_000)
+            self.aggs, self.where = [("sum", "a")], ("<", "a", {"c2": 100_000, "c2_1pct": 10_000, "c2_50pct": 500_000}[name])
         elif name == "c1":
             self.t = {"v": g.gen_f64(rows, 1, row0)}
             self.aggs, self.where = [("sum", "v")], None
