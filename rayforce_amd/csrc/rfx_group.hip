@@ -44,19 +44,21 @@ __global__ __launch_bounds__(BLOCK) void k_group_dense(const Plan P, const Group
     PredSet<RFX_MAX_PREDS> S;
     predset_load<RFX_MAX_PREDS>(P, S);
 
-    // LDS layout: [first | acc0 | (cnt0) | acc1 | ...] each `range` cells
+    // LDS layout (compact: more groups fit): [acc arrays: u64 x range each] [first: u32 x range, local row, 0xffffffff = none]
+    // [count arrays: u32 x range each].  Local rows and per-workgroup counts fit 32 bits because nrows < 2^32 on this path.
+    int nacc = 0, ncnt = 0;
+    for (int a = 0; a < G.nagg; a++) {
+        nacc++;
+        if (agg_has_cnt(P.aggs[a].kind, P.aggs[a].f64)) ncnt++;
+    }
+    unsigned *lfirst = (unsigned *)(smem + (i64)nacc * range);
+    unsigned *lcnt = lfirst + range;
     if (LDS) {
-        for (i64 i = tid; i < range; i += BLOCK) smem[i] = (u64)RFX_INF_I64_D;
-        int arr = 1;
+        for (i64 i = tid; i < range; i += BLOCK) lfirst[i] = 0xffffffffu;
+        for (i64 i = tid; i < (i64)ncnt * range; i += BLOCK) lcnt[i] = 0;
         for (int a = 0; a < G.nagg; a++) {
-            const PlanAgg ag = P.aggs[a];
-            u64 id = acc_identity(ag.kind, ag.f64);
-            for (i64 i = tid; i < range; i += BLOCK) smem[(i64)arr * range + i] = id;
-            arr++;
-            if (agg_has_cnt(ag.kind, ag.f64)) {
-                for (i64 i = tid; i < range; i += BLOCK) smem[(i64)arr * range + i] = 0;
-                arr++;
-            }
+            const u64 id = acc_identity(P.aggs[a].kind, P.aggs[a].f64);
+            for (i64 i = tid; i < range; i += BLOCK) smem[(i64)a * range + i] = id;
         }
         __syncthreads();
     }
@@ -116,13 +118,14 @@ __global__ __launch_bounds__(BLOCK) void k_group_dense(const Plan P, const Group
             if (slot >= (u64)range) continue; // outside the agreed scope (cannot happen when scope came from these rows)
             const u64 row = (u64)(P.row0 + base + (i64)(e >> 1) * JSTRIDE + (e & 1));
             if (LDS) {
-                if (row < smem[slot]) atomicMin((unsigned long long *)&smem[slot], (unsigned long long)row);
+                const unsigned lrow = (unsigned)(base + (i64)(e >> 1) * JSTRIDE + (e & 1));
+                if (lrow < lfirst[slot]) atomicMin(&lfirst[slot], lrow);
             } else {
                 // plain pre-check: a stale (larger) value only costs a redundant atomic, never a wrong minimum
                 if (row < G.first[slot]) atomicMin((unsigned long long *)&G.first[slot], (unsigned long long)row);
             }
         }
-        int arr = 1;
+        int ci = 0; // index of this aggregate's count array in LDS
         for (int a = 0; a < G.nagg; a++) {
             const PlanAgg ag = P.aggs[a];
             const bool hc = agg_has_cnt(ag.kind, ag.f64);
@@ -134,26 +137,27 @@ __global__ __launch_bounds__(BLOCK) void k_group_dense(const Plan P, const Group
                 if (!((m >> e) & 1u)) continue;
                 const u64 slot = key[e];
                 if (slot >= (u64)range) continue;
-                if (LDS) group_apply(&smem[(i64)arr * range + slot], &smem[(i64)(arr + 1) * range + slot], ag.kind, ag.f64, x[e], ag.skipnull);
+                if (LDS) group_apply(&smem[(i64)a * range + slot], &lcnt[(i64)ci * range + slot], ag.kind, ag.f64, x[e], ag.skipnull);
                 else group_apply(&G.acc[a][slot], G.cnt[a] ? &G.cnt[a][slot] : (u64 *)0, ag.kind, ag.f64, x[e], ag.skipnull);
             }
-            arr += hc ? 2 : 1;
+            ci += hc ? 1 : 0;
         }
     }
 
     if (LDS) {
         __syncthreads();
         for (i64 i = tid; i < range; i += BLOCK) {
-            const u64 f = smem[i];
-            if (f == (u64)RFX_INF_I64_D) continue; // slot untouched by this workgroup
+            const unsigned lf = lfirst[i];
+            if (lf == 0xffffffffu) continue; // slot untouched by this workgroup
+            const u64 f = (u64)(P.row0 + (i64)lf);
             if (f < G.first[i]) atomicMin((unsigned long long *)&G.first[i], (unsigned long long)f);
-            int arr = 1;
+            int ci = 0;
             for (int a = 0; a < G.nagg; a++) {
                 const PlanAgg ag = P.aggs[a];
                 const bool hc = agg_has_cnt(ag.kind, ag.f64);
-                group_merge_cell(&G.acc[a][i], hc ? &G.cnt[a][i] : (u64 *)0, ag.kind, ag.f64, smem[(i64)arr * range + i],
-                                 hc ? smem[(i64)(arr + 1) * range + i] : 0ULL);
-                arr += hc ? 2 : 1;
+                group_merge_cell(&G.acc[a][i], hc ? &G.cnt[a][i] : (u64 *)0, ag.kind, ag.f64, smem[(i64)a * range + i],
+                                 hc ? (u64)lcnt[(i64)ci * range + i] : 0ULL);
+                ci += hc ? 1 : 0;
             }
         }
     }
@@ -227,6 +231,13 @@ static int launch_group(rfx_ctx *c, const Plan &P, const GroupArgs &G, int grid,
 }
 
 // two parts of a table set: aggregates [0, h) and [h, nagg) over the same `first` array (h <= 0: halves)
+// bytes of the compact LDS table set: 8 per aggregate + 4 (first) + 4 per count array, per slot
+static size_t lds_table_bytes(i64 range, const rfx_agg_t *aggs, int nagg) {
+    size_t per = 4;
+    for (int a = 0; a < nagg; a++) per += 8 + (agg_has_cnt(aggs[a].kind, rfx_agg_input_type(&aggs[a]) == RFX_F64) ? 4 : 0);
+    return ((size_t)range * per + 15) & ~(size_t)15;
+}
+
 static int split_tables(const rfx_group_tables_t *t, rfx_group_tables_t *t1, rfx_group_tables_t *t2, int h = 0) {
     if (h <= 0) h = t->nagg / 2;
     *t1 = *t;
@@ -246,13 +257,14 @@ static int split_tables(const rfx_group_tables_t *t, rfx_group_tables_t *t1, rfx
 // leading aggregates the first pass takes, 0 when no split is called for.
 static int lds_pass_split(const rfx_ctx *c, const rfx_agg_t *aggs, const rfx_group_tables_t *t) {
     if (t->nagg < 2 || (c->flags & (RFX_TUNE_NO_LDS_TABLES | RFX_TUNE_NO_LDS_SPLIT))) return 0;
+    if (lds_table_bytes(t->range, aggs, t->nagg) <= ((c->flags & RFX_TUNE_NO_BIG_LDS) ? RFX_LDS_GROUP_BYTES : RFX_LDS_GROUP_BIG_BYTES)) return 0;
     const size_t cap = (c->flags & RFX_TUNE_NO_BIG_LDS) ? RFX_LDS_GROUP_BYTES : RFX_LDS_GROUP_BIG_BYTES;
-    const size_t cell = (size_t)t->range * 8;
+    const size_t cell = (size_t)t->range * 4; // the first-row array
     size_t total = cell, run = cell;
     int h = 0;
     bool open = true;
     for (int a = 0; a < t->nagg; a++) {
-        const size_t mine = cell * (1 + (agg_has_cnt(aggs[a].kind, rfx_agg_input_type(&aggs[a]) == RFX_F64) ? 1 : 0));
+        const size_t mine = (size_t)t->range * (8 + (agg_has_cnt(aggs[a].kind, rfx_agg_input_type(&aggs[a]) == RFX_F64) ? 4 : 0)) + 16;
         if (cell + mine > cap) return 0; // this aggregate alone does not fit
         total += mine;
         if (open && run + mine <= cap) {
@@ -274,9 +286,10 @@ static int group_dense_run(rfx_ctx_t *c, Plan &P, GroupArgs &G, const rfx_agg_t 
         G.cnt[a] = (u64 *)t->d_cnt[a];
         narr += 1 + (agg_has_cnt(aggs[a].kind, rfx_agg_input_type(&aggs[a]) == RFX_F64) ? 1 : 0);
     }
-    size_t lds_bytes = (size_t)narr * (size_t)t->range * 8;
+    (void)narr;
+    size_t lds_bytes = lds_table_bytes(t->range, aggs, t->nagg);
     const size_t lds_cap = (c->flags & RFX_TUNE_NO_BIG_LDS) ? RFX_LDS_GROUP_BYTES : RFX_LDS_GROUP_BIG_BYTES;
-    const bool use_lds = lds_bytes <= lds_cap && !(c->flags & RFX_TUNE_NO_LDS_TABLES);
+    const bool use_lds = lds_bytes <= lds_cap && !(c->flags & RFX_TUNE_NO_LDS_TABLES) && P.nrows < (1LL << 32);
     if (need_materialise) {
         // several keys: fold them on the fly only where the LDS tables make the pass stream; the big-range paths
         // (partitioned, device atomics) want the one materialised key column the reference builds too
@@ -434,6 +447,8 @@ __global__ __launch_bounds__(RFX_BLOCK) void k_slot_gid(const u64 *__restrict__ 
 
 // shared by the dense and the hashed tables
 int rfx_rank_slots(rfx_ctx *c, const u64 *d_first, i64 slots, i64 row_base, i64 total_rows, i64 *ngroups) {
+    c->pc_bitmap = 0; // ranking marks first rows in the context's bitmap
+    c->where_n = -1;
     RFX_REQUIRE(total_rows >= 0, RFX_EINVAL, "total_rows < 0");
     const i64 nchunks = (total_rows + RFX_CHUNK - 1) / RFX_CHUNK;
     int rc = rfx_bitmap_reserve(c, nchunks * RFX_CHUNK);

@@ -101,6 +101,27 @@ __device__ __forceinline__ void group_apply(P64 acc, P64 cnt, int kind, int f64,
     }
 }
 
+// LDS form with a 32-bit count cell (compact tables of k_group_dense).
+__device__ __forceinline__ void group_apply(u64 *acc, unsigned *cnt, int kind, int f64, u64 x, int skip = 0) {
+    switch (kind) {
+        case RFX_AGG_SUM:
+            if (f64) {
+                if (!skip || !rfx_isnan_bits(x)) unsafeAtomicAdd((double *)acc, rfx_as_f64(x));
+            } else if ((i64)x == RFX_NULL_I64_D) atomicAdd(cnt, 1u);
+            else atomicAdd((unsigned long long *)acc, (unsigned long long)x);
+            break;
+        case RFX_AGG_AVG:
+            if (f64 ? !rfx_isnan_bits(x) : ((i64)x != RFX_NULL_I64_D)) {
+                unsafeAtomicAdd((double *)acc, f64 ? rfx_as_f64(x) : (double)(i64)x);
+                atomicAdd(cnt, 1u);
+            }
+            break;
+        default:
+            group_apply(acc, (u64 *)0, kind, f64, x, skip); // MIN / MAX / COUNT never touch the count cell
+            break;
+    }
+}
+
 // Merge one LDS cell into the global tables.
 __device__ __forceinline__ void group_merge_cell(u64 *gacc, u64 *gcnt, int kind, int f64, u64 a, u64 c) {
     switch (kind) {

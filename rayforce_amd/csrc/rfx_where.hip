@@ -462,6 +462,7 @@ extern "C" int rfx_hip_where_begin(rfx_ctx_t *c, const rfx_pred_t *preds, int np
     RFX_REQUIRE(c && count, RFX_EINVAL, "NULL argument");
     RFX_REQUIRE(nrows >= 0, RFX_EINVAL, "nrows < 0");
     c->where_n = -1;
+    c->pc_bitmap = 0; // the context's bitmap is about to be overwritten: a scope pass's selection is gone
     *count = 0;
     if (nrows == 0) {
         c->where_n = 0;
