@@ -309,6 +309,11 @@ int rfx_hip_group_dense_accumulate_keys(rfx_ctx_t *ctx, const void *const *d_key
                                         int nkeys, const rfx_pred_t *preds, int npred, int logic, const rfx_agg_t *aggs,
                                         int64_t nrows, int64_t row0, const rfx_group_tables_t *t);
 
+/* ---- bucketed group keys: (xbar col width), XBARI64 core/ops.h:192-193 ----
+ * d_out[r] = null for a null input, else the largest multiple of `width` (> 0) that is <= d_col[r].  Group on the result
+ * (`by: {t: (xbar ts 60000)}`). */
+int rfx_hip_xbar_i64(rfx_ctx_t *ctx, const int64_t *d_col, int64_t nrows, int64_t width, int64_t *d_out);
+
 /* ---- hash primitives pinned against the reference (core/hash.c:530-542, core/hash.h:86-97) ---- */
 int rfx_hip_hash_fnv1a_i64(rfx_ctx_t *ctx, const int64_t *d_in, int64_t n, uint64_t *d_out);
 int rfx_hip_hash_mix_u64(rfx_ctx_t *ctx, const uint64_t *d_in, int64_t n, uint64_t seed_or_prev, uint64_t *d_out);

@@ -37,6 +37,7 @@ double rfo_avg_f64(const double *x, int64_t l);
 
 int rfo_binop(int op, int ltype, const void *l, int l_atom, int rtype, const void *r, int r_atom, int64_t n, void *out);
 void rfo_aggr_fold(int fn, int type, const void *in, const int64_t *gids, int64_t len, int64_t groups, void *res);
+void rfo_xbar_i64(const int64_t *x, int64_t n, int64_t y, int64_t *out);
 void rfo_scope_i64(const int64_t *values, const int64_t *indices, int64_t len, int64_t *pmin, int64_t *pmax);
 int64_t rfo_group_dense(const int64_t *values, const int64_t *indices, int64_t len, int64_t min, int64_t range, int64_t *hk,
                         int64_t *firsts, int64_t *gids);

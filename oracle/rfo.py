@@ -59,6 +59,7 @@ def lib() -> C.CDLL:
             "rfo_aggr_first": (None, [p, p, p, i64, p]),
             "rfo_binop": (C.c_int, [C.c_int, C.c_int, p, C.c_int, C.c_int, p, C.c_int, i64, p]),
             "rfo_aggr_fold": (None, [C.c_int, C.c_int, p, p, i64, i64, p]),
+            "rfo_xbar_i64": (None, [p, i64, i64, p]),
             "rfo_composite_plan": (C.c_int, [p, p, C.c_int, p, C.POINTER(i64)]),
             "rfo_composite_key": (None, [p, p, p, C.c_int, p, i64, p]),
         }
@@ -236,6 +237,22 @@ def binop(op: str, lhs, rhs) -> np.ndarray:
     return out
 
 
+def xbar(col, width: int) -> np.ndarray:
+    """(xbar col width) over an i64 column."""
+    c = _col(col)
+    out = np.empty(len(c), np.int64)
+    lib().rfo_xbar_i64(_ptr(c), len(c), int(width), _ptr(out))
+    return out
+
+
+def key_column(spec, table):
+    """A `by:` entry: a column name, or ("xbar", column, width)."""
+    if isinstance(spec, tuple):
+        assert spec[0] == "xbar", spec
+        return xbar(table[spec[1]], spec[2])
+    return table[spec]
+
+
 def eval_arg(arg, table):
     """An aggregate's argument: a column name, or (op, lhs, rhs) with operands column names / atoms."""
     if isinstance(arg, tuple):
@@ -297,7 +314,7 @@ def select(query: dict) -> dict:
         ids = where(mask_of(where_spec, table))
     if by is not None:
         if isinstance(by, dict):  # by: {name: col ...} -- several key columns (index_group_list, core/query.c:93-135)
-            names, srcs = list(by.keys()), [table[c] for c in by.values()]
+            names, srcs = list(by.keys()), [key_column(c, table) for c in by.values()]
             if len(srcs) == 1:
                 key = srcs[0]
                 gids, firsts, groups, _ = group_index(key, ids)

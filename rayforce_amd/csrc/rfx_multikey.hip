@@ -138,3 +138,32 @@ extern "C" int rfx_hip_composite_decode(rfx_ctx_t *c, const int64_t *d_comp, int
     RFX_HIP_CHECK(hipGetLastError());
     return RFX_OK;
 }
+
+// ---- time / value bucketing as a group key: (xbar col width), XBARI64 core/ops.h:192-193, ray_xbar_partial core/math.c:1635 ----
+// out = null when x is null, else ((x < 0 ? x + 1 - w : x) / w) * w -- floor to a multiple of w for w > 0 (C division truncates
+// towards zero, hence the shift for negative x).  Only w > 0 is taken here; the adjustment wraps like the reference's.
+__global__ __launch_bounds__(RFX_BLOCK) void k_xbar_i64(const u64 *__restrict__ in, i64 nrows, i64 w, u64 *__restrict__ out) {
+    const i64 npairs = nrows / 2;
+    for (i64 i = blockIdx.x * (i64)RFX_BLOCK + threadIdx.x; i < npairs; i += (i64)gridDim.x * RFX_BLOCK) {
+        const u64x2 t = rfx_ld2(in + 2 * i);
+        u64x2 o;
+        const i64 x0 = (i64)t.x, x1 = (i64)t.y;
+        o.x = (x0 == RFX_NULL_I64_D) ? t.x : (u64)(((x0 < 0) ? (i64)((u64)x0 + 1u - (u64)w) : x0) / w * w);
+        o.y = (x1 == RFX_NULL_I64_D) ? t.y : (u64)(((x1 < 0) ? (i64)((u64)x1 + 1u - (u64)w) : x1) / w * w);
+        *(u64x2 *)(out + 2 * i) = o;
+    }
+    if ((nrows & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+        const i64 x = (i64)in[nrows - 1];
+        out[nrows - 1] = (x == RFX_NULL_I64_D) ? (u64)x : (u64)(((x < 0) ? (i64)((u64)x + 1u - (u64)w) : x) / w * w);
+    }
+}
+
+extern "C" int rfx_hip_xbar_i64(rfx_ctx_t *c, const int64_t *d_col, int64_t nrows, int64_t width, int64_t *d_out) {
+    RFX_REQUIRE(c, RFX_EINVAL, "ctx is NULL");
+    RFX_REQUIRE(width > 0, RFX_EINVAL, "xbar width must be positive on this path");
+    if (nrows <= 0) return RFX_OK;
+    RFX_REQUIRE(d_col && d_out && ((uintptr_t)d_col & 15) == 0 && ((uintptr_t)d_out & 15) == 0, RFX_EINVAL, "16-byte aligned device buffers expected");
+    hipLaunchKernelGGL(k_xbar_i64, dim3(c->num_cus * 8), dim3(RFX_BLOCK), 0, c->stream, (const u64 *)d_col, (i64)nrows, (i64)width, (u64 *)d_out);
+    RFX_HIP_CHECK(hipGetLastError());
+    return RFX_OK;
+}

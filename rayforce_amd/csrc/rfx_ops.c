@@ -43,15 +43,16 @@ static struct {
     /* the host's own built-ins, for recognising function objects inside parsed expressions and for delegation */
     void *f[32];
 } H;
-enum { F_SUM, F_AVG, F_MIN, F_MAX, F_COUNT, F_FIRST, F_EQ, F_NE, F_LT, F_GT, F_LE, F_GE, F_AND, F_OR, F_SELECT, F_ADD, F_SUB, F_MUL, F_FDIV, F_N };
+enum { F_SUM, F_AVG, F_MIN, F_MAX, F_COUNT, F_FIRST, F_EQ, F_NE, F_LT, F_GT, F_LE, F_GE, F_AND, F_OR, F_SELECT, F_ADD, F_SUB, F_MUL, F_FDIV, F_XBAR, F_N };
 static const char *HOST_FN[F_N] = {"ray_sum", "ray_avg", "ray_min", "ray_max", "ray_count", "ray_first", "ray_eq",  "ray_ne",  "ray_lt",  "ray_gt",
-                                   "ray_le",  "ray_ge",  "ray_and", "ray_or",  "ray_select", "ray_add",  "ray_sub", "ray_mul", "ray_fdiv"};
+                                   "ray_le",  "ray_ge",  "ray_and", "ray_or",  "ray_select", "ray_add",  "ray_sub", "ray_mul", "ray_fdiv", "ray_xbar"};
 /* + - * div are recognised inside aggregate arguments only; as stand-alone operators they are the host's.  The
  * standalone object model still needs distinct function objects for them: these stubs are never called by this library. */
 static obj_p x_stub_add(obj_p a, obj_p b) { (void)a; (void)b; return NULL; }
 static obj_p x_stub_sub(obj_p a, obj_p b) { (void)a; (void)b; return NULL; }
 static obj_p x_stub_mul(obj_p a, obj_p b) { (void)a; (void)b; return NULL; }
 static obj_p x_stub_fdiv(obj_p a, obj_p b) { (void)a; (void)b; return NULL; }
+static obj_p x_stub_xbar(obj_p a, obj_p b) { (void)a; (void)b; return NULL; }
 static void *OUR_FN[F_N];
 static char g_err[640];
 static int g_last_gpu = 0;
@@ -65,7 +66,7 @@ int rfx_host_bind(void) {
     OUR_FN[F_COUNT] = (void *)rfx_count; OUR_FN[F_FIRST] = (void *)rfx_first; OUR_FN[F_EQ] = (void *)rfx_eq; OUR_FN[F_NE] = (void *)rfx_ne;
     OUR_FN[F_LT] = (void *)rfx_lt; OUR_FN[F_GT] = (void *)rfx_gt; OUR_FN[F_LE] = (void *)rfx_le; OUR_FN[F_GE] = (void *)rfx_ge;
     OUR_FN[F_AND] = (void *)rfx_and; OUR_FN[F_OR] = (void *)rfx_or; OUR_FN[F_SELECT] = (void *)rfx_select;
-    OUR_FN[F_ADD] = (void *)x_stub_add; OUR_FN[F_SUB] = (void *)x_stub_sub; OUR_FN[F_MUL] = (void *)x_stub_mul; OUR_FN[F_FDIV] = (void *)x_stub_fdiv;
+    OUR_FN[F_ADD] = (void *)x_stub_add; OUR_FN[F_SUB] = (void *)x_stub_sub; OUR_FN[F_MUL] = (void *)x_stub_mul; OUR_FN[F_FDIV] = (void *)x_stub_fdiv; OUR_FN[F_XBAR] = (void *)x_stub_xbar;
     void *v = dlsym(RTLD_DEFAULT, "vector"), *t = dlsym(RTLD_DEFAULT, "table"), *e = dlsym(RTLD_DEFAULT, "eval");
     void *rs = dlsym(RTLD_DEFAULT, "ray_select"), *nu = dlsym(RTLD_DEFAULT, "__NULL_OBJ");
     if (v && t && e && rs && nu && !getenv("RFX_FORCE_STANDALONE")) {
@@ -110,7 +111,7 @@ obj_p rfx_host_fn(const char *name) {
         {">", F_GT, RFX_TYPE_BINARY, RFX_FN_ATOMIC}, {"<=", F_LE, RFX_TYPE_BINARY, RFX_FN_ATOMIC}, {">=", F_GE, RFX_TYPE_BINARY, RFX_FN_ATOMIC},
         {"and", F_AND, RFX_TYPE_VARY, RFX_FN_SPECIAL_FORM}, {"or", F_OR, RFX_TYPE_VARY, RFX_FN_SPECIAL_FORM}, {"select", F_SELECT, RFX_TYPE_UNARY, 0},
         {"+", F_ADD, RFX_TYPE_BINARY, RFX_FN_ATOMIC}, {"-", F_SUB, RFX_TYPE_BINARY, RFX_FN_ATOMIC}, {"*", F_MUL, RFX_TYPE_BINARY, RFX_FN_ATOMIC},
-        {"div", F_FDIV, RFX_TYPE_BINARY, RFX_FN_ATOMIC}};
+        {"div", F_FDIV, RFX_TYPE_BINARY, RFX_FN_ATOMIC}, {"xbar", F_XBAR, RFX_TYPE_BINARY, RFX_FN_ATOMIC}};
     rfx_host_bind();
     for (size_t i = 0; i < sizeof(T) / sizeof(T[0]); i++)
         if (strcmp(T[i].n, name) == 0) {
@@ -415,7 +416,7 @@ rfx_obj_p rfx_select(rfx_obj_p dict) {
         wplan_t wp;
         int flat = 1;
         int64_t *d_ids = NULL, nsel = 0;
-        void *tmp[2 * RFX_MAX_AGGS + 4];
+        void *tmp[2 * RFX_MAX_AGGS + RFX_MAX_KEYS + 4];
         int ntmp = 0;
         int rc = plan_where(tab, where, &wp);
         if (rc == -2) { res = fail_hip("column upload"); goto done; }
@@ -488,7 +489,7 @@ rfx_obj_p rfx_select(rfx_obj_p dict) {
          * columns fold into one composite key (index_group_list_perfect, core/index.c:2308-2424). */
         obj_p kcs[RFX_MAX_KEYS] = {0};
         const void *dks[RFX_MAX_KEYS] = {0};
-        int64_t knames[RFX_MAX_KEYS];
+        int64_t knames[RFX_MAX_KEYS], kxbar[RFX_MAX_KEYS] = {0};
         int nkeys = 0;
         const void *dk = NULL;
         int64_t kmins[RFX_MAX_KEYS], kmaxs[RFX_MAX_KEYS], kmults[RFX_MAX_KEYS], comp_max = 0;
@@ -501,9 +502,15 @@ rfx_obj_p rfx_select(rfx_obj_p dict) {
                 if (bk->len < 1 || bk->len > RFX_MAX_KEYS || bv->len != bk->len) { why = "by: dict shape"; goto out; }
                 for (int64_t i = 0; i < bk->len; i++) {
                     int64_t sym;
+                    obj_p bx = (bv->type == RFX_TYPE_LIST) ? RFX_AS_LIST(bv)[i] : NULL;
+                    kxbar[nkeys] = 0;
                     if (bv->type == RFX_TYPE_SYMBOL) sym = RFX_AS_I64(bv)[i];
-                    else if (bv->type == RFX_TYPE_LIST && RFX_AS_LIST(bv)[i]->type == -RFX_TYPE_SYMBOL) sym = RFX_AS_LIST(bv)[i]->i64;
-                    else { why = "by: key is an expression"; goto out; }
+                    else if (bx && bx->type == -RFX_TYPE_SYMBOL) sym = bx->i64;
+                    else if (bx && bx->type == RFX_TYPE_LIST && bx->len == 3 && fn_id(RFX_AS_LIST(bx)[0]) == F_XBAR &&
+                             RFX_AS_LIST(bx)[1]->type == -RFX_TYPE_SYMBOL && RFX_AS_LIST(bx)[2]->type == -RFX_TYPE_I64 && RFX_AS_LIST(bx)[2]->i64 > 0) {
+                        sym = RFX_AS_LIST(bx)[1]->i64; /* (xbar column width): bucketed key, evaluated on the device below */
+                        kxbar[nkeys] = RFX_AS_LIST(bx)[2]->i64;
+                    } else { why = "by: key is an expression other than (xbar column positive-width)"; goto out; }
                     knames[nkeys] = RFX_AS_I64(bk)[i];
                     kcs[nkeys++] = table_col(tab, sym);
                 }
@@ -515,6 +522,14 @@ rfx_obj_p rfx_select(rfx_obj_p dict) {
                     goto out;
                 }
                 if (resident(kcs[i], 0, &dks[i]) != RFX_OK) { res = fail_hip("column upload"); goto done; }
+                if (kxbar[i] > 0) { /* ray_xbar, core/math.c:1635: the reference evaluates the bucket column before grouping, so do we */
+                    if (kcs[i]->type == RFX_TYPE_SYMBOL) { why = "xbar over a symbol column"; goto out; }
+                    void *xb = NULL;
+                    if (rfx_hip_malloc(g_ctx, &xb, (size_t)(nrows ? nrows : 1) * 8) != RFX_OK) { res = fail_hip("xbar key"); goto done; }
+                    tmp[ntmp++] = xb;
+                    if (rfx_hip_xbar_i64(g_ctx, (const int64_t *)dks[i], nrows, kxbar[i], (int64_t *)xb) != RFX_OK) { res = fail_hip("xbar key"); goto done; }
+                    dks[i] = xb;
+                }
             }
             /* where: + several keys: the reference's own result is defective (its composite index drops the filter, so key
              * columns and aggregates are taken from the wrong rows -- DESIGN.md "reference defects"); leave that to the host

@@ -503,15 +503,16 @@ class Engine:
                     r["results"] += part["results"]
             return r
         multi = None
-        if isinstance(key, (list, tuple)) and len(key) == 1:
+        is_xbar = lambda k: isinstance(k, tuple) and len(k) == 3 and k[0] == "xbar"
+        if isinstance(key, (list, tuple)) and not is_xbar(key) and len(key) == 1:
             key = key[0]
-        if isinstance(key, (list, tuple)):
+        if isinstance(key, (list, tuple)) and not is_xbar(key):
             # several key columns -> one composite dense key (index_group_list_perfect, core/index.c:2308-2424)
-            kcols = [self._check_col(self._resolve(k, table)) for k in key]
+            kcols = [self._key_col(k, table) for k in key]
             tmax, seen, multi = self._composite_plan(kcols, where, table, _collective)
             key = kcols[0]
         else:
-            key = self._check_col(self._resolve(key, table))
+            key = self._key_col(key, table)
         if key.dtype != torch.int64:
             raise RfxError("group key must be i64 on this path (f64 keys group on their bit pattern: view as int64)")
         n = key.numel()
@@ -614,6 +615,18 @@ class Engine:
                 r["key_columns"].append(kc)
         self.sync()
         return r
+
+    def _key_col(self, spec, table) -> torch.Tensor:
+        """A `by:` entry: a column, or ("xbar", column, width) -- the bucketed key is evaluated once into a scratch column
+        (ray_xbar, core/math.c:1635; the reference does the same before grouping)."""
+        if isinstance(spec, tuple) and len(spec) == 3 and spec[0] == "xbar":
+            col = self._check_col(self._resolve(spec[1], table))
+            if col.dtype != torch.int64:
+                raise RfxError("xbar over a non-integer column is not on this path")
+            out = self.empty(col.numel())
+            L.check(self.lib.rfx_hip_xbar_i64(self._ctx, col.data_ptr(), col.numel(), int(spec[2]), out.data_ptr()), "xbar_i64")
+            return out
+        return self._check_col(self._resolve(spec, table))
 
     def _composite_plan(self, kcols, where, table, _collective):
         """Scopes of every key column (through the predicates) and the reference's multiplier plan (core/index.c:2340-2383).

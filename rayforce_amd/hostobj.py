@@ -133,7 +133,7 @@ def select_dict(query: Dict, tab: int) -> int:
     for k, v in query.items():
         keys.append(k)
         if k == "by" and isinstance(v, dict):  # by: {name: column ...} -> DICT of SYMBOL keys, LIST of symbol atoms
-            vals.append(lib().rfx_host_dict(symbols(list(v.keys())), list_of([atom(c) for c in v.values()])))
+            vals.append(lib().rfx_host_dict(symbols(list(v.keys())), list_of([expr(c) for c in v.values()])))  # column symbol or (xbar col w)
         else:
             vals.append(atom(v) if k == "by" else expr(v))
     keys.append("from")

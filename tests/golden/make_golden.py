@@ -195,6 +195,28 @@ def main():
                     arrays[f"xagg_{xi_}_{wi}_{bi}_{o}"] = r[o]
         cases.append({"kind": "xagg", "index": xi_, "n": n, "seed": seed, "keys": keys})
 
+    # ---- 4d. bucketed keys: (xbar col width), truth table on special values and a grouped query ----
+    xb = np.array([0, 1, -1, 9, 10, 11, -9, -10, -11, NULL, 2**63 - 1, -(2**63) + 1, 25, -25], np.int64)
+    arrays["xbar_in"] = xb
+    t = gen_table(70_003, 61, 4000, False)
+    t["ts"] = rfo.gen_i64(70_003, 62, 60_000) - 30_000
+    with ref.Session() as s:
+        s.put("xb", xb)
+        s.table("t", t)
+        for w in (1, 3, 10, 60000):
+            s.out(f"xbar_{w}", f"(xbar xb {w})")
+        s.eval("(set r (select {s: (sum v) c: (count a) from: t by: {b: (xbar ts 1000)}}))")
+        s.eval("(set r2 (select {mx: (max a) from: t where: (> v 0.5) by: {k: k b: (xbar ts 20000)}}))")
+        for o in ("b", "s", "c"):
+            s.out(f"xbarq_{o}", f"(at r '{o})")
+        for o in ("k", "b", "mx"):
+            s.out(f"xbarq2_{o}", f"(at r2 '{o})")
+        r = s.run(threads=8)
+    for k, v in r.items():
+        if k.startswith("xbar"):
+            arrays[k] = v
+    cases.append({"kind": "xbar", "widths": [1, 3, 10, 60000], "table": dict(n=70_003, seed=61, keys=4000)})
+
     # ---- 5. null-semantics known answers (verified against the reference here) ----
     k = np.array([1, 1, 2, 3, 3], np.int64)
     v = np.array([1, NULL, 5, NULL, NULL], np.int64)

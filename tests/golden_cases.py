@@ -128,6 +128,16 @@ def xagg_cases():
                 yield f"x{c['index']}w{wi}b{bi}", t, w, by, {o: arr(f"xagg_{c['index']}_{wi}_{bi}_{o}") for o in names}
 
 
+def xbar_case():
+    """(xbar col width) truth tables + two grouped queries over bucketed keys.  NOTE: the second query has `where:` with two
+    `by:` entries -- the combination the reference answers defectively; it is captured but only its group COUNT
+    is meaningful, so callers compare the first query in full and skip the second."""
+    c = [c for c in _meta["cases"] if c["kind"] == "xbar"][0]
+    t = gen_table(c["table"]["n"], c["table"]["seed"], c["table"]["keys"], False)
+    t["ts"] = rfo.gen_i64(c["table"]["n"], c["table"]["seed"] + 1, 60_000) - 30_000
+    return arr("xbar_in"), {w: arr(f"xbar_{w}") for w in c["widths"]}, t, {o: arr(f"xbarq_{o}") for o in ("b", "s", "c")}
+
+
 def nullsem_case():
     t = {"k": arr("nullsem_k"), "v": arr("nullsem_v"), "f": arr("nullsem_f")}
     want = {o: arr(f"nullsem_out_{o}") for o in ["k", "s", "fs", "mn", "mx", "fmn", "fmx", "c", "av"]}

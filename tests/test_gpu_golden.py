@@ -67,6 +67,19 @@ def test_aggregates_over_expressions(eng, case):
         G.same(got[o].cpu().numpy(), want[o], o)
 
 
+def test_xbar_buckets(eng):
+    x, tables, t, want = G.xbar_case()
+    from rayforce_amd import _lib as L
+    d = eng.column(x)
+    for w, ref_out in tables.items():
+        out = eng.empty(len(x))
+        L.check(eng.lib.rfx_hip_xbar_i64(eng._ctx, d.data_ptr(), len(x), w, out.data_ptr()))
+        assert np.array_equal(out.cpu().numpy(), ref_out), w
+    got = eng.select({"from": {k: eng.column(v) for k, v in t.items()}, "by": {"b": ("xbar", "ts", 1000)}, "s": ("sum", "v"), "c": ("count", "a")})
+    for o in want:
+        G.same(got[o].cpu().numpy(), want[o], o)
+
+
 def test_group_by_sparse_keys(eng):
     t, want = G.sparse_case()
     got = eng.select({"from": dev(eng, t), "by": "k", "sf": ("sum", "v"), "c": ("count", "a"), "mxi": ("max", "a")})

@@ -464,3 +464,22 @@ def test_expression_aggregates_refusals(eng):
         eng.select({"from": d, "f": ("first", ("*", "a", "v")), "by": "k"})
     with pytest.raises(RfxError, match="unsupported expression"):
         eng.select({"from": d, "s": ("sum", ("/", "a", "k"))})
+
+
+def test_group_by_xbar_buckets(eng):
+    """by: {b: (xbar a width)} -- bucketed keys (negative values, dense and sparse bucket ranges, one or two key columns, with
+    where:).  Null keys are left out: they take the sparse path, where one null group here stands against one group per null
+    row in the reference (DESIGN.md deviation 3)."""
+    n = 300_007
+    host = table(n, keys=5000)
+    host["ts"] = rfo.gen_i64(n, 55, 10**9) - 5 * 10**8
+    for by in ({"b": ("xbar", "ts", 60_000)}, {"b": ("xbar", "ts", 1_000_003)}, {"b": ("xbar", "a", 7)}, {"k": "k", "b": ("xbar", "a", 250_000)}):
+        q = {"by": by, "s": ("sum", "v"), "c": ("count", "a"), "mx": ("max", "w")}
+        try:
+            check_select(eng, host, q)
+            check_select(eng, host, {**q, "where": (">", "v", 0.4)})
+        except rfo.NotPerfect:
+            pass
+    from rayforce_amd._lib import RfxError
+    with pytest.raises(RfxError, match="width must be positive"):
+        eng.select({"from": dev(eng, host), "by": {"b": ("xbar", "a", 0)}, "s": ("sum", "v")})

@@ -119,6 +119,16 @@ def test_select_expression_aggregates(ops):
         run_select(ops, host, {"c": ("count", ("*", "a", "v"))})
 
 
+def test_select_by_xbar(ops):
+    host = host_table(300_007, keys=4000)
+    q = {"s": ("sum", "v"), "c": ("count", "a")}
+    for by in ({"b": ("xbar", "a", 1000)}, {"k": "k", "b": ("xbar", "a", 250_000)}):
+        check(run_select(ops, host, {**q, "by": by}), rfo.select({"from": host, **q, "by": by}))
+        assert ops.rfx_last_select_on_gpu() == 1
+    check(run_select(ops, host, {**q, "by": {"b": ("xbar", "a", 1000)}, "where": (">", "v", 0.5)}),
+          rfo.select({"from": host, **q, "by": {"b": ("xbar", "a", 1000)}, "where": (">", "v", 0.5)}))
+
+
 def test_nested_tree_and_projection(ops):
     host = host_table(200_003)
     nested = ("and", ("or", ("<", "a", 1000), (">", "v", 0.9)), ("!=", "k", 3))

@@ -118,6 +118,15 @@ def test_aggregates_over_expressions(case):
         G.same(got[o], want[o], o)
 
 
+def test_xbar_buckets():
+    x, tables, t, want = G.xbar_case()
+    for w, ref_out in tables.items():
+        assert np.array_equal(rfo.xbar(x, w), ref_out), w
+    got = rfo.select({"from": t, "by": {"b": ("xbar", "ts", 1000)}, "s": ("sum", "v"), "c": ("count", "a")})
+    for o in want:
+        G.same(got[o], want[o], o)
+
+
 def test_null_semantics():
     t, want, scalar_sum = G.nullsem_case()
     got = rfo.select({"from": t, "by": "k", "s": ("sum", "v"), "fs": ("sum", "f"), "mn": ("min", "v"), "mx": ("max", "v"), "fmn": ("min", "f"),
