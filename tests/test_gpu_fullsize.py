@@ -84,3 +84,52 @@ def test_c3_group_by_full_size(eng, big):
     r3 = eng.group_by("k", [("count", "v")], ("<", "a", 100_000), big)
     (sel,), _ = eng.filter_aggr([("count", "a")], ("<", "a", 100_000), big)
     assert int(r3["results"][0].sum()) == sel and bool((r3["first"][1:] > r3["first"][:-1]).all())
+
+
+def test_c3w_filtered_group_by_full_size(eng, big):
+    """The metric's literal shape at 1e9 rows: compaction-first path vs the write-combining scatter with predicates (tune 256)."""
+    w = ("<", "a", 100_000)
+    r = eng.group_by("k", [("sum", "v"), ("count", "a"), ("min", "a")], w, big)
+    (sel, tot), _ = eng.filter_aggr([("count", "a"), ("sum", "v")], w, big)
+    assert int(r["results"][1].sum()) == sel and abs(float(r["results"][0].sum()) - tot) <= 1e-9 * tot
+    assert bool((r["first"][1:] > r["first"][:-1]).all()) and torch.equal(eng.at_ids(big["k"], r["first"]), r["keys"])
+    assert bool((eng.at_ids(big["a"], r["first"]) < 100_000).all()) and int(r["results"][2].max()) < 100_000
+    eng.tune(flags=256)  # RFX_TUNE_NO_SEL_COMPACT
+    try:
+        r2 = eng.group_by("k", [("sum", "v"), ("count", "a"), ("min", "a")], w, big)
+    finally:
+        eng.tune(flags=0)
+    assert torch.equal(r2["keys"], r["keys"]) and torch.equal(r2["first"], r["first"])
+    assert torch.equal(r2["results"][1], r["results"][1]) and torch.equal(r2["results"][2], r["results"][2])
+    assert torch.allclose(r2["results"][0], r["results"][0], rtol=1e-9, atol=0)
+
+
+def test_multikey_expression_and_sparse_full_size(eng, big):
+    """1e9 rows through the widened paths: two by: columns, an expression aggregate, bucketed keys, sparse keys (partitioned hash
+    path vs the device-wide table)."""
+    id1, id2 = eng.gen_i64(N, 10, 100), eng.gen_i64(N, 11, 100)
+    r = eng.group_by([id1, id2], [("sum", big["v"]), ("count", big["a"])], None, None)
+    assert r["groups"] == 10_000 and int(r["results"][1].sum()) == N
+    k1, k2 = r["key_columns"]
+    assert torch.equal(eng.at_ids(id1, r["first"]), k1) and torch.equal(eng.at_ids(id2, r["first"]), k2)
+    assert int(torch.unique(k1 * 100 + k2).numel()) == 10_000 and bool((r["first"][1:] > r["first"][:-1]).all())
+    del id1, id2, r
+    # sum(v * a) = sum over groups of sum(v * a); i64 product sum exact
+    (xs, xi), _ = eng.filter_aggr([("sum", ("*", big["v"], big["a"])), ("sum", ("*", big["a"], 3))], ("<", big["a"], 500_000), None)
+    rg = eng.group_by(("xbar", big["a"], 1000), [("sum", ("*", big["v"], big["a"])), ("sum", ("*", big["a"], 3)), ("count", big["a"])],
+                      ("<", big["a"], 500_000), None)
+    assert rg["groups"] == 500 and int(rg["results"][1].sum()) == xi and abs(float(rg["results"][0].sum()) - xs) <= 1e-9 * abs(xs)
+    assert bool((rg["keys"] % 1000 == 0).all())
+    del rg
+    # sparse keys: 1e6 distinct keys spread over 1e12
+    ks = big["k"] * 1_000_003 - 77
+    r = eng.group_by(ks, [("sum", big["v"]), ("count", big["a"])], None, None)
+    assert r["groups"] == 1_000_000 and not r["dense"] and int(r["results"][1].sum()) == N
+    assert torch.equal(eng.at_ids(ks, r["first"]), r["keys"]) and bool((r["first"][1:] > r["first"][:-1]).all())
+    eng.tune(flags=2)
+    try:
+        r2 = eng.group_by(ks, [("sum", big["v"]), ("count", big["a"])], None, None)
+    finally:
+        eng.tune(flags=0)
+    assert torch.equal(r2["keys"], r["keys"]) and torch.equal(r2["results"][1], r["results"][1])
+    assert torch.allclose(r2["results"][0], r["results"][0], rtol=1e-9, atol=0)
