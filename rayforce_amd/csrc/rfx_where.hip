@@ -253,8 +253,17 @@ __global__ __launch_bounds__(RFX_BLOCK) void k_emit_ids_wc(const u64 *__restrict
     const u64 below = lanemask_lt();
     i64 gpos = chunk_off[q0]; // global output index of the ring's head
     unsigned head = 0, fill = 0;
+    u64 nxt[8]; // the next chunk's bitmap words, fetched while the current chunk goes through the ring
+#pragma unroll
+    for (int i = 0; i < 8; i++) nxt[i] = bitmap[q0 * 8 + i];
     for (i64 q = q0; q < q1; q++) {
-        const u64 *w = bitmap + q * 8;
+        u64 w[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) w[i] = nxt[i];
+        if (q + 1 < q1) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) nxt[i] = bitmap[(q + 1) * 8 + i];
+        }
 #pragma unroll
         for (int g = 0; g < 4; g++) {
             const u64 w0 = w[2 * g], w1 = w[2 * g + 1];
