@@ -1,6 +1,6 @@
 """Randomised (fixed-seed) select / where / by shapes against the CPU oracle: sizes around every tile / chunk / threshold
 boundary, key counts that land on each group-by path (64 KB LDS tables, 160 KB LDS tables, partitioned, compaction-first,
-device atomics, hashed), 0-3 predicates of any selectivity, 1-5 aggregates (some over element-wise expressions), nulls / NaNs, one or two key columns."""
+device atomics, hashed), 0-3 predicates of any selectivity, 1-5 aggregates (some over element-wise expressions), nulls / NaNs, one to three key columns, bucketed (xbar) keys, column-to-column predicates."""
 import numpy as np
 import pytest
 
@@ -20,6 +20,8 @@ def make_case(rng):
     t = {"k": rfo.gen_i64(n, int(rng.integers(1, 1 << 30)), keys) + int(rng.integers(-5, 5)),
          "j": rfo.gen_i64(n, int(rng.integers(1, 1 << 30)), int(rng.choice([2, 5, 40]))) - 1,
          "a": rfo.gen_i64(n, int(rng.integers(1, 1 << 30)), 1_000_000),
+         "ts": rfo.gen_i64(n, int(rng.integers(1, 1 << 30)), 1_000_000) - 500_000,  # never null: bucketed-key source (a null key takes
+                                                                                   # the sparse path, DESIGN.md deviation 3)
          "v": rfo.gen_f64(n, int(rng.integers(1, 1 << 30))),
          "w": rfo.gen_f64(n, int(rng.integers(1, 1 << 30))) - 0.5}
     if rng.random() < 0.4:
@@ -39,6 +41,8 @@ def make_case(rng):
             rhs = int(rng.integers(0, keys + 1))
         else:
             rhs = float(rng.choice([0.05, 0.25, 0.5, 0.9])) - (0.5 if col == "w" else 0.0)
+        if rng.random() < 0.15:  # column (x) column comparison, mixed types included
+            rhs = str(rng.choice(["a", "v", "w", "k", "j"]))
         preds.append((op, col, rhs))
     where = None
     if len(preds) == 1:
@@ -57,10 +61,15 @@ def make_case(rng):
     if where is not None:
         q["where"] = where
     mode = rng.random()
-    if mode < 0.55:
+    small = abs(int(t["k"].max()) if n else 0) < 2**40
+    if mode < 0.45:
         q["by"] = "k"
-    elif mode < 0.75 and abs(int(t["k"].max()) if n else 0) < 2**40:
+    elif mode < 0.6 and small:
         q["by"] = {"g1": "k", "g2": "j"}
+    elif mode < 0.68 and small:
+        q["by"] = {"g1": "j", "g2": ("xbar", "ts", int(rng.choice([1000, 50_000, 333_333]))), "g3": "k"}
+    elif mode < 0.78:
+        q["by"] = {"b": ("xbar", str(rng.choice(["ts", "k"])), int(rng.choice([1, 7, 1000, 250_000])))}
     return t, q
 
 
