@@ -848,11 +848,29 @@ static obj_p fold_op(int f, int kind, obj_p x) {
     rfx_host_bind();
     if (!x) return fail("aggregate: null argument");
     if (x->type == RFX_TYPE_MAPFILTER) {
-        obj_p g = rfx_at(RFX_AS_LIST(x)[0], RFX_AS_LIST(x)[1]);
-        if (g->type == RFX_TYPE_ERR) return g;
-        obj_p r = fold_op(f, kind, g);
-        H.drop(g);
-        return r;
+        /* the lazy (val, ids) pair an FN_AGGR built-in receives (core/eval.c:723-728): gather on the device, fold there --
+         * the filtered vector the reference would materialise (filter_collect) never exists on the host */
+        obj_p val = RFX_AS_LIST(x)[0], ids = RFX_AS_LIST(x)[1];
+        if (!(val->type > 0 && col_ctype(val) && val->type != RFX_TYPE_SYMBOL) || ids->type != RFX_TYPE_I64) {
+            if (H.bound == 1 && H.f[f]) return ((rfx_unary_f)H.f[f])(x);
+            return fail("aggregate: only (i64/f64 vector, i64 ids) MAPFILTER pairs run on the MI355X path");
+        }
+        if (ensure_ctx() != RFX_OK) return fail_hip("no usable MI355X");
+        const void *dv, *di;
+        if (resident(val, 0, &dv) != RFX_OK || resident(ids, 0, &di) != RFX_OK) return fail_hip("column upload");
+        void *dg = NULL;
+        rfx_agg_t a;
+        memset(&a, 0, sizeof(a));
+        a.col_type = col_ctype(val);
+        a.kind = kind;
+        rfx_value_t v;
+        int ok = rfx_hip_malloc(g_ctx, &dg, (size_t)(ids->len ? ids->len : 1) * 8) == RFX_OK &&
+                 rfx_hip_gather(g_ctx, dv, (const int64_t *)di, ids->len, dg) == RFX_OK;
+        a.d_col = dg;
+        ok = ok && rfx_hip_filter_aggr_host(g_ctx, NULL, 0, RFX_AND, &a, 1, ids->len, &v, NULL) == RFX_OK;
+        if (dg) rfx_hip_free(g_ctx, dg);
+        if (!ok) return fail_hip("filter_aggr over a MAPFILTER");
+        return value_atom(&v);
     }
     if (!(x->type > 0 && col_ctype(x) && x->type != RFX_TYPE_SYMBOL)) {
         if (H.bound == 1 && H.f[f]) return ((rfx_unary_f)H.f[f])(x);

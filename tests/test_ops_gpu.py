@@ -179,6 +179,30 @@ def test_single_operators(ops):
         ops.rfx_host_drop(o)
 
 
+def test_lazy_mapfilter_aggregates(ops):
+    """An FN_AGGR built-in receives the lazy TYPE_MAPFILTER pair (val, ids) (core/eval.c:723-728, core/filter.c:44-46): gathered and
+    folded on the device."""
+    n = 200_003
+    host = host_table(n)
+    host["a"][::97] = NULL
+    ids = rfo.where(rfo.cmp("<", host["a"], 400_000))
+    for col, fns in (("a", ("sum", "min", "max", "avg", "count")), ("v", ("sum", "min", "max", "avg"))):
+        val, idv = H.vector(host[col]), H.vector(ids)
+        pair = H.list_of([val, idv])
+        H.header(pair).type = 71  # TYPE_MAPFILTER
+        for fn in fns:
+            r = getattr(ops, f"rfx_{fn}")(pair)
+            assert not H.is_error(r), H.error_text(r)
+            want = rfo.fold(fn, host[col][ids])
+            got = C.c_double.from_address(r + 8).value if H.header(r).type == -H.T_F64 else C.c_int64.from_address(r + 8).value
+            if isinstance(want, float):
+                assert abs(got - want) <= 1e-9 * abs(want), (col, fn)
+            else:
+                assert got == (len(ids) if fn == "count" else want), (col, fn, got, want)
+            ops.rfx_host_drop(r)
+        ops.rfx_host_drop(pair)
+
+
 def test_residency_cache(ops):
     ops.rfx_cache_clear()
     host = host_table(200_000)
