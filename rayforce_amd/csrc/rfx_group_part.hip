@@ -276,18 +276,42 @@ int rfx_part_scope_hist(rfx_ctx *c, const int64_t *d_key, const rfx_pred_t *pred
 }
 
 // ---- offsets: offsets[w][p] = part_start[p] + sum_{w' < w} counts[w'][p] ----
+// Exclusive scan down every partition's column of the [nwg][nparts] count matrix.  One thread per partition walking nwg
+// dependent loads was 0.18 ms; here a workgroup takes 32 partitions x 8 slices of workgroups: slice sums, an 8-step LDS scan,
+// then the slice's own running offsets.
+#define COLSCAN_P 32
+#define COLSCAN_S (RFX_BLOCK / COLSCAN_P)
 __global__ __launch_bounds__(RFX_BLOCK) void k_part_colscan(const PartArgs A, int nwg) {
-    const int p = blockIdx.x * RFX_BLOCK + threadIdx.x;
-    if (p >= A.nparts) return;
-    u64 run = 0;
-    for (int w = 0; w < nwg; w++) {
+    __shared__ u64 slice_sum[COLSCAN_S][COLSCAN_P];
+    const int pl = threadIdx.x % COLSCAN_P, sl = threadIdx.x / COLSCAN_P;
+    const int p = blockIdx.x * COLSCAN_P + pl;
+    const int per = (nwg + COLSCAN_S - 1) / COLSCAN_S;
+    const int w0 = sl * per, w1 = (w0 + per < nwg) ? w0 + per : nwg;
+    const bool live = p < A.nparts;
+    u64 sum = 0;
+    if (live)
+        for (int w = w0; w < w1; w++) {
+            u64 c = A.offsets[(size_t)w * A.nparts + p];
+            if (A.wc) c = (c + A.wc - 1) / A.wc * A.wc; // every (workgroup, partition) region is whole 128-byte store groups
+            sum += c;
+        }
+    slice_sum[sl][pl] = sum;
+    __syncthreads();
+    u64 run = 0, total = 0;
+    for (int s2 = 0; s2 < COLSCAN_S; s2++) {
+        const u64 v = slice_sum[s2][pl];
+        if (s2 < sl) run += v;
+        total += v;
+    }
+    if (!live) return;
+    for (int w = w0; w < w1; w++) {
         const size_t i = (size_t)w * A.nparts + p;
         u64 c = A.offsets[i];
-        if (A.wc) c = (c + A.wc - 1) / A.wc * A.wc; // every (workgroup, partition) region is whole 128-byte store groups
+        if (A.wc) c = (c + A.wc - 1) / A.wc * A.wc;
         A.offsets[i] = run;
         run += c;
     }
-    A.part_start[p] = run; // column total, scanned by k_part_startscan
+    if (sl == 0) A.part_start[p] = total; // column total, scanned by k_part_startscan
 }
 __global__ __launch_bounds__(PART_MAX) void k_part_startscan(const PartArgs A) {
     __shared__ u64 tmp[PART_MAX + 1];
@@ -939,7 +963,7 @@ static int launch_part(rfx_ctx *c, const Plan &P, const PartArgs &A, int nwg) {
             default: launch_hist<4>(c, Ph, Ah, nwg); break;
         }
     }
-    hipLaunchKernelGGL(k_part_colscan, dim3((A.nparts + RFX_BLOCK - 1) / RFX_BLOCK), dim3(RFX_BLOCK), 0, c->stream, A, nwg);
+    hipLaunchKernelGGL(k_part_colscan, dim3((A.nparts + COLSCAN_P - 1) / COLSCAN_P), dim3(RFX_BLOCK), 0, c->stream, A, nwg);
     hipLaunchKernelGGL(k_part_startscan, dim3(1), dim3(PART_MAX), 0, c->stream, A);
     switch (A.nv) {
         case 0: launch_scatter<NC, 0>(c, P, A, nwg); break;
