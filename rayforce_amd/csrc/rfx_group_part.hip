@@ -1045,26 +1045,40 @@ __global__ __launch_bounds__(PH_THREADS) void k_part_hash_aggregate(const Plan P
     const u64 *__restrict__ recs = A.recs;
     constexpr int RSU = (NVT == 1) ? 2 : 4;
     const size_t cap = (size_t)A.cap;
-    for (u64 i = beg + tid; i < end; i += PH_THREADS) {
+    constexpr int RU = 4; // records in flight per lane (8: 15.5 ms against 10.4 -- registers): the loads of a batch are issued before any of them is hashed
+    for (u64 i0 = beg; i0 < end; i0 += (u64)PH_THREADS * RU) {
         typedef u64 v2 __attribute__((ext_vector_type(2)));
-        u64 h, key, val[2] = {0, 0};
-        if (A.soa) { // planes: headers, keys, values
-            h = __builtin_nontemporal_load(&recs[i]);
-            if (h == WC_SENTINEL) continue;
-            key = __builtin_nontemporal_load(&recs[cap + i]);
-            if (NVT > 1) val[0] = __builtin_nontemporal_load(&recs[2 * cap + i]);
-            if (NVT > 2) val[1] = __builtin_nontemporal_load(&recs[3 * cap + i]);
-        } else {
-            const v2 q0 = __builtin_nontemporal_load((const v2 *)(recs + RSU * i));
-            h = q0.x;
-            key = q0.y;
-            if (h == WC_SENTINEL) continue; // padding of the write-combining scatter
-            if (NVT > 1) {
-                const v2 q1 = __builtin_nontemporal_load((const v2 *)(recs + RSU * i + 2));
-                val[0] = q1.x;
-                val[1] = q1.y;
+        u64 hs[RU], keys[RU], vals[RU][2];
+        bool live[RU];
+#pragma unroll
+        for (int r = 0; r < RU; r++) {
+            const u64 i = i0 + (u64)r * PH_THREADS + tid;
+            live[r] = i < end;
+            hs[r] = WC_SENTINEL;
+            keys[r] = 0;
+            vals[r][0] = vals[r][1] = 0;
+            if (!live[r]) continue;
+            if (A.soa) { // planes: headers, keys, values
+                hs[r] = __builtin_nontemporal_load(&recs[i]);
+                keys[r] = __builtin_nontemporal_load(&recs[cap + i]);
+                if (NVT > 1) vals[r][0] = __builtin_nontemporal_load(&recs[2 * cap + i]);
+                if (NVT > 2) vals[r][1] = __builtin_nontemporal_load(&recs[3 * cap + i]);
+            } else {
+                const v2 q0 = __builtin_nontemporal_load((const v2 *)(recs + RSU * i));
+                hs[r] = q0.x;
+                keys[r] = q0.y;
+                if (NVT > 1) {
+                    const v2 q1 = __builtin_nontemporal_load((const v2 *)(recs + RSU * i + 2));
+                    vals[r][0] = q1.x;
+                    vals[r][1] = q1.y;
+                }
             }
         }
+#pragma unroll
+        for (int r = 0; r < RU; r++) {
+        const u64 h = hs[r], key = keys[r];
+        const u64 val[2] = {vals[r][0], vals[r][1]};
+        if (!live[r] || h == WC_SENTINEL) continue; // beyond the partition / padding of the write-combining scatter
         const unsigned lrow = (unsigned)(h >> 32);
         // find-or-insert in the LDS table
         int idx = -1;
@@ -1104,6 +1118,7 @@ __global__ __launch_bounds__(PH_THREADS) void k_part_hash_aggregate(const Plan P
                 const u64 x = (plane[a] == 1) ? val[0] : ((plane[a] == 2) ? val[1] : 0ULL);
                 group_apply(&X.H.acc[a][g], X.H.cnt[a] ? &X.H.cnt[a][g] : (u64 *)0, kind[a], f64[a], x, skip[a]);
             }
+        }
         }
     }
     __syncthreads();
