@@ -405,6 +405,8 @@ rfx_obj_p rfx_select(rfx_obj_p dict) {
     if (!tab || tab->type == RFX_TYPE_ERR) return tab;
     obj_p res = NULL;
     const char *why = NULL;
+    void *tmp[2 * RFX_MAX_AGGS + RFX_MAX_KEYS + 4]; /* device scratch of this query (gathered columns, bucket / composite keys): freed at `done` */
+    int ntmp = 0;
     obj_p where = dict_get(dict, "where"), by = dict_get(dict, "by");
     obj_p dkeys = RFX_AS_LIST(dict)[0], dvals = RFX_AS_LIST(dict)[1];
     int64_t s_from = H.intern("from", 4), s_where = H.intern("where", 5), s_by = H.intern("by", 2);
@@ -416,8 +418,6 @@ rfx_obj_p rfx_select(rfx_obj_p dict) {
         wplan_t wp;
         int flat = 1;
         int64_t *d_ids = NULL, nsel = 0;
-        void *tmp[2 * RFX_MAX_AGGS + RFX_MAX_KEYS + 4];
-        int ntmp = 0;
         int rc = plan_where(tab, where, &wp);
         if (rc == -2) { res = fail_hip("column upload"); goto done; }
         if (rc) { /* not one comparison / one flat and|or: a nested tree, evaluated through masks */
@@ -593,7 +593,7 @@ rfx_obj_p rfx_select(rfx_obj_p dict) {
             }
             if (d_ids) rfx_hip_free(g_ctx, d_ids);
             d_ids = NULL;
-            if (!ok) { for (int i = 0; i < ntmp; i++) rfx_hip_free(g_ctx, tmp[i]); res = fail_hip("gather"); goto done; }
+            if (!ok) { res = fail_hip("gather"); goto done; }
             nrows = nsel;
         }
         if (by) {
@@ -614,7 +614,6 @@ rfx_obj_p rfx_select(rfx_obj_p dict) {
                         if (rfx_hip_malloc(g_ctx, &comp, (size_t)nrows * 8) != RFX_OK) { res = fail_hip("composite key"); goto done; }
                         tmp[ntmp++] = comp;
                         if (rfx_hip_composite_key(g_ctx, dks, kmins, kmults, nkeys, nrows, (int64_t *)comp) != RFX_OK) {
-                            for (int i = 0; i < ntmp; i++) rfx_hip_free(g_ctx, tmp[i]);
                             res = fail_hip("composite key");
                             goto done;
                         }
@@ -704,7 +703,6 @@ rfx_obj_p rfx_select(rfx_obj_p dict) {
                     if (okeys) H.drop(okeys);
                     for (int i = 0; i < nkeys; i++) if (okcols[i]) H.drop(okcols[i]);
                     for (int a = 0; a < nagg; a++) if (ocols[a]) H.drop(ocols[a]);
-                    for (int i = 0; i < ntmp; i++) rfx_hip_free(g_ctx, tmp[i]);
                     res = fail_hip("group-by");
                     goto done;
                 }
@@ -719,7 +717,6 @@ rfx_obj_p rfx_select(rfx_obj_p dict) {
                 RFX_AS_I64(rk)[a + nkeys] = names[a];
                 RFX_AS_LIST(rv)[a + nkeys] = ocols[a] ? ocols[a] : H.vector((int8_t)outtype[a], 0);
             }
-            for (int i = 0; i < ntmp; i++) rfx_hip_free(g_ctx, tmp[i]);
             res = H.table(rk, rv);
             g_last_gpu = 1;
             goto done;
@@ -728,7 +725,6 @@ rfx_obj_p rfx_select(rfx_obj_p dict) {
         int64_t selected = 0;
         {
             int frc = rfx_hip_filter_aggr_host(g_ctx, wp.preds, wp.npred, wp.logic, aggs, nagg, nrows, vals, &selected);
-            for (int i = 0; i < ntmp; i++) rfx_hip_free(g_ctx, tmp[i]);
             if (frc != RFX_OK) { res = fail_hip("filter_aggr"); goto done; }
         }
         obj_p rk = H.vector(RFX_TYPE_SYMBOL, nagg), rv = H.vector(RFX_TYPE_LIST, nagg);
@@ -743,6 +739,7 @@ rfx_obj_p rfx_select(rfx_obj_p dict) {
 out:
     res = delegate_select(dict, why ? why : "unsupported");
 done:
+    for (int i = 0; i < ntmp; i++) rfx_hip_free(g_ctx, tmp[i]);
     H.drop(tab);
     return res;
 }
