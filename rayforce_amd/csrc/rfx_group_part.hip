@@ -25,7 +25,9 @@
 
 #define PART_TILE_ROWS 2048 /* rows per workgroup per tile: 256 lanes x 8 rows */
 #define PART_MAX 1024       /* max partitions */
-#define PART_LDS_BYTES (64 * 1024)
+#define PART_LDS_BYTES (64 * 1024)      /* pass-2 tables of a partition: two 512-thread workgroups per CU */
+#define PART_LDS_BIG_BYTES (144 * 1024) /* ... or one 1024-thread workgroup per CU owning (nearly) the whole LDS, when that keeps the partition count within
+                                        * what the write-combining scatter handles (several aggregates over ~1e6 keys) */
 #define PART_AGG_THREADS 512
 #define WC_B 8 /* write-combining scatter: records per store group = 128 bytes */
 #define WC_MAXP 256
@@ -806,8 +808,8 @@ static void launch_scatter_soa(rfx_ctx *c, const Plan &P, const PartArgs &A, int
 }
 
 // ---- pass 2: per-partition LDS aggregation ----
-template <int NV>
-__global__ __launch_bounds__(PART_AGG_THREADS) void k_part_aggregate(const Plan P, const PartArgs A) {
+template <int NV, int THREADS>
+__global__ __launch_bounds__(THREADS) void k_part_aggregate(const Plan P, const PartArgs A) {
     extern __shared__ __attribute__((aligned(16))) u64 smem[];
     const int tid = threadIdx.x;
     const int p = blockIdx.x / A.split, s = blockIdx.x % A.split;
@@ -827,14 +829,14 @@ __global__ __launch_bounds__(PART_AGG_THREADS) void k_part_aggregate(const Plan 
         }
     }
     // LDS layout: [first | acc0 | (cnt0) | acc1 ...] each `local` cells
-    for (i64 i = tid; i < local; i += PART_AGG_THREADS) smem[i] = (u64)RFX_INF_I64_D;
+    for (i64 i = tid; i < local; i += THREADS) smem[i] = (u64)RFX_INF_I64_D;
 #pragma unroll
     for (int a = 0; a < RFX_MAX_AGGS; a++) {
         if (kind[a] < 0) continue;
         const u64 id = acc_identity(kind[a], f64[a]);
-        for (i64 i = tid; i < local; i += PART_AGG_THREADS) smem[(i64)arr_of[a] * local + i] = id;
+        for (i64 i = tid; i < local; i += THREADS) smem[(i64)arr_of[a] * local + i] = id;
         if (agg_has_cnt(kind[a], f64[a])) {
-            for (i64 i = tid; i < local; i += PART_AGG_THREADS) smem[(i64)(arr_of[a] + 1) * local + i] = 0;
+            for (i64 i = tid; i < local; i += THREADS) smem[(i64)(arr_of[a] + 1) * local + i] = 0;
         }
     }
     __syncthreads();
@@ -847,12 +849,12 @@ __global__ __launch_bounds__(PART_AGG_THREADS) void k_part_aggregate(const Plan 
     const u64 *__restrict__ recs = A.recs;
     const size_t cap = (size_t)A.cap;
     constexpr int RU = 4; // records in flight per lane
-    for (u64 i0 = b0; i0 < b1; i0 += (u64)PART_AGG_THREADS * RU) {
+    for (u64 i0 = b0; i0 < b1; i0 += (u64)THREADS * RU) {
         u64 h[RU], val[RU][NV > 0 ? NV : 1];
         bool in[RU];
 #pragma unroll
         for (int r = 0; r < RU; r++) {
-            const u64 i = i0 + (u64)r * PART_AGG_THREADS + tid;
+            const u64 i = i0 + (u64)r * THREADS + tid;
             in[r] = i < b1;
             h[r] = 0;
             if (!in[r]) continue;
@@ -895,7 +897,7 @@ __global__ __launch_bounds__(PART_AGG_THREADS) void k_part_aggregate(const Plan 
     __syncthreads();
     // merge into the global tables (several workgroups may share a partition: atomics)
     const i64 gbase = (i64)p << A.lb;
-    for (i64 i = tid; i < local; i += PART_AGG_THREADS) {
+    for (i64 i = tid; i < local; i += THREADS) {
         const u64 f = smem[i];
         if (f == (u64)RFX_INF_I64_D) continue;
         const i64 g = A.lowbit ? ((i << 8) | (i64)(((u64)p - (u64)A.kmin) & 255ULL)) : (gbase + i);
@@ -1281,18 +1283,24 @@ int rfx_group_part_accumulate(rfx_ctx *c, const Plan &P, int key_idx, const rfx_
         if (lowbit) {
             const i64 per = (t->range + 255) >> 8; // slots per partition: those congruent to one residue mod 256
             while ((1LL << lb) < per) lb++;
-            if ((1LL << lb) * narr * 8 > PART_LDS_BYTES) lowbit = 0;
+            if ((1LL << lb) * narr * 8 > PART_LDS_BIG_BYTES) lowbit = 0;
         }
     }
     c->pc_valid = 0; // consumed (or stale) either way
     i64 nparts;
     if (lowbit) nparts = 256;
     else {
-        // slots per partition: largest power of two whose tables fit the LDS budget
-        lb = 0;
-        while ((1LL << (lb + 1)) * narr * 8 <= PART_LDS_BYTES) lb++;
+        // slots per partition: largest power of two whose tables fit the LDS budget -- the small budget if that keeps the
+        // partition count within the write-combining scatter's reach, else the big one
+        size_t budget = PART_LDS_BYTES;
+        for (int attempt = 0; attempt < 2; attempt++) {
+            lb = 0;
+            while ((size_t)(1LL << (lb + 1)) * narr * 8 <= budget) lb++;
+            nparts = (t->range + (1LL << lb) - 1) >> lb;
+            if (nparts <= WC_MAXP || (c->flags & RFX_TUNE_NO_BIG_LDS)) break;
+            budget = PART_LDS_BIG_BYTES;
+        }
         if (lb < 8) return RFX_ESTATE;
-        nparts = (t->range + (1LL << lb) - 1) >> lb;
         if (nparts > PART_MAX || nparts < 2) return RFX_ESTATE;
     }
     A.lowbit = lowbit;
@@ -1338,12 +1346,33 @@ int rfx_group_part_accumulate(rfx_ctx *c, const Plan &P, int key_idx, const rfx_
         default: return RFX_ESTATE;
     }
     const size_t lds = (size_t)narr * (1ULL << lb) * 8;
-    const int grid2 = (int)(nparts * A.split);
-    switch (A.nv) {
-        case 0: hipLaunchKernelGGL((k_part_aggregate<0>), dim3(grid2), dim3(PART_AGG_THREADS), lds, c->stream, P, A); break;
-        case 1: hipLaunchKernelGGL((k_part_aggregate<1>), dim3(grid2), dim3(PART_AGG_THREADS), lds, c->stream, P, A); break;
-        case 2: hipLaunchKernelGGL((k_part_aggregate<2>), dim3(grid2), dim3(PART_AGG_THREADS), lds, c->stream, P, A); break;
-        default: hipLaunchKernelGGL((k_part_aggregate<3>), dim3(grid2), dim3(PART_AGG_THREADS), lds, c->stream, P, A); break;
+    if (lds > PART_LDS_BYTES) {
+        // one 1024-thread workgroup per partition (and per CU): dynamic LDS above 64 KB is opted into once per instance
+        static bool attr_set[4] = {false, false, false, false};
+#define RFX_PA(N)                                                                                                                                  \
+    case N:                                                                                                                                        \
+        if (!attr_set[N]) {                                                                                                                        \
+            RFX_HIP_CHECK(hipFuncSetAttribute((const void *)k_part_aggregate<N, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));  \
+            attr_set[N] = true;                                                                                                                    \
+        }                                                                                                                                          \
+        hipLaunchKernelGGL((k_part_aggregate<N, 1024>), dim3((int)nparts), dim3(1024), lds, c->stream, P, A);                                     \
+        break
+        A.split = 1;
+        switch (A.nv) {
+            RFX_PA(0);
+            RFX_PA(1);
+            RFX_PA(2);
+            default: RFX_PA(3);
+        }
+#undef RFX_PA
+    } else {
+        const int grid2 = (int)(nparts * A.split);
+        switch (A.nv) {
+            case 0: hipLaunchKernelGGL((k_part_aggregate<0, PART_AGG_THREADS>), dim3(grid2), dim3(PART_AGG_THREADS), lds, c->stream, P, A); break;
+            case 1: hipLaunchKernelGGL((k_part_aggregate<1, PART_AGG_THREADS>), dim3(grid2), dim3(PART_AGG_THREADS), lds, c->stream, P, A); break;
+            case 2: hipLaunchKernelGGL((k_part_aggregate<2, PART_AGG_THREADS>), dim3(grid2), dim3(PART_AGG_THREADS), lds, c->stream, P, A); break;
+            default: hipLaunchKernelGGL((k_part_aggregate<3, PART_AGG_THREADS>), dim3(grid2), dim3(PART_AGG_THREADS), lds, c->stream, P, A); break;
+        }
     }
     RFX_KERNEL_END(c);
     RFX_HIP_CHECK(hipGetLastError());

@@ -9,7 +9,7 @@ v1, v2, v3 = eng.gen_f64(N, 11), eng.gen_f64(N, 12), eng.gen_f64(N, 13)
 for keys in (100, 10_000, 100_000, 1_000_000):
     k = eng.gen_i64(N, 4, keys)
     t = {"k": k, "v1": v1, "v2": v2, "v3": v3}
-    for name, aggs in (("sum v1", [("sum", "v1")]), ("avg v1,v2,v3", [("avg", "v1"), ("avg", "v2"), ("avg", "v3")]),
+    for name, aggs in (("sum v1", [("sum", "v1")]), ("sum v1, avg v3", [("sum", "v1"), ("avg", "v3")]), ("avg v1,v2,v3", [("avg", "v1"), ("avg", "v2"), ("avg", "v3")]),
                        ("sum v1,v2,v3", [("sum", "v1"), ("sum", "v2"), ("sum", "v3")])):
         for _ in range(2):
             r = eng.group_by("k", aggs, None, t)
