@@ -133,3 +133,24 @@ def test_multikey_expression_and_sparse_full_size(eng, big):
         eng.tune(flags=0)
     assert torch.equal(r2["keys"], r["keys"]) and torch.equal(r2["results"][1], r["results"][1])
     assert torch.allclose(r2["results"][0], r["results"][0], rtol=1e-9, atol=0)
+
+
+def test_beyond_32_bit_row_counts(eng):
+    """2^32 + 12 345 rows (34 GB per column): K1, `where` and the group-by fall-backs index rows with 64 bits."""
+    free, _ = torch.cuda.mem_get_info()
+    if free < 150 * 2**30:
+        pytest.skip("needs ~150 GB of free HBM")
+    n = (1 << 32) + 12_345
+    a = eng.gen_i64(n, 2, 1_000_000)
+    (cnt, s, mx), sel = eng.filter_aggr([("count", a), ("sum", a), ("max", a)], ("<", a, 100_000), None)
+    (cnt2, s2), sel2 = eng.filter_aggr([("count", a), ("sum", a)], (">=", a, 100_000), None)
+    (tot,), _ = eng.filter_aggr([("sum", a)], None, None, nrows=n)
+    assert sel + sel2 == n and cnt == sel and s + s2 == tot and mx == 99_999
+    ids = eng.where(("<", a, 100), None)
+    assert bool((ids[1:] > ids[:-1]).all()) and int(ids[-1]) < n and int(ids[-1]) > (1 << 32) - 10_000_000
+    assert bool((eng.at_ids(a, ids) < 100).all())
+    del ids
+    k = eng.gen_i64(n, 4, 1000)
+    r = eng.group_by(k, [("count", a), ("sum", a)], None, None)
+    assert r["groups"] == 1000 and int(r["results"][0].sum()) == n and int(r["results"][1].sum()) == tot
+    assert bool((r["first"][1:] > r["first"][:-1]).all()) and torch.equal(eng.at_ids(k, r["first"]), r["keys"])
