@@ -16,6 +16,7 @@ Workloads (BASELINE.json configs / SURVEY 8d):
   c1   configs[0]  (sum v)                             v: f64[1e7]                         8 B/row   (plumbing case)
   c3w  metric      select sum(v) by k where a < 100000 k, v as c3 + a as c2                24 B/row
   q2   8f-1        select sum(v) by {id1, id2}         id1, id2: i64[1e9] in [0,100), v    24 B/row
+  q1   8f-3        TPC-H Q1 shape: 8 aggregates, two of them nested expressions, by {rf, ls} where sd <= 2400  56 B/row
   k9   a10         select sum(v) by k, sparse keys (range > rows: open-addressing path)          16 B/row
   x6   8f-3        select sum(p*d) where q<24 and .05<=d<=.07   p, d: f64[1e9], q: i64[1e9]   24 B/row (TPC-H Q6 shape)
   c5   configs[4]  avg,min,max(d) where a<.316228 & b>.683772 & c!=.25   4 x f64[2.5e8]/GPU 32 B/row
@@ -64,6 +65,9 @@ WORKLOADS = {
                bytes_per_row=24, dtype="f64", kernel="k_part_scope_hist<1, 0> x2 + k_group_dense<3, true, 1024>"),
     "x6": dict(desc="expression aggregate (TPC-H Q6 shape): select sum(p * d) where q < 24 and d >= 0.05 and d <= 0.07; p f64 seed 12, d f64 seed 13 "
                     "scaled to [0,0.1), q i64 uniform [0,50) seed 14", rows=1_000_000_000, bytes_per_row=24, dtype="f64", kernel="k_filter_aggr<3, 4, 4, 4, 1>"),
+    "q1": dict(desc="nested expressions (TPC-H Q1 shape): sum(q), sum(p), sum(p*(1-d)), sum(p*(1-d)*(1+t)), avg(q), avg(p), avg(d), count by {rf, ls} "
+                    "where sd <= 2400; rf in [0,3), ls in [0,2), q i64 [1,50], p f64, d f64 [0,.1), t f64 [0,.08), sd i64 [0,2500)", rows=1_000_000_000,
+               bytes_per_row=56, dtype="f64", kernel="k_part_scope_hist<2, 8> x2 + k_group_dense<7, true, 256>"),
     "k9": dict(desc="sparse keys (range > rows -> the reference's open-addressing path): select sum(v) by k, k = 1000003 * (i64 uniform [0,1e6) seed 4) - 77, "
                     "v f64 seed 5", rows=1_000_000_000, bytes_per_row=16, dtype="f64", kernel="k_part_hist<1, 0> + k_part_scatter_soa<2, 2, 0> + k_part_hash_aggregate<2>"),
     "w2": dict(desc="where ids: (where (< a 100000)) on the C2 column -> 1e8 ascending i64 row ids (8 B/row in + 8 B/selected row out)", rows=1_000_000_000,
@@ -100,6 +104,17 @@ class Job:
             self.t = {"p": g.gen_f64(rows, 12, row0), "d": d, "q": g.gen_i64(rows, 14, 50, row0)}
             self.aggs = [("sum", ("*", "p", "d"))]
             self.where = ("and", ("<", "q", 24), (">=", "d", 0.05), ("<=", "d", 0.07))
+        elif name == "q1":
+            q = g.gen_i64(rows, 73, 50, row0)
+            q.add_(1)
+            d, t = g.gen_f64(rows, 75, row0), g.gen_f64(rows, 76, row0)
+            d.mul_(0.1)
+            t.mul_(0.08)  # plumbing: scale the synthetic columns once, outside every timed region
+            self.t = {"rf": g.gen_i64(rows, 71, 3, row0), "ls": g.gen_i64(rows, 72, 2, row0), "q": q, "p": g.gen_f64(rows, 74, row0), "d": d, "t": t,
+                      "sd": g.gen_i64(rows, 77, 2500, row0)}
+            self.aggs = [("sum", "q"), ("sum", "p"), ("sum", ("*", "p", ("-", 1, "d"))), ("sum", ("*", ("*", "p", ("-", 1, "d")), ("+", 1, "t"))),
+                         ("avg", "q"), ("avg", "p"), ("avg", "d"), ("count", "q")]
+            self.where, self.key = ("<=", "sd", 2400), ["rf", "ls"]
         elif name == "k9":
             k = g.gen_i64(rows, 4, 1_000_000, row0)
             k.mul_(1_000_003).sub_(77)  # plumbing: spread the keys once, outside every timed region
@@ -145,7 +160,7 @@ class Job:
             ids = self.sh.where(self.where, self.t) if self.sh is not None else self.eng.where(self.where, self.t)
             self.eng.sync()
             return ([int(ids.numel())], int(ids.numel()))
-        if self.name in ("c3", "c3w", "q2", "k9"):
+        if self.name in ("c3", "c3w", "q2", "k9", "q1"):
             if self.sh is not None:
                 return self.sh.group_by(self.key, self.aggs, self.where, self.t)
             return self.eng.group_by(self.key, self.aggs, self.where, self.t)
@@ -185,7 +200,7 @@ def run_workload(name, eng, sharded, rows, row0, steps, warmup, world):
     job = Job(name, eng, sharded, rows, row0)
     dt, kms, res = timed(job, steps, warmup, world)
     ms_step = dt * 1e3 / steps
-    if name in ("c3", "c3w", "q2", "k9", "w2"):
+    if name in ("c3", "c3w", "q2", "k9", "q1", "w2"):
         kms = ms_step  # several dependent kernels (scope+hist, scatter, aggregate, rank, emit): price the whole query
     value = world * rows / (dt / steps)
     alg_bytes = w["bytes_per_row"] * rows  # per launch, per GPU (SURVEY 8d figures, stated in DESIGN.md)

@@ -88,20 +88,42 @@ typedef struct rfx_pred {
 enum { RFX_X_NONE = 0, RFX_X_ADD = 1, RFX_X_SUB = 2, RFX_X_MUL = 3, RFX_X_FDIV = 4 };
 enum { RFX_XF_SWAP = 1 }; /* operands swapped: input = rhs OP column (for `(- 2 a)`, `(div 1 a)`) */
 
+/* Deeper expressions -- `(sum (* price (- 1 disc)))`, up to RFX_MAX_XNODES operations -- are given as a node list in evaluation
+ * order; an operand is a column, an atom, or the result of an EARLIER node.  The aggregate folds the LAST node.  Every node
+ * follows the same scalar rules and type promotion as the single-operation form. */
+#define RFX_MAX_XNODES 4
+enum { RFX_XK_COL = 0, RFX_XK_ATOM = 1, RFX_XK_NODE = 2 };
+typedef struct rfx_xoperand {
+    int32_t kind; /* RFX_XK_*                                        */
+    int32_t type; /* RFX_I64 | RFX_F64 (COL, ATOM); ignored for NODE */
+    const void *d_col;
+    union {
+        int64_t i;    /* ATOM of type i64           */
+        double f;     /* ATOM of type f64           */
+        int64_t node; /* NODE: index of an earlier node */
+    };
+} rfx_xoperand_t;
+typedef struct rfx_xnode {
+    int32_t op; /* RFX_X_ADD .. RFX_X_FDIV */
+    int32_t _pad;
+    rfx_xoperand_t l, r;
+} rfx_xnode_t;
+
 typedef struct rfx_agg {
     const void *d_col; /* may be NULL for RFX_AGG_COUNT */
     int32_t col_type;  /* RFX_I64 | RFX_F64 */
     int32_t kind;      /* RFX_AGG_*         */
-    /* optional expression: all zero = the aggregate reads d_col itself */
+    /* optional single-operation expression: all zero = the aggregate reads d_col itself */
     int32_t xop;             /* RFX_X_*                                                            */
     int32_t xflags;          /* RFX_XF_*                                                           */
     const void *d_xrhs_col;  /* second operand: a column of the same length, or NULL for the atom  */
     int32_t xrhs_type;       /* RFX_I64 | RFX_F64                                                  */
-    int32_t _pad;
+    int32_t nxnodes;         /* > 0: the expression is xnodes[0 .. nxnodes) instead (d_col / xop / xrhs_* are ignored) */
     union {
         int64_t xrhs_i;
         double xrhs_f;
     };
+    const rfx_xnode_t *xnodes; /* host memory, read during the call only */
 } rfx_agg_t;
 /* Element type the aggregate folds (= the column's type, or the expression's result type).  Pure host helper. */
 int rfx_agg_input_type(const rfx_agg_t *a);

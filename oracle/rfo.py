@@ -257,7 +257,8 @@ def eval_arg(arg, table):
     """An aggregate's argument: a column name, or (op, lhs, rhs) with operands column names / atoms."""
     if isinstance(arg, tuple):
         op, l, r = arg
-        return binop(op, table[l] if isinstance(l, str) else l, table[r] if isinstance(r, str) else r)
+        ev = lambda x: eval_arg(x, table) if isinstance(x, (tuple, str)) else x  # nested expressions compose: temporaries, as the reference
+        return binop(op, ev(l), ev(r))
     return table[arg]
 
 

@@ -38,19 +38,36 @@ class _XRhsUnion(C.Union):
     _fields_ = [("xrhs_i", C.c_int64), ("xrhs_f", C.c_double)]
 
 
+class _XOpUnion(C.Union):
+    _fields_ = [("i", C.c_int64), ("f", C.c_double), ("node", C.c_int64)]
+
+
+class XOperand(C.Structure):
+    _anonymous_ = ("u",)
+    _fields_ = [("kind", C.c_int32), ("type", C.c_int32), ("d_col", C.c_void_p), ("u", _XOpUnion)]
+
+
+class XNode(C.Structure):
+    _fields_ = [("op", C.c_int32), ("_pad", C.c_int32), ("l", XOperand), ("r", XOperand)]
+
+
 class Agg(C.Structure):
     """rfx_agg_t: the aggregate's column plus the optional element-wise expression feeding it (include/rfx_hip.h)."""
     _anonymous_ = ("xu",)
     _fields_ = [("d_col", C.c_void_p), ("col_type", C.c_int32), ("kind", C.c_int32), ("xop", C.c_int32), ("xflags", C.c_int32),
-                ("d_xrhs_col", C.c_void_p), ("xrhs_type", C.c_int32), ("_pad", C.c_int32), ("xu", _XRhsUnion)]
+                ("d_xrhs_col", C.c_void_p), ("xrhs_type", C.c_int32), ("nxnodes", C.c_int32), ("xu", _XRhsUnion), ("xnodes", C.POINTER(XNode))]
 
 
+RFX_XK_COL, RFX_XK_ATOM, RFX_XK_NODE = 0, 1, 2
+RFX_MAX_XNODES = 4
 XOPS = {"+": 1, "-": 2, "*": 3, "div": 4}
 RFX_XF_SWAP = 1
 
 
 def agg_input_type(a: "Agg") -> int:
     """rfx_agg_input_type: the element type the aggregate folds."""
+    if a.nxnodes > 0:
+        return load_library().rfx_agg_input_type(C.byref(a))
     if a.xop == 0:
         return a.col_type
     return RFX_F64 if (a.xop == 4 or a.col_type == RFX_F64 or a.xrhs_type == RFX_F64) else RFX_I64
@@ -80,7 +97,7 @@ class HashTables(C.Structure):
                 ("d_first", C.c_void_p), ("d_acc", C.c_void_p * RFX_MAX_AGGS), ("d_cnt", C.c_void_p * RFX_MAX_AGGS)]
 
 
-assert C.sizeof(Pred) == 40 and C.sizeof(Agg) == 48 and C.sizeof(Partial) == 64 and C.sizeof(Value) == 16
+assert C.sizeof(Pred) == 40 and C.sizeof(Agg) == 56 and C.sizeof(XNode) == 56 and C.sizeof(Partial) == 64 and C.sizeof(Value) == 16
 
 _P = C.POINTER
 _ctx = C.c_void_p

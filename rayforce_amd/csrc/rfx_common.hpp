@@ -117,13 +117,20 @@ struct PlanAgg {
     int skipnull; // grouped: fold with the SCALAR rules (nulls skipped, all-null group -> null) -- what the reference does
                   // when the aggregate's argument is an expression (per-group vectors folded one by one)
 };
-// One element-wise expression  out = l OP r  (SURVEY 8f-3).  Operands: a plan column or an atom (col < 0).
-struct PlanExpr {
+// One element-wise expression: up to RFX_MAX_XNODES operations in evaluation order.  An operand is a plan
+// column, an atom, or the result of an earlier operation; the expression's value is the last operation's result.
+struct PlanXNode {
     int op;             // RFX_X_ADD .. RFX_X_FDIV
-    int out_f64;        // result type
-    int l_col, r_col;   // index into Plan::cols, or -1: atom
+    int o_f64;          // result type of this operation
+    int l_kind, r_kind; // RFX_XK_COL / RFX_XK_ATOM / RFX_XK_NODE
+    int l_idx, r_idx;   // plan column index (COL) or earlier node index (NODE)
     int l_f64, r_f64;   // operand element types
     u64 l_atom, r_atom; // atom bits in the operand's own type
+};
+struct PlanExpr {
+    int nops;
+    int out_f64; // == ops[nops - 1].o_f64
+    PlanXNode ops[RFX_MAX_XNODES];
 };
 struct Plan {
     int ncols, npred, nagg, logic;
@@ -138,6 +145,13 @@ struct Plan {
 // Evaluate every expression into context scratch and rewrite the plan to read the results as plain columns (nx = 0):
 // for the kernels that do not fold expressions on the fly (partitioned and hashed group-by).
 int rfx_plan_materialise_exprs(rfx_ctx *c, Plan *P);
+// Any expression tree (more than one operation)?  The group-by kernels evaluate single operations in place and read trees as
+// materialised scratch columns.
+static inline bool rfx_plan_has_deep_expr(const Plan &P) {
+    for (int i = 0; i < P.nx; i++)
+        if (P.xs[i].nops > 1) return true;
+    return false;
+}
 
 // Build a Plan from the public descriptors (dedupes columns, promotes atoms).  Returns RFX_OK or an error.
 int rfx_plan_build(Plan *P, const rfx_pred_t *preds, int npred, int logic, const rfx_agg_t *aggs, int nagg,

@@ -199,25 +199,23 @@ int rfx_comp_reserve(rfx_ctx *c, size_t bytes) {
 // ---- expressions as plain columns (for the kernels that do not fold them on the fly) ----
 struct DeriveArgs {
     PlanExpr x;
-    const u64 *l, *r;
+    const u64 *cols[RFX_MAX_COLS];
     u64 *out;
 };
+__device__ __forceinline__ u64 derive_operand(const DeriveArgs &A, int kind, int idx, u64 atom, i64 row, const u64 (&res)[RFX_MAX_XNODES]) {
+    if (kind == RFX_XK_COL) return A.cols[idx][row];
+    if (kind == RFX_XK_ATOM) return atom;
+    return res[idx];
+}
 __global__ __launch_bounds__(RFX_BLOCK) void k_derive(const DeriveArgs A, i64 nrows) {
-    const PlanExpr x = A.x;
-    const i64 npairs = nrows / 2;
-    for (i64 i = blockIdx.x * (i64)RFX_BLOCK + threadIdx.x; i < npairs; i += (i64)gridDim.x * RFX_BLOCK) {
-        u64x2 l, r, o;
-        if (A.l) l = rfx_ld2(A.l + 2 * i);
-        else l.x = l.y = x.l_atom;
-        if (A.r) r = rfx_ld2(A.r + 2 * i);
-        else r.x = r.y = x.r_atom;
-        o.x = rfx_expr_eval(x.op, x.out_f64, x.l_f64, x.r_f64, l.x, r.x);
-        o.y = rfx_expr_eval(x.op, x.out_f64, x.l_f64, x.r_f64, l.y, r.y);
-        *(u64x2 *)(A.out + 2 * i) = o;
-    }
-    if ((nrows & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
-        const i64 i = nrows - 1;
-        A.out[i] = rfx_expr_eval(x.op, x.out_f64, x.l_f64, x.r_f64, A.l ? A.l[i] : x.l_atom, A.r ? A.r[i] : x.r_atom);
+    for (i64 i = blockIdx.x * (i64)RFX_BLOCK + threadIdx.x; i < nrows; i += (i64)gridDim.x * RFX_BLOCK) {
+        u64 res[RFX_MAX_XNODES] = {0, 0, 0, 0};
+        for (int k = 0; k < A.x.nops; k++) {
+            const PlanXNode n = A.x.ops[k];
+            const u64 l = derive_operand(A, n.l_kind, n.l_idx, n.l_atom, i, res), r = derive_operand(A, n.r_kind, n.r_idx, n.r_atom, i, res);
+            res[k] = rfx_expr_eval(n.op, n.o_f64, n.l_f64, n.r_f64, l, r);
+        }
+        A.out[i] = res[A.x.nops - 1];
     }
 }
 
@@ -231,8 +229,7 @@ int rfx_plan_materialise_exprs(rfx_ctx *c, Plan *P) {
     for (int i = 0; i < P->nx; i++) {
         DeriveArgs A;
         A.x = P->xs[i];
-        A.l = A.x.l_col >= 0 ? P->cols[A.x.l_col] : NULL;
-        A.r = A.x.r_col >= 0 ? P->cols[A.x.r_col] : NULL;
+        for (int cc = 0; cc < RFX_MAX_COLS; cc++) A.cols[cc] = (cc < P->ncols) ? P->cols[cc] : NULL;
         A.out = (u64 *)((char *)c->d_expr + col_bytes * (size_t)i);
         hipLaunchKernelGGL(k_derive, dim3(c->num_cus * 8), dim3(RFX_BLOCK), 0, c->stream, A, P->nrows);
         RFX_HIP_CHECK(hipGetLastError());
@@ -399,10 +396,64 @@ int rfx_plan_build(Plan *P, const rfx_pred_t *preds, int npred, int logic, const
         if (a->kind == RFX_AGG_COUNT) {
             // (count expr) is not the reference's count of the expression's rows when grouped (it answers the number of
             // groups, a quirk of its lazy-argument collection): not reproduced, refused instead
-            RFX_REQUIRE(a->xop == RFX_X_NONE, RFX_EINVAL, "count of an expression is not supported");
+            RFX_REQUIRE(a->xop == RFX_X_NONE && a->nxnodes == 0, RFX_EINVAL, "count of an expression is not supported");
             q->col = -1;
             q->f64 = 0;
         } else {
+            if (a->nxnodes > 0) { // expression tree: nodes in evaluation order
+                RFX_REQUIRE(a->nxnodes <= RFX_MAX_XNODES && a->xnodes != NULL, RFX_ELIMIT, "1..RFX_MAX_XNODES expression nodes");
+                RFX_REQUIRE(a->kind != RFX_AGG_FIRST, RFX_EINVAL, "first of an expression is not supported");
+                PlanExpr x;
+                memset(&x, 0, sizeof(x));
+                x.nops = a->nxnodes;
+                for (int i = 0; i < a->nxnodes; i++) {
+                    const rfx_xnode_t *src = &a->xnodes[i];
+                    PlanXNode &n = x.ops[i];
+                    RFX_REQUIRE(src->op >= RFX_X_ADD && src->op <= RFX_X_FDIV, RFX_EINVAL, "bad expression operator");
+                    n.op = src->op;
+                    const rfx_xoperand_t *opnd[2] = {&src->l, &src->r};
+                    int kind[2], idx[2], f64[2];
+                    u64 atoms[2];
+                    for (int j = 0; j < 2; j++) {
+                        const rfx_xoperand_t *o = opnd[j];
+                        kind[j] = o->kind;
+                        idx[j] = 0;
+                        atoms[j] = 0;
+                        if (o->kind == RFX_XK_COL) {
+                            RFX_REQUIRE(o->d_col != NULL && (o->type == RFX_I64 || o->type == RFX_F64), RFX_EINVAL, "expression column operand");
+                            idx[j] = plan_col(P, o->d_col);
+                            RFX_REQUIRE(idx[j] >= 0, RFX_ELIMIT, "too many distinct columns");
+                            f64[j] = o->type == RFX_F64;
+                        } else if (o->kind == RFX_XK_ATOM) {
+                            RFX_REQUIRE(o->type == RFX_I64 || o->type == RFX_F64, RFX_EINVAL, "expression atom type");
+                            f64[j] = o->type == RFX_F64;
+                            atoms[j] = f64[j] ? host_f64_bits(o->f) : (u64)o->i;
+                        } else {
+                            RFX_REQUIRE(o->kind == RFX_XK_NODE && o->node >= 0 && o->node < i && o->node < RFX_MAX_XNODES - 1, RFX_EINVAL,
+                                        "expression node operand must reference an earlier node");
+                            idx[j] = (int)o->node;
+                            f64[j] = x.ops[o->node].o_f64;
+                        }
+                    }
+                    n.l_kind = kind[0]; n.r_kind = kind[1];
+                    n.l_idx = idx[0]; n.r_idx = idx[1];
+                    n.l_f64 = f64[0]; n.r_f64 = f64[1];
+                    n.l_atom = atoms[0]; n.r_atom = atoms[1];
+                    n.o_f64 = (n.op == RFX_X_FDIV) || n.l_f64 || n.r_f64;
+                }
+                x.out_f64 = x.ops[x.nops - 1].o_f64;
+                int xi = 0;
+                for (; xi < P->nx; xi++)
+                    if (memcmp(&P->xs[xi], &x, sizeof(x)) == 0) break;
+                if (xi == P->nx) {
+                    RFX_REQUIRE(P->nx < RFX_MAX_EXPRS, RFX_ELIMIT, "too many distinct expressions");
+                    P->xs[P->nx++] = x;
+                }
+                q->col = RFX_XCOL + xi;
+                q->f64 = x.out_f64;
+                q->skipnull = 1;
+                continue;
+            }
             RFX_REQUIRE(a->d_col != NULL || nrows == 0, RFX_EINVAL, "aggregate column is NULL");
             RFX_REQUIRE(a->col_type == RFX_I64 || a->col_type == RFX_F64, RFX_EINVAL, "aggregate column type must be i64 or f64");
             const int ci = plan_col(P, a->d_col);
@@ -416,7 +467,9 @@ int rfx_plan_build(Plan *P, const rfx_pred_t *preds, int npred, int logic, const
                 RFX_REQUIRE(a->kind != RFX_AGG_FIRST, RFX_EINVAL, "first of an expression is not supported");
                 PlanExpr x;
                 memset(&x, 0, sizeof(x));
-                x.op = a->xop;
+                x.nops = 1;
+                PlanXNode &n = x.ops[0];
+                n.op = a->xop;
                 int oc = -1;
                 if (a->d_xrhs_col) {
                     oc = plan_col(P, a->d_xrhs_col);
@@ -424,13 +477,17 @@ int rfx_plan_build(Plan *P, const rfx_pred_t *preds, int npred, int logic, const
                 }
                 const u64 atom = (a->xrhs_type == RFX_F64) ? host_f64_bits(a->xrhs_f) : (u64)a->xrhs_i;
                 const bool swap = (a->xflags & RFX_XF_SWAP) != 0;
-                x.l_col = swap ? oc : ci;
-                x.r_col = swap ? ci : oc;
-                x.l_f64 = swap ? (a->xrhs_type == RFX_F64) : (a->col_type == RFX_F64);
-                x.r_f64 = swap ? (a->col_type == RFX_F64) : (a->xrhs_type == RFX_F64);
-                x.l_atom = (swap && oc < 0) ? atom : 0;
-                x.r_atom = (!swap && oc < 0) ? atom : 0;
-                x.out_f64 = (rfx_agg_input_type(a) == RFX_F64);
+                const int ck = RFX_XK_COL, ok = (oc >= 0) ? RFX_XK_COL : RFX_XK_ATOM;
+                n.l_kind = swap ? ok : ck;
+                n.r_kind = swap ? ck : ok;
+                n.l_idx = swap ? oc : ci;
+                n.r_idx = swap ? ci : oc;
+                n.l_f64 = swap ? (a->xrhs_type == RFX_F64) : (a->col_type == RFX_F64);
+                n.r_f64 = swap ? (a->col_type == RFX_F64) : (a->xrhs_type == RFX_F64);
+                n.l_atom = (swap && oc < 0) ? atom : 0;
+                n.r_atom = (!swap && oc < 0) ? atom : 0;
+                n.o_f64 = (a->xop == RFX_X_FDIV) || n.l_f64 || n.r_f64;
+                x.out_f64 = n.o_f64;
                 int xi = 0;
                 for (; xi < P->nx; xi++)
                     if (memcmp(&P->xs[xi], &x, sizeof(x)) == 0) break;

@@ -276,6 +276,14 @@ static int lds_pass_split(const rfx_ctx *c, const rfx_agg_t *aggs, const rfx_gro
 }
 
 static int group_dense_run(rfx_ctx_t *c, Plan &P, GroupArgs &G, const rfx_agg_t *aggs, const rfx_group_tables_t *t, bool allow_part, bool *need_materialise) {
+    if (rfx_plan_has_deep_expr(P)) { // expression trees: evaluated into scratch columns first (k_derive), then plain columns
+        if (P.ncols + P.nx > RFX_MAX_COLS) {
+            rfx_set_error("group_dense_accumulate: too many distinct columns once the expression trees are materialised");
+            return RFX_ELIMIT;
+        }
+        const int rc0 = rfx_plan_materialise_exprs(c, &P);
+        if (rc0 != RFX_OK) return rc0;
+    }
     G.kmin = t->kmin;
     G.range = t->range;
     G.nagg = t->nagg;
@@ -332,6 +340,7 @@ extern "C" int rfx_hip_group_dense_accumulate(rfx_ctx_t *c, const int64_t *d_key
     int key_idx = 0;
     const int hs = lds_pass_split(c, aggs, t);
     rc = hs ? RFX_ELIMIT : rfx_plan_build(&P, preds, npred, logic, aggs, t->nagg, d_key, &key_idx, nrows, row0);
+    if (rc == RFX_OK && rfx_plan_has_deep_expr(P) && P.ncols + P.nx > RFX_MAX_COLS) rc = RFX_ELIMIT; // no room to materialise the trees
     if (rc == RFX_ELIMIT && t->nagg > 1) { // too many columns / expressions for one launch, or tables that fit LDS only in parts
         rfx_group_tables_t t1, t2;
         const int h = split_tables(t, &t1, &t2, hs);
@@ -362,6 +371,7 @@ extern "C" int rfx_hip_group_dense_accumulate_keys(rfx_ctx_t *c, const void *con
     int k0 = 0;
     const int hs = lds_pass_split(c, aggs, t);
     rc = hs ? RFX_ELIMIT : rfx_plan_build(&P, preds, npred, logic, aggs, t->nagg, d_keys[0], &k0, nrows, row0);
+    if (rc == RFX_OK && rfx_plan_has_deep_expr(P) && P.ncols + (nkeys - 1) + P.nx > RFX_MAX_COLS) rc = RFX_ELIMIT; // (upper bound on the key columns still to add)
     if (rc == RFX_ELIMIT && t->nagg > 1) {
         rfx_group_tables_t t1, t2;
         const int h = split_tables(t, &t1, &t2, hs);
@@ -542,7 +552,7 @@ extern "C" int rfx_hip_group_emit(rfx_ctx_t *c, const rfx_agg_t *aggs, const rfx
     for (int a = 0; a < t->nagg; a++) {
         A.kinds[a] = aggs[a].kind;
         A.f64s[a] = rfx_agg_input_type(&aggs[a]) == RFX_F64;
-        A.skips[a] = aggs[a].xop != RFX_X_NONE;
+        A.skips[a] = aggs[a].xop != RFX_X_NONE || aggs[a].nxnodes > 0;
         A.acc[a] = (const u64 *)t->d_acc[a];
         A.cnt[a] = (const u64 *)t->d_cnt[a];
         A.col[a] = (const u64 *)aggs[a].d_col;

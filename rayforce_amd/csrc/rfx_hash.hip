@@ -159,6 +159,7 @@ extern "C" int rfx_hip_group_hash_accumulate(rfx_ctx_t *c, const int64_t *d_key,
     Plan P;
     int key_idx = 0;
     rc = rfx_plan_build(&P, preds, npred, logic, aggs, t->nagg, d_key, &key_idx, nrows, row0);
+    if (rc == RFX_OK && rfx_plan_has_deep_expr(P) && P.ncols + P.nx > RFX_MAX_COLS) rc = RFX_ELIMIT; // no room to materialise the trees
     if (rc == RFX_ELIMIT && t->nagg > 1) { // too many columns / expressions for one launch: two passes, same keys and slots
         const int h = t->nagg / 2;
         rfx_hash_tables_t t1 = *t, t2 = *t;
@@ -173,6 +174,11 @@ extern "C" int rfx_hip_group_hash_accumulate(rfx_ctx_t *c, const int64_t *d_key,
         return rfx_hip_group_hash_accumulate(c, d_key, preds, npred, logic, aggs + h, nrows, row0, &t2);
     }
     if (rc != RFX_OK) return rc;
+    if (rfx_plan_has_deep_expr(P)) { // expression trees: scratch columns first (the kernels here evaluate single operations only)
+        RFX_REQUIRE(P.ncols + P.nx <= RFX_MAX_COLS, RFX_ELIMIT, "too many distinct columns once the expression trees are materialised");
+        rc = rfx_plan_materialise_exprs(c, &P);
+        if (rc != RFX_OK) return rc;
+    }
     HashArgs H;
     memset(&H, 0, sizeof(H));
     H.capacity = t->capacity;
@@ -263,7 +269,7 @@ extern "C" int rfx_hip_hash_emit(rfx_ctx_t *c, const rfx_agg_t *aggs, const rfx_
     for (int a = 0; a < t->nagg; a++) {
         A.kinds[a] = aggs[a].kind;
         A.f64s[a] = rfx_agg_input_type(&aggs[a]) == RFX_F64;
-        A.skips[a] = aggs[a].xop != RFX_X_NONE;
+        A.skips[a] = aggs[a].xop != RFX_X_NONE || aggs[a].nxnodes > 0;
         A.acc[a] = (const u64 *)t->d_acc[a];
         A.cnt[a] = (const u64 *)t->d_cnt[a];
         A.col[a] = (const u64 *)aggs[a].d_col;

@@ -394,6 +394,47 @@ static obj_p delegate_select(obj_p dict, const char *why) {
     return fail(b);
 }
 
+/* (op x y) with x / y a column symbol, an i64 / f64 atom or another such list -> nodes in evaluation order (rfx_xnode_t).
+ * Returns the index of the node holding the value, -1 with *why set when the shape is not covered, -2 on an upload error. */
+static int build_xnodes(obj_p tab, obj_p e, rfx_xnode_t *nodes, int *nn, int *ncols, const char **why) {
+    if (e->type != RFX_TYPE_LIST || e->len != 3) { *why = "expression is not (op x y)"; return -1; }
+    int xf = fn_id(RFX_AS_LIST(e)[0]);
+    if (xf < F_ADD || xf > F_FDIV) { *why = "expression operator is not + - * div"; return -1; }
+    rfx_xnode_t node;
+    memset(&node, 0, sizeof(node));
+    node.op = RFX_X_ADD + (xf - F_ADD);
+    rfx_xoperand_t *ops[2] = {&node.l, &node.r};
+    for (int j = 0; j < 2; j++) {
+        obj_p x = RFX_AS_LIST(e)[1 + j];
+        if (x->type == -RFX_TYPE_SYMBOL) {
+            obj_p c = table_col(tab, x->i64);
+            if (!c || !(c->type == RFX_TYPE_I64 || c->type == RFX_TYPE_F64)) { *why = "expression operand column type"; return -1; }
+            const void *d;
+            if (resident(c, 0, &d) != RFX_OK) return -2;
+            ops[j]->kind = RFX_XK_COL;
+            ops[j]->type = col_ctype(c);
+            ops[j]->d_col = d;
+            (*ncols)++;
+        } else if (x->type == -RFX_TYPE_I64) {
+            ops[j]->kind = RFX_XK_ATOM;
+            ops[j]->type = RFX_I64;
+            ops[j]->i = x->i64;
+        } else if (x->type == -RFX_TYPE_F64) {
+            ops[j]->kind = RFX_XK_ATOM;
+            ops[j]->type = RFX_F64;
+            ops[j]->f = x->f64;
+        } else if (x->type == RFX_TYPE_LIST) {
+            int sub = build_xnodes(tab, x, nodes, nn, ncols, why);
+            if (sub < 0) return sub;
+            ops[j]->kind = RFX_XK_NODE;
+            ops[j]->node = sub;
+        } else { *why = "expression operand is neither a column, an i64/f64 atom nor an expression"; return -1; }
+    }
+    if (*nn >= RFX_MAX_XNODES) { *why = "expression deeper than RFX_MAX_XNODES operations"; return -1; }
+    nodes[*nn] = node;
+    return (*nn)++;
+}
+
 /* ------------------------------------------------------------------------------------------------ select */
 rfx_obj_p rfx_select(rfx_obj_p dict) {
     rfx_host_bind();
@@ -405,7 +446,7 @@ rfx_obj_p rfx_select(rfx_obj_p dict) {
     if (!tab || tab->type == RFX_TYPE_ERR) return tab;
     obj_p res = NULL;
     const char *why = NULL;
-    void *tmp[2 * RFX_MAX_AGGS + RFX_MAX_KEYS + 4]; /* device scratch of this query (gathered columns, bucket / composite keys): freed at `done` */
+    void *tmp[RFX_MAX_AGGS * (2 + 2 * RFX_MAX_XNODES) + RFX_MAX_KEYS + 4]; /* device scratch of this query (gathered columns, bucket / composite keys): freed at `done` */
     int ntmp = 0;
     obj_p where = dict_get(dict, "where"), by = dict_get(dict, "by");
     obj_p dkeys = RFX_AS_LIST(dict)[0], dvals = RFX_AS_LIST(dict)[1];
@@ -427,6 +468,7 @@ rfx_obj_p rfx_select(rfx_obj_p dict) {
         }
         /* output mappings */
         rfx_agg_t aggs[RFX_MAX_AGGS];
+        rfx_xnode_t xnodes[RFX_MAX_AGGS][RFX_MAX_XNODES];
         int64_t names[RFX_MAX_AGGS];
         int outtype[RFX_MAX_AGGS];
         int nagg = 0;
@@ -442,35 +484,16 @@ rfx_obj_p rfx_select(rfx_obj_p dict) {
             memset(&aggs[nagg], 0, sizeof(aggs[nagg]));
             aggs[nagg].kind = KIND[f - F_SUM];
             if (a->type == RFX_TYPE_LIST && a->len == 3) {
-                /* (aggr (op x y)), op in + - * div, x / y a column or an i64 / f64 atom: folded on the device */
-                int xf = fn_id(RFX_AS_LIST(a)[0]);
-                obj_p xo[2] = {RFX_AS_LIST(a)[1], RFX_AS_LIST(a)[2]}, xc[2] = {NULL, NULL};
-                if (xf < F_ADD || xf > F_FDIV || f == F_COUNT || f == F_FIRST) { why = "mapping argument is not (+|-|*|div x y) under sum/avg/min/max"; goto out; }
-                for (int j = 0; j < 2; j++) {
-                    if (xo[j]->type == -RFX_TYPE_SYMBOL) {
-                        xc[j] = table_col(tab, xo[j]->i64);
-                        if (!xc[j] || !(xc[j]->type == RFX_TYPE_I64 || xc[j]->type == RFX_TYPE_F64)) { why = "expression operand column type"; goto out; }
-                    } else if (xo[j]->type != -RFX_TYPE_I64 && xo[j]->type != -RFX_TYPE_F64) { why = "expression operand is neither a column nor an i64/f64 atom"; goto out; }
-                }
-                if (!xc[0] && !xc[1]) { why = "expression without a column"; goto out; }
-                const int ci = xc[0] ? 0 : 1, oi = 1 - ci; /* ci: the operand stored as the aggregate's column */
-                const void *d;
-                if (resident(xc[ci], 0, &d) != RFX_OK) { res = fail_hip("column upload"); goto done; }
-                aggs[nagg].d_col = d;
-                aggs[nagg].col_type = col_ctype(xc[ci]);
-                aggs[nagg].xop = RFX_X_ADD + (xf - F_ADD);
-                aggs[nagg].xflags = (ci == 1) ? RFX_XF_SWAP : 0;
-                if (xc[oi]) {
-                    if (resident(xc[oi], 0, &d) != RFX_OK) { res = fail_hip("column upload"); goto done; }
-                    aggs[nagg].d_xrhs_col = d;
-                    aggs[nagg].xrhs_type = col_ctype(xc[oi]);
-                } else if (xo[oi]->type == -RFX_TYPE_F64) {
-                    aggs[nagg].xrhs_type = RFX_F64;
-                    aggs[nagg].xrhs_f = xo[oi]->f64;
-                } else {
-                    aggs[nagg].xrhs_type = RFX_I64;
-                    aggs[nagg].xrhs_i = xo[oi]->i64;
-                }
+                /* (aggr expr), expr = (op x y) over columns, atoms and nested expressions: folded on the device */
+                if (f == F_COUNT || f == F_FIRST) { why = "count / first of an expression"; goto out; }
+                int nn = 0, ncols = 0;
+                int top = build_xnodes(tab, a, xnodes[nagg], &nn, &ncols, &why);
+                if (top == -2) { res = fail_hip("column upload"); goto done; }
+                if (top < 0) goto out;
+                if (ncols == 0) { why = "expression without a column"; goto out; }
+                aggs[nagg].nxnodes = nn;
+                aggs[nagg].xnodes = xnodes[nagg];
+                aggs[nagg].col_type = RFX_I64;
                 outtype[nagg] = (f == F_AVG || rfx_agg_input_type(&aggs[nagg]) == RFX_F64) ? RFX_TYPE_F64 : RFX_TYPE_I64;
                 names[nagg++] = k;
                 continue;
@@ -570,13 +593,23 @@ rfx_obj_p rfx_select(rfx_obj_p dict) {
             if (rc == -1) { why = "where: shape"; goto out; }
             if (rc) { res = fail_hip("where"); goto done; }
             int ok = 1;
-            const void *seen_src[2 * RFX_MAX_AGGS + 1];
-            void *seen_dst[2 * RFX_MAX_AGGS + 1];
+            const void *seen_src[RFX_MAX_AGGS * (2 + 2 * RFX_MAX_XNODES) + 1];
+            void *seen_dst[RFX_MAX_AGGS * (2 + 2 * RFX_MAX_XNODES) + 1];
             int nseen = 0;
-            for (int a = 0; a <= 2 * nagg && ok; a++) {
-                /* every device column the aggregates read (argument and second expression operand), then the key */
-                const void **slot = (a < nagg) ? &aggs[a].d_col : (a < 2 * nagg) ? &aggs[a - nagg].d_xrhs_col : &dk;
-                if (a == 2 * nagg && !by) break;
+            /* every device column the aggregates read (plain argument, single-operation operand, expression-tree leaves), then the key */
+            const void **slots[RFX_MAX_AGGS * (2 + 2 * RFX_MAX_XNODES) + 1];
+            int nslots = 0;
+            for (int a = 0; a < nagg; a++) {
+                slots[nslots++] = &aggs[a].d_col;
+                slots[nslots++] = &aggs[a].d_xrhs_col;
+                for (int j = 0; j < aggs[a].nxnodes; j++) {
+                    if (xnodes[a][j].l.kind == RFX_XK_COL) slots[nslots++] = &xnodes[a][j].l.d_col;
+                    if (xnodes[a][j].r.kind == RFX_XK_COL) slots[nslots++] = &xnodes[a][j].r.d_col;
+                }
+            }
+            if (by) slots[nslots++] = &dk;
+            for (int si = 0; si < nslots && ok; si++) {
+                const void **slot = slots[si];
                 if (!*slot) continue;
                 int j = 0;
                 for (; j < nseen; j++)

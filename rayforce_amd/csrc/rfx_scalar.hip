@@ -140,7 +140,22 @@ extern "C" int rfx_hip_filter_aggr(rfx_ctx_t *c, const rfx_pred_t *preds, int np
 }
 
 extern "C" int rfx_agg_input_type(const rfx_agg_t *a) {
-    if (!a || a->xop == RFX_X_NONE) return a ? a->col_type : RFX_I64;
+    if (!a) return RFX_I64;
+    if (a->nxnodes > 0 && a->xnodes) { // expression tree: a node is f64 when it divides or any operand is f64
+        int f64[RFX_MAX_XNODES] = {0, 0, 0, 0};
+        const int n = a->nxnodes < RFX_MAX_XNODES ? a->nxnodes : RFX_MAX_XNODES;
+        for (int i = 0; i < n; i++) {
+            const rfx_xoperand_t *o[2] = {&a->xnodes[i].l, &a->xnodes[i].r};
+            int f = a->xnodes[i].op == RFX_X_FDIV;
+            for (int j = 0; j < 2; j++) {
+                if (o[j]->kind == RFX_XK_NODE) f |= (o[j]->node >= 0 && o[j]->node < i) ? f64[o[j]->node] : 0;
+                else f |= o[j]->type == RFX_F64;
+            }
+            f64[i] = f;
+        }
+        return f64[n - 1] ? RFX_F64 : RFX_I64;
+    }
+    if (a->xop == RFX_X_NONE) return a->col_type;
     return (a->xop == RFX_X_FDIV || a->col_type == RFX_F64 || a->xrhs_type == RFX_F64) ? RFX_F64 : RFX_I64;
 }
 

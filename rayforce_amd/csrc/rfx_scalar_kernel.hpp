@@ -77,21 +77,62 @@ __device__ __forceinline__ void sel_col(u64 (&x)[E], const u64 (&v)[NC][E], int 
 }
 
 // The input of an expression aggregate, computed from the register tile: no temporary column exists.
+// Operations run in order; operand selection is wave-uniform (column index / atom / earlier result), values are per lane.
+template <int NC, int E>
+__device__ __forceinline__ void expr_operand(u64 (&o)[E], const u64 (&v)[NC][E], int kind, int idx, u64 atom, const u64 (&r0)[E], const u64 (&r1)[E],
+                                             const u64 (&r2)[E]) {
+    if (kind == RFX_XK_COL) sel_col<NC, E>(o, v, idx);
+    else if (kind == RFX_XK_ATOM) {
+#pragma unroll
+        for (int e = 0; e < E; e++) o[e] = atom;
+    } else {
+#pragma unroll
+        for (int e = 0; e < E; e++) o[e] = (idx == 0) ? r0[e] : ((idx == 1) ? r1[e] : r2[e]);
+    }
+}
+// One operation over columns / atoms: the common case, and the only one the group-by kernels evaluate in place (keeping the
+// general evaluator out of them keeps their register count where it was).
 template <int NC, int E>
 __device__ __forceinline__ void expr_input(u64 (&x)[E], const u64 (&v)[NC][E], const PlanExpr &X) {
+    const PlanXNode n = X.ops[0];
     u64 l[E], r[E];
-    if (X.l_col >= 0) sel_col<NC, E>(l, v, X.l_col);
+    if (n.l_kind == RFX_XK_COL) sel_col<NC, E>(l, v, n.l_idx);
     else {
 #pragma unroll
-        for (int e = 0; e < E; e++) l[e] = X.l_atom;
+        for (int e = 0; e < E; e++) l[e] = n.l_atom;
     }
-    if (X.r_col >= 0) sel_col<NC, E>(r, v, X.r_col);
+    if (n.r_kind == RFX_XK_COL) sel_col<NC, E>(r, v, n.r_idx);
     else {
 #pragma unroll
-        for (int e = 0; e < E; e++) r[e] = X.r_atom;
+        for (int e = 0; e < E; e++) r[e] = n.r_atom;
     }
 #pragma unroll
-    for (int e = 0; e < E; e++) x[e] = rfx_expr_eval(X.op, X.out_f64, X.l_f64, X.r_f64, l[e], r[e]);
+    for (int e = 0; e < E; e++) x[e] = rfx_expr_eval(n.op, n.o_f64, n.l_f64, n.r_f64, l[e], r[e]);
+}
+// Expression trees (up to RFX_MAX_XNODES operations, operands may be earlier results): K1's DEEP instantiations only.
+template <int NC, int E>
+__device__ __forceinline__ void expr_input_deep(u64 (&x)[E], const u64 (&v)[NC][E], const PlanExpr &X) {
+    u64 res[RFX_MAX_XNODES - 1][E]; // results of the operations before the last one (never read beyond nops - 2)
+#pragma unroll
+    for (int i = 0; i < RFX_MAX_XNODES - 1; i++) {
+#pragma unroll
+        for (int e = 0; e < E; e++) res[i][e] = 0;
+    }
+#pragma unroll
+    for (int i = 0; i < RFX_MAX_XNODES; i++) {
+        if (i >= X.nops) break; // wave-uniform
+        const PlanXNode n = X.ops[i];
+        u64 l[E], r[E];
+        expr_operand<NC, E>(l, v, n.l_kind, n.l_idx, n.l_atom, res[0], res[1], res[2]);
+        expr_operand<NC, E>(r, v, n.r_kind, n.r_idx, n.r_atom, res[0], res[1], res[2]);
+        if (i == X.nops - 1) {
+#pragma unroll
+            for (int e = 0; e < E; e++) x[e] = rfx_expr_eval(n.op, n.o_f64, n.l_f64, n.r_f64, l[e], r[e]);
+        } else if (i < RFX_MAX_XNODES - 1) {
+#pragma unroll
+            for (int e = 0; e < E; e++) res[i][e] = rfx_expr_eval(n.op, n.o_f64, n.l_f64, n.r_f64, l[e], r[e]);
+        }
+    }
 }
 
 
@@ -324,7 +365,7 @@ __device__ __forceinline__ void acc_update(Acc &a, int kind, int f64, const u64 
 struct AggR {
     int col, f64, kind;
 };
-template <int NC, int NA, int E, int NP, int NX = 0>
+template <int NC, int NA, int E, int NP, int NX = 0, bool DEEP = false>
 __device__ __forceinline__ void fold_tile(const PredSet<NP> &S, const AggR (&ag)[NA], const u64 (&v)[NC][E], const bool (&valid)[E], Acc (&acc)[NA],
                                           i64 &nsel, i64 row_of_e0, int jstride, const PlanExpr *xs = nullptr) {
     bool sel[E];
@@ -352,7 +393,8 @@ __device__ __forceinline__ void fold_tile(const PredSet<NP> &S, const AggR (&ag)
             for (int a = 0; a < NA; a++) used |= (ag[a].kind >= 0 && ag[a].col == RFX_XCOL + i);
             if (!used) continue; // wave-uniform
             u64 x[E];
-            expr_input<NC, E>(x, v, xs[i]);
+            if (DEEP) expr_input_deep<NC, E>(x, v, xs[i]);
+            else expr_input<NC, E>(x, v, xs[i]);
 #pragma unroll
             for (int a = 0; a < NA; a++) {
                 if (ag[a].kind >= 0 && ag[a].kind != RFX_AGG_COUNT && ag[a].col == RFX_XCOL + i)
@@ -363,7 +405,7 @@ __device__ __forceinline__ void fold_tile(const PredSet<NP> &S, const AggR (&ag)
 }
 
 // Workgroup partial layout in the workspace: ws[(block * (NA + 1) + a)] ; slot NA = selected-row count.
-template <int NC, int NA, int U, int NP, int NX = 0>
+template <int NC, int NA, int U, int NP, int NX = 0, bool DEEP = false>
 __global__ __launch_bounds__(RFX_BLOCK) void k_filter_aggr(const Plan P, Acc *__restrict__ ws) {
     constexpr int E = 2 * U;
     constexpr int TILE = RFX_BLOCK * E;     // rows per workgroup per iteration
@@ -406,7 +448,7 @@ __global__ __launch_bounds__(RFX_BLOCK) void k_filter_aggr(const Plan P, Acc *__
                 v[c][2 * j + 1] = q.y;
             }
         }
-        fold_tile<NC, NA, E, NP, NX>(S, ag, v, all, acc, nsel, row0 + base, JSTRIDE, xs);
+        fold_tile<NC, NA, E, NP, NX, DEEP>(S, ag, v, all, acc, nsel, row0 + base, JSTRIDE, xs);
     }
     // ragged tail: one workgroup, guarded element loads
     const i64 tail0 = nfull * TILE;
@@ -421,7 +463,7 @@ __global__ __launch_bounds__(RFX_BLOCK) void k_filter_aggr(const Plan P, Acc *__
 #pragma unroll
             for (int c = 0; c < NC; c++) v[c][e] = valid[e] ? cols[c][row] : 0ULL;
         }
-        fold_tile<NC, NA, E, NP, NX>(S, ag, v, valid, acc, nsel, row0 + base, JSTRIDE, xs);
+        fold_tile<NC, NA, E, NP, NX, DEEP>(S, ag, v, valid, acc, nsel, row0 + base, JSTRIDE, xs);
     }
 
     // wave reduction (64 lanes), then across the 4 waves through LDS.  Counts are wave-uniform already: keep lane 0's.

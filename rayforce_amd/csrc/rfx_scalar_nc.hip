@@ -7,18 +7,25 @@
 
 // Fast shapes (<= 4 distinct columns, <= 4 predicates, <= 4 aggregates) get tight instantiations; everything else
 // runs the one fully general instantiation of its column count.
-template <int NC, int NA, int NP, int NX = 0>
+template <int NC, int NA, int NP, int NX = 0, bool DEEP = false>
 static void launch_shape(rfx_ctx *c, const Plan &P, int grid, Acc *ws) {
     // 16-byte loads in flight per lane = NC * U.  In-process sweep on MI355X (bench.py --ab): U = 4 wins
     // for 1..4 columns (C2 6.77, C2b 6.92, C5 6.10 TB/s); the matching workgroups-per-CU choice is rfx_scalar_grid().
     constexpr int U = (NC <= 4) ? 4 : (NC <= 6) ? 2 : 1;
-    hipLaunchKernelGGL((k_filter_aggr<NC, NA, U, NP, NX>), dim3(grid), dim3(RFX_BLOCK), 0, c->stream, P, ws);
+    hipLaunchKernelGGL((k_filter_aggr<NC, NA, U, NP, NX, DEEP>), dim3(grid), dim3(RFX_BLOCK), 0, c->stream, P, ws);
 }
 
 #define RFX_CAT2(a, b) a##b
 #define RFX_CAT(a, b) RFX_CAT2(a, b)
 int RFX_CAT(rfx_launch_filter_aggr_nc, RFX_NC)(rfx_ctx *c, const Plan &P, int grid, Acc *ws, int *na_stride) {
     if (P.nx > 0) { // aggregates over element-wise expressions, folded on the fly
+        bool deep = false; // any expression tree (more than one operation)?  Those take the general evaluator's instantiation.
+        for (int i = 0; i < P.nx; i++) deep |= P.xs[i].nops > 1;
+        if (deep) {
+            *na_stride = 9;
+            launch_shape<RFX_NC, 8, 8, RFX_MAX_EXPRS, true>(c, P, grid, ws);
+            return RFX_OK;
+        }
 #if RFX_NC <= 4
         if (P.npred <= 4 && P.nagg <= 4) {
             *na_stride = 5;

@@ -235,6 +235,8 @@ class Engine:
         """``(fn (op lhs rhs))``: lhs / rhs are columns or atoms, at least one a column."""
         if len(expr) != 3 or expr[0] not in L.XOPS:
             raise RfxError(f"unsupported expression {expr!r}: (op lhs rhs) with op in + - * div")
+        if isinstance(expr[1], tuple) or isinstance(expr[2], tuple):
+            return self._agg_expr_tree(a, expr, table, n)
         op, lhs, rhs = expr
         l = self._resolve(lhs, table) if isinstance(lhs, (str, torch.Tensor)) else lhs
         r = self._resolve(rhs, table) if isinstance(rhs, (str, torch.Tensor)) else rhs
@@ -264,7 +266,9 @@ class Engine:
         distinct argument columns each (predicate and key columns need plan slots too)."""
         chunks, cur, nx, cols = [], [], 0, set()
         for fn, col in aggs:
-            ops = [x for x in col[1:] if isinstance(x, (str, torch.Tensor))] if isinstance(col, tuple) else ([col] if col is not None else [])
+            def leaves(e):
+                return [y for x in e[1:] for y in (leaves(x) if isinstance(x, tuple) else [x])]
+            ops = [x for x in leaves(col) if isinstance(x, (str, torch.Tensor))] if isinstance(col, tuple) else ([col] if col is not None else [])
             ids = {x if isinstance(x, str) else x.data_ptr() for x in ops}
             x = 1 if isinstance(col, tuple) else 0
             if cur and (len(cur) >= L.RFX_MAX_AGGS or nx + x > L.RFX_MAX_EXPRS or len(cols | ids) > 4):
@@ -277,10 +281,51 @@ class Engine:
             chunks.append(cur)
         return chunks or [[]]
 
+    def _agg_expr_tree(self, a, expr, table, n):
+        """Nested expression -> rfx_xnode_t list in evaluation order (operands: column / atom / earlier node)."""
+        nodes = []
+
+        def operand(x, o):
+            nonlocal n
+            if isinstance(x, tuple):
+                o.kind, o.node = L.RFX_XK_NODE, build(x)
+                return
+            x = self._resolve(x, table) if isinstance(x, (str, torch.Tensor)) else x
+            if isinstance(x, torch.Tensor):
+                col = self._check_col(x, n)
+                n = col.numel() if n is None else n
+                o.kind, o.type, o.d_col = L.RFX_XK_COL, _ctype_of(col), col.data_ptr()
+                self._keep.append(col)
+            elif isinstance(x, float):
+                o.kind, o.type, o.f = L.RFX_XK_ATOM, L.RFX_F64, x
+            else:
+                o.kind, o.type, o.i = L.RFX_XK_ATOM, L.RFX_I64, L.NULL_I64 if x is None else int(x)
+
+        def build(e) -> int:
+            if len(e) != 3 or e[0] not in L.XOPS:
+                raise RfxError(f"unsupported expression {e!r}: (op lhs rhs) with op in + - * div")
+            node = L.XNode()
+            node.op = L.XOPS[e[0]]
+            operand(e[1], node.l)
+            operand(e[2], node.r)
+            nodes.append(node)
+            return len(nodes) - 1
+
+        build(expr)
+        if len(nodes) > L.RFX_MAX_XNODES:
+            raise RfxError(f"expression too deep: at most {L.RFX_MAX_XNODES} operations")
+        arr = (L.XNode * len(nodes))(*nodes)
+        self._keep.append(arr)
+        a.nxnodes, a.xnodes = len(nodes), arr
+        a.d_col, a.col_type = None, L.RFX_I64
+        return n
+
     def _arg_f64(self, col, table) -> bool:
         """Element type of an aggregate's argument: a column, or (op lhs rhs) with the reference's promotion."""
         if isinstance(col, tuple):
             def f(x):
+                if isinstance(x, tuple):
+                    return self._arg_f64(x, table)
                 x = self._resolve(x, table) if isinstance(x, (str, torch.Tensor)) else x
                 return x.dtype == torch.float64 if isinstance(x, torch.Tensor) else isinstance(x, float)
             return col[0] == "div" or f(col[1]) or f(col[2])
@@ -341,7 +386,9 @@ class Engine:
 
         for fn, col in aggs:
             if isinstance(col, tuple):
-                gathered.append((fn, (col[0], pick(col[1]), pick(col[2]))))
+                def pick_tree(e):
+                    return (e[0],) + tuple(pick_tree(x) if isinstance(x, tuple) else pick(x) for x in e[1:])
+                gathered.append((fn, pick_tree(col)))
                 continue
             col = self._resolve(col, table) if col is not None else None
             gathered.append((fn, self.at_ids(col, ids) if col is not None else None))

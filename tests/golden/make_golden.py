@@ -195,6 +195,33 @@ def main():
                     arrays[f"xagg_{xi_}_{wi}_{bi}_{o}"] = r[o]
         cases.append({"kind": "xagg", "index": xi_, "n": n, "seed": seed, "keys": keys})
 
+    # ---- 4c'. nested expressions (TPC-H Q1 shape): sum(p*(1-d)), sum(p*(1-d)*(1+t)) ... by two low-cardinality keys ----
+    n = 70_003
+    q1 = {"rf": rfo.gen_i64(n, 71, 3), "ls": rfo.gen_i64(n, 72, 2), "q": rfo.gen_i64(n, 73, 50) + 1, "p": rfo.gen_f64(n, 74) * 1e5,
+          "d": np.round(rfo.gen_f64(n, 75) * 0.1, 2), "t": np.round(rfo.gen_f64(n, 76) * 0.08, 2), "sd": rfo.gen_i64(n, 77, 2500)}
+    q1["d"][rfo.gen_i64(n, 78, 60) == 0] = np.nan
+    q1["q"][rfo.gen_i64(n, 79, 70) == 0] = NULL
+    # inputs are regenerated from the same seeds by tests/golden_cases.py::q1_table (np.round is deterministic)
+    Q1 = ("sq: (sum q) sp: (sum p) sdp: (sum (* p (- 1 d))) sch: (sum (* (* p (- 1 d)) (+ 1 t))) aq: (avg q) ap: (avg p) ad: (avg d) "
+          "mx: (max (div (* p q) (+ q 1))) c: (count q)")
+    with ref.Session() as s:
+        s.table("t", q1)
+        s.eval(f"(set r1 (select {{{Q1} from: t by: {{rf: rf ls: ls}}}}))")          # no where: with two keys (reference defect otherwise)
+        s.eval(f"(set r2 (select {{{Q1} from: t where: (<= sd 2400) by: rf}}))")      # where: with one key
+        s.eval(f"(set r3 (select {{{Q1} from: t where: (<= sd 2400)}}))")              # scalar
+        outs = ["sq", "sp", "sdp", "sch", "aq", "ap", "ad", "mx", "c"]
+        for o in outs + ["rf", "ls"]:
+            s.out(f"q1a_{o}", f"(at r1 '{o})")
+        for o in outs + ["rf"]:
+            s.out(f"q1b_{o}", f"(at r2 '{o})")
+        for o in outs:
+            s.out(f"q1c_{o}", f"(at r3 '{o})")
+        r = s.run(threads=8)
+    for k, v in r.items():
+        if k.startswith("q1"):
+            arrays[k] = v
+    cases.append({"kind": "q1"})
+
     # ---- 4d. bucketed keys: (xbar col width), truth table on special values and a grouped query ----
     xb = np.array([0, 1, -1, 9, 10, 11, -9, -10, -11, NULL, 2**63 - 1, -(2**63) + 1, 25, -25], np.int64)
     arrays["xbar_in"] = xb

@@ -128,6 +128,28 @@ def xagg_cases():
                 yield f"x{c['index']}w{wi}b{bi}", t, w, by, {o: arr(f"xagg_{c['index']}_{wi}_{bi}_{o}") for o in names}
 
 
+Q1 = {"sq": ("sum", "q"), "sp": ("sum", "p"), "sdp": ("sum", ("*", "p", ("-", 1, "d"))), "sch": ("sum", ("*", ("*", "p", ("-", 1, "d")), ("+", 1, "t"))),
+      "aq": ("avg", "q"), "ap": ("avg", "p"), "ad": ("avg", "d"), "mx": ("max", ("div", ("*", "p", "q"), ("+", "q", 1))), "c": ("count", "q")}
+
+
+def q1_table():
+    """The Q1-shaped table of tests/golden/make_golden.py section 4c', from the same seeds."""
+    n = 70_003
+    t = {"rf": rfo.gen_i64(n, 71, 3), "ls": rfo.gen_i64(n, 72, 2), "q": rfo.gen_i64(n, 73, 50) + 1, "p": rfo.gen_f64(n, 74) * 1e5,
+         "d": np.round(rfo.gen_f64(n, 75) * 0.1, 2), "t": np.round(rfo.gen_f64(n, 76) * 0.08, 2), "sd": rfo.gen_i64(n, 77, 2500)}
+    t["d"][rfo.gen_i64(n, 78, 60) == 0] = np.nan
+    t["q"][rfo.gen_i64(n, 79, 70) == 0] = NULL
+    return t
+
+
+def q1_cases():
+    """TPC-H Q1 shape with nested expressions: (id, table, extra clauses, wanted columns)."""
+    t = q1_table()
+    yield "two-keys", t, {"by": {"rf": "rf", "ls": "ls"}}, {o: arr(f"q1a_{o}") for o in list(Q1) + ["rf", "ls"]}
+    yield "where-one-key", t, {"where": ("<=", "sd", 2400), "by": "rf"}, {o: arr(f"q1b_{o}") for o in list(Q1) + ["rf"]}
+    yield "where-scalar", t, {"where": ("<=", "sd", 2400)}, {o: arr(f"q1c_{o}") for o in Q1}
+
+
 def xbar_case():
     """(xbar col width) truth tables + two grouped queries over bucketed keys.  NOTE: the second query has `where:` with two
     `by:` entries -- the combination the reference answers defectively; it is captured but only its group COUNT

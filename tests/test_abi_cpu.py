@@ -32,7 +32,8 @@ def test_library_exports_every_declared_symbol(built):
 def test_struct_layouts(built):
     from rayforce_amd import _lib as L
     assert C.sizeof(L.Pred) == 40 and L.Pred.op.offset == 24 and L.Pred.u.offset == 32
-    assert C.sizeof(L.Agg) == 48 and L.Agg.xop.offset == 16 and L.Agg.d_xrhs_col.offset == 24 and L.Agg.xu.offset == 40
+    assert C.sizeof(L.Agg) == 56 and L.Agg.xop.offset == 16 and L.Agg.d_xrhs_col.offset == 24 and L.Agg.nxnodes.offset == 36 and L.Agg.xu.offset == 40
+    assert L.Agg.xnodes.offset == 48 and C.sizeof(L.XNode) == 56 and L.XNode.r.offset == 32
     assert C.sizeof(L.Partial) == 64 and C.sizeof(L.Value) == 16
     assert C.sizeof(L.GroupTables) == 8 + 8 + 8 + 8 + 64 + 64
     from rayforce_amd.hostobj import Header
@@ -42,7 +43,7 @@ def test_struct_layouts(built):
 def test_abi_header_compiles_as_c_and_cxx(built, tmp_path):
     import subprocess
     src = tmp_path / "t.c"
-    src.write_text('#include "rfx_abi.h"\n#include "rfx_hip.h"\n#include "rfx_ops.h"\nint main(void){return (sizeof(rfx_obj_t)==16 && sizeof(rfx_agg_t)==48 && sizeof(rfx_pred_t)==40 && sizeof(rfx_partial_t)==64)?0:1;}\n')
+    src.write_text('#include "rfx_abi.h"\n#include "rfx_hip.h"\n#include "rfx_ops.h"\nint main(void){return (sizeof(rfx_obj_t)==16 && sizeof(rfx_agg_t)==56 && sizeof(rfx_xnode_t)==56 && sizeof(rfx_pred_t)==40 && sizeof(rfx_partial_t)==64)?0:1;}\n')
     for cc, std in (("gcc", "-std=c11"), ("g++", "-std=c++17")):
         exe = tmp_path / ("a_" + cc)
         subprocess.run([cc, std, "-x", "c" if cc == "gcc" else "c++", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)

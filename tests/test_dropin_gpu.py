@@ -26,6 +26,10 @@ QUERIES = [
     ("q9", "{rev: (sum (* v a)) m: (max (- 100 a)) av: (avg (div a k2)) from: t where: (and (< a 500000) (> v 0.05))}", ["rev", "m", "av"]),
     ("q10", "{s: (sum (* v 2.0)) d: (sum (- a k3)) mn: (min (* v a)) from: t by: k1}", ["k1", "s", "d", "mn"]),
     ("q11", "{s: (sum (+ v a)) from: t where: (> v 0.5) by: k}", ["k", "s"]),
+    # nested expressions: TPC-H Q1 shape (two keys, no where: -- see the reference defect) and Q1's filter with one key
+    ("q14", "{sq: (sum a) dp: (sum (* v (- 1 v))) ch: (sum (* (* v (- 1 v)) (+ 1 k2))) aq: (avg a) c: (count a) from: t by: {k1: k1 k3: k3}}",
+     ["k1", "k3", "sq", "dp", "ch", "aq", "c"]),
+    ("q15", "{dp: (sum (* v (- 1 v))) m: (max (div (* v a) (+ k2 1))) from: t where: (<= a 900000) by: k1}", ["k1", "dp", "m"]),
     # bucketed keys: (xbar column width)
     ("q12", "{s: (sum v) c: (count a) from: t by: {b: (xbar k 10)}}", ["b", "s", "c"]),
     ("q13", "{m: (max v) from: t where: (< a 700000) by: {b: (xbar a 50000)}}", ["b", "m"]),  # value span > rows: sparse arm, see UNORDERED

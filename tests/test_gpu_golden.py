@@ -67,6 +67,15 @@ def test_aggregates_over_expressions(eng, case):
         G.same(got[o].cpu().numpy(), want[o], o)
 
 
+@pytest.mark.parametrize("case", list(G.q1_cases()), ids=lambda c: c[0])
+def test_nested_expressions_q1_shape(eng, case):
+    """TPC-H Q1 shape: nine aggregates, four of them over expressions up to three operations deep, folded on the fly."""
+    _, t, extra, want = case
+    got = eng.select({"from": {k: eng.column(v) for k, v in t.items()}, **G.Q1, **extra})
+    for o in want:
+        G.same(got[o].cpu().numpy(), want[o], o)
+
+
 def test_xbar_buckets(eng):
     x, tables, t, want = G.xbar_case()
     from rayforce_amd import _lib as L

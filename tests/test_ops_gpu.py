@@ -117,6 +117,14 @@ def test_select_expression_aggregates(ops):
     check(run_select(ops, host2, {**q2, "by": "k"}), rfo.select({"from": host2, **q2, "by": "k"}))
     with pytest.raises(RuntimeError, match="not covered by the MI355X path"):
         run_select(ops, host, {"c": ("count", ("*", "a", "v"))})
+    # nested expressions (TPC-H Q1 shape): up to four operations, folded on the fly
+    q3 = {"dp": ("sum", ("*", "v", ("-", 1, "v"))), "ch": ("sum", ("*", ("*", "v", ("-", 1.0, "v")), ("+", 1, "b"))),
+          "mx": ("max", ("div", ("*", "v", "a"), ("+", "b", 2))), "plain": ("avg", "a")}
+    for extra in ({}, {"where": ("<", "b", 5)}, {"where": nested}, {"by": "k"}, {"by": "k", "where": nested}):
+        check(run_select(ops, host, {**q3, **extra}), rfo.select({"from": host, **q3, **extra}))
+        assert ops.rfx_last_select_on_gpu() == 1
+    with pytest.raises(RuntimeError, match="deeper than"):
+        run_select(ops, host, {"s": ("sum", ("+", ("+", ("+", ("+", ("+", "a", 1), 1), 1), 1), 1))})
 
 
 def test_select_by_xbar(ops):

@@ -118,6 +118,14 @@ def test_aggregates_over_expressions(case):
         G.same(got[o], want[o], o)
 
 
+@pytest.mark.parametrize("case", list(G.q1_cases()), ids=lambda c: c[0])
+def test_nested_expressions_q1_shape(case):
+    _, t, extra, want = case
+    got = rfo.select({"from": t, **G.Q1, **extra})
+    for o in want:
+        G.same(got[o], want[o], o)
+
+
 def test_xbar_buckets():
     x, tables, t, want = G.xbar_case()
     for w, ref_out in tables.items():
