@@ -4,6 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from rayforce_amd.engine import Engine
 eng = Engine(0)
+eng.tune(flags=int(os.environ.get("RFX_FLAGS", "0")))
 N = int(float(sys.argv[1])) if len(sys.argv) > 1 else 1_000_000_000
 v1, v2, v3 = eng.gen_f64(N, 11), eng.gen_f64(N, 12), eng.gen_f64(N, 13)
 for keys in (100, 10_000, 100_000, 1_000_000):
