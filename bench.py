@@ -49,14 +49,14 @@ def log(*a):
 
 WORKLOADS = {
     "c1": dict(desc="configs[0]: (sum v), v f64[1e7] uniform [0,1), seed 1 -- the reference's `make bench` plumbing case, here on the GPU", rows=10_000_000,
-               bytes_per_row=8, dtype="f64", kernel="k_filter_aggr<1, 1, 4, 1, 0>"),
+               bytes_per_row=8, dtype="f64", kernel="k_filter_aggr<1, 1, 4, 1, 0, false>"),
     "c2": dict(desc="configs[1]: select sum(a) where a < 100000, a i64 uniform [0,1e6), seed 2", rows=1_000_000_000, bytes_per_row=8, dtype="int64",
-               kernel="k_filter_aggr<1, 1, 4, 1, 0>"),
+               kernel="k_filter_aggr<1, 1, 4, 1, 0, false>"),
     "c2_1pct": dict(desc="C2 at 1 % selectivity (a < 10000) -- SURVEY 8d asks for 1 / 10 / 50 %", rows=1_000_000_000, bytes_per_row=8, dtype="int64",
-                    kernel="k_filter_aggr<1, 1, 4, 1, 0>"),
-    "c2_50pct": dict(desc="C2 at 50 % selectivity (a < 500000)", rows=1_000_000_000, bytes_per_row=8, dtype="int64", kernel="k_filter_aggr<1, 1, 4, 1, 0>"),
+                    kernel="k_filter_aggr<1, 1, 4, 1, 0, false>"),
+    "c2_50pct": dict(desc="C2 at 50 % selectivity (a < 500000)", rows=1_000_000_000, bytes_per_row=8, dtype="int64", kernel="k_filter_aggr<1, 1, 4, 1, 0, false>"),
     "c2b": dict(desc="north-star: select sum(b) where a < 100000, a i64 seed 2, b f64 seed 3", rows=1_000_000_000, bytes_per_row=16, dtype="f64",
-                kernel="k_filter_aggr<2, 1, 4, 1, 0>"),
+                kernel="k_filter_aggr<2, 1, 4, 1, 0, false>"),
     "c3": dict(desc="configs[2]: select sum(v) by k, k i64 uniform [0,1e6) seed 4, v f64 seed 5", rows=1_000_000_000, bytes_per_row=16, dtype="f64",
                kernel="k_part_scope_hist<1, 0> + k_part_scatter_wc<2, 0> + k_part_aggregate<1>"),
     "c3w": dict(desc="metric shape filter->group-by->sum: select sum(v) by k where a < 100000 (10 %), k/v as C3, a as C2", rows=1_000_000_000,
@@ -64,10 +64,10 @@ WORKLOADS = {
     "q2": dict(desc="several by: columns (H2O Q2 shape): select sum(v) by {id1, id2}, id1/id2 i64 uniform [0,100) seeds 10/11, v f64 seed 5", rows=1_000_000_000,
                bytes_per_row=24, dtype="f64", kernel="k_part_scope_hist<1, 0> x2 + k_group_dense<3, true, 1024>"),
     "x6": dict(desc="expression aggregate (TPC-H Q6 shape): select sum(p * d) where q < 24 and d >= 0.05 and d <= 0.07; p f64 seed 12, d f64 seed 13 "
-                    "scaled to [0,0.1), q i64 uniform [0,50) seed 14", rows=1_000_000_000, bytes_per_row=24, dtype="f64", kernel="k_filter_aggr<3, 4, 4, 4, 1>"),
+                    "scaled to [0,0.1), q i64 uniform [0,50) seed 14", rows=1_000_000_000, bytes_per_row=24, dtype="f64", kernel="k_filter_aggr<3, 4, 4, 4, 1, false>"),
     "q1": dict(desc="nested expressions (TPC-H Q1 shape): sum(q), sum(p), sum(p*(1-d)), sum(p*(1-d)*(1+t)), avg(q), avg(p), avg(d), count by {rf, ls} "
                     "where sd <= 2400; rf in [0,3), ls in [0,2), q i64 [1,50], p f64, d f64 [0,.1), t f64 [0,.08), sd i64 [0,2500)", rows=1_000_000_000,
-               bytes_per_row=56, dtype="f64", kernel="k_part_scope_hist<2, 8> x2 + k_group_dense<7, true, 256>"),
+               bytes_per_row=56, dtype="f64", kernel="k_part_scope_hist<2, 8> x2 + k_derive x2 + k_group_dense<5|6|8, true, 256> (three passes)"),
     "k9": dict(desc="sparse keys (range > rows -> the reference's open-addressing path): select sum(v) by k, k = 1000003 * (i64 uniform [0,1e6) seed 4) - 77, "
                     "v f64 seed 5", rows=1_000_000_000, bytes_per_row=16, dtype="f64", kernel="k_part_hist<1, 0> + k_part_scatter_soa<2, 2, 0> + k_part_hash_aggregate<2>"),
     "w2": dict(desc="where ids: (where (< a 100000)) on the C2 column -> 1e8 ascending i64 row ids (8 B/row in + 8 B/selected row out)", rows=1_000_000_000,
@@ -77,7 +77,7 @@ WORKLOADS = {
     "g2": dict(desc="gather: (at b ids) for the 1e8 ids of w2 (8 B id + 8 B random read + 8 B write per id)", rows=1_000_000_000, bytes_per_row=2.4,
                dtype="f64", kernel="k_gather8"),
     "c5": dict(desc="configs[4] per-GPU shard: avg,min,max(d) where a<0.316228 and b>0.683772 and c!=0.25, 4 x f64 seeds 6-9", rows=250_000_000,
-               bytes_per_row=32, dtype="f64", kernel="k_filter_aggr<4, 4, 4, 4, 0>"),
+               bytes_per_row=32, dtype="f64", kernel="k_filter_aggr<4, 4, 4, 4, 0, false>"),
 }
 
 
