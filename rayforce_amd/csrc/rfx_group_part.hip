@@ -194,6 +194,7 @@ __global__ __launch_bounds__(RFX_BLOCK) void k_part_scope_hist(const Plan P, int
 template <int NC>
 static void launch_scope_hist(rfx_ctx *c, const Plan &P, int key_idx, int nwg, ScopePart *parts, u64 *bitmap) {
     if (P.npred == 0) hipLaunchKernelGGL((k_part_scope_hist<NC, 0>), dim3(nwg), dim3(RFX_BLOCK), 0, c->stream, P, key_idx, c->d_pc_counts, parts, (u64 *)0);
+    else if (P.npred == 1) hipLaunchKernelGGL((k_part_scope_hist<NC, 1>), dim3(nwg), dim3(RFX_BLOCK), 0, c->stream, P, key_idx, c->d_pc_counts, parts, bitmap); // one predicate: the C3w shape
     else hipLaunchKernelGGL((k_part_scope_hist<NC, RFX_MAX_PREDS>), dim3(nwg), dim3(RFX_BLOCK), 0, c->stream, P, key_idx, c->d_pc_counts, parts, bitmap);
 }
 
