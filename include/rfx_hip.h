@@ -178,7 +178,9 @@ enum {
     RFX_TUNE_NO_SOA_WC = 2048,      /* partitioned path, 2-3 value planes: 32-byte register-direct records instead of tile-sorted planes */
     RFX_TUNE_NO_LDS_SPLIT = 1024,   /* dense group-by: never split the aggregates into several LDS-table passes */
     RFX_TUNE_NO_EMIT_WC = 512,      /* where: plain masked id stores instead of the LDS-ring write-combining emit */
-    RFX_TUNE_NO_SEL_COMPACT = 256   /* partitioned path under a filter: never compact the selected rows first */
+    RFX_TUNE_NO_SEL_COMPACT = 256,  /* partitioned path under a filter: never compact the selected rows first */
+    RFX_TUNE_NO_DEEP_GROUP = 4096,  /* dense group-by, LDS tables: materialise expression trees (k_derive) instead of evaluating them in the pass */
+    RFX_TUNE_NO_LDS_REPLICAS = 8192 /* dense group-by, a handful of groups: one LDS table set per workgroup, no lane-private replicas */
 };
 int rfx_hip_ctx_tune(rfx_ctx_t *ctx, int blocks_per_cu, int flags);
 

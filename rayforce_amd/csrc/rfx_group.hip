@@ -26,14 +26,22 @@ struct GroupArgs {
     int kidx[RFX_MAX_KEYS];
     u64 kmn[RFX_MAX_KEYS];
     u64 kmul[RFX_MAX_KEYS];
+    int rep_shift; // TINY form: log2 of the number of lane-private table replicas
     u64 *first;
     u64 *acc[RFX_MAX_AGGS];
     u64 *cnt[RFX_MAX_AGGS];
 };
 
 // ---- K7 + K10, one pass.  LDS = true: tables privatised in dynamic LDS, merged at the end. ----
-template <int NC, bool LDS, int BLOCK>
+// TINY = true (256-lane LDS form only), two things for small table sets:
+//  * expression TREES are evaluated on the fly too (expr_input_deep) instead of being materialised by k_derive, so a wide plan
+//    (TPC-H Q1: 7 columns, 8 outputs) streams ONCE;
+//  * the tables are replicated 2^rep_shift times, replica = low bits of the lane id: with two to four groups all 64 lanes of
+//    a ds_add hit the same addresses and the LDS serialises them; with lane-private replicas every lane of an instruction has
+//    its own cell and bank.  Replicas are folded before the merge.
+template <int NC, bool LDS, int BLOCK, bool TINY = false>
 __global__ __launch_bounds__(BLOCK) void k_group_dense(const Plan P, const GroupArgs G) {
+    constexpr bool DEEP = TINY;
     constexpr int U = (NC <= 2) ? 4 : (NC <= 4 ? 2 : 1);
     constexpr int E = 2 * U;
     constexpr int TILE = BLOCK * E;
@@ -51,14 +59,17 @@ __global__ __launch_bounds__(BLOCK) void k_group_dense(const Plan P, const Group
         nacc++;
         if (agg_has_cnt(P.aggs[a].kind, P.aggs[a].f64)) ncnt++;
     }
-    unsigned *lfirst = (unsigned *)(smem + (i64)nacc * range);
-    unsigned *lcnt = lfirst + range;
+    const int rs = TINY ? G.rep_shift : 0;
+    const i64 lrange = range << rs; // cells per LDS array
+    const unsigned rl = TINY ? ((unsigned)tid & ((1u << rs) - 1u)) : 0u; // this lane's replica
+    unsigned *lfirst = (unsigned *)(smem + (i64)nacc * lrange);
+    unsigned *lcnt = lfirst + lrange;
     if (LDS) {
-        for (i64 i = tid; i < range; i += BLOCK) lfirst[i] = 0xffffffffu;
-        for (i64 i = tid; i < (i64)ncnt * range; i += BLOCK) lcnt[i] = 0;
+        for (i64 i = tid; i < lrange; i += BLOCK) lfirst[i] = 0xffffffffu;
+        for (i64 i = tid; i < (i64)ncnt * lrange; i += BLOCK) lcnt[i] = 0;
         for (int a = 0; a < G.nagg; a++) {
             const u64 id = acc_identity(P.aggs[a].kind, P.aggs[a].f64);
-            for (i64 i = tid; i < range; i += BLOCK) smem[(i64)a * range + i] = id;
+            for (i64 i = tid; i < lrange; i += BLOCK) smem[(i64)a * lrange + i] = id;
         }
         __syncthreads();
     }
@@ -119,7 +130,8 @@ __global__ __launch_bounds__(BLOCK) void k_group_dense(const Plan P, const Group
             const u64 row = (u64)(P.row0 + base + (i64)(e >> 1) * JSTRIDE + (e & 1));
             if (LDS) {
                 const unsigned lrow = (unsigned)(base + (i64)(e >> 1) * JSTRIDE + (e & 1));
-                if (lrow < lfirst[slot]) atomicMin(&lfirst[slot], lrow);
+                const u64 ls = TINY ? ((slot << rs) + rl) : slot;
+                if (lrow < lfirst[ls]) atomicMin(&lfirst[ls], lrow);
             } else {
                 // plain pre-check: a stale (larger) value only costs a redundant atomic, never a wrong minimum
                 if (row < G.first[slot]) atomicMin((unsigned long long *)&G.first[slot], (unsigned long long)row);
@@ -130,14 +142,19 @@ __global__ __launch_bounds__(BLOCK) void k_group_dense(const Plan P, const Group
             const PlanAgg ag = P.aggs[a];
             const bool hc = agg_has_cnt(ag.kind, ag.f64);
             u64 x[E];
-            if (ag.col >= RFX_XCOL) expr_input<NC, E>(x, v, P.xs[ag.col - RFX_XCOL]); // expression folded on the fly
-            else if (ag.col >= 0) sel_col<NC, E>(x, v, ag.col);
+            if (ag.col >= RFX_XCOL) { // expression folded on the fly
+                if (DEEP) expr_input_deep<NC, E>(x, v, P.xs[ag.col - RFX_XCOL]);
+                else expr_input<NC, E>(x, v, P.xs[ag.col - RFX_XCOL]);
+            } else if (ag.col >= 0) sel_col<NC, E>(x, v, ag.col);
 #pragma unroll
             for (int e = 0; e < E; e++) {
                 if (!((m >> e) & 1u)) continue;
                 const u64 slot = key[e];
                 if (slot >= (u64)range) continue;
-                if (LDS) group_apply(&smem[(i64)a * range + slot], &lcnt[(i64)ci * range + slot], ag.kind, ag.f64, x[e], ag.skipnull);
+                if (LDS) {
+                    const u64 ls = TINY ? ((slot << rs) + rl) : slot;
+                    group_apply(&smem[(i64)a * lrange + ls], &lcnt[(i64)ci * lrange + ls], ag.kind, ag.f64, x[e], ag.skipnull);
+                }
                 else group_apply(&G.acc[a][slot], G.cnt[a] ? &G.cnt[a][slot] : (u64 *)0, ag.kind, ag.f64, x[e], ag.skipnull);
             }
             ci += hc ? 1 : 0;
@@ -146,8 +163,10 @@ __global__ __launch_bounds__(BLOCK) void k_group_dense(const Plan P, const Group
 
     if (LDS) {
         __syncthreads();
+        const int nrep = 1 << rs;
         for (i64 i = tid; i < range; i += BLOCK) {
-            const unsigned lf = lfirst[i];
+            unsigned lf = lfirst[i << rs];
+            for (int r = 1; r < nrep; r++) lf = min(lf, lfirst[(i << rs) + r]);
             if (lf == 0xffffffffu) continue; // slot untouched by this workgroup
             const u64 f = (u64)(P.row0 + (i64)lf);
             if (f < G.first[i]) atomicMin((unsigned long long *)&G.first[i], (unsigned long long)f);
@@ -155,8 +174,22 @@ __global__ __launch_bounds__(BLOCK) void k_group_dense(const Plan P, const Group
             for (int a = 0; a < G.nagg; a++) {
                 const PlanAgg ag = P.aggs[a];
                 const bool hc = agg_has_cnt(ag.kind, ag.f64);
-                group_merge_cell(&G.acc[a][i], hc ? &G.cnt[a][i] : (u64 *)0, ag.kind, ag.f64, smem[(i64)a * range + i],
-                                 hc ? (u64)lcnt[(i64)ci * range + i] : 0ULL);
+                u64 av = smem[(i64)a * lrange + (i << rs)];
+                u64 cv = hc ? (u64)lcnt[(i64)ci * lrange + (i << rs)] : 0ULL;
+                for (int r = 1; r < nrep; r++) { // fold the replicas (replica order: fixed, so a workgroup's partial is reproducible)
+                    const u64 x = smem[(i64)a * lrange + (i << rs) + r];
+                    if (hc) cv += (u64)lcnt[(i64)ci * lrange + (i << rs) + r];
+                    switch (ag.kind) {
+                        case RFX_AGG_MIN: av = ((i64)x < (i64)av) ? x : av; break;
+                        case RFX_AGG_MAX: av = ((i64)x > (i64)av) ? x : av; break;
+                        case RFX_AGG_COUNT: av += x; break;
+                        case RFX_AGG_SUM:
+                            if (!ag.f64) { av += x; break; }
+                            [[fallthrough]];
+                        default: av = (u64)__double_as_longlong(rfx_as_f64(av) + rfx_as_f64(x)); break; // f64 SUM, AVG
+                    }
+                }
+                group_merge_cell(&G.acc[a][i], hc ? &G.cnt[a][i] : (u64 *)0, ag.kind, ag.f64, av, cv);
                 ci += hc ? 1 : 0;
             }
         }
@@ -217,7 +250,11 @@ extern "C" int rfx_hip_group_tables_init(rfx_ctx_t *c, const rfx_agg_t *aggs, co
 #define RFX_LDS_GROUP_BIG_BYTES (160 * 1024) /* one 1024-thread workgroup per CU owning the whole LDS (mid-range key counts) */
 
 template <int NC>
-static int launch_group(rfx_ctx *c, const Plan &P, const GroupArgs &G, int grid, size_t lds_bytes) {
+static int launch_group(rfx_ctx *c, const Plan &P, const GroupArgs &G, int grid, size_t lds_bytes, bool deep) {
+    if (deep) { // TINY form (group_dense_run decides): 256 lanes, table replicas within the 64 KB LDS budget
+        hipLaunchKernelGGL((k_group_dense<NC, true, RFX_BLOCK, true>), dim3(grid), dim3(RFX_BLOCK), lds_bytes, c->stream, P, G);
+        return RFX_OK;
+    }
     if (lds_bytes > RFX_LDS_GROUP_BYTES) {
         static bool attr_set = false; // per template instance: dynamic LDS above 64 KB must be opted into once
         if (!attr_set) {
@@ -275,8 +312,16 @@ static int lds_pass_split(const rfx_ctx *c, const rfx_agg_t *aggs, const rfx_gro
     return (total > cap && h >= 1 && h < t->nagg) ? h : 0;
 }
 
+// Expression trees stay inside the scatter pass when the table set fits the 64 KB LDS form: nothing is materialised and the
+// operand columns are read once.  Everywhere else (big LDS, partitioned, atomics) k_derive writes them out first.
+#define RFX_LDS_TINY_BYTES ((size_t)32 << 10)
+static bool group_deep_inline(const rfx_ctx *c, const rfx_agg_t *aggs, const rfx_group_tables_t *t, i64 nrows) {
+    return !(c->flags & (RFX_TUNE_NO_LDS_TABLES | RFX_TUNE_NO_DEEP_GROUP)) && nrows < (1LL << 32) && lds_table_bytes(t->range, aggs, t->nagg) <= RFX_LDS_GROUP_BYTES;
+}
+
 static int group_dense_run(rfx_ctx_t *c, Plan &P, GroupArgs &G, const rfx_agg_t *aggs, const rfx_group_tables_t *t, bool allow_part, bool *need_materialise) {
-    if (rfx_plan_has_deep_expr(P)) { // expression trees: evaluated into scratch columns first (k_derive), then plain columns
+    const bool deep = rfx_plan_has_deep_expr(P) && group_deep_inline(c, aggs, t, P.nrows);
+    if (rfx_plan_has_deep_expr(P) && !deep) { // expression trees: evaluated into scratch columns first (k_derive), then plain columns
         if (P.ncols + P.nx > RFX_MAX_COLS) {
             rfx_set_error("group_dense_accumulate: too many distinct columns once the expression trees are materialised");
             return RFX_ELIMIT;
@@ -295,7 +340,15 @@ static int group_dense_run(rfx_ctx_t *c, Plan &P, GroupArgs &G, const rfx_agg_t 
         narr += 1 + (agg_has_cnt(aggs[a].kind, rfx_agg_input_type(&aggs[a]) == RFX_F64) ? 1 : 0);
     }
     (void)narr;
-    size_t lds_bytes = lds_table_bytes(t->range, aggs, t->nagg);
+    // TINY form: expression trees inline, or two to four groups under several aggregates (lane-private replicas, <= 32 KB).
+    // Measured (1e9 rows, avg v1,v2,v3): 2 groups 16.7 -> 9.9 ms with replicas; from 6 groups on the same-address serialisation
+    // hides behind the stream and replicas change nothing (keys 6 / 32 / 100: 9.1 vs 8.8-9.5 ms), so they stay off there.
+    int rs = 0;
+    if (t->range <= 4 && group_deep_inline(c, aggs, t, P.nrows) && !(c->flags & RFX_TUNE_NO_LDS_REPLICAS))
+        while (rs < 6 && lds_table_bytes(t->range << (rs + 1), aggs, t->nagg) <= RFX_LDS_TINY_BYTES) rs++;
+    const bool tiny = deep || (rs >= 3 && t->nagg >= 2);
+    G.rep_shift = tiny ? rs : 0;
+    size_t lds_bytes = lds_table_bytes(tiny ? (t->range << rs) : t->range, aggs, t->nagg);
     const size_t lds_cap = (c->flags & RFX_TUNE_NO_BIG_LDS) ? RFX_LDS_GROUP_BYTES : RFX_LDS_GROUP_BIG_BYTES;
     const bool use_lds = lds_bytes <= lds_cap && !(c->flags & RFX_TUNE_NO_LDS_TABLES) && P.nrows < (1LL << 32);
     if (need_materialise) {
@@ -314,14 +367,14 @@ static int group_dense_run(rfx_ctx_t *c, Plan &P, GroupArgs &G, const rfx_agg_t 
     rc = RFX_OK;
     RFX_KERNEL_BEGIN(c);
     switch (P.ncols) {
-        case 1: rc = launch_group<1>(c, P, G, grid, lds_bytes); break;
-        case 2: rc = launch_group<2>(c, P, G, grid, lds_bytes); break;
-        case 3: rc = launch_group<3>(c, P, G, grid, lds_bytes); break;
-        case 4: rc = launch_group<4>(c, P, G, grid, lds_bytes); break;
-        case 5: rc = launch_group<5>(c, P, G, grid, lds_bytes); break;
-        case 6: rc = launch_group<6>(c, P, G, grid, lds_bytes); break;
-        case 7: rc = launch_group<7>(c, P, G, grid, lds_bytes); break;
-        default: rc = launch_group<8>(c, P, G, grid, lds_bytes); break;
+        case 1: rc = launch_group<1>(c, P, G, grid, lds_bytes, tiny); break;
+        case 2: rc = launch_group<2>(c, P, G, grid, lds_bytes, tiny); break;
+        case 3: rc = launch_group<3>(c, P, G, grid, lds_bytes, tiny); break;
+        case 4: rc = launch_group<4>(c, P, G, grid, lds_bytes, tiny); break;
+        case 5: rc = launch_group<5>(c, P, G, grid, lds_bytes, tiny); break;
+        case 6: rc = launch_group<6>(c, P, G, grid, lds_bytes, tiny); break;
+        case 7: rc = launch_group<7>(c, P, G, grid, lds_bytes, tiny); break;
+        default: rc = launch_group<8>(c, P, G, grid, lds_bytes, tiny); break;
     }
     RFX_KERNEL_END(c);
     if (rc != RFX_OK) return rc;
@@ -340,7 +393,7 @@ extern "C" int rfx_hip_group_dense_accumulate(rfx_ctx_t *c, const int64_t *d_key
     int key_idx = 0;
     const int hs = lds_pass_split(c, aggs, t);
     rc = hs ? RFX_ELIMIT : rfx_plan_build(&P, preds, npred, logic, aggs, t->nagg, d_key, &key_idx, nrows, row0);
-    if (rc == RFX_OK && rfx_plan_has_deep_expr(P) && P.ncols + P.nx > RFX_MAX_COLS) rc = RFX_ELIMIT; // no room to materialise the trees
+    if (rc == RFX_OK && rfx_plan_has_deep_expr(P) && !group_deep_inline(c, aggs, t, nrows) && P.ncols + P.nx > RFX_MAX_COLS) rc = RFX_ELIMIT; // no room to materialise the trees
     if (rc == RFX_ELIMIT && t->nagg > 1) { // too many columns / expressions for one launch, or tables that fit LDS only in parts
         rfx_group_tables_t t1, t2;
         const int h = split_tables(t, &t1, &t2, hs);
@@ -371,7 +424,7 @@ extern "C" int rfx_hip_group_dense_accumulate_keys(rfx_ctx_t *c, const void *con
     int k0 = 0;
     const int hs = lds_pass_split(c, aggs, t);
     rc = hs ? RFX_ELIMIT : rfx_plan_build(&P, preds, npred, logic, aggs, t->nagg, d_keys[0], &k0, nrows, row0);
-    if (rc == RFX_OK && rfx_plan_has_deep_expr(P) && P.ncols + (nkeys - 1) + P.nx > RFX_MAX_COLS) rc = RFX_ELIMIT; // (upper bound on the key columns still to add)
+    if (rc == RFX_OK && rfx_plan_has_deep_expr(P) && !group_deep_inline(c, aggs, t, nrows) && P.ncols + (nkeys - 1) + P.nx > RFX_MAX_COLS) rc = RFX_ELIMIT; // (upper bound on the key columns still to add)
     if (rc == RFX_ELIMIT && t->nagg > 1) {
         rfx_group_tables_t t1, t2;
         const int h = split_tables(t, &t1, &t2, hs);

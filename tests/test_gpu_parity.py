@@ -455,6 +455,31 @@ def test_expression_aggregates(eng, n, keys):
     check_select(eng, host, {"plain": ("sum", "v"), "x": ("sum", ("*", "v", "w")), "c": ("count", "a"), "by": "k"})  # mixed plain / expression
 
 
+@pytest.mark.parametrize("flags", [0, 4096, 8192])
+@pytest.mark.parametrize("keys", [2, 3, 5, 600, 40_000])
+def test_nested_expression_trees_by_group(eng, flags, keys):
+    """Expression TREES under by: -- evaluated inside the LDS-table pass (flags 0, tables <= 64 KB) or materialised by k_derive
+    (flags 4096, and every larger table): same answers, nulls / NaN in the operands included; wide plans (7 distinct columns,
+    8 outputs, two key columns) stay in one launch.  Two to four groups: lane-private table replicas (off with flags 8192)."""
+    n = 250_003
+    host = table(n, keys=keys, nulls=True)
+    host["b"] = rfo.gen_i64(n, 77, 9) - 1
+    host["g"] = rfo.gen_i64(n, 78, 3)
+    q = {"s1": ("sum", ("*", "v", ("-", 1, "w"))), "s2": ("sum", ("*", ("*", "v", ("-", 1, "w")), ("+", 1, "w"))), "s3": ("sum", ("+", ("*", "a", "b"), "b")),
+         "mx": ("max", ("-", ("*", "a", 2), "b")), "av": ("avg", ("*", ("+", "a", 1), "v")), "p": ("sum", "v"), "c": ("count", "a"), "mn": ("min", ("div", ("+", "a", "b"), 3))}
+    try:
+        eng.tune(flags=flags)
+        check_select(eng, host, {**q, "by": "k"})
+        check_select(eng, host, {**q, "by": "k", "where": ("and", ("<", "b", 6), (">", "v", 0.05))})
+        if keys <= 600:
+            check_select(eng, host, {**q, "by": {"g": "g", "k": "k"}})
+        if keys <= 3:  # plain aggregates over a handful of groups take the replicated form too
+            check_select(eng, host, {"by": "k", "s": ("sum", "v"), "si": ("sum", "a"), "av": ("avg", "w"), "mn": ("min", "a"), "mx": ("max", "v"), "c": ("count", "a"), "f": ("first", "a")})
+            check_select(eng, host, {"by": "k", "where": (">", "v", 0.5), "av": ("avg", "a"), "s": ("sum", "w")})
+    finally:
+        eng.tune(flags=0)
+
+
 def test_expression_aggregates_refusals(eng):
     from rayforce_amd._lib import RfxError
     d = dev(eng, table(100))

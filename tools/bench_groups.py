@@ -7,7 +7,8 @@ eng = Engine(0)
 eng.tune(flags=int(os.environ.get("RFX_FLAGS", "0")))
 N = int(float(sys.argv[1])) if len(sys.argv) > 1 else 1_000_000_000
 v1, v2, v3 = eng.gen_f64(N, 11), eng.gen_f64(N, 12), eng.gen_f64(N, 13)
-for keys in (100, 10_000, 100_000, 1_000_000):
+KEYS = [int(float(x)) for x in os.environ.get("RFX_KEYS", "100,1e4,1e5,1e6").split(",")]
+for keys in KEYS:
     k = eng.gen_i64(N, 4, keys)
     t = {"k": k, "v1": v1, "v2": v2, "v3": v3}
     for name, aggs in (("sum v1", [("sum", "v1")]), ("sum v1, avg v3", [("sum", "v1"), ("avg", "v3")]), ("avg v1,v2,v3", [("avg", "v1"), ("avg", "v2"), ("avg", "v3")]),
