@@ -333,6 +333,15 @@ int rfx_hip_group_dense_accumulate_keys(rfx_ctx_t *ctx, const void *const *d_key
                                         int nkeys, const rfx_pred_t *preds, int npred, int logic, const rfx_agg_t *aggs,
                                         int64_t nrows, int64_t row0, const rfx_group_tables_t *t);
 
+/* ---- several key columns whose ranges overflow the composite key: the row-hash path (index_group_list, core/index.c:2731-2790) ----
+ * d_out[r] = the reference's row hash of the key tuple: h = U64_HASH_SEED, then for every column in order
+ * h = hash_index_u64(h, col_c[r]) (value_first = 0: unfiltered i64-like columns, core/hash.h:130-143) or
+ * h = hash_index_u64(col_c[r], h) (value_first = 1: filtered rows / f64 columns, core/index.c:155-175).
+ * Group on d_out with the sparse-key path; rfx_hip_replace_null_i64
+ * (d_out[r] = d_col[r] is null ? repl : d_col[r]) prepares key columns with nulls for the min == max collision proof. */
+int rfx_hip_row_hash(rfx_ctx_t *ctx, const void *const *d_cols, int nkeys, int64_t nrows, int value_first, int64_t *d_out);
+int rfx_hip_replace_null_i64(rfx_ctx_t *ctx, const int64_t *d_col, int64_t nrows, int64_t repl, int64_t *d_out);
+
 /* ---- bucketed group keys: (xbar col width), XBARI64 core/ops.h:192-193 ----
  * d_out[r] = null for a null input, else the largest multiple of `width` (> 0) that is <= d_col[r].  Group on the result
  * (`by: {t: (xbar ts 60000)}`). */

@@ -186,7 +186,57 @@ def mask_of(where_spec, table) -> np.ndarray:
 
 
 class NotPerfect(Exception):
-    """index_group_list_perfect returned NULL_OBJ: the reference takes its row-hash path (not restated)."""
+    """index_group_list_perfect returned NULL_OBJ: the reference takes its row-hash path (group_rows below)."""
+
+
+U64_HASH_SEED = np.uint64(0x9DDFEA08EB382D69)  # core/hash.h:35
+
+
+def hash_index_u64(h, k):
+    """hash_index_u64(h, k), core/hash.h:86-97, over uint64 arrays (wrapping arithmetic)."""
+    h, k = np.asarray(h, np.uint64), np.asarray(k, np.uint64)
+    with np.errstate(over="ignore"):
+        a = (h ^ k) * U64_HASH_SEED
+        a ^= a >> np.uint64(47)
+        b = (((k << np.uint64(31)) | (k >> np.uint64(33))) ^ a) * U64_HASH_SEED
+        b ^= b >> np.uint64(47)
+        b *= U64_HASH_SEED
+    return b
+
+
+def row_hash(cols, filter_ids=None) -> np.ndarray:
+    """__index_list_precalc_hash (core/index.c:274-309): start from U64_HASH_SEED, fold every key column in.  Unfiltered
+    i64-like columns go through hash_index_i64_batch = hash_index_u64(running, value) (core/hash.h:130-143); filtered rows and
+    f64 columns through hash_index_u64(value, running) (index_hash_obj_partial, core/index.c:155-175)."""
+    cols = [_col(c) for c in cols]
+    n = len(cols[0]) if filter_ids is None else len(filter_ids)
+    h = np.full(n, U64_HASH_SEED, np.uint64)
+    for c in cols:
+        v = (c if filter_ids is None else c[filter_ids]).view(np.uint64)
+        h = hash_index_u64(v, h) if (filter_ids is not None or c.dtype == np.float64) else hash_index_u64(h, v)
+    return h.view(np.int64)
+
+
+def group_rows(keys, filter_ids=None, order="first"):
+    """index_group_list after the perfect path gave up (core/index.c:2731-2790): rows with bitwise-equal key tuples
+    (__index_list_cmp_row, :59-104) form a group.  order="first": the single-threaded arm (:2760-2781), groups in first
+    occurrence order; order="radix": the multi-threaded arm (index_group_list_radix, :2556-2729), groups ordered by
+    (row hash & 1023, first occurrence).  Returns (group id per selected row, first selected row per group, groups)."""
+    cols = [_col(k) if filter_ids is None else _col(k)[filter_ids] for k in keys]
+    n = len(cols[0])
+    if n == 0:
+        return np.empty(0, np.int64), np.empty(0, np.int64), 0
+    rows = np.stack([c.view(np.int64) for c in cols], axis=1)
+    _, first, inv = np.unique(rows, axis=0, return_index=True, return_inverse=True)
+    inv = inv.reshape(-1)
+    if order == "radix":
+        h = row_hash(keys, filter_ids)
+        rank = np.lexsort((first, h[first] & 1023))
+    else:
+        rank = np.argsort(first, kind="stable")
+    new_id = np.empty(len(first), np.int64)
+    new_id[rank] = np.arange(len(first))
+    return new_id[inv], first[rank].astype(np.int64), len(first)
 
 
 def composite_key(keys, filter_ids=None):
@@ -309,7 +359,7 @@ def select(query: dict) -> dict:
     """Same contract as rayforce_amd.Engine.select, numpy in / numpy out."""
     table = query["from"]
     where_spec, by = query.get("where"), query.get("by")
-    outs = [(k, v) for k, v in query.items() if k not in ("from", "where", "by", "take")]
+    outs = [(k, v) for k, v in query.items() if k not in ("from", "where", "by", "take", "order")]
     ids = None
     if where_spec is not None:
         ids = where(mask_of(where_spec, table))
@@ -320,10 +370,15 @@ def select(query: dict) -> dict:
                 key = srcs[0]
                 gids, firsts, groups, _ = group_index(key, ids)
             else:
-                comp, tmax, _, _ = composite_key(srcs, ids)
                 key = srcs[0]
-                # the composite column is already restricted to the selected rows: no filter below this line
-                gids, firsts, groups, _ = group_index(comp, None, scope=(0, tmax))
+                try:
+                    comp, tmax, _, _ = composite_key(srcs, ids)
+                    # the composite column is already restricted to the selected rows: no filter below this line
+                    gids, firsts, groups, _ = group_index(comp, None, scope=(0, tmax))
+                except NotPerfect:
+                    if any(_col(c).dtype != np.int64 for c in srcs):
+                        raise
+                    gids, firsts, groups = group_rows(srcs, ids, query.get("order", "first"))
             pos = firsts if ids is None else ids[firsts]
             res = {nm: (_col(c)[pos] if groups else np.empty(0, np.int64)) for nm, c in zip(names, srcs)}
         else:

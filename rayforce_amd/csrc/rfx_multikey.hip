@@ -9,7 +9,7 @@
 // pass that writes the composite column (NK x 8 B/row in, 8 B/row out; the reference materialises the same column, :2386),
 // k_composite_decode turns the emitted composite keys back into one key column (groups elements; replaces the reference's
 // at_ids gather over first rows, which on several GPUs would need rows another rank owns).
-#include "rfx_common.hpp"
+#include "rfx_group_common.hpp"
 
 struct KeyParts {
     int n;
@@ -164,6 +164,104 @@ extern "C" int rfx_hip_xbar_i64(rfx_ctx_t *c, const int64_t *d_col, int64_t nrow
     if (nrows <= 0) return RFX_OK;
     RFX_REQUIRE(d_col && d_out && ((uintptr_t)d_col & 15) == 0 && ((uintptr_t)d_out & 15) == 0, RFX_EINVAL, "16-byte aligned device buffers expected");
     hipLaunchKernelGGL(k_xbar_i64, dim3(c->num_cus * 8), dim3(RFX_BLOCK), 0, c->stream, (const u64 *)d_col, (i64)nrows, (i64)width, (u64 *)d_out);
+    RFX_HIP_CHECK(hipGetLastError());
+    return RFX_OK;
+}
+
+// ---- several key columns whose ranges do NOT multiply into 64 bits: the row-hash path (index_group_list, core/index.c:2731-2790) ----
+// The reference hashes every row's key tuple -- h = U64_HASH_SEED, then column by column h = hash_index_u64(h, col_c[row]) for
+// unfiltered i64-like columns (hash_index_i64_batch, core/hash.h:130-143) but hash_index_u64(col_c[row], h) -- arguments the
+// other way round -- under a filter and for f64 columns (index_hash_obj_partial, core/index.c:155-175): `value_first` picks --
+// and groups rows by hash with a full tuple comparison on collision (__index_list_cmp_row, :59-104).  k_row_hash writes that same hash as one i64 column
+// (NK x 8 B/row in, 8 B/row out); the sparse-key group-by then runs on it, and the caller proves the absence of collisions
+// from per-group min == max of every key column (Engine._group_by_row_hash).  With the reference's own hash the radix order
+// of its multi-threaded path (hash & 1023, then first occurrence; :2465-2729) can be reproduced exactly.
+template <int NK>
+__global__ __launch_bounds__(RFX_BLOCK) void k_row_hash(const KeyParts K, i64 nrows, int value_first, u64 *__restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const i64 wave_id = (i64)blockIdx.x * (RFX_BLOCK / RFX_WAVE) + (threadIdx.x >> 6);
+    const i64 nwaves = (i64)gridDim.x * (RFX_BLOCK / RFX_WAVE);
+    const i64 nfull = nrows / 512;
+    for (i64 q = wave_id; q < nfull; q += nwaves) {
+        const i64 base = q * 512 + lane * 2;
+        u64 h[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) h[e] = RFX_U64_HASH_SEED;
+#pragma unroll
+        for (int c = 0; c < NK; c++) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const u64x2 t = rfx_ld2(K.col[c] + base + j * 128);
+                h[2 * j] = value_first ? rfx_hash_index_u64(t.x, h[2 * j]) : rfx_hash_index_u64(h[2 * j], t.x);
+                h[2 * j + 1] = value_first ? rfx_hash_index_u64(t.y, h[2 * j + 1]) : rfx_hash_index_u64(h[2 * j + 1], t.y);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            u64x2 o;
+            o.x = h[2 * j];
+            o.y = h[2 * j + 1];
+            *(u64x2 *)(out + base + j * 128) = o;
+        }
+    }
+    if (blockIdx.x == 0) {
+        for (i64 r = nfull * 512 + threadIdx.x; r < nrows; r += RFX_BLOCK) {
+            u64 h = RFX_U64_HASH_SEED;
+#pragma unroll
+            for (int c = 0; c < NK; c++) h = value_first ? rfx_hash_index_u64(K.col[c][r], h) : rfx_hash_index_u64(h, K.col[c][r]);
+            out[r] = h;
+        }
+    }
+}
+
+extern "C" int rfx_hip_row_hash(rfx_ctx_t *c, const void *const *d_cols, int nkeys, int64_t nrows, int value_first, int64_t *d_out) {
+    RFX_REQUIRE(c && d_cols, RFX_EINVAL, "NULL argument");
+    RFX_REQUIRE(nkeys >= 1 && nkeys <= RFX_MAX_KEYS, RFX_ELIMIT, "1..RFX_MAX_KEYS key columns");
+    if (nrows <= 0) return RFX_OK;
+    RFX_REQUIRE(d_out && ((uintptr_t)d_out & 15) == 0, RFX_EINVAL, "output must be a 16-byte aligned device buffer");
+    KeyParts K;
+    memset(&K, 0, sizeof(K));
+    K.n = nkeys;
+    for (int i = 0; i < nkeys; i++) {
+        RFX_REQUIRE(d_cols[i] && ((uintptr_t)d_cols[i] & 15) == 0, RFX_EINVAL, "key columns must be 16-byte aligned device buffers");
+        K.col[i] = (const u64 *)d_cols[i];
+    }
+    const int grid = c->num_cus * 8;
+    RFX_KERNEL_BEGIN(c);
+#define RFX_RH(N) case N: hipLaunchKernelGGL((k_row_hash<N>), dim3(grid), dim3(RFX_BLOCK), 0, c->stream, K, (i64)nrows, value_first, (u64 *)d_out); break
+    switch (nkeys) {
+        RFX_RH(1);
+        RFX_RH(2);
+        RFX_RH(3);
+        RFX_RH(4);
+        RFX_RH(5);
+        RFX_RH(6);
+        RFX_RH(7);
+        default: RFX_RH(8);
+    }
+#undef RFX_RH
+    RFX_KERNEL_END(c);
+    RFX_HIP_CHECK(hipGetLastError());
+    return RFX_OK;
+}
+
+// out = (x is null) ? repl : x -- lets min / max (which skip nulls) see a null key as a value of its own in the collision proof
+__global__ __launch_bounds__(RFX_BLOCK) void k_replace_null_i64(const u64 *__restrict__ in, i64 nrows, u64 repl, u64 *__restrict__ out) {
+    const i64 npairs = nrows / 2;
+    for (i64 i = blockIdx.x * (i64)RFX_BLOCK + threadIdx.x; i < npairs; i += (i64)gridDim.x * RFX_BLOCK) {
+        u64x2 t = rfx_ld2(in + 2 * i);
+        t.x = ((i64)t.x == RFX_NULL_I64_D) ? repl : t.x;
+        t.y = ((i64)t.y == RFX_NULL_I64_D) ? repl : t.y;
+        *(u64x2 *)(out + 2 * i) = t;
+    }
+    if ((nrows & 1) && blockIdx.x == 0 && threadIdx.x == 0) out[nrows - 1] = ((i64)in[nrows - 1] == RFX_NULL_I64_D) ? repl : in[nrows - 1];
+}
+
+extern "C" int rfx_hip_replace_null_i64(rfx_ctx_t *c, const int64_t *d_col, int64_t nrows, int64_t repl, int64_t *d_out) {
+    RFX_REQUIRE(c, RFX_EINVAL, "ctx is NULL");
+    if (nrows <= 0) return RFX_OK;
+    RFX_REQUIRE(d_col && d_out && ((uintptr_t)d_col & 15) == 0 && ((uintptr_t)d_out & 15) == 0, RFX_EINVAL, "16-byte aligned device buffers expected");
+    hipLaunchKernelGGL(k_replace_null_i64, dim3(c->num_cus * 8), dim3(RFX_BLOCK), 0, c->stream, (const u64 *)d_col, (i64)nrows, (u64)repl, (u64 *)d_out);
     RFX_HIP_CHECK(hipGetLastError());
     return RFX_OK;
 }

@@ -166,8 +166,8 @@ class GroupHook:
             kmin, kmax, seen, device = payload
             return allreduce_scope(kmin, kmax, seen, device, g)
         if phase == "tables":
-            store, layout = payload
-            allreduce_tables(store, layout, self.kinds, self.f64s, g)
+            store, layout, kinds, f64s = payload if len(payload) == 4 else (*payload, self.kinds, self.f64s)
+            allreduce_tables(store, layout, kinds, f64s, g)
             return None
         if phase == "flag":  # logical OR of a per-rank flag
             if self.shard.world == 1:

@@ -533,17 +533,19 @@ class Engine:
                 t.d_cnt[a] = None
         return t, store, layout
 
-    def group_by(self, key, aggs, where=None, table=None, total_rows: Optional[int] = None, row0: int = 0, _collective=None):
+    def group_by(self, key, aggs, where=None, table=None, total_rows: Optional[int] = None, row0: int = 0, _collective=None,
+                 order: str = "first"):
         """``select {aggs} from t [where p] by key`` -> dict(keys=, first=, results=[...], groups=n) of device tensors.
 
-        Group order is first occurrence.  `_collective(store, layout, aggs_arr, hashed)` -- if given -- is called
+        Group order is first occurrence (`order="radix"`: for key tuples that take the row-hash path, the order of the
+        reference's multi-threaded radix grouping instead -- hash & 1023, then first occurrence).  `_collective(store, layout, aggs_arr, hashed)` -- if given -- is called
         between the local scatter pass and the ranking step so that several GPUs can merge their tables.  (syncs)
         """
         chunks = self._agg_chunks(aggs)
         if len(chunks) > 1:  # more outputs than one table set carries: several passes (same groups, same order)
             r = None
             for ch in chunks:
-                part = self.group_by(key, ch, where, table, total_rows, row0, _collective)
+                part = self.group_by(key, ch, where, table, total_rows, row0, _collective, order)
                 if r is None:
                     r = part
                 else:
@@ -556,7 +558,10 @@ class Engine:
         if isinstance(key, (list, tuple)) and not is_xbar(key):
             # several key columns -> one composite dense key (index_group_list_perfect, core/index.c:2308-2424)
             kcols = [self._key_col(k, table) for k in key]
-            tmax, seen, multi = self._composite_plan(kcols, where, table, _collective)
+            try:
+                tmax, seen, multi = self._composite_plan(kcols, where, table, _collective)
+            except _NotPerfect as e:  # ranges overflow 64 bits / null keys: the reference's row-hash path (core/index.c:2731-2790)
+                return self._group_by_row_hash(kcols, e.scopes, aggs, where, table, total_rows, row0, _collective, order)
             key = kcols[0]
         else:
             key = self._key_col(key, table)
@@ -606,8 +611,9 @@ class Engine:
                 ptrs = (C.c_void_p * k)(*[kc.data_ptr() for kc in kcols])
                 L.check(self.lib.rfx_hip_group_dense_accumulate_keys(self._ctx, ptrs, (C.c_int64 * k)(*multi[0]), (C.c_int64 * k)(*multi[1]), k, parr,
                                                                      len(flat), logic, aarr, n, row0, C.byref(t)), "group_dense_accumulate_keys")
-            if _collective is not None:
-                _collective("tables", (store, layout))
+            if _collective is not None:  # the kinds of THIS launch's aggregates (a chunk of the query's, or the row-hash path's extras)
+                _collective("tables", (store, layout, [int(aarr[i].kind) for i in range(nagg)],
+                                       [L.agg_input_type(aarr[i]) == L.RFX_F64 for i in range(nagg)]))
             L.check(self.lib.rfx_hip_group_rank(self._ctx, C.byref(t), total_rows, C.byref(ng)), "group_rank")
         else:
             if multi is not None:  # sparse composite: the hashed path keys on the materialised column (core/index.c:2421 -> :2092)
@@ -663,6 +669,52 @@ class Engine:
         self.sync()
         return r
 
+    def row_hash(self, kcols, value_first: bool = False) -> torch.Tensor:
+        """The reference's row hash of the key tuples (__index_list_precalc_hash, core/index.c:274-309) as one i64 column."""
+        k, n = len(kcols), kcols[0].numel()
+        out = self.empty(n)
+        ptrs = (C.c_void_p * k)(*[kc.data_ptr() for kc in kcols])
+        L.check(self.lib.rfx_hip_row_hash(self._ctx, ptrs, k, n, int(value_first), out.data_ptr()), "row_hash")
+        return out
+
+    def _group_by_row_hash(self, kcols, scopes, aggs, where, table, total_rows, row0, _collective, order):
+        """Key tuples that do not fold into one 64-bit composite (H2O Q7: six keys; or null keys): group on the reference's
+        64-bit row hash with the sparse-key machinery, and PROVE the grouping: every key column rides along as a (min, max)
+        aggregate pair, and a group whose rows all agree on every key column is exactly one tuple.  A group with min != max
+        is a hash collision (two tuples, one hash; probability ~ groups^2 / 2^65) and raises instead of answering wrongly.
+        Nulls are keys like any other there (the reference compares tuples bitwise): min / max skip nulls, so a column that
+        holds nulls is checked through a copy with the nulls replaced by a value above its maximum."""
+        n = kcols[0].numel()
+        h = self.row_hash(kcols, value_first=where is not None)
+        checks, repl = [], []
+        for kc, (mn, mx) in zip(kcols, scopes):
+            if mn == L.NULL_I64:  # scope saw a null (INT64_MIN sorts lowest)
+                if mx == 2**63 - 1:
+                    raise RfxError("row-hash group-by: a key column holds both nulls and INT64_MAX; no spare value for the collision proof")
+                c2 = self.empty(n)
+                L.check(self.lib.rfx_hip_replace_null_i64(self._ctx, kc.data_ptr(), n, mx + 1, c2.data_ptr()), "replace_null_i64")
+                checks.append(c2)
+                repl.append(mx + 1)
+            else:
+                checks.append(kc)
+                repl.append(None)
+        extra = [(fn, c) for c in checks for fn in ("min", "max")]
+        r = self.group_by(h, list(aggs) + extra, where, table, total_rows, row0, _collective)
+        res, ex = r["results"][:len(aggs)], r["results"][len(aggs):]
+        key_columns = []
+        for i, rp in enumerate(repl):
+            mn, mx = ex[2 * i], ex[2 * i + 1]
+            if r["groups"] and not bool(torch.equal(mn, mx)):
+                raise RfxError("row-hash group-by: two key tuples share one 64-bit row hash (collision); not answered on this path")
+            key_columns.append(mx if rp is None else torch.where(mx == rp, torch.full_like(mx, L.NULL_I64), mx))
+        r["results"], r["key_columns"] = res, key_columns
+        if order == "radix" and r["groups"] > 1:  # (hash & 1023, first occurrence): core/index.c:2465-2729
+            perm = torch.argsort((r["keys"] & 1023) * (1 << 40) + torch.argsort(torch.argsort(r["first"])), stable=True)
+            r["keys"], r["first"] = r["keys"][perm], r["first"][perm]
+            r["results"] = [x[perm] for x in r["results"]]
+            r["key_columns"] = [x[perm] for x in r["key_columns"]]
+        return r
+
     def _key_col(self, spec, table) -> torch.Tensor:
         """A `by:` entry: a column, or ("xbar", column, width) -- the bucketed key is evaluated once into a scratch column
         (ray_xbar, core/math.c:1635; the reference does the same before grouping)."""
@@ -695,7 +747,8 @@ class Engine:
             return -1, 0, ([0] * k, [1] * k, [1] * k)
         amin, amax, amul = (C.c_int64 * k)(*mins), (C.c_int64 * k)(*maxs), (C.c_int64 * k)()
         tmax = C.c_int64()
-        L.check(self.lib.rfx_composite_plan(amin, amax, k, amul, C.byref(tmax)), "composite_plan")
+        if self.lib.rfx_composite_plan(amin, amax, k, amul, C.byref(tmax)) == L.RFX_ELIMIT:
+            raise _NotPerfect(list(zip(mins, maxs)), seen)
         return int(tmax.value), seen, (mins, list(amul), [mx - mn + 1 for mn, mx in zip(mins, maxs)])
 
     # ------------------------------------------------------------------ the select surface (core/query.c:607-654)
@@ -710,7 +763,7 @@ class Engine:
             raise RfxError("'select' expects 'from' param")  # core/query.c:281
         table = query["from"]
         where, by = query.get("where"), query.get("by")
-        outs = [(k, v) for k, v in query.items() if k not in ("from", "where", "by", "take")]
+        outs = [(k, v) for k, v in query.items() if k not in ("from", "where", "by", "take", "order")]
         lens = {int(c.numel()) for c in table.values()}
         if len(lens) > 1:
             raise RfxError("table columns differ in length")
@@ -718,7 +771,7 @@ class Engine:
         if by is not None:
             aggs = [(fn, col) for _, (fn, col) in outs]
             if isinstance(by, dict):  # by: {name: column ...}
-                r = self.group_by(list(by.values()), aggs, where, table)
+                r = self.group_by(list(by.values()), aggs, where, table, order=query.get("order", "first"))
                 res = dict(zip(by.keys(), r["key_columns"])) if len(by) > 1 else {next(iter(by)): r["keys"]}
             else:
                 r = self.group_by(by, aggs, where, table)
@@ -744,3 +797,11 @@ class Engine:
 
 class _NotFlat(Exception):
     pass
+
+
+class _NotPerfect(Exception):
+    """The key ranges do not multiply into a 64-bit composite key (index_group_list_perfect gives up, core/index.c:2364-2383)."""
+
+    def __init__(self, scopes, seen):
+        super().__init__("key ranges overflow the composite key")
+        self.scopes, self.seen = scopes, seen

@@ -49,8 +49,52 @@ def rf_where(w):
     return f"({op} {l} {r})"
 
 
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from golden_cases import rowhash_table  # noqa: E402  (the table builder is shared with the tests)
+
+
+def rowhash_section(arrays, cases):
+    # ---- 4e. several `by:` columns on the ROW-HASH path (index_group_list, core/index.c:2731-2790): H2O Q7 shape ----
+    # -c 1: single-threaded arm, groups in first-occurrence order; -c 8 on enough rows: radix arm, (hash & 1023, first occurrence)
+    for ri, (n, seed, kind, thr) in enumerate([(20_011, 31, "wide", 1), (262_147, 32, "wide", 8), (20_011, 33, "nulls", 1), (262_147, 34, "nulls", 8)]):
+        t = rowhash_table(n, seed, kind)
+        names = [k for k in t if k.startswith("k")]
+        with ref.Session() as s:
+            s.table("t", t)
+            bytxt = " ".join(f"{nm}: {nm}" for nm in names)
+            s.eval(f"(set r (select {{sf: (sum v) c: (count a) mxi: (max a) avf: (avg v) from: t by: {{{bytxt}}}}}))")
+            outs = names + ["sf", "c", "mxi", "avf"]
+            for o in outs:
+                s.out(o, f"(at r '{o})")
+            r = s.run(threads=thr)
+        for o in outs:
+            arrays[f"rowhash_{ri}_{o}"] = r[o]
+        # which arm the reference took shows in the order of its groups; the restatement must reproduce one of the two exactly
+        q = {"from": t, "by": {nm: nm for nm in names}, "sf": ("sum", "v")}
+        order = None
+        for cand in ("first", "radix"):
+            got = rfo.select({**q, "order": cand})
+            if all(np.array_equal(got[nm], r[nm]) for nm in names):
+                order = cand
+        assert order is not None, f"rowhash case {ri}: neither group order of the restatement matches the reference"
+        cases.append({"kind": "rowhash", "index": ri, "n": n, "seed": seed, "keys": kind, "threads": thr, "order": order})
+        print(f"rowhash case {ri}: {len(r[names[0]])} groups, reference order = {order}")
+
+
 def main():
     assert ref.build(), "reference not buildable here"
+    if "--only-rowhash" in sys.argv:  # refresh section 4e inside the existing fixture (the other sections take minutes)
+        z = np.load(os.path.join(HERE, "ref_golden.npz"))
+        arrays = {k: z[k] for k in z.files if not k.startswith("rowhash_")}
+        meta = json.load(open(os.path.join(HERE, "ref_golden.json")))
+        cases = [c for c in meta["cases"] if c["kind"] != "rowhash"]
+        rowhash_section(arrays, cases)
+        np.savez_compressed(os.path.join(HERE, "ref_golden.npz"), **arrays)
+        meta["cases"] = cases
+        with open(os.path.join(HERE, "ref_golden.json"), "w") as fjs:
+            json.dump(meta, fjs, indent=1)
+        print(f"wrote {len(arrays)} arrays")
+        return
     arrays, cases = {}, []
 
     # ---- 1. comparison truth tables on special values (mirrors the intent of tests/lang.c:3378-3605) ----
@@ -154,6 +198,8 @@ def main():
         for o in outs:
             arrays[f"multikey_{mi}_{o}"] = r[o]
         cases.append({"kind": "multikey", "index": mi, "n": n, "seed": seed, "mods": list(mods), "offs": list(offs)})
+
+    rowhash_section(arrays, cases)
 
     # ---- 4c. element-wise arithmetic: truth tables on special values, then aggregates over expressions ----
     xi = np.array([0, 1, -1, NULL, 2**63 - 1, 5, -5, 7], np.int64)

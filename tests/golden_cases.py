@@ -98,6 +98,29 @@ def multikey_cases():
         yield f"m{c['index']}", t, names, {o: arr(f"multikey_{c['index']}_{o}") for o in names + list(MULTIKEY_Q)}
 
 
+def rowhash_table(n, seed, kind):
+    """Key tuples the composite ("perfect") key cannot hold: ranges that multiply beyond 64 bits, or null keys."""
+    if kind == "wide":
+        t = {"k1": rfo.gen_i64(n, seed, 50) * (1 << 50), "k2": rfo.gen_i64(n, seed + 10, 40) * (1 << 45) - (1 << 50), "k3": rfo.gen_i64(n, seed + 20, 3)}
+    else:  # "nulls": small ranges, but k1 holds nulls (INT64_MIN makes the range wrap)
+        t = {"k1": rfo.gen_i64(n, seed, 7), "k2": rfo.gen_i64(n, seed + 10, 13) - 5}
+        t["k1"][rfo.gen_i64(n, seed + 30, 50) == 0] = NULL
+    t["v"] = rfo.gen_f64(n, seed + 5)
+    t["a"] = rfo.gen_i64(n, seed + 6, 1_000_000)
+    return t
+
+
+def rowhash_cases():
+    """Several `by:` columns on the reference's ROW-HASH path (ranges beyond 64 bits / null keys; H2O Q7 shape).  Yields
+    (id, table, key names, group order the reference produced -- "first" single-threaded, "radix" multi-threaded --, wanted)."""
+    for c in _meta["cases"]:
+        if c["kind"] != "rowhash":
+            continue
+        t = rowhash_table(c["n"], c["seed"], c["keys"])
+        names = [k for k in t if k.startswith("k")]
+        yield f"r{c['index']}-{c['keys']}-{c['order']}", t, names, c["order"], {o: arr(f"rowhash_{c['index']}_{o}") for o in names + list(MULTIKEY_Q)}
+
+
 XTAGS = {"ii": ("x_i", "x_j"), "if": ("x_i", "x_g"), "fi": ("x_f", "x_j"), "ff": ("x_f", "x_g"), "ia": ("x_i", 3), "ai": (3, "x_j"), "iaf": ("x_i", 2.5),
          "fa": ("x_f", 2), "faf": ("x_f", -1.5), "afi": (2.5, "x_j"), "iz": ("x_i", 0), "fz": ("x_f", 0.0)}
 XQ = {"s1": ("sum", ("*", "a", "v")), "s2": ("sum", ("*", "a", "b")), "s3": ("sum", ("+", "v", "w")), "av": ("avg", ("-", "a", "b")),

@@ -78,6 +78,26 @@ def _worker(rank, world, port, q):
         r = sh.group_by("k", [("sum", "v"), ("count", "a")], None, mine_s)
         want = rfo.select({"from": sparse, "by": "k", "s": ("sum", "v"), "c": ("count", "a")})
         assert np.array_equal(r["keys"].cpu().numpy(), want["k"]) and np.array_equal(r["results"][1].cpu().numpy(), want["c"])
+        # more outputs than one table set carries: several launches, each all-reduced with ITS aggregates' reduce ops
+        many = [("max", "a"), ("sum", "v"), ("min", "a"), ("avg", "v"), ("count", "a"), ("sum", "a"), ("min", "v"), ("max", "v"), ("avg", "a"), ("min", "a"), ("sum", "v")]
+        r = sh.group_by("k", many, None, mine)
+        want = rfo.select({"from": full, "by": "k", **{f"o{i}": a for i, a in enumerate(many)}})
+        for i, res in enumerate(r["results"]):
+            g, w = res.cpu().numpy(), want[f"o{i}"]
+            if w.dtype == np.float64:
+                ok = ~np.isnan(w)
+                assert np.array_equal(np.isnan(g), np.isnan(w)) and np.allclose(g[ok], w[ok], rtol=1e-9, atol=0), many[i]
+            else:
+                assert np.array_equal(g, w), many[i]
+        # key tuples beyond the composite key (row-hash path): global scopes, per-rank hashes, hashed tables merged, collision proof
+        wide = {"k1": rfo.gen_i64(n, 41, 50) * (1 << 50), "k2": rfo.gen_i64(n, 42, 40) * (1 << 45) - (1 << 50), "k3": rfo.gen_i64(n, 43, 3), "v": full["v"], "a": full["a"]}
+        wide["k3"][::101] = NULL
+        mine_w = {c: eng.column(x[cut[rank]:cut[rank + 1]]) for c, x in wide.items()}
+        r = sh.group_by(["k1", "k2", "k3"], [("sum", "v"), ("count", "a"), ("max", "a")], None, mine_w)
+        want = rfo.select({"from": wide, "by": {"k1": "k1", "k2": "k2", "k3": "k3"}, "s": ("sum", "v"), "c": ("count", "a"), "m": ("max", "a")})
+        for i, nm in enumerate(("k1", "k2", "k3")):
+            assert np.array_equal(r["key_columns"][i].cpu().numpy(), want[nm]), nm
+        assert np.array_equal(r["results"][1].cpu().numpy(), want["c"]) and np.array_equal(r["results"][2].cpu().numpy(), want["m"])
         eng.close()
         q.put((rank, "ok"))
     except Exception:  # noqa: BLE001

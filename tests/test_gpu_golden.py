@@ -53,6 +53,17 @@ def test_group_by_several_keys(eng, case):
         G.same(got[o].cpu().numpy(), want[o], o)
 
 
+@pytest.mark.parametrize("case", list(G.rowhash_cases()), ids=lambda c: c[0])
+def test_group_by_several_keys_row_hash_path(eng, case):
+    """Ranges beyond 64 bits / null keys: grouped on the reference's row hash (k_row_hash + sparse-key machinery, collision-proof
+    through per-group min == max of every key column); groups, key columns, order (both arms of the reference) and values."""
+    _, t, names, order, want = case
+    got = eng.select({"from": {k: eng.column(v) for k, v in t.items()}, "by": {nm: nm for nm in names}, "order": order, **G.MULTIKEY_Q})
+    assert list(got.keys()) == list(want.keys())
+    for o in want:
+        G.same(got[o].cpu().numpy(), want[o], o)
+
+
 @pytest.mark.parametrize("case", list(G.xagg_cases()), ids=lambda c: c[0])
 def test_aggregates_over_expressions(eng, case):
     """(sum (* a v)) & co: folded on the fly in the scalar and LDS-table kernels, materialised for the partitioned path."""

@@ -387,13 +387,16 @@ def test_group_by_several_keys_every_path(eng, flags):
         eng.tune(flags=0)
 
 
-def test_group_by_several_keys_overflow_is_refused(eng):
-    """Product of ranges beyond i64 (a null key always is): the reference leaves its perfect path; this library says so."""
-    from rayforce_amd._lib import RfxError
+def test_group_by_several_keys_overflow_takes_the_row_hash_path(eng):
+    """Product of ranges beyond i64 (a null key always is): the reference leaves its perfect path for the row-hash one; so
+    does the Engine (the flat composite entry points still say RFX_ELIMIT: rfx_composite_plan)."""
+    from rayforce_amd import _lib as L
+    import ctypes as C
     host = mk_table(1000, (10, 10), (0, 0))
     host["k2"][7] = NULL
-    with pytest.raises(RfxError, match="overflow"):
-        eng.select({"from": dev(eng, host), "by": {"x": "k1", "y": "k2"}, "s": ("sum", "v")})
+    check_select(eng, host, {"by": {"x": "k1", "y": "k2"}, "s": ("sum", "v")})
+    mults, tmax = (C.c_int64 * 2)(), C.c_int64()
+    assert eng.lib.rfx_composite_plan((C.c_int64 * 2)(0, NULL), (C.c_int64 * 2)(9, 9), 2, mults, C.byref(tmax)) == L.RFX_ELIMIT
     # one key through the dict spelling is the plain single-key path (null key -> hashed), core/index.c:2741-2742
     check_select(eng, host, {"by": {"y": "k2"}, "s": ("sum", "v")})
 
@@ -489,6 +492,28 @@ def test_expression_aggregates_refusals(eng):
         eng.select({"from": d, "f": ("first", ("*", "a", "v")), "by": "k"})
     with pytest.raises(RfxError, match="unsupported expression"):
         eng.select({"from": d, "s": ("sum", ("/", "a", "k"))})
+
+
+def test_group_by_key_tuples_beyond_the_composite_key(eng):
+    """Row-hash path (index_group_list, core/index.c:2731-2790): six key columns whose ranges multiply beyond 64 bits (H2O Q7
+    shape), null keys, `where:`, expression aggregates, more outputs than one launch carries; both group orders."""
+    n = 300_007
+    host = table(n, keys=100, nulls=True)
+    host.update({"id1": rfo.gen_i64(n, 81, 100) * 1_000_000_007, "id2": rfo.gen_i64(n, 82, 100) - 50, "id3": rfo.gen_i64(n, 83, 1000) * (1 << 40),
+                 "id4": rfo.gen_i64(n, 84, 100), "id5": rfo.gen_i64(n, 85, 100) * 3, "id6": rfo.gen_i64(n, 86, 1000) * (1 << 33)})
+    by6 = {f"id{i}": f"id{i}" for i in range(1, 7)}
+    check_select(eng, host, {"by": by6, "s": ("sum", "v"), "c": ("count", "a")})  # H2O Q7
+    check_select(eng, host, {"by": by6, "order": "radix", "s": ("sum", "w"), "mx": ("max", "a")})
+    two = {"id1": "id1", "id3": "id3"}
+    q = {"by": two, "s": ("sum", "v"), "si": ("sum", "a"), "av": ("avg", "w"), "mn": ("min", "a"), "mx": ("max", "v"), "c": ("count", "a"),
+         "x": ("sum", ("*", "v", ("-", 1, "w"))), "f": ("first", "a"), "av2": ("avg", "a")}
+    check_select(eng, host, q)
+    check_select(eng, host, {**q, "where": ("and", (">", "v", 0.3), ("<", "a", 700_000))})
+    host["id2"][rfo.gen_i64(n, 87, 40) == 0] = NULL  # null keys are keys like any other here
+    host["id4"][rfo.gen_i64(n, 88, 30) == 0] = NULL
+    check_select(eng, host, {"by": {"id2": "id2", "id4": "id4"}, "s": ("sum", "v"), "c": ("count", "a")})
+    check_select(eng, host, {"by": {"id2": "id2", "id4": "id4"}, "order": "radix", "where": (">", "v", 0.5), "s": ("sum", "v"), "c": ("count", "a")})
+    check_select(eng, host, {"by": by6, "s": ("sum", "v")})
 
 
 def test_group_by_xbar_buckets(eng):

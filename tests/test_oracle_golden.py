@@ -73,6 +73,18 @@ def test_group_by_several_keys(case):
         G.same(got[o], want[o], o)
 
 
+@pytest.mark.parametrize("case", list(G.rowhash_cases()), ids=lambda c: c[0])
+def test_group_by_several_keys_row_hash_path(case):
+    """Key tuples beyond the composite key (ranges overflow 64 bits / null keys): index_group_list's row-hash arms.  The
+    restatement reproduces the reference's groups AND their order: first occurrence single-threaded, (hash & 1023, first
+    occurrence) from the radix arm -- which pins the row hash itself (argument order of hash_index_u64 included)."""
+    _, t, names, order, want = case
+    got = rfo.select({"from": t, "by": {nm: nm for nm in names}, "order": order, **G.MULTIKEY_Q})
+    assert list(got.keys()) == list(want.keys())
+    for o in want:
+        G.same(got[o], want[o], o)
+
+
 def test_composite_plan_overflow_rules():
     """core/index.c:2364-2383: the perfect path is abandoned when the product of ranges leaves i64 -- a null key always does."""
     n = 1000
