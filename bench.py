@@ -63,6 +63,9 @@ WORKLOADS = {
                 bytes_per_row=24, dtype="f64", kernel="k_part_scope_hist<2, 1> + k_compact_cols<2> + k_part_scatter_wc<2, 0> + k_part_aggregate<1, 512>"),
     "q2": dict(desc="several by: columns (H2O Q2 shape): select sum(v) by {id1, id2}, id1/id2 i64 uniform [0,100) seeds 10/11, v f64 seed 5", rows=1_000_000_000,
                bytes_per_row=24, dtype="f64", kernel="k_part_scope_hist<1, 0> x2 + k_group_dense<3, true, 1024>"),
+    "q7": dict(desc="key tuples beyond the composite key (H2O Q7 shape, row-hash path): select sum(v), count by {id1..id6}; id1,id2,id4,id5 i64 uniform [0,100), "
+                    "id3,id6 i64 uniform [0,1e6) seeds 20-25, v f64 seed 5 (ranges multiply to 1e20 > 2^63; ~1e8 groups)", rows=100_000_000,
+               bytes_per_row=56, dtype="f64", kernel="k_row_hash<6> + sparse-key passes (k_part_scatter_soa / k_part_hash_aggregate), 14 key-proof aggregates in 2 launches"),
     "x6": dict(desc="expression aggregate (TPC-H Q6 shape): select sum(p * d) where q < 24 and d >= 0.05 and d <= 0.07; p f64 seed 12, d f64 seed 13 "
                     "scaled to [0,0.1), q i64 uniform [0,50) seed 14", rows=1_000_000_000, bytes_per_row=24, dtype="f64", kernel="k_filter_aggr<3, 4, 4, 4, 1, false>"),
     "q1": dict(desc="nested expressions (TPC-H Q1 shape): sum(q), sum(p), sum(p*(1-d)), sum(p*(1-d)*(1+t)), avg(q), avg(p), avg(d), count by {rf, ls} "
@@ -123,6 +126,11 @@ class Job:
         elif name == "q2":
             self.t = {"id1": g.gen_i64(rows, 10, 100, row0), "id2": g.gen_i64(rows, 11, 100, row0), "v": g.gen_f64(rows, 5, row0)}
             self.aggs, self.where, self.key = [("sum", "v")], None, ["id1", "id2"]
+        elif name == "q7":
+            mods = (100, 100, 1_000_000, 100, 100, 1_000_000)
+            self.t = {f"id{i + 1}": g.gen_i64(rows, 20 + i, m, row0) for i, m in enumerate(mods)}
+            self.t["v"] = g.gen_f64(rows, 5, row0)
+            self.aggs, self.where, self.key = [("sum", "v"), ("count", "v")], None, [f"id{i + 1}" for i in range(6)]
         elif name in ("w2", "m2"):
             self.t = {"a": g.gen_i64(rows, 2, 1_000_000, row0)}
             self.aggs, self.where = [], ("<", "a", 100_000)
@@ -160,7 +168,7 @@ class Job:
             ids = self.sh.where(self.where, self.t) if self.sh is not None else self.eng.where(self.where, self.t)
             self.eng.sync()
             return ([int(ids.numel())], int(ids.numel()))
-        if self.name in ("c3", "c3w", "q2", "k9", "q1"):
+        if self.name in ("c3", "c3w", "q2", "k9", "q1", "q7"):
             if self.sh is not None:
                 return self.sh.group_by(self.key, self.aggs, self.where, self.t)
             return self.eng.group_by(self.key, self.aggs, self.where, self.t)
@@ -200,7 +208,7 @@ def run_workload(name, eng, sharded, rows, row0, steps, warmup, world):
     job = Job(name, eng, sharded, rows, row0)
     dt, kms, res = timed(job, steps, warmup, world)
     ms_step = dt * 1e3 / steps
-    if name in ("c3", "c3w", "q2", "k9", "q1", "w2"):
+    if name in ("c3", "c3w", "q2", "k9", "q1", "q7", "w2"):
         kms = ms_step  # several dependent kernels (scope+hist, scatter, aggregate, rank, emit): price the whole query
     value = world * rows / (dt / steps)
     alg_bytes = w["bytes_per_row"] * rows  # per launch, per GPU (SURVEY 8d figures, stated in DESIGN.md)

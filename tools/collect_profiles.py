@@ -24,6 +24,8 @@ DOMINANT = {"c2": ["k_filter_aggr<"], "c2b": ["k_filter_aggr<"], "c5": ["k_filte
             "q2": ["k_part_scope_hist", "k_group_dense", "k_composite", "k_mark_first", "k_group_emit", "k_slot_gid", "k_bitmap_counts", "k_fill_u64"],
             "k9": ["k_part_scope_hist", "k_part_hist", "k_part_scatter", "k_part_hash_aggregate", "k_part_colscan", "k_group_hash", "k_mark_first", "k_group_emit",
                    "k_slot_gid", "k_bitmap_counts", "k_fill_u64"],
+            "q7": ["k_row_hash", "k_part_scope_hist", "k_part_hist", "k_part_scatter", "k_part_hash_aggregate", "k_part_colscan", "k_group_hash", "k_mark_first",
+                   "k_group_emit", "k_slot_gid", "k_bitmap_counts", "k_fill_u64", "k_replace_null"],
             "w2": ["k_sel_bitmap", "k_chunk_counts", "k_emit_ids"], "m2": ["k_cmp_mask"]}
 
 
