@@ -57,3 +57,58 @@ def test_splayed_table_written_by_the_reference(eng, tmp_path):
     assert np.allclose(got["s"].cpu().numpy(), want["s"], rtol=1e-9, atol=0) and np.allclose(got["x"].cpu().numpy(), want["x"], rtol=1e-9, atol=0)
     only = eng.load_splayed(d, ["v"])
     assert list(only) == ["v"] and np.array_equal(only["v"].cpu().numpy(), host["v"])
+
+
+@pytest.mark.skipif(not ref.available(), reason="oracle/_ref/rayforce not built")
+def test_parted_table_written_by_the_reference(eng, tmp_path):
+    """`(get-parted root 'tab)` layout (core/vary.c:185-392): one splayed table per date directory, written by the reference;
+    loaded whole and with partition pruning on the virtual Date column; a pruned partition is never opened (its files are
+    deleted before the pruned load); the reference's own answers over its parted table stand beside the device's."""
+    import datetime
+    import shutil
+    root = str(tmp_path / "db") + "/"
+    dates = ["2024.01.03", "2024.01.01", "2024.02.29", "2024.01.02"]  # directory order is not date order
+    lens = [70_001, 50_000, 33_333, 0 + 90_007]
+    hosts = {}
+    for i, (d, n) in enumerate(zip(dates, lens)):  # one reference process per partition (a session stages its columns by name)
+        hosts[d] = {"k": rfo.gen_i64(n, 40 + i, 500), "a": rfo.gen_i64(n, 50 + i, 1_000_000), "v": rfo.gen_f64(n, 60 + i)}
+        with ref.Session() as s:
+            s.table("t", hosts[d])
+            s.eval(f'(set "{root}{d}/tab/" t)')
+            s.run(threads=8)
+    with ref.Session() as s:
+        s.eval(f"(set p (get-parted \"{root}\" 'tab))")
+        s.eval("(set r1 (select {s: (sum v) c: (count a) from: p where: (== Date 2024.01.02)}))")
+        s.out("s1", "(at r1 's)")
+        s.out("c1", "(at r1 'c)")
+        r = s.run(threads=8)
+    order = sorted(dates)
+    whole = {c: np.concatenate([hosts[d][c] for d in order]) for c in ("k", "a", "v")}
+    day = lambda d: (datetime.date(*map(int, d.split("."))) - datetime.date(2000, 1, 1)).days
+    whole["Date"] = np.concatenate([np.full(len(hosts[d]["k"]), day(d), np.int64) for d in order])
+    t = eng.load_parted(root, "tab")
+    assert list(t) == ["Date", "k", "a", "v"]
+    for c in whole:
+        assert np.array_equal(t[c].cpu().numpy(), whole[c]), c
+    q = {"where": ("<", "a", 400_000), "by": "Date", "s": ("sum", "v"), "c": ("count", "a"), "m": ("max", "k")}
+    got, want = eng.select({"from": t, **q}), rfo.select({"from": whole, **q})
+    assert np.array_equal(got["Date"].cpu().numpy(), want["Date"]) and np.array_equal(got["c"].cpu().numpy(), want["c"])
+    assert np.allclose(got["s"].cpu().numpy(), want["s"], rtol=1e-9, atol=0)
+    # the reference's answers over ITS parted table
+    one = eng.load_parted(root, "tab", where=("==", "Date", "2024.01.02"))
+    assert one["v"].numel() == 90_007 and int(one["Date"][0]) == day("2024.01.02")
+    g1 = eng.select({"from": one, "s": ("sum", "v"), "c": ("count", "a")})
+    assert int(g1["c"][0]) == int(r["c1"][0]) and abs(float(g1["s"][0]) - float(r["s1"][0])) <= 1e-9 * abs(float(r["s1"][0]))
+    # (a Date predicate AND-ed with a column predicate is not compared with the reference: it answers twice one partition's sum
+    #  there -- 2 x 124.92 where the rows add up to 371.63 on a two-partition probe -- so the oracle stands in)
+    late = eng.load_parted(root, "tab", ["a", "v"], where=(">=", "Date", "2024.01.02"))
+    g2 = eng.select({"from": late, "where": ("<", "a", 500_000), "s": ("sum", "v")})
+    sel = (whole["Date"] >= day("2024.01.02")) & (whole["a"] < 500_000)
+    assert abs(float(g2["s"][0]) - float(whole["v"][sel].sum())) <= 1e-9 * float(whole["v"][sel].sum())
+    # pruning happens on the directory list: a partition that fails the predicate is not even opened
+    shutil.rmtree(os.path.join(root, "2024.01.01", "tab"))
+    again = eng.load_parted(root, "tab", ["a", "v"], where=("or", ("==", "Date", "2024.02.29"), ("and", (">", "Date", "2024.01.01"), ("<", "Date", day("2024.01.03")))))
+    assert again["v"].numel() == 90_007 + 33_333
+    from rayforce_amd._lib import RfxError
+    with pytest.raises(RfxError, match="Date column only"):
+        eng.load_parted(root, "tab", where=("<", "a", 5))
