@@ -446,7 +446,7 @@ rfx_obj_p rfx_select(rfx_obj_p dict) {
     if (!tab || tab->type == RFX_TYPE_ERR) return tab;
     obj_p res = NULL;
     const char *why = NULL;
-    void *tmp[RFX_MAX_AGGS * (2 + 2 * RFX_MAX_XNODES) + RFX_MAX_KEYS + 4]; /* device scratch of this query (gathered columns, bucket / composite keys): freed at `done` */
+    void *tmp[RFX_MAX_AGGS * (2 + 2 * RFX_MAX_XNODES) + 2 * RFX_MAX_KEYS + 6]; /* device scratch of this query (gathered columns, bucket / composite keys): freed at `done` */
     int ntmp = 0;
     obj_p where = dict_get(dict, "where"), by = dict_get(dict, "by");
     obj_p dkeys = RFX_AS_LIST(dict)[0], dvals = RFX_AS_LIST(dict)[1];
@@ -516,6 +516,9 @@ rfx_obj_p rfx_select(rfx_obj_p dict) {
         int nkeys = 0;
         const void *dk = NULL;
         int64_t kmins[RFX_MAX_KEYS], kmaxs[RFX_MAX_KEYS], kmults[RFX_MAX_KEYS], comp_max = 0;
+        int rowhash = 0, nagg_run = 0;            /* row-hash path: aggregates [nagg, nagg_run) are the (min, max) proof pairs of the key columns */
+        int64_t krepl[RFX_MAX_KEYS] = {0};         /* stand-in value of a null key inside its proof pair */
+        int khasnull[RFX_MAX_KEYS] = {0};
         if (by) {
             if (by->type == -RFX_TYPE_SYMBOL) {
                 knames[0] = by->i64;
@@ -639,7 +642,40 @@ rfx_obj_p rfx_select(rfx_obj_p dict) {
                 kmin = 0;
                 kmax = -1;
                 if (seen > 0) {
-                    if (rfx_composite_plan(kmins, kmaxs, nkeys, kmults, &comp_max) != RFX_OK) { why = "by: key ranges overflow the composite key (row-hash path)"; goto out; }
+                    if (rfx_composite_plan(kmins, kmaxs, nkeys, kmults, &comp_max) != RFX_OK) {
+                        /* ranges beyond 64 bits / a null key: the reference's row-hash path (index_group_list, core/index.c:2731-2790).
+                         * Group on the reference's own row hash; every key column rides along as a (min, max) pair: equal in every
+                         * group = one tuple per group (proof instead of the reference's tuple compare), and max IS the key column. */
+                        if (nagg + 2 * nkeys > RFX_MAX_AGGS) { why = "by: key tuple on the row-hash path with more outputs than one launch carries"; goto out; }
+                        void *hh = NULL;
+                        if (rfx_hip_malloc(g_ctx, &hh, (size_t)nrows * 8) != RFX_OK) { res = fail_hip("row hash"); goto done; }
+                        tmp[ntmp++] = hh;
+                        if (rfx_hip_row_hash(g_ctx, dks, nkeys, nrows, 0, (int64_t *)hh) != RFX_OK) { res = fail_hip("row hash"); goto done; }
+                        for (int i = 0; i < nkeys; i++) {
+                            const void *chk = dks[i];
+                            if (kmins[i] == RFX_NULL_I64) { /* min / max skip nulls: give the null key a value of its own above the maximum */
+                                if (kmaxs[i] == INT64_MAX) { why = "by: key column with nulls and INT64_MAX on the row-hash path"; goto out; }
+                                void *c2 = NULL;
+                                if (rfx_hip_malloc(g_ctx, &c2, (size_t)nrows * 8) != RFX_OK) { res = fail_hip("row hash"); goto done; }
+                                tmp[ntmp++] = c2;
+                                if (rfx_hip_replace_null_i64(g_ctx, (const int64_t *)dks[i], nrows, kmaxs[i] + 1, (int64_t *)c2) != RFX_OK) { res = fail_hip("row hash"); goto done; }
+                                chk = c2;
+                                khasnull[i] = 1;
+                                krepl[i] = kmaxs[i] + 1;
+                            }
+                            for (int j = 0; j < 2; j++) {
+                                rfx_agg_t *pa = &aggs[nagg + 2 * i + j];
+                                memset(pa, 0, sizeof(*pa));
+                                pa->d_col = chk;
+                                pa->col_type = RFX_I64;
+                                pa->kind = j ? RFX_AGG_MAX : RFX_AGG_MIN;
+                            }
+                        }
+                        rowhash = 1;
+                        nagg_run = nagg + 2 * nkeys;
+                        dk = hh;
+                        if (rfx_hip_scope_i64(g_ctx, (const int64_t *)hh, NULL, 0, RFX_AND, nrows, &kmin, &kmax, &seen) != RFX_OK) { res = fail_hip("scope"); goto done; }
+                    } else {
                     kmax = comp_max; /* forced scope {0, max}, core/index.c:2421 */
                     if ((uint64_t)comp_max + 1 > (uint64_t)seen) {
                         /* sparse composite: the hashed path keys on the materialised column */
@@ -652,16 +688,18 @@ rfx_obj_p rfx_select(rfx_obj_p dict) {
                         }
                         dk = comp;
                     }
+                    }
                 }
             } else if (rfx_hip_scope_i64(g_ctx, (const int64_t *)dk, wp.preds, wp.npred, wp.logic, nrows, &kmin, &kmax, &seen) != RFX_OK) { res = fail_hip("scope"); goto done; }
             int64_t groups = 0;
+            if (!rowhash) nagg_run = nagg;
             obj_p okeys = NULL, ocols[RFX_MAX_AGGS] = {0}, okcols[RFX_MAX_KEYS] = {0};
             if (seen > 0) {
                 /* dense "perfect hash" iff range <= rows (core/index.c:2013), like the reference; else open addressing */
                 uint64_t range = (uint64_t)kmax - (uint64_t)kmin + 1;
                 int dense = range != 0 && range <= (uint64_t)seen && kmin != RFX_NULL_I64;
                 int narr = 0;
-                rfx_hip_group_table_arrays(aggs, nagg, &narr);
+                rfx_hip_group_table_arrays(aggs, nagg_run, &narr);
                 int64_t cells = dense ? (int64_t)range : 0;
                 int64_t cap = 16, cap_max = 16;
                 if (!dense) {
@@ -681,9 +719,9 @@ rfx_obj_p rfx_select(rfx_obj_p dict) {
                 rfx_hash_tables_t ht;
                 memset(&gt, 0, sizeof(gt));
                 memset(&ht, 0, sizeof(ht));
-                if (dense) { gt.kmin = kmin; gt.range = (int64_t)range; gt.nagg = nagg; gt.d_first = base + (k++) * cells; }
-                else { ht.capacity = cap; ht.nagg = nagg; ht.d_keys = base + (k++) * cells; ht.d_first = base + (k++) * cells; }
-                for (int a = 0; a < nagg; a++) {
+                if (dense) { gt.kmin = kmin; gt.range = (int64_t)range; gt.nagg = nagg_run; gt.d_first = base + (k++) * cells; }
+                else { ht.capacity = cap; ht.nagg = nagg_run; ht.d_keys = base + (k++) * cells; ht.d_first = base + (k++) * cells; }
+                for (int a = 0; a < nagg_run; a++) {
                     void *acc = base + (k++) * cells;
                     int hc = aggs[a].kind == RFX_AGG_AVG || (aggs[a].kind == RFX_AGG_SUM && rfx_agg_input_type(&aggs[a]) == RFX_I64);
                     int64_t *cnt = hc ? base + (k++) * cells : NULL;
@@ -691,7 +729,7 @@ rfx_obj_p rfx_select(rfx_obj_p dict) {
                 }
                 if (dense) {
                     ok = rfx_hip_group_tables_init(g_ctx, aggs, &gt) == RFX_OK &&
-                         (nkeys > 1 ? rfx_hip_group_dense_accumulate_keys(g_ctx, dks, kmins, kmults, nkeys, wp.preds, wp.npred, wp.logic, aggs, nrows, 0, &gt)
+                         (nkeys > 1 && !rowhash ? rfx_hip_group_dense_accumulate_keys(g_ctx, dks, kmins, kmults, nkeys, wp.preds, wp.npred, wp.logic, aggs, nrows, 0, &gt)
                                     : rfx_hip_group_dense_accumulate(g_ctx, (const int64_t *)dk, wp.preds, wp.npred, wp.logic, aggs, nrows, 0, &gt)) == RFX_OK &&
                          rfx_hip_group_rank(g_ctx, &gt, nrows, &groups) == RFX_OK;
                 } else {
@@ -706,14 +744,37 @@ rfx_obj_p rfx_select(rfx_obj_p dict) {
                     }
                 }
                 void *dout = NULL;
-                if (ok && groups > 0) ok = rfx_hip_malloc(g_ctx, &dout, (size_t)(nagg + 1) * (size_t)groups * 8) == RFX_OK;
+                if (ok && groups > 0) ok = rfx_hip_malloc(g_ctx, &dout, (size_t)(nagg_run + 1) * (size_t)groups * 8) == RFX_OK;
                 if (ok && groups > 0) {
                     void *ptrs[RFX_MAX_AGGS];
-                    for (int a = 0; a < nagg; a++) ptrs[a] = (int64_t *)dout + (size_t)(a + 1) * groups;
+                    for (int a = 0; a < nagg_run; a++) ptrs[a] = (int64_t *)dout + (size_t)(a + 1) * groups;
                     ok = (dense ? rfx_hip_group_emit(g_ctx, aggs, &gt, (int64_t *)dout, NULL, ptrs) : rfx_hip_hash_emit(g_ctx, aggs, &ht, (int64_t *)dout, NULL, ptrs)) == RFX_OK;
                     if (nkeys == 1) {
                         okeys = H.vector(kcs[0]->type, groups);
                         if (ok) ok = rfx_hip_d2h(g_ctx, RFX_AS_RAW(okeys), dout, (size_t)groups * 8) == RFX_OK;
+                    } else if (rowhash) {
+                        /* proof: min == max of every key column in every group; the maxima are the key columns (nulls restored) */
+                        int64_t *mn = (int64_t *)malloc((size_t)groups * 8);
+                        ok = ok && mn != NULL;
+                        int collision = 0;
+                        for (int i = 0; i < nkeys && ok; i++) {
+                            okcols[i] = H.vector(kcs[i]->type, groups);
+                            int64_t *mx = (int64_t *)RFX_AS_RAW(okcols[i]);
+                            ok = rfx_hip_d2h(g_ctx, mn, ptrs[nagg + 2 * i], (size_t)groups * 8) == RFX_OK &&
+                                 rfx_hip_d2h(g_ctx, mx, ptrs[nagg + 2 * i + 1], (size_t)groups * 8) == RFX_OK;
+                            for (int64_t g = 0; g < groups && ok; g++) {
+                                if (mn[g] != mx[g]) collision = 1;
+                                if (khasnull[i] && mx[g] == krepl[i]) mx[g] = RFX_NULL_I64;
+                            }
+                        }
+                        free(mn);
+                        if (ok && collision) { /* two key tuples, one 64-bit row hash: leave the query to the host rather than answer wrongly */
+                            if (dout) rfx_hip_free(g_ctx, dout);
+                            rfx_hip_free(g_ctx, store);
+                            for (int i = 0; i < nkeys; i++) if (okcols[i]) H.drop(okcols[i]);
+                            why = "row-hash collision between two key tuples";
+                            goto out;
+                        }
                     } else {
                         /* key column i = min_i + (composite / mult_i) % range_i  (= key_i[first row], core/query.c:110-135) */
                         void *dec = NULL;

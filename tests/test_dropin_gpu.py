@@ -33,10 +33,13 @@ QUERIES = [
     # bucketed keys: (xbar column width)
     ("q12", "{s: (sum v) c: (count a) from: t by: {b: (xbar k 10)}}", ["b", "s", "c"]),
     ("q13", "{m: (max v) from: t where: (< a 700000) by: {b: (xbar a 50000)}}", ["b", "m"]),  # value span > rows: sparse arm, see UNORDERED
+    # key tuple beyond the composite key (ranges multiply past 64 bits): the reference's row-hash path, answered by the plugin
+    # from the reference's own row hash + the (min, max) proof pairs of the key columns
+    ("q16", "{s: (sum v) c: (count a) from: t by: {w1: w1 w2: w2 k3: k3}}", ["w1", "w2", "k3", "s", "c"]),
 ]
 
 
-UNORDERED = {"q13"}
+UNORDERED = {"q13": 1, "q16": 3}  # name -> leading key columns: group order there depends on the reference's executor count
 
 
 @pytest.mark.skipif(not ref.available(), reason="oracle/_ref/rayforce not built (needs /root/reference at build time)")
@@ -46,7 +49,8 @@ def test_plugin_inside_the_real_reference(built):
         pytest.skip("no GPU")
     n = 300_007
     cols = {"k": rfo.gen_i64(n, 4, 5000), "a": rfo.gen_i64(n, 2, 1_000_000), "v": rfo.gen_f64(n, 5),
-            "k1": rfo.gen_i64(n, 14, 7), "k2": rfo.gen_i64(n, 15, 11) + 100, "k3": rfo.gen_i64(n, 16, 50) - 25}
+            "k1": rfo.gen_i64(n, 14, 7), "k2": rfo.gen_i64(n, 15, 11) + 100, "k3": rfo.gen_i64(n, 16, 50) - 25,
+            "w1": rfo.gen_i64(n, 17, 50) * (1 << 50), "w2": rfo.gen_i64(n, 18, 40) * (1 << 45) - (1 << 50)}
     with ref.Session() as s:
         s.table("t", cols)
         s.eval(f'(set gsel (loadfn "{LIB}" "rfx_select" 1))')
@@ -73,7 +77,9 @@ def test_plugin_inside_the_real_reference(built):
         res = s.run(threads=8)
     for name, _, outs in QUERIES:
         if name in UNORDERED:  # the reference's sparse-key group order is implementation-defined with several executors: compare as maps
-            gi, ri = np.argsort(res[f"g_{name}_{outs[0]}"], kind="stable"), np.argsort(res[f"r_{name}_{outs[0]}"], kind="stable")
+            nk = UNORDERED[name]
+            gi = np.lexsort([res[f"g_{name}_{o}"] for o in outs[:nk]][::-1])
+            ri = np.lexsort([res[f"r_{name}_{o}"] for o in outs[:nk]][::-1])
             for o in outs:
                 res[f"g_{name}_{o}"], res[f"r_{name}_{o}"] = res[f"g_{name}_{o}"][gi], res[f"r_{name}_{o}"][ri]
         for o in outs:

@@ -95,11 +95,22 @@ def test_select_by_several_keys(ops):
     # where: + several keys is left to the host (the reference's own answer for it is defective); no host here -> loud error
     with pytest.raises(RuntimeError, match="several by: columns"):
         run_select(ops, host, {**q, "by": {"a1": "k1", "a2": "k2"}, "where": ("<", "a", 5)})
-    # product of ranges beyond i64 (null key) -> the reference's row-hash path, not covered
+    # product of ranges beyond i64 (a null key always is) -> the reference's row-hash path: answered here too, key columns
+    # and first-occurrence group order included, as long as the (min, max) proof pairs fit the launch
     host["k2"][3] = NULL
+    host["k1"][::1013] = NULL
     ops.rfx_cache_clear()  # a rebuilt column may land on the freed one's address; one changed cell can escape the sampled checksum
-    with pytest.raises(RuntimeError, match="overflow"):
-        run_select(ops, host, {**q, "by": {"a1": "k1", "a2": "k2"}})
+    check(run_select(ops, host, {**q, "by": {"a1": "k1", "a2": "k2"}}), rfo.select({"from": host, **q, "by": {"a1": "k1", "a2": "k2"}}))
+    assert ops.rfx_last_select_on_gpu() == 1
+    wide = dict(host)
+    wide["k1"] = rfo.gen_i64(n, 31, 100) * (1 << 50)
+    wide["k2"] = rfo.gen_i64(n, 41, 90) * (1 << 44) - (1 << 52)
+    ops.rfx_cache_clear()
+    by3 = {"x": "k1", "y": "k2", "z": "k3"}
+    check(run_select(ops, wide, {"s": ("sum", "v"), "c": ("count", "a"), "by": by3}), rfo.select({"from": wide, "s": ("sum", "v"), "c": ("count", "a"), "by": by3}))
+    assert ops.rfx_last_select_on_gpu() == 1
+    with pytest.raises(RuntimeError, match="more outputs than one launch"):  # 3 outputs + 3 x 2 proof aggregates > 8: host's
+        run_select(ops, wide, {**q, "by": by3})
 
 
 def test_select_expression_aggregates(ops):
