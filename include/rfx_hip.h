@@ -15,6 +15,7 @@
  *   rfx_hip_where_* ......... ray_where -> ops_where, core/items.c:1366-1372, core/ops.c:254-273
  *   rfx_hip_gather .......... at_ids / at_ids_partial, core/rayforce.c:1036-1158
  *   rfx_hip_scope_i64 ....... index_scope_i64, core/index.c:376-435
+ *   rfx_hip_join_* .......... index_left_join_obj / index_inner_join_obj, core/index.c:2886-2990 (lj / ij, core/join.c:158-298)
  *   rfx_composite_* ......... index_group_list_perfect, core/index.c:2238-2424 (several `by:` columns -> one dense key)
  *   rfx_hip_group_* ......... index_group_i64_scoped (core/index.c:2002-2092), index_group_distribute
  *                             (core/index.c:1777-1911, core/hash.c:35-148) and AGGR_ITER/AGGR_COLLECT with
@@ -341,6 +342,19 @@ int rfx_hip_group_dense_accumulate_keys(rfx_ctx_t *ctx, const void *const *d_key
  * (d_out[r] = d_col[r] is null ? repl : d_col[r]) prepares key columns with nulls for the min == max collision proof. */
 int rfx_hip_row_hash(rfx_ctx_t *ctx, const void *const *d_cols, int nkeys, int64_t nrows, int value_first, int64_t *d_out);
 int rfx_hip_replace_null_i64(rfx_ctx_t *ctx, const int64_t *d_col, int64_t nrows, int64_t repl, int64_t *d_out);
+
+/* ---- equi-joins: lj / ij (ray_left_join / ray_inner_join, core/join.c:158-298; index_left_join_obj, core/index.c:2886-2928) ----
+ * The reference's join index is, per LEFT row, the FIRST right row with an equal key, or null.  Build side = the group-by's
+ * first-occurrence table over the RIGHT key column with zero aggregates (rfx_hip_group_dense_accumulate into d_first, or
+ * rfx_hip_group_hash_accumulate into a hashed table set); these probe it with the LEFT keys:
+ *   d_ids[i] = first right row whose key equals d_left_keys[i], else null (INT64_MIN).
+ * Several key columns: probe on rfx_hip_row_hash of both sides, then compare the gathered key columns (Engine.join_index).
+ * rfx_hip_gather_or assembles a result column (select_column, core/join.c:38-66):
+ *   d_out[i] = d_ids[i] is null ? (d_left ? d_left[i] : fill_bits) : d_right[d_ids[i]]. */
+int rfx_hip_join_probe_dense(rfx_ctx_t *ctx, const int64_t *d_left_keys, int64_t nleft, int64_t kmin, int64_t range, const int64_t *d_first,
+                             int64_t *d_ids);
+int rfx_hip_join_probe_hash(rfx_ctx_t *ctx, const int64_t *d_left_keys, int64_t nleft, const rfx_hash_tables_t *t, int64_t *d_ids);
+int rfx_hip_gather_or(rfx_ctx_t *ctx, const void *d_right, const void *d_left, const int64_t *d_ids, int64_t n, uint64_t fill_bits, void *d_out);
 
 /* ---- bucketed group keys: (xbar col width), XBARI64 core/ops.h:192-193 ----
  * d_out[r] = null for a null input, else the largest multiple of `width` (> 0) that is <= d_col[r].  Group on the result

@@ -355,6 +355,67 @@ def aggr(fn: str, col, gids, filter_ids, groups):
     return out
 
 
+def join_index(keys, left: dict, right: dict) -> np.ndarray:
+    """index_left_join_obj (core/index.c:2886-2928; one key: ray_find): per left row the FIRST right row whose key tuple is
+    bitwise equal, else null."""
+    keys = [keys] if isinstance(keys, str) else list(keys)
+    lk = np.stack([_col(left[k]).view(np.int64) for k in keys], axis=1)
+    rk = np.stack([_col(right[k]).view(np.int64) for k in keys], axis=1)
+    nl, nr = len(lk), len(rk)
+    if nl == 0 or nr == 0:
+        return np.full(nl, NULL_I64, np.int64)
+    _, inv = np.unique(np.concatenate([rk, lk]), axis=0, return_inverse=True)
+    inv = inv.reshape(-1)
+    big = np.iinfo(np.int64).max
+    first = np.full(int(inv.max()) + 1, big, np.int64)
+    np.minimum.at(first, inv[:nr], np.arange(nr, dtype=np.int64))
+    ids = first[inv[nr:]]
+    ids[ids == big] = NULL_I64
+    return ids
+
+
+def _null_of(dtype):
+    return np.nan if dtype == np.float64 else NULL_I64
+
+
+def left_join(keys, left: dict, right: dict) -> dict:
+    """ray_left_join + __left_join_inner + select_column (core/join.c:38-66,83-198)."""
+    keys = [keys] if isinstance(keys, str) else list(keys)
+    nl = len(next(iter(left.values()))) if left else 0
+    nr = len(next(iter(right.values()))) if right else 0
+    if nl == 0 or nr == 0:
+        return dict(left)
+    ids = join_index(keys, left, right)
+    hit = ids != NULL_I64
+    out = {k: _col(left[k]) for k in keys}
+    for name in [c for c in left if c not in keys] + [c for c in right if c not in keys and c not in left]:
+        if name not in right:
+            out[name] = _col(left[name])
+            continue
+        rc = _col(right[name])
+        lc = _col(left[name]) if name in left else np.full(nl, _null_of(rc.dtype), rc.dtype)
+        o = lc.copy()
+        o[hit] = rc[ids[hit]]
+        out[name] = o
+    return out
+
+
+def inner_join(keys, left: dict, right: dict) -> dict:
+    """ray_inner_join + index_inner_join_obj + get_column (core/join.c:68-81,200-298; core/index.c:2930-2990)."""
+    keys = [keys] if isinstance(keys, str) else list(keys)
+    nl = len(next(iter(left.values()))) if left else 0
+    nr = len(next(iter(right.values()))) if right else 0
+    if nl == 0 or nr == 0:
+        return dict(left)
+    ids = join_index(keys, left, right)
+    lids = np.nonzero(ids != NULL_I64)[0]
+    rids = ids[lids]
+    out = {}
+    for name in keys + [c for c in left if c not in keys] + [c for c in right if c not in keys and c not in left]:
+        out[name] = _col(right[name])[rids] if name in right else _col(left[name])[lids]
+    return out
+
+
 def select(query: dict) -> dict:
     """Same contract as rayforce_amd.Engine.select, numpy in / numpy out."""
     table = query["from"]

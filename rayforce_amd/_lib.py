@@ -150,6 +150,9 @@ PROTOTYPES = {
     "rfx_hip_hash_mix_u64": (C.c_int, [_ctx, C.c_void_p, C.c_int64, C.c_uint64, C.c_void_p]),
     "rfx_agg_input_type": (C.c_int, [_P(Agg)]),
     "rfx_hip_xbar_i64": (C.c_int, [_ctx, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),
+    "rfx_hip_join_probe_dense": (C.c_int, [_ctx, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
+    "rfx_hip_join_probe_hash": (C.c_int, [_ctx, C.c_void_p, C.c_int64, _P(HashTables), C.c_void_p]),
+    "rfx_hip_gather_or": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_uint64, C.c_void_p]),
     "rfx_hip_row_hash": (C.c_int, [_ctx, C.POINTER(C.c_void_p), C.c_int, C.c_int64, C.c_int, C.c_void_p]),
     "rfx_hip_replace_null_i64": (C.c_int, [_ctx, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),
     "rfx_hip_h2d_pipelined": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_size_t]),

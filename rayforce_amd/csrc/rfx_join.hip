@@ -1,0 +1,101 @@
+// rfx_join.hip -- equi-join index and column assembly, built on the group-by tables.
+//
+// Reference: lj / ij (ray_left_join / ray_inner_join, core/join.c:158-298) ask index_left_join_obj / index_inner_join_obj
+// (core/index.c:2886-2990) for, per LEFT row, the FIRST right row with an equal key (ray_find for one key column; an
+// open-addressing table over row hashes with a tuple comparison for several), or null.  Then every non-key column is
+// assembled row by row: right[idx] where a match exists, else the left row's own value (select_column, core/join.c:38-66);
+// the inner join keeps the matched pairs only (get_column, :68-81).
+//
+// "First right row per key" is exactly the first-occurrence table of the group-by (K7: d_first[slot] = min row id), so the
+// BUILD side is rfx_hip_group_dense_accumulate / rfx_hip_group_hash_accumulate with zero aggregates; this file adds the PROBE
+// (one streaming pass over the left keys, one random 8-byte read per row) and the null-aware gather.
+//   k_join_probe_dense   idx = first[key - kmin] when the key is inside the right side's scope and the slot is occupied
+//   k_join_probe_hash    read-only walk of the open-addressing table the hashed group-by filled (same hash, same probing)
+//   k_gather_or          out[i] = ids[i] is null ? (left ? left[i] : fill) : right[ids[i]]
+#include "rfx_group_common.hpp"
+
+__global__ __launch_bounds__(RFX_BLOCK) void k_join_probe_dense(const u64 *__restrict__ keys, i64 n, u64 kmin, u64 range, const u64 *__restrict__ first,
+                                                                i64 *__restrict__ out) {
+    for (i64 i = blockIdx.x * (i64)RFX_BLOCK + threadIdx.x; i < n; i += (i64)gridDim.x * RFX_BLOCK) {
+        const u64 slot = keys[i] - kmin;
+        i64 r = RFX_NULL_I64_D;
+        if (slot < range) {
+            const u64 f = first[slot];
+            if (f != (u64)RFX_INF_I64_D) r = (i64)f;
+        }
+        out[i] = r;
+    }
+}
+
+__global__ __launch_bounds__(RFX_BLOCK) void k_join_probe_hash(const u64 *__restrict__ keys, i64 n, const u64 *__restrict__ tab, i64 capacity,
+                                                               const u64 *__restrict__ first, i64 *__restrict__ out) {
+    const u64 mask = (u64)capacity - 1;
+    for (i64 i = blockIdx.x * (i64)RFX_BLOCK + threadIdx.x; i < n; i += (i64)gridDim.x * RFX_BLOCK) {
+        const u64 key = keys[i];
+        i64 r = RFX_NULL_I64_D;
+        if ((i64)key == RFX_NULL_I64_D) { // the null key has its own cell behind the table (hash_slot)
+            const u64 f = first[capacity];
+            if (f != (u64)RFX_INF_I64_D) r = (i64)f;
+        } else {
+            u64 s = rfx_hash_index_u64(RFX_U64_HASH_SEED, key) & mask;
+            for (i64 probe = 0; probe < capacity; probe++) {
+                const u64 k = tab[s];
+                if (k == key) {
+                    r = (i64)first[s];
+                    break;
+                }
+                if ((i64)k == RFX_NULL_I64_D) break; // an empty slot ends the probe sequence: the key is not on the right side
+                s = (s + 1) & mask;
+            }
+        }
+        out[i] = r;
+    }
+}
+
+__global__ __launch_bounds__(RFX_BLOCK) void k_gather_or(const u64 *__restrict__ right, const u64 *__restrict__ left, const i64 *__restrict__ ids, i64 n, u64 fill,
+                                                         u64 *__restrict__ out) {
+    for (i64 i = blockIdx.x * (i64)RFX_BLOCK + threadIdx.x; i < n; i += (i64)gridDim.x * RFX_BLOCK) {
+        const i64 id = ids[i];
+        out[i] = (id != RFX_NULL_I64_D) ? right[id] : (left ? left[i] : fill);
+    }
+}
+
+static int join_grid(rfx_ctx *c, i64 n) {
+    const i64 blocks = (n + RFX_BLOCK - 1) / RFX_BLOCK;
+    int grid = rfx_grid(c) * 4;
+    if (blocks < grid) grid = (int)blocks;
+    return grid;
+}
+
+extern "C" int rfx_hip_join_probe_dense(rfx_ctx_t *c, const int64_t *d_left_keys, int64_t nleft, int64_t kmin, int64_t range, const int64_t *d_first,
+                                        int64_t *d_ids) {
+    RFX_REQUIRE(c, RFX_EINVAL, "ctx is NULL");
+    if (nleft <= 0) return RFX_OK;
+    RFX_REQUIRE(d_left_keys && d_first && d_ids, RFX_EINVAL, "NULL argument");
+    RFX_REQUIRE(range > 0, RFX_EINVAL, "range must be > 0");
+    hipLaunchKernelGGL(k_join_probe_dense, dim3(join_grid(c, nleft)), dim3(RFX_BLOCK), 0, c->stream, (const u64 *)d_left_keys, (i64)nleft, (u64)kmin, (u64)range,
+                       (const u64 *)d_first, (i64 *)d_ids);
+    RFX_HIP_CHECK(hipGetLastError());
+    return RFX_OK;
+}
+
+extern "C" int rfx_hip_join_probe_hash(rfx_ctx_t *c, const int64_t *d_left_keys, int64_t nleft, const rfx_hash_tables_t *t, int64_t *d_ids) {
+    RFX_REQUIRE(c, RFX_EINVAL, "ctx is NULL");
+    if (nleft <= 0) return RFX_OK;
+    RFX_REQUIRE(d_left_keys && d_ids && t && t->d_keys && t->d_first, RFX_EINVAL, "NULL argument");
+    RFX_REQUIRE(t->capacity >= 2 && (t->capacity & (t->capacity - 1)) == 0, RFX_EINVAL, "capacity must be a power of two >= 2");
+    hipLaunchKernelGGL(k_join_probe_hash, dim3(join_grid(c, nleft)), dim3(RFX_BLOCK), 0, c->stream, (const u64 *)d_left_keys, (i64)nleft, (const u64 *)t->d_keys,
+                       (i64)t->capacity, (const u64 *)t->d_first, (i64 *)d_ids);
+    RFX_HIP_CHECK(hipGetLastError());
+    return RFX_OK;
+}
+
+extern "C" int rfx_hip_gather_or(rfx_ctx_t *c, const void *d_right, const void *d_left, const int64_t *d_ids, int64_t n, uint64_t fill_bits, void *d_out) {
+    RFX_REQUIRE(c, RFX_EINVAL, "ctx is NULL");
+    if (n <= 0) return RFX_OK;
+    RFX_REQUIRE(d_right && d_ids && d_out, RFX_EINVAL, "NULL argument");
+    hipLaunchKernelGGL(k_gather_or, dim3(join_grid(c, n)), dim3(RFX_BLOCK), 0, c->stream, (const u64 *)d_right, (const u64 *)d_left, (const i64 *)d_ids, (i64)n,
+                       (u64)fill_bits, (u64 *)d_out);
+    RFX_HIP_CHECK(hipGetLastError());
+    return RFX_OK;
+}

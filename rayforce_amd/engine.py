@@ -795,6 +795,124 @@ class Engine:
             r["key_columns"] = [x[perm] for x in r["key_columns"]]
         return r
 
+    # ------------------------------------------------------------------ equi-joins: lj / ij, core/join.c:158-298
+    def join_index(self, keys, left: Dict[str, torch.Tensor], right: Dict[str, torch.Tensor]) -> torch.Tensor:
+        """Per LEFT row the FIRST right row with an equal key tuple, or null (index_left_join_obj, core/index.c:2886-2928;
+        one key column: ray_find).  Build = the group-by's first-occurrence table over the right keys (no aggregates), probe =
+        one pass over the left keys.  Several key columns probe on the reference's row hash of both sides and are then
+        compared column by column at the matched rows; a mismatch (two tuples, one hash) raises."""
+        keys = [keys] if isinstance(keys, str) else list(keys)
+        lk = [self._check_col(self._resolve(k, left)) for k in keys]
+        rk = [self._check_col(self._resolve(k, right)) for k in keys]
+        if any(c.dtype != torch.int64 for c in lk + rk):
+            raise RfxError("join keys must be i64-like columns on this path")
+        nl, nr = lk[0].numel(), rk[0].numel()
+        ids = self.empty(nl)
+        if nl == 0:
+            return ids
+        if nr == 0:
+            return ids.fill_(L.NULL_I64)
+        exact = True
+        if len(keys) == 1:
+            lkey, rkey = lk[0], rk[0]
+        else:
+            # ranges (over BOTH sides) that multiply into 64 bits: one injective composite key per side, as the group-by's
+            # "perfect" path builds it -- exact, no hashing; else the reference's own route, the row hash
+            k = len(keys)
+            mins, maxs = [], []
+            for lc, rc_ in zip(lk, rk):
+                a, b = self.scope(lc), self.scope(rc_)
+                mins.append(min(a[0], b[0]))
+                maxs.append(max(a[1], b[1]))
+            amin, amax, amul, tmax = (C.c_int64 * k)(*mins), (C.c_int64 * k)(*maxs), (C.c_int64 * k)(), C.c_int64()
+            if self.lib.rfx_composite_plan(amin, amax, k, amul, C.byref(tmax)) == L.RFX_OK:
+                lkey, rkey = self.empty(nl), self.empty(nr)
+                for cols, n_, out in ((lk, nl, lkey), (rk, nr, rkey)):
+                    ptrs = (C.c_void_p * k)(*[c.data_ptr() for c in cols])
+                    L.check(self.lib.rfx_hip_composite_key(self._ctx, ptrs, amin, amul, k, n_, out.data_ptr()), "composite_key")
+            else:
+                lkey, rkey, exact = self.row_hash(lk), self.row_hash(rk), False
+        kmin, kmax, seen = self.scope(rkey)
+        rng = kmax - kmin + 1
+        aarr = (L.Agg * 1)()
+        # dense first-occurrence table where the group-by would choose one (range <= rows), and beyond that while it stays small
+        # next to the right side (8 B per slot, <= 4 x rows or 16 M slots): a table fill is cheaper than hashing every right row
+        if 0 < rng <= max(seen, 4 * nr, 1 << 24) and rng <= (1 << 29) and kmin != L.NULL_I64:
+            t, store, _ = self.group_tables(aarr, 0, kmin, rng)
+            L.check(self.lib.rfx_hip_group_tables_init(self._ctx, aarr, C.byref(t)), "group_tables_init")
+            L.check(self.lib.rfx_hip_group_dense_accumulate(self._ctx, rkey.data_ptr(), None, 0, L.RFX_AND, aarr, nr, 0, C.byref(t)), "group_dense_accumulate")
+            L.check(self.lib.rfx_hip_join_probe_dense(self._ctx, lkey.data_ptr(), nl, kmin, rng, t.d_first, ids.data_ptr()), "join_probe_dense")
+        else:
+            cap_max = 1 << max(4, math.ceil(math.log2(max(2 * nr, 16))))
+            cap = min(cap_max, 1 << 22)
+            while True:
+                t, store, _ = self.group_tables(aarr, 0, 0, cap, hashed=True)
+                L.check(self.lib.rfx_hip_hash_tables_init(self._ctx, aarr, C.byref(t)), "hash_tables_init")
+                rc = self.lib.rfx_hip_group_hash_accumulate(self._ctx, rkey.data_ptr(), None, 0, L.RFX_AND, aarr, nr, 0, C.byref(t))
+                if rc != L.RFX_ELIMIT or cap >= cap_max:
+                    L.check(rc, "group_hash_accumulate")
+                    break
+                del t, store
+                cap = min(cap_max, cap << 4)
+            L.check(self.lib.rfx_hip_join_probe_hash(self._ctx, lkey.data_ptr(), nl, C.byref(t), ids.data_ptr()), "join_probe_hash")
+        if not exact:  # the tuple comparison the reference does on every probe (__index_list_cmp_row), done once on the result
+            chk = self.empty(nl)
+            for lc, rc_ in zip(lk, rk):
+                L.check(self.lib.rfx_hip_gather_or(self._ctx, rc_.data_ptr(), lc.data_ptr(), ids.data_ptr(), nl, 0, chk.data_ptr()), "gather_or")
+                if not bool(torch.equal(chk, lc)):
+                    raise RfxError("join: two key tuples share one 64-bit row hash (collision); not answered on this path")
+        self.sync()
+        return ids
+
+    def _join_fill(self, col: torch.Tensor) -> int:
+        return 0x7FF8000000000000 if col.dtype == torch.float64 else (1 << 63)  # NaN / NULL_I64 bit patterns
+
+    def left_join(self, keys, left: Dict[str, torch.Tensor], right: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+        """``(lj [keys] left right)`` -- ray_left_join, core/join.c:158-198: every left row; a non-key column that the right
+        table has takes the matched right row's value, else the left row's own (null when the left table lacks the column);
+        columns: keys, then the other left columns, then the right-only ones.  Empty side -> the left table."""
+        keys = [keys] if isinstance(keys, str) else list(keys)
+        nl = next(iter(left.values())).numel() if left else 0
+        nr = next(iter(right.values())).numel() if right else 0
+        if nl == 0 or nr == 0:
+            return dict(left)
+        ids = self.join_index(keys, left, right)
+        out = {k: left[k] for k in keys}
+        for name in [c for c in left if c not in keys] + [c for c in right if c not in keys and c not in left]:
+            if name not in right:
+                out[name] = left[name]
+                continue
+            rc, lc = right[name], left.get(name)
+            if lc is not None and lc.dtype != rc.dtype:
+                raise RfxError(f"join: column {name} has different types in the two tables")
+            o = torch.empty(nl, dtype=rc.dtype, device=self.device)
+            L.check(self.lib.rfx_hip_gather_or(self._ctx, rc.data_ptr(), lc.data_ptr() if lc is not None else None, ids.data_ptr(), nl, self._join_fill(rc),
+                                               o.data_ptr()), "gather_or")
+            out[name] = o
+        self.sync()
+        return out
+
+    def inner_join(self, keys, left: Dict[str, torch.Tensor], right: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+        """``(ij [keys] left right)`` -- ray_inner_join, core/join.c:200-298: the left rows that have a match, in left order,
+        paired with their first matching right row; a column the right table has comes from the right row."""
+        keys = [keys] if isinstance(keys, str) else list(keys)
+        nl = next(iter(left.values())).numel() if left else 0
+        nr = next(iter(right.values())).numel() if right else 0
+        if nl == 0 or nr == 0:
+            return dict(left)
+        ids = self.join_index(keys, left, right)
+        lids = self.where(("!=", ids, None))  # ascending left rows with a match
+        rids = self.at_ids(ids, lids)
+        out = {}
+        for name in keys + [c for c in left if c not in keys] + [c for c in right if c not in keys and c not in left]:
+            if name in right:
+                if name in left and left[name].dtype != right[name].dtype:
+                    raise RfxError(f"join: column {name} has different types in the two tables")
+                out[name] = self.at_ids(right[name], rids)
+            else:
+                out[name] = self.at_ids(left[name], lids)
+        return out
+
     def _key_col(self, spec, table) -> torch.Tensor:
         """A `by:` entry: a column, or ("xbar", column, width) -- the bucketed key is evaluated once into a scratch column
         (ray_xbar, core/math.c:1635; the reference does the same before grouping)."""

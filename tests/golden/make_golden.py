@@ -81,8 +81,52 @@ def rowhash_section(arrays, cases):
         print(f"rowhash case {ri}: {len(r[names[0]])} groups, reference order = {order}")
 
 
+def join_section(arrays, cases):
+    # ---- 4f. equi-joins: (left-join [keys] x y) / (inner-join [keys] x y), core/join.c:158-298 ----
+    from golden_cases import JOIN_SHAPES, join_tables
+    for i, nl, nr, seed, keys, mod, mul, nulls in JOIN_SHAPES:
+        left, right = join_tables(nl, nr, seed, keys, mod, mul, nulls)
+        with ref.Session() as s:
+            for side, t in (("x", left), ("y", right)):  # a session stages columns by NAME: keep the two tables' names apart
+                for c, v in t.items():
+                    s.put(f"{side}_{c}", v)
+                s.eval(f"(set {side} (table [{' '.join(t)}] (list {' '.join(f'{side}_{c}' for c in t)})))")
+            kk = " ".join(keys)
+            s.eval(f"(set rl (left-join [{kk}] x y))")
+            if not nulls:  # inner-join with null keys on both sides kills the reference (SIGSEGV, any pool size): left-join only there
+                s.eval(f"(set ri (inner-join [{kk}] x y))")
+            cols = keys + ["a", "v", "w", "z"]
+            # left-join: the right-only columns w, z come back from the reference as generic LISTS holding `Null` objects for the
+            # unmatched rows (ins_obj of a NULL_OBJ turns the typed vector into a list, core/join.c:55-62) -- not exportable as
+            # column files and not captured; the typed columns (keys, a, v) are, and the inner join pins w / z on the matched rows
+            ljcols = keys + ["a", "v"]
+            for o in ljcols:
+                s.out(f"lj_{o}", f"(at rl '{o})")
+            for o in ([] if nulls else cols):
+                s.out(f"ij_{o}", f"(at ri '{o})")
+            r = s.run(threads=8)
+        for o in ljcols:
+            arrays[f"join_{i}_lj_{o}"] = r[f"lj_{o}"]
+        for o in ([] if nulls else cols):
+            arrays[f"join_{i}_ij_{o}"] = r[f"ij_{o}"]
+        cases.append({"kind": "join", "index": i})
+        print(f"join case {i}: lj {len(r['lj_' + keys[0]])} rows, ij {'-' if nulls else len(r['ij_' + keys[0]])} rows")
+
+
 def main():
     assert ref.build(), "reference not buildable here"
+    if "--only-joins" in sys.argv:  # refresh section 4f inside the existing fixture
+        z = np.load(os.path.join(HERE, "ref_golden.npz"))
+        arrays = {k: z[k] for k in z.files if not k.startswith("join_")}
+        meta = json.load(open(os.path.join(HERE, "ref_golden.json")))
+        cases = [c for c in meta["cases"] if c["kind"] != "join"]
+        join_section(arrays, cases)
+        np.savez_compressed(os.path.join(HERE, "ref_golden.npz"), **arrays)
+        meta["cases"] = cases
+        with open(os.path.join(HERE, "ref_golden.json"), "w") as fjs:
+            json.dump(meta, fjs, indent=1)
+        print(f"wrote {len(arrays)} arrays")
+        return
     if "--only-rowhash" in sys.argv:  # refresh section 4e inside the existing fixture (the other sections take minutes)
         z = np.load(os.path.join(HERE, "ref_golden.npz"))
         arrays = {k: z[k] for k in z.files if not k.startswith("rowhash_")}
@@ -200,6 +244,7 @@ def main():
         cases.append({"kind": "multikey", "index": mi, "n": n, "seed": seed, "mods": list(mods), "offs": list(offs)})
 
     rowhash_section(arrays, cases)
+    join_section(arrays, cases)
 
     # ---- 4c. element-wise arithmetic: truth tables on special values, then aggregates over expressions ----
     xi = np.array([0, 1, -1, NULL, 2**63 - 1, 5, -5, 7], np.int64)

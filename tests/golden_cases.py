@@ -110,6 +110,50 @@ def rowhash_table(n, seed, kind):
     return t
 
 
+JOIN_SHAPES = [  # (index, left rows, right rows, seed, key columns, key modulus, key multiplier, nulls in keys)
+    (0, 20_011, 300, 51, ["k"], 700, 1, False),
+    (1, 20_011, 3_000, 52, ["k"], 5_000, 1_000_003, False),
+    (2, 30_011, 2_000, 53, ["k1", "k2"], 60, 1, False),
+    (3, 20_011, 500, 54, ["k"], 600, 1, True),
+    (4, 30_011, 2_000, 55, ["k1", "k2"], 60, 1 << 40, True),
+]
+
+
+def join_tables(nl, nr, seed, keys, mod, mul, nulls):
+    """Left / right tables of a join case: key columns with duplicates on BOTH sides (first right occurrence matters), a shared
+    non-key column `v` (the right one wins where a row matches), a left-only `a` and right-only `w` (f64) / `z` (i64)."""
+    left, right = {}, {}
+    for j, k in enumerate(keys):
+        left[k] = rfo.gen_i64(nl, seed + 10 * j, mod) * mul - 7
+        right[k] = rfo.gen_i64(nr, seed + 10 * j + 1, mod + mod // 3) * mul - 7  # some right keys never asked for, some left keys unmatched
+        if nulls:
+            left[k][rfo.gen_i64(nl, seed + 10 * j + 2, 40) == 0] = NULL
+            right[k][rfo.gen_i64(nr, seed + 10 * j + 3, 25) == 0] = NULL
+    left["a"] = rfo.gen_i64(nl, seed + 5, 1_000_000)
+    left["v"] = rfo.gen_f64(nl, seed + 6)
+    right["v"] = rfo.gen_f64(nr, seed + 7) + 10.0
+    right["w"] = rfo.gen_f64(nr, seed + 8)
+    right["z"] = rfo.gen_i64(nr, seed + 9, 1000)
+    return left, right
+
+
+def join_cases():
+    """left-join / inner-join through the reference: yields (id, key names, left, right, wanted lj columns, wanted ij columns;
+    the latter empty where keys hold nulls on both sides -- the reference's inner-join dies there)."""
+    for c in _meta["cases"]:
+        if c["kind"] != "join":
+            continue
+        i, nl, nr, seed, keys, mod, mul, nulls = JOIN_SHAPES[c["index"]]
+        left, right = join_tables(nl, nr, seed, keys, mod, mul, nulls)
+        cols = keys + ["a", "v", "w", "z"]
+        # (lj: the reference returns its right-only columns w, z as generic lists with Null objects; only typed columns are pinned)
+        # ONE key column with nulls on both sides: the reference's ray_find answers the same right row for nearly every left row
+        # (19 499 of 20 011 rows take v = 10.2558...) and its inner-join dies -- a defect, captured but not compared; the two-key
+        # case with nulls (row-hash arm) is sound and pins "null keys match null keys"
+        defect = nulls and len(keys) == 1
+        yield f"j{i}", keys, left, right, ({} if defect else {o: arr(f"join_{i}_lj_{o}") for o in keys + ["a", "v"]}), ({} if nulls else {o: arr(f"join_{i}_ij_{o}") for o in cols})
+
+
 def rowhash_cases():
     """Several `by:` columns on the reference's ROW-HASH path (ranges beyond 64 bits / null keys; H2O Q7 shape).  Yields
     (id, table, key names, group order the reference produced -- "first" single-threaded, "radix" multi-threaded --, wanted)."""

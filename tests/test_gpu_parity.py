@@ -516,6 +516,38 @@ def test_group_by_key_tuples_beyond_the_composite_key(eng):
     check_select(eng, host, {"by": by6, "s": ("sum", "v")})
 
 
+def test_equi_joins_at_size_and_edges(eng):
+    """left_join / inner_join / join_index against the oracle: 1e6-row left side, dense and hashed right tables, three key
+    columns (row hash + tuple check), f64 and i64 payloads, no match at all, every row matching, empty sides."""
+    nl, nr = 1_000_003, 200_001
+    for keys, mul in ((["k"], 1), (["k"], 1_000_003), (["k", "g", "h"], 1), (["k", "g", "h"], 1 << 45)):  # dense / hashed / composite key / row hash
+        left = {"k": rfo.gen_i64(nl, 91, 150_000) * mul, "g": rfo.gen_i64(nl, 92, 3), "h": rfo.gen_i64(nl, 93, 2) - 1, "a": rfo.gen_i64(nl, 94, 10**6), "v": rfo.gen_f64(nl, 95)}
+        right = {"k": rfo.gen_i64(nr, 96, 180_000) * mul, "g": rfo.gen_i64(nr, 97, 3), "h": rfo.gen_i64(nr, 98, 2) - 1, "v": rfo.gen_f64(nr, 99) + 5, "z": rfo.gen_i64(nr, 90, 77)}
+        left["v"][::53] = np.nan
+        right["z"][::31] = NULL
+        dl, dr = dev(eng, left), dev(eng, right)
+        assert np.array_equal(eng.join_index(keys, dl, dr).cpu().numpy(), rfo.join_index(keys, left, right))
+        for fn in ("left_join", "inner_join"):
+            got, want = getattr(eng, fn)(keys, dl, dr), getattr(rfo, fn)(keys, left, right)
+            assert list(got) == list(want), fn
+            for c in want:
+                g = got[c].cpu().numpy()
+                assert g.dtype == want[c].dtype and np.array_equal(g.view(np.int64), want[c].view(np.int64)), (fn, keys, c)  # bit-exact, NaN included
+    # nothing matches / everything matches / empty sides
+    left = {"k": np.arange(1000, dtype=np.int64), "v": rfo.gen_f64(1000, 1)}
+    right = {"k": np.arange(5000, 6000, dtype=np.int64), "w": rfo.gen_f64(1000, 2)}
+    dl, dr = dev(eng, left), dev(eng, right)
+    assert (eng.join_index("k", dl, dr).cpu().numpy() == NULL).all() and eng.inner_join("k", dl, dr)["k"].numel() == 0
+    assert np.isnan(eng.left_join("k", dl, dr)["w"].cpu().numpy()).all()
+    same = eng.inner_join("k", dl, dl)
+    assert np.array_equal(same["v"].cpu().numpy(), left["v"])
+    empty = {"k": eng.empty(0), "w": eng.empty(0, torch.float64)}
+    assert list(eng.left_join("k", dl, empty)) == ["k", "v"] and list(eng.inner_join("k", empty, dr)) == ["k", "w"]
+    from rayforce_amd._lib import RfxError
+    with pytest.raises(RfxError, match="i64-like"):
+        eng.join_index("v", dl, dev(eng, {"v": left["v"]}))
+
+
 def test_group_by_xbar_buckets(eng):
     """by: {b: (xbar a width)} -- bucketed keys (negative values, dense and sparse bucket ranges, one or two key columns, with
     where:).  Null keys are left out: they take the sparse path, where one null group here stands against one group per null

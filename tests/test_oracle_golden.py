@@ -85,6 +85,22 @@ def test_group_by_several_keys_row_hash_path(case):
         G.same(got[o], want[o], o)
 
 
+@pytest.mark.parametrize("case", list(G.join_cases()), ids=lambda c: c[0])
+def test_equi_joins(case):
+    """left-join / inner-join (core/join.c:158-298): first right row per key tuple, right column wins on a match, left value
+    otherwise; null keys match null keys."""
+    _, keys, left, right, want_lj, want_ij = case
+    got = rfo.left_join(keys, left, right)
+    assert list(got.keys()) == keys + ["a", "v", "w", "z"]
+    for o in want_lj:  # (empty for the one-key null case: reference defect, see golden_cases.join_cases)
+        G.same(got[o], want_lj[o], "lj " + o)
+    if want_ij:
+        got = rfo.inner_join(keys, left, right)
+        assert list(got.keys()) == list(want_ij.keys())
+        for o in want_ij:
+            G.same(got[o], want_ij[o], "ij " + o)
+
+
 def test_composite_plan_overflow_rules():
     """core/index.c:2364-2383: the perfect path is abandoned when the product of ranges leaves i64 -- a null key always does."""
     n = 1000
