@@ -90,3 +90,50 @@ def test_random_select(eng, seed):
         check_select(eng, t, q)
     finally:
         eng.tune(flags=0)
+
+
+@pytest.mark.parametrize("seed", range(80))
+def test_random_key_tuples_row_hash(eng, seed):
+    """Two to five key columns that cannot fold into one 64-bit key (wide strides and / or null keys): the row-hash path, both group
+    orders, with and without where:, plain and expression aggregates."""
+    rng = np.random.default_rng(5000 + seed)
+    t, q = make_case(rng)
+    n = len(t["a"])
+    nk = int(rng.integers(2, 6))
+    by = {}
+    for i in range(nk):
+        c = rfo.gen_i64(n, int(rng.integers(1, 1 << 30)), int(rng.choice([2, 9, 300]))) * int(rng.choice([1, 1 << 33, 1 << 47, 1_000_000_007])) - int(rng.integers(0, 9))
+        if rng.random() < 0.4 and n:
+            c[rfo.gen_i64(n, int(rng.integers(1, 1 << 30)), int(rng.choice([3, 40]))) == 0] = NULL
+        t[f"x{i}"] = c
+        by[f"x{i}"] = f"x{i}"
+    q["by"] = by
+    if rng.random() < 0.5:
+        q["order"] = "radix"
+    check_select(eng, t, q)  # (tuples whose ranges happen to fit take the composite path: same contract)
+
+
+@pytest.mark.parametrize("seed", range(60))
+def test_random_joins(eng, seed):
+    rng = np.random.default_rng(7000 + seed)
+    nl, nr = int(rng.choice(SIZES)), int(rng.choice([1, 2, 64, 513, 4000, 70_001, 300_007]))
+    nk = int(rng.integers(1, 4))
+    keys = [f"k{i}" for i in range(nk)]
+    left, right = {}, {}
+    for k in keys:
+        mod, mul = int(rng.choice([2, 50, 3000, 200_000])), int(rng.choice([1, 1, 1_000_003, 1 << 44]))
+        left[k] = rfo.gen_i64(nl, int(rng.integers(1, 1 << 30)), mod) * mul
+        right[k] = rfo.gen_i64(nr, int(rng.integers(1, 1 << 30)), mod + mod // 2) * mul
+        if rng.random() < 0.3:
+            left[k][rfo.gen_i64(nl, int(rng.integers(1, 1 << 30)), 30) == 0] = NULL
+            right[k][rfo.gen_i64(nr, int(rng.integers(1, 1 << 30)), 20) == 0] = NULL
+    left["v"], left["a"] = rfo.gen_f64(nl, int(rng.integers(1, 1 << 30))), rfo.gen_i64(nl, int(rng.integers(1, 1 << 30)), 1000)
+    right["v"], right["z"] = rfo.gen_f64(nr, int(rng.integers(1, 1 << 30))) + 3, rfo.gen_i64(nr, int(rng.integers(1, 1 << 30)), 1000)
+    dl, dr = {k: eng.column(v) for k, v in left.items()}, {k: eng.column(v) for k, v in right.items()}
+    assert np.array_equal(eng.join_index(keys, dl, dr).cpu().numpy(), rfo.join_index(keys, left, right))
+    for fn in ("left_join", "inner_join"):
+        got, want = getattr(eng, fn)(keys, dl, dr), getattr(rfo, fn)(keys, left, right)
+        assert list(got) == list(want)
+        for c in want:
+            g = got[c].cpu().numpy()
+            assert g.dtype == want[c].dtype and np.array_equal(g.view(np.int64), want[c].view(np.int64)), (fn, c)
