@@ -343,6 +343,12 @@ int rfx_hip_group_dense_accumulate_keys(rfx_ctx_t *ctx, const void *const *d_key
 int rfx_hip_row_hash(rfx_ctx_t *ctx, const void *const *d_cols, int nkeys, int64_t nrows, int value_first, int64_t *d_out);
 int rfx_hip_replace_null_i64(rfx_ctx_t *ctx, const int64_t *d_col, int64_t nrows, int64_t repl, int64_t *d_out);
 
+/* ---- element-wise arithmetic as a column: ray_add / ray_sub / ray_mul / ray_div over vectors and atoms (binop_map, core/math.c:2280-2345) ----
+ * `expr` describes (op x y) or an expression tree exactly as an aggregate's argument does (xop / xnodes fields of rfx_agg_t; kind
+ * and d_col are ignored); d_out receives one 8-byte value per row, *out_type its element type.  One pass, no temporaries per
+ * operation.  Also what `where:` needs for predicates over expressions: evaluate, then compare the column. */
+int rfx_hip_eval_expr(rfx_ctx_t *ctx, const rfx_agg_t *expr, int64_t nrows, void *d_out, int32_t *out_type);
+
 /* ---- equi-joins: lj / ij (ray_left_join / ray_inner_join, core/join.c:158-298; index_left_join_obj, core/index.c:2886-2928) ----
  * The reference's join index is, per LEFT row, the FIRST right row with an equal key, or null.  Build side = the group-by's
  * first-occurrence table over the RIGHT key column with zero aggregates (rfx_hip_group_dense_accumulate into d_first, or

@@ -178,8 +178,9 @@ def mask_of(where_spec, table) -> np.ndarray:
     head = where_spec[0]
     if head in OPS:
         _, lhs, rhs = where_spec
-        lhs = table[lhs] if isinstance(lhs, str) else lhs
-        rhs = table[rhs] if isinstance(rhs, str) else rhs
+        # an operand may be an element-wise expression: the reference evaluates it first (eval -> binop_map), then compares
+        lhs = table[lhs] if isinstance(lhs, str) else (eval_arg(lhs, table) if isinstance(lhs, tuple) else lhs)
+        rhs = table[rhs] if isinstance(rhs, str) else (eval_arg(rhs, table) if isinstance(rhs, tuple) else rhs)
         return cmp(head, lhs, rhs)
     subs = [mask_of(w, table) for w in where_spec[1:]]
     return and_(*subs) if head == "and" else or_(*subs)

@@ -150,6 +150,7 @@ PROTOTYPES = {
     "rfx_hip_hash_mix_u64": (C.c_int, [_ctx, C.c_void_p, C.c_int64, C.c_uint64, C.c_void_p]),
     "rfx_agg_input_type": (C.c_int, [_P(Agg)]),
     "rfx_hip_xbar_i64": (C.c_int, [_ctx, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),
+    "rfx_hip_eval_expr": (C.c_int, [_ctx, _P(Agg), C.c_int64, C.c_void_p, _P(C.c_int32)]),
     "rfx_hip_join_probe_dense": (C.c_int, [_ctx, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
     "rfx_hip_join_probe_hash": (C.c_int, [_ctx, C.c_void_p, C.c_int64, _P(HashTables), C.c_void_p]),
     "rfx_hip_gather_or": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_uint64, C.c_void_p]),

@@ -266,6 +266,29 @@ int rfx_plan_materialise_exprs(rfx_ctx *c, Plan *P) {
     return RFX_OK;
 }
 
+// Element-wise evaluation into a caller's column: binop_map / ray_{add,sub,mul,div}_partial (core/math.c:251-1782,2280-2345) as one
+// streaming pass -- every operand column read once with 16-byte loads, the result written once, no intermediate per operation.
+extern "C" int rfx_hip_eval_expr(rfx_ctx_t *c, const rfx_agg_t *expr, int64_t nrows, void *d_out, int32_t *out_type) {
+    RFX_REQUIRE(c && expr, RFX_EINVAL, "NULL argument");
+    RFX_REQUIRE(expr->xop != RFX_X_NONE || expr->nxnodes > 0, RFX_EINVAL, "not an expression");
+    rfx_agg_t a = *expr;
+    a.kind = RFX_AGG_SUM; // any kind that accepts an expression: only the expression part of the plan is used
+    Plan P;
+    int rc = rfx_plan_build(&P, NULL, 0, RFX_AND, &a, 1, NULL, NULL, nrows, 0);
+    if (rc != RFX_OK) return rc;
+    RFX_REQUIRE(P.nx == 1, RFX_EINVAL, "not an expression");
+    if (out_type) *out_type = P.xs[0].out_f64 ? RFX_F64 : RFX_I64;
+    if (nrows <= 0) return RFX_OK;
+    RFX_REQUIRE(d_out && ((uintptr_t)d_out & 15) == 0, RFX_EINVAL, "output must be a 16-byte aligned device buffer");
+    DeriveArgs A;
+    A.x = P.xs[0];
+    for (int cc = 0; cc < RFX_MAX_COLS; cc++) A.cols[cc] = (cc < P.ncols) ? P.cols[cc] : NULL;
+    A.out = (u64 *)d_out;
+    hipLaunchKernelGGL(k_derive, dim3(c->num_cus * 8), dim3(RFX_BLOCK), 0, c->stream, A, (i64)nrows);
+    RFX_HIP_CHECK(hipGetLastError());
+    return RFX_OK;
+}
+
 // ---- plain memory ----
 extern "C" int rfx_hip_malloc(rfx_ctx_t *c, void **d_ptr, size_t bytes) {
     RFX_REQUIRE(c && d_ptr, RFX_EINVAL, "NULL argument");

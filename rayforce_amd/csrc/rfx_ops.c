@@ -870,6 +870,53 @@ static obj_p cmp_op(int op, obj_p x, obj_p y) {
     if (!ok) { H.drop(out); return fail_hip("cmp_mask"); }
     return out;
 }
+/* ray_add / ray_sub / ray_mul / ray_fdiv over an i64 / f64 vector and a vector or atom (binop_map, core/math.c:2280-2345) */
+static obj_p arith_op(int xop, int fidx, obj_p x, obj_p y) {
+    rfx_host_bind();
+    if (!x || !y) return fail("arith: null argument");
+    const int xv = x->type > 0 && col_ctype(x) && x->type != RFX_TYPE_SYMBOL, yv = y->type > 0 && col_ctype(y) && y->type != RFX_TYPE_SYMBOL;
+    const int xa = x->type == -RFX_TYPE_I64 || x->type == -RFX_TYPE_F64, ya = y->type == -RFX_TYPE_I64 || y->type == -RFX_TYPE_F64;
+    if (!((xv && (yv || ya)) || (xa && yv))) {
+        if (H.bound == 1 && H.f[fidx]) return ((rfx_binary_f)H.f[fidx])(x, y);
+        return fail("arith: only i64/f64 vector (x) vector|atom runs on the MI355X path");
+    }
+    if (xv && yv && x->len != y->len) return fail("length");
+    if (ensure_ctx() != RFX_OK) return fail_hip("no usable MI355X");
+    rfx_agg_t a;
+    memset(&a, 0, sizeof(a));
+    a.kind = RFX_AGG_SUM;
+    a.xop = xop;
+    obj_p col = xv ? x : y, other = xv ? y : x;
+    if (!xv) a.xflags = RFX_XF_SWAP; /* atom (op) vector */
+    const void *d;
+    if (resident(col, 0, &d) != RFX_OK) return fail_hip("column upload");
+    a.d_col = d;
+    a.col_type = col_ctype(col);
+    if (other->type > 0) {
+        if (resident(other, 0, &d) != RFX_OK) return fail_hip("column upload");
+        a.d_xrhs_col = d;
+        a.xrhs_type = col_ctype(other);
+    } else if (other->type == -RFX_TYPE_I64) { a.xrhs_type = RFX_I64; a.xrhs_i = other->i64; }
+    else { a.xrhs_type = RFX_F64; a.xrhs_f = other->f64; }
+    const int64_t n = col->len;
+    void *dout = NULL;
+    if (rfx_hip_malloc(g_ctx, &dout, (size_t)(n ? n : 1) * 8) != RFX_OK) return fail_hip("arith");
+    int32_t ot = RFX_I64;
+    int ok = rfx_hip_eval_expr(g_ctx, &a, n, dout, &ot) == RFX_OK;
+    obj_p out = NULL;
+    if (ok) {
+        out = H.vector(ot == RFX_F64 ? RFX_TYPE_F64 : RFX_TYPE_I64, n);
+        ok = n == 0 || rfx_hip_d2h(g_ctx, RFX_AS_RAW(out), dout, (size_t)n * 8) == RFX_OK;
+    }
+    rfx_hip_free(g_ctx, dout);
+    if (!ok) { if (out) H.drop(out); return fail_hip("eval_expr"); }
+    return out;
+}
+rfx_obj_p rfx_add(rfx_obj_p x, rfx_obj_p y) { return arith_op(RFX_X_ADD, F_ADD, x, y); }
+rfx_obj_p rfx_sub(rfx_obj_p x, rfx_obj_p y) { return arith_op(RFX_X_SUB, F_SUB, x, y); }
+rfx_obj_p rfx_mul(rfx_obj_p x, rfx_obj_p y) { return arith_op(RFX_X_MUL, F_MUL, x, y); }
+rfx_obj_p rfx_div(rfx_obj_p x, rfx_obj_p y) { return arith_op(RFX_X_FDIV, F_FDIV, x, y); }
+
 rfx_obj_p rfx_eq(rfx_obj_p x, rfx_obj_p y) { return cmp_op(RFX_EQ, x, y); }
 rfx_obj_p rfx_ne(rfx_obj_p x, rfx_obj_p y) { return cmp_op(RFX_NE, x, y); }
 rfx_obj_p rfx_lt(rfx_obj_p x, rfx_obj_p y) { return cmp_op(RFX_LT, x, y); }

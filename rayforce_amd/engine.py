@@ -249,7 +249,23 @@ class Engine:
             if table is None or x not in table:
                 raise RfxError(f"unknown column {x!r}")
             return table[x]
+        if isinstance(x, tuple) and x and x[0] in L.XOPS:  # an expression where a column is expected: evaluate it once (k_derive)
+            col = self.eval_expr(x, table)
+            self._keep.append(col)
+            return col
         return x
+
+    def eval_expr(self, expr, table=None) -> torch.Tensor:
+        """``(op x y)`` / an expression tree over columns and atoms as a device column: ray_add / ray_sub / ray_mul / ray_div
+        (binop_map, core/math.c:2280-2345) in ONE pass whatever the depth.  Also how `where:` takes predicates over expressions."""
+        a = L.Agg()
+        n = self._agg_expr(a, "sum", expr, table, None)
+        if n is None:
+            raise RfxError("an expression needs at least one column operand")
+        out = torch.empty(n, dtype=torch.float64 if L.agg_input_type(a) == L.RFX_F64 else torch.int64, device=self.device)
+        t = C.c_int32()
+        L.check(self.lib.rfx_hip_eval_expr(self._ctx, C.byref(a), n, out.data_ptr(), C.byref(t)), "eval_expr")
+        return out
 
     def _preds(self, preds: Sequence[tuple], table, n: Optional[int]):
         if len(preds) > L.RFX_MAX_PREDS:
@@ -262,7 +278,7 @@ class Engine:
             p.d_col = lhs.data_ptr()
             p.col_type = _ctype_of(lhs)
             p.op = L.OPS[op]
-            rhs = self._resolve(rhs, table) if isinstance(rhs, str) else rhs
+            rhs = self._resolve(rhs, table) if isinstance(rhs, (str, tuple)) else rhs
             if isinstance(rhs, torch.Tensor):
                 rhs = self._check_col(rhs, n)
                 p.d_rhs_col = rhs.data_ptr()

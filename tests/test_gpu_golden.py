@@ -64,6 +64,24 @@ def test_group_by_several_keys_row_hash_path(eng, case):
         G.same(got[o].cpu().numpy(), want[o], o)
 
 
+def test_binop_truth_tables_as_columns(eng):
+    """The reference's element-wise + - * div answers on the special-value vectors (48 tables), through rfx_hip_eval_expr."""
+    for op, tag, l, r, want in G.binop_cases():
+        t, e = {}, [op, l, r]
+        for i, x in enumerate((l, r)):
+            if isinstance(x, np.ndarray):
+                t[f"c{i}"] = eng.column(x)
+                e[1 + i] = f"c{i}"
+        got = eng.eval_expr(tuple(e), t).cpu().numpy()
+        assert got.dtype == want.dtype, (op, tag)
+        if want.dtype == np.float64:
+            fin = np.isfinite(want)
+            assert np.array_equal(np.isnan(got), np.isnan(want)) and np.array_equal(got[np.isinf(want)], want[np.isinf(want)]), (op, tag)
+            assert np.all(np.abs(got[fin] - want[fin]) <= 2.3e-16 * np.abs(want[fin])), (op, tag)
+        else:
+            assert np.array_equal(got, want), (op, tag)
+
+
 @pytest.mark.parametrize("case", list(G.join_cases()), ids=lambda c: c[0])
 def test_equi_joins(eng, case):
     """left-join / inner-join against the reference's answers: dense and hashed first-occurrence tables, two key columns through

@@ -483,6 +483,31 @@ def test_nested_expression_trees_by_group(eng, flags, keys):
         eng.tune(flags=0)
 
 
+def test_expressions_as_columns_and_inside_predicates(eng):
+    """(op x y) and expression trees as device columns (ray_add / sub / mul / div over vectors and atoms, one pass whatever the
+    depth), and as operands of `where:` comparisons -- flat, nested, under by:, against a column or an atom, nulls / NaN included."""
+    n = 300_007
+    host = table(n, keys=700, nulls=True)
+    host["b"] = rfo.gen_i64(n, 77, 9) - 1
+    d = dev(eng, host)
+    for e in (("*", "a", "v"), ("-", 100, "a"), ("div", "a", "b"), ("+", ("*", "a", "b"), "b"), ("*", ("*", "v", ("-", 1, "w")), ("+", 1, "w")),
+              ("div", ("+", "a", "b"), 3), ("-", ("*", "a", 2), "b"), ("*", "w", 2.0)):
+        got, want = eng.eval_expr(e, d).cpu().numpy(), rfo.eval_arg(e, host)
+        assert got.dtype == want.dtype, e
+        if want.dtype == np.float64:
+            same_f64(got, want)
+        else:
+            assert np.array_equal(got, want), e
+    q = {"s": ("sum", "v"), "c": ("count", "a"), "mx": ("max", ("*", "a", "v"))}
+    for w in ((">", ("*", "a", "v"), 250_000.0), ("<=", ("-", "a", ("*", "b", 100_000)), "a"), ("and", ("<", ("+", "v", "w"), 0.6), (">", "a", 1000)),
+              ("or", ("==", ("div", "a", 1000), 7), ("and", (">", ("*", "v", 2.0), 1.5), ("!=", "b", 3))), ("<", "v", ("*", "w", 3.0))):
+        check_select(eng, host, {**q, "where": w})
+        if not (w[0] in ("and", "or") and any(x[0] in ("and", "or") for x in w[1:])):  # (nested trees are not fused with by: here)
+            check_select(eng, host, {**q, "where": w, "by": "k"})
+        ids = eng.where(w, d).cpu().numpy()
+        assert np.array_equal(ids, rfo.where(rfo.mask_of(w, host)))
+
+
 def test_expression_aggregates_refusals(eng):
     from rayforce_amd._lib import RfxError
     d = dev(eng, table(100))

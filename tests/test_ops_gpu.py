@@ -198,6 +198,39 @@ def test_single_operators(ops):
         ops.rfx_host_drop(o)
 
 
+def test_arithmetic_operators(ops):
+    """rfx_add / sub / mul / div: binary_f over an i64 / f64 vector and a vector or atom (either order), the reference's promotion
+    and null rules (oracle binop, pinned on the reference's 48 truth tables)."""
+    n = 100_003
+    host = host_table(n)
+    host["a"][::97] = NULL
+    host["b"] = rfo.gen_i64(n, 9, 9) - 1
+    objs = {c: H.vector(host[c]) for c in ("a", "b", "v")}
+    for name, op in (("add", "+"), ("sub", "-"), ("mul", "*"), ("div", "div")):
+        for l, r in (("a", "b"), ("a", "v"), ("v", "a"), ("v", "v"), ("a", 7), (7, "a"), ("v", 2.5), (-1.5, "v"), ("a", 2.5), (3, "v")):
+            lo = objs[l] if isinstance(l, str) else H.atom(l)
+            ro = objs[r] if isinstance(r, str) else H.atom(r)
+            out = getattr(ops, f"rfx_{name}")(lo, ro)
+            assert not H.is_error(out), (name, l, r, H.error_text(out))
+            got = H.to_numpy(out)
+            want = rfo.binop(op, host[l] if isinstance(l, str) else l, host[r] if isinstance(r, str) else r)
+            assert got.dtype == want.dtype, (name, l, r)
+            if want.dtype == np.float64:
+                fin = np.isfinite(want)
+                assert np.array_equal(np.isnan(got), np.isnan(want)) and np.array_equal(got[np.isinf(want)], want[np.isinf(want)]), (name, l, r)
+                assert np.all(np.abs(got[fin] - want[fin]) <= 2.3e-16 * np.abs(want[fin])), (name, l, r)
+            else:
+                assert np.array_equal(got, want), (name, l, r)
+            ops.rfx_host_drop(out)
+            for o, x in ((lo, l), (ro, r)):
+                if not isinstance(x, str):
+                    ops.rfx_host_drop(o)
+    bad = ops.rfx_add(H.atom(1), H.atom(2))  # no vector: not this path's business, and no host to hand it to here
+    assert H.is_error(bad)
+    for o in list(objs.values()) + [bad]:
+        ops.rfx_host_drop(o)
+
+
 def test_lazy_mapfilter_aggregates(ops):
     """An FN_AGGR built-in receives the lazy TYPE_MAPFILTER pair (val, ids) (core/eval.c:723-728, core/filter.c:44-46): gathered and
     folded on the device."""
