@@ -275,28 +275,75 @@ typedef struct {
 } wplan_t;
 
 /* one comparison `(op colsym atom|colsym)` -> descriptor; 0 ok, -1 unsupported shape */
+/* device scratch a query's PREDICATES allocate (operands that are expressions): released at the end of rfx_select */
+static void *g_qtmp[2 * RFX_MAX_PREDS * 4];
+static int g_nqtmp;
+static void qtmp_release(void) {
+    for (int i = 0; i < g_nqtmp; i++) rfx_hip_free(g_ctx, g_qtmp[i]);
+    g_nqtmp = 0;
+}
+static int build_xnodes(obj_p tab, obj_p e, rfx_xnode_t *nodes, int *nn, int *ncols, const char **why);
+/* a comparison operand that is an element-wise expression (op x y): the reference evaluates it first (eval -> binop_map), so do
+ * we -- one pass into a scratch column (rfx_hip_eval_expr), then the comparison reads it like any column */
+static int expr_operand(obj_p tab, obj_p e, const void **d, int *ctype) {
+    rfx_xnode_t nodes[RFX_MAX_XNODES];
+    int nn = 0, ncols = 0;
+    const char *why = NULL;
+    int top = build_xnodes(tab, e, nodes, &nn, &ncols, &why);
+    if (top == -2) return -2;
+    if (top < 0 || ncols == 0 || g_nqtmp >= (int)(sizeof(g_qtmp) / sizeof(g_qtmp[0]))) return -1;
+    obj_p tcols = RFX_AS_LIST(tab)[1];
+    const int64_t nrows = tcols->len ? RFX_AS_LIST(tcols)[0]->len : 0;
+    rfx_agg_t a;
+    memset(&a, 0, sizeof(a));
+    a.kind = RFX_AGG_SUM;
+    a.col_type = RFX_I64;
+    a.nxnodes = nn;
+    a.xnodes = nodes;
+    void *out = NULL;
+    int32_t ot = RFX_I64;
+    if (rfx_hip_malloc(g_ctx, &out, (size_t)(nrows ? nrows : 1) * 8) != RFX_OK) return -2;
+    g_qtmp[g_nqtmp++] = out;
+    if (rfx_hip_eval_expr(g_ctx, &a, nrows, out, &ot) != RFX_OK) return -2;
+    *d = out;
+    *ctype = ot;
+    return 0;
+}
 static int plan_cmp(obj_p tab, obj_p e, rfx_pred_t *p) {
     if (e->type != RFX_TYPE_LIST || e->len != 3) return -1;
     int f = fn_id(RFX_AS_LIST(e)[0]);
     if (f < F_EQ || f > F_GE) return -1;
     obj_p l = RFX_AS_LIST(e)[1], r = RFX_AS_LIST(e)[2];
-    if (l->type != -RFX_TYPE_SYMBOL) return -1;
-    obj_p lc = table_col(tab, l->i64);
-    if (!lc || !col_ctype(lc)) return -1;
     memset(p, 0, sizeof(*p));
     p->op = f - F_EQ; /* F_EQ..F_GE are in RFX_EQ..RFX_GE order */
-    p->col_type = col_ctype(lc);
     const void *d;
-    if (resident(lc, 0, &d) != RFX_OK) return -2;
+    int64_t llen = -1;
+    if (l->type == RFX_TYPE_LIST) {
+        int ct = RFX_I64, rc0 = expr_operand(tab, l, &d, &ct);
+        if (rc0) return rc0;
+        p->col_type = ct;
+    } else {
+        if (l->type != -RFX_TYPE_SYMBOL) return -1;
+        obj_p lc = table_col(tab, l->i64);
+        if (!lc || !col_ctype(lc)) return -1;
+        p->col_type = col_ctype(lc);
+        if (resident(lc, 0, &d) != RFX_OK) return -2;
+        llen = lc->len;
+    }
     p->d_col = d;
     if (r->type == -RFX_TYPE_I64) { p->rhs_type = RFX_I64; p->rhs_i = r->i64; }
     else if (r->type == -RFX_TYPE_F64) { p->rhs_type = RFX_F64; p->rhs_f = r->f64; }
     else if (r->type == -RFX_TYPE_SYMBOL) {
         obj_p rc = table_col(tab, r->i64);
-        if (!rc || !col_ctype(rc) || rc->len != lc->len) return -1;
+        if (!rc || !col_ctype(rc) || (llen >= 0 && rc->len != llen)) return -1;
         if (resident(rc, 0, &d) != RFX_OK) return -2;
         p->d_rhs_col = d;
         p->rhs_type = col_ctype(rc);
+    } else if (r->type == RFX_TYPE_LIST) {
+        int ct = RFX_I64, rc0 = expr_operand(tab, r, &d, &ct);
+        if (rc0) return rc0;
+        p->d_rhs_col = d;
+        p->rhs_type = ct;
     } else return -1;
     return 0;
 }
@@ -834,6 +881,7 @@ out:
     res = delegate_select(dict, why ? why : "unsupported");
 done:
     for (int i = 0; i < ntmp; i++) rfx_hip_free(g_ctx, tmp[i]);
+    qtmp_release();
     H.drop(tab);
     return res;
 }

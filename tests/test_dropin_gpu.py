@@ -36,6 +36,10 @@ QUERIES = [
     # key tuple beyond the composite key (ranges multiply past 64 bits): the reference's row-hash path, answered by the plugin
     # from the reference's own row hash + the (min, max) proof pairs of the key columns
     ("q16", "{s: (sum v) c: (count a) from: t by: {w1: w1 w2: w2 k3: k3}}", ["w1", "w2", "k3", "s", "c"]),
+    # predicates over element-wise expressions: evaluated into a scratch column on the device, then compared
+    ("q17", "{s: (sum v) c: (count a) from: t where: (> (* a v) 250000.0)}", ["s", "c"]),
+    ("q18", "{s: (sum v) m: (max a) from: t where: (and (< (+ v v) 0.6) (> a 1000) (<= (- a (* k2 1000)) a)) by: k1}", ["k1", "s", "m"]),
+    ("q19", "{c: (count a) from: t where: (or (== (div a 1000) 7) (and (> (* v 2.0) 1.5) (!= k3 3)))}", ["c"]),
 ]
 
 

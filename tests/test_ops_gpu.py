@@ -198,6 +198,17 @@ def test_single_operators(ops):
         ops.rfx_host_drop(o)
 
 
+def test_select_predicates_over_expressions(ops):
+    host = host_table(200_003, keys=900)
+    host["b"] = rfo.gen_i64(200_003, 9, 9) - 1
+    q = {"s": ("sum", "v"), "c": ("count", "a"), "mx": ("max", ("*", "a", "v"))}
+    for w in ((">", ("*", "a", "v"), 250_000.0), ("<=", ("-", "a", ("*", "b", 100_000)), "a"), ("and", ("<", ("+", "v", "v"), 0.6), (">", "a", 1000)),
+              ("or", ("==", ("div", "a", 1000), 7), ("and", (">", ("*", "v", 2.0), 1.5), ("!=", "b", 3))), ("<", "v", ("*", "v", 3.0))):
+        for extra in ({}, {"by": "k"}):
+            check(run_select(ops, host, {**q, "where": w, **extra}), rfo.select({"from": host, **q, "where": w, **extra}))
+            assert ops.rfx_last_select_on_gpu() == 1
+
+
 def test_arithmetic_operators(ops):
     """rfx_add / sub / mul / div: binary_f over an i64 / f64 vector and a vector or atom (either order), the reference's promotion
     and null rules (oracle binop, pinned on the reference's 48 truth tables)."""
