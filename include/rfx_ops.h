@@ -26,6 +26,8 @@
  *   rfx_min rfx_max        ray_min ray_max       core/math.c:2428-2429           unary_f
  *   rfx_count rfx_first    ray_count ray_first   core/misc.c:43-60, core/items.c unary_f
  *   rfx_at                 at_ids via ray_at     core/rayforce.c:1100-1158       binary_f  (column, I64 ids) -> gathered column
+ *   rfx_left_join          ray_left_join         core/join.c:158-198             vary_f    (key symbols, left table, right table)
+ *   rfx_inner_join         ray_inner_join        core/join.c:200-298             vary_f
  *   rfx_add rfx_sub        ray_add ray_sub       core/math.c:2280-2345 (binop_map)   binary_f  vector (x) vector | atom -> vector
  *   rfx_mul rfx_div        ray_mul ray_fdiv (`div`)                                  binary_f  (i64 / f64, the reference's promotion)
  *
@@ -70,6 +72,9 @@ rfx_obj_p rfx_add(rfx_obj_p x, rfx_obj_p y);
 rfx_obj_p rfx_sub(rfx_obj_p x, rfx_obj_p y);
 rfx_obj_p rfx_mul(rfx_obj_p x, rfx_obj_p y);
 rfx_obj_p rfx_div(rfx_obj_p x, rfx_obj_p y);
+
+rfx_obj_p rfx_left_join(rfx_obj_p *x, int64_t n);  /* (keys symbol vector, left table, right table) */
+rfx_obj_p rfx_inner_join(rfx_obj_p *x, int64_t n);
 
 rfx_obj_p rfx_and(rfx_obj_p *x, int64_t n);
 rfx_obj_p rfx_or(rfx_obj_p *x, int64_t n);

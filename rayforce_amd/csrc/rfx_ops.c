@@ -43,9 +43,10 @@ static struct {
     /* the host's own built-ins, for recognising function objects inside parsed expressions and for delegation */
     void *f[32];
 } H;
-enum { F_SUM, F_AVG, F_MIN, F_MAX, F_COUNT, F_FIRST, F_EQ, F_NE, F_LT, F_GT, F_LE, F_GE, F_AND, F_OR, F_SELECT, F_ADD, F_SUB, F_MUL, F_FDIV, F_XBAR, F_N };
+enum { F_SUM, F_AVG, F_MIN, F_MAX, F_COUNT, F_FIRST, F_EQ, F_NE, F_LT, F_GT, F_LE, F_GE, F_AND, F_OR, F_SELECT, F_ADD, F_SUB, F_MUL, F_FDIV, F_XBAR, F_LJ, F_IJ, F_N };
 static const char *HOST_FN[F_N] = {"ray_sum", "ray_avg", "ray_min", "ray_max", "ray_count", "ray_first", "ray_eq",  "ray_ne",  "ray_lt",  "ray_gt",
-                                   "ray_le",  "ray_ge",  "ray_and", "ray_or",  "ray_select", "ray_add",  "ray_sub", "ray_mul", "ray_fdiv", "ray_xbar"};
+                                   "ray_le",  "ray_ge",  "ray_and", "ray_or",  "ray_select", "ray_add",  "ray_sub", "ray_mul", "ray_fdiv", "ray_xbar",
+                                   "ray_left_join", "ray_inner_join"};
 /* + - * div are recognised inside aggregate arguments only; as stand-alone operators they are the host's.  The
  * standalone object model still needs distinct function objects for them: these stubs are never called by this library. */
 static obj_p x_stub_add(obj_p a, obj_p b) { (void)a; (void)b; return NULL; }
@@ -1013,6 +1014,188 @@ rfx_obj_p rfx_where(rfx_obj_p mask) {
     if (!ok) { H.drop(out); return fail_hip("where"); }
     return out;
 }
+
+/* ------------------------------------------------------------------------------------------------ equi-joins
+ * (left-join [keys] x y) / (inner-join [keys] x y): ray_left_join / ray_inner_join, core/join.c:158-298 -- vary_f over (key symbols,
+ * left table, right table).  Index = per left row the first right row with an equal key tuple (index_left_join_obj,
+ * core/index.c:2886-2928): the group-by's first-occurrence table over the right keys (zero aggregates), probed with the left keys. */
+static obj_p join_op(int inner, obj_p *x, int64_t n) {
+    rfx_host_bind();
+    const int fidx = inner ? F_IJ : F_LJ;
+    if (n != 3 || !x[0] || !x[1] || !x[2]) return fail("join: expected (keys, left table, right table)");
+    if (x[0]->type != RFX_TYPE_SYMBOL || x[1]->type != RFX_TYPE_TABLE || x[2]->type != RFX_TYPE_TABLE) return fail("join: expected (symbol vector, table, table)");
+    obj_p ksyms = x[0], lt = x[1], rt = x[2];
+    obj_p lnames = RFX_AS_LIST(lt)[0], lcols = RFX_AS_LIST(lt)[1], rnames = RFX_AS_LIST(rt)[0], rcols = RFX_AS_LIST(rt)[1];
+    const int64_t nl = lcols->len ? RFX_AS_LIST(lcols)[0]->len : 0, nr = rcols->len ? RFX_AS_LIST(rcols)[0]->len : 0;
+    const int nk = (int)ksyms->len;
+    const char *why = NULL;
+    void *tmp[4 * RFX_MAX_KEYS + 8];
+    int ntmp = 0;
+    obj_p res = NULL;
+    if (nl == 0 || nr == 0) return H.clone(lt); /* core/join.c:171-172 */
+    if (nk < 1 || nk > RFX_MAX_KEYS) { why = "1..8 key columns"; goto out; }
+    obj_p lk[RFX_MAX_KEYS], rk[RFX_MAX_KEYS];
+    const void *dlk[RFX_MAX_KEYS], *drk[RFX_MAX_KEYS];
+    for (int i = 0; i < nk; i++) {
+        lk[i] = table_col(lt, RFX_AS_I64(ksyms)[i]);
+        rk[i] = table_col(rt, RFX_AS_I64(ksyms)[i]);
+        if (!lk[i] || !rk[i] || col_ctype(lk[i]) != RFX_I64 || col_ctype(rk[i]) != RFX_I64 || lk[i]->type != rk[i]->type) { why = "join key is not an 8-byte integer column of both tables"; goto out; }
+    }
+    for (int64_t i = 0; i < lcols->len; i++) if (!col_ctype(RFX_AS_LIST(lcols)[i])) { why = "non-8-byte column"; goto out; }
+    for (int64_t i = 0; i < rcols->len; i++) {
+        obj_p rc = RFX_AS_LIST(rcols)[i], lc = table_col(lt, RFX_AS_I64(rnames)[i]);
+        if (!col_ctype(rc)) { why = "non-8-byte column"; goto out; }
+        if (lc && lc->type != rc->type) return fail("join: a column has different types in the two tables"); /* err_type, core/join.c:50-51 */
+    }
+    if (ensure_ctx() != RFX_OK) return fail_hip("no usable MI355X");
+    for (int i = 0; i < nk; i++)
+        if (resident(lk[i], 0, &dlk[i]) != RFX_OK || resident(rk[i], 0, &drk[i]) != RFX_OK) { res = fail_hip("column upload"); goto done; }
+#define JOIN_TMP(ptr, bytes) do { ptr = NULL; if (rfx_hip_malloc(g_ctx, &ptr, (bytes)) != RFX_OK) { res = fail_hip("join scratch"); goto done; } tmp[ntmp++] = ptr; } while (0)
+    const void *lkey = dlk[0], *rkey = drk[0];
+    int exact = 1;
+    if (nk > 1) {
+        int64_t mins[RFX_MAX_KEYS], maxs[RFX_MAX_KEYS], mults[RFX_MAX_KEYS], tmax = 0, seen = 0;
+        for (int i = 0; i < nk; i++) { /* scopes over BOTH sides: one injective composite key per side when they multiply into 64 bits */
+            int64_t a0, a1, b0, b1;
+            if (rfx_hip_scope_i64(g_ctx, (const int64_t *)dlk[i], NULL, 0, RFX_AND, nl, &a0, &a1, &seen) != RFX_OK ||
+                rfx_hip_scope_i64(g_ctx, (const int64_t *)drk[i], NULL, 0, RFX_AND, nr, &b0, &b1, &seen) != RFX_OK) { res = fail_hip("scope"); goto done; }
+            mins[i] = a0 < b0 ? a0 : b0;
+            maxs[i] = a1 > b1 ? a1 : b1;
+        }
+        void *lc = NULL, *rc = NULL;
+        JOIN_TMP(lc, (size_t)nl * 8);
+        JOIN_TMP(rc, (size_t)nr * 8);
+        if (rfx_composite_plan(mins, maxs, nk, mults, &tmax) == RFX_OK) {
+            if (rfx_hip_composite_key(g_ctx, dlk, mins, mults, nk, nl, (int64_t *)lc) != RFX_OK || rfx_hip_composite_key(g_ctx, drk, mins, mults, nk, nr, (int64_t *)rc) != RFX_OK) { res = fail_hip("composite key"); goto done; }
+        } else { /* the reference's own route: its row hash; matched rows are compared column by column below */
+            if (rfx_hip_row_hash(g_ctx, dlk, nk, nl, 0, (int64_t *)lc) != RFX_OK || rfx_hip_row_hash(g_ctx, drk, nk, nr, 0, (int64_t *)rc) != RFX_OK) { res = fail_hip("row hash"); goto done; }
+            exact = 0;
+        }
+        lkey = lc;
+        rkey = rc;
+    }
+    void *ids = NULL;
+    JOIN_TMP(ids, (size_t)nl * 8);
+    {
+        int64_t kmin, kmax, seen = 0;
+        if (rfx_hip_scope_i64(g_ctx, (const int64_t *)rkey, NULL, 0, RFX_AND, nr, &kmin, &kmax, &seen) != RFX_OK) { res = fail_hip("scope"); goto done; }
+        const uint64_t range = (uint64_t)kmax - (uint64_t)kmin + 1;
+        rfx_agg_t none;
+        memset(&none, 0, sizeof(none));
+        uint64_t lim = 4 * (uint64_t)nr > (1u << 24) ? 4 * (uint64_t)nr : (1u << 24);
+        if (range != 0 && range <= lim && range <= (1ull << 29) && kmin != RFX_NULL_I64) {
+            void *first = NULL;
+            JOIN_TMP(first, (size_t)range * 8);
+            rfx_group_tables_t gt;
+            memset(&gt, 0, sizeof(gt));
+            gt.kmin = kmin; gt.range = (int64_t)range; gt.nagg = 0; gt.d_first = (int64_t *)first;
+            if (rfx_hip_group_tables_init(g_ctx, &none, &gt) != RFX_OK || rfx_hip_group_dense_accumulate(g_ctx, (const int64_t *)rkey, NULL, 0, RFX_AND, &none, nr, 0, &gt) != RFX_OK ||
+                rfx_hip_join_probe_dense(g_ctx, (const int64_t *)lkey, nl, kmin, (int64_t)range, (const int64_t *)first, (int64_t *)ids) != RFX_OK) { res = fail_hip("join index"); goto done; }
+        } else {
+            int64_t cap_max = 16, cap;
+            while (cap_max < 2 * nr) cap_max <<= 1;
+            cap = cap_max < (1 << 22) ? cap_max : (1 << 22);
+            for (;;) {
+                void *store = NULL;
+                if (rfx_hip_malloc(g_ctx, &store, (size_t)2 * (size_t)(cap + 1) * 8) != RFX_OK) { res = fail_hip("join table"); goto done; }
+                rfx_hash_tables_t ht;
+                memset(&ht, 0, sizeof(ht));
+                ht.capacity = cap; ht.nagg = 0; ht.d_keys = (int64_t *)store; ht.d_first = (int64_t *)store + (cap + 1);
+                int arc = RFX_EINVAL;
+                int ok = rfx_hip_hash_tables_init(g_ctx, &none, &ht) == RFX_OK &&
+                         (arc = rfx_hip_group_hash_accumulate(g_ctx, (const int64_t *)rkey, NULL, 0, RFX_AND, &none, nr, 0, &ht)) == RFX_OK &&
+                         rfx_hip_join_probe_hash(g_ctx, (const int64_t *)lkey, nl, &ht, (int64_t *)ids) == RFX_OK;
+                if (ok) ok = rfx_hip_ctx_sync(g_ctx) == RFX_OK; /* the probe has read the table before it is freed */
+                rfx_hip_free(g_ctx, store);
+                if (ok) break;
+                if (arc == RFX_ELIMIT && cap < cap_max) { cap = (cap << 4) < cap_max ? (cap << 4) : cap_max; continue; }
+                res = fail_hip("join index");
+                goto done;
+            }
+        }
+    }
+    if (!exact) { /* __index_list_cmp_row, once on the result: every matched row must agree on every key column */
+        void *chk = NULL;
+        JOIN_TMP(chk, (size_t)nl * 8);
+        for (int i = 0; i < nk; i++) {
+            rfx_pred_t p;
+            memset(&p, 0, sizeof(p));
+            p.d_col = chk; p.col_type = RFX_I64; p.op = RFX_NE; p.d_rhs_col = dlk[i]; p.rhs_type = RFX_I64;
+            rfx_value_t dummy[1];
+            int64_t differ = 0;
+            if (rfx_hip_gather_or(g_ctx, drk[i], dlk[i], (const int64_t *)ids, nl, 0, chk) != RFX_OK ||
+                rfx_hip_filter_aggr_host(g_ctx, &p, 1, RFX_AND, NULL, 0, nl, dummy, &differ) != RFX_OK) { res = fail_hip("join check"); goto done; }
+            if (differ) { why = "row-hash collision between two key tuples"; goto out; }
+        }
+    }
+    /* result columns: keys, then the other left columns, then the right-only ones (ray_union / ray_except order, core/join.c:83-156) */
+    {
+        int64_t names[64];
+        int ncol = 0;
+        for (int i = 0; i < nk; i++) names[ncol++] = RFX_AS_I64(ksyms)[i];
+        for (int pass = 0; pass < 2; pass++) {
+            obj_p nm = pass ? rnames : lnames;
+            for (int64_t i = 0; i < nm->len && ncol < 64; i++) {
+                int64_t sy = RFX_AS_I64(nm)[i];
+                int dup = 0;
+                for (int j = 0; j < ncol; j++) dup |= names[j] == sy;
+                if (!dup) names[ncol++] = sy;
+            }
+        }
+        if (ncol >= 64) { why = "too many columns"; goto out; }
+        void *lids = NULL, *rids = NULL, *dcol = NULL;
+        int64_t nout = nl;
+        if (inner) { /* matched left rows in order, paired with their right rows (index_inner_join_obj) */
+            rfx_pred_t p;
+            memset(&p, 0, sizeof(p));
+            p.d_col = ids; p.col_type = RFX_I64; p.op = RFX_NE; p.rhs_type = RFX_I64; p.rhs_i = RFX_NULL_I64;
+            if (rfx_hip_where_begin(g_ctx, &p, 1, RFX_AND, NULL, nl, &nout) != RFX_OK) { res = fail_hip("join where"); goto done; }
+            JOIN_TMP(lids, (size_t)(nout ? nout : 1) * 8);
+            JOIN_TMP(rids, (size_t)(nout ? nout : 1) * 8);
+            if (rfx_hip_where_emit(g_ctx, 0, (int64_t *)lids) != RFX_OK || (nout && rfx_hip_gather(g_ctx, ids, (const int64_t *)lids, nout, rids) != RFX_OK)) { res = fail_hip("join where"); goto done; }
+        }
+        JOIN_TMP(dcol, (size_t)(nout ? nout : 1) * 8);
+        obj_p rk_ = H.vector(RFX_TYPE_SYMBOL, ncol), rv = H.vector(RFX_TYPE_LIST, ncol);
+        int ok = 1;
+        for (int c = 0; c < ncol; c++) {
+            RFX_AS_I64(rk_)[c] = names[c];
+            obj_p lc = table_col(lt, names[c]), rc = table_col(rt, names[c]);
+            const int iskey = c < nk;
+            obj_p o = NULL;
+            if (!inner && (iskey || !rc)) o = H.clone(lc); /* left join: key columns and left-only columns are the left table's own */
+            else {
+                obj_p src = (inner ? (rc ? rc : lc) : rc);
+                o = H.vector(src->type, nout);
+                const void *dsrc, *dleft = NULL;
+                ok = ok && resident(src, 0, &dsrc) == RFX_OK;
+                if (ok && !inner && lc) ok = resident(lc, 0, &dleft) == RFX_OK;
+                if (ok && nout) {
+                    if (inner) ok = rfx_hip_gather(g_ctx, dsrc, (const int64_t *)(rc ? rids : lids), nout, dcol) == RFX_OK;
+                    else ok = rfx_hip_gather_or(g_ctx, dsrc, dleft, (const int64_t *)ids, nout, col_ctype(src) == RFX_F64 ? 0x7FF8000000000000ull : 0x8000000000000000ull, dcol) == RFX_OK;
+                    ok = ok && rfx_hip_d2h(g_ctx, RFX_AS_RAW(o), dcol, (size_t)nout * 8) == RFX_OK;
+                }
+            }
+            RFX_AS_LIST(rv)[c] = o;
+        }
+        if (!ok) { H.drop(rk_); H.drop(rv); res = fail_hip("join columns"); goto done; }
+        res = H.table(rk_, rv);
+        g_last_gpu = 1;
+        goto done;
+    }
+out:
+    if (H.bound == 1 && H.f[fidx]) res = ((rfx_vary_f)H.f[fidx])(x, n);
+    else {
+        char b[320];
+        snprintf(b, sizeof(b), "join: shape not covered by the MI355X path (%s) and no host function to delegate to", why ? why : "unsupported");
+        res = fail(b);
+    }
+done:
+    for (int i = 0; i < ntmp; i++) rfx_hip_free(g_ctx, tmp[i]);
+    return res;
+#undef JOIN_TMP
+}
+rfx_obj_p rfx_left_join(rfx_obj_p *x, int64_t n) { return join_op(0, x, n); }
+rfx_obj_p rfx_inner_join(rfx_obj_p *x, int64_t n) { return join_op(1, x, n); }
 
 rfx_obj_p rfx_at(rfx_obj_p col, rfx_obj_p ids) {
     rfx_host_bind();

@@ -24,6 +24,8 @@ OPS_PROTOTYPES = {
     **{f"rfx_{n}": (C.c_void_p, [C.c_void_p, C.c_void_p]) for n in ("eq", "ne", "lt", "gt", "le", "ge", "at", "add", "sub", "mul", "div")},
     "rfx_and": (C.c_void_p, [C.POINTER(C.c_void_p), C.c_int64]),
     "rfx_or": (C.c_void_p, [C.POINTER(C.c_void_p), C.c_int64]),
+    "rfx_left_join": (C.c_void_p, [C.POINTER(C.c_void_p), C.c_int64]),
+    "rfx_inner_join": (C.c_void_p, [C.POINTER(C.c_void_p), C.c_int64]),
     **{f"rfx_{n}": (C.c_void_p, [C.c_void_p]) for n in ("where", "sum", "avg", "min", "max", "count", "first", "pin", "unpin")},
     "rfx_cache_clear": (None, []),
     "rfx_cache_bytes": (C.c_int64, []),

@@ -76,6 +76,26 @@ def test_plugin_inside_the_real_reference(built):
         s.eval("(set r_del (select {c: (count a) from: t by: v}))")
         s.out("g_del_n", "(enlist (count (at g_del 'c)))")
         s.out("r_del_n", "(enlist (count (at r_del 'c)))")
+        # joins: the plugin's vary_f entry points beside the reference's own left-join / inner-join (typed columns compared: the
+        # reference returns a left join's right-only columns as generic lists holding Null objects)
+        s.put("y_k", rfo.gen_i64(4000, 61, 6000))
+        s.put("y_k1", rfo.gen_i64(4000, 62, 7))
+        s.put("y_v", rfo.gen_f64(4000, 63) + 10.0)
+        s.put("y_z", rfo.gen_i64(4000, 64, 1000))
+        s.eval("(set y (table [k k1 v z] (list y_k y_k1 y_v y_z)))")
+        s.eval(f'(set glj (loadfn "{LIB}" "rfx_left_join" 3))')
+        s.eval(f'(set gij (loadfn "{LIB}" "rfx_inner_join" 3))')
+        for tag, kk in (("j1", "[k]"), ("j2", "[k k1]")):
+            s.eval(f"(set g_{tag}l (glj {kk} t y))")
+            s.eval(f"(set r_{tag}l (left-join {kk} t y))")
+            s.eval(f"(set g_{tag}i (gij {kk} t y))")
+            s.eval(f"(set r_{tag}i (inner-join {kk} t y))")
+            for o in ("k", "k1", "a", "v"):
+                s.out(f"g_{tag}l_{o}", f"(at g_{tag}l '{o})")
+                s.out(f"r_{tag}l_{o}", f"(at r_{tag}l '{o})")
+            for o in ("k", "k1", "a", "v", "z"):
+                s.out(f"g_{tag}i_{o}", f"(at g_{tag}i '{o})")
+                s.out(f"r_{tag}i_{o}", f"(at r_{tag}i '{o})")
         # -c 8: the reference's page-aligned chunking (core/pool.c:495-507) overshoots small inputs when the pool is large
         # (it segfaults on this 300k-row table with 64+ executors, with or without the plugin) -- keep its pool small here
         res = s.run(threads=8)
@@ -93,6 +113,11 @@ def test_plugin_inside_the_real_reference(built):
                 assert np.allclose(g, r, rtol=1e-9, atol=0), (name, o)
             else:
                 assert np.array_equal(g, r), (name, o)
+    for tag in ("j1", "j2"):
+        for kind, outs in (("l", ("k", "k1", "a", "v")), ("i", ("k", "k1", "a", "v", "z"))):
+            for o in outs:
+                g, r = res[f"g_{tag}{kind}_{o}"], res[f"r_{tag}{kind}_{o}"]
+                assert g.dtype == r.dtype and np.array_equal(g.view(np.int64), r.view(np.int64)), (tag, kind, o)
     assert np.array_equal(res["g_proj_a"], cols["a"][cols["a"] < 1000])
     assert np.array_equal(res["g_nest_s"], res["r_nest_s"])
     assert np.array_equal(res["g_del_n"], res["r_del_n"])

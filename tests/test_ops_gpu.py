@@ -209,6 +209,36 @@ def test_select_predicates_over_expressions(ops):
             assert ops.rfx_last_select_on_gpu() == 1
 
 
+def test_join_operators(ops):
+    """rfx_left_join / rfx_inner_join: vary_f over (key symbols, left table, right table) with the reference's column rules; one
+    key (dense and hashed tables), two keys (composite key), wide / null key tuples (row hash + column-by-column check)."""
+    import golden_cases as G
+    for case in G.join_cases():
+        name, keys, left, right, want_lj, want_ij = case
+        lt, rt, ks = H.table(left), H.table(right), H.symbols(keys)
+        args = (C.c_void_p * 3)(ks, lt, rt)
+        for fn, ora, want in (("rfx_left_join", rfo.left_join, want_lj), ("rfx_inner_join", rfo.inner_join, want_ij)):
+            out = getattr(ops, fn)(args, 3)
+            assert not H.is_error(out), (name, fn, H.error_text(out))
+            got, o = H.table_to_numpy(out), ora(keys, left, right)
+            assert list(got) == list(o), (name, fn)
+            for c in o:
+                assert got[c].dtype == o[c].dtype and np.array_equal(got[c].view(np.int64), o[c].view(np.int64)), (name, fn, c)  # bit-exact, NaN fill included
+            for c in want:  # the reference's own answers where it gives typed columns
+                G.same(got[c], want[c], f"{name} {fn} {c}")
+            ops.rfx_host_drop(out)
+        for o in (lt, rt, ks):
+            ops.rfx_host_drop(o)
+    # empty right side -> the left table; a non-table argument -> error object
+    lt, rt, ks = H.table({"k": np.arange(5, dtype=np.int64), "v": np.arange(5, dtype=np.float64)}), H.table({"k": np.empty(0, np.int64), "w": np.empty(0, np.float64)}), H.symbols(["k"])
+    out = ops.rfx_left_join((C.c_void_p * 3)(ks, lt, rt), 3)
+    assert list(H.table_to_numpy(out)) == ["k", "v"]
+    bad = ops.rfx_inner_join((C.c_void_p * 3)(ks, ks, rt), 3)
+    assert H.is_error(bad)
+    for o in (out, bad, lt, rt, ks):
+        ops.rfx_host_drop(o)
+
+
 def test_arithmetic_operators(ops):
     """rfx_add / sub / mul / div: binary_f over an i64 / f64 vector and a vector or atom (either order), the reference's promotion
     and null rules (oracle binop, pinned on the reference's 48 truth tables)."""
