@@ -47,12 +47,8 @@ enum { F_SUM, F_AVG, F_MIN, F_MAX, F_COUNT, F_FIRST, F_EQ, F_NE, F_LT, F_GT, F_L
 static const char *HOST_FN[F_N] = {"ray_sum", "ray_avg", "ray_min", "ray_max", "ray_count", "ray_first", "ray_eq",  "ray_ne",  "ray_lt",  "ray_gt",
                                    "ray_le",  "ray_ge",  "ray_and", "ray_or",  "ray_select", "ray_add",  "ray_sub", "ray_mul", "ray_fdiv", "ray_xbar",
                                    "ray_left_join", "ray_inner_join"};
-/* + - * div are recognised inside aggregate arguments only; as stand-alone operators they are the host's.  The
- * standalone object model still needs distinct function objects for them: these stubs are never called by this library. */
-static obj_p x_stub_add(obj_p a, obj_p b) { (void)a; (void)b; return NULL; }
-static obj_p x_stub_sub(obj_p a, obj_p b) { (void)a; (void)b; return NULL; }
-static obj_p x_stub_mul(obj_p a, obj_p b) { (void)a; (void)b; return NULL; }
-static obj_p x_stub_fdiv(obj_p a, obj_p b) { (void)a; (void)b; return NULL; }
+/* xbar is recognised inside `by:` only; the standalone object model still needs a distinct function object for it:
+ * this stub is never called by this library. */
 static obj_p x_stub_xbar(obj_p a, obj_p b) { (void)a; (void)b; return NULL; }
 static void *OUR_FN[F_N];
 static char g_err[640];
@@ -67,7 +63,8 @@ int rfx_host_bind(void) {
     OUR_FN[F_COUNT] = (void *)rfx_count; OUR_FN[F_FIRST] = (void *)rfx_first; OUR_FN[F_EQ] = (void *)rfx_eq; OUR_FN[F_NE] = (void *)rfx_ne;
     OUR_FN[F_LT] = (void *)rfx_lt; OUR_FN[F_GT] = (void *)rfx_gt; OUR_FN[F_LE] = (void *)rfx_le; OUR_FN[F_GE] = (void *)rfx_ge;
     OUR_FN[F_AND] = (void *)rfx_and; OUR_FN[F_OR] = (void *)rfx_or; OUR_FN[F_SELECT] = (void *)rfx_select;
-    OUR_FN[F_ADD] = (void *)x_stub_add; OUR_FN[F_SUB] = (void *)x_stub_sub; OUR_FN[F_MUL] = (void *)x_stub_mul; OUR_FN[F_FDIV] = (void *)x_stub_fdiv; OUR_FN[F_XBAR] = (void *)x_stub_xbar;
+    OUR_FN[F_ADD] = (void *)rfx_add; OUR_FN[F_SUB] = (void *)rfx_sub; OUR_FN[F_MUL] = (void *)rfx_mul; OUR_FN[F_FDIV] = (void *)rfx_div; OUR_FN[F_XBAR] = (void *)x_stub_xbar;
+    OUR_FN[F_LJ] = (void *)rfx_left_join; OUR_FN[F_IJ] = (void *)rfx_inner_join;
     void *v = dlsym(RTLD_DEFAULT, "vector"), *t = dlsym(RTLD_DEFAULT, "table"), *e = dlsym(RTLD_DEFAULT, "eval");
     void *rs = dlsym(RTLD_DEFAULT, "ray_select"), *nu = dlsym(RTLD_DEFAULT, "__NULL_OBJ");
     if (v && t && e && rs && nu && !getenv("RFX_FORCE_STANDALONE")) {
