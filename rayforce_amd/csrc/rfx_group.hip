@@ -107,7 +107,8 @@ __global__ __launch_bounds__(BLOCK) void k_group_dense(const Plan P, const Group
         if (m == 0) continue;
         u64 key[E]; // slot in the dense table
         if (G.nkeys <= 1) {
-            sel_col<NC, E>(key, v, G.key_idx);
+            if (TINY) sel_col_sw<NC, E>(key, v, G.key_idx);
+            else sel_col<NC, E>(key, v, G.key_idx);
 #pragma unroll
             for (int e = 0; e < E; e++) key[e] -= (u64)G.kmin;
         } else {
@@ -115,7 +116,8 @@ __global__ __launch_bounds__(BLOCK) void k_group_dense(const Plan P, const Group
             for (int e = 0; e < E; e++) key[e] = 0;
             for (int i = 0; i < G.nkeys; i++) {
                 u64 x[E];
-                sel_col<NC, E>(x, v, G.kidx[i]);
+                if (TINY) sel_col_sw<NC, E>(x, v, G.kidx[i]);
+                else sel_col<NC, E>(x, v, G.kidx[i]);
                 const u64 mn = G.kmn[i], mu = G.kmul[i];
 #pragma unroll
                 for (int e = 0; e < E; e++) key[e] += (x[e] - mn) * mu;
@@ -143,9 +145,12 @@ __global__ __launch_bounds__(BLOCK) void k_group_dense(const Plan P, const Group
             const bool hc = agg_has_cnt(ag.kind, ag.f64);
             u64 x[E];
             if (ag.col >= RFX_XCOL) { // expression folded on the fly
-                if (DEEP) expr_input_deep<NC, E>(x, v, P.xs[ag.col - RFX_XCOL]);
+                if (DEEP) expr_input_deep_sw<NC, E>(x, v, P.xs[ag.col - RFX_XCOL]);
                 else expr_input<NC, E>(x, v, P.xs[ag.col - RFX_XCOL]);
-            } else if (ag.col >= 0) sel_col<NC, E>(x, v, ag.col);
+            } else if (ag.col >= 0) {
+                if (TINY) sel_col_sw<NC, E>(x, v, ag.col);
+                else sel_col<NC, E>(x, v, ag.col);
+            }
 #pragma unroll
             for (int e = 0; e < E; e++) {
                 if (!((m >> e) & 1u)) continue;

@@ -136,6 +136,60 @@ __device__ __forceinline__ void expr_input_deep(u64 (&x)[E], const u64 (&v)[NC][
 }
 
 
+// The same selections through a wave-uniform SWITCH (one scalar branch, then plain moves from the statically indexed column)
+// instead of a compare-and-select chain over all NC columns (NC x E x 2 v_cndmask per selection): for wide plans -- 7 columns,
+// a dozen selections per tile -- the chains were a quarter of the group kernel's instructions.  Used by k_group_dense's TINY form.
+template <int NC, int E>
+__device__ __forceinline__ void sel_col_sw(u64 (&x)[E], const u64 (&v)[NC][E], int col) {
+#define RFX_SEL_CASE(c)                                  \
+    case c:                                              \
+        if (c < NC) {                                    \
+            _Pragma("unroll") for (int e = 0; e < E; e++) x[e] = v[c < NC ? c : 0][e]; \
+        }                                                \
+        break;
+    switch (col) {
+        RFX_SEL_CASE(0) RFX_SEL_CASE(1) RFX_SEL_CASE(2) RFX_SEL_CASE(3) RFX_SEL_CASE(4) RFX_SEL_CASE(5) RFX_SEL_CASE(6) RFX_SEL_CASE(7)
+        default: break;
+    }
+#undef RFX_SEL_CASE
+}
+template <int NC, int E>
+__device__ __forceinline__ void expr_input_deep_sw(u64 (&x)[E], const u64 (&v)[NC][E], const PlanExpr &X) {
+    u64 res[RFX_MAX_XNODES - 1][E];
+#pragma unroll
+    for (int i = 0; i < RFX_MAX_XNODES - 1; i++) {
+#pragma unroll
+        for (int e = 0; e < E; e++) res[i][e] = 0;
+    }
+#pragma unroll
+    for (int i = 0; i < RFX_MAX_XNODES; i++) {
+        if (i >= X.nops) break; // wave-uniform
+        const PlanXNode n = X.ops[i];
+        u64 l[E], r[E];
+#pragma unroll
+        for (int side = 0; side < 2; side++) {
+            u64(&o)[E] = side ? r : l;
+            const int kind = side ? n.r_kind : n.l_kind, idx = side ? n.r_idx : n.l_idx;
+            const u64 atom = side ? n.r_atom : n.l_atom;
+            if (kind == RFX_XK_COL) sel_col_sw<NC, E>(o, v, idx);
+            else if (kind == RFX_XK_ATOM) {
+#pragma unroll
+                for (int e = 0; e < E; e++) o[e] = atom;
+            } else { // an earlier result: i static, idx < i
+#pragma unroll
+                for (int e = 0; e < E; e++) o[e] = (idx == 0) ? res[0][e] : ((idx == 1) ? res[1][e] : res[2][e]);
+            }
+        }
+        if (i == X.nops - 1) {
+#pragma unroll
+            for (int e = 0; e < E; e++) x[e] = rfx_expr_eval(n.op, n.o_f64, n.l_f64, n.r_f64, l[e], r[e]);
+        } else if (i < RFX_MAX_XNODES - 1) {
+#pragma unroll
+            for (int e = 0; e < E; e++) res[i][e] = rfx_expr_eval(n.op, n.o_f64, n.l_f64, n.r_f64, l[e], r[e]);
+        }
+    }
+}
+
 // Predicate / aggregate descriptors copied out of the kernarg segment ONCE per kernel into SGPRs (indexing the by-value
 // Plan with a runtime loop counter inside the tile loop makes every field a dependent s_load + s_waitcnt per tile).
 //
