@@ -39,7 +39,7 @@ struct GroupArgs {
 //  * the tables are replicated 2^rep_shift times, replica = low bits of the lane id: with two to four groups all 64 lanes of
 //    a ds_add hit the same addresses and the LDS serialises them; with lane-private replicas every lane of an instruction has
 //    its own cell and bank.  Replicas are folded before the merge.
-template <int NC, bool LDS, int BLOCK, bool TINY = false>
+template <int NC, bool LDS, int BLOCK, bool TINY = false, int NPT = RFX_MAX_PREDS>
 __global__ __launch_bounds__(BLOCK) void k_group_dense(const Plan P, const GroupArgs G) {
     constexpr bool DEEP = TINY;
     constexpr int U = (NC <= 2) ? 4 : (NC <= 4 ? 2 : 1);
@@ -49,8 +49,8 @@ __global__ __launch_bounds__(BLOCK) void k_group_dense(const Plan P, const Group
     extern __shared__ __attribute__((aligned(16))) u64 smem[];
     const int tid = threadIdx.x;
     const i64 range = G.range;
-    PredSet<RFX_MAX_PREDS> S;
-    predset_load<RFX_MAX_PREDS>(P, S);
+    PredSet<NPT> S; // (the TINY form is instantiated for 0 / <= 2 / <= 8 predicates: 8 descriptor sets in SGPRs cost it 10 ms per 1e9 rows)
+    predset_load<NPT>(P, S);
 
     // LDS layout (compact: more groups fit): [acc arrays: u64 x range each] [first: u32 x range, local row, 0xffffffff = none]
     // [count arrays: u32 x range each].  Local rows and per-workgroup counts fit 32 bits because nrows < 2^32 on this path.
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(BLOCK) void k_group_dense(const Plan P, const Group
                 for (int c = 0; c < NC; c++) v[c][e] = in ? P.cols[c][row] : 0ULL;
             }
         }
-        const unsigned m = eval_preds<NC, E, RFX_MAX_PREDS>(S, v, valid);
+        const unsigned m = eval_preds<NC, E, NPT>(S, v, valid);
         if (m == 0) continue;
         u64 key[E]; // slot in the dense table
         if (G.nkeys <= 1) {
@@ -257,7 +257,9 @@ extern "C" int rfx_hip_group_tables_init(rfx_ctx_t *c, const rfx_agg_t *aggs, co
 template <int NC>
 static int launch_group(rfx_ctx *c, const Plan &P, const GroupArgs &G, int grid, size_t lds_bytes, bool deep) {
     if (deep) { // TINY form (group_dense_run decides): 256 lanes, table replicas within the 64 KB LDS budget
-        hipLaunchKernelGGL((k_group_dense<NC, true, RFX_BLOCK, true>), dim3(grid), dim3(RFX_BLOCK), lds_bytes, c->stream, P, G);
+        if (P.npred == 0) hipLaunchKernelGGL((k_group_dense<NC, true, RFX_BLOCK, true, 0>), dim3(grid), dim3(RFX_BLOCK), lds_bytes, c->stream, P, G);
+        else if (P.npred <= 2) hipLaunchKernelGGL((k_group_dense<NC, true, RFX_BLOCK, true, 2>), dim3(grid), dim3(RFX_BLOCK), lds_bytes, c->stream, P, G);
+        else hipLaunchKernelGGL((k_group_dense<NC, true, RFX_BLOCK, true, RFX_MAX_PREDS>), dim3(grid), dim3(RFX_BLOCK), lds_bytes, c->stream, P, G);
         return RFX_OK;
     }
     if (lds_bytes > RFX_LDS_GROUP_BYTES) {
@@ -351,7 +353,9 @@ static int group_dense_run(rfx_ctx_t *c, Plan &P, GroupArgs &G, const rfx_agg_t 
     int rs = 0;
     if (t->range <= 4 && group_deep_inline(c, aggs, t, P.nrows) && !(c->flags & RFX_TUNE_NO_LDS_REPLICAS))
         while (rs < 6 && lds_table_bytes(t->range << (rs + 1), aggs, t->nagg) <= RFX_LDS_TINY_BYTES) rs++;
-    const bool tiny = deep || (rs >= 3 && t->nagg >= 2);
+    // ... and wide plans (>= 5 distinct columns) whatever the group count: predicate descriptors sized to the query and switch-selected
+    // column operands are worth 20-30 % there (8 plain aggregates over 7 columns: 33.7 ms per 1e9 rows in the common form)
+    const bool tiny = deep || (rs >= 3 && t->nagg >= 2) || ((P.ncols >= 5 || P.npred >= 1) && !rfx_plan_has_deep_expr(P) && group_deep_inline(c, aggs, t, P.nrows));
     G.rep_shift = tiny ? rs : 0;
     size_t lds_bytes = lds_table_bytes(tiny ? (t->range << rs) : t->range, aggs, t->nagg);
     const size_t lds_cap = (c->flags & RFX_TUNE_NO_BIG_LDS) ? RFX_LDS_GROUP_BYTES : RFX_LDS_GROUP_BIG_BYTES;
