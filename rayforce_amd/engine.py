@@ -630,7 +630,7 @@ class Engine:
         return t, store, layout
 
     def group_by(self, key, aggs, where=None, table=None, total_rows: Optional[int] = None, row0: int = 0, _collective=None,
-                 order: str = "first"):
+                 order: str = "first", _cap_hint: int = 0):
         """``select {aggs} from t [where p] by key`` -> dict(keys=, first=, results=[...], groups=n) of device tensors.
 
         Group order is first occurrence (`order="radix"`: for key tuples that take the row-hash path, the order of the
@@ -640,8 +640,8 @@ class Engine:
         chunks = self._agg_chunks(aggs)
         if len(chunks) > 1:  # more outputs than one table set carries: several passes (same groups, same order)
             r = None
-            for ch in chunks:
-                part = self.group_by(key, ch, where, table, total_rows, row0, _collective, order)
+            for ch in chunks:  # (a later launch starts from the hashed-table capacity the first one ended with: same groups)
+                part = self.group_by(key, ch, where, table, total_rows, row0, _collective, order, r.get("cap", 0) if r else 0)
                 if r is None:
                     r = part
                 else:
@@ -721,7 +721,7 @@ class Engine:
             # capacity: the reference sizes its table by the row count (ht_oa_create(len), core/index.c:1805); the distinct keys
             # are usually far fewer, so start at 4 M slots (>= 2 M distinct keys) and grow x16 whenever the table reports full
             cap_max = 1 << max(4, math.ceil(math.log2(max(2 * seen, 16))))
-            cap = min(cap_max, 1 << 22)
+            cap = min(cap_max, max(1 << 22, _cap_hint))
             while True:
                 t, store, layout = self.group_tables(aarr, nagg, 0, cap, hashed=True)
                 L.check(self.lib.rfx_hip_hash_tables_init(self._ctx, aarr, C.byref(t)), "hash_tables_init")
@@ -754,7 +754,7 @@ class Engine:
             L.check(self.lib.rfx_hip_group_emit(self._ctx, aarr, C.byref(t), keys.data_ptr(), first.data_ptr(), ptrs), "group_emit")
         else:
             L.check(self.lib.rfx_hip_hash_emit(self._ctx, aarr, C.byref(t), keys.data_ptr(), first.data_ptr(), ptrs), "hash_emit")
-        r = dict(groups=g, keys=keys, first=first, results=results, dense=dense)
+        r = dict(groups=g, keys=keys, first=first, results=results, dense=dense, cap=0 if dense else cap)
         if multi is not None:
             mins, mults, ranges = multi
             r["key_columns"] = []
