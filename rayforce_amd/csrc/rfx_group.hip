@@ -353,9 +353,10 @@ static int group_dense_run(rfx_ctx_t *c, Plan &P, GroupArgs &G, const rfx_agg_t 
     int rs = 0;
     if (t->range <= 4 && group_deep_inline(c, aggs, t, P.nrows) && !(c->flags & RFX_TUNE_NO_LDS_REPLICAS))
         while (rs < 6 && lds_table_bytes(t->range << (rs + 1), aggs, t->nagg) <= RFX_LDS_TINY_BYTES) rs++;
-    // ... and wide plans (>= 5 distinct columns) whatever the group count: predicate descriptors sized to the query and switch-selected
-    // column operands are worth 20-30 % there (8 plain aggregates over 7 columns: 33.7 ms per 1e9 rows in the common form)
-    const bool tiny = deep || (rs >= 3 && t->nagg >= 2) || ((P.ncols >= 5 || P.npred >= 1) && !rfx_plan_has_deep_expr(P) && group_deep_inline(c, aggs, t, P.nrows));
+    // ... and, since the TINY form also carries predicate descriptors sized to the query and switch-selected column operands, every
+    // plan whose tables fit the 64 KB form: 20-30 % on wide plans (8 plain aggregates over 7 columns 33.7 -> 28.1 ms per 1e9 rows), 8 %
+    // on filtered narrow ones, 1-3 % elsewhere.  RFX_TUNE_NO_DEEP_GROUP brings the common form back (A/B, tests).
+    const bool tiny = deep || group_deep_inline(c, aggs, t, P.nrows);
     G.rep_shift = tiny ? rs : 0;
     size_t lds_bytes = lds_table_bytes(tiny ? (t->range << rs) : t->range, aggs, t->nagg);
     const size_t lds_cap = (c->flags & RFX_TUNE_NO_BIG_LDS) ? RFX_LDS_GROUP_BYTES : RFX_LDS_GROUP_BIG_BYTES;

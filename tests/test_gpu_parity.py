@@ -318,7 +318,7 @@ def test_sharded_engine_single_rank(eng):
     assert np.array_equal(sh.where(("<", "a", 1000), d).cpu().numpy(), rfo.where(rfo.mask_of(("<", "a", 1000), host)))
 
 
-@pytest.mark.parametrize("flags", [0, 1, 2, 3, 4, 6, 8, 16, 32, 128, 144, 160, 256, 384, 1024, 1028, 2048, 2064])
+@pytest.mark.parametrize("flags", [0, 1, 2, 3, 4, 6, 8, 16, 32, 128, 144, 160, 256, 384, 1024, 1028, 2048, 2064, 4096, 4100])
 def test_group_by_every_code_path_agrees(eng, flags):
     """RFX_TUNE_* force the LDS-table / partitioned (fused and unfused scope) / device-atomic paths: same answers."""
     n = 400_003
