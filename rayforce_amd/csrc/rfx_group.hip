@@ -42,7 +42,7 @@ struct GroupArgs {
 template <int NC, bool LDS, int BLOCK, bool TINY = false, int NPT = RFX_MAX_PREDS>
 __global__ __launch_bounds__(BLOCK) void k_group_dense(const Plan P, const GroupArgs G) {
     constexpr bool DEEP = TINY;
-    constexpr int U = (NC <= 2) ? 4 : (NC <= 4 ? 2 : 1);
+    constexpr int U = TINY ? (NC <= 5 ? 4 : 3) : ((NC <= 2) ? 4 : (NC <= 4 ? 2 : 1)); // rows per lane = 2 U; TINY: measured per NC (tools/q1_variants.py)
     constexpr int E = 2 * U;
     constexpr int TILE = BLOCK * E;
     constexpr int JSTRIDE = BLOCK * 2;
