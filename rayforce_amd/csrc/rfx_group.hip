@@ -42,6 +42,7 @@ struct GroupArgs {
 template <int NC, bool LDS, int BLOCK, bool TINY = false, int NPT = RFX_MAX_PREDS>
 __global__ __launch_bounds__(BLOCK) void k_group_dense(const Plan P, const GroupArgs G) {
     constexpr bool DEEP = TINY;
+    constexpr bool SW = TINY || BLOCK == 1024; // column operands through a wave-uniform switch instead of select chains
     constexpr int U = TINY ? (NC <= 5 ? 4 : 3) : ((NC <= 2) ? 4 : (NC <= 4 ? 2 : 1)); // rows per lane = 2 U; TINY: measured per NC (tools/q1_variants.py)
     constexpr int E = 2 * U;
     constexpr int TILE = BLOCK * E;
@@ -107,7 +108,7 @@ __global__ __launch_bounds__(BLOCK) void k_group_dense(const Plan P, const Group
         if (m == 0) continue;
         u64 key[E]; // slot in the dense table
         if (G.nkeys <= 1) {
-            if (TINY) sel_col_sw<NC, E>(key, v, G.key_idx);
+            if (SW) sel_col_sw<NC, E>(key, v, G.key_idx);
             else sel_col<NC, E>(key, v, G.key_idx);
 #pragma unroll
             for (int e = 0; e < E; e++) key[e] -= (u64)G.kmin;
@@ -116,7 +117,7 @@ __global__ __launch_bounds__(BLOCK) void k_group_dense(const Plan P, const Group
             for (int e = 0; e < E; e++) key[e] = 0;
             for (int i = 0; i < G.nkeys; i++) {
                 u64 x[E];
-                if (TINY) sel_col_sw<NC, E>(x, v, G.kidx[i]);
+                if (SW) sel_col_sw<NC, E>(x, v, G.kidx[i]);
                 else sel_col<NC, E>(x, v, G.kidx[i]);
                 const u64 mn = G.kmn[i], mu = G.kmul[i];
 #pragma unroll
@@ -148,7 +149,7 @@ __global__ __launch_bounds__(BLOCK) void k_group_dense(const Plan P, const Group
                 if (DEEP) expr_input_deep_sw<NC, E>(x, v, P.xs[ag.col - RFX_XCOL]);
                 else expr_input<NC, E>(x, v, P.xs[ag.col - RFX_XCOL]);
             } else if (ag.col >= 0) {
-                if (TINY) sel_col_sw<NC, E>(x, v, ag.col);
+                if (SW) sel_col_sw<NC, E>(x, v, ag.col);
                 else sel_col<NC, E>(x, v, ag.col);
             }
 #pragma unroll
@@ -263,12 +264,20 @@ static int launch_group(rfx_ctx *c, const Plan &P, const GroupArgs &G, int grid,
         return RFX_OK;
     }
     if (lds_bytes > RFX_LDS_GROUP_BYTES) {
-        static bool attr_set = false; // per template instance: dynamic LDS above 64 KB must be opted into once
-        if (!attr_set) {
-            RFX_HIP_CHECK(hipFuncSetAttribute((const void *)k_group_dense<NC, true, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, RFX_LDS_GROUP_BIG_BYTES));
-            attr_set = true;
-        }
-        hipLaunchKernelGGL((k_group_dense<NC, true, 1024>), dim3(c->num_cus), dim3(1024), lds_bytes, c->stream, P, G);
+        // (dynamic LDS above 64 KB must be opted into once per template instance)
+#define RFX_BIG_LAUNCH(...)                                                                                                                           \
+    do {                                                                                                                                              \
+        static bool attr_set = false;                                                                                                                 \
+        if (!attr_set) {                                                                                                                              \
+            RFX_HIP_CHECK(hipFuncSetAttribute((const void *)k_group_dense<__VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, RFX_LDS_GROUP_BIG_BYTES)); \
+            attr_set = true;                                                                                                                          \
+        }                                                                                                                                             \
+        hipLaunchKernelGGL((k_group_dense<__VA_ARGS__>), dim3(c->num_cus), dim3(1024), lds_bytes, c->stream, P, G);                                    \
+    } while (0)
+        if (P.npred == 0) RFX_BIG_LAUNCH(NC, true, 1024, false, 0); // predicate descriptor sets sized to the query, as in the TINY form
+        else if (P.npred <= 2) RFX_BIG_LAUNCH(NC, true, 1024, false, 2);
+        else RFX_BIG_LAUNCH(NC, true, 1024, false, RFX_MAX_PREDS);
+#undef RFX_BIG_LAUNCH
     } else if (lds_bytes) hipLaunchKernelGGL((k_group_dense<NC, true, RFX_BLOCK>), dim3(grid), dim3(RFX_BLOCK), lds_bytes, c->stream, P, G);
     else hipLaunchKernelGGL((k_group_dense<NC, false, RFX_BLOCK>), dim3(grid), dim3(RFX_BLOCK), 0, c->stream, P, G);
     return RFX_OK;

@@ -312,8 +312,8 @@ extern "C" int rfx_hip_scope_i64(rfx_ctx_t *c, const int64_t *d_key, const rfx_p
 // (128 B contiguous per wave instruction).
 template <int NC>
 __global__ __launch_bounds__(RFX_BLOCK) void k_cmp_mask(const Plan P, int8_t *__restrict__ out) {
-    PredSet<RFX_MAX_PREDS> S;
-    predset_load<RFX_MAX_PREDS>(P, S);
+    PredSet<1> S; // exactly one comparison: one descriptor set in SGPRs, not eight
+    predset_load<1>(P, S);
     const int lane = threadIdx.x & 63;
     const i64 wave_id = (i64)blockIdx.x * (RFX_BLOCK / RFX_WAVE) + (threadIdx.x >> 6);
     const i64 nwaves = (i64)gridDim.x * (RFX_BLOCK / RFX_WAVE);
@@ -330,7 +330,7 @@ __global__ __launch_bounds__(RFX_BLOCK) void k_cmp_mask(const Plan P, int8_t *__
                 v[c][2 * j + 1] = t.y;
             }
         }
-        const unsigned m = eval_preds<NC, 8, RFX_MAX_PREDS>(S, v, 0xffu);
+        const unsigned m = eval_preds<NC, 8, 1>(S, v, 0xffu);
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const unsigned short two = (unsigned short)(((m >> (2 * j)) & 1u) | (((m >> (2 * j + 1)) & 1u) << 8));
@@ -343,7 +343,7 @@ __global__ __launch_bounds__(RFX_BLOCK) void k_cmp_mask(const Plan P, int8_t *__
             u64 v[NC][1];
 #pragma unroll
             for (int c = 0; c < NC; c++) v[c][0] = P.cols[c][r];
-            out[r] = (int8_t)(eval_preds<NC, 1, RFX_MAX_PREDS>(S, v, 1u) & 1u);
+            out[r] = (int8_t)(eval_preds<NC, 1, 1>(S, v, 1u) & 1u);
         }
     }
 }
