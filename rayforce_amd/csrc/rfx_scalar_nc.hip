@@ -28,6 +28,11 @@ int RFX_CAT(rfx_launch_filter_aggr_nc, RFX_NC)(rfx_ctx *c, const Plan &P, int gr
         }
 #if RFX_NC <= 4
         if (P.npred <= 4 && P.nagg <= 4) {
+            if (P.nx == 1 && P.nagg == 1) { // one aggregate over one expression (TPC-H Q6 itself): one accumulator, not four
+                *na_stride = 2;
+                launch_shape<RFX_NC, 1, 4, 1>(c, P, grid, ws);
+                return RFX_OK;
+            }
             *na_stride = 5;
             if (P.nx == 1) launch_shape<RFX_NC, 4, 4, 1>(c, P, grid, ws); // the common one-expression query (TPC-H Q6 shape)
             else launch_shape<RFX_NC, 4, 4, RFX_MAX_EXPRS>(c, P, grid, ws);
