@@ -637,6 +637,36 @@ class Engine:
         reference's multi-threaded radix grouping instead -- hash & 1023, then first occurrence).  `_collective(store, layout, aggs_arr, hashed)` -- if given -- is called
         between the local scatter pass and the ranking step so that several GPUs can merge their tables.  (syncs)
         """
+        if where is not None and not isinstance(where, torch.Tensor):
+            try:
+                self._flatten(where, table)
+            except _NotFlat:
+                # a nested boolean tree: the reference's own plan -- masks, where, gather (filter_collect), then group the gathered
+                # columns (core/query.c:607-654) -- on the device; `first` is translated back through the ids
+                if _collective is not None:
+                    raise RfxError("nested boolean trees are not fused with `by:` across GPUs; pass ids via where() + at_ids()")
+                names = set()
+
+                def leaves(e):
+                    for x in e[1:]:
+                        if isinstance(x, tuple):
+                            leaves(x)
+                        elif isinstance(x, str):
+                            names.add(x)
+                        elif isinstance(x, torch.Tensor):
+                            raise RfxError("nested boolean trees with `by:` need columns given by name")
+
+                for k in (key if isinstance(key, list) else [key]):
+                    leaves(("k", k[1]) if isinstance(k, tuple) else ("k", k))
+                for _, col in aggs:
+                    if col is not None:
+                        leaves(col if isinstance(col, tuple) else ("a", col))
+                ids = self.where(where, table)
+                sub = {nm: self.at_ids(self._check_col(self._resolve(nm, table)), ids) for nm in names}
+                r = self.group_by(key, aggs, None, sub, None, 0, None, order)
+                if r["groups"]:
+                    r["first"] = self.at_ids(ids, r["first"])
+                return r
         chunks = self._agg_chunks(aggs)
         if len(chunks) > 1:  # more outputs than one table set carries: several passes (same groups, same order)
             r = None

@@ -502,8 +502,7 @@ def test_expressions_as_columns_and_inside_predicates(eng):
     for w in ((">", ("*", "a", "v"), 250_000.0), ("<=", ("-", "a", ("*", "b", 100_000)), "a"), ("and", ("<", ("+", "v", "w"), 0.6), (">", "a", 1000)),
               ("or", ("==", ("div", "a", 1000), 7), ("and", (">", ("*", "v", 2.0), 1.5), ("!=", "b", 3))), ("<", "v", ("*", "w", 3.0))):
         check_select(eng, host, {**q, "where": w})
-        if not (w[0] in ("and", "or") and any(x[0] in ("and", "or") for x in w[1:])):  # (nested trees are not fused with by: here)
-            check_select(eng, host, {**q, "where": w, "by": "k"})
+        check_select(eng, host, {**q, "where": w, "by": "k"})  # (a nested tree under by: goes masks -> ids -> gather -> group, as the reference)
         ids = eng.where(w, d).cpu().numpy()
         assert np.array_equal(ids, rfo.where(rfo.mask_of(w, host)))
 
@@ -571,6 +570,23 @@ def test_equi_joins_at_size_and_edges(eng):
     from rayforce_amd._lib import RfxError
     with pytest.raises(RfxError, match="i64-like"):
         eng.join_index("v", dl, dev(eng, {"v": left["v"]}))
+
+
+def test_nested_where_tree_under_by(eng):
+    """and / or trees of any depth with by: -- the reference's own plan (masks, where, gather, group) on the device: one key, two
+    keys, bucketed key, key tuples on the row-hash path, `first`, expression aggregates."""
+    n = 300_007
+    host = table(n, keys=3000, nulls=True)
+    host["b"] = rfo.gen_i64(n, 77, 9) - 1
+    host["ts"] = rfo.gen_i64(n, 55, 10**6) - 5 * 10**5
+    host["wide"] = rfo.gen_i64(n, 56, 40) * (1 << 58)
+    w = ("or", ("and", ("<", "a", 300_000), (">", "v", 0.2)), ("and", ("==", "b", 3), ("or", ("<", "w", -0.3), (">=", "a", 900_000))))
+    q = {"s": ("sum", "v"), "c": ("count", "a"), "mx": ("max", ("*", "a", "v")), "f": ("first", "a"), "av": ("avg", "w")}
+    for by in ("k", {"k": "k", "b": "b"}, {"t": ("xbar", "ts", 50_000)}, {"wide": "wide", "k": "k", "b": "b"}):
+        check_select(eng, host, {**q, "where": w, "by": by})
+    r = eng.group_by("k", [("sum", "v")], w, dev(eng, host))
+    gi, fi, _, _ = rfo.group_index(host["k"], rfo.where(rfo.mask_of(w, host)))
+    assert np.array_equal(r["first"].cpu().numpy(), rfo.where(rfo.mask_of(w, host))[fi])  # first = ORIGINAL row ids
 
 
 def test_group_by_xbar_buckets(eng):
