@@ -971,6 +971,28 @@ class Engine:
             return out
         return self._check_col(self._resolve(spec, table))
 
+    def _scopes_fused(self, kcols, where, table, n):
+        """(min, max, rows seen) of two to four key columns in ONE pass: K1 with a min and a max aggregate per column reads every
+        key and predicate column once (one index_scope_i64 pass per column re-reads the predicate columns each time).  K1's min / max
+        skip nulls where the reference's scope takes INT64_MIN as the smallest key: a column whose non-null count is below the
+        selected-row count holds a null, so its minimum is null.  None when the shape does not fit one K1 launch."""
+        try:
+            part = self.filter_aggr_partials([(fn, kc) for kc in kcols for fn in ("min", "max")], where, table, nrows=n)
+        except RfxError:
+            return None
+        p = part.view(torch.int64).reshape(-1, 8).cpu().tolist()  # rfx_partial_t: isum, fsum, cnt, ext, pos, ...
+        seen = p[2 * len(kcols)][2]
+        out = []
+        for i in range(len(kcols)):
+            nonnull, mn, mx = p[2 * i][2], p[2 * i][3], p[2 * i + 1][3]
+            if seen == 0:
+                out.append((0, -1, 0))
+            elif nonnull == 0:
+                out.append((L.NULL_I64, L.NULL_I64, seen))
+            else:
+                out.append((L.NULL_I64 if nonnull < seen else mn, mx, seen))
+        return out
+
     def _composite_plan(self, kcols, where, table, _collective):
         """Scopes of every key column (through the predicates) and the reference's multiplier plan (core/index.c:2340-2383).
         Returns (composite max, rows seen, (mins, mults, ranges))."""
@@ -981,7 +1003,11 @@ class Engine:
         for kc in kcols:
             if kc.dtype != torch.int64 or kc.numel() != n:
                 raise RfxError("key columns must be equally long i64 columns on this path")
-            mn, mx, seen = self.scope(kc, where, table)
+        # (only under a filter: unfiltered, one 1.2 ms scope pass per key column beats K1 with 2 x keys min / max aggregates --
+        #  two keys, 1e9 rows: 2.4 against 3.8 ms -- while with predicates every separate pass re-reads the predicate columns)
+        local = self._scopes_fused(kcols, where, table, n) if (where is not None and 2 <= len(kcols) <= 4) else None
+        for i, kc in enumerate(kcols):
+            mn, mx, seen = local[i] if local is not None else self.scope(kc, where, table)
             if _collective is not None:
                 mn, mx, seen = _collective("scope", (mn, mx, seen, self.device))
             mins.append(mn)
