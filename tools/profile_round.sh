@@ -8,7 +8,8 @@ REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-for w in c2 c2b c3 c3w q2 x6 q1 k9 c5 w2 q7; do
+WL=${2:-"c2 c2b c3 c3w q2 x6 q1 k9 c5 w2 q7"}   # optional second argument: only these workloads
+for w in $WL; do
   rm -rf /tmp/rp_$w
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp_$w -o $w -- python $REPO/bench.py --no-cpu-baseline --no-also --workload $w --steps 10 > $OUT/${w}_bench.log 2>&1
   f=$(find /tmp/rp_$w -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $OUT/${w}_kernel_stats.csv
