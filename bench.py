@@ -1,25 +1,29 @@
 #!/usr/bin/env python
 """bench.py -- the hot-path benchmark of BASELINE.json on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c2b|c3|c5] [--rows R] [--no-cpu-baseline] [--no-also]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3w|c2|c2b|c3|c5|...] [--scaling strong|weak] [--rows R] [--no-cpu-baseline] [--no-also]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks ITSELF (it re-executes under
+torch.distributed.run on 127.0.0.1); a rank count that differs from --gpus is an error, never a silent 1-GPU run.
+
 A "step" = one execution of the query over the HBM-resident synthetic columns of this rank (kernels + the one merge
-collective + result read-back).  Weak scaling: every GPU holds `rows` rows (rows [rank*rows, (rank+1)*rows) of a
-virtual N*rows-row table, generated on the device with the counter-based splitmix64 of SURVEY 8d), so per-GPU work is
-fixed and `value` = N*rows / max-over-ranks step time.
+collective + result read-back).  The table is rows [0, TOTAL) generated on the device with the counter-based splitmix64 of
+SURVEY 8d; rank r holds the row range [r * TOTAL / N, (r + 1) * TOTAL / N).  --scaling strong (default; SURVEY 8d C4/C5: the
+SAME 1e9 / 2e9 rows split N ways): TOTAL = the workload's BASELINE size; --scaling weak: TOTAL = N x that size.
+`value` = TOTAL / max-over-ranks step time.
 
 Workloads (BASELINE.json configs / SURVEY 8d):
-  c2   configs[1]  select sum(a) where a < 100000      a: i64[1e9] in [0,1e6)              8 B/row   <- default, `value`
+  c2   configs[1]  select sum(a) where a < 100000      a: i64[1e9] in [0,1e6)              8 B/row
   c2b  north-star  select sum(b) where a < 100000      + b: f64[1e9]                       16 B/row
   c3   configs[2]  select sum(v) by k                  k: i64[1e9] in [0,1e6), v: f64      16 B/row
   c1   configs[0]  (sum v)                             v: f64[1e7]                         8 B/row   (plumbing case)
-  c3w  metric      select sum(v) by k where a < 100000 k, v as c3 + a as c2                24 B/row
+  c3w  metric      select sum(v) by k where a < 100000 k, v as c3 + a as c2                24 B/row  <- default, `value` (filter->group-by->sum)
   q2   8f-1        select sum(v) by {id1, id2}         id1, id2: i64[1e9] in [0,100), v    24 B/row
   q1   8f-3        TPC-H Q1 shape: 8 aggregates, two of them nested expressions, by {rf, ls} where sd <= 2400  56 B/row
   k9   a10         select sum(v) by k, sparse keys (range > rows: open-addressing path)          16 B/row
   x6   8f-3        select sum(p*d) where q<24 and .05<=d<=.07   p, d: f64[1e9], q: i64[1e9]   24 B/row (TPC-H Q6 shape)
-  c5   configs[4]  avg,min,max(d) where a<.316228 & b>.683772 & c!=.25   4 x f64[2.5e8]/GPU 32 B/row
+  c5   configs[4]  avg,min,max(d) where a<.316228 & b>.683772 & c!=.25   4 x f64[2e9]       32 B/row
 One JSON line on stdout (rank 0); everything else goes to stderr.
 """
 from __future__ import annotations
@@ -79,7 +83,7 @@ WORKLOADS = {
                dtype="int64", kernel="k_cmp_mask<1>"),
     "g2": dict(desc="gather: (at b ids) for the 1e8 ids of w2 (8 B id + 8 B random read + 8 B write per id)", rows=1_000_000_000, bytes_per_row=2.4,
                dtype="f64", kernel="k_gather8"),
-    "c5": dict(desc="configs[4] per-GPU shard: avg,min,max(d) where a<0.316228 and b>0.683772 and c!=0.25, 4 x f64 seeds 6-9", rows=250_000_000,
+    "c5": dict(desc="configs[4]: avg,min,max(d) where a<0.316228 and b>0.683772 and c!=0.25, 4 x f64[2e9] seeds 6-9 (64 GB: 2.5e8 rows per GPU at 8)", rows=2_000_000_000,
                bytes_per_row=32, dtype="f64", kernel="k_filter_aggr<4, 4, 4, 4, 0, false>"),
 }
 
@@ -203,21 +207,30 @@ def timed(job: Job, steps: int, warmup: int, world: int):
     return dt, sum(kms) / max(1, len(kms)), res
 
 
-def run_workload(name, eng, sharded, rows, row0, steps, warmup, world):
+def run_workload(name, eng, sharded, rows, row0, steps, warmup, world, total_rows=None):
+    """rows = this rank's rows; total_rows = rows of the whole job (all ranks)."""
     w = WORKLOADS[name]
+    total_rows = rows * world if total_rows is None else total_rows
     job = Job(name, eng, sharded, rows, row0)
     dt, kms, res = timed(job, steps, warmup, world)
     ms_step = dt * 1e3 / steps
-    if name in ("c3", "c3w", "q2", "k9", "q1", "q7", "w2"):
-        kms = ms_step  # several dependent kernels (scope+hist, scatter, aggregate, rank, emit): price the whole query
-    value = world * rows / (dt / steps)
-    alg_bytes = w["bytes_per_row"] * rows  # per launch, per GPU (SURVEY 8d figures, stated in DESIGN.md)
+    if name in ("c3", "c3w", "q2", "k9", "q1", "q7", "w2") or world > 1:
+        kms = ms_step  # several dependent kernels (partition, aggregate, rank, emit) / the merge collective: price the whole query
+    value = total_rows / (dt / steps)
+    alg_bytes = w["bytes_per_row"] * total_rows / world  # per launch, per GPU (SURVEY 8d figures, stated in DESIGN.md)
     achieved = alg_bytes / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
-    out = dict(workload=name, rows_per_gpu=rows, ms_per_step=ms_step, rows_per_s=value, kernel_ms=kms, achieved_GBps=achieved,
+    out = dict(workload=name, rows_per_gpu=rows, total_rows=total_rows, ms_per_step=ms_step, rows_per_s=value, kernel_ms=kms, achieved_GBps=achieved,
                frac=achieved / HBM_PEAK_GBPS, result=_brief(res))
     del job
     torch.cuda.empty_cache()
     return out
+
+
+def roofline_block(name, r, world):
+    w = WORKLOADS[name]
+    return {"bound": "hbm", "achieved": r["achieved_GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": r["frac"],
+            "traffic": pmc_traffic(name) if world == 1 and r["total_rows"] == w["rows"] else None, "kernel": w["kernel"], "kernel_ms": r["kernel_ms"],
+            "algorithmic_bytes_per_launch": w["bytes_per_row"] * r["total_rows"] / world}
 
 
 def _brief(res):
@@ -321,38 +334,91 @@ def cpu_baseline(name, sample_rows, timeout=120):
                        f"best of {reps}")
 
 
+def shard_range(total, world, rank):
+    """Row range [lo, hi) of `rank`: contiguous, sizes differ by at most one row."""
+    return total * rank // world, total * (rank + 1) // world
+
+
+def respawn(n):
+    """`python bench.py --gpus N` outside a launcher: start the N ranks (one per GPU) under torch.distributed.run on 127.0.0.1."""
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    log(f"[bench] --gpus {n} without a launcher: starting {n} ranks: {' '.join(cmd[1:10])} ...")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.execv(sys.executable, cmd)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="c2", choices=list(WORKLOADS))
-    ap.add_argument("--rows", type=int, default=0, help="rows per GPU (default: the workload's BASELINE size)")
+    ap.add_argument("--workload", default="c3w", choices=list(WORKLOADS))
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
+                    help="strong: the workload's BASELINE row count in TOTAL, split over the ranks (SURVEY 8d C4/C5); weak: that many rows PER rank")
+    ap.add_argument("--rows", type=int, default=0, help="override the workload's BASELINE row count (total under strong scaling, per rank under weak)")
     ap.add_argument("--cpu-sample-rows", type=int, default=100_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sharded", action="store_true", help="use the row-sharded driver (collectives) even with one rank")
     ap.add_argument("--no-also", action="store_true", help="skip the secondary workloads in the 'also' field")
+    ap.add_argument("--dry-run", action="store_true", help="no device work: rendezvous, shard arithmetic and the JSON line only (CPU test of the launch contract)")
     ap.add_argument("--blocks-per-cu", type=int, default=0)
     ap.add_argument("--ab", default="", help="dev: comma list of tune flags to A/B in ONE process (same box, same clocks); prints one line per run")
     ap.add_argument("--tune-flags", type=int, default=0, help="rfx_hip_ctx_tune flags (kernel-variant experiments)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        respawn(args.gpus)  # does not return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks -- refusing to report a {world}-GPU run as {args.gpus} GPUs")
+    name = args.workload
+    base_rows = args.rows or WORKLOADS[name]["rows"]
+    total_rows = base_rows if args.scaling == "strong" else base_rows * world
+    lo, hi = shard_range(total_rows, world, rank)
+    rows, row0 = hi - lo, lo
+
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        backend = os.environ.get("RFX_BENCH_BACKEND", "nccl")  # "gloo" + RFX_BENCH_SAME_DEVICE=1: dry-run N ranks on ONE GPU
+        backend = "gloo" if args.dry_run else os.environ.get("RFX_BENCH_BACKEND", "nccl")  # "gloo" + RFX_BENCH_SAME_DEVICE=1: N ranks on ONE GPU
         if os.environ.get("RFX_BENCH_SAME_DEVICE"):
             local_rank = 0
-        torch.cuda.set_device(local_rank)
         if backend == "nccl":
+            torch.cuda.set_device(local_rank)
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
+            if not args.dry_run:
+                torch.cuda.set_device(local_rank)
             dist.init_process_group(backend)
-    if args.gpus != world:
-        log(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE")
+    if args.dry_run:
+        # the launch contract without a device: every rank reports its shard, rank 0 checks the shards tile [0, total) and prints the line
+        shards = [None] * world
+        if world > 1:
+            dist.all_gather_object(shards, (row0, rows))
+            dist.barrier()
+        else:
+            shards = [(row0, rows)]
+        if rank == 0:
+            pos = 0
+            for r0, n in shards:
+                assert r0 == pos, (shards, "shards must tile the table")
+                pos += n
+            assert pos == total_rows
+            w = WORKLOADS[name]
+            print(json.dumps({"metric": METRIC, "value": None, "unit": "rows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": None,
+                              "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": w["dtype"], "data": "synthetic", "dry_run": True,
+                              "config": {"workload": f"{name}: {w['desc']}", "total_rows": total_rows, "rows_per_gpu": [n for _, n in shards],
+                                         "sharding": f"row-range x{world}" if world > 1 else "single GPU"}}), flush=True)
+        if dist.is_initialized():
+            dist.destroy_process_group()
+        return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the MI355X path has no CPU fallback")
 
@@ -361,14 +427,11 @@ def main():
     eng = Engine(local_rank)
     if args.blocks_per_cu or args.tune_flags:
         eng.tune(blocks_per_cu=args.blocks_per_cu, flags=args.tune_flags)
-    name = args.workload
-    rows = args.rows or WORKLOADS[name]["rows"]
     if args.sharded and world == 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
     sharded = ShardedEngine(eng, rows) if (world > 1 or args.sharded) else None
-    row0 = rank * rows
 
     if args.ab:
         job = Job(name, eng, sharded, rows, row0)
@@ -380,16 +443,21 @@ def main():
                 log(f"[ab] rep {rep} flags:bpc {item}: ms_per_step {dt * 1e3 / args.steps:.3f} kernel_ms {kms:.3f} "
                     f"GB/s {WORKLOADS[name]['bytes_per_row'] * rows / kms / 1e6:.0f}")
         return
-    main_r = run_workload(name, eng, sharded, rows, row0, args.steps, args.warmup, world)
+    main_r = run_workload(name, eng, sharded, rows, row0, args.steps, args.warmup, world, total_rows)
     log(f"[bench] {name}: {main_r}")
     also = {}
+    FULL = ("c3w", "c2", "c2b", "c3", "c5")  # the BASELINE configs: the full step count, their own roofline block and CPU baseline
     if not args.no_also and world == 1 and not args.rows:
         for other in WORKLOADS:
             if other == name:
                 continue
             try:
-                r = run_workload(other, eng, None, WORKLOADS[other]["rows"], 0, max(3, args.steps // 4), 2, 1)
+                full = other in FULL
+                r = run_workload(other, eng, None, WORKLOADS[other]["rows"], 0, args.steps if full else max(3, args.steps // 4), args.warmup if full else 2, 1)
                 also[other] = {k: r[k] for k in ("rows_per_gpu", "ms_per_step", "rows_per_s", "kernel_ms", "achieved_GBps", "frac")}
+                also[other]["steps"] = args.steps if full else max(3, args.steps // 4)
+                if full:
+                    also[other]["roofline"] = roofline_block(other, r, 1)
                 log(f"[bench] also {other}: {also[other]}")
             except Exception as e:  # noqa: BLE001
                 also[other] = {"error": str(e)[:200]}
@@ -403,8 +471,8 @@ def main():
             cpu = None
         # the reference's CPU path beside the secondary workloads too (smaller samples: the whole run stays within minutes)
         t_cpu = time.perf_counter()
-        for other in also:
-            if other in ("c1", "c2b", "c3", "c3w", "q2", "x6", "k9", "c5") and "error" not in also[other]:
+        for other in sorted(also, key=lambda o: (o not in FULL, o)):
+            if other in ("c1", "c2", "c2b", "c3", "c3w", "q2", "x6", "k9", "c5") and "error" not in also[other]:
                 if time.perf_counter() - t_cpu > 150:  # keep the default run within minutes
                     log(f"[bench] cpu_baseline({other}) skipped: time budget for the secondary baselines used up")
                     continue
@@ -426,16 +494,14 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": main_r["ms_per_step"],
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": w["dtype"],
             "data": "synthetic",
-            "config": {"workload": f"{name}: {w['desc']}", "rows_per_gpu": rows, "total_rows": rows * world,
+            "config": {"workload": f"{name}: {w['desc']}", "rows_per_gpu": rows, "total_rows": total_rows,
                        "sharding": f"row-range x{world}" if world > 1 else "single GPU", "resident": "HBM (columns generated on device)",
                        "result": main_r["result"]},
-            "roofline": {"bound": "hbm", "achieved": main_r["achieved_GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": main_r["frac"],
-                         "traffic": pmc_traffic(name), "kernel": w["kernel"], "kernel_ms": main_r["kernel_ms"],
-                         "algorithmic_bytes_per_launch": w["bytes_per_row"] * rows},
+            "roofline": roofline_block(name, main_r, world),
             "cpu_baseline": cpu,
         }
         if also:

@@ -181,7 +181,10 @@ enum {
     RFX_TUNE_NO_EMIT_WC = 512,      /* where: plain masked id stores instead of the LDS-ring write-combining emit */
     RFX_TUNE_NO_SEL_COMPACT = 256,  /* partitioned path under a filter: never compact the selected rows first */
     RFX_TUNE_NO_DEEP_GROUP = 4096,  /* dense group-by, LDS tables: materialise expression trees (k_derive) instead of evaluating them in the pass */
-    RFX_TUNE_NO_LDS_REPLICAS = 8192 /* dense group-by, a handful of groups: one LDS table set per workgroup, no lane-private replicas */
+    RFX_TUNE_NO_LDS_REPLICAS = 8192, /* dense group-by, a handful of groups: one LDS table set per workgroup, no lane-private replicas */
+    RFX_TUNE_NO_CHUNK = 16384,       /* rfx_hip_group_scope: plain scope pass, never the one-pass chunk partitioning */
+    RFX_TUNE_CHUNK_SMALL = 32768,    /* rfx_hip_group_scope: one-pass chunk partitioning from 2^16 rows on (default 2^22): for tests */
+    RFX_TUNE_CHUNK_CONTIG = 65536    /* one-pass chunk partitioning: every workgroup takes one contiguous row range instead of grid-stride tiles */
 };
 int rfx_hip_ctx_tune(rfx_ctx_t *ctx, int blocks_per_cu, int flags);
 
@@ -249,6 +252,13 @@ int rfx_hip_gather(rfx_ctx_t *ctx, const void *d_col, const int64_t *d_ids, int6
  * (syncs)  *count = rows seen; min/max undefined when *count == 0. */
 int rfx_hip_scope_i64(rfx_ctx_t *ctx, const int64_t *d_key, const rfx_pred_t *preds, int npred, int logic,
                       int64_t nrows, int64_t *min, int64_t *max, int64_t *count);
+
+/* Scope pass of a group-by whose aggregates are known: the same answers as rfx_hip_scope_i64, and for key ranges whose tables
+ * overflow one workgroup's LDS the SAME streaming read also radix-partitions the (key, value) rows into context scratch
+ * (rfx_group_chunk.hip), so that the rfx_hip_group_dense_accumulate call that follows with the same key / predicates /
+ * aggregates only has to aggregate the partitions: the columns are read once instead of three times.  (syncs) */
+int rfx_hip_group_scope(rfx_ctx_t *ctx, const int64_t *d_key, const rfx_pred_t *preds, int npred, int logic,
+                        const rfx_agg_t *aggs, int nagg, int64_t nrows, int64_t *min, int64_t *max, int64_t *count);
 
 /* ---- K7/K8/K10: dense group-by over [kmin, kmin + range) ----
  * Table layout (device, caller-visible so that several GPUs can all-reduce them):

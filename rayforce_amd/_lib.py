@@ -135,6 +135,7 @@ PROTOTYPES = {
     "rfx_hip_where_emit": (C.c_int, [_ctx, C.c_int64, C.c_void_p]),
     "rfx_hip_gather": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "rfx_hip_scope_i64": (C.c_int, [_ctx, C.c_void_p, _P(Pred), C.c_int, C.c_int, C.c_int64, _P(C.c_int64), _P(C.c_int64), _P(C.c_int64)]),
+    "rfx_hip_group_scope": (C.c_int, [_ctx, C.c_void_p, _P(Pred), C.c_int, C.c_int, _P(Agg), C.c_int, C.c_int64, _P(C.c_int64), _P(C.c_int64), _P(C.c_int64)]),
     "rfx_hip_group_table_arrays": (C.c_int, [_P(Agg), C.c_int, _P(C.c_int)]),
     "rfx_hip_group_tables_init": (C.c_int, [_ctx, _P(Agg), _P(GroupTables)]),
     "rfx_hip_group_dense_accumulate": (C.c_int, [_ctx, C.c_void_p, _P(Pred), C.c_int, C.c_int, _P(Agg), C.c_int64, C.c_int64, _P(GroupTables)]),

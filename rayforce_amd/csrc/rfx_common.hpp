@@ -82,6 +82,14 @@ struct rfx_ctx {
     i64 pc_nrows;
     i64 pc_seen;        // rows that passed the predicates in that scope pass
     u64 pc_sig[RFX_MAX_PREDS][6];
+    // one-pass chunk partitioning left by rfx_hip_group_scope (rfx_group_chunk.hip) for the next group_dense_accumulate
+    void *d_chunk;      // ctl + scope partials + chunk counts + metas + chunk lists + record pool (grow-only)
+    size_t chunk_bytes;
+    int ck_valid, ck_npred, ck_logic, ck_nwg, ck_chs;
+    const void *ck_key, *ck_val;
+    i64 ck_nrows, ck_tpw;
+    size_t ck_max_chunks;
+    u64 ck_sig[RFX_MAX_PREDS][6];
 };
 
 int rfx_ws_reserve(rfx_ctx *ctx, size_t bytes);
@@ -92,6 +100,7 @@ int rfx_comp_reserve(rfx_ctx *ctx, size_t bytes);
 int rfx_expr_reserve(rfx_ctx *ctx, size_t bytes);
 void rfx_io_release(rfx_ctx *ctx);
 int rfx_sel_reserve(rfx_ctx *ctx, size_t bytes);
+int rfx_chunk_reserve(rfx_ctx *ctx, size_t bytes);
 int rfx_plan_add_col(struct Plan *P, const void *col); // index of `col` in P->cols (added if new), -1 when full
 #define RFX_KERNEL_BEGIN(c) do { if ((c)->profile) { (void)hipEventRecord((c)->evk0, (c)->stream); } } while (0)
 #define RFX_KERNEL_END(c) do { if ((c)->profile) { (void)hipEventRecord((c)->evk1, (c)->stream); (c)->evk_valid = 1; } } while (0)

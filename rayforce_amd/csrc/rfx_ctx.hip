@@ -68,6 +68,7 @@ extern "C" int rfx_hip_ctx_destroy(rfx_ctx_t *c) {
     if (c->d_comp) (void)hipFree(c->d_comp);
     if (c->d_sel) (void)hipFree(c->d_sel);
     if (c->d_expr) (void)hipFree(c->d_expr);
+    if (c->d_chunk) (void)hipFree(c->d_chunk);
     rfx_io_release(c);
     if (c->d_pc_counts) (void)hipFree(c->d_pc_counts);
     if (c->h_pin) (void)hipHostFree(c->h_pin);
@@ -182,6 +183,17 @@ int rfx_sel_reserve(rfx_ctx *c, size_t bytes) {
     c->sel_bytes = 0;
     RFX_HIP_CHECK(hipMalloc(&c->d_sel, bytes));
     c->sel_bytes = bytes;
+    return RFX_OK;
+}
+
+int rfx_chunk_reserve(rfx_ctx *c, size_t bytes) {
+    if (c->chunk_bytes >= bytes) return RFX_OK;
+    RFX_HIP_CHECK(hipStreamSynchronize(c->stream));
+    if (c->d_chunk) RFX_HIP_CHECK(hipFree(c->d_chunk));
+    c->d_chunk = NULL;
+    c->chunk_bytes = 0;
+    RFX_HIP_CHECK(hipMalloc(&c->d_chunk, bytes));
+    c->chunk_bytes = bytes;
     return RFX_OK;
 }
 

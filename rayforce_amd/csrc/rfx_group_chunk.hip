@@ -1,0 +1,1081 @@
+// rfx_group_chunk.hip -- ONE-PASS radix partitioning for the dense group-by whose tables do not fit one workgroup's LDS
+// (BASELINE C3: 1e9 rows, 1e6 i64 keys, sum(f64); C3w: the same under `where a < k`).
+//
+// rfx_group_part.hip needs the exact size of every (workgroup, partition) region before it can scatter, i.e. a histogram
+// pass over the key column in front (8 B/row), and the key scope (index_scope_i64, core/index.c:376-435) before that.  Here
+// the scope pass IS the scatter:
+//
+//   k_chunk_scatter   reads predicate + key + value columns ONCE; partition = key & 255 needs no kmin, the record header
+//                     keeps (key >> 8) mod 2^32 instead of a kmin-relative slot, and space comes in CHUNKS of 256 records
+//                     (4 KB) that a (workgroup, partition) takes from its workgroup's slab (slabs of 256 chunks come from one
+//                     device-wide cursor: ~1 returning global atomic per 32 tiles).  Same tile sort + 128-byte write
+//                     combining as k_part_scatter_wc.  Side product: min / max / count of the selected keys.
+//   k_chunk_offsets   per partition: exclusive scan of the chunk counts over workgroups (one 1024-lane workgroup)
+//   k_chunk_place     chunk list of every partition, ordered by (workgroup, allocation order) -- no atomics
+//   k_chunk_aggregate one or two workgroups per partition walk its chunk list and aggregate into LDS tables
+//                     (slot = kh + ((p - kmin) >> 8), exact in 32-bit modular arithmetic), then merge into the global tables.
+//
+// Bytes per row: 16 read + 16 written + 16 read = 48 (was 8 + 16 + 16 + 16 = 56 plus a second scope read under a filter);
+// under a 10 % filter 24 + 1.6 + 1.6.  The host learns the scope from the same pass, decides dense / sparse exactly as before
+// (core/index.c:2013) and rfx_hip_group_dense_accumulate then finds the partitions ready (or falls back to the column passes
+// when the tables turn out not to fit: nothing here changes a result).
+#include "rfx_part_common.hpp"
+
+#define CK_FREE 0xFFFFFFFFFFFFFFFFULL
+#define CK_PARTS 256
+#define CK_SLAB_BYTES (1u << 20) /* a workgroup takes chunks from the device-wide cursor one megabyte at a time */
+#define CK_QCAP 1792             /* selective form: records queued in LDS before they are ranked and placed */
+#define CK_QTILE 1024            /* selective form: rows per tile (4 per lane, the next tile is in flight while this one is evaluated) */
+
+struct ChunkArgs {
+    int key_idx, vcol, nwg, chs; // chs: log2(records per chunk), 8..12
+    int dbg, _pad2;              // experiments only: 1 = drop every survivor, 2 = skip the predicate too
+    i64 tiles_per_wg;            // in 2048-row tiles; 0: grid-stride (tile t of workgroup b = b + t * nwg)
+    u64x2 *pool;         // chunk c = records [c << chs, (c + 1) << chs)
+    u64 *meta;           // per chunk: partition | workgroup << 8 | records << 20 | ordinal within (workgroup, partition) << 40
+    unsigned *ctl;       // [0] chunk cursor, [1] pool exhausted
+    unsigned *wcount;    // [nwg][256] chunks of (workgroup, partition); k_chunk_offsets turns them into exclusive offsets
+    u64 *part_start;     // [257] first chunk-list entry of every partition
+    u64 *plist;          // chunk lists: chunk | records << 32
+    ScopePart *parts;    // [nwg]
+    unsigned max_chunks;
+};
+
+// Per-workgroup state of the chunk-allocating write combiner.  Lane p OWNS partition p: its running state (records carried, room
+// in the current chunk, chunk count ...) lives in that lane's registers (CkLane); LDS holds only what the other lanes need to place
+// a record -- one 16-byte read each: pi[p] = {exclusive batch offset, carried, flushing now, room}, di[p] = {cursor, first new chunk}.
+struct CkDst {
+    u64 cursor;    // next record index inside the partition's current chunk (pool coordinates)
+    unsigned noff; // this batch: first new chunk of the partition, relative to tile_alloc
+    unsigned _pad;
+};
+struct CkLds {
+    unsigned cnt[CK_PARTS]; // per batch: record count per partition (rank atomics)
+    uint4 pi[CK_PARTS];     // x: exclusive offset of the partition's run in the batch, y: records carried over (< WC_B), z: records of
+                            // (carry ++ batch) that leave now (multiple of WC_B), w: records the current chunk still takes
+    CkDst di[CK_PARTS];
+    u64x2 carry[CK_PARTS][WC_B];
+    unsigned scan_w[RFX_BLOCK / RFX_WAVE];
+    unsigned tile_total, tile_alloc, slab_next, slab_end, dead;
+    ScopePart red[RFX_BLOCK / RFX_WAVE];
+};
+struct CkLane {
+    unsigned pre, room, nch, cur; // carried records, room in the current chunk (0 only before the first batch), chunks so far, current chunk
+    u64 cursor;
+    unsigned x, pf, noff;         // this batch: records, records flushing, first new chunk
+};
+
+template <typename LDS>
+__device__ __forceinline__ void ck_init(LDS &L, CkLane &M) {
+    M.pre = M.room = M.nch = M.cur = 0;
+    M.cursor = 0;
+    M.x = M.pf = M.noff = 0;
+    if (threadIdx.x == 0) {
+        L.slab_next = 0;
+        L.slab_end = 0;
+        L.dead = 0;
+    }
+}
+__device__ __forceinline__ u64 ck_meta(unsigned p, unsigned wg, unsigned nrec, unsigned ord) {
+    return (u64)p | ((u64)wg << 8) | ((u64)nrec << 20) | ((u64)ord << 40);
+}
+// LDS-only barrier: the phases exchange data through LDS alone, global loads / stores in flight need not land first
+__device__ __forceinline__ void ck_barrier() { __syncthreads(); }
+
+// One lane per partition, after the batch's per-partition counts are in cnt[]: exclusive scan of (count | new chunks << 16),
+// the flush decision, the chunk request.  Contains one barrier; the caller adds one after it.
+template <int G, typename LDS>
+__device__ __forceinline__ void ck_plan(LDS &L, CkLane &M, const ChunkArgs &A) {
+    const int tid = threadIdx.x;
+    const unsigned CH = 1u << A.chs;
+    const unsigned x = L.cnt[tid];
+    const unsigned pf = ((M.pre + x) / G) * G; // G = 1: every record leaves at once (no carry)
+    const unsigned rm = M.room;
+    const unsigned need = (pf >= rm) ? ((pf - rm) >> A.chs) + 1 : 0;
+    const unsigned packed = x | (need << 16);
+    unsigned inc = packed;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        unsigned o = __shfl_up(inc, d, 64);
+        if ((tid & 63) >= d) inc += o;
+    }
+    if ((tid & 63) == 63) L.scan_w[tid >> 6] = inc;
+    ck_barrier();
+    unsigned wbase = 0;
+    for (int w = 0; w < (tid >> 6); w++) wbase += L.scan_w[w];
+    const unsigned excl = wbase + inc - packed;
+    M.x = x;
+    M.pf = pf;
+    M.noff = excl >> 16;
+    L.pi[tid] = make_uint4(excl & 0xFFFFu, M.pre, pf, rm);
+    CkDst d;
+    d.cursor = M.cursor;
+    d.noff = M.noff;
+    d._pad = 0;
+    L.di[tid] = d;
+    if (tid == RFX_BLOCK - 1) {
+        const unsigned tot = wbase + inc;
+        L.tile_total = tot & 0xFFFFu;
+        const unsigned tn = tot >> 16;
+        if (tn) {
+            unsigned sn = L.slab_next;
+            if (sn + tn > L.slab_end) { // the rest of the old slab stays unused: its chunk metas keep CK_FREE
+                const unsigned slab = (CK_SLAB_BYTES / 16u) / CH;
+                const unsigned g = tn > slab ? tn : slab;
+                sn = atomicAdd(&A.ctl[0], g);
+                L.slab_end = sn + g;
+                if (sn + g > A.max_chunks || sn + g < sn) {
+                    L.dead = 1;
+                    atomicExch(&A.ctl[1], 1u);
+                }
+            }
+            L.tile_alloc = sn;
+            L.slab_next = sn + tn;
+        }
+    }
+}
+// where record `pos` of partition p's flush sequence goes (pos < pfl), given pi[p]
+template <typename LDS>
+__device__ __forceinline__ u64 ck_dst(const LDS &L, const ChunkArgs &A, unsigned p, unsigned pos, unsigned rm) {
+    const CkDst d = L.di[p];
+    return (pos < rm) ? d.cursor + pos : (((u64)L.tile_alloc + d.noff) << A.chs) + (pos - rm);
+}
+// old carry -> global for the partitions that flush (positions 0 .. pre-1 of their sequence)
+__device__ __forceinline__ void ck_flush_carry(const CkLds &L, const ChunkArgs &A) {
+#pragma unroll
+    for (int k = 0; k < CK_PARTS * WC_B / RFX_BLOCK; k++) {
+        const int idx = threadIdx.x + k * RFX_BLOCK;
+        const int p = idx / WC_B;
+        const unsigned j = idx % WC_B;
+        const uint4 pi = L.pi[p];
+        if (j < pi.y && pi.z > 0) A.pool[ck_dst(L, A, p, j, pi.w)] = L.carry[p][j];
+    }
+}
+// one lane per partition, after the batch's records are placed
+template <typename LDS>
+__device__ __forceinline__ void ck_update(CkLane &M, const LDS &L, const ChunkArgs &A) {
+    const int tid = threadIdx.x;
+    const unsigned CH = 1u << A.chs;
+    const unsigned pf = M.pf, rm = M.room;
+    if (pf >= rm) { // the current chunk is full (or there is none yet): the partition moves on to its new chunks
+        const unsigned k = ((pf - rm) >> A.chs) + 1;
+        const unsigned first_new = L.tile_alloc + M.noff;
+        for (unsigned j = 0; j < k; j++) A.meta[first_new + j] = ck_meta(tid, blockIdx.x, CH, M.nch + j);
+        M.nch += k;
+        const unsigned last = first_new + k - 1;
+        const unsigned used = (pf - rm) - ((k - 1) << A.chs);
+        M.cur = last;
+        M.room = CH - used;
+        M.cursor = ((u64)last << A.chs) + used;
+    } else {
+        M.room = rm - pf;
+        M.cursor += pf;
+    }
+    M.pre = M.pre + M.x - pf;
+}
+// tails (one 128-byte group per partition that still carries records: its chunk has room, room > 0 after every batch), the
+// final record count of every open chunk, the per-partition chunk counts and the workgroup's scope
+template <bool CARRY, typename LDS>
+__device__ __forceinline__ void ck_finish(LDS &L, const CkLane &M, const ChunkArgs &A, i64 mn, i64 mx, i64 sel, i64 nulls) {
+    const int tid = threadIdx.x;
+    const unsigned CH = 1u << A.chs;
+    if constexpr (CARRY) {
+        if (M.pre > 0) {
+            for (unsigned j = 0; j < WC_B; j++) A.pool[M.cursor + j] = L.carry[tid][j]; // entries j >= pre are padding: the chunk's record count ends before them
+        }
+    }
+    if (M.nch > 0) A.meta[M.cur] = ck_meta(tid, blockIdx.x, CH - M.room + M.pre, M.nch - 1);
+    A.wcount[(size_t)blockIdx.x * CK_PARTS + tid] = M.nch;
+    for (int s = 32; s >= 1; s >>= 1) {
+        const i64 omn = (i64)rfx_shfl_xor_u64((u64)mn, s), omx = (i64)rfx_shfl_xor_u64((u64)mx, s);
+        mn = omn < mn ? omn : mn;
+        mx = omx > mx ? omx : mx;
+        sel += (i64)rfx_shfl_xor_u64((u64)sel, s);
+        nulls += (i64)rfx_shfl_xor_u64((u64)nulls, s);
+    }
+    if ((tid & 63) == 0) L.red[tid >> 6] = ScopePart{mn, mx, sel, nulls};
+    __syncthreads();
+    if (tid == 0) {
+        ScopePart r = L.red[0];
+        for (int w = 1; w < RFX_BLOCK / RFX_WAVE; w++) {
+            r.mn = L.red[w].mn < r.mn ? L.red[w].mn : r.mn;
+            r.mx = L.red[w].mx > r.mx ? L.red[w].mx : r.mx;
+            r.sel += L.red[w].sel;
+            r.nulls += L.red[w].nulls;
+        }
+        A.parts[blockIdx.x] = r;
+    }
+}
+
+// 8 rows per lane of one 2048-row tile as four 16-byte loads per column; bit e of the result = row e exists
+template <int NC>
+__device__ __forceinline__ unsigned ck_load_tile(const Plan &P, i64 tile, u64 (&v)[NC][8]) {
+    const i64 base = tile * PART_TILE_ROWS + threadIdx.x * 2;
+    unsigned valid = 0xffu;
+    if ((tile + 1) * PART_TILE_ROWS <= P.nrows) {
+#pragma unroll
+        for (int c = 0; c < NC; c++) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                u64x2 q = rfx_ld2(P.cols[c] + base + (i64)j * (RFX_BLOCK * 2));
+                v[c][2 * j] = q.x;
+                v[c][2 * j + 1] = q.y;
+            }
+        }
+    } else {
+        valid = 0;
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const i64 row = base + (i64)(e >> 1) * (RFX_BLOCK * 2) + (e & 1);
+            const bool in = row < P.nrows;
+            valid |= (unsigned)in << e;
+#pragma unroll
+            for (int c = 0; c < NC; c++) v[c][e] = in ? P.cols[c][row] : 0ULL;
+        }
+    }
+    return valid;
+}
+
+// ---- every (or most) rows selected: 2048-row tiles sorted by partition in LDS, as k_part_scatter_wc ----
+template <int NC, int NP>
+__global__ __launch_bounds__(RFX_BLOCK) void k_chunk_scatter(const Plan P, const ChunkArgs A) {
+    __shared__ CkLds L;
+    __shared__ u64x2 stag[PART_TILE_ROWS];
+    __shared__ unsigned char stag_p[PART_TILE_ROWS];
+    PredSet<NP> S;
+    predset_load<NP>(P, S);
+    const int tid = threadIdx.x;
+    CkLane M;
+    ck_init(L, M);
+    i64 mn = RFX_INF_I64_D, mx = RFX_NULL_I64_D, sel = 0, nulls = 0;
+    const i64 ntiles = (P.nrows + PART_TILE_ROWS - 1) / PART_TILE_ROWS;
+    const i64 step = A.tiles_per_wg ? 1 : (i64)gridDim.x;
+    const i64 t0 = A.tiles_per_wg ? (i64)blockIdx.x * A.tiles_per_wg : (i64)blockIdx.x;
+    const i64 t1 = A.tiles_per_wg ? ((t0 + A.tiles_per_wg < ntiles) ? t0 + A.tiles_per_wg : ntiles) : ntiles;
+    const int vc = A.vcol;
+    // Two register sets, loop unrolled by two: the next tile's loads are issued before this tile's LDS phases and land while the
+    // phases run (copying an in-flight set into "the current one" would wait for it: the roles alternate instead).
+    u64 va[NC][8], vb[NC][8];
+    unsigned valid_a = 0, valid_b = 0;
+    bool alive = true;
+    auto tile_body = [&](const u64 (&v)[NC][8], const unsigned valid, const i64 t) {
+        const unsigned m = (NP == 0) ? valid : eval_preds<NC, 8, NP>(S, v, valid);
+        u64 key[8], val[8];
+        sel_col<NC, 8>(key, v, A.key_idx);
+        sel_col<NC, 8>(val, v, vc);
+        unsigned rank[8];
+        const i64 base = t * PART_TILE_ROWS + tid * 2;
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            rank[e] = 0;
+            if ((m >> e) & 1u) {
+                const i64 k = (i64)key[e];
+                rank[e] = atomicAdd(&L.cnt[key[e] & 255ULL], 1u);
+                sel++;
+                if (k == RFX_NULL_I64_D) nulls++;
+                else {
+                    mn = k < mn ? k : mn;
+                    mx = k > mx ? k : mx;
+                }
+            }
+        }
+        ck_barrier();
+        ck_plan<WC_B>(L, M, A);
+        ck_barrier();
+        if (L.dead) { // pool exhausted: the host sees ctl[1] and runs the column passes instead (uniform exit)
+            alive = false;
+            return;
+        }
+        // stage this tile's records in partition order
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            if (!((m >> e) & 1u)) continue;
+            const unsigned p = (unsigned)(key[e] & 255ULL);
+            const unsigned idx = L.pi[p].x + rank[e];
+            const u64 lrow = (u64)(base + (i64)(e >> 1) * (RFX_BLOCK * 2) + (e & 1));
+            u64x2 r;
+            r.x = (lrow << 32) | (u64)(unsigned)((i64)key[e] >> 8);
+            r.y = val[e];
+            stag[idx] = r;
+            stag_p[idx] = (unsigned char)p;
+        }
+        ck_flush_carry(L, A);
+        ck_barrier();
+        // new records: the first (pfl - pre) of a partition complete the 128-byte groups, the rest is the new carry
+        const unsigned total = L.tile_total;
+#pragma unroll
+        for (int k = 0; k < PART_TILE_ROWS / RFX_BLOCK; k++) {
+            const unsigned i = tid + k * RFX_BLOCK;
+            if (i < total) {
+                const unsigned p = stag_p[i];
+                const uint4 pi = L.pi[p];
+                const unsigned pos = pi.y + (i - pi.x);
+                if (pos < pi.z) A.pool[ck_dst(L, A, p, pos, pi.w)] = stag[i];
+                else L.carry[p][pos - pi.z] = stag[i];
+            }
+        }
+        ck_barrier();
+        ck_update(M, L, A);
+    };
+    if (t0 < t1) valid_a = ck_load_tile<NC>(P, t0, va);
+    for (i64 t = t0; t < t1; t += 2 * step) {
+        L.cnt[tid] = 0;
+        ck_barrier();
+        if (t + step < t1) valid_b = ck_load_tile<NC>(P, t + step, vb);
+        tile_body(va, valid_a, t);
+        if (!alive) return;
+        if (t + step >= t1) break;
+        L.cnt[tid] = 0;
+        ck_barrier();
+        if (t + 2 * step < t1) valid_a = ck_load_tile<NC>(P, t + 2 * step, va);
+        tile_body(vb, valid_b, t + step);
+        if (!alive) return;
+    }
+    ck_barrier();
+    ck_finish<true>(L, M, A, mn, mx, sel, nulls);
+}
+
+// ---- selective filters: a streaming kernel (4 workgroups per CU, as K1) whose survivors queue up in LDS; ranking, chunk
+// requests and placement run once per ~1000 survivors, not once per tile.  No write combining: a survivor goes straight to its
+// place in the partition's chunk -- under a selective filter the records are a small fraction of the bytes read, and the 32 KB of
+// carry buffers would halve the occupancy that the 24 B/row read needs. ----
+struct CkLdsLite {
+    unsigned cnt[CK_PARTS];
+    uint4 pi[CK_PARTS];
+    CkDst di[CK_PARTS];
+    unsigned scan_w[RFX_BLOCK / RFX_WAVE];
+    unsigned tile_total, tile_alloc, slab_next, slab_end, dead;
+    ScopePart red[RFX_BLOCK / RFX_WAVE];
+};
+template <int NC, int RPL>
+__device__ __forceinline__ unsigned ck_load_qtile(const Plan &P, i64 tile, u64 (&v)[NC][RPL]) {
+    constexpr int ROWS = RFX_BLOCK * RPL;
+    const i64 base = tile * ROWS + threadIdx.x * 2;
+    unsigned valid = (1u << RPL) - 1u;
+    if ((tile + 1) * ROWS <= P.nrows) {
+#pragma unroll
+        for (int c = 0; c < NC; c++) {
+#pragma unroll
+            for (int j = 0; j < RPL / 2; j++) {
+                u64x2 q = rfx_ld2(P.cols[c] + base + (i64)j * (RFX_BLOCK * 2));
+                v[c][2 * j] = q.x;
+                v[c][2 * j + 1] = q.y;
+            }
+        }
+    } else {
+        valid = 0;
+#pragma unroll
+        for (int e = 0; e < RPL; e++) {
+            const i64 row = base + (i64)(e >> 1) * (RFX_BLOCK * 2) + (e & 1);
+            const bool in = row < P.nrows;
+            valid |= (unsigned)in << e;
+#pragma unroll
+            for (int c = 0; c < NC; c++) v[c][e] = in ? P.cols[c][row] : 0ULL;
+        }
+    }
+    return valid;
+}
+
+#define CK_SEL_WROWS 512 /* rows per wave step: 8 per lane, four 16-byte loads per lane and column */
+#define CK_RING 8        /* chunk ids a partition keeps published */
+#define CK_SEL_THREADS 1024
+#define CK_SEL_WAVES (CK_SEL_THREADS / RFX_WAVE)
+#define CK_SEL_LDS (CK_PARTS * 16 * 16 + CK_PARTS * CK_RING * 8 + CK_PARTS * 4 * 6 + CK_SEL_WAVES * 128 * 17 + CK_SEL_WAVES * 32)
+// One 1024-lane workgroup per CU (16 waves, as many as K1 keeps resident), NO barrier and no queue shared between waves in the
+// stream: a wave evaluates its own 512-row steps, collects its survivors in a wave-private LDS queue and places them 64 at a time,
+// one per lane:
+//   * position in the (workgroup, partition) record stream: one LDS atomic, pos[p]++ ;
+//   * the record goes into the partition's LDS write-combining buffer (two groups of 8 records); the lane whose arrival completes a
+//     group stores it as ONE aligned 128-byte line (single 16-byte record stores are partial-line writes, read-modify-write at the
+//     memory side: measured 2.0 ms per 1e8 records against 0.4 ms for everything else the placement does);
+//   * the lane that draws place 0 of a chunk allocates it (one returning device atomic per CH records) and publishes its id in the
+//     partition's ring.
+// Every wait is a RETRY, never a spin inside divergent code: a lane whose precondition does not hold yet (the buffer half still
+// holds an unflushed group, the chunk id is not published yet, the ring entry is still needed) skips and tries again in the next
+// round of the loop while the lanes that can proceed do -- lanes of one wave may depend on each other.  Dependencies always point to
+// older records of the same partition, so the oldest unfinished record can always proceed; a bounded retry count turns anything
+// unforeseen into the host's fallback to the column passes instead of a hang.
+template <int NC, int NP>
+__global__ __launch_bounds__(CK_SEL_THREADS) void k_chunk_scatter_sel(const Plan P, const ChunkArgs A) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char ck_smem[];
+    u64x2(*buf)[16] = (u64x2(*)[16])ck_smem;                                         // [256][16] two groups of 8 records
+    u64(*ring)[CK_RING] = (u64(*)[CK_RING])(ck_smem + CK_PARTS * 256);                // (chunk ordinal + 1) << 32 | chunk id
+    unsigned *pos = (unsigned *)(ck_smem + CK_PARTS * 256 + CK_PARTS * CK_RING * 8); // records drawn
+    unsigned *done = pos + CK_PARTS;                                                 // records stored
+    unsigned(*arrived)[2] = (unsigned(*)[2])(done + CK_PARTS);                       // records written into the buffer half
+    unsigned(*fl)[2] = (unsigned(*)[2])(done + 3 * CK_PARTS);                        // flushes of the buffer half so far
+    u64x2(*wq)[128] = (u64x2(*)[128])(ck_smem + CK_PARTS * 256 + CK_PARTS * CK_RING * 8 + CK_PARTS * 24);
+    unsigned char(*wqp)[128] = (unsigned char(*)[128])((unsigned char *)wq + CK_SEL_WAVES * 128 * 16);
+    ScopePart *red = (ScopePart *)((unsigned char *)wqp + CK_SEL_WAVES * 128);
+    PredSet<NP> S;
+    predset_load<NP>(P, S);
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid < CK_PARTS) {
+        pos[tid] = 0;
+        done[tid] = 0;
+        arrived[tid][0] = arrived[tid][1] = 0;
+        fl[tid][0] = fl[tid][1] = 0;
+#pragma unroll
+        for (int r = 0; r < CK_RING; r++) ring[tid][r] = 0;
+    }
+    __syncthreads();
+    const unsigned chs = (unsigned)A.chs, CH = 1u << chs;
+    i64 mn = RFX_INF_I64_D, mx = RFX_NULL_I64_D, sel = 0, nulls = 0;
+    const i64 nsteps = (P.nrows + CK_SEL_WROWS - 1) / CK_SEL_WROWS;
+    const i64 nwaves = (i64)gridDim.x * CK_SEL_WAVES;
+    const int vc = A.vcol;
+    auto alloc_chunk = [&](const unsigned p, const unsigned c) -> unsigned {
+        unsigned id = atomicAdd(&A.ctl[0], 1u);
+        if (id >= A.max_chunks) { // pool exhausted: the host sees ctl[1] and runs the column passes instead
+            atomicExch(&A.ctl[1], 1u);
+            id = 0xFFFFFFFFu;
+        } else A.meta[id] = ck_meta(p, blockIdx.x, CH, c);
+        *(volatile u64 *)&ring[p][c & (CK_RING - 1)] = ((u64)(c + 1u) << 32) | (u64)id;
+        return id;
+    };
+    // the first `cnt` (<= 64) queued records of this wave, one per lane
+    auto place = [&](const unsigned cnt) {
+        const bool act = (unsigned)lane < cnt;
+        u64x2 r;
+        r.x = r.y = 0;
+        unsigned p = 0, my = 0;
+        if (act) {
+            r = wq[wv][lane];
+            p = wqp[wv][lane];
+            my = atomicAdd(&pos[p], 1u);
+        }
+        const unsigned g = my >> 3, j = my & 7u, half = g & 1u, c = my >> chs, o = my & (CH - 1u);
+        int st = act ? (o == 0 ? 0 : 1) : 3; // 0 allocate the chunk, 1 write into the buffer, 2 flush the group, 3 finished
+        unsigned tries = 0;
+        while (__ballot(st != 3)) {
+            if (st == 0) { // ring entry c & 7 still names chunk c - 8 until all of that chunk's records are stored
+                if (c < CK_RING || *(volatile unsigned *)&done[p] >= ((c - CK_RING + 1u) << chs)) {
+                    alloc_chunk(p, c);
+                    st = 1;
+                }
+            }
+            if (st == 1) { // the buffer half is free once group g - 2 has left it
+                if (*(volatile unsigned *)&fl[p][half] >= (g >> 1)) {
+                    buf[p][half * 8 + j] = r;
+                    st = (atomicAdd(&arrived[p][half], 1u) == 7u) ? 2 : 3;
+                }
+            }
+            // last arrivals of their groups: the groups leave as aligned 128-byte lines, eight lanes per group (one 16-byte record each,
+            // one store instruction for up to eight lines) -- a lane storing its whole group alone costs eight instructions at 1/8 occupancy
+            bool ready = false, want = false;
+            u64 dsti = 0;
+            if (st == 2) {
+                const u64 ent = *(volatile u64 *)&ring[p][c & (CK_RING - 1)];
+                if ((ent >> 32) == (u64)(c + 1u)) {
+                    ready = true;
+                    const unsigned id = (unsigned)ent;
+                    want = id != 0xFFFFFFFFu && !(A.dbg & 2);
+                    dsti = ((u64)id << chs) + (o - j);
+                }
+            }
+            const u64 fb = __ballot(ready);
+            if (fb) { // wave-uniform
+                if (ready) { // the queue's first 64 entries are in registers by now: their LDS space carries the flush descriptors
+                    const unsigned fr = __builtin_amdgcn_mbcnt_hi((unsigned)(fb >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)fb, 0u));
+                    u64x2 d;
+                    d.x = dsti;
+                    d.y = (u64)p | ((u64)half << 8) | ((u64)want << 16);
+                    wq[wv][fr] = d;
+                }
+                const unsigned nfl = (unsigned)__popcll(fb);
+                for (unsigned f0 = 0; f0 < nfl; f0 += 8) {
+                    const unsigned f = f0 + ((unsigned)lane >> 3), k = (unsigned)lane & 7u;
+                    if (f < nfl) {
+                        const u64x2 d = wq[wv][f];
+                        const u64x2 rec = buf[(unsigned)d.y & 255u][(((unsigned)d.y >> 8) & 1u) * 8 + k];
+                        if ((d.y >> 16) & 1ULL) A.pool[d.x + k] = rec;
+                    }
+                }
+                if (ready) {
+                    arrived[p][half] = 0;
+                    atomicAdd(&fl[p][half], 1u);
+                    atomicAdd(&done[p], 8u);
+                    st = 3;
+                }
+            }
+            if (++tries >= (1u << 20)) { // never seen; a stuck wave must not hang the device: the host falls back
+                atomicExch(&A.ctl[1], 1u);
+                break;
+            }
+            if (tries > 4) __builtin_amdgcn_s_sleep(2);
+        }
+    };
+    unsigned qn = 0; // queued records of this wave (wave-uniform)
+    for (i64 ws = (i64)blockIdx.x * CK_SEL_WAVES + wv; ws < nsteps; ws += nwaves) {
+        u64 v[NC][8];
+        const i64 base = ws * CK_SEL_WROWS + lane * 2;
+        unsigned valid = 0xffu;
+        if ((ws + 1) * CK_SEL_WROWS <= P.nrows) {
+#pragma unroll
+            for (int c = 0; c < NC; c++) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    u64x2 t = rfx_ld2(P.cols[c] + base + j * 128);
+                    v[c][2 * j] = t.x;
+                    v[c][2 * j + 1] = t.y;
+                }
+            }
+        } else {
+            valid = 0;
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const i64 row = base + (e >> 1) * 128 + (e & 1);
+                const bool in = row < P.nrows;
+                valid |= (unsigned)in << e;
+#pragma unroll
+                for (int c = 0; c < NC; c++) v[c][e] = in ? P.cols[c][row] : 0ULL;
+            }
+        }
+        unsigned m = (NP == 0) ? valid : eval_preds<NC, 8, NP>(S, v, valid);
+        if (A.dbg & 1) m &= (unsigned)(v[0][0] == 0x123456789ULL);
+        if (__ballot(m != 0) == 0) continue;
+        u64 key[8], val[8];
+        sel_col<NC, 8>(key, v, A.key_idx);
+        sel_col<NC, 8>(val, v, vc);
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const bool s = (m >> e) & 1u;
+            const u64 b = __ballot(s);
+            if (b == 0) continue; // wave-uniform
+            if (s) {
+                const unsigned at = qn + __builtin_amdgcn_mbcnt_hi((unsigned)(b >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b, 0u));
+                const i64 k = (i64)key[e];
+                const u64 lrow = (u64)(base + (e >> 1) * 128 + (e & 1));
+                u64x2 r;
+                r.x = (lrow << 32) | (u64)(unsigned)(k >> 8);
+                r.y = val[e];
+                wq[wv][at] = r;
+                wqp[wv][at] = (unsigned char)(key[e] & 255ULL);
+                sel++;
+                if (k == RFX_NULL_I64_D) nulls++;
+                else {
+                    mn = k < mn ? k : mn;
+                    mx = k > mx ? k : mx;
+                }
+            }
+            qn += (unsigned)__popcll(b);
+            if (qn >= 64) { // wave-uniform
+                place(64);
+                const unsigned rest = qn - 64;
+                u64x2 tr;
+                unsigned char tp = 0;
+                tr.x = tr.y = 0;
+                if ((unsigned)lane < rest) {
+                    tr = wq[wv][64 + lane];
+                    tp = wqp[wv][64 + lane];
+                }
+                if ((unsigned)lane < rest) {
+                    wq[wv][lane] = tr;
+                    wqp[wv][lane] = tp;
+                }
+                qn = rest;
+            }
+        }
+    }
+    place(qn);
+    __syncthreads();
+    if (tid < CK_PARTS) {
+        const unsigned n = pos[tid];
+        const unsigned nch = (n + CH - 1u) >> chs;
+        if (n & 7u) { // the stream's last group is partly filled: store it padded (the chunk's record count ends before the padding)
+            const unsigned g = n >> 3, half = g & 1u, gb = g << 3, c = gb >> chs, o0 = gb & (CH - 1u);
+            const unsigned id = (unsigned)ring[tid][c & (CK_RING - 1)]; // place gb < n was drawn, so whoever drew the chunk's place 0 has published it
+            if (id != 0xFFFFFFFFu) {
+                u64x2 *dst = A.pool + ((u64)id << chs) + o0;
+#pragma unroll
+                for (int k = 0; k < 8; k++) dst[k] = buf[tid][half * 8 + k];
+            }
+        }
+        if (n & (CH - 1u)) { // the stream's last chunk is partly filled
+            const unsigned c = nch - 1u;
+            const unsigned id = (unsigned)ring[tid][c & (CK_RING - 1)];
+            if (id != 0xFFFFFFFFu) A.meta[id] = ck_meta(tid, blockIdx.x, n & (CH - 1u), c);
+        }
+        A.wcount[(size_t)blockIdx.x * CK_PARTS + tid] = nch;
+    }
+    for (int s = 32; s >= 1; s >>= 1) {
+        const i64 omn = (i64)rfx_shfl_xor_u64((u64)mn, s), omx = (i64)rfx_shfl_xor_u64((u64)mx, s);
+        mn = omn < mn ? omn : mn;
+        mx = omx > mx ? omx : mx;
+        sel += (i64)rfx_shfl_xor_u64((u64)sel, s);
+        nulls += (i64)rfx_shfl_xor_u64((u64)nulls, s);
+    }
+    if (lane == 0) red[wv] = ScopePart{mn, mx, sel, nulls};
+    __syncthreads();
+    if (tid == 0) {
+        ScopePart r = red[0];
+        for (int w = 1; w < CK_SEL_WAVES; w++) {
+            r.mn = red[w].mn < r.mn ? red[w].mn : r.mn;
+            r.mx = red[w].mx > r.mx ? red[w].mx : r.mx;
+            r.sel += red[w].sel;
+            r.nulls += red[w].nulls;
+        }
+        A.parts[blockIdx.x] = r;
+    }
+}
+
+// wcount[w][p] -> exclusive offset of (w, p) inside partition p's chunk list; part_start[p] = first entry of partition p.
+__global__ __launch_bounds__(1024) void k_chunk_offsets(const ChunkArgs A) {
+    __shared__ unsigned slice_sum[4][CK_PARTS];
+    __shared__ u64 tot[CK_PARTS];
+    const int p = threadIdx.x & 255, sl = threadIdx.x >> 8;
+    const int per = (A.nwg + 3) / 4;
+    const int w0 = sl * per, w1 = (w0 + per < A.nwg) ? w0 + per : A.nwg;
+    unsigned sum = 0;
+    for (int w = w0; w < w1; w++) sum += A.wcount[(size_t)w * CK_PARTS + p];
+    slice_sum[sl][p] = sum;
+    __syncthreads();
+    unsigned run = 0, total = 0;
+    for (int s2 = 0; s2 < 4; s2++) {
+        const unsigned v = slice_sum[s2][p];
+        if (s2 < sl) run += v;
+        total += v;
+    }
+    for (int w = w0; w < w1; w++) {
+        const size_t i = (size_t)w * CK_PARTS + p;
+        const unsigned c = A.wcount[i];
+        A.wcount[i] = run;
+        run += c;
+    }
+    if (sl == 0) tot[p] = total;
+    __syncthreads();
+    for (int s = 1; s < CK_PARTS; s <<= 1) {
+        u64 add = 0;
+        if (sl == 0 && p >= s) add = tot[p - s];
+        __syncthreads();
+        if (sl == 0) tot[p] += add;
+        __syncthreads();
+    }
+    if (sl == 0) {
+        A.part_start[p + 1] = tot[p];
+        if (p == 0) A.part_start[0] = 0;
+    }
+}
+
+__global__ __launch_bounds__(RFX_BLOCK) void k_chunk_place(const ChunkArgs A) {
+    const unsigned n = A.ctl[0] < A.max_chunks ? A.ctl[0] : A.max_chunks;
+    for (unsigned c = blockIdx.x * RFX_BLOCK + threadIdx.x; c < n; c += gridDim.x * RFX_BLOCK) {
+        const u64 m = A.meta[c];
+        if (m == CK_FREE) continue;
+        const unsigned p = (unsigned)(m & 255ULL), w = (unsigned)((m >> 8) & 0xFFFULL), nrec = (unsigned)((m >> 20) & 0xFFFFFULL), ord = (unsigned)(m >> 40);
+        A.plist[A.part_start[p] + A.wcount[(size_t)w * CK_PARTS + p] + ord] = (u64)c | ((u64)nrec << 32);
+    }
+}
+
+// ---- per-partition LDS aggregation over a chunk list (one value plane) ----
+struct ChunkAggArgs {
+    i64 kmin, range;
+    i64 local;  // table cells per partition: slots congruent to one residue mod 256
+    int split;  // workgroups per partition
+    int chs;    // log2(records per chunk)
+    const u64x2 *pool;
+    const u64 *part_start;
+    const u64 *plist;
+    u64 *first;
+    u64 *acc[RFX_MAX_AGGS];
+    u64 *cnt[RFX_MAX_AGGS];
+};
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void k_chunk_aggregate(const Plan P, const ChunkAggArgs A) {
+    extern __shared__ __attribute__((aligned(16))) u64 smem[];
+    const int tid = threadIdx.x;
+    const int p = blockIdx.x / A.split, s = blockIdx.x % A.split;
+    const i64 local = A.local;
+    int kind[RFX_MAX_AGGS], f64[RFX_MAX_AGGS], arr_of[RFX_MAX_AGGS], skip[RFX_MAX_AGGS], hasv[RFX_MAX_AGGS];
+    {
+        int arr = 1;
+#pragma unroll
+        for (int a = 0; a < RFX_MAX_AGGS; a++) {
+            kind[a] = (a < P.nagg) ? P.aggs[a].kind : -1;
+            f64[a] = (a < P.nagg) ? P.aggs[a].f64 : 0;
+            skip[a] = (a < P.nagg) ? P.aggs[a].skipnull : 0;
+            hasv[a] = (a < P.nagg) ? (P.aggs[a].col >= 0) : 0;
+            arr_of[a] = arr;
+            if (kind[a] >= 0) arr += agg_has_cnt(kind[a], f64[a]) ? 2 : 1;
+        }
+    }
+    for (i64 i = tid; i < local; i += THREADS) smem[i] = (u64)RFX_INF_I64_D;
+#pragma unroll
+    for (int a = 0; a < RFX_MAX_AGGS; a++) {
+        if (kind[a] < 0) continue;
+        const u64 id = acc_identity(kind[a], f64[a]);
+        for (i64 i = tid; i < local; i += THREADS) smem[(i64)arr_of[a] * local + i] = id;
+        if (agg_has_cnt(kind[a], f64[a])) {
+            for (i64 i = tid; i < local; i += THREADS) smem[(i64)(arr_of[a] + 1) * local + i] = 0;
+        }
+    }
+    __syncthreads();
+    const u64 beg = A.part_start[p], end = A.part_start[p + 1];
+    const u64 len = end - beg;
+    const u64 per = (len + A.split - 1) / A.split;
+    const u64 b0 = beg + per * s;
+    const u64 b1 = (b0 + per < end) ? (b0 + per) : end;
+    const u64 row0 = (u64)P.row0;
+    const unsigned shift = (unsigned)(((i64)p - A.kmin) >> 8); // slot = (key - kmin) >> 8 = kh + floor((p - kmin) / 256), key = kh * 256 + p
+    constexpr int RU = 4; // records in flight per lane
+    const unsigned chs = (unsigned)A.chs;
+    const u64 vend = (b1 - b0) << chs; // the chunk list as one virtual record range
+    // chunk-list entries are fetched one step ahead: the record loads of a step never wait on a dependent load
+    u64 ent[RU];
+#pragma unroll
+    for (int r = 0; r < RU; r++) {
+        const u64 vi = (u64)r * THREADS + tid;
+        ent[r] = (vi < vend) ? A.plist[b0 + (vi >> chs)] : 0ULL;
+    }
+    for (u64 v0 = 0; v0 < vend; v0 += (u64)THREADS * RU) {
+        u64x2 q[RU];
+        bool in[RU];
+#pragma unroll
+        for (int r = 0; r < RU; r++) {
+            const u64 vi = v0 + (u64)r * THREADS + tid;
+            const unsigned rec = (unsigned)vi & ((1u << chs) - 1u);
+            in[r] = vi < vend && rec < (unsigned)(ent[r] >> 32);
+            q[r].x = 0;
+            q[r].y = 0;
+            if (in[r]) {
+                typedef u64 v2 __attribute__((ext_vector_type(2)));
+                const v2 t = __builtin_nontemporal_load((const v2 *)(A.pool + ((ent[r] & 0xFFFFFFFFULL) << chs) + rec));
+                q[r].x = t.x;
+                q[r].y = t.y;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < RU; r++) {
+            const u64 vi = v0 + (u64)THREADS * RU + (u64)r * THREADS + tid;
+            ent[r] = (vi < vend) ? A.plist[b0 + (vi >> chs)] : 0ULL;
+        }
+#pragma unroll
+        for (int r = 0; r < RU; r++) {
+            if (!in[r]) continue;
+            const u64 slot = (u64)(unsigned)((unsigned)q[r].x + shift);
+            if (slot >= (u64)local) continue; // a key outside the scope the tables were sized for: not ours
+            const u64 row = row0 + (q[r].x >> 32);
+            if (row < smem[slot]) atomicMin((unsigned long long *)&smem[slot], (unsigned long long)row);
+#pragma unroll
+            for (int a = 0; a < RFX_MAX_AGGS; a++) {
+                if (kind[a] < 0) continue;
+                group_apply(&smem[(i64)arr_of[a] * local + slot], &smem[(i64)(arr_of[a] + 1) * local + slot], kind[a], f64[a], hasv[a] ? q[r].y : 0ULL, skip[a]);
+            }
+        }
+    }
+    __syncthreads();
+    for (i64 i = tid; i < local; i += THREADS) {
+        const u64 f = smem[i];
+        if (f == (u64)RFX_INF_I64_D) continue;
+        const i64 g = (i << 8) | (i64)(((u64)p - (u64)A.kmin) & 255ULL);
+        if (g >= A.range) continue;
+        if (f < A.first[g]) atomicMin((unsigned long long *)&A.first[g], (unsigned long long)f);
+#pragma unroll
+        for (int a = 0; a < RFX_MAX_AGGS; a++) {
+            if (kind[a] < 0) continue;
+            const bool hc = agg_has_cnt(kind[a], f64[a]);
+            group_merge_cell(&A.acc[a][g], hc ? &A.cnt[a][g] : (u64 *)0, kind[a], f64[a], smem[(i64)arr_of[a] * local + i],
+                             hc ? smem[(i64)(arr_of[a] + 1) * local + i] : 0ULL);
+        }
+    }
+}
+
+// ---- strided sample: a first guess of the key range and of the filter's selectivity, only to choose the pass (never a result) ----
+template <int NC>
+__global__ __launch_bounds__(RFX_BLOCK) void k_scope_sample(const Plan P, int key_idx, i64 stride, i64 nsamp, i64 *__restrict__ out) {
+    __shared__ i64 red[3][RFX_BLOCK / RFX_WAVE];
+    PredSet<RFX_MAX_PREDS> S;
+    predset_load<RFX_MAX_PREDS>(P, S);
+    i64 mn = RFX_INF_I64_D, mx = RFX_NULL_I64_D, sel = 0;
+    for (i64 i = (i64)blockIdx.x * RFX_BLOCK + threadIdx.x; i < nsamp; i += (i64)gridDim.x * RFX_BLOCK) {
+        const i64 r = i * stride;
+        if (r >= P.nrows) break;
+        u64 v[NC][1];
+#pragma unroll
+        for (int c = 0; c < NC; c++) v[c][0] = P.cols[c][r];
+        u64 key[1];
+        sel_col<NC, 1>(key, v, key_idx);
+        const i64 k = (i64)key[0];
+        mn = k < mn ? k : mn;
+        mx = k > mx ? k : mx;
+        sel += (P.npred == 0) ? 1 : (i64)(eval_preds<NC, 1, RFX_MAX_PREDS>(S, v, 1u) & 1u);
+    }
+    for (int s = 32; s >= 1; s >>= 1) {
+        const i64 omn = (i64)rfx_shfl_xor_u64((u64)mn, s), omx = (i64)rfx_shfl_xor_u64((u64)mx, s);
+        mn = omn < mn ? omn : mn;
+        mx = omx > mx ? omx : mx;
+        sel += (i64)rfx_shfl_xor_u64((u64)sel, s);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        red[0][threadIdx.x >> 6] = mn;
+        red[1][threadIdx.x >> 6] = mx;
+        red[2][threadIdx.x >> 6] = sel;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < RFX_BLOCK / RFX_WAVE; w++) {
+            mn = red[0][w] < mn ? red[0][w] : mn;
+            mx = red[1][w] > mx ? red[1][w] : mx;
+            sel += red[2][w];
+        }
+        out[4 * blockIdx.x] = mn;
+        out[4 * blockIdx.x + 1] = mx;
+        out[4 * blockIdx.x + 2] = sel;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+int rfx_chunk_reserve(rfx_ctx *c, size_t bytes);
+
+static void chunk_pred_sig(const Plan &P, u64 (*sig)[6]) {
+    for (int i = 0; i < P.npred; i++) {
+        const PlanPred &q = P.preds[i];
+        sig[i][0] = (u64)(uintptr_t)P.cols[q.col];
+        sig[i][1] = q.rhs_col >= 0 ? (u64)(uintptr_t)P.cols[q.rhs_col] : 0;
+        sig[i][2] = (u64)q.op;
+        sig[i][3] = (u64)(q.dom_f64 | (q.lhs_cvt << 1) | (q.rhs_cvt << 2));
+        sig[i][4] = q.rhs_bits;
+        sig[i][5] = 0;
+    }
+}
+
+static int narr_of(const Plan &P) {
+    int narr = 1;
+    for (int a = 0; a < P.nagg; a++) narr += 1 + (agg_has_cnt(P.aggs[a].kind, P.aggs[a].f64) ? 1 : 0);
+    return narr;
+}
+
+// The single value plane of a plan: every aggregate reads the same column (or none).  -1: no plane / several.
+static int single_value_col(const Plan &P) {
+    int vc = -1;
+    for (int a = 0; a < P.nagg; a++) {
+        const PlanAgg &ag = P.aggs[a];
+        if (ag.kind == RFX_AGG_COUNT || ag.kind == RFX_AGG_FIRST || ag.col < 0) continue;
+        if (ag.col >= RFX_XCOL) return -1;
+        if (vc >= 0 && vc != ag.col) return -1;
+        vc = ag.col;
+    }
+    return vc;
+}
+
+template <int NC, int NP>
+static int launch_chunk_scatter_sel(rfx_ctx *c, const Plan &P, const ChunkArgs &A) {
+    static bool attr_set = false; // per instantiation
+    if (!attr_set) {
+        RFX_HIP_CHECK(hipFuncSetAttribute((const void *)k_chunk_scatter_sel<NC, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, CK_SEL_LDS));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_chunk_scatter_sel<NC, NP>), dim3(A.nwg), dim3(CK_SEL_THREADS), CK_SEL_LDS, c->stream, P, A);
+    return RFX_OK;
+}
+template <int NC>
+static int launch_chunk_scatter(rfx_ctx *c, const Plan &P, const ChunkArgs &A, bool selective) {
+    if (P.npred == 0) hipLaunchKernelGGL((k_chunk_scatter<NC, 0>), dim3(A.nwg), dim3(RFX_BLOCK), 0, c->stream, P, A);
+    else if (selective) {
+        if (P.npred == 1) return launch_chunk_scatter_sel<NC, 1>(c, P, A);
+        if (P.npred <= 3) return launch_chunk_scatter_sel<NC, 3>(c, P, A);
+        return launch_chunk_scatter_sel<NC, RFX_MAX_PREDS>(c, P, A);
+    } else if (P.npred <= 2) hipLaunchKernelGGL((k_chunk_scatter<NC, 2>), dim3(A.nwg), dim3(RFX_BLOCK), 0, c->stream, P, A);
+    else hipLaunchKernelGGL((k_chunk_scatter<NC, RFX_MAX_PREDS>), dim3(A.nwg), dim3(RFX_BLOCK), 0, c->stream, P, A);
+    return RFX_OK;
+}
+
+static size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+// the scratch block: [ctl 256 B][scope partials][chunk counts][part_start][metas][chunk lists][record pool]
+static void chunk_layout(rfx_ctx *c, int nwg, size_t max_chunks, ChunkArgs *A, size_t *total) {
+    const size_t o_parts = 256, o_wcount = o_parts + al256((size_t)nwg * sizeof(ScopePart));
+    const size_t o_start = o_wcount + al256((size_t)nwg * CK_PARTS * 4), o_meta = o_start + al256((CK_PARTS + 2) * 8);
+    const size_t o_plist = o_meta + al256(max_chunks * 8), o_pool = o_plist + al256(max_chunks * 8);
+    if (total) *total = o_pool + ((max_chunks << A->chs) * 16);
+    char *w = (char *)c->d_chunk;
+    A->nwg = nwg;
+    A->ctl = (unsigned *)w;
+    A->parts = (ScopePart *)(w + o_parts);
+    A->wcount = (unsigned *)(w + o_wcount);
+    A->part_start = (u64 *)(w + o_start);
+    A->meta = (u64 *)(w + o_meta);
+    A->plist = (u64 *)(w + o_plist);
+    A->pool = (u64x2 *)(w + o_pool);
+    A->max_chunks = (unsigned)max_chunks;
+}
+
+// Scope pass that also partitions.  RFX_ESTATE: not applicable, the caller runs the plain scope pass.
+int rfx_chunk_scope(rfx_ctx *c, const int64_t *d_key, const rfx_pred_t *preds, int npred, int logic, const rfx_agg_t *aggs, int nagg, i64 nrows,
+                    i64 *kmin, i64 *kmax, i64 *seen) {
+    c->ck_valid = 0;
+    if ((c->flags & (RFX_TUNE_NO_PARTITION | RFX_TUNE_NO_CHUNK)) || nrows >= (1LL << 32) || nrows < ((c->flags & RFX_TUNE_CHUNK_SMALL) ? (1LL << 16) : (1LL << 22)) || nagg < 1) return RFX_ESTATE;
+    Plan P;
+    int key_idx = 0;
+    int rc = rfx_plan_build(&P, preds, npred, logic, aggs, nagg, d_key, &key_idx, nrows, 0);
+    if (rc != RFX_OK) return RFX_ESTATE; // the accumulate call reports it
+    if (P.nx > 0 || P.ncols > 4) return RFX_ESTATE;
+    const int vc = single_value_col(P);
+    if (vc < 0) return RFX_ESTATE;
+    const int narr = narr_of(P);
+    // a strided sample guesses the key range and the selectivity: only ranges whose tables overflow one workgroup's LDS but fit
+    // 256 partitions come here (the LDS-direct kernel is one pass already; wider ranges need more partitions than the low 8 bits give)
+    const i64 nsamp = 1 << 14;
+    const int sgrid = 16;
+    rc = rfx_ws_reserve(c, (size_t)sgrid * 32);
+    if (rc != RFX_OK) return rc;
+    switch (P.ncols) {
+        case 1: hipLaunchKernelGGL(k_scope_sample<1>, dim3(sgrid), dim3(RFX_BLOCK), 0, c->stream, P, key_idx, nrows / nsamp, nsamp, (i64 *)c->d_ws); break;
+        case 2: hipLaunchKernelGGL(k_scope_sample<2>, dim3(sgrid), dim3(RFX_BLOCK), 0, c->stream, P, key_idx, nrows / nsamp, nsamp, (i64 *)c->d_ws); break;
+        case 3: hipLaunchKernelGGL(k_scope_sample<3>, dim3(sgrid), dim3(RFX_BLOCK), 0, c->stream, P, key_idx, nrows / nsamp, nsamp, (i64 *)c->d_ws); break;
+        default: hipLaunchKernelGGL(k_scope_sample<4>, dim3(sgrid), dim3(RFX_BLOCK), 0, c->stream, P, key_idx, nrows / nsamp, nsamp, (i64 *)c->d_ws); break;
+    }
+    RFX_HIP_CHECK(hipGetLastError());
+    i64 *hs = (i64 *)c->h_pin;
+    RFX_HIP_CHECK(hipMemcpyAsync(hs, c->d_ws, (size_t)sgrid * 32, hipMemcpyDeviceToHost, c->stream));
+    RFX_HIP_CHECK(hipStreamSynchronize(c->stream));
+    i64 smn = RFX_INF_I64_D, smx = RFX_NULL_I64_D, ssel = 0;
+    for (int i = 0; i < sgrid; i++) {
+        smn = hs[4 * i] < smn ? hs[4 * i] : smn;
+        smx = hs[4 * i + 1] > smx ? hs[4 * i + 1] : smx;
+        ssel += hs[4 * i + 2];
+    }
+    if (smn == RFX_NULL_I64_D || smx < smn || ssel == 0) return RFX_ESTATE;
+    const unsigned long long est = (unsigned long long)smx - (unsigned long long)smn + 1ULL;
+    if (est == 0 || est > (1ULL << 40)) return RFX_ESTATE;
+    if ((size_t)est * 12 <= (size_t)150 * 1024) return RFX_ESTATE;                                    // LDS-direct territory
+    if ((size_t)((est + 255) >> 8) * narr * 8 > (size_t)PART_LDS_BIG_BYTES) return RFX_ESTATE;         // needs more than 256 partitions
+    const double frac = (double)ssel / (double)nsamp;
+    i64 est_rows = (i64)((double)nrows * (frac * 1.5 + 0.02));
+    if (est_rows > nrows || npred == 0) est_rows = nrows;
+    if (est > (unsigned long long)est_rows * 2) return RFX_ESTATE;                                    // sparse keys: the hashed path
+    const bool selective = npred > 0 && frac <= 0.5;
+    const i64 ntiles = (nrows + PART_TILE_ROWS - 1) / PART_TILE_ROWS;
+    int nwg = c->num_cus * (selective ? 1 : 2); // what the kernels' LDS lets a CU hold (the selective form: one 1024-lane workgroup)
+    if ((i64)nwg * 16 > ntiles) nwg = (int)((ntiles + 15) / 16);
+    const i64 tpw = (ntiles + nwg - 1) / nwg;
+    nwg = (int)((ntiles + tpw - 1) / tpw);
+    ChunkArgs A;
+    memset(&A, 0, sizeof(A));
+    // records per chunk: about a third of what one (workgroup, partition) will see, 256 .. 2048 (4 .. 32 KB); the selective form
+    // allocates chunk by chunk from the device-wide cursor and wants few, large ones
+    A.chs = 8;
+    while (A.chs < 11 && (est_rows / ((i64)nwg * CK_PARTS)) / 3 >= (2LL << A.chs)) A.chs++;
+    if (selective && A.chs < 10) A.chs = 10;
+    const size_t CH = (size_t)1 << A.chs;
+    const size_t slab = (CK_SLAB_BYTES / 16) / CH;
+    const size_t data_chunks = (size_t)((est_rows + (i64)CH - 1) / (i64)CH);
+    const size_t max_chunks = data_chunks + data_chunks / 4 + (size_t)nwg * (CK_PARTS + 2 * slab) + 1024;
+    if (max_chunks >= (1ULL << 32)) return RFX_ESTATE;
+    size_t need = 0;
+    chunk_layout(c, nwg, max_chunks, &A, &need);
+    rc = rfx_chunk_reserve(c, need);
+    if (rc != RFX_OK) return RFX_ESTATE; // no room for the pool: the column passes need less
+    chunk_layout(c, nwg, max_chunks, &A, NULL);
+    A.key_idx = key_idx;
+    A.vcol = vc;
+    A.tiles_per_wg = (c->flags & RFX_TUNE_CHUNK_CONTIG) ? tpw : 0;
+    A.dbg = (c->flags >> 17) & 3;
+    RFX_HIP_CHECK(hipMemsetAsync(A.ctl, 0, 256, c->stream));
+    RFX_HIP_CHECK(hipMemsetAsync(A.meta, 0xFF, max_chunks * 8, c->stream));
+    RFX_KERNEL_BEGIN(c);
+    switch (P.ncols) {
+        case 1: rc = launch_chunk_scatter<1>(c, P, A, selective); break;
+        case 2: rc = launch_chunk_scatter<2>(c, P, A, selective); break;
+        case 3: rc = launch_chunk_scatter<3>(c, P, A, selective); break;
+        default: rc = launch_chunk_scatter<4>(c, P, A, selective); break;
+    }
+    if (rc != RFX_OK) return rc;
+    RFX_KERNEL_END(c);
+    RFX_HIP_CHECK(hipGetLastError());
+    RFX_REQUIRE((size_t)nwg * sizeof(ScopePart) + 16 <= c->pin_bytes, RFX_ELIMIT, "pinned staging too small");
+    ScopePart *h = (ScopePart *)c->h_pin;
+    unsigned *hctl = (unsigned *)((char *)c->h_pin + (size_t)nwg * sizeof(ScopePart));
+    RFX_HIP_CHECK(hipMemcpyAsync(h, A.parts, (size_t)nwg * sizeof(ScopePart), hipMemcpyDeviceToHost, c->stream));
+    RFX_HIP_CHECK(hipMemcpyAsync(hctl, A.ctl, 8, hipMemcpyDeviceToHost, c->stream));
+    RFX_HIP_CHECK(hipStreamSynchronize(c->stream));
+    if (hctl[1]) return RFX_ESTATE; // pool exhausted (the sample underestimated the selection): plain passes
+    i64 mn = RFX_INF_I64_D, mx = RFX_NULL_I64_D, sel = 0, nulls = 0;
+    for (int i = 0; i < nwg; i++) {
+        mn = h[i].mn < mn ? h[i].mn : mn;
+        mx = h[i].mx > mx ? h[i].mx : mx;
+        sel += h[i].sel;
+        nulls += h[i].nulls;
+    }
+    *seen = sel;
+    if (nulls > 0) { // a null key is the value INT64_MIN for index_scope_i64
+        mn = RFX_NULL_I64_D;
+        if (nulls == sel) mx = RFX_NULL_I64_D;
+    }
+    *kmin = mn;
+    *kmax = mx;
+    if (sel > 0 && nulls == 0) {
+        c->ck_valid = 1;
+        c->ck_key = d_key;
+        c->ck_val = (const void *)P.cols[vc];
+        c->ck_nrows = nrows;
+        c->ck_npred = npred;
+        c->ck_logic = logic;
+        c->ck_nwg = nwg;
+        c->ck_tpw = tpw;
+        c->ck_chs = A.chs;
+        c->ck_max_chunks = max_chunks;
+        chunk_pred_sig(P, c->ck_sig);
+    }
+    return RFX_OK;
+}
+
+// Pass 2 over the partitions rfx_chunk_scope left, if they are the partitions of exactly this plan.  RFX_ESTATE: not so.
+int rfx_chunk_accumulate(rfx_ctx *c, const Plan &P, int key_idx, const rfx_group_tables_t *t) {
+    if (!c->ck_valid) return RFX_ESTATE;
+    bool ok = c->ck_key == (const void *)P.cols[key_idx] && c->ck_nrows == P.nrows && c->ck_npred == P.npred && c->ck_logic == P.logic && P.nx == 0;
+    const int vc = ok ? single_value_col(P) : -1;
+    ok = ok && vc >= 0 && c->ck_val == (const void *)P.cols[vc];
+    if (ok && P.npred > 0) {
+        u64 sig[RFX_MAX_PREDS][6];
+        chunk_pred_sig(P, sig);
+        ok = memcmp(sig, c->ck_sig, sizeof(u64) * 6 * (size_t)P.npred) == 0;
+    }
+    c->ck_valid = 0; // consumed (or stale) either way
+    if (!ok || t->range <= 256) return RFX_ESTATE;
+    const int narr = narr_of(P);
+    const i64 local = (t->range + 255) >> 8;
+    const size_t lds = (size_t)narr * (size_t)local * 8;
+    if (lds > PART_LDS_BIG_BYTES) return RFX_ESTATE;
+    ChunkArgs A;
+    memset(&A, 0, sizeof(A));
+    A.chs = c->ck_chs;
+    chunk_layout(c, c->ck_nwg, c->ck_max_chunks, &A, NULL);
+    ChunkAggArgs G;
+    memset(&G, 0, sizeof(G));
+    G.kmin = t->kmin;
+    G.range = t->range;
+    G.local = local;
+    G.chs = A.chs;
+    G.pool = A.pool;
+    G.part_start = A.part_start;
+    G.plist = A.plist;
+    G.first = (u64 *)t->d_first;
+    for (int a = 0; a < t->nagg; a++) {
+        G.acc[a] = (u64 *)t->d_acc[a];
+        G.cnt[a] = (u64 *)t->d_cnt[a];
+    }
+    RFX_KERNEL_BEGIN(c);
+    hipLaunchKernelGGL(k_chunk_offsets, dim3(1), dim3(1024), 0, c->stream, A);
+    int pgrid = (int)((c->ck_max_chunks + RFX_BLOCK - 1) / RFX_BLOCK);
+    if (pgrid > c->num_cus * 8) pgrid = c->num_cus * 8;
+    hipLaunchKernelGGL(k_chunk_place, dim3(pgrid), dim3(RFX_BLOCK), 0, c->stream, A);
+    if (lds > PART_LDS_BYTES) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            RFX_HIP_CHECK(hipFuncSetAttribute((const void *)k_chunk_aggregate<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr_set = true;
+        }
+        G.split = 1;
+        hipLaunchKernelGGL((k_chunk_aggregate<1024>), dim3(CK_PARTS), dim3(1024), lds, c->stream, P, G);
+    } else {
+        G.split = (2 * c->num_cus + CK_PARTS - 1) / CK_PARTS;
+        if (G.split < 1) G.split = 1;
+        hipLaunchKernelGGL((k_chunk_aggregate<512>), dim3(CK_PARTS * G.split), dim3(512), lds, c->stream, P, G);
+    }
+    RFX_KERNEL_END(c);
+    RFX_HIP_CHECK(hipGetLastError());
+    return RFX_OK;
+}

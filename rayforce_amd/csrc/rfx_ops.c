@@ -735,7 +735,7 @@ rfx_obj_p rfx_select(rfx_obj_p dict) {
                     }
                     }
                 }
-            } else if (rfx_hip_scope_i64(g_ctx, (const int64_t *)dk, wp.preds, wp.npred, wp.logic, nrows, &kmin, &kmax, &seen) != RFX_OK) { res = fail_hip("scope"); goto done; }
+            } else if (rfx_hip_group_scope(g_ctx, (const int64_t *)dk, wp.preds, wp.npred, wp.logic, aggs, nagg, nrows, &kmin, &kmax, &seen) != RFX_OK) { res = fail_hip("scope"); goto done; }
             int64_t groups = 0;
             if (!rowhash) nagg_run = nagg;
             obj_p okeys = NULL, ocols[RFX_MAX_AGGS] = {0}, okcols[RFX_MAX_KEYS] = {0};

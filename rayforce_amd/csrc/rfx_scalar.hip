@@ -306,6 +306,18 @@ extern "C" int rfx_hip_scope_i64(rfx_ctx_t *c, const int64_t *d_key, const rfx_p
     return RFX_OK;
 }
 
+int rfx_chunk_scope(rfx_ctx *c, const int64_t *d_key, const rfx_pred_t *preds, int npred, int logic, const rfx_agg_t *aggs, int nagg, i64 nrows,
+                    i64 *kmin, i64 *kmax, i64 *seen); // rfx_group_chunk.hip
+extern "C" int rfx_hip_group_scope(rfx_ctx_t *c, const int64_t *d_key, const rfx_pred_t *preds, int npred, int logic,
+                                   const rfx_agg_t *aggs, int nagg, int64_t nrows, int64_t *min, int64_t *max, int64_t *count) {
+    RFX_REQUIRE(c && d_key && min && max && count, RFX_EINVAL, "NULL argument");
+    if (aggs && nagg > 0) {
+        int prc = rfx_chunk_scope(c, d_key, preds, npred, logic, aggs, nagg, nrows, (i64 *)min, (i64 *)max, (i64 *)count);
+        if (prc != RFX_ESTATE) return prc;
+    }
+    return rfx_hip_scope_i64(c, d_key, preds, npred, logic, nrows, min, max, count);
+}
+
 // ---------------- K2: byte masks ----------------
 // A wave owns 512 consecutive rows per step: lane l loads rows 2l, 2l+1 of each 128-row group (one 16-byte load per
 // group and column, 1 KB contiguous per wave instruction) and stores their two mask bytes as one 16-bit store

@@ -586,8 +586,9 @@ class Engine:
         return out
 
     # ------------------------------------------------------------------ K6: scope
-    def scope(self, key: torch.Tensor, where=None, table=None) -> Tuple[int, int, int]:
-        """index_scope_i64: (min, max, rows_seen).  (syncs)"""
+    def scope(self, key: torch.Tensor, where=None, table=None, aggs=None) -> Tuple[int, int, int]:
+        """index_scope_i64: (min, max, rows_seen).  (syncs)  With `aggs` (the group-by's aggregates) the pass may also leave the
+        rows radix-partitioned for the group_dense_accumulate call that follows (rfx_hip_group_scope)."""
         self._check_col(key)
         if key.dtype != torch.int64:
             raise RfxError("group key must be i64 on this path")
@@ -595,8 +596,13 @@ class Engine:
         self._keep.clear()
         parr, n = self._preds(flat, table, key.numel())
         mn, mx, cnt = C.c_int64(), C.c_int64(), C.c_int64()
-        L.check(self.lib.rfx_hip_scope_i64(self._ctx, key.data_ptr(), parr, len(flat), logic, key.numel(), C.byref(mn), C.byref(mx),
-                                           C.byref(cnt)), "scope_i64")
+        if aggs:
+            aarr, _ = self._aggs(aggs, table, key.numel())
+            L.check(self.lib.rfx_hip_group_scope(self._ctx, key.data_ptr(), parr, len(flat), logic, aarr, len(aggs), key.numel(),
+                                                 C.byref(mn), C.byref(mx), C.byref(cnt)), "group_scope")
+        else:
+            L.check(self.lib.rfx_hip_scope_i64(self._ctx, key.data_ptr(), parr, len(flat), logic, key.numel(), C.byref(mn), C.byref(mx),
+                                               C.byref(cnt)), "scope_i64")
         return int(mn.value), int(mx.value), int(cnt.value)
 
     # ------------------------------------------------------------------ K7/K8/K10 dense group-by, K9 hashed
@@ -699,7 +705,7 @@ class Engine:
         except _NotFlat:
             raise RfxError("nested boolean trees are not fused with `by:`; pass ids via where() + at_ids()")
         if multi is None:
-            kmin, kmax, seen = self.scope(key, where, table)
+            kmin, kmax, seen = self.scope(key, where, table, aggs)
             if _collective is not None:
                 kmin, kmax, seen = _collective("scope", (kmin, kmax, seen, self.device))
         else:

@@ -323,7 +323,7 @@ def test_sharded_engine_single_rank(eng):
     assert np.array_equal(sh.where(("<", "a", 1000), d).cpu().numpy(), rfo.where(rfo.mask_of(("<", "a", 1000), host)))
 
 
-@pytest.mark.parametrize("flags", [0, 1, 2, 3, 4, 6, 8, 16, 32, 128, 144, 160, 256, 384, 1024, 1028, 2048, 2064, 4096, 4100])
+@pytest.mark.parametrize("flags", [0, 1, 2, 3, 4, 6, 8, 16, 32, 128, 144, 160, 256, 384, 1024, 1028, 2048, 2064, 4096, 4100, 16384, 32768, 32772])
 def test_group_by_every_code_path_agrees(eng, flags):
     """RFX_TUNE_* force the LDS-table / partitioned (fused and unfused scope) / device-atomic paths: same answers."""
     n = 400_003
@@ -337,7 +337,7 @@ def test_group_by_every_code_path_agrees(eng, flags):
         eng.tune(flags=0)
 
 
-@pytest.mark.parametrize("flags", [0, 128, 256, 2048])
+@pytest.mark.parametrize("flags", [0, 128, 256, 2048, 32768])
 @pytest.mark.parametrize("thr", [1_000, 100_000, 480_000, 520_000, 990_000])
 def test_filtered_partitioned_group_by(eng, flags, thr):
     """Partitioned path under a filter: <= 50 % selected -> compact (bitmap, ordered compaction of key / value planes / row
@@ -354,6 +354,45 @@ def test_filtered_partitioned_group_by(eng, flags, thr):
         check_select(eng, host, {"where": ("and", w, (">", "v", 0.2)), "by": "k", "s": ("sum", "v"), "mx": ("max", "a"), "av": ("avg", "w"), "f": ("first", "a")})
     finally:
         eng.tune(flags=0)
+
+
+CHUNK_SMALL = 32768  # RFX_TUNE_CHUNK_SMALL: the one-pass chunk partitioning from 2^16 rows on
+
+
+@pytest.mark.parametrize("flags", [CHUNK_SMALL, CHUNK_SMALL | 4, 16384])
+@pytest.mark.parametrize("shape", ["uniform", "offset", "skew", "wide", "narrow"])
+def test_chunk_partitioned_group_by(eng, flags, shape):
+    """rfx_hip_group_scope: the scope pass that also radix-partitions (rfx_group_chunk.hip) -- chunk allocation, slab switches,
+    one partition taking every row (several chunks per tile), negative keys / key >> 8 wrap, filtered and unfiltered, every
+    single-column aggregate set; flag 16384 (RFX_TUNE_NO_CHUNK) is the column-pass form of the same queries."""
+    n = 700_001
+    host = table(n, keys=200_000, nulls=True)
+    if shape == "offset":
+        host["k"] = host["k"] - 70_000  # negative keys: (key >> 8) is an arithmetic shift, the header keeps it mod 2^32
+    elif shape == "skew":
+        host["k"] = (host["k"] % 900) * 256 + 7  # every key in partition 7
+    elif shape == "wide":
+        host["k"] = rfo.gen_i64(n, 41, 600_000) + (1 << 40)
+    elif shape == "narrow":
+        host["k"] = rfo.gen_i64(n, 42, 20_000) * 3 - 1
+    try:
+        eng.tune(flags=flags)
+        check_select(eng, host, {"by": "k", "s": ("sum", "v")})
+        check_select(eng, host, {"by": "k", "s": ("sum", "v"), "c": ("count", "v"), "mn": ("min", "v"), "av": ("avg", "v"), "f": ("first", "v")})
+        check_select(eng, host, {"by": "k", "si": ("sum", "a"), "mx": ("max", "a")})
+        check_select(eng, host, {"where": ("<", "a", 100_000), "by": "k", "s": ("sum", "v")})
+        check_select(eng, host, {"where": ("and", ("<", "a", 600_000), (">", "w", -0.25)), "by": "k", "s": ("sum", "v"), "c": ("count", "a")})
+        check_select(eng, host, {"where": ("<", "a", -5), "by": "k", "s": ("sum", "v")})  # nothing (or only nulls) selected
+    finally:
+        eng.tune(flags=0)
+
+
+def test_chunk_partitioned_group_by_larger(eng):
+    """5e6 rows: more than one slab per workgroup, uneven last workgroup, the default row threshold (2^22)."""
+    n = 5_000_011
+    host = table(n, keys=1_000_000)
+    check_select(eng, host, {"by": "k", "s": ("sum", "v")})
+    check_select(eng, host, {"where": ("<", "a", 100_000), "by": "k", "s": ("sum", "v"), "c": ("count", "v")})
 
 
 # ---------------------------------------------------------------- several `by:` columns (composite key, SURVEY 8f-1)
