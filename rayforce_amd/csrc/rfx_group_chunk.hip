@@ -24,12 +24,9 @@
 #define CK_FREE 0xFFFFFFFFFFFFFFFFULL
 #define CK_PARTS 256
 #define CK_SLAB_BYTES (1u << 20) /* a workgroup takes chunks from the device-wide cursor one megabyte at a time */
-#define CK_QCAP 1792             /* selective form: records queued in LDS before they are ranked and placed */
-#define CK_QTILE 1024            /* selective form: rows per tile (4 per lane, the next tile is in flight while this one is evaluated) */
 
 struct ChunkArgs {
     int key_idx, vcol, nwg, chs; // chs: log2(records per chunk), 8..12
-    int dbg, _pad2;              // experiments only: 1 = drop every survivor, 2 = skip the predicate too
     i64 tiles_per_wg;            // in 2048-row tiles; 0: grid-stride (tile t of workgroup b = b + t * nwg)
     u64x2 *pool;         // chunk c = records [c << chs, (c + 1) << chs)
     u64 *meta;           // per chunk: partition | workgroup << 8 | records << 20 | ordinal within (workgroup, partition) << 40
@@ -335,268 +332,225 @@ __global__ __launch_bounds__(RFX_BLOCK) void k_chunk_scatter(const Plan P, const
     ck_finish<true>(L, M, A, mn, mx, sel, nulls);
 }
 
-// ---- selective filters: a streaming kernel (4 workgroups per CU, as K1) whose survivors queue up in LDS; ranking, chunk
-// requests and placement run once per ~1000 survivors, not once per tile.  No write combining: a survivor goes straight to its
-// place in the partition's chunk -- under a selective filter the records are a small fraction of the bytes read, and the 32 KB of
-// carry buffers would halve the occupancy that the 24 B/row read needs. ----
-struct CkLdsLite {
+#define CK_SEL_WROWS 512 /* rows per wave step: 8 per lane, four 16-byte loads per lane and column */
+// ---- selective filters: ONE 1024-lane workgroup per CU (16 waves, as many as K1 keeps resident) with a 4096-record queue ----
+// Waves run decoupled: each takes its own 512-row steps (grid-stride over waves), reserves queue space with one LDS atomic and never
+// waits for the others -- until a reservation does not fit.  Then that wave raises a flag and parks at the barrier with its survivors
+// still in registers; the others see the flag at their next step and join; the queue (the records before the first failed
+// reservation) is ranked per partition, chunks are requested, every record is stored at its place in its partition's chunk; all
+// resume.  The phases run once per 4096 survivors, not once per tile, and no carry buffers take LDS from the queue.
+// Measured on C3w (1e9 rows x 24 B, 10 % selected; the same kernel dropping its survivors: 3.7-3.9 ms): this form 5.3 ms; 256-lane
+// workgroups with a 1024..1792-record queue, waves coupled by a barrier per tile or decoupled, write-combined (carry buffers) or not
+// 5.5-5.9 ms; per-tile LDS phases (the unfiltered kernel with predicates) 6.8 ms; lock-free placement without a shared queue 6.2 ms
+// (single 16-byte record stores are partial-line writes: 2.0 ms per 1e8 records), with per-partition LDS combining buffers
+// 6.1-6.6 ms; compacting first and partitioning the compacted rows with the unfiltered kernel 4.9 + 0.9 ms.
+#define CK_SELQ 4096
+#define CK_SELT 1024
+struct CkSelLds {
     unsigned cnt[CK_PARTS];
     uint4 pi[CK_PARTS];
     CkDst di[CK_PARTS];
-    unsigned scan_w[RFX_BLOCK / RFX_WAVE];
+    unsigned scan_w[4];
     unsigned tile_total, tile_alloc, slab_next, slab_end, dead;
-    ScopePart red[RFX_BLOCK / RFX_WAVE];
+    unsigned q_tail, q_valid, q_flag, alive[2];
+    ScopePart red[CK_SELT / RFX_WAVE];
 };
-template <int NC, int RPL>
-__device__ __forceinline__ unsigned ck_load_qtile(const Plan &P, i64 tile, u64 (&v)[NC][RPL]) {
-    constexpr int ROWS = RFX_BLOCK * RPL;
-    const i64 base = tile * ROWS + threadIdx.x * 2;
-    unsigned valid = (1u << RPL) - 1u;
-    if ((tile + 1) * ROWS <= P.nrows) {
-#pragma unroll
-        for (int c = 0; c < NC; c++) {
-#pragma unroll
-            for (int j = 0; j < RPL / 2; j++) {
-                u64x2 q = rfx_ld2(P.cols[c] + base + (i64)j * (RFX_BLOCK * 2));
-                v[c][2 * j] = q.x;
-                v[c][2 * j + 1] = q.y;
-            }
-        }
-    } else {
-        valid = 0;
-#pragma unroll
-        for (int e = 0; e < RPL; e++) {
-            const i64 row = base + (i64)(e >> 1) * (RFX_BLOCK * 2) + (e & 1);
-            const bool in = row < P.nrows;
-            valid |= (unsigned)in << e;
-#pragma unroll
-            for (int c = 0; c < NC; c++) v[c][e] = in ? P.cols[c][row] : 0ULL;
-        }
-    }
-    return valid;
-}
-
-#define CK_SEL_WROWS 512 /* rows per wave step: 8 per lane, four 16-byte loads per lane and column */
-#define CK_RING 8        /* chunk ids a partition keeps published */
-#define CK_SEL_THREADS 1024
-#define CK_SEL_WAVES (CK_SEL_THREADS / RFX_WAVE)
-#define CK_SEL_LDS (CK_PARTS * 16 * 16 + CK_PARTS * CK_RING * 8 + CK_PARTS * 4 * 6 + CK_SEL_WAVES * 128 * 17 + CK_SEL_WAVES * 32)
-// One 1024-lane workgroup per CU (16 waves, as many as K1 keeps resident), NO barrier and no queue shared between waves in the
-// stream: a wave evaluates its own 512-row steps, collects its survivors in a wave-private LDS queue and places them 64 at a time,
-// one per lane:
-//   * position in the (workgroup, partition) record stream: one LDS atomic, pos[p]++ ;
-//   * the record goes into the partition's LDS write-combining buffer (two groups of 8 records); the lane whose arrival completes a
-//     group stores it as ONE aligned 128-byte line (single 16-byte record stores are partial-line writes, read-modify-write at the
-//     memory side: measured 2.0 ms per 1e8 records against 0.4 ms for everything else the placement does);
-//   * the lane that draws place 0 of a chunk allocates it (one returning device atomic per CH records) and publishes its id in the
-//     partition's ring.
-// Every wait is a RETRY, never a spin inside divergent code: a lane whose precondition does not hold yet (the buffer half still
-// holds an unflushed group, the chunk id is not published yet, the ring entry is still needed) skips and tries again in the next
-// round of the loop while the lanes that can proceed do -- lanes of one wave may depend on each other.  Dependencies always point to
-// older records of the same partition, so the oldest unfinished record can always proceed; a bounded retry count turns anything
-// unforeseen into the host's fallback to the column passes instead of a hang.
 template <int NC, int NP>
-__global__ __launch_bounds__(CK_SEL_THREADS) void k_chunk_scatter_sel(const Plan P, const ChunkArgs A) {
+__global__ __launch_bounds__(CK_SELT) void k_chunk_scatter_sel(const Plan P, const ChunkArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char ck_smem[];
-    u64x2(*buf)[16] = (u64x2(*)[16])ck_smem;                                         // [256][16] two groups of 8 records
-    u64(*ring)[CK_RING] = (u64(*)[CK_RING])(ck_smem + CK_PARTS * 256);                // (chunk ordinal + 1) << 32 | chunk id
-    unsigned *pos = (unsigned *)(ck_smem + CK_PARTS * 256 + CK_PARTS * CK_RING * 8); // records drawn
-    unsigned *done = pos + CK_PARTS;                                                 // records stored
-    unsigned(*arrived)[2] = (unsigned(*)[2])(done + CK_PARTS);                       // records written into the buffer half
-    unsigned(*fl)[2] = (unsigned(*)[2])(done + 3 * CK_PARTS);                        // flushes of the buffer half so far
-    u64x2(*wq)[128] = (u64x2(*)[128])(ck_smem + CK_PARTS * 256 + CK_PARTS * CK_RING * 8 + CK_PARTS * 24);
-    unsigned char(*wqp)[128] = (unsigned char(*)[128])((unsigned char *)wq + CK_SEL_WAVES * 128 * 16);
-    ScopePart *red = (ScopePart *)((unsigned char *)wqp + CK_SEL_WAVES * 128);
+    u64x2 *q = (u64x2 *)ck_smem;                                                   // [CK_SELQ]
+    unsigned short *q_rank = (unsigned short *)(ck_smem + CK_SELQ * 16);           // [CK_SELQ]
+    unsigned char *q_part = ck_smem + CK_SELQ * 18;                                // [CK_SELQ]
+    CkSelLds &L = *(CkSelLds *)(ck_smem + CK_SELQ * 19 + 64);
     PredSet<NP> S;
     predset_load<NP>(P, S);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    if (tid < CK_PARTS) {
-        pos[tid] = 0;
-        done[tid] = 0;
-        arrived[tid][0] = arrived[tid][1] = 0;
-        fl[tid][0] = fl[tid][1] = 0;
-#pragma unroll
-        for (int r = 0; r < CK_RING; r++) ring[tid][r] = 0;
+    CkLane M; // lanes 0..255 own partition tid
+    M.pre = M.room = M.nch = M.cur = 0;
+    M.cursor = 0;
+    M.x = M.pf = M.noff = 0;
+    if (tid == 0) {
+        L.slab_next = L.slab_end = L.dead = 0;
+        L.q_tail = 0;
+        L.q_valid = 0xFFFFFFFFu;
+        L.q_flag = 0;
+        L.alive[0] = L.alive[1] = 0;
     }
     __syncthreads();
-    const unsigned chs = (unsigned)A.chs, CH = 1u << chs;
     i64 mn = RFX_INF_I64_D, mx = RFX_NULL_I64_D, sel = 0, nulls = 0;
     const i64 nsteps = (P.nrows + CK_SEL_WROWS - 1) / CK_SEL_WROWS;
-    const i64 nwaves = (i64)gridDim.x * CK_SEL_WAVES;
-    const int vc = A.vcol;
-    auto alloc_chunk = [&](const unsigned p, const unsigned c) -> unsigned {
-        unsigned id = atomicAdd(&A.ctl[0], 1u);
-        if (id >= A.max_chunks) { // pool exhausted: the host sees ctl[1] and runs the column passes instead
-            atomicExch(&A.ctl[1], 1u);
-            id = 0xFFFFFFFFu;
-        } else A.meta[id] = ck_meta(p, blockIdx.x, CH, c);
-        *(volatile u64 *)&ring[p][c & (CK_RING - 1)] = ((u64)(c + 1u) << 32) | (u64)id;
-        return id;
-    };
-    // the first `cnt` (<= 64) queued records of this wave, one per lane
-    auto place = [&](const unsigned cnt) {
-        const bool act = (unsigned)lane < cnt;
-        u64x2 r;
-        r.x = r.y = 0;
-        unsigned p = 0, my = 0;
-        if (act) {
-            r = wq[wv][lane];
-            p = wqp[wv][lane];
-            my = atomicAdd(&pos[p], 1u);
-        }
-        const unsigned g = my >> 3, j = my & 7u, half = g & 1u, c = my >> chs, o = my & (CH - 1u);
-        int st = act ? (o == 0 ? 0 : 1) : 3; // 0 allocate the chunk, 1 write into the buffer, 2 flush the group, 3 finished
-        unsigned tries = 0;
-        while (__ballot(st != 3)) {
-            if (st == 0) { // ring entry c & 7 still names chunk c - 8 until all of that chunk's records are stored
-                if (c < CK_RING || *(volatile unsigned *)&done[p] >= ((c - CK_RING + 1u) << chs)) {
-                    alloc_chunk(p, c);
-                    st = 1;
-                }
-            }
-            if (st == 1) { // the buffer half is free once group g - 2 has left it
-                if (*(volatile unsigned *)&fl[p][half] >= (g >> 1)) {
-                    buf[p][half * 8 + j] = r;
-                    st = (atomicAdd(&arrived[p][half], 1u) == 7u) ? 2 : 3;
-                }
-            }
-            // last arrivals of their groups: the groups leave as aligned 128-byte lines, eight lanes per group (one 16-byte record each,
-            // one store instruction for up to eight lines) -- a lane storing its whole group alone costs eight instructions at 1/8 occupancy
-            bool ready = false, want = false;
-            u64 dsti = 0;
-            if (st == 2) {
-                const u64 ent = *(volatile u64 *)&ring[p][c & (CK_RING - 1)];
-                if ((ent >> 32) == (u64)(c + 1u)) {
-                    ready = true;
-                    const unsigned id = (unsigned)ent;
-                    want = id != 0xFFFFFFFFu && !(A.dbg & 2);
-                    dsti = ((u64)id << chs) + (o - j);
-                }
-            }
-            const u64 fb = __ballot(ready);
-            if (fb) { // wave-uniform
-                if (ready) { // the queue's first 64 entries are in registers by now: their LDS space carries the flush descriptors
-                    const unsigned fr = __builtin_amdgcn_mbcnt_hi((unsigned)(fb >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)fb, 0u));
-                    u64x2 d;
-                    d.x = dsti;
-                    d.y = (u64)p | ((u64)half << 8) | ((u64)want << 16);
-                    wq[wv][fr] = d;
-                }
-                const unsigned nfl = (unsigned)__popcll(fb);
-                for (unsigned f0 = 0; f0 < nfl; f0 += 8) {
-                    const unsigned f = f0 + ((unsigned)lane >> 3), k = (unsigned)lane & 7u;
-                    if (f < nfl) {
-                        const u64x2 d = wq[wv][f];
-                        const u64x2 rec = buf[(unsigned)d.y & 255u][(((unsigned)d.y >> 8) & 1u) * 8 + k];
-                        if ((d.y >> 16) & 1ULL) A.pool[d.x + k] = rec;
+    const i64 nwaves = (i64)gridDim.x * (CK_SELT / RFX_WAVE);
+    i64 ws = (i64)blockIdx.x * (CK_SELT / RFX_WAVE) + wv; // this wave's next step
+    constexpr int VC = NC > 1 ? 1 : 0; // the host put the key in plan column 0 and the value in column 1 (0 when it is the key itself)
+    u64 v[NC][8];
+    u64 b[8];
+    unsigned m = 0, wtot = 0;
+    i64 base = 0;
+    bool pending = false;
+    unsigned round = 0;
+    for (;;) {
+        // ---- run ahead until a reservation fails, the flag is up, or this wave has nothing left ----
+        for (;;) {
+            if (!pending) {
+                if (ws >= nsteps) break;
+                base = ws * CK_SEL_WROWS + lane * 2;
+                unsigned valid = 0xffu;
+                if ((ws + 1) * CK_SEL_WROWS <= P.nrows) {
+#pragma unroll
+                    for (int c = 0; c < NC; c++) {
+#pragma unroll
+                        for (int j = 0; j < 4; j++) {
+                            u64x2 t = rfx_ld2(P.cols[c] + base + j * 128);
+                            v[c][2 * j] = t.x;
+                            v[c][2 * j + 1] = t.y;
+                        }
+                    }
+                } else {
+                    valid = 0;
+#pragma unroll
+                    for (int e = 0; e < 8; e++) {
+                        const i64 row = base + (e >> 1) * 128 + (e & 1);
+                        const bool in = row < P.nrows;
+                        valid |= (unsigned)in << e;
+#pragma unroll
+                        for (int c = 0; c < NC; c++) v[c][e] = in ? P.cols[c][row] : 0ULL;
                     }
                 }
-                if (ready) {
-                    arrived[p][half] = 0;
-                    atomicAdd(&fl[p][half], 1u);
-                    atomicAdd(&done[p], 8u);
-                    st = 3;
+                ws += nwaves;
+                m = (NP == 0) ? valid : eval_preds<NC, 8, NP>(S, v, valid);
+                wtot = 0;
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    b[e] = __ballot((m >> e) & 1u);
+                    wtot += (unsigned)__popcll(b[e]);
                 }
+                if (wtot == 0) continue;
+                pending = true;
             }
-            if (++tries >= (1u << 20)) { // never seen; a stuck wave must not hang the device: the host falls back
-                atomicExch(&A.ctl[1], 1u);
+            if (*(volatile unsigned *)&L.q_flag) break; // a drain has been called: join it, append afterwards
+            unsigned wb = 0;
+            if (lane == 0) wb = atomicAdd(&L.q_tail, wtot);
+            wb = __shfl(wb, 0, 64);
+            if (wb + wtot > CK_SELQ) { // does not fit: everything from wb on is invalid, call the drain
+                if (lane == 0) {
+                    atomicMin(&L.q_valid, wb);
+                    *(volatile unsigned *)&L.q_flag = 1u;
+                }
                 break;
             }
-            if (tries > 4) __builtin_amdgcn_s_sleep(2);
-        }
-    };
-    unsigned qn = 0; // queued records of this wave (wave-uniform)
-    for (i64 ws = (i64)blockIdx.x * CK_SEL_WAVES + wv; ws < nsteps; ws += nwaves) {
-        u64 v[NC][8];
-        const i64 base = ws * CK_SEL_WROWS + lane * 2;
-        unsigned valid = 0xffu;
-        if ((ws + 1) * CK_SEL_WROWS <= P.nrows) {
-#pragma unroll
-            for (int c = 0; c < NC; c++) {
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    u64x2 t = rfx_ld2(P.cols[c] + base + j * 128);
-                    v[c][2 * j] = t.x;
-                    v[c][2 * j + 1] = t.y;
-                }
-            }
-        } else {
-            valid = 0;
 #pragma unroll
             for (int e = 0; e < 8; e++) {
-                const i64 row = base + (e >> 1) * 128 + (e & 1);
-                const bool in = row < P.nrows;
-                valid |= (unsigned)in << e;
-#pragma unroll
-                for (int c = 0; c < NC; c++) v[c][e] = in ? P.cols[c][row] : 0ULL;
+                if ((m >> e) & 1u) {
+                    const unsigned at = wb + __builtin_amdgcn_mbcnt_hi((unsigned)(b[e] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b[e], 0u));
+                    const i64 k = (i64)v[0][e];
+                    const u64 lrow = (u64)(base + (e >> 1) * 128 + (e & 1));
+                    u64x2 r;
+                    r.x = (lrow << 32) | (u64)(unsigned)(k >> 8);
+                    r.y = A.vcol == 0 ? v[0][e] : v[VC][e];
+                    q[at] = r;
+                    q_part[at] = (unsigned char)(v[0][e] & 255ULL);
+                    sel++;
+                    if (k == RFX_NULL_I64_D) nulls++;
+                    else {
+                        mn = k < mn ? k : mn;
+                        mx = k > mx ? k : mx;
+                    }
+                }
+                wb += (unsigned)__popcll(b[e]);
             }
+            pending = false;
         }
-        unsigned m = (NP == 0) ? valid : eval_preds<NC, 8, NP>(S, v, valid);
-        if (A.dbg & 1) m &= (unsigned)(v[0][0] == 0x123456789ULL);
-        if (__ballot(m != 0) == 0) continue;
-        u64 key[8], val[8];
-        sel_col<NC, 8>(key, v, A.key_idx);
-        sel_col<NC, 8>(val, v, vc);
+        // ---- drain round (all 16 waves) ----
+        if (lane == 0 && (pending || ws < nsteps)) atomicAdd(&L.alive[round & 1], 1u);
+        __syncthreads();
+        const unsigned vq = L.q_valid, tq = L.q_tail;
+        const unsigned n = vq != 0xFFFFFFFFu ? vq : tq;
+        const unsigned still = L.alive[round & 1];
+        if (n > 0) {
+            if (tid < CK_PARTS) L.cnt[tid] = 0;
+            __syncthreads();
 #pragma unroll
-        for (int e = 0; e < 8; e++) {
-            const bool s = (m >> e) & 1u;
-            const u64 b = __ballot(s);
-            if (b == 0) continue; // wave-uniform
-            if (s) {
-                const unsigned at = qn + __builtin_amdgcn_mbcnt_hi((unsigned)(b >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b, 0u));
-                const i64 k = (i64)key[e];
-                const u64 lrow = (u64)(base + (e >> 1) * 128 + (e & 1));
-                u64x2 r;
-                r.x = (lrow << 32) | (u64)(unsigned)(k >> 8);
-                r.y = val[e];
-                wq[wv][at] = r;
-                wqp[wv][at] = (unsigned char)(key[e] & 255ULL);
-                sel++;
-                if (k == RFX_NULL_I64_D) nulls++;
-                else {
-                    mn = k < mn ? k : mn;
-                    mx = k > mx ? k : mx;
+            for (int k = 0; k < CK_SELQ / CK_SELT; k++) {
+                const unsigned i = tid + k * CK_SELT;
+                if (i < n) q_rank[i] = (unsigned short)atomicAdd(&L.cnt[q_part[i]], 1u);
+            }
+            __syncthreads();
+            // one lane per partition (waves 0..3): chunk requests, as ck_plan<1>
+            unsigned inc = 0, packed = 0;
+            if (tid < CK_PARTS) {
+                const unsigned x = L.cnt[tid];
+                const unsigned rm = M.room;
+                const unsigned need = (x >= rm) ? ((x - rm) >> A.chs) + 1 : 0;
+                packed = x | (need << 16);
+                inc = packed;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    unsigned o = __shfl_up(inc, d, 64);
+                    if (lane >= d) inc += o;
+                }
+                if (lane == 63) L.scan_w[wv] = inc;
+            }
+            __syncthreads();
+            if (tid < CK_PARTS) {
+                unsigned wbase = 0;
+                for (int w = 0; w < wv; w++) wbase += L.scan_w[w];
+                const unsigned excl = wbase + inc - packed;
+                M.x = packed & 0xFFFFu;
+                M.pf = M.x;
+                M.noff = excl >> 16;
+                L.pi[tid] = make_uint4(excl & 0xFFFFu, 0u, M.x, M.room);
+                CkDst d;
+                d.cursor = M.cursor;
+                d.noff = M.noff;
+                d._pad = 0;
+                L.di[tid] = d;
+                if (tid == CK_PARTS - 1) {
+                    const unsigned tn = (wbase + inc) >> 16;
+                    if (tn) {
+                        unsigned sn = L.slab_next;
+                        if (sn + tn > L.slab_end) {
+                            const unsigned slab = (CK_SLAB_BYTES / 16u) >> A.chs;
+                            const unsigned g = tn > slab ? tn : slab;
+                            sn = atomicAdd(&A.ctl[0], g);
+                            L.slab_end = sn + g;
+                            if (sn + g > A.max_chunks || sn + g < sn) {
+                                L.dead = 1;
+                                atomicExch(&A.ctl[1], 1u);
+                            }
+                        }
+                        L.tile_alloc = sn;
+                        L.slab_next = sn + tn;
+                    }
                 }
             }
-            qn += (unsigned)__popcll(b);
-            if (qn >= 64) { // wave-uniform
-                place(64);
-                const unsigned rest = qn - 64;
-                u64x2 tr;
-                unsigned char tp = 0;
-                tr.x = tr.y = 0;
-                if ((unsigned)lane < rest) {
-                    tr = wq[wv][64 + lane];
-                    tp = wqp[wv][64 + lane];
+            __syncthreads();
+            if (L.dead) return;
+#pragma unroll
+            for (int k = 0; k < CK_SELQ / CK_SELT; k++) {
+                const unsigned i = tid + k * CK_SELT;
+                if (i < n) {
+                    const unsigned p = q_part[i];
+                    A.pool[ck_dst(L, A, p, q_rank[i], L.pi[p].w)] = q[i];
                 }
-                if ((unsigned)lane < rest) {
-                    wq[wv][lane] = tr;
-                    wqp[wv][lane] = tp;
-                }
-                qn = rest;
             }
+            __syncthreads();
+            if (tid < CK_PARTS) ck_update(M, L, A);
         }
+        if (tid == 0) {
+            L.q_tail = 0;
+            L.q_valid = 0xFFFFFFFFu;
+            L.q_flag = 0;
+            L.alive[(round + 1) & 1] = 0;
+        }
+        __syncthreads();
+        round++;
+        if (still == 0) break; // nobody has rows or survivors left
     }
-    place(qn);
-    __syncthreads();
+    // final record counts of the open chunks, chunk counts, scope
     if (tid < CK_PARTS) {
-        const unsigned n = pos[tid];
-        const unsigned nch = (n + CH - 1u) >> chs;
-        if (n & 7u) { // the stream's last group is partly filled: store it padded (the chunk's record count ends before the padding)
-            const unsigned g = n >> 3, half = g & 1u, gb = g << 3, c = gb >> chs, o0 = gb & (CH - 1u);
-            const unsigned id = (unsigned)ring[tid][c & (CK_RING - 1)]; // place gb < n was drawn, so whoever drew the chunk's place 0 has published it
-            if (id != 0xFFFFFFFFu) {
-                u64x2 *dst = A.pool + ((u64)id << chs) + o0;
-#pragma unroll
-                for (int k = 0; k < 8; k++) dst[k] = buf[tid][half * 8 + k];
-            }
-        }
-        if (n & (CH - 1u)) { // the stream's last chunk is partly filled
-            const unsigned c = nch - 1u;
-            const unsigned id = (unsigned)ring[tid][c & (CK_RING - 1)];
-            if (id != 0xFFFFFFFFu) A.meta[id] = ck_meta(tid, blockIdx.x, n & (CH - 1u), c);
-        }
-        A.wcount[(size_t)blockIdx.x * CK_PARTS + tid] = nch;
+        const unsigned CH = 1u << A.chs;
+        if (M.nch > 0) A.meta[M.cur] = ck_meta(tid, blockIdx.x, CH - M.room, M.nch - 1);
+        A.wcount[(size_t)blockIdx.x * CK_PARTS + tid] = M.nch;
     }
     for (int s = 32; s >= 1; s >>= 1) {
         const i64 omn = (i64)rfx_shfl_xor_u64((u64)mn, s), omx = (i64)rfx_shfl_xor_u64((u64)mx, s);
@@ -605,19 +559,20 @@ __global__ __launch_bounds__(CK_SEL_THREADS) void k_chunk_scatter_sel(const Plan
         sel += (i64)rfx_shfl_xor_u64((u64)sel, s);
         nulls += (i64)rfx_shfl_xor_u64((u64)nulls, s);
     }
-    if (lane == 0) red[wv] = ScopePart{mn, mx, sel, nulls};
+    if (lane == 0) L.red[wv] = ScopePart{mn, mx, sel, nulls};
     __syncthreads();
     if (tid == 0) {
-        ScopePart r = red[0];
-        for (int w = 1; w < CK_SEL_WAVES; w++) {
-            r.mn = red[w].mn < r.mn ? red[w].mn : r.mn;
-            r.mx = red[w].mx > r.mx ? red[w].mx : r.mx;
-            r.sel += red[w].sel;
-            r.nulls += red[w].nulls;
+        ScopePart r = L.red[0];
+        for (int w = 1; w < CK_SELT / RFX_WAVE; w++) {
+            r.mn = L.red[w].mn < r.mn ? L.red[w].mn : r.mn;
+            r.mx = L.red[w].mx > r.mx ? L.red[w].mx : r.mx;
+            r.sel += L.red[w].sel;
+            r.nulls += L.red[w].nulls;
         }
         A.parts[blockIdx.x] = r;
     }
 }
+#define CK_SEL_LDS (CK_SELQ * 19 + 64 + sizeof(CkSelLds) + 64)
 
 // wcount[w][p] -> exclusive offset of (w, p) inside partition p's chunk list; part_start[p] = first entry of partition p.
 __global__ __launch_bounds__(1024) void k_chunk_offsets(const ChunkArgs A) {
@@ -719,48 +674,76 @@ __global__ __launch_bounds__(THREADS) void k_chunk_aggregate(const Plan P, const
     const unsigned shift = (unsigned)(((i64)p - A.kmin) >> 8); // slot = (key - kmin) >> 8 = kh + floor((p - kmin) / 256), key = kh * 256 + p
     constexpr int RU = 4; // records in flight per lane
     const unsigned chs = (unsigned)A.chs;
-    const u64 vend = (b1 - b0) << chs; // the chunk list as one virtual record range
-    // chunk-list entries are fetched one step ahead: the record loads of a step never wait on a dependent load
-    u64 ent[RU];
+    auto apply = [&](const u64x2 &rec) {
+        const u64 slot = (u64)(unsigned)((unsigned)rec.x + shift);
+        if (slot >= (u64)local) return; // a key outside the scope the tables were sized for: not ours
+        const u64 row = row0 + (rec.x >> 32);
+        if (row < smem[slot]) atomicMin((unsigned long long *)&smem[slot], (unsigned long long)row);
 #pragma unroll
-    for (int r = 0; r < RU; r++) {
-        const u64 vi = (u64)r * THREADS + tid;
-        ent[r] = (vi < vend) ? A.plist[b0 + (vi >> chs)] : 0ULL;
-    }
-    for (u64 v0 = 0; v0 < vend; v0 += (u64)THREADS * RU) {
-        u64x2 q[RU];
-        bool in[RU];
+        for (int a = 0; a < RFX_MAX_AGGS; a++) {
+            if (kind[a] < 0) continue;
+            group_apply(&smem[(i64)arr_of[a] * local + slot], &smem[(i64)(arr_of[a] + 1) * local + slot], kind[a], f64[a], hasv[a] ? rec.y : 0ULL, skip[a]);
+        }
+    };
+    typedef u64 v2 __attribute__((ext_vector_type(2)));
+    if ((1u << chs) >= (unsigned)THREADS) {
+        // a chunk is at least one record per lane: walk the list chunk by chunk (the entry is wave-uniform: a scalar load)
+        for (u64 ci = b0; ci < b1; ci++) {
+            const u64 e = A.plist[ci];
+            const unsigned nrec = (unsigned)(e >> 32);
+            const u64x2 *src = A.pool + ((e & 0xFFFFFFFFULL) << chs);
+            for (unsigned r0 = 0; r0 < nrec; r0 += THREADS * RU) {
+                u64x2 q[RU];
+                bool in[RU];
 #pragma unroll
-        for (int r = 0; r < RU; r++) {
-            const u64 vi = v0 + (u64)r * THREADS + tid;
-            const unsigned rec = (unsigned)vi & ((1u << chs) - 1u);
-            in[r] = vi < vend && rec < (unsigned)(ent[r] >> 32);
-            q[r].x = 0;
-            q[r].y = 0;
-            if (in[r]) {
-                typedef u64 v2 __attribute__((ext_vector_type(2)));
-                const v2 t = __builtin_nontemporal_load((const v2 *)(A.pool + ((ent[r] & 0xFFFFFFFFULL) << chs) + rec));
-                q[r].x = t.x;
-                q[r].y = t.y;
+                for (int r = 0; r < RU; r++) {
+                    const unsigned rec = r0 + (unsigned)r * THREADS + tid;
+                    in[r] = rec < nrec;
+                    q[r].x = q[r].y = 0;
+                    if (in[r]) {
+                        const v2 t = __builtin_nontemporal_load((const v2 *)(src + rec));
+                        q[r].x = t.x;
+                        q[r].y = t.y;
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < RU; r++)
+                    if (in[r]) apply(q[r]);
             }
         }
+    } else {
+        const u64 vend = (b1 - b0) << chs; // the chunk list as one virtual record range
+        // chunk-list entries are fetched one step ahead: the record loads of a step never wait on a dependent load
+        u64 ent[RU];
 #pragma unroll
         for (int r = 0; r < RU; r++) {
-            const u64 vi = v0 + (u64)THREADS * RU + (u64)r * THREADS + tid;
+            const u64 vi = (u64)r * THREADS + tid;
             ent[r] = (vi < vend) ? A.plist[b0 + (vi >> chs)] : 0ULL;
         }
+        for (u64 v0 = 0; v0 < vend; v0 += (u64)THREADS * RU) {
+            u64x2 q[RU];
+            bool in[RU];
 #pragma unroll
-        for (int r = 0; r < RU; r++) {
-            if (!in[r]) continue;
-            const u64 slot = (u64)(unsigned)((unsigned)q[r].x + shift);
-            if (slot >= (u64)local) continue; // a key outside the scope the tables were sized for: not ours
-            const u64 row = row0 + (q[r].x >> 32);
-            if (row < smem[slot]) atomicMin((unsigned long long *)&smem[slot], (unsigned long long)row);
-#pragma unroll
-            for (int a = 0; a < RFX_MAX_AGGS; a++) {
-                if (kind[a] < 0) continue;
-                group_apply(&smem[(i64)arr_of[a] * local + slot], &smem[(i64)(arr_of[a] + 1) * local + slot], kind[a], f64[a], hasv[a] ? q[r].y : 0ULL, skip[a]);
+            for (int r = 0; r < RU; r++) {
+                const u64 vi = v0 + (u64)r * THREADS + tid;
+                const unsigned rec = (unsigned)vi & ((1u << chs) - 1u);
+                in[r] = vi < vend && rec < (unsigned)(ent[r] >> 32);
+                q[r].x = 0;
+                q[r].y = 0;
+                if (in[r]) {
+                    const v2 t = __builtin_nontemporal_load((const v2 *)(A.pool + ((ent[r] & 0xFFFFFFFFULL) << chs) + rec));
+                    q[r].x = t.x;
+                    q[r].y = t.y;
+                }
             }
+#pragma unroll
+            for (int r = 0; r < RU; r++) {
+                const u64 vi = v0 + (u64)THREADS * RU + (u64)r * THREADS + tid;
+                ent[r] = (vi < vend) ? A.plist[b0 + (vi >> chs)] : 0ULL;
+            }
+#pragma unroll
+            for (int r = 0; r < RU; r++)
+                if (in[r]) apply(q[r]);
         }
     }
     __syncthreads();
@@ -860,28 +843,28 @@ static int single_value_col(const Plan &P) {
     return vc;
 }
 
+template <int NC>
+static void launch_chunk_scatter(rfx_ctx *c, const Plan &P, const ChunkArgs &A) {
+    if (P.npred == 0) hipLaunchKernelGGL((k_chunk_scatter<NC, 0>), dim3(A.nwg), dim3(RFX_BLOCK), 0, c->stream, P, A);
+    else if (P.npred <= 2) hipLaunchKernelGGL((k_chunk_scatter<NC, 2>), dim3(A.nwg), dim3(RFX_BLOCK), 0, c->stream, P, A);
+    else hipLaunchKernelGGL((k_chunk_scatter<NC, RFX_MAX_PREDS>), dim3(A.nwg), dim3(RFX_BLOCK), 0, c->stream, P, A);
+}
 template <int NC, int NP>
-static int launch_chunk_scatter_sel(rfx_ctx *c, const Plan &P, const ChunkArgs &A) {
+static int launch_chunk_scatter_sel_np(rfx_ctx *c, const Plan &P, const ChunkArgs &A) {
     static bool attr_set = false; // per instantiation
     if (!attr_set) {
-        RFX_HIP_CHECK(hipFuncSetAttribute((const void *)k_chunk_scatter_sel<NC, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, CK_SEL_LDS));
+        RFX_HIP_CHECK(hipFuncSetAttribute((const void *)k_chunk_scatter_sel<NC, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CK_SEL_LDS));
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_chunk_scatter_sel<NC, NP>), dim3(A.nwg), dim3(CK_SEL_THREADS), CK_SEL_LDS, c->stream, P, A);
+    hipLaunchKernelGGL((k_chunk_scatter_sel<NC, NP>), dim3(A.nwg), dim3(CK_SELT), CK_SEL_LDS, c->stream, P, A);
     return RFX_OK;
 }
 template <int NC>
-static int launch_chunk_scatter(rfx_ctx *c, const Plan &P, const ChunkArgs &A, bool selective) {
-    if (P.npred == 0) hipLaunchKernelGGL((k_chunk_scatter<NC, 0>), dim3(A.nwg), dim3(RFX_BLOCK), 0, c->stream, P, A);
-    else if (selective) {
-        if (P.npred == 1) return launch_chunk_scatter_sel<NC, 1>(c, P, A);
-        if (P.npred <= 3) return launch_chunk_scatter_sel<NC, 3>(c, P, A);
-        return launch_chunk_scatter_sel<NC, RFX_MAX_PREDS>(c, P, A);
-    } else if (P.npred <= 2) hipLaunchKernelGGL((k_chunk_scatter<NC, 2>), dim3(A.nwg), dim3(RFX_BLOCK), 0, c->stream, P, A);
-    else hipLaunchKernelGGL((k_chunk_scatter<NC, RFX_MAX_PREDS>), dim3(A.nwg), dim3(RFX_BLOCK), 0, c->stream, P, A);
-    return RFX_OK;
+static int launch_chunk_scatter_sel(rfx_ctx *c, const Plan &P, const ChunkArgs &A) {
+    if (P.npred == 1) return launch_chunk_scatter_sel_np<NC, 1>(c, P, A);
+    if (P.npred <= 3) return launch_chunk_scatter_sel_np<NC, 3>(c, P, A);
+    return launch_chunk_scatter_sel_np<NC, RFX_MAX_PREDS>(c, P, A);
 }
-
 static size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 // the scratch block: [ctl 256 B][scope partials][chunk counts][part_start][metas][chunk lists][record pool]
@@ -900,6 +883,48 @@ static void chunk_layout(rfx_ctx *c, int nwg, size_t max_chunks, ChunkArgs *A, s
     A->plist = (u64 *)(w + o_plist);
     A->pool = (u64x2 *)(w + o_pool);
     A->max_chunks = (unsigned)max_chunks;
+}
+
+// Geometry of one tile-sorted scatter over `nrows` input rows of which about `est_rows` are selected; reserves the scratch block.
+static int chunk_geometry(rfx_ctx *c, i64 nrows, i64 est_rows, ChunkArgs *A, i64 *tpw_out) {
+    const i64 ntiles = (nrows + PART_TILE_ROWS - 1) / PART_TILE_ROWS;
+    int nwg = c->num_cus * 2; // what the kernel's LDS lets a CU hold
+    if ((i64)nwg * 16 > ntiles) nwg = (int)((ntiles + 15) / 16);
+    const i64 tpw = (ntiles + nwg - 1) / nwg;
+    nwg = (int)((ntiles + tpw - 1) / tpw);
+    // records per chunk: about a third of what one (workgroup, partition) will see, 256 .. 2048 (4 .. 32 KB)
+    A->chs = 9; // >= 512 records: pass 2 then walks the list chunk by chunk with wave-uniform entries
+    while (A->chs < 11 && (est_rows / ((i64)nwg * CK_PARTS)) / 3 >= (2LL << A->chs)) A->chs++;
+    const size_t CH = (size_t)1 << A->chs;
+    const size_t slab = (CK_SLAB_BYTES / 16) / CH;
+    const size_t data_chunks = (size_t)((est_rows + (i64)CH - 1) / (i64)CH);
+    const size_t max_chunks = data_chunks + data_chunks / 4 + (size_t)nwg * (CK_PARTS + 2 * slab) + 1024;
+    if (max_chunks >= (1ULL << 32)) return RFX_ESTATE;
+    size_t need = 0;
+    chunk_layout(c, nwg, max_chunks, A, &need);
+    if (rfx_chunk_reserve(c, need) != RFX_OK) return RFX_ESTATE; // no room for the pool: the column passes need less
+    chunk_layout(c, nwg, max_chunks, A, NULL);
+    A->tiles_per_wg = (c->flags & RFX_TUNE_CHUNK_CONTIG) ? tpw : 0;
+    *tpw_out = tpw;
+    return RFX_OK;
+}
+
+static void fold_scope(const ScopePart *h, int n, i64 *kmin, i64 *kmax, i64 *seen, i64 *nulls_out) {
+    i64 mn = RFX_INF_I64_D, mx = RFX_NULL_I64_D, sel = 0, nulls = 0;
+    for (int i = 0; i < n; i++) {
+        mn = h[i].mn < mn ? h[i].mn : mn;
+        mx = h[i].mx > mx ? h[i].mx : mx;
+        sel += h[i].sel;
+        nulls += h[i].nulls;
+    }
+    *seen = sel;
+    if (nulls > 0) { // a null key is the value INT64_MIN for index_scope_i64
+        mn = RFX_NULL_I64_D;
+        if (nulls == sel) mx = RFX_NULL_I64_D;
+    }
+    *kmin = mn;
+    *kmax = mx;
+    *nulls_out = nulls;
 }
 
 // Scope pass that also partitions.  RFX_ESTATE: not applicable, the caller runs the plain scope pass.
@@ -946,79 +971,113 @@ int rfx_chunk_scope(rfx_ctx *c, const int64_t *d_key, const rfx_pred_t *preds, i
     i64 est_rows = (i64)((double)nrows * (frac * 1.5 + 0.02));
     if (est_rows > nrows || npred == 0) est_rows = nrows;
     if (est > (unsigned long long)est_rows * 2) return RFX_ESTATE;                                    // sparse keys: the hashed path
-    const bool selective = npred > 0 && frac <= 0.5;
-    const i64 ntiles = (nrows + PART_TILE_ROWS - 1) / PART_TILE_ROWS;
-    int nwg = c->num_cus * (selective ? 1 : 2); // what the kernels' LDS lets a CU hold (the selective form: one 1024-lane workgroup)
-    if ((i64)nwg * 16 > ntiles) nwg = (int)((ntiles + 15) / 16);
-    const i64 tpw = (ntiles + nwg - 1) / nwg;
-    nwg = (int)((ntiles + tpw - 1) / tpw);
+    const bool selective = npred > 0 && frac <= 0.4;
     ChunkArgs A;
     memset(&A, 0, sizeof(A));
-    // records per chunk: about a third of what one (workgroup, partition) will see, 256 .. 2048 (4 .. 32 KB); the selective form
-    // allocates chunk by chunk from the device-wide cursor and wants few, large ones
-    A.chs = 8;
-    while (A.chs < 11 && (est_rows / ((i64)nwg * CK_PARTS)) / 3 >= (2LL << A.chs)) A.chs++;
-    if (selective && A.chs < 10) A.chs = 10;
-    const size_t CH = (size_t)1 << A.chs;
-    const size_t slab = (CK_SLAB_BYTES / 16) / CH;
-    const size_t data_chunks = (size_t)((est_rows + (i64)CH - 1) / (i64)CH);
-    const size_t max_chunks = data_chunks + data_chunks / 4 + (size_t)nwg * (CK_PARTS + 2 * slab) + 1024;
-    if (max_chunks >= (1ULL << 32)) return RFX_ESTATE;
-    size_t need = 0;
-    chunk_layout(c, nwg, max_chunks, &A, &need);
-    rc = rfx_chunk_reserve(c, need);
-    if (rc != RFX_OK) return RFX_ESTATE; // no room for the pool: the column passes need less
-    chunk_layout(c, nwg, max_chunks, &A, NULL);
-    A.key_idx = key_idx;
-    A.vcol = vc;
-    A.tiles_per_wg = (c->flags & RFX_TUNE_CHUNK_CONTIG) ? tpw : 0;
-    A.dbg = (c->flags >> 17) & 3;
-    RFX_HIP_CHECK(hipMemsetAsync(A.ctl, 0, 256, c->stream));
-    RFX_HIP_CHECK(hipMemsetAsync(A.meta, 0xFF, max_chunks * 8, c->stream));
-    RFX_KERNEL_BEGIN(c);
-    switch (P.ncols) {
-        case 1: rc = launch_chunk_scatter<1>(c, P, A, selective); break;
-        case 2: rc = launch_chunk_scatter<2>(c, P, A, selective); break;
-        case 3: rc = launch_chunk_scatter<3>(c, P, A, selective); break;
-        default: rc = launch_chunk_scatter<4>(c, P, A, selective); break;
+    i64 tpw = 0, nulls = 0;
+    Plan Pc = P; // key -> column 0, value -> column 1 (the selective kernels read them without a run-time select)
+    if (selective) {
+        int perm[RFX_MAX_COLS], n2 = 0; // perm[new] = old
+        perm[n2++] = key_idx;
+        if (vc != key_idx) perm[n2++] = vc;
+        for (int i = 0; i < P.ncols; i++)
+            if (i != key_idx && i != vc) perm[n2++] = i;
+        int inv[RFX_MAX_COLS];
+        for (int i = 0; i < n2; i++) {
+            Pc.cols[i] = P.cols[perm[i]];
+            inv[perm[i]] = i;
+        }
+        for (int i = 0; i < P.npred; i++) {
+            Pc.preds[i].col = inv[P.preds[i].col];
+            if (P.preds[i].rhs_col >= 0) Pc.preds[i].rhs_col = inv[P.preds[i].rhs_col];
+        }
     }
-    if (rc != RFX_OK) return rc;
-    RFX_KERNEL_END(c);
-    RFX_HIP_CHECK(hipGetLastError());
-    RFX_REQUIRE((size_t)nwg * sizeof(ScopePart) + 16 <= c->pin_bytes, RFX_ELIMIT, "pinned staging too small");
-    ScopePart *h = (ScopePart *)c->h_pin;
-    unsigned *hctl = (unsigned *)((char *)c->h_pin + (size_t)nwg * sizeof(ScopePart));
-    RFX_HIP_CHECK(hipMemcpyAsync(h, A.parts, (size_t)nwg * sizeof(ScopePart), hipMemcpyDeviceToHost, c->stream));
-    RFX_HIP_CHECK(hipMemcpyAsync(hctl, A.ctl, 8, hipMemcpyDeviceToHost, c->stream));
-    RFX_HIP_CHECK(hipStreamSynchronize(c->stream));
-    if (hctl[1]) return RFX_ESTATE; // pool exhausted (the sample underestimated the selection): plain passes
-    i64 mn = RFX_INF_I64_D, mx = RFX_NULL_I64_D, sel = 0, nulls = 0;
-    for (int i = 0; i < nwg; i++) {
-        mn = h[i].mn < mn ? h[i].mn : mn;
-        mx = h[i].mx > mx ? h[i].mx : mx;
-        sel += h[i].sel;
-        nulls += h[i].nulls;
-    }
-    *seen = sel;
-    if (nulls > 0) { // a null key is the value INT64_MIN for index_scope_i64
-        mn = RFX_NULL_I64_D;
-        if (nulls == sel) mx = RFX_NULL_I64_D;
-    }
-    *kmin = mn;
-    *kmax = mx;
-    if (sel > 0 && nulls == 0) {
+    if (selective) {
+        // ---- one kernel: filter, queue, place (1024-lane workgroups, one per CU) ----
+        const int nwg = (int)((nrows / CK_SEL_WROWS / (CK_SELT / RFX_WAVE)) < c->num_cus ? (nrows / CK_SEL_WROWS / (CK_SELT / RFX_WAVE)) + 1 : c->num_cus);
+        A.chs = 10; // few, large chunks: 65 K (workgroup, partition) streams share the selection
+        while (A.chs < 11 && (est_rows / ((i64)nwg * CK_PARTS)) / 3 >= (2LL << A.chs)) A.chs++;
+        const size_t CH = (size_t)1 << A.chs;
+        const size_t slab = (CK_SLAB_BYTES / 16) / CH;
+        const size_t data_chunks = (size_t)((est_rows + (i64)CH - 1) / (i64)CH);
+        const size_t max_chunks = data_chunks + data_chunks / 4 + (size_t)nwg * (CK_PARTS + 2 * slab) + 1024;
+        if (max_chunks >= (1ULL << 32)) return RFX_ESTATE;
+        size_t need = 0;
+        chunk_layout(c, nwg, max_chunks, &A, &need);
+        if (rfx_chunk_reserve(c, need) != RFX_OK) return RFX_ESTATE;
+        chunk_layout(c, nwg, max_chunks, &A, NULL);
+        A.key_idx = 0;
+        A.vcol = vc == key_idx ? 0 : 1;
+        RFX_HIP_CHECK(hipMemsetAsync(A.ctl, 0, 256, c->stream));
+        RFX_HIP_CHECK(hipMemsetAsync(A.meta, 0xFF, (size_t)A.max_chunks * 8, c->stream));
+        RFX_KERNEL_BEGIN(c);
+        switch (P.ncols) {
+            case 1: rc = launch_chunk_scatter_sel<1>(c, Pc, A); break;
+            case 2: rc = launch_chunk_scatter_sel<2>(c, Pc, A); break;
+            case 3: rc = launch_chunk_scatter_sel<3>(c, Pc, A); break;
+            default: rc = launch_chunk_scatter_sel<4>(c, Pc, A); break;
+        }
+        RFX_KERNEL_END(c);
+        if (rc != RFX_OK) return rc;
+        RFX_HIP_CHECK(hipGetLastError());
+        RFX_REQUIRE((size_t)A.nwg * sizeof(ScopePart) + 16 <= c->pin_bytes, RFX_ELIMIT, "pinned staging too small");
+        ScopePart *h = (ScopePart *)c->h_pin;
+        unsigned *hctl = (unsigned *)((char *)c->h_pin + (size_t)A.nwg * sizeof(ScopePart));
+        RFX_HIP_CHECK(hipMemcpyAsync(h, A.parts, (size_t)A.nwg * sizeof(ScopePart), hipMemcpyDeviceToHost, c->stream));
+        RFX_HIP_CHECK(hipMemcpyAsync(hctl, A.ctl, 8, hipMemcpyDeviceToHost, c->stream));
+        RFX_HIP_CHECK(hipStreamSynchronize(c->stream));
+        if (hctl[1]) return RFX_ESTATE; // pool exhausted (the sample underestimated the selection): plain passes
+        fold_scope(h, A.nwg, kmin, kmax, seen, &nulls);
+        if (*seen == 0 || nulls > 0) return RFX_OK;
         c->ck_valid = 1;
         c->ck_key = d_key;
         c->ck_val = (const void *)P.cols[vc];
         c->ck_nrows = nrows;
         c->ck_npred = npred;
         c->ck_logic = logic;
-        c->ck_nwg = nwg;
-        c->ck_tpw = tpw;
+        c->ck_nwg = A.nwg;
+        c->ck_tpw = 0;
         c->ck_chs = A.chs;
-        c->ck_max_chunks = max_chunks;
+        c->ck_max_chunks = A.max_chunks;
         chunk_pred_sig(P, c->ck_sig);
+        return RFX_OK;
     }
+    // ---- every (or most) rows selected: the tile-sorted write-combining scatter ----
+    rc = chunk_geometry(c, nrows, est_rows, &A, &tpw);
+    if (rc != RFX_OK) return rc;
+    A.key_idx = key_idx;
+    A.vcol = vc;
+    RFX_HIP_CHECK(hipMemsetAsync(A.ctl, 0, 256, c->stream));
+    RFX_HIP_CHECK(hipMemsetAsync(A.meta, 0xFF, (size_t)A.max_chunks * 8, c->stream));
+    RFX_KERNEL_BEGIN(c);
+    switch (P.ncols) {
+        case 1: launch_chunk_scatter<1>(c, P, A); break;
+        case 2: launch_chunk_scatter<2>(c, P, A); break;
+        case 3: launch_chunk_scatter<3>(c, P, A); break;
+        default: launch_chunk_scatter<4>(c, P, A); break;
+    }
+    RFX_KERNEL_END(c);
+    RFX_HIP_CHECK(hipGetLastError());
+    RFX_REQUIRE((size_t)A.nwg * sizeof(ScopePart) + 16 <= c->pin_bytes, RFX_ELIMIT, "pinned staging too small");
+    ScopePart *h = (ScopePart *)c->h_pin;
+    unsigned *hctl = (unsigned *)((char *)c->h_pin + (size_t)A.nwg * sizeof(ScopePart));
+    RFX_HIP_CHECK(hipMemcpyAsync(h, A.parts, (size_t)A.nwg * sizeof(ScopePart), hipMemcpyDeviceToHost, c->stream));
+    RFX_HIP_CHECK(hipMemcpyAsync(hctl, A.ctl, 8, hipMemcpyDeviceToHost, c->stream));
+    RFX_HIP_CHECK(hipStreamSynchronize(c->stream));
+    if (hctl[1]) return RFX_ESTATE; // pool exhausted: plain passes
+    fold_scope(h, A.nwg, kmin, kmax, seen, &nulls);
+    if (*seen == 0 || nulls > 0) return RFX_OK;
+    c->ck_valid = 1;
+    c->ck_key = d_key;
+    c->ck_val = (const void *)P.cols[vc];
+    c->ck_nrows = nrows;
+    c->ck_npred = npred;
+    c->ck_logic = logic;
+    c->ck_nwg = A.nwg;
+    c->ck_tpw = tpw;
+    c->ck_chs = A.chs;
+    c->ck_max_chunks = A.max_chunks;
+    chunk_pred_sig(P, c->ck_sig);
     return RFX_OK;
 }
 

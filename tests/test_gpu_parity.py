@@ -383,6 +383,12 @@ def test_chunk_partitioned_group_by(eng, flags, shape):
         check_select(eng, host, {"where": ("<", "a", 100_000), "by": "k", "s": ("sum", "v")})
         check_select(eng, host, {"where": ("and", ("<", "a", 600_000), (">", "w", -0.25)), "by": "k", "s": ("sum", "v"), "c": ("count", "a")})
         check_select(eng, host, {"where": ("<", "a", -5), "by": "k", "s": ("sum", "v")})  # nothing (or only nulls) selected
+        # the selective kernel's instantiations: 1 / <= 3 / <= 8 predicates, predicate on the key and on the value, key == value column
+        check_select(eng, host, {"where": ("and", ("<", "a", 300_000), (">", "w", -0.4), ("<", "v", 0.7)), "by": "k", "mx": ("max", "v")})
+        check_select(eng, host, {"where": ("and", ("<", "a", 400_000), (">", "w", -0.4), ("<", "v", 0.9), (">=", "a", 5), ("!=", "k", 77)), "by": "k", "s": ("sum", "v")})
+        check_select(eng, host, {"where": ("<", "v", 0.25), "by": "k", "s": ("sum", "v"), "c": ("count", "v")})
+        check_select(eng, host, {"where": ("<", "a", 250_000), "by": "k", "s": ("sum", "k"), "mn": ("min", "k")})
+        check_select(eng, host, {"where": ("or", ("<", "a", 50_000), (">", "a", 950_000)), "by": "k", "s": ("sum", "v")})
     finally:
         eng.tune(flags=0)
 
