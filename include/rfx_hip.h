@@ -247,6 +247,10 @@ int rfx_hip_where_emit(rfx_ctx_t *ctx, int64_t row0, int64_t *d_ids);
 
 /* ---- K4: gather of 8-byte elements: d_out[i] = d_col[d_ids[i]] ---- */
 int rfx_hip_gather(rfx_ctx_t *ctx, const void *d_col, const int64_t *d_ids, int64_t m, void *d_out);
+/* The same for ids that come from OUTSIDE (the `at` operator, a MAPFILTER pair handed over by the host): an id that is null,
+ * negative or >= col_len yields the typed null (NULL_I64 / NaN) as at_vec_*_by_i64 does (core/items.c:53-72) -- never a read
+ * beyond the column.  rfx_hip_gather stays unchecked for ids the library produced itself. */
+int rfx_hip_gather_checked(rfx_ctx_t *ctx, const void *d_col, int64_t col_len, int32_t col_type, const int64_t *d_ids, int64_t m, void *d_out);
 
 /* ---- K6: key scope (min / max of an i64 column, optionally only over rows passing the predicates) ----
  * (syncs)  *count = rows seen; min/max undefined when *count == 0. */
@@ -296,6 +300,11 @@ int rfx_hip_group_rank(rfx_ctx_t *ctx, const rfx_group_tables_t *t, int64_t tota
  * Any of d_keys / d_first_ids / d_results[a] may be NULL to skip it. */
 int rfx_hip_group_emit(rfx_ctx_t *ctx, const rfx_agg_t *aggs, const rfx_group_tables_t *t, int64_t *d_keys,
                        int64_t *d_first_ids, void *const *d_results);
+/* Row-range sharding: the tables hold GLOBAL first-row ids after the merge, the aggregate columns are this GPU's rows
+ * [row0, row0 + local_rows).  FIRST results are the value where this GPU owns the group's first row and 0 elsewhere: summing the
+ * result column over the GPUs (as integers) yields the value -- exactly one GPU contributes.  Everything else as rfx_hip_group_emit. */
+int rfx_hip_group_emit_sharded(rfx_ctx_t *ctx, const rfx_agg_t *aggs, const rfx_group_tables_t *t, int64_t row0, int64_t local_rows,
+                               int64_t *d_keys, int64_t *d_first_ids, void *const *d_results);
 
 /* ---- K9: sparse keys (range > rows): open-addressed table, same table/merge contract keyed by slot ---- */
 typedef struct rfx_hash_tables {
@@ -316,6 +325,8 @@ int rfx_hip_hash_tables_merge(rfx_ctx_t *ctx, const rfx_agg_t *aggs, const rfx_h
 int rfx_hip_hash_rank(rfx_ctx_t *ctx, const rfx_hash_tables_t *t, int64_t total_rows, int64_t *ngroups);
 int rfx_hip_hash_emit(rfx_ctx_t *ctx, const rfx_agg_t *aggs, const rfx_hash_tables_t *t, int64_t *d_keys,
                       int64_t *d_first_ids, void *const *d_results);
+int rfx_hip_hash_emit_sharded(rfx_ctx_t *ctx, const rfx_agg_t *aggs, const rfx_hash_tables_t *t, int64_t row0, int64_t local_rows,
+                              int64_t *d_keys, int64_t *d_first_ids, void *const *d_results);
 
 /* ---- per-row group ids (INDEX_TYPE_IDS payload, core/index.c:2069-2089) -- only when a caller wants it ---- */
 int rfx_hip_group_ids_dense(rfx_ctx_t *ctx, const int64_t *d_key, int64_t nrows, const rfx_group_tables_t *t,
@@ -371,6 +382,32 @@ int rfx_hip_join_probe_dense(rfx_ctx_t *ctx, const int64_t *d_left_keys, int64_t
                              int64_t *d_ids);
 int rfx_hip_join_probe_hash(rfx_ctx_t *ctx, const int64_t *d_left_keys, int64_t nleft, const rfx_hash_tables_t *t, int64_t *d_ids);
 int rfx_hip_gather_or(rfx_ctx_t *ctx, const void *d_right, const void *d_left, const int64_t *d_ids, int64_t n, uint64_t fill_bits, void *d_out);
+
+/* ---- multi-GPU: row-range sharding, one process per GPU, ONE exchange per query over RCCL / xGMI (rfx_dist.hip) ----
+ * GPU g holds rows [row0_g, row0_g + n_g) of every column; the per-GPU partial states merge exactly as the reference merges its
+ * per-thread partials (AGGR_COLLECT core/aggr.c:163-181, unop_fold core/math.c:2206-2228, core/index.c:1866-1906).
+ * Communicator: rank 0 draws 128 bytes with rfx_dist_unique_id, hands them to every rank through the host's own side channel,
+ * every rank calls rfx_dist_init (collective).  RCCL is loaded at that moment (dlopen), never by single-GPU users.  Without a
+ * communicator every call below is the identity (world 1). */
+#define RFX_DIST_ID_BYTES 128
+int rfx_dist_unique_id(void *id128);
+int rfx_dist_init(rfx_ctx_t *ctx, int world, int rank, const void *id128); /* collective */
+int rfx_dist_finalize(rfx_ctx_t *ctx);
+int rfx_dist_world(rfx_ctx_t *ctx, int *world, int *rank);
+/* key scope agreed over the ranks: in = this rank's (min, max, rows seen), out = the table's.  One all-gather of 32 B.  (syncs) */
+int rfx_dist_scope(rfx_ctx_t *ctx, int64_t *kmin, int64_t *kmax, int64_t *seen);
+/* dense group tables, in place: first MIN, sums / counts SUM, min / max MIN / MAX on the ordered image -- one fused exchange
+ * (ncclGroupStart .. End; neighbouring arrays of one class become one call), asynchronous on the context's stream */
+int rfx_dist_group_tables_allreduce(rfx_ctx_t *ctx, const rfx_agg_t *aggs, const rfx_group_tables_t *t);
+/* scalar partials: d_all[r * n + i] = rank r's d_local[i]; asynchronous */
+int rfx_dist_partials_allgather(rfx_ctx_t *ctx, const rfx_partial_t *d_local, int n, rfx_partial_t *d_all);
+/* rfx_hip_filter_aggr_host over the sharded table: local fused pass + one all-gather + the rank-ordered fold.  (syncs) */
+int rfx_dist_filter_aggr_host(rfx_ctx_t *ctx, const rfx_pred_t *preds, int npred, int logic, const rfx_agg_t *aggs, int nagg,
+                              int64_t nrows, int64_t row0, rfx_value_t *values, int64_t *selected);
+/* in-place all-reduce of 8-byte integers, op 0 SUM / 1 MIN / 2 MAX; all-gather of `bytes` bytes per rank; both asynchronous */
+int rfx_dist_allreduce_i64(rfx_ctx_t *ctx, int64_t *d_buf, int64_t n, int op);
+int rfx_dist_allgather(rfx_ctx_t *ctx, const void *d_in, size_t bytes, void *d_out);
+int64_t rfx_dist_calls(rfx_ctx_t *ctx); /* collectives issued so far */
 
 /* ---- bucketed group keys: (xbar col width), XBARI64 core/ops.h:192-193 ----
  * d_out[r] = null for a null input, else the largest multiple of `width` (> 0) that is <= d_col[r].  Group on the result

@@ -91,6 +91,12 @@ rfx_obj_p rfx_first(rfx_obj_p x);
 /* ---- residency ---------------------------------------------------------------------------------------------------- */
 rfx_obj_p rfx_pin(rfx_obj_p table_or_column);   /* unary_f: upload + keep resident; returns a clone of its argument */
 rfx_obj_p rfx_unpin(rfx_obj_p table_or_column); /* unary_f: drop the device copies */
+/* unary_f: the host writes into this vector / this table's columns in place -- drop every cached device copy overlapping them
+ * (needed for PINNED entries only: unpinned ones are re-validated against a checksum of the full payload on every use) */
+rfx_obj_p rfx_invalidate(rfx_obj_p table_or_column);
+/* unary_f: I64[8] counters since load: {selects on the GPU, selects delegated to the host, joins on the GPU, joins delegated,
+ * uploads, cache hits, stale entries refreshed, operator calls}; the argument is ignored */
+rfx_obj_p rfx_stats(rfx_obj_p ignored);
 void rfx_cache_clear(void);
 int64_t rfx_cache_bytes(void);
 /* statistics of the most recent rfx_select: 1 = ran on the GPU path, 0 = delegated to the host's ray_select */

@@ -134,6 +134,7 @@ PROTOTYPES = {
     "rfx_hip_where_begin": (C.c_int, [_ctx, _P(Pred), C.c_int, C.c_int, C.c_void_p, C.c_int64, _P(C.c_int64)]),
     "rfx_hip_where_emit": (C.c_int, [_ctx, C.c_int64, C.c_void_p]),
     "rfx_hip_gather": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "rfx_hip_gather_checked": (C.c_int, [_ctx, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]),
     "rfx_hip_scope_i64": (C.c_int, [_ctx, C.c_void_p, _P(Pred), C.c_int, C.c_int, C.c_int64, _P(C.c_int64), _P(C.c_int64), _P(C.c_int64)]),
     "rfx_hip_group_scope": (C.c_int, [_ctx, C.c_void_p, _P(Pred), C.c_int, C.c_int, _P(Agg), C.c_int, C.c_int64, _P(C.c_int64), _P(C.c_int64), _P(C.c_int64)]),
     "rfx_hip_group_table_arrays": (C.c_int, [_P(Agg), C.c_int, _P(C.c_int)]),
@@ -141,12 +142,25 @@ PROTOTYPES = {
     "rfx_hip_group_dense_accumulate": (C.c_int, [_ctx, C.c_void_p, _P(Pred), C.c_int, C.c_int, _P(Agg), C.c_int64, C.c_int64, _P(GroupTables)]),
     "rfx_hip_group_rank": (C.c_int, [_ctx, _P(GroupTables), C.c_int64, _P(C.c_int64)]),
     "rfx_hip_group_emit": (C.c_int, [_ctx, _P(Agg), _P(GroupTables), C.c_void_p, C.c_void_p, _P(C.c_void_p)]),
+    "rfx_hip_group_emit_sharded": (C.c_int, [_ctx, _P(Agg), _P(GroupTables), C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, _P(C.c_void_p)]),
+    "rfx_hip_hash_emit_sharded": (C.c_int, [_ctx, _P(Agg), _P(HashTables), C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, _P(C.c_void_p)]),
     "rfx_hip_hash_tables_init": (C.c_int, [_ctx, _P(Agg), _P(HashTables)]),
     "rfx_hip_group_hash_accumulate": (C.c_int, [_ctx, C.c_void_p, _P(Pred), C.c_int, C.c_int, _P(Agg), C.c_int64, C.c_int64, _P(HashTables)]),
     "rfx_hip_hash_tables_merge": (C.c_int, [_ctx, _P(Agg), _P(HashTables), _P(HashTables)]),
     "rfx_hip_hash_rank": (C.c_int, [_ctx, _P(HashTables), C.c_int64, _P(C.c_int64)]),
     "rfx_hip_hash_emit": (C.c_int, [_ctx, _P(Agg), _P(HashTables), C.c_void_p, C.c_void_p, _P(C.c_void_p)]),
     "rfx_hip_group_ids_dense": (C.c_int, [_ctx, C.c_void_p, C.c_int64, _P(GroupTables), C.c_void_p]),
+    "rfx_dist_unique_id": (C.c_int, [C.c_void_p]),
+    "rfx_dist_init": (C.c_int, [_ctx, C.c_int, C.c_int, C.c_void_p]),
+    "rfx_dist_finalize": (C.c_int, [_ctx]),
+    "rfx_dist_world": (C.c_int, [_ctx, _P(C.c_int), _P(C.c_int)]),
+    "rfx_dist_scope": (C.c_int, [_ctx, _P(C.c_int64), _P(C.c_int64), _P(C.c_int64)]),
+    "rfx_dist_group_tables_allreduce": (C.c_int, [_ctx, _P(Agg), _P(GroupTables)]),
+    "rfx_dist_partials_allgather": (C.c_int, [_ctx, C.c_void_p, C.c_int, C.c_void_p]),
+    "rfx_dist_filter_aggr_host": (C.c_int, [_ctx, _P(Pred), C.c_int, C.c_int, _P(Agg), C.c_int, C.c_int64, C.c_int64, _P(Value), _P(C.c_int64)]),
+    "rfx_dist_allreduce_i64": (C.c_int, [_ctx, C.c_void_p, C.c_int64, C.c_int]),
+    "rfx_dist_allgather": (C.c_int, [_ctx, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "rfx_dist_calls": (C.c_int64, [_ctx]),
     "rfx_hip_hash_fnv1a_i64": (C.c_int, [_ctx, C.c_void_p, C.c_int64, C.c_void_p]),
     "rfx_hip_hash_mix_u64": (C.c_int, [_ctx, C.c_void_p, C.c_int64, C.c_uint64, C.c_void_p]),
     "rfx_agg_input_type": (C.c_int, [_P(Agg)]),

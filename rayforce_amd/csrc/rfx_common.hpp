@@ -90,6 +90,14 @@ struct rfx_ctx {
     i64 ck_nrows, ck_tpw;
     size_t ck_max_chunks;
     u64 ck_sig[RFX_MAX_PREDS][6];
+    // multi-GPU exchange (rfx_dist.hip): RCCL communicator of this context's rank, scratch for the small gathers
+    void *comm;
+    int world, rank;
+    void *d_dist;
+    size_t dist_bytes;
+    i64 dist_calls;     // collectives issued (tests count them)
+    void *ext_p[8];     // reserved: new state goes here without touching the layout every translation unit was compiled against
+    i64 ext_i[8];
 };
 
 int rfx_ws_reserve(rfx_ctx *ctx, size_t bytes);

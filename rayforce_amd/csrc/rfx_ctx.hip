@@ -60,6 +60,8 @@ extern "C" int rfx_hip_ctx_destroy(rfx_ctx_t *c) {
     if (!c) return RFX_OK;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    (void)rfx_dist_finalize(c);
+    if (c->d_dist) (void)hipFree(c->d_dist);
     if (c->d_ws) (void)hipFree(c->d_ws);
     if (c->d_bitmap) (void)hipFree(c->d_bitmap);
     if (c->d_blksum) (void)hipFree(c->d_blksum);

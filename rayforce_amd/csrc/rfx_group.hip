@@ -591,7 +591,10 @@ __global__ __launch_bounds__(RFX_BLOCK) void k_group_emit(const EmitArgs A, cons
         if (A.out_first) A.out_first[g] = (i64)f;
         for (int a = 0; a < A.nagg; a++) {
             if (!A.out[a]) continue;
-            if (A.kinds[a] == RFX_AGG_FIRST) A.out[a][g] = A.col[a] ? A.col[a][(i64)f - A.row0] : 0ULL;
+            if (A.kinds[a] == RFX_AGG_FIRST) {
+                const i64 lr = (i64)f - A.row0; // row-range sharding: only the GPU that owns the group's first row has its value
+                A.out[a][g] = (A.col[a] && lr >= 0 && (A.nloc == 0 || lr < A.nloc)) ? A.col[a][lr] : 0ULL;
+            }
             else A.out[a][g] = group_final(A.kinds[a], A.f64s[a], A.acc[a][i], A.cnt[a] ? A.cnt[a][i] : 0ULL, A.skips[a]);
         }
     }
@@ -609,7 +612,12 @@ int rfx_emit_slots(rfx_ctx *c, const EmitArgs &A) {
 
 extern "C" int rfx_hip_group_emit(rfx_ctx_t *c, const rfx_agg_t *aggs, const rfx_group_tables_t *t, int64_t *d_keys,
                                   int64_t *d_first_ids, void *const *d_results) {
+    return rfx_hip_group_emit_sharded(c, aggs, t, 0, 0, d_keys, d_first_ids, d_results);
+}
+extern "C" int rfx_hip_group_emit_sharded(rfx_ctx_t *c, const rfx_agg_t *aggs, const rfx_group_tables_t *t, int64_t row0, int64_t local_rows,
+                                          int64_t *d_keys, int64_t *d_first_ids, void *const *d_results) {
     RFX_REQUIRE(c, RFX_EINVAL, "ctx is NULL");
+    RFX_REQUIRE(local_rows >= 0, RFX_EINVAL, "local_rows < 0");
     int rc = check_tables(aggs, t);
     if (rc != RFX_OK) return rc;
     RFX_REQUIRE(c->gid_cap >= (size_t)t->range, RFX_ESTATE, "group_emit without group_rank");
@@ -621,6 +629,8 @@ extern "C" int rfx_hip_group_emit(rfx_ctx_t *c, const rfx_agg_t *aggs, const rfx
     A.first = (const u64 *)t->d_first;
     A.out_keys = (i64 *)d_keys;
     A.out_first = (i64 *)d_first_ids;
+    A.row0 = row0;
+    A.nloc = local_rows;
     for (int a = 0; a < t->nagg; a++) {
         A.kinds[a] = aggs[a].kind;
         A.f64s[a] = rfx_agg_input_type(&aggs[a]) == RFX_F64;

@@ -165,6 +165,7 @@ struct EmitArgs {
     const u64 *cnt[RFX_MAX_AGGS];
     const u64 *col[RFX_MAX_AGGS]; // FIRST: source column (local rows), may be NULL
     i64 row0;                     // FIRST: global id of col[0]
+    i64 nloc;                     // FIRST: rows col[] holds (0 = unbounded): a first row another GPU owns reads as 0 here, the owner supplies it
     i64 *out_keys;
     i64 *out_first;
     u64 *out[RFX_MAX_AGGS];

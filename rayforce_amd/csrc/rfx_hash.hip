@@ -254,7 +254,12 @@ extern "C" int rfx_hip_hash_rank(rfx_ctx_t *c, const rfx_hash_tables_t *t, int64
 
 extern "C" int rfx_hip_hash_emit(rfx_ctx_t *c, const rfx_agg_t *aggs, const rfx_hash_tables_t *t, int64_t *d_keys,
                                  int64_t *d_first_ids, void *const *d_results) {
+    return rfx_hip_hash_emit_sharded(c, aggs, t, 0, 0, d_keys, d_first_ids, d_results);
+}
+extern "C" int rfx_hip_hash_emit_sharded(rfx_ctx_t *c, const rfx_agg_t *aggs, const rfx_hash_tables_t *t, int64_t row0, int64_t local_rows,
+                                         int64_t *d_keys, int64_t *d_first_ids, void *const *d_results) {
     RFX_REQUIRE(c, RFX_EINVAL, "ctx is NULL");
+    RFX_REQUIRE(local_rows >= 0, RFX_EINVAL, "local_rows < 0");
     int rc = check_hash(aggs, t);
     if (rc != RFX_OK) return rc;
     RFX_REQUIRE(c->gid_cap >= (size_t)t->capacity + 1, RFX_ESTATE, "hash_emit without hash_rank");
@@ -266,6 +271,8 @@ extern "C" int rfx_hip_hash_emit(rfx_ctx_t *c, const rfx_agg_t *aggs, const rfx_
     A.keys = (const u64 *)t->d_keys;
     A.out_keys = (i64 *)d_keys;
     A.out_first = (i64 *)d_first_ids;
+    A.row0 = row0;
+    A.nloc = local_rows;
     for (int a = 0; a < t->nagg; a++) {
         A.kinds[a] = aggs[a].kind;
         A.f64s[a] = rfx_agg_input_type(&aggs[a]) == RFX_F64;

@@ -62,10 +62,28 @@ extern "C" int rfx_hip_h2d_pipelined(rfx_ctx_t *c, void *d_dst, const void *src,
     if (!bytes) return RFX_OK;
     RFX_REQUIRE(d_dst && src, RFX_EINVAL, "NULL argument");
     if (bytes < IO_CHUNK) return rfx_hip_h2d(c, d_dst, src, bytes);
-    if (!c->io_stage[0]) {
+    if (!c->io_stage[IO_NBUF - 1]) { // all buffers and events exist, or none is published (a half-built set is torn down)
+        void *st[IO_NBUF] = {NULL, NULL, NULL, NULL};
+        hipEvent_t ev[IO_NBUF];
+        bool have_ev[IO_NBUF] = {false, false, false, false};
+        hipError_t e = hipSuccess;
+        for (int i = 0; i < IO_NBUF && e == hipSuccess; i++) {
+            e = hipHostMalloc(&st[i], IO_CHUNK, hipHostMallocDefault);
+            if (e == hipSuccess) {
+                e = hipEventCreateWithFlags(&ev[i], hipEventDisableTiming);
+                have_ev[i] = e == hipSuccess;
+            }
+        }
+        if (e != hipSuccess) {
+            for (int i = 0; i < IO_NBUF; i++) {
+                if (have_ev[i]) (void)hipEventDestroy(ev[i]);
+                if (st[i]) (void)hipHostFree(st[i]);
+            }
+            RFX_HIP_CHECK(e);
+        }
         for (int i = 0; i < IO_NBUF; i++) {
-            RFX_HIP_CHECK(hipHostMalloc(&c->io_stage[i], IO_CHUNK, hipHostMallocDefault));
-            RFX_HIP_CHECK(hipEventCreateWithFlags(&c->io_done[i], hipEventDisableTiming));
+            c->io_done[i] = ev[i];
+            c->io_stage[i] = st[i];
         }
     }
     size_t off = 0;
@@ -137,7 +155,7 @@ extern "C" int rfx_column_file_stat(const char *path, int32_t *type, int64_t *le
         rfx_set_error("rfx_column_file_stat: %s holds type %d; only 8-byte columns (i64 / symbol ids / timestamp / f64) are on this path", path, (int)h.type);
         return RFX_EINVAL;
     }
-    if (h.len < 0 || (int64_t)st.st_size < 16 + h.len * es) {
+    if (h.len < 0 || st.st_size < 16 || h.len > ((int64_t)st.st_size - 16) / es) { // (no 16 + len * es: a corrupt length must not overflow the test)
         rfx_set_error("rfx_column_file_stat: %s is truncated (%lld rows declared)", path, (long long)h.len);
         return RFX_EINVAL;
     }

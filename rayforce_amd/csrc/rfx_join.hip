@@ -60,6 +60,15 @@ __global__ __launch_bounds__(RFX_BLOCK) void k_gather_or(const u64 *__restrict__
     }
 }
 
+// at_vec_i64_by_i64 / at_vec_f64_by_i64 (core/items.c:53-72): an index that is null, negative or >= len reads as the typed null
+__global__ __launch_bounds__(RFX_BLOCK) void k_gather_checked(const u64 *__restrict__ col, i64 len, const i64 *__restrict__ ids, i64 n, u64 null_bits,
+                                                              u64 *__restrict__ out) {
+    for (i64 i = blockIdx.x * (i64)RFX_BLOCK + threadIdx.x; i < n; i += (i64)gridDim.x * RFX_BLOCK) {
+        const i64 id = ids[i];
+        out[i] = (id >= 0 && id < len) ? col[id] : null_bits;
+    }
+}
+
 static int join_grid(rfx_ctx *c, i64 n) {
     const i64 blocks = (n + RFX_BLOCK - 1) / RFX_BLOCK;
     int grid = rfx_grid(c) * 4;
@@ -96,6 +105,17 @@ extern "C" int rfx_hip_gather_or(rfx_ctx_t *c, const void *d_right, const void *
     RFX_REQUIRE(d_right && d_ids && d_out, RFX_EINVAL, "NULL argument");
     hipLaunchKernelGGL(k_gather_or, dim3(join_grid(c, n)), dim3(RFX_BLOCK), 0, c->stream, (const u64 *)d_right, (const u64 *)d_left, (const i64 *)d_ids, (i64)n,
                        (u64)fill_bits, (u64 *)d_out);
+    RFX_HIP_CHECK(hipGetLastError());
+    return RFX_OK;
+}
+
+extern "C" int rfx_hip_gather_checked(rfx_ctx_t *c, const void *d_col, int64_t col_len, int32_t col_type, const int64_t *d_ids, int64_t m, void *d_out) {
+    RFX_REQUIRE(c, RFX_EINVAL, "ctx is NULL");
+    if (m <= 0) return RFX_OK;
+    RFX_REQUIRE((d_col || col_len == 0) && d_ids && d_out && col_len >= 0, RFX_EINVAL, "NULL argument");
+    RFX_REQUIRE(col_type == RFX_I64 || col_type == RFX_F64, RFX_EINVAL, "column type must be RFX_I64 or RFX_F64");
+    hipLaunchKernelGGL(k_gather_checked, dim3(join_grid(c, m)), dim3(RFX_BLOCK), 0, c->stream, (const u64 *)d_col, (i64)col_len, (const i64 *)d_ids, (i64)m,
+                       col_type == RFX_F64 ? (u64)RFX_NAN_BITS : (u64)RFX_NULL_I64_D, (u64 *)d_out);
     RFX_HIP_CHECK(hipGetLastError());
     return RFX_OK;
 }

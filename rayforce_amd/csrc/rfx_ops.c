@@ -12,7 +12,9 @@
 #include <dlfcn.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <pthread.h>
 #include <stdlib.h>
+#include <unistd.h>
 #include <string.h>
 #include "rfx_abi.h"
 #include "rfx_hip.h"
@@ -158,37 +160,94 @@ static int ensure_ctx(void) {
     return rfx_hip_ctx_create(g_device, NULL, &g_ctx);
 }
 
+/* Residency cache: host vector payload -> device copy, keyed by (payload address, length, type).
+ *
+ * A cached copy is used again only if it is PROVEN current:
+ *   - default: the FULL payload is checksummed on every use (threaded multiply-xor over every 8-byte word, position dependent) and
+ *     compared with the checksum taken at upload -- an in-place write of any single cell, a copy-on-write successor that the
+ *     allocator put at the same address, a freed temporary whose address was recycled: all change the checksum and cost one
+ *     re-upload, never a stale answer.  (Round 1 sampled 64 cells: one changed cell could escape; B8 masks collided almost
+ *     always.)  Reading the host payload costs ~10 ms per GB on the box's cores -- still 15x cheaper than the PCIe upload it saves;
+ *   - rfx_pin: the host promises to call rfx_invalidate / rfx_unpin before it writes into the vector (INTEGRATION.md shows the
+ *     two places in the reference: `set` of a column and the rc == 1 in-place arithmetic, core/math.c:2248); a pinned entry is
+ *     trusted without the checksum, which is what makes repeated queries over 8 GB columns free of host work.
+ * Entries touched by the operator call in flight are never evicted (its descriptors hold their device pointers); temporaries
+ * that only live for one call (masks handed to `where`, id vectors of `at` / MAPFILTER) are uploaded into per-call scratch and
+ * not cached at all. */
 typedef struct {
     const void *host;
     int64_t len;
     int type;
-    uint64_t stamp;
+    uint64_t sum;
     void *dev;
     size_t bytes;
     int pinned;
-    uint64_t tick;
+    uint64_t tick, epoch;
 } resident_t;
 static resident_t *g_res;
 static int g_nres, g_capres;
-static uint64_t g_tick;
+static uint64_t g_tick, g_epoch = 1;
 static size_t g_res_bytes;
+static int64_t g_stat[8]; /* see rfx_stats */
+enum { ST_SELECT_GPU, ST_SELECT_DELEGATED, ST_JOIN_GPU, ST_JOIN_DELEGATED, ST_UPLOADS, ST_CACHE_HITS, ST_CACHE_STALE, ST_OPS };
 
-static uint64_t stamp_of(const void *p, int64_t len, int esz) {
-    /* sampled checksum: 64 probes across the payload catch in-place rewrites of a cached column (not every single-cell
-     * update: mutate-in-place callers should rfx_unpin / rfx_cache_clear) */
-    uint64_t h = 1469598103934665603ULL ^ (uint64_t)len;
-    if (len <= 0) return h;
-    const unsigned char *b = (const unsigned char *)p;
-    int64_t step = len / 64 + 1;
-    for (int64_t i = 0; i < len; i += step) {
-        uint64_t v = 0;
-        memcpy(&v, b + (size_t)i * esz, (size_t)(esz < 8 ? esz : 8));
-        h = (h ^ v) * 1099511628211ULL;
-    }
-    uint64_t v = 0;
-    memcpy(&v, b + (size_t)(len - 1) * esz, (size_t)(esz < 8 ? esz : 8));
-    return (h ^ v) * 1099511628211ULL;
+typedef struct {
+    const unsigned char *p;
+    size_t bytes;
+    uint64_t h;
+} sum_job_t;
+static uint64_t sum_range(const unsigned char *p, size_t bytes) {
+    /* four independent multiply-xor lanes (the multiply's latency is the limit of a single chain), folded in a fixed order */
+    const uint64_t K = 0x9E3779B97F4A7C15ULL;
+    uint64_t h0 = 0x243F6A8885A308D3ULL, h1 = 0x13198A2E03707344ULL, h2 = 0xA4093822299F31D0ULL, h3 = 0x082EFA98EC4E6C89ULL;
+    size_t nw = bytes / 8, i = 0;
+    const uint64_t *w = (const uint64_t *)p; /* payloads are 8-byte aligned (obj + 16, 32-byte aligned blocks) */
+    if (((uintptr_t)p & 7) == 0) {
+        for (; i + 4 <= nw; i += 4) {
+            h0 = (h0 ^ w[i]) * K;
+            h1 = (h1 ^ w[i + 1]) * K;
+            h2 = (h2 ^ w[i + 2]) * K;
+            h3 = (h3 ^ w[i + 3]) * K;
+        }
+        for (; i < nw; i++) h0 = (h0 ^ w[i]) * K;
+    } else i = 0, nw = 0;
+    uint64_t h = ((h0 ^ (h1 >> 29)) * K) ^ ((h2 ^ (h3 >> 31)) * K);
+    for (size_t b = nw * 8; b < bytes; b++) h = (h ^ p[b]) * K;
+    return h ^ (h >> 32);
 }
+static void *sum_worker(void *arg) {
+    sum_job_t *j = (sum_job_t *)arg;
+    j->h = sum_range(j->p, j->bytes);
+    return NULL;
+}
+static uint64_t payload_sum(const void *p, size_t bytes) {
+    enum { MAXT = 32 };
+    int nt = 1;
+    if (bytes >= ((size_t)8 << 20)) {
+        long cores = sysconf(_SC_NPROCESSORS_ONLN);
+        nt = cores > MAXT ? MAXT : (cores < 1 ? 1 : (int)cores);
+        if ((size_t)nt > bytes >> 22) nt = (int)(bytes >> 22); /* >= 4 MB per thread */
+    }
+    if (nt <= 1) return sum_range((const unsigned char *)p, bytes) ^ (uint64_t)bytes;
+    sum_job_t job[MAXT];
+    pthread_t th[MAXT];
+    size_t per = ((bytes / (size_t)nt) + 63) & ~(size_t)63, off = 0;
+    int started = 0;
+    for (int i = 0; i < nt; i++) {
+        job[i].p = (const unsigned char *)p + off;
+        job[i].bytes = (i == nt - 1 || off + per > bytes) ? bytes - off : per;
+        off += job[i].bytes;
+        if (i < nt - 1 && pthread_create(&th[i], NULL, sum_worker, &job[i]) == 0) started |= 1 << i;
+        else sum_worker(&job[i]);
+    }
+    uint64_t h = (uint64_t)bytes;
+    for (int i = 0; i < nt; i++) {
+        if (started & (1 << i)) pthread_join(th[i], NULL);
+        h = (h ^ job[i].h) * 0x9E3779B97F4A7C15ULL; /* chunk order matters: a value moved between chunks changes the sum */
+    }
+    return h;
+}
+
 static void res_free(int i) {
     if (g_res[i].dev) rfx_hip_free(g_ctx, g_res[i].dev);
     g_res_bytes -= g_res[i].bytes;
@@ -204,28 +263,70 @@ static size_t cache_budget(void) {
     return e ? (size_t)strtoull(e, NULL, 10) : (size_t)200 << 30; /* of the 288 GB of HBM3E */
 }
 
+/* per-call device scratch (temporaries of the operator call in flight): released by op_end() */
+static void *g_optmp[64];
+static int g_noptmp;
+static void op_begin(void) {
+    g_epoch++;
+    g_stat[ST_OPS]++;
+}
+static void op_end(void) {
+    for (int i = 0; i < g_noptmp; i++) rfx_hip_free(g_ctx, g_optmp[i]);
+    g_noptmp = 0;
+}
+/* device copy of a vector that lives for this call only (never cached) */
+static int transient(obj_p v, const void **dev) {
+    const int esz = (v->type == RFX_TYPE_B8) ? 1 : 8;
+    const size_t bytes = (size_t)v->len * esz;
+    if (g_noptmp >= (int)(sizeof(g_optmp) / sizeof(g_optmp[0]))) return RFX_ELIMIT;
+    void *d = NULL;
+    int rc = rfx_hip_malloc(g_ctx, &d, bytes ? bytes : 8);
+    if (rc != RFX_OK) return rc;
+    g_optmp[g_noptmp++] = d;
+    if (bytes) rc = rfx_hip_h2d_pipelined(g_ctx, d, RFX_AS_RAW(v), bytes);
+    g_stat[ST_UPLOADS]++;
+    *dev = d;
+    return rc;
+}
+
 /* device pointer of a host vector's payload (uploading it if needed) */
 static int resident(obj_p col, int pin, const void **dev) {
-    int esz = (col->type == RFX_TYPE_B8) ? 1 : 8;
+    const int esz = (col->type == RFX_TYPE_B8) ? 1 : 8;
     const void *host = RFX_AS_RAW(col);
-    uint64_t st = stamp_of(host, col->len, esz);
+    const size_t bytes = (size_t)col->len * esz;
+    int have_sum = 0;
+    uint64_t sum = 0;
     for (int i = 0; i < g_nres; i++)
         if (g_res[i].host == host && g_res[i].len == col->len && g_res[i].type == col->type) {
-            if (g_res[i].stamp == st) {
+            if (!g_res[i].pinned) { /* unpinned: prove the copy current */
+                sum = payload_sum(host, bytes);
+                have_sum = 1;
+            }
+            if (g_res[i].pinned || g_res[i].sum == sum) {
                 g_res[i].tick = ++g_tick;
+                g_res[i].epoch = g_epoch;
                 g_res[i].pinned |= pin;
+                g_stat[ST_CACHE_HITS]++;
                 *dev = g_res[i].dev;
                 return RFX_OK;
             }
-            res_free(i); /* stale */
-            break;
+            /* stale: the payload changed under the same address -- refresh the device copy in place */
+            g_stat[ST_CACHE_STALE]++;
+            int rc = rfx_hip_h2d_pipelined(g_ctx, g_res[i].dev, host, bytes);
+            if (rc != RFX_OK) { res_free(i); return rc; }
+            g_stat[ST_UPLOADS]++;
+            g_res[i].sum = sum;
+            g_res[i].tick = ++g_tick;
+            g_res[i].epoch = g_epoch;
+            g_res[i].pinned |= pin;
+            *dev = g_res[i].dev;
+            return RFX_OK;
         }
-    size_t bytes = (size_t)col->len * esz;
     while (g_nres && g_res_bytes + bytes > cache_budget()) {
-        int victim = -1;
+        int victim = -1; /* least recently used, not pinned, not in use by the call in flight */
         for (int i = 0; i < g_nres; i++)
-            if (!g_res[i].pinned && (victim < 0 || g_res[i].tick < g_res[victim].tick)) victim = i;
-        if (victim < 0) break;
+            if (!g_res[i].pinned && g_res[i].epoch != g_epoch && (victim < 0 || g_res[i].tick < g_res[victim].tick)) victim = i;
+        if (victim < 0) break; /* everything left is pinned or in use: go over budget rather than free what the call reads */
         res_free(victim);
     }
     void *d = NULL;
@@ -233,14 +334,27 @@ static int resident(obj_p col, int pin, const void **dev) {
     if (rc != RFX_OK) return rc;
     rc = rfx_hip_h2d_pipelined(g_ctx, d, host, bytes); /* heap vector or mmapped column file alike: staged through pinned buffers */
     if (rc != RFX_OK) { rfx_hip_free(g_ctx, d); return rc; }
+    g_stat[ST_UPLOADS]++;
+    if (!have_sum) sum = payload_sum(host, bytes);
     if (g_nres == g_capres) {
         g_capres = g_capres ? g_capres * 2 : 32;
         g_res = (resident_t *)realloc(g_res, sizeof(resident_t) * (size_t)g_capres);
     }
-    g_res[g_nres++] = (resident_t){host, col->len, col->type, st, d, bytes, pin, ++g_tick};
+    g_res[g_nres++] = (resident_t){host, col->len, col->type, sum, d, bytes, pin, ++g_tick, g_epoch};
     g_res_bytes += bytes;
     *dev = d;
     return RFX_OK;
+}
+/* drop every cached copy that overlaps the vector's payload */
+static void invalidate_payload(obj_p v) {
+    if (!v || v->type <= 0) return;
+    const int esz = (v->type == RFX_TYPE_B8) ? 1 : 8;
+    const char *lo = (const char *)RFX_AS_RAW(v), *hi = lo + (size_t)v->len * esz;
+    for (int i = 0; i < g_nres;) {
+        const char *a = (const char *)g_res[i].host, *b = a + g_res[i].bytes;
+        if (a < hi && lo < b) res_free(i);
+        else i++;
+    }
 }
 
 static int col_ctype(obj_p c) {
@@ -481,7 +595,7 @@ static int build_xnodes(obj_p tab, obj_p e, rfx_xnode_t *nodes, int *nn, int *nc
 }
 
 /* ------------------------------------------------------------------------------------------------ select */
-rfx_obj_p rfx_select(rfx_obj_p dict) {
+static obj_p select_impl(obj_p dict) {
     rfx_host_bind();
     if (!dict || dict->type != RFX_TYPE_DICT || RFX_AS_LIST(dict)[0]->type != RFX_TYPE_SYMBOL) return fail("select: expected a dict");
     obj_p from = dict_get(dict, "from");
@@ -883,9 +997,17 @@ done:
     H.drop(tab);
     return res;
 }
+rfx_obj_p rfx_select(rfx_obj_p dict) {
+    op_begin();
+    g_last_gpu = 0;
+    obj_p r = select_impl(dict);
+    g_stat[g_last_gpu ? ST_SELECT_GPU : ST_SELECT_DELEGATED]++;
+    op_end();
+    return r;
+}
 
 /* ------------------------------------------------------------------------------------------------ single operators */
-static obj_p cmp_op(int op, obj_p x, obj_p y) {
+static obj_p cmp_impl(int op, obj_p x, obj_p y) {
     rfx_host_bind();
     if (!x || !y) return fail("cmp: null argument");
     if (!(x->type > 0 && col_ctype(x) && (y->type == -RFX_TYPE_I64 || y->type == -RFX_TYPE_F64 || (y->type > 0 && col_ctype(y))))) {
@@ -916,8 +1038,14 @@ static obj_p cmp_op(int op, obj_p x, obj_p y) {
     if (!ok) { H.drop(out); return fail_hip("cmp_mask"); }
     return out;
 }
+static obj_p cmp_op(int op, obj_p x, obj_p y) {
+    op_begin();
+    obj_p r = cmp_impl(op, x, y);
+    op_end();
+    return r;
+}
 /* ray_add / ray_sub / ray_mul / ray_fdiv over an i64 / f64 vector and a vector or atom (binop_map, core/math.c:2280-2345) */
-static obj_p arith_op(int xop, int fidx, obj_p x, obj_p y) {
+static obj_p arith_impl(int xop, int fidx, obj_p x, obj_p y) {
     rfx_host_bind();
     if (!x || !y) return fail("arith: null argument");
     const int xv = x->type > 0 && col_ctype(x) && x->type != RFX_TYPE_SYMBOL, yv = y->type > 0 && col_ctype(y) && y->type != RFX_TYPE_SYMBOL;
@@ -958,6 +1086,12 @@ static obj_p arith_op(int xop, int fidx, obj_p x, obj_p y) {
     if (!ok) { if (out) H.drop(out); return fail_hip("eval_expr"); }
     return out;
 }
+static obj_p arith_op(int xop, int fidx, obj_p x, obj_p y) {
+    op_begin();
+    obj_p r = arith_impl(xop, fidx, x, y);
+    op_end();
+    return r;
+}
 rfx_obj_p rfx_add(rfx_obj_p x, rfx_obj_p y) { return arith_op(RFX_X_ADD, F_ADD, x, y); }
 rfx_obj_p rfx_sub(rfx_obj_p x, rfx_obj_p y) { return arith_op(RFX_X_SUB, F_SUB, x, y); }
 rfx_obj_p rfx_mul(rfx_obj_p x, rfx_obj_p y) { return arith_op(RFX_X_MUL, F_MUL, x, y); }
@@ -992,12 +1126,12 @@ static obj_p logic_op(int logic, obj_p *x, int64_t n) {
 rfx_obj_p rfx_and(rfx_obj_p *x, int64_t n) { return logic_op(RFX_AND, x, n); }
 rfx_obj_p rfx_or(rfx_obj_p *x, int64_t n) { return logic_op(RFX_OR, x, n); }
 
-rfx_obj_p rfx_where(rfx_obj_p mask) {
+static obj_p where_impl(obj_p mask) {
     rfx_host_bind();
     if (!mask || mask->type != RFX_TYPE_B8) return fail("where: expected a B8 mask"); /* err_type, core/items.c:1395 */
     if (ensure_ctx() != RFX_OK) return fail_hip("no usable MI355X");
     const void *dm;
-    if (resident(mask, 0, &dm) != RFX_OK) return fail_hip("mask upload");
+    if (transient(mask, &dm) != RFX_OK) return fail_hip("mask upload"); /* a mask is a temporary: per-call scratch, never cached */
     int64_t count = 0;
     if (rfx_hip_where_begin(g_ctx, NULL, 0, RFX_AND, (const int8_t *)dm, mask->len, &count) != RFX_OK) return fail_hip("where");
     obj_p out = H.vector(RFX_TYPE_I64, count);
@@ -1012,11 +1146,18 @@ rfx_obj_p rfx_where(rfx_obj_p mask) {
     return out;
 }
 
+rfx_obj_p rfx_where(rfx_obj_p mask) {
+    op_begin();
+    obj_p r = where_impl(mask);
+    op_end();
+    return r;
+}
+
 /* ------------------------------------------------------------------------------------------------ equi-joins
  * (left-join [keys] x y) / (inner-join [keys] x y): ray_left_join / ray_inner_join, core/join.c:158-298 -- vary_f over (key symbols,
  * left table, right table).  Index = per left row the first right row with an equal key tuple (index_left_join_obj,
  * core/index.c:2886-2928): the group-by's first-occurrence table over the right keys (zero aggregates), probed with the left keys. */
-static obj_p join_op(int inner, obj_p *x, int64_t n) {
+static obj_p join_impl(int inner, obj_p *x, int64_t n) {
     rfx_host_bind();
     const int fidx = inner ? F_IJ : F_LJ;
     if (n != 3 || !x[0] || !x[1] || !x[2]) return fail("join: expected (keys, left table, right table)");
@@ -1191,26 +1332,42 @@ done:
     return res;
 #undef JOIN_TMP
 }
+static obj_p join_op(int inner, obj_p *x, int64_t n) {
+    op_begin();
+    g_last_gpu = 0;
+    obj_p r = join_impl(inner, x, n);
+    g_stat[g_last_gpu ? ST_JOIN_GPU : ST_JOIN_DELEGATED]++;
+    op_end();
+    return r;
+}
 rfx_obj_p rfx_left_join(rfx_obj_p *x, int64_t n) { return join_op(0, x, n); }
 rfx_obj_p rfx_inner_join(rfx_obj_p *x, int64_t n) { return join_op(1, x, n); }
 
-rfx_obj_p rfx_at(rfx_obj_p col, rfx_obj_p ids) {
+static obj_p at_impl(obj_p col, obj_p ids) {
     rfx_host_bind();
     if (!col || !ids || !col_ctype(col) || ids->type != RFX_TYPE_I64) return fail("at: expected (i64|f64 column, I64 ids)");
     if (ensure_ctx() != RFX_OK) return fail_hip("no usable MI355X");
     const void *dc, *di;
-    if (resident(col, 0, &dc) != RFX_OK || resident(ids, 0, &di) != RFX_OK) return fail_hip("upload");
+    if (resident(col, 0, &dc) != RFX_OK || transient(ids, &di) != RFX_OK) return fail_hip("upload");
     obj_p out = H.vector(col->type, ids->len);
     void *dout = NULL;
-    int ok = rfx_hip_malloc(g_ctx, &dout, (size_t)ids->len * 8 + 8) == RFX_OK && rfx_hip_gather(g_ctx, dc, (const int64_t *)di, ids->len, dout) == RFX_OK &&
+    /* ids come from the caller: null / negative / out-of-range ids read as the typed null (at_vec_*_by_i64, core/items.c:53-72) */
+    int ok = rfx_hip_malloc(g_ctx, &dout, (size_t)ids->len * 8 + 8) == RFX_OK &&
+             rfx_hip_gather_checked(g_ctx, dc, col->len, col_ctype(col), (const int64_t *)di, ids->len, dout) == RFX_OK &&
              rfx_hip_d2h(g_ctx, RFX_AS_RAW(out), dout, (size_t)ids->len * 8) == RFX_OK;
     if (dout) rfx_hip_free(g_ctx, dout);
     if (!ok) { H.drop(out); return fail_hip("gather"); }
     return out;
 }
+rfx_obj_p rfx_at(rfx_obj_p col, rfx_obj_p ids) {
+    op_begin();
+    obj_p r = at_impl(col, ids);
+    op_end();
+    return r;
+}
 
 /* scalar aggregates of a vector or of a lazy MAPFILTER (val, ids) pair (core/filter.c:29-49, core/math.c:1874-1890) */
-static obj_p fold_op(int f, int kind, obj_p x) {
+static obj_p fold_impl(int f, int kind, obj_p x) {
     rfx_host_bind();
     if (!x) return fail("aggregate: null argument");
     if (x->type == RFX_TYPE_MAPFILTER) {
@@ -1223,7 +1380,7 @@ static obj_p fold_op(int f, int kind, obj_p x) {
         }
         if (ensure_ctx() != RFX_OK) return fail_hip("no usable MI355X");
         const void *dv, *di;
-        if (resident(val, 0, &dv) != RFX_OK || resident(ids, 0, &di) != RFX_OK) return fail_hip("column upload");
+        if (resident(val, 0, &dv) != RFX_OK || transient(ids, &di) != RFX_OK) return fail_hip("column upload");
         void *dg = NULL;
         rfx_agg_t a;
         memset(&a, 0, sizeof(a));
@@ -1231,7 +1388,7 @@ static obj_p fold_op(int f, int kind, obj_p x) {
         a.kind = kind;
         rfx_value_t v;
         int ok = rfx_hip_malloc(g_ctx, &dg, (size_t)(ids->len ? ids->len : 1) * 8) == RFX_OK &&
-                 rfx_hip_gather(g_ctx, dv, (const int64_t *)di, ids->len, dg) == RFX_OK;
+                 rfx_hip_gather_checked(g_ctx, dv, val->len, col_ctype(val), (const int64_t *)di, ids->len, dg) == RFX_OK;
         a.d_col = dg;
         ok = ok && rfx_hip_filter_aggr_host(g_ctx, NULL, 0, RFX_AND, &a, 1, ids->len, &v, NULL) == RFX_OK;
         if (dg) rfx_hip_free(g_ctx, dg);
@@ -1253,6 +1410,12 @@ static obj_p fold_op(int f, int kind, obj_p x) {
     rfx_value_t v;
     if (rfx_hip_filter_aggr_host(g_ctx, NULL, 0, RFX_AND, &a, 1, x->len, &v, NULL) != RFX_OK) return fail_hip("filter_aggr");
     return value_atom(&v);
+}
+static obj_p fold_op(int f, int kind, obj_p x) {
+    op_begin();
+    obj_p r = fold_impl(f, kind, x);
+    op_end();
+    return r;
 }
 rfx_obj_p rfx_sum(rfx_obj_p x) { return fold_op(F_SUM, RFX_AGG_SUM, x); }
 rfx_obj_p rfx_avg(rfx_obj_p x) { return fold_op(F_AVG, RFX_AGG_AVG, x); }
@@ -1283,3 +1446,25 @@ static obj_p pin_op(obj_p x, int pin) {
 }
 rfx_obj_p rfx_pin(rfx_obj_p x) { return pin_op(x, 1); }
 rfx_obj_p rfx_unpin(rfx_obj_p x) { return pin_op(x, 0); }
+/* (rfx_invalidate x): the host is about to write (or has just written) into vector x / the columns of table x in place: every
+ * cached device copy that overlaps their payload is dropped, pinned or not.  The hook a host patch calls from `set` on a column and
+ * from the rc == 1 in-place arithmetic (core/math.c:2248, :2310), see INTEGRATION.md. */
+rfx_obj_p rfx_invalidate(rfx_obj_p x) {
+    rfx_host_bind();
+    if (!x) return fail("invalidate: null argument");
+    if (x->type == RFX_TYPE_TABLE) {
+        obj_p cols = RFX_AS_LIST(x)[1];
+        for (int64_t i = 0; i < cols->len; i++) invalidate_payload(RFX_AS_LIST(cols)[i]);
+    } else invalidate_payload(x);
+    return H.clone(x);
+}
+/* (rfx_stats 0): counters since load as an I64 vector -- [selects answered on the GPU, selects handed back to the host's
+ * ray_select, joins on the GPU, joins delegated, host-to-device uploads, cache hits, stale cache entries refreshed, operator
+ * calls].  What a drop-in test asserts to know that an answer really came from the device. */
+rfx_obj_p rfx_stats(rfx_obj_p x) {
+    (void)x;
+    rfx_host_bind();
+    obj_p out = H.vector(RFX_TYPE_I64, 8);
+    for (int i = 0; i < 8; i++) RFX_AS_I64(out)[i] = g_stat[i];
+    return out;
+}

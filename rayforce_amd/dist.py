@@ -155,23 +155,44 @@ def allreduce_scope(kmin: int, kmax: int, seen: int, device, group=None) -> Tupl
 class GroupHook:
     """The `_collective` callback Engine.group_by calls between its local phases."""
 
-    def __init__(self, shard: RowShard, aggs_kinds: Sequence[int], aggs_f64: Sequence[bool]):
+    def __init__(self, shard: RowShard, aggs_kinds: Sequence[int], aggs_f64: Sequence[bool], native=None):
         self.shard = shard
         self.kinds = list(aggs_kinds)
         self.f64s = list(aggs_f64)
+        self.native = native
 
     def __call__(self, phase: str, payload):
         g = self.shard.group
+        nat = self.native  # (engine, lib): the exchange runs in C over RCCL (rfx_dist.hip); None: torch.distributed (gloo tests)
         if phase == "scope":
             kmin, kmax, seen, device = payload
+            if nat:
+                a, b, c = C.c_int64(kmin), C.c_int64(kmax), C.c_int64(seen)
+                L.check(nat[1].rfx_dist_scope(nat[0]._ctx, C.byref(a), C.byref(b), C.byref(c)), "dist_scope")
+                return int(a.value), int(b.value), int(c.value)
             return allreduce_scope(kmin, kmax, seen, device, g)
         if phase == "tables":
-            store, layout, kinds, f64s = payload if len(payload) == 4 else (*payload, self.kinds, self.f64s)
+            store, layout, kinds, f64s = payload[:4] if len(payload) >= 4 else (*payload, self.kinds, self.f64s)
+            if nat and len(payload) >= 6:  # one fused exchange, no host synchronisation
+                L.check(nat[1].rfx_dist_group_tables_allreduce(nat[0]._ctx, payload[5], C.byref(payload[4])), "dist_group_tables_allreduce")
+                return None
             allreduce_tables(store, layout, kinds, f64s, g)
+            return None
+        if phase == "first_values":  # grouped FIRST: exactly one rank contributed each value, the others 0 -> integer SUM
+            for col in payload:
+                if nat:
+                    L.check(nat[1].rfx_dist_allreduce_i64(nat[0]._ctx, col.data_ptr(), col.numel(), 0), "dist_allreduce")
+                else:
+                    _all_reduce(col.view(torch.int64), dist.ReduceOp.SUM, g)
             return None
         if phase == "flag":  # logical OR of a per-rank flag
             if self.shard.world == 1:
                 return payload
+            if nat:
+                t = torch.tensor([int(payload)], dtype=torch.int64, device=nat[0].device)
+                L.check(nat[1].rfx_dist_allreduce_i64(nat[0]._ctx, t.data_ptr(), 1, 2), "dist_allreduce")
+                nat[0].sync()
+                return int(t[0])
             t = torch.tensor([int(payload)], dtype=torch.int64, device="cpu" if _gloo(g) else torch.device("cuda", torch.cuda.current_device()))
             _all_reduce(t, dist.ReduceOp.MAX, g)
             return int(t[0])
@@ -180,7 +201,12 @@ class GroupHook:
             world = self.shard.world
             if world == 1:
                 return None
-            bufs = _all_gather(store, g)
+            if nat:
+                whole = torch.empty((world,) + tuple(store.shape), dtype=store.dtype, device=store.device)
+                L.check(nat[1].rfx_dist_allgather(nat[0]._ctx, store.data_ptr(), store.numel() * store.element_size(), whole.data_ptr()), "dist_allgather")
+                bufs = list(whole.unbind(0))
+            else:
+                bufs = _all_gather(store, g)
             for r, other in enumerate(bufs):
                 if r != self.shard.rank:
                     merge(make_tables(other))
@@ -189,10 +215,25 @@ class GroupHook:
 
 
 # ---------------------------------------------------------------------------------------------- where ids
-def gather_ids(local_ids: torch.Tensor, group=None) -> torch.Tensor:
+def gather_ids(local_ids: torch.Tensor, group=None, native=None) -> torch.Tensor:
     """Concatenate per-rank ascending GLOBAL ids (already offset by row0) into the global ascending id vector."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return local_ids
+    if native:
+        eng, lib = native
+        world = dist.get_world_size(group)
+        cnt = torch.tensor([local_ids.numel()], dtype=torch.int64, device=local_ids.device)
+        cnts = torch.empty(world, dtype=torch.int64, device=local_ids.device)
+        L.check(lib.rfx_dist_allgather(eng._ctx, cnt.data_ptr(), 8, cnts.data_ptr()), "dist_allgather")
+        eng.sync()
+        sizes = [int(x) for x in cnts.cpu()]
+        m = max(sizes) if sizes else 0
+        pad = torch.zeros(max(m, 1), dtype=torch.int64, device=local_ids.device)
+        pad[: local_ids.numel()] = local_ids
+        whole = torch.empty((world, max(m, 1)), dtype=torch.int64, device=local_ids.device)
+        L.check(lib.rfx_dist_allgather(eng._ctx, pad.data_ptr(), max(m, 1) * 8, whole.data_ptr()), "dist_allgather")
+        eng.sync()
+        return torch.cat([whole[r, :s] for r, s in enumerate(sizes)])
     world = dist.get_world_size(group)
     cnt = torch.tensor([local_ids.numel()], dtype=torch.int64, device=local_ids.device)
     cnts = _all_gather(cnt, group)
@@ -212,9 +253,35 @@ class ShardedEngine:
     def __init__(self, engine, local_rows: int, group=None):
         self.eng = engine
         self.shard = RowShard(local_rows, group)
+        # Under NCCL the exchange is the library's own (rfx_dist.hip: RCCL communicator inside the context, collectives issued from
+        # C on the context's stream); torch.distributed only carries the communicator's 128-byte id.  Under gloo (CPU tests, two
+        # ranks sharing one GPU) the same merges run through torch.distributed.
+        self.native = None
+        if dist.is_initialized() and dist.get_backend(group) == "nccl":
+            lib = engine.lib
+            ident = [None]
+            if self.shard.rank == 0:
+                buf = C.create_string_buffer(128)
+                L.check(lib.rfx_dist_unique_id(buf), "dist_unique_id")
+                ident = [buf.raw]
+            if self.shard.world > 1:
+                dist.broadcast_object_list(ident, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+            L.check(lib.rfx_dist_init(engine._ctx, self.shard.world, self.shard.rank, C.c_char_p(ident[0])), "dist_init")
+            self.native = (engine, lib)
+
+    def close(self):
+        if self.native:
+            L.check(self.native[1].rfx_dist_finalize(self.eng._ctx), "dist_finalize")
+            self.native = None
 
     def filter_aggr(self, aggs, where=None, table=None):
         eng = self.eng
+        if self.native and len(aggs) <= L.RFX_MAX_AGGS:
+            try:
+                return eng.filter_aggr_dist(aggs, where, table, nrows=self.shard.local_rows, row0=self.shard.row0)
+            except Exception as e:  # nested predicate trees take the general path below
+                if type(e).__name__ != "_NotFlat":
+                    raise
         part = eng.filter_aggr_partials(aggs, where, table, nrows=self.shard.local_rows, row0=self.shard.row0)
         kinds = [L.AGGS[fn] for fn, _ in aggs]
         ctypes_ = [L.RFX_F64 if (col is not None and eng._arg_f64(col, table)) else L.RFX_I64 for fn, col in aggs]
@@ -222,10 +289,10 @@ class ShardedEngine:
 
     def where(self, where, table=None) -> torch.Tensor:
         ids = self.eng.where(where, table, row0=self.shard.row0)
-        return gather_ids(ids, self.shard.group)
+        return gather_ids(ids, self.shard.group, self.native)
 
     def group_by(self, key, aggs, where=None, table=None):
         kinds = [L.AGGS[fn] for fn, _ in aggs]
         f64s = [col is not None and self.eng._arg_f64(col, table) for fn, col in aggs]
-        hook = GroupHook(self.shard, kinds, f64s)
+        hook = GroupHook(self.shard, kinds, f64s, self.native)
         return self.eng.group_by(key, aggs, where, table, total_rows=self.shard.total_rows, row0=self.shard.row0, _collective=hook)

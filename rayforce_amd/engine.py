@@ -206,6 +206,8 @@ class Engine:
         """Host numpy array (i64 / f64) -> device column through the pipelined path (what rfx_ops.c's residency cache uses)."""
         import numpy as np
         a = np.ascontiguousarray(host_array)
+        if a.ndim != 1 or a.dtype not in (np.int64, np.float64):
+            raise RfxError(f"upload: a 1-d int64 / float64 array is expected, not {a.dtype} with shape {a.shape}")
         out = torch.empty(a.shape[0], dtype=torch.float64 if a.dtype == np.float64 else torch.int64, device=self.device)
         L.check(self.lib.rfx_hip_h2d_pipelined(self._ctx, out.data_ptr(), a.ctypes.data, a.nbytes), "h2d_pipelined")
         return out
@@ -470,6 +472,20 @@ class Engine:
         sel = C.c_int64()
         L.check(self.lib.rfx_hip_filter_aggr_host(self._ctx, parr, len(flat), logic, aarr, len(aggs), n, vals, C.byref(sel)),
                 "filter_aggr")
+        return [self._value(vals[i]) for i in range(len(aggs))], int(sel.value)
+
+    def filter_aggr_dist(self, aggs, where=None, table=None, nrows: Optional[int] = None, row0: int = 0):
+        """The same over the row-range SHARDED table, through the C exchange (rfx_dist_filter_aggr_host: local fused pass, one
+        ncclAllGather of the partials, rank-ordered fold).  Flat predicates and at most RFX_MAX_AGGS aggregates.  (syncs)"""
+        logic, flat = self._flatten(where, table)
+        self._keep.clear()
+        parr, n = self._preds(flat, table, nrows)
+        aarr, n = self._aggs(aggs, table, n)
+        if n is None:
+            raise RfxError("cannot infer the row count")
+        vals = (L.Value * max(1, len(aggs)))()
+        sel = C.c_int64()
+        L.check(self.lib.rfx_dist_filter_aggr_host(self._ctx, parr, len(flat), logic, aarr, len(aggs), n, row0, vals, C.byref(sel)), "dist_filter_aggr")
         return [self._value(vals[i]) for i in range(len(aggs))], int(sel.value)
 
     def _filter_aggr_via_ids(self, aggs, where, table):
@@ -745,7 +761,7 @@ class Engine:
                                                                      len(flat), logic, aarr, n, row0, C.byref(t)), "group_dense_accumulate_keys")
             if _collective is not None:  # the kinds of THIS launch's aggregates (a chunk of the query's, or the row-hash path's extras)
                 _collective("tables", (store, layout, [int(aarr[i].kind) for i in range(nagg)],
-                                       [L.agg_input_type(aarr[i]) == L.RFX_F64 for i in range(nagg)]))
+                                       [L.agg_input_type(aarr[i]) == L.RFX_F64 for i in range(nagg)], t, aarr))
             L.check(self.lib.rfx_hip_group_rank(self._ctx, C.byref(t), total_rows, C.byref(ng)), "group_rank")
         else:
             if multi is not None:  # sparse composite: the hashed path keys on the materialised column (core/index.c:2421 -> :2092)
@@ -787,9 +803,15 @@ class Engine:
         results = [self.empty(g, d) for d in out_dtypes]
         ptrs = (C.c_void_p * max(1, nagg))(*[r.data_ptr() for r in results])
         if dense:
-            L.check(self.lib.rfx_hip_group_emit(self._ctx, aarr, C.byref(t), keys.data_ptr(), first.data_ptr(), ptrs), "group_emit")
+            L.check(self.lib.rfx_hip_group_emit_sharded(self._ctx, aarr, C.byref(t), row0, n if _collective is not None else 0, keys.data_ptr(),
+                                                        first.data_ptr(), ptrs), "group_emit")
         else:
-            L.check(self.lib.rfx_hip_hash_emit(self._ctx, aarr, C.byref(t), keys.data_ptr(), first.data_ptr(), ptrs), "hash_emit")
+            L.check(self.lib.rfx_hip_hash_emit_sharded(self._ctx, aarr, C.byref(t), row0, n if _collective is not None else 0, keys.data_ptr(),
+                                                       first.data_ptr(), ptrs), "hash_emit")
+        if _collective is not None:  # FIRST: only the rank that owns a group's first row had its value; the others emitted 0
+            firsts = [results[i] for i in range(nagg) if int(aarr[i].kind) == L.RFX_AGG_FIRST]
+            if firsts:
+                _collective("first_values", firsts)
         r = dict(groups=g, keys=keys, first=first, results=results, dense=dense, cap=0 if dense else cap)
         if multi is not None:
             mins, mults, ranges = multi

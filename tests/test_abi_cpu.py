@@ -136,3 +136,28 @@ def test_column_file_header_is_read_without_a_device(built, tmp_path):
     (tmp_path / "junk").write_bytes(b"x" * 40)
     assert lib.rfx_column_file_stat(str(tmp_path / "junk").encode(), C.byref(t), C.byref(n)) == -2
     assert b"not a RayforceDB column file" in lib.rfx_hip_last_error()
+
+
+def test_bench_launch_contract_dry_run():
+    """`python bench.py --gpus 2` must start two ranks by itself (no launcher), shard the workload's BASELINE rows over them
+    (strong scaling) and report n_gpus == 2 -- checked here without a device (--dry-run: rendezvous over gloo + shard arithmetic)."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    for wl, total in (("c3w", 1_000_000_000), ("c5", 2_000_000_000)):
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", wl, "--dry-run"], env=env, capture_output=True,
+                             text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+        assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["dry_run"] is True
+        assert line["config"]["total_rows"] == total and line["config"]["rows_per_gpu"] == [total // 2, total - total // 2]
+    # weak scaling on request: every rank holds the BASELINE row count
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "c2", "--scaling", "weak", "--dry-run"], env=env,
+                         capture_output=True, text=True, timeout=300)
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["config"]["total_rows"] == 2_000_000_000
+    # a launcher that started a different number of ranks than --gpus is an error, not a silent 1-GPU run
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--dry-run"], env={**env, "WORLD_SIZE": "1", "RANK": "0"},
+                         capture_output=True, text=True, timeout=120)
+    assert bad.returncode != 0 and "refusing" in (bad.stderr + bad.stdout)

@@ -54,7 +54,7 @@ def _worker(rank, world, port, q):
         ids = sh.where(("<", "a", 50_000), mine)
         assert np.array_equal(ids.cpu().numpy(), rfo.where(rfo.mask_of(("<", "a", 50_000), full)))
         # dense group-by (partitioned path on each rank, tables all-reduced, ranked by GLOBAL first row)
-        gaggs = [("sum", "v"), ("sum", "a"), ("min", "v"), ("max", "a"), ("avg", "a"), ("count", "v")]
+        gaggs = [("sum", "v"), ("sum", "a"), ("min", "v"), ("max", "a"), ("avg", "a"), ("count", "v"), ("first", "a"), ("first", "v")]
         for w_ in (None, (">", "v", -0.25)):
             r = sh.group_by("k", gaggs, w_, mine)
             qq = {"from": full, "by": "k", **{f"o{i}": a for i, a in enumerate(gaggs)}}
@@ -121,3 +121,80 @@ def test_two_ranks_one_gpu(built):
         p.join(timeout=60)
     for rank, msg in res:
         assert msg == "ok", f"rank {rank}: {msg}"
+
+
+def _nccl_worker(port, q):
+    """ONE rank under NCCL: the exchange runs through the library's C entry points (rfx_dist.hip, RCCL communicator in the context)."""
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        from oracle import rfo
+        from rayforce_amd.dist import ShardedEngine
+        from rayforce_amd.engine import Engine
+        rfo.set_threads(4)
+        n = 500_009
+        full = {"k": rfo.gen_i64(n, 4, 60_000), "a": rfo.gen_i64(n, 2, 1_000_000), "v": rfo.gen_f64(n, 5) - 0.5}
+        full["a"][::97] = NULL
+        eng = Engine(0)
+        mine = {c: eng.column(x) for c, x in full.items()}
+        sh = ShardedEngine(eng, n)
+        assert sh.native is not None, "under NCCL the exchange must be the C one"
+        lib = eng.lib
+        c0 = lib.rfx_dist_calls(eng._ctx)
+        aggs = [("sum", "a"), ("sum", "v"), ("min", "v"), ("max", "a"), ("avg", "v"), ("count", "a")]
+        where = ("<", "a", 600_000)
+        vals, sel = sh.filter_aggr(aggs, where, mine)
+        assert lib.rfx_dist_calls(eng._ctx) - c0 == 1, "scalar aggregates: ONE all-gather"
+        want = rfo.select({"from": full, "where": where, **{f"o{i}": a for i, a in enumerate(aggs)}})
+        for i, v in enumerate(vals):
+            w = want[f"o{i}"][0]
+            assert (abs(v - w) <= 1e-9 * abs(w)) if isinstance(v, float) else v == int(w), (aggs[i], v, w)
+        assert sel == int(rfo.mask_of(where, full).sum())
+        c0 = lib.rfx_dist_calls(eng._ctx)
+        r = sh.group_by("k", [("sum", "v")], None, mine)
+        assert lib.rfx_dist_calls(eng._ctx) - c0 == 2, "select sum(v) by k: first MIN + sums SUM in one fused exchange (the scope gather is not counted)"
+        want = rfo.select({"from": full, "by": "k", "s": ("sum", "v")})
+        assert np.array_equal(r["keys"].cpu().numpy(), want["k"]) and np.allclose(r["results"][0].cpu().numpy(), want["s"], rtol=1e-9, atol=0)
+        gaggs = [("sum", "v"), ("sum", "a"), ("min", "v"), ("max", "a"), ("avg", "a"), ("count", "v"), ("first", "a")]
+        r = sh.group_by("k", gaggs, (">", "v", -0.25), mine)
+        want = rfo.select({"from": full, "by": "k", "where": (">", "v", -0.25), **{f"o{i}": a for i, a in enumerate(gaggs)}})
+        assert np.array_equal(r["keys"].cpu().numpy(), want["k"])
+        for i, res in enumerate(r["results"]):
+            g, w = res.cpu().numpy(), want[f"o{i}"]
+            if w.dtype == np.float64:
+                ok = ~np.isnan(w)
+                assert np.array_equal(np.isnan(g), np.isnan(w)) and np.allclose(g[ok], w[ok], rtol=1e-9, atol=0), gaggs[i]
+            else:
+                assert np.array_equal(g, w), gaggs[i]
+        ids = sh.where(("<", "a", 50_000), mine)
+        assert np.array_equal(ids.cpu().numpy(), rfo.where(rfo.mask_of(("<", "a", 50_000), full)))
+        sparse = {**mine, "k": eng.column(full["k"] * 1_000_003 - 5)}
+        r = sh.group_by("k", [("sum", "v"), ("count", "a")], None, sparse)
+        want = rfo.select({"from": {**full, "k": full["k"] * 1_000_003 - 5}, "by": "k", "s": ("sum", "v"), "c": ("count", "a")})
+        assert np.array_equal(r["keys"].cpu().numpy(), want["k"]) and np.array_equal(r["results"][1].cpu().numpy(), want["c"])
+        sh.close()
+        eng.close()
+        q.put("ok")
+    except Exception:  # noqa: BLE001
+        import traceback
+        q.put(traceback.format_exc())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_c_exchange_over_rccl_one_rank(built):
+    """The C entry points of the exchange (rfx_dist_*) under a real RCCL communicator: one rank (RCCL refuses two per device), every
+    collective really issued; dense group-by = two calls in one ncclGroup, scalar aggregates = one all-gather."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_nccl_worker, args=(_free_port(), q))
+    p.start()
+    msg = q.get(timeout=300)
+    p.join(timeout=60)
+    assert msg == "ok", msg

@@ -306,3 +306,106 @@ def test_residency_cache(ops):
     assert ops.rfx_cache_bytes() == 0
     for o in (p, u, tab):
         ops.rfx_host_drop(o)
+
+
+def _sum_of(ops, vec):
+    s = ops.rfx_sum(vec)
+    assert not H.is_error(s), H.error_text(s)
+    got = C.c_int64.from_address(s + 8).value
+    ops.rfx_host_drop(s)
+    return got
+
+
+def test_cache_never_serves_a_stale_cell(ops):
+    """An unpinned cached column is re-validated against a checksum of its FULL payload on every use: flip ONE random cell of a
+    cached 1e7-row column in place, 1 000 times -- the answer follows every time (round 1 sampled 64 cells and could miss it)."""
+    ops.rfx_cache_clear()
+    n = 10_000_000
+    a = rfo.gen_i64(n, 2, 1_000_000)
+    vec = H.vector(a)
+    view = np.frombuffer((C.c_char * (n * 8)).from_address(H.payload(vec)), dtype=np.int64)
+    total = int(a.sum())
+    assert _sum_of(ops, vec) == total
+    rng = np.random.default_rng(7)
+    before = H.to_numpy(ops.rfx_stats(0))
+    for i in range(1000):
+        j = int(rng.integers(0, n))
+        delta = int(rng.integers(1, 1 << 40))
+        view[j] += delta  # in place: same address, same length, same type
+        total += delta
+        assert _sum_of(ops, vec) == total, (i, j)
+    after = H.to_numpy(ops.rfx_stats(0))
+    assert after[6] - before[6] == 1000  # every change was noticed (stale entries refreshed) ...
+    assert _sum_of(ops, vec) == total and H.to_numpy(ops.rfx_stats(0))[5] == after[5] + 1  # ... and an unchanged column is a cache hit
+    ops.rfx_host_drop(vec)
+
+
+def test_cache_pin_trusts_until_invalidated(ops):
+    """rfx_pin: no per-use validation (the host promises rfx_invalidate before it writes); rfx_invalidate drops the copy."""
+    ops.rfx_cache_clear()
+    a = rfo.gen_i64(1_000_003, 3, 1000)
+    vec = H.vector(a)
+    view = np.frombuffer((C.c_char * (a.size * 8)).from_address(H.payload(vec)), dtype=np.int64)
+    p = ops.rfx_pin(vec)
+    assert _sum_of(ops, vec) == int(a.sum())
+    view[12345] += 5
+    assert _sum_of(ops, vec) == int(a.sum())  # pinned: the device copy is trusted (documented contract)
+    iv = ops.rfx_invalidate(vec)
+    assert ops.rfx_cache_bytes() == 0
+    assert _sum_of(ops, vec) == int(a.sum()) + 5
+    for o in (p, iv, vec):
+        ops.rfx_host_drop(o)
+
+
+def test_temporaries_at_recycled_addresses(ops):
+    """Masks / id vectors are temporaries: freed by the host right after the call, the next one usually lands at the same address.
+    (where (== c 5)) followed by (where (== c 7)) must not answer the first query's ids."""
+    n = 300_007
+    c = rfo.gen_i64(n, 11, 1000)
+    col = H.vector(c)
+    for k in (5, 7, 5, 900, 7):
+        m = ops.rfx_eq(col, H.atom(k))
+        ids = ops.rfx_where(m)
+        assert np.array_equal(H.to_numpy(ids), np.nonzero(c == k)[0]), k
+        g = ops.rfx_at(col, ids)
+        assert np.array_equal(H.to_numpy(g), np.full(int((c == k).sum()), k, np.int64))
+        for o in (g, ids, m):
+            ops.rfx_host_drop(o)  # the standalone host frees: the next mask reuses the block
+    ops.rfx_host_drop(col)
+
+
+def test_at_out_of_range_ids_read_null(ops):
+    """at_vec_i64_by_i64 / at_vec_f64_by_i64 (core/items.c:53-72): idx < 0 (null included) or >= len -> typed null, never a read
+    beyond the column."""
+    a = np.arange(1000, dtype=np.int64) * 3
+    v = np.arange(1000, dtype=np.float64) / 7
+    ids = np.array([0, 999, 1000, -1, NULL, 5, 2**40, 17], np.int64)
+    av, vv, iv = H.vector(a), H.vector(v), H.vector(ids)
+    ga, gv = ops.rfx_at(av, iv), ops.rfx_at(vv, iv)
+    ok = (ids >= 0) & (ids < 1000)
+    want_a = np.where(ok, a[np.where(ok, ids, 0)], NULL)
+    got_v = H.to_numpy(gv)
+    assert np.array_equal(H.to_numpy(ga), want_a)
+    assert np.array_equal(np.isnan(got_v), ~ok) and np.array_equal(got_v[ok], v[ids[ok]])
+    # the lazy MAPFILTER pair takes host ids too
+    pair = H.list_of([av, iv])
+    H.header(pair).type = 71
+    s = ops.rfx_sum(pair)
+    assert C.c_int64.from_address(s + 8).value == int(a[ids[ok]].sum())  # null entries are skipped by the scalar sum
+    for o in (s, pair, ga, gv):
+        ops.rfx_host_drop(o)
+
+
+def test_cache_budget_never_evicts_what_the_call_reads(ops, monkeypatch):
+    """A budget smaller than one query's columns: entries touched by the call in flight are not evictable (the descriptors hold
+    their device pointers), the cache goes over budget instead."""
+    ops.rfx_cache_clear()
+    host = host_table(400_003, keys=1000)
+    monkeypatch.setenv("RFX_CACHE_BYTES", str(400_003 * 8 + 100))  # room for ONE column
+    try:
+        q = {"s": ("sum", "v"), "mx": ("max", "a"), "by": "k", "where": ("<", "a", 700_000)}
+        for _ in range(3):
+            check(run_select(ops, host, q), rfo.select({"from": host, **q}))
+    finally:
+        monkeypatch.delenv("RFX_CACHE_BYTES")
+        ops.rfx_cache_clear()
