@@ -853,6 +853,14 @@ static obj_p select_impl(obj_p dict) {
             int64_t groups = 0;
             if (!rowhash) nagg_run = nagg;
             obj_p okeys = NULL, ocols[RFX_MAX_AGGS] = {0}, okcols[RFX_MAX_KEYS] = {0};
+            if (seen > 0 && nkeys == 1 && kmin == RFX_NULL_I64) {
+                /* a selected key is null: the reference's open-addressing table uses NULL_I64 as its EMPTY marker, so every null-key
+                 * row opens a group of its own there (core/index.c:1808-1816).  The device tables keep one null group; at this
+                 * boundary the answer must be the reference's, so the host's own select answers (the Python Engine documents the
+                 * one-group rule as its own semantics). */
+                why = "null group key";
+                goto out;
+            }
             if (seen > 0) {
                 /* dense "perfect hash" iff range <= rows (core/index.c:2013), like the reference; else open addressing */
                 uint64_t range = (uint64_t)kmax - (uint64_t)kmin + 1;

@@ -96,6 +96,9 @@ def test_plugin_inside_the_real_reference(built):
             for o in ("k", "k1", "a", "v", "z"):
                 s.out(f"g_{tag}i_{o}", f"(at g_{tag}i '{o})")
                 s.out(f"r_{tag}i_{o}", f"(at r_{tag}i '{o})")
+        # who answered what: [selects on the GPU, selects delegated, joins on the GPU, joins delegated, uploads, hits, stale, calls]
+        s.eval(f'(set gstat (loadfn "{LIB}" "rfx_stats" 1))')
+        s.out("stats", "(gstat 0)")
         # -c 8: the reference's page-aligned chunking (core/pool.c:495-507) overshoots small inputs when the pool is large
         # (it segfaults on this 300k-row table with 64+ executors, with or without the plugin) -- keep its pool small here
         res = s.run(threads=8)
@@ -121,3 +124,10 @@ def test_plugin_inside_the_real_reference(built):
     assert np.array_equal(res["g_proj_a"], cols["a"][cols["a"] < 1000])
     assert np.array_equal(res["g_nest_s"], res["r_nest_s"])
     assert np.array_equal(res["g_del_n"], res["r_del_n"])
+    # every query above was answered by the device path -- not vacuously by a silent hand-back to ray_select -- except the one
+    # shape that is delegated on purpose (f64 key); all four joins ran on the device.  (Null group keys are delegated too -- the
+    # reference's one-group-per-null-row rule is not reproduced -- but the reference itself panics in its heap on every single-key
+    # group-by over a key column with nulls (2 003 .. 300 007 rows, -c 1 and -c 8), so that hand-back is asserted in standalone mode.)
+    st = res["stats"]
+    assert int(st[0]) == len(QUERIES) + 2 and int(st[1]) == 1, st
+    assert int(st[2]) == 4 and int(st[3]) == 0, st

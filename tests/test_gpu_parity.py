@@ -21,7 +21,10 @@ def dev(eng, table):
     return {k: eng.column(v) for k, v in table.items()}
 
 
-def same_f64(a, b, rtol=RTOL):
+def same_f64(a, b, rtol=RTOL, scale=None):
+    """<= 1e-9 relative (the north star's bound for f64 sums).  `scale` = the per-group sum of |x_i|: the bound a
+    summation in ANY order can be held to -- a group whose terms cancel (sum of w in [-0.5, 0.5)) has |result| << sum |x_i|, and the
+    device's order (atomics) differs from the CPU's chunks.  Without `scale` (min / max / first, exact operations) the value itself."""
     a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
     assert a.shape == b.shape
     nan_a, nan_b = np.isnan(a), np.isnan(b)
@@ -31,13 +34,22 @@ def same_f64(a, b, rtol=RTOL):
         inf = np.isinf(a[ok]) | np.isinf(b[ok])
         assert np.array_equal(a[ok][inf], b[ok][inf])
         fin = ~inf
-        # 1e-9 relative (the north star's bound for f64 sums), measured against the value itself -- or, for a group whose terms
-        # cancel to almost nothing (sum of w in [-0.5, 0.5): |result| << |terms|), against 1e-3 of the column's largest magnitude:
-        # the summation ORDER differs between the device (atomics) and the CPU's chunks, and no order is exact there
-        # (observed: 1.2e-9 of a group average of ~1e-5 in 1 of 6 000 random queries)
-        col = float(np.max(np.abs(b[ok][fin]))) if fin.any() else 0.0
-        scale = np.maximum(np.maximum(np.abs(b[ok][fin]), 1e-3 * col), 1e-300)
-        assert np.all(np.abs(a[ok][fin] - b[ok][fin]) <= rtol * scale), float(np.max(np.abs(a[ok][fin] - b[ok][fin]) / scale))
+        ref_scale = np.abs(b[ok][fin]) if scale is None else np.maximum(np.abs(np.asarray(scale, np.float64)[ok][fin]), np.abs(b[ok][fin]))
+        ref_scale = np.maximum(np.where(np.isnan(ref_scale), np.abs(b[ok][fin]), ref_scale), 1e-300)
+        assert np.all(np.abs(a[ok][fin] - b[ok][fin]) <= rtol * ref_scale), float(np.max(np.abs(a[ok][fin] - b[ok][fin]) / ref_scale))
+
+
+def _abs_scale(host, q, name):
+    """sum / avg of |column| over the same selection and groups: the scale of the f64 tolerance for output `name` (None: exact op)."""
+    spec = q[name]
+    if not (isinstance(spec, tuple) and spec[0] in ("sum", "avg") and isinstance(spec[1], str)):
+        return None
+    col = host[spec[1]]
+    habs = dict(host)
+    habs["__abs"] = np.abs(col.astype(np.float64)) if col.dtype == np.float64 else np.abs(np.where(col == NULL, 0, col)).astype(np.float64)
+    q2 = {k: v for k, v in q.items() if k in ("where", "by")}
+    q2[name] = (spec[0], "__abs")
+    return rfo.select({"from": habs, **q2})[name]
 
 
 def check_select(eng, host, q):
@@ -49,7 +61,7 @@ def check_select(eng, host, q):
         w = want[name]
         assert g.dtype == w.dtype, (name, g.dtype, w.dtype)
         if w.dtype == np.float64:
-            same_f64(g, w)
+            same_f64(g, w, scale=_abs_scale(host, q, name) if name in q else None)
         else:
             assert np.array_equal(g, w), name
     return got

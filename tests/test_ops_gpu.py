@@ -409,3 +409,16 @@ def test_cache_budget_never_evicts_what_the_call_reads(ops, monkeypatch):
     finally:
         monkeypatch.delenv("RFX_CACHE_BYTES")
         ops.rfx_cache_clear()
+
+
+def test_null_group_keys_are_handed_back(ops):
+    """A selected null key: the reference opens one group per null-key row (NULL_I64 is the empty marker of its table,
+    core/index.c:1808-1816).  rfx_select does not answer differently at the boundary: it hands the query to the host -- here, with no
+    host behind it, that is a loud error naming the reason."""
+    host = host_table(50_000, keys=700)
+    host["k"][::997] = NULL
+    with pytest.raises(RuntimeError, match="null group key"):
+        run_select(ops, host, {"s": ("sum", "v"), "by": "k"})
+    # a filter that removes the null keys makes the query answerable again
+    q = {"s": ("sum", "v"), "c": ("count", "a"), "by": "k", "where": (">", "k", 5)}
+    check(run_select(ops, host, q), rfo.select({"from": host, **q}))
