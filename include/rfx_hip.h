@@ -332,6 +332,10 @@ int rfx_hip_hash_emit_sharded(rfx_ctx_t *ctx, const rfx_agg_t *aggs, const rfx_h
 int rfx_hip_group_ids_dense(rfx_ctx_t *ctx, const int64_t *d_key, int64_t nrows, const rfx_group_tables_t *t,
                             int64_t *d_gids);
 
+/* slot -> group id of dense tables after rfx_hip_group_rank, NULL_I64 for an unoccupied slot: the key table of the reference's
+ * INDEX_TYPE_SHIFT group index (core/index.c:2037-2062). */
+int rfx_hip_group_slot_ids(rfx_ctx_t *ctx, const rfx_group_tables_t *t, int64_t *d_out);
+
 /* ---- several `by:` columns: composite ("perfect hash") key, index_group_list_perfect, core/index.c:2308-2424 ----
  * rfx_composite_plan (host, no device work): from the per-column scopes [mins[i], maxs[i]] compute the multipliers
  * mult_0 = 1, mult_i = mult_{i-1} * range_{i-1} and the composite maximum, with the reference's overflow tests

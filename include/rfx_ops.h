@@ -89,6 +89,10 @@ rfx_obj_p rfx_count(rfx_obj_p x);
 rfx_obj_p rfx_first(rfx_obj_p x);
 
 /* ---- residency ---------------------------------------------------------------------------------------------------- */
+/* unary_f: the reference's 7-slot group index of an i64 key column (index_group_i64_scoped, core/index.c:2002-2092), built on the
+ * device: what a link-time replacement of index_group hands to the FN_AGGR built-ins inside a MAPGROUP pair.  rfx_sum .. rfx_first
+ * accept such pairs (val, index) -- with indexes built here or by the reference -- besides vectors and MAPFILTER pairs. */
+rfx_obj_p rfx_group(rfx_obj_p keys);
 rfx_obj_p rfx_pin(rfx_obj_p table_or_column);   /* unary_f: upload + keep resident; returns a clone of its argument */
 rfx_obj_p rfx_unpin(rfx_obj_p table_or_column); /* unary_f: drop the device copies */
 /* unary_f: the host writes into this vector / this table's columns in place -- drop every cached device copy overlapping them

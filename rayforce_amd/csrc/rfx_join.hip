@@ -119,3 +119,19 @@ extern "C" int rfx_hip_gather_checked(rfx_ctx_t *c, const void *d_col, int64_t c
     RFX_HIP_CHECK(hipGetLastError());
     return RFX_OK;
 }
+
+// slot -> group id of the dense tables `t` after rfx_hip_group_rank (the key table of the reference's INDEX_TYPE_SHIFT index,
+// core/index.c:2037-2062): NULL_I64 for a slot no row maps to.
+__global__ __launch_bounds__(RFX_BLOCK) void k_slot_ids(const i64 *__restrict__ gid, i64 n, i64 *__restrict__ out) {
+    for (i64 i = blockIdx.x * (i64)RFX_BLOCK + threadIdx.x; i < n; i += (i64)gridDim.x * RFX_BLOCK) {
+        const i64 g = gid[i];
+        out[i] = g < 0 ? RFX_NULL_I64_D : g;
+    }
+}
+extern "C" int rfx_hip_group_slot_ids(rfx_ctx_t *c, const rfx_group_tables_t *t, int64_t *d_out) {
+    RFX_REQUIRE(c && t && d_out, RFX_EINVAL, "NULL argument");
+    RFX_REQUIRE(t->range > 0 && c->gid_cap >= (size_t)t->range && c->d_gid, RFX_ESTATE, "group_slot_ids without group_rank");
+    hipLaunchKernelGGL(k_slot_ids, dim3(join_grid(c, t->range)), dim3(RFX_BLOCK), 0, c->stream, (const i64 *)c->d_gid, (i64)t->range, (i64 *)d_out);
+    RFX_HIP_CHECK(hipGetLastError());
+    return RFX_OK;
+}

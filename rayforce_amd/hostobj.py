@@ -26,7 +26,7 @@ OPS_PROTOTYPES = {
     "rfx_or": (C.c_void_p, [C.POINTER(C.c_void_p), C.c_int64]),
     "rfx_left_join": (C.c_void_p, [C.POINTER(C.c_void_p), C.c_int64]),
     "rfx_inner_join": (C.c_void_p, [C.POINTER(C.c_void_p), C.c_int64]),
-    **{f"rfx_{n}": (C.c_void_p, [C.c_void_p]) for n in ("where", "sum", "avg", "min", "max", "count", "first", "pin", "unpin", "invalidate", "stats")},
+    **{f"rfx_{n}": (C.c_void_p, [C.c_void_p]) for n in ("where", "sum", "avg", "min", "max", "count", "first", "pin", "unpin", "invalidate", "stats", "group")},
     "rfx_cache_clear": (None, []),
     "rfx_cache_bytes": (C.c_int64, []),
     "rfx_last_select_on_gpu": (C.c_int, []),

@@ -246,3 +246,27 @@ def same(got, want, name=""):
         assert np.all(np.abs(g - w) <= 1e-9 * np.maximum(np.abs(w), 1e-300)), name
     else:
         assert np.array_equal(got.astype(want.dtype), want), name
+
+
+# ---- group indexes / lazy MAPGROUP pairs (tests/golden/make_mapgroup_golden.py) ----
+# (rows, distinct keys, key offset, filtered?): 500 / 5 000 keys -> SHIFT index; ranges beyond 524 288 within the row count -> IDS
+MAPGROUP_CASES = [(100_003, 500, 0, False), (100_003, 500, -77, True), (600_011, 300_000, 1000, False), (1_400_003, 545_000, 5, True),
+                  (100_003, 5000, 10**12, False), (700_001, 600_000, -3, False)]
+
+
+def mapgroup_inputs(ci):
+    """(keys, i64 values with nulls, f64 values with NaNs, filter ids or None) of case `ci`: generator + seed, as the fixture script used."""
+    from oracle import rfo
+    n, keys, off, filt = MAPGROUP_CASES[ci]
+    k = rfo.gen_i64(n, 4 + ci, keys) + off
+    vi = rfo.gen_i64(n, 2 + ci, 1_000_000)
+    vf = rfo.gen_f64(n, 5 + ci) - 0.25
+    vi[::97] = -(2**63)
+    vf[::89] = np.nan
+    ids = np.nonzero(rfo.gen_i64(n, 50 + ci, 100) < 40)[0].astype(np.int64) if filt else None
+    return k, vi, vf, ids
+
+
+def mapgroup_sample(groups):
+    """group positions whose f64 results the fixture keeps"""
+    return np.unique(np.concatenate([np.arange(min(groups, 512)), np.arange(0, groups, 61)]))

@@ -1,0 +1,136 @@
+"""Lazy MAPGROUP pairs and the group index at the operator boundary.
+
+* The reference's own group indexes (index_group) and grouped aggregates (aggr_sum ... aggr_first), captured from the compiled
+  reference by tests/golden/make_mapgroup_golden.py, pin (1) the index this repo rebuilds here -- bit for bit, through sha-256 digests
+  of its id / first arrays -- and (2) what rfx_sum .. rfx_first answer when they are handed (val, index) pairs laid out as the
+  reference lays them out (both flavours: INDEX_TYPE_SHIFT with key table + source column, INDEX_TYPE_IDS with per-row ids; with and
+  without filter ids).
+* rfx_group builds that index on the device: compared slot by slot with the same digests, then fed to the oracle's AGGR."""
+import ctypes as C
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+from golden_cases import MAPGROUP_CASES, mapgroup_inputs, mapgroup_sample
+from oracle import rfo
+from rayforce_amd import hostobj as H
+
+pytestmark = pytest.mark.gpu
+NULL = -(2**63)
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "mapgroup_golden.npz")
+T_MAPGROUP = 72
+
+
+@pytest.fixture(scope="module")
+def ops(built):
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    l = H.lib()
+    assert l.rfx_host_bind() == 0
+    yield l
+    l.rfx_cache_clear()
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return dict(np.load(GOLD))
+
+
+def sha(a):
+    return np.frombuffer(hashlib.sha256(np.ascontiguousarray(a).tobytes()).digest(), dtype=np.uint8)
+
+
+def reference_shaped_index(ci, gold):
+    """The case's index as index_group_i64_scoped builds it, from the oracle's restatement; checked against the reference's digests."""
+    k, vi, vf, ids = mapgroup_inputs(ci)
+    _, _, itype, groups, shift, filt, _ = (int(x) for x in gold["cases"][ci])
+    gids, firsts, g, dense = rfo.group_index(k, ids)
+    assert dense and g == groups
+    if itype == 1:  # SHIFT: key table slot -> group id (NULL where no row maps), source column kept
+        sel = k if ids is None else k[ids]
+        table = np.full(int(sel.max() - sel.min()) + 1, NULL, np.int64)
+        table[sel - shift] = gids
+        group_ids = table
+    else:
+        group_ids = gids
+    assert np.array_equal(sha(group_ids), gold[f"mg{ci}_group_ids_sha"]), "the rebuilt index differs from the reference's"
+    assert np.array_equal(sha(firsts), gold[f"mg{ci}_first_ids_sha"])
+    return k, vi, vf, ids, itype, groups, shift, group_ids, firsts
+
+
+def host_index(itype, groups, shift, group_ids, firsts, source, filt):
+    ix = H.lib().rfx_host_list(7)  # slots start out null
+    arr = (C.c_void_p * 7).from_address(H.payload(ix))
+    arr[0], arr[1] = H.atom(itype), H.atom(groups)
+    arr[2] = H.vector(group_ids)
+    arr[3] = H.atom(shift if itype == 1 else NULL)
+    if itype == 1:
+        arr[4] = H.vector(source)
+    if filt is not None:
+        arr[5] = H.vector(filt)
+    arr[6] = H.vector(firsts)
+    return ix
+
+
+@pytest.mark.parametrize("ci", range(len(MAPGROUP_CASES)))
+def test_aggregates_over_reference_indexes(ops, gold, ci):
+    k, vi, vf, ids, itype, groups, shift, group_ids, firsts = reference_shaped_index(ci, gold)
+    samp = mapgroup_sample(groups)
+    gids_rows = rfo.group_index(k, ids)[0]
+    for col, vals in (("vi", vi), ("vf", vf)):
+        for fn in ("sum", "min", "max", "avg", "count", "first"):
+            index = host_index(itype, groups, shift, group_ids, firsts, k, ids)
+            pair = H.list_of([H.vector(vals), index])
+            H.header(pair).type = T_MAPGROUP
+            r = getattr(ops, f"rfx_{fn}")(pair)
+            assert r and not H.is_error(r), (fn, col, H.error_text(r))
+            got = H.to_numpy(r)
+            assert len(got) == groups
+            if got.dtype == np.float64:
+                want = gold[f"mg{ci}_{fn}_{col}_sample"]
+                g = got[samp]
+                assert np.array_equal(np.isnan(g), np.isnan(want)), (fn, col)
+                ok = ~np.isnan(want) & ~np.isinf(want)
+                assert np.array_equal(g[~ok & ~np.isnan(want)], want[~ok & ~np.isnan(want)])
+                if fn in ("sum", "avg"):  # scale: the group's sum (avg) of |x| -- any summation order is within 1e-9 of it
+                    av = np.abs(np.where(vals == NULL, 0, vals).astype(np.float64)) if vals.dtype == np.int64 else np.abs(vals)
+                    scale = rfo.aggr(fn, av, gids_rows, ids, groups)[samp]
+                    scale = np.maximum(np.where(np.isnan(scale), 0, scale), np.abs(want))
+                else:
+                    scale = np.abs(want)
+                assert np.all(np.abs(g[ok] - want[ok]) <= 1e-9 * np.maximum(scale[ok], 1e-300)), (fn, col)
+            else:
+                assert np.array_equal(sha(got), gold[f"mg{ci}_{fn}_{col}_sha"]), (fn, col)
+            ops.rfx_host_drop(r)
+            ops.rfx_host_drop(pair)
+
+
+@pytest.mark.parametrize("ci", [i for i, c in enumerate(MAPGROUP_CASES) if not c[3]])
+def test_rfx_group_builds_the_reference_index(ops, gold, ci):
+    k, vi, vf, ids = mapgroup_inputs(ci)
+    _, _, itype, groups, shift, _, _ = (int(x) for x in gold["cases"][ci])
+    kv = H.vector(k)
+    ix = ops.rfx_group(kv)
+    assert ix and not H.is_error(ix), H.error_text(ix)
+    slots = H.list_items(ix)
+    assert H.header(ix).len == 7
+    assert C.c_int64.from_address(slots[0] + 8).value == itype and C.c_int64.from_address(slots[1] + 8).value == groups
+    assert C.c_int64.from_address(slots[3] + 8).value == (shift if itype == 1 else NULL)
+    gids, firsts = H.to_numpy(slots[2]), H.to_numpy(slots[6])
+    assert np.array_equal(sha(gids), gold[f"mg{ci}_group_ids_sha"]) and np.array_equal(sha(firsts), gold[f"mg{ci}_first_ids_sha"])
+    if itype == 1:
+        assert np.array_equal(H.to_numpy(slots[4]), k)  # the source column rides along
+    # ours -> the oracle's AGGR: per-row ids (through the key table for SHIFT) aggregate to the reference's answers
+    rows = gids[k - shift] if itype == 1 else gids
+    for fn in ("sum", "min", "max", "count"):
+        assert np.array_equal(sha(rfo.aggr(fn, vi, rows, None, groups)), gold[f"mg{ci}_{fn}_vi_sha"]), fn
+    # and back into our own aggregates
+    pair = H.list_of([H.vector(vi), ix])
+    H.header(pair).type = T_MAPGROUP
+    r = ops.rfx_max(pair)
+    assert np.array_equal(sha(H.to_numpy(r)), gold[f"mg{ci}_max_vi_sha"])
+    for o in (r, pair, kv):
+        ops.rfx_host_drop(o)
