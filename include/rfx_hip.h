@@ -413,6 +413,16 @@ int rfx_dist_allreduce_i64(rfx_ctx_t *ctx, int64_t *d_buf, int64_t n, int op);
 int rfx_dist_allgather(rfx_ctx_t *ctx, const void *d_in, size_t bytes, void *d_out);
 int64_t rfx_dist_calls(rfx_ctx_t *ctx); /* collectives issued so far */
 
+/* ---- `update ... where / by` (ray_update, core/update.c:936-1106): the writes, on a device copy of the column ----
+ * rfx_hip_update_set:   d_col[d_ids[i]] = d_vals ? d_vals[d_ids[i]] : atom_bits   for i < m  (d_ids == NULL: rows 0 .. m-1).  d_vals is the
+ *                       element-wise mapping evaluated over ALL rows (rfx_hip_eval_expr), so its value at a selected row is what
+ *                       the reference's evaluation over the filtered table yields (set_ids, update.c filter arm).
+ * rfx_hip_update_group: d_col[row] = the final aggregate of row's group, for the selected rows -- tables of ONE aggregate filled by
+ *                       rfx_hip_group_dense_accumulate over the same selection (aggr_row + set_ids per group, update.c:781-850). */
+int rfx_hip_update_set(rfx_ctx_t *ctx, void *d_col, const int64_t *d_ids, int64_t m, const void *d_vals, uint64_t atom_bits);
+int rfx_hip_update_group(rfx_ctx_t *ctx, void *d_col, const int64_t *d_key, const int64_t *d_ids, int64_t m, const rfx_agg_t *agg,
+                         const rfx_group_tables_t *t);
+
 /* ---- bucketed group keys: (xbar col width), XBARI64 core/ops.h:192-193 ----
  * d_out[r] = null for a null input, else the largest multiple of `width` (> 0) that is <= d_col[r].  Group on the result
  * (`by: {t: (xbar ts 60000)}`). */

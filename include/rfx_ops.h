@@ -89,6 +89,11 @@ rfx_obj_p rfx_count(rfx_obj_p x);
 rfx_obj_p rfx_first(rfx_obj_p x);
 
 /* ---- residency ---------------------------------------------------------------------------------------------------- */
+/* unary_f: (update {col: mapping ... from: t [where: p] [by: k]}) -- ray_update, core/update.c:936-1106: a NEW table whose named columns
+ * carry the mapping's values at the selected rows (value i at row ids[i]; under by: every group's aggregate at all of its selected
+ * rows; unknown names become new columns, null elsewhere).  `from:` must be a table value; the in-place form on a quoted global and
+ * everything the device path does not cover go to the host's ray_update. */
+rfx_obj_p rfx_update(rfx_obj_p update_dict);
 /* unary_f: the reference's 7-slot group index of an i64 key column (index_group_i64_scoped, core/index.c:2002-2092), built on the
  * device: what a link-time replacement of index_group hands to the FN_AGGR built-ins inside a MAPGROUP pair.  rfx_sum .. rfx_first
  * accept such pairs (val, index) -- with indexes built here or by the reference -- besides vectors and MAPFILTER pairs. */

@@ -417,6 +417,44 @@ def inner_join(keys, left: dict, right: dict) -> dict:
     return out
 
 
+def update(query: dict) -> dict:
+    """ray_update (core/update.c:936-1106) restated over numpy columns: `where:` -> row ids (ray_where, :1001); the mappings are
+    evaluated over the filtered table (remap_filter, :1036-1042: value i belongs to row ids[i]) or, with `by:`, as one aggregate per
+    group of the selected rows (index_group(groupby, filters), :1021-1023); __update_table (:753-935) then writes value i to row
+    ids[i] / each group's value to all of its rows (aggr_row + set_ids), a name the table lacks becoming a new column that is null
+    elsewhere (nullv).  Returns the new table (the value form, `from: t`)."""
+    table = query["from"]
+    where_spec, by = query.get("where"), query.get("by")
+    outs = [(k, v) for k, v in query.items() if k not in ("from", "where", "by")]
+    n = len(next(iter(table.values())))
+    ids = where(mask_of(where_spec, table)) if where_spec is not None else np.arange(n, dtype=np.int64)
+    res = dict(table)
+    if by is not None:
+        gids, firsts, groups, _ = group_index(table[by], ids if where_spec is not None else None)
+    for name, m in outs:
+        if by is not None:
+            fn, col = m
+            if fn == "first":
+                c = _col(table[col])
+                per_group = c[ids[firsts]] if groups else np.empty(0, c.dtype)
+            else:
+                per_group = aggr(fn, table[col], gids, ids if where_spec is not None else None, groups)
+            vals = per_group[gids]
+        elif isinstance(m, (tuple, str)):
+            vals = _col(eval_arg(m, table))[ids]
+        else:
+            vals = np.full(len(ids), m, np.float64 if isinstance(m, float) else np.int64)
+        if name in table:
+            old = _col(table[name])
+            assert old.dtype == vals.dtype, "type conversion on update is not restated (the reference casts f64 into i64 columns)"
+            new = old.copy()
+        else:
+            new = np.full(n, np.nan if vals.dtype == np.float64 else NULL_I64, vals.dtype)
+        new[ids] = vals
+        res[name] = new
+    return res
+
+
 def select(query: dict) -> dict:
     """Same contract as rayforce_amd.Engine.select, numpy in / numpy out."""
     table = query["from"]

@@ -45,10 +45,10 @@ static struct {
     /* the host's own built-ins, for recognising function objects inside parsed expressions and for delegation */
     void *f[32];
 } H;
-enum { F_SUM, F_AVG, F_MIN, F_MAX, F_COUNT, F_FIRST, F_EQ, F_NE, F_LT, F_GT, F_LE, F_GE, F_AND, F_OR, F_SELECT, F_ADD, F_SUB, F_MUL, F_FDIV, F_XBAR, F_LJ, F_IJ, F_N };
+enum { F_SUM, F_AVG, F_MIN, F_MAX, F_COUNT, F_FIRST, F_EQ, F_NE, F_LT, F_GT, F_LE, F_GE, F_AND, F_OR, F_SELECT, F_ADD, F_SUB, F_MUL, F_FDIV, F_XBAR, F_LJ, F_IJ, F_UPDATE, F_N };
 static const char *HOST_FN[F_N] = {"ray_sum", "ray_avg", "ray_min", "ray_max", "ray_count", "ray_first", "ray_eq",  "ray_ne",  "ray_lt",  "ray_gt",
                                    "ray_le",  "ray_ge",  "ray_and", "ray_or",  "ray_select", "ray_add",  "ray_sub", "ray_mul", "ray_fdiv", "ray_xbar",
-                                   "ray_left_join", "ray_inner_join"};
+                                   "ray_left_join", "ray_inner_join", "ray_update"};
 /* xbar is recognised inside `by:` only; the standalone object model still needs a distinct function object for it:
  * this stub is never called by this library. */
 static obj_p x_stub_xbar(obj_p a, obj_p b) { (void)a; (void)b; return NULL; }
@@ -66,7 +66,7 @@ int rfx_host_bind(void) {
     OUR_FN[F_LT] = (void *)rfx_lt; OUR_FN[F_GT] = (void *)rfx_gt; OUR_FN[F_LE] = (void *)rfx_le; OUR_FN[F_GE] = (void *)rfx_ge;
     OUR_FN[F_AND] = (void *)rfx_and; OUR_FN[F_OR] = (void *)rfx_or; OUR_FN[F_SELECT] = (void *)rfx_select;
     OUR_FN[F_ADD] = (void *)rfx_add; OUR_FN[F_SUB] = (void *)rfx_sub; OUR_FN[F_MUL] = (void *)rfx_mul; OUR_FN[F_FDIV] = (void *)rfx_div; OUR_FN[F_XBAR] = (void *)x_stub_xbar;
-    OUR_FN[F_LJ] = (void *)rfx_left_join; OUR_FN[F_IJ] = (void *)rfx_inner_join;
+    OUR_FN[F_LJ] = (void *)rfx_left_join; OUR_FN[F_IJ] = (void *)rfx_inner_join; OUR_FN[F_UPDATE] = (void *)rfx_update;
     void *v = dlsym(RTLD_DEFAULT, "vector"), *t = dlsym(RTLD_DEFAULT, "table"), *e = dlsym(RTLD_DEFAULT, "eval");
     void *rs = dlsym(RTLD_DEFAULT, "ray_select"), *nu = dlsym(RTLD_DEFAULT, "__NULL_OBJ");
     if (v && t && e && rs && nu && !getenv("RFX_FORCE_STANDALONE")) {
@@ -111,7 +111,7 @@ obj_p rfx_host_fn(const char *name) {
         {">", F_GT, RFX_TYPE_BINARY, RFX_FN_ATOMIC}, {"<=", F_LE, RFX_TYPE_BINARY, RFX_FN_ATOMIC}, {">=", F_GE, RFX_TYPE_BINARY, RFX_FN_ATOMIC},
         {"and", F_AND, RFX_TYPE_VARY, RFX_FN_SPECIAL_FORM}, {"or", F_OR, RFX_TYPE_VARY, RFX_FN_SPECIAL_FORM}, {"select", F_SELECT, RFX_TYPE_UNARY, 0},
         {"+", F_ADD, RFX_TYPE_BINARY, RFX_FN_ATOMIC}, {"-", F_SUB, RFX_TYPE_BINARY, RFX_FN_ATOMIC}, {"*", F_MUL, RFX_TYPE_BINARY, RFX_FN_ATOMIC},
-        {"div", F_FDIV, RFX_TYPE_BINARY, RFX_FN_ATOMIC}, {"xbar", F_XBAR, RFX_TYPE_BINARY, RFX_FN_ATOMIC}};
+        {"div", F_FDIV, RFX_TYPE_BINARY, RFX_FN_ATOMIC}, {"xbar", F_XBAR, RFX_TYPE_BINARY, RFX_FN_ATOMIC}, {"update", F_UPDATE, RFX_TYPE_UNARY, 0}};
     rfx_host_bind();
     for (size_t i = 0; i < sizeof(T) / sizeof(T[0]); i++)
         if (strcmp(T[i].n, name) == 0) {
@@ -1010,6 +1010,231 @@ rfx_obj_p rfx_select(rfx_obj_p dict) {
     g_last_gpu = 0;
     obj_p r = select_impl(dict);
     g_stat[g_last_gpu ? ST_SELECT_GPU : ST_SELECT_DELEGATED]++;
+    op_end();
+    return r;
+}
+
+/* ------------------------------------------------------------------------------------------------ update
+ * (update {col: mapping ... from: t [where: p] [by: k]}) -- ray_update, core/update.c:936-1106.  The reference turns `where:` into
+ * row ids (ray_where), evaluates every mapping over the filtered / grouped table and writes: under a filter, value i goes to row
+ * ids[i]; under `by:`, each group's aggregate goes to all of that group's selected rows; a name the table does not have becomes a
+ * new column that is null elsewhere (__update_table).  Covered here: `from:` a table VALUE (the quoted-symbol form updates the
+ * host's global in place: the host's own job), flat or nested `where:`, mappings that are an i64 / f64 atom, a column, an
+ * element-wise expression (+ - * div, nested) -- and, with `by:` one 8-byte integer key column, (aggr column) for sum / avg / min /
+ * max / count / first under a flat `where:`.  Value and column types must agree (the reference also casts f64 into i64 columns:
+ * delegated).  Anything else is the host's ray_update. */
+static obj_p delegate_update(obj_p dict, const char *why) {
+    if (H.bound == 1 && H.f[F_UPDATE]) return ((rfx_unary_f)H.f[F_UPDATE])(dict);
+    char b[300];
+    snprintf(b, sizeof(b), "rfx_update: shape not covered by the MI355X path (%s) and no host ray_update to delegate to", why);
+    return fail(b);
+}
+static obj_p update_impl(obj_p dict) {
+    rfx_host_bind();
+    if (!dict || dict->type != RFX_TYPE_DICT || RFX_AS_LIST(dict)[0]->type != RFX_TYPE_SYMBOL) return fail("update: expected a dict");
+    obj_p from = dict_get(dict, "from");
+    if (!from) return fail("'update' expects 'from' param");
+    if (from->type == RFX_TYPE_LIST || from->type == -RFX_TYPE_SYMBOL) {
+        /* `from: 't` parses as (quote t): the in-place form on a global -- evaluated by the host only */
+        if (from->type == RFX_TYPE_LIST) return delegate_update(dict, "from: is an expression (in-place update of a global)");
+    }
+    obj_p tab = H.eval(from);
+    if (!tab || tab->type == RFX_TYPE_ERR) return tab;
+    if (tab->type != RFX_TYPE_TABLE) {
+        H.drop(tab);
+        return delegate_update(dict, "from: does not evaluate to a table value");
+    }
+    obj_p res = NULL;
+    const char *why = NULL;
+    void *tmp[3 * RFX_MAX_AGGS + 8];
+    int ntmp = 0;
+    obj_p where = dict_get(dict, "where"), by = dict_get(dict, "by");
+    obj_p dkeys = RFX_AS_LIST(dict)[0], dvals = RFX_AS_LIST(dict)[1];
+    const int64_t s_from = H.intern("from", 4), s_where = H.intern("where", 5), s_by = H.intern("by", 2);
+    obj_p tnames = RFX_AS_LIST(tab)[0], tcols = RFX_AS_LIST(tab)[1];
+    const int64_t nrows = tcols->len ? RFX_AS_LIST(tcols)[0]->len : 0;
+    obj_p newcols[RFX_MAX_AGGS] = {0};
+    int64_t mnames[RFX_MAX_AGGS];
+    obj_p mexpr[RFX_MAX_AGGS];
+    int nmap = 0;
+    for (int64_t i = 0; i < dkeys->len; i++) {
+        const int64_t k = RFX_AS_I64(dkeys)[i];
+        if (k == s_from || k == s_where || k == s_by) continue;
+        if (nmap >= RFX_MAX_AGGS) { why = "more than 8 mappings"; goto out; }
+        mnames[nmap] = k;
+        mexpr[nmap++] = RFX_AS_LIST(dvals)[i];
+    }
+    if (nmap == 0) { why = "no mapping"; goto out; }
+    if (nrows == 0) { why = "empty table"; goto out; }
+    for (int64_t i = 0; i < tcols->len; i++)
+        if (RFX_AS_LIST(tcols)[i]->len != nrows) { why = "ragged table"; goto out; }
+    if (ensure_ctx() != RFX_OK) { res = fail_hip("no usable MI355X"); goto done; }
+    {
+        /* ---- where: -> row ids (ray_where) ---- */
+        wplan_t wp;
+        memset(&wp, 0, sizeof(wp));
+        wp.logic = RFX_AND;
+        int flat = 1;
+        int64_t *d_ids = NULL, m = nrows;
+        if (where) {
+            int prc = plan_where(tab, where, &wp);
+            if (prc == -2) { res = fail_hip("column upload"); goto done; }
+            if (prc < 0) flat = 0;
+            if (by && !flat) { why = "by: with a nested where: tree"; goto out; }
+            int wrc = where_ids(tab, where, &wp, flat, nrows, &d_ids, &m);
+            if (wrc == -2) { res = fail_hip("where"); goto done; }
+            if (wrc < 0) { why = "where: shape"; goto out; }
+            if (d_ids) tmp[ntmp++] = d_ids;
+        }
+        /* ---- by: one 8-byte integer key column ---- */
+        const void *dk = NULL;
+        int64_t kmin = 0, kmax = -1, seen = 0;
+        if (by) {
+            if (by->type != -RFX_TYPE_SYMBOL) { why = "by: is not one column"; goto out; }
+            obj_p kc = table_col(tab, by->i64);
+            if (!kc || !(kc->type == RFX_TYPE_I64 || kc->type == RFX_TYPE_SYMBOL || kc->type == RFX_TYPE_TIMESTAMP)) { why = "by: key is not an 8-byte integer column"; goto out; }
+            if (resident(kc, 0, &dk) != RFX_OK) { res = fail_hip("column upload"); goto done; }
+            if (rfx_hip_scope_i64(g_ctx, (const int64_t *)dk, wp.preds, wp.npred, wp.logic, nrows, &kmin, &kmax, &seen) != RFX_OK) { res = fail_hip("scope"); goto done; }
+            const uint64_t range = seen > 0 ? (uint64_t)kmax - (uint64_t)kmin + 1 : 0;
+            if (seen > 0 && !(range != 0 && range <= (uint64_t)seen && kmin != RFX_NULL_I64 && range <= (1ull << 31))) { why = "by: sparse or null keys"; goto out; }
+        }
+        for (int i = 0; i < nmap; i++) {
+            obj_p e = mexpr[i];
+            obj_p tc = table_col(tab, mnames[i]);
+            int vtype = 0;          /* RFX_I64 | RFX_F64: element type of the values */
+            const void *dvals_col = NULL; /* full-length value column (no by:) */
+            uint64_t atom_bits = 0;
+            rfx_agg_t agg;
+            memset(&agg, 0, sizeof(agg));
+            if (by) {
+                if (e->type != RFX_TYPE_LIST || e->len != 2) { why = "by: mapping is not (aggr column)"; goto out; }
+                const int f = fn_id(RFX_AS_LIST(e)[0]);
+                static const int KIND[] = {RFX_AGG_SUM, RFX_AGG_AVG, RFX_AGG_MIN, RFX_AGG_MAX, RFX_AGG_COUNT, RFX_AGG_FIRST};
+                obj_p a = RFX_AS_LIST(e)[1];
+                if (f < F_SUM || f > F_FIRST || a->type != -RFX_TYPE_SYMBOL) { why = "by: mapping is not (aggr column)"; goto out; }
+                obj_p c = table_col(tab, a->i64);
+                if (!c || !col_ctype(c) || c->type == RFX_TYPE_SYMBOL) { why = "aggregate column type"; goto out; }
+                const void *d;
+                if (resident(c, 0, &d) != RFX_OK) { res = fail_hip("column upload"); goto done; }
+                agg.d_col = d;
+                agg.col_type = col_ctype(c);
+                agg.kind = KIND[f - F_SUM];
+                vtype = (f == F_AVG) ? RFX_F64 : (f == F_COUNT) ? RFX_I64 : col_ctype(c);
+            } else if (e->type == -RFX_TYPE_I64) { vtype = RFX_I64; atom_bits = (uint64_t)e->i64; }
+            else if (e->type == -RFX_TYPE_F64) { vtype = RFX_F64; memcpy(&atom_bits, &e->f64, 8); }
+            else if (e->type == -RFX_TYPE_SYMBOL) {
+                obj_p c = table_col(tab, e->i64);
+                if (!c || !(c->type == RFX_TYPE_I64 || c->type == RFX_TYPE_F64)) { why = "mapping column type"; goto out; }
+                if (resident(c, 0, &dvals_col) != RFX_OK) { res = fail_hip("column upload"); goto done; }
+                vtype = col_ctype(c);
+            } else if (e->type == RFX_TYPE_LIST && e->len == 3) {
+                rfx_xnode_t nodes[RFX_MAX_XNODES];
+                int nn = 0, ncols = 0;
+                int top = build_xnodes(tab, e, nodes, &nn, &ncols, &why);
+                if (top == -2) { res = fail_hip("column upload"); goto done; }
+                if (top < 0) goto out;
+                if (ncols == 0) { why = "expression without a column"; goto out; }
+                rfx_agg_t xa;
+                memset(&xa, 0, sizeof(xa));
+                xa.kind = RFX_AGG_SUM;
+                xa.col_type = RFX_I64;
+                xa.nxnodes = nn;
+                xa.xnodes = nodes;
+                void *dx = NULL;
+                if (rfx_hip_malloc(g_ctx, &dx, (size_t)nrows * 8) != RFX_OK) { res = fail_hip("expression column"); goto done; }
+                tmp[ntmp++] = dx;
+                int32_t ot = RFX_I64;
+                if (rfx_hip_eval_expr(g_ctx, &xa, nrows, dx, &ot) != RFX_OK) { res = fail_hip("eval_expr"); goto done; }
+                dvals_col = dx;
+                vtype = ot;
+            } else { why = "mapping is neither an atom, a column nor an element-wise expression"; goto out; }
+            /* __suitable_types (update.c:81-107): same type, or an i64 column taking f64 values by conversion -- the latter is the host's */
+            int8_t out_type = vtype == RFX_F64 ? RFX_TYPE_F64 : RFX_TYPE_I64;
+            if (tc) {
+                if (!(tc->type == RFX_TYPE_I64 || tc->type == RFX_TYPE_F64)) { why = "updated column is not i64 / f64"; goto out; }
+                if (col_ctype(tc) != vtype) { why = "value type differs from the column's (the reference converts; delegated)"; goto out; }
+                out_type = tc->type;
+            }
+            /* device copy of the column (or nulls for a new one), then the writes */
+            void *dcol = NULL;
+            if (rfx_hip_malloc(g_ctx, &dcol, (size_t)nrows * 8) != RFX_OK) { res = fail_hip("column copy"); goto done; }
+            tmp[ntmp++] = dcol;
+            if (tc) {
+                const void *dold;
+                if (resident(tc, 0, &dold) != RFX_OK) { res = fail_hip("column upload"); goto done; }
+                if (rfx_hip_update_set(g_ctx, dcol, NULL, nrows, dold, 0) != RFX_OK) { res = fail_hip("column copy"); goto done; } /* copy: ids NULL, vals = old */
+            } else if (rfx_hip_update_set(g_ctx, dcol, NULL, nrows, NULL, vtype == RFX_F64 ? 0x7FF8000000000000ull : 0x8000000000000000ull) != RFX_OK) {
+                res = fail_hip("column fill");
+                goto done;
+            }
+            if (m > 0) {
+                if (!by) {
+                    if (rfx_hip_update_set(g_ctx, dcol, d_ids, m, dvals_col, atom_bits) != RFX_OK) { res = fail_hip("update_set"); goto done; }
+                } else if (seen > 0) {
+                    const int64_t range = (int64_t)((uint64_t)kmax - (uint64_t)kmin + 1);
+                    int narr = 0;
+                    rfx_hip_group_table_arrays(&agg, 1, &narr);
+                    void *store = NULL;
+                    if (rfx_hip_malloc(g_ctx, &store, (size_t)narr * (size_t)range * 8) != RFX_OK) { res = fail_hip("group tables"); goto done; }
+                    tmp[ntmp++] = store;
+                    int64_t *base = (int64_t *)store;
+                    rfx_group_tables_t gt;
+                    memset(&gt, 0, sizeof(gt));
+                    gt.kmin = kmin;
+                    gt.range = range;
+                    gt.nagg = 1;
+                    gt.d_first = base;
+                    gt.d_acc[0] = base + range;
+                    gt.d_cnt[0] = narr > 2 ? base + 2 * range : NULL;
+                    if (rfx_hip_group_tables_init(g_ctx, &agg, &gt) != RFX_OK ||
+                        rfx_hip_group_dense_accumulate(g_ctx, (const int64_t *)dk, wp.preds, wp.npred, wp.logic, &agg, nrows, 0, &gt) != RFX_OK ||
+                        rfx_hip_update_group(g_ctx, dcol, (const int64_t *)dk, d_ids, m, &agg, &gt) != RFX_OK) { res = fail_hip("grouped update"); goto done; }
+                }
+            }
+            newcols[i] = H.vector(out_type, nrows);
+            if (rfx_hip_d2h(g_ctx, RFX_AS_RAW(newcols[i]), dcol, (size_t)nrows * 8) != RFX_OK) { res = fail_hip("read-back"); goto done; }
+        }
+        /* the result table: the old columns (shared), replaced or extended by the updated ones */
+        int64_t nnew = 0;
+        for (int i = 0; i < nmap; i++)
+            if (!table_col(tab, mnames[i])) {
+                int dup = 0;
+                for (int j = 0; j < i; j++) dup |= mnames[j] == mnames[i];
+                if (!dup) nnew++;
+            }
+        obj_p rk = H.vector(RFX_TYPE_SYMBOL, tnames->len + nnew), rv = H.vector(RFX_TYPE_LIST, tnames->len + nnew);
+        for (int64_t c = 0; c < tnames->len; c++) {
+            RFX_AS_I64(rk)[c] = RFX_AS_I64(tnames)[c];
+            obj_p col = NULL;
+            for (int i = nmap - 1; i >= 0 && !col; i--)
+                if (mnames[i] == RFX_AS_I64(tnames)[c] && newcols[i]) { col = newcols[i]; newcols[i] = NULL; }
+            RFX_AS_LIST(rv)[c] = col ? col : H.clone(RFX_AS_LIST(tcols)[c]);
+        }
+        int64_t at = tnames->len;
+        for (int i = 0; i < nmap; i++)
+            if (newcols[i] && !table_col(tab, mnames[i])) {
+                RFX_AS_I64(rk)[at] = mnames[i];
+                RFX_AS_LIST(rv)[at++] = newcols[i];
+                newcols[i] = NULL;
+            }
+        res = H.table(rk, rv);
+        g_last_gpu = 1;
+        goto done;
+    }
+out:
+    res = delegate_update(dict, why ? why : "unsupported");
+done:
+    for (int i = 0; i < nmap && i < RFX_MAX_AGGS; i++)
+        if (newcols[i]) H.drop(newcols[i]);
+    for (int i = 0; i < ntmp; i++) rfx_hip_free(g_ctx, tmp[i]);
+    qtmp_release();
+    H.drop(tab);
+    return res;
+}
+rfx_obj_p rfx_update(rfx_obj_p dict) {
+    op_begin();
+    g_last_gpu = 0;
+    obj_p r = update_impl(dict);
     op_end();
     return r;
 }

@@ -21,6 +21,7 @@ OPS_PROTOTYPES = {
     "rfx_ops_set_device": (C.c_int, [C.c_int]),
     "rfx_ops_last_error": (C.c_char_p, []),
     "rfx_select": (C.c_void_p, [C.c_void_p]),
+    "rfx_update": (C.c_void_p, [C.c_void_p]),
     **{f"rfx_{n}": (C.c_void_p, [C.c_void_p, C.c_void_p]) for n in ("eq", "ne", "lt", "gt", "le", "ge", "at", "add", "sub", "mul", "div")},
     "rfx_and": (C.c_void_p, [C.POINTER(C.c_void_p), C.c_int64]),
     "rfx_or": (C.c_void_p, [C.POINTER(C.c_void_p), C.c_int64]),

@@ -43,6 +43,15 @@ QUERIES = [
 ]
 
 
+UPDATES = [
+    ("u1", "{v: 99.5 from: t where: (== k 7)}", ["v", "a"]),
+    ("u2", "{v: (* v 1.5) from: t where: (> a 500000)}", ["v"]),
+    ("u3", "{a: (+ a (* k2 10)) n: 7 from: t where: (and (< a 300000) (> v 0.25))}", ["a", "n"]),
+    ("u4", "{tot: (sum v) c: (count a) from: t by: k}", ["tot", "c"]),
+    ("u5", "{v: (avg v) from: t where: (< a 600000) by: k1}", ["v"]),
+    ("u6", "{n: 100 from: t}", ["n", "k"]),
+]
+
 UNORDERED = {"q13": 1, "q16": 3}  # name -> leading key columns: group order there depends on the reference's executor count
 
 
@@ -96,6 +105,14 @@ def test_plugin_inside_the_real_reference(built):
             for o in ("k", "k1", "a", "v", "z"):
                 s.out(f"g_{tag}i_{o}", f"(at g_{tag}i '{o})")
                 s.out(f"r_{tag}i_{o}", f"(at r_{tag}i '{o})")
+        # update ... where / by: the plugin's rfx_update beside the reference's own update (value form: from: t)
+        s.eval(f'(set gupd (loadfn "{LIB}" "rfx_update" 1))')
+        for name, q, outs in UPDATES:
+            s.eval(f"(set g_{name} (gupd {q}))")
+            s.eval(f"(set r_{name} (update {q}))")
+            for o in outs:
+                s.out(f"g_{name}_{o}", f"(at g_{name} '{o})")
+                s.out(f"r_{name}_{o}", f"(at r_{name} '{o})")
         # who answered what: [selects on the GPU, selects delegated, joins on the GPU, joins delegated, uploads, hits, stale, calls]
         s.eval(f'(set gstat (loadfn "{LIB}" "rfx_stats" 1))')
         s.out("stats", "(gstat 0)")
@@ -114,6 +131,14 @@ def test_plugin_inside_the_real_reference(built):
             assert g.dtype == r.dtype and g.shape == r.shape, (name, o)
             if g.dtype == np.float64:
                 assert np.allclose(g, r, rtol=1e-9, atol=0), (name, o)
+            else:
+                assert np.array_equal(g, r), (name, o)
+    for name, _, outs in UPDATES:
+        for o in outs:
+            g, r = res[f"g_{name}_{o}"], res[f"r_{name}_{o}"]
+            assert g.dtype == r.dtype and g.shape == r.shape, (name, o)
+            if g.dtype == np.float64:
+                assert np.array_equal(np.isnan(g), np.isnan(r)) and np.allclose(g[~np.isnan(g)], r[~np.isnan(r)], rtol=1e-9, atol=0), (name, o)
             else:
                 assert np.array_equal(g, r), (name, o)
     for tag in ("j1", "j2"):

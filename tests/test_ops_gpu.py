@@ -422,3 +422,54 @@ def test_null_group_keys_are_handed_back(ops):
     # a filter that removes the null keys makes the query answerable again
     q = {"s": ("sum", "v"), "c": ("count", "a"), "by": "k", "where": (">", "k", 5)}
     check(run_select(ops, host, q), rfo.select({"from": host, **q}))
+
+
+def run_update(ops, host, query):
+    tab = H.table(host)
+    d = H.select_dict(query, tab)
+    r = ops.rfx_update(d)
+    assert r, "null result"
+    if H.is_error(r):
+        msg = H.error_text(r)
+        for o in (r, d, tab):
+            ops.rfx_host_drop(o)
+        raise RuntimeError(msg)
+    out = H.table_to_numpy(r)
+    for o in (r, d, tab):
+        ops.rfx_host_drop(o)
+    return out
+
+
+UPDATES = [
+    {"v": 99.5, "where": ("==", "k", 7)},                                   # atom under a filter (tests/lang.c:3060)
+    {"v": ("*", "v", 1.5)},                                                 # element-wise, every row (tests/lang.c:3173)
+    {"v": ("*", "v", 1.5), "where": (">", "a", 500_000)},                   # ... under a filter (tests/lang.c:3180)
+    {"a": ("+", "a", ("*", "k", 10)), "where": ("and", ("<", "a", 300_000), (">", "v", 0.25))},
+    {"n": 100},                                                             # new column, every row (tests/lang.c:3053)
+    {"n": 7, "f": ("div", "a", 3), "where": ("<", "a", 100_000)},            # new columns: null outside the selection
+    {"a": "k", "where": ("or", ("<", "a", 1000), (">", "v", 0.99))},         # a column as the mapping; nested where tree
+    {"tot": ("sum", "v"), "by": "k"},                                       # per-group aggregate into a new column (tests/lang.c:3067)
+    {"v": ("avg", "v"), "mx": ("max", "a"), "c": ("count", "a"), "by": "k"},
+    {"v": ("sum", "v"), "fa": ("first", "a"), "by": "k", "where": ("<", "a", 600_000)},
+    {"v": 1.0, "where": ("<", "a", -5)},                                    # nothing selected: the table comes back unchanged
+]
+
+
+@pytest.mark.parametrize("n,keys", [(1000, 13), (300_007, 5000)])
+def test_update_where_by(ops, n, keys):
+    """(update {...}) -- SURVEY 8f-4: K3 row ids + element-wise mappings / K7+K10 group aggregates + the two write kernels, against
+    the oracle's restatement of ray_update (core/update.c:936-1106)."""
+    host = host_table(n, keys=keys)
+    host["a"][::97] = NULL
+    for q in UPDATES:
+        got = run_update(ops, host, q)
+        assert ops.rfx_last_select_on_gpu() == 1, q
+        want = rfo.update({"from": host, **q})
+        check(got, want)
+    # shapes that are the host's: a type conversion (f64 values into an i64 column), a sparse by: key
+    with pytest.raises(RuntimeError, match="value type differs"):
+        run_update(ops, host, {"a": 1.5, "where": ("<", "a", 10)})
+    sparse = dict(host)
+    sparse["k"] = host["k"] * 1_000_003
+    with pytest.raises(RuntimeError, match="sparse or null keys"):
+        run_update(ops, sparse, {"t": ("sum", "v"), "by": "k"})
