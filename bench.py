@@ -251,6 +251,51 @@ def pmc_traffic(name):
         return None
 
 
+# ------------------------------------------------------------------------------------------------ the operator boundary
+def boundary_overhead(eng, rows=100_000_000, reps=10):
+    """The same query through BOTH doors at one size: Engine.group_by on device-resident columns (what `value` times) and the C operator
+    boundary -- rfx_select over host vectors laid out as RayforceDB objects (standalone host object model), columns pinned (rfx_pin:
+    uploaded once, trusted until rfx_invalidate) -- result table built on the host included.  Reports ms per query of each and the
+    difference: plan walk + cache lookups + result read-back + host table construction."""
+    import ctypes as C
+    from rayforce_amd import hostobj as H
+    ops = H.lib()
+    ops.rfx_host_bind()
+    cols = {"k": eng.gen_i64(rows, 4, 1_000_000), "v": eng.gen_f64(rows, 5), "a": eng.gen_i64(rows, 2, 1_000_000)}
+    q = {"where": ("<", "a", 100_000), "by": "k", "s": ("sum", "v")}
+    for _ in range(2):
+        eng.select({"from": cols, **q})
+    eng.sync()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        eng.select({"from": cols, **q})
+    eng.sync()
+    ms_engine = (time.perf_counter() - t0) * 1e3 / reps
+    host = {k: v.cpu().numpy() for k, v in cols.items()}
+    del cols
+    tab = H.table(host)
+    t0 = time.perf_counter()
+    p = ops.rfx_pin(tab)
+    pin_s = time.perf_counter() - t0
+    d = H.select_dict(q, tab)
+    for _ in range(2):
+        ops.rfx_host_drop(ops.rfx_select(d))
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        r = ops.rfx_select(d)
+        assert r and not H.is_error(r), H.error_text(r)
+        ops.rfx_host_drop(r)
+    ms_c = (time.perf_counter() - t0) * 1e3 / reps
+    on_gpu = int(ops.rfx_last_select_on_gpu())
+    u = ops.rfx_unpin(tab)
+    for o in (p, u, d, tab):
+        ops.rfx_host_drop(o)
+    ops.rfx_cache_clear()
+    return {"query": "select sum(v) by k where a < 100000 (c3w shape)", "rows": rows, "engine_ms": ms_engine, "rfx_select_ms": ms_c,
+            "boundary_overhead_ms": ms_c - ms_engine, "answered_on_gpu": on_gpu, "pin_upload_s": pin_s,
+            "pin_upload_GBps": 3 * rows * 8 / pin_s / 1e9}
+
+
 # ------------------------------------------------------------------------------------------------ CPU baseline
 def cpu_baseline(name, sample_rows, timeout=120):
     """The reference itself (oracle/_ref/rayforce, kind 'reference') or -- when it is not built -- the C restatement
@@ -462,6 +507,13 @@ def main():
             except Exception as e:  # noqa: BLE001
                 also[other] = {"error": str(e)[:200]}
 
+    boundary = None
+    if rank == 0 and world == 1 and not args.no_also and not args.rows:
+        try:
+            boundary = boundary_overhead(eng)
+            log(f"[bench] boundary: {boundary}")
+        except Exception as e:  # noqa: BLE001
+            boundary = {"error": str(e)[:200]}
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
@@ -506,6 +558,8 @@ def main():
         }
         if also:
             line["also"] = also
+        if boundary:
+            line["boundary"] = boundary
         print(json.dumps(line), flush=True)
     if dist.is_initialized():
         dist.barrier()

@@ -3,8 +3,9 @@
 // template instantiations compile in parallel), rfx_where.hip and the group-by files.
 //
 // Shape of the hot loop (what the ISA should look like on gfx950):
-//   * every lane owns E = 2*U rows of a tile: U x global_load_dwordx4 ... nt per column, issued for tile t+1 BEFORE
-//     tile t is evaluated (register double buffering) so HBM requests stay in flight across the ALU section;
+//   * every lane owns E = 2*U rows of a tile: U x global_load_dwordx4 ... nt per column, all issued before the first is used.
+//     There is NO register double buffering across tiles (the loop loads a tile, then folds it): what keeps HBM requests in
+//     flight across the ALU section is occupancy -- four 256-lane workgroups per CU (C2: 4.3 -> 6.7 TB/s from 2 -> 4 per CU);
 //   * a predicate is ONE v_cmp per row whose result lives in an SGPR pair (a wave-wide lane mask); AND/OR of several
 //     predicates are s_and_b64 / s_or_b64 on those masks -- no per-lane integer bit fiddling;
 //   * sums are v_cndmask + 64-bit add per selected row; every COUNT-like quantity is s_bcnt1 of the mask, kept

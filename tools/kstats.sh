@@ -5,6 +5,6 @@ rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks -o k -- python $
 python - <<'PY'
 import csv,glob
 f=glob.glob('/tmp/ks/**/*kernel_stats.csv',recursive=True)[0]
-for r in list(csv.DictReader(open(f)))[:7]:
+for r in list(csv.DictReader(open(f)))[:18]:
     print(f"{float(r['AverageNs'])/1e6:8.3f} ms  x{r['Calls']:>3}  {r['Name'][:70]}")
 PY
