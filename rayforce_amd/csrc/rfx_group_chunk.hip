@@ -40,33 +40,38 @@ struct ChunkArgs {
 
 // Per-workgroup state of the chunk-allocating write combiner.  Lane p OWNS partition p: its running state (records carried, room
 // in the current chunk, chunk count ...) lives in that lane's registers (CkLane); LDS holds only what the other lanes need to place
-// a record -- one 16-byte read each: pi[p] = {exclusive batch offset, carried, flushing now, room}, di[p] = {cursor, first new chunk}.
+// a record -- one 16-byte read each: pi[p] = {exclusive batch offset, carried, first place in the flush order, room},
+// di[p] = {cursor, first new chunk}.
 struct CkDst {
     u64 cursor;    // next record index inside the partition's current chunk (pool coordinates)
     unsigned noff; // this batch: first new chunk of the partition, relative to tile_alloc
     unsigned _pad;
 };
+#define CK_MAX_GROUPS ((PART_TILE_ROWS + CK_PARTS * (WC_B - 1)) / WC_B) /* whole 128-byte groups one batch can complete */
+#define CK_REL 0x80000000u
 struct CkLds {
-    unsigned cnt[CK_PARTS]; // per batch: record count per partition (rank atomics)
-    uint4 pi[CK_PARTS];     // x: exclusive offset of the partition's run in the batch, y: records carried over (< WC_B), z: records of
-                            // (carry ++ batch) that leave now (multiple of WC_B), w: records the current chunk still takes
-    CkDst di[CK_PARTS];
+    unsigned cnt[CK_PARTS];  // per batch: record count per partition (rank atomics)
+    unsigned excl[CK_PARTS]; // exclusive offset of the partition's run in the staged batch
+    // one descriptor per flushing 128-byte group -- x, y: pool index of its first record (y & CK_REL: relative to the batch's first
+    // new chunk), z: staging index of its record 0 (may be negative: the first `cut` records come from the carry buffer instead),
+    // w: cut | partition << 8
+    uint4 gd[CK_MAX_GROUPS + 32];
     u64x2 carry[CK_PARTS][WC_B];
     unsigned scan_w[RFX_BLOCK / RFX_WAVE];
-    unsigned tile_total, tile_alloc, slab_next, slab_end, dead;
+    unsigned tile_groups, tile_alloc, slab_next, slab_end, dead;
     ScopePart red[RFX_BLOCK / RFX_WAVE];
 };
 struct CkLane {
     unsigned pre, room, nch, cur; // carried records, room in the current chunk (0 only before the first batch), chunks so far, current chunk
     u64 cursor;
-    unsigned x, pf, noff;         // this batch: records, records flushing, first new chunk
+    unsigned x, pf, noff, excl;   // this batch: records, records flushing, first new chunk, offset of the partition's run
 };
 
 template <typename LDS>
 __device__ __forceinline__ void ck_init(LDS &L, CkLane &M) {
     M.pre = M.room = M.nch = M.cur = 0;
     M.cursor = 0;
-    M.x = M.pf = M.noff = 0;
+    M.x = M.pf = M.noff = M.excl = 0;
     if (threadIdx.x == 0) {
         L.slab_next = 0;
         L.slab_end = 0;
@@ -79,17 +84,42 @@ __device__ __forceinline__ u64 ck_meta(unsigned p, unsigned wg, unsigned nrec, u
 // LDS-only barrier: the phases exchange data through LDS alone, global loads / stores in flight need not land first
 __device__ __forceinline__ void ck_barrier() { __syncthreads(); }
 
-// One lane per partition, after the batch's per-partition counts are in cnt[]: exclusive scan of (count | new chunks << 16),
-// the flush decision, the chunk request.  Contains one barrier; the caller adds one after it.
-template <int G, typename LDS>
-__device__ __forceinline__ void ck_plan(LDS &L, CkLane &M, const ChunkArgs &A) {
+// thread RFX_BLOCK-1 / CK_PARTS-1, with the batch's chunk request: a slab refill when the workgroup's slab is used up
+template <typename LDS>
+__device__ __forceinline__ void ck_request(LDS &L, const ChunkArgs &A, unsigned tn) {
+    if (!tn) return;
+    const unsigned sn = L.slab_next;
+    if (sn + tn > L.slab_end) { // the rest of the old slab stays unused: its chunk metas keep CK_FREE
+        const unsigned slab = (CK_SLAB_BYTES / 16u) >> A.chs;
+        const unsigned g = tn > slab ? tn : slab;
+        const unsigned fresh = atomicAdd(&A.ctl[0], g);
+        // the returned value is consumed INSIDE this branch: a use after the join makes the compiler wait for every vector-memory
+        // operation in flight (the next tile's loads among them) on every batch, refill or not
+        asm volatile("" ::"v"(fresh));
+        L.slab_end = fresh + g;
+        if (fresh + g > A.max_chunks || fresh + g < fresh) {
+            L.dead = 1;
+            atomicExch(&A.ctl[1], 1u);
+        }
+        L.tile_alloc = fresh;
+        L.slab_next = fresh + tn;
+    } else {
+        L.tile_alloc = sn;
+        L.slab_next = sn + tn;
+    }
+}
+
+// One lane per partition, after the batch's per-partition counts are in cnt[]: exclusive scan of (count | flushing groups << 12 |
+// new chunks << 21), the flush decision, the chunk request, the partition of every flushing group.  Contains one barrier; the
+// caller adds one after it.  cnt[] is zero again afterwards.
+__device__ __forceinline__ void ck_plan(CkLds &L, CkLane &M, const ChunkArgs &A) {
     const int tid = threadIdx.x;
-    const unsigned CH = 1u << A.chs;
     const unsigned x = L.cnt[tid];
-    const unsigned pf = ((M.pre + x) / G) * G; // G = 1: every record leaves at once (no carry)
+    L.cnt[tid] = 0;
+    const unsigned pf = ((M.pre + x) / WC_B) * WC_B; // whole 128-byte groups leave, the rest waits in the carry buffer
     const unsigned rm = M.room;
     const unsigned need = (pf >= rm) ? ((pf - rm) >> A.chs) + 1 : 0;
-    const unsigned packed = x | (need << 16);
+    const unsigned packed = x | ((pf / WC_B) << 12) | (need << 21); // sums: <= 2048, <= CK_MAX_GROUPS (480), <= 256 + 2048 / 512
     unsigned inc = packed;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -101,34 +131,21 @@ __device__ __forceinline__ void ck_plan(LDS &L, CkLane &M, const ChunkArgs &A) {
     unsigned wbase = 0;
     for (int w = 0; w < (tid >> 6); w++) wbase += L.scan_w[w];
     const unsigned excl = wbase + inc - packed;
+    const unsigned g0 = (excl >> 12) & 0x1FFu;
     M.x = x;
     M.pf = pf;
-    M.noff = excl >> 16;
-    L.pi[tid] = make_uint4(excl & 0xFFFFu, M.pre, pf, rm);
-    CkDst d;
-    d.cursor = M.cursor;
-    d.noff = M.noff;
-    d._pad = 0;
-    L.di[tid] = d;
+    M.noff = excl >> 21;
+    M.excl = excl & 0xFFFu;
+    L.excl[tid] = M.excl;
+    for (unsigned g = 0; g < pf / WC_B; g++) {
+        const unsigned pos0 = g * WC_B;
+        const u64 dst = pos0 < rm ? M.cursor + pos0 : (((u64)M.noff << A.chs) + (pos0 - rm)) | ((u64)CK_REL << 32);
+        L.gd[g0 + g] = make_uint4((unsigned)dst, (unsigned)(dst >> 32), M.excl - M.pre + pos0, (g == 0 ? M.pre : 0u) | ((unsigned)tid << 8));
+    }
     if (tid == RFX_BLOCK - 1) {
         const unsigned tot = wbase + inc;
-        L.tile_total = tot & 0xFFFFu;
-        const unsigned tn = tot >> 16;
-        if (tn) {
-            unsigned sn = L.slab_next;
-            if (sn + tn > L.slab_end) { // the rest of the old slab stays unused: its chunk metas keep CK_FREE
-                const unsigned slab = (CK_SLAB_BYTES / 16u) / CH;
-                const unsigned g = tn > slab ? tn : slab;
-                sn = atomicAdd(&A.ctl[0], g);
-                L.slab_end = sn + g;
-                if (sn + g > A.max_chunks || sn + g < sn) {
-                    L.dead = 1;
-                    atomicExch(&A.ctl[1], 1u);
-                }
-            }
-            L.tile_alloc = sn;
-            L.slab_next = sn + tn;
-        }
+        L.tile_groups = (tot >> 12) & 0x1FFu;
+        ck_request(L, A, tot >> 21);
     }
 }
 // where record `pos` of partition p's flush sequence goes (pos < pfl), given pi[p]
@@ -136,17 +153,6 @@ template <typename LDS>
 __device__ __forceinline__ u64 ck_dst(const LDS &L, const ChunkArgs &A, unsigned p, unsigned pos, unsigned rm) {
     const CkDst d = L.di[p];
     return (pos < rm) ? d.cursor + pos : (((u64)L.tile_alloc + d.noff) << A.chs) + (pos - rm);
-}
-// old carry -> global for the partitions that flush (positions 0 .. pre-1 of their sequence)
-__device__ __forceinline__ void ck_flush_carry(const CkLds &L, const ChunkArgs &A) {
-#pragma unroll
-    for (int k = 0; k < CK_PARTS * WC_B / RFX_BLOCK; k++) {
-        const int idx = threadIdx.x + k * RFX_BLOCK;
-        const int p = idx / WC_B;
-        const unsigned j = idx % WC_B;
-        const uint4 pi = L.pi[p];
-        if (j < pi.y && pi.z > 0) A.pool[ck_dst(L, A, p, j, pi.w)] = L.carry[p][j];
-    }
 }
 // one lane per partition, after the batch's records are placed
 template <typename LDS>
@@ -204,7 +210,21 @@ __device__ __forceinline__ void ck_finish(LDS &L, const CkLane &M, const ChunkAr
     }
 }
 
-// 8 rows per lane of one 2048-row tile as four 16-byte loads per column; bit e of the result = row e exists
+// 8 rows per lane of a full 2048-row tile as four 16-byte loads per column
+template <int NC>
+__device__ __forceinline__ void ck_load_full(const Plan &P, i64 tile, u64 (&v)[NC][8]) {
+    const i64 base = tile * PART_TILE_ROWS + threadIdx.x * 2;
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            u64x2 q = rfx_ld2(P.cols[c] + base + (i64)j * (RFX_BLOCK * 2));
+            v[c][2 * j] = q.x;
+            v[c][2 * j + 1] = q.y;
+        }
+    }
+}
+// the same for any tile; bit e of the result = row e exists
 template <int NC>
 __device__ __forceinline__ unsigned ck_load_tile(const Plan &P, i64 tile, u64 (&v)[NC][8]) {
     const i64 base = tile * PART_TILE_ROWS + threadIdx.x * 2;
@@ -238,12 +258,13 @@ template <int NC, int NP>
 __global__ __launch_bounds__(RFX_BLOCK) void k_chunk_scatter(const Plan P, const ChunkArgs A) {
     __shared__ CkLds L;
     __shared__ u64x2 stag[PART_TILE_ROWS];
-    __shared__ unsigned char stag_p[PART_TILE_ROWS];
     PredSet<NP> S;
     predset_load<NP>(P, S);
     const int tid = threadIdx.x;
     CkLane M;
     ck_init(L, M);
+    L.cnt[tid] = 0;
+    ck_barrier();
     i64 mn = RFX_INF_I64_D, mx = RFX_NULL_I64_D, sel = 0, nulls = 0;
     const i64 ntiles = (P.nrows + PART_TILE_ROWS - 1) / PART_TILE_ROWS;
     const i64 step = A.tiles_per_wg ? 1 : (i64)gridDim.x;
@@ -253,7 +274,6 @@ __global__ __launch_bounds__(RFX_BLOCK) void k_chunk_scatter(const Plan P, const
     // Two register sets, loop unrolled by two: the next tile's loads are issued before this tile's LDS phases and land while the
     // phases run (copying an in-flight set into "the current one" would wait for it: the roles alternate instead).
     u64 va[NC][8], vb[NC][8];
-    unsigned valid_a = 0, valid_b = 0;
     bool alive = true;
     auto tile_body = [&](const u64 (&v)[NC][8], const unsigned valid, const i64 t) {
         const unsigned m = (NP == 0) ? valid : eval_preds<NC, 8, NP>(S, v, valid);
@@ -277,7 +297,7 @@ __global__ __launch_bounds__(RFX_BLOCK) void k_chunk_scatter(const Plan P, const
             }
         }
         ck_barrier();
-        ck_plan<WC_B>(L, M, A);
+        ck_plan(L, M, A);
         ck_barrier();
         if (L.dead) { // pool exhausted: the host sees ctl[1] and runs the column passes instead (uniform exit)
             alive = false;
@@ -288,44 +308,83 @@ __global__ __launch_bounds__(RFX_BLOCK) void k_chunk_scatter(const Plan P, const
         for (int e = 0; e < 8; e++) {
             if (!((m >> e) & 1u)) continue;
             const unsigned p = (unsigned)(key[e] & 255ULL);
-            const unsigned idx = L.pi[p].x + rank[e];
+            const unsigned idx = L.excl[p] + rank[e];
             const u64 lrow = (u64)(base + (i64)(e >> 1) * (RFX_BLOCK * 2) + (e & 1));
             u64x2 r;
             r.x = (lrow << 32) | (u64)(unsigned)((i64)key[e] >> 8);
             r.y = val[e];
             stag[idx] = r;
-            stag_p[idx] = (unsigned char)p;
         }
-        ck_flush_carry(L, A);
         ck_barrier();
-        // new records: the first (pfl - pre) of a partition complete the 128-byte groups, the rest is the new carry
-        const unsigned total = L.tile_total;
+        // Whole 128-byte groups leave: eight neighbouring lanes store one group = one full line, its first records from the carry
+        // buffer, the rest from the staged tile.  (Carry and new records stored separately are two partial-line writes per group:
+        // measured on C3, 1e9 records, those were 5 ms of the kernel's 8.)
+        // The loop is unrolled over a whole tile's worth of places with the LDS reads of all eight issued together: one
+        // descriptor + one record per lane and place, two dependent LDS latencies per tile instead of two per place.
+        const unsigned nflush = L.tile_groups * WC_B;
+        const u64 fresh = (u64)L.tile_alloc << A.chs;
+        for (unsigned i0 = 0; i0 < nflush; i0 += PART_TILE_ROWS) {
+            uint4 d[PART_TILE_ROWS / RFX_BLOCK];
+            u64x2 r[PART_TILE_ROWS / RFX_BLOCK];
 #pragma unroll
-        for (int k = 0; k < PART_TILE_ROWS / RFX_BLOCK; k++) {
-            const unsigned i = tid + k * RFX_BLOCK;
-            if (i < total) {
-                const unsigned p = stag_p[i];
-                const uint4 pi = L.pi[p];
-                const unsigned pos = pi.y + (i - pi.x);
-                if (pos < pi.z) A.pool[ck_dst(L, A, p, pos, pi.w)] = stag[i];
-                else L.carry[p][pos - pi.z] = stag[i];
+            for (int k = 0; k < PART_TILE_ROWS / RFX_BLOCK; k++) {
+                const unsigned i = i0 + tid + k * RFX_BLOCK;
+                d[k] = L.gd[i < nflush ? i / WC_B : 0];
+            }
+#pragma unroll
+            for (int k = 0; k < PART_TILE_ROWS / RFX_BLOCK; k++) {
+                const unsigned j = tid % WC_B;
+                r[k] = j < (d[k].w & 0xffu) ? L.carry[d[k].w >> 8][j] : stag[(d[k].z + j) & (PART_TILE_ROWS - 1)];
+            }
+#pragma unroll
+            for (int k = 0; k < PART_TILE_ROWS / RFX_BLOCK; k++) {
+                const unsigned i = i0 + tid + k * RFX_BLOCK;
+                if (i < nflush) {
+                    const u64 at = (((u64)(d[k].y & ~CK_REL) << 32) | d[k].x) + ((d[k].y & CK_REL) ? fresh : 0ULL) + tid % WC_B;
+                    A.pool[at] = r[k];
+                }
             }
         }
         ck_barrier();
+        // the partition's lane keeps what did not fill a group (< WC_B records): reads first, then writes
+        {
+            const unsigned left = M.pre + M.x - M.pf;
+            const unsigned from = M.pf > 0 ? M.excl + (M.pf - M.pre) : M.excl, to = M.pf > 0 ? 0u : M.pre, n = M.pf > 0 ? left : M.x;
+            u64x2 keep[WC_B - 1];
+#pragma unroll
+            for (int j = 0; j < WC_B - 1; j++) keep[j] = stag[(from + j) & (PART_TILE_ROWS - 1)];
+#pragma unroll
+            for (int j = 0; j < WC_B - 1; j++)
+                if ((unsigned)j < n) L.carry[tid][to + j] = keep[j];
+        }
         ck_update(M, L, A);
     };
-    if (t0 < t1) valid_a = ck_load_tile<NC>(P, t0, va);
-    for (i64 t = t0; t < t1; t += 2 * step) {
-        L.cnt[tid] = 0;
-        ck_barrier();
-        if (t + step < t1) valid_b = ck_load_tile<NC>(P, t + step, vb);
-        tile_body(va, valid_a, t);
-        if (!alive) return;
-        if (t + step >= t1) break;
-        L.cnt[tid] = 0;
-        ck_barrier();
-        if (t + 2 * step < t1) valid_a = ck_load_tile<NC>(P, t + 2 * step, va);
-        tile_body(vb, valid_b, t + step);
+    // The main loop takes full tiles only and ALWAYS issues the next tile's eight loads (a tile past the end is clamped to the last
+    // one and never used): with a fixed number of loads behind the ones it waits for, the compiler waits with vmcnt(8); a
+    // conditional or ragged load in the loop turns that into vmcnt(0) -- every tile then waits out its successor's loads.
+    const i64 nfull = P.nrows / PART_TILE_ROWS;
+    const i64 e1 = t1 < nfull ? t1 : nfull; // full tiles of this workgroup: t0, t0 + step, ... < e1
+    if (t0 < e1) {
+        const i64 last = t0 + ((e1 - 1 - t0) / step) * step;
+        ck_load_full<NC>(P, t0, va);
+        for (i64 t = t0;;) {
+            i64 tn = t + step;
+            ck_load_full<NC>(P, tn < e1 ? tn : last, vb);
+            tile_body(va, 0xffu, t);
+            if (!alive) return;
+            t = tn;
+            if (t >= e1) break;
+            tn = t + step;
+            ck_load_full<NC>(P, tn < e1 ? tn : last, va);
+            tile_body(vb, 0xffu, t);
+            if (!alive) return;
+            t = tn;
+            if (t >= e1) break;
+        }
+    }
+    if (nfull < ntiles && nfull >= t0 && nfull < t1 && (nfull - t0) % step == 0) { // the ragged last tile is this workgroup's
+        const unsigned valid = ck_load_tile<NC>(P, nfull, va);
+        tile_body(va, valid, nfull);
         if (!alive) return;
     }
     ck_barrier();
