@@ -184,7 +184,9 @@ enum {
     RFX_TUNE_NO_LDS_REPLICAS = 8192, /* dense group-by, a handful of groups: one LDS table set per workgroup, no lane-private replicas */
     RFX_TUNE_NO_CHUNK = 16384,       /* rfx_hip_group_scope: plain scope pass, never the one-pass chunk partitioning */
     RFX_TUNE_CHUNK_SMALL = 32768,    /* rfx_hip_group_scope: one-pass chunk partitioning from 2^16 rows on (default 2^22): for tests */
-    RFX_TUNE_CHUNK_CONTIG = 65536    /* one-pass chunk partitioning: every workgroup takes one contiguous row range instead of grid-stride tiles */
+    RFX_TUNE_CHUNK_CONTIG = 65536,   /* one-pass chunk partitioning: every workgroup takes one contiguous row range instead of grid-stride tiles */
+    RFX_TUNE_CHUNK_QUEUE = 131072,   /* one-pass chunk partitioning under a selective filter: always the sorted-queue kernel (as for skewed keys), never per-partition bins */
+    RFX_TUNE_CHUNK_BINS = 262144     /* ... always per-partition bins, however the sampled keys spread: for tests */
 };
 int rfx_hip_ctx_tune(rfx_ctx_t *ctx, int blocks_per_cu, int flags);
 

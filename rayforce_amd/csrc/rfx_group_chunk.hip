@@ -651,6 +651,214 @@ __global__ __launch_bounds__(CK_SELT) void k_chunk_scatter_sel(const Plan P, con
         A.parts[blockIdx.x] = r;
     }
 }
+// ---- selective filters, keys spread over the partitions: per-partition LDS bins instead of a queue ----
+// The same 1024-lane workgroup per CU and the same decoupled waves, but a survivor goes straight into ITS PARTITION's bin (one
+// returning LDS atomic for the place, one 16-byte LDS store); when a bin is full the wave keeps the rows that did not fit, raises the
+// flag, and all waves meet.  Then every partition's whole 128-byte groups leave -- eight neighbouring lanes store one group from
+// eight neighbouring bin entries: a full line, where the queue kernel's records (in arrival order) leave as lone 16-byte stores,
+// partial-line writes -- and the < 8 records left move to the front of the bin.  No ranking, no staging, no carry buffers.
+// A hot partition fills its bin every few records: the host picks this kernel only when the sample's low key bytes are spread.
+#define CK_BIN_CAP 32
+struct CkBinLds {
+    unsigned tail[CK_PARTS]; // records in the bin (may overshoot CK_BIN_CAP: those lanes keep their rows)
+    uint4 pd[CK_PARTS];      // drain: x, y: cursor, z: room | flushing << 16, w: first new chunk (relative)
+    unsigned scan_w[4];
+    unsigned tile_alloc, slab_next, slab_end, dead;
+    unsigned q_flag, alive[2];
+    ScopePart red[CK_SELT / RFX_WAVE];
+};
+#define CK_BIN_LDS (CK_PARTS * CK_BIN_CAP * 16 + sizeof(CkBinLds) + 64)
+template <int NC, int NP>
+__global__ __launch_bounds__(CK_SELT) void k_chunk_scatter_bin(const Plan P, const ChunkArgs A) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char ck_smem[];
+    u64x2 *bins = (u64x2 *)ck_smem; // [CK_PARTS][CK_BIN_CAP]
+    CkBinLds &L = *(CkBinLds *)(ck_smem + CK_PARTS * CK_BIN_CAP * 16);
+    PredSet<NP> S;
+    predset_load<NP>(P, S);
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    CkLane M; // lanes 0..255 own partition tid; M.pre = records waiting in the bin
+    M.pre = M.room = M.nch = M.cur = 0;
+    M.cursor = 0;
+    M.x = M.pf = M.noff = M.excl = 0;
+    if (tid < CK_PARTS) L.tail[tid] = 0;
+    if (tid == 0) {
+        L.slab_next = L.slab_end = L.dead = 0;
+        L.q_flag = 0;
+        L.alive[0] = L.alive[1] = 0;
+    }
+    __syncthreads();
+    i64 mn = RFX_INF_I64_D, mx = RFX_NULL_I64_D, sel = 0, nulls = 0;
+    const i64 nsteps = (P.nrows + CK_SEL_WROWS - 1) / CK_SEL_WROWS;
+    const i64 nwaves = (i64)gridDim.x * (CK_SELT / RFX_WAVE);
+    i64 ws = (i64)blockIdx.x * (CK_SELT / RFX_WAVE) + wv; // this wave's next step
+    constexpr int VC = NC > 1 ? 1 : 0; // the host put the key in plan column 0 and the value in column 1 (0 when it is the key itself)
+    u64 v[NC][8];
+    unsigned m = 0; // rows of the current step still to be placed
+    i64 base = 0;
+    unsigned round = 0;
+    for (;;) {
+        // ---- run ahead until a bin is full, the flag is up, or this wave has nothing left ----
+        for (;;) {
+            if (!__any(m != 0)) {
+                if (ws >= nsteps) break;
+                base = ws * CK_SEL_WROWS + lane * 2;
+                unsigned valid = 0xffu;
+                if ((ws + 1) * CK_SEL_WROWS <= P.nrows) {
+#pragma unroll
+                    for (int c = 0; c < NC; c++) {
+#pragma unroll
+                        for (int j = 0; j < 4; j++) {
+                            u64x2 t = rfx_ld2(P.cols[c] + base + j * 128);
+                            v[c][2 * j] = t.x;
+                            v[c][2 * j + 1] = t.y;
+                        }
+                    }
+                } else {
+                    valid = 0;
+#pragma unroll
+                    for (int e = 0; e < 8; e++) {
+                        const i64 row = base + (e >> 1) * 128 + (e & 1);
+                        const bool in = row < P.nrows;
+                        valid |= (unsigned)in << e;
+#pragma unroll
+                        for (int c = 0; c < NC; c++) v[c][e] = in ? P.cols[c][row] : 0ULL;
+                    }
+                }
+                ws += nwaves;
+                m = (NP == 0) ? valid : eval_preds<NC, 8, NP>(S, v, valid);
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    if ((m >> e) & 1u) {
+                        const i64 k = (i64)v[0][e];
+                        sel++;
+                        if (k == RFX_NULL_I64_D) nulls++;
+                        else {
+                            mn = k < mn ? k : mn;
+                            mx = k > mx ? k : mx;
+                        }
+                    }
+                }
+                if (!__any(m != 0)) continue;
+            }
+            if (*(volatile unsigned *)&L.q_flag) break; // a drain has been called: join it, place afterwards
+            bool full = false;
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                if ((m >> e) & 1u) {
+                    const unsigned p = (unsigned)(v[0][e] & 255ULL);
+                    const unsigned at = atomicAdd(&L.tail[p], 1u);
+                    if (at < CK_BIN_CAP) {
+                        const i64 k = (i64)v[0][e];
+                        const u64 lrow = (u64)(base + (e >> 1) * 128 + (e & 1));
+                        u64x2 r;
+                        r.x = (lrow << 32) | (u64)(unsigned)(k >> 8);
+                        r.y = A.vcol == 0 ? v[0][e] : v[VC][e];
+                        bins[p * CK_BIN_CAP + at] = r;
+                        m &= ~(1u << e);
+                    } else full = true;
+                }
+            }
+            if (__any(full)) {
+                if (lane == 0) *(volatile unsigned *)&L.q_flag = 1u;
+                break;
+            }
+        }
+        // ---- drain round (all 16 waves) ----
+        if (lane == 0 && (__any(m != 0) || ws < nsteps)) atomicAdd(&L.alive[round & 1], 1u);
+        __syncthreads();
+        const unsigned still = L.alive[round & 1];
+        unsigned have = 0, inc = 0, need = 0;
+        if (tid < CK_PARTS) { // one lane per partition (waves 0..3): what leaves, chunk requests
+            const unsigned t = L.tail[tid];
+            have = t < CK_BIN_CAP ? t : CK_BIN_CAP;
+            const unsigned pf = (have / WC_B) * WC_B;
+            need = (pf >= M.room) ? 1u : 0u; // a drain moves at most CK_BIN_CAP records of a partition: never more than one new chunk
+            M.pf = pf;
+            inc = need;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                unsigned o = __shfl_up(inc, d, 64);
+                if (lane >= d) inc += o;
+            }
+            if (lane == 63) L.scan_w[wv] = inc;
+        }
+        __syncthreads();
+        if (tid < CK_PARTS) {
+            unsigned wbase = 0;
+            for (int w = 0; w < wv; w++) wbase += L.scan_w[w];
+            M.noff = wbase + inc - need;
+            L.pd[tid] = make_uint4((unsigned)M.cursor, (unsigned)(M.cursor >> 32), M.room | (M.pf << 16), M.noff);
+            if (tid == CK_PARTS - 1) ck_request(L, A, wbase + inc);
+        }
+        __syncthreads();
+        if (L.dead) return;
+        {
+            const u64 fresh = (u64)L.tile_alloc << A.chs;
+#pragma unroll
+            for (int k = 0; k < CK_PARTS * CK_BIN_CAP / CK_SELT; k++) {
+                const unsigned idx = tid + k * CK_SELT;
+                const unsigned p = idx / CK_BIN_CAP, pos = idx % CK_BIN_CAP;
+                const uint4 d = L.pd[p];
+                const unsigned rm = d.z & 0xffffu;
+                if (pos < (d.z >> 16)) {
+                    const u64 at = pos < rm ? (((u64)d.y << 32) | d.x) + pos : fresh + ((u64)d.w << A.chs) + (pos - rm);
+                    A.pool[at] = bins[idx];
+                }
+            }
+        }
+        __syncthreads();
+        if (tid < CK_PARTS) {
+            const unsigned left = have - M.pf; // < WC_B
+            if (M.pf > 0) {
+                u64x2 keep[WC_B - 1];
+#pragma unroll
+                for (int j = 0; j < WC_B - 1; j++) keep[j] = bins[tid * CK_BIN_CAP + ((M.pf + j) & (CK_BIN_CAP - 1))];
+#pragma unroll
+                for (int j = 0; j < WC_B - 1; j++)
+                    if ((unsigned)j < left) bins[tid * CK_BIN_CAP + j] = keep[j];
+            }
+            L.tail[tid] = left;
+            M.x = have - M.pre; // ck_update: pre <- pre + x - pf = left
+            ck_update(M, L, A);
+        }
+        if (tid == 0) {
+            L.q_flag = 0;
+            L.alive[(round + 1) & 1] = 0;
+        }
+        __syncthreads();
+        round++;
+        if (still == 0) break; // nobody has rows left
+    }
+    // the last, padded group of every partition, final record counts of the open chunks, chunk counts, scope
+    if (tid < CK_PARTS) {
+        const unsigned CH = 1u << A.chs;
+        if (M.pre > 0) { // its chunk has room (room > 0 after every drain); the record count ends before the padding
+            for (unsigned j = 0; j < WC_B; j++) A.pool[M.cursor + j] = bins[tid * CK_BIN_CAP + j];
+        }
+        if (M.nch > 0) A.meta[M.cur] = ck_meta(tid, blockIdx.x, CH - M.room + M.pre, M.nch - 1);
+        A.wcount[(size_t)blockIdx.x * CK_PARTS + tid] = M.nch;
+    }
+    for (int s = 32; s >= 1; s >>= 1) {
+        const i64 omn = (i64)rfx_shfl_xor_u64((u64)mn, s), omx = (i64)rfx_shfl_xor_u64((u64)mx, s);
+        mn = omn < mn ? omn : mn;
+        mx = omx > mx ? omx : mx;
+        sel += (i64)rfx_shfl_xor_u64((u64)sel, s);
+        nulls += (i64)rfx_shfl_xor_u64((u64)nulls, s);
+    }
+    if (lane == 0) L.red[wv] = ScopePart{mn, mx, sel, nulls};
+    __syncthreads();
+    if (tid == 0) {
+        ScopePart r = L.red[0];
+        for (int w = 1; w < CK_SELT / RFX_WAVE; w++) {
+            r.mn = L.red[w].mn < r.mn ? L.red[w].mn : r.mn;
+            r.mx = L.red[w].mx > r.mx ? L.red[w].mx : r.mx;
+            r.sel += L.red[w].sel;
+            r.nulls += L.red[w].nulls;
+        }
+        A.parts[blockIdx.x] = r;
+    }
+}
+
 #define CK_SEL_LDS (CK_SELQ * 19 + 64 + CK_PARTS * WC_B * 16 + sizeof(CkSelLds) + 64)
 
 // wcount[w][p] -> exclusive offset of (w, p) inside partition p's chunk list; part_start[p] = first entry of partition p.
@@ -844,7 +1052,7 @@ __global__ __launch_bounds__(THREADS) void k_chunk_aggregate(const Plan P, const
 
 // ---- strided sample: a first guess of the key range and of the filter's selectivity, only to choose the pass (never a result) ----
 template <int NC>
-__global__ __launch_bounds__(RFX_BLOCK) void k_scope_sample(const Plan P, int key_idx, i64 stride, i64 nsamp, i64 *__restrict__ out) {
+__global__ __launch_bounds__(RFX_BLOCK) void k_scope_sample(const Plan P, int key_idx, i64 stride, i64 nsamp, i64 *__restrict__ out, unsigned *__restrict__ hist) {
     __shared__ i64 red[3][RFX_BLOCK / RFX_WAVE];
     PredSet<RFX_MAX_PREDS> S;
     predset_load<RFX_MAX_PREDS>(P, S);
@@ -860,7 +1068,9 @@ __global__ __launch_bounds__(RFX_BLOCK) void k_scope_sample(const Plan P, int ke
         const i64 k = (i64)key[0];
         mn = k < mn ? k : mn;
         mx = k > mx ? k : mx;
-        sel += (P.npred == 0) ? 1 : (i64)(eval_preds<NC, 1, RFX_MAX_PREDS>(S, v, 1u) & 1u);
+        const unsigned hit = (P.npred == 0) ? 1u : (eval_preds<NC, 1, RFX_MAX_PREDS>(S, v, 1u) & 1u);
+        sel += hit;
+        if (hit) atomicAdd(&hist[(unsigned)((u64)k & 255ULL)], 1u); // how evenly the selection spreads over the 256 partitions
     }
     for (int s = 32; s >= 1; s >>= 1) {
         const i64 omn = (i64)rfx_shfl_xor_u64((u64)mn, s), omx = (i64)rfx_shfl_xor_u64((u64)mx, s);
@@ -937,6 +1147,22 @@ static int launch_chunk_scatter_sel_np(rfx_ctx *c, const Plan &P, const ChunkArg
     }
     hipLaunchKernelGGL((k_chunk_scatter_sel<NC, NP>), dim3(A.nwg), dim3(CK_SELT), CK_SEL_LDS, c->stream, P, A);
     return RFX_OK;
+}
+template <int NC, int NP>
+static int launch_chunk_scatter_bin_np(rfx_ctx *c, const Plan &P, const ChunkArgs &A) {
+    static bool attr_set = false; // per instantiation
+    if (!attr_set) {
+        RFX_HIP_CHECK(hipFuncSetAttribute((const void *)k_chunk_scatter_bin<NC, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CK_BIN_LDS));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_chunk_scatter_bin<NC, NP>), dim3(A.nwg), dim3(CK_SELT), CK_BIN_LDS, c->stream, P, A);
+    return RFX_OK;
+}
+template <int NC>
+static int launch_chunk_scatter_bin(rfx_ctx *c, const Plan &P, const ChunkArgs &A) {
+    if (P.npred == 1) return launch_chunk_scatter_bin_np<NC, 1>(c, P, A);
+    if (P.npred <= 3) return launch_chunk_scatter_bin_np<NC, 3>(c, P, A);
+    return launch_chunk_scatter_bin_np<NC, RFX_MAX_PREDS>(c, P, A);
 }
 template <int NC>
 static int launch_chunk_scatter_sel(rfx_ctx *c, const Plan &P, const ChunkArgs &A) {
@@ -1023,18 +1249,23 @@ int rfx_chunk_scope(rfx_ctx *c, const int64_t *d_key, const rfx_pred_t *preds, i
     // 256 partitions come here (the LDS-direct kernel is one pass already; wider ranges need more partitions than the low 8 bits give)
     const i64 nsamp = 1 << 14;
     const int sgrid = 16;
-    rc = rfx_ws_reserve(c, (size_t)sgrid * 32);
+    rc = rfx_ws_reserve(c, (size_t)sgrid * 32 + CK_PARTS * 4);
     if (rc != RFX_OK) return rc;
+    unsigned *d_hist = (unsigned *)((char *)c->d_ws + (size_t)sgrid * 32);
+    RFX_HIP_CHECK(hipMemsetAsync(d_hist, 0, CK_PARTS * 4, c->stream));
     switch (P.ncols) {
-        case 1: hipLaunchKernelGGL(k_scope_sample<1>, dim3(sgrid), dim3(RFX_BLOCK), 0, c->stream, P, key_idx, nrows / nsamp, nsamp, (i64 *)c->d_ws); break;
-        case 2: hipLaunchKernelGGL(k_scope_sample<2>, dim3(sgrid), dim3(RFX_BLOCK), 0, c->stream, P, key_idx, nrows / nsamp, nsamp, (i64 *)c->d_ws); break;
-        case 3: hipLaunchKernelGGL(k_scope_sample<3>, dim3(sgrid), dim3(RFX_BLOCK), 0, c->stream, P, key_idx, nrows / nsamp, nsamp, (i64 *)c->d_ws); break;
-        default: hipLaunchKernelGGL(k_scope_sample<4>, dim3(sgrid), dim3(RFX_BLOCK), 0, c->stream, P, key_idx, nrows / nsamp, nsamp, (i64 *)c->d_ws); break;
+        case 1: hipLaunchKernelGGL(k_scope_sample<1>, dim3(sgrid), dim3(RFX_BLOCK), 0, c->stream, P, key_idx, nrows / nsamp, nsamp, (i64 *)c->d_ws, d_hist); break;
+        case 2: hipLaunchKernelGGL(k_scope_sample<2>, dim3(sgrid), dim3(RFX_BLOCK), 0, c->stream, P, key_idx, nrows / nsamp, nsamp, (i64 *)c->d_ws, d_hist); break;
+        case 3: hipLaunchKernelGGL(k_scope_sample<3>, dim3(sgrid), dim3(RFX_BLOCK), 0, c->stream, P, key_idx, nrows / nsamp, nsamp, (i64 *)c->d_ws, d_hist); break;
+        default: hipLaunchKernelGGL(k_scope_sample<4>, dim3(sgrid), dim3(RFX_BLOCK), 0, c->stream, P, key_idx, nrows / nsamp, nsamp, (i64 *)c->d_ws, d_hist); break;
     }
     RFX_HIP_CHECK(hipGetLastError());
     i64 *hs = (i64 *)c->h_pin;
-    RFX_HIP_CHECK(hipMemcpyAsync(hs, c->d_ws, (size_t)sgrid * 32, hipMemcpyDeviceToHost, c->stream));
+    RFX_HIP_CHECK(hipMemcpyAsync(hs, c->d_ws, (size_t)sgrid * 32 + CK_PARTS * 4, hipMemcpyDeviceToHost, c->stream));
     RFX_HIP_CHECK(hipStreamSynchronize(c->stream));
+    const unsigned *hh = (const unsigned *)((const char *)hs + (size_t)sgrid * 32);
+    unsigned hot = 0;
+    for (int i = 0; i < CK_PARTS; i++) hot = hh[i] > hot ? hh[i] : hot;
     i64 smn = RFX_INF_I64_D, smx = RFX_NULL_I64_D, ssel = 0;
     for (int i = 0; i < sgrid; i++) {
         smn = hs[4 * i] < smn ? hs[4 * i] : smn;
@@ -1051,6 +1282,9 @@ int rfx_chunk_scope(rfx_ctx *c, const int64_t *d_key, const rfx_pred_t *preds, i
     if (est_rows > nrows || npred == 0) est_rows = nrows;
     if (est > (unsigned long long)est_rows * 2) return RFX_ESTATE;                                    // sparse keys: the hashed path
     const bool selective = npred > 0 && frac <= 0.4;
+    // bins fill evenly when no partition takes much more than its 1/256 of the selection (sampled: the fullest bin against the mean)
+    const bool spread = (double)hot <= 6.0 * ((double)ssel / CK_PARTS) + 24.0;
+    const bool bins = selective && (spread || (c->flags & RFX_TUNE_CHUNK_BINS)) && !(c->flags & RFX_TUNE_CHUNK_QUEUE);
     ChunkArgs A;
     memset(&A, 0, sizeof(A));
     i64 tpw = 0, nulls = 0;
@@ -1090,11 +1324,20 @@ int rfx_chunk_scope(rfx_ctx *c, const int64_t *d_key, const rfx_pred_t *preds, i
         RFX_HIP_CHECK(hipMemsetAsync(A.ctl, 0, 256, c->stream));
         RFX_HIP_CHECK(hipMemsetAsync(A.meta, 0xFF, (size_t)A.max_chunks * 8, c->stream));
         RFX_KERNEL_BEGIN(c);
-        switch (P.ncols) {
-            case 1: rc = launch_chunk_scatter_sel<1>(c, Pc, A); break;
-            case 2: rc = launch_chunk_scatter_sel<2>(c, Pc, A); break;
-            case 3: rc = launch_chunk_scatter_sel<3>(c, Pc, A); break;
-            default: rc = launch_chunk_scatter_sel<4>(c, Pc, A); break;
+        if (bins) {
+            switch (P.ncols) {
+                case 1: rc = launch_chunk_scatter_bin<1>(c, Pc, A); break;
+                case 2: rc = launch_chunk_scatter_bin<2>(c, Pc, A); break;
+                case 3: rc = launch_chunk_scatter_bin<3>(c, Pc, A); break;
+                default: rc = launch_chunk_scatter_bin<4>(c, Pc, A); break;
+            }
+        } else {
+            switch (P.ncols) {
+                case 1: rc = launch_chunk_scatter_sel<1>(c, Pc, A); break;
+                case 2: rc = launch_chunk_scatter_sel<2>(c, Pc, A); break;
+                case 3: rc = launch_chunk_scatter_sel<3>(c, Pc, A); break;
+                default: rc = launch_chunk_scatter_sel<4>(c, Pc, A); break;
+            }
         }
         RFX_KERNEL_END(c);
         if (rc != RFX_OK) return rc;

@@ -371,12 +371,17 @@ def test_filtered_partitioned_group_by(eng, flags, thr):
 CHUNK_SMALL = 32768  # RFX_TUNE_CHUNK_SMALL: the one-pass chunk partitioning from 2^16 rows on
 
 
-@pytest.mark.parametrize("flags", [CHUNK_SMALL, CHUNK_SMALL | 4, 16384])
+CHUNK_QUEUE, CHUNK_BINS = 131072, 262144  # selective filters: always the sorted-queue kernel / always per-partition bins
+
+
+@pytest.mark.parametrize("flags", [CHUNK_SMALL, CHUNK_SMALL | 4, CHUNK_SMALL | CHUNK_QUEUE, CHUNK_SMALL | CHUNK_BINS, 16384])
 @pytest.mark.parametrize("shape", ["uniform", "offset", "skew", "wide", "narrow"])
 def test_chunk_partitioned_group_by(eng, flags, shape):
     """rfx_hip_group_scope: the scope pass that also radix-partitions (rfx_group_chunk.hip) -- chunk allocation, slab switches,
     one partition taking every row (several chunks per tile), negative keys / key >> 8 wrap, filtered and unfiltered, every
-    single-column aggregate set; flag 16384 (RFX_TUNE_NO_CHUNK) is the column-pass form of the same queries."""
+    single-column aggregate set; flag 16384 (RFX_TUNE_NO_CHUNK) is the column-pass form of the same queries.  Selective filters take
+    per-partition bins when the sampled keys spread and the sorted queue otherwise ("skew"): both kernels forced on every shape
+    (bins under skew: a drain every 32 survivors)."""
     n = 700_001
     host = table(n, keys=200_000, nulls=True)
     if shape == "offset":
