@@ -64,7 +64,7 @@ WORKLOADS = {
     "c3": dict(desc="configs[2]: select sum(v) by k, k i64 uniform [0,1e6) seed 4, v f64 seed 5", rows=1_000_000_000, bytes_per_row=16, dtype="f64",
                kernel="k_chunk_scatter<2, 0> (scope + partition in one pass) + k_chunk_aggregate<512>"),
     "c3w": dict(desc="metric shape filter->group-by->sum: select sum(v) by k where a < 100000 (10 %), k/v as C3, a as C2", rows=1_000_000_000,
-                bytes_per_row=24, dtype="f64", kernel="k_chunk_scatter_sel<3, 1> (filter + scope + partition in one pass) + k_chunk_aggregate<512>"),
+                bytes_per_row=24, dtype="f64", kernel="k_chunk_scatter_bin<3, 1> (filter + scope + partition in one pass) + k_chunk_aggregate<512>"),
     "q2": dict(desc="several by: columns (H2O Q2 shape): select sum(v) by {id1, id2}, id1/id2 i64 uniform [0,100) seeds 10/11, v f64 seed 5", rows=1_000_000_000,
                bytes_per_row=24, dtype="f64", kernel="k_part_scope_hist<1, 0> x2 + k_group_dense<3, true, 1024>"),
     "q7": dict(desc="key tuples beyond the composite key (H2O Q7 shape, row-hash path): select sum(v), count by {id1..id6}; id1,id2,id4,id5 i64 uniform [0,100), "

@@ -764,7 +764,8 @@ __global__ __launch_bounds__(CK_SELT) void k_chunk_scatter_bin(const Plan P, con
             }
         }
         // ---- drain round (all 16 waves) ----
-        if (lane == 0 && (__any(m != 0) || ws < nsteps)) atomicAdd(&L.alive[round & 1], 1u);
+        const bool waiting = __any(m != 0); // all lanes vote: lane 0 alone may have placed its rows
+        if (lane == 0 && (waiting || ws < nsteps)) atomicAdd(&L.alive[round & 1], 1u);
         __syncthreads();
         const unsigned still = L.alive[round & 1];
         unsigned have = 0, inc = 0, need = 0;
@@ -1160,6 +1161,7 @@ static int launch_chunk_scatter_bin_np(rfx_ctx *c, const Plan &P, const ChunkArg
 }
 template <int NC>
 static int launch_chunk_scatter_bin(rfx_ctx *c, const Plan &P, const ChunkArgs &A) {
+    if (P.npred == 0) return launch_chunk_scatter_bin_np<NC, 0>(c, P, A);
     if (P.npred == 1) return launch_chunk_scatter_bin_np<NC, 1>(c, P, A);
     if (P.npred <= 3) return launch_chunk_scatter_bin_np<NC, 3>(c, P, A);
     return launch_chunk_scatter_bin_np<NC, RFX_MAX_PREDS>(c, P, A);
@@ -1281,7 +1283,7 @@ int rfx_chunk_scope(rfx_ctx *c, const int64_t *d_key, const rfx_pred_t *preds, i
     i64 est_rows = (i64)((double)nrows * (frac * 1.5 + 0.02));
     if (est_rows > nrows || npred == 0) est_rows = nrows;
     if (est > (unsigned long long)est_rows * 2) return RFX_ESTATE;                                    // sparse keys: the hashed path
-    const bool selective = npred > 0 && frac <= 0.4;
+    const bool selective = (npred > 0 && frac <= 0.4) || (c->flags & RFX_TUNE_CHUNK_BINS);
     // bins fill evenly when no partition takes much more than its 1/256 of the selection (sampled: the fullest bin against the mean)
     const bool spread = (double)hot <= 6.0 * ((double)ssel / CK_PARTS) + 24.0;
     const bool bins = selective && (spread || (c->flags & RFX_TUNE_CHUNK_BINS)) && !(c->flags & RFX_TUNE_CHUNK_QUEUE);
