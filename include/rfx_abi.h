@@ -35,8 +35,11 @@ enum {
     RFX_TYPE_TIME = 8,
     RFX_TYPE_TIMESTAMP = 9,
     RFX_TYPE_F64 = 10,
+    RFX_TYPE_ENUM = 20,      /* (key symbol, I64 indices) pair, or -- mmapped -- the indices with the key one page before -- core/util.h:103-105 */
     RFX_TYPE_MAPFILTER = 71, /* lazy (val, row-index) pair -- core/filter.c:29-49 */
     RFX_TYPE_MAPGROUP = 72,  /* lazy (val, group-index) pair -- core/group.c:26-46 */
+    RFX_TYPE_MAPCOMMON = 74, /* virtual column of a parted table: (one value per partition, rows per partition) -- core/vary.c:354-361 */
+    RFX_TYPE_PARTEDLIST = 77, /* + element type: LIST of one (mmapped) vector per partition -- core/rayforce.h:70-82 */
     RFX_TYPE_TABLE = 98,
     RFX_TYPE_DICT = 99,
     RFX_TYPE_UNARY = 101,

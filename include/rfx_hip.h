@@ -196,6 +196,8 @@ int rfx_hip_free(rfx_ctx_t *ctx, void *d_ptr);
 int rfx_hip_h2d(rfx_ctx_t *ctx, void *d_dst, const void *src, size_t bytes); /* (syncs) */
 int rfx_hip_d2h(rfx_ctx_t *ctx, void *dst, const void *d_src, size_t bytes); /* (syncs) */
 int rfx_hip_memset(rfx_ctx_t *ctx, void *d_dst, int byte, size_t bytes);
+/* d_dst[0..n) = value (8-byte cells): the virtual Date column of a parted table, expanded partition by partition */
+int rfx_hip_fill_i64(rfx_ctx_t *ctx, int64_t *d_dst, int64_t n, int64_t value);
 
 /* Host-to-device at link speed from ANY host memory (heap vector, mmapped column file): chunks are staged through pinned
  * buffers by worker threads while the previous chunk is in flight.  (syncs) */

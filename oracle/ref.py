@@ -21,6 +21,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 BIN = os.path.join(_HERE, "_ref", "rayforce")
 _TYPES = {np.dtype(np.int8): 1, np.dtype(np.bool_): 1, np.dtype(np.int64): 5, np.dtype(np.float64): 10}
 _DTYPES = {1: np.int8, 5: np.int64, 10: np.float64, 9: np.int64, 6: np.int64}
+LAST_STDERR = ""  # of the last run_script (a plugin loaded into the reference may trace there)
 
 
 def available() -> bool:
@@ -64,6 +65,8 @@ def run_script(text: str, threads: int | None = None, timeout: float = 600.0, cw
         p = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, cwd=cwd, stdin=subprocess.DEVNULL)
         if p.returncode != 0:
             raise RuntimeError(f"reference exited with {p.returncode}: {p.stdout[-2000:]} {p.stderr[-2000:]}")
+        global LAST_STDERR
+        LAST_STDERR = p.stderr
         return p.stdout
     finally:
         os.unlink(script)

@@ -289,17 +289,138 @@ static int transient(obj_p v, const void **dev) {
     return rc;
 }
 
+#define RFX_MAX_PROXY 128
+/* ---- parted tables (get-parted, core/vary.c:185-392) ----
+ * A parted table's columns are LISTs of one mmapped vector per partition (TYPE_PARTEDLIST + element type) plus ONE virtual
+ * column (TYPE_MAPCOMMON: a value per partition and the partition's row count; `Date`).  On the device a parted column is what
+ * the reference's PARTED_MAP loops over (core/aggr.c:183-260) laid end to end: one contiguous column, partition after partition.
+ * For the duration of one operator call such a table is seen through a VIEW: a table-shaped object of ours whose columns are
+ * proxy headers {element type, total rows} that only resident() knows how to upload (partition by partition into its slice; the
+ * virtual column is expanded on the device).  Proxies never reach the host: results are built from device data. */
+typedef struct {
+    rfx_obj_t hdr; /* type = element type (I64 for the virtual column), len = total rows */
+    obj_p src;     /* the parted LIST / the MAPCOMMON pair */
+    int kind;      /* 1: parted data column, 2: virtual (MAPCOMMON) column */
+    int8_t vtype;  /* kind 2: type of the per-partition values (DATE / I64) */
+} proxy_t;
+static proxy_t *g_px[RFX_MAX_PROXY];
+static int g_npx;
+static void *g_pxmem[3];
+static proxy_t *proxy_of(obj_p o) {
+    for (int i = 0; i < g_npx; i++)
+        if ((obj_p)g_px[i] == o) return g_px[i];
+    return NULL;
+}
+static int is_parted_table(obj_p tab) {
+    obj_p cols = RFX_AS_LIST(tab)[1];
+    for (int64_t i = 0; i < cols->len; i++) {
+        const int t = RFX_AS_LIST(cols)[i]->type;
+        if (t == RFX_TYPE_MAPCOMMON || t >= RFX_TYPE_PARTEDLIST) return 1;
+    }
+    return 0;
+}
+static void parted_view_release(void) {
+    for (int i = 0; i < g_npx; i++) free(g_px[i]);
+    g_npx = 0;
+    for (int i = 0; i < 3; i++) { free(g_pxmem[i]); g_pxmem[i] = NULL; }
+}
+/* rows of one partition's vector: an mmapped ENUM is its index vector, an in-memory one the pair (core/util.h:105) */
+static obj_p enum_indices(obj_p e) { return e->mmod == RFX_MMOD_INTERNAL ? RFX_AS_LIST(e)[1] : e; }
+static obj_p parted_view(obj_p tab) {
+    obj_p names = RFX_AS_LIST(tab)[0], cols = RFX_AS_LIST(tab)[1];
+    if (cols->len > RFX_MAX_PROXY) return NULL;
+    rfx_obj_t *fc = (rfx_obj_t *)calloc(1, sizeof(rfx_obj_t) + (size_t)cols->len * sizeof(obj_p));
+    rfx_obj_t *ft = (rfx_obj_t *)calloc(1, sizeof(rfx_obj_t) + 2 * sizeof(obj_p));
+    if (!fc || !ft) { free(fc); free(ft); return NULL; }
+    g_pxmem[0] = fc;
+    g_pxmem[1] = ft;
+    fc->type = RFX_TYPE_LIST;
+    fc->len = cols->len;
+    ft->type = RFX_TYPE_TABLE;
+    ft->len = 2;
+    RFX_AS_LIST(ft)[0] = names;
+    RFX_AS_LIST(ft)[1] = fc;
+    for (int64_t i = 0; i < cols->len; i++) {
+        obj_p c = RFX_AS_LIST(cols)[i];
+        if (c->type != RFX_TYPE_MAPCOMMON && c->type < RFX_TYPE_PARTEDLIST) { RFX_AS_LIST(fc)[i] = c; continue; }
+        proxy_t *px = (proxy_t *)calloc(1, sizeof(proxy_t));
+        if (!px) return NULL;
+        g_px[g_npx++] = px;
+        px->src = c;
+        int64_t total = 0;
+        if (c->type == RFX_TYPE_MAPCOMMON) {
+            obj_p vals = RFX_AS_LIST(c)[0], cnts = RFX_AS_LIST(c)[1];
+            px->kind = 2;
+            px->vtype = vals->type;
+            px->hdr.type = (vals->type == RFX_TYPE_DATE || vals->type == RFX_TYPE_I64) ? RFX_TYPE_I64 : RFX_TYPE_LIST; /* LIST: not usable */
+            for (int64_t j = 0; j < cnts->len; j++) total += RFX_AS_I64(cnts)[j];
+        } else {
+            px->kind = 1;
+            px->hdr.type = (int8_t)(c->type - RFX_TYPE_PARTEDLIST); /* LIST (0) for a generic parted list: not usable */
+            for (int64_t j = 0; j < c->len; j++) {
+                obj_p part = RFX_AS_LIST(c)[j];
+                if (part->type != px->hdr.type) { px->hdr.type = RFX_TYPE_LIST; break; }
+                total += (part->type == RFX_TYPE_ENUM) ? enum_indices(part)->len : part->len;
+            }
+        }
+        px->hdr.len = total;
+        RFX_AS_LIST(fc)[i] = (obj_p)px;
+    }
+    return (obj_p)ft;
+}
+/* checksum over everything a proxy's device copy is made from */
+static uint64_t proxy_sum(const proxy_t *px) {
+    uint64_t h = 0x6A09E667F3BCC908ULL;
+    if (px->kind == 2) {
+        obj_p vals = RFX_AS_LIST(px->src)[0], cnts = RFX_AS_LIST(px->src)[1];
+        h ^= payload_sum(RFX_AS_RAW(vals), (size_t)vals->len * (vals->type == RFX_TYPE_DATE ? 4 : 8));
+        return (h * 0x9E3779B97F4A7C15ULL) ^ payload_sum(RFX_AS_RAW(cnts), (size_t)cnts->len * 8);
+    }
+    for (int64_t j = 0; j < px->src->len; j++) {
+        obj_p part = RFX_AS_LIST(px->src)[j];
+        if (part->type == RFX_TYPE_ENUM) part = enum_indices(part);
+        h = ((h ^ payload_sum(RFX_AS_RAW(part), (size_t)part->len * 8)) * 0x9E3779B97F4A7C15ULL) ^ (uint64_t)part->len;
+    }
+    return h;
+}
+static int proxy_upload(const proxy_t *px, void *dev) {
+    int64_t off = 0;
+    if (px->kind == 2) {
+        obj_p vals = RFX_AS_LIST(px->src)[0], cnts = RFX_AS_LIST(px->src)[1];
+        for (int64_t j = 0; j < cnts->len; j++) {
+            const int64_t n = RFX_AS_I64(cnts)[j];
+            const int64_t v = vals->type == RFX_TYPE_DATE ? (int64_t)((const int32_t *)RFX_AS_RAW(vals))[j] : RFX_AS_I64(vals)[j];
+            int rc = rfx_hip_fill_i64(g_ctx, (int64_t *)dev + off, n, v);
+            if (rc != RFX_OK) return rc;
+            off += n;
+        }
+        return RFX_OK;
+    }
+    for (int64_t j = 0; j < px->src->len; j++) { /* every partition's column file goes straight into its slice */
+        obj_p part = RFX_AS_LIST(px->src)[j];
+        if (part->type == RFX_TYPE_ENUM) part = enum_indices(part);
+        if (part->len) {
+            int rc = rfx_hip_h2d_pipelined(g_ctx, (int64_t *)dev + off, RFX_AS_RAW(part), (size_t)part->len * 8);
+            if (rc != RFX_OK) return rc;
+        }
+        off += part->len;
+    }
+    return RFX_OK;
+}
+
 /* device pointer of a host vector's payload (uploading it if needed) */
 static int resident(obj_p col, int pin, const void **dev) {
+    const proxy_t *px = g_npx ? proxy_of(col) : NULL;
     const int esz = (col->type == RFX_TYPE_B8) ? 1 : 8;
-    const void *host = RFX_AS_RAW(col);
+    const void *host = px ? (const void *)px->src : RFX_AS_RAW(col); /* a parted column is known by its LIST object */
     const size_t bytes = (size_t)col->len * esz;
+    const int ktype = px ? 64 + col->type : col->type;
     int have_sum = 0;
     uint64_t sum = 0;
     for (int i = 0; i < g_nres; i++)
-        if (g_res[i].host == host && g_res[i].len == col->len && g_res[i].type == col->type) {
+        if (g_res[i].host == host && g_res[i].len == col->len && g_res[i].type == ktype) {
             if (!g_res[i].pinned) { /* unpinned: prove the copy current */
-                sum = payload_sum(host, bytes);
+                sum = px ? proxy_sum(px) : payload_sum(host, bytes);
                 have_sum = 1;
             }
             if (g_res[i].pinned || g_res[i].sum == sum) {
@@ -312,7 +433,7 @@ static int resident(obj_p col, int pin, const void **dev) {
             }
             /* stale: the payload changed under the same address -- refresh the device copy in place */
             g_stat[ST_CACHE_STALE]++;
-            int rc = rfx_hip_h2d_pipelined(g_ctx, g_res[i].dev, host, bytes);
+            int rc = px ? proxy_upload(px, g_res[i].dev) : rfx_hip_h2d_pipelined(g_ctx, g_res[i].dev, host, bytes);
             if (rc != RFX_OK) { res_free(i); return rc; }
             g_stat[ST_UPLOADS]++;
             g_res[i].sum = sum;
@@ -332,15 +453,15 @@ static int resident(obj_p col, int pin, const void **dev) {
     void *d = NULL;
     int rc = rfx_hip_malloc(g_ctx, &d, bytes ? bytes : 8);
     if (rc != RFX_OK) return rc;
-    rc = rfx_hip_h2d_pipelined(g_ctx, d, host, bytes); /* heap vector or mmapped column file alike: staged through pinned buffers */
+    rc = px ? proxy_upload(px, d) : rfx_hip_h2d_pipelined(g_ctx, d, host, bytes); /* heap vector or mmapped column file alike: staged through pinned buffers */
     if (rc != RFX_OK) { rfx_hip_free(g_ctx, d); return rc; }
     g_stat[ST_UPLOADS]++;
-    if (!have_sum) sum = payload_sum(host, bytes);
+    if (!have_sum) sum = px ? proxy_sum(px) : payload_sum(host, bytes);
     if (g_nres == g_capres) {
         g_capres = g_capres ? g_capres * 2 : 32;
         g_res = (resident_t *)realloc(g_res, sizeof(resident_t) * (size_t)g_capres);
     }
-    g_res[g_nres++] = (resident_t){host, col->len, col->type, sum, d, bytes, pin, ++g_tick, g_epoch};
+    g_res[g_nres++] = (resident_t){host, col->len, ktype, sum, d, bytes, pin, ++g_tick, g_epoch};
     g_res_bytes += bytes;
     *dev = d;
     return RFX_OK;
@@ -421,6 +542,7 @@ static int expr_operand(obj_p tab, obj_p e, const void **d, int *ctype) {
     *ctype = ot;
     return 0;
 }
+static int g_where_virtual, g_where_data; /* comparisons of the where: in flight that read the virtual column / data columns of a parted table */
 static int plan_cmp(obj_p tab, obj_p e, rfx_pred_t *p) {
     if (e->type != RFX_TYPE_LIST || e->len != 3) return -1;
     int f = fn_id(RFX_AS_LIST(e)[0]);
@@ -430,6 +552,7 @@ static int plan_cmp(obj_p tab, obj_p e, rfx_pred_t *p) {
     p->op = f - F_EQ; /* F_EQ..F_GE are in RFX_EQ..RFX_GE order */
     const void *d;
     int64_t llen = -1;
+    int lvirt = 0, ldate = 0;
     if (l->type == RFX_TYPE_LIST) {
         int ct = RFX_I64, rc0 = expr_operand(tab, l, &d, &ct);
         if (rc0) return rc0;
@@ -441,13 +564,20 @@ static int plan_cmp(obj_p tab, obj_p e, rfx_pred_t *p) {
         p->col_type = col_ctype(lc);
         if (resident(lc, 0, &d) != RFX_OK) return -2;
         llen = lc->len;
+        const proxy_t *px = g_npx ? proxy_of(lc) : NULL;
+        lvirt = px && px->kind == 2;
+        ldate = lvirt && px->vtype == RFX_TYPE_DATE;
     }
+    if (lvirt) g_where_virtual++;
+    else g_where_data++;
     p->d_col = d;
     if (r->type == -RFX_TYPE_I64) { p->rhs_type = RFX_I64; p->rhs_i = r->i64; }
+    else if (r->type == -RFX_TYPE_DATE && ldate) { p->rhs_type = RFX_I64; p->rhs_i = (int64_t)r->i32; } /* (== Date 2024.01.03): partition pruning, core/cmp.c:341-358 */
     else if (r->type == -RFX_TYPE_F64) { p->rhs_type = RFX_F64; p->rhs_f = r->f64; }
     else if (r->type == -RFX_TYPE_SYMBOL) {
         obj_p rc = table_col(tab, r->i64);
         if (!rc || !col_ctype(rc) || (llen >= 0 && rc->len != llen)) return -1;
+        g_where_data++;
         if (resident(rc, 0, &d) != RFX_OK) return -2;
         p->d_rhs_col = d;
         p->rhs_type = col_ctype(rc);
@@ -547,6 +677,8 @@ static obj_p one_row(const rfx_value_t *v) {
 
 static obj_p delegate_select(obj_p dict, const char *why) {
     g_last_gpu = 0;
+    snprintf(g_err, sizeof(g_err), "rfx_select: handed to the host (%s)", why); /* rfx_ops_last_error(): why the last query was delegated */
+    if (getenv("RFX_TRACE")) fprintf(stderr, "[rfx] select delegated: %s\n", why);
     if (H.bound == 1 && H.f[F_SELECT]) return ((rfx_unary_f)H.f[F_SELECT])(dict);
     char b[300];
     snprintf(b, sizeof(b), "rfx_select: query shape not covered by the MI355X path (%s) and no host ray_select to delegate to", why);
@@ -601,8 +733,10 @@ static obj_p select_impl(obj_p dict) {
     obj_p from = dict_get(dict, "from");
     if (!from) return fail("'select' expects 'from' param"); /* core/query.c:281 */
     if (dict_get(dict, "take")) return delegate_select(dict, "take:");
-    obj_p tab = H.eval(from);
-    if (!tab || tab->type == RFX_TYPE_ERR) return tab;
+    obj_p host_tab = H.eval(from);
+    if (!host_tab || host_tab->type == RFX_TYPE_ERR) return host_tab;
+    obj_p tab = host_tab; /* the table the plan reads: host_tab itself, or the view of a parted table */
+    int parted = 0;
     obj_p res = NULL;
     const char *why = NULL;
     void *tmp[RFX_MAX_AGGS * (2 + 2 * RFX_MAX_XNODES) + 2 * RFX_MAX_KEYS + 6]; /* device scratch of this query (gathered columns, bucket / composite keys): freed at `done` */
@@ -612,18 +746,33 @@ static obj_p select_impl(obj_p dict) {
     int64_t s_from = H.intern("from", 4), s_where = H.intern("where", 5), s_by = H.intern("by", 2);
     if (tab->type != RFX_TYPE_TABLE) { why = "from: is not a table"; goto out; }
     if (ensure_ctx() != RFX_OK) { res = fail_hip("no usable MI355X"); goto done; }
+    if (is_parted_table(host_tab)) {
+        tab = parted_view(host_tab);
+        if (!tab) { parted_view_release(); tab = host_tab; why = "parted table: view"; goto out; }
+        parted = 1;
+    }
     {
         obj_p tcols = RFX_AS_LIST(tab)[1];
         int64_t nrows = tcols->len ? RFX_AS_LIST(tcols)[0]->len : 0;
         wplan_t wp;
         int flat = 1;
         int64_t *d_ids = NULL, nsel = 0;
+        g_where_virtual = g_where_data = 0;
         int rc = plan_where(tab, where, &wp);
         if (rc == -2) { res = fail_hip("column upload"); goto done; }
         if (rc) { /* not one comparison / one flat and|or: a nested tree, evaluated through masks */
             flat = 0;
             wp.npred = 0;
             wp.logic = RFX_AND;
+        }
+        if (parted) {
+            /* What the reference answers correctly over a parted table, and so what is answered here: aggregates, over everything or
+             * grouped by the virtual column, filtered by the virtual column (partition pruning) or -- ungrouped -- by data columns.
+             * A filter mixing both kinds, and a data-column filter under by:, come out wrong there (DESIGN.md "reference defects"):
+             * left to the host so that this entry point never answers differently. */
+            if (!flat) { why = "parted table: where: is not a flat and / or of comparisons"; goto out; }
+            if (g_where_virtual && g_where_data) { why = "parted table: where: mixes the virtual column with data columns"; goto out; }
+            if (by && g_where_data) { why = "parted table: by: under a data-column filter"; goto out; }
         }
         /* output mappings */
         rfx_agg_t aggs[RFX_MAX_AGGS];
@@ -678,6 +827,8 @@ static obj_p select_impl(obj_p dict) {
         int rowhash = 0, nagg_run = 0;            /* row-hash path: aggregates [nagg, nagg_run) are the (min, max) proof pairs of the key columns */
         int64_t krepl[RFX_MAX_KEYS] = {0};         /* stand-in value of a null key inside its proof pair */
         int khasnull[RFX_MAX_KEYS] = {0};
+        int8_t key_out_type = RFX_TYPE_I64; /* one key: type of the result's key column */
+        obj_p kenum = NULL;                 /* one key, an ENUM column */
         if (by) {
             if (by->type == -RFX_TYPE_SYMBOL) {
                 knames[0] = by->i64;
@@ -701,11 +852,24 @@ static obj_p select_impl(obj_p dict) {
                 }
             } else { why = "by: is neither a column nor a dict of columns"; goto out; }
             for (int i = 0; i < nkeys; i++) {
+                if (parted) { /* only the virtual column groups a parted table in the reference (INDEX_TYPE_PARTEDCOMMON, core/index.c:2199-2222) */
+                    const proxy_t *px = kcs[i] ? proxy_of(kcs[i]) : NULL;
+                    if (nkeys != 1 || !px || px->kind != 2 || kcs[i]->type != RFX_TYPE_I64) { why = "parted table: by: is not the virtual column"; goto out; }
+                    key_out_type = px->vtype;
+                } else if (kcs[i] && kcs[i]->type == RFX_TYPE_ENUM && nkeys == 1 && !kxbar[i]) {
+                    /* an enumerated symbol column groups on its indices (index_group_i64(ENUM_VAL(val)), core/index.c:2190-2191); the
+                     * result's key column is decoded through the enum's domain (aggr_first, core/aggr.c:515-546) */
+                    kenum = kcs[i];
+                    if (resident(enum_indices(kcs[i]), 0, &dks[i]) != RFX_OK) { res = fail_hip("column upload"); goto done; }
+                    key_out_type = RFX_TYPE_SYMBOL;
+                    continue;
+                }
                 /* index_group's 8-byte integer arms: I64 / SYMBOL / TIMESTAMP group on the raw i64 (core/index.c:2183-2186) */
                 if (!kcs[i] || !(kcs[i]->type == RFX_TYPE_I64 || kcs[i]->type == RFX_TYPE_SYMBOL || kcs[i]->type == RFX_TYPE_TIMESTAMP)) {
                     why = "by: key is not an 8-byte integer column";
                     goto out;
                 }
+                if (nkeys == 1 && !parted) key_out_type = kcs[i]->type;
                 if (resident(kcs[i], 0, &dks[i]) != RFX_OK) { res = fail_hip("column upload"); goto done; }
                 if (kxbar[i] > 0) { /* ray_xbar, core/math.c:1635: the reference evaluates the bucket column before grouping, so do we */
                     if (kcs[i]->type == RFX_TYPE_SYMBOL) { why = "xbar over a symbol column"; goto out; }
@@ -724,6 +888,7 @@ static obj_p select_impl(obj_p dict) {
         }
         if (!by && nagg == 0) {
             /* projection: filter_collect of every column (core/filter.c:51-165): where -> ids -> gather */
+            if (parted) { why = "parted table: projection"; goto out; } /* the reference keeps such a result lazy (filter maps over the partitions) */
             if (!where) { res = H.clone(tab); g_last_gpu = 1; goto done; }
             for (int64_t i = 0; i < tcols->len; i++)
                 if (!col_ctype(RFX_AS_LIST(tcols)[i])) { why = "projection of a non-8-byte column"; goto out; }
@@ -916,9 +1081,41 @@ static obj_p select_impl(obj_p dict) {
                     void *ptrs[RFX_MAX_AGGS];
                     for (int a = 0; a < nagg_run; a++) ptrs[a] = (int64_t *)dout + (size_t)(a + 1) * groups;
                     ok = (dense ? rfx_hip_group_emit(g_ctx, aggs, &gt, (int64_t *)dout, NULL, ptrs) : rfx_hip_hash_emit(g_ctx, aggs, &ht, (int64_t *)dout, NULL, ptrs)) == RFX_OK;
-                    if (nkeys == 1) {
-                        okeys = H.vector(kcs[0]->type, groups);
+                    if (nkeys == 1 && key_out_type == RFX_TYPE_DATE) { /* the virtual Date column: 4-byte days */
+                        okeys = H.vector(RFX_TYPE_DATE, groups);
+                        int64_t *k8 = (int64_t *)malloc((size_t)groups * 8);
+                        ok = ok && k8 && rfx_hip_d2h(g_ctx, k8, dout, (size_t)groups * 8) == RFX_OK;
+                        for (int64_t g = 0; g < groups && ok; g++) ((int32_t *)RFX_AS_RAW(okeys))[g] = (int32_t)k8[g];
+                        free(k8);
+                    } else if (nkeys == 1) {
+                        okeys = H.vector(key_out_type, groups);
                         if (ok) ok = rfx_hip_d2h(g_ctx, RFX_AS_RAW(okeys), dout, (size_t)groups * 8) == RFX_OK;
+                        if (ok && kenum) { /* indices -> symbols of the enum's domain (the global its key names) */
+                            int64_t key_id;
+                            if (kenum->mmod == RFX_MMOD_INTERNAL) key_id = RFX_AS_LIST(kenum)[0]->i64;
+                            else { /* mmapped: the key's characters sit one page before the indices (core/util.h:103-104) */
+                                const char *ks = (const char *)kenum - 4096 + sizeof(rfx_obj_t); /* NUL-terminated, core/binary.c:135-137 */
+                                key_id = H.intern(ks, (int64_t)strnlen(ks, 4096 - sizeof(rfx_obj_t)));
+                            }
+                            obj_p ka = H.i64(key_id);
+                            ka->type = -RFX_TYPE_SYMBOL;
+                            obj_p dom = H.eval(ka);
+                            H.drop(ka);
+                            int good = dom && dom->type == RFX_TYPE_SYMBOL;
+                            int64_t *kk = RFX_AS_I64(okeys);
+                            for (int64_t g = 0; g < groups && good; g++) {
+                                if (kk[g] < 0 || kk[g] >= dom->len) good = 0;
+                                else kk[g] = RFX_AS_I64(dom)[kk[g]];
+                            }
+                            if (dom) H.drop(dom);
+                            if (!good) {
+                                if (dout) rfx_hip_free(g_ctx, dout);
+                                rfx_hip_free(g_ctx, store);
+                                H.drop(okeys);
+                                why = "by: enum column whose domain cannot be resolved";
+                                goto out;
+                            }
+                        }
                     } else if (rowhash) {
                         /* proof: min == max of every key column in every group; the maxima are the key columns (nulls restored) */
                         int64_t *mn = (int64_t *)malloc((size_t)groups * 8);
@@ -968,7 +1165,7 @@ static obj_p select_impl(obj_p dict) {
                     goto done;
                 }
             }
-            if (nkeys == 1) okcols[0] = okeys ? okeys : H.vector(kcs[0]->type, 0);
+            if (nkeys == 1) okcols[0] = okeys ? okeys : H.vector(key_out_type, 0);
             obj_p rk = H.vector(RFX_TYPE_SYMBOL, nagg + nkeys), rv = H.vector(RFX_TYPE_LIST, nagg + nkeys);
             for (int i = 0; i < nkeys; i++) {
                 RFX_AS_I64(rk)[i] = knames[i];
@@ -1002,7 +1199,8 @@ out:
 done:
     for (int i = 0; i < ntmp; i++) rfx_hip_free(g_ctx, tmp[i]);
     qtmp_release();
-    H.drop(tab);
+    if (parted) parted_view_release();
+    H.drop(host_tab);
     return res;
 }
 rfx_obj_p rfx_select(rfx_obj_p dict) {

@@ -73,3 +73,19 @@ extern "C" int rfx_hip_update_group(rfx_ctx_t *c, void *d_col, const int64_t *d_
     RFX_HIP_CHECK(hipGetLastError());
     return RFX_OK;
 }
+
+// ---- d_dst[0..n) = value: the virtual column of a parted table (one value per partition, core/vary.c:354-361) ----
+__global__ __launch_bounds__(RFX_BLOCK) void k_fill_i64(i64 *p, i64 n, i64 val) {
+    for (i64 i = blockIdx.x * (i64)RFX_BLOCK + threadIdx.x; i < n; i += (i64)gridDim.x * RFX_BLOCK) p[i] = val;
+}
+extern "C" int rfx_hip_fill_i64(rfx_ctx_t *ctx, int64_t *d_dst, int64_t n, int64_t value) {
+    rfx_ctx *c = (rfx_ctx *)ctx;
+    if (!c || n < 0 || (n > 0 && !d_dst)) return RFX_EINVAL;
+    if (n == 0) return RFX_OK;
+    i64 blocks = (n + RFX_BLOCK - 1) / RFX_BLOCK;
+    int grid = rfx_grid(c) * 4;
+    if (blocks < grid) grid = (int)blocks;
+    hipLaunchKernelGGL(k_fill_i64, dim3(grid), dim3(RFX_BLOCK), 0, c->stream, (i64 *)d_dst, (i64)n, (i64)value);
+    RFX_HIP_CHECK(hipGetLastError());
+    return RFX_OK;
+}

@@ -156,3 +156,81 @@ def test_plugin_inside_the_real_reference(built):
     st = res["stats"]
     assert int(st[0]) == len(QUERIES) + 2 and int(st[1]) == 1, st
     assert int(st[2]) == 4 and int(st[3]) == 0, st
+
+
+PARTED = [  # (name, query over the parted table p, outputs, answered on the device?)
+    ("p1", "{s: (sum v) c: (count a) mn: (min v) mx: (max a) av: (avg v) f: (first a) from: p}", ["s", "c", "mn", "mx", "av", "f"], True),
+    ("p2", "{s: (sum v) c: (count a) m: (max a) f: (first v) from: p by: Date}", ["Date", "s", "c", "m", "f"], True),
+    ("p3", "{s: (sum v) m: (max a) f: (first v) from: p where: (== Date 2024.01.02)}", ["s", "m", "f"], True),
+    ("p4", "{s: (sum v) c: (count a) from: p where: (and (>= Date 2024.01.02) (<= Date 2024.01.03)) by: Date}", ["Date", "s", "c"], True),
+    ("p5", "{s: (sum v) c: (count a) from: p where: (< a 400000)}", ["s", "c"], True),
+    ("p6", "{s: (sum v) mx: (max k) from: p where: (and (< a 400000) (> v 0.25))}", ["s", "mx"], True),
+    ("p7", "{s: (sum v) from: p where: (or (== Date 2024.01.01) (> Date 2024.01.03))}", ["s"], True),
+    # handed back: shapes the reference itself answers wrongly (DESIGN.md "reference defects") -- identical answers either way
+    ("p8", "{s: (sum v) from: p where: (< a 400000) by: Date}", ["Date", "s"], False),
+    ("p9", "{c: (count a) from: p where: (and (== Date 2024.01.02) (< a 500000))}", ["c"], False),
+]
+ENUMS = [
+    ("e1", "{c: (count a) sm: (sum v) from: u by: s}", ["c", "sm"], True),        # mmapped ENUM column of a splayed table
+    ("e2", "{m: (max a) from: u where: (< a 500000) by: s}", ["m"], True),
+    ("e3", "{c: (sum a) from: w by: s}", ["c"], True),                             # in-memory (enum 'sym ...) pair
+]
+
+
+@pytest.mark.skipif(not ref.available(), reason="oracle/_ref/rayforce not built (needs /root/reference at build time)")
+def test_parted_and_enum_columns_inside_the_real_reference(built, tmp_path):
+    """SURVEY 8f-2 at the operator boundary: a `get-parted` table (TYPE_PARTED* columns + the virtual MAPCOMMON Date, core/vary.c:185-392)
+    and ENUM key columns (core/util.h:103-105) handed to rfx_select by the real reference, in ONE process beside ray_select: the
+    families of the reference's own tests/parted.c (global aggregates, by: Date, Date filters = partition pruning, data-column
+    filters) answered on the device; the two shapes the reference answers wrongly are handed back (rfx_stats asserts who answered)."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    root = str(tmp_path / "db") + "/"
+    dates = ["2024.01.03", "2024.01.01", "2024.02.29", "2024.01.02"]  # directory order is not date order
+    lens = [70_001, 50_000, 33_333, 90_007]
+    for i, (d, n) in enumerate(zip(dates, lens)):  # one reference process per partition
+        with ref.Session() as s:
+            s.table("t", {"k": rfo.gen_i64(n, 40 + i, 500), "a": rfo.gen_i64(n, 50 + i, 1_000_000), "v": rfo.gen_f64(n, 60 + i)})
+            s.eval(f'(set "{root}{d}/tab/" t)')
+            s.run(threads=8)
+    n = 120_011
+    with ref.Session() as s:
+        s.eval(f"(set p (get-parted \"{root}\" 'tab))")
+        s.eval(f'(set gsel (loadfn "{LIB}" "rfx_select" 1))')
+        s.put("a", rfo.gen_i64(n, 71, 1_000_000))
+        s.put("v", rfo.gen_f64(n, 72))
+        s.put("ki", rfo.gen_i64(n, 73, 9))
+        s.eval("(set sy (at ['aa 'bb 'cc 'dd 'ee 'ff 'gg 'hh 'ii] ki))")
+        s.eval("(set t2 (table [s a v] (list sy a v)))")
+        s.eval(f'(set-splayed "{root}spl/t2/" t2)')
+        s.eval(f'(set u (get-splayed "{root}spl/t2/"))')
+        s.eval("(set w (table [s a] (list (enum 'sym sy) a)))")
+        for name, q, outs, _ in PARTED + ENUMS:
+            s.eval(f"(set g_{name} (gsel {q}))")
+            s.eval(f"(set r_{name} (select {q}))")
+            for o in outs:
+                cast = "(as 'I64 {})" if o == "Date" else "{}"
+                s.out(f"g_{name}_{o}", cast.format(f"(at g_{name} '{o})"))
+                s.out(f"r_{name}_{o}", cast.format(f"(at r_{name} '{o})"))
+            if name[0] == "e" and "by:" in q:  # key columns are SYMBOL vectors decoded from the enum's domain: compared in the host
+                s.out(f"eq_{name}", f"(as 'I64 (== (at g_{name} 's) (at r_{name} 's)))")
+                s.out(f"ty_{name}", f"(as 'I64 (enlist (== (type (at g_{name} 's)) (type (at r_{name} 's)))))")
+        s.eval(f'(set gstat (loadfn "{LIB}" "rfx_stats" 1))')
+        s.out("stats", "(gstat 0)")
+        res = s.run(threads=8)
+    for name, q, outs, _ in PARTED + ENUMS:
+        for o in outs:
+            g, r = res[f"g_{name}_{o}"], res[f"r_{name}_{o}"]
+            assert g.dtype == r.dtype and g.shape == r.shape, (name, o, g.shape, r.shape)
+            if g.dtype == np.float64:
+                assert np.allclose(g, r, rtol=1e-9, atol=0), (name, o)
+            else:
+                assert np.array_equal(g, r), (name, o)
+        if f"eq_{name}" in res:
+            assert res[f"eq_{name}"].all() and res[f"ty_{name}"].all(), name
+    st = res["stats"]
+    on_gpu = sum(1 for *_, gpu in PARTED + ENUMS if gpu)
+    print(ref.LAST_STDERR)  # RFX_TRACE=1: why a query was handed back
+    assert int(st[0]) == on_gpu and int(st[1]) == len(PARTED + ENUMS) - on_gpu, st
+    assert len(res["g_p2_Date"]) == 4 and len(res["g_p4_Date"]) == 2
