@@ -54,6 +54,29 @@ __device__ __forceinline__ i64 hash_slot(u64 *keys, i64 capacity, u64 key) {
     return -1; // table (locally) full
 }
 
+// the same, counting the slots this call claimed (the device-wide kernel stops a launch once the table is 3/4 full: long before
+// probe runs reach RFX_HASH_MAX_PROBES, which is what made an undersized first attempt as slow as the final one)
+__device__ __forceinline__ i64 hash_slot_ins(u64 *keys, i64 capacity, u64 key, unsigned &inserted) {
+    if ((i64)key == RFX_NULL_I64_D) return capacity;
+    const u64 mask = (u64)capacity - 1;
+    u64 s = rfx_hash_index_u64(RFX_U64_HASH_SEED, key) & mask;
+    const i64 bound = capacity < RFX_HASH_MAX_PROBES ? capacity : RFX_HASH_MAX_PROBES;
+    for (i64 probe = 0; probe < bound; probe++) {
+        u64 k = keys[s];
+        if (k == key) return (i64)s;
+        if ((i64)k == RFX_NULL_I64_D) {
+            u64 old = atomicCAS((unsigned long long *)&keys[s], (unsigned long long)RFX_NULL_I64_D, (unsigned long long)key);
+            if ((i64)old == RFX_NULL_I64_D) {
+                inserted++;
+                return (i64)s;
+            }
+            if (old == key) return (i64)s;
+        }
+        s = (s + 1) & mask;
+    }
+    return -1;
+}
+
 // identity element of an accumulator cell
 __device__ __host__ __forceinline__ u64 acc_identity(int kind, int f64) {
     (void)f64;

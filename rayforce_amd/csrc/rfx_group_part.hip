@@ -1316,8 +1316,51 @@ int rfx_group_part_accumulate(rfx_ctx *c, const Plan &P, int key_idx, const rfx_
 }
 
 // Sparse-key form.  RFX_ESTATE: not applicable (tiny input, too many value planes) -- the caller runs the direct kernel.
+// How many distinct keys?  2^15 strided sample keys go into a 2^18-slot scratch table; with s samples of D equally likely keys
+// about s^2 / 2D of them find their key already there (birthday), so D ~ s^2 / (2 x duplicates): 1e6 keys -> ~540 duplicates,
+// 1e8 -> ~5.  Clustered or filtered inputs make the estimate too HIGH, which only sends the query to the device-wide table.
+#define DSAMP_SLOTS (1 << 18)
+__global__ __launch_bounds__(RFX_BLOCK) void k_distinct_sample(const u64 *__restrict__ keys, i64 stride, i64 nsamp, u64 *__restrict__ table,
+                                                              unsigned *__restrict__ dups) {
+    for (i64 i = blockIdx.x * (i64)RFX_BLOCK + threadIdx.x; i < nsamp; i += (i64)gridDim.x * RFX_BLOCK) {
+        const u64 k = keys[i * stride];
+        if ((i64)k == RFX_NULL_I64_D) continue;
+        u64 s = rfx_hash_index_u64(RFX_U64_HASH_SEED, k) & (DSAMP_SLOTS - 1);
+        for (int probe = 0; probe < 64; probe++) {
+            const u64 old = atomicCAS((unsigned long long *)&table[s], (unsigned long long)RFX_NULL_I64_D, (unsigned long long)k);
+            if ((i64)old == RFX_NULL_I64_D) break;
+            if (old == k) { atomicAdd(dups, 1u); break; }
+            s = (s + 1) & (DSAMP_SLOTS - 1);
+        }
+    }
+}
+static int estimate_distinct(rfx_ctx *c, const u64 *d_key, i64 nrows, double *est) {
+    const i64 nsamp = nrows < (1 << 15) ? nrows : (1 << 15);
+    int rc = rfx_ws_reserve(c, (size_t)DSAMP_SLOTS * 8 + 512);
+    if (rc != RFX_OK) return rc;
+    u64 *table = (u64 *)((char *)c->d_ws + 512); // the first bytes of the workspace hold the caller's overflow flag
+    unsigned *dups = (unsigned *)((char *)c->d_ws + 256);
+    if ((rc = rfx_fill_u64(c, table, DSAMP_SLOTS, (u64)RFX_NULL_I64_D)) != RFX_OK) return rc;
+    RFX_HIP_CHECK(hipMemsetAsync(dups, 0, 4, c->stream));
+    hipLaunchKernelGGL(k_distinct_sample, dim3(32), dim3(RFX_BLOCK), 0, c->stream, d_key, nrows / nsamp, nsamp, table, dups);
+    RFX_HIP_CHECK(hipGetLastError());
+    unsigned *h = (unsigned *)c->h_pin;
+    RFX_HIP_CHECK(hipMemcpyAsync(h, dups, 4, hipMemcpyDeviceToHost, c->stream));
+    RFX_HIP_CHECK(hipStreamSynchronize(c->stream));
+    *est = (double)nsamp * (double)nsamp / (2.0 * ((double)h[0] + 0.5));
+    return RFX_OK;
+}
+
 int rfx_group_part_hash_accumulate(rfx_ctx *c, const Plan &P0, int key_idx, const HashArgs &H, int *d_overflow) {
     if (P0.nrows >= (1LL << 32) || P0.nrows < (1 << 16) || (c->flags & RFX_TUNE_NO_PARTITION)) return RFX_ESTATE;
+    {
+        // 256 partitions x one CU's LDS hold a few thousand keys each: beyond ~4 M distinct keys nearly every record overflows its
+        // partition's table into the device-wide one (1e8 keys: 820 ms against 30) -- those go to the device-wide table directly
+        double est = 0;
+        const int rc = estimate_distinct(c, (const u64 *)P0.cols[key_idx], P0.nrows, &est);
+        if (rc != RFX_OK) return rc;
+        if (est > 4.0e6) return RFX_ESTATE;
+    }
     Plan P = P0;
     if (P.nx > 0) { // expression aggregates: the records carry plain values
         if (P.ncols + P.nx > RFX_MAX_COLS) return RFX_ESTATE;

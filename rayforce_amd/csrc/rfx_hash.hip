@@ -33,6 +33,7 @@ __global__ __launch_bounds__(RFX_BLOCK) void k_group_hash(const Plan P, const Ha
     PredSet<RFX_MAX_PREDS> S;
     predset_load<RFX_MAX_PREDS>(P, S);
     const i64 ntiles = (P.nrows + TILE - 1) / TILE;
+    unsigned pending = 0;
     for (i64 t = blockIdx.x; t < ntiles; t += gridDim.x) {
         if (*(volatile int *)overflow) return; // another workgroup has found the table full: the caller will grow it and retry
         const i64 base = t * TILE + tid * 2;
@@ -47,21 +48,32 @@ __global__ __launch_bounds__(RFX_BLOCK) void k_group_hash(const Plan P, const Ha
             for (int c = 0; c < NC; c++) v[c][e] = in ? P.cols[c][row] : 0ULL;
         }
         const unsigned m = eval_preds<NC, E, RFX_MAX_PREDS>(S, v, valid);
-        if (m == 0) continue;
+        if (__ballot(m != 0) == 0) continue; // wave-uniform: the slot count below is reduced across the wave
         u64 key[E];
         sel_col<NC, E>(key, v, H.key_idx);
         i64 slot[E];
+        unsigned fresh = 0;
 #pragma unroll
         for (int e = 0; e < E; e++) {
             slot[e] = -1;
             if (!((m >> e) & 1u)) continue;
-            slot[e] = hash_slot(H.keys, H.capacity, key[e]);
+            slot[e] = hash_slot_ins(H.keys, H.capacity, key[e], fresh);
             if (slot[e] < 0) {
                 atomicExch(overflow, 1);
                 continue;
             }
             const u64 row = (u64)(P.row0 + base + (i64)(e >> 1) * JSTRIDE + (e & 1));
             if (row < H.first[slot[e]]) atomicMin((unsigned long long *)&H.first[slot[e]], (unsigned long long)row);
+        }
+        // load factor: one counter update per wave and tile that claimed slots; beyond 3/4 the launch is abandoned (grow and retry)
+        for (int sft = 32; sft >= 1; sft >>= 1) fresh += __shfl_xor(fresh, sft, 64);
+        pending += fresh; // wave-uniform; pushed to the one global counter in batches (a single address takes ~10 M atomics/s)
+        if (pending >= 4096u || (pending && t + gridDim.x >= ntiles)) {
+            if ((tid & 63) == 0) {
+                const unsigned long long used = atomicAdd((unsigned long long *)(overflow + 2), (unsigned long long)pending) + pending;
+                if (used * 4 > (unsigned long long)H.capacity * 3) atomicExch(overflow, 1);
+            }
+            pending = 0;
         }
         for (int a = 0; a < H.nagg; a++) {
             const PlanAgg ag = P.aggs[a];
@@ -190,10 +202,10 @@ extern "C" int rfx_hip_group_hash_accumulate(rfx_ctx_t *c, const int64_t *d_key,
         H.acc[a] = (u64 *)t->d_acc[a];
         H.cnt[a] = (u64 *)t->d_cnt[a];
     }
-    rc = rfx_ws_reserve(c, 256);
+    rc = rfx_ws_reserve(c, ((size_t)1 << 21) + 512); // the flag block + the distinct-count sample's table (rfx_group_part.hip): reserved once, the flag must not move
     if (rc != RFX_OK) return rc;
     int *flag = (int *)c->d_ws;
-    RFX_HIP_CHECK(hipMemsetAsync(flag, 0, 4, c->stream));
+    RFX_HIP_CHECK(hipMemsetAsync(flag, 0, 16, c->stream)); // [0] full, [2..3] slots claimed by this launch
     // large inputs: partition by hash, aggregate every partition in an LDS table, merge once (rfx_group_part.hip)
     rc = rfx_group_part_hash_accumulate(c, P, key_idx, H, flag);
     if (rc == RFX_OK) return read_overflow(c, flag, "group_hash_accumulate");

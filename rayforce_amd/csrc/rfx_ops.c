@@ -1071,7 +1071,7 @@ static obj_p select_impl(obj_p dict) {
                          rfx_hip_hash_rank(g_ctx, &ht, nrows, &groups) == RFX_OK;
                     if (!ok && arc == RFX_ELIMIT && cap < cap_max) { /* table full: grow and run again */
                         rfx_hip_free(g_ctx, store);
-                        cap = (cap << 4) < cap_max ? (cap << 4) : cap_max;
+                        cap = cap_max; /* the launch gave up at 3/4 load, early: take the reference's size (2 x rows) */
                         goto grow;
                     }
                 }

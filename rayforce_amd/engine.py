@@ -652,7 +652,7 @@ class Engine:
         return t, store, layout
 
     def group_by(self, key, aggs, where=None, table=None, total_rows: Optional[int] = None, row0: int = 0, _collective=None,
-                 order: str = "first", _cap_hint: int = 0):
+                 order: str = "first", _cap_hint: int = 0, _probe_first: Optional[torch.Tensor] = None):
         """``select {aggs} from t [where p] by key`` -> dict(keys=, first=, results=[...], groups=n) of device tensors.
 
         Group order is first occurrence (`order="radix"`: for key tuples that take the row-hash path, the order of the
@@ -693,7 +693,8 @@ class Engine:
         if len(chunks) > 1:  # more outputs than one table set carries: several passes (same groups, same order)
             r = None
             for ch in chunks:  # (a later launch starts from the hashed-table capacity the first one ended with: same groups)
-                part = self.group_by(key, ch, where, table, total_rows, row0, _collective, order, r.get("cap", 0) if r else 0)
+                part = self.group_by(key, ch, where, table, total_rows, row0, _collective, order, r.get("cap", 0) if r else 0,
+                                     _probe_first if r is None else None)
                 if r is None:
                     r = part
                 else:
@@ -787,7 +788,7 @@ class Engine:
                 if cap >= cap_max:
                     L.check(rc, "group_hash_accumulate")
                 del t, store
-                cap = min(cap_max, cap << 4)
+                cap = cap_max  # the launch gave up at 3/4 load, early: far more distinct keys than the first guess, take the reference's size
             if _collective is not None:
                 def make_tables(other_store):
                     return self.group_tables(aarr, nagg, 0, cap, hashed=True, store=other_store)[0]
@@ -796,6 +797,8 @@ class Engine:
                     L.check(self.lib.rfx_hip_hash_tables_merge(self._ctx, aarr, C.byref(t), C.byref(other)), "hash_tables_merge")
 
                 _collective("hash_tables", (self, make_tables, store, merge))
+            if _probe_first is not None:  # per row the first row of its group (K11's probe against the group-by's own table)
+                L.check(self.lib.rfx_hip_join_probe_hash(self._ctx, key.data_ptr(), n, C.byref(t), _probe_first.data_ptr()), "join_probe_hash")
             L.check(self.lib.rfx_hip_hash_rank(self._ctx, C.byref(t), total_rows, C.byref(ng)), "hash_rank")
         g = int(ng.value)
         keys = self.empty(g)
@@ -840,6 +843,29 @@ class Engine:
         holds nulls is checked through a copy with the nulls replaced by a value above its maximum."""
         n = kcols[0].numel()
         h = self.row_hash(kcols, value_first=where is not None)
+        if _collective is None and row0 == 0:
+            # One GPU: the reference's own proof shape -- the tuple comparison of every row with its group's first row
+            # (__index_list_cmp_row, core/index.c:2731-2790) -- done once after grouping instead of on every probe: per row the first
+            # row of its group (the join probe against the group-by's own hashed table), then one gather + compare per key column;
+            # the key columns of the result are the tuples at the groups' first rows.  Twelve (min, max) proof aggregates cost
+            # 1.2e9 device atomics per 1e8 rows (two launches, 94 ms); this costs seven random reads per row.
+            ids = self.empty(n)
+            r = self.group_by(h, list(aggs), where, table, total_rows, row0, None, _probe_first=ids)
+            if r["dense"]:
+                raise RfxError("row-hash group-by: the hash column took the dense path")
+            chk = self.empty(n)
+            for kc in kcols:
+                L.check(self.lib.rfx_hip_gather_or(self._ctx, kc.data_ptr(), kc.data_ptr(), ids.data_ptr(), n, 0, chk.data_ptr()), "gather_or")
+                if not bool(torch.equal(chk, kc)):  # an unselected row probes nothing (null id) and compares with itself
+                    raise RfxError("row-hash group-by: two key tuples share one 64-bit row hash (collision); not answered on this path")
+            del chk, ids
+            r["key_columns"] = [self.at_ids(kc, r["first"]) if r["groups"] else self.empty(0) for kc in kcols]
+            if order == "radix" and r["groups"] > 1:  # (hash & 1023, first occurrence): core/index.c:2465-2729
+                perm = torch.argsort((r["keys"] & 1023) * (1 << 40) + torch.argsort(torch.argsort(r["first"])), stable=True)
+                r["keys"], r["first"] = r["keys"][perm], r["first"][perm]
+                r["results"] = [x[perm] for x in r["results"]]
+                r["key_columns"] = [x[perm] for x in r["key_columns"]]
+            return r
         checks, repl = [], []
         for kc, (mn, mx) in zip(kcols, scopes):
             if mn == L.NULL_I64:  # scope saw a null (INT64_MIN sorts lowest)
