@@ -299,6 +299,12 @@ int rfx_hip_group_dense_accumulate(rfx_ctx_t *ctx, const int64_t *d_key, const r
 /* Rank occupied slots by first row (first-occurrence order, core/index.c:2037-2055).  total_rows = global
  * number of rows the row ids in d_first range over.  Returns the group count.  (syncs) */
 int rfx_hip_group_rank(rfx_ctx_t *ctx, const rfx_group_tables_t *t, int64_t total_rows, int64_t *ngroups);
+/* Few slots (a dense table of at most RFX_RANK_SMALL): rfx_hip_group_rank + rfx_hip_group_emit as ONE launch without a host round
+ * trip.  d_block receives [group count][keys][first rows][one array per aggregate], every array `t->range` cells long (the first
+ * `group count` of them valid, in first-occurrence order): 1 + (2 + nagg) * range cells, copied to the host in one piece.
+ * Replaces the groups++ loop of core/index.c:2037-2055 + the collection of core/aggr.c:163-181 for small key ranges. */
+#define RFX_RANK_SMALL 2048
+int rfx_hip_group_rank_emit_small(rfx_ctx_t *ctx, const rfx_agg_t *aggs, const rfx_group_tables_t *t, int64_t row0, int64_t local_rows, int64_t *d_block);
 /* Emit, in group order: keys, first row ids, and one result column per aggregate (8-byte elements typed as the
  * reference types them: sum keeps the input type, avg -> f64, count -> i64, min/max keep the input type).
  * Any of d_keys / d_first_ids / d_results[a] may be NULL to skip it. */

@@ -11,6 +11,7 @@ RFX_EQ, RFX_NE, RFX_LT, RFX_GT, RFX_LE, RFX_GE = range(6)
 RFX_AND, RFX_OR = 0, 1
 RFX_AGG_SUM, RFX_AGG_MIN, RFX_AGG_MAX, RFX_AGG_COUNT, RFX_AGG_AVG, RFX_AGG_FIRST = range(6)
 RFX_MAX_PREDS = RFX_MAX_AGGS = RFX_MAX_COLS = RFX_MAX_KEYS = 8
+RFX_RANK_SMALL = 2048
 RFX_MAX_EXPRS = 4
 NULL_I64 = -(2**63)
 INF_I64 = 2**63 - 1
@@ -143,6 +144,7 @@ PROTOTYPES = {
     "rfx_hip_group_dense_accumulate": (C.c_int, [_ctx, C.c_void_p, _P(Pred), C.c_int, C.c_int, _P(Agg), C.c_int64, C.c_int64, _P(GroupTables)]),
     "rfx_hip_group_rank": (C.c_int, [_ctx, _P(GroupTables), C.c_int64, _P(C.c_int64)]),
     "rfx_hip_group_emit": (C.c_int, [_ctx, _P(Agg), _P(GroupTables), C.c_void_p, C.c_void_p, _P(C.c_void_p)]),
+    "rfx_hip_group_rank_emit_small": (C.c_int, [_ctx, _P(Agg), _P(GroupTables), C.c_int64, C.c_int64, C.c_void_p]),
     "rfx_hip_group_emit_sharded": (C.c_int, [_ctx, _P(Agg), _P(GroupTables), C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, _P(C.c_void_p)]),
     "rfx_hip_hash_emit_sharded": (C.c_int, [_ctx, _P(Agg), _P(HashTables), C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, _P(C.c_void_p)]),
     "rfx_hip_hash_tables_init": (C.c_int, [_ctx, _P(Agg), _P(HashTables)]),

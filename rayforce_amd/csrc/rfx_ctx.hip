@@ -56,6 +56,7 @@ extern "C" int rfx_hip_ctx_create(int device, void *stream, rfx_ctx_t **out) {
     return RFX_OK;
 }
 
+static void pool_release(rfx_ctx *c);
 extern "C" int rfx_hip_ctx_destroy(rfx_ctx_t *c) {
     if (!c) return RFX_OK;
     (void)hipSetDevice(c->device);
@@ -72,6 +73,7 @@ extern "C" int rfx_hip_ctx_destroy(rfx_ctx_t *c) {
     if (c->d_expr) (void)hipFree(c->d_expr);
     if (c->d_chunk) (void)hipFree(c->d_chunk);
     rfx_io_release(c);
+    pool_release(c);
     if (c->d_pc_counts) (void)hipFree(c->d_pc_counts);
     if (c->h_pin) (void)hipHostFree(c->h_pin);
     (void)hipEventDestroy(c->ev0);
@@ -304,15 +306,71 @@ extern "C" int rfx_hip_eval_expr(rfx_ctx_t *c, const rfx_agg_t *expr, int64_t nr
 }
 
 // ---- plain memory ----
+// Small device blocks (<= 4 MB: group tables, result blocks, masks of small queries) are recycled inside the context: hipMalloc +
+// hipFree cost tens of microseconds and hipFree waits for the device -- more than the whole rest of a 1e6-row query.  Blocks are
+// power-of-two sized; everything that touches them runs on the context's one stream, so a recycled block is never read by work
+// still in flight.  Not thread-safe, like the context itself.
+#define POOL_MAX_LOG 22
+#define POOL_MIN_LOG 8
+#define POOL_KEEP 8
+#define POOL_LIVE 1024
+struct SmallPool {
+    void *live_p[POOL_LIVE];
+    unsigned char live_c[POOL_LIVE];
+    int nlive;
+    void *freep[POOL_MAX_LOG + 1][POOL_KEEP];
+    int nfree[POOL_MAX_LOG + 1];
+};
+static void pool_release(rfx_ctx *c) {
+    SmallPool *sp = (SmallPool *)c->ext_p[0];
+    if (!sp) return;
+    for (int k = 0; k <= POOL_MAX_LOG; k++)
+        for (int i = 0; i < sp->nfree[k]; i++) (void)hipFree(sp->freep[k][i]);
+    free(sp);
+    c->ext_p[0] = NULL;
+}
 extern "C" int rfx_hip_malloc(rfx_ctx_t *c, void **d_ptr, size_t bytes) {
     RFX_REQUIRE(c && d_ptr, RFX_EINVAL, "NULL argument");
+    if (bytes <= ((size_t)1 << POOL_MAX_LOG)) {
+        SmallPool *sp = (SmallPool *)c->ext_p[0];
+        if (!sp) c->ext_p[0] = sp = (SmallPool *)calloc(1, sizeof(SmallPool));
+        if (sp && sp->nlive < POOL_LIVE) {
+            int k = POOL_MIN_LOG;
+            while (((size_t)1 << k) < bytes) k++;
+            void *p = NULL;
+            if (sp->nfree[k] > 0) p = sp->freep[k][--sp->nfree[k]];
+            else {
+                RFX_HIP_CHECK(hipSetDevice(c->device));
+                RFX_HIP_CHECK(hipMalloc(&p, (size_t)1 << k));
+            }
+            sp->live_p[sp->nlive] = p;
+            sp->live_c[sp->nlive++] = (unsigned char)k;
+            *d_ptr = p;
+            return RFX_OK;
+        }
+    }
     RFX_HIP_CHECK(hipSetDevice(c->device));
     RFX_HIP_CHECK(hipMalloc(d_ptr, bytes ? bytes : 8));
     return RFX_OK;
 }
 extern "C" int rfx_hip_free(rfx_ctx_t *c, void *d_ptr) {
     RFX_REQUIRE(c, RFX_EINVAL, "ctx is NULL");
-    if (d_ptr) RFX_HIP_CHECK(hipFree(d_ptr));
+    if (!d_ptr) return RFX_OK;
+    SmallPool *sp = (SmallPool *)c->ext_p[0];
+    if (sp) {
+        for (int i = sp->nlive - 1; i >= 0; i--)
+            if (sp->live_p[i] == d_ptr) {
+                const int k = sp->live_c[i];
+                sp->live_p[i] = sp->live_p[sp->nlive - 1];
+                sp->live_c[i] = sp->live_c[--sp->nlive];
+                if (sp->nfree[k] < POOL_KEEP) {
+                    sp->freep[k][sp->nfree[k]++] = d_ptr;
+                    return RFX_OK;
+                }
+                break;
+            }
+    }
+    RFX_HIP_CHECK(hipFree(d_ptr));
     return RFX_OK;
 }
 extern "C" int rfx_hip_h2d(rfx_ctx_t *c, void *d_dst, const void *src, size_t bytes) {

@@ -235,10 +235,44 @@ static int check_tables(const rfx_agg_t *aggs, const rfx_group_tables_t *t) {
     return RFX_OK;
 }
 
+// small tables: every array of the set in ONE launch (a launch per array is most of a small query's cost)
+struct FillSet {
+    u64 *p[1 + 2 * RFX_MAX_AGGS];
+    u64 v[1 + 2 * RFX_MAX_AGGS];
+    int n;
+    i64 cells;
+};
+__global__ __launch_bounds__(RFX_BLOCK) void k_fill_tables(const FillSet F) {
+    const i64 total = F.cells * F.n;
+    for (i64 i = blockIdx.x * (i64)RFX_BLOCK + threadIdx.x; i < total; i += (i64)gridDim.x * RFX_BLOCK) {
+        const int a = (int)(i / F.cells);
+        F.p[a][i - (i64)a * F.cells] = F.v[a];
+    }
+}
 extern "C" int rfx_hip_group_tables_init(rfx_ctx_t *c, const rfx_agg_t *aggs, const rfx_group_tables_t *t) {
     RFX_REQUIRE(c, RFX_EINVAL, "ctx is NULL");
     int rc = check_tables(aggs, t);
     if (rc != RFX_OK) return rc;
+    if (t->range <= (1 << 16)) {
+        FillSet F;
+        F.n = 0;
+        F.cells = t->range;
+        F.p[F.n] = (u64 *)t->d_first;
+        F.v[F.n++] = (u64)RFX_INF_I64_D;
+        for (int a = 0; a < t->nagg; a++) {
+            F.p[F.n] = (u64 *)t->d_acc[a];
+            F.v[F.n++] = acc_identity(aggs[a].kind, rfx_agg_input_type(&aggs[a]) == RFX_F64);
+            if (t->d_cnt[a]) {
+                F.p[F.n] = (u64 *)t->d_cnt[a];
+                F.v[F.n++] = 0;
+            }
+        }
+        const i64 blocks = (F.cells * F.n + RFX_BLOCK - 1) / RFX_BLOCK;
+        const int grid = blocks < rfx_grid((rfx_ctx *)c) * 4 ? (int)blocks : rfx_grid((rfx_ctx *)c) * 4;
+        hipLaunchKernelGGL(k_fill_tables, dim3(grid), dim3(RFX_BLOCK), 0, ((rfx_ctx *)c)->stream, F);
+        RFX_HIP_CHECK(hipGetLastError());
+        return RFX_OK;
+    }
     rc = rfx_fill_u64(c, t->d_first, t->range, (u64)RFX_INF_I64_D);
     if (rc != RFX_OK) return rc;
     for (int a = 0; a < t->nagg; a++) {
@@ -640,6 +674,67 @@ int rfx_emit_slots(rfx_ctx *c, const EmitArgs &A) {
     int sgrid = rfx_grid(c) * 4;
     if (sb < sgrid) sgrid = (int)sb;
     hipLaunchKernelGGL(k_group_emit, dim3(sgrid), dim3(RFX_BLOCK), 0, c->stream, A, (const i64 *)c->d_gid);
+    RFX_HIP_CHECK(hipGetLastError());
+    return RFX_OK;
+}
+
+// ---------------- few slots: rank and emit in ONE launch, no host round trip in between ----------------
+// A dense table of <= RFX_RANK_SMALL slots: one 1024-lane workgroup holds every slot's first row in LDS, a group's id is the
+// number of occupied slots whose first row is smaller (first rows are distinct: a row belongs to one group), and every lane
+// writes its slots' results at that place.  d_block = [group count][keys: slots cells][first rows: slots][one array of `slots`
+// cells per aggregate]: the caller copies it to the host in one piece and learns the group count from its first cell.
+__global__ __launch_bounds__(1024) void k_rank_emit_small(const EmitArgs A, i64 *__restrict__ block) {
+    __shared__ u64 f[RFX_RANK_SMALL];
+    __shared__ unsigned n_occ;
+    const int tid = threadIdx.x;
+    const i64 S = A.slots;
+    for (int i = tid; i < RFX_RANK_SMALL; i += 1024) f[i] = i < S ? A.first[i] : (u64)RFX_INF_I64_D;
+    if (tid == 0) n_occ = 0;
+    __syncthreads();
+    for (int i = tid; i < (int)S; i += 1024) {
+        const u64 mine = f[i];
+        if (mine == (u64)RFX_INF_I64_D) continue;
+        unsigned g = 0;
+        for (int j = 0; j < (int)S; j++) g += (f[j] < mine) ? 1u : 0u;
+        atomicAdd(&n_occ, 1u);
+        A.out_keys[g] = A.kmin + i;
+        A.out_first[g] = (i64)mine;
+        for (int a = 0; a < A.nagg; a++) {
+            if (A.kinds[a] == RFX_AGG_FIRST) {
+                const i64 lr = (i64)mine - A.row0;
+                A.out[a][g] = (A.col[a] && lr >= 0 && (A.nloc == 0 || lr < A.nloc)) ? A.col[a][lr] : 0ULL;
+            } else A.out[a][g] = group_final(A.kinds[a], A.f64s[a], A.acc[a][i], A.cnt[a] ? A.cnt[a][i] : 0ULL, A.skips[a]);
+        }
+    }
+    __syncthreads();
+    if (tid == 0) block[0] = (i64)n_occ;
+}
+extern "C" int rfx_hip_group_rank_emit_small(rfx_ctx_t *c, const rfx_agg_t *aggs, const rfx_group_tables_t *t, int64_t row0, int64_t local_rows,
+                                             int64_t *d_block) {
+    RFX_REQUIRE(c && d_block, RFX_EINVAL, "NULL argument");
+    int rc = check_tables(aggs, t);
+    if (rc != RFX_OK) return rc;
+    RFX_REQUIRE(t->range >= 1 && t->range <= RFX_RANK_SMALL, RFX_EINVAL, "rank_emit_small: 1 .. RFX_RANK_SMALL slots");
+    EmitArgs A;
+    memset(&A, 0, sizeof(A));
+    A.kmin = t->kmin;
+    A.slots = t->range;
+    A.nagg = t->nagg;
+    A.first = (const u64 *)t->d_first;
+    A.out_keys = (i64 *)d_block + 1;
+    A.out_first = (i64 *)d_block + 1 + t->range;
+    A.row0 = row0;
+    A.nloc = local_rows;
+    for (int a = 0; a < t->nagg; a++) {
+        A.kinds[a] = aggs[a].kind;
+        A.f64s[a] = rfx_agg_input_type(&aggs[a]) == RFX_F64;
+        A.skips[a] = aggs[a].xop != RFX_X_NONE || aggs[a].nxnodes > 0;
+        A.acc[a] = (const u64 *)t->d_acc[a];
+        A.cnt[a] = (const u64 *)t->d_cnt[a];
+        A.col[a] = (const u64 *)aggs[a].d_col;
+        A.out[a] = (u64 *)d_block + 1 + (size_t)(2 + a) * t->range;
+    }
+    hipLaunchKernelGGL(k_rank_emit_small, dim3(1), dim3(1024), 0, ((rfx_ctx *)c)->stream, A, (i64 *)d_block);
     RFX_HIP_CHECK(hipGetLastError());
     return RFX_OK;
 }

@@ -727,6 +727,18 @@ static int build_xnodes(obj_p tab, obj_p e, rfx_xnode_t *nodes, int *nn, int *nc
 }
 
 /* ------------------------------------------------------------------------------------------------ select */
+/* results of a small group-by arrive on the host in ONE copy (rfx_hip_group_rank_emit_small's block); the code that builds the
+ * result vectors reads device addresses through fetch(), which serves addresses inside that block from its host mirror */
+static const char *g_mirror_dev, *g_mirror_host;
+static size_t g_mirror_bytes;
+static int fetch(void *dst, const void *d_src, size_t bytes) {
+    if (g_mirror_host && (const char *)d_src >= g_mirror_dev && (const char *)d_src + bytes <= g_mirror_dev + g_mirror_bytes) {
+        memcpy(dst, g_mirror_host + ((const char *)d_src - g_mirror_dev), bytes);
+        return RFX_OK;
+    }
+    return rfx_hip_d2h(g_ctx, dst, d_src, bytes);
+}
+
 static obj_p select_impl(obj_p dict) {
     rfx_host_bind();
     if (!dict || dict->type != RFX_TYPE_DICT || RFX_AS_LIST(dict)[0]->type != RFX_TYPE_SYMBOL) return fail("select: expected a dict");
@@ -1059,7 +1071,25 @@ static obj_p select_impl(obj_p dict) {
                     int64_t *cnt = hc ? base + (k++) * cells : NULL;
                     if (dense) { gt.d_acc[a] = acc; gt.d_cnt[a] = cnt; } else { ht.d_acc[a] = acc; ht.d_cnt[a] = cnt; }
                 }
-                if (dense) {
+                void *dout = NULL;
+                int64_t *mirror = NULL;
+                const int small = dense && nkeys == 1 && range <= RFX_RANK_SMALL;
+                if (small) {
+                    /* few slots: init, accumulate, rank + emit are three launches and the result block comes back in one copy -- the
+                     * only host round trip after the scope pass (a dozen launches and three more round trips otherwise) */
+                    const size_t bcells = 1 + (size_t)(2 + nagg_run) * (size_t)range;
+                    void *blk = NULL;
+                    ok = rfx_hip_malloc(g_ctx, &blk, bcells * 8) == RFX_OK && (mirror = (int64_t *)malloc(bcells * 8)) != NULL &&
+                         rfx_hip_group_tables_init(g_ctx, aggs, &gt) == RFX_OK &&
+                         rfx_hip_group_dense_accumulate(g_ctx, (const int64_t *)dk, wp.preds, wp.npred, wp.logic, aggs, nrows, 0, &gt) == RFX_OK &&
+                         rfx_hip_group_rank_emit_small(g_ctx, aggs, &gt, 0, 0, (int64_t *)blk) == RFX_OK &&
+                         rfx_hip_d2h(g_ctx, mirror, blk, bcells * 8) == RFX_OK;
+                    g_mirror_host = (const char *)mirror; /* released at `done` */
+                    g_mirror_dev = (const char *)blk;
+                    g_mirror_bytes = ok ? bcells * 8 : 0;
+                    if (ok) groups = mirror[0];
+                    dout = blk;
+                } else if (dense) {
                     ok = rfx_hip_group_tables_init(g_ctx, aggs, &gt) == RFX_OK &&
                          (nkeys > 1 && !rowhash ? rfx_hip_group_dense_accumulate_keys(g_ctx, dks, kmins, kmults, nkeys, wp.preds, wp.npred, wp.logic, aggs, nrows, 0, &gt)
                                     : rfx_hip_group_dense_accumulate(g_ctx, (const int64_t *)dk, wp.preds, wp.npred, wp.logic, aggs, nrows, 0, &gt)) == RFX_OK &&
@@ -1075,21 +1105,27 @@ static obj_p select_impl(obj_p dict) {
                         goto grow;
                     }
                 }
-                void *dout = NULL;
-                if (ok && groups > 0) ok = rfx_hip_malloc(g_ctx, &dout, (size_t)(nagg_run + 1) * (size_t)groups * 8) == RFX_OK;
+                const void *dkeys_out = NULL; /* device address of the result's key cells */
+                if (ok && groups > 0 && !small) ok = rfx_hip_malloc(g_ctx, &dout, (size_t)(nagg_run + 1) * (size_t)groups * 8) == RFX_OK;
                 if (ok && groups > 0) {
                     void *ptrs[RFX_MAX_AGGS];
-                    for (int a = 0; a < nagg_run; a++) ptrs[a] = (int64_t *)dout + (size_t)(a + 1) * groups;
-                    ok = (dense ? rfx_hip_group_emit(g_ctx, aggs, &gt, (int64_t *)dout, NULL, ptrs) : rfx_hip_hash_emit(g_ctx, aggs, &ht, (int64_t *)dout, NULL, ptrs)) == RFX_OK;
+                    if (small) {
+                        dkeys_out = (int64_t *)dout + 1;
+                        for (int a = 0; a < nagg_run; a++) ptrs[a] = (int64_t *)dout + 1 + (size_t)(2 + a) * (size_t)range;
+                    } else {
+                        dkeys_out = dout;
+                        for (int a = 0; a < nagg_run; a++) ptrs[a] = (int64_t *)dout + (size_t)(a + 1) * groups;
+                        ok = (dense ? rfx_hip_group_emit(g_ctx, aggs, &gt, (int64_t *)dout, NULL, ptrs) : rfx_hip_hash_emit(g_ctx, aggs, &ht, (int64_t *)dout, NULL, ptrs)) == RFX_OK;
+                    }
                     if (nkeys == 1 && key_out_type == RFX_TYPE_DATE) { /* the virtual Date column: 4-byte days */
                         okeys = H.vector(RFX_TYPE_DATE, groups);
                         int64_t *k8 = (int64_t *)malloc((size_t)groups * 8);
-                        ok = ok && k8 && rfx_hip_d2h(g_ctx, k8, dout, (size_t)groups * 8) == RFX_OK;
+                        ok = ok && k8 && fetch(k8, dkeys_out, (size_t)groups * 8) == RFX_OK;
                         for (int64_t g = 0; g < groups && ok; g++) ((int32_t *)RFX_AS_RAW(okeys))[g] = (int32_t)k8[g];
                         free(k8);
                     } else if (nkeys == 1) {
                         okeys = H.vector(key_out_type, groups);
-                        if (ok) ok = rfx_hip_d2h(g_ctx, RFX_AS_RAW(okeys), dout, (size_t)groups * 8) == RFX_OK;
+                        if (ok) ok = fetch(RFX_AS_RAW(okeys), dkeys_out, (size_t)groups * 8) == RFX_OK;
                         if (ok && kenum) { /* indices -> symbols of the enum's domain (the global its key names) */
                             int64_t key_id;
                             if (kenum->mmod == RFX_MMOD_INTERNAL) key_id = RFX_AS_LIST(kenum)[0]->i64;
@@ -1152,7 +1188,7 @@ static obj_p select_impl(obj_p dict) {
                     }
                     for (int a = 0; a < nagg && ok; a++) {
                         ocols[a] = H.vector((int8_t)outtype[a], groups);
-                        ok = rfx_hip_d2h(g_ctx, RFX_AS_RAW(ocols[a]), ptrs[a], (size_t)groups * 8) == RFX_OK;
+                        ok = fetch(RFX_AS_RAW(ocols[a]), ptrs[a], (size_t)groups * 8) == RFX_OK;
                     }
                 }
                 if (dout) rfx_hip_free(g_ctx, dout);
@@ -1200,6 +1236,8 @@ done:
     for (int i = 0; i < ntmp; i++) rfx_hip_free(g_ctx, tmp[i]);
     qtmp_release();
     if (parted) parted_view_release();
+    free((void *)g_mirror_host);
+    g_mirror_host = NULL;
     H.drop(host_tab);
     return res;
 }

@@ -763,6 +763,21 @@ class Engine:
             if _collective is not None:  # the kinds of THIS launch's aggregates (a chunk of the query's, or the row-hash path's extras)
                 _collective("tables", (store, layout, [int(aarr[i].kind) for i in range(nagg)],
                                        [L.agg_input_type(aarr[i]) == L.RFX_F64 for i in range(nagg)], t, aarr))
+            if rng <= L.RFX_RANK_SMALL and _collective is None:
+                # few slots: rank + emit in ONE launch, results sliced out of its block after one host round trip (the group count)
+                block = self.empty(1 + (2 + nagg) * rng)
+                L.check(self.lib.rfx_hip_group_rank_emit_small(self._ctx, aarr, C.byref(t), row0, 0, block.data_ptr()), "group_rank_emit_small")
+                g = int(block[0])
+                r = dict(groups=g, keys=block[1:1 + g], first=block[1 + rng:1 + rng + g], dense=True, cap=0,
+                         results=[block[1 + (2 + a) * rng:1 + (2 + a) * rng + g].view(out_dtypes[a]) for a in range(nagg)])
+                if multi is not None:
+                    mins, mults, ranges = multi
+                    r["key_columns"] = []
+                    for mn, mu, rg in zip(mins, mults, ranges):
+                        kc = self.empty(g)
+                        L.check(self.lib.rfx_hip_composite_decode(self._ctx, r["keys"].data_ptr(), g, mn, mu, rg, kc.data_ptr()), "composite_decode")
+                        r["key_columns"].append(kc)
+                return r
             L.check(self.lib.rfx_hip_group_rank(self._ctx, C.byref(t), total_rows, C.byref(ng)), "group_rank")
         else:
             if multi is not None:  # sparse composite: the hashed path keys on the materialised column (core/index.c:2421 -> :2092)

@@ -13,6 +13,7 @@ eng = Engine(0)
 for n in (10_000, 100_000, 1_000_000, 10_000_000):
     host = {"k": rfo.gen_i64(n, 4, 1000), "a": rfo.gen_i64(n, 2, 1_000_000), "v": rfo.gen_f64(n, 5)}
     tab = H.table(host)
+    ops.rfx_host_drop(ops.rfx_pin(tab))  # resident and trusted: without it every call re-validates the columns with a full checksum
     dev = {k: eng.column(v) for k, v in host.items()}
     for name, q in (("where-sum", {"s": ("sum", "v"), "where": ("<", "a", 100_000)}), ("by-sum", {"s": ("sum", "v"), "by": "k"}),
                     ("where-by", {"s": ("sum", "v"), "c": ("count", "a"), "where": ("<", "a", 500_000), "by": "k"})):
