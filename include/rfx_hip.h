@@ -24,7 +24,9 @@
 #ifndef RFX_HIP_H
 #define RFX_HIP_H
 
+#ifndef __HIPCC_RTC__ /* run-time compiled kernels (hiprtc) see this header too: it has no <stddef.h>, size_t is built in */
 #include <stddef.h>
+#endif
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -186,7 +188,8 @@ enum {
     RFX_TUNE_CHUNK_SMALL = 32768,    /* rfx_hip_group_scope: one-pass chunk partitioning from 2^16 rows on (default 2^22): for tests */
     RFX_TUNE_CHUNK_CONTIG = 65536,   /* one-pass chunk partitioning: every workgroup takes one contiguous row range instead of grid-stride tiles */
     RFX_TUNE_CHUNK_QUEUE = 131072,   /* one-pass chunk partitioning under a selective filter: always the sorted-queue kernel (as for skewed keys), never per-partition bins */
-    RFX_TUNE_CHUNK_BINS = 262144     /* ... always per-partition bins, however the sampled keys spread: for tests */
+    RFX_TUNE_CHUNK_BINS = 262144,    /* ... always per-partition bins, however the sampled keys spread: for tests */
+    RFX_TUNE_NO_RTC = 524288         /* never compile a plan-specialised kernel at run time (hiprtc): the prebuilt kernels only */
 };
 int rfx_hip_ctx_tune(rfx_ctx_t *ctx, int blocks_per_cu, int flags);
 
@@ -198,6 +201,10 @@ int rfx_hip_d2h(rfx_ctx_t *ctx, void *dst, const void *d_src, size_t bytes); /* 
 int rfx_hip_memset(rfx_ctx_t *ctx, void *d_dst, int byte, size_t bytes);
 /* d_dst[0..n) = value (8-byte cells): the virtual Date column of a parted table, expanded partition by partition */
 int rfx_hip_fill_i64(rfx_ctx_t *ctx, int64_t *d_dst, int64_t n, int64_t value);
+/* Kernels compiled at run time for one plan (hiprtc, loaded on first use; group-bys over at most 8 slots take one): how many launches
+ * went through such a kernel and how many were compiled so far in this process.  RFX_TUNE_NO_RTC / RFX_NO_RTC=1 keep to the prebuilt
+ * kernels; so does a box without libhiprtc.so or without the library's source tree beside librfx.so. */
+void rfx_hip_rtc_stats(int64_t *launches, int64_t *compiles);
 
 /* Host-to-device at link speed from ANY host memory (heap vector, mmapped column file): chunks are staged through pinned
  * buffers by worker threads while the previous chunk is in flight.  (syncs) */

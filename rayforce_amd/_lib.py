@@ -120,6 +120,7 @@ PROTOTYPES = {
     "rfx_hip_d2h": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_size_t]),
     "rfx_hip_memset": (C.c_int, [_ctx, C.c_void_p, C.c_int, C.c_size_t]),
     "rfx_hip_fill_i64": (C.c_int, [_ctx, C.c_void_p, C.c_int64, C.c_int64]),
+    "rfx_hip_rtc_stats": (None, [_P(C.c_int64), _P(C.c_int64)]),
     "rfx_hip_timer_start": (C.c_int, [_ctx]),
     "rfx_hip_timer_stop": (C.c_int, [_ctx, _P(C.c_float)]),
     "rfx_hip_ctx_profile": (C.c_int, [_ctx, C.c_int]),

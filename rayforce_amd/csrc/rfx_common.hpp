@@ -1,10 +1,14 @@
 // rfx_common.hpp -- internal (not part of the C ABI): context layout, launch plan, device-side scalar rules.
 // gfx950 / wave64 only.  The scalar rules restate core/ops.h:63-197 of the reference (cited per function).
 #pragma once
+// Kernels compiled at run time for one plan (hiprtc, rfx_rtc.hip) include this header as well: there the HIP device builtins are
+// pre-included, the C library headers do not exist, and everything host-side is left out (__HIPCC_RTC__).
+#ifndef __HIPCC_RTC__
 #include <hip/hip_runtime.h>
-#include <stdint.h>
 #include <stdio.h>
 #include <string.h>
+#endif
+#include <stdint.h>
 #include "../../include/rfx_hip.h"
 
 #define RFX_WAVE 64
@@ -17,6 +21,7 @@
 typedef unsigned long long u64;
 typedef long long i64;
 
+#ifndef __HIPCC_RTC__
 void rfx_set_error(const char *fmt, ...);
 
 #define RFX_HIP_CHECK(expr)                                                                       \
@@ -113,6 +118,9 @@ int rfx_plan_add_col(struct Plan *P, const void *col); // index of `col` in P->c
 #define RFX_KERNEL_BEGIN(c) do { if ((c)->profile) { (void)hipEventRecord((c)->evk0, (c)->stream); } } while (0)
 #define RFX_KERNEL_END(c) do { if ((c)->profile) { (void)hipEventRecord((c)->evk1, (c)->stream); (c)->evk_valid = 1; } } while (0)
 static inline int rfx_grid(const rfx_ctx *ctx) { return ctx->num_cus * ctx->blocks_per_cu; }
+#else
+struct rfx_ctx;
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // Launch plan: what one fused pass reads and computes.  Passed to kernels by value (kernarg segment).

@@ -15,22 +15,6 @@
 
 int rfx_group_part_accumulate(rfx_ctx *c, const Plan &P, int key_idx, const rfx_group_tables_t *t); // rfx_group_part.hip
 
-struct GroupArgs {
-    i64 kmin;
-    i64 range;
-    int key_idx; // column index of the key inside Plan::cols
-    int nagg;
-    // several key columns folded on the fly (index_group_list_perfect_partial, core/index.c:2238-2305): nkeys >= 2,
-    // slot = sum_i (col[kidx[i]] - kmn[i]) * kmul[i]; kmin is 0 then
-    int nkeys;
-    int kidx[RFX_MAX_KEYS];
-    u64 kmn[RFX_MAX_KEYS];
-    u64 kmul[RFX_MAX_KEYS];
-    int rep_shift; // TINY form: log2 of the number of lane-private table replicas
-    u64 *first;
-    u64 *acc[RFX_MAX_AGGS];
-    u64 *cnt[RFX_MAX_AGGS];
-};
 
 // ---- K7 + K10, one pass.  LDS = true: tables privatised in dynamic LDS, merged at the end. ----
 // TINY = true (256-lane LDS form only), two things for small table sets:
@@ -40,7 +24,7 @@ struct GroupArgs {
 //    a ds_add hit the same addresses and the LDS serialises them; with lane-private replicas every lane of an instruction has
 //    its own cell and bank.  Replicas are folded before the merge.
 template <int NC, bool LDS, int BLOCK, bool TINY = false, int NPT = RFX_MAX_PREDS>
-__global__ __launch_bounds__(BLOCK) void k_group_dense(const Plan P, const GroupArgs G) {
+__device__ __forceinline__ void group_dense_body(const Plan &P, const GroupArgs &G) {
     constexpr bool DEEP = TINY;
     constexpr bool SW = TINY || BLOCK == 1024; // column operands through a wave-uniform switch instead of select chains
     constexpr int U = TINY ? (NC <= 5 ? 4 : 3) : ((NC <= 2) ? 4 : (NC <= 4 ? 2 : 1)); // rows per lane = 2 U; TINY: measured per NC (tools/q1_variants.py)
@@ -201,6 +185,10 @@ __global__ __launch_bounds__(BLOCK) void k_group_dense(const Plan P, const Group
         }
     }
 }
+template <int NC, bool LDS, int BLOCK, bool TINY = false, int NPT = RFX_MAX_PREDS>
+__global__ __launch_bounds__(BLOCK) void k_group_dense(const Plan P, const GroupArgs G) {
+    group_dense_body<NC, LDS, BLOCK, TINY, NPT>(P, G);
+}
 
 // ---- table init ----
 __global__ __launch_bounds__(RFX_BLOCK) void k_fill_u64(u64 *p, i64 n, u64 val) {
@@ -289,8 +277,34 @@ extern "C" int rfx_hip_group_tables_init(rfx_ctx_t *c, const rfx_agg_t *aggs, co
 #define RFX_LDS_GROUP_BYTES (64 * 1024)      /* per 256-thread workgroup: two workgroups per CU keep streaming at full rate */
 #define RFX_LDS_GROUP_BIG_BYTES (160 * 1024) /* one 1024-thread workgroup per CU owning the whole LDS (mid-range key counts) */
 
+// RFX_DUMP_PLAN=1: the descriptor fields of a launch as C++ conditions (development: what a plan-specialised kernel would fix)
+static void dump_plan(const Plan &P, const GroupArgs &G, int nc, int grid, size_t lds, bool deep) {
+    fprintf(stderr, "// NC %d deep %d grid %d lds %zu nrows %lld\n", nc, (int)deep, grid, lds, (long long)P.nrows);
+    fprintf(stderr, "A(P.ncols == %d); A(P.npred == %d); A(P.nagg == %d); A(P.logic == %d); A(P.nx == %d);\n", P.ncols, P.npred, P.nagg, P.logic, P.nx);
+    for (int i = 0; i < P.npred; i++)
+        fprintf(stderr, "A(P.preds[%d].col == %d); A(P.preds[%d].rhs_col == %d); A(P.preds[%d].op == %d); A(P.preds[%d].dom_f64 == %d); A(P.preds[%d].lhs_cvt == %d); A(P.preds[%d].rhs_cvt == %d);\n",
+                i, P.preds[i].col, i, P.preds[i].rhs_col, i, P.preds[i].op, i, P.preds[i].dom_f64, i, P.preds[i].lhs_cvt, i, P.preds[i].rhs_cvt);
+    for (int a = 0; a < P.nagg; a++)
+        fprintf(stderr, "A(P.aggs[%d].col == %d); A(P.aggs[%d].f64 == %d); A(P.aggs[%d].kind == %d); A(P.aggs[%d].skipnull == %d);\n", a, P.aggs[a].col, a, P.aggs[a].f64, a,
+                P.aggs[a].kind, a, P.aggs[a].skipnull);
+    for (int x = 0; x < P.nx; x++) {
+        fprintf(stderr, "A(P.xs[%d].nops == %d); A(P.xs[%d].out_f64 == %d);\n", x, P.xs[x].nops, x, P.xs[x].out_f64);
+        const int *w = (const int *)P.xs[x].ops;
+        for (int j = 0; j < P.xs[x].nops * (int)(sizeof(PlanXNode) / 4); j++) fprintf(stderr, "A(((const int *)P.xs[%d].ops)[%d] == %d); ", x, j, w[j]);
+        fprintf(stderr, "\n");
+    }
+    fprintf(stderr, "A(G.key_idx == %d); A(G.nagg == %d); A(G.nkeys == %d); A(G.rep_shift == %d); A(G.range == %lld); A(G.kmin == %lld);\n", G.key_idx, G.nagg, G.nkeys, G.rep_shift,
+            (long long)G.range, (long long)G.kmin);
+    for (int i = 0; i < G.nkeys; i++) fprintf(stderr, "A(G.kidx[%d] == %d); A(G.kmn[%d] == %lluULL); A(G.kmul[%d] == %lluULL);\n", i, G.kidx[i], i, (unsigned long long)G.kmn[i], i, (unsigned long long)G.kmul[i]);
+}
 template <int NC>
 static int launch_group(rfx_ctx *c, const Plan &P, const GroupArgs &G, int grid, size_t lds_bytes, bool deep) {
+    if (getenv("RFX_DUMP_PLAN")) dump_plan(P, G, NC, grid, lds_bytes, deep);
+    // a handful of groups: register accumulators, one kernel per plan compiled at run time (rfx_rtc.hip); RFX_ESTATE = not available
+    if (deep && G.range <= RFX_FEW_MAX_GROUPS && !(c->flags & RFX_TUNE_NO_RTC)) {
+        const int rrc = rfx_rtc_group_few(c, P, G, grid);
+        if (rrc != RFX_ESTATE) return rrc;
+    }
     if (deep) { // TINY form (group_dense_run decides): 256 lanes, table replicas within the 64 KB LDS budget
         if (P.npred == 0) hipLaunchKernelGGL((k_group_dense<NC, true, RFX_BLOCK, true, 0>), dim3(grid), dim3(RFX_BLOCK), lds_bytes, c->stream, P, G);
         else if (P.npred <= 2) hipLaunchKernelGGL((k_group_dense<NC, true, RFX_BLOCK, true, 2>), dim3(grid), dim3(RFX_BLOCK), lds_bytes, c->stream, P, G);

@@ -77,6 +77,28 @@ __device__ __forceinline__ i64 hash_slot_ins(u64 *keys, i64 capacity, u64 key, u
     return -1;
 }
 
+struct GroupArgs {
+    i64 kmin;
+    i64 range;
+    int key_idx; // column index of the key inside Plan::cols
+    int nagg;
+    // several key columns folded on the fly (index_group_list_perfect_partial, core/index.c:2238-2305): nkeys >= 2,
+    // slot = sum_i (col[kidx[i]] - kmn[i]) * kmul[i]; kmin is 0 then
+    int nkeys;
+    int kidx[RFX_MAX_KEYS];
+    u64 kmn[RFX_MAX_KEYS];
+    u64 kmul[RFX_MAX_KEYS];
+    int rep_shift; // TINY form: log2 of the number of lane-private table replicas
+    u64 *first;
+    u64 *acc[RFX_MAX_AGGS];
+    u64 *cnt[RFX_MAX_AGGS];
+};
+
+#define RFX_FEW_MAX_GROUPS 8
+#ifndef __HIPCC_RTC__
+int rfx_rtc_group_few(rfx_ctx *c, const Plan &P, const GroupArgs &G, int grid); // rfx_rtc.hip; RFX_ESTATE: no run-time compiler / sources
+#endif
+
 // identity element of an accumulator cell
 __device__ __host__ __forceinline__ u64 acc_identity(int kind, int f64) {
     (void)f64;

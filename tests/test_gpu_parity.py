@@ -5,6 +5,8 @@ All calls go through the C ABI of librfx.so (rayforce_amd.engine is a ctypes hos
 checker only."""
 import math
 
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -673,3 +675,64 @@ def test_group_by_xbar_buckets(eng):
     from rayforce_amd._lib import RfxError
     with pytest.raises(RfxError, match="width must be positive"):
         eng.select({"from": dev(eng, host), "by": {"b": ("xbar", "a", 0)}, "s": ("sum", "v")})
+
+
+# ---------------------------------------------------------------- a handful of groups: one kernel per plan, compiled at run time
+NO_RTC = 524288  # RFX_TUNE_NO_RTC
+
+
+def _rtc_stats(eng):
+    import ctypes as C
+    a, b = C.c_int64(), C.c_int64()
+    eng.lib.rfx_hip_rtc_stats(C.byref(a), C.byref(b))
+    return int(a.value), int(b.value)
+
+
+@pytest.mark.parametrize("groups", [1, 2, 6, 8])
+@pytest.mark.parametrize("n", [1, 700, 300_007])
+def test_few_groups_run_time_compiled_kernels(eng, groups, n):
+    """Group-bys over at most 8 slots take a kernel generated for the plan (rfx_group_few_rtc.hpp through hiprtc: per-lane register
+    accumulators for every (aggregate, group), no atomics in the row loop): every aggregate kind over i64 / f64 with nulls and
+    NaNs, expressions, 0 / 1 / 3 / 5 predicates, one and two key columns, a key offset -- against the oracle, and against the
+    prebuilt LDS-table kernel (RFX_TUNE_NO_RTC) bit for bit on everything that is not an f64 sum."""
+    host = table(n, seed=groups, keys=groups, nulls=True)
+    host["k"] = host["k"] + 1000  # kmin != 0
+    if n > 100:  # infinities: the masked-fma accumulation zeroes them out of its products and adds them on a side path
+        host["w"][7::97] = np.inf
+        host["w"][11::389] = -np.inf
+        host["v"][13::211] = np.inf
+    host["g2"] = rfo.gen_i64(n, 77, 2)
+    host["k4"] = rfo.gen_i64(n, 78, max(1, groups // 2))
+    queries = [
+        {"by": "k", "s": ("sum", "v"), "c": ("count", "v"), "mn": ("min", "v"), "mx": ("max", "v"), "av": ("avg", "v"), "f": ("first", "v")},
+        {"by": "k", "si": ("sum", "a"), "mi": ("min", "a"), "xa": ("max", "a"), "aa": ("avg", "a"), "fa": ("first", "a"), "ca": ("count", "a")},
+        {"where": ("<", "a", 600_000), "by": "k", "s": ("sum", "w"), "mx": ("max", "a")},
+        {"where": ("and", ("<", "a", 800_000), (">", "w", -0.4), ("<", "v", 0.9)), "by": "k", "s": ("sum", "v"), "av": ("avg", "a")},
+        {"where": ("or", ("<", "a", 100_000), (">", "a", 900_000), ("<", "w", -0.45), (">", "v", 0.97), ("==", "k", 1000)), "by": "k", "c": ("count", "a")},
+        {"by": "k", "e1": ("sum", ("*", "v", ("-", 1.0, "w"))), "e2": ("sum", ("*", ("*", "v", ("-", 1.0, "w")), ("+", 1.0, "v"))), "e3": ("max", ("+", "a", 5)), "c": ("count", "a")},
+        {"where": ("<=", "a", 950_000), "by": {"x": "k4", "y": "g2"}, "s": ("sum", "v"), "q": ("sum", "a"), "av": ("avg", "w"), "c": ("count", "a")},
+        {"where": ("<", "a", -1), "by": "k", "s": ("sum", "v")},  # nothing selected
+    ]
+    l0, c0 = _rtc_stats(eng)
+    results = []
+    os.environ["RFX_RTC_EAGER"] = "1"  # compile at first sight (the library waits for a plan to come back over >= 2^24 rows)
+    try:
+        for q in queries:
+            results.append(check_select(eng, host, q))
+    finally:
+        del os.environ["RFX_RTC_EAGER"]
+    l1, c1 = _rtc_stats(eng)
+    if c1 == c0 and l1 == l0:
+        pytest.skip("no run-time compiler on this box (libhiprtc.so / kernel sources): the prebuilt kernels answered")
+    assert l1 > l0
+    try:
+        eng.tune(flags=NO_RTC)
+        for q, r in zip(queries, results):
+            again = check_select(eng, host, q)
+            for name in r:
+                a, b = r[name].cpu().numpy(), again[name].cpu().numpy()
+                if a.dtype != np.float64 or (name in q and q[name][0] in ("min", "max", "first")):
+                    assert np.array_equal(a.view(np.int64), b.view(np.int64)), name
+        assert _rtc_stats(eng)[0] == l1  # the flag kept every launch on the prebuilt kernels
+    finally:
+        eng.tune(flags=0)
