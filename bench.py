@@ -69,12 +69,12 @@ WORKLOADS = {
                bytes_per_row=24, dtype="f64", kernel="k_part_scope_hist<1, 0> x2 + k_group_dense<3, true, 1024>"),
     "q7": dict(desc="key tuples beyond the composite key (H2O Q7 shape, row-hash path): select sum(v), count by {id1..id6}; id1,id2,id4,id5 i64 uniform [0,100), "
                     "id3,id6 i64 uniform [0,1e6) seeds 20-25, v f64 seed 5 (ranges multiply to 1e20 > 2^63; ~1e8 groups)", rows=100_000_000,
-               bytes_per_row=56, dtype="f64", kernel="k_row_hash<6> + sparse-key passes (k_part_scatter_soa / k_part_hash_aggregate), 14 key-proof aggregates in 2 launches"),
+               bytes_per_row=56, dtype="f64", kernel="k_row_hash<6> + k_group_hash<2> (device-wide table) + k_join_probe_hash + 6 x (k_gather_or, compare): tuple proof at the groups' first rows + k_group_emit_by_group"),
     "x6": dict(desc="expression aggregate (TPC-H Q6 shape): select sum(p * d) where q < 24 and d >= 0.05 and d <= 0.07; p f64 seed 12, d f64 seed 13 "
                     "scaled to [0,0.1), q i64 uniform [0,50) seed 14", rows=1_000_000_000, bytes_per_row=24, dtype="f64", kernel="k_filter_aggr<3, 1, 4, 4, 1, false>"),
     "q1": dict(desc="nested expressions (TPC-H Q1 shape): sum(q), sum(p), sum(p*(1-d)), sum(p*(1-d)*(1+t)), avg(q), avg(p), avg(d), count by {rf, ls} "
                     "where sd <= 2400; rf in [0,3), ls in [0,2), q i64 [1,50], p f64, d f64 [0,.1), t f64 [0,.08), sd i64 [0,2500)", rows=1_000_000_000,
-               bytes_per_row=56, dtype="f64", kernel="k_filter_aggr<3, 4, 4, 1, 0, false> (both key scopes) + k_group_dense<7, true, 256, true, 2> (one pass, expression trees evaluated in it)"),
+               bytes_per_row=56, dtype="f64", kernel="k_filter_aggr<3, 4, 4, 1, 0, false> (both key scopes) + k_group_few (compiled at run time for the plan: register accumulators per (aggregate, group); prebuilt k_group_dense<7, true, 256, true, 2> without hiprtc)"),
     "k9": dict(desc="sparse keys (range > rows -> the reference's open-addressing path): select sum(v) by k, k = 1000003 * (i64 uniform [0,1e6) seed 4) - 77, "
                     "v f64 seed 5", rows=1_000_000_000, bytes_per_row=16, dtype="f64", kernel="k_part_hist<1, 0> + k_part_scatter_soa<2, 2, 0> + k_part_hash_aggregate<2>"),
     "w2": dict(desc="where ids: (where (< a 100000)) on the C2 column -> 1e8 ascending i64 row ids (8 B/row in + 8 B/selected row out)", rows=1_000_000_000,
