@@ -118,6 +118,7 @@ int rfx_plan_add_col(struct Plan *P, const void *col); // index of `col` in P->c
 #define RFX_KERNEL_BEGIN(c) do { if ((c)->profile) { (void)hipEventRecord((c)->evk0, (c)->stream); } } while (0)
 #define RFX_KERNEL_END(c) do { if ((c)->profile) { (void)hipEventRecord((c)->evk1, (c)->stream); (c)->evk_valid = 1; } } while (0)
 static inline int rfx_grid(const rfx_ctx *ctx) { return ctx->num_cus * ctx->blocks_per_cu; }
+int rfx_rtc_filter_aggr(rfx_ctx *c, const struct Plan &P, int grid, void *ws, int *na_stride); // rfx_rtc.hip; RFX_ESTATE: the prebuilt kernels run
 #else
 struct rfx_ctx;
 #endif

@@ -10,7 +10,7 @@
 //
 // Generated before the #include:  FEW_NC (plan columns)  FEW_NA (aggregates)  FEW_NG (slots of the dense table = key range)
 //   FEW_NPT (predicate descriptor sets: 0 / 2 / RFX_MAX_PREDS)  FEW_U (16-byte loads per lane, column and tile)
-//   FEW_PLAN  the plan's DESCRIPTOR part as a braced initialiser of `Plan` (column pointers null, row counts 0: those and the
+//   RTC_PLAN  the plan's DESCRIPTOR part as a braced initialiser of `Plan` (column pointers null, row counts 0: those and the
 //             predicates' right-hand atoms come from the kernel argument at run time, so one kernel serves every constant of a
 //             filter; a NaN atom is part of the signature because it selects the comparison's code path)
 //   FEW_KEY_IDX, FEW_NKEYS, FEW_KIDX {..}  the key column(s) of the dense slot
@@ -82,7 +82,7 @@ __device__ __forceinline__ void few_merge_lds(u64 *lacc, unsigned *lcnt, int kin
 }
 
 extern "C" __global__ __launch_bounds__(RFX_BLOCK) void k_group_few(const Plan P0, const GroupArgs G) {
-    constexpr Plan P = FEW_PLAN; // descriptors only
+    constexpr Plan P = RTC_PLAN; // descriptors only
     constexpr int KIDX[RFX_MAX_KEYS] = FEW_KIDX;
     constexpr int NC = FEW_NC, NA = FEW_NA, NG = FEW_NG, U = FEW_U, E = 2 * U;
     constexpr int TILE = RFX_BLOCK * E, JSTRIDE = RFX_BLOCK * 2;

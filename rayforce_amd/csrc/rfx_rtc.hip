@@ -71,10 +71,10 @@ static bool rtc_ready() {
 // The plan's descriptor part as a braced initialiser of `Plan` (field order of rfx_common.hpp), the key columns as macros: the text is
 // both what the kernel is compiled from and -- with the sizes -- its cache key.  Run-time values stay out of it: column pointers,
 // row counts, the predicates' atoms (only whether an f64 atom is NaN, which picks the comparison's code), kmin / multipliers.
-static void plan_text(const Plan &P, const GroupArgs &G, std::string &o) {
+static void plan_text(const Plan &P, const GroupArgs *G, std::string &o) {
     char b[512];
 #define ADD(...) do { snprintf(b, sizeof(b), __VA_ARGS__); o += b; } while (0)
-    ADD("#define FEW_PLAN { %d, %d, %d, %d, {}, { ", P.ncols, P.npred, P.nagg, P.logic);
+    ADD("#define RTC_PLAN { %d, %d, %d, %d, {}, { ", P.ncols, P.npred, P.nagg, P.logic);
     for (int i = 0; i < P.npred; i++) {
         const bool cnan = P.preds[i].rhs_col < 0 && P.preds[i].dom_f64 && (P.preds[i].rhs_bits & 0x7FF0000000000000ULL) == 0x7FF0000000000000ULL && (P.preds[i].rhs_bits & 0x000FFFFFFFFFFFFFULL) != 0;
         ADD("{ %d, %d, %d, %d, %d, %d, %s }, ", P.preds[i].col, P.preds[i].rhs_col, P.preds[i].op, P.preds[i].dom_f64, P.preds[i].lhs_cvt, P.preds[i].rhs_cvt,
@@ -93,9 +93,11 @@ static void plan_text(const Plan &P, const GroupArgs &G, std::string &o) {
         o += "} }, ";
     }
     o += "} }\n";
-    ADD("#define FEW_KEY_IDX %d\n#define FEW_NKEYS %d\n#define FEW_KIDX { ", G.key_idx, G.nkeys);
-    for (int i = 0; i < G.nkeys; i++) ADD("%d, ", G.kidx[i]);
-    o += "}\n";
+    if (G) {
+        ADD("#define FEW_KEY_IDX %d\n#define FEW_NKEYS %d\n#define FEW_KIDX { ", G->key_idx, G->nkeys);
+        for (int i = 0; i < G->nkeys; i++) ADD("%d, ", G->kidx[i]);
+        o += "}\n";
+    }
 #undef ADD
 }
 
@@ -128,6 +130,56 @@ static hipFunction_t build(const std::string &src, const char *name) {
     return fn; // (the module lives as long as the process: a handful of plans)
 }
 
+// the kernel of a generated text: from the cache, or compiled now if the plan has come back often enough over enough rows
+static hipFunction_t plan_kernel(const std::string &sig, const std::string &src, const char *name, i64 nrows, const char *what) {
+    if (!g_cache) g_cache = new std::map<std::string, hipFunction_t>();
+    auto it = g_cache->find(sig);
+    if (it != g_cache->end()) return it->second;
+    // Compiling takes seconds: only a plan that comes back, over enough rows for the faster kernel to matter, is worth it.  The
+    // first occurrence (and any small input) runs the prebuilt kernel.  RFX_RTC_EAGER=1: compile at first sight (tests).
+    static std::map<std::string, int> *seen;
+    if (!seen) seen = new std::map<std::string, int>();
+    const int times = ++(*seen)[sig];
+    if (!getenv("RFX_RTC_EAGER") && (times < 2 || nrows < (1LL << 24))) return NULL;
+    if (trace()) fprintf(stderr, "[rfx] rtc: compiling %s ...\n", what);
+    hipFunction_t fn = build(src, name);
+    g_compiles++;
+    (*g_cache)[sig] = fn;
+    if (trace()) fprintf(stderr, "[rfx] rtc: %s\n", fn ? "ready" : "not available for this plan: the prebuilt kernel runs");
+    return fn;
+}
+
+// K1 for one plan: rfx_scalar_kernel.hpp's body with the plan's descriptors as a constexpr (every kind / column / operator test
+// folds away).  *na_stride = accumulator slots per workgroup in ws (k_filter_aggr_final reads them).
+int rfx_rtc_filter_aggr(rfx_ctx *c, const Plan &P, int grid, void *ws, int *na_stride) {
+    if (P.nagg < 1 || (c->flags & RFX_TUNE_NO_RTC) || !rtc_ready()) return RFX_ESTATE;
+    bool deep = false;
+    for (int i = 0; i < P.nx; i++) deep |= P.xs[i].nops > 1;
+    const int nc = P.ncols < 1 ? 1 : P.ncols;
+    const int u = nc <= 4 ? 4 : (nc <= 6 ? 2 : 1);
+    char head[256];
+    snprintf(head, sizeof(head), "#define FA_NC %d\n#define FA_NA %d\n#define FA_U %d\n#define FA_NP %d\n#define FA_NX %d\n#define FA_DEEP %s\n", nc, P.nagg, u, P.npred, P.nx,
+             deep ? "true" : "false");
+    std::string cond;
+    plan_text(P, NULL, cond);
+    const std::string sig = std::string(head) + cond;
+    const std::string src = sig +
+                            "#include \"rfx_scalar_kernel.hpp\"\n"
+                            "extern \"C\" __global__ __launch_bounds__(RFX_BLOCK) void k_filter_aggr_plan(const Plan P0, Acc *__restrict__ ws) {\n"
+                            "    constexpr Plan D = RTC_PLAN;\n"
+                            "    filter_aggr_body<FA_NC, FA_NA, FA_U, FA_NP, FA_NX, FA_DEEP>(D, P0, ws);\n"
+                            "}\n";
+    hipFunction_t fn = plan_kernel(sig, src, "k_filter_aggr_plan", P.nrows, "a fused filter + aggregate kernel for this plan");
+    if (!fn) return RFX_ESTATE;
+    Plan Pv = P;
+    void *wsv = ws;
+    void *args[] = {&Pv, &wsv};
+    RFX_HIP_CHECK(hipModuleLaunchKernel(fn, (unsigned)grid, 1, 1, RFX_BLOCK, 1, 1, 0, c->stream, args, NULL));
+    g_launches++;
+    *na_stride = P.nagg + 1;
+    return RFX_OK;
+}
+
 int rfx_rtc_group_few(rfx_ctx *c, const Plan &P, const GroupArgs &G, int grid) {
     if (G.range < 1 || G.range > RFX_FEW_MAX_GROUPS || P.nagg < 1 || P.nrows >= (1LL << 32)) return RFX_ESTATE;
     if (!rtc_ready()) return RFX_ESTATE;
@@ -138,26 +190,10 @@ int rfx_rtc_group_few(rfx_ctx *c, const Plan &P, const GroupArgs &G, int grid) {
     snprintf(head, sizeof(head), "#define FEW_NC %d\n#define FEW_NA %d\n#define FEW_NG %d\n#define FEW_NPT %d\n#define FEW_U %d\n#define FEW_FMA %d\n", P.ncols, P.nagg, (int)G.range, npt, u,
              getenv("RFX_FEW_NO_FMA") ? atoi(getenv("RFX_FEW_NO_FMA")) : 1); // development: 0 = selects instead of the masked fma
     std::string cond;
-    plan_text(P, G, cond);
+    plan_text(P, &G, cond);
     const std::string sig = std::string(head) + cond;
-    if (!g_cache) g_cache = new std::map<std::string, hipFunction_t>();
-    auto it = g_cache->find(sig);
-    hipFunction_t fn;
-    if (it != g_cache->end()) fn = it->second;
-    else {
-        // Compiling takes seconds: only a plan that comes back, over enough rows for the faster kernel to matter, is worth it.  The
-        // first occurrence (and any small input) runs the prebuilt kernel.  RFX_RTC_EAGER=1: compile at first sight (tests).
-        static std::map<std::string, int> *seen;
-        if (!seen) seen = new std::map<std::string, int>();
-        const int times = ++(*seen)[sig];
-        if (!getenv("RFX_RTC_EAGER") && (times < 2 || P.nrows < (1LL << 24))) return RFX_ESTATE;
-        const std::string src = std::string(head) + cond + "#include \"rfx_group_few_rtc.hpp\"\n";
-        if (trace()) fprintf(stderr, "[rfx] rtc: compiling a kernel for this plan (%d columns, %d aggregates, %d groups) ...\n", P.ncols, P.nagg, (int)G.range);
-        fn = build(src, "k_group_few");
-        g_compiles++;
-        (*g_cache)[sig] = fn;
-        if (trace()) fprintf(stderr, "[rfx] rtc: %s\n", fn ? "ready" : "not available for this plan: the prebuilt kernel runs");
-    }
+    const std::string src = std::string(head) + cond + "#include \"rfx_group_few_rtc.hpp\"\n";
+    hipFunction_t fn = plan_kernel(sig, src, "k_group_few", P.nrows, "a register-accumulator group-by kernel for this plan");
     if (!fn) return RFX_ESTATE;
     Plan Pv = P;
     GroupArgs Gv = G;

@@ -86,6 +86,7 @@ int rfx_run_filter_aggr(rfx_ctx *c, Plan &P, rfx_partial_t *d_out) {
     Acc *ws = (Acc *)c->d_ws;
     int na_stride = 0;
     RFX_KERNEL_BEGIN(c);
+    if (rfx_rtc_filter_aggr(c, P, grid, ws, &na_stride) == RFX_OK) goto launched; // this plan has a kernel of its own (rfx_rtc.hip)
     switch (P.ncols) {
         case 0:
         case 1: rfx_launch_filter_aggr_nc1(c, P, grid, ws, &na_stride); break;
@@ -97,6 +98,7 @@ int rfx_run_filter_aggr(rfx_ctx *c, Plan &P, rfx_partial_t *d_out) {
         case 7: rfx_launch_filter_aggr_nc7(c, P, grid, ws, &na_stride); break;
         default: rfx_launch_filter_aggr_nc8(c, P, grid, ws, &na_stride); break;
     }
+launched:
     RFX_KERNEL_END(c);
     RFX_HIP_CHECK(hipGetLastError());
     hipLaunchKernelGGL(k_filter_aggr_final, dim3(1), dim3(RFX_BLOCK), 0, c->stream, P, (const Acc *)ws, grid, na_stride, d_out);

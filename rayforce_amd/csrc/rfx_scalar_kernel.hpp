@@ -460,14 +460,20 @@ __device__ __forceinline__ void fold_tile(const PredSet<NP> &S, const AggR (&ag)
 }
 
 // Workgroup partial layout in the workspace: ws[(block * (NA + 1) + a)] ; slot NA = selected-row count.
-template <int NC, int NA, int U, int NP, int NX = 0, bool DEEP = false>
-__global__ __launch_bounds__(RFX_BLOCK) void k_filter_aggr(const Plan P, Acc *__restrict__ ws) {
+// D: the plan's DESCRIPTORS (which columns, predicates, aggregates, expressions), R: its run-time values (column pointers, row
+// counts, the predicates' atoms).  The prebuilt kernels pass one plan for both; a kernel compiled at run time for one plan
+// (rfx_rtc.hip) passes a constexpr D, which turns every descriptor test below into a constant.
+template <int NC, int NA, int U, int NP, int NX, bool DEEP>
+__device__ __forceinline__ void filter_aggr_body(const Plan &D, const Plan &R, Acc *__restrict__ ws) {
+    const Plan &P = D;
     constexpr int E = 2 * U;
     constexpr int TILE = RFX_BLOCK * E;     // rows per workgroup per iteration
     constexpr int JSTRIDE = RFX_BLOCK * 2;  // row distance between the U loads of one lane
     const int tid = threadIdx.x;
     PredSet<NP> S;
     predset_load<NP>(P, S);
+#pragma unroll
+    for (int i = 0; i < NP; i++) S.p[i].rhs = R.preds[i].rhs_bits;
     AggR ag[NA];
     Acc acc[NA];
     i64 nsel = 0; // wave-uniform
@@ -480,8 +486,8 @@ __global__ __launch_bounds__(RFX_BLOCK) void k_filter_aggr(const Plan P, Acc *__
     }
     const u64 *cols[NC];
 #pragma unroll
-    for (int c = 0; c < NC; c++) cols[c] = P.cols[c];
-    const i64 nrows = P.nrows, row0 = P.row0;
+    for (int c = 0; c < NC; c++) cols[c] = R.cols[c];
+    const i64 nrows = R.nrows, row0 = R.row0;
     PlanExpr xs[NX > 0 ? NX : 1]; // expression descriptors, hoisted like the others (static indices only)
 #pragma unroll
     for (int i = 0; i < (NX > 0 ? NX : 1); i++) xs[i] = P.xs[i];
@@ -555,7 +561,14 @@ __global__ __launch_bounds__(RFX_BLOCK) void k_filter_aggr(const Plan P, Acc *__
     }
 }
 
+template <int NC, int NA, int U, int NP, int NX = 0, bool DEEP = false>
+__global__ __launch_bounds__(RFX_BLOCK) void k_filter_aggr(const Plan P, Acc *__restrict__ ws) {
+    filter_aggr_body<NC, NA, U, NP, NX, DEEP>(P, P, ws);
+}
+
+#ifndef __HIPCC_RTC__
 // one launcher per distinct-column count, defined in rfx_scalar_nc.hip compiled with -DRFX_NC=<n>
 #define RFX_DECL_LAUNCH(n) int rfx_launch_filter_aggr_nc##n(rfx_ctx *c, const Plan &P, int grid, Acc *ws, int *na_stride);
 RFX_DECL_LAUNCH(1) RFX_DECL_LAUNCH(2) RFX_DECL_LAUNCH(3) RFX_DECL_LAUNCH(4)
 RFX_DECL_LAUNCH(5) RFX_DECL_LAUNCH(6) RFX_DECL_LAUNCH(7) RFX_DECL_LAUNCH(8)
+#endif
