@@ -48,32 +48,6 @@ __device__ __forceinline__ void sel_chunk_load(const Plan &P, i64 q, int lane, u
         }
     }
 }
-template <int NC>
-__device__ __forceinline__ void sel_chunk_load_full(const Plan &P, i64 q, int lane, u64 (&v)[NC][8]) {
-    const i64 base = q * RFX_CHUNK + lane * 2;
-#pragma unroll
-    for (int c = 0; c < NC; c++) {
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            u64x2 t = rfx_ld2(P.cols[c] + base + j * 128);
-            v[c][2 * j] = t.x;
-            v[c][2 * j + 1] = t.y;
-        }
-    }
-}
-template <int NC, int NP>
-__device__ __forceinline__ u64 sel_chunk_words_full(const PredSet<NP> &S, int lane, int lane_off, const u64 (&v)[NC][8], u64 mine) {
-    bool valid[8], sel[8];
-#pragma unroll
-    for (int e = 0; e < 8; e++) valid[e] = true;
-    eval_sel<NC, 8, NP>(S, v, valid, sel);
-#pragma unroll
-    for (int e = 0; e < 8; e++) {
-        const u64 b = __ballot(sel[e]);
-        mine = (lane == e + lane_off) ? b : mine;
-    }
-    return mine;
-}
 template <int NC, int NP>
 __device__ __forceinline__ u64 sel_chunk_words(const PredSet<NP> &S, int lane, int lane_off, const u64 (&v)[NC][8], const bool (&valid)[8], u64 mine) {
     bool sel[8];
@@ -103,42 +77,7 @@ __global__ __launch_bounds__(RFX_BLOCK) void k_sel_bitmap(const Plan P, u64 *__r
     // 64 words leave as ONE 512-byte store (eight pairs with two stores per step: slower again, 1.59 ms).  Stores share the vector-memory counter with the loads the wave waits on: with one
     // 128-byte store per pair the pass took 1.53 ms, without any store 1.21 ms (measured) -- so store rarely, and whole.
     const i64 nquads = (nchunks + 7) / 8;
-    // Whole steps (all eight chunks inside the column) first, with their loads unconditional and the PREVIOUS step's store issued
-    // right after this step's first loads: the wait for those loads is then vmcnt(1) -- the store stays in flight -- where a store
-    // issued before them has to land first (in-order counter), once per step.  A load or a store under a condition would make the
-    // compiler assume the shorter path and wait with vmcnt(0) again, hence the peeled first step and the separate ragged loop below.
-    const i64 full_quads = P.nrows / (8 * RFX_CHUNK);
-    i64 p4 = wave_id;
-    if (p4 < full_quads) {
-        u64 pend = 0;
-        {
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                u64 v0[NC][8], v1[NC][8];
-                sel_chunk_load_full<NC>(P, 8 * p4 + 2 * i, lane, v0);
-                sel_chunk_load_full<NC>(P, 8 * p4 + 2 * i + 1, lane, v1);
-                pend = sel_chunk_words_full<NC, NP>(S, lane, 16 * i, v0, pend);
-                pend = sel_chunk_words_full<NC, NP>(S, lane, 16 * i + 8, v1, pend);
-            }
-        }
-        i64 pend_at = p4;
-        for (p4 += nwaves; p4 < full_quads; p4 += nwaves) {
-            u64 mine = 0;
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                u64 v0[NC][8], v1[NC][8];
-                sel_chunk_load_full<NC>(P, 8 * p4 + 2 * i, lane, v0);
-                sel_chunk_load_full<NC>(P, 8 * p4 + 2 * i + 1, lane, v1);
-                if (i == 0) bitmap[pend_at * 64 + lane] = pend;
-                mine = sel_chunk_words_full<NC, NP>(S, lane, 16 * i, v0, mine);
-                mine = sel_chunk_words_full<NC, NP>(S, lane, 16 * i + 8, v1, mine);
-            }
-            pend = mine;
-            pend_at = p4;
-        }
-        bitmap[pend_at * 64 + lane] = pend;
-    }
-    for (p4 = full_quads + ((wave_id + nwaves - (full_quads % nwaves)) % nwaves); p4 < nquads; p4 += nwaves) { // the last, ragged step(s)
+    for (i64 p4 = wave_id; p4 < nquads; p4 += nwaves) {
         u64 mine = 0;
 #pragma unroll
         for (int i = 0; i < 4; i++) {
