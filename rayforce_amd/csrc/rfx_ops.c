@@ -45,10 +45,10 @@ static struct {
     /* the host's own built-ins, for recognising function objects inside parsed expressions and for delegation */
     void *f[32];
 } H;
-enum { F_SUM, F_AVG, F_MIN, F_MAX, F_COUNT, F_FIRST, F_EQ, F_NE, F_LT, F_GT, F_LE, F_GE, F_AND, F_OR, F_SELECT, F_ADD, F_SUB, F_MUL, F_FDIV, F_XBAR, F_LJ, F_IJ, F_UPDATE, F_N };
+enum { F_SUM, F_AVG, F_MIN, F_MAX, F_COUNT, F_FIRST, F_EQ, F_NE, F_LT, F_GT, F_LE, F_GE, F_AND, F_OR, F_SELECT, F_ADD, F_SUB, F_MUL, F_FDIV, F_XBAR, F_LJ, F_IJ, F_UPDATE, F_TAKE, F_N };
 static const char *HOST_FN[F_N] = {"ray_sum", "ray_avg", "ray_min", "ray_max", "ray_count", "ray_first", "ray_eq",  "ray_ne",  "ray_lt",  "ray_gt",
                                    "ray_le",  "ray_ge",  "ray_and", "ray_or",  "ray_select", "ray_add",  "ray_sub", "ray_mul", "ray_fdiv", "ray_xbar",
-                                   "ray_left_join", "ray_inner_join", "ray_update"};
+                                   "ray_left_join", "ray_inner_join", "ray_update", "ray_take"};
 /* xbar is recognised inside `by:` only; the standalone object model still needs a distinct function object for it:
  * this stub is never called by this library. */
 static obj_p x_stub_xbar(obj_p a, obj_p b) { (void)a; (void)b; return NULL; }
@@ -744,7 +744,9 @@ static obj_p select_impl(obj_p dict) {
     if (!dict || dict->type != RFX_TYPE_DICT || RFX_AS_LIST(dict)[0]->type != RFX_TYPE_SYMBOL) return fail("select: expected a dict");
     obj_p from = dict_get(dict, "from");
     if (!from) return fail("'select' expects 'from' param"); /* core/query.c:281 */
-    if (dict_get(dict, "take")) return delegate_select(dict, "take:");
+    /* take: is applied to the finished result table (ray_take(res, take), core/query.c:294-303,596-599): by the host's own ray_take */
+    obj_p take = dict_get(dict, "take");
+    if (take && !(H.bound == 1 && H.f[F_TAKE])) return delegate_select(dict, "take: without the host's ray_take");
     obj_p host_tab = H.eval(from);
     if (!host_tab || host_tab->type == RFX_TYPE_ERR) return host_tab;
     obj_p tab = host_tab; /* the table the plan reads: host_tab itself, or the view of a parted table */
@@ -755,7 +757,7 @@ static obj_p select_impl(obj_p dict) {
     int ntmp = 0;
     obj_p where = dict_get(dict, "where"), by = dict_get(dict, "by");
     obj_p dkeys = RFX_AS_LIST(dict)[0], dvals = RFX_AS_LIST(dict)[1];
-    int64_t s_from = H.intern("from", 4), s_where = H.intern("where", 5), s_by = H.intern("by", 2);
+    int64_t s_from = H.intern("from", 4), s_where = H.intern("where", 5), s_by = H.intern("by", 2), s_take = H.intern("take", 4);
     if (tab->type != RFX_TYPE_TABLE) { why = "from: is not a table"; goto out; }
     if (ensure_ctx() != RFX_OK) { res = fail_hip("no usable MI355X"); goto done; }
     if (is_parted_table(host_tab)) {
@@ -794,7 +796,7 @@ static obj_p select_impl(obj_p dict) {
         int nagg = 0;
         for (int64_t i = 0; i < dkeys->len; i++) {
             int64_t k = RFX_AS_I64(dkeys)[i];
-            if (k == s_from || k == s_where || k == s_by) continue;
+            if (k == s_from || k == s_where || k == s_by || k == s_take) continue;
             obj_p e = RFX_AS_LIST(dvals)[i];
             if (nagg >= RFX_MAX_AGGS || e->type != RFX_TYPE_LIST || e->len != 2) { why = "mapping shape"; goto out; }
             int f = fn_id(RFX_AS_LIST(e)[0]);
@@ -1239,6 +1241,18 @@ done:
     free((void *)g_mirror_host);
     g_mirror_host = NULL;
     H.drop(host_tab);
+    if (take && g_last_gpu && res && res->type == RFX_TYPE_TABLE) { /* (a delegated query had its take: applied by ray_select) */
+        obj_p tv = H.eval(take);
+        if (tv && tv->type != RFX_TYPE_ERR) {
+            obj_p cut = ((rfx_binary_f)H.f[F_TAKE])(res, tv);
+            H.drop(res);
+            res = cut;
+        } else {
+            H.drop(res);
+            res = tv;
+        }
+        if (tv && res != tv) H.drop(tv);
+    }
     return res;
 }
 rfx_obj_p rfx_select(rfx_obj_p dict) {

@@ -40,6 +40,9 @@ QUERIES = [
     ("q17", "{s: (sum v) c: (count a) from: t where: (> (* a v) 250000.0)}", ["s", "c"]),
     ("q18", "{s: (sum v) m: (max a) from: t where: (and (< (+ v v) 0.6) (> a 1000) (<= (- a (* k2 1000)) a)) by: k1}", ["k1", "s", "m"]),
     ("q19", "{c: (count a) from: t where: (or (== (div a 1000) 7) (and (> (* v 2.0) 1.5) (!= k3 3)))}", ["c"]),
+    # take: cuts the finished result (ray_take on the result table, core/query.c:294-303,596-599): first rows, and -- negative -- last rows
+    ("q20", "{s: (sum v) c: (count a) from: t by: k take: 7}", ["k", "s", "c"]),
+    ("q21", "{m: (max a) from: t where: (< a 500000) by: k1 take: -3}", ["k1", "m"]),
 ]
 
 
