@@ -878,8 +878,13 @@ static obj_p select_impl(obj_p dict) {
                     key_out_type = RFX_TYPE_SYMBOL;
                     continue;
                 }
-                /* index_group's 8-byte integer arms: I64 / SYMBOL / TIMESTAMP group on the raw i64 (core/index.c:2183-2186) */
-                if (!kcs[i] || !(kcs[i]->type == RFX_TYPE_I64 || kcs[i]->type == RFX_TYPE_SYMBOL || kcs[i]->type == RFX_TYPE_TIMESTAMP)) {
+                /* index_group's 8-byte integer arms: I64 / SYMBOL / TIMESTAMP group on the raw i64 (core/index.c:2183-2186); an F64 key
+                 * column groups on its BIT PATTERN through the open-addressing path (index_group_f64 = index_group_i64_unscoped,
+                 * core/index.c:2108,1959-1977): the same device column read as i64 -- a range of bit patterns is never dense, so the
+                 * hashed tables take it here too; -0.0 has the bits of NULL_I64, the reference's empty-slot marker: handed back like
+                 * any null key.  One key column only (several keys with an f64 among them are the host's). */
+                const int f64key = kcs[i] && kcs[i]->type == RFX_TYPE_F64 && nkeys == 1 && !kxbar[i] && !parted;
+                if (!kcs[i] || !(kcs[i]->type == RFX_TYPE_I64 || kcs[i]->type == RFX_TYPE_SYMBOL || kcs[i]->type == RFX_TYPE_TIMESTAMP || f64key)) {
                     why = "by: key is not an 8-byte integer column";
                     goto out;
                 }

@@ -43,6 +43,9 @@ QUERIES = [
     # take: cuts the finished result (ray_take on the result table, core/query.c:294-303,596-599): first rows, and -- negative -- last rows
     ("q20", "{s: (sum v) c: (count a) from: t by: k take: 7}", ["k", "s", "c"]),
     ("q21", "{m: (max a) from: t where: (< a 500000) by: k1 take: -3}", ["k1", "m"]),
+    # an f64 key column groups on its bit pattern (index_group_f64 -> the open-addressing path, core/index.c:2108): here on the hashed tables
+    ("q22", "{c: (count a) s: (sum a) from: t by: vq}", ["vq", "c", "s"]),
+    ("q23", "{m: (max v) from: t where: (< a 300000) by: vq}", ["vq", "m"]),
 ]
 
 
@@ -55,7 +58,7 @@ UPDATES = [
     ("u6", "{n: 100 from: t}", ["n", "k"]),
 ]
 
-UNORDERED = {"q13": 1, "q16": 3}  # name -> leading key columns: group order there depends on the reference's executor count
+UNORDERED = {"q13": 1, "q16": 3, "q22": 1, "q23": 1}  # name -> leading key columns: group order there depends on the reference's executor count
 
 
 @pytest.mark.skipif(not ref.available(), reason="oracle/_ref/rayforce not built (needs /root/reference at build time)")
@@ -66,7 +69,8 @@ def test_plugin_inside_the_real_reference(built):
     n = 300_007
     cols = {"k": rfo.gen_i64(n, 4, 5000), "a": rfo.gen_i64(n, 2, 1_000_000), "v": rfo.gen_f64(n, 5),
             "k1": rfo.gen_i64(n, 14, 7), "k2": rfo.gen_i64(n, 15, 11) + 100, "k3": rfo.gen_i64(n, 16, 50) - 25,
-            "w1": rfo.gen_i64(n, 17, 50) * (1 << 50), "w2": rfo.gen_i64(n, 18, 40) * (1 << 45) - (1 << 50)}
+            "w1": rfo.gen_i64(n, 17, 50) * (1 << 50), "w2": rfo.gen_i64(n, 18, 40) * (1 << 45) - (1 << 50),
+            "vq": np.round(rfo.gen_f64(n, 19) * 400.0) / 8.0 - 20.0}  # 401 distinct f64 values, negative ones and +0.0 among them
     with ref.Session() as s:
         s.table("t", cols)
         s.eval(f'(set gsel (loadfn "{LIB}" "rfx_select" 1))')
@@ -83,9 +87,9 @@ def test_plugin_inside_the_real_reference(built):
         s.eval("(set r_nest (select {s: (sum a) from: t where: (and (or (< a 1000) (> v 0.9)) (!= k 3))}))")
         s.out("g_nest_s", "(at g_nest 's)")
         s.out("r_nest_s", "(at r_nest 's)")
-        # ... and a shape the GPU path does not cover (f64 group key) is handed back to the host's own ray_select by the plugin
-        s.eval("(set g_del (gsel {c: (count a) from: t by: v}))")
-        s.eval("(set r_del (select {c: (count a) from: t by: v}))")
+        # ... and a shape the GPU path does not cover (an f64 column among several keys) is handed back to the host's own ray_select by the plugin
+        s.eval("(set g_del (gsel {c: (count a) from: t by: {x: v y: k1}}))")
+        s.eval("(set r_del (select {c: (count a) from: t by: {x: v y: k1}}))")
         s.out("g_del_n", "(enlist (count (at g_del 'c)))")
         s.out("r_del_n", "(enlist (count (at r_del 'c)))")
         # joins: the plugin's vary_f entry points beside the reference's own left-join / inner-join (typed columns compared: the
@@ -153,7 +157,7 @@ def test_plugin_inside_the_real_reference(built):
     assert np.array_equal(res["g_nest_s"], res["r_nest_s"])
     assert np.array_equal(res["g_del_n"], res["r_del_n"])
     # every query above was answered by the device path -- not vacuously by a silent hand-back to ray_select -- except the one
-    # shape that is delegated on purpose (f64 key); all four joins ran on the device.  (Null group keys are delegated too -- the
+    # shape that is delegated on purpose (an f64 column among several keys); all four joins ran on the device.  (Null group keys are delegated too -- the
     # reference's one-group-per-null-row rule is not reproduced -- but the reference itself panics in its heap on every single-key
     # group-by over a key column with nulls (2 003 .. 300 007 rows, -c 1 and -c 8), so that hand-back is asserted in standalone mode.)
     st = res["stats"]

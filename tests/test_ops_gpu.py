@@ -164,7 +164,7 @@ def test_nested_tree_and_projection(ops):
 def test_unsupported_shape_fails_loudly_without_host(ops):
     host = host_table(100)
     with pytest.raises(RuntimeError, match="not covered by the MI355X path"):
-        run_select(ops, host, {"s": ("sum", "a"), "by": "v"})  # f64 group key: the reference host would take it
+        run_select(ops, host, {"s": ("sum", "a"), "by": {"x": "v", "y": "k"}})  # an f64 column among several keys: the reference host would take it
     assert ops.rfx_last_select_on_gpu() == 0
 
 
