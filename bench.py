@@ -53,14 +53,14 @@ def log(*a):
 
 WORKLOADS = {
     "c1": dict(desc="configs[0]: (sum v), v f64[1e7] uniform [0,1), seed 1 -- the reference's `make bench` plumbing case, here on the GPU", rows=10_000_000,
-               bytes_per_row=8, dtype="f64", kernel="k_filter_aggr<1, 1, 4, 1, 0, false>"),
+               bytes_per_row=8, dtype="f64", kernel="k_filter_aggr_plan (K1 compiled at run time for the plan; prebuilt k_filter_aggr<1, 1, 4, 1, 0, false> without hiprtc)"),
     "c2": dict(desc="configs[1]: select sum(a) where a < 100000, a i64 uniform [0,1e6), seed 2", rows=1_000_000_000, bytes_per_row=8, dtype="int64",
-               kernel="k_filter_aggr<1, 1, 4, 1, 0, false>"),
+               kernel="k_filter_aggr_plan (K1 compiled at run time for the plan; prebuilt k_filter_aggr<1, 1, 4, 1, 0, false> without hiprtc)"),
     "c2_1pct": dict(desc="C2 at 1 % selectivity (a < 10000) -- SURVEY 8d asks for 1 / 10 / 50 %", rows=1_000_000_000, bytes_per_row=8, dtype="int64",
-                    kernel="k_filter_aggr<1, 1, 4, 1, 0, false>"),
-    "c2_50pct": dict(desc="C2 at 50 % selectivity (a < 500000)", rows=1_000_000_000, bytes_per_row=8, dtype="int64", kernel="k_filter_aggr<1, 1, 4, 1, 0, false>"),
+                    kernel="k_filter_aggr_plan (K1 compiled at run time for the plan; prebuilt k_filter_aggr<1, 1, 4, 1, 0, false> without hiprtc)"),
+    "c2_50pct": dict(desc="C2 at 50 % selectivity (a < 500000)", rows=1_000_000_000, bytes_per_row=8, dtype="int64", kernel="k_filter_aggr_plan (K1 compiled at run time for the plan; prebuilt k_filter_aggr<1, 1, 4, 1, 0, false> without hiprtc)"),
     "c2b": dict(desc="north-star: select sum(b) where a < 100000, a i64 seed 2, b f64 seed 3", rows=1_000_000_000, bytes_per_row=16, dtype="f64",
-                kernel="k_filter_aggr<2, 1, 4, 1, 0, false>"),
+                kernel="k_filter_aggr_plan (K1 compiled at run time for the plan; prebuilt k_filter_aggr<2, 1, 4, 1, 0, false> without hiprtc)"),
     "c3": dict(desc="configs[2]: select sum(v) by k, k i64 uniform [0,1e6) seed 4, v f64 seed 5", rows=1_000_000_000, bytes_per_row=16, dtype="f64",
                kernel="k_chunk_scatter<2, 0> (scope + partition in one pass) + k_chunk_aggregate<512>"),
     "c3w": dict(desc="metric shape filter->group-by->sum: select sum(v) by k where a < 100000 (10 %), k/v as C3, a as C2", rows=1_000_000_000,
@@ -71,7 +71,7 @@ WORKLOADS = {
                     "id3,id6 i64 uniform [0,1e6) seeds 20-25, v f64 seed 5 (ranges multiply to 1e20 > 2^63; ~1e8 groups)", rows=100_000_000,
                bytes_per_row=56, dtype="f64", kernel="k_row_hash<6> + k_group_hash<2> (device-wide table) + k_join_probe_hash + 6 x (k_gather_or, compare): tuple proof at the groups' first rows + k_group_emit_by_group"),
     "x6": dict(desc="expression aggregate (TPC-H Q6 shape): select sum(p * d) where q < 24 and d >= 0.05 and d <= 0.07; p f64 seed 12, d f64 seed 13 "
-                    "scaled to [0,0.1), q i64 uniform [0,50) seed 14", rows=1_000_000_000, bytes_per_row=24, dtype="f64", kernel="k_filter_aggr<3, 1, 4, 4, 1, false>"),
+                    "scaled to [0,0.1), q i64 uniform [0,50) seed 14", rows=1_000_000_000, bytes_per_row=24, dtype="f64", kernel="k_filter_aggr_plan (K1 compiled at run time for the plan; prebuilt k_filter_aggr<3, 1, 4, 4, 1, false> without hiprtc)"),
     "q1": dict(desc="nested expressions (TPC-H Q1 shape): sum(q), sum(p), sum(p*(1-d)), sum(p*(1-d)*(1+t)), avg(q), avg(p), avg(d), count by {rf, ls} "
                     "where sd <= 2400; rf in [0,3), ls in [0,2), q i64 [1,50], p f64, d f64 [0,.1), t f64 [0,.08), sd i64 [0,2500)", rows=1_000_000_000,
                bytes_per_row=56, dtype="f64", kernel="k_filter_aggr<3, 4, 4, 1, 0, false> (both key scopes) + k_group_few (compiled at run time for the plan: register accumulators per (aggregate, group); prebuilt k_group_dense<7, true, 256, true, 2> without hiprtc)"),
@@ -84,7 +84,7 @@ WORKLOADS = {
     "g2": dict(desc="gather: (at b ids) for the 1e8 ids of w2 (8 B id + 8 B random read + 8 B write per id)", rows=1_000_000_000, bytes_per_row=2.4,
                dtype="f64", kernel="k_gather8"),
     "c5": dict(desc="configs[4]: avg,min,max(d) where a<0.316228 and b>0.683772 and c!=0.25, 4 x f64[2e9] seeds 6-9 (64 GB: 2.5e8 rows per GPU at 8)", rows=2_000_000_000,
-               bytes_per_row=32, dtype="f64", kernel="k_filter_aggr<4, 4, 4, 4, 0, false>"),
+               bytes_per_row=32, dtype="f64", kernel="k_filter_aggr_plan (K1 compiled at run time for the plan; prebuilt k_filter_aggr<4, 4, 4, 4, 0, false> without hiprtc)"),
 }
 
 
