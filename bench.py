@@ -62,7 +62,7 @@ WORKLOADS = {
     "c2b": dict(desc="north-star: select sum(b) where a < 100000, a i64 seed 2, b f64 seed 3", rows=1_000_000_000, bytes_per_row=16, dtype="f64",
                 kernel="k_filter_aggr_plan (K1 compiled at run time for the plan; prebuilt k_filter_aggr<2, 1, 4, 1, 0, false> without hiprtc)"),
     "c3": dict(desc="configs[2]: select sum(v) by k, k i64 uniform [0,1e6) seed 4, v f64 seed 5", rows=1_000_000_000, bytes_per_row=16, dtype="f64",
-               kernel="k_chunk_scatter<2, 0> (scope + partition in one pass) + k_chunk_aggregate<512>"),
+               kernel="k_chunk_scatter_bin<2, 0> (scope + partition in one pass; k_chunk_scatter<2, 0> for skewed keys) + k_chunk_aggregate<512>"),
     "c3w": dict(desc="metric shape filter->group-by->sum: select sum(v) by k where a < 100000 (10 %), k/v as C3, a as C2", rows=1_000_000_000,
                 bytes_per_row=24, dtype="f64", kernel="k_chunk_scatter_bin<3, 1> (filter + scope + partition in one pass) + k_chunk_aggregate<512>"),
     "q2": dict(desc="several by: columns (H2O Q2 shape): select sum(v) by {id1, id2}, id1/id2 i64 uniform [0,100) seeds 10/11, v f64 seed 5", rows=1_000_000_000,
