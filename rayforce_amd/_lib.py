@@ -6,6 +6,7 @@ import os
 
 RFX_OK = 0
 RFX_ELIMIT = -5
+RFX_ESTATE = -6
 RFX_B8, RFX_I64, RFX_F64 = 1, 5, 10
 RFX_EQ, RFX_NE, RFX_LT, RFX_GT, RFX_LE, RFX_GE = range(6)
 RFX_AND, RFX_OR = 0, 1
@@ -145,6 +146,9 @@ PROTOTYPES = {
     "rfx_hip_group_dense_accumulate": (C.c_int, [_ctx, C.c_void_p, _P(Pred), C.c_int, C.c_int, _P(Agg), C.c_int64, C.c_int64, _P(GroupTables)]),
     "rfx_hip_group_rank": (C.c_int, [_ctx, _P(GroupTables), C.c_int64, _P(C.c_int64)]),
     "rfx_hip_group_emit": (C.c_int, [_ctx, _P(Agg), _P(GroupTables), C.c_void_p, C.c_void_p, _P(C.c_void_p)]),
+    "rfx_hip_scope_sample_i64": (C.c_int, [_ctx, C.c_void_p, C.c_int64, _P(C.c_int64), _P(C.c_int64)]),
+    "rfx_hip_ctx_speculative": (C.c_int, [_ctx, C.c_int]),
+    "rfx_hip_group_out_of_scope": (C.c_int, [_ctx, _P(C.c_int)]),
     "rfx_hip_group_rank_emit_small": (C.c_int, [_ctx, _P(Agg), _P(GroupTables), C.c_int64, C.c_int64, C.c_void_p]),
     "rfx_hip_group_emit_sharded": (C.c_int, [_ctx, _P(Agg), _P(GroupTables), C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, _P(C.c_void_p)]),
     "rfx_hip_hash_emit_sharded": (C.c_int, [_ctx, _P(Agg), _P(HashTables), C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, _P(C.c_void_p)]),

@@ -74,6 +74,7 @@ extern "C" int rfx_hip_ctx_destroy(rfx_ctx_t *c) {
     if (c->d_chunk) (void)hipFree(c->d_chunk);
     rfx_io_release(c);
     pool_release(c);
+    if (c->ext_p[1]) (void)hipFree(c->ext_p[1]);
     if (c->d_pc_counts) (void)hipFree(c->d_pc_counts);
     if (c->h_pin) (void)hipHostFree(c->h_pin);
     (void)hipEventDestroy(c->ev0);

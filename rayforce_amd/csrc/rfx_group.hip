@@ -99,21 +99,32 @@ __device__ __forceinline__ void group_dense_body(const Plan &P, const GroupArgs 
         } else {
 #pragma unroll
             for (int e = 0; e < E; e++) key[e] = 0;
+            bool out[E];
+#pragma unroll
+            for (int e = 0; e < E; e++) out[e] = false;
             for (int i = 0; i < G.nkeys; i++) {
                 u64 x[E];
                 if (SW) sel_col_sw<NC, E>(x, v, G.kidx[i]);
                 else sel_col<NC, E>(x, v, G.kidx[i]);
-                const u64 mn = G.kmn[i], mu = G.kmul[i];
+                const u64 mn = G.kmn[i], mu = G.kmul[i], rg = G.krng[i];
 #pragma unroll
-                for (int e = 0; e < E; e++) key[e] += (x[e] - mn) * mu;
+                for (int e = 0; e < E; e++) {
+                    out[e] |= (x[e] - mn) >= rg; // (a key outside its column's range could wrap the composite back into the table)
+                    key[e] += (x[e] - mn) * mu;
+                }
             }
+#pragma unroll
+            for (int e = 0; e < E; e++) key[e] = out[e] ? ~0ULL : key[e];
         }
         // first-occurrence table
 #pragma unroll
         for (int e = 0; e < E; e++) {
             if (!((m >> e) & 1u)) continue;
             const u64 slot = key[e];
-            if (slot >= (u64)range) continue; // outside the agreed scope (cannot happen when scope came from these rows)
+            if (slot >= (u64)range) { // outside the agreed scope: impossible when the scope came from these rows, reported when it was sampled
+                if (G.oob) *(volatile unsigned *)G.oob = 1u;
+                continue;
+            }
             const u64 row = (u64)(P.row0 + base + (i64)(e >> 1) * JSTRIDE + (e & 1));
             if (LDS) {
                 const unsigned lrow = (unsigned)(base + (i64)(e >> 1) * JSTRIDE + (e & 1));
@@ -397,6 +408,9 @@ static int group_dense_run(rfx_ctx_t *c, Plan &P, GroupArgs &G, const rfx_agg_t 
     G.range = t->range;
     G.nagg = t->nagg;
     G.first = (u64 *)t->d_first;
+    G.oob = (unsigned *)c->ext_p[1]; // NULL until rfx_hip_ctx_speculative was called once
+    for (int i = 0; i < G.nkeys; i++) // column i's range from the multipliers (mult_i = product of the ranges before it)
+        G.krng[i] = (i + 1 < G.nkeys) ? (G.kmul[i] ? G.kmul[i + 1] / G.kmul[i] : 0) : (G.kmul[i] ? (u64)t->range / G.kmul[i] : 0);
     int narr = 1;
     for (int a = 0; a < t->nagg; a++) {
         G.acc[a] = (u64 *)t->d_acc[a];
@@ -418,6 +432,7 @@ static int group_dense_run(rfx_ctx_t *c, Plan &P, GroupArgs &G, const rfx_agg_t 
     size_t lds_bytes = lds_table_bytes(tiny ? (t->range << rs) : t->range, aggs, t->nagg);
     const size_t lds_cap = (c->flags & RFX_TUNE_NO_BIG_LDS) ? RFX_LDS_GROUP_BYTES : RFX_LDS_GROUP_BIG_BYTES;
     const bool use_lds = lds_bytes <= lds_cap && !(c->flags & RFX_TUNE_NO_LDS_TABLES) && P.nrows < (1LL << 32);
+    if (c->ext_i[1] && !use_lds) return RFX_ESTATE; // the scope was sampled: only the LDS-table kernels report keys outside it -- take the exact scope
     if (need_materialise) {
         // several keys: fold them on the fly only where the LDS tables make the pass stream; the big-range paths
         // (partitioned, device atomics) want the one materialised key column the reference builds too
@@ -512,6 +527,7 @@ extern "C" int rfx_hip_group_dense_accumulate_keys(rfx_ctx_t *c, const void *con
         G.kmul[i] = (u64)mults[i];
     }
     bool materialise = !fits;
+    if (c->ext_i[1] && !fits) return RFX_ESTATE; // sampled scope and a materialised composite key: not checked, take the exact scope
     if (fits) {
         rc = group_dense_run(c, P, G, aggs, t, false, &materialise);
         if (rc != RFX_OK || !materialise) return rc;
@@ -522,6 +538,88 @@ extern "C" int rfx_hip_group_dense_accumulate_keys(rfx_ctx_t *c, const void *con
     rc = rfx_hip_composite_key(c, d_keys, mins, mults, nkeys, nrows, (int64_t *)c->d_comp);
     if (rc != RFX_OK) return rc;
     return rfx_hip_group_dense_accumulate(c, (const int64_t *)c->d_comp, preds, npred, logic, aggs, nrows, row0, t);
+}
+
+// ---------------- a SAMPLED scope, and the report that keeps it honest ----------------
+// index_scope_i64 (core/index.c:376-435) reads the whole key column to learn [min, max] before it groups: for a key of a few
+// hundred values over 1e9 rows that pass is a quarter to a third of the query.  A strided sample of 2^14 rows plus the first and
+// last 2^11 almost always sees the whole range of such a key; "almost" is made exact by the kernels themselves: a selected row
+// whose key lies outside the agreed scope is REPORTED (GroupArgs::oob) instead of dropped, the host asks rfx_hip_group_out_of_scope
+// after the pass and, if anything was reported (an outlier, a null key, a range the sample missed), runs the exact scope and the
+// pass again.  A sampled range can only be too SMALL (the sample is a subset), so an unreported pass is the exact pass.
+__global__ __launch_bounds__(RFX_BLOCK) void k_scope_sample_i64(const i64 *__restrict__ key, i64 n, i64 stride, i64 nsamp, i64 edge, i64 *__restrict__ out) {
+    __shared__ i64 red[2][RFX_BLOCK / RFX_WAVE];
+    i64 mn = RFX_INF_I64_D, mx = RFX_NULL_I64_D;
+    const i64 total = nsamp + 2 * edge;
+    for (i64 i = blockIdx.x * (i64)RFX_BLOCK + threadIdx.x; i < total; i += (i64)gridDim.x * RFX_BLOCK) {
+        const i64 r = i < nsamp ? i * stride : (i < nsamp + edge ? i - nsamp : n - 1 - (i - nsamp - edge));
+        if (r < 0 || r >= n) continue;
+        const i64 k = key[r];
+        mn = k < mn ? k : mn; // a null key is INT64_MIN: it shows as the minimum
+        mx = k > mx ? k : mx;
+    }
+    for (int s = 32; s >= 1; s >>= 1) {
+        const i64 omn = (i64)rfx_shfl_xor_u64((u64)mn, s), omx = (i64)rfx_shfl_xor_u64((u64)mx, s);
+        mn = omn < mn ? omn : mn;
+        mx = omx > mx ? omx : mx;
+    }
+    if ((threadIdx.x & 63) == 0) {
+        red[0][threadIdx.x >> 6] = mn;
+        red[1][threadIdx.x >> 6] = mx;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < RFX_BLOCK / RFX_WAVE; w++) {
+            mn = red[0][w] < mn ? red[0][w] : mn;
+            mx = red[1][w] > mx ? red[1][w] : mx;
+        }
+        out[2 * blockIdx.x] = mn;
+        out[2 * blockIdx.x + 1] = mx;
+    }
+}
+extern "C" int rfx_hip_scope_sample_i64(rfx_ctx_t *c, const int64_t *d_key, int64_t nrows, int64_t *min, int64_t *max) {
+    RFX_REQUIRE(c && d_key && min && max && nrows > 0, RFX_EINVAL, "bad argument");
+    const int grid = 16;
+    const i64 nsamp = nrows < (1 << 14) ? nrows : (1 << 14), edge = nrows < (1 << 11) ? 0 : (1 << 11);
+    int rc = rfx_ws_reserve(c, (size_t)grid * 16);
+    if (rc != RFX_OK) return rc;
+    hipLaunchKernelGGL(k_scope_sample_i64, dim3(grid), dim3(RFX_BLOCK), 0, c->stream, (const i64 *)d_key, (i64)nrows, (i64)(nrows / nsamp), nsamp, edge, (i64 *)c->d_ws);
+    RFX_HIP_CHECK(hipGetLastError());
+    i64 *h = (i64 *)c->h_pin;
+    RFX_HIP_CHECK(hipMemcpyAsync(h, c->d_ws, (size_t)grid * 16, hipMemcpyDeviceToHost, c->stream));
+    RFX_HIP_CHECK(hipStreamSynchronize(c->stream));
+    i64 mn = RFX_INF_I64_D, mx = RFX_NULL_I64_D;
+    for (int i = 0; i < grid; i++) {
+        mn = h[2 * i] < mn ? h[2 * i] : mn;
+        mx = h[2 * i + 1] > mx ? h[2 * i + 1] : mx;
+    }
+    *min = mn;
+    *max = mx;
+    return RFX_OK;
+}
+// on = 1: clears the report; the next accumulate calls run under a sampled scope (paths that cannot report out-of-scope keys answer
+// RFX_ESTATE instead of running).  on = 0: back to normal, the report stays readable.
+extern "C" int rfx_hip_ctx_speculative(rfx_ctx_t *c, int on) {
+    RFX_REQUIRE(c, RFX_EINVAL, "ctx is NULL");
+    if (!c->ext_p[1]) {
+        void *p = NULL;
+        RFX_HIP_CHECK(hipMalloc(&p, 256));
+        c->ext_p[1] = p;
+    }
+    if (on) RFX_HIP_CHECK(hipMemsetAsync(c->ext_p[1], 0, 4, c->stream));
+    c->ext_i[1] = on ? 1 : 0;
+    return RFX_OK;
+}
+// did a pass since rfx_hip_ctx_speculative(ctx, 1) meet a selected row with a key outside the agreed scope?  (syncs)
+extern "C" int rfx_hip_group_out_of_scope(rfx_ctx_t *c, int *violated) {
+    RFX_REQUIRE(c && violated, RFX_EINVAL, "NULL argument");
+    *violated = 0;
+    if (!c->ext_p[1]) return RFX_OK;
+    unsigned *h = (unsigned *)c->h_pin;
+    RFX_HIP_CHECK(hipMemcpyAsync(h, c->ext_p[1], 4, hipMemcpyDeviceToHost, c->stream));
+    RFX_HIP_CHECK(hipStreamSynchronize(c->stream));
+    *violated = h[0] != 0;
+    return RFX_OK;
 }
 
 // ---------------- K8: rank occupied slots by first row ----------------

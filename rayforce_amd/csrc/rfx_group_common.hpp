@@ -92,6 +92,10 @@ struct GroupArgs {
     u64 *first;
     u64 *acc[RFX_MAX_AGGS];
     u64 *cnt[RFX_MAX_AGGS];
+    // a selected row whose key lies outside the agreed scope (possible when the scope was SAMPLED, rfx_hip_scope_sample_i64): counted
+    // here instead of being dropped silently; several keys are checked column by column (krng: each column's range)
+    unsigned *oob;
+    u64 krng[RFX_MAX_KEYS];
 };
 
 #define RFX_FEW_MAX_GROUPS 8

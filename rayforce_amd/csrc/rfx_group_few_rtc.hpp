@@ -153,14 +153,28 @@ extern "C" __global__ __launch_bounds__(RFX_BLOCK) void k_group_few(const Plan P
         } else {
 #pragma unroll
             for (int e = 0; e < E; e++) key[e] = 0;
+            bool out[E];
+#pragma unroll
+            for (int e = 0; e < E; e++) out[e] = false;
 #pragma unroll
             for (int i = 0; i < FEW_NKEYS; i++) {
                 u64 x[E];
                 sel_col_sw<NC, E>(x, v, KIDX[i]);
-                const u64 mn = G.kmn[i], mu = G.kmul[i];
+                const u64 mn = G.kmn[i], mu = G.kmul[i], rg = G.krng[i];
 #pragma unroll
-                for (int e = 0; e < E; e++) key[e] += (x[e] - mn) * mu;
+                for (int e = 0; e < E; e++) {
+                    out[e] |= (x[e] - mn) >= rg;
+                    key[e] += (x[e] - mn) * mu;
+                }
             }
+#pragma unroll
+            for (int e = 0; e < E; e++) key[e] = out[e] ? ~0ULL : key[e];
+        }
+        {   // a selected row outside the agreed scope (a sampled scope missed its key): reported, the host runs the exact scope
+            bool bad = false;
+#pragma unroll
+            for (int e = 0; e < E; e++) bad |= ((m >> e) & 1u) && key[e] >= (u64)NG;
+            if (bad && G.oob) *(volatile unsigned *)G.oob = 1u;
         }
         double hitd[E][NG]; // 1.0: row e is selected and belongs to group g
 #pragma unroll

@@ -188,8 +188,8 @@ static resident_t *g_res;
 static int g_nres, g_capres;
 static uint64_t g_tick, g_epoch = 1;
 static size_t g_res_bytes;
-static int64_t g_stat[8]; /* see rfx_stats */
-enum { ST_SELECT_GPU, ST_SELECT_DELEGATED, ST_JOIN_GPU, ST_JOIN_DELEGATED, ST_UPLOADS, ST_CACHE_HITS, ST_CACHE_STALE, ST_OPS };
+static int64_t g_stat[10]; /* see rfx_stats */
+enum { ST_SELECT_GPU, ST_SELECT_DELEGATED, ST_JOIN_GPU, ST_JOIN_DELEGATED, ST_UPLOADS, ST_CACHE_HITS, ST_CACHE_STALE, ST_OPS, ST_SCOPE_SAMPLED, ST_SCOPE_RETRIED };
 
 typedef struct {
     const unsigned char *p;
@@ -727,6 +727,27 @@ static int build_xnodes(obj_p tab, obj_p e, rfx_xnode_t *nodes, int *nn, int *nc
 }
 
 /* ------------------------------------------------------------------------------------------------ select */
+/* One dense accumulate pass, under an exact or a SAMPLED scope (`spec`).  0: done.  1: the sampled scope did not hold (a selected row's
+ * key outside it, or a path that cannot report such rows): nothing of the result may be used, the caller takes the exact scope and runs
+ * again.  -1: error. */
+static int dense_pass(int spec, int fused_keys, const void **dks, const int64_t *kmins, const int64_t *kmults, int nkeys, const void *dk, const wplan_t *wp,
+                      const rfx_agg_t *aggs, int64_t nrows, const rfx_group_tables_t *gt) {
+    if (spec && rfx_hip_ctx_speculative(g_ctx, 1) != RFX_OK) return -1;
+    int rc = fused_keys ? rfx_hip_group_dense_accumulate_keys(g_ctx, dks, kmins, kmults, nkeys, wp->preds, wp->npred, wp->logic, aggs, nrows, 0, gt)
+                        : rfx_hip_group_dense_accumulate(g_ctx, (const int64_t *)dk, wp->preds, wp->npred, wp->logic, aggs, nrows, 0, gt);
+    if (spec) {
+        rfx_hip_ctx_speculative(g_ctx, 0);
+        if (rc == RFX_ESTATE) return 1;
+    }
+    if (rc != RFX_OK) return -1;
+    if (spec) {
+        int bad = 0;
+        if (rfx_hip_group_out_of_scope(g_ctx, &bad) != RFX_OK) return -1;
+        if (bad) return 1;
+    }
+    return 0;
+}
+
 /* results of a small group-by arrive on the host in ONE copy (rfx_hip_group_rank_emit_small's block); the code that builds the
  * result vectors reads device addresses through fetch(), which serves addresses inside that block from its host mirror */
 static const char *g_mirror_dev, *g_mirror_host;
@@ -975,12 +996,30 @@ static obj_p select_impl(obj_p dict) {
             if (!ok) { res = fail_hip("gather"); goto done; }
             nrows = nsel;
         }
+        /* Large inputs: the key scope(s) from a SAMPLE first (rfx_hip_scope_sample_i64) when the range is LDS-sized -- index_scope_i64's
+         * full pass is a quarter to a third of such a query -- with the kernels reporting any selected key outside it; a report (or a
+         * path that cannot report) comes back here for the exact scope.  RFX_NO_SAMPLED_SCOPE=1 turns it off. */
+        int spec_ok = by && nrows >= ((int64_t)1 << 24) && !getenv("RFX_NO_SAMPLED_SCOPE");
+    rescope:;
+        int spec = 0;
+        if (by && !spec_ok && nrows >= ((int64_t)1 << 24) && !getenv("RFX_NO_SAMPLED_SCOPE")) g_stat[ST_SCOPE_RETRIED]++; /* back here after a report */
         if (by) {
             int64_t kmin, kmax, seen;
             if (nkeys > 1) {
                 /* scopes of every key column, then the reference's multiplier plan (core/index.c:2340-2383); no where: here */
                 seen = 0;
-                for (int i = 0; i < nkeys; i++)
+                if (spec_ok) {
+                    int64_t prod = 1;
+                    spec = 1;
+                    for (int i = 0; i < nkeys && spec; i++) {
+                        if (rfx_hip_scope_sample_i64(g_ctx, (const int64_t *)dks[i], nrows, &kmins[i], &kmaxs[i]) != RFX_OK) { res = fail_hip("scope"); goto done; }
+                        if (kmins[i] == RFX_NULL_I64 || kmaxs[i] < kmins[i] || (uint64_t)(kmaxs[i] - kmins[i]) >= (1u << 14)) spec = 0;
+                        else prod *= kmaxs[i] - kmins[i] + 1;
+                        if (prod > (1 << 14)) spec = 0;
+                    }
+                    if (spec) seen = nrows;
+                }
+                for (int i = 0; i < nkeys && !spec; i++)
                     if (rfx_hip_scope_i64(g_ctx, (const int64_t *)dks[i], NULL, 0, RFX_AND, nrows, &kmins[i], &kmaxs[i], &seen) != RFX_OK) { res = fail_hip("scope"); goto done; }
                 kmin = 0;
                 kmax = -1;
@@ -1033,7 +1072,16 @@ static obj_p select_impl(obj_p dict) {
                     }
                     }
                 }
-            } else if (rfx_hip_group_scope(g_ctx, (const int64_t *)dk, wp.preds, wp.npred, wp.logic, aggs, nagg, nrows, &kmin, &kmax, &seen) != RFX_OK) { res = fail_hip("scope"); goto done; }
+            } else {
+                if (spec_ok) {
+                    if (rfx_hip_scope_sample_i64(g_ctx, (const int64_t *)dk, nrows, &kmin, &kmax) != RFX_OK) { res = fail_hip("scope"); goto done; }
+                    spec = kmin != RFX_NULL_I64 && kmax >= kmin && (uint64_t)(kmax - kmin) < (1u << 14);
+                    seen = nrows;
+                }
+                if (!spec && rfx_hip_group_scope(g_ctx, (const int64_t *)dk, wp.preds, wp.npred, wp.logic, aggs, nagg, nrows, &kmin, &kmax, &seen) != RFX_OK) { res = fail_hip("scope"); goto done; }
+            }
+            if (spec && rowhash) spec = 0; /* (cannot happen: the row-hash path needs ranges beyond 64 bits) */
+            if (spec) g_stat[ST_SCOPE_SAMPLED]++;
             int64_t groups = 0;
             if (!rowhash) nagg_run = nagg;
             obj_p okeys = NULL, ocols[RFX_MAX_AGGS] = {0}, okcols[RFX_MAX_KEYS] = {0};
@@ -1049,6 +1097,7 @@ static obj_p select_impl(obj_p dict) {
                 /* dense "perfect hash" iff range <= rows (core/index.c:2013), like the reference; else open addressing */
                 uint64_t range = (uint64_t)kmax - (uint64_t)kmin + 1;
                 int dense = range != 0 && range <= (uint64_t)seen && kmin != RFX_NULL_I64;
+                if (spec && !dense) { spec_ok = 0; goto rescope; }
                 int narr = 0;
                 rfx_hip_group_table_arrays(aggs, nagg_run, &narr);
                 int64_t cells = dense ? (int64_t)range : 0;
@@ -1086,21 +1135,34 @@ static obj_p select_impl(obj_p dict) {
                      * only host round trip after the scope pass (a dozen launches and three more round trips otherwise) */
                     const size_t bcells = 1 + (size_t)(2 + nagg_run) * (size_t)range;
                     void *blk = NULL;
+                    int pr = -1;
                     ok = rfx_hip_malloc(g_ctx, &blk, bcells * 8) == RFX_OK && (mirror = (int64_t *)malloc(bcells * 8)) != NULL &&
                          rfx_hip_group_tables_init(g_ctx, aggs, &gt) == RFX_OK &&
-                         rfx_hip_group_dense_accumulate(g_ctx, (const int64_t *)dk, wp.preds, wp.npred, wp.logic, aggs, nrows, 0, &gt) == RFX_OK &&
+                         (pr = dense_pass(spec, 0, dks, kmins, kmults, nkeys, dk, &wp, aggs, nrows, &gt)) == 0 &&
                          rfx_hip_group_rank_emit_small(g_ctx, aggs, &gt, 0, 0, (int64_t *)blk) == RFX_OK &&
                          rfx_hip_d2h(g_ctx, mirror, blk, bcells * 8) == RFX_OK;
+                    if (pr == 1) { /* the sampled scope did not hold: exact scope, again */
+                        if (blk) rfx_hip_free(g_ctx, blk);
+                        free(mirror);
+                        rfx_hip_free(g_ctx, store);
+                        spec_ok = 0;
+                        goto rescope;
+                    }
                     g_mirror_host = (const char *)mirror; /* released at `done` */
                     g_mirror_dev = (const char *)blk;
                     g_mirror_bytes = ok ? bcells * 8 : 0;
                     if (ok) groups = mirror[0];
                     dout = blk;
                 } else if (dense) {
+                    int pr = -1;
                     ok = rfx_hip_group_tables_init(g_ctx, aggs, &gt) == RFX_OK &&
-                         (nkeys > 1 && !rowhash ? rfx_hip_group_dense_accumulate_keys(g_ctx, dks, kmins, kmults, nkeys, wp.preds, wp.npred, wp.logic, aggs, nrows, 0, &gt)
-                                    : rfx_hip_group_dense_accumulate(g_ctx, (const int64_t *)dk, wp.preds, wp.npred, wp.logic, aggs, nrows, 0, &gt)) == RFX_OK &&
+                         (pr = dense_pass(spec, nkeys > 1 && !rowhash, dks, kmins, kmults, nkeys, dk, &wp, aggs, nrows, &gt)) == 0 &&
                          rfx_hip_group_rank(g_ctx, &gt, nrows, &groups) == RFX_OK;
+                    if (pr == 1) {
+                        rfx_hip_free(g_ctx, store);
+                        spec_ok = 0;
+                        goto rescope;
+                    }
                 } else {
                     int arc = RFX_EINVAL;
                     ok = rfx_hip_hash_tables_init(g_ctx, aggs, &ht) == RFX_OK &&
@@ -2129,7 +2191,7 @@ rfx_obj_p rfx_invalidate(rfx_obj_p x) {
 rfx_obj_p rfx_stats(rfx_obj_p x) {
     (void)x;
     rfx_host_bind();
-    obj_p out = H.vector(RFX_TYPE_I64, 8);
-    for (int i = 0; i < 8; i++) RFX_AS_I64(out)[i] = g_stat[i];
+    obj_p out = H.vector(RFX_TYPE_I64, 10);
+    for (int i = 0; i < 10; i++) RFX_AS_I64(out)[i] = g_stat[i];
     return out;
 }

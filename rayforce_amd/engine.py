@@ -13,6 +13,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 from typing import Dict, List, Optional, Sequence, Tuple, Union
 
 import torch
@@ -651,8 +652,10 @@ class Engine:
                 t.d_cnt[a] = None
         return t, store, layout
 
+    spec_retries = 0  # sampled scopes that a pass reported as too small (the query then ran again under the exact scope)
+
     def group_by(self, key, aggs, where=None, table=None, total_rows: Optional[int] = None, row0: int = 0, _collective=None,
-                 order: str = "first", _cap_hint: int = 0, _probe_first: Optional[torch.Tensor] = None):
+                 order: str = "first", _cap_hint: int = 0, _probe_first: Optional[torch.Tensor] = None, _spec: bool = True):
         """``select {aggs} from t [where p] by key`` -> dict(keys=, first=, results=[...], groups=n) of device tensors.
 
         Group order is first occurrence (`order="radix"`: for key tuples that take the row-hash path, the order of the
@@ -694,7 +697,7 @@ class Engine:
             r = None
             for ch in chunks:  # (a later launch starts from the hashed-table capacity the first one ended with: same groups)
                 part = self.group_by(key, ch, where, table, total_rows, row0, _collective, order, r.get("cap", 0) if r else 0,
-                                     _probe_first if r is None else None)
+                                     _probe_first if r is None else None, _spec)
                 if r is None:
                     r = part
                 else:
@@ -708,7 +711,11 @@ class Engine:
             # several key columns -> one composite dense key (index_group_list_perfect, core/index.c:2308-2424)
             kcols = [self._key_col(k, table) for k in key]
             try:
-                tmax, seen, multi = self._composite_plan(kcols, where, table, _collective)
+                spec_keys = _spec and self._may_speculate(kcols[0].numel(), _collective)
+                tmax, seen, multi = self._composite_plan(kcols, where, table, _collective, sampled=spec_keys)
+                if spec_keys and multi is None:
+                    spec_keys = False
+                    tmax, seen, multi = self._composite_plan(kcols, where, table, _collective)
             except _NotPerfect as e:  # ranges overflow 64 bits / null keys: the reference's row-hash path (core/index.c:2731-2790)
                 return self._group_by_row_hash(kcols, e.scopes, aggs, where, table, total_rows, row0, _collective, order)
             key = kcols[0]
@@ -721,12 +728,19 @@ class Engine:
             logic, flat = self._flatten(where, table)
         except _NotFlat:
             raise RfxError("nested boolean trees are not fused with `by:`; pass ids via where() + at_ids()")
+        spec = False  # the scope below was SAMPLED: the pass reports keys outside it, a report sends the query through the exact scope
         if multi is None:
-            kmin, kmax, seen = self.scope(key, where, table, aggs)
-            if _collective is not None:
-                kmin, kmax, seen = _collective("scope", (kmin, kmax, seen, self.device))
+            if _spec and self._may_speculate(n, _collective):
+                smn, smx = self.scope_sample(key)
+                if smn != L.NULL_I64 and 0 < smx - smn + 1 <= self.SPEC_MAX_SLOTS:
+                    kmin, kmax, seen, spec = smn, smx, n, True
+            if not spec:
+                kmin, kmax, seen = self.scope(key, where, table, aggs)
+                if _collective is not None:
+                    kmin, kmax, seen = _collective("scope", (kmin, kmax, seen, self.device))
         else:
             kmin, kmax = 0, tmax  # forced scope, core/index.c:2421
+            spec = bool(locals().get("spec_keys", False))
         self._keep.clear()
         parr, _ = self._preds(flat, table, n)
         aarr, _ = self._aggs(aggs, table, n)
@@ -749,17 +763,39 @@ class Engine:
         # index_group_i64_scoped: dense "perfect hash" iff range <= rows (core/index.c:2013); else open addressing
         dense = 0 < rng <= max(seen, 1) and kmin != L.NULL_I64
         ng = C.c_int64()
+        if spec and not dense:
+            return self.group_by(key if multi is None else kcols, aggs, where, table, total_rows, row0, _collective, order, _cap_hint, _probe_first, False)
         if dense:
             t, store, layout = self.group_tables(aarr, nagg, kmin, rng)
             L.check(self.lib.rfx_hip_group_tables_init(self._ctx, aarr, C.byref(t)), "group_tables_init")
-            if multi is None:
-                L.check(self.lib.rfx_hip_group_dense_accumulate(self._ctx, key.data_ptr(), parr, len(flat), logic, aarr, n, row0, C.byref(t)),
-                        "group_dense_accumulate")
+            if spec:
+                L.check(self.lib.rfx_hip_ctx_speculative(self._ctx, 1), "ctx_speculative")
+            try:
+                if multi is None:
+                    rc = self.lib.rfx_hip_group_dense_accumulate(self._ctx, key.data_ptr(), parr, len(flat), logic, aarr, n, row0, C.byref(t))
+                else:
+                    k = len(kcols)
+                    ptrs = (C.c_void_p * k)(*[kc.data_ptr() for kc in kcols])
+                    rc = self.lib.rfx_hip_group_dense_accumulate_keys(self._ctx, ptrs, (C.c_int64 * k)(*multi[0]), (C.c_int64 * k)(*multi[1]), k, parr,
+                                                                      len(flat), logic, aarr, n, row0, C.byref(t))
+            finally:
+                if spec:
+                    self.lib.rfx_hip_ctx_speculative(self._ctx, 0)  # (the report stays readable until the next speculative(1))
+            redo = False
+            if spec:
+                if rc == L.RFX_ESTATE:  # the pass would have taken a path that cannot report out-of-scope keys: nothing ran
+                    redo = True
+                else:
+                    L.check(rc, "group_dense_accumulate")
+                    bad = C.c_int(0)
+                    L.check(self.lib.rfx_hip_group_out_of_scope(self._ctx, C.byref(bad)), "group_out_of_scope")
+                    redo = bool(bad.value)
             else:
-                k = len(kcols)
-                ptrs = (C.c_void_p * k)(*[kc.data_ptr() for kc in kcols])
-                L.check(self.lib.rfx_hip_group_dense_accumulate_keys(self._ctx, ptrs, (C.c_int64 * k)(*multi[0]), (C.c_int64 * k)(*multi[1]), k, parr,
-                                                                     len(flat), logic, aarr, n, row0, C.byref(t)), "group_dense_accumulate_keys")
+                L.check(rc, "group_dense_accumulate")
+            if redo:  # an outlier, a null key, a range the sample missed: the exact scope and the pass again
+                del t, store
+                self.spec_retries += 1
+                return self.group_by(key if multi is None else kcols, aggs, where, table, total_rows, row0, _collective, order, _cap_hint, _probe_first, False)
             if _collective is not None:  # the kinds of THIS launch's aggregates (a chunk of the query's, or the row-hash path's extras)
                 _collective("tables", (store, layout, [int(aarr[i].kind) for i in range(nagg)],
                                        [L.agg_input_type(aarr[i]) == L.RFX_F64 for i in range(nagg)], t, aarr))
@@ -1062,7 +1098,19 @@ class Engine:
                 out.append((L.NULL_I64 if nonnull < seen else mn, mx, seen))
         return out
 
-    def _composite_plan(self, kcols, where, table, _collective):
+    SPEC_MAX_SLOTS = 1 << 14  # sampled scopes only for ranges whose tables are LDS-sized (the kernels that report out-of-scope keys)
+
+    def _may_speculate(self, n: int, _collective) -> bool:
+        """A sampled key scope instead of the full scope pass?  Large single-GPU inputs only; RFX_NO_SAMPLED_SCOPE=1 turns it off."""
+        return n >= (1 << 24) and _collective is None and not os.environ.get("RFX_NO_SAMPLED_SCOPE")
+
+    def scope_sample(self, key: torch.Tensor) -> Tuple[int, int]:
+        """[min, max] of 2^14 strided rows + the column's first and last 2^11 (rfx_hip_scope_sample_i64).  (syncs)"""
+        mn, mx = C.c_int64(), C.c_int64()
+        L.check(self.lib.rfx_hip_scope_sample_i64(self._ctx, key.data_ptr(), key.numel(), C.byref(mn), C.byref(mx)), "scope_sample")
+        return int(mn.value), int(mx.value)
+
+    def _composite_plan(self, kcols, where, table, _collective, sampled: bool = False):
         """Scopes of every key column (through the predicates) and the reference's multiplier plan (core/index.c:2340-2383).
         Returns (composite max, rows seen, (mins, mults, ranges))."""
         if len(kcols) > L.RFX_MAX_KEYS:
@@ -1074,6 +1122,22 @@ class Engine:
                 raise RfxError("key columns must be equally long i64 columns on this path")
         # (only under a filter: unfiltered, one 1.2 ms scope pass per key column beats K1 with 2 x keys min / max aggregates --
         #  two keys, 1e9 rows: 2.4 against 3.8 ms -- while with predicates every separate pass re-reads the predicate columns)
+        if sampled:  # every column's scope from a sample; (None: not usable -- a null key, or tables beyond the LDS forms)
+            prod = 1
+            for kc in kcols:
+                mn, mx = self.scope_sample(kc)
+                if mn == L.NULL_I64 or mx < mn:
+                    return -1, 0, None
+                prod *= mx - mn + 1
+                mins.append(mn)
+                maxs.append(mx)
+            if prod > self.SPEC_MAX_SLOTS:
+                return -1, 0, None
+            k = len(kcols)
+            amin, amax, amul, tmax = (C.c_int64 * k)(*mins), (C.c_int64 * k)(*maxs), (C.c_int64 * k)(), C.c_int64()
+            if self.lib.rfx_composite_plan(amin, amax, k, amul, C.byref(tmax)) != L.RFX_OK:
+                return -1, 0, None
+            return int(tmax.value), n, (mins, list(amul), [mx - mn + 1 for mn, mx in zip(mins, maxs)])
         local = self._scopes_fused(kcols, where, table, n) if (where is not None and 2 <= len(kcols) <= 4) else None
         for i, kc in enumerate(kcols):
             mn, mx, seen = local[i] if local is not None else self.scope(kc, where, table)

@@ -736,3 +736,68 @@ def test_few_groups_run_time_compiled_kernels(eng, groups, n):
         assert _rtc_stats(eng)[0] == l1  # the flag kept every launch on the prebuilt kernels
     finally:
         eng.tune(flags=0)
+
+
+# ---------------------------------------------------------------- sampled key scopes (large inputs, LDS-sized ranges)
+def test_sampled_scope_reports_what_it_missed(eng):
+    """From 2^24 rows on, a group-by over an LDS-sized key range takes its scope from a SAMPLE (2^14 strided rows + both ends) instead of
+    index_scope_i64's full pass, and the LDS-table kernels report selected rows whose key lies outside it; a report sends the
+    query through the exact scope.  Here: ranges the sample sees completely (no retry), one outlier key / a null key / a key
+    below the minimum hidden between the sampled rows (retry, same answer), an outlier that the filter removes (no report),
+    one and two key columns -- device against itself with the feature off (RFX_NO_SAMPLED_SCOPE) on everything that is
+    order-independent, and against numpy on counts."""
+    n = (1 << 24) + 12_345
+    k = eng.gen_i64(n, 4, 100)
+    k2 = eng.gen_i64(n, 14, 7)
+    v = eng.gen_f64(n, 5)
+    a = eng.gen_i64(n, 2, 1_000_000)
+    t = {"k": k, "k2": k2, "v": v, "a": a}
+
+    def run(key, where=None):
+        r = eng.group_by(key, [("sum", "a"), ("count", "a"), ("max", "a"), ("first", "a")], where, t)
+        return r
+
+    def same(r1, r2):
+        assert r1["groups"] == r2["groups"]
+        assert torch.equal(r1["keys"], r2["keys"]) and torch.equal(r1["first"], r2["first"])
+        for x, y in zip(r1["results"], r2["results"]):
+            assert torch.equal(x, y)
+        for x, y in zip(r1.get("key_columns", []), r2.get("key_columns", [])):
+            assert torch.equal(x, y)
+
+    def exact(key, where=None):
+        os.environ["RFX_NO_SAMPLED_SCOPE"] = "1"
+        try:
+            return run(key, where)
+        finally:
+            del os.environ["RFX_NO_SAMPLED_SCOPE"]
+
+    hidden = 5  # stride = n >> 14 = 1024: row 5 + 1024 * j is never sampled, and lies past the first 2^11 rows only for j >= 2
+    spot = hidden + 1024 * 4097
+    base = eng.spec_retries
+    same(run("k"), exact("k"))
+    same(run(["k", "k2"]), exact(["k", "k2"]))
+    same(run("k", ("<", "a", 500_000)), exact("k", ("<", "a", 500_000)))
+    assert eng.spec_retries == base  # the sample saw the whole range: no second pass
+    counts = torch.bincount(k, minlength=100)
+    assert torch.equal(run("k")["results"][1].sum(), counts.sum())
+    for bad in (1_000, -3, L_NULL):
+        keep = int(k[spot])
+        k[spot] = bad
+        before = eng.spec_retries
+        same(run("k"), exact("k"))
+        assert eng.spec_retries == before + 1, bad  # reported, ran again under the exact scope
+        before = eng.spec_retries
+        same(run(["k", "k2"]), exact(["k", "k2"]))
+        assert eng.spec_retries == before + 1, bad
+        if bad != L_NULL:
+            a_keep = int(a[spot])
+            a[spot] = 999_999  # the filter drops the outlier's row: nothing to report
+            before = eng.spec_retries
+            same(run("k", ("<", "a", 500_000)), exact("k", ("<", "a", 500_000)))
+            assert eng.spec_retries == before
+            a[spot] = a_keep
+        k[spot] = keep
+
+
+L_NULL = -(2**63)

@@ -473,3 +473,58 @@ def test_update_where_by(ops, n, keys):
     sparse["k"] = host["k"] * 1_000_003
     with pytest.raises(RuntimeError, match="sparse or null keys"):
         run_update(ops, sparse, {"t": ("sum", "v"), "by": "k"})
+
+
+def test_sampled_scope_at_the_operator_boundary(ops):
+    """From 2^24 rows on rfx_select takes LDS-sized key scopes from a sample and its kernels report selected keys outside them (a report =
+    the exact scope and the pass again): the same queries with the feature off (RFX_NO_SAMPLED_SCOPE) answer identically -- complete
+    ranges, an outlier / a null key hidden between the sampled rows (unpinned columns: the changed cell is picked up by the payload
+    validation), one and two key columns, with and without a filter."""
+    import os
+    n = (1 << 24) + 77
+    host = {"k": rfo.gen_i64(n, 4, 100), "k2": rfo.gen_i64(n, 14, 7), "a": rfo.gen_i64(n, 2, 1_000_000), "v": rfo.gen_f64(n, 5)}
+    queries = [{"s": ("sum", "a"), "c": ("count", "a"), "m": ("max", "a"), "f": ("first", "a"), "by": "k"},
+               {"s": ("sum", "a"), "c": ("count", "v"), "by": {"x": "k", "y": "k2"}},
+               {"s": ("sum", "a"), "mn": ("min", "v"), "where": ("<", "a", 500_000), "by": "k"}]
+
+    def both(q):
+        got = run_select(ops, host, q)
+        os.environ["RFX_NO_SAMPLED_SCOPE"] = "1"
+        try:
+            want = run_select(ops, host, q)
+        finally:
+            del os.environ["RFX_NO_SAMPLED_SCOPE"]
+        assert list(got) == list(want)
+        for name in want:
+            assert np.array_equal(got[name].view(np.int64), want[name].view(np.int64)), name
+        return got
+
+    def stats():
+        r = ops.rfx_stats(None)
+        out = H.to_numpy(r).copy()
+        ops.rfx_host_drop(r)
+        return out
+
+    s0 = stats()
+    g = both(queries[0])
+    assert np.array_equal(np.sort(g["k"]), np.arange(100)) and int(g["c"].sum()) == n
+    assert np.array_equal(g["c"][np.argsort(g["k"])], np.bincount(host["k"], minlength=100))
+    both(queries[1])
+    both(queries[2])
+    s1 = stats()
+    assert s1[8] - s0[8] == 3 and s1[9] == s0[9], (s0, s1)  # three sampled scopes, none reported too small
+    spot = 5 + 1024 * 4097  # never sampled (stride 1024 from row 0, both ends 2^11 rows)
+    for bad in (7_000, NULL):
+        keep = host["k"][spot]
+        host["k"][spot] = bad
+        try:
+            if bad == NULL:  # a null group key is handed back to the host (no host here: loud failure), sampled scope or not
+                with pytest.raises(RuntimeError, match="null group key"):
+                    run_select(ops, host, queries[0])
+            else:
+                g = both(queries[0])
+                assert len(g["k"]) == 101 and int(g["c"][g["k"] == bad][0]) == 1
+                both(queries[1])
+                assert stats()[9] - s1[9] == 2  # both sampled scopes were reported too small and the queries ran again
+        finally:
+            host["k"][spot] = keep
