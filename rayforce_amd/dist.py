@@ -262,12 +262,24 @@ class ShardedEngine:
             ident = [None]
             if self.shard.rank == 0:
                 buf = C.create_string_buffer(128)
-                L.check(lib.rfx_dist_unique_id(buf), "dist_unique_id")
-                ident = [buf.raw]
+                ident = [buf.raw if lib.rfx_dist_unique_id(buf) == L.RFX_OK else None]
             if self.shard.world > 1:
                 dist.broadcast_object_list(ident, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
-            L.check(lib.rfx_dist_init(engine._ctx, self.shard.world, self.shard.rank, C.c_char_p(ident[0])), "dist_init")
-            self.native = (engine, lib)
+            ok = ident[0] is not None and lib.rfx_dist_init(engine._ctx, self.shard.world, self.shard.rank, C.c_char_p(ident[0])) == L.RFX_OK
+            if self.shard.world > 1:  # every rank takes the same door: the library's exchange only if ALL communicators came up
+                flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=engine.device)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+                all_ok = bool(int(flag[0]))
+            else:
+                all_ok = ok
+            if all_ok:
+                self.native = (engine, lib)
+            else:
+                if ok:
+                    lib.rfx_dist_finalize(engine._ctx)
+                import sys
+                print(f"[rfx] rank {self.shard.rank}: the library's own RCCL exchange did not come up ({L.last_error(lib) if hasattr(L, 'last_error') else 'rfx_dist_init failed'}); "
+                      "torch.distributed (RCCL) carries the collectives instead", file=sys.stderr, flush=True)
 
     def close(self):
         if self.native:
