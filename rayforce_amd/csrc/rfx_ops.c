@@ -290,6 +290,8 @@ static int transient(obj_p v, const void **dev) {
 }
 
 #define RFX_MAX_PROXY 128
+/* the virtual column, or TYPE_PARTEDLIST + an element type (B8 .. ENUM), core/rayforce.h:67-82 */
+#define IS_PARTED_TYPE(t) ((t) == RFX_TYPE_MAPCOMMON || ((t) >= RFX_TYPE_PARTEDLIST && (t) <= RFX_TYPE_PARTEDLIST + RFX_TYPE_ENUM))
 /* ---- parted tables (get-parted, core/vary.c:185-392) ----
  * A parted table's columns are LISTs of one mmapped vector per partition (TYPE_PARTEDLIST + element type) plus ONE virtual
  * column (TYPE_MAPCOMMON: a value per partition and the partition's row count; `Date`).  On the device a parted column is what
@@ -315,7 +317,7 @@ static int is_parted_table(obj_p tab) {
     obj_p cols = RFX_AS_LIST(tab)[1];
     for (int64_t i = 0; i < cols->len; i++) {
         const int t = RFX_AS_LIST(cols)[i]->type;
-        if (t == RFX_TYPE_MAPCOMMON || t >= RFX_TYPE_PARTEDLIST) return 1;
+        if (IS_PARTED_TYPE(t)) return 1;
     }
     return 0;
 }
@@ -342,7 +344,7 @@ static obj_p parted_view(obj_p tab) {
     RFX_AS_LIST(ft)[1] = fc;
     for (int64_t i = 0; i < cols->len; i++) {
         obj_p c = RFX_AS_LIST(cols)[i];
-        if (c->type != RFX_TYPE_MAPCOMMON && c->type < RFX_TYPE_PARTEDLIST) { RFX_AS_LIST(fc)[i] = c; continue; }
+        if (!IS_PARTED_TYPE(c->type)) { RFX_AS_LIST(fc)[i] = c; continue; }
         proxy_t *px = (proxy_t *)calloc(1, sizeof(proxy_t));
         if (!px) return NULL;
         g_px[g_npx++] = px;
@@ -468,6 +470,13 @@ static int resident(obj_p col, int pin, const void **dev) {
 }
 /* drop every cached copy that overlaps the vector's payload */
 static void invalidate_payload(obj_p v) {
+    if (v && IS_PARTED_TYPE(v->type)) { /* a parted column: cached under its LIST object */
+        for (int i = 0; i < g_nres;) {
+            if (g_res[i].host == (const void *)v) res_free(i);
+            else i++;
+        }
+        return;
+    }
     if (!v || v->type <= 0) return;
     const int esz = (v->type == RFX_TYPE_B8) ? 1 : 8;
     const char *lo = (const char *)RFX_AS_RAW(v), *hi = lo + (size_t)v->len * esz;
@@ -2158,6 +2167,23 @@ static obj_p pin_op(obj_p x, int pin) {
     if (ensure_ctx() != RFX_OK) return fail_hip("no usable MI355X");
     obj_p cols = (x->type == RFX_TYPE_TABLE) ? RFX_AS_LIST(x)[1] : NULL;
     int64_t n = cols ? cols->len : 1;
+    if (cols && is_parted_table(x)) { /* a get-parted table: its columns are known to the cache by their LIST objects (parted_view) */
+        obj_p view = pin ? parted_view(x) : NULL;
+        int bad = pin && !view;
+        for (int64_t i = 0; i < n && !bad; i++) {
+            obj_p c = RFX_AS_LIST(cols)[i];
+            if (pin) {
+                obj_p pc = RFX_AS_LIST(RFX_AS_LIST(view)[1])[i];
+                const void *d;
+                if ((col_ctype(pc) || pc->type == RFX_TYPE_B8) && pc->type > 0 && resident(pc, 1, &d) != RFX_OK) bad = 1;
+            } else {
+                for (int j = 0; j < g_nres; j++)
+                    if (g_res[j].host == (const void *)c || g_res[j].host == RFX_AS_RAW(c)) { res_free(j); break; }
+            }
+        }
+        parted_view_release();
+        return bad ? fail_hip("pin") : H.clone(x);
+    }
     for (int64_t i = 0; i < n; i++) {
         obj_p c = cols ? RFX_AS_LIST(cols)[i] : x;
         if (!(c->type > 0 && (col_ctype(c) || c->type == RFX_TYPE_B8))) continue;

@@ -205,6 +205,8 @@ def test_parted_and_enum_columns_inside_the_real_reference(built, tmp_path):
     with ref.Session() as s:
         s.eval(f"(set p (get-parted \"{root}\" 'tab))")
         s.eval(f'(set gsel (loadfn "{LIB}" "rfx_select" 1))')
+        s.eval(f'(set gpin (loadfn "{LIB}" "rfx_pin" 1))')
+        s.eval("(gpin p)")  # every partition's column files uploaded once, the parted columns trusted until rfx_invalidate / rfx_unpin
         s.put("a", rfo.gen_i64(n, 71, 1_000_000))
         s.put("v", rfo.gen_f64(n, 72))
         s.put("ki", rfo.gen_i64(n, 73, 9))
@@ -241,3 +243,4 @@ def test_parted_and_enum_columns_inside_the_real_reference(built, tmp_path):
     print(ref.LAST_STDERR)  # RFX_TRACE=1: why a query was handed back
     assert int(st[0]) == on_gpu and int(st[1]) == len(PARTED + ENUMS) - on_gpu, st
     assert len(res["g_p2_Date"]) == 4 and len(res["g_p4_Date"]) == 2
+    assert int(st[4]) <= 4 + 3 + 2  # uploads: the parted table's four columns once (pinned), the splayed / in-memory tables' columns
