@@ -306,11 +306,13 @@ int rfx_hip_group_dense_accumulate(rfx_ctx_t *ctx, const int64_t *d_key, const r
 /* Rank occupied slots by first row (first-occurrence order, core/index.c:2037-2055).  total_rows = global
  * number of rows the row ids in d_first range over.  Returns the group count.  (syncs) */
 int rfx_hip_group_rank(rfx_ctx_t *ctx, const rfx_group_tables_t *t, int64_t total_rows, int64_t *ngroups);
-/* A SAMPLED key scope and the report that keeps it exact.  rfx_hip_scope_sample_i64: [min, max] of 2^14 strided rows + the first and
+/* A SAMPLED key scope and the report that keeps it exact.  rfx_hip_scope_sample_i64: [min, max] of 2^18 strided rows + the first and
  * last 2^11 (one tiny launch instead of index_scope_i64's pass over the column, core/index.c:376-435; a null key shows as INT64_MIN).
  * rfx_hip_ctx_speculative(ctx, 1) before rfx_hip_group_dense_accumulate(_keys): LDS-table kernels then REPORT a selected row whose key
  * lies outside the tables' scope (paths that cannot, answer RFX_ESTATE without running); rfx_hip_group_out_of_scope afterwards: nothing
  * reported = the pass is the exact pass (a sampled range is never too large); reported = take rfx_hip_scope_i64 and run again. */
+#define RFX_SCOPE_SAMPLE_ROWS (1 << 18) /* strided rows of the sample; trust it for ranges <= RFX_SCOPE_SAMPLE_ROWS / 10 (extreme missed: e^-10) */
+#define RFX_SCOPE_SAMPLE_MAX_RANGE 16384 /* ... and only for ranges whose tables are LDS-sized */
 int rfx_hip_scope_sample_i64(rfx_ctx_t *ctx, const int64_t *d_key, int64_t nrows, int64_t *min, int64_t *max);
 int rfx_hip_ctx_speculative(rfx_ctx_t *ctx, int on);
 int rfx_hip_group_out_of_scope(rfx_ctx_t *ctx, int *violated);

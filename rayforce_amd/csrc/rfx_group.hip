@@ -542,8 +542,9 @@ extern "C" int rfx_hip_group_dense_accumulate_keys(rfx_ctx_t *c, const void *con
 
 // ---------------- a SAMPLED scope, and the report that keeps it honest ----------------
 // index_scope_i64 (core/index.c:376-435) reads the whole key column to learn [min, max] before it groups: for a key of a few
-// hundred values over 1e9 rows that pass is a quarter to a third of the query.  A strided sample of 2^14 rows plus the first and
-// last 2^11 almost always sees the whole range of such a key; "almost" is made exact by the kernels themselves: a selected row
+// hundred values over 1e9 rows that pass is a quarter to a third of the query.  A strided sample of 2^18 rows plus the first and
+// last 2^11 almost always sees the whole range of such a key (callers only trust it for ranges of at most a tenth of the sample: a
+// uniformly drawn extreme value is then missed with probability e^-10); "almost" is made exact by the kernels themselves: a selected row
 // whose key lies outside the agreed scope is REPORTED (GroupArgs::oob) instead of dropped, the host asks rfx_hip_group_out_of_scope
 // after the pass and, if anything was reported (an outlier, a null key, a range the sample missed), runs the exact scope and the
 // pass again.  A sampled range can only be too SMALL (the sample is a subset), so an unreported pass is the exact pass.
@@ -579,8 +580,8 @@ __global__ __launch_bounds__(RFX_BLOCK) void k_scope_sample_i64(const i64 *__res
 }
 extern "C" int rfx_hip_scope_sample_i64(rfx_ctx_t *c, const int64_t *d_key, int64_t nrows, int64_t *min, int64_t *max) {
     RFX_REQUIRE(c && d_key && min && max && nrows > 0, RFX_EINVAL, "bad argument");
-    const int grid = 16;
-    const i64 nsamp = nrows < (1 << 14) ? nrows : (1 << 14), edge = nrows < (1 << 11) ? 0 : (1 << 11);
+    const int grid = 64;
+    const i64 nsamp = nrows < RFX_SCOPE_SAMPLE_ROWS ? nrows : RFX_SCOPE_SAMPLE_ROWS, edge = nrows < (1 << 11) ? 0 : (1 << 11);
     int rc = rfx_ws_reserve(c, (size_t)grid * 16);
     if (rc != RFX_OK) return rc;
     hipLaunchKernelGGL(k_scope_sample_i64, dim3(grid), dim3(RFX_BLOCK), 0, c->stream, (const i64 *)d_key, (i64)nrows, (i64)(nrows / nsamp), nsamp, edge, (i64 *)c->d_ws);

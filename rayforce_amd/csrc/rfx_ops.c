@@ -736,6 +736,8 @@ static int build_xnodes(obj_p tab, obj_p e, rfx_xnode_t *nodes, int *nn, int *nc
 }
 
 /* ------------------------------------------------------------------------------------------------ select */
+static const void *g_spec_failed[32]; /* device key columns whose sampled scope was reported too small: not sampled again */
+static int g_nspec_failed, g_spec_retry;
 /* One dense accumulate pass, under an exact or a SAMPLED scope (`spec`).  0: done.  1: the sampled scope did not hold (a selected row's
  * key outside it, or a path that cannot report such rows): nothing of the result may be used, the caller takes the exact scope and runs
  * again.  -1: error. */
@@ -1009,9 +1011,16 @@ static obj_p select_impl(obj_p dict) {
          * full pass is a quarter to a third of such a query -- with the kernels reporting any selected key outside it; a report (or a
          * path that cannot report) comes back here for the exact scope.  RFX_NO_SAMPLED_SCOPE=1 turns it off. */
         int spec_ok = by && nrows >= ((int64_t)1 << 24) && !getenv("RFX_NO_SAMPLED_SCOPE");
+        for (int i = 0; i < g_nspec_failed && spec_ok; i++) /* a sample that missed this key column's range before (a rare extreme value) will again */
+            if (g_spec_failed[i] == dk) spec_ok = 0;
     rescope:;
         int spec = 0;
-        if (by && !spec_ok && nrows >= ((int64_t)1 << 24) && !getenv("RFX_NO_SAMPLED_SCOPE")) g_stat[ST_SCOPE_RETRIED]++; /* back here after a report */
+        if (g_spec_retry) { /* back here after a report */
+            g_spec_retry = 0;
+            g_stat[ST_SCOPE_RETRIED]++;
+            g_spec_failed[g_nspec_failed % 32] = dk;
+            if (g_nspec_failed < 32) g_nspec_failed++;
+        }
         if (by) {
             int64_t kmin, kmax, seen;
             if (nkeys > 1) {
@@ -1022,9 +1031,9 @@ static obj_p select_impl(obj_p dict) {
                     spec = 1;
                     for (int i = 0; i < nkeys && spec; i++) {
                         if (rfx_hip_scope_sample_i64(g_ctx, (const int64_t *)dks[i], nrows, &kmins[i], &kmaxs[i]) != RFX_OK) { res = fail_hip("scope"); goto done; }
-                        if (kmins[i] == RFX_NULL_I64 || kmaxs[i] < kmins[i] || (uint64_t)(kmaxs[i] - kmins[i]) >= (1u << 14)) spec = 0;
+                        if (kmins[i] == RFX_NULL_I64 || kmaxs[i] < kmins[i] || (uint64_t)(kmaxs[i] - kmins[i]) >= RFX_SCOPE_SAMPLE_MAX_RANGE) spec = 0;
                         else prod *= kmaxs[i] - kmins[i] + 1;
-                        if (prod > (1 << 14)) spec = 0;
+                        if (prod > RFX_SCOPE_SAMPLE_MAX_RANGE) spec = 0;
                     }
                     if (spec) seen = nrows;
                 }
@@ -1084,7 +1093,7 @@ static obj_p select_impl(obj_p dict) {
             } else {
                 if (spec_ok) {
                     if (rfx_hip_scope_sample_i64(g_ctx, (const int64_t *)dk, nrows, &kmin, &kmax) != RFX_OK) { res = fail_hip("scope"); goto done; }
-                    spec = kmin != RFX_NULL_I64 && kmax >= kmin && (uint64_t)(kmax - kmin) < (1u << 14);
+                    spec = kmin != RFX_NULL_I64 && kmax >= kmin && (uint64_t)(kmax - kmin) < RFX_SCOPE_SAMPLE_MAX_RANGE;
                     seen = nrows;
                 }
                 if (!spec && rfx_hip_group_scope(g_ctx, (const int64_t *)dk, wp.preds, wp.npred, wp.logic, aggs, nagg, nrows, &kmin, &kmax, &seen) != RFX_OK) { res = fail_hip("scope"); goto done; }
@@ -1106,7 +1115,7 @@ static obj_p select_impl(obj_p dict) {
                 /* dense "perfect hash" iff range <= rows (core/index.c:2013), like the reference; else open addressing */
                 uint64_t range = (uint64_t)kmax - (uint64_t)kmin + 1;
                 int dense = range != 0 && range <= (uint64_t)seen && kmin != RFX_NULL_I64;
-                if (spec && !dense) { spec_ok = 0; goto rescope; }
+                if (spec && !dense) { spec_ok = 0; goto rescope; } /* (not a miss of the sample: nothing to remember) */
                 int narr = 0;
                 rfx_hip_group_table_arrays(aggs, nagg_run, &narr);
                 int64_t cells = dense ? (int64_t)range : 0;
@@ -1155,6 +1164,7 @@ static obj_p select_impl(obj_p dict) {
                         free(mirror);
                         rfx_hip_free(g_ctx, store);
                         spec_ok = 0;
+                        g_spec_retry = 1;
                         goto rescope;
                     }
                     g_mirror_host = (const char *)mirror; /* released at `done` */
@@ -1170,6 +1180,7 @@ static obj_p select_impl(obj_p dict) {
                     if (pr == 1) {
                         rfx_hip_free(g_ctx, store);
                         spec_ok = 0;
+                        g_spec_retry = 1;
                         goto rescope;
                     }
                 } else {

@@ -711,7 +711,7 @@ class Engine:
             # several key columns -> one composite dense key (index_group_list_perfect, core/index.c:2308-2424)
             kcols = [self._key_col(k, table) for k in key]
             try:
-                spec_keys = _spec and self._may_speculate(kcols[0].numel(), _collective)
+                spec_keys = _spec and self._may_speculate(kcols[0].numel(), _collective, kcols[0])
                 tmax, seen, multi = self._composite_plan(kcols, where, table, _collective, sampled=spec_keys)
                 if spec_keys and multi is None:
                     spec_keys = False
@@ -730,7 +730,7 @@ class Engine:
             raise RfxError("nested boolean trees are not fused with `by:`; pass ids via where() + at_ids()")
         spec = False  # the scope below was SAMPLED: the pass reports keys outside it, a report sends the query through the exact scope
         if multi is None:
-            if _spec and self._may_speculate(n, _collective):
+            if _spec and self._may_speculate(n, _collective, key):
                 smn, smx = self.scope_sample(key)
                 if smn != L.NULL_I64 and 0 < smx - smn + 1 <= self.SPEC_MAX_SLOTS:
                     kmin, kmax, seen, spec = smn, smx, n, True
@@ -795,6 +795,8 @@ class Engine:
             if redo:  # an outlier, a null key, a range the sample missed: the exact scope and the pass again
                 del t, store
                 self.spec_retries += 1
+                kk = key if multi is None else kcols[0]
+                self.__dict__.setdefault("_spec_failed", set()).add((kk.data_ptr(), kk.numel()))
                 return self.group_by(key if multi is None else kcols, aggs, where, table, total_rows, row0, _collective, order, _cap_hint, _probe_first, False)
             if _collective is not None:  # the kinds of THIS launch's aggregates (a chunk of the query's, or the row-hash path's extras)
                 _collective("tables", (store, layout, [int(aarr[i].kind) for i in range(nagg)],
@@ -1099,9 +1101,13 @@ class Engine:
         return out
 
     SPEC_MAX_SLOTS = 1 << 14  # sampled scopes only for ranges whose tables are LDS-sized (the kernels that report out-of-scope keys)
+    # ... and at most a tenth of the sample (2^18 rows): a uniformly drawn extreme value is then missed with probability e^-10
 
-    def _may_speculate(self, n: int, _collective) -> bool:
-        """A sampled key scope instead of the full scope pass?  Large single-GPU inputs only; RFX_NO_SAMPLED_SCOPE=1 turns it off."""
+    def _may_speculate(self, n: int, _collective, key: Optional[torch.Tensor] = None) -> bool:
+        """A sampled key scope instead of the full scope pass?  Large single-GPU inputs only; not for a key column whose sampled
+        scope was reported too small before (a rare extreme value: the sample would miss it again); RFX_NO_SAMPLED_SCOPE=1 turns it off."""
+        if key is not None and (key.data_ptr(), key.numel()) in self.__dict__.setdefault("_spec_failed", set()):  # (per engine)
+            return False
         return n >= (1 << 24) and _collective is None and not os.environ.get("RFX_NO_SAMPLED_SCOPE")
 
     def scope_sample(self, key: torch.Tensor) -> Tuple[int, int]:

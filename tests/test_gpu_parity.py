@@ -740,7 +740,7 @@ def test_few_groups_run_time_compiled_kernels(eng, groups, n):
 
 # ---------------------------------------------------------------- sampled key scopes (large inputs, LDS-sized ranges)
 def test_sampled_scope_reports_what_it_missed(eng):
-    """From 2^24 rows on, a group-by over an LDS-sized key range takes its scope from a SAMPLE (2^14 strided rows + both ends) instead of
+    """From 2^24 rows on, a group-by over an LDS-sized key range takes its scope from a SAMPLE (2^18 strided rows + both ends) instead of
     index_scope_i64's full pass, and the LDS-table kernels report selected rows whose key lies outside it; a report sends the
     query through the exact scope.  Here: ranges the sample sees completely (no retry), one outlier key / a null key / a key
     below the minimum hidden between the sampled rows (retry, same answer), an outlier that the filter removes (no report),
@@ -772,8 +772,8 @@ def test_sampled_scope_reports_what_it_missed(eng):
         finally:
             del os.environ["RFX_NO_SAMPLED_SCOPE"]
 
-    hidden = 5  # stride = n >> 14 = 1024: row 5 + 1024 * j is never sampled, and lies past the first 2^11 rows only for j >= 2
-    spot = hidden + 1024 * 4097
+    hidden = 5  # stride = n >> 18 = 64: row 5 + 64 * j is never sampled, and lies past the first 2^11 rows for j >= 32
+    spot = hidden + 64 * 65_537
     base = eng.spec_retries
     same(run("k"), exact("k"))
     same(run(["k", "k2"]), exact(["k", "k2"]))
@@ -784,12 +784,17 @@ def test_sampled_scope_reports_what_it_missed(eng):
     for bad in (1_000, -3, L_NULL):
         keep = int(k[spot])
         k[spot] = bad
+        eng.__dict__.setdefault("_spec_failed", set()).clear()  # (a column whose sample failed is not sampled again: forget that between the cases)
         before = eng.spec_retries
         same(run("k"), exact("k"))
         assert eng.spec_retries == before + 1, bad  # reported, ran again under the exact scope
+        same(run("k"), exact("k"))
+        assert eng.spec_retries == before + 1, bad  # ... and remembered: the same column is not sampled a second time
+        eng.__dict__.setdefault("_spec_failed", set()).clear()
         before = eng.spec_retries
         same(run(["k", "k2"]), exact(["k", "k2"]))
         assert eng.spec_retries == before + 1, bad
+        eng.__dict__.setdefault("_spec_failed", set()).clear()
         if bad != L_NULL:
             a_keep = int(a[spot])
             a[spot] = 999_999  # the filter drops the outlier's row: nothing to report
