@@ -418,6 +418,7 @@ def main():
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         respawn(args.gpus)  # does not return
+    _stdout_is_for_the_json_line_only()  # (after the respawn decision: the ranks started above inherit the untouched stdout)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -565,6 +566,15 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     eng.close()
+
+
+def _stdout_is_for_the_json_line_only():
+    """Libraries write to the process's stdout too (RCCL prints a version banner there when a communicator comes up): from here on file
+    descriptor 1 points at stderr, and `print` keeps the real stdout -- which only the JSON line is printed to."""
+    sys.stdout.flush()
+    real = os.dup(1)
+    os.dup2(2, 1)
+    sys.stdout = os.fdopen(real, "w", buffering=1)
 
 
 if __name__ == "__main__":
