@@ -1352,6 +1352,7 @@ static int estimate_distinct(rfx_ctx *c, const u64 *d_key, i64 nrows, double *es
 }
 
 int rfx_group_part_hash_accumulate(rfx_ctx *c, const Plan &P0, int key_idx, const HashArgs &H, int *d_overflow) {
+    c->ext_i[2] = 0;
     if (P0.nrows >= (1LL << 32) || P0.nrows < (1 << 16) || (c->flags & RFX_TUNE_NO_PARTITION)) return RFX_ESTATE;
     {
         // 256 partitions x one CU's LDS hold a few thousand keys each: beyond ~4 M distinct keys nearly every record overflows its
@@ -1359,6 +1360,7 @@ int rfx_group_part_hash_accumulate(rfx_ctx *c, const Plan &P0, int key_idx, cons
         double est = 0;
         const int rc = estimate_distinct(c, (const u64 *)P0.cols[key_idx], P0.nrows, &est);
         if (rc != RFX_OK) return rc;
+        c->ext_i[2] = (i64)est; // (the device-wide kernel's caller sizes its table by it)
         if (est > 4.0e6) return RFX_ESTATE;
     }
     Plan P = P0;

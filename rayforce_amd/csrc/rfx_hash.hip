@@ -210,6 +210,12 @@ extern "C" int rfx_hip_group_hash_accumulate(rfx_ctx_t *c, const int64_t *d_key,
     rc = rfx_group_part_hash_accumulate(c, P, key_idx, H, flag);
     if (rc == RFX_OK) return read_overflow(c, flag, "group_hash_accumulate");
     if (rc != RFX_ESTATE) return rc;
+    if (c->ext_i[2] > 0 && npred == 0 && t->capacity < 2 * nrows && (double)c->ext_i[2] > 0.6 * (double)t->capacity) {
+        // (unfiltered inputs only, and never at the reference's own size of 2 x rows: there the estimate -- which errs high -- cannot turn into an error)
+        // the sampled distinct-key estimate says this table is too small: say so before a launch finds out at 3/4 load (6 ms at 1e8 keys)
+        rfx_set_error("group_hash_accumulate: about %lld distinct keys for %lld slots (sampled estimate): hash table too small", (long long)c->ext_i[2], (long long)t->capacity);
+        return RFX_ELIMIT;
+    }
     int grid = rfx_grid(c) * 4;
     switch (P.ncols) {
         case 1: launch_hash<1>(c, P, H, grid, flag); break;
