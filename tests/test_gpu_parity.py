@@ -806,3 +806,48 @@ def test_sampled_scope_reports_what_it_missed(eng):
 
 
 L_NULL = -(2**63)
+
+
+def test_k1_plan_kernels_match_the_prebuilt_kernels(eng):
+    """K1 compiled at run time for one plan (filter_aggr_body with the plan's descriptors as a constexpr, rfx_rtc.hip) against the
+    prebuilt instantiations (RFX_TUNE_NO_RTC) on 2^24 + rows: every aggregate kind over i64 / f64 columns with nulls and NaNs, 0 / 1 /
+    3 / 6 predicates (atoms, a column operand, a NaN atom), AND / OR, one expression and an expression tree, a ragged tail --
+    integer results and exact operations bit for bit, f64 sums to 1e-9 of the column scale."""
+    n = (1 << 24) + 4_321
+    a = eng.gen_i64(n, 2, 1_000_000)
+    b = eng.gen_i64(n, 3, 1_000)
+    v = eng.gen_f64(n, 5)
+    w = eng.gen_f64(n, 6) - 0.5
+    a[17::1009] = L_NULL
+    v[23::997] = float("nan")
+    t = {"a": a, "b": b, "v": v, "w": w}
+    plans = [
+        ([("sum", "a"), ("count", "a"), ("min", "a"), ("max", "a"), ("avg", "a"), ("first", "a")], None),
+        ([("sum", "v"), ("count", "v"), ("min", "v"), ("max", "v"), ("avg", "v"), ("first", "v")], ("<", "a", 300_000)),
+        ([("sum", "w"), ("max", "b")], ("and", ("<", "a", 900_000), (">", "w", -0.3), ("!=", "b", 7))),
+        ([("avg", "w"), ("min", "a")], ("or", ("<", "a", 10_000), (">", "w", 0.45), ("==", "b", 3), (">=", "v", 0.99), ("<", "b", "a"), ("<", "v", float("nan")))),
+        ([("sum", ("*", "v", "w"))], ("and", ("<", "b", 500), (">=", "w", -0.25), ("<=", "w", 0.25))),
+        ([("sum", ("*", ("*", "v", ("-", 1.0, "w")), ("+", 1.0, "v"))), ("max", ("+", "a", "b"))], (">", "a", 123_456)),
+    ]
+    l0, c0 = _rtc_stats(eng)
+    os.environ["RFX_RTC_EAGER"] = "1"
+    try:
+        fast = [eng.filter_aggr(aggs, where, t) for aggs, where in plans]
+    finally:
+        del os.environ["RFX_RTC_EAGER"]
+    l1, c1 = _rtc_stats(eng)
+    if l1 == l0:
+        pytest.skip("no run-time compiler on this box (libhiprtc.so / kernel sources): the prebuilt kernels answered")
+    try:
+        eng.tune(flags=NO_RTC)
+        slow = [eng.filter_aggr(aggs, where, t) for aggs, where in plans]
+        assert _rtc_stats(eng)[0] == l1
+    finally:
+        eng.tune(flags=0)
+    for (aggs, where), (fv, fs), (sv, ss) in zip(plans, fast, slow):
+        assert fs == ss, where
+        for (fn, col), x, y in zip(aggs, fv, sv):
+            if isinstance(x, float) and fn in ("sum", "avg"):
+                assert (math.isnan(x) and math.isnan(y)) or abs(x - y) <= 1e-9 * n * 2.1, (fn, col, x, y)  # 1e-9 of sum |x_i| <= 2.1 n: the two kernels differ in summation order only
+            else:
+                assert (x == y) or (isinstance(x, float) and math.isnan(x) and math.isnan(y)), (fn, col, x, y)
