@@ -870,9 +870,7 @@ static obj_p select_impl(obj_p dict) {
         int nkeys = 0;
         const void *dk = NULL;
         int64_t kmins[RFX_MAX_KEYS], kmaxs[RFX_MAX_KEYS], kmults[RFX_MAX_KEYS], comp_max = 0;
-        int rowhash = 0, nagg_run = 0;            /* row-hash path: aggregates [nagg, nagg_run) are the (min, max) proof pairs of the key columns */
-        int64_t krepl[RFX_MAX_KEYS] = {0};         /* stand-in value of a null key inside its proof pair */
-        int khasnull[RFX_MAX_KEYS] = {0};
+        int rowhash = 0, nagg_run = 0;            /* row-hash path: the key tuples group on the reference's row hash */
         int8_t key_out_type = RFX_TYPE_I64; /* one key: type of the result's key column */
         obj_p kenum = NULL;                 /* one key, an ENUM column */
         if (by) {
@@ -1044,35 +1042,14 @@ static obj_p select_impl(obj_p dict) {
                 if (seen > 0) {
                     if (rfx_composite_plan(kmins, kmaxs, nkeys, kmults, &comp_max) != RFX_OK) {
                         /* ranges beyond 64 bits / a null key: the reference's row-hash path (index_group_list, core/index.c:2731-2790).
-                         * Group on the reference's own row hash; every key column rides along as a (min, max) pair: equal in every
-                         * group = one tuple per group (proof instead of the reference's tuple compare), and max IS the key column. */
-                        if (nagg + 2 * nkeys > RFX_MAX_AGGS) { why = "by: key tuple on the row-hash path with more outputs than one launch carries"; goto out; }
+                         * Group on the reference's own row hash; the tuple comparison the reference makes on every probe
+                         * (__index_list_cmp_row) is made once, afterwards: every row against its group's first row (below). */
                         void *hh = NULL;
                         if (rfx_hip_malloc(g_ctx, &hh, (size_t)nrows * 8) != RFX_OK) { res = fail_hip("row hash"); goto done; }
                         tmp[ntmp++] = hh;
                         if (rfx_hip_row_hash(g_ctx, dks, nkeys, nrows, 0, (int64_t *)hh) != RFX_OK) { res = fail_hip("row hash"); goto done; }
-                        for (int i = 0; i < nkeys; i++) {
-                            const void *chk = dks[i];
-                            if (kmins[i] == RFX_NULL_I64) { /* min / max skip nulls: give the null key a value of its own above the maximum */
-                                if (kmaxs[i] == INT64_MAX) { why = "by: key column with nulls and INT64_MAX on the row-hash path"; goto out; }
-                                void *c2 = NULL;
-                                if (rfx_hip_malloc(g_ctx, &c2, (size_t)nrows * 8) != RFX_OK) { res = fail_hip("row hash"); goto done; }
-                                tmp[ntmp++] = c2;
-                                if (rfx_hip_replace_null_i64(g_ctx, (const int64_t *)dks[i], nrows, kmaxs[i] + 1, (int64_t *)c2) != RFX_OK) { res = fail_hip("row hash"); goto done; }
-                                chk = c2;
-                                khasnull[i] = 1;
-                                krepl[i] = kmaxs[i] + 1;
-                            }
-                            for (int j = 0; j < 2; j++) {
-                                rfx_agg_t *pa = &aggs[nagg + 2 * i + j];
-                                memset(pa, 0, sizeof(*pa));
-                                pa->d_col = chk;
-                                pa->col_type = RFX_I64;
-                                pa->kind = j ? RFX_AGG_MAX : RFX_AGG_MIN;
-                            }
-                        }
                         rowhash = 1;
-                        nagg_run = nagg + 2 * nkeys;
+                        nagg_run = nagg;
                         dk = hh;
                         if (rfx_hip_scope_i64(g_ctx, (const int64_t *)hh, NULL, 0, RFX_AND, nrows, &kmin, &kmax, &seen) != RFX_OK) { res = fail_hip("scope"); goto done; }
                     } else {
@@ -1194,8 +1171,43 @@ static obj_p select_impl(obj_p dict) {
                         goto grow;
                     }
                 }
+                if (ok && rowhash && groups > 0) {
+                    /* one hash = one tuple?  Every row's group-first row (the join probe against the group-by's own table), then per key
+                     * column: the column gathered at those rows must equal the column itself (K1 counts the rows where it does not). */
+                    void *ids = NULL, *chk = NULL;
+                    ok = rfx_hip_malloc(g_ctx, &ids, (size_t)nrows * 8) == RFX_OK && rfx_hip_malloc(g_ctx, &chk, (size_t)nrows * 8) == RFX_OK &&
+                         rfx_hip_join_probe_hash(g_ctx, (const int64_t *)dk, nrows, &ht, (int64_t *)ids) == RFX_OK;
+                    int collision = 0;
+                    for (int i = 0; i < nkeys && ok && !collision; i++) {
+                        rfx_pred_t ne;
+                        rfx_agg_t cnt;
+                        rfx_value_t cv;
+                        int64_t differ = 0;
+                        memset(&ne, 0, sizeof(ne));
+                        memset(&cnt, 0, sizeof(cnt));
+                        ne.d_col = chk;
+                        ne.col_type = RFX_I64;
+                        ne.op = RFX_NE;
+                        ne.d_rhs_col = dks[i];
+                        ne.rhs_type = RFX_I64;
+                        cnt.kind = RFX_AGG_COUNT;
+                        cnt.col_type = RFX_I64;
+                        ok = rfx_hip_gather_or(g_ctx, dks[i], dks[i], (const int64_t *)ids, nrows, 0, chk) == RFX_OK &&
+                             rfx_hip_filter_aggr_host(g_ctx, &ne, 1, RFX_AND, &cnt, 1, nrows, &cv, &differ) == RFX_OK;
+                        if (ok && differ) collision = 1;
+                    }
+                    if (ids) rfx_hip_free(g_ctx, ids);
+                    if (chk) rfx_hip_free(g_ctx, chk);
+                    if (ok && collision) { /* two key tuples, one 64-bit row hash: leave the query to the host rather than answer wrongly */
+                        rfx_hip_free(g_ctx, store);
+                        why = "row-hash collision between two key tuples";
+                        goto out;
+                    }
+                }
                 const void *dkeys_out = NULL; /* device address of the result's key cells */
+                void *dfirst = NULL;          /* row-hash path: the groups' first rows (the key columns are gathered there) */
                 if (ok && groups > 0 && !small) ok = rfx_hip_malloc(g_ctx, &dout, (size_t)(nagg_run + 1) * (size_t)groups * 8) == RFX_OK;
+                if (ok && groups > 0 && rowhash) ok = rfx_hip_malloc(g_ctx, &dfirst, (size_t)groups * 8) == RFX_OK;
                 if (ok && groups > 0) {
                     void *ptrs[RFX_MAX_AGGS];
                     if (small) {
@@ -1204,7 +1216,7 @@ static obj_p select_impl(obj_p dict) {
                     } else {
                         dkeys_out = dout;
                         for (int a = 0; a < nagg_run; a++) ptrs[a] = (int64_t *)dout + (size_t)(a + 1) * groups;
-                        ok = (dense ? rfx_hip_group_emit(g_ctx, aggs, &gt, (int64_t *)dout, NULL, ptrs) : rfx_hip_hash_emit(g_ctx, aggs, &ht, (int64_t *)dout, NULL, ptrs)) == RFX_OK;
+                        ok = (dense ? rfx_hip_group_emit(g_ctx, aggs, &gt, (int64_t *)dout, NULL, ptrs) : rfx_hip_hash_emit(g_ctx, aggs, &ht, (int64_t *)dout, (int64_t *)dfirst, ptrs)) == RFX_OK;
                     }
                     if (nkeys == 1 && key_out_type == RFX_TYPE_DATE) { /* the virtual Date column: 4-byte days */
                         okeys = H.vector(RFX_TYPE_DATE, groups);
@@ -1242,28 +1254,15 @@ static obj_p select_impl(obj_p dict) {
                             }
                         }
                     } else if (rowhash) {
-                        /* proof: min == max of every key column in every group; the maxima are the key columns (nulls restored) */
-                        int64_t *mn = (int64_t *)malloc((size_t)groups * 8);
-                        ok = ok && mn != NULL;
-                        int collision = 0;
+                        /* the key columns of the result: the tuples at the groups' first rows */
+                        void *kg = NULL;
+                        ok = ok && rfx_hip_malloc(g_ctx, &kg, (size_t)groups * 8) == RFX_OK;
                         for (int i = 0; i < nkeys && ok; i++) {
                             okcols[i] = H.vector(kcs[i]->type, groups);
-                            int64_t *mx = (int64_t *)RFX_AS_RAW(okcols[i]);
-                            ok = rfx_hip_d2h(g_ctx, mn, ptrs[nagg + 2 * i], (size_t)groups * 8) == RFX_OK &&
-                                 rfx_hip_d2h(g_ctx, mx, ptrs[nagg + 2 * i + 1], (size_t)groups * 8) == RFX_OK;
-                            for (int64_t g = 0; g < groups && ok; g++) {
-                                if (mn[g] != mx[g]) collision = 1;
-                                if (khasnull[i] && mx[g] == krepl[i]) mx[g] = RFX_NULL_I64;
-                            }
+                            ok = rfx_hip_gather(g_ctx, dks[i], (const int64_t *)dfirst, groups, kg) == RFX_OK &&
+                                 rfx_hip_d2h(g_ctx, RFX_AS_RAW(okcols[i]), kg, (size_t)groups * 8) == RFX_OK;
                         }
-                        free(mn);
-                        if (ok && collision) { /* two key tuples, one 64-bit row hash: leave the query to the host rather than answer wrongly */
-                            if (dout) rfx_hip_free(g_ctx, dout);
-                            rfx_hip_free(g_ctx, store);
-                            for (int i = 0; i < nkeys; i++) if (okcols[i]) H.drop(okcols[i]);
-                            why = "row-hash collision between two key tuples";
-                            goto out;
-                        }
+                        if (kg) rfx_hip_free(g_ctx, kg);
                     } else {
                         /* key column i = min_i + (composite / mult_i) % range_i  (= key_i[first row], core/query.c:110-135) */
                         void *dec = NULL;
@@ -1281,6 +1280,7 @@ static obj_p select_impl(obj_p dict) {
                     }
                 }
                 if (dout) rfx_hip_free(g_ctx, dout);
+                if (dfirst) rfx_hip_free(g_ctx, dfirst);
                 rfx_hip_free(g_ctx, store);
                 if (!ok) {
                     if (okeys) H.drop(okeys);

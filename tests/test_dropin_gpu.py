@@ -46,6 +46,9 @@ QUERIES = [
     # an f64 key column groups on its bit pattern (index_group_f64 -> the open-addressing path, core/index.c:2108): here on the hashed tables
     ("q22", "{c: (count a) s: (sum a) from: t by: vq}", ["vq", "c", "s"]),
     ("q23", "{m: (max v) from: t where: (< a 300000) by: vq}", ["vq", "m"]),
+    # six key columns (the H2O Q7 shape) on the row-hash path, more outputs than proof aggregates would have left room for
+    ("q24", "{s: (sum v) c: (count a) mx: (max a) mn: (min v) av: (avg v) from: t by: {k1: k1 k2: k2 k3: k3 w1: w1 w2: w2 k: k}}",
+     ["k1", "k2", "k3", "w1", "w2", "k", "s", "c", "mx", "mn", "av"]),
 ]
 
 
@@ -58,7 +61,7 @@ UPDATES = [
     ("u6", "{n: 100 from: t}", ["n", "k"]),
 ]
 
-UNORDERED = {"q13": 1, "q16": 3, "q22": 1, "q23": 1}  # name -> leading key columns: group order there depends on the reference's executor count
+UNORDERED = {"q13": 1, "q16": 3, "q22": 1, "q23": 1, "q24": 6}  # name -> leading key columns: group order there depends on the reference's executor count
 
 
 @pytest.mark.skipif(not ref.available(), reason="oracle/_ref/rayforce not built (needs /root/reference at build time)")
