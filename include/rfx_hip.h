@@ -189,9 +189,19 @@ enum {
     RFX_TUNE_CHUNK_CONTIG = 65536,   /* one-pass chunk partitioning: every workgroup takes one contiguous row range instead of grid-stride tiles */
     RFX_TUNE_CHUNK_QUEUE = 131072,   /* one-pass chunk partitioning under a selective filter: always the sorted-queue kernel (as for skewed keys), never per-partition bins */
     RFX_TUNE_CHUNK_BINS = 262144,    /* ... always per-partition bins, however the sampled keys spread: for tests */
-    RFX_TUNE_NO_RTC = 524288         /* never compile a plan-specialised kernel at run time (hiprtc): the prebuilt kernels only */
+    RFX_TUNE_NO_RTC = 524288,        /* never compile a plan-specialised kernel at run time (hiprtc): the prebuilt kernels only */
+    RFX_TUNE_NO_PLANE = 1048576      /* one-pass partitioning: 16-byte records in chunks (round 2), never the 8 + 4-byte planes */
 };
 int rfx_hip_ctx_tune(rfx_ctx_t *ctx, int blocks_per_cu, int flags);
+/* Path counters of a context since its creation: which partitioning kernels answered (tests assert them, bench.py reports them). */
+enum {
+    RFX_STAT_PLANE_SCATTER = 0,   /* k_plane_scatter launches (8 + 4-byte planes, rfx_group_plane.hip) */
+    RFX_STAT_PLANE_FALLBACK = 1,  /* ... that gave up (a region overflowed / a ring did not drain): the chunk kernels took over */
+    RFX_STAT_PLANE_AGGREGATE = 2, /* k_plane_aggregate launches */
+    RFX_STAT_CHUNK_SCATTER = 3,   /* k_chunk_scatter* launches (16-byte records, rfx_group_chunk.hip) */
+    RFX_STAT_CHUNK_AGGREGATE = 4  /* k_chunk_aggregate launches */
+};
+int64_t rfx_hip_ctx_stat(rfx_ctx_t *ctx, int which);
 
 /* ---- plain device memory for C hosts (Python hosts pass torch-owned pointers instead) ---- */
 int rfx_hip_malloc(rfx_ctx_t *ctx, void **d_ptr, size_t bytes);

@@ -57,6 +57,8 @@ extern "C" int rfx_hip_ctx_create(int device, void *stream, rfx_ctx_t **out) {
 }
 
 static void pool_release(rfx_ctx *c);
+void rfx_plane_release(rfx_ctx *c); // rfx_group_plane.hip
+void rfx_plane_invalidate(rfx_ctx *c);
 extern "C" int rfx_hip_ctx_destroy(rfx_ctx_t *c) {
     if (!c) return RFX_OK;
     (void)hipSetDevice(c->device);
@@ -75,6 +77,7 @@ extern "C" int rfx_hip_ctx_destroy(rfx_ctx_t *c) {
     rfx_io_release(c);
     pool_release(c);
     if (c->ext_p[1]) (void)hipFree(c->ext_p[1]);
+    rfx_plane_release(c);
     if (c->d_pc_counts) (void)hipFree(c->d_pc_counts);
     if (c->h_pin) (void)hipHostFree(c->h_pin);
     (void)hipEventDestroy(c->ev0);
@@ -84,6 +87,11 @@ extern "C" int rfx_hip_ctx_destroy(rfx_ctx_t *c) {
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     free(c);
     return RFX_OK;
+}
+
+extern "C" int64_t rfx_hip_ctx_stat(rfx_ctx_t *c, int which) {
+    if (!c || which < 0 || which > 4) return -1;
+    return c->ext_i[3 + which];
 }
 
 extern "C" int rfx_hip_ctx_sync(rfx_ctx_t *c) {
@@ -377,6 +385,11 @@ extern "C" int rfx_hip_free(rfx_ctx_t *c, void *d_ptr) {
 extern "C" int rfx_hip_h2d(rfx_ctx_t *c, void *d_dst, const void *src, size_t bytes) {
     RFX_REQUIRE(c, RFX_EINVAL, "ctx is NULL");
     if (!bytes) return RFX_OK;
+    // device data changed under whatever a scope pass left partitioned (the residency cache refreshes stale columns IN PLACE, at the same
+    // device address): partitions are matched by pointers and sizes only, so none survives an upload
+    c->ck_valid = 0;
+    c->pc_valid = 0;
+    rfx_plane_invalidate(c);
     RFX_HIP_CHECK(hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, c->stream));
     RFX_HIP_CHECK(hipStreamSynchronize(c->stream));
     return RFX_OK;
@@ -391,6 +404,9 @@ extern "C" int rfx_hip_d2h(rfx_ctx_t *c, void *dst, const void *d_src, size_t by
 extern "C" int rfx_hip_memset(rfx_ctx_t *c, void *d_dst, int byte, size_t bytes) {
     RFX_REQUIRE(c, RFX_EINVAL, "ctx is NULL");
     if (!bytes) return RFX_OK;
+    c->ck_valid = 0;
+    c->pc_valid = 0;
+    rfx_plane_invalidate(c);
     RFX_HIP_CHECK(hipMemsetAsync(d_dst, byte, bytes, c->stream));
     return RFX_OK;
 }

@@ -1101,6 +1101,11 @@ __global__ __launch_bounds__(RFX_BLOCK) void k_scope_sample(const Plan P, int ke
 // host side
 // ------------------------------------------------------------------------------------------------
 int rfx_chunk_reserve(rfx_ctx *c, size_t bytes);
+// the plane form of this pass (rfx_group_plane.hip): 12-byte records in two planes, tried first where it applies
+int rfx_plane_scope(rfx_ctx *c, const Plan &P, int key_idx, const void *d_key, int npred, int logic, unsigned long long est_range, double frac,
+                    i64 *kmin, i64 *kmax, i64 *seen);
+int rfx_plane_accumulate(rfx_ctx *c, const Plan &P, int key_idx, const rfx_group_tables_t *t);
+void rfx_plane_invalidate(rfx_ctx *c);
 
 static void chunk_pred_sig(const Plan &P, u64 (*sig)[6]) {
     for (int i = 0; i < P.npred; i++) {
@@ -1238,6 +1243,7 @@ static void fold_scope(const ScopePart *h, int n, i64 *kmin, i64 *kmax, i64 *see
 int rfx_chunk_scope(rfx_ctx *c, const int64_t *d_key, const rfx_pred_t *preds, int npred, int logic, const rfx_agg_t *aggs, int nagg, i64 nrows,
                     i64 *kmin, i64 *kmax, i64 *seen) {
     c->ck_valid = 0;
+    rfx_plane_invalidate(c);
     if ((c->flags & (RFX_TUNE_NO_PARTITION | RFX_TUNE_NO_CHUNK)) || nrows >= (1LL << 32) || nrows < ((c->flags & RFX_TUNE_CHUNK_SMALL) ? (1LL << 16) : (1LL << 22)) || nagg < 1) return RFX_ESTATE;
     Plan P;
     int key_idx = 0;
@@ -1290,6 +1296,11 @@ int rfx_chunk_scope(rfx_ctx *c, const int64_t *d_key, const rfx_pred_t *preds, i
     // skewed and the mildly filtered inputs (RFX_TUNE_CHUNK_QUEUE: everywhere).
     const bool selective = (npred > 0 && frac <= 0.4) || (c->flags & RFX_TUNE_CHUNK_BINS) || (npred == 0 && spread && !(c->flags & RFX_TUNE_CHUNK_QUEUE));
     const bool bins = selective && (spread || (c->flags & RFX_TUNE_CHUNK_BINS)) && !(c->flags & RFX_TUNE_CHUNK_QUEUE);
+    if (spread && !(c->flags & (RFX_TUNE_CHUNK_QUEUE | RFX_TUNE_CHUNK_BINS | RFX_TUNE_CHUNK_CONTIG))) {
+        // spread keys: two planes of 8 + 4 bytes per record through decoupled LDS rings (40 instead of 48 bytes moved per row on C3)
+        const int prc = rfx_plane_scope(c, P, key_idx, d_key, npred, logic, est, frac, kmin, kmax, seen);
+        if (prc != RFX_ESTATE) return prc;
+    }
     ChunkArgs A;
     memset(&A, 0, sizeof(A));
     i64 tpw = 0, nulls = 0;
@@ -1328,6 +1339,7 @@ int rfx_chunk_scope(rfx_ctx *c, const int64_t *d_key, const rfx_pred_t *preds, i
         A.vcol = vc == key_idx ? 0 : 1;
         RFX_HIP_CHECK(hipMemsetAsync(A.ctl, 0, 256, c->stream));
         RFX_HIP_CHECK(hipMemsetAsync(A.meta, 0xFF, (size_t)A.max_chunks * 8, c->stream));
+        c->ext_i[3 + RFX_STAT_CHUNK_SCATTER]++;
         RFX_KERNEL_BEGIN(c);
         if (bins) {
             switch (P.ncols) {
@@ -1376,6 +1388,7 @@ int rfx_chunk_scope(rfx_ctx *c, const int64_t *d_key, const rfx_pred_t *preds, i
     A.vcol = vc;
     RFX_HIP_CHECK(hipMemsetAsync(A.ctl, 0, 256, c->stream));
     RFX_HIP_CHECK(hipMemsetAsync(A.meta, 0xFF, (size_t)A.max_chunks * 8, c->stream));
+    c->ext_i[3 + RFX_STAT_CHUNK_SCATTER]++;
     RFX_KERNEL_BEGIN(c);
     switch (P.ncols) {
         case 1: launch_chunk_scatter<1>(c, P, A); break;
@@ -1410,6 +1423,13 @@ int rfx_chunk_scope(rfx_ctx *c, const int64_t *d_key, const rfx_pred_t *preds, i
 
 // Pass 2 over the partitions rfx_chunk_scope left, if they are the partitions of exactly this plan.  RFX_ESTATE: not so.
 int rfx_chunk_accumulate(rfx_ctx *c, const Plan &P, int key_idx, const rfx_group_tables_t *t) {
+    {
+        const int prc = rfx_plane_accumulate(c, P, key_idx, t);
+        if (prc != RFX_ESTATE) {
+            c->ck_valid = 0;
+            return prc;
+        }
+    }
     if (!c->ck_valid) return RFX_ESTATE;
     bool ok = c->ck_key == (const void *)P.cols[key_idx] && c->ck_nrows == P.nrows && c->ck_npred == P.npred && c->ck_logic == P.logic && P.nx == 0;
     const int vc = ok ? single_value_col(P) : -1;
@@ -1443,6 +1463,7 @@ int rfx_chunk_accumulate(rfx_ctx *c, const Plan &P, int key_idx, const rfx_group
         G.acc[a] = (u64 *)t->d_acc[a];
         G.cnt[a] = (u64 *)t->d_cnt[a];
     }
+    c->ext_i[3 + RFX_STAT_CHUNK_AGGREGATE]++;
     RFX_KERNEL_BEGIN(c);
     hipLaunchKernelGGL(k_chunk_offsets, dim3(1), dim3(1024), 0, c->stream, A);
     int pgrid = (int)((c->ck_max_chunks + RFX_BLOCK - 1) / RFX_BLOCK);

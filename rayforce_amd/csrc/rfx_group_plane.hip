@@ -1,0 +1,809 @@
+// rfx_group_plane.hip -- one-pass radix partitioning into PLANES: the dense group-by whose tables do not fit one workgroup's LDS
+// (BASELINE C3 / C3w: 1e9 rows, 1e6 i64 keys, sum(f64)), moved with 12 (10) bytes per record instead of 16.
+//
+// What the reference does here: index_group_i64_scoped (core/index.c:2002-2092) walks the key column once, single-threaded, and
+// AGGR_ITER (core/aggr.c:73-181) folds the value column through the group ids.  rfx_group_chunk.hip partitions 16-byte records
+// {row:32 | key >> 8, value}: 16 B read + 16 written + 16 read per row, and a scatter that spends a third of its time in workgroup
+// barriers.  Measured bound on this part (tools/write_probe.hip, profiles/r03_write_probe.jsonl): a scatter keeps up with HBM only when
+// every store instruction covers >= 128 contiguous bytes per stream with 8..16 bytes per lane (128 B: 4.7-4.9 TB/s of mixed traffic,
+// 64 B: 3.7, 32 B: 3.1, 16 B: 2.5) -- so the record is split into planes that each leave in whole 128-byte lines:
+//
+//   value plane(s)  8 B per record, 16 records per line
+//   meta plane      4 B per record {slot-in-partition : 14 | row - block_base : 18}, 32 records per line        ("row" blocks)
+//                   2 B per record {slot-in-partition : 16}, 64 records per line                                ("plain" blocks, see below)
+//
+//   k_plane_scatter   one 1024-lane workgroup per ROW BLOCK of 2^18 rows (thousands of blocks: the dispatcher balances them).  Waves run
+//                     DECOUPLED, no workgroup barrier in the loop: a selected row takes the next place of its partition's LDS ring with
+//                     one returning LDS atomic, writes value + meta there, and counts itself into the ring group's arrival word; the
+//                     lane that completes a group queues it, and its wave stores queued groups as full lines (eight lanes x 16 B per line,
+//                     non-temporal) before it goes on.  A (block, partition) region has a FIXED place and size (no allocator): too many
+//                     records for a region (skew the sample did not show) or a stuck ring raise a flag and the caller takes the
+//                     chunk / column paths.  Side product, as before: min / max / count of the selected keys (index_scope_i64).
+//   k_plane_aggregate one LDS table set per partition (first row as 32 bits, accumulators 64, counts 32), regions streamed with the
+//                     next region's loads in flight, merged into the global tables.
+//
+// Bytes per row (C3): 16 read + 12 written + 12 read = 40 (was 48).
+#include "rfx_part_common.hpp"
+#include <stdlib.h>
+
+#define PL_T 1024
+#define PL_WAVES (PL_T / RFX_WAVE)
+#define PL_WROWS 512         /* rows per wave step: 8 per lane, four 16-byte loads per lane and column */
+#define PL_BLOCK_ROWS (1 << 18)
+#define PL_DELTA_BITS 18
+#define PL_SLOT_BITS 14
+#define PL_QCAP 320          /* per-wave queue of completed groups */
+#define PL_QFLUSH 24         /* ... stored once this many are queued (and at the end of every step) */
+#define PL_SPIN_LIMIT (1u << 14)
+#define PL_MAX_NV 3
+
+struct PlaneArgs {
+    int nblk, nrowblk; // row blocks; blocks [0, nrowblk) carry row deltas (4-byte meta), the rest 2-byte meta
+    int nv;            // value planes
+    i64 block_rows;
+    unsigned c0;       // records per (block, partition) region, a multiple of 64
+    u64 *vals[PL_MAX_NV];
+    unsigned *meta;    // region (b, p) starts at entry ((b << PBITS) + p) * c0 of every plane (4 bytes per entry in the meta plane)
+    unsigned *cnt;     // [nblk << PBITS] records per region
+    unsigned *ctl;     // 256 bytes, zeroed before the launch.  [1]: some region overflowed / a ring did not drain -> the caller falls back;
+                       // bytes 64..95: the scope of all selected keys {~image(min), image(max), count, nulls} (see the kernel's end)
+};
+struct PlSh {
+    unsigned dead, _pad[3];
+    ScopePart red[PL_WAVES];
+};
+// A value group is 2^VGL records (16: one 128-byte line per plane, 32: two), a partition's ring two groups; the meta plane's groups are
+// twice (4-byte entries) or four times (2-byte entries) as many records, so that they fill the same number of bytes.
+template <int NV, int PBITS, int VGL>
+__host__ __device__ constexpr size_t pl_lds_bytes() {
+    return (size_t)(1 << PBITS) * ((size_t)NV * (2 << VGL) * 8 + (16 << VGL) + 16 + 4) + (size_t)PL_WAVES * PL_QCAP * 4 + sizeof(PlSh) + 64;
+}
+typedef u64 pl_v2 __attribute__((ext_vector_type(2)));
+typedef unsigned pl_m2 __attribute__((ext_vector_type(2), aligned(4)));
+// LDS words other waves write: relaxed workgroup-scope atomics keep the LDS address space (a volatile cast turns them into FLAT
+// accesses that wait for every global load in flight)
+#define PL_LD(ptr) __hip_atomic_load((ptr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+#define PL_ST(ptr, v) __hip_atomic_store((ptr), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+
+template <int NC, int NP, int NV, int PBITS, int VGL>
+__global__ __launch_bounds__(PL_T) void k_plane_scatter(const Plan P, const PlaneArgs A) {
+    constexpr int PARTS = 1 << PBITS;
+    constexpr unsigned VG = 1u << VGL, RING = 2u << VGL; // records per value group / per ring
+    constexpr unsigned GB = 8u << VGL;                   // bytes of a group in any plane (128 or 256)
+    constexpr unsigned LPD = GB / 16;                    // lanes that store one group (16 bytes each)
+    extern __shared__ __attribute__((aligned(16))) unsigned char pl_smem[];
+    u64 *vring = (u64 *)pl_smem;                                   // [NV][PARTS][RING]
+    unsigned char *mring = pl_smem + (size_t)NV * PARTS * RING * 8; // [PARTS][2 * GB]
+    uint4 *words = (uint4 *)(mring + PARTS * 2 * GB);              // [PARTS] {value half 0, value half 1, meta half 0, meta half 1}: generation << 8 | arrivals
+    unsigned *tail = (unsigned *)(words + PARTS);                  // [PARTS] records handed out
+    unsigned *fq = tail + PARTS;                                   // [PL_WAVES][PL_QCAP]
+    PlSh &L = *(PlSh *)(fq + PL_WAVES * PL_QCAP);
+    PredSet<NP> S;
+    predset_load<NP>(P, S);
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    unsigned *myq = fq + wv * PL_QCAP;
+    const bool rows = (int)blockIdx.x < A.nrowblk;
+    const unsigned msh = rows ? VGL + 1u : VGL + 2u; // log2(records per meta group)
+    const unsigned mk = 1u << (msh - VGL);           // value groups per meta group
+    const i64 r0 = (i64)blockIdx.x * A.block_rows;
+    const i64 r1 = (r0 + A.block_rows < P.nrows) ? r0 + A.block_rows : P.nrows;
+    const u64 region = ((u64)blockIdx.x << PBITS) * A.c0;
+    for (int i = tid; i < PARTS; i += PL_T) {
+        tail[i] = 0;
+        words[i] = make_uint4(0, 0, 0, 0);
+    }
+    if (tid == 0) L.dead = 0;
+    __syncthreads();
+    i64 mn = RFX_INF_I64_D, mx = RFX_NULL_I64_D, sel = 0, nulls = 0;
+    int qn = 0; // wave-uniform
+
+    // completed groups of this wave -> global memory as whole lines (LPD lanes x 16 bytes per group), then their ring halves are released
+    auto flush_queue = [&]() __attribute__((always_inline)) {
+        asm volatile("" ::: "memory");
+        for (int i0 = 0; i0 < qn; i0 += 64 / (int)LPD) {
+            const int idx = i0 + (lane / (int)LPD);
+            if (idx < qn) {
+                const unsigned d = myq[idx];
+                const unsigned p = d & 0xFFu, gi = (d >> 8) & 0x3FFFFFu, pl = d >> 30, sub = lane & (LPD - 1u);
+                if (pl < 3) {
+                    const pl_v2 x = *(const pl_v2 *)(vring + ((size_t)pl * PARTS + p) * RING + (gi & 1u) * VG + sub * 2);
+                    u64 *dst = (NV == 1 ? A.vals[0] : (pl == 0 ? A.vals[0] : (pl == 1 ? A.vals[1] : A.vals[2])));
+                    __builtin_nontemporal_store(x, (pl_v2 *)(dst + region + (u64)p * A.c0 + (u64)gi * VG + sub * 2));
+                } else {
+                    const pl_v2 x = *(const pl_v2 *)(mring + p * (2 * GB) + (gi & 1u) * GB + sub * 16);
+                    __builtin_nontemporal_store(x, (pl_v2 *)((char *)A.meta + (region + (u64)p * A.c0) * 4 + (u64)gi * GB + sub * 16));
+                }
+            }
+        }
+        asm volatile("" ::: "memory"); // ring reads above, releases below
+        for (int i = lane; i < qn; i += 64) {
+            const unsigned d = myq[i];
+            const unsigned p = d & 0xFFu, gi = (d >> 8) & 0x3FFFFFu, pl = d >> 30;
+            unsigned *w = (unsigned *)&words[p];
+            if (pl == 0) atomicAdd(&w[gi & 1u], 256u - VG);              // VG arrivals -> 0, generation + 1
+            else if (pl == 3) atomicAdd(&w[2 + (gi & 1u)], 256u - mk);
+        }
+        qn = 0;
+    };
+
+    // one selected row per lane (or none): takes its place in its partition's ring, writes, counts itself in, queues completed groups
+    auto place = [&](const bool on, const u64 key, const u64 (&val)[NV], const unsigned delta) __attribute__((always_inline)) {
+        const unsigned p = (unsigned)key & (unsigned)(PARTS - 1);
+        unsigned seq = 0;
+        if (on) {
+            const i64 k = (i64)key;
+            if (k != RFX_NULL_I64_D) {
+                mn = k < mn ? k : mn;
+                mx = k > mx ? k : mx;
+            }
+            seq = atomicAdd(&tail[p], 1u);
+            if (seq >= A.c0) PL_ST(&L.dead, 1u); // the region is full (skew / selectivity the sample did not show): the caller falls back
+        }
+        sel += __popcll(__ballot(on)); // wave-uniform counters
+        nulls += __popcll(__ballot(on && (i64)key == RFX_NULL_I64_D));
+        const unsigned g = seq >> VGL, G = seq >> msh;
+        unsigned *w = (unsigned *)&words[p];
+        bool todo = on && seq < A.c0;
+        // A record goes into its ring place once the group that used the place before has left (generation check); almost always at
+        // once.  When not, the lanes that CAN write do so first (the awaited group may be waiting for exactly them), the wave stores what
+        // it owes (nobody may wait while holding completed groups), and only then polls.
+        for (unsigned it = 0;; it++) {
+            bool ready = false;
+            if (todo) {
+                unsigned vw, mw;
+                if (it == 0) {
+                    const uint4 q = words[p];
+                    vw = (g & 1u) ? q.y : q.x;
+                    mw = (G & 1u) ? q.w : q.z;
+                } else {
+                    vw = PL_LD(&w[g & 1u]);
+                    mw = PL_LD(&w[2 + (G & 1u)]);
+                }
+                ready = (vw >> 8) == (g >> 1) && (mw >> 8) == (G >> 1);
+            }
+            bool comp = false, mcomp = false;
+            if (ready) {
+#pragma unroll
+                for (int j = 0; j < NV; j++) vring[((size_t)j * PARTS + p) * RING + (seq & (RING - 1u))] = val[j];
+                const unsigned kh = (unsigned)(key >> PBITS);
+                if (rows) ((unsigned *)(mring + p * (2 * GB)))[seq & (4u * VG - 1u)] = (kh & ((1u << PL_SLOT_BITS) - 1u)) | (delta << PL_SLOT_BITS);
+                else ((unsigned short *)(mring + p * (2 * GB)))[seq & (8u * VG - 1u)] = (unsigned short)kh;
+                asm volatile("" ::: "memory"); // the record is in the ring before it is counted (LDS executes a wave's operations in order)
+                const unsigned old = atomicAdd(&w[g & 1u], 1u);
+                if ((old & 0xFFu) == VG - 1u) {
+                    comp = true;
+                    const unsigned oldm = atomicAdd(&w[2 + (G & 1u)], 1u);
+                    mcomp = (oldm & 0xFFu) == mk - 1u;
+                }
+                todo = false;
+            }
+            const u64 cb = __ballot(comp);
+            if (cb) {
+                if (comp) {
+                    const unsigned at = (unsigned)qn + (unsigned)NV * __builtin_amdgcn_mbcnt_hi((unsigned)(cb >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)cb, 0u));
+#pragma unroll
+                    for (int j = 0; j < NV; j++) myq[at + j] = p | (g << 8) | ((unsigned)j << 30);
+                }
+                qn += NV * __popcll(cb);
+                const u64 mb = __ballot(mcomp);
+                if (mcomp) myq[(unsigned)qn + __builtin_amdgcn_mbcnt_hi((unsigned)(mb >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mb, 0u))] = p | (G << 8) | (3u << 30);
+                qn += __popcll(mb);
+            }
+            if (!__any(todo)) break;
+            flush_queue();
+            if (PL_LD(&L.dead) || it > PL_SPIN_LIMIT) {
+                PL_ST(&L.dead, 1u);
+                break;
+            }
+            if (it) __builtin_amdgcn_s_sleep(4);
+        }
+        if (qn >= PL_QFLUSH) flush_queue();
+    };
+
+    bool alive = true;
+    auto step = [&](const u64 (&v)[NC][8], const unsigned valid, const i64 sbase) __attribute__((always_inline)) {
+        const unsigned dbase = (unsigned)(sbase - r0);
+        if constexpr (NP == 0) {
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                u64 val[NV];
+#pragma unroll
+                for (int j = 0; j < NV; j++) val[j] = v[1 + j][e]; // plane j = plan column 1 + j
+                place((valid >> e) & 1u, v[0][e], val, dbase + (unsigned)((e >> 1) * 128 + (e & 1)));
+            }
+        } else {
+            // Under a filter a lane keeps few of its eight rows (10 %: none 43 %, one 38 %, two 15 %): instead of eight passes over mostly
+            // idle lanes, every pass takes each lane's NEXT selected row -- as many passes as the busiest lane has rows (three or four).
+            unsigned rem = eval_preds<NC, 8, NP>(S, v, valid);
+            while (__any(rem != 0u)) {
+                const bool on = rem != 0u;
+                const unsigned e = (unsigned)__builtin_ctz(rem | 0x100u);
+                rem &= rem - 1u;
+                u64 key = v[0][0], val[NV];
+#pragma unroll
+                for (int j = 0; j < NV; j++) val[j] = v[1 + j][0];
+#pragma unroll
+                for (int q = 1; q < 8; q++) {
+                    const bool is = e == (unsigned)q;
+                    key = is ? v[0][q] : key;
+#pragma unroll
+                    for (int j = 0; j < NV; j++) val[j] = is ? v[1 + j][q] : val[j];
+                }
+                place(on, key, val, dbase + (e >> 1) * 128u + (e & 1u));
+            }
+        }
+        flush_queue();
+        if (PL_LD(&L.dead)) alive = false;
+    };
+
+    const i64 nsteps = (r1 - r0 + PL_WROWS - 1) / PL_WROWS; // of this block
+    const i64 nfull = (r1 - r0) / PL_WROWS;
+    {
+        u64 va[NC][8];
+        for (i64 s = wv; s < nfull && alive; s += PL_WAVES) {
+            const i64 base = r0 + s * PL_WROWS + lane * 2;
+#pragma unroll
+            for (int c = 0; c < NC; c++) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const u64x2 t = rfx_ld2(P.cols[c] + base + j * 128);
+                    va[c][2 * j] = t.x;
+                    va[c][2 * j + 1] = t.y;
+                }
+            }
+            step(va, 0xffu, base);
+        }
+    }
+    if (nfull < nsteps && (nfull % PL_WAVES) == wv && alive) { // the ragged last step of the block
+        u64 va[NC][8];
+        const i64 base = r0 + nfull * PL_WROWS + lane * 2;
+        unsigned valid = 0;
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const i64 row = base + (e >> 1) * 128 + (e & 1);
+            const bool in = row < r1;
+            valid |= (unsigned)in << e;
+#pragma unroll
+            for (int c = 0; c < NC; c++) va[c][e] = in ? P.cols[c][row] : 0ULL;
+        }
+        step(va, valid, base);
+    }
+    __syncthreads();
+    if (L.dead) {
+        if (tid == 0) atomicExch(&A.ctl[1], 1u);
+        return;
+    }
+    // the last, partly filled group of every plane of every partition (the region has room: c0 is a multiple of the largest group; the
+    // record count ends before the padding)
+    for (int i = tid; i < PARTS * (NV + 1) * (int)LPD; i += PL_T) {
+        const unsigned sub = (unsigned)i & (LPD - 1u), p = ((unsigned)i / LPD) & (unsigned)(PARTS - 1), pl = ((unsigned)i / LPD) >> PBITS;
+        const unsigned t = tail[p];
+        if (pl < (unsigned)NV) {
+            if (t & (VG - 1u)) {
+                const unsigned gi = t >> VGL;
+                const pl_v2 x = *(const pl_v2 *)(vring + ((size_t)pl * PARTS + p) * RING + (gi & 1u) * VG + sub * 2);
+                u64 *dst = (NV == 1 ? A.vals[0] : (pl == 0 ? A.vals[0] : (pl == 1 ? A.vals[1] : A.vals[2])));
+                *(pl_v2 *)(dst + region + (u64)p * A.c0 + (u64)gi * VG + sub * 2) = x;
+            }
+        } else if (t & ((1u << msh) - 1u)) {
+            const unsigned gi = t >> msh;
+            const pl_v2 x = *(const pl_v2 *)(mring + p * (2 * GB) + (gi & 1u) * GB + sub * 16);
+            *(pl_v2 *)((char *)A.meta + (region + (u64)p * A.c0) * 4 + (u64)gi * GB + sub * 16) = x;
+        }
+    }
+    for (int i = tid; i < PARTS; i += PL_T) A.cnt[((size_t)blockIdx.x << PBITS) + i] = tail[i];
+    for (int s2 = 32; s2 >= 1; s2 >>= 1) {
+        const i64 omn = (i64)rfx_shfl_xor_u64((u64)mn, s2), omx = (i64)rfx_shfl_xor_u64((u64)mx, s2);
+        mn = omn < mn ? omn : mn;
+        mx = omx > mx ? omx : mx;
+    }
+    if (lane == 0) L.red[wv] = ScopePart{mn, mx, sel, nulls};
+    __syncthreads();
+    if (tid == 0) {
+        ScopePart r = L.red[0];
+        for (int w2 = 1; w2 < PL_WAVES; w2++) {
+            r.mn = L.red[w2].mn < r.mn ? L.red[w2].mn : r.mn;
+            r.mx = L.red[w2].mx > r.mx ? L.red[w2].mx : r.mx;
+            r.sel += L.red[w2].sel;
+            r.nulls += L.red[w2].nulls;
+        }
+        // the whole launch's scope, folded with four atomics per block into cells that start at zero: the minimum as the maximum of the
+        // inverted order-preserving image (0 = +inf), the maximum as the maximum of the image (0 = INT64_MIN = "no key")
+        unsigned long long *g = (unsigned long long *)A.ctl + 8;
+        if (r.sel > 0) {
+            atomicMax(&g[0], ~((unsigned long long)r.mn ^ 0x8000000000000000ULL));
+            atomicMax(&g[1], (unsigned long long)r.mx ^ 0x8000000000000000ULL);
+            atomicAdd(&g[2], (unsigned long long)r.sel);
+            if (r.nulls) atomicAdd(&g[3], (unsigned long long)r.nulls);
+        }
+    }
+}
+
+// ---- per-partition LDS aggregation over the regions of one partition ----
+struct PlaneAggArgs {
+    i64 kmin, range;
+    i64 local; // table cells per partition: slots congruent to one residue mod 2^pbits
+    int split; // workgroups per partition
+    int nblk, nrowblk, pbits;
+    int plane[PL_MAX_NV];      // scatter plane behind loaded plane j
+    int agg_pl[RFX_MAX_AGGS];  // loaded plane of aggregate a (-1: none: COUNT / FIRST)
+    i64 block_rows;
+    unsigned c0;
+    const u64 *vals[PL_MAX_NV];
+    const unsigned *meta;
+    const unsigned *cnt;
+    u64 *first;
+    u64 *acc[RFX_MAX_AGGS];
+    u64 *cntt[RFX_MAX_AGGS];
+    int dbg; // timing experiments only (RFX_PLANE_DBG): 1 = FAST kernel without its accumulator atomics
+};
+#define PL_FIRST_NONE 0xFFFFFFFFu
+
+// LDS: [nagg accumulators u64 x local][first u32 x local][counts u32 x local each]
+// FAST: exactly one aggregate, a plain f64 sum (C3 / C3w): first row + one ds_add_f64 per record, no per-record dispatch on the aggregate kinds
+template <int THREADS, int NVL, bool FAST>
+__global__ __launch_bounds__(THREADS) void k_plane_aggregate(const Plan P, const PlaneAggArgs A) {
+    extern __shared__ __attribute__((aligned(16))) u64 pl_agg_smem[];
+    const int tid = threadIdx.x;
+    const int p = blockIdx.x / A.split, s = blockIdx.x % A.split;
+    const i64 local = A.local;
+    int kind[RFX_MAX_AGGS], f64[RFX_MAX_AGGS], skip[RFX_MAX_AGGS], cnt_of[RFX_MAX_AGGS], apl[RFX_MAX_AGGS];
+    int ncnt = 0;
+#pragma unroll
+    for (int a = 0; a < RFX_MAX_AGGS; a++) {
+        kind[a] = (a < P.nagg) ? P.aggs[a].kind : -1;
+        f64[a] = (a < P.nagg) ? P.aggs[a].f64 : 0;
+        skip[a] = (a < P.nagg) ? P.aggs[a].skipnull : 0;
+        apl[a] = (a < P.nagg) ? A.agg_pl[a] : -1;
+        cnt_of[a] = -1;
+        if (kind[a] >= 0 && agg_has_cnt(kind[a], f64[a])) cnt_of[a] = ncnt++;
+    }
+    u64 *accs = pl_agg_smem;                                   // [nagg][local]
+    unsigned *first = (unsigned *)(accs + (i64)P.nagg * local); // [local]
+    unsigned *cnts = first + local;                            // [ncnt][local]
+    for (i64 i = tid; i < local; i += THREADS) first[i] = PL_FIRST_NONE;
+#pragma unroll
+    for (int a = 0; a < RFX_MAX_AGGS; a++) {
+        if (kind[a] < 0) continue;
+        const u64 id = acc_identity(kind[a], f64[a]);
+        for (i64 i = tid; i < local; i += THREADS) accs[(i64)a * local + i] = id;
+        if (cnt_of[a] >= 0) {
+            for (i64 i = tid; i < local; i += THREADS) cnts[(i64)cnt_of[a] * local + i] = 0u;
+        }
+    }
+    __syncthreads();
+    const unsigned shift = (unsigned)(((i64)p - A.kmin) >> A.pbits); // slot = (key - kmin) >> pbits = (key >> pbits) + floor((p - kmin) / 2^pbits), modular
+    auto apply = [&](unsigned mm, bool rows, i64 rbase, const u64 (&x)[NVL]) __attribute__((always_inline)) {
+        const unsigned mask = rows ? ((1u << PL_SLOT_BITS) - 1u) : 0xFFFFu;
+        const unsigned slot = ((mm & mask) + shift) & mask;
+        if ((i64)slot >= local) return; // a key outside the scope the tables were sized for: not ours
+        if (rows) {
+            const unsigned row = (unsigned)(rbase + (i64)(mm >> PL_SLOT_BITS));
+            if (row < first[slot]) atomicMin(&first[slot], row);
+        }
+        if constexpr (FAST) {
+            if (!(A.dbg & 1)) unsafeAtomicAdd((double *)&accs[slot], rfx_as_f64(x[0]));
+            return;
+        }
+#pragma unroll
+        for (int a = 0; a < RFX_MAX_AGGS; a++) {
+            if (kind[a] < 0) continue;
+            u64 xv = 0;
+#pragma unroll
+            for (int j = 0; j < NVL; j++)
+                if (apl[a] == j) xv = x[j];
+            group_apply(&accs[(i64)a * local + slot], cnt_of[a] >= 0 ? &cnts[(i64)cnt_of[a] * local + slot] : (unsigned *)0, kind[a], f64[a], xv, skip[a]);
+        }
+    };
+    // Every WAVE streams its own regions (blocks q, q + Q, ... of this partition): a region holds a few hundred to a thousand records,
+    // a 64-lane wave keeps its lanes busy on that where a whole workgroup would not.  One "batch" = up to two record pairs per lane
+    // (256 records) of one region; the next batch's loads are issued before this one is applied.
+    const int lane = tid & 63;
+    constexpr int NW = THREADS / 64;
+    const int Q = A.split * NW;
+    struct Batch {
+        pl_v2 val[NVL][2];
+        u64 m[2];
+        unsigned n, i0;
+        int b;
+    };
+    // Loads are UNCONDITIONAL: a fixed number per call whatever the region's size (a pair past the region's end is clamped to its last
+    // allocated pair and ignored).  With a load inside a condition the compiler cannot count what is in flight and waits with vmcnt(0):
+    // consuming one batch would wait for the other batch's loads too.
+    auto load = [&](bool live, int b, unsigned i0, unsigned n, Batch &B) __attribute__((always_inline)) {
+        B.b = live ? b : 0;
+        B.i0 = live ? i0 : 0u;
+        B.n = live ? n : 0u;
+        const u64 base = (((u64)B.b << A.pbits) + (u64)p) * A.c0;
+        const bool rows = B.b < A.nrowblk;
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            unsigned i = B.i0 + ((unsigned)k * 64u + (unsigned)lane) * 2u;
+            i = i < A.c0 - 2u ? i : A.c0 - 2u;
+#pragma unroll
+            for (int j = 0; j < NVL; j++) B.val[j][k] = __builtin_nontemporal_load((const pl_v2 *)(A.vals[j] + base + i));
+            // one 8-byte load in either form (two 4-byte entries, or two 2-byte entries and what follows them): two alternative loads
+            // into the same registers would be issued both, with a vmcnt(0) between them
+            const pl_m2 t = __builtin_nontemporal_load((const pl_m2 *)((const char *)(A.meta + base) + ((size_t)i << (rows ? 2 : 1))));
+            B.m[k] = (u64)t.x | ((u64)t.y << 32);
+        }
+    };
+    auto consume = [&](const Batch &B) __attribute__((always_inline)) {
+        const bool rows = B.b < A.nrowblk;
+        const i64 rbase = (i64)B.b * A.block_rows;
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const unsigned i = B.i0 + ((unsigned)k * 64u + (unsigned)lane) * 2u;
+            if (i < B.n) {
+                u64 x[NVL];
+#pragma unroll
+                for (int j = 0; j < NVL; j++) x[j] = B.val[j][k].x;
+                apply(rows ? (unsigned)B.m[k] : (unsigned)(B.m[k] & 0xFFFFu), rows, rbase, x);
+                if (i + 1 < B.n) {
+#pragma unroll
+                    for (int j = 0; j < NVL; j++) x[j] = B.val[j][k].y;
+                    apply(rows ? (unsigned)(B.m[k] >> 32) : (unsigned)((B.m[k] >> 16) & 0xFFFFu), rows, rbase, x);
+                }
+            }
+        }
+    };
+    // Cursor over (region, batch within the region) -- wave-uniform.  This wave's regions are blocks q, q + Q, ...; their record counts come
+    // 64 at a time through a wave-private LDS window (one vector load + ds_write per 64 regions, waited for on the spot -- rare; the count
+    // of the next region is then an LDS read).  A global load per region whose result is needed at once would be the YOUNGEST load in
+    // flight: waiting for it waits for every batch load before it.
+    const int q = __builtin_amdgcn_readfirstlane(s * NW + (tid >> 6));
+    const int nreg = q < A.nblk ? (A.nblk - q + Q - 1) / Q : 0; // regions of this wave
+    unsigned *wcnt = cnts + (i64)ncnt * local + (tid >> 6) * 64; // [NW][64] behind the tables
+    int r = -1;
+    int b = q;
+    unsigned i0 = 0, n = 0;
+    auto advance = [&]() __attribute__((always_inline)) { // to the next non-empty batch position; false at the end
+        for (;;) {
+            if (r >= 0 && i0 < n) return true;
+            r++;
+            if (r >= nreg) return false;
+            if ((r & 63) == 0) {
+                const int r0 = r + lane;
+                wcnt[lane] = (r0 < nreg) ? A.cnt[((size_t)(q + r0 * Q) << A.pbits) + p] : 0u;
+            }
+            n = (unsigned)__builtin_amdgcn_readfirstlane((int)wcnt[r & 63]);
+            b = q + r * Q;
+            i0 = 0;
+        }
+    };
+    Batch B0, B1;
+    bool h0 = advance();
+    load(h0, b, i0, n, B0);
+    i0 += 256u;
+    while (h0) {
+        const bool h1 = advance();
+        load(h1, b, i0, n, B1);
+        i0 += 256u;
+        consume(B0);
+        if (!h1) break;
+        h0 = advance();
+        load(h0, b, i0, n, B0);
+        i0 += 256u;
+        consume(B1);
+    }
+    __syncthreads();
+    for (i64 i = tid; i < local; i += THREADS) {
+        const unsigned f = first[i];
+        if (f == PL_FIRST_NONE) continue;
+        const i64 g = (i << A.pbits) | (i64)(((u64)p - (u64)A.kmin) & (u64)((1 << A.pbits) - 1));
+        if (g >= A.range) continue;
+        const u64 fr = (u64)P.row0 + (u64)f;
+        if (fr < A.first[g]) atomicMin((unsigned long long *)&A.first[g], (unsigned long long)fr);
+#pragma unroll
+        for (int a = 0; a < RFX_MAX_AGGS; a++) {
+            if (kind[a] < 0) continue;
+            const bool hc = cnt_of[a] >= 0;
+            group_merge_cell(&A.acc[a][g], hc ? &A.cntt[a][g] : (u64 *)0, kind[a], f64[a], accs[(i64)a * local + i], hc ? (u64)cnts[(i64)cnt_of[a] * local + i] : 0ULL);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+int rfx_chunk_reserve(rfx_ctx *c, size_t bytes);
+static size_t pl_al256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+// scratch block: [ctl 256 B][region counts][meta plane][value planes]
+static void plane_layout(rfx_ctx *c, int nblk, int pbits, unsigned c0, int nv, PlaneArgs *A, size_t *total) {
+    const size_t regions = (size_t)nblk << pbits;
+    const size_t o_cnt = 256;
+    const size_t o_meta = o_cnt + pl_al256(regions * 4), o_val = o_meta + pl_al256(regions * c0 * 4);
+    const size_t plane = pl_al256(regions * c0 * 8);
+    if (total) *total = o_val + plane * nv;
+    char *w = (char *)c->d_chunk;
+    A->nblk = nblk;
+    A->nv = nv;
+    A->c0 = c0;
+    A->ctl = (unsigned *)w;
+    A->cnt = (unsigned *)(w + o_cnt);
+    A->meta = (unsigned *)(w + o_meta);
+    for (int j = 0; j < nv; j++) A->vals[j] = (u64 *)(w + o_val + plane * j);
+}
+
+template <int NC, int NP, int NV, int PBITS, int VGL>
+static int launch_plane_scatter_inst(rfx_ctx *c, const Plan &P, const PlaneArgs &A) {
+    constexpr size_t lds = pl_lds_bytes<NV, PBITS, VGL>();
+    static bool attr_set = false; // per instantiation
+    if (!attr_set) {
+        RFX_HIP_CHECK(hipFuncSetAttribute((const void *)k_plane_scatter<NC, NP, NV, PBITS, VGL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_plane_scatter<NC, NP, NV, PBITS, VGL>), dim3(A.nblk), dim3(PL_T), lds, c->stream, P, A);
+    return RFX_OK;
+}
+template <int NC, int NV, int PBITS, int VGL>
+static int launch_plane_scatter_np(rfx_ctx *c, const Plan &P, const PlaneArgs &A) {
+    if (P.npred == 0) return launch_plane_scatter_inst<NC, 0, NV, PBITS, VGL>(c, P, A);
+    if (P.npred == 1) return launch_plane_scatter_inst<NC, 1, NV, PBITS, VGL>(c, P, A);
+    if (P.npred <= 3) return launch_plane_scatter_inst<NC, 3, NV, PBITS, VGL>(c, P, A);
+    return launch_plane_scatter_inst<NC, RFX_MAX_PREDS, NV, PBITS, VGL>(c, P, A);
+}
+template <int NV, int PBITS, int VGL>
+static int launch_plane_scatter_nc(rfx_ctx *c, const Plan &P, const PlaneArgs &A) {
+    switch (P.ncols) {
+        case 2: return launch_plane_scatter_np<2, NV, PBITS, VGL>(c, P, A);
+        case 3: return launch_plane_scatter_np<3, NV, PBITS, VGL>(c, P, A);
+        default: return launch_plane_scatter_np<4, NV, PBITS, VGL>(c, P, A);
+    }
+}
+// one value plane: 256 partitions with 128-byte groups, or -- when the tables of a partition twice as wide still fit a CU's LDS -- 128
+// partitions with 256-byte groups (same LDS for the rings; the scatter's stores are the part's bound: tools/write_probe.hip, 256-byte
+// pieces 5 - 7 % faster than 128-byte ones)
+static int launch_plane_scatter(rfx_ctx *c, const Plan &P, const PlaneArgs &A, int pbits) {
+    if (A.nv != 1 || P.ncols < 2) return RFX_ESTATE;
+    return pbits == 7 ? launch_plane_scatter_nc<1, 7, 5>(c, P, A) : launch_plane_scatter_nc<1, 8, 4>(c, P, A);
+}
+
+// the value planes of a plan: distinct plain columns the aggregates read (COUNT / FIRST read none).  -1: expressions / more than PL_MAX_NV
+static int plane_value_cols(const Plan &P, int *vcol, int *agg_plane) {
+    int nv = 0;
+    for (int a = 0; a < P.nagg; a++) {
+        const PlanAgg &ag = P.aggs[a];
+        agg_plane[a] = -1;
+        if (ag.kind == RFX_AGG_COUNT || ag.kind == RFX_AGG_FIRST || ag.col < 0) continue;
+        if (ag.col >= RFX_XCOL) return -1;
+        int j = 0;
+        for (; j < nv; j++)
+            if (vcol[j] == ag.col) break;
+        if (j == nv) {
+            if (nv >= PL_MAX_NV) return -1;
+            vcol[nv++] = ag.col;
+        }
+        agg_plane[a] = j;
+    }
+    return nv;
+}
+// LDS bytes of the aggregate pass for a subset [a0, a1) of the aggregates
+static size_t plane_agg_lds(const Plan &P, int a0, int a1, i64 local) {
+    size_t cells8 = 0, cells4 = 1;
+    for (int a = a0; a < a1; a++) {
+        cells8++;
+        if (agg_has_cnt(P.aggs[a].kind, P.aggs[a].f64)) cells4++;
+    }
+    return (size_t)local * (cells8 * 8 + cells4 * 4) + 16 * 64 * 4 + 64; // tables + the waves' count windows
+}
+#define PL_AGG_LDS_MAX (150 * 1024)
+
+struct PlaneState { // what rfx_plane_scope leaves for rfx_plane_accumulate (lives in the context: ext_p[2])
+    int valid, npred, logic, nblk, nrowblk, pbits, nv;
+    unsigned c0;
+    const void *key;
+    const void *val[PL_MAX_NV];
+    i64 nrows;
+    u64 sig[RFX_MAX_PREDS][6];
+};
+static PlaneState *plane_state(rfx_ctx *c) {
+    if (!c->ext_p[2]) c->ext_p[2] = calloc(1, sizeof(PlaneState));
+    return (PlaneState *)c->ext_p[2];
+}
+void rfx_plane_invalidate(rfx_ctx *c) {
+    if (c->ext_p[2]) ((PlaneState *)c->ext_p[2])->valid = 0;
+}
+void rfx_plane_release(rfx_ctx *c) {
+    free(c->ext_p[2]);
+    c->ext_p[2] = NULL;
+}
+static void plane_pred_sig(const Plan &P, u64 (*sig)[6]) {
+    for (int i = 0; i < P.npred; i++) {
+        const PlanPred &q = P.preds[i];
+        sig[i][0] = (u64)(uintptr_t)P.cols[q.col];
+        sig[i][1] = q.rhs_col >= 0 ? (u64)(uintptr_t)P.cols[q.rhs_col] : 0;
+        sig[i][2] = (u64)q.op;
+        sig[i][3] = (u64)(q.dom_f64 | (q.lhs_cvt << 1) | (q.rhs_cvt << 2));
+        sig[i][4] = q.rhs_bits;
+        sig[i][5] = 0;
+    }
+}
+// Scope pass that also partitions into planes.  P: the plan as built (key at key_idx); est_range / frac: the sample's guesses.
+// RFX_ESTATE: not applicable / gave up (nothing is left behind), the caller goes on with the chunk kernels.
+int rfx_plane_scope(rfx_ctx *c, const Plan &P, int key_idx, const void *d_key, int npred, int logic, unsigned long long est_range, double frac,
+                    i64 *kmin, i64 *kmax, i64 *seen) {
+    PlaneState *st = plane_state(c);
+    if (!st) return RFX_ESTATE;
+    st->valid = 0;
+    if (c->flags & RFX_TUNE_NO_PLANE) return RFX_ESTATE;
+    int vcol[PL_MAX_NV], agg_plane[RFX_MAX_AGGS];
+    const int nv = plane_value_cols(P, vcol, agg_plane);
+    if (nv != 1) return RFX_ESTATE; // (two and three planes: 128 partitions, not built yet)
+    // 128 partitions (256-byte groups) when a partition twice as wide still fits the aggregate pass's LDS with a quarter to spare (the
+    // sampled range can only be too small), else 256
+    int pbits = 7;
+    {
+        static const char *force = getenv("RFX_PLANE_PBITS"); // (A/B)
+        const i64 l7 = (i64)((est_range + 127) >> 7);
+        if (l7 + l7 / 4 > (1 << PL_SLOT_BITS) || plane_agg_lds(P, 0, P.nagg, l7 + l7 / 4) > PL_AGG_LDS_MAX) pbits = 8;
+        if (force) pbits = atoi(force) == 7 ? 7 : 8;
+    }
+    const i64 est_local = (i64)((est_range + (1ULL << pbits) - 1) >> pbits);
+    if (est_local > (1 << PL_SLOT_BITS)) return RFX_ESTATE;
+    if (plane_agg_lds(P, 0, P.nagg, est_local) > PL_AGG_LDS_MAX) return RFX_ESTATE;
+    const i64 nrows = P.nrows;
+    const i64 block_rows = PL_BLOCK_ROWS;
+    const i64 nblk64 = (nrows + block_rows - 1) / block_rows;
+    if (nblk64 > (1 << 20)) return RFX_ESTATE;
+    // region size: the expected share of a partition plus room for its spread (uniform keys: sigma = sqrt(share)), whole 64-record lines
+    double share = (double)block_rows / (double)(1 << pbits);
+    if (npred > 0) share *= (frac * 1.3 + 0.01 < 1.0 ? frac * 1.3 + 0.01 : 1.0);
+    unsigned c0 = (unsigned)(share * 1.25 + 160.0);
+    c0 = (c0 + 127u) & ~127u;
+    PlaneArgs A;
+    memset(&A, 0, sizeof(A));
+    size_t need = 0;
+    plane_layout(c, (int)nblk64, pbits, c0, nv, &A, &need);
+    if (rfx_chunk_reserve(c, need) != RFX_OK) return RFX_ESTATE;
+    plane_layout(c, (int)nblk64, pbits, c0, nv, &A, NULL);
+    A.nrowblk = A.nblk;
+    A.block_rows = block_rows;
+    // key -> column 0, value plane j -> column 1 + j (the kernel reads them without a run-time select; a value column that IS the key
+    // column is listed a second time), the predicates' other columns behind them
+    Plan Pc = P;
+    {
+        int perm[RFX_MAX_COLS + PL_MAX_NV], inv[RFX_MAX_COLS], n2 = 0;
+        for (int i = 0; i < P.ncols; i++) inv[i] = -1;
+        perm[n2++] = key_idx;
+        inv[key_idx] = 0;
+        for (int j = 0; j < nv; j++) {
+            if (inv[vcol[j]] < 0) inv[vcol[j]] = n2;
+            perm[n2++] = vcol[j];
+        }
+        for (int i = 0; i < P.ncols; i++)
+            if (inv[i] < 0) {
+                inv[i] = n2;
+                perm[n2++] = i;
+            }
+        if (n2 > 4) return RFX_ESTATE;
+        Pc.ncols = n2;
+        for (int i = 0; i < n2; i++) Pc.cols[i] = P.cols[perm[i]];
+        for (int i = 0; i < P.npred; i++) {
+            Pc.preds[i].col = inv[P.preds[i].col];
+            if (P.preds[i].rhs_col >= 0) Pc.preds[i].rhs_col = inv[P.preds[i].rhs_col];
+        }
+    }
+    RFX_HIP_CHECK(hipMemsetAsync(A.ctl, 0, 256, c->stream));
+    c->ext_i[3 + RFX_STAT_PLANE_SCATTER]++;
+    RFX_KERNEL_BEGIN(c);
+    int rc = launch_plane_scatter(c, Pc, A, pbits);
+    RFX_KERNEL_END(c);
+    if (rc != RFX_OK) return rc;
+    RFX_HIP_CHECK(hipGetLastError());
+    unsigned *hctl = (unsigned *)c->h_pin;
+    RFX_HIP_CHECK(hipMemcpyAsync(hctl, A.ctl, 256, hipMemcpyDeviceToHost, c->stream));
+    RFX_HIP_CHECK(hipStreamSynchronize(c->stream));
+    if (hctl[1]) { // a region overflowed (skew or selectivity the sample did not show): the chunk kernels take over
+        c->ext_i[3 + RFX_STAT_PLANE_FALLBACK]++;
+        return RFX_ESTATE;
+    }
+    const u64 *hs = (const u64 *)hctl + 8;
+    i64 nulls = (i64)hs[3];
+    *seen = (i64)hs[2];
+    *kmin = (i64)(~hs[0] ^ 0x8000000000000000ULL);
+    *kmax = (i64)(hs[1] ^ 0x8000000000000000ULL);
+    if (nulls > 0) { // a null key is the value INT64_MIN for index_scope_i64
+        *kmin = RFX_NULL_I64_D;
+        if (nulls == *seen) *kmax = RFX_NULL_I64_D;
+    }
+    if (*seen == 0 || nulls > 0) return RFX_OK;
+    st->valid = 1;
+    st->key = d_key;
+    for (int j = 0; j < nv; j++) st->val[j] = (const void *)P.cols[vcol[j]];
+    st->nrows = nrows;
+    st->npred = npred;
+    st->logic = logic;
+    st->nblk = A.nblk;
+    st->nrowblk = A.nrowblk;
+    st->pbits = pbits;
+    st->nv = nv;
+    st->c0 = c0;
+    plane_pred_sig(P, st->sig);
+    return RFX_OK;
+}
+
+template <int THREADS, bool FAST>
+static int launch_plane_aggregate(rfx_ctx *c, const Plan &P, const PlaneAggArgs &G, int grid, size_t lds, int lds_max) {
+    static bool attr_set = false; // per instantiation
+    if (!attr_set) {
+        RFX_HIP_CHECK(hipFuncSetAttribute((const void *)k_plane_aggregate<THREADS, 1, FAST>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_plane_aggregate<THREADS, 1, FAST>), dim3(grid), dim3(THREADS), lds, c->stream, P, G);
+    return RFX_OK;
+}
+
+// Pass 2 over the planes rfx_plane_scope left, if they are the planes of exactly this plan.  RFX_ESTATE: not so.
+int rfx_plane_accumulate(rfx_ctx *c, const Plan &P, int key_idx, const rfx_group_tables_t *t) {
+    PlaneState *st = (PlaneState *)c->ext_p[2];
+    if (!st || !st->valid) return RFX_ESTATE;
+    int vcol[PL_MAX_NV], agg_plane[RFX_MAX_AGGS];
+    bool ok = st->key == (const void *)P.cols[key_idx] && st->nrows == P.nrows && st->npred == P.npred && st->logic == P.logic && P.nx == 0;
+    const int nv = ok ? plane_value_cols(P, vcol, agg_plane) : -1;
+    ok = ok && nv == st->nv;
+    for (int j = 0; ok && j < nv; j++) ok = st->val[j] == (const void *)P.cols[vcol[j]];
+    if (ok && P.npred > 0) {
+        u64 sig[RFX_MAX_PREDS][6];
+        plane_pred_sig(P, sig);
+        ok = memcmp(sig, st->sig, sizeof(u64) * 6 * (size_t)P.npred) == 0;
+    }
+    st->valid = 0; // consumed (or stale) either way
+    if (!ok || t->range <= (1 << st->pbits)) return RFX_ESTATE;
+    const i64 local = (t->range + (1 << st->pbits) - 1) >> st->pbits;
+    if (local > (1 << PL_SLOT_BITS)) return RFX_ESTATE;
+    const size_t lds = plane_agg_lds(P, 0, P.nagg, local);
+    if (lds > PL_AGG_LDS_MAX) return RFX_ESTATE;
+    PlaneArgs A;
+    memset(&A, 0, sizeof(A));
+    plane_layout(c, st->nblk, st->pbits, st->c0, st->nv, &A, NULL);
+    PlaneAggArgs G;
+    memset(&G, 0, sizeof(G));
+    G.kmin = t->kmin;
+    G.range = t->range;
+    G.local = local;
+    G.nblk = st->nblk;
+    G.nrowblk = st->nrowblk;
+    G.pbits = st->pbits;
+    G.block_rows = PL_BLOCK_ROWS;
+    G.c0 = st->c0;
+    for (int j = 0; j < nv; j++) {
+        G.plane[j] = j;
+        G.vals[j] = A.vals[j];
+    }
+    for (int a = 0; a < RFX_MAX_AGGS; a++) G.agg_pl[a] = a < P.nagg ? agg_plane[a] : -1;
+    G.meta = A.meta;
+    G.cnt = A.cnt;
+    G.first = (u64 *)t->d_first;
+    for (int a = 0; a < t->nagg; a++) {
+        G.acc[a] = (u64 *)t->d_acc[a];
+        G.cntt[a] = (u64 *)t->d_cnt[a];
+    }
+    const int nparts = 1 << st->pbits;
+    c->ext_i[3 + RFX_STAT_PLANE_AGGREGATE]++;
+    {
+        static const char *dbg = getenv("RFX_PLANE_DBG");
+        G.dbg = dbg ? atoi(dbg) : 0;
+    }
+    int rc = RFX_OK;
+    const bool fast = P.nagg == 1 && P.aggs[0].kind == RFX_AGG_SUM && P.aggs[0].f64 && !P.aggs[0].skipnull && agg_plane[0] == 0;
+    RFX_KERNEL_BEGIN(c);
+    if (lds > 48 * 1024) {
+        // big tables: one 1024-lane workgroup per CU
+        G.split = (c->num_cus + nparts - 1) / nparts;
+        if (G.split < 1) G.split = 1;
+        if (fast) rc = launch_plane_aggregate<1024, true>(c, P, G, nparts * G.split, lds, 160 * 1024);
+        else rc = launch_plane_aggregate<1024, false>(c, P, G, nparts * G.split, lds, 160 * 1024);
+    } else {
+        const int per_cu = (int)((150 * 1024) / (lds > 1 ? lds : 1)) < 4 ? (int)((150 * 1024) / lds) : 4; // 512-lane workgroups a CU can hold: 3 at 47 KB
+        G.split = (per_cu * c->num_cus + nparts - 1) / nparts;
+        if (G.split < 1) G.split = 1;
+        if (fast) rc = launch_plane_aggregate<512, true>(c, P, G, nparts * G.split, lds, 64 * 1024);
+        else rc = launch_plane_aggregate<512, false>(c, P, G, nparts * G.split, lds, 64 * 1024);
+    }
+    RFX_KERNEL_END(c);
+    if (rc != RFX_OK) return rc;
+    RFX_HIP_CHECK(hipGetLastError());
+    return RFX_OK;
+}

@@ -57,11 +57,15 @@ static void parallel_copy(char *dst, const char *src, size_t bytes) {
         if (started[i]) pthread_join(th[i], NULL);
 }
 
+void rfx_plane_invalidate(rfx_ctx *c); // rfx_group_plane.hip
 extern "C" int rfx_hip_h2d_pipelined(rfx_ctx_t *c, void *d_dst, const void *src, size_t bytes) {
     RFX_REQUIRE(c, RFX_EINVAL, "ctx is NULL");
     if (!bytes) return RFX_OK;
     RFX_REQUIRE(d_dst && src, RFX_EINVAL, "NULL argument");
     if (bytes < IO_CHUNK) return rfx_hip_h2d(c, d_dst, src, bytes);
+    c->ck_valid = 0; // as rfx_hip_h2d: partitions left by a scope pass do not survive an upload
+    c->pc_valid = 0;
+    rfx_plane_invalidate(c);
     if (!c->io_stage[IO_NBUF - 1]) { // all buffers and events exist, or none is published (a half-built set is torn down)
         void *st[IO_NBUF] = {NULL, NULL, NULL, NULL};
         hipEvent_t ev[IO_NBUF];

@@ -68,6 +68,11 @@ class Engine:
     def tune(self, blocks_per_cu: int = 0, flags: int = 0) -> None:
         L.check(self.lib.rfx_hip_ctx_tune(self._ctx, blocks_per_cu, flags), "tune")
 
+    def stat(self, which):
+        """Path counters of this context (include/rfx_hip.h RFX_STAT_*): 0 plane scatter launches, 1 plane fallbacks, 2 plane aggregate
+        launches, 3 chunk scatter launches, 4 chunk aggregate launches."""
+        return int(self.lib.rfx_hip_ctx_stat(self._ctx, which))
+
     def timer_start(self) -> None:
         L.check(self.lib.rfx_hip_timer_start(self._ctx), "timer_start")
 

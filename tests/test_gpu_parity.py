@@ -376,7 +376,10 @@ CHUNK_SMALL = 32768  # RFX_TUNE_CHUNK_SMALL: the one-pass chunk partitioning fro
 CHUNK_QUEUE, CHUNK_BINS = 131072, 262144  # selective filters: always the sorted-queue kernel / always per-partition bins
 
 
-@pytest.mark.parametrize("flags", [CHUNK_SMALL, CHUNK_SMALL | 4, CHUNK_SMALL | CHUNK_QUEUE, CHUNK_SMALL | CHUNK_BINS, 16384])
+NO_PLANE = 1048576  # RFX_TUNE_NO_PLANE: round 2's 16-byte records in chunks, never the 8 + 4-byte planes
+
+
+@pytest.mark.parametrize("flags", [CHUNK_SMALL, CHUNK_SMALL | 4, CHUNK_SMALL | NO_PLANE, CHUNK_SMALL | CHUNK_QUEUE, CHUNK_SMALL | CHUNK_BINS, 16384])
 @pytest.mark.parametrize("shape", ["uniform", "offset", "skew", "wide", "narrow"])
 def test_chunk_partitioned_group_by(eng, flags, shape):
     """rfx_hip_group_scope: the scope pass that also radix-partitions (rfx_group_chunk.hip) -- chunk allocation, slab switches,
@@ -418,6 +421,54 @@ def test_chunk_partitioned_group_by_larger(eng):
     host = table(n, keys=1_000_000)
     check_select(eng, host, {"by": "k", "s": ("sum", "v")})
     check_select(eng, host, {"where": ("<", "a", 100_000), "by": "k", "s": ("sum", "v"), "c": ("count", "v")})
+
+
+def test_plane_partitioned_group_by_takes_the_plane_kernels(eng):
+    """Spread keys go through k_plane_scatter / k_plane_aggregate (rfx_group_plane.hip): the context's path counters say so; RFX_TUNE_NO_PLANE
+    and a skewed low key byte keep to the chunk kernels.  Same answers (the oracle) either way."""
+    n = 700_001
+    host = table(n, keys=50_000, nulls=True)  # (50 000 keys: the 10 % selection below still has more rows than slots -- the dense arm)
+    qs = [{"by": "k", "s": ("sum", "v")}, {"where": ("<", "a", 100_000), "by": "k", "s": ("sum", "v"), "c": ("count", "v"), "f": ("first", "v")}]
+    try:
+        eng.tune(flags=CHUNK_SMALL)
+        before = [eng.stat(i) for i in range(5)]
+        for q in qs:
+            check_select(eng, host, q)
+        after = [eng.stat(i) for i in range(5)]
+        assert after[0] - before[0] == 2 and after[2] - before[2] == 2 and after[1] == before[1], (before, after)
+        assert after[3] == before[3] and after[4] == before[4], (before, after)
+        eng.tune(flags=CHUNK_SMALL | NO_PLANE)
+        before = after
+        for q in qs:
+            check_select(eng, host, q)
+        after = [eng.stat(i) for i in range(5)]
+        assert after[0] == before[0] and after[3] - before[3] == 2 and after[4] - before[4] == 2, (before, after)
+    finally:
+        eng.tune(flags=0)
+
+
+@pytest.mark.parametrize("run", [64, 4096])
+def test_plane_rings_under_pressure_and_region_overflow(eng, run):
+    """Keys whose low byte comes in runs: the strided sample sees the 256 partitions evenly filled, a wave step does not.  run = 64: eight
+    partitions take a whole 512-row step (every ring half is waited for, the slow path of k_plane_scatter), regions still fill evenly;
+    run = 4096: a row block feeds 64 partitions only, their regions overflow, the launch gives up (counter 1) and the chunk kernels answer."""
+    n = 900_001
+    i = np.arange(n, dtype=np.int64)
+    host = table(n, keys=10)
+    host["k"] = ((i // run) % 256) + 256 * rfo.gen_i64(n, 77, 700)
+    try:
+        eng.tune(flags=CHUNK_SMALL)
+        before = [eng.stat(j) for j in range(5)]
+        check_select(eng, host, {"by": "k", "s": ("sum", "v"), "mn": ("min", "v")})
+        check_select(eng, host, {"where": ("<", "a", 500_000), "by": "k", "s": ("sum", "v"), "f": ("first", "v")})
+        after = [eng.stat(j) for j in range(5)]
+        assert after[0] - before[0] == 2, (before, after)
+        if run == 64:
+            assert after[1] == before[1] and after[2] - before[2] == 2, (before, after)
+        else:
+            assert after[1] - before[1] == 2 and after[2] == before[2], (before, after)
+    finally:
+        eng.tune(flags=0)
 
 
 # ---------------------------------------------------------------- several `by:` columns (composite key, SURVEY 8f-1)
