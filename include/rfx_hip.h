@@ -199,7 +199,8 @@ enum {
     RFX_STAT_PLANE_FALLBACK = 1,  /* ... that gave up (a region overflowed / a ring did not drain): the chunk kernels took over */
     RFX_STAT_PLANE_AGGREGATE = 2, /* k_plane_aggregate launches */
     RFX_STAT_CHUNK_SCATTER = 3,   /* k_chunk_scatter* launches (16-byte records, rfx_group_chunk.hip) */
-    RFX_STAT_CHUNK_AGGREGATE = 4  /* k_chunk_aggregate launches */
+    RFX_STAT_CHUNK_AGGREGATE = 4, /* k_chunk_aggregate launches */
+    RFX_STAT_PLANE_REDO = 5       /* plane passes run again with row ids in every block (a group's first row turned up in a block without them) */
 };
 int64_t rfx_hip_ctx_stat(rfx_ctx_t *ctx, int which);
 

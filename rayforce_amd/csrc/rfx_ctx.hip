@@ -90,8 +90,8 @@ extern "C" int rfx_hip_ctx_destroy(rfx_ctx_t *c) {
 }
 
 extern "C" int64_t rfx_hip_ctx_stat(rfx_ctx_t *c, int which) {
-    if (!c || which < 0 || which > 4) return -1;
-    return c->ext_i[3 + which];
+    if (!c || which < 0 || which > 5) return -1;
+    return which == RFX_STAT_PLANE_REDO ? c->ext_i[0] : c->ext_i[3 + which];
 }
 
 extern "C" int rfx_hip_ctx_sync(rfx_ctx_t *c) {

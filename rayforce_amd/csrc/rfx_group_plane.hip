@@ -338,6 +338,7 @@ struct PlaneAggArgs {
     int dbg; // timing experiments only (RFX_PLANE_DBG): 1 = FAST kernel without its accumulator atomics
 };
 #define PL_FIRST_NONE 0xFFFFFFFFu
+#define PL_FIRST_TOUCHED 0xFFFFFFFEu /* LDS; in the global table: RFX_INF_I64_D - 1 */
 
 // LDS: [nagg accumulators u64 x local][first u32 x local][counts u32 x local each]
 // FAST: exactly one aggregate, a plain f64 sum (C3 / C3w): first row + one ds_add_f64 per record, no per-record dispatch on the aggregate kinds
@@ -380,6 +381,8 @@ __global__ __launch_bounds__(THREADS) void k_plane_aggregate(const Plan P, const
         if (rows) {
             const unsigned row = (unsigned)(rbase + (i64)(mm >> PL_SLOT_BITS));
             if (row < first[slot]) atomicMin(&first[slot], row);
+        } else if (first[slot] == PL_FIRST_NONE) {
+            atomicMin(&first[slot], PL_FIRST_TOUCHED); // reached by a record without a row: some block with rows must supply the first row
         }
         if constexpr (FAST) {
             if (!(A.dbg & 1)) unsafeAtomicAdd((double *)&accs[slot], rfx_as_f64(x[0]));
@@ -492,7 +495,7 @@ __global__ __launch_bounds__(THREADS) void k_plane_aggregate(const Plan P, const
         if (f == PL_FIRST_NONE) continue;
         const i64 g = (i << A.pbits) | (i64)(((u64)p - (u64)A.kmin) & (u64)((1 << A.pbits) - 1));
         if (g >= A.range) continue;
-        const u64 fr = (u64)P.row0 + (u64)f;
+        const u64 fr = (f == PL_FIRST_TOUCHED) ? (u64)RFX_INF_I64_D - 1ULL : (u64)P.row0 + (u64)f;
         if (fr < A.first[g]) atomicMin((unsigned long long *)&A.first[g], (unsigned long long)fr);
 #pragma unroll
         for (int a = 0; a < RFX_MAX_AGGS; a++) {
@@ -501,6 +504,13 @@ __global__ __launch_bounds__(THREADS) void k_plane_aggregate(const Plan P, const
             group_merge_cell(&A.acc[a][g], hc ? &A.cntt[a][g] : (u64 *)0, kind[a], f64[a], accs[(i64)a * local + i], hc ? (u64)cnts[(i64)cnt_of[a] * local + i] : 0ULL);
         }
     }
+}
+
+// any slot that only row-less records reached?  (its first row lies in a block that carried no rows: the caller runs the query again with rows)
+__global__ __launch_bounds__(RFX_BLOCK) void k_plane_check(const u64 *__restrict__ first, i64 range, unsigned *__restrict__ flag) {
+    bool bad = false;
+    for (i64 i = blockIdx.x * (i64)RFX_BLOCK + threadIdx.x; i < range; i += (i64)gridDim.x * RFX_BLOCK) bad |= first[i] == (u64)RFX_INF_I64_D - 1ULL;
+    if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1u);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -597,6 +607,10 @@ struct PlaneState { // what rfx_plane_scope leaves for rfx_plane_accumulate (liv
     const void *val[PL_MAX_NV];
     i64 nrows;
     u64 sig[RFX_MAX_PREDS][6];
+    // key columns whose groups' first rows turned up late (row-less blocks did not do): rows everywhere from the start next time
+    const void *late_key[8];
+    i64 late_rows[8];
+    int late_n;
 };
 static PlaneState *plane_state(rfx_ctx *c) {
     if (!c->ext_p[2]) c->ext_p[2] = calloc(1, sizeof(PlaneState));
@@ -609,6 +623,20 @@ void rfx_plane_release(rfx_ctx *c) {
     free(c->ext_p[2]);
     c->ext_p[2] = NULL;
 }
+static bool plane_late_keys(rfx_ctx *c, const void *key, i64 nrows) {
+    PlaneState *st = (PlaneState *)c->ext_p[2];
+    if (!st) return false;
+    for (int i = 0; i < 8 && i < st->late_n; i++)
+        if (st->late_key[i] == key && st->late_rows[i] == nrows) return true;
+    return false;
+}
+static void plane_late_keys_add(rfx_ctx *c, const void *key, i64 nrows) {
+    PlaneState *st = (PlaneState *)c->ext_p[2];
+    if (!st || plane_late_keys(c, key, nrows)) return;
+    st->late_key[st->late_n % 8] = key;
+    st->late_rows[st->late_n % 8] = nrows;
+    st->late_n++;
+}
 static void plane_pred_sig(const Plan &P, u64 (*sig)[6]) {
     for (int i = 0; i < P.npred; i++) {
         const PlanPred &q = P.preds[i];
@@ -620,46 +648,16 @@ static void plane_pred_sig(const Plan &P, u64 (*sig)[6]) {
         sig[i][5] = 0;
     }
 }
-// Scope pass that also partitions into planes.  P: the plan as built (key at key_idx); est_range / frac: the sample's guesses.
-// RFX_ESTATE: not applicable / gave up (nothing is left behind), the caller goes on with the chunk kernels.
-int rfx_plane_scope(rfx_ctx *c, const Plan &P, int key_idx, const void *d_key, int npred, int logic, unsigned long long est_range, double frac,
-                    i64 *kmin, i64 *kmax, i64 *seen) {
-    PlaneState *st = plane_state(c);
-    if (!st) return RFX_ESTATE;
-    st->valid = 0;
-    if (c->flags & RFX_TUNE_NO_PLANE) return RFX_ESTATE;
-    int vcol[PL_MAX_NV], agg_plane[RFX_MAX_AGGS];
-    const int nv = plane_value_cols(P, vcol, agg_plane);
-    if (nv != 1) return RFX_ESTATE; // (two and three planes: 128 partitions, not built yet)
-    // 128 partitions (256-byte groups) when a partition twice as wide still fits the aggregate pass's LDS with a quarter to spare (the
-    // sampled range can only be too small), else 256
-    int pbits = 7;
-    {
-        static const char *force = getenv("RFX_PLANE_PBITS"); // (A/B)
-        const i64 l7 = (i64)((est_range + 127) >> 7);
-        if (l7 + l7 / 4 > (1 << PL_SLOT_BITS) || plane_agg_lds(P, 0, P.nagg, l7 + l7 / 4) > PL_AGG_LDS_MAX) pbits = 8;
-        if (force) pbits = atoi(force) == 7 ? 7 : 8;
-    }
-    const i64 est_local = (i64)((est_range + (1ULL << pbits) - 1) >> pbits);
-    if (est_local > (1 << PL_SLOT_BITS)) return RFX_ESTATE;
-    if (plane_agg_lds(P, 0, P.nagg, est_local) > PL_AGG_LDS_MAX) return RFX_ESTATE;
-    const i64 nrows = P.nrows;
-    const i64 block_rows = PL_BLOCK_ROWS;
-    const i64 nblk64 = (nrows + block_rows - 1) / block_rows;
-    if (nblk64 > (1 << 20)) return RFX_ESTATE;
-    // region size: the expected share of a partition plus room for its spread (uniform keys: sigma = sqrt(share)), whole 64-record lines
-    double share = (double)block_rows / (double)(1 << pbits);
-    if (npred > 0) share *= (frac * 1.3 + 0.01 < 1.0 ? frac * 1.3 + 0.01 : 1.0);
-    unsigned c0 = (unsigned)(share * 1.25 + 160.0);
-    c0 = (c0 + 127u) & ~127u;
+// One scatter launch over the whole input (layout, column order, launch, read-back of the control block).  RFX_ESTATE: gave up.
+static int plane_scatter_run(rfx_ctx *c, const Plan &P, int key_idx, const int *vcol, int nv, int pbits, unsigned c0, int nblk, int nrowblk, unsigned **hctl_out) {
     PlaneArgs A;
     memset(&A, 0, sizeof(A));
     size_t need = 0;
-    plane_layout(c, (int)nblk64, pbits, c0, nv, &A, &need);
+    plane_layout(c, nblk, pbits, c0, nv, &A, &need);
     if (rfx_chunk_reserve(c, need) != RFX_OK) return RFX_ESTATE;
-    plane_layout(c, (int)nblk64, pbits, c0, nv, &A, NULL);
-    A.nrowblk = A.nblk;
-    A.block_rows = block_rows;
+    plane_layout(c, nblk, pbits, c0, nv, &A, NULL);
+    A.nrowblk = nrowblk;
+    A.block_rows = PL_BLOCK_ROWS;
     // key -> column 0, value plane j -> column 1 + j (the kernel reads them without a run-time select; a value column that IS the key
     // column is listed a second time), the predicates' other columns behind them
     Plan Pc = P;
@@ -693,12 +691,63 @@ int rfx_plane_scope(rfx_ctx *c, const Plan &P, int key_idx, const void *d_key, i
     if (rc != RFX_OK) return rc;
     RFX_HIP_CHECK(hipGetLastError());
     unsigned *hctl = (unsigned *)c->h_pin;
+    *hctl_out = hctl;
     RFX_HIP_CHECK(hipMemcpyAsync(hctl, A.ctl, 256, hipMemcpyDeviceToHost, c->stream));
     RFX_HIP_CHECK(hipStreamSynchronize(c->stream));
     if (hctl[1]) { // a region overflowed (skew or selectivity the sample did not show): the chunk kernels take over
         c->ext_i[3 + RFX_STAT_PLANE_FALLBACK]++;
         return RFX_ESTATE;
     }
+    return RFX_OK;
+}
+
+// Scope pass that also partitions into planes.  P: the plan as built (key at key_idx); est_range / frac: the sample's guesses.
+// RFX_ESTATE: not applicable / gave up (nothing is left behind), the caller goes on with the chunk kernels.
+int rfx_plane_scope(rfx_ctx *c, const Plan &P, int key_idx, const void *d_key, int npred, int logic, unsigned long long est_range, double frac,
+                    i64 *kmin, i64 *kmax, i64 *seen) {
+    PlaneState *st = plane_state(c);
+    if (!st) return RFX_ESTATE;
+    st->valid = 0;
+    if (c->flags & RFX_TUNE_NO_PLANE) return RFX_ESTATE;
+    int vcol[PL_MAX_NV], agg_plane[RFX_MAX_AGGS];
+    const int nv = plane_value_cols(P, vcol, agg_plane);
+    if (nv != 1) return RFX_ESTATE; // (two and three planes: 128 partitions, not built yet)
+    // 128 partitions (256-byte groups) when a partition twice as wide still fits the aggregate pass's LDS with a quarter to spare (the
+    // sampled range can only be too small), else 256
+    int pbits = 7;
+    {
+        static const char *force = getenv("RFX_PLANE_PBITS"); // (A/B)
+        const i64 l7 = (i64)((est_range + 127) >> 7);
+        if (l7 + l7 / 4 > (1 << PL_SLOT_BITS) || plane_agg_lds(P, 0, P.nagg, l7 + l7 / 4) > PL_AGG_LDS_MAX) pbits = 8;
+        if (force) pbits = atoi(force) == 7 ? 7 : 8;
+    }
+    const i64 est_local = (i64)((est_range + (1ULL << pbits) - 1) >> pbits);
+    if (est_local > (1 << PL_SLOT_BITS)) return RFX_ESTATE;
+    if (plane_agg_lds(P, 0, P.nagg, est_local) > PL_AGG_LDS_MAX) return RFX_ESTATE;
+    const i64 nrows = P.nrows;
+    const i64 block_rows = PL_BLOCK_ROWS;
+    const i64 nblk64 = (nrows + block_rows - 1) / block_rows;
+    if (nblk64 > (1 << 20) || nrows >= 0xFFFFFFF0LL) return RFX_ESTATE;
+    // region size: the expected share of a partition plus room for its spread (uniform keys: sigma = sqrt(share)), whole 64-record lines
+    double share = (double)block_rows / (double)(1 << pbits);
+    if (npred > 0) share *= (frac * 1.3 + 0.01 < 1.0 ? frac * 1.3 + 0.01 : 1.0);
+    unsigned c0 = (unsigned)(share * 1.25 + 160.0);
+    c0 = (c0 + 127u) & ~127u;
+    // Row ids only where `first` can still change: once every slot of the range has been met, a later row is never a group's first one,
+    // and its record needs no row (2-byte meta instead of 4).  With spread keys every slot turns up within a few times the range's rows:
+    // the first blocks -- 32 x range selected rows -- carry rows, the rest do not.  The aggregate pass marks slots that only row-less
+    // records reached; any such slot left at the end (keys that first appear late: sorted or drifting data) sends the query through
+    // again with rows everywhere (rfx_plane_accumulate), and the key column is remembered so that the next query starts that way.
+    i64 nrowblk = nblk64;
+    {
+        static const int no_plain = getenv("RFX_PLANE_ALL_ROWS") != NULL; // (A/B)
+        const double per_block = (double)block_rows * (npred > 0 ? (frac > 0.001 ? frac : 0.001) : 1.0);
+        const double want = 32.0 * (double)est_range / per_block + 2.0;
+        if (!no_plain && !plane_late_keys(c, d_key, nrows) && want < (double)nblk64 * 0.5) nrowblk = (i64)want;
+    }
+    unsigned *hctl = NULL;
+    int rc = plane_scatter_run(c, P, key_idx, vcol, nv, pbits, c0, (int)nblk64, (int)nrowblk, &hctl);
+    if (rc != RFX_OK) return rc;
     const u64 *hs = (const u64 *)hctl + 8;
     i64 nulls = (i64)hs[3];
     *seen = (i64)hs[2];
@@ -715,8 +764,8 @@ int rfx_plane_scope(rfx_ctx *c, const Plan &P, int key_idx, const void *d_key, i
     st->nrows = nrows;
     st->npred = npred;
     st->logic = logic;
-    st->nblk = A.nblk;
-    st->nrowblk = A.nrowblk;
+    st->nblk = (int)nblk64;
+    st->nrowblk = (int)nrowblk;
     st->pbits = pbits;
     st->nv = nv;
     st->c0 = c0;
@@ -781,29 +830,58 @@ int rfx_plane_accumulate(rfx_ctx *c, const Plan &P, int key_idx, const rfx_group
         G.cntt[a] = (u64 *)t->d_cnt[a];
     }
     const int nparts = 1 << st->pbits;
-    c->ext_i[3 + RFX_STAT_PLANE_AGGREGATE]++;
     {
         static const char *dbg = getenv("RFX_PLANE_DBG");
         G.dbg = dbg ? atoi(dbg) : 0;
     }
-    int rc = RFX_OK;
     const bool fast = P.nagg == 1 && P.aggs[0].kind == RFX_AGG_SUM && P.aggs[0].f64 && !P.aggs[0].skipnull && agg_plane[0] == 0;
-    RFX_KERNEL_BEGIN(c);
-    if (lds > 48 * 1024) {
-        // big tables: one 1024-lane workgroup per CU
-        G.split = (c->num_cus + nparts - 1) / nparts;
-        if (G.split < 1) G.split = 1;
-        if (fast) rc = launch_plane_aggregate<1024, true>(c, P, G, nparts * G.split, lds, 160 * 1024);
-        else rc = launch_plane_aggregate<1024, false>(c, P, G, nparts * G.split, lds, 160 * 1024);
-    } else {
-        const int per_cu = (int)((150 * 1024) / (lds > 1 ? lds : 1)) < 4 ? (int)((150 * 1024) / lds) : 4; // 512-lane workgroups a CU can hold: 3 at 47 KB
-        G.split = (per_cu * c->num_cus + nparts - 1) / nparts;
-        if (G.split < 1) G.split = 1;
-        if (fast) rc = launch_plane_aggregate<512, true>(c, P, G, nparts * G.split, lds, 64 * 1024);
-        else rc = launch_plane_aggregate<512, false>(c, P, G, nparts * G.split, lds, 64 * 1024);
+    for (int attempt = 0;; attempt++) {
+        int rc = RFX_OK;
+        c->ext_i[3 + RFX_STAT_PLANE_AGGREGATE]++;
+        RFX_KERNEL_BEGIN(c);
+        if (lds > 52 * 1024) {
+            // big tables: one 1024-lane workgroup per CU
+            G.split = (c->num_cus + nparts - 1) / nparts;
+            if (G.split < 1) G.split = 1;
+            if (fast) rc = launch_plane_aggregate<1024, true>(c, P, G, nparts * G.split, lds, 160 * 1024);
+            else rc = launch_plane_aggregate<1024, false>(c, P, G, nparts * G.split, lds, 160 * 1024);
+        } else {
+            const int per_cu = (int)((156 * 1024) / (lds > 1 ? lds : 1)) < 4 ? (int)((156 * 1024) / lds) : 4; // 512-lane workgroups a CU can hold: 3 at 51 KB
+            G.split = (per_cu * c->num_cus + nparts - 1) / nparts;
+            if (G.split < 1) G.split = 1;
+            if (fast) rc = launch_plane_aggregate<512, true>(c, P, G, nparts * G.split, lds, 64 * 1024);
+            else rc = launch_plane_aggregate<512, false>(c, P, G, nparts * G.split, lds, 64 * 1024);
+        }
+        RFX_KERNEL_END(c);
+        if (rc != RFX_OK) return rc;
+        RFX_HIP_CHECK(hipGetLastError());
+        if (G.nrowblk >= G.nblk) return RFX_OK; // every record carried its row: nothing to verify
+        // did every slot get its first row from a block with rows?
+        int cgrid = (int)((t->range + RFX_BLOCK - 1) / RFX_BLOCK);
+        if (cgrid > c->num_cus * 4) cgrid = c->num_cus * 4;
+        hipLaunchKernelGGL(k_plane_check, dim3(cgrid), dim3(RFX_BLOCK), 0, c->stream, (const u64 *)t->d_first, (i64)t->range, A.ctl + 2);
+        RFX_HIP_CHECK(hipGetLastError());
+        unsigned *hflag = (unsigned *)c->h_pin;
+        RFX_HIP_CHECK(hipMemcpyAsync(hflag, A.ctl + 2, 4, hipMemcpyDeviceToHost, c->stream));
+        RFX_HIP_CHECK(hipStreamSynchronize(c->stream));
+        if (!hflag[0]) return RFX_OK;
+        // Late keys: some group's first row lies in a block that carried no rows.  Start over with rows in every block: tables back to
+        // their initial state, the scatter again, the aggregate again; and remember the key column.
+        if (attempt > 0) {
+            rfx_set_error("plane partitioning: a slot without a first row after the pass with rows everywhere");
+            return RFX_EHIP;
+        }
+        c->ext_i[0]++; // RFX_STAT_PLANE_REDO
+        plane_late_keys_add(c, (const void *)P.cols[key_idx], P.nrows);
+        rc = rfx_fill_u64(c, t->d_first, t->range, (u64)RFX_INF_I64_D);
+        for (int a2 = 0; rc == RFX_OK && a2 < t->nagg; a2++) {
+            rc = rfx_fill_u64(c, t->d_acc[a2], t->range, acc_identity(P.aggs[a2].kind, P.aggs[a2].f64));
+            if (rc == RFX_OK && t->d_cnt[a2]) rc = rfx_fill_u64(c, t->d_cnt[a2], t->range, 0ULL);
+        }
+        if (rc != RFX_OK) return rc;
+        unsigned *hctl = NULL;
+        rc = plane_scatter_run(c, P, key_idx, vcol, nv, st->pbits, st->c0, st->nblk, st->nblk, &hctl);
+        if (rc != RFX_OK) return rc; // (RFX_ESTATE: the tables are clean again, the caller's other paths may run)
+        G.nrowblk = G.nblk;
     }
-    RFX_KERNEL_END(c);
-    if (rc != RFX_OK) return rc;
-    RFX_HIP_CHECK(hipGetLastError());
-    return RFX_OK;
 }

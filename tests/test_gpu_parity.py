@@ -54,8 +54,8 @@ def _abs_scale(host, q, name):
     return rfo.select({"from": habs, **q2})[name]
 
 
-def check_select(eng, host, q):
-    got = eng.select({"from": dev(eng, host), **q})
+def check_select(eng, host, q, devt=None):
+    got = eng.select({"from": dev(eng, host) if devt is None else devt, **q})
     want = rfo.select({"from": host, **q})
     assert list(got.keys()) == list(want.keys())
     for name in want:
@@ -467,6 +467,34 @@ def test_plane_rings_under_pressure_and_region_overflow(eng, run):
             assert after[1] == before[1] and after[2] - before[2] == 2, (before, after)
         else:
             assert after[1] - before[1] == 2 and after[2] == before[2], (before, after)
+    finally:
+        eng.tune(flags=0)
+
+
+def test_plane_blocks_without_row_ids_and_late_keys(eng):
+    """Beyond the first 32 x range selected rows the plane records carry no row id (2-byte meta): every slot has met its first row by then
+    -- when the keys are spread.  Keys that first turn up late (here: 384 keys confined to the last rows) leave slots that only row-less
+    records reached; the pass notices, runs again with row ids everywhere (counter 5) and remembers the key column (no second retry)."""
+    n = 4_500_001
+    host = table(n, keys=16_000)
+    host["k"][-200_000:] = 16_000 + rfo.gen_i64(200_000, 123, 384)
+    even = table(n, keys=16_384)
+    qs = [{"by": "k", "s": ("sum", "v")}, {"where": ("<", "a", 500_000), "by": "k", "s": ("sum", "v"), "c": ("count", "v"), "f": ("first", "a"), "mn": ("min", "v")}]
+    try:
+        eng.tune(flags=0)
+        st = lambda: [eng.stat(i) for i in range(6)]
+        b0 = st()
+        for q in qs:
+            check_select(eng, even, q)
+        b1 = st()
+        assert b1[0] - b0[0] == 2 and b1[2] - b0[2] == 2 and b1[1] == b0[1] and b1[5] == b0[5], (b0, b1)
+        devt = dev(eng, host)  # (one upload: the key column is remembered by its device address)
+        check_select(eng, host, qs[0], devt)
+        b2 = st()
+        assert b2[5] - b1[5] == 1 and b2[0] - b1[0] == 2 and b2[2] - b1[2] == 2, (b1, b2)
+        check_select(eng, host, qs[1], devt)  # same key column: rows everywhere from the start
+        b3 = st()
+        assert b3[5] == b2[5] and b3[0] - b2[0] == 1 and b3[2] - b2[2] == 1, (b2, b3)
     finally:
         eng.tune(flags=0)
 
