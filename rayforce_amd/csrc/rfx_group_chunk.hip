@@ -1249,9 +1249,8 @@ int rfx_chunk_scope(rfx_ctx *c, const int64_t *d_key, const rfx_pred_t *preds, i
     int key_idx = 0;
     int rc = rfx_plan_build(&P, preds, npred, logic, aggs, nagg, d_key, &key_idx, nrows, 0);
     if (rc != RFX_OK) return RFX_ESTATE; // the accumulate call reports it
-    if (P.nx > 0 || P.ncols > 4) return RFX_ESTATE;
-    const int vc = single_value_col(P);
-    if (vc < 0) return RFX_ESTATE;
+    if (P.nx > 0 || P.ncols > 6) return RFX_ESTATE;
+    const int vc = single_value_col(P); // (< 0: several value columns -- only the plane kernels carry those)
     const int narr = narr_of(P);
     // a strided sample guesses the key range and the selectivity: only ranges whose tables overflow one workgroup's LDS but fit
     // 256 partitions come here (the LDS-direct kernel is one pass already; wider ranges need more partitions than the low 8 bits give)
@@ -1265,7 +1264,9 @@ int rfx_chunk_scope(rfx_ctx *c, const int64_t *d_key, const rfx_pred_t *preds, i
         case 1: hipLaunchKernelGGL(k_scope_sample<1>, dim3(sgrid), dim3(RFX_BLOCK), 0, c->stream, P, key_idx, nrows / nsamp, nsamp, (i64 *)c->d_ws, d_hist); break;
         case 2: hipLaunchKernelGGL(k_scope_sample<2>, dim3(sgrid), dim3(RFX_BLOCK), 0, c->stream, P, key_idx, nrows / nsamp, nsamp, (i64 *)c->d_ws, d_hist); break;
         case 3: hipLaunchKernelGGL(k_scope_sample<3>, dim3(sgrid), dim3(RFX_BLOCK), 0, c->stream, P, key_idx, nrows / nsamp, nsamp, (i64 *)c->d_ws, d_hist); break;
-        default: hipLaunchKernelGGL(k_scope_sample<4>, dim3(sgrid), dim3(RFX_BLOCK), 0, c->stream, P, key_idx, nrows / nsamp, nsamp, (i64 *)c->d_ws, d_hist); break;
+        case 4: hipLaunchKernelGGL(k_scope_sample<4>, dim3(sgrid), dim3(RFX_BLOCK), 0, c->stream, P, key_idx, nrows / nsamp, nsamp, (i64 *)c->d_ws, d_hist); break;
+        case 5: hipLaunchKernelGGL(k_scope_sample<5>, dim3(sgrid), dim3(RFX_BLOCK), 0, c->stream, P, key_idx, nrows / nsamp, nsamp, (i64 *)c->d_ws, d_hist); break;
+        default: hipLaunchKernelGGL(k_scope_sample<6>, dim3(sgrid), dim3(RFX_BLOCK), 0, c->stream, P, key_idx, nrows / nsamp, nsamp, (i64 *)c->d_ws, d_hist); break;
     }
     RFX_HIP_CHECK(hipGetLastError());
     i64 *hs = (i64 *)c->h_pin;
@@ -1284,7 +1285,6 @@ int rfx_chunk_scope(rfx_ctx *c, const int64_t *d_key, const rfx_pred_t *preds, i
     const unsigned long long est = (unsigned long long)smx - (unsigned long long)smn + 1ULL;
     if (est == 0 || est > (1ULL << 40)) return RFX_ESTATE;
     if ((size_t)est * 12 <= (size_t)150 * 1024) return RFX_ESTATE;                                    // LDS-direct territory
-    if ((size_t)((est + 255) >> 8) * narr * 8 > (size_t)PART_LDS_BIG_BYTES) return RFX_ESTATE;         // needs more than 256 partitions
     const double frac = (double)ssel / (double)nsamp;
     i64 est_rows = (i64)((double)nrows * (frac * 1.5 + 0.02));
     if (est_rows > nrows || npred == 0) est_rows = nrows;
@@ -1301,6 +1301,8 @@ int rfx_chunk_scope(rfx_ctx *c, const int64_t *d_key, const rfx_pred_t *preds, i
         const int prc = rfx_plane_scope(c, P, key_idx, d_key, npred, logic, est, frac, kmin, kmax, seen);
         if (prc != RFX_ESTATE) return prc;
     }
+    if (vc < 0 || P.ncols > 4) return RFX_ESTATE;                                                      // the chunk records carry one value
+    if ((size_t)((est + 255) >> 8) * narr * 8 > (size_t)PART_LDS_BIG_BYTES) return RFX_ESTATE;         // needs more than 256 partitions
     ChunkArgs A;
     memset(&A, 0, sizeof(A));
     i64 tpw = 0, nulls = 0;

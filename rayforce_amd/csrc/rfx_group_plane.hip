@@ -1,28 +1,31 @@
 // rfx_group_plane.hip -- one-pass radix partitioning into PLANES: the dense group-by whose tables do not fit one workgroup's LDS
-// (BASELINE C3 / C3w: 1e9 rows, 1e6 i64 keys, sum(f64)), moved with 12 (10) bytes per record instead of 16.
+// (BASELINE C3 / C3w: 1e9 rows, 1e6 i64 keys, sum(f64); the H2O shapes with two or three value columns), moved with 8 bytes per value
+// + 4 bytes of meta per record instead of 16 / 32-byte records.
 //
 // What the reference does here: index_group_i64_scoped (core/index.c:2002-2092) walks the key column once, single-threaded, and
-// AGGR_ITER (core/aggr.c:73-181) folds the value column through the group ids.  rfx_group_chunk.hip partitions 16-byte records
-// {row:32 | key >> 8, value}: 16 B read + 16 written + 16 read per row, and a scatter that spends a third of its time in workgroup
-// barriers.  Measured bound on this part (tools/write_probe.hip, profiles/r03_write_probe.jsonl): a scatter keeps up with HBM only when
-// every store instruction covers >= 128 contiguous bytes per stream with 8..16 bytes per lane (128 B: 4.7-4.9 TB/s of mixed traffic,
-// 64 B: 3.7, 32 B: 3.1, 16 B: 2.5) -- so the record is split into planes that each leave in whole 128-byte lines:
+// AGGR_ITER (core/aggr.c:73-181) folds every value column through the group ids.  rfx_group_chunk.hip partitions 16-byte records
+// {row:32 | key >> 8, value} (one value column only): 16 B read + 16 written + 16 read per row, with a scatter that spends a third of its
+// time in workgroup barriers.  Measured on this part (tools/write_probe.hip, profiles/r03_write_probe.jsonl): a scatter keeps up with HBM
+// only when every store instruction covers >= 128 contiguous bytes per stream with 8..16 bytes per lane (256 B: 4.9-5.2 TB/s of mixed
+// traffic, 128 B: 4.7-4.9, 64 B: 3.7, 32 B: 3.1, 16 B: 2.5) -- so the record is split into planes that each leave in whole lines:
 //
-//   value plane(s)  8 B per record, 16 records per line
-//   meta plane      4 B per record {slot-in-partition : 14 | row - block_base : 18}, 32 records per line        ("row" blocks)
-//                   2 B per record {slot-in-partition : 16}, 64 records per line                                ("plain" blocks, see below)
+//   value plane(s)  8 B per record (one plane per distinct value column, up to three)
+//   meta plane      4 B per record {slot-in-partition : 14 | row - block_base : 18}
 //
 //   k_plane_scatter   one 1024-lane workgroup per ROW BLOCK of 2^18 rows (thousands of blocks: the dispatcher balances them).  Waves run
 //                     DECOUPLED, no workgroup barrier in the loop: a selected row takes the next place of its partition's LDS ring with
-//                     one returning LDS atomic, writes value + meta there, and counts itself into the ring group's arrival word; the
-//                     lane that completes a group queues it, and its wave stores queued groups as full lines (eight lanes x 16 B per line,
-//                     non-temporal) before it goes on.  A (block, partition) region has a FIXED place and size (no allocator): too many
-//                     records for a region (skew the sample did not show) or a stuck ring raise a flag and the caller takes the
-//                     chunk / column paths.  Side product, as before: min / max / count of the selected keys (index_scope_i64).
-//   k_plane_aggregate one LDS table set per partition (first row as 32 bits, accumulators 64, counts 32), regions streamed with the
-//                     next region's loads in flight, merged into the global tables.
+//                     one returning LDS atomic, writes its values + meta there, and counts itself into the ring half's arrival word; the
+//                     lane that completes a half (a "group": 32 or 16 records) queues it, and its wave stores queued groups as whole lines
+//                     (16 B per lane, non-temporal) before it goes on.  A (block, partition) region has a FIXED place and size (no
+//                     allocator): too many records for a region (skew the sample did not show) or a stuck ring raise a flag and the caller
+//                     takes the chunk / column paths.  Side product, as before: min / max / count of the selected keys (index_scope_i64).
+//   k_plane_aggregate one LDS table set per partition (first row as 32 bits, accumulators 64, counts 32); every wave streams its own
+//                     regions with the next batch's loads in flight; merged into the global tables.  Several value planes: one pass per
+//                     set of aggregates whose tables fit a CU's LDS (each reads the meta plane + its own value planes).
 //
-// Bytes per row (C3): 16 read + 12 written + 12 read = 40 (was 48).
+// Bytes per row (C3): 16 read + 12 written + 12 read = 40 (was 48).  Both kernels turned out INSTRUCTION-bound, not byte-bound (rocprofv3
+// SQ counters, profiles/r03_pmc_plane.txt: ~200 wave instructions per 64 rows in the scatter): a 2-byte meta plane for the rows that cannot
+// be a group's first one (36 B/row) was built, measured at the same 7.6 ms per 1e9 rows, and taken out again (git d52b3d2).
 #include "rfx_part_common.hpp"
 #include <stdlib.h>
 
@@ -38,28 +41,28 @@
 #define PL_MAX_NV 3
 
 struct PlaneArgs {
-    int nblk, nrowblk; // row blocks; blocks [0, nrowblk) carry row deltas (4-byte meta), the rest 2-byte meta
+    int nblk;          // row blocks
     int nv;            // value planes
     i64 block_rows;
-    unsigned c0;       // records per (block, partition) region, a multiple of 64
+    unsigned c0;       // records per (block, partition) region, a multiple of 32
     u64 *vals[PL_MAX_NV];
-    unsigned *meta;    // region (b, p) starts at entry ((b << PBITS) + p) * c0 of every plane (4 bytes per entry in the meta plane)
+    unsigned *meta;    // region (b, p) starts at entry ((b << PBITS) + p) * c0 of every plane
     unsigned *cnt;     // [nblk << PBITS] records per region
     unsigned *ctl;     // 256 bytes, zeroed before the launch.  [1]: some region overflowed / a ring did not drain -> the caller falls back;
-                       // bytes 64..95: the scope of all selected keys {~image(min), image(max), count, nulls} (see the kernel's end)
+                       // bytes 64..87: the scope of all selected keys {~image(min), image(max), count} (see the kernel's end)
 };
 struct PlSh {
     unsigned dead, _pad[3];
-    ScopePart red[PL_WAVES];
+    i64 red[3][PL_WAVES];
 };
-// A value group is 2^VGL records (16: one 128-byte line per plane, 32: two), a partition's ring two groups; the meta plane's groups are
-// twice (4-byte entries) or four times (2-byte entries) as many records, so that they fill the same number of bytes.
+// A group is 2^VGL records (32: two 128-byte lines per value plane and one of meta; 16: one line and half a line), a partition's ring two
+// groups per plane.
 template <int NV, int PBITS, int VGL>
 __host__ __device__ constexpr size_t pl_lds_bytes() {
-    return (size_t)(1 << PBITS) * ((size_t)NV * (2 << VGL) * 8 + (16 << VGL) + 16 + 4) + (size_t)PL_WAVES * PL_QCAP * 4 + sizeof(PlSh) + 64;
+    return (size_t)(1 << PBITS) * ((size_t)(2 << VGL) * (NV * 8 + 4) + 8 + 4) + (size_t)PL_WAVES * PL_QCAP * 4 + sizeof(PlSh) + 64;
 }
 typedef u64 pl_v2 __attribute__((ext_vector_type(2)));
-typedef unsigned pl_m2 __attribute__((ext_vector_type(2), aligned(4)));
+typedef unsigned pl_m2 __attribute__((ext_vector_type(2)));
 // LDS words other waves write: relaxed workgroup-scope atomics keep the LDS address space (a volatile cast turns them into FLAT
 // accesses that wait for every global load in flight)
 #define PL_LD(ptr) __hip_atomic_load((ptr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
@@ -68,36 +71,34 @@ typedef unsigned pl_m2 __attribute__((ext_vector_type(2), aligned(4)));
 template <int NC, int NP, int NV, int PBITS, int VGL>
 __global__ __launch_bounds__(PL_T) void k_plane_scatter(const Plan P, const PlaneArgs A) {
     constexpr int PARTS = 1 << PBITS;
-    constexpr unsigned VG = 1u << VGL, RING = 2u << VGL; // records per value group / per ring
-    constexpr unsigned GB = 8u << VGL;                   // bytes of a group in any plane (128 or 256)
-    constexpr unsigned LPD = GB / 16;                    // lanes that store one group (16 bytes each)
+    constexpr unsigned VG = 1u << VGL, RING = 2u << VGL; // records per group / per ring
+    constexpr unsigned LPD = VG / 2;                     // lanes that store one value group (16 bytes = two records each); meta: half of them
     extern __shared__ __attribute__((aligned(16))) unsigned char pl_smem[];
-    u64 *vring = (u64 *)pl_smem;                                   // [NV][PARTS][RING]
-    unsigned char *mring = pl_smem + (size_t)NV * PARTS * RING * 8; // [PARTS][2 * GB]
-    uint4 *words = (uint4 *)(mring + PARTS * 2 * GB);              // [PARTS] {value half 0, value half 1, meta half 0, meta half 1}: generation << 8 | arrivals
-    unsigned *tail = (unsigned *)(words + PARTS);                  // [PARTS] records handed out
-    unsigned *fq = tail + PARTS;                                   // [PL_WAVES][PL_QCAP]
+    u64 *vring = (u64 *)pl_smem;                                       // [NV][PARTS][RING]
+    unsigned *mring = (unsigned *)(vring + (size_t)NV * PARTS * RING); // [PARTS][RING]
+    unsigned *words = mring + (size_t)PARTS * RING;                    // [PARTS][2] ring halves: generation << 8 | arrivals
+    unsigned *tail = words + PARTS * 2;                                // [PARTS] records handed out
+    unsigned *fq = tail + PARTS;                                       // [PL_WAVES][PL_QCAP]
     PlSh &L = *(PlSh *)(fq + PL_WAVES * PL_QCAP);
     PredSet<NP> S;
     predset_load<NP>(P, S);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     unsigned *myq = fq + wv * PL_QCAP;
-    const bool rows = (int)blockIdx.x < A.nrowblk;
-    const unsigned msh = rows ? VGL + 1u : VGL + 2u; // log2(records per meta group)
-    const unsigned mk = 1u << (msh - VGL);           // value groups per meta group
     const i64 r0 = (i64)blockIdx.x * A.block_rows;
     const i64 r1 = (r0 + A.block_rows < P.nrows) ? r0 + A.block_rows : P.nrows;
     const u64 region = ((u64)blockIdx.x << PBITS) * A.c0;
     for (int i = tid; i < PARTS; i += PL_T) {
         tail[i] = 0;
-        words[i] = make_uint4(0, 0, 0, 0);
+        words[2 * i] = 0;
+        words[2 * i + 1] = 0;
     }
     if (tid == 0) L.dead = 0;
     __syncthreads();
-    i64 mn = RFX_INF_I64_D, mx = RFX_NULL_I64_D, sel = 0, nulls = 0;
-    int qn = 0; // wave-uniform
+    i64 mn = RFX_INF_I64_D, mx = RFX_NULL_I64_D; // over ALL selected keys: a null key (INT64_MIN) shows as the minimum, as for index_scope_i64
+    unsigned nsel = 0;                           // selected rows of this lane
+    int qn = 0;                                  // wave-uniform
 
-    // completed groups of this wave -> global memory as whole lines (LPD lanes x 16 bytes per group), then their ring halves are released
+    // completed groups of this wave -> global memory as whole lines, then their ring halves are released
     auto flush_queue = [&]() __attribute__((always_inline)) {
         asm volatile("" ::: "memory");
         for (int i0 = 0; i0 < qn; i0 += 64 / (int)LPD) {
@@ -109,19 +110,16 @@ __global__ __launch_bounds__(PL_T) void k_plane_scatter(const Plan P, const Plan
                     const pl_v2 x = *(const pl_v2 *)(vring + ((size_t)pl * PARTS + p) * RING + (gi & 1u) * VG + sub * 2);
                     u64 *dst = (NV == 1 ? A.vals[0] : (pl == 0 ? A.vals[0] : (pl == 1 ? A.vals[1] : A.vals[2])));
                     __builtin_nontemporal_store(x, (pl_v2 *)(dst + region + (u64)p * A.c0 + (u64)gi * VG + sub * 2));
-                } else {
-                    const pl_v2 x = *(const pl_v2 *)(mring + p * (2 * GB) + (gi & 1u) * GB + sub * 16);
-                    __builtin_nontemporal_store(x, (pl_v2 *)((char *)A.meta + (region + (u64)p * A.c0) * 4 + (u64)gi * GB + sub * 16));
+                } else if (sub < LPD / 2) {
+                    const pl_v2 x = *(const pl_v2 *)(mring + (size_t)p * RING + (gi & 1u) * VG + sub * 4);
+                    __builtin_nontemporal_store(x, (pl_v2 *)(A.meta + region + (u64)p * A.c0 + (u64)gi * VG + sub * 4));
                 }
             }
         }
         asm volatile("" ::: "memory"); // ring reads above, releases below
         for (int i = lane; i < qn; i += 64) {
             const unsigned d = myq[i];
-            const unsigned p = d & 0xFFu, gi = (d >> 8) & 0x3FFFFFu, pl = d >> 30;
-            unsigned *w = (unsigned *)&words[p];
-            if (pl == 0) atomicAdd(&w[gi & 1u], 256u - VG);              // VG arrivals -> 0, generation + 1
-            else if (pl == 3) atomicAdd(&w[2 + (gi & 1u)], 256u - mk);
+            if ((d >> 30) == 3u) atomicAdd(&words[2 * (d & 0xFFu) + ((d >> 8) & 1u)], 256u - VG); // VG arrivals -> 0, generation + 1
         }
         qn = 0;
     };
@@ -132,62 +130,39 @@ __global__ __launch_bounds__(PL_T) void k_plane_scatter(const Plan P, const Plan
         unsigned seq = 0;
         if (on) {
             const i64 k = (i64)key;
-            if (k != RFX_NULL_I64_D) {
-                mn = k < mn ? k : mn;
-                mx = k > mx ? k : mx;
-            }
+            mn = k < mn ? k : mn;
+            mx = k > mx ? k : mx;
             seq = atomicAdd(&tail[p], 1u);
             if (seq >= A.c0) PL_ST(&L.dead, 1u); // the region is full (skew / selectivity the sample did not show): the caller falls back
         }
-        sel += __popcll(__ballot(on)); // wave-uniform counters
-        nulls += __popcll(__ballot(on && (i64)key == RFX_NULL_I64_D));
-        const unsigned g = seq >> VGL, G = seq >> msh;
-        unsigned *w = (unsigned *)&words[p];
+        const unsigned g = seq >> VGL;
+        unsigned *w = &words[2 * p + (g & 1u)];
         bool todo = on && seq < A.c0;
         // A record goes into its ring place once the group that used the place before has left (generation check); almost always at
         // once.  When not, the lanes that CAN write do so first (the awaited group may be waiting for exactly them), the wave stores what
         // it owes (nobody may wait while holding completed groups), and only then polls.
         for (unsigned it = 0;; it++) {
             bool ready = false;
-            if (todo) {
-                unsigned vw, mw;
-                if (it == 0) {
-                    const uint4 q = words[p];
-                    vw = (g & 1u) ? q.y : q.x;
-                    mw = (G & 1u) ? q.w : q.z;
-                } else {
-                    vw = PL_LD(&w[g & 1u]);
-                    mw = PL_LD(&w[2 + (G & 1u)]);
-                }
-                ready = (vw >> 8) == (g >> 1) && (mw >> 8) == (G >> 1);
-            }
-            bool comp = false, mcomp = false;
+            if (todo) ready = (PL_LD(w) >> 8) == (g >> 1);
+            bool comp = false;
             if (ready) {
+                const unsigned at = p * RING + (seq & (RING - 1u));
 #pragma unroll
-                for (int j = 0; j < NV; j++) vring[((size_t)j * PARTS + p) * RING + (seq & (RING - 1u))] = val[j];
-                const unsigned kh = (unsigned)(key >> PBITS);
-                if (rows) ((unsigned *)(mring + p * (2 * GB)))[seq & (4u * VG - 1u)] = (kh & ((1u << PL_SLOT_BITS) - 1u)) | (delta << PL_SLOT_BITS);
-                else ((unsigned short *)(mring + p * (2 * GB)))[seq & (8u * VG - 1u)] = (unsigned short)kh;
+                for (int j = 0; j < NV; j++) vring[(size_t)j * PARTS * RING + at] = val[j];
+                mring[at] = ((unsigned)(key >> PBITS) & ((1u << PL_SLOT_BITS) - 1u)) | (delta << PL_SLOT_BITS);
                 asm volatile("" ::: "memory"); // the record is in the ring before it is counted (LDS executes a wave's operations in order)
-                const unsigned old = atomicAdd(&w[g & 1u], 1u);
-                if ((old & 0xFFu) == VG - 1u) {
-                    comp = true;
-                    const unsigned oldm = atomicAdd(&w[2 + (G & 1u)], 1u);
-                    mcomp = (oldm & 0xFFu) == mk - 1u;
-                }
+                comp = (atomicAdd(w, 1u) & 0xFFu) == VG - 1u;
                 todo = false;
             }
             const u64 cb = __ballot(comp);
             if (cb) {
                 if (comp) {
-                    const unsigned at = (unsigned)qn + (unsigned)NV * __builtin_amdgcn_mbcnt_hi((unsigned)(cb >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)cb, 0u));
+                    const unsigned at = (unsigned)qn + (unsigned)(NV + 1) * __builtin_amdgcn_mbcnt_hi((unsigned)(cb >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)cb, 0u));
 #pragma unroll
                     for (int j = 0; j < NV; j++) myq[at + j] = p | (g << 8) | ((unsigned)j << 30);
+                    myq[at + NV] = p | (g << 8) | (3u << 30); // the meta plane last: its descriptor also releases the ring half
                 }
-                qn += NV * __popcll(cb);
-                const u64 mb = __ballot(mcomp);
-                if (mcomp) myq[(unsigned)qn + __builtin_amdgcn_mbcnt_hi((unsigned)(mb >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mb, 0u))] = p | (G << 8) | (3u << 30);
-                qn += __popcll(mb);
+                qn += (NV + 1) * __popcll(cb);
             }
             if (!__any(todo)) break;
             flush_queue();
@@ -204,6 +179,7 @@ __global__ __launch_bounds__(PL_T) void k_plane_scatter(const Plan P, const Plan
     auto step = [&](const u64 (&v)[NC][8], const unsigned valid, const i64 sbase) __attribute__((always_inline)) {
         const unsigned dbase = (unsigned)(sbase - r0);
         if constexpr (NP == 0) {
+            nsel += (unsigned)__popc(valid);
 #pragma unroll
             for (int e = 0; e < 8; e++) {
                 u64 val[NV];
@@ -215,6 +191,7 @@ __global__ __launch_bounds__(PL_T) void k_plane_scatter(const Plan P, const Plan
             // Under a filter a lane keeps few of its eight rows (10 %: none 43 %, one 38 %, two 15 %): instead of eight passes over mostly
             // idle lanes, every pass takes each lane's NEXT selected row -- as many passes as the busiest lane has rows (three or four).
             unsigned rem = eval_preds<NC, 8, NP>(S, v, valid);
+            nsel += (unsigned)__popc(rem);
             while (__any(rem != 0u)) {
                 const bool on = rem != 0u;
                 const unsigned e = (unsigned)__builtin_ctz(rem | 0x100u);
@@ -273,48 +250,49 @@ __global__ __launch_bounds__(PL_T) void k_plane_scatter(const Plan P, const Plan
         if (tid == 0) atomicExch(&A.ctl[1], 1u);
         return;
     }
-    // the last, partly filled group of every plane of every partition (the region has room: c0 is a multiple of the largest group; the
-    // record count ends before the padding)
+    // the last, partly filled group of every plane of every partition (the region has room: c0 is a multiple of the group; the record count
+    // ends before the padding)
     for (int i = tid; i < PARTS * (NV + 1) * (int)LPD; i += PL_T) {
         const unsigned sub = (unsigned)i & (LPD - 1u), p = ((unsigned)i / LPD) & (unsigned)(PARTS - 1), pl = ((unsigned)i / LPD) >> PBITS;
         const unsigned t = tail[p];
+        if (!(t & (VG - 1u))) continue;
+        const unsigned gi = t >> VGL;
         if (pl < (unsigned)NV) {
-            if (t & (VG - 1u)) {
-                const unsigned gi = t >> VGL;
-                const pl_v2 x = *(const pl_v2 *)(vring + ((size_t)pl * PARTS + p) * RING + (gi & 1u) * VG + sub * 2);
-                u64 *dst = (NV == 1 ? A.vals[0] : (pl == 0 ? A.vals[0] : (pl == 1 ? A.vals[1] : A.vals[2])));
-                *(pl_v2 *)(dst + region + (u64)p * A.c0 + (u64)gi * VG + sub * 2) = x;
-            }
-        } else if (t & ((1u << msh) - 1u)) {
-            const unsigned gi = t >> msh;
-            const pl_v2 x = *(const pl_v2 *)(mring + p * (2 * GB) + (gi & 1u) * GB + sub * 16);
-            *(pl_v2 *)((char *)A.meta + (region + (u64)p * A.c0) * 4 + (u64)gi * GB + sub * 16) = x;
+            const pl_v2 x = *(const pl_v2 *)(vring + ((size_t)pl * PARTS + p) * RING + (gi & 1u) * VG + sub * 2);
+            u64 *dst = (NV == 1 ? A.vals[0] : (pl == 0 ? A.vals[0] : (pl == 1 ? A.vals[1] : A.vals[2])));
+            *(pl_v2 *)(dst + region + (u64)p * A.c0 + (u64)gi * VG + sub * 2) = x;
+        } else if (sub < LPD / 2) {
+            const pl_v2 x = *(const pl_v2 *)(mring + (size_t)p * RING + (gi & 1u) * VG + sub * 4);
+            *(pl_v2 *)(A.meta + region + (u64)p * A.c0 + (u64)gi * VG + sub * 4) = x;
         }
     }
     for (int i = tid; i < PARTS; i += PL_T) A.cnt[((size_t)blockIdx.x << PBITS) + i] = tail[i];
+    i64 sel = (i64)nsel;
     for (int s2 = 32; s2 >= 1; s2 >>= 1) {
         const i64 omn = (i64)rfx_shfl_xor_u64((u64)mn, s2), omx = (i64)rfx_shfl_xor_u64((u64)mx, s2);
         mn = omn < mn ? omn : mn;
         mx = omx > mx ? omx : mx;
+        sel += (i64)rfx_shfl_xor_u64((u64)sel, s2);
     }
-    if (lane == 0) L.red[wv] = ScopePart{mn, mx, sel, nulls};
+    if (lane == 0) {
+        L.red[0][wv] = mn;
+        L.red[1][wv] = mx;
+        L.red[2][wv] = sel;
+    }
     __syncthreads();
     if (tid == 0) {
-        ScopePart r = L.red[0];
         for (int w2 = 1; w2 < PL_WAVES; w2++) {
-            r.mn = L.red[w2].mn < r.mn ? L.red[w2].mn : r.mn;
-            r.mx = L.red[w2].mx > r.mx ? L.red[w2].mx : r.mx;
-            r.sel += L.red[w2].sel;
-            r.nulls += L.red[w2].nulls;
+            mn = L.red[0][w2] < mn ? L.red[0][w2] : mn;
+            mx = L.red[1][w2] > mx ? L.red[1][w2] : mx;
+            sel += L.red[2][w2];
         }
-        // the whole launch's scope, folded with four atomics per block into cells that start at zero: the minimum as the maximum of the
+        // the whole launch's scope, folded with three atomics per block into cells that start at zero: the minimum as the maximum of the
         // inverted order-preserving image (0 = +inf), the maximum as the maximum of the image (0 = INT64_MIN = "no key")
         unsigned long long *g = (unsigned long long *)A.ctl + 8;
-        if (r.sel > 0) {
-            atomicMax(&g[0], ~((unsigned long long)r.mn ^ 0x8000000000000000ULL));
-            atomicMax(&g[1], (unsigned long long)r.mx ^ 0x8000000000000000ULL);
-            atomicAdd(&g[2], (unsigned long long)r.sel);
-            if (r.nulls) atomicAdd(&g[3], (unsigned long long)r.nulls);
+        if (sel > 0) {
+            atomicMax(&g[0], ~((unsigned long long)mn ^ 0x8000000000000000ULL));
+            atomicMax(&g[1], (unsigned long long)mx ^ 0x8000000000000000ULL);
+            atomicAdd(&g[2], (unsigned long long)sel);
         }
     }
 }
@@ -324,23 +302,20 @@ struct PlaneAggArgs {
     i64 kmin, range;
     i64 local; // table cells per partition: slots congruent to one residue mod 2^pbits
     int split; // workgroups per partition
-    int nblk, nrowblk, pbits;
-    int plane[PL_MAX_NV];      // scatter plane behind loaded plane j
-    int agg_pl[RFX_MAX_AGGS];  // loaded plane of aggregate a (-1: none: COUNT / FIRST)
+    int nblk, pbits;
+    int agg_pl[RFX_MAX_AGGS]; // loaded plane of aggregate a (-1: none: COUNT / FIRST)
     i64 block_rows;
     unsigned c0;
-    const u64 *vals[PL_MAX_NV];
+    const u64 *vals[PL_MAX_NV]; // the planes this pass loads
     const unsigned *meta;
     const unsigned *cnt;
     u64 *first;
     u64 *acc[RFX_MAX_AGGS];
     u64 *cntt[RFX_MAX_AGGS];
-    int dbg; // timing experiments only (RFX_PLANE_DBG): 1 = FAST kernel without its accumulator atomics
 };
 #define PL_FIRST_NONE 0xFFFFFFFFu
-#define PL_FIRST_TOUCHED 0xFFFFFFFEu /* LDS; in the global table: RFX_INF_I64_D - 1 */
 
-// LDS: [nagg accumulators u64 x local][first u32 x local][counts u32 x local each]
+// LDS: [nagg accumulators u64 x local][first u32 x local][counts u32 x local each][count windows 64 x u32 per wave]
 // FAST: exactly one aggregate, a plain f64 sum (C3 / C3w): first row + one ds_add_f64 per record, no per-record dispatch on the aggregate kinds
 template <int THREADS, int NVL, bool FAST>
 __global__ __launch_bounds__(THREADS) void k_plane_aggregate(const Plan P, const PlaneAggArgs A) {
@@ -374,18 +349,14 @@ __global__ __launch_bounds__(THREADS) void k_plane_aggregate(const Plan P, const
     }
     __syncthreads();
     const unsigned shift = (unsigned)(((i64)p - A.kmin) >> A.pbits); // slot = (key - kmin) >> pbits = (key >> pbits) + floor((p - kmin) / 2^pbits), modular
-    auto apply = [&](unsigned mm, bool rows, i64 rbase, const u64 (&x)[NVL]) __attribute__((always_inline)) {
-        const unsigned mask = rows ? ((1u << PL_SLOT_BITS) - 1u) : 0xFFFFu;
+    auto apply = [&](unsigned mm, i64 rbase, const u64 (&x)[NVL]) __attribute__((always_inline)) {
+        const unsigned mask = (1u << PL_SLOT_BITS) - 1u;
         const unsigned slot = ((mm & mask) + shift) & mask;
         if ((i64)slot >= local) return; // a key outside the scope the tables were sized for: not ours
-        if (rows) {
-            const unsigned row = (unsigned)(rbase + (i64)(mm >> PL_SLOT_BITS));
-            if (row < first[slot]) atomicMin(&first[slot], row);
-        } else if (first[slot] == PL_FIRST_NONE) {
-            atomicMin(&first[slot], PL_FIRST_TOUCHED); // reached by a record without a row: some block with rows must supply the first row
-        }
+        const unsigned row = (unsigned)(rbase + (i64)(mm >> PL_SLOT_BITS));
+        if (row < first[slot]) atomicMin(&first[slot], row);
         if constexpr (FAST) {
-            if (!(A.dbg & 1)) unsafeAtomicAdd((double *)&accs[slot], rfx_as_f64(x[0]));
+            unsafeAtomicAdd((double *)&accs[slot], rfx_as_f64(x[0]));
             return;
         }
 #pragma unroll
@@ -398,15 +369,15 @@ __global__ __launch_bounds__(THREADS) void k_plane_aggregate(const Plan P, const
             group_apply(&accs[(i64)a * local + slot], cnt_of[a] >= 0 ? &cnts[(i64)cnt_of[a] * local + slot] : (unsigned *)0, kind[a], f64[a], xv, skip[a]);
         }
     };
-    // Every WAVE streams its own regions (blocks q, q + Q, ... of this partition): a region holds a few hundred to a thousand records,
-    // a 64-lane wave keeps its lanes busy on that where a whole workgroup would not.  One "batch" = up to two record pairs per lane
-    // (256 records) of one region; the next batch's loads are issued before this one is applied.
+    // Every WAVE streams its own regions (blocks q, q + Q, ... of this partition): a region holds a few hundred to a few thousand
+    // records, a 64-lane wave keeps its lanes busy on that where a whole workgroup would not.  One "batch" = up to two record pairs per
+    // lane (256 records) of one region; the next batch's loads are issued before this one is applied.
     const int lane = tid & 63;
     constexpr int NW = THREADS / 64;
     const int Q = A.split * NW;
     struct Batch {
         pl_v2 val[NVL][2];
-        u64 m[2];
+        pl_m2 m[2];
         unsigned n, i0;
         int b;
     };
@@ -418,21 +389,16 @@ __global__ __launch_bounds__(THREADS) void k_plane_aggregate(const Plan P, const
         B.i0 = live ? i0 : 0u;
         B.n = live ? n : 0u;
         const u64 base = (((u64)B.b << A.pbits) + (u64)p) * A.c0;
-        const bool rows = B.b < A.nrowblk;
 #pragma unroll
         for (int k = 0; k < 2; k++) {
             unsigned i = B.i0 + ((unsigned)k * 64u + (unsigned)lane) * 2u;
             i = i < A.c0 - 2u ? i : A.c0 - 2u;
 #pragma unroll
             for (int j = 0; j < NVL; j++) B.val[j][k] = __builtin_nontemporal_load((const pl_v2 *)(A.vals[j] + base + i));
-            // one 8-byte load in either form (two 4-byte entries, or two 2-byte entries and what follows them): two alternative loads
-            // into the same registers would be issued both, with a vmcnt(0) between them
-            const pl_m2 t = __builtin_nontemporal_load((const pl_m2 *)((const char *)(A.meta + base) + ((size_t)i << (rows ? 2 : 1))));
-            B.m[k] = (u64)t.x | ((u64)t.y << 32);
+            B.m[k] = __builtin_nontemporal_load((const pl_m2 *)(A.meta + base + i));
         }
     };
     auto consume = [&](const Batch &B) __attribute__((always_inline)) {
-        const bool rows = B.b < A.nrowblk;
         const i64 rbase = (i64)B.b * A.block_rows;
 #pragma unroll
         for (int k = 0; k < 2; k++) {
@@ -441,11 +407,11 @@ __global__ __launch_bounds__(THREADS) void k_plane_aggregate(const Plan P, const
                 u64 x[NVL];
 #pragma unroll
                 for (int j = 0; j < NVL; j++) x[j] = B.val[j][k].x;
-                apply(rows ? (unsigned)B.m[k] : (unsigned)(B.m[k] & 0xFFFFu), rows, rbase, x);
+                apply(B.m[k].x, rbase, x);
                 if (i + 1 < B.n) {
 #pragma unroll
                     for (int j = 0; j < NVL; j++) x[j] = B.val[j][k].y;
-                    apply(rows ? (unsigned)(B.m[k] >> 32) : (unsigned)((B.m[k] >> 16) & 0xFFFFu), rows, rbase, x);
+                    apply(B.m[k].y, rbase, x);
                 }
             }
         }
@@ -495,7 +461,7 @@ __global__ __launch_bounds__(THREADS) void k_plane_aggregate(const Plan P, const
         if (f == PL_FIRST_NONE) continue;
         const i64 g = (i << A.pbits) | (i64)(((u64)p - (u64)A.kmin) & (u64)((1 << A.pbits) - 1));
         if (g >= A.range) continue;
-        const u64 fr = (f == PL_FIRST_TOUCHED) ? (u64)RFX_INF_I64_D - 1ULL : (u64)P.row0 + (u64)f;
+        const u64 fr = (u64)P.row0 + (u64)f;
         if (fr < A.first[g]) atomicMin((unsigned long long *)&A.first[g], (unsigned long long)fr);
 #pragma unroll
         for (int a = 0; a < RFX_MAX_AGGS; a++) {
@@ -504,13 +470,6 @@ __global__ __launch_bounds__(THREADS) void k_plane_aggregate(const Plan P, const
             group_merge_cell(&A.acc[a][g], hc ? &A.cntt[a][g] : (u64 *)0, kind[a], f64[a], accs[(i64)a * local + i], hc ? (u64)cnts[(i64)cnt_of[a] * local + i] : 0ULL);
         }
     }
-}
-
-// any slot that only row-less records reached?  (its first row lies in a block that carried no rows: the caller runs the query again with rows)
-__global__ __launch_bounds__(RFX_BLOCK) void k_plane_check(const u64 *__restrict__ first, i64 range, unsigned *__restrict__ flag) {
-    bool bad = false;
-    for (i64 i = blockIdx.x * (i64)RFX_BLOCK + threadIdx.x; i < range; i += (i64)gridDim.x * RFX_BLOCK) bad |= first[i] == (u64)RFX_INF_I64_D - 1ULL;
-    if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1u);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -539,6 +498,7 @@ static void plane_layout(rfx_ctx *c, int nblk, int pbits, unsigned c0, int nv, P
 template <int NC, int NP, int NV, int PBITS, int VGL>
 static int launch_plane_scatter_inst(rfx_ctx *c, const Plan &P, const PlaneArgs &A) {
     constexpr size_t lds = pl_lds_bytes<NV, PBITS, VGL>();
+    static_assert(lds <= 160 * 1024, "rings beyond a CU's LDS");
     static bool attr_set = false; // per instantiation
     if (!attr_set) {
         RFX_HIP_CHECK(hipFuncSetAttribute((const void *)k_plane_scatter<NC, NP, NV, PBITS, VGL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -554,20 +514,19 @@ static int launch_plane_scatter_np(rfx_ctx *c, const Plan &P, const PlaneArgs &A
     if (P.npred <= 3) return launch_plane_scatter_inst<NC, 3, NV, PBITS, VGL>(c, P, A);
     return launch_plane_scatter_inst<NC, RFX_MAX_PREDS, NV, PBITS, VGL>(c, P, A);
 }
-template <int NV, int PBITS, int VGL>
-static int launch_plane_scatter_nc(rfx_ctx *c, const Plan &P, const PlaneArgs &A) {
-    switch (P.ncols) {
-        case 2: return launch_plane_scatter_np<2, NV, PBITS, VGL>(c, P, A);
-        case 3: return launch_plane_scatter_np<3, NV, PBITS, VGL>(c, P, A);
-        default: return launch_plane_scatter_np<4, NV, PBITS, VGL>(c, P, A);
-    }
-}
-// one value plane: 256 partitions with 128-byte groups, or -- when the tables of a partition twice as wide still fit a CU's LDS -- 128
-// partitions with 256-byte groups (same LDS for the rings; the scatter's stores are the part's bound: tools/write_probe.hip, 256-byte
-// pieces 5 - 7 % faster than 128-byte ones)
+// One value plane: 128 partitions with 32-record groups (256-byte value lines, 128 bytes of meta) when a partition twice as wide still
+// fits the aggregate pass's LDS, else 256 partitions with 16-record groups.  Two and three planes: 128 partitions, 16-record groups (the
+// rings of every plane share the CU's LDS).
 static int launch_plane_scatter(rfx_ctx *c, const Plan &P, const PlaneArgs &A, int pbits) {
-    if (A.nv != 1 || P.ncols < 2) return RFX_ESTATE;
-    return pbits == 7 ? launch_plane_scatter_nc<1, 7, 5>(c, P, A) : launch_plane_scatter_nc<1, 8, 4>(c, P, A);
+    const int extra = P.ncols - 1 - A.nv; // predicate columns beside the key and the value planes
+    if (extra < 0 || extra > 2) return RFX_ESTATE;
+    if (A.nv == 1) {
+        if (pbits == 7) return extra == 0 ? launch_plane_scatter_np<2, 1, 7, 5>(c, P, A) : (extra == 1 ? launch_plane_scatter_np<3, 1, 7, 5>(c, P, A) : launch_plane_scatter_np<4, 1, 7, 5>(c, P, A));
+        return extra == 0 ? launch_plane_scatter_np<2, 1, 8, 4>(c, P, A) : (extra == 1 ? launch_plane_scatter_np<3, 1, 8, 4>(c, P, A) : launch_plane_scatter_np<4, 1, 8, 4>(c, P, A));
+    }
+    if (pbits != 7 || extra > 1) return RFX_ESTATE;
+    if (A.nv == 2) return extra == 0 ? launch_plane_scatter_np<3, 2, 7, 4>(c, P, A) : launch_plane_scatter_np<4, 2, 7, 4>(c, P, A);
+    return extra == 0 ? launch_plane_scatter_np<4, 3, 7, 4>(c, P, A) : launch_plane_scatter_np<5, 3, 7, 4>(c, P, A);
 }
 
 // the value planes of a plan: distinct plain columns the aggregates read (COUNT / FIRST read none).  -1: expressions / more than PL_MAX_NV
@@ -589,7 +548,7 @@ static int plane_value_cols(const Plan &P, int *vcol, int *agg_plane) {
     }
     return nv;
 }
-// LDS bytes of the aggregate pass for a subset [a0, a1) of the aggregates
+// LDS bytes of the aggregate pass for the aggregates [a0, a1)
 static size_t plane_agg_lds(const Plan &P, int a0, int a1, i64 local) {
     size_t cells8 = 0, cells4 = 1;
     for (int a = a0; a < a1; a++) {
@@ -599,18 +558,20 @@ static size_t plane_agg_lds(const Plan &P, int a0, int a1, i64 local) {
     return (size_t)local * (cells8 * 8 + cells4 * 4) + 16 * 64 * 4 + 64; // tables + the waves' count windows
 }
 #define PL_AGG_LDS_MAX (150 * 1024)
+// can every aggregate be served by SOME pass?  (each alone must fit; passes then take as many as fit)
+static bool plane_agg_fits(const Plan &P, i64 local) {
+    for (int a = 0; a < P.nagg; a++)
+        if (plane_agg_lds(P, a, a + 1, local) > PL_AGG_LDS_MAX) return false;
+    return P.nagg >= 1;
+}
 
 struct PlaneState { // what rfx_plane_scope leaves for rfx_plane_accumulate (lives in the context: ext_p[2])
-    int valid, npred, logic, nblk, nrowblk, pbits, nv;
+    int valid, npred, logic, nblk, pbits, nv;
     unsigned c0;
     const void *key;
     const void *val[PL_MAX_NV];
     i64 nrows;
     u64 sig[RFX_MAX_PREDS][6];
-    // key columns whose groups' first rows turned up late (row-less blocks did not do): rows everywhere from the start next time
-    const void *late_key[8];
-    i64 late_rows[8];
-    int late_n;
 };
 static PlaneState *plane_state(rfx_ctx *c) {
     if (!c->ext_p[2]) c->ext_p[2] = calloc(1, sizeof(PlaneState));
@@ -623,20 +584,6 @@ void rfx_plane_release(rfx_ctx *c) {
     free(c->ext_p[2]);
     c->ext_p[2] = NULL;
 }
-static bool plane_late_keys(rfx_ctx *c, const void *key, i64 nrows) {
-    PlaneState *st = (PlaneState *)c->ext_p[2];
-    if (!st) return false;
-    for (int i = 0; i < 8 && i < st->late_n; i++)
-        if (st->late_key[i] == key && st->late_rows[i] == nrows) return true;
-    return false;
-}
-static void plane_late_keys_add(rfx_ctx *c, const void *key, i64 nrows) {
-    PlaneState *st = (PlaneState *)c->ext_p[2];
-    if (!st || plane_late_keys(c, key, nrows)) return;
-    st->late_key[st->late_n % 8] = key;
-    st->late_rows[st->late_n % 8] = nrows;
-    st->late_n++;
-}
 static void plane_pred_sig(const Plan &P, u64 (*sig)[6]) {
     for (int i = 0; i < P.npred; i++) {
         const PlanPred &q = P.preds[i];
@@ -648,15 +595,44 @@ static void plane_pred_sig(const Plan &P, u64 (*sig)[6]) {
         sig[i][5] = 0;
     }
 }
-// One scatter launch over the whole input (layout, column order, launch, read-back of the control block).  RFX_ESTATE: gave up.
-static int plane_scatter_run(rfx_ctx *c, const Plan &P, int key_idx, const int *vcol, int nv, int pbits, unsigned c0, int nblk, int nrowblk, unsigned **hctl_out) {
+
+// Scope pass that also partitions into planes.  P: the plan as built (key at key_idx); est_range / frac: the sample's guesses.
+// RFX_ESTATE: not applicable / gave up (nothing is left behind), the caller goes on with the chunk kernels or the plain scope pass.
+int rfx_plane_scope(rfx_ctx *c, const Plan &P, int key_idx, const void *d_key, int npred, int logic, unsigned long long est_range, double frac,
+                    i64 *kmin, i64 *kmax, i64 *seen) {
+    PlaneState *st = plane_state(c);
+    if (!st) return RFX_ESTATE;
+    st->valid = 0;
+    if (c->flags & RFX_TUNE_NO_PLANE) return RFX_ESTATE;
+    int vcol[PL_MAX_NV], agg_plane[RFX_MAX_AGGS];
+    const int nv = plane_value_cols(P, vcol, agg_plane);
+    if (nv < 1 || P.nx > 0) return RFX_ESTATE;
+    // 128 partitions when a partition twice as wide still fits the aggregate pass's LDS with a sixteenth to spare (the sampled range can
+    // only be too small; a range that turns out wider costs the scatter and falls back), else -- one plane only -- 256
+    int pbits = 7;
+    {
+        static const char *force = getenv("RFX_PLANE_PBITS"); // (A/B)
+        const i64 l7 = (i64)((est_range + 127) >> 7);
+        if (l7 + l7 / 16 > (1 << PL_SLOT_BITS) || !plane_agg_fits(P, l7 + l7 / 16)) pbits = 8;
+        if (force && nv == 1) pbits = atoi(force) == 7 ? 7 : 8;
+    }
+    if (pbits == 8 && nv > 1) return RFX_ESTATE;
+    const i64 est_local = (i64)((est_range + (1ULL << pbits) - 1) >> pbits);
+    if (est_local > (1 << PL_SLOT_BITS) || !plane_agg_fits(P, est_local)) return RFX_ESTATE;
+    const i64 nrows = P.nrows;
+    const i64 nblk64 = (nrows + PL_BLOCK_ROWS - 1) / PL_BLOCK_ROWS;
+    if (nblk64 > (1 << 20) || nrows >= 0xFFFFFFF0LL) return RFX_ESTATE;
+    // region size: the expected share of a partition plus room for its spread (uniform keys: sigma = sqrt(share)), whole groups
+    double share = (double)PL_BLOCK_ROWS / (double)(1 << pbits);
+    if (npred > 0) share *= (frac * 1.3 + 0.01 < 1.0 ? frac * 1.3 + 0.01 : 1.0);
+    unsigned c0 = (unsigned)(share * 1.25 + 160.0);
+    c0 = (c0 + 127u) & ~127u;
     PlaneArgs A;
     memset(&A, 0, sizeof(A));
     size_t need = 0;
-    plane_layout(c, nblk, pbits, c0, nv, &A, &need);
+    plane_layout(c, (int)nblk64, pbits, c0, nv, &A, &need);
     if (rfx_chunk_reserve(c, need) != RFX_OK) return RFX_ESTATE;
-    plane_layout(c, nblk, pbits, c0, nv, &A, NULL);
-    A.nrowblk = nrowblk;
+    plane_layout(c, (int)nblk64, pbits, c0, nv, &A, NULL);
     A.block_rows = PL_BLOCK_ROWS;
     // key -> column 0, value plane j -> column 1 + j (the kernel reads them without a run-time select; a value column that IS the key
     // column is listed a second time), the predicates' other columns behind them
@@ -675,7 +651,7 @@ static int plane_scatter_run(rfx_ctx *c, const Plan &P, int key_idx, const int *
                 inv[i] = n2;
                 perm[n2++] = i;
             }
-        if (n2 > 4) return RFX_ESTATE;
+        if (n2 > 1 + nv + 2 || n2 > RFX_MAX_COLS) return RFX_ESTATE;
         Pc.ncols = n2;
         for (int i = 0; i < n2; i++) Pc.cols[i] = P.cols[perm[i]];
         for (int i = 0; i < P.npred; i++) {
@@ -691,73 +667,18 @@ static int plane_scatter_run(rfx_ctx *c, const Plan &P, int key_idx, const int *
     if (rc != RFX_OK) return rc;
     RFX_HIP_CHECK(hipGetLastError());
     unsigned *hctl = (unsigned *)c->h_pin;
-    *hctl_out = hctl;
     RFX_HIP_CHECK(hipMemcpyAsync(hctl, A.ctl, 256, hipMemcpyDeviceToHost, c->stream));
     RFX_HIP_CHECK(hipStreamSynchronize(c->stream));
     if (hctl[1]) { // a region overflowed (skew or selectivity the sample did not show): the chunk kernels take over
         c->ext_i[3 + RFX_STAT_PLANE_FALLBACK]++;
         return RFX_ESTATE;
     }
-    return RFX_OK;
-}
-
-// Scope pass that also partitions into planes.  P: the plan as built (key at key_idx); est_range / frac: the sample's guesses.
-// RFX_ESTATE: not applicable / gave up (nothing is left behind), the caller goes on with the chunk kernels.
-int rfx_plane_scope(rfx_ctx *c, const Plan &P, int key_idx, const void *d_key, int npred, int logic, unsigned long long est_range, double frac,
-                    i64 *kmin, i64 *kmax, i64 *seen) {
-    PlaneState *st = plane_state(c);
-    if (!st) return RFX_ESTATE;
-    st->valid = 0;
-    if (c->flags & RFX_TUNE_NO_PLANE) return RFX_ESTATE;
-    int vcol[PL_MAX_NV], agg_plane[RFX_MAX_AGGS];
-    const int nv = plane_value_cols(P, vcol, agg_plane);
-    if (nv != 1) return RFX_ESTATE; // (two and three planes: 128 partitions, not built yet)
-    // 128 partitions (256-byte groups) when a partition twice as wide still fits the aggregate pass's LDS with a quarter to spare (the
-    // sampled range can only be too small), else 256
-    int pbits = 7;
-    {
-        static const char *force = getenv("RFX_PLANE_PBITS"); // (A/B)
-        const i64 l7 = (i64)((est_range + 127) >> 7);
-        if (l7 + l7 / 4 > (1 << PL_SLOT_BITS) || plane_agg_lds(P, 0, P.nagg, l7 + l7 / 4) > PL_AGG_LDS_MAX) pbits = 8;
-        if (force) pbits = atoi(force) == 7 ? 7 : 8;
-    }
-    const i64 est_local = (i64)((est_range + (1ULL << pbits) - 1) >> pbits);
-    if (est_local > (1 << PL_SLOT_BITS)) return RFX_ESTATE;
-    if (plane_agg_lds(P, 0, P.nagg, est_local) > PL_AGG_LDS_MAX) return RFX_ESTATE;
-    const i64 nrows = P.nrows;
-    const i64 block_rows = PL_BLOCK_ROWS;
-    const i64 nblk64 = (nrows + block_rows - 1) / block_rows;
-    if (nblk64 > (1 << 20) || nrows >= 0xFFFFFFF0LL) return RFX_ESTATE;
-    // region size: the expected share of a partition plus room for its spread (uniform keys: sigma = sqrt(share)), whole 64-record lines
-    double share = (double)block_rows / (double)(1 << pbits);
-    if (npred > 0) share *= (frac * 1.3 + 0.01 < 1.0 ? frac * 1.3 + 0.01 : 1.0);
-    unsigned c0 = (unsigned)(share * 1.25 + 160.0);
-    c0 = (c0 + 127u) & ~127u;
-    // Row ids only where `first` can still change: once every slot of the range has been met, a later row is never a group's first one,
-    // and its record needs no row (2-byte meta instead of 4).  With spread keys every slot turns up within a few times the range's rows:
-    // the first blocks -- 32 x range selected rows -- carry rows, the rest do not.  The aggregate pass marks slots that only row-less
-    // records reached; any such slot left at the end (keys that first appear late: sorted or drifting data) sends the query through
-    // again with rows everywhere (rfx_plane_accumulate), and the key column is remembered so that the next query starts that way.
-    i64 nrowblk = nblk64;
-    {
-        static const int no_plain = getenv("RFX_PLANE_ALL_ROWS") != NULL; // (A/B)
-        const double per_block = (double)block_rows * (npred > 0 ? (frac > 0.001 ? frac : 0.001) : 1.0);
-        const double want = 32.0 * (double)est_range / per_block + 2.0;
-        if (!no_plain && !plane_late_keys(c, d_key, nrows) && want < (double)nblk64 * 0.5) nrowblk = (i64)want;
-    }
-    unsigned *hctl = NULL;
-    int rc = plane_scatter_run(c, P, key_idx, vcol, nv, pbits, c0, (int)nblk64, (int)nrowblk, &hctl);
-    if (rc != RFX_OK) return rc;
     const u64 *hs = (const u64 *)hctl + 8;
-    i64 nulls = (i64)hs[3];
     *seen = (i64)hs[2];
     *kmin = (i64)(~hs[0] ^ 0x8000000000000000ULL);
     *kmax = (i64)(hs[1] ^ 0x8000000000000000ULL);
-    if (nulls > 0) { // a null key is the value INT64_MIN for index_scope_i64
-        *kmin = RFX_NULL_I64_D;
-        if (nulls == *seen) *kmax = RFX_NULL_I64_D;
-    }
-    if (*seen == 0 || nulls > 0) return RFX_OK;
+    if (*seen > 0 && *kmin == RFX_NULL_I64_D) return RFX_ESTATE; // a null key among the selected rows: the exact scope pass counts them
+    if (*seen == 0) return RFX_OK;
     st->valid = 1;
     st->key = d_key;
     for (int j = 0; j < nv; j++) st->val[j] = (const void *)P.cols[vcol[j]];
@@ -765,7 +686,6 @@ int rfx_plane_scope(rfx_ctx *c, const Plan &P, int key_idx, const void *d_key, i
     st->npred = npred;
     st->logic = logic;
     st->nblk = (int)nblk64;
-    st->nrowblk = (int)nrowblk;
     st->pbits = pbits;
     st->nv = nv;
     st->c0 = c0;
@@ -773,15 +693,21 @@ int rfx_plane_scope(rfx_ctx *c, const Plan &P, int key_idx, const void *d_key, i
     return RFX_OK;
 }
 
-template <int THREADS, bool FAST>
-static int launch_plane_aggregate(rfx_ctx *c, const Plan &P, const PlaneAggArgs &G, int grid, size_t lds, int lds_max) {
+template <int THREADS, int NVL, bool FAST>
+static int launch_plane_aggregate_inst(rfx_ctx *c, const Plan &P, const PlaneAggArgs &G, int grid, size_t lds, int lds_max) {
     static bool attr_set = false; // per instantiation
     if (!attr_set) {
-        RFX_HIP_CHECK(hipFuncSetAttribute((const void *)k_plane_aggregate<THREADS, 1, FAST>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
+        RFX_HIP_CHECK(hipFuncSetAttribute((const void *)k_plane_aggregate<THREADS, NVL, FAST>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_plane_aggregate<THREADS, 1, FAST>), dim3(grid), dim3(THREADS), lds, c->stream, P, G);
+    hipLaunchKernelGGL((k_plane_aggregate<THREADS, NVL, FAST>), dim3(grid), dim3(THREADS), lds, c->stream, P, G);
     return RFX_OK;
+}
+template <int THREADS>
+static int launch_plane_aggregate(rfx_ctx *c, const Plan &P, const PlaneAggArgs &G, int nvl, bool fast, int grid, size_t lds, int lds_max) {
+    if (nvl <= 1) return fast ? launch_plane_aggregate_inst<THREADS, 1, true>(c, P, G, grid, lds, lds_max) : launch_plane_aggregate_inst<THREADS, 1, false>(c, P, G, grid, lds, lds_max);
+    if (nvl == 2) return launch_plane_aggregate_inst<THREADS, 2, false>(c, P, G, grid, lds, lds_max);
+    return launch_plane_aggregate_inst<THREADS, 3, false>(c, P, G, grid, lds, lds_max);
 }
 
 // Pass 2 over the planes rfx_plane_scope left, if they are the planes of exactly this plan.  RFX_ESTATE: not so.
@@ -801,87 +727,74 @@ int rfx_plane_accumulate(rfx_ctx *c, const Plan &P, int key_idx, const rfx_group
     st->valid = 0; // consumed (or stale) either way
     if (!ok || t->range <= (1 << st->pbits)) return RFX_ESTATE;
     const i64 local = (t->range + (1 << st->pbits) - 1) >> st->pbits;
-    if (local > (1 << PL_SLOT_BITS)) return RFX_ESTATE;
-    const size_t lds = plane_agg_lds(P, 0, P.nagg, local);
-    if (lds > PL_AGG_LDS_MAX) return RFX_ESTATE;
+    if (local > (1 << PL_SLOT_BITS) || !plane_agg_fits(P, local)) return RFX_ESTATE;
     PlaneArgs A;
     memset(&A, 0, sizeof(A));
     plane_layout(c, st->nblk, st->pbits, st->c0, st->nv, &A, NULL);
-    PlaneAggArgs G;
-    memset(&G, 0, sizeof(G));
-    G.kmin = t->kmin;
-    G.range = t->range;
-    G.local = local;
-    G.nblk = st->nblk;
-    G.nrowblk = st->nrowblk;
-    G.pbits = st->pbits;
-    G.block_rows = PL_BLOCK_ROWS;
-    G.c0 = st->c0;
-    for (int j = 0; j < nv; j++) {
-        G.plane[j] = j;
-        G.vals[j] = A.vals[j];
-    }
-    for (int a = 0; a < RFX_MAX_AGGS; a++) G.agg_pl[a] = a < P.nagg ? agg_plane[a] : -1;
-    G.meta = A.meta;
-    G.cnt = A.cnt;
-    G.first = (u64 *)t->d_first;
-    for (int a = 0; a < t->nagg; a++) {
-        G.acc[a] = (u64 *)t->d_acc[a];
-        G.cntt[a] = (u64 *)t->d_cnt[a];
-    }
     const int nparts = 1 << st->pbits;
-    {
-        static const char *dbg = getenv("RFX_PLANE_DBG");
-        G.dbg = dbg ? atoi(dbg) : 0;
-    }
-    const bool fast = P.nagg == 1 && P.aggs[0].kind == RFX_AGG_SUM && P.aggs[0].f64 && !P.aggs[0].skipnull && agg_plane[0] == 0;
-    for (int attempt = 0;; attempt++) {
-        int rc = RFX_OK;
+    RFX_KERNEL_BEGIN(c);
+    int rc = RFX_OK;
+    // one pass per run of aggregates whose tables fit the LDS together
+    for (int a0 = 0; a0 < P.nagg && rc == RFX_OK;) {
+        int a1 = a0 + 1;
+        while (a1 < P.nagg && plane_agg_lds(P, a0, a1 + 1, local) <= PL_AGG_LDS_MAX) a1++;
+        Plan Ps = P;
+        Ps.nagg = a1 - a0;
+        PlaneAggArgs G;
+        memset(&G, 0, sizeof(G));
+        G.kmin = t->kmin;
+        G.range = t->range;
+        G.local = local;
+        G.nblk = st->nblk;
+        G.pbits = st->pbits;
+        G.block_rows = PL_BLOCK_ROWS;
+        G.c0 = st->c0;
+        G.meta = A.meta;
+        G.cnt = A.cnt;
+        G.first = (u64 *)t->d_first;
+        int used[PL_MAX_NV] = {-1, -1, -1}, nvl = 0; // scatter planes this pass loads
+        for (int a = a0; a < a1; a++) {
+            Ps.aggs[a - a0] = P.aggs[a];
+            G.acc[a - a0] = (u64 *)t->d_acc[a];
+            G.cntt[a - a0] = (u64 *)t->d_cnt[a];
+            G.agg_pl[a - a0] = -1;
+            if (agg_plane[a] < 0) continue;
+            int j = 0;
+            for (; j < nvl; j++)
+                if (used[j] == agg_plane[a]) break;
+            if (j == nvl) {
+                used[nvl] = agg_plane[a];
+                G.vals[nvl] = A.vals[agg_plane[a]];
+                nvl++;
+            }
+            G.agg_pl[a - a0] = j;
+        }
+        for (int a = a1 - a0; a < RFX_MAX_AGGS; a++) {
+            Ps.aggs[a].kind = -1;
+            G.agg_pl[a] = -1;
+        }
+        if (nvl == 0) { // COUNT / FIRST only: any plane keeps the loads uniform
+            G.vals[0] = A.vals[0];
+            nvl = 1;
+        }
+        const size_t lds = plane_agg_lds(P, a0, a1, local);
+        const bool fast = Ps.nagg == 1 && Ps.aggs[0].kind == RFX_AGG_SUM && Ps.aggs[0].f64 && !Ps.aggs[0].skipnull && G.agg_pl[0] == 0;
         c->ext_i[3 + RFX_STAT_PLANE_AGGREGATE]++;
-        RFX_KERNEL_BEGIN(c);
         if (lds > 52 * 1024) {
             // big tables: one 1024-lane workgroup per CU
             G.split = (c->num_cus + nparts - 1) / nparts;
             if (G.split < 1) G.split = 1;
-            if (fast) rc = launch_plane_aggregate<1024, true>(c, P, G, nparts * G.split, lds, 160 * 1024);
-            else rc = launch_plane_aggregate<1024, false>(c, P, G, nparts * G.split, lds, 160 * 1024);
+            rc = launch_plane_aggregate<1024>(c, Ps, G, nvl, fast, nparts * G.split, lds, 160 * 1024);
         } else {
-            const int per_cu = (int)((156 * 1024) / (lds > 1 ? lds : 1)) < 4 ? (int)((156 * 1024) / lds) : 4; // 512-lane workgroups a CU can hold: 3 at 51 KB
+            const int per_cu = (int)((156 * 1024) / lds) < 4 ? (int)((156 * 1024) / lds) : 4; // 512-lane workgroups a CU can hold: 3 at 51 KB
             G.split = (per_cu * c->num_cus + nparts - 1) / nparts;
             if (G.split < 1) G.split = 1;
-            if (fast) rc = launch_plane_aggregate<512, true>(c, P, G, nparts * G.split, lds, 64 * 1024);
-            else rc = launch_plane_aggregate<512, false>(c, P, G, nparts * G.split, lds, 64 * 1024);
+            rc = launch_plane_aggregate<512>(c, Ps, G, nvl, fast, nparts * G.split, lds, 64 * 1024);
         }
-        RFX_KERNEL_END(c);
-        if (rc != RFX_OK) return rc;
-        RFX_HIP_CHECK(hipGetLastError());
-        if (G.nrowblk >= G.nblk) return RFX_OK; // every record carried its row: nothing to verify
-        // did every slot get its first row from a block with rows?
-        int cgrid = (int)((t->range + RFX_BLOCK - 1) / RFX_BLOCK);
-        if (cgrid > c->num_cus * 4) cgrid = c->num_cus * 4;
-        hipLaunchKernelGGL(k_plane_check, dim3(cgrid), dim3(RFX_BLOCK), 0, c->stream, (const u64 *)t->d_first, (i64)t->range, A.ctl + 2);
-        RFX_HIP_CHECK(hipGetLastError());
-        unsigned *hflag = (unsigned *)c->h_pin;
-        RFX_HIP_CHECK(hipMemcpyAsync(hflag, A.ctl + 2, 4, hipMemcpyDeviceToHost, c->stream));
-        RFX_HIP_CHECK(hipStreamSynchronize(c->stream));
-        if (!hflag[0]) return RFX_OK;
-        // Late keys: some group's first row lies in a block that carried no rows.  Start over with rows in every block: tables back to
-        // their initial state, the scatter again, the aggregate again; and remember the key column.
-        if (attempt > 0) {
-            rfx_set_error("plane partitioning: a slot without a first row after the pass with rows everywhere");
-            return RFX_EHIP;
-        }
-        c->ext_i[0]++; // RFX_STAT_PLANE_REDO
-        plane_late_keys_add(c, (const void *)P.cols[key_idx], P.nrows);
-        rc = rfx_fill_u64(c, t->d_first, t->range, (u64)RFX_INF_I64_D);
-        for (int a2 = 0; rc == RFX_OK && a2 < t->nagg; a2++) {
-            rc = rfx_fill_u64(c, t->d_acc[a2], t->range, acc_identity(P.aggs[a2].kind, P.aggs[a2].f64));
-            if (rc == RFX_OK && t->d_cnt[a2]) rc = rfx_fill_u64(c, t->d_cnt[a2], t->range, 0ULL);
-        }
-        if (rc != RFX_OK) return rc;
-        unsigned *hctl = NULL;
-        rc = plane_scatter_run(c, P, key_idx, vcol, nv, st->pbits, st->c0, st->nblk, st->nblk, &hctl);
-        if (rc != RFX_OK) return rc; // (RFX_ESTATE: the tables are clean again, the caller's other paths may run)
-        G.nrowblk = G.nblk;
+        a0 = a1;
     }
+    RFX_KERNEL_END(c);
+    if (rc != RFX_OK) return rc;
+    RFX_HIP_CHECK(hipGetLastError());
+    return RFX_OK;
 }

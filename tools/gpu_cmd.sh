@@ -1,5 +1,2 @@
-mkdir -p gpurun_out
-for K in k_plane_scatter k_plane_aggregate; do
-echo "== c3 $K"
-bash tools/pmc_any.sh c3 $K "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM" "SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_WAVES GRBM_GUI_ACTIVE SQ_INSTS_FLAT_LDS_ONLY SQ_ACTIVE_INST_MISC SQ_INSTS_BRANCH" "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_EA0_WRREQ_STALL_sum TCC_EA0_RDREQ_sum" "TCP_TCC_WRITE_REQ_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_TA_TCP_STATE_READ_sum"
-done 2>&1 | tee gpurun_out/pmc_plane.txt
+bash tools/gpu_step.sh "chunk or plane" "c3 c3w" "0,1048576"
+echo GROUPS; timeout 600 python tools/bench_groups.py 2>&1 | tail -12
