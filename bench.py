@@ -29,6 +29,7 @@ One JSON line on stdout (rank 0); everything else goes to stderr.
 from __future__ import annotations
 
 import argparse
+import ctypes as C
 import json
 import os
 import sys
@@ -62,9 +63,9 @@ WORKLOADS = {
     "c2b": dict(desc="north-star: select sum(b) where a < 100000, a i64 seed 2, b f64 seed 3", rows=1_000_000_000, bytes_per_row=16, dtype="f64",
                 kernel="k_filter_aggr_plan (K1 compiled at run time for the plan; prebuilt k_filter_aggr<2, 1, 4, 1, 0, false> without hiprtc)"),
     "c3": dict(desc="configs[2]: select sum(v) by k, k i64 uniform [0,1e6) seed 4, v f64 seed 5", rows=1_000_000_000, bytes_per_row=16, dtype="f64",
-               kernel="k_chunk_scatter_bin<2, 0> (scope + partition in one pass; k_chunk_scatter<2, 0> for skewed keys) + k_chunk_aggregate<512>"),
+               kernel="k_plane_scatter<2, 0, 1, 7, 5> (scope + partition into 8 + 4-byte planes in one pass; the 16-byte chunk kernels for skewed keys) + k_plane_aggregate<1024, 1, true>"),
     "c3w": dict(desc="metric shape filter->group-by->sum: select sum(v) by k where a < 100000 (10 %), k/v as C3, a as C2", rows=1_000_000_000,
-                bytes_per_row=24, dtype="f64", kernel="k_chunk_scatter_bin<3, 1> (filter + scope + partition in one pass) + k_chunk_aggregate<512>"),
+                bytes_per_row=24, dtype="f64", kernel="k_plane_scatter<3, 1, 1, 7, 5> (filter + scope + partition into 8 + 4-byte planes in one pass) + k_plane_aggregate<1024, 1, true>"),
     "q2": dict(desc="several by: columns (H2O Q2 shape): select sum(v) by {id1, id2}, id1/id2 i64 uniform [0,100) seeds 10/11, v f64 seed 5", rows=1_000_000_000,
                bytes_per_row=24, dtype="f64", kernel="k_part_scope_hist<1, 0> x2 + k_group_dense<3, true, 1024>"),
     "q7": dict(desc="key tuples beyond the composite key (H2O Q7 shape, row-hash path): select sum(v), count by {id1..id6}; id1,id2,id4,id5 i64 uniform [0,100), "
@@ -171,6 +172,7 @@ class Job:
         if self.name == "w2":
             ids = self.sh.where(self.where, self.t) if self.sh is not None else self.eng.where(self.where, self.t)
             self.eng.sync()
+            self._ids_keep = ids
             return ([int(ids.numel())], int(ids.numel()))
         if self.name in ("c3", "c3w", "q2", "k9", "q1", "q7"):
             if self.sh is not None:
@@ -179,6 +181,84 @@ class Job:
         if self.sh is not None:
             return self.sh.filter_aggr(self.aggs, self.where, self.t)
         return self.eng.filter_aggr(self.aggs, self.where, self.t, nrows=self.rows)
+
+    def verify(self, res):
+        """One UNTIMED check of the timed path's answer against an independent computation (plain torch ops on the same device columns):
+        ties the benchmark to the parity tests.  Returns a short description; raises on a mismatch."""
+        import torch as T
+        t, name = self.t, self.name
+
+        def close(a, b, what):
+            a, b = float(a), float(b)
+            if not abs(a - b) <= 1e-9 * max(abs(a), abs(b), 1e-300):
+                raise SystemExit(f"bench.py: {name}: {what} differs: {a!r} vs torch {b!r}")
+
+        def mask(w):
+            if w is None:
+                return None
+            op = w[0]
+            if op in ("and", "or"):
+                ms = [mask(x) for x in w[1:]]
+                m = ms[0]
+                for x in ms[1:]:
+                    m = (m & x) if op == "and" else (m | x)
+                return m
+            col, c = t[w[1]], w[2]
+            return {"<": col < c, ">": col > c, "<=": col <= c, ">=": col >= c, "==": col == c, "!=": col != c}[op]
+
+        if name in ("c2", "c2_1pct", "c2_50pct", "c2b", "c1", "c5", "x6"):
+            vals, sel = res
+            m = mask(self.where)
+            nsel = int(m.sum()) if m is not None else self.rows
+            if int(sel) != nsel:
+                raise SystemExit(f"bench.py: {name}: selected {sel} vs torch {nsel}")
+            for (fn, col), got in zip(self.aggs, vals):
+                x = t[col] if isinstance(col, str) else (t[col[1]] * t[col[2]])
+                x = x if m is None else x[m]
+                want = {"sum": x.sum, "avg": lambda: x.mean(), "min": x.min, "max": x.max}[fn]()
+                if x.dtype == T.int64 or fn in ("min", "max"):
+                    if float(got) != float(want):
+                        raise SystemExit(f"bench.py: {name}: {fn} {got!r} vs torch {want!r}")
+                else:
+                    close(got, want, fn)
+            return f"selected rows and {len(vals)} aggregate(s) equal torch's on the same columns"
+        if name in ("c3", "c3w", "k9", "q2"):
+            m = mask(self.where)
+            if name == "q2":
+                dense = t["id1"] * 100 + t["id2"]
+                size = 10_000
+                gk = res["key_columns"][0] * 100 + res["key_columns"][1]
+            elif name == "k9":
+                dense = (t["k"] + 77) // 1_000_003
+                size = 1_000_000
+                gk = (res["keys"] + 77) // 1_000_003
+            else:
+                dense, size, gk = t["k"], 1_000_000, res["keys"]
+            v = t["v"]
+            if m is not None:
+                dense, v = dense[m], v[m]
+            want = T.zeros(size, dtype=T.float64, device=v.device).index_add_(0, dense, v)
+            seen = T.zeros(size, dtype=T.bool, device=v.device)
+            seen[dense] = True
+            if int(res["groups"]) != int(seen.sum()):
+                raise SystemExit(f"bench.py: {name}: {res['groups']} groups vs torch {int(seen.sum())}")
+            got = T.zeros(size, dtype=T.float64, device=v.device)
+            got[gk] = res["results"][0]
+            scale = T.zeros(size, dtype=T.float64, device=v.device).index_add_(0, dense, v.abs())
+            bad = ((got - want).abs() > 1e-9 * scale + 1e-300).sum()
+            if int(bad):
+                raise SystemExit(f"bench.py: {name}: {int(bad)} group sums differ from torch index_add_ by more than 1e-9 relative")
+            first = res["first"]
+            if int((first[1:] <= first[:-1]).sum()):
+                raise SystemExit(f"bench.py: {name}: groups are not in first-occurrence order")
+            return f"{int(res['groups'])} groups: every sum within 1e-9 of torch index_add_, first rows strictly ascending"
+        if name == "w2":
+            ids, n = self._ids_keep, int(mask(self.where).sum())
+            ok = ids.numel() == n and bool((ids[1:] > ids[:-1]).all()) and bool((t["a"][ids] < 100_000).all())
+            if not ok:
+                raise SystemExit("bench.py: w2: ids are not the ascending selected rows")
+            return f"{n} ids: ascending, all selected, count equals torch's"
+        return None
 
 
 def timed(job: Job, steps: int, warmup: int, world: int):
@@ -212,7 +292,10 @@ def run_workload(name, eng, sharded, rows, row0, steps, warmup, world, total_row
     w = WORKLOADS[name]
     total_rows = rows * world if total_rows is None else total_rows
     job = Job(name, eng, sharded, rows, row0)
+    before = [eng.stat(i) for i in range(5)]
     dt, kms, res = timed(job, steps, warmup, world)
+    paths = dict(zip(("plane_scatter", "plane_fallback", "plane_aggregate", "chunk_scatter", "chunk_aggregate"), [eng.stat(i) - b for i, b in enumerate(before)]))
+    checked = job.verify(res) if (world == 1 and sharded is None) else None
     ms_step = dt * 1e3 / steps
     if name in ("c3", "c3w", "q2", "k9", "q1", "q7", "w2") or world > 1:
         kms = ms_step  # several dependent kernels (partition, aggregate, rank, emit) / the merge collective: price the whole query
@@ -220,7 +303,7 @@ def run_workload(name, eng, sharded, rows, row0, steps, warmup, world, total_row
     alg_bytes = w["bytes_per_row"] * total_rows / world  # per launch, per GPU (SURVEY 8d figures, stated in DESIGN.md)
     achieved = alg_bytes / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
     out = dict(workload=name, rows_per_gpu=rows, total_rows=total_rows, ms_per_step=ms_step, rows_per_s=value, kernel_ms=kms, achieved_GBps=achieved,
-               frac=achieved / HBM_PEAK_GBPS, result=_brief(res))
+               frac=achieved / HBM_PEAK_GBPS, result=_brief(res), verified=checked, paths={k: v for k, v in paths.items() if v})
     del job
     torch.cuda.empty_cache()
     return out
@@ -295,6 +378,79 @@ def boundary_overhead(eng, rows=100_000_000, reps=10):
             "boundary_overhead_ms": ms_c - ms_engine, "answered_on_gpu": on_gpu, "pin_upload_s": pin_s,
             "pin_upload_GBps": 3 * rows * 8 / pin_s / 1e9}
 
+
+
+# ------------------------------------------------------------------------------------------------ the product's door at full size
+C_DOOR = {
+    "c3w": ({"k": ("i64", 4, 1_000_000), "v": ("f64", 5), "a": ("i64", 2, 1_000_000)}, {"where": ("<", "a", 100_000), "by": "k", "s": ("sum", "v")}),
+    "c3": ({"k": ("i64", 4, 1_000_000), "v": ("f64", 5)}, {"by": "k", "s": ("sum", "v")}),
+    "c2": ({"a": ("i64", 2, 1_000_000)}, {"where": ("<", "a", 100_000), "s": ("sum", "a")}),
+    "c2b": ({"a": ("i64", 2, 1_000_000), "b": ("f64", 3)}, {"where": ("<", "a", 100_000), "s": ("sum", "b")}),
+    "c5": ({c: ("f64", sd) for c, sd in zip("abcd", (6, 7, 8, 9))},
+           {"where": ("and", ("<", "a", 0.316228), (">", "b", 0.683772), ("!=", "c", 0.25)), "x": ("avg", "d"), "y": ("min", "d"), "z": ("max", "d")}),
+}
+
+
+def c_door(name, eng, rows, steps, warmup):
+    """The workload through rfx_select -- the C operator boundary the reference's evaluator (or `loadfn`) binds -- at the workload's full
+    size: host vectors laid out as RayforceDB objects, pinned (uploaded once, trusted until rfx_invalidate), K timed calls, each returning the
+    finished host result table (result read-back and table construction are inside the timed region).  The answer of the last call is checked
+    against Engine's (itself checked against torch in run_workload)."""
+    import numpy as np
+    from rayforce_amd import hostobj as H
+    ops = H.lib()
+    ops.rfx_host_bind()
+    spec, q = C_DOOR[name]
+    host = {}
+    for cname, sp in spec.items():
+        dcol = eng.gen_i64(rows, sp[1], sp[2]) if sp[0] == "i64" else eng.gen_f64(rows, sp[1])
+        host[cname] = dcol.cpu().numpy()
+        del dcol
+    torch.cuda.empty_cache()
+    tab = H.table(host)
+    del host
+    t0 = time.perf_counter()
+    pin = ops.rfx_pin(tab)
+    pin_s = time.perf_counter() - t0
+    d = H.select_dict(q, tab)
+    for _ in range(max(1, warmup)):
+        ops.rfx_host_drop(ops.rfx_select(d))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    r = None
+    for _ in range(steps):
+        if r:
+            ops.rfx_host_drop(r)
+        r = ops.rfx_select(d)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert r and not H.is_error(r), H.error_text(r)
+    on_gpu = int(ops.rfx_last_select_on_gpu())
+    got = H.table_to_numpy(r)
+    ops.rfx_host_drop(r)
+    # the same query through Engine on the same data (device-generated again), compared column by column
+    cols = {cname: (eng.gen_i64(rows, sp[1], sp[2]) if sp[0] == "i64" else eng.gen_f64(rows, sp[1])) for cname, sp in spec.items()}
+    want = eng.select({"from": cols, **q})
+    for cname, w in want.items():
+        w = w.cpu().numpy()
+        g = got[cname]
+        if w.dtype == np.float64:
+            okc = g.shape == w.shape and bool(np.all(np.abs(g - w) <= 1e-9 * np.maximum(np.abs(w), 1e-300) + 0.0))
+        else:
+            okc = g.shape == w.shape and bool(np.array_equal(g, w))
+        if not okc:
+            raise SystemExit(f"bench.py: rfx_select({name}) column {cname} differs from Engine.select on the same data")
+    del cols, want
+    u = ops.rfx_unpin(tab)
+    for o in (pin, u, d, tab):
+        ops.rfx_host_drop(o)
+    ops.rfx_cache_clear()
+    torch.cuda.empty_cache()
+    if not on_gpu:
+        raise SystemExit(f"bench.py: rfx_select({name}) was not answered on the GPU")
+    return {"door": "rfx_select (C operator boundary, include/rfx_ops.h) on pinned host columns; result table built on the host inside the timed region",
+            "rows": rows, "steps": steps, "ms_per_step": dt * 1e3 / steps, "rows_per_s": rows / (dt / steps), "answered_on_gpu": on_gpu,
+            "pin_upload_s": pin_s, "verified": "every result column equals Engine.select's on the same data (f64 within 1e-9)"}
 
 # ------------------------------------------------------------------------------------------------ CPU baseline
 def cpu_baseline(name, sample_rows, timeout=120):
@@ -410,6 +566,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sharded", action="store_true", help="use the row-sharded driver (collectives) even with one rank")
     ap.add_argument("--no-also", action="store_true", help="skip the secondary workloads in the 'also' field")
+    ap.add_argument("--engine-door", action="store_true", help="report Engine.group_by / filter_aggr (ctypes host, device-resident results) as `value` instead of rfx_select")
     ap.add_argument("--dry-run", action="store_true", help="no device work: rendezvous, shard arithmetic and the JSON line only (CPU test of the launch contract)")
     ap.add_argument("--blocks-per-cu", type=int, default=0)
     ap.add_argument("--ab", default="", help="dev: comma list of tune flags to A/B in ONE process (same box, same clocks); prints one line per run")
@@ -491,6 +648,11 @@ def main():
         return
     main_r = run_workload(name, eng, sharded, rows, row0, args.steps, args.warmup, world, total_rows)
     log(f"[bench] {name}: {main_r}")
+    door = None
+    if world == 1 and sharded is None and name in C_DOOR and not args.engine_door:
+        # the headline goes through the product's own door: the C operator rfx_select (Engine's time for the same query rides beside it)
+        door = c_door(name, eng, rows, args.steps, args.warmup)
+        log(f"[bench] {name} through rfx_select: {door}")
     also = {}
     FULL = ("c3w", "c2", "c2b", "c3", "c5")  # the BASELINE configs: the full step count, their own roofline block and CPU baseline
     if not args.no_also and world == 1 and not args.rows:
@@ -500,7 +662,7 @@ def main():
             try:
                 full = other in FULL
                 r = run_workload(other, eng, None, WORKLOADS[other]["rows"], 0, args.steps if full else max(3, args.steps // 4), args.warmup if full else 2, 1)
-                also[other] = {k: r[k] for k in ("rows_per_gpu", "ms_per_step", "rows_per_s", "kernel_ms", "achieved_GBps", "frac")}
+                also[other] = {k: r[k] for k in ("rows_per_gpu", "ms_per_step", "rows_per_s", "kernel_ms", "achieved_GBps", "frac", "verified", "paths")}
                 also[other]["steps"] = args.steps if full else max(3, args.steps // 4)
                 if full:
                     also[other]["roofline"] = roofline_block(other, r, 1)
@@ -538,14 +700,21 @@ def main():
 
     if rank == 0:
         w = WORKLOADS[name]
+        head = dict(main_r)
+        if door:  # value = the C operator boundary; the Engine figures stay in `engine`
+            head.update(ms_per_step=door["ms_per_step"], rows_per_s=door["rows_per_s"], kernel_ms=door["ms_per_step"])
+            head["achieved_GBps"] = w["bytes_per_row"] * total_rows / (door["ms_per_step"] * 1e-3) / 1e9
+            head["frac"] = head["achieved_GBps"] / HBM_PEAK_GBPS
+        rl, rc = C.c_int64(), C.c_int64()
+        eng.lib.rfx_hip_rtc_stats(C.byref(rl), C.byref(rc))
         line = {
             "metric": METRIC,
-            "value": main_r["rows_per_s"],
+            "value": head["rows_per_s"],
             "unit": "rows/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": main_r["ms_per_step"],
+            "ms_per_step": head["ms_per_step"],
             "higher_is_better": True,
             "scaling": args.scaling,
             "vs_baseline": None,
@@ -553,10 +722,15 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{name}: {w['desc']}", "rows_per_gpu": rows, "total_rows": total_rows,
                        "sharding": f"row-range x{world}" if world > 1 else "single GPU", "resident": "HBM (columns generated on device)",
-                       "result": main_r["result"]},
-            "roofline": roofline_block(name, main_r, world),
+                       "result": main_r["result"], "verified": main_r["verified"], "paths": main_r["paths"],
+                       "door": door["door"] if door else "Engine (ctypes host over the flat device ABI, results stay on the device)"},
+            "roofline": roofline_block(name, head, world),
             "cpu_baseline": cpu,
+            "rtc": {"launches_through_run_time_compiled_kernels": int(rl.value), "plans_compiled": int(rc.value)},
         }
+        if door:
+            line["door"] = door
+            line["engine"] = {k: main_r[k] for k in ("ms_per_step", "rows_per_s", "frac")}
         if also:
             line["also"] = also
         if boundary:

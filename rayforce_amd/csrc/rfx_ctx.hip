@@ -319,7 +319,8 @@ extern "C" int rfx_hip_eval_expr(rfx_ctx_t *c, const rfx_agg_t *expr, int64_t nr
 // hipFree cost tens of microseconds and hipFree waits for the device -- more than the whole rest of a 1e6-row query.  Blocks are
 // power-of-two sized; everything that touches them runs on the context's one stream, so a recycled block is never read by work
 // still in flight.  Not thread-safe, like the context itself.
-#define POOL_MAX_LOG 22
+#define POOL_MAX_LOG 28 /* blocks up to 256 MB are recycled (group tables and result blocks of a 1e6-group query are 16 MB each: a hipMalloc / hipFree pair
+                         * per query cost more than the query's kernels at 1e8 rows) */
 #define POOL_MIN_LOG 8
 #define POOL_KEEP 8
 #define POOL_LIVE 1024
@@ -372,7 +373,7 @@ extern "C" int rfx_hip_free(rfx_ctx_t *c, void *d_ptr) {
                 const int k = sp->live_c[i];
                 sp->live_p[i] = sp->live_p[sp->nlive - 1];
                 sp->live_c[i] = sp->live_c[--sp->nlive];
-                if (sp->nfree[k] < POOL_KEEP) {
+                if (sp->nfree[k] < (k > 22 ? 2 : POOL_KEEP)) { // (two spares per size class above 4 MB)
                     sp->freep[k][sp->nfree[k]++] = d_ptr;
                     return RFX_OK;
                 }

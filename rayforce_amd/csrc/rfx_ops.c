@@ -16,6 +16,7 @@
 #include <stdlib.h>
 #include <unistd.h>
 #include <string.h>
+#include <time.h>
 #include "rfx_abi.h"
 #include "rfx_hip.h"
 #include "rfx_ops.h"
@@ -771,8 +772,29 @@ static int fetch(void *dst, const void *d_src, size_t bytes) {
     return rfx_hip_d2h(g_ctx, dst, d_src, bytes);
 }
 
+/* RFX_TRACE=2: where a select's wall time goes (microseconds between marks), one line per query on stderr */
+static double g_tm[12];
+static int g_ntm;
+static void tm_mark(void) {
+    if (g_ntm < 12) {
+        struct timespec ts;
+        clock_gettime(CLOCK_MONOTONIC, &ts);
+        g_tm[g_ntm++] = ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3;
+    }
+}
+static void tm_print(void) {
+    static int on = -1;
+    if (on < 0) { const char *e = getenv("RFX_TRACE"); on = e && atoi(e) >= 2; }
+    if (on && g_ntm > 1) {
+        fprintf(stderr, "[rfx] select us:");
+        for (int i = 1; i < g_ntm; i++) fprintf(stderr, " %.0f", g_tm[i] - g_tm[i - 1]);
+        fprintf(stderr, "  (plan | scope | tables+pass+rank | emit | fetch | build+free) total %.0f\n", g_tm[g_ntm - 1] - g_tm[0]);
+    }
+}
 static obj_p select_impl(obj_p dict) {
     rfx_host_bind();
+    g_ntm = 0;
+    tm_mark();
     if (!dict || dict->type != RFX_TYPE_DICT || RFX_AS_LIST(dict)[0]->type != RFX_TYPE_SYMBOL) return fail("select: expected a dict");
     obj_p from = dict_get(dict, "from");
     if (!from) return fail("'select' expects 'from' param"); /* core/query.c:281 */
@@ -1068,6 +1090,7 @@ static obj_p select_impl(obj_p dict) {
                     }
                 }
             } else {
+                tm_mark();
                 if (spec_ok) {
                     if (rfx_hip_scope_sample_i64(g_ctx, (const int64_t *)dk, nrows, &kmin, &kmax) != RFX_OK) { res = fail_hip("scope"); goto done; }
                     spec = kmin != RFX_NULL_I64 && kmax >= kmin && (uint64_t)(kmax - kmin) < RFX_SCOPE_SAMPLE_MAX_RANGE;
@@ -1075,6 +1098,7 @@ static obj_p select_impl(obj_p dict) {
                 }
                 if (!spec && rfx_hip_group_scope(g_ctx, (const int64_t *)dk, wp.preds, wp.npred, wp.logic, aggs, nagg, nrows, &kmin, &kmax, &seen) != RFX_OK) { res = fail_hip("scope"); goto done; }
             }
+            tm_mark();
             if (spec && rowhash) spec = 0; /* (cannot happen: the row-hash path needs ranges beyond 64 bits) */
             if (spec) g_stat[ST_SCOPE_SAMPLED]++;
             int64_t groups = 0;
@@ -1204,6 +1228,7 @@ static obj_p select_impl(obj_p dict) {
                         goto out;
                     }
                 }
+                tm_mark();
                 const void *dkeys_out = NULL; /* device address of the result's key cells */
                 void *dfirst = NULL;          /* row-hash path: the groups' first rows (the key columns are gathered there) */
                 if (ok && groups > 0 && !small) ok = rfx_hip_malloc(g_ctx, &dout, (size_t)(nagg_run + 1) * (size_t)groups * 8) == RFX_OK;
@@ -1218,6 +1243,7 @@ static obj_p select_impl(obj_p dict) {
                         for (int a = 0; a < nagg_run; a++) ptrs[a] = (int64_t *)dout + (size_t)(a + 1) * groups;
                         ok = (dense ? rfx_hip_group_emit(g_ctx, aggs, &gt, (int64_t *)dout, NULL, ptrs) : rfx_hip_hash_emit(g_ctx, aggs, &ht, (int64_t *)dout, (int64_t *)dfirst, ptrs)) == RFX_OK;
                     }
+                    tm_mark();
                     if (nkeys == 1 && key_out_type == RFX_TYPE_DATE) { /* the virtual Date column: 4-byte days */
                         okeys = H.vector(RFX_TYPE_DATE, groups);
                         int64_t *k8 = (int64_t *)malloc((size_t)groups * 8);
@@ -1279,6 +1305,7 @@ static obj_p select_impl(obj_p dict) {
                         ok = fetch(RFX_AS_RAW(ocols[a]), ptrs[a], (size_t)groups * 8) == RFX_OK;
                     }
                 }
+                tm_mark();
                 if (dout) rfx_hip_free(g_ctx, dout);
                 if (dfirst) rfx_hip_free(g_ctx, dfirst);
                 rfx_hip_free(g_ctx, store);
@@ -1328,6 +1355,8 @@ done:
     free((void *)g_mirror_host);
     g_mirror_host = NULL;
     H.drop(host_tab);
+    tm_mark();
+    tm_print();
     if (take && g_last_gpu && res && res->type == RFX_TYPE_TABLE) { /* (a delegated query had its take: applied by ray_select) */
         obj_p tv = H.eval(take);
         if (tv && tv->type != RFX_TYPE_ERR) {
