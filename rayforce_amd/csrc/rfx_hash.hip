@@ -68,7 +68,7 @@ __global__ __launch_bounds__(RFX_BLOCK) void k_group_hash(const Plan P, const Ha
         // load factor: one counter update per wave and tile that claimed slots; beyond 3/4 the launch is abandoned (grow and retry)
         for (int sft = 32; sft >= 1; sft >>= 1) fresh += __shfl_xor(fresh, sft, 64);
         pending += fresh; // wave-uniform; pushed to the one global counter in batches (a single address takes ~10 M atomics/s)
-        if (pending >= 4096u || (pending && t + gridDim.x >= ntiles)) {
+        if (pending >= 4096u) {
             if ((tid & 63) == 0) {
                 const unsigned long long used = atomicAdd((unsigned long long *)(overflow + 2), (unsigned long long)pending) + pending;
                 if (used * 4 > (unsigned long long)H.capacity * 3) atomicExch(overflow, 1);
@@ -86,6 +86,11 @@ __global__ __launch_bounds__(RFX_BLOCK) void k_group_hash(const Plan P, const Ha
                 group_apply(&H.acc[a][slot[e]], H.cnt[a] ? &H.cnt[a][slot[e]] : (u64 *)0, ag.kind, ag.f64, x[e], ag.skipnull);
             }
         }
+    }
+    // what is left of the batch (a last tile without selected rows skips the loop body: the flush cannot live there)
+    if (pending && (tid & 63) == 0) {
+        const unsigned long long used = atomicAdd((unsigned long long *)(overflow + 2), (unsigned long long)pending) + pending;
+        if (used * 4 > (unsigned long long)H.capacity * 3) atomicExch(overflow, 1);
     }
 }
 

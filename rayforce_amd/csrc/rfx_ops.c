@@ -362,7 +362,8 @@ static obj_p parted_view(obj_p tab) {
             px->hdr.type = (int8_t)(c->type - RFX_TYPE_PARTEDLIST); /* LIST (0) for a generic parted list: not usable */
             for (int64_t j = 0; j < c->len; j++) {
                 obj_p part = RFX_AS_LIST(c)[j];
-                if (part->type != px->hdr.type) { px->hdr.type = RFX_TYPE_LIST; break; }
+                if (part->type != (int8_t)(c->type - RFX_TYPE_PARTEDLIST)) px->hdr.type = RFX_TYPE_LIST; /* mixed partition types: not usable -- but the row
+                                                                                                          * count stays the table's (column 0 gives nrows) */
                 total += (part->type == RFX_TYPE_ENUM) ? enum_indices(part)->len : part->len;
             }
         }
@@ -737,8 +738,9 @@ static int build_xnodes(obj_p tab, obj_p e, rfx_xnode_t *nodes, int *nn, int *nc
 }
 
 /* ------------------------------------------------------------------------------------------------ select */
-static const void *g_spec_failed[32]; /* device key columns whose sampled scope was reported too small: not sampled again */
-static int g_nspec_failed, g_spec_retry;
+static const void *g_spec_failed[32]; /* HOST key columns (payload address of the first by: column) whose sampled scope was reported too small:
+                                       * not sampled again.  (Device addresses are per-query scratch for bucketed / composite keys.) */
+static int g_nspec_failed, g_spec_ring, g_spec_retry;
 /* One dense accumulate pass, under an exact or a SAMPLED scope (`spec`).  0: done.  1: the sampled scope did not hold (a selected row's
  * key outside it, or a path that cannot report such rows): nothing of the result may be used, the caller takes the exact scope and runs
  * again.  -1: error. */
@@ -1031,14 +1033,15 @@ static obj_p select_impl(obj_p dict) {
          * full pass is a quarter to a third of such a query -- with the kernels reporting any selected key outside it; a report (or a
          * path that cannot report) comes back here for the exact scope.  RFX_NO_SAMPLED_SCOPE=1 turns it off. */
         int spec_ok = by && nrows >= ((int64_t)1 << 24) && !getenv("RFX_NO_SAMPLED_SCOPE");
+        const void *spec_id = (nkeys > 0 && kcs[0]) ? (const void *)RFX_AS_RAW(kcs[0]) : NULL;
         for (int i = 0; i < g_nspec_failed && spec_ok; i++) /* a sample that missed this key column's range before (a rare extreme value) will again */
-            if (g_spec_failed[i] == dk) spec_ok = 0;
+            if (g_spec_failed[i] == spec_id) spec_ok = 0;
     rescope:;
         int spec = 0;
         if (g_spec_retry) { /* back here after a report */
             g_spec_retry = 0;
             g_stat[ST_SCOPE_RETRIED]++;
-            g_spec_failed[g_nspec_failed % 32] = dk;
+            g_spec_failed[g_spec_ring++ % 32] = spec_id;
             if (g_nspec_failed < 32) g_nspec_failed++;
         }
         if (by) {
@@ -2215,7 +2218,9 @@ static obj_p pin_op(obj_p x, int pin) {
             if (pin) {
                 obj_p pc = RFX_AS_LIST(RFX_AS_LIST(view)[1])[i];
                 const void *d;
-                if ((col_ctype(pc) || pc->type == RFX_TYPE_B8) && pc->type > 0 && resident(pc, 1, &d) != RFX_OK) bad = 1;
+                /* only 8-byte proxies: proxy_upload / proxy_sum address partitions as 8-byte cells (a B8 proxy would overrun its 1-byte-per-row
+                 * device block and read past the mmapped partition files) */
+                if (col_ctype(pc) && pc->type > 0 && resident(pc, 1, &d) != RFX_OK) bad = 1;
             } else {
                 for (int j = 0; j < g_nres; j++)
                     if (g_res[j].host == (const void *)c || g_res[j].host == RFX_AS_RAW(c)) { res_free(j); break; }

@@ -201,7 +201,8 @@ def test_parted_and_enum_columns_inside_the_real_reference(built, tmp_path):
     lens = [70_001, 50_000, 33_333, 90_007]
     for i, (d, n) in enumerate(zip(dates, lens)):  # one reference process per partition
         with ref.Session() as s:
-            s.table("t", {"k": rfo.gen_i64(n, 40 + i, 500), "a": rfo.gen_i64(n, 50 + i, 1_000_000), "v": rfo.gen_f64(n, 60 + i)})
+            s.table("t", {"k": rfo.gen_i64(n, 40 + i, 500), "a": rfo.gen_i64(n, 50 + i, 1_000_000), "v": rfo.gen_f64(n, 60 + i),
+                          "flag": (rfo.gen_i64(n, 80 + i, 2) == 1)})  # a B8 column: pinning the table must leave 1-byte parted columns alone
             s.eval(f'(set "{root}{d}/tab/" t)')
             s.run(threads=8)
     n = 120_011
@@ -246,4 +247,4 @@ def test_parted_and_enum_columns_inside_the_real_reference(built, tmp_path):
     print(ref.LAST_STDERR)  # RFX_TRACE=1: why a query was handed back
     assert int(st[0]) == on_gpu and int(st[1]) == len(PARTED + ENUMS) - on_gpu, st
     assert len(res["g_p2_Date"]) == 4 and len(res["g_p4_Date"]) == 2
-    assert int(st[4]) <= 4 + 3 + 2  # uploads: the parted table's four columns once (pinned), the splayed / in-memory tables' columns
+    assert int(st[4]) <= 4 + 3 + 2  # uploads: the parted table's four 8-byte columns once (pinned; the B8 column is not uploaded), the splayed / in-memory tables' columns
