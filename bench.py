@@ -635,6 +635,13 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
     sharded = ShardedEngine(eng, rows) if (world > 1 or args.sharded) else None
+    ranks_seen = None
+    if sharded is not None and getattr(sharded, "native", None) is not None:
+        w_, r_ = C.c_int(), C.c_int()
+        eng.lib.rfx_dist_world(eng._ctx, C.byref(w_), C.byref(r_))  # ncclCommCount / ncclCommUserRank of the context's communicator
+        ranks_seen = int(w_.value)
+        if ranks_seen != world:
+            raise SystemExit(f"bench.py: the RCCL communicator spans {ranks_seen} ranks, the launcher started {world}")
 
     if args.ab:
         job = Job(name, eng, sharded, rows, row0)
@@ -721,7 +728,7 @@ def main():
             "dtype": w["dtype"],
             "data": "synthetic",
             "config": {"workload": f"{name}: {w['desc']}", "rows_per_gpu": rows, "total_rows": total_rows,
-                       "sharding": f"row-range x{world}" if world > 1 else "single GPU", "resident": "HBM (columns generated on device)",
+                       "sharding": f"row-range x{world}" if world > 1 else "single GPU", "ranks_seen": ranks_seen, "resident": "HBM (columns generated on device)",
                        "result": main_r["result"], "verified": main_r["verified"], "paths": main_r["paths"],
                        "door": door["door"] if door else "Engine (ctypes host over the flat device ABI, results stay on the device)"},
             "roofline": roofline_block(name, head, world),

@@ -88,7 +88,14 @@ typedef struct rfx_pred {
 /* Element-wise arithmetic feeding an aggregate: input = lhs OP rhs with the reference's scalar rules
  * (ADD/SUB/MUL{I64,F64}, FDIV{I64,F64}: core/ops.h:153-174 -- null in -> null out, i64 wraps, i64 (x) f64 promotes the
  * i64 side with null -> NaN, `div` by zero -> NaN; result type f64 unless both sides are i64 and OP is not FDIV). */
-enum { RFX_X_NONE = 0, RFX_X_ADD = 1, RFX_X_SUB = 2, RFX_X_MUL = 3, RFX_X_FDIV = 4 };
+enum { RFX_X_NONE = 0, RFX_X_ADD = 1, RFX_X_SUB = 2, RFX_X_MUL = 3, RFX_X_FDIV = 4, RFX_X_DIV = 5, RFX_X_MOD = 6 };
+/* RFX_X_DIV = the reference's `/` (ray_div, core/math.c:1138-1364): FLOOR division -- DIVI64 / DIVF64, core/ops.h:165-171 -- whose
+ * result takes the LEFT operand's type (infer_div_type, core/math.c:149-188: i64 / f64 -> i64 through f64_to_i64(floor(x / y)));
+ * RFX_X_MOD = `%` (ray_mod, :1449-1530): x - floor(x / y) * y, i64 only when both sides are (infer_mod_type, :190-220).  A zero
+ * divisor or a null on either side gives null.  Result element type of one operation: */
+static inline int rfx_xop_result_f64(int op, int l_f64, int r_f64) {
+    return op == RFX_X_FDIV ? 1 : (op == RFX_X_DIV ? l_f64 : (l_f64 || r_f64));
+}
 enum { RFX_XF_SWAP = 1 }; /* operands swapped: input = rhs OP column (for `(- 2 a)`, `(div 1 a)`) */
 
 /* Deeper expressions -- `(sum (* price (- 1 disc)))`, up to RFX_MAX_XNODES operations -- are given as a node list in evaluation
@@ -107,7 +114,7 @@ typedef struct rfx_xoperand {
     };
 } rfx_xoperand_t;
 typedef struct rfx_xnode {
-    int32_t op; /* RFX_X_ADD .. RFX_X_FDIV */
+    int32_t op; /* RFX_X_ADD .. RFX_X_MOD */
     int32_t _pad;
     rfx_xoperand_t l, r;
 } rfx_xnode_t;

@@ -30,6 +30,7 @@
  *   rfx_inner_join         ray_inner_join        core/join.c:200-298             vary_f
  *   rfx_add rfx_sub        ray_add ray_sub       core/math.c:2280-2345 (binop_map)   binary_f  vector (x) vector | atom -> vector
  *   rfx_mul rfx_div        ray_mul ray_fdiv (`div`)                                  binary_f  (i64 / f64, the reference's promotion)
+ *   rfx_floordiv rfx_mod   ray_div (`/`: floor division, left operand's type) ray_mod (`%`)   binary_f  (core/math.c:1138-1364, 1449-1530)
  *
  * Everything below runs on the MI355X through the flat ABI of rfx_hip.h.  There is NO CPU implementation behind these
  * entry points: queries whose shape the GPU path does not cover are handed back to the host's own ray_* function when
@@ -72,6 +73,8 @@ rfx_obj_p rfx_add(rfx_obj_p x, rfx_obj_p y);
 rfx_obj_p rfx_sub(rfx_obj_p x, rfx_obj_p y);
 rfx_obj_p rfx_mul(rfx_obj_p x, rfx_obj_p y);
 rfx_obj_p rfx_div(rfx_obj_p x, rfx_obj_p y);
+rfx_obj_p rfx_floordiv(rfx_obj_p x, rfx_obj_p y);
+rfx_obj_p rfx_mod(rfx_obj_p x, rfx_obj_p y);
 
 rfx_obj_p rfx_left_join(rfx_obj_p *x, int64_t n);  /* (keys symbol vector, left table, right table) */
 rfx_obj_p rfx_inner_join(rfx_obj_p *x, int64_t n);

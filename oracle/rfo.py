@@ -267,7 +267,7 @@ def composite_key(keys, filter_ids=None):
     return out, tmax.value, mins, list(amul)
 
 
-XOPS = {"+": 1, "-": 2, "*": 3, "div": 4}
+XOPS = {"+": 1, "-": 2, "*": 3, "div": 4, "/": 5, "%": 6}
 
 
 def binop(op: str, lhs, rhs) -> np.ndarray:
@@ -282,7 +282,7 @@ def binop(op: str, lhs, rhs) -> np.ndarray:
     la, l_atom, lt = prep(lhs)
     ra, r_atom, rt = prep(rhs)
     n = len(la) if not l_atom else len(ra)
-    out_f64 = op == "div" or lt == 10 or rt == 10
+    out_f64 = (lt == 10) if op == "/" else (op == "div" or lt == 10 or rt == 10)  # `/` keeps the left operand's type
     out = np.empty(n, np.float64 if out_f64 else np.int64)
     lib().rfo_binop(XOPS[op], lt, _ptr(la), l_atom, rt, _ptr(ra), r_atom, n, _ptr(out))
     return out

@@ -62,17 +62,15 @@ class Agg(C.Structure):
 
 RFX_XK_COL, RFX_XK_ATOM, RFX_XK_NODE = 0, 1, 2
 RFX_MAX_XNODES = 4
-XOPS = {"+": 1, "-": 2, "*": 3, "div": 4}
+XOPS = {"+": 1, "-": 2, "*": 3, "div": 4, "/": 5, "%": 6}  # div = ray_fdiv, / = ray_div (floor, left operand's type), % = ray_mod
 RFX_XF_SWAP = 1
 
 
 def agg_input_type(a: "Agg") -> int:
     """rfx_agg_input_type: the element type the aggregate folds."""
-    if a.nxnodes > 0:
-        return load_library().rfx_agg_input_type(C.byref(a))
-    if a.xop == 0:
+    if a.xop == 0 and a.nxnodes == 0:
         return a.col_type
-    return RFX_F64 if (a.xop == 4 or a.col_type == RFX_F64 or a.xrhs_type == RFX_F64) else RFX_I64
+    return load_library().rfx_agg_input_type(C.byref(a))  # the library's own rule (rfx_xop_result_f64: `/` keeps the left operand's type)
 
 
 class Partial(C.Structure):

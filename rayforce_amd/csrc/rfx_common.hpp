@@ -146,7 +146,7 @@ struct PlanAgg {
 // One element-wise expression: up to RFX_MAX_XNODES operations in evaluation order.  An operand is a plan
 // column, an atom, or the result of an earlier operation; the expression's value is the last operation's result.
 struct PlanXNode {
-    int op;             // RFX_X_ADD .. RFX_X_FDIV
+    int op;             // RFX_X_ADD .. RFX_X_MOD
     int o_f64;          // result type of this operation
     int l_kind, r_kind; // RFX_XK_COL / RFX_XK_ATOM / RFX_XK_NODE
     int l_idx, r_idx;   // plan column index (COL) or earlier node index (NODE)
@@ -200,7 +200,32 @@ __device__ __forceinline__ u64 rfx_i64_to_f64_bits(u64 x) {
 
 // ADD/SUB/MUL{I64,F64}, FDIV{I64,F64} -- core/ops.h:153-174, with the binop type promotion of core/math.c (i64 (x) f64 ->
 // f64 through i64_to_f64).  lx / rx are the operands' raw bits in their own types.
+// DIVI64 / MODI64 (core/ops.h:165-176): floor division (EUCL_DIV rounds the truncated quotient down when the signs differ and the
+// division is inexact), the remainder takes the divisor's sign; a zero divisor or a null -> null.  DIVF64 / MODF64 (:167-177):
+// floor(x / y), x - floor(x / y) * y.  ray_div keeps the LEFT operand's type: i64 / f64 -> f64_to_i64(floor((double)x / y)).
 __device__ __forceinline__ u64 rfx_expr_eval(int op, int out_f64, int l_f64, int r_f64, u64 lx, u64 rx) {
+    if (op >= RFX_X_DIV) {
+        if (!l_f64 && !r_f64) {
+            const i64 x = (i64)lx, y = (i64)rx;
+            if (y == 0 || x == RFX_NULL_I64_D || y == RFX_NULL_I64_D) return (u64)RFX_NULL_I64_D;
+            i64 q = x / y;
+            if (((x < 0) != (y < 0)) && q * y != x) q -= 1;
+            return op == RFX_X_DIV ? (u64)q : (u64)(x - q * y);
+        }
+        const u64 lb = l_f64 ? lx : rfx_i64_to_f64_bits(lx), rb = r_f64 ? rx : rfx_i64_to_f64_bits(rx);
+        const double a = rfx_as_f64(lb), b = rfx_as_f64(rb);
+        double r = 0.0;
+        bool null = b == 0.0 || rfx_isnan_bits(lb) || rfx_isnan_bits(rb);
+        if (!null) {
+            const double q = floor(a / b);
+            r = op == RFX_X_DIV ? q : fma(-q, b, a); // (fused, as the reference's build contracts it: tests/golden/divmod_golden.npz)
+            null = rfx_isnan_bits(rfx_as_u64(r)); // (inf / inf and the like: a NaN result is the null)
+        }
+        if (out_f64) return null ? RFX_NAN_BITS : rfx_as_u64(r);
+        // i64 result of i64 / f64: f64_to_i64 (core/ops.h:255), out of range -> the null (x86's cvttsd2si "indefinite" = INT64_MIN)
+        if (null || !(r > -9223372036854775808.0 && r < 9223372036854775808.0)) return (u64)RFX_NULL_I64_D;
+        return (u64)(i64)r;
+    }
     if (!out_f64) { // i64 (x) i64, op in {ADD, SUB, MUL}: null in -> null out, two's-complement wrap
         if ((i64)lx == RFX_NULL_I64_D || (i64)rx == RFX_NULL_I64_D) return (u64)RFX_NULL_I64_D;
         return op == RFX_X_ADD ? lx + rx : (op == RFX_X_SUB ? lx - rx : lx * rx);

@@ -545,7 +545,7 @@ int rfx_plan_build(Plan *P, const rfx_pred_t *preds, int npred, int logic, const
                 for (int i = 0; i < a->nxnodes; i++) {
                     const rfx_xnode_t *src = &a->xnodes[i];
                     PlanXNode &n = x.ops[i];
-                    RFX_REQUIRE(src->op >= RFX_X_ADD && src->op <= RFX_X_FDIV, RFX_EINVAL, "bad expression operator");
+                    RFX_REQUIRE(src->op >= RFX_X_ADD && src->op <= RFX_X_MOD, RFX_EINVAL, "bad expression operator");
                     n.op = src->op;
                     const rfx_xoperand_t *opnd[2] = {&src->l, &src->r};
                     int kind[2], idx[2], f64[2];
@@ -575,7 +575,7 @@ int rfx_plan_build(Plan *P, const rfx_pred_t *preds, int npred, int logic, const
                     n.l_idx = idx[0]; n.r_idx = idx[1];
                     n.l_f64 = f64[0]; n.r_f64 = f64[1];
                     n.l_atom = atoms[0]; n.r_atom = atoms[1];
-                    n.o_f64 = (n.op == RFX_X_FDIV) || n.l_f64 || n.r_f64;
+                    n.o_f64 = rfx_xop_result_f64(n.op, n.l_f64, n.r_f64);
                 }
                 x.out_f64 = x.ops[x.nops - 1].o_f64;
                 int xi = 0;
@@ -598,7 +598,7 @@ int rfx_plan_build(Plan *P, const rfx_pred_t *preds, int npred, int logic, const
                 q->col = ci;
                 q->f64 = (a->col_type == RFX_F64);
             } else {
-                RFX_REQUIRE(a->xop >= RFX_X_ADD && a->xop <= RFX_X_FDIV, RFX_EINVAL, "bad expression operator");
+                RFX_REQUIRE(a->xop >= RFX_X_ADD && a->xop <= RFX_X_MOD, RFX_EINVAL, "bad expression operator");
                 RFX_REQUIRE(a->xrhs_type == RFX_I64 || a->xrhs_type == RFX_F64, RFX_EINVAL, "expression operand type must be i64 or f64");
                 RFX_REQUIRE(a->kind != RFX_AGG_FIRST, RFX_EINVAL, "first of an expression is not supported");
                 PlanExpr x;
@@ -622,7 +622,7 @@ int rfx_plan_build(Plan *P, const rfx_pred_t *preds, int npred, int logic, const
                 n.r_f64 = swap ? (a->col_type == RFX_F64) : (a->xrhs_type == RFX_F64);
                 n.l_atom = (swap && oc < 0) ? atom : 0;
                 n.r_atom = (!swap && oc < 0) ? atom : 0;
-                n.o_f64 = (a->xop == RFX_X_FDIV) || n.l_f64 || n.r_f64;
+                n.o_f64 = rfx_xop_result_f64(a->xop, n.l_f64, n.r_f64);
                 x.out_f64 = n.o_f64;
                 int xi = 0;
                 for (; xi < P->nx; xi++)

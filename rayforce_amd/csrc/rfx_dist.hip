@@ -31,6 +31,8 @@ struct RcclApi {
     ncclResult_t (*GetUniqueId)(ncclUniqueId *);
     ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int);
     ncclResult_t (*CommDestroy)(ncclComm_t);
+    ncclResult_t (*CommCount)(const ncclComm_t, int *);
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int *);
     ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t);
     ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t);
     ncclResult_t (*GroupStart)(void);
@@ -56,6 +58,8 @@ static int rccl_bind(void) {
     }
     RFX_SYM(GetUniqueId, "ncclGetUniqueId");
     RFX_SYM(CommInitRank, "ncclCommInitRank");
+    RFX_SYM(CommCount, "ncclCommCount");
+    RFX_SYM(CommUserRank, "ncclCommUserRank");
     RFX_SYM(CommDestroy, "ncclCommDestroy");
     RFX_SYM(AllReduce, "ncclAllReduce");
     RFX_SYM(AllGather, "ncclAllGather");
@@ -116,8 +120,15 @@ extern "C" int rfx_dist_finalize(rfx_ctx_t *c) {
 
 extern "C" int rfx_dist_world(rfx_ctx_t *c, int *world, int *rank) {
     RFX_REQUIRE(c, RFX_EINVAL, "ctx is NULL");
-    if (world) *world = c->comm ? c->world : 1;
-    if (rank) *rank = c->comm ? c->rank : 0;
+    if (world) *world = 1;
+    if (rank) *rank = 0;
+    if (c->comm) { // what the COMMUNICATOR says (ncclCommCount / ncclCommUserRank), not what the caller passed to rfx_dist_init
+        int w = 0, r = 0;
+        RFX_NCCL_CHECK(g_nccl.CommCount((ncclComm_t)c->comm, &w));
+        RFX_NCCL_CHECK(g_nccl.CommUserRank((ncclComm_t)c->comm, &r));
+        if (world) *world = w;
+        if (rank) *rank = r;
+    }
     return RFX_OK;
 }
 

@@ -46,9 +46,9 @@ static struct {
     /* the host's own built-ins, for recognising function objects inside parsed expressions and for delegation */
     void *f[32];
 } H;
-enum { F_SUM, F_AVG, F_MIN, F_MAX, F_COUNT, F_FIRST, F_EQ, F_NE, F_LT, F_GT, F_LE, F_GE, F_AND, F_OR, F_SELECT, F_ADD, F_SUB, F_MUL, F_FDIV, F_XBAR, F_LJ, F_IJ, F_UPDATE, F_TAKE, F_N };
+enum { F_SUM, F_AVG, F_MIN, F_MAX, F_COUNT, F_FIRST, F_EQ, F_NE, F_LT, F_GT, F_LE, F_GE, F_AND, F_OR, F_SELECT, F_ADD, F_SUB, F_MUL, F_FDIV, F_DIV, F_MOD, F_XBAR, F_LJ, F_IJ, F_UPDATE, F_TAKE, F_N };
 static const char *HOST_FN[F_N] = {"ray_sum", "ray_avg", "ray_min", "ray_max", "ray_count", "ray_first", "ray_eq",  "ray_ne",  "ray_lt",  "ray_gt",
-                                   "ray_le",  "ray_ge",  "ray_and", "ray_or",  "ray_select", "ray_add",  "ray_sub", "ray_mul", "ray_fdiv", "ray_xbar",
+                                   "ray_le",  "ray_ge",  "ray_and", "ray_or",  "ray_select", "ray_add",  "ray_sub", "ray_mul", "ray_fdiv", "ray_div", "ray_mod", "ray_xbar",
                                    "ray_left_join", "ray_inner_join", "ray_update", "ray_take"};
 /* xbar is recognised inside `by:` only; the standalone object model still needs a distinct function object for it:
  * this stub is never called by this library. */
@@ -66,7 +66,8 @@ int rfx_host_bind(void) {
     OUR_FN[F_COUNT] = (void *)rfx_count; OUR_FN[F_FIRST] = (void *)rfx_first; OUR_FN[F_EQ] = (void *)rfx_eq; OUR_FN[F_NE] = (void *)rfx_ne;
     OUR_FN[F_LT] = (void *)rfx_lt; OUR_FN[F_GT] = (void *)rfx_gt; OUR_FN[F_LE] = (void *)rfx_le; OUR_FN[F_GE] = (void *)rfx_ge;
     OUR_FN[F_AND] = (void *)rfx_and; OUR_FN[F_OR] = (void *)rfx_or; OUR_FN[F_SELECT] = (void *)rfx_select;
-    OUR_FN[F_ADD] = (void *)rfx_add; OUR_FN[F_SUB] = (void *)rfx_sub; OUR_FN[F_MUL] = (void *)rfx_mul; OUR_FN[F_FDIV] = (void *)rfx_div; OUR_FN[F_XBAR] = (void *)x_stub_xbar;
+    OUR_FN[F_ADD] = (void *)rfx_add; OUR_FN[F_SUB] = (void *)rfx_sub; OUR_FN[F_MUL] = (void *)rfx_mul; OUR_FN[F_FDIV] = (void *)rfx_div; OUR_FN[F_DIV] = (void *)rfx_floordiv; OUR_FN[F_MOD] = (void *)rfx_mod;
+    OUR_FN[F_XBAR] = (void *)x_stub_xbar;
     OUR_FN[F_LJ] = (void *)rfx_left_join; OUR_FN[F_IJ] = (void *)rfx_inner_join; OUR_FN[F_UPDATE] = (void *)rfx_update;
     void *v = dlsym(RTLD_DEFAULT, "vector"), *t = dlsym(RTLD_DEFAULT, "table"), *e = dlsym(RTLD_DEFAULT, "eval");
     void *rs = dlsym(RTLD_DEFAULT, "ray_select"), *nu = dlsym(RTLD_DEFAULT, "__NULL_OBJ");
@@ -112,7 +113,7 @@ obj_p rfx_host_fn(const char *name) {
         {">", F_GT, RFX_TYPE_BINARY, RFX_FN_ATOMIC}, {"<=", F_LE, RFX_TYPE_BINARY, RFX_FN_ATOMIC}, {">=", F_GE, RFX_TYPE_BINARY, RFX_FN_ATOMIC},
         {"and", F_AND, RFX_TYPE_VARY, RFX_FN_SPECIAL_FORM}, {"or", F_OR, RFX_TYPE_VARY, RFX_FN_SPECIAL_FORM}, {"select", F_SELECT, RFX_TYPE_UNARY, 0},
         {"+", F_ADD, RFX_TYPE_BINARY, RFX_FN_ATOMIC}, {"-", F_SUB, RFX_TYPE_BINARY, RFX_FN_ATOMIC}, {"*", F_MUL, RFX_TYPE_BINARY, RFX_FN_ATOMIC},
-        {"div", F_FDIV, RFX_TYPE_BINARY, RFX_FN_ATOMIC}, {"xbar", F_XBAR, RFX_TYPE_BINARY, RFX_FN_ATOMIC}, {"update", F_UPDATE, RFX_TYPE_UNARY, 0}};
+        {"div", F_FDIV, RFX_TYPE_BINARY, RFX_FN_ATOMIC}, {"/", F_DIV, RFX_TYPE_BINARY, RFX_FN_ATOMIC}, {"%", F_MOD, RFX_TYPE_BINARY, RFX_FN_ATOMIC}, {"xbar", F_XBAR, RFX_TYPE_BINARY, RFX_FN_ATOMIC}, {"update", F_UPDATE, RFX_TYPE_UNARY, 0}};
     rfx_host_bind();
     for (size_t i = 0; i < sizeof(T) / sizeof(T[0]); i++)
         if (strcmp(T[i].n, name) == 0) {
@@ -254,8 +255,12 @@ static void res_free(int i) {
     g_res_bytes -= g_res[i].bytes;
     g_res[i] = g_res[--g_nres];
 }
+static void op_begin(void);
+static void op_end(void);
 void rfx_cache_clear(void) {
+    op_begin();
     while (g_nres) res_free(g_nres - 1);
+    op_end();
 }
 int64_t rfx_cache_bytes(void) { return (int64_t)g_res_bytes; }
 
@@ -267,14 +272,43 @@ static size_t cache_budget(void) {
 /* per-call device scratch (temporaries of the operator call in flight): released by op_end() */
 static void *g_optmp[64];
 static int g_noptmp;
+/* ONE lock around everything this file keeps between calls (residency cache, per-operator scratch lists, the device context): the reference
+ * calls built-ins from its pool workers, each with its own VM (core/pool.c:168-219), so two rfx_* calls may arrive at once.  An operator
+ * holds the lock from op_begin to op_end; a thread that re-enters (the host evaluating `from:` calls an rfx_* built-in) counts depth
+ * instead of locking twice.  Calls BACK into the host that may fan out to its pool (a delegated select / update / join / fold) run with
+ * the lock released -- after the operator has let go of its device scratch -- so that workers calling rfx_* are not shut out. */
+static pthread_mutex_t g_op_lock = PTHREAD_MUTEX_INITIALIZER;
+static __thread int t_op_depth;
 static void op_begin(void) {
+    if (t_op_depth++ == 0) pthread_mutex_lock(&g_op_lock);
     g_epoch++;
     g_stat[ST_OPS]++;
 }
-static void op_end(void) {
+static void op_scratch_release(void) {
     for (int i = 0; i < g_noptmp; i++) rfx_hip_free(g_ctx, g_optmp[i]);
     g_noptmp = 0;
 }
+static void op_end(void) {
+    if (t_op_depth == 1) op_scratch_release(); /* (a nested operator leaves the outer one's scratch alone) */
+    if (--t_op_depth == 0) pthread_mutex_unlock(&g_op_lock);
+}
+/* around a call into the host that may run for long / on other threads: returns the depth to hand back to host_call_end */
+static int host_call_begin(void) {
+    const int d = t_op_depth;
+    if (d > 0) {
+        if (d == 1) op_scratch_release();
+        t_op_depth = 0;
+        pthread_mutex_unlock(&g_op_lock);
+    }
+    return d;
+}
+static void host_call_end(int d) {
+    if (d > 0) {
+        pthread_mutex_lock(&g_op_lock);
+        t_op_depth = d;
+    }
+}
+#define HOST_CALL(call) ({ const int _hd = host_call_begin(); obj_p _hr = (call); host_call_end(_hd); _hr; })
 /* device copy of a vector that lives for this call only (never cached) */
 static int transient(obj_p v, const void **dev) {
     const int esz = (v->type == RFX_TYPE_B8) ? 1 : 8;
@@ -690,7 +724,7 @@ static obj_p delegate_select(obj_p dict, const char *why) {
     g_last_gpu = 0;
     snprintf(g_err, sizeof(g_err), "rfx_select: handed to the host (%s)", why); /* rfx_ops_last_error(): why the last query was delegated */
     if (getenv("RFX_TRACE")) fprintf(stderr, "[rfx] select delegated: %s\n", why);
-    if (H.bound == 1 && H.f[F_SELECT]) return ((rfx_unary_f)H.f[F_SELECT])(dict);
+    if (H.bound == 1 && H.f[F_SELECT]) return HOST_CALL(((rfx_unary_f)H.f[F_SELECT])(dict));
     char b[300];
     snprintf(b, sizeof(b), "rfx_select: query shape not covered by the MI355X path (%s) and no host ray_select to delegate to", why);
     return fail(b);
@@ -701,7 +735,7 @@ static obj_p delegate_select(obj_p dict, const char *why) {
 static int build_xnodes(obj_p tab, obj_p e, rfx_xnode_t *nodes, int *nn, int *ncols, const char **why) {
     if (e->type != RFX_TYPE_LIST || e->len != 3) { *why = "expression is not (op x y)"; return -1; }
     int xf = fn_id(RFX_AS_LIST(e)[0]);
-    if (xf < F_ADD || xf > F_FDIV) { *why = "expression operator is not + - * div"; return -1; }
+    if (xf < F_ADD || xf > F_MOD) { *why = "expression operator is not + - * div / %"; return -1; }
     rfx_xnode_t node;
     memset(&node, 0, sizeof(node));
     node.op = RFX_X_ADD + (xf - F_ADD);
@@ -1349,7 +1383,12 @@ static obj_p select_impl(obj_p dict) {
         g_last_gpu = 1;
         goto done;
     }
-out:
+out: /* hand the query to the host -- with this call's device scratch released first (the host may fan out to its pool: HOST_CALL) */
+    for (int i = 0; i < ntmp; i++) rfx_hip_free(g_ctx, tmp[i]);
+    ntmp = 0;
+    qtmp_release();
+    if (parted) parted_view_release();
+    parted = 0;
     res = delegate_select(dict, why ? why : "unsupported");
 done:
     for (int i = 0; i < ntmp; i++) rfx_hip_free(g_ctx, tmp[i]);
@@ -1393,7 +1432,7 @@ rfx_obj_p rfx_select(rfx_obj_p dict) {
  * max / count / first under a flat `where:`.  Value and column types must agree (the reference also casts f64 into i64 columns:
  * delegated).  Anything else is the host's ray_update. */
 static obj_p delegate_update(obj_p dict, const char *why) {
-    if (H.bound == 1 && H.f[F_UPDATE]) return ((rfx_unary_f)H.f[F_UPDATE])(dict);
+    if (H.bound == 1 && H.f[F_UPDATE]) return HOST_CALL(((rfx_unary_f)H.f[F_UPDATE])(dict));
     char b[300];
     snprintf(b, sizeof(b), "rfx_update: shape not covered by the MI355X path (%s) and no host ray_update to delegate to", why);
     return fail(b);
@@ -1591,6 +1630,9 @@ static obj_p update_impl(obj_p dict) {
         goto done;
     }
 out:
+    for (int i = 0; i < ntmp; i++) rfx_hip_free(g_ctx, tmp[i]);
+    ntmp = 0;
+    qtmp_release();
     res = delegate_update(dict, why ? why : "unsupported");
 done:
     for (int i = 0; i < nmap && i < RFX_MAX_AGGS; i++)
@@ -1613,7 +1655,7 @@ static obj_p cmp_impl(int op, obj_p x, obj_p y) {
     rfx_host_bind();
     if (!x || !y) return fail("cmp: null argument");
     if (!(x->type > 0 && col_ctype(x) && (y->type == -RFX_TYPE_I64 || y->type == -RFX_TYPE_F64 || (y->type > 0 && col_ctype(y))))) {
-        if (H.bound == 1 && H.f[F_EQ + op]) return ((rfx_binary_f)H.f[F_EQ + op])(x, y);
+        if (H.bound == 1 && H.f[F_EQ + op]) return HOST_CALL(((rfx_binary_f)H.f[F_EQ + op])(x, y));
         return fail("cmp: only i64/f64 column (x) atom|column runs on the MI355X path");
     }
     if (y->type > 0 && y->len != x->len) return fail("length"); /* err_length, core/cmp.c:633-640 */
@@ -1646,14 +1688,14 @@ static obj_p cmp_op(int op, obj_p x, obj_p y) {
     op_end();
     return r;
 }
-/* ray_add / ray_sub / ray_mul / ray_fdiv over an i64 / f64 vector and a vector or atom (binop_map, core/math.c:2280-2345) */
+/* ray_add / ray_sub / ray_mul / ray_fdiv / ray_div / ray_mod over an i64 / f64 vector and a vector or atom (binop_map, core/math.c:2280-2345) */
 static obj_p arith_impl(int xop, int fidx, obj_p x, obj_p y) {
     rfx_host_bind();
     if (!x || !y) return fail("arith: null argument");
     const int xv = x->type > 0 && col_ctype(x) && x->type != RFX_TYPE_SYMBOL, yv = y->type > 0 && col_ctype(y) && y->type != RFX_TYPE_SYMBOL;
     const int xa = x->type == -RFX_TYPE_I64 || x->type == -RFX_TYPE_F64, ya = y->type == -RFX_TYPE_I64 || y->type == -RFX_TYPE_F64;
     if (!((xv && (yv || ya)) || (xa && yv))) {
-        if (H.bound == 1 && H.f[fidx]) return ((rfx_binary_f)H.f[fidx])(x, y);
+        if (H.bound == 1 && H.f[fidx]) return HOST_CALL(((rfx_binary_f)H.f[fidx])(x, y));
         return fail("arith: only i64/f64 vector (x) vector|atom runs on the MI355X path");
     }
     if (xv && yv && x->len != y->len) return fail("length");
@@ -1698,6 +1740,8 @@ rfx_obj_p rfx_add(rfx_obj_p x, rfx_obj_p y) { return arith_op(RFX_X_ADD, F_ADD, 
 rfx_obj_p rfx_sub(rfx_obj_p x, rfx_obj_p y) { return arith_op(RFX_X_SUB, F_SUB, x, y); }
 rfx_obj_p rfx_mul(rfx_obj_p x, rfx_obj_p y) { return arith_op(RFX_X_MUL, F_MUL, x, y); }
 rfx_obj_p rfx_div(rfx_obj_p x, rfx_obj_p y) { return arith_op(RFX_X_FDIV, F_FDIV, x, y); }
+rfx_obj_p rfx_floordiv(rfx_obj_p x, rfx_obj_p y) { return arith_op(RFX_X_DIV, F_DIV, x, y); } /* the reference's `/` (ray_div) */
+rfx_obj_p rfx_mod(rfx_obj_p x, rfx_obj_p y) { return arith_op(RFX_X_MOD, F_MOD, x, y); }      /* `%` (ray_mod) */
 
 rfx_obj_p rfx_eq(rfx_obj_p x, rfx_obj_p y) { return cmp_op(RFX_EQ, x, y); }
 rfx_obj_p rfx_ne(rfx_obj_p x, rfx_obj_p y) { return cmp_op(RFX_NE, x, y); }
@@ -1923,7 +1967,9 @@ static obj_p join_impl(int inner, obj_p *x, int64_t n) {
         goto done;
     }
 out:
-    if (H.bound == 1 && H.f[fidx]) res = ((rfx_vary_f)H.f[fidx])(x, n);
+    for (int i = 0; i < ntmp; i++) rfx_hip_free(g_ctx, tmp[i]);
+    ntmp = 0;
+    if (H.bound == 1 && H.f[fidx]) res = HOST_CALL(((rfx_vary_f)H.f[fidx])(x, n));
     else {
         char b[320];
         snprintf(b, sizeof(b), "join: shape not covered by the MI355X path (%s) and no host function to delegate to", why ? why : "unsupported");
@@ -2062,7 +2108,9 @@ static obj_p fold_mapgroup(int f, int kind, obj_p x) {
         goto done;
     }
 out:
-    if (H.bound == 1 && H.f[f]) res = ((rfx_unary_f)H.f[f])(x);
+    for (int i = 0; i < ntmp; i++) rfx_hip_free(g_ctx, tmp[i]);
+    ntmp = 0;
+    if (H.bound == 1 && H.f[f]) res = HOST_CALL(((rfx_unary_f)H.f[f])(x));
     else {
         char b[256];
         snprintf(b, sizeof(b), "aggregate over a MAPGROUP pair: not covered by the MI355X path (%s) and no host function to delegate to", why ? why : "unsupported");
@@ -2154,7 +2202,7 @@ static obj_p fold_impl(int f, int kind, obj_p x) {
          * the filtered vector the reference would materialise (filter_collect) never exists on the host */
         obj_p val = RFX_AS_LIST(x)[0], ids = RFX_AS_LIST(x)[1];
         if (!(val->type > 0 && col_ctype(val) && val->type != RFX_TYPE_SYMBOL) || ids->type != RFX_TYPE_I64) {
-            if (H.bound == 1 && H.f[f]) return ((rfx_unary_f)H.f[f])(x);
+            if (H.bound == 1 && H.f[f]) return HOST_CALL(((rfx_unary_f)H.f[f])(x));
             return fail("aggregate: only (i64/f64 vector, i64 ids) MAPFILTER pairs run on the MI355X path");
         }
         if (ensure_ctx() != RFX_OK) return fail_hip("no usable MI355X");
@@ -2175,7 +2223,7 @@ static obj_p fold_impl(int f, int kind, obj_p x) {
         return value_atom(&v);
     }
     if (!(x->type > 0 && col_ctype(x) && x->type != RFX_TYPE_SYMBOL)) {
-        if (H.bound == 1 && H.f[f]) return ((rfx_unary_f)H.f[f])(x);
+        if (H.bound == 1 && H.f[f]) return HOST_CALL(((rfx_unary_f)H.f[f])(x));
         return fail("aggregate: only i64/f64 vectors run on the MI355X path");
     }
     if (ensure_ctx() != RFX_OK) return fail_hip("no usable MI355X");
@@ -2204,7 +2252,14 @@ rfx_obj_p rfx_count(rfx_obj_p x) { return fold_op(F_COUNT, RFX_AGG_COUNT, x); }
 rfx_obj_p rfx_first(rfx_obj_p x) { return fold_op(F_FIRST, RFX_AGG_FIRST, x); }
 
 /* ------------------------------------------------------------------------------------------------ residency verbs */
+static obj_p pin_impl(obj_p x, int pin);
 static obj_p pin_op(obj_p x, int pin) {
+    op_begin();
+    obj_p r = pin_impl(x, pin);
+    op_end();
+    return r;
+}
+static obj_p pin_impl(obj_p x, int pin) {
     rfx_host_bind();
     if (!x) return fail("pin: null argument");
     if (ensure_ctx() != RFX_OK) return fail_hip("no usable MI355X");
@@ -2250,10 +2305,12 @@ rfx_obj_p rfx_unpin(rfx_obj_p x) { return pin_op(x, 0); }
 rfx_obj_p rfx_invalidate(rfx_obj_p x) {
     rfx_host_bind();
     if (!x) return fail("invalidate: null argument");
+    op_begin();
     if (x->type == RFX_TYPE_TABLE) {
         obj_p cols = RFX_AS_LIST(x)[1];
         for (int64_t i = 0; i < cols->len; i++) invalidate_payload(RFX_AS_LIST(cols)[i]);
     } else invalidate_payload(x);
+    op_end();
     return H.clone(x);
 }
 /* (rfx_stats 0): counters since load as an I64 vector -- [selects answered on the GPU, selects handed back to the host's

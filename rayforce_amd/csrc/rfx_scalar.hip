@@ -148,17 +148,18 @@ extern "C" int rfx_agg_input_type(const rfx_agg_t *a) {
         const int n = a->nxnodes < RFX_MAX_XNODES ? a->nxnodes : RFX_MAX_XNODES;
         for (int i = 0; i < n; i++) {
             const rfx_xoperand_t *o[2] = {&a->xnodes[i].l, &a->xnodes[i].r};
-            int f = a->xnodes[i].op == RFX_X_FDIV;
+            int of[2];
             for (int j = 0; j < 2; j++) {
-                if (o[j]->kind == RFX_XK_NODE) f |= (o[j]->node >= 0 && o[j]->node < i) ? f64[o[j]->node] : 0;
-                else f |= o[j]->type == RFX_F64;
+                if (o[j]->kind == RFX_XK_NODE) of[j] = (o[j]->node >= 0 && o[j]->node < i) ? f64[o[j]->node] : 0;
+                else of[j] = o[j]->type == RFX_F64;
             }
-            f64[i] = f;
+            f64[i] = rfx_xop_result_f64(a->xnodes[i].op, of[0], of[1]);
         }
         return f64[n - 1] ? RFX_F64 : RFX_I64;
     }
     if (a->xop == RFX_X_NONE) return a->col_type;
-    return (a->xop == RFX_X_FDIV || a->col_type == RFX_F64 || a->xrhs_type == RFX_F64) ? RFX_F64 : RFX_I64;
+    const int cf = a->col_type == RFX_F64, of = a->xrhs_type == RFX_F64, swap = (a->xflags & RFX_XF_SWAP) != 0;
+    return rfx_xop_result_f64(a->xop, swap ? of : cf, swap ? cf : of) ? RFX_F64 : RFX_I64;
 }
 
 // ---------------- host-side partial algebra ----------------

@@ -432,6 +432,8 @@ class Engine:
                     return self._arg_f64(x, table)
                 x = self._resolve(x, table) if isinstance(x, (str, torch.Tensor)) else x
                 return x.dtype == torch.float64 if isinstance(x, torch.Tensor) else isinstance(x, float)
+            if col[0] == "/":  # ray_div keeps the left operand's type (infer_div_type, core/math.c:149-188)
+                return f(col[1])
             return col[0] == "div" or f(col[1]) or f(col[2])
         return self._resolve(col, table).dtype == torch.float64
 

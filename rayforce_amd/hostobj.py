@@ -22,7 +22,7 @@ OPS_PROTOTYPES = {
     "rfx_ops_last_error": (C.c_char_p, []),
     "rfx_select": (C.c_void_p, [C.c_void_p]),
     "rfx_update": (C.c_void_p, [C.c_void_p]),
-    **{f"rfx_{n}": (C.c_void_p, [C.c_void_p, C.c_void_p]) for n in ("eq", "ne", "lt", "gt", "le", "ge", "at", "add", "sub", "mul", "div")},
+    **{f"rfx_{n}": (C.c_void_p, [C.c_void_p, C.c_void_p]) for n in ("eq", "ne", "lt", "gt", "le", "ge", "at", "add", "sub", "mul", "div", "floordiv", "mod")},
     "rfx_and": (C.c_void_p, [C.POINTER(C.c_void_p), C.c_int64]),
     "rfx_or": (C.c_void_p, [C.POINTER(C.c_void_p), C.c_int64]),
     "rfx_left_join": (C.c_void_p, [C.POINTER(C.c_void_p), C.c_int64]),

@@ -49,6 +49,9 @@ QUERIES = [
     # six key columns (the H2O Q7 shape) on the row-hash path, more outputs than proof aggregates would have left room for
     ("q24", "{s: (sum v) c: (count a) mx: (max a) mn: (min v) av: (avg v) from: t by: {k1: k1 k2: k2 k3: k3 w1: w1 w2: w2 k: k}}",
      ["k1", "k2", "k3", "w1", "w2", "k", "s", "c", "mx", "mn", "av"]),
+    # `/` (ray_div: floor division, left operand's type) and `%` (ray_mod) inside aggregates and predicates
+    ("q25", "{q: (sum (/ a k2)) r: (max (% a 7)) f: (sum (% v 0.25)) d: (min (/ a 2.5)) from: t where: (< a 800000)}", ["q", "r", "f", "d"]),
+    ("q26", "{s: (sum (% a (+ k3 30))) m: (max (/ v 0.125)) from: t where: (== (% a 3) 1) by: k1}", ["k1", "s", "m"]),
 ]
 
 

@@ -166,3 +166,32 @@ def test_hash_primitives(eng):
     assert G.has("hash_index_u64")  # pinned by tests/golden/hash_index_harness.c (the reference's own `inline` header function)
     L.check(eng.lib.rfx_hip_hash_mix_u64(eng._ctx, d.data_ptr(), len(keys), 0x9ddfea08eb382d69, out.data_ptr()))
     assert np.array_equal(out.cpu().numpy().view(np.uint64), G.arr("hash_index_u64"))
+
+
+# ---------------------------------------------------------------- `/` (ray_div) and `%` (ray_mod): SURVEY 8f-3, second half
+import divmod_cases as DM  # noqa: E402
+
+
+def test_div_mod_truth_tables_as_columns(eng):
+    """The reference's `/` and `%` on the special-value vectors (32 tables) through rfx_hip_eval_expr: bit for bit (floor and the fused
+    remainder are exact operations: no tolerance)."""
+    for op, tag, l, r, want in DM.truth_tables():
+        t, e = {}, [op, l, r]
+        for i, x in enumerate((l, r)):
+            if isinstance(x, np.ndarray):
+                t[f"c{i}"] = eng.column(x)
+                e[1 + i] = f"c{i}"
+        DM.same(eng.eval_expr(tuple(e), t).cpu().numpy(), want, (op, tag))
+
+
+@pytest.mark.parametrize("case", list(DM.query_cases()), ids=lambda c: c[0])
+def test_aggregates_over_div_mod(eng, case):
+    _, (n, seed, keys), w, grouped, want = case
+    q = {"from": {k: eng.column(v) for k, v in DM.gen_table(n, seed, keys).items()}, **DM.XQ}
+    if w:
+        q["where"] = w
+    if grouped:
+        q["by"] = "k"
+    got = eng.select(q)
+    for o in want:
+        DM.same(got[o].cpu().numpy(), want[o], o, sums=DM.XQ.get(o, ("", ""))[0] in ("sum", "avg"))

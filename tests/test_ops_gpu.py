@@ -530,3 +530,49 @@ def test_sampled_scope_at_the_operator_boundary(ops):
                 assert stats()[9] - s1[9] == 1  # the first sampled scope was reported too small, the query ran again -- and that key column is not sampled a second time
         finally:
             host["k"][spot] = keep
+
+
+def test_two_threads_hammer_the_operator_boundary(ops):
+    """The reference calls built-ins from its pool workers (core/pool.c:168-219): two threads calling rfx_select / rfx_sum / rfx_lt at once
+    must each get their own right answer (one lock around the residency cache, the per-call scratch and the device context).  Objects
+    are built up front on the main thread (the standalone host model's intern table is not the thing under test)."""
+    import threading
+    n = 200_003
+    hosts = [host_table(n, keys=300, seed=s) for s in (0, 7)]
+    tabs = [H.table(h) for h in hosts]
+    queries = [{"where": ("<", "a", 400_000), "by": "k", "s": ("sum", "v"), "c": ("count", "a")}, {"where": (">", "v", 0.25), "s": ("sum", "a"), "m": ("max", "v")}]
+    dicts = [[H.select_dict(q, t) for q in queries] for t in tabs]
+    vecs = [H.vector(h["a"]) for h in hosts]
+    want_sel = [[rfo.select({"from": h, **q}) for q in queries] for h in hosts]
+    want_sum = [int(np.sum(h["a"])) for h in hosts]
+    errors = []
+
+    def work(t):
+        try:
+            for it in range(60):
+                for qi in range(2):
+                    r = ops.rfx_select(dicts[t][qi])
+                    assert r and not H.is_error(r), H.error_text(r)
+                    got = H.table_to_numpy(r)
+                    ops.rfx_host_drop(r)
+                    for name, w in want_sel[t][qi].items():
+                        g = got[name]
+                        if w.dtype == np.float64:
+                            assert np.allclose(g, w, rtol=1e-9, atol=0), (t, qi, name, it)
+                        else:
+                            assert np.array_equal(g, w), (t, qi, name, it)
+                r = ops.rfx_sum(vecs[t])
+                assert r and not H.is_error(r)
+                assert int(C.c_int64.from_address(r + 8).value) == want_sum[t], (t, it)  # (an atom keeps its value where a vector keeps its length)
+                ops.rfx_host_drop(r)
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    th = [threading.Thread(target=work, args=(t,)) for t in range(2)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    for o in [d for dd in dicts for d in dd] + vecs + tabs:
+        ops.rfx_host_drop(o)
+    assert not errors, errors[:3]

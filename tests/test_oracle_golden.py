@@ -215,3 +215,30 @@ def test_pool_chunking_policy():
     assert L.rfo_pool_split_by_mem(16383, 0, 8) == 1 and L.rfo_pool_split_by_mem(16384, 0, 8) == 8
     assert L.rfo_pool_split_by_mem(10**7, 10**6, 8) == 8 and L.rfo_pool_split_by_mem(10**7, 10**7, 8) == 1  # 64 MB budget
     assert L.rfo_pool_chunk_aligned(25001, 8, 8) == 3584 and L.rfo_pool_chunk_aligned(100, 1, 8) == 100
+
+
+# ---------------------------------------------------------------- `/` (ray_div) and `%` (ray_mod): SURVEY 8f-3, second half
+import divmod_cases as DM  # noqa: E402
+
+
+def test_div_mod_truth_tables():
+    """Floor division keeping the left operand's type, the remainder with the divisor's sign, zero divisors and nulls -> null, i64 / f64 ->
+    i64 through f64_to_i64, the fused x - q * y of the reference's build: 32 tables from the compiled reference, bit for bit."""
+    n = 0
+    for op, tag, l, r, want in DM.truth_tables():
+        DM.same(rfo.binop(op, l, r), want, (op, tag))
+        n += 1
+    assert n == 32
+
+
+@pytest.mark.parametrize("case", list(DM.query_cases()), ids=lambda c: c[0])
+def test_aggregates_over_div_mod(case):
+    _, (n, seed, keys), w, grouped, want = case
+    q = {"from": DM.gen_table(n, seed, keys), **DM.XQ}
+    if w:
+        q["where"] = w
+    if grouped:
+        q["by"] = "k"
+    got = rfo.select(q)
+    for o in want:
+        DM.same(got[o], want[o], o, sums=DM.XQ.get(o, ("", ""))[0] in ("sum", "avg"))
