@@ -93,9 +93,7 @@ enum { RFX_X_NONE = 0, RFX_X_ADD = 1, RFX_X_SUB = 2, RFX_X_MUL = 3, RFX_X_FDIV =
  * result takes the LEFT operand's type (infer_div_type, core/math.c:149-188: i64 / f64 -> i64 through f64_to_i64(floor(x / y)));
  * RFX_X_MOD = `%` (ray_mod, :1449-1530): x - floor(x / y) * y, i64 only when both sides are (infer_mod_type, :190-220).  A zero
  * divisor or a null on either side gives null.  Result element type of one operation: */
-static inline int rfx_xop_result_f64(int op, int l_f64, int r_f64) {
-    return op == RFX_X_FDIV ? 1 : (op == RFX_X_DIV ? l_f64 : (l_f64 || r_f64));
-}
+#define RFX_XOP_RESULT_F64(op, l_f64, r_f64) ((op) == RFX_X_FDIV ? 1 : ((op) == RFX_X_DIV ? ((l_f64) != 0) : ((l_f64) || (r_f64))))
 enum { RFX_XF_SWAP = 1 }; /* operands swapped: input = rhs OP column (for `(- 2 a)`, `(div 1 a)`) */
 
 /* Deeper expressions -- `(sum (* price (- 1 disc)))`, up to RFX_MAX_XNODES operations -- are given as a node list in evaluation

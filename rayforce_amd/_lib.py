@@ -70,7 +70,7 @@ def agg_input_type(a: "Agg") -> int:
     """rfx_agg_input_type: the element type the aggregate folds."""
     if a.xop == 0 and a.nxnodes == 0:
         return a.col_type
-    return load_library().rfx_agg_input_type(C.byref(a))  # the library's own rule (rfx_xop_result_f64: `/` keeps the left operand's type)
+    return load_library().rfx_agg_input_type(C.byref(a))  # the library's own rule (RFX_XOP_RESULT_F64: `/` keeps the left operand's type)
 
 
 class Partial(C.Structure):

@@ -575,7 +575,7 @@ int rfx_plan_build(Plan *P, const rfx_pred_t *preds, int npred, int logic, const
                     n.l_idx = idx[0]; n.r_idx = idx[1];
                     n.l_f64 = f64[0]; n.r_f64 = f64[1];
                     n.l_atom = atoms[0]; n.r_atom = atoms[1];
-                    n.o_f64 = rfx_xop_result_f64(n.op, n.l_f64, n.r_f64);
+                    n.o_f64 = RFX_XOP_RESULT_F64(n.op, n.l_f64, n.r_f64);
                 }
                 x.out_f64 = x.ops[x.nops - 1].o_f64;
                 int xi = 0;
@@ -622,7 +622,7 @@ int rfx_plan_build(Plan *P, const rfx_pred_t *preds, int npred, int logic, const
                 n.r_f64 = swap ? (a->col_type == RFX_F64) : (a->xrhs_type == RFX_F64);
                 n.l_atom = (swap && oc < 0) ? atom : 0;
                 n.r_atom = (!swap && oc < 0) ? atom : 0;
-                n.o_f64 = rfx_xop_result_f64(a->xop, n.l_f64, n.r_f64);
+                n.o_f64 = RFX_XOP_RESULT_F64(a->xop, n.l_f64, n.r_f64);
                 x.out_f64 = n.o_f64;
                 int xi = 0;
                 for (; xi < P->nx; xi++)

@@ -153,13 +153,13 @@ extern "C" int rfx_agg_input_type(const rfx_agg_t *a) {
                 if (o[j]->kind == RFX_XK_NODE) of[j] = (o[j]->node >= 0 && o[j]->node < i) ? f64[o[j]->node] : 0;
                 else of[j] = o[j]->type == RFX_F64;
             }
-            f64[i] = rfx_xop_result_f64(a->xnodes[i].op, of[0], of[1]);
+            f64[i] = RFX_XOP_RESULT_F64(a->xnodes[i].op, of[0], of[1]);
         }
         return f64[n - 1] ? RFX_F64 : RFX_I64;
     }
     if (a->xop == RFX_X_NONE) return a->col_type;
     const int cf = a->col_type == RFX_F64, of = a->xrhs_type == RFX_F64, swap = (a->xflags & RFX_XF_SWAP) != 0;
-    return rfx_xop_result_f64(a->xop, swap ? of : cf, swap ? cf : of) ? RFX_F64 : RFX_I64;
+    return RFX_XOP_RESULT_F64(a->xop, swap ? of : cf, swap ? cf : of) ? RFX_F64 : RFX_I64;
 }
 
 // ---------------- host-side partial algebra ----------------

@@ -16,9 +16,9 @@ src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
 dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
 DOMINANT = {"c2": ["k_filter_aggr_plan"], "c2b": ["k_filter_aggr_plan"], "c5": ["k_filter_aggr_plan"], "x6": ["k_filter_aggr_plan"],  # (the prebuilt k_filter_aggr<...> runs once, at a plan's first occurrence)
-            "c3": ["k_chunk_", "k_scope_sample", "k_part_scope_hist", "k_part_hist", "k_part_scatter", "k_part_aggregate", "k_part_colscan", "k_mark_first", "k_group_emit",
+            "c3": ["k_plane_", "k_chunk_", "k_scope_sample", "k_part_scope_hist", "k_part_hist", "k_part_scatter", "k_part_aggregate", "k_part_colscan", "k_mark_first", "k_group_emit",
                    "k_slot_gid", "k_bitmap_counts", "k_fill_u64"],
-            "c3w": ["k_chunk_scatter", "k_chunk_offsets", "k_chunk_place", "k_chunk_aggregate", "k_scope_sample", "k_part_scope_hist", "k_chunk_counts", "k_compact_cols", "k_part_hist", "k_part_scatter", "k_part_aggregate", "k_part_colscan", "k_first_translate",
+            "c3w": ["k_plane_", "k_chunk_scatter", "k_chunk_offsets", "k_chunk_place", "k_chunk_aggregate", "k_scope_sample", "k_part_scope_hist", "k_chunk_counts", "k_compact_cols", "k_part_hist", "k_part_scatter", "k_part_aggregate", "k_part_colscan", "k_first_translate",
                     "k_mark_first", "k_group_emit", "k_slot_gid", "k_bitmap_counts", "k_fill_u64", "k_sel_bitmap"],
             "q1": ["k_part_scope_hist", "k_filter_aggr_plan", "k_group_few",  # (k_group_dense runs once, at the plan's first occurrence, before the plan kernel exists)
                     "k_rank_emit_small", "k_fill_tables", "k_derive", "k_mark_first", "k_group_emit", "k_slot_gid", "k_bitmap_counts", "k_fill_u64", "k_composite"],

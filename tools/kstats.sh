@@ -1,7 +1,7 @@
 #!/bin/bash
 # tools/kstats.sh <workload> <tune-flags> -- per-kernel average durations (rocprofv3 --kernel-trace --stats)
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}; cd /tmp; export TMPDIR=/tmp; rm -rf /tmp/ks
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks -o k -- python $REPO/bench.py --no-cpu-baseline --no-also --workload $1 --steps 5 --tune-flags $2 > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks -o k -- python $REPO/bench.py --no-cpu-baseline --no-also --engine-door --workload $1 --steps 5 --tune-flags $2 > /dev/null 2>&1
 python - <<'PY'
 import csv,glob
 f=glob.glob('/tmp/ks/**/*kernel_stats.csv',recursive=True)[0]

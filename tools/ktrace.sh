@@ -1,7 +1,7 @@
 #!/bin/bash
 # tools/ktrace.sh <workload> <tune-flags> <kernel-substring> -- every dispatch's duration (ms) of the kernels matching the substring, in launch order
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}; cd /tmp; export TMPDIR=/tmp; rm -rf /tmp/kt
-rocprofv3 --kernel-trace --output-format csv -d /tmp/kt -o k -- python $REPO/bench.py --no-cpu-baseline --no-also --workload $1 --steps 2 --warmup 1 --tune-flags $2 > /dev/null 2>&1
+rocprofv3 --kernel-trace --output-format csv -d /tmp/kt -o k -- python $REPO/bench.py --no-cpu-baseline --no-also --engine-door --workload $1 --steps 2 --warmup 1 --tune-flags $2 > /dev/null 2>&1
 python - "$3" <<'PY'
 import csv,glob,sys
 f=glob.glob('/tmp/kt/**/*kernel_trace.csv',recursive=True)[0]

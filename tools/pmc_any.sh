@@ -5,7 +5,7 @@ REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
 for set in "$@"; do
   rm -rf /tmp/pa
-  timeout 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d /tmp/pa -o x -- python $REPO/bench.py --no-cpu-baseline --no-also --workload $W --steps 2 --warmup 1 > /tmp/pa.log 2>&1
+  timeout 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d /tmp/pa -o x -- python $REPO/bench.py --no-cpu-baseline --no-also --engine-door --workload $W --steps 2 --warmup 1 > /tmp/pa.log 2>&1
   f=$(find /tmp/pa -name "*counter_collection.csv" | head -1)
   [ -z "$f" ] && { echo "no output for: $set"; tail -3 /tmp/pa.log; continue; }
   python - "$f" "$K" <<'PY'

@@ -7,7 +7,7 @@ cd /tmp && export TMPDIR=/tmp
 for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" \
            "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM"; do
   rm -rf /tmp/sq_$W
-  timeout 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d /tmp/sq_$W -o $W -- python $REPO/bench.py --no-cpu-baseline --no-also --workload $W --steps 2 --warmup 1 > /tmp/sq_$W.log 2>&1
+  timeout 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d /tmp/sq_$W -o $W -- python $REPO/bench.py --no-cpu-baseline --no-also --engine-door --workload $W --steps 2 --warmup 1 > /tmp/sq_$W.log 2>&1
   f=$(find /tmp/sq_$W -name "*counter_collection.csv" | head -1)
   python - "$f" <<'PY'
 import csv, sys, collections

@@ -10,12 +10,13 @@ mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 WL=${2:-"c2 c2b c3 c3w q2 x6 q1 k9 c5 w2 q7"}   # optional second argument: only these workloads
 for w in $WL; do
+  DOOR="--engine-door"; [ "$w" = "c3w" ] && DOOR=""   # the headline workload: the same command as the bench line (rfx_select leg included)
   rm -rf /tmp/rp_$w
-  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp_$w -o $w -- python $REPO/bench.py --no-cpu-baseline --no-also --workload $w --steps 10 > $OUT/${w}_bench.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp_$w -o $w -- python $REPO/bench.py --no-cpu-baseline --no-also --workload $w $DOOR --steps 10 > $OUT/${w}_bench.log 2>&1
   f=$(find /tmp/rp_$w -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $OUT/${w}_kernel_stats.csv
   for c in FETCH_SIZE WRITE_SIZE; do
     rm -rf /tmp/rpc_${w}_$c
-    timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/rpc_${w}_$c -o $w -- python $REPO/bench.py --no-cpu-baseline --no-also --workload $w --steps 3 --warmup 1 > $OUT/${w}_pmc_$c.log 2>&1
+    timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/rpc_${w}_$c -o $w -- python $REPO/bench.py --no-cpu-baseline --no-also --workload $w --engine-door --steps 3 --warmup 1 > $OUT/${w}_pmc_$c.log 2>&1
     f=$(find /tmp/rpc_${w}_$c -name "*counter_collection.csv" | head -1)
     if [ -n "$f" ]; then
       python - "$f" "$c" > $OUT/${w}_pmc_$c.txt <<'PY'
