@@ -81,6 +81,12 @@ rfx_obj_p rfx_inner_join(rfx_obj_p *x, int64_t n);
 
 rfx_obj_p rfx_and(rfx_obj_p *x, int64_t n);
 rfx_obj_p rfx_or(rfx_obj_p *x, int64_t n);
+/* the same two as the SPECIAL FORMS the reference registers (FN_SPECIAL_FORM, core/env.c:224-225; logic_map evaluates its own arms,
+ * core/logic.c:89-260): the arms arrive unevaluated.  Comparison trees over i64 / f64 vectors become one mask on the device; arms that are
+ * B8 masks already take rfx_and / rfx_or; anything else is handed to the host's ray_and / ray_or.  These are the entry points to put in
+ * place of ray_and / ray_or themselves (INTEGRATION.md sections 2 and 3). */
+rfx_obj_p rfx_and_sf(rfx_obj_p *x, int64_t n);
+rfx_obj_p rfx_or_sf(rfx_obj_p *x, int64_t n);
 rfx_obj_p rfx_where(rfx_obj_p mask);
 rfx_obj_p rfx_at(rfx_obj_p col, rfx_obj_p ids);
 

@@ -1772,6 +1772,128 @@ static obj_p logic_op(int logic, obj_p *x, int64_t n) {
 rfx_obj_p rfx_and(rfx_obj_p *x, int64_t n) { return logic_op(RFX_AND, x, n); }
 rfx_obj_p rfx_or(rfx_obj_p *x, int64_t n) { return logic_op(RFX_OR, x, n); }
 
+/* ---- `and` / `or` as the SPECIAL FORMS the reference registers (FN_SPECIAL_FORM, core/env.c:224-225): the arms arrive UNEVALUATED and
+ * logic_map evaluates them itself (core/logic.c:89-260).  rfx_and_sf / rfx_or_sf take the same (obj_p *arms, n): when every arm is a
+ * comparison -- or a nested and / or of comparisons -- over i64 / f64 vectors (a symbol the host's eval resolves, or the vector object
+ * itself) and atoms, the whole tree becomes one B8 mask on the device (K2 masks + rfx_hip_mask_logic, no host round trip between the arms);
+ * arms that are already B8 masks take rfx_and / rfx_or; anything else is the host's own ray_and / ray_or. ---- */
+#define SF_MAX_COLS 16
+typedef struct {
+    int n;
+    obj_p src[SF_MAX_COLS];  /* the operand as written: a symbol atom or a vector object */
+    obj_p val[SF_MAX_COLS];  /* what it evaluates to (owned) */
+    int64_t name[SF_MAX_COLS];
+} sf_cols_t;
+/* a copy of `e` whose vector / symbol operands are replaced by synthetic column symbols (collected in c); NULL: shape not covered */
+static obj_p sf_rewrite(obj_p e, sf_cols_t *c, int top) {
+    if (!e) return NULL;
+    if (e->type == RFX_TYPE_LIST) {
+        if (e->len != 3 && !(e->len >= 2 && (fn_id(RFX_AS_LIST(e)[0]) == F_AND || fn_id(RFX_AS_LIST(e)[0]) == F_OR))) return NULL;
+        const int f = fn_id(RFX_AS_LIST(e)[0]);
+        if (f < 0 || (top && !((f >= F_EQ && f <= F_GE) || f == F_AND || f == F_OR))) return NULL;
+        obj_p out = H.vector(RFX_TYPE_LIST, e->len);
+        RFX_AS_LIST(out)[0] = H.clone(RFX_AS_LIST(e)[0]);
+        for (int64_t i = 1; i < e->len; i++) {
+            const int sub_top = (f == F_AND || f == F_OR); /* arms of and / or must be boolean trees again; operands of a comparison may be arithmetic */
+            obj_p r = sf_rewrite(RFX_AS_LIST(e)[i], c, sub_top);
+            if (!r) {
+                for (int64_t j = i; j < e->len; j++) RFX_AS_LIST(out)[j] = H.null_obj ? H.null_obj : rfx_host_null();
+                H.drop(out);
+                return NULL;
+            }
+            RFX_AS_LIST(out)[i] = r;
+        }
+        return out;
+    }
+    if (top) return NULL; /* an arm that is not a call */
+    if (e->type == -RFX_TYPE_I64 || e->type == -RFX_TYPE_F64) return H.clone(e);
+    if (e->type == -RFX_TYPE_SYMBOL || (e->type > 0 && col_ctype(e) && e->type != RFX_TYPE_SYMBOL)) {
+        int k = 0;
+        for (; k < c->n; k++)
+            if (c->src[k] == e || (e->type == -RFX_TYPE_SYMBOL && c->src[k]->type == -RFX_TYPE_SYMBOL && c->src[k]->i64 == e->i64)) break;
+        if (k == c->n) {
+            if (c->n >= SF_MAX_COLS) return NULL;
+            obj_p v = H.eval(e); /* a symbol: the host's binding; a vector: itself */
+            if (!v || v->type <= 0 || !col_ctype(v) || v->type == RFX_TYPE_SYMBOL || (c->n > 0 && v->len != c->val[0]->len)) {
+                if (v) H.drop(v);
+                return NULL;
+            }
+            char nm[16];
+            snprintf(nm, sizeof(nm), "rfxsf%d", c->n);
+            c->src[c->n] = e;
+            c->val[c->n] = v;
+            c->name[c->n] = H.intern(nm, (int64_t)strlen(nm));
+            c->n++;
+        }
+        obj_p sym = H.i64(c->name[k]);
+        sym->type = -RFX_TYPE_SYMBOL;
+        return sym;
+    }
+    return NULL;
+}
+static obj_p sf_logic_impl(int f, obj_p *x, int64_t n) {
+    rfx_host_bind();
+    if (n == 0) return rfx_host_b8(0); /* logic_map: (and) -> false, core/logic.c:96-97 */
+    int all_masks = 1;
+    for (int64_t i = 0; i < n; i++) all_masks = all_masks && x[i] && x[i]->type == RFX_TYPE_B8;
+    if (all_masks) return logic_op(f == F_AND ? RFX_AND : RFX_OR, x, n); /* bound through a loader that evaluates the arguments first */
+    const char *why = "an arm is not a comparison tree over i64 / f64 vectors";
+    sf_cols_t c;
+    memset(&c, 0, sizeof(c));
+    obj_p tree = H.vector(RFX_TYPE_LIST, n + 1), tab = NULL, res = NULL;
+    obj_p fo = H.i64((int64_t)(intptr_t)OUR_FN[f]);
+    fo->type = RFX_TYPE_VARY;
+    RFX_AS_LIST(tree)[0] = fo;
+    int ok = 1;
+    for (int64_t i = 0; i < n; i++) {
+        obj_p r = ok ? sf_rewrite(x[i], &c, 1) : NULL;
+        if (!r) ok = 0;
+        RFX_AS_LIST(tree)[1 + i] = r ? r : (H.null_obj ? H.null_obj : rfx_host_null());
+    }
+    if (ok && c.n == 0) { ok = 0; why = "no vector operand"; }
+    if (ok && ensure_ctx() != RFX_OK) { res = fail_hip("no usable MI355X"); ok = 0; }
+    if (ok) {
+        obj_p names = H.vector(RFX_TYPE_SYMBOL, c.n), cols = H.vector(RFX_TYPE_LIST, c.n);
+        for (int k = 0; k < c.n; k++) {
+            RFX_AS_I64(names)[k] = c.name[k];
+            RFX_AS_LIST(cols)[k] = c.val[k];
+            c.val[k] = NULL; /* the table owns it now */
+        }
+        tab = H.table(names, cols);
+        const int64_t nrows = RFX_AS_LIST(RFX_AS_LIST(tab)[1])[0]->len;
+        int8_t *mask = NULL;
+        const int rc = mask_of_expr(tab, tree, nrows, &mask);
+        if (rc == 0) {
+            res = H.vector(RFX_TYPE_B8, nrows);
+            if (nrows && rfx_hip_d2h(g_ctx, RFX_AS_RAW(res), mask, (size_t)nrows) != RFX_OK) {
+                H.drop(res);
+                res = fail_hip("mask read-back");
+            }
+            rfx_hip_free(g_ctx, mask);
+        } else if (rc == -2) res = fail_hip("and/or: device");
+        else ok = 0;
+        qtmp_release();
+    }
+    for (int k = 0; k < c.n; k++)
+        if (c.val[k]) H.drop(c.val[k]);
+    H.drop(tree);
+    if (tab) H.drop(tab);
+    if (res) return res;
+    /* not covered: the host's own special form evaluates the arms */
+    if (H.bound == 1 && H.f[f]) return HOST_CALL(((rfx_vary_f)H.f[f])(x, n));
+    char b[256];
+    snprintf(b, sizeof(b), "and/or (special form): not covered by the MI355X path (%s) and no host function to delegate to", why);
+    return fail(b);
+}
+static obj_p sf_logic(int f, obj_p *x, int64_t n) {
+    op_begin();
+    obj_p r = sf_logic_impl(f, x, n);
+    op_end();
+    return r;
+}
+rfx_obj_p rfx_and_sf(rfx_obj_p *x, int64_t n) { return sf_logic(F_AND, x, n); }
+rfx_obj_p rfx_or_sf(rfx_obj_p *x, int64_t n) { return sf_logic(F_OR, x, n); }
+
 static obj_p where_impl(obj_p mask) {
     rfx_host_bind();
     if (!mask || mask->type != RFX_TYPE_B8) return fail("where: expected a B8 mask"); /* err_type, core/items.c:1395 */

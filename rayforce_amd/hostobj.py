@@ -25,6 +25,8 @@ OPS_PROTOTYPES = {
     **{f"rfx_{n}": (C.c_void_p, [C.c_void_p, C.c_void_p]) for n in ("eq", "ne", "lt", "gt", "le", "ge", "at", "add", "sub", "mul", "div", "floordiv", "mod")},
     "rfx_and": (C.c_void_p, [C.POINTER(C.c_void_p), C.c_int64]),
     "rfx_or": (C.c_void_p, [C.POINTER(C.c_void_p), C.c_int64]),
+    "rfx_and_sf": (C.c_void_p, [C.POINTER(C.c_void_p), C.c_int64]),
+    "rfx_or_sf": (C.c_void_p, [C.POINTER(C.c_void_p), C.c_int64]),
     "rfx_left_join": (C.c_void_p, [C.POINTER(C.c_void_p), C.c_int64]),
     "rfx_inner_join": (C.c_void_p, [C.POINTER(C.c_void_p), C.c_int64]),
     **{f"rfx_{n}": (C.c_void_p, [C.c_void_p]) for n in ("where", "sum", "avg", "min", "max", "count", "first", "pin", "unpin", "invalidate", "stats", "group")},

@@ -576,3 +576,43 @@ def test_two_threads_hammer_the_operator_boundary(ops):
     for o in [d for dd in dicts for d in dd] + vecs + tabs:
         ops.rfx_host_drop(o)
     assert not errors, errors[:3]
+
+
+def test_and_or_as_special_forms(ops):
+    """rfx_and_sf / rfx_or_sf take UNEVALUATED arms like the reference's special forms (core/env.c:224-225, core/logic.c:89-260): comparison
+    trees over vectors -- nested and / or, arithmetic operands -- become one mask on the device; evaluated B8 masks are combined as rfx_and
+    does; without a host to delegate to, anything else fails loudly."""
+    n = 100_003
+    h = host_table(n)
+    a, v, k = H.vector(h["a"]), H.vector(h["v"]), H.vector(h["k"])
+
+    def call(fn, *arms):
+        arr = (C.c_void_p * len(arms))(*arms)
+        r = fn(arr, len(arms))
+        assert r and not H.is_error(r), H.error_text(r)
+        out = H.to_numpy(r)
+        ops.rfx_host_drop(r)
+        return out
+
+    fnobj = lambda nm: ops.rfx_host_fn(nm.encode())
+    cmp_ = lambda op, vec, atom: H.list_of([fnobj(op), ops.rfx_host_clone(vec), H.atom(atom)])  # the vector object itself as the operand (it evaluates to itself)
+    lt, gt, ne = cmp_("<", a, 300_000), cmp_(">", v, 0.5), cmp_("!=", k, 7)
+    want_and = (rfo.cmp("<", h["a"], 300_000) & rfo.cmp(">", h["v"], 0.5) & rfo.cmp("!=", h["k"], 7)).astype(np.int8)
+    assert np.array_equal(call(ops.rfx_and_sf, lt, gt, ne), want_and)
+    want_or = (rfo.cmp("<", h["a"], 300_000) | rfo.cmp(">", h["v"], 0.5)).astype(np.int8)
+    assert np.array_equal(call(ops.rfx_or_sf, lt, gt), want_or)
+    # a nested tree, an arithmetic operand: (or (and (< a 300000) (> v 0.5)) (== (% a 3) 1))
+    inner = H.list_of([fnobj("and"), ops.rfx_host_clone(lt), ops.rfx_host_clone(gt)])
+    mod = H.list_of([fnobj("=="), H.list_of([fnobj("%"), ops.rfx_host_clone(a), H.atom(3)]), H.atom(1)])
+    want = ((rfo.cmp("<", h["a"], 300_000) & rfo.cmp(">", h["v"], 0.5)) | rfo.cmp("==", rfo.binop("%", h["a"], 3), 1)).astype(np.int8)
+    assert np.array_equal(call(ops.rfx_or_sf, inner, mod), want)
+    # evaluated masks (a loader that evaluates the arguments first): the plain and / or
+    m1, m2 = H.vector(rfo.cmp("<", h["a"], 300_000).astype(np.int8)), H.vector(rfo.cmp(">", h["v"], 0.5).astype(np.int8))
+    assert np.array_equal(call(ops.rfx_and_sf, m1, m2), (rfo.cmp("<", h["a"], 300_000) & rfo.cmp(">", h["v"], 0.5)).astype(np.int8))
+    # not a comparison tree and no host to hand it to: a loud error, never a guess
+    arr = (C.c_void_p * 2)(lt, a)
+    r = ops.rfx_and_sf(arr, 2)
+    assert r and H.is_error(r) and "not covered" in H.error_text(r)
+    ops.rfx_host_drop(r)
+    for o in (lt, gt, ne, inner, mod, m1, m2, a, v, k):
+        ops.rfx_host_drop(o)
