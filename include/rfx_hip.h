@@ -71,14 +71,18 @@ enum {
 
 /* One comparison `col OP rhs`.  rhs is an atom (d_rhs_col == NULL, value in rhs_i / rhs_f according to
  * rhs_type) or a second column of the same length (d_rhs_col != NULL).  i64 (x) f64 promotes the i64 side
- * to f64 with null -> NaN exactly as core/cmp.c:197-198 + core/ops.h:250 do. */
+ * to f64 with null -> NaN exactly as core/cmp.c:197-198 + core/ops.h:250 do.
+ * `more` = 1: this comparison and the NEXT one stand in the same parenthesis, combined with the OPPOSITE of the call's
+ * `logic` -- a two-level tree `(and (or A B) C)` is {A more, B, C} with logic RFX_AND, `(or A (and B C))` is {A, B more, C}
+ * with RFX_OR -- evaluated in the same single pass (core/logic.c's and / or over the comparisons' B8 vectors, never materialised).
+ * 0 everywhere = the flat list.  The last comparison's `more` must be 0. */
 typedef struct rfx_pred {
     const void *d_col;
     const void *d_rhs_col;
     int32_t col_type; /* RFX_I64 | RFX_F64 */
     int32_t rhs_type; /* RFX_I64 | RFX_F64 */
     int32_t op;       /* RFX_EQ .. RFX_GE  */
-    int32_t _pad;
+    int32_t more;     /* 1: same parenthesis as the next comparison (see above) */
     union {
         int64_t rhs_i;
         double rhs_f;
@@ -205,7 +209,7 @@ enum {
     RFX_STAT_PLANE_AGGREGATE = 2, /* k_plane_aggregate launches */
     RFX_STAT_CHUNK_SCATTER = 3,   /* k_chunk_scatter* launches (16-byte records, rfx_group_chunk.hip) */
     RFX_STAT_CHUNK_AGGREGATE = 4, /* k_chunk_aggregate launches */
-    RFX_STAT_PLANE_REDO = 5       /* plane passes run again with row ids in every block (a group's first row turned up in a block without them) */
+    RFX_STAT_MASK_PASSES = 5      /* materialised B8 passes: rfx_hip_cmp_mask + rfx_hip_mask_logic launches (a fused `where:` tree runs none) */
 };
 int64_t rfx_hip_ctx_stat(rfx_ctx_t *ctx, int which);
 

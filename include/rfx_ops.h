@@ -112,8 +112,9 @@ rfx_obj_p rfx_unpin(rfx_obj_p table_or_column); /* unary_f: drop the device copi
 /* unary_f: the host writes into this vector / this table's columns in place -- drop every cached device copy overlapping them
  * (needed for PINNED entries only: unpinned ones are re-validated against a checksum of the full payload on every use) */
 rfx_obj_p rfx_invalidate(rfx_obj_p table_or_column);
-/* unary_f: I64[8] counters since load: {selects on the GPU, selects delegated to the host, joins on the GPU, joins delegated,
- * uploads, cache hits, stale entries refreshed, operator calls}; the argument is ignored */
+/* unary_f: I64[11] counters since load: {selects on the GPU, selects delegated to the host, joins on the GPU, joins delegated,
+ * uploads, cache hits, stale entries refreshed, operator calls, group scopes sampled, sampled scopes retried exactly,
+ * materialised B8 mask passes (RFX_STAT_MASK_PASSES: a fused `where:` tree runs none)}; the argument is ignored */
 rfx_obj_p rfx_stats(rfx_obj_p ignored);
 void rfx_cache_clear(void);
 int64_t rfx_cache_bytes(void);

@@ -33,7 +33,7 @@ class _RhsUnion(C.Union):
 class Pred(C.Structure):
     _anonymous_ = ("u",)
     _fields_ = [("d_col", C.c_void_p), ("d_rhs_col", C.c_void_p), ("col_type", C.c_int32), ("rhs_type", C.c_int32),
-                ("op", C.c_int32), ("_pad", C.c_int32), ("u", _RhsUnion)]
+                ("op", C.c_int32), ("more", C.c_int32), ("u", _RhsUnion)]
 
 
 class _XRhsUnion(C.Union):

@@ -134,6 +134,7 @@ struct PlanPred {
     int lhs_cvt;  // 1: column is i64 but domain is f64 -> i64_to_f64 (null -> NaN), core/ops.h:250
     int rhs_cvt;  // same for a vector rhs
     u64 rhs_bits; // atom, already promoted to the comparison domain on the host
+    int more;     // 1: same parenthesis as the next predicate (rfx_pred_t::more); the parenthesis combines with the opposite of Plan::logic
 };
 #define RFX_XCOL 64 /* PlanAgg::col >= RFX_XCOL: the aggregate folds expression Plan::xs[col - RFX_XCOL] */
 struct PlanAgg {

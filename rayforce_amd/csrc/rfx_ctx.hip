@@ -91,7 +91,7 @@ extern "C" int rfx_hip_ctx_destroy(rfx_ctx_t *c) {
 
 extern "C" int64_t rfx_hip_ctx_stat(rfx_ctx_t *c, int which) {
     if (!c || which < 0 || which > 5) return -1;
-    return which == RFX_STAT_PLANE_REDO ? c->ext_i[0] : c->ext_i[3 + which];
+    return which == RFX_STAT_MASK_PASSES ? c->ext_i[0] : c->ext_i[3 + which];
 }
 
 extern "C" int rfx_hip_ctx_sync(rfx_ctx_t *c) {
@@ -507,6 +507,8 @@ int rfx_plan_build(Plan *P, const rfx_pred_t *preds, int npred, int logic, const
         q->col = plan_col(P, p->d_col);
         RFX_REQUIRE(q->col >= 0, RFX_ELIMIT, "too many distinct columns");
         q->op = p->op;
+        RFX_REQUIRE((p->more == 0 || p->more == 1) && !(p->more && i == npred - 1), RFX_EINVAL, "predicate `more` must be 0 / 1, and 0 on the last one");
+        q->more = p->more;
         q->dom_f64 = (p->col_type == RFX_F64 || p->rhs_type == RFX_F64);
         q->lhs_cvt = q->dom_f64 && p->col_type == RFX_I64;
         if (p->d_rhs_col) {

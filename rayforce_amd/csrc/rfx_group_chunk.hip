@@ -1113,7 +1113,7 @@ static void chunk_pred_sig(const Plan &P, u64 (*sig)[6]) {
         sig[i][0] = (u64)(uintptr_t)P.cols[q.col];
         sig[i][1] = q.rhs_col >= 0 ? (u64)(uintptr_t)P.cols[q.rhs_col] : 0;
         sig[i][2] = (u64)q.op;
-        sig[i][3] = (u64)(q.dom_f64 | (q.lhs_cvt << 1) | (q.rhs_cvt << 2));
+        sig[i][3] = (u64)(q.dom_f64 | (q.lhs_cvt << 1) | (q.rhs_cvt << 2) | (q.more << 3));
         sig[i][4] = q.rhs_bits;
         sig[i][5] = 0;
     }

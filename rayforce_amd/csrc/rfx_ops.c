@@ -635,6 +635,36 @@ static int plan_cmp(obj_p tab, obj_p e, rfx_pred_t *p) {
     return 0;
 }
 /* where: a comparison, or a flat (and ...) / (or ...) of comparisons */
+/* One arm of the top-level and / or: a comparison; a list of the SAME operator (and inside and: associative, its arms are this level's);
+ * or a parenthesis of the OPPOSITE operator over comparisons -- `more` set on all but its last (rfx_pred_t: the fused kernels fold a
+ * parenthesis with the opposite operator in the same pass).  Anything deeper: -1 (the mask path answers it). */
+static int plan_arm(obj_p tab, obj_p e, int top, wplan_t *wp) {
+    if (!e || e->type != RFX_TYPE_LIST || e->len < 1) return -1;
+    int f = fn_id(RFX_AS_LIST(e)[0]);
+    if (f != F_AND && f != F_OR) {
+        if (wp->npred >= RFX_MAX_PREDS) return -1;
+        int rc = plan_cmp(tab, e, &wp->preds[wp->npred]);
+        if (rc == 0) wp->npred++;
+        return rc;
+    }
+    if (e->len < 2) return -1;
+    if (f == top) {
+        for (int64_t i = 1; i < e->len; i++) {
+            int rc = plan_arm(tab, RFX_AS_LIST(e)[i], top, wp);
+            if (rc) return rc;
+        }
+        return 0;
+    }
+    for (int64_t i = 1; i < e->len; i++) {
+        if (wp->npred >= RFX_MAX_PREDS) return -1;
+        int rc = plan_cmp(tab, RFX_AS_LIST(e)[i], &wp->preds[wp->npred]);
+        if (rc) return rc;
+        wp->preds[wp->npred].more = (i + 1 < e->len);
+        wp->npred++;
+    }
+    return 0;
+}
+
 static int plan_where(obj_p tab, obj_p w, wplan_t *wp) {
     wp->npred = 0;
     wp->logic = RFX_AND;
@@ -642,14 +672,9 @@ static int plan_where(obj_p tab, obj_p w, wplan_t *wp) {
     if (w->type != RFX_TYPE_LIST || w->len < 1) return -1;
     int f = fn_id(RFX_AS_LIST(w)[0]);
     if (f == F_AND || f == F_OR) {
-        if (w->len - 1 > RFX_MAX_PREDS || w->len < 2) return -1;
+        if (w->len < 2) return -1;
         wp->logic = (f == F_AND) ? RFX_AND : RFX_OR;
-        for (int64_t i = 1; i < w->len; i++) {
-            int rc = plan_cmp(tab, RFX_AS_LIST(w)[i], &wp->preds[wp->npred]);
-            if (rc) return rc;
-            wp->npred++;
-        }
-        return 0;
+        return plan_arm(tab, w, f, wp);
     }
     int rc = plan_cmp(tab, w, &wp->preds[0]);
     if (rc) return rc;
@@ -864,7 +889,7 @@ static obj_p select_impl(obj_p dict) {
         g_where_virtual = g_where_data = 0;
         int rc = plan_where(tab, where, &wp);
         if (rc == -2) { res = fail_hip("column upload"); goto done; }
-        if (rc) { /* not one comparison / one flat and|or: a nested tree, evaluated through masks */
+        if (rc) { /* deeper than (and|or (cmp | (or|and cmp ...)) ...): evaluated through masks */
             flat = 0;
             wp.npred = 0;
             wp.logic = RFX_AND;
@@ -875,6 +900,8 @@ static obj_p select_impl(obj_p dict) {
              * A filter mixing both kinds, and a data-column filter under by:, come out wrong there (DESIGN.md "reference defects"):
              * left to the host so that this entry point never answers differently. */
             if (!flat) { why = "parted table: where: is not a flat and / or of comparisons"; goto out; }
+            for (int i = 0; i < wp.npred; i++)
+                if (wp.preds[i].more) { why = "parted table: where: is not a flat and / or of comparisons"; goto out; }
             if (g_where_virtual && g_where_data) { why = "parted table: where: mixes the virtual column with data columns"; goto out; }
             if (by && g_where_data) { why = "parted table: by: under a data-column filter"; goto out; }
         }
@@ -2441,7 +2468,8 @@ rfx_obj_p rfx_invalidate(rfx_obj_p x) {
 rfx_obj_p rfx_stats(rfx_obj_p x) {
     (void)x;
     rfx_host_bind();
-    obj_p out = H.vector(RFX_TYPE_I64, 10);
+    obj_p out = H.vector(RFX_TYPE_I64, 11);
     for (int i = 0; i < 10; i++) RFX_AS_I64(out)[i] = g_stat[i];
+    RFX_AS_I64(out)[10] = g_ctx ? rfx_hip_ctx_stat(g_ctx, RFX_STAT_MASK_PASSES) : 0;
     return out;
 }

@@ -77,8 +77,8 @@ static void plan_text(const Plan &P, const GroupArgs *G, std::string &o) {
     ADD("#define RTC_PLAN { %d, %d, %d, %d, {}, { ", P.ncols, P.npred, P.nagg, P.logic);
     for (int i = 0; i < P.npred; i++) {
         const bool cnan = P.preds[i].rhs_col < 0 && P.preds[i].dom_f64 && (P.preds[i].rhs_bits & 0x7FF0000000000000ULL) == 0x7FF0000000000000ULL && (P.preds[i].rhs_bits & 0x000FFFFFFFFFFFFFULL) != 0;
-        ADD("{ %d, %d, %d, %d, %d, %d, %s }, ", P.preds[i].col, P.preds[i].rhs_col, P.preds[i].op, P.preds[i].dom_f64, P.preds[i].lhs_cvt, P.preds[i].rhs_cvt,
-            cnan ? "0x7FF8000000000000ULL" : "0ULL");
+        ADD("{ %d, %d, %d, %d, %d, %d, %s, %d }, ", P.preds[i].col, P.preds[i].rhs_col, P.preds[i].op, P.preds[i].dom_f64, P.preds[i].lhs_cvt, P.preds[i].rhs_cvt,
+            cnan ? "0x7FF8000000000000ULL" : "0ULL", P.preds[i].more);
     }
     o += "}, { ";
     for (int a = 0; a < P.nagg; a++) ADD("{ %d, %d, %d, %d }, ", P.aggs[a].col, P.aggs[a].f64, P.aggs[a].kind, P.aggs[a].skipnull);

@@ -366,6 +366,7 @@ __global__ __launch_bounds__(RFX_BLOCK) void k_cmp_mask(const Plan P, int8_t *__
 extern "C" int rfx_hip_cmp_mask(rfx_ctx_t *c, const rfx_pred_t *pred, int64_t nrows, int8_t *d_mask) {
     RFX_REQUIRE(c && pred && (d_mask || nrows == 0), RFX_EINVAL, "NULL argument");
     if (nrows == 0) return RFX_OK;
+    c->ext_i[0]++; // RFX_STAT_MASK_PASSES
     RFX_REQUIRE(((uintptr_t)d_mask & 7) == 0, RFX_EINVAL, "mask must be 8-byte aligned");
     Plan P;
     int rc = rfx_plan_build(&P, pred, 1, RFX_AND, NULL, 0, NULL, NULL, nrows, 0);
@@ -401,6 +402,7 @@ extern "C" int rfx_hip_mask_logic(rfx_ctx_t *c, int logic, int8_t *d_acc, const 
     RFX_REQUIRE(c && (d_acc || nrows == 0), RFX_EINVAL, "NULL argument");
     RFX_REQUIRE(logic == RFX_AND || logic == RFX_OR, RFX_EINVAL, "logic must be RFX_AND or RFX_OR");
     if (nrows == 0) return RFX_OK;
+    c->ext_i[0]++; // RFX_STAT_MASK_PASSES
     RFX_REQUIRE(((uintptr_t)d_acc & 7) == 0 && ((uintptr_t)d_next & 7) == 0, RFX_EINVAL, "masks must be 8-byte aligned");
     hipLaunchKernelGGL(k_mask_logic, dim3(rfx_grid(c)), dim3(RFX_BLOCK), 0, c->stream, d_acc, d_next, scalar, logic, (i64)nrows);
     RFX_HIP_CHECK(hipGetLastError());

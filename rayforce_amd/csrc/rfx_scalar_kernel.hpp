@@ -198,7 +198,7 @@ __device__ __forceinline__ void expr_input_deep_sw(u64 (&x)[E], const u64 (&v)[N
 // reference's total order (core/ops.h:76-123: NaN lowest, NaN == NaN, -0.0 == 0.0, i64 plain signed), and the operator
 // only decides which of {lt, eq, gt = !(lt|eq)} it keeps -- three wave-uniform booleans, combined with s_and/s_or on
 // the masks.  So the op costs no per-row branch and no per-op code copy.
-enum { PF_F64DOM = 1, PF_LCVT = 2, PF_RCVT = 4, PF_CNAN = 8, PF_RCOL = 16, PF_KEEP_LT = 256, PF_KEEP_EQ = 512, PF_KEEP_GT = 1024 };
+enum { PF_F64DOM = 1, PF_LCVT = 2, PF_RCVT = 4, PF_CNAN = 8, PF_RCOL = 16, PF_KEEP_LT = 256, PF_KEEP_EQ = 512, PF_KEEP_GT = 1024, PF_MORE = 2048 };
 struct PredR {
     int col, rhs_col, flags;
     u64 rhs;
@@ -207,6 +207,7 @@ template <int NP>
 struct PredSet {
     int npred;
     bool is_and;
+    bool grouped; // some predicate has PF_MORE: a two-level tree (parentheses of the opposite operator)
     PredR p[NP > 0 ? NP : 1];
 };
 __device__ __forceinline__ int pred_keep_bits(int op) {
@@ -223,6 +224,7 @@ template <int NP>
 __device__ __forceinline__ void predset_load(const Plan &P, PredSet<NP> &S) {
     S.npred = P.npred;
     S.is_and = (P.logic == RFX_AND);
+    S.grouped = false;
 #pragma unroll
     for (int i = 0; i < NP; i++) {
         const PlanPred q = P.preds[i];
@@ -235,6 +237,10 @@ __device__ __forceinline__ void predset_load(const Plan &P, PredSet<NP> &S) {
         if (q.rhs_cvt) f |= PF_RCVT;
         if (q.rhs_col >= 0) f |= PF_RCOL;
         else if (q.dom_f64 && rfx_isnan_bits(q.rhs_bits)) f |= PF_CNAN;
+        if (i < P.npred && q.more) {
+            f |= PF_MORE;
+            S.grouped = true;
+        }
         S.p[i].flags = f;
     }
 }
@@ -291,8 +297,10 @@ __device__ __forceinline__ void pred_lt_eq(const PredR &pr, const u64 (&x)[E], c
     }
 }
 
-// Evaluate all predicates on a register tile: sel[e] = valid[e] && combine(pred_p(row e)).  Column-major: the
-// predicates that read column c are evaluated straight on v[c] (no register copies).
+// Evaluate all predicates on a register tile: sel[e] = valid[e] && combine(pred_p(row e)).  Each predicate is evaluated straight on
+// the tile of the column it reads (the static `col == c` chain: no register copies).  Flat lists fold into sel directly; a two-level
+// tree (PF_MORE: "the next predicate is in the same parenthesis") folds each parenthesis with the OPPOSITE operator into `par`, and
+// `par` into sel when the parenthesis closes -- lane masks in SGPRs, wave-uniform selects, no per-row branch.
 template <int NC, int E, int NP>
 __device__ __forceinline__ void eval_sel(const PredSet<NP> &S, const u64 (&v)[NC][E], const bool (&valid)[E], bool (&sel)[E]) {
     if (NP == 0 || S.npred == 0) {
@@ -300,21 +308,35 @@ __device__ __forceinline__ void eval_sel(const PredSet<NP> &S, const u64 (&v)[NC
         for (int e = 0; e < E; e++) sel[e] = valid[e];
         return;
     }
-    const bool is_and = S.is_and;
+    const bool is_and = S.is_and, grouped = S.grouped;
+    bool par[E];
 #pragma unroll
-    for (int e = 0; e < E; e++) sel[e] = is_and;
+    for (int e = 0; e < E; e++) {
+        sel[e] = is_and;
+        par[e] = !is_and;
+    }
 #pragma unroll
-    for (int c = 0; c < NC; c++) {
+    for (int p = 0; p < NP; p++) {
+        if (p < S.npred) {
 #pragma unroll
-        for (int p = 0; p < NP; p++) {
-            if (p < S.npred && S.p[p].col == c) {
-                bool lt[E], eq[E];
-                pred_lt_eq<NC, E>(S.p[p], v[c], v, lt, eq);
-                const bool klt = (S.p[p].flags & PF_KEEP_LT) != 0, keq = (S.p[p].flags & PF_KEEP_EQ) != 0, kgt = (S.p[p].flags & PF_KEEP_GT) != 0;
+            for (int c = 0; c < NC; c++) {
+                if (S.p[p].col == c) {
+                    bool lt[E], eq[E];
+                    pred_lt_eq<NC, E>(S.p[p], v[c], v, lt, eq);
+                    const bool klt = (S.p[p].flags & PF_KEEP_LT) != 0, keq = (S.p[p].flags & PF_KEEP_EQ) != 0, kgt = (S.p[p].flags & PF_KEEP_GT) != 0;
+#pragma unroll
+                    for (int e = 0; e < E; e++) {
+                        const bool pm = (lt[e] && klt) || (eq[e] && keq) || (!(lt[e] || eq[e]) && kgt);
+                        if (!grouped) sel[e] = is_and ? (sel[e] && pm) : (sel[e] || pm);
+                        else par[e] = is_and ? (par[e] || pm) : (par[e] && pm);
+                    }
+                }
+            }
+            if (grouped && !(S.p[p].flags & PF_MORE)) {
 #pragma unroll
                 for (int e = 0; e < E; e++) {
-                    const bool pm = (lt[e] && klt) || (eq[e] && keq) || (!(lt[e] || eq[e]) && kgt);
-                    sel[e] = is_and ? (sel[e] && pm) : (sel[e] || pm);
+                    sel[e] = is_and ? (sel[e] && par[e]) : (sel[e] || par[e]);
+                    par[e] = !is_and;
                 }
             }
         }

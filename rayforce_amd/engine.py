@@ -239,18 +239,36 @@ class Engine:
         return t
 
     def _flatten(self, where, table) -> Tuple[int, List[tuple]]:
-        """Return (logic, [simple predicates]) or raise NotFlat for nested trees."""
+        """Return (logic, [simple predicates]) or raise NotFlat for trees deeper than two levels.  A two-level tree --
+        ``(and (or A B) C)``, ``(or A (and B C))`` -- stays ONE fused pass: the comparisons of a parenthesis of the opposite operator
+        are marked ``_More`` (rfx_pred_t::more) on all but the last; the same operator nested in itself is associative and flattened."""
         if where is None:
             return L.RFX_AND, []
         head = where[0]
         if head in L.OPS:
             return L.RFX_AND, [where]
-        if head in ("and", "or"):
-            subs = list(where[1:])
-            if all(s[0] in L.OPS for s in subs):
-                return (L.RFX_AND if head == "and" else L.RFX_OR), subs
+        if head not in ("and", "or"):
+            raise RfxError(f"unknown predicate head {head!r}")
+        out: List[tuple] = []
+
+        def arm(e):
+            h = e[0]
+            if h in L.OPS:
+                out.append(tuple(e))
+            elif h == head:
+                for s in e[1:]:
+                    arm(s)
+            elif h in ("and", "or") and len(e) > 1 and all(s[0] in L.OPS for s in e[1:]):
+                out.extend(_More(s) for s in e[1:-1])
+                out.append(tuple(e[-1]))
+            else:
+                raise _NotFlat()
+
+        for s in where[1:]:
+            arm(s)
+        if len(out) > L.RFX_MAX_PREDS:
             raise _NotFlat()
-        raise RfxError(f"unknown predicate head {head!r}")
+        return (L.RFX_AND if head == "and" else L.RFX_OR), out
 
     def _resolve(self, x, table):
         if isinstance(x, str):
@@ -279,10 +297,12 @@ class Engine:
         if len(preds) > L.RFX_MAX_PREDS:
             raise RfxError("too many predicates for one fused pass")
         arr = (L.Pred * max(1, len(preds)))()
-        for i, (op, lhs, rhs) in enumerate(preds):
+        for i, pr in enumerate(preds):
+            op, lhs, rhs = pr
             lhs = self._check_col(self._resolve(lhs, table), n)
             n = lhs.numel() if n is None else n
             p = arr[i]
+            p.more = 1 if isinstance(pr, _More) else 0
             p.d_col = lhs.data_ptr()
             p.col_type = _ctype_of(lhs)
             p.op = L.OPS[op]
@@ -1213,6 +1233,10 @@ class Engine:
 
 class _NotFlat(Exception):
     pass
+
+
+class _More(tuple):
+    """A comparison that shares its parenthesis with the next one (rfx_pred_t::more)."""
 
 
 class _NotPerfect(Exception):

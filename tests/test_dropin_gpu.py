@@ -169,6 +169,7 @@ def test_plugin_inside_the_real_reference(built):
     st = res["stats"]
     assert int(st[0]) == len(QUERIES) + 2 and int(st[1]) == 1, st
     assert int(st[2]) == 4 and int(st[3]) == 0, st
+    assert int(st[10]) == 0, st  # q19 / g_nest: two-level where: trees in ONE fused pass -- no comparison mask was materialised
 
 
 PARTED = [  # (name, query over the parted table p, outputs, answered on the device?)

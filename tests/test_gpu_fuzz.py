@@ -92,6 +92,70 @@ def test_random_select(eng, seed):
         eng.tune(flags=0)
 
 
+def two_level_tree(rng, keys):
+    """(and|or arm ...), an arm a comparison or a parenthesis of the opposite operator over 2-3 comparisons; sometimes the same operator
+    nested in itself (associative: flattened)."""
+    def cmp():
+        col = str(rng.choice(["a", "v", "w", "k"]))
+        op = str(rng.choice(["<", ">", "<=", ">=", "!=", "=="]))
+        if col == "a":
+            rhs = int(rng.choice([5_000, 100_000, 500_000, 900_000, 999_999]))
+        elif col == "k":
+            rhs = int(rng.integers(0, keys + 1))
+        else:
+            rhs = float(rng.choice([0.05, 0.25, 0.5, 0.9])) - (0.5 if col == "w" else 0.0)
+        if rng.random() < 0.15:
+            rhs = str(rng.choice(["a", "v", "w", "k", "j"]))
+        return (op, col, rhs)
+    top = str(rng.choice(["and", "or"]))
+    other = "or" if top == "and" else "and"
+    arms, left = [], 8
+    while left > 0 and len(arms) < int(rng.integers(2, 5)):
+        r = rng.random()
+        if r < 0.35 or left < 2:
+            arms.append(cmp())
+            left -= 1
+        elif r < 0.9:
+            m = min(left, int(rng.integers(2, 4)))
+            arms.append((other, *[cmp() for _ in range(m)]))
+            left -= m
+        else:
+            m = min(left, 2)
+            arms.append((top, *[cmp() for _ in range(m)]))
+            left -= m
+    if not any(a[0] == other for a in arms) and left >= 2:
+        arms.append((other, cmp(), cmp()))
+    return (top, *arms)
+
+
+MASK_PASSES = 5  # RFX_STAT_MASK_PASSES
+
+
+@pytest.mark.parametrize("seed", range(240))
+def test_random_two_level_where_trees(eng, seed):
+    """`(and (or A B) C)`, `(or A (and B C) (and D E F))` ...: ONE fused pass on every path (scalar, dense / LDS / partitioned / hashed
+    group-by, key tuples, where), the oracle evaluating the tree as the reference does (a B8 vector per comparison, core/logic.c)."""
+    rng = np.random.default_rng(9000 + seed)
+    t, q = make_case(rng)
+    q["where"] = two_level_tree(rng, max(1, int(t["k"].max())) if len(t["k"]) else 1)
+    flags = int(rng.choice([0, 0, 0, 1, 2, 4, 16, 32, 64, 128, 256]))
+    try:
+        eng.tune(flags=flags)
+        try:
+            rfo.select({"from": t, **q})
+        except rfo.NotPerfect:
+            pytest.skip("composite key overflows: the reference's row-hash path is not covered")
+        m0 = eng.stat(MASK_PASSES)
+        check_select(eng, t, q)
+        assert eng.stat(MASK_PASSES) == m0, "a two-level tree must not materialise comparison masks"
+        if seed % 4 == 0:
+            d = {k: eng.column(v) for k, v in t.items()}
+            assert np.array_equal(eng.where(q["where"], d).cpu().numpy(), rfo.where(rfo.mask_of(q["where"], t)))
+            assert eng.stat(MASK_PASSES) == m0
+    finally:
+        eng.tune(flags=0)
+
+
 @pytest.mark.parametrize("seed", range(80))
 def test_random_key_tuples_row_hash(eng, seed):
     """Two to five key columns that cannot fold into one 64-bit key (wide strides and / or null keys): the row-hash path, both group

@@ -152,11 +152,20 @@ def test_select_by_xbar(ops):
 
 def test_nested_tree_and_projection(ops):
     host = host_table(200_003)
+    host["b"] = rfo.gen_i64(200_003, 77, 9) - 1
     nested = ("and", ("or", ("<", "a", 1000), (">", "v", 0.9)), ("!=", "k", 3))
     q = {"s": ("sum", "a"), "f": ("sum", "v"), "c": ("count", "a"), "fi": ("first", "a")}
+    m0 = H.to_numpy(ops.rfx_stats(0))[10]
     check(run_select(ops, host, {**q, "where": nested}), rfo.select({"from": host, **q, "where": nested}))
     assert ops.rfx_last_select_on_gpu() == 1
     check(run_select(ops, host, {**q, "where": nested, "by": "k"}), rfo.select({"from": host, **q, "where": nested, "by": "k"}))
+    q19 = ("or", ("==", ("div", "a", 1000), 7), ("and", (">", ("*", "v", 2.0), 1.5), ("!=", "k", 3)), ("and", ("<", "b", 2), ("<", "a", 50_000), (">=", "v", 0.5)))
+    for extra in ({}, {"by": "k"}, {"by": {"t": ("xbar", "a", 1000)}}):  # (where: with several by: columns is handed to the host: reference defect)
+        check(run_select(ops, host, {**q, "where": q19, **extra}), rfo.select({"from": host, **q, "where": q19, **extra}))
+    assert H.to_numpy(ops.rfx_stats(0))[10] == m0, "two-level trees: one fused pass, no materialised comparison masks"
+    deep = ("or", ("and", ("<", "a", 300_000), (">", "v", 0.2)), ("and", ("==", "b", 3), ("or", ("<", "v", 0.3), (">=", "a", 900_000))))
+    check(run_select(ops, host, {**q, "where": deep}), rfo.select({"from": host, **q, "where": deep}))
+    assert H.to_numpy(ops.rfx_stats(0))[10] > m0  # (three levels: the reference's own plan -- masks, where -- on the device)
     # projection = filter_collect of every column (core/filter.c:51-165), flat and nested predicates
     check(run_select(ops, host, {"where": ("<", "a", 1000)}), rfo.select({"from": host, "where": ("<", "a", 1000)}))
     check(run_select(ops, host, {"where": nested}), rfo.select({"from": host, "where": nested}))
