@@ -714,6 +714,8 @@ def main():
             head["frac"] = head["achieved_GBps"] / HBM_PEAK_GBPS
         rl, rc = C.c_int64(), C.c_int64()
         eng.lib.rfx_hip_rtc_stats(C.byref(rl), C.byref(rc))
+        rd, rw = C.c_int64(), C.c_int64()
+        eng.lib.rfx_hip_rtc_cache_stats(C.byref(rd), C.byref(rw))
         line = {
             "metric": METRIC,
             "value": head["rows_per_s"],
@@ -733,7 +735,8 @@ def main():
                        "door": door["door"] if door else "Engine (ctypes host over the flat device ABI, results stay on the device)"},
             "roofline": roofline_block(name, head, world),
             "cpu_baseline": cpu,
-            "rtc": {"launches_through_run_time_compiled_kernels": int(rl.value), "plans_compiled": int(rc.value)},
+            "rtc": {"launches_through_run_time_compiled_kernels": int(rl.value), "plans_compiled": int(rc.value),
+                    "plans_loaded_from_the_disk_cache": int(rd.value), "code_objects_written": int(rw.value)},
         }
         if door:
             line["door"] = door

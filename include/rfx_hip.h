@@ -222,9 +222,17 @@ int rfx_hip_memset(rfx_ctx_t *ctx, void *d_dst, int byte, size_t bytes);
 /* d_dst[0..n) = value (8-byte cells): the virtual Date column of a parted table, expanded partition by partition */
 int rfx_hip_fill_i64(rfx_ctx_t *ctx, int64_t *d_dst, int64_t n, int64_t value);
 /* Kernels compiled at run time for one plan (hiprtc, loaded on first use; group-bys over at most 8 slots take one): how many launches
- * went through such a kernel and how many were compiled so far in this process.  RFX_TUNE_NO_RTC / RFX_NO_RTC=1 keep to the prebuilt
- * kernels; so does a box without libhiprtc.so or without the library's source tree beside librfx.so. */
+ * went through such a kernel and how many compilations ran so far in this process.  RFX_TUNE_NO_RTC / RFX_NO_RTC=1 keep to the prebuilt
+ * kernels; so does a box without libhiprtc.so.  The kernel headers are embedded in librfx.so (no source tree needed beside it). */
 void rfx_hip_rtc_stats(int64_t *launches, int64_t *compiles);
+/* Code objects persist on disk -- <dir of librfx.so>/rtc_cache, RFX_RTC_CACHE=<dir> elsewhere, RFX_RTC_CACHE=0 off -- keyed by the
+ * generated text, the embedded headers, the compiler version and options: a plan compiled by ANY earlier process is loaded at first
+ * sight.  Counters of this process: plans loaded from disk / code objects written. */
+void rfx_hip_rtc_cache_stats(int64_t *loaded_from_disk, int64_t *written_to_disk);
+/* Compile the fused filter + aggregate kernel of a plan into that cache WITHOUT a device (the build step pre-warms the BASELINE plans;
+ * a deployment can do the same for its recurring queries).  d_col pointers only tell columns apart (any distinct non-NULL values).
+ * RFX_OK: the code object is on disk; RFX_ESTATE: no compiler / no cache directory / the plan does not compile. */
+int rfx_hip_rtc_prewarm_filter_aggr(const rfx_pred_t *preds, int npred, int logic, const rfx_agg_t *aggs, int nagg);
 
 /* Host-to-device at link speed from ANY host memory (heap vector, mmapped column file): chunks are staged through pinned
  * buffers by worker threads while the previous chunk is in flight.  (syncs) */

@@ -121,6 +121,8 @@ PROTOTYPES = {
     "rfx_hip_memset": (C.c_int, [_ctx, C.c_void_p, C.c_int, C.c_size_t]),
     "rfx_hip_fill_i64": (C.c_int, [_ctx, C.c_void_p, C.c_int64, C.c_int64]),
     "rfx_hip_rtc_stats": (None, [_P(C.c_int64), _P(C.c_int64)]),
+    "rfx_hip_rtc_cache_stats": (None, [_P(C.c_int64), _P(C.c_int64)]),
+    "rfx_hip_rtc_prewarm_filter_aggr": (C.c_int, [_P(Pred), C.c_int, C.c_int, _P(Agg), C.c_int]),
     "rfx_hip_timer_start": (C.c_int, [_ctx]),
     "rfx_hip_timer_stop": (C.c_int, [_ctx, _P(C.c_float)]),
     "rfx_hip_ctx_profile": (C.c_int, [_ctx, C.c_int]),
@@ -195,7 +197,8 @@ _LIB = None
 
 
 def lib_path() -> str:
-    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "librfx.so")
+    """The in-tree build, or RFX_LIB=<path to a librfx.so installed elsewhere> (it carries its kernel headers inside: no source tree needed)."""
+    return os.environ.get("RFX_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "librfx.so")
 
 
 def load_library() -> C.CDLL:

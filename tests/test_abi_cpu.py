@@ -161,3 +161,45 @@ def test_bench_launch_contract_dry_run():
     bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--dry-run"], env={**env, "WORLD_SIZE": "1", "RANK": "0"},
                          capture_output=True, text=True, timeout=120)
     assert bad.returncode != 0 and "refusing" in (bad.stderr + bad.stdout)
+
+
+def test_plan_kernels_prewarm_into_the_disk_cache_without_a_device(built, tmp_path):
+    """rfx_hip_rtc_prewarm_filter_aggr: the plan kernel of C2b is compiled by hiprtc from the headers EMBEDDED in librfx.so (the library
+    is loaded from a copy in an empty directory: no source tree beside it), written to RFX_RTC_CACHE; asking again -- in the same
+    process and in a new one -- finds the code object and compiles nothing; another plan is another file."""
+    import shutil
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lone = tmp_path / "lone"
+    lone.mkdir()
+    shutil.copy(os.path.join(root, "rayforce_amd", "librfx.so"), lone / "librfx.so")
+    cache = tmp_path / "cache"
+    prog = (
+        "import ctypes as C, sys\n"
+        f"sys.path.insert(0, {root!r})\n"
+        "from rayforce_amd import _lib as L, prewarm\n"
+        "lib = L.load_library()\n"
+        "r = [prewarm.filter_aggr(*prewarm.BASELINE_PLANS['c2b']) for _ in range(2)]\n"
+        "if len(sys.argv) > 1: r.append(prewarm.filter_aggr(*prewarm.BASELINE_PLANS['c5']))\n"
+        "a, b = C.c_int64(), C.c_int64()\n"
+        "lib.rfx_hip_rtc_stats(C.byref(a), C.byref(b))\n"
+        "import json; print('RESULT', json.dumps([r, b.value, prewarm.cache_stats()[1]]))\n")
+    env = dict(os.environ, RFX_RTC_CACHE=str(cache), RFX_LIB=str(lone / "librfx.so"))
+
+    def run(*args):
+        out = subprocess.run([sys.executable, "-c", prog, *args], env=env, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        line = [ln for ln in out.stdout.splitlines() if ln.startswith("RESULT")][0]
+        import json
+        return json.loads(line[len("RESULT "):])  # [[plan in the cache? ...], compilations, files written]
+
+    first = run()
+    if first[0] == [False, False]:
+        pytest.skip("libhiprtc.so is not loadable here: the prebuilt kernels are what runs")
+    assert first == [[True, True], 1, 1], first  # compiled once, the second call read the file
+    files = sorted(os.listdir(cache))
+    assert len(files) == 1 and files[0].endswith(".co") and open(cache / files[0], "rb").read(4) == b"\x7fELF"
+    again = run("more")
+    assert again == [[True, True, True], 1, 1], again  # a new process: C2b from disk, only C5 compiled
+    assert len(os.listdir(cache)) == 2
