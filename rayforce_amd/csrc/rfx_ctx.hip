@@ -58,8 +58,6 @@ extern "C" int rfx_hip_ctx_create(int device, void *stream, rfx_ctx_t **out) {
 
 static void pool_release(rfx_ctx *c);
 void rfx_plane_release(rfx_ctx *c); // rfx_group_plane.hip
-void rfx_dict_release(rfx_ctx *c);  // rfx_group_dict.hip
-i64 rfx_dict_stat(rfx_ctx *c, int which);
 void rfx_plane_invalidate(rfx_ctx *c);
 extern "C" int rfx_hip_ctx_destroy(rfx_ctx_t *c) {
     if (!c) return RFX_OK;
@@ -80,7 +78,6 @@ extern "C" int rfx_hip_ctx_destroy(rfx_ctx_t *c) {
     pool_release(c);
     if (c->ext_p[1]) (void)hipFree(c->ext_p[1]);
     rfx_plane_release(c);
-    rfx_dict_release(c);
     if (c->d_pc_counts) (void)hipFree(c->d_pc_counts);
     if (c->h_pin) (void)hipHostFree(c->h_pin);
     (void)hipEventDestroy(c->ev0);
@@ -93,7 +90,6 @@ extern "C" int rfx_hip_ctx_destroy(rfx_ctx_t *c) {
 }
 
 extern "C" int64_t rfx_hip_ctx_stat(rfx_ctx_t *c, int which) {
-    if (c && (which == 6 || which == 7)) return rfx_dict_stat(c, which - 6); // RFX_STAT_DICT_PASSES / RFX_STAT_DICT_FALLBACK
     if (!c || which < 0 || which > 5) return -1;
     return which == RFX_STAT_MASK_PASSES ? c->ext_i[0] : c->ext_i[3 + which];
 }

@@ -1334,7 +1334,7 @@ __global__ __launch_bounds__(RFX_BLOCK) void k_distinct_sample(const u64 *__rest
         }
     }
 }
-int rfx_estimate_distinct(rfx_ctx *c, const u64 *d_key, i64 nrows, double *est) { // (also the dictionary route's sizing, rfx_group_dict.hip)
+static int estimate_distinct(rfx_ctx *c, const u64 *d_key, i64 nrows, double *est) {
     const i64 nsamp = nrows < (1 << 15) ? nrows : (1 << 15);
     int rc = rfx_ws_reserve(c, (size_t)DSAMP_SLOTS * 8 + 512);
     if (rc != RFX_OK) return rc;
@@ -1358,7 +1358,7 @@ int rfx_group_part_hash_accumulate(rfx_ctx *c, const Plan &P0, int key_idx, cons
         // 256 partitions x one CU's LDS hold a few thousand keys each: beyond ~4 M distinct keys nearly every record overflows its
         // partition's table into the device-wide one (1e8 keys: 820 ms against 30) -- those go to the device-wide table directly
         double est = 0;
-        const int rc = rfx_estimate_distinct(c, (const u64 *)P0.cols[key_idx], P0.nrows, &est);
+        const int rc = estimate_distinct(c, (const u64 *)P0.cols[key_idx], P0.nrows, &est);
         if (rc != RFX_OK) return rc;
         c->ext_i[2] = (i64)est; // (the device-wide kernel's caller sizes its table by it)
         if (est > 4.0e6) return RFX_ESTATE;

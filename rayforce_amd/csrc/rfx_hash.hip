@@ -96,7 +96,6 @@ __global__ __launch_bounds__(RFX_BLOCK) void k_group_hash(const Plan P, const Ha
 
 struct MergeArgs {
     i64 capacity;
-    i64 fcells, fnull; // cells of the `from` arrays; which of them is the null key's (its key array has no entry worth reading there)
     int nagg;
     int kinds[RFX_MAX_AGGS];
     int f64s[RFX_MAX_AGGS];
@@ -111,10 +110,10 @@ struct MergeArgs {
 };
 
 __global__ __launch_bounds__(RFX_BLOCK) void k_hash_merge(const MergeArgs M, int *__restrict__ overflow) {
-    for (i64 i = blockIdx.x * (i64)RFX_BLOCK + threadIdx.x; i < M.fcells; i += (i64)gridDim.x * RFX_BLOCK) {
+    for (i64 i = blockIdx.x * (i64)RFX_BLOCK + threadIdx.x; i <= M.capacity; i += (i64)gridDim.x * RFX_BLOCK) {
         const u64 f = M.ffirst[i];
         if (f == (u64)RFX_INF_I64_D) continue;
-        const u64 key = (i == M.fnull) ? (u64)RFX_NULL_I64_D : M.fkeys[i];
+        const u64 key = (i == M.capacity) ? (u64)RFX_NULL_I64_D : M.fkeys[i];
         const i64 s = hash_slot(M.keys, M.capacity, key);
         if (s < 0) {
             atomicExch(overflow, 1);
@@ -125,9 +124,6 @@ __global__ __launch_bounds__(RFX_BLOCK) void k_hash_merge(const MergeArgs M, int
             group_merge_cell(&M.acc[a][s], M.cnt[a] ? &M.cnt[a][s] : (u64 *)0, M.kinds[a], M.f64s[a], M.facc[a][i], M.fcnt[a] ? M.fcnt[a][i] : 0ULL);
     }
 }
-
-int rfx_group_dict_hash_accumulate(rfx_ctx *c, const int64_t *d_key, const rfx_pred_t *preds, int npred, int logic, const rfx_agg_t *aggs,
-                                   int64_t nrows, int64_t row0, const rfx_hash_tables_t *t); // rfx_group_dict.hip
 
 static int check_hash(const rfx_agg_t *aggs, const rfx_hash_tables_t *t) {
     RFX_REQUIRE(t && t->d_keys && t->d_first, RFX_EINVAL, "hash tables / d_keys / d_first is NULL");
@@ -195,9 +191,6 @@ extern "C" int rfx_hip_group_hash_accumulate(rfx_ctx_t *c, const int64_t *d_key,
         return rfx_hip_group_hash_accumulate(c, d_key, preds, npred, logic, aggs + h, nrows, row0, &t2);
     }
     if (rc != RFX_OK) return rc;
-    // large inputs with few enough distinct keys: dictionary pass (key -> dense id) + the dense plane-partitioned group-by on the ids
-    rc = rfx_group_dict_hash_accumulate(c, d_key, preds, npred, logic, aggs, nrows, row0, t);
-    if (rc != RFX_ESTATE) return rc;
     if (rfx_plan_has_deep_expr(P)) { // expression trees: scratch columns first (the kernels here evaluate single operations only)
         RFX_REQUIRE(P.ncols + P.nx <= RFX_MAX_COLS, RFX_ELIMIT, "too many distinct columns once the expression trees are materialised");
         rc = rfx_plan_materialise_exprs(c, &P);
@@ -243,37 +236,6 @@ extern "C" int rfx_hip_group_hash_accumulate(rfx_ctx_t *c, const int64_t *d_key,
     return read_overflow(c, flag, "group_hash_accumulate");
 }
 
-// Dense tables keyed by a dictionary id (rfx_group_dict.hip: d_from_keys[id] = the key, id `from_null` = the null key) into a hashed
-// table set: one find-or-insert per occupied cell.
-int rfx_hash_merge_cells(rfx_ctx *c, const rfx_agg_t *aggs, const rfx_hash_tables_t *into, const rfx_group_tables_t *from, const u64 *d_from_keys,
-                         i64 from_null) {
-    MergeArgs M;
-    memset(&M, 0, sizeof(M));
-    M.capacity = into->capacity;
-    M.fcells = from->range;
-    M.fnull = from_null;
-    M.nagg = into->nagg;
-    M.keys = (u64 *)into->d_keys;
-    M.first = (u64 *)into->d_first;
-    M.fkeys = d_from_keys;
-    M.ffirst = (const u64 *)from->d_first;
-    for (int a = 0; a < into->nagg; a++) {
-        M.kinds[a] = aggs[a].kind;
-        M.f64s[a] = rfx_agg_input_type(&aggs[a]) == RFX_F64;
-        M.acc[a] = (u64 *)into->d_acc[a];
-        M.cnt[a] = (u64 *)into->d_cnt[a];
-        M.facc[a] = (const u64 *)from->d_acc[a];
-        M.fcnt[a] = (const u64 *)from->d_cnt[a];
-    }
-    int rc = rfx_ws_reserve(c, 256);
-    if (rc != RFX_OK) return rc;
-    int *flag = (int *)c->d_ws;
-    RFX_HIP_CHECK(hipMemsetAsync(flag, 0, 4, c->stream));
-    hipLaunchKernelGGL(k_hash_merge, dim3(rfx_grid(c) * 4), dim3(RFX_BLOCK), 0, c->stream, M, flag);
-    RFX_HIP_CHECK(hipGetLastError());
-    return read_overflow(c, flag, "group_hash_accumulate");
-}
-
 extern "C" int rfx_hip_hash_tables_merge(rfx_ctx_t *c, const rfx_agg_t *aggs, const rfx_hash_tables_t *into,
                                          const rfx_hash_tables_t *from) {
     RFX_REQUIRE(c, RFX_EINVAL, "ctx is NULL");
@@ -285,8 +247,6 @@ extern "C" int rfx_hip_hash_tables_merge(rfx_ctx_t *c, const rfx_agg_t *aggs, co
     MergeArgs M;
     memset(&M, 0, sizeof(M));
     M.capacity = into->capacity;
-    M.fcells = from->capacity + 1;
-    M.fnull = from->capacity;
     M.nagg = into->nagg;
     M.keys = (u64 *)into->d_keys;
     M.first = (u64 *)into->d_first;

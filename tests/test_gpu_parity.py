@@ -301,76 +301,6 @@ def test_sparse_keys_partitioned_hash_path(eng, flags):
         eng.tune(flags=0)
 
 
-@pytest.mark.parametrize("distinct", [40, 3000, 150_000, 390_000])
-def test_sparse_keys_dictionary_route(eng, distinct, monkeypatch):
-    """rfx_group_dict.hip: sparse keys as key -> dense id (one find-or-insert pass) + the dense group-by on the ids + one merge per distinct
-    key into the hashed tables.  Forced from 2^16 rows on (RFX_TUNE_CHUNK_SMALL); the context's counters say the route ran and did not give
-    up; RFX_NO_DICT=1 keeps to round 2's partition-by-hash kernels -- same answers (the oracle) either way.  Null keys (id 0 -> the tables'
-    dedicated slot), predicates (the dictionary ignores them: ids of unselected keys stay empty), several value columns, first / min / avg,
-    expression aggregates."""
-    n = 400_003
-    host = table(n, keys=distinct, nulls=True)
-    host["k"] = host["k"] * 1_000_003 - 77_777
-    qs = [{"by": "k", "s": ("sum", "v"), "c": ("count", "a")},
-          {"by": "k", "mx": ("max", "a"), "av": ("avg", "w"), "f": ("first", "v")},
-          {"where": ("<", "a", 400_000), "by": "k", "s": ("sum", ("*", "v", "a")), "c": ("count", "a")},
-          {"where": ("and", ("<", "a", 100_000), (">", "w", -0.3)), "by": "k", "s": ("sum", "v"), "mn": ("min", "w")},
-          {"by": "k", "s1": ("sum", "v"), "s2": ("sum", "w"), "s3": ("sum", "a")}]
-    try:
-        eng.tune(flags=CHUNK_SMALL)
-        before = (eng.stat(6), eng.stat(7))
-        for q in qs:
-            check_select(eng, host, q)
-        assert eng.stat(6) - before[0] >= len(qs) and eng.stat(7) == before[1], (before, eng.stat(6), eng.stat(7))
-        monkeypatch.setenv("RFX_NO_DICT", "1")
-        before = eng.stat(6)
-        check_select(eng, host, qs[0])
-        assert eng.stat(6) == before
-        monkeypatch.delenv("RFX_NO_DICT")
-        # a null key among sparse keys: ONE group (the flat ABI's rule), in first-occurrence order
-        host = table(n, keys=3000)
-        host["k"] = host["k"] * 1_000_003 - 77_777
-        nul = rfo.gen_i64(n, 321, 97) == 0
-        host["k"][nul] = NULL
-        got = eng.select({"from": dev(eng, host), "by": "k", "c": ("count", "a"), "s": ("sum", "v")})
-        gk = got["k"].cpu().numpy()
-        assert (gk == NULL).sum() == 1 and len(gk) == len(np.unique(host["k"]))
-        i = int(np.nonzero(gk == NULL)[0][0])
-        assert int(got["c"][i]) == int(nul.sum()) and abs(float(got["s"][i]) - host["v"][nul].sum()) <= 1e-9 * host["v"][nul].sum()
-        first_rows = {k: r for r, k in reversed(list(enumerate(host["k"].tolist())))}
-        assert [first_rows[k] for k in gk.tolist()] == sorted(first_rows.values())
-    finally:
-        eng.tune(flags=0)
-
-
-def test_sparse_keys_dictionary_route_default_threshold(eng):
-    """5e6 rows, 1e6 sparse keys: the route at its default row threshold (2^22), ids through the plane kernels."""
-    n = 5_000_011
-    host = table(n, keys=1_000_000)
-    host["k"] = host["k"] * 999_983 + 12_345
-    before = (eng.stat(6), eng.stat(0))
-    check_select(eng, host, {"by": "k", "s": ("sum", "v")})
-    check_select(eng, host, {"where": ("<", "a", 500_000), "by": "k", "s": ("sum", "v"), "c": ("count", "v")})
-    assert eng.stat(6) - before[0] == 2 and eng.stat(0) - before[1] == 2, (before, eng.stat(6), eng.stat(0))
-
-
-def test_sparse_keys_dictionary_gives_up_when_the_sample_lied(eng):
-    """Distinct keys the strided sample cannot see (every row its own key in the first tenth of the column, few keys after): the id space
-    overflows, the launch gives up (counter 7) and round 2's kernels answer."""
-    n = 900_001
-    host = table(n, keys=50)
-    host["k"] = host["k"] * 1_000_003 + 5
-    m = n // 3
-    host["k"][:m] = np.arange(m, dtype=np.int64) * 7_000_001 + 3  # unique keys, contiguous: the sample (stride n / 2^15) sees 1/27 of them
-    try:
-        eng.tune(flags=CHUNK_SMALL)
-        before = (eng.stat(6), eng.stat(7))
-        check_select(eng, host, {"by": "k", "s": ("sum", "v"), "c": ("count", "a")})
-        assert eng.stat(6) - before[0] >= 1, (before, eng.stat(6), eng.stat(7))
-    finally:
-        eng.tune(flags=0)
-
-
 def test_hash_primitives_pinned(eng):
     import ctypes as C
     from rayforce_amd import _lib as L
