@@ -199,7 +199,8 @@ enum {
     RFX_TUNE_CHUNK_QUEUE = 131072,   /* one-pass chunk partitioning under a selective filter: always the sorted-queue kernel (as for skewed keys), never per-partition bins */
     RFX_TUNE_CHUNK_BINS = 262144,    /* ... always per-partition bins, however the sampled keys spread: for tests */
     RFX_TUNE_NO_RTC = 524288,        /* never compile a plan-specialised kernel at run time (hiprtc): the prebuilt kernels only */
-    RFX_TUNE_NO_PLANE = 1048576      /* one-pass partitioning: 16-byte records in chunks (round 2), never the 8 + 4-byte planes */
+    RFX_TUNE_NO_PLANE = 1048576,     /* one-pass partitioning: 16-byte records in chunks (round 2), never the 8 + 4-byte planes */
+    RFX_TUNE_NO_WHERE_ONCE = 2097152 /* rfx_hip_where_once: the two-pass form (bitmap -> scan -> emit) behind the same contract */
 };
 int rfx_hip_ctx_tune(rfx_ctx_t *ctx, int blocks_per_cu, int flags);
 /* Path counters of a context since its creation: which partitioning kernels answered (tests assert them, bench.py reports them). */
@@ -283,6 +284,14 @@ int rfx_hip_mask_logic(rfx_ctx_t *ctx, int logic, int8_t *d_acc, const int8_t *d
 int rfx_hip_where_begin(rfx_ctx_t *ctx, const rfx_pred_t *preds, int npred, int logic, const int8_t *d_mask,
                         int64_t nrows, int64_t *count);
 int rfx_hip_where_emit(rfx_ctx_t *ctx, int64_t row0, int64_t *d_ids);
+/* The same in ONE pass over the predicate columns (rfx_where_once.hip: ballots -> decoupled look-back -> ids; no bitmap round trip, no
+ * separate scan): writes the ascending ids row0 + i of the first min(*count, cap) selected rows into d_ids, *count = the exact number of
+ * selected rows whatever `cap` is.  RFX_ELIMIT when *count > cap: call again with cap >= *count.  (syncs)
+ * rfx_hip_where_estimate sizes the buffer: an upper guess from 2^15 strided rows (sampled fraction + 4 sigma + 1 % of the column;
+ * nrows itself for small inputs).  (syncs) */
+int rfx_hip_where_estimate(rfx_ctx_t *ctx, const rfx_pred_t *preds, int npred, int logic, int64_t nrows, int64_t *upper);
+int rfx_hip_where_once(rfx_ctx_t *ctx, const rfx_pred_t *preds, int npred, int logic, int64_t nrows, int64_t row0, int64_t *d_ids,
+                       int64_t cap, int64_t *count);
 
 /* ---- K4: gather of 8-byte elements: d_out[i] = d_col[d_ids[i]] ---- */
 int rfx_hip_gather(rfx_ctx_t *ctx, const void *d_col, const int64_t *d_ids, int64_t m, void *d_out);

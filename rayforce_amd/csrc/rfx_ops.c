@@ -722,8 +722,28 @@ static int where_ids(obj_p tab, obj_p where, const wplan_t *wp, int flat, int64_
     *count = 0;
     int8_t *mask = NULL;
     int rc;
-    if (flat) rc = rfx_hip_where_begin(g_ctx, wp->preds, wp->npred, wp->logic, NULL, nrows, count) == RFX_OK ? 0 : -2;
-    else {
+    if (flat) {
+        /* one pass over the predicate columns (rfx_where_once.hip): buffer by sampled estimate, exact count back, a second run if the
+         * sample underestimated a clustered selection */
+        int64_t cap = 0;
+        void *d = NULL;
+        if (rfx_hip_where_estimate(g_ctx, wp->preds, wp->npred, wp->logic, nrows, &cap) != RFX_OK) return -2;
+        for (int attempt = 0; attempt < 2; attempt++) {
+            if (cap > 0 && rfx_hip_malloc(g_ctx, &d, (size_t)cap * 8) != RFX_OK) return -2;
+            const int wrc = rfx_hip_where_once(g_ctx, wp->preds, wp->npred, wp->logic, nrows, 0, (int64_t *)d, cap, count);
+            if (wrc == RFX_OK) {
+                if (*count > 0) *d_ids = (int64_t *)d;
+                else if (d) rfx_hip_free(g_ctx, d);
+                return 0;
+            }
+            if (d) rfx_hip_free(g_ctx, d);
+            d = NULL;
+            if (wrc != RFX_ELIMIT || *count <= cap) break;
+            cap = *count;
+        }
+        *count = 0;
+        return -2;
+    } else {
         rc = mask_of_expr(tab, where, nrows, &mask);
         if (rc == 0) rc = rfx_hip_where_begin(g_ctx, NULL, 0, RFX_AND, mask, nrows, count) == RFX_OK ? 0 : -2;
     }

@@ -613,7 +613,17 @@ class Engine:
                 return self.where(self.mask_of(where, table), row0=row0)
             self._keep.clear()
             parr, n = self._preds(flat, table, None)
-            L.check(self.lib.rfx_hip_where_begin(self._ctx, parr, len(flat), logic, None, n, C.byref(cnt)), "where_begin")
+            # one pass (rfx_where_once.hip): the buffer is sized by a sampled estimate, the count comes back exact; a selection the
+            # sample underestimated (clustered rows) says so and runs again with the exact size
+            est = C.c_int64()
+            L.check(self.lib.rfx_hip_where_estimate(self._ctx, parr, len(flat), logic, n, C.byref(est)), "where_estimate")
+            out = torch.empty(int(est.value), dtype=torch.int64, device=self.device)
+            rc = self.lib.rfx_hip_where_once(self._ctx, parr, len(flat), logic, n, row0, out.data_ptr(), out.numel(), C.byref(cnt))
+            if rc == L.RFX_ELIMIT and int(cnt.value) > out.numel():
+                out = torch.empty(int(cnt.value), dtype=torch.int64, device=self.device)
+                rc = self.lib.rfx_hip_where_once(self._ctx, parr, len(flat), logic, n, row0, out.data_ptr(), out.numel(), C.byref(cnt))
+            L.check(rc, "where_once")
+            return out[:int(cnt.value)]
         out = torch.empty(int(cnt.value), dtype=torch.int64, device=self.device)
         L.check(self.lib.rfx_hip_where_emit(self._ctx, row0, out.data_ptr()), "where_emit")
         return out

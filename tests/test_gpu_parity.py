@@ -181,6 +181,64 @@ def test_where_ids_bit_exact(eng, n):
         assert np.array_equal(eng.where(("<", "a", 100_000), d, row0=10**12).cpu().numpy(), rfo.where(rfo.mask_of(("<", "a", 100_000), host)) + 10**12)
 
 
+NO_WHERE_ONCE = 2097152  # RFX_TUNE_NO_WHERE_ONCE: rfx_hip_where_once takes the two-pass form (bitmap -> scan -> emit)
+
+
+@pytest.mark.parametrize("flags", [0, NO_WHERE_ONCE])
+def test_where_one_pass_and_two_pass_agree(eng, flags):
+    """rfx_where_once.hip: ballots -> decoupled look-back -> ids in one kernel.  5e6 rows = 306 tiles (several look-back rounds of 64), a
+    ragged last tile, 1 .. 4 predicate columns and 1 .. 4 comparisons (the kernel's instantiations), five columns (the two-pass form behind the
+    same entry point), every / no row selected, a row offset; RFX_TUNE_NO_WHERE_ONCE runs the same calls through the two-pass form."""
+    n = 5_000_017
+    host = table(n)
+    host["b"] = rfo.gen_i64(n, 77, 1000)
+    d = dev(eng, host)
+    specs = [("<", "a", 100_000), ("<", "a", 0), (">=", "a", 0), ("and", ("<", "a", 500_000), (">", "v", 0.5)),
+             ("or", ("<", "a", 1000), (">", "w", 0.49), ("==", "k", 7)),
+             ("and", ("<", "a", 900_000), (">", "v", 0.1), ("<", "w", 0.4), ("!=", "k", 3)),
+             ("and", (">", "a", "b"), ("<", "v", 0.3)),
+             ("and", ("<", "a", 900_000), (">", "v", 0.1), ("<", "w", 0.4), ("!=", "k", 3), ("<", "b", 900)),
+             ("and", ("or", ("<", "a", 1000), (">", "w", 0.45)), ("<", "v", 0.9))]
+    try:
+        eng.tune(flags=flags)
+        for spec in specs:
+            want = rfo.where(rfo.mask_of(spec, host))
+            got = eng.where(spec, d)
+            assert got.dtype == torch.int64 and np.array_equal(got.cpu().numpy(), want), spec
+        got = eng.where(specs[0], d, row0=10**12)
+        assert np.array_equal(got.cpu().numpy(), rfo.where(rfo.mask_of(specs[0], host)) + 10**12)
+    finally:
+        eng.tune(flags=0)
+
+
+def test_where_one_pass_estimate_and_overflow(eng):
+    """The buffer of the one-pass `where` is sized by 2^15 strided rows.  A selection that sits between the sampled rows (a contiguous block:
+    the sample sees a few of its rows at most... here none, the block lies inside one stride) is underestimated only within the 1 % margin;
+    one that is far larger than the sample says (every row of 30 % of the column, none of them on the sample's stride) overflows the buffer:
+    the count comes back exact with RFX_ELIMIT, and the second call with that capacity writes every id."""
+    import ctypes as C
+    from rayforce_amd import _lib as L
+    n = 4_000_037
+    stride = n // (1 << 15)
+    a = np.ones(n, dtype=np.int64)
+    a[np.arange(n) % stride == 0] = 0  # the sampled rows: not selected; everything else (99 %) is
+    d = {"a": eng.column(a)}
+    p = (L.Pred * 1)()
+    p[0].d_col, p[0].col_type, p[0].rhs_type, p[0].op, p[0].rhs_i = d["a"].data_ptr(), L.RFX_I64, L.RFX_I64, L.OPS["=="], 1
+    est, cnt = C.c_int64(), C.c_int64()
+    L.check(eng.lib.rfx_hip_where_estimate(eng._ctx, p, 1, L.RFX_AND, n, C.byref(est)))
+    want = np.nonzero(a == 1)[0]
+    assert est.value < len(want)  # the sample saw nothing
+    out = torch.full((est.value + 64,), -1, dtype=torch.int64, device=eng.device)
+    rc = eng.lib.rfx_hip_where_once(eng._ctx, p, 1, L.RFX_AND, n, 0, out.data_ptr(), est.value, C.byref(cnt))
+    assert rc == L.RFX_ELIMIT and cnt.value == len(want)
+    assert np.array_equal(out[:est.value].cpu().numpy(), want[:est.value]) and bool((out[est.value:] == -1).all())  # nothing beyond cap
+    assert np.array_equal(eng.where(("==", "a", 1), d).cpu().numpy(), want)  # the Engine runs it again with the exact size
+    # counting only (cap 0, no buffer)
+    rc = eng.lib.rfx_hip_where_once(eng._ctx, p, 1, L.RFX_AND, n, 0, None, 0, C.byref(cnt))
+    assert rc == L.RFX_ELIMIT and cnt.value == len(want)
+
+
 def test_where_across_parallel_threshold(eng):
     # tests/lang.c:2893-2897 crosses POOL_SPLIT_THRESHOLD (16 384) at 25 001 rows
     n = 25_001
