@@ -587,6 +587,26 @@ static int expr_operand(obj_p tab, obj_p e, const void **d, int *ctype) {
     *ctype = ot;
     return 0;
 }
+/* the SYMBOL vector an ENUM column indexes: the global its key names (in-memory pair: the key symbol; mmapped: the key's characters sit
+ * one page before the indices, core/util.h:103-105, core/binary.c:135-137).  NULL when it does not resolve; the caller drops it. */
+static obj_p enum_domain(obj_p e) {
+    int64_t key_id;
+    if (e->mmod == RFX_MMOD_INTERNAL) key_id = RFX_AS_LIST(e)[0]->i64;
+    else {
+        const char *ks = (const char *)e - 4096 + sizeof(rfx_obj_t);
+        key_id = H.intern(ks, (int64_t)strnlen(ks, 4096 - sizeof(rfx_obj_t)));
+    }
+    obj_p ka = H.i64(key_id);
+    ka->type = -RFX_TYPE_SYMBOL;
+    obj_p dom = H.eval(ka);
+    H.drop(ka);
+    if (dom && dom->type != RFX_TYPE_SYMBOL) {
+        H.drop(dom);
+        dom = NULL;
+    }
+    return dom;
+}
+#define RFX_ATTR_QUOTED 8 /* ATTR_QUOTED, core/ops.h:55: a symbol atom that stands for itself ('x), not for a column */
 static int g_where_virtual, g_where_data; /* comparisons of the where: in flight that read the virtual column / data columns of a parted table */
 static int plan_cmp(obj_p tab, obj_p e, rfx_pred_t *p) {
     if (e->type != RFX_TYPE_LIST || e->len != 3) return -1;
@@ -605,6 +625,25 @@ static int plan_cmp(obj_p tab, obj_p e, rfx_pred_t *p) {
     } else {
         if (l->type != -RFX_TYPE_SYMBOL) return -1;
         obj_p lc = table_col(tab, l->i64);
+        if (lc && lc->type == RFX_TYPE_ENUM) {
+            /* (== enum-column 'sym): the reference compares the domain's symbol at every index with the atom (MTYPE2(TYPE_ENUM, -TYPE_SYMBOL),
+             * core/cmp.c:260-281); the symbol's place in the domain is found once on the host and the INDEX column is compared on the
+             * device -- a symbol the domain does not hold selects nothing (index -1).  Only == : the other operators are the host's. */
+            if (f != F_EQ || r->type != -RFX_TYPE_SYMBOL || !(r->attrs & RFX_ATTR_QUOTED)) return -1;
+            obj_p dom = enum_domain(lc);
+            if (!dom) return -1;
+            int64_t at = -1;
+            for (int64_t i = 0; i < dom->len && at < 0; i++)
+                if (RFX_AS_I64(dom)[i] == r->i64) at = i;
+            H.drop(dom);
+            if (resident(enum_indices(lc), 0, &d) != RFX_OK) return -2;
+            g_where_data++;
+            p->d_col = d;
+            p->col_type = RFX_I64;
+            p->rhs_type = RFX_I64;
+            p->rhs_i = at;
+            return 0;
+        }
         if (!lc || !col_ctype(lc)) return -1;
         p->col_type = col_ctype(lc);
         if (resident(lc, 0, &d) != RFX_OK) return -2;
@@ -619,7 +658,14 @@ static int plan_cmp(obj_p tab, obj_p e, rfx_pred_t *p) {
     if (r->type == -RFX_TYPE_I64) { p->rhs_type = RFX_I64; p->rhs_i = r->i64; }
     else if (r->type == -RFX_TYPE_DATE && ldate) { p->rhs_type = RFX_I64; p->rhs_i = (int64_t)r->i32; } /* (== Date 2024.01.03): partition pruning, core/cmp.c:341-358 */
     else if (r->type == -RFX_TYPE_F64) { p->rhs_type = RFX_F64; p->rhs_f = r->f64; }
-    else if (r->type == -RFX_TYPE_SYMBOL) {
+    else if (r->type == -RFX_TYPE_SYMBOL && (r->attrs & RFX_ATTR_QUOTED)) {
+        /* a quoted symbol is a value, never a column name -- even when the table has a column of that name (eval_sym, core/eval.c:829):
+         * a SYMBOL column compares its interned ids with it (== and != ; the ordering of symbols is the host's business) */
+        obj_p lc = (l->type == -RFX_TYPE_SYMBOL) ? table_col(tab, l->i64) : NULL;
+        if (!lc || lc->type != RFX_TYPE_SYMBOL || (f != F_EQ && f != F_NE)) return -1;
+        p->rhs_type = RFX_I64;
+        p->rhs_i = r->i64;
+    } else if (r->type == -RFX_TYPE_SYMBOL) {
         obj_p rc = table_col(tab, r->i64);
         if (!rc || !col_ctype(rc) || (llen >= 0 && rc->len != llen)) return -1;
         g_where_data++;
@@ -1338,17 +1384,8 @@ static obj_p select_impl(obj_p dict) {
                         okeys = H.vector(key_out_type, groups);
                         if (ok) ok = fetch(RFX_AS_RAW(okeys), dkeys_out, (size_t)groups * 8) == RFX_OK;
                         if (ok && kenum) { /* indices -> symbols of the enum's domain (the global its key names) */
-                            int64_t key_id;
-                            if (kenum->mmod == RFX_MMOD_INTERNAL) key_id = RFX_AS_LIST(kenum)[0]->i64;
-                            else { /* mmapped: the key's characters sit one page before the indices (core/util.h:103-104) */
-                                const char *ks = (const char *)kenum - 4096 + sizeof(rfx_obj_t); /* NUL-terminated, core/binary.c:135-137 */
-                                key_id = H.intern(ks, (int64_t)strnlen(ks, 4096 - sizeof(rfx_obj_t)));
-                            }
-                            obj_p ka = H.i64(key_id);
-                            ka->type = -RFX_TYPE_SYMBOL;
-                            obj_p dom = H.eval(ka);
-                            H.drop(ka);
-                            int good = dom && dom->type == RFX_TYPE_SYMBOL;
+                            obj_p dom = enum_domain(kenum);
+                            int good = dom != NULL;
                             int64_t *kk = RFX_AS_I64(okeys);
                             for (int64_t g = 0; g < groups && good; g++) {
                                 if (kk[g] < 0 || kk[g] >= dom->len) good = 0;

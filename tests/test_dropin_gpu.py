@@ -188,6 +188,13 @@ ENUMS = [
     ("e1", "{c: (count a) sm: (sum v) from: u by: s}", ["c", "sm"], True),        # mmapped ENUM column of a splayed table
     ("e2", "{m: (max a) from: u where: (< a 500000) by: s}", ["m"], True),
     ("e3", "{c: (sum a) from: w by: s}", ["c"], True),                             # in-memory (enum 'sym ...) pair
+    # symbol comparisons (round 3): an ENUM column against a quoted symbol = its index column against the symbol's place in the domain
+    ("e4", "{c: (count a) sm: (sum v) from: u where: (== s 'cc)}", ["c", "sm"], True),
+    ("e5", "{c: (sum a) m: (max a) from: w where: (and (== s 'bb) (< a 500000))}", ["c", "m"], True),
+    ("e6", "{c: (count a) from: u where: (== s 'zz)}", ["c"], True),               # a symbol the domain does not hold: nothing selected
+    ("e7", "{c: (count a) sm: (sum v) from: t2 where: (== s 'dd)}", ["c", "sm"], True),  # a plain SYMBOL column: interned ids
+    ("e8", "{c: (count a) from: t2 where: (and (!= s 'dd) (!= s 'a))}", ["c"], True),    # ... and a quoted symbol that is ALSO a column's name
+    ("e9", "{c: (count a) from: u where: (!= s 'cc)}", ["c"], False),              # only == on enums (core/cmp.c:260-281): handed back
 ]
 
 
@@ -251,4 +258,4 @@ def test_parted_and_enum_columns_inside_the_real_reference(built, tmp_path):
     print(ref.LAST_STDERR)  # RFX_TRACE=1: why a query was handed back
     assert int(st[0]) == on_gpu and int(st[1]) == len(PARTED + ENUMS) - on_gpu, st
     assert len(res["g_p2_Date"]) == 4 and len(res["g_p4_Date"]) == 2
-    assert int(st[4]) <= 4 + 3 + 2  # uploads: the parted table's four 8-byte columns once (pinned; the B8 column is not uploaded), the splayed / in-memory tables' columns
+    assert int(st[4]) <= 4 + 3 + 2 + 3  # uploads (t2: three more): the parted table's four 8-byte columns once (pinned; the B8 column is not uploaded), the splayed / in-memory tables' columns
