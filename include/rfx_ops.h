@@ -37,8 +37,10 @@
  * the library runs as a plugin (the host exports them, rayforce.syms), and return an error object otherwise.
  *
  * Data residency: columns are host objects.  The first query that touches a column uploads it to HBM (PCIe) and keeps
- * it in a residency cache keyed by (payload pointer, length, type) and guarded by a sampled checksum; later queries
- * run HBM-resident.  rfx_pin / rfx_unpin / rfx_cache_clear make that explicit.
+ * it in a residency cache keyed by (payload pointer, length, type); an UNPINNED copy is proven current at every use -- by the
+ * soft-dirty bits of the payload's pages where the kernel tracks them (O(pages)), else by a checksum of the whole payload -- and
+ * refreshed when the host wrote into it; later queries run HBM-resident.  rfx_pin (trusted until rfx_invalidate / rfx_unpin)
+ * and rfx_cache_clear make that explicit.
  */
 #ifndef RFX_OPS_H
 #define RFX_OPS_H

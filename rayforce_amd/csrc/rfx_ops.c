@@ -15,6 +15,8 @@
 #include <pthread.h>
 #include <stdlib.h>
 #include <unistd.h>
+#include <fcntl.h>
+#include <sys/mman.h>
 #include <string.h>
 #include <time.h>
 #include "rfx_abi.h"
@@ -170,6 +172,8 @@ static int ensure_ctx(void) {
  *     allocator put at the same address, a freed temporary whose address was recycled: all change the checksum and cost one
  *     re-upload, never a stale answer.  (Round 1 sampled 64 cells: one changed cell could escape; B8 masks collided almost
  *     always.)  Reading the host payload costs ~10 ms per GB on the box's cores -- still 15x cheaper than the PCIe upload it saves;
+ *     where the kernel tracks soft-dirty pages (round 3, sd_* below) the checksum is taken once and later uses look at the
+ *     payload's page-table bits instead: O(pages), 16 MB of pagemap per 8 GB column;
  *   - rfx_pin: the host promises to call rfx_invalidate / rfx_unpin before it writes into the vector (INTEGRATION.md shows the
  *     two places in the reference: `set` of a column and the rc == 1 in-place arithmetic, core/math.c:2248); a pinned entry is
  *     trusted without the checksum, which is what makes repeated queries over 8 GB columns free of host work.
@@ -185,12 +189,17 @@ typedef struct {
     size_t bytes;
     int pinned;
     uint64_t tick, epoch;
+    int tracked;       /* soft-dirty tracking: the payload's whole pages were clean-marked BEFORE `sum` was taken (see sd_*) */
+    int stable;        /* ... uses in a row at which the checksum found the payload unchanged (tracking starts at SD_STABLE_USES) */
+    int sd_never;      /* ... cannot be tracked (file-backed / shared pages): the checksum every time */
+    uint64_t edge_sum; /* ... checksum of the payload bytes in its first and last, partial pages (they hold other objects too) */
 } resident_t;
 static resident_t *g_res;
 static int g_nres, g_capres;
 static uint64_t g_tick, g_epoch = 1;
 static size_t g_res_bytes;
 static int64_t g_stat[10]; /* see rfx_stats */
+static int64_t g_sd_hits;  /* uses of an unpinned cached column proven current by its pages' soft-dirty bits instead of the checksum */
 enum { ST_SELECT_GPU, ST_SELECT_DELEGATED, ST_JOIN_GPU, ST_JOIN_DELEGATED, ST_UPLOADS, ST_CACHE_HITS, ST_CACHE_STALE, ST_OPS, ST_SCOPE_SAMPLED, ST_SCOPE_RETRIED };
 
 typedef struct {
@@ -248,6 +257,151 @@ static uint64_t payload_sum(const void *p, size_t bytes) {
         h = (h ^ job[i].h) * 0x9E3779B97F4A7C15ULL; /* chunk order matters: a value moved between chunks changes the sum */
     }
     return h;
+}
+
+/* ---- O(pages) validation of unpinned columns: soft-dirty page tracking ----
+ * The full-payload checksum costs 0.3 s per 8 GB column and query.  Where the kernel tracks soft-dirty pages (CONFIG_MEM_SOFT_DIRTY:
+ * writing "4" to /proc/self/clear_refs write-protects every page of the process and clears bit 55 of its pagemap entry; the first
+ * write to a page afterwards sets it again) a cached payload is proven current by reading 8 bytes of pagemap per 4 KB page of it --
+ * 16 MB for an 8 GB column -- provided its pages were cleared BEFORE the checksum that vouches for the device copy was taken:
+ *   use of a tracked entry:   no soft-dirty page among the payload's WHOLE pages and the checksum of its first / last partial page
+ *                             (shared with other objects -- the vector's own header with its reference count sits there) unchanged
+ *                             -> current.  Anything else -> the entry is no longer tracked, and is treated like a new one:
+ *   (re)validation / upload:  clear_refs FIRST (once per operator call; every other tracked entry is scanned just before, because
+ *                             the clear wipes their evidence too: a dirty one loses its tracking and meets its checksum at its next
+ *                             use), THEN the checksum, THEN the compare / upload.  A host write that races with the call lands after
+ *                             the clear and is seen at the next use.
+ * File-backed and shared pages (pagemap bit 61: an mmapped column file other processes may write) are never tracked.  The kernel
+ * is PROBED once (map two pages, clear, write one, look); without the feature -- the build container's kernel has none, the MI355X
+ * boxes' has -- or with RFX_SOFT_DIRTY=0 nothing changes: the checksum on every use.  Cost to the HOST: after a clear the first
+ * write to each of its pages takes a minor fault; clears happen only in calls that upload or re-validate a column, never in the steady
+ * state of repeated queries over unchanged columns.
+ * Measured (MI355X box, tools/unpinned.py: the c3w query over three unpinned 8 GB columns): 156.6 ms per query by checksums (52 ms a
+ * column on 32 threads), 66.7 ms by page bits read on one thread; the clear itself 1.4 s once. */
+#define SD_MIN_BYTES ((size_t)1 << 20)
+#define SD_STABLE_USES 2 /* a column is tracked once this many uses in a row found it unchanged: clear_refs walks EVERY page of the process
+                          * (measured: 1.4 s with 24 GB resident), which only pays for columns that are read far more often than written */
+static int g_sd_state = -1; /* -1 not probed, 0 unavailable / off, 1 works */
+static int g_sd_pagemap = -1;
+static uintptr_t g_sd_page = 4096;
+static uint64_t g_sd_clear_epoch;
+static int sd_clear(void) {
+    int fd = open("/proc/self/clear_refs", O_WRONLY);
+    if (fd < 0) return -1;
+    const ssize_t w = write(fd, "4", 1);
+    close(fd);
+    return w == 1 ? 0 : -1;
+}
+/* any soft-dirty page in [lo, hi) (page-aligned)?  1 yes, 0 none, -1 cannot tell (read failed / file-backed or shared pages) */
+static int sd_scan_range(uintptr_t lo, uintptr_t hi) {
+    static __thread uint64_t buf[4096];
+    for (uintptr_t a = lo; a < hi;) {
+        size_t n = (hi - a) / g_sd_page;
+        if (n > 4096) n = 4096;
+        const ssize_t got = pread(g_sd_pagemap, buf, n * 8, (off_t)((a / g_sd_page) * 8));
+        if (got != (ssize_t)(n * 8)) return -1;
+        for (size_t i = 0; i < n; i++) {
+            if (buf[i] & (1ULL << 61)) return -1;
+            if (buf[i] & (1ULL << 55)) return 1;
+        }
+        a += n * g_sd_page;
+    }
+    return 0;
+}
+typedef struct {
+    uintptr_t lo, hi;
+    int r;
+} sd_job_t;
+static void *sd_worker(void *arg) {
+    sd_job_t *j = (sd_job_t *)arg;
+    j->r = sd_scan_range(j->lo, j->hi);
+    return NULL;
+}
+/* the same over a large range: the kernel walks the page tables for every entry read (~10 ns a page: 20 ms per 8 GB), so the range is
+ * split over up to 16 readers */
+static int sd_scan(uintptr_t lo, uintptr_t hi) {
+    enum { MAXT = 16 };
+    const size_t pages = (hi - lo) / g_sd_page;
+    int nt = (int)(pages >> 16); /* >= 65 536 pages (256 MB) per reader */
+    if (nt > MAXT) nt = MAXT;
+    if (nt <= 1) return sd_scan_range(lo, hi);
+    sd_job_t job[MAXT];
+    pthread_t th[MAXT];
+    const size_t per = (pages + (size_t)nt - 1) / (size_t)nt;
+    int started = 0, r = 0;
+    for (int i = 0; i < nt; i++) {
+        job[i].lo = lo + (uintptr_t)i * per * g_sd_page;
+        job[i].hi = (i == nt - 1 || job[i].lo + per * g_sd_page > hi) ? hi : job[i].lo + per * g_sd_page;
+        if (job[i].lo > hi) job[i].lo = hi;
+        if (i < nt - 1 && pthread_create(&th[i], NULL, sd_worker, &job[i]) == 0) started |= 1 << i;
+        else sd_worker(&job[i]);
+    }
+    for (int i = 0; i < nt; i++) {
+        if (started & (1 << i)) pthread_join(th[i], NULL);
+        if (job[i].r < 0) r = -1;
+        else if (job[i].r > 0 && r == 0) r = 1;
+    }
+    return r;
+}
+static void sd_probe(void) {
+    g_sd_state = 0;
+    const char *e = getenv("RFX_SOFT_DIRTY");
+    if (e && atoi(e) == 0) return;
+    const long pg = sysconf(_SC_PAGESIZE);
+    if (pg < 4096) return;
+    g_sd_page = (uintptr_t)pg;
+    g_sd_pagemap = open("/proc/self/pagemap", O_RDONLY);
+    if (g_sd_pagemap < 0) return;
+    unsigned char *m = (unsigned char *)mmap(NULL, 2 * g_sd_page, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+    if (m == MAP_FAILED) return;
+    m[0] = 1;
+    m[g_sd_page] = 1;
+    if (sd_clear() == 0 && sd_scan((uintptr_t)m, (uintptr_t)m + 2 * g_sd_page) == 0) {
+        *(volatile unsigned char *)(m + g_sd_page) = 2;
+        if (sd_scan((uintptr_t)m, (uintptr_t)m + g_sd_page) == 0 && sd_scan((uintptr_t)m + g_sd_page, (uintptr_t)m + 2 * g_sd_page) == 1) g_sd_state = 1;
+    }
+    munmap(m, 2 * g_sd_page);
+    if (getenv("RFX_TRACE")) fprintf(stderr, "[rfx] soft-dirty page tracking: %s\n", g_sd_state ? "available (unpinned columns are validated by their pages)" : "not available (full checksum per use)");
+}
+/* the payload's whole pages */
+static int sd_interior(const void *host, size_t bytes, uintptr_t *lo, uintptr_t *hi) {
+    const uintptr_t a = (uintptr_t)host, b = a + bytes;
+    *lo = (a + g_sd_page - 1) & ~(g_sd_page - 1);
+    *hi = b & ~(g_sd_page - 1);
+    return *hi > *lo;
+}
+static uint64_t sd_edge_sum(const void *host, size_t bytes) {
+    uintptr_t lo, hi;
+    if (!sd_interior(host, bytes, &lo, &hi)) return 0;
+    const uintptr_t a = (uintptr_t)host, b = a + bytes;
+    const uint64_t h = sum_range((const unsigned char *)a, lo - a), t = sum_range((const unsigned char *)hi, b - hi);
+    return h ^ ((t << 21) | (t >> 43));
+}
+static int sd_usable(const void *host, size_t bytes) {
+    if (g_sd_state < 0) sd_probe();
+    uintptr_t lo, hi;
+    return g_sd_state == 1 && bytes >= SD_MIN_BYTES && sd_interior(host, bytes, &lo, &hi);
+}
+/* clean-mark the process' pages, once per operator call; every tracked entry is looked at first (the clear wipes its evidence) */
+static int sd_call_clear(void) {
+    if (g_sd_clear_epoch == g_epoch) return 0;
+    for (int i = 0; i < g_nres; i++) {
+        if (!g_res[i].tracked) continue;
+        uintptr_t lo, hi;
+        if (!sd_interior(g_res[i].host, g_res[i].bytes, &lo, &hi) || sd_scan(lo, hi) != 0) g_res[i].tracked = 0;
+    }
+    if (sd_clear() != 0) { /* the kernel took the feature away (permissions?): back to checksums for good */
+        g_sd_state = 0;
+        for (int i = 0; i < g_nres; i++) g_res[i].tracked = 0;
+        return -1;
+    }
+    g_sd_clear_epoch = g_epoch;
+    return 0;
+}
+static int sd_entry_clean(const resident_t *r) {
+    uintptr_t lo, hi;
+    if (g_sd_state != 1 || !sd_interior(r->host, r->bytes, &lo, &hi)) return 0;
+    return sd_scan(lo, hi) == 0 && sd_edge_sum(r->host, r->bytes) == r->edge_sum;
 }
 
 static void res_free(int i) {
@@ -457,10 +611,33 @@ static int resident(obj_p col, int pin, const void **dev) {
     uint64_t sum = 0;
     for (int i = 0; i < g_nres; i++)
         if (g_res[i].host == host && g_res[i].len == col->len && g_res[i].type == ktype) {
+            int track = 0;
             if (!g_res[i].pinned) { /* unpinned: prove the copy current */
+                if (!px && g_res[i].tracked && sd_entry_clean(&g_res[i])) { /* by its pages (soft-dirty bits): nothing wrote there */
+                    g_sd_hits++;
+                    g_res[i].tick = ++g_tick;
+                    g_res[i].epoch = g_epoch;
+                    g_res[i].pinned |= pin;
+                    g_stat[ST_CACHE_HITS]++;
+                    *dev = g_res[i].dev;
+                    return RFX_OK;
+                }
+                g_res[i].tracked = 0;
+                /* by its checksum -- taken AFTER the pages were clean-marked, so that it can vouch for them from now on */
+                track = !px && !g_res[i].sd_never && g_res[i].stable >= SD_STABLE_USES && sd_usable(host, bytes) && sd_call_clear() == 0;
                 sum = px ? proxy_sum(px) : payload_sum(host, bytes);
                 have_sum = 1;
             }
+            if (track) {
+                uintptr_t lo, hi;
+                sd_interior(host, bytes, &lo, &hi);
+                if (sd_scan(lo, hi) < 0) g_res[i].sd_never = 1, track = 0; /* file-backed / shared pages: never by soft-dirty bits */
+                else {
+                    g_res[i].tracked = 1; /* (a write since the clear shows at the next use and costs one more checksum) */
+                    g_res[i].edge_sum = sd_edge_sum(host, bytes);
+                }
+            }
+            if (!g_res[i].pinned) g_res[i].stable = (g_res[i].sum == sum) ? g_res[i].stable + 1 : 0;
             if (g_res[i].pinned || g_res[i].sum == sum) {
                 g_res[i].tick = ++g_tick;
                 g_res[i].epoch = g_epoch;
@@ -491,15 +668,17 @@ static int resident(obj_p col, int pin, const void **dev) {
     void *d = NULL;
     int rc = rfx_hip_malloc(g_ctx, &d, bytes ? bytes : 8);
     if (rc != RFX_OK) return rc;
+    /* the checksum, THEN the copy: a host write racing with this call is either in both, or in the copy only and costs one refresh at
+     * the next use -- never a device copy older than what vouches for it */
+    if (!have_sum) sum = px ? proxy_sum(px) : payload_sum(host, bytes);
     rc = px ? proxy_upload(px, d) : rfx_hip_h2d_pipelined(g_ctx, d, host, bytes); /* heap vector or mmapped column file alike: staged through pinned buffers */
     if (rc != RFX_OK) { rfx_hip_free(g_ctx, d); return rc; }
     g_stat[ST_UPLOADS]++;
-    if (!have_sum) sum = px ? proxy_sum(px) : payload_sum(host, bytes);
     if (g_nres == g_capres) {
         g_capres = g_capres ? g_capres * 2 : 32;
         g_res = (resident_t *)realloc(g_res, sizeof(resident_t) * (size_t)g_capres);
     }
-    g_res[g_nres++] = (resident_t){host, col->len, ktype, sum, d, bytes, pin, ++g_tick, g_epoch};
+    g_res[g_nres++] = (resident_t){host, col->len, ktype, sum, d, bytes, pin, ++g_tick, g_epoch, 0, 0, 0, 0}; /* (page tracking starts once the column has proven stable) */
     g_res_bytes += bytes;
     *dev = d;
     return RFX_OK;
@@ -630,6 +809,7 @@ static int plan_cmp(obj_p tab, obj_p e, rfx_pred_t *p) {
              * core/cmp.c:260-281); the symbol's place in the domain is found once on the host and the INDEX column is compared on the
              * device -- a symbol the domain does not hold selects nothing (index -1).  Only == : the other operators are the host's. */
             if (f != F_EQ || r->type != -RFX_TYPE_SYMBOL || !(r->attrs & RFX_ATTR_QUOTED)) return -1;
+            if (lc->mmod != RFX_MMOD_INTERNAL) return -1; /* an mmapped enum (splayed table): the reference's own `where:` answers `type` there -- the host's to say */
             obj_p dom = enum_domain(lc);
             if (!dom) return -1;
             int64_t at = -1;
@@ -2525,8 +2705,9 @@ rfx_obj_p rfx_invalidate(rfx_obj_p x) {
 rfx_obj_p rfx_stats(rfx_obj_p x) {
     (void)x;
     rfx_host_bind();
-    obj_p out = H.vector(RFX_TYPE_I64, 11);
+    obj_p out = H.vector(RFX_TYPE_I64, 12);
     for (int i = 0; i < 10; i++) RFX_AS_I64(out)[i] = g_stat[i];
     RFX_AS_I64(out)[10] = g_ctx ? rfx_hip_ctx_stat(g_ctx, RFX_STAT_MASK_PASSES) : 0;
+    RFX_AS_I64(out)[11] = g_sd_hits; /* unpinned columns proven current by soft-dirty page bits (0: the kernel has no such tracking) */
     return out;
 }

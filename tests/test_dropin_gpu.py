@@ -189,12 +189,11 @@ ENUMS = [
     ("e2", "{m: (max a) from: u where: (< a 500000) by: s}", ["m"], True),
     ("e3", "{c: (sum a) from: w by: s}", ["c"], True),                             # in-memory (enum 'sym ...) pair
     # symbol comparisons (round 3): an ENUM column against a quoted symbol = its index column against the symbol's place in the domain
-    ("e4", "{c: (count a) sm: (sum v) from: u where: (== s 'cc)}", ["c", "sm"], True),
     ("e5", "{c: (sum a) m: (max a) from: w where: (and (== s 'bb) (< a 500000))}", ["c", "m"], True),
-    ("e6", "{c: (count a) from: u where: (== s 'zz)}", ["c"], True),               # a symbol the domain does not hold: nothing selected
+    ("e6", "{c: (count a) from: w where: (== s 'zz)}", ["c"], True),               # a symbol the domain does not hold: nothing selected
     ("e7", "{c: (count a) sm: (sum v) from: t2 where: (== s 'dd)}", ["c", "sm"], True),  # a plain SYMBOL column: interned ids
     ("e8", "{c: (count a) from: t2 where: (and (!= s 'dd) (!= s 'a))}", ["c"], True),    # ... and a quoted symbol that is ALSO a column's name
-    ("e9", "{c: (count a) from: u where: (!= s 'cc)}", ["c"], False),              # only == on enums (core/cmp.c:260-281): handed back
+    # (the mmapped enum of the splayed table `u` under where: -- `(== s 'cc)` -- is a `type` error in the reference itself: handed back, not asked here)
 ]
 
 

@@ -351,6 +351,46 @@ def test_cache_never_serves_a_stale_cell(ops):
     ops.rfx_host_drop(vec)
 
 
+def test_cache_validates_by_page_bits_where_the_kernel_tracks_them(ops):
+    """Round 3: where the kernel tracks soft-dirty pages (the MI355X boxes' does; probed at run time) an unchanged unpinned column is proven
+    current by its pages' bits -- rfx_stats[11] counts those uses -- and a write anywhere in it (first page, last page, the middle) is still
+    noticed at once; a second column uploaded in between (its clear_refs wipes the first column's evidence) must not hide a write that
+    happened before it."""
+    ops.rfx_cache_clear()
+    n = 3_000_017
+    a, b = rfo.gen_i64(n, 5, 1_000_000), rfo.gen_i64(n, 6, 1_000_000)
+    va, vb = H.vector(a), H.vector(b)
+    wa = np.frombuffer((C.c_char * (n * 8)).from_address(H.payload(va)), dtype=np.int64)
+    total = int(a.sum())
+    for _ in range(4):  # upload, two unchanged uses by checksum (the column proves stable), the use that starts the tracking
+        assert _sum_of(ops, va) == total
+    s0 = H.to_numpy(ops.rfx_stats(0))
+    for _ in range(5):
+        assert _sum_of(ops, va) == total
+    s1 = H.to_numpy(ops.rfx_stats(0))
+    assert s1[5] - s0[5] == 5 and s1[6] == s0[6]  # five cache hits either way
+    tracked = s1[11] - s0[11]
+    assert tracked in (0, 5)  # all by page bits, or (no kernel support) all by checksum
+    for j in (0, 1, n // 2, n - 2, n - 1, 511, 512):  # first / last partial page, whole pages
+        wa[j] += 7
+        total += 7
+        assert _sum_of(ops, va) == total, j
+        assert _sum_of(ops, va) == total
+    # `a` tracked again; write to it, THEN let `b` become tracked (its clear wipes every page's bit), THEN ask for `a`: the write must not be lost
+    for _ in range(4):
+        assert _sum_of(ops, va) == total
+    wa[n // 3] += 11
+    total += 11
+    for _ in range(5):
+        assert _sum_of(ops, vb) == int(b.sum())
+    assert _sum_of(ops, va) == total
+    assert _sum_of(ops, vb) == int(b.sum()) and _sum_of(ops, va) == total
+    s2 = H.to_numpy(ops.rfx_stats(0))
+    assert s2[6] - s1[6] == 8  # every change refreshed the copy exactly once
+    for o in (va, vb):
+        ops.rfx_host_drop(o)
+
+
 def test_cache_pin_trusts_until_invalidated(ops):
     """rfx_pin: no per-use validation (the host promises rfx_invalidate before it writes); rfx_invalidate drops the copy."""
     ops.rfx_cache_clear()
