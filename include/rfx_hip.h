@@ -243,6 +243,10 @@ int rfx_hip_h2d_pipelined(rfx_ctx_t *ctx, void *d_dst, const void *src, size_t b
  * rfx_hip_column_file_load maps the file and moves its nrows 8-byte elements into d_dst with the pipelined path.  (syncs) */
 int rfx_column_file_stat(const char *path, int32_t *type, int64_t *len);
 int rfx_hip_column_file_load(rfx_ctx_t *ctx, const char *path, void *d_dst, int64_t nrows);
+/* A 4-byte integer column (I32 / DATE / TIME) as an 8-byte device column: d_out[i] = i32_to_i64(d_in[i]) (core/ops.h:240: NULL_I32 ->
+ * NULL_I64, else sign-extended) -- order and equality survive, nulls included, so the 8-byte comparison kernels answer what the
+ * reference's i32 comparison arms answer (core/cmp.c:150-166). */
+int rfx_hip_widen_i32(rfx_ctx_t *ctx, const int32_t *d_in, int64_t n, int64_t *d_out);
 
 /* ---- timing on the context's stream (bench.py measures kernels with these HIP events) ---- */
 int rfx_hip_timer_start(rfx_ctx_t *ctx);

@@ -19,8 +19,8 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 BIN = os.path.join(_HERE, "_ref", "rayforce")
-_TYPES = {np.dtype(np.int8): 1, np.dtype(np.bool_): 1, np.dtype(np.int64): 5, np.dtype(np.float64): 10}
-_DTYPES = {1: np.int8, 5: np.int64, 10: np.float64, 9: np.int64, 6: np.int64}
+_TYPES = {np.dtype(np.int8): 1, np.dtype(np.bool_): 1, np.dtype(np.int32): 4, np.dtype(np.int64): 5, np.dtype(np.float64): 10}
+_DTYPES = {1: np.int8, 4: np.int32, 5: np.int64, 7: np.int32, 8: np.int32, 10: np.float64, 9: np.int64, 6: np.int64}
 LAST_STDERR = ""  # of the last run_script (a plugin loaded into the reference may trace there)
 
 
@@ -36,10 +36,11 @@ def build(ref_root: str = "/root/reference") -> bool:
     return available()
 
 
-def write_col(path: str, a: np.ndarray) -> None:
+def write_col(path: str, a: np.ndarray, tp: int | None = None) -> None:
+    """tp: the reference's vector type code when the dtype does not say it (int32 payloads: 4 I32, 7 DATE = days, 8 TIME = milliseconds)."""
     a = np.ascontiguousarray(a)
     with open(path, "wb") as f:
-        f.write(struct.pack("<BBbBIq", 0xFD, 0, _TYPES[a.dtype], 0, 0, a.size))
+        f.write(struct.pack("<BBbBIq", 0xFD, 0, _TYPES[a.dtype] if tp is None else tp, 0, 0, a.size))
         f.write(a.tobytes())
 
 
@@ -89,9 +90,9 @@ class Session:
     def __exit__(self, *a):
         self.close()
 
-    def put(self, name: str, a: np.ndarray) -> None:
+    def put(self, name: str, a: np.ndarray, tp: int | None = None) -> None:
         path = os.path.join(self.dir, f"in_{name}")
-        write_col(path, a)
+        write_col(path, a, tp)
         self.lines.append(f'(set {name} (get "{path}"))')
 
     def table(self, tname: str, cols: dict) -> None:

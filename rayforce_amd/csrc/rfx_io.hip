@@ -191,3 +191,25 @@ extern "C" int rfx_hip_column_file_load(rfx_ctx_t *c, const char *path, void *d_
     munmap(m, bytes);
     return rc;
 }
+
+// ---- 4-byte integer columns (I32 / DATE / TIME, core/rayforce.h:54-58) as 8-byte device columns ----
+// The kernels read 8-byte elements; a 4-byte column is uploaded as it is (half the PCIe bytes) and widened on the device with the
+// reference's own promotion (i32_to_i64, core/ops.h:240: NULL_I32 -> NULL_I64, everything else sign-extended), which keeps order and
+// equality -- nulls included -- so that comparisons on the widened column answer what cmp.c's i32 arms answer (core/cmp.c:150-166).
+__global__ __launch_bounds__(256) void k_widen_i32(const int32_t *__restrict__ in, long long n, long long *__restrict__ out) {
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n; i += (long long)gridDim.x * 256LL) {
+        const int32_t x = in[i];
+        out[i] = x == (int32_t)0x80000000 ? (long long)0x8000000000000000ULL : (long long)x;
+    }
+}
+extern "C" int rfx_hip_widen_i32(rfx_ctx_t *c, const int32_t *d_in, int64_t n, int64_t *d_out) {
+    RFX_REQUIRE(c, RFX_EINVAL, "ctx is NULL");
+    if (n <= 0) return RFX_OK;
+    RFX_REQUIRE(d_in && d_out, RFX_EINVAL, "NULL argument");
+    long long blocks = (n + 255) / 256;
+    int grid = c->num_cus * 16;
+    if (blocks < grid) grid = (int)blocks;
+    hipLaunchKernelGGL(k_widen_i32, dim3(grid), dim3(256), 0, c->stream, d_in, (long long)n, (long long *)d_out);
+    RFX_HIP_CHECK(hipGetLastError());
+    return RFX_OK;
+}

@@ -193,6 +193,7 @@ typedef struct {
     int stable;        /* ... uses in a row at which the checksum found the payload unchanged (tracking starts at SD_STABLE_USES) */
     int sd_never;      /* ... cannot be tracked (file-backed / shared pages): the checksum every time */
     uint64_t edge_sum; /* ... checksum of the payload bytes in its first and last, partial pages (they hold other objects too) */
+    size_t dbytes;     /* bytes of the device copy (`bytes` are the host payload's: a 4-byte column is widened on the device) */
 } resident_t;
 static resident_t *g_res;
 static int g_nres, g_capres;
@@ -406,7 +407,7 @@ static int sd_entry_clean(const resident_t *r) {
 
 static void res_free(int i) {
     if (g_res[i].dev) rfx_hip_free(g_ctx, g_res[i].dev);
-    g_res_bytes -= g_res[i].bytes;
+    g_res_bytes -= g_res[i].dbytes;
     g_res[i] = g_res[--g_nres];
 }
 static void op_begin(void);
@@ -601,11 +602,27 @@ static int proxy_upload(const proxy_t *px, void *dev) {
 }
 
 /* device pointer of a host vector's payload (uploading it if needed) */
+/* 4-byte integer columns (I32 / DATE / TIME): comparable on the device through a widened copy (rfx_hip_widen_i32) */
+#define IS_I32_FAMILY(t) ((t) == RFX_TYPE_I32 || (t) == RFX_TYPE_DATE || (t) == RFX_TYPE_TIME)
+/* host payload -> device copy: 8-byte and 1-byte columns as they are, 4-byte integers widened to 8 bytes on the device */
+static int payload_upload(int type, void *dev, const void *host, int64_t len) {
+    if (!IS_I32_FAMILY(type)) return rfx_hip_h2d_pipelined(g_ctx, dev, host, (size_t)len * (type == RFX_TYPE_B8 ? 1 : 8));
+    void *raw = NULL;
+    int rc = rfx_hip_malloc(g_ctx, &raw, (size_t)(len ? len : 1) * 4);
+    if (rc != RFX_OK) return rc;
+    rc = rfx_hip_h2d_pipelined(g_ctx, raw, host, (size_t)len * 4);
+    if (rc == RFX_OK) rc = rfx_hip_widen_i32(g_ctx, (const int32_t *)raw, len, (int64_t *)dev);
+    if (rc == RFX_OK) rc = rfx_hip_ctx_sync(g_ctx); /* (the raw block goes back to the pool: the widening must have read it) */
+    rfx_hip_free(g_ctx, raw);
+    return rc;
+}
 static int resident(obj_p col, int pin, const void **dev) {
     const proxy_t *px = g_npx ? proxy_of(col) : NULL;
-    const int esz = (col->type == RFX_TYPE_B8) ? 1 : 8;
+    const int narrow = !px && IS_I32_FAMILY(col->type);
+    const int esz = (col->type == RFX_TYPE_B8) ? 1 : (narrow ? 4 : 8);
     const void *host = px ? (const void *)px->src : RFX_AS_RAW(col); /* a parted column is known by its LIST object */
-    const size_t bytes = (size_t)col->len * esz;
+    const size_t bytes = (size_t)col->len * esz;          /* of the HOST payload: what is validated */
+    const size_t dbytes = (size_t)col->len * (narrow ? 8 : esz); /* of the device copy: what the budget counts */
     const int ktype = px ? 64 + col->type : col->type;
     int have_sum = 0;
     uint64_t sum = 0;
@@ -648,7 +665,7 @@ static int resident(obj_p col, int pin, const void **dev) {
             }
             /* stale: the payload changed under the same address -- refresh the device copy in place */
             g_stat[ST_CACHE_STALE]++;
-            int rc = px ? proxy_upload(px, g_res[i].dev) : rfx_hip_h2d_pipelined(g_ctx, g_res[i].dev, host, bytes);
+            int rc = px ? proxy_upload(px, g_res[i].dev) : payload_upload(col->type, g_res[i].dev, host, col->len);
             if (rc != RFX_OK) { res_free(i); return rc; }
             g_stat[ST_UPLOADS]++;
             g_res[i].sum = sum;
@@ -658,7 +675,7 @@ static int resident(obj_p col, int pin, const void **dev) {
             *dev = g_res[i].dev;
             return RFX_OK;
         }
-    while (g_nres && g_res_bytes + bytes > cache_budget()) {
+    while (g_nres && g_res_bytes + dbytes > cache_budget()) {
         int victim = -1; /* least recently used, not pinned, not in use by the call in flight */
         for (int i = 0; i < g_nres; i++)
             if (!g_res[i].pinned && g_res[i].epoch != g_epoch && (victim < 0 || g_res[i].tick < g_res[victim].tick)) victim = i;
@@ -666,20 +683,20 @@ static int resident(obj_p col, int pin, const void **dev) {
         res_free(victim);
     }
     void *d = NULL;
-    int rc = rfx_hip_malloc(g_ctx, &d, bytes ? bytes : 8);
+    int rc = rfx_hip_malloc(g_ctx, &d, dbytes ? dbytes : 8);
     if (rc != RFX_OK) return rc;
     /* the checksum, THEN the copy: a host write racing with this call is either in both, or in the copy only and costs one refresh at
      * the next use -- never a device copy older than what vouches for it */
     if (!have_sum) sum = px ? proxy_sum(px) : payload_sum(host, bytes);
-    rc = px ? proxy_upload(px, d) : rfx_hip_h2d_pipelined(g_ctx, d, host, bytes); /* heap vector or mmapped column file alike: staged through pinned buffers */
+    rc = px ? proxy_upload(px, d) : payload_upload(col->type, d, host, col->len); /* heap vector or mmapped column file alike: staged through pinned buffers */
     if (rc != RFX_OK) { rfx_hip_free(g_ctx, d); return rc; }
     g_stat[ST_UPLOADS]++;
     if (g_nres == g_capres) {
         g_capres = g_capres ? g_capres * 2 : 32;
         g_res = (resident_t *)realloc(g_res, sizeof(resident_t) * (size_t)g_capres);
     }
-    g_res[g_nres++] = (resident_t){host, col->len, ktype, sum, d, bytes, pin, ++g_tick, g_epoch, 0, 0, 0, 0}; /* (page tracking starts once the column has proven stable) */
-    g_res_bytes += bytes;
+    g_res[g_nres++] = (resident_t){host, col->len, ktype, sum, d, bytes, pin, ++g_tick, g_epoch, 0, 0, 0, 0, dbytes}; /* (page tracking starts once the column has proven stable) */
+    g_res_bytes += dbytes;
     *dev = d;
     return RFX_OK;
 }
@@ -693,7 +710,7 @@ static void invalidate_payload(obj_p v) {
         return;
     }
     if (!v || v->type <= 0) return;
-    const int esz = (v->type == RFX_TYPE_B8) ? 1 : 8;
+    const int esz = (v->type == RFX_TYPE_B8) ? 1 : (IS_I32_FAMILY(v->type) ? 4 : 8);
     const char *lo = (const char *)RFX_AS_RAW(v), *hi = lo + (size_t)v->len * esz;
     for (int i = 0; i < g_nres;) {
         const char *a = (const char *)g_res[i].host, *b = a + g_res[i].bytes;
@@ -823,6 +840,29 @@ static int plan_cmp(obj_p tab, obj_p e, rfx_pred_t *p) {
             p->rhs_type = RFX_I64;
             p->rhs_i = at;
             return 0;
+        }
+        if (lc && IS_I32_FAMILY(lc->type)) {
+            /* a 4-byte integer column (I32 / DATE / TIME) in a comparison: its widened device copy against an atom or a column of the
+             * types the reference's i32 arms take (core/cmp.c:148-166: the same 4-byte type; for I32 also I64 / F64, promoted as
+             * i32_to_i64 / i32_to_f64 do -- which is what the widened column compares as) */
+            if (resident(lc, 0, &d) != RFX_OK) return -2;
+            g_where_data++;
+            p->d_col = d;
+            p->col_type = RFX_I64;
+            const int8_t lt = lc->type;
+            if (r->type == -lt) { p->rhs_type = RFX_I64; p->rhs_i = r->i32 == INT32_MIN ? RFX_NULL_I64 : (int64_t)r->i32; return 0; }
+            if (lt == RFX_TYPE_I32 && r->type == -RFX_TYPE_I64) { p->rhs_type = RFX_I64; p->rhs_i = r->i64; return 0; }
+            if (lt == RFX_TYPE_I32 && r->type == -RFX_TYPE_F64) { p->rhs_type = RFX_F64; p->rhs_f = r->f64; return 0; }
+            if (r->type == -RFX_TYPE_SYMBOL && !(r->attrs & RFX_ATTR_QUOTED)) {
+                obj_p rc = table_col(tab, r->i64);
+                if (!rc || rc->len != lc->len) return -1;
+                if (!(rc->type == lt || (lt == RFX_TYPE_I32 && (rc->type == RFX_TYPE_I64 || rc->type == RFX_TYPE_F64)))) return -1;
+                if (resident(rc, 0, &d) != RFX_OK) return -2;
+                p->d_rhs_col = d;
+                p->rhs_type = rc->type == RFX_TYPE_F64 ? RFX_F64 : RFX_I64;
+                return 0;
+            }
+            return -1;
         }
         if (!lc || !col_ctype(lc)) return -1;
         p->col_type = col_ctype(lc);

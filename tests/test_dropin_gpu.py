@@ -197,6 +197,70 @@ ENUMS = [
 ]
 
 
+NARROW = [  # 4-byte integer columns (DATE = days, TIME = milliseconds, I32) in comparisons: widened on the device (rfx_hip_widen_i32)
+    ("n1", "{s: (sum v) c: (count a) from: dt where: (>= d 2024.01.15)}", ["s", "c"], True),
+    ("n2", "{s: (sum v) mx: (max a) from: dt where: (and (>= d 2024.01.10) (< d 2024.02.01) (> a 500000))}", ["s", "mx"], True),
+    ("n3", "{s: (sum v) c: (count a) from: dt where: (< tm 12:00:00.000) by: k}", ["k", "s", "c"], True),
+    ("n4", "{m: (max a) c: (count a) from: dt where: (== i 7)}", ["m", "c"], True),           # I32 column against an i64 atom
+    ("n5", "{c: (count a) from: dt where: (or (> i 95.5) (< d 2024.01.03))}", ["c"], True),    # ... an f64 atom; null dates sort lowest
+    ("n6", "{c: (count a) s: (sum v) from: dt where: (== d d2)}", ["c", "s"], True),           # two DATE columns
+    ("n7", "{c: (count a) from: dt where: (and (!= d 2024.01.20) (<= tm 23:00:00.000) (>= i a))}", ["c"], True),  # I32 column against an I64 column
+    ("n8", "{s: (sum i) from: dt where: (> a 10)}", ["s"], False),                              # aggregates OVER 4-byte columns stay the host's
+]
+
+
+@pytest.mark.skipif(not ref.available(), reason="oracle/_ref/rayforce not built (needs /root/reference at build time)")
+def test_date_time_i32_columns_in_predicates_inside_the_real_reference(built):
+    """SURVEY 8f-2 breadth (round 3): DATE / TIME / I32 columns -- 4-byte payloads -- under `where:`, beside ray_select in ONE reference process.
+    The column is uploaded as it is and widened on the device with the reference's own promotion (NULL_I32 -> NULL_I64), so every comparison
+    arm of core/cmp.c:148-166 (same type, I32 against i64 / f64 atoms and columns) keeps its answer, null rows included."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    n = 200_003
+    NULL32 = -(2**31)
+    day0 = 8766  # 2024.01.01 as days since 2000.01.01
+    d = (day0 + rfo.gen_i64(n, 91, 45)).astype(np.int32)
+    d[rfo.gen_i64(n, 92, 53) == 0] = NULL32
+    d2 = d.copy()
+    d2[rfo.gen_i64(n, 93, 3) == 0] += 1
+    tm = (rfo.gen_i64(n, 94, 86_400_000)).astype(np.int32)
+    i32 = (rfo.gen_i64(n, 95, 100)).astype(np.int32)
+    i32[rfo.gen_i64(n, 96, 41) == 0] = NULL32
+    with ref.Session() as s:
+        s.put("k", rfo.gen_i64(n, 97, 300))
+        s.put("a", rfo.gen_i64(n, 98, 1_000_000))
+        s.put("v", rfo.gen_f64(n, 99))
+        s.put("d", d, tp=7)
+        s.put("d2", d2, tp=7)
+        s.put("tm", tm, tp=8)
+        s.put("i", i32, tp=4)
+        s.eval("(set dt (table [k a v d d2 tm i] (list k a v d d2 tm i)))")
+        s.eval(f'(set gsel (loadfn "{LIB}" "rfx_select" 1))')
+        for name, q, outs, _ in NARROW:
+            s.eval(f"(set g_{name} (gsel {q}))")
+            s.eval(f"(set r_{name} (select {q}))")
+            for o in outs:
+                s.out(f"g_{name}_{o}", f"(at g_{name} '{o})")
+                s.out(f"r_{name}_{o}", f"(at r_{name} '{o})")
+        s.eval(f'(set gstat (loadfn "{LIB}" "rfx_stats" 1))')
+        s.out("stats", "(gstat 0)")
+        res = s.run(threads=8)
+    for name, q, outs, _ in NARROW:
+        for o in outs:
+            g, r = res[f"g_{name}_{o}"], res[f"r_{name}_{o}"]
+            assert g.dtype == r.dtype and g.shape == r.shape, (name, o, g.shape, r.shape)
+            if g.dtype == np.float64:
+                assert np.allclose(g, r, rtol=1e-9, atol=0), (name, o)
+            else:
+                assert np.array_equal(g, r), (name, o)
+    st = res["stats"]
+    on_gpu = sum(1 for *_, gpu in NARROW if gpu)
+    print(ref.LAST_STDERR)
+    assert int(st[0]) == on_gpu and int(st[1]) == len(NARROW) - on_gpu, st
+    assert int(res["g_n1_c"][0]) > 0 and int(res["g_n6_c"][0]) > 0
+
+
 @pytest.mark.skipif(not ref.available(), reason="oracle/_ref/rayforce not built (needs /root/reference at build time)")
 def test_parted_and_enum_columns_inside_the_real_reference(built, tmp_path):
     """SURVEY 8f-2 at the operator boundary: a `get-parted` table (TYPE_PARTED* columns + the virtual MAPCOMMON Date, core/vary.c:185-392)
