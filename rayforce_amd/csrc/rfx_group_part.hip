@@ -1334,7 +1334,7 @@ __global__ __launch_bounds__(RFX_BLOCK) void k_distinct_sample(const u64 *__rest
         }
     }
 }
-static int estimate_distinct(rfx_ctx *c, const u64 *d_key, i64 nrows, double *est) {
+int rfx_estimate_distinct(rfx_ctx *c, const u64 *d_key, i64 nrows, double *est) { // (also sizes the plane form of this path, rfx_group_plane.hip)
     const i64 nsamp = nrows < (1 << 15) ? nrows : (1 << 15);
     int rc = rfx_ws_reserve(c, (size_t)DSAMP_SLOTS * 8 + 512);
     if (rc != RFX_OK) return rc;
@@ -1348,6 +1348,9 @@ static int estimate_distinct(rfx_ctx *c, const u64 *d_key, i64 nrows, double *es
     RFX_HIP_CHECK(hipMemcpyAsync(h, dups, 4, hipMemcpyDeviceToHost, c->stream));
     RFX_HIP_CHECK(hipStreamSynchronize(c->stream));
     *est = (double)nsamp * (double)nsamp / (2.0 * ((double)h[0] + 0.5));
+    // (the birthday figure cannot fall below nsamp / 2; when most samples WERE duplicates the sample has seen nearly every key, and what it
+    // saw is the estimate: D (1 - e^(-s/D)) distinct values among s samples)
+    if ((i64)h[0] * 2 > nsamp) *est = (double)(nsamp - (i64)h[0]) * 1.3;
     return RFX_OK;
 }
 
@@ -1358,7 +1361,7 @@ int rfx_group_part_hash_accumulate(rfx_ctx *c, const Plan &P0, int key_idx, cons
         // 256 partitions x one CU's LDS hold a few thousand keys each: beyond ~4 M distinct keys nearly every record overflows its
         // partition's table into the device-wide one (1e8 keys: 820 ms against 30) -- those go to the device-wide table directly
         double est = 0;
-        const int rc = estimate_distinct(c, (const u64 *)P0.cols[key_idx], P0.nrows, &est);
+        const int rc = rfx_estimate_distinct(c, (const u64 *)P0.cols[key_idx], P0.nrows, &est);
         if (rc != RFX_OK) return rc;
         c->ext_i[2] = (i64)est; // (the device-wide kernel's caller sizes its table by it)
         if (est > 4.0e6) return RFX_ESTATE;

@@ -69,7 +69,9 @@ typedef unsigned pl_m2 __attribute__((ext_vector_type(2)));
 #define PL_LD(ptr) __hip_atomic_load((ptr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
 #define PL_ST(ptr, v) __hip_atomic_store((ptr), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
 
-template <int NC, int NP, int NV, int PBITS, int VGL>
+// HK: sparse keys -- the partition is the top PBITS bits of hash_index_u64(key) and the meta word carries the next 14 bits of the hash
+// (where the aggregate pass starts probing its LDS table) instead of the slot inside the partition; plane 0 is then the key column itself.
+template <int NC, int NP, int NV, int PBITS, int VGL, bool HK = false>
 __global__ __launch_bounds__(PL_T) void k_plane_scatter(const Plan P, const PlaneArgs A) {
     constexpr int PARTS = 1 << PBITS;
     constexpr unsigned VG = 1u << VGL, RING = 2u << VGL; // records per group / per ring
@@ -127,7 +129,8 @@ __global__ __launch_bounds__(PL_T) void k_plane_scatter(const Plan P, const Plan
 
     // one selected row per lane (or none): takes its place in its partition's ring, writes, counts itself in, queues completed groups
     auto place = [&](const bool on, const u64 key, const u64 (&val)[NV], const unsigned delta) __attribute__((always_inline)) {
-        const unsigned p = (unsigned)key & (unsigned)(PARTS - 1);
+        const u64 kh = HK ? rfx_hash_index_u64(RFX_U64_HASH_SEED, key) : key;
+        const unsigned p = HK ? (unsigned)(kh >> (64 - PBITS)) : ((unsigned)key & (unsigned)(PARTS - 1));
         unsigned seq = 0;
         if (on) {
             const i64 k = (i64)key;
@@ -150,7 +153,7 @@ __global__ __launch_bounds__(PL_T) void k_plane_scatter(const Plan P, const Plan
                 const unsigned at = p * RING + (seq & (RING - 1u));
 #pragma unroll
                 for (int j = 0; j < NV; j++) vring[(size_t)j * PARTS * RING + at] = val[j];
-                mring[at] = ((unsigned)(key >> PBITS) & ((1u << PL_SLOT_BITS) - 1u)) | (delta << PL_SLOT_BITS);
+                mring[at] = ((unsigned)(HK ? (kh >> (64 - PBITS - PL_SLOT_BITS)) : (key >> PBITS)) & ((1u << PL_SLOT_BITS) - 1u)) | (delta << PL_SLOT_BITS);
                 asm volatile("" ::: "memory"); // the record is in the ring before it is counted (LDS executes a wave's operations in order)
                 comp = (atomicAdd(w, 1u) & 0xFFu) == VG - 1u;
                 todo = false;
@@ -533,24 +536,24 @@ static void plane_layout(rfx_ctx *c, int nblk, int pbits, unsigned c0, int nv, P
     for (int j = 0; j < nv; j++) A->vals[j] = (u64 *)(w + o_val + plane * j);
 }
 
-template <int NC, int NP, int NV, int PBITS, int VGL>
+template <int NC, int NP, int NV, int PBITS, int VGL, bool HK = false>
 static int launch_plane_scatter_inst(rfx_ctx *c, const Plan &P, const PlaneArgs &A) {
     constexpr size_t lds = pl_lds_bytes<NV, PBITS, VGL>();
     static_assert(lds <= 160 * 1024, "rings beyond a CU's LDS");
     static bool attr_set = false; // per instantiation
     if (!attr_set) {
-        RFX_HIP_CHECK(hipFuncSetAttribute((const void *)k_plane_scatter<NC, NP, NV, PBITS, VGL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        RFX_HIP_CHECK(hipFuncSetAttribute((const void *)k_plane_scatter<NC, NP, NV, PBITS, VGL, HK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_plane_scatter<NC, NP, NV, PBITS, VGL>), dim3(A.nblk), dim3(PL_T), lds, c->stream, P, A);
+    hipLaunchKernelGGL((k_plane_scatter<NC, NP, NV, PBITS, VGL, HK>), dim3(A.nblk), dim3(PL_T), lds, c->stream, P, A);
     return RFX_OK;
 }
-template <int NC, int NV, int PBITS, int VGL>
+template <int NC, int NV, int PBITS, int VGL, bool HK = false>
 static int launch_plane_scatter_np(rfx_ctx *c, const Plan &P, const PlaneArgs &A) {
-    if (P.npred == 0) return launch_plane_scatter_inst<NC, 0, NV, PBITS, VGL>(c, P, A);
-    if (P.npred == 1) return launch_plane_scatter_inst<NC, 1, NV, PBITS, VGL>(c, P, A);
-    if (P.npred <= 3) return launch_plane_scatter_inst<NC, 3, NV, PBITS, VGL>(c, P, A);
-    return launch_plane_scatter_inst<NC, RFX_MAX_PREDS, NV, PBITS, VGL>(c, P, A);
+    if (P.npred == 0) return launch_plane_scatter_inst<NC, 0, NV, PBITS, VGL, HK>(c, P, A);
+    if (P.npred == 1) return launch_plane_scatter_inst<NC, 1, NV, PBITS, VGL, HK>(c, P, A);
+    if (P.npred <= 3) return launch_plane_scatter_inst<NC, 3, NV, PBITS, VGL, HK>(c, P, A);
+    return launch_plane_scatter_inst<NC, RFX_MAX_PREDS, NV, PBITS, VGL, HK>(c, P, A);
 }
 // One value plane: 128 partitions with 32-record groups (256-byte value lines, 128 bytes of meta) when a partition twice as wide still
 // fits the aggregate pass's LDS, else 256 partitions with 16-record groups.  Two and three planes: 128 partitions, 16-record groups (the
@@ -838,6 +841,313 @@ int rfx_plane_accumulate(rfx_ctx *c, const Plan &P, int key_idx, const rfx_group
     }
     RFX_KERNEL_END(c);
     if (rc != RFX_OK) return rc;
+    RFX_HIP_CHECK(hipGetLastError());
+    return RFX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Sparse keys (K9) through the same planes: partition = top 7 bits of hash_index_u64(key), planes {key 8 B, value 8 B, meta 4 B
+// {14 more hash bits | row - block base}}; every partition is then aggregated in LDS OPEN-ADDRESSED tables.
+//
+// The reference: index_group_distribute (core/index.c:1777-1911) -- one ht_oa table per CPU chunk (core/hash.c:35-148), merged one after
+// the other.  Round 1's device form (rfx_group_part.hip): histogram pass -> exact-offset scatter of {row, key, value} as three
+// tile-sorted planes (15 ms per 1e9 rows) -> one LDS hash table per partition (10 ms): 29 ms, 86 GB moved for 16 algorithmic.  Here
+// the scatter is k_plane_scatter itself (no histogram pass, barrier-free rings, whole lines), and because 128 partitions of 1e6 keys
+// hold 7 800 keys each -- more than one CU's LDS takes at 20 bytes an entry -- every partition is aggregated by `halves` workgroups
+// that all stream the partition's records and keep those whose next hash bits are theirs.
+//   k_plane_hash_aggregate  one 1024-lane workgroup per (partition, half): LDS table {key 64, first row 32, accumulators 64, counts 32}
+//                           probed from (hash bits x capacity) >> bits, ds_cmpst insert; a key that finds no room (or the null key) goes
+//                           to the caller's device-wide table directly; at the end one insert per distinct key into that table.
+// ------------------------------------------------------------------------------------------------
+struct PlaneHashArgs {
+    HashArgs H;
+    int nblk, pbits, hbits; // hbits: log2(workgroups per partition)
+    i64 block_rows;
+    unsigned c0;
+    unsigned lcap; // LDS table entries
+    int narr;      // 8-byte arrays per entry beside the key (accumulators, wide counts)
+    int agg_pl[RFX_MAX_AGGS]; // 1: the value plane, -1: none (COUNT / FIRST)
+    const u64 *keys, *vals;
+    const unsigned *meta, *cnt;
+    int *overflow;
+};
+#define PLH_T 1024
+#define PLH_PROBES 512
+
+// FAST: exactly one aggregate, a plain f64 sum over the value plane (the K9 shape): no per-record dispatch on the aggregate kinds
+template <bool FAST>
+__global__ __launch_bounds__(PLH_T) void k_plane_hash_aggregate(const Plan P, const PlaneHashArgs X) {
+    extern __shared__ __attribute__((aligned(16))) u64 plh_smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int p = blockIdx.x >> X.hbits, half = blockIdx.x & ((1 << X.hbits) - 1);
+    const unsigned C = X.lcap;
+    u64 *lkey = plh_smem;                                                       // [C]
+    u64 *larr = plh_smem + C;                                                   // [narr][C]
+    unsigned *lfirst = (unsigned *)(plh_smem + (size_t)(1 + X.narr) * C);       // [C] local row of the first occurrence
+    unsigned *wcnt = lfirst + C;                                                // [16][64] region counts, a window per wave
+    int kind[RFX_MAX_AGGS], f64[RFX_MAX_AGGS], apl[RFX_MAX_AGGS], arr_of[RFX_MAX_AGGS], skip[RFX_MAX_AGGS];
+    {
+        int arr = 0;
+#pragma unroll
+        for (int a = 0; a < RFX_MAX_AGGS; a++) {
+            kind[a] = (a < P.nagg) ? P.aggs[a].kind : -1;
+            f64[a] = (a < P.nagg) ? P.aggs[a].f64 : 0;
+            skip[a] = (a < P.nagg) ? P.aggs[a].skipnull : 0;
+            apl[a] = (a < P.nagg) ? X.agg_pl[a] : -1;
+            arr_of[a] = arr;
+            if (kind[a] >= 0) arr += agg_has_cnt(kind[a], f64[a]) ? 2 : 1;
+        }
+    }
+    for (unsigned i = tid; i < C; i += PLH_T) {
+        lkey[i] = (u64)RFX_NULL_I64_D;
+        lfirst[i] = 0xffffffffu;
+    }
+#pragma unroll
+    for (int a = 0; a < RFX_MAX_AGGS; a++) {
+        if (kind[a] < 0) continue;
+        const u64 id = acc_identity(kind[a], f64[a]);
+        for (unsigned i = tid; i < C; i += PLH_T) larr[(size_t)arr_of[a] * C + i] = id;
+        if (agg_has_cnt(kind[a], f64[a]))
+            for (unsigned i = tid; i < C; i += PLH_T) larr[(size_t)(arr_of[a] + 1) * C + i] = 0;
+    }
+    __syncthreads();
+    const unsigned sbits = PL_SLOT_BITS - (unsigned)X.hbits; // hash bits left for the place in the table
+    auto apply = [&](const unsigned mm, const i64 rbase, const u64 key, const u64 val) __attribute__((always_inline)) {
+        const unsigned hb = mm & ((1u << PL_SLOT_BITS) - 1u);
+        if ((int)(hb >> sbits) != half) return; // another workgroup's share of this partition
+        const unsigned lrow = (unsigned)(rbase + (i64)(mm >> PL_SLOT_BITS));
+        int idx = -1;
+        if ((i64)key != RFX_NULL_I64_D) {
+            unsigned s = (unsigned)(((u64)(hb & ((1u << sbits) - 1u)) * (u64)C) >> sbits);
+            for (int probe = 0; probe < PLH_PROBES; probe++) {
+                const u64 k = lkey[s];
+                if (k == key) { idx = (int)s; break; }
+                if ((i64)k == RFX_NULL_I64_D) {
+                    const u64 old = atomicCAS((unsigned long long *)&lkey[s], (unsigned long long)RFX_NULL_I64_D, (unsigned long long)key);
+                    if ((i64)old == RFX_NULL_I64_D || old == key) { idx = (int)s; break; }
+                }
+                s = (s + 1 == C) ? 0 : s + 1;
+            }
+        }
+        if (idx >= 0) {
+            if (lrow < lfirst[idx]) atomicMin(&lfirst[idx], lrow);
+            if constexpr (FAST) {
+                unsafeAtomicAdd((double *)&larr[idx], rfx_as_f64(val));
+                return;
+            }
+#pragma unroll
+            for (int a = 0; a < RFX_MAX_AGGS; a++) {
+                if (kind[a] < 0) continue;
+                group_apply(&larr[(size_t)arr_of[a] * C + idx], &larr[(size_t)(arr_of[a] + 1) * C + idx], kind[a], f64[a], apl[a] == 1 ? val : 0ULL, skip[a]);
+            }
+        } else { // no room in LDS for this key (or the null key): straight to the device-wide table
+            const i64 g = hash_slot(X.H.keys, X.H.capacity, key);
+            if (g < 0) {
+                atomicExch(X.overflow, 1);
+                return;
+            }
+            const u64 row = (u64)P.row0 + lrow;
+            if (row < X.H.first[g]) atomicMin((unsigned long long *)&X.H.first[g], (unsigned long long)row);
+#pragma unroll
+            for (int a = 0; a < RFX_MAX_AGGS; a++) {
+                if (kind[a] < 0) continue;
+                group_apply(&X.H.acc[a][g], X.H.cnt[a] ? &X.H.cnt[a][g] : (u64 *)0, kind[a], f64[a], apl[a] == 1 ? val : 0ULL, skip[a]);
+            }
+        }
+    };
+    // every WAVE streams its own regions (blocks q, q + 16, ...) of the partition, two record pairs per lane and plane per batch, the
+    // next batch's loads in flight while this one is applied (the structure of k_plane_aggregate; unconditional, clamped loads)
+    constexpr int NW = PLH_T / 64;
+    struct Batch {
+        pl_v2 key[2], val[2];
+        pl_m2 m[2];
+        unsigned n, i0;
+        int b;
+    };
+    auto load = [&](bool live, int b, unsigned i0, unsigned n, Batch &B) __attribute__((always_inline)) {
+        B.b = live ? b : 0;
+        B.i0 = live ? i0 : 0u;
+        B.n = live ? n : 0u;
+        const u64 base = (((u64)B.b << X.pbits) + (u64)p) * X.c0;
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            unsigned i = B.i0 + ((unsigned)k * 64u + (unsigned)lane) * 2u;
+            i = i < X.c0 - 2u ? i : X.c0 - 2u;
+            B.key[k] = __builtin_nontemporal_load((const pl_v2 *)(X.keys + base + i));
+            B.val[k] = __builtin_nontemporal_load((const pl_v2 *)(X.vals + base + i));
+            B.m[k] = __builtin_nontemporal_load((const pl_m2 *)(X.meta + base + i));
+        }
+    };
+    auto consume = [&](const Batch &B) __attribute__((always_inline)) {
+        const i64 rbase = (i64)B.b * X.block_rows;
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const unsigned i = B.i0 + ((unsigned)k * 64u + (unsigned)lane) * 2u;
+            if (i < B.n) {
+                apply(B.m[k].x, rbase, B.key[k].x, B.val[k].x);
+                if (i + 1 < B.n) apply(B.m[k].y, rbase, B.key[k].y, B.val[k].y);
+            }
+        }
+    };
+    const int q = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nreg = q < X.nblk ? (X.nblk - q + NW - 1) / NW : 0;
+    unsigned *mywcnt = wcnt + (tid >> 6) * 64;
+    int r = -1;
+    int b = q;
+    unsigned i0 = 0, n = 0;
+    auto advance = [&]() __attribute__((always_inline)) {
+        for (;;) {
+            if (r >= 0 && i0 < n) return true;
+            r++;
+            if (r >= nreg) return false;
+            if ((r & 63) == 0) {
+                const int r0 = r + lane;
+                mywcnt[lane] = (r0 < nreg) ? X.cnt[((size_t)(q + r0 * NW) << X.pbits) + p] : 0u;
+            }
+            n = (unsigned)__builtin_amdgcn_readfirstlane((int)mywcnt[r & 63]);
+            b = q + r * NW;
+            i0 = 0;
+        }
+    };
+    Batch B0, B1;
+    bool h0 = advance();
+    load(h0, b, i0, n, B0);
+    i0 += 256u;
+    while (h0) {
+        const bool h1 = advance();
+        load(h1, b, i0, n, B1);
+        i0 += 256u;
+        consume(B0);
+        if (!h1) break;
+        h0 = advance();
+        load(h0, b, i0, n, B0);
+        i0 += 256u;
+        consume(B1);
+    }
+    __syncthreads();
+    // the partition's groups into the device-wide table: one insert per distinct key
+    for (unsigned i = tid; i < C; i += PLH_T) {
+        const u64 key = lkey[i];
+        if ((i64)key == RFX_NULL_I64_D) continue;
+        const i64 g = hash_slot(X.H.keys, X.H.capacity, key);
+        if (g < 0) {
+            atomicExch(X.overflow, 1);
+            continue;
+        }
+        const u64 row = (u64)P.row0 + lfirst[i];
+        if (row < X.H.first[g]) atomicMin((unsigned long long *)&X.H.first[g], (unsigned long long)row);
+#pragma unroll
+        for (int a = 0; a < RFX_MAX_AGGS; a++) {
+            if (kind[a] < 0) continue;
+            const bool hc = agg_has_cnt(kind[a], f64[a]);
+            group_merge_cell(&X.H.acc[a][g], hc ? &X.H.cnt[a][g] : (u64 *)0, kind[a], f64[a], larr[(size_t)arr_of[a] * C + i],
+                             hc ? larr[(size_t)(arr_of[a] + 1) * C + i] : 0ULL);
+        }
+    }
+}
+
+// Sparse-key group-by through the planes.  est = sampled distinct-key estimate.  RFX_ESTATE: not applicable / gave up BEFORE anything
+// touched the caller's tables (the caller takes round 1's kernels); otherwise the tables hold the answer unless *d_overflow is set.
+int rfx_plane_hash_accumulate(rfx_ctx *c, const Plan &P, int key_idx, const HashArgs &H, double est, int *d_overflow) {
+    if (c->flags & (RFX_TUNE_NO_PLANE | RFX_TUNE_NO_PARTITION)) return RFX_ESTATE;
+    const i64 nrows = P.nrows;
+    if (nrows < ((c->flags & RFX_TUNE_CHUNK_SMALL) ? (1LL << 16) : (1LL << 22)) || nrows >= 0xFFFFFFF0LL || P.nx > 0 || P.nagg < 1) return RFX_ESTATE;
+    int vcol[PL_MAX_NV], agg_plane[RFX_MAX_AGGS];
+    const int nv = plane_value_cols(P, vcol, agg_plane);
+    if (nv < 0 || nv > 1) return RFX_ESTATE; // the records carry the key and ONE value
+    int narr = 0;
+    for (int a = 0; a < P.nagg; a++) narr += agg_has_cnt(P.aggs[a].kind, P.aggs[a].f64) ? 2 : 1;
+    // LDS: entry = key 8 + narr x 8 + first 4; beside it the waves' count windows
+    const size_t entry = 8 + (size_t)narr * 8 + 4;
+    const unsigned lcap = (unsigned)((((size_t)150 * 1024) - 16 * 64 * 4) / entry) & ~63u;
+    if (est < 4096.0) return RFX_ESTATE; // a few keys do not spread over 128 partitions: one of them would overflow its regions
+    const int pbits = 7;
+    int hbits = 0;
+    while (hbits < 2 && est * 1.6 / (double)((1 << pbits) << hbits) > (double)lcap) hbits++; // (every workgroup of a partition streams ALL its records: 4 is where that stops paying)
+    if (est * 1.6 / (double)((1 << pbits) << hbits) > (double)lcap) return RFX_ESTATE; // more keys than 512 LDS tables hold: round 1's kernels / the device-wide table
+    const i64 nblk64 = (nrows + PL_BLOCK_ROWS - 1) / PL_BLOCK_ROWS;
+    if (nblk64 > (1 << 20)) return RFX_ESTATE;
+    // key -> columns 0 and 1 (plane 0 IS the key), the value column -> 2 (plane 1; without one, the key again), the predicates' columns behind
+    Plan Pc = P;
+    {
+        int perm[RFX_MAX_COLS + 2], inv[RFX_MAX_COLS], n2 = 0;
+        for (int i = 0; i < P.ncols; i++) inv[i] = -1;
+        perm[n2++] = key_idx;
+        inv[key_idx] = 0;
+        perm[n2++] = key_idx;
+        perm[n2++] = nv == 1 ? vcol[0] : key_idx;
+        if (nv == 1 && inv[vcol[0]] < 0) inv[vcol[0]] = 2;
+        for (int i = 0; i < P.ncols; i++)
+            if (inv[i] < 0) {
+                inv[i] = n2;
+                perm[n2++] = i;
+            }
+        if (n2 > 4 || n2 > RFX_MAX_COLS) return RFX_ESTATE; // one predicate column beside key and value
+        Pc.ncols = n2;
+        for (int i = 0; i < n2; i++) Pc.cols[i] = P.cols[perm[i]];
+        for (int i = 0; i < P.npred; i++) {
+            Pc.preds[i].col = inv[P.preds[i].col];
+            if (P.preds[i].rhs_col >= 0) Pc.preds[i].rhs_col = inv[P.preds[i].rhs_col];
+        }
+    }
+    // selectivity: unknown here -- regions sized for every row (a selective filter only leaves them emptier)
+    double share = (double)PL_BLOCK_ROWS / (double)(1 << pbits);
+    unsigned c0 = (unsigned)(share * 1.25 + 160.0);
+    c0 = (c0 + 127u) & ~127u;
+    PlaneArgs A;
+    memset(&A, 0, sizeof(A));
+    size_t need = 0;
+    plane_layout(c, (int)nblk64, pbits, c0, 2, &A, &need);
+    if (rfx_chunk_reserve(c, need) != RFX_OK) return RFX_ESTATE;
+    plane_layout(c, (int)nblk64, pbits, c0, 2, &A, NULL);
+    A.block_rows = PL_BLOCK_ROWS;
+    for (int i = 0; i < Pc.npred; i++) {
+        A.pmask |= 1u << Pc.preds[i].col;
+        if (Pc.preds[i].rhs_col >= 0) A.pmask |= 1u << Pc.preds[i].rhs_col;
+    }
+    c->ck_valid = 0;
+    rfx_plane_invalidate(c);
+    RFX_HIP_CHECK(hipMemsetAsync(A.ctl, 0, 256, c->stream));
+    c->ext_i[3 + RFX_STAT_PLANE_SCATTER]++;
+    RFX_KERNEL_BEGIN(c);
+    int rc = Pc.ncols == 3 ? launch_plane_scatter_np<3, 2, 7, 4, true>(c, Pc, A) : launch_plane_scatter_np<4, 2, 7, 4, true>(c, Pc, A);
+    if (rc != RFX_OK) return rc;
+    RFX_HIP_CHECK(hipGetLastError());
+    unsigned *hctl = (unsigned *)c->h_pin;
+    RFX_HIP_CHECK(hipMemcpyAsync(hctl, A.ctl, 256, hipMemcpyDeviceToHost, c->stream));
+    RFX_HIP_CHECK(hipStreamSynchronize(c->stream));
+    if (hctl[1]) { // a region overflowed (one key takes a large share of the rows): round 1's kernels
+        c->ext_i[3 + RFX_STAT_PLANE_FALLBACK]++;
+        return RFX_ESTATE;
+    }
+    PlaneHashArgs X;
+    memset(&X, 0, sizeof(X));
+    X.H = H;
+    X.nblk = (int)nblk64;
+    X.pbits = pbits;
+    X.hbits = hbits;
+    X.block_rows = PL_BLOCK_ROWS;
+    X.c0 = c0;
+    X.lcap = lcap;
+    X.narr = narr;
+    for (int a = 0; a < RFX_MAX_AGGS; a++) X.agg_pl[a] = (a < P.nagg && agg_plane[a] == 0) ? 1 : -1;
+    X.keys = A.vals[0];
+    X.vals = A.vals[1];
+    X.meta = A.meta;
+    X.cnt = A.cnt;
+    X.overflow = d_overflow;
+    const size_t lds = (size_t)lcap * entry + 16 * 64 * 4 + 64;
+    static bool attr_set = false;
+    if (!attr_set) {
+        RFX_HIP_CHECK(hipFuncSetAttribute((const void *)k_plane_hash_aggregate<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        RFX_HIP_CHECK(hipFuncSetAttribute((const void *)k_plane_hash_aggregate<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    c->ext_i[3 + RFX_STAT_PLANE_AGGREGATE]++;
+    const bool fast = P.nagg == 1 && P.aggs[0].kind == RFX_AGG_SUM && P.aggs[0].f64 && !P.aggs[0].skipnull && X.agg_pl[0] == 1;
+    if (fast) hipLaunchKernelGGL(k_plane_hash_aggregate<true>, dim3((1 << pbits) << hbits), dim3(PLH_T), lds, c->stream, Pc, X);
+    else hipLaunchKernelGGL(k_plane_hash_aggregate<false>, dim3((1 << pbits) << hbits), dim3(PLH_T), lds, c->stream, Pc, X);
+    RFX_KERNEL_END(c);
     RFX_HIP_CHECK(hipGetLastError());
     return RFX_OK;
 }

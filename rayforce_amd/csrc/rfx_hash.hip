@@ -125,6 +125,9 @@ __global__ __launch_bounds__(RFX_BLOCK) void k_hash_merge(const MergeArgs M, int
     }
 }
 
+int rfx_estimate_distinct(rfx_ctx *c, const u64 *d_key, i64 nrows, double *est);                                          // rfx_group_part.hip
+int rfx_plane_hash_accumulate(rfx_ctx *c, const Plan &P, int key_idx, const HashArgs &H, double est, int *d_overflow); // rfx_group_plane.hip
+
 static int check_hash(const rfx_agg_t *aggs, const rfx_hash_tables_t *t) {
     RFX_REQUIRE(t && t->d_keys && t->d_first, RFX_EINVAL, "hash tables / d_keys / d_first is NULL");
     RFX_REQUIRE(t->capacity >= 2 && (t->capacity & (t->capacity - 1)) == 0, RFX_EINVAL, "capacity must be a power of two >= 2");
@@ -211,7 +214,17 @@ extern "C" int rfx_hip_group_hash_accumulate(rfx_ctx_t *c, const int64_t *d_key,
     if (rc != RFX_OK) return rc;
     int *flag = (int *)c->d_ws;
     RFX_HIP_CHECK(hipMemsetAsync(flag, 0, 16, c->stream)); // [0] full, [2..3] slots claimed by this launch
-    // large inputs: partition by hash, aggregate every partition in an LDS table, merge once (rfx_group_part.hip)
+    // large inputs, round 3: hash-partitioned PLANES {key, value, meta} through barrier-free LDS rings, LDS hash tables per partition share
+    // (rfx_group_plane.hip); sized by the sampled distinct-key estimate
+    if (nrows >= (1 << 16) && nrows < (1LL << 32) && !(c->flags & RFX_TUNE_NO_PARTITION)) {
+        double est = 0;
+        rc = rfx_estimate_distinct(c, (const u64 *)P.cols[key_idx], nrows, &est);
+        if (rc != RFX_OK) return rc;
+        rc = rfx_plane_hash_accumulate(c, P, key_idx, H, est, flag);
+        if (rc == RFX_OK) return read_overflow(c, flag, "group_hash_accumulate");
+        if (rc != RFX_ESTATE) return rc;
+    }
+    // round 1's form: partition by hash (histogram, exact offsets), aggregate every partition in an LDS table, merge once (rfx_group_part.hip)
     rc = rfx_group_part_hash_accumulate(c, P, key_idx, H, flag);
     if (rc == RFX_OK) return read_overflow(c, flag, "group_hash_accumulate");
     if (rc != RFX_ESTATE) return rc;

@@ -359,6 +359,74 @@ def test_sparse_keys_partitioned_hash_path(eng, flags):
         eng.tune(flags=0)
 
 
+@pytest.mark.parametrize("distinct", [40, 3000, 150_000, 390_000])
+def test_sparse_keys_through_hash_partitioned_planes(eng, distinct):
+    """Round 3 (rfx_group_plane.hip: k_plane_scatter<..., HK> + k_plane_hash_aggregate): sparse keys partitioned by hash into {key, value,
+    meta} planes, every partition aggregated in LDS open-addressed tables by 1 / 2 / 4 workgroups (each keeps its share of the hash bits).
+    Forced from 2^16 rows on (RFX_TUNE_CHUNK_SMALL); the context's counters say which queries took it: one value column (+ count / first),
+    at most one predicate column beside key and value; the others (two value columns, two predicate columns, expressions) keep round 1's
+    kernels.  Same answers (the oracle) either way; null keys form ONE group (the flat ABI's rule) through the device-wide table."""
+    n = 400_003
+    host = table(n, keys=distinct, nulls=True)
+    host["k"] = host["k"] * 1_000_003 - 77_777
+    planes = [{"by": "k", "s": ("sum", "v")},
+              {"by": "k", "s": ("sum", "v"), "c": ("count", "a")},
+              {"by": "k", "mx": ("max", "a"), "f": ("first", "a"), "mn": ("min", "a")},
+              {"by": "k", "av": ("avg", "w")},
+              {"where": ("<", "a", 400_000), "by": "k", "av": ("avg", "v"), "c": ("count", "v")},
+              {"where": (">", "v", 0.9), "by": "k", "s": ("sum", "v")},
+              {"by": "k", "s": ("sum", "k"), "c": ("count", "k")}]
+    others = [{"where": ("and", ("<", "a", 100_000), (">", "w", -0.3)), "by": "k", "s": ("sum", "v")},
+              {"by": "k", "s1": ("sum", "v"), "s2": ("sum", "w")},
+              {"where": ("<", "a", 400_000), "by": "k", "s": ("sum", ("*", "v", "a"))}]
+    try:
+        eng.tune(flags=CHUNK_SMALL)
+        before = (eng.stat(0), eng.stat(1), eng.stat(2))
+        for q in planes:
+            check_select(eng, host, q)
+        after = (eng.stat(0), eng.stat(1), eng.stat(2))
+        took = len(planes) if distinct >= 100_000 else 0  # (a few thousand keys or fewer: the sampled estimate keeps them on round 1's LDS kernels)
+        assert after[0] - before[0] == took and after[2] - before[2] == took and after[1] == before[1], (before, after)
+        for q in others:
+            check_select(eng, host, q)
+        assert (eng.stat(0), eng.stat(2)) == (after[0], after[2])
+        eng.tune(flags=CHUNK_SMALL | NO_PLANE)
+        check_select(eng, host, planes[1])
+        assert eng.stat(0) == after[0]
+        eng.tune(flags=CHUNK_SMALL)
+        host = table(n, keys=3000)
+        host["k"] = host["k"] * 1_000_003 - 77_777
+        nul = rfo.gen_i64(n, 321, 97) == 0
+        host["k"][nul] = NULL
+        got = eng.select({"from": dev(eng, host), "by": "k", "c": ("count", "a"), "s": ("sum", "v")})
+        gk = got["k"].cpu().numpy()
+        assert (gk == NULL).sum() == 1 and len(gk) == len(np.unique(host["k"]))
+        i = int(np.nonzero(gk == NULL)[0][0])
+        assert int(got["c"][i]) == int(nul.sum()) and abs(float(got["s"][i]) - host["v"][nul].sum()) <= 1e-9 * host["v"][nul].sum()
+        first_rows = {k: r for r, k in reversed(list(enumerate(host["k"].tolist())))}
+        assert [first_rows[k] for k in gk.tolist()] == sorted(first_rows.values())
+        # one key takes a third of the rows: its partition's regions overflow, the launch gives up (counter 1), round 1's kernels answer
+        host = table(n, keys=50_000)
+        host["k"] = host["k"] * 1_000_003 + 9
+        host["k"][rfo.gen_i64(n, 55, 3) == 0] = 424_242_424_242
+        fb = eng.stat(1)
+        check_select(eng, host, {"by": "k", "s": ("sum", "v")})
+        assert eng.stat(1) == fb + 1
+    finally:
+        eng.tune(flags=0)
+
+
+def test_sparse_keys_through_hash_partitioned_planes_default_threshold(eng):
+    """5e6 rows, 1e6 sparse keys: the route at its default row threshold (2^22), two workgroups per partition."""
+    n = 5_000_011
+    host = table(n, keys=1_000_000)
+    host["k"] = host["k"] * 999_983 + 12_345
+    before = eng.stat(0)
+    check_select(eng, host, {"by": "k", "s": ("sum", "v")})
+    check_select(eng, host, {"where": ("<", "a", 500_000), "by": "k", "s": ("sum", "v"), "c": ("count", "v")})
+    assert eng.stat(0) - before == 2
+
+
 def test_hash_primitives_pinned(eng):
     import ctypes as C
     from rayforce_amd import _lib as L
