@@ -1061,8 +1061,11 @@ int rfx_plane_hash_accumulate(rfx_ctx *c, const Plan &P, int key_idx, const Hash
     const size_t entry = 8 + (size_t)narr * 8 + 4;
     const unsigned lcap = (unsigned)((((size_t)150 * 1024) - 16 * 64 * 4) / entry) & ~63u;
     if (est < 4096.0) return RFX_ESTATE; // a few keys do not spread over 128 partitions: one of them would overflow its regions
-    const int pbits = 7;
-    int hbits = 0;
+    // 128 partitions (16-record store groups: 128-byte value lines), shared by 2 / 4 workgroups when a partition's keys overflow one LDS
+    // table; 256 partitions (8-record groups: 64-byte lines) only beyond that.  Measured at 1e6 keys: 128 x 2 workgroups 8.1 + 12.6 ms,
+    // 256 x 1 13.3 + 8.2 ms -- the short lines cost the scatter more than the single stream saves the aggregate.
+    int pbits = 7, hbits = 0;
+    if (est * 1.6 / (128.0 * 4.0) > (double)lcap) pbits = 8;
     while (hbits < 2 && est * 1.6 / (double)((1 << pbits) << hbits) > (double)lcap) hbits++; // (every workgroup of a partition streams ALL its records: 4 is where that stops paying)
     if (est * 1.6 / (double)((1 << pbits) << hbits) > (double)lcap) return RFX_ESTATE; // more keys than 512 LDS tables hold: round 1's kernels / the device-wide table
     const i64 nblk64 = (nrows + PL_BLOCK_ROWS - 1) / PL_BLOCK_ROWS;
@@ -1110,7 +1113,9 @@ int rfx_plane_hash_accumulate(rfx_ctx *c, const Plan &P, int key_idx, const Hash
     RFX_HIP_CHECK(hipMemsetAsync(A.ctl, 0, 256, c->stream));
     c->ext_i[3 + RFX_STAT_PLANE_SCATTER]++;
     RFX_KERNEL_BEGIN(c);
-    int rc = Pc.ncols == 3 ? launch_plane_scatter_np<3, 2, 7, 4, true>(c, Pc, A) : launch_plane_scatter_np<4, 2, 7, 4, true>(c, Pc, A);
+    int rc;
+    if (pbits == 7) rc = Pc.ncols == 3 ? launch_plane_scatter_np<3, 2, 7, 4, true>(c, Pc, A) : launch_plane_scatter_np<4, 2, 7, 4, true>(c, Pc, A);
+    else rc = Pc.ncols == 3 ? launch_plane_scatter_np<3, 2, 8, 3, true>(c, Pc, A) : launch_plane_scatter_np<4, 2, 8, 3, true>(c, Pc, A);
     if (rc != RFX_OK) return rc;
     RFX_HIP_CHECK(hipGetLastError());
     unsigned *hctl = (unsigned *)c->h_pin;

@@ -23,11 +23,11 @@ DOMINANT = {"c2": ["k_filter_aggr_plan"], "c2b": ["k_filter_aggr_plan"], "c5": [
             "q1": ["k_part_scope_hist", "k_filter_aggr_plan", "k_group_few",  # (k_group_dense runs once, at the plan's first occurrence, before the plan kernel exists)
                     "k_rank_emit_small", "k_fill_tables", "k_derive", "k_mark_first", "k_group_emit", "k_slot_gid", "k_bitmap_counts", "k_fill_u64", "k_composite"],
             "q2": ["k_part_scope_hist", "k_group_dense", "k_composite", "k_mark_first", "k_group_emit", "k_slot_gid", "k_bitmap_counts", "k_fill_u64"],
-            "k9": ["k_part_scope_hist", "k_part_hist", "k_part_scatter", "k_part_hash_aggregate", "k_part_colscan", "k_group_hash", "k_distinct_sample", "k_mark_first", "k_group_emit",
+            "k9": ["k_plane_", "k_part_scope_hist", "k_part_hist", "k_part_scatter", "k_part_hash_aggregate", "k_part_colscan", "k_group_hash", "k_distinct_sample", "k_mark_first", "k_group_emit",
                    "k_slot_gid", "k_bitmap_counts", "k_fill_u64"],
             "q7": ["k_row_hash", "k_part_scope_hist", "k_part_hist", "k_part_scatter", "k_part_hash_aggregate", "k_part_colscan", "k_group_hash", "k_join_probe_hash", "k_gather_or", "k_gather8", "k_emit_perm", "k_group_emit_by_group", "k_distinct_sample", "k_mark_first",
                    "k_group_emit", "k_slot_gid", "k_bitmap_counts", "k_fill_u64", "k_replace_null"],
-            "w2": ["k_sel_bitmap", "k_chunk_counts", "k_emit_ids"], "m2": ["k_cmp_mask"]}
+            "w2": ["k_where_once", "k_where_sample", "k_sel_bitmap", "k_chunk_counts", "k_emit_ids"], "m2": ["k_cmp_mask"]}
 
 
 def read_pmc(path):
