@@ -1138,6 +1138,180 @@ static void tm_print(void) {
         fprintf(stderr, "  (plan | scope | tables+pass+rank | emit | fetch | build+free) total %.0f\n", g_tm[g_ntm - 1] - g_tm[0]);
     }
 }
+/* ---- rfx_select, piece by piece.  Every piece answers SEL_GO (carry on), SEL_OUT (*why says which shape the host must answer) or
+ * SEL_DONE (an error / a finished result: the caller stops). ---- */
+enum { SEL_GO = 0, SEL_OUT = 1, SEL_DONE = 2 };
+/* the output mappings {name: (aggr column | expression)} of a select dict (everything but from: where: by: take:) as aggregate
+ * descriptors over resident device columns */
+typedef struct {
+    rfx_agg_t aggs[RFX_MAX_AGGS];
+    rfx_xnode_t xnodes[RFX_MAX_AGGS][RFX_MAX_XNODES];
+    int64_t names[RFX_MAX_AGGS];
+    int outtype[RFX_MAX_AGGS];
+    int nagg;
+} sel_maps_t;
+static int sel_mappings(obj_p tab, obj_p dkeys, obj_p dvals, sel_maps_t *M, const char **why) {
+    const int64_t s_from = H.intern("from", 4), s_where = H.intern("where", 5), s_by = H.intern("by", 2), s_take = H.intern("take", 4);
+    M->nagg = 0;
+    for (int64_t i = 0; i < dkeys->len; i++) {
+        int64_t k = RFX_AS_I64(dkeys)[i];
+        if (k == s_from || k == s_where || k == s_by || k == s_take) continue;
+        obj_p e = RFX_AS_LIST(dvals)[i];
+        const int n = M->nagg;
+        if (n >= RFX_MAX_AGGS || e->type != RFX_TYPE_LIST || e->len != 2) { *why = "mapping shape"; return SEL_OUT; }
+        int f = fn_id(RFX_AS_LIST(e)[0]);
+        obj_p a = RFX_AS_LIST(e)[1];
+        static const int KIND[] = {RFX_AGG_SUM, RFX_AGG_AVG, RFX_AGG_MIN, RFX_AGG_MAX, RFX_AGG_COUNT, RFX_AGG_FIRST};
+        if (f < F_SUM || f > F_FIRST) { *why = "mapping is not (aggr ...)"; return SEL_OUT; }
+        memset(&M->aggs[n], 0, sizeof(M->aggs[n]));
+        M->aggs[n].kind = KIND[f - F_SUM];
+        if (a->type == RFX_TYPE_LIST && a->len == 3) {
+            /* (aggr expr), expr = (op x y) over columns, atoms and nested expressions: folded on the device.  (count expr)
+             * answers the number of groups in the reference and (first expr) under by: is a `length` error there: the host's */
+            if (f == F_COUNT || f == F_FIRST) { *why = "count / first of an expression"; return SEL_OUT; }
+            int nn = 0, ncols = 0;
+            int top = build_xnodes(tab, a, M->xnodes[n], &nn, &ncols, why);
+            if (top == -2) return SEL_DONE;
+            if (top < 0) return SEL_OUT;
+            if (ncols == 0) { *why = "expression without a column"; return SEL_OUT; }
+            M->aggs[n].nxnodes = nn;
+            M->aggs[n].xnodes = M->xnodes[n];
+            M->aggs[n].col_type = RFX_I64;
+            M->outtype[n] = (f == F_AVG || rfx_agg_input_type(&M->aggs[n]) == RFX_F64) ? RFX_TYPE_F64 : RFX_TYPE_I64;
+            M->names[M->nagg++] = k;
+            continue;
+        }
+        if (a->type != -RFX_TYPE_SYMBOL) { *why = "mapping is not (aggr column)"; return SEL_OUT; }
+        obj_p c = table_col(tab, a->i64);
+        if (!c || !col_ctype(c) || c->type == RFX_TYPE_SYMBOL) { *why = "aggregate column type"; return SEL_OUT; }
+        const void *d;
+        if (resident(c, 0, &d) != RFX_OK) return SEL_DONE;
+        M->aggs[n].d_col = d;
+        M->aggs[n].col_type = col_ctype(c);
+        M->outtype[n] = (f == F_AVG) ? RFX_TYPE_F64 : (f == F_COUNT) ? RFX_TYPE_I64 : c->type;
+        M->names[M->nagg++] = k;
+    }
+    return SEL_GO;
+}
+
+/* select without aggregates: filter_collect of every column (core/filter.c:51-165) -- where -> ids -> gather */
+static int where_ids(obj_p tab, obj_p where, const wplan_t *wp, int flat, int64_t nrows, int64_t **d_ids, int64_t *count);
+static int sel_projection(obj_p tab, obj_p where, const wplan_t *wp, int flat, int parted, int64_t nrows, obj_p *res, const char **why) {
+    obj_p tcols = RFX_AS_LIST(tab)[1];
+    if (parted) { *why = "parted table: projection"; return SEL_OUT; } /* the reference keeps such a result lazy (filter maps over the partitions) */
+    if (!where) { *res = H.clone(tab); g_last_gpu = 1; return SEL_DONE; }
+    for (int64_t i = 0; i < tcols->len; i++)
+        if (!col_ctype(RFX_AS_LIST(tcols)[i])) { *why = "projection of a non-8-byte column"; return SEL_OUT; }
+    int64_t *d_ids = NULL, nsel = 0;
+    const int rc = where_ids(tab, where, wp, flat, nrows, &d_ids, &nsel);
+    if (rc == -1) { *why = "where: shape"; return SEL_OUT; }
+    if (rc) { *res = fail_hip("where"); return SEL_DONE; }
+    obj_p rv = H.vector(RFX_TYPE_LIST, tcols->len);
+    void *dg = NULL;
+    int ok = nsel == 0 || rfx_hip_malloc(g_ctx, &dg, (size_t)nsel * 8) == RFX_OK;
+    for (int64_t i = 0; i < tcols->len && ok; i++) {
+        obj_p c = RFX_AS_LIST(tcols)[i];
+        obj_p o = H.vector(c->type, nsel);
+        RFX_AS_LIST(rv)[i] = o;
+        const void *dc;
+        if (nsel == 0) continue;
+        ok = resident(c, 0, &dc) == RFX_OK && rfx_hip_gather(g_ctx, dc, d_ids, nsel, dg) == RFX_OK &&
+             rfx_hip_d2h(g_ctx, RFX_AS_RAW(o), dg, (size_t)nsel * 8) == RFX_OK;
+    }
+    if (dg) rfx_hip_free(g_ctx, dg);
+    if (d_ids) rfx_hip_free(g_ctx, d_ids);
+    if (!ok) { H.drop(rv); *res = fail_hip("projection"); return SEL_DONE; }
+    *res = H.table(H.clone(RFX_AS_LIST(tab)[0]), rv);
+    g_last_gpu = 1;
+    return SEL_DONE;
+}
+
+/* the key column(s) of a group-by result, read back in group order: one key as the cells the device emitted (the virtual Date column of a
+ * parted table narrowed to 4-byte days, ENUM indices decoded through the enum's domain -- aggr_first, core/aggr.c:515-546); several keys
+ * decoded from the composite key (key_i = min_i + (composite / mult_i) % range_i = key_i[first row], core/query.c:110-135) or, on the
+ * row-hash path, gathered at the groups' first rows.  *ok carries the device-call status on; SEL_OUT: an enum whose domain does not
+ * resolve (nothing is left allocated here). */
+typedef struct {
+    int nkeys;
+    int8_t key_out_type;
+    obj_p kenum;
+    int rowhash;
+    obj_p *kcs;
+    const void **dks;
+    const int64_t *kmins, *kmaxs, *kmults;
+} sel_keys_t;
+static int sel_key_columns(const sel_keys_t *K, int64_t groups, const void *dkeys_out, const int64_t *d_comp, const int64_t *d_first, obj_p *okeys,
+                           obj_p *okcols, int *okp) {
+    int ok = *okp;
+    if (K->nkeys == 1 && K->key_out_type == RFX_TYPE_DATE) { /* the virtual Date column: 4-byte days */
+        *okeys = H.vector(RFX_TYPE_DATE, groups);
+        int64_t *k8 = (int64_t *)malloc((size_t)groups * 8);
+        ok = ok && k8 && fetch(k8, dkeys_out, (size_t)groups * 8) == RFX_OK;
+        for (int64_t g = 0; g < groups && ok; g++) ((int32_t *)RFX_AS_RAW(*okeys))[g] = (int32_t)k8[g];
+        free(k8);
+    } else if (K->nkeys == 1) {
+        *okeys = H.vector(K->key_out_type, groups);
+        if (ok) ok = fetch(RFX_AS_RAW(*okeys), dkeys_out, (size_t)groups * 8) == RFX_OK;
+        if (ok && K->kenum) { /* indices -> symbols of the enum's domain (the global its key names) */
+            obj_p dom = enum_domain(K->kenum);
+            int good = dom != NULL;
+            int64_t *kk = RFX_AS_I64(*okeys);
+            for (int64_t g = 0; g < groups && good; g++) {
+                if (kk[g] < 0 || kk[g] >= dom->len) good = 0;
+                else kk[g] = RFX_AS_I64(dom)[kk[g]];
+            }
+            if (dom) H.drop(dom);
+            if (!good) {
+                H.drop(*okeys);
+                *okeys = NULL;
+                return SEL_OUT;
+            }
+        }
+    } else {
+        void *cell = NULL; /* one key column at a time on the device */
+        ok = ok && rfx_hip_malloc(g_ctx, &cell, (size_t)groups * 8) == RFX_OK;
+        for (int i = 0; i < K->nkeys && ok; i++) {
+            okcols[i] = H.vector(K->kcs[i]->type, groups);
+            ok = (K->rowhash ? rfx_hip_gather(g_ctx, K->dks[i], d_first, groups, cell)
+                             : rfx_hip_composite_decode(g_ctx, d_comp, groups, K->kmins[i], K->kmults[i], K->kmaxs[i] - K->kmins[i] + 1, (int64_t *)cell)) == RFX_OK &&
+                 rfx_hip_d2h(g_ctx, RFX_AS_RAW(okcols[i]), cell, (size_t)groups * 8) == RFX_OK;
+        }
+        if (cell) rfx_hip_free(g_ctx, cell);
+    }
+    *okp = ok;
+    return SEL_GO;
+}
+
+/* by: a column symbol, or a dict {name: column | (xbar column positive-width) ...} (get_gkeys / get_gvals, core/query.c:165-240): the key
+ * columns as the table holds them, the names they take in the result, and the bucket width of the bucketed ones */
+static int sel_by_shape(obj_p tab, obj_p by, obj_p *kcs, int64_t *knames, int64_t *kxbar, int *nkeys, const char **why) {
+    *nkeys = 0;
+    if (by->type == -RFX_TYPE_SYMBOL) {
+        knames[0] = by->i64;
+        kxbar[0] = 0;
+        kcs[(*nkeys)++] = table_col(tab, by->i64);
+        return SEL_GO;
+    }
+    if (!(by->type == RFX_TYPE_DICT && RFX_AS_LIST(by)[0]->type == RFX_TYPE_SYMBOL)) { *why = "by: is neither a column nor a dict of columns"; return SEL_OUT; }
+    obj_p bk = RFX_AS_LIST(by)[0], bv = RFX_AS_LIST(by)[1];
+    if (bk->len < 1 || bk->len > RFX_MAX_KEYS || bv->len != bk->len) { *why = "by: dict shape"; return SEL_OUT; }
+    for (int64_t i = 0; i < bk->len; i++) {
+        int64_t sym;
+        obj_p bx = (bv->type == RFX_TYPE_LIST) ? RFX_AS_LIST(bv)[i] : NULL;
+        kxbar[*nkeys] = 0;
+        if (bv->type == RFX_TYPE_SYMBOL) sym = RFX_AS_I64(bv)[i];
+        else if (bx && bx->type == -RFX_TYPE_SYMBOL) sym = bx->i64;
+        else if (bx && bx->type == RFX_TYPE_LIST && bx->len == 3 && fn_id(RFX_AS_LIST(bx)[0]) == F_XBAR && RFX_AS_LIST(bx)[1]->type == -RFX_TYPE_SYMBOL &&
+                 RFX_AS_LIST(bx)[2]->type == -RFX_TYPE_I64 && RFX_AS_LIST(bx)[2]->i64 > 0) {
+            sym = RFX_AS_LIST(bx)[1]->i64; /* (xbar column width): bucketed key, evaluated on the device by the caller */
+            kxbar[*nkeys] = RFX_AS_LIST(bx)[2]->i64;
+        } else { *why = "by: key is an expression other than (xbar column positive-width)"; return SEL_OUT; }
+        knames[*nkeys] = RFX_AS_I64(bk)[i];
+        kcs[(*nkeys)++] = table_col(tab, sym);
+    }
+    return SEL_GO;
+}
+
 static obj_p select_impl(obj_p dict) {
     rfx_host_bind();
     g_ntm = 0;
@@ -1158,7 +1332,6 @@ static obj_p select_impl(obj_p dict) {
     int ntmp = 0;
     obj_p where = dict_get(dict, "where"), by = dict_get(dict, "by");
     obj_p dkeys = RFX_AS_LIST(dict)[0], dvals = RFX_AS_LIST(dict)[1];
-    int64_t s_from = H.intern("from", 4), s_where = H.intern("where", 5), s_by = H.intern("by", 2), s_take = H.intern("take", 4);
     if (tab->type != RFX_TYPE_TABLE) { why = "from: is not a table"; goto out; }
     if (ensure_ctx() != RFX_OK) { res = fail_hip("no usable MI355X"); goto done; }
     if (is_parted_table(host_tab)) {
@@ -1192,47 +1365,17 @@ static obj_p select_impl(obj_p dict) {
             if (by && g_where_data) { why = "parted table: by: under a data-column filter"; goto out; }
         }
         /* output mappings */
-        rfx_agg_t aggs[RFX_MAX_AGGS];
-        rfx_xnode_t xnodes[RFX_MAX_AGGS][RFX_MAX_XNODES];
-        int64_t names[RFX_MAX_AGGS];
-        int outtype[RFX_MAX_AGGS];
-        int nagg = 0;
-        for (int64_t i = 0; i < dkeys->len; i++) {
-            int64_t k = RFX_AS_I64(dkeys)[i];
-            if (k == s_from || k == s_where || k == s_by || k == s_take) continue;
-            obj_p e = RFX_AS_LIST(dvals)[i];
-            if (nagg >= RFX_MAX_AGGS || e->type != RFX_TYPE_LIST || e->len != 2) { why = "mapping shape"; goto out; }
-            int f = fn_id(RFX_AS_LIST(e)[0]);
-            obj_p a = RFX_AS_LIST(e)[1];
-            static const int KIND[] = {RFX_AGG_SUM, RFX_AGG_AVG, RFX_AGG_MIN, RFX_AGG_MAX, RFX_AGG_COUNT, RFX_AGG_FIRST};
-            if (f < F_SUM || f > F_FIRST) { why = "mapping is not (aggr ...)"; goto out; }
-            memset(&aggs[nagg], 0, sizeof(aggs[nagg]));
-            aggs[nagg].kind = KIND[f - F_SUM];
-            if (a->type == RFX_TYPE_LIST && a->len == 3) {
-                /* (aggr expr), expr = (op x y) over columns, atoms and nested expressions: folded on the device */
-                if (f == F_COUNT || f == F_FIRST) { why = "count / first of an expression"; goto out; }
-                int nn = 0, ncols = 0;
-                int top = build_xnodes(tab, a, xnodes[nagg], &nn, &ncols, &why);
-                if (top == -2) { res = fail_hip("column upload"); goto done; }
-                if (top < 0) goto out;
-                if (ncols == 0) { why = "expression without a column"; goto out; }
-                aggs[nagg].nxnodes = nn;
-                aggs[nagg].xnodes = xnodes[nagg];
-                aggs[nagg].col_type = RFX_I64;
-                outtype[nagg] = (f == F_AVG || rfx_agg_input_type(&aggs[nagg]) == RFX_F64) ? RFX_TYPE_F64 : RFX_TYPE_I64;
-                names[nagg++] = k;
-                continue;
-            }
-            if (a->type != -RFX_TYPE_SYMBOL) { why = "mapping is not (aggr column)"; goto out; }
-            obj_p c = table_col(tab, a->i64);
-            if (!c || !col_ctype(c) || c->type == RFX_TYPE_SYMBOL) { why = "aggregate column type"; goto out; }
-            const void *d;
-            if (resident(c, 0, &d) != RFX_OK) { res = fail_hip("column upload"); goto done; }
-            aggs[nagg].d_col = d;
-            aggs[nagg].col_type = col_ctype(c);
-            outtype[nagg] = (f == F_AVG) ? RFX_TYPE_F64 : (f == F_COUNT) ? RFX_TYPE_I64 : c->type;
-            names[nagg++] = k;
+        sel_maps_t M;
+        {
+            const int mrc = sel_mappings(tab, dkeys, dvals, &M, &why);
+            if (mrc == SEL_DONE) { res = fail_hip("column upload"); goto done; }
+            if (mrc == SEL_OUT) goto out;
         }
+        rfx_agg_t *const aggs = M.aggs;
+        rfx_xnode_t (*const xnodes)[RFX_MAX_XNODES] = M.xnodes;
+        const int64_t *const names = M.names;
+        const int *const outtype = M.outtype;
+        const int nagg = M.nagg;
         /* by: a column symbol, or a dict {name: column ...} (get_gkeys / get_gvals, core/query.c:165-240).  Several key
          * columns fold into one composite key (index_group_list_perfect, core/index.c:2308-2424). */
         obj_p kcs[RFX_MAX_KEYS] = {0};
@@ -1245,27 +1388,7 @@ static obj_p select_impl(obj_p dict) {
         int8_t key_out_type = RFX_TYPE_I64; /* one key: type of the result's key column */
         obj_p kenum = NULL;                 /* one key, an ENUM column */
         if (by) {
-            if (by->type == -RFX_TYPE_SYMBOL) {
-                knames[0] = by->i64;
-                kcs[nkeys++] = table_col(tab, by->i64);
-            } else if (by->type == RFX_TYPE_DICT && RFX_AS_LIST(by)[0]->type == RFX_TYPE_SYMBOL) {
-                obj_p bk = RFX_AS_LIST(by)[0], bv = RFX_AS_LIST(by)[1];
-                if (bk->len < 1 || bk->len > RFX_MAX_KEYS || bv->len != bk->len) { why = "by: dict shape"; goto out; }
-                for (int64_t i = 0; i < bk->len; i++) {
-                    int64_t sym;
-                    obj_p bx = (bv->type == RFX_TYPE_LIST) ? RFX_AS_LIST(bv)[i] : NULL;
-                    kxbar[nkeys] = 0;
-                    if (bv->type == RFX_TYPE_SYMBOL) sym = RFX_AS_I64(bv)[i];
-                    else if (bx && bx->type == -RFX_TYPE_SYMBOL) sym = bx->i64;
-                    else if (bx && bx->type == RFX_TYPE_LIST && bx->len == 3 && fn_id(RFX_AS_LIST(bx)[0]) == F_XBAR &&
-                             RFX_AS_LIST(bx)[1]->type == -RFX_TYPE_SYMBOL && RFX_AS_LIST(bx)[2]->type == -RFX_TYPE_I64 && RFX_AS_LIST(bx)[2]->i64 > 0) {
-                        sym = RFX_AS_LIST(bx)[1]->i64; /* (xbar column width): bucketed key, evaluated on the device below */
-                        kxbar[nkeys] = RFX_AS_LIST(bx)[2]->i64;
-                    } else { why = "by: key is an expression other than (xbar column positive-width)"; goto out; }
-                    knames[nkeys] = RFX_AS_I64(bk)[i];
-                    kcs[nkeys++] = table_col(tab, sym);
-                }
-            } else { why = "by: is neither a column nor a dict of columns"; goto out; }
+            if (sel_by_shape(tab, by, kcs, knames, kxbar, &nkeys, &why) == SEL_OUT) goto out;
             for (int i = 0; i < nkeys; i++) {
                 if (parted) { /* only the virtual column groups a parted table in the reference (INDEX_TYPE_PARTEDCOMMON, core/index.c:2199-2222) */
                     const proxy_t *px = kcs[i] ? proxy_of(kcs[i]) : NULL;
@@ -1306,32 +1429,8 @@ static obj_p select_impl(obj_p dict) {
             if (nkeys > 1 && where) { why = "where: with several by: columns"; goto out; }
             dk = dks[0];
         }
-        if (!by && nagg == 0) {
-            /* projection: filter_collect of every column (core/filter.c:51-165): where -> ids -> gather */
-            if (parted) { why = "parted table: projection"; goto out; } /* the reference keeps such a result lazy (filter maps over the partitions) */
-            if (!where) { res = H.clone(tab); g_last_gpu = 1; goto done; }
-            for (int64_t i = 0; i < tcols->len; i++)
-                if (!col_ctype(RFX_AS_LIST(tcols)[i])) { why = "projection of a non-8-byte column"; goto out; }
-            rc = where_ids(tab, where, &wp, flat, nrows, &d_ids, &nsel);
-            if (rc == -1) { why = "where: shape"; goto out; }
-            if (rc) { res = fail_hip("where"); goto done; }
-            obj_p rv = H.vector(RFX_TYPE_LIST, tcols->len);
-            void *dg = NULL;
-            int ok = nsel == 0 || rfx_hip_malloc(g_ctx, &dg, (size_t)nsel * 8) == RFX_OK;
-            for (int64_t i = 0; i < tcols->len && ok; i++) {
-                obj_p c = RFX_AS_LIST(tcols)[i];
-                obj_p o = H.vector(c->type, nsel);
-                RFX_AS_LIST(rv)[i] = o;
-                const void *dc;
-                if (nsel == 0) continue;
-                ok = resident(c, 0, &dc) == RFX_OK && rfx_hip_gather(g_ctx, dc, d_ids, nsel, dg) == RFX_OK &&
-                     rfx_hip_d2h(g_ctx, RFX_AS_RAW(o), dg, (size_t)nsel * 8) == RFX_OK;
-            }
-            if (dg) rfx_hip_free(g_ctx, dg);
-            if (d_ids) rfx_hip_free(g_ctx, d_ids);
-            if (!ok) { H.drop(rv); res = fail_hip("projection"); goto done; }
-            res = H.table(H.clone(RFX_AS_LIST(tab)[0]), rv);
-            g_last_gpu = 1;
+        if (!by && nagg == 0) { /* projection */
+            if (sel_projection(tab, where, &wp, flat, parted, nrows, &res, &why) == SEL_OUT) goto out;
             goto done;
         }
         if (!flat) {
@@ -1594,52 +1693,15 @@ static obj_p select_impl(obj_p dict) {
                         ok = (dense ? rfx_hip_group_emit(g_ctx, aggs, &gt, (int64_t *)dout, NULL, ptrs) : rfx_hip_hash_emit(g_ctx, aggs, &ht, (int64_t *)dout, (int64_t *)dfirst, ptrs)) == RFX_OK;
                     }
                     tm_mark();
-                    if (nkeys == 1 && key_out_type == RFX_TYPE_DATE) { /* the virtual Date column: 4-byte days */
-                        okeys = H.vector(RFX_TYPE_DATE, groups);
-                        int64_t *k8 = (int64_t *)malloc((size_t)groups * 8);
-                        ok = ok && k8 && fetch(k8, dkeys_out, (size_t)groups * 8) == RFX_OK;
-                        for (int64_t g = 0; g < groups && ok; g++) ((int32_t *)RFX_AS_RAW(okeys))[g] = (int32_t)k8[g];
-                        free(k8);
-                    } else if (nkeys == 1) {
-                        okeys = H.vector(key_out_type, groups);
-                        if (ok) ok = fetch(RFX_AS_RAW(okeys), dkeys_out, (size_t)groups * 8) == RFX_OK;
-                        if (ok && kenum) { /* indices -> symbols of the enum's domain (the global its key names) */
-                            obj_p dom = enum_domain(kenum);
-                            int good = dom != NULL;
-                            int64_t *kk = RFX_AS_I64(okeys);
-                            for (int64_t g = 0; g < groups && good; g++) {
-                                if (kk[g] < 0 || kk[g] >= dom->len) good = 0;
-                                else kk[g] = RFX_AS_I64(dom)[kk[g]];
-                            }
-                            if (dom) H.drop(dom);
-                            if (!good) {
-                                if (dout) rfx_hip_free(g_ctx, dout);
-                                rfx_hip_free(g_ctx, store);
-                                H.drop(okeys);
-                                why = "by: enum column whose domain cannot be resolved";
-                                goto out;
-                            }
+                    {
+                        const sel_keys_t K = {nkeys, key_out_type, kenum, rowhash, kcs, dks, kmins, kmaxs, kmults};
+                        const int krc = sel_key_columns(&K, groups, dkeys_out, (const int64_t *)dout, (const int64_t *)dfirst, &okeys, okcols, &ok);
+                        if (krc == SEL_OUT) {
+                            if (dout) rfx_hip_free(g_ctx, dout);
+                            rfx_hip_free(g_ctx, store);
+                            why = "by: enum column whose domain cannot be resolved";
+                            goto out;
                         }
-                    } else if (rowhash) {
-                        /* the key columns of the result: the tuples at the groups' first rows */
-                        void *kg = NULL;
-                        ok = ok && rfx_hip_malloc(g_ctx, &kg, (size_t)groups * 8) == RFX_OK;
-                        for (int i = 0; i < nkeys && ok; i++) {
-                            okcols[i] = H.vector(kcs[i]->type, groups);
-                            ok = rfx_hip_gather(g_ctx, dks[i], (const int64_t *)dfirst, groups, kg) == RFX_OK &&
-                                 rfx_hip_d2h(g_ctx, RFX_AS_RAW(okcols[i]), kg, (size_t)groups * 8) == RFX_OK;
-                        }
-                        if (kg) rfx_hip_free(g_ctx, kg);
-                    } else {
-                        /* key column i = min_i + (composite / mult_i) % range_i  (= key_i[first row], core/query.c:110-135) */
-                        void *dec = NULL;
-                        ok = ok && rfx_hip_malloc(g_ctx, &dec, (size_t)groups * 8) == RFX_OK;
-                        for (int i = 0; i < nkeys && ok; i++) {
-                            okcols[i] = H.vector(kcs[i]->type, groups);
-                            ok = rfx_hip_composite_decode(g_ctx, (const int64_t *)dout, groups, kmins[i], kmults[i], kmaxs[i] - kmins[i] + 1, (int64_t *)dec) == RFX_OK &&
-                                 rfx_hip_d2h(g_ctx, RFX_AS_RAW(okcols[i]), dec, (size_t)groups * 8) == RFX_OK;
-                        }
-                        if (dec) rfx_hip_free(g_ctx, dec);
                     }
                     for (int a = 0; a < nagg && ok; a++) {
                         ocols[a] = H.vector((int8_t)outtype[a], groups);
