@@ -45,6 +45,7 @@ struct WoArgs {
     i64 cap;          // ids beyond `cap` are counted, not written
     i64 row0;
     i64 ntiles;
+    int delay;        // look-back starts this many 3.4-us naps after the tile's count went out
 };
 
 void rfx_where_once_launch_nc1(rfx_ctx *c, const Plan &P, const WoArgs &A, int grid);
@@ -144,11 +145,15 @@ __global__ __launch_bounds__(WO_T) __attribute__((amdgpu_waves_per_eu(WO_NC <= 2
                 // lane l looks at tiles j - l, j - 64 - l, j - 128 - l, j - 192 - l (four loads in flight: a round covers 256 predecessors --
                 // with ~1 000 workgroups in flight the nearest tile that knows its prefix is up to that far back, and a device-scope load
                 // under full HBM load takes microseconds); before tile 0 lies an inclusive prefix of zero
+                // (no hurry: the answer is needed a whole tile time from now, and a look-back that starts at once finds its neighbours'
+                // counts not published yet and polls -- a thousand control waves reading the same few status lines device-wide)
+                for (int z = 0; z < A.delay; z++) __builtin_amdgcn_s_sleep(127);
                 for (i64 j = prev - 1;; j -= 256) {
                     u64 s[4];
-                    bool again, done;
+                    bool again = false, done;
                     u64 add;
                     do {
+                        if (again) __builtin_amdgcn_s_sleep(127);
 #pragma unroll
                         for (int k = 0; k < 4; k++) {
                             const i64 idx = j - 64 * k - lane;
@@ -403,6 +408,7 @@ extern "C" int rfx_hip_where_once(rfx_ctx_t *c, const rfx_pred_t *preds, int npr
     A.cap = cap;
     A.row0 = row0;
     A.ntiles = ntiles;
+    A.delay = 6; /* (0 .. 20 measured: 1.955 / 1.93 / 1.92 / 1.925 / 1.95 ms per 1e9 rows, 10 % selected) */
     RFX_HIP_CHECK(hipMemsetAsync(c->d_ws, 0, 256 + (size_t)ntiles * 8, c->stream));
     int grid = c->num_cus * (P.ncols <= 2 ? 4 : 2); // workgroups a CU holds (5 waves each)
     if ((i64)grid > ntiles) grid = (int)ntiles;
