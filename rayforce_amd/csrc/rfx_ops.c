@@ -1150,7 +1150,13 @@ typedef struct {
     int outtype[RFX_MAX_AGGS];
     int nagg;
 } sel_maps_t;
-static int sel_mappings(obj_p tab, obj_p dkeys, obj_p dvals, sel_maps_t *M, const char **why) {
+/* result cells of an aggregate over a widened 4-byte column, back in the column's own width: the i64 null and the i64 identities of an
+ * all-null group (core/aggr.c:1246) become the 4-byte ones */
+static void sel_narrow_i32(obj_p col, const int64_t *cells, int64_t n) {
+    int32_t *o = (int32_t *)RFX_AS_RAW(col);
+    for (int64_t i = 0; i < n; i++) o[i] = cells[i] == RFX_NULL_I64 ? INT32_MIN : (cells[i] == INT64_MAX ? INT32_MAX : (int32_t)cells[i]);
+}
+static int sel_mappings(obj_p tab, obj_p dkeys, obj_p dvals, int grouped, sel_maps_t *M, const char **why) {
     const int64_t s_from = H.intern("from", 4), s_where = H.intern("where", 5), s_by = H.intern("by", 2), s_take = H.intern("take", 4);
     M->nagg = 0;
     for (int64_t i = 0; i < dkeys->len; i++) {
@@ -1183,11 +1189,15 @@ static int sel_mappings(obj_p tab, obj_p dkeys, obj_p dvals, sel_maps_t *M, cons
         }
         if (a->type != -RFX_TYPE_SYMBOL) { *why = "mapping is not (aggr column)"; return SEL_OUT; }
         obj_p c = table_col(tab, a->i64);
-        if (!c || !col_ctype(c) || c->type == RFX_TYPE_SYMBOL) { *why = "aggregate column type"; return SEL_OUT; }
+        /* a 4-byte integer column (I32 / DATE / TIME): min / max / first / count fold its widened device copy and the result cells are
+         * narrowed back (sel_narrow_i32); sum / avg wrap in 32 bits in the reference (FOLD_ADDI32, core/math.c:1864-1871): the host's */
+        const int narrow = c && IS_I32_FAMILY(c->type) && (f == F_MIN || f == F_MAX || f == F_FIRST || f == F_COUNT) &&
+                           !(grouped && c->type == RFX_TYPE_I32); /* (grouped min / max over I32 is a `type` error in the reference: its to say) */
+        if (!c || (!narrow && (!col_ctype(c) || c->type == RFX_TYPE_SYMBOL))) { *why = "aggregate column type"; return SEL_OUT; }
         const void *d;
         if (resident(c, 0, &d) != RFX_OK) return SEL_DONE;
         M->aggs[n].d_col = d;
-        M->aggs[n].col_type = col_ctype(c);
+        M->aggs[n].col_type = narrow ? RFX_I64 : col_ctype(c);
         M->outtype[n] = (f == F_AVG) ? RFX_TYPE_F64 : (f == F_COUNT) ? RFX_TYPE_I64 : c->type;
         M->names[M->nagg++] = k;
     }
@@ -1367,7 +1377,7 @@ static obj_p select_impl(obj_p dict) {
         /* output mappings */
         sel_maps_t M;
         {
-            const int mrc = sel_mappings(tab, dkeys, dvals, &M, &why);
+            const int mrc = sel_mappings(tab, dkeys, dvals, by != NULL, &M, &why);
             if (mrc == SEL_DONE) { res = fail_hip("column upload"); goto done; }
             if (mrc == SEL_OUT) goto out;
         }
@@ -1705,7 +1715,12 @@ static obj_p select_impl(obj_p dict) {
                     }
                     for (int a = 0; a < nagg && ok; a++) {
                         ocols[a] = H.vector((int8_t)outtype[a], groups);
-                        ok = fetch(RFX_AS_RAW(ocols[a]), ptrs[a], (size_t)groups * 8) == RFX_OK;
+                        if (IS_I32_FAMILY(outtype[a])) {
+                            int64_t *c8 = (int64_t *)malloc((size_t)(groups ? groups : 1) * 8);
+                            ok = c8 && fetch(c8, ptrs[a], (size_t)groups * 8) == RFX_OK;
+                            if (ok) sel_narrow_i32(ocols[a], c8, groups);
+                            free(c8);
+                        } else ok = fetch(RFX_AS_RAW(ocols[a]), ptrs[a], (size_t)groups * 8) == RFX_OK;
                     }
                 }
                 tm_mark();
@@ -1743,7 +1758,10 @@ static obj_p select_impl(obj_p dict) {
         obj_p rk = H.vector(RFX_TYPE_SYMBOL, nagg), rv = H.vector(RFX_TYPE_LIST, nagg);
         for (int a = 0; a < nagg; a++) {
             RFX_AS_I64(rk)[a] = names[a];
-            RFX_AS_LIST(rv)[a] = one_row(&vals[a]);
+            if (IS_I32_FAMILY(outtype[a])) {
+                RFX_AS_LIST(rv)[a] = H.vector((int8_t)outtype[a], 1);
+                sel_narrow_i32(RFX_AS_LIST(rv)[a], &vals[a].i, 1);
+            } else RFX_AS_LIST(rv)[a] = one_row(&vals[a]);
         }
         res = H.table(rk, rv);
         g_last_gpu = 1;
