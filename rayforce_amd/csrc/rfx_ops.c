@@ -876,6 +876,10 @@ static int plan_cmp(obj_p tab, obj_p e, rfx_pred_t *p) {
     else g_where_data++;
     p->d_col = d;
     if (r->type == -RFX_TYPE_I64) { p->rhs_type = RFX_I64; p->rhs_i = r->i64; }
+    else if (r->type == -RFX_TYPE_TIMESTAMP && l->type == -RFX_TYPE_SYMBOL && table_col(tab, l->i64) && table_col(tab, l->i64)->type == RFX_TYPE_TIMESTAMP) {
+        p->rhs_type = RFX_I64; /* a TIMESTAMP column against a timestamp atom: nanoseconds as i64 on both sides (core/cmp.c) */
+        p->rhs_i = r->i64;
+    }
     else if (r->type == -RFX_TYPE_DATE && ldate) { p->rhs_type = RFX_I64; p->rhs_i = (int64_t)r->i32; } /* (== Date 2024.01.03): partition pruning, core/cmp.c:341-358 */
     else if (r->type == -RFX_TYPE_F64) { p->rhs_type = RFX_F64; p->rhs_f = r->f64; }
     else if (r->type == -RFX_TYPE_SYMBOL && (r->attrs & RFX_ATTR_QUOTED)) {
@@ -1761,7 +1765,10 @@ static obj_p select_impl(obj_p dict) {
             if (IS_I32_FAMILY(outtype[a])) {
                 RFX_AS_LIST(rv)[a] = H.vector((int8_t)outtype[a], 1);
                 sel_narrow_i32(RFX_AS_LIST(rv)[a], &vals[a].i, 1);
-            } else RFX_AS_LIST(rv)[a] = one_row(&vals[a]);
+            } else {
+                RFX_AS_LIST(rv)[a] = one_row(&vals[a]);
+                if (outtype[a] == RFX_TYPE_TIMESTAMP && vals[a].type != RFX_F64) RFX_AS_LIST(rv)[a]->type = RFX_TYPE_TIMESTAMP; /* min / max / first of a TIMESTAMP column */
+            }
         }
         res = H.table(rk, rv);
         g_last_gpu = 1;

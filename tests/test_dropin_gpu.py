@@ -210,6 +210,9 @@ NARROW = [  # 4-byte integer columns (DATE = days, TIME = milliseconds, I32) in 
     ("n9", "{mx: (max d) mn: (min tm) f: (first i) c: (count d) from: dt where: (> a 10)}", ["mx", "mn", "f", "c"], True),
     ("n10", "{mx: (max d) mn: (min d) f: (first tm) c: (count tm) from: dt by: k}", ["k", "mx", "mn", "f", "c"], True),
     ("n11", "{mx: (max d) mn: (min d) f: (first d) from: dt where: (< d 2024.01.01) by: k}", ["k", "mx", "mn", "f"], True),  # only null dates selected (null sorts lowest)
+    # TIMESTAMP columns (8-byte nanoseconds): against timestamp atoms, as aggregate arguments, bucketed as a key
+    ("n12", "{s: (sum v) mx: (max ts) mn: (min ts) from: dt where: (and (>= ts 2024.01.01D06:00:00.000000000) (< ts 2024.01.01D18:00:00.000000000))}", ["s", "mx", "mn"], True),
+    ("n13", "{f: (first ts) mx: (max ts) c: (count a) from: dt where: (> a 500000) by: k}", ["k", "f", "mx", "c"], True),
 ]
 
 
@@ -239,7 +242,8 @@ def test_date_time_i32_columns_in_predicates_inside_the_real_reference(built):
         s.put("d2", d2, tp=7)
         s.put("tm", tm, tp=8)
         s.put("i", i32, tp=4)
-        s.eval("(set dt (table [k a v d d2 tm i] (list k a v d d2 tm i)))")
+        s.put("ts", np.int64(day0) * 86_400_000_000_000 + rfo.gen_i64(n, 89, 86_400_000_000_000), tp=9)  # nanoseconds within 2024.01.01
+        s.eval("(set dt (table [k a v d d2 tm i ts] (list k a v d d2 tm i ts)))")
         s.eval(f'(set gsel (loadfn "{LIB}" "rfx_select" 1))')
         for name, q, outs, _ in NARROW:
             s.eval(f"(set g_{name} (gsel {q}))")
@@ -247,6 +251,7 @@ def test_date_time_i32_columns_in_predicates_inside_the_real_reference(built):
             for o in outs:
                 s.out(f"g_{name}_{o}", f"(at g_{name} '{o})")
                 s.out(f"r_{name}_{o}", f"(at r_{name} '{o})")
+                s.out(f"ty_{name}_{o}", f"(as 'I64 (enlist (== (type (at g_{name} '{o})) (type (at r_{name} '{o})))))")  # DATE / TIME / TIMESTAMP stay what they are
         s.eval(f'(set gstat (loadfn "{LIB}" "rfx_stats" 1))')
         s.out("stats", "(gstat 0)")
         res = s.run(threads=8)
@@ -258,6 +263,7 @@ def test_date_time_i32_columns_in_predicates_inside_the_real_reference(built):
                 assert np.allclose(g, r, rtol=1e-9, atol=0), (name, o)
             else:
                 assert np.array_equal(g, r), (name, o)
+            assert res[f"ty_{name}_{o}"].all(), (name, o, "result column type")
     st = res["stats"]
     on_gpu = sum(1 for *_, gpu in NARROW if gpu)
     print(ref.LAST_STDERR)
