@@ -48,10 +48,10 @@ static struct {
     /* the host's own built-ins, for recognising function objects inside parsed expressions and for delegation */
     void *f[32];
 } H;
-enum { F_SUM, F_AVG, F_MIN, F_MAX, F_COUNT, F_FIRST, F_EQ, F_NE, F_LT, F_GT, F_LE, F_GE, F_AND, F_OR, F_SELECT, F_ADD, F_SUB, F_MUL, F_FDIV, F_DIV, F_MOD, F_XBAR, F_LJ, F_IJ, F_UPDATE, F_TAKE, F_N };
+enum { F_SUM, F_AVG, F_MIN, F_MAX, F_COUNT, F_FIRST, F_EQ, F_NE, F_LT, F_GT, F_LE, F_GE, F_AND, F_OR, F_SELECT, F_ADD, F_SUB, F_MUL, F_FDIV, F_DIV, F_MOD, F_XBAR, F_LJ, F_IJ, F_UPDATE, F_TAKE, F_IN, F_WITHIN, F_NOT, F_N };
 static const char *HOST_FN[F_N] = {"ray_sum", "ray_avg", "ray_min", "ray_max", "ray_count", "ray_first", "ray_eq",  "ray_ne",  "ray_lt",  "ray_gt",
                                    "ray_le",  "ray_ge",  "ray_and", "ray_or",  "ray_select", "ray_add",  "ray_sub", "ray_mul", "ray_fdiv", "ray_div", "ray_mod", "ray_xbar",
-                                   "ray_left_join", "ray_inner_join", "ray_update", "ray_take"};
+                                   "ray_left_join", "ray_inner_join", "ray_update", "ray_take", "ray_in", "ray_within", "ray_not"}; /* (in / within / not: recognised inside where: only) */
 /* xbar is recognised inside `by:` only; the standalone object model still needs a distinct function object for it:
  * this stub is never called by this library. */
 static obj_p x_stub_xbar(obj_p a, obj_p b) { (void)a; (void)b; return NULL; }
@@ -143,7 +143,7 @@ static int fn_id(obj_p o) {
     if (!o || (o->type != RFX_TYPE_UNARY && o->type != RFX_TYPE_BINARY && o->type != RFX_TYPE_VARY)) return -1;
     void *p = (void *)(intptr_t)o->i64;
     for (int i = 0; i < F_N; i++)
-        if (p == OUR_FN[i] || (H.f[i] && p == H.f[i])) return i;
+        if ((OUR_FN[i] && p == OUR_FN[i]) || (H.f[i] && p == H.f[i])) return i;
     return -1;
 }
 
@@ -805,6 +805,14 @@ static obj_p enum_domain(obj_p e) {
 #define RFX_ATTR_QUOTED 8 /* ATTR_QUOTED, core/ops.h:55: a symbol atom that stands for itself ('x), not for a column */
 static int g_where_virtual, g_where_data; /* comparisons of the where: in flight that read the virtual column / data columns of a parted table */
 static int plan_cmp(obj_p tab, obj_p e, rfx_pred_t *p) {
+    if (e->type == RFX_TYPE_LIST && e->len == 2 && fn_id(RFX_AS_LIST(e)[0]) == F_NOT) {
+        /* (not (cmp x y)) = the complementary comparison: the reference's order is total (nulls and NaN sort lowest, core/ops.h:97), so
+         * exactly one of < == > holds for every pair of cells and the complement of a set of them is the rest */
+        static const int COMPLEMENT[6] = {RFX_NE, RFX_EQ, RFX_GE, RFX_LE, RFX_GT, RFX_LT}; /* of EQ NE LT GT LE GE */
+        const int rc = plan_cmp(tab, RFX_AS_LIST(e)[1], p);
+        if (rc == 0) p->op = COMPLEMENT[p->op];
+        return rc;
+    }
     if (e->type != RFX_TYPE_LIST || e->len != 3) return -1;
     int f = fn_id(RFX_AS_LIST(e)[0]);
     if (f < F_EQ || f > F_GE) return -1;
@@ -904,6 +912,42 @@ static int plan_cmp(obj_p tab, obj_p e, rfx_pred_t *p) {
     } else return -1;
     return 0;
 }
+/* (within col [lo hi]) = lo <= col <= hi (ray_within, core/items.c:848-872: an I64 column against a two-element I64 vector, raw integer
+ * order) and (in col [v1 .. vn]) = col == v1 or ... (ray_in, core/items.c:736+ -> index_in_i64_i64: raw equality; I64 / TIMESTAMP / SYMBOL
+ * columns against a vector of their own type) as comparisons of the fused pass: appends them to out[0 .. room) and says through *glogic
+ * how they combine among themselves.  Returns how many (>= 1), -1 when `e` is not such a form (or too long), -2 on an upload error. */
+static int plan_set_cmp(obj_p tab, obj_p e, rfx_pred_t *out, int room, int *glogic) {
+    if (!e || e->type != RFX_TYPE_LIST || e->len != 3) return -1;
+    const int f = fn_id(RFX_AS_LIST(e)[0]);
+    if (f != F_IN && f != F_WITHIN) return -1;
+    obj_p l = RFX_AS_LIST(e)[1], r = RFX_AS_LIST(e)[2];
+    if (l->type != -RFX_TYPE_SYMBOL || (l->attrs & RFX_ATTR_QUOTED) || r->type <= 0) return -1;
+    obj_p lc = table_col(tab, l->i64);
+    if (!lc || g_npx) return -1; /* (parted tables: the reference prunes partitions through these forms -- not taken apart here) */
+    int n;
+    if (f == F_WITHIN) {
+        if (lc->type != RFX_TYPE_I64 || r->type != RFX_TYPE_I64 || r->len != 2) return -1;
+        n = 2;
+        *glogic = RFX_AND;
+    } else {
+        if (!(lc->type == RFX_TYPE_I64 || lc->type == RFX_TYPE_TIMESTAMP || lc->type == RFX_TYPE_SYMBOL) || r->type != lc->type || r->len < 1 || r->len > RFX_MAX_PREDS) return -1;
+        n = (int)r->len;
+        *glogic = RFX_OR;
+    }
+    if (n > room) return -1;
+    const void *d;
+    if (resident(lc, 0, &d) != RFX_OK) return -2;
+    g_where_data++;
+    for (int i = 0; i < n; i++) {
+        memset(&out[i], 0, sizeof(out[i]));
+        out[i].d_col = d;
+        out[i].col_type = RFX_I64;
+        out[i].rhs_type = RFX_I64;
+        out[i].rhs_i = RFX_AS_I64(r)[i];
+        out[i].op = f == F_WITHIN ? (i == 0 ? RFX_GE : RFX_LE) : RFX_EQ;
+    }
+    return n;
+}
 /* where: a comparison, or a flat (and ...) / (or ...) of comparisons */
 /* One arm of the top-level and / or: a comparison; a list of the SAME operator (and inside and: associative, its arms are this level's);
  * or a parenthesis of the OPPOSITE operator over comparisons -- `more` set on all but its last (rfx_pred_t: the fused kernels fold a
@@ -911,6 +955,15 @@ static int plan_cmp(obj_p tab, obj_p e, rfx_pred_t *p) {
 static int plan_arm(obj_p tab, obj_p e, int top, wplan_t *wp) {
     if (!e || e->type != RFX_TYPE_LIST || e->len < 1) return -1;
     int f = fn_id(RFX_AS_LIST(e)[0]);
+    if (f == F_IN || f == F_WITHIN) { /* a group of comparisons: flat when it combines like this level, else a parenthesis of its own */
+        int gl = RFX_AND;
+        const int n = plan_set_cmp(tab, e, &wp->preds[wp->npred], RFX_MAX_PREDS - wp->npred, &gl);
+        if (n < 0) return n;
+        if (gl != (top == F_AND ? RFX_AND : RFX_OR))
+            for (int i = 0; i + 1 < n; i++) wp->preds[wp->npred + i].more = 1;
+        wp->npred += n;
+        return 0;
+    }
     if (f != F_AND && f != F_OR) {
         if (wp->npred >= RFX_MAX_PREDS) return -1;
         int rc = plan_cmp(tab, e, &wp->preds[wp->npred]);
@@ -925,12 +978,20 @@ static int plan_arm(obj_p tab, obj_p e, int top, wplan_t *wp) {
         }
         return 0;
     }
-    for (int64_t i = 1; i < e->len; i++) {
+    for (int64_t i = 1; i < e->len; i++) { /* a parenthesis of the opposite operator */
         if (wp->npred >= RFX_MAX_PREDS) return -1;
-        int rc = plan_cmp(tab, RFX_AS_LIST(e)[i], &wp->preds[wp->npred]);
-        if (rc) return rc;
-        wp->preds[wp->npred].more = (i + 1 < e->len);
-        wp->npred++;
+        int gl = RFX_AND;
+        int n = plan_set_cmp(tab, RFX_AS_LIST(e)[i], &wp->preds[wp->npred], RFX_MAX_PREDS - wp->npred, &gl);
+        if (n == -2) return -2;
+        if (n > 0 && gl != (f == F_AND ? RFX_AND : RFX_OR)) return -1; /* a third level: the mask path / the host */
+        if (n < 0) {
+            int rc = plan_cmp(tab, RFX_AS_LIST(e)[i], &wp->preds[wp->npred]);
+            if (rc) return rc;
+            n = 1;
+        }
+        for (int j = 0; j < n; j++) wp->preds[wp->npred + j].more = 1;
+        wp->npred += n;
+        if (i + 1 == e->len) wp->preds[wp->npred - 1].more = 0;
     }
     return 0;
 }
@@ -945,6 +1006,12 @@ static int plan_where(obj_p tab, obj_p w, wplan_t *wp) {
         if (w->len < 2) return -1;
         wp->logic = (f == F_AND) ? RFX_AND : RFX_OR;
         return plan_arm(tab, w, f, wp);
+    }
+    if (f == F_IN || f == F_WITHIN) {
+        const int n = plan_set_cmp(tab, w, wp->preds, RFX_MAX_PREDS, &wp->logic);
+        if (n < 0) return n;
+        wp->npred = n;
+        return 0;
     }
     int rc = plan_cmp(tab, w, &wp->preds[0]);
     if (rc) return rc;

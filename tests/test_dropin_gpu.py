@@ -52,6 +52,13 @@ QUERIES = [
     # `/` (ray_div: floor division, left operand's type) and `%` (ray_mod) inside aggregates and predicates
     ("q25", "{q: (sum (/ a k2)) r: (max (% a 7)) f: (sum (% v 0.25)) d: (min (/ a 2.5)) from: t where: (< a 800000)}", ["q", "r", "f", "d"]),
     ("q26", "{s: (sum (% a (+ k3 30))) m: (max (/ v 0.125)) from: t where: (== (% a 3) 1) by: k1}", ["k1", "s", "m"]),
+    # (within col [lo hi]) and (in col [..]) as comparisons of the fused pass (round 3): alone, under and / or, inside a parenthesis
+    ("q27", "{s: (sum v) c: (count a) from: t where: (within a [100000 300000])}", ["s", "c"]),
+    ("q28", "{s: (sum v) c: (count a) from: t where: (in k [3 7 11 500])}", ["s", "c"]),
+    ("q29", "{s: (sum v) from: t where: (and (in k [1 2 3]) (within a [0 500000]) (> v 0.25)) by: k1}", ["k1", "s"]),
+    ("q30", "{c: (count a) from: t where: (or (within a [10 20000]) (in k [5 6]) (> v 0.99))}", ["c"]),
+    ("q31", "{c: (count a) m: (max a) from: t where: (and (or (in k [5 6 7]) (< a 1000)) (within a [0 900000]))}", ["c", "m"]),
+    ("q32", "{c: (count a) s: (sum v) from: t where: (and (not (< a 500000)) (not (== k 7)) (not (>= v 0.75)))}", ["c", "s"]),
 ]
 
 
