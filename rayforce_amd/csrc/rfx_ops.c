@@ -1260,10 +1260,13 @@ static int sel_mappings(obj_p tab, obj_p dkeys, obj_p dvals, int grouped, sel_ma
         }
         if (a->type != -RFX_TYPE_SYMBOL) { *why = "mapping is not (aggr column)"; return SEL_OUT; }
         obj_p c = table_col(tab, a->i64);
-        /* a 4-byte integer column (I32 / DATE / TIME): min / max / first / count fold its widened device copy and the result cells are
-         * narrowed back (sel_narrow_i32); sum / avg wrap in 32 bits in the reference (FOLD_ADDI32, core/math.c:1864-1871): the host's */
-        const int narrow = c && IS_I32_FAMILY(c->type) && (f == F_MIN || f == F_MAX || f == F_FIRST || f == F_COUNT) &&
-                           !(grouped && c->type == RFX_TYPE_I32); /* (grouped min / max over I32 is a `type` error in the reference: its to say) */
+        /* a 4-byte integer column (I32 / DATE / TIME): min / max / first / count / sum fold its widened device copy and the result cells
+         * are narrowed back (sel_narrow_i32); avg and the sum of dates are the host's */
+        const int narrow = c && IS_I32_FAMILY(c->type) && !(grouped && c->type == RFX_TYPE_I32) && /* (any grouped aggregate over an I32 column is a `type` error in the reference: its to say) */
+                           ((f == F_MIN || f == F_MAX || f == F_FIRST || f == F_COUNT) ||
+                            /* sums of I32 / TIME columns wrap in 32 bits there (FOLD_ADDI32 / ADDI32, core/math.c:1864-1871, core/aggr.c:1095-1100):
+                             * the low 32 bits of the 64-bit sum of the widened column are that sum */
+                            (f == F_SUM && !grouped && (c->type == RFX_TYPE_I32 || c->type == RFX_TYPE_TIME))); /* (grouped: a `type` error there) */
         if (!c || (!narrow && (!col_ctype(c) || c->type == RFX_TYPE_SYMBOL))) { *why = "aggregate column type"; return SEL_OUT; }
         const void *d;
         if (resident(c, 0, &d) != RFX_OK) return SEL_DONE;

@@ -212,7 +212,8 @@ NARROW = [  # 4-byte integer columns (DATE = days, TIME = milliseconds, I32) in 
     ("n5", "{c: (count a) from: dt where: (or (> i 95.5) (< d 2024.01.03))}", ["c"], True),    # ... an f64 atom; null dates sort lowest
     ("n6", "{c: (count a) s: (sum v) from: dt where: (== d d2)}", ["c", "s"], True),           # two DATE columns
     ("n7", "{c: (count a) from: dt where: (and (!= d 2024.01.20) (<= tm 23:00:00.000) (>= i a))}", ["c"], True),  # I32 column against an I64 column
-    ("n8", "{s: (sum i) from: dt where: (> a 10)}", ["s"], False),                              # sums over 4-byte columns wrap in 32 bits there: the host's
+    ("n8", "{s: (avg i) from: dt where: (> a 10)}", ["s"], False),                              # averages over 4-byte columns: the host's
+    ("n14", "{s: (sum i) t: (sum tm) from: dt where: (> a 10)}", ["s", "t"], True),            # sums wrap in 32 bits there: the low half of the 64-bit sum
     # min / max / first / count OVER 4-byte columns: folded on the widened copy, the cells narrowed back
     ("n9", "{mx: (max d) mn: (min tm) f: (first i) c: (count d) from: dt where: (> a 10)}", ["mx", "mn", "f", "c"], True),
     ("n10", "{mx: (max d) mn: (min d) f: (first tm) c: (count tm) from: dt by: k}", ["k", "mx", "mn", "f", "c"], True),
