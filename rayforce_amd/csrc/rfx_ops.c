@@ -194,6 +194,8 @@ typedef struct {
     int sd_never;      /* ... cannot be tracked (file-backed / shared pages): the checksum every time */
     uint64_t edge_sum; /* ... checksum of the payload bytes in its first and last, partial pages (they hold other objects too) */
     size_t dbytes;     /* bytes of the device copy (`bytes` are the host payload's: a 4-byte column is widened on the device) */
+    int scope_ok;      /* [smin, smax] = index_scope_i64 of the WHOLE column (no filter), taken from this very copy: valid as long as the copy is */
+    int64_t smin, smax;
 } resident_t;
 static resident_t *g_res;
 static int g_nres, g_capres;
@@ -668,6 +670,7 @@ static int resident(obj_p col, int pin, const void **dev) {
             int rc = px ? proxy_upload(px, g_res[i].dev) : payload_upload(col->type, g_res[i].dev, host, col->len);
             if (rc != RFX_OK) { res_free(i); return rc; }
             g_stat[ST_UPLOADS]++;
+            g_res[i].scope_ok = 0; /* (new cells: the scope remembered for the old ones is gone) */
             g_res[i].sum = sum;
             g_res[i].tick = ++g_tick;
             g_res[i].epoch = g_epoch;
@@ -695,10 +698,19 @@ static int resident(obj_p col, int pin, const void **dev) {
         g_capres = g_capres ? g_capres * 2 : 32;
         g_res = (resident_t *)realloc(g_res, sizeof(resident_t) * (size_t)g_capres);
     }
-    g_res[g_nres++] = (resident_t){host, col->len, ktype, sum, d, bytes, pin, ++g_tick, g_epoch, 0, 0, 0, 0, dbytes}; /* (page tracking starts once the column has proven stable) */
+    g_res[g_nres++] = (resident_t){host, col->len, ktype, sum, d, bytes, pin, ++g_tick, g_epoch, 0, 0, 0, 0, dbytes, 0, 0, 0}; /* (page tracking starts once the column has proven stable) */
     g_res_bytes += dbytes;
     *dev = d;
     return RFX_OK;
+}
+/* The key scope of a WHOLE resident column (index_scope_i64 without a filter, core/index.c:376-435), remembered with the copy it was taken
+ * from.  A group-by over a few thousand slots is two host round trips -- the scope, the result -- and ~25 us each: the remembered scope
+ * (a superset of any filtered selection's, which is all the tables' sizing needs) saves the first one for every later query over that key
+ * column, whatever its filter.  Only entries proven current in THIS operator call are asked (epoch), a refreshed copy forgets its scope. */
+static resident_t *resident_entry(const void *dev) {
+    for (int i = 0; i < g_nres; i++)
+        if (g_res[i].dev == dev && g_res[i].epoch == g_epoch) return &g_res[i];
+    return NULL;
 }
 /* drop every cached copy that overlaps the vector's payload */
 static void invalidate_payload(obj_p v) {
@@ -1629,7 +1641,25 @@ static obj_p select_impl(obj_p dict) {
                     spec = kmin != RFX_NULL_I64 && kmax >= kmin && (uint64_t)(kmax - kmin) < RFX_SCOPE_SAMPLE_MAX_RANGE;
                     seen = nrows;
                 }
-                if (!spec && rfx_hip_group_scope(g_ctx, (const int64_t *)dk, wp.preds, wp.npred, wp.logic, aggs, nagg, nrows, &kmin, &kmax, &seen) != RFX_OK) { res = fail_hip("scope"); goto done; }
+                /* small inputs, a plain resident key column: its whole-column scope, remembered (or taken now, without the filter: the same
+                 * pass) -- when it is LDS-sized the tables take it as it is; `seen` = every row (an upper bound: table sizing and the dense /
+                 * hashed choice only; an empty selection comes out as zero groups) */
+                resident_t *ke = (!spec && !parted && flat && nrows > 0 && nrows < ((int64_t)1 << 24) && dk == dks[0] && !kxbar[0]) ? resident_entry(dk) : NULL;
+                int cached = 0;
+                if (ke) {
+                    if (!ke->scope_ok) {
+                        int64_t c0 = 0;
+                        if (rfx_hip_scope_i64(g_ctx, (const int64_t *)dk, NULL, 0, RFX_AND, nrows, &ke->smin, &ke->smax, &c0) != RFX_OK) { res = fail_hip("scope"); goto done; }
+                        ke->scope_ok = 1;
+                    }
+                    if (ke->smin != RFX_NULL_I64 && ke->smax >= ke->smin && (uint64_t)(ke->smax - ke->smin) < RFX_SCOPE_SAMPLE_MAX_RANGE) {
+                        kmin = ke->smin;
+                        kmax = ke->smax;
+                        seen = nrows;
+                        cached = 1;
+                    }
+                }
+                if (!spec && !cached && rfx_hip_group_scope(g_ctx, (const int64_t *)dk, wp.preds, wp.npred, wp.logic, aggs, nagg, nrows, &kmin, &kmax, &seen) != RFX_OK) { res = fail_hip("scope"); goto done; }
             }
             tm_mark();
             if (spec && rowhash) spec = 0; /* (cannot happen: the row-hash path needs ranges beyond 64 bits) */

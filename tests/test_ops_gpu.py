@@ -391,6 +391,53 @@ def test_cache_validates_by_page_bits_where_the_kernel_tracks_them(ops):
         ops.rfx_host_drop(o)
 
 
+def test_remembered_key_scope_follows_the_column(ops):
+    """Small inputs: the whole-column scope of a resident key column is remembered with its device copy (one host round trip less per
+    group-by); a write into the column -- a key outside the old scope -- refreshes the copy and forgets the scope; a filter that selects
+    nothing comes out as zero groups; a pinned column keeps copy and scope until rfx_invalidate."""
+    ops.rfx_cache_clear()
+    n = 60_007
+    host = host_table(n, keys=100)
+    tab = H.table(host)
+    kvec = H.list_items(H.list_items(tab)[1])[0]
+    kview = np.frombuffer((C.c_char * (n * 8)).from_address(H.payload(kvec)), dtype=np.int64)
+
+    def ask(q):
+        d = H.select_dict(q, tab)
+        r = ops.rfx_select(d)
+        assert r and not H.is_error(r), H.error_text(r)
+        out = H.table_to_numpy(r)
+        ops.rfx_host_drop(r)
+        ops.rfx_host_drop(d)
+        return out
+
+    q = {"s": ("sum", "v"), "c": ("count", "a"), "by": "k"}
+    qf = {"s": ("sum", "v"), "mx": ("max", "a"), "where": ("<", "a", 300_000), "by": "k"}
+    for _ in range(3):  # the second and third ask find the scope remembered
+        check(ask(q), rfo.select({"from": host, **q}))
+        check(ask(qf), rfo.select({"from": host, **qf}))
+    none = ask({"s": ("sum", "v"), "where": ("<", "a", -5), "by": "k"})
+    assert len(none["k"]) == 0 and len(none["s"]) == 0
+    kview[12_345] = 5_000  # far outside [0, 100): the old scope would drop (or misplace) this row
+    host["k"] = kview.copy()
+    check(ask(q), rfo.select({"from": host, **q}))
+    check(ask(qf), rfo.select({"from": host, **qf}))
+    kview[77] = -40  # ... and below it
+    host["k"] = kview.copy()
+    check(ask(q), rfo.select({"from": host, **q}))
+    # pinned: trusted (copy and scope) until invalidated
+    p = ops.rfx_pin(tab)
+    check(ask(q), rfo.select({"from": host, **q}))
+    kview[5] = 9_000
+    stale = ask(q)
+    assert 9_000 not in stale["k"]  # (documented contract of rfx_pin)
+    iv = ops.rfx_invalidate(tab)
+    host["k"] = kview.copy()
+    check(ask(q), rfo.select({"from": host, **q}))
+    for o in (p, iv, tab):
+        ops.rfx_host_drop(o)
+
+
 def test_cache_pin_trusts_until_invalidated(ops):
     """rfx_pin: no per-use validation (the host promises rfx_invalidate before it writes); rfx_invalidate drops the copy."""
     ops.rfx_cache_clear()
