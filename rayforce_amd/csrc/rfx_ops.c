@@ -1408,6 +1408,52 @@ static int sel_by_shape(obj_p tab, obj_p by, obj_p *kcs, int64_t *knames, int64_
     return SEL_GO;
 }
 
+/* A nested boolean tree over aggregates: the reference's own plan (filter_collect, then fold / group -- core/filter.c:51-165), on the device:
+ * where -> ids, then every device column the aggregates read (plain arguments, single-operation operands, expression-tree leaves) and the
+ * key column are gathered at the ids and the descriptors repointed; *nrows becomes the number of selected rows.  The gathered columns
+ * join the query's scratch list (tmp) and are freed with it. */
+static int sel_gather_selected(obj_p tab, obj_p where, const wplan_t *wp, sel_maps_t *M, const void **dk, void **tmp, int *ntmp, int64_t *nrows, obj_p *res,
+                               const char **why) {
+    int64_t *d_ids = NULL, nsel = 0;
+    const int rc = where_ids(tab, where, wp, 0, *nrows, &d_ids, &nsel);
+    if (rc == -1) { *why = "where: shape"; return SEL_OUT; }
+    if (rc) { *res = fail_hip("where"); return SEL_DONE; }
+    int ok = 1;
+    const void *seen_src[RFX_MAX_AGGS * (2 + 2 * RFX_MAX_XNODES) + 1];
+    void *seen_dst[RFX_MAX_AGGS * (2 + 2 * RFX_MAX_XNODES) + 1];
+    int nseen = 0;
+    const void **slots[RFX_MAX_AGGS * (2 + 2 * RFX_MAX_XNODES) + 1];
+    int nslots = 0;
+    for (int a = 0; a < M->nagg; a++) {
+        slots[nslots++] = &M->aggs[a].d_col;
+        slots[nslots++] = &M->aggs[a].d_xrhs_col;
+        for (int j = 0; j < M->aggs[a].nxnodes; j++) {
+            if (M->xnodes[a][j].l.kind == RFX_XK_COL) slots[nslots++] = &M->xnodes[a][j].l.d_col;
+            if (M->xnodes[a][j].r.kind == RFX_XK_COL) slots[nslots++] = &M->xnodes[a][j].r.d_col;
+        }
+    }
+    if (dk) slots[nslots++] = dk;
+    for (int si = 0; si < nslots && ok; si++) {
+        const void **slot = slots[si];
+        if (!*slot) continue;
+        int j = 0;
+        for (; j < nseen; j++)
+            if (seen_src[j] == *slot) break;
+        if (j == nseen) { /* a column several descriptors read is gathered once */
+            void *g = NULL;
+            ok = rfx_hip_malloc(g_ctx, &g, (size_t)(nsel ? nsel : 1) * 8) == RFX_OK && (nsel == 0 || rfx_hip_gather(g_ctx, *slot, d_ids, nsel, g) == RFX_OK);
+            if (g) tmp[(*ntmp)++] = g;
+            seen_src[nseen] = *slot;
+            seen_dst[nseen++] = g;
+        }
+        if (ok) *slot = seen_dst[j];
+    }
+    if (d_ids) rfx_hip_free(g_ctx, d_ids);
+    if (!ok) { *res = fail_hip("gather"); return SEL_DONE; }
+    *nrows = nsel;
+    return SEL_GO;
+}
+
 static obj_p select_impl(obj_p dict) {
     rfx_host_bind();
     g_ntm = 0;
@@ -1440,7 +1486,6 @@ static obj_p select_impl(obj_p dict) {
         int64_t nrows = tcols->len ? RFX_AS_LIST(tcols)[0]->len : 0;
         wplan_t wp;
         int flat = 1;
-        int64_t *d_ids = NULL, nsel = 0;
         g_where_virtual = g_where_data = 0;
         int rc = plan_where(tab, where, &wp);
         if (rc == -2) { res = fail_hip("column upload"); goto done; }
@@ -1468,7 +1513,6 @@ static obj_p select_impl(obj_p dict) {
             if (mrc == SEL_OUT) goto out;
         }
         rfx_agg_t *const aggs = M.aggs;
-        rfx_xnode_t (*const xnodes)[RFX_MAX_XNODES] = M.xnodes;
         const int64_t *const names = M.names;
         const int *const outtype = M.outtype;
         const int nagg = M.nagg;
@@ -1529,47 +1573,10 @@ static obj_p select_impl(obj_p dict) {
             if (sel_projection(tab, where, &wp, flat, parted, nrows, &res, &why) == SEL_OUT) goto out;
             goto done;
         }
-        if (!flat) {
-            /* nested tree + aggregates: the reference's own plan (filter_collect then fold / group) on gathered columns */
-            rc = where_ids(tab, where, &wp, 0, nrows, &d_ids, &nsel);
-            if (rc == -1) { why = "where: shape"; goto out; }
-            if (rc) { res = fail_hip("where"); goto done; }
-            int ok = 1;
-            const void *seen_src[RFX_MAX_AGGS * (2 + 2 * RFX_MAX_XNODES) + 1];
-            void *seen_dst[RFX_MAX_AGGS * (2 + 2 * RFX_MAX_XNODES) + 1];
-            int nseen = 0;
-            /* every device column the aggregates read (plain argument, single-operation operand, expression-tree leaves), then the key */
-            const void **slots[RFX_MAX_AGGS * (2 + 2 * RFX_MAX_XNODES) + 1];
-            int nslots = 0;
-            for (int a = 0; a < nagg; a++) {
-                slots[nslots++] = &aggs[a].d_col;
-                slots[nslots++] = &aggs[a].d_xrhs_col;
-                for (int j = 0; j < aggs[a].nxnodes; j++) {
-                    if (xnodes[a][j].l.kind == RFX_XK_COL) slots[nslots++] = &xnodes[a][j].l.d_col;
-                    if (xnodes[a][j].r.kind == RFX_XK_COL) slots[nslots++] = &xnodes[a][j].r.d_col;
-                }
-            }
-            if (by) slots[nslots++] = &dk;
-            for (int si = 0; si < nslots && ok; si++) {
-                const void **slot = slots[si];
-                if (!*slot) continue;
-                int j = 0;
-                for (; j < nseen; j++)
-                    if (seen_src[j] == *slot) break;
-                if (j == nseen) {
-                    void *g = NULL;
-                    ok = rfx_hip_malloc(g_ctx, &g, (size_t)(nsel ? nsel : 1) * 8) == RFX_OK &&
-                         (nsel == 0 || rfx_hip_gather(g_ctx, *slot, d_ids, nsel, g) == RFX_OK);
-                    if (g) tmp[ntmp++] = g;
-                    seen_src[nseen] = *slot;
-                    seen_dst[nseen++] = g;
-                }
-                if (ok) *slot = seen_dst[j];
-            }
-            if (d_ids) rfx_hip_free(g_ctx, d_ids);
-            d_ids = NULL;
-            if (!ok) { res = fail_hip("gather"); goto done; }
-            nrows = nsel;
+        if (!flat) { /* a where: tree the fused descriptors cannot express: ids through masks, then everything on gathered columns */
+            const int grc = sel_gather_selected(tab, where, &wp, &M, by ? &dk : NULL, tmp, &ntmp, &nrows, &res, &why);
+            if (grc == SEL_OUT) goto out;
+            if (grc == SEL_DONE) goto done;
         }
         /* Large inputs: the key scope(s) from a SAMPLE first (rfx_hip_scope_sample_i64) when the range is LDS-sized -- index_scope_i64's
          * full pass is a quarter to a third of such a query -- with the kernels reporting any selected key outside it; a report (or a
