@@ -348,8 +348,10 @@ static int sd_scan(uintptr_t lo, uintptr_t hi) {
 }
 static void sd_probe(void) {
     g_sd_state = 0;
-    const char *e = getenv("RFX_SOFT_DIRTY");
-    if (e && atoi(e) == 0) return;
+    const char *e = getenv("RFX_SOFT_DIRTY"); /* OPT-IN (RFX_SOFT_DIRTY=1): clear_refs write-protects every page of the HOST process -- 0.7-1.4 s with
+                                               * 24 GB resident, then a minor fault on the host's next write to each page, and other users of soft-dirty
+                                               * bits in the same process (CRIU-style checkpointing) lose theirs.  tools/unpinned.py measures both sides. */
+    if (!e || atoi(e) == 0) return;
     const long pg = sysconf(_SC_PAGESIZE);
     if (pg < 4096) return;
     g_sd_page = (uintptr_t)pg;
@@ -385,20 +387,25 @@ static int sd_usable(const void *host, size_t bytes) {
     uintptr_t lo, hi;
     return g_sd_state == 1 && bytes >= SD_MIN_BYTES && sd_interior(host, bytes, &lo, &hi);
 }
-/* clean-mark the process' pages, once per operator call; every tracked entry is looked at first (the clear wipes its evidence) */
+/* clean-mark the process' pages, once per operator call.  The clear wipes every OTHER tracked entry's evidence too, and a scan taken before
+ * it cannot vouch for them: a host thread writing between that scan and the clear would leave a stale copy that looks clean for ever.  So
+ * the order is clear FIRST, then every tracked entry meets its CHECKSUM again (52 ms per 8 GB; clears are rare -- only calls that start
+ * tracking a column make one): a write before the clear changes the checksum (the entry loses its tracking and is refreshed at its next
+ * use), a write after it sets the page's bit again.  Soft-dirty validation still assumes what the checksum assumes -- host writes go
+ * through the CPU's page tables (device DMA into registered host memory marks nothing) -- which is why it is OPT-IN. */
 static int sd_call_clear(void) {
     if (g_sd_clear_epoch == g_epoch) return 0;
-    for (int i = 0; i < g_nres; i++) {
-        if (!g_res[i].tracked) continue;
-        uintptr_t lo, hi;
-        if (!sd_interior(g_res[i].host, g_res[i].bytes, &lo, &hi) || sd_scan(lo, hi) != 0) g_res[i].tracked = 0;
-    }
     if (sd_clear() != 0) { /* the kernel took the feature away (permissions?): back to checksums for good */
         g_sd_state = 0;
         for (int i = 0; i < g_nres; i++) g_res[i].tracked = 0;
         return -1;
     }
     g_sd_clear_epoch = g_epoch;
+    for (int i = 0; i < g_nres; i++) {
+        if (!g_res[i].tracked) continue;
+        if (payload_sum(g_res[i].host, g_res[i].bytes) != g_res[i].sum) g_res[i].tracked = 0, g_res[i].stable = 0;
+        else g_res[i].edge_sum = sd_edge_sum(g_res[i].host, g_res[i].bytes);
+    }
     return 0;
 }
 static int sd_entry_clean(const resident_t *r) {
@@ -437,8 +444,10 @@ static int g_noptmp;
 static pthread_mutex_t g_op_lock = PTHREAD_MUTEX_INITIALIZER;
 static __thread int t_op_depth;
 static void op_begin(void) {
-    if (t_op_depth++ == 0) pthread_mutex_lock(&g_op_lock);
-    g_epoch++;
+    if (t_op_depth++ == 0) {
+        pthread_mutex_lock(&g_op_lock);
+        g_epoch++; /* (a nested operator keeps the outer one's epoch: the outer call's columns stay protected from eviction) */
+    }
     g_stat[ST_OPS]++;
 }
 static void op_scratch_release(void) {
@@ -861,7 +870,7 @@ static int plan_cmp(obj_p tab, obj_p e, rfx_pred_t *p) {
             p->rhs_i = at;
             return 0;
         }
-        if (lc && IS_I32_FAMILY(lc->type)) {
+        if (lc && IS_I32_FAMILY(lc->type) && !(g_npx && proxy_of(lc))) { /* (a parted table's 4-byte columns are the host's: proxies upload 8-byte partitions only) */
             /* a 4-byte integer column (I32 / DATE / TIME) in a comparison: its widened device copy against an atom or a column of the
              * types the reference's i32 arms take (core/cmp.c:148-166: the same 4-byte type; for I32 also I64 / F64, promoted as
              * i32_to_i64 / i32_to_f64 do -- which is what the widened column compares as) */
@@ -1235,8 +1244,12 @@ typedef struct {
 } sel_maps_t;
 /* result cells of an aggregate over a widened 4-byte column, back in the column's own width: the i64 null and the i64 identities of an
  * all-null group (core/aggr.c:1246) become the 4-byte ones */
-static void sel_narrow_i32(obj_p col, const int64_t *cells, int64_t n) {
+static void sel_narrow_i32(obj_p col, const int64_t *cells, int64_t n, int kind) {
     int32_t *o = (int32_t *)RFX_AS_RAW(col);
+    if (kind == RFX_AGG_SUM) { /* FOLD_ADDI32's result IS the low half of the 64-bit sum, whatever that sum is (no null / identity to translate) */
+        for (int64_t i = 0; i < n; i++) o[i] = (int32_t)(uint32_t)(uint64_t)cells[i];
+        return;
+    }
     for (int64_t i = 0; i < n; i++) o[i] = cells[i] == RFX_NULL_I64 ? INT32_MIN : (cells[i] == INT64_MAX ? INT32_MAX : (int32_t)cells[i]);
 }
 static int sel_mappings(obj_p tab, obj_p dkeys, obj_p dvals, int grouped, sel_maps_t *M, const char **why) {
@@ -1274,7 +1287,7 @@ static int sel_mappings(obj_p tab, obj_p dkeys, obj_p dvals, int grouped, sel_ma
         obj_p c = table_col(tab, a->i64);
         /* a 4-byte integer column (I32 / DATE / TIME): min / max / first / count / sum fold its widened device copy and the result cells
          * are narrowed back (sel_narrow_i32); avg and the sum of dates are the host's */
-        const int narrow = c && IS_I32_FAMILY(c->type) && !(grouped && c->type == RFX_TYPE_I32) && /* (any grouped aggregate over an I32 column is a `type` error in the reference: its to say) */
+        const int narrow = c && IS_I32_FAMILY(c->type) && !(g_npx && proxy_of(c)) && !(grouped && c->type == RFX_TYPE_I32) && /* (any grouped aggregate over an I32 column is a `type` error in the reference: its to say) */
                            ((f == F_MIN || f == F_MAX || f == F_FIRST || f == F_COUNT) ||
                             /* sums of I32 / TIME columns wrap in 32 bits there (FOLD_ADDI32 / ADDI32, core/math.c:1864-1871, core/aggr.c:1095-1100):
                              * the low 32 bits of the 64-bit sum of the widened column are that sum */
@@ -1464,7 +1477,7 @@ static obj_p select_impl(obj_p dict) {
     /* take: is applied to the finished result table (ray_take(res, take), core/query.c:294-303,596-599): by the host's own ray_take */
     obj_p take = dict_get(dict, "take");
     if (take && !(H.bound == 1 && H.f[F_TAKE])) return delegate_select(dict, "take: without the host's ray_take");
-    obj_p host_tab = H.eval(from);
+    obj_p host_tab = HOST_CALL(H.eval(from)); /* (the host may fan this out to pool workers that call rfx_* built-ins: not under our lock; no device state is held yet) */
     if (!host_tab || host_tab->type == RFX_TYPE_ERR) return host_tab;
     obj_p tab = host_tab; /* the table the plan reads: host_tab itself, or the view of a parted table */
     int parted = 0;
@@ -1829,7 +1842,7 @@ static obj_p select_impl(obj_p dict) {
                         if (IS_I32_FAMILY(outtype[a])) {
                             int64_t *c8 = (int64_t *)malloc((size_t)(groups ? groups : 1) * 8);
                             ok = c8 && fetch(c8, ptrs[a], (size_t)groups * 8) == RFX_OK;
-                            if (ok) sel_narrow_i32(ocols[a], c8, groups);
+                            if (ok) sel_narrow_i32(ocols[a], c8, groups, aggs[a].kind);
                             free(c8);
                         } else ok = fetch(RFX_AS_RAW(ocols[a]), ptrs[a], (size_t)groups * 8) == RFX_OK;
                     }
@@ -1871,7 +1884,7 @@ static obj_p select_impl(obj_p dict) {
             RFX_AS_I64(rk)[a] = names[a];
             if (IS_I32_FAMILY(outtype[a])) {
                 RFX_AS_LIST(rv)[a] = H.vector((int8_t)outtype[a], 1);
-                sel_narrow_i32(RFX_AS_LIST(rv)[a], &vals[a].i, 1);
+                sel_narrow_i32(RFX_AS_LIST(rv)[a], &vals[a].i, 1, aggs[a].kind);
             } else {
                 RFX_AS_LIST(rv)[a] = one_row(&vals[a]);
                 if (outtype[a] == RFX_TYPE_TIMESTAMP && vals[a].type != RFX_F64) RFX_AS_LIST(rv)[a]->type = RFX_TYPE_TIMESTAMP; /* min / max / first of a TIMESTAMP column */
@@ -1898,9 +1911,9 @@ done:
     tm_mark();
     tm_print();
     if (take && g_last_gpu && res && res->type == RFX_TYPE_TABLE) { /* (a delegated query had its take: applied by ray_select) */
-        obj_p tv = H.eval(take);
+        obj_p tv = HOST_CALL(H.eval(take));
         if (tv && tv->type != RFX_TYPE_ERR) {
-            obj_p cut = ((rfx_binary_f)H.f[F_TAKE])(res, tv);
+            obj_p cut = HOST_CALL(((rfx_binary_f)H.f[F_TAKE])(res, tv));
             H.drop(res);
             res = cut;
         } else {
@@ -1944,7 +1957,7 @@ static obj_p update_impl(obj_p dict) {
         /* `from: 't` parses as (quote t): the in-place form on a global -- evaluated by the host only */
         if (from->type == RFX_TYPE_LIST) return delegate_update(dict, "from: is an expression (in-place update of a global)");
     }
-    obj_p tab = H.eval(from);
+    obj_p tab = HOST_CALL(H.eval(from)); /* (not under our lock: the host may fan the evaluation out) */
     if (!tab || tab->type == RFX_TYPE_ERR) return tab;
     if (tab->type != RFX_TYPE_TABLE) {
         H.drop(tab);

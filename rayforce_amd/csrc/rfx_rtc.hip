@@ -89,7 +89,7 @@ static bool rtc_ready() {
     const char *env = getenv("RFX_RTC_CACHE");
     R.cache_dir.clear();
     if (!env || (strcmp(env, "0") != 0 && env[0])) {
-        std::string cand[2];
+        std::string cand[3];
         int nc = 0;
         if (env) cand[nc++] = env;
         else {
@@ -99,12 +99,20 @@ static bool rtc_ready() {
                 const size_t cut = so.find_last_of('/');
                 cand[nc++] = (cut == std::string::npos ? std::string(".") : so.substr(0, cut)) + "/rtc_cache";
             }
+            // a per-user directory: $XDG_CACHE_HOME/rfx_rtc, ~/.cache/rfx_rtc, and only then /tmp (a name anybody can guess: see the check below)
+            const char *xdg = getenv("XDG_CACHE_HOME"), *home = getenv("HOME");
+            if (xdg && xdg[0] == '/') cand[nc++] = std::string(xdg) + "/rfx_rtc";
+            else if (home && home[0] == '/') cand[nc++] = std::string(home) + "/.cache/rfx_rtc";
             char tmp[64];
             snprintf(tmp, sizeof(tmp), "/tmp/rfx_rtc_cache_%u", (unsigned)getuid());
             cand[nc++] = tmp;
         }
         for (int i = 0; i < nc && R.cache_dir.empty(); i++) {
-            (void)mkdir(cand[i].c_str(), 0755);
+            (void)mkdir(cand[i].c_str(), 0700);
+            // code objects found here are LOADED AND RUN: the directory must be a real directory of ours that nobody else can write into
+            // (another local user could pre-create a guessable /tmp name and plant <hash>.co files); anything else: no disk cache
+            struct stat st;
+            if (lstat(cand[i].c_str(), &st) != 0 || !S_ISDIR(st.st_mode) || st.st_uid != geteuid() || (st.st_mode & (S_IWGRP | S_IWOTH))) continue;
             if (access(cand[i].c_str(), W_OK | X_OK) == 0) R.cache_dir = cand[i];
         }
         if (!R.cache_dir.empty()) {
