@@ -75,7 +75,15 @@ enum {
  * `more` = 1: this comparison and the NEXT one stand in the same parenthesis, combined with the OPPOSITE of the call's
  * `logic` -- a two-level tree `(and (or A B) C)` is {A more, B, C} with logic RFX_AND, `(or A (and B C))` is {A, B more, C}
  * with RFX_OR -- evaluated in the same single pass (core/logic.c's and / or over the comparisons' B8 vectors, never materialised).
- * 0 everywhere = the flat list.  The last comparison's `more` must be 0. */
+ * 0 everywhere = the flat list.  The last comparison's `more` must be 0.
+ * ARBITRARY trees (logic_map nests and / or freely, core/logic.c:89-260) -- round 4: every comparison carries
+ * `more = RFX_PRED_TREE | depth | close << 4`: the comparisons are the tree's leaves in order, `depth` = how many parentheses the
+ * leaf sits in (level 0 combines with the call's `logic`, each deeper level with the OPPOSITE of the level above; the same operator
+ * nested in itself is flattened by the caller), `close` = how many parentheses end after it.  `(and A (or B (and C D)) E)` is
+ * {A: 0/0, B: 1/0, C: 2/0, D: 2/2, E: 0/0} with logic RFX_AND.  Depth <= 3 (four levels), at least three comparisons, still one fused
+ * pass with nothing materialised; all comparisons of a call use this form or none does (RFX_EINVAL). */
+#define RFX_PRED_TREE 256
+#define RFX_PRED_LEAF(depth, close) (RFX_PRED_TREE | (depth) | ((close) << 4))
 typedef struct rfx_pred {
     const void *d_col;
     const void *d_rhs_col;
@@ -480,6 +488,26 @@ int rfx_dist_filter_aggr_host(rfx_ctx_t *ctx, const rfx_pred_t *preds, int npred
 int rfx_dist_allreduce_i64(rfx_ctx_t *ctx, int64_t *d_buf, int64_t n, int op);
 int rfx_dist_allgather(rfx_ctx_t *ctx, const void *d_in, size_t bytes, void *d_out);
 int64_t rfx_dist_calls(rfx_ctx_t *ctx); /* collectives issued so far */
+
+/* ---- ONE process driving several devices / several shards per device (rfx_exec.c: the operator layer's planner) ----
+ * rfx_dist_init_all: one communicator per context, created by THIS process (ncclCommInitAll) -- the contexts sit on distinct devices;
+ * such communicators are process-local (rfx_dist_is_local): what the host can fold itself never goes through RCCL.  The *_all calls
+ * issue one fused exchange over the contexts from the calling thread (ncclGroupStart .. End). */
+int rfx_dist_init_all(rfx_ctx_t *const *ctxs, int n);
+int rfx_dist_is_local(rfx_ctx_t *ctx);
+int rfx_dist_has_comm(rfx_ctx_t *ctx); /* 1: the context carries a communicator (of either kind) */
+int rfx_dist_group_tables_allreduce_all(rfx_ctx_t *const *ctxs, int n, const rfx_agg_t *aggs, const rfx_group_tables_t *const *tables);
+int rfx_dist_allreduce_i64_all(rfx_ctx_t *const *ctxs, int n, int64_t *const *d_bufs, int64_t cells, int op);
+int rfx_dist_allgather_all(rfx_ctx_t *const *ctxs, int n, const void *const *d_ins, size_t bytes, void *const *d_outs);
+/* `bytes` of HOST memory from every rank in rank order (scopes, scalar partials, flags); identity without a communicator.  (syncs) */
+int rfx_dist_allgather_host(rfx_ctx_t *ctx, const void *in, size_t bytes, void *out);
+/* shards that share a device merge by a kernel: into[slot] (op)= from[slot] for every array of two dense table sets over one scope
+ * (first MIN, sums / counts SUM, min / max on the ordered image) -- AGGR_COLLECT's element-wise merge, core/aggr.c:163-181 */
+int rfx_hip_group_tables_merge(rfx_ctx_t *ctx, const rfx_agg_t *aggs, const rfx_group_tables_t *into, const rfx_group_tables_t *from);
+int rfx_hip_add_i64(rfx_ctx_t *ctx, int64_t *d_into, const int64_t *d_from, int64_t n); /* FIRST values: one shard contributed each */
+int rfx_hip_d2d(rfx_ctx_t *ctx, void *d_dst, const void *d_src, size_t bytes);           /* asynchronous; the source may sit on a peer device */
+int rfx_hip_ctx_bind_thread(rfx_ctx_t *ctx); /* hipSetDevice(ctx's device) for the calling thread */
+int rfx_hip_ctx_device(rfx_ctx_t *ctx);
 
 /* ---- `update ... where / by` (ray_update, core/update.c:936-1106): the writes, on a device copy of the column ----
  * rfx_hip_update_set:   d_col[d_ids[i]] = d_vals ? d_vals[d_ids[i]] : atom_bits   for i < m  (d_ids == NULL: rows 0 .. m-1).  d_vals is the

@@ -59,6 +59,17 @@ extern "C" {
 int rfx_host_bind(void);
 /* GPU ordinal used by the operator layer (default 0 or $RFX_DEVICE).  Call before the first operator. */
 int rfx_ops_set_device(int device);
+/* SHARDS: the operator layer plans through rfx_exec.h over one context per shard.  Before the first operator: the devices to use
+ * (ndevices = 0: $RFX_DEVICES = "0,1,2" | "all", else the one device above) and how many shards in all (0: $RFX_SHARDS, else one per
+ * device; more shards than devices share devices round robin).  With more than one shard every column is split row-range over the
+ * shards when it is uploaded (rfx_pin / first touch), rfx_select answers from all of them -- each shard's pass on its own host thread,
+ * the partial states merged by a device kernel (same device) and ONE fused RCCL exchange (across devices) before rank / emit, as
+ * ray_select merges its pool workers' partials (core/query.c:607-654, core/aggr.c:163-181,375, core/pool.c:369-424) -- and the
+ * operators that need a column whole on one device return an error object. */
+int rfx_ops_set_shards(const int *devices, int ndevices, int nshards);
+int rfx_ops_shards(void);
+struct rfx_exec;
+struct rfx_exec *rfx_ops_exec(void); /* the operator layer's planner (NULL before the first operator): counters, transport */
 const char *rfx_ops_last_error(void);
 
 /* ---- the operator surface ---------------------------------------------------------------------------------------- */
@@ -125,6 +136,11 @@ int rfx_last_select_on_gpu(void);
 
 /* ---- standalone host (rfx_host.c): just enough object model to build queries without the reference ---------------- */
 rfx_obj_p rfx_host_vector(int8_t type, int64_t len);
+/* A DEVICE column handle for standalone hosts that keep their columns in HBM already: a vector header whose payload is the cells' device
+ * address instead of the cells.  nptrs = 1: one allocation (shards on the same device take their row ranges of it); nptrs = shards: one
+ * address per shard (rows rfx_exec_split(len, shards, s)).  Types: I64 / F64 / SYMBOL / TIMESTAMP / B8.  The memory is borrowed: the
+ * operators never upload, cache, validate or free it; rfx_host_drop frees the header only. */
+rfx_obj_p rfx_host_device_vector(int8_t type, int64_t len, const void *const *d_ptrs, int nptrs);
 rfx_obj_p rfx_host_i64(int64_t v);
 rfx_obj_p rfx_host_f64(double v);
 rfx_obj_p rfx_host_symbol(const char *name);             /* symbol atom */

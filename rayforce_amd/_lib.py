@@ -99,6 +99,48 @@ class HashTables(C.Structure):
 
 assert C.sizeof(Pred) == 40 and C.sizeof(Agg) == 56 and C.sizeof(XNode) == 56 and C.sizeof(Partial) == 64 and C.sizeof(Value) == 16
 
+# ---- include/rfx_exec.h: the planner's structures ----
+RFX_MAX_SHARDS = 16
+RFX_EXEC_MAX_AGGS = 32
+RFX_PRED_TREE = 256
+RFX_Q_NO_SAMPLED_SCOPE, RFX_Q_REFUSE_NULL_KEY, RFX_Q_WANT_FIRST, RFX_Q_NO_SMALL, RFX_Q_PROBE_FIRST = 1, 2, 4, 8, 16
+RFX_PATH_DENSE, RFX_PATH_DENSE_SMALL, RFX_PATH_HASH, RFX_PATH_ROWHASH = 1, 2, 3, 4
+RFX_XSTAT_SCOPE_SAMPLED, RFX_XSTAT_SCOPE_RETRIED, RFX_XSTAT_SCOPE_REMEMBERED, RFX_XSTAT_HASH_GROWN, RFX_XSTAT_MERGES_KERNEL, RFX_XSTAT_MERGES_RCCL, \
+    RFX_XSTAT_MERGES_TRANSPORT, RFX_XSTAT_QUERIES = range(8)
+
+
+class QCol(C.Structure):
+    _fields_ = [("d", C.c_void_p * RFX_MAX_SHARDS)]
+
+
+class Query(C.Structure):
+    _fields_ = [("preds", C.POINTER(Pred)), ("npred", C.c_int32), ("logic", C.c_int32), ("d_mask", C.c_void_p), ("aggs", C.POINTER(Agg)),
+                ("nagg", C.c_int32), ("nkeys", C.c_int32), ("d_keys", C.POINTER(C.c_void_p)), ("kxbar", C.POINTER(C.c_int64)), ("nrows", C.c_int64),
+                ("cols", C.POINTER(QCol)), ("ncols", C.c_int32), ("flags", C.c_int32), ("key_scope", C.POINTER(C.c_int64)), ("row0", C.c_int64)]
+
+
+class Ids(C.Structure):
+    _fields_ = [("nshards", C.c_int32), ("total", C.c_int64), ("count", C.c_int64 * RFX_MAX_SHARDS), ("d_ids", C.c_void_p * RFX_MAX_SHARDS)]
+
+
+class Groups(C.Structure):
+    _fields_ = [("groups", C.c_int64), ("path", C.c_int32), ("nkeys", C.c_int32), ("nagg", C.c_int32), ("d_keys", C.c_void_p),
+                ("d_keycols", C.c_void_p * RFX_MAX_KEYS), ("d_first", C.c_void_p), ("d_results", C.c_void_p * RFX_EXEC_MAX_AGGS),
+                ("result_type", C.c_int32 * RFX_EXEC_MAX_AGGS), ("d_probe", C.c_void_p), ("capacity", C.c_int64), ("d_block", C.c_void_p),
+                ("h_block", C.c_void_p), ("block_bytes", C.c_size_t), ("own", C.c_void_p * (RFX_EXEC_MAX_AGGS + RFX_MAX_KEYS + 6)), ("nown", C.c_int32)]
+
+
+TR_WORLD_RANK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int))
+TR_ALLGATHER_HOST = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+TR_ALLREDUCE = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int)
+TR_ALLGATHER_DEV = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+
+
+class Transport(C.Structure):
+    _fields_ = [("user", C.c_void_p), ("world_rank", TR_WORLD_RANK), ("allgather_host", TR_ALLGATHER_HOST), ("allreduce", TR_ALLREDUCE),
+                ("allgather_dev", TR_ALLGATHER_DEV)]
+
+
 _P = C.POINTER
 _ctx = C.c_void_p
 
@@ -194,7 +236,43 @@ PROTOTYPES = {
     "rfx_hip_group_dense_accumulate_keys": (C.c_int, [_ctx, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_int, _P(Pred),
                                                       C.c_int, C.c_int, _P(Agg), C.c_int64, C.c_int64, _P(GroupTables)]),
     "rfx_hip_composite_decode": (C.c_int, [_ctx, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_void_p]),
+    # one process, several devices / shards (include/rfx_hip.h, round 4)
+    "rfx_dist_init_all": (C.c_int, [_P(_ctx), C.c_int]),
+    "rfx_dist_is_local": (C.c_int, [_ctx]),
+    "rfx_dist_has_comm": (C.c_int, [_ctx]),
+    "rfx_dist_group_tables_allreduce_all": (C.c_int, [_P(_ctx), C.c_int, _P(Agg), _P(_P(GroupTables))]),
+    "rfx_dist_allreduce_i64_all": (C.c_int, [_P(_ctx), C.c_int, _P(C.c_void_p), C.c_int64, C.c_int]),
+    "rfx_dist_allgather_all": (C.c_int, [_P(_ctx), C.c_int, _P(C.c_void_p), C.c_size_t, _P(C.c_void_p)]),
+    "rfx_dist_allgather_host": (C.c_int, [_ctx, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "rfx_hip_group_tables_merge": (C.c_int, [_ctx, _P(Agg), _P(GroupTables), _P(GroupTables)]),
+    "rfx_hip_add_i64": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_int64]),
+    "rfx_hip_d2d": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "rfx_hip_ctx_bind_thread": (C.c_int, [_ctx]),
+    "rfx_hip_ctx_device": (C.c_int, [_ctx]),
 }
+
+# include/rfx_exec.h: the planner
+_exec = C.c_void_p
+EXEC_PROTOTYPES = {
+    "rfx_exec_create": (C.c_int, [_P(_ctx), C.c_int, _P(_exec)]),
+    "rfx_exec_destroy": (C.c_int, [_exec]),
+    "rfx_exec_shards": (C.c_int, [_exec]),
+    "rfx_exec_ctx": (_ctx, [_exec, C.c_int]),
+    "rfx_exec_split": (None, [C.c_int64, C.c_int, C.c_int, _P(C.c_int64), _P(C.c_int64)]),
+    "rfx_exec_comm_init_all": (C.c_int, [_exec]),
+    "rfx_exec_set_transport": (C.c_int, [_exec, _P(Transport)]),
+    "rfx_exec_filter_aggr": (C.c_int, [_exec, _P(Query), _P(Value), _P(C.c_int64)]),
+    "rfx_exec_where": (C.c_int, [_exec, _P(Query), _P(Ids)]),
+    "rfx_exec_ids_free": (None, [_exec, _P(Ids)]),
+    "rfx_exec_group_by": (C.c_int, [_exec, _P(Query), _P(Groups)]),
+    "rfx_exec_groups_fetch": (C.c_int, [_exec, _P(Groups), C.c_void_p, C.c_void_p, C.c_size_t]),
+    "rfx_exec_groups_free": (None, [_exec, _P(Groups)]),
+    "rfx_exec_join_index": (C.c_int, [_exec, _P(C.c_void_p), _P(C.c_void_p), C.c_int, C.c_int64, C.c_int64, C.c_void_p, _P(C.c_int)]),
+    "rfx_exec_stat": (C.c_int64, [_exec, C.c_int]),
+    "rfx_exec_forget_scopes": (None, [_exec]),
+    "rfx_exec_last_error": (C.c_char_p, [_exec]),
+}
+PROTOTYPES.update(EXEC_PROTOTYPES)
 
 _LIB = None
 

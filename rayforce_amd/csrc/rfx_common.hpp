@@ -135,6 +135,9 @@ struct PlanPred {
     int rhs_cvt;  // same for a vector rhs
     u64 rhs_bits; // atom, already promoted to the comparison domain on the host
     int more;     // 1: same parenthesis as the next predicate (rfx_pred_t::more); the parenthesis combines with the opposite of Plan::logic
+    int tree;     // 0: flat list / two-level form (`more`).  Else RFX_PRED_TREE | depth | close << 4: a leaf of an arbitrarily nested and / or
+                  // tree (rfx_pred_t::more, RFX_PRED_TREE form) -- level 0 combines with Plan::logic, every deeper level with the opposite
+                  // of the level above; `close` parentheses end after this leaf
 };
 #define RFX_XCOL 64 /* PlanAgg::col >= RFX_XCOL: the aggregate folds expression Plan::xs[col - RFX_XCOL] */
 struct PlanAgg {

@@ -90,7 +90,8 @@ extern "C" int rfx_hip_ctx_destroy(rfx_ctx_t *c) {
 }
 
 extern "C" int64_t rfx_hip_ctx_stat(rfx_ctx_t *c, int which) {
-    if (!c || which < 0 || which > 5) return -1;
+    if (!c || which < 0 || which > 6) return -1;
+    if (which == 6) return (int64_t)(uintptr_t)c->ext_p[4]; // RFX_STAT_WHERE_ONCE: k_where_once launches (rfx_where_once.hip)
     return which == RFX_STAT_MASK_PASSES ? c->ext_i[0] : c->ext_i[3 + which];
 }
 
@@ -507,8 +508,17 @@ int rfx_plan_build(Plan *P, const rfx_pred_t *preds, int npred, int logic, const
         q->col = plan_col(P, p->d_col);
         RFX_REQUIRE(q->col >= 0, RFX_ELIMIT, "too many distinct columns");
         q->op = p->op;
-        RFX_REQUIRE((p->more == 0 || p->more == 1) && !(p->more && i == npred - 1), RFX_EINVAL, "predicate `more` must be 0 / 1, and 0 on the last one");
-        q->more = p->more;
+        if (p->more & RFX_PRED_TREE) { // a leaf of a nested tree: depth (0..3) and the parentheses that close after it
+            const int d = p->more & 15, k = (p->more >> 4) & 15;
+            RFX_REQUIRE((p->more & ~(RFX_PRED_TREE | 255)) == 0 && d <= 3 && k <= d, RFX_EINVAL, "predicate tree: depth 0..3, close <= depth");
+            RFX_REQUIRE(npred >= 3, RFX_EINVAL, "predicate tree: a tree deeper than two levels has at least three comparisons");
+            q->more = 0;
+            q->tree = RFX_PRED_TREE | d | (k << 4);
+        } else {
+            RFX_REQUIRE((p->more == 0 || p->more == 1) && !(p->more && i == npred - 1), RFX_EINVAL, "predicate `more` must be 0 / 1, and 0 on the last one");
+            q->more = p->more;
+            q->tree = 0;
+        }
         q->dom_f64 = (p->col_type == RFX_F64 || p->rhs_type == RFX_F64);
         q->lhs_cvt = q->dom_f64 && p->col_type == RFX_I64;
         if (p->d_rhs_col) {
@@ -523,6 +533,18 @@ int rfx_plan_build(Plan *P, const rfx_pred_t *preds, int npred, int logic, const
             else if (p->rhs_type == RFX_F64) q->rhs_bits = host_f64_bits(p->rhs_f);
             else q->rhs_bits = (p->rhs_i == RFX_NULL_I64_D) ? RFX_NAN_BITS : host_f64_bits((double)p->rhs_i); // i64_to_f64, core/ops.h:250
         }
+    }
+    { // either every comparison is a tree leaf or none is; the parentheses must nest (a leaf never sits above the level left open before it)
+        int ntree = 0, cur = 0;
+        for (int i = 0; i < npred; i++) {
+            const int t = P->preds[i].tree;
+            if (!t) continue;
+            ntree++;
+            const int d = t & 15, k = (t >> 4) & 15;
+            RFX_REQUIRE(d >= cur, RFX_EINVAL, "predicate tree: a comparison above the level its predecessor left open");
+            cur = d - k;
+        }
+        RFX_REQUIRE(ntree == 0 || (ntree == npred && cur == 0), RFX_EINVAL, "predicate tree: every comparison must carry the tree form, and every parenthesis must close");
     }
     for (int i = 0; i < RFX_MAX_AGGS; i++) P->aggs[i].kind = -1;
     for (int i = 0; i < nagg; i++) {

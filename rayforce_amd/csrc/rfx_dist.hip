@@ -30,6 +30,7 @@ struct RcclApi {
     void *lib;
     ncclResult_t (*GetUniqueId)(ncclUniqueId *);
     ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int);
+    ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *);
     ncclResult_t (*CommDestroy)(ncclComm_t);
     ncclResult_t (*CommCount)(const ncclComm_t, int *);
     ncclResult_t (*CommUserRank)(const ncclComm_t, int *);
@@ -58,6 +59,7 @@ static int rccl_bind(void) {
     }
     RFX_SYM(GetUniqueId, "ncclGetUniqueId");
     RFX_SYM(CommInitRank, "ncclCommInitRank");
+    RFX_SYM(CommInitAll, "ncclCommInitAll");
     RFX_SYM(CommCount, "ncclCommCount");
     RFX_SYM(CommUserRank, "ncclCommUserRank");
     RFX_SYM(CommDestroy, "ncclCommDestroy");
@@ -115,6 +117,7 @@ extern "C" int rfx_dist_finalize(rfx_ctx_t *c) {
     c->comm = NULL;
     c->world = 0;
     c->rank = 0;
+    c->ext_p[3] = NULL;
     return RFX_OK;
 }
 
@@ -201,33 +204,36 @@ struct ArrCall {
     ncclDataType_t dt;
     ncclRedOp_t op;
 };
-static int allreduce_arrays(rfx_ctx *c, ArrCall *a, int n) {
-    // neighbours of one class become one call
+// neighbours of one class become one call; the calls are ENQUEUED only (the caller brackets them with ncclGroupStart / End)
+static int allreduce_arrays_enqueue(rfx_ctx *c, ArrCall *a, int n) {
     int m = 0;
     for (int i = 0; i < n; i++) {
         if (m > 0 && a[m - 1].dt == a[i].dt && a[m - 1].op == a[i].op && (char *)a[m - 1].p + a[m - 1].n * 8 == (char *)a[i].p) a[m - 1].n += a[i].n;
         else a[m++] = a[i];
     }
-    RFX_NCCL_CHECK(g_nccl.GroupStart());
     for (int i = 0; i < m; i++) {
         ncclResult_t r = g_nccl.AllReduce(a[i].p, a[i].p, a[i].n, a[i].dt, a[i].op, (ncclComm_t)c->comm, c->stream);
         if (r != ncclSuccess) {
-            (void)g_nccl.GroupEnd();
             rfx_set_error("rfx_dist: ncclAllReduce -> %s", g_nccl.GetErrorString(r));
             return RFX_EHIP;
         }
     }
-    RFX_NCCL_CHECK(g_nccl.GroupEnd());
     c->dist_calls += m;
+    return RFX_OK;
+}
+static int allreduce_arrays(rfx_ctx *c, ArrCall *a, int n) {
+    RFX_NCCL_CHECK(g_nccl.GroupStart());
+    const int rc = allreduce_arrays_enqueue(c, a, n);
+    if (rc != RFX_OK) {
+        (void)g_nccl.GroupEnd();
+        return rc;
+    }
+    RFX_NCCL_CHECK(g_nccl.GroupEnd());
     return RFX_OK;
 }
 
 // Dense group tables: in-place all-reduce of every array, one fused exchange, asynchronous on the context's stream.
-extern "C" int rfx_dist_group_tables_allreduce(rfx_ctx_t *c, const rfx_agg_t *aggs, const rfx_group_tables_t *t) {
-    RFX_REQUIRE(c && t && (aggs || t->nagg == 0), RFX_EINVAL, "NULL argument");
-    RFX_REQUIRE(t->nagg >= 0 && t->nagg <= RFX_MAX_AGGS && t->range > 0 && t->d_first, RFX_EINVAL, "bad tables");
-    if (!c->comm) return RFX_OK;
-    ArrCall a[1 + 2 * RFX_MAX_AGGS];
+static int tables_arrays(const rfx_agg_t *aggs, const rfx_group_tables_t *t, ArrCall *a) {
     int n = 0;
     a[n].p = t->d_first;
     a[n].n = (size_t)t->range;
@@ -248,7 +254,189 @@ extern "C" int rfx_dist_group_tables_allreduce(rfx_ctx_t *c, const rfx_agg_t *ag
             n++;
         }
     }
-    return allreduce_arrays(c, a, n);
+    return n;
+}
+extern "C" int rfx_dist_group_tables_allreduce(rfx_ctx_t *c, const rfx_agg_t *aggs, const rfx_group_tables_t *t) {
+    RFX_REQUIRE(c && t && (aggs || t->nagg == 0), RFX_EINVAL, "NULL argument");
+    RFX_REQUIRE(t->nagg >= 0 && t->nagg <= RFX_MAX_AGGS && t->range > 0 && t->d_first, RFX_EINVAL, "bad tables");
+    if (!c->comm) return RFX_OK;
+    ArrCall a[1 + 2 * RFX_MAX_AGGS];
+    return allreduce_arrays(c, a, tables_arrays(aggs, t, a));
+}
+
+// ---- ONE process, several devices (the evaluator process that owns all 8 GPUs of a node: rfx_exec.c) ----
+// rfx_dist_init_all: one communicator per context, all created by this process (ncclCommInitAll); the contexts must sit on DISTINCT
+// devices (RCCL refuses two ranks on one device: shards that share a device are merged by a kernel instead, rfx_hip_group_tables_merge).
+// Such communicators are marked process-local: what the host can fold itself (scopes, scalar partials, flags) never goes through RCCL.
+extern "C" int rfx_dist_init_all(rfx_ctx_t *const *ctxs, int n) {
+    RFX_REQUIRE(ctxs && n >= 1 && n <= 64, RFX_EINVAL, "bad argument");
+    int devs[64];
+    for (int i = 0; i < n; i++) {
+        RFX_REQUIRE(ctxs[i] && ctxs[i]->comm == NULL, RFX_ESTATE, "a context is NULL or already has a communicator");
+        devs[i] = ctxs[i]->device;
+        for (int j = 0; j < i; j++) RFX_REQUIRE(devs[j] != devs[i], RFX_EINVAL, "two contexts on one device: RCCL takes one rank per device");
+    }
+    int rc = rccl_bind();
+    if (rc != RFX_OK) return rc;
+    ncclComm_t comms[64];
+    RFX_NCCL_CHECK(g_nccl.CommInitAll(comms, n, devs));
+    for (int i = 0; i < n; i++) {
+        ctxs[i]->comm = comms[i];
+        ctxs[i]->world = n;
+        ctxs[i]->rank = i;
+        ctxs[i]->ext_p[3] = (void *)(uintptr_t)1; // process-local communicator
+    }
+    RFX_HIP_CHECK(hipSetDevice(ctxs[0]->device));
+    return RFX_OK;
+}
+extern "C" int rfx_dist_is_local(rfx_ctx_t *c) { return c && c->comm && c->ext_p[3] ? 1 : 0; }
+extern "C" int rfx_dist_has_comm(rfx_ctx_t *c) { return c && c->comm ? 1 : 0; }
+// the table sets of n contexts (one per device, same range and aggregates), all-reduced in place in ONE fused exchange issued by this thread
+extern "C" int rfx_dist_group_tables_allreduce_all(rfx_ctx_t *const *ctxs, int n, const rfx_agg_t *aggs, const rfx_group_tables_t *const *ts) {
+    RFX_REQUIRE(ctxs && ts && n >= 1, RFX_EINVAL, "bad argument");
+    if (n == 1) return rfx_dist_group_tables_allreduce(ctxs[0], aggs, ts[0]);
+    RFX_NCCL_CHECK(g_nccl.GroupStart());
+    int rc = RFX_OK;
+    for (int i = 0; i < n && rc == RFX_OK; i++) {
+        if (!ctxs[i]->comm) { rfx_set_error("rfx_dist: a context has no communicator"); rc = RFX_ESTATE; break; }
+        ArrCall a[1 + 2 * RFX_MAX_AGGS];
+        rc = allreduce_arrays_enqueue(ctxs[i], a, tables_arrays(aggs, ts[i], a));
+    }
+    if (rc != RFX_OK) {
+        (void)g_nccl.GroupEnd();
+        return rc;
+    }
+    RFX_NCCL_CHECK(g_nccl.GroupEnd());
+    return RFX_OK;
+}
+// in-place all-reduce (op 0 SUM / 1 MIN / 2 MAX) of one buffer of n 8-byte integers per context; all-gather of `bytes` bytes per context
+extern "C" int rfx_dist_allreduce_i64_all(rfx_ctx_t *const *ctxs, int n, int64_t *const *d_bufs, int64_t cells, int op) {
+    RFX_REQUIRE(ctxs && d_bufs && n >= 1 && op >= 0 && op <= 2, RFX_EINVAL, "bad argument");
+    if (cells == 0) return RFX_OK;
+    RFX_NCCL_CHECK(g_nccl.GroupStart());
+    for (int i = 0; i < n; i++) {
+        ncclResult_t r = ctxs[i]->comm ? g_nccl.AllReduce(d_bufs[i], d_bufs[i], (size_t)cells, ncclInt64, op == 0 ? ncclSum : (op == 1 ? ncclMin : ncclMax), (ncclComm_t)ctxs[i]->comm, ctxs[i]->stream)
+                                       : (ncclResult_t)1;
+        if (r != ncclSuccess) {
+            (void)g_nccl.GroupEnd();
+            rfx_set_error("rfx_dist: ncclAllReduce (all) failed");
+            return RFX_EHIP;
+        }
+        ctxs[i]->dist_calls += 1;
+    }
+    RFX_NCCL_CHECK(g_nccl.GroupEnd());
+    return RFX_OK;
+}
+extern "C" int rfx_dist_allgather_all(rfx_ctx_t *const *ctxs, int n, const void *const *d_ins, size_t bytes, void *const *d_outs) {
+    RFX_REQUIRE(ctxs && d_ins && d_outs && n >= 1, RFX_EINVAL, "bad argument");
+    RFX_NCCL_CHECK(g_nccl.GroupStart());
+    for (int i = 0; i < n; i++) {
+        ncclResult_t r = ctxs[i]->comm ? g_nccl.AllGather(d_ins[i], d_outs[i], bytes, ncclInt8, (ncclComm_t)ctxs[i]->comm, ctxs[i]->stream) : (ncclResult_t)1;
+        if (r != ncclSuccess) {
+            (void)g_nccl.GroupEnd();
+            rfx_set_error("rfx_dist: ncclAllGather (all) failed");
+            return RFX_EHIP;
+        }
+        ctxs[i]->dist_calls += 1;
+    }
+    RFX_NCCL_CHECK(g_nccl.GroupEnd());
+    return RFX_OK;
+}
+
+// ---- shards that SHARE a device: merged by a kernel (what AGGR_COLLECT does with the per-thread arrays, core/aggr.c:163-181) ----
+struct MergeArgs {
+    i64 range;
+    int n;
+    int op[1 + 2 * RFX_MAX_AGGS]; // 0 add i64, 1 add f64, 2 min i64, 3 max i64
+    u64 *into[1 + 2 * RFX_MAX_AGGS];
+    const u64 *from[1 + 2 * RFX_MAX_AGGS];
+};
+__global__ __launch_bounds__(RFX_BLOCK) void k_tables_merge(const MergeArgs A) {
+    const i64 stride = (i64)gridDim.x * RFX_BLOCK;
+    for (i64 i = (i64)blockIdx.x * RFX_BLOCK + threadIdx.x; i < A.range; i += stride) {
+#pragma unroll 1
+        for (int k = 0; k < A.n; k++) {
+            const u64 a = A.into[k][i], b = A.from[k][i];
+            u64 r;
+            switch (A.op[k]) {
+                case 0: r = a + b; break;
+                case 1: r = rfx_as_u64(rfx_as_f64(a) + rfx_as_f64(b)); break;
+                case 2: r = (u64)((i64)a < (i64)b ? (i64)a : (i64)b); break;
+                default: r = (u64)((i64)a > (i64)b ? (i64)a : (i64)b); break;
+            }
+            A.into[k][i] = r;
+        }
+    }
+}
+// into[slot] (op)= from[slot] for every array of two dense table sets over the same scope, on the context's device and stream
+extern "C" int rfx_hip_group_tables_merge(rfx_ctx_t *c, const rfx_agg_t *aggs, const rfx_group_tables_t *into, const rfx_group_tables_t *from) {
+    RFX_REQUIRE(c && into && from && (aggs || into->nagg == 0), RFX_EINVAL, "NULL argument");
+    RFX_REQUIRE(into->range == from->range && into->kmin == from->kmin && into->nagg == from->nagg && into->nagg <= RFX_MAX_AGGS, RFX_EINVAL, "table sets differ");
+    if (into->range <= 0) return RFX_OK;
+    ArrCall a[1 + 2 * RFX_MAX_AGGS], b[1 + 2 * RFX_MAX_AGGS];
+    const int n = tables_arrays(aggs, into, a);
+    RFX_REQUIRE(tables_arrays(aggs, from, b) == n, RFX_EINVAL, "table sets differ");
+    MergeArgs M;
+    M.range = into->range;
+    M.n = n;
+    for (int k = 0; k < n; k++) {
+        M.op[k] = a[k].op == ncclMin ? 2 : (a[k].op == ncclMax ? 3 : (a[k].dt == ncclFloat64 ? 1 : 0));
+        M.into[k] = (u64 *)a[k].p;
+        M.from[k] = (const u64 *)b[k].p;
+    }
+    const i64 blocks = (into->range + RFX_BLOCK - 1) / RFX_BLOCK;
+    hipLaunchKernelGGL(k_tables_merge, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(RFX_BLOCK), 0, c->stream, M);
+    RFX_HIP_CHECK(hipGetLastError());
+    return RFX_OK;
+}
+// into[i] += from[i] (8-byte integers): FIRST values, of which exactly one shard contributed each
+__global__ __launch_bounds__(RFX_BLOCK) void k_add_i64(u64 *__restrict__ into, const u64 *__restrict__ from, i64 n) {
+    const i64 stride = (i64)gridDim.x * RFX_BLOCK;
+    for (i64 i = (i64)blockIdx.x * RFX_BLOCK + threadIdx.x; i < n; i += stride) into[i] += from[i];
+}
+extern "C" int rfx_hip_add_i64(rfx_ctx_t *c, int64_t *d_into, const int64_t *d_from, int64_t n) {
+    RFX_REQUIRE(c && (n == 0 || (d_into && d_from)), RFX_EINVAL, "NULL argument");
+    if (n <= 0) return RFX_OK;
+    const i64 blocks = (n + RFX_BLOCK - 1) / RFX_BLOCK;
+    hipLaunchKernelGGL(k_add_i64, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(RFX_BLOCK), 0, c->stream, (u64 *)d_into, (const u64 *)d_from, (i64)n);
+    RFX_HIP_CHECK(hipGetLastError());
+    return RFX_OK;
+}
+// device-to-device on the context's stream; the source may live on another device of this process (hipMemcpyPeer semantics through
+// the unified address space).  Asynchronous.
+extern "C" int rfx_hip_d2d(rfx_ctx_t *c, void *d_dst, const void *d_src, size_t bytes) {
+    RFX_REQUIRE(c && (bytes == 0 || (d_dst && d_src)), RFX_EINVAL, "NULL argument");
+    if (!bytes) return RFX_OK;
+    RFX_HIP_CHECK(hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDefault, c->stream));
+    return RFX_OK;
+}
+// the calling thread issues this context's work from now on (hipSetDevice): every thread of a host that drives several devices calls
+// it once before its first call on the context
+extern "C" int rfx_hip_ctx_bind_thread(rfx_ctx_t *c) {
+    RFX_REQUIRE(c, RFX_EINVAL, "ctx is NULL");
+    RFX_HIP_CHECK(hipSetDevice(c->device));
+    return RFX_OK;
+}
+extern "C" int rfx_hip_ctx_device(rfx_ctx_t *c) { return c ? c->device : -1; }
+// `bytes` of HOST memory from every rank, rank order, through the context's communicator (the small exchanges the host folds itself:
+// scopes, scalar partials, flags).  Without a communicator: out = in.  (syncs)
+extern "C" int rfx_dist_allgather_host(rfx_ctx_t *c, const void *in, size_t bytes, void *out) {
+    RFX_REQUIRE(c && in && out && bytes > 0, RFX_EINVAL, "bad argument");
+    if (!c->comm) {
+        memcpy(out, in, bytes);
+        return RFX_OK;
+    }
+    const int W = c->world;
+    const size_t pad = (bytes + 15) & ~(size_t)15;
+    int rc = dist_scratch(c, pad * (size_t)(W + 1));
+    if (rc != RFX_OK) return rc;
+    char *d = (char *)c->d_dist;
+    RFX_HIP_CHECK(hipMemcpyAsync(d, in, bytes, hipMemcpyHostToDevice, c->stream));
+    RFX_NCCL_CHECK(g_nccl.AllGather(d, d + pad, pad, ncclInt8, (ncclComm_t)c->comm, c->stream));
+    c->dist_calls += 1;
+    for (int r = 0; r < W; r++) RFX_HIP_CHECK(hipMemcpyAsync((char *)out + (size_t)r * bytes, d + pad + (size_t)r * pad, bytes, hipMemcpyDeviceToHost, c->stream));
+    RFX_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return RFX_OK;
 }
 
 // Scalar partials: d_all[r * n .. (r + 1) * n) = rank r's d_local[0 .. n).  Asynchronous.  d_all may be NULL: context scratch is

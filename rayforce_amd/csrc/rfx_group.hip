@@ -326,10 +326,10 @@ static int launch_group(rfx_ctx *c, const Plan &P, const GroupArgs &G, int grid,
         // (dynamic LDS above 64 KB must be opted into once per template instance)
 #define RFX_BIG_LAUNCH(...)                                                                                                                           \
     do {                                                                                                                                              \
-        static bool attr_set = false;                                                                                                                 \
-        if (!attr_set) {                                                                                                                              \
+        static unsigned long long attr_set = 0; /* one bit per device: function attributes are per device */                                                                                                                 \
+        if (!((attr_set >> (c->device & 63)) & 1ull)) {                                                                                                                              \
             RFX_HIP_CHECK(hipFuncSetAttribute((const void *)k_group_dense<__VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, RFX_LDS_GROUP_BIG_BYTES)); \
-            attr_set = true;                                                                                                                          \
+            __atomic_fetch_or(&attr_set, 1ull << (c->device & 63), __ATOMIC_RELAXED);                                                                                                                          \
         }                                                                                                                                             \
         hipLaunchKernelGGL((k_group_dense<__VA_ARGS__>), dim3(c->num_cus), dim3(1024), lds_bytes, c->stream, P, G);                                    \
     } while (0)

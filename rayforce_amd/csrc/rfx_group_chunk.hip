@@ -1113,7 +1113,7 @@ static void chunk_pred_sig(const Plan &P, u64 (*sig)[6]) {
         sig[i][0] = (u64)(uintptr_t)P.cols[q.col];
         sig[i][1] = q.rhs_col >= 0 ? (u64)(uintptr_t)P.cols[q.rhs_col] : 0;
         sig[i][2] = (u64)q.op;
-        sig[i][3] = (u64)(q.dom_f64 | (q.lhs_cvt << 1) | (q.rhs_cvt << 2) | (q.more << 3));
+        sig[i][3] = (u64)(q.dom_f64 | (q.lhs_cvt << 1) | (q.rhs_cvt << 2) | (q.more << 3) | ((u64)q.tree << 4));
         sig[i][4] = q.rhs_bits;
         sig[i][5] = 0;
     }
@@ -1146,20 +1146,20 @@ static void launch_chunk_scatter(rfx_ctx *c, const Plan &P, const ChunkArgs &A) 
 }
 template <int NC, int NP>
 static int launch_chunk_scatter_sel_np(rfx_ctx *c, const Plan &P, const ChunkArgs &A) {
-    static bool attr_set = false; // per instantiation
-    if (!attr_set) {
+    static unsigned long long attr_set = 0; /* one bit per device: function attributes are per device */ // per instantiation
+    if (!((attr_set >> (c->device & 63)) & 1ull)) {
         RFX_HIP_CHECK(hipFuncSetAttribute((const void *)k_chunk_scatter_sel<NC, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CK_SEL_LDS));
-        attr_set = true;
+        __atomic_fetch_or(&attr_set, 1ull << (c->device & 63), __ATOMIC_RELAXED);
     }
     hipLaunchKernelGGL((k_chunk_scatter_sel<NC, NP>), dim3(A.nwg), dim3(CK_SELT), CK_SEL_LDS, c->stream, P, A);
     return RFX_OK;
 }
 template <int NC, int NP>
 static int launch_chunk_scatter_bin_np(rfx_ctx *c, const Plan &P, const ChunkArgs &A) {
-    static bool attr_set = false; // per instantiation
-    if (!attr_set) {
+    static unsigned long long attr_set = 0; /* one bit per device: function attributes are per device */ // per instantiation
+    if (!((attr_set >> (c->device & 63)) & 1ull)) {
         RFX_HIP_CHECK(hipFuncSetAttribute((const void *)k_chunk_scatter_bin<NC, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)CK_BIN_LDS));
-        attr_set = true;
+        __atomic_fetch_or(&attr_set, 1ull << (c->device & 63), __ATOMIC_RELAXED);
     }
     hipLaunchKernelGGL((k_chunk_scatter_bin<NC, NP>), dim3(A.nwg), dim3(CK_SELT), CK_BIN_LDS, c->stream, P, A);
     return RFX_OK;
@@ -1472,10 +1472,10 @@ int rfx_chunk_accumulate(rfx_ctx *c, const Plan &P, int key_idx, const rfx_group
     if (pgrid > c->num_cus * 8) pgrid = c->num_cus * 8;
     hipLaunchKernelGGL(k_chunk_place, dim3(pgrid), dim3(RFX_BLOCK), 0, c->stream, A);
     if (lds > PART_LDS_BYTES) {
-        static bool attr_set = false;
-        if (!attr_set) {
+        static unsigned long long attr_set = 0; /* one bit per device: function attributes are per device */
+        if (!((attr_set >> (c->device & 63)) & 1ull)) {
             RFX_HIP_CHECK(hipFuncSetAttribute((const void *)k_chunk_aggregate<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            attr_set = true;
+            __atomic_fetch_or(&attr_set, 1ull << (c->device & 63), __ATOMIC_RELAXED);
         }
         G.split = 1;
         hipLaunchKernelGGL((k_chunk_aggregate<1024>), dim3(CK_PARTS), dim3(1024), lds, c->stream, P, G);

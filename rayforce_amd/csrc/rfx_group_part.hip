@@ -132,7 +132,7 @@ static void plan_pred_sig(const Plan &P, u64 (*sig)[6]) {
         sig[i][0] = (u64)(uintptr_t)P.cols[q.col];
         sig[i][1] = q.rhs_col >= 0 ? (u64)(uintptr_t)P.cols[q.rhs_col] : 0;
         sig[i][2] = (u64)q.op;
-        sig[i][3] = (u64)(q.dom_f64 | (q.lhs_cvt << 1) | (q.rhs_cvt << 2) | (q.more << 3));
+        sig[i][3] = (u64)(q.dom_f64 | (q.lhs_cvt << 1) | (q.rhs_cvt << 2) | (q.more << 3) | ((u64)q.tree << 4));
         sig[i][4] = q.rhs_bits;
         sig[i][5] = 0;
     }
@@ -1284,12 +1284,12 @@ int rfx_group_part_accumulate(rfx_ctx *c, const Plan &P, int key_idx, const rfx_
     const size_t lds = (size_t)narr * (1ULL << lb) * 8;
     if (lds > PART_LDS_BYTES) {
         // one 1024-thread workgroup per partition (and per CU): dynamic LDS above 64 KB is opted into once per instance
-        static bool attr_set[4] = {false, false, false, false};
+        static unsigned long long attr_set[4] = {0};
 #define RFX_PA(N)                                                                                                                                  \
     case N:                                                                                                                                        \
-        if (!attr_set[N]) {                                                                                                                        \
+        if (!((attr_set[N] >> (c->device & 63)) & 1ull)) {                                                                                                                        \
             RFX_HIP_CHECK(hipFuncSetAttribute((const void *)k_part_aggregate<N, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));  \
-            attr_set[N] = true;                                                                                                                    \
+            __atomic_fetch_or(&attr_set[N], 1ull << (c->device & 63), __ATOMIC_RELAXED);                                                                                                                    \
         }                                                                                                                                          \
         hipLaunchKernelGGL((k_part_aggregate<N, 1024>), dim3((int)nparts), dim3(1024), lds, c->stream, P, A);                                     \
         break
@@ -1433,12 +1433,12 @@ int rfx_group_part_hash_accumulate(rfx_ctx *c, const Plan &P0, int key_idx, cons
     const size_t entry = 8 + (size_t)narr * 8 + 4;
     X.lcap = (unsigned)(((size_t)150 * 1024) / entry) & ~63u;
     const size_t lds = (((size_t)X.lcap * (8 + (size_t)narr * 8)) + (size_t)X.lcap * 4 + 15) & ~(size_t)15;
-    static bool attr_set[3] = {false, false, false};
+    static unsigned long long attr_set[3] = {0};
 #define RFX_PH(N)                                                                                                                              \
     case N:                                                                                                                                    \
-        if (!attr_set[N - 1]) {                                                                                                                \
+        if (!((attr_set[N - 1] >> (c->device & 63)) & 1ull)) {                                                                                                                \
             RFX_HIP_CHECK(hipFuncSetAttribute((const void *)k_part_hash_aggregate<N>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
-            attr_set[N - 1] = true;                                                                                                            \
+            __atomic_fetch_or(&attr_set[N - 1], 1ull << (c->device & 63), __ATOMIC_RELAXED);                                                                                                            \
         }                                                                                                                                      \
         hipLaunchKernelGGL((k_part_hash_aggregate<N>), dim3(A.nparts), dim3(PH_THREADS), lds, c->stream, P, A, X);                             \
         break

@@ -540,10 +540,10 @@ template <int NC, int NP, int NV, int PBITS, int VGL, bool HK = false>
 static int launch_plane_scatter_inst(rfx_ctx *c, const Plan &P, const PlaneArgs &A) {
     constexpr size_t lds = pl_lds_bytes<NV, PBITS, VGL>();
     static_assert(lds <= 160 * 1024, "rings beyond a CU's LDS");
-    static bool attr_set = false; // per instantiation
-    if (!attr_set) {
+    static unsigned long long attr_set = 0; /* one bit per device: function attributes are per device */ // per instantiation
+    if (!((attr_set >> (c->device & 63)) & 1ull)) {
         RFX_HIP_CHECK(hipFuncSetAttribute((const void *)k_plane_scatter<NC, NP, NV, PBITS, VGL, HK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
+        __atomic_fetch_or(&attr_set, 1ull << (c->device & 63), __ATOMIC_RELAXED);
     }
     hipLaunchKernelGGL((k_plane_scatter<NC, NP, NV, PBITS, VGL, HK>), dim3(A.nblk), dim3(PL_T), lds, c->stream, P, A);
     return RFX_OK;
@@ -631,7 +631,7 @@ static void plane_pred_sig(const Plan &P, u64 (*sig)[6]) {
         sig[i][0] = (u64)(uintptr_t)P.cols[q.col];
         sig[i][1] = q.rhs_col >= 0 ? (u64)(uintptr_t)P.cols[q.rhs_col] : 0;
         sig[i][2] = (u64)q.op;
-        sig[i][3] = (u64)(q.dom_f64 | (q.lhs_cvt << 1) | (q.rhs_cvt << 2) | (q.more << 3));
+        sig[i][3] = (u64)(q.dom_f64 | (q.lhs_cvt << 1) | (q.rhs_cvt << 2) | (q.more << 3) | ((u64)q.tree << 4));
         sig[i][4] = q.rhs_bits;
         sig[i][5] = 0;
     }
@@ -741,10 +741,10 @@ int rfx_plane_scope(rfx_ctx *c, const Plan &P, int key_idx, const void *d_key, i
 
 template <int THREADS, int NVL, bool FAST>
 static int launch_plane_aggregate_inst(rfx_ctx *c, const Plan &P, const PlaneAggArgs &G, int grid, size_t lds, int lds_max) {
-    static bool attr_set = false; // per instantiation
-    if (!attr_set) {
+    static unsigned long long attr_set = 0; /* one bit per device: function attributes are per device */ // per instantiation
+    if (!((attr_set >> (c->device & 63)) & 1ull)) {
         RFX_HIP_CHECK(hipFuncSetAttribute((const void *)k_plane_aggregate<THREADS, NVL, FAST>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max));
-        attr_set = true;
+        __atomic_fetch_or(&attr_set, 1ull << (c->device & 63), __ATOMIC_RELAXED);
     }
     hipLaunchKernelGGL((k_plane_aggregate<THREADS, NVL, FAST>), dim3(grid), dim3(THREADS), lds, c->stream, P, G);
     return RFX_OK;
@@ -1142,11 +1142,11 @@ int rfx_plane_hash_accumulate(rfx_ctx *c, const Plan &P, int key_idx, const Hash
     X.cnt = A.cnt;
     X.overflow = d_overflow;
     const size_t lds = (size_t)lcap * entry + 16 * 64 * 4 + 64;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static unsigned long long attr_set = 0; /* one bit per device: function attributes are per device */
+    if (!((attr_set >> (c->device & 63)) & 1ull)) {
         RFX_HIP_CHECK(hipFuncSetAttribute((const void *)k_plane_hash_aggregate<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         RFX_HIP_CHECK(hipFuncSetAttribute((const void *)k_plane_hash_aggregate<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
+        __atomic_fetch_or(&attr_set, 1ull << (c->device & 63), __ATOMIC_RELAXED);
     }
     c->ext_i[3 + RFX_STAT_PLANE_AGGREGATE]++;
     const bool fast = P.nagg == 1 && P.aggs[0].kind == RFX_AGG_SUM && P.aggs[0].f64 && !P.aggs[0].skipnull && X.agg_pl[0] == 1;

@@ -21,6 +21,7 @@
 #include <time.h>
 #include "rfx_abi.h"
 #include "rfx_hip.h"
+#include "rfx_exec.h"
 #include "rfx_ops.h"
 
 typedef rfx_obj_p obj_p;
@@ -137,6 +138,11 @@ static obj_p fail_hip(const char *what) {
     snprintf(b, sizeof(b), "%s: %s", what, rfx_hip_last_error());
     return fail(b);
 }
+static int g_refused_sharded;
+static obj_p fail_ctx(void) {
+    if (g_refused_sharded) return fail("this operator needs its columns whole on one device: with RFX_SHARDS / RFX_DEVICES the operator layer answers rfx_select (and pin / unpin / invalidate / stats) only");
+    return fail_hip("no usable MI355X");
+}
 
 /* which built-in does this function object denote? -1 if none */
 static int fn_id(obj_p o) {
@@ -148,20 +154,88 @@ static int fn_id(obj_p o) {
 }
 
 /* ------------------------------------------------------------------------------------------------ device + residency */
+/* The operator layer owns ONE planner (rfx_exec.h) over one context per SHARD.  Default: one shard on device $RFX_DEVICE (0).
+ * RFX_DEVICES="0,1,2,3" | "all": one shard per listed device -- the evaluator process that owns the node's GPUs: every column is split
+ * row-range over them at upload (rfx_pin), rfx_select runs every shard's pass on its own host thread and merges the partial tables with
+ * ONE fused RCCL exchange (core/query.c:607-654 -> aggr_map core/aggr.c:375 / AGGR_COLLECT :163-181, one level up).
+ * RFX_SHARDS=k: k shards over the listed devices round robin (k > devices: several per device, merged by a kernel -- how the sharded
+ * door is tested on a one-GPU box).  g_ctx is shard 0's context: the operators that are not sharded run there. */
 static rfx_ctx_t *g_ctx;
+static rfx_ctx_t *g_ctxs[RFX_MAX_SHARDS];
+static rfx_exec_t *g_x;
+static int g_nshards = 1;
 static int g_device = -1;
+static int g_cfg_devices[RFX_MAX_SHARDS], g_cfg_ndev, g_cfg_shards;
 int rfx_ops_set_device(int device) {
     if (g_ctx) return RFX_ESTATE;
     g_device = device;
     return RFX_OK;
 }
+int rfx_ops_set_shards(const int *devices, int ndevices, int nshards) {
+    if (g_ctx) return RFX_ESTATE;
+    if (ndevices < 0 || ndevices > RFX_MAX_SHARDS || nshards < 0 || nshards > RFX_MAX_SHARDS || (ndevices && !devices)) return RFX_EINVAL;
+    for (int i = 0; i < ndevices; i++) g_cfg_devices[i] = devices[i];
+    g_cfg_ndev = ndevices;
+    g_cfg_shards = nshards;
+    return RFX_OK;
+}
+int rfx_ops_shards(void) { return g_nshards; }
+rfx_exec_t *rfx_ops_exec(void) { return g_x; }
 static int ensure_ctx(void) {
     if (g_ctx) return RFX_OK;
-    if (g_device < 0) {
-        const char *e = getenv("RFX_DEVICE");
-        g_device = e ? atoi(e) : 0;
+    int devs[RFX_MAX_SHARDS], ndev = g_cfg_ndev, nsh = g_cfg_shards;
+    for (int i = 0; i < ndev; i++) devs[i] = g_cfg_devices[i];
+    if (ndev == 0) {
+        const char *e = getenv("RFX_DEVICES");
+        if (e && strcmp(e, "all") == 0) {
+            const int n = rfx_hip_device_count();
+            for (int i = 0; i < n && i < RFX_MAX_SHARDS; i++) devs[ndev++] = i;
+        } else if (e && *e) {
+            for (const char *q = e; *q && ndev < RFX_MAX_SHARDS;) {
+                devs[ndev++] = atoi(q);
+                while (*q && *q != ',') q++;
+                if (*q == ',') q++;
+            }
+        }
     }
-    return rfx_hip_ctx_create(g_device, NULL, &g_ctx);
+    if (ndev == 0) {
+        if (g_device < 0) {
+            const char *e = getenv("RFX_DEVICE");
+            g_device = e ? atoi(e) : 0;
+        }
+        devs[ndev++] = g_device;
+    }
+    if (nsh == 0) {
+        const char *e = getenv("RFX_SHARDS");
+        nsh = e ? atoi(e) : 0;
+    }
+    if (nsh < ndev) nsh = ndev;
+    if (nsh > RFX_MAX_SHARDS) nsh = RFX_MAX_SHARDS;
+    int rc = RFX_OK, made = 0;
+    for (int s = 0; s < nsh && rc == RFX_OK; s++) {
+        rc = rfx_hip_ctx_create(devs[s % ndev], NULL, &g_ctxs[s]);
+        if (rc == RFX_OK) made++;
+    }
+    if (rc == RFX_OK) rc = rfx_exec_create(g_ctxs, nsh, &g_x);
+    if (rc == RFX_OK) rc = rfx_exec_comm_init_all(g_x); /* (communicators among the devices when there are several) */
+    if (rc != RFX_OK) {
+        if (g_x) rfx_exec_destroy(g_x);
+        g_x = NULL;
+        for (int s = 0; s < made; s++) { rfx_hip_ctx_destroy(g_ctxs[s]); g_ctxs[s] = NULL; }
+        return rc;
+    }
+    g_device = devs[0];
+    g_nshards = nsh;
+    g_ctx = g_ctxs[0];
+    rfx_hip_ctx_bind_thread(g_ctx);
+    if (getenv("RFX_TRACE")) fprintf(stderr, "[rfx] operator layer: %d shard(s) over %d device(s)\n", nsh, ndev);
+    return RFX_OK;
+}
+/* for the operators that need a column WHOLE on one device (everything but rfx_select / rfx_pin / rfx_unpin / rfx_invalidate / rfx_stats) */
+static int ensure_ctx1(void) {
+    const int rc = ensure_ctx();
+    g_refused_sharded = rc == RFX_OK && g_nshards > 1;
+    return g_refused_sharded ? RFX_ELIMIT : rc;
 }
 
 /* Residency cache: host vector payload -> device copy, keyed by (payload address, length, type).
@@ -196,6 +270,7 @@ typedef struct {
     size_t dbytes;     /* bytes of the device copy (`bytes` are the host payload's: a 4-byte column is widened on the device) */
     int scope_ok;      /* [smin, smax] = index_scope_i64 of the WHOLE column (no filter), taken from this very copy: valid as long as the copy is */
     int64_t smin, smax;
+    void *devs[RFX_MAX_SHARDS]; /* the copy, shard by shard (devs[0] == dev): rows rfx_exec_split(len, shards, s) of the column */
 } resident_t;
 static resident_t *g_res;
 static int g_nres, g_capres;
@@ -415,9 +490,26 @@ static int sd_entry_clean(const resident_t *r) {
 }
 
 static void res_free(int i) {
-    if (g_res[i].dev) rfx_hip_free(g_ctx, g_res[i].dev);
+    for (int s = 0; s < g_nshards; s++)
+        if (g_res[i].devs[s]) {
+            if (g_nshards > 1) rfx_hip_ctx_bind_thread(g_ctxs[s]);
+            rfx_hip_free(g_ctxs[s], g_res[i].devs[s]);
+        }
+    if (g_nshards > 1) rfx_hip_ctx_bind_thread(g_ctx);
     g_res_bytes -= g_res[i].dbytes;
     g_res[i] = g_res[--g_nres];
+}
+/* the columns the operator call in flight has named, shard by shard: what the planner translates shard 0's addresses with */
+static rfx_qcol_t g_qcols[64];
+static int g_nqcols;
+static int qcol_add(void *const *devs) {
+    if (g_nshards == 1) return RFX_OK;
+    for (int i = 0; i < g_nqcols; i++)
+        if (g_qcols[i].d[0] == devs[0]) return RFX_OK;
+    if (g_nqcols >= (int)(sizeof(g_qcols) / sizeof(g_qcols[0]))) return RFX_ELIMIT;
+    for (int s = 0; s < RFX_MAX_SHARDS; s++) g_qcols[g_nqcols].d[s] = s < g_nshards ? devs[s] : NULL;
+    g_nqcols++;
+    return RFX_OK;
 }
 static void op_begin(void);
 static void op_end(void);
@@ -447,6 +539,8 @@ static void op_begin(void) {
     if (t_op_depth++ == 0) {
         pthread_mutex_lock(&g_op_lock);
         g_epoch++; /* (a nested operator keeps the outer one's epoch: the outer call's columns stay protected from eviction) */
+        g_nqcols = 0;
+        if (g_ctx) rfx_hip_ctx_bind_thread(g_ctx); /* (the host calls built-ins from any of its threads) */
     }
     g_stat[ST_OPS]++;
 }
@@ -616,19 +710,80 @@ static int proxy_upload(const proxy_t *px, void *dev) {
 /* 4-byte integer columns (I32 / DATE / TIME): comparable on the device through a widened copy (rfx_hip_widen_i32) */
 #define IS_I32_FAMILY(t) ((t) == RFX_TYPE_I32 || (t) == RFX_TYPE_DATE || (t) == RFX_TYPE_TIME)
 /* host payload -> device copy: 8-byte and 1-byte columns as they are, 4-byte integers widened to 8 bytes on the device */
-static int payload_upload(int type, void *dev, const void *host, int64_t len) {
-    if (!IS_I32_FAMILY(type)) return rfx_hip_h2d_pipelined(g_ctx, dev, host, (size_t)len * (type == RFX_TYPE_B8 ? 1 : 8));
+static int payload_upload_one(rfx_ctx_t *c, int type, void *dev, const void *host, int64_t len) {
+    if (!IS_I32_FAMILY(type)) return rfx_hip_h2d_pipelined(c, dev, host, (size_t)len * (type == RFX_TYPE_B8 ? 1 : 8));
     void *raw = NULL;
-    int rc = rfx_hip_malloc(g_ctx, &raw, (size_t)(len ? len : 1) * 4);
+    int rc = rfx_hip_malloc(c, &raw, (size_t)(len ? len : 1) * 4);
     if (rc != RFX_OK) return rc;
-    rc = rfx_hip_h2d_pipelined(g_ctx, raw, host, (size_t)len * 4);
-    if (rc == RFX_OK) rc = rfx_hip_widen_i32(g_ctx, (const int32_t *)raw, len, (int64_t *)dev);
-    if (rc == RFX_OK) rc = rfx_hip_ctx_sync(g_ctx); /* (the raw block goes back to the pool: the widening must have read it) */
-    rfx_hip_free(g_ctx, raw);
+    rc = rfx_hip_h2d_pipelined(c, raw, host, (size_t)len * 4);
+    if (rc == RFX_OK) rc = rfx_hip_widen_i32(c, (const int32_t *)raw, len, (int64_t *)dev);
+    if (rc == RFX_OK) rc = rfx_hip_ctx_sync(c); /* (the raw block goes back to the pool: the widening must have read it) */
+    rfx_hip_free(c, raw);
     return rc;
 }
+/* the whole payload, every shard its row range (rfx_exec_split) */
+static int payload_upload(int type, void *const *devs, const void *host, int64_t len) {
+    const int esz = type == RFX_TYPE_B8 ? 1 : (IS_I32_FAMILY(type) ? 4 : 8);
+    int rc = RFX_OK;
+    for (int s = 0; s < g_nshards && rc == RFX_OK; s++) {
+        int64_t r0, n;
+        rfx_exec_split(len, g_nshards, s, &r0, &n);
+        if (g_nshards > 1) rfx_hip_ctx_bind_thread(g_ctxs[s]);
+        if (n > 0) rc = payload_upload_one(g_ctxs[s], type, devs[s], (const char *)host + (size_t)r0 * esz, n);
+    }
+    if (g_nshards > 1) rfx_hip_ctx_bind_thread(g_ctx);
+    return rc;
+}
+static int shards_alloc(void **devs, int64_t len, size_t desz) {
+    int rc = RFX_OK;
+    for (int s = 0; s < RFX_MAX_SHARDS; s++) devs[s] = NULL;
+    for (int s = 0; s < g_nshards && rc == RFX_OK; s++) {
+        int64_t n;
+        rfx_exec_split(len, g_nshards, s, NULL, &n);
+        if (g_nshards > 1) rfx_hip_ctx_bind_thread(g_ctxs[s]);
+        rc = rfx_hip_malloc(g_ctxs[s], &devs[s], (size_t)(n ? n : 1) * desz);
+    }
+    if (rc != RFX_OK)
+        for (int s = 0; s < g_nshards; s++)
+            if (devs[s]) { rfx_hip_ctx_bind_thread(g_ctxs[s]); rfx_hip_free(g_ctxs[s], devs[s]); devs[s] = NULL; }
+    if (g_nshards > 1) rfx_hip_ctx_bind_thread(g_ctx);
+    return rc;
+}
+/* A DEVICE column handle: a vector header of ours (mmod RFX_MMOD_DEVICE) whose payload is not the cells but their device address(es) --
+ * what a host that already keeps its columns in HBM (bench.py, the Python test host, a C host with its own loader) hands to the
+ * operators in place of a host vector.  Borrowed memory: never uploaded, cached, validated or freed here. */
+#define RFX_MMOD_DEVICE 0xde
+typedef struct {
+    const void *d[RFX_MAX_SHARDS]; /* d[s] NULL beyond the first: one allocation, shard s = d[0] + its row range (shards on one device) */
+} devcol_t;
+rfx_obj_p rfx_host_device_vector(int8_t type, int64_t len, const void *const *d_ptrs, int nptrs) {
+    if (len < 0 || !d_ptrs || nptrs < 1 || nptrs > RFX_MAX_SHARDS) return NULL;
+    rfx_obj_p o = rfx_host_vector(RFX_TYPE_I64, (int64_t)(sizeof(devcol_t) / 8));
+    if (!o) return NULL;
+    devcol_t *dc = (devcol_t *)RFX_AS_RAW(o);
+    memset(dc, 0, sizeof(*dc));
+    for (int i = 0; i < nptrs; i++) dc->d[i] = d_ptrs[i];
+    o->mmod = RFX_MMOD_DEVICE;
+    o->type = type < 0 ? (int8_t)-type : type;
+    o->len = len;
+    return o;
+}
 static int resident(obj_p col, int pin, const void **dev) {
+    if (col->mmod == RFX_MMOD_DEVICE) {
+        const devcol_t *dc = (const devcol_t *)RFX_AS_RAW(col);
+        const int esz = (col->type == RFX_TYPE_B8) ? 1 : 8;
+        void *devs[RFX_MAX_SHARDS];
+        for (int s = 0; s < g_nshards; s++) {
+            int64_t r0;
+            rfx_exec_split(col->len, g_nshards, s, &r0, NULL);
+            devs[s] = (s == 0 || dc->d[s]) ? (void *)dc->d[s] : (void *)((const char *)dc->d[0] + (size_t)r0 * esz);
+        }
+        if (IS_I32_FAMILY(col->type)) return RFX_EINVAL; /* (device columns are 8-byte or B8 cells) */
+        *dev = devs[0];
+        return qcol_add(devs);
+    }
     const proxy_t *px = g_npx ? proxy_of(col) : NULL;
+    if (px && g_nshards > 1) return RFX_ELIMIT; /* (parted views run on one shard: the caller hands such tables to the host) */
     const int narrow = !px && IS_I32_FAMILY(col->type);
     const int esz = (col->type == RFX_TYPE_B8) ? 1 : (narrow ? 4 : 8);
     const void *host = px ? (const void *)px->src : RFX_AS_RAW(col); /* a parted column is known by its LIST object */
@@ -648,7 +803,7 @@ static int resident(obj_p col, int pin, const void **dev) {
                     g_res[i].pinned |= pin;
                     g_stat[ST_CACHE_HITS]++;
                     *dev = g_res[i].dev;
-                    return RFX_OK;
+                    return qcol_add(g_res[i].devs);
                 }
                 g_res[i].tracked = 0;
                 /* by its checksum -- taken AFTER the pages were clean-marked, so that it can vouch for them from now on */
@@ -672,11 +827,11 @@ static int resident(obj_p col, int pin, const void **dev) {
                 g_res[i].pinned |= pin;
                 g_stat[ST_CACHE_HITS]++;
                 *dev = g_res[i].dev;
-                return RFX_OK;
+                return qcol_add(g_res[i].devs);
             }
             /* stale: the payload changed under the same address -- refresh the device copy in place */
             g_stat[ST_CACHE_STALE]++;
-            int rc = px ? proxy_upload(px, g_res[i].dev) : payload_upload(col->type, g_res[i].dev, host, col->len);
+            int rc = px ? proxy_upload(px, g_res[i].dev) : payload_upload(col->type, g_res[i].devs, host, col->len);
             if (rc != RFX_OK) { res_free(i); return rc; }
             g_stat[ST_UPLOADS]++;
             g_res[i].scope_ok = 0; /* (new cells: the scope remembered for the old ones is gone) */
@@ -685,7 +840,7 @@ static int resident(obj_p col, int pin, const void **dev) {
             g_res[i].epoch = g_epoch;
             g_res[i].pinned |= pin;
             *dev = g_res[i].dev;
-            return RFX_OK;
+            return qcol_add(g_res[i].devs);
         }
     while (g_nres && g_res_bytes + dbytes > cache_budget()) {
         int victim = -1; /* least recently used, not pinned, not in use by the call in flight */
@@ -694,23 +849,31 @@ static int resident(obj_p col, int pin, const void **dev) {
         if (victim < 0) break; /* everything left is pinned or in use: go over budget rather than free what the call reads */
         res_free(victim);
     }
-    void *d = NULL;
-    int rc = rfx_hip_malloc(g_ctx, &d, dbytes ? dbytes : 8);
+    void *devs[RFX_MAX_SHARDS];
+    int rc = shards_alloc(devs, col->len, narrow ? 8 : (size_t)esz);
     if (rc != RFX_OK) return rc;
     /* the checksum, THEN the copy: a host write racing with this call is either in both, or in the copy only and costs one refresh at
      * the next use -- never a device copy older than what vouches for it */
     if (!have_sum) sum = px ? proxy_sum(px) : payload_sum(host, bytes);
-    rc = px ? proxy_upload(px, d) : payload_upload(col->type, d, host, col->len); /* heap vector or mmapped column file alike: staged through pinned buffers */
-    if (rc != RFX_OK) { rfx_hip_free(g_ctx, d); return rc; }
+    rc = px ? proxy_upload(px, devs[0]) : payload_upload(col->type, devs, host, col->len); /* heap vector or mmapped column file alike: staged through pinned buffers */
+    if (rc != RFX_OK) {
+        for (int s = 0; s < g_nshards; s++) { if (g_nshards > 1) rfx_hip_ctx_bind_thread(g_ctxs[s]); rfx_hip_free(g_ctxs[s], devs[s]); }
+        if (g_nshards > 1) rfx_hip_ctx_bind_thread(g_ctx);
+        return rc;
+    }
     g_stat[ST_UPLOADS]++;
     if (g_nres == g_capres) {
         g_capres = g_capres ? g_capres * 2 : 32;
         g_res = (resident_t *)realloc(g_res, sizeof(resident_t) * (size_t)g_capres);
     }
-    g_res[g_nres++] = (resident_t){host, col->len, ktype, sum, d, bytes, pin, ++g_tick, g_epoch, 0, 0, 0, 0, dbytes, 0, 0, 0}; /* (page tracking starts once the column has proven stable) */
+    resident_t e;
+    memset(&e, 0, sizeof(e));
+    e.host = host; e.len = col->len; e.type = ktype; e.sum = sum; e.dev = devs[0]; e.bytes = bytes; e.pinned = pin; e.tick = ++g_tick; e.epoch = g_epoch; e.dbytes = dbytes;
+    for (int s = 0; s < g_nshards; s++) e.devs[s] = devs[s];
+    g_res[g_nres++] = e; /* (page tracking starts once the column has proven stable) */
     g_res_bytes += dbytes;
-    *dev = d;
-    return RFX_OK;
+    *dev = devs[0];
+    return qcol_add(devs);
 }
 /* The key scope of a WHOLE resident column (index_scope_i64 without a filter, core/index.c:376-435), remembered with the copy it was taken
  * from.  A group-by over a few thousand slots is two host round trips -- the scope, the result -- and ~25 us each: the remembered scope
@@ -969,74 +1132,78 @@ static int plan_set_cmp(obj_p tab, obj_p e, rfx_pred_t *out, int room, int *glog
     }
     return n;
 }
-/* where: a comparison, or a flat (and ...) / (or ...) of comparisons */
-/* One arm of the top-level and / or: a comparison; a list of the SAME operator (and inside and: associative, its arms are this level's);
- * or a parenthesis of the OPPOSITE operator over comparisons -- `more` set on all but its last (rfx_pred_t: the fused kernels fold a
- * parenthesis with the opposite operator in the same pass).  Anything deeper: -1 (the mask path answers it). */
-static int plan_arm(obj_p tab, obj_p e, int top, wplan_t *wp) {
+/* where: a comparison, or ANY tree of and / or over comparisons (logic_map nests freely, core/logic.c:89-260) -- its leaves in order, each
+ * with the depth of parentheses it sits in and the parentheses that close after it.  Level 0 combines with the root's operator, every
+ * deeper level with the opposite of the level above: the same operator nested in itself is associative and stays on its level.  Up to
+ * RFX_MAX_PREDS comparisons and four levels run in ONE fused pass (rfx_pred_t: the two-level `more` form where it suffices -- the
+ * kernels' short path -- else the RFX_PRED_TREE form); anything beyond: -1 (the mask path answers it). */
+typedef struct {
+    int dep[RFX_MAX_PREDS], clo[RFX_MAX_PREDS];
+} wtree_t;
+static int plan_node(obj_p tab, obj_p e, int level_op, int depth, wplan_t *wp, wtree_t *wt) {
     if (!e || e->type != RFX_TYPE_LIST || e->len < 1) return -1;
-    int f = fn_id(RFX_AS_LIST(e)[0]);
-    if (f == F_IN || f == F_WITHIN) { /* a group of comparisons: flat when it combines like this level, else a parenthesis of its own */
+    const int f = fn_id(RFX_AS_LIST(e)[0]);
+    if (f == F_IN || f == F_WITHIN) { /* a group of comparisons: on this level when it combines like it, else a parenthesis of its own */
         int gl = RFX_AND;
         const int n = plan_set_cmp(tab, e, &wp->preds[wp->npred], RFX_MAX_PREDS - wp->npred, &gl);
         if (n < 0) return n;
-        if (gl != (top == F_AND ? RFX_AND : RFX_OR))
-            for (int i = 0; i + 1 < n; i++) wp->preds[wp->npred + i].more = 1;
+        const int own = n > 1 && gl != (level_op == F_AND ? RFX_AND : RFX_OR);
+        for (int i = 0; i < n; i++) {
+            wt->dep[wp->npred + i] = depth + own;
+            wt->clo[wp->npred + i] = 0;
+        }
+        if (own) wt->clo[wp->npred + n - 1] = 1;
         wp->npred += n;
         return 0;
     }
     if (f != F_AND && f != F_OR) {
         if (wp->npred >= RFX_MAX_PREDS) return -1;
-        int rc = plan_cmp(tab, e, &wp->preds[wp->npred]);
-        if (rc == 0) wp->npred++;
-        return rc;
-    }
-    if (e->len < 2) return -1;
-    if (f == top) {
-        for (int64_t i = 1; i < e->len; i++) {
-            int rc = plan_arm(tab, RFX_AS_LIST(e)[i], top, wp);
-            if (rc) return rc;
-        }
+        const int rc = plan_cmp(tab, e, &wp->preds[wp->npred]);
+        if (rc) return rc;
+        wt->dep[wp->npred] = depth;
+        wt->clo[wp->npred] = 0;
+        wp->npred++;
         return 0;
     }
-    for (int64_t i = 1; i < e->len; i++) { /* a parenthesis of the opposite operator */
-        if (wp->npred >= RFX_MAX_PREDS) return -1;
-        int gl = RFX_AND;
-        int n = plan_set_cmp(tab, RFX_AS_LIST(e)[i], &wp->preds[wp->npred], RFX_MAX_PREDS - wp->npred, &gl);
-        if (n == -2) return -2;
-        if (n > 0 && gl != (f == F_AND ? RFX_AND : RFX_OR)) return -1; /* a third level: the mask path / the host */
-        if (n < 0) {
-            int rc = plan_cmp(tab, RFX_AS_LIST(e)[i], &wp->preds[wp->npred]);
-            if (rc) return rc;
-            n = 1;
-        }
-        for (int j = 0; j < n; j++) wp->preds[wp->npred + j].more = 1;
-        wp->npred += n;
-        if (i + 1 == e->len) wp->preds[wp->npred - 1].more = 0;
+    if (e->len < 2) return -1;
+    const int own = f != level_op; /* the opposite operator: a parenthesis one level down, closed after its last leaf */
+    const int first = wp->npred;
+    for (int64_t i = 1; i < e->len; i++) {
+        const int rc = plan_node(tab, RFX_AS_LIST(e)[i], f, depth + own, wp, wt);
+        if (rc) return rc;
     }
+    if (own && wp->npred > first) wt->clo[wp->npred - 1]++;
     return 0;
 }
-
 static int plan_where(obj_p tab, obj_p w, wplan_t *wp) {
     wp->npred = 0;
     wp->logic = RFX_AND;
     if (!w) return 0;
     if (w->type != RFX_TYPE_LIST || w->len < 1) return -1;
-    int f = fn_id(RFX_AS_LIST(w)[0]);
+    const int f = fn_id(RFX_AS_LIST(w)[0]);
+    wtree_t wt;
     if (f == F_AND || f == F_OR) {
         if (w->len < 2) return -1;
         wp->logic = (f == F_AND) ? RFX_AND : RFX_OR;
-        return plan_arm(tab, w, f, wp);
-    }
-    if (f == F_IN || f == F_WITHIN) {
+    } else if (f == F_IN || f == F_WITHIN) {
         const int n = plan_set_cmp(tab, w, wp->preds, RFX_MAX_PREDS, &wp->logic);
         if (n < 0) return n;
         wp->npred = n;
         return 0;
     }
-    int rc = plan_cmp(tab, w, &wp->preds[0]);
+    const int rc = plan_node(tab, w, (f == F_AND || f == F_OR) ? f : F_AND, 0, wp, &wt);
     if (rc) return rc;
-    wp->npred = 1;
+    int maxd = 0;
+    for (int i = 0; i < wp->npred; i++) {
+        if (wt.dep[i] > maxd) maxd = wt.dep[i];
+        if (wt.clo[i] > wt.dep[i]) return -1; /* (cannot happen: a parenthesis closes on the level it opened) */
+    }
+    if (maxd > 3 || (maxd > 1 && wp->npred < 3)) return -1; /* deeper than four levels (or a degenerate nest of one-armed parentheses): through masks */
+    if (maxd <= 1) { /* flat, or parentheses of the opposite operator over comparisons: the two-level form */
+        for (int i = 0; i < wp->npred; i++) wp->preds[i].more = (wt.dep[i] == 1 && wt.clo[i] == 0) ? 1 : 0;
+        return 0;
+    }
+    for (int i = 0; i < wp->npred; i++) wp->preds[i].more = RFX_PRED_LEAF(wt.dep[i], wt.clo[i]);
     return 0;
 }
 
@@ -1175,42 +1342,6 @@ static int build_xnodes(obj_p tab, obj_p e, rfx_xnode_t *nodes, int *nn, int *nc
 }
 
 /* ------------------------------------------------------------------------------------------------ select */
-static const void *g_spec_failed[32]; /* HOST key columns (payload address of the first by: column) whose sampled scope was reported too small:
-                                       * not sampled again.  (Device addresses are per-query scratch for bucketed / composite keys.) */
-static int g_nspec_failed, g_spec_ring, g_spec_retry;
-/* One dense accumulate pass, under an exact or a SAMPLED scope (`spec`).  0: done.  1: the sampled scope did not hold (a selected row's
- * key outside it, or a path that cannot report such rows): nothing of the result may be used, the caller takes the exact scope and runs
- * again.  -1: error. */
-static int dense_pass(int spec, int fused_keys, const void **dks, const int64_t *kmins, const int64_t *kmults, int nkeys, const void *dk, const wplan_t *wp,
-                      const rfx_agg_t *aggs, int64_t nrows, const rfx_group_tables_t *gt) {
-    if (spec && rfx_hip_ctx_speculative(g_ctx, 1) != RFX_OK) return -1;
-    int rc = fused_keys ? rfx_hip_group_dense_accumulate_keys(g_ctx, dks, kmins, kmults, nkeys, wp->preds, wp->npred, wp->logic, aggs, nrows, 0, gt)
-                        : rfx_hip_group_dense_accumulate(g_ctx, (const int64_t *)dk, wp->preds, wp->npred, wp->logic, aggs, nrows, 0, gt);
-    if (spec) {
-        rfx_hip_ctx_speculative(g_ctx, 0);
-        if (rc == RFX_ESTATE) return 1;
-    }
-    if (rc != RFX_OK) return -1;
-    if (spec) {
-        int bad = 0;
-        if (rfx_hip_group_out_of_scope(g_ctx, &bad) != RFX_OK) return -1;
-        if (bad) return 1;
-    }
-    return 0;
-}
-
-/* results of a small group-by arrive on the host in ONE copy (rfx_hip_group_rank_emit_small's block); the code that builds the
- * result vectors reads device addresses through fetch(), which serves addresses inside that block from its host mirror */
-static const char *g_mirror_dev, *g_mirror_host;
-static size_t g_mirror_bytes;
-static int fetch(void *dst, const void *d_src, size_t bytes) {
-    if (g_mirror_host && (const char *)d_src >= g_mirror_dev && (const char *)d_src + bytes <= g_mirror_dev + g_mirror_bytes) {
-        memcpy(dst, g_mirror_host + ((const char *)d_src - g_mirror_dev), bytes);
-        return RFX_OK;
-    }
-    return rfx_hip_d2h(g_ctx, dst, d_src, bytes);
-}
-
 /* RFX_TRACE=2: where a select's wall time goes (microseconds between marks), one line per query on stderr */
 static double g_tm[12];
 static int g_ntm;
@@ -1303,89 +1434,48 @@ static int sel_mappings(obj_p tab, obj_p dkeys, obj_p dvals, int grouped, sel_ma
     return SEL_GO;
 }
 
-/* select without aggregates: filter_collect of every column (core/filter.c:51-165) -- where -> ids -> gather */
-static int where_ids(obj_p tab, obj_p where, const wplan_t *wp, int flat, int64_t nrows, int64_t **d_ids, int64_t *count);
-static int sel_projection(obj_p tab, obj_p where, const wplan_t *wp, int flat, int parted, int64_t nrows, obj_p *res, const char **why) {
-    obj_p tcols = RFX_AS_LIST(tab)[1];
-    if (parted) { *why = "parted table: projection"; return SEL_OUT; } /* the reference keeps such a result lazy (filter maps over the partitions) */
-    if (!where) { *res = H.clone(tab); g_last_gpu = 1; return SEL_DONE; }
-    for (int64_t i = 0; i < tcols->len; i++)
-        if (!col_ctype(RFX_AS_LIST(tcols)[i])) { *why = "projection of a non-8-byte column"; return SEL_OUT; }
-    int64_t *d_ids = NULL, nsel = 0;
-    const int rc = where_ids(tab, where, wp, flat, nrows, &d_ids, &nsel);
-    if (rc == -1) { *why = "where: shape"; return SEL_OUT; }
-    if (rc) { *res = fail_hip("where"); return SEL_DONE; }
-    obj_p rv = H.vector(RFX_TYPE_LIST, tcols->len);
-    void *dg = NULL;
-    int ok = nsel == 0 || rfx_hip_malloc(g_ctx, &dg, (size_t)nsel * 8) == RFX_OK;
-    for (int64_t i = 0; i < tcols->len && ok; i++) {
-        obj_p c = RFX_AS_LIST(tcols)[i];
-        obj_p o = H.vector(c->type, nsel);
-        RFX_AS_LIST(rv)[i] = o;
-        const void *dc;
-        if (nsel == 0) continue;
-        ok = resident(c, 0, &dc) == RFX_OK && rfx_hip_gather(g_ctx, dc, d_ids, nsel, dg) == RFX_OK &&
-             rfx_hip_d2h(g_ctx, RFX_AS_RAW(o), dg, (size_t)nsel * 8) == RFX_OK;
-    }
-    if (dg) rfx_hip_free(g_ctx, dg);
-    if (d_ids) rfx_hip_free(g_ctx, d_ids);
-    if (!ok) { H.drop(rv); *res = fail_hip("projection"); return SEL_DONE; }
-    *res = H.table(H.clone(RFX_AS_LIST(tab)[0]), rv);
-    g_last_gpu = 1;
-    return SEL_DONE;
-}
-
-/* the key column(s) of a group-by result, read back in group order: one key as the cells the device emitted (the virtual Date column of a
- * parted table narrowed to 4-byte days, ENUM indices decoded through the enum's domain -- aggr_first, core/aggr.c:515-546); several keys
- * decoded from the composite key (key_i = min_i + (composite / mult_i) % range_i = key_i[first row], core/query.c:110-135) or, on the
- * row-hash path, gathered at the groups' first rows.  *ok carries the device-call status on; SEL_OUT: an enum whose domain does not
- * resolve (nothing is left allocated here). */
+/* the key column(s) of a group-by result, read back in group order from what the planner emitted: one key as its cells (the virtual Date
+ * column of a parted table narrowed to 4-byte days, ENUM indices decoded through the enum's domain -- aggr_first, core/aggr.c:515-546);
+ * several keys as the planner's key columns (decoded from the composite key = key_i[first row], core/query.c:110-135, or gathered at the
+ * groups' first rows on the row-hash path).  *ok carries the device-call status on; SEL_OUT: an enum whose domain does not resolve. */
 typedef struct {
     int nkeys;
     int8_t key_out_type;
     obj_p kenum;
-    int rowhash;
     obj_p *kcs;
-    const void **dks;
-    const int64_t *kmins, *kmaxs, *kmults;
 } sel_keys_t;
-static int sel_key_columns(const sel_keys_t *K, int64_t groups, const void *dkeys_out, const int64_t *d_comp, const int64_t *d_first, obj_p *okeys,
-                           obj_p *okcols, int *okp) {
+static int sel_key_columns(const sel_keys_t *K, const rfx_groups_t *R, obj_p *okcols, int *okp) {
     int ok = *okp;
+    const int64_t groups = R->groups;
     if (K->nkeys == 1 && K->key_out_type == RFX_TYPE_DATE) { /* the virtual Date column: 4-byte days */
-        *okeys = H.vector(RFX_TYPE_DATE, groups);
-        int64_t *k8 = (int64_t *)malloc((size_t)groups * 8);
-        ok = ok && k8 && fetch(k8, dkeys_out, (size_t)groups * 8) == RFX_OK;
-        for (int64_t g = 0; g < groups && ok; g++) ((int32_t *)RFX_AS_RAW(*okeys))[g] = (int32_t)k8[g];
+        okcols[0] = H.vector(RFX_TYPE_DATE, groups);
+        int64_t *k8 = (int64_t *)malloc((size_t)(groups ? groups : 1) * 8);
+        ok = ok && k8 && rfx_exec_groups_fetch(g_x, R, k8, R->d_keys, (size_t)groups * 8) == RFX_OK;
+        for (int64_t g = 0; g < groups && ok; g++) ((int32_t *)RFX_AS_RAW(okcols[0]))[g] = (int32_t)k8[g];
         free(k8);
     } else if (K->nkeys == 1) {
-        *okeys = H.vector(K->key_out_type, groups);
-        if (ok) ok = fetch(RFX_AS_RAW(*okeys), dkeys_out, (size_t)groups * 8) == RFX_OK;
+        okcols[0] = H.vector(K->key_out_type, groups);
+        if (ok) ok = rfx_exec_groups_fetch(g_x, R, RFX_AS_RAW(okcols[0]), R->d_keys, (size_t)groups * 8) == RFX_OK;
         if (ok && K->kenum) { /* indices -> symbols of the enum's domain (the global its key names) */
             obj_p dom = enum_domain(K->kenum);
             int good = dom != NULL;
-            int64_t *kk = RFX_AS_I64(*okeys);
+            int64_t *kk = RFX_AS_I64(okcols[0]);
             for (int64_t g = 0; g < groups && good; g++) {
                 if (kk[g] < 0 || kk[g] >= dom->len) good = 0;
                 else kk[g] = RFX_AS_I64(dom)[kk[g]];
             }
             if (dom) H.drop(dom);
             if (!good) {
-                H.drop(*okeys);
-                *okeys = NULL;
+                H.drop(okcols[0]);
+                okcols[0] = NULL;
                 return SEL_OUT;
             }
         }
     } else {
-        void *cell = NULL; /* one key column at a time on the device */
-        ok = ok && rfx_hip_malloc(g_ctx, &cell, (size_t)groups * 8) == RFX_OK;
         for (int i = 0; i < K->nkeys && ok; i++) {
             okcols[i] = H.vector(K->kcs[i]->type, groups);
-            ok = (K->rowhash ? rfx_hip_gather(g_ctx, K->dks[i], d_first, groups, cell)
-                             : rfx_hip_composite_decode(g_ctx, d_comp, groups, K->kmins[i], K->kmults[i], K->kmaxs[i] - K->kmins[i] + 1, (int64_t *)cell)) == RFX_OK &&
-                 rfx_hip_d2h(g_ctx, RFX_AS_RAW(okcols[i]), cell, (size_t)groups * 8) == RFX_OK;
+            ok = rfx_exec_groups_fetch(g_x, R, RFX_AS_RAW(okcols[i]), R->d_keycols[i], (size_t)groups * 8) == RFX_OK;
         }
-        if (cell) rfx_hip_free(g_ctx, cell);
     }
     *okp = ok;
     return SEL_GO;
@@ -1421,50 +1511,103 @@ static int sel_by_shape(obj_p tab, obj_p by, obj_p *kcs, int64_t *knames, int64_
     return SEL_GO;
 }
 
-/* A nested boolean tree over aggregates: the reference's own plan (filter_collect, then fold / group -- core/filter.c:51-165), on the device:
- * where -> ids, then every device column the aggregates read (plain arguments, single-operation operands, expression-tree leaves) and the
- * key column are gathered at the ids and the descriptors repointed; *nrows becomes the number of selected rows.  The gathered columns
- * join the query's scratch list (tmp) and are freed with it. */
-static int sel_gather_selected(obj_p tab, obj_p where, const wplan_t *wp, sel_maps_t *M, const void **dk, void **tmp, int *ntmp, int64_t *nrows, obj_p *res,
-                               const char **why) {
-    int64_t *d_ids = NULL, nsel = 0;
-    const int rc = where_ids(tab, where, wp, 0, *nrows, &d_ids, &nsel);
-    if (rc == -1) { *why = "where: shape"; return SEL_OUT; }
-    if (rc) { *res = fail_hip("where"); return SEL_DONE; }
+/* select without aggregates: filter_collect of every column (core/filter.c:51-165) -- where -> ids (every shard its own, rfx_exec_where) ->
+ * every column gathered at them where its rows live, straight into the result vectors */
+static int sel_projection(obj_p tab, const rfx_query_t *Q, int parted, obj_p *res, const char **why) {
+    obj_p tcols = RFX_AS_LIST(tab)[1];
+    if (parted) { *why = "parted table: projection"; return SEL_OUT; } /* the reference keeps such a result lazy (filter maps over the partitions) */
+    if (!Q->npred && !Q->d_mask) { *res = H.clone(tab); g_last_gpu = 1; return SEL_DONE; }
+    for (int64_t i = 0; i < tcols->len; i++)
+        if (!col_ctype(RFX_AS_LIST(tcols)[i])) { *why = "projection of a non-8-byte column"; return SEL_OUT; }
+    rfx_ids_t ids;
+    if (rfx_exec_where(g_x, Q, &ids) != RFX_OK) { *res = fail(rfx_exec_last_error(g_x)); return SEL_DONE; }
+    const int64_t nsel = ids.total;
+    obj_p rv = H.vector(RFX_TYPE_LIST, tcols->len);
     int ok = 1;
-    const void *seen_src[RFX_MAX_AGGS * (2 + 2 * RFX_MAX_XNODES) + 1];
-    void *seen_dst[RFX_MAX_AGGS * (2 + 2 * RFX_MAX_XNODES) + 1];
-    int nseen = 0;
-    const void **slots[RFX_MAX_AGGS * (2 + 2 * RFX_MAX_XNODES) + 1];
-    int nslots = 0;
-    for (int a = 0; a < M->nagg; a++) {
-        slots[nslots++] = &M->aggs[a].d_col;
-        slots[nslots++] = &M->aggs[a].d_xrhs_col;
-        for (int j = 0; j < M->aggs[a].nxnodes; j++) {
-            if (M->xnodes[a][j].l.kind == RFX_XK_COL) slots[nslots++] = &M->xnodes[a][j].l.d_col;
-            if (M->xnodes[a][j].r.kind == RFX_XK_COL) slots[nslots++] = &M->xnodes[a][j].r.d_col;
+    for (int64_t i = 0; i < tcols->len && ok; i++) {
+        obj_p c = RFX_AS_LIST(tcols)[i];
+        obj_p o = H.vector(c->type, nsel);
+        RFX_AS_LIST(rv)[i] = o;
+        const void *dc;
+        if (nsel == 0) continue;
+        ok = resident(c, 0, &dc) == RFX_OK;
+        int64_t at = 0;
+        for (int sh = 0; sh < ids.nshards && ok; sh++) {
+            if (!ids.count[sh]) continue;
+            int64_t r0;
+            rfx_exec_split(Q->nrows, ids.nshards, sh, &r0, NULL);
+            const void *dcs = dc; /* this shard's slice, addressed by the GLOBAL ids it emitted */
+            for (int k = 0; k < g_nqcols && sh > 0; k++)
+                if (g_qcols[k].d[0] == dc) dcs = g_qcols[k].d[sh];
+            void *dg = NULL;
+            if (g_nshards > 1) rfx_hip_ctx_bind_thread(g_ctxs[sh]);
+            ok = rfx_hip_malloc(g_ctxs[sh], &dg, (size_t)ids.count[sh] * 8) == RFX_OK &&
+                 rfx_hip_gather(g_ctxs[sh], (const char *)dcs - (size_t)r0 * 8, ids.d_ids[sh], ids.count[sh], dg) == RFX_OK &&
+                 rfx_hip_d2h(g_ctxs[sh], (char *)RFX_AS_RAW(o) + (size_t)at * 8, dg, (size_t)ids.count[sh] * 8) == RFX_OK;
+            if (dg) rfx_hip_free(g_ctxs[sh], dg);
+            at += ids.count[sh];
+        }
+        if (g_nshards > 1) rfx_hip_ctx_bind_thread(g_ctx);
+    }
+    rfx_exec_ids_free(g_x, &ids);
+    if (!ok) { H.drop(rv); *res = fail_hip("projection"); return SEL_DONE; }
+    *res = H.table(H.clone(RFX_AS_LIST(tab)[0]), rv);
+    g_last_gpu = 1;
+    return SEL_DONE;
+}
+
+/* rfx_select = PLAN (the dict's clauses as descriptors over resident columns: sel_mappings, plan_where, sel_by_shape -- and what the
+ * reference answers differently is handed back before anything runs) -> RUN (the planner: rfx_exec_group_by / rfx_exec_filter_aggr /
+ * rfx_exec_where over the operator layer's shards) -> BUILD (the result table from the planner's device columns). */
+static obj_p sel_build_groups(const rfx_groups_t *R, const sel_maps_t *M, const sel_keys_t *K, const int64_t *knames, const char **why) {
+    const int nagg = M->nagg, nkeys = K->nkeys;
+    obj_p ocols[RFX_MAX_AGGS] = {0}, okcols[RFX_MAX_KEYS] = {0};
+    int ok = 1;
+    if (R->groups > 0) {
+        if (sel_key_columns(K, R, okcols, &ok) == SEL_OUT) {
+            *why = "by: enum column whose domain cannot be resolved";
+            return NULL;
+        }
+        for (int a = 0; a < nagg && ok; a++) {
+            ocols[a] = H.vector((int8_t)M->outtype[a], R->groups);
+            if (IS_I32_FAMILY(M->outtype[a])) {
+                int64_t *c8 = (int64_t *)malloc((size_t)R->groups * 8);
+                ok = c8 && rfx_exec_groups_fetch(g_x, R, c8, R->d_results[a], (size_t)R->groups * 8) == RFX_OK;
+                if (ok) sel_narrow_i32(ocols[a], c8, R->groups, M->aggs[a].kind);
+                free(c8);
+            } else ok = rfx_exec_groups_fetch(g_x, R, RFX_AS_RAW(ocols[a]), R->d_results[a], (size_t)R->groups * 8) == RFX_OK;
         }
     }
-    if (dk) slots[nslots++] = dk;
-    for (int si = 0; si < nslots && ok; si++) {
-        const void **slot = slots[si];
-        if (!*slot) continue;
-        int j = 0;
-        for (; j < nseen; j++)
-            if (seen_src[j] == *slot) break;
-        if (j == nseen) { /* a column several descriptors read is gathered once */
-            void *g = NULL;
-            ok = rfx_hip_malloc(g_ctx, &g, (size_t)(nsel ? nsel : 1) * 8) == RFX_OK && (nsel == 0 || rfx_hip_gather(g_ctx, *slot, d_ids, nsel, g) == RFX_OK);
-            if (g) tmp[(*ntmp)++] = g;
-            seen_src[nseen] = *slot;
-            seen_dst[nseen++] = g;
-        }
-        if (ok) *slot = seen_dst[j];
+    if (!ok) {
+        for (int i = 0; i < nkeys; i++) if (okcols[i]) H.drop(okcols[i]);
+        for (int a = 0; a < nagg; a++) if (ocols[a]) H.drop(ocols[a]);
+        return fail_hip("group-by result");
     }
-    if (d_ids) rfx_hip_free(g_ctx, d_ids);
-    if (!ok) { *res = fail_hip("gather"); return SEL_DONE; }
-    *nrows = nsel;
-    return SEL_GO;
+    obj_p rk = H.vector(RFX_TYPE_SYMBOL, nagg + nkeys), rv = H.vector(RFX_TYPE_LIST, nagg + nkeys);
+    for (int i = 0; i < nkeys; i++) {
+        RFX_AS_I64(rk)[i] = knames[i];
+        RFX_AS_LIST(rv)[i] = okcols[i] ? okcols[i] : H.vector(nkeys == 1 ? K->key_out_type : K->kcs[i]->type, 0);
+    }
+    for (int a = 0; a < nagg; a++) {
+        RFX_AS_I64(rk)[a + nkeys] = M->names[a];
+        RFX_AS_LIST(rv)[a + nkeys] = ocols[a] ? ocols[a] : H.vector((int8_t)M->outtype[a], 0);
+    }
+    return H.table(rk, rv);
+}
+static obj_p sel_build_scalar(const rfx_value_t *vals, const sel_maps_t *M) {
+    const int nagg = M->nagg;
+    obj_p rk = H.vector(RFX_TYPE_SYMBOL, nagg), rv = H.vector(RFX_TYPE_LIST, nagg);
+    for (int a = 0; a < nagg; a++) {
+        RFX_AS_I64(rk)[a] = M->names[a];
+        if (IS_I32_FAMILY(M->outtype[a])) {
+            RFX_AS_LIST(rv)[a] = H.vector((int8_t)M->outtype[a], 1);
+            sel_narrow_i32(RFX_AS_LIST(rv)[a], &vals[a].i, 1, M->aggs[a].kind);
+        } else {
+            RFX_AS_LIST(rv)[a] = one_row(&vals[a]);
+            if (M->outtype[a] == RFX_TYPE_TIMESTAMP && vals[a].type != RFX_F64) RFX_AS_LIST(rv)[a]->type = RFX_TYPE_TIMESTAMP; /* min / max / first of a TIMESTAMP column */
+        }
+    }
+    return H.table(rk, rv);
 }
 
 static obj_p select_impl(obj_p dict) {
@@ -1483,26 +1626,28 @@ static obj_p select_impl(obj_p dict) {
     int parted = 0;
     obj_p res = NULL;
     const char *why = NULL;
-    void *tmp[RFX_MAX_AGGS * (2 + 2 * RFX_MAX_XNODES) + 2 * RFX_MAX_KEYS + 6]; /* device scratch of this query (gathered columns, bucket / composite keys): freed at `done` */
+    void *tmp[2 * RFX_MAX_KEYS + 6]; /* device scratch of this query on shard 0 (a mask): freed at `done` */
     int ntmp = 0;
     obj_p where = dict_get(dict, "where"), by = dict_get(dict, "by");
     obj_p dkeys = RFX_AS_LIST(dict)[0], dvals = RFX_AS_LIST(dict)[1];
     if (tab->type != RFX_TYPE_TABLE) { why = "from: is not a table"; goto out; }
     if (ensure_ctx() != RFX_OK) { res = fail_hip("no usable MI355X"); goto done; }
     if (is_parted_table(host_tab)) {
+        if (g_nshards > 1) { why = "parted table: the sharded operator layer takes in-memory tables"; goto out; }
         tab = parted_view(host_tab);
         if (!tab) { parted_view_release(); tab = host_tab; why = "parted table: view"; goto out; }
         parted = 1;
     }
     {
+        /* ---------------------------------------------------------------- PLAN */
         obj_p tcols = RFX_AS_LIST(tab)[1];
-        int64_t nrows = tcols->len ? RFX_AS_LIST(tcols)[0]->len : 0;
+        const int64_t nrows = tcols->len ? RFX_AS_LIST(tcols)[0]->len : 0;
         wplan_t wp;
         int flat = 1;
         g_where_virtual = g_where_data = 0;
         int rc = plan_where(tab, where, &wp);
         if (rc == -2) { res = fail_hip("column upload"); goto done; }
-        if (rc) { /* deeper than (and|or (cmp | (or|and cmp ...)) ...): evaluated through masks */
+        if (rc) { /* more comparisons / levels than the fused form carries: its selection comes as a mask */
             flat = 0;
             wp.npred = 0;
             wp.logic = RFX_AND;
@@ -1518,26 +1663,17 @@ static obj_p select_impl(obj_p dict) {
             if (g_where_virtual && g_where_data) { why = "parted table: where: mixes the virtual column with data columns"; goto out; }
             if (by && g_where_data) { why = "parted table: by: under a data-column filter"; goto out; }
         }
-        /* output mappings */
         sel_maps_t M;
         {
             const int mrc = sel_mappings(tab, dkeys, dvals, by != NULL, &M, &why);
             if (mrc == SEL_DONE) { res = fail_hip("column upload"); goto done; }
             if (mrc == SEL_OUT) goto out;
         }
-        rfx_agg_t *const aggs = M.aggs;
-        const int64_t *const names = M.names;
-        const int *const outtype = M.outtype;
-        const int nagg = M.nagg;
-        /* by: a column symbol, or a dict {name: column ...} (get_gkeys / get_gvals, core/query.c:165-240).  Several key
-         * columns fold into one composite key (index_group_list_perfect, core/index.c:2308-2424). */
+        /* by: a column symbol, or a dict {name: column ...} (get_gkeys / get_gvals, core/query.c:165-240) */
         obj_p kcs[RFX_MAX_KEYS] = {0};
         const void *dks[RFX_MAX_KEYS] = {0};
         int64_t knames[RFX_MAX_KEYS], kxbar[RFX_MAX_KEYS] = {0};
         int nkeys = 0;
-        const void *dk = NULL;
-        int64_t kmins[RFX_MAX_KEYS], kmaxs[RFX_MAX_KEYS], kmults[RFX_MAX_KEYS], comp_max = 0;
-        int rowhash = 0, nagg_run = 0;            /* row-hash path: the key tuples group on the reference's row hash */
         int8_t key_out_type = RFX_TYPE_I64; /* one key: type of the result's key column */
         obj_p kenum = NULL;                 /* one key, an ENUM column */
         if (by) {
@@ -1565,332 +1701,79 @@ static obj_p select_impl(obj_p dict) {
                     why = "by: key is not an 8-byte integer column";
                     goto out;
                 }
+                if (kxbar[i] > 0 && kcs[i]->type == RFX_TYPE_SYMBOL) { why = "xbar over a symbol column"; goto out; }
                 if (nkeys == 1 && !parted) key_out_type = kcs[i]->type;
                 if (resident(kcs[i], 0, &dks[i]) != RFX_OK) { res = fail_hip("column upload"); goto done; }
-                if (kxbar[i] > 0) { /* ray_xbar, core/math.c:1635: the reference evaluates the bucket column before grouping, so do we */
-                    if (kcs[i]->type == RFX_TYPE_SYMBOL) { why = "xbar over a symbol column"; goto out; }
-                    void *xb = NULL;
-                    if (rfx_hip_malloc(g_ctx, &xb, (size_t)(nrows ? nrows : 1) * 8) != RFX_OK) { res = fail_hip("xbar key"); goto done; }
-                    tmp[ntmp++] = xb;
-                    if (rfx_hip_xbar_i64(g_ctx, (const int64_t *)dks[i], nrows, kxbar[i], (int64_t *)xb) != RFX_OK) { res = fail_hip("xbar key"); goto done; }
-                    dks[i] = xb;
-                }
             }
             /* where: + several keys: the reference's own result is defective (its composite index drops the filter, so key
              * columns and aggregates are taken from the wrong rows -- DESIGN.md "reference defects"); leave that to the host
              * so that this entry point never answers differently from ray_select. */
             if (nkeys > 1 && where) { why = "where: with several by: columns"; goto out; }
-            dk = dks[0];
         }
-        if (!by && nagg == 0) { /* projection */
-            if (sel_projection(tab, where, &wp, flat, parted, nrows, &res, &why) == SEL_OUT) goto out;
+        rfx_query_t Q;
+        memset(&Q, 0, sizeof(Q));
+        Q.preds = wp.preds;
+        Q.npred = wp.npred;
+        Q.logic = wp.logic;
+        Q.aggs = M.aggs;
+        Q.nagg = M.nagg;
+        Q.nkeys = nkeys;
+        Q.d_keys = dks;
+        Q.kxbar = kxbar;
+        Q.nrows = nrows;
+        if (!flat) { /* the tree as ONE B8 mask on the device (core/cmp.c -> K2, core/logic.c in place), handed to the planner beside the query */
+            if (g_nshards > 1) { why = "sharded table: where: tree beyond the fused form"; goto out; }
+            int8_t *m = NULL;
+            const int mrc = mask_of_expr(tab, where, nrows, &m);
+            if (mrc == -1) { why = "where: shape"; goto out; }
+            if (mrc) { res = fail_hip("where"); goto done; }
+            tmp[ntmp++] = m;
+            Q.d_mask = m;
+        }
+        Q.cols = g_nshards > 1 ? g_qcols : NULL;
+        Q.ncols = g_nqcols;
+        tm_mark();
+        /* ---------------------------------------------------------------- RUN + BUILD */
+        if (!by && M.nagg == 0) { /* projection */
+            if (sel_projection(tab, &Q, parted, &res, &why) == SEL_OUT) goto out;
             goto done;
         }
-        if (!flat) { /* a where: tree the fused descriptors cannot express: ids through masks, then everything on gathered columns */
-            const int grc = sel_gather_selected(tab, where, &wp, &M, by ? &dk : NULL, tmp, &ntmp, &nrows, &res, &why);
-            if (grc == SEL_OUT) goto out;
-            if (grc == SEL_DONE) goto done;
-        }
-        /* Large inputs: the key scope(s) from a SAMPLE first (rfx_hip_scope_sample_i64) when the range is LDS-sized -- index_scope_i64's
-         * full pass is a quarter to a third of such a query -- with the kernels reporting any selected key outside it; a report (or a
-         * path that cannot report) comes back here for the exact scope.  RFX_NO_SAMPLED_SCOPE=1 turns it off. */
-        int spec_ok = by && nrows >= ((int64_t)1 << 24) && !getenv("RFX_NO_SAMPLED_SCOPE");
-        const void *spec_id = (nkeys > 0 && kcs[0]) ? (const void *)RFX_AS_RAW(kcs[0]) : NULL;
-        for (int i = 0; i < g_nspec_failed && spec_ok; i++) /* a sample that missed this key column's range before (a rare extreme value) will again */
-            if (g_spec_failed[i] == spec_id) spec_ok = 0;
-    rescope:;
-        int spec = 0;
-        if (g_spec_retry) { /* back here after a report */
-            g_spec_retry = 0;
-            g_stat[ST_SCOPE_RETRIED]++;
-            g_spec_failed[g_spec_ring++ % 32] = spec_id;
-            if (g_nspec_failed < 32) g_nspec_failed++;
-        }
         if (by) {
-            int64_t kmin, kmax, seen;
-            if (nkeys > 1) {
-                /* scopes of every key column, then the reference's multiplier plan (core/index.c:2340-2383); no where: here */
-                seen = 0;
-                if (spec_ok) {
-                    int64_t prod = 1;
-                    spec = 1;
-                    for (int i = 0; i < nkeys && spec; i++) {
-                        if (rfx_hip_scope_sample_i64(g_ctx, (const int64_t *)dks[i], nrows, &kmins[i], &kmaxs[i]) != RFX_OK) { res = fail_hip("scope"); goto done; }
-                        if (kmins[i] == RFX_NULL_I64 || kmaxs[i] < kmins[i] || (uint64_t)(kmaxs[i] - kmins[i]) >= RFX_SCOPE_SAMPLE_MAX_RANGE) spec = 0;
-                        else prod *= kmaxs[i] - kmins[i] + 1;
-                        if (prod > RFX_SCOPE_SAMPLE_MAX_RANGE) spec = 0;
-                    }
-                    if (spec) seen = nrows;
+            /* small inputs over a plain resident key column: its whole-column scope, remembered with the device copy (or taken now, without
+             * the filter: the same pass) -- a superset of any selection's, which is all the tables' sizing needs; the planner takes it when it
+             * is LDS-sized and saves the scope round trip */
+            int64_t kscope[2];
+            Q.flags = RFX_Q_REFUSE_NULL_KEY; /* the reference opens one group per null-key row (core/index.c:1808-1816): its own select answers those */
+            resident_t *ke = (g_nshards == 1 && nkeys == 1 && !parted && flat && nrows > 0 && nrows < ((int64_t)1 << 24) && !kxbar[0]) ? resident_entry(dks[0]) : NULL;
+            if (ke) {
+                if (!ke->scope_ok) {
+                    int64_t c0 = 0;
+                    if (rfx_hip_scope_i64(g_ctx, (const int64_t *)dks[0], NULL, 0, RFX_AND, nrows, &ke->smin, &ke->smax, &c0) != RFX_OK) { res = fail_hip("scope"); goto done; }
+                    ke->scope_ok = 1;
                 }
-                for (int i = 0; i < nkeys && !spec; i++)
-                    if (rfx_hip_scope_i64(g_ctx, (const int64_t *)dks[i], NULL, 0, RFX_AND, nrows, &kmins[i], &kmaxs[i], &seen) != RFX_OK) { res = fail_hip("scope"); goto done; }
-                kmin = 0;
-                kmax = -1;
-                if (seen > 0) {
-                    if (rfx_composite_plan(kmins, kmaxs, nkeys, kmults, &comp_max) != RFX_OK) {
-                        /* ranges beyond 64 bits / a null key: the reference's row-hash path (index_group_list, core/index.c:2731-2790).
-                         * Group on the reference's own row hash; the tuple comparison the reference makes on every probe
-                         * (__index_list_cmp_row) is made once, afterwards: every row against its group's first row (below). */
-                        void *hh = NULL;
-                        if (rfx_hip_malloc(g_ctx, &hh, (size_t)nrows * 8) != RFX_OK) { res = fail_hip("row hash"); goto done; }
-                        tmp[ntmp++] = hh;
-                        if (rfx_hip_row_hash(g_ctx, dks, nkeys, nrows, 0, (int64_t *)hh) != RFX_OK) { res = fail_hip("row hash"); goto done; }
-                        rowhash = 1;
-                        nagg_run = nagg;
-                        dk = hh;
-                        if (rfx_hip_scope_i64(g_ctx, (const int64_t *)hh, NULL, 0, RFX_AND, nrows, &kmin, &kmax, &seen) != RFX_OK) { res = fail_hip("scope"); goto done; }
-                    } else {
-                    kmax = comp_max; /* forced scope {0, max}, core/index.c:2421 */
-                    if ((uint64_t)comp_max + 1 > (uint64_t)seen) {
-                        /* sparse composite: the hashed path keys on the materialised column */
-                        void *comp = NULL;
-                        if (rfx_hip_malloc(g_ctx, &comp, (size_t)nrows * 8) != RFX_OK) { res = fail_hip("composite key"); goto done; }
-                        tmp[ntmp++] = comp;
-                        if (rfx_hip_composite_key(g_ctx, dks, kmins, kmults, nkeys, nrows, (int64_t *)comp) != RFX_OK) {
-                            res = fail_hip("composite key");
-                            goto done;
-                        }
-                        dk = comp;
-                    }
-                    }
-                }
-            } else {
-                tm_mark();
-                if (spec_ok) {
-                    if (rfx_hip_scope_sample_i64(g_ctx, (const int64_t *)dk, nrows, &kmin, &kmax) != RFX_OK) { res = fail_hip("scope"); goto done; }
-                    spec = kmin != RFX_NULL_I64 && kmax >= kmin && (uint64_t)(kmax - kmin) < RFX_SCOPE_SAMPLE_MAX_RANGE;
-                    seen = nrows;
-                }
-                /* small inputs, a plain resident key column: its whole-column scope, remembered (or taken now, without the filter: the same
-                 * pass) -- when it is LDS-sized the tables take it as it is; `seen` = every row (an upper bound: table sizing and the dense /
-                 * hashed choice only; an empty selection comes out as zero groups) */
-                resident_t *ke = (!spec && !parted && flat && nrows > 0 && nrows < ((int64_t)1 << 24) && dk == dks[0] && !kxbar[0]) ? resident_entry(dk) : NULL;
-                int cached = 0;
-                if (ke) {
-                    if (!ke->scope_ok) {
-                        int64_t c0 = 0;
-                        if (rfx_hip_scope_i64(g_ctx, (const int64_t *)dk, NULL, 0, RFX_AND, nrows, &ke->smin, &ke->smax, &c0) != RFX_OK) { res = fail_hip("scope"); goto done; }
-                        ke->scope_ok = 1;
-                    }
-                    if (ke->smin != RFX_NULL_I64 && ke->smax >= ke->smin && (uint64_t)(ke->smax - ke->smin) < RFX_SCOPE_SAMPLE_MAX_RANGE) {
-                        kmin = ke->smin;
-                        kmax = ke->smax;
-                        seen = nrows;
-                        cached = 1;
-                    }
-                }
-                if (!spec && !cached && rfx_hip_group_scope(g_ctx, (const int64_t *)dk, wp.preds, wp.npred, wp.logic, aggs, nagg, nrows, &kmin, &kmax, &seen) != RFX_OK) { res = fail_hip("scope"); goto done; }
+                kscope[0] = ke->smin;
+                kscope[1] = ke->smax;
+                Q.key_scope = kscope;
             }
+            rfx_groups_t R;
+            const int grc = rfx_exec_group_by(g_x, &Q, &R);
             tm_mark();
-            if (spec && rowhash) spec = 0; /* (cannot happen: the row-hash path needs ranges beyond 64 bits) */
-            if (spec) g_stat[ST_SCOPE_SAMPLED]++;
-            int64_t groups = 0;
-            if (!rowhash) nagg_run = nagg;
-            obj_p okeys = NULL, ocols[RFX_MAX_AGGS] = {0}, okcols[RFX_MAX_KEYS] = {0};
-            if (seen > 0 && nkeys == 1 && kmin == RFX_NULL_I64) {
-                /* a selected key is null: the reference's open-addressing table uses NULL_I64 as its EMPTY marker, so every null-key
-                 * row opens a group of its own there (core/index.c:1808-1816).  The device tables keep one null group; at this
-                 * boundary the answer must be the reference's, so the host's own select answers (the Python Engine documents the
-                 * one-group rule as its own semantics). */
-                why = "null group key";
-                goto out;
-            }
-            if (seen > 0) {
-                /* dense "perfect hash" iff range <= rows (core/index.c:2013), like the reference; else open addressing */
-                uint64_t range = (uint64_t)kmax - (uint64_t)kmin + 1;
-                int dense = range != 0 && range <= (uint64_t)seen && kmin != RFX_NULL_I64;
-                if (spec && !dense) { spec_ok = 0; goto rescope; } /* (not a miss of the sample: nothing to remember) */
-                int narr = 0;
-                rfx_hip_group_table_arrays(aggs, nagg_run, &narr);
-                int64_t cells = dense ? (int64_t)range : 0;
-                int64_t cap = 16, cap_max = 16;
-                if (!dense) {
-                    /* the reference sizes its table by the row count (ht_oa_create(len)); distinct keys are usually far fewer:
-                     * start at 4 M slots and grow x16 whenever the table reports full */
-                    while (cap_max < 2 * seen) cap_max <<= 1;
-                    cap = cap_max < (1 << 22) ? cap_max : (1 << 22);
-                    narr += 1;
-                }
-            grow:
-                if (!dense) cells = cap + 1;
-                void *store = NULL;
-                if (rfx_hip_malloc(g_ctx, &store, (size_t)narr * (size_t)cells * 8) != RFX_OK) { res = fail_hip("group tables"); goto done; }
-                int64_t *base = (int64_t *)store;
-                int k = 0, ok = 1;
-                rfx_group_tables_t gt;
-                rfx_hash_tables_t ht;
-                memset(&gt, 0, sizeof(gt));
-                memset(&ht, 0, sizeof(ht));
-                if (dense) { gt.kmin = kmin; gt.range = (int64_t)range; gt.nagg = nagg_run; gt.d_first = base + (k++) * cells; }
-                else { ht.capacity = cap; ht.nagg = nagg_run; ht.d_keys = base + (k++) * cells; ht.d_first = base + (k++) * cells; }
-                for (int a = 0; a < nagg_run; a++) {
-                    void *acc = base + (k++) * cells;
-                    int hc = aggs[a].kind == RFX_AGG_AVG || (aggs[a].kind == RFX_AGG_SUM && rfx_agg_input_type(&aggs[a]) == RFX_I64);
-                    int64_t *cnt = hc ? base + (k++) * cells : NULL;
-                    if (dense) { gt.d_acc[a] = acc; gt.d_cnt[a] = cnt; } else { ht.d_acc[a] = acc; ht.d_cnt[a] = cnt; }
-                }
-                void *dout = NULL;
-                int64_t *mirror = NULL;
-                const int small = dense && nkeys == 1 && range <= RFX_RANK_SMALL;
-                if (small) {
-                    /* few slots: init, accumulate, rank + emit are three launches and the result block comes back in one copy -- the
-                     * only host round trip after the scope pass (a dozen launches and three more round trips otherwise) */
-                    const size_t bcells = 1 + (size_t)(2 + nagg_run) * (size_t)range;
-                    void *blk = NULL;
-                    int pr = -1;
-                    ok = rfx_hip_malloc(g_ctx, &blk, bcells * 8) == RFX_OK && (mirror = (int64_t *)malloc(bcells * 8)) != NULL &&
-                         rfx_hip_group_tables_init(g_ctx, aggs, &gt) == RFX_OK &&
-                         (pr = dense_pass(spec, 0, dks, kmins, kmults, nkeys, dk, &wp, aggs, nrows, &gt)) == 0 &&
-                         rfx_hip_group_rank_emit_small(g_ctx, aggs, &gt, 0, 0, (int64_t *)blk) == RFX_OK &&
-                         rfx_hip_d2h(g_ctx, mirror, blk, bcells * 8) == RFX_OK;
-                    if (pr == 1) { /* the sampled scope did not hold: exact scope, again */
-                        if (blk) rfx_hip_free(g_ctx, blk);
-                        free(mirror);
-                        rfx_hip_free(g_ctx, store);
-                        spec_ok = 0;
-                        g_spec_retry = 1;
-                        goto rescope;
-                    }
-                    g_mirror_host = (const char *)mirror; /* released at `done` */
-                    g_mirror_dev = (const char *)blk;
-                    g_mirror_bytes = ok ? bcells * 8 : 0;
-                    if (ok) groups = mirror[0];
-                    dout = blk;
-                } else if (dense) {
-                    int pr = -1;
-                    ok = rfx_hip_group_tables_init(g_ctx, aggs, &gt) == RFX_OK &&
-                         (pr = dense_pass(spec, nkeys > 1 && !rowhash, dks, kmins, kmults, nkeys, dk, &wp, aggs, nrows, &gt)) == 0 &&
-                         rfx_hip_group_rank(g_ctx, &gt, nrows, &groups) == RFX_OK;
-                    if (pr == 1) {
-                        rfx_hip_free(g_ctx, store);
-                        spec_ok = 0;
-                        g_spec_retry = 1;
-                        goto rescope;
-                    }
-                } else {
-                    int arc = RFX_EINVAL;
-                    ok = rfx_hip_hash_tables_init(g_ctx, aggs, &ht) == RFX_OK &&
-                         (arc = rfx_hip_group_hash_accumulate(g_ctx, (const int64_t *)dk, wp.preds, wp.npred, wp.logic, aggs, nrows, 0, &ht)) == RFX_OK &&
-                         rfx_hip_hash_rank(g_ctx, &ht, nrows, &groups) == RFX_OK;
-                    if (!ok && arc == RFX_ELIMIT && cap < cap_max) { /* table full: grow and run again */
-                        rfx_hip_free(g_ctx, store);
-                        cap = cap_max; /* the launch gave up at 3/4 load, early: take the reference's size (2 x rows) */
-                        goto grow;
-                    }
-                }
-                if (ok && rowhash && groups > 0) {
-                    /* one hash = one tuple?  Every row's group-first row (the join probe against the group-by's own table), then per key
-                     * column: the column gathered at those rows must equal the column itself (K1 counts the rows where it does not). */
-                    void *ids = NULL, *chk = NULL;
-                    ok = rfx_hip_malloc(g_ctx, &ids, (size_t)nrows * 8) == RFX_OK && rfx_hip_malloc(g_ctx, &chk, (size_t)nrows * 8) == RFX_OK &&
-                         rfx_hip_join_probe_hash(g_ctx, (const int64_t *)dk, nrows, &ht, (int64_t *)ids) == RFX_OK;
-                    int collision = 0;
-                    for (int i = 0; i < nkeys && ok && !collision; i++) {
-                        rfx_pred_t ne;
-                        rfx_agg_t cnt;
-                        rfx_value_t cv;
-                        int64_t differ = 0;
-                        memset(&ne, 0, sizeof(ne));
-                        memset(&cnt, 0, sizeof(cnt));
-                        ne.d_col = chk;
-                        ne.col_type = RFX_I64;
-                        ne.op = RFX_NE;
-                        ne.d_rhs_col = dks[i];
-                        ne.rhs_type = RFX_I64;
-                        cnt.kind = RFX_AGG_COUNT;
-                        cnt.col_type = RFX_I64;
-                        ok = rfx_hip_gather_or(g_ctx, dks[i], dks[i], (const int64_t *)ids, nrows, 0, chk) == RFX_OK &&
-                             rfx_hip_filter_aggr_host(g_ctx, &ne, 1, RFX_AND, &cnt, 1, nrows, &cv, &differ) == RFX_OK;
-                        if (ok && differ) collision = 1;
-                    }
-                    if (ids) rfx_hip_free(g_ctx, ids);
-                    if (chk) rfx_hip_free(g_ctx, chk);
-                    if (ok && collision) { /* two key tuples, one 64-bit row hash: leave the query to the host rather than answer wrongly */
-                        rfx_hip_free(g_ctx, store);
-                        why = "row-hash collision between two key tuples";
-                        goto out;
-                    }
-                }
-                tm_mark();
-                const void *dkeys_out = NULL; /* device address of the result's key cells */
-                void *dfirst = NULL;          /* row-hash path: the groups' first rows (the key columns are gathered there) */
-                if (ok && groups > 0 && !small) ok = rfx_hip_malloc(g_ctx, &dout, (size_t)(nagg_run + 1) * (size_t)groups * 8) == RFX_OK;
-                if (ok && groups > 0 && rowhash) ok = rfx_hip_malloc(g_ctx, &dfirst, (size_t)groups * 8) == RFX_OK;
-                if (ok && groups > 0) {
-                    void *ptrs[RFX_MAX_AGGS];
-                    if (small) {
-                        dkeys_out = (int64_t *)dout + 1;
-                        for (int a = 0; a < nagg_run; a++) ptrs[a] = (int64_t *)dout + 1 + (size_t)(2 + a) * (size_t)range;
-                    } else {
-                        dkeys_out = dout;
-                        for (int a = 0; a < nagg_run; a++) ptrs[a] = (int64_t *)dout + (size_t)(a + 1) * groups;
-                        ok = (dense ? rfx_hip_group_emit(g_ctx, aggs, &gt, (int64_t *)dout, NULL, ptrs) : rfx_hip_hash_emit(g_ctx, aggs, &ht, (int64_t *)dout, (int64_t *)dfirst, ptrs)) == RFX_OK;
-                    }
-                    tm_mark();
-                    {
-                        const sel_keys_t K = {nkeys, key_out_type, kenum, rowhash, kcs, dks, kmins, kmaxs, kmults};
-                        const int krc = sel_key_columns(&K, groups, dkeys_out, (const int64_t *)dout, (const int64_t *)dfirst, &okeys, okcols, &ok);
-                        if (krc == SEL_OUT) {
-                            if (dout) rfx_hip_free(g_ctx, dout);
-                            rfx_hip_free(g_ctx, store);
-                            why = "by: enum column whose domain cannot be resolved";
-                            goto out;
-                        }
-                    }
-                    for (int a = 0; a < nagg && ok; a++) {
-                        ocols[a] = H.vector((int8_t)outtype[a], groups);
-                        if (IS_I32_FAMILY(outtype[a])) {
-                            int64_t *c8 = (int64_t *)malloc((size_t)(groups ? groups : 1) * 8);
-                            ok = c8 && fetch(c8, ptrs[a], (size_t)groups * 8) == RFX_OK;
-                            if (ok) sel_narrow_i32(ocols[a], c8, groups, aggs[a].kind);
-                            free(c8);
-                        } else ok = fetch(RFX_AS_RAW(ocols[a]), ptrs[a], (size_t)groups * 8) == RFX_OK;
-                    }
-                }
-                tm_mark();
-                if (dout) rfx_hip_free(g_ctx, dout);
-                if (dfirst) rfx_hip_free(g_ctx, dfirst);
-                rfx_hip_free(g_ctx, store);
-                if (!ok) {
-                    if (okeys) H.drop(okeys);
-                    for (int i = 0; i < nkeys; i++) if (okcols[i]) H.drop(okcols[i]);
-                    for (int a = 0; a < nagg; a++) if (ocols[a]) H.drop(ocols[a]);
-                    res = fail_hip("group-by");
-                    goto done;
-                }
-            }
-            if (nkeys == 1) okcols[0] = okeys ? okeys : H.vector(key_out_type, 0);
-            obj_p rk = H.vector(RFX_TYPE_SYMBOL, nagg + nkeys), rv = H.vector(RFX_TYPE_LIST, nagg + nkeys);
-            for (int i = 0; i < nkeys; i++) {
-                RFX_AS_I64(rk)[i] = knames[i];
-                RFX_AS_LIST(rv)[i] = okcols[i] ? okcols[i] : H.vector(kcs[i]->type, 0);
-            }
-            for (int a = 0; a < nagg; a++) {
-                RFX_AS_I64(rk)[a + nkeys] = names[a];
-                RFX_AS_LIST(rv)[a + nkeys] = ocols[a] ? ocols[a] : H.vector((int8_t)outtype[a], 0);
-            }
-            res = H.table(rk, rv);
-            g_last_gpu = 1;
+            if (grc == RFX_EXEC_NULL_KEY) { why = "null group key"; goto out; }
+            if (grc == RFX_ESTATE && strstr(rfx_exec_last_error(g_x), "collision")) { why = "row-hash collision between two key tuples"; goto out; }
+            if (grc == RFX_ELIMIT && g_nshards > 1) { why = "sharded table: shape the planner runs on one shard"; goto out; }
+            if (grc != RFX_OK) { res = fail(rfx_exec_last_error(g_x)); goto done; }
+            const sel_keys_t K = {nkeys, key_out_type, kenum, kcs};
+            res = sel_build_groups(&R, &M, &K, knames, &why);
+            rfx_exec_groups_free(g_x, &R);
+            tm_mark();
+            if (!res) goto out;
+            g_last_gpu = res->type == RFX_TYPE_TABLE;
             goto done;
         }
         rfx_value_t vals[RFX_MAX_AGGS];
         int64_t selected = 0;
-        {
-            int frc = rfx_hip_filter_aggr_host(g_ctx, wp.preds, wp.npred, wp.logic, aggs, nagg, nrows, vals, &selected);
-            if (frc != RFX_OK) { res = fail_hip("filter_aggr"); goto done; }
-        }
-        obj_p rk = H.vector(RFX_TYPE_SYMBOL, nagg), rv = H.vector(RFX_TYPE_LIST, nagg);
-        for (int a = 0; a < nagg; a++) {
-            RFX_AS_I64(rk)[a] = names[a];
-            if (IS_I32_FAMILY(outtype[a])) {
-                RFX_AS_LIST(rv)[a] = H.vector((int8_t)outtype[a], 1);
-                sel_narrow_i32(RFX_AS_LIST(rv)[a], &vals[a].i, 1, aggs[a].kind);
-            } else {
-                RFX_AS_LIST(rv)[a] = one_row(&vals[a]);
-                if (outtype[a] == RFX_TYPE_TIMESTAMP && vals[a].type != RFX_F64) RFX_AS_LIST(rv)[a]->type = RFX_TYPE_TIMESTAMP; /* min / max / first of a TIMESTAMP column */
-            }
-        }
-        res = H.table(rk, rv);
+        if (rfx_exec_filter_aggr(g_x, &Q, vals, &selected) != RFX_OK) { res = fail(rfx_exec_last_error(g_x)); goto done; }
+        res = sel_build_scalar(vals, &M);
         g_last_gpu = 1;
         goto done;
     }
@@ -1905,8 +1788,6 @@ done:
     for (int i = 0; i < ntmp; i++) rfx_hip_free(g_ctx, tmp[i]);
     qtmp_release();
     if (parted) parted_view_release();
-    free((void *)g_mirror_host);
-    g_mirror_host = NULL;
     H.drop(host_tab);
     tm_mark();
     tm_print();
@@ -1987,7 +1868,7 @@ static obj_p update_impl(obj_p dict) {
     if (nrows == 0) { why = "empty table"; goto out; }
     for (int64_t i = 0; i < tcols->len; i++)
         if (RFX_AS_LIST(tcols)[i]->len != nrows) { why = "ragged table"; goto out; }
-    if (ensure_ctx() != RFX_OK) { res = fail_hip("no usable MI355X"); goto done; }
+    if (ensure_ctx1() != RFX_OK) { res = fail_ctx(); goto done; }
     {
         /* ---- where: -> row ids (ray_where) ---- */
         wplan_t wp;
@@ -2170,7 +2051,7 @@ static obj_p cmp_impl(int op, obj_p x, obj_p y) {
         return fail("cmp: only i64/f64 column (x) atom|column runs on the MI355X path");
     }
     if (y->type > 0 && y->len != x->len) return fail("length"); /* err_length, core/cmp.c:633-640 */
-    if (ensure_ctx() != RFX_OK) return fail_hip("no usable MI355X");
+    if (ensure_ctx1() != RFX_OK) return fail_ctx();
     rfx_pred_t p;
     memset(&p, 0, sizeof(p));
     const void *d;
@@ -2210,7 +2091,7 @@ static obj_p arith_impl(int xop, int fidx, obj_p x, obj_p y) {
         return fail("arith: only i64/f64 vector (x) vector|atom runs on the MI355X path");
     }
     if (xv && yv && x->len != y->len) return fail("length");
-    if (ensure_ctx() != RFX_OK) return fail_hip("no usable MI355X");
+    if (ensure_ctx1() != RFX_OK) return fail_ctx();
     rfx_agg_t a;
     memset(&a, 0, sizeof(a));
     a.kind = RFX_AGG_SUM;
@@ -2266,7 +2147,7 @@ static obj_p logic_op(int logic, obj_p *x, int64_t n) {
     if (n == 0) return rfx_host_b8(0); /* logic_map: (and) -> false, core/logic.c:96-97 */
     for (int64_t i = 0; i < n; i++)
         if (!x[i] || x[i]->type != RFX_TYPE_B8 || x[i]->len != x[0]->len) return fail("and/or: expected B8 masks of one length");
-    if (ensure_ctx() != RFX_OK) return fail_hip("no usable MI355X");
+    if (ensure_ctx1() != RFX_OK) return fail_ctx();
     int64_t len = x[0]->len;
     void *acc = NULL, *nxt = NULL;
     if (rfx_hip_malloc(g_ctx, &acc, (size_t)len + 8) != RFX_OK || rfx_hip_malloc(g_ctx, &nxt, (size_t)len + 8) != RFX_OK) return fail_hip("mask");
@@ -2362,7 +2243,7 @@ static obj_p sf_logic_impl(int f, obj_p *x, int64_t n) {
         RFX_AS_LIST(tree)[1 + i] = r ? r : (H.null_obj ? H.null_obj : rfx_host_null());
     }
     if (ok && c.n == 0) { ok = 0; why = "no vector operand"; }
-    if (ok && ensure_ctx() != RFX_OK) { res = fail_hip("no usable MI355X"); ok = 0; }
+    if (ok && ensure_ctx1() != RFX_OK) { res = fail_ctx(); ok = 0; }
     if (ok) {
         obj_p names = H.vector(RFX_TYPE_SYMBOL, c.n), cols = H.vector(RFX_TYPE_LIST, c.n);
         for (int k = 0; k < c.n; k++) {
@@ -2408,7 +2289,7 @@ rfx_obj_p rfx_or_sf(rfx_obj_p *x, int64_t n) { return sf_logic(F_OR, x, n); }
 static obj_p where_impl(obj_p mask) {
     rfx_host_bind();
     if (!mask || mask->type != RFX_TYPE_B8) return fail("where: expected a B8 mask"); /* err_type, core/items.c:1395 */
-    if (ensure_ctx() != RFX_OK) return fail_hip("no usable MI355X");
+    if (ensure_ctx1() != RFX_OK) return fail_ctx();
     const void *dm;
     if (transient(mask, &dm) != RFX_OK) return fail_hip("mask upload"); /* a mask is a temporary: per-call scratch, never cached */
     int64_t count = 0;
@@ -2464,86 +2345,19 @@ static obj_p join_impl(int inner, obj_p *x, int64_t n) {
         if (!col_ctype(rc)) { why = "non-8-byte column"; goto out; }
         if (lc && lc->type != rc->type) return fail("join: a column has different types in the two tables"); /* err_type, core/join.c:50-51 */
     }
-    if (ensure_ctx() != RFX_OK) return fail_hip("no usable MI355X");
+    if (ensure_ctx1() != RFX_OK) return fail_ctx();
     for (int i = 0; i < nk; i++)
         if (resident(lk[i], 0, &dlk[i]) != RFX_OK || resident(rk[i], 0, &drk[i]) != RFX_OK) { res = fail_hip("column upload"); goto done; }
 #define JOIN_TMP(ptr, bytes) do { ptr = NULL; if (rfx_hip_malloc(g_ctx, &ptr, (bytes)) != RFX_OK) { res = fail_hip("join scratch"); goto done; } tmp[ntmp++] = ptr; } while (0)
-    const void *lkey = dlk[0], *rkey = drk[0];
-    int exact = 1;
-    if (nk > 1) {
-        int64_t mins[RFX_MAX_KEYS], maxs[RFX_MAX_KEYS], mults[RFX_MAX_KEYS], tmax = 0, seen = 0;
-        for (int i = 0; i < nk; i++) { /* scopes over BOTH sides: one injective composite key per side when they multiply into 64 bits */
-            int64_t a0, a1, b0, b1;
-            if (rfx_hip_scope_i64(g_ctx, (const int64_t *)dlk[i], NULL, 0, RFX_AND, nl, &a0, &a1, &seen) != RFX_OK ||
-                rfx_hip_scope_i64(g_ctx, (const int64_t *)drk[i], NULL, 0, RFX_AND, nr, &b0, &b1, &seen) != RFX_OK) { res = fail_hip("scope"); goto done; }
-            mins[i] = a0 < b0 ? a0 : b0;
-            maxs[i] = a1 > b1 ? a1 : b1;
-        }
-        void *lc = NULL, *rc = NULL;
-        JOIN_TMP(lc, (size_t)nl * 8);
-        JOIN_TMP(rc, (size_t)nr * 8);
-        if (rfx_composite_plan(mins, maxs, nk, mults, &tmax) == RFX_OK) {
-            if (rfx_hip_composite_key(g_ctx, dlk, mins, mults, nk, nl, (int64_t *)lc) != RFX_OK || rfx_hip_composite_key(g_ctx, drk, mins, mults, nk, nr, (int64_t *)rc) != RFX_OK) { res = fail_hip("composite key"); goto done; }
-        } else { /* the reference's own route: its row hash; matched rows are compared column by column below */
-            if (rfx_hip_row_hash(g_ctx, dlk, nk, nl, 0, (int64_t *)lc) != RFX_OK || rfx_hip_row_hash(g_ctx, drk, nk, nr, 0, (int64_t *)rc) != RFX_OK) { res = fail_hip("row hash"); goto done; }
-            exact = 0;
-        }
-        lkey = lc;
-        rkey = rc;
-    }
+    /* the join index -- per left row the first right row with an equal key tuple, or null -- is the planner's (rfx_exec_join_index: dense
+     * first-occurrence table or the hashed one, composite key or the reference's row hash + the tuple check) */
     void *ids = NULL;
     JOIN_TMP(ids, (size_t)nl * 8);
     {
-        int64_t kmin, kmax, seen = 0;
-        if (rfx_hip_scope_i64(g_ctx, (const int64_t *)rkey, NULL, 0, RFX_AND, nr, &kmin, &kmax, &seen) != RFX_OK) { res = fail_hip("scope"); goto done; }
-        const uint64_t range = (uint64_t)kmax - (uint64_t)kmin + 1;
-        rfx_agg_t none;
-        memset(&none, 0, sizeof(none));
-        uint64_t lim = 4 * (uint64_t)nr > (1u << 24) ? 4 * (uint64_t)nr : (1u << 24);
-        if (range != 0 && range <= lim && range <= (1ull << 29) && kmin != RFX_NULL_I64) {
-            void *first = NULL;
-            JOIN_TMP(first, (size_t)range * 8);
-            rfx_group_tables_t gt;
-            memset(&gt, 0, sizeof(gt));
-            gt.kmin = kmin; gt.range = (int64_t)range; gt.nagg = 0; gt.d_first = (int64_t *)first;
-            if (rfx_hip_group_tables_init(g_ctx, &none, &gt) != RFX_OK || rfx_hip_group_dense_accumulate(g_ctx, (const int64_t *)rkey, NULL, 0, RFX_AND, &none, nr, 0, &gt) != RFX_OK ||
-                rfx_hip_join_probe_dense(g_ctx, (const int64_t *)lkey, nl, kmin, (int64_t)range, (const int64_t *)first, (int64_t *)ids) != RFX_OK) { res = fail_hip("join index"); goto done; }
-        } else {
-            int64_t cap_max = 16, cap;
-            while (cap_max < 2 * nr) cap_max <<= 1;
-            cap = cap_max < (1 << 22) ? cap_max : (1 << 22);
-            for (;;) {
-                void *store = NULL;
-                if (rfx_hip_malloc(g_ctx, &store, (size_t)2 * (size_t)(cap + 1) * 8) != RFX_OK) { res = fail_hip("join table"); goto done; }
-                rfx_hash_tables_t ht;
-                memset(&ht, 0, sizeof(ht));
-                ht.capacity = cap; ht.nagg = 0; ht.d_keys = (int64_t *)store; ht.d_first = (int64_t *)store + (cap + 1);
-                int arc = RFX_EINVAL;
-                int ok = rfx_hip_hash_tables_init(g_ctx, &none, &ht) == RFX_OK &&
-                         (arc = rfx_hip_group_hash_accumulate(g_ctx, (const int64_t *)rkey, NULL, 0, RFX_AND, &none, nr, 0, &ht)) == RFX_OK &&
-                         rfx_hip_join_probe_hash(g_ctx, (const int64_t *)lkey, nl, &ht, (int64_t *)ids) == RFX_OK;
-                if (ok) ok = rfx_hip_ctx_sync(g_ctx) == RFX_OK; /* the probe has read the table before it is freed */
-                rfx_hip_free(g_ctx, store);
-                if (ok) break;
-                if (arc == RFX_ELIMIT && cap < cap_max) { cap = (cap << 4) < cap_max ? (cap << 4) : cap_max; continue; }
-                res = fail_hip("join index");
-                goto done;
-            }
-        }
-    }
-    if (!exact) { /* __index_list_cmp_row, once on the result: every matched row must agree on every key column */
-        void *chk = NULL;
-        JOIN_TMP(chk, (size_t)nl * 8);
-        for (int i = 0; i < nk; i++) {
-            rfx_pred_t p;
-            memset(&p, 0, sizeof(p));
-            p.d_col = chk; p.col_type = RFX_I64; p.op = RFX_NE; p.d_rhs_col = dlk[i]; p.rhs_type = RFX_I64;
-            rfx_value_t dummy[1];
-            int64_t differ = 0;
-            if (rfx_hip_gather_or(g_ctx, drk[i], dlk[i], (const int64_t *)ids, nl, 0, chk) != RFX_OK ||
-                rfx_hip_filter_aggr_host(g_ctx, &p, 1, RFX_AND, NULL, 0, nl, dummy, &differ) != RFX_OK) { res = fail_hip("join check"); goto done; }
-            if (differ) { why = "row-hash collision between two key tuples"; goto out; }
-        }
+        int collision = 0;
+        const int jrc = rfx_exec_join_index(g_x, dlk, drk, nk, nl, nr, (int64_t *)ids, &collision);
+        if (jrc != RFX_OK && collision) { why = "row-hash collision between two key tuples"; goto out; }
+        if (jrc != RFX_OK) { res = fail(rfx_exec_last_error(g_x)); goto done; }
     }
     /* result columns: keys, then the other left columns, then the right-only ones (ray_union / ray_except order, core/join.c:83-156) */
     {
@@ -2627,7 +2441,7 @@ rfx_obj_p rfx_inner_join(rfx_obj_p *x, int64_t n) { return join_op(1, x, n); }
 static obj_p at_impl(obj_p col, obj_p ids) {
     rfx_host_bind();
     if (!col || !ids || !col_ctype(col) || ids->type != RFX_TYPE_I64) return fail("at: expected (i64|f64 column, I64 ids)");
-    if (ensure_ctx() != RFX_OK) return fail_hip("no usable MI355X");
+    if (ensure_ctx1() != RFX_OK) return fail_ctx();
     const void *dc, *di;
     if (resident(col, 0, &dc) != RFX_OK || transient(ids, &di) != RFX_OK) return fail_hip("upload");
     obj_p out = H.vector(col->type, ids->len);
@@ -2676,7 +2490,7 @@ static obj_p fold_mapgroup(int f, int kind, obj_p x) {
     if (!filtered && val->len != n) return fail("length");
     const int out_f64 = kind == RFX_AGG_AVG || (kind != RFX_AGG_COUNT && col_ctype(val) == RFX_F64);
     if (groups == 0 || n == 0) return H.vector(out_f64 ? RFX_TYPE_F64 : RFX_TYPE_I64, 0);
-    if (ensure_ctx() != RFX_OK) return fail_hip("no usable MI355X");
+    if (ensure_ctx1() != RFX_OK) return fail_ctx();
     {
         const void *dv = NULL, *dk = NULL, *dfl = NULL;
         if (resident(val, 0, &dv) != RFX_OK) { res = fail_hip("column upload"); goto done; }
@@ -2761,7 +2575,7 @@ static obj_p group_impl(obj_p keys) {
     rfx_host_bind();
     if (!keys || keys->type <= 0 || col_ctype(keys) != RFX_I64) return fail("group: expected an i64-like vector");
     const int64_t n = keys->len;
-    if (ensure_ctx() != RFX_OK) return fail_hip("no usable MI355X");
+    if (ensure_ctx1() != RFX_OK) return fail_ctx();
     const void *dk = NULL;
     if (n && resident(keys, 0, &dk) != RFX_OK) return fail_hip("column upload");
     int64_t kmin = 0, kmax = -1, seen = 0;
@@ -2838,7 +2652,7 @@ static obj_p fold_impl(int f, int kind, obj_p x) {
             if (H.bound == 1 && H.f[f]) return HOST_CALL(((rfx_unary_f)H.f[f])(x));
             return fail("aggregate: only (i64/f64 vector, i64 ids) MAPFILTER pairs run on the MI355X path");
         }
-        if (ensure_ctx() != RFX_OK) return fail_hip("no usable MI355X");
+        if (ensure_ctx1() != RFX_OK) return fail_ctx();
         const void *dv, *di;
         if (resident(val, 0, &dv) != RFX_OK || transient(ids, &di) != RFX_OK) return fail_hip("column upload");
         void *dg = NULL;
@@ -2859,7 +2673,7 @@ static obj_p fold_impl(int f, int kind, obj_p x) {
         if (H.bound == 1 && H.f[f]) return HOST_CALL(((rfx_unary_f)H.f[f])(x));
         return fail("aggregate: only i64/f64 vectors run on the MI355X path");
     }
-    if (ensure_ctx() != RFX_OK) return fail_hip("no usable MI355X");
+    if (ensure_ctx1() != RFX_OK) return fail_ctx();
     const void *d;
     if (resident(x, 0, &d) != RFX_OK) return fail_hip("column upload");
     rfx_agg_t a;
@@ -2954,6 +2768,10 @@ rfx_obj_p rfx_stats(rfx_obj_p x) {
     rfx_host_bind();
     obj_p out = H.vector(RFX_TYPE_I64, 12);
     for (int i = 0; i < 10; i++) RFX_AS_I64(out)[i] = g_stat[i];
+    if (g_x) { /* scopes sampled / sampled scopes retried exactly: the planner's counters */
+        RFX_AS_I64(out)[ST_SCOPE_SAMPLED] = rfx_exec_stat(g_x, RFX_XSTAT_SCOPE_SAMPLED);
+        RFX_AS_I64(out)[ST_SCOPE_RETRIED] = rfx_exec_stat(g_x, RFX_XSTAT_SCOPE_RETRIED);
+    }
     RFX_AS_I64(out)[10] = g_ctx ? rfx_hip_ctx_stat(g_ctx, RFX_STAT_MASK_PASSES) : 0;
     RFX_AS_I64(out)[11] = g_sd_hits; /* unpinned columns proven current by soft-dirty page bits (0: the kernel has no such tracking) */
     return out;

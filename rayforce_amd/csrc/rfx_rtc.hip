@@ -18,6 +18,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 #include <map>
+#include <mutex>
 #include <string>
 #include "rfx_group_common.hpp"
 #include "build/rfx_rtc_headers.inc" // RTC_NHDR, RTC_HDR_NAMES[], RTC_HDR_TEXTS[]: the kernel headers as text
@@ -57,7 +58,13 @@ static void fnv2(u64 h[2], const void *p, size_t n) {
 }
 
 static bool trace() { return getenv("RFX_TRACE") != NULL; }
+static bool rtc_ready_once();
 static bool rtc_ready() {
+    static std::mutex once;
+    std::lock_guard<std::mutex> hold(once);
+    return rtc_ready_once();
+}
+static bool rtc_ready_once() {
     if (R.state) return R.state > 0;
     R.state = -1;
     if (getenv("RFX_NO_RTC")) return false;
@@ -172,8 +179,8 @@ static void plan_text(const Plan &P, const GroupArgs *G, std::string &o) {
     ADD("#define RTC_PLAN { %d, %d, %d, %d, {}, { ", P.ncols, P.npred, P.nagg, P.logic);
     for (int i = 0; i < P.npred; i++) {
         const bool cnan = P.preds[i].rhs_col < 0 && P.preds[i].dom_f64 && (P.preds[i].rhs_bits & 0x7FF0000000000000ULL) == 0x7FF0000000000000ULL && (P.preds[i].rhs_bits & 0x000FFFFFFFFFFFFFULL) != 0;
-        ADD("{ %d, %d, %d, %d, %d, %d, %s, %d }, ", P.preds[i].col, P.preds[i].rhs_col, P.preds[i].op, P.preds[i].dom_f64, P.preds[i].lhs_cvt, P.preds[i].rhs_cvt,
-            cnan ? "0x7FF8000000000000ULL" : "0ULL", P.preds[i].more);
+        ADD("{ %d, %d, %d, %d, %d, %d, %s, %d, %d }, ", P.preds[i].col, P.preds[i].rhs_col, P.preds[i].op, P.preds[i].dom_f64, P.preds[i].lhs_cvt, P.preds[i].rhs_cvt,
+            cnan ? "0x7FF8000000000000ULL" : "0ULL", P.preds[i].more, P.preds[i].tree);
     }
     o += "}, { ";
     for (int a = 0; a < P.nagg; a++) ADD("{ %d, %d, %d, %d }, ", P.aggs[a].col, P.aggs[a].f64, P.aggs[a].kind, P.aggs[a].skipnull);
@@ -228,7 +235,17 @@ static hipFunction_t load(const std::string &code, const char *name) {
 }
 
 // the kernel of a generated text: from the cache, or compiled now if the plan has come back often enough over enough rows
-static hipFunction_t plan_kernel(const std::string &sig, const std::string &src, const char *name, i64 nrows, const char *what) {
+// (a loaded kernel belongs to ONE device: the key carries the device ordinal; one lock around the maps -- a host that drives several
+//  devices plans from one thread per device, rfx_exec.c)
+static std::mutex g_rtc_lock;
+static hipFunction_t plan_kernel_locked(const std::string &sig, const std::string &src, const char *name, i64 nrows, const char *what);
+static hipFunction_t plan_kernel(int device, const std::string &sig0, const std::string &src, const char *name, i64 nrows, const char *what) {
+    std::lock_guard<std::mutex> hold(g_rtc_lock);
+    char dv[24];
+    snprintf(dv, sizeof(dv), "//dev%d\n", device);
+    return plan_kernel_locked(std::string(dv) + sig0, src, name, nrows, what);
+}
+static hipFunction_t plan_kernel_locked(const std::string &sig, const std::string &src, const char *name, i64 nrows, const char *what) {
     if (!g_cache) g_cache = new std::map<std::string, hipFunction_t>();
     auto it = g_cache->find(sig);
     if (it != g_cache->end()) return it->second;
@@ -285,13 +302,13 @@ int rfx_rtc_filter_aggr(rfx_ctx *c, const Plan &P, int grid, void *ws, int *na_s
     if (P.nagg < 1 || (c->flags & RFX_TUNE_NO_RTC) || !rtc_ready()) return RFX_ESTATE;
     std::string sig, src;
     filter_aggr_text(P, sig, src);
-    hipFunction_t fn = plan_kernel(sig, src, "k_filter_aggr_plan", P.nrows, "a fused filter + aggregate kernel for this plan");
+    hipFunction_t fn = plan_kernel(c->device, sig, src, "k_filter_aggr_plan", P.nrows, "a fused filter + aggregate kernel for this plan");
     if (!fn) return RFX_ESTATE;
     Plan Pv = P;
     void *wsv = ws;
     void *args[] = {&Pv, &wsv};
     RFX_HIP_CHECK(hipModuleLaunchKernel(fn, (unsigned)grid, 1, 1, RFX_BLOCK, 1, 1, 0, c->stream, args, NULL));
-    g_launches++;
+    __atomic_fetch_add(&g_launches, 1, __ATOMIC_RELAXED);
     *na_stride = P.nagg + 1;
     return RFX_OK;
 }
@@ -309,13 +326,13 @@ int rfx_rtc_group_few(rfx_ctx *c, const Plan &P, const GroupArgs &G, int grid) {
     plan_text(P, &G, cond);
     const std::string sig = std::string(head) + cond;
     const std::string src = std::string(head) + cond + "#include \"rfx_group_few_rtc.hpp\"\n";
-    hipFunction_t fn = plan_kernel(sig, src, "k_group_few", P.nrows, "a register-accumulator group-by kernel for this plan");
+    hipFunction_t fn = plan_kernel(c->device, sig, src, "k_group_few", P.nrows, "a register-accumulator group-by kernel for this plan");
     if (!fn) return RFX_ESTATE;
     Plan Pv = P;
     GroupArgs Gv = G;
     void *args[] = {&Pv, &Gv};
     RFX_HIP_CHECK(hipModuleLaunchKernel(fn, (unsigned)grid, 1, 1, RFX_BLOCK, 1, 1, 0, c->stream, args, NULL));
-    g_launches++;
+    __atomic_fetch_add(&g_launches, 1, __ATOMIC_RELAXED);
     return RFX_OK;
 }
 

@@ -198,7 +198,7 @@ __device__ __forceinline__ void expr_input_deep_sw(u64 (&x)[E], const u64 (&v)[N
 // reference's total order (core/ops.h:76-123: NaN lowest, NaN == NaN, -0.0 == 0.0, i64 plain signed), and the operator
 // only decides which of {lt, eq, gt = !(lt|eq)} it keeps -- three wave-uniform booleans, combined with s_and/s_or on
 // the masks.  So the op costs no per-row branch and no per-op code copy.
-enum { PF_F64DOM = 1, PF_LCVT = 2, PF_RCVT = 4, PF_CNAN = 8, PF_RCOL = 16, PF_KEEP_LT = 256, PF_KEEP_EQ = 512, PF_KEEP_GT = 1024, PF_MORE = 2048 };
+enum { PF_F64DOM = 1, PF_LCVT = 2, PF_RCVT = 4, PF_CNAN = 8, PF_RCOL = 16, PF_KEEP_LT = 256, PF_KEEP_EQ = 512, PF_KEEP_GT = 1024, PF_MORE = 2048, PF_DEPTH_SHIFT = 12 /* 2 bits */, PF_CLOSE_SHIFT = 14 /* 2 bits */ };
 struct PredR {
     int col, rhs_col, flags;
     u64 rhs;
@@ -208,6 +208,7 @@ struct PredSet {
     int npred;
     bool is_and;
     bool grouped; // some predicate has PF_MORE: a two-level tree (parentheses of the opposite operator)
+    bool deep;    // the predicates are the leaves of a deeper tree (PlanPred::tree: depth and closing parentheses per leaf)
     PredR p[NP > 0 ? NP : 1];
 };
 __device__ __forceinline__ int pred_keep_bits(int op) {
@@ -225,6 +226,7 @@ __device__ __forceinline__ void predset_load(const Plan &P, PredSet<NP> &S) {
     S.npred = P.npred;
     S.is_and = (P.logic == RFX_AND);
     S.grouped = false;
+    S.deep = false;
 #pragma unroll
     for (int i = 0; i < NP; i++) {
         const PlanPred q = P.preds[i];
@@ -240,6 +242,10 @@ __device__ __forceinline__ void predset_load(const Plan &P, PredSet<NP> &S) {
         if (i < P.npred && q.more) {
             f |= PF_MORE;
             S.grouped = true;
+        }
+        if (NP >= 3 && i < P.npred && q.tree) {
+            f |= ((q.tree & 3) << PF_DEPTH_SHIFT) | (((q.tree >> 4) & 3) << PF_CLOSE_SHIFT);
+            S.deep = true;
         }
         S.p[i].flags = f;
     }
@@ -297,6 +303,87 @@ __device__ __forceinline__ void pred_lt_eq(const PredR &pr, const u64 (&x)[E], c
     }
 }
 
+// The general form: the comparisons are the leaves of an and / or tree, in order; leaf p sits `depth` parentheses deep (level 0 = the
+// query's own operator, every level below the opposite of the one above -- the same operator nested in itself is flattened by the
+// host) and `close` parentheses end after it.  One accumulator mask per level; depth and close are wave-uniform plan constants, so
+// every branch below is a scalar branch (and folds away in a kernel compiled for the plan).  Four levels: what core/logic.c's
+// recursion reaches with eight comparisons in practice; deeper trees take the mask path.
+template <int NC, int E, int NP>
+__device__ __forceinline__ void eval_sel_tree(const PredSet<NP> &S, const u64 (&v)[NC][E], const bool (&valid)[E], bool (&sel)[E]) {
+    const bool and0 = S.is_and; // level l folds with AND iff (l even) == and0; the identity of AND is true, of OR false
+    bool a1[E], a2[E], a3[E];
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+        sel[e] = and0;
+        a1[e] = a2[e] = a3[e] = false;
+    }
+    int cur = 0; // deepest open level (wave-uniform)
+#pragma unroll
+    for (int p = 0; p < NP; p++) {
+        if (p < S.npred) {
+            const int f = S.p[p].flags, d = (f >> PF_DEPTH_SHIFT) & 3, k = (f >> PF_CLOSE_SHIFT) & 3;
+            bool pm[E];
+#pragma unroll
+            for (int e = 0; e < E; e++) pm[e] = false;
+#pragma unroll
+            for (int c = 0; c < NC; c++) {
+                if (S.p[p].col == c) {
+                    bool lt[E], eq[E];
+                    pred_lt_eq<NC, E>(S.p[p], v[c], v, lt, eq);
+                    const bool klt = (f & PF_KEEP_LT) != 0, keq = (f & PF_KEEP_EQ) != 0, kgt = (f & PF_KEEP_GT) != 0;
+#pragma unroll
+                    for (int e = 0; e < E; e++) pm[e] = (lt[e] && klt) || (eq[e] && keq) || (!(lt[e] || eq[e]) && kgt);
+                }
+            }
+            // parentheses that open before this leaf start at their operator's identity
+            if (d >= 1 && cur < 1) {
+#pragma unroll
+                for (int e = 0; e < E; e++) a1[e] = !and0;
+            }
+            if (d >= 2 && cur < 2) {
+#pragma unroll
+                for (int e = 0; e < E; e++) a2[e] = and0;
+            }
+            if (d >= 3 && cur < 3) {
+#pragma unroll
+                for (int e = 0; e < E; e++) a3[e] = !and0;
+            }
+            cur = d;
+            if (d == 0) {
+#pragma unroll
+                for (int e = 0; e < E; e++) sel[e] = and0 ? (sel[e] && pm[e]) : (sel[e] || pm[e]);
+            } else if (d == 1) {
+#pragma unroll
+                for (int e = 0; e < E; e++) a1[e] = !and0 ? (a1[e] && pm[e]) : (a1[e] || pm[e]);
+            } else if (d == 2) {
+#pragma unroll
+                for (int e = 0; e < E; e++) a2[e] = and0 ? (a2[e] && pm[e]) : (a2[e] || pm[e]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < E; e++) a3[e] = !and0 ? (a3[e] && pm[e]) : (a3[e] || pm[e]);
+            }
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                if (j < k) {
+                    if (cur == 3) {
+#pragma unroll
+                        for (int e = 0; e < E; e++) a2[e] = and0 ? (a2[e] && a3[e]) : (a2[e] || a3[e]);
+                    } else if (cur == 2) {
+#pragma unroll
+                        for (int e = 0; e < E; e++) a1[e] = !and0 ? (a1[e] && a2[e]) : (a1[e] || a2[e]);
+                    } else if (cur == 1) {
+#pragma unroll
+                        for (int e = 0; e < E; e++) sel[e] = and0 ? (sel[e] && a1[e]) : (sel[e] || a1[e]);
+                    }
+                    cur--;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < E; e++) sel[e] = sel[e] && valid[e];
+}
+
 // Evaluate all predicates on a register tile: sel[e] = valid[e] && combine(pred_p(row e)).  Each predicate is evaluated straight on
 // the tile of the column it reads (the static `col == c` chain: no register copies).  Flat lists fold into sel directly; a two-level
 // tree (PF_MORE: "the next predicate is in the same parenthesis") folds each parenthesis with the OPPOSITE operator into `par`, and
@@ -309,6 +396,12 @@ __device__ __forceinline__ void eval_sel(const PredSet<NP> &S, const u64 (&v)[NC
         return;
     }
     const bool is_and = S.is_and, grouped = S.grouped;
+    if constexpr (NP >= 3) {
+        if (S.deep) { // an arbitrarily nested tree (logic_map, core/logic.c:89-260): still ONE pass, still lane masks only
+            eval_sel_tree<NC, E, NP>(S, v, valid, sel);
+            return;
+        }
+    }
     bool par[E];
 #pragma unroll
     for (int e = 0; e < E; e++) {

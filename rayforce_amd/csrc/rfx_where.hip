@@ -94,6 +94,7 @@ __global__ __launch_bounds__(RFX_BLOCK) void k_sel_bitmap(const Plan P, u64 *__r
     }
 }
 
+#ifndef WH_NC // (the TUs that only instantiate k_sel_bitmap for one column count -- build/rfx_where_nc<k>.o -- stop before the rest)
 // ---------------- pass A': byte mask -> bitmap + per-chunk counts ----------------
 __global__ __launch_bounds__(RFX_BLOCK) void k_mask_bitmap(const int8_t *__restrict__ mask, i64 nrows, u64 *__restrict__ bitmap,
                                                          i64 *__restrict__ chunk_cnt) {
@@ -296,13 +297,31 @@ __global__ __launch_bounds__(RFX_BLOCK) void k_emit_ids_wc(const u64 *__restrict
     if ((unsigned)lane < fill) out[gpos + lane] = R[(head + lane) & (EMIT_RING - 1)];
 }
 
+#endif
+// k_sel_bitmap is instantiated per column count in its OWN translation unit (rfx_where.hip compiled with -DWH_NC=<k>: 24 instantiations in
+// one TU took 20 minutes of a 16-way build); this TU calls them through rfx_launch_sel_bitmap<NC>
 template <int NC>
-static void launch_sel_bitmap(rfx_ctx *c, const Plan &P, int grid) {
+void rfx_launch_sel_bitmap(rfx_ctx *c, const Plan &P, int grid)
+#ifdef WH_NC
+{
     if (P.npred <= 1) hipLaunchKernelGGL((k_sel_bitmap<NC, 1>), dim3(grid), dim3(RFX_BLOCK), 0, c->stream, P, c->d_bitmap, c->d_blksum);
     else if (P.npred <= 4) hipLaunchKernelGGL((k_sel_bitmap<NC, 4>), dim3(grid), dim3(RFX_BLOCK), 0, c->stream, P, c->d_bitmap, c->d_blksum);
     else hipLaunchKernelGGL((k_sel_bitmap<NC, RFX_MAX_PREDS>), dim3(grid), dim3(RFX_BLOCK), 0, c->stream, P, c->d_bitmap, c->d_blksum);
 }
+template void rfx_launch_sel_bitmap<WH_NC>(rfx_ctx *, const Plan &, int);
+#else
+;
+extern template void rfx_launch_sel_bitmap<1>(rfx_ctx *, const Plan &, int);
+extern template void rfx_launch_sel_bitmap<2>(rfx_ctx *, const Plan &, int);
+extern template void rfx_launch_sel_bitmap<3>(rfx_ctx *, const Plan &, int);
+extern template void rfx_launch_sel_bitmap<4>(rfx_ctx *, const Plan &, int);
+extern template void rfx_launch_sel_bitmap<5>(rfx_ctx *, const Plan &, int);
+extern template void rfx_launch_sel_bitmap<6>(rfx_ctx *, const Plan &, int);
+extern template void rfx_launch_sel_bitmap<7>(rfx_ctx *, const Plan &, int);
+extern template void rfx_launch_sel_bitmap<8>(rfx_ctx *, const Plan &, int);
+#endif
 
+#ifndef WH_NC
 static int where_reserve(rfx_ctx *c, i64 nrows) {
     int rc = rfx_bitmap_reserve(c, ((nrows + 4095) / 4096) * 4096); // whole 4096-row wave steps of k_sel_bitmap
     if (rc != RFX_OK) return rc;
@@ -325,14 +344,14 @@ static void where_launch_bitmap(rfx_ctx *c, const Plan &P) {
     int grid = c->num_cus * 4;
     if ((i64)grid * 4 > nchunks) grid = (int)((nchunks + 3) / 4);
     switch (P.ncols) {
-        case 1: launch_sel_bitmap<1>(c, P, grid); break;
-        case 2: launch_sel_bitmap<2>(c, P, grid); break;
-        case 3: launch_sel_bitmap<3>(c, P, grid); break;
-        case 4: launch_sel_bitmap<4>(c, P, grid); break;
-        case 5: launch_sel_bitmap<5>(c, P, grid); break;
-        case 6: launch_sel_bitmap<6>(c, P, grid); break;
-        case 7: launch_sel_bitmap<7>(c, P, grid); break;
-        default: launch_sel_bitmap<8>(c, P, grid); break;
+        case 1: rfx_launch_sel_bitmap<1>(c, P, grid); break;
+        case 2: rfx_launch_sel_bitmap<2>(c, P, grid); break;
+        case 3: rfx_launch_sel_bitmap<3>(c, P, grid); break;
+        case 4: rfx_launch_sel_bitmap<4>(c, P, grid); break;
+        case 5: rfx_launch_sel_bitmap<5>(c, P, grid); break;
+        case 6: rfx_launch_sel_bitmap<6>(c, P, grid); break;
+        case 7: rfx_launch_sel_bitmap<7>(c, P, grid); break;
+        default: rfx_launch_sel_bitmap<8>(c, P, grid); break;
     }
 }
 
@@ -546,3 +565,5 @@ extern "C" int rfx_hip_gather(rfx_ctx_t *c, const void *d_col, const int64_t *d_
     RFX_HIP_CHECK(hipGetLastError());
     return RFX_OK;
 }
+
+#endif // WH_NC

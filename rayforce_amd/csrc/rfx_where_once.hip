@@ -412,6 +412,7 @@ extern "C" int rfx_hip_where_once(rfx_ctx_t *c, const rfx_pred_t *preds, int npr
     RFX_HIP_CHECK(hipMemsetAsync(c->d_ws, 0, 256 + (size_t)ntiles * 8, c->stream));
     int grid = c->num_cus * (P.ncols <= 2 ? 4 : 2); // workgroups a CU holds (5 waves each)
     if ((i64)grid > ntiles) grid = (int)ntiles;
+    c->ext_p[4] = (void *)((uintptr_t)c->ext_p[4] + 1); // RFX_STAT_WHERE_ONCE: k_where_once launches
     RFX_KERNEL_BEGIN(c);
     switch (P.ncols) {
         case 1: rfx_where_once_launch_nc1(c, P, A, grid); break;

@@ -152,68 +152,6 @@ def allreduce_scope(kmin: int, kmax: int, seen: int, device, group=None) -> Tupl
     return mn, -negmx, -int(s[0])
 
 
-class GroupHook:
-    """The `_collective` callback Engine.group_by calls between its local phases."""
-
-    def __init__(self, shard: RowShard, aggs_kinds: Sequence[int], aggs_f64: Sequence[bool], native=None):
-        self.shard = shard
-        self.kinds = list(aggs_kinds)
-        self.f64s = list(aggs_f64)
-        self.native = native
-
-    def __call__(self, phase: str, payload):
-        g = self.shard.group
-        nat = self.native  # (engine, lib): the exchange runs in C over RCCL (rfx_dist.hip); None: torch.distributed (gloo tests)
-        if phase == "scope":
-            kmin, kmax, seen, device = payload
-            if nat:
-                a, b, c = C.c_int64(kmin), C.c_int64(kmax), C.c_int64(seen)
-                L.check(nat[1].rfx_dist_scope(nat[0]._ctx, C.byref(a), C.byref(b), C.byref(c)), "dist_scope")
-                return int(a.value), int(b.value), int(c.value)
-            return allreduce_scope(kmin, kmax, seen, device, g)
-        if phase == "tables":
-            store, layout, kinds, f64s = payload[:4] if len(payload) >= 4 else (*payload, self.kinds, self.f64s)
-            if nat and len(payload) >= 6:  # one fused exchange, no host synchronisation
-                L.check(nat[1].rfx_dist_group_tables_allreduce(nat[0]._ctx, payload[5], C.byref(payload[4])), "dist_group_tables_allreduce")
-                return None
-            allreduce_tables(store, layout, kinds, f64s, g)
-            return None
-        if phase == "first_values":  # grouped FIRST: exactly one rank contributed each value, the others 0 -> integer SUM
-            for col in payload:
-                if nat:
-                    L.check(nat[1].rfx_dist_allreduce_i64(nat[0]._ctx, col.data_ptr(), col.numel(), 0), "dist_allreduce")
-                else:
-                    _all_reduce(col.view(torch.int64), dist.ReduceOp.SUM, g)
-            return None
-        if phase == "flag":  # logical OR of a per-rank flag
-            if self.shard.world == 1:
-                return payload
-            if nat:
-                t = torch.tensor([int(payload)], dtype=torch.int64, device=nat[0].device)
-                L.check(nat[1].rfx_dist_allreduce_i64(nat[0]._ctx, t.data_ptr(), 1, 2), "dist_allreduce")
-                nat[0].sync()
-                return int(t[0])
-            t = torch.tensor([int(payload)], dtype=torch.int64, device="cpu" if _gloo(g) else torch.device("cuda", torch.cuda.current_device()))
-            _all_reduce(t, dist.ReduceOp.MAX, g)
-            return int(t[0])
-        if phase == "hash_tables":
-            eng, make_tables, store, merge = payload
-            world = self.shard.world
-            if world == 1:
-                return None
-            if nat:
-                whole = torch.empty((world,) + tuple(store.shape), dtype=store.dtype, device=store.device)
-                L.check(nat[1].rfx_dist_allgather(nat[0]._ctx, store.data_ptr(), store.numel() * store.element_size(), whole.data_ptr()), "dist_allgather")
-                bufs = list(whole.unbind(0))
-            else:
-                bufs = _all_gather(store, g)
-            for r, other in enumerate(bufs):
-                if r != self.shard.rank:
-                    merge(make_tables(other))
-            return None
-        raise ValueError(phase)
-
-
 # ---------------------------------------------------------------------------------------------- where ids
 def gather_ids(local_ids: torch.Tensor, group=None, native=None) -> torch.Tensor:
     """Concatenate per-rank ascending GLOBAL ids (already offset by row0) into the global ascending id vector."""
@@ -246,19 +184,74 @@ def gather_ids(local_ids: torch.Tensor, group=None, native=None) -> torch.Tensor
 
 
 # ---------------------------------------------------------------------------------------------- sharded front-end
+class _TorchTransport:
+    """rfx_transport_t over torch.distributed: what carries the planner's inter-process exchanges when the processes cannot share an RCCL
+    communicator (the tests: two ranks on ONE GPU under gloo).  Device buffers take a host round trip -- test plumbing, not a data path."""
+
+    def __init__(self, engine, group):
+        self.eng, self.group = engine, group
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        self.calls = 0
+        self.struct = L.Transport()
+        self.struct.world_rank = L.TR_WORLD_RANK(self._world_rank)
+        self.struct.allgather_host = L.TR_ALLGATHER_HOST(self._allgather_host)
+        self.struct.allreduce = L.TR_ALLREDUCE(self._allreduce)
+        self.struct.allgather_dev = L.TR_ALLGATHER_DEV(self._allgather_dev)
+
+    def _guard(self, fn):
+        try:
+            fn()
+            self.calls += 1
+            return L.RFX_OK
+        except Exception:  # noqa: BLE001 -- a Python exception must not unwind through the C planner
+            import traceback
+            traceback.print_exc()
+            return -4
+
+    def _world_rank(self, user, pw, pr):
+        pw[0], pr[0] = self.world, self.rank
+        return L.RFX_OK
+
+    def _gather_bytes(self, raw: bytes):
+        t = torch.frombuffer(bytearray(raw), dtype=torch.uint8)
+        bufs = [torch.empty_like(t) for _ in range(self.world)]
+        dist.all_gather(bufs, t, group=self.group)
+        return b"".join(bytes(b.numpy().tobytes()) for b in bufs)
+
+    def _allgather_host(self, user, pin, nbytes, pout):
+        return self._guard(lambda: C.memmove(pout, self._gather_bytes(C.string_at(pin, nbytes)), nbytes * self.world))
+
+    def _dev_bytes(self, d_ptr, nbytes) -> bytes:
+        buf = C.create_string_buffer(nbytes)
+        L.check(self.eng.lib.rfx_hip_d2h(self.eng._ctx, buf, C.c_void_p(d_ptr), nbytes), "d2h")
+        return buf.raw
+
+    def _allreduce(self, user, d_buf, n, typ, op):
+        def run():
+            h = torch.frombuffer(bytearray(self._dev_bytes(d_buf, n * 8)), dtype=torch.float64 if typ == 1 else torch.int64)
+            dist.all_reduce(h, op=(dist.ReduceOp.SUM, dist.ReduceOp.MIN, dist.ReduceOp.MAX)[op], group=self.group)
+            L.check(self.eng.lib.rfx_hip_h2d(self.eng._ctx, C.c_void_p(d_buf), h.numpy().ctypes.data, n * 8), "h2d")
+        return self._guard(run)
+
+    def _allgather_dev(self, user, d_in, nbytes, d_out):
+        def run():
+            whole = self._gather_bytes(self._dev_bytes(d_in, nbytes))
+            L.check(self.eng.lib.rfx_hip_h2d(self.eng._ctx, C.c_void_p(d_out), whole, len(whole)), "h2d")
+        return self._guard(run)
+
+
 class ShardedEngine:
-    """Engine + RowShard: the same select surface, every rank holding its row range of every column; results are
-    replicated on all ranks."""
+    """One process per GPU, every rank holding its row range of every column: the same calls as Engine, answered by the library's planner
+    with its inter-process exchange switched on -- under NCCL the lead context's own RCCL communicator (rfx_dist_init; torch.distributed
+    only carries the 128-byte id), under gloo a transport over torch.distributed.  Results are replicated on all ranks."""
 
     def __init__(self, engine, local_rows: int, group=None):
         self.eng = engine
         self.shard = RowShard(local_rows, group)
-        # Under NCCL the exchange is the library's own (rfx_dist.hip: RCCL communicator inside the context, collectives issued from
-        # C on the context's stream); torch.distributed only carries the communicator's 128-byte id.  Under gloo (CPU tests, two
-        # ranks sharing one GPU) the same merges run through torch.distributed.
         self.native = None
+        self.transport = None
+        lib = engine.lib
         if dist.is_initialized() and dist.get_backend(group) == "nccl":
-            lib = engine.lib
             ident = [None]
             if self.shard.rank == 0:
                 buf = C.create_string_buffer(128)
@@ -266,45 +259,31 @@ class ShardedEngine:
             if self.shard.world > 1:
                 dist.broadcast_object_list(ident, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
             ok = ident[0] is not None and lib.rfx_dist_init(engine._ctx, self.shard.world, self.shard.rank, C.c_char_p(ident[0])) == L.RFX_OK
-            if self.shard.world > 1:  # every rank takes the same door: the library's exchange only if ALL communicators came up
+            if self.shard.world > 1:  # every rank takes the same door
                 flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=engine.device)
                 dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
-                all_ok = bool(int(flag[0]))
-            else:
-                all_ok = ok
-            if all_ok:
-                self.native = (engine, lib)
-            else:
-                if ok:
-                    lib.rfx_dist_finalize(engine._ctx)
-                import sys
-                print(f"[rfx] rank {self.shard.rank}: the library's own RCCL exchange did not come up ({L.last_error(lib) if hasattr(L, 'last_error') else 'rfx_dist_init failed'}); "
-                      "torch.distributed (RCCL) carries the collectives instead", file=sys.stderr, flush=True)
+                ok = bool(int(flag[0]))
+            if not ok:
+                raise L.RfxError("the library's RCCL communicator did not come up on every rank (rfx_dist_init)")
+            self.native = (engine, lib)
+        elif dist.is_initialized():
+            self.transport = _TorchTransport(engine, group)
+            L.check(lib.rfx_exec_set_transport(engine._x, C.byref(self.transport.struct)), "exec_set_transport")
 
     def close(self):
         if self.native:
             L.check(self.native[1].rfx_dist_finalize(self.eng._ctx), "dist_finalize")
             self.native = None
+        if self.transport:
+            self.eng.lib.rfx_exec_set_transport(self.eng._x, None)
+            self.transport = None
 
     def filter_aggr(self, aggs, where=None, table=None):
-        eng = self.eng
-        if self.native and len(aggs) <= L.RFX_MAX_AGGS:
-            try:
-                return eng.filter_aggr_dist(aggs, where, table, nrows=self.shard.local_rows, row0=self.shard.row0)
-            except Exception as e:  # nested predicate trees take the general path below
-                if type(e).__name__ != "_NotFlat":
-                    raise
-        part = eng.filter_aggr_partials(aggs, where, table, nrows=self.shard.local_rows, row0=self.shard.row0)
-        kinds = [L.AGGS[fn] for fn, _ in aggs]
-        ctypes_ = [L.RFX_F64 if (col is not None and eng._arg_f64(col, table)) else L.RFX_I64 for fn, col in aggs]
-        return merge_scalar_partials(part, kinds, ctypes_, self.shard.group)
+        return self.eng.filter_aggr(aggs, where, table, nrows=self.shard.local_rows)
 
     def where(self, where, table=None) -> torch.Tensor:
         ids = self.eng.where(where, table, row0=self.shard.row0)
         return gather_ids(ids, self.shard.group, self.native)
 
     def group_by(self, key, aggs, where=None, table=None):
-        kinds = [L.AGGS[fn] for fn, _ in aggs]
-        f64s = [col is not None and self.eng._arg_f64(col, table) for fn, col in aggs]
-        hook = GroupHook(self.shard, kinds, f64s, self.native)
-        return self.eng.group_by(key, aggs, where, table, total_rows=self.shard.total_rows, row0=self.shard.row0, _collective=hook)
+        return self.eng.group_by(key, aggs, where, table)

@@ -20,6 +20,10 @@ OPS_PROTOTYPES = {
     "rfx_host_bind": (C.c_int, []),
     "rfx_ops_set_device": (C.c_int, [C.c_int]),
     "rfx_ops_last_error": (C.c_char_p, []),
+    "rfx_ops_set_shards": (C.c_int, [C.POINTER(C.c_int), C.c_int, C.c_int]),
+    "rfx_ops_shards": (C.c_int, []),
+    "rfx_ops_exec": (C.c_void_p, []),
+    "rfx_host_device_vector": (C.c_void_p, [C.c_int8, C.c_int64, C.POINTER(C.c_void_p), C.c_int]),
     "rfx_select": (C.c_void_p, [C.c_void_p]),
     "rfx_update": (C.c_void_p, [C.c_void_p]),
     **{f"rfx_{n}": (C.c_void_p, [C.c_void_p, C.c_void_p]) for n in ("eq", "ne", "lt", "gt", "le", "ge", "at", "add", "sub", "mul", "div", "floordiv", "mod")},
@@ -114,6 +118,20 @@ def symbols(names: Sequence[str]) -> int:
 
 def table(cols: Dict[str, np.ndarray]) -> int:
     return lib().rfx_host_table(symbols(list(cols)), list_of([vector(v) for v in cols.values()]))
+
+
+def device_vector(t, ptrs=None) -> int:
+    """A DEVICE column handle (rfx_host_device_vector): a torch CUDA tensor's cells handed to the operators where they are.  `ptrs`: one
+    device address per shard (columns kept shard by shard on several devices); default: the tensor's one allocation."""
+    import torch
+    tp = {torch.int64: T_I64, torch.float64: T_F64, torch.int8: T_B8}[t.dtype]
+    ps = [t.data_ptr()] if ptrs is None else list(ptrs)
+    return lib().rfx_host_device_vector(tp, t.numel(), (C.c_void_p * len(ps))(*ps), len(ps))
+
+
+def device_table(cols) -> int:
+    """dict name -> CUDA tensor as a table object whose columns are device handles (the tensors must outlive the table)."""
+    return lib().rfx_host_table(symbols(list(cols)), list_of([device_vector(v) for v in cols.values()]))
 
 
 def atom(x) -> int:

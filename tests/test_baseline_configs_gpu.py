@@ -7,7 +7,7 @@ properties (partition of unity, group sums adding up to the scalar sum).  The te
   C2b north star  select sum(b) where a < 100000, + b f64 seed 3
   C3  configs[2]  select sum(v) by k, k i64 seed 4 mod 1e6, v f64 seed 5
   C3w metric      C3 where a < 100000
-  C4  configs[3]  C3 row-range sharded (ranks on one device here; N > 1 devices: tests/test_dist_gpu.py)
+  C4  configs[3]  C3 row-range sharded: tests/test_sharded_gpu.py (the planner's shards on one device), tests/test_dist_multi_gpu.py (N devices)
   C5  configs[4]  avg, min, max(d) where a < 0.316228 and b > 0.683772 and c != 0.25, a, b, c, d f64 seeds 6, 7, 8, 9
 """
 import numpy as np
@@ -104,25 +104,3 @@ def test_c5_full_size_partition_of_unity(eng):
     assert abs(sel / n - 0.1) < 1e-3 and abs(av - s / c) <= RTOL * av and mn_all <= mn <= av <= mx <= mx_all
     del t
     torch.cuda.empty_cache()
-
-
-def test_c4_row_range_shards_merge_to_the_unsharded_answer(eng):
-    """configs[3]: the C3 group-by over row-range shards (here: 4 shards on one device, merged as the ranks' tables are -- MIN of first
-    rows, SUM of sums) equals the unsharded answer group for group."""
-    n, shards = 6_000_008, 4  # (shard boundaries on even rows: columns are read 16 bytes at a time)
-    host = host_columns("c4", n)
-    want = rfo.select({"from": host, **QUERIES["c3"]})
-    dev = {k: eng.column(v) for k, v in host.items()}
-    whole = eng.group_by("k", [("sum", "v")], None, dev)
-    assert np.array_equal(whole["keys"].cpu().numpy(), want["k"])
-    acc = torch.zeros(1_000_000, dtype=torch.float64, device=whole["keys"].device)
-    first = torch.full((1_000_000,), 2**62, dtype=torch.int64, device=acc.device)
-    for r in range(shards):
-        lo, hi = n * r // shards, n * (r + 1) // shards
-        part = eng.group_by("k", [("sum", "v")], None, {k: v[lo:hi] for k, v in dev.items()}, row0=lo, total_rows=n)
-        acc.index_add_(0, part["keys"], part["results"][0])
-        first.scatter_reduce_(0, part["keys"], part["first"], reduce="amin")
-    order = torch.argsort(first[whole["keys"]])
-    assert bool((order == torch.arange(order.numel(), device=order.device)).all())  # first-occurrence order survives the merge
-    got = acc[whole["keys"]].cpu().numpy()
-    assert np.all(np.abs(got - want["s"]) <= RTOL * np.abs(want["s"]))

@@ -89,15 +89,24 @@ def _worker(rank, world, port, q):
                 assert np.array_equal(np.isnan(g), np.isnan(w)) and np.allclose(g[ok], w[ok], rtol=1e-9, atol=0), many[i]
             else:
                 assert np.array_equal(g, w), many[i]
-        # key tuples beyond the composite key (row-hash path): global scopes, per-rank hashes, hashed tables merged, collision proof
+        # key tuples beyond the composite key (the reference's row-hash path) are planned on ONE shard: across ranks the planner says so
+        # (rfx_select hands such a query to the host) instead of answering from local tuples
         wide = {"k1": rfo.gen_i64(n, 41, 50) * (1 << 50), "k2": rfo.gen_i64(n, 42, 40) * (1 << 45) - (1 << 50), "k3": rfo.gen_i64(n, 43, 3), "v": full["v"], "a": full["a"]}
-        wide["k3"][::101] = NULL
         mine_w = {c: eng.column(x[cut[rank]:cut[rank + 1]]) for c, x in wide.items()}
-        r = sh.group_by(["k1", "k2", "k3"], [("sum", "v"), ("count", "a"), ("max", "a")], None, mine_w)
-        want = rfo.select({"from": wide, "by": {"k1": "k1", "k2": "k2", "k3": "k3"}, "s": ("sum", "v"), "c": ("count", "a"), "m": ("max", "a")})
-        for i, nm in enumerate(("k1", "k2", "k3")):
+        from rayforce_amd._lib import RfxError
+        try:
+            sh.group_by(["k1", "k2", "k3"], [("sum", "v")], None, mine_w)
+            raise AssertionError("a row-hash group-by across ranks was answered")
+        except RfxError as e:
+            assert "one shard" in str(e), str(e)
+        # ... while composite keys that fit 64 bits group across the ranks like any dense / hashed key
+        r = sh.group_by(["k", "k3"], [("sum", "v"), ("count", "a"), ("max", "a")], None, {**mine, "k3": mine_w["k3"]})
+        want = rfo.select({"from": {**full, "k3": wide["k3"]}, "by": {"k": "k", "k3": "k3"}, "s": ("sum", "v"), "c": ("count", "a"), "m": ("max", "a")})
+        for i, nm in enumerate(("k", "k3")):
             assert np.array_equal(r["key_columns"][i].cpu().numpy(), want[nm]), nm
         assert np.array_equal(r["results"][1].cpu().numpy(), want["c"]) and np.array_equal(r["results"][2].cpu().numpy(), want["m"])
+        assert sh.transport.calls > 0
+        sh.close()
         eng.close()
         q.put((rank, "ok"))
     except Exception:  # noqa: BLE001
@@ -156,7 +165,7 @@ def _nccl_worker(port, q):
         assert sel == int(rfo.mask_of(where, full).sum())
         c0 = lib.rfx_dist_calls(eng._ctx)
         r = sh.group_by("k", [("sum", "v")], None, mine)
-        assert lib.rfx_dist_calls(eng._ctx) - c0 == 2, "select sum(v) by k: first MIN + sums SUM in one fused exchange (the scope gather is not counted)"
+        assert lib.rfx_dist_calls(eng._ctx) - c0 == 3, "select sum(v) by k: the scope gather + first MIN and sums SUM in one fused exchange"
         want = rfo.select({"from": full, "by": "k", "s": ("sum", "v")})
         assert np.array_equal(r["keys"].cpu().numpy(), want["k"]) and np.allclose(r["results"][0].cpu().numpy(), want["s"], rtol=1e-9, atol=0)
         gaggs = [("sum", "v"), ("sum", "a"), ("min", "v"), ("max", "a"), ("avg", "a"), ("count", "v"), ("first", "a")]

@@ -48,7 +48,7 @@ def _worker(rank, world, port, q):
         mine = {"k": eng.gen_i64(hi - lo, 4, 1_000_000, lo), "v": eng.gen_f64(hi - lo, 5, lo)}
         c0 = lib.rfx_dist_calls(eng._ctx)
         r = sh.group_by("k", [("sum", "v")], None, mine)
-        assert lib.rfx_dist_calls(eng._ctx) - c0 == 2, "dense group-by: first MIN + sums SUM in one fused exchange"
+        assert lib.rfx_dist_calls(eng._ctx) - c0 == 3, "dense group-by: the scope gather + first MIN and sums SUM in one fused exchange"
         if rank == 0:
             want = rfo.select({"from": {"k": rfo.gen_i64(n, 4, 1_000_000), "v": rfo.gen_f64(n, 5)}, "by": "k", "s": ("sum", "v")})
             assert np.array_equal(r["keys"].cpu().numpy(), want["k"]), "keys / first-occurrence order across the shards"

@@ -55,7 +55,8 @@ def test_hash_table_overflow_is_reported(eng):
     v = eng.gen_f64(n, 3)
     ag = (L.Agg * 1)()
     ag[0].d_col, ag[0].col_type, ag[0].kind = v.data_ptr(), L.RFX_F64, L.RFX_AGG_SUM
-    t, store, layout = eng.group_tables(ag, 1, 0, 1024, hashed=True)  # 1024 slots for 10 000 distinct keys
+    from flat_util import group_tables
+    t, store, layout = group_tables(eng, ag, 1, 0, 1024, hashed=True)  # 1024 slots for 10 000 distinct keys
     L.check(eng.lib.rfx_hip_hash_tables_init(eng._ctx, ag, C.byref(t)))
     rc = eng.lib.rfx_hip_group_hash_accumulate(eng._ctx, k.data_ptr(), None, 0, L.RFX_AND, ag, n, 0, C.byref(t))
     assert rc == -5 and b"hash table full" in eng.lib.rfx_hip_last_error()

@@ -988,17 +988,17 @@ def test_sampled_scope_reports_what_it_missed(eng):
     for bad in (1_000, -3, L_NULL):
         keep = int(k[spot])
         k[spot] = bad
-        eng.__dict__.setdefault("_spec_failed", set()).clear()  # (a column whose sample failed is not sampled again: forget that between the cases)
+        eng.forget_scopes()  # (a column whose sample failed is not sampled again: forget that between the cases)
         before = eng.spec_retries
         same(run("k"), exact("k"))
         assert eng.spec_retries == before + 1, bad  # reported, ran again under the exact scope
         same(run("k"), exact("k"))
         assert eng.spec_retries == before + 1, bad  # ... and remembered: the same column is not sampled a second time
-        eng.__dict__.setdefault("_spec_failed", set()).clear()
+        eng.forget_scopes()
         before = eng.spec_retries
         same(run(["k", "k2"]), exact(["k", "k2"]))
         assert eng.spec_retries == before + 1, bad
-        eng.__dict__.setdefault("_spec_failed", set()).clear()
+        eng.forget_scopes()
         if bad != L_NULL:
             a_keep = int(a[spot])
             a[spot] = 999_999  # the filter drops the outlier's row: nothing to report

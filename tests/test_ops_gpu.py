@@ -165,7 +165,11 @@ def test_nested_tree_and_projection(ops):
     assert H.to_numpy(ops.rfx_stats(0))[10] == m0, "two-level trees: one fused pass, no materialised comparison masks"
     deep = ("or", ("and", ("<", "a", 300_000), (">", "v", 0.2)), ("and", ("==", "b", 3), ("or", ("<", "v", 0.3), (">=", "a", 900_000))))
     check(run_select(ops, host, {**q, "where": deep}), rfo.select({"from": host, **q, "where": deep}))
-    assert H.to_numpy(ops.rfx_stats(0))[10] > m0  # (three levels: the reference's own plan -- masks, where -- on the device)
+    assert H.to_numpy(ops.rfx_stats(0))[10] == m0  # (round 4: three and four levels run in the fused pass too -- rfx_pred_t's tree form)
+    wide = ("or", *[("and", ("<", "a", 100_000 * (i + 1)), (">", "v", 0.1 * i)) for i in range(5)])  # ten comparisons: more than one pass carries
+    check(run_select(ops, host, {**q, "where": wide}), rfo.select({"from": host, **q, "where": wide}))
+    check(run_select(ops, host, {**q, "where": wide, "by": "k"}), rfo.select({"from": host, **q, "where": wide, "by": "k"}))
+    assert H.to_numpy(ops.rfx_stats(0))[10] > m0  # ... the reference's own plan -- masks, where -- on the device
     # projection = filter_collect of every column (core/filter.c:51-165), flat and nested predicates
     check(run_select(ops, host, {"where": ("<", "a", 1000)}), rfo.select({"from": host, "where": ("<", "a", 1000)}))
     check(run_select(ops, host, {"where": nested}), rfo.select({"from": host, "where": nested}))

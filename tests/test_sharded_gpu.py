@@ -1,0 +1,172 @@
+"""The planner's SHARDED mode (include/rfx_exec.h) on one GPU: a table split row-range over k shards -- each with its own context, stream and
+host thread -- must answer what the unsharded oracle answers, whatever the path: scalar partials folded in shard order, dense tables merged
+by the device kernel (the merge ray_select makes of its pool workers' partials, core/aggr.c:163-181), hashed tables re-inserted,
+FIRST values read where the rows live, `where` ids concatenated in shard order.  The same through the C operator door: RFX_SHARDS=k
+splits every pinned / uploaded column and rfx_select answers from all shards; RFX_EXEC_FORCE_RCCL=1 adds a one-rank RCCL world so that the
+fused exchange of the multi-device case (rfx_dist_group_tables_allreduce_all) really runs."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from oracle import rfo
+from test_gpu_parity import check_select, same_f64
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+NULL = -(2**63)
+CHUNK_SMALL = 32768
+
+
+def table(n, keys=3000, nulls=True):
+    t = {"k": rfo.gen_i64(n, 4, keys) - 7, "j": rfo.gen_i64(n, 14, 13), "a": rfo.gen_i64(n, 2, 1_000_000), "ts": rfo.gen_i64(n, 3, 1_000_000),
+         "v": rfo.gen_f64(n, 5) - 0.5, "w": rfo.gen_f64(n, 6)}
+    if nulls:
+        t["a"][::97] = NULL
+        t["v"][::89] = np.nan
+    return t
+
+
+QUERIES = [
+    {"s": ("sum", "a"), "f": ("sum", "v"), "mn": ("min", "v"), "mx": ("max", "a"), "av": ("avg", "a"), "c": ("count", "v"), "fi": ("first", "w"), "where": ("and", ("<", "a", 600_000), (">", "v", -0.4))},
+    {"s": ("sum", ("*", "w", ("-", 1, "v"))), "where": ("or", ("<", "a", 1000), ("and", (">", "w", 0.5), ("<", "v", 0.0)))},
+    {"by": "k", "s": ("sum", "v"), "s2": ("sum", "a"), "mn": ("min", "v"), "mx": ("max", "a"), "av": ("avg", "a"), "c": ("count", "v"), "fa": ("first", "a"), "fv": ("first", "w")},
+    {"by": "k", "s": ("sum", "w"), "fa": ("first", "a"), "where": (">", "v", -0.25)},
+    {"by": {"g1": "j", "g2": "k"}, "s": ("sum", "w"), "c": ("count", "a"), "mx": ("max", "a")},
+    {"by": {"b": ("xbar", "ts", 50_000)}, "s": ("sum", "w"), "f": ("first", "a")},
+    {"by": "k", **{f"o{i}": (fn, c) for i, (fn, c) in enumerate([("max", "a"), ("sum", "v"), ("min", "a"), ("avg", "v"), ("count", "a"), ("sum", "a"), ("min", "v"), ("max", "v"), ("avg", "a"), ("first", "w"), ("sum", "w")])}},
+]
+
+
+@pytest.mark.parametrize("shards", [2, 3, 5])
+def test_sharded_engine_matches_the_oracle(built, shards):
+    from rayforce_amd import _lib as L
+    from rayforce_amd.engine import Engine
+    e = Engine(0, shards=shards)
+    try:
+        for n in (1_000_003, 2_047, 1):  # uneven shards, shards without rows
+            host = table(n)
+            dev = {c: e.column(x) for c, x in host.items()}
+            for q in QUERIES:
+                check_select(e, host, q, dev)
+            ids = e.where(("<", "a", 100_000), dev)
+            assert np.array_equal(ids.cpu().numpy(), rfo.where(rfo.mask_of(("<", "a", 100_000), host)))
+        # sparse keys: every shard's hashed table re-inserted into the lead's
+        host = table(600_011, keys=40_000)
+        host["k"] = host["k"] * 1_000_003 - 5
+        dev = {c: e.column(x) for c, x in host.items()}
+        check_select(e, host, {"by": "k", "s": ("sum", "w"), "c": ("count", "a"), "f": ("first", "v")}, dev)
+        assert e.xstat(L.RFX_XSTAT_MERGES_KERNEL) > 0
+        # wide key range: every shard partitions its rows into planes, aggregates them into its own tables under the AGREED scope
+        e.tune(flags=CHUNK_SMALL)
+        host = table(1_500_007, keys=300_000, nulls=False)
+        dev = {c: e.column(x) for c, x in host.items()}
+        before = e.stat(0)
+        check_select(e, host, {"by": "k", "s": ("sum", "w")}, dev)
+        check_select(e, host, {"by": "k", "s": ("sum", "w"), "where": ("<", "a", 300_000)}, dev)
+        assert e.stat(0) - before >= shards  # RFX_STAT_PLANE_SCATTER: one scatter per shard and query at least
+        e.tune(flags=0)
+    finally:
+        e.close()
+
+
+def test_c4_row_range_shards_merge_to_the_unsharded_answer(built):
+    """configs[3]: the C3 group-by (1e6 keys, sum of f64) over 4 row-range shards equals the unsharded answer group for group, first-occurrence
+    order included -- through the planner, whose merge is what the ranks' exchange computes (MIN of first rows, SUM of sums)."""
+    from rayforce_amd.engine import Engine
+    n = 6_000_007
+    host = {"k": rfo.gen_i64(n, 4, 1_000_000), "v": rfo.gen_f64(n, 5)}
+    want = rfo.select({"from": host, "by": "k", "s": ("sum", "v")})
+    e = Engine(0, shards=4)
+    try:
+        e.tune(flags=CHUNK_SMALL)
+        dev = {k: e.column(v) for k, v in host.items()}
+        r = e.group_by("k", [("sum", "v")], None, dev)
+        assert np.array_equal(r["keys"].cpu().numpy(), want["k"])
+        first = r["first"].cpu().numpy()
+        assert np.all(first[1:] > first[:-1]) and np.array_equal(host["k"][first], want["k"])
+        same_f64(r["results"][0].cpu().numpy(), want["s"])
+        assert e.stat(0) >= 4 and e.stat(2) >= 4  # plane scatter + plane aggregate on every shard
+    finally:
+        e.close()
+
+
+_DOOR = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+from oracle import rfo
+from rayforce_amd import hostobj as H, _lib as L
+from test_gpu_parity import same_f64
+import ctypes as C
+ops = H.lib()
+ops.rfx_host_bind()
+NULL = -(2**63)
+n = 2_000_003
+host = {"k": rfo.gen_i64(n, 4, 100_000), "a": rfo.gen_i64(n, 2, 1_000_000), "v": rfo.gen_f64(n, 5), "b": rfo.gen_f64(n, 3), "c": rfo.gen_f64(n, 8), "d": rfo.gen_f64(n, 9)}
+host["a"][::101] = NULL
+tab = H.table(host)
+queries = [
+    {"s": ("sum", "a"), "where": ("<", "a", 100_000)},
+    {"s": ("sum", "b"), "c": ("count", "a"), "f": ("first", "v"), "where": ("<", "a", 100_000)},
+    {"s": ("sum", "v"), "by": "k"},
+    {"s": ("sum", "v"), "f": ("first", "a"), "m": ("max", "a"), "by": "k", "where": ("<", "a", 100_000)},
+    {"x": ("avg", "d"), "y": ("min", "d"), "z": ("max", "d"), "where": ("and", ("<", "v", 0.316228), (">", "b", 0.683772), ("!=", "c", 0.25))},
+    {"s": ("sum", ("*", "v", "b")), "where": ("and", ("or", ("<", "a", 5000), ("and", (">", "v", 0.5), ("<", "b", 0.5))), (">", "c", 0.1))},
+    {"where": ("<", "a", 3000)},
+]
+def ask(q, t):
+    d = H.select_dict(q, t)
+    r = ops.rfx_select(d)
+    assert r and not H.is_error(r), H.error_text(r)
+    assert ops.rfx_last_select_on_gpu() == 1, (q, ops.rfx_ops_last_error())
+    out = H.table_to_numpy(r)
+    ops.rfx_host_drop(r); ops.rfx_host_drop(d)
+    return out
+def same(got, want, q):
+    assert list(got) == list(want), (list(got), list(want))
+    for name in want:
+        g, w = got[name], want[name]
+        assert g.dtype == w.dtype and g.shape == w.shape, name
+        if w.dtype == np.float64 and name in q and q[name][0] in ("sum", "avg"):
+            same_f64(g, w)
+        else:
+            assert np.array_equal(g, w, equal_nan=w.dtype == np.float64), name
+for rep in range(2):  # first touch uploads every column shard by shard; the second round finds them resident
+    for q in queries:
+        same(ask(q, tab), rfo.select({"from": host, **q}), q)
+assert ops.rfx_ops_shards() == SHARDS, ops.rfx_ops_shards()
+# the same table as DEVICE columns (one allocation each: the shards take their row ranges of it)
+import torch
+from rayforce_amd.engine import Engine
+eng = Engine(0)
+dev = {c: eng.column(x) for c, x in host.items()}
+dtab = H.device_table(dev)
+torch.cuda.synchronize()
+for q in queries:
+    same(ask(q, dtab), rfo.select({"from": host, **q}), q)
+x = C.c_void_p(ops.rfx_ops_exec())
+assert ops.rfx_exec_shards(x) == SHARDS
+assert ops.rfx_exec_stat(x, L.RFX_XSTAT_MERGES_KERNEL) > 0
+if os.environ.get("RFX_EXEC_FORCE_RCCL"):
+    assert ops.rfx_exec_stat(x, L.RFX_XSTAT_MERGES_RCCL) > 0 and ops.rfx_dist_calls(C.c_void_p(ops.rfx_exec_ctx(x, 0))) > 0
+# an operator that needs its column whole on one device says so instead of answering from one shard
+col = H.vector(host["a"])
+r = ops.rfx_lt(col, H.atom(5))
+assert H.is_error(r) and "whole on one device" in H.error_text(r)
+print("DOOR-OK")
+'''
+
+
+@pytest.mark.parametrize("shards,rccl", [(4, False), (3, True)])
+def test_sharded_operator_door(built, shards, rccl):
+    """rfx_select with RFX_SHARDS=k in a process of its own (the operator layer's shards are fixed at its first call)."""
+    env = dict(os.environ, RFX_SHARDS=str(shards), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("RFX_EXEC_FORCE_RCCL", None)
+    if rccl:
+        env["RFX_EXEC_FORCE_RCCL"] = "1"
+    code = f"ROOT = {ROOT!r}\nSHARDS = {shards}\n" + _DOOR
+    p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "DOOR-OK" in p.stdout, p.stdout[-3000:] + p.stderr[-3000:]
