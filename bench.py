@@ -4,8 +4,13 @@
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3w|c2|c2b|c3|c5|...] [--scaling strong|weak] [--rows R] [--no-cpu-baseline] [--no-also]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks ITSELF (it re-executes under
-torch.distributed.run on 127.0.0.1); a rank count that differs from --gpus is an error, never a silent 1-GPU run.
+Two ways to N GPUs, both through the product's door (the C operator rfx_select) and both planned by the library's one planner (rfx_exec.c):
+  * under a launcher (WORLD_SIZE set: the driver's `python -m torch.distributed.run ... bench.py --gpus N`): ONE PROCESS PER GPU; every rank hands
+    rfx_select its row range as device columns, the operator layer's context joins an RCCL communicator (rfx_ops_dist_init) and every rank gets
+    the whole answer -- one exchange of scopes + one fused all-reduce of the group tables per query;
+  * `python bench.py --gpus N` without a launcher: ONE PROCESS, N DEVICES (rfx_ops_set_shards) -- the evaluator process that owns the node:
+    every shard's pass on its own host thread, the partial tables merged by one fused RCCL exchange issued from that process.
+A rank count that differs from --gpus is an error, never a silent 1-GPU run.
 
 A "step" = one execution of the query over the HBM-resident synthetic columns of this rank (kernels + the one merge
 collective + result read-back).  The table is rows [0, TOTAL) generated on the device with the counter-based splitmix64 of
@@ -163,11 +168,13 @@ class Job:
             self.eng.timer_start()
             m = self.eng.cmp("<", self.t["a"], 100_000)
             self.kms = self.eng.timer_stop()
+            self._mask_keep = m
             return ([int(m.numel())], int(m.numel()))
         if self.name == "g2":
             self.eng.timer_start()
             out = self.eng.at_ids(self.t["b"], self.ids)
             self.kms = self.eng.timer_stop()
+            self._out_keep = out
             return ([int(out.numel())], int(out.numel()))
         if self.name == "w2":
             ids = self.sh.where(self.where, self.t) if self.sh is not None else self.eng.where(self.where, self.t)
@@ -252,6 +259,46 @@ class Job:
             if int((first[1:] <= first[:-1]).sum()):
                 raise SystemExit(f"bench.py: {name}: groups are not in first-occurrence order")
             return f"{int(res['groups'])} groups: every sum within 1e-9 of torch index_add_, first rows strictly ascending"
+        if name == "m2":
+            want = (t["a"] < 100_000).to(T.int8)
+            if not bool(T.equal(self._mask_keep, want)):
+                raise SystemExit("bench.py: m2: the B8 mask differs from torch's comparison")
+            return f"{int(want.sum())} of {want.numel()} mask bytes set: equal to torch's (a < 100000)"
+        if name == "g2":
+            if not bool(T.equal(self._out_keep, t["b"][self.ids])):
+                raise SystemExit("bench.py: g2: gathered cells differ from torch's b[ids]")
+            return f"{self.ids.numel()} gathered cells equal torch's b[ids]"
+        if name == "q1":
+            # six groups, eight aggregates: every cell against torch over the group's selected rows (f64 within 1e-9 of sum |x|)
+            sel = t["sd"] <= 2400
+            kc = res["key_columns"]
+            for g in range(int(res["groups"])):
+                m = sel & (t["rf"] == int(kc[0][g])) & (t["ls"] == int(kc[1][g]))
+                q_, p_, d_, tx = t["q"][m], t["p"][m], t["d"][m], t["t"][m]
+                want = [q_.sum(), p_.sum(), (p_ * (1 - d_)).sum(), (p_ * (1 - d_) * (1 + tx)).sum(), q_.double().mean(), p_.mean(), d_.mean(), m.sum()]
+                for a, w_ in enumerate(want):
+                    got = res["results"][a][g]
+                    if got.dtype == T.int64:
+                        if int(got) != int(w_):
+                            raise SystemExit(f"bench.py: q1: group {g} aggregate {a}: {int(got)} vs torch {int(w_)}")
+                    else:
+                        close(got, w_, f"group {g} aggregate {a}")
+            first = res["first"]
+            if int((first[1:] <= first[:-1]).sum()):
+                raise SystemExit("bench.py: q1: groups are not in first-occurrence order")
+            return f"{int(res['groups'])} groups x 8 aggregates equal torch's over each group's selected rows"
+        if name == "q7":
+            # ~1e8 groups of (almost) one row: every group's key tuple IS its first row's, counts add up to the rows, sums to the column's sum
+            first, kc = res["first"], res["key_columns"]
+            if int((first[1:] <= first[:-1]).sum()):
+                raise SystemExit("bench.py: q7: groups are not in first-occurrence order")
+            for i in range(6):
+                if not bool(T.equal(t[f"id{i + 1}"][first], kc[i])):
+                    raise SystemExit(f"bench.py: q7: key column {i} differs from the column at the groups' first rows")
+            if int(res["results"][1].sum()) != self.rows:
+                raise SystemExit("bench.py: q7: group counts do not add up to the rows")
+            close(res["results"][0].sum(), t["v"].sum(), "sum over the groups' sums")
+            return f"{int(res['groups'])} groups: key tuples equal the first rows', counts add up to the rows, sums to the column's sum"
         if name == "w2":
             ids, n = self._ids_keep, int(mask(self.where).sum())
             ok = ids.numel() == n and bool((ids[1:] > ids[:-1]).all()) and bool((t["a"][ids] < 100_000).all())
@@ -291,10 +338,16 @@ def run_workload(name, eng, sharded, rows, row0, steps, warmup, world, total_row
     """rows = this rank's rows; total_rows = rows of the whole job (all ranks)."""
     w = WORKLOADS[name]
     total_rows = rows * world if total_rows is None else total_rows
+    import gc
+    from rayforce_amd import _lib as L
     job = Job(name, eng, sharded, rows, row0)
-    before = [eng.stat(i) for i in range(5)]
+    PATHS = ("plane_scatter", "plane_fallback", "plane_aggregate", "chunk_scatter", "chunk_aggregate", "mask_passes", "where_once")
+    XSTATS = {"scopes_sampled": L.RFX_XSTAT_SCOPE_SAMPLED, "sampled_scopes_retried": L.RFX_XSTAT_SCOPE_RETRIED, "hash_tables_grown": L.RFX_XSTAT_HASH_GROWN}
+    before, xbefore, rbefore = [eng.stat(i) for i in range(len(PATHS))], {k: eng.xstat(v) for k, v in XSTATS.items()}, rtc_counters(eng)
     dt, kms, res = timed(job, steps, warmup, world)
-    paths = dict(zip(("plane_scatter", "plane_fallback", "plane_aggregate", "chunk_scatter", "chunk_aggregate"), [eng.stat(i) - b for i, b in enumerate(before)]))
+    paths = dict(zip(PATHS, [eng.stat(i) - b for i, b in enumerate(before)]))
+    planner = {k: eng.xstat(v) - xbefore[k] for k, v in XSTATS.items()}
+    rtc = {k: v - rbefore[k] for k, v in rtc_counters(eng).items()}
     checked = job.verify(res) if (world == 1 and sharded is None) else None
     ms_step = dt * 1e3 / steps
     if name in ("c3", "c3w", "q2", "k9", "q1", "q7", "w2") or world > 1:
@@ -303,14 +356,37 @@ def run_workload(name, eng, sharded, rows, row0, steps, warmup, world, total_row
     alg_bytes = w["bytes_per_row"] * total_rows / world  # per launch, per GPU (SURVEY 8d figures, stated in DESIGN.md)
     achieved = alg_bytes / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
     out = dict(workload=name, rows_per_gpu=rows, total_rows=total_rows, ms_per_step=ms_step, rows_per_s=value, kernel_ms=kms, achieved_GBps=achieved,
-               frac=achieved / HBM_PEAK_GBPS, result=_brief(res), verified=checked, paths={k: v for k, v in paths.items() if v})
-    del job
+               frac=achieved / HBM_PEAK_GBPS, result=_brief(res), verified=checked, paths={k: v for k, v in paths.items() if v},
+               planner={k: v for k, v in planner.items() if v}, rtc=rtc)
+    del job, res
+    gc.collect()  # (verify's recursive closures hold the columns in a reference cycle: 240 GB of them by the last workload otherwise)
+    eng.trim()
     torch.cuda.empty_cache()
     return out
 
 
+def rtc_counters(eng):
+    """launches that went through run-time compiled plan kernels / plans compiled / loaded from the on-disk code-object cache, so far in this process"""
+    rl, rc, rd, rw = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
+    eng.lib.rfx_hip_rtc_stats(C.byref(rl), C.byref(rc))
+    eng.lib.rfx_hip_rtc_cache_stats(C.byref(rd), C.byref(rw))
+    return {"launches_through_plan_kernels": int(rl.value), "plans_compiled": int(rc.value), "plans_loaded_from_disk": int(rd.value)}
+
+
+def kernel_that_ran(label, rtc):
+    """WORKLOADS' labels name both forms of a plan kernel; the run's own counters say which one launched."""
+    if "prebuilt " not in label or not rtc:
+        return label
+    plan, _, rest = label.partition(" (")
+    prebuilt = rest.split("prebuilt ", 1)[1].split(" without hiprtc")[0]
+    if rtc.get("launches_through_plan_kernels", 0) > 0:
+        return plan + " (compiled at run time for the plan" + (", loaded from the on-disk code-object cache" if rtc.get("plans_compiled", 0) == 0 else "") + ")"
+    return prebuilt + " (prebuilt: no run-time compiled plan kernel launched)"
+
+
 def roofline_block(name, r, world):
-    w = WORKLOADS[name]
+    w = dict(WORKLOADS[name])
+    w["kernel"] = kernel_that_ran(w["kernel"], r.get("rtc"))
     return {"bound": "hbm", "achieved": r["achieved_GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": r["frac"],
             "traffic": pmc_traffic(name) if world == 1 and r["total_rows"] == w["rows"] else None, "kernel": w["kernel"], "kernel_ms": r["kernel_ms"],
             "algorithmic_bytes_per_launch": w["bytes_per_row"] * r["total_rows"] / world}
@@ -388,33 +464,24 @@ C_DOOR = {
     "c2b": ({"a": ("i64", 2, 1_000_000), "b": ("f64", 3)}, {"where": ("<", "a", 100_000), "s": ("sum", "b")}),
     "c5": ({c: ("f64", sd) for c, sd in zip("abcd", (6, 7, 8, 9))},
            {"where": ("and", ("<", "a", 0.316228), (">", "b", 0.683772), ("!=", "c", 0.25)), "x": ("avg", "d"), "y": ("min", "d"), "z": ("max", "d")}),
+    "q7": ({**{f"id{i + 1}": ("i64", 20 + i, m) for i, m in enumerate((100, 100, 1_000_000, 100, 100, 1_000_000))}, "v": ("f64", 5)},
+           {"by": {f"id{i + 1}": f"id{i + 1}" for i in range(6)}, "s": ("sum", "v"), "c": ("count", "v")}),
 }
 
 
-def c_door(name, eng, rows, steps, warmup):
-    """The workload through rfx_select -- the C operator boundary the reference's evaluator (or `loadfn`) binds -- at the workload's full
-    size: host vectors laid out as RayforceDB objects, pinned (uploaded once, trusted until rfx_invalidate), K timed calls, each returning the
-    finished host result table (result read-back and table construction are inside the timed region).  The answer of the last call is checked
-    against Engine's (itself checked against torch in run_workload)."""
-    import numpy as np
-    from rayforce_amd import hostobj as H
-    ops = H.lib()
-    ops.rfx_host_bind()
-    spec, q = C_DOOR[name]
-    host = {}
-    for cname, sp in spec.items():
-        dcol = eng.gen_i64(rows, sp[1], sp[2]) if sp[0] == "i64" else eng.gen_f64(rows, sp[1])
-        host[cname] = dcol.cpu().numpy()
-        del dcol
-    torch.cuda.empty_cache()
-    tab = H.table(host)
-    del host
-    t0 = time.perf_counter()
-    pin = ops.rfx_pin(tab)
-    pin_s = time.perf_counter() - t0
-    d = H.select_dict(q, tab)
+def door_columns(eng, spec, rows, row0=0):
+    return {c: (eng.gen_i64(rows, sp[1], sp[2], row0) if sp[0] == "i64" else eng.gen_f64(rows, sp[1], row0)) for c, sp in spec.items()}
+
+
+def door_run(ops, H, d, steps, warmup, world=1):
+    """K timed calls of rfx_select on the dict `d`, each returning the finished HOST result table (read-back and table construction inside the
+    timed region); under a launcher bracketed by barriers, the maximum over the ranks."""
     for _ in range(max(1, warmup)):
-        ops.rfx_host_drop(ops.rfx_select(d))
+        r = ops.rfx_select(d)
+        assert r and not H.is_error(r), H.error_text(r)
+        ops.rfx_host_drop(r)
+    if world > 1:
+        dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     r = None
@@ -423,34 +490,217 @@ def c_door(name, eng, rows, steps, warmup):
             ops.rfx_host_drop(r)
         r = ops.rfx_select(d)
     torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
     dt = time.perf_counter() - t0
     assert r and not H.is_error(r), H.error_text(r)
-    on_gpu = int(ops.rfx_last_select_on_gpu())
+    if not int(ops.rfx_last_select_on_gpu()):
+        raise SystemExit("bench.py: rfx_select handed the query back instead of answering it on the GPU")
     got = H.table_to_numpy(r)
     ops.rfx_host_drop(r)
-    # the same query through Engine on the same data (device-generated again), compared column by column
-    cols = {cname: (eng.gen_i64(rows, sp[1], sp[2]) if sp[0] == "i64" else eng.gen_f64(rows, sp[1])) for cname, sp in spec.items()}
-    want = eng.select({"from": cols, **q})
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t[0])
+    return dt, got
+
+
+def door_same(name, got, want, what):
+    import numpy as np
     for cname, w in want.items():
-        w = w.cpu().numpy()
+        w = w.cpu().numpy() if hasattr(w, "cpu") else np.asarray(w)
         g = got[cname]
         if w.dtype == np.float64:
             okc = g.shape == w.shape and bool(np.all(np.abs(g - w) <= 1e-9 * np.maximum(np.abs(w), 1e-300) + 0.0))
         else:
             okc = g.shape == w.shape and bool(np.array_equal(g, w))
         if not okc:
-            raise SystemExit(f"bench.py: rfx_select({name}) column {cname} differs from Engine.select on the same data")
-    del cols, want
-    u = ops.rfx_unpin(tab)
-    for o in (pin, u, d, tab):
+            raise SystemExit(f"bench.py: rfx_select({name}) column {cname} differs from {what}")
+
+
+def c_door(name, eng, rows, steps, warmup, device_columns=False):
+    """The workload through rfx_select -- the C operator boundary the reference's evaluator (or `loadfn`) binds -- at the workload's full size.
+    Default: host vectors laid out as RayforceDB objects, pinned (uploaded once, trusted until rfx_invalidate); device_columns: the columns
+    stay where the device generator left them and the table's columns are device handles.  The answer of the last call is checked against
+    Engine's on the same data (itself checked against torch in run_workload)."""
+    from rayforce_amd import hostobj as H
+    ops = H.lib()
+    ops.rfx_host_bind()
+    spec, q = C_DOOR[name]
+    pin_s, pin, keep = None, None, None
+    if device_columns:
+        keep = door_columns(eng, spec, rows)
+        eng.sync()
+        tab = H.device_table(keep)
+    else:
+        host = {}
+        for cname in spec:
+            dcol = door_columns(eng, {cname: spec[cname]}, rows)[cname]
+            host[cname] = dcol.cpu().numpy()
+            del dcol
+        torch.cuda.empty_cache()
+        tab = H.table(host)
+        del host
+        t0 = time.perf_counter()
+        pin = ops.rfx_pin(tab)
+        pin_s = time.perf_counter() - t0
+    d = H.select_dict(q, tab)
+    dt, got = door_run(ops, H, d, steps, warmup)
+    cols = keep if device_columns else door_columns(eng, spec, rows)
+    want = eng.select({"from": cols, **q})
+    door_same(name, got, want, "Engine.select on the same data")
+    del cols, want, keep
+    for o in ([pin, ops.rfx_unpin(tab)] if pin else []) + [d, tab]:
         ops.rfx_host_drop(o)
     ops.rfx_cache_clear()
     torch.cuda.empty_cache()
-    if not on_gpu:
-        raise SystemExit(f"bench.py: rfx_select({name}) was not answered on the GPU")
-    return {"door": "rfx_select (C operator boundary, include/rfx_ops.h) on pinned host columns; result table built on the host inside the timed region",
-            "rows": rows, "steps": steps, "ms_per_step": dt * 1e3 / steps, "rows_per_s": rows / (dt / steps), "answered_on_gpu": on_gpu,
+    return {"door": "rfx_select (C operator boundary, include/rfx_ops.h) on " + ("device column handles" if device_columns else "pinned host columns") +
+                    "; result table built on the host inside the timed region",
+            "rows": rows, "steps": steps, "ms_per_step": dt * 1e3 / steps, "rows_per_s": rows / (dt / steps), "answered_on_gpu": 1,
             "pin_upload_s": pin_s, "verified": "every result column equals Engine.select's on the same data (f64 within 1e-9)"}
+
+
+def door_property_check(name, got, cols_by_shard, q, reduce_sum):
+    """N > 1: no unsharded copy exists to compare with -- the answer's invariants instead.  Scalar: selected sums / extrema from torch per shard,
+    folded; grouped: the groups' sums add up to the selected rows' sum, the group count is the number of distinct selected keys (torch.unique
+    per shard, folded by a presence table), first-occurrence order = every key new where it stands (no duplicates)."""
+    import numpy as np
+    where = q.get("where")
+
+    def mask(t, w):
+        if w[0] == "and":
+            m = mask(t, w[1])
+            for x in w[2:]:
+                m = m & mask(t, x)
+            return m
+        col, c = t[w[1]], w[2]
+        return {"<": col < c, ">": col > c, "!=": col != c}[w[0]]
+
+    if "by" in q:
+        loc_sum, pres = 0.0, None
+        for t in cols_by_shard:
+            with torch.cuda.device(t["v"].device):
+                m = mask(t, where) if where else None
+                v = t["v"][m] if m is not None else t["v"]
+                k = t["k"][m] if m is not None else t["k"]
+                loc_sum += float(v.sum())
+                p = torch.zeros(1_000_000, dtype=torch.int64, device=k.device)
+                p[k] = 1
+                pres = p.cpu() if pres is None else torch.maximum(pres, p.cpu())
+        tot = reduce_sum(loc_sum)
+        pres = reduce_sum(pres.double()).clamp(max=1.0)
+        groups = int(pres.sum())
+        if len(got["k"]) != groups or len(np.unique(got["k"])) != groups:
+            raise SystemExit(f"bench.py: {name}: {len(got['k'])} groups vs {groups} distinct selected keys")
+        if not abs(float(got["s"].sum()) - tot) <= 1e-9 * abs(tot):
+            raise SystemExit(f"bench.py: {name}: the groups' sums add up to {float(got['s'].sum())!r}, the selected rows' to {tot!r}")
+        return f"{groups} groups = distinct selected keys, no key twice, the groups' sums add up to the selected rows' sum (1e-9)"
+    sums = 0.0
+    for t in cols_by_shard:
+        with torch.cuda.device(next(iter(t.values())).device):
+            m = mask(t, where)
+            col = t[q[next(k for k in q if k != "where")][1]]
+            sums += float(col[m].sum())
+    tot = reduce_sum(sums)
+    first = next(k for k in q if k != "where")
+    if q[first][0] == "sum" and not abs(float(got[first][0]) - tot) <= 1e-9 * abs(tot):
+        raise SystemExit(f"bench.py: {name}: sum {float(got[first][0])!r} vs torch over the shards {tot!r}")
+    return "the aggregate equals torch's over the shards' selected rows (1e-9)" if q[first][0] == "sum" else "answered (avg / min / max: see tests/test_dist_multi_gpu.py)"
+
+
+def one_process(args):
+    """`python bench.py --gpus N` without a launcher: ONE process drives N devices through the sharded operator layer (rfx_ops_set_shards): the
+    evaluator process of INTEGRATION.md.  RFX_BENCH_SAME_DEVICE=1 puts the N shards on device 0 (merged by the planner's kernel instead of RCCL):
+    the same code on a one-GPU box."""
+    _stdout_is_for_the_json_line_only()
+    from rayforce_amd import hostobj as H, _lib as L
+    from rayforce_amd.engine import Engine
+    name, N = args.workload, args.gpus
+    if name not in C_DOOR or name == "q7":
+        raise SystemExit(f"bench.py: --gpus {N} in one process runs the BASELINE configs ({', '.join(k for k in C_DOOR if k != 'q7')})")
+    same = bool(os.environ.get("RFX_BENCH_SAME_DEVICE"))
+    if not same and torch.cuda.device_count() < N:
+        raise SystemExit(f"bench.py: --gpus {N} but this box has {torch.cuda.device_count()} device(s)")
+    devs = [0] * N if same else list(range(N))
+    ops = H.lib()
+    ops.rfx_host_bind()
+    uniq = sorted(set(devs))
+    L.check(ops.rfx_ops_set_shards((C.c_int * len(uniq))(*uniq), len(uniq), N), "ops_set_shards")
+    spec, q = C_DOOR[name]
+    base = args.rows or WORKLOADS[name]["rows"]
+    total = base if args.scaling == "strong" else base * N
+    engs, shards = {}, []
+    r0, ln = C.c_int64(), C.c_int64()
+    for s_ in range(N):
+        e = engs.setdefault(devs[s_], Engine(devs[s_]))
+        ops.rfx_exec_split(total, N, s_, C.byref(r0), C.byref(ln))
+        shards.append(door_columns(e, spec, ln.value, r0.value))
+        e.sync()
+    cols = [H.device_vector(shards[0][c], ptrs=[sh[c].data_ptr() for sh in shards]) for c in spec]
+    for cv, c in zip(cols, spec):  # the handle's length is the whole column's
+        H.header(cv).len = total
+    tab = ops.rfx_host_table(H.symbols(list(spec)), H.list_of(cols))
+    d = H.select_dict(q, tab)
+    dt, got = door_run(ops, H, d, args.steps, args.warmup)
+    checked = door_property_check(name, got, shards, q, lambda x: x)
+    x = C.c_void_p(ops.rfx_ops_exec())
+    w = WORKLOADS[name]
+    ms = dt * 1e3 / args.steps
+    achieved = w["bytes_per_row"] * total / N / (ms * 1e-3) / 1e9
+    print(json.dumps({
+        "metric": METRIC, "value": total / (dt / args.steps), "unit": "rows/s", "n_gpus": N, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
+        "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": w["dtype"], "data": "synthetic",
+        "config": {"workload": f"{name}: {w['desc']}", "total_rows": total, "rows_per_gpu": total // N,
+                   "sharding": f"ONE process, {N} shards on {len(uniq)} device(s): every shard's pass on its own host thread, partial tables merged by "
+                               + ("the planner's device kernel" if len(uniq) == 1 else "one fused RCCL exchange over xGMI"),
+                   "door": "rfx_select on per-shard device column handles (rfx_ops_set_shards); result table built on the host inside the timed region",
+                   "verified": checked, "resident": "HBM (columns generated on every device)",
+                   "planner": {"merges_by_kernel": int(ops.rfx_exec_stat(x, L.RFX_XSTAT_MERGES_KERNEL)), "fused_rccl_exchanges": int(ops.rfx_exec_stat(x, L.RFX_XSTAT_MERGES_RCCL))}},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "kernel": w["kernel"],
+                     "kernel_ms": ms, "algorithmic_bytes_per_launch": w["bytes_per_row"] * total / N},
+        "cpu_baseline": None}), flush=True)
+    for e in engs.values():
+        e.close()
+
+
+def launcher_door(args, name, eng, world, rank, rows, row0, total_rows):
+    """Under a launcher, world > 1: this rank's row range as device columns through rfx_select with the operator layer's context in the
+    RCCL communicator (rfx_ops_dist_init): every rank gets the whole answer."""
+    from rayforce_amd import hostobj as H, _lib as L
+    ops = H.lib()
+    ops.rfx_host_bind()
+    L.check(ops.rfx_ops_set_device(eng.device.index), "ops_set_device")
+    ident = [None]
+    if rank == 0:
+        buf = C.create_string_buffer(128)
+        L.check(ops.rfx_dist_unique_id(buf), "dist_unique_id")
+        ident = [buf.raw]
+    dist.broadcast_object_list(ident, src=0)
+    L.check(ops.rfx_ops_dist_init(world, rank, C.c_char_p(ident[0])), "ops_dist_init")
+    spec, q = C_DOOR[name]
+    cols = door_columns(eng, spec, rows, row0)
+    eng.sync()
+    tab = H.device_table(cols)
+    d = H.select_dict(q, tab)
+    dt, got = door_run(ops, H, d, args.steps, args.warmup, world)
+
+    def reduce_sum(x):
+        t = torch.tensor([x], dtype=torch.float64, device="cuda") if isinstance(x, float) else x.cuda()
+        dist.all_reduce(t)
+        return float(t[0]) if isinstance(x, float) else t.cpu()
+
+    checked = door_property_check(name, got, [cols], q, reduce_sum)
+    x = C.c_void_p(ops.rfx_ops_exec())
+    w_, r_ = C.c_int(), C.c_int()
+    ops.rfx_dist_world(C.c_void_p(ops.rfx_exec_ctx(x, 0)), C.byref(w_), C.byref(r_))
+    if int(w_.value) != world:
+        raise SystemExit(f"bench.py: the RCCL communicator spans {int(w_.value)} ranks, the launcher started {world}")
+    out = {"ms_per_step": dt * 1e3 / args.steps, "rows_per_s": total_rows / (dt / args.steps), "verified": checked, "ranks_seen": int(w_.value),
+           "collectives_per_query": int(ops.rfx_dist_calls(C.c_void_p(ops.rfx_exec_ctx(x, 0)))) / (args.steps + max(1, args.warmup)),
+           "result": {"groups": len(got[next(iter(got))])} if "by" in q else {"values": [float(v[0]) for v in got.values()]}}
+    ops.rfx_ops_dist_finalize()
+    return out
+
 
 # ------------------------------------------------------------------------------------------------ CPU baseline
 def cpu_baseline(name, sample_rows, timeout=120):
@@ -567,6 +817,7 @@ def main():
     ap.add_argument("--sharded", action="store_true", help="use the row-sharded driver (collectives) even with one rank")
     ap.add_argument("--no-also", action="store_true", help="skip the secondary workloads in the 'also' field")
     ap.add_argument("--engine-door", action="store_true", help="report Engine.group_by / filter_aggr (ctypes host, device-resident results) as `value` instead of rfx_select")
+    ap.add_argument("--spawn", action="store_true", help="--gpus N without a launcher: start N ranks under torch.distributed.run (one process per GPU) instead of one process over N devices")
     ap.add_argument("--dry-run", action="store_true", help="no device work: rendezvous, shard arithmetic and the JSON line only (CPU test of the launch contract)")
     ap.add_argument("--blocks-per-cu", type=int, default=0)
     ap.add_argument("--ab", default="", help="dev: comma list of tune flags to A/B in ONE process (same box, same clocks); prints one line per run")
@@ -574,7 +825,9 @@ def main():
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        respawn(args.gpus)  # does not return
+        if args.spawn or args.dry_run:
+            respawn(args.gpus)  # does not return
+        return one_process(args)  # ONE process over the N devices: the sharded operator layer
     _stdout_is_for_the_json_line_only()  # (after the respawn decision: the ranks started above inherit the untouched stdout)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -653,7 +906,22 @@ def main():
                 log(f"[ab] rep {rep} flags:bpc {item}: ms_per_step {dt * 1e3 / args.steps:.3f} kernel_ms {kms:.3f} "
                     f"GB/s {WORKLOADS[name]['bytes_per_row'] * rows / kms / 1e6:.0f}")
         return
-    main_r = run_workload(name, eng, sharded, rows, row0, args.steps, args.warmup, world, total_rows)
+    ldoor = None
+    if world > 1 and name in C_DOOR and name != "q7" and not args.engine_door:
+        # every rank's shard through rfx_select, the operator layer's context inside the RCCL communicator: `value` is this door's
+        if sharded is not None:
+            sharded.close()
+            sharded = None
+        ldoor = launcher_door(args, name, eng, world, rank, rows, row0, total_rows)
+        log(f"[bench] rank {rank}: {name} through rfx_select over {world} processes: {ldoor}")
+        w = WORKLOADS[name]
+        kms = ldoor["ms_per_step"]
+        ach = w["bytes_per_row"] * total_rows / world / (kms * 1e-3) / 1e9
+        main_r = dict(workload=name, rows_per_gpu=rows, total_rows=total_rows, ms_per_step=kms, rows_per_s=ldoor["rows_per_s"], kernel_ms=kms, achieved_GBps=ach,
+                      frac=ach / HBM_PEAK_GBPS, result=ldoor["result"], verified=ldoor["verified"], paths={}, planner={}, rtc={})
+        ranks_seen = ldoor["ranks_seen"]
+    else:
+        main_r = run_workload(name, eng, sharded, rows, row0, args.steps, args.warmup, world, total_rows)
     log(f"[bench] {name}: {main_r}")
     door = None
     if world == 1 and sharded is None and name in C_DOOR and not args.engine_door:
@@ -669,7 +937,11 @@ def main():
             try:
                 full = other in FULL
                 r = run_workload(other, eng, None, WORKLOADS[other]["rows"], 0, args.steps if full else max(3, args.steps // 4), args.warmup if full else 2, 1)
-                also[other] = {k: r[k] for k in ("rows_per_gpu", "ms_per_step", "rows_per_s", "kernel_ms", "achieved_GBps", "frac", "verified", "paths")}
+                also[other] = {k: r[k] for k in ("rows_per_gpu", "ms_per_step", "rows_per_s", "kernel_ms", "achieved_GBps", "frac", "verified", "paths", "planner", "rtc")}
+                if other == "q7":  # the six-key row-hash shape through the C operator too (device column handles: the planner keeps its blocks)
+                    dq = c_door("q7", eng, WORKLOADS["q7"]["rows"], max(3, args.steps // 4), 2, device_columns=True)
+                    also[other]["rfx_select_ms_per_step"] = dq["ms_per_step"]
+                    also[other]["rfx_select_verified"] = dq["verified"]
                 also[other]["steps"] = args.steps if full else max(3, args.steps // 4)
                 if full:
                     also[other]["roofline"] = roofline_block(other, r, 1)
@@ -732,7 +1004,10 @@ def main():
             "config": {"workload": f"{name}: {w['desc']}", "rows_per_gpu": rows, "total_rows": total_rows,
                        "sharding": f"row-range x{world}" if world > 1 else "single GPU", "ranks_seen": ranks_seen, "resident": "HBM (columns generated on device)",
                        "result": main_r["result"], "verified": main_r["verified"], "paths": main_r["paths"],
-                       "door": door["door"] if door else "Engine (ctypes host over the flat device ABI, results stay on the device)"},
+                       "planner": main_r.get("planner"),
+                       "door": door["door"] if door else ("rfx_select on this rank's row range as device column handles, the operator layer's context in the RCCL "
+                                                          "communicator (rfx_ops_dist_init): every rank gets the whole answer" if ldoor else
+                                                          "Engine (ctypes host over the library's planner, results stay on the device)")},
             "roofline": roofline_block(name, head, world),
             "cpu_baseline": cpu,
             "rtc": {"launches_through_run_time_compiled_kernels": int(rl.value), "plans_compiled": int(rc.value),
@@ -741,6 +1016,8 @@ def main():
         if door:
             line["door"] = door
             line["engine"] = {k: main_r[k] for k in ("ms_per_step", "rows_per_s", "frac")}
+        if ldoor:
+            line["door"] = {k: ldoor[k] for k in ("ms_per_step", "rows_per_s", "verified", "collectives_per_query")}
         if also:
             line["also"] = also
         if boundary:

@@ -218,13 +218,17 @@ enum {
     RFX_STAT_PLANE_AGGREGATE = 2, /* k_plane_aggregate launches */
     RFX_STAT_CHUNK_SCATTER = 3,   /* k_chunk_scatter* launches (16-byte records, rfx_group_chunk.hip) */
     RFX_STAT_CHUNK_AGGREGATE = 4, /* k_chunk_aggregate launches */
-    RFX_STAT_MASK_PASSES = 5      /* materialised B8 passes: rfx_hip_cmp_mask + rfx_hip_mask_logic launches (a fused `where:` tree runs none) */
+    RFX_STAT_MASK_PASSES = 5,     /* materialised B8 passes: rfx_hip_cmp_mask + rfx_hip_mask_logic launches (a fused `where:` tree runs none) */
+    RFX_STAT_WHERE_ONCE = 6       /* k_where_once launches (the one-pass where, rfx_where_once.hip) */
 };
 int64_t rfx_hip_ctx_stat(rfx_ctx_t *ctx, int which);
 
 /* ---- plain device memory for C hosts (Python hosts pass torch-owned pointers instead) ---- */
 int rfx_hip_malloc(rfx_ctx_t *ctx, void **d_ptr, size_t bytes);
 int rfx_hip_free(rfx_ctx_t *ctx, void *d_ptr);
+/* Freed blocks are kept for reuse inside the context (hipMalloc / hipFree cost more than small queries' kernels, and tens of milliseconds
+ * per gigabyte-sized block): rfx_hip_ctx_trim gives them back to the device.  (syncs) */
+int rfx_hip_ctx_trim(rfx_ctx_t *ctx);
 int rfx_hip_h2d(rfx_ctx_t *ctx, void *d_dst, const void *src, size_t bytes); /* (syncs) */
 int rfx_hip_d2h(rfx_ctx_t *ctx, void *dst, const void *d_src, size_t bytes); /* (syncs) */
 int rfx_hip_memset(rfx_ctx_t *ctx, void *d_dst, int byte, size_t bytes);

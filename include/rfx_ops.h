@@ -68,6 +68,10 @@ int rfx_ops_set_device(int device);
  * operators that need a column whole on one device return an error object. */
 int rfx_ops_set_shards(const int *devices, int ndevices, int nshards);
 int rfx_ops_shards(void);
+/* one process per device instead: the operator layer's context joins an RCCL communicator of `world` processes (id from rfx_dist_unique_id on
+ * rank 0, shipped by the host); from then on rfx_select over this process' row range of the table answers for the WHOLE table */
+int rfx_ops_dist_init(int world, int rank, const void *id128);
+int rfx_ops_dist_finalize(void);
 struct rfx_exec;
 struct rfx_exec *rfx_ops_exec(void); /* the operator layer's planner (NULL before the first operator): counters, transport */
 const char *rfx_ops_last_error(void);

@@ -158,6 +158,7 @@ PROTOTYPES = {
     "rfx_hip_ctx_stat": (C.c_int64, [_ctx, C.c_int]),
     "rfx_hip_malloc": (C.c_int, [_ctx, _P(C.c_void_p), C.c_size_t]),
     "rfx_hip_free": (C.c_int, [_ctx, C.c_void_p]),
+    "rfx_hip_ctx_trim": (C.c_int, [_ctx]),
     "rfx_hip_h2d": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_size_t]),
     "rfx_hip_d2h": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_size_t]),
     "rfx_hip_memset": (C.c_int, [_ctx, C.c_void_p, C.c_int, C.c_size_t]),

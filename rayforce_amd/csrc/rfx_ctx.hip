@@ -325,18 +325,32 @@ extern "C" int rfx_hip_eval_expr(rfx_ctx_t *c, const rfx_agg_t *expr, int64_t nr
 #define POOL_MIN_LOG 8
 #define POOL_KEEP 8
 #define POOL_LIVE 1024
+#define BIG_KEEP 12                          /* blocks above 256 MB kept for reuse ... */
+#define BIG_KEEP_BYTES ((size_t)40 << 30)    /* ... up to this much in all (of 288 GB); rfx_hip_ctx_trim gives them back */
+#define BIG_LIVE 64
 struct SmallPool {
     void *live_p[POOL_LIVE];
     unsigned char live_c[POOL_LIVE];
     int nlive;
     void *freep[POOL_MAX_LOG + 1][POOL_KEEP];
     int nfree[POOL_MAX_LOG + 1];
+    // Blocks above 256 MB (the tables, result columns and id vectors of queries over 1e8+ groups / ids): hipMalloc + hipFree of gigabytes
+    // cost tens of milliseconds each (page-table work) -- the six-key row-hash query spent 0.6 s of its 0.65 s there.  Sized in 64 MB
+    // steps, kept when freed, handed out again to a request they fit with at most a quarter to spare.
+    void *big_live_p[BIG_LIVE];
+    size_t big_live_b[BIG_LIVE];
+    int nbig_live;
+    void *big_free_p[BIG_KEEP];
+    size_t big_free_b[BIG_KEEP];
+    int nbig_free;
+    size_t big_free_total;
 };
 static void pool_release(rfx_ctx *c) {
     SmallPool *sp = (SmallPool *)c->ext_p[0];
     if (!sp) return;
     for (int k = 0; k <= POOL_MAX_LOG; k++)
         for (int i = 0; i < sp->nfree[k]; i++) (void)hipFree(sp->freep[k][i]);
+    for (int i = 0; i < sp->nbig_free; i++) (void)hipFree(sp->big_free_p[i]);
     free(sp);
     c->ext_p[0] = NULL;
 }
@@ -360,8 +374,56 @@ extern "C" int rfx_hip_malloc(rfx_ctx_t *c, void **d_ptr, size_t bytes) {
             return RFX_OK;
         }
     }
+    SmallPool *bp = (SmallPool *)c->ext_p[0];
+    if (!bp) c->ext_p[0] = bp = (SmallPool *)calloc(1, sizeof(SmallPool));
+    const size_t want = (bytes + (((size_t)64 << 20) - 1)) & ~(((size_t)64 << 20) - 1);
+    if (bp && bp->nbig_live < BIG_LIVE) {
+        int best = -1;
+        for (int i = 0; i < bp->nbig_free; i++)
+            if (bp->big_free_b[i] >= want && bp->big_free_b[i] <= want + want / 4 && (best < 0 || bp->big_free_b[i] < bp->big_free_b[best])) best = i;
+        void *p = NULL;
+        size_t got = want;
+        if (best >= 0) {
+            p = bp->big_free_p[best];
+            got = bp->big_free_b[best];
+            bp->big_free_total -= got;
+            bp->big_free_p[best] = bp->big_free_p[bp->nbig_free - 1];
+            bp->big_free_b[best] = bp->big_free_b[--bp->nbig_free];
+        } else {
+            RFX_HIP_CHECK(hipSetDevice(c->device));
+            hipError_t e = hipMalloc(&p, want);
+            if (e == hipErrorOutOfMemory && bp->nbig_free > 0) { // what is kept for reuse goes back first
+                (void)hipGetLastError();
+                (void)hipStreamSynchronize(c->stream);
+                for (int i = 0; i < bp->nbig_free; i++) (void)hipFree(bp->big_free_p[i]);
+                bp->nbig_free = 0;
+                bp->big_free_total = 0;
+                e = hipMalloc(&p, want);
+            }
+            RFX_HIP_CHECK(e);
+        }
+        bp->big_live_p[bp->nbig_live] = p;
+        bp->big_live_b[bp->nbig_live++] = got;
+        *d_ptr = p;
+        return RFX_OK;
+    }
     RFX_HIP_CHECK(hipSetDevice(c->device));
     RFX_HIP_CHECK(hipMalloc(d_ptr, bytes ? bytes : 8));
+    return RFX_OK;
+}
+// give every block kept for reuse back to the device (a host about to need the memory for something else)
+extern "C" int rfx_hip_ctx_trim(rfx_ctx_t *c) {
+    RFX_REQUIRE(c, RFX_EINVAL, "ctx is NULL");
+    SmallPool *sp = (SmallPool *)c->ext_p[0];
+    if (!sp) return RFX_OK;
+    RFX_HIP_CHECK(hipStreamSynchronize(c->stream));
+    for (int k = 0; k <= POOL_MAX_LOG; k++) {
+        for (int i = 0; i < sp->nfree[k]; i++) (void)hipFree(sp->freep[k][i]);
+        sp->nfree[k] = 0;
+    }
+    for (int i = 0; i < sp->nbig_free; i++) (void)hipFree(sp->big_free_p[i]);
+    sp->nbig_free = 0;
+    sp->big_free_total = 0;
     return RFX_OK;
 }
 extern "C" int rfx_hip_free(rfx_ctx_t *c, void *d_ptr) {
@@ -376,6 +438,19 @@ extern "C" int rfx_hip_free(rfx_ctx_t *c, void *d_ptr) {
                 sp->live_c[i] = sp->live_c[--sp->nlive];
                 if (sp->nfree[k] < (k > 22 ? 2 : POOL_KEEP)) { // (two spares per size class above 4 MB)
                     sp->freep[k][sp->nfree[k]++] = d_ptr;
+                    return RFX_OK;
+                }
+                break;
+            }
+        for (int i = sp->nbig_live - 1; i >= 0; i--)
+            if (sp->big_live_p[i] == d_ptr) {
+                const size_t b = sp->big_live_b[i];
+                sp->big_live_p[i] = sp->big_live_p[sp->nbig_live - 1];
+                sp->big_live_b[i] = sp->big_live_b[--sp->nbig_live];
+                if (sp->nbig_free < BIG_KEEP && sp->big_free_total + b <= BIG_KEEP_BYTES) {
+                    sp->big_free_p[sp->nbig_free] = d_ptr;
+                    sp->big_free_b[sp->nbig_free++] = b;
+                    sp->big_free_total += b;
                     return RFX_OK;
                 }
                 break;

@@ -604,6 +604,7 @@ typedef struct {
     int want_first, need_first_values, all_rank;
     int phase_key;          /* which key column a per-key phase works on */
     int scope_filtered;     /* per-key exact scopes: through the predicates */
+    int sparse_sampled;     /* the sample alone sent the key to the hashed tables: a null key shows in their null slot */
     int64_t groups;
 } gq_t;
 
@@ -1086,7 +1087,7 @@ static int group_by_pass(rfx_exec_t *x, const rfx_query_t *q, int a0, int na, in
                   !spec_known_bad(x, spec_id, q->nrows);
     int retried = 0;
 rescope:
-    G->spec = G->rowhash = G->fused_keys = 0;
+    G->spec = G->rowhash = G->fused_keys = G->sparse_sampled = 0;
     for (int s = 0; s < S; s++) sh[s].key = sh[s].keys[0];
     if (G->nkeys == 1) {
         int have = 0;
@@ -1095,6 +1096,15 @@ rescope:
             if ((rc = fold_scope(G, 0, &G->kmin, &G->kmax, &G->seen)) != RFX_OK) goto done;
             G->spec = G->seen > 0 && G->kmin != NULL_I64 && G->kmax >= G->kmin && (uint64_t)(G->kmax - G->kmin) < RFX_SCOPE_SAMPLE_MAX_RANGE;
             have = G->spec;
+            /* SPARSE keys by the sample alone: a sampled range can only be too small, so one that already exceeds the row count decides
+             * "range > rows" -- open addressing (core/index.c:2013) -- without index_scope_i64's pass over the column (8 GB per 1e9 rows, a
+             * twentieth of such a query): the tables are sized by the row count as the reference sizes them, and a null key the sample did
+             * not see shows in the tables' own null slot afterwards */
+            if (!have && G->seen > 0 && G->kmin != NULL_I64 && G->kmax >= G->kmin && (uint64_t)G->kmax - (uint64_t)G->kmin + 1 > (uint64_t)q->nrows) {
+                G->seen = q->nrows;
+                G->sparse_sampled = 1;
+                have = 1;
+            }
         }
         if (!have && q->key_scope && !any_xbar && !q->d_mask && !G->exch && q->key_scope[0] != NULL_I64 && q->key_scope[1] >= q->key_scope[0] &&
             (uint64_t)(q->key_scope[1] - q->key_scope[0]) < RFX_SCOPE_SAMPLE_MAX_RANGE) {
@@ -1214,6 +1224,18 @@ grow:;
         }
     }
     rfx_hip_ctx_bind_thread(x->ctx[0]);
+    if (G->sparse_sampled && !G->dense && (q->flags & RFX_Q_REFUSE_NULL_KEY)) { /* did a null key come by after all?  its slot is the tables' last */
+        int null_seen = 0;
+        for (int s = 0; s < S && rc == RFX_OK; s++) {
+            int64_t f = INF_I64;
+            if (S > 1) rfx_hip_ctx_bind_thread(x->ctx[s]);
+            rc = rfx_hip_d2h(x->ctx[s], &f, sh[s].ht.d_first + G->cap, 8);
+            null_seen |= f != INF_I64;
+        }
+        if (S > 1) rfx_hip_ctx_bind_thread(x->ctx[0]);
+        if (rc != RFX_OK) { snprintf(x->err, sizeof(x->err), "%s", rfx_hip_last_error()); goto done; }
+        if (null_seen) { rc = RFX_EXEC_NULL_KEY; goto done; }
+    }
     out->path = G->rowhash ? RFX_PATH_ROWHASH : (G->dense ? RFX_PATH_DENSE : RFX_PATH_HASH);
     out->capacity = G->dense ? 0 : G->cap;
     /* ---- one hash = one tuple?  Every row's group-first row (the join probe against the group-by's own table), then per key column:

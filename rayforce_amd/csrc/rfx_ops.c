@@ -231,6 +231,28 @@ static int ensure_ctx(void) {
     if (getenv("RFX_TRACE")) fprintf(stderr, "[rfx] operator layer: %d shard(s) over %d device(s)\n", nsh, ndev);
     return RFX_OK;
 }
+static void op_begin(void);
+static void op_end(void);
+/* ONE PROCESS PER DEVICE (torch.distributed launches, bench.py --gpus N under a launcher): every process owns the rows [row0, row0 + n) of
+ * every table; rank 0 draws the 128-byte id (rfx_dist_unique_id), the host ships it, every process calls rfx_ops_dist_init -- after that
+ * rfx_select's planner exchanges scopes / partials / group tables with the other processes through the context's RCCL communicator and every
+ * process returns the WHOLE answer.  (Projections stay local: a process returns its own rows.) */
+int rfx_ops_dist_init(int world, int rank, const void *id128) {
+    rfx_host_bind();
+    op_begin();
+    int rc = ensure_ctx();
+    if (rc == RFX_OK && g_nshards > 1) rc = RFX_ESTATE; /* (shards inside a process and processes: one or the other) */
+    if (rc == RFX_OK) rc = rfx_dist_init(g_ctx, world, rank, id128);
+    op_end();
+    return rc;
+}
+int rfx_ops_dist_finalize(void) {
+    if (!g_ctx) return RFX_OK;
+    op_begin();
+    const int rc = rfx_dist_finalize(g_ctx);
+    op_end();
+    return rc;
+}
 /* for the operators that need a column WHOLE on one device (everything but rfx_select / rfx_pin / rfx_unpin / rfx_invalidate / rfx_stats) */
 static int ensure_ctx1(void) {
     const int rc = ensure_ctx();
@@ -516,6 +538,11 @@ static void op_end(void);
 void rfx_cache_clear(void) {
     op_begin();
     while (g_nres) res_free(g_nres - 1);
+    for (int sh = 0; sh < g_nshards && g_ctx; sh++) { /* ... and the blocks the contexts keep for reuse go back to the device */
+        if (g_nshards > 1) rfx_hip_ctx_bind_thread(g_ctxs[sh]);
+        rfx_hip_ctx_trim(g_ctxs[sh]);
+    }
+    if (g_nshards > 1) rfx_hip_ctx_bind_thread(g_ctx);
     op_end();
 }
 int64_t rfx_cache_bytes(void) { return (int64_t)g_res_bytes; }

@@ -18,21 +18,31 @@ from typing import Dict, List, Optional, Sequence, Tuple, Union
 import torch
 
 from . import _lib as L
+from . import marshal as M
 from ._lib import RfxError
+from .marshal import NotFused as _NotFused, ctype_of as _ctype_of
 
 Column = torch.Tensor
 
 
-def _ctype_of(t: torch.Tensor) -> int:
-    if t.dtype == torch.int64:
-        return L.RFX_I64
-    if t.dtype == torch.float64:
-        return L.RFX_F64
-    raise RfxError(f"unsupported column dtype {t.dtype} (the path handles i64 and f64 columns)")
+class _Owner:
+    """Holds a result struct of the planner (rfx_groups_t / rfx_ids_t) until no tensor views its device blocks any more."""
+
+    def __init__(self, eng, struct, free):
+        self.eng, self.struct, self.free = eng, struct, free
+
+    def __del__(self):
+        try:
+            if self.eng._x:
+                self.free(self.eng._x, C.byref(self.struct))
+        except Exception:  # pragma: no cover -- interpreter shutdown
+            pass
 
 
-class _NotFused(Exception):
-    """The where: tree has more comparisons / levels than one fused pass carries."""
+class _View:
+    def __init__(self, owner, ptr: int, n: int, typestr: str):
+        self.owner = owner
+        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": typestr, "data": (int(ptr), False), "version": 2}
 
 
 class Engine:
@@ -81,6 +91,11 @@ class Engine:
 
     def sync(self) -> None:
         L.check(self.lib.rfx_hip_ctx_sync(self._ctx), "sync")
+
+    def trim(self) -> None:
+        """Give the blocks the contexts keep for reuse back to the device (before a phase that needs the memory for columns)."""
+        for s in range(self.shards):
+            L.check(self.lib.rfx_hip_ctx_trim(C.c_void_p(self._ctxs[s])), "ctx_trim")
 
     def tune(self, blocks_per_cu: int = 0, flags: int = 0) -> None:
         for s in range(self.shards):
@@ -160,154 +175,12 @@ class Engine:
         from . import colfiles
         return colfiles.load_parted(self, root, table, columns, where)
 
-    # ------------------------------------------------------------------ marshalling: tuples -> descriptors
-    def _check_col(self, t: torch.Tensor, n: Optional[int] = None) -> torch.Tensor:
-        if not isinstance(t, torch.Tensor) or t.dim() != 1 or not t.is_contiguous():
-            raise RfxError("columns must be contiguous 1-D tensors")
-        if t.device != self.device:
-            raise RfxError(f"column lives on {t.device}, engine on {self.device}")
-        if n is not None and t.numel() != n:
-            raise RfxError("length mismatch")  # reference: err_length (core/cmp.c:633-640)
-        return t
+    # ------------------------------------------------------------------ marshalling: tuples -> descriptors (rayforce_amd/marshal.py)
+    def _check_col(self, t, n=None):
+        return M.check_col(self, t, n)
 
     def _resolve(self, x, table):
-        if isinstance(x, str):
-            if table is None or x not in table:
-                raise RfxError(f"unknown column {x!r}")
-            return table[x]
-        if isinstance(x, tuple) and x and x[0] in L.XOPS:  # an expression where a column is expected: evaluated once (k_derive), as the reference does
-            col = self.eval_expr(x, table)
-            self._keep.append(col)
-            return col
-        return x
-
-    def _leaves(self, where) -> Tuple[int, List[tuple], List[int]]:
-        """(logic, comparisons in order, rfx_pred_t.more per comparison): the where: tree's leaves with the depth of parentheses each sits
-        in and the parentheses closing after it (rfx_hip.h: the two-level `more` form where it suffices, else RFX_PRED_TREE)."""
-        if where is None:
-            return L.RFX_AND, [], []
-        head = where[0]
-        if head in L.OPS:
-            return L.RFX_AND, [tuple(where)], [0]
-        if head not in ("and", "or"):
-            raise RfxError(f"unknown predicate head {head!r}")
-        leaves: List[tuple] = []
-        dep: List[int] = []
-        clo: List[int] = []
-
-        def node(e, level_op, depth):
-            h = e[0]
-            if h in L.OPS:
-                leaves.append(tuple(e))
-                dep.append(depth)
-                clo.append(0)
-                return
-            if h not in ("and", "or"):
-                raise RfxError(f"unknown predicate head {h!r}")
-            own = int(h != level_op)  # the opposite operator opens a parenthesis one level down; the same one is associative
-            first = len(leaves)
-            for sub in e[1:]:
-                node(sub, h, depth + own)
-            if own and len(leaves) > first:
-                clo[-1] += 1
-
-        node(where, head, 0)
-        maxd = max(dep) if dep else 0
-        if len(leaves) > L.RFX_MAX_PREDS or maxd > 3 or (maxd > 1 and len(leaves) < 3):
-            raise _NotFused()
-        if maxd <= 1:
-            more = [1 if (d == 1 and c == 0) else 0 for d, c in zip(dep, clo)]
-        else:
-            more = [L.RFX_PRED_TREE | d | (c << 4) for d, c in zip(dep, clo)]
-        return (L.RFX_AND if head == "and" else L.RFX_OR), leaves, more
-
-    def _preds(self, leaves: Sequence[tuple], more: Sequence[int], table, n: Optional[int]):
-        arr = (L.Pred * max(1, len(leaves)))()
-        for i, (op, lhs, rhs) in enumerate(leaves):
-            lhs = self._check_col(self._resolve(lhs, table), n)
-            n = lhs.numel() if n is None else n
-            p = arr[i]
-            p.more = more[i]
-            p.d_col, p.col_type, p.op = lhs.data_ptr(), _ctype_of(lhs), L.OPS[op]
-            rhs = self._resolve(rhs, table) if isinstance(rhs, (str, tuple)) else rhs
-            if isinstance(rhs, torch.Tensor):
-                rhs = self._check_col(rhs, n)
-                p.d_rhs_col, p.rhs_type = rhs.data_ptr(), _ctype_of(rhs)
-                self._keep.append(rhs)
-            elif isinstance(rhs, bool):
-                raise RfxError("boolean atoms are not comparable on this path")
-            elif isinstance(rhs, int):
-                p.d_rhs_col, p.rhs_type, p.rhs_i = None, L.RFX_I64, rhs
-            elif isinstance(rhs, float):
-                p.d_rhs_col, p.rhs_type, p.rhs_f = None, L.RFX_F64, rhs
-            elif rhs is None:  # null atom compares as 0Nl
-                p.d_rhs_col, p.rhs_type, p.rhs_i = None, L.RFX_I64, L.NULL_I64
-            else:
-                raise RfxError(f"unsupported rhs {type(rhs)}")
-            self._keep.append(lhs)
-        return arr, n
-
-    def _aggs(self, aggs: Sequence[Tuple[str, object]], table, n: Optional[int]):
-        if len(aggs) > L.RFX_EXEC_MAX_AGGS:
-            raise RfxError(f"more than {L.RFX_EXEC_MAX_AGGS} output columns in one query")
-        arr = (L.Agg * max(1, len(aggs)))()
-        for i, (fn, col) in enumerate(aggs):
-            a = arr[i]
-            a.kind = L.AGGS[fn]
-            if isinstance(col, tuple):
-                n = self._agg_expr(a, col, table, n)
-                continue
-            col = self._resolve(col, table) if col is not None else None
-            if col is None:
-                if fn != "count":
-                    raise RfxError(f"{fn} needs a column")
-                a.d_col, a.col_type = None, L.RFX_I64
-            else:
-                col = self._check_col(col, n)
-                n = col.numel() if n is None else n
-                a.d_col, a.col_type = col.data_ptr(), _ctype_of(col)
-                self._keep.append(col)
-        return arr, n
-
-    def _agg_expr(self, a, expr, table, n):
-        """``(op x y)`` with x / y columns, atoms or such expressions -> rfx_xnode_t list in evaluation order."""
-        nodes = []
-
-        def operand(x, o):
-            nonlocal n
-            if isinstance(x, tuple):
-                o.kind, o.node = L.RFX_XK_NODE, build(x)
-                return
-            x = self._resolve(x, table) if isinstance(x, (str, torch.Tensor)) else x
-            if isinstance(x, torch.Tensor):
-                col = self._check_col(x, n)
-                n = col.numel() if n is None else n
-                o.kind, o.type, o.d_col = L.RFX_XK_COL, _ctype_of(col), col.data_ptr()
-                self._keep.append(col)
-            elif isinstance(x, float):
-                o.kind, o.type, o.f = L.RFX_XK_ATOM, L.RFX_F64, x
-            else:
-                o.kind, o.type, o.i = L.RFX_XK_ATOM, L.RFX_I64, L.NULL_I64 if x is None else int(x)
-
-        def build(e) -> int:
-            if len(e) != 3 or e[0] not in L.XOPS:
-                raise RfxError(f"unsupported expression {e!r}: (op lhs rhs) with op in + - * div / %")
-            node = L.XNode()
-            node.op = L.XOPS[e[0]]
-            operand(e[1], node.l)
-            operand(e[2], node.r)
-            nodes.append(node)
-            return len(nodes) - 1
-
-        build(expr)
-        if len(nodes) > L.RFX_MAX_XNODES:
-            raise RfxError(f"expression too deep: at most {L.RFX_MAX_XNODES} operations")
-        if not any(o.kind == L.RFX_XK_COL for nd in nodes for o in (nd.l, nd.r)):
-            raise RfxError("an expression needs at least one column operand")
-        arr = (L.XNode * len(nodes))(*nodes)
-        self._keep.append(arr)
-        a.nxnodes, a.xnodes, a.d_col, a.col_type = len(nodes), arr, None, L.RFX_I64
-        return n
+        return M.resolve(self, x, table)
 
     def _query(self, where, aggs, table, nrows: Optional[int], keys=None, flags: int = 0) -> Tuple[L.Query, int]:
         """The planner's query over this engine's shards: descriptors in shard 0's addresses + every column's address per shard."""
@@ -322,13 +195,13 @@ class Engine:
             self._keep.append(m)
         else:
             try:
-                logic, leaves, more = self._leaves(where)
+                logic, leaves, more = M.tree_leaves(self, where)
             except _NotFused:
                 return self._query(self.mask_of(where, table), aggs, table, nrows, keys, flags)
-            parr, n = self._preds(leaves, more, table, n)
+            parr, n = M.preds(self, leaves, more, table, n)
             q.preds, q.npred, q.logic = parr, len(leaves), logic
             self._keep.append(parr)
-        aarr, n = self._aggs(aggs or [], table, n)
+        aarr, n = M.aggs(self, aggs or [], table, n)
         q.aggs, q.nagg = aarr, len(aggs or [])
         self._keep.append(aarr)
         if keys:
@@ -373,11 +246,12 @@ class Engine:
             return float("nan") if v.is_null else float(v.f)
         return None if v.is_null else int(v.i)
 
-    def _copy_out(self, d_src: int, n: int, dtype) -> torch.Tensor:
-        out = self.empty(n, dtype)
-        if n:
-            L.check(self.lib.rfx_hip_d2d(self._ctx, out.data_ptr(), C.c_void_p(d_src), n * 8), "d2d")
-        return out
+    def _view(self, owner, d_src: int, n: int, dtype) -> torch.Tensor:
+        """A planner-owned device column as a torch tensor WITHOUT a copy: torch aliases the memory through __cuda_array_interface__ and keeps
+        `owner` alive; the planner's blocks are released when the last tensor over them dies."""
+        if not n or not d_src:
+            return self.empty(0, dtype)
+        return torch.as_tensor(_View(owner, d_src, n, "<f8" if dtype == torch.float64 else "<i8"), device=self.device)
 
     # ------------------------------------------------------------------ scalar aggregates (K1/K5)
     def filter_aggr(self, aggs, where=None, table=None, nrows: Optional[int] = None):
@@ -400,7 +274,7 @@ class Engine:
     def cmp(self, op: str, lhs, rhs, table=None) -> torch.Tensor:
         """ray_eq .. ray_ge on a column: B8 byte mask (int8 tensor of 0/1)."""
         self._keep.clear()
-        parr, n = self._preds([(op, lhs, rhs)], [0], table, None)
+        parr, n = M.preds(self, [(op, lhs, rhs)], [0], table, None)
         out = torch.empty(n, dtype=torch.int8, device=self.device)
         L.check(self.lib.rfx_hip_cmp_mask(self._ctx, parr, n, out.data_ptr()), "cmp_mask")
         return out
@@ -443,14 +317,15 @@ class Engine:
         q.row0 = row0
         ids = L.Ids()
         self._xcheck(self.lib.rfx_exec_where(self._x, C.byref(q), C.byref(ids)), "where")
-        out = self.empty(int(ids.total))
-        at = 0
+        owner = _Owner(self, ids, self.lib.rfx_exec_ids_free)
+        if ids.nshards == 1:
+            return self._view(owner, ids.d_ids[0], int(ids.total), torch.int64)
+        out, at = self.empty(int(ids.total)), 0
         for s in range(ids.nshards):  # shard order = row order
             if ids.count[s]:
                 L.check(self.lib.rfx_hip_d2d(self._ctx, out.data_ptr() + at * 8, C.c_void_p(ids.d_ids[s]), ids.count[s] * 8), "d2d")
                 at += ids.count[s]
         self.sync()
-        self.lib.rfx_exec_ids_free(self._x, C.byref(ids))
         return out
 
     def at_ids(self, col: torch.Tensor, ids: torch.Tensor) -> torch.Tensor:
@@ -468,7 +343,7 @@ class Engine:
         core/math.c:2280-2345) in ONE pass whatever the depth."""
         a = L.Agg()
         keep, self._keep = self._keep, []
-        n = self._agg_expr(a, expr, table, None)
+        n = M.agg_expr(self, a, expr, table, None)
         out = torch.empty(n, dtype=torch.float64 if L.agg_input_type(a) == L.RFX_F64 else torch.int64, device=self.device)
         t = C.c_int32()
         L.check(self.lib.rfx_hip_eval_expr(self._ctx, C.byref(a), n, out.data_ptr(), C.byref(t)), "eval_expr")
@@ -478,8 +353,8 @@ class Engine:
     def scope(self, key: torch.Tensor, where=None, table=None) -> Tuple[int, int, int]:
         """index_scope_i64 (core/index.c:376-435): (min, max, rows seen) of a key column through the predicates.  (syncs)"""
         self._keep.clear()
-        logic, leaves, more = self._leaves(where)
-        parr, n = self._preds(leaves, more, table, self._check_col(key).numel())
+        logic, leaves, more = M.tree_leaves(self, where)
+        parr, n = M.preds(self, leaves, more, table, self._check_col(key).numel())
         mn, mx, cnt = C.c_int64(), C.c_int64(), C.c_int64()
         L.check(self.lib.rfx_hip_scope_i64(self._ctx, key.data_ptr(), parr, len(leaves), logic, n, C.byref(mn), C.byref(mx), C.byref(cnt)), "scope_i64")
         return int(mn.value), int(mx.value), int(cnt.value)
@@ -501,19 +376,16 @@ class Engine:
         q, n = self._query(where, aggs, table, None, keys, flags | L.RFX_Q_WANT_FIRST | (L.RFX_Q_PROBE_FIRST if probe_first else 0))
         g = L.Groups()
         self._xcheck(self.lib.rfx_exec_group_by(self._x, C.byref(q), C.byref(g)), "group_by")
-        try:
-            ng = int(g.groups)
-            res = [self._copy_out(g.d_results[a], ng, torch.float64 if g.result_type[a] == L.RFX_F64 else torch.int64) for a in range(len(aggs))] if ng else \
-                  [self.empty(0, torch.float64 if (fn == "avg" or (fn != "count" and col is not None and self._arg_f64(col, table))) else torch.int64) for fn, col in aggs]
-            r = dict(groups=ng, keys=self._copy_out(g.d_keys, ng, torch.int64), first=self._copy_out(g.d_first, ng, torch.int64), results=res,
-                     dense=g.path in (L.RFX_PATH_DENSE, L.RFX_PATH_DENSE_SMALL), cap=int(g.capacity), path=int(g.path))
-            if len(keys) > 1:
-                r["key_columns"] = [self._copy_out(g.d_keycols[i], ng, torch.int64) for i in range(len(keys))]
-            if probe_first and g.d_probe:
-                r["probe"] = self._copy_out(g.d_probe, n, torch.int64)
-            self.sync()
-        finally:
-            self.lib.rfx_exec_groups_free(self._x, C.byref(g))
+        own = _Owner(self, g, self.lib.rfx_exec_groups_free)
+        ng = int(g.groups)
+        res = [self._view(own, g.d_results[a], ng, torch.float64 if g.result_type[a] == L.RFX_F64 else torch.int64) for a in range(len(aggs))] if ng else \
+              [self.empty(0, torch.float64 if (fn == "avg" or (fn != "count" and col is not None and self._arg_f64(col, table))) else torch.int64) for fn, col in aggs]
+        r = dict(groups=ng, keys=self._view(own, g.d_keys, ng, torch.int64), first=self._view(own, g.d_first, ng, torch.int64), results=res,
+                 dense=g.path in (L.RFX_PATH_DENSE, L.RFX_PATH_DENSE_SMALL), cap=int(g.capacity), path=int(g.path))
+        if len(keys) > 1:
+            r["key_columns"] = [self._view(own, g.d_keycols[i], ng, torch.int64) for i in range(len(keys))]
+        if probe_first and g.d_probe:
+            r["probe"] = self._view(own, g.d_probe, n, torch.int64)
         if order == "radix" and r["groups"] > 1 and r["path"] == L.RFX_PATH_ROWHASH:  # a different ORDER of the same groups, for the golden sets of that arm
             perm = torch.argsort((r["keys"] & 1023) * (1 << 40) + torch.argsort(torch.argsort(r["first"])), stable=True)
             r["keys"], r["first"] = r["keys"][perm], r["first"][perm]
@@ -526,76 +398,23 @@ class Engine:
         if isinstance(col, tuple):
             a = L.Agg()
             keep, self._keep = self._keep, []
-            self._agg_expr(a, col, table, None)
+            M.agg_expr(self, a, col, table, None)
             self._keep = keep
             return L.agg_input_type(a) == L.RFX_F64
         return self._resolve(col, table).dtype == torch.float64
 
-    # ------------------------------------------------------------------ equi-joins: lj / ij, core/join.c:158-298
-    def join_index(self, keys, left: Dict[str, torch.Tensor], right: Dict[str, torch.Tensor]) -> torch.Tensor:
-        """Per LEFT row the FIRST right row with an equal key tuple, or null (index_left_join_obj, core/index.c:2886-2928): the planner's
-        rfx_exec_join_index (dense / hashed build side, composite key or row hash + tuple check)."""
-        keys = [keys] if isinstance(keys, str) else list(keys)
-        lk = [self._check_col(self._resolve(k, left)) for k in keys]
-        rk = [self._check_col(self._resolve(k, right)) for k in keys]
-        if any(c.dtype != torch.int64 for c in lk + rk):
-            raise RfxError("join keys must be i64-like columns on this path")
-        nl, nr = lk[0].numel(), rk[0].numel()
-        ids = self.empty(nl)
-        k = len(keys)
-        col = C.c_int(0)
-        rc = self.lib.rfx_exec_join_index(self._x, (C.c_void_p * k)(*[c.data_ptr() for c in lk]), (C.c_void_p * k)(*[c.data_ptr() for c in rk]), k, nl, nr,
-                                          ids.data_ptr(), C.byref(col))
-        if rc != L.RFX_OK and col.value:
-            raise RfxError("join: two key tuples share one 64-bit row hash (collision); not answered on this path")
-        self._xcheck(rc, "join_index")
-        return ids
+    # ------------------------------------------------------------------ equi-joins: rayforce_amd/joins.py
+    def join_index(self, keys, left, right) -> torch.Tensor:
+        from . import joins
+        return joins.join_index(self, keys, left, right)
 
-    def left_join(self, keys, left: Dict[str, torch.Tensor], right: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
-        """``(lj [keys] left right)`` -- ray_left_join, core/join.c:158-198: every left row; a non-key column that the right table has takes
-        the matched right row's value, else the left row's own (null when the left table lacks the column); columns: keys, then the other
-        left columns, then the right-only ones.  Empty side -> the left table."""
-        keys = [keys] if isinstance(keys, str) else list(keys)
-        nl = next(iter(left.values())).numel() if left else 0
-        nr = next(iter(right.values())).numel() if right else 0
-        if nl == 0 or nr == 0:
-            return dict(left)
-        ids = self.join_index(keys, left, right)
-        out = {k: left[k] for k in keys}
-        for name in [c for c in left if c not in keys] + [c for c in right if c not in keys and c not in left]:
-            if name not in right:
-                out[name] = left[name]
-                continue
-            rc, lc = right[name], left.get(name)
-            if lc is not None and lc.dtype != rc.dtype:
-                raise RfxError(f"join: column {name} has different types in the two tables")
-            o = torch.empty(nl, dtype=rc.dtype, device=self.device)
-            fill = 0x7FF8000000000000 if rc.dtype == torch.float64 else (1 << 63)  # NaN / NULL_I64 bit patterns
-            L.check(self.lib.rfx_hip_gather_or(self._ctx, rc.data_ptr(), lc.data_ptr() if lc is not None else None, ids.data_ptr(), nl, fill, o.data_ptr()), "gather_or")
-            out[name] = o
-        self.sync()
-        return out
+    def left_join(self, keys, left, right) -> Dict[str, torch.Tensor]:
+        from . import joins
+        return joins.left_join(self, keys, left, right)
 
-    def inner_join(self, keys, left: Dict[str, torch.Tensor], right: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
-        """``(ij [keys] left right)`` -- ray_inner_join, core/join.c:200-298: the left rows that have a match, in left order, paired with
-        their first matching right row; a column the right table has comes from the right row."""
-        keys = [keys] if isinstance(keys, str) else list(keys)
-        nl = next(iter(left.values())).numel() if left else 0
-        nr = next(iter(right.values())).numel() if right else 0
-        if nl == 0 or nr == 0:
-            return dict(left)
-        ids = self.join_index(keys, left, right)
-        lids = self.where(("!=", ids, None))  # ascending left rows with a match
-        rids = self.at_ids(ids, lids)
-        out = {}
-        for name in keys + [c for c in left if c not in keys] + [c for c in right if c not in keys and c not in left]:
-            if name in right:
-                if name in left and left[name].dtype != right[name].dtype:
-                    raise RfxError(f"join: column {name} has different types in the two tables")
-                out[name] = self.at_ids(right[name], rids)
-            else:
-                out[name] = self.at_ids(left[name], lids)
-        return out
+    def inner_join(self, keys, left, right) -> Dict[str, torch.Tensor]:
+        from . import joins
+        return joins.inner_join(self, keys, left, right)
 
     # ------------------------------------------------------------------ the select surface (core/query.c:607-654)
     def select(self, query: Dict) -> Dict[str, torch.Tensor]:

@@ -20,8 +20,8 @@ def declared(header):
 def test_library_exports_every_declared_symbol(built):
     from rayforce_amd import _lib, hostobj
     lib = _lib.load_library()
-    names = declared("rfx_hip.h") + declared("rfx_ops.h")
-    assert len(names) > 70
+    names = declared("rfx_hip.h") + declared("rfx_ops.h") + declared("rfx_exec.h")
+    assert len(names) > 100
     missing = [n for n in names if not hasattr(lib, n)]
     assert not missing, missing
     # the python prototypes cover the headers one to one
@@ -36,6 +36,15 @@ def test_struct_layouts(built):
     assert L.Agg.xnodes.offset == 48 and C.sizeof(L.XNode) == 56 and L.XNode.r.offset == 32
     assert C.sizeof(L.Partial) == 64 and C.sizeof(L.Value) == 16
     assert C.sizeof(L.GroupTables) == 8 + 8 + 8 + 8 + 64 + 64
+    # include/rfx_exec.h: the planner's structures as the C compiler lays them out (a small program prints the sizes)
+    import subprocess, tempfile
+    with tempfile.TemporaryDirectory() as td:
+        src = os.path.join(td, "s.c")
+        open(src, "w").write('#include <stdio.h>\n#include <stddef.h>\n#include "rfx_exec.h"\nint main(void){printf("%zu %zu %zu %zu %zu %zu %zu\\n", sizeof(rfx_query_t), '
+                             'sizeof(rfx_groups_t), sizeof(rfx_ids_t), sizeof(rfx_qcol_t), sizeof(rfx_transport_t), offsetof(rfx_query_t, key_scope), offsetof(rfx_groups_t, d_block));return 0;}\n')
+        subprocess.run(["gcc", "-std=c11", "-I", os.path.join(ROOT, "include"), src, "-o", os.path.join(td, "s")], check=True)
+        sizes = [int(x) for x in subprocess.run([os.path.join(td, "s")], capture_output=True, text=True, check=True).stdout.split()]
+    assert sizes == [C.sizeof(L.Query), C.sizeof(L.Groups), C.sizeof(L.Ids), C.sizeof(L.QCol), C.sizeof(L.Transport), L.Query.key_scope.offset, L.Groups.d_block.offset], sizes
     from rayforce_amd.hostobj import Header
     assert C.sizeof(Header) == 16 and Header.type.offset == 2 and Header.rc.offset == 4 and Header.len.offset == 8
 
@@ -43,7 +52,7 @@ def test_struct_layouts(built):
 def test_abi_header_compiles_as_c_and_cxx(built, tmp_path):
     import subprocess
     src = tmp_path / "t.c"
-    src.write_text('#include "rfx_abi.h"\n#include "rfx_hip.h"\n#include "rfx_ops.h"\nint main(void){return (sizeof(rfx_obj_t)==16 && sizeof(rfx_agg_t)==56 && sizeof(rfx_xnode_t)==56 && sizeof(rfx_pred_t)==40 && sizeof(rfx_partial_t)==64)?0:1;}\n')
+    src.write_text('#include "rfx_abi.h"\n#include "rfx_hip.h"\n#include "rfx_exec.h"\n#include "rfx_ops.h"\nint main(void){return (sizeof(rfx_obj_t)==16 && sizeof(rfx_agg_t)==56 && sizeof(rfx_xnode_t)==56 && sizeof(rfx_pred_t)==40 && sizeof(rfx_partial_t)==64)?0:1;}\n')
     for cc, std in (("gcc", "-std=c11"), ("g++", "-std=c++17")):
         exe = tmp_path / ("a_" + cc)
         subprocess.run([cc, std, "-x", "c" if cc == "gcc" else "c++", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
