@@ -52,6 +52,10 @@ struct rfx_exec {
     const void *spec_failed[32];
     int64_t spec_failed_n[32];
     int nspec_failed, spec_ring;
+    /* ... and key columns whose sample said "wider than the LDS forms": the sample (a launch and a round trip) is not taken again for them */
+    const void *spec_wide[32];
+    int64_t spec_wide_n[32];
+    int nspec_wide, wide_ring;
     int64_t stat[RFX_XSTAT_N];
     char err[512];
 };
@@ -170,7 +174,7 @@ rfx_ctx_t *rfx_exec_ctx(const rfx_exec_t *x, int shard) { return (x && shard >= 
 int64_t rfx_exec_stat(const rfx_exec_t *x, int which) { return (x && which >= 0 && which < RFX_XSTAT_N) ? x->stat[which] : -1; }
 const char *rfx_exec_last_error(const rfx_exec_t *x) { return x ? x->err : "rfx_exec: NULL"; }
 void rfx_exec_forget_scopes(rfx_exec_t *x) {
-    if (x) x->nspec_failed = x->spec_ring = 0;
+    if (x) x->nspec_failed = x->spec_ring = x->nspec_wide = x->wide_ring = 0;
 }
 
 void rfx_exec_split(int64_t nrows, int nshards, int shard, int64_t *row0, int64_t *len) {
@@ -777,7 +781,8 @@ static int ph_pass(void *arg, int s) {
         }
         if (rc != RFX_OK) return rc;
     }
-    return rfx_hip_ctx_sync(c);
+    /* a phase ends when the shard's stream is idle -- what the merge needs; ONE shard goes on in stream order (a sync is ~25 us of idle device) */
+    return (G->S > 1 || G->exch) ? rfx_hip_ctx_sync(c) : RFX_OK;
 }
 /* shards that share a device: the device's lead folds their tables into its own (kernel / re-insertion), on its own stream */
 static int ph_merge_local(void *arg, int s) {
@@ -987,7 +992,7 @@ static int ph_rank_emit(void *arg, int s) {
     rc = G->dense ? rfx_hip_group_emit_sharded(c, h->aggs, &h->gt, r0, nloc, (int64_t *)h->dout, (int64_t *)h->dfirst, ptrs)
                   : rfx_hip_hash_emit_sharded(c, h->aggs, &h->ht, r0, nloc, (int64_t *)h->dout, (int64_t *)h->dfirst, ptrs);
     if (rc != RFX_OK) return rc;
-    return rfx_hip_ctx_sync(c);
+    return multi ? rfx_hip_ctx_sync(c) : RFX_OK; /* (one shard: the tables are released in stream order, the caller reads in stream order) */
 }
 /* FIRST columns of the shards beside a lead, added into the lead's (exactly one shard wrote each value) */
 static int ph_first_local(void *arg, int s) {
@@ -1042,6 +1047,18 @@ static void spec_remember_bad(rfx_exec_t *x, const void *key, int64_t n) {
     x->spec_failed_n[i] = n;
     if (x->nspec_failed < 32) x->nspec_failed++;
 }
+static int spec_known_wide(rfx_exec_t *x, const void *key, int64_t n) {
+    for (int i = 0; i < x->nspec_wide; i++)
+        if (x->spec_wide[i] == key && x->spec_wide_n[i] == n) return 1;
+    return 0;
+}
+static void spec_remember_wide(rfx_exec_t *x, const void *key, int64_t n) {
+    if (spec_known_wide(x, key, n)) return;
+    const int i = x->wide_ring++ % 32;
+    x->spec_wide[i] = key;
+    x->spec_wide_n[i] = n;
+    if (x->nspec_wide < 32) x->nspec_wide++;
+}
 static void own(rfx_groups_t *g, void *p) {
     if (p && g->nown < (int)(sizeof(g->own) / sizeof(g->own[0]))) g->own[g->nown++] = p;
 }
@@ -1091,7 +1108,8 @@ rescope:
     for (int s = 0; s < S; s++) sh[s].key = sh[s].keys[0];
     if (G->nkeys == 1) {
         int have = 0;
-        if (spec_ok) {
+        /* (a DENSE key range the sample found wider than the LDS forms last time takes the scope pass at once: that pass samples for itself) */
+        if (spec_ok && !(any_xbar == 0 && spec_known_wide(x, spec_id, q->nrows))) {
             if ((rc = run_shards(x, ph_scope_sample, G)) != RFX_OK) goto done;
             if ((rc = fold_scope(G, 0, &G->kmin, &G->kmax, &G->seen)) != RFX_OK) goto done;
             G->spec = G->seen > 0 && G->kmin != NULL_I64 && G->kmax >= G->kmin && (uint64_t)(G->kmax - G->kmin) < RFX_SCOPE_SAMPLE_MAX_RANGE;
@@ -1105,6 +1123,7 @@ rescope:
                 G->sparse_sampled = 1;
                 have = 1;
             }
+            if (!have && !any_xbar && G->kmin != NULL_I64) spec_remember_wide(x, spec_id, q->nrows); /* neither LDS-sized nor sparse: dense and wide */
         }
         if (!have && q->key_scope && !any_xbar && !q->d_mask && !G->exch && q->key_scope[0] != NULL_I64 && q->key_scope[1] >= q->key_scope[0] &&
             (uint64_t)(q->key_scope[1] - q->key_scope[0]) < RFX_SCOPE_SAMPLE_MAX_RANGE) {

@@ -58,9 +58,15 @@ struct PlSh {
 };
 // A group is 2^VGL records (32: two 128-byte lines per value plane and one of meta; 16: one line and half a line), a partition's ring two
 // groups per plane.
-template <int NV, int PBITS, int VGL>
+// PARTITIONS: 2^PBITS -- except the sparse-key form <PBITS 8, VGL 4, HK>: 192 partitions by multiply-shift of the hash (round 4).  192 x 16-record
+// rings of {key, value, meta} fill 125 KB of LDS, and 1e6 keys / 192 = 5 208 keys of 20 bytes fit ONE workgroup's LDS table in the aggregate
+// pass: every record is streamed once there, where 128 partitions needed two workgroups per partition that each streamed all of it
+// (42.8 of the 88 GB the query moved).
+template <int PBITS, int VGL, bool HK>
+__host__ __device__ constexpr int pl_parts() { return (HK && PBITS == 8 && VGL == 4) ? 192 : (1 << PBITS); }
+template <int NV, int PBITS, int VGL, bool HK = false>
 __host__ __device__ constexpr size_t pl_lds_bytes() {
-    return (size_t)(1 << PBITS) * ((size_t)(2 << VGL) * (NV * 8 + 4) + 8 + 4) + (size_t)PL_WAVES * PL_QCAP * 4 + sizeof(PlSh) + 64;
+    return (size_t)pl_parts<PBITS, VGL, HK>() * ((size_t)(2 << VGL) * (NV * 8 + 4) + 8 + 4) + (size_t)PL_WAVES * PL_QCAP * 4 + sizeof(PlSh) + 64;
 }
 typedef u64 pl_v2 __attribute__((ext_vector_type(2)));
 typedef unsigned pl_m2 __attribute__((ext_vector_type(2)));
@@ -73,7 +79,8 @@ typedef unsigned pl_m2 __attribute__((ext_vector_type(2)));
 // (where the aggregate pass starts probing its LDS table) instead of the slot inside the partition; plane 0 is then the key column itself.
 template <int NC, int NP, int NV, int PBITS, int VGL, bool HK = false>
 __global__ __launch_bounds__(PL_T) void k_plane_scatter(const Plan P, const PlaneArgs A) {
-    constexpr int PARTS = 1 << PBITS;
+    constexpr int PARTS = pl_parts<PBITS, VGL, HK>();
+    constexpr bool P192 = PARTS != (1 << PBITS); // multiply-shift partitions (not a power of two): regions at (block * PARTS + p)
     constexpr unsigned VG = 1u << VGL, RING = 2u << VGL; // records per group / per ring
     constexpr unsigned LPD = VG / 2;                     // lanes that store one value group (16 bytes = two records each); meta: half of them
     extern __shared__ __attribute__((aligned(16))) unsigned char pl_smem[];
@@ -89,7 +96,7 @@ __global__ __launch_bounds__(PL_T) void k_plane_scatter(const Plan P, const Plan
     unsigned *myq = fq + wv * PL_QCAP;
     const i64 r0 = (i64)blockIdx.x * A.block_rows;
     const i64 r1 = (r0 + A.block_rows < P.nrows) ? r0 + A.block_rows : P.nrows;
-    const u64 region = ((u64)blockIdx.x << PBITS) * A.c0;
+    const u64 region = ((u64)blockIdx.x * (u64)PARTS) * A.c0;
     for (int i = tid; i < PARTS; i += PL_T) {
         tail[i] = 0;
         words[2 * i] = 0;
@@ -130,7 +137,7 @@ __global__ __launch_bounds__(PL_T) void k_plane_scatter(const Plan P, const Plan
     // one selected row per lane (or none): takes its place in its partition's ring, writes, counts itself in, queues completed groups
     auto place = [&](const bool on, const u64 key, const u64 (&val)[NV], const unsigned delta) __attribute__((always_inline)) {
         const u64 kh = HK ? rfx_hash_index_u64(RFX_U64_HASH_SEED, key) : key;
-        const unsigned p = HK ? (unsigned)(kh >> (64 - PBITS)) : ((unsigned)key & (unsigned)(PARTS - 1));
+        const unsigned p = P192 ? (unsigned)(((kh >> 32) * (u64)PARTS) >> 32) : (HK ? (unsigned)(kh >> (64 - PBITS)) : ((unsigned)key & (unsigned)(PARTS - 1)));
         unsigned seq = 0;
         if (on) {
             const i64 k = (i64)key;
@@ -153,7 +160,7 @@ __global__ __launch_bounds__(PL_T) void k_plane_scatter(const Plan P, const Plan
                 const unsigned at = p * RING + (seq & (RING - 1u));
 #pragma unroll
                 for (int j = 0; j < NV; j++) vring[(size_t)j * PARTS * RING + at] = val[j];
-                mring[at] = ((unsigned)(HK ? (kh >> (64 - PBITS - PL_SLOT_BITS)) : (key >> PBITS)) & ((1u << PL_SLOT_BITS) - 1u)) | (delta << PL_SLOT_BITS);
+                mring[at] = ((unsigned)(P192 ? (kh >> 18) : (HK ? (kh >> (64 - PBITS - PL_SLOT_BITS)) : (key >> PBITS))) & ((1u << PL_SLOT_BITS) - 1u)) | (delta << PL_SLOT_BITS);
                 asm volatile("" ::: "memory"); // the record is in the ring before it is counted (LDS executes a wave's operations in order)
                 comp = (atomicAdd(w, 1u) & 0xFFu) == VG - 1u;
                 todo = false;
@@ -294,7 +301,7 @@ __global__ __launch_bounds__(PL_T) void k_plane_scatter(const Plan P, const Plan
     // the last, partly filled group of every plane of every partition (the region has room: c0 is a multiple of the group; the record count
     // ends before the padding)
     for (int i = tid; i < PARTS * (NV + 1) * (int)LPD; i += PL_T) {
-        const unsigned sub = (unsigned)i & (LPD - 1u), p = ((unsigned)i / LPD) & (unsigned)(PARTS - 1), pl = ((unsigned)i / LPD) >> PBITS;
+        const unsigned sub = (unsigned)i & (LPD - 1u), p = ((unsigned)i / LPD) % (unsigned)PARTS, pl = ((unsigned)i / LPD) / (unsigned)PARTS;
         const unsigned t = tail[p];
         if (!(t & (VG - 1u))) continue;
         const unsigned gi = t >> VGL;
@@ -307,7 +314,7 @@ __global__ __launch_bounds__(PL_T) void k_plane_scatter(const Plan P, const Plan
             *(pl_v2 *)(A.meta + region + (u64)p * A.c0 + (u64)gi * VG + sub * 4) = x;
         }
     }
-    for (int i = tid; i < PARTS; i += PL_T) A.cnt[((size_t)blockIdx.x << PBITS) + i] = tail[i];
+    for (int i = tid; i < PARTS; i += PL_T) A.cnt[(size_t)blockIdx.x * PARTS + i] = tail[i];
     i64 sel = (i64)nsel;
     for (int s2 = 32; s2 >= 1; s2 >>= 1) {
         const i64 omn = (i64)rfx_shfl_xor_u64((u64)mn, s2), omx = (i64)rfx_shfl_xor_u64((u64)mx, s2);
@@ -520,8 +527,8 @@ int rfx_chunk_reserve(rfx_ctx *c, size_t bytes);
 static size_t pl_al256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 // scratch block: [ctl 256 B][region counts][meta plane][value planes]
-static void plane_layout(rfx_ctx *c, int nblk, int pbits, unsigned c0, int nv, PlaneArgs *A, size_t *total) {
-    const size_t regions = (size_t)nblk << pbits;
+static void plane_layout(rfx_ctx *c, int nblk, int pbits, unsigned c0, int nv, PlaneArgs *A, size_t *total, int parts = 0) {
+    const size_t regions = parts ? (size_t)nblk * (size_t)parts : (size_t)nblk << pbits;
     const size_t o_cnt = 256;
     const size_t o_meta = o_cnt + pl_al256(regions * 4), o_val = o_meta + pl_al256(regions * c0 * 4);
     const size_t plane = pl_al256(regions * c0 * 8);
@@ -538,7 +545,7 @@ static void plane_layout(rfx_ctx *c, int nblk, int pbits, unsigned c0, int nv, P
 
 template <int NC, int NP, int NV, int PBITS, int VGL, bool HK = false>
 static int launch_plane_scatter_inst(rfx_ctx *c, const Plan &P, const PlaneArgs &A) {
-    constexpr size_t lds = pl_lds_bytes<NV, PBITS, VGL>();
+    constexpr size_t lds = pl_lds_bytes<NV, PBITS, VGL, HK>();
     static_assert(lds <= 160 * 1024, "rings beyond a CU's LDS");
     static unsigned long long attr_set = 0; /* one bit per device: function attributes are per device */ // per instantiation
     if (!((attr_set >> (c->device & 63)) & 1ull)) {
@@ -862,6 +869,7 @@ int rfx_plane_accumulate(rfx_ctx *c, const Plan &P, int key_idx, const rfx_group
 struct PlaneHashArgs {
     HashArgs H;
     int nblk, pbits, hbits; // hbits: log2(workgroups per partition)
+    int parts;              // partitions (2^pbits, or 192): region (b, p) sits at entry (b * parts + p) * c0
     i64 block_rows;
     unsigned c0;
     unsigned lcap; // LDS table entries
@@ -968,7 +976,7 @@ __global__ __launch_bounds__(PLH_T) void k_plane_hash_aggregate(const Plan P, co
         B.b = live ? b : 0;
         B.i0 = live ? i0 : 0u;
         B.n = live ? n : 0u;
-        const u64 base = (((u64)B.b << X.pbits) + (u64)p) * X.c0;
+        const u64 base = ((u64)B.b * (u64)X.parts + (u64)p) * X.c0;
 #pragma unroll
         for (int k = 0; k < 2; k++) {
             unsigned i = B.i0 + ((unsigned)k * 64u + (unsigned)lane) * 2u;
@@ -1002,7 +1010,7 @@ __global__ __launch_bounds__(PLH_T) void k_plane_hash_aggregate(const Plan P, co
             if (r >= nreg) return false;
             if ((r & 63) == 0) {
                 const int r0 = r + lane;
-                mywcnt[lane] = (r0 < nreg) ? X.cnt[((size_t)(q + r0 * NW) << X.pbits) + p] : 0u;
+                mywcnt[lane] = (r0 < nreg) ? X.cnt[(size_t)(q + r0 * NW) * (size_t)X.parts + p] : 0u;
             }
             n = (unsigned)__builtin_amdgcn_readfirstlane((int)mywcnt[r & 63]);
             b = q + r * NW;
@@ -1064,10 +1072,21 @@ int rfx_plane_hash_accumulate(rfx_ctx *c, const Plan &P, int key_idx, const Hash
     // 128 partitions (16-record store groups: 128-byte value lines), shared by 2 / 4 workgroups when a partition's keys overflow one LDS
     // table; 256 partitions (8-record groups: 64-byte lines) only beyond that.  Measured at 1e6 keys: 128 x 2 workgroups 8.1 + 12.6 ms,
     // 256 x 1 13.3 + 8.2 ms -- the short lines cost the scatter more than the single stream saves the aggregate.
-    int pbits = 7, hbits = 0;
-    if (est * 1.6 / (128.0 * 4.0) > (double)lcap) pbits = 8;
-    while (hbits < 2 && est * 1.6 / (double)((1 << pbits) << hbits) > (double)lcap) hbits++; // (every workgroup of a partition streams ALL its records: 4 is where that stops paying)
-    if (est * 1.6 / (double)((1 << pbits) << hbits) > (double)lcap) return RFX_ESTATE; // more keys than 512 LDS tables hold: round 1's kernels / the device-wide table
+    int pbits = 7, hbits = 0, parts = 128;
+    static const char *force = getenv("RFX_PLANE_HASH_PARTS"); // (A/B: 192 = the one-workgroup-per-partition form)
+    if (force && atoi(force) == 192 && est * 1.6 / 128.0 > (double)lcap && est * 1.2 / 192.0 <= (double)lcap) {
+        // round 4 experiment, OPT-IN (RFX_PLANE_HASH_PARTS=192): 192 partitions, ONE workgroup each -- every record streamed once (traffic
+        // 80 -> 58 GB).  Measured at 1e9 rows / 1e6 keys: scatter 7.8 ms (as with 128 partitions: same 16-record lines), aggregate 27 ms against
+        // 12.6 -- the aggregate is bound by LDS probing per record (192 CUs at load 0.70 instead of 256 at 0.53), not by the bytes it streams:
+        // the double stream was never the bottleneck.  Kept for the record and for tables that would otherwise overflow to the device-wide one.
+        pbits = 8;
+        parts = 192;
+    } else {
+        if (est * 1.6 / (128.0 * 4.0) > (double)lcap) pbits = 8;
+        while (hbits < 2 && est * 1.6 / (double)((1 << pbits) << hbits) > (double)lcap) hbits++; // (every workgroup of a partition streams ALL its records: 4 is where that stops paying)
+        if (est * 1.6 / (double)((1 << pbits) << hbits) > (double)lcap) return RFX_ESTATE; // more keys than 512 LDS tables hold: round 1's kernels / the device-wide table
+        parts = 1 << pbits;
+    }
     const i64 nblk64 = (nrows + PL_BLOCK_ROWS - 1) / PL_BLOCK_ROWS;
     if (nblk64 > (1 << 20)) return RFX_ESTATE;
     // key -> columns 0 and 1 (plane 0 IS the key), the value column -> 2 (plane 1; without one, the key again), the predicates' columns behind
@@ -1094,15 +1113,15 @@ int rfx_plane_hash_accumulate(rfx_ctx *c, const Plan &P, int key_idx, const Hash
         }
     }
     // selectivity: unknown here -- regions sized for every row (a selective filter only leaves them emptier)
-    double share = (double)PL_BLOCK_ROWS / (double)(1 << pbits);
+    double share = (double)PL_BLOCK_ROWS / (double)parts;
     unsigned c0 = (unsigned)(share * 1.25 + 160.0);
     c0 = (c0 + 127u) & ~127u;
     PlaneArgs A;
     memset(&A, 0, sizeof(A));
     size_t need = 0;
-    plane_layout(c, (int)nblk64, pbits, c0, 2, &A, &need);
+    plane_layout(c, (int)nblk64, pbits, c0, 2, &A, &need, parts);
     if (rfx_chunk_reserve(c, need) != RFX_OK) return RFX_ESTATE;
-    plane_layout(c, (int)nblk64, pbits, c0, 2, &A, NULL);
+    plane_layout(c, (int)nblk64, pbits, c0, 2, &A, NULL, parts);
     A.block_rows = PL_BLOCK_ROWS;
     for (int i = 0; i < Pc.npred; i++) {
         A.pmask |= 1u << Pc.preds[i].col;
@@ -1114,7 +1133,8 @@ int rfx_plane_hash_accumulate(rfx_ctx *c, const Plan &P, int key_idx, const Hash
     c->ext_i[3 + RFX_STAT_PLANE_SCATTER]++;
     RFX_KERNEL_BEGIN(c);
     int rc;
-    if (pbits == 7) rc = Pc.ncols == 3 ? launch_plane_scatter_np<3, 2, 7, 4, true>(c, Pc, A) : launch_plane_scatter_np<4, 2, 7, 4, true>(c, Pc, A);
+    if (parts == 192) rc = Pc.ncols == 3 ? launch_plane_scatter_np<3, 2, 8, 4, true>(c, Pc, A) : launch_plane_scatter_np<4, 2, 8, 4, true>(c, Pc, A);
+    else if (pbits == 7) rc = Pc.ncols == 3 ? launch_plane_scatter_np<3, 2, 7, 4, true>(c, Pc, A) : launch_plane_scatter_np<4, 2, 7, 4, true>(c, Pc, A);
     else rc = Pc.ncols == 3 ? launch_plane_scatter_np<3, 2, 8, 3, true>(c, Pc, A) : launch_plane_scatter_np<4, 2, 8, 3, true>(c, Pc, A);
     if (rc != RFX_OK) return rc;
     RFX_HIP_CHECK(hipGetLastError());
@@ -1131,6 +1151,7 @@ int rfx_plane_hash_accumulate(rfx_ctx *c, const Plan &P, int key_idx, const Hash
     X.nblk = (int)nblk64;
     X.pbits = pbits;
     X.hbits = hbits;
+    X.parts = parts;
     X.block_rows = PL_BLOCK_ROWS;
     X.c0 = c0;
     X.lcap = lcap;
@@ -1150,8 +1171,8 @@ int rfx_plane_hash_accumulate(rfx_ctx *c, const Plan &P, int key_idx, const Hash
     }
     c->ext_i[3 + RFX_STAT_PLANE_AGGREGATE]++;
     const bool fast = P.nagg == 1 && P.aggs[0].kind == RFX_AGG_SUM && P.aggs[0].f64 && !P.aggs[0].skipnull && X.agg_pl[0] == 1;
-    if (fast) hipLaunchKernelGGL(k_plane_hash_aggregate<true>, dim3((1 << pbits) << hbits), dim3(PLH_T), lds, c->stream, Pc, X);
-    else hipLaunchKernelGGL(k_plane_hash_aggregate<false>, dim3((1 << pbits) << hbits), dim3(PLH_T), lds, c->stream, Pc, X);
+    if (fast) hipLaunchKernelGGL(k_plane_hash_aggregate<true>, dim3(parts << hbits), dim3(PLH_T), lds, c->stream, Pc, X);
+    else hipLaunchKernelGGL(k_plane_hash_aggregate<false>, dim3(parts << hbits), dim3(PLH_T), lds, c->stream, Pc, X);
     RFX_KERNEL_END(c);
     RFX_HIP_CHECK(hipGetLastError());
     return RFX_OK;
