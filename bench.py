@@ -675,7 +675,8 @@ def launcher_door(args, name, eng, world, rank, rows, row0, total_rows):
         buf = C.create_string_buffer(128)
         L.check(ops.rfx_dist_unique_id(buf), "dist_unique_id")
         ident = [buf.raw]
-    dist.broadcast_object_list(ident, src=0)
+    if world > 1:
+        dist.broadcast_object_list(ident, src=0)
     L.check(ops.rfx_ops_dist_init(world, rank, C.c_char_p(ident[0])), "ops_dist_init")
     spec, q = C_DOOR[name]
     cols = door_columns(eng, spec, rows, row0)
@@ -686,7 +687,8 @@ def launcher_door(args, name, eng, world, rank, rows, row0, total_rows):
 
     def reduce_sum(x):
         t = torch.tensor([x], dtype=torch.float64, device="cuda") if isinstance(x, float) else x.cuda()
-        dist.all_reduce(t)
+        if world > 1:
+            dist.all_reduce(t)
         return float(t[0]) if isinstance(x, float) else t.cpu()
 
     checked = door_property_check(name, got, [cols], q, reduce_sum)
@@ -907,7 +909,7 @@ def main():
                     f"GB/s {WORKLOADS[name]['bytes_per_row'] * rows / kms / 1e6:.0f}")
         return
     ldoor = None
-    if world > 1 and name in C_DOOR and name != "q7" and not args.engine_door:
+    if (world > 1 or os.environ.get("RFX_BENCH_FORCE_LAUNCHER_DOOR")) and name in C_DOOR and name != "q7" and not args.engine_door:  # (the env: the N > 1 code on one rank)
         # every rank's shard through rfx_select, the operator layer's context inside the RCCL communicator: `value` is this door's
         if sharded is not None:
             sharded.close()

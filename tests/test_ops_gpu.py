@@ -1,6 +1,7 @@
 """Operator-level C ABI (include/rfx_ops.h) driven through obj_p arguments laid out like RayforceDB objects, by the
 standalone host object model (no reference process).  Checker: the CPU oracle."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -374,7 +375,10 @@ def test_cache_validates_by_page_bits_where_the_kernel_tracks_them(ops):
     s1 = H.to_numpy(ops.rfx_stats(0))
     assert s1[5] - s0[5] == 5 and s1[6] == s0[6]  # five cache hits either way
     tracked = s1[11] - s0[11]
-    assert tracked in (0, 5)  # all by page bits, or (no kernel support) all by checksum
+    if os.environ.get("RFX_SOFT_DIRTY") == "1":
+        assert tracked in (0, 5)  # opted in: all by page bits, or (no kernel support) all by checksum
+    else:
+        assert tracked == 0  # round 4: page tracking is OPT-IN (clear_refs write-protects every page of the host process)
     for j in (0, 1, n // 2, n - 2, n - 1, 511, 512):  # first / last partial page, whole pages
         wa[j] += 7
         total += 7
@@ -393,6 +397,18 @@ def test_cache_validates_by_page_bits_where_the_kernel_tracks_them(ops):
     assert s2[6] - s1[6] == 8  # every change refreshed the copy exactly once
     for o in (va, vb):
         ops.rfx_host_drop(o)
+
+
+def test_page_bit_validation_when_opted_in(built):
+    """The same test in a process started with RFX_SOFT_DIRTY=1: the soft-dirty path itself (clear -> checksum of every tracked column -> trust)."""
+    import subprocess, sys
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    env = dict(os.environ, RFX_SOFT_DIRTY="1")
+    p = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-p", "no:cacheprovider", "-k", "test_cache_validates_by_page_bits"],
+                       env=env, capture_output=True, text=True, timeout=600, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert p.returncode == 0 and "1 passed" in p.stdout, p.stdout[-2000:] + p.stderr[-2000:]
 
 
 def test_remembered_key_scope_follows_the_column(ops):
