@@ -488,28 +488,24 @@ __global__ __launch_bounds__(THREADS) void k_plane_aggregate(const Plan P, const
             i0 = 0;
         }
     };
-    // DEPTH batches in flight per wave (round 4; two before).  Under a selective filter a region holds a few hundred records -- ONE batch -- and
-    // a wave walks ~120 of them; the suspicion was one region per memory round trip.  Measured (C3w, 1e9 rows): 0.435 -> 0.424 ms with four in
-    // flight -- that was not it: 0.17 ms of the pass are the 4e6 device atomics of the final merge (two workgroups per partition share its slots),
-    // the rest the LDS atomics per record.  Kept at four (no cost: C3 2.11 ms either way).  Batches live in named register sets (the loops below
-    // are fully unrolled, every index a constant), every load stays unconditional, so the compiler still counts what is in flight.
-    constexpr int DEPTH = (NVL == 1) ? 4 : 2;
-    Batch B[DEPTH];
-    bool h[DEPTH];
-#pragma unroll
-    for (int k = 0; k < DEPTH; k++) {
-        h[k] = advance();
-        load(h[k], b, i0, n, B[k]);
+    // (Round 4 tried FOUR batches in flight per wave -- under a selective filter a region is one batch and a wave walks ~120 of them, the
+    // suspicion was one region per memory round trip.  C3w: 0.435 -> 0.424 ms, i.e. not it -- 0.17 ms of the pass are the 4e6 device atomics of the
+    // final merge (two workgroups per partition share its slots), the rest the LDS atomics per record -- and the general (non-FAST) form spilled:
+    // `avg v1, v2, v3` at 1e6 keys 18.9 -> 32.1 ms.  Two it stays.)
+    Batch B0, B1;
+    bool h0 = advance();
+    load(h0, b, i0, n, B0);
+    i0 += 256u;
+    while (h0) {
+        const bool h1 = advance();
+        load(h1, b, i0, n, B1);
         i0 += 256u;
-    }
-    while (h[0]) {
-#pragma unroll
-        for (int k = 0; k < DEPTH; k++) {
-            consume(B[k]); // (a batch past the end has n = 0: nothing is applied)
-            h[k] = advance();
-            load(h[k], b, i0, n, B[k]);
-            i0 += 256u;
-        }
+        consume(B0);
+        if (!h1) break;
+        h0 = advance();
+        load(h0, b, i0, n, B0);
+        i0 += 256u;
+        consume(B1);
     }
     __syncthreads();
     for (i64 i = tid; i < local; i += THREADS) {
