@@ -84,7 +84,7 @@ WORKLOADS = {
     "k9": dict(desc="sparse keys (range > rows -> the reference's open-addressing path): select sum(v) by k, k = 1000003 * (i64 uniform [0,1e6) seed 4) - 77, "
                     "v f64 seed 5", rows=1_000_000_000, bytes_per_row=16, dtype="f64", kernel="k_plane_scatter<3, 0, 2, 7, 4, true> (hash-partitioned planes) + k_plane_hash_aggregate<true>"),
     "w2": dict(desc="where ids: (where (< a 100000)) on the C2 column -> 1e8 ascending i64 row ids (8 B/row in + 8 B/selected row out)", rows=1_000_000_000,
-               bytes_per_row=8.8, dtype="int64", kernel="k_where_once<1, 1> (one pass: ballots -> decoupled look-back -> ids)"),
+               bytes_per_row=8.8, dtype="int64", kernel="k_where_once_plan (one pass: ballots -> decoupled look-back -> ids, compiled at run time for the plan; prebuilt k_where_once<1, 1> without hiprtc)"),
     "m2": dict(desc="B8 mask: (< a 100000) materialised as the reference's byte mask (8 B/row in + 1 B/row out)", rows=1_000_000_000, bytes_per_row=9,
                dtype="int64", kernel="k_cmp_mask<1>"),
     "g2": dict(desc="gather: (at b ids) for the 1e8 ids of w2 (8 B id + 8 B random read + 8 B write per id)", rows=1_000_000_000, bytes_per_row=2.4,

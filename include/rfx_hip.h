@@ -246,6 +246,8 @@ void rfx_hip_rtc_cache_stats(int64_t *loaded_from_disk, int64_t *written_to_disk
  * a deployment can do the same for its recurring queries).  d_col pointers only tell columns apart (any distinct non-NULL values).
  * RFX_OK: the code object is on disk; RFX_ESTATE: no compiler / no cache directory / the plan does not compile. */
 int rfx_hip_rtc_prewarm_filter_aggr(const rfx_pred_t *preds, int npred, int logic, const rfx_agg_t *aggs, int nagg);
+/* The same for the one-pass `where` kernel of a predicate list / tree (rfx_hip_where_once takes the plan's kernel when there is one). */
+int rfx_hip_rtc_prewarm_where(const rfx_pred_t *preds, int npred, int logic);
 
 /* Host-to-device at link speed from ANY host memory (heap vector, mmapped column file): chunks are staged through pinned
  * buffers by worker threads while the previous chunk is in flight.  (syncs) */

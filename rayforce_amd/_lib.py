@@ -166,6 +166,7 @@ PROTOTYPES = {
     "rfx_hip_rtc_stats": (None, [_P(C.c_int64), _P(C.c_int64)]),
     "rfx_hip_rtc_cache_stats": (None, [_P(C.c_int64), _P(C.c_int64)]),
     "rfx_hip_rtc_prewarm_filter_aggr": (C.c_int, [_P(Pred), C.c_int, C.c_int, _P(Agg), C.c_int]),
+    "rfx_hip_rtc_prewarm_where": (C.c_int, [_P(Pred), C.c_int, C.c_int]),
     "rfx_hip_timer_start": (C.c_int, [_ctx]),
     "rfx_hip_timer_stop": (C.c_int, [_ctx, _P(C.c_float)]),
     "rfx_hip_ctx_profile": (C.c_int, [_ctx, C.c_int]),

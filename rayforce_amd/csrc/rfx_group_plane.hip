@@ -205,19 +205,31 @@ __global__ __launch_bounds__(PL_T) void k_plane_scatter(const Plan P, const Plan
             // idle lanes, every pass takes each lane's NEXT selected row -- as many passes as the busiest lane has rows (three or four).
             unsigned rem = m;
             nsel += (unsigned)__popc(rem);
+            // (the rows as opaque register values: left as elements of the tile, the select chain below is folded back into ONE load with a
+            //  per-lane index, and a tile beyond 128 bytes -- two or three value planes -- then lives in scratch memory: 208-272 bytes per
+            //  lane written and gathered back every step)
+            u64 t[1 + NV][8];
+#pragma unroll
+            for (int c = 0; c < 1 + NV; c++) {
+#pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    t[c][q] = v[c][q];
+                    if constexpr (NV > 1) asm volatile("" : "+v"(t[c][q]));
+                }
+            }
             while (__any(rem != 0u)) {
                 const bool on = rem != 0u;
                 const unsigned e = (unsigned)__builtin_ctz(rem | 0x100u);
                 rem &= rem - 1u;
-                u64 key = v[0][0], val[NV];
+                u64 key = t[0][0], val[NV];
 #pragma unroll
-                for (int j = 0; j < NV; j++) val[j] = v[1 + j][0];
+                for (int j = 0; j < NV; j++) val[j] = t[1 + j][0];
 #pragma unroll
                 for (int q = 1; q < 8; q++) {
                     const bool is = e == (unsigned)q;
-                    key = is ? v[0][q] : key;
+                    key = is ? t[0][q] : key;
 #pragma unroll
-                    for (int j = 0; j < NV; j++) val[j] = is ? v[1 + j][q] : val[j];
+                    for (int j = 0; j < NV; j++) val[j] = is ? t[1 + j][q] : val[j];
                 }
                 place(on, key, val, dbase + (e >> 1) * 128u + (e & 1u));
             }

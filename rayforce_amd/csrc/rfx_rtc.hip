@@ -21,6 +21,7 @@
 #include <mutex>
 #include <string>
 #include "rfx_group_common.hpp"
+#include "rfx_where_once_kernel.hpp"
 #include "build/rfx_rtc_headers.inc" // RTC_NHDR, RTC_HDR_NAMES[], RTC_HDR_TEXTS[]: the kernel headers as text
 
 typedef struct _hiprtcProgram *rtcProgram;
@@ -334,6 +335,49 @@ int rfx_rtc_group_few(rfx_ctx *c, const Plan &P, const GroupArgs &G, int grid) {
     RFX_HIP_CHECK(hipModuleLaunchKernel(fn, (unsigned)grid, 1, 1, RFX_BLOCK, 1, 1, 0, c->stream, args, NULL));
     __atomic_fetch_add(&g_launches, 1, __ATOMIC_RELAXED);
     return RFX_OK;
+}
+
+// K3's one-pass `where` for one plan: rfx_where_once_kernel.hpp's body with the comparisons as constants (the prebuilt instantiations decode
+// operator, domain and conversions per predicate at run time: 96 registers and scratch; one i64 comparison as a plan: 69, none).
+static void where_once_text(const Plan &P, std::string &sig, std::string &src) {
+    const int nc = P.ncols < 1 ? 1 : P.ncols;
+    char head[128];
+    snprintf(head, sizeof(head), "#define WOP_NC %d\n#define WOP_NP %d\n", nc, P.npred < 1 ? 1 : P.npred);
+    std::string cond;
+    plan_text(P, NULL, cond);
+    sig = std::string("//where_once\n") + head + cond;
+    src = sig +
+          "#include \"rfx_where_once_kernel.hpp\"\n"
+          "extern \"C\" __global__ __launch_bounds__(WO_T) __attribute__((amdgpu_waves_per_eu(WOP_NC <= 2 ? 5 : 3))) void k_where_once_plan(const Plan P0, const WoArgs A) {\n"
+          "    constexpr Plan D = RTC_PLAN;\n"
+          "    where_once_body<WOP_NC, WOP_NP>(D, P0, A);\n"
+          "}\n";
+}
+int rfx_rtc_where_once(rfx_ctx *c, const Plan &P, const WoArgs &A, int grid) {
+    if (P.npred < 1 || P.npred > 4 || P.ncols > 4 || (c->flags & RFX_TUNE_NO_RTC) || !rtc_ready()) return RFX_ESTATE;
+    std::string sig, src;
+    where_once_text(P, sig, src);
+    hipFunction_t fn = plan_kernel(c->device, sig, src, "k_where_once_plan", P.nrows, "a one-pass where kernel for this plan");
+    if (!fn) return RFX_ESTATE;
+    Plan Pv = P;
+    WoArgs Av = A;
+    void *args[] = {&Pv, &Av};
+    RFX_HIP_CHECK(hipModuleLaunchKernel(fn, (unsigned)grid, 1, 1, WO_T, 1, 1, 0, c->stream, args, NULL));
+    __atomic_fetch_add(&g_launches, 1, __ATOMIC_RELAXED);
+    return RFX_OK;
+}
+extern "C" int rfx_hip_rtc_prewarm_where(const rfx_pred_t *preds, int npred, int logic) {
+    Plan P;
+    int rc = rfx_plan_build(&P, preds, npred, logic, NULL, 0, NULL, NULL, 1, 0);
+    if (rc != RFX_OK) return rc;
+    if (P.npred < 1 || P.npred > 4 || P.ncols > 4 || !rtc_ready() || R.cache_dir.empty()) return RFX_ESTATE;
+    std::string sig, src, code;
+    where_once_text(P, sig, src);
+    const std::string path = cache_path(src);
+    if (read_code(path, code)) return RFX_OK;
+    if (!compile(src, code)) return RFX_ESTATE;
+    write_code(path, code);
+    return read_code(path, code) ? RFX_OK : RFX_ESTATE;
 }
 
 // Compile the K1 kernel of a plan INTO THE DISK CACHE without a device (hiprtc needs none for an explicit --offload-arch): the build

@@ -31,10 +31,7 @@ def _flat(where):
     return (L.RFX_AND if top == "and" else L.RFX_OR), out
 
 
-def filter_aggr(where, aggs: Sequence[Tuple[str, Optional[str]]], types: Dict[str, str]) -> bool:
-    """True: the plan's code object is in the cache (already, or compiled now).  False: no run-time compiler / no cache directory."""
-    lib = L.load_library()
-    ident = {name: 4096 * (i + 1) for i, name in enumerate(types)}  # stand-ins for device pointers: they only tell columns apart
+def _preds(where, types, ident):
     logic, preds = _flat(where)
     parr = (L.Pred * max(1, len(preds)))()
     for p, ((op, lhs, rhs), more) in zip(parr, preds):
@@ -45,11 +42,27 @@ def filter_aggr(where, aggs: Sequence[Tuple[str, Optional[str]]], types: Dict[st
             p.rhs_type, p.rhs_f = L.RFX_F64, rhs
         else:
             p.rhs_type, p.rhs_i = L.RFX_I64, int(rhs)
+    return parr, len(preds), logic
+
+
+def where(where, types: Dict[str, str]) -> bool:
+    """The one-pass `where` kernel of a predicate list (rfx_hip_rtc_prewarm_where): True = its code object is in the cache."""
+    lib = L.load_library()
+    ident = {name: 4096 * (i + 1) for i, name in enumerate(types)}
+    parr, n, logic = _preds(where, types, ident)
+    return lib.rfx_hip_rtc_prewarm_where(parr, n, logic) == L.RFX_OK
+
+
+def filter_aggr(where, aggs: Sequence[Tuple[str, Optional[str]]], types: Dict[str, str]) -> bool:
+    """True: the plan's code object is in the cache (already, or compiled now).  False: no run-time compiler / no cache directory."""
+    lib = L.load_library()
+    ident = {name: 4096 * (i + 1) for i, name in enumerate(types)}  # stand-ins for device pointers: they only tell columns apart
+    parr, npred, logic = _preds(where, types, ident)
     aarr = (L.Agg * max(1, len(aggs)))()
     for a, (fn, col) in zip(aarr, aggs):
         a.kind = L.AGGS[fn]
         a.d_col, a.col_type = (ident[col], _TYPES[types[col]]) if col is not None else (None, L.RFX_I64)
-    return lib.rfx_hip_rtc_prewarm_filter_aggr(parr, len(preds), logic, aarr, len(aggs)) == L.RFX_OK
+    return lib.rfx_hip_rtc_prewarm_filter_aggr(parr, npred, logic, aarr, len(aggs)) == L.RFX_OK
 
 
 BASELINE_PLANS = {  # BASELINE.json configs (bench.py's workloads of the same names) whose hot kernel is a plan kernel
@@ -61,8 +74,15 @@ BASELINE_PLANS = {  # BASELINE.json configs (bench.py's workloads of the same na
 }
 
 
+WHERE_PLANS = {  # bench.py's `where` workloads
+    "w2": (("<", "a", 100_000), {"a": "i64"}),
+}
+
+
 def baseline() -> Dict[str, bool]:
-    return {name: filter_aggr(*plan) for name, plan in BASELINE_PLANS.items()}
+    done = {name: filter_aggr(*plan) for name, plan in BASELINE_PLANS.items()}
+    done.update({name: where(*plan) for name, plan in WHERE_PLANS.items()})
+    return done
 
 
 def cache_stats() -> Tuple[int, int]:

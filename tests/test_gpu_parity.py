@@ -211,6 +211,41 @@ def test_where_one_pass_and_two_pass_agree(eng, flags):
         eng.tune(flags=0)
 
 
+def test_where_plan_kernels(eng):
+    """rfx_rtc.hip: the one-pass `where` compiled for ONE predicate list (operators, domains and conversions as constants) -- the same specs as
+    above through kernels built at first sight (RFX_RTC_EAGER), against the oracle; atoms are kernel arguments (a second constant reuses the
+    kernel: no further compilation); a deeper tree, null / NaN atoms and column-against-column comparisons included."""
+    n = 3_000_019
+    host = table(n)
+    host["b"] = rfo.gen_i64(n, 77, 1000)
+    host["a"][5::1013] = L_NULL
+    host["v"][3::977] = np.nan
+    d = dev(eng, host)
+    specs = [("<", "a", 100_000), ("!=", "a", L_NULL), (">=", "v", 0.25), ("==", "v", float("nan")),
+             ("and", ("<", "a", 500_000), (">", "v", 0.5)),
+             ("or", ("<", "a", 1000), (">", "w", 0.49), ("==", "k", 7)),
+             ("and", ("<", "a", 900_000), (">", "v", 0.1), ("<", "w", 0.4), ("!=", "k", 3)),
+             ("and", (">", "a", "b"), ("<", "v", 0.3)), ("<", "a", "v"),
+             ("and", ("or", ("<", "a", 1000), (">", "w", 0.45)), ("<", "v", 0.9)),
+             ("or", ("and", ("<", "a", 300_000), ("or", (">", "w", 0.3), ("<", "v", 0.2))), ("==", "k", 5))]
+    l0, c0 = _rtc_stats(eng)
+    os.environ["RFX_RTC_EAGER"] = "1"
+    try:
+        for spec in specs:
+            want = rfo.where(rfo.mask_of(spec, host))
+            got = eng.where(spec, d)
+            assert got.dtype == torch.int64 and np.array_equal(got.cpu().numpy(), want), spec
+        l1, c1 = _rtc_stats(eng)
+        if c1 == c0 and l1 == l0:
+            pytest.skip("no run-time compiler on this box: the prebuilt kernels answered")
+        assert l1 - l0 >= len(specs)
+        got = eng.where(("<", "a", 7_777), d, row0=10**12)  # another atom, a row offset: the first spec's kernel
+        assert np.array_equal(got.cpu().numpy(), rfo.where(rfo.mask_of(("<", "a", 7_777), host)) + 10**12)
+        assert _rtc_stats(eng)[1] == c1
+    finally:
+        del os.environ["RFX_RTC_EAGER"]
+
+
 def test_where_one_pass_estimate_and_overflow(eng):
     """The buffer of the one-pass `where` is sized by 2^15 strided rows.  A selection that sits between the sampled rows (a contiguous block:
     the sample sees a few of its rows at most... here none, the block lies inside one stride) is underestimated only within the 1 % margin;

@@ -1,5 +1,6 @@
-"""dev: time Engine.where (rfx_hip_where_estimate + rfx_hip_where_once) on the w2 shape: tools/where_ab.py <rows> <a < threshold of 1e6>."""
-import sys, time, torch
+"""dev: time Engine.where (rfx_hip_where_estimate + rfx_hip_where_once) on the w2 shape and check the ids against torch:
+tools/where_ab.py <rows> <a < threshold of 1e6>; RFX_WHERE_SPLIT=k picks the split-role kernel with k workgroups per CU."""
+import os, sys, time, torch
 sys.path.insert(0, ".")
 from rayforce_amd.engine import Engine
 eng = Engine(0)
@@ -13,4 +14,15 @@ t = time.perf_counter()
 for _ in range(10):
     ids = eng.where(("<", "a", thr), {"a": a})
 torch.cuda.synchronize()
-print(f"rows {n} selected {ids.numel()} ms/query {(time.perf_counter() - t) * 100:.3f}")
+ms = (time.perf_counter() - t) * 100
+ids = torch.as_tensor(ids, device="cuda")
+ok = True
+step = 1 << 28
+pos = 0
+for lo in range(0, n, step):
+    want = torch.nonzero(a[lo:lo + step] < thr).flatten() + lo
+    got = ids[pos:pos + want.numel()]
+    ok = ok and got.numel() == want.numel() and bool((got == want).all())
+    pos += want.numel()
+ok = ok and pos == ids.numel()
+print(f"split {os.environ.get('RFX_WHERE_SPLIT', '0')} rows {n} selected {ids.numel()} ms/query {ms:.3f} ids {'ok' if ok else 'WRONG'}", flush=True)
