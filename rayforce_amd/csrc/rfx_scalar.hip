@@ -323,8 +323,10 @@ extern "C" int rfx_hip_group_scope(rfx_ctx_t *c, const int64_t *d_key, const rfx
 
 // ---------------- K2: byte masks ----------------
 // A wave owns 512 consecutive rows per step: lane l loads rows 2l, 2l+1 of each 128-row group (one 16-byte load per
-// group and column, 1 KB contiguous per wave instruction) and stores their two mask bytes as one 16-bit store
-// (128 B contiguous per wave instruction).
+// group and column, 1 KB contiguous per wave instruction).  The mask bytes leave TRANSPOSED: the step's eight ballots are wave-uniform
+// words, lane l picks the two that hold rows 8l .. 8l + 7 (group l / 16, even and odd rows), spreads four bits of each into bytes and
+// stores 8 bytes -- 512 contiguous bytes per wave instruction, non-temporal.  (Round 3 stored each lane's own two bytes as one 16-bit
+// store: 2-byte stores reach 1.3-1.7 TB/s on this part, profiles/r03_write_probe.jsonl; m2 1.90 ms -> see DESIGN section 3.)
 template <int NC>
 __global__ __launch_bounds__(RFX_BLOCK) void k_cmp_mask(const Plan P, int8_t *__restrict__ out) {
     PredSet<1> S; // exactly one comparison: one descriptor set in SGPRs, not eight
@@ -346,11 +348,19 @@ __global__ __launch_bounds__(RFX_BLOCK) void k_cmp_mask(const Plan P, int8_t *__
             }
         }
         const unsigned m = eval_preds<NC, 8, 1>(S, v, 0xffu);
+        u64 be = 0, bo = 0; // ballots of the even / odd rows of this lane's OUTPUT group (lane / 16)
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            const unsigned short two = (unsigned short)(((m >> (2 * j)) & 1u) | (((m >> (2 * j + 1)) & 1u) << 8));
-            *(unsigned short *)(out + base + j * 128) = two;
+            const u64 b0 = __ballot((m >> (2 * j)) & 1u), b1 = __ballot((m >> (2 * j + 1)) & 1u);
+            const bool mine = (lane >> 4) == j;
+            be = mine ? b0 : be;
+            bo = mine ? b1 : bo;
         }
+        const unsigned sh = 4u * ((unsigned)lane & 15u);
+        const unsigned x0 = (unsigned)(be >> sh) & 15u, x1 = (unsigned)(bo >> sh) & 15u; // rows 8l, 8l+2, 8l+4, 8l+6 / 8l+1, ...
+        const unsigned lo = (x0 & 1u) | ((x1 & 1u) << 8) | (((x0 >> 1) & 1u) << 16) | (((x1 >> 1) & 1u) << 24);
+        const unsigned hi = ((x0 >> 2) & 1u) | (((x1 >> 2) & 1u) << 8) | (((x0 >> 3) & 1u) << 16) | (((x1 >> 3) & 1u) << 24);
+        __builtin_nontemporal_store(((u64)hi << 32) | lo, (u64 *)(out + q * 512 + lane * 8));
     }
     // tail rows
     if (blockIdx.x == 0) {
