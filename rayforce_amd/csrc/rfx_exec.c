@@ -610,6 +610,12 @@ typedef struct {
     int scope_filtered;     /* per-key exact scopes: through the predicates */
     int sparse_sampled;     /* the sample alone sent the key to the hashed tables: a null key shows in their null slot */
     int64_t groups;
+    /* the pass being run */
+    int a0, first_pass, multi, any_xbar;
+    int spec_ok, retried;   /* may the scope be sampled; did a sampled scope fail already */
+    const void *spec_id;    /* what the planner remembers sampled scopes by */
+    int64_t cap_hint;
+    rfx_groups_t *out;
 } gq_t;
 
 static int has_cnt(const rfx_agg_t *a) { return a->kind == RFX_AGG_AVG || (a->kind == RFX_AGG_SUM && rfx_agg_input_type(a) == RFX_I64); }
@@ -1063,142 +1069,157 @@ static void own(rfx_groups_t *g, void *p) {
     if (p && g->nown < (int)(sizeof(g->own) / sizeof(g->own[0]))) g->own[g->nown++] = p;
 }
 
-/* one pass: aggregates [a0, a0 + na) of the query.  first_pass: also the key columns / first rows of the result */
-static int group_by_pass(rfx_exec_t *x, const rfx_query_t *q, int a0, int na, int first_pass, int64_t cap_hint, rfx_groups_t *out) {
-    const int S = x->nshards;
-    gq_t *G = (gq_t *)calloc(1, sizeof(gq_t));
-    shard_t *sh = (shard_t *)calloc((size_t)S, sizeof(shard_t));
-    if (!G || !sh) { free(G); free(sh); return RFX_ENOMEM; }
+/* ---- one pass of a group-by (aggregates [a0, a0 + na) of the query; the first pass also makes the key columns / first rows), step by step:
+ * gb_setup -> { gb_scope -> gb_size -> gb_passes } (once more under the exact scope when the sampled one did not hold) -> gb_null_slot ->
+ * gb_prove_tuples -> gb_emit_small | gb_emit.  Every step answers RFX_OK or an error (x->err says which); group_by_pass owns the cleanup. ---- */
+#define GB_AGAIN 2 /* gb_passes: a key outside the sampled scope -- the scope again, exactly, then the passes again */
+
+/* the shards' views of the query, a mask selection gathered, xbar keys bucketed; whether the scope may be sampled */
+static int gb_setup(gq_t *G) {
+    rfx_exec_t *x = G->x;
+    const rfx_query_t *q = G->q;
+    shard_t *sh = G->sh;
+    const int S = G->S;
+    const int na = G->na;
     int rc = RFX_OK;
-    G->x = x;
-    G->q = q;
-    G->sh = sh;
-    G->S = S;
-    G->exch = world_rank(x, &G->world, &G->rank);
-    G->na = na;
-    G->npred = q->npred;
-    G->nkeys = q->nkeys;
-    G->total_rows = q->nrows;
-    G->want_first = (q->flags & RFX_Q_WANT_FIRST) != 0;
     for (int s = 0; s < S && rc == RFX_OK; s++) {
-        rc = shard_view(q, S, s, a0, na, &sh[s]);
+        rc = shard_view(q, S, s, G->a0, na, &sh[s]);
         rfx_exec_split(q->nrows, S, s, &sh[s].row0, &sh[s].nrows);
     }
-    if (rc != RFX_OK) { snprintf(x->err, sizeof(x->err), "rfx_exec: a column of the query has no per-shard address"); goto done; }
+    if (rc != RFX_OK) { snprintf(x->err, sizeof(x->err), "rfx_exec: a column of the query has no per-shard address"); return rc; }
     for (int a = 0; a < na; a++) G->need_first_values |= sh[0].aggs[a].kind == RFX_AGG_FIRST;
     G->all_rank = G->need_first_values && (S > 1 || G->exch);
-    const int multi = S > 1 || G->exch;
+    G->multi = S > 1 || G->exch;
+    const int multi = G->multi;
     if (q->d_mask) {
-        if (multi || q->npred) { snprintf(x->err, sizeof(x->err), "rfx_exec: a mask selection runs on one shard, without comparisons beside it"); rc = RFX_ELIMIT; goto done; }
-        if ((rc = gather_selected(x, &sh[0], na, q->nkeys)) != RFX_OK) { snprintf(x->err, sizeof(x->err), "%s", rfx_hip_last_error()); goto done; }
+        if (multi || q->npred) { snprintf(x->err, sizeof(x->err), "rfx_exec: a mask selection runs on one shard, without comparisons beside it"); rc = RFX_ELIMIT; return rc; }
+        if ((rc = gather_selected(x, &sh[0], na, q->nkeys)) != RFX_OK) { snprintf(x->err, sizeof(x->err), "%s", rfx_hip_last_error()); return rc; }
         G->npred = 0;
         G->total_rows = sh[0].nrows; /* first rows rank among the SELECTED rows; translated back at the end */
     }
-    int any_xbar = 0;
-    for (int k = 0; k < q->nkeys; k++) any_xbar |= q->kxbar && q->kxbar[k] > 0;
-    if (any_xbar && (rc = run_shards(x, ph_xbar, G)) != RFX_OK) goto done;
+    for (int k = 0; k < q->nkeys; k++) G->any_xbar |= q->kxbar && q->kxbar[k] > 0;
+    if (G->any_xbar && (rc = run_shards(x, ph_xbar, G)) != RFX_OK) return rc;
     /* ---- the scope ---- */
-    const void *spec_id = q->d_keys[0];
+    G->spec_id = q->d_keys[0];
     /* (one process only: whether to sample must be decided alike by every process, and row counts / remembered misses are local) */
-    int spec_ok = !(q->flags & RFX_Q_NO_SAMPLED_SCOPE) && !q->d_mask && !G->exch && q->nrows >= ((int64_t)1 << 24) && !getenv("RFX_NO_SAMPLED_SCOPE") &&
-                  !spec_known_bad(x, spec_id, q->nrows);
-    int retried = 0;
-rescope:
-    G->spec = G->rowhash = G->fused_keys = G->sparse_sampled = 0;
-    for (int s = 0; s < S; s++) sh[s].key = sh[s].keys[0];
-    if (G->nkeys == 1) {
-        int have = 0;
-        /* (a DENSE key range the sample found wider than the LDS forms last time takes the scope pass at once: that pass samples for itself) */
-        if (spec_ok && !(any_xbar == 0 && spec_known_wide(x, spec_id, q->nrows))) {
-            if ((rc = run_shards(x, ph_scope_sample, G)) != RFX_OK) goto done;
-            if ((rc = fold_scope(G, 0, &G->kmin, &G->kmax, &G->seen)) != RFX_OK) goto done;
-            G->spec = G->seen > 0 && G->kmin != NULL_I64 && G->kmax >= G->kmin && (uint64_t)(G->kmax - G->kmin) < RFX_SCOPE_SAMPLE_MAX_RANGE;
-            have = G->spec;
-            /* SPARSE keys by the sample alone: a sampled range can only be too small, so one that already exceeds the row count decides
-             * "range > rows" -- open addressing (core/index.c:2013) -- without index_scope_i64's pass over the column (8 GB per 1e9 rows, a
-             * twentieth of such a query): the tables are sized by the row count as the reference sizes them, and a null key the sample did
-             * not see shows in the tables' own null slot afterwards */
-            if (!have && G->seen > 0 && G->kmin != NULL_I64 && G->kmax >= G->kmin && (uint64_t)G->kmax - (uint64_t)G->kmin + 1 > (uint64_t)q->nrows) {
+    G->spec_ok = !(q->flags & RFX_Q_NO_SAMPLED_SCOPE) && !q->d_mask && !G->exch && q->nrows >= ((int64_t)1 << 24) && !getenv("RFX_NO_SAMPLED_SCOPE") &&
+                  !spec_known_bad(x, G->spec_id, q->nrows);
+    G->retried = 0;
+    return RFX_OK;
+}
+
+/* the scope: sampled / remembered / exact, one key or several (composite plan, row hash); decides dense vs. hashed */
+static int gb_scope(gq_t *G) {
+    rfx_exec_t *x = G->x;
+    const rfx_query_t *q = G->q;
+    shard_t *sh = G->sh;
+    const int S = G->S;
+    const int multi = G->multi;
+    const int any_xbar = G->any_xbar;
+    rfx_groups_t *out = G->out;
+    int rc = RFX_OK;
+    for (;;) {
+        G->spec = G->rowhash = G->fused_keys = G->sparse_sampled = 0;
+        for (int s = 0; s < S; s++) sh[s].key = sh[s].keys[0];
+        if (G->nkeys == 1) {
+            int have = 0;
+            /* (a DENSE key range the sample found wider than the LDS forms last time takes the scope pass at once: that pass samples for itself) */
+            if (G->spec_ok && !(any_xbar == 0 && spec_known_wide(x, G->spec_id, q->nrows))) {
+                if ((rc = run_shards(x, ph_scope_sample, G)) != RFX_OK) return rc;
+                if ((rc = fold_scope(G, 0, &G->kmin, &G->kmax, &G->seen)) != RFX_OK) return rc;
+                G->spec = G->seen > 0 && G->kmin != NULL_I64 && G->kmax >= G->kmin && (uint64_t)(G->kmax - G->kmin) < RFX_SCOPE_SAMPLE_MAX_RANGE;
+                have = G->spec;
+                /* SPARSE keys by the sample alone: a sampled range can only be too small, so one that already exceeds the row count decides
+                 * "range > rows" -- open addressing (core/index.c:2013) -- without index_scope_i64's pass over the column (8 GB per 1e9 rows, a
+                 * twentieth of such a query): the tables are sized by the row count as the reference sizes them, and a null key the sample did
+                 * not see shows in the tables' own null slot afterwards */
+                if (!have && G->seen > 0 && G->kmin != NULL_I64 && G->kmax >= G->kmin && (uint64_t)G->kmax - (uint64_t)G->kmin + 1 > (uint64_t)q->nrows) {
+                    G->seen = q->nrows;
+                    G->sparse_sampled = 1;
+                    have = 1;
+                }
+                if (!have && !any_xbar && G->kmin != NULL_I64) spec_remember_wide(x, G->spec_id, q->nrows); /* neither LDS-sized nor sparse: dense and wide */
+            }
+            if (!have && q->key_scope && !any_xbar && !q->d_mask && !G->exch && q->key_scope[0] != NULL_I64 && q->key_scope[1] >= q->key_scope[0] &&
+                (uint64_t)(q->key_scope[1] - q->key_scope[0]) < RFX_SCOPE_SAMPLE_MAX_RANGE) {
+                /* the caller's remembered whole-column scope: LDS-sized, a superset of any selection's -- `seen` = every row (an upper bound
+                 * that only sizes tables; an empty selection comes out as zero groups) */
+                G->kmin = q->key_scope[0];
+                G->kmax = q->key_scope[1];
                 G->seen = q->nrows;
-                G->sparse_sampled = 1;
                 have = 1;
+                x->stat[RFX_XSTAT_SCOPE_REMEMBERED]++;
             }
-            if (!have && !any_xbar && G->kmin != NULL_I64) spec_remember_wide(x, spec_id, q->nrows); /* neither LDS-sized nor sparse: dense and wide */
-        }
-        if (!have && q->key_scope && !any_xbar && !q->d_mask && !G->exch && q->key_scope[0] != NULL_I64 && q->key_scope[1] >= q->key_scope[0] &&
-            (uint64_t)(q->key_scope[1] - q->key_scope[0]) < RFX_SCOPE_SAMPLE_MAX_RANGE) {
-            /* the caller's remembered whole-column scope: LDS-sized, a superset of any selection's -- `seen` = every row (an upper bound
-             * that only sizes tables; an empty selection comes out as zero groups) */
-            G->kmin = q->key_scope[0];
-            G->kmax = q->key_scope[1];
-            G->seen = q->nrows;
-            have = 1;
-            x->stat[RFX_XSTAT_SCOPE_REMEMBERED]++;
-        }
-        if (!have) {
-            if ((rc = run_shards(x, ph_scope_group, G)) != RFX_OK) goto done;
-            if ((rc = fold_scope(G, 0, &G->kmin, &G->kmax, &G->seen)) != RFX_OK) goto done;
-        }
-    } else {
-        /* scopes of every key column, then the reference's multiplier plan (core/index.c:2340-2383) */
-        int planned = 0;
-        if (spec_ok) {
-            if ((rc = run_shards(x, ph_scope_sample, G)) != RFX_OK) goto done;
-            int64_t prod = 1;
-            G->spec = 1;
-            for (int k = 0; k < G->nkeys && G->spec; k++) {
-                if ((rc = fold_scope(G, k, &G->kmins[k], &G->kmaxs[k], &G->seen)) != RFX_OK) goto done;
-                if (G->seen <= 0 || G->kmins[k] == NULL_I64 || G->kmaxs[k] < G->kmins[k] || (uint64_t)(G->kmaxs[k] - G->kmins[k]) >= RFX_SCOPE_SAMPLE_MAX_RANGE) G->spec = 0;
-                else prod *= G->kmaxs[k] - G->kmins[k] + 1;
-                if (prod > RFX_SCOPE_SAMPLE_MAX_RANGE) G->spec = 0;
+            if (!have) {
+                if ((rc = run_shards(x, ph_scope_group, G)) != RFX_OK) return rc;
+                if ((rc = fold_scope(G, 0, &G->kmin, &G->kmax, &G->seen)) != RFX_OK) return rc;
             }
-            planned = G->spec;
-        }
-        if (!planned) {
-            G->scope_filtered = G->npred > 0;
-            for (int k = 0; k < G->nkeys; k++) {
-                G->phase_key = k;
-                if ((rc = run_shards(x, ph_scope_col, G)) != RFX_OK) goto done;
-                if ((rc = fold_scope(G, k, &G->kmins[k], &G->kmaxs[k], &G->seen)) != RFX_OK) goto done;
+        } else {
+            /* scopes of every key column, then the reference's multiplier plan (core/index.c:2340-2383) */
+            int planned = 0;
+            if (G->spec_ok) {
+                if ((rc = run_shards(x, ph_scope_sample, G)) != RFX_OK) return rc;
+                int64_t prod = 1;
+                G->spec = 1;
+                for (int k = 0; k < G->nkeys && G->spec; k++) {
+                    if ((rc = fold_scope(G, k, &G->kmins[k], &G->kmaxs[k], &G->seen)) != RFX_OK) return rc;
+                    if (G->seen <= 0 || G->kmins[k] == NULL_I64 || G->kmaxs[k] < G->kmins[k] || (uint64_t)(G->kmaxs[k] - G->kmins[k]) >= RFX_SCOPE_SAMPLE_MAX_RANGE) G->spec = 0;
+                    else prod *= G->kmaxs[k] - G->kmins[k] + 1;
+                    if (prod > RFX_SCOPE_SAMPLE_MAX_RANGE) G->spec = 0;
+                }
+                planned = G->spec;
             }
-        }
-        G->kmin = 0;
-        G->kmax = -1;
-        if (G->seen > 0) {
-            if (rfx_composite_plan(G->kmins, G->kmaxs, G->nkeys, G->kmults, &G->comp_max) != RFX_OK) {
-                /* ranges beyond 64 bits / a null key: the reference's row-hash path (index_group_list, core/index.c:2731-2790) -- grouped on
-                 * the reference's own row hash; its tuple comparison on every probe is made once, afterwards (below) */
-                if (multi) { snprintf(x->err, sizeof(x->err), "rfx_exec: key tuples beyond a 64-bit composite key run on one shard"); rc = RFX_ELIMIT; goto done; }
-                if ((rc = run_shards(x, ph_row_hash, G)) != RFX_OK) goto done;
-                G->rowhash = 1;
-                G->spec = 0;
-                G->phase_key = -1;
+            if (!planned) {
                 G->scope_filtered = G->npred > 0;
-                if ((rc = run_shards(x, ph_scope_col, G)) != RFX_OK) goto done;
-                if ((rc = fold_scope(G, 0, &G->kmin, &G->kmax, &G->seen)) != RFX_OK) goto done;
-            } else {
-                G->kmax = G->comp_max; /* forced scope {0, max}, core/index.c:2421 */
-                if ((uint64_t)G->comp_max + 1 > (uint64_t)G->seen) {
-                    if ((rc = run_shards(x, ph_composite, G)) != RFX_OK) goto done;
-                } else G->fused_keys = 1;
+                for (int k = 0; k < G->nkeys; k++) {
+                    G->phase_key = k;
+                    if ((rc = run_shards(x, ph_scope_col, G)) != RFX_OK) return rc;
+                    if ((rc = fold_scope(G, k, &G->kmins[k], &G->kmaxs[k], &G->seen)) != RFX_OK) return rc;
+                }
+            }
+            G->kmin = 0;
+            G->kmax = -1;
+            if (G->seen > 0) {
+                if (rfx_composite_plan(G->kmins, G->kmaxs, G->nkeys, G->kmults, &G->comp_max) != RFX_OK) {
+                    /* ranges beyond 64 bits / a null key: the reference's row-hash path (index_group_list, core/index.c:2731-2790) -- grouped on
+                     * the reference's own row hash; its tuple comparison on every probe is made once, afterwards (below) */
+                    if (multi) { snprintf(x->err, sizeof(x->err), "rfx_exec: key tuples beyond a 64-bit composite key run on one shard"); rc = RFX_ELIMIT; return rc; }
+                    if ((rc = run_shards(x, ph_row_hash, G)) != RFX_OK) return rc;
+                    G->rowhash = 1;
+                    G->spec = 0;
+                    G->phase_key = -1;
+                    G->scope_filtered = G->npred > 0;
+                    if ((rc = run_shards(x, ph_scope_col, G)) != RFX_OK) return rc;
+                    if ((rc = fold_scope(G, 0, &G->kmin, &G->kmax, &G->seen)) != RFX_OK) return rc;
+                } else {
+                    G->kmax = G->comp_max; /* forced scope {0, max}, core/index.c:2421 */
+                    if ((uint64_t)G->comp_max + 1 > (uint64_t)G->seen) {
+                        if ((rc = run_shards(x, ph_composite, G)) != RFX_OK) return rc;
+                    } else G->fused_keys = 1;
+                }
             }
         }
+        if (G->seen > 0 && G->nkeys == 1 && G->kmin == NULL_I64 && (q->flags & RFX_Q_REFUSE_NULL_KEY)) { rc = RFX_EXEC_NULL_KEY; return rc; }
+        if (G->spec) x->stat[RFX_XSTAT_SCOPE_SAMPLED]++;
+        out->nkeys = G->nkeys;
+        if (G->seen <= 0) return RFX_OK; /* nothing selected: zero groups (group_by_pass says so) */
+        /* dense "perfect hash" iff range <= rows (core/index.c:2013), like the reference; else open addressing */
+        G->range = (uint64_t)G->kmax - (uint64_t)G->kmin + 1;
+        G->dense = G->range != 0 && G->range <= (uint64_t)G->seen && G->kmin != NULL_I64 && !G->rowhash;
+        if (G->rowhash) G->dense = 0;
+        if (G->spec && !G->dense) { /* (not a miss of the sample: nothing to remember) */
+            G->spec_ok = 0;
+            continue;
+        }
+        return RFX_OK;
     }
-    if (G->seen > 0 && G->nkeys == 1 && G->kmin == NULL_I64 && (q->flags & RFX_Q_REFUSE_NULL_KEY)) { rc = RFX_EXEC_NULL_KEY; goto done; }
-    if (G->spec) x->stat[RFX_XSTAT_SCOPE_SAMPLED]++;
-    out->nkeys = G->nkeys;
-    if (G->seen <= 0) { /* nothing selected: zero groups */
-        out->groups = 0;
-        goto done;
-    }
-    /* dense "perfect hash" iff range <= rows (core/index.c:2013), like the reference; else open addressing */
-    G->range = (uint64_t)G->kmax - (uint64_t)G->kmin + 1;
-    G->dense = G->range != 0 && G->range <= (uint64_t)G->seen && G->kmin != NULL_I64 && !G->rowhash;
-    if (G->rowhash) G->dense = 0;
-    if (G->spec && !G->dense) { /* (not a miss of the sample: nothing to remember) */
-        spec_ok = 0;
-        goto rescope;
-    }
+}
+
+/* table sizes, the small-range form, global row ids under an exchange */
+static void gb_size(gq_t *G) {
+    const rfx_query_t *q = G->q;
+    shard_t *sh = G->sh;
+    const int S = G->S, na = G->na, multi = G->multi;
     rfx_hip_group_table_arrays(sh[0].aggs, na, &G->narr);
     G->cap = G->cap_max = 16;
     if (!G->dense) {
@@ -1206,7 +1227,7 @@ rescope:
          * start at 4 M slots and take the reference's size when a pass reports the table full */
         while (G->cap_max < 2 * G->seen) G->cap_max <<= 1;
         G->cap = G->cap_max < (1 << 22) ? G->cap_max : (1 << 22);
-        if (cap_hint > G->cap && cap_hint <= G->cap_max) G->cap = cap_hint;
+        if (G->cap_hint > G->cap && G->cap_hint <= G->cap_max) G->cap = G->cap_hint;
         G->narr += 1;
         G->fused_keys = 0;
     }
@@ -1217,33 +1238,53 @@ rescope:
             rfx_exec_split(q->nrows, S, s, &r0, NULL);
             sh[s].row0 = G->proc_row0 + r0;
         }
-grow:;
-    if ((rc = run_shards(x, ph_pass, G)) != RFX_OK) goto done;
-    {
-        int flag = 0, any = 0;
-        for (int s = 0; s < S; s++) flag |= sh[s].flag;
-        /* (a dense pass under an exact scope has nothing to report: no exchange for it) */
-        if ((rc = xp_any(x, (G->exch && (G->spec || !G->dense)) ? G->world : 0, flag, &any)) != RFX_OK) goto done;
-        if (any && G->dense) { /* the sampled scope did not hold somewhere: the exact scope, and the pass again */
-            spec_ok = 0;
-            if (!retried) {
-                retried = 1;
-                x->stat[RFX_XSTAT_SCOPE_RETRIED]++;
-                spec_remember_bad(x, spec_id, q->nrows);
+}
+
+/* the passes over the shards and the merge of their tables; a full hashed table grows (every shard and process together) and runs again */
+static int gb_passes(gq_t *G) {
+    rfx_exec_t *x = G->x;
+    const rfx_query_t *q = G->q;
+    shard_t *sh = G->sh;
+    const int S = G->S;
+    const int multi = G->multi;
+    int rc = RFX_OK;
+    for (;;) {
+        if ((rc = run_shards(x, ph_pass, G)) != RFX_OK) return rc;
+        {
+            int flag = 0, any = 0;
+            for (int s = 0; s < S; s++) flag |= sh[s].flag;
+            /* (a dense pass under an exact scope has nothing to report: no exchange for it) */
+            if ((rc = xp_any(x, (G->exch && (G->spec || !G->dense)) ? G->world : 0, flag, &any)) != RFX_OK) return rc;
+            if (any && G->dense) { /* the sampled scope did not hold somewhere: the exact scope, and the pass again */
+                G->spec_ok = 0;
+                if (!G->retried) {
+                    G->retried = 1;
+                    x->stat[RFX_XSTAT_SCOPE_RETRIED]++;
+                    spec_remember_bad(x, G->spec_id, q->nrows);
+                }
+                return GB_AGAIN;
             }
-            goto rescope;
+            int full = any;
+            if (!full && multi && (rc = merge_tables(G, &full)) != RFX_OK) return rc;
+            if (full) { /* table full (a pass gives up at 3/4 load, early): every shard and process grows together */
+                if (G->cap >= G->cap_max) { snprintf(x->err, sizeof(x->err), "rfx_exec: the hashed group table is full at the reference's own size"); rc = RFX_ELIMIT; return rc; }
+                G->cap = G->cap_max;
+                x->stat[RFX_XSTAT_HASH_GROWN]++;
+                continue;
+            }
         }
-        int full = any;
-        if (!full && multi && (rc = merge_tables(G, &full)) != RFX_OK) goto done;
-        if (full) { /* table full (a pass gives up at 3/4 load, early): every shard and process grows together */
-            if (G->cap >= G->cap_max) { snprintf(x->err, sizeof(x->err), "rfx_exec: the hashed group table is full at the reference's own size"); rc = RFX_ELIMIT; goto done; }
-            G->cap = G->cap_max;
-            x->stat[RFX_XSTAT_HASH_GROWN]++;
-            goto grow;
-        }
+        return RFX_OK;
     }
-    rfx_hip_ctx_bind_thread(x->ctx[0]);
-    if (G->sparse_sampled && !G->dense && (q->flags & RFX_Q_REFUSE_NULL_KEY)) { /* did a null key come by after all?  its slot is the tables' last */
+}
+
+/* sparse keys routed by the sample alone: did a null key come by after all?  its slot is the tables' last */
+static int gb_null_slot(gq_t *G) {
+    rfx_exec_t *x = G->x;
+    const rfx_query_t *q = G->q;
+    shard_t *sh = G->sh;
+    const int S = G->S;
+    int rc = RFX_OK;
+    if (G->sparse_sampled && !G->dense && (q->flags & RFX_Q_REFUSE_NULL_KEY)) {
         int null_seen = 0;
         for (int s = 0; s < S && rc == RFX_OK; s++) {
             int64_t f = INF_I64;
@@ -1252,97 +1293,120 @@ grow:;
             null_seen |= f != INF_I64;
         }
         if (S > 1) rfx_hip_ctx_bind_thread(x->ctx[0]);
-        if (rc != RFX_OK) { snprintf(x->err, sizeof(x->err), "%s", rfx_hip_last_error()); goto done; }
-        if (null_seen) { rc = RFX_EXEC_NULL_KEY; goto done; }
+        if (rc != RFX_OK) { snprintf(x->err, sizeof(x->err), "%s", rfx_hip_last_error()); return rc; }
+        if (null_seen) { rc = RFX_EXEC_NULL_KEY; return rc; }
     }
-    out->path = G->rowhash ? RFX_PATH_ROWHASH : (G->dense ? RFX_PATH_DENSE : RFX_PATH_HASH);
-    out->capacity = G->dense ? 0 : G->cap;
-    /* ---- one hash = one tuple?  Every row's group-first row (the join probe against the group-by's own table), then per key column:
-     * the column gathered at those rows must equal the column itself (K1 counts the rows where it does not) ---- */
-    if (G->rowhash || (q->flags & RFX_Q_PROBE_FIRST)) {
-        shard_t *h = &sh[0];
-        rfx_ctx_t *c = x->ctx[0];
-        if (G->dense || multi) { if (q->flags & RFX_Q_PROBE_FIRST) { rc = RFX_ESTATE; snprintf(x->err, sizeof(x->err), "rfx_exec: a first-row probe needs the hashed path on one shard"); goto done; } }
-        else {
-            void *ids = NULL, *chk = NULL;
-            rc = rfx_hip_malloc(c, &ids, (size_t)(h->nrows ? h->nrows : 1) * 8);
-            if (rc == RFX_OK) rc = rfx_hip_join_probe_hash(c, (const int64_t *)h->key, h->nrows, &h->ht, (int64_t *)ids);
-            int collision = 0;
-            if (rc == RFX_OK && G->rowhash) rc = rfx_hip_malloc(c, &chk, (size_t)(h->nrows ? h->nrows : 1) * 8);
-            for (int k = 0; k < G->nkeys && rc == RFX_OK && G->rowhash && !collision; k++) {
-                rfx_pred_t ne;
-                rfx_value_t cv;
-                int64_t differ = 0;
-                memset(&ne, 0, sizeof(ne));
-                ne.d_col = chk;
-                ne.col_type = RFX_I64;
-                ne.op = RFX_NE;
-                ne.d_rhs_col = h->keys[k];
-                ne.rhs_type = RFX_I64;
-                rc = rfx_hip_gather_or(c, h->keys[k], h->keys[k], (const int64_t *)ids, h->nrows, 0, chk);
-                if (rc == RFX_OK) rc = rfx_hip_filter_aggr_host(c, &ne, 1, RFX_AND, NULL, 0, h->nrows, &cv, &differ);
-                if (rc == RFX_OK && differ) collision = 1;
-            }
-            if (chk) rfx_hip_free(c, chk);
-            if ((q->flags & RFX_Q_PROBE_FIRST) && rc == RFX_OK && !collision && first_pass) {
-                out->d_probe = (int64_t *)ids;
-                own(out, ids);
-            } else if (ids) rfx_hip_free(c, ids);
-            if (rc == RFX_OK && collision) {
-                snprintf(x->err, sizeof(x->err), "row-hash collision between two key tuples");
-                rc = RFX_ESTATE;
-            }
-            if (rc != RFX_OK) { if (!x->err[0]) snprintf(x->err, sizeof(x->err), "%s", rfx_hip_last_error()); goto done; }
+    return RFX_OK;
+}
+
+/* ---- one hash = one tuple?  Every row's group-first row (the join probe against the group-by's own table), then per key column:
+ * the column gathered at those rows must equal the column itself (K1 counts the rows where it does not) ---- */
+static int gb_prove_tuples(gq_t *G) {
+    rfx_exec_t *x = G->x;
+    const rfx_query_t *q = G->q;
+    shard_t *sh = G->sh;
+    const int multi = G->multi;
+    rfx_groups_t *out = G->out;
+    int rc = RFX_OK;
+    if (!G->rowhash && !(q->flags & RFX_Q_PROBE_FIRST)) return RFX_OK;
+    shard_t *h = &sh[0];
+    rfx_ctx_t *c = x->ctx[0];
+    if (G->dense || multi) { if (q->flags & RFX_Q_PROBE_FIRST) { rc = RFX_ESTATE; snprintf(x->err, sizeof(x->err), "rfx_exec: a first-row probe needs the hashed path on one shard"); return rc; } }
+    else {
+        void *ids = NULL, *chk = NULL;
+        rc = rfx_hip_malloc(c, &ids, (size_t)(h->nrows ? h->nrows : 1) * 8);
+        if (rc == RFX_OK) rc = rfx_hip_join_probe_hash(c, (const int64_t *)h->key, h->nrows, &h->ht, (int64_t *)ids);
+        int collision = 0;
+        if (rc == RFX_OK && G->rowhash) rc = rfx_hip_malloc(c, &chk, (size_t)(h->nrows ? h->nrows : 1) * 8);
+        for (int k = 0; k < G->nkeys && rc == RFX_OK && G->rowhash && !collision; k++) {
+            rfx_pred_t ne;
+            rfx_value_t cv;
+            int64_t differ = 0;
+            memset(&ne, 0, sizeof(ne));
+            ne.d_col = chk;
+            ne.col_type = RFX_I64;
+            ne.op = RFX_NE;
+            ne.d_rhs_col = h->keys[k];
+            ne.rhs_type = RFX_I64;
+            rc = rfx_hip_gather_or(c, h->keys[k], h->keys[k], (const int64_t *)ids, h->nrows, 0, chk);
+            if (rc == RFX_OK) rc = rfx_hip_filter_aggr_host(c, &ne, 1, RFX_AND, NULL, 0, h->nrows, &cv, &differ);
+            if (rc == RFX_OK && differ) collision = 1;
         }
+        if (chk) rfx_hip_free(c, chk);
+        if ((q->flags & RFX_Q_PROBE_FIRST) && rc == RFX_OK && !collision && G->first_pass) {
+            out->d_probe = (int64_t *)ids;
+            own(out, ids);
+        } else if (ids) rfx_hip_free(c, ids);
+        if (rc == RFX_OK && collision) {
+            snprintf(x->err, sizeof(x->err), "row-hash collision between two key tuples");
+            rc = RFX_ESTATE;
+        }
+        if (rc != RFX_OK) { if (!x->err[0]) snprintf(x->err, sizeof(x->err), "%s", rfx_hip_last_error()); return rc; }
     }
-    /* ---- rank + emit ---- */
-    if (G->small) {
-        /* few slots: rank + emit are ONE launch and the result block comes back in one copy -- the only host round trip after the pass */
-        shard_t *h = &sh[0];
-        rfx_ctx_t *c = x->ctx[0];
-        const size_t bcells = 1 + (size_t)(2 + na) * (size_t)G->range;
-        void *blk = NULL;
-        int64_t *mirror = (int64_t *)malloc(bcells * 8);
-        rc = mirror ? rfx_hip_malloc(c, &blk, bcells * 8) : RFX_ENOMEM;
-        if (rc == RFX_OK) rc = rfx_hip_group_rank_emit_small(c, h->aggs, &h->gt, 0, 0, (int64_t *)blk);
-        if (rc == RFX_OK) rc = rfx_hip_d2h(c, mirror, blk, bcells * 8);
-        if (rc != RFX_OK) {
-            free(mirror);
-            if (blk) rfx_hip_free(c, blk);
-            snprintf(x->err, sizeof(x->err), "%s", rfx_hip_last_error());
-            goto done;
-        }
-        if (first_pass) {
-            out->groups = mirror[0];
-            out->path = RFX_PATH_DENSE_SMALL;
-            out->d_block = (const char *)blk;
-            out->h_block = (const char *)mirror;
-            out->block_bytes = bcells * 8;
-            out->d_keys = (int64_t *)blk + 1;
-            out->d_first = (int64_t *)blk + 1 + G->range;
-            own(out, blk);
-        }
-        if (!first_pass) { /* a later pass of a long output list: its own block, no mirror (fetched through the device) */
-            free(mirror);
-            own(out, blk);
-        }
-        for (int a = 0; a < na; a++) out->d_results[a0 + a] = (int64_t *)blk + 1 + (size_t)(2 + a) * (size_t)G->range;
-        goto results_typed;
+    return RFX_OK;
+}
+
+/* few slots: rank + emit are ONE launch and the result block comes back in one copy -- the only host round trip after the pass */
+static int gb_emit_small(gq_t *G) {
+    rfx_exec_t *x = G->x;
+    shard_t *sh = G->sh;
+    const int na = G->na;
+    rfx_groups_t *out = G->out;
+    int rc = RFX_OK;
+    shard_t *h = &sh[0];
+    rfx_ctx_t *c = x->ctx[0];
+    const size_t bcells = 1 + (size_t)(2 + na) * (size_t)G->range;
+    void *blk = NULL;
+    int64_t *mirror = (int64_t *)malloc(bcells * 8);
+    rc = mirror ? rfx_hip_malloc(c, &blk, bcells * 8) : RFX_ENOMEM;
+    if (rc == RFX_OK) rc = rfx_hip_group_rank_emit_small(c, h->aggs, &h->gt, 0, 0, (int64_t *)blk);
+    if (rc == RFX_OK) rc = rfx_hip_d2h(c, mirror, blk, bcells * 8);
+    if (rc != RFX_OK) {
+        free(mirror);
+        if (blk) rfx_hip_free(c, blk);
+        snprintf(x->err, sizeof(x->err), "%s", rfx_hip_last_error());
+        return rc;
     }
-    if ((rc = run_shards(x, ph_rank_emit, G)) != RFX_OK) goto done;
-    if (G->all_rank && (rc = merge_first_values(G)) != RFX_OK) goto done;
+    if (G->first_pass) {
+        out->groups = mirror[0];
+        out->path = RFX_PATH_DENSE_SMALL;
+        out->d_block = (const char *)blk;
+        out->h_block = (const char *)mirror;
+        out->block_bytes = bcells * 8;
+        out->d_keys = (int64_t *)blk + 1;
+        out->d_first = (int64_t *)blk + 1 + G->range;
+        own(out, blk);
+    }
+    if (!G->first_pass) { /* a later pass of a long output list: its own block, no mirror (fetched through the device) */
+        free(mirror);
+        own(out, blk);
+    }
+    for (int a = 0; a < na; a++) out->d_results[G->a0 + a] = (int64_t *)blk + 1 + (size_t)(2 + a) * (size_t)G->range;
+    return RFX_OK;
+}
+
+/* rank + emit on every shard, first values merged across them, the result's key columns */
+static int gb_emit(gq_t *G) {
+    rfx_exec_t *x = G->x;
+    const rfx_query_t *q = G->q;
+    shard_t *sh = G->sh;
+    const int na = G->na;
+    rfx_groups_t *out = G->out;
+    int rc = RFX_OK;
+    if ((rc = run_shards(x, ph_rank_emit, G)) != RFX_OK) return rc;
+    if (G->all_rank && (rc = merge_first_values(G)) != RFX_OK) return rc;
     rfx_hip_ctx_bind_thread(x->ctx[0]);
     {
         shard_t *h = &sh[0];
         rfx_ctx_t *c = x->ctx[0];
         const int64_t g = h->groups;
         G->groups = g;
-        if (first_pass) out->groups = g;
-        else if (out->groups != g) { snprintf(x->err, sizeof(x->err), "rfx_exec: two passes of one query disagree on the groups"); rc = RFX_ESTATE; goto done; }
+        if (G->first_pass) out->groups = g;
+        else if (out->groups != g) { snprintf(x->err, sizeof(x->err), "rfx_exec: two passes of one query disagree on the groups"); rc = RFX_ESTATE; return rc; }
         if (g > 0) {
-            for (int a = 0; a < na; a++) out->d_results[a0 + a] = (int64_t *)h->dout + (size_t)(a + 1) * (size_t)g;
+            for (int a = 0; a < na; a++) out->d_results[G->a0 + a] = (int64_t *)h->dout + (size_t)(a + 1) * (size_t)g;
             own(out, h->dout);
-            if (first_pass) {
+            if (G->first_pass) {
                 out->d_keys = (int64_t *)h->dout;
                 /* several keys: the result's key columns -- decoded from the composite key (key_i = min_i + (composite / mult_i) % range_i
                  * = key_i[first row], core/query.c:110-135) or, on the row-hash path, gathered at the groups' first rows */
@@ -1368,17 +1432,57 @@ grow:;
                 out->d_first = (int64_t *)h->dfirst;
                 own(out, h->dfirst);
                 if (rc == RFX_OK) rc = rfx_hip_ctx_sync(c);
-                if (rc != RFX_OK) { snprintf(x->err, sizeof(x->err), "%s", rfx_hip_last_error()); h->dout = h->dfirst = NULL; goto done; }
+                if (rc != RFX_OK) { snprintf(x->err, sizeof(x->err), "%s", rfx_hip_last_error()); h->dout = h->dfirst = NULL; return rc; }
             } else if (h->dfirst) rfx_hip_free(c, h->dfirst);
             h->dout = h->dfirst = NULL; /* the result owns them now */
         }
     }
-results_typed:
-    for (int a = 0; a < na; a++) {
-        const rfx_agg_t *g = &sh[0].aggs[a];
-        out->result_type[a0 + a] = g->kind == RFX_AGG_AVG ? RFX_F64 : (g->kind == RFX_AGG_COUNT ? RFX_I64 : rfx_agg_input_type(g));
+    return RFX_OK;
+}
+
+static int group_by_pass(rfx_exec_t *x, const rfx_query_t *q, int a0, int na, int first_pass, int64_t cap_hint, rfx_groups_t *out) {
+    const int S = x->nshards;
+    gq_t *G = (gq_t *)calloc(1, sizeof(gq_t));
+    shard_t *sh = (shard_t *)calloc((size_t)S, sizeof(shard_t));
+    if (!G || !sh) { free(G); free(sh); return RFX_ENOMEM; }
+    G->x = x;
+    G->q = q;
+    G->sh = sh;
+    G->S = S;
+    G->exch = world_rank(x, &G->world, &G->rank);
+    G->a0 = a0;
+    G->na = na;
+    G->first_pass = first_pass;
+    G->cap_hint = cap_hint;
+    G->out = out;
+    G->npred = q->npred;
+    G->nkeys = q->nkeys;
+    G->total_rows = q->nrows;
+    G->want_first = (q->flags & RFX_Q_WANT_FIRST) != 0;
+    int rc = gb_setup(G);
+    while (rc == RFX_OK) {
+        rc = gb_scope(G);
+        if (rc != RFX_OK || G->seen <= 0) break;
+        gb_size(G);
+        rc = gb_passes(G);
+        if (rc != GB_AGAIN) break;
+        rc = RFX_OK;
     }
-done:
+    if (rc == RFX_OK && G->seen <= 0) out->groups = 0;
+    else if (rc == RFX_OK) {
+        rfx_hip_ctx_bind_thread(x->ctx[0]);
+        rc = gb_null_slot(G);
+        if (rc == RFX_OK) {
+            out->path = G->rowhash ? RFX_PATH_ROWHASH : (G->dense ? RFX_PATH_DENSE : RFX_PATH_HASH);
+            out->capacity = G->dense ? 0 : G->cap;
+            rc = gb_prove_tuples(G);
+        }
+        if (rc == RFX_OK) rc = G->small ? gb_emit_small(G) : gb_emit(G);
+        for (int a = 0; a < na && rc == RFX_OK; a++) {
+            const rfx_agg_t *g = &sh[0].aggs[a];
+            out->result_type[a0 + a] = g->kind == RFX_AGG_AVG ? RFX_F64 : (g->kind == RFX_AGG_COUNT ? RFX_I64 : rfx_agg_input_type(g));
+        }
+    }
     for (int s = 0; s < S; s++) {
         if (S > 1) rfx_hip_ctx_bind_thread(x->ctx[s]);
         sh_release(x, &sh[s], s);
