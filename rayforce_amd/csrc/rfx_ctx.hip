@@ -77,6 +77,7 @@ extern "C" int rfx_hip_ctx_destroy(rfx_ctx_t *c) {
     rfx_io_release(c);
     pool_release(c);
     if (c->ext_p[1]) (void)hipFree(c->ext_p[1]);
+    free(c->ext_p[5]); // rfx_chunk_scope's sample memo
     rfx_plane_release(c);
     if (c->d_pc_counts) (void)hipFree(c->d_pc_counts);
     if (c->h_pin) (void)hipHostFree(c->h_pin);
@@ -467,6 +468,7 @@ extern "C" int rfx_hip_h2d(rfx_ctx_t *c, void *d_dst, const void *src, size_t by
     c->ck_valid = 0;
     c->pc_valid = 0;
     rfx_plane_invalidate(c);
+    if (c->ext_p[5]) memset(c->ext_p[5], 0, 256); // ... nor does a remembered sample (rfx_chunk_scope; it only sizes and routes, but why keep it)
     RFX_HIP_CHECK(hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, c->stream));
     RFX_HIP_CHECK(hipStreamSynchronize(c->stream));
     return RFX_OK;
@@ -484,6 +486,7 @@ extern "C" int rfx_hip_memset(rfx_ctx_t *c, void *d_dst, int byte, size_t bytes)
     c->ck_valid = 0;
     c->pc_valid = 0;
     rfx_plane_invalidate(c);
+    if (c->ext_p[5]) memset(c->ext_p[5], 0, 256);
     RFX_HIP_CHECK(hipMemsetAsync(d_dst, byte, bytes, c->stream));
     return RFX_OK;
 }

@@ -1256,6 +1256,37 @@ int rfx_chunk_scope(rfx_ctx *c, const int64_t *d_key, const rfx_pred_t *preds, i
     // 256 partitions come here (the LDS-direct kernel is one pass already; wider ranges need more partitions than the low 8 bits give)
     const i64 nsamp = 1 << 14;
     const int sgrid = 16;
+    // The sample of the SAME query over the SAME columns is remembered (four of them per context: the kernel, its memset, the copy back and
+    // the wait are 30 us of a 5 ms query).  Whatever comes out of it only sizes and routes -- ranges, capacities, which kernel -- and every
+    // form downstream reports what did not fit, so a remembered sample that no longer describes the data (a column changed in place behind
+    // the context's back) costs a fallback, never an answer; uploads through the context drop it (rfx_hip_h2d).
+    u64 sig = 0xCBF29CE484222325ULL;
+    {
+        auto mix = [&](u64 v) { sig = (sig ^ v) * 0x100000001B3ULL; sig ^= sig >> 29; };
+        mix((u64)(uintptr_t)d_key); mix((u64)nrows); mix((u64)P.npred); mix((u64)P.logic); mix((u64)P.ncols); mix((u64)key_idx);
+        for (int i = 0; i < P.ncols; i++) mix((u64)(uintptr_t)P.cols[i]);
+        for (int i = 0; i < P.npred; i++) {
+            const PlanPred &q = P.preds[i];
+            mix((u64)q.col | ((u64)(unsigned)q.rhs_col << 8) | ((u64)q.op << 16) | ((u64)q.dom_f64 << 20) | ((u64)q.lhs_cvt << 21) | ((u64)q.rhs_cvt << 22) | ((u64)q.more << 23) | ((u64)(unsigned)q.tree << 24));
+            mix(q.rhs_bits);
+        }
+        if (sig == 0) sig = 1;
+    }
+    struct SampleMemo { u64 sig; i64 smn, smx, ssel; unsigned hot, age; }; // 4 x 40 bytes <= the 256 rfx_ctx.hip clears
+    static_assert(4 * sizeof(SampleMemo) <= 256, "memo block");
+    if (!c->ext_p[5]) c->ext_p[5] = calloc(1, 256);
+    SampleMemo *memo = (SampleMemo *)c->ext_p[5];
+    i64 smn = RFX_INF_I64_D, smx = RFX_NULL_I64_D, ssel = 0;
+    unsigned hot = 0;
+    bool remembered = false;
+    static unsigned memo_clock = 0; // (shared by the contexts of a process: it only orders the entries of each)
+    for (int i = 0; memo && i < 4 && !getenv("RFX_NO_SAMPLE_MEMO"); i++)
+        if (memo[i].sig == sig) {
+            smn = memo[i].smn, smx = memo[i].smx, ssel = memo[i].ssel, hot = memo[i].hot;
+            memo[i].age = __atomic_add_fetch(&memo_clock, 1u, __ATOMIC_RELAXED);
+            remembered = true;
+        }
+    if (!remembered) {
     rc = rfx_ws_reserve(c, (size_t)sgrid * 32 + CK_PARTS * 4);
     if (rc != RFX_OK) return rc;
     unsigned *d_hist = (unsigned *)((char *)c->d_ws + (size_t)sgrid * 32);
@@ -1273,13 +1304,18 @@ int rfx_chunk_scope(rfx_ctx *c, const int64_t *d_key, const rfx_pred_t *preds, i
     RFX_HIP_CHECK(hipMemcpyAsync(hs, c->d_ws, (size_t)sgrid * 32 + CK_PARTS * 4, hipMemcpyDeviceToHost, c->stream));
     RFX_HIP_CHECK(hipStreamSynchronize(c->stream));
     const unsigned *hh = (const unsigned *)((const char *)hs + (size_t)sgrid * 32);
-    unsigned hot = 0;
     for (int i = 0; i < CK_PARTS; i++) hot = hh[i] > hot ? hh[i] : hot;
-    i64 smn = RFX_INF_I64_D, smx = RFX_NULL_I64_D, ssel = 0;
     for (int i = 0; i < sgrid; i++) {
         smn = hs[4 * i] < smn ? hs[4 * i] : smn;
         smx = hs[4 * i + 1] > smx ? hs[4 * i + 1] : smx;
         ssel += hs[4 * i + 2];
+    }
+    if (memo) { // replaces the entry used longest ago
+        int at = 0;
+        for (int i = 1; i < 4; i++)
+            if (memo[i].age < memo[at].age) at = i;
+        memo[at] = SampleMemo{sig, smn, smx, ssel, hot, __atomic_add_fetch(&memo_clock, 1u, __ATOMIC_RELAXED)};
+    }
     }
     if (smn == RFX_NULL_I64_D || smx < smn || ssel == 0) return RFX_ESTATE;
     const unsigned long long est = (unsigned long long)smx - (unsigned long long)smn + 1ULL;

@@ -4,7 +4,7 @@
 #include "rfx_scalar_kernel.hpp"
 
 #define RFX_CHUNK 512
-int rfx_scan_counts(rfx_ctx *c, i64 *d_cnt, i64 n, i64 *d_total);
+int rfx_scan_counts(rfx_ctx *c, i64 *d_cnt, i64 n, i64 *d_total, const i64 *d_n_eff = nullptr); // d_n_eff: a device-side bound on n (entries beyond it are zero, untouched)
 int rfx_rank_slots(rfx_ctx *c, const u64 *d_first, i64 slots, i64 row_base, i64 total_rows, i64 *ngroups);
 int rfx_fill_u64(rfx_ctx *c, void *p, i64 n, u64 val);
 // partitioned form of the sparse-key (hashed) group-by, rfx_group_part.hip.  RFX_ESTATE: not applicable.

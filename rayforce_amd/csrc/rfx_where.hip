@@ -147,9 +147,15 @@ __device__ __forceinline__ i64 block_exclusive_scan(i64 x, i64 *lds /* >= 4 entr
     return wbase + inc - x;
 }
 
-__global__ __launch_bounds__(RFX_BLOCK) void k_scan_partial(const i64 *__restrict__ cnt, i64 n, i64 *__restrict__ span_sum) {
+// (n_eff, when given: a device-side bound on n -- entries beyond it count as zero and are neither read nor written; rfx_rank_slots)
+__global__ __launch_bounds__(RFX_BLOCK) void k_scan_partial(const i64 *__restrict__ cnt, i64 n, i64 *__restrict__ span_sum, const i64 *__restrict__ n_eff) {
     __shared__ i64 lds[4];
     const i64 base = (i64)blockIdx.x * SCAN_SPAN;
+    if (n_eff && *n_eff < n) n = *n_eff;
+    if (base >= n) { // (wave-uniform)
+        if (threadIdx.x == 0) span_sum[blockIdx.x] = 0;
+        return;
+    }
     i64 s = 0;
     for (int i = threadIdx.x; i < SCAN_SPAN; i += RFX_BLOCK) {
         i64 idx = base + i;
@@ -176,9 +182,11 @@ __global__ __launch_bounds__(RFX_BLOCK) void k_scan_spans(i64 *__restrict__ span
     if (threadIdx.x == 0) *total = carry;
 }
 
-__global__ __launch_bounds__(RFX_BLOCK) void k_scan_apply(i64 *__restrict__ cnt, i64 n, const i64 *__restrict__ span_off) {
+__global__ __launch_bounds__(RFX_BLOCK) void k_scan_apply(i64 *__restrict__ cnt, i64 n, const i64 *__restrict__ span_off, const i64 *__restrict__ n_eff) {
     __shared__ i64 lds[4];
     const i64 base = (i64)blockIdx.x * SCAN_SPAN;
+    if (n_eff && *n_eff < n) n = *n_eff;
+    if (base >= n) return;
     i64 carry = span_off[blockIdx.x];
     // each thread owns SCAN_SPAN / RFX_BLOCK = 8 consecutive entries
     constexpr int PER = SCAN_SPAN / RFX_BLOCK;
@@ -201,17 +209,17 @@ __global__ __launch_bounds__(RFX_BLOCK) void k_scan_apply(i64 *__restrict__ cnt,
 
 // Exclusive scan of d_cnt[0..n) in place; total written to d_total (device).  Uses the tail of d_cnt's
 // allocation?  No: span sums live in the context workspace.
-int rfx_scan_counts(rfx_ctx *c, i64 *d_cnt, i64 n, i64 *d_total) {
+int rfx_scan_counts(rfx_ctx *c, i64 *d_cnt, i64 n, i64 *d_total, const i64 *d_n_eff) {
     const i64 nspans = (n + SCAN_SPAN - 1) / SCAN_SPAN;
     int rc = rfx_ws_reserve(c, (size_t)(nspans + 8) * 8);
     if (rc != RFX_OK) return rc;
     i64 *spans = (i64 *)c->d_ws;
     if (nspans > 0) {
-        hipLaunchKernelGGL(k_scan_partial, dim3((unsigned)nspans), dim3(RFX_BLOCK), 0, c->stream, (const i64 *)d_cnt, n, spans);
+        hipLaunchKernelGGL(k_scan_partial, dim3((unsigned)nspans), dim3(RFX_BLOCK), 0, c->stream, (const i64 *)d_cnt, n, spans, d_n_eff);
     }
     hipLaunchKernelGGL(k_scan_spans, dim3(1), dim3(RFX_BLOCK), 0, c->stream, spans, nspans, d_total);
     if (nspans > 0) {
-        hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nspans), dim3(RFX_BLOCK), 0, c->stream, d_cnt, n, (const i64 *)spans);
+        hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nspans), dim3(RFX_BLOCK), 0, c->stream, d_cnt, n, (const i64 *)spans, d_n_eff);
     }
     RFX_HIP_CHECK(hipGetLastError());
     return RFX_OK;
@@ -375,7 +383,7 @@ static int where_scan_total(rfx_ctx *c, i64 nrows, i64 *count, bool counts_from_
         RFX_HIP_CHECK(hipGetLastError());
     }
     i64 *d_total = c->d_blksum + nchunks;
-    int rc = rfx_scan_counts(c, c->d_blksum, nchunks, d_total);
+    int rc = rfx_scan_counts(c, c->d_blksum, nchunks, d_total, NULL);
     if (rc != RFX_OK) return rc;
     i64 *h = (i64 *)c->h_pin;
     RFX_HIP_CHECK(hipMemcpyAsync(h, d_total, 8, hipMemcpyDeviceToHost, c->stream));
