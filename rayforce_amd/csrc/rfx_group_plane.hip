@@ -501,9 +501,11 @@ __global__ __launch_bounds__(THREADS) void k_plane_aggregate(const Plan P, const
         }
     };
     // (Round 4 tried FOUR batches in flight per wave -- under a selective filter a region is one batch and a wave walks ~120 of them, the
-    // suspicion was one region per memory round trip.  C3w: 0.435 -> 0.424 ms, i.e. not it -- 0.17 ms of the pass are the 4e6 device atomics of the
-    // final merge (two workgroups per partition share its slots), the rest the LDS atomics per record -- and the general (non-FAST) form spilled:
-    // `avg v1, v2, v3` at 1e6 keys 18.9 -> 32.1 ms.  Two it stays.)
+    // suspicion was one region per memory round trip.  C3w: 0.435 -> 0.424 ms, i.e. not it, and the general (non-FAST) form spilled:
+    // `avg v1, v2, v3` at 1e6 keys 18.9 -> 32.1 ms.  Two it stays.  Nor is it the final merge below (a strided read and two device atomics
+    // per cell from two workgroups per partition): the tables written out as they are, whole lines, and folded into the device-wide tables
+    // by a transposing kernel of 31 us -- built, the whole suite green, C3w 4.74 against 4.70 ms with the atomics, C3 7.57 against 7.62:
+    // nothing, taken out again (profiles/r04_plane_combine_ab.txt).)
     Batch B0, B1;
     bool h0 = advance();
     load(h0, b, i0, n, B0);
