@@ -977,6 +977,30 @@ def test_few_groups_run_time_compiled_kernels(eng, groups, n):
         eng.tune(flags=0)
 
 
+# ---------------------------------------------------------------- the ranking's device-side bound, the remembered sample
+@pytest.mark.parametrize("shape", ["last_row", "first_rows", "one_group", "spread"])
+def test_rank_stops_at_the_last_first_row(eng, shape):
+    """rfx_rank_slots bounds its bitmap, chunk counts and scan by the last first row, found on the device (k_first_bound): a key that shows up
+    in the table's LAST row only (the bound is the whole table), cyclic keys (every first row within the first 200 000 rows: the bound is a
+    few hundred chunks), one group, random keys -- group order, first rows and sums against the oracle, on the plane path (2^22+ rows) with
+    and without a filter.  The same query runs twice: the second one takes rfx_chunk_scope's remembered sample and must answer alike."""
+    n = (1 << 22) + 4_099
+    host = table(n, seed=3, keys=200_000)
+    if shape == "last_row":
+        host["k"][-1] = 777_777
+        host["a"][-1] = 5  # (selected by the filter below)
+    elif shape == "first_rows":
+        host["k"] = (np.arange(n, dtype=np.int64) * 7) % 200_000
+    elif shape == "one_group":
+        host["k"][:] = 42
+    d = dev(eng, host)
+    for q in ({"by": "k", "s": ("sum", "v"), "f": ("first", "a")}, {"where": ("<", "a", 300_000), "by": "k", "s": ("sum", "v"), "c": ("count", "a")}):
+        r1 = check_select(eng, host, q, d)
+        r2 = check_select(eng, host, q, d)
+        for name in r1:
+            assert torch.equal(r1[name].view(torch.int64), r2[name].view(torch.int64)) or name == "s", name
+
+
 # ---------------------------------------------------------------- sampled key scopes (large inputs, LDS-sized ranges)
 def test_sampled_scope_reports_what_it_missed(eng):
     """From 2^24 rows on, a group-by over an LDS-sized key range takes its scope from a SAMPLE (2^18 strided rows + both ends) instead of
