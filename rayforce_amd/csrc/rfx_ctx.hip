@@ -78,6 +78,7 @@ extern "C" int rfx_hip_ctx_destroy(rfx_ctx_t *c) {
     pool_release(c);
     if (c->ext_p[1]) (void)hipFree(c->ext_p[1]);
     free(c->ext_p[5]); // rfx_chunk_scope's sample memo
+    free(c->ext_p[6]); // rfx_hip_where_estimate's
     rfx_plane_release(c);
     if (c->d_pc_counts) (void)hipFree(c->d_pc_counts);
     if (c->h_pin) (void)hipHostFree(c->h_pin);
@@ -469,6 +470,7 @@ extern "C" int rfx_hip_h2d(rfx_ctx_t *c, void *d_dst, const void *src, size_t by
     c->pc_valid = 0;
     rfx_plane_invalidate(c);
     if (c->ext_p[5]) memset(c->ext_p[5], 0, 256); // ... nor does a remembered sample (rfx_chunk_scope; it only sizes and routes, but why keep it)
+    if (c->ext_p[6]) memset(c->ext_p[6], 0, 256); // ... or a remembered `where` estimate
     RFX_HIP_CHECK(hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, c->stream));
     RFX_HIP_CHECK(hipStreamSynchronize(c->stream));
     return RFX_OK;
@@ -487,6 +489,7 @@ extern "C" int rfx_hip_memset(rfx_ctx_t *c, void *d_dst, int byte, size_t bytes)
     c->pc_valid = 0;
     rfx_plane_invalidate(c);
     if (c->ext_p[5]) memset(c->ext_p[5], 0, 256);
+    if (c->ext_p[6]) memset(c->ext_p[6], 0, 256);
     RFX_HIP_CHECK(hipMemsetAsync(d_dst, byte, bytes, c->stream));
     return RFX_OK;
 }

@@ -74,6 +74,32 @@ extern "C" int rfx_hip_where_estimate(rfx_ctx_t *c, const rfx_pred_t *preds, int
     int rc = rfx_plan_build(&P, preds, npred, logic, NULL, 0, NULL, NULL, nrows, 0);
     if (rc != RFX_OK) return rc;
     if (P.ncols > 4 || P.npred > 4) return RFX_OK; // (the sampler has the one-pass kernel's shapes; wider filters: the whole column)
+    // The estimate of the SAME predicates over the SAME columns is remembered (four per context; the sample kernel, its copy back and the
+    // wait are 25 us of a 1.7 ms query).  It only sizes the id buffer: a remembered figure that no longer fits the data comes back from
+    // rfx_hip_where_once as RFX_ELIMIT with the exact count, like any underestimate; uploads through the context drop it (rfx_hip_h2d).
+    u64 sig = 0xCBF29CE484222325ULL;
+    {
+        auto mix = [&](u64 v) { sig = (sig ^ v) * 0x100000001B3ULL; sig ^= sig >> 29; };
+        mix((u64)nrows); mix((u64)P.npred); mix((u64)P.logic); mix((u64)P.ncols);
+        for (int i = 0; i < P.ncols; i++) mix((u64)(uintptr_t)P.cols[i]);
+        for (int i = 0; i < P.npred; i++) {
+            const PlanPred &q = P.preds[i];
+            mix((u64)q.col | ((u64)(unsigned)q.rhs_col << 8) | ((u64)q.op << 16) | ((u64)q.dom_f64 << 20) | ((u64)q.lhs_cvt << 21) | ((u64)q.rhs_cvt << 22) | ((u64)q.more << 23) | ((u64)(unsigned)q.tree << 24));
+            mix(q.rhs_bits);
+        }
+        if (sig == 0) sig = 1;
+    }
+    struct EstMemo { u64 sig; i64 upper; unsigned age, pad; }; // 4 x 24 bytes <= the 256 rfx_ctx.hip clears
+    static_assert(4 * sizeof(EstMemo) <= 256, "memo block");
+    if (!c->ext_p[6]) c->ext_p[6] = calloc(1, 256);
+    EstMemo *memo = (EstMemo *)c->ext_p[6];
+    static unsigned memo_clock = 0; // (only orders the entries of each context)
+    for (int i = 0; memo && i < 4 && !getenv("RFX_NO_SAMPLE_MEMO"); i++)
+        if (memo[i].sig == sig) {
+            memo[i].age = __atomic_add_fetch(&memo_clock, 1u, __ATOMIC_RELAXED);
+            *upper = memo[i].upper;
+            return RFX_OK;
+        }
     rc = rfx_ws_reserve(c, 256);
     if (rc != RFX_OK) return rc;
     unsigned *hits = (unsigned *)c->d_ws;
@@ -97,6 +123,12 @@ extern "C" int rfx_hip_where_estimate(rfx_ctx_t *c, const rfx_pred_t *preds, int
     double up = ((f + 4.0 * sd + 0.01) * (double)nrows) + 1024.0;
     if (up > (double)nrows) up = (double)nrows;
     *upper = (int64_t)up;
+    if (memo) { // replaces the entry used longest ago
+        int at = 0;
+        for (int i = 1; i < 4; i++)
+            if (memo[i].age < memo[at].age) at = i;
+        memo[at] = EstMemo{sig, *upper, __atomic_add_fetch(&memo_clock, 1u, __ATOMIC_RELAXED), 0u};
+    }
     return RFX_OK;
 }
 
