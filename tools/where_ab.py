@@ -1,5 +1,5 @@
 """dev: time Engine.where (rfx_hip_where_estimate + rfx_hip_where_once) on the w2 shape and check the ids against torch:
-tools/where_ab.py <rows> <a < threshold of 1e6>; RFX_WHERE_SPLIT=k picks the split-role kernel with k workgroups per CU."""
+tools/where_ab.py <rows> <a < threshold of 1e6>; RFX_NO_RTC=1: the prebuilt kernel instead of the one compiled for the predicate list."""
 import os, sys, time, torch
 sys.path.insert(0, ".")
 from rayforce_amd.engine import Engine
@@ -25,4 +25,4 @@ for lo in range(0, n, step):
     ok = ok and got.numel() == want.numel() and bool((got == want).all())
     pos += want.numel()
 ok = ok and pos == ids.numel()
-print(f"split {os.environ.get('RFX_WHERE_SPLIT', '0')} rows {n} selected {ids.numel()} ms/query {ms:.3f} ids {'ok' if ok else 'WRONG'}", flush=True)
+print(f"rtc {'off' if os.environ.get('RFX_NO_RTC') else 'on'} rows {n} selected {ids.numel()} ms/query {ms:.3f} ids {'ok' if ok else 'WRONG'}", flush=True)
