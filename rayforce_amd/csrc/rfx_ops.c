@@ -961,10 +961,16 @@ typedef struct {
 
 /* one comparison `(op colsym atom|colsym)` -> descriptor; 0 ok, -1 unsupported shape */
 /* device scratch a query's PREDICATES allocate (operands that are expressions): released at the end of rfx_select */
-static void *g_qtmp[2 * RFX_MAX_PREDS * 4];
+static struct { void *d[RFX_MAX_SHARDS]; } g_qtmp[2 * RFX_MAX_PREDS * 4]; /* (per shard: every shard evaluates its own rows) */
 static int g_nqtmp;
 static void qtmp_release(void) {
-    for (int i = 0; i < g_nqtmp; i++) rfx_hip_free(g_ctx, g_qtmp[i]);
+    for (int i = 0; i < g_nqtmp; i++)
+        for (int s = 0; s < g_nshards; s++) {
+            if (!g_qtmp[i].d[s]) continue;
+            if (g_nshards > 1) rfx_hip_ctx_bind_thread(g_ctxs[s]);
+            rfx_hip_free(g_ctxs[s], g_qtmp[i].d[s]);
+        }
+    if (g_nqtmp && g_nshards > 1) rfx_hip_ctx_bind_thread(g_ctx);
     g_nqtmp = 0;
 }
 static int build_xnodes(obj_p tab, obj_p e, rfx_xnode_t *nodes, int *nn, int *ncols, const char **why);
@@ -985,12 +991,38 @@ static int expr_operand(obj_p tab, obj_p e, const void **d, int *ctype) {
     a.col_type = RFX_I64;
     a.nxnodes = nn;
     a.xnodes = nodes;
-    void *out = NULL;
     int32_t ot = RFX_I64;
-    if (rfx_hip_malloc(g_ctx, &out, (size_t)(nrows ? nrows : 1) * 8) != RFX_OK) return -2;
-    g_qtmp[g_nqtmp++] = out;
-    if (rfx_hip_eval_expr(g_ctx, &a, nrows, out, &ot) != RFX_OK) return -2;
-    *d = out;
+    /* every shard evaluates ITS rows of the operand columns on its own context (a shard holds its row range only: one evaluation over
+     * the whole length would read past shard 0's piece); the scratch column then is a column of the query like any other (qcol_add) */
+    memset(&g_qtmp[g_nqtmp], 0, sizeof(g_qtmp[0]));
+    void **devs = g_qtmp[g_nqtmp++].d;
+    int rc = RFX_OK;
+    for (int s = 0; s < g_nshards && rc == RFX_OK; s++) {
+        rfx_xnode_t mine[RFX_MAX_XNODES];
+        int64_t n = nrows;
+        if (g_nshards > 1) {
+            rfx_exec_split(nrows, g_nshards, s, NULL, &n);
+            for (int j = 0; j < nn; j++) {
+                mine[j] = nodes[j];
+                rfx_xoperand_t *o[2] = {&mine[j].l, &mine[j].r};
+                for (int k = 0; k < 2; k++) {
+                    if (o[k]->kind != RFX_XK_COL) continue;
+                    const void *there = NULL;
+                    for (int i = 0; i < g_nqcols && !there; i++)
+                        if (g_qcols[i].d[0] == o[k]->d_col) there = g_qcols[i].d[s];
+                    if (!there) rc = RFX_EINVAL; /* (cannot happen: build_xnodes made every column resident, shard by shard) */
+                    o[k]->d_col = there;
+                }
+            }
+            a.xnodes = mine;
+            rfx_hip_ctx_bind_thread(g_ctxs[s]);
+        }
+        if (rc == RFX_OK) rc = rfx_hip_malloc(g_ctxs[s], &devs[s], (size_t)(n ? n : 1) * 8);
+        if (rc == RFX_OK) rc = rfx_hip_eval_expr(g_ctxs[s], &a, n, devs[s], &ot);
+    }
+    if (g_nshards > 1) rfx_hip_ctx_bind_thread(g_ctx);
+    if (rc != RFX_OK || qcol_add(devs) != RFX_OK) return -2;
+    *d = devs[0];
     *ctype = ot;
     return 0;
 }

@@ -116,6 +116,9 @@ queries = [
     {"x": ("avg", "d"), "y": ("min", "d"), "z": ("max", "d"), "where": ("and", ("<", "v", 0.316228), (">", "b", 0.683772), ("!=", "c", 0.25))},
     {"s": ("sum", ("*", "v", "b")), "where": ("and", ("or", ("<", "a", 5000), ("and", (">", "v", 0.5), ("<", "b", 0.5))), (">", "c", 0.1))},
     {"where": ("<", "a", 3000)},
+    # comparison operands that are element-wise expressions: every shard evaluates ITS rows into a scratch column of its own
+    {"s": ("sum", "v"), "c": ("count", "a"), "where": ("or", ("==", ("div", "a", 1000), 7), ("and", (">", ("*", "v", 2.0), 1.5), ("!=", "k", 3)))},
+    {"s": ("sum", "b"), "by": "k", "where": ("and", ("<", ("+", "v", "b"), 0.7), (">", ("-", "a", "k"), 1000))},
 ]
 def ask(q, t):
     d = H.select_dict(q, t)
