@@ -143,6 +143,11 @@ static obj_p fail_ctx(void) {
     if (g_refused_sharded) return fail("this operator needs its columns whole on one device: with RFX_SHARDS / RFX_DEVICES the operator layer answers rfx_select (and pin / unpin / invalidate / stats) only");
     return fail_hip("no usable MI355X");
 }
+/* ... unless there is a host beside us: then the operator is simply the host's own again (the shards hold row ranges; RFX_SHARDS /
+ * RFX_DEVICES is about rfx_select).  Defined below, once HOST_CALL is. */
+static obj_p refused1(int f, obj_p x);
+static obj_p refused2(int f, obj_p x, obj_p y);
+static obj_p refusedn(int f, obj_p *x, int64_t n);
 
 /* which built-in does this function object denote? -1 if none */
 static int fn_id(obj_p o) {
@@ -1349,6 +1354,18 @@ static obj_p one_row(const rfx_value_t *v) {
     return c;
 }
 
+static obj_p refused1(int f, obj_p x) {
+    if (g_refused_sharded && H.bound == 1 && f >= 0 && f < F_N && H.f[f]) return HOST_CALL(((rfx_unary_f)H.f[f])(x));
+    return fail_ctx();
+}
+static obj_p refused2(int f, obj_p x, obj_p y) {
+    if (g_refused_sharded && H.bound == 1 && f >= 0 && f < F_N && H.f[f]) return HOST_CALL(((rfx_binary_f)H.f[f])(x, y));
+    return fail_ctx();
+}
+static obj_p refusedn(int f, obj_p *x, int64_t n) {
+    if (g_refused_sharded && H.bound == 1 && f >= 0 && f < F_N && H.f[f]) return HOST_CALL(((rfx_vary_f)H.f[f])(x, n));
+    return fail_ctx();
+}
 static obj_p delegate_select(obj_p dict, const char *why) {
     g_last_gpu = 0;
     snprintf(g_err, sizeof(g_err), "rfx_select: handed to the host (%s)", why); /* rfx_ops_last_error(): why the last query was delegated */
@@ -2100,7 +2117,7 @@ static obj_p update_impl(obj_p dict) {
     if (st == UPD_GO && u.nrows == 0) st = upd_back(&u, "empty table");
     for (int64_t i = 0; i < tcols->len && st == UPD_GO; i++)
         if (RFX_AS_LIST(tcols)[i]->len != u.nrows) st = upd_back(&u, "ragged table");
-    if (st == UPD_GO && ensure_ctx1() != RFX_OK) st = upd_stop(&u, fail_ctx());
+    if (st == UPD_GO && ensure_ctx1() != RFX_OK) st = g_refused_sharded ? upd_back(&u, "sharded operator layer: update is the host's") : upd_stop(&u, fail_ctx());
     if (st == UPD_GO && where) st = upd_where(&u, where, by);
     if (st == UPD_GO && by) st = upd_by(&u, by);
     for (int i = 0; i < nmap && st == UPD_GO; i++) {
@@ -2143,7 +2160,7 @@ static obj_p cmp_impl(int op, obj_p x, obj_p y) {
         return fail("cmp: only i64/f64 column (x) atom|column runs on the MI355X path");
     }
     if (y->type > 0 && y->len != x->len) return fail("length"); /* err_length, core/cmp.c:633-640 */
-    if (ensure_ctx1() != RFX_OK) return fail_ctx();
+    if (ensure_ctx1() != RFX_OK) return refused2(F_EQ + op, x, y);
     rfx_pred_t p;
     memset(&p, 0, sizeof(p));
     const void *d;
@@ -2183,7 +2200,7 @@ static obj_p arith_impl(int xop, int fidx, obj_p x, obj_p y) {
         return fail("arith: only i64/f64 vector (x) vector|atom runs on the MI355X path");
     }
     if (xv && yv && x->len != y->len) return fail("length");
-    if (ensure_ctx1() != RFX_OK) return fail_ctx();
+    if (ensure_ctx1() != RFX_OK) return refused2(fidx, x, y);
     rfx_agg_t a;
     memset(&a, 0, sizeof(a));
     a.kind = RFX_AGG_SUM;
@@ -2239,7 +2256,7 @@ static obj_p logic_op(int logic, obj_p *x, int64_t n) {
     if (n == 0) return rfx_host_b8(0); /* logic_map: (and) -> false, core/logic.c:96-97 */
     for (int64_t i = 0; i < n; i++)
         if (!x[i] || x[i]->type != RFX_TYPE_B8 || x[i]->len != x[0]->len) return fail("and/or: expected B8 masks of one length");
-    if (ensure_ctx1() != RFX_OK) return fail_ctx();
+    if (ensure_ctx1() != RFX_OK) return refusedn(logic == RFX_AND ? F_AND : F_OR, x, n);
     int64_t len = x[0]->len;
     void *acc = NULL, *nxt = NULL;
     if (rfx_hip_malloc(g_ctx, &acc, (size_t)len + 8) != RFX_OK || rfx_hip_malloc(g_ctx, &nxt, (size_t)len + 8) != RFX_OK) return fail_hip("mask");
@@ -2335,7 +2352,11 @@ static obj_p sf_logic_impl(int f, obj_p *x, int64_t n) {
         RFX_AS_LIST(tree)[1 + i] = r ? r : (H.null_obj ? H.null_obj : rfx_host_null());
     }
     if (ok && c.n == 0) { ok = 0; why = "no vector operand"; }
-    if (ok && ensure_ctx1() != RFX_OK) { res = fail_ctx(); ok = 0; }
+    if (ok && ensure_ctx1() != RFX_OK) {
+        if (g_refused_sharded) why = "sharded operator layer: the comparison tree is the host's"; /* (handed back below, like any shape that is not ours) */
+        else res = fail_ctx();
+        ok = 0;
+    }
     if (ok) {
         obj_p names = H.vector(RFX_TYPE_SYMBOL, c.n), cols = H.vector(RFX_TYPE_LIST, c.n);
         for (int k = 0; k < c.n; k++) {
@@ -2437,7 +2458,7 @@ static obj_p join_impl(int inner, obj_p *x, int64_t n) {
         if (!col_ctype(rc)) { why = "non-8-byte column"; goto out; }
         if (lc && lc->type != rc->type) return fail("join: a column has different types in the two tables"); /* err_type, core/join.c:50-51 */
     }
-    if (ensure_ctx1() != RFX_OK) return fail_ctx();
+    if (ensure_ctx1() != RFX_OK) return refusedn(fidx, x, n);
     for (int i = 0; i < nk; i++)
         if (resident(lk[i], 0, &dlk[i]) != RFX_OK || resident(rk[i], 0, &drk[i]) != RFX_OK) { res = fail_hip("column upload"); goto done; }
 #define JOIN_TMP(ptr, bytes) do { ptr = NULL; if (rfx_hip_malloc(g_ctx, &ptr, (bytes)) != RFX_OK) { res = fail_hip("join scratch"); goto done; } tmp[ntmp++] = ptr; } while (0)
@@ -2582,7 +2603,7 @@ static obj_p fold_mapgroup(int f, int kind, obj_p x) {
     if (!filtered && val->len != n) return fail("length");
     const int out_f64 = kind == RFX_AGG_AVG || (kind != RFX_AGG_COUNT && col_ctype(val) == RFX_F64);
     if (groups == 0 || n == 0) return H.vector(out_f64 ? RFX_TYPE_F64 : RFX_TYPE_I64, 0);
-    if (ensure_ctx1() != RFX_OK) return fail_ctx();
+    if (ensure_ctx1() != RFX_OK) return refused1(f, x);
     {
         const void *dv = NULL, *dk = NULL, *dfl = NULL;
         if (resident(val, 0, &dv) != RFX_OK) { res = fail_hip("column upload"); goto done; }
@@ -2744,7 +2765,7 @@ static obj_p fold_impl(int f, int kind, obj_p x) {
             if (H.bound == 1 && H.f[f]) return HOST_CALL(((rfx_unary_f)H.f[f])(x));
             return fail("aggregate: only (i64/f64 vector, i64 ids) MAPFILTER pairs run on the MI355X path");
         }
-        if (ensure_ctx1() != RFX_OK) return fail_ctx();
+        if (ensure_ctx1() != RFX_OK) return refused1(f, x);
         const void *dv, *di;
         if (resident(val, 0, &dv) != RFX_OK || transient(ids, &di) != RFX_OK) return fail_hip("column upload");
         void *dg = NULL;
@@ -2765,7 +2786,7 @@ static obj_p fold_impl(int f, int kind, obj_p x) {
         if (H.bound == 1 && H.f[f]) return HOST_CALL(((rfx_unary_f)H.f[f])(x));
         return fail("aggregate: only i64/f64 vectors run on the MI355X path");
     }
-    if (ensure_ctx1() != RFX_OK) return fail_ctx();
+    if (ensure_ctx1() != RFX_OK) return refused1(f, x);
     const void *d;
     if (resident(x, 0, &d) != RFX_OK) return fail_hip("column upload");
     rfx_agg_t a;
@@ -2805,6 +2826,7 @@ static obj_p pin_impl(obj_p x, int pin) {
     obj_p cols = (x->type == RFX_TYPE_TABLE) ? RFX_AS_LIST(x)[1] : NULL;
     int64_t n = cols ? cols->len : 1;
     if (cols && is_parted_table(x)) { /* a get-parted table: its columns are known to the cache by their LIST objects (parted_view) */
+        if (g_nshards > 1) return H.clone(x); /* (selects over parted tables are the host's under RFX_SHARDS / RFX_DEVICES: nothing to keep resident) */
         obj_p view = pin ? parted_view(x) : NULL;
         int bad = pin && !view;
         for (int64_t i = 0; i < n && !bad; i++) {

@@ -74,8 +74,14 @@ UPDATES = [
 UNORDERED = {"q13": 1, "q16": 3, "q22": 1, "q23": 1, "q24": 6}  # name -> leading key columns: group order there depends on the reference's executor count
 
 
+@pytest.mark.parametrize("shards", [1, 2])
 @pytest.mark.skipif(not ref.available(), reason="oracle/_ref/rayforce not built (needs /root/reference at build time)")
-def test_plugin_inside_the_real_reference(built):
+def test_plugin_inside_the_real_reference(built, shards, monkeypatch):
+    # shards = 2: the same script with RFX_SHARDS=2 in the reference process' environment -- rfx_select splits every table in two row ranges
+    # on the one device, and every OTHER operator of the plugin (joins, update, the comparison special forms) is the host's own again
+    # (they need their columns whole): the answers must not change, who gives them does
+    if shards > 1:
+        monkeypatch.setenv("RFX_SHARDS", str(shards))
     import torch
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
@@ -174,6 +180,10 @@ def test_plugin_inside_the_real_reference(built):
     # reference's one-group-per-null-row rule is not reproduced -- but the reference itself panics in its heap on every single-key
     # group-by over a key column with nulls (2 003 .. 300 007 rows, -c 1 and -c 8), so that hand-back is asserted in standalone mode.)
     st = res["stats"]
+    if shards > 1:  # key tuples on the row-hash path and a where: tree beyond the fused form run on one shard: the host's here; so are the joins
+        assert int(st[0]) >= len(QUERIES) - 2 and 1 <= int(st[1]) <= 4, st
+        assert int(st[2]) == 0 and int(st[3]) == 4, st
+        return
     assert int(st[0]) == len(QUERIES) + 2 and int(st[1]) == 1, st
     assert int(st[2]) == 4 and int(st[3]) == 0, st
     assert int(st[10]) == 0, st  # q19 / g_nest: two-level where: trees in ONE fused pass -- no comparison mask was materialised
@@ -279,8 +289,11 @@ def test_date_time_i32_columns_in_predicates_inside_the_real_reference(built):
     assert int(res["g_n1_c"][0]) > 0 and int(res["g_n6_c"][0]) > 0
 
 
+@pytest.mark.parametrize("shards", [1, 2])
 @pytest.mark.skipif(not ref.available(), reason="oracle/_ref/rayforce not built (needs /root/reference at build time)")
-def test_parted_and_enum_columns_inside_the_real_reference(built, tmp_path):
+def test_parted_and_enum_columns_inside_the_real_reference(built, tmp_path, shards, monkeypatch):
+    if shards > 1:  # parted tables are the host's under RFX_SHARDS (pinning one is a no-op): same answers, fewer of them from the device
+        monkeypatch.setenv("RFX_SHARDS", str(shards))
     """SURVEY 8f-2 at the operator boundary: a `get-parted` table (TYPE_PARTED* columns + the virtual MAPCOMMON Date, core/vary.c:185-392)
     and ENUM key columns (core/util.h:103-105) handed to rfx_select by the real reference, in ONE process beside ray_select: the
     families of the reference's own tests/parted.c (global aggregates, by: Date, Date filters = partition pruning, data-column
@@ -337,6 +350,9 @@ def test_parted_and_enum_columns_inside_the_real_reference(built, tmp_path):
     st = res["stats"]
     on_gpu = sum(1 for *_, gpu in PARTED + ENUMS if gpu)
     print(ref.LAST_STDERR)  # RFX_TRACE=1: why a query was handed back
+    if shards > 1:
+        assert int(st[0]) + int(st[1]) == len(PARTED + ENUMS) and 0 < int(st[0]) < on_gpu, st
+        return
     assert int(st[0]) == on_gpu and int(st[1]) == len(PARTED + ENUMS) - on_gpu, st
     assert len(res["g_p2_Date"]) == 4 and len(res["g_p4_Date"]) == 2
     assert int(st[4]) <= 4 + 3 + 2 + 3  # uploads (t2: three more): the parted table's four 8-byte columns once (pinned; the B8 column is not uploaded), the splayed / in-memory tables' columns
