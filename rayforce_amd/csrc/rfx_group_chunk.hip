@@ -1272,19 +1272,24 @@ int rfx_chunk_scope(rfx_ctx *c, const int64_t *d_key, const rfx_pred_t *preds, i
         }
         if (sig == 0) sig = 1;
     }
-    struct SampleMemo { u64 sig; i64 smn, smx, ssel; unsigned hot, age; }; // 4 x 40 bytes <= the 256 rfx_ctx.hip clears
+    struct SampleMemo { u64 sig; i64 smn, smx, ssel; unsigned hot, age, uses, pad; }; // 4 x 48 bytes <= the 256 rfx_ctx.hip clears
     static_assert(4 * sizeof(SampleMemo) <= 256, "memo block");
     if (!c->ext_p[5]) c->ext_p[5] = calloc(1, 256);
     SampleMemo *memo = (SampleMemo *)c->ext_p[5];
     i64 smn = RFX_INF_I64_D, smx = RFX_NULL_I64_D, ssel = 0;
     unsigned hot = 0;
     bool remembered = false;
+    int hit = -1;
     static unsigned memo_clock = 0; // (shared by the contexts of a process: it only orders the entries of each)
     for (int i = 0; memo && i < 4 && !getenv("RFX_NO_SAMPLE_MEMO"); i++)
         if (memo[i].sig == sig) {
+            // (a remembered sample serves 32 queries, then the data is sampled again: what a stale one costs -- a slower route, e.g. the hashed
+            //  tables for keys it calls sparse -- is bounded, and the 30 us come back once in 33 queries)
+            if (++memo[i].uses > 32u) { memo[i].sig = 0; break; }
             smn = memo[i].smn, smx = memo[i].smx, ssel = memo[i].ssel, hot = memo[i].hot;
             memo[i].age = __atomic_add_fetch(&memo_clock, 1u, __ATOMIC_RELAXED);
             remembered = true;
+            hit = i;
         }
     if (!remembered) {
     rc = rfx_ws_reserve(c, (size_t)sgrid * 32 + CK_PARTS * 4);
@@ -1314,7 +1319,7 @@ int rfx_chunk_scope(rfx_ctx *c, const int64_t *d_key, const rfx_pred_t *preds, i
         int at = 0;
         for (int i = 1; i < 4; i++)
             if (memo[i].age < memo[at].age) at = i;
-        memo[at] = SampleMemo{sig, smn, smx, ssel, hot, __atomic_add_fetch(&memo_clock, 1u, __ATOMIC_RELAXED)};
+        memo[at] = SampleMemo{sig, smn, smx, ssel, hot, __atomic_add_fetch(&memo_clock, 1u, __ATOMIC_RELAXED), 0u, 0u};
     }
     }
     if (smn == RFX_NULL_I64_D || smx < smn || ssel == 0) return RFX_ESTATE;
@@ -1336,6 +1341,7 @@ int rfx_chunk_scope(rfx_ctx *c, const int64_t *d_key, const rfx_pred_t *preds, i
         // spread keys: two planes of 8 + 4 bytes per record through decoupled LDS rings (40 instead of 48 bytes moved per row on C3)
         const int prc = rfx_plane_scope(c, P, key_idx, d_key, npred, logic, est, frac, kmin, kmax, seen);
         if (prc != RFX_ESTATE) return prc;
+        if (remembered && hit >= 0) memo[hit].sig = 0; // the planes gave up on what a REMEMBERED sample promised (a region overflowed, ...): sample afresh next time
     }
     if (vc < 0 || P.ncols > 4) return RFX_ESTATE;                                                      // the chunk records carry one value
     if ((size_t)((est + 255) >> 8) * narr * 8 > (size_t)PART_LDS_BIG_BYTES) return RFX_ESTATE;         // needs more than 256 partitions

@@ -89,13 +89,14 @@ extern "C" int rfx_hip_where_estimate(rfx_ctx_t *c, const rfx_pred_t *preds, int
         }
         if (sig == 0) sig = 1;
     }
-    struct EstMemo { u64 sig; i64 upper; unsigned age, pad; }; // 4 x 24 bytes <= the 256 rfx_ctx.hip clears
+    struct EstMemo { u64 sig; i64 upper; unsigned age, uses; }; // 4 x 24 bytes <= the 256 rfx_ctx.hip clears
     static_assert(4 * sizeof(EstMemo) <= 256, "memo block");
     if (!c->ext_p[6]) c->ext_p[6] = calloc(1, 256);
     EstMemo *memo = (EstMemo *)c->ext_p[6];
     static unsigned memo_clock = 0; // (only orders the entries of each context)
     for (int i = 0; memo && i < 4 && !getenv("RFX_NO_SAMPLE_MEMO"); i++)
         if (memo[i].sig == sig) {
+            if (++memo[i].uses > 32u) { memo[i].sig = 0; break; } // (serves 32 queries, then the column is sampled again: staleness is bounded)
             memo[i].age = __atomic_add_fetch(&memo_clock, 1u, __ATOMIC_RELAXED);
             *upper = memo[i].upper;
             return RFX_OK;

@@ -608,6 +608,34 @@ def test_plane_partitioned_group_by_takes_the_plane_kernels(eng):
         eng.tune(flags=0)
 
 
+def test_remembered_sample_does_not_outlive_its_use(eng):
+    """rfx_chunk_scope remembers the sample of a repeated query (key range, selectivity).  A column rewritten IN PLACE behind the context's
+    back (a torch tensor; the operator layer's uploads drop the memory themselves) makes it wrong: the filter now keeps every row instead
+    of 1 %, and a sample that still says "1 %" routes the query elsewhere (few rows over a wide range: the hashed tables) -- slower, never
+    wrong.  A remembered sample serves 32 queries: every answer in between equals the oracle's, and within 34 queries the planes answer
+    again (RFX_STAT_PLANE_SCATTER moves)."""
+    n = 700_001
+    host = table(n, keys=50_000)
+    q = {"where": ("<", "a", 10_000), "by": "k", "s": ("sum", "v"), "c": ("count", "a")}
+    try:
+        eng.tune(flags=CHUNK_SMALL)
+        d = dev(eng, host)
+        check_select(eng, host, q, d)
+        check_select(eng, host, q, d)  # (the remembered sample)
+        d["a"] //= 100  # in place: a < 10 000 now keeps every row
+        host2 = dict(host, a=host["a"] // 100)
+        s0 = eng.stat(0)
+        back = 0
+        for i in range(34):
+            check_select(eng, host2, q, d)
+            if eng.stat(0) > s0:
+                back = i + 1
+                break
+        assert 0 < back <= 34, back
+    finally:
+        eng.tune(flags=0)
+
+
 @pytest.mark.parametrize("run", [64, 4096])
 def test_plane_rings_under_pressure_and_region_overflow(eng, run):
     """Keys whose low byte comes in runs: the strided sample sees the 256 partitions evenly filled, a wave step does not.  run = 64: eight
