@@ -100,3 +100,77 @@ def test_c4_c5_shards_over_rccl(built, world):
         p.join(timeout=120)
     for rank, msg in res:
         assert msg == "ok", f"rank {rank}: {msg}"
+
+
+# ---------------------------------------------------------------- ONE evaluator process over the node's devices (RFX_DEVICES)
+_ONE_PROCESS = r'''
+import os, sys
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+from oracle import rfo
+from rayforce_amd import hostobj as H, _lib as L
+from test_gpu_parity import same_f64
+import ctypes as C
+ops = H.lib()
+ops.rfx_host_bind()
+n = 4_000_037
+host = {"k": rfo.gen_i64(n, 4, 100_000), "a": rfo.gen_i64(n, 2, 1_000_000), "v": rfo.gen_f64(n, 5), "b": rfo.gen_f64(n, 3), "c": rfo.gen_f64(n, 8), "d": rfo.gen_f64(n, 9)}
+host["ks"] = host["k"] * 1_000_003 + 17  # sparse keys: the hashed tables, merged by an all-gather
+tab = H.table(host)
+queries = [
+    {"s": ("sum", "a"), "c": ("count", "a"), "where": ("<", "a", 100_000)},                                     # C4's shape
+    {"x": ("avg", "d"), "y": ("min", "d"), "z": ("max", "d"), "where": ("and", ("<", "v", 0.316228), (">", "b", 0.683772), ("!=", "c", 0.25))},  # C5's
+    {"s": ("sum", "v"), "by": "k", "where": ("<", "a", 100_000)},                                               # the metric's
+    {"s": ("sum", "v"), "f": ("first", "a"), "m": ("max", "a"), "by": "k"},
+    {"s": ("sum", "v"), "c": ("count", "a"), "by": "ks"},
+    {"s": ("sum", "b"), "by": "k", "where": ("and", ("<", ("+", "v", "b"), 0.7), (">", ("-", "a", "k"), 1000))},
+    {"where": ("<", "a", 3000)},
+]
+def ask(q):
+    d = H.select_dict(q, tab)
+    r = ops.rfx_select(d)
+    assert r and not H.is_error(r), H.error_text(r)
+    assert ops.rfx_last_select_on_gpu() == 1, (q, ops.rfx_ops_last_error())
+    out = H.table_to_numpy(r)
+    ops.rfx_host_drop(r); ops.rfx_host_drop(d)
+    return out
+for rep in range(2):
+    for q in queries:
+        got, want = ask(q), rfo.select({"from": host, **q})
+        assert list(got) == list(want)
+        for name in want:
+            g, w = got[name], want[name]
+            assert g.dtype == w.dtype and g.shape == w.shape, name
+            if w.dtype == np.float64 and name in q and q[name][0] in ("sum", "avg"):
+                same_f64(g, w)
+            else:
+                assert np.array_equal(g, w, equal_nan=w.dtype == np.float64), (name, q)
+x = C.c_void_p(ops.rfx_ops_exec())
+if WORLD > 1:
+    assert ops.rfx_ops_shards() == WORLD and ops.rfx_exec_shards(x) == WORLD
+    devs = {ops.rfx_hip_ctx_device(C.c_void_p(ops.rfx_exec_ctx(x, s))) for s in range(WORLD)}
+    assert len(devs) == WORLD, devs                                   # one shard per device
+    assert ops.rfx_exec_stat(x, L.RFX_XSTAT_MERGES_RCCL) > 0          # the fused exchange over xGMI merged the tables
+    assert ops.rfx_exec_stat(x, L.RFX_XSTAT_MERGES_KERNEL) == 0       # (no two shards share a device)
+else:  # the same script on the one device of the builder's boxes: two shards on it, merged by the kernel
+    assert ops.rfx_ops_shards() == 2 and ops.rfx_exec_stat(x, L.RFX_XSTAT_MERGES_KERNEL) > 0
+print("ONE-PROCESS-OK")
+'''
+
+
+@pytest.mark.parametrize("world", [1, 2, 4, 8])  # (1: the script itself on one device, as two shards of it)
+def test_one_evaluator_process_over_the_devices(built, world):
+    """RFX_DEVICES=0,..,world-1: ONE process, one shard per device -- what a RayforceDB evaluator that owns the node does.  rfx_select splits the
+    host table row-range over the devices at first touch, every device's pass runs on its own host thread, the group tables merge in one fused
+    RCCL exchange (ncclCommInitAll): answers against the UNSHARDED oracle, the planner's counters say who merged."""
+    import os, subprocess, sys
+    if not torch.cuda.is_available() or torch.cuda.device_count() < world:
+        pytest.skip(f"needs {world} devices (this box has {torch.cuda.device_count() if torch.cuda.is_available() else 0})")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RFX_DEVICES=",".join(str(i) for i in range(world)), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("RFX_SHARDS", None)
+    if world == 1:
+        env["RFX_SHARDS"] = "2"
+    code = f"ROOT = {root!r}\nWORLD = {world}\n" + _ONE_PROCESS
+    p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0 and "ONE-PROCESS-OK" in p.stdout, p.stdout[-3000:] + p.stderr[-3000:]
