@@ -57,6 +57,7 @@ static const char *HOST_FN[F_N] = {"ray_sum", "ray_avg", "ray_min", "ray_max", "
  * this stub is never called by this library. */
 static obj_p x_stub_xbar(obj_p a, obj_p b) { (void)a; (void)b; return NULL; }
 static void *OUR_FN[F_N];
+static void *g_host_where, *g_host_at, *g_host_group; /* the host's built-ins behind rfx_where / rfx_at / rfx_group (NULL without a host) */
 static char g_err[640];
 static int g_last_gpu = 0;
 
@@ -87,6 +88,9 @@ int rfx_host_bind(void) {
         H.symname = (const char *(*)(int64_t))dlsym(RTLD_DEFAULT, "str_from_symbol");
         H.null_obj = (obj_p)nu;
         for (int i = 0; i < F_N; i++) H.f[i] = dlsym(RTLD_DEFAULT, HOST_FN[i]);
+        g_host_where = dlsym(RTLD_DEFAULT, "ray_where"); /* (not in H.f: never recognised inside a query, only handed back to -- refused1x) */
+        g_host_at = dlsym(RTLD_DEFAULT, "ray_at");
+        g_host_group = dlsym(RTLD_DEFAULT, "ray_group");
         if (H.i64 && H.f64 && H.drop && H.clone && H.err && H.intern && H.symname) {
             H.bound = 1;
             return 1;
@@ -2402,7 +2406,7 @@ rfx_obj_p rfx_or_sf(rfx_obj_p *x, int64_t n) { return sf_logic(F_OR, x, n); }
 static obj_p where_impl(obj_p mask) {
     rfx_host_bind();
     if (!mask || mask->type != RFX_TYPE_B8) return fail("where: expected a B8 mask"); /* err_type, core/items.c:1395 */
-    if (ensure_ctx1() != RFX_OK) return fail_ctx();
+    if (ensure_ctx1() != RFX_OK) return (g_refused_sharded && H.bound == 1 && g_host_where) ? HOST_CALL(((rfx_unary_f)g_host_where)(mask)) : fail_ctx();
     const void *dm;
     if (transient(mask, &dm) != RFX_OK) return fail_hip("mask upload"); /* a mask is a temporary: per-call scratch, never cached */
     int64_t count = 0;
@@ -2554,7 +2558,7 @@ rfx_obj_p rfx_inner_join(rfx_obj_p *x, int64_t n) { return join_op(1, x, n); }
 static obj_p at_impl(obj_p col, obj_p ids) {
     rfx_host_bind();
     if (!col || !ids || !col_ctype(col) || ids->type != RFX_TYPE_I64) return fail("at: expected (i64|f64 column, I64 ids)");
-    if (ensure_ctx1() != RFX_OK) return fail_ctx();
+    if (ensure_ctx1() != RFX_OK) return (g_refused_sharded && H.bound == 1 && g_host_at) ? HOST_CALL(((rfx_binary_f)g_host_at)(col, ids)) : fail_ctx();
     const void *dc, *di;
     if (resident(col, 0, &dc) != RFX_OK || transient(ids, &di) != RFX_OK) return fail_hip("upload");
     obj_p out = H.vector(col->type, ids->len);
@@ -2688,7 +2692,7 @@ static obj_p group_impl(obj_p keys) {
     rfx_host_bind();
     if (!keys || keys->type <= 0 || col_ctype(keys) != RFX_I64) return fail("group: expected an i64-like vector");
     const int64_t n = keys->len;
-    if (ensure_ctx1() != RFX_OK) return fail_ctx();
+    if (ensure_ctx1() != RFX_OK) return (g_refused_sharded && H.bound == 1 && g_host_group) ? HOST_CALL(((rfx_unary_f)g_host_group)(keys)) : fail_ctx();
     const void *dk = NULL;
     if (n && resident(keys, 0, &dk) != RFX_OK) return fail_hip("column upload");
     int64_t kmin = 0, kmax = -1, seen = 0;
