@@ -9,7 +9,7 @@ from oracle import rfo
 from rayforce_amd.engine import Engine
 from test_gpu_parity import check_select, dev
 lo, hi = int(sys.argv[1]), int(sys.argv[2])
-eng = Engine(0)
+eng = Engine(0, shards=int(os.environ.get("FUZZ_SHARDS", "1")))
 fails = 0
 for seed in range(lo, hi):
     rng = np.random.default_rng(seed)
