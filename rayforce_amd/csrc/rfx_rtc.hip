@@ -284,7 +284,8 @@ static void filter_aggr_text(const Plan &P, std::string &sig, std::string &src) 
     bool deep = false;
     for (int i = 0; i < P.nx; i++) deep |= P.xs[i].nops > 1;
     const int nc = P.ncols < 1 ? 1 : P.ncols;
-    const int u = nc <= 4 ? 4 : (nc <= 6 ? 2 : 1);
+    int u = nc <= 4 ? 4 : (nc <= 6 ? 2 : 1);
+    if (getenv("RFX_FA_U")) u = atoi(getenv("RFX_FA_U")) >= 4 ? 4 : (atoi(getenv("RFX_FA_U")) >= 2 ? 2 : 1); // development: row pairs per lane and tile
     char head[256];
     snprintf(head, sizeof(head), "#define FA_NC %d\n#define FA_NA %d\n#define FA_U %d\n#define FA_NP %d\n#define FA_NX %d\n#define FA_DEEP %s\n", nc, P.nagg, u, P.npred, P.nx,
              deep ? "true" : "false");
