@@ -1,4 +1,5 @@
 // rfx_ctx.hip -- context, device memory, timers, synthetic-column generator, plan builder.
+#include <pthread.h>
 #include "rfx_common.hpp"
 #include <stdarg.h>
 #include <stdlib.h>
@@ -321,7 +322,7 @@ extern "C" int rfx_hip_eval_expr(rfx_ctx_t *c, const rfx_agg_t *expr, int64_t nr
 // Small device blocks (<= 4 MB: group tables, result blocks, masks of small queries) are recycled inside the context: hipMalloc +
 // hipFree cost tens of microseconds and hipFree waits for the device -- more than the whole rest of a 1e6-row query.  Blocks are
 // power-of-two sized; everything that touches them runs on the context's one stream, so a recycled block is never read by work
-// still in flight.  Not thread-safe, like the context itself.
+// still in flight.  One process-wide lock guards the pools (contexts that share a device trim each other's idle blocks when memory runs out).
 #define POOL_MAX_LOG 28 /* blocks up to 256 MB are recycled (group tables and result blocks of a 1e6-group query are 16 MB each: a hipMalloc / hipFree pair
                          * per query cost more than the query's kernels at 1e8 rows) */
 #define POOL_MIN_LOG 8
@@ -347,90 +348,142 @@ struct SmallPool {
     int nbig_free;
     size_t big_free_total;
 };
-static void pool_release(rfx_ctx *c) {
+// Several contexts may share a device (RFX_SHARDS=k, the Python host's Engine(shards=k)), each driven by its own host thread: ONE lock
+// around every pool operation of the process, a registry of the live contexts, and the kept-for-reuse budget counted PER DEVICE -- so
+// that a context out of memory can give back what its siblings keep idle instead of failing beside tens of idle gigabytes.
+#define POOL_MAX_DEV 64
+#define POOL_MAX_CTX 256
+static pthread_mutex_t g_pool_mu = PTHREAD_MUTEX_INITIALIZER;
+static rfx_ctx *g_pool_ctx[POOL_MAX_CTX];
+static int g_pool_nctx;
+static size_t g_dev_kept[POOL_MAX_DEV]; // bytes of big blocks kept for reuse on a device, all contexts
+static void pool_register(rfx_ctx *c) {
+    for (int i = 0; i < g_pool_nctx; i++)
+        if (g_pool_ctx[i] == c) return;
+    if (g_pool_nctx < POOL_MAX_CTX) g_pool_ctx[g_pool_nctx++] = c;
+}
+// every block `c` keeps for reuse goes back to the device (the lock is held)
+static void pool_drop_kept(rfx_ctx *c, int small_too) {
     SmallPool *sp = (SmallPool *)c->ext_p[0];
     if (!sp) return;
-    for (int k = 0; k <= POOL_MAX_LOG; k++)
-        for (int i = 0; i < sp->nfree[k]; i++) (void)hipFree(sp->freep[k][i]);
+    if (small_too)
+        for (int k = 0; k <= POOL_MAX_LOG; k++) {
+            for (int i = 0; i < sp->nfree[k]; i++) (void)hipFree(sp->freep[k][i]);
+            sp->nfree[k] = 0;
+        }
     for (int i = 0; i < sp->nbig_free; i++) (void)hipFree(sp->big_free_p[i]);
-    free(sp);
-    c->ext_p[0] = NULL;
+    if (c->device >= 0 && c->device < POOL_MAX_DEV) g_dev_kept[c->device] -= sp->big_free_total < g_dev_kept[c->device] ? sp->big_free_total : g_dev_kept[c->device];
+    sp->nbig_free = 0;
+    sp->big_free_total = 0;
 }
-extern "C" int rfx_hip_malloc(rfx_ctx_t *c, void **d_ptr, size_t bytes) {
-    RFX_REQUIRE(c && d_ptr, RFX_EINVAL, "NULL argument");
+// out of memory on c's device: what c and every sibling context on that device keep idle goes back (hipFree waits for the device, so
+// nothing in flight on a sibling's stream still reads a block that sat in its free list)
+static void pool_trim_device(rfx_ctx *c) {
+    (void)hipGetLastError();
+    (void)hipDeviceSynchronize();
+    for (int i = 0; i < g_pool_nctx; i++)
+        if (g_pool_ctx[i]->device == c->device) pool_drop_kept(g_pool_ctx[i], 1);
+}
+static void pool_release(rfx_ctx *c) {
+    pthread_mutex_lock(&g_pool_mu);
+    for (int i = 0; i < g_pool_nctx; i++)
+        if (g_pool_ctx[i] == c) { g_pool_ctx[i] = g_pool_ctx[--g_pool_nctx]; break; }
+    SmallPool *sp = (SmallPool *)c->ext_p[0];
+    if (sp) {
+        pool_drop_kept(c, 1);
+        free(sp);
+        c->ext_p[0] = NULL;
+    }
+    pthread_mutex_unlock(&g_pool_mu);
+}
+static int pool_malloc_locked(rfx_ctx *c, void **d_ptr, size_t bytes) {
+    SmallPool *sp = (SmallPool *)c->ext_p[0];
+    if (!sp) {
+        c->ext_p[0] = sp = (SmallPool *)calloc(1, sizeof(SmallPool));
+        pool_register(c);
+    }
+    RFX_HIP_CHECK(hipSetDevice(c->device));
     if (bytes <= ((size_t)1 << POOL_MAX_LOG)) {
-        SmallPool *sp = (SmallPool *)c->ext_p[0];
-        if (!sp) c->ext_p[0] = sp = (SmallPool *)calloc(1, sizeof(SmallPool));
         if (sp && sp->nlive < POOL_LIVE) {
             int k = POOL_MIN_LOG;
             while (((size_t)1 << k) < bytes) k++;
             void *p = NULL;
             if (sp->nfree[k] > 0) p = sp->freep[k][--sp->nfree[k]];
             else {
-                RFX_HIP_CHECK(hipSetDevice(c->device));
-                RFX_HIP_CHECK(hipMalloc(&p, (size_t)1 << k));
+                hipError_t e = hipMalloc(&p, (size_t)1 << k);
+                if (e == hipErrorOutOfMemory) {
+                    pool_trim_device(c);
+                    e = hipMalloc(&p, (size_t)1 << k);
+                }
+                RFX_HIP_CHECK(e);
             }
             sp->live_p[sp->nlive] = p;
             sp->live_c[sp->nlive++] = (unsigned char)k;
             *d_ptr = p;
             return RFX_OK;
         }
+        // (the table of live small blocks is full: an untracked block of the size asked for -- not one of the 64 big slots, not 64 MB)
+        hipError_t e = hipMalloc(d_ptr, bytes ? bytes : 8);
+        if (e == hipErrorOutOfMemory) {
+            pool_trim_device(c);
+            e = hipMalloc(d_ptr, bytes ? bytes : 8);
+        }
+        RFX_HIP_CHECK(e);
+        return RFX_OK;
     }
-    SmallPool *bp = (SmallPool *)c->ext_p[0];
-    if (!bp) c->ext_p[0] = bp = (SmallPool *)calloc(1, sizeof(SmallPool));
     const size_t want = (bytes + (((size_t)64 << 20) - 1)) & ~(((size_t)64 << 20) - 1);
-    if (bp && bp->nbig_live < BIG_LIVE) {
+    if (sp && sp->nbig_live < BIG_LIVE) {
         int best = -1;
-        for (int i = 0; i < bp->nbig_free; i++)
-            if (bp->big_free_b[i] >= want && bp->big_free_b[i] <= want + want / 4 && (best < 0 || bp->big_free_b[i] < bp->big_free_b[best])) best = i;
+        for (int i = 0; i < sp->nbig_free; i++)
+            if (sp->big_free_b[i] >= want && sp->big_free_b[i] <= want + want / 4 && (best < 0 || sp->big_free_b[i] < sp->big_free_b[best])) best = i;
         void *p = NULL;
         size_t got = want;
         if (best >= 0) {
-            p = bp->big_free_p[best];
-            got = bp->big_free_b[best];
-            bp->big_free_total -= got;
-            bp->big_free_p[best] = bp->big_free_p[bp->nbig_free - 1];
-            bp->big_free_b[best] = bp->big_free_b[--bp->nbig_free];
+            p = sp->big_free_p[best];
+            got = sp->big_free_b[best];
+            sp->big_free_total -= got;
+            if (c->device >= 0 && c->device < POOL_MAX_DEV) g_dev_kept[c->device] -= got < g_dev_kept[c->device] ? got : g_dev_kept[c->device];
+            sp->big_free_p[best] = sp->big_free_p[sp->nbig_free - 1];
+            sp->big_free_b[best] = sp->big_free_b[--sp->nbig_free];
         } else {
-            RFX_HIP_CHECK(hipSetDevice(c->device));
             hipError_t e = hipMalloc(&p, want);
-            if (e == hipErrorOutOfMemory && bp->nbig_free > 0) { // what is kept for reuse goes back first
-                (void)hipGetLastError();
-                (void)hipStreamSynchronize(c->stream);
-                for (int i = 0; i < bp->nbig_free; i++) (void)hipFree(bp->big_free_p[i]);
-                bp->nbig_free = 0;
-                bp->big_free_total = 0;
+            if (e == hipErrorOutOfMemory) { // what this context AND its siblings on the device keep for reuse goes back first
+                pool_trim_device(c);
                 e = hipMalloc(&p, want);
             }
             RFX_HIP_CHECK(e);
         }
-        bp->big_live_p[bp->nbig_live] = p;
-        bp->big_live_b[bp->nbig_live++] = got;
+        sp->big_live_p[sp->nbig_live] = p;
+        sp->big_live_b[sp->nbig_live++] = got;
         *d_ptr = p;
         return RFX_OK;
     }
-    RFX_HIP_CHECK(hipSetDevice(c->device));
-    RFX_HIP_CHECK(hipMalloc(d_ptr, bytes ? bytes : 8));
+    hipError_t e = hipMalloc(d_ptr, bytes);
+    if (e == hipErrorOutOfMemory) {
+        pool_trim_device(c);
+        e = hipMalloc(d_ptr, bytes);
+    }
+    RFX_HIP_CHECK(e);
     return RFX_OK;
+}
+extern "C" int rfx_hip_malloc(rfx_ctx_t *c, void **d_ptr, size_t bytes) {
+    RFX_REQUIRE(c && d_ptr, RFX_EINVAL, "NULL argument");
+    pthread_mutex_lock(&g_pool_mu);
+    const int rc = pool_malloc_locked(c, d_ptr, bytes);
+    pthread_mutex_unlock(&g_pool_mu);
+    return rc;
 }
 // give every block kept for reuse back to the device (a host about to need the memory for something else)
 extern "C" int rfx_hip_ctx_trim(rfx_ctx_t *c) {
     RFX_REQUIRE(c, RFX_EINVAL, "ctx is NULL");
-    SmallPool *sp = (SmallPool *)c->ext_p[0];
-    if (!sp) return RFX_OK;
+    if (!c->ext_p[0]) return RFX_OK;
     RFX_HIP_CHECK(hipStreamSynchronize(c->stream));
-    for (int k = 0; k <= POOL_MAX_LOG; k++) {
-        for (int i = 0; i < sp->nfree[k]; i++) (void)hipFree(sp->freep[k][i]);
-        sp->nfree[k] = 0;
-    }
-    for (int i = 0; i < sp->nbig_free; i++) (void)hipFree(sp->big_free_p[i]);
-    sp->nbig_free = 0;
-    sp->big_free_total = 0;
+    pthread_mutex_lock(&g_pool_mu);
+    pool_drop_kept(c, 1);
+    pthread_mutex_unlock(&g_pool_mu);
     return RFX_OK;
 }
-extern "C" int rfx_hip_free(rfx_ctx_t *c, void *d_ptr) {
-    RFX_REQUIRE(c, RFX_EINVAL, "ctx is NULL");
-    if (!d_ptr) return RFX_OK;
+static int pool_free_locked(rfx_ctx *c, void *d_ptr) {
     SmallPool *sp = (SmallPool *)c->ext_p[0];
     if (sp) {
         for (int i = sp->nlive - 1; i >= 0; i--)
@@ -449,10 +502,12 @@ extern "C" int rfx_hip_free(rfx_ctx_t *c, void *d_ptr) {
                 const size_t b = sp->big_live_b[i];
                 sp->big_live_p[i] = sp->big_live_p[sp->nbig_live - 1];
                 sp->big_live_b[i] = sp->big_live_b[--sp->nbig_live];
-                if (sp->nbig_free < BIG_KEEP && sp->big_free_total + b <= BIG_KEEP_BYTES) {
+                const int dv = (c->device >= 0 && c->device < POOL_MAX_DEV) ? c->device : 0;
+                if (sp->nbig_free < BIG_KEEP && g_dev_kept[dv] + b <= BIG_KEEP_BYTES) { // (the budget is the DEVICE's, whatever the number of contexts on it)
                     sp->big_free_p[sp->nbig_free] = d_ptr;
                     sp->big_free_b[sp->nbig_free++] = b;
                     sp->big_free_total += b;
+                    g_dev_kept[dv] += b;
                     return RFX_OK;
                 }
                 break;
@@ -460,6 +515,14 @@ extern "C" int rfx_hip_free(rfx_ctx_t *c, void *d_ptr) {
     }
     RFX_HIP_CHECK(hipFree(d_ptr));
     return RFX_OK;
+}
+extern "C" int rfx_hip_free(rfx_ctx_t *c, void *d_ptr) {
+    RFX_REQUIRE(c, RFX_EINVAL, "ctx is NULL");
+    if (!d_ptr) return RFX_OK;
+    pthread_mutex_lock(&g_pool_mu);
+    const int rc = pool_free_locked(c, d_ptr);
+    pthread_mutex_unlock(&g_pool_mu);
+    return rc;
 }
 extern "C" int rfx_hip_h2d(rfx_ctx_t *c, void *d_dst, const void *src, size_t bytes) {
     RFX_REQUIRE(c, RFX_EINVAL, "ctx is NULL");

@@ -353,6 +353,7 @@ static int agg_chunk(const rfx_query_t *q, int a0) {
         const void *mine[2 + 2 * RFX_MAX_XNODES];
         int nm = 0;
         const int isx = g->nxnodes > 0 || g->xop != RFX_X_NONE;
+        if (g->nxnodes < 0 || g->nxnodes > RFX_MAX_XNODES || (g->nxnodes > 0 && !g->xnodes)) return -1; /* (the callers answer RFX_EINVAL) */
         if (g->nxnodes > 0) {
             for (int j = 0; j < g->nxnodes; j++) {
                 if (g->xnodes[j].l.kind == RFX_XK_COL) mine[nm++] = g->xnodes[j].l.d_col;
@@ -447,23 +448,27 @@ int rfx_exec_filter_aggr(rfx_exec_t *x, const rfx_query_t *q, rfx_value_t *value
     const int S = x->nshards;
     int world, rank;
     const int exch = world_rank(x, &world, &rank);
+    x->err[0] = 0;
     if (q->d_mask && (S > 1 || exch || q->npred)) {
         snprintf(x->err, sizeof(x->err), "rfx_exec: a mask selection runs on one shard, without comparisons beside it");
         return RFX_ELIMIT;
     }
     rfx_hip_ctx_bind_thread(x->ctx[0]);
     x->stat[RFX_XSTAT_QUERIES]++;
+    x->err[0] = 0;
     shard_t *sh = (shard_t *)calloc((size_t)S, sizeof(shard_t));
     if (!sh) return RFX_ENOMEM;
     int rc = RFX_OK;
     if (selected) *selected = 0;
     for (int a0 = 0; (a0 < q->nagg || (a0 == 0 && q->nagg == 0)) && rc == RFX_OK;) {
         const int na = q->nagg ? agg_chunk(q, a0) : 0;
+        if (na < 0) { snprintf(x->err, sizeof(x->err), "rfx_exec: aggregate %d: nxnodes outside 0..%d or xnodes NULL", a0, RFX_MAX_XNODES); rc = RFX_EINVAL; break; }
         fa_t F = {x, q, S, na, q->npred, 0, sh};
         for (int s = 0; s < S && rc == RFX_OK; s++) {
             rc = shard_view(q, S, s, a0, na, &sh[s]);
             rfx_exec_split(q->nrows, S, s, &sh[s].row0, &sh[s].nrows);
         }
+        if (rc != RFX_OK) snprintf(x->err, sizeof(x->err), "rfx_exec: a column of the query has no per-shard address");
         if (rc == RFX_OK && q->d_mask) {
             rc = gather_selected(x, &sh[0], na, 0);
             F.npred = 0;
@@ -558,6 +563,7 @@ int rfx_exec_where(rfx_exec_t *x, const rfx_query_t *q, rfx_ids_t *out) {
     if (q->d_mask && q->npred) return RFX_EINVAL;
     rfx_hip_ctx_bind_thread(x->ctx[0]);
     x->stat[RFX_XSTAT_QUERIES]++;
+    x->err[0] = 0;
     memset(out, 0, sizeof(*out));
     shard_t *sh = (shard_t *)calloc((size_t)S, sizeof(shard_t));
     if (!sh) return RFX_ENOMEM;
@@ -567,6 +573,7 @@ int rfx_exec_where(rfx_exec_t *x, const rfx_query_t *q, rfx_ids_t *out) {
         rfx_exec_split(q->nrows, S, s, &sh[s].row0, &sh[s].nrows);
         sh[s].row0 += q->row0;
     }
+    if (rc != RFX_OK) snprintf(x->err, sizeof(x->err), "rfx_exec: a column of the query has no per-shard address");
     wh_t W = {x, q, sh};
     if (rc == RFX_OK) rc = run_shards(x, ph_where, &W);
     out->nshards = S;
@@ -862,6 +869,14 @@ static int merge_tables(gq_t *G, int *full) {
         rc = run_shards(x, ph_merge_local, G);
         if (rc != RFX_OK) return rc;
         for (int s = 0; s < G->S; s++) *full |= (x->lead[s] == s && G->sh[s].flag);
+    }
+    /* a hashed re-insertion that ran out of room on ONE process must stop EVERY process before the exchange below: a process that skipped
+     * it alone would meet the others' collective with the next pass' (a hang under RCCL, a size mismatch under gloo).  Asked by every
+     * process alike, whatever its own shard layout; dense merges never fill up and need no such agreement. */
+    if (G->exch && !G->dense) {
+        int any = 0;
+        if ((rc = xp_any(x, G->world, *full, &any)) != RFX_OK) return rc;
+        *full = any;
     }
     if (x->ndev > 1 && !x->comm_all) {
         snprintf(x->err, sizeof(x->err), "rfx_exec: several devices without communicators (rfx_exec_comm_init_all)");
@@ -1504,6 +1519,7 @@ int rfx_exec_group_by(rfx_exec_t *x, const rfx_query_t *q, rfx_groups_t *out) {
     int64_t cap = 0;
     for (int a0 = 0; rc == RFX_OK && (a0 < q->nagg || first);) { /* more outputs than one table set carries: several passes, same groups, same order */
         const int na = q->nagg ? agg_chunk(q, a0) : 0;
+        if (na < 0) { snprintf(x->err, sizeof(x->err), "rfx_exec: aggregate %d: nxnodes outside 0..%d or xnodes NULL", a0, RFX_MAX_XNODES); rc = RFX_EINVAL; break; }
         rc = group_by_pass(x, q, a0, na, first, cap, out);
         cap = out->capacity;
         first = 0;
@@ -1540,6 +1556,7 @@ int rfx_exec_join_index(rfx_exec_t *x, const void *const *dlk, const void *const
     rfx_ctx_t *c = x->ctx[0];
     rfx_hip_ctx_bind_thread(c);
     x->stat[RFX_XSTAT_QUERIES]++;
+    x->err[0] = 0;
     if (collision) *collision = 0;
     void *tmp[8];
     int ntmp = 0, rc = RFX_OK, exact = 1;

@@ -602,6 +602,11 @@ static void host_call_end(int d) {
     if (d > 0) {
         pthread_mutex_lock(&g_op_lock);
         t_op_depth = d;
+        if (d == 1) { /* other threads' operators ran meanwhile: the per-call column table may hold THEIR (freed) entries -- start over as op_begin does */
+            g_epoch++;
+            g_nqcols = 0;
+            if (g_ctx) rfx_hip_ctx_bind_thread(g_ctx);
+        }
     }
 }
 #define HOST_CALL(call) ({ const int _hd = host_call_begin(); obj_p _hr = (call); host_call_end(_hd); _hr; })
