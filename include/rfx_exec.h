@@ -76,7 +76,12 @@ enum {
                                  * such queries to the host: the reference opens one group per null-key row, core/index.c:1808-1816) */
     RFX_Q_WANT_FIRST = 4,       /* rfx_groups_t.d_first is wanted (the groups' first rows: costs one more result column) */
     RFX_Q_NO_SMALL = 8,         /* never the one-launch rank + emit of small dense tables (tests) */
-    RFX_Q_PROBE_FIRST = 16      /* hashed path, one shard: also leave, per row, the first row of its group (rfx_groups_t.d_probe) */
+    RFX_Q_PROBE_FIRST = 16,     /* hashed path, one shard: also leave, per row, the first row of its group (rfx_groups_t.d_probe) */
+    RFX_Q_SLICED = 32           /* the caller reads the result through rfx_exec_groups_fetch_all only: the planner may leave it as SLICES -- after the
+                                 * merge every device holds the whole tables, ranks them (the same order everywhere) and emits only ITS range of the
+                                 * groups; fetch_all copies every slice into the host columns from the owning shard's own thread, over its own PCIe
+                                 * link (rfx_groups_t.nslices / slice[]).  Without the flag -- or with one device, or with FIRST aggregates -- the
+                                 * whole result is on shard 0 as before (nslices == 1) */
 };
 #define RFX_EXEC_NULL_KEY 1 /* positive: not an error, see RFX_Q_REFUSE_NULL_KEY */
 
@@ -127,11 +132,27 @@ typedef struct rfx_groups {
      * rfx_exec_groups_fetch and they cost no further round trip */
     const char *d_block, *h_block;
     size_t block_bytes;
-    void *own[RFX_EXEC_MAX_AGGS + RFX_MAX_KEYS + 6]; /* device blocks to release (lead shard) */
+    void *own[RFX_MAX_SHARDS * 4 + RFX_EXEC_MAX_AGGS + RFX_MAX_KEYS + 6]; /* device blocks to release ... */
+    int8_t own_shard[RFX_MAX_SHARDS * 4 + RFX_EXEC_MAX_AGGS + RFX_MAX_KEYS + 6]; /* ... and the shard whose context each came from */
     int32_t nown;
+    /* RFX_Q_SLICED: column c of the result = the concatenation of slice[0..nslices)'s pieces; slice i holds the groups [g0, g0 + n) on shard
+     * `shard`.  The column pointers above are slice 0's (with one slice: the whole columns, as without the flag) */
+    int32_t nslices;
+    struct rfx_gslice {
+        int32_t shard;
+        int64_t g0, n;
+        int64_t *d_keys, *d_first;
+        int64_t *d_keycols[RFX_MAX_KEYS];
+        void *d_results[RFX_EXEC_MAX_AGGS];
+    } slice[RFX_MAX_SHARDS];
 } rfx_groups_t;
 int rfx_exec_group_by(rfx_exec_t *x, const rfx_query_t *q, rfx_groups_t *out);
 int rfx_exec_groups_fetch(rfx_exec_t *x, const rfx_groups_t *g, void *dst, const void *d_src, size_t bytes); /* device result -> host (syncs) */
+/* n result columns to host memory in ONE call: dst[i] receives the whole column src[i] -- a column pointer out of `g` (d_keys, d_first,
+ * d_keycols[k], d_results[a]), groups * 8 bytes.  Every slice is copied by the shard that owns it, on that shard's host thread and stream;
+ * one wait per shard at the end instead of one per column.  Columns above 64 MB go through pinned staging with several host threads
+ * writing the destination (first-touch page faults of a freshly allocated vector are taken in parallel). */
+int rfx_exec_groups_fetch_all(rfx_exec_t *x, const rfx_groups_t *g, int n, const void *const *d_srcs, void *const *dsts);
 void rfx_exec_groups_free(rfx_exec_t *x, rfx_groups_t *g);
 
 /* ---- join index (index_left_join_obj, core/index.c:2886-2928): d_ids[i] = first right row whose key tuple equals left row i's, else null.
@@ -149,8 +170,24 @@ enum {
     RFX_XSTAT_MERGES_RCCL = 5,   /* fused RCCL exchanges issued (process-local communicators) */
     RFX_XSTAT_MERGES_TRANSPORT = 6, /* inter-process exchanges issued */
     RFX_XSTAT_QUERIES = 7,
-    RFX_XSTAT_N = 8
+    RFX_XSTAT_SLICED = 8,        /* group-by results left as more than one slice */
+    /* per-phase wall time of the calling thread, nanoseconds, accumulated over the group-bys since rfx_exec_timing(x, 1) (which zeroes
+     * them): scope (samples, exact scopes, the scope exchange), pass (tables + scatter / aggregate kernels on every shard, to the last
+     * shard's stream idle), merge (kernel merges, the fused exchange, copy-back), rank (slot ranking incl. its one round trip), emit
+     * (+ key columns, FIRST values), fetch (rfx_exec_groups_fetch / _fetch_all: device -> host result).  With timing on every phase
+     * ends with its shards' streams idle (a one-shard query otherwise runs on in stream order), so the sum is a little above the
+     * untimed query */
+    RFX_XSTAT_NS_SCOPE = 9,
+    RFX_XSTAT_NS_PASS = 10,
+    RFX_XSTAT_NS_MERGE = 11,
+    RFX_XSTAT_NS_RANK = 12,
+    RFX_XSTAT_NS_EMIT = 13,
+    RFX_XSTAT_NS_FETCH = 14,
+    RFX_XSTAT_NS_TOTAL = 15,     /* rfx_exec_group_by entry to exit, + the fetches */
+    RFX_XSTAT_N = 16
 };
+/* on = 1: zero the RFX_XSTAT_NS_* counters and time the phases from now on (a sync per phase); on = 0: stop */
+void rfx_exec_timing(rfx_exec_t *x, int on);
 int64_t rfx_exec_stat(const rfx_exec_t *x, int which);
 /* forget which key columns' sampled scopes were reported too small (the planner does not sample those again: tests start over with this) */
 void rfx_exec_forget_scopes(rfx_exec_t *x);

@@ -231,6 +231,7 @@ int rfx_hip_free(rfx_ctx_t *ctx, void *d_ptr);
 int rfx_hip_ctx_trim(rfx_ctx_t *ctx);
 int rfx_hip_h2d(rfx_ctx_t *ctx, void *d_dst, const void *src, size_t bytes); /* (syncs) */
 int rfx_hip_d2h(rfx_ctx_t *ctx, void *dst, const void *d_src, size_t bytes); /* (syncs) */
+int rfx_hip_d2h_async(rfx_ctx_t *ctx, void *dst, const void *d_src, size_t bytes); /* (in stream order; rfx_hip_ctx_sync before `dst` is read) */
 int rfx_hip_memset(rfx_ctx_t *ctx, void *d_dst, int byte, size_t bytes);
 /* d_dst[0..n) = value (8-byte cells): the virtual Date column of a parted table, expanded partition by partition */
 int rfx_hip_fill_i64(rfx_ctx_t *ctx, int64_t *d_dst, int64_t n, int64_t value);
@@ -387,6 +388,12 @@ int rfx_hip_group_emit(rfx_ctx_t *ctx, const rfx_agg_t *aggs, const rfx_group_ta
  * result column over the GPUs (as integers) yields the value -- exactly one GPU contributes.  Everything else as rfx_hip_group_emit. */
 int rfx_hip_group_emit_sharded(rfx_ctx_t *ctx, const rfx_agg_t *aggs, const rfx_group_tables_t *t, int64_t row0, int64_t local_rows,
                                int64_t *d_keys, int64_t *d_first_ids, void *const *d_results);
+/* Emit WINDOW: until it is reset (n = 0), rfx_hip_group_emit(_sharded) / rfx_hip_hash_emit(_sharded) on this context write only the groups
+ * [g0, g0 + n) -- group g at cell g - g0 of every output, which then need n cells.  The sharded tail of a group-by: after the merge every
+ * device holds the whole tables, ranks them (the same order everywhere) and emits ITS slice of the groups, which its own host thread
+ * copies into the host result at the slice's offset -- N PCIe links instead of one.  What the reference's pool does for the same step:
+ * AGGR_COLLECT fans the per-group finalisation out over its workers by group range (core/aggr.c:163-181, core/pool.c:369-424). */
+int rfx_hip_ctx_emit_window(rfx_ctx_t *ctx, int64_t g0, int64_t n);
 
 /* ---- K9: sparse keys (range > rows): open-addressed table, same table/merge contract keyed by slot ---- */
 typedef struct rfx_hash_tables {

@@ -103,10 +103,12 @@ assert C.sizeof(Pred) == 40 and C.sizeof(Agg) == 56 and C.sizeof(XNode) == 56 an
 RFX_MAX_SHARDS = 16
 RFX_EXEC_MAX_AGGS = 32
 RFX_PRED_TREE = 256
-RFX_Q_NO_SAMPLED_SCOPE, RFX_Q_REFUSE_NULL_KEY, RFX_Q_WANT_FIRST, RFX_Q_NO_SMALL, RFX_Q_PROBE_FIRST = 1, 2, 4, 8, 16
+RFX_Q_NO_SAMPLED_SCOPE, RFX_Q_REFUSE_NULL_KEY, RFX_Q_WANT_FIRST, RFX_Q_NO_SMALL, RFX_Q_PROBE_FIRST, RFX_Q_SLICED = 1, 2, 4, 8, 16, 32
 RFX_PATH_DENSE, RFX_PATH_DENSE_SMALL, RFX_PATH_HASH, RFX_PATH_ROWHASH = 1, 2, 3, 4
 RFX_XSTAT_SCOPE_SAMPLED, RFX_XSTAT_SCOPE_RETRIED, RFX_XSTAT_SCOPE_REMEMBERED, RFX_XSTAT_HASH_GROWN, RFX_XSTAT_MERGES_KERNEL, RFX_XSTAT_MERGES_RCCL, \
-    RFX_XSTAT_MERGES_TRANSPORT, RFX_XSTAT_QUERIES = range(8)
+    RFX_XSTAT_MERGES_TRANSPORT, RFX_XSTAT_QUERIES, RFX_XSTAT_SLICED, RFX_XSTAT_NS_SCOPE, RFX_XSTAT_NS_PASS, RFX_XSTAT_NS_MERGE, RFX_XSTAT_NS_RANK, \
+    RFX_XSTAT_NS_EMIT, RFX_XSTAT_NS_FETCH, RFX_XSTAT_NS_TOTAL = range(16)
+RFX_XSTAT_PHASES = (("scope", 9), ("pass", 10), ("merge", 11), ("rank", 12), ("emit", 13), ("fetch", 14), ("total", 15))
 
 
 class QCol(C.Structure):
@@ -123,11 +125,20 @@ class Ids(C.Structure):
     _fields_ = [("nshards", C.c_int32), ("total", C.c_int64), ("count", C.c_int64 * RFX_MAX_SHARDS), ("d_ids", C.c_void_p * RFX_MAX_SHARDS)]
 
 
+class GSlice(C.Structure):
+    _fields_ = [("shard", C.c_int32), ("g0", C.c_int64), ("n", C.c_int64), ("d_keys", C.c_void_p), ("d_first", C.c_void_p),
+                ("d_keycols", C.c_void_p * RFX_MAX_KEYS), ("d_results", C.c_void_p * RFX_EXEC_MAX_AGGS)]
+
+
+_GROUPS_OWN = RFX_MAX_SHARDS * 4 + RFX_EXEC_MAX_AGGS + RFX_MAX_KEYS + 6
+
+
 class Groups(C.Structure):
     _fields_ = [("groups", C.c_int64), ("path", C.c_int32), ("nkeys", C.c_int32), ("nagg", C.c_int32), ("d_keys", C.c_void_p),
                 ("d_keycols", C.c_void_p * RFX_MAX_KEYS), ("d_first", C.c_void_p), ("d_results", C.c_void_p * RFX_EXEC_MAX_AGGS),
                 ("result_type", C.c_int32 * RFX_EXEC_MAX_AGGS), ("d_probe", C.c_void_p), ("capacity", C.c_int64), ("d_block", C.c_void_p),
-                ("h_block", C.c_void_p), ("block_bytes", C.c_size_t), ("own", C.c_void_p * (RFX_EXEC_MAX_AGGS + RFX_MAX_KEYS + 6)), ("nown", C.c_int32)]
+                ("h_block", C.c_void_p), ("block_bytes", C.c_size_t), ("own", C.c_void_p * _GROUPS_OWN), ("own_shard", C.c_int8 * _GROUPS_OWN), ("nown", C.c_int32),
+                ("nslices", C.c_int32), ("slice", GSlice * RFX_MAX_SHARDS)]
 
 
 TR_WORLD_RANK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int))
@@ -161,6 +172,7 @@ PROTOTYPES = {
     "rfx_hip_ctx_trim": (C.c_int, [_ctx]),
     "rfx_hip_h2d": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_size_t]),
     "rfx_hip_d2h": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "rfx_hip_d2h_async": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_size_t]),
     "rfx_hip_memset": (C.c_int, [_ctx, C.c_void_p, C.c_int, C.c_size_t]),
     "rfx_hip_fill_i64": (C.c_int, [_ctx, C.c_void_p, C.c_int64, C.c_int64]),
     "rfx_hip_rtc_stats": (None, [_P(C.c_int64), _P(C.c_int64)]),
@@ -196,6 +208,7 @@ PROTOTYPES = {
     "rfx_hip_group_emit": (C.c_int, [_ctx, _P(Agg), _P(GroupTables), C.c_void_p, C.c_void_p, _P(C.c_void_p)]),
     "rfx_hip_scope_sample_i64": (C.c_int, [_ctx, C.c_void_p, C.c_int64, _P(C.c_int64), _P(C.c_int64)]),
     "rfx_hip_ctx_speculative": (C.c_int, [_ctx, C.c_int]),
+    "rfx_hip_ctx_emit_window": (C.c_int, [_ctx, C.c_int64, C.c_int64]),
     "rfx_hip_group_out_of_scope": (C.c_int, [_ctx, _P(C.c_int)]),
     "rfx_hip_group_rank_emit_small": (C.c_int, [_ctx, _P(Agg), _P(GroupTables), C.c_int64, C.c_int64, C.c_void_p]),
     "rfx_hip_group_emit_sharded": (C.c_int, [_ctx, _P(Agg), _P(GroupTables), C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, _P(C.c_void_p)]),
@@ -268,7 +281,9 @@ EXEC_PROTOTYPES = {
     "rfx_exec_ids_free": (None, [_exec, _P(Ids)]),
     "rfx_exec_group_by": (C.c_int, [_exec, _P(Query), _P(Groups)]),
     "rfx_exec_groups_fetch": (C.c_int, [_exec, _P(Groups), C.c_void_p, C.c_void_p, C.c_size_t]),
+    "rfx_exec_groups_fetch_all": (C.c_int, [_exec, _P(Groups), C.c_int, _P(C.c_void_p), _P(C.c_void_p)]),
     "rfx_exec_groups_free": (None, [_exec, _P(Groups)]),
+    "rfx_exec_timing": (None, [_exec, C.c_int]),
     "rfx_exec_join_index": (C.c_int, [_exec, _P(C.c_void_p), _P(C.c_void_p), C.c_int, C.c_int64, C.c_int64, C.c_void_p, _P(C.c_int)]),
     "rfx_exec_stat": (C.c_int64, [_exec, C.c_int]),
     "rfx_exec_forget_scopes": (None, [_exec]),

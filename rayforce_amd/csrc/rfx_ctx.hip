@@ -545,6 +545,12 @@ extern "C" int rfx_hip_d2h(rfx_ctx_t *c, void *dst, const void *d_src, size_t by
     RFX_HIP_CHECK(hipStreamSynchronize(c->stream));
     return RFX_OK;
 }
+extern "C" int rfx_hip_d2h_async(rfx_ctx_t *c, void *dst, const void *d_src, size_t bytes) {
+    RFX_REQUIRE(c, RFX_EINVAL, "ctx is NULL");
+    if (!bytes) return RFX_OK;
+    RFX_HIP_CHECK(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, c->stream));
+    return RFX_OK;
+}
 extern "C" int rfx_hip_memset(rfx_ctx_t *c, void *d_dst, int byte, size_t bytes) {
     RFX_REQUIRE(c, RFX_EINVAL, "ctx is NULL");
     if (!bytes) return RFX_OK;

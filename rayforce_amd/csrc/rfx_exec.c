@@ -21,6 +21,8 @@
 #include <string.h>
 #include "rfx_exec.h"
 
+#include <time.h>
+
 #define NULL_I64 ((int64_t)0x8000000000000000LL)
 #define INF_I64 ((int64_t)0x7FFFFFFFFFFFFFFFLL)
 
@@ -57,8 +59,23 @@ struct rfx_exec {
     int64_t spec_wide_n[32];
     int nspec_wide, wide_ring;
     int64_t stat[RFX_XSTAT_N];
+    int timing;       /* rfx_exec_timing: per-phase wall time into stat[RFX_XSTAT_NS_*], a sync at every phase end */
+    int slice_shards; /* RFX_EXEC_SLICE_SHARDS=1: every SHARD owns a slice of a sliced result, not only every device's lead (how the sharded
+                       * tail runs on a one-GPU box: the merged tables are copied to the shards beside their lead first) */
     char err[512];
 };
+static inline int64_t now_ns(void) {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (int64_t)ts.tv_sec * 1000000000LL + ts.tv_nsec;
+}
+#define T_BEGIN(x) const int64_t t0_ = (x)->timing ? now_ns() : 0
+#define T_END(x, which) do { if ((x)->timing) (x)->stat[which] += now_ns() - t0_; } while (0)
+void rfx_exec_timing(rfx_exec_t *x, int on) {
+    if (!x) return;
+    if (on) for (int i = RFX_XSTAT_NS_SCOPE; i <= RFX_XSTAT_NS_TOTAL; i++) x->stat[i] = 0;
+    x->timing = on ? 1 : 0;
+}
 
 /* ------------------------------------------------------------------------------------------------ shards and workers */
 typedef struct {
@@ -125,6 +142,7 @@ int rfx_exec_create(rfx_ctx_t *const *ctxs, int nshards, rfx_exec_t **out) {
     rfx_exec_t *x = (rfx_exec_t *)calloc(1, sizeof(*x));
     if (!x) return RFX_ENOMEM;
     x->nshards = nshards;
+    x->slice_shards = getenv("RFX_EXEC_SLICE_SHARDS") != NULL;
     for (int s = 0; s < nshards; s++) {
         if (!ctxs[s]) { free(x); return RFX_EINVAL; }
         x->ctx[s] = ctxs[s];
@@ -282,6 +300,9 @@ typedef struct {
     /* rank + emit */
     int64_t groups;
     void *dout, *dfirst;
+    int64_t g0, gn;              /* the slice of the groups this shard emitted (the whole result: 0, groups) */
+    void *kc[RFX_MAX_KEYS];      /* sliced result, several keys: this slice's key columns */
+    int64_t t_rank;              /* timing: when this shard's ranking was done */
     /* where */
     int64_t *d_ids, count;
     /* the selection of a mask query as ids (first rows are translated back through them) */
@@ -339,6 +360,10 @@ static void sh_release(rfx_exec_t *x, shard_t *h, int s) {
     if (h->dout) rfx_hip_free(x->ctx[s], h->dout);
     if (h->dfirst) rfx_hip_free(x->ctx[s], h->dfirst);
     h->dout = h->dfirst = NULL;
+    for (int k = 0; k < RFX_MAX_KEYS; k++) {
+        if (h->kc[k]) rfx_hip_free(x->ctx[s], h->kc[k]);
+        h->kc[k] = NULL;
+    }
     if (h->sel_ids) rfx_hip_free(x->ctx[s], h->sel_ids);
     h->sel_ids = NULL;
 }
@@ -613,6 +638,7 @@ typedef struct {
     int64_t cap, cap_max;
     int narr;
     int want_first, need_first_values, all_rank;
+    int nsl, slown[RFX_MAX_SHARDS], slidx[RFX_MAX_SHARDS], slice_all; /* result slices: their owners, a shard's slice (-1: none), owners beside device leads */
     int phase_key;          /* which key column a per-key phase works on */
     int scope_filtered;     /* per-key exact scopes: through the predicates */
     int sparse_sampled;     /* the sample alone sent the key to the hashed tables: a null key shows in their null slot */
@@ -987,33 +1013,54 @@ static int merge_tables(gq_t *G, int *full) {
         }
     }
     /* FIRST values are read where the rows are: the merged tables go down from every device's lead to the shards beside it */
-    if (G->all_rank && !*full && G->S > x->ndev) rc = run_shards(x, ph_copy_back, G);
+    if ((G->all_rank || G->slice_all) && !*full && G->S > x->ndev) rc = run_shards(x, ph_copy_back, G);
     return rc;
 }
 
-/* rank by first row (first-occurrence order, core/index.c:2037-2055) and emit, on the lead -- and on every shard when FIRST values are
- * asked for: a group's first value is read by the shard that owns its first row, the others write 0 */
+/* rank by first row (first-occurrence order, core/index.c:2037-2055) and emit: on the lead; on every shard when FIRST values are asked
+ * for (a group's first value is read by the shard that owns its first row, the others write 0); on every SLICE OWNER of a sliced result
+ * (every owner ranks the same merged tables -- redundant, and parallel -- and emits only its range of the groups) */
 static int ph_rank_emit(void *arg, int s) {
     gq_t *G = (gq_t *)arg;
     rfx_exec_t *x = G->x;
-    if (s != 0 && !G->all_rank) return RFX_OK;
+    const int si = G->slidx[s];
+    if (si < 0 && !G->all_rank) return RFX_OK;
     shard_t *h = &G->sh[s];
     rfx_ctx_t *c = x->ctx[s];
     int rc = G->dense ? rfx_hip_group_rank(c, &h->gt, G->total_rows, &h->groups) : rfx_hip_hash_rank(c, &h->ht, G->total_rows, &h->groups);
+    if (x->timing) h->t_rank = now_ns();
+    h->g0 = h->gn = 0;
     if (rc != RFX_OK || h->groups == 0) return rc;
     const int64_t g = h->groups;
-    if ((rc = rfx_hip_malloc(c, &h->dout, (size_t)(G->na + 1) * (size_t)g * 8)) != RFX_OK) return rc;
-    if ((G->want_first || !G->dense) && (rc = rfx_hip_malloc(c, &h->dfirst, (size_t)g * 8)) != RFX_OK) return rc;
+    int64_t g0 = 0, gn = g;
+    if (G->nsl > 1) { /* this owner's range of the groups */
+        g0 = (int64_t)((__int128)g * si / G->nsl);
+        gn = (int64_t)((__int128)g * (si + 1) / G->nsl) - g0;
+    }
+    h->g0 = g0;
+    h->gn = gn;
+    if (gn == 0) return RFX_OK; /* (fewer groups than slices) */
+    if ((rc = rfx_hip_malloc(c, &h->dout, (size_t)(G->na + 1) * (size_t)gn * 8)) != RFX_OK) return rc;
+    if ((G->want_first || !G->dense) && (rc = rfx_hip_malloc(c, &h->dfirst, (size_t)gn * 8)) != RFX_OK) return rc;
     void *ptrs[RFX_MAX_AGGS];
-    for (int a = 0; a < G->na; a++) ptrs[a] = (int64_t *)h->dout + (size_t)(a + 1) * (size_t)g;
+    for (int a = 0; a < G->na; a++) ptrs[a] = (int64_t *)h->dout + (size_t)(a + 1) * (size_t)gn;
     /* FIRST: a first row is owned by the shard whose rows [row0, row0 + nloc) hold it (nloc 0 = the one shard owns every row); a shard
      * without rows owns none (a row offset no first row reaches) */
     const int multi = G->S > 1 || G->exch;
     const int64_t nloc = multi ? (h->nrows > 0 ? h->nrows : 1) : 0, r0 = (multi && h->nrows == 0) ? INF_I64 : h->row0;
+    if (G->nsl > 1 && (rc = rfx_hip_ctx_emit_window(c, g0, gn)) != RFX_OK) return rc;
     rc = G->dense ? rfx_hip_group_emit_sharded(c, h->aggs, &h->gt, r0, nloc, (int64_t *)h->dout, (int64_t *)h->dfirst, ptrs)
                   : rfx_hip_hash_emit_sharded(c, h->aggs, &h->ht, r0, nloc, (int64_t *)h->dout, (int64_t *)h->dfirst, ptrs);
+    if (G->nsl > 1) rfx_hip_ctx_emit_window(c, 0, 0);
     if (rc != RFX_OK) return rc;
-    return multi ? rfx_hip_ctx_sync(c) : RFX_OK; /* (one shard: the tables are released in stream order, the caller reads in stream order) */
+    if (G->nsl > 1 && G->first_pass && G->nkeys > 1) /* this slice's key columns, decoded from its composite keys (core/query.c:110-135) */
+        for (int k = 0; k < G->nkeys; k++) {
+            if ((rc = rfx_hip_malloc(c, &h->kc[k], (size_t)gn * 8)) != RFX_OK) return rc;
+            if ((rc = rfx_hip_composite_decode(c, (const int64_t *)h->dout, gn, G->kmins[k], G->kmults[k], G->kmaxs[k] - G->kmins[k] + 1, (int64_t *)h->kc[k])) != RFX_OK) return rc;
+        }
+    /* FIRST values merge across the shards next: their streams must be idle.  A slice is read back on its own stream (fetch_all) and one
+     * shard goes on in stream order: no wait (the tables go back to the pool of the stream that read them) */
+    return (G->all_rank || x->timing) ? rfx_hip_ctx_sync(c) : RFX_OK;
 }
 /* FIRST columns of the shards beside a lead, added into the lead's (exactly one shard wrote each value) */
 static int ph_first_local(void *arg, int s) {
@@ -1080,9 +1127,13 @@ static void spec_remember_wide(rfx_exec_t *x, const void *key, int64_t n) {
     x->spec_wide_n[i] = n;
     if (x->nspec_wide < 32) x->nspec_wide++;
 }
-static void own(rfx_groups_t *g, void *p) {
-    if (p && g->nown < (int)(sizeof(g->own) / sizeof(g->own[0]))) g->own[g->nown++] = p;
+static void own_on(rfx_groups_t *g, void *p, int shard) {
+    if (p && g->nown < (int)(sizeof(g->own) / sizeof(g->own[0]))) {
+        g->own_shard[g->nown] = (int8_t)shard;
+        g->own[g->nown++] = p;
+    }
 }
+static void own(rfx_groups_t *g, void *p) { own_on(g, p, 0); }
 
 /* ---- one pass of a group-by (aggregates [a0, a0 + na) of the query; the first pass also makes the key columns / first rows), step by step:
  * gb_setup -> { gb_scope -> gb_size -> gb_passes } (once more under the exact scope when the sampled one did not hold) -> gb_null_slot ->
@@ -1105,6 +1156,23 @@ static int gb_setup(gq_t *G) {
     for (int a = 0; a < na; a++) G->need_first_values |= sh[0].aggs[a].kind == RFX_AGG_FIRST;
     G->all_rank = G->need_first_values && (S > 1 || G->exch);
     G->multi = S > 1 || G->exch;
+    /* the tail, sharded: one slice of the groups per device (its lead ranks, emits and -- rfx_exec_groups_fetch_all -- reads it back); FIRST
+     * values live with the rows and keep the every-shard emit + SUM merge on the lead */
+    G->nsl = 1;
+    G->slown[0] = 0;
+    G->slice_all = 0;
+    if ((q->flags & RFX_Q_SLICED) && !G->need_first_values && !q->d_mask && S > 1) {
+        if (x->slice_shards) {
+            G->nsl = S;
+            for (int s = 0; s < S; s++) G->slown[s] = s;
+            G->slice_all = S > x->ndev;
+        } else if (x->ndev > 1) {
+            G->nsl = x->ndev;
+            for (int d = 0; d < x->ndev; d++) G->slown[d] = x->devlead[d];
+        }
+    }
+    for (int s = 0; s < S; s++) G->slidx[s] = -1;
+    for (int i = 0; i < G->nsl; i++) G->slidx[G->slown[i]] = i;
     const int multi = G->multi;
     if (q->d_mask) {
         if (multi || q->npred) { snprintf(x->err, sizeof(x->err), "rfx_exec: a mask selection runs on one shard, without comparisons beside it"); rc = RFX_ELIMIT; return rc; }
@@ -1264,7 +1332,13 @@ static int gb_passes(gq_t *G) {
     const int multi = G->multi;
     int rc = RFX_OK;
     for (;;) {
-        if ((rc = run_shards(x, ph_pass, G)) != RFX_OK) return rc;
+        {
+            T_BEGIN(x);
+            rc = run_shards(x, ph_pass, G);
+            if (rc == RFX_OK && x->timing && !multi) rc = rfx_hip_ctx_sync(x->ctx[0]);
+            T_END(x, RFX_XSTAT_NS_PASS);
+            if (rc != RFX_OK) return rc;
+        }
         {
             int flag = 0, any = 0;
             for (int s = 0; s < S; s++) flag |= sh[s].flag;
@@ -1280,7 +1354,12 @@ static int gb_passes(gq_t *G) {
                 return GB_AGAIN;
             }
             int full = any;
-            if (!full && multi && (rc = merge_tables(G, &full)) != RFX_OK) return rc;
+            if (!full && multi) {
+                T_BEGIN(x);
+                rc = merge_tables(G, &full);
+                T_END(x, RFX_XSTAT_NS_MERGE);
+                if (rc != RFX_OK) return rc;
+            }
             if (full) { /* table full (a pass gives up at 3/4 load, early): every shard and process grows together */
                 if (G->cap >= G->cap_max) { snprintf(x->err, sizeof(x->err), "rfx_exec: the hashed group table is full at the reference's own size"); rc = RFX_ELIMIT; return rc; }
                 G->cap = G->cap_max;
@@ -1408,9 +1487,59 @@ static int gb_emit(gq_t *G) {
     const int na = G->na;
     rfx_groups_t *out = G->out;
     int rc = RFX_OK;
+    const int64_t t_emit0 = x->timing ? now_ns() : 0;
     if ((rc = run_shards(x, ph_rank_emit, G)) != RFX_OK) return rc;
+    if (x->timing) { /* rank = to the last shard's ranking done; emit = the rest of the phase (+ FIRST values, key columns below) */
+        int64_t tr = t_emit0;
+        for (int s = 0; s < G->S; s++)
+            if ((G->slidx[s] >= 0 || G->all_rank) && sh[s].t_rank > tr) tr = sh[s].t_rank;
+        x->stat[RFX_XSTAT_NS_RANK] += tr - t_emit0;
+        x->stat[RFX_XSTAT_NS_EMIT] += now_ns() - tr;
+    }
+    T_BEGIN(x);
     if (G->all_rank && (rc = merge_first_values(G)) != RFX_OK) return rc;
     rfx_hip_ctx_bind_thread(x->ctx[0]);
+    if (G->nsl > 1) { /* a sliced result: every owner's pieces, in group order */
+        const int64_t g = sh[G->slown[0]].groups;
+        for (int i = 1; i < G->nsl; i++)
+            if (sh[G->slown[i]].groups != g) { snprintf(x->err, sizeof(x->err), "rfx_exec: the devices disagree on the groups of the merged tables"); return RFX_ESTATE; }
+        G->groups = g;
+        if (G->first_pass) out->groups = g;
+        else if (out->groups != g) { snprintf(x->err, sizeof(x->err), "rfx_exec: two passes of one query disagree on the groups"); return RFX_ESTATE; }
+        if (G->first_pass) out->nslices = G->nsl;
+        for (int i = 0; i < G->nsl && g > 0; i++) {
+            const int s = G->slown[i];
+            shard_t *h = &sh[s];
+            struct rfx_gslice *sl = &out->slice[i];
+            sl->shard = s;
+            sl->g0 = h->g0;
+            sl->n = h->gn;
+            for (int a = 0; a < na; a++) sl->d_results[G->a0 + a] = h->gn ? (int64_t *)h->dout + (size_t)(a + 1) * (size_t)h->gn : NULL;
+            own_on(out, h->dout, s);
+            if (G->first_pass) {
+                sl->d_keys = (int64_t *)h->dout;
+                sl->d_first = (int64_t *)h->dfirst;
+                own_on(out, h->dfirst, s);
+                for (int k = 0; k < G->nkeys && G->nkeys > 1; k++) {
+                    sl->d_keycols[k] = (int64_t *)h->kc[k];
+                    own_on(out, h->kc[k], s);
+                    h->kc[k] = NULL;
+                }
+            } else if (h->dfirst) rfx_hip_free(x->ctx[s], h->dfirst);
+            h->dout = h->dfirst = NULL; /* the result owns them now */
+        }
+        if (g > 0) { /* the column pointers a caller names columns by: slice 0's */
+            for (int a = 0; a < na; a++) out->d_results[G->a0 + a] = out->slice[0].d_results[G->a0 + a];
+            if (G->first_pass) {
+                out->d_keys = out->slice[0].d_keys;
+                out->d_first = out->slice[0].d_first;
+                for (int k = 0; k < G->nkeys && G->nkeys > 1; k++) out->d_keycols[k] = out->slice[0].d_keycols[k];
+            }
+            if (G->first_pass) x->stat[RFX_XSTAT_SLICED]++;
+        }
+        T_END(x, RFX_XSTAT_NS_EMIT);
+        return RFX_OK;
+    }
     {
         shard_t *h = &sh[0];
         rfx_ctx_t *c = x->ctx[0];
@@ -1452,6 +1581,7 @@ static int gb_emit(gq_t *G) {
             h->dout = h->dfirst = NULL; /* the result owns them now */
         }
     }
+    T_END(x, RFX_XSTAT_NS_EMIT);
     return RFX_OK;
 }
 
@@ -1476,7 +1606,11 @@ static int group_by_pass(rfx_exec_t *x, const rfx_query_t *q, int a0, int na, in
     G->want_first = (q->flags & RFX_Q_WANT_FIRST) != 0;
     int rc = gb_setup(G);
     while (rc == RFX_OK) {
-        rc = gb_scope(G);
+        {
+            T_BEGIN(x);
+            rc = gb_scope(G);
+            T_END(x, RFX_XSTAT_NS_SCOPE);
+        }
         if (rc != RFX_OK || G->seen <= 0) break;
         gb_size(G);
         rc = gb_passes(G);
@@ -1515,6 +1649,7 @@ int rfx_exec_group_by(rfx_exec_t *x, const rfx_query_t *q, rfx_groups_t *out) {
     x->stat[RFX_XSTAT_QUERIES]++;
     x->err[0] = 0;
     memset(out, 0, sizeof(*out));
+    T_BEGIN(x);
     int rc = RFX_OK, first = 1;
     int64_t cap = 0;
     for (int a0 = 0; rc == RFX_OK && (a0 < q->nagg || first);) { /* more outputs than one table set carries: several passes, same groups, same order */
@@ -1527,7 +1662,85 @@ int rfx_exec_group_by(rfx_exec_t *x, const rfx_query_t *q, rfx_groups_t *out) {
         if (q->nagg == 0 || out->groups == 0) break;
     }
     out->nagg = q->nagg;
+    if (rc == RFX_OK && out->nslices <= 1) { /* the whole result on shard 0: one slice, so that every reader walks slices */
+        out->nslices = 1;
+        out->slice[0].shard = 0;
+        out->slice[0].g0 = 0;
+        out->slice[0].n = out->groups;
+        out->slice[0].d_keys = out->d_keys;
+        out->slice[0].d_first = out->d_first;
+        for (int k = 0; k < RFX_MAX_KEYS; k++) out->slice[0].d_keycols[k] = out->d_keycols[k];
+        for (int a = 0; a < RFX_EXEC_MAX_AGGS; a++) out->slice[0].d_results[a] = out->d_results[a];
+    }
+    T_END(x, RFX_XSTAT_NS_TOTAL);
     if (rc != RFX_OK) rfx_exec_groups_free(x, out);
+    return rc;
+}
+/* ---- the result to the host ---- */
+typedef struct {
+    rfx_exec_t *x;
+    const rfx_groups_t *g;
+    int n;
+    const void *const *srcs;
+    void *const *dsts;
+} fetch_t;
+/* the piece of column `src0` (a column pointer of slice 0) that slice i holds */
+static const void *slice_col(const rfx_groups_t *g, int i, const void *src0) {
+    const struct rfx_gslice *a = &g->slice[0], *b = &g->slice[i];
+    if (!src0) return NULL;
+    if (src0 == a->d_keys) return b->d_keys;
+    if (src0 == a->d_first) return b->d_first;
+    for (int k = 0; k < RFX_MAX_KEYS; k++)
+        if (src0 == a->d_keycols[k]) return b->d_keycols[k];
+    for (int r = 0; r < RFX_EXEC_MAX_AGGS; r++)
+        if (src0 == a->d_results[r]) return b->d_results[r];
+    return NULL;
+}
+static int ph_fetch(void *arg, int s) {
+    fetch_t *F = (fetch_t *)arg;
+    const rfx_groups_t *g = F->g;
+    rfx_ctx_t *c = F->x->ctx[s];
+    int any = 0, rc = RFX_OK;
+    for (int i = 0; i < g->nslices && rc == RFX_OK; i++) {
+        if (g->slice[i].shard != s || g->slice[i].n == 0) continue;
+        for (int j = 0; j < F->n && rc == RFX_OK; j++) {
+            const void *p = slice_col(g, i, F->srcs[j]);
+            if (!p) { rfx_hip_ctx_sync(c); return RFX_EINVAL; }
+            rc = rfx_hip_d2h_async(c, (char *)F->dsts[j] + (size_t)g->slice[i].g0 * 8, p, (size_t)g->slice[i].n * 8);
+            any = 1;
+        }
+    }
+    if (any) { /* ONE wait for all of this shard's copies */
+        const int src = rfx_hip_ctx_sync(c);
+        if (rc == RFX_OK) rc = src;
+    }
+    return rc;
+}
+int rfx_exec_groups_fetch_all(rfx_exec_t *x, const rfx_groups_t *g, int n, const void *const *d_srcs, void *const *dsts) {
+    if (!x || !g || n < 0 || (n && (!d_srcs || !dsts))) return RFX_EINVAL;
+    if (n == 0 || g->groups == 0) return RFX_OK;
+    T_BEGIN(x);
+    int rc = RFX_OK;
+    if (g->h_block) { /* small dense tables: the block is mirrored on the host already */
+        for (int j = 0; j < n && rc == RFX_OK; j++) {
+            const char *p = (const char *)d_srcs[j];
+            if (p >= g->d_block && p + (size_t)g->groups * 8 <= g->d_block + g->block_bytes) memcpy(dsts[j], g->h_block + (p - g->d_block), (size_t)g->groups * 8);
+            else rc = rfx_hip_d2h(x->ctx[0], dsts[j], p, (size_t)g->groups * 8);
+        }
+    } else {
+        fetch_t F = {x, g, n, d_srcs, dsts};
+        if (g->nslices <= 1) {
+            rfx_hip_ctx_bind_thread(x->ctx[0]);
+            if (g->nslices == 1 && g->slice[0].d_keys == NULL && g->slice[0].n == 0) rc = RFX_OK; /* (an empty result) */
+            else rc = ph_fetch(&F, g->nslices == 1 ? g->slice[0].shard : 0);
+        } else rc = run_shards(x, ph_fetch, &F);
+        if (rc != RFX_OK && !x->err[0]) snprintf(x->err, sizeof(x->err), "rfx_exec: result read-back: %s", rc == RFX_EINVAL ? "a column that is not the result's" : rfx_hip_last_error());
+    }
+    if (x->timing) {
+        const int64_t dt = now_ns() - t0_;
+        x->stat[RFX_XSTAT_NS_FETCH] += dt;
+        x->stat[RFX_XSTAT_NS_TOTAL] += dt;
+    }
     return rc;
 }
 int rfx_exec_groups_fetch(rfx_exec_t *x, const rfx_groups_t *g, void *dst, const void *d_src, size_t bytes) {
@@ -1536,11 +1749,27 @@ int rfx_exec_groups_fetch(rfx_exec_t *x, const rfx_groups_t *g, void *dst, const
         memcpy(dst, g->h_block + ((const char *)d_src - g->d_block), bytes);
         return RFX_OK;
     }
-    return rfx_hip_d2h(x->ctx[0], dst, d_src, bytes);
+    if (g->nslices > 1) { /* a sliced column: whole or not at all */
+        if (bytes != (size_t)g->groups * 8) return RFX_EINVAL;
+        const void *srcs[1] = {d_src};
+        void *dsts[1] = {dst};
+        return rfx_exec_groups_fetch_all(x, g, 1, srcs, dsts);
+    }
+    T_BEGIN(x);
+    const int rc = rfx_hip_d2h(x->ctx[0], dst, d_src, bytes);
+    if (x->timing) {
+        const int64_t dt = now_ns() - t0_;
+        x->stat[RFX_XSTAT_NS_FETCH] += dt;
+        x->stat[RFX_XSTAT_NS_TOTAL] += dt;
+    }
+    return rc;
 }
 void rfx_exec_groups_free(rfx_exec_t *x, rfx_groups_t *g) {
     if (!x || !g) return;
-    for (int i = 0; i < g->nown; i++) rfx_hip_free(x->ctx[0], g->own[i]);
+    for (int i = 0; i < g->nown; i++) {
+        const int s = g->own_shard[i] >= 0 && g->own_shard[i] < x->nshards ? g->own_shard[i] : 0;
+        rfx_hip_free(x->ctx[s], g->own[i]);
+    }
     free((void *)g->h_block);
     memset(g, 0, sizeof(*g));
 }

@@ -767,8 +767,10 @@ extern "C" int rfx_hip_group_rank(rfx_ctx_t *c, const rfx_group_tables_t *t, int
 // ---------------- emit in group order ----------------
 __global__ __launch_bounds__(RFX_BLOCK) void k_group_emit(const EmitArgs A, const i64 *__restrict__ gid) {
     for (i64 i = blockIdx.x * (i64)RFX_BLOCK + threadIdx.x; i < A.slots; i += (i64)gridDim.x * RFX_BLOCK) {
-        const i64 g = gid[i];
+        i64 g = gid[i];
         if (g < 0) continue;
+        g -= A.g0;
+        if ((u64)g >= (u64)A.gn) continue; // outside this device's slice of the groups
         if (A.out_keys) A.out_keys[g] = A.keys ? (i64)A.keys[i] : A.kmin + i;
         const u64 f = A.first[i];
         if (A.out_first) A.out_first[g] = (i64)f;
@@ -793,8 +795,9 @@ __global__ __launch_bounds__(RFX_BLOCK) void k_emit_perm(const i64 *__restrict__
     }
 }
 __global__ __launch_bounds__(RFX_BLOCK) void k_group_emit_by_group(const EmitArgs A, const i64 *__restrict__ perm, i64 groups) {
-    for (i64 g = blockIdx.x * (i64)RFX_BLOCK + threadIdx.x; g < groups; g += (i64)gridDim.x * RFX_BLOCK) {
-        const i64 i = perm[g];
+    const i64 gend = (A.gn < groups - A.g0 ? A.gn : groups - A.g0); // the window's groups are written from cell 0 on
+    for (i64 g = blockIdx.x * (i64)RFX_BLOCK + threadIdx.x; g < gend; g += (i64)gridDim.x * RFX_BLOCK) {
+        const i64 i = perm[g + A.g0];
         if (A.out_keys) A.out_keys[g] = A.keys ? (i64)A.keys[i] : A.kmin + i;
         const u64 f = A.first[i];
         if (A.out_first) A.out_first[g] = (i64)f;
@@ -809,8 +812,17 @@ __global__ __launch_bounds__(RFX_BLOCK) void k_group_emit_by_group(const EmitArg
     }
 }
 
-int rfx_emit_slots(rfx_ctx *c, const EmitArgs &A) {
-    if (A.slots <= 0 || c->rank_groups == 0) return RFX_OK;
+extern "C" int rfx_hip_ctx_emit_window(rfx_ctx_t *c, int64_t g0, int64_t n) {
+    RFX_REQUIRE(c && g0 >= 0 && n >= 0, RFX_EINVAL, "bad emit window");
+    c->ext_i[3] = g0;
+    c->ext_i[4] = n; // 0: no window
+    return RFX_OK;
+}
+int rfx_emit_slots(rfx_ctx *c, const EmitArgs &A0) {
+    if (A0.slots <= 0 || c->rank_groups == 0) return RFX_OK;
+    EmitArgs A = A0;
+    A.g0 = c->ext_i[4] > 0 ? c->ext_i[3] : 0;
+    A.gn = c->ext_i[4] > 0 ? c->ext_i[4] : (i64)0x7FFFFFFFFFFFFFFFLL;
     if (c->rank_groups >= (1LL << 22) && rfx_ws_reserve(c, (size_t)c->rank_groups * 8) == RFX_OK) {
         i64 *perm = (i64 *)c->d_ws;
         const int grid = rfx_grid(c) * 4;

@@ -218,6 +218,8 @@ struct EmitArgs {
     i64 *out_keys;
     i64 *out_first;
     u64 *out[RFX_MAX_AGGS];
+    i64 g0, gn; // emit WINDOW (rfx_hip_ctx_emit_window): only the groups [g0, g0 + gn) are written, group g at out[g - g0] -- one slice of a result
+                // whose other slices other devices emit (each reads its own back over its own PCIe link)
 };
 
 // Final grouped value of one cell -- core/aggr.c rules, see DESIGN.md "NULL semantics".

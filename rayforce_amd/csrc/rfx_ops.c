@@ -1529,40 +1529,64 @@ typedef struct {
     obj_p kenum;
     obj_p *kcs;
 } sel_keys_t;
-static int sel_key_columns(const sel_keys_t *K, const rfx_groups_t *R, obj_p *okcols, int *okp) {
-    int ok = *okp;
+/* (two steps around ONE read-back of every result column -- rfx_exec_groups_fetch_all, each slice over its own device's link:
+ * sel_key_columns_plan makes the vectors and names (device column, host destination) pairs, sel_key_columns_finish narrows / decodes) */
+typedef struct {
+    int n;
+    const void *src[RFX_MAX_KEYS + RFX_MAX_AGGS];
+    void *dst[RFX_MAX_KEYS + RFX_MAX_AGGS];
+    void *tmp[RFX_MAX_KEYS + RFX_MAX_AGGS]; /* 8-byte staging of a column whose vector is 4 bytes wide (freed by the caller) */
+    int ntmp;
+} sel_fetch_t;
+static int sel_fetch_add(sel_fetch_t *F, const void *src, void *dst) {
+    if (F->n >= (int)(sizeof(F->src) / sizeof(F->src[0]))) return 0;
+    F->src[F->n] = src;
+    F->dst[F->n++] = dst;
+    return 1;
+}
+static void *sel_fetch_tmp(sel_fetch_t *F, int64_t groups) {
+    void *t = malloc((size_t)(groups ? groups : 1) * 8);
+    if (t) F->tmp[F->ntmp++] = t;
+    return t;
+}
+static int sel_key_columns_plan(const sel_keys_t *K, const rfx_groups_t *R, obj_p *okcols, sel_fetch_t *F, int64_t **k8) {
     const int64_t groups = R->groups;
+    int ok = 1;
+    *k8 = NULL;
     if (K->nkeys == 1 && K->key_out_type == RFX_TYPE_DATE) { /* the virtual Date column: 4-byte days */
         okcols[0] = H.vector(RFX_TYPE_DATE, groups);
-        int64_t *k8 = (int64_t *)malloc((size_t)(groups ? groups : 1) * 8);
-        ok = ok && k8 && rfx_exec_groups_fetch(g_x, R, k8, R->d_keys, (size_t)groups * 8) == RFX_OK;
-        for (int64_t g = 0; g < groups && ok; g++) ((int32_t *)RFX_AS_RAW(okcols[0]))[g] = (int32_t)k8[g];
-        free(k8);
+        *k8 = (int64_t *)sel_fetch_tmp(F, groups);
+        ok = *k8 && sel_fetch_add(F, R->d_keys, *k8);
     } else if (K->nkeys == 1) {
         okcols[0] = H.vector(K->key_out_type, groups);
-        if (ok) ok = rfx_exec_groups_fetch(g_x, R, RFX_AS_RAW(okcols[0]), R->d_keys, (size_t)groups * 8) == RFX_OK;
-        if (ok && K->kenum) { /* indices -> symbols of the enum's domain (the global its key names) */
-            obj_p dom = enum_domain(K->kenum);
-            int good = dom != NULL;
-            int64_t *kk = RFX_AS_I64(okcols[0]);
-            for (int64_t g = 0; g < groups && good; g++) {
-                if (kk[g] < 0 || kk[g] >= dom->len) good = 0;
-                else kk[g] = RFX_AS_I64(dom)[kk[g]];
-            }
-            if (dom) H.drop(dom);
-            if (!good) {
-                H.drop(okcols[0]);
-                okcols[0] = NULL;
-                return SEL_OUT;
-            }
-        }
+        ok = sel_fetch_add(F, R->d_keys, RFX_AS_RAW(okcols[0]));
     } else {
         for (int i = 0; i < K->nkeys && ok; i++) {
             okcols[i] = H.vector(K->kcs[i]->type, groups);
-            ok = rfx_exec_groups_fetch(g_x, R, RFX_AS_RAW(okcols[i]), R->d_keycols[i], (size_t)groups * 8) == RFX_OK;
+            ok = sel_fetch_add(F, R->d_keycols[i], RFX_AS_RAW(okcols[i]));
         }
     }
-    *okp = ok;
+    return ok;
+}
+static int sel_key_columns_finish(const sel_keys_t *K, const rfx_groups_t *R, obj_p *okcols, const int64_t *k8) {
+    const int64_t groups = R->groups;
+    if (K->nkeys == 1 && K->key_out_type == RFX_TYPE_DATE) {
+        for (int64_t g = 0; g < groups; g++) ((int32_t *)RFX_AS_RAW(okcols[0]))[g] = (int32_t)k8[g];
+    } else if (K->nkeys == 1 && K->kenum) { /* indices -> symbols of the enum's domain (the global its key names) */
+        obj_p dom = enum_domain(K->kenum);
+        int good = dom != NULL;
+        int64_t *kk = RFX_AS_I64(okcols[0]);
+        for (int64_t g = 0; g < groups && good; g++) {
+            if (kk[g] < 0 || kk[g] >= dom->len) good = 0;
+            else kk[g] = RFX_AS_I64(dom)[kk[g]];
+        }
+        if (dom) H.drop(dom);
+        if (!good) {
+            H.drop(okcols[0]);
+            okcols[0] = NULL;
+            return SEL_OUT;
+        }
+    }
     return SEL_GO;
 }
 
@@ -1647,25 +1671,36 @@ static int sel_projection(obj_p tab, const rfx_query_t *Q, int parted, obj_p *re
 static obj_p sel_build_groups(const rfx_groups_t *R, const sel_maps_t *M, const sel_keys_t *K, const int64_t *knames, const char **why) {
     const int nagg = M->nagg, nkeys = K->nkeys;
     obj_p ocols[RFX_MAX_AGGS] = {0}, okcols[RFX_MAX_KEYS] = {0};
-    int ok = 1;
+    int ok = 1, enum_out = 0;
     if (R->groups > 0) {
-        if (sel_key_columns(K, R, okcols, &ok) == SEL_OUT) {
-            *why = "by: enum column whose domain cannot be resolved";
-            return NULL;
-        }
+        /* every result vector first, then ONE read-back of all of them (every slice of a sliced result by the shard that holds it, over that
+         * device's own link: the table construction of core/query.c:559-605 with N writers), then the 4-byte narrowing / enum decoding */
+        sel_fetch_t F;
+        int64_t *k8 = NULL, *c8[RFX_MAX_AGGS] = {0};
+        memset(&F, 0, sizeof(F));
+        ok = sel_key_columns_plan(K, R, okcols, &F, &k8);
         for (int a = 0; a < nagg && ok; a++) {
             ocols[a] = H.vector((int8_t)M->outtype[a], R->groups);
             if (IS_I32_FAMILY(M->outtype[a])) {
-                int64_t *c8 = (int64_t *)malloc((size_t)R->groups * 8);
-                ok = c8 && rfx_exec_groups_fetch(g_x, R, c8, R->d_results[a], (size_t)R->groups * 8) == RFX_OK;
-                if (ok) sel_narrow_i32(ocols[a], c8, R->groups, M->aggs[a].kind);
-                free(c8);
-            } else ok = rfx_exec_groups_fetch(g_x, R, RFX_AS_RAW(ocols[a]), R->d_results[a], (size_t)R->groups * 8) == RFX_OK;
+                c8[a] = (int64_t *)sel_fetch_tmp(&F, R->groups);
+                ok = c8[a] && sel_fetch_add(&F, R->d_results[a], c8[a]);
+            } else ok = sel_fetch_add(&F, R->d_results[a], RFX_AS_RAW(ocols[a]));
         }
+        if (ok) ok = rfx_exec_groups_fetch_all(g_x, R, F.n, F.src, F.dst) == RFX_OK;
+        if (ok) {
+            enum_out = sel_key_columns_finish(K, R, okcols, k8) == SEL_OUT;
+            for (int a = 0; a < nagg && !enum_out; a++)
+                if (c8[a]) sel_narrow_i32(ocols[a], c8[a], R->groups, M->aggs[a].kind);
+        }
+        for (int i = 0; i < F.ntmp; i++) free(F.tmp[i]);
     }
-    if (!ok) {
+    if (!ok || enum_out) {
         for (int i = 0; i < nkeys; i++) if (okcols[i]) H.drop(okcols[i]);
         for (int a = 0; a < nagg; a++) if (ocols[a]) H.drop(ocols[a]);
+        if (enum_out) {
+            *why = "by: enum column whose domain cannot be resolved";
+            return NULL;
+        }
         return fail_hip("group-by result");
     }
     obj_p rk = H.vector(RFX_TYPE_SYMBOL, nagg + nkeys), rv = H.vector(RFX_TYPE_LIST, nagg + nkeys);
@@ -1828,7 +1863,8 @@ static obj_p select_impl(obj_p dict) {
              * the filter: the same pass) -- a superset of any selection's, which is all the tables' sizing needs; the planner takes it when it
              * is LDS-sized and saves the scope round trip */
             int64_t kscope[2];
-            Q.flags = RFX_Q_REFUSE_NULL_KEY; /* the reference opens one group per null-key row (core/index.c:1808-1816): its own select answers those */
+            Q.flags = RFX_Q_REFUSE_NULL_KEY | /* the reference opens one group per null-key row (core/index.c:1808-1816): its own select answers those */
+                      RFX_Q_SLICED;           /* the result is read through rfx_exec_groups_fetch_all only: every device may keep and read back its own slice */
             resident_t *ke = (g_nshards == 1 && nkeys == 1 && !parted && flat && nrows > 0 && nrows < ((int64_t)1 << 24) && !kxbar[0]) ? resident_entry(dks[0]) : NULL;
             if (ke) {
                 if (!ke->scope_ok) {

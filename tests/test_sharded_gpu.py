@@ -107,6 +107,7 @@ NULL = -(2**63)
 n = 2_000_003
 host = {"k": rfo.gen_i64(n, 4, 100_000), "a": rfo.gen_i64(n, 2, 1_000_000), "v": rfo.gen_f64(n, 5), "b": rfo.gen_f64(n, 3), "c": rfo.gen_f64(n, 8), "d": rfo.gen_f64(n, 9)}
 host["a"][::101] = NULL
+host["k2"] = rfo.gen_i64(n, 14, 13)
 tab = H.table(host)
 queries = [
     {"s": ("sum", "a"), "where": ("<", "a", 100_000)},
@@ -116,6 +117,8 @@ queries = [
     {"x": ("avg", "d"), "y": ("min", "d"), "z": ("max", "d"), "where": ("and", ("<", "v", 0.316228), (">", "b", 0.683772), ("!=", "c", 0.25))},
     {"s": ("sum", ("*", "v", "b")), "where": ("and", ("or", ("<", "a", 5000), ("and", (">", "v", 0.5), ("<", "b", 0.5))), (">", "c", 0.1))},
     {"where": ("<", "a", 3000)},
+    {"s": ("sum", "v"), "c": ("count", "a"), "m": ("min", "b"), "by": {"g1": "k2", "g2": "k"}},
+    {"by": "k", **{f"o{i}": (fn, c) for i, (fn, c) in enumerate([("max", "a"), ("sum", "v"), ("min", "a"), ("avg", "v"), ("sum", "b"), ("avg", "c"), ("min", "d"), ("count", "a")])}},  # five argument columns: two passes, the same slices
     # comparison operands that are element-wise expressions: every shard evaluates ITS rows into a scratch column of its own
     {"s": ("sum", "v"), "c": ("count", "a"), "where": ("or", ("==", ("div", "a", 1000), 7), ("and", (">", ("*", "v", 2.0), 1.5), ("!=", "k", 3)))},
     {"s": ("sum", "b"), "by": "k", "where": ("and", ("<", ("+", "v", "b"), 0.7), (">", ("-", "a", "k"), 1000))},
@@ -155,6 +158,8 @@ assert ops.rfx_exec_shards(x) == SHARDS
 assert ops.rfx_exec_stat(x, L.RFX_XSTAT_MERGES_KERNEL) > 0
 if os.environ.get("RFX_EXEC_FORCE_RCCL"):
     assert ops.rfx_exec_stat(x, L.RFX_XSTAT_MERGES_RCCL) > 0 and ops.rfx_dist_calls(C.c_void_p(ops.rfx_exec_ctx(x, 0))) > 0
+# grouped results without FIRST values came back as one slice per shard when every shard owns one (the FIRST ones stay whole on the lead)
+assert (ops.rfx_exec_stat(x, L.RFX_XSTAT_SLICED) > 0) == bool(os.environ.get("RFX_EXEC_SLICE_SHARDS")), ops.rfx_exec_stat(x, L.RFX_XSTAT_SLICED)
 # an operator that needs its column whole on one device says so instead of answering from one shard
 col = H.vector(host["a"])
 r = ops.rfx_lt(col, H.atom(5))
@@ -163,13 +168,93 @@ print("DOOR-OK")
 '''
 
 
-@pytest.mark.parametrize("shards,rccl", [(4, False), (3, True)])
-def test_sharded_operator_door(built, shards, rccl):
-    """rfx_select with RFX_SHARDS=k in a process of its own (the operator layer's shards are fixed at its first call)."""
+@pytest.mark.parametrize("shards,rccl,sliced", [(4, False, False), (3, True, False), (4, False, True), (3, True, True)])
+def test_sharded_operator_door(built, shards, rccl, sliced):
+    """rfx_select with RFX_SHARDS=k in a process of its own (the operator layer's shards are fixed at its first call).  sliced: every shard
+    owns a slice of every group-by result (RFX_EXEC_SLICE_SHARDS=1: the sharded tail of the multi-device case -- every owner ranks the merged
+    tables, emits its range of the groups and copies it into the host table from its own thread -- on one GPU)."""
     env = dict(os.environ, RFX_SHARDS=str(shards), HSA_ENABLE_IPC_MODE_LEGACY="0")
     env.pop("RFX_EXEC_FORCE_RCCL", None)
+    env.pop("RFX_EXEC_SLICE_SHARDS", None)
     if rccl:
         env["RFX_EXEC_FORCE_RCCL"] = "1"
+    if sliced:
+        env["RFX_EXEC_SLICE_SHARDS"] = "1"
     code = f"ROOT = {ROOT!r}\nSHARDS = {shards}\n" + _DOOR
     p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0 and "DOOR-OK" in p.stdout, p.stdout[-3000:] + p.stderr[-3000:]
+
+
+_PLANE_DOOR = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+from oracle import rfo
+from rayforce_amd import hostobj as H, _lib as L
+from test_gpu_parity import same_f64
+import ctypes as C
+ops = H.lib()
+ops.rfx_host_bind()
+n = 17_000_003   # 4 shards x 4.25e6 rows: every shard above the 2^22-row threshold of the plane kernels, DEFAULT thresholds
+host = {"k": rfo.gen_i64(n, 4, 1_000_000), "a": rfo.gen_i64(n, 2, 1_000_000), "v": rfo.gen_f64(n, 5), "b": rfo.gen_f64(n, 3)}
+host["ks"] = host["k"] * 1_000_003 - 77   # sparse: the hash-partitioned planes, hashed tables re-inserted on the lead
+tab = H.table(host)
+queries = [
+    {"s": ("sum", "v"), "by": "k"},                                     # configs[2] / [3]
+    {"s": ("sum", "v"), "by": "k", "where": ("<", "a", 100_000)},       # the metric's shape
+    {"s": ("sum", "v"), "x": ("avg", "b"), "c": ("count", "a"), "m": ("max", "a"), "by": "k", "where": ("<", "a", 500_000)},
+    {"s": ("sum", "v"), "f": ("first", "a"), "by": "k"},                # FIRST values: the whole result on the lead
+    {"s": ("sum", "v"), "by": "ks"},
+]
+def ask(q):
+    d = H.select_dict(q, tab)
+    r = ops.rfx_select(d)
+    assert r and not H.is_error(r), H.error_text(r)
+    assert ops.rfx_last_select_on_gpu() == 1, (q, ops.rfx_ops_last_error())
+    out = H.table_to_numpy(r)
+    ops.rfx_host_drop(r); ops.rfx_host_drop(d)
+    return out
+x = None
+for rep in range(2):
+    for q in queries:
+        got, want = ask(q), rfo.select({"from": host, **q})
+        assert list(got) == list(want)
+        for name in want:
+            g, w = got[name], want[name]
+            assert g.dtype == w.dtype and g.shape == w.shape, name
+            if w.dtype == np.float64 and name in q and q[name][0] in ("sum", "avg"):
+                same_f64(g, w)
+            else:
+                assert np.array_equal(g, w), name
+x = C.c_void_p(ops.rfx_ops_exec())
+assert ops.rfx_exec_shards(x) == SHARDS
+scatter = sum(int(ops.rfx_hip_ctx_stat(C.c_void_p(ops.rfx_exec_ctx(x, s)), 0)) for s in range(SHARDS))
+aggregate = sum(int(ops.rfx_hip_ctx_stat(C.c_void_p(ops.rfx_exec_ctx(x, s)), 2)) for s in range(SHARDS))
+assert scatter >= 2 * 5 * SHARDS and aggregate >= 2 * 5 * SHARDS, (scatter, aggregate)   # the plane kernels ran on EVERY shard for every query
+assert (ops.rfx_exec_stat(x, L.RFX_XSTAT_SLICED) > 0) == bool(os.environ.get("RFX_EXEC_SLICE_SHARDS"))
+print("PLANE-DOOR-OK")
+'''
+
+
+@pytest.mark.parametrize("sliced", [False, True])
+def test_sharded_door_at_plane_path_sizes(built, sliced):
+    """The C door over 4 shards at 1.7e7 rows with the DEFAULT thresholds: every shard runs k_plane_scatter / k_plane_aggregate (and the
+    hash-partitioned planes for sparse keys), the tables merge, and -- sliced -- every shard emits and reads back its range of the 1e6 groups."""
+    env = dict(os.environ, RFX_SHARDS="4", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("RFX_EXEC_FORCE_RCCL", None)
+    env.pop("RFX_EXEC_SLICE_SHARDS", None)
+    if sliced:
+        env["RFX_EXEC_SLICE_SHARDS"] = "1"
+    code = f"ROOT = {ROOT!r}\nSHARDS = 4\n" + _PLANE_DOOR
+    p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0 and "PLANE-DOOR-OK" in p.stdout, p.stdout[-3000:] + p.stderr[-3000:]
+
+
+@pytest.mark.parametrize("seeds", [(0, 6), (100, 106)])
+@pytest.mark.parametrize("shards", [1, 3])
+def test_fuzz_large_collected(built, seeds, shards):
+    """tools/fuzz_large.py's loop as collected seeds: random group-bys at plane-path sizes (2^22 .. 2^24 rows) against the oracle, over one
+    and over three shards of the device."""
+    env = dict(os.environ, FUZZ_SHARDS=str(shards), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_large.py"), str(seeds[0]), str(seeds[1])], env=env, capture_output=True, text=True, timeout=1500)
+    assert p.returncode == 0 and f"done seeds {seeds[0]}..{seeds[1]}: 0 failures" in p.stdout, p.stdout[-3000:] + p.stderr[-3000:]
