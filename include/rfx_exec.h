@@ -186,6 +186,9 @@ enum {
     RFX_XSTAT_NS_TOTAL = 15,     /* rfx_exec_group_by entry to exit, + the fetches */
     RFX_XSTAT_N = 16
 };
+/* what ONE phase hand-over to nshards - 1 worker threads costs the calling thread (microseconds; a bare pool without devices, `reps` empty
+ * phases) -- the planner's own overhead per phase of a sharded query, which a one-GPU box can measure */
+double rfx_exec_probe_handover_us(int nshards, int reps);
 /* on = 1: zero the RFX_XSTAT_NS_* counters and time the phases from now on (a sync per phase); on = 0: stop */
 void rfx_exec_timing(rfx_exec_t *x, int on);
 int64_t rfx_exec_stat(const rfx_exec_t *x, int which);

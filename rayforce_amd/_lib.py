@@ -284,6 +284,7 @@ EXEC_PROTOTYPES = {
     "rfx_exec_groups_fetch_all": (C.c_int, [_exec, _P(Groups), C.c_int, _P(C.c_void_p), _P(C.c_void_p)]),
     "rfx_exec_groups_free": (None, [_exec, _P(Groups)]),
     "rfx_exec_timing": (None, [_exec, C.c_int]),
+    "rfx_exec_probe_handover_us": (C.c_double, [C.c_int, C.c_int]),
     "rfx_exec_join_index": (C.c_int, [_exec, _P(C.c_void_p), _P(C.c_void_p), C.c_int, C.c_int64, C.c_int64, C.c_void_p, _P(C.c_int)]),
     "rfx_exec_stat": (C.c_int64, [_exec, C.c_int]),
     "rfx_exec_forget_scopes": (None, [_exec]),

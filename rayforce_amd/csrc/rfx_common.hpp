@@ -105,6 +105,13 @@ struct rfx_ctx {
     i64 ext_i[8];
 };
 
+// more context state without touching the layout above: ext_p[7] points at this block (made by rfx_hip_ctx_create, zeroed)
+struct CtxExt {
+    i64 emit_g0, emit_gn; // emit window (rfx_hip_ctx_emit_window): gn == 0 = none
+    i64 spare[30];
+};
+static inline CtxExt *rfx_ext(rfx_ctx *c) { return (CtxExt *)c->ext_p[7]; }
+
 int rfx_ws_reserve(rfx_ctx *ctx, size_t bytes);
 int rfx_bitmap_reserve(rfx_ctx *ctx, i64 nrows);
 int rfx_gid_reserve(rfx_ctx *ctx, i64 slots);

@@ -36,6 +36,8 @@ extern "C" int rfx_hip_ctx_create(int device, void *stream, rfx_ctx_t **out) {
     rfx_ctx *c = (rfx_ctx *)calloc(1, sizeof(rfx_ctx));
     RFX_REQUIRE(c != NULL, RFX_ENOMEM, "host calloc failed");
     c->device = device;
+    c->ext_p[7] = calloc(1, sizeof(CtxExt));
+    RFX_REQUIRE(c->ext_p[7] != NULL, RFX_ENOMEM, "host calloc failed");
     c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     c->blocks_per_cu = 2; // tools/probe_hw: 2 workgroups per CU streams fastest (7.0 TB/s)
     if (stream) {
@@ -78,6 +80,7 @@ extern "C" int rfx_hip_ctx_destroy(rfx_ctx_t *c) {
     rfx_io_release(c);
     pool_release(c);
     if (c->ext_p[1]) (void)hipFree(c->ext_p[1]);
+    free(c->ext_p[7]); // CtxExt
     free(c->ext_p[5]); // rfx_chunk_scope's sample memo
     free(c->ext_p[6]); // rfx_hip_where_estimate's
     rfx_plane_release(c);

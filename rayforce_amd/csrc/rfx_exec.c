@@ -42,7 +42,7 @@ struct rfx_exec {
     pthread_mutex_t mu;
     pthread_cond_t cv_go, cv_done;
     uint64_t gen;
-    int pending, stop;
+    int pending, stop, sleepers;
     shard_fn fn;
     void *arg;
     int rcs[RFX_MAX_SHARDS];
@@ -83,16 +83,33 @@ typedef struct {
     int s;
 } worker_arg_t;
 
+/* A phase hand-over is on the query's critical path four to six times (a condition-variable round trip is ~20 us per phase: 0.1 ms of a
+ * 0.8 ms query at 8 devices): workers and the caller SPIN on the generation / pending words for a bounded time first (a phase follows the
+ * previous one within microseconds while a query runs) and only then sleep on the condition variable (between queries). */
+#define SPIN_ROUNDS 4000 /* ~50 us of polling (a `pause` is ~40-60 cycles) */
+static inline void cpu_relax(void) {
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#endif
+}
 static void *worker_main(void *p) {
     worker_arg_t *wa = (worker_arg_t *)p;
     rfx_exec_t *x = wa->x;
     const int s = wa->s;
     free(wa);
-    rfx_hip_ctx_bind_thread(x->ctx[s]);
+    if (x->ctx[s]) rfx_hip_ctx_bind_thread(x->ctx[s]);
     uint64_t seen = 0;
     for (;;) {
+        for (int i = 0; i < SPIN_ROUNDS; i++) {
+            if (__atomic_load_n(&x->gen, __ATOMIC_ACQUIRE) != seen || __atomic_load_n(&x->stop, __ATOMIC_ACQUIRE)) break;
+            cpu_relax();
+        }
         pthread_mutex_lock(&x->mu);
-        while (x->gen == seen && !x->stop) pthread_cond_wait(&x->cv_go, &x->mu);
+        while (x->gen == seen && !x->stop) {
+            x->sleepers++;
+            pthread_cond_wait(&x->cv_go, &x->mu);
+            x->sleepers--;
+        }
         if (x->stop) {
             pthread_mutex_unlock(&x->mu);
             return NULL;
@@ -103,10 +120,12 @@ static void *worker_main(void *p) {
         pthread_mutex_unlock(&x->mu);
         const int rc = fn(arg, s);
         if (rc != RFX_OK) snprintf(x->errs[s], sizeof(x->errs[s]), "shard %d: %s", s, rfx_hip_last_error());
-        pthread_mutex_lock(&x->mu);
         x->rcs[s] = rc;
-        if (--x->pending == 0) pthread_cond_signal(&x->cv_done);
-        pthread_mutex_unlock(&x->mu);
+        if (__atomic_sub_fetch(&x->pending, 1, __ATOMIC_ACQ_REL) == 0) {
+            pthread_mutex_lock(&x->mu); /* (the caller may be asleep on cv_done by now) */
+            pthread_cond_signal(&x->cv_done);
+            pthread_mutex_unlock(&x->mu);
+        }
     }
 }
 
@@ -120,15 +139,18 @@ static int run_shards(rfx_exec_t *x, shard_fn fn, void *arg) {
     pthread_mutex_lock(&x->mu);
     x->fn = fn;
     x->arg = arg;
-    x->pending = x->nshards - 1;
-    x->gen++;
-    pthread_cond_broadcast(&x->cv_go);
+    __atomic_store_n(&x->pending, x->nshards - 1, __ATOMIC_RELEASE);
+    __atomic_store_n(&x->gen, x->gen + 1, __ATOMIC_RELEASE);
+    if (x->sleepers) pthread_cond_broadcast(&x->cv_go);
     pthread_mutex_unlock(&x->mu);
     x->rcs[0] = fn(arg, 0);
     if (x->rcs[0] != RFX_OK) snprintf(x->errs[0], sizeof(x->errs[0]), "shard 0: %s", rfx_hip_last_error());
-    pthread_mutex_lock(&x->mu);
-    while (x->pending) pthread_cond_wait(&x->cv_done, &x->mu);
-    pthread_mutex_unlock(&x->mu);
+    for (int i = 0; i < SPIN_ROUNDS && __atomic_load_n(&x->pending, __ATOMIC_ACQUIRE); i++) cpu_relax();
+    if (__atomic_load_n(&x->pending, __ATOMIC_ACQUIRE)) {
+        pthread_mutex_lock(&x->mu);
+        while (__atomic_load_n(&x->pending, __ATOMIC_ACQUIRE)) pthread_cond_wait(&x->cv_done, &x->mu);
+        pthread_mutex_unlock(&x->mu);
+    }
     for (int s = 0; s < x->nshards; s++)
         if (x->rcs[s] != RFX_OK) {
             snprintf(x->err, sizeof(x->err), "%s", x->errs[s]);
@@ -174,7 +196,7 @@ int rfx_exec_create(rfx_ctx_t *const *ctxs, int nshards, rfx_exec_t **out) {
 int rfx_exec_destroy(rfx_exec_t *x) {
     if (!x) return RFX_OK;
     pthread_mutex_lock(&x->mu);
-    x->stop = 1;
+    __atomic_store_n(&x->stop, 1, __ATOMIC_RELEASE);
     pthread_cond_broadcast(&x->cv_go);
     pthread_mutex_unlock(&x->mu);
     for (int s = 1; s <= x->nthreads; s++) pthread_join(x->th[s], NULL);
@@ -187,6 +209,35 @@ int rfx_exec_destroy(rfx_exec_t *x) {
     return RFX_OK;
 }
 
+/* what one phase hand-over costs the calling thread with `nshards` shards: a pool of nshards - 1 bare worker threads (no device), `reps`
+ * empty phases, microseconds per phase.  bench.py's predicted T(N) charges it per phase of a sharded query. */
+static int ph_nothing(void *arg, int s) { (void)arg; (void)s; return RFX_OK; }
+double rfx_exec_probe_handover_us(int nshards, int reps) {
+    if (nshards < 1 || nshards > RFX_MAX_SHARDS || reps < 1) return -1.0;
+    rfx_exec_t *x = (rfx_exec_t *)calloc(1, sizeof(*x));
+    if (!x) return -1.0;
+    x->nshards = nshards;
+    pthread_mutex_init(&x->mu, NULL);
+    pthread_cond_init(&x->cv_go, NULL);
+    pthread_cond_init(&x->cv_done, NULL);
+    for (int s = 1; s < nshards; s++) {
+        worker_arg_t *wa = (worker_arg_t *)malloc(sizeof(*wa));
+        if (!wa) break;
+        wa->x = x;
+        wa->s = s;
+        if (pthread_create(&x->th[s], NULL, worker_main, wa) != 0) { free(wa); break; }
+        x->nthreads = s;
+    }
+    double us = -1.0;
+    if (x->nthreads == nshards - 1) {
+        for (int i = 0; i < 16; i++) run_shards(x, ph_nothing, NULL);
+        const int64_t t0 = now_ns();
+        for (int i = 0; i < reps; i++) run_shards(x, ph_nothing, NULL);
+        us = (double)(now_ns() - t0) / 1e3 / reps;
+    }
+    rfx_exec_destroy(x);
+    return us;
+}
 int rfx_exec_shards(const rfx_exec_t *x) { return x ? x->nshards : 0; }
 rfx_ctx_t *rfx_exec_ctx(const rfx_exec_t *x, int shard) { return (x && shard >= 0 && shard < x->nshards) ? x->ctx[shard] : NULL; }
 int64_t rfx_exec_stat(const rfx_exec_t *x, int which) { return (x && which >= 0 && which < RFX_XSTAT_N) ? x->stat[which] : -1; }

@@ -814,15 +814,15 @@ __global__ __launch_bounds__(RFX_BLOCK) void k_group_emit_by_group(const EmitArg
 
 extern "C" int rfx_hip_ctx_emit_window(rfx_ctx_t *c, int64_t g0, int64_t n) {
     RFX_REQUIRE(c && g0 >= 0 && n >= 0, RFX_EINVAL, "bad emit window");
-    c->ext_i[3] = g0;
-    c->ext_i[4] = n; // 0: no window
+    rfx_ext(c)->emit_g0 = g0;
+    rfx_ext(c)->emit_gn = n; // 0: no window
     return RFX_OK;
 }
 int rfx_emit_slots(rfx_ctx *c, const EmitArgs &A0) {
     if (A0.slots <= 0 || c->rank_groups == 0) return RFX_OK;
     EmitArgs A = A0;
-    A.g0 = c->ext_i[4] > 0 ? c->ext_i[3] : 0;
-    A.gn = c->ext_i[4] > 0 ? c->ext_i[4] : (i64)0x7FFFFFFFFFFFFFFFLL;
+    A.g0 = rfx_ext(c)->emit_gn > 0 ? rfx_ext(c)->emit_g0 : 0;
+    A.gn = rfx_ext(c)->emit_gn > 0 ? rfx_ext(c)->emit_gn : (i64)0x7FFFFFFFFFFFFFFFLL;
     if (c->rank_groups >= (1LL << 22) && rfx_ws_reserve(c, (size_t)c->rank_groups * 8) == RFX_OK) {
         i64 *perm = (i64 *)c->d_ws;
         const int grid = rfx_grid(c) * 4;
