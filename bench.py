@@ -519,14 +519,18 @@ def door_phases(ops, H, d, steps=5):
     x = C.c_void_p(ops.rfx_ops_exec())
     ops.rfx_exec_timing(x, 1)
     t0 = time.perf_counter()
+    walls = []
     for _ in range(steps):
+        t1 = time.perf_counter()
         r = ops.rfx_select(d)
+        walls.append((time.perf_counter() - t1) * 1e3)
         assert r and not H.is_error(r), H.error_text(r)
         ops.rfx_host_drop(r)
     wall = (time.perf_counter() - t0) * 1e3 / steps
     out = {k: int(ops.rfx_exec_stat(x, i)) / 1e6 / steps for k, i in L.RFX_XSTAT_PHASES}
     ops.rfx_exec_timing(x, 0)
     out["rfx_select_wall"] = wall  # + the dict walk, the plan and the host table's construction around the planner
+    out["rfx_select_wall_min_max"] = [min(walls), max(walls)]
     return out
 
 
@@ -636,7 +640,7 @@ def predicted_scaling(name, eng, steps=5):
         t = ph["scope"] + ph["pass"] + merge + ph["rank"] + (ph["emit"] + ph["fetch"]) / n + host + handover
         if n == 1:
             base = t
-        out["per_n"][str(n)] = {"rows_per_device": rows, "groups": groups, "measured_ms": {k: round(v, 4) for k, v in ph.items()}, "merge_model_ms": round(merge, 4),
+        out["per_n"][str(n)] = {"rows_per_device": rows, "groups": groups, "measured_ms": {k: round(v, 4) for k, v in ph.items() if not isinstance(v, list)}, "merge_model_ms": round(merge, 4),
                                 "host_ms": round(host, 4), "handover_ms": round(handover, 4), "T_ms": round(t, 4), "speedup": round(base / t, 3)}
     return out
 
@@ -1135,7 +1139,7 @@ def main():
             return None if v is None else round(float(v), 3)
         compact = {"summary": name, "door_ms": r3(door["ms_per_step"]) if door else None, "engine_ms": r3(main_r["ms_per_step"]), "frac": r3(head["frac"]),
                    "steps_ms": {k: r3(v) for k, v in door["steps_ms"].items()} if door else None,
-                   "phases_ms": {k: r3(v) for k, v in door["phases_ms"].items()} if door and door.get("phases_ms") else None,
+                   "phases_ms": {k: r3(v) for k, v in door["phases_ms"].items() if not isinstance(v, list)} if door and door.get("phases_ms") else None,
                    "also": {k: ([r3(v.get("ms_per_step")), r3(v.get("frac"))] + ([r3(v["rfx_select_ms_per_step"])] if "rfx_select_ms_per_step" in v else [])
                                 if "error" not in v else "error") for k, v in also.items()},
                    "T_N": {n: [v["T_ms"], v["speedup"]] for n, v in predicted["per_n"].items()} if predicted and "per_n" in predicted else None,

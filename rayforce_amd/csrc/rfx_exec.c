@@ -60,6 +60,7 @@ struct rfx_exec {
     int nspec_wide, wide_ring;
     int64_t stat[RFX_XSTAT_N];
     int timing;       /* rfx_exec_timing: per-phase wall time into stat[RFX_XSTAT_NS_*], a sync at every phase end */
+    int no_fused_rank; /* RFX_NO_FUSED_RANK=1: rank and emit as the ten launches of rounds 1-4 (A/B, and the form tables beyond RFX_RANK_FUSED_MAX slots take) */
     int slice_shards; /* RFX_EXEC_SLICE_SHARDS=1: every SHARD owns a slice of a sliced result, not only every device's lead (how the sharded
                        * tail runs on a one-GPU box: the merged tables are copied to the shards beside their lead first) */
     char err[512];
@@ -165,6 +166,7 @@ int rfx_exec_create(rfx_ctx_t *const *ctxs, int nshards, rfx_exec_t **out) {
     if (!x) return RFX_ENOMEM;
     x->nshards = nshards;
     x->slice_shards = getenv("RFX_EXEC_SLICE_SHARDS") != NULL;
+    x->no_fused_rank = getenv("RFX_NO_FUSED_RANK") != NULL;
     for (int s = 0; s < nshards; s++) {
         if (!ctxs[s]) { free(x); return RFX_EINVAL; }
         x->ctx[s] = ctxs[s];
@@ -352,6 +354,7 @@ typedef struct {
     int64_t groups;
     void *dout, *dfirst;
     int64_t g0, gn;              /* the slice of the groups this shard emitted (the whole result: 0, groups) */
+    int64_t gstride;             /* cells between two columns of dout (gn, or the bound the one-launch rank + emit sized them by) */
     void *kc[RFX_MAX_KEYS];      /* sliced result, several keys: this slice's key columns */
     int64_t t_rank;              /* timing: when this shard's ranking was done */
     /* where */
@@ -1078,36 +1081,59 @@ static int ph_rank_emit(void *arg, int s) {
     if (si < 0 && !G->all_rank) return RFX_OK;
     shard_t *h = &G->sh[s];
     rfx_ctx_t *c = x->ctx[s];
-    int rc = G->dense ? rfx_hip_group_rank(c, &h->gt, G->total_rows, &h->groups) : rfx_hip_hash_rank(c, &h->ht, G->total_rows, &h->groups);
-    if (x->timing) h->t_rank = now_ns();
-    h->g0 = h->gn = 0;
-    if (rc != RFX_OK || h->groups == 0) return rc;
-    const int64_t g = h->groups;
-    int64_t g0 = 0, gn = g;
-    if (G->nsl > 1) { /* this owner's range of the groups */
-        g0 = (int64_t)((__int128)g * si / G->nsl);
-        gn = (int64_t)((__int128)g * (si + 1) / G->nsl) - g0;
-    }
-    h->g0 = g0;
-    h->gn = gn;
-    if (gn == 0) return RFX_OK; /* (fewer groups than slices) */
-    if ((rc = rfx_hip_malloc(c, &h->dout, (size_t)(G->na + 1) * (size_t)gn * 8)) != RFX_OK) return rc;
-    if ((G->want_first || !G->dense) && (rc = rfx_hip_malloc(c, &h->dfirst, (size_t)gn * 8)) != RFX_OK) return rc;
-    void *ptrs[RFX_MAX_AGGS];
-    for (int a = 0; a < G->na; a++) ptrs[a] = (int64_t *)h->dout + (size_t)(a + 1) * (size_t)gn;
     /* FIRST: a first row is owned by the shard whose rows [row0, row0 + nloc) hold it (nloc 0 = the one shard owns every row); a shard
      * without rows owns none (a row offset no first row reaches) */
     const int multi = G->S > 1 || G->exch;
     const int64_t nloc = multi ? (h->nrows > 0 ? h->nrows : 1) : 0, r0 = (multi && h->nrows == 0) ? INF_I64 : h->row0;
-    if (G->nsl > 1 && (rc = rfx_hip_ctx_emit_window(c, g0, gn)) != RFX_OK) return rc;
-    rc = G->dense ? rfx_hip_group_emit_sharded(c, h->aggs, &h->gt, r0, nloc, (int64_t *)h->dout, (int64_t *)h->dfirst, ptrs)
-                  : rfx_hip_hash_emit_sharded(c, h->aggs, &h->ht, r0, nloc, (int64_t *)h->dout, (int64_t *)h->dfirst, ptrs);
-    if (G->nsl > 1) rfx_hip_ctx_emit_window(c, 0, 0);
-    if (rc != RFX_OK) return rc;
+    const int64_t slots = G->dense ? (int64_t)G->range : G->cap + 1;
+    const int nsl = G->nsl > 1 ? G->nsl : 1, sl = G->nsl > 1 ? si : 0;
+    void *ptrs[RFX_MAX_AGGS];
+    int rc;
+    h->g0 = h->gn = 0;
+    if (!x->no_fused_rank && slots <= RFX_RANK_FUSED_MAX) {
+        /* ONE launch: the outputs are sized before the group count is known -- groups <= min(slots, selected rows), a slice its share + 1 */
+        int64_t bound = slots < G->seen ? slots : G->seen;
+        if (bound < 1) bound = 1;
+        const int64_t cap = bound / nsl + 1;
+        if ((rc = rfx_hip_malloc(c, &h->dout, (size_t)(G->na + 1) * (size_t)cap * 8)) != RFX_OK) return rc;
+        if ((G->want_first || !G->dense) && (rc = rfx_hip_malloc(c, &h->dfirst, (size_t)cap * 8)) != RFX_OK) return rc;
+        for (int a = 0; a < G->na; a++) ptrs[a] = (int64_t *)h->dout + (size_t)(a + 1) * (size_t)cap;
+        h->gstride = cap;
+        rc = G->dense ? rfx_hip_group_rank_emit(c, h->aggs, &h->gt, G->total_rows, r0, nloc, nsl, sl, cap, (int64_t *)h->dout, (int64_t *)h->dfirst, ptrs, &h->groups)
+                      : rfx_hip_hash_rank_emit(c, h->aggs, &h->ht, G->total_rows, r0, nloc, nsl, sl, cap, (int64_t *)h->dout, (int64_t *)h->dfirst, ptrs, &h->groups);
+        if (x->timing) h->t_rank = now_ns();
+        if (rc != RFX_OK) return rc;
+        const int64_t g = h->groups;
+        h->g0 = nsl > 1 ? (int64_t)((__int128)g * sl / nsl) : 0;
+        h->gn = nsl > 1 ? (int64_t)((__int128)g * (sl + 1) / nsl) - h->g0 : g;
+        if (g == 0 || h->gn == 0) return RFX_OK;
+    } else {
+        rc = G->dense ? rfx_hip_group_rank(c, &h->gt, G->total_rows, &h->groups) : rfx_hip_hash_rank(c, &h->ht, G->total_rows, &h->groups);
+        if (x->timing) h->t_rank = now_ns();
+        if (rc != RFX_OK || h->groups == 0) return rc;
+        const int64_t g = h->groups;
+        int64_t g0 = 0, gn = g;
+        if (nsl > 1) { /* this owner's range of the groups */
+            g0 = (int64_t)((__int128)g * sl / nsl);
+            gn = (int64_t)((__int128)g * (sl + 1) / nsl) - g0;
+        }
+        h->g0 = g0;
+        h->gn = gn;
+        h->gstride = gn;
+        if (gn == 0) return RFX_OK; /* (fewer groups than slices) */
+        if ((rc = rfx_hip_malloc(c, &h->dout, (size_t)(G->na + 1) * (size_t)gn * 8)) != RFX_OK) return rc;
+        if ((G->want_first || !G->dense) && (rc = rfx_hip_malloc(c, &h->dfirst, (size_t)gn * 8)) != RFX_OK) return rc;
+        for (int a = 0; a < G->na; a++) ptrs[a] = (int64_t *)h->dout + (size_t)(a + 1) * (size_t)gn;
+        if (nsl > 1 && (rc = rfx_hip_ctx_emit_window(c, g0, gn)) != RFX_OK) return rc;
+        rc = G->dense ? rfx_hip_group_emit_sharded(c, h->aggs, &h->gt, r0, nloc, (int64_t *)h->dout, (int64_t *)h->dfirst, ptrs)
+                      : rfx_hip_hash_emit_sharded(c, h->aggs, &h->ht, r0, nloc, (int64_t *)h->dout, (int64_t *)h->dfirst, ptrs);
+        if (nsl > 1) rfx_hip_ctx_emit_window(c, 0, 0);
+        if (rc != RFX_OK) return rc;
+    }
     if (G->nsl > 1 && G->first_pass && G->nkeys > 1) /* this slice's key columns, decoded from its composite keys (core/query.c:110-135) */
         for (int k = 0; k < G->nkeys; k++) {
-            if ((rc = rfx_hip_malloc(c, &h->kc[k], (size_t)gn * 8)) != RFX_OK) return rc;
-            if ((rc = rfx_hip_composite_decode(c, (const int64_t *)h->dout, gn, G->kmins[k], G->kmults[k], G->kmaxs[k] - G->kmins[k] + 1, (int64_t *)h->kc[k])) != RFX_OK) return rc;
+            if ((rc = rfx_hip_malloc(c, &h->kc[k], (size_t)h->gn * 8)) != RFX_OK) return rc;
+            if ((rc = rfx_hip_composite_decode(c, (const int64_t *)h->dout, h->gn, G->kmins[k], G->kmults[k], G->kmaxs[k] - G->kmins[k] + 1, (int64_t *)h->kc[k])) != RFX_OK) return rc;
         }
     /* FIRST values merge across the shards next: their streams must be idle.  A slice is read back on its own stream (fetch_all) and one
      * shard goes on in stream order: no wait (the tables go back to the pool of the stream that read them) */
@@ -1124,7 +1150,7 @@ static int ph_first_local(void *arg, int s) {
         if (x->lead[t] != s) continue;
         for (int a = 0; a < G->na; a++) {
             if (h->aggs[a].kind != RFX_AGG_FIRST) continue;
-            const int rc = rfx_hip_add_i64(x->ctx[s], (int64_t *)h->dout + (size_t)(a + 1) * (size_t)g, (const int64_t *)G->sh[t].dout + (size_t)(a + 1) * (size_t)g, g);
+            const int rc = rfx_hip_add_i64(x->ctx[s], (int64_t *)h->dout + (size_t)(a + 1) * (size_t)h->gstride, (const int64_t *)G->sh[t].dout + (size_t)(a + 1) * (size_t)G->sh[t].gstride, g);
             if (rc != RFX_OK) return rc;
         }
     }
@@ -1143,12 +1169,12 @@ static int merge_first_values(gq_t *G) {
             int64_t *bufs[RFX_MAX_SHARDS];
             for (int d = 0; d < x->ndev; d++) {
                 leads[d] = x->ctx[x->devlead[d]];
-                bufs[d] = (int64_t *)G->sh[x->devlead[d]].dout + (size_t)(a + 1) * (size_t)g;
+                bufs[d] = (int64_t *)G->sh[x->devlead[d]].dout + (size_t)(a + 1) * (size_t)G->sh[x->devlead[d]].gstride;
             }
             rc = rfx_dist_allreduce_i64_all(leads, x->ndev, bufs, g, 0);
             x->stat[RFX_XSTAT_MERGES_RCCL]++;
         }
-        if (rc == RFX_OK && G->exch) rc = xp_allreduce(x, (int64_t *)G->sh[0].dout + (size_t)(a + 1) * (size_t)g, g, 0, 0);
+        if (rc == RFX_OK && G->exch) rc = xp_allreduce(x, (int64_t *)G->sh[0].dout + (size_t)(a + 1) * (size_t)G->sh[0].gstride, g, 0, 0);
     }
     if (rc == RFX_OK && (x->comm_all || G->exch)) rc = run_shards(x, ph_sync, G);
     if (rc != RFX_OK && !x->err[0]) snprintf(x->err, sizeof(x->err), "%s", rfx_hip_last_error());
@@ -1565,7 +1591,7 @@ static int gb_emit(gq_t *G) {
             sl->shard = s;
             sl->g0 = h->g0;
             sl->n = h->gn;
-            for (int a = 0; a < na; a++) sl->d_results[G->a0 + a] = h->gn ? (int64_t *)h->dout + (size_t)(a + 1) * (size_t)h->gn : NULL;
+            for (int a = 0; a < na; a++) sl->d_results[G->a0 + a] = h->gn ? (int64_t *)h->dout + (size_t)(a + 1) * (size_t)h->gstride : NULL;
             own_on(out, h->dout, s);
             if (G->first_pass) {
                 sl->d_keys = (int64_t *)h->dout;
@@ -1599,7 +1625,7 @@ static int gb_emit(gq_t *G) {
         if (G->first_pass) out->groups = g;
         else if (out->groups != g) { snprintf(x->err, sizeof(x->err), "rfx_exec: two passes of one query disagree on the groups"); rc = RFX_ESTATE; return rc; }
         if (g > 0) {
-            for (int a = 0; a < na; a++) out->d_results[G->a0 + a] = (int64_t *)h->dout + (size_t)(a + 1) * (size_t)g;
+            for (int a = 0; a < na; a++) out->d_results[G->a0 + a] = (int64_t *)h->dout + (size_t)(a + 1) * (size_t)h->gstride;
             own(out, h->dout);
             if (G->first_pass) {
                 out->d_keys = (int64_t *)h->dout;
