@@ -253,6 +253,9 @@ int rfx_hip_rtc_prewarm_where(const rfx_pred_t *preds, int npred, int logic);
 /* Host-to-device at link speed from ANY host memory (heap vector, mmapped column file): chunks are staged through pinned
  * buffers by worker threads while the previous chunk is in flight.  (syncs) */
 int rfx_hip_h2d_pipelined(rfx_ctx_t *ctx, void *d_dst, const void *src, size_t bytes);
+/* device -> host for LARGE blocks (>= 64 MB; smaller ones take rfx_hip_d2h): pinned staging, up to four 32 MB chunks in flight, the destination written by
+ * several host threads -- the first touch of a freshly allocated result vector's pages happens in parallel instead of inside one pageable copy.  (syncs) */
+int rfx_hip_d2h_pipelined(rfx_ctx_t *ctx, void *dst, const void *d_src, size_t bytes);
 /* RayforceDB column files (16-byte header {mmod 0xfd, order, type, attrs, rc, len} + raw payload, core/binary.c:263-311):
  * rfx_column_file_stat reads type (the reference's vector type code) and length -- host only, no device needed;
  * rfx_hip_column_file_load maps the file and moves its nrows 8-byte elements into d_dst with the pipelined path.  (syncs) */
@@ -388,14 +391,6 @@ int rfx_hip_group_emit(rfx_ctx_t *ctx, const rfx_agg_t *aggs, const rfx_group_ta
  * result column over the GPUs (as integers) yields the value -- exactly one GPU contributes.  Everything else as rfx_hip_group_emit. */
 int rfx_hip_group_emit_sharded(rfx_ctx_t *ctx, const rfx_agg_t *aggs, const rfx_group_tables_t *t, int64_t row0, int64_t local_rows,
                                int64_t *d_keys, int64_t *d_first_ids, void *const *d_results);
-/* Rank + emit as ONE launch (tables of at most RFX_RANK_FUSED_MAX slots): the steps of rfx_hip_group_rank and rfx_hip_group_emit_sharded as phases
- * of one persistent kernel, the group count back in one 8-byte copy (syncs).  The outputs are sized BEFORE the count is known: `out_cap`
- * cells per column (an upper bound of the window's groups: min(slots, selected rows) / nsl rounded up; RFX_ELIMIT when it did not hold).
- * nsl > 1: only the groups [g * si / nsl, g * (si + 1) / nsl) are written, from cell 0 on (the emit window, computed on the device).
- * rfx_hip_group_ids_dense / the join probes find the slot -> group id table as after rfx_hip_group_rank. */
-#define RFX_RANK_FUSED_MAX (1 << 23)
-int rfx_hip_group_rank_emit(rfx_ctx_t *ctx, const rfx_agg_t *aggs, const rfx_group_tables_t *t, int64_t total_rows, int64_t row0, int64_t local_rows,
-                            int nsl, int si, int64_t out_cap, int64_t *d_keys, int64_t *d_first_ids, void *const *d_results, int64_t *ngroups);
 /* Emit WINDOW: until it is reset (n = 0), rfx_hip_group_emit(_sharded) / rfx_hip_hash_emit(_sharded) on this context write only the groups
  * [g0, g0 + n) -- group g at cell g - g0 of every output, which then need n cells.  The sharded tail of a group-by: after the merge every
  * device holds the whole tables, ranks them (the same order everywhere) and emits ITS slice of the groups, which its own host thread
@@ -424,8 +419,6 @@ int rfx_hip_hash_emit(rfx_ctx_t *ctx, const rfx_agg_t *aggs, const rfx_hash_tabl
                       int64_t *d_first_ids, void *const *d_results);
 int rfx_hip_hash_emit_sharded(rfx_ctx_t *ctx, const rfx_agg_t *aggs, const rfx_hash_tables_t *t, int64_t row0, int64_t local_rows,
                               int64_t *d_keys, int64_t *d_first_ids, void *const *d_results);
-int rfx_hip_hash_rank_emit(rfx_ctx_t *ctx, const rfx_agg_t *aggs, const rfx_hash_tables_t *t, int64_t total_rows, int64_t row0, int64_t local_rows,
-                           int nsl, int si, int64_t out_cap, int64_t *d_keys, int64_t *d_first_ids, void *const *d_results, int64_t *ngroups);
 
 /* ---- per-row group ids (INDEX_TYPE_IDS payload, core/index.c:2069-2089) -- only when a caller wants it ---- */
 int rfx_hip_group_ids_dense(rfx_ctx_t *ctx, const int64_t *d_key, int64_t nrows, const rfx_group_tables_t *t,

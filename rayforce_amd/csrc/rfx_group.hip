@@ -11,7 +11,6 @@
 // always-correct fallback in this file, direct device-scope atomics.
 // The rank step reuses `where`'s bitmap machinery: mark bit first[slot] in a 1-bit-per-row bitmap, prefix-popcount
 // it, and the rank of a slot's first row IS its group id (first-occurrence order, bit-exact with the reference).
-#include <pthread.h>
 #include "rfx_group_common.hpp"
 
 int rfx_group_part_accumulate(rfx_ctx *c, const Plan &P, int key_idx, const rfx_group_tables_t *t); // rfx_group_part.hip
@@ -840,243 +839,10 @@ int rfx_emit_slots(rfx_ctx *c, const EmitArgs &A0) {
     return RFX_OK;
 }
 
-// ---------------- rank + emit as ONE launch (round 5) ----------------
-// The ranking above is nine launches and a round trip, the emit a tenth: ~0.14 ms of a 1e6-group query whose kernels do 60 us of work --
-// a fixed cost at any device count (the tail of the sharded group-by).  k_rank_emit_fused runs the same steps -- bound, clear, mark, chunk
-// counts, scan, slot -> group id, emit -- as phases of ONE persistent launch of RANK_FUSED_WGS co-resident workgroups separated by a grid
-// barrier (one monotonic arrival counter, agent-scope release / acquire around it: an XCD's L2 is written back and invalidated there,
-// which is what makes the other XCDs' plain stores visible).  The host learns the group count from ONE 8-byte copy after the launch, so
-// the outputs are sized by an upper bound (`out_cap` cells a column) and the emit WINDOW of a sliced result -- groups
-// [g * si / nsl, g * (si + 1) / nsl) -- is computed by the kernel itself once it knows g.
-#define RANK_FUSED_WGS 128
-#define RANK_FUSED_BLOCK 256
-struct RankCtl {
-    i64 bound;    // chunks up to the last first row
-    i64 total;    // groups
-    unsigned bar; // grid barrier: arrivals so far
-    unsigned _pad;
-    i64 wg_sum[RANK_FUSED_WGS];
-};
-__device__ __forceinline__ void rank_grid_barrier(RankCtl *ctl, unsigned nwg, unsigned &epoch) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); // every wave: its stores are out of this XCD's L2 before anyone is told
-    __syncthreads();
-    epoch += nwg;
-    if (threadIdx.x == 0) {
-        __hip_atomic_fetch_add(&ctl->bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        while (__hip_atomic_load(&ctl->bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < epoch) __builtin_amdgcn_s_sleep(2);
-    }
-    __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); // every wave: what its caches held of the other workgroups' data is dropped
-}
-__global__ __launch_bounds__(RANK_FUSED_BLOCK) void k_rank_emit_fused(const EmitArgs A0, i64 row_base, u64 *__restrict__ bitmap, i64 nchunks_cap,
-                                                                      i64 *__restrict__ chunk_off, i64 *__restrict__ gid, RankCtl *__restrict__ ctl,
-                                                                      int nsl, int si, i64 out_cap, int *__restrict__ overflow) {
-    __shared__ i64 red[RANK_FUSED_BLOCK];
-    __shared__ i64 wg_off[RANK_FUSED_WGS + 1];
-    const unsigned nwg = gridDim.x;
-    const int tid = threadIdx.x;
-    const i64 gtid = blockIdx.x * (i64)RANK_FUSED_BLOCK + tid, gsz = (i64)nwg * RANK_FUSED_BLOCK;
-    const u64 *__restrict__ first = A0.first;
-    const i64 slots = A0.slots;
-    unsigned epoch = 0;
-    // ---- 1: chunks up to the last first row
-    {
-        i64 mx = 0;
-        for (i64 i = gtid; i < slots; i += gsz) {
-            const u64 f = first[i];
-            if (f == (u64)RFX_INF_I64_D) continue;
-            const i64 q = (i64)((f - (u64)row_base) >> 9) + 1;
-            mx = q > mx ? q : mx;
-        }
-        red[tid] = mx;
-        __syncthreads();
-        for (int s = RANK_FUSED_BLOCK / 2; s >= 1; s >>= 1) {
-            if (tid < s) red[tid] = red[tid + s] > red[tid] ? red[tid + s] : red[tid];
-            __syncthreads();
-        }
-        if (tid == 0 && red[0] > 0) atomicMax((long long *)&ctl->bound, (long long)red[0]);
-    }
-    rank_grid_barrier(ctl, nwg, epoch);
-    i64 nch = __hip_atomic_load(&ctl->bound, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    nch = nch < nchunks_cap ? nch : nchunks_cap;
-    // ---- 2: clear the bitmap that far
-    for (i64 i = gtid; i < nch * 8; i += gsz) bitmap[i] = 0;
-    rank_grid_barrier(ctl, nwg, epoch);
-    // ---- 3: mark the first rows
-    for (i64 i = gtid; i < slots; i += gsz) {
-        const u64 f = first[i];
-        if (f == (u64)RFX_INF_I64_D) continue;
-        u64 w;
-        unsigned b;
-        bitpos(f - (u64)row_base, &w, &b);
-        atomicOr((unsigned long long *)&bitmap[w], 1ULL << b);
-    }
-    rank_grid_barrier(ctl, nwg, epoch);
-    // ---- 4: popcount per chunk, exclusive prefix inside this workgroup's contiguous range of chunks, the range's total
-    const i64 per = (nch + nwg - 1) / nwg, q0 = (i64)blockIdx.x * per, q1 = q0 + per < nch ? q0 + per : nch;
-    {
-        i64 carry = 0;
-        for (i64 base = q0; base < q1; base += RANK_FUSED_BLOCK) {
-            const i64 q = base + tid;
-            i64 c = 0;
-            if (q < q1) {
-                const u64 *w = bitmap + q * 8;
-#pragma unroll
-                for (int i = 0; i < 8; i++) c += __popcll(w[i]);
-            }
-            red[tid] = c;
-            __syncthreads();
-            for (int s = 1; s < RANK_FUSED_BLOCK; s <<= 1) { // inclusive scan (Hillis-Steele over 256 cells)
-                const i64 add = tid >= s ? red[tid - s] : 0;
-                __syncthreads();
-                red[tid] += add;
-                __syncthreads();
-            }
-            if (q < q1) chunk_off[q] = carry + red[tid] - c;
-            carry += red[RANK_FUSED_BLOCK - 1];
-            __syncthreads();
-        }
-        if (tid == 0) ctl->wg_sum[blockIdx.x] = carry;
-    }
-    rank_grid_barrier(ctl, nwg, epoch);
-    // ---- the ranges' offsets (every workgroup for itself: <= 128 values), the group count, this device's window of the groups
-    if (tid == 0) {
-        i64 run = 0;
-        for (unsigned w = 0; w < nwg; w++) {
-            wg_off[w] = run;
-            run += __hip_atomic_load(&ctl->wg_sum[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        wg_off[nwg] = run;
-        if (blockIdx.x == 0) ctl->total = run;
-    }
-    __syncthreads();
-    const i64 groups = wg_off[nwg];
-    EmitArgs A = A0;
-    A.g0 = 0;
-    A.gn = groups;
-    if (nsl > 1) {
-        A.g0 = (i64)((__int128)groups * si / nsl);
-        A.gn = (i64)((__int128)groups * (si + 1) / nsl) - A.g0;
-    }
-    if (A.gn > out_cap) { // the caller's bound did not hold: nothing is written, the host hears of it
-        if (gtid == 0) *overflow = 1;
-        A.gn = 0;
-    }
-    // ---- 5: slot -> group id, and the group's result cells where it falls into the window
-    for (i64 i = gtid; i < slots; i += gsz) {
-        const u64 f = first[i];
-        if (f == (u64)RFX_INF_I64_D) {
-            gid[i] = -1;
-            continue;
-        }
-        const u64 row = f - (u64)row_base;
-        const u64 q = row >> 9;
-        const unsigned within = (unsigned)(row & 511);
-        const unsigned gq = within >> 7, r = within & 127, lane = r >> 1, par = r & 1;
-        const u64 *w = bitmap + q * 8;
-        i64 rank = chunk_off[q] + wg_off[per > 0 ? (i64)q / per : 0];
-        for (unsigned gg = 0; gg < gq; gg++) rank += __popcll(w[2 * gg]) + __popcll(w[2 * gg + 1]);
-        const u64 below = lane ? (~0ULL >> (64 - lane)) : 0ULL;
-        rank += __popcll(w[2 * gq] & below) + __popcll(w[2 * gq + 1] & below);
-        if (par) rank += (i64)((w[2 * gq] >> lane) & 1ULL);
-        gid[i] = rank;
-        const i64 g = rank - A.g0;
-        if ((u64)g >= (u64)A.gn) continue;
-        if (A.out_keys) A.out_keys[g] = A.keys ? (i64)A.keys[i] : A.kmin + i;
-        if (A.out_first) A.out_first[g] = (i64)f;
-        for (int a = 0; a < A.nagg; a++) {
-            if (!A.out[a]) continue;
-            if (A.kinds[a] == RFX_AGG_FIRST) {
-                const i64 lr = (i64)f - A.row0;
-                A.out[a][g] = (A.col[a] && lr >= 0 && (A.nloc == 0 || lr < A.nloc)) ? A.col[a][lr] : 0ULL;
-            } else A.out[a][g] = group_final(A.kinds[a], A.f64s[a], A.acc[a][i], A.cnt[a] ? A.cnt[a][i] : 0ULL, A.skips[a]);
-        }
-    }
-}
-// one persistent launch at a time per device and process: the kernel's workgroups wait for each other (shards that share a device would
-// otherwise compete for the residency each launch needs whole); the lock spans launch -> group count back
-static pthread_mutex_t g_rank_fused_mu[64] = {PTHREAD_MUTEX_INITIALIZER};
-static pthread_once_t g_rank_fused_once = PTHREAD_ONCE_INIT;
-static void rank_fused_init(void) {
-    for (int i = 0; i < 64; i++) pthread_mutex_init(&g_rank_fused_mu[i], NULL);
-}
-int rfx_rank_emit_fused(rfx_ctx *c, const EmitArgs &A, i64 total_rows, int nsl, int si, i64 out_cap, i64 *ngroups) {
-    c->pc_bitmap = 0;
-    c->where_n = -1;
-    *ngroups = 0;
-    c->rank_groups = 0;
-    RFX_REQUIRE(total_rows >= 0 && nsl >= 1 && si >= 0 && si < nsl && out_cap >= 0, RFX_EINVAL, "rank_emit: bad argument");
-    const i64 nchunks = (total_rows + RFX_CHUNK - 1) / RFX_CHUNK;
-    int rc = rfx_bitmap_reserve(c, nchunks * RFX_CHUNK);
-    if (rc != RFX_OK) return rc;
-    if (c->blksum_cap < (size_t)nchunks + 2) {
-        RFX_HIP_CHECK(hipStreamSynchronize(c->stream));
-        if (c->d_blksum) RFX_HIP_CHECK(hipFree(c->d_blksum));
-        c->d_blksum = NULL;
-        c->blksum_cap = 0;
-        RFX_HIP_CHECK(hipMalloc((void **)&c->d_blksum, ((size_t)nchunks + 2) * 8));
-        c->blksum_cap = (size_t)nchunks + 2;
-    }
-    rc = rfx_gid_reserve(c, A.slots);
-    if (rc != RFX_OK) return rc;
-    if (nchunks == 0 || A.slots == 0) return RFX_OK;
-    rc = rfx_ws_reserve(c, sizeof(RankCtl) + 64);
-    if (rc != RFX_OK) return rc;
-    RankCtl *ctl = (RankCtl *)c->d_ws;
-    int *overflow = (int *)((char *)c->d_ws + sizeof(RankCtl));
-    pthread_once(&g_rank_fused_once, rank_fused_init);
-    pthread_mutex_t *mu = &g_rank_fused_mu[c->device & 63];
-    pthread_mutex_lock(mu);
-    hipError_t e = hipMemsetAsync(ctl, 0, sizeof(RankCtl) + 64, c->stream);
-    if (e == hipSuccess) {
-        int nwg = c->num_cus < RANK_FUSED_WGS ? c->num_cus : RANK_FUSED_WGS;
-        hipLaunchKernelGGL(k_rank_emit_fused, dim3(nwg), dim3(RANK_FUSED_BLOCK), 0, c->stream, A, (i64)0, c->d_bitmap, nchunks, c->d_blksum, c->d_gid, ctl, nsl, si,
-                           out_cap, overflow);
-        e = hipGetLastError();
-    }
-    i64 *h = (i64 *)c->h_pin;
-    if (e == hipSuccess) e = hipMemcpyAsync(h, &ctl->total, 8, hipMemcpyDeviceToHost, c->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(h + 1, overflow, 4, hipMemcpyDeviceToHost, c->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    pthread_mutex_unlock(mu);
-    RFX_HIP_CHECK(e);
-    c->rank_groups = h[0];
-    *ngroups = h[0];
-    RFX_REQUIRE((int)h[1] == 0, RFX_ELIMIT, "rank_emit: more groups in the window than the output columns hold");
-    return RFX_OK;
-}
-static void emit_args_dense(EmitArgs &A, const rfx_agg_t *aggs, const rfx_group_tables_t *t, int64_t row0, int64_t local_rows, int64_t *d_keys, int64_t *d_first_ids,
-                            void *const *d_results) {
-    memset(&A, 0, sizeof(A));
-    A.kmin = t->kmin;
-    A.slots = t->range;
-    A.nagg = t->nagg;
-    A.first = (const u64 *)t->d_first;
-    A.out_keys = (i64 *)d_keys;
-    A.out_first = (i64 *)d_first_ids;
-    A.row0 = row0;
-    A.nloc = local_rows;
-    for (int a = 0; a < t->nagg; a++) {
-        A.kinds[a] = aggs[a].kind;
-        A.f64s[a] = rfx_agg_input_type(&aggs[a]) == RFX_F64;
-        A.skips[a] = aggs[a].xop != RFX_X_NONE || aggs[a].nxnodes > 0;
-        A.acc[a] = (const u64 *)t->d_acc[a];
-        A.cnt[a] = (const u64 *)t->d_cnt[a];
-        A.col[a] = (const u64 *)aggs[a].d_col;
-        A.out[a] = d_results ? (u64 *)d_results[a] : NULL;
-    }
-}
-extern "C" int rfx_hip_group_rank_emit(rfx_ctx_t *c, const rfx_agg_t *aggs, const rfx_group_tables_t *t, int64_t total_rows, int64_t row0, int64_t local_rows,
-                                       int nsl, int si, int64_t out_cap, int64_t *d_keys, int64_t *d_first_ids, void *const *d_results, int64_t *ngroups) {
-    RFX_REQUIRE(c && t && ngroups, RFX_EINVAL, "NULL argument");
-    RFX_REQUIRE(local_rows >= 0, RFX_EINVAL, "local_rows < 0");
-    int rc = check_tables(aggs, t);
-    if (rc != RFX_OK) return rc;
-    RFX_REQUIRE(t->range >= 1 && t->range <= RFX_RANK_FUSED_MAX, RFX_EINVAL, "rank_emit: 1 .. RFX_RANK_FUSED_MAX slots");
-    EmitArgs A;
-    emit_args_dense(A, aggs, t, row0, local_rows, d_keys, d_first_ids, d_results);
-    return rfx_rank_emit_fused(c, A, total_rows, nsl, si, out_cap, (i64 *)ngroups);
-}
+// (Round 5 built rank + emit as ONE persistent launch -- bound, clear, mark, counts, scan, slot ids and emit as phases behind a grid barrier --
+// and withdrew it: what one workgroup hands another between two phases must bypass the XCDs' non-coherent L2s (agent-scope atomic loads /
+// stores) or pay a cache-wide write-back + invalidate per barrier; either way the launch took 0.22-0.28 ms for 1e6 slots where the ten
+// launches above take 0.15 with their round trip.  profiles/r05_rank_ab.txt; git c54b80e has the kernel.)
 
 // ---------------- few slots: rank and emit in ONE launch, no host round trip in between ----------------
 // A dense table of <= RFX_RANK_SMALL slots: one 1024-lane workgroup holds every slot's first row in LDS, a group's id is the

@@ -257,4 +257,3 @@ __device__ __forceinline__ u64 group_final(int kind, int f64, u64 a, u64 c, int 
 
 
 int rfx_emit_slots(rfx_ctx *c, const EmitArgs &A);
-int rfx_rank_emit_fused(rfx_ctx *c, const EmitArgs &A, i64 total_rows, int nsl, int si, i64 out_cap, i64 *ngroups); // rank + emit, one launch (rfx_group.hip)
