@@ -517,6 +517,9 @@ def door_phases(ops, H, d, steps=5):
     `steps` more calls, untimed by `value`: ms per step of scope / pass / merge / rank / emit / fetch and the step's total."""
     from rayforce_amd import _lib as L
     x = C.c_void_p(ops.rfx_ops_exec())
+    r = ops.rfx_select(d)  # (one unrecorded query: the first one after the host turned the last result into numpy arrays has been seen 20 ms slow)
+    assert r and not H.is_error(r), H.error_text(r)
+    ops.rfx_host_drop(r)
     ops.rfx_exec_timing(x, 1)
     t0 = time.perf_counter()
     walls = []
