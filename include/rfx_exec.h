@@ -100,6 +100,11 @@ typedef struct rfx_query {
     int32_t flags;           /* RFX_Q_* */
     const int64_t *key_scope; /* optional {min, max}: a scope of key 0 the caller remembers (a superset of any selection's): saves the scope pass when LDS-sized */
     int64_t row0;            /* rfx_exec_where only: the id of the table's row 0 (ids come out as row0 + row) */
+    /* rfx_exec_filter_aggr only -- the selection as ROW IDS, shard by shard (a lazy MAPFILTER (values, ids) pair, core/filter.c:29-49): shard s
+     * folds its columns gathered at the sel_count[s] GLOBAL row ids d_sel_ids[s] (on shard s's device; every one inside the shard's row range
+     * -- the caller vouches for that; order kept: FIRST is the value at the first id of the first non-empty shard).  npred must be 0 */
+    const int64_t *const *d_sel_ids;
+    const int64_t *sel_count;
 } rfx_query_t;
 
 /* ---- scalar aggregates: select {aggs} from t where p ---- */

@@ -118,7 +118,8 @@ class QCol(C.Structure):
 class Query(C.Structure):
     _fields_ = [("preds", C.POINTER(Pred)), ("npred", C.c_int32), ("logic", C.c_int32), ("d_mask", C.c_void_p), ("aggs", C.POINTER(Agg)),
                 ("nagg", C.c_int32), ("nkeys", C.c_int32), ("d_keys", C.POINTER(C.c_void_p)), ("kxbar", C.POINTER(C.c_int64)), ("nrows", C.c_int64),
-                ("cols", C.POINTER(QCol)), ("ncols", C.c_int32), ("flags", C.c_int32), ("key_scope", C.POINTER(C.c_int64)), ("row0", C.c_int64)]
+                ("cols", C.POINTER(QCol)), ("ncols", C.c_int32), ("flags", C.c_int32), ("key_scope", C.POINTER(C.c_int64)), ("row0", C.c_int64),
+                ("d_sel_ids", C.POINTER(C.c_void_p)), ("sel_count", C.POINTER(C.c_int64))]
 
 
 class Ids(C.Structure):

@@ -510,6 +510,40 @@ typedef struct {
     int64_t proc_row0;
     shard_t *sh;
 } fa_t;
+/* a selection by row ids: every column the aggregates read, gathered at this shard's ids (filter_collect, core/filter.c:51-165, on the
+ * device); the fold then runs over the gathered rows, positioned after the lower shards' ids */
+static int gather_at_ids(rfx_exec_t *x, shard_t *h, int s, int na, const int64_t *d_ids, int64_t n, int64_t shard_row0) {
+    rfx_ctx_t *c = x->ctx[s];
+    const void **slots[RFX_MAX_AGGS * (2 + 2 * RFX_MAX_XNODES)];
+    int nslots = 0;
+    for (int a = 0; a < na; a++) {
+        slots[nslots++] = &h->aggs[a].d_col;
+        slots[nslots++] = &h->aggs[a].d_xrhs_col;
+        for (int j = 0; j < h->aggs[a].nxnodes; j++) {
+            if (h->xn[a][j].l.kind == RFX_XK_COL) slots[nslots++] = &h->xn[a][j].l.d_col;
+            if (h->xn[a][j].r.kind == RFX_XK_COL) slots[nslots++] = &h->xn[a][j].r.d_col;
+        }
+    }
+    const void *src[RFX_MAX_AGGS * (2 + 2 * RFX_MAX_XNODES)];
+    void *dst[RFX_MAX_AGGS * (2 + 2 * RFX_MAX_XNODES)];
+    int nseen = 0, rc;
+    for (int i = 0; i < nslots; i++) {
+        if (!*slots[i]) continue;
+        int j = 0;
+        for (; j < nseen; j++)
+            if (src[j] == *slots[i]) break;
+        if (j == nseen) {
+            void *g = NULL;
+            if ((rc = sh_malloc(x, h, s, &g, (size_t)(n ? n : 1) * 8)) != RFX_OK) return rc;
+            /* (the shard's piece addressed by GLOBAL ids: its base moved back by the shard's first row) */
+            if (n && (rc = rfx_hip_gather(c, (const char *)*slots[i] - (size_t)shard_row0 * 8, d_ids, n, g)) != RFX_OK) return rc;
+            src[nseen] = *slots[i];
+            dst[nseen++] = g;
+        }
+        *slots[i] = dst[j];
+    }
+    return RFX_OK;
+}
 static int ph_filter_aggr(void *arg, int s) {
     fa_t *F = (fa_t *)arg;
     shard_t *h = &F->sh[s];
@@ -517,6 +551,13 @@ static int ph_filter_aggr(void *arg, int s) {
     void *d = NULL;
     int rc = sh_malloc(F->x, h, s, &d, sizeof(rfx_partial_t) * (size_t)(F->na + 1));
     if (rc != RFX_OK) return rc;
+    if (F->q->d_sel_ids) {
+        int64_t before = 0;
+        for (int t = 0; t < s; t++) before += F->q->sel_count[t];
+        if ((rc = gather_at_ids(F->x, h, s, F->na, F->q->d_sel_ids[s], F->q->sel_count[s], h->row0)) != RFX_OK) return rc;
+        h->nrows = F->q->sel_count[s];
+        h->row0 = before;
+    }
     rc = rfx_hip_filter_aggr(c, h->preds, F->npred, F->q->logic, h->aggs, F->na, h->nrows, h->row0, (rfx_partial_t *)d);
     if (rc != RFX_OK) return rc;
     return rfx_hip_d2h(c, h->part, d, sizeof(rfx_partial_t) * (size_t)(F->na + 1));
@@ -531,6 +572,10 @@ int rfx_exec_filter_aggr(rfx_exec_t *x, const rfx_query_t *q, rfx_value_t *value
     if (q->d_mask && (S > 1 || exch || q->npred)) {
         snprintf(x->err, sizeof(x->err), "rfx_exec: a mask selection runs on one shard, without comparisons beside it");
         return RFX_ELIMIT;
+    }
+    if (q->d_sel_ids && (q->npred || q->d_mask || exch || !q->sel_count)) {
+        snprintf(x->err, sizeof(x->err), "rfx_exec: a selection by row ids stands alone (no comparisons, no mask) inside one process");
+        return RFX_EINVAL;
     }
     rfx_hip_ctx_bind_thread(x->ctx[0]);
     x->stat[RFX_XSTAT_QUERIES]++;

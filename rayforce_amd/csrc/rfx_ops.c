@@ -2444,10 +2444,112 @@ static obj_p sf_logic(int f, obj_p *x, int64_t n) {
 rfx_obj_p rfx_and_sf(rfx_obj_p *x, int64_t n) { return sf_logic(F_AND, x, n); }
 rfx_obj_p rfx_or_sf(rfx_obj_p *x, int64_t n) { return sf_logic(F_OR, x, n); }
 
+/* ---- the operators beside rfx_select over the shards (round 5): what the reference parallelises over its pool for every FN_AGGR
+ * built-in (aggr_map core/aggr.c:375, unop_fold core/math.c:2176-2231), planned through rfx_exec on every shard ---- */
+/* a per-call device copy of a host vector, every shard its row range (rfx_exec_split) -- a column of the query like any other */
+static int transient_sharded(obj_p v, const void **dev) {
+    if (g_nqtmp >= (int)(sizeof(g_qtmp) / sizeof(g_qtmp[0]))) return RFX_ELIMIT;
+    const size_t esz = v->type == RFX_TYPE_B8 ? 1 : 8;
+    void *devs[RFX_MAX_SHARDS];
+    int rc = shards_alloc(devs, v->len, esz);
+    if (rc != RFX_OK) return rc;
+    memset(&g_qtmp[g_nqtmp], 0, sizeof(g_qtmp[0]));
+    for (int s = 0; s < g_nshards; s++) g_qtmp[g_nqtmp].d[s] = devs[s];
+    g_nqtmp++; /* (released by qtmp_release, shard by shard) */
+    rc = payload_upload(v->type == RFX_TYPE_B8 ? RFX_TYPE_B8 : RFX_TYPE_I64, devs, RFX_AS_RAW(v), v->len);
+    g_stat[ST_UPLOADS]++;
+    if (rc != RFX_OK) return rc;
+    *dev = devs[0];
+    return qcol_add(devs);
+}
+/* the ids of a lazy MAPFILTER pair cut at the shards' row boundaries: piece s = the ids inside shard s's rows of an nrows-row column.  Filter ids
+ * ascend (ops_where, core/ops.c:254-273), so the pieces are sub-ranges of the vector, found by binary search; every piece is then PROVEN to lie
+ * inside its shard's rows on the device (min / max of the piece) -- ids in any other order answer 1 and the caller hands the pair to the host */
+static int sel_ids_sharded(obj_p ids, int64_t nrows, const int64_t **d_ids, int64_t *cnt) {
+    const int64_t *p = RFX_AS_I64(ids), n = ids->len;
+    int64_t cut[RFX_MAX_SHARDS + 1];
+    cut[0] = 0;
+    for (int s = 1; s < g_nshards; s++) {
+        int64_t r0, lo = cut[s - 1], hi = n;
+        rfx_exec_split(nrows, g_nshards, s, &r0, NULL);
+        while (lo < hi) {
+            const int64_t mid = lo + (hi - lo) / 2;
+            if (p[mid] < r0) lo = mid + 1;
+            else hi = mid;
+        }
+        cut[s] = lo;
+    }
+    cut[g_nshards] = n;
+    if (g_nqtmp >= (int)(sizeof(g_qtmp) / sizeof(g_qtmp[0]))) return RFX_ELIMIT;
+    memset(&g_qtmp[g_nqtmp], 0, sizeof(g_qtmp[0]));
+    void **devs = g_qtmp[g_nqtmp++].d;
+    int rc = RFX_OK, outside = 0;
+    for (int s = 0; s < g_nshards && rc == RFX_OK; s++) {
+        int64_t r0, len;
+        rfx_exec_split(nrows, g_nshards, s, &r0, &len);
+        cnt[s] = cut[s + 1] - cut[s];
+        rfx_hip_ctx_bind_thread(g_ctxs[s]);
+        rc = rfx_hip_malloc(g_ctxs[s], &devs[s], (size_t)(cnt[s] ? cnt[s] : 1) * 8);
+        if (rc == RFX_OK && cnt[s]) rc = rfx_hip_h2d_pipelined(g_ctxs[s], devs[s], p + cut[s], (size_t)cnt[s] * 8);
+        if (rc == RFX_OK && cnt[s]) {
+            int64_t mn = 0, mx = -1, seen = 0;
+            rc = rfx_hip_scope_i64(g_ctxs[s], (const int64_t *)devs[s], NULL, 0, RFX_AND, cnt[s], &mn, &mx, &seen);
+            if (rc == RFX_OK && (mn < r0 || mx >= r0 + len)) outside = 1;
+        }
+        d_ids[s] = (const int64_t *)devs[s];
+    }
+    rfx_hip_ctx_bind_thread(g_ctx);
+    g_stat[ST_UPLOADS]++;
+    return rc != RFX_OK ? rc : (outside ? 1 : RFX_OK);
+}
+/* one aggregate of a column over every shard (the whole column, or its rows at per-shard ids) */
+static int fold_sharded(const rfx_agg_t *a, int64_t nrows, const int64_t *const *d_ids, const int64_t *cnt, rfx_value_t *v) {
+    rfx_query_t Q;
+    memset(&Q, 0, sizeof(Q));
+    Q.aggs = a;
+    Q.nagg = 1;
+    Q.logic = RFX_AND;
+    Q.nrows = nrows;
+    Q.cols = g_qcols;
+    Q.ncols = g_nqcols;
+    Q.d_sel_ids = d_ids;
+    Q.sel_count = cnt;
+    return rfx_exec_filter_aggr(g_x, &Q, v, NULL);
+}
+
 static obj_p where_impl(obj_p mask) {
     rfx_host_bind();
     if (!mask || mask->type != RFX_TYPE_B8) return fail("where: expected a B8 mask"); /* err_type, core/items.c:1395 */
-    if (ensure_ctx1() != RFX_OK) return (g_refused_sharded && H.bound == 1 && g_host_where) ? HOST_CALL(((rfx_unary_f)g_host_where)(mask)) : fail_ctx();
+    if (ensure_ctx() != RFX_OK) return fail_hip("no usable MI355X");
+    if (g_nshards > 1) { /* every shard turns ITS rows of the mask into ids (global: its row offset added), the runs concatenated in shard order */
+        const void *dms = NULL;
+        rfx_query_t Q;
+        rfx_ids_t ids;
+        memset(&Q, 0, sizeof(Q));
+        int rc = mask->len ? transient_sharded(mask, &dms) : RFX_OK;
+        Q.d_mask = (const int8_t *)dms;
+        Q.logic = RFX_AND;
+        Q.nrows = mask->len;
+        Q.cols = g_qcols;
+        Q.ncols = g_nqcols;
+        if (rc == RFX_OK && mask->len == 0) { qtmp_release(); return H.vector(RFX_TYPE_I64, 0); }
+        if (rc == RFX_OK) rc = rfx_exec_where(g_x, &Q, &ids);
+        if (rc != RFX_OK) { qtmp_release(); return fail(rc == RFX_OK ? "where" : (rfx_exec_last_error(g_x)[0] ? rfx_exec_last_error(g_x) : rfx_hip_last_error())); }
+        obj_p outv = H.vector(RFX_TYPE_I64, ids.total);
+        int64_t at = 0;
+        int ok2 = 1;
+        for (int sh = 0; sh < ids.nshards && ok2; sh++) {
+            if (!ids.count[sh]) continue;
+            rfx_hip_ctx_bind_thread(g_ctxs[sh]);
+            ok2 = rfx_hip_d2h(g_ctxs[sh], (char *)RFX_AS_RAW(outv) + (size_t)at * 8, ids.d_ids[sh], (size_t)ids.count[sh] * 8) == RFX_OK;
+            at += ids.count[sh];
+        }
+        rfx_hip_ctx_bind_thread(g_ctx);
+        rfx_exec_ids_free(g_x, &ids);
+        qtmp_release();
+        if (!ok2) { H.drop(outv); return fail_hip("where"); }
+        return outv;
+    }
     const void *dm;
     if (transient(mask, &dm) != RFX_OK) return fail_hip("mask upload"); /* a mask is a temporary: per-call scratch, never cached */
     int64_t count = 0;
@@ -2648,7 +2750,51 @@ static obj_p fold_mapgroup(int f, int kind, obj_p x) {
     if (!filtered && val->len != n) return fail("length");
     const int out_f64 = kind == RFX_AGG_AVG || (kind != RFX_AGG_COUNT && col_ctype(val) == RFX_F64);
     if (groups == 0 || n == 0) return H.vector(out_f64 ? RFX_TYPE_F64 : RFX_TYPE_I64, 0);
-    if (ensure_ctx1() != RFX_OK) return refused1(f, x);
+    if (ensure_ctx() != RFX_OK) return fail_hip("no usable MI355X");
+    if (g_nshards > 1) {
+        /* over the shards: a dense group-by keyed by the index's id column (IDS) or its source column (SHIFT), planned like any by: -- every
+         * shard scatters its rows, the tables merge, the groups come out in first-occurrence order = the index's group ids.  A filtered index
+         * aligns its ids with filter positions, not rows: the host's own aggregate. */
+        if (filtered) { g_refused_sharded = 1; return refused1(f, x); }
+        const void *dvs = NULL, *dks = NULL;
+        int rc = resident(val, 0, &dvs);
+        if (rc == RFX_OK) rc = itype == RFX_INDEX_TYPE_IDS ? transient_sharded(gids, &dks) : resident(source, 0, &dks);
+        if (rc != RFX_OK) { qtmp_release(); return fail_hip("column upload"); }
+        rfx_agg_t as;
+        memset(&as, 0, sizeof(as));
+        as.d_col = dvs;
+        as.col_type = col_ctype(val);
+        as.kind = kind;
+        rfx_query_t Q;
+        memset(&Q, 0, sizeof(Q));
+        const void *dkeys[1] = {dks};
+        Q.aggs = &as;
+        Q.nagg = 1;
+        Q.logic = RFX_AND;
+        Q.nkeys = 1;
+        Q.d_keys = dkeys;
+        Q.nrows = n;
+        Q.cols = g_qcols;
+        Q.ncols = g_nqcols;
+        Q.flags = RFX_Q_SLICED;
+        rfx_groups_t R;
+        rc = rfx_exec_group_by(g_x, &Q, &R);
+        if (rc != RFX_OK) { qtmp_release(); return fail(rfx_exec_last_error(g_x)[0] ? rfx_exec_last_error(g_x) : rfx_hip_last_error()); }
+        if (R.groups != groups) {
+            rfx_exec_groups_free(g_x, &R);
+            qtmp_release();
+            why = "group count of the index does not match its rows";
+            goto out;
+        }
+        obj_p outv = H.vector(out_f64 ? RFX_TYPE_F64 : RFX_TYPE_I64, groups);
+        const void *srcs[1] = {R.d_results[0]};
+        void *dsts[1] = {RFX_AS_RAW(outv)};
+        rc = rfx_exec_groups_fetch_all(g_x, &R, 1, srcs, dsts);
+        rfx_exec_groups_free(g_x, &R);
+        qtmp_release();
+        if (rc != RFX_OK) { H.drop(outv); return fail_hip("group emit"); }
+        return outv;
+    }
     {
         const void *dv = NULL, *dk = NULL, *dfl = NULL;
         if (resident(val, 0, &dv) != RFX_OK) { res = fail_hip("column upload"); goto done; }
@@ -2810,7 +2956,29 @@ static obj_p fold_impl(int f, int kind, obj_p x) {
             if (H.bound == 1 && H.f[f]) return HOST_CALL(((rfx_unary_f)H.f[f])(x));
             return fail("aggregate: only (i64/f64 vector, i64 ids) MAPFILTER pairs run on the MI355X path");
         }
-        if (ensure_ctx1() != RFX_OK) return refused1(f, x);
+        if (ensure_ctx() != RFX_OK) return fail_hip("no usable MI355X");
+        if (g_nshards > 1) { /* every shard gathers and folds the ids inside its rows; partials folded in shard order (rfx_exec_filter_aggr) */
+            const void *dvs;
+            const int64_t *dsel[RFX_MAX_SHARDS];
+            int64_t nsel[RFX_MAX_SHARDS];
+            rfx_agg_t as;
+            rfx_value_t vs;
+            if (resident(val, 0, &dvs) != RFX_OK) return fail_hip("column upload");
+            int rc = sel_ids_sharded(ids, val->len, dsel, nsel);
+            if (rc == 1) { /* ids that do not ascend through the shards' row ranges: not a filter's -- the host's own aggregate */
+                qtmp_release();
+                g_refused_sharded = 1;
+                return refused1(f, x);
+            }
+            memset(&as, 0, sizeof(as));
+            as.d_col = dvs;
+            as.col_type = col_ctype(val);
+            as.kind = kind;
+            if (rc == RFX_OK) rc = fold_sharded(&as, val->len, dsel, nsel, &vs);
+            qtmp_release();
+            if (rc != RFX_OK) return fail(rfx_exec_last_error(g_x)[0] ? rfx_exec_last_error(g_x) : rfx_hip_last_error());
+            return value_atom(&vs);
+        }
         const void *dv, *di;
         if (resident(val, 0, &dv) != RFX_OK || transient(ids, &di) != RFX_OK) return fail_hip("column upload");
         void *dg = NULL;
@@ -2831,7 +2999,7 @@ static obj_p fold_impl(int f, int kind, obj_p x) {
         if (H.bound == 1 && H.f[f]) return HOST_CALL(((rfx_unary_f)H.f[f])(x));
         return fail("aggregate: only i64/f64 vectors run on the MI355X path");
     }
-    if (ensure_ctx1() != RFX_OK) return refused1(f, x);
+    if (ensure_ctx() != RFX_OK) return fail_hip("no usable MI355X");
     const void *d;
     if (resident(x, 0, &d) != RFX_OK) return fail_hip("column upload");
     rfx_agg_t a;
@@ -2840,6 +3008,10 @@ static obj_p fold_impl(int f, int kind, obj_p x) {
     a.col_type = col_ctype(x);
     a.kind = kind;
     rfx_value_t v;
+    if (g_nshards > 1) { /* the fold on every shard, the partials in shard order (unop_fold's two levels, core/math.c:2176-2231) */
+        if (fold_sharded(&a, x->len, NULL, NULL, &v) != RFX_OK) return fail(rfx_exec_last_error(g_x)[0] ? rfx_exec_last_error(g_x) : rfx_hip_last_error());
+        return value_atom(&v);
+    }
     if (rfx_hip_filter_aggr_host(g_ctx, NULL, 0, RFX_AND, &a, 1, x->len, &v, NULL) != RFX_OK) return fail_hip("filter_aggr");
     return value_atom(&v);
 }

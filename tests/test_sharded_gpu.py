@@ -160,7 +160,73 @@ if os.environ.get("RFX_EXEC_FORCE_RCCL"):
     assert ops.rfx_exec_stat(x, L.RFX_XSTAT_MERGES_RCCL) > 0 and ops.rfx_dist_calls(C.c_void_p(ops.rfx_exec_ctx(x, 0))) > 0
 # grouped results without FIRST values came back as one slice per shard when every shard owns one (the FIRST ones stay whole on the lead)
 assert (ops.rfx_exec_stat(x, L.RFX_XSTAT_SLICED) > 0) == bool(os.environ.get("RFX_EXEC_SLICE_SHARDS")), ops.rfx_exec_stat(x, L.RFX_XSTAT_SLICED)
-# an operator that needs its column whole on one device says so instead of answering from one shard
+# ---- the operators beside rfx_select, over the shards (the reference runs every FN_AGGR built-in over its pool: aggr_map core/aggr.c:375,
+# unop_fold core/math.c:2176-2231): folds of a vector, of a lazy MAPFILTER (values, ids) pair, of a MAPGROUP (values, index) pair; where
+def atom_of(r):
+    assert not H.is_error(r), H.error_text(r)
+    v = C.c_double.from_address(r + 8).value if H.header(r).type == -H.T_F64 else C.c_int64.from_address(r + 8).value
+    ops.rfx_host_drop(r)
+    return v
+def close(got, want, what):
+    if want is None:  # null
+        assert got == NULL or got != got, (what, got)
+    elif isinstance(want, float):
+        assert abs(got - want) <= 1e-9 * max(abs(want), 1e-300), (what, got, want)
+    else:
+        assert got == want, (what, got, want)
+before = ops.rfx_exec_stat(x, L.RFX_XSTAT_QUERIES)
+sel = rfo.where(rfo.cmp("<", host["a"], 400_000))
+for cname, fns in (("a", ("sum", "min", "max", "avg", "count", "first")), ("v", ("sum", "min", "max", "avg", "first"))):
+    vec, idv = H.vector(host[cname]), H.vector(sel)
+    pair = H.list_of([vec, idv])
+    H.header(pair).type = 71  # TYPE_MAPFILTER
+    for fn in fns:
+        close(atom_of(getattr(ops, f"rfx_{fn}")(vec)), len(host[cname]) if fn == "count" else rfo.fold(fn, host[cname]), (cname, fn, "vector"))
+        close(atom_of(getattr(ops, f"rfx_{fn}")(pair)), len(sel) if fn == "count" else rfo.fold(fn, host[cname][sel]), (cname, fn, "mapfilter"))
+    ops.rfx_host_drop(pair)
+# ids that do not ascend through the shards are not a filter's: said so (no host here to take them), never answered from the wrong rows
+pair = H.list_of([H.vector(host["v"]), H.vector(sel[::-1].copy())])
+H.header(pair).type = 71
+r = ops.rfx_sum(pair)
+assert H.is_error(r), "descending ids must not be answered shard by shard"
+ops.rfx_host_drop(r); ops.rfx_host_drop(pair)
+# MAPGROUP: the reference's group index over k (IDS form: a group id per row; SHIFT form: the key table + the source column), values folded per group
+gids, firsts, groups, dense = rfo.group_index(host["k"], None)
+assert dense
+def host_index(itype, shift, group_ids, source):
+    ix = ops.rfx_host_list(7)
+    arr = (C.c_void_p * 7).from_address(H.payload(ix))
+    arr[0], arr[1] = H.atom(itype), H.atom(groups)
+    arr[2] = H.vector(group_ids)
+    arr[3] = H.atom(shift if itype == 1 else NULL)
+    if itype == 1:
+        arr[4] = H.vector(source)
+    arr[6] = H.vector(firsts)
+    return ix
+kmin = int(host["k"].min())
+table = np.full(int(host["k"].max()) - kmin + 1, NULL, np.int64)
+table[host["k"] - kmin] = gids
+want_by = rfo.select({"from": host, "by": "k", "s": ("sum", "v"), "m": ("max", "a"), "c": ("count", "a"), "av": ("avg", "v"), "f": ("first", "a")})
+for ix in (host_index(0, 0, gids, None), host_index(1, kmin, table, host["k"])):
+    for fn, cname, out in (("sum", "v", "s"), ("max", "a", "m"), ("count", "a", "c"), ("avg", "v", "av"), ("first", "a", "f")):
+        pair = H.list_of([H.vector(host[cname]), ix])
+        H.header(pair).type = 72  # TYPE_MAPGROUP
+        r = getattr(ops, f"rfx_{fn}")(pair)
+        assert not H.is_error(r), H.error_text(r)
+        got = H.to_numpy(r)
+        if got.dtype == np.float64:
+            same_f64(got, want_by[out])
+        else:
+            assert np.array_equal(got, want_by[out]), (fn, cname)
+        ops.rfx_host_drop(r)
+# where: a B8 mask -> ascending global row ids, every shard its rows
+m = (host["a"] < 300_000) & (host["v"] > 0.25)
+r = ops.rfx_where(H.vector(m))  # (a bool array is a B8 vector)
+assert not H.is_error(r), H.error_text(r)
+assert np.array_equal(H.to_numpy(r), np.nonzero(m)[0])
+ops.rfx_host_drop(r)
+assert ops.rfx_exec_stat(x, L.RFX_XSTAT_QUERIES) - before >= 30   # all of it went through the planner's shards
+# an operator that still needs its column whole on one device says so instead of answering from one shard
 col = H.vector(host["a"])
 r = ops.rfx_lt(col, H.atom(5))
 assert H.is_error(r) and "whole on one device" in H.error_text(r)
