@@ -137,8 +137,8 @@ typedef struct rfx_groups {
      * rfx_exec_groups_fetch and they cost no further round trip */
     const char *d_block, *h_block;
     size_t block_bytes;
-    void *own[RFX_MAX_SHARDS * 4 + RFX_EXEC_MAX_AGGS + RFX_MAX_KEYS + 6]; /* device blocks to release ... */
-    int8_t own_shard[RFX_MAX_SHARDS * 4 + RFX_EXEC_MAX_AGGS + RFX_MAX_KEYS + 6]; /* ... and the shard whose context each came from */
+    void *own[RFX_MAX_SHARDS * 8 + RFX_EXEC_MAX_AGGS + RFX_MAX_KEYS + 6]; /* device blocks to release ... */
+    int8_t own_shard[RFX_MAX_SHARDS * 8 + RFX_EXEC_MAX_AGGS + RFX_MAX_KEYS + 6]; /* ... and the shard whose context each came from */
     int32_t nown;
     /* RFX_Q_SLICED: column c of the result = the concatenation of slice[0..nslices)'s pieces; slice i holds the groups [g0, g0 + n) on shard
      * `shard`.  The column pointers above are slice 0's (with one slice: the whole columns, as without the flag) */

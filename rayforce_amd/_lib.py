@@ -131,7 +131,7 @@ class GSlice(C.Structure):
                 ("d_keycols", C.c_void_p * RFX_MAX_KEYS), ("d_results", C.c_void_p * RFX_EXEC_MAX_AGGS)]
 
 
-_GROUPS_OWN = RFX_MAX_SHARDS * 4 + RFX_EXEC_MAX_AGGS + RFX_MAX_KEYS + 6
+_GROUPS_OWN = RFX_MAX_SHARDS * 8 + RFX_EXEC_MAX_AGGS + RFX_MAX_KEYS + 6
 
 
 class Groups(C.Structure):

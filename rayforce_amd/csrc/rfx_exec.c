@@ -1157,7 +1157,7 @@ static int ph_rank_emit(void *arg, int s) {
         if (nsl > 1) rfx_hip_ctx_emit_window(c, 0, 0);
         if (rc != RFX_OK) return rc;
     }
-    if (G->nsl > 1 && G->first_pass && G->nkeys > 1) /* this slice's key columns, decoded from its composite keys (core/query.c:110-135) */
+    if (G->nsl > 1 && G->first_pass && G->nkeys > 1 && !G->rowhash) /* this slice's key columns, decoded from its composite keys (core/query.c:110-135) */
         for (int k = 0; k < G->nkeys; k++) {
             if ((rc = rfx_hip_malloc(c, &h->kc[k], (size_t)h->gn * 8)) != RFX_OK) return rc;
             if ((rc = rfx_hip_composite_decode(c, (const int64_t *)h->dout, h->gn, G->kmins[k], G->kmults[k], G->kmaxs[k] - G->kmins[k] + 1, (int64_t *)h->kc[k])) != RFX_OK) return rc;
@@ -1370,7 +1370,11 @@ static int gb_scope(gq_t *G) {
                 if (rfx_composite_plan(G->kmins, G->kmaxs, G->nkeys, G->kmults, &G->comp_max) != RFX_OK) {
                     /* ranges beyond 64 bits / a null key: the reference's row-hash path (index_group_list, core/index.c:2731-2790) -- grouped on
                      * the reference's own row hash; its tuple comparison on every probe is made once, afterwards (below) */
-                    if (multi) { snprintf(x->err, sizeof(x->err), "rfx_exec: key tuples beyond a 64-bit composite key run on one shard"); rc = RFX_ELIMIT; return rc; }
+                    /* over several shards / processes the tuple proof is made by aggregates (rfx_exec_group_by: a MIN and a MAX per key column ride
+                     * through the same merge; one hash = one tuple iff they agree) -- which skip nulls, so a null among the keys stays on one shard */
+                    if (multi)
+                        for (int k = 0; k < G->nkeys; k++)
+                            if (G->kmins[k] == NULL_I64) { snprintf(x->err, sizeof(x->err), "rfx_exec: key tuples with a null key run on one shard"); rc = RFX_ELIMIT; return rc; }
                     if ((rc = run_shards(x, ph_row_hash, G)) != RFX_OK) return rc;
                     G->rowhash = 1;
                     G->spec = 0;
@@ -1658,7 +1662,8 @@ static int gb_emit(gq_t *G) {
                 out->d_keys = (int64_t *)h->dout;
                 /* several keys: the result's key columns -- decoded from the composite key (key_i = min_i + (composite / mult_i) % range_i
                  * = key_i[first row], core/query.c:110-135) or, on the row-hash path, gathered at the groups' first rows */
-                for (int k = 0; k < G->nkeys && G->nkeys > 1 && rc == RFX_OK; k++) {
+                /* (row hash over several shards: the proof passes of rfx_exec_group_by bring the key columns -- no shard holds every first row) */
+                for (int k = 0; k < G->nkeys && G->nkeys > 1 && !(G->rowhash && G->multi) && rc == RFX_OK; k++) {
                     void *cell = NULL;
                     rc = rfx_hip_malloc(c, &cell, (size_t)g * 8);
                     if (rc != RFX_OK) break;
@@ -1746,6 +1751,72 @@ static int group_by_pass(rfx_exec_t *x, const rfx_query_t *q, int a0, int na, in
     return rc;
 }
 
+static int world_is_multi(rfx_exec_t *x) {
+    int w, r;
+    return world_rank(x, &w, &r);
+}
+/* Key tuples grouped on their row hash over SEVERAL shards: one hash = one tuple?  On one shard every row is compared with its group's first
+ * row (gb_prove_tuples); across shards no row id leaves its shard, so every key column rides through the group-by once more as a (MIN, MAX)
+ * pair -- the same hashed tables, the same merge, the same group order and slices -- and a group whose rows agree on every key column
+ * (min == max) is exactly one tuple; the maxima ARE the result's key columns.  A disagreement is a 64-bit hash collision between two
+ * tuples (probability ~ groups^2 / 2^65): RFX_ESTATE "collision", nothing is answered.  (index_group_list's __index_list_cmp_row, made
+ * once per group instead of on every probe: core/index.c:2731-2790.) */
+static int rowhash_proof_passes(rfx_exec_t *x, const rfx_query_t *q, int64_t cap, rfx_groups_t *out) {
+    int rc = RFX_OK;
+    for (int k0 = 0; k0 < q->nkeys && rc == RFX_OK; k0 += RFX_MAX_AGGS / 2) {
+        const int nk = q->nkeys - k0 < RFX_MAX_AGGS / 2 ? q->nkeys - k0 : RFX_MAX_AGGS / 2;
+        rfx_agg_t pa[RFX_MAX_AGGS];
+        memset(pa, 0, sizeof(pa));
+        for (int j = 0; j < nk; j++) {
+            pa[2 * j].kind = RFX_AGG_MIN;
+            pa[2 * j + 1].kind = RFX_AGG_MAX;
+            pa[2 * j].d_col = pa[2 * j + 1].d_col = q->d_keys[k0 + j];
+            pa[2 * j].col_type = pa[2 * j + 1].col_type = RFX_I64;
+        }
+        rfx_query_t q2 = *q;
+        q2.aggs = pa;
+        q2.nagg = 2 * nk;
+        rfx_groups_t *P = (rfx_groups_t *)calloc(1, sizeof(*P));
+        if (!P) return RFX_ENOMEM;
+        P->groups = out->groups;
+        P->nslices = out->nslices;
+        P->nkeys = out->nkeys;
+        rc = group_by_pass(x, &q2, 0, 2 * nk, 0, cap, P);
+        const int nsl = P->nslices > 1 ? P->nslices : 1;
+        for (int i = 0; i < nsl && rc == RFX_OK; i++) {
+            const int s = P->nslices > 1 ? P->slice[i].shard : 0;
+            const int64_t n = P->nslices > 1 ? P->slice[i].n : P->groups;
+            if (n == 0) continue;
+            rfx_hip_ctx_bind_thread(x->ctx[s]);
+            for (int j = 0; j < nk && rc == RFX_OK; j++) {
+                const void *mn = P->nslices > 1 ? P->slice[i].d_results[2 * j] : P->d_results[2 * j], *mx = P->nslices > 1 ? P->slice[i].d_results[2 * j + 1] : P->d_results[2 * j + 1];
+                rfx_pred_t ne;
+                rfx_value_t cv;
+                int64_t differ = 0;
+                memset(&ne, 0, sizeof(ne));
+                ne.d_col = mn;
+                ne.col_type = RFX_I64;
+                ne.op = RFX_NE;
+                ne.d_rhs_col = mx;
+                ne.rhs_type = RFX_I64;
+                rc = rfx_hip_filter_aggr_host(x->ctx[s], &ne, 1, RFX_AND, NULL, 0, n, &cv, &differ);
+                if (rc == RFX_OK && differ) {
+                    snprintf(x->err, sizeof(x->err), "row-hash collision between two key tuples");
+                    rc = RFX_ESTATE;
+                }
+                if (rc == RFX_OK) {
+                    if (P->nslices > 1) out->slice[i].d_keycols[k0 + j] = (int64_t *)mx;
+                    if (i == 0) out->d_keycols[k0 + j] = (int64_t *)mx;
+                }
+            }
+        }
+        rfx_hip_ctx_bind_thread(x->ctx[0]);
+        if (rc != RFX_OK && !x->err[0]) snprintf(x->err, sizeof(x->err), "%s", rfx_hip_last_error());
+        for (int i = 0; i < P->nown; i++) own_on(out, P->own[i], P->own_shard[i]); /* the key columns live in the proof passes' blocks */
+        free(P);
+    }
+    return rc;
+}
 int rfx_exec_group_by(rfx_exec_t *x, const rfx_query_t *q, rfx_groups_t *out) {
     if (!x || !q || !out || q->nkeys < 1 || q->nkeys > RFX_MAX_KEYS || !q->d_keys || q->nagg < 0 || q->nagg > RFX_EXEC_MAX_AGGS || q->npred < 0 || q->npred > RFX_MAX_PREDS)
         return RFX_EINVAL;
@@ -1766,6 +1837,7 @@ int rfx_exec_group_by(rfx_exec_t *x, const rfx_query_t *q, rfx_groups_t *out) {
         if (q->nagg == 0 || out->groups == 0) break;
     }
     out->nagg = q->nagg;
+    if (rc == RFX_OK && out->path == RFX_PATH_ROWHASH && out->groups > 0 && (x->nshards > 1 || world_is_multi(x))) rc = rowhash_proof_passes(x, q, cap, out);
     if (rc == RFX_OK && out->nslices <= 1) { /* the whole result on shard 0: one slice, so that every reader walks slices */
         out->nslices = 1;
         out->slice[0].shard = 0;

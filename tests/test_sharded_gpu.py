@@ -108,6 +108,8 @@ n = 2_000_003
 host = {"k": rfo.gen_i64(n, 4, 100_000), "a": rfo.gen_i64(n, 2, 1_000_000), "v": rfo.gen_f64(n, 5), "b": rfo.gen_f64(n, 3), "c": rfo.gen_f64(n, 8), "d": rfo.gen_f64(n, 9)}
 host["a"][::101] = NULL
 host["k2"] = rfo.gen_i64(n, 14, 13)
+for i, m in enumerate((1000, 1000, 1_000_000, 1000, 1000, 1_000_000)):  # six key columns whose ranges multiply to 1e24 > 2^63: the H2O Q7 shape
+    host[f"id{i + 1}"] = rfo.gen_i64(n, 20 + i, m)
 tab = H.table(host)
 queries = [
     {"s": ("sum", "a"), "where": ("<", "a", 100_000)},
@@ -119,6 +121,9 @@ queries = [
     {"where": ("<", "a", 3000)},
     {"s": ("sum", "v"), "c": ("count", "a"), "m": ("min", "b"), "by": {"g1": "k2", "g2": "k"}},
     {"by": "k", **{f"o{i}": (fn, c) for i, (fn, c) in enumerate([("max", "a"), ("sum", "v"), ("min", "a"), ("avg", "v"), ("sum", "b"), ("avg", "c"), ("min", "d"), ("count", "a")])}},  # five argument columns: two passes, the same slices
+    # key tuples beyond a 64-bit composite key: every shard groups ITS rows on the reference's row hash, the hashed tables are re-inserted, and the
+    # tuples are PROVEN by a (min, max) pair per key column riding through the same merge (index_group_list, core/index.c:2731-2790)
+    {"s": ("sum", "v"), "c": ("count", "a"), "m": ("max", "b"), "by": {f"id{i + 1}": f"id{i + 1}" for i in range(6)}},
     # comparison operands that are element-wise expressions: every shard evaluates ITS rows into a scratch column of its own
     {"s": ("sum", "v"), "c": ("count", "a"), "where": ("or", ("==", ("div", "a", 1000), 7), ("and", (">", ("*", "v", 2.0), 1.5), ("!=", "k", 3)))},
     {"s": ("sum", "b"), "by": "k", "where": ("and", ("<", ("+", "v", "b"), 0.7), (">", ("-", "a", "k"), 1000))},
