@@ -87,7 +87,9 @@ WORKLOADS = {
                bytes_per_row=8.8, dtype="int64", kernel="k_where_once_plan (one pass: ballots -> decoupled look-back -> ids, compiled at run time for the plan; prebuilt k_where_once<1, 1> without hiprtc)"),
     "m2": dict(desc="B8 mask: (< a 100000) materialised as the reference's byte mask (8 B/row in + 1 B/row out)", rows=1_000_000_000, bytes_per_row=9,
                dtype="int64", kernel="k_cmp_mask<1>"),
-    "g2": dict(desc="gather: (at b ids) for the 1e8 ids of w2 (8 B id + 8 B random read + 8 B write per id)", rows=1_000_000_000, bytes_per_row=2.4,
+    # (round 5: the bytes a monotone gather at 10 % MUST move are line-granular -- 1 - 0.9^16 = 81 % of b's 128-byte lines hold a selected row: 6.5 GB of
+    #  the 8 GB column + 0.8 GB of ids + 0.8 GB written = 8.1 B per table row; rounds 1-4 priced it at 24 B per SELECTED row = 2.4, which no gather can reach)
+    "g2": dict(desc="gather: (at b ids) for the 1e8 ascending ids of w2: 8 B id + 8 B write per id + the 81 % of b's 128-byte lines that hold a selected row", rows=1_000_000_000, bytes_per_row=8.1,
                dtype="f64", kernel="k_gather8"),
     "c5": dict(desc="configs[4]: avg,min,max(d) where a<0.316228 and b>0.683772 and c!=0.25, 4 x f64[2e9] seeds 6-9 (64 GB: 2.5e8 rows per GPU at 8)", rows=2_000_000_000,
                bytes_per_row=32, dtype="f64", kernel="k_filter_aggr_plan (K1 compiled at run time for the plan; prebuilt k_filter_aggr<4, 4, 4, 4, 0, false> without hiprtc)"),

@@ -1,0 +1,149 @@
+/* rfx_ops_join.c -- part of the operator layer's ONE translation unit (rfx_ops.c #includes it -- the Makefile does not compile it on its own; the pieces share file-static state and helpers).
+ * equi-joins. */
+/* ------------------------------------------------------------------------------------------------ equi-joins
+ * (left-join [keys] x y) / (inner-join [keys] x y): ray_left_join / ray_inner_join, core/join.c:158-298 -- vary_f over (key symbols,
+ * left table, right table).  Index = per left row the first right row with an equal key tuple (index_left_join_obj,
+ * core/index.c:2886-2928): the group-by's first-occurrence table over the right keys (zero aggregates), probed with the left keys. */
+static obj_p join_impl(int inner, obj_p *x, int64_t n) {
+    rfx_host_bind();
+    const int fidx = inner ? F_IJ : F_LJ;
+    if (n != 3 || !x[0] || !x[1] || !x[2]) return fail("join: expected (keys, left table, right table)");
+    if (x[0]->type != RFX_TYPE_SYMBOL || x[1]->type != RFX_TYPE_TABLE || x[2]->type != RFX_TYPE_TABLE) return fail("join: expected (symbol vector, table, table)");
+    obj_p ksyms = x[0], lt = x[1], rt = x[2];
+    obj_p lnames = RFX_AS_LIST(lt)[0], lcols = RFX_AS_LIST(lt)[1], rnames = RFX_AS_LIST(rt)[0], rcols = RFX_AS_LIST(rt)[1];
+    const int64_t nl = lcols->len ? RFX_AS_LIST(lcols)[0]->len : 0, nr = rcols->len ? RFX_AS_LIST(rcols)[0]->len : 0;
+    const int nk = (int)ksyms->len;
+    const char *why = NULL;
+    void *tmp[4 * RFX_MAX_KEYS + 8];
+    int ntmp = 0;
+    obj_p res = NULL;
+    if (nl == 0 || nr == 0) return H.clone(lt); /* core/join.c:171-172 */
+    if (nk < 1 || nk > RFX_MAX_KEYS) { why = "1..8 key columns"; goto out; }
+    obj_p lk[RFX_MAX_KEYS], rk[RFX_MAX_KEYS];
+    const void *dlk[RFX_MAX_KEYS], *drk[RFX_MAX_KEYS];
+    for (int i = 0; i < nk; i++) {
+        lk[i] = table_col(lt, RFX_AS_I64(ksyms)[i]);
+        rk[i] = table_col(rt, RFX_AS_I64(ksyms)[i]);
+        if (!lk[i] || !rk[i] || col_ctype(lk[i]) != RFX_I64 || col_ctype(rk[i]) != RFX_I64 || lk[i]->type != rk[i]->type) { why = "join key is not an 8-byte integer column of both tables"; goto out; }
+    }
+    for (int64_t i = 0; i < lcols->len; i++) if (!col_ctype(RFX_AS_LIST(lcols)[i])) { why = "non-8-byte column"; goto out; }
+    for (int64_t i = 0; i < rcols->len; i++) {
+        obj_p rc = RFX_AS_LIST(rcols)[i], lc = table_col(lt, RFX_AS_I64(rnames)[i]);
+        if (!col_ctype(rc)) { why = "non-8-byte column"; goto out; }
+        if (lc && lc->type != rc->type) return fail("join: a column has different types in the two tables"); /* err_type, core/join.c:50-51 */
+    }
+    if (ensure_ctx1() != RFX_OK) return refusedn(fidx, x, n);
+    for (int i = 0; i < nk; i++)
+        if (resident(lk[i], 0, &dlk[i]) != RFX_OK || resident(rk[i], 0, &drk[i]) != RFX_OK) { res = fail_hip("column upload"); goto done; }
+#define JOIN_TMP(ptr, bytes) do { ptr = NULL; if (rfx_hip_malloc(g_ctx, &ptr, (bytes)) != RFX_OK) { res = fail_hip("join scratch"); goto done; } tmp[ntmp++] = ptr; } while (0)
+    /* the join index -- per left row the first right row with an equal key tuple, or null -- is the planner's (rfx_exec_join_index: dense
+     * first-occurrence table or the hashed one, composite key or the reference's row hash + the tuple check) */
+    void *ids = NULL;
+    JOIN_TMP(ids, (size_t)nl * 8);
+    {
+        int collision = 0;
+        const int jrc = rfx_exec_join_index(g_x, dlk, drk, nk, nl, nr, (int64_t *)ids, &collision);
+        if (jrc != RFX_OK && collision) { why = "row-hash collision between two key tuples"; goto out; }
+        if (jrc != RFX_OK) { res = fail(rfx_exec_last_error(g_x)); goto done; }
+    }
+    /* result columns: keys, then the other left columns, then the right-only ones (ray_union / ray_except order, core/join.c:83-156) */
+    {
+        int64_t names[64];
+        int ncol = 0;
+        for (int i = 0; i < nk; i++) names[ncol++] = RFX_AS_I64(ksyms)[i];
+        for (int pass = 0; pass < 2; pass++) {
+            obj_p nm = pass ? rnames : lnames;
+            for (int64_t i = 0; i < nm->len && ncol < 64; i++) {
+                int64_t sy = RFX_AS_I64(nm)[i];
+                int dup = 0;
+                for (int j = 0; j < ncol; j++) dup |= names[j] == sy;
+                if (!dup) names[ncol++] = sy;
+            }
+        }
+        if (ncol >= 64) { why = "too many columns"; goto out; }
+        void *lids = NULL, *rids = NULL, *dcol = NULL;
+        int64_t nout = nl;
+        if (inner) { /* matched left rows in order, paired with their right rows (index_inner_join_obj) */
+            rfx_pred_t p;
+            memset(&p, 0, sizeof(p));
+            p.d_col = ids; p.col_type = RFX_I64; p.op = RFX_NE; p.rhs_type = RFX_I64; p.rhs_i = RFX_NULL_I64;
+            if (rfx_hip_where_begin(g_ctx, &p, 1, RFX_AND, NULL, nl, &nout) != RFX_OK) { res = fail_hip("join where"); goto done; }
+            JOIN_TMP(lids, (size_t)(nout ? nout : 1) * 8);
+            JOIN_TMP(rids, (size_t)(nout ? nout : 1) * 8);
+            if (rfx_hip_where_emit(g_ctx, 0, (int64_t *)lids) != RFX_OK || (nout && rfx_hip_gather(g_ctx, ids, (const int64_t *)lids, nout, rids) != RFX_OK)) { res = fail_hip("join where"); goto done; }
+        }
+        JOIN_TMP(dcol, (size_t)(nout ? nout : 1) * 8);
+        obj_p rk_ = H.vector(RFX_TYPE_SYMBOL, ncol), rv = H.vector(RFX_TYPE_LIST, ncol);
+        int ok = 1;
+        for (int c = 0; c < ncol; c++) {
+            RFX_AS_I64(rk_)[c] = names[c];
+            obj_p lc = table_col(lt, names[c]), rc = table_col(rt, names[c]);
+            const int iskey = c < nk;
+            obj_p o = NULL;
+            if (!inner && (iskey || !rc)) o = H.clone(lc); /* left join: key columns and left-only columns are the left table's own */
+            else {
+                obj_p src = (inner ? (rc ? rc : lc) : rc);
+                o = H.vector(src->type, nout);
+                const void *dsrc, *dleft = NULL;
+                ok = ok && resident(src, 0, &dsrc) == RFX_OK;
+                if (ok && !inner && lc) ok = resident(lc, 0, &dleft) == RFX_OK;
+                if (ok && nout) {
+                    if (inner) ok = rfx_hip_gather(g_ctx, dsrc, (const int64_t *)(rc ? rids : lids), nout, dcol) == RFX_OK;
+                    else ok = rfx_hip_gather_or(g_ctx, dsrc, dleft, (const int64_t *)ids, nout, col_ctype(src) == RFX_F64 ? 0x7FF8000000000000ull : 0x8000000000000000ull, dcol) == RFX_OK;
+                    ok = ok && rfx_hip_d2h(g_ctx, RFX_AS_RAW(o), dcol, (size_t)nout * 8) == RFX_OK;
+                }
+            }
+            RFX_AS_LIST(rv)[c] = o;
+        }
+        if (!ok) { H.drop(rk_); H.drop(rv); res = fail_hip("join columns"); goto done; }
+        res = H.table(rk_, rv);
+        g_last_gpu = 1;
+        goto done;
+    }
+out:
+    for (int i = 0; i < ntmp; i++) rfx_hip_free(g_ctx, tmp[i]);
+    ntmp = 0;
+    if (H.bound == 1 && H.f[fidx]) res = HOST_CALL(((rfx_vary_f)H.f[fidx])(x, n));
+    else {
+        char b[320];
+        snprintf(b, sizeof(b), "join: shape not covered by the MI355X path (%s) and no host function to delegate to", why ? why : "unsupported");
+        res = fail(b);
+    }
+done:
+    for (int i = 0; i < ntmp; i++) rfx_hip_free(g_ctx, tmp[i]);
+    return res;
+#undef JOIN_TMP
+}
+static obj_p join_op(int inner, obj_p *x, int64_t n) {
+    op_begin();
+    g_last_gpu = 0;
+    obj_p r = join_impl(inner, x, n);
+    g_stat[g_last_gpu ? ST_JOIN_GPU : ST_JOIN_DELEGATED]++;
+    op_end();
+    return r;
+}
+rfx_obj_p rfx_left_join(rfx_obj_p *x, int64_t n) { return join_op(0, x, n); }
+rfx_obj_p rfx_inner_join(rfx_obj_p *x, int64_t n) { return join_op(1, x, n); }
+
+static obj_p at_impl(obj_p col, obj_p ids) {
+    rfx_host_bind();
+    if (!col || !ids || !col_ctype(col) || ids->type != RFX_TYPE_I64) return fail("at: expected (i64|f64 column, I64 ids)");
+    if (ensure_ctx1() != RFX_OK) return (g_refused_sharded && H.bound == 1 && g_host_at) ? HOST_CALL(((rfx_binary_f)g_host_at)(col, ids)) : fail_ctx();
+    const void *dc, *di;
+    if (resident(col, 0, &dc) != RFX_OK || transient(ids, &di) != RFX_OK) return fail_hip("upload");
+    obj_p out = H.vector(col->type, ids->len);
+    void *dout = NULL;
+    /* ids come from the caller: null / negative / out-of-range ids read as the typed null (at_vec_*_by_i64, core/items.c:53-72) */
+    int ok = rfx_hip_malloc(g_ctx, &dout, (size_t)ids->len * 8 + 8) == RFX_OK &&
+             rfx_hip_gather_checked(g_ctx, dc, col->len, col_ctype(col), (const int64_t *)di, ids->len, dout) == RFX_OK &&
+             rfx_hip_d2h(g_ctx, RFX_AS_RAW(out), dout, (size_t)ids->len * 8) == RFX_OK;
+    if (dout) rfx_hip_free(g_ctx, dout);
+    if (!ok) { H.drop(out); return fail_hip("gather"); }
+    return out;
+}
+rfx_obj_p rfx_at(rfx_obj_p col, rfx_obj_p ids) {
+    op_begin();
+    obj_p r = at_impl(col, ids);
+    op_end();
+    return r;
+}
