@@ -82,6 +82,11 @@ __global__ __launch_bounds__(PL_T) void k_plane_scatter(const Plan P, const Plan
     constexpr int PARTS = pl_parts<PBITS, VGL, HK>();
     constexpr bool P192 = PARTS != (1 << PBITS); // multiply-shift partitions (not a power of two): regions at (block * PARTS + p)
     constexpr unsigned VG = 1u << VGL, RING = 2u << VGL; // records per group / per ring
+    // KVI (round 5, sparse keys over 256 partitions): 8-record groups are 64-byte pieces per plane -- half lines, which cost the scatter 13.3 ms
+    // where 128-byte lines cost 7.6 (profiles/r03_write_probe.jsonl: 64 B 3.7 TB/s, 128 B 4.7).  The key group and the value group of the SAME
+    // eight records are therefore laid side by side in ONE plane of 16-byte-per-record regions: [keys of group g: 64 B][values of group g: 64 B],
+    // stored by eight neighbouring lanes of one instruction as one whole 128-byte line.
+    constexpr bool KVI = HK && NV == 2 && PBITS == 8 && VGL == 3;
     constexpr unsigned LPD = VG / 2;                     // lanes that store one value group (16 bytes = two records each); meta: half of them
     extern __shared__ __attribute__((aligned(16))) unsigned char pl_smem[];
     u64 *vring = (u64 *)pl_smem;                                       // [NV][PARTS][RING]
@@ -118,11 +123,18 @@ __global__ __launch_bounds__(PL_T) void k_plane_scatter(const Plan P, const Plan
                 const unsigned p = d & 0xFFu, gi = (d >> 8) & 0x3FFFFFu, pl = d >> 30, sub = lane & (LPD - 1u);
                 if (pl < 3) {
                     const pl_v2 x = *(const pl_v2 *)(vring + ((size_t)pl * PARTS + p) * RING + (gi & 1u) * VG + sub * 2);
-                    u64 *dst = (NV == 1 ? A.vals[0] : (pl == 0 ? A.vals[0] : (pl == 1 ? A.vals[1] : A.vals[2])));
-                    __builtin_nontemporal_store(x, (pl_v2 *)(dst + region + (u64)p * A.c0 + (u64)gi * VG + sub * 2));
+                    if constexpr (KVI) {
+                        __builtin_nontemporal_store(x, (pl_v2 *)(A.vals[0] + 2 * (region + (u64)p * A.c0 + (u64)gi * VG) + (u64)pl * VG + sub * 2));
+                    } else {
+                        u64 *dst = (NV == 1 ? A.vals[0] : (pl == 0 ? A.vals[0] : (pl == 1 ? A.vals[1] : A.vals[2])));
+                        __builtin_nontemporal_store(x, (pl_v2 *)(dst + region + (u64)p * A.c0 + (u64)gi * VG + sub * 2));
+                    }
                 } else if (sub < LPD / 2) {
                     const pl_v2 x = *(const pl_v2 *)(mring + (size_t)p * RING + (gi & 1u) * VG + sub * 4);
-                    __builtin_nontemporal_store(x, (pl_v2 *)(A.meta + region + (u64)p * A.c0 + (u64)gi * VG + sub * 4));
+                    // (KVI: a meta group is 32 bytes -- a quarter line; non-temporal stores of that size are the slowest thing the write probe found
+                    //  (1.5 TB/s), ordinary ones meet their neighbours in L2)
+                    if constexpr (KVI) *(pl_v2 *)(A.meta + region + (u64)p * A.c0 + (u64)gi * VG + sub * 4) = x;
+                    else __builtin_nontemporal_store(x, (pl_v2 *)(A.meta + region + (u64)p * A.c0 + (u64)gi * VG + sub * 4));
                 }
             }
         }
@@ -319,8 +331,12 @@ __global__ __launch_bounds__(PL_T) void k_plane_scatter(const Plan P, const Plan
         const unsigned gi = t >> VGL;
         if (pl < (unsigned)NV) {
             const pl_v2 x = *(const pl_v2 *)(vring + ((size_t)pl * PARTS + p) * RING + (gi & 1u) * VG + sub * 2);
-            u64 *dst = (NV == 1 ? A.vals[0] : (pl == 0 ? A.vals[0] : (pl == 1 ? A.vals[1] : A.vals[2])));
-            *(pl_v2 *)(dst + region + (u64)p * A.c0 + (u64)gi * VG + sub * 2) = x;
+            if constexpr (KVI) {
+                *(pl_v2 *)(A.vals[0] + 2 * (region + (u64)p * A.c0 + (u64)gi * VG) + (u64)pl * VG + sub * 2) = x;
+            } else {
+                u64 *dst = (NV == 1 ? A.vals[0] : (pl == 0 ? A.vals[0] : (pl == 1 ? A.vals[1] : A.vals[2])));
+                *(pl_v2 *)(dst + region + (u64)p * A.c0 + (u64)gi * VG + sub * 2) = x;
+            }
         } else if (sub < LPD / 2) {
             const pl_v2 x = *(const pl_v2 *)(mring + (size_t)p * RING + (gi & 1u) * VG + sub * 4);
             *(pl_v2 *)(A.meta + region + (u64)p * A.c0 + (u64)gi * VG + sub * 4) = x;
@@ -896,6 +912,7 @@ struct PlaneHashArgs {
     const u64 *keys, *vals;
     const unsigned *meta, *cnt;
     int *overflow;
+    int kvi; // the key and value planes are ONE plane of interleaved 8-record groups (k_plane_scatter's KVI form: 256 partitions)
 };
 #define PLH_T 1024
 #define PLH_PROBES 512
@@ -999,8 +1016,12 @@ __global__ __launch_bounds__(PLH_T) void k_plane_hash_aggregate(const Plan P, co
         for (int k = 0; k < 2; k++) {
             unsigned i = B.i0 + ((unsigned)k * 64u + (unsigned)lane) * 2u;
             i = i < X.c0 - 2u ? i : X.c0 - 2u;
-            B.key[k] = __builtin_nontemporal_load((const pl_v2 *)(X.keys + base + i));
-            B.val[k] = __builtin_nontemporal_load((const pl_v2 *)(X.vals + base + i));
+            // (one load each, the address computed: two alternative loads under a uniform condition would be issued both, with a vmcnt(0) between)
+            const u64 ko = X.kvi ? 2 * (base + (u64)(i & ~7u)) + (u64)(i & 7u) : base + (u64)i;
+            const u64 *vb = X.kvi ? X.keys : X.vals;
+            const u64 vo = X.kvi ? ko + 8 : base + (u64)i;
+            B.key[k] = __builtin_nontemporal_load((const pl_v2 *)(X.keys + ko));
+            B.val[k] = __builtin_nontemporal_load((const pl_v2 *)(vb + vo));
             B.m[k] = __builtin_nontemporal_load((const pl_m2 *)(X.meta + base + i));
         }
     };
@@ -1101,6 +1122,10 @@ int rfx_plane_hash_accumulate(rfx_ctx *c, const Plan &P, int key_idx, const Hash
         parts = 192;
     } else {
         if (est * 1.6 / (128.0 * 4.0) > (double)lcap) pbits = 8;
+        // round 5: keys that overflow ONE LDS table per partition at 128 partitions take 256 partitions with ONE workgroup each -- every record
+        // streamed once (the two workgroups per partition of round 3 each streamed all of it: 42.8 of the query's 80 GB) -- now that the
+        // 256-partition scatter stores whole 128-byte lines (KVI).  RFX_PLANE_HASH_PARTS=128 keeps the two-workgroup form (A/B).
+        if (est * 1.6 / 128.0 > (double)lcap && est * 1.6 / 256.0 <= (double)lcap && !(force && atoi(force) == 128)) pbits = 8;
         while (hbits < 2 && est * 1.6 / (double)((1 << pbits) << hbits) > (double)lcap) hbits++; // (every workgroup of a partition streams ALL its records: 4 is where that stops paying)
         if (est * 1.6 / (double)((1 << pbits) << hbits) > (double)lcap) return RFX_ESTATE; // more keys than 512 LDS tables hold: round 1's kernels / the device-wide table
         parts = 1 << pbits;
@@ -1177,6 +1202,7 @@ int rfx_plane_hash_accumulate(rfx_ctx *c, const Plan &P, int key_idx, const Hash
     for (int a = 0; a < RFX_MAX_AGGS; a++) X.agg_pl[a] = (a < P.nagg && agg_plane[a] == 0) ? 1 : -1;
     X.keys = A.vals[0];
     X.vals = A.vals[1];
+    X.kvi = (parts == 256); // (<.., 2, 8, 3, true>: the interleaved key | value plane)
     X.meta = A.meta;
     X.cnt = A.cnt;
     X.overflow = d_overflow;

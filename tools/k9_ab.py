@@ -1,4 +1,4 @@
-"""dev: K9 (sparse keys) A/B in one process: RFX_PLANE_HASH_PARTS=128 (round 3's shared partitions) vs the default (192 partitions, one workgroup each)."""
+"""dev: K9 (sparse keys) A/B in one process: RFX_PLANE_HASH_PARTS=128 (round 3: 128 partitions, two workgroups each) | unset (round 5: 256 partitions with the interleaved key|value plane, one workgroup each) | 192."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -22,4 +22,4 @@ for w in (None, ("<", "v", 0.5)):
     want = torch.zeros(1_000_000, dtype=torch.float64, device=v.device).index_add_(0, d, v)
     got = torch.zeros_like(want); got[(r["keys"] + 77) // 1_000_003] = r["results"][0]
     ok = bool(((got - want).abs() <= 1e-9 * want.abs() + 1e-300).all()) and bool((r["first"][1:] > r["first"][:-1]).all())
-    print(f"PARTS={os.environ.get('RFX_PLANE_HASH_PARTS', '192')} where={w} rows={rows}: {ms:.2f} ms/query groups={r['groups']} ok={ok} scatter={eng.stat(0)} fallback={eng.stat(1)}", flush=True)
+    print(f"PARTS={os.environ.get('RFX_PLANE_HASH_PARTS', 'default(256 kvi)')} where={w} rows={rows}: {ms:.2f} ms/query groups={r['groups']} ok={ok} scatter={eng.stat(0)} fallback={eng.stat(1)}", flush=True)
