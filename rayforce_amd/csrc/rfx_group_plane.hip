@@ -39,6 +39,11 @@
 #define PL_QFLUSH 24         /* ... stored once this many are queued (and at the end of every step) */
 #define PL_SPIN_LIMIT (1u << 14)
 #define PL_MAX_NV 3
+#ifndef PL_META64_PLAIN
+#define PL_META64_PLAIN 1 /* ordinary (not non-temporal) stores for the 64-byte meta groups of 16-record groups too: A/B at 1e9 rows, 1e6 keys -- `sum v1, avg v3`
+                           * 13.85 -> 12.34 ms, `sum v1,v2,v3` 18.46 -> 17.84, `avg v1,v2,v3` 19.20 -> 18.75 (round 5; half and quarter lines written non-temporally
+                           * bypass the L2 that would have merged them with their neighbours) */
+#endif
 
 struct PlaneArgs {
     int nblk;          // row blocks
@@ -133,7 +138,7 @@ __global__ __launch_bounds__(PL_T) void k_plane_scatter(const Plan P, const Plan
                     const pl_v2 x = *(const pl_v2 *)(mring + (size_t)p * RING + (gi & 1u) * VG + sub * 4);
                     // (KVI: a meta group is 32 bytes -- a quarter line; non-temporal stores of that size are the slowest thing the write probe found
                     //  (1.5 TB/s), ordinary ones meet their neighbours in L2)
-                    if constexpr (KVI) *(pl_v2 *)(A.meta + region + (u64)p * A.c0 + (u64)gi * VG + sub * 4) = x;
+                    if constexpr (KVI || (VGL == 4 && PL_META64_PLAIN)) *(pl_v2 *)(A.meta + region + (u64)p * A.c0 + (u64)gi * VG + sub * 4) = x;
                     else __builtin_nontemporal_store(x, (pl_v2 *)(A.meta + region + (u64)p * A.c0 + (u64)gi * VG + sub * 4));
                 }
             }

@@ -12,7 +12,7 @@ WL=${2:-"c2 c2b c3 c3w q2 x6 q1 k9 c5 w2 q7"}   # optional second argument: only
 for w in $WL; do
   DOOR="--engine-door"; [ "$w" = "c3w" ] && DOOR=""   # the headline workload: the same command as the bench line (rfx_select leg included)
   rm -rf /tmp/rp_$w
-  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp_$w -o $w -- python $REPO/bench.py --no-cpu-baseline --no-also --workload $w $DOOR --steps 10 > $OUT/${w}_bench.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp_$w -o $w -- python $REPO/bench.py --no-cpu-baseline --no-also --no-predict --workload $w $DOOR --steps 10 > $OUT/${w}_bench.log 2>&1
   f=$(find /tmp/rp_$w -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $OUT/${w}_kernel_stats.csv
   for c in FETCH_SIZE WRITE_SIZE; do
     rm -rf /tmp/rpc_${w}_$c
