@@ -89,14 +89,26 @@ def _worker(rank, world, port, q):
                 assert np.array_equal(np.isnan(g), np.isnan(w)) and np.allclose(g[ok], w[ok], rtol=1e-9, atol=0), many[i]
             else:
                 assert np.array_equal(g, w), many[i]
-        # key tuples beyond the composite key (the reference's row-hash path) are planned on ONE shard: across ranks the planner says so
-        # (rfx_select hands such a query to the host) instead of answering from local tuples
+        # key tuples beyond the composite key (the reference's row-hash path) across ranks (round 5): every rank groups its rows on the row hash, the
+        # hashed tables are gathered and re-inserted, the tuples proven by a (min, max) pair per key column through the same exchange -- the maxima are
+        # the result's key columns (index_group_list, core/index.c:2731-2790)
         wide = {"k1": rfo.gen_i64(n, 41, 50) * (1 << 50), "k2": rfo.gen_i64(n, 42, 40) * (1 << 45) - (1 << 50), "k3": rfo.gen_i64(n, 43, 3), "v": full["v"], "a": full["a"]}
         mine_w = {c: eng.column(x[cut[rank]:cut[rank + 1]]) for c, x in wide.items()}
         from rayforce_amd._lib import RfxError
+        r = sh.group_by(["k1", "k2", "k3"], [("sum", "v"), ("count", "a")], None, mine_w)
+        want = rfo.select({"from": wide, "by": {"k1": "k1", "k2": "k2", "k3": "k3"}, "s": ("sum", "v"), "c": ("count", "a")})
+        for i, nm in enumerate(("k1", "k2", "k3")):
+            assert np.array_equal(r["key_columns"][i].cpu().numpy(), want[nm]), nm
+        assert np.array_equal(r["results"][1].cpu().numpy(), want["c"]) and np.allclose(r["results"][0].cpu().numpy(), want["s"], rtol=1e-9, atol=0)
+        # ... a null among the key tuples still runs on one shard (MIN / MAX skip nulls: no proof): across ranks the planner says so
+        wide_n = dict(wide)
+        wide_n["k3"] = wide["k3"].copy()
+        wide_n["k3"][5] = -(2**63)
+        mine_n = dict(mine_w)
+        mine_n["k3"] = eng.column(wide_n["k3"][cut[rank]:cut[rank + 1]])
         try:
-            sh.group_by(["k1", "k2", "k3"], [("sum", "v")], None, mine_w)
-            raise AssertionError("a row-hash group-by across ranks was answered")
+            sh.group_by(["k1", "k2", "k3"], [("sum", "v")], None, mine_n)
+            raise AssertionError("key tuples with a null key across ranks were answered")
         except RfxError as e:
             assert "one shard" in str(e), str(e)
         # ... while composite keys that fit 64 bits group across the ranks like any dense / hashed key
