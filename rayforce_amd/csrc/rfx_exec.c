@@ -105,20 +105,21 @@ static void *worker_main(void *p) {
             if (__atomic_load_n(&x->gen, __ATOMIC_ACQUIRE) != seen || __atomic_load_n(&x->stop, __ATOMIC_ACQUIRE)) break;
             cpu_relax();
         }
-        pthread_mutex_lock(&x->mu);
-        while (x->gen == seen && !x->stop) {
-            x->sleepers++;
-            pthread_cond_wait(&x->cv_go, &x->mu);
-            x->sleepers--;
-        }
-        if (x->stop) {
+        if (__atomic_load_n(&x->gen, __ATOMIC_ACQUIRE) == seen && !__atomic_load_n(&x->stop, __ATOMIC_ACQUIRE)) { /* nothing came while polling: sleep */
+            pthread_mutex_lock(&x->mu);
+            while (x->gen == seen && !x->stop) {
+                x->sleepers++;
+                pthread_cond_wait(&x->cv_go, &x->mu);
+                x->sleepers--;
+            }
             pthread_mutex_unlock(&x->mu);
-            return NULL;
         }
-        seen = x->gen;
+        if (__atomic_load_n(&x->stop, __ATOMIC_ACQUIRE)) return NULL;
+        /* (the fast path takes no lock: fn / arg were written before the generation's release store -- seven workers queueing for one mutex were
+         *  most of a hand-over's 11 us at 8 shards) */
+        seen = __atomic_load_n(&x->gen, __ATOMIC_ACQUIRE);
         shard_fn fn = x->fn;
         void *arg = x->arg;
-        pthread_mutex_unlock(&x->mu);
         const int rc = fn(arg, s);
         if (rc != RFX_OK) snprintf(x->errs[s], sizeof(x->errs[s]), "shard %d: %s", s, rfx_hip_last_error());
         x->rcs[s] = rc;
