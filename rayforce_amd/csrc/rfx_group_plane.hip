@@ -917,6 +917,7 @@ struct PlaneHashArgs {
     const u64 *keys, *vals;
     const unsigned *meta, *cnt;
     int *overflow;
+    int dbg; // RFX_PLH_DBG (ablation, WRONG answers): 1 no first-row update, 2 + no probing (the start slot is taken), 3 loads only
     int kvi; // the key and value planes are ONE plane of interleaved 8-record groups (k_plane_scatter's KVI form: 256 partitions)
 };
 #define PLH_T 1024
@@ -960,25 +961,30 @@ __global__ __launch_bounds__(PLH_T) void k_plane_hash_aggregate(const Plan P, co
     }
     __syncthreads();
     const unsigned sbits = PL_SLOT_BITS - (unsigned)X.hbits; // hash bits left for the place in the table
-    auto apply = [&](const unsigned mm, const i64 rbase, const u64 key, const u64 val) __attribute__((always_inline)) {
+    // where a record starts probing: from the meta word's hash bits
+    auto start_of = [&](const unsigned mm) __attribute__((always_inline)) {
         const unsigned hb = mm & ((1u << PL_SLOT_BITS) - 1u);
-        if ((int)(hb >> sbits) != half) return; // another workgroup's share of this partition
-        const unsigned lrow = (unsigned)(rbase + (i64)(mm >> PL_SLOT_BITS));
-        int idx = -1;
-        if ((i64)key != RFX_NULL_I64_D) {
-            unsigned s = (unsigned)(((u64)(hb & ((1u << sbits) - 1u)) * (u64)C) >> sbits);
-            for (int probe = 0; probe < PLH_PROBES; probe++) {
-                const u64 k = lkey[s];
-                if (k == key) { idx = (int)s; break; }
-                if ((i64)k == RFX_NULL_I64_D) {
-                    const u64 old = atomicCAS((unsigned long long *)&lkey[s], (unsigned long long)RFX_NULL_I64_D, (unsigned long long)key);
-                    if ((i64)old == RFX_NULL_I64_D || old == key) { idx = (int)s; break; }
-                }
-                s = (s + 1 == C) ? 0 : s + 1;
+        return (unsigned)(((u64)(hb & ((1u << sbits) - 1u)) * (u64)C) >> sbits);
+    };
+    auto mine_of = [&](const unsigned mm) __attribute__((always_inline)) { return (int)((mm & ((1u << PL_SLOT_BITS) - 1u)) >> sbits) == half; };
+    // the slot of `key` (find or insert), the FIRST probe already read: k0 = lkey[s] as it stood a moment ago (a slot never changes once it
+    // holds a key; an empty one is claimed by ds_cmpst, whose answer says who got it).  -1: no room / the null key
+    auto slot_of = [&](const u64 key, unsigned s, u64 k0) __attribute__((always_inline)) {
+        if ((i64)key == RFX_NULL_I64_D) return -1;
+        for (int probe = 0; probe < PLH_PROBES; probe++) {
+            const u64 k = probe ? lkey[s] : k0;
+            if (k == key) return (int)s;
+            if ((i64)k == RFX_NULL_I64_D) {
+                const u64 old = atomicCAS((unsigned long long *)&lkey[s], (unsigned long long)RFX_NULL_I64_D, (unsigned long long)key);
+                if ((i64)old == RFX_NULL_I64_D || old == key) return (int)s;
             }
+            s = (s + 1 == C) ? 0 : s + 1;
         }
+        return -1;
+    };
+    auto fold = [&](const int idx, const unsigned lrow, const unsigned f0, const u64 key, const u64 val) __attribute__((always_inline)) {
         if (idx >= 0) {
-            if (lrow < lfirst[idx]) atomicMin(&lfirst[idx], lrow);
+            if (X.dbg != 1 && lrow < f0) atomicMin(&lfirst[idx], lrow); // (f0: lfirst[idx] as read a moment ago -- it only ever goes down)
             if constexpr (FAST) {
                 unsafeAtomicAdd((double *)&larr[idx], rfx_as_f64(val));
                 return;
@@ -1030,16 +1036,48 @@ __global__ __launch_bounds__(PLH_T) void k_plane_hash_aggregate(const Plan P, co
             B.m[k] = __builtin_nontemporal_load((const pl_m2 *)(X.meta + base + i));
         }
     };
+    // A lane's FOUR records of a batch go through the table together (round 5): the four first probes are read back to back, then the four
+    // slots are settled (the rare longer chains and the inserts one by one), then the four first-row words are read back to back, then the
+    // folds -- four LDS round trips in flight where the record-by-record form waited for each in turn (the pass is bound by exactly that
+    // latency: with the probes switched off it runs at the speed of its loads, tools/k9_ablate.py).
     auto consume = [&](const Batch &B) __attribute__((always_inline)) {
         const i64 rbase = (i64)B.b * X.block_rows;
+        unsigned mm[4], st[4], lrow[4], f0[4];
+        u64 key[4], val[4], k0[4];
+        bool on[4];
+        int idx[4];
 #pragma unroll
         for (int k = 0; k < 2; k++) {
             const unsigned i = B.i0 + ((unsigned)k * 64u + (unsigned)lane) * 2u;
-            if (i < B.n) {
-                apply(B.m[k].x, rbase, B.key[k].x, B.val[k].x);
-                if (i + 1 < B.n) apply(B.m[k].y, rbase, B.key[k].y, B.val[k].y);
-            }
+            mm[2 * k] = B.m[k].x, mm[2 * k + 1] = B.m[k].y;
+            key[2 * k] = B.key[k].x, key[2 * k + 1] = B.key[k].y;
+            val[2 * k] = B.val[k].x, val[2 * k + 1] = B.val[k].y;
+            on[2 * k] = i < B.n && mine_of(mm[2 * k]);
+            on[2 * k + 1] = i + 1 < B.n && mine_of(mm[2 * k + 1]);
         }
+        if (X.dbg >= 2) { // ablations (WRONG answers): 3 = the loads only, 2 = + one f64 add at the start slot, no probing
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                asm volatile("" ::"v"(key[j]), "v"(val[j]), "v"(mm[j]));
+                if (X.dbg == 2 && on[j]) unsafeAtomicAdd((double *)&larr[start_of(mm[j])], rfx_as_f64(val[j]));
+            }
+            return;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            st[j] = start_of(mm[j]);
+            k0[j] = lkey[st[j]];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) idx[j] = on[j] ? slot_of(key[j], st[j], k0[j]) : -1;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            lrow[j] = (unsigned)(rbase + (i64)(mm[j] >> PL_SLOT_BITS));
+            f0[j] = lfirst[idx[j] >= 0 ? idx[j] : 0];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            if (on[j]) fold(idx[j], lrow[j], f0[j], key[j], val[j]);
     };
     const int q = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nreg = q < X.nblk ? (X.nblk - q + NW - 1) / NW : 0;
@@ -1208,6 +1246,10 @@ int rfx_plane_hash_accumulate(rfx_ctx *c, const Plan &P, int key_idx, const Hash
     X.keys = A.vals[0];
     X.vals = A.vals[1];
     X.kvi = (parts == 256); // (<.., 2, 8, 3, true>: the interleaved key | value plane)
+    {
+        static const char *dbg = getenv("RFX_PLH_DBG");
+        X.dbg = dbg ? atoi(dbg) : 0;
+    }
     X.meta = A.meta;
     X.cnt = A.cnt;
     X.overflow = d_overflow;
