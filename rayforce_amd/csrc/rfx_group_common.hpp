@@ -171,6 +171,36 @@ __device__ __forceinline__ void group_apply(u64 *acc, unsigned *cnt, int kind, i
     }
 }
 
+// ... the same without atomics, for a cell only this workgroup writes during the launch
+__device__ __forceinline__ void group_merge_cell_plain(u64 *gacc, u64 *gcnt, int kind, int f64, u64 a, u64 c) {
+    switch (kind) {
+        case RFX_AGG_SUM:
+            if (f64) { if (a != 0ULL) *gacc = rfx_as_u64(rfx_as_f64(*gacc) + rfx_as_f64(a)); }
+            else {
+                if (a) *gacc += a;
+                if (c) *gcnt += c;
+            }
+            break;
+        case RFX_AGG_AVG:
+            if (c) {
+                *gacc = rfx_as_u64(rfx_as_f64(*gacc) + rfx_as_f64(a));
+                *gcnt += c;
+            }
+            break;
+        case RFX_AGG_MIN:
+            if ((i64)a != RFX_INF_I64_D && (i64)a < (i64)*gacc) *gacc = a;
+            break;
+        case RFX_AGG_MAX:
+            if ((i64)a != RFX_NULL_I64_D && (i64)a > (i64)*gacc) *gacc = a;
+            break;
+        case RFX_AGG_COUNT:
+            if (a) *gacc += a;
+            break;
+        default:
+            break;
+    }
+}
+
 // Merge one LDS cell into the global tables.
 __device__ __forceinline__ void group_merge_cell(u64 *gacc, u64 *gcnt, int kind, int f64, u64 a, u64 c) {
     switch (kind) {

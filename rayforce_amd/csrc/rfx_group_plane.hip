@@ -383,6 +383,7 @@ struct PlaneAggArgs {
     i64 kmin, range;
     i64 local; // table cells per partition: slots congruent to one residue mod 2^pbits
     int split; // workgroups per partition
+    int excl;  // split == 1: this workgroup alone writes its partition's slots during the launch -- the write-out needs no atomics
     int nblk, pbits;
     int agg_pl[RFX_MAX_AGGS]; // loaded plane of aggregate a (-1: none: COUNT / FIRST)
     i64 block_rows;
@@ -549,6 +550,16 @@ __global__ __launch_bounds__(THREADS) void k_plane_aggregate(const Plan P, const
         const i64 g = (i << A.pbits) | (i64)(((u64)p - (u64)A.kmin) & (u64)((1 << A.pbits) - 1));
         if (g >= A.range) continue;
         const u64 fr = (u64)P.row0 + (u64)f;
+        if (A.excl) { // (round 5) nobody else touches slot g while this launch runs: plain read-modify-write instead of two to four device atomics a slot
+            if (fr < A.first[g]) A.first[g] = fr;
+#pragma unroll
+            for (int a = 0; a < RFX_MAX_AGGS; a++) {
+                if (kind[a] < 0) continue;
+                const bool hc = cnt_of[a] >= 0;
+                group_merge_cell_plain(&A.acc[a][g], hc ? &A.cntt[a][g] : (u64 *)0, kind[a], f64[a], accs[(i64)a * local + i], hc ? (u64)cnts[(i64)cnt_of[a] * local + i] : 0ULL);
+            }
+            continue;
+        }
         if (fr < A.first[g]) atomicMin((unsigned long long *)&A.first[g], (unsigned long long)fr);
 #pragma unroll
         for (int a = 0; a < RFX_MAX_AGGS; a++) {
@@ -658,6 +669,7 @@ struct PlaneState { // what rfx_plane_scope leaves for rfx_plane_accumulate (liv
     const void *key;
     const void *val[PL_MAX_NV];
     i64 nrows;
+    i64 seen; // records in the planes (the selected rows)
     u64 sig[RFX_MAX_PREDS][6];
 };
 static PlaneState *plane_state(rfx_ctx *c) {
@@ -767,6 +779,7 @@ int rfx_plane_scope(rfx_ctx *c, const Plan &P, int key_idx, const void *d_key, i
     }
     const u64 *hs = (const u64 *)hctl + 8;
     *seen = (i64)hs[2];
+    plane_state(c)->seen = *seen;
     *kmin = (i64)(~hs[0] ^ 0x8000000000000000ULL);
     *kmax = (i64)(hs[1] ^ 0x8000000000000000ULL);
     if (*seen > 0 && *kmin == RFX_NULL_I64_D) return RFX_ESTATE; // a null key among the selected rows: the exact scope pass counts them
@@ -876,6 +889,16 @@ int rfx_plane_accumulate(rfx_ctx *c, const Plan &P, int key_idx, const rfx_group
             // big tables: one 1024-lane workgroup per CU
             G.split = (c->num_cus + nparts - 1) / nparts;
             if (G.split < 1) G.split = 1;
+            // A SHORT pass (round 5): two workgroups per partition each fold their LDS table into the device tables by atomics -- 4e6 of them for
+            // 1e6 slots, 0.16 ms whatever the record count (the per-device pass of an 8-way split, a 1e8-row table: more than the records cost).
+            // One workgroup per partition owns its slots for the launch and writes them plainly; its record loop takes twice as long, which
+            // pays below ~4e7 records.  RFX_PLANE_AGG_SPLIT=<n> forces the split (A/B).
+            {
+                static const char *fs = getenv("RFX_PLANE_AGG_SPLIT");
+                if (fs && atoi(fs) >= 1) G.split = atoi(fs);
+                else if (st->seen > 0 && st->seen <= 40000000) G.split = 1;
+            }
+            G.excl = G.split == 1;
             rc = launch_plane_aggregate<1024>(c, Ps, G, nvl, fast, nparts * G.split, lds, 160 * 1024);
         } else {
             const int per_cu = (int)((156 * 1024) / lds) < 4 ? (int)((156 * 1024) / lds) : 4; // 512-lane workgroups a CU can hold: 3 at 51 KB

@@ -47,7 +47,11 @@ class _View:
 
 class Engine:
     """One GPU.  ``shards=k`` splits every query row-range over k contexts on that GPU (each on its own stream and host thread, merged by
-    the planner's device kernels): the logic one evaluator process runs over the GPUs of a node, testable on one."""
+    the planner's device kernels): the logic one evaluator process runs over the GPUs of a node, testable on one.
+
+    An Engine is driven by ONE Python thread at a time (the planner and its contexts are not re-entrant).  Results hold their device blocks
+    through an owner object whose finaliser may run on whatever thread the garbage collector picks: that is safe -- it only hands blocks
+    back to the contexts' pools, which share one process-wide lock (rfx_ctx.hip) -- but it is the only cross-thread call that is."""
 
     def __init__(self, device: Union[int, torch.device, None] = None, shards: int = 1):
         self.lib = L.load_library()
