@@ -212,3 +212,14 @@ def test_plan_kernels_prewarm_into_the_disk_cache_without_a_device(built, tmp_pa
     again = run("more")
     assert again == [[True, True, True], 1, 1], again  # a new process: C2b from disk, only C5 compiled
     assert len(os.listdir(cache)) == 2
+
+
+def test_phase_handover_probe_runs_without_a_device(built):
+    """rfx_exec_probe_handover_us: the planner's phase hand-over over a bare worker pool (what bench.py's predicted T(N) charges per phase)."""
+    from rayforce_amd import _lib
+    lib = _lib.load_library()
+    assert lib.rfx_exec_probe_handover_us(1, 10) == 0.0 or lib.rfx_exec_probe_handover_us(1, 10) < 5.0
+    for n in (2, 4, 8):
+        us = lib.rfx_exec_probe_handover_us(n, 500)
+        assert 0.0 < us < 5000.0, (n, us)
+    assert lib.rfx_exec_probe_handover_us(0, 10) < 0 and lib.rfx_exec_probe_handover_us(99, 10) < 0

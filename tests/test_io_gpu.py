@@ -112,3 +112,18 @@ def test_parted_table_written_by_the_reference(eng, tmp_path):
     from rayforce_amd._lib import RfxError
     with pytest.raises(RfxError, match="Date column only"):
         eng.load_parted(root, "tab", where=("<", "a", 5))
+
+
+def test_large_blocks_come_back_through_pinned_staging(eng):
+    """rfx_hip_d2h_pipelined (what rfx_exec_groups_fetch_all uses for result columns >= 64 MB): 32 MB chunks through pinned staging, the destination written
+    by several host threads -- every byte where it belongs, ragged tail included; small blocks take the plain copy."""
+    import ctypes as C
+    import numpy as np
+    import torch
+    for n in (1 << 20, (200 << 20) // 8 + 12_345):
+        src = torch.arange(n, dtype=torch.int64, device="cuda") * 3 + 1
+        dst = np.empty(n, dtype=np.int64)
+        torch.cuda.synchronize()
+        rc = eng.lib.rfx_hip_d2h_pipelined(eng._ctx, C.c_void_p(dst.ctypes.data), C.c_void_p(src.data_ptr()), C.c_size_t(n * 8))
+        assert rc == 0
+        assert dst[0] == 1 and dst[-1] == 3 * (n - 1) + 1 and np.array_equal(dst, np.arange(n, dtype=np.int64) * 3 + 1)
