@@ -732,6 +732,8 @@ def one_process(args):
     tab = ops.rfx_host_table(H.symbols(list(spec)), H.list_of(cols))
     d = H.select_dict(q, tab)
     dt, got = door_run(ops, H, d, args.steps, args.warmup)
+    steps_ms = dict(door_run.last_steps_ms)
+    phases = door_phases(ops, H, d) if "by" in q else None
     checked = door_property_check(name, got, shards, q, lambda x: x)
     x = C.c_void_p(ops.rfx_ops_exec())
     w = WORKLOADS[name]
@@ -745,7 +747,9 @@ def one_process(args):
                                + ("the planner's device kernel" if len(uniq) == 1 else "one fused RCCL exchange over xGMI"),
                    "door": "rfx_select on per-shard device column handles (rfx_ops_set_shards); result table built on the host inside the timed region",
                    "verified": checked, "resident": "HBM (columns generated on every device)",
-                   "planner": {"merges_by_kernel": int(ops.rfx_exec_stat(x, L.RFX_XSTAT_MERGES_KERNEL)), "fused_rccl_exchanges": int(ops.rfx_exec_stat(x, L.RFX_XSTAT_MERGES_RCCL))}},
+                   "planner": {"merges_by_kernel": int(ops.rfx_exec_stat(x, L.RFX_XSTAT_MERGES_KERNEL)), "fused_rccl_exchanges": int(ops.rfx_exec_stat(x, L.RFX_XSTAT_MERGES_RCCL)),
+                               "sliced_results": int(ops.rfx_exec_stat(x, L.RFX_XSTAT_SLICED))}},
+        "steps_ms": steps_ms, "phases_ms": phases,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "kernel": w["kernel"],
                      "kernel_ms": ms, "algorithmic_bytes_per_launch": w["bytes_per_row"] * total / N},
         "cpu_baseline": None}), flush=True)
