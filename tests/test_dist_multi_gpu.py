@@ -152,6 +152,7 @@ if WORLD > 1:
     assert len(devs) == WORLD, devs                                   # one shard per device
     assert ops.rfx_exec_stat(x, L.RFX_XSTAT_MERGES_RCCL) > 0          # the fused exchange over xGMI merged the tables
     assert ops.rfx_exec_stat(x, L.RFX_XSTAT_MERGES_KERNEL) == 0       # (no two shards share a device)
+    assert ops.rfx_exec_stat(x, L.RFX_XSTAT_SLICED) > 0               # every device emitted and read back ITS range of the groups (the FIRST query stays whole)
 else:  # the same script on the one device of the builder's boxes: two shards on it, merged by the kernel
     assert ops.rfx_ops_shards() == 2 and ops.rfx_exec_stat(x, L.RFX_XSTAT_MERGES_KERNEL) > 0
 print("ONE-PROCESS-OK")
