@@ -391,6 +391,13 @@ int rfx_hip_group_emit(rfx_ctx_t *ctx, const rfx_agg_t *aggs, const rfx_group_ta
  * result column over the GPUs (as integers) yields the value -- exactly one GPU contributes.  Everything else as rfx_hip_group_emit. */
 int rfx_hip_group_emit_sharded(rfx_ctx_t *ctx, const rfx_agg_t *aggs, const rfx_group_tables_t *t, int64_t row0, int64_t local_rows,
                                int64_t *d_keys, int64_t *d_first_ids, void *const *d_results);
+/* Rank -> emit as ONE sequence of launches with no host round trip between them (tables of at most RFX_RANK_EMIT_MAX slots): rfx_hip_group_rank's
+ * steps, the last of which also writes the result cells (rfx_hip_group_emit_sharded's), and the group count back at the end (syncs).  The outputs are
+ * sized BEFORE the count is known: `out_cap` cells per column (>= the window's groups: min(slots, selected rows) / nsl + 1; RFX_ELIMIT if it did not
+ * hold).  nsl > 1: only the groups [g * si / nsl, g * (si + 1) / nsl) are written, from cell 0 on (the emit window, computed on the device). */
+#define RFX_RANK_EMIT_MAX (1 << 22)
+int rfx_hip_group_rank_emit(rfx_ctx_t *ctx, const rfx_agg_t *aggs, const rfx_group_tables_t *t, int64_t total_rows, int64_t row0, int64_t local_rows,
+                            int nsl, int si, int64_t out_cap, int64_t *d_keys, int64_t *d_first_ids, void *const *d_results, int64_t *ngroups);
 /* Emit WINDOW: until it is reset (n = 0), rfx_hip_group_emit(_sharded) / rfx_hip_hash_emit(_sharded) on this context write only the groups
  * [g0, g0 + n) -- group g at cell g - g0 of every output, which then need n cells.  The sharded tail of a group-by: after the merge every
  * device holds the whole tables, ranks them (the same order everywhere) and emits ITS slice of the groups, which its own host thread
@@ -419,6 +426,8 @@ int rfx_hip_hash_emit(rfx_ctx_t *ctx, const rfx_agg_t *aggs, const rfx_hash_tabl
                       int64_t *d_first_ids, void *const *d_results);
 int rfx_hip_hash_emit_sharded(rfx_ctx_t *ctx, const rfx_agg_t *aggs, const rfx_hash_tables_t *t, int64_t row0, int64_t local_rows,
                               int64_t *d_keys, int64_t *d_first_ids, void *const *d_results);
+int rfx_hip_hash_rank_emit(rfx_ctx_t *ctx, const rfx_agg_t *aggs, const rfx_hash_tables_t *t, int64_t total_rows, int64_t row0, int64_t local_rows,
+                           int nsl, int si, int64_t out_cap, int64_t *d_keys, int64_t *d_first_ids, void *const *d_results, int64_t *ngroups);
 
 /* ---- per-row group ids (INDEX_TYPE_IDS payload, core/index.c:2069-2089) -- only when a caller wants it ---- */
 int rfx_hip_group_ids_dense(rfx_ctx_t *ctx, const int64_t *d_key, int64_t nrows, const rfx_group_tables_t *t,

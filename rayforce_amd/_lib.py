@@ -211,6 +211,10 @@ PROTOTYPES = {
     "rfx_hip_scope_sample_i64": (C.c_int, [_ctx, C.c_void_p, C.c_int64, _P(C.c_int64), _P(C.c_int64)]),
     "rfx_hip_ctx_speculative": (C.c_int, [_ctx, C.c_int]),
     "rfx_hip_ctx_emit_window": (C.c_int, [_ctx, C.c_int64, C.c_int64]),
+    "rfx_hip_group_rank_emit": (C.c_int, [_ctx, _P(Agg), _P(GroupTables), C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p,
+                                          _P(C.c_void_p), _P(C.c_int64)]),
+    "rfx_hip_hash_rank_emit": (C.c_int, [_ctx, _P(Agg), _P(HashTables), C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p,
+                                         _P(C.c_void_p), _P(C.c_int64)]),
     "rfx_hip_group_out_of_scope": (C.c_int, [_ctx, _P(C.c_int)]),
     "rfx_hip_group_rank_emit_small": (C.c_int, [_ctx, _P(Agg), _P(GroupTables), C.c_int64, C.c_int64, C.c_void_p]),
     "rfx_hip_group_emit_sharded": (C.c_int, [_ctx, _P(Agg), _P(GroupTables), C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, _P(C.c_void_p)]),

@@ -60,6 +60,7 @@ struct rfx_exec {
     int nspec_wide, wide_ring;
     int64_t stat[RFX_XSTAT_N];
     int timing;       /* rfx_exec_timing: per-phase wall time into stat[RFX_XSTAT_NS_*], a sync at every phase end */
+    int two_step_rank;   /* RFX_TWO_STEP_RANK=1: rank, the group count back, then emit (rounds 1-4; A/B) instead of rank -> emit without the round trip */
     int no_d2h_pipeline; /* RFX_NO_D2H_PIPELINE=1: large result columns by one plain copy each (A/B) */
     int slice_shards; /* RFX_EXEC_SLICE_SHARDS=1: every SHARD owns a slice of a sliced result, not only every device's lead (how the sharded
                        * tail runs on a one-GPU box: the merged tables are copied to the shards beside their lead first) */
@@ -168,6 +169,7 @@ int rfx_exec_create(rfx_ctx_t *const *ctxs, int nshards, rfx_exec_t **out) {
     x->nshards = nshards;
     x->slice_shards = getenv("RFX_EXEC_SLICE_SHARDS") != NULL;
     x->no_d2h_pipeline = getenv("RFX_NO_D2H_PIPELINE") != NULL;
+    x->two_step_rank = getenv("RFX_TWO_STEP_RANK") != NULL;
     for (int s = 0; s < nshards; s++) {
         if (!ctxs[s]) { free(x); return RFX_EINVAL; }
         x->ctx[s] = ctxs[s];
@@ -1135,7 +1137,26 @@ static int ph_rank_emit(void *arg, int s) {
     void *ptrs[RFX_MAX_AGGS];
     int rc;
     h->g0 = h->gn = 0;
-    {
+    const int64_t slots = G->dense ? (int64_t)G->range : G->cap + 1;
+    if (!x->two_step_rank && slots <= RFX_RANK_EMIT_MAX) {
+        /* rank -> emit with no host round trip between them: the outputs are sized before the group count is known -- groups <= min(slots, selected
+         * rows), a slice its share + 1 -- and the count comes back once everything is enqueued */
+        int64_t bound = slots < G->seen ? slots : G->seen;
+        if (bound < 1) bound = 1;
+        const int64_t cap = bound / nsl + 1;
+        if ((rc = rfx_hip_malloc(c, &h->dout, (size_t)(G->na + 1) * (size_t)cap * 8)) != RFX_OK) return rc;
+        if ((G->want_first || !G->dense) && (rc = rfx_hip_malloc(c, &h->dfirst, (size_t)cap * 8)) != RFX_OK) return rc;
+        for (int a = 0; a < G->na; a++) ptrs[a] = (int64_t *)h->dout + (size_t)(a + 1) * (size_t)cap;
+        h->gstride = cap;
+        rc = G->dense ? rfx_hip_group_rank_emit(c, h->aggs, &h->gt, G->total_rows, r0, nloc, nsl, sl, cap, (int64_t *)h->dout, (int64_t *)h->dfirst, ptrs, &h->groups)
+                      : rfx_hip_hash_rank_emit(c, h->aggs, &h->ht, G->total_rows, r0, nloc, nsl, sl, cap, (int64_t *)h->dout, (int64_t *)h->dfirst, ptrs, &h->groups);
+        if (x->timing) h->t_rank = now_ns();
+        if (rc != RFX_OK) return rc;
+        const int64_t g = h->groups;
+        h->g0 = nsl > 1 ? (int64_t)((__int128)g * sl / nsl) : 0;
+        h->gn = nsl > 1 ? (int64_t)((__int128)g * (sl + 1) / nsl) - h->g0 : g;
+        if (g == 0 || h->gn == 0) return RFX_OK;
+    } else {
         rc = G->dense ? rfx_hip_group_rank(c, &h->gt, G->total_rows, &h->groups) : rfx_hip_hash_rank(c, &h->ht, G->total_rows, &h->groups);
         if (x->timing) h->t_rank = now_ns();
         if (rc != RFX_OK || h->groups == 0) return rc;

@@ -708,21 +708,68 @@ __global__ __launch_bounds__(RFX_BLOCK) void k_slot_gid(const u64 *__restrict__ 
     }
 }
 
+// k_slot_gid + k_group_emit in one step: a slot's group id, and at once its result cells where the group falls into the window
+// [g * si / nsl, g * (si + 1) / nsl) -- g read from the scan's total on the device.  *overflow: the window holds more groups than out_cap cells
+__global__ __launch_bounds__(RFX_BLOCK) void k_slot_gid_emit(const EmitArgs A0, i64 row_base, const u64 *__restrict__ bitmap, const i64 *__restrict__ chunk_off,
+                                                            i64 *__restrict__ gid, const i64 *__restrict__ d_total, int nsl, int si, i64 out_cap, int *__restrict__ overflow) {
+    const i64 groups = *d_total;
+    EmitArgs A = A0;
+    A.g0 = 0;
+    A.gn = groups;
+    if (nsl > 1) {
+        A.g0 = (i64)((__int128)groups * si / nsl);
+        A.gn = (i64)((__int128)groups * (si + 1) / nsl) - A.g0;
+    }
+    if (A.gn > out_cap) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) *overflow = 1;
+        A.gn = 0;
+    }
+    for (i64 i = blockIdx.x * (i64)RFX_BLOCK + threadIdx.x; i < A.slots; i += (i64)gridDim.x * RFX_BLOCK) {
+        const u64 f = A.first[i];
+        if (f == (u64)RFX_INF_I64_D) {
+            gid[i] = -1;
+            continue;
+        }
+        const u64 row = f - (u64)row_base;
+        const u64 q = row >> 9;
+        const unsigned within = (unsigned)(row & 511);
+        const unsigned gq = within >> 7, r = within & 127, lane = r >> 1, par = r & 1;
+        const u64 *w = bitmap + q * 8;
+        i64 rank = chunk_off[q];
+        for (unsigned gg = 0; gg < gq; gg++) rank += __popcll(w[2 * gg]) + __popcll(w[2 * gg + 1]);
+        const u64 below = lane ? (~0ULL >> (64 - lane)) : 0ULL;
+        rank += __popcll(w[2 * gq] & below) + __popcll(w[2 * gq + 1] & below);
+        if (par) rank += (i64)((w[2 * gq] >> lane) & 1ULL);
+        gid[i] = rank;
+        const i64 g = rank - A.g0;
+        if ((u64)g >= (u64)A.gn) continue;
+        if (A.out_keys) A.out_keys[g] = A.keys ? (i64)A.keys[i] : A.kmin + i;
+        if (A.out_first) A.out_first[g] = (i64)f;
+        for (int a = 0; a < A.nagg; a++) {
+            if (!A.out[a]) continue;
+            if (A.kinds[a] == RFX_AGG_FIRST) {
+                const i64 lr = (i64)f - A.row0;
+                A.out[a][g] = (A.col[a] && lr >= 0 && (A.nloc == 0 || lr < A.nloc)) ? A.col[a][lr] : 0ULL;
+            } else A.out[a][g] = group_final(A.kinds[a], A.f64s[a], A.acc[a][i], A.cnt[a] ? A.cnt[a][i] : 0ULL, A.skips[a]);
+        }
+    }
+}
+
 // shared by the dense and the hashed tables
-int rfx_rank_slots(rfx_ctx *c, const u64 *d_first, i64 slots, i64 row_base, i64 total_rows, i64 *ngroups) {
+static int rfx_rank_slots_emit(rfx_ctx *c, const u64 *d_first, i64 slots, i64 row_base, i64 total_rows, i64 *ngroups, const EmitArgs *emit, int nsl, int si, i64 out_cap) {
     c->pc_bitmap = 0; // ranking marks first rows in the context's bitmap
     c->where_n = -1;
     RFX_REQUIRE(total_rows >= 0, RFX_EINVAL, "total_rows < 0");
     const i64 nchunks = (total_rows + RFX_CHUNK - 1) / RFX_CHUNK;
     int rc = rfx_bitmap_reserve(c, nchunks * RFX_CHUNK);
     if (rc != RFX_OK) return rc;
-    if (c->blksum_cap < (size_t)nchunks + 2) {
+    if (c->blksum_cap < (size_t)nchunks + 3) {
         RFX_HIP_CHECK(hipStreamSynchronize(c->stream));
         if (c->d_blksum) RFX_HIP_CHECK(hipFree(c->d_blksum));
         c->d_blksum = NULL;
         c->blksum_cap = 0;
-        RFX_HIP_CHECK(hipMalloc((void **)&c->d_blksum, ((size_t)nchunks + 2) * 8));
-        c->blksum_cap = (size_t)nchunks + 2;
+        RFX_HIP_CHECK(hipMalloc((void **)&c->d_blksum, ((size_t)nchunks + 3) * 8));
+        c->blksum_cap = (size_t)nchunks + 3;
     }
     rc = rfx_gid_reserve(c, slots);
     if (rc != RFX_OK) return rc;
@@ -733,7 +780,7 @@ int rfx_rank_slots(rfx_ctx *c, const u64 *d_first, i64 slots, i64 row_base, i64 
         return RFX_OK;
     }
     i64 *d_total = c->d_blksum + nchunks, *d_bound = c->d_blksum + nchunks + 1; // chunks up to the last first row (device-side)
-    RFX_HIP_CHECK(hipMemsetAsync(d_bound, 0, 8, c->stream));
+    RFX_HIP_CHECK(hipMemsetAsync(d_bound, 0, 16, c->stream)); // (the bound and, behind it, the emit's overflow flag)
     i64 sb = (slots + RFX_BLOCK - 1) / RFX_BLOCK;
     int sgrid = rfx_grid(c) * 4;
     if (sb < sgrid) sgrid = (int)sb;
@@ -747,15 +794,30 @@ int rfx_rank_slots(rfx_ctx *c, const u64 *d_first, i64 slots, i64 row_base, i64 
     RFX_HIP_CHECK(hipGetLastError());
     rc = rfx_scan_counts(c, c->d_blksum, nchunks, d_total, d_bound);
     if (rc != RFX_OK) return rc;
-    hipLaunchKernelGGL(k_slot_gid, dim3(sgrid), dim3(RFX_BLOCK), 0, c->stream, d_first, slots, row_base, (const u64 *)c->d_bitmap,
-                       (const i64 *)c->d_blksum, c->d_gid);
+    if (emit) { // rank -> emit WITHOUT the host in between: the last step also writes the groups' result cells (the window from the count on the device)
+        EmitArgs A = *emit;
+        hipLaunchKernelGGL(k_slot_gid_emit, dim3(sgrid), dim3(RFX_BLOCK), 0, c->stream, A, row_base, (const u64 *)c->d_bitmap, (const i64 *)c->d_blksum, c->d_gid,
+                           (const i64 *)d_total, nsl, si, out_cap, (int *)(d_bound + 1));
+    } else
+        hipLaunchKernelGGL(k_slot_gid, dim3(sgrid), dim3(RFX_BLOCK), 0, c->stream, d_first, slots, row_base, (const u64 *)c->d_bitmap,
+                           (const i64 *)c->d_blksum, c->d_gid);
     RFX_HIP_CHECK(hipGetLastError());
     i64 *h = (i64 *)c->h_pin;
-    RFX_HIP_CHECK(hipMemcpyAsync(h, d_total, 8, hipMemcpyDeviceToHost, c->stream));
+    RFX_HIP_CHECK(hipMemcpyAsync(h, d_total, emit ? 24 : 8, hipMemcpyDeviceToHost, c->stream)); // (total, bound, overflow flag: neighbours)
     RFX_HIP_CHECK(hipStreamSynchronize(c->stream));
     c->rank_groups = h[0];
     *ngroups = h[0];
+    RFX_REQUIRE(!emit || (int)h[2] == 0, RFX_ELIMIT, "rank_emit: more groups in the window than the output columns hold");
     return RFX_OK;
+}
+int rfx_rank_slots(rfx_ctx *c, const u64 *d_first, i64 slots, i64 row_base, i64 total_rows, i64 *ngroups) {
+    return rfx_rank_slots_emit(c, d_first, slots, row_base, total_rows, ngroups, nullptr, 1, 0, 0);
+}
+// rank + emit, launch after launch with no host round trip between them (round 5): the host learns the group count when everything is enqueued,
+// so the outputs are sized by an upper bound (`out_cap` cells a column); tables beyond 2^22 slots keep the two-step form (their emit walks the groups)
+int rfx_rank_emit(rfx_ctx *c, const EmitArgs &A, i64 total_rows, int nsl, int si, i64 out_cap, i64 *ngroups) {
+    RFX_REQUIRE(nsl >= 1 && si >= 0 && si < nsl && out_cap >= 0, RFX_EINVAL, "rank_emit: bad window");
+    return rfx_rank_slots_emit(c, A.first, A.slots, 0, total_rows, ngroups, &A, nsl, si, out_cap);
 }
 
 extern "C" int rfx_hip_group_rank(rfx_ctx_t *c, const rfx_group_tables_t *t, int64_t total_rows, int64_t *ngroups) {
@@ -905,6 +967,34 @@ extern "C" int rfx_hip_group_rank_emit_small(rfx_ctx_t *c, const rfx_agg_t *aggs
     return RFX_OK;
 }
 
+extern "C" int rfx_hip_group_rank_emit(rfx_ctx_t *c, const rfx_agg_t *aggs, const rfx_group_tables_t *t, int64_t total_rows, int64_t row0, int64_t local_rows,
+                                       int nsl, int si, int64_t out_cap, int64_t *d_keys, int64_t *d_first_ids, void *const *d_results, int64_t *ngroups) {
+    RFX_REQUIRE(c && t && ngroups, RFX_EINVAL, "NULL argument");
+    RFX_REQUIRE(local_rows >= 0, RFX_EINVAL, "local_rows < 0");
+    int rc = check_tables(aggs, t);
+    if (rc != RFX_OK) return rc;
+    RFX_REQUIRE(t->range >= 1 && t->range <= RFX_RANK_EMIT_MAX, RFX_EINVAL, "rank_emit: 1 .. RFX_RANK_EMIT_MAX slots");
+    EmitArgs A;
+    memset(&A, 0, sizeof(A));
+    A.kmin = t->kmin;
+    A.slots = t->range;
+    A.nagg = t->nagg;
+    A.first = (const u64 *)t->d_first;
+    A.out_keys = (i64 *)d_keys;
+    A.out_first = (i64 *)d_first_ids;
+    A.row0 = row0;
+    A.nloc = local_rows;
+    for (int a = 0; a < t->nagg; a++) {
+        A.kinds[a] = aggs[a].kind;
+        A.f64s[a] = rfx_agg_input_type(&aggs[a]) == RFX_F64;
+        A.skips[a] = aggs[a].xop != RFX_X_NONE || aggs[a].nxnodes > 0;
+        A.acc[a] = (const u64 *)t->d_acc[a];
+        A.cnt[a] = (const u64 *)t->d_cnt[a];
+        A.col[a] = (const u64 *)aggs[a].d_col;
+        A.out[a] = d_results ? (u64 *)d_results[a] : NULL;
+    }
+    return rfx_rank_emit(c, A, total_rows, nsl, si, out_cap, (i64 *)ngroups);
+}
 extern "C" int rfx_hip_group_emit(rfx_ctx_t *c, const rfx_agg_t *aggs, const rfx_group_tables_t *t, int64_t *d_keys,
                                   int64_t *d_first_ids, void *const *d_results) {
     return rfx_hip_group_emit_sharded(c, aggs, t, 0, 0, d_keys, d_first_ids, d_results);

@@ -287,3 +287,4 @@ __device__ __forceinline__ u64 group_final(int kind, int f64, u64 a, u64 c, int 
 
 
 int rfx_emit_slots(rfx_ctx *c, const EmitArgs &A);
+int rfx_rank_emit(rfx_ctx *c, const EmitArgs &A, i64 total_rows, int nsl, int si, i64 out_cap, i64 *ngroups); // rank -> emit, no round trip between (rfx_group.hip)

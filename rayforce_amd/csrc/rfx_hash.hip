@@ -321,6 +321,35 @@ extern "C" int rfx_hip_hash_emit_sharded(rfx_ctx_t *c, const rfx_agg_t *aggs, co
     return rfx_emit_slots(c, A);
 }
 
+extern "C" int rfx_hip_hash_rank_emit(rfx_ctx_t *c, const rfx_agg_t *aggs, const rfx_hash_tables_t *t, int64_t total_rows, int64_t row0, int64_t local_rows,
+                                      int nsl, int si, int64_t out_cap, int64_t *d_keys, int64_t *d_first_ids, void *const *d_results, int64_t *ngroups) {
+    RFX_REQUIRE(c && t && ngroups, RFX_EINVAL, "NULL argument");
+    RFX_REQUIRE(local_rows >= 0, RFX_EINVAL, "local_rows < 0");
+    int rc = check_hash(aggs, t);
+    if (rc != RFX_OK) return rc;
+    RFX_REQUIRE(t->capacity + 1 <= RFX_RANK_EMIT_MAX, RFX_EINVAL, "rank_emit: at most RFX_RANK_EMIT_MAX slots");
+    EmitArgs A;
+    memset(&A, 0, sizeof(A));
+    A.slots = t->capacity + 1;
+    A.nagg = t->nagg;
+    A.first = (const u64 *)t->d_first;
+    A.keys = (const u64 *)t->d_keys;
+    A.out_keys = (i64 *)d_keys;
+    A.out_first = (i64 *)d_first_ids;
+    A.row0 = row0;
+    A.nloc = local_rows;
+    for (int a = 0; a < t->nagg; a++) {
+        A.kinds[a] = aggs[a].kind;
+        A.f64s[a] = rfx_agg_input_type(&aggs[a]) == RFX_F64;
+        A.skips[a] = aggs[a].xop != RFX_X_NONE || aggs[a].nxnodes > 0;
+        A.acc[a] = (const u64 *)t->d_acc[a];
+        A.cnt[a] = (const u64 *)t->d_cnt[a];
+        A.col[a] = (const u64 *)aggs[a].d_col;
+        A.out[a] = d_results ? (u64 *)d_results[a] : NULL;
+    }
+    return rfx_rank_emit(c, A, total_rows, nsl, si, out_cap, (i64 *)ngroups);
+}
+
 // ---------------- hash primitives (pinned against the compiled reference in tests/golden) ----------------
 __global__ __launch_bounds__(RFX_BLOCK) void k_fnv1a(const u64 *__restrict__ in, i64 n, u64 *__restrict__ out) {
     for (i64 i = blockIdx.x * (i64)RFX_BLOCK + threadIdx.x; i < n; i += (i64)gridDim.x * RFX_BLOCK) out[i] = rfx_hash_fnv1a(in[i]);
