@@ -150,7 +150,7 @@ static obj_p fail_ctx(void) {
 /* ... unless there is a host beside us: then the operator is simply the host's own again (the shards hold row ranges; RFX_SHARDS /
  * RFX_DEVICES is about rfx_select).  Defined below, once HOST_CALL is. */
 static obj_p refused1(int f, obj_p x);
-static obj_p refused2(int f, obj_p x, obj_p y);
+__attribute__((unused)) static obj_p refused2(int f, obj_p x, obj_p y);
 static obj_p refusedn(int f, obj_p *x, int64_t n);
 
 /* which built-in does this function object denote? -1 if none */

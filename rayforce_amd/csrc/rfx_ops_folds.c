@@ -158,7 +158,62 @@ static obj_p group_impl(obj_p keys) {
     rfx_host_bind();
     if (!keys || keys->type <= 0 || col_ctype(keys) != RFX_I64) return fail("group: expected an i64-like vector");
     const int64_t n = keys->len;
-    if (ensure_ctx1() != RFX_OK) return (g_refused_sharded && H.bound == 1 && g_host_group) ? HOST_CALL(((rfx_unary_f)g_host_group)(keys)) : fail_ctx();
+    if (ensure_ctx() != RFX_OK) return fail_hip("no usable MI355X");
+    if (g_nshards > 1 && n > 0) {
+        /* over the shards: the planner's group-by without aggregates gives the groups' keys and first rows in first-occurrence order; the key-table form
+         * of the index (INDEX_TYPE_SHIFT, range <= INDEX_SCOPE_LIMIT) is then a table of at most 524 288 cells built from them.  The per-row form
+         * (INDEX_TYPE_IDS) needs every row's group id where the rows live: the host's own `group` */
+        const void *dks = NULL;
+        if (resident(keys, 0, &dks) != RFX_OK) return fail_hip("column upload");
+        const void *dkeys[1] = {dks};
+        rfx_query_t Q;
+        memset(&Q, 0, sizeof(Q));
+        Q.logic = RFX_AND;
+        Q.nkeys = 1;
+        Q.d_keys = dkeys;
+        Q.nrows = n;
+        Q.cols = g_qcols;
+        Q.ncols = g_nqcols;
+        Q.flags = RFX_Q_WANT_FIRST | RFX_Q_REFUSE_NULL_KEY;
+        rfx_groups_t R;
+        const int grc = rfx_exec_group_by(g_x, &Q, &R);
+        if (grc != RFX_OK && grc != RFX_EXEC_NULL_KEY) return fail(rfx_exec_last_error(g_x)[0] ? rfx_exec_last_error(g_x) : rfx_hip_last_error());
+        obj_p res_s = NULL;
+        if (grc == RFX_OK && (R.path == RFX_PATH_DENSE || R.path == RFX_PATH_DENSE_SMALL) && R.groups > 0 && R.groups <= RFX_INDEX_SCOPE_LIMIT) {
+            obj_p gk = H.vector(RFX_TYPE_I64, R.groups), firsts_s = H.vector(RFX_TYPE_I64, R.groups);
+            const void *srcs[2] = {R.d_keys, R.d_first};
+            void *dsts[2] = {RFX_AS_RAW(gk), RFX_AS_RAW(firsts_s)};
+            int ok = rfx_exec_groups_fetch_all(g_x, &R, 2, srcs, dsts) == RFX_OK;
+            int64_t lo = RFX_INF_I64, hi = RFX_NULL_I64;
+            for (int64_t g = 0; g < R.groups && ok; g++) {
+                const int64_t kk = RFX_AS_I64(gk)[g];
+                lo = kk < lo ? kk : lo;
+                hi = kk > hi ? kk : hi;
+            }
+            const uint64_t range_s = ok ? (uint64_t)hi - (uint64_t)lo + 1 : 0;
+            if (ok && range_s != 0 && range_s <= RFX_INDEX_SCOPE_LIMIT && range_s <= (uint64_t)n) {
+                obj_p table = H.vector(RFX_TYPE_I64, (int64_t)range_s);
+                for (uint64_t i = 0; i < range_s; i++) RFX_AS_I64(table)[i] = RFX_NULL_I64;
+                for (int64_t g = 0; g < R.groups; g++) RFX_AS_I64(table)[RFX_AS_I64(gk)[g] - lo] = g;
+                res_s = H.vector(RFX_TYPE_LIST, 7);
+                obj_p *ixs = RFX_AS_LIST(res_s);
+                ixs[0] = H.i64(RFX_INDEX_TYPE_SHIFT);
+                ixs[1] = H.i64(R.groups);
+                ixs[2] = table;
+                ixs[3] = H.i64(lo);
+                ixs[4] = H.clone(keys);
+                ixs[5] = H.null_obj;
+                ixs[6] = firsts_s;
+                firsts_s = NULL;
+            }
+            H.drop(gk);
+            if (firsts_s) H.drop(firsts_s);
+        }
+        if (grc == RFX_OK) rfx_exec_groups_free(g_x, &R);
+        if (res_s) return res_s;
+        g_refused_sharded = 1; /* the per-row id form, sparse or null keys: the host's own */
+        return (H.bound == 1 && g_host_group) ? HOST_CALL(((rfx_unary_f)g_host_group)(keys)) : fail_ctx();
+    }
     const void *dk = NULL;
     if (n && resident(keys, 0, &dk) != RFX_OK) return fail_hip("column upload");
     int64_t kmin = 0, kmax = -1, seen = 0;

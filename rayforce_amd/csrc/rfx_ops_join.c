@@ -128,7 +128,50 @@ rfx_obj_p rfx_inner_join(rfx_obj_p *x, int64_t n) { return join_op(1, x, n); }
 static obj_p at_impl(obj_p col, obj_p ids) {
     rfx_host_bind();
     if (!col || !ids || !col_ctype(col) || ids->type != RFX_TYPE_I64) return fail("at: expected (i64|f64 column, I64 ids)");
-    if (ensure_ctx1() != RFX_OK) return (g_refused_sharded && H.bound == 1 && g_host_at) ? HOST_CALL(((rfx_binary_f)g_host_at)(col, ids)) : fail_ctx();
+    if (ensure_ctx() != RFX_OK) return fail_hip("no usable MI355X");
+    if (g_nshards > 1) {
+        /* over the shards: ids that ascend through the shards' row ranges (a filter's: ops_where) are cut at the boundaries, every shard gathers ITS
+         * ids from its piece and its values go to the result at the ids' positions; ids in any other order (or null / out of range: they read as
+         * nulls, at_vec_*_by_i64 core/items.c:53-72) need the column whole: the host's own `at` */
+        const void *dcs;
+        const int64_t *dsel[RFX_MAX_SHARDS];
+        int64_t nsel[RFX_MAX_SHARDS];
+        if (resident(col, 0, &dcs) != RFX_OK) return fail_hip("upload");
+        int rc = ids->len ? sel_ids_sharded(ids, col->len, dsel, nsel) : RFX_OK;
+        if (rc == 1) {
+            qtmp_release();
+            g_refused_sharded = 1;
+            return (H.bound == 1 && g_host_at) ? HOST_CALL(((rfx_binary_f)g_host_at)(col, ids)) : fail_ctx();
+        }
+        obj_p outs = H.vector(col->type, ids->len);
+        void *dg[RFX_MAX_SHARDS] = {0};
+        int64_t at = 0;
+        for (int sh = 0; sh < g_nshards && rc == RFX_OK && ids->len; sh++) {
+            int64_t r0;
+            rfx_exec_split(col->len, g_nshards, sh, &r0, NULL);
+            if (nsel[sh]) {
+                const void *piece = dcs;
+                for (int k = 0; k < g_nqcols && sh > 0; k++)
+                    if (g_qcols[k].d[0] == dcs) piece = g_qcols[k].d[sh];
+                rfx_hip_ctx_bind_thread(g_ctxs[sh]);
+                rc = rfx_hip_malloc(g_ctxs[sh], &dg[sh], (size_t)nsel[sh] * 8);
+                if (rc == RFX_OK) rc = rfx_hip_gather(g_ctxs[sh], (const char *)piece - (size_t)r0 * 8, dsel[sh], nsel[sh], dg[sh]); /* (global ids: the piece's base moved back) */
+                if (rc == RFX_OK) rc = rfx_hip_d2h_async(g_ctxs[sh], (char *)RFX_AS_RAW(outs) + (size_t)at * 8, dg[sh], (size_t)nsel[sh] * 8);
+            }
+            at += nsel[sh];
+        }
+        for (int sh = 0; sh < g_nshards; sh++) {
+            if (!dg[sh]) continue;
+            rfx_hip_ctx_bind_thread(g_ctxs[sh]);
+            const int src = rfx_hip_ctx_sync(g_ctxs[sh]);
+            if (rc == RFX_OK) rc = src;
+            rfx_hip_free(g_ctxs[sh], dg[sh]);
+        }
+        rfx_hip_ctx_bind_thread(g_ctx);
+        qtmp_release();
+        if (rc != RFX_OK) { H.drop(outs); return fail_hip("gather"); }
+        return outs;
+    }
     const void *dc, *di;
     if (resident(col, 0, &dc) != RFX_OK || transient(ids, &di) != RFX_OK) return fail_hip("upload");
     obj_p out = H.vector(col->type, ids->len);

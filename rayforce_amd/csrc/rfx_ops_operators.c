@@ -1,6 +1,65 @@
 /* rfx_ops_operators.c -- part of the operator layer's ONE translation unit (rfx_ops.c #includes it -- the Makefile does not compile it on its own; the pieces share file-static state and helpers).
  * the single operators: comparisons, arithmetic, and / or (+ special forms), where, the sharded folds' helpers. */
 /* ------------------------------------------------------------------------------------------------ single operators */
+/* ---- element-wise operators over the shards (round 5): every shard works on its rows of the operands and its piece of the result goes to the
+ * host vector at the piece's offset (the reference maps them over its pool in row chunks: cmp_map core/cmp.c:35-68, binop_map core/math.c:2280-2345) ---- */
+static int transient_sharded(obj_p v, const void **dev); /* (below, with the sharded folds' helpers) */
+static const void *shard_piece(const void *p, int s) {
+    if (!p || s == 0) return p;
+    for (int i = 0; i < g_nqcols; i++)
+        if (g_qcols[i].d[0] == p) return g_qcols[i].d[s];
+    return NULL;
+}
+typedef int (*piece_fn)(void *arg, int s, int64_t r0, int64_t n, void *d_out); /* the shard's kernel(s), enqueued on g_ctxs[s] */
+static int map_shards(obj_p out, size_t esz, piece_fn fn, void *arg) {
+    void *dout[RFX_MAX_SHARDS] = {0};
+    const int64_t len = out->len;
+    int rc = RFX_OK;
+    for (int s = 0; s < g_nshards && rc == RFX_OK; s++) { /* everything enqueued first ... */
+        int64_t r0, n;
+        rfx_exec_split(len, g_nshards, s, &r0, &n);
+        if (n <= 0) continue;
+        rfx_hip_ctx_bind_thread(g_ctxs[s]);
+        rc = rfx_hip_malloc(g_ctxs[s], &dout[s], (size_t)n * esz + 16);
+        if (rc == RFX_OK) rc = fn(arg, s, r0, n, dout[s]);
+        if (rc == RFX_OK) rc = rfx_hip_d2h_async(g_ctxs[s], (char *)RFX_AS_RAW(out) + (size_t)r0 * esz, dout[s], (size_t)n * esz);
+    }
+    for (int s = 0; s < g_nshards; s++) { /* ... then one wait per shard */
+        if (!dout[s]) continue;
+        rfx_hip_ctx_bind_thread(g_ctxs[s]);
+        const int src = rfx_hip_ctx_sync(g_ctxs[s]);
+        if (rc == RFX_OK) rc = src;
+        rfx_hip_free(g_ctxs[s], dout[s]);
+    }
+    rfx_hip_ctx_bind_thread(g_ctx);
+    return rc;
+}
+typedef struct { rfx_pred_t p; } cmp_arg_t;
+static int cmp_piece(void *arg, int s, int64_t r0, int64_t n, void *d_out) {
+    (void)r0;
+    rfx_pred_t p = ((cmp_arg_t *)arg)->p;
+    p.d_col = shard_piece(p.d_col, s);
+    p.d_rhs_col = shard_piece(p.d_rhs_col, s);
+    return rfx_hip_cmp_mask(g_ctxs[s], &p, n, (int8_t *)d_out);
+}
+typedef struct { rfx_agg_t a; int32_t ot; } arith_arg_t;
+static int arith_piece(void *arg, int s, int64_t r0, int64_t n, void *d_out) {
+    (void)r0;
+    rfx_agg_t a = ((arith_arg_t *)arg)->a;
+    a.d_col = shard_piece(a.d_col, s);
+    a.d_xrhs_col = shard_piece(a.d_xrhs_col, s);
+    int32_t ot = RFX_I64;
+    return rfx_hip_eval_expr(g_ctxs[s], &a, n, d_out, &ot);
+}
+typedef struct { int logic; int64_t nin; const void *d_in[16]; } logic_arg_t;
+static int logic_piece(void *arg, int s, int64_t r0, int64_t n, void *d_out) {
+    (void)r0;
+    logic_arg_t *L = (logic_arg_t *)arg;
+    int rc = rfx_hip_d2d(g_ctxs[s], d_out, shard_piece(L->d_in[0], s), (size_t)n);
+    for (int64_t i = 1; i < L->nin && rc == RFX_OK; i++) rc = rfx_hip_mask_logic(g_ctxs[s], L->logic, (int8_t *)d_out, (const int8_t *)shard_piece(L->d_in[i], s), 0, n);
+    return rc;
+}
+
 static obj_p cmp_impl(int op, obj_p x, obj_p y) {
     rfx_host_bind();
     if (!x || !y) return fail("cmp: null argument");
@@ -9,7 +68,7 @@ static obj_p cmp_impl(int op, obj_p x, obj_p y) {
         return fail("cmp: only i64/f64 column (x) atom|column runs on the MI355X path");
     }
     if (y->type > 0 && y->len != x->len) return fail("length"); /* err_length, core/cmp.c:633-640 */
-    if (ensure_ctx1() != RFX_OK) return refused2(F_EQ + op, x, y);
+    if (ensure_ctx() != RFX_OK) return fail_hip("no usable MI355X");
     rfx_pred_t p;
     memset(&p, 0, sizeof(p));
     const void *d;
@@ -23,6 +82,12 @@ static obj_p cmp_impl(int op, obj_p x, obj_p y) {
         if (resident(y, 0, &d) != RFX_OK) return fail_hip("column upload");
         p.d_rhs_col = d;
         p.rhs_type = col_ctype(y);
+    }
+    if (g_nshards > 1) {
+        cmp_arg_t A = {p};
+        obj_p outs = H.vector(RFX_TYPE_B8, x->len);
+        if (map_shards(outs, 1, cmp_piece, &A) != RFX_OK) { H.drop(outs); return fail_hip("cmp_mask"); }
+        return outs;
     }
     void *dm = NULL;
     if (rfx_hip_malloc(g_ctx, &dm, (size_t)x->len + 8) != RFX_OK) return fail_hip("mask");
@@ -49,7 +114,7 @@ static obj_p arith_impl(int xop, int fidx, obj_p x, obj_p y) {
         return fail("arith: only i64/f64 vector (x) vector|atom runs on the MI355X path");
     }
     if (xv && yv && x->len != y->len) return fail("length");
-    if (ensure_ctx1() != RFX_OK) return refused2(fidx, x, y);
+    if (ensure_ctx() != RFX_OK) return fail_hip("no usable MI355X");
     rfx_agg_t a;
     memset(&a, 0, sizeof(a));
     a.kind = RFX_AGG_SUM;
@@ -67,6 +132,15 @@ static obj_p arith_impl(int xop, int fidx, obj_p x, obj_p y) {
     } else if (other->type == -RFX_TYPE_I64) { a.xrhs_type = RFX_I64; a.xrhs_i = other->i64; }
     else { a.xrhs_type = RFX_F64; a.xrhs_f = other->f64; }
     const int64_t n = col->len;
+    if (g_nshards > 1) {
+        arith_arg_t A;
+        A.a = a;
+        A.ot = RFX_I64;
+        if (rfx_hip_eval_expr(g_ctx, &a, 0, NULL, &A.ot) != RFX_OK) return fail_hip("eval_expr"); /* (no rows: the result type only) */
+        obj_p outs = H.vector(A.ot == RFX_F64 ? RFX_TYPE_F64 : RFX_TYPE_I64, n);
+        if (map_shards(outs, 8, arith_piece, &A) != RFX_OK) { H.drop(outs); return fail_hip("eval_expr"); }
+        return outs;
+    }
     void *dout = NULL;
     if (rfx_hip_malloc(g_ctx, &dout, (size_t)(n ? n : 1) * 8) != RFX_OK) return fail_hip("arith");
     int32_t ot = RFX_I64;
@@ -105,8 +179,21 @@ static obj_p logic_op(int logic, obj_p *x, int64_t n) {
     if (n == 0) return rfx_host_b8(0); /* logic_map: (and) -> false, core/logic.c:96-97 */
     for (int64_t i = 0; i < n; i++)
         if (!x[i] || x[i]->type != RFX_TYPE_B8 || x[i]->len != x[0]->len) return fail("and/or: expected B8 masks of one length");
-    if (ensure_ctx1() != RFX_OK) return refusedn(logic == RFX_AND ? F_AND : F_OR, x, n);
+    if (ensure_ctx() != RFX_OK) return fail_hip("no usable MI355X");
     int64_t len = x[0]->len;
+    if (g_nshards > 1) {
+        logic_arg_t A;
+        A.logic = logic;
+        A.nin = n;
+        if (n > 16) { g_refused_sharded = 1; return refusedn(logic == RFX_AND ? F_AND : F_OR, x, n); }
+        int rcs = RFX_OK;
+        for (int64_t i = 0; i < n && rcs == RFX_OK; i++) rcs = len ? transient_sharded(x[i], &A.d_in[i]) : RFX_OK;
+        obj_p outs = H.vector(RFX_TYPE_B8, len);
+        if (rcs == RFX_OK && len) rcs = map_shards(outs, 1, logic_piece, &A);
+        qtmp_release();
+        if (rcs != RFX_OK) { H.drop(outs); return fail_hip("mask_logic"); }
+        return outs;
+    }
     void *acc = NULL, *nxt = NULL;
     if (rfx_hip_malloc(g_ctx, &acc, (size_t)len + 8) != RFX_OK || rfx_hip_malloc(g_ctx, &nxt, (size_t)len + 8) != RFX_OK) return fail_hip("mask");
     int ok = rfx_hip_h2d(g_ctx, acc, RFX_AS_RAW(x[0]), (size_t)len) == RFX_OK;

@@ -415,7 +415,7 @@ static obj_p refused1(int f, obj_p x) {
     if (g_refused_sharded && H.bound == 1 && f >= 0 && f < F_N && H.f[f]) return HOST_CALL(((rfx_unary_f)H.f[f])(x));
     return fail_ctx();
 }
-static obj_p refused2(int f, obj_p x, obj_p y) {
+__attribute__((unused)) static obj_p refused2(int f, obj_p x, obj_p y) {
     if (g_refused_sharded && H.bound == 1 && f >= 0 && f < F_N && H.f[f]) return HOST_CALL(((rfx_binary_f)H.f[f])(x, y));
     return fail_ctx();
 }

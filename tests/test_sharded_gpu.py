@@ -231,10 +231,39 @@ assert not H.is_error(r), H.error_text(r)
 assert np.array_equal(H.to_numpy(r), np.nonzero(m)[0])
 ops.rfx_host_drop(r)
 assert ops.rfx_exec_stat(x, L.RFX_XSTAT_QUERIES) - before >= 30   # all of it went through the planner's shards
-# an operator that still needs its column whole on one device says so instead of answering from one shard
-col = H.vector(host["a"])
-r = ops.rfx_lt(col, H.atom(5))
+# element-wise operators: every shard its rows, the pieces of the result at their offsets (cmp_map core/cmp.c:35-68, binop_map core/math.c:2280-2345)
+va, vv, vb = H.vector(host["a"]), H.vector(host["v"]), H.vector(host["b"])
+def vec_of(r):
+    assert not H.is_error(r), H.error_text(r)
+    out = H.to_numpy(r).copy()
+    ops.rfx_host_drop(r)
+    return out
+assert np.array_equal(vec_of(ops.rfx_lt(va, H.atom(400_000))).astype(bool), rfo.cmp("<", host["a"], 400_000).astype(bool))
+assert np.array_equal(vec_of(ops.rfx_ge(vv, vb)).astype(bool), rfo.cmp(">=", host["v"], host["b"]).astype(bool))
+assert np.array_equal(vec_of(ops.rfx_ne(va, H.atom(NULL))).astype(bool), rfo.cmp("!=", host["a"], NULL).astype(bool))
+got = vec_of(ops.rfx_mul(vv, vb)); assert got.dtype == np.float64 and np.array_equal(got, host["v"] * host["b"])
+got = vec_of(ops.rfx_add(va, H.atom(7))); want = host["a"] + 7; want[host["a"] == NULL] = NULL
+assert got.dtype == np.int64 and np.array_equal(got, want)
+m1, m2, m3 = host["a"] < 300_000, host["v"] > 0.25, host["b"] < 0.9
+masks = (C.c_void_p * 3)(H.vector(m1), H.vector(m2), H.vector(m3))
+assert np.array_equal(vec_of(ops.rfx_and(masks, 3)).astype(bool), m1 & m2 & m3)
+assert np.array_equal(vec_of(ops.rfx_or(masks, 2)).astype(bool), m1 | m2)
+# at: a filter's ids (ascending) are cut at the shards' rows; descending ids need the column whole (no host here: said so)
+assert np.array_equal(vec_of(ops.rfx_at(vv, H.vector(sel))), host["v"][sel])
+r = ops.rfx_at(vv, H.vector(sel[::-1].copy()))
 assert H.is_error(r) and "whole on one device" in H.error_text(r)
+ops.rfx_host_drop(r)
+# group: the key-table form of the index (INDEX_TYPE_SHIFT) from the planner's sharded group-by
+r = ops.rfx_group(H.vector(host["k"]))
+assert not H.is_error(r), H.error_text(r)
+items = H.list_items(r)
+assert C.c_int64.from_address(items[0] + 8).value == 1 and C.c_int64.from_address(items[1] + 8).value == groups and C.c_int64.from_address(items[3] + 8).value == kmin
+assert np.array_equal(H.to_numpy(items[2]), table) and np.array_equal(H.to_numpy(items[6]), firsts)
+ops.rfx_host_drop(r)
+# the joins (and update) still need their tables whole on one device and say so instead of answering from one shard
+r = ops.rfx_left_join((C.c_void_p * 3)(H.symbols(["k"]), tab, tab), 3)
+assert H.is_error(r) and "whole on one device" in H.error_text(r), H.error_text(r)
+ops.rfx_host_drop(r)
 print("DOOR-OK")
 '''
 
