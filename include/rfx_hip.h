@@ -432,6 +432,8 @@ int rfx_hip_hash_rank_emit(rfx_ctx_t *ctx, const rfx_agg_t *aggs, const rfx_hash
 /* ---- per-row group ids (INDEX_TYPE_IDS payload, core/index.c:2069-2089) -- only when a caller wants it ---- */
 int rfx_hip_group_ids_dense(rfx_ctx_t *ctx, const int64_t *d_key, int64_t nrows, const rfx_group_tables_t *t,
                             int64_t *d_gids);
+/* ... through a slot -> group id table of the caller's (range cells, on this context's device): a shard that holds rows but did not rank the merged tables */
+int rfx_hip_group_ids_table(rfx_ctx_t *ctx, const int64_t *d_key, int64_t nrows, int64_t kmin, int64_t range, const int64_t *d_table, int64_t *d_gids);
 
 /* slot -> group id of dense tables after rfx_hip_group_rank, NULL_I64 for an unoccupied slot: the key table of the reference's
  * INDEX_TYPE_SHIFT group index (core/index.c:2037-2062). */

@@ -226,6 +226,7 @@ PROTOTYPES = {
     "rfx_hip_hash_emit": (C.c_int, [_ctx, _P(Agg), _P(HashTables), C.c_void_p, C.c_void_p, _P(C.c_void_p)]),
     "rfx_hip_group_slot_ids": (C.c_int, [_ctx, _P(GroupTables), C.c_void_p]),
     "rfx_hip_group_ids_dense": (C.c_int, [_ctx, C.c_void_p, C.c_int64, _P(GroupTables), C.c_void_p]),
+    "rfx_hip_group_ids_table": (C.c_int, [_ctx, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
     "rfx_hip_update_set": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_uint64]),
     "rfx_hip_update_group": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, _P(Agg), _P(GroupTables)]),
     "rfx_dist_unique_id": (C.c_int, [C.c_void_p]),

@@ -1037,6 +1037,15 @@ __global__ __launch_bounds__(RFX_BLOCK) void k_group_ids(const i64 *__restrict__
     }
 }
 
+// ... the same through a caller's slot -> group id table (a shard that did not rank the merged tables itself)
+extern "C" int rfx_hip_group_ids_table(rfx_ctx_t *c, const int64_t *d_key, int64_t nrows, int64_t kmin, int64_t range, const int64_t *d_table, int64_t *d_gids) {
+    RFX_REQUIRE(c, RFX_EINVAL, "ctx is NULL");
+    if (nrows <= 0) return RFX_OK;
+    RFX_REQUIRE(d_key && d_gids && d_table && range > 0, RFX_EINVAL, "NULL argument");
+    hipLaunchKernelGGL(k_group_ids, dim3(rfx_grid(c) * 4), dim3(RFX_BLOCK), 0, c->stream, (const i64 *)d_key, (i64)nrows, (i64)kmin, (i64)range, (const i64 *)d_table, (i64 *)d_gids);
+    RFX_HIP_CHECK(hipGetLastError());
+    return RFX_OK;
+}
 extern "C" int rfx_hip_group_ids_dense(rfx_ctx_t *c, const int64_t *d_key, int64_t nrows, const rfx_group_tables_t *t,
                                        int64_t *d_gids) {
     RFX_REQUIRE(c && t, RFX_EINVAL, "NULL argument");

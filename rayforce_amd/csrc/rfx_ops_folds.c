@@ -161,8 +161,8 @@ static obj_p group_impl(obj_p keys) {
     if (ensure_ctx() != RFX_OK) return fail_hip("no usable MI355X");
     if (g_nshards > 1 && n > 0) {
         /* over the shards: the planner's group-by without aggregates gives the groups' keys and first rows in first-occurrence order; the key-table form
-         * of the index (INDEX_TYPE_SHIFT, range <= INDEX_SCOPE_LIMIT) is then a table of at most 524 288 cells built from them.  The per-row form
-         * (INDEX_TYPE_IDS) needs every row's group id where the rows live: the host's own `group` */
+         * of the index (INDEX_TYPE_SHIFT, range <= INDEX_SCOPE_LIMIT) is then a table of at most 524 288 cells built from them; the per-row form
+         * (INDEX_TYPE_IDS) maps every row through that table where the rows live.  Sparse or null keys: the host's own `group` */
         const void *dks = NULL;
         if (resident(keys, 0, &dks) != RFX_OK) return fail_hip("column upload");
         const void *dkeys[1] = {dks};
@@ -179,7 +179,7 @@ static obj_p group_impl(obj_p keys) {
         const int grc = rfx_exec_group_by(g_x, &Q, &R);
         if (grc != RFX_OK && grc != RFX_EXEC_NULL_KEY) return fail(rfx_exec_last_error(g_x)[0] ? rfx_exec_last_error(g_x) : rfx_hip_last_error());
         obj_p res_s = NULL;
-        if (grc == RFX_OK && (R.path == RFX_PATH_DENSE || R.path == RFX_PATH_DENSE_SMALL) && R.groups > 0 && R.groups <= RFX_INDEX_SCOPE_LIMIT) {
+        if (grc == RFX_OK && (R.path == RFX_PATH_DENSE || R.path == RFX_PATH_DENSE_SMALL) && R.groups > 0) {
             obj_p gk = H.vector(RFX_TYPE_I64, R.groups), firsts_s = H.vector(RFX_TYPE_I64, R.groups);
             const void *srcs[2] = {R.d_keys, R.d_first};
             void *dsts[2] = {RFX_AS_RAW(gk), RFX_AS_RAW(firsts_s)};
@@ -191,27 +191,61 @@ static obj_p group_impl(obj_p keys) {
                 hi = kk > hi ? kk : hi;
             }
             const uint64_t range_s = ok ? (uint64_t)hi - (uint64_t)lo + 1 : 0;
-            if (ok && range_s != 0 && range_s <= RFX_INDEX_SCOPE_LIMIT && range_s <= (uint64_t)n) {
+            if (ok && range_s != 0 && range_s <= (uint64_t)n) {
                 obj_p table = H.vector(RFX_TYPE_I64, (int64_t)range_s);
                 for (uint64_t i = 0; i < range_s; i++) RFX_AS_I64(table)[i] = RFX_NULL_I64;
                 for (int64_t g = 0; g < R.groups; g++) RFX_AS_I64(table)[RFX_AS_I64(gk)[g] - lo] = g;
-                res_s = H.vector(RFX_TYPE_LIST, 7);
-                obj_p *ixs = RFX_AS_LIST(res_s);
-                ixs[0] = H.i64(RFX_INDEX_TYPE_SHIFT);
-                ixs[1] = H.i64(R.groups);
-                ixs[2] = table;
-                ixs[3] = H.i64(lo);
-                ixs[4] = H.clone(keys);
-                ixs[5] = H.null_obj;
-                ixs[6] = firsts_s;
-                firsts_s = NULL;
+                const int shift_s = range_s <= RFX_INDEX_SCOPE_LIMIT;
+                obj_p ids_s = NULL;
+                if (!shift_s) { /* INDEX_TYPE_IDS: every row's group id, computed where the rows live through the table (uploaded to every shard) */
+                    ids_s = H.vector(RFX_TYPE_I64, n);
+                    void *dt[RFX_MAX_SHARDS] = {0}, *dg[RFX_MAX_SHARDS] = {0};
+                    int rc2 = RFX_OK;
+                    for (int sh = 0; sh < g_nshards && rc2 == RFX_OK; sh++) {
+                        int64_t r0, len;
+                        rfx_exec_split(n, g_nshards, sh, &r0, &len);
+                        if (len <= 0) continue;
+                        const void *piece = dks;
+                        for (int k = 0; k < g_nqcols && sh > 0; k++)
+                            if (g_qcols[k].d[0] == dks) piece = g_qcols[k].d[sh];
+                        rfx_hip_ctx_bind_thread(g_ctxs[sh]);
+                        rc2 = rfx_hip_malloc(g_ctxs[sh], &dt[sh], (size_t)range_s * 8);
+                        if (rc2 == RFX_OK) rc2 = rfx_hip_malloc(g_ctxs[sh], &dg[sh], (size_t)len * 8);
+                        if (rc2 == RFX_OK) rc2 = rfx_hip_h2d_pipelined(g_ctxs[sh], dt[sh], RFX_AS_RAW(table), (size_t)range_s * 8);
+                        if (rc2 == RFX_OK) rc2 = rfx_hip_group_ids_table(g_ctxs[sh], (const int64_t *)piece, len, lo, (int64_t)range_s, (const int64_t *)dt[sh], (int64_t *)dg[sh]);
+                        if (rc2 == RFX_OK) rc2 = rfx_hip_d2h_pipelined(g_ctxs[sh], (char *)RFX_AS_RAW(ids_s) + (size_t)r0 * 8, dg[sh], (size_t)len * 8);
+                    }
+                    for (int sh = 0; sh < g_nshards; sh++) {
+                        if (!dt[sh] && !dg[sh]) continue;
+                        rfx_hip_ctx_bind_thread(g_ctxs[sh]);
+                        rfx_hip_ctx_sync(g_ctxs[sh]);
+                        if (dt[sh]) rfx_hip_free(g_ctxs[sh], dt[sh]);
+                        if (dg[sh]) rfx_hip_free(g_ctxs[sh], dg[sh]);
+                    }
+                    rfx_hip_ctx_bind_thread(g_ctx);
+                    H.drop(table);
+                    table = NULL;
+                    if (rc2 != RFX_OK) { H.drop(ids_s); ids_s = NULL; }
+                }
+                if (shift_s || ids_s) {
+                    res_s = H.vector(RFX_TYPE_LIST, 7);
+                    obj_p *ixs = RFX_AS_LIST(res_s);
+                    ixs[0] = H.i64(shift_s ? RFX_INDEX_TYPE_SHIFT : RFX_INDEX_TYPE_IDS);
+                    ixs[1] = H.i64(R.groups);
+                    ixs[2] = shift_s ? table : ids_s;
+                    ixs[3] = H.i64(shift_s ? lo : RFX_NULL_I64);
+                    ixs[4] = shift_s ? H.clone(keys) : H.null_obj;
+                    ixs[5] = H.null_obj;
+                    ixs[6] = firsts_s;
+                    firsts_s = NULL;
+                }
             }
             H.drop(gk);
             if (firsts_s) H.drop(firsts_s);
         }
         if (grc == RFX_OK) rfx_exec_groups_free(g_x, &R);
         if (res_s) return res_s;
-        g_refused_sharded = 1; /* the per-row id form, sparse or null keys: the host's own */
+        g_refused_sharded = 1; /* sparse or null keys: the host's own */
         return (H.bound == 1 && g_host_group) ? HOST_CALL(((rfx_unary_f)g_host_group)(keys)) : fail_ctx();
     }
     const void *dk = NULL;

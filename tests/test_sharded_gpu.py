@@ -260,6 +260,20 @@ items = H.list_items(r)
 assert C.c_int64.from_address(items[0] + 8).value == 1 and C.c_int64.from_address(items[1] + 8).value == groups and C.c_int64.from_address(items[3] + 8).value == kmin
 assert np.array_equal(H.to_numpy(items[2]), table) and np.array_equal(H.to_numpy(items[6]), firsts)
 ops.rfx_host_drop(r)
+# ... and the per-row form (INDEX_TYPE_IDS: a key range beyond INDEX_SCOPE_LIMIT = 524 288): every row mapped through the key table where it lives
+kbig = rfo.gen_i64(n, 31, 900_000)
+gids_b, firsts_b, groups_b, dense_b = rfo.group_index(kbig, None)
+assert dense_b
+r = ops.rfx_group(H.vector(kbig))
+assert not H.is_error(r), H.error_text(r)
+items = H.list_items(r)
+assert C.c_int64.from_address(items[0] + 8).value == 0 and C.c_int64.from_address(items[1] + 8).value == groups_b
+assert np.array_equal(H.to_numpy(items[2]), gids_b) and np.array_equal(H.to_numpy(items[6]), firsts_b)
+ops.rfx_host_drop(r)
+# sparse keys stay the host's (said so without one)
+r = ops.rfx_group(H.vector(kbig * 1_000_003))
+assert H.is_error(r) and "whole on one device" in H.error_text(r), H.error_text(r)
+ops.rfx_host_drop(r)
 # the joins (and update) still need their tables whole on one device and say so instead of answering from one shard
 r = ops.rfx_left_join((C.c_void_p * 3)(H.symbols(["k"]), tab, tab), 3)
 assert H.is_error(r) and "whole on one device" in H.error_text(r), H.error_text(r)
