@@ -265,6 +265,8 @@ int rfx_hip_column_file_load(rfx_ctx_t *ctx, const char *path, void *d_dst, int6
  * NULL_I64, else sign-extended) -- order and equality survive, nulls included, so the 8-byte comparison kernels answer what the
  * reference's i32 comparison arms answer (core/cmp.c:150-166). */
 int rfx_hip_widen_i32(rfx_ctx_t *ctx, const int32_t *d_in, int64_t n, int64_t *d_out);
+/* a B8 mask as an i64 column of 0 / 1 (a mask-only selection as one comparison of the fused pass) */
+int rfx_hip_widen_b8(rfx_ctx_t *ctx, const int8_t *d_in, int64_t n, int64_t *d_out);
 
 /* ---- timing on the context's stream (bench.py measures kernels with these HIP events) ---- */
 int rfx_hip_timer_start(rfx_ctx_t *ctx);

@@ -197,6 +197,7 @@ PROTOTYPES = {
     "rfx_hip_where_begin": (C.c_int, [_ctx, _P(Pred), C.c_int, C.c_int, C.c_void_p, C.c_int64, _P(C.c_int64)]),
     "rfx_hip_where_emit": (C.c_int, [_ctx, C.c_int64, C.c_void_p]),
     "rfx_hip_widen_i32": (C.c_int, [_ctx, C.c_void_p, C.c_int64, C.c_void_p]),
+    "rfx_hip_widen_b8": (C.c_int, [_ctx, C.c_void_p, C.c_int64, C.c_void_p]),
     "rfx_hip_where_estimate": (C.c_int, [_ctx, _P(Pred), C.c_int, C.c_int, C.c_int64, _P(C.c_int64)]),
     "rfx_hip_where_once": (C.c_int, [_ctx, _P(Pred), C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, _P(C.c_int64)]),
     "rfx_hip_gather": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),

@@ -238,6 +238,22 @@ __global__ __launch_bounds__(256) void k_widen_i32(const int32_t *__restrict__ i
         out[i] = x == (int32_t)0x80000000 ? (long long)0x8000000000000000ULL : (long long)x;
     }
 }
+// a B8 mask as an i64 column of 0 / 1: what lets a selection that exists only as a mask (a `where:` tree beyond the fused form) run as ONE
+// comparison `(!= m 0)` of the fused pass on every shard, instead of mask -> ids -> gathered columns on one
+__global__ __launch_bounds__(256) void k_widen_b8(const int8_t *__restrict__ in, long long n, long long *__restrict__ out) {
+    for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n; i += (long long)gridDim.x * 256LL) out[i] = in[i] ? 1LL : 0LL;
+}
+extern "C" int rfx_hip_widen_b8(rfx_ctx_t *c, const int8_t *d_in, int64_t n, int64_t *d_out) {
+    RFX_REQUIRE(c, RFX_EINVAL, "ctx is NULL");
+    if (n <= 0) return RFX_OK;
+    RFX_REQUIRE(d_in && d_out, RFX_EINVAL, "NULL argument");
+    long long blocks = (n + 255) / 256;
+    int grid = c->num_cus * 16;
+    if (blocks < grid) grid = (int)blocks;
+    hipLaunchKernelGGL(k_widen_b8, dim3(grid), dim3(256), 0, c->stream, d_in, (long long)n, (long long *)d_out);
+    RFX_HIP_CHECK(hipGetLastError());
+    return RFX_OK;
+}
 extern "C" int rfx_hip_widen_i32(rfx_ctx_t *c, const int32_t *d_in, int64_t n, int64_t *d_out) {
     RFX_REQUIRE(c, RFX_EINVAL, "ctx is NULL");
     if (n <= 0) return RFX_OK;

@@ -362,6 +362,76 @@ static int mask_of_expr(obj_p tab, obj_p e, int64_t nrows, int8_t **out) {
     return 0;
 }
 
+/* ... over the shards (round 5): every comparison of the tree as a mask piece per shard (its operands are resident shard by shard), and / or in place per
+ * shard, and the finished mask WIDENED to an i64 column of 0 / 1 that the query reads as ONE comparison `(!= m 0)` of its fused pass on every shard -- no
+ * ids, no gathered columns, first rows stay table rows.  The column is a per-call scratch column of the query (g_qtmp, qcol_add).  0 / -1 shape / -2 device */
+static int mask_tree_sharded(obj_p tab, obj_p e, int64_t nrows, int8_t **m) {
+    for (int s = 0; s < RFX_MAX_SHARDS; s++) m[s] = NULL;
+    if (!e || e->type != RFX_TYPE_LIST || e->len < 2) return -1;
+    const int f = fn_id(RFX_AS_LIST(e)[0]);
+    int rc = 0;
+    if (f >= F_EQ && f <= F_GE) {
+        rfx_pred_t p;
+        if ((rc = plan_cmp(tab, e, &p)) != 0) return rc;
+        for (int s = 0; s < g_nshards && rc == 0; s++) {
+            int64_t n;
+            rfx_exec_split(nrows, g_nshards, s, NULL, &n);
+            rfx_pred_t ps = p;
+            for (int k = 0; k < g_nqcols && s > 0; k++) {
+                if (g_qcols[k].d[0] == p.d_col) ps.d_col = g_qcols[k].d[s];
+                if (p.d_rhs_col && g_qcols[k].d[0] == p.d_rhs_col) ps.d_rhs_col = g_qcols[k].d[s];
+            }
+            rfx_hip_ctx_bind_thread(g_ctxs[s]);
+            void *b = NULL;
+            if (rfx_hip_malloc(g_ctxs[s], &b, (size_t)n + 16) != RFX_OK) rc = -2;
+            m[s] = (int8_t *)b;
+            if (rc == 0 && n > 0 && rfx_hip_cmp_mask(g_ctxs[s], &ps, n, m[s]) != RFX_OK) rc = -2;
+        }
+    } else if (f == F_AND || f == F_OR) {
+        for (int64_t i = 1; i < e->len && rc == 0; i++) {
+            int8_t *sub[RFX_MAX_SHARDS];
+            rc = mask_tree_sharded(tab, RFX_AS_LIST(e)[i], nrows, sub);
+            for (int s = 0; s < g_nshards; s++) {
+                int64_t n;
+                rfx_exec_split(nrows, g_nshards, s, NULL, &n);
+                rfx_hip_ctx_bind_thread(g_ctxs[s]);
+                if (rc == 0 && !m[s]) { m[s] = sub[s]; continue; }
+                if (rc == 0 && n > 0 && rfx_hip_mask_logic(g_ctxs[s], f == F_AND ? RFX_AND : RFX_OR, m[s], sub[s], 0, n) != RFX_OK) rc = -2;
+                if (sub[s]) { rfx_hip_ctx_sync(g_ctxs[s]); rfx_hip_free(g_ctxs[s], sub[s]); }
+            }
+        }
+    } else rc = -1;
+    if (rc != 0)
+        for (int s = 0; s < g_nshards; s++)
+            if (m[s]) { rfx_hip_ctx_bind_thread(g_ctxs[s]); rfx_hip_ctx_sync(g_ctxs[s]); rfx_hip_free(g_ctxs[s], m[s]); m[s] = NULL; }
+    rfx_hip_ctx_bind_thread(g_ctx);
+    return rc;
+}
+static int mask_column_sharded(obj_p tab, obj_p where, int64_t nrows, const void **d_col) {
+    int8_t *m[RFX_MAX_SHARDS];
+    int rc = mask_tree_sharded(tab, where, nrows, m);
+    if (rc != 0) return rc;
+    if (g_nqtmp >= (int)(sizeof(g_qtmp) / sizeof(g_qtmp[0]))) rc = -2;
+    void *devs[RFX_MAX_SHARDS];
+    if (rc == 0 && shards_alloc(devs, nrows, 8) != RFX_OK) rc = -2;
+    if (rc == 0) {
+        memset(&g_qtmp[g_nqtmp], 0, sizeof(g_qtmp[0]));
+        for (int s = 0; s < g_nshards; s++) g_qtmp[g_nqtmp].d[s] = devs[s];
+        g_nqtmp++;
+    }
+    for (int s = 0; s < g_nshards; s++) {
+        int64_t n;
+        rfx_exec_split(nrows, g_nshards, s, NULL, &n);
+        rfx_hip_ctx_bind_thread(g_ctxs[s]);
+        if (rc == 0 && n > 0 && rfx_hip_widen_b8(g_ctxs[s], m[s], n, (int64_t *)devs[s]) != RFX_OK) rc = -2;
+        if (m[s]) { rfx_hip_ctx_sync(g_ctxs[s]); rfx_hip_free(g_ctxs[s], m[s]); }
+    }
+    rfx_hip_ctx_bind_thread(g_ctx);
+    if (rc == 0 && qcol_add(devs) != RFX_OK) rc = -2;
+    if (rc == 0) *d_col = devs[0];
+    return rc;
+}
+
 /* selection of `where` as ascending device row ids (flat predicates fused, nested trees through masks) */
 static int where_ids(obj_p tab, obj_p where, const wplan_t *wp, int flat, int64_t nrows, int64_t **d_ids, int64_t *count) {
     *d_ids = NULL;

@@ -415,8 +415,23 @@ static obj_p select_impl(obj_p dict) {
         Q.d_keys = dks;
         Q.kxbar = kxbar;
         Q.nrows = nrows;
-        if (!flat) { /* the tree as ONE B8 mask on the device (core/cmp.c -> K2, core/logic.c in place), handed to the planner beside the query */
-            if (g_nshards > 1) { why = "sharded table: where: tree beyond the fused form"; goto out; }
+        if (!flat && g_nshards > 1) { /* over the shards: the tree as a 0 / 1 column per shard, read by ONE comparison of the fused pass */
+            const void *mcol = NULL;
+            const int mrc = mask_column_sharded(tab, where, nrows, &mcol);
+            if (mrc == -1) { why = "where: shape"; goto out; }
+            if (mrc) { res = fail_hip("where"); goto done; }
+            memset(&wp.preds[0], 0, sizeof(wp.preds[0]));
+            wp.preds[0].d_col = mcol;
+            wp.preds[0].col_type = RFX_I64;
+            wp.preds[0].op = RFX_NE;
+            wp.preds[0].rhs_type = RFX_I64;
+            wp.preds[0].rhs_i = 0;
+            wp.npred = 1;
+            wp.logic = RFX_AND;
+            Q.preds = wp.preds;
+            Q.npred = 1;
+            Q.logic = RFX_AND;
+        } else if (!flat) { /* the tree as ONE B8 mask on the device (core/cmp.c -> K2, core/logic.c in place), handed to the planner beside the query */
             int8_t *m = NULL;
             const int mrc = mask_of_expr(tab, where, nrows, &m);
             if (mrc == -1) { why = "where: shape"; goto out; }

@@ -111,6 +111,8 @@ host["k2"] = rfo.gen_i64(n, 14, 13)
 for i, m in enumerate((1000, 1000, 1_000_000, 1000, 1000, 1_000_000)):  # six key columns whose ranges multiply to 1e24 > 2^63: the H2O Q7 shape
     host[f"id{i + 1}"] = rfo.gen_i64(n, 20 + i, m)
 tab = H.table(host)
+_WIDE = ("or", ("and", ("<", "a", 100_000), (">", "v", 0.1)), ("and", (">", "a", 900_000), ("<", "v", 0.9)), ("and", ("==", "k", 5), ("!=", "b", 0.5)),
+         ("and", ("<", "c", 0.05), (">", "d", 0.95)), ("and", (">=", "a", 450_000), ("<=", "a", 460_000)))
 queries = [
     {"s": ("sum", "a"), "where": ("<", "a", 100_000)},
     {"s": ("sum", "b"), "c": ("count", "a"), "f": ("first", "v"), "where": ("<", "a", 100_000)},
@@ -121,6 +123,10 @@ queries = [
     {"where": ("<", "a", 3000)},
     {"s": ("sum", "v"), "c": ("count", "a"), "m": ("min", "b"), "by": {"g1": "k2", "g2": "k"}},
     {"by": "k", **{f"o{i}": (fn, c) for i, (fn, c) in enumerate([("max", "a"), ("sum", "v"), ("min", "a"), ("avg", "v"), ("sum", "b"), ("avg", "c"), ("min", "d"), ("count", "a")])}},  # five argument columns: two passes, the same slices
+    # where: trees beyond the fused form (ten comparisons): every shard evaluates the tree over ITS rows into a 0 / 1 column that the query reads as one comparison
+    {"s": ("sum", "v"), "c": ("count", "a"), "f": ("first", "b"), "by": "k", "where": _WIDE},
+    {"s": ("sum", "b"), "m": ("min", "a"), "where": _WIDE},
+    {"where": ("and", _WIDE, ("<", "a", 200_000))},
     # key tuples beyond a 64-bit composite key: every shard groups ITS rows on the reference's row hash, the hashed tables are re-inserted, and the
     # tuples are PROVEN by a (min, max) pair per key column riding through the same merge (index_group_list, core/index.c:2731-2790)
     {"s": ("sum", "v"), "c": ("count", "a"), "m": ("max", "b"), "by": {f"id{i + 1}": f"id{i + 1}" for i in range(6)}},
