@@ -396,8 +396,12 @@ int rfx_hip_group_emit_sharded(rfx_ctx_t *ctx, const rfx_agg_t *aggs, const rfx_
 /* Rank -> emit as ONE sequence of launches with no host round trip between them (tables of at most RFX_RANK_EMIT_MAX slots): rfx_hip_group_rank's
  * steps, the last of which also writes the result cells (rfx_hip_group_emit_sharded's), and the group count back at the end (syncs).  The outputs are
  * sized BEFORE the count is known: `out_cap` cells per column (>= the window's groups: min(slots, selected rows) / nsl + 1; RFX_ELIMIT if it did not
- * hold).  nsl > 1: only the groups [g * si / nsl, g * (si + 1) / nsl) are written, from cell 0 on (the emit window, computed on the device). */
+ * hold).  nsl > 1: only the groups of slice si (RFX_SLICE_G0 / _GN) are written, from cell 0 on (the emit window, computed on the device). */
 #define RFX_RANK_EMIT_MAX (1 << 22)
+/* slice i of nsl over g groups: every slice g / nsl groups, the first g % nsl one more -- so that slice 0 is never empty while there are groups (a result's
+ * columns are named by slice 0's pointers).  The device computes the same window from the group count it finds. */
+#define RFX_SLICE_G0(g, i, nsl) ((int64_t)(i) * ((g) / (nsl)) + ((int64_t)(i) < (g) % (nsl) ? (int64_t)(i) : (g) % (nsl)))
+#define RFX_SLICE_GN(g, i, nsl) ((g) / (nsl) + ((int64_t)(i) < (g) % (nsl) ? 1 : 0))
 int rfx_hip_group_rank_emit(rfx_ctx_t *ctx, const rfx_agg_t *aggs, const rfx_group_tables_t *t, int64_t total_rows, int64_t row0, int64_t local_rows,
                             int nsl, int si, int64_t out_cap, int64_t *d_keys, int64_t *d_first_ids, void *const *d_results, int64_t *ngroups);
 /* Emit WINDOW: until it is reset (n = 0), rfx_hip_group_emit(_sharded) / rfx_hip_hash_emit(_sharded) on this context write only the groups

@@ -1153,8 +1153,8 @@ static int ph_rank_emit(void *arg, int s) {
         if (x->timing) h->t_rank = now_ns();
         if (rc != RFX_OK) return rc;
         const int64_t g = h->groups;
-        h->g0 = nsl > 1 ? (int64_t)((__int128)g * sl / nsl) : 0;
-        h->gn = nsl > 1 ? (int64_t)((__int128)g * (sl + 1) / nsl) - h->g0 : g;
+        h->g0 = nsl > 1 ? RFX_SLICE_G0(g, sl, nsl) : 0;
+        h->gn = nsl > 1 ? RFX_SLICE_GN(g, sl, nsl) : g;
         if (g == 0 || h->gn == 0) return RFX_OK;
     } else {
         rc = G->dense ? rfx_hip_group_rank(c, &h->gt, G->total_rows, &h->groups) : rfx_hip_hash_rank(c, &h->ht, G->total_rows, &h->groups);
@@ -1163,8 +1163,8 @@ static int ph_rank_emit(void *arg, int s) {
         const int64_t g = h->groups;
         int64_t g0 = 0, gn = g;
         if (nsl > 1) { /* this owner's range of the groups */
-            g0 = (int64_t)((__int128)g * sl / nsl);
-            gn = (int64_t)((__int128)g * (sl + 1) / nsl) - g0;
+            g0 = RFX_SLICE_G0(g, sl, nsl);
+            gn = RFX_SLICE_GN(g, sl, nsl);
         }
         h->g0 = g0;
         h->gn = gn;

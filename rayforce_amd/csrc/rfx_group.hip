@@ -709,7 +709,7 @@ __global__ __launch_bounds__(RFX_BLOCK) void k_slot_gid(const u64 *__restrict__ 
 }
 
 // k_slot_gid + k_group_emit in one step: a slot's group id, and at once its result cells where the group falls into the window
-// [g * si / nsl, g * (si + 1) / nsl) -- g read from the scan's total on the device.  *overflow: the window holds more groups than out_cap cells
+// of slice si of nsl (RFX_SLICE_G0 / _GN) -- g read from the scan's total on the device.  *overflow: the window holds more groups than out_cap cells
 __global__ __launch_bounds__(RFX_BLOCK) void k_slot_gid_emit(const EmitArgs A0, i64 row_base, const u64 *__restrict__ bitmap, const i64 *__restrict__ chunk_off,
                                                             i64 *__restrict__ gid, const i64 *__restrict__ d_total, int nsl, int si, i64 out_cap, int *__restrict__ overflow) {
     const i64 groups = *d_total;
@@ -717,8 +717,8 @@ __global__ __launch_bounds__(RFX_BLOCK) void k_slot_gid_emit(const EmitArgs A0, 
     A.g0 = 0;
     A.gn = groups;
     if (nsl > 1) {
-        A.g0 = (i64)((__int128)groups * si / nsl);
-        A.gn = (i64)((__int128)groups * (si + 1) / nsl) - A.g0;
+        A.g0 = RFX_SLICE_G0(groups, si, nsl);
+        A.gn = RFX_SLICE_GN(groups, si, nsl);
     }
     if (A.gn > out_cap) {
         if (blockIdx.x == 0 && threadIdx.x == 0) *overflow = 1;

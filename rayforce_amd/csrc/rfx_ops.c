@@ -144,7 +144,7 @@ static obj_p fail_hip(const char *what) {
 }
 static int g_refused_sharded;
 static obj_p fail_ctx(void) {
-    if (g_refused_sharded) return fail("this operator needs its columns whole on one device: with RFX_SHARDS / RFX_DEVICES the operator layer answers rfx_select (and pin / unpin / invalidate / stats) only");
+    if (g_refused_sharded) return fail("this operator (or this shape of its arguments) needs its columns whole on one device: with RFX_SHARDS / RFX_DEVICES it is the host's own built-in -- joins, update, at over unordered ids, group over sparse keys, filtered MAPGROUP pairs");
     return fail_hip("no usable MI355X");
 }
 /* ... unless there is a host beside us: then the operator is simply the host's own again (the shards hold row ranges; RFX_SHARDS /

@@ -288,9 +288,8 @@ static obj_p sf_logic_impl(int f, obj_p *x, int64_t n) {
         RFX_AS_LIST(tree)[1 + i] = r ? r : (H.null_obj ? H.null_obj : rfx_host_null());
     }
     if (ok && c.n == 0) { ok = 0; why = "no vector operand"; }
-    if (ok && ensure_ctx1() != RFX_OK) {
-        if (g_refused_sharded) why = "sharded operator layer: the comparison tree is the host's"; /* (handed back below, like any shape that is not ours) */
-        else res = fail_ctx();
+    if (ok && ensure_ctx() != RFX_OK) {
+        res = fail_hip("no usable MI355X");
         ok = 0;
     }
     if (ok) {
@@ -303,6 +302,25 @@ static obj_p sf_logic_impl(int f, obj_p *x, int64_t n) {
         tab = H.table(names, cols);
         const int64_t nrows = RFX_AS_LIST(RFX_AS_LIST(tab)[1])[0]->len;
         int8_t *mask = NULL;
+        if (g_nshards > 1) { /* every shard evaluates the tree over its rows (mask_tree_sharded), the pieces of the mask at their offsets */
+            int8_t *ms[RFX_MAX_SHARDS];
+            const int rcs = mask_tree_sharded(tab, tree, nrows, ms);
+            if (rcs == 0) {
+                res = H.vector(RFX_TYPE_B8, nrows);
+                int good = 1;
+                for (int sh = 0; sh < g_nshards; sh++) {
+                    int64_t r0, len;
+                    rfx_exec_split(nrows, g_nshards, sh, &r0, &len);
+                    rfx_hip_ctx_bind_thread(g_ctxs[sh]);
+                    if (good && len > 0 && rfx_hip_d2h(g_ctxs[sh], (char *)RFX_AS_RAW(res) + r0, ms[sh], (size_t)len) != RFX_OK) good = 0;
+                    if (ms[sh]) rfx_hip_free(g_ctxs[sh], ms[sh]);
+                }
+                rfx_hip_ctx_bind_thread(g_ctx);
+                if (!good) { H.drop(res); res = fail_hip("mask read-back"); }
+            } else if (rcs == -2) res = fail_hip("and/or: device");
+            else ok = 0;
+            qtmp_release();
+        } else {
         const int rc = mask_of_expr(tab, tree, nrows, &mask);
         if (rc == 0) {
             res = H.vector(RFX_TYPE_B8, nrows);
@@ -314,6 +332,7 @@ static obj_p sf_logic_impl(int f, obj_p *x, int64_t n) {
         } else if (rc == -2) res = fail_hip("and/or: device");
         else ok = 0;
         qtmp_release();
+        }
     }
     for (int k = 0; k < c.n; k++)
         if (c.val[k]) H.drop(c.val[k]);

@@ -108,6 +108,7 @@ n = 2_000_003
 host = {"k": rfo.gen_i64(n, 4, 100_000), "a": rfo.gen_i64(n, 2, 1_000_000), "v": rfo.gen_f64(n, 5), "b": rfo.gen_f64(n, 3), "c": rfo.gen_f64(n, 8), "d": rfo.gen_f64(n, 9)}
 host["a"][::101] = NULL
 host["k2"] = rfo.gen_i64(n, 14, 13)
+host["kk"] = (host["k"] % 2) * 1_000_000   # two groups over a range beyond the small-table form: fewer groups than slices (slice 0 must not be the empty one)
 for i, m in enumerate((1000, 1000, 1_000_000, 1000, 1000, 1_000_000)):  # six key columns whose ranges multiply to 1e24 > 2^63: the H2O Q7 shape
     host[f"id{i + 1}"] = rfo.gen_i64(n, 20 + i, m)
 tab = H.table(host)
@@ -121,6 +122,8 @@ queries = [
     {"x": ("avg", "d"), "y": ("min", "d"), "z": ("max", "d"), "where": ("and", ("<", "v", 0.316228), (">", "b", 0.683772), ("!=", "c", 0.25))},
     {"s": ("sum", ("*", "v", "b")), "where": ("and", ("or", ("<", "a", 5000), ("and", (">", "v", 0.5), ("<", "b", 0.5))), (">", "c", 0.1))},
     {"where": ("<", "a", 3000)},
+    {"s": ("sum", "v"), "c": ("count", "a"), "by": "kk"},
+    {"s": ("sum", "v"), "by": "kk", "where": ("<", "kk", 5)},   # ONE group
     {"s": ("sum", "v"), "c": ("count", "a"), "m": ("min", "b"), "by": {"g1": "k2", "g2": "k"}},
     {"by": "k", **{f"o{i}": (fn, c) for i, (fn, c) in enumerate([("max", "a"), ("sum", "v"), ("min", "a"), ("avg", "v"), ("sum", "b"), ("avg", "c"), ("min", "d"), ("count", "a")])}},  # five argument columns: two passes, the same slices
     # where: trees beyond the fused form (ten comparisons): every shard evaluates the tree over ITS rows into a 0 / 1 column that the query reads as one comparison
