@@ -476,6 +476,9 @@ int rfx_hip_group_dense_accumulate_keys(rfx_ctx_t *ctx, const void *const *d_key
  * (d_out[r] = d_col[r] is null ? repl : d_col[r]) prepares key columns with nulls for the min == max collision proof. */
 int rfx_hip_row_hash(rfx_ctx_t *ctx, const void *const *d_cols, int nkeys, int64_t nrows, int value_first, int64_t *d_out);
 int rfx_hip_replace_null_i64(rfx_ctx_t *ctx, const int64_t *d_col, int64_t nrows, int64_t repl, int64_t *d_out);
+/* d_out[r] = d_col[r] == from ? to : d_col[r]; any alignment, d_out may be d_col (a null key through the MIN / MAX proof of a sharded row-hash
+ * result and back: rfx_exec_group_by) */
+int rfx_hip_replace_i64(rfx_ctx_t *ctx, const int64_t *d_col, int64_t nrows, int64_t from, int64_t to, int64_t *d_out);
 
 /* ---- element-wise arithmetic as a column: ray_add / ray_sub / ray_mul / ray_div over vectors and atoms (binop_map, core/math.c:2280-2345) ----
  * `expr` describes (op x y) or an expression tree exactly as an aggregate's argument does (xop / xnodes fields of rfx_agg_t; kind

@@ -251,6 +251,7 @@ PROTOTYPES = {
     "rfx_hip_gather_or": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_uint64, C.c_void_p]),
     "rfx_hip_row_hash": (C.c_int, [_ctx, C.POINTER(C.c_void_p), C.c_int, C.c_int64, C.c_int, C.c_void_p]),
     "rfx_hip_replace_null_i64": (C.c_int, [_ctx, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),
+    "rfx_hip_replace_i64": (C.c_int, [_ctx, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p]),
     "rfx_hip_h2d_pipelined": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_size_t]),
     "rfx_column_file_stat": (C.c_int, [C.c_char_p, C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
     "rfx_hip_column_file_load": (C.c_int, [_ctx, C.c_char_p, C.c_void_p, C.c_int64]),

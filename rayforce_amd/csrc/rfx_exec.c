@@ -60,6 +60,7 @@ struct rfx_exec {
     int nspec_wide, wide_ring;
     int64_t stat[RFX_XSTAT_N];
     int timing;       /* rfx_exec_timing: per-phase wall time into stat[RFX_XSTAT_NS_*], a sync at every phase end */
+    int64_t rh_kmin[RFX_MAX_KEYS], rh_kmax[RFX_MAX_KEYS]; /* the key columns' scopes of the last row-hash query (a null key's stand-in in the sharded proof) */
     int two_step_rank;   /* RFX_TWO_STEP_RANK=1: rank, the group count back, then emit (rounds 1-4; A/B) instead of rank -> emit without the round trip */
     int no_d2h_pipeline; /* RFX_NO_D2H_PIPELINE=1: large result columns by one plain copy each (A/B) */
     int slice_shards; /* RFX_EXEC_SLICE_SHARDS=1: every SHARD owns a slice of a sliced result, not only every device's lead (how the sharded
@@ -1393,10 +1394,16 @@ static int gb_scope(gq_t *G) {
                     /* ranges beyond 64 bits / a null key: the reference's row-hash path (index_group_list, core/index.c:2731-2790) -- grouped on
                      * the reference's own row hash; its tuple comparison on every probe is made once, afterwards (below) */
                     /* over several shards / processes the tuple proof is made by aggregates (rfx_exec_group_by: a MIN and a MAX per key column ride
-                     * through the same merge; one hash = one tuple iff they agree) -- which skip nulls, so a null among the keys stays on one shard */
-                    if (multi)
-                        for (int k = 0; k < G->nkeys; k++)
-                            if (G->kmins[k] == NULL_I64) { snprintf(x->err, sizeof(x->err), "rfx_exec: key tuples with a null key run on one shard"); rc = RFX_ELIMIT; return rc; }
+                     * through the same merge; one hash = one tuple iff they agree) -- which skip nulls: a null key rides as max + 1 there and comes back as the null */
+                    for (int k = 0; k < G->nkeys; k++) {
+                        x->rh_kmin[k] = G->kmins[k];
+                        x->rh_kmax[k] = G->kmaxs[k];
+                        if (multi && G->kmins[k] == NULL_I64 && G->kmaxs[k] == INT64_MAX) { /* no value left to stand in for the null */
+                            snprintf(x->err, sizeof(x->err), "rfx_exec: key tuples with a null key beside INT64_MAX run on one shard");
+                            rc = RFX_ELIMIT;
+                            return rc;
+                        }
+                    }
                     if ((rc = run_shards(x, ph_row_hash, G)) != RFX_OK) return rc;
                     G->rowhash = 1;
                     G->spec = 0;
@@ -1785,27 +1792,66 @@ static int world_is_multi(rfx_exec_t *x) {
  * once per group instead of on every probe: core/index.c:2731-2790.) */
 static int rowhash_proof_passes(rfx_exec_t *x, const rfx_query_t *q, int64_t cap, rfx_groups_t *out) {
     int rc = RFX_OK;
+    const int S = x->nshards;
     for (int k0 = 0; k0 < q->nkeys && rc == RFX_OK; k0 += RFX_MAX_AGGS / 2) {
         const int nk = q->nkeys - k0 < RFX_MAX_AGGS / 2 ? q->nkeys - k0 : RFX_MAX_AGGS / 2;
         rfx_agg_t pa[RFX_MAX_AGGS];
+        /* MIN / MAX skip nulls: a key column with nulls rides as a copy whose nulls read max + 1 (no key has it), shard by shard */
+        void *tmp[RFX_MAX_AGGS / 2][RFX_MAX_SHARDS];
+        int64_t repl[RFX_MAX_AGGS / 2];
+        int nnull = 0;
+        rfx_qcol_t *cols2 = NULL;
         memset(pa, 0, sizeof(pa));
+        memset(tmp, 0, sizeof(tmp));
+        for (int j = 0; j < nk; j++) nnull += x->rh_kmin[k0 + j] == NULL_I64;
+        if (nnull) {
+            cols2 = (rfx_qcol_t *)calloc((size_t)(q->ncols + nk), sizeof(*cols2));
+            if (!cols2) return RFX_ENOMEM;
+            if (q->ncols) memcpy(cols2, q->cols, (size_t)q->ncols * sizeof(*cols2));
+        }
+        int nc2 = q->ncols;
         for (int j = 0; j < nk; j++) {
+            const void *kcol = q->d_keys[k0 + j];
+            if (x->rh_kmin[k0 + j] == NULL_I64) {
+                repl[j] = x->rh_kmax[k0 + j] == NULL_I64 ? 0 : x->rh_kmax[k0 + j] + 1;
+                for (int s = 0; s < S && rc == RFX_OK; s++) {
+                    int64_t r0, len;
+                    int bad = 0;
+                    rfx_exec_split(q->nrows, S, s, &r0, &len);
+                    const void *src = xlate(q, s, kcol, &bad);
+                    if (bad) { rc = RFX_EINVAL; break; }
+                    rfx_hip_ctx_bind_thread(x->ctx[s]);
+                    rc = rfx_hip_malloc(x->ctx[s], &tmp[j][s], (size_t)(len > 0 ? len : 1) * 8);
+                    if (rc == RFX_OK) rc = rfx_hip_replace_i64(x->ctx[s], (const int64_t *)src, len, NULL_I64, repl[j], (int64_t *)tmp[j][s]);
+                }
+                rfx_hip_ctx_bind_thread(x->ctx[0]);
+                if (rc != RFX_OK) break;
+                for (int s = 0; s < S; s++) cols2[nc2].d[s] = tmp[j][s];
+                nc2++;
+                kcol = tmp[j][0];
+            }
             pa[2 * j].kind = RFX_AGG_MIN;
             pa[2 * j + 1].kind = RFX_AGG_MAX;
-            pa[2 * j].d_col = pa[2 * j + 1].d_col = q->d_keys[k0 + j];
+            pa[2 * j].d_col = pa[2 * j + 1].d_col = kcol;
             pa[2 * j].col_type = pa[2 * j + 1].col_type = RFX_I64;
         }
         rfx_query_t q2 = *q;
         q2.aggs = pa;
         q2.nagg = 2 * nk;
-        rfx_groups_t *P = (rfx_groups_t *)calloc(1, sizeof(*P));
-        if (!P) return RFX_ENOMEM;
-        P->groups = out->groups;
-        P->nslices = out->nslices;
-        P->nkeys = out->nkeys;
-        rc = group_by_pass(x, &q2, 0, 2 * nk, 0, cap, P);
-        const int nsl = P->nslices > 1 ? P->nslices : 1;
-        for (int i = 0; i < nsl && rc == RFX_OK; i++) {
+        if (cols2) {
+            q2.cols = cols2;
+            q2.ncols = nc2;
+        }
+        rfx_groups_t *P = rc == RFX_OK ? (rfx_groups_t *)calloc(1, sizeof(*P)) : NULL;
+        if (!P && rc == RFX_OK) rc = RFX_ENOMEM;
+        if (P) {
+            P->groups = out->groups;
+            P->nslices = out->nslices;
+            P->nkeys = out->nkeys;
+            rc = group_by_pass(x, &q2, 0, 2 * nk, 0, cap, P);
+        }
+        const int nsl = P && P->nslices > 1 ? P->nslices : 1;
+        for (int i = 0; P && i < nsl && rc == RFX_OK; i++) {
             const int s = P->nslices > 1 ? P->slice[i].shard : 0;
             const int64_t n = P->nslices > 1 ? P->slice[i].n : P->groups;
             if (n == 0) continue;
@@ -1826,16 +1872,24 @@ static int rowhash_proof_passes(rfx_exec_t *x, const rfx_query_t *q, int64_t cap
                     snprintf(x->err, sizeof(x->err), "row-hash collision between two key tuples");
                     rc = RFX_ESTATE;
                 }
+                if (rc == RFX_OK && tmp[j][0]) rc = rfx_hip_replace_i64(x->ctx[s], (const int64_t *)mx, n, repl[j], NULL_I64, (int64_t *)mx);
                 if (rc == RFX_OK) {
                     if (P->nslices > 1) out->slice[i].d_keycols[k0 + j] = (int64_t *)mx;
                     if (i == 0) out->d_keycols[k0 + j] = (int64_t *)mx;
                 }
             }
         }
+        for (int j = 0; j < nk; j++)
+            for (int s = 0; s < S; s++)
+                if (tmp[j][s]) { /* (stream-ordered: the passes that read it are enqueued before the free) */
+                    rfx_hip_ctx_bind_thread(x->ctx[s]);
+                    rfx_hip_free(x->ctx[s], tmp[j][s]);
+                }
         rfx_hip_ctx_bind_thread(x->ctx[0]);
         if (rc != RFX_OK && !x->err[0]) snprintf(x->err, sizeof(x->err), "%s", rfx_hip_last_error());
-        for (int i = 0; i < P->nown; i++) own_on(out, P->own[i], P->own_shard[i]); /* the key columns live in the proof passes' blocks */
+        for (int i = 0; P && i < P->nown; i++) own_on(out, P->own[i], P->own_shard[i]); /* the key columns live in the proof passes' blocks */
         free(P);
+        free(cols2);
     }
     return rc;
 }

@@ -265,3 +265,22 @@ extern "C" int rfx_hip_replace_null_i64(rfx_ctx_t *c, const int64_t *d_col, int6
     RFX_HIP_CHECK(hipGetLastError());
     return RFX_OK;
 }
+
+// out = (x == from) ? to : x, any alignment (the key columns of a sharded row-hash result: a null key rides through the MIN / MAX proof
+// as a value no key has and comes back as the null)
+__global__ __launch_bounds__(RFX_BLOCK) void k_replace_i64(const i64 *__restrict__ in, i64 nrows, i64 from, i64 to, i64 *__restrict__ out) {
+    for (i64 i = blockIdx.x * (i64)RFX_BLOCK + threadIdx.x; i < nrows; i += (i64)gridDim.x * RFX_BLOCK) {
+        const i64 t = in[i];
+        out[i] = t == from ? to : t;
+    }
+}
+extern "C" int rfx_hip_replace_i64(rfx_ctx_t *c, const int64_t *d_col, int64_t nrows, int64_t from, int64_t to, int64_t *d_out) {
+    RFX_REQUIRE(c, RFX_EINVAL, "ctx is NULL");
+    if (nrows <= 0) return RFX_OK;
+    RFX_REQUIRE(d_col && d_out, RFX_EINVAL, "device buffers expected");
+    const i64 want = (nrows + RFX_BLOCK - 1) / RFX_BLOCK;
+    hipLaunchKernelGGL(k_replace_i64, dim3((unsigned)(want < c->num_cus * 16 ? want : c->num_cus * 16)), dim3(RFX_BLOCK), 0, c->stream, (const i64 *)d_col, (i64)nrows, (i64)from, (i64)to,
+                       (i64 *)d_out);
+    RFX_HIP_CHECK(hipGetLastError());
+    return RFX_OK;
+}

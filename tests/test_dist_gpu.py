@@ -103,17 +103,17 @@ def _worker(rank, world, port, q):
         gs, ws = r["results"][0].cpu().numpy(), want["s"]
         okv = ~np.isnan(ws)  # (v holds NaNs: a group's sum over them is NaN on both sides)
         assert np.array_equal(np.isnan(gs), np.isnan(ws)) and np.allclose(gs[okv], ws[okv], rtol=1e-9, atol=1e-12)
-        # ... a null among the key tuples still runs on one shard (MIN / MAX skip nulls: no proof): across ranks the planner says so
+        # ... a null among the key tuples rides through the proof as max + 1 (MIN / MAX skip nulls) and comes back as the null
         wide_n = dict(wide)
         wide_n["k3"] = wide["k3"].copy()
-        wide_n["k3"][5] = -(2**63)
+        wide_n["k3"][5::97] = -(2**63)
         mine_n = dict(mine_w)
         mine_n["k3"] = eng.column(wide_n["k3"][cut[rank]:cut[rank + 1]])
-        try:
-            sh.group_by(["k1", "k2", "k3"], [("sum", "v")], None, mine_n)
-            raise AssertionError("key tuples with a null key across ranks were answered")
-        except RfxError as e:
-            assert "one shard" in str(e), str(e)
+        r = sh.group_by(["k1", "k2", "k3"], [("count", "a")], None, mine_n)
+        want = rfo.select({"from": wide_n, "by": {"k1": "k1", "k2": "k2", "k3": "k3"}, "c": ("count", "a")})
+        for i, nm in enumerate(("k1", "k2", "k3")):
+            assert np.array_equal(r["key_columns"][i].cpu().numpy(), want[nm]), nm
+        assert np.array_equal(r["results"][0].cpu().numpy(), want["c"])
         # ... while composite keys that fit 64 bits group across the ranks like any dense / hashed key
         r = sh.group_by(["k", "k3"], [("sum", "v"), ("count", "a"), ("max", "a")], None, {**mine, "k3": mine_w["k3"]})
         want = rfo.select({"from": {**full, "k3": wide["k3"]}, "by": {"k": "k", "k3": "k3"}, "s": ("sum", "v"), "c": ("count", "a"), "m": ("max", "a")})

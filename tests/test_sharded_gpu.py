@@ -108,6 +108,7 @@ n = 2_000_003
 host = {"k": rfo.gen_i64(n, 4, 100_000), "a": rfo.gen_i64(n, 2, 1_000_000), "v": rfo.gen_f64(n, 5), "b": rfo.gen_f64(n, 3), "c": rfo.gen_f64(n, 8), "d": rfo.gen_f64(n, 9)}
 host["a"][::101] = NULL
 host["k2"] = rfo.gen_i64(n, 14, 13)
+host["nn"] = np.full(n, NULL, dtype=np.int64)
 host["kk"] = (host["k"] % 2) * 1_000_000   # two groups over a range beyond the small-table form: fewer groups than slices (slice 0 must not be the empty one)
 for i, m in enumerate((1000, 1000, 1_000_000, 1000, 1000, 1_000_000)):  # six key columns whose ranges multiply to 1e24 > 2^63: the H2O Q7 shape
     host[f"id{i + 1}"] = rfo.gen_i64(n, 20 + i, m)
@@ -133,6 +134,9 @@ queries = [
     # key tuples beyond a 64-bit composite key: every shard groups ITS rows on the reference's row hash, the hashed tables are re-inserted, and the
     # tuples are PROVEN by a (min, max) pair per key column riding through the same merge (index_group_list, core/index.c:2731-2790)
     {"s": ("sum", "v"), "c": ("count", "a"), "m": ("max", "b"), "by": {f"id{i + 1}": f"id{i + 1}" for i in range(6)}},
+    # ... nulls among the key tuples too (MIN / MAX skip nulls: a null key rides through the proof as max + 1 and comes back as the null); a key column of nulls only
+    {"s": ("sum", "v"), "c": ("count", "k"), "by": {"a1": "a", "g": "k2"}},
+    {"s": ("sum", "v"), "m": ("min", "b"), "by": {"x": "nn", "g": "k2", "y": "a"}},
     # comparison operands that are element-wise expressions: every shard evaluates ITS rows into a scratch column of its own
     {"s": ("sum", "v"), "c": ("count", "a"), "where": ("or", ("==", ("div", "a", 1000), 7), ("and", (">", ("*", "v", 2.0), 1.5), ("!=", "k", 3)))},
     {"s": ("sum", "b"), "by": "k", "where": ("and", ("<", ("+", "v", "b"), 0.7), (">", ("-", "a", "k"), 1000))},
