@@ -764,14 +764,31 @@ def launcher_door(args, name, eng, world, rank, rows, row0, total_rows):
     ops = H.lib()
     ops.rfx_host_bind()
     L.check(ops.rfx_ops_set_device(eng.device.index), "ops_set_device")
-    ident = [None]
-    if rank == 0:
-        buf = C.create_string_buffer(128)
-        L.check(ops.rfx_dist_unique_id(buf), "dist_unique_id")
-        ident = [buf.raw]
-    if world > 1:
-        dist.broadcast_object_list(ident, src=0)
-    L.check(ops.rfx_ops_dist_init(world, rank, C.c_char_p(ident[0])), "ops_dist_init")
+    transport = None
+    if world > 1 and dist.get_backend() == "gloo":
+        # test plumbing (RFX_BENCH_BACKEND=gloo RFX_BENCH_SAME_DEVICE=1: N ranks on ONE GPU, where RCCL refuses a communicator): the planner's
+        # exchanges ride torch.distributed through the rfx_transport_t hooks -- the launch, the door and the record are the N > 1 code
+        from rayforce_amd.dist import _TorchTransport
+        import numpy as np
+        v0 = H.vector(np.arange(4, dtype=np.int64))  # (any operator call brings the layer's context and planner up)
+        r0 = ops.rfx_sum(v0)
+        ops.rfx_host_drop(r0)
+        ops.rfx_host_drop(v0)
+
+        class _OpsCtx:
+            lib = ops
+            _ctx = C.c_void_p(ops.rfx_exec_ctx(C.c_void_p(ops.rfx_ops_exec()), 0))
+        transport = _TorchTransport(_OpsCtx, None)
+        L.check(ops.rfx_exec_set_transport(C.c_void_p(ops.rfx_ops_exec()), C.byref(transport.struct)), "exec_set_transport")
+    else:
+        ident = [None]
+        if rank == 0:
+            buf = C.create_string_buffer(128)
+            L.check(ops.rfx_dist_unique_id(buf), "dist_unique_id")
+            ident = [buf.raw]
+        if world > 1:
+            dist.broadcast_object_list(ident, src=0)
+        L.check(ops.rfx_ops_dist_init(world, rank, C.c_char_p(ident[0])), "ops_dist_init")
     spec, q = C_DOOR[name]
     cols = door_columns(eng, spec, rows, row0)
     eng.sync()
@@ -788,13 +805,19 @@ def launcher_door(args, name, eng, world, rank, rows, row0, total_rows):
     checked = door_property_check(name, got, [cols], q, reduce_sum)
     x = C.c_void_p(ops.rfx_ops_exec())
     w_, r_ = C.c_int(), C.c_int()
-    ops.rfx_dist_world(C.c_void_p(ops.rfx_exec_ctx(x, 0)), C.byref(w_), C.byref(r_))
-    if int(w_.value) != world:
-        raise SystemExit(f"bench.py: the RCCL communicator spans {int(w_.value)} ranks, the launcher started {world}")
-    out = {"ms_per_step": dt * 1e3 / args.steps, "rows_per_s": total_rows / (dt / args.steps), "verified": checked, "ranks_seen": int(w_.value),
-           "collectives_per_query": int(ops.rfx_dist_calls(C.c_void_p(ops.rfx_exec_ctx(x, 0)))) / (args.steps + max(1, args.warmup)),
+    if transport is None:
+        ops.rfx_dist_world(C.c_void_p(ops.rfx_exec_ctx(x, 0)), C.byref(w_), C.byref(r_))
+        if int(w_.value) != world:
+            raise SystemExit(f"bench.py: the RCCL communicator spans {int(w_.value)} ranks, the launcher started {world}")
+    calls = transport.calls if transport else int(ops.rfx_dist_calls(C.c_void_p(ops.rfx_exec_ctx(x, 0))))
+    out = {"ms_per_step": dt * 1e3 / args.steps, "rows_per_s": total_rows / (dt / args.steps), "verified": checked, "ranks_seen": transport.world if transport else int(w_.value),
+           "collectives_per_query": calls / (args.steps + max(1, args.warmup)),
            "result": {"groups": len(got[next(iter(got))])} if "by" in q else {"values": [float(v[0]) for v in got.values()]}}
-    ops.rfx_ops_dist_finalize()
+    if transport:
+        ops.rfx_exec_set_transport(x, None)
+        out["exchange"] = "torch.distributed (gloo) through rfx_transport_t: test plumbing, not a data path"
+    else:
+        ops.rfx_ops_dist_finalize()
     return out
 
 
@@ -1136,6 +1159,9 @@ def main():
             line["engine"] = {k: main_r[k] for k in ("ms_per_step", "rows_per_s", "frac")}
         if ldoor:
             line["door"] = {k: ldoor[k] for k in ("ms_per_step", "rows_per_s", "verified", "collectives_per_query")}
+            if ldoor.get("exchange"):  # (the gloo test plumbing: the time is a host round trip per exchange, not the product's)
+                line["door"]["exchange"] = ldoor["exchange"]
+                line["config"]["door"] = line["config"]["door"].replace("in the RCCL communicator (rfx_ops_dist_init)", "exchanging through " + ldoor["exchange"])
         if also:
             line["also"] = also
         if boundary:

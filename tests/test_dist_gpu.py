@@ -222,3 +222,27 @@ def test_c_exchange_over_rccl_one_rank(built):
     msg = q.get(timeout=300)
     p.join(timeout=60)
     assert msg == "ok", msg
+
+
+@pytest.mark.parametrize("workload", ["c3w", "c2"])
+def test_bench_under_the_launcher_two_ranks_one_gpu(workload):
+    """The driver's N > 1 command line -- `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` -- with two ranks on ONE
+    GPU: every rank's row range through rfx_select, the planner's exchanges over gloo (RFX_BENCH_BACKEND: RCCL refuses two ranks on a
+    device), rank 0's single JSON line on stdout.  The time is a host round trip per exchange; the launch, the door, the property check
+    of the answer and the record are the N > 1 code."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, RFX_BENCH_SAME_DEVICE="1", RFX_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
+                          str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--rows", "40000000", "--workload", workload],
+                         env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines  # stdout carries the one line only
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["config"]["ranks_seen"] == 2 and rec["config"]["total_rows"] == 40_000_000
+    assert rec["value"] > 0 and rec["ms_per_step"] > 0 and rec["roofline"]["frac"] > 0 and rec["cpu_baseline"] is None
+    assert rec["door"]["verified"] and rec["door"]["collectives_per_query"] >= 1 and "gloo" in rec["door"]["exchange"]
+    if workload == "c3w":
+        assert 950_000 < rec["config"]["result"]["groups"] <= 1_000_000 and rec["door"]["collectives_per_query"] == 3  # scope, tables, first rows' order
