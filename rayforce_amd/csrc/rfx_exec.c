@@ -1288,7 +1288,10 @@ static int gb_setup(gq_t *G) {
     G->nsl = 1;
     G->slown[0] = 0;
     G->slice_all = 0;
-    if ((q->flags & RFX_Q_SLICED) && !G->need_first_values && !q->d_mask && S > 1) {
+    /* (decided for the QUERY, not for this pass's chunk of the aggregates: every pass of one query leaves its columns the same way) */
+    int any_first = 0;
+    for (int a = 0; a < q->nagg; a++) any_first |= q->aggs[a].kind == RFX_AGG_FIRST;
+    if ((q->flags & RFX_Q_SLICED) && !any_first && !q->d_mask && S > 1) {
         if (x->slice_shards) {
             G->nsl = S;
             for (int s = 0; s < S; s++) G->slown[s] = s;
@@ -1838,6 +1841,7 @@ static int rowhash_proof_passes(rfx_exec_t *x, const rfx_query_t *q, int64_t cap
         rfx_query_t q2 = *q;
         q2.aggs = pa;
         q2.nagg = 2 * nk;
+        if (out->nslices <= 1) q2.flags &= ~RFX_Q_SLICED; /* a whole result (FIRST values among its columns): whole key columns beside it */
         if (cols2) {
             q2.cols = cols2;
             q2.ncols = nc2;

@@ -154,23 +154,27 @@ typedef struct {
     size_t bytes;
     uint64_t h;
 } sum_job_t;
+#define SUM_ROTL(x, r) (((x) << (r)) | ((x) >> (64 - (r))))
 static uint64_t sum_range(const unsigned char *p, size_t bytes) {
-    /* four independent multiply-xor lanes (the multiply's latency is the limit of a single chain), folded in a fixed order */
+    /* four independent rotate-multiply lanes (the multiply's latency is the limit of a single chain), folded in a fixed order.  The ROTATE is
+     * what carries a word's high bits into the low half: a bare (h ^ w) * K only ever moves a difference UPWARD, so cells that differ in bit 63
+     * alone -- NULL_I64 against 0, an f64 against its negative -- were remembered by their parity per lane, and a column of nulls over a
+     * recycled column of zeros of the same length passed for current (rounds 2-5, found by tools/fuzz_null_tuples.py) */
     const uint64_t K = 0x9E3779B97F4A7C15ULL;
     uint64_t h0 = 0x243F6A8885A308D3ULL, h1 = 0x13198A2E03707344ULL, h2 = 0xA4093822299F31D0ULL, h3 = 0x082EFA98EC4E6C89ULL;
     size_t nw = bytes / 8, i = 0;
     const uint64_t *w = (const uint64_t *)p; /* payloads are 8-byte aligned (obj + 16, 32-byte aligned blocks) */
     if (((uintptr_t)p & 7) == 0) {
         for (; i + 4 <= nw; i += 4) {
-            h0 = (h0 ^ w[i]) * K;
-            h1 = (h1 ^ w[i + 1]) * K;
-            h2 = (h2 ^ w[i + 2]) * K;
-            h3 = (h3 ^ w[i + 3]) * K;
+            h0 = SUM_ROTL(h0 ^ w[i], 31) * K;
+            h1 = SUM_ROTL(h1 ^ w[i + 1], 31) * K;
+            h2 = SUM_ROTL(h2 ^ w[i + 2], 31) * K;
+            h3 = SUM_ROTL(h3 ^ w[i + 3], 31) * K;
         }
-        for (; i < nw; i++) h0 = (h0 ^ w[i]) * K;
+        for (; i < nw; i++) h0 = SUM_ROTL(h0 ^ w[i], 31) * K;
     } else i = 0, nw = 0;
-    uint64_t h = ((h0 ^ (h1 >> 29)) * K) ^ ((h2 ^ (h3 >> 31)) * K);
-    for (size_t b = nw * 8; b < bytes; b++) h = (h ^ p[b]) * K;
+    uint64_t h = (SUM_ROTL(h0 ^ (h1 >> 29), 31) * K) ^ (SUM_ROTL(h2 ^ (h3 >> 31) ^ (h1 << 35) ^ (h3 << 33), 27) * K);
+    for (size_t b = nw * 8; b < bytes; b++) h = SUM_ROTL(h ^ p[b], 31) * K;
     return h ^ (h >> 32);
 }
 static void *sum_worker(void *arg) {
@@ -201,7 +205,7 @@ static uint64_t payload_sum(const void *p, size_t bytes) {
     uint64_t h = (uint64_t)bytes;
     for (int i = 0; i < nt; i++) {
         if (started & (1 << i)) pthread_join(th[i], NULL);
-        h = (h ^ job[i].h) * 0x9E3779B97F4A7C15ULL; /* chunk order matters: a value moved between chunks changes the sum */
+        h = SUM_ROTL(h ^ job[i].h, 31) * 0x9E3779B97F4A7C15ULL; /* chunk order matters: a value moved between chunks changes the sum */
     }
     return h;
 }

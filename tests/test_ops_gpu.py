@@ -356,6 +356,50 @@ def test_cache_never_serves_a_stale_cell(ops):
     ops.rfx_host_drop(vec)
 
 
+def test_cache_sees_changes_in_the_top_bit_alone(ops):
+    """Cells that change in bit 63 only -- 0 <-> NULL_I64, an f64 <-> its negative -- in an even number of places: the checksum's lanes must
+    carry high bits downward (a bare multiply-xor remembered such changes by their parity per lane, and a column of nulls written over a
+    column of zeros of the same length at the same address was served from the stale copy: found by tools/fuzz_null_tuples.py, round 5)."""
+    ops.rfx_cache_clear()
+    for n in (8, 4096, 1 << 20, (1 << 21) + 8):  # (the last: checksummed by several threads)
+        v = np.ones(n, np.float64)
+        vec = H.vector(v)
+        view = np.frombuffer((C.c_char * (n * 8)).from_address(H.payload(vec)), dtype=np.uint64)
+        s = ops.rfx_sum(vec)
+        assert C.c_double.from_address(s + 8).value == float(n)
+        ops.rfx_host_drop(s)
+        before = H.to_numpy(ops.rfx_stats(0))[6]
+        view ^= np.uint64(1 << 63)  # every cell negated, in place
+        s = ops.rfx_sum(vec)
+        assert C.c_double.from_address(s + 8).value == -float(n), n
+        ops.rfx_host_drop(s)
+        view[8 % n] ^= np.uint64(1 << 63)  # ... and two cells of one lane
+        view[(8 % n + 4) % n] ^= np.uint64(1 << 63)
+        s = ops.rfx_sum(vec)
+        assert C.c_double.from_address(s + 8).value == -float(n) + 4.0, n
+        ops.rfx_host_drop(s)
+        assert H.to_numpy(ops.rfx_stats(0))[6] - before == 2
+        ops.rfx_host_drop(vec)
+        # zeros -> nulls through a group-by key: one group either way, the KEY differs
+        kv, vv = H.vector(np.zeros(n, np.int64)), H.vector(np.ones(n, np.float64))
+        tab = ops.rfx_host_table(H.symbols(["k", "v"]), H.list_of([kv, vv]))
+        d = H.select_dict({"c": ("count", "v"), "by": {"g": "k", "h": "k"}}, tab)
+        r = ops.rfx_select(d)
+        assert not H.is_error(r), H.error_text(r)
+        got = H.table_to_numpy(r)
+        ops.rfx_host_drop(r)
+        assert got["g"].tolist() == [0] and got["c"].tolist() == [n]
+        kview = np.frombuffer((C.c_char * (n * 8)).from_address(H.payload(kv)), dtype=np.uint64)
+        kview ^= np.uint64(1 << 63)  # every key 0 -> NULL_I64
+        r = ops.rfx_select(d)
+        assert not H.is_error(r), H.error_text(r)
+        got = H.table_to_numpy(r)
+        ops.rfx_host_drop(r)
+        assert got["g"].tolist() == [NULL] and got["h"].tolist() == [NULL] and got["c"].tolist() == [n], n
+        ops.rfx_host_drop(d)
+        ops.rfx_host_drop(tab)
+
+
 def test_cache_validates_by_page_bits_where_the_kernel_tracks_them(ops):
     """Round 3: where the kernel tracks soft-dirty pages (the MI355X boxes' does; probed at run time) an unchanged unpinned column is proven
     current by its pages' bits -- rfx_stats[11] counts those uses -- and a write anywhere in it (first page, last page, the middle) is still

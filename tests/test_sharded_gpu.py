@@ -137,6 +137,11 @@ queries = [
     # ... nulls among the key tuples too (MIN / MAX skip nulls: a null key rides through the proof as max + 1 and comes back as the null); a key column of nulls only
     {"s": ("sum", "v"), "c": ("count", "k"), "by": {"a1": "a", "g": "k2"}},
     {"s": ("sum", "v"), "m": ("min", "b"), "by": {"x": "nn", "g": "k2", "y": "a"}},
+    # ... FIRST values beside them: the result stays whole on the lead, and so do the proof passes' key columns (how a result is left is
+    # decided for the QUERY: every pass of it -- the proof's, a second chunk of aggregates -- follows)
+    {"f": ("first", "v"), "s": ("sum", "v"), "by": {f"id{i + 1}": f"id{i + 1}" for i in range(6)}},
+    {"f": ("first", "b"), "c": ("count", "k"), "by": {"a1": "a", "g": "k2"}},
+    {"by": "k", **{f"o{i}": (fn, c) for i, (fn, c) in enumerate([("max", "a"), ("sum", "v"), ("min", "a"), ("avg", "v"), ("sum", "b"), ("avg", "c"), ("min", "d"), ("first", "d")])}},
     # comparison operands that are element-wise expressions: every shard evaluates ITS rows into a scratch column of its own
     {"s": ("sum", "v"), "c": ("count", "a"), "where": ("or", ("==", ("div", "a", 1000), 7), ("and", (">", ("*", "v", 2.0), 1.5), ("!=", "k", 3)))},
     {"s": ("sum", "b"), "by": "k", "where": ("and", ("<", ("+", "v", "b"), 0.7), (">", ("-", "a", "k"), 1000))},
