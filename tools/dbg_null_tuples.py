@@ -1,6 +1,8 @@
+"""One seed of tools/fuzz_null_tuples.py alone (a fresh process: no history in the residency cache), with the columns of small cases printed:
+python tools/dbg_null_tuples.py <seed> ...  (DBG_COUNT_ONLY=1: a count per tuple instead of the seed's own aggregates)"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, "/tmp")
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 from oracle import rfo
 from rayforce_amd import hostobj as H

@@ -1,3 +1,4 @@
+"""The cases of tools/fuzz_null_tuples.py: gen(seed) -> rows, table, by, (kind, span, nulls) per key column, query."""
 import numpy as np
 NULL=-(2**63)
 def gen(seed):
