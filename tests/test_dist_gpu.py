@@ -109,11 +109,12 @@ def _worker(rank, world, port, q):
         wide_n["k3"][5::97] = -(2**63)
         mine_n = dict(mine_w)
         mine_n["k3"] = eng.column(wide_n["k3"][cut[rank]:cut[rank + 1]])
-        r = sh.group_by(["k1", "k2", "k3"], [("count", "a")], None, mine_n)
-        want = rfo.select({"from": wide_n, "by": {"k1": "k1", "k2": "k2", "k3": "k3"}, "c": ("count", "a")})
+        r = sh.group_by(["k1", "k2", "k3"], [("count", "a"), ("first", "a"), ("max", "a")], None, mine_n)  # (FIRST values beside the proven tuples)
+        want = rfo.select({"from": wide_n, "by": {"k1": "k1", "k2": "k2", "k3": "k3"}, "c": ("count", "a"), "f": ("first", "a"), "m": ("max", "a")})
         for i, nm in enumerate(("k1", "k2", "k3")):
             assert np.array_equal(r["key_columns"][i].cpu().numpy(), want[nm]), nm
-        assert np.array_equal(r["results"][0].cpu().numpy(), want["c"])
+        for i, nm in enumerate(("c", "f", "m")):
+            assert np.array_equal(r["results"][i].cpu().numpy(), want[nm]), nm
         # ... while composite keys that fit 64 bits group across the ranks like any dense / hashed key
         r = sh.group_by(["k", "k3"], [("sum", "v"), ("count", "a"), ("max", "a")], None, {**mine, "k3": mine_w["k3"]})
         want = rfo.select({"from": {**full, "k3": wide["k3"]}, "by": {"k": "k", "k3": "k3"}, "s": ("sum", "v"), "c": ("count", "a"), "m": ("max", "a")})
