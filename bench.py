@@ -509,9 +509,33 @@ def door_run(ops, H, d, steps, warmup, world=1):
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t[0])
-    per = sorted((b - a) * 1e3 for a, b in zip(marks, marks[1:]))
-    door_run.last_steps_ms = {"min": per[0], "median": per[len(per) // 2], "p90": per[min(len(per) - 1, int(0.9 * len(per)))], "max": per[-1]}
+    inorder = [(b - a) * 1e3 for a, b in zip(marks, marks[1:])]
+    per = sorted(inorder)
+    median = per[len(per) // 2] if len(per) % 2 else 0.5 * (per[len(per) // 2 - 1] + per[len(per) // 2])
+    door_run.last_steps_ms = {"min": per[0], "median": median, "p90": per[min(len(per) - 1, int(0.9 * len(per)))], "max": per[-1],
+                              "argmax": inorder.index(per[-1]), "in_order": [round(x, 4) for x in inorder]}
     return dt, got
+
+
+def door_kernels(ops, H, d, steps=5):
+    """HIP-event durations of the bracketed kernels of `steps` more calls (untimed by `value`), on the stream they are launched on
+    (rfx_hip_ctx_profile / rfx_hip_profile_kernels on the operator layer's context): per-kernel averages in launch order."""
+    from rayforce_amd import _lib as L
+    x = C.c_void_p(ops.rfx_ops_exec())
+    ctx = C.c_void_p(ops.rfx_exec_ctx(x, 0))
+    L.check(ops.rfx_hip_ctx_profile(ctx, 1), "ctx_profile")
+    runs, buf, n = [], (C.c_float * 8)(), C.c_int()
+    try:
+        for _ in range(steps):
+            r = ops.rfx_select(d)
+            assert r and not H.is_error(r), H.error_text(r)
+            ops.rfx_host_drop(r)
+            L.check(ops.rfx_hip_profile_kernels(ctx, buf, 8, C.byref(n)), "profile_kernels")
+            runs.append([float(buf[i]) for i in range(n.value)])
+    finally:
+        ops.rfx_hip_ctx_profile(ctx, 0)
+    runs = [r for r in runs if len(r) == len(runs[-1])]  # (a first call may run an extra sampled-scope kernel)
+    return [sum(col) / len(col) for col in zip(*runs)] if runs else []
 
 
 def door_phases(ops, H, d, steps=5):
@@ -582,6 +606,11 @@ def c_door(name, eng, rows, steps, warmup, device_columns=False):
     dt, got = door_run(ops, H, d, steps, warmup)
     steps_ms = dict(door_run.last_steps_ms)
     phases = door_phases(ops, H, d) if "by" in q else None
+    try:
+        kernels_ms = door_kernels(ops, H, d)
+    except Exception as e:  # noqa: BLE001
+        log(f"[bench] door_kernels failed: {e}")
+        kernels_ms = []
     cols = keep if device_columns else door_columns(eng, spec, rows)
     want = eng.select({"from": cols, **q})
     door_same(name, got, want, "Engine.select on the same data")
@@ -593,7 +622,8 @@ def c_door(name, eng, rows, steps, warmup, device_columns=False):
     return {"door": "rfx_select (C operator boundary, include/rfx_ops.h) on " + ("device column handles" if device_columns else "pinned host columns") +
                     "; result table built on the host inside the timed region",
             "rows": rows, "steps": steps, "ms_per_step": dt * 1e3 / steps, "rows_per_s": rows / (dt / steps), "answered_on_gpu": 1,
-            "steps_ms": steps_ms, "phases_ms": phases,
+            "median_ms": steps_ms["median"], "rows_per_s_median": rows / (steps_ms["median"] * 1e-3),
+            "steps_ms": steps_ms, "phases_ms": phases, "kernels_ms": kernels_ms,
             "pin_upload_s": pin_s, "verified": "every result column equals Engine.select's on the same data (f64 within 1e-9)"}
 
 
@@ -630,7 +660,18 @@ def predicted_scaling(name, eng, steps=5):
             assert r and not H.is_error(r), H.error_text(r)
             groups = len(next(iter(H.table_to_numpy(r).values())))
             ops.rfx_host_drop(r)
-        ph = door_phases(ops, H, d, steps)
+        if "by" in q:
+            ph = door_phases(ops, H, d, steps)
+        else:  # a scalar fold has no planner phases: the whole call, timed from outside (median), is the device's part
+            walls = []
+            for _ in range(max(steps, 5)):
+                t1 = time.perf_counter()
+                r = ops.rfx_select(d)
+                walls.append((time.perf_counter() - t1) * 1e3)
+                assert r and not H.is_error(r), H.error_text(r)
+                ops.rfx_host_drop(r)
+            wall = sorted(walls)[len(walls) // 2]
+            ph = {"scope": 0.0, "pass": wall, "merge": 0.0, "rank": 0.0, "emit": 0.0, "fetch": 0.0, "total": wall, "rfx_select_wall": wall}
         for o in (d, tab):
             ops.rfx_host_drop(o)
         del cols
@@ -641,7 +682,7 @@ def predicted_scaling(name, eng, steps=5):
         merge = 0.0 if n == 1 else 2 * (table_bytes / n) / (XGMI_LINK_GBPS * 1e9 * XGMI_EFFICIENCY) * 1e3 + XGMI_LATENCY_MS
         host = max(0.0, ph["rfx_select_wall"] - ph["total"])
         # six phases of a sharded group-by hand the work to N - 1 worker threads (scope sample, scope / partition, pass, merge wait, rank + emit, fetch)
-        handover = 0.0 if n == 1 else 6 * float(ops.rfx_exec_probe_handover_us(n, 2000)) / 1e3
+        handover = 0.0 if n == 1 else (6 if "by" in q else 2) * float(ops.rfx_exec_probe_handover_us(n, 2000)) / 1e3  # (a scalar fold: the pass and the gather of the partials)
         t = ph["scope"] + ph["pass"] + merge + ph["rank"] + (ph["emit"] + ph["fetch"]) / n + host + handover
         if n == 1:
             base = t
@@ -739,6 +780,26 @@ def one_process(args):
     w = WORKLOADS[name]
     ms = dt * 1e3 / args.steps
     achieved = w["bytes_per_row"] * total / N / (ms * 1e-3) / 1e9
+    # did RCCL see N ranks?  ncclCommCount of every shard's lead communicator (rfx_exec_comm_init_all -> ncclCommInitAll over the devices)
+    seen = []
+    w_, r_ = C.c_int(), C.c_int()
+    for s_ in range(N):
+        L.check(ops.rfx_dist_world(C.c_void_p(ops.rfx_exec_ctx(x, s_)), C.byref(w_), C.byref(r_)), "dist_world")
+        seen.append([int(w_.value), int(r_.value)])
+    ranks_seen = seen[0][0]
+    fused = int(ops.rfx_exec_stat(x, L.RFX_XSTAT_MERGES_RCCL))
+    if len(uniq) > 1:  # several devices: the merge MUST have been the fused RCCL exchange among exactly that many ranks -- anything else is not an N-GPU run
+        if fused == 0:
+            raise SystemExit(f"bench.py: --gpus {N} over {len(uniq)} devices but the planner ran 0 fused RCCL exchanges (merges by kernel: "
+                             f"{int(ops.rfx_exec_stat(x, L.RFX_XSTAT_MERGES_KERNEL))}) -- refusing to report this as an {N}-GPU run")
+        if ranks_seen != len(uniq) or sorted(r for _, r in seen) != list(range(len(uniq))):
+            raise SystemExit(f"bench.py: the communicators of the {len(uniq)} devices report (count, rank) = {seen}")
+    cpu = None
+    if not args.no_cpu_baseline:  # the same bounded CPU sample as at N = 1 (the reference's CPU path does not change with the GPU count)
+        try:
+            cpu = cpu_baseline(name, min(args.cpu_sample_rows, base, 20_000_000), timeout=45, pools=(32,), sweep_budget_s=20)  # (a smaller sample than N = 1's: N > 1 runs follow back to back)
+        except Exception as e:  # noqa: BLE001
+            log(f"[bench] cpu_baseline failed: {e}")
     print(json.dumps({
         "metric": METRIC, "value": total / (dt / args.steps), "unit": "rows/s", "n_gpus": N, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
         "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": w["dtype"], "data": "synthetic",
@@ -748,11 +809,13 @@ def one_process(args):
                    "door": "rfx_select on per-shard device column handles (rfx_ops_set_shards); result table built on the host inside the timed region",
                    "verified": checked, "resident": "HBM (columns generated on every device)",
                    "planner": {"merges_by_kernel": int(ops.rfx_exec_stat(x, L.RFX_XSTAT_MERGES_KERNEL)), "fused_rccl_exchanges": int(ops.rfx_exec_stat(x, L.RFX_XSTAT_MERGES_RCCL)),
-                               "sliced_results": int(ops.rfx_exec_stat(x, L.RFX_XSTAT_SLICED))}},
+                               "sliced_results": int(ops.rfx_exec_stat(x, L.RFX_XSTAT_SLICED))},
+                   "ranks_seen": ranks_seen, "communicators": seen},
+        "median_ms": steps_ms["median"], "value_median": total / (steps_ms["median"] * 1e-3), "value_basis": "mean step of the timed loop (N > 1: the launch contract's max-over-ranks form); value_median beside it",
         "steps_ms": steps_ms, "phases_ms": phases,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "kernel": w["kernel"],
                      "kernel_ms": ms, "algorithmic_bytes_per_launch": w["bytes_per_row"] * total / N},
-        "cpu_baseline": None}), flush=True)
+        "cpu_baseline": cpu}), flush=True)
     for e in engs.values():
         e.close()
 
@@ -1090,13 +1153,21 @@ def main():
             log(f"[bench] boundary: {boundary}")
         except Exception as e:  # noqa: BLE001
             boundary = {"error": str(e)[:200]}
-    predicted = None
-    if rank == 0 and world == 1 and door and not args.rows and not args.no_predict and "by" in C_DOOR[name][1]:
+    predicted, predicted_more = None, {}
+    if rank == 0 and world == 1 and door and not args.rows and not args.no_predict:
         try:
             predicted = predicted_scaling(name, eng)
             log(f"[bench] predicted_scaling: {predicted}")
         except Exception as e:  # noqa: BLE001
             predicted = {"error": str(e)[:200]}
+        for other in ("c3", "c5"):  # BASELINE configs[3] (C4 = C3 over 8 devices) and configs[4] (C5): the configs BASELINE.json names for 8 GPUs
+            if other == name:
+                continue
+            try:
+                predicted_more[other] = predicted_scaling(other, eng)
+                log(f"[bench] predicted_scaling[{other}]: {predicted_more[other]}")
+            except Exception as e:  # noqa: BLE001
+                predicted_more[other] = {"error": str(e)[:200]}
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
@@ -1122,9 +1193,13 @@ def main():
         w = WORKLOADS[name]
         head = dict(main_r)
         if door:  # value = the C operator boundary; the Engine figures stay in `engine`
-            head.update(ms_per_step=door["ms_per_step"], rows_per_s=door["rows_per_s"], kernel_ms=door["ms_per_step"])
-            head["achieved_GBps"] = w["bytes_per_row"] * total_rows / (door["ms_per_step"] * 1e-3) / 1e9
+            # SURVEY 8d defines the metric on the MEDIAN step: `value`, `roofline.achieved / frac` come from it; `ms_per_step` stays the mean of the
+            # timed loop (what a clock around the run sees) and the mean-based figures ride beside (value_mean, roofline.frac_mean)
+            head.update(ms_per_step=door["ms_per_step"], rows_per_s=door["rows_per_s_median"], kernel_ms=door["median_ms"])
+            head["achieved_GBps"] = w["bytes_per_row"] * total_rows / (door["median_ms"] * 1e-3) / 1e9
             head["frac"] = head["achieved_GBps"] / HBM_PEAK_GBPS
+            head["rows_per_s_mean"] = door["rows_per_s"]
+            head["frac_mean"] = w["bytes_per_row"] * total_rows / (door["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBPS
         rl, rc = C.c_int64(), C.c_int64()
         eng.lib.rfx_hip_rtc_stats(C.byref(rl), C.byref(rc))
         rd, rw = C.c_int64(), C.c_int64()
@@ -1151,12 +1226,23 @@ def main():
                                                           "Engine (ctypes host over the library's planner, results stay on the device)")},
             "roofline": roofline_block(name, head, world),
             "cpu_baseline": cpu,
+            "value_basis": ("median step of the timed loop (SURVEY 8d); ms_per_step = its mean, value_mean = rows / mean step" if door else "mean step of the timed loop"),
+            "value_mean": head.get("rows_per_s_mean", head["rows_per_s"]),
+            "median_ms": door["median_ms"] if door else None,
+            "steps_ms_in_order": door["steps_ms"]["in_order"] if door else None,
             "rtc": {"launches_through_run_time_compiled_kernels": int(rl.value), "plans_compiled": int(rc.value),
                     "plans_loaded_from_the_disk_cache": int(rd.value), "code_objects_written": int(rw.value)},
         }
         if door:
             line["door"] = door
             line["engine"] = {k: main_r[k] for k in ("ms_per_step", "rows_per_s", "frac")}
+            line["roofline"]["frac_mean"] = head["frac_mean"]
+            line["roofline"]["basis"] = "whole query through rfx_select (every kernel, the plan walk, the result's read-back and host table), median step; dominant_kernel = that kernel alone by HIP events"
+            if door.get("kernels_ms"):  # the dominant kernel alone: HIP events on the stream it is launched on, averaged over 5 more (untimed) steps
+                km = max(door["kernels_ms"])
+                line["roofline"]["dominant_kernel"] = {"avg_ms": km, "achieved": w["bytes_per_row"] * total_rows / (km * 1e-3) / 1e9,
+                                                       "frac": w["bytes_per_row"] * total_rows / (km * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                                                       "all_bracketed_kernels_ms": door["kernels_ms"], "how": "hipEventRecord around the launch on the context's stream (rfx_hip_profile_kernels), 5 steps after the timed loop"}
         if ldoor:
             line["door"] = {k: ldoor[k] for k in ("ms_per_step", "rows_per_s", "verified", "collectives_per_query")}
             if ldoor.get("exchange"):  # (the gloo test plumbing: the time is a host round trip per exchange, not the product's)
@@ -1168,16 +1254,21 @@ def main():
             line["boundary"] = boundary
         if predicted:
             line["predicted_scaling"] = predicted
+        for other, pr in predicted_more.items():
+            line["predicted_scaling_" + other] = pr
         print(json.dumps(line), flush=True)
         # the same run in <= 2 KB, LAST on stderr: a truncated tail of the record still carries every workload and the engine / door split
         def r3(v):
             return None if v is None else round(float(v), 3)
         compact = {"summary": name, "door_ms": r3(door["ms_per_step"]) if door else None, "engine_ms": r3(main_r["ms_per_step"]), "frac": r3(head["frac"]),
-                   "steps_ms": {k: r3(v) for k, v in door["steps_ms"].items()} if door else None,
+                   "median_ms": r3(door["median_ms"]) if door else None, "frac_mean": r3(head.get("frac_mean")),
+                   "steps": [r3(v) for v in door["steps_ms"]["in_order"]] if door else None,
+                   "kernels_ms": [r3(v) for v in door.get("kernels_ms") or []] if door else None,
                    "phases_ms": {k: r3(v) for k, v in door["phases_ms"].items() if not isinstance(v, list)} if door and door.get("phases_ms") else None,
                    "also": {k: ([r3(v.get("ms_per_step")), r3(v.get("frac"))] + ([r3(v["rfx_select_ms_per_step"])] if "rfx_select_ms_per_step" in v else [])
                                 if "error" not in v else "error") for k, v in also.items()},
                    "T_N": {n: [v["T_ms"], v["speedup"]] for n, v in predicted["per_n"].items()} if predicted and "per_n" in predicted else None,
+                   **{"T_N_" + o: {n: [v["T_ms"], v["speedup"]] for n, v in pr["per_n"].items()} for o, pr in predicted_more.items() if "per_n" in pr},
                    "cpu": [cpu.get("value"), cpu.get("cores"), (cpu.get("all_cores") or {}).get("value")] if cpu else None}
         print(json.dumps(compact, separators=(",", ":")), file=sys.stderr, flush=True)
     if dist.is_initialized():

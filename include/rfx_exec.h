@@ -34,6 +34,10 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+#ifndef __HIPCC_RTC__
+#pragma GCC visibility push(default) /* librfx.so is built with -fvisibility=hidden: what include/*.h declare is its WHOLE dynamic surface (plugins are
+                                      * dlopen'ed RTLD_GLOBAL, core/dynlib.c:131 -- internals must not land in the host's namespace) */
+#endif
 
 #define RFX_MAX_SHARDS 16
 #define RFX_EXEC_MAX_AGGS 32 /* more than RFX_MAX_AGGS outputs run as several passes over the same selection / the same groups */
@@ -196,11 +200,18 @@ enum {
 double rfx_exec_probe_handover_us(int nshards, int reps);
 /* on = 1: zero the RFX_XSTAT_NS_* counters and time the phases from now on (a sync per phase); on = 0: stop */
 void rfx_exec_timing(rfx_exec_t *x, int on);
+/* fn(arg, shard) on EVERY shard at once -- shard 0 on the calling thread, the others on the planner's own shard threads (each with its shard's
+ * context bound) -- the first failure's code back.  How the operator layer uploads a column: every shard's row range through its own device's
+ * copy engine and PCIe link at the same time (rfx_pin / first touch), as the reference maps every column file where it lies (core/io.c:1310-1364). */
+int rfx_exec_run(rfx_exec_t *x, int (*fn)(void *arg, int shard), void *arg);
 int64_t rfx_exec_stat(const rfx_exec_t *x, int which);
 /* forget which key columns' sampled scopes were reported too small (the planner does not sample those again: tests start over with this) */
 void rfx_exec_forget_scopes(rfx_exec_t *x);
 const char *rfx_exec_last_error(const rfx_exec_t *x);
 
+#ifndef __HIPCC_RTC__
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

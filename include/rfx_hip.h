@@ -32,6 +32,10 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+#ifndef __HIPCC_RTC__
+#pragma GCC visibility push(default) /* librfx.so is built with -fvisibility=hidden: what include/*.h declare is its WHOLE dynamic surface (plugins are
+                                      * dlopen'ed RTLD_GLOBAL, core/dynlib.c:131 -- internals must not land in the host's namespace) */
+#endif
 
 /* ---- status codes ---- */
 enum {
@@ -276,6 +280,9 @@ int rfx_hip_timer_stop(rfx_ctx_t *ctx, float *ms); /* (syncs) */
  * the context's stream; rfx_hip_last_kernel_ms returns that kernel time of the most recent call.  (syncs) */
 int rfx_hip_ctx_profile(rfx_ctx_t *ctx, int enable);
 int rfx_hip_last_kernel_ms(rfx_ctx_t *ctx, float *ms);
+/* ... and of EVERY bracketed kernel launched since the last call of this function (or since profiling was switched on), in launch order -- a
+ * group-by through the plane path: [k_plane_scatter, k_plane_aggregate].  At most the last eight; *n = how many were written.  (syncs) */
+int rfx_hip_profile_kernels(rfx_ctx_t *ctx, float *ms, int cap, int *n);
 
 /* ---- synthetic columns: counter-based splitmix64, element r = mix(seed + (r+1)*0x9E3779B97F4A7C15) ----
  * i64: value % modulus (modulus > 0);  f64: (value >> 11) * 2^-53 in [0,1).  row0 = global id of d_out[0]. */
@@ -564,6 +571,9 @@ int rfx_hip_xbar_i64(rfx_ctx_t *ctx, const int64_t *d_col, int64_t nrows, int64_
 int rfx_hip_hash_fnv1a_i64(rfx_ctx_t *ctx, const int64_t *d_in, int64_t n, uint64_t *d_out);
 int rfx_hip_hash_mix_u64(rfx_ctx_t *ctx, const uint64_t *d_in, int64_t n, uint64_t seed_or_prev, uint64_t *d_out);
 
+#ifndef __HIPCC_RTC__
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

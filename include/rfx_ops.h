@@ -50,6 +50,10 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+#ifndef __HIPCC_RTC__
+#pragma GCC visibility push(default) /* librfx.so is built with -fvisibility=hidden: what include/*.h declare is its WHOLE dynamic surface (plugins are
+                                      * dlopen'ed RTLD_GLOBAL, core/dynlib.c:131 -- internals must not land in the host's namespace) */
+#endif
 
 /* ---- host binding ------------------------------------------------------------------------------------------------
  * The shim needs the host's constructors (vector, table, i64, f64, b8, drop_obj, clone_obj, eval, ray_err,
@@ -124,14 +128,24 @@ rfx_obj_p rfx_update(rfx_obj_p update_dict);
  * device: what a link-time replacement of index_group hands to the FN_AGGR built-ins inside a MAPGROUP pair.  rfx_sum .. rfx_first
  * accept such pairs (val, index) -- with indexes built here or by the reference -- besides vectors and MAPFILTER pairs. */
 rfx_obj_p rfx_group(rfx_obj_p keys);
-rfx_obj_p rfx_pin(rfx_obj_p table_or_column);   /* unary_f: upload + keep resident; returns a clone of its argument */
-rfx_obj_p rfx_unpin(rfx_obj_p table_or_column); /* unary_f: drop the device copies */
-/* unary_f: the host writes into this vector / this table's columns in place -- drop every cached device copy overlapping them
- * (needed for PINNED entries only: unpinned ones are re-validated against a checksum of the full payload on every use) */
+/* Residency (round 6): a cached device copy HOLDS A REFERENCE to its host vector (clone_obj / drop_obj, rayforce.syms:25-26).  By the reference's
+ * own rule -- in-place writes only with rc == 1: cow_obj core/rayforce.c:3003-3026, core/math.c:2248,2310, every writer of core/update.c --
+ * its cells cannot change and its address cannot be reused while the copy lives, so a later use is validated by ONE pointer compare, pinned or not,
+ * and an UNPATCHED reference never sees a stale answer.  Entries whose vector nobody else refers to any more are released at the next operator call. */
+rfx_obj_p rfx_pin(rfx_obj_p table_or_column);   /* unary_f: upload NOW + exempt from LRU eviction; returns a clone of its argument */
+rfx_obj_p rfx_unpin(rfx_obj_p table_or_column); /* unary_f: drop the device copies (and the cache's references) */
+/* unary_f: drop every cached device copy overlapping this vector / this table's columns.  Never needed under validation by ownership; in
+ * checksum mode (below) it is what a host that writes PINNED vectors in place calls afterwards */
 rfx_obj_p rfx_invalidate(rfx_obj_p table_or_column);
-/* unary_f: I64[11] counters since load: {selects on the GPU, selects delegated to the host, joins on the GPU, joins delegated,
+/* How cached copies are proven current: 0 = by ownership (default), 1 = by a checksum of the full payload on every use of an unpinned entry,
+ * keyed by (payload address, length, type) -- for a host that writes payloads in place without looking at reference counts (raw views over the
+ * standalone host's vectors).  Also RFX_VALIDATE=checksum in the environment.  Switching drops the cached copies. */
+int rfx_ops_set_validation(int mode);
+/* unary_f: I64[15] counters since load: {selects on the GPU, selects delegated to the host, joins on the GPU, joins delegated,
  * uploads, cache hits, stale entries refreshed, operator calls, group scopes sampled, sampled scopes retried exactly,
- * materialised B8 mask passes (RFX_STAT_MASK_PASSES: a fused `where:` tree runs none)}; the argument is ignored */
+ * materialised B8 mask passes (RFX_STAT_MASK_PASSES: a fused `where:` tree runs none), uses validated by soft-dirty page bits,
+ * uses that cost a full-payload checksum (0 under ownership), uses validated by ownership, entries released because the cache held the
+ * last reference}; the argument is ignored */
 rfx_obj_p rfx_stats(rfx_obj_p ignored);
 void rfx_cache_clear(void);
 int64_t rfx_cache_bytes(void);
@@ -158,6 +172,9 @@ int64_t rfx_host_intern(const char *s, int64_t len);
 const char *rfx_host_symbol_name(int64_t id);
 const char *rfx_host_error_text(rfx_obj_p err);          /* message of an error object made by the standalone host */
 
+#ifndef __HIPCC_RTC__
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -185,6 +185,7 @@ PROTOTYPES = {
     "rfx_hip_timer_stop": (C.c_int, [_ctx, _P(C.c_float)]),
     "rfx_hip_ctx_profile": (C.c_int, [_ctx, C.c_int]),
     "rfx_hip_last_kernel_ms": (C.c_int, [_ctx, _P(C.c_float)]),
+    "rfx_hip_profile_kernels": (C.c_int, [_ctx, _P(C.c_float), C.c_int, _P(C.c_int)]),
     "rfx_hip_gen_i64": (C.c_int, [_ctx, C.c_void_p, C.c_int64, C.c_uint64, C.c_int64, C.c_uint64]),
     "rfx_hip_gen_f64": (C.c_int, [_ctx, C.c_void_p, C.c_int64, C.c_uint64, C.c_int64]),
     "rfx_hip_filter_aggr": (C.c_int, [_ctx, _P(Pred), C.c_int, C.c_int, _P(Agg), C.c_int, C.c_int64, C.c_int64, C.c_void_p]),
@@ -296,6 +297,7 @@ EXEC_PROTOTYPES = {
     "rfx_exec_probe_handover_us": (C.c_double, [C.c_int, C.c_int]),
     "rfx_exec_join_index": (C.c_int, [_exec, _P(C.c_void_p), _P(C.c_void_p), C.c_int, C.c_int64, C.c_int64, C.c_void_p, _P(C.c_int)]),
     "rfx_exec_stat": (C.c_int64, [_exec, C.c_int]),
+    "rfx_exec_run": (C.c_int, [_exec, C.c_void_p, C.c_void_p]),
     "rfx_exec_forget_scopes": (None, [_exec]),
     "rfx_exec_last_error": (C.c_char_p, [_exec]),
 }

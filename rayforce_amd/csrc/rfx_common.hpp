@@ -49,7 +49,8 @@ struct rfx_ctx {
     int blocks_per_cu; // streaming-kernel grid = num_cus * blocks_per_cu
     int flags;
     hipEvent_t ev0, ev1;
-    hipEvent_t evk0, evk1; // dominant-kernel bracket (profile mode)
+    hipEvent_t evk[8][2]; // kernel brackets (profile mode): pair (evk_n & 7) is the next one -- the last eight bracketed kernels, in launch order
+    int evk_n;
     int profile;
     int evk_valid;
     // scratch: per-block partials of the fused reductions
@@ -122,8 +123,8 @@ void rfx_io_release(rfx_ctx *ctx);
 int rfx_sel_reserve(rfx_ctx *ctx, size_t bytes);
 int rfx_chunk_reserve(rfx_ctx *ctx, size_t bytes);
 int rfx_plan_add_col(struct Plan *P, const void *col); // index of `col` in P->cols (added if new), -1 when full
-#define RFX_KERNEL_BEGIN(c) do { if ((c)->profile) { (void)hipEventRecord((c)->evk0, (c)->stream); } } while (0)
-#define RFX_KERNEL_END(c) do { if ((c)->profile) { (void)hipEventRecord((c)->evk1, (c)->stream); (c)->evk_valid = 1; } } while (0)
+#define RFX_KERNEL_BEGIN(c) do { if ((c)->profile) { (void)hipEventRecord((c)->evk[(c)->evk_n & 7][0], (c)->stream); } } while (0)
+#define RFX_KERNEL_END(c) do { if ((c)->profile) { (void)hipEventRecord((c)->evk[(c)->evk_n & 7][1], (c)->stream); (c)->evk_n++; (c)->evk_valid = 1; } } while (0)
 static inline int rfx_grid(const rfx_ctx *ctx) { return ctx->num_cus * ctx->blocks_per_cu; }
 int rfx_rtc_filter_aggr(rfx_ctx *c, const struct Plan &P, int grid, void *ws, int *na_stride); // rfx_rtc.hip; RFX_ESTATE: the prebuilt kernels run
 #else

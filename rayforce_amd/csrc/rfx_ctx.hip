@@ -49,8 +49,10 @@ extern "C" int rfx_hip_ctx_create(int device, void *stream, rfx_ctx_t **out) {
     }
     RFX_HIP_CHECK(hipEventCreate(&c->ev0));
     RFX_HIP_CHECK(hipEventCreate(&c->ev1));
-    RFX_HIP_CHECK(hipEventCreate(&c->evk0));
-    RFX_HIP_CHECK(hipEventCreate(&c->evk1));
+    for (int i = 0; i < 8; i++) {
+        RFX_HIP_CHECK(hipEventCreate(&c->evk[i][0]));
+        RFX_HIP_CHECK(hipEventCreate(&c->evk[i][1]));
+    }
     c->pin_bytes = 1 << 16;
     RFX_HIP_CHECK(hipHostMalloc(&c->h_pin, c->pin_bytes, hipHostMallocDefault));
     int rc = rfx_ws_reserve(c, 4u << 20);
@@ -88,8 +90,10 @@ extern "C" int rfx_hip_ctx_destroy(rfx_ctx_t *c) {
     if (c->h_pin) (void)hipHostFree(c->h_pin);
     (void)hipEventDestroy(c->ev0);
     (void)hipEventDestroy(c->ev1);
-    (void)hipEventDestroy(c->evk0);
-    (void)hipEventDestroy(c->evk1);
+    for (int i = 0; i < 8; i++) {
+        (void)hipEventDestroy(c->evk[i][0]);
+        (void)hipEventDestroy(c->evk[i][1]);
+    }
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     free(c);
     return RFX_OK;
@@ -584,13 +588,32 @@ extern "C" int rfx_hip_ctx_profile(rfx_ctx_t *c, int enable) {
     RFX_REQUIRE(c, RFX_EINVAL, "ctx is NULL");
     c->profile = enable ? 1 : 0;
     c->evk_valid = 0;
+    c->evk_n = 0;
+    return RFX_OK;
+}
+// Every bracketed kernel since the last call of this function (or since profiling was switched on), in launch order: their HIP-event durations
+// on the context's stream.  At most the last eight are kept; *n = how many were written.  (syncs)
+extern "C" int rfx_hip_profile_kernels(rfx_ctx_t *c, float *ms, int cap, int *n) {
+    RFX_REQUIRE(c && ms && n && cap >= 0, RFX_EINVAL, "NULL argument");
+    RFX_REQUIRE(c->profile, RFX_ESTATE, "profiling is off (call rfx_hip_ctx_profile(ctx, 1) first)");
+    const int have = c->evk_n < 8 ? c->evk_n : 8, first = c->evk_n - have;
+    int w = 0;
+    for (int i = 0; i < have && w < cap; i++, w++) {
+        hipEvent_t *p = c->evk[(first + i) & 7];
+        RFX_HIP_CHECK(hipEventSynchronize(p[1]));
+        RFX_HIP_CHECK(hipEventElapsedTime(&ms[w], p[0], p[1]));
+    }
+    *n = w;
+    c->evk_n = 0;
+    c->evk_valid = 0;
     return RFX_OK;
 }
 extern "C" int rfx_hip_last_kernel_ms(rfx_ctx_t *c, float *ms) {
     RFX_REQUIRE(c && ms, RFX_EINVAL, "NULL argument");
     RFX_REQUIRE(c->profile && c->evk_valid, RFX_ESTATE, "no profiled kernel recorded (call rfx_hip_ctx_profile(ctx, 1) first)");
-    RFX_HIP_CHECK(hipEventSynchronize(c->evk1));
-    RFX_HIP_CHECK(hipEventElapsedTime(ms, c->evk0, c->evk1));
+    hipEvent_t *p = c->evk[(c->evk_n - 1) & 7];
+    RFX_HIP_CHECK(hipEventSynchronize(p[1]));
+    RFX_HIP_CHECK(hipEventElapsedTime(ms, p[0], p[1]));
     return RFX_OK;
 }
 

@@ -163,6 +163,11 @@ static int run_shards(rfx_exec_t *x, shard_fn fn, void *arg) {
     return RFX_OK;
 }
 
+int rfx_exec_run(rfx_exec_t *x, int (*fn)(void *arg, int shard), void *arg) {
+    if (!x || !fn) return RFX_EINVAL;
+    return run_shards(x, fn, arg);
+}
+
 int rfx_exec_create(rfx_ctx_t *const *ctxs, int nshards, rfx_exec_t **out) {
     if (!ctxs || !out || nshards < 1 || nshards > RFX_MAX_SHARDS) return RFX_EINVAL;
     rfx_exec_t *x = (rfx_exec_t *)calloc(1, sizeof(*x));

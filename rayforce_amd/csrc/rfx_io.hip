@@ -23,38 +23,94 @@
 
 #define IO_CHUNK ((size_t)32 << 20) /* staging buffer size */
 #define IO_NBUF 4
-#define IO_THREADS 16 /* staging-copy threads: first-touch faults on an mmapped file are what they parallelise */
+#define IO_PIECE ((size_t)2 << 20) /* what one worker copies at a time */
+#define IO_MAX_WORKERS 64
+#define IO_QUEUE 4096
 
-struct CopyJob {
+// The staging copies run on a PERSISTENT set of worker threads shared by every context of the process (round 6; rounds 2-5 created and joined 16
+// threads per 32 MB chunk: 4 096 pthread_create per 8 GB column, ~0.4 ms of every chunk's ~0.6 ms).  A copy is cut into 2 MB pieces queued to the
+// workers; the submitter gets a ticket (a counter of pieces left) and waits for it only when it needs the bytes -- so a transfer keeps TWO chunks of
+// read-ahead in flight behind the one the DMA engine is moving, and the uploads of several shards / devices (one host thread each, rfx_exec_run)
+// share the workers.  Workers: a quarter of the online CPUs, 16..64 (one device at PCIe speed needs ~16; eight devices at once are bound by host
+// memory bandwidth, not by threads).  They live as long as the process (the library is never unloaded by the reference: core/dynlib.c keeps handles).
+struct IoJob {
     char *dst;
     const char *src;
     size_t bytes;
+    int *left; // pieces of this copy still to do (guarded by g_io.mu)
 };
-static void *copy_worker(void *p) {
-    CopyJob *j = (CopyJob *)p;
-    memcpy(j->dst, j->src, j->bytes);
+static struct {
+    pthread_mutex_t mu;
+    pthread_cond_t cv_work, cv_done;
+    IoJob q[IO_QUEUE];
+    unsigned head, tail; // jobs [head, tail) are queued
+    int nworkers, state; // state: 0 not started, 1 running, -1 no threads to be had (copies run on the caller)
+    pthread_t th[IO_MAX_WORKERS];
+} g_io = {PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, PTHREAD_COND_INITIALIZER, {}, 0, 0, 0, 0, {}};
+static void *io_worker(void *) {
+    pthread_mutex_lock(&g_io.mu);
+    for (;;) {
+        while (g_io.head == g_io.tail) pthread_cond_wait(&g_io.cv_work, &g_io.mu);
+        const IoJob j = g_io.q[g_io.head++ % IO_QUEUE];
+        pthread_mutex_unlock(&g_io.mu);
+        memcpy(j.dst, j.src, j.bytes); // (touching an mmapped source's pages -- the file I/O -- happens here, in parallel)
+        pthread_mutex_lock(&g_io.mu);
+        if (--*j.left == 0) pthread_cond_broadcast(&g_io.cv_done);
+    }
     return NULL;
 }
-// memcpy split over IO_THREADS threads (the staging copy is what touches the source pages)
-static void parallel_copy(char *dst, const char *src, size_t bytes) {
-    if (bytes < ((size_t)4 << 20)) {
+static void io_pool_start_locked(void) {
+    long cpus = sysconf(_SC_NPROCESSORS_ONLN);
+    int want = (int)(cpus / 4);
+    if (want < 16) want = cpus >= 16 ? 16 : (cpus > 1 ? (int)cpus : 1);
+    if (want > IO_MAX_WORKERS) want = IO_MAX_WORKERS;
+    if (const char *e = getenv("RFX_IO_THREADS")) {
+        const int v = atoi(e);
+        if (v >= 1 && v <= IO_MAX_WORKERS) want = v;
+    }
+    pthread_attr_t at;
+    pthread_attr_init(&at);
+    pthread_attr_setdetachstate(&at, PTHREAD_CREATE_DETACHED);
+    for (int i = 0; i < want; i++) {
+        if (pthread_create(&g_io.th[g_io.nworkers], &at, io_worker, NULL) != 0) break;
+        g_io.nworkers++;
+    }
+    pthread_attr_destroy(&at);
+    g_io.state = g_io.nworkers > 0 ? 1 : -1;
+}
+// queue dst <- src for the workers; *left counts the pieces (the caller keeps it alive until io_wait returns)
+static void io_submit(char *dst, const char *src, size_t bytes, int *left) {
+    *left = 0;
+    if (!bytes) return;
+    pthread_mutex_lock(&g_io.mu);
+    if (g_io.state == 0) io_pool_start_locked();
+    if (g_io.state < 0 || bytes < IO_PIECE) { // nothing to hand it to / not worth a hand-over
+        pthread_mutex_unlock(&g_io.mu);
         memcpy(dst, src, bytes);
         return;
     }
-    pthread_t th[IO_THREADS];
-    bool started[IO_THREADS];
-    CopyJob job[IO_THREADS];
-    const size_t per = (((bytes + IO_THREADS - 1) / IO_THREADS) + 4095) & ~(size_t)4095;
-    int n = 0;
-    for (size_t off = 0; off < bytes; off += per, n++) {
-        job[n].dst = dst + off;
-        job[n].src = src + off;
-        job[n].bytes = (bytes - off < per) ? bytes - off : per;
-        started[n] = pthread_create(&th[n], NULL, copy_worker, &job[n]) == 0;
-        if (!started[n]) memcpy(job[n].dst, job[n].src, job[n].bytes); // no thread to be had: copy here
+    size_t off = 0;
+    int queued = 0;
+    while (off < bytes && g_io.tail - g_io.head < IO_QUEUE) {
+        const size_t n = bytes - off < IO_PIECE + IO_PIECE / 2 ? bytes - off : IO_PIECE;
+        g_io.q[g_io.tail++ % IO_QUEUE] = IoJob{dst + off, src + off, n, left};
+        off += n;
+        queued++;
     }
-    for (int i = 0; i < n; i++)
-        if (started[i]) pthread_join(th[i], NULL);
+    *left = queued;
+    if (queued) pthread_cond_broadcast(&g_io.cv_work);
+    pthread_mutex_unlock(&g_io.mu);
+    if (off < bytes) memcpy(dst + off, src + off, bytes - off); // (the queue was full: the rest here)
+}
+static void io_wait(int *left) {
+    pthread_mutex_lock(&g_io.mu);
+    while (*left > 0) pthread_cond_wait(&g_io.cv_done, &g_io.mu);
+    pthread_mutex_unlock(&g_io.mu);
+}
+static void parallel_copy(char *dst, const char *src, size_t bytes) {
+    int left;
+    io_submit(dst, src, bytes, &left);
+    io_wait(&left);
 }
 
 static int io_stage_ready(rfx_ctx *c);
@@ -71,20 +127,32 @@ extern "C" int rfx_hip_h2d_pipelined(rfx_ctx_t *c, void *d_dst, const void *src,
         const int src_rc = io_stage_ready(c);
         if (src_rc != RFX_OK) return src_rc;
     }
-    size_t off = 0;
-    int k = 0;
+    // chunk k is staged by the workers while chunks k - 1, k - 2 ... are on the wire: up to IO_AHEAD staging copies are queued beyond the one
+    // the loop is waiting for, each into a buffer whose previous transfer has completed
+    enum { IO_AHEAD = 2 };
+    const size_t nchunks = (bytes + IO_CHUNK - 1) / IO_CHUNK;
     bool used[IO_NBUF] = {false, false, false, false};
-    while (off < bytes) {
-        const size_t n = (bytes - off < IO_CHUNK) ? bytes - off : IO_CHUNK;
-        const int b = k % IO_NBUF;
-        if (used[b]) RFX_HIP_CHECK(hipEventSynchronize(c->io_done[b])); // its previous transfer has left the buffer
-        parallel_copy((char *)c->io_stage[b], (const char *)src + off, n);
-        RFX_HIP_CHECK(hipMemcpyAsync((char *)d_dst + off, c->io_stage[b], n, hipMemcpyHostToDevice, c->stream));
-        RFX_HIP_CHECK(hipEventRecord(c->io_done[b], c->stream));
+    int left[IO_NBUF] = {0, 0, 0, 0};
+    size_t staged = 0; // chunks whose staging copy has been queued
+    hipError_t err = hipSuccess;
+    for (size_t k = 0; k < nchunks && err == hipSuccess; k++) {
+        for (; staged < nchunks && staged <= k + IO_AHEAD && err == hipSuccess; staged++) {
+            const int b = (int)(staged % IO_NBUF);
+            if (used[b]) err = hipEventSynchronize(c->io_done[b]); // its previous transfer has left the buffer
+            if (err != hipSuccess) break;
+            const size_t off = staged * IO_CHUNK, n = (bytes - off < IO_CHUNK) ? bytes - off : IO_CHUNK;
+            io_submit((char *)c->io_stage[b], (const char *)src + off, n, &left[b]);
+        }
+        if (err != hipSuccess) break;
+        const int b = (int)(k % IO_NBUF);
+        const size_t off = k * IO_CHUNK, n = (bytes - off < IO_CHUNK) ? bytes - off : IO_CHUNK;
+        io_wait(&left[b]);
+        err = hipMemcpyAsync((char *)d_dst + off, c->io_stage[b], n, hipMemcpyHostToDevice, c->stream);
+        if (err == hipSuccess) err = hipEventRecord(c->io_done[b], c->stream);
         used[b] = true;
-        off += n;
-        k++;
     }
+    for (int b = 0; b < IO_NBUF; b++) io_wait(&left[b]); // (an error above: no worker may still write into a counter on this stack)
+    RFX_HIP_CHECK(err);
     RFX_HIP_CHECK(hipStreamSynchronize(c->stream));
     return RFX_OK;
 }
@@ -118,7 +186,7 @@ static int io_stage_ready(rfx_ctx *c) {
 
 // The other direction, for LARGE results (the 1e8-group row-hash query returns 6.4 GB of host columns): a plain copy into a freshly
 // allocated vector takes every page fault of the destination one after the other inside the driver's pinning path (7 GB/s measured:
-// 908 ms for that result).  Here the DMA engine fills pinned staging buffers, up to four chunks ahead, and IO_THREADS host threads write
+// 908 ms for that result).  Here the DMA engine fills pinned staging buffers, up to four chunks ahead, and the staging workers write
 // each chunk into the destination -- the first touch of its pages is theirs, in parallel -- while the next chunks are in flight.
 extern "C" int rfx_hip_d2h_pipelined(rfx_ctx_t *c, void *dst, const void *d_src, size_t bytes) {
     RFX_REQUIRE(c, RFX_EINVAL, "ctx is NULL");

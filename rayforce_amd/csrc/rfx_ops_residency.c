@@ -107,10 +107,20 @@ static int ensure_ctx1(void) {
     return g_refused_sharded ? RFX_ELIMIT : rc;
 }
 
-/* Residency cache: host vector payload -> device copy, keyed by (payload address, length, type).
+/* Residency cache: host vector -> device copy.
  *
  * A cached copy is used again only if it is PROVEN current:
- *   - default: the FULL payload is checksummed on every use (threaded multiply-xor over every 8-byte word, position dependent) and
+ *   - default (round 6), BY OWNERSHIP: the entry holds a reference to the host vector (`owner` = clone_obj(col), rayforce.syms:25-26).  The
+ *     reference never writes a vector in place unless it is the only owner -- cow_obj core/rayforce.c:3003-3026 (rc == 1 or copy), the
+ *     in-place arithmetic core/math.c:2248,2310 (rc_obj(x) == 1), every writer of core/update.c through cow_obj -- and never frees what is
+ *     referenced, so while the cache holds its reference the cells cannot change and the address cannot be recycled: validation is ONE
+ *     POINTER COMPARE (the same object), pinned or not.  An entry whose count has fallen to 1 (only the cache is left: nobody can name the
+ *     vector any more) is released at the next operator call (op_begin), LRU eviction / rfx_unpin / rfx_invalidate / rfx_cache_clear drop
+ *     the reference with the copy.  References are taken and dropped through the HOST's clone_obj / drop_obj on the calling thread (they
+ *     switch to atomics under pool_run themselves, VM->rc_sync).  Cost to the host: an owner that would have written in place copies
+ *     instead (its column is rc >= 2 while cached) -- the copy the device needs anyway, since new cells mean a new upload;
+ *   - RFX_VALIDATE=checksum / rfx_ops_set_validation(1), for a host that writes vectors in place WITHOUT looking at the count (raw numpy
+ *     views over the standalone host's payloads in tests/test_ops_gpu.py): keyed by (payload address, length, type), the FULL payload is checksummed on every use (threaded multiply-xor over every 8-byte word, position dependent) and
  *     compared with the checksum taken at upload -- an in-place write of any single cell, a copy-on-write successor that the
  *     allocator put at the same address, a freed temporary whose address was recycled: all change the checksum and cost one
  *     re-upload, never a stale answer.  (Round 1 sampled 64 cells: one changed cell could escape; B8 masks collided almost
@@ -140,6 +150,7 @@ typedef struct {
     int scope_ok;      /* [smin, smax] = index_scope_i64 of the WHOLE column (no filter), taken from this very copy: valid as long as the copy is */
     int64_t smin, smax;
     void *devs[RFX_MAX_SHARDS]; /* the copy, shard by shard (devs[0] == dev): rows rfx_exec_split(len, shards, s) of the column */
+    obj_p owner;       /* validation by ownership: OUR reference to the host vector (a parted column: to its LIST); NULL in checksum mode */
 } resident_t;
 static resident_t *g_res;
 static int g_nres, g_capres;
@@ -147,6 +158,18 @@ static uint64_t g_tick, g_epoch = 1;
 static size_t g_res_bytes;
 static int64_t g_stat[10]; /* see rfx_stats */
 static int64_t g_sd_hits;  /* uses of an unpinned cached column proven current by its pages' soft-dirty bits instead of the checksum */
+static int64_t g_sum_validations; /* uses of a cached column that cost a full-payload checksum (0 under validation by ownership) */
+static int64_t g_own_hits;        /* uses of a cached column proven current by being the very object the cache holds a reference to */
+static int64_t g_own_released;    /* entries released because the cache's reference was the last one */
+static int g_validate = -1;       /* 0 ownership (default), 1 checksum: RFX_VALIDATE=checksum, rfx_ops_set_validation */
+static int validate_mode(void) {
+    if (g_validate < 0) {
+        const char *e = getenv("RFX_VALIDATE");
+        g_validate = (e && (strcmp(e, "checksum") == 0 || strcmp(e, "1") == 0)) ? 1 : 0;
+    }
+    return g_validate;
+}
+static inline uint32_t obj_rc(obj_p o) { return __atomic_load_n(&o->rc, __ATOMIC_RELAXED); } /* (rc_obj, core/rayforce.c:3028-3032) */
 enum { ST_SELECT_GPU, ST_SELECT_DELEGATED, ST_JOIN_GPU, ST_JOIN_DELEGATED, ST_UPLOADS, ST_CACHE_HITS, ST_CACHE_STALE, ST_OPS, ST_SCOPE_SAMPLED, ST_SCOPE_RETRIED };
 
 typedef struct {
@@ -370,7 +393,16 @@ static void res_free(int i) {
         }
     if (g_nshards > 1) rfx_hip_ctx_bind_thread(g_ctx);
     g_res_bytes -= g_res[i].dbytes;
+    obj_p owner = g_res[i].owner;
     g_res[i] = g_res[--g_nres];
+    if (owner) H.drop(owner); /* (last: when ours was the last reference the host frees the vector here) */
+}
+/* entries nobody but the cache refers to any more: the host dropped the vector, no operator call can name it again */
+static void release_unowned(void) {
+    for (int i = 0; i < g_nres;) {
+        if (g_res[i].owner && obj_rc(g_res[i].owner) == 1) { res_free(i); g_own_released++; }
+        else i++;
+    }
 }
 /* the columns the operator call in flight has named, shard by shard: what the planner translates shard 0's addresses with */
 static rfx_qcol_t g_qcols[64];
@@ -397,6 +429,19 @@ void rfx_cache_clear(void) {
     op_end();
 }
 int64_t rfx_cache_bytes(void) { return (int64_t)g_res_bytes; }
+/* how cached copies are proven current: 0 by ownership (default), 1 by checksum (hosts that write payloads in place whatever the reference count).
+ * Entries validated the other way are dropped. */
+int rfx_ops_set_validation(int mode) {
+    if (mode != 0 && mode != 1) return RFX_EINVAL;
+    rfx_host_bind();
+    op_begin();
+    if (validate_mode() != mode) {
+        while (g_nres) res_free(g_nres - 1);
+        g_validate = mode;
+    }
+    op_end();
+    return RFX_OK;
+}
 
 static size_t cache_budget(void) {
     const char *e = getenv("RFX_CACHE_BYTES");
@@ -419,6 +464,7 @@ static void op_begin(void) {
         g_epoch++; /* (a nested operator keeps the outer one's epoch: the outer call's columns stay protected from eviction) */
         g_nqcols = 0;
         if (g_ctx) rfx_hip_ctx_bind_thread(g_ctx); /* (the host calls built-ins from any of its threads) */
+        if (g_nres) release_unowned();
     }
     g_stat[ST_OPS]++;
 }
@@ -605,16 +651,26 @@ static int payload_upload_one(rfx_ctx_t *c, int type, void *dev, const void *hos
     return rc;
 }
 /* the whole payload, every shard its row range (rfx_exec_split) */
+typedef struct {
+    int type, esz;
+    void *const *devs;
+    const char *host;
+    int64_t len;
+} upload_job_t;
+static int upload_shard(void *arg, int s) {
+    const upload_job_t *u = (const upload_job_t *)arg;
+    int64_t r0, n;
+    rfx_exec_split(u->len, g_nshards, s, &r0, &n);
+    return n > 0 ? payload_upload_one(g_ctxs[s], u->type, u->devs[s], u->host + (size_t)r0 * u->esz, n) : RFX_OK;
+}
+/* Round 6: every shard's row range at once, each on its shard's own thread (rfx_exec_run), through its own context's staging set and stream: on an
+ * 8-device node eight copy engines and eight PCIe links move the column together (rounds 4-5 walked the shards in a loop around a blocking copy: 24 GB of
+ * c3w columns crossed one link at a time).  The staging copies of all of them share the library's persistent workers (rfx_io.hip). */
 static int payload_upload(int type, void *const *devs, const void *host, int64_t len) {
-    const int esz = type == RFX_TYPE_B8 ? 1 : (IS_I32_FAMILY(type) ? 4 : 8);
-    int rc = RFX_OK;
-    for (int s = 0; s < g_nshards && rc == RFX_OK; s++) {
-        int64_t r0, n;
-        rfx_exec_split(len, g_nshards, s, &r0, &n);
-        if (g_nshards > 1) rfx_hip_ctx_bind_thread(g_ctxs[s]);
-        if (n > 0) rc = payload_upload_one(g_ctxs[s], type, devs[s], (const char *)host + (size_t)r0 * esz, n);
-    }
-    if (g_nshards > 1) rfx_hip_ctx_bind_thread(g_ctx);
+    upload_job_t u = {type, type == RFX_TYPE_B8 ? 1 : (IS_I32_FAMILY(type) ? 4 : 8), devs, (const char *)host, len};
+    if (g_nshards == 1) return upload_shard(&u, 0);
+    const int rc = rfx_exec_run(g_x, upload_shard, &u);
+    rfx_hip_ctx_bind_thread(g_ctx);
     return rc;
 }
 static int shards_alloc(void **devs, int64_t len, size_t desz) {
@@ -675,7 +731,20 @@ static int resident(obj_p col, int pin, const void **dev) {
     const int ktype = px ? 64 + col->type : col->type;
     int have_sum = 0;
     uint64_t sum = 0;
-    for (int i = 0; i < g_nres; i++)
+    const int own = validate_mode() == 0;
+    obj_p keyobj = px ? px->src : col; /* the host object the cells belong to (a parted column: its LIST of partition vectors) */
+    for (int i = 0; i < g_nres; i++) {
+        if (g_res[i].owner) { /* by ownership: the very object we hold a reference to -- nothing could have written its cells or reused its address */
+            if (g_res[i].owner != keyobj) continue;
+            if (g_res[i].len != col->len || g_res[i].type != ktype) { res_free(i); break; } /* (cannot happen under the host's rule: take it as new) */
+            g_own_hits++;
+            g_res[i].tick = ++g_tick;
+            g_res[i].epoch = g_epoch;
+            g_res[i].pinned |= pin;
+            g_stat[ST_CACHE_HITS]++;
+            *dev = g_res[i].dev;
+            return qcol_add(g_res[i].devs);
+        }
         if (g_res[i].host == host && g_res[i].len == col->len && g_res[i].type == ktype) {
             int track = 0;
             if (!g_res[i].pinned) { /* unpinned: prove the copy current */
@@ -692,6 +761,7 @@ static int resident(obj_p col, int pin, const void **dev) {
                 /* by its checksum -- taken AFTER the pages were clean-marked, so that it can vouch for them from now on */
                 track = !px && !g_res[i].sd_never && g_res[i].stable >= SD_STABLE_USES && sd_usable(host, bytes) && sd_call_clear() == 0;
                 sum = px ? proxy_sum(px) : payload_sum(host, bytes);
+                g_sum_validations++;
                 have_sum = 1;
             }
             if (track) {
@@ -725,6 +795,7 @@ static int resident(obj_p col, int pin, const void **dev) {
             *dev = g_res[i].dev;
             return qcol_add(g_res[i].devs);
         }
+    }
     while (g_nres && g_res_bytes + dbytes > cache_budget()) {
         int victim = -1; /* least recently used, not pinned, not in use by the call in flight */
         for (int i = 0; i < g_nres; i++)
@@ -737,7 +808,7 @@ static int resident(obj_p col, int pin, const void **dev) {
     if (rc != RFX_OK) return rc;
     /* the checksum, THEN the copy: a host write racing with this call is either in both, or in the copy only and costs one refresh at
      * the next use -- never a device copy older than what vouches for it */
-    if (!have_sum) sum = px ? proxy_sum(px) : payload_sum(host, bytes);
+    if (!have_sum && !own) sum = px ? proxy_sum(px) : payload_sum(host, bytes);
     rc = px ? proxy_upload(px, devs[0]) : payload_upload(col->type, devs, host, col->len); /* heap vector or mmapped column file alike: staged through pinned buffers */
     if (rc != RFX_OK) {
         for (int s = 0; s < g_nshards; s++) { if (g_nshards > 1) rfx_hip_ctx_bind_thread(g_ctxs[s]); rfx_hip_free(g_ctxs[s], devs[s]); }
@@ -752,6 +823,7 @@ static int resident(obj_p col, int pin, const void **dev) {
     resident_t e;
     memset(&e, 0, sizeof(e));
     e.host = host; e.len = col->len; e.type = ktype; e.sum = sum; e.dev = devs[0]; e.bytes = bytes; e.pinned = pin; e.tick = ++g_tick; e.epoch = g_epoch; e.dbytes = dbytes;
+    e.owner = own ? H.clone(keyobj) : NULL; /* from here on the host copies before it writes, and cannot free */
     for (int s = 0; s < g_nshards; s++) e.devs[s] = devs[s];
     g_res[g_nres++] = e; /* (page tracking starts once the column has proven stable) */
     g_res_bytes += dbytes;

@@ -27,6 +27,13 @@ def test_library_exports_every_declared_symbol(built):
     # the python prototypes cover the headers one to one
     proto = set(_lib.PROTOTYPES) | set(hostobj.OPS_PROTOTYPES)
     assert set(names) <= proto, sorted(set(names) - proto)
+    # ... and NOTHING else is exported (round 6: -fvisibility=hidden, the headers push default visibility): the reference dlopens plugins
+    # RTLD_GLOBAL (core/dynlib.c:131) -- C++-mangled internals and __device_stub__ kernel stubs must not land in the host's namespace
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.lib_path()], capture_output=True, text=True, check=True).stdout
+    exported = {ln.split()[-1] for ln in out.splitlines() if ln.strip() and ln.split()[-2] in "TtDdBbRrWwVvi"}
+    extra = sorted(exported - set(names))
+    assert not extra, extra[:40]
 
 
 def test_struct_layouts(built):

@@ -356,3 +356,76 @@ def test_parted_and_enum_columns_inside_the_real_reference(built, tmp_path, shar
     assert int(st[0]) == on_gpu and int(st[1]) == len(PARTED + ENUMS) - on_gpu, st
     assert len(res["g_p2_Date"]) == 4 and len(res["g_p4_Date"]) == 2
     assert int(st[4]) <= 4 + 3 + 2 + 3  # uploads (t2: three more): the parted table's four 8-byte columns once (pinned; the B8 column is not uploaded), the splayed / in-memory tables' columns
+
+
+@pytest.mark.parametrize("shards", [1, 3])
+@pytest.mark.skipif(not ref.available(), reason="oracle/_ref/rayforce not built (needs /root/reference at build time)")
+def test_writes_of_the_unpatched_reference_are_never_served_stale(built, shards, monkeypatch):
+    """Residency by ownership (round 6): the cache holds clone_obj(col) on every column it keeps on the device, so the UNPATCHED reference's own rule
+    -- write in place only with rc == 1 (cow_obj core/rayforce.c:3003-3026; update's writers core/update.c:1001,1060-1064; the in-place arithmetic
+    core/math.c:2248,2310) -- makes it copy instead, and the copy is a new object: select -> update in place on the quoted global -> select
+    answers the new cells with no rfx_invalidate / rfx_pin anywhere and without ONE checksum (rfx_stats[12] == 0)."""
+    if shards > 1:
+        monkeypatch.setenv("RFX_SHARDS", str(shards))
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    n = 400_003
+    cols = {"k": rfo.gen_i64(n, 4, 500), "a": rfo.gen_i64(n, 2, 1_000_000), "v": rfo.gen_f64(n, 5)}
+    Q = "{s: (sum v) c: (count a) m: (max a) from: t where: (< a 900000) by: k}"
+    steps = [
+        None,
+        "(update {v: (+ v 1.0) from: 't})",                       # a whole new column (binop over the borrowed column: rc >= 2 -> fresh vector)
+        "(update {v: 100.5 from: 't where: (== k 7)})",            # the column is rc == 1 in the table now: WITHOUT the cache's reference this writes in place
+        "(update {a: (+ a 1000) from: 't where: (< a 1000)})",     # ... an i64 column, rows that change which rows the filter selects
+        "(update {v: (* v 0.5) k: 3 from: 't where: (> v 50.0)})",  # two columns at once, the key column among them
+        "(set t (update {v: (- v 1.0) from: t}))",                 # the value form: a new table
+    ]
+    with ref.Session() as s:
+        s.table("t", cols)
+        s.eval(f'(set gsel (loadfn "{LIB}" "rfx_select" 1))')
+        s.eval(f'(set gsum (loadfn "{LIB}" "rfx_sum" 1))')
+        s.eval(f'(set gstat (loadfn "{LIB}" "rfx_stats" 1))')
+        for i, st in enumerate(steps):
+            if st:
+                s.eval(st)
+            s.eval(f"(set g{i} (gsel {Q}))")
+            s.eval(f"(set r{i} (select {Q}))")
+            for o in ("k", "s", "c", "m"):
+                s.out(f"g{i}_{o}", f"(at g{i} '{o})")
+                s.out(f"r{i}_{o}", f"(at r{i} '{o})")
+            s.out(f"rc{i}", "(enlist (rc (at t 'v)))")  # the table's reference + the cache's
+        # heap vectors through the folds: the rc == 1 in-place arithmetic of binop_map / unop_map on temporaries, the same variable rebound
+        s.eval("(set w (+ (at t 'a) 0))")
+        s.out("w0_g", "(enlist (gsum w))")
+        s.out("w0_r", "(enlist (sum w))")
+        s.out("w0_rc", "(enlist (rc w))")
+        s.eval("(set w (+ w 5))")
+        s.out("w1_g", "(enlist (gsum w))")
+        s.out("w1_r", "(enlist (sum w))")
+        s.out("w2_g", "(enlist (gsum (+ (+ w 1) 1)))")  # (+ w 1) is a temporary with rc == 1: the outer + writes INTO it, then it is handed to the fold
+        s.out("w2_r", "(enlist (sum (+ (+ w 1) 1)))")
+        s.out("w3_g", "(enlist (gsum (+ (+ w 1) 2)))")  # ... the next temporary, very likely at the address the last one was freed at
+        s.out("w3_r", "(enlist (sum (+ (+ w 1) 2)))")
+        s.out("stats", "(gstat 0)")
+        res = s.run(threads=8)
+    for i in range(len(steps)):
+        for o in ("k", "s", "c", "m"):
+            g, r = res[f"g{i}_{o}"], res[f"r{i}_{o}"]
+            assert g.dtype == r.dtype and g.shape == r.shape, (i, o)
+            if g.dtype == np.float64:
+                assert np.allclose(g, r, rtol=1e-9, atol=0), (i, o)
+            else:
+                assert np.array_equal(g, r), (i, o)
+    # the answers really moved (a stale copy would have repeated step 0's)
+    assert not np.allclose(res["g1_s"], res["g0_s"]) and not np.allclose(res["g2_s"], res["g1_s"]) and not np.array_equal(res["g3_c"], res["g2_c"])
+    for tag in ("w0", "w1", "w2", "w3"):
+        assert res[f"{tag}_g"][0] == res[f"{tag}_r"][0], tag
+    assert res["w1_g"][0] == res["w0_g"][0] + 5 * n
+    st = res["stats"]
+    assert int(st[0]) == len(steps) and int(st[1]) == 0, st  # every gsel on the device
+    assert int(st[12]) == 0 and int(st[6]) == 0 and int(st[11]) == 0, st  # no checksum, no stale refresh, no page bits: pointer compares only
+    assert int(st[13]) > 0 and int(st[14]) > 0, st  # hits by ownership; replaced columns were released once the host let go of them
+    # references to the table's `v` after each select: the table's + the cache's (+ the global `v` the first column was built from)
+    assert [int(res[f"rc{i}"][0]) for i in range(len(steps))] == [3] + [2] * (len(steps) - 1), [int(res[f"rc{i}"][0]) for i in range(len(steps))]
+    assert int(res["w0_rc"][0]) == 2

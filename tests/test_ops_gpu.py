@@ -24,6 +24,16 @@ def ops(built):
     l.rfx_cache_clear()
 
 
+@pytest.fixture
+def checksum_mode(ops):
+    """Validation by checksum (rfx_ops_set_validation(1)): for the tests below that write a cached payload IN PLACE through a raw numpy view,
+    whatever its reference count -- what the reference itself never does (cow_obj, core/rayforce.c:3003-3026).  The default, validation by
+    ownership, is back afterwards."""
+    assert ops.rfx_ops_set_validation(1) == 0
+    yield
+    assert ops.rfx_ops_set_validation(0) == 0
+
+
 def host_table(n, keys=1000, seed=0):
     return {"k": rfo.gen_i64(n, 4 + seed, keys), "a": rfo.gen_i64(n, 2 + seed, 1_000_000), "v": rfo.gen_f64(n, 5 + seed)}
 
@@ -324,6 +334,82 @@ def test_residency_cache(ops):
         ops.rfx_host_drop(o)
 
 
+def test_residency_by_ownership(ops):
+    """Round 6, the default: a cached copy holds a reference to its host vector (clone_obj); a later use of the SAME object is a pointer compare
+    (rfx_stats[13]), never a checksum (rfx_stats[12]); a host that follows the reference's rule -- write in place only with rc == 1, else copy
+    (cow_obj, core/rayforce.c:3003-3026) -- cannot be served a stale cell; a vector the host has dropped is released at the next operator call."""
+    ops.rfx_cache_clear()
+    n = 1_000_003
+    a = rfo.gen_i64(n, 3, 1000)
+    vec = H.vector(a)
+    assert H.header(vec).rc == 1
+    s0 = H.to_numpy(ops.rfx_stats(0))
+    assert _sum_of(ops, vec) == int(a.sum())
+    assert H.header(vec).rc == 2  # the cache's reference: from now on an owner that looks at the count copies before it writes
+    for _ in range(5):
+        assert _sum_of(ops, vec) == int(a.sum())
+    s1 = H.to_numpy(ops.rfx_stats(0))
+    assert s1[4] - s0[4] == 1 and s1[13] - s0[13] == 5 and s1[12] == s0[12] and s1[6] == s0[6]  # one upload, five pointer compares, no checksum
+
+    def host_write(v, j, val):
+        """what every writer of the reference does: cow_obj -- the object itself with rc == 1, a copy otherwise; the old reference is dropped"""
+        if H.header(v).rc == 1:
+            w = v
+        else:
+            w = H.vector(H.to_numpy(v))
+            ops.rfx_host_drop(v)
+        np.frombuffer((C.c_char * (n * 8)).from_address(H.payload(w)), dtype=np.int64)[j] = val
+        return w
+
+    total = int(a.sum())
+    rng = np.random.default_rng(11)
+    for i in range(40):
+        j = int(rng.integers(0, n))
+        old = int(H.to_numpy(vec)[j])
+        new = int(rng.integers(0, 1 << 40))
+        was = vec
+        vec = host_write(vec, j, new)
+        assert (vec == was) == (i % 2 == 0 and i > 0)  # (every other write finds rc == 1 -- the vector was not used in between -- and goes in place)
+        total += new - old
+        if i % 2 == 0:
+            assert _sum_of(ops, vec) == total, i  # the copy is a new object -> a new upload; the old one is released at this call
+            assert H.header(vec).rc == 2
+    assert _sum_of(ops, vec) == total
+    s2 = H.to_numpy(ops.rfx_stats(0))
+    assert s2[12] == s0[12] and s2[6] == s0[6] and s2[14] - s1[14] >= 19  # still no checksum; the replaced vectors were let go
+    assert ops.rfx_cache_bytes() == n * 8  # ... and their device copies with them
+    # pinned or not: a dropped vector is released; rfx_invalidate / rfx_unpin give the reference back
+    p = ops.rfx_pin(vec)
+    assert H.header(vec).rc == 3  # (ours, the cache's, the clone rfx_pin returned)
+    ops.rfx_host_drop(p)
+    iv = ops.rfx_invalidate(vec)
+    ops.rfx_host_drop(iv)
+    assert H.header(vec).rc == 1 and ops.rfx_cache_bytes() == 0
+    p = ops.rfx_pin(vec)
+    ops.rfx_host_drop(p)
+    ops.rfx_host_drop(vec)  # the host lets go of a pinned vector: nobody can name it any more
+    other = H.vector(a[:1000].copy())
+    assert _sum_of(ops, other) == int(a[:1000].sum())
+    assert ops.rfx_cache_bytes() == 1000 * 8
+    ops.rfx_host_drop(other)
+    # tables: every column the query names is held; dropping the table releases them all
+    host = host_table(100_003)
+    tab = H.table(host)
+    cols = H.list_items(H.list_items(tab)[1])
+    d = H.select_dict({"s": ("sum", "v"), "where": ("<", "a", 500_000), "by": "k"}, tab)
+    for _ in range(3):
+        r = ops.rfx_select(d)
+        assert not H.is_error(r), H.error_text(r)
+        check(H.table_to_numpy(r), rfo.select({"from": host, "s": ("sum", "v"), "where": ("<", "a", 500_000), "by": "k"}))
+        ops.rfx_host_drop(r)
+    assert [H.header(c).rc for c in cols] == [2, 2, 2]
+    ops.rfx_host_drop(d)
+    ops.rfx_host_drop(tab)
+    s3 = H.to_numpy(ops.rfx_stats(0))  # (an operator call like any other: what only the cache still refers to goes)
+    assert ops.rfx_cache_bytes() == 0 and s3[12] == s0[12]
+    assert ops.rfx_ops_set_validation(7) != 0
+
+
 def _sum_of(ops, vec):
     s = ops.rfx_sum(vec)
     assert not H.is_error(s), H.error_text(s)
@@ -332,7 +418,7 @@ def _sum_of(ops, vec):
     return got
 
 
-def test_cache_never_serves_a_stale_cell(ops):
+def test_cache_never_serves_a_stale_cell(ops, checksum_mode):
     """An unpinned cached column is re-validated against a checksum of its FULL payload on every use: flip ONE random cell of a
     cached 1e7-row column in place, 1 000 times -- the answer follows every time (round 1 sampled 64 cells and could miss it)."""
     ops.rfx_cache_clear()
@@ -356,7 +442,7 @@ def test_cache_never_serves_a_stale_cell(ops):
     ops.rfx_host_drop(vec)
 
 
-def test_cache_sees_changes_in_the_top_bit_alone(ops):
+def test_cache_sees_changes_in_the_top_bit_alone(ops, checksum_mode):
     """Cells that change in bit 63 only -- 0 <-> NULL_I64, an f64 <-> its negative -- in an even number of places: the checksum's lanes must
     carry high bits downward (a bare multiply-xor remembered such changes by their parity per lane, and a column of nulls written over a
     column of zeros of the same length at the same address was served from the stale copy: found by tools/fuzz_null_tuples.py, round 5)."""
@@ -400,7 +486,7 @@ def test_cache_sees_changes_in_the_top_bit_alone(ops):
         ops.rfx_host_drop(tab)
 
 
-def test_cache_validates_by_page_bits_where_the_kernel_tracks_them(ops):
+def test_cache_validates_by_page_bits_where_the_kernel_tracks_them(ops, checksum_mode):
     """Round 3: where the kernel tracks soft-dirty pages (the MI355X boxes' does; probed at run time) an unchanged unpinned column is proven
     current by its pages' bits -- rfx_stats[11] counts those uses -- and a write anywhere in it (first page, last page, the middle) is still
     noticed at once; a second column uploaded in between (its clear_refs wipes the first column's evidence) must not hide a write that
@@ -455,7 +541,7 @@ def test_page_bit_validation_when_opted_in(built):
     assert p.returncode == 0 and "1 passed" in p.stdout, p.stdout[-2000:] + p.stderr[-2000:]
 
 
-def test_remembered_key_scope_follows_the_column(ops):
+def test_remembered_key_scope_follows_the_column(ops, checksum_mode):
     """Small inputs: the whole-column scope of a resident key column is remembered with its device copy (one host round trip less per
     group-by); a write into the column -- a key outside the old scope -- refreshes the copy and forgets the scope; a filter that selects
     nothing comes out as zero groups; a pinned column keeps copy and scope until rfx_invalidate."""
@@ -502,7 +588,7 @@ def test_remembered_key_scope_follows_the_column(ops):
         ops.rfx_host_drop(o)
 
 
-def test_cache_pin_trusts_until_invalidated(ops):
+def test_cache_pin_trusts_until_invalidated(ops, checksum_mode):
     """rfx_pin: no per-use validation (the host promises rfx_invalidate before it writes); rfx_invalidate drops the copy."""
     ops.rfx_cache_clear()
     a = rfo.gen_i64(1_000_003, 3, 1000)
