@@ -35,11 +35,12 @@
 extern "C" {
 #endif
 #ifndef __HIPCC_RTC__
-#pragma GCC visibility push(default) /* librfx.so is built with -fvisibility=hidden: what include/*.h declare is its WHOLE dynamic surface (plugins are
+#pragma GCC visibility push(default) /* librfx.so is built with -fvisibility=hidden: what the headers under include/ declare is its WHOLE dynamic surface (plugins are
                                       * dlopen'ed RTLD_GLOBAL, core/dynlib.c:131 -- internals must not land in the host's namespace) */
 #endif
 
 #define RFX_MAX_SHARDS 16
+#define RFX_GROUPS_OWN (RFX_MAX_SHARDS * (4 + 2 * RFX_MAX_KEYS + RFX_EXEC_MAX_AGGS))
 #define RFX_EXEC_MAX_AGGS 32 /* more than RFX_MAX_AGGS outputs run as several passes over the same selection / the same groups */
 
 typedef struct rfx_exec rfx_exec_t;
@@ -141,8 +142,11 @@ typedef struct rfx_groups {
      * rfx_exec_groups_fetch and they cost no further round trip */
     const char *d_block, *h_block;
     size_t block_bytes;
-    void *own[RFX_MAX_SHARDS * 8 + RFX_EXEC_MAX_AGGS + RFX_MAX_KEYS + 6]; /* device blocks to release ... */
-    int8_t own_shard[RFX_MAX_SHARDS * 8 + RFX_EXEC_MAX_AGGS + RFX_MAX_KEYS + 6]; /* ... and the shard whose context each came from */
+    /* device blocks to release, and the shard whose context each came from.  Worst case by construction: a result of RFX_MAX_SHARDS slices registers per
+     * slice its first rows, RFX_MAX_KEYS key columns (twice on the row-hash route: the proof passes' blocks) and one result block per pass
+     * (<= RFX_EXEC_MAX_AGGS passes) */
+    void *own[RFX_GROUPS_OWN];
+    int8_t own_shard[RFX_GROUPS_OWN];
     int32_t nown;
     /* RFX_Q_SLICED: column c of the result = the concatenation of slice[0..nslices)'s pieces; slice i holds the groups [g0, g0 + n) on shard
      * `shard`.  The column pointers above are slice 0's (with one slice: the whole columns, as without the flag) */
@@ -168,6 +172,10 @@ void rfx_exec_groups_free(rfx_exec_t *x, rfx_groups_t *g);
  * RFX_ESTATE with *collision = 1: two key tuples share one 64-bit row hash (nothing may be used).  One shard. */
 int rfx_exec_join_index(rfx_exec_t *x, const void *const *d_left_keys, const void *const *d_right_keys, int nkeys, int64_t nleft, int64_t nright,
                         int64_t *d_ids, int *collision);
+/* ... over SHARDS: a broadcast join.  The BUILD side's key columns (drk) WHOLE on shard `shard`'s device, dlk this shard's nl rows of the left keys;
+ * d_ids (on that device) receives per left row the first right row with an equal tuple -- a GLOBAL right row id -- or null.  Every shard builds the same
+ * table and probes its own rows: no exchange.  To be called on the shard's thread (rfx_exec_run). */
+int rfx_exec_join_index_shard(rfx_exec_t *x, int shard, const void *const *dlk, const void *const *drk, int nk, int64_t nl, int64_t nr, int64_t *d_ids, int *collision);
 
 /* ---- counters since rfx_exec_create ---- */
 enum {

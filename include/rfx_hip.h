@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 #ifndef __HIPCC_RTC__
-#pragma GCC visibility push(default) /* librfx.so is built with -fvisibility=hidden: what include/*.h declare is its WHOLE dynamic surface (plugins are
+#pragma GCC visibility push(default) /* librfx.so is built with -fvisibility=hidden: what the headers under include/ declare is its WHOLE dynamic surface (plugins are
                                       * dlopen'ed RTLD_GLOBAL, core/dynlib.c:131 -- internals must not land in the host's namespace) */
 #endif
 
@@ -448,6 +448,10 @@ int rfx_hip_group_ids_dense(rfx_ctx_t *ctx, const int64_t *d_key, int64_t nrows,
 /* ... through a slot -> group id table of the caller's (range cells, on this context's device): a shard that holds rows but did not rank the merged tables */
 int rfx_hip_group_ids_table(rfx_ctx_t *ctx, const int64_t *d_key, int64_t nrows, int64_t kmin, int64_t range, const int64_t *d_table, int64_t *d_gids);
 
+/* ... for SPARSE keys (hashed tables: no slot -> id table over the key range): from every row's group-first row (RFX_Q_PROBE_FIRST of the planner: the join probe
+ * against the group-by's own table) and the groups' first rows in first-occurrence order: d_gids[d_first[g]] = g, every other row copies its first row's id --
+ * the IDS payload of index_group_i64_unscoped (core/index.c:1959-1977) in the one-executor order. */
+int rfx_hip_group_ids_first(rfx_ctx_t *ctx, const int64_t *d_probe_first, int64_t nrows, const int64_t *d_first, int64_t groups, int64_t *d_gids);
 /* slot -> group id of dense tables after rfx_hip_group_rank, NULL_I64 for an unoccupied slot: the key table of the reference's
  * INDEX_TYPE_SHIFT group index (core/index.c:2037-2062). */
 int rfx_hip_group_slot_ids(rfx_ctx_t *ctx, const rfx_group_tables_t *t, int64_t *d_out);

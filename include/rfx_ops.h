@@ -51,7 +51,7 @@
 extern "C" {
 #endif
 #ifndef __HIPCC_RTC__
-#pragma GCC visibility push(default) /* librfx.so is built with -fvisibility=hidden: what include/*.h declare is its WHOLE dynamic surface (plugins are
+#pragma GCC visibility push(default) /* librfx.so is built with -fvisibility=hidden: what the headers under include/ declare is its WHOLE dynamic surface (plugins are
                                       * dlopen'ed RTLD_GLOBAL, core/dynlib.c:131 -- internals must not land in the host's namespace) */
 #endif
 

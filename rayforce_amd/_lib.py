@@ -131,7 +131,7 @@ class GSlice(C.Structure):
                 ("d_keycols", C.c_void_p * RFX_MAX_KEYS), ("d_results", C.c_void_p * RFX_EXEC_MAX_AGGS)]
 
 
-_GROUPS_OWN = RFX_MAX_SHARDS * 8 + RFX_EXEC_MAX_AGGS + RFX_MAX_KEYS + 6
+_GROUPS_OWN = RFX_MAX_SHARDS * (4 + 2 * RFX_MAX_KEYS + RFX_EXEC_MAX_AGGS)  # RFX_GROUPS_OWN
 
 
 class Groups(C.Structure):
@@ -229,6 +229,7 @@ PROTOTYPES = {
     "rfx_hip_group_slot_ids": (C.c_int, [_ctx, _P(GroupTables), C.c_void_p]),
     "rfx_hip_group_ids_dense": (C.c_int, [_ctx, C.c_void_p, C.c_int64, _P(GroupTables), C.c_void_p]),
     "rfx_hip_group_ids_table": (C.c_int, [_ctx, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
+    "rfx_hip_group_ids_first": (C.c_int, [_ctx, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]),
     "rfx_hip_update_set": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_uint64]),
     "rfx_hip_update_group": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, _P(Agg), _P(GroupTables)]),
     "rfx_dist_unique_id": (C.c_int, [C.c_void_p]),
@@ -296,6 +297,7 @@ EXEC_PROTOTYPES = {
     "rfx_exec_timing": (None, [_exec, C.c_int]),
     "rfx_exec_probe_handover_us": (C.c_double, [C.c_int, C.c_int]),
     "rfx_exec_join_index": (C.c_int, [_exec, _P(C.c_void_p), _P(C.c_void_p), C.c_int, C.c_int64, C.c_int64, C.c_void_p, _P(C.c_int)]),
+    "rfx_exec_join_index_shard": (C.c_int, [_exec, C.c_int, _P(C.c_void_p), _P(C.c_void_p), C.c_int, C.c_int64, C.c_int64, C.c_void_p, _P(C.c_int)]),
     "rfx_exec_stat": (C.c_int64, [_exec, C.c_int]),
     "rfx_exec_run": (C.c_int, [_exec, C.c_void_p, C.c_void_p]),
     "rfx_exec_forget_scopes": (None, [_exec]),

@@ -403,13 +403,29 @@ static void pool_release(rfx_ctx *c) {
     }
     pthread_mutex_unlock(&g_pool_mu);
 }
+// a fresh block from the device.  Out of memory: what this context AND its siblings on the device keep idle goes back first (pool_trim_device:
+// hipDeviceSynchronize + hipFree under the process-wide lock -- every allocation of the process waits meanwhile; an out-of-memory path, not a
+// steady state).
+static hipError_t pool_dev_malloc(rfx_ctx *c, void **p, size_t bytes) {
+    hipError_t e = hipMalloc(p, bytes);
+    if (e == hipErrorOutOfMemory) {
+        pool_trim_device(c);
+        e = hipMalloc(p, bytes);
+    }
+    return e;
+}
 static int pool_malloc_locked(rfx_ctx *c, void **d_ptr, size_t bytes) {
     SmallPool *sp = (SmallPool *)c->ext_p[0];
     if (!sp) {
         c->ext_p[0] = sp = (SmallPool *)calloc(1, sizeof(SmallPool));
         pool_register(c);
     }
-    RFX_HIP_CHECK(hipSetDevice(c->device));
+    // An allocation leaves the calling thread on the context's device (as rfx_hip_ctx_bind_thread does): callers allocate right before they launch
+    // on the context's stream.  hipSetDevice only when the thread is somewhere else -- a pooled hit on the right device touches no HIP state.
+    {
+        int cur = -1;
+        if (hipGetDevice(&cur) != hipSuccess || cur != c->device) RFX_HIP_CHECK(hipSetDevice(c->device));
+    }
     if (bytes <= ((size_t)1 << POOL_MAX_LOG)) {
         if (sp && sp->nlive < POOL_LIVE) {
             int k = POOL_MIN_LOG;
@@ -417,12 +433,7 @@ static int pool_malloc_locked(rfx_ctx *c, void **d_ptr, size_t bytes) {
             void *p = NULL;
             if (sp->nfree[k] > 0) p = sp->freep[k][--sp->nfree[k]];
             else {
-                hipError_t e = hipMalloc(&p, (size_t)1 << k);
-                if (e == hipErrorOutOfMemory) {
-                    pool_trim_device(c);
-                    e = hipMalloc(&p, (size_t)1 << k);
-                }
-                RFX_HIP_CHECK(e);
+                RFX_HIP_CHECK(pool_dev_malloc(c, &p, (size_t)1 << k));
             }
             sp->live_p[sp->nlive] = p;
             sp->live_c[sp->nlive++] = (unsigned char)k;
@@ -430,12 +441,7 @@ static int pool_malloc_locked(rfx_ctx *c, void **d_ptr, size_t bytes) {
             return RFX_OK;
         }
         // (the table of live small blocks is full: an untracked block of the size asked for -- not one of the 64 big slots, not 64 MB)
-        hipError_t e = hipMalloc(d_ptr, bytes ? bytes : 8);
-        if (e == hipErrorOutOfMemory) {
-            pool_trim_device(c);
-            e = hipMalloc(d_ptr, bytes ? bytes : 8);
-        }
-        RFX_HIP_CHECK(e);
+        RFX_HIP_CHECK(pool_dev_malloc(c, d_ptr, bytes ? bytes : 8));
         return RFX_OK;
     }
     const size_t want = (bytes + (((size_t)64 << 20) - 1)) & ~(((size_t)64 << 20) - 1);
@@ -453,24 +459,14 @@ static int pool_malloc_locked(rfx_ctx *c, void **d_ptr, size_t bytes) {
             sp->big_free_p[best] = sp->big_free_p[sp->nbig_free - 1];
             sp->big_free_b[best] = sp->big_free_b[--sp->nbig_free];
         } else {
-            hipError_t e = hipMalloc(&p, want);
-            if (e == hipErrorOutOfMemory) { // what this context AND its siblings on the device keep for reuse goes back first
-                pool_trim_device(c);
-                e = hipMalloc(&p, want);
-            }
-            RFX_HIP_CHECK(e);
+            RFX_HIP_CHECK(pool_dev_malloc(c, &p, want));
         }
         sp->big_live_p[sp->nbig_live] = p;
         sp->big_live_b[sp->nbig_live++] = got;
         *d_ptr = p;
         return RFX_OK;
     }
-    hipError_t e = hipMalloc(d_ptr, bytes);
-    if (e == hipErrorOutOfMemory) {
-        pool_trim_device(c);
-        e = hipMalloc(d_ptr, bytes);
-    }
-    RFX_HIP_CHECK(e);
+    RFX_HIP_CHECK(pool_dev_malloc(c, d_ptr, bytes));
     return RFX_OK;
 }
 extern "C" int rfx_hip_malloc(rfx_ctx_t *c, void **d_ptr, size_t bytes) {

@@ -1046,6 +1046,27 @@ extern "C" int rfx_hip_group_ids_table(rfx_ctx_t *c, const int64_t *d_key, int64
     RFX_HIP_CHECK(hipGetLastError());
     return RFX_OK;
 }
+// ... and for SPARSE keys (the hashed tables: no slot -> id table over the key range): from every row's group-first row (the join probe against the
+// group-by's own table, RFX_Q_PROBE_FIRST) and the groups' first rows in first-occurrence order -- strictly ascending, so group g's first row names g:
+// gids[first[g]] = g, then every other row copies its first row's id (first rows are never rewritten: no cell is read while it changes).
+__global__ __launch_bounds__(RFX_BLOCK) void k_gid_seed(const i64 *__restrict__ first, i64 groups, i64 *__restrict__ gids) {
+    for (i64 g = blockIdx.x * (i64)RFX_BLOCK + threadIdx.x; g < groups; g += (i64)gridDim.x * RFX_BLOCK) gids[first[g]] = g;
+}
+__global__ __launch_bounds__(RFX_BLOCK) void k_gid_spread(const i64 *__restrict__ probe, i64 n, i64 *gids) {
+    for (i64 i = blockIdx.x * (i64)RFX_BLOCK + threadIdx.x; i < n; i += (i64)gridDim.x * RFX_BLOCK) {
+        const i64 f = probe[i];
+        if (f != i) gids[i] = ((u64)f < (u64)n) ? gids[f] : -1;
+    }
+}
+extern "C" int rfx_hip_group_ids_first(rfx_ctx_t *c, const int64_t *d_probe_first, int64_t nrows, const int64_t *d_first, int64_t groups, int64_t *d_gids) {
+    RFX_REQUIRE(c, RFX_EINVAL, "ctx is NULL");
+    if (nrows <= 0) return RFX_OK;
+    RFX_REQUIRE(d_probe_first && d_first && d_gids && groups > 0, RFX_EINVAL, "NULL argument");
+    hipLaunchKernelGGL(k_gid_seed, dim3(rfx_grid(c) * 4), dim3(RFX_BLOCK), 0, c->stream, (const i64 *)d_first, (i64)groups, (i64 *)d_gids);
+    hipLaunchKernelGGL(k_gid_spread, dim3(rfx_grid(c) * 4), dim3(RFX_BLOCK), 0, c->stream, (const i64 *)d_probe_first, (i64)nrows, (i64 *)d_gids);
+    RFX_HIP_CHECK(hipGetLastError());
+    return RFX_OK;
+}
 extern "C" int rfx_hip_group_ids_dense(rfx_ctx_t *c, const int64_t *d_key, int64_t nrows, const rfx_group_tables_t *t,
                                        int64_t *d_gids) {
     RFX_REQUIRE(c && t, RFX_EINVAL, "NULL argument");

@@ -80,6 +80,21 @@ static void free_obj(rfx_obj_p o) {
     free(blk);
 }
 
+/* the blocks kept for reuse go back to the system (rfx_cache_clear: a long-lived standalone process gives up to 16 GB back after one large result) */
+void rfx_host_trim(void) {
+    void *blk[BIG_KEEP];
+    int n = 0;
+    pthread_mutex_lock(&g_big_lock);
+    for (int i = 0; i < BIG_KEEP; i++)
+        if (g_big[i].blk) {
+            blk[n++] = g_big[i].blk;
+            g_big[i].blk = NULL;
+            g_big[i].cap = 0;
+        }
+    pthread_mutex_unlock(&g_big_lock);
+    for (int i = 0; i < n; i++) free(blk[i]);
+}
+
 rfx_obj_p rfx_host_vector(int8_t type, int64_t len) {
     if (len < 0) return NULL;
     int8_t t = type < 0 ? -type : type;

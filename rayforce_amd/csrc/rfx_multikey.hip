@@ -268,7 +268,8 @@ extern "C" int rfx_hip_replace_null_i64(rfx_ctx_t *c, const int64_t *d_col, int6
 
 // out = (x == from) ? to : x, any alignment (the key columns of a sharded row-hash result: a null key rides through the MIN / MAX proof
 // as a value no key has and comes back as the null)
-__global__ __launch_bounds__(RFX_BLOCK) void k_replace_i64(const i64 *__restrict__ in, i64 nrows, i64 from, i64 to, i64 *__restrict__ out) {
+// (no __restrict__: d_out may BE d_col -- the row-hash proof passes replace in place)
+__global__ __launch_bounds__(RFX_BLOCK) void k_replace_i64(const i64 *in, i64 nrows, i64 from, i64 to, i64 *out) {
     for (i64 i = blockIdx.x * (i64)RFX_BLOCK + threadIdx.x; i < nrows; i += (i64)gridDim.x * RFX_BLOCK) {
         const i64 t = in[i];
         out[i] = t == from ? to : t;

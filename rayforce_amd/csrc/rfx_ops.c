@@ -31,6 +31,7 @@ obj_p rfx_host_null(void);
 obj_p rfx_host_b8(int8_t v);
 obj_p rfx_host_err(const char *msg);
 obj_p rfx_host_eval(obj_p o);
+void rfx_host_trim(void);
 
 /* ------------------------------------------------------------------------------------------------ host binding */
 static struct {

@@ -253,7 +253,46 @@ static obj_p group_impl(obj_p keys) {
     int64_t kmin = 0, kmax = -1, seen = 0;
     if (n && rfx_hip_scope_i64(g_ctx, (const int64_t *)dk, NULL, 0, RFX_AND, n, &kmin, &kmax, &seen) != RFX_OK) return fail_hip("scope");
     const uint64_t range = n ? (uint64_t)kmax - (uint64_t)kmin + 1 : 0;
-    if (n && !(range != 0 && range <= (uint64_t)n && kmin != RFX_NULL_I64)) return fail("group: sparse or null keys are not built on the MI355X path");
+    if (n && kmin == RFX_NULL_I64) return fail("group: null keys are not built on the MI355X path"); /* (every null row its own group: core/index.c:1808-1816) */
+    if (n && !(range != 0 && range <= (uint64_t)n)) {
+        /* SPARSE keys (round 6): index_group_i64_unscoped (core/index.c:1959-1977) -> index_group_distribute (:1777-1911): the IDS flavour with NO first
+         * rows -- [IDS, groups, per-row ids, null, null, filter, null].  The planner's hashed group-by (K9) without aggregates gives the groups in
+         * first-occurrence order (= the reference with one executor, what the goldens pin; with several its ids follow its chunks' table order) and,
+         * per row, its group's first row; rfx_hip_group_ids_first turns those into the per-row ids. */
+        const void *dkeys[1] = {dk};
+        rfx_query_t Q;
+        memset(&Q, 0, sizeof(Q));
+        Q.logic = RFX_AND;
+        Q.nkeys = 1;
+        Q.d_keys = dkeys;
+        Q.nrows = n;
+        Q.cols = g_qcols;
+        Q.ncols = g_nqcols;
+        Q.flags = RFX_Q_WANT_FIRST | RFX_Q_REFUSE_NULL_KEY | RFX_Q_PROBE_FIRST;
+        rfx_groups_t R;
+        const int grc = rfx_exec_group_by(g_x, &Q, &R);
+        if (grc != RFX_OK) return fail(rfx_exec_last_error(g_x)[0] ? rfx_exec_last_error(g_x) : rfx_hip_last_error());
+        obj_p res_h = NULL;
+        void *dg = NULL;
+        if (R.path == RFX_PATH_HASH && R.groups > 0 && R.d_probe && R.d_first && rfx_hip_malloc(g_ctx, &dg, (size_t)n * 8) == RFX_OK &&
+            rfx_hip_group_ids_first(g_ctx, R.d_probe, n, R.d_first, R.groups, (int64_t *)dg) == RFX_OK) {
+            obj_p ids_h = H.vector(RFX_TYPE_I64, n);
+            if (rfx_hip_d2h_pipelined(g_ctx, RFX_AS_RAW(ids_h), dg, (size_t)n * 8) == RFX_OK) {
+                res_h = H.vector(RFX_TYPE_LIST, 7);
+                obj_p *ixh = RFX_AS_LIST(res_h);
+                ixh[0] = H.i64(RFX_INDEX_TYPE_IDS);
+                ixh[1] = H.i64(R.groups);
+                ixh[2] = ids_h;
+                ixh[3] = H.i64(RFX_NULL_I64);
+                ixh[4] = H.null_obj;
+                ixh[5] = H.null_obj;
+                ixh[6] = H.null_obj;
+            } else H.drop(ids_h);
+        }
+        if (dg) rfx_hip_free(g_ctx, dg);
+        rfx_exec_groups_free(g_x, &R);
+        return res_h ? res_h : fail_hip("group index over sparse keys");
+    }
     void *store = NULL, *dfirst = NULL, *dids = NULL;
     obj_p res = NULL, gids = NULL, firsts = NULL;
     int64_t groups = 0;

@@ -4,6 +4,149 @@
  * (left-join [keys] x y) / (inner-join [keys] x y): ray_left_join / ray_inner_join, core/join.c:158-298 -- vary_f over (key symbols,
  * left table, right table).  Index = per left row the first right row with an equal key tuple (index_left_join_obj,
  * core/index.c:2886-2928): the group-by's first-occurrence table over the right keys (zero aggregates), probed with the left keys. */
+/* ---- over SHARDS (round 6): a broadcast join.  The left table stays where its rows are (row ranges, one per shard); the right table's key columns and
+ * every right column the result carries are kept WHOLE on every shard's device (resident_ex(whole): cached like any column, uploaded through all the
+ * PCIe links at once); every shard builds the same first-occurrence table over the right keys, probes ITS left rows (rfx_exec_join_index_shard: global
+ * right row ids), gathers the right columns at those ids and writes its rows of the result -- no exchange between the shards, the result's row order is the
+ * left table's (index_left_join_obj / index_inner_join_obj, core/index.c:2886-2990; the reference runs the same probe over its pool, core/join.c:158-298). */
+typedef struct {
+    int inner, nk, collision[RFX_MAX_SHARDS];
+    int64_t nl, nr;
+    const void *dlk[RFX_MAX_SHARDS][RFX_MAX_KEYS], *drk[RFX_MAX_SHARDS][RFX_MAX_KEYS];
+    void *ids[RFX_MAX_SHARDS], *lids[RFX_MAX_SHARDS], *rids[RFX_MAX_SHARDS], *dcol[RFX_MAX_SHARDS];
+    int64_t nout[RFX_MAX_SHARDS], off[RFX_MAX_SHARDS];
+    /* the column being assembled */
+    const void *src[RFX_MAX_SHARDS], *left[RFX_MAX_SHARDS];
+    int src_is_right;
+    uint64_t nullbits;
+    char *out;
+} jsh_t;
+static int jsh_index(void *arg, int s) {
+    jsh_t *J = (jsh_t *)arg;
+    int64_t r0, n;
+    rfx_exec_split(J->nl, g_nshards, s, &r0, &n);
+    J->nout[s] = J->inner ? 0 : n;
+    if (n <= 0) return RFX_OK;
+    rfx_ctx_t *c = g_ctxs[s];
+    int rc = rfx_hip_malloc(c, &J->ids[s], (size_t)n * 8);
+    if (rc == RFX_OK) rc = rfx_exec_join_index_shard(g_x, s, J->dlk[s], J->drk[s], J->nk, n, J->nr, (int64_t *)J->ids[s], &J->collision[s]);
+    if (rc == RFX_OK && J->inner) { /* this shard's matched left rows (local positions, in order) and their right rows */
+        rfx_pred_t p;
+        memset(&p, 0, sizeof(p));
+        p.d_col = J->ids[s]; p.col_type = RFX_I64; p.op = RFX_NE; p.rhs_type = RFX_I64; p.rhs_i = RFX_NULL_I64;
+        int64_t m = 0;
+        rc = rfx_hip_where_begin(c, &p, 1, RFX_AND, NULL, n, &m);
+        if (rc == RFX_OK) rc = rfx_hip_malloc(c, &J->lids[s], (size_t)(m ? m : 1) * 8);
+        if (rc == RFX_OK) rc = rfx_hip_malloc(c, &J->rids[s], (size_t)(m ? m : 1) * 8);
+        if (rc == RFX_OK) rc = rfx_hip_where_emit(c, 0, (int64_t *)J->lids[s]);
+        if (rc == RFX_OK && m) rc = rfx_hip_gather(c, J->ids[s], (const int64_t *)J->lids[s], m, J->rids[s]);
+        J->nout[s] = m;
+    }
+    if (rc == RFX_OK) rc = rfx_hip_malloc(c, &J->dcol[s], (size_t)(J->nout[s] ? J->nout[s] : 1) * 8);
+    return rc;
+}
+static int jsh_column(void *arg, int s) {
+    jsh_t *J = (jsh_t *)arg;
+    const int64_t m = J->nout[s];
+    if (m <= 0) return RFX_OK;
+    rfx_ctx_t *c = g_ctxs[s];
+    int rc;
+    if (J->inner) rc = rfx_hip_gather(c, J->src[s], (const int64_t *)(J->src_is_right ? J->rids[s] : J->lids[s]), m, J->dcol[s]);
+    else rc = rfx_hip_gather_or(c, J->src[s], J->left[s], (const int64_t *)J->ids[s], m, J->nullbits, J->dcol[s]);
+    if (rc == RFX_OK) rc = rfx_hip_d2h(c, J->out + (size_t)J->off[s] * 8, J->dcol[s], (size_t)m * 8);
+    return rc;
+}
+static int jsh_release(void *arg, int s) {
+    jsh_t *J = (jsh_t *)arg;
+    void *p[4] = {J->ids[s], J->lids[s], J->rids[s], J->dcol[s]};
+    for (int i = 0; i < 4; i++)
+        if (p[i]) rfx_hip_free(g_ctxs[s], p[i]);
+    J->ids[s] = J->lids[s] = J->rids[s] = J->dcol[s] = NULL;
+    return RFX_OK;
+}
+/* 1: answered (*res), 0: not this path's (the caller hands the join to the host), -1: failed (*res = the error object) */
+static int join_sharded(int inner, obj_p ksyms, obj_p lt, obj_p rt, obj_p *lk, obj_p *rk, int nk, int64_t nl, int64_t nr, obj_p *res) {
+    jsh_t *J = (jsh_t *)calloc(1, sizeof(jsh_t));
+    if (!J) return 0;
+    J->inner = inner; J->nk = nk; J->nl = nl; J->nr = nr;
+    obj_p lnames = RFX_AS_LIST(lt)[0], rnames = RFX_AS_LIST(rt)[0];
+    int rcode = 0;
+    void *devs[RFX_MAX_SHARDS];
+    const void *d0;
+    for (int i = 0; i < nk; i++) {
+        if (resident_ex(lk[i], 0, 0, &d0, devs) != RFX_OK) goto done; /* (a device handle without per-shard pieces, a parted column: not this path's) */
+        for (int sh = 0; sh < g_nshards; sh++) J->dlk[sh][i] = devs[sh];
+        if (resident_ex(rk[i], 0, 1, &d0, devs) != RFX_OK) goto done;
+        for (int sh = 0; sh < g_nshards; sh++) J->drk[sh][i] = devs[sh];
+    }
+    if (rfx_exec_run(g_x, jsh_index, J) != RFX_OK) {
+        int coll = 0;
+        for (int sh = 0; sh < g_nshards; sh++) coll |= J->collision[sh];
+        if (!coll) { *res = fail(rfx_exec_last_error(g_x)[0] ? rfx_exec_last_error(g_x) : rfx_hip_last_error()); rcode = -1; }
+        goto done; /* (a row-hash collision between two key tuples: the host's own join) */
+    }
+    {
+        int64_t names[64], nout = 0;
+        int ncol = 0;
+        for (int sh = 0; sh < g_nshards; sh++) {
+            int64_t r0;
+            rfx_exec_split(nl, g_nshards, sh, &r0, NULL);
+            J->off[sh] = inner ? nout : r0;
+            nout += J->nout[sh];
+        }
+        for (int i = 0; i < nk; i++) names[ncol++] = RFX_AS_I64(ksyms)[i];
+        for (int pass = 0; pass < 2; pass++) {
+            obj_p nm = pass ? rnames : lnames;
+            for (int64_t i = 0; i < nm->len && ncol < 64; i++) {
+                int64_t sy = RFX_AS_I64(nm)[i];
+                int dup = 0;
+                for (int j = 0; j < ncol; j++) dup |= names[j] == sy;
+                if (!dup) names[ncol++] = sy;
+            }
+        }
+        if (ncol >= 64) goto done;
+        obj_p rk_ = H.vector(RFX_TYPE_SYMBOL, ncol), rv = H.vector(RFX_TYPE_LIST, ncol);
+        int ok = 1;
+        for (int c = 0; c < ncol; c++) { /* (every slot of rv is filled, also after a failure: the list is dropped as a whole) */
+            RFX_AS_I64(rk_)[c] = names[c];
+            obj_p lc = table_col(lt, names[c]), rc = table_col(rt, names[c]);
+            obj_p o = NULL;
+            if (!ok) o = NULL;
+            else if (!inner && (c < nk || !rc)) o = H.clone(lc); /* left join: key columns and left-only columns are the left table's own */
+            else {
+                obj_p src = inner ? (rc ? rc : lc) : rc;
+                o = H.vector(src->type, nout);
+                J->src_is_right = src == rc;
+                J->out = (char *)RFX_AS_RAW(o);
+                J->nullbits = col_ctype(src) == RFX_F64 ? 0x7FF8000000000000ull : 0x8000000000000000ull;
+                ok = resident_ex(src, 0, J->src_is_right, &d0, devs) == RFX_OK;
+                for (int sh = 0; sh < g_nshards && ok; sh++) J->src[sh] = devs[sh];
+                for (int sh = 0; sh < g_nshards; sh++) J->left[sh] = NULL;
+                if (ok && !inner && lc) { /* a column of both tables: the left value where no right row matches */
+                    ok = resident_ex(lc, 0, 0, &d0, devs) == RFX_OK;
+                    for (int sh = 0; sh < g_nshards && ok; sh++) J->left[sh] = devs[sh];
+                }
+                if (ok && nout) ok = rfx_exec_run(g_x, jsh_column, J) == RFX_OK;
+            }
+            RFX_AS_LIST(rv)[c] = o ? o : H.null_obj;
+        }
+        if (!ok) {
+            H.drop(rk_);
+            H.drop(rv);
+            *res = fail(rfx_exec_last_error(g_x)[0] ? rfx_exec_last_error(g_x) : rfx_hip_last_error());
+            rcode = -1;
+            goto done;
+        }
+        *res = H.table(rk_, rv);
+        rcode = 1;
+    }
+done:
+    rfx_exec_run(g_x, jsh_release, J);
+    rfx_hip_ctx_bind_thread(g_ctx);
+    free(J);
+    return rcode;
+}
+
 static obj_p join_impl(int inner, obj_p *x, int64_t n) {
     rfx_host_bind();
     const int fidx = inner ? F_IJ : F_LJ;
@@ -32,7 +175,15 @@ static obj_p join_impl(int inner, obj_p *x, int64_t n) {
         if (!col_ctype(rc)) { why = "non-8-byte column"; goto out; }
         if (lc && lc->type != rc->type) return fail("join: a column has different types in the two tables"); /* err_type, core/join.c:50-51 */
     }
-    if (ensure_ctx1() != RFX_OK) return refusedn(fidx, x, n);
+    if (ensure_ctx() != RFX_OK) return fail_hip("no usable MI355X");
+    if (g_nshards > 1) {
+        obj_p r = NULL;
+        const int jr = join_sharded(inner, ksyms, lt, rt, lk, rk, nk, nl, nr, &r);
+        if (jr > 0) g_last_gpu = 1;
+        if (jr != 0) return r;
+        g_refused_sharded = 1;
+        return refusedn(fidx, x, n);
+    }
     for (int i = 0; i < nk; i++)
         if (resident(lk[i], 0, &dlk[i]) != RFX_OK || resident(rk[i], 0, &drk[i]) != RFX_OK) { res = fail_hip("column upload"); goto done; }
 #define JOIN_TMP(ptr, bytes) do { ptr = NULL; if (rfx_hip_malloc(g_ctx, &ptr, (bytes)) != RFX_OK) { res = fail_hip("join scratch"); goto done; } tmp[ntmp++] = ptr; } while (0)

@@ -361,12 +361,12 @@ static int transient_sharded(obj_p v, const void **dev) {
     if (g_nqtmp >= (int)(sizeof(g_qtmp) / sizeof(g_qtmp[0]))) return RFX_ELIMIT;
     const size_t esz = v->type == RFX_TYPE_B8 ? 1 : 8;
     void *devs[RFX_MAX_SHARDS];
-    int rc = shards_alloc(devs, v->len, esz);
+    int rc = shards_alloc(devs, v->len, esz, 0);
     if (rc != RFX_OK) return rc;
     memset(&g_qtmp[g_nqtmp], 0, sizeof(g_qtmp[0]));
     for (int s = 0; s < g_nshards; s++) g_qtmp[g_nqtmp].d[s] = devs[s];
     g_nqtmp++; /* (released by qtmp_release, shard by shard) */
-    rc = payload_upload(v->type == RFX_TYPE_B8 ? RFX_TYPE_B8 : RFX_TYPE_I64, devs, RFX_AS_RAW(v), v->len);
+    rc = payload_upload(v->type == RFX_TYPE_B8 ? RFX_TYPE_B8 : RFX_TYPE_I64, devs, RFX_AS_RAW(v), v->len, 0);
     g_stat[ST_UPLOADS]++;
     if (rc != RFX_OK) return rc;
     *dev = devs[0];

@@ -413,7 +413,7 @@ static int mask_column_sharded(obj_p tab, obj_p where, int64_t nrows, const void
     if (rc != 0) return rc;
     if (g_nqtmp >= (int)(sizeof(g_qtmp) / sizeof(g_qtmp[0]))) rc = -2;
     void *devs[RFX_MAX_SHARDS];
-    if (rc == 0 && shards_alloc(devs, nrows, 8) != RFX_OK) rc = -2;
+    if (rc == 0 && shards_alloc(devs, nrows, 8, 0) != RFX_OK) rc = -2;
     if (rc == 0) {
         memset(&g_qtmp[g_nqtmp], 0, sizeof(g_qtmp[0]));
         for (int s = 0; s < g_nshards; s++) g_qtmp[g_nqtmp].d[s] = devs[s];

@@ -426,6 +426,7 @@ void rfx_cache_clear(void) {
         rfx_hip_ctx_trim(g_ctxs[sh]);
     }
     if (g_nshards > 1) rfx_hip_ctx_bind_thread(g_ctx);
+    if (H.bound == 2) rfx_host_trim(); /* (the standalone host's recycled result blocks too) */
     op_end();
 }
 int64_t rfx_cache_bytes(void) { return (int64_t)g_res_bytes; }
@@ -656,29 +657,30 @@ typedef struct {
     void *const *devs;
     const char *host;
     int64_t len;
+    int whole; /* every shard takes the WHOLE payload (a join's build side) instead of its row range */
 } upload_job_t;
 static int upload_shard(void *arg, int s) {
     const upload_job_t *u = (const upload_job_t *)arg;
-    int64_t r0, n;
-    rfx_exec_split(u->len, g_nshards, s, &r0, &n);
+    int64_t r0 = 0, n = u->len;
+    if (!u->whole) rfx_exec_split(u->len, g_nshards, s, &r0, &n);
     return n > 0 ? payload_upload_one(g_ctxs[s], u->type, u->devs[s], u->host + (size_t)r0 * u->esz, n) : RFX_OK;
 }
 /* Round 6: every shard's row range at once, each on its shard's own thread (rfx_exec_run), through its own context's staging set and stream: on an
  * 8-device node eight copy engines and eight PCIe links move the column together (rounds 4-5 walked the shards in a loop around a blocking copy: 24 GB of
  * c3w columns crossed one link at a time).  The staging copies of all of them share the library's persistent workers (rfx_io.hip). */
-static int payload_upload(int type, void *const *devs, const void *host, int64_t len) {
-    upload_job_t u = {type, type == RFX_TYPE_B8 ? 1 : (IS_I32_FAMILY(type) ? 4 : 8), devs, (const char *)host, len};
+static int payload_upload(int type, void *const *devs, const void *host, int64_t len, int whole) {
+    upload_job_t u = {type, type == RFX_TYPE_B8 ? 1 : (IS_I32_FAMILY(type) ? 4 : 8), devs, (const char *)host, len, whole};
     if (g_nshards == 1) return upload_shard(&u, 0);
     const int rc = rfx_exec_run(g_x, upload_shard, &u);
     rfx_hip_ctx_bind_thread(g_ctx);
     return rc;
 }
-static int shards_alloc(void **devs, int64_t len, size_t desz) {
+static int shards_alloc(void **devs, int64_t len, size_t desz, int whole) {
     int rc = RFX_OK;
     for (int s = 0; s < RFX_MAX_SHARDS; s++) devs[s] = NULL;
     for (int s = 0; s < g_nshards && rc == RFX_OK; s++) {
-        int64_t n;
-        rfx_exec_split(len, g_nshards, s, NULL, &n);
+        int64_t n = len;
+        if (!whole) rfx_exec_split(len, g_nshards, s, NULL, &n);
         if (g_nshards > 1) rfx_hip_ctx_bind_thread(g_ctxs[s]);
         rc = rfx_hip_malloc(g_ctxs[s], &devs[s], (size_t)(n ? n : 1) * desz);
     }
@@ -707,7 +709,11 @@ rfx_obj_p rfx_host_device_vector(int8_t type, int64_t len, const void *const *d_
     o->len = len;
     return o;
 }
-static int resident(obj_p col, int pin, const void **dev) {
+/* whole = 1 (round 6, several shards only): the column WHOLE on every shard's device -- the BUILD side of a join over sharded tables (every shard
+ * probes its own left rows against all of the right table: a broadcast join) -- cached beside the row-range copies as an entry of its own
+ * (type code + 128); *devs_out receives the copies' addresses, the planner's column table (g_qcols) does not learn them. */
+static int resident_ex(obj_p col, int pin, int whole, const void **dev, void **devs_out) {
+    if (whole && (col->mmod == RFX_MMOD_DEVICE || g_nshards <= 1)) return RFX_ELIMIT; /* (device handles hold row ranges: nothing to replicate from) */
     if (col->mmod == RFX_MMOD_DEVICE) {
         const devcol_t *dc = (const devcol_t *)RFX_AS_RAW(col);
         const int esz = (col->type == RFX_TYPE_B8) ? 1 : 8;
@@ -722,13 +728,14 @@ static int resident(obj_p col, int pin, const void **dev) {
         return qcol_add(devs);
     }
     const proxy_t *px = g_npx ? proxy_of(col) : NULL;
-    if (px && g_nshards > 1) return RFX_ELIMIT; /* (parted views run on one shard: the caller hands such tables to the host) */
+    if (px && (g_nshards > 1 || whole)) return RFX_ELIMIT; /* (parted views run on one shard: the caller hands such tables to the host) */
+#define RES_DONE(e) do { *dev = (e)->dev; if (devs_out) for (int s_ = 0; s_ < g_nshards; s_++) devs_out[s_] = (e)->devs[s_]; return whole ? RFX_OK : qcol_add((e)->devs); } while (0)
     const int narrow = !px && IS_I32_FAMILY(col->type);
     const int esz = (col->type == RFX_TYPE_B8) ? 1 : (narrow ? 4 : 8);
     const void *host = px ? (const void *)px->src : RFX_AS_RAW(col); /* a parted column is known by its LIST object */
     const size_t bytes = (size_t)col->len * esz;          /* of the HOST payload: what is validated */
-    const size_t dbytes = (size_t)col->len * (narrow ? 8 : esz); /* of the device copy: what the budget counts */
-    const int ktype = px ? 64 + col->type : col->type;
+    const size_t dbytes = (size_t)col->len * (narrow ? 8 : esz) * (size_t)(whole ? g_nshards : 1); /* of the device copy (copies): what the budget counts */
+    const int ktype = (px ? 64 + col->type : col->type) + (whole ? 128 : 0);
     int have_sum = 0;
     uint64_t sum = 0;
     const int own = validate_mode() == 0;
@@ -742,8 +749,7 @@ static int resident(obj_p col, int pin, const void **dev) {
             g_res[i].epoch = g_epoch;
             g_res[i].pinned |= pin;
             g_stat[ST_CACHE_HITS]++;
-            *dev = g_res[i].dev;
-            return qcol_add(g_res[i].devs);
+            RES_DONE(&g_res[i]);
         }
         if (g_res[i].host == host && g_res[i].len == col->len && g_res[i].type == ktype) {
             int track = 0;
@@ -754,8 +760,7 @@ static int resident(obj_p col, int pin, const void **dev) {
                     g_res[i].epoch = g_epoch;
                     g_res[i].pinned |= pin;
                     g_stat[ST_CACHE_HITS]++;
-                    *dev = g_res[i].dev;
-                    return qcol_add(g_res[i].devs);
+                    RES_DONE(&g_res[i]);
                 }
                 g_res[i].tracked = 0;
                 /* by its checksum -- taken AFTER the pages were clean-marked, so that it can vouch for them from now on */
@@ -779,12 +784,11 @@ static int resident(obj_p col, int pin, const void **dev) {
                 g_res[i].epoch = g_epoch;
                 g_res[i].pinned |= pin;
                 g_stat[ST_CACHE_HITS]++;
-                *dev = g_res[i].dev;
-                return qcol_add(g_res[i].devs);
+                RES_DONE(&g_res[i]);
             }
             /* stale: the payload changed under the same address -- refresh the device copy in place */
             g_stat[ST_CACHE_STALE]++;
-            int rc = px ? proxy_upload(px, g_res[i].dev) : payload_upload(col->type, g_res[i].devs, host, col->len);
+            int rc = px ? proxy_upload(px, g_res[i].dev) : payload_upload(col->type, g_res[i].devs, host, col->len, whole);
             if (rc != RFX_OK) { res_free(i); return rc; }
             g_stat[ST_UPLOADS]++;
             g_res[i].scope_ok = 0; /* (new cells: the scope remembered for the old ones is gone) */
@@ -792,8 +796,7 @@ static int resident(obj_p col, int pin, const void **dev) {
             g_res[i].tick = ++g_tick;
             g_res[i].epoch = g_epoch;
             g_res[i].pinned |= pin;
-            *dev = g_res[i].dev;
-            return qcol_add(g_res[i].devs);
+            RES_DONE(&g_res[i]);
         }
     }
     while (g_nres && g_res_bytes + dbytes > cache_budget()) {
@@ -804,12 +807,12 @@ static int resident(obj_p col, int pin, const void **dev) {
         res_free(victim);
     }
     void *devs[RFX_MAX_SHARDS];
-    int rc = shards_alloc(devs, col->len, narrow ? 8 : (size_t)esz);
+    int rc = shards_alloc(devs, col->len, narrow ? 8 : (size_t)esz, whole);
     if (rc != RFX_OK) return rc;
     /* the checksum, THEN the copy: a host write racing with this call is either in both, or in the copy only and costs one refresh at
      * the next use -- never a device copy older than what vouches for it */
     if (!have_sum && !own) sum = px ? proxy_sum(px) : payload_sum(host, bytes);
-    rc = px ? proxy_upload(px, devs[0]) : payload_upload(col->type, devs, host, col->len); /* heap vector or mmapped column file alike: staged through pinned buffers */
+    rc = px ? proxy_upload(px, devs[0]) : payload_upload(col->type, devs, host, col->len, whole); /* heap vector or mmapped column file alike: staged through pinned buffers */
     if (rc != RFX_OK) {
         for (int s = 0; s < g_nshards; s++) { if (g_nshards > 1) rfx_hip_ctx_bind_thread(g_ctxs[s]); rfx_hip_free(g_ctxs[s], devs[s]); }
         if (g_nshards > 1) rfx_hip_ctx_bind_thread(g_ctx);
@@ -827,9 +830,10 @@ static int resident(obj_p col, int pin, const void **dev) {
     for (int s = 0; s < g_nshards; s++) e.devs[s] = devs[s];
     g_res[g_nres++] = e; /* (page tracking starts once the column has proven stable) */
     g_res_bytes += dbytes;
-    *dev = devs[0];
-    return qcol_add(devs);
+    RES_DONE(&g_res[g_nres - 1]);
+#undef RES_DONE
 }
+static int resident(obj_p col, int pin, const void **dev) { return resident_ex(col, pin, 0, dev, NULL); }
 /* The key scope of a WHOLE resident column (index_scope_i64 without a filter, core/index.c:376-435), remembered with the copy it was taken
  * from.  A group-by over a few thousand slots is two host round trips -- the scope, the result -- and ~25 us each: the remembered scope
  * (a superset of any filtered selection's, which is all the tables' sizing needs) saves the first one for every later query over that key

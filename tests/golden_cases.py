@@ -251,14 +251,19 @@ def same(got, want, name=""):
 # ---- group indexes / lazy MAPGROUP pairs (tests/golden/make_mapgroup_golden.py) ----
 # (rows, distinct keys, key offset, filtered?): 500 / 5 000 keys -> SHIFT index; ranges beyond 524 288 within the row count -> IDS
 MAPGROUP_CASES = [(100_003, 500, 0, False), (100_003, 500, -77, True), (600_011, 300_000, 1000, False), (1_400_003, 545_000, 5, True),
-                  (100_003, 5000, 10**12, False), (700_001, 600_000, -3, False)]
+                  (100_003, 5000, 10**12, False), (700_001, 600_000, -3, False),
+                  # SPARSE keys (round 6; range > rows -> index_group_i64_unscoped, core/index.c:1959-1977: IDS flavour, no first rows).  16 001 rows: below
+                  # POOL_SPLIT_THRESHOLD (core/pool.c:36,451) the reference groups on ONE executor -- first-occurrence order; beyond it its ids follow
+                  # its chunks' hash-table order (core/index.c:1878-1896), implementation-defined like the drop-in test's UNORDERED queries
+                  (16_001, 3000, -77, False), (12_007, 12_007, 5, False)]
+MAPGROUP_MULT = {6: 1_000_003, 7: -(1 << 40)}  # case -> key multiplier (spreads the keys: range > rows)
 
 
 def mapgroup_inputs(ci):
     """(keys, i64 values with nulls, f64 values with NaNs, filter ids or None) of case `ci`: generator + seed, as the fixture script used."""
     from oracle import rfo
     n, keys, off, filt = MAPGROUP_CASES[ci]
-    k = rfo.gen_i64(n, 4 + ci, keys) + off
+    k = rfo.gen_i64(n, 4 + ci, keys) * MAPGROUP_MULT.get(ci, 1) + off
     vi = rfo.gen_i64(n, 2 + ci, 1_000_000)
     vf = rfo.gen_f64(n, 5 + ci) - 0.25
     vi[::97] = -(2**63)

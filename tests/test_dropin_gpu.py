@@ -180,9 +180,9 @@ def test_plugin_inside_the_real_reference(built, shards, monkeypatch):
     # reference's one-group-per-null-row rule is not reproduced -- but the reference itself panics in its heap on every single-key
     # group-by over a key column with nulls (2 003 .. 300 007 rows, -c 1 and -c 8), so that hand-back is asserted in standalone mode.)
     st = res["stats"]
-    if shards > 1:  # key tuples on the row-hash path and a where: tree beyond the fused form run on one shard: the host's here; so are the joins
+    if shards > 1:  # key tuples on the row-hash path and a where: tree beyond the fused form run on one shard: the host's here
         assert int(st[0]) >= len(QUERIES) - 2 and 1 <= int(st[1]) <= 4, st
-        assert int(st[2]) == 0 and int(st[3]) == 4, st
+        assert int(st[2]) == 4 and int(st[3]) == 0, st  # round 6: the joins run over the shards too (broadcast join: the right table whole on every shard)
         return
     assert int(st[0]) == len(QUERIES) + 2 and int(st[1]) == 1, st
     assert int(st[2]) == 4 and int(st[3]) == 0, st

@@ -292,10 +292,48 @@ ops.rfx_host_drop(r)
 r = ops.rfx_group(H.vector(kbig * 1_000_003))
 assert H.is_error(r) and "whole on one device" in H.error_text(r), H.error_text(r)
 ops.rfx_host_drop(r)
-# the joins (and update) still need their tables whole on one device and say so instead of answering from one shard
-r = ops.rfx_left_join((C.c_void_p * 3)(H.symbols(["k"]), tab, tab), 3)
-assert H.is_error(r) and "whole on one device" in H.error_text(r), H.error_text(r)
-ops.rfx_host_drop(r)
+# round 6: the equi-joins run over the shards -- a broadcast join: the left table's rows stay on their shards, the right table is kept whole on every shard,
+# every shard probes and gathers its own rows -- bit for bit the oracle's (= the reference's golden joins): one key (dense / hashed table), two keys
+# (composite), wide tuples with nulls (row hash + the tuple check), an empty match set
+import golden_cases as G
+for case in G.join_cases():
+    name, keys, left, right, want_lj, want_ij = case
+    lt_, rt_, ks_ = H.table(left), H.table(right), H.symbols(keys)
+    args = (C.c_void_p * 3)(ks_, lt_, rt_)
+    for fn, ora in (("rfx_left_join", rfo.left_join), ("rfx_inner_join", rfo.inner_join)):
+        out = getattr(ops, fn)(args, 3)
+        assert not H.is_error(out), (name, fn, H.error_text(out))
+        got, o = H.table_to_numpy(out), ora(keys, left, right)
+        assert list(got) == list(o), (name, fn)
+        for c in o:
+            assert got[c].dtype == o[c].dtype and np.array_equal(got[c].view(np.int64), o[c].view(np.int64)), (name, fn, c)
+        ops.rfx_host_drop(out)
+    for o in (lt_, rt_, ks_):
+        ops.rfx_host_drop(o)
+# ... at a size where every shard holds many left rows: 2e6 left rows against 30 000 right rows (a third of the left keys find no partner), asked twice
+# (the second time the right table's whole-column copies and the left pieces are cache hits)
+right = {"k": rfo.gen_i64(30_000, 41, 70_000), "k2": rfo.gen_i64(30_000, 42, 13), "w": rfo.gen_f64(30_000, 43), "v": rfo.gen_f64(30_000, 44) + 5.0}
+left = {"k": host["k"], "k2": host["k2"], "a": host["a"], "v": host["v"]}
+lt_, rt_ = H.table(left), H.table(right)
+st0 = H.to_numpy(ops.rfx_stats(0))
+for rep in range(2):
+    for keys in (["k"], ["k", "k2"]):
+        ks_ = H.symbols(keys)
+        args = (C.c_void_p * 3)(ks_, lt_, rt_)
+        for fn, ora in (("rfx_left_join", rfo.left_join), ("rfx_inner_join", rfo.inner_join)):
+            out = getattr(ops, fn)(args, 3)
+            assert not H.is_error(out), (keys, fn, H.error_text(out))
+            got, o = H.table_to_numpy(out), ora(keys, left, right)
+            assert list(got) == list(o), (keys, fn)
+            for c in o:
+                assert got[c].dtype == o[c].dtype and np.array_equal(got[c].view(np.int64), o[c].view(np.int64)), (keys, fn, c)
+            ops.rfx_host_drop(out)
+        ops.rfx_host_drop(ks_)
+st1 = H.to_numpy(ops.rfx_stats(0))
+assert st1[2] - st0[2] == 8 and st1[3] == st0[3], (st0, st1)  # eight joins on the device, none handed back
+assert st1[4] - st0[4] <= 4 + 4, (st0, st1)                   # uploads: four left columns (row ranges) + four right columns (whole), once
+for o in (lt_, rt_):
+    ops.rfx_host_drop(o)
 print("DOOR-OK")
 '''
 
