@@ -947,7 +947,12 @@ struct PlaneHashArgs {
 #define PLH_PROBES 512
 
 // FAST: exactly one aggregate, a plain f64 sum over the value plane (the K9 shape): no per-record dispatch on the aggregate kinds
-template <bool FAST>
+// VAR 0: round 5's form (a lane's four records settle their slots one after the other).  VAR 1 (round 6): LOCKSTEP probing -- every round reads the four
+// records' candidate slots back to back and settles them together, so a batch costs max-over-records probe rounds (5-6 at load 0.53) instead of their sum
+// (~20 dependent LDS round trips and as many divergent loops); the first-row word is not read first: one no-return ds_min_u32 per record; a record
+// that finds no room in the LDS table (or carries the null key) goes to the caller's device-wide table in a COLD loop behind the batch -- one copy of
+// that code per batch instead of one per record between the LDS atomics of its neighbours (round 5: 24 800 lines of ISA for this kernel).
+template <bool FAST, int VAR>
 __global__ __launch_bounds__(PLH_T) void k_plane_hash_aggregate(const Plan P, const PlaneHashArgs X) {
     extern __shared__ __attribute__((aligned(16))) u64 plh_smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1007,7 +1012,8 @@ __global__ __launch_bounds__(PLH_T) void k_plane_hash_aggregate(const Plan P, co
     };
     auto fold = [&](const int idx, const unsigned lrow, const unsigned f0, const u64 key, const u64 val) __attribute__((always_inline)) {
         if (idx >= 0) {
-            if (X.dbg != 1 && lrow < f0) atomicMin(&lfirst[idx], lrow); // (f0: lfirst[idx] as read a moment ago -- it only ever goes down)
+            if (X.dbg == 4) __hip_atomic_fetch_min(&lfirst[idx], lrow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); // (A/B: no read of the word first -- one no-return ds_min_u32 per record)
+            else if (X.dbg != 1 && lrow < f0) atomicMin(&lfirst[idx], lrow); // (f0: lfirst[idx] as read a moment ago -- it only ever goes down)
             if constexpr (FAST) {
                 unsafeAtomicAdd((double *)&larr[idx], rfx_as_f64(val));
                 return;
@@ -1096,11 +1102,86 @@ __global__ __launch_bounds__(PLH_T) void k_plane_hash_aggregate(const Plan P, co
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             lrow[j] = (unsigned)(rbase + (i64)(mm[j] >> PL_SLOT_BITS));
-            f0[j] = lfirst[idx[j] >= 0 ? idx[j] : 0];
+            f0[j] = X.dbg == 4 ? 0u : lfirst[idx[j] >= 0 ? idx[j] : 0];
         }
 #pragma unroll
         for (int j = 0; j < 4; j++)
             if (on[j]) fold(idx[j], lrow[j], f0[j], key[j], val[j]);
+    };
+    auto consume1 = [&](const Batch &B) __attribute__((always_inline)) {
+        const i64 rbase = (i64)B.b * X.block_rows;
+        unsigned mm[4], st[4];
+        u64 key[4], val[4];
+        bool on[4], pend[4];
+        int idx[4];
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const unsigned i = B.i0 + ((unsigned)k * 64u + (unsigned)lane) * 2u;
+            mm[2 * k] = B.m[k].x, mm[2 * k + 1] = B.m[k].y;
+            key[2 * k] = B.key[k].x, key[2 * k + 1] = B.key[k].y;
+            val[2 * k] = B.val[k].x, val[2 * k + 1] = B.val[k].y;
+            on[2 * k] = i < B.n && mine_of(mm[2 * k]);
+            on[2 * k + 1] = i + 1 < B.n && mine_of(mm[2 * k + 1]);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            st[j] = start_of(mm[j]);
+            idx[j] = -1;
+            pend[j] = on[j] && (i64)key[j] != RFX_NULL_I64_D;
+        }
+        for (int round = 0; round < PLH_PROBES; round++) {
+            if (!__builtin_amdgcn_ballot_w64(pend[0] | pend[1] | pend[2] | pend[3])) break;
+            u64 k[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) k[j] = lkey[st[j]]; // (unconditional: st is always a valid slot -- four reads in flight)
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                if (!pend[j]) continue;
+                bool hit = k[j] == key[j];
+                if (!hit && (i64)k[j] == RFX_NULL_I64_D) { // an empty slot: claim it (3 906 inserts per partition out of 3.9e6 records)
+                    const u64 old = atomicCAS((unsigned long long *)&lkey[st[j]], (unsigned long long)RFX_NULL_I64_D, (unsigned long long)key[j]);
+                    hit = (i64)old == RFX_NULL_I64_D || old == key[j];
+                }
+                if (hit) {
+                    idx[j] = (int)st[j];
+                    pend[j] = false;
+                } else st[j] = (st[j] + 1 == C) ? 0 : st[j] + 1;
+            }
+        }
+        unsigned lrow[4];
+        bool cold[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            lrow[j] = (unsigned)(rbase + (i64)(mm[j] >> PL_SLOT_BITS));
+            cold[j] = on[j] && idx[j] < 0;
+            if (!on[j] || idx[j] < 0) continue;
+            __hip_atomic_fetch_min(&lfirst[idx[j]], lrow[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if constexpr (FAST) unsafeAtomicAdd((double *)&larr[idx[j]], rfx_as_f64(val[j]));
+            else {
+#pragma unroll
+                for (int a = 0; a < RFX_MAX_AGGS; a++) {
+                    if (kind[a] < 0) continue;
+                    group_apply(&larr[(size_t)arr_of[a] * C + idx[j]], &larr[(size_t)(arr_of[a] + 1) * C + idx[j]], kind[a], f64[a], apl[a] == 1 ? val[j] : 0ULL, skip[a]);
+                }
+            }
+        }
+        // COLD: every lane hands its records without a slot to the device-wide table, one per round
+        while (__builtin_expect(__builtin_amdgcn_ballot_w64(cold[0] | cold[1] | cold[2] | cold[3]) != 0, 0)) {
+            const bool any = cold[0] | cold[1] | cold[2] | cold[3];
+            const int pick = cold[0] ? 0 : cold[1] ? 1 : cold[2] ? 2 : 3;
+            const u64 ck = pick == 0 ? key[0] : pick == 1 ? key[1] : pick == 2 ? key[2] : key[3];
+            const u64 cv = pick == 0 ? val[0] : pick == 1 ? val[1] : pick == 2 ? val[2] : val[3];
+            const unsigned cr = pick == 0 ? lrow[0] : pick == 1 ? lrow[1] : pick == 2 ? lrow[2] : lrow[3];
+            cold[0] = cold[0] && pick != 0;
+            cold[1] = cold[1] && pick != 1;
+            cold[2] = cold[2] && pick != 2;
+            cold[3] = cold[3] && pick != 3;
+            if (any) fold(-1, cr, 0u, ck, cv);
+        }
+    };
+    auto consume_v = [&](const Batch &B) __attribute__((always_inline)) {
+        if constexpr (VAR == 1) consume1(B);
+        else consume(B);
     };
     const int q = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nreg = q < X.nblk ? (X.nblk - q + NW - 1) / NW : 0;
@@ -1130,12 +1211,12 @@ __global__ __launch_bounds__(PLH_T) void k_plane_hash_aggregate(const Plan P, co
         const bool h1 = advance();
         load(h1, b, i0, n, B1);
         i0 += 256u;
-        consume(B0);
+        consume_v(B0);
         if (!h1) break;
         h0 = advance();
         load(h0, b, i0, n, B0);
         i0 += 256u;
-        consume(B1);
+        consume_v(B1);
     }
     __syncthreads();
     // the partition's groups into the device-wide table: one insert per distinct key
@@ -1279,14 +1360,23 @@ int rfx_plane_hash_accumulate(rfx_ctx *c, const Plan &P, int key_idx, const Hash
     const size_t lds = (size_t)lcap * entry + 16 * 64 * 4 + 64;
     static unsigned long long attr_set = 0; /* one bit per device: function attributes are per device */
     if (!((attr_set >> (c->device & 63)) & 1ull)) {
-        RFX_HIP_CHECK(hipFuncSetAttribute((const void *)k_plane_hash_aggregate<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        RFX_HIP_CHECK(hipFuncSetAttribute((const void *)k_plane_hash_aggregate<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        RFX_HIP_CHECK(hipFuncSetAttribute((const void *)k_plane_hash_aggregate<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        RFX_HIP_CHECK(hipFuncSetAttribute((const void *)k_plane_hash_aggregate<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        RFX_HIP_CHECK(hipFuncSetAttribute((const void *)k_plane_hash_aggregate<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        RFX_HIP_CHECK(hipFuncSetAttribute((const void *)k_plane_hash_aggregate<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         __atomic_fetch_or(&attr_set, 1ull << (c->device & 63), __ATOMIC_RELAXED);
     }
     c->ext_i[3 + RFX_STAT_PLANE_AGGREGATE]++;
     const bool fast = P.nagg == 1 && P.aggs[0].kind == RFX_AGG_SUM && P.aggs[0].f64 && !P.aggs[0].skipnull && X.agg_pl[0] == 1;
-    if (fast) hipLaunchKernelGGL(k_plane_hash_aggregate<true>, dim3(parts << hbits), dim3(PLH_T), lds, c->stream, Pc, X);
-    else hipLaunchKernelGGL(k_plane_hash_aggregate<false>, dim3(parts << hbits), dim3(PLH_T), lds, c->stream, Pc, X);
+    static const char *var_env = getenv("RFX_PLH_VAR"); // (A/B: 0 = round 5's record-by-record probing)
+    const int var = var_env ? atoi(var_env) : 1;
+    if (var == 0) {
+        if (fast) hipLaunchKernelGGL((k_plane_hash_aggregate<true, 0>), dim3(parts << hbits), dim3(PLH_T), lds, c->stream, Pc, X);
+        else hipLaunchKernelGGL((k_plane_hash_aggregate<false, 0>), dim3(parts << hbits), dim3(PLH_T), lds, c->stream, Pc, X);
+    } else {
+        if (fast) hipLaunchKernelGGL((k_plane_hash_aggregate<true, 1>), dim3(parts << hbits), dim3(PLH_T), lds, c->stream, Pc, X);
+        else hipLaunchKernelGGL((k_plane_hash_aggregate<false, 1>), dim3(parts << hbits), dim3(PLH_T), lds, c->stream, Pc, X);
+    }
     RFX_KERNEL_END(c);
     RFX_HIP_CHECK(hipGetLastError());
     return RFX_OK;
