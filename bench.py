@@ -315,6 +315,10 @@ def timed(job: Job, steps: int, warmup: int, world: int):
     for _ in range(warmup):
         job.step()
     eng.profile(True)
+    import gc
+    gc.collect()  # (as in door_run: no stop-the-world collection of the Python host inside the timed region)
+    gc_was = gc.isenabled()
+    gc.disable()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -328,6 +332,8 @@ def timed(job: Job, steps: int, warmup: int, world: int):
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    if gc_was:
+        gc.enable()
     eng.profile(False)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else eng.device)
@@ -485,6 +491,13 @@ def door_run(ops, H, d, steps, warmup, world=1):
         r = ops.rfx_select(d)
         assert r and not H.is_error(r), H.error_text(r)
         ops.rfx_host_drop(r)
+    # The timed region belongs to the C library: the Python host around it must not stop the world inside it.  A generation-2 collection of this process
+    # (torch imported: ~1e6 tracked objects) takes ~10 ms -- BENCH_r05's ONE 14.2 ms step among twenty 4.7 ms ones (10 % of the mean) has exactly that
+    # shape; collected NOW, switched off until the loop ends.
+    import gc
+    gc.collect()
+    gc_was = gc.isenabled()
+    gc.disable()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -500,6 +513,8 @@ def door_run(ops, H, d, steps, warmup, world=1):
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    if gc_was:
+        gc.enable()
     assert r and not H.is_error(r), H.error_text(r)
     if not int(ops.rfx_last_select_on_gpu()):
         raise SystemExit("bench.py: rfx_select handed the query back instead of answering it on the GPU")

@@ -439,6 +439,12 @@ int rfx_hip_hash_emit(rfx_ctx_t *ctx, const rfx_agg_t *aggs, const rfx_hash_tabl
                       int64_t *d_first_ids, void *const *d_results);
 int rfx_hip_hash_emit_sharded(rfx_ctx_t *ctx, const rfx_agg_t *aggs, const rfx_hash_tables_t *t, int64_t row0, int64_t local_rows,
                               int64_t *d_keys, int64_t *d_first_ids, void *const *d_results);
+/* Emit by ROWS (many groups: the table is large against the rows): the groups are the rows that head their own group (d_probe_first[r] == r, from
+ * rfx_hip_join_probe_hash_slots over the group-by's own table), ascending = first-occurrence order.  _begin counts them (syncs); _emit writes the first rows
+ * (d_first_ids, ngroups cells), the keys and every aggregate's column from the slots of those rows -- no ranking of the slots, no permutation. */
+int rfx_hip_hash_rows_begin(rfx_ctx_t *ctx, const int64_t *d_probe_first, int64_t nrows, int64_t *ngroups);
+int rfx_hip_hash_rows_emit(rfx_ctx_t *ctx, const rfx_agg_t *aggs, const rfx_hash_tables_t *t, const int64_t *d_row_slots, int64_t row0, int64_t local_rows,
+                           int64_t ngroups, int64_t *d_keys, int64_t *d_first_ids, void *const *d_results);
 int rfx_hip_hash_rank_emit(rfx_ctx_t *ctx, const rfx_agg_t *aggs, const rfx_hash_tables_t *t, int64_t total_rows, int64_t row0, int64_t local_rows,
                            int nsl, int si, int64_t out_cap, int64_t *d_keys, int64_t *d_first_ids, void *const *d_results, int64_t *ngroups);
 
@@ -508,6 +514,11 @@ int rfx_hip_eval_expr(rfx_ctx_t *ctx, const rfx_agg_t *expr, int64_t nrows, void
 int rfx_hip_join_probe_dense(rfx_ctx_t *ctx, const int64_t *d_left_keys, int64_t nleft, int64_t kmin, int64_t range, const int64_t *d_first,
                              int64_t *d_ids);
 int rfx_hip_join_probe_hash(rfx_ctx_t *ctx, const int64_t *d_left_keys, int64_t nleft, const rfx_hash_tables_t *t, int64_t *d_ids);
+/* ... also leaving, per left row, the table SLOT its key sits in (capacity = the null key's cell, -1 = absent) */
+int rfx_hip_join_probe_hash_slots(rfx_ctx_t *ctx, const int64_t *d_left_keys, int64_t nleft, const rfx_hash_tables_t *t, int64_t *d_ids, int64_t *d_slots);
+/* one hash = one tuple (__index_list_cmp_row, core/index.c:2465-2790, once per row): *differ = cells of the nk key columns that differ between a row and its
+ * group's first row d_first_of_row[r] (0: every row hash stands for exactly one key tuple).  One pass, one counter back.  (syncs) */
+int rfx_hip_tuple_check(rfx_ctx_t *ctx, const void *const *d_keys, int nk, const int64_t *d_first_of_row, int64_t nrows, int64_t *differ);
 int rfx_hip_gather_or(rfx_ctx_t *ctx, const void *d_right, const void *d_left, const int64_t *d_ids, int64_t n, uint64_t fill_bits, void *d_out);
 
 /* ---- multi-GPU: row-range sharding, one process per GPU, ONE exchange per query over RCCL / xGMI (rfx_dist.hip) ----
@@ -563,6 +574,8 @@ int rfx_hip_ctx_device(rfx_ctx_t *ctx);
  * rfx_hip_update_group: d_col[row] = the final aggregate of row's group, for the selected rows -- tables of ONE aggregate filled by
  *                       rfx_hip_group_dense_accumulate over the same selection (aggr_row + set_ids per group, update.c:781-850). */
 int rfx_hip_update_set(rfx_ctx_t *ctx, void *d_col, const int64_t *d_ids, int64_t m, const void *d_vals, uint64_t atom_bits);
+/* over shards: d_out[i] = (d_mask01 ? d_mask01[i] != 0 : 1) ? (d_vals ? d_vals[i] : atom_bits) : (d_old ? d_old[i] : null_bits) -- one row-local write, no ids */
+int rfx_hip_update_select(rfx_ctx_t *ctx, void *d_out, const void *d_old, uint64_t null_bits, const int64_t *d_mask01, const void *d_vals, uint64_t atom_bits, int64_t n);
 int rfx_hip_update_group(rfx_ctx_t *ctx, void *d_col, const int64_t *d_key, const int64_t *d_ids, int64_t m, const rfx_agg_t *agg,
                          const rfx_group_tables_t *t);
 

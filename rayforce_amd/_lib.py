@@ -231,6 +231,7 @@ PROTOTYPES = {
     "rfx_hip_group_ids_table": (C.c_int, [_ctx, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
     "rfx_hip_group_ids_first": (C.c_int, [_ctx, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]),
     "rfx_hip_update_set": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_uint64]),
+    "rfx_hip_update_select": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int64]),
     "rfx_hip_update_group": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, _P(Agg), _P(GroupTables)]),
     "rfx_dist_unique_id": (C.c_int, [C.c_void_p]),
     "rfx_dist_init": (C.c_int, [_ctx, C.c_int, C.c_int, C.c_void_p]),
@@ -250,6 +251,10 @@ PROTOTYPES = {
     "rfx_hip_eval_expr": (C.c_int, [_ctx, _P(Agg), C.c_int64, C.c_void_p, _P(C.c_int32)]),
     "rfx_hip_join_probe_dense": (C.c_int, [_ctx, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
     "rfx_hip_join_probe_hash": (C.c_int, [_ctx, C.c_void_p, C.c_int64, _P(HashTables), C.c_void_p]),
+    "rfx_hip_join_probe_hash_slots": (C.c_int, [_ctx, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "rfx_hip_tuple_check": (C.c_int, [_ctx, _P(C.c_void_p), C.c_int, C.c_void_p, C.c_int64, _P(C.c_int64)]),
+    "rfx_hip_hash_rows_begin": (C.c_int, [_ctx, C.c_void_p, C.c_int64, _P(C.c_int64)]),
+    "rfx_hip_hash_rows_emit": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, _P(C.c_void_p)]),
     "rfx_hip_gather_or": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_uint64, C.c_void_p]),
     "rfx_hip_row_hash": (C.c_int, [_ctx, C.POINTER(C.c_void_p), C.c_int, C.c_int64, C.c_int, C.c_void_p]),
     "rfx_hip_replace_null_i64": (C.c_int, [_ctx, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),

@@ -322,30 +322,31 @@ static int gb_prove_tuples(gq_t *G) {
     rfx_ctx_t *c = x->ctx[0];
     if (G->dense || multi) { if (q->flags & RFX_Q_PROBE_FIRST) { rc = RFX_ESTATE; snprintf(x->err, sizeof(x->err), "rfx_exec: a first-row probe needs the hashed path on one shard"); return rc; } }
     else {
-        void *ids = NULL, *chk = NULL;
+        /* every row's group-first row AND table slot in one probe; the tuple proof as ONE pass over the key columns with one counter back (round 5: a
+         * gather, a compare pass and a sync per key column); both arrays stay with the shard: a table that is large against the rows is emitted by
+         * ROWS (ph_rank_emit) instead of by ranking its slots */
+        void *ids = NULL, *slots = NULL;
         rc = rfx_hip_malloc(c, &ids, (size_t)(h->nrows ? h->nrows : 1) * 8);
-        if (rc == RFX_OK) rc = rfx_hip_join_probe_hash(c, (const int64_t *)h->key, h->nrows, &h->ht, (int64_t *)ids);
+        if (rc == RFX_OK) rc = rfx_hip_malloc(c, &slots, (size_t)(h->nrows ? h->nrows : 1) * 8);
+        if (rc == RFX_OK) rc = rfx_hip_join_probe_hash_slots(c, (const int64_t *)h->key, h->nrows, &h->ht, (int64_t *)ids, (int64_t *)slots);
         int collision = 0;
-        if (rc == RFX_OK && G->rowhash) rc = rfx_hip_malloc(c, &chk, (size_t)(h->nrows ? h->nrows : 1) * 8);
-        for (int k = 0; k < G->nkeys && rc == RFX_OK && G->rowhash && !collision; k++) {
-            rfx_pred_t ne;
-            rfx_value_t cv;
+        if (rc == RFX_OK && G->rowhash) {
             int64_t differ = 0;
-            memset(&ne, 0, sizeof(ne));
-            ne.d_col = chk;
-            ne.col_type = RFX_I64;
-            ne.op = RFX_NE;
-            ne.d_rhs_col = h->keys[k];
-            ne.rhs_type = RFX_I64;
-            rc = rfx_hip_gather_or(c, h->keys[k], h->keys[k], (const int64_t *)ids, h->nrows, 0, chk);
-            if (rc == RFX_OK) rc = rfx_hip_filter_aggr_host(c, &ne, 1, RFX_AND, NULL, 0, h->nrows, &cv, &differ);
+            rc = rfx_hip_tuple_check(c, h->keys, G->nkeys, (const int64_t *)ids, h->nrows, &differ);
             if (rc == RFX_OK && differ) collision = 1;
         }
-        if (chk) rfx_hip_free(c, chk);
-        if ((q->flags & RFX_Q_PROBE_FIRST) && rc == RFX_OK && !collision && G->first_pass) {
-            out->d_probe = (int64_t *)ids;
-            own(x, out, ids);
-        } else if (ids) rfx_hip_free(c, ids);
+        if (rc == RFX_OK && !collision) {
+            h->probe_ids = (int64_t *)ids;
+            h->probe_slots = (int64_t *)slots;
+            ids = slots = NULL;
+            if ((q->flags & RFX_Q_PROBE_FIRST) && G->first_pass) {
+                out->d_probe = h->probe_ids;
+                own(x, out, h->probe_ids);
+                h->probe_owned_by_result = 1;
+            }
+        }
+        if (ids) rfx_hip_free(c, ids);
+        if (slots) rfx_hip_free(c, slots);
         if (rc == RFX_OK && collision) {
             snprintf(x->err, sizeof(x->err), "row-hash collision between two key tuples");
             rc = RFX_ESTATE;

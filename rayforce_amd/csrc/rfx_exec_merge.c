@@ -154,7 +154,25 @@ static int ph_rank_emit(void *arg, int s) {
      *  8 aggregates over 4M slots would pin 300 MB for what may be a handful of groups -- the group count comes back first and the block is exact) */
     const int64_t bound0 = (slots < G->seen ? slots : G->seen) < 1 ? 1 : (slots < G->seen ? slots : G->seen);
     const int one_launch_fits = (size_t)(G->na + 1) * (size_t)(bound0 / (G->nsl > 1 ? G->nsl : 1) + 1) * 8 <= ((size_t)64 << 20);
-    if (!x->two_step_rank && slots <= RFX_RANK_EMIT_MAX && one_launch_fits) {
+    static int by_rows_env = -1; /* RFX_EMIT_BY_ROWS=0: the slot-ranking form everywhere (A/B) */
+    if (by_rows_env < 0) by_rows_env = getenv("RFX_EMIT_BY_ROWS") ? atoi(getenv("RFX_EMIT_BY_ROWS")) : 1;
+    /* (RFX_EMIT_BY_ROWS=2: wherever the probe arrays exist, whatever the sizes -- how the small tests reach this path) */
+    if (by_rows_env && !G->dense && !multi && nsl == 1 && h->probe_ids && h->probe_slots && ((slots > RFX_RANK_EMIT_MAX && h->nrows <= 4 * slots) || by_rows_env == 2)) {
+        /* MANY groups in a table that is large against the rows (the row-hash route's 1e8 groups in 2.7e8 slots): the groups are the rows that head
+         * their own group, in ascending order -- a compaction over the probe's first rows and one gather per table array at those rows' slots, instead
+         * of five passes over the slots, a slot -> id array, an inverse permutation and a gather through it (rfx_hip_hash_rows_*) */
+        rc = rfx_hip_hash_rows_begin(c, h->probe_ids, h->nrows, &h->groups);
+        if (x->timing) h->t_rank = now_ns();
+        if (rc != RFX_OK || h->groups == 0) return rc;
+        const int64_t gn = h->groups;
+        h->g0 = 0;
+        h->gn = gn;
+        h->gstride = gn;
+        if ((rc = rfx_hip_malloc(c, &h->dout, (size_t)(G->na + 1) * (size_t)gn * 8)) != RFX_OK) return rc;
+        if ((rc = rfx_hip_malloc(c, &h->dfirst, (size_t)gn * 8)) != RFX_OK) return rc;
+        for (int a = 0; a < G->na; a++) ptrs[a] = (int64_t *)h->dout + (size_t)(a + 1) * (size_t)gn;
+        if ((rc = rfx_hip_hash_rows_emit(c, h->aggs, &h->ht, h->probe_slots, r0, nloc, gn, (int64_t *)h->dout, (int64_t *)h->dfirst, ptrs)) != RFX_OK) return rc;
+    } else if (!x->two_step_rank && slots <= RFX_RANK_EMIT_MAX && one_launch_fits) {
         /* rank -> emit with no host round trip between them: the outputs are sized before the group count is known -- groups <= min(slots, selected
          * rows), a slice its share + 1 -- and the count comes back once everything is enqueued */
         int64_t bound = slots < G->seen ? slots : G->seen;

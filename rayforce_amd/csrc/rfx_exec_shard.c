@@ -31,6 +31,9 @@ typedef struct {
     int64_t *d_ids, count;
     /* the selection of a mask query as ids (first rows are translated back through them) */
     int64_t *sel_ids;
+    /* hashed path on one shard: per row the first row of its group and the table slot of its key (gb_prove_tuples' probe), kept for an emit by rows */
+    int64_t *probe_ids, *probe_slots;
+    int probe_owned_by_result; /* (RFX_Q_PROBE_FIRST: the result took probe_ids over) */
 } shard_t;
 
 static const void *xlate(const rfx_query_t *q, int s, const void *p, int *bad) {
@@ -90,6 +93,9 @@ static void sh_release(rfx_exec_t *x, shard_t *h, int s) {
     }
     if (h->sel_ids) rfx_hip_free(x->ctx[s], h->sel_ids);
     h->sel_ids = NULL;
+    if (h->probe_ids && !h->probe_owned_by_result) rfx_hip_free(x->ctx[s], h->probe_ids);
+    if (h->probe_slots) rfx_hip_free(x->ctx[s], h->probe_slots);
+    h->probe_ids = h->probe_slots = NULL;
 }
 
 /* how many of the aggregates from a0 on one pass carries: <= RFX_MAX_AGGS, <= RFX_MAX_EXPRS expressions and a handful of distinct argument

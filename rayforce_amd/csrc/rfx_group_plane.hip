@@ -947,11 +947,12 @@ struct PlaneHashArgs {
 #define PLH_PROBES 512
 
 // FAST: exactly one aggregate, a plain f64 sum over the value plane (the K9 shape): no per-record dispatch on the aggregate kinds
-// VAR 0: round 5's form (a lane's four records settle their slots one after the other).  VAR 1 (round 6): LOCKSTEP probing -- every round reads the four
-// records' candidate slots back to back and settles them together, so a batch costs max-over-records probe rounds (5-6 at load 0.53) instead of their sum
-// (~20 dependent LDS round trips and as many divergent loops); the first-row word is not read first: one no-return ds_min_u32 per record; a record
-// that finds no room in the LDS table (or carries the null key) goes to the caller's device-wide table in a COLD loop behind the batch -- one copy of
-// that code per batch instead of one per record between the LDS atomics of its neighbours (round 5: 24 800 lines of ISA for this kernel).
+// VAR 0: a lane's four records settle their slots one after the other, the spill path inline.  VAR 1: the same with the spill path as ONE cold loop behind
+// the batch.  Both (round 6) update a slot's first row with ONE no-return ds_min_u32 per record instead of reading the word first and comparing: the read was
+// a second dependent LDS round trip and a divergent branch per record -- the aggregate fell from 8.8 to 3.6 ms at 1e9 rows / 1e6 keys (RFX_PLH_DBG=5 is the
+// read-first form; profiles/r06_k9_ab.txt).  Also measured and withdrawn: LOCKSTEP probing (every round reads the four records' candidate slots back to
+// back and settles them together: max-over-records rounds instead of their sum) -- 23.5 ms per query against 17.4: the unconditional reads of settled
+// records and the per-round ballots cost more than the shorter dependency chain saves (git 37867ef has the kernel).
 template <bool FAST, int VAR>
 __global__ __launch_bounds__(PLH_T) void k_plane_hash_aggregate(const Plan P, const PlaneHashArgs X) {
     extern __shared__ __attribute__((aligned(16))) u64 plh_smem[];
@@ -1012,8 +1013,9 @@ __global__ __launch_bounds__(PLH_T) void k_plane_hash_aggregate(const Plan P, co
     };
     auto fold = [&](const int idx, const unsigned lrow, const unsigned f0, const u64 key, const u64 val) __attribute__((always_inline)) {
         if (idx >= 0) {
-            if (X.dbg == 4) __hip_atomic_fetch_min(&lfirst[idx], lrow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); // (A/B: no read of the word first -- one no-return ds_min_u32 per record)
-            else if (X.dbg != 1 && lrow < f0) atomicMin(&lfirst[idx], lrow); // (f0: lfirst[idx] as read a moment ago -- it only ever goes down)
+            if (X.dbg == 5) { // (A/B: round 5's form -- the word read first, the atomic only when the row is smaller)
+                if (lrow < f0) atomicMin(&lfirst[idx], lrow);
+            } else if (X.dbg != 1) __hip_atomic_fetch_min(&lfirst[idx], lrow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); // one no-return ds_min_u32 per record
             if constexpr (FAST) {
                 unsafeAtomicAdd((double *)&larr[idx], rfx_as_f64(val));
                 return;
@@ -1102,17 +1104,19 @@ __global__ __launch_bounds__(PLH_T) void k_plane_hash_aggregate(const Plan P, co
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             lrow[j] = (unsigned)(rbase + (i64)(mm[j] >> PL_SLOT_BITS));
-            f0[j] = X.dbg == 4 ? 0u : lfirst[idx[j] >= 0 ? idx[j] : 0];
+            f0[j] = X.dbg == 5 ? lfirst[idx[j] >= 0 ? idx[j] : 0] : 0u;
         }
 #pragma unroll
         for (int j = 0; j < 4; j++)
             if (on[j]) fold(idx[j], lrow[j], f0[j], key[j], val[j]);
     };
+    // VAR 1: the same probing, the no-room / null-key records in ONE cold loop behind the batch instead of inline between the LDS atomics of their
+    // neighbours (the kernel's ISA: 24 800 -> ~10 000 lines)
     auto consume1 = [&](const Batch &B) __attribute__((always_inline)) {
         const i64 rbase = (i64)B.b * X.block_rows;
-        unsigned mm[4], st[4];
-        u64 key[4], val[4];
-        bool on[4], pend[4];
+        unsigned mm[4], st[4], lrow[4];
+        u64 key[4], val[4], k0[4];
+        bool on[4], cold[4];
         int idx[4];
 #pragma unroll
         for (int k = 0; k < 2; k++) {
@@ -1126,30 +1130,10 @@ __global__ __launch_bounds__(PLH_T) void k_plane_hash_aggregate(const Plan P, co
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             st[j] = start_of(mm[j]);
-            idx[j] = -1;
-            pend[j] = on[j] && (i64)key[j] != RFX_NULL_I64_D;
+            k0[j] = lkey[st[j]];
         }
-        for (int round = 0; round < PLH_PROBES; round++) {
-            if (!__builtin_amdgcn_ballot_w64(pend[0] | pend[1] | pend[2] | pend[3])) break;
-            u64 k[4];
 #pragma unroll
-            for (int j = 0; j < 4; j++) k[j] = lkey[st[j]]; // (unconditional: st is always a valid slot -- four reads in flight)
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                if (!pend[j]) continue;
-                bool hit = k[j] == key[j];
-                if (!hit && (i64)k[j] == RFX_NULL_I64_D) { // an empty slot: claim it (3 906 inserts per partition out of 3.9e6 records)
-                    const u64 old = atomicCAS((unsigned long long *)&lkey[st[j]], (unsigned long long)RFX_NULL_I64_D, (unsigned long long)key[j]);
-                    hit = (i64)old == RFX_NULL_I64_D || old == key[j];
-                }
-                if (hit) {
-                    idx[j] = (int)st[j];
-                    pend[j] = false;
-                } else st[j] = (st[j] + 1 == C) ? 0 : st[j] + 1;
-            }
-        }
-        unsigned lrow[4];
-        bool cold[4];
+        for (int j = 0; j < 4; j++) idx[j] = on[j] ? slot_of(key[j], st[j], k0[j]) : -1;
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             lrow[j] = (unsigned)(rbase + (i64)(mm[j] >> PL_SLOT_BITS));
@@ -1165,7 +1149,6 @@ __global__ __launch_bounds__(PLH_T) void k_plane_hash_aggregate(const Plan P, co
                 }
             }
         }
-        // COLD: every lane hands its records without a slot to the device-wide table, one per round
         while (__builtin_expect(__builtin_amdgcn_ballot_w64(cold[0] | cold[1] | cold[2] | cold[3]) != 0, 0)) {
             const bool any = cold[0] | cold[1] | cold[2] | cold[3];
             const int pick = cold[0] ? 0 : cold[1] ? 1 : cold[2] ? 2 : 3;
@@ -1368,8 +1351,8 @@ int rfx_plane_hash_accumulate(rfx_ctx *c, const Plan &P, int key_idx, const Hash
     }
     c->ext_i[3 + RFX_STAT_PLANE_AGGREGATE]++;
     const bool fast = P.nagg == 1 && P.aggs[0].kind == RFX_AGG_SUM && P.aggs[0].f64 && !P.aggs[0].skipnull && X.agg_pl[0] == 1;
-    static const char *var_env = getenv("RFX_PLH_VAR"); // (A/B: 0 = round 5's record-by-record probing)
-    const int var = var_env ? atoi(var_env) : 1;
+    static const char *var_env = getenv("RFX_PLH_VAR"); // (A/B: 1 = the spill path as a cold loop behind the batch)
+    const int var = var_env ? atoi(var_env) : 0;
     if (var == 0) {
         if (fast) hipLaunchKernelGGL((k_plane_hash_aggregate<true, 0>), dim3(parts << hbits), dim3(PLH_T), lds, c->stream, Pc, X);
         else hipLaunchKernelGGL((k_plane_hash_aggregate<false, 0>), dim3(parts << hbits), dim3(PLH_T), lds, c->stream, Pc, X);

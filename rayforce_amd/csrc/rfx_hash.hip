@@ -321,6 +321,76 @@ extern "C" int rfx_hip_hash_emit_sharded(rfx_ctx_t *c, const rfx_agg_t *aggs, co
     return rfx_emit_slots(c, A);
 }
 
+// ---------------- emit by ROWS (round 6) ----------------
+// A hashed group-by over MANY groups (the row-hash route's 1e8 groups in 2.7e8 slots) spent most of its time ranking and walking SLOTS: five passes over
+// the 2.1 GB first-row array, a 2.1 GB slot -> id array, an inverse permutation written at random and a gather of every table array through it (52 GB read
+// to write 3.2 GB: profiles/r05_pmc_detail.json).  With every row's group-first row at hand (the probe the tuple proof makes anyway) the groups ARE the rows
+// that head their own group (probe[r] == r), and those rows in ascending order are the first-occurrence order: a byte mask, the `where` compaction
+// (rfx_hip_where_begin / _emit) and ONE gather per table array at the representative rows' slots (k_join_probe_hash's slot_out).
+__global__ __launch_bounds__(RFX_BLOCK) void k_rep_mask(const i64 *__restrict__ probe, i64 n, signed char *__restrict__ mask) {
+    for (i64 i = blockIdx.x * (i64)RFX_BLOCK + threadIdx.x; i < n; i += (i64)gridDim.x * RFX_BLOCK) mask[i] = probe[i] == i;
+}
+__global__ __launch_bounds__(RFX_BLOCK) void k_emit_rows(const EmitArgs A, const i64 *__restrict__ row_slot, i64 groups) {
+    for (i64 g = blockIdx.x * (i64)RFX_BLOCK + threadIdx.x; g < groups; g += (i64)gridDim.x * RFX_BLOCK) {
+        const i64 f = A.out_first[g]; // (the compaction wrote the representative rows there: the groups' first rows, ascending)
+        const i64 i = row_slot[f];
+        if (A.out_keys) A.out_keys[g] = (i64)A.keys[i];
+        for (int a = 0; a < A.nagg; a++) {
+            if (!A.out[a]) continue;
+            if (A.kinds[a] == RFX_AGG_FIRST) {
+                const i64 lr = f - A.row0;
+                A.out[a][g] = (A.col[a] && lr >= 0 && (A.nloc == 0 || lr < A.nloc)) ? A.col[a][lr] : 0ULL;
+            } else A.out[a][g] = group_final(A.kinds[a], A.f64s[a], A.acc[a][i], A.cnt[a] ? A.cnt[a][i] : 0ULL, A.skips[a]);
+        }
+    }
+}
+extern "C" int rfx_hip_hash_rows_begin(rfx_ctx_t *c, const int64_t *d_probe_first, int64_t nrows, int64_t *ngroups) {
+    RFX_REQUIRE(c && ngroups, RFX_EINVAL, "NULL argument");
+    *ngroups = 0;
+    if (nrows <= 0) return RFX_OK;
+    RFX_REQUIRE(d_probe_first, RFX_EINVAL, "NULL argument");
+    void *mask = NULL;
+    int rc = rfx_hip_malloc(c, &mask, (size_t)nrows + 64);
+    if (rc != RFX_OK) return rc;
+    hipLaunchKernelGGL(k_rep_mask, dim3(rfx_grid(c) * 4), dim3(RFX_BLOCK), 0, c->stream, (const i64 *)d_probe_first, (i64)nrows, (signed char *)mask);
+    rc = hipGetLastError() == hipSuccess ? rfx_hip_where_begin(c, NULL, 0, RFX_AND, (const int8_t *)mask, nrows, ngroups) : RFX_EHIP; // (syncs: the mask has been read)
+    rfx_hip_free(c, mask);
+    return rc;
+}
+extern "C" int rfx_hip_hash_rows_emit(rfx_ctx_t *c, const rfx_agg_t *aggs, const rfx_hash_tables_t *t, const int64_t *d_row_slots, int64_t row0, int64_t local_rows,
+                                      int64_t ngroups, int64_t *d_keys, int64_t *d_first_ids, void *const *d_results) {
+    RFX_REQUIRE(c, RFX_EINVAL, "ctx is NULL");
+    RFX_REQUIRE(local_rows >= 0 && ngroups >= 0, RFX_EINVAL, "bad argument");
+    int rc = check_hash(aggs, t);
+    if (rc != RFX_OK) return rc;
+    if (ngroups == 0) return RFX_OK;
+    RFX_REQUIRE(d_row_slots && d_first_ids, RFX_EINVAL, "NULL argument");
+    rc = rfx_hip_where_emit(c, 0, d_first_ids); // the representative rows, ascending: the groups' first rows in first-occurrence order
+    if (rc != RFX_OK) return rc;
+    EmitArgs A;
+    memset(&A, 0, sizeof(A));
+    A.slots = t->capacity + 1;
+    A.nagg = t->nagg;
+    A.first = (const u64 *)t->d_first;
+    A.keys = (const u64 *)t->d_keys;
+    A.out_keys = (i64 *)d_keys;
+    A.out_first = (i64 *)d_first_ids;
+    A.row0 = row0;
+    A.nloc = local_rows;
+    for (int a = 0; a < t->nagg; a++) {
+        A.kinds[a] = aggs[a].kind;
+        A.f64s[a] = rfx_agg_input_type(&aggs[a]) == RFX_F64;
+        A.skips[a] = aggs[a].xop != RFX_X_NONE || aggs[a].nxnodes > 0;
+        A.acc[a] = (const u64 *)t->d_acc[a];
+        A.cnt[a] = (const u64 *)t->d_cnt[a];
+        A.col[a] = (const u64 *)aggs[a].d_col;
+        A.out[a] = d_results ? (u64 *)d_results[a] : NULL;
+    }
+    hipLaunchKernelGGL(k_emit_rows, dim3(rfx_grid(c) * 4), dim3(RFX_BLOCK), 0, c->stream, A, (const i64 *)d_row_slots, (i64)ngroups);
+    RFX_HIP_CHECK(hipGetLastError());
+    return RFX_OK;
+}
+
 extern "C" int rfx_hip_hash_rank_emit(rfx_ctx_t *c, const rfx_agg_t *aggs, const rfx_hash_tables_t *t, int64_t total_rows, int64_t row0, int64_t local_rows,
                                       int nsl, int si, int64_t out_cap, int64_t *d_keys, int64_t *d_first_ids, void *const *d_results, int64_t *ngroups) {
     RFX_REQUIRE(c && t && ngroups, RFX_EINVAL, "NULL argument");

@@ -36,8 +36,9 @@
 // memory bandwidth, not by threads).  They live as long as the process (the library is never unloaded by the reference: core/dynlib.c keeps handles).
 struct IoJob {
     char *dst;
-    const char *src;
+    const char *src; // host address -- or, with fd >= 0, the byte OFFSET in that file
     size_t bytes;
+    int fd;
     int *left; // pieces of this copy still to do (guarded by g_io.mu)
 };
 static struct {
@@ -48,21 +49,23 @@ static struct {
     int nworkers, state; // state: 0 not started, 1 running, -1 no threads to be had (copies run on the caller)
     pthread_t th[IO_MAX_WORKERS];
 } g_io = {PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, PTHREAD_COND_INITIALIZER, {}, 0, 0, 0, 0, {}};
-static volatile int g_io_populate = 1; // RFX_IO_POPULATE=0 switches the hint off (A/B)
 static void *io_worker(void *) {
     pthread_mutex_lock(&g_io.mu);
     for (;;) {
         while (g_io.head == g_io.tail) pthread_cond_wait(&g_io.cv_work, &g_io.mu);
         const IoJob j = g_io.q[g_io.head++ % IO_QUEUE];
         pthread_mutex_unlock(&g_io.mu);
-        // An mmapped source (the reference maps column files, core/io.c:1310-1364): its pages enter this process' page tables one minor fault (16 pages
-        // with fault-around) at a time under the copy -- 33-35 GB/s where a heap source reaches 55.  MADV_POPULATE_READ (Linux 5.14) maps the piece's
-        // pages in ONE call before the copy reads them; on memory that is mapped already it only walks the page tables.  A kernel without it says
-        // EINVAL once and the hint is dropped for good.
-        if (g_io_populate) {
-            const uintptr_t a = (uintptr_t)j.src & ~(uintptr_t)4095, e = ((uintptr_t)j.src + j.bytes + 4095) & ~(uintptr_t)4095;
-            if (madvise((void *)a, e - a, 22 /* MADV_POPULATE_READ */) != 0 && errno == EINVAL) g_io_populate = 0;
-        }
+        if (j.fd >= 0) { // a column FILE (rfx_hip_column_file_load): read straight into the pinned staging buffer -- no mapping, no page faults
+            size_t got = 0;
+            while (got < j.bytes) {
+                const ssize_t r = pread(j.fd, j.dst + got, j.bytes - got, (off_t)((size_t)j.src + got));
+                if (r <= 0) { // (short file / error: the tail stays zero; the loader checked the size before)
+                    memset(j.dst + got, 0, j.bytes - got);
+                    break;
+                }
+                got += (size_t)r;
+            }
+        } else
         memcpy(j.dst, j.src, j.bytes); // (touching an mmapped source's pages -- the file I/O -- happens here, in parallel)
         pthread_mutex_lock(&g_io.mu);
         if (--*j.left == 0) pthread_cond_broadcast(&g_io.cv_done);
@@ -74,7 +77,6 @@ static void io_pool_start_locked(void) {
     int want = (int)(cpus / 4);
     if (want < 16) want = cpus >= 16 ? 16 : (cpus > 1 ? (int)cpus : 1);
     if (want > IO_MAX_WORKERS) want = IO_MAX_WORKERS;
-    if (const char *e = getenv("RFX_IO_POPULATE")) g_io_populate = atoi(e) != 0;
     if (const char *e = getenv("RFX_IO_THREADS")) {
         const int v = atoi(e);
         if (v >= 1 && v <= IO_MAX_WORKERS) want = v;
@@ -90,28 +92,43 @@ static void io_pool_start_locked(void) {
     g_io.state = g_io.nworkers > 0 ? 1 : -1;
 }
 // queue dst <- src for the workers; *left counts the pieces (the caller keeps it alive until io_wait returns)
-static void io_submit(char *dst, const char *src, size_t bytes, int *left) {
+static void io_read_here(char *dst, const char *src, size_t bytes, int fd) {
+    if (fd < 0) {
+        memcpy(dst, src, bytes);
+        return;
+    }
+    size_t got = 0;
+    while (got < bytes) {
+        const ssize_t r = pread(fd, dst + got, bytes - got, (off_t)((size_t)src + got));
+        if (r <= 0) {
+            memset(dst + got, 0, bytes - got);
+            return;
+        }
+        got += (size_t)r;
+    }
+}
+static void io_submit(char *dst, const char *src, size_t bytes, int *left, int fd = -1) {
     *left = 0;
     if (!bytes) return;
     pthread_mutex_lock(&g_io.mu);
     if (g_io.state == 0) io_pool_start_locked();
     if (g_io.state < 0 || bytes < IO_PIECE) { // nothing to hand it to / not worth a hand-over
         pthread_mutex_unlock(&g_io.mu);
-        memcpy(dst, src, bytes);
+        io_read_here(dst, src, bytes, fd);
         return;
     }
     size_t off = 0;
     int queued = 0;
     while (off < bytes && g_io.tail - g_io.head < IO_QUEUE) {
         const size_t n = bytes - off < IO_PIECE + IO_PIECE / 2 ? bytes - off : IO_PIECE;
-        g_io.q[g_io.tail++ % IO_QUEUE] = IoJob{dst + off, src + off, n, left};
+        g_io.q[g_io.tail++ % IO_QUEUE] = IoJob{dst + off, src + off, n, fd, left};
         off += n;
         queued++;
     }
     *left = queued;
     if (queued) pthread_cond_broadcast(&g_io.cv_work);
     pthread_mutex_unlock(&g_io.mu);
-    if (off < bytes) memcpy(dst + off, src + off, bytes - off); // (the queue was full: the rest here)
+    if (off < bytes) io_read_here(dst + off, src + off, bytes - off, fd); // (the queue was full: the rest here)
 }
 static void io_wait(int *left) {
     pthread_mutex_lock(&g_io.mu);
@@ -126,11 +143,16 @@ static void parallel_copy(char *dst, const char *src, size_t bytes) {
 
 static int io_stage_ready(rfx_ctx *c);
 void rfx_plane_invalidate(rfx_ctx *c); // rfx_group_plane.hip
+static int h2d_pipelined_from(rfx_ctx_t *c, void *d_dst, const void *src, size_t bytes, int fd);
 extern "C" int rfx_hip_h2d_pipelined(rfx_ctx_t *c, void *d_dst, const void *src, size_t bytes) {
     RFX_REQUIRE(c, RFX_EINVAL, "ctx is NULL");
     if (!bytes) return RFX_OK;
     RFX_REQUIRE(d_dst && src, RFX_EINVAL, "NULL argument");
     if (bytes < IO_CHUNK) return rfx_hip_h2d(c, d_dst, src, bytes);
+    return h2d_pipelined_from(c, d_dst, src, bytes, -1);
+}
+// src: a host address, or (fd >= 0) the byte offset in the file the staging workers pread from
+static int h2d_pipelined_from(rfx_ctx_t *c, void *d_dst, const void *src, size_t bytes, int fd) {
     c->ck_valid = 0; // as rfx_hip_h2d: partitions left by a scope pass do not survive an upload
     c->pc_valid = 0;
     rfx_plane_invalidate(c);
@@ -152,7 +174,7 @@ extern "C" int rfx_hip_h2d_pipelined(rfx_ctx_t *c, void *d_dst, const void *src,
             if (used[b]) err = hipEventSynchronize(c->io_done[b]); // its previous transfer has left the buffer
             if (err != hipSuccess) break;
             const size_t off = staged * IO_CHUNK, n = (bytes - off < IO_CHUNK) ? bytes - off : IO_CHUNK;
-            io_submit((char *)c->io_stage[b], (const char *)src + off, n, &left[b]);
+            io_submit((char *)c->io_stage[b], (const char *)src + off, n, &left[b], fd);
         }
         if (err != hipSuccess) break;
         const int b = (int)(k % IO_NBUF);
@@ -294,16 +316,22 @@ extern "C" int rfx_hip_column_file_load(rfx_ctx_t *c, const char *path, void *d_
     RFX_REQUIRE(d_dst != NULL, RFX_EINVAL, "d_dst is NULL");
     int fd = open(path, O_RDONLY);
     RFX_REQUIRE(fd >= 0, RFX_EINVAL, "cannot open the column file");
-    const size_t bytes = 16 + (size_t)len * 8;
-    void *m = mmap(NULL, bytes, PROT_READ, MAP_PRIVATE, fd, 0);
+    // Round 6: the file is READ (pread by the staging workers, straight into the pinned buffers), not mapped: an mmapped source reaches 33-37 GB/s -- its
+    // pages enter the process one minor fault (16 pages with fault-around) at a time under the copy; MADV_POPULATE_READ per piece was measured and does not
+    // help: 33.9 against 36.6 GB/s, profiles/r06_h2d.txt -- where a heap source reaches 55.  (Columns the HOST has mapped -- the reference's `get` -- still
+    // arrive as addresses: rfx_hip_h2d_pipelined from the mapping.)
+    const size_t bytes = (size_t)len * 8;
+    if (bytes < IO_CHUNK) { // small: one read into the staging area of rfx_hip_h2d
+        void *tmp = malloc(bytes);
+        if (!tmp) {
+            close(fd);
+            return RFX_ENOMEM;
+        }
+        io_read_here((char *)tmp, (const char *)(size_t)16, bytes, fd);
+        rc = rfx_hip_h2d(c, d_dst, tmp, bytes);
+        free(tmp);
+    } else rc = h2d_pipelined_from(c, d_dst, (const void *)(size_t)16, bytes, fd);
     close(fd);
-    if (m == MAP_FAILED) {
-        rfx_set_error("rfx_hip_column_file_load: mmap of %s failed", path);
-        return RFX_EINVAL;
-    }
-    (void)madvise(m, bytes, MADV_SEQUENTIAL);
-    rc = rfx_hip_h2d_pipelined(c, d_dst, (const char *)m + 16, (size_t)len * 8);
-    munmap(m, bytes);
     return rc;
 }
 

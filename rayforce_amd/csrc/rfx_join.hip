@@ -27,21 +27,24 @@ __global__ __launch_bounds__(RFX_BLOCK) void k_join_probe_dense(const u64 *__res
     }
 }
 
+// slot_out (optional): the table slot the row's key sits in (capacity = the null key's cell, -1 = not in the table): what lets a group-by emit its
+// result by walking ROWS -- a group's representative row already knows its slot -- instead of ranking 2.7e8 slots (rfx_hip_hash_rows_emit)
 __global__ __launch_bounds__(RFX_BLOCK) void k_join_probe_hash(const u64 *__restrict__ keys, i64 n, const u64 *__restrict__ tab, i64 capacity,
-                                                               const u64 *__restrict__ first, i64 *__restrict__ out) {
+                                                               const u64 *__restrict__ first, i64 *__restrict__ out, i64 *__restrict__ slot_out) {
     const u64 mask = (u64)capacity - 1;
     for (i64 i = blockIdx.x * (i64)RFX_BLOCK + threadIdx.x; i < n; i += (i64)gridDim.x * RFX_BLOCK) {
         const u64 key = keys[i];
-        i64 r = RFX_NULL_I64_D;
+        i64 r = RFX_NULL_I64_D, at = -1;
         if ((i64)key == RFX_NULL_I64_D) { // the null key has its own cell behind the table (hash_slot)
             const u64 f = first[capacity];
-            if (f != (u64)RFX_INF_I64_D) r = (i64)f;
+            if (f != (u64)RFX_INF_I64_D) r = (i64)f, at = capacity;
         } else {
             u64 s = rfx_hash_index_u64(RFX_U64_HASH_SEED, key) & mask;
             for (i64 probe = 0; probe < capacity; probe++) {
                 const u64 k = tab[s];
                 if (k == key) {
                     r = (i64)first[s];
+                    at = (i64)s;
                     break;
                 }
                 if ((i64)k == RFX_NULL_I64_D) break; // an empty slot ends the probe sequence: the key is not on the right side
@@ -49,7 +52,29 @@ __global__ __launch_bounds__(RFX_BLOCK) void k_join_probe_hash(const u64 *__rest
             }
         }
         out[i] = r;
+        if (slot_out) slot_out[i] = at;
     }
+}
+
+// One hash = one tuple?  ids[r] = the first row of r's group (the probe above, keyed by the row hash): every key column must hold the same cell at r and at
+// ids[r] (__index_list_cmp_row, core/index.c:2465-2790, done once per row instead of once per probe step).  ONE pass over the nk key columns -- a row that
+// heads its own group (ids[r] == r: every row of the H2O Q7 shape) reads nothing twice -- and ONE counter back (round 5: a gather + a compare pass + a sync
+// per key column).
+struct TupleKeys {
+    const u64 *k[RFX_MAX_KEYS];
+};
+__global__ __launch_bounds__(RFX_BLOCK) void k_tuple_check(const TupleKeys K, int nk, const i64 *__restrict__ ids, i64 n, unsigned long long *__restrict__ differ) {
+    unsigned bad = 0;
+    for (i64 i = blockIdx.x * (i64)RFX_BLOCK + threadIdx.x; i < n; i += (i64)gridDim.x * RFX_BLOCK) {
+        const i64 f = ids[i];
+        if (f == i) continue;
+        if ((u64)f >= (u64)n) { // (a row whose own hash is not in the table: cannot happen after the group-by over the same rows)
+            bad++;
+            continue;
+        }
+        for (int c = 0; c < nk; c++) bad += K.k[c][i] != K.k[c][f];
+    }
+    if (__builtin_amdgcn_ballot_w64(bad != 0) && bad) atomicAdd(differ, (unsigned long long)bad);
 }
 
 __global__ __launch_bounds__(RFX_BLOCK) void k_gather_or(const u64 *__restrict__ right, const u64 *__restrict__ left, const i64 *__restrict__ ids, i64 n, u64 fill,
@@ -94,8 +119,37 @@ extern "C" int rfx_hip_join_probe_hash(rfx_ctx_t *c, const int64_t *d_left_keys,
     RFX_REQUIRE(d_left_keys && d_ids && t && t->d_keys && t->d_first, RFX_EINVAL, "NULL argument");
     RFX_REQUIRE(t->capacity >= 2 && (t->capacity & (t->capacity - 1)) == 0, RFX_EINVAL, "capacity must be a power of two >= 2");
     hipLaunchKernelGGL(k_join_probe_hash, dim3(join_grid(c, nleft)), dim3(RFX_BLOCK), 0, c->stream, (const u64 *)d_left_keys, (i64)nleft, (const u64 *)t->d_keys,
-                       (i64)t->capacity, (const u64 *)t->d_first, (i64 *)d_ids);
+                       (i64)t->capacity, (const u64 *)t->d_first, (i64 *)d_ids, (i64 *)nullptr);
     RFX_HIP_CHECK(hipGetLastError());
+    return RFX_OK;
+}
+extern "C" int rfx_hip_join_probe_hash_slots(rfx_ctx_t *c, const int64_t *d_left_keys, int64_t nleft, const rfx_hash_tables_t *t, int64_t *d_ids, int64_t *d_slots) {
+    RFX_REQUIRE(c, RFX_EINVAL, "ctx is NULL");
+    if (nleft <= 0) return RFX_OK;
+    RFX_REQUIRE(d_left_keys && d_ids && d_slots && t && t->d_keys && t->d_first, RFX_EINVAL, "NULL argument");
+    RFX_REQUIRE(t->capacity >= 2 && (t->capacity & (t->capacity - 1)) == 0, RFX_EINVAL, "capacity must be a power of two >= 2");
+    hipLaunchKernelGGL(k_join_probe_hash, dim3(join_grid(c, nleft)), dim3(RFX_BLOCK), 0, c->stream, (const u64 *)d_left_keys, (i64)nleft, (const u64 *)t->d_keys,
+                       (i64)t->capacity, (const u64 *)t->d_first, (i64 *)d_ids, (i64 *)d_slots);
+    RFX_HIP_CHECK(hipGetLastError());
+    return RFX_OK;
+}
+extern "C" int rfx_hip_tuple_check(rfx_ctx_t *c, const void *const *d_keys, int nk, const int64_t *d_first_of_row, int64_t nrows, int64_t *differ) {
+    RFX_REQUIRE(c && differ, RFX_EINVAL, "NULL argument");
+    *differ = 0;
+    if (nrows <= 0) return RFX_OK;
+    RFX_REQUIRE(d_keys && d_first_of_row && nk >= 1 && nk <= RFX_MAX_KEYS, RFX_EINVAL, "bad argument");
+    TupleKeys K;
+    for (int i = 0; i < RFX_MAX_KEYS; i++) K.k[i] = i < nk ? (const u64 *)d_keys[i] : nullptr;
+    int rc = rfx_ws_reserve(c, 256);
+    if (rc != RFX_OK) return rc;
+    unsigned long long *cnt = (unsigned long long *)c->d_ws;
+    RFX_HIP_CHECK(hipMemsetAsync(cnt, 0, 8, c->stream));
+    hipLaunchKernelGGL(k_tuple_check, dim3(join_grid(c, nrows)), dim3(RFX_BLOCK), 0, c->stream, K, nk, (const i64 *)d_first_of_row, (i64)nrows, cnt);
+    RFX_HIP_CHECK(hipGetLastError());
+    unsigned long long *h = (unsigned long long *)c->h_pin;
+    RFX_HIP_CHECK(hipMemcpyAsync(h, cnt, 8, hipMemcpyDeviceToHost, c->stream));
+    RFX_HIP_CHECK(hipStreamSynchronize(c->stream));
+    *differ = (int64_t)h[0];
     return RFX_OK;
 }
 

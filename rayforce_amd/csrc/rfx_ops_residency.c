@@ -101,7 +101,7 @@ int rfx_ops_dist_finalize(void) {
     return rc;
 }
 /* for the operators that need a column WHOLE on one device (everything but rfx_select / rfx_pin / rfx_unpin / rfx_invalidate / rfx_stats) */
-static int ensure_ctx1(void) {
+__attribute__((unused)) static int ensure_ctx1(void) {
     const int rc = ensure_ctx();
     g_refused_sharded = rc == RFX_OK && g_nshards > 1;
     return g_refused_sharded ? RFX_ELIMIT : rc;

@@ -189,6 +189,182 @@ static obj_p upd_result(obj_p tab, const int64_t *mnames, obj_p *newcols, int nm
     return H.table(rk, rv);
 }
 
+/* ---- over SHARDS (round 6).  An update is row-local once every row knows its value: every shard writes ITS rows of the new column in one pass --
+ *   new[i] = selected(i) ? value(i) : old(i)            (rfx_hip_update_select)
+ * with `selected` = the where: tree as a 0 / 1 column per shard (mask_column_sharded: the comparisons' operands are resident shard by shard), and `value`
+ * an atom, the shard's piece of a column, an element-wise expression evaluated over the shard's rows (expr_operand) or, under by:, the row's group
+ * aggregate: the planner's sharded group-by over the same selection (every shard scatters its rows, the tables merge: rfx_exec_group_by) gives (key,
+ * aggregate) per group, which becomes a value table over the key range that every shard looks its rows' keys up in (rfx_hip_group_ids_table).  The
+ * reference runs the same three steps over its pool: ray_where -> the mappings over the MAPFILTER / MAPGROUP columns -> set_ids (core/update.c:1001,
+ * 1048-1080, 781-850). ---- */
+typedef int (*piece_fn)(void *arg, int s, int64_t r0, int64_t n, void *d_out);
+static int map_shards(obj_p out, size_t esz, piece_fn fn, void *arg);
+static const void *shard_piece(const void *p, int s);
+static int mask_column_sharded(obj_p tab, obj_p where, int64_t nrows, const void **d_col);
+typedef struct {
+    const void *d_old, *d_mask, *d_vals; /* shard 0's addresses (pieces through shard_piece); NULL: none */
+    uint64_t null_bits, atom_bits;
+    /* by: */
+    const void *d_key;
+    int64_t kmin, range;
+    void *table[RFX_MAX_SHARDS], *looked[RFX_MAX_SHARDS];
+} usel_t;
+static int usel_piece(void *arg, int s, int64_t r0, int64_t n, void *d_out) {
+    (void)r0;
+    usel_t *U = (usel_t *)arg;
+    const void *vals = shard_piece(U->d_vals, s);
+    if (U->d_key) { /* by: every row's group aggregate through the value table */
+        int rc = rfx_hip_malloc(g_ctxs[s], &U->looked[s], (size_t)n * 8);
+        if (rc == RFX_OK) rc = rfx_hip_group_ids_table(g_ctxs[s], (const int64_t *)shard_piece(U->d_key, s), n, U->kmin, U->range, (const int64_t *)U->table[s], (int64_t *)U->looked[s]);
+        if (rc != RFX_OK) return rc;
+        vals = U->looked[s];
+    }
+    return rfx_hip_update_select(g_ctxs[s], d_out, shard_piece(U->d_old, s), U->null_bits, (const int64_t *)shard_piece(U->d_mask, s), vals, U->atom_bits, n);
+}
+/* UPD_GO: newcols[] filled; UPD_BACK / UPD_STOP as the one-device steps */
+static int upd_sharded(upd_t *u, obj_p where, obj_p by, int nmap, const int64_t *mnames, obj_p *mexpr, obj_p *newcols) {
+    obj_p tab = u->tab;
+    const int64_t nrows = u->nrows;
+    const void *dmask = NULL, *dk = NULL;
+    if (where) {
+        const int mrc = mask_column_sharded(tab, where, nrows, &dmask);
+        if (mrc == -2) return upd_stop(u, fail_hip("where"));
+        if (mrc != 0) return upd_back(u, "where: shape");
+    }
+    if (by) {
+        if (by->type != -RFX_TYPE_SYMBOL) return upd_back(u, "by: is not one column");
+        obj_p kc = table_col(tab, by->i64);
+        if (!kc || !(kc->type == RFX_TYPE_I64 || kc->type == RFX_TYPE_SYMBOL || kc->type == RFX_TYPE_TIMESTAMP)) return upd_back(u, "by: key is not an 8-byte integer column");
+        if (resident(kc, 0, &dk) != RFX_OK) return upd_stop(u, fail_hip("column upload"));
+    }
+    for (int i = 0; i < nmap; i++) {
+        obj_p e = mexpr[i], tc = table_col(tab, mnames[i]);
+        usel_t U;
+        memset(&U, 0, sizeof(U));
+        int vtype = 0, st = UPD_GO;
+        rfx_groups_t R;
+        int have_R = 0;
+        obj_p gk = NULL, gv = NULL;
+        if (by) {
+            if (e->type != RFX_TYPE_LIST || e->len != 2) return upd_back(u, "by: mapping is not (aggr column)");
+            const int f = fn_id(RFX_AS_LIST(e)[0]);
+            static const int KIND[] = {RFX_AGG_SUM, RFX_AGG_AVG, RFX_AGG_MIN, RFX_AGG_MAX, RFX_AGG_COUNT, RFX_AGG_FIRST};
+            obj_p a = RFX_AS_LIST(e)[1];
+            if (f < F_SUM || f > F_FIRST || a->type != -RFX_TYPE_SYMBOL) return upd_back(u, "by: mapping is not (aggr column)");
+            obj_p c = table_col(tab, a->i64);
+            if (!c || !col_ctype(c) || c->type == RFX_TYPE_SYMBOL) return upd_back(u, "aggregate column type");
+            const void *dc;
+            if (resident(c, 0, &dc) != RFX_OK) return upd_stop(u, fail_hip("column upload"));
+            vtype = (f == F_AVG) ? RFX_F64 : (f == F_COUNT) ? RFX_I64 : col_ctype(c);
+            /* the groups over the SAME selection, through the planner: scatter on every shard, merged tables, groups in first-occurrence order */
+            rfx_agg_t ag;
+            memset(&ag, 0, sizeof(ag));
+            ag.d_col = dc;
+            ag.col_type = col_ctype(c);
+            ag.kind = KIND[f - F_SUM];
+            rfx_pred_t pm;
+            memset(&pm, 0, sizeof(pm));
+            pm.d_col = dmask; pm.col_type = RFX_I64; pm.op = RFX_NE; pm.rhs_type = RFX_I64; pm.rhs_i = 0;
+            const void *dkeys[1] = {dk};
+            rfx_query_t Q;
+            memset(&Q, 0, sizeof(Q));
+            Q.preds = dmask ? &pm : NULL;
+            Q.npred = dmask ? 1 : 0;
+            Q.logic = RFX_AND;
+            Q.aggs = &ag;
+            Q.nagg = 1;
+            Q.nkeys = 1;
+            Q.d_keys = dkeys;
+            Q.nrows = nrows;
+            Q.cols = g_qcols;
+            Q.ncols = g_nqcols;
+            Q.flags = RFX_Q_REFUSE_NULL_KEY | RFX_Q_SLICED;
+            const int grc = rfx_exec_group_by(g_x, &Q, &R);
+            if (grc == RFX_EXEC_NULL_KEY) return upd_back(u, "by: sparse or null keys");
+            if (grc != RFX_OK) return upd_stop(u, fail(rfx_exec_last_error(g_x)[0] ? rfx_exec_last_error(g_x) : rfx_hip_last_error()));
+            have_R = 1;
+            if (!(R.path == RFX_PATH_DENSE || R.path == RFX_PATH_DENSE_SMALL)) { rfx_exec_groups_free(g_x, &R); return upd_back(u, "by: sparse or null keys"); }
+            U.d_key = dk;
+            if (R.groups > 0) {
+                gk = H.vector(RFX_TYPE_I64, R.groups);
+                gv = H.vector(RFX_TYPE_I64, R.groups);
+                const void *srcs[2] = {R.d_keys, R.d_results[0]};
+                void *dsts[2] = {RFX_AS_RAW(gk), RFX_AS_RAW(gv)};
+                if (rfx_exec_groups_fetch_all(g_x, &R, 2, srcs, dsts) != RFX_OK) st = upd_stop(u, fail_hip("group results"));
+                int64_t lo = RFX_INF_I64, hi = RFX_NULL_I64;
+                for (int64_t g = 0; g < R.groups && st == UPD_GO; g++) {
+                    const int64_t kk = RFX_AS_I64(gk)[g];
+                    lo = kk < lo ? kk : lo;
+                    hi = kk > hi ? kk : hi;
+                }
+                const uint64_t range = st == UPD_GO ? (uint64_t)hi - (uint64_t)lo + 1 : 0;
+                if (st == UPD_GO && !(range != 0 && range <= (1ull << 28))) st = upd_back(u, "by: sparse or null keys");
+                if (st == UPD_GO) {
+                    obj_p tbl = H.vector(RFX_TYPE_I64, (int64_t)range);
+                    for (uint64_t k = 0; k < range; k++) RFX_AS_I64(tbl)[k] = 0;
+                    for (int64_t g = 0; g < R.groups; g++) RFX_AS_I64(tbl)[RFX_AS_I64(gk)[g] - lo] = RFX_AS_I64(gv)[g];
+                    U.kmin = lo;
+                    U.range = (int64_t)range;
+                    for (int sh = 0; sh < g_nshards && st == UPD_GO; sh++) { /* (a table of the key range on every shard: small against the rows) */
+                        rfx_hip_ctx_bind_thread(g_ctxs[sh]);
+                        if (rfx_hip_malloc(g_ctxs[sh], &U.table[sh], (size_t)range * 8) != RFX_OK || rfx_hip_h2d_pipelined(g_ctxs[sh], U.table[sh], RFX_AS_RAW(tbl), (size_t)range * 8) != RFX_OK)
+                            st = upd_stop(u, fail_hip("value table"));
+                    }
+                    rfx_hip_ctx_bind_thread(g_ctx);
+                    H.drop(tbl);
+                }
+            } else { /* nothing selected: no row is written */
+                U.d_key = NULL;
+                U.d_vals = NULL;
+            }
+        } else if (e->type == -RFX_TYPE_I64) { vtype = RFX_I64; U.atom_bits = (uint64_t)e->i64; }
+        else if (e->type == -RFX_TYPE_F64) { vtype = RFX_F64; memcpy(&U.atom_bits, &e->f64, 8); }
+        else if (e->type == -RFX_TYPE_SYMBOL) {
+            obj_p c = table_col(tab, e->i64);
+            if (!c || !(c->type == RFX_TYPE_I64 || c->type == RFX_TYPE_F64)) return upd_back(u, "mapping column type");
+            if (resident(c, 0, &U.d_vals) != RFX_OK) return upd_stop(u, fail_hip("column upload"));
+            vtype = col_ctype(c);
+        } else if (e->type == RFX_TYPE_LIST && e->len == 3) {
+            int ct = RFX_I64;
+            const int xrc = expr_operand(tab, e, &U.d_vals, &ct); /* (every shard evaluates its rows into a scratch column of the call) */
+            if (xrc == -2) return upd_stop(u, fail_hip("eval_expr"));
+            if (xrc != 0) return upd_back(u, "mapping is neither an atom, a column nor an element-wise expression");
+            vtype = ct;
+        } else return upd_back(u, "mapping is neither an atom, a column nor an element-wise expression");
+        int8_t out_type = vtype == RFX_F64 ? RFX_TYPE_F64 : RFX_TYPE_I64;
+        if (st == UPD_GO && tc) {
+            if (!(tc->type == RFX_TYPE_I64 || tc->type == RFX_TYPE_F64)) st = upd_back(u, "updated column is not i64 / f64");
+            else if (col_ctype(tc) != vtype) st = upd_back(u, "value type differs from the column's (the reference converts; delegated)");
+            else {
+                out_type = tc->type;
+                if (resident(tc, 0, &U.d_old) != RFX_OK) st = upd_stop(u, fail_hip("column upload"));
+            }
+        }
+        if (st == UPD_GO) {
+            U.null_bits = vtype == RFX_F64 ? 0x7FF8000000000000ull : 0x8000000000000000ull;
+            U.d_mask = (by && !U.d_key) ? NULL : dmask;
+            if (by && !U.d_key) { /* (by: with an empty selection: the old column, or nulls for a new one) */
+                U.d_vals = U.d_old;
+                U.atom_bits = U.null_bits;
+            }
+            newcols[i] = H.vector(out_type, nrows);
+            if (map_shards(newcols[i], 8, usel_piece, &U) != RFX_OK) st = upd_stop(u, fail_hip("update over the shards"));
+        }
+        for (int sh = 0; sh < g_nshards; sh++) {
+            if (!U.table[sh] && !U.looked[sh]) continue;
+            rfx_hip_ctx_bind_thread(g_ctxs[sh]);
+            if (U.table[sh]) rfx_hip_free(g_ctxs[sh], U.table[sh]);
+            if (U.looked[sh]) rfx_hip_free(g_ctxs[sh], U.looked[sh]);
+        }
+        rfx_hip_ctx_bind_thread(g_ctx);
+        if (gk) H.drop(gk);
+        if (gv) H.drop(gv);
+        if (have_R) rfx_exec_groups_free(g_x, &R);
+        if (st != UPD_GO) return st;
+    }
+    return UPD_GO;
+}
+
 static obj_p update_impl(obj_p dict) {
     rfx_host_bind();
     if (!dict || dict->type != RFX_TYPE_DICT || RFX_AS_LIST(dict)[0]->type != RFX_TYPE_SYMBOL) return fail("update: expected a dict");
@@ -227,10 +403,16 @@ static obj_p update_impl(obj_p dict) {
     if (st == UPD_GO && u.nrows == 0) st = upd_back(&u, "empty table");
     for (int64_t i = 0; i < tcols->len && st == UPD_GO; i++)
         if (RFX_AS_LIST(tcols)[i]->len != u.nrows) st = upd_back(&u, "ragged table");
-    if (st == UPD_GO && ensure_ctx1() != RFX_OK) st = g_refused_sharded ? upd_back(&u, "sharded operator layer: update is the host's") : upd_stop(&u, fail_ctx());
+    if (st == UPD_GO && ensure_ctx() != RFX_OK) st = upd_stop(&u, fail_hip("no usable MI355X"));
+    if (st == UPD_GO && g_nshards > 1) {
+        st = upd_sharded(&u, where, by, nmap, mnames, mexpr, newcols);
+        if (st == UPD_BACK) g_refused_sharded = 1;
+        nmap = st == UPD_GO ? nmap : nmap; /* (newcols[] are dropped below unless the result takes them) */
+    } else {
     if (st == UPD_GO && where) st = upd_where(&u, where, by);
     if (st == UPD_GO && by) st = upd_by(&u, by);
-    for (int i = 0; i < nmap && st == UPD_GO; i++) {
+    }
+    for (int i = 0; i < nmap && st == UPD_GO && g_nshards == 1; i++) {
         upd_val_t v;
         st = upd_value(&u, mexpr[i], by, &v);
         if (st == UPD_GO) st = upd_column(&u, table_col(tab, mnames[i]), by, &v, &newcols[i]);

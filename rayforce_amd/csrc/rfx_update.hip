@@ -89,3 +89,25 @@ extern "C" int rfx_hip_fill_i64(rfx_ctx_t *ctx, int64_t *d_dst, int64_t n, int64
     RFX_HIP_CHECK(hipGetLastError());
     return RFX_OK;
 }
+
+// ---- over SHARDS (round 6): one row-local write per shard, no ids ----
+//   k_update_select   out[i] = (mask01 ? mask01[i] != 0 : 1) ? (vals ? vals[i] : atom) : (old ? old[i] : null_bits)
+// mask01: the where: tree as an i64 column of 0 / 1 (rfx_hip_widen_b8: what the planner reads as one comparison too); vals: the mapping evaluated over the
+// shard's rows (element-wise), or -- under by: -- every row's group aggregate looked up through the merged groups' value table.
+__global__ __launch_bounds__(RFX_BLOCK) void k_update_select(u64 *__restrict__ out, const u64 *__restrict__ old, u64 null_bits, const i64 *__restrict__ mask01,
+                                                             const u64 *__restrict__ vals, u64 atom, i64 n) {
+    for (i64 i = blockIdx.x * (i64)RFX_BLOCK + threadIdx.x; i < n; i += (i64)gridDim.x * RFX_BLOCK) {
+        const bool sel = mask01 ? mask01[i] != 0 : true;
+        out[i] = sel ? (vals ? vals[i] : atom) : (old ? old[i] : null_bits);
+    }
+}
+extern "C" int rfx_hip_update_select(rfx_ctx_t *c, void *d_out, const void *d_old, uint64_t null_bits, const int64_t *d_mask01, const void *d_vals, uint64_t atom_bits,
+                                     int64_t n) {
+    RFX_REQUIRE(c, RFX_EINVAL, "ctx is NULL");
+    if (n <= 0) return RFX_OK;
+    RFX_REQUIRE(d_out, RFX_EINVAL, "NULL argument");
+    hipLaunchKernelGGL(k_update_select, dim3(upd_grid(c, n)), dim3(RFX_BLOCK), 0, c->stream, (u64 *)d_out, (const u64 *)d_old, (u64)null_bits, (const i64 *)d_mask01,
+                       (const u64 *)d_vals, (u64)atom_bits, (i64)n);
+    RFX_HIP_CHECK(hipGetLastError());
+    return RFX_OK;
+}

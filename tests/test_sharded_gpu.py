@@ -329,6 +329,28 @@ for rep in range(2):
                 assert got[c].dtype == o[c].dtype and np.array_equal(got[c].view(np.int64), o[c].view(np.int64)), (keys, fn, c)
             ops.rfx_host_drop(out)
         ops.rfx_host_drop(ks_)
+# ... and `update ... where / by` (round 6): every shard writes its rows of the new column (selection as a 0 / 1 column per shard, values element-wise per shard or --
+# under by: -- every row's group aggregate looked up in the value table of the merged groups); the families of tests/test_ops_gpu.py::UPDATES against the oracle
+from test_ops_gpu import UPDATES, check
+uh = {"k": rfo.gen_i64(n, 4, 300), "a": host["a"], "v": host["v"]}
+ut = H.table(uh)
+for q in UPDATES + [{"f": ("first", "a"), "mn": ("min", "v"), "where": (">", "v", 0.5), "by": "k"}, {"s": ("sum", "a"), "where": ("<", "a", -5), "by": "k"}]:
+    d = H.select_dict(q, ut)
+    r = ops.rfx_update(d)
+    assert r and not H.is_error(r), (q, H.error_text(r))
+    assert ops.rfx_last_select_on_gpu() == 1, q
+    check(H.table_to_numpy(r), rfo.update({"from": uh, **q}))
+    ops.rfx_host_drop(r)
+    ops.rfx_host_drop(d)
+# the shapes that stay the host's say so
+for q, why in (({"a": 1.5, "where": ("<", "a", 10)}, "value type differs"), ({"t": ("sum", "v"), "by": "kw"}, "sparse or null keys")):
+    t2 = H.table({**uh, "kw": uh["k"] * 1_000_003})
+    d = H.select_dict(q, t2)
+    r = ops.rfx_update(d)
+    assert H.is_error(r) and why in H.error_text(r), (q, H.error_text(r))
+    for o in (r, d, t2):
+        ops.rfx_host_drop(o)
+ops.rfx_host_drop(ut)
 st1 = H.to_numpy(ops.rfx_stats(0))
 assert st1[2] - st0[2] == 8 and st1[3] == st0[3], (st0, st1)  # eight joins on the device, none handed back
 assert st1[4] - st0[4] <= 4 + 4, (st0, st1)                   # uploads: four left columns (row ranges) + four right columns (whole), once
