@@ -1154,6 +1154,10 @@ def main():
                     dq = c_door("q7", eng, WORKLOADS["q7"]["rows"], max(3, args.steps // 4), 2, device_columns=True)
                     also[other]["rfx_select_ms_per_step"] = dq["ms_per_step"]
                     also[other]["rfx_select_verified"] = dq["verified"]
+                if other == "g2":  # BOTH figures: `frac` prices the gather at LINE granularity (8.1 B per table row: what a monotone gather at 10 % must move);
+                    # SURVEY App. A K4's own bytes are 8 B id + 8 B read + 8 B write per SELECTED row = 2.4 B per table row -- no gather can reach that on 128-byte lines
+                    km = r["kernel_ms"] if r["kernel_ms"] > 0 else r["ms_per_step"]
+                    also[other]["frac_survey_app_a_bytes"] = 2.4 * WORKLOADS[other]["rows"] / (km * 1e-3) / 1e9 / HBM_PEAK_GBPS
                 also[other]["steps"] = args.steps if full else max(3, args.steps // 4)
                 if full:
                     also[other]["roofline"] = roofline_block(other, r, 1)

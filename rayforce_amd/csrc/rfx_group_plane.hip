@@ -384,6 +384,7 @@ struct PlaneAggArgs {
     i64 local; // table cells per partition: slots congruent to one residue mod 2^pbits
     int split; // workgroups per partition
     int excl;  // split == 1: this workgroup alone writes its partition's slots during the launch -- the write-out needs no atomics
+    int first_read; // A/B (RFX_PL_FIRST_READ=1): rounds 3-5's first-row update -- read the word, compare, atomic only when smaller -- instead of one no-return ds_min_u32
     int nblk, pbits;
     int agg_pl[RFX_MAX_AGGS]; // loaded plane of aggregate a (-1: none: COUNT / FIRST)
     i64 block_rows;
@@ -436,7 +437,11 @@ __global__ __launch_bounds__(THREADS) void k_plane_aggregate(const Plan P, const
         const unsigned slot = ((mm & mask) + shift) & mask;
         if ((i64)slot >= local) return; // a key outside the scope the tables were sized for: not ours
         const unsigned row = (unsigned)(rbase + (i64)(mm >> PL_SLOT_BITS));
-        if (row < first[slot]) atomicMin(&first[slot], row);
+        // (round 6: one no-return ds_min_u32 per record; reading the word first cost a dependent LDS round trip and a divergent branch per record -- what took
+        //  the hashed aggregate from 8.8 to 3.6 ms, profiles/r06_k9_ab.txt)
+        if (A.first_read) {
+            if (row < first[slot]) atomicMin(&first[slot], row);
+        } else __hip_atomic_fetch_min(&first[slot], row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if constexpr (FAST) {
             unsafeAtomicAdd((double *)&accs[slot], rfx_as_f64(x[0]));
             return;
@@ -850,6 +855,10 @@ int rfx_plane_accumulate(rfx_ctx *c, const Plan &P, int key_idx, const rfx_group
         G.kmin = t->kmin;
         G.range = t->range;
         G.local = local;
+        {
+            static const char *fr = getenv("RFX_PL_FIRST_READ");
+            G.first_read = fr ? atoi(fr) : 0;
+        }
         G.nblk = st->nblk;
         G.pbits = st->pbits;
         G.block_rows = PL_BLOCK_ROWS;
@@ -1162,8 +1171,89 @@ __global__ __launch_bounds__(PLH_T) void k_plane_hash_aggregate(const Plan P, co
             if (any) fold(-1, cr, 0u, ck, cv);
         }
     };
+    // VAR 2 (round 6): the key table as BUCKETS of four keys -- one lookup reads a whole bucket (two ds_read_b128) and compares its four keys at once; a full
+    // bucket sends the key to the next one.  At load 0.53 a bucket of four overflows with probability ~6 %, so a batch settles in 2-3 rounds where slot-by-slot
+    // linear probing needs the LONGEST of 64 lanes' chains (5-6 rounds of read -> wait -> compare -> branch per record: the 3.5 ms the probing costs on top of
+    // the loads, tools/k9_ablate.py).  Same arrays, same slot numbering (slot = bucket * 4 + place): first rows / accumulators / the final walk do not change.
+    auto bucket_find = [&](const u64 key, unsigned b, pl_v2 q0, pl_v2 q1) __attribute__((always_inline)) {
+        if ((i64)key == RFX_NULL_I64_D) return -1;
+        const unsigned nb = C >> 2;
+        unsigned steps = 0;
+        bool fresh = true; // q0 / q1 hold bucket b as it stood a moment ago
+        for (;;) {
+            if (!fresh) {
+                q0 = *(const pl_v2 *)&lkey[(size_t)b * 4];
+                q1 = *(const pl_v2 *)&lkey[(size_t)b * 4 + 2];
+            }
+            fresh = false;
+            const int hit = q0.x == key ? 0 : q0.y == key ? 1 : q1.x == key ? 2 : q1.y == key ? 3 : -1;
+            if (hit >= 0) return (int)(b * 4u) + hit;
+            const int e = (i64)q0.x == RFX_NULL_I64_D ? 0 : (i64)q0.y == RFX_NULL_I64_D ? 1 : (i64)q1.x == RFX_NULL_I64_D ? 2 : (i64)q1.y == RFX_NULL_I64_D ? 3 : -1;
+            if (e >= 0) { // room here: claim the first empty place (places only ever fill up; a lost race re-reads the SAME bucket: at most four times)
+                const u64 old = atomicCAS((unsigned long long *)&lkey[(size_t)b * 4 + e], (unsigned long long)RFX_NULL_I64_D, (unsigned long long)key);
+                if ((i64)old == RFX_NULL_I64_D || old == key) return (int)(b * 4u) + e;
+                continue;
+            }
+            if (++steps >= nb) break; // every bucket is full: no room in this table
+            b = (b + 1 == nb) ? 0 : b + 1;
+        }
+        return -1;
+    };
+    auto consume2 = [&](const Batch &B) __attribute__((always_inline)) {
+        const i64 rbase = (i64)B.b * X.block_rows;
+        unsigned mm[4], sb[4], lrow[4];
+        u64 key[4], val[4];
+        pl_v2 q0[4], q1[4];
+        bool on[4], cold[4];
+        int idx[4];
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const unsigned i = B.i0 + ((unsigned)k * 64u + (unsigned)lane) * 2u;
+            mm[2 * k] = B.m[k].x, mm[2 * k + 1] = B.m[k].y;
+            key[2 * k] = B.key[k].x, key[2 * k + 1] = B.key[k].y;
+            val[2 * k] = B.val[k].x, val[2 * k + 1] = B.val[k].y;
+            on[2 * k] = i < B.n && mine_of(mm[2 * k]);
+            on[2 * k + 1] = i + 1 < B.n && mine_of(mm[2 * k + 1]);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) { // the four first buckets back to back: eight 16-byte LDS reads in flight
+            sb[j] = start_of(mm[j]) >> 2;
+            q0[j] = *(const pl_v2 *)&lkey[(size_t)sb[j] * 4];
+            q1[j] = *(const pl_v2 *)&lkey[(size_t)sb[j] * 4 + 2];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) idx[j] = on[j] ? bucket_find(key[j], sb[j], q0[j], q1[j]) : -1;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            lrow[j] = (unsigned)(rbase + (i64)(mm[j] >> PL_SLOT_BITS));
+            cold[j] = on[j] && idx[j] < 0;
+            if (!on[j] || idx[j] < 0) continue;
+            __hip_atomic_fetch_min(&lfirst[idx[j]], lrow[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if constexpr (FAST) unsafeAtomicAdd((double *)&larr[idx[j]], rfx_as_f64(val[j]));
+            else {
+#pragma unroll
+                for (int a = 0; a < RFX_MAX_AGGS; a++) {
+                    if (kind[a] < 0) continue;
+                    group_apply(&larr[(size_t)arr_of[a] * C + idx[j]], &larr[(size_t)(arr_of[a] + 1) * C + idx[j]], kind[a], f64[a], apl[a] == 1 ? val[j] : 0ULL, skip[a]);
+                }
+            }
+        }
+        while (__builtin_expect(__builtin_amdgcn_ballot_w64(cold[0] | cold[1] | cold[2] | cold[3]) != 0, 0)) {
+            const bool any = cold[0] | cold[1] | cold[2] | cold[3];
+            const int pick = cold[0] ? 0 : cold[1] ? 1 : cold[2] ? 2 : 3;
+            const u64 ck = pick == 0 ? key[0] : pick == 1 ? key[1] : pick == 2 ? key[2] : key[3];
+            const u64 cv = pick == 0 ? val[0] : pick == 1 ? val[1] : pick == 2 ? val[2] : val[3];
+            const unsigned cr = pick == 0 ? lrow[0] : pick == 1 ? lrow[1] : pick == 2 ? lrow[2] : lrow[3];
+            cold[0] = cold[0] && pick != 0;
+            cold[1] = cold[1] && pick != 1;
+            cold[2] = cold[2] && pick != 2;
+            cold[3] = cold[3] && pick != 3;
+            if (any) fold(-1, cr, 0u, ck, cv);
+        }
+    };
     auto consume_v = [&](const Batch &B) __attribute__((always_inline)) {
         if constexpr (VAR == 1) consume1(B);
+        else if constexpr (VAR == 2) consume2(B);
         else consume(B);
     };
     const int q = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1347,6 +1437,8 @@ int rfx_plane_hash_accumulate(rfx_ctx *c, const Plan &P, int key_idx, const Hash
         RFX_HIP_CHECK(hipFuncSetAttribute((const void *)k_plane_hash_aggregate<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         RFX_HIP_CHECK(hipFuncSetAttribute((const void *)k_plane_hash_aggregate<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         RFX_HIP_CHECK(hipFuncSetAttribute((const void *)k_plane_hash_aggregate<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        RFX_HIP_CHECK(hipFuncSetAttribute((const void *)k_plane_hash_aggregate<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        RFX_HIP_CHECK(hipFuncSetAttribute((const void *)k_plane_hash_aggregate<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         __atomic_fetch_or(&attr_set, 1ull << (c->device & 63), __ATOMIC_RELAXED);
     }
     c->ext_i[3 + RFX_STAT_PLANE_AGGREGATE]++;
@@ -1356,6 +1448,9 @@ int rfx_plane_hash_accumulate(rfx_ctx *c, const Plan &P, int key_idx, const Hash
     if (var == 0) {
         if (fast) hipLaunchKernelGGL((k_plane_hash_aggregate<true, 0>), dim3(parts << hbits), dim3(PLH_T), lds, c->stream, Pc, X);
         else hipLaunchKernelGGL((k_plane_hash_aggregate<false, 0>), dim3(parts << hbits), dim3(PLH_T), lds, c->stream, Pc, X);
+    } else if (var == 2) {
+        if (fast) hipLaunchKernelGGL((k_plane_hash_aggregate<true, 2>), dim3(parts << hbits), dim3(PLH_T), lds, c->stream, Pc, X);
+        else hipLaunchKernelGGL((k_plane_hash_aggregate<false, 2>), dim3(parts << hbits), dim3(PLH_T), lds, c->stream, Pc, X);
     } else {
         if (fast) hipLaunchKernelGGL((k_plane_hash_aggregate<true, 1>), dim3(parts << hbits), dim3(PLH_T), lds, c->stream, Pc, X);
         else hipLaunchKernelGGL((k_plane_hash_aggregate<false, 1>), dim3(parts << hbits), dim3(PLH_T), lds, c->stream, Pc, X);

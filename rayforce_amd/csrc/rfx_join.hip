@@ -67,8 +67,8 @@ __global__ __launch_bounds__(RFX_BLOCK) void k_tuple_check(const TupleKeys K, in
     unsigned bad = 0;
     for (i64 i = blockIdx.x * (i64)RFX_BLOCK + threadIdx.x; i < n; i += (i64)gridDim.x * RFX_BLOCK) {
         const i64 f = ids[i];
-        if (f == i) continue;
-        if ((u64)f >= (u64)n) { // (a row whose own hash is not in the table: cannot happen after the group-by over the same rows)
+        if (f == i || f == RFX_NULL_I64_D) continue; // (null: a row the query's filter did not select -- its hash may not be in the table at all)
+        if ((u64)f >= (u64)n) { // (cannot happen: first rows are rows of this table)
             bad++;
             continue;
         }

@@ -329,6 +329,9 @@ for rep in range(2):
                 assert got[c].dtype == o[c].dtype and np.array_equal(got[c].view(np.int64), o[c].view(np.int64)), (keys, fn, c)
             ops.rfx_host_drop(out)
         ops.rfx_host_drop(ks_)
+st1 = H.to_numpy(ops.rfx_stats(0))
+assert st1[2] - st0[2] == 8 and st1[3] == st0[3], (st0, st1)  # eight joins on the device, none handed back
+assert st1[4] - st0[4] <= 4 + 4, (st0, st1)                   # uploads: four left columns (row ranges) + four right columns (whole), once
 # ... and `update ... where / by` (round 6): every shard writes its rows of the new column (selection as a 0 / 1 column per shard, values element-wise per shard or --
 # under by: -- every row's group aggregate looked up in the value table of the merged groups); the families of tests/test_ops_gpu.py::UPDATES against the oracle
 from test_ops_gpu import UPDATES, check
@@ -351,9 +354,6 @@ for q, why in (({"a": 1.5, "where": ("<", "a", 10)}, "value type differs"), ({"t
     for o in (r, d, t2):
         ops.rfx_host_drop(o)
 ops.rfx_host_drop(ut)
-st1 = H.to_numpy(ops.rfx_stats(0))
-assert st1[2] - st0[2] == 8 and st1[3] == st0[3], (st0, st1)  # eight joins on the device, none handed back
-assert st1[4] - st0[4] <= 4 + 4, (st0, st1)                   # uploads: four left columns (row ranges) + four right columns (whole), once
 for o in (lt_, rt_):
     ops.rfx_host_drop(o)
 print("DOOR-OK")
