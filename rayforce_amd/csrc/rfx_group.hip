@@ -129,9 +129,7 @@ __device__ __forceinline__ void group_dense_body(const Plan &P, const GroupArgs 
             if (LDS) {
                 const unsigned lrow = (unsigned)(base + (i64)(e >> 1) * JSTRIDE + (e & 1));
                 const u64 ls = TINY ? ((slot << rs) + rl) : slot;
-                // (round 6: one no-return ds_min_u32 per selected row; rounds 1-5 read the word first and compared -- a dependent LDS round trip and a
-                //  divergent branch per row, see k_plane_hash_aggregate)
-                __hip_atomic_fetch_min(&lfirst[ls], lrow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (lrow < lfirst[ls]) atomicMin(&lfirst[ls], lrow); // (round 6 A/B: one no-return ds_min_u32 instead changes nothing -- q2 3.78 ms either way)
             } else {
                 // plain pre-check: a stale (larger) value only costs a redundant atomic, never a wrong minimum
                 if (row < G.first[slot]) atomicMin((unsigned long long *)&G.first[slot], (unsigned long long)row);

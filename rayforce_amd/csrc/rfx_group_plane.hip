@@ -437,8 +437,8 @@ __global__ __launch_bounds__(THREADS) void k_plane_aggregate(const Plan P, const
         const unsigned slot = ((mm & mask) + shift) & mask;
         if ((i64)slot >= local) return; // a key outside the scope the tables were sized for: not ours
         const unsigned row = (unsigned)(rbase + (i64)(mm >> PL_SLOT_BITS));
-        // (round 6: one no-return ds_min_u32 per record; reading the word first cost a dependent LDS round trip and a divergent branch per record -- what took
-        //  the hashed aggregate from 8.8 to 3.6 ms, profiles/r06_k9_ab.txt)
+        // (round 6 A/B, profiles/r06_first_read.txt: one no-return ds_min_u32 per record instead of read + compare + rare atomic changes nothing here --
+        //  C3 7.42 against 7.28 ms, c3w 4.38 against 4.37 -- the read-first form stays)
         if (A.first_read) {
             if (row < first[slot]) atomicMin(&first[slot], row);
         } else __hip_atomic_fetch_min(&first[slot], row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -856,8 +856,8 @@ int rfx_plane_accumulate(rfx_ctx *c, const Plan &P, int key_idx, const rfx_group
         G.range = t->range;
         G.local = local;
         {
-            static const char *fr = getenv("RFX_PL_FIRST_READ");
-            G.first_read = fr ? atoi(fr) : 0;
+            static const char *fr = getenv("RFX_PL_FIRST_READ"); // (0: one no-return ds_min_u32 per record instead -- measured: C3 7.42 against 7.28 ms, c3w 4.38 / 4.37: no gain here)
+            G.first_read = fr ? atoi(fr) : 1;
         }
         G.nblk = st->nblk;
         G.pbits = st->pbits;
@@ -956,12 +956,11 @@ struct PlaneHashArgs {
 #define PLH_PROBES 512
 
 // FAST: exactly one aggregate, a plain f64 sum over the value plane (the K9 shape): no per-record dispatch on the aggregate kinds
-// VAR 0: a lane's four records settle their slots one after the other, the spill path inline.  VAR 1: the same with the spill path as ONE cold loop behind
-// the batch.  Both (round 6) update a slot's first row with ONE no-return ds_min_u32 per record instead of reading the word first and comparing: the read was
-// a second dependent LDS round trip and a divergent branch per record -- the aggregate fell from 8.8 to 3.6 ms at 1e9 rows / 1e6 keys (RFX_PLH_DBG=5 is the
-// read-first form; profiles/r06_k9_ab.txt).  Also measured and withdrawn: LOCKSTEP probing (every round reads the four records' candidate slots back to
-// back and settles them together: max-over-records rounds instead of their sum) -- 23.5 ms per query against 17.4: the unconditional reads of settled
-// records and the per-round ballots cost more than the shorter dependency chain saves (git 37867ef has the kernel).
+// VAR 0: a lane's four records settle their slots one after the other (slot-by-slot linear probing), the spill path inline.  VAR 1: the same with the spill
+// path as ONE cold loop behind the batch (the kernel's ISA: 24 800 -> ~10 000 lines).  VAR 2: the key table as buckets of four keys (below).  The first-row
+// update is one no-return ds_min_u32 per record (RFX_PLH_DBG=5: round 5's read-first form).  Measured and withdrawn: LOCKSTEP probing (every round reads the
+// four records' candidate slots back to back and settles them together: max-over-records rounds instead of their sum) -- 23.5 ms per query against 17.4: the
+// unconditional reads of settled records and the per-round ballots cost more than the shorter dependency chain saves (git 37867ef has the kernel).
 template <bool FAST, int VAR>
 __global__ __launch_bounds__(PLH_T) void k_plane_hash_aggregate(const Plan P, const PlaneHashArgs X) {
     extern __shared__ __attribute__((aligned(16))) u64 plh_smem[];
@@ -1095,7 +1094,7 @@ __global__ __launch_bounds__(PLH_T) void k_plane_hash_aggregate(const Plan P, co
             on[2 * k] = i < B.n && mine_of(mm[2 * k]);
             on[2 * k + 1] = i + 1 < B.n && mine_of(mm[2 * k + 1]);
         }
-        if (X.dbg >= 2) { // ablations (WRONG answers): 3 = the loads only, 2 = + one f64 add at the start slot, no probing
+        if (X.dbg == 2 || X.dbg == 3) { // ablations (WRONG answers): 3 = the loads only, 2 = + one f64 add at the start slot, no probing
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 asm volatile("" ::"v"(key[j]), "v"(val[j]), "v"(mm[j]));

@@ -17,6 +17,7 @@
 #include <dirent.h>
 #include <sys/stat.h>
 #include <unistd.h>
+#include <functional>
 #include <map>
 #include <mutex>
 #include <string>
@@ -254,6 +255,16 @@ static hipFunction_t plan_kernel_locked(const std::string &sig, const std::strin
     if (!seen) seen = new std::map<std::string, int>();
     const int times = ++(*seen)[sig];
     const std::string path = cache_path(src);
+    if (times == 1) { // development: RFX_RTC_DUMP=<dir> keeps every plan's generated text (compile it offline with hipcc -S to read its ISA / registers)
+        if (const char *dump = getenv("RFX_RTC_DUMP")) {
+            char fn[512];
+            snprintf(fn, sizeof(fn), "%s/%s_%zx.hip", dump, name, std::hash<std::string>()(src));
+            if (FILE *f = fopen(fn, "w")) {
+                fwrite(src.data(), 1, src.size(), f);
+                fclose(f);
+            }
+        }
+    }
     std::string code;
     if (times == 1 && read_code(path, code)) { // compiled by an earlier process (or by the build step): milliseconds
         hipFunction_t fn = load(code, name);

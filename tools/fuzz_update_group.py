@@ -90,7 +90,10 @@ for seed in range(lo, hi):
             items = H.list_items(r)
             itype = C.c_int64.from_address(items[0] + 8).value
             assert C.c_int64.from_address(items[1] + 8).value == groups, (what, "groups")
-            assert np.array_equal(H.to_numpy(items[6]), firsts), (what, "firsts")
+            if dense:
+                assert np.array_equal(H.to_numpy(items[6]), firsts), (what, "firsts")
+            else:  # sparse keys (round 6): the IDS flavour of index_group_i64_unscoped carries no first rows (core/index.c:1959-1977)
+                assert itype == 0 and H.header(items[6]).type == 126, (what, "sparse index: no first rows")
             if itype == 0:
                 assert np.array_equal(H.to_numpy(items[2]), gids), (what, "ids")
             for cname in (ic, fc):
