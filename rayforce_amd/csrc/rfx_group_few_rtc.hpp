@@ -117,10 +117,11 @@ extern "C" __global__ __launch_bounds__(RFX_BLOCK) void k_group_few(const Plan P
     const i64 nrows = P0.nrows;
     const i64 nfull = nrows / TILE;
     const i64 ntiles = nfull + ((nfull * TILE < nrows) ? 1 : 0);
-    for (i64 t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    // Round 6: the NEXT tile's loads are issued before this tile is folded (FEW_PREFETCH, default on): with 48 register accumulators the kernel runs at two
+    // waves per SIMD (210 VGPRs), i.e. 8 waves x 64 lanes x NC x 16 bytes = 57 KB in flight per CU -- 14.7 MB on the part, at the edge of what 6+ TB/s needs at
+    // ~2 us of loaded latency (the Q1 shape read 4.9 TB/s); the second tile in flight costs NC x E x 2 registers and doubles that.
+    auto load_tile = [&](const i64 t, u64 (&v)[NC][E], unsigned &valid) __attribute__((always_inline)) {
         const i64 base = t * TILE + tid * 2;
-        u64 v[NC][E];
-        unsigned valid;
         if (t < nfull) {
             valid = (1u << E) - 1u;
 #pragma unroll
@@ -144,6 +145,26 @@ extern "C" __global__ __launch_bounds__(RFX_BLOCK) void k_group_few(const Plan P
                 for (int c = 0; c < NC; c++) v[c][e] = in ? P0.cols[c][row] : 0ULL;
             }
         }
+    };
+#ifndef FEW_PREFETCH
+#define FEW_PREFETCH 1
+#endif
+    u64 vn[NC][E];
+    unsigned validn = 0;
+    if (FEW_PREFETCH && (i64)blockIdx.x < ntiles) load_tile(blockIdx.x, vn, validn);
+    for (i64 t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const i64 base = t * TILE + tid * 2;
+        u64 v[NC][E];
+        unsigned valid;
+        if (FEW_PREFETCH) {
+#pragma unroll
+            for (int c = 0; c < NC; c++) {
+#pragma unroll
+                for (int e = 0; e < E; e++) v[c][e] = vn[c][e];
+            }
+            valid = validn;
+            if (t + (i64)gridDim.x < ntiles) load_tile(t + gridDim.x, vn, validn);
+        } else load_tile(t, v, valid);
         const unsigned m = eval_preds<NC, E, FEW_NPT>(S, v, valid);
         u64 key[E]; // slot in the dense table
         if (FEW_NKEYS <= 1) {

@@ -1312,6 +1312,12 @@ __global__ __launch_bounds__(PLH_T) void k_plane_hash_aggregate(const Plan P, co
     }
 }
 
+// which probing form k_plane_hash_aggregate runs: 2 = four-key buckets (default since round 6: 16.3 -> 13.2 ms per 1e9 rows / 1e6 keys, profiles/r06_k9_ab.txt),
+// 0 = slot-by-slot linear probing (rounds 3-5), 1 = 0 with the spill path as a cold loop.  RFX_PLH_VAR for A/B.
+static int plh_var() {
+    static const char *var_env = getenv("RFX_PLH_VAR");
+    return var_env ? atoi(var_env) : 2;
+}
 // Sparse-key group-by through the planes.  est = sampled distinct-key estimate.  RFX_ESTATE: not applicable / gave up BEFORE anything
 // touched the caller's tables (the caller takes round 1's kernels); otherwise the tables hold the answer unless *d_overflow is set.
 int rfx_plane_hash_accumulate(rfx_ctx *c, const Plan &P, int key_idx, const HashArgs &H, double est, int *d_overflow) {
@@ -1330,9 +1336,13 @@ int rfx_plane_hash_accumulate(rfx_ctx *c, const Plan &P, int key_idx, const Hash
     // 128 partitions (16-record store groups: 128-byte value lines), shared by 2 / 4 workgroups when a partition's keys overflow one LDS
     // table; 256 partitions (8-record groups: 64-byte lines) only beyond that.  Measured at 1e6 keys: 128 x 2 workgroups 8.1 + 12.6 ms,
     // 256 x 1 13.3 + 8.2 ms -- the short lines cost the scatter more than the single stream saves the aggregate.
+    // headroom of the LDS tables over the estimated keys of a partition: slot-by-slot linear probing wants load <= 0.6 (chains grow fast beyond), four-key
+    // buckets hold up to ~0.8 (a bucket overflows into the next one): 1.3 lets sum + count (28-byte entries, 5 248 per table) keep ONE workgroup per
+    // partition at 1e6 keys where 1.6 split every partition between two workgroups that each streamed all of its records (30 ms)
+    const double HEAD = plh_var() == 2 ? 1.3 : 1.6;
     int pbits = 7, hbits = 0, parts = 128;
     static const char *force = getenv("RFX_PLANE_HASH_PARTS"); // (A/B: 192 = the one-workgroup-per-partition form)
-    if (force && atoi(force) == 192 && est * 1.6 / 128.0 > (double)lcap && est * 1.2 / 192.0 <= (double)lcap) {
+    if (force && atoi(force) == 192 && est * HEAD / 128.0 > (double)lcap && est * 1.2 / 192.0 <= (double)lcap) {
         // round 4 experiment, OPT-IN (RFX_PLANE_HASH_PARTS=192): 192 partitions, ONE workgroup each -- every record streamed once (traffic
         // 80 -> 58 GB).  Measured at 1e9 rows / 1e6 keys: scatter 7.8 ms (as with 128 partitions: same 16-record lines), aggregate 27 ms against
         // 12.6 -- the aggregate is bound by LDS probing per record (192 CUs at load 0.70 instead of 256 at 0.53), not by the bytes it streams:
@@ -1340,13 +1350,13 @@ int rfx_plane_hash_accumulate(rfx_ctx *c, const Plan &P, int key_idx, const Hash
         pbits = 8;
         parts = 192;
     } else {
-        if (est * 1.6 / (128.0 * 4.0) > (double)lcap) pbits = 8;
+        if (est * HEAD / (128.0 * 4.0) > (double)lcap) pbits = 8;
         // round 5: keys that overflow ONE LDS table per partition at 128 partitions take 256 partitions with ONE workgroup each -- every record
         // streamed once (the two workgroups per partition of round 3 each streamed all of it: 42.8 of the query's 80 GB) -- now that the
         // 256-partition scatter stores whole 128-byte lines (KVI).  RFX_PLANE_HASH_PARTS=128 keeps the two-workgroup form (A/B).
-        if (est * 1.6 / 128.0 > (double)lcap && est * 1.6 / 256.0 <= (double)lcap && !(force && atoi(force) == 128)) pbits = 8;
-        while (hbits < 2 && est * 1.6 / (double)((1 << pbits) << hbits) > (double)lcap) hbits++; // (every workgroup of a partition streams ALL its records: 4 is where that stops paying)
-        if (est * 1.6 / (double)((1 << pbits) << hbits) > (double)lcap) return RFX_ESTATE; // more keys than 512 LDS tables hold: round 1's kernels / the device-wide table
+        if (est * HEAD / 128.0 > (double)lcap && est * HEAD / 256.0 <= (double)lcap && !(force && atoi(force) == 128)) pbits = 8;
+        while (hbits < 2 && est * HEAD / (double)((1 << pbits) << hbits) > (double)lcap) hbits++; // (every workgroup of a partition streams ALL its records: 4 is where that stops paying)
+        if (est * HEAD / (double)((1 << pbits) << hbits) > (double)lcap) return RFX_ESTATE; // more keys than 512 LDS tables hold: round 1's kernels / the device-wide table
         parts = 1 << pbits;
     }
     const i64 nblk64 = (nrows + PL_BLOCK_ROWS - 1) / PL_BLOCK_ROWS;
@@ -1442,8 +1452,7 @@ int rfx_plane_hash_accumulate(rfx_ctx *c, const Plan &P, int key_idx, const Hash
     }
     c->ext_i[3 + RFX_STAT_PLANE_AGGREGATE]++;
     const bool fast = P.nagg == 1 && P.aggs[0].kind == RFX_AGG_SUM && P.aggs[0].f64 && !P.aggs[0].skipnull && X.agg_pl[0] == 1;
-    static const char *var_env = getenv("RFX_PLH_VAR"); // (A/B: 1 = the spill path as a cold loop behind the batch)
-    const int var = var_env ? atoi(var_env) : 0;
+    const int var = plh_var();
     if (var == 0) {
         if (fast) hipLaunchKernelGGL((k_plane_hash_aggregate<true, 0>), dim3(parts << hbits), dim3(PLH_T), lds, c->stream, Pc, X);
         else hipLaunchKernelGGL((k_plane_hash_aggregate<false, 0>), dim3(parts << hbits), dim3(PLH_T), lds, c->stream, Pc, X);

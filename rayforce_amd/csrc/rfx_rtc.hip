@@ -333,8 +333,9 @@ int rfx_rtc_group_few(rfx_ctx *c, const Plan &P, const GroupArgs &G, int grid) {
     int u = P.ncols <= 4 ? 2 : 1;
     if (getenv("RFX_FEW_U")) u = atoi(getenv("RFX_FEW_U")) >= 2 ? 2 : 1; // development: rows per lane and tile
     char head[256];
-    snprintf(head, sizeof(head), "#define FEW_NC %d\n#define FEW_NA %d\n#define FEW_NG %d\n#define FEW_NPT %d\n#define FEW_U %d\n#define FEW_FMA %d\n", P.ncols, P.nagg, (int)G.range, npt, u,
-             getenv("RFX_FEW_NO_FMA") ? atoi(getenv("RFX_FEW_NO_FMA")) : 1); // development: 0 = selects instead of the masked fma
+    snprintf(head, sizeof(head), "#define FEW_NC %d\n#define FEW_NA %d\n#define FEW_NG %d\n#define FEW_NPT %d\n#define FEW_U %d\n#define FEW_FMA %d\n#define FEW_PREFETCH %d\n", P.ncols, P.nagg, (int)G.range, npt, u,
+             getenv("RFX_FEW_NO_FMA") ? atoi(getenv("RFX_FEW_NO_FMA")) : 1, // development: 0 = selects instead of the masked fma
+             getenv("RFX_FEW_PREFETCH") ? atoi(getenv("RFX_FEW_PREFETCH")) : 1); // development: 0 = no next-tile prefetch (rounds 2-5)
     std::string cond;
     plan_text(P, &G, cond);
     const std::string sig = std::string(head) + cond;

@@ -377,7 +377,7 @@ def test_writes_of_the_unpatched_reference_are_never_served_stale(built, shards,
         None,
         "(update {v: (+ v 1.0) from: 't})",                       # a whole new column (binop over the borrowed column: rc >= 2 -> fresh vector)
         "(update {v: 100.5 from: 't where: (== k 7)})",            # the column is rc == 1 in the table now: WITHOUT the cache's reference this writes in place
-        "(update {a: (+ a 1000) from: 't where: (< a 1000)})",     # ... an i64 column, rows that change which rows the filter selects
+        "(update {a: (+ a 900000) from: 't where: (< a 100000)})",  # ... an i64 column: a tenth of the rows leave the query's selection
         "(update {v: (* v 0.5) k: 3 from: 't where: (> v 50.0)})",  # two columns at once, the key column among them
         "(set t (update {v: (- v 1.0) from: t}))",                 # the value form: a new table
     ]

@@ -1142,3 +1142,22 @@ def test_k1_plan_kernels_match_the_prebuilt_kernels(eng):
                 assert (math.isnan(x) and math.isnan(y)) or abs(x - y) <= 1e-9 * 2.1 * (n if fn == "sum" else 1), (fn, col, x, y)  # 1e-9 of sum |x_i| <= 2.1 n (avg: per row): summation order only
             else:
                 assert (x == y) or (isinstance(x, float) and math.isnan(x) and math.isnan(y)), (fn, col, x, y)
+
+
+@pytest.mark.parametrize("knob", ["RFX_EMIT_BY_ROWS=2", "RFX_EMIT_BY_ROWS=0", "RFX_PLH_VAR=0", "RFX_PLH_VAR=1"])
+def test_path_variants_in_a_process_of_their_own(built, knob):
+    """Path choices that are read once per process: the hashed group-by's result emitted BY ROWS wherever the probe exists (RFX_EMIT_BY_ROWS=2: the
+    route 1e8-group row-hash queries take, forced at test sizes) / by ranking the slots only (=0); the sparse-key aggregate's slot-by-slot probing forms
+    (RFX_PLH_VAR=0 / 1; the default is the four-key buckets).  The row-hash, key-tuple, join and sparse-key tests of this file and the golden sets must
+    answer the same under each."""
+    import subprocess, sys
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    name, val = knob.split("=")
+    env = dict(os.environ, **{name: val})
+    here = os.path.dirname(os.path.abspath(__file__))
+    sel = "row_hash or key_tuples or several_keys or join" if name == "RFX_EMIT_BY_ROWS" else "sparse or hash"
+    p = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_parity.py"), os.path.join(here, "test_gpu_golden.py"), "-q", "-m", "gpu", "-x", "-p", "no:cacheprovider",
+                        "-k", f"({sel}) and not variants_in_a_process"], env=env, capture_output=True, text=True, timeout=900, cwd=os.path.dirname(here))
+    assert p.returncode == 0 and " passed" in p.stdout, p.stdout[-2500:] + p.stderr[-1500:]
