@@ -443,8 +443,9 @@ int rfx_hip_hash_emit_sharded(rfx_ctx_t *ctx, const rfx_agg_t *aggs, const rfx_h
  * rfx_hip_join_probe_hash_slots over the group-by's own table), ascending = first-occurrence order.  _begin counts them (syncs); _emit writes the first rows
  * (d_first_ids, ngroups cells), the keys and every aggregate's column from the slots of those rows -- no ranking of the slots, no permutation. */
 int rfx_hip_hash_rows_begin(rfx_ctx_t *ctx, const int64_t *d_probe_first, int64_t nrows, int64_t *ngroups);
-int rfx_hip_hash_rows_emit(rfx_ctx_t *ctx, const rfx_agg_t *aggs, const rfx_hash_tables_t *t, const int64_t *d_row_slots, int64_t row0, int64_t local_rows,
-                           int64_t ngroups, int64_t *d_keys, int64_t *d_first_ids, void *const *d_results);
+/* (d_row_keys: the grouped-on column itself, or NULL -- a group's key is then read from it at the group's first row instead of from the table) */
+int rfx_hip_hash_rows_emit(rfx_ctx_t *ctx, const rfx_agg_t *aggs, const rfx_hash_tables_t *t, const int64_t *d_row_slots, const int64_t *d_row_keys, int64_t row0,
+                           int64_t local_rows, int64_t ngroups, int64_t *d_keys, int64_t *d_first_ids, void *const *d_results);
 int rfx_hip_hash_rank_emit(rfx_ctx_t *ctx, const rfx_agg_t *aggs, const rfx_hash_tables_t *t, int64_t total_rows, int64_t row0, int64_t local_rows,
                            int nsl, int si, int64_t out_cap, int64_t *d_keys, int64_t *d_first_ids, void *const *d_results, int64_t *ngroups);
 

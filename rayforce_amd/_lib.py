@@ -254,7 +254,7 @@ PROTOTYPES = {
     "rfx_hip_join_probe_hash_slots": (C.c_int, [_ctx, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "rfx_hip_tuple_check": (C.c_int, [_ctx, _P(C.c_void_p), C.c_int, C.c_void_p, C.c_int64, _P(C.c_int64)]),
     "rfx_hip_hash_rows_begin": (C.c_int, [_ctx, C.c_void_p, C.c_int64, _P(C.c_int64)]),
-    "rfx_hip_hash_rows_emit": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, _P(C.c_void_p)]),
+    "rfx_hip_hash_rows_emit": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, _P(C.c_void_p)]),
     "rfx_hip_gather_or": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_uint64, C.c_void_p]),
     "rfx_hip_row_hash": (C.c_int, [_ctx, C.POINTER(C.c_void_p), C.c_int, C.c_int64, C.c_int, C.c_void_p]),
     "rfx_hip_replace_null_i64": (C.c_int, [_ctx, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),

@@ -171,7 +171,7 @@ static int ph_rank_emit(void *arg, int s) {
         if ((rc = rfx_hip_malloc(c, &h->dout, (size_t)(G->na + 1) * (size_t)gn * 8)) != RFX_OK) return rc;
         if ((rc = rfx_hip_malloc(c, &h->dfirst, (size_t)gn * 8)) != RFX_OK) return rc;
         for (int a = 0; a < G->na; a++) ptrs[a] = (int64_t *)h->dout + (size_t)(a + 1) * (size_t)gn;
-        if ((rc = rfx_hip_hash_rows_emit(c, h->aggs, &h->ht, h->probe_slots, r0, nloc, gn, (int64_t *)h->dout, (int64_t *)h->dfirst, ptrs)) != RFX_OK) return rc;
+        if ((rc = rfx_hip_hash_rows_emit(c, h->aggs, &h->ht, h->probe_slots, (const int64_t *)h->key, r0, nloc, gn, (int64_t *)h->dout, (int64_t *)h->dfirst, ptrs)) != RFX_OK) return rc;
     } else if (!x->two_step_rank && slots <= RFX_RANK_EMIT_MAX && one_launch_fits) {
         /* rank -> emit with no host round trip between them: the outputs are sized before the group count is known -- groups <= min(slots, selected
          * rows), a slice its share + 1 -- and the count comes back once everything is enqueued */

@@ -330,11 +330,12 @@ extern "C" int rfx_hip_hash_emit_sharded(rfx_ctx_t *c, const rfx_agg_t *aggs, co
 __global__ __launch_bounds__(RFX_BLOCK) void k_rep_mask(const i64 *__restrict__ probe, i64 n, signed char *__restrict__ mask) {
     for (i64 i = blockIdx.x * (i64)RFX_BLOCK + threadIdx.x; i < n; i += (i64)gridDim.x * RFX_BLOCK) mask[i] = probe[i] == i;
 }
-__global__ __launch_bounds__(RFX_BLOCK) void k_emit_rows(const EmitArgs A, const i64 *__restrict__ row_slot, i64 groups) {
+__global__ __launch_bounds__(RFX_BLOCK) void k_emit_rows(const EmitArgs A, const i64 *__restrict__ row_slot, const i64 *__restrict__ row_keys, i64 groups) {
     for (i64 g = blockIdx.x * (i64)RFX_BLOCK + threadIdx.x; g < groups; g += (i64)gridDim.x * RFX_BLOCK) {
         const i64 f = A.out_first[g]; // (the compaction wrote the representative rows there: the groups' first rows, ascending)
         const i64 i = row_slot[f];
-        if (A.out_keys) A.out_keys[g] = (i64)A.keys[i];
+        // the group's key = its first row's key: read from the grouped-on COLUMN at an ascending row (a stream) where the table's key array would be one more random line
+        if (A.out_keys) A.out_keys[g] = row_keys ? row_keys[f] : (i64)A.keys[i];
         for (int a = 0; a < A.nagg; a++) {
             if (!A.out[a]) continue;
             if (A.kinds[a] == RFX_AGG_FIRST) {
@@ -357,8 +358,8 @@ extern "C" int rfx_hip_hash_rows_begin(rfx_ctx_t *c, const int64_t *d_probe_firs
     rfx_hip_free(c, mask);
     return rc;
 }
-extern "C" int rfx_hip_hash_rows_emit(rfx_ctx_t *c, const rfx_agg_t *aggs, const rfx_hash_tables_t *t, const int64_t *d_row_slots, int64_t row0, int64_t local_rows,
-                                      int64_t ngroups, int64_t *d_keys, int64_t *d_first_ids, void *const *d_results) {
+extern "C" int rfx_hip_hash_rows_emit(rfx_ctx_t *c, const rfx_agg_t *aggs, const rfx_hash_tables_t *t, const int64_t *d_row_slots, const int64_t *d_row_keys, int64_t row0,
+                                      int64_t local_rows, int64_t ngroups, int64_t *d_keys, int64_t *d_first_ids, void *const *d_results) {
     RFX_REQUIRE(c, RFX_EINVAL, "ctx is NULL");
     RFX_REQUIRE(local_rows >= 0 && ngroups >= 0, RFX_EINVAL, "bad argument");
     int rc = check_hash(aggs, t);
@@ -386,7 +387,7 @@ extern "C" int rfx_hip_hash_rows_emit(rfx_ctx_t *c, const rfx_agg_t *aggs, const
         A.col[a] = (const u64 *)aggs[a].d_col;
         A.out[a] = d_results ? (u64 *)d_results[a] : NULL;
     }
-    hipLaunchKernelGGL(k_emit_rows, dim3(rfx_grid(c) * 4), dim3(RFX_BLOCK), 0, c->stream, A, (const i64 *)d_row_slots, (i64)ngroups);
+    hipLaunchKernelGGL(k_emit_rows, dim3(rfx_grid(c) * 4), dim3(RFX_BLOCK), 0, c->stream, A, (const i64 *)d_row_slots, (const i64 *)d_row_keys, (i64)ngroups);
     RFX_HIP_CHECK(hipGetLastError());
     return RFX_OK;
 }
