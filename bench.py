@@ -16,7 +16,9 @@ A "step" = one execution of the query over the HBM-resident synthetic columns of
 collective + result read-back).  The table is rows [0, TOTAL) generated on the device with the counter-based splitmix64 of
 SURVEY 8d; rank r holds the row range [r * TOTAL / N, (r + 1) * TOTAL / N).  --scaling strong (default; SURVEY 8d C4/C5: the
 SAME 1e9 / 2e9 rows split N ways): TOTAL = the workload's BASELINE size; --scaling weak: TOTAL = N x that size.
-`value` = TOTAL / max-over-ranks step time.
+`value` = TOTAL / max-over-ranks step time.  At N = 1 through rfx_select (round 6): `value` and `roofline.frac` are taken on the MEDIAN step (SURVEY 8d defines the
+metric so); `ms_per_step` stays the mean of the timed loop, `value_mean` / `roofline.frac_mean` ride beside, `steps_ms_in_order` lists every timed step, and
+`roofline.dominant_kernel` is the scatter kernel alone by HIP events on its stream.
 
 Workloads (BASELINE.json configs / SURVEY 8d):
   c2   configs[1]  select sum(a) where a < 100000      a: i64[1e9] in [0,1e6)              8 B/row
