@@ -400,8 +400,14 @@ static void res_free(int i) {
 /* entries nobody but the cache refers to any more: the host dropped the vector, no operator call can name it again */
 static void release_unowned(void) {
     for (int i = 0; i < g_nres;) {
-        if (g_res[i].owner && obj_rc(g_res[i].owner) == 1) { res_free(i); g_own_released++; }
-        else i++;
+        obj_p o = g_res[i].owner;
+        if (!o) { i++; continue; }
+        uint32_t mine = 0; /* (one vector may have two copies -- row ranges and a join's whole copy per shard -- each with its own reference) */
+        for (int j = 0; j < g_nres; j++) mine += g_res[j].owner == o;
+        if (obj_rc(o) > mine) { i++; continue; }
+        for (int j = g_nres - 1; j >= 0; j--)
+            if (g_res[j].owner == o) { res_free(j); g_own_released++; }
+        i = 0; /* (the array was compacted: start over -- releases are rare) */
     }
 }
 /* the columns the operator call in flight has named, shard by shard: what the planner translates shard 0's addresses with */
@@ -742,8 +748,8 @@ static int resident_ex(obj_p col, int pin, int whole, const void **dev, void **d
     obj_p keyobj = px ? px->src : col; /* the host object the cells belong to (a parted column: its LIST of partition vectors) */
     for (int i = 0; i < g_nres; i++) {
         if (g_res[i].owner) { /* by ownership: the very object we hold a reference to -- nothing could have written its cells or reused its address */
-            if (g_res[i].owner != keyobj) continue;
-            if (g_res[i].len != col->len || g_res[i].type != ktype) { res_free(i); break; } /* (cannot happen under the host's rule: take it as new) */
+            if (g_res[i].owner != keyobj || g_res[i].type != ktype) continue; /* (another object -- or the same one's OTHER copy: row ranges and a whole copy per shard live side by side) */
+            if (g_res[i].len != col->len) { res_free(i); break; } /* (cannot happen under the host's rule: take it as new) */
             g_own_hits++;
             g_res[i].tick = ++g_tick;
             g_res[i].epoch = g_epoch;

@@ -27,8 +27,9 @@ static obj_p pin_impl(obj_p x, int pin) {
                  * device block and read past the mmapped partition files) */
                 if (col_ctype(pc) && pc->type > 0 && resident(pc, 1, &d) != RFX_OK) bad = 1;
             } else {
-                for (int j = 0; j < g_nres; j++)
-                    if (g_res[j].host == (const void *)c || g_res[j].host == RFX_AS_RAW(c)) { res_free(j); break; }
+                for (int j = 0; j < g_nres;) /* (every copy of it: row ranges and, after a join over shards, the whole copies) */
+                    if (g_res[j].host == (const void *)c || g_res[j].host == RFX_AS_RAW(c)) res_free(j);
+                    else j++;
             }
         }
         parted_view_release();
@@ -41,8 +42,9 @@ static obj_p pin_impl(obj_p x, int pin) {
             const void *d;
             if (resident(c, 1, &d) != RFX_OK) return fail_hip("pin");
         } else {
-            for (int j = 0; j < g_nres; j++)
-                if (g_res[j].host == RFX_AS_RAW(c)) { res_free(j); break; }
+            for (int j = 0; j < g_nres;)
+                if (g_res[j].host == RFX_AS_RAW(c)) res_free(j);
+                else j++;
         }
     }
     return H.clone(x);

@@ -329,9 +329,23 @@ for rep in range(2):
                 assert got[c].dtype == o[c].dtype and np.array_equal(got[c].view(np.int64), o[c].view(np.int64)), (keys, fn, c)
             ops.rfx_host_drop(out)
         ops.rfx_host_drop(ks_)
+# a table joined WITH ITSELF: the same column objects are needed as row ranges (left) and whole on every shard (right) -- two cache entries per vector, both alive
+selfc = {"k": rfo.gen_i64(50_003, 45, 20_000), "v": rfo.gen_f64(50_003, 46)}
+st_ = H.table(selfc)
+for fn, ora in (("rfx_left_join", rfo.left_join), ("rfx_inner_join", rfo.inner_join)):
+    ks_ = H.symbols(["k"])
+    out = getattr(ops, fn)((C.c_void_p * 3)(ks_, st_, st_), 3)
+    assert not H.is_error(out), (fn, H.error_text(out))
+    got, o = H.table_to_numpy(out), ora(["k"], selfc, selfc)
+    assert list(got) == list(o) and all(np.array_equal(got[c].view(np.int64), o[c].view(np.int64)) for c in o), fn
+    ops.rfx_host_drop(out)
+    ops.rfx_host_drop(ks_)
+kcol = H.list_items(H.list_items(st_)[1])[0]
+assert H.header(kcol).rc == 3  # the table's reference + one per cached copy (row ranges, whole)
+ops.rfx_host_drop(st_)
 st1 = H.to_numpy(ops.rfx_stats(0))
-assert st1[2] - st0[2] == 8 and st1[3] == st0[3], (st0, st1)  # eight joins on the device, none handed back
-assert st1[4] - st0[4] <= 4 + 4, (st0, st1)                   # uploads: four left columns (row ranges) + four right columns (whole), once
+assert st1[2] - st0[2] == 10 and st1[3] == st0[3], (st0, st1)  # ten joins on the device, none handed back
+assert st1[4] - st0[4] <= 4 + 4 + 4, (st0, st1)               # uploads: four left columns (row ranges) + four right columns (whole), once; the self-join's two columns twice
 # ... and `update ... where / by` (round 6): every shard writes its rows of the new column (selection as a 0 / 1 column per shard, values element-wise per shard or --
 # under by: -- every row's group aggregate looked up in the value table of the merged groups); the families of tests/test_ops_gpu.py::UPDATES against the oracle
 from test_ops_gpu import UPDATES, check
