@@ -580,6 +580,12 @@ int rfx_hip_update_select(rfx_ctx_t *ctx, void *d_out, const void *d_old, uint64
 int rfx_hip_update_group(rfx_ctx_t *ctx, void *d_col, const int64_t *d_key, const int64_t *d_ids, int64_t m, const rfx_agg_t *agg,
                          const rfx_group_tables_t *t);
 
+/* ---- reproducible grouped f64 sums (opt-in; rfx_ops_set_deterministic): a column scaled by 2^k and rounded to i64 once per cell sums to the same bits in
+ * any order.  rfx_hip_absmax_f64: max |x| over the column and whether a NaN / infinity occurs (syncs); rfx_hip_fix_f64: d_out[i] = llrint(d_in[i] * 2^k),
+ * d_out may be d_in. */
+int rfx_hip_absmax_f64(rfx_ctx_t *ctx, const double *d_in, int64_t n, double *absmax, int *nonfinite);
+int rfx_hip_fix_f64(rfx_ctx_t *ctx, const double *d_in, int64_t n, int k, int64_t *d_out);
+
 /* ---- bucketed group keys: (xbar col width), XBARI64 core/ops.h:192-193 ----
  * d_out[r] = null for a null input, else the largest multiple of `width` (> 0) that is <= d_col[r].  Group on the result
  * (`by: {t: (xbar ts 60000)}`). */

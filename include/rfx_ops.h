@@ -141,6 +141,11 @@ rfx_obj_p rfx_invalidate(rfx_obj_p table_or_column);
  * keyed by (payload address, length, type) -- for a host that writes payloads in place without looking at reference counts (raw views over the
  * standalone host's vectors).  Also RFX_VALIDATE=checksum in the environment.  Switching drops the cached copies. */
 int rfx_ops_set_validation(int mode);
+/* Reproducible grouped f64 sums (opt-in; also RFX_DETERMINISTIC=1): rfx_select runs every (sum x) / (avg x) over f64 under by: as an INTEGER sum over x
+ * scaled by a power of two and rounded once per cell -- the same bits whatever order the rows reach their group in (the reference is bit-stable for a fixed
+ * pool size, core/pool.c:415-424; the default path's f64 atomics are not).  Costs two more passes over the argument; a cell is rounded to a multiple of
+ * 2^(e + b - 62) (2^e > max |x|, 2^b >= rows); a column holding a NaN or an infinity keeps the default path.  DESIGN.md section 4. */
+int rfx_ops_set_deterministic(int on);
 /* unary_f: I64[15] counters since load: {selects on the GPU, selects delegated to the host, joins on the GPU, joins delegated,
  * uploads, cache hits, stale entries refreshed, operator calls, group scopes sampled, sampled scopes retried exactly,
  * materialised B8 mask passes (RFX_STAT_MASK_PASSES: a fused `where:` tree runs none), uses validated by soft-dirty page bits,

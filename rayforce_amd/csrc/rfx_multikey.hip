@@ -285,3 +285,54 @@ extern "C" int rfx_hip_replace_i64(rfx_ctx_t *c, const int64_t *d_col, int64_t n
     RFX_HIP_CHECK(hipGetLastError());
     return RFX_OK;
 }
+
+// ---- reproducible grouped f64 sums (round 6, opt-in: RFX_DETERMINISTIC / rfx_ops_set_deterministic) ----
+// Grouped f64 sums reach their accumulators through LDS / device atomics in whatever order the waves run: the last bits differ from run to run.  Integer
+// addition is associative: a column scaled by a power of two and rounded to i64 ONCE per cell sums to the same bits in any order.  Two small kernels make
+// that column; the planner then runs an ordinary i64 SUM over it (rfx_ops_select.c: det_rewrite).
+//   k_absmax_f64   max |x| over the column as ordered bits (|x| >= 0: the bit pattern of a non-negative double orders like an integer) + a flag for NaN / inf
+//   k_fix_f64      out[i] = llrint(x[i] * 2^k)   (in place allowed)
+__global__ __launch_bounds__(RFX_BLOCK) void k_absmax_f64(const u64 *__restrict__ in, i64 n, unsigned long long *__restrict__ out /* [0] max bits, [1] non-finite seen */) {
+    u64 mx = 0, bad = 0;
+    for (i64 i = blockIdx.x * (i64)RFX_BLOCK + threadIdx.x; i < n; i += (i64)gridDim.x * RFX_BLOCK) {
+        const u64 a = in[i] & 0x7FFFFFFFFFFFFFFFULL;
+        if (a >= 0x7FF0000000000000ULL) bad = 1;
+        else mx = a > mx ? a : mx;
+    }
+    for (int m = 32; m >= 1; m >>= 1) {
+        const u64 o = rfx_shfl_xor_u64(mx, m);
+        mx = o > mx ? o : mx;
+    }
+    if ((threadIdx.x & 63) == 0 && mx) atomicMax(&out[0], (unsigned long long)mx);
+    if (bad) atomicOr(&out[1], 1ULL);
+}
+__global__ __launch_bounds__(RFX_BLOCK) void k_fix_f64(const double *in, i64 n, int k, i64 *out) {
+    for (i64 i = blockIdx.x * (i64)RFX_BLOCK + threadIdx.x; i < n; i += (i64)gridDim.x * RFX_BLOCK) out[i] = (i64)__builtin_llrint(__builtin_ldexp(in[i], k));
+}
+extern "C" int rfx_hip_absmax_f64(rfx_ctx_t *c, const double *d_in, int64_t n, double *absmax, int *nonfinite) {
+    RFX_REQUIRE(c && absmax && nonfinite, RFX_EINVAL, "NULL argument");
+    *absmax = 0.0;
+    *nonfinite = 0;
+    if (n <= 0) return RFX_OK;
+    RFX_REQUIRE(d_in, RFX_EINVAL, "NULL argument");
+    int rc = rfx_ws_reserve(c, 256);
+    if (rc != RFX_OK) return rc;
+    unsigned long long *o = (unsigned long long *)c->d_ws;
+    RFX_HIP_CHECK(hipMemsetAsync(o, 0, 16, c->stream));
+    hipLaunchKernelGGL(k_absmax_f64, dim3(c->num_cus * 8), dim3(RFX_BLOCK), 0, c->stream, (const u64 *)d_in, (i64)n, o);
+    RFX_HIP_CHECK(hipGetLastError());
+    unsigned long long *h = (unsigned long long *)c->h_pin;
+    RFX_HIP_CHECK(hipMemcpyAsync(h, o, 16, hipMemcpyDeviceToHost, c->stream));
+    RFX_HIP_CHECK(hipStreamSynchronize(c->stream));
+    memcpy(absmax, &h[0], 8);
+    *nonfinite = h[1] != 0;
+    return RFX_OK;
+}
+extern "C" int rfx_hip_fix_f64(rfx_ctx_t *c, const double *d_in, int64_t n, int k, int64_t *d_out) {
+    RFX_REQUIRE(c, RFX_EINVAL, "ctx is NULL");
+    if (n <= 0) return RFX_OK;
+    RFX_REQUIRE(d_in && d_out && k > -1100 && k < 1100, RFX_EINVAL, "bad argument");
+    hipLaunchKernelGGL(k_fix_f64, dim3(c->num_cus * 8), dim3(RFX_BLOCK), 0, c->stream, d_in, (i64)n, k, (i64 *)d_out);
+    RFX_HIP_CHECK(hipGetLastError());
+    return RFX_OK;
+}

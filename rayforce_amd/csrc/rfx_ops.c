@@ -18,6 +18,7 @@
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <string.h>
+#include <math.h>
 #include <time.h>
 #include "rfx_abi.h"
 #include "rfx_hip.h"

@@ -31,6 +31,11 @@ typedef struct {
     int64_t names[RFX_MAX_AGGS];
     int outtype[RFX_MAX_AGGS];
     int nagg;
+    /* reproducible grouped f64 sums (det_rewrite): aggregate a runs as an i64 SUM over its argument scaled by 2^det_k[a]; an average also needs the groups'
+     * row counts: ONE hidden COUNT aggregate behind the query's own (index nagg) */
+    unsigned char det_on[RFX_MAX_AGGS], det_avg[RFX_MAX_AGGS];
+    int det_k[RFX_MAX_AGGS];
+    int nhidden;
 } sel_maps_t;
 /* result cells of an aggregate over a widened 4-byte column, back in the column's own width: the i64 null and the i64 identities of an
  * all-null group (core/aggr.c:1246) become the 4-byte ones */
@@ -45,6 +50,9 @@ static void sel_narrow_i32(obj_p col, const int64_t *cells, int64_t n, int kind)
 static int sel_mappings(obj_p tab, obj_p dkeys, obj_p dvals, int grouped, sel_maps_t *M, const char **why) {
     const int64_t s_from = H.intern("from", 4), s_where = H.intern("where", 5), s_by = H.intern("by", 2), s_take = H.intern("take", 4);
     M->nagg = 0;
+    M->nhidden = 0;
+    memset(M->det_on, 0, sizeof(M->det_on));
+    memset(M->det_avg, 0, sizeof(M->det_avg));
     for (int64_t i = 0; i < dkeys->len; i++) {
         int64_t k = RFX_AS_I64(dkeys)[i];
         if (k == s_from || k == s_where || k == s_by || k == s_take) continue;
@@ -242,10 +250,122 @@ static int sel_projection(obj_p tab, const rfx_query_t *Q, int parted, obj_p *re
 /* rfx_select = PLAN (the dict's clauses as descriptors over resident columns: sel_mappings, plan_where, sel_by_shape -- and what the
  * reference answers differently is handed back before anything runs) -> RUN (the planner: rfx_exec_group_by / rfx_exec_filter_aggr /
  * rfx_exec_where over the operator layer's shards) -> BUILD (the result table from the planner's device columns). */
+/* ---- reproducible grouped f64 sums (round 6; opt-in: RFX_DETERMINISTIC=1 / rfx_ops_set_deterministic(1)) ----
+ * The reference's grouped sums are bit-stable for a fixed pool size (its workers' partials merge in task order, core/pool.c:415-424); here rows reach a
+ * group's f64 accumulator through atomics in the order the waves happen to run.  In this mode every `(sum x)` / `(avg x)` over f64 under by: runs as an
+ * INTEGER sum -- associative, so any order gives the same bits -- over x scaled by a power of two and rounded to i64 once per cell:
+ *   M = max |x| over the column (rfx_hip_absmax_f64; a NaN / infinity anywhere leaves the aggregate as it was), 2^e > M, 2^b >= rows,
+ *   k = 62 - e - b  (no sum of <= rows cells can leave 63 bits),   fixed = llrint(x * 2^k)  (rfx_hip_fix_f64, every shard its rows),
+ *   result = (double)sum(fixed) * 2^-k   (/ the group's row count for avg: one hidden COUNT aggregate).
+ * What it costs: two more passes over the argument (8 B read; 8 B read + 8 B written per row) and an i64 sum (no f64 fast paths).  What it gives up: a
+ * cell is rounded to a multiple of 2^-k = 2^(e + b - 62): for 1e9 rows of values up to 1.0 that is 2^-32 -- 1.2e-10 absolute per cell; data whose typical
+ * magnitude is far below its maximum loses relative precision accordingly (a group's sum is off by at most rows_in_group * 2^-(k + 1)). */
+static int g_det = -1;
+static int det_mode(void) {
+    if (g_det < 0) {
+        const char *e = getenv("RFX_DETERMINISTIC");
+        g_det = e && atoi(e) != 0;
+    }
+    return g_det;
+}
+int rfx_ops_set_deterministic(int on) {
+    g_det = on ? 1 : 0;
+    return RFX_OK;
+}
+static const void *shard_piece(const void *p, int s);
+/* 0: done (aggregates rewritten where possible), -2: device failure */
+static int det_rewrite(sel_maps_t *M, int64_t nrows) {
+    if (nrows <= 0) return 0;
+    int need_count = 0;
+    for (int a = 0; a < M->nagg; a++) {
+        rfx_agg_t *ag = &M->aggs[a];
+        if (!(ag->kind == RFX_AGG_SUM || ag->kind == RFX_AGG_AVG) || rfx_agg_input_type(ag) != RFX_F64) continue;
+        if (ag->kind == RFX_AGG_AVG && M->nagg + 1 > RFX_MAX_AGGS) continue; /* (no room for the hidden count: this average stays as it is) */
+        if (g_nqtmp >= (int)(sizeof(g_qtmp) / sizeof(g_qtmp[0]))) continue;
+        /* the argument as ONE f64 scratch column, every shard its rows: an expression evaluated, a plain column read where it lies */
+        const int is_expr = ag->nxnodes > 0 || ag->xop != RFX_X_NONE;
+        void *devs[RFX_MAX_SHARDS];
+        if (shards_alloc(devs, nrows, 8, 0) != RFX_OK) return -2;
+        memset(&g_qtmp[g_nqtmp], 0, sizeof(g_qtmp[0]));
+        for (int s = 0; s < g_nshards; s++) g_qtmp[g_nqtmp].d[s] = devs[s];
+        g_nqtmp++; /* (released with the query's scratch) */
+        int rc = RFX_OK, bad = 0, f64_out = 1;
+        double mx = 0.0;
+        for (int s = 0; s < g_nshards && rc == RFX_OK; s++) {
+            int64_t n;
+            rfx_exec_split(nrows, g_nshards, s, NULL, &n);
+            if (g_nshards == 1) n = nrows;
+            if (n <= 0) continue;
+            if (g_nshards > 1) rfx_hip_ctx_bind_thread(g_ctxs[s]);
+            const void *src = shard_piece(ag->d_col, s);
+            if (is_expr) {
+                rfx_agg_t as = *ag;
+                rfx_xnode_t xn[RFX_MAX_XNODES];
+                as.d_col = shard_piece(ag->d_col, s);
+                as.d_xrhs_col = shard_piece(ag->d_xrhs_col, s);
+                for (int j = 0; j < ag->nxnodes && j < RFX_MAX_XNODES; j++) {
+                    xn[j] = ag->xnodes[j];
+                    if (xn[j].l.kind == RFX_XK_COL) xn[j].l.d_col = shard_piece(ag->xnodes[j].l.d_col, s);
+                    if (xn[j].r.kind == RFX_XK_COL) xn[j].r.d_col = shard_piece(ag->xnodes[j].r.d_col, s);
+                }
+                if (ag->nxnodes > 0) as.xnodes = xn;
+                int32_t ot = RFX_I64;
+                rc = rfx_hip_eval_expr(g_ctxs[s], &as, n, devs[s], &ot);
+                if (ot != RFX_F64) f64_out = 0;
+                src = devs[s];
+            }
+            double m1 = 0.0;
+            int b1 = 0;
+            if (rc == RFX_OK && f64_out) rc = rfx_hip_absmax_f64(g_ctxs[s], (const double *)src, n, &m1, &b1);
+            mx = m1 > mx ? m1 : mx;
+            bad |= b1;
+        }
+        if (rc == RFX_OK && !bad && f64_out) {
+            int e = 0, b = 0;
+            if (mx > 0.0) { (void)frexp(mx, &e); } /* mx = f * 2^e, 0.5 <= f < 1: mx < 2^e */
+            while (b < 62 && ((int64_t)1 << b) < nrows) b++;
+            const int k = 62 - e - b;
+            if (k > -1000 && k < 1000) {
+                for (int s = 0; s < g_nshards && rc == RFX_OK; s++) {
+                    int64_t n;
+                    rfx_exec_split(nrows, g_nshards, s, NULL, &n);
+                    if (g_nshards == 1) n = nrows;
+                    if (n <= 0) continue;
+                    if (g_nshards > 1) rfx_hip_ctx_bind_thread(g_ctxs[s]);
+                    rc = rfx_hip_fix_f64(g_ctxs[s], (const double *)(is_expr ? devs[s] : shard_piece(ag->d_col, s)), n, k, (int64_t *)devs[s]);
+                }
+                if (rc == RFX_OK && qcol_add(devs) == RFX_OK) {
+                    M->det_on[a] = 1;
+                    M->det_avg[a] = ag->kind == RFX_AGG_AVG;
+                    M->det_k[a] = k;
+                    need_count |= M->det_avg[a];
+                    memset(ag, 0, sizeof(*ag));
+                    ag->d_col = devs[0];
+                    ag->col_type = RFX_I64;
+                    ag->kind = RFX_AGG_SUM;
+                }
+            }
+        }
+        if (g_nshards > 1) rfx_hip_ctx_bind_thread(g_ctx);
+        if (rc != RFX_OK) return -2;
+    }
+    if (need_count) { /* the groups' row counts, once, behind the query's own aggregates */
+        rfx_agg_t *c = &M->aggs[M->nagg];
+        memset(c, 0, sizeof(*c));
+        for (int a = 0; a < M->nagg; a++)
+            if (M->det_on[a]) { c->d_col = M->aggs[a].d_col; break; }
+        c->col_type = RFX_I64;
+        c->kind = RFX_AGG_COUNT;
+        M->nhidden = 1;
+    }
+    return 0;
+}
+
 static obj_p sel_build_groups(const rfx_groups_t *R, const sel_maps_t *M, const sel_keys_t *K, const int64_t *knames, const char **why) {
     const int nagg = M->nagg, nkeys = K->nkeys;
     obj_p ocols[RFX_MAX_AGGS] = {0}, okcols[RFX_MAX_KEYS] = {0};
     int ok = 1, enum_out = 0;
+    int64_t *hidden_cnt = NULL;
     if (R->groups > 0) {
         /* every result vector first, then ONE read-back of all of them (every slice of a sliced result by the shard that holds it, over that
          * device's own link: the table construction of core/query.c:559-605 with N writers), then the 4-byte narrowing / enum decoding */
@@ -260,7 +380,20 @@ static obj_p sel_build_groups(const rfx_groups_t *R, const sel_maps_t *M, const 
                 ok = c8[a] && sel_fetch_add(&F, R->d_results[a], c8[a]);
             } else ok = sel_fetch_add(&F, R->d_results[a], RFX_AS_RAW(ocols[a]));
         }
+        if (ok && M->nhidden) {
+            hidden_cnt = (int64_t *)sel_fetch_tmp(&F, R->groups);
+            ok = hidden_cnt && sel_fetch_add(&F, R->d_results[nagg], hidden_cnt);
+        }
         if (ok) ok = rfx_exec_groups_fetch_all(g_x, R, F.n, F.src, F.dst) == RFX_OK;
+        for (int a = 0; a < nagg && ok; a++) { /* reproducible sums: the integer sums back as f64 (an i64 sum's null cannot occur: no null went in, no sum leaves 63 bits) */
+            if (!M->det_on[a]) continue;
+            int64_t *raw = (int64_t *)RFX_AS_RAW(ocols[a]);
+            double *out = (double *)RFX_AS_RAW(ocols[a]);
+            for (int64_t g = 0; g < R->groups; g++) {
+                const double v = ldexp((double)raw[g], -M->det_k[a]);
+                out[g] = M->det_avg[a] ? (hidden_cnt[g] ? v / (double)hidden_cnt[g] : NAN) : v;
+            }
+        }
         if (ok) {
             enum_out = sel_key_columns_finish(K, R, okcols, k8) == SEL_OUT;
             for (int a = 0; a < nagg && !enum_out; a++)
@@ -438,6 +571,10 @@ static obj_p select_impl(obj_p dict) {
             if (mrc) { res = fail_hip("where"); goto done; }
             tmp[ntmp++] = m;
             Q.d_mask = m;
+        }
+        if (by && !parted && det_mode()) { /* reproducible grouped f64 sums: the aggregates' arguments as scaled i64 columns (opt-in) */
+            if (det_rewrite(&M, nrows) != 0) { res = fail_hip("deterministic sums"); goto done; }
+            Q.nagg = M.nagg + M.nhidden;
         }
         Q.cols = g_nshards > 1 ? g_qcols : NULL;
         Q.ncols = g_nqcols;

@@ -50,3 +50,76 @@ def test_two_runs_agree(eng, shape):
             assert (u == w) or (u != u and w != w), (shape, u, w)
             if isinstance(u, float):
                 assert np.float64(u).view(np.uint64) == np.float64(w).view(np.uint64), (shape, u, w)
+
+
+_DET = r'''
+import os, sys, hashlib
+import numpy as np
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+from oracle import rfo
+from rayforce_amd import hostobj as H
+ops = H.lib()
+ops.rfx_host_bind()
+assert ops.rfx_ops_set_deterministic(1) == 0
+NULL = -(2**63)
+out = []
+for shape, n, keys in (("lds", 1_000_003, 3000), ("plane", 6_000_011, 700_000), ("hash", 5_000_017, 300_000)):
+    host = {"k": rfo.gen_i64(n, 4, keys), "a": rfo.gen_i64(n, 2, 1_000_000), "v": rfo.gen_f64(n, 5) - 0.5, "w": rfo.gen_f64(n, 6) * 1000.0}
+    if shape == "hash":
+        host["k"] = host["k"] * 1_000_003 - 77
+    tab = H.table(host)
+    for q in ({"s": ("sum", "v"), "x": ("avg", "w"), "e": ("sum", ("*", "v", ("-", 1, "w"))), "i": ("sum", "a"), "c": ("count", "v"), "m": ("min", "v"), "by": "k"},
+              {"s": ("sum", "v"), "x": ("avg", "w"), "where": ("<", "a", 300_000), "by": "k"}):
+        d = H.select_dict(q, tab)
+        runs = []
+        for _ in range(3):
+            r = ops.rfx_select(d)
+            assert r and not H.is_error(r), H.error_text(r)
+            runs.append(H.table_to_numpy(r))
+            ops.rfx_host_drop(r)
+        want = rfo.select({"from": host, **q})
+        for name in want:
+            for b in runs[1:]:
+                assert np.array_equal(np.ascontiguousarray(runs[0][name]).view(np.uint64), np.ascontiguousarray(b[name]).view(np.uint64)), (shape, name, "run to run")
+            g, w = runs[0][name], want[name]
+            assert g.dtype == w.dtype and g.shape == w.shape, (shape, name)
+            if w.dtype == np.float64:  # against the oracle: 1e-9 of the group's sum of magnitudes (the fixed-point cells are exact to 2^-(k+1) each)
+                scale = np.maximum(np.abs(w), 1e-3 * (1000.0 if name == "x" else 1.0))
+                assert np.all(np.abs(g - w) <= 1e-9 * scale * 50), (shape, name, float(np.abs(g - w).max()))
+            else:
+                assert np.array_equal(g, w), (shape, name)
+            out.append(hashlib.sha256(np.ascontiguousarray(runs[0][name]).tobytes()).hexdigest())
+        ops.rfx_host_drop(d)
+    # a NaN in the argument: that aggregate keeps the default path (NaN semantics as ever), the others stay reproducible
+    host2 = dict(host)
+    host2["v"] = host["v"].copy()
+    host2["v"][12345] = np.nan
+    t2 = H.table(host2)
+    d = H.select_dict({"s": ("sum", "v"), "x": ("avg", "w"), "by": "k"}, t2)
+    r = ops.rfx_select(d)
+    assert r and not H.is_error(r), H.error_text(r)
+    got, want = H.table_to_numpy(r), rfo.select({"from": host2, "s": ("sum", "v"), "x": ("avg", "w"), "by": "k"})
+    assert np.array_equal(np.isnan(got["s"]), np.isnan(want["s"])) and int(np.isnan(got["s"]).sum()) == 1
+    for o in (r, d, t2, tab):
+        ops.rfx_host_drop(o)
+print("DIGEST", hashlib.sha256("".join(out).encode()).hexdigest())
+'''
+
+
+def test_deterministic_mode_is_bit_stable_across_runs_and_shard_counts(built):
+    """Opt-in reproducible grouped f64 sums (rfx_ops_set_deterministic / RFX_DETERMINISTIC; DESIGN.md section 4): (sum x) / (avg x) over f64 under by: run as
+    integer sums over x scaled by a power of two -- bit-identical from run to run, AND across 1 / 3 / 4 shards (the scale depends on the table only), within
+    1e-9 of the oracle; expression aggregates too; a column with a NaN keeps the default path."""
+    import os, subprocess, sys
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    digests = []
+    for shards, extra in ((1, {}), (3, {"RFX_EXEC_SLICE_SHARDS": "1"}), (4, {})):
+        env = dict(os.environ, RFX_SHARDS=str(shards), **extra)
+        env.pop("RFX_DETERMINISTIC", None)
+        p = subprocess.run([sys.executable, "-c", f"ROOT = {root!r}\n" + _DET], env=env, capture_output=True, text=True, timeout=900)
+        assert p.returncode == 0 and "DIGEST" in p.stdout, p.stdout[-2000:] + p.stderr[-3000:]
+        digests.append(p.stdout.split("DIGEST")[1].split()[0])
+    assert len(set(digests)) == 1, digests
