@@ -146,11 +146,11 @@ int rfx_ops_set_validation(int mode);
  * pool size, core/pool.c:415-424; the default path's f64 atomics are not).  Costs two more passes over the argument; a cell is rounded to a multiple of
  * 2^(e + b - 62) (2^e > max |x|, 2^b >= rows); a column holding a NaN or an infinity keeps the default path.  DESIGN.md section 4. */
 int rfx_ops_set_deterministic(int on);
-/* unary_f: I64[15] counters since load: {selects on the GPU, selects delegated to the host, joins on the GPU, joins delegated,
+/* unary_f: I64[17] counters since load: {selects on the GPU, selects delegated to the host, joins on the GPU, joins delegated,
  * uploads, cache hits, stale entries refreshed, operator calls, group scopes sampled, sampled scopes retried exactly,
  * materialised B8 mask passes (RFX_STAT_MASK_PASSES: a fused `where:` tree runs none), uses validated by soft-dirty page bits,
  * uses that cost a full-payload checksum (0 under ownership), uses validated by ownership, entries released because the cache held the
- * last reference}; the argument is ignored */
+ * last reference, fixed-point images of resident f64 columns made for the reproducible sums, such images found again}; the argument is ignored */
 rfx_obj_p rfx_stats(rfx_obj_p ignored);
 void rfx_cache_clear(void);
 int64_t rfx_cache_bytes(void);

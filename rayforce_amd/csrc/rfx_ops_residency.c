@@ -151,6 +151,9 @@ typedef struct {
     int64_t smin, smax;
     void *devs[RFX_MAX_SHARDS]; /* the copy, shard by shard (devs[0] == dev): rows rfx_exec_split(len, shards, s) of the column */
     obj_p owner;       /* validation by ownership: OUR reference to the host vector (a parted column: to its LIST); NULL in checksum mode */
+    int amax_ok;       /* reproducible sums (resident_fixed): 1 = amax is max |x| over this f64 copy, 2 = the copy holds a NaN / an infinity; 0 = not looked at */
+    double amax;
+    int fix_k;         /* a DERIVED entry (type code + 256): this column's fixed-point image llrint(x * 2^fix_k) as i64, owned like the copy it was made from */
 } resident_t;
 static resident_t *g_res;
 static int g_nres, g_capres;
@@ -161,6 +164,7 @@ static int64_t g_sd_hits;  /* uses of an unpinned cached column proven current b
 static int64_t g_sum_validations; /* uses of a cached column that cost a full-payload checksum (0 under validation by ownership) */
 static int64_t g_own_hits;        /* uses of a cached column proven current by being the very object the cache holds a reference to */
 static int64_t g_own_released;    /* entries released because the cache's reference was the last one */
+static int64_t g_fix_built, g_fix_hits; /* fixed-point images made / found again (reproducible sums) */
 static int g_validate = -1;       /* 0 ownership (default), 1 checksum: RFX_VALIDATE=checksum, rfx_ops_set_validation */
 static int validate_mode(void) {
     if (g_validate < 0) {
@@ -718,6 +722,23 @@ rfx_obj_p rfx_host_device_vector(int8_t type, int64_t len, const void *const *d_
 /* whole = 1 (round 6, several shards only): the column WHOLE on every shard's device -- the BUILD side of a join over sharded tables (every shard
  * probes its own left rows against all of the right table: a broadcast join) -- cached beside the row-range copies as an entry of its own
  * (type code + 128); *devs_out receives the copies' addresses, the planner's column table (g_qcols) does not learn them. */
+static void res_make_room(size_t dbytes) {
+    while (g_nres && g_res_bytes + dbytes > cache_budget()) {
+        int victim = -1; /* least recently used, not pinned, not in use by the call in flight */
+        for (int i = 0; i < g_nres; i++)
+            if (!g_res[i].pinned && g_res[i].epoch != g_epoch && (victim < 0 || g_res[i].tick < g_res[victim].tick)) victim = i;
+        if (victim < 0) break; /* everything left is pinned or in use: go over budget rather than free what the call reads */
+        res_free(victim);
+    }
+}
+static void res_append(const resident_t *e) {
+    if (g_nres == g_capres) {
+        g_capres = g_capres ? g_capres * 2 : 32;
+        g_res = (resident_t *)realloc(g_res, sizeof(resident_t) * (size_t)g_capres);
+    }
+    g_res[g_nres++] = *e;
+    g_res_bytes += e->dbytes;
+}
 static int resident_ex(obj_p col, int pin, int whole, const void **dev, void **devs_out) {
     if (whole && (col->mmod == RFX_MMOD_DEVICE || g_nshards <= 1)) return RFX_ELIMIT; /* (device handles hold row ranges: nothing to replicate from) */
     if (col->mmod == RFX_MMOD_DEVICE) {
@@ -798,6 +819,7 @@ static int resident_ex(obj_p col, int pin, int whole, const void **dev, void **d
             if (rc != RFX_OK) { res_free(i); return rc; }
             g_stat[ST_UPLOADS]++;
             g_res[i].scope_ok = 0; /* (new cells: the scope remembered for the old ones is gone) */
+            g_res[i].amax_ok = 0;
             g_res[i].sum = sum;
             g_res[i].tick = ++g_tick;
             g_res[i].epoch = g_epoch;
@@ -805,13 +827,7 @@ static int resident_ex(obj_p col, int pin, int whole, const void **dev, void **d
             RES_DONE(&g_res[i]);
         }
     }
-    while (g_nres && g_res_bytes + dbytes > cache_budget()) {
-        int victim = -1; /* least recently used, not pinned, not in use by the call in flight */
-        for (int i = 0; i < g_nres; i++)
-            if (!g_res[i].pinned && g_res[i].epoch != g_epoch && (victim < 0 || g_res[i].tick < g_res[victim].tick)) victim = i;
-        if (victim < 0) break; /* everything left is pinned or in use: go over budget rather than free what the call reads */
-        res_free(victim);
-    }
+    res_make_room(dbytes);
     void *devs[RFX_MAX_SHARDS];
     int rc = shards_alloc(devs, col->len, narrow ? 8 : (size_t)esz, whole);
     if (rc != RFX_OK) return rc;
@@ -825,17 +841,12 @@ static int resident_ex(obj_p col, int pin, int whole, const void **dev, void **d
         return rc;
     }
     g_stat[ST_UPLOADS]++;
-    if (g_nres == g_capres) {
-        g_capres = g_capres ? g_capres * 2 : 32;
-        g_res = (resident_t *)realloc(g_res, sizeof(resident_t) * (size_t)g_capres);
-    }
     resident_t e;
     memset(&e, 0, sizeof(e));
     e.host = host; e.len = col->len; e.type = ktype; e.sum = sum; e.dev = devs[0]; e.bytes = bytes; e.pinned = pin; e.tick = ++g_tick; e.epoch = g_epoch; e.dbytes = dbytes;
     e.owner = own ? H.clone(keyobj) : NULL; /* from here on the host copies before it writes, and cannot free */
     for (int s = 0; s < g_nshards; s++) e.devs[s] = devs[s];
-    g_res[g_nres++] = e; /* (page tracking starts once the column has proven stable) */
-    g_res_bytes += dbytes;
+    res_append(&e); /* (page tracking starts once the column has proven stable) */
     RES_DONE(&g_res[g_nres - 1]);
 #undef RES_DONE
 }
@@ -848,6 +859,87 @@ static resident_t *resident_entry(const void *dev) {
     for (int i = 0; i < g_nres; i++)
         if (g_res[i].dev == dev && g_res[i].epoch == g_epoch) return &g_res[i];
     return NULL;
+}
+/* Reproducible grouped f64 sums (rfx_ops_select.c: det_rewrite): the scale of a column's fixed-point image.  2^e > max |x|, 2^b >= rows: no sum of `rows`
+ * cells llrint(x * 2^k), k = 62 - e - b, leaves 63 bits -- and k depends on the column and the table's length alone, not on how the rows are sharded. */
+static int det_scale(double amax, int64_t nrows) {
+    int e = 0, b = 0;
+    if (amax > 0.0) (void)frexp(amax, &e); /* amax = f * 2^e, 0.5 <= f < 1 */
+    while (b < 62 && ((int64_t)1 << b) < nrows) b++;
+    return 62 - e - b;
+}
+/* ... and the image itself for a column the cache holds BY OWNERSHIP: made once (max |x| remembered with the copy, the image a cache entry of its own --
+ * type code + 256, the same owner: immutable for as long as it lives, released with the owner, evicted like any unpinned copy), so that a repeated query in
+ * the reproducible mode runs at the default path's speed; the price is a second 8 bytes per row of HBM for the f64 columns such queries sum.  1: not a
+ * column this applies to (a device vector, checksum mode, a NaN / an infinity inside) -- det_rewrite's per-query scratch path decides. */
+static int resident_fixed(const void *base_dev, int64_t nrows, int *k_out, const void **dev_out) {
+    resident_t *re = resident_entry(base_dev);
+    if (!re || !re->owner || re->type != RFX_TYPE_F64 || re->len != nrows || nrows <= 0) return 1;
+    int rc = RFX_OK;
+    if (!re->amax_ok) {
+        double mx = 0.0;
+        int bad = 0;
+        for (int s = 0; s < g_nshards && rc == RFX_OK; s++) {
+            int64_t n;
+            rfx_exec_split(nrows, g_nshards, s, NULL, &n);
+            if (g_nshards == 1) n = nrows;
+            if (n <= 0) continue;
+            if (g_nshards > 1) rfx_hip_ctx_bind_thread(g_ctxs[s]);
+            double m1 = 0.0;
+            int b1 = 0;
+            rc = rfx_hip_absmax_f64(g_ctxs[s], (const double *)re->devs[s], n, &m1, &b1);
+            mx = m1 > mx ? m1 : mx;
+            bad |= b1;
+        }
+        if (g_nshards > 1) rfx_hip_ctx_bind_thread(g_ctx);
+        if (rc != RFX_OK) return rc;
+        re->amax = mx;
+        re->amax_ok = bad ? 2 : 1;
+    }
+    if (re->amax_ok != 1) return 1;
+    const int k = det_scale(re->amax, nrows);
+    if (k <= -1000 || k >= 1000) return 1;
+    for (int i = 0; i < g_nres; i++) {
+        if (g_res[i].owner != re->owner || g_res[i].type != RFX_TYPE_F64 + 256) continue;
+        if (g_res[i].len != nrows || g_res[i].fix_k != k) { res_free(i); re = resident_entry(base_dev); break; } /* (cannot happen: the owner's cells do not change) */
+        g_res[i].tick = ++g_tick;
+        g_res[i].epoch = g_epoch;
+        g_fix_hits++;
+        *k_out = k;
+        *dev_out = g_res[i].dev;
+        return qcol_add(g_res[i].devs);
+    }
+    if (!re) return 1;
+    const resident_t base = *re; /* (the table of entries may move below) */
+    res_make_room((size_t)nrows * 8);
+    void *devs[RFX_MAX_SHARDS];
+    rc = shards_alloc(devs, nrows, 8, 0);
+    if (rc != RFX_OK) return rc;
+    for (int s = 0; s < g_nshards && rc == RFX_OK; s++) {
+        int64_t n;
+        rfx_exec_split(nrows, g_nshards, s, NULL, &n);
+        if (g_nshards == 1) n = nrows;
+        if (n <= 0) continue;
+        if (g_nshards > 1) rfx_hip_ctx_bind_thread(g_ctxs[s]);
+        rc = rfx_hip_fix_f64(g_ctxs[s], (const double *)base.devs[s], n, k, (int64_t *)devs[s]);
+    }
+    if (rc != RFX_OK) {
+        for (int s = 0; s < g_nshards; s++) { if (g_nshards > 1) rfx_hip_ctx_bind_thread(g_ctxs[s]); rfx_hip_free(g_ctxs[s], devs[s]); }
+        if (g_nshards > 1) rfx_hip_ctx_bind_thread(g_ctx);
+        return rc;
+    }
+    if (g_nshards > 1) rfx_hip_ctx_bind_thread(g_ctx);
+    resident_t e;
+    memset(&e, 0, sizeof(e));
+    e.host = base.host; e.len = nrows; e.type = RFX_TYPE_F64 + 256; e.dev = devs[0]; e.bytes = base.bytes; e.tick = ++g_tick; e.epoch = g_epoch; e.dbytes = (size_t)nrows * 8;
+    e.owner = H.clone(base.owner);
+    e.fix_k = k;
+    for (int s = 0; s < g_nshards; s++) e.devs[s] = devs[s];
+    res_append(&e);
+    g_fix_built++;
+    *k_out = k;
+    *dev_out = devs[0];
+    return qcol_add(devs);
 }
 /* drop every cached copy that overlaps the vector's payload */
 static void invalidate_payload(obj_p v) {

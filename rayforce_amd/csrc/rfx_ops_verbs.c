@@ -72,7 +72,7 @@ rfx_obj_p rfx_stats(rfx_obj_p x) {
     (void)x;
     rfx_host_bind();
     op_begin(); /* (the counters of other threads' operators stand still; entries only the cache refers to are released like at any call) */
-    obj_p out = H.vector(RFX_TYPE_I64, 15);
+    obj_p out = H.vector(RFX_TYPE_I64, 17);
     for (int i = 0; i < 10; i++) RFX_AS_I64(out)[i] = g_stat[i];
     if (g_x) { /* scopes sampled / sampled scopes retried exactly: the planner's counters */
         RFX_AS_I64(out)[ST_SCOPE_SAMPLED] = rfx_exec_stat(g_x, RFX_XSTAT_SCOPE_SAMPLED);
@@ -83,6 +83,8 @@ rfx_obj_p rfx_stats(rfx_obj_p x) {
     RFX_AS_I64(out)[12] = g_sum_validations; /* uses of a cached column that cost a checksum over its whole payload (checksum mode only) */
     RFX_AS_I64(out)[13] = g_own_hits;        /* uses proven current by ownership: the object the cache holds a reference to */
     RFX_AS_I64(out)[14] = g_own_released;    /* entries released because the cache's reference was the last one */
+    RFX_AS_I64(out)[15] = g_fix_built;       /* reproducible sums: fixed-point images of resident f64 columns made ... */
+    RFX_AS_I64(out)[16] = g_fix_hits;        /* ... and found again by a later query */
     op_end();
     return out;
 }

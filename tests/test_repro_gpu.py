@@ -68,6 +68,7 @@ for shape, n, keys in (("lds", 1_000_003, 3000), ("plane", 6_000_011, 700_000), 
     if shape == "hash":
         host["k"] = host["k"] * 1_000_003 - 77
     tab = H.table(host)
+    st0 = H.to_numpy(ops.rfx_stats(0))
     for q in ({"s": ("sum", "v"), "x": ("avg", "w"), "e": ("sum", ("*", "v", ("-", 1, "w"))), "i": ("sum", "a"), "c": ("count", "v"), "m": ("min", "v"), "by": "k"},
               {"s": ("sum", "v"), "x": ("avg", "w"), "where": ("<", "a", 300_000), "by": "k"}):
         d = H.select_dict(q, tab)
@@ -103,6 +104,9 @@ for shape, n, keys in (("lds", 1_000_003, 3000), ("plane", 6_000_011, 700_000), 
                 assert np.array_equal(g, w), (shape, name)
             out.append(hashlib.sha256(np.ascontiguousarray(runs[0][name]).tobytes()).hexdigest())
         ops.rfx_host_drop(d)
+    # the plain columns' fixed-point images were made ONCE (v, w: two per table) and found again by the later calls; the expression went through scratch
+    st = H.to_numpy(ops.rfx_stats(0))
+    assert int(st[15] - st0[15]) == 2 and int(st[16] - st0[16]) == 10, (shape, int(st[15] - st0[15]), int(st[16] - st0[16]))
     # a NaN in the argument: that aggregate keeps the default path (NaN semantics as ever), the others stay reproducible
     host2 = dict(host)
     host2["v"] = host["v"].copy()
