@@ -868,10 +868,37 @@ static int det_scale(double amax, int64_t nrows) {
     while (b < 62 && ((int64_t)1 << b) < nrows) b++;
     return 62 - e - b;
 }
+/* One process per device (rfx_ops_dist_init: every rank holds a row range of the table and the planner merges the ranks' tables): the scale must be the SAME
+ * on every rank -- the ranks' integer sums are added to each other -- so max |x|, the row count and the "holds a NaN / an infinity" flag are taken over all
+ * ranks' ranges.  Exactly ONE small all-gather per rewritten aggregate on every rank, whichever path (cached image / scratch) a rank takes; nothing in one
+ * process, however many devices it drives (its shards are looked at together). */
+static int det_ranks(void) { /* ranks of a one-process-per-device world this process is one of; 1 otherwise */
+    int world = 1, rank = 0;
+    if (!g_ctx || !rfx_dist_has_comm(g_ctx) || rfx_dist_is_local(g_ctx)) return 1;
+    return rfx_dist_world(g_ctx, &world, &rank) == RFX_OK && world > 1 ? world : 1;
+}
+static int det_world_agree(double *amax, int64_t *nrows, int *bad) {
+    const int world = det_ranks();
+    if (world <= 1) return RFX_OK;
+    int rc;
+    typedef struct { double a; int64_t n, b; } agree_t;
+    agree_t mine = {*amax, *nrows, *bad}, *all = (agree_t *)malloc(sizeof(agree_t) * (size_t)world);
+    if (!all) return RFX_ENOMEM;
+    rc = rfx_dist_allgather_host(g_ctx, &mine, sizeof(mine), all);
+    if (rc == RFX_OK) {
+        double a = 0.0;
+        int64_t n = 0, b = 0;
+        for (int r = 0; r < world; r++) { a = all[r].a > a ? all[r].a : a; n += all[r].n; b |= all[r].b; }
+        *amax = a; *nrows = n; *bad = b != 0;
+    }
+    free(all);
+    return rc;
+}
 /* ... and the image itself for a column the cache holds BY OWNERSHIP: made once (max |x| remembered with the copy, the image a cache entry of its own --
  * type code + 256, the same owner: immutable for as long as it lives, released with the owner, evicted like any unpinned copy), so that a repeated query in
  * the reproducible mode runs at the default path's speed; the price is a second 8 bytes per row of HBM for the f64 columns such queries sum.  1: not a
- * column this applies to (a device vector, checksum mode, a NaN / an infinity inside) -- det_rewrite's per-query scratch path decides. */
+ * column this applies to (a device vector, checksum mode) -- det_rewrite's per-query scratch path decides; 2: a NaN / an infinity inside (on some rank): this
+ * aggregate keeps the default path. */
 static int resident_fixed(const void *base_dev, int64_t nrows, int *k_out, const void **dev_out) {
     resident_t *re = resident_entry(base_dev);
     if (!re || !re->owner || re->type != RFX_TYPE_F64 || re->len != nrows || nrows <= 0) return 1;
@@ -896,9 +923,13 @@ static int resident_fixed(const void *base_dev, int64_t nrows, int *k_out, const
         re->amax = mx;
         re->amax_ok = bad ? 2 : 1;
     }
-    if (re->amax_ok != 1) return 1;
-    const int k = det_scale(re->amax, nrows);
-    if (k <= -1000 || k >= 1000) return 1;
+    double amax = re->amax;
+    int64_t world_rows = nrows;
+    int bad = re->amax_ok != 1;
+    rc = det_world_agree(&amax, &world_rows, &bad);
+    if (rc != RFX_OK) return rc;
+    const int k = det_scale(amax, world_rows);
+    if (bad || k <= -1000 || k >= 1000) return 2;
     for (int i = 0; i < g_nres; i++) {
         if (g_res[i].owner != re->owner || g_res[i].type != RFX_TYPE_F64 + 256) continue;
         if (g_res[i].len != nrows || g_res[i].fix_k != k) { res_free(i); re = resident_entry(base_dev); break; } /* (cannot happen: the owner's cells do not change) */

@@ -275,7 +275,7 @@ int rfx_ops_set_deterministic(int on) {
 static const void *shard_piece(const void *p, int s);
 /* 0: done (aggregates rewritten where possible), -2: device failure */
 static int det_rewrite(sel_maps_t *M, int64_t nrows) {
-    if (nrows <= 0) return 0;
+    if (nrows <= 0 && det_ranks() == 1) return 0; /* (a rank without rows still takes part in the ranks' agreement on the scale, and folds the same aggregates) */
     int need_count = 0, count_type = RFX_I64;
     const void *count_col = NULL;
     for (int a = 0; a < M->nagg; a++) {
@@ -288,6 +288,7 @@ static int det_rewrite(sel_maps_t *M, int64_t nrows) {
             int k = 0;
             const void *img = NULL;
             const int frc = resident_fixed(ag->d_col, nrows, &k, &img);
+            if (frc == 2) continue; /* (a NaN / an infinity in the column: the default path and its poisoning rules) */
             if (frc != RFX_OK && frc != 1) return -2;
             if (frc == RFX_OK) {
                 if (!count_col) count_col = ag->d_col, count_type = ag->col_type;
@@ -340,8 +341,11 @@ static int det_rewrite(sel_maps_t *M, int64_t nrows) {
             mx = m1 > mx ? m1 : mx;
             bad |= b1;
         }
-        if (rc == RFX_OK && !bad && f64_out) {
-            const int k = det_scale(mx, nrows);
+        int64_t world_rows = nrows;
+        bad |= !f64_out;
+        if (rc == RFX_OK) rc = det_world_agree(&mx, &world_rows, &bad);
+        if (rc == RFX_OK && !bad) {
+            const int k = det_scale(mx, world_rows);
             if (k > -1000 && k < 1000) {
                 for (int s = 0; s < g_nshards && rc == RFX_OK; s++) {
                     int64_t n;
