@@ -924,7 +924,11 @@ def launcher_door(args, name, eng, world, rank, rows, row0, total_rows):
         if int(w_.value) != world:
             raise SystemExit(f"bench.py: the RCCL communicator spans {int(w_.value)} ranks, the launcher started {world}")
     calls = transport.calls if transport else int(ops.rfx_dist_calls(C.c_void_p(ops.rfx_exec_ctx(x, 0))))
+    import hashlib
+    import numpy as np
+    digest = hashlib.sha256(b"".join(np.ascontiguousarray(got[c]).tobytes() for c in sorted(got))).hexdigest()  # (bit-stable across rank counts in the reproducible mode only)
     out = {"ms_per_step": dt * 1e3 / args.steps, "rows_per_s": total_rows / (dt / args.steps), "verified": checked, "ranks_seen": transport.world if transport else int(w_.value),
+           "result_digest": digest, "reproducible_mode": os.environ.get("RFX_DETERMINISTIC") == "1",
            "collectives_per_query": calls / (args.steps + max(1, args.warmup)),
            "result": {"groups": len(got[next(iter(got))])} if "by" in q else {"values": [float(v[0]) for v in got.values()]}}
     if transport:
@@ -1172,7 +1176,7 @@ def main():
         main_r = run_workload(name, eng, sharded, rows, row0, args.steps, args.warmup, world, total_rows)
     log(f"[bench] {name}: {main_r}")
     door = None
-    if world == 1 and sharded is None and name in C_DOOR and not args.engine_door:
+    if world == 1 and sharded is None and ldoor is None and name in C_DOOR and not args.engine_door:
         # the headline goes through the product's own door: the C operator rfx_select (Engine's time for the same query rides beside it)
         door = c_door(name, eng, rows, args.steps, args.warmup)
         log(f"[bench] {name} through rfx_select: {door}")
@@ -1299,7 +1303,7 @@ def main():
                                                        "frac": w["bytes_per_row"] * total_rows / (km * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                                                        "all_bracketed_kernels_ms": door["kernels_ms"], "how": "hipEventRecord around the launch on the context's stream (rfx_hip_profile_kernels), 5 steps after the timed loop"}
         if ldoor:
-            line["door"] = {k: ldoor[k] for k in ("ms_per_step", "rows_per_s", "verified", "collectives_per_query")}
+            line["door"] = {k: ldoor[k] for k in ("ms_per_step", "rows_per_s", "verified", "collectives_per_query", "result_digest", "reproducible_mode")}
             if ldoor.get("exchange"):  # (the gloo test plumbing: the time is a host round trip per exchange, not the product's)
                 line["door"]["exchange"] = ldoor["exchange"]
                 line["config"]["door"] = line["config"]["door"].replace("in the RCCL communicator (rfx_ops_dist_init)", "exchanging through " + ldoor["exchange"])

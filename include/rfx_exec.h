@@ -69,6 +69,11 @@ typedef struct rfx_transport {
     int (*allgather_dev)(void *user, const void *d_in, size_t bytes, void *d_out);
 } rfx_transport_t;
 int rfx_exec_set_transport(rfx_exec_t *x, const rfx_transport_t *t); /* NULL: back to the default */
+/* The inter-process side as the planner itself sees it (the host's transport, else the lead context's RCCL communicator unless that one is process-local):
+ * how many processes share the table (1: no exchange), and `bytes` of host memory from each of them in rank order -- for a caller that must agree on a
+ * small fact before it builds the query (rfx_select's reproducible sums: one scale for all ranks). */
+int rfx_exec_ranks(rfx_exec_t *x);
+int rfx_exec_allgather_host(rfx_exec_t *x, const void *in, size_t bytes, void *out);
 
 /* ---- the query ---- */
 typedef struct rfx_qcol {

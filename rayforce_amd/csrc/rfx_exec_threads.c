@@ -242,6 +242,15 @@ static int xp_allgather_host(rfx_exec_t *x, const void *in, size_t bytes, void *
     if (x->has_tr) return x->tr.allgather_host(x->tr.user, in, bytes, out);
     return rfx_dist_allgather_host(x->ctx[0], in, bytes, out);
 }
+int rfx_exec_ranks(rfx_exec_t *x) {
+    int w = 1, r = 0;
+    if (!x || !world_rank(x, &w, &r)) return 1;
+    return w > 1 ? w : 1;
+}
+int rfx_exec_allgather_host(rfx_exec_t *x, const void *in, size_t bytes, void *out) {
+    if (!x || !in || !out || !bytes) return RFX_EINVAL;
+    return xp_allgather_host(x, in, bytes, out);
+}
 static int xp_allreduce(rfx_exec_t *x, void *d_buf, int64_t n, int type, int op) {
     x->stat[RFX_XSTAT_MERGES_TRANSPORT]++;
     if (x->has_tr) return x->tr.allreduce(x->tr.user, d_buf, n, type, op);

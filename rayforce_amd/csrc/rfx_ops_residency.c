@@ -870,13 +870,9 @@ static int det_scale(double amax, int64_t nrows) {
 }
 /* One process per device (rfx_ops_dist_init: every rank holds a row range of the table and the planner merges the ranks' tables): the scale must be the SAME
  * on every rank -- the ranks' integer sums are added to each other -- so max |x|, the row count and the "holds a NaN / an infinity" flag are taken over all
- * ranks' ranges.  Exactly ONE small all-gather per rewritten aggregate on every rank, whichever path (cached image / scratch) a rank takes; nothing in one
+ * ranks' ranges (through the planner's own inter-process side: the host's transport or the RCCL communicator).  Exactly ONE small all-gather per rewritten aggregate on every rank, whichever path (cached image / scratch) a rank takes; nothing in one
  * process, however many devices it drives (its shards are looked at together). */
-static int det_ranks(void) { /* ranks of a one-process-per-device world this process is one of; 1 otherwise */
-    int world = 1, rank = 0;
-    if (!g_ctx || !rfx_dist_has_comm(g_ctx) || rfx_dist_is_local(g_ctx)) return 1;
-    return rfx_dist_world(g_ctx, &world, &rank) == RFX_OK && world > 1 ? world : 1;
-}
+static int det_ranks(void) { return g_x ? rfx_exec_ranks(g_x) : 1; } /* ranks of a one-process-per-device world this process is one of; 1 otherwise */
 static int det_world_agree(double *amax, int64_t *nrows, int *bad) {
     const int world = det_ranks();
     if (world <= 1) return RFX_OK;
@@ -884,7 +880,7 @@ static int det_world_agree(double *amax, int64_t *nrows, int *bad) {
     typedef struct { double a; int64_t n, b; } agree_t;
     agree_t mine = {*amax, *nrows, *bad}, *all = (agree_t *)malloc(sizeof(agree_t) * (size_t)world);
     if (!all) return RFX_ENOMEM;
-    rc = rfx_dist_allgather_host(g_ctx, &mine, sizeof(mine), all);
+    rc = rfx_exec_allgather_host(g_x, &mine, sizeof(mine), all);
     if (rc == RFX_OK) {
         double a = 0.0;
         int64_t n = 0, b = 0;

@@ -247,3 +247,25 @@ def test_bench_under_the_launcher_two_ranks_one_gpu(workload):
     assert rec["door"]["verified"] and rec["door"]["collectives_per_query"] >= 1 and "gloo" in rec["door"]["exchange"]
     if workload == "c3w":
         assert 950_000 < rec["config"]["result"]["groups"] <= 1_000_000 and rec["door"]["collectives_per_query"] == 3  # scope, tables, first rows' order
+
+
+def test_reproducible_sums_across_rank_counts():
+    """RFX_DETERMINISTIC=1 under the launcher: the ranks agree on ONE scale for the fixed-point sums (max |x| and the row count over all ranks' row ranges: one
+    more small all-gather per query), so two ranks over the halves of the table return the very bits one rank returns over the whole of it."""
+    import json
+    import subprocess
+    import sys
+    recs = []
+    for ranks in (2, 1):
+        env = dict(os.environ, RFX_DETERMINISTIC="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        env.update({"RFX_BENCH_SAME_DEVICE": "1", "RFX_BENCH_BACKEND": "gloo"} if ranks > 1 else {"RFX_BENCH_FORCE_LAUNCHER_DOOR": "1"})
+        cmd = [os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--steps", "2", "--warmup", "1", "--rows", "30000001", "--workload", "c3w", "--no-also", "--no-cpu-baseline", "--no-predict"]
+        if ranks > 1:
+            cmd = ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr", "127.0.0.1", "--master-port", str(_free_port())] + cmd
+        out = subprocess.run([sys.executable] + cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+        assert out.returncode == 0, out.stderr[-3000:]
+        recs.append(json.loads([ln for ln in out.stdout.splitlines() if ln.strip()][-1]))
+    two, one = recs
+    assert two["door"]["reproducible_mode"] and one["door"]["reproducible_mode"] and two["door"]["verified"] and one["door"]["verified"]
+    assert two["door"]["collectives_per_query"] == 4  # scope, tables, first rows' order + the scale
+    assert two["config"]["result"]["groups"] == one["config"]["result"]["groups"] and two["door"]["result_digest"] == one["door"]["result_digest"]
