@@ -742,7 +742,7 @@ def predicted_scaling(name, eng, steps=5):
     return out
 
 
-def door_property_check(name, got, cols_by_shard, q, reduce_sum):
+def door_property_check(name, got, cols_by_shard, q, reduce_sum, sliced=False):
     """N > 1: no unsharded copy exists to compare with -- the answer's invariants instead.  Scalar: selected sums / extrema from torch per shard,
     folded; grouped: the groups' sums add up to the selected rows' sum, the group count is the number of distinct selected keys (torch.unique
     per shard, folded by a presence table), first-occurrence order = every key new where it stands (no duplicates)."""
@@ -772,6 +772,16 @@ def door_property_check(name, got, cols_by_shard, q, reduce_sum):
         tot = reduce_sum(loc_sum)
         pres = reduce_sum(pres.double()).clamp(max=1.0)
         groups = int(pres.sum())
+        if sliced:  # `got` is this rank's range of the groups: the ranks' pieces together are every distinct key exactly once, their sums add up
+            mine = torch.zeros(1_000_000, dtype=torch.float64)
+            mine[torch.from_numpy(np.ascontiguousarray(got["k"]))] += 1.0
+            seen = reduce_sum(mine)
+            n_all, s_all = int(reduce_sum(float(len(got["k"])))), reduce_sum(float(got["s"].sum()))
+            if n_all != groups or len(np.unique(got["k"])) != len(got["k"]) or float(seen.max()) > 1.0 or int(seen.sum()) != groups or not torch.equal(seen > 0, pres > 0):
+                raise SystemExit(f"bench.py: {name}: the ranks' slices hold {n_all} groups ({int((seen > 1).sum())} keys twice) vs {groups} distinct selected keys")
+            if not abs(s_all - tot) <= 1e-9 * abs(tot):
+                raise SystemExit(f"bench.py: {name}: the slices' sums add up to {s_all!r}, the selected rows' to {tot!r}")
+            return f"{groups} groups over the ranks' slices = the distinct selected keys, each exactly once, the groups' sums add up to the selected rows' sum (1e-9)"
         if len(got["k"]) != groups or len(np.unique(got["k"])) != groups:
             raise SystemExit(f"bench.py: {name}: {len(got['k'])} groups vs {groups} distinct selected keys")
         if not abs(float(got["s"].sum()) - tot) <= 1e-9 * abs(tot):
@@ -873,7 +883,7 @@ def one_process(args):
 
 def launcher_door(args, name, eng, world, rank, rows, row0, total_rows):
     """Under a launcher, world > 1: this rank's row range as device columns through rfx_select with the operator layer's context in the
-    RCCL communicator (rfx_ops_dist_init): every rank gets the whole answer."""
+    RCCL communicator (rfx_ops_dist_init): a scalar answer whole on every rank, a grouped one sliced over the ranks (every rank its range of the groups)."""
     from rayforce_amd import hostobj as H, _lib as L
     ops = H.lib()
     ops.rfx_host_bind()
@@ -904,6 +914,10 @@ def launcher_door(args, name, eng, world, rank, rows, row0, total_rows):
             dist.broadcast_object_list(ident, src=0)
         L.check(ops.rfx_ops_dist_init(world, rank, C.c_char_p(ident[0])), "ops_dist_init")
     spec, q = C_DOOR[name]
+    # a grouped answer stays SLICED over the ranks: every rank reads back and returns only its range of the groups (rfx_ops_set_rank_slices; the ranks' tables
+    # end to end are the answer) -- the whole 16 MB result on every rank is a constant that does not shrink with the ranks.  RFX_BENCH_WHOLE_RESULT=1: as before
+    sliced = "by" in q and not os.environ.get("RFX_BENCH_WHOLE_RESULT")
+    L.check(ops.rfx_ops_set_rank_slices(1 if sliced else 0), "ops_set_rank_slices")
     cols = door_columns(eng, spec, rows, row0)
     eng.sync()
     tab = H.device_table(cols)
@@ -916,7 +930,7 @@ def launcher_door(args, name, eng, world, rank, rows, row0, total_rows):
             dist.all_reduce(t)
         return float(t[0]) if isinstance(x, float) else t.cpu()
 
-    checked = door_property_check(name, got, [cols], q, reduce_sum)
+    checked = door_property_check(name, got, [cols], q, reduce_sum, sliced=sliced and world > 1)
     x = C.c_void_p(ops.rfx_ops_exec())
     w_, r_ = C.c_int(), C.c_int()
     if transport is None:
@@ -930,7 +944,10 @@ def launcher_door(args, name, eng, world, rank, rows, row0, total_rows):
     out = {"ms_per_step": dt * 1e3 / args.steps, "rows_per_s": total_rows / (dt / args.steps), "verified": checked, "ranks_seen": transport.world if transport else int(w_.value),
            "result_digest": digest, "reproducible_mode": os.environ.get("RFX_DETERMINISTIC") == "1",
            "collectives_per_query": calls / (args.steps + max(1, args.warmup)),
-           "result": {"groups": len(got[next(iter(got))])} if "by" in q else {"values": [float(v[0]) for v in got.values()]}}
+           "result": ({"groups": int(reduce_sum(float(len(got[next(iter(got))])))) if sliced and world > 1 else len(got[next(iter(got))]),
+                       "returned": "every rank its range of the groups" if sliced and world > 1 else "the whole answer on every rank"}
+                      if "by" in q else {"values": [float(v[0]) for v in got.values()]})}
+    ops.rfx_ops_set_rank_slices(0)
     if transport:
         ops.rfx_exec_set_transport(x, None)
         out["exchange"] = "torch.distributed (gloo) through rfx_transport_t: test plumbing, not a data path"
@@ -1281,7 +1298,7 @@ def main():
                        "result": main_r["result"], "verified": main_r["verified"], "paths": main_r["paths"],
                        "planner": main_r.get("planner"),
                        "door": door["door"] if door else ("rfx_select on this rank's row range as device column handles, the operator layer's context in the RCCL "
-                                                          "communicator (rfx_ops_dist_init): every rank gets the whole answer" if ldoor else
+                                                          "communicator (rfx_ops_dist_init): a grouped answer stays sliced over the ranks (rfx_ops_set_rank_slices)" if ldoor else
                                                           "Engine (ctypes host over the library's planner, results stay on the device)")},
             "roofline": roofline_block(name, head, world),
             "cpu_baseline": cpu,

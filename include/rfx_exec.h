@@ -72,7 +72,7 @@ int rfx_exec_set_transport(rfx_exec_t *x, const rfx_transport_t *t); /* NULL: ba
 /* The inter-process side as the planner itself sees it (the host's transport, else the lead context's RCCL communicator unless that one is process-local):
  * how many processes share the table (1: no exchange), and `bytes` of host memory from each of them in rank order -- for a caller that must agree on a
  * small fact before it builds the query (rfx_select's reproducible sums: one scale for all ranks). */
-int rfx_exec_ranks(rfx_exec_t *x);
+int rfx_exec_ranks(rfx_exec_t *x, int *rank); /* (rank may be NULL) */
 int rfx_exec_allgather_host(rfx_exec_t *x, const void *in, size_t bytes, void *out);
 
 /* ---- the query ---- */
@@ -171,6 +171,10 @@ int rfx_exec_groups_fetch(rfx_exec_t *x, const rfx_groups_t *g, void *dst, const
  * one wait per shard at the end instead of one per column.  Columns above 64 MB go through pinned staging with several host threads
  * writing the destination (first-touch page faults of a freshly allocated vector are taken in parallel). */
 int rfx_exec_groups_fetch_all(rfx_exec_t *x, const rfx_groups_t *g, int n, const void *const *d_srcs, void *const *dsts);
+/* The groups [g0, g0 + n) of a result as a result of its own: a VIEW on the same device blocks (it owns nothing: release the original, not the view), read
+ * through rfx_exec_groups_fetch / _fetch_all like any other.  What one rank of several returns when every rank is to keep only ITS range of the answer
+ * (rfx_ops_set_rank_slices).  Results of one slice only (RFX_EINVAL otherwise). */
+int rfx_exec_groups_window(const rfx_groups_t *g, int64_t g0, int64_t n, rfx_groups_t *out);
 void rfx_exec_groups_free(rfx_exec_t *x, rfx_groups_t *g);
 
 /* ---- join index (index_left_join_obj, core/index.c:2886-2928): d_ids[i] = first right row whose key tuple equals left row i's, else null.

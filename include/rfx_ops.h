@@ -146,6 +146,10 @@ int rfx_ops_set_validation(int mode);
  * pool size, core/pool.c:415-424; the default path's f64 atomics are not).  Costs two more passes over the argument; a cell is rounded to a multiple of
  * 2^(e + b - 62) (2^e > max |x|, 2^b >= rows); a column holding a NaN or an infinity keeps the default path.  DESIGN.md section 4. */
 int rfx_ops_set_deterministic(int on);
+/* One process per device (rfx_ops_dist_init, or a transport on the planner): 1 = a grouped rfx_select returns only THIS rank's range of the groups
+ * (rfx_exec_split(groups, ranks, rank) in the answer's order: the ranks' tables end to end are the answer) instead of the whole answer on every rank; also
+ * RFX_RANK_SLICES=1.  Nothing changes in a process of its own. */
+int rfx_ops_set_rank_slices(int on);
 /* unary_f: I64[17] counters since load: {selects on the GPU, selects delegated to the host, joins on the GPU, joins delegated,
  * uploads, cache hits, stale entries refreshed, operator calls, group scopes sampled, sampled scopes retried exactly,
  * materialised B8 mask passes (RFX_STAT_MASK_PASSES: a fused `where:` tree runs none), uses validated by soft-dirty page bits,

@@ -294,7 +294,8 @@ EXEC_PROTOTYPES = {
     "rfx_exec_split": (None, [C.c_int64, C.c_int, C.c_int, _P(C.c_int64), _P(C.c_int64)]),
     "rfx_exec_comm_init_all": (C.c_int, [_exec]),
     "rfx_exec_set_transport": (C.c_int, [_exec, _P(Transport)]),
-    "rfx_exec_ranks": (C.c_int, [_exec]),
+    "rfx_exec_ranks": (C.c_int, [_exec, _P(C.c_int)]),
+    "rfx_exec_groups_window": (C.c_int, [_P(Groups), C.c_int64, C.c_int64, _P(Groups)]),
     "rfx_exec_allgather_host": (C.c_int, [_exec, C.c_void_p, C.c_size_t, C.c_void_p]),
     "rfx_exec_filter_aggr": (C.c_int, [_exec, _P(Query), _P(Value), _P(C.c_int64)]),
     "rfx_exec_where": (C.c_int, [_exec, _P(Query), _P(Ids)]),

@@ -71,6 +71,29 @@ int rfx_exec_groups_fetch_all(rfx_exec_t *x, const rfx_groups_t *g, int n, const
     }
     return rc;
 }
+int rfx_exec_groups_window(const rfx_groups_t *g, int64_t g0, int64_t n, rfx_groups_t *out) {
+    if (!g || !out || g0 < 0 || n < 0 || g0 + n > g->groups || g->nslices > 1) return RFX_EINVAL;
+    *out = *g;
+    out->nown = 0; /* (a view: the blocks stay the original's) */
+    out->groups = n;
+    out->d_probe = NULL; /* (per row, not per group) */
+#define WIN(p) do { if (p) p = (void *)((char *)(p) + (size_t)g0 * 8); } while (0)
+    WIN(out->d_keys);
+    WIN(out->d_first);
+    for (int k = 0; k < RFX_MAX_KEYS; k++) WIN(out->d_keycols[k]);
+    for (int a = 0; a < RFX_EXEC_MAX_AGGS; a++) WIN(out->d_results[a]);
+    if (out->nslices == 1) {
+        struct rfx_gslice *sl = &out->slice[0];
+        WIN(sl->d_keys);
+        WIN(sl->d_first);
+        for (int k = 0; k < RFX_MAX_KEYS; k++) WIN(sl->d_keycols[k]);
+        for (int a = 0; a < RFX_EXEC_MAX_AGGS; a++) WIN(sl->d_results[a]);
+        sl->g0 = 0;
+        sl->n = n;
+    }
+#undef WIN
+    return RFX_OK;
+}
 int rfx_exec_groups_fetch(rfx_exec_t *x, const rfx_groups_t *g, void *dst, const void *d_src, size_t bytes) {
     if (!x || !g || (!dst && bytes)) return RFX_EINVAL;
     if (g->h_block && (const char *)d_src >= g->d_block && (const char *)d_src + bytes <= g->d_block + g->block_bytes) {

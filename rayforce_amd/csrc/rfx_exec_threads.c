@@ -242,10 +242,12 @@ static int xp_allgather_host(rfx_exec_t *x, const void *in, size_t bytes, void *
     if (x->has_tr) return x->tr.allgather_host(x->tr.user, in, bytes, out);
     return rfx_dist_allgather_host(x->ctx[0], in, bytes, out);
 }
-int rfx_exec_ranks(rfx_exec_t *x) {
+int rfx_exec_ranks(rfx_exec_t *x, int *rank) {
     int w = 1, r = 0;
-    if (!x || !world_rank(x, &w, &r)) return 1;
-    return w > 1 ? w : 1;
+    if (rank) *rank = 0;
+    if (!x || !world_rank(x, &w, &r) || w <= 1) return 1;
+    if (rank) *rank = r;
+    return w;
 }
 int rfx_exec_allgather_host(rfx_exec_t *x, const void *in, size_t bytes, void *out) {
     if (!x || !in || !out || !bytes) return RFX_EINVAL;

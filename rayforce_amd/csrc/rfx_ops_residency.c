@@ -872,7 +872,7 @@ static int det_scale(double amax, int64_t nrows) {
  * on every rank -- the ranks' integer sums are added to each other -- so max |x|, the row count and the "holds a NaN / an infinity" flag are taken over all
  * ranks' ranges (through the planner's own inter-process side: the host's transport or the RCCL communicator).  Exactly ONE small all-gather per rewritten aggregate on every rank, whichever path (cached image / scratch) a rank takes; nothing in one
  * process, however many devices it drives (its shards are looked at together). */
-static int det_ranks(void) { return g_x ? rfx_exec_ranks(g_x) : 1; } /* ranks of a one-process-per-device world this process is one of; 1 otherwise */
+static int det_ranks(void) { return g_x ? rfx_exec_ranks(g_x, NULL) : 1; } /* ranks of a one-process-per-device world this process is one of; 1 otherwise */
 static int det_world_agree(double *amax, int64_t *nrows, int *bad) {
     const int world = det_ranks();
     if (world <= 1) return RFX_OK;

@@ -24,6 +24,7 @@ OPS_PROTOTYPES = {
     "rfx_ops_shards": (C.c_int, []),
     "rfx_ops_set_validation": (C.c_int, [C.c_int]),
     "rfx_ops_set_deterministic": (C.c_int, [C.c_int]),
+    "rfx_ops_set_rank_slices": (C.c_int, [C.c_int]),
     "rfx_ops_dist_init": (C.c_int, [C.c_int, C.c_int, C.c_void_p]),
     "rfx_ops_dist_finalize": (C.c_int, []),
     "rfx_ops_exec": (C.c_void_p, []),

@@ -123,6 +123,56 @@ def _worker(rank, world, port, q):
         assert np.array_equal(r["results"][1].cpu().numpy(), want["c"]) and np.array_equal(r["results"][2].cpu().numpy(), want["m"])
         assert sh.transport.calls > 0
         sh.close()
+        # The same two ranks through the C OPERATOR (rfx_select on this rank's rows as host columns, the planner's exchanges through the transport hooks),
+        # every rank keeping only ITS range of the groups (rfx_ops_set_rank_slices): the ranks' tables end to end are the oracle's answer, in its order --
+        # in the default mode and with reproducible sums (one more small gather: the ranks agree on the scale)
+        import ctypes as C
+        from rayforce_amd import hostobj as H, _lib as L
+        from rayforce_amd.dist import _TorchTransport
+        ops = H.lib()
+        ops.rfx_host_bind()
+        v0 = H.vector(np.arange(4, dtype=np.int64))  # (any operator call brings the layer's context and planner up)
+        ops.rfx_host_drop(ops.rfx_sum(v0))
+        ops.rfx_host_drop(v0)
+        xo = C.c_void_p(ops.rfx_ops_exec())
+
+        class _OpsCtx:
+            lib = ops
+            _ctx = C.c_void_p(ops.rfx_exec_ctx(xo, 0))
+        tr = _TorchTransport(_OpsCtx, None)
+        L.check(ops.rfx_exec_set_transport(xo, C.byref(tr.struct)), "exec_set_transport")
+        rk = C.c_int(-1)
+        assert ops.rfx_exec_ranks(xo, C.byref(rk)) == 2 and rk.value == rank
+        whole = dict(full, w=rfo.gen_f64(n, 6) * 100.0 - 30.0)
+        tab = H.table({c: np.ascontiguousarray(x[cut[rank]:cut[rank + 1]]) for c, x in whole.items()})
+        qd = {"s": ("sum", "w"), "x": ("avg", "w"), "c": ("count", "a"), "m": ("max", "a"), "where": (">", "w", -10.0), "by": "k"}
+        d = H.select_dict(qd, tab)
+        want = rfo.select({"from": whole, **qd})
+        ncalls = {}
+        for slices in (0, 1):
+            for det in (0, 1):
+                assert ops.rfx_ops_set_rank_slices(slices) == 0 and ops.rfx_ops_set_deterministic(det) == 0
+                c0 = tr.calls
+                r = ops.rfx_select(d)
+                assert r and not H.is_error(r), H.error_text(r)
+                assert int(ops.rfx_last_select_on_gpu()) == 1
+                ncalls[slices, det] = tr.calls - c0
+                got = H.table_to_numpy(r)
+                ops.rfx_host_drop(r)
+                g0, gn = C.c_int64(0), C.c_int64(len(want["k"]))
+                if slices:
+                    ops.rfx_exec_split(len(want["k"]), 2, rank, C.byref(g0), C.byref(gn))
+                    assert 0 < gn.value < len(want["k"])
+                for nm, w in want.items():
+                    w = w[g0.value:g0.value + gn.value]
+                    assert got[nm].shape == w.shape, (slices, det, nm, got[nm].shape, w.shape)
+                    assert np.allclose(got[nm], w, rtol=1e-9, atol=1e-9) if w.dtype == np.float64 else np.array_equal(got[nm], w), (slices, det, nm)
+        assert ncalls[0, 0] >= 3 and ncalls[1, 0] == ncalls[0, 0] and ncalls[0, 1] == ncalls[0, 0] + 2 == ncalls[1, 1], ncalls  # (one gather per rewritten aggregate)
+        ops.rfx_ops_set_rank_slices(0)
+        ops.rfx_ops_set_deterministic(0)
+        ops.rfx_exec_set_transport(xo, None)
+        for o in (d, tab):
+            ops.rfx_host_drop(o)
         eng.close()
         q.put((rank, "ok"))
     except Exception:  # noqa: BLE001
@@ -247,6 +297,8 @@ def test_bench_under_the_launcher_two_ranks_one_gpu(workload):
     assert rec["door"]["verified"] and rec["door"]["collectives_per_query"] >= 1 and "gloo" in rec["door"]["exchange"]
     if workload == "c3w":
         assert 950_000 < rec["config"]["result"]["groups"] <= 1_000_000 and rec["door"]["collectives_per_query"] == 3  # scope, tables, first rows' order
+        # every rank read back and returned only ITS range of the groups (rfx_ops_set_rank_slices); the property check folded the ranks' pieces
+        assert rec["config"]["result"]["returned"].startswith("every rank its range") and "over the ranks' slices" in rec["door"]["verified"]
 
 
 def test_reproducible_sums_across_rank_counts():
@@ -257,7 +309,7 @@ def test_reproducible_sums_across_rank_counts():
     import sys
     recs = []
     for ranks in (2, 1):
-        env = dict(os.environ, RFX_DETERMINISTIC="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        env = dict(os.environ, RFX_DETERMINISTIC="1", HSA_ENABLE_IPC_MODE_LEGACY="0", RFX_BENCH_WHOLE_RESULT="1")  # (the digest is of the whole answer)
         env.update({"RFX_BENCH_SAME_DEVICE": "1", "RFX_BENCH_BACKEND": "gloo"} if ranks > 1 else {"RFX_BENCH_FORCE_LAUNCHER_DOOR": "1"})
         cmd = [os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--steps", "2", "--warmup", "1", "--rows", "30000001", "--workload", "c3w", "--no-also", "--no-cpu-baseline", "--no-predict"]
         if ranks > 1:
