@@ -635,37 +635,42 @@ def c_door(name, eng, rows, steps, warmup, device_columns=False):
     del cols, want, keep
     det = None
     if "by" in q and not device_columns and os.environ.get("RFX_DETERMINISTIC") is None and os.environ.get("RFX_VALIDATE") is None:
-        # the same query in the reproducible mode (grouped f64 sums as integer sums over the column's fixed-point image: DESIGN.md section 4): the first call
-        # makes the image (two passes over the column, kept with the resident copy), the later ones run on it
-        assert ops.rfx_ops_set_deterministic(1) == 0
-        try:
-            t0 = time.perf_counter()
-            r = ops.rfx_select(d)
-            first_ms = (time.perf_counter() - t0) * 1e3
-            assert r and not H.is_error(r), H.error_text(r)
-            ops.rfx_host_drop(r)
-            ddt, dgot = door_run(ops, H, d, min(steps, 10), 2)
-            dsteps = dict(door_run.last_steps_ms)
-            r = ops.rfx_select(d)
-            again = H.table_to_numpy(r)
-            ops.rfx_host_drop(r)
-            import numpy as np
-            same_bits = all(np.array_equal(np.ascontiguousarray(dgot[c]).view(np.uint8), np.ascontiguousarray(again[c]).view(np.uint8)) for c in dgot)
-            close = all(bool(np.all(np.abs(dgot[c] - got[c]) <= 1e-9 * np.maximum(np.abs(got[c]), 1e-300))) if got[c].dtype == np.float64 else bool(np.array_equal(dgot[c], got[c]))
-                        for c in got)
-            if not (same_bits and close):
-                raise SystemExit(f"bench.py: rfx_select({name}) in the reproducible mode: bit-identical between two calls {same_bits}, within 1e-9 of the default path {close}")
-            st = H.to_numpy(ops.rfx_stats(0))
+        # the same query in the reproducible modes (grouped f64 sums as integer sums over the column's fixed-point image, one limb or two: DESIGN.md section 4):
+        # the first call makes the image(s) (kept with the resident copy), the later ones run on them
+        import numpy as np
+        det = {}
+        for mode, label in ((1, "one_limb"), (2, "two_limbs")):
+            st0 = H.to_numpy(ops.rfx_stats(0))
+            assert ops.rfx_ops_set_deterministic(mode) == 0
             try:
-                dk = door_kernels(ops, H, d)
-            except Exception as e:  # noqa: BLE001
-                log(f"[bench] door_kernels (reproducible mode) failed: {e}")
-                dk = []
-            det = {"first_call_ms": first_ms, "kernels_ms": dk, "phases_ms": door_phases(ops, H, d), "median_ms": dsteps["median"], "ms_per_step": ddt * 1e3 / min(steps, 10), "steps_ms_in_order": dsteps["in_order"],
-                   "images_made": int(st[15]), "images_found_again": int(st[16]),
-                   "verified": "two calls bit-identical; every column within 1e-9 of the default path's"}
-        finally:
-            ops.rfx_ops_set_deterministic(0)
+                t0 = time.perf_counter()
+                r = ops.rfx_select(d)
+                first_ms = (time.perf_counter() - t0) * 1e3
+                assert r and not H.is_error(r), H.error_text(r)
+                ops.rfx_host_drop(r)
+                ddt, dgot = door_run(ops, H, d, min(steps, 10), 2)
+                dsteps = dict(door_run.last_steps_ms)
+                r = ops.rfx_select(d)
+                again = H.table_to_numpy(r)
+                ops.rfx_host_drop(r)
+                same_bits = all(np.array_equal(np.ascontiguousarray(dgot[c]).view(np.uint8), np.ascontiguousarray(again[c]).view(np.uint8)) for c in dgot)
+                err = max([float(np.max(np.abs(dgot[c] - got[c]) / np.maximum(np.abs(got[c]), 1e-300))) for c in got if got[c].dtype == np.float64] + [0.0])
+                exact = all(bool(np.array_equal(dgot[c], got[c])) for c in got if got[c].dtype != np.float64)
+                if not (same_bits and exact and err <= 1e-9):
+                    raise SystemExit(f"bench.py: rfx_select({name}) in reproducible mode {mode}: bit-identical between two calls {same_bits}, "
+                                     f"largest relative distance from the default path {err:.3g}")
+                st = H.to_numpy(ops.rfx_stats(0))
+                try:
+                    dk = door_kernels(ops, H, d)
+                except Exception as e:  # noqa: BLE001
+                    log(f"[bench] door_kernels (reproducible mode) failed: {e}")
+                    dk = []
+                det[label] = {"first_call_ms": first_ms, "kernels_ms": dk, "phases_ms": door_phases(ops, H, d),
+                              "median_ms": dsteps["median"], "ms_per_step": ddt * 1e3 / min(steps, 10), "steps_ms_in_order": dsteps["in_order"],
+                              "images_made": int(st[15] - st0[15]), "images_found_again": int(st[16] - st0[16]), "largest_relative_distance_from_the_default_path": err,
+                              "verified": "two calls bit-identical; every column within 1e-9 of the default path's"}
+            finally:
+                ops.rfx_ops_set_deterministic(0)
     for o in ([pin, ops.rfx_unpin(tab)] if pin else []) + [d, tab]:
         ops.rfx_host_drop(o)
     ops.rfx_cache_clear()

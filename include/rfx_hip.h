@@ -585,6 +585,8 @@ int rfx_hip_update_group(rfx_ctx_t *ctx, void *d_col, const int64_t *d_key, cons
  * d_out may be d_in. */
 int rfx_hip_absmax_f64(rfx_ctx_t *ctx, const double *d_in, int64_t n, double *absmax, int *nonfinite);
 int rfx_hip_fix_f64(rfx_ctx_t *ctx, const double *d_in, int64_t n, int k, int64_t *d_out);
+/* ... and the part of every cell that rfx_hip_fix_f64 rounded away, as a second limb: llrint((x * 2^k - rint(x * 2^k)) * 2^m), 0 <= m <= 62 (not in place) */
+int rfx_hip_fix_f64_low(rfx_ctx_t *ctx, const double *d_in, int64_t n, int k, int m, int64_t *d_out);
 
 /* ---- bucketed group keys: (xbar col width), XBARI64 core/ops.h:192-193 ----
  * d_out[r] = null for a null input, else the largest multiple of `width` (> 0) that is <= d_col[r].  Group on the result

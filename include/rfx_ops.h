@@ -143,9 +143,12 @@ rfx_obj_p rfx_invalidate(rfx_obj_p table_or_column);
 int rfx_ops_set_validation(int mode);
 /* Reproducible grouped f64 sums (opt-in; also RFX_DETERMINISTIC=1): rfx_select runs every (sum x) / (avg x) over f64 under by: as an INTEGER sum over x
  * scaled by a power of two and rounded once per cell -- the same bits whatever order the rows reach their group in (the reference is bit-stable for a fixed
- * pool size, core/pool.c:415-424; the default path's f64 atomics are not).  Costs two more passes over the argument; a cell is rounded to a multiple of
- * 2^(e + b - 62) (2^e > max |x|, 2^b >= rows); a column holding a NaN or an infinity keeps the default path.  DESIGN.md section 4. */
-int rfx_ops_set_deterministic(int on);
+ * pool size, core/pool.c:415-424; the default path's f64 atomics are not).  mode 1: ONE i64 limb -- a cell is rounded to a multiple of 2^(e + b - 62)
+ * (2^e > max |x|, 2^b >= rows): absolute, so a group of values far below the column's largest loses relative precision; mode 2 (RFX_DETERMINISTIC=2): a
+ * SECOND limb adds up what the first one's cells rounded away, scaled by 2^(62 - b) more -- 2^(e + 2b - 124) per cell, below an f64 sum's own rounding for
+ * any data whose magnitudes span less than ~2^60; one more i64 sum per aggregate.  The images of a resident column are made once and cached with it (8 bytes
+ * of HBM per row and limb); a column holding a NaN or an infinity keeps the default path.  DESIGN.md section 4. */
+int rfx_ops_set_deterministic(int mode);
 /* One process per device (rfx_ops_dist_init, or a transport on the planner): 1 = a grouped rfx_select returns only THIS rank's range of the groups
  * (rfx_exec_split(groups, ranks, rank) in the answer's order: the ranks' tables end to end are the answer) instead of the whole answer on every rank; also
  * RFX_RANK_SLICES=1.  Nothing changes in a process of its own. */

@@ -328,6 +328,21 @@ extern "C" int rfx_hip_absmax_f64(rfx_ctx_t *c, const double *d_in, int64_t n, d
     *nonfinite = h[1] != 0;
     return RFX_OK;
 }
+// two limbs: y = x * 2^k (exact), h = rint(y) -- limb 0 -- and limb 1 = llrint((y - h) * 2^m): the part of the cell the first limb rounded away (y - h is exact)
+__global__ __launch_bounds__(RFX_BLOCK) void k_fix_f64_low(const double *in, i64 n, int k, int m, i64 *out) {
+    for (i64 i = blockIdx.x * (i64)RFX_BLOCK + threadIdx.x; i < n; i += (i64)gridDim.x * RFX_BLOCK) {
+        const double y = __builtin_ldexp(in[i], k);
+        out[i] = (i64)__builtin_llrint(__builtin_ldexp(y - __builtin_rint(y), m));
+    }
+}
+extern "C" int rfx_hip_fix_f64_low(rfx_ctx_t *c, const double *d_in, int64_t n, int k, int m, int64_t *d_out) {
+    RFX_REQUIRE(c, RFX_EINVAL, "NULL argument");
+    if (n <= 0) return RFX_OK;
+    RFX_REQUIRE(d_in && d_out && k > -1100 && k < 1100 && m >= 0 && m <= 62, RFX_EINVAL, "bad argument");
+    hipLaunchKernelGGL(k_fix_f64_low, dim3(c->num_cus * 8), dim3(RFX_BLOCK), 0, c->stream, d_in, (i64)n, k, m, (i64 *)d_out);
+    RFX_HIP_CHECK(hipGetLastError());
+    return RFX_OK;
+}
 extern "C" int rfx_hip_fix_f64(rfx_ctx_t *c, const double *d_in, int64_t n, int k, int64_t *d_out) {
     RFX_REQUIRE(c, RFX_EINVAL, "ctx is NULL");
     if (n <= 0) return RFX_OK;

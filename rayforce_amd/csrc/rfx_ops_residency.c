@@ -153,7 +153,8 @@ typedef struct {
     obj_p owner;       /* validation by ownership: OUR reference to the host vector (a parted column: to its LIST); NULL in checksum mode */
     int amax_ok;       /* reproducible sums (resident_fixed): 1 = amax is max |x| over this f64 copy, 2 = the copy holds a NaN / an infinity; 0 = not looked at */
     double amax;
-    int fix_k;         /* a DERIVED entry (type code + 256): this column's fixed-point image llrint(x * 2^fix_k) as i64, owned like the copy it was made from */
+    int fix_k, fix_m;  /* a DERIVED entry (type code + 256, + 512 for the second limb): this column's fixed-point image llrint(x * 2^fix_k) as i64 (the second limb:
+                        * what that rounded away, scaled by 2^fix_m more), owned like the copy it was made from */
 } resident_t;
 static resident_t *g_res;
 static int g_nres, g_capres;
@@ -862,10 +863,11 @@ static resident_t *resident_entry(const void *dev) {
 }
 /* Reproducible grouped f64 sums (rfx_ops_select.c: det_rewrite): the scale of a column's fixed-point image.  2^e > max |x|, 2^b >= rows: no sum of `rows`
  * cells llrint(x * 2^k), k = 62 - e - b, leaves 63 bits -- and k depends on the column and the table's length alone, not on how the rows are sharded. */
-static int det_scale(double amax, int64_t nrows) {
+static int det_scale(double amax, int64_t nrows, int *m) {
     int e = 0, b = 0;
     if (amax > 0.0) (void)frexp(amax, &e); /* amax = f * 2^e, 0.5 <= f < 1 */
     while (b < 62 && ((int64_t)1 << b) < nrows) b++;
+    if (m) *m = 62 - b; /* the second limb: |cell| <= 2^(m - 1), `rows` of them stay inside 63 bits too */
     return 62 - e - b;
 }
 /* One process per device (rfx_ops_dist_init: every rank holds a row range of the table and the planner merges the ranks' tables): the scale must be the SAME
@@ -895,7 +897,7 @@ static int det_world_agree(double *amax, int64_t *nrows, int *bad) {
  * the reproducible mode runs at the default path's speed; the price is a second 8 bytes per row of HBM for the f64 columns such queries sum.  1: not a
  * column this applies to (a device vector, checksum mode) -- det_rewrite's per-query scratch path decides; 2: a NaN / an infinity inside (on some rank): this
  * aggregate keeps the default path. */
-static int resident_fixed(const void *base_dev, int64_t nrows, int *k_out, const void **dev_out) {
+static int resident_fixed(const void *base_dev, int64_t nrows, int limbs, int *k_out, int *m_out, const void **dev_out /* [limbs] */) {
     resident_t *re = resident_entry(base_dev);
     if (!re || !re->owner || re->type != RFX_TYPE_F64 || re->len != nrows || nrows <= 0) return 1;
     int rc = RFX_OK;
@@ -924,49 +926,64 @@ static int resident_fixed(const void *base_dev, int64_t nrows, int *k_out, const
     int bad = re->amax_ok != 1;
     rc = det_world_agree(&amax, &world_rows, &bad);
     if (rc != RFX_OK) return rc;
-    const int k = det_scale(amax, world_rows);
+    int m = 0;
+    const int k = det_scale(amax, world_rows, &m);
     if (bad || k <= -1000 || k >= 1000) return 2;
-    for (int i = 0; i < g_nres; i++) {
-        if (g_res[i].owner != re->owner || g_res[i].type != RFX_TYPE_F64 + 256) continue;
-        if (g_res[i].len != nrows || g_res[i].fix_k != k) { res_free(i); re = resident_entry(base_dev); break; } /* (cannot happen: the owner's cells do not change) */
-        g_res[i].tick = ++g_tick;
-        g_res[i].epoch = g_epoch;
-        g_fix_hits++;
-        *k_out = k;
-        *dev_out = g_res[i].dev;
-        return qcol_add(g_res[i].devs);
-    }
-    if (!re) return 1;
-    const resident_t base = *re; /* (the table of entries may move below) */
-    res_make_room((size_t)nrows * 8);
-    void *devs[RFX_MAX_SHARDS];
-    rc = shards_alloc(devs, nrows, 8, 0);
-    if (rc != RFX_OK) return rc;
-    for (int s = 0; s < g_nshards && rc == RFX_OK; s++) {
-        int64_t n;
-        rfx_exec_split(nrows, g_nshards, s, NULL, &n);
-        if (g_nshards == 1) n = nrows;
-        if (n <= 0) continue;
-        if (g_nshards > 1) rfx_hip_ctx_bind_thread(g_ctxs[s]);
-        rc = rfx_hip_fix_f64(g_ctxs[s], (const double *)base.devs[s], n, k, (int64_t *)devs[s]);
-    }
-    if (rc != RFX_OK) {
-        for (int s = 0; s < g_nshards; s++) { if (g_nshards > 1) rfx_hip_ctx_bind_thread(g_ctxs[s]); rfx_hip_free(g_ctxs[s], devs[s]); }
-        if (g_nshards > 1) rfx_hip_ctx_bind_thread(g_ctx);
-        return rc;
-    }
-    if (g_nshards > 1) rfx_hip_ctx_bind_thread(g_ctx);
-    resident_t e;
-    memset(&e, 0, sizeof(e));
-    e.host = base.host; e.len = nrows; e.type = RFX_TYPE_F64 + 256; e.dev = devs[0]; e.bytes = base.bytes; e.tick = ++g_tick; e.epoch = g_epoch; e.dbytes = (size_t)nrows * 8;
-    e.owner = H.clone(base.owner);
-    e.fix_k = k;
-    for (int s = 0; s < g_nshards; s++) e.devs[s] = devs[s];
-    res_append(&e);
-    g_fix_built++;
     *k_out = k;
-    *dev_out = devs[0];
-    return qcol_add(devs);
+    *m_out = m;
+    for (int limb = 0; limb < limbs; limb++) {
+        const int itype = RFX_TYPE_F64 + 256 * (limb + 1);
+        int found = 0;
+        re = resident_entry(base_dev);
+        if (!re) return 1;
+        for (int i = 0; i < g_nres && !found; i++) {
+            if (g_res[i].owner != re->owner || g_res[i].type != itype) continue;
+            if (g_res[i].len != nrows || g_res[i].fix_k != k || g_res[i].fix_m != m) { res_free(i); break; } /* (one process: cannot happen, the owner's cells do not change; ranks: another rank's did) */
+            g_res[i].tick = ++g_tick;
+            g_res[i].epoch = g_epoch;
+            g_fix_hits++;
+            dev_out[limb] = g_res[i].dev;
+            rc = qcol_add(g_res[i].devs);
+            if (rc != RFX_OK) return rc;
+            found = 1;
+        }
+        if (found) continue;
+        re = resident_entry(base_dev);
+        if (!re) return 1;
+        const resident_t base = *re; /* (the table of entries may move below) */
+        res_make_room((size_t)nrows * 8);
+        void *devs[RFX_MAX_SHARDS];
+        rc = shards_alloc(devs, nrows, 8, 0);
+        if (rc != RFX_OK) return rc;
+        for (int s = 0; s < g_nshards && rc == RFX_OK; s++) {
+            int64_t n;
+            rfx_exec_split(nrows, g_nshards, s, NULL, &n);
+            if (g_nshards == 1) n = nrows;
+            if (n <= 0) continue;
+            if (g_nshards > 1) rfx_hip_ctx_bind_thread(g_ctxs[s]);
+            rc = limb ? rfx_hip_fix_f64_low(g_ctxs[s], (const double *)base.devs[s], n, k, m, (int64_t *)devs[s])
+                      : rfx_hip_fix_f64(g_ctxs[s], (const double *)base.devs[s], n, k, (int64_t *)devs[s]);
+        }
+        if (rc != RFX_OK) {
+            for (int s = 0; s < g_nshards; s++) { if (g_nshards > 1) rfx_hip_ctx_bind_thread(g_ctxs[s]); rfx_hip_free(g_ctxs[s], devs[s]); }
+            if (g_nshards > 1) rfx_hip_ctx_bind_thread(g_ctx);
+            return rc;
+        }
+        if (g_nshards > 1) rfx_hip_ctx_bind_thread(g_ctx);
+        resident_t e;
+        memset(&e, 0, sizeof(e));
+        e.host = base.host; e.len = nrows; e.type = itype; e.dev = devs[0]; e.bytes = base.bytes; e.tick = ++g_tick; e.epoch = g_epoch; e.dbytes = (size_t)nrows * 8;
+        e.owner = H.clone(base.owner);
+        e.fix_k = k;
+        e.fix_m = m;
+        for (int s = 0; s < g_nshards; s++) e.devs[s] = devs[s];
+        res_append(&e);
+        g_fix_built++;
+        dev_out[limb] = devs[0];
+        rc = qcol_add(devs);
+        if (rc != RFX_OK) return rc;
+    }
+    return RFX_OK;
 }
 /* drop every cached copy that overlaps the vector's payload */
 static void invalidate_payload(obj_p v) {

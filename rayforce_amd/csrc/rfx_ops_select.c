@@ -25,17 +25,20 @@ static void tm_print(void) {
 enum { SEL_GO = 0, SEL_OUT = 1, SEL_DONE = 2 };
 /* the output mappings {name: (aggr column | expression)} of a select dict (everything but from: where: by: take:) as aggregate
  * descriptors over resident device columns */
+#define SEL_AGGS (2 * RFX_MAX_AGGS + 1) /* the query's own + the hidden ones of the reproducible sums: a second limb per rewritten aggregate, one COUNT */
 typedef struct {
-    rfx_agg_t aggs[RFX_MAX_AGGS];
+    rfx_agg_t aggs[SEL_AGGS];
     rfx_xnode_t xnodes[RFX_MAX_AGGS][RFX_MAX_XNODES];
     int64_t names[RFX_MAX_AGGS];
     int outtype[RFX_MAX_AGGS];
     int nagg;
-    /* reproducible grouped f64 sums (det_rewrite): aggregate a runs as an i64 SUM over its argument scaled by 2^det_k[a]; an average also needs the groups'
-     * row counts: ONE hidden COUNT aggregate behind the query's own (index nagg) */
+    /* reproducible grouped f64 sums (det_rewrite): aggregate a runs as an i64 SUM over its argument scaled by 2^det_k[a]; with two limbs a second, hidden
+     * i64 SUM (aggregate det_lo[a], behind the query's own) adds up what the first limb's cells rounded away, scaled by 2^det_m[a] more; an average also
+     * needs the groups' row counts: ONE hidden COUNT aggregate (det_cnt) */
     unsigned char det_on[RFX_MAX_AGGS], det_avg[RFX_MAX_AGGS];
-    int det_k[RFX_MAX_AGGS];
-    int nhidden;
+    signed char det_lo[RFX_MAX_AGGS];
+    int det_k[RFX_MAX_AGGS], det_m[RFX_MAX_AGGS];
+    int nhidden, det_cnt;
 } sel_maps_t;
 /* result cells of an aggregate over a widened 4-byte column, back in the column's own width: the i64 null and the i64 identities of an
  * all-null group (core/aggr.c:1246) become the 4-byte ones */
@@ -51,6 +54,8 @@ static int sel_mappings(obj_p tab, obj_p dkeys, obj_p dvals, int grouped, sel_ma
     const int64_t s_from = H.intern("from", 4), s_where = H.intern("where", 5), s_by = H.intern("by", 2), s_take = H.intern("take", 4);
     M->nagg = 0;
     M->nhidden = 0;
+    M->det_cnt = -1;
+    memset(M->det_lo, -1, sizeof(M->det_lo));
     memset(M->det_on, 0, sizeof(M->det_on));
     memset(M->det_avg, 0, sizeof(M->det_avg));
     for (int64_t i = 0; i < dkeys->len; i++) {
@@ -115,9 +120,9 @@ typedef struct {
  * sel_key_columns_plan makes the vectors and names (device column, host destination) pairs, sel_key_columns_finish narrows / decodes) */
 typedef struct {
     int n;
-    const void *src[RFX_MAX_KEYS + RFX_MAX_AGGS];
-    void *dst[RFX_MAX_KEYS + RFX_MAX_AGGS];
-    void *tmp[RFX_MAX_KEYS + RFX_MAX_AGGS]; /* 8-byte staging of a column whose vector is 4 bytes wide (freed by the caller) */
+    const void *src[RFX_MAX_KEYS + SEL_AGGS];
+    void *dst[RFX_MAX_KEYS + SEL_AGGS];
+    void *tmp[RFX_MAX_KEYS + SEL_AGGS]; /* 8-byte staging of a column whose vector is 4 bytes wide (freed by the caller) */
     int ntmp;
 } sel_fetch_t;
 static int sel_fetch_add(sel_fetch_t *F, const void *src, void *dst) {
@@ -264,12 +269,13 @@ static int g_det = -1;
 static int det_mode(void) {
     if (g_det < 0) {
         const char *e = getenv("RFX_DETERMINISTIC");
-        g_det = e && atoi(e) != 0;
+        g_det = e ? atoi(e) : 0;
+        if (g_det < 0 || g_det > 2) g_det = 1;
     }
     return g_det;
 }
-int rfx_ops_set_deterministic(int on) {
-    g_det = on ? 1 : 0;
+int rfx_ops_set_deterministic(int mode) {
+    g_det = mode <= 0 ? 0 : (mode >= 2 ? 2 : 1);
     return RFX_OK;
 }
 /* One process per device, every rank a row range of the table (rfx_ops_dist_init / a transport): by default every rank's rfx_select returns the WHOLE answer
@@ -292,109 +298,122 @@ static const void *shard_piece(const void *p, int s);
 /* 0: done (aggregates rewritten where possible), -2: device failure */
 static int det_rewrite(sel_maps_t *M, int64_t nrows) {
     if (nrows <= 0 && det_ranks() == 1) return 0; /* (a rank without rows still takes part in the ranks' agreement on the scale, and folds the same aggregates) */
+    const int limbs = det_mode() >= 2 ? 2 : 1;
     int need_count = 0, count_type = RFX_I64;
     const void *count_col = NULL;
     for (int a = 0; a < M->nagg; a++) {
         rfx_agg_t *ag = &M->aggs[a];
         if (!(ag->kind == RFX_AGG_SUM || ag->kind == RFX_AGG_AVG) || rfx_agg_input_type(ag) != RFX_F64) continue;
-        if (ag->kind == RFX_AGG_AVG && M->nagg + 1 > RFX_MAX_AGGS) continue; /* (no room for the hidden count: this average stays as it is) */
-        if (g_nqtmp >= (int)(sizeof(g_qtmp) / sizeof(g_qtmp[0]))) continue;
-        const int is_expr = ag->nxnodes > 0 || ag->xop != RFX_X_NONE;
+        if (g_nqtmp + limbs > (int)(sizeof(g_qtmp) / sizeof(g_qtmp[0]))) continue;
+        const int is_expr = ag->nxnodes > 0 || ag->xop != RFX_X_NONE, is_avg = ag->kind == RFX_AGG_AVG;
+        int k = 0, m = 0, done = 0;
+        const void *img[2] = {NULL, NULL};
         if (!is_expr) { /* a plain column the cache holds by ownership: its fixed-point image is made ONCE and kept with it (resident_fixed) */
-            int k = 0;
-            const void *img = NULL;
-            const int frc = resident_fixed(ag->d_col, nrows, &k, &img);
+            const int frc = resident_fixed(ag->d_col, nrows, limbs, &k, &m, img);
             if (frc == 2) continue; /* (a NaN / an infinity in the column: the default path and its poisoning rules) */
             if (frc != RFX_OK && frc != 1) return -2;
             if (frc == RFX_OK) {
                 if (!count_col) count_col = ag->d_col, count_type = ag->col_type;
-                M->det_on[a] = 1;
-                M->det_avg[a] = ag->kind == RFX_AGG_AVG;
-                M->det_k[a] = k;
-                need_count |= M->det_avg[a];
-                memset(ag, 0, sizeof(*ag));
-                ag->d_col = img;
-                ag->col_type = RFX_I64;
-                ag->kind = RFX_AGG_SUM;
-                continue;
+                done = 1;
             }
         }
-        /* otherwise (an expression; a device vector; checksum mode) the argument as ONE f64 scratch column of this query, every shard its rows: an
-         * expression evaluated, a plain column read where it lies */
-        void *devs[RFX_MAX_SHARDS];
-        if (shards_alloc(devs, nrows, 8, 0) != RFX_OK) return -2;
-        memset(&g_qtmp[g_nqtmp], 0, sizeof(g_qtmp[0]));
-        for (int s = 0; s < g_nshards; s++) g_qtmp[g_nqtmp].d[s] = devs[s];
-        g_nqtmp++; /* (released with the query's scratch) */
-        int rc = RFX_OK, bad = 0, f64_out = 1;
-        double mx = 0.0;
-        for (int s = 0; s < g_nshards && rc == RFX_OK; s++) {
-            int64_t n;
-            rfx_exec_split(nrows, g_nshards, s, NULL, &n);
-            if (g_nshards == 1) n = nrows;
-            if (n <= 0) continue;
-            if (g_nshards > 1) rfx_hip_ctx_bind_thread(g_ctxs[s]);
-            const void *src = shard_piece(ag->d_col, s);
-            if (is_expr) {
-                rfx_agg_t as = *ag;
-                rfx_xnode_t xn[RFX_MAX_XNODES];
-                as.d_col = shard_piece(ag->d_col, s);
-                as.d_xrhs_col = shard_piece(ag->d_xrhs_col, s);
-                for (int j = 0; j < ag->nxnodes && j < RFX_MAX_XNODES; j++) {
-                    xn[j] = ag->xnodes[j];
-                    if (xn[j].l.kind == RFX_XK_COL) xn[j].l.d_col = shard_piece(ag->xnodes[j].l.d_col, s);
-                    if (xn[j].r.kind == RFX_XK_COL) xn[j].r.d_col = shard_piece(ag->xnodes[j].r.d_col, s);
-                }
-                if (ag->nxnodes > 0) as.xnodes = xn;
-                int32_t ot = RFX_I64;
-                rc = rfx_hip_eval_expr(g_ctxs[s], &as, n, devs[s], &ot);
-                if (ot != RFX_F64) f64_out = 0;
-                src = devs[s];
+        if (!done) {
+            /* otherwise (an expression; a device vector; checksum mode) the argument as ONE f64 scratch column of this query, every shard its rows: an
+             * expression evaluated, a plain column read where it lies -- and the image(s) made from it */
+            void *devs[2][RFX_MAX_SHARDS];
+            for (int l = 0; l < limbs; l++) {
+                if (shards_alloc(devs[l], nrows, 8, 0) != RFX_OK) return -2;
+                memset(&g_qtmp[g_nqtmp], 0, sizeof(g_qtmp[0]));
+                for (int s = 0; s < g_nshards; s++) g_qtmp[g_nqtmp].d[s] = devs[l][s];
+                g_nqtmp++; /* (released with the query's scratch) */
             }
-            double m1 = 0.0;
-            int b1 = 0;
-            if (rc == RFX_OK && f64_out) rc = rfx_hip_absmax_f64(g_ctxs[s], (const double *)src, n, &m1, &b1);
-            mx = m1 > mx ? m1 : mx;
-            bad |= b1;
-        }
-        int64_t world_rows = nrows;
-        bad |= !f64_out;
-        if (rc == RFX_OK) rc = det_world_agree(&mx, &world_rows, &bad);
-        if (rc == RFX_OK && !bad) {
-            const int k = det_scale(mx, world_rows);
-            if (k > -1000 && k < 1000) {
-                for (int s = 0; s < g_nshards && rc == RFX_OK; s++) {
-                    int64_t n;
-                    rfx_exec_split(nrows, g_nshards, s, NULL, &n);
-                    if (g_nshards == 1) n = nrows;
-                    if (n <= 0) continue;
-                    if (g_nshards > 1) rfx_hip_ctx_bind_thread(g_ctxs[s]);
-                    rc = rfx_hip_fix_f64(g_ctxs[s], (const double *)(is_expr ? devs[s] : shard_piece(ag->d_col, s)), n, k, (int64_t *)devs[s]);
+            int rc = RFX_OK, bad = 0, f64_out = 1;
+            double mx = 0.0;
+            for (int s = 0; s < g_nshards && rc == RFX_OK; s++) {
+                int64_t n;
+                rfx_exec_split(nrows, g_nshards, s, NULL, &n);
+                if (g_nshards == 1) n = nrows;
+                if (n <= 0) continue;
+                if (g_nshards > 1) rfx_hip_ctx_bind_thread(g_ctxs[s]);
+                const void *src = shard_piece(ag->d_col, s);
+                if (is_expr) {
+                    rfx_agg_t as = *ag;
+                    rfx_xnode_t xn[RFX_MAX_XNODES];
+                    as.d_col = shard_piece(ag->d_col, s);
+                    as.d_xrhs_col = shard_piece(ag->d_xrhs_col, s);
+                    for (int j = 0; j < ag->nxnodes && j < RFX_MAX_XNODES; j++) {
+                        xn[j] = ag->xnodes[j];
+                        if (xn[j].l.kind == RFX_XK_COL) xn[j].l.d_col = shard_piece(ag->xnodes[j].l.d_col, s);
+                        if (xn[j].r.kind == RFX_XK_COL) xn[j].r.d_col = shard_piece(ag->xnodes[j].r.d_col, s);
+                    }
+                    if (ag->nxnodes > 0) as.xnodes = xn;
+                    int32_t ot = RFX_I64;
+                    rc = rfx_hip_eval_expr(g_ctxs[s], &as, n, devs[0][s], &ot);
+                    if (ot != RFX_F64) f64_out = 0;
+                    src = devs[0][s];
                 }
-                if (rc == RFX_OK && qcol_add(devs) == RFX_OK) {
-                    M->det_on[a] = 1;
-                    M->det_avg[a] = ag->kind == RFX_AGG_AVG;
-                    M->det_k[a] = k;
-                    need_count |= M->det_avg[a];
-                    memset(ag, 0, sizeof(*ag));
-                    ag->d_col = devs[0];
-                    ag->col_type = RFX_I64;
-                    ag->kind = RFX_AGG_SUM;
+                double m1 = 0.0;
+                int b1 = 0;
+                if (rc == RFX_OK && f64_out) rc = rfx_hip_absmax_f64(g_ctxs[s], (const double *)src, n, &m1, &b1);
+                mx = m1 > mx ? m1 : mx;
+                bad |= b1;
+            }
+            int64_t world_rows = nrows;
+            bad |= !f64_out;
+            if (rc == RFX_OK) rc = det_world_agree(&mx, &world_rows, &bad);
+            if (rc == RFX_OK && !bad) {
+                k = det_scale(mx, world_rows, &m);
+                if (k > -1000 && k < 1000) {
+                    for (int s = 0; s < g_nshards && rc == RFX_OK; s++) {
+                        int64_t n;
+                        rfx_exec_split(nrows, g_nshards, s, NULL, &n);
+                        if (g_nshards == 1) n = nrows;
+                        if (n <= 0) continue;
+                        if (g_nshards > 1) rfx_hip_ctx_bind_thread(g_ctxs[s]);
+                        const double *src = (const double *)(is_expr ? devs[0][s] : shard_piece(ag->d_col, s));
+                        if (limbs == 2) rc = rfx_hip_fix_f64_low(g_ctxs[s], src, n, k, m, (int64_t *)devs[1][s]); /* (first: the other limb goes in place) */
+                        if (rc == RFX_OK) rc = rfx_hip_fix_f64(g_ctxs[s], src, n, k, (int64_t *)devs[0][s]);
+                    }
+                    for (int l = 0; l < limbs && rc == RFX_OK; l++) {
+                        rc = qcol_add(devs[l]);
+                        img[l] = devs[l][0];
+                    }
+                    done = rc == RFX_OK;
                 }
             }
+            if (g_nshards > 1) rfx_hip_ctx_bind_thread(g_ctx);
+            if (rc != RFX_OK) return -2;
         }
-        if (g_nshards > 1) rfx_hip_ctx_bind_thread(g_ctx);
-        if (rc != RFX_OK) return -2;
+        if (!done) continue;
+        M->det_on[a] = 1;
+        M->det_avg[a] = (unsigned char)is_avg;
+        M->det_k[a] = k;
+        M->det_m[a] = m;
+        need_count |= is_avg;
+        memset(ag, 0, sizeof(*ag));
+        ag->d_col = img[0];
+        ag->col_type = RFX_I64;
+        ag->kind = RFX_AGG_SUM;
+        if (limbs == 2) { /* the second limb: a hidden i64 SUM behind the query's own aggregates */
+            const int idx = M->nagg + M->nhidden++;
+            rfx_agg_t *lo = &M->aggs[idx];
+            memset(lo, 0, sizeof(*lo));
+            lo->d_col = img[1];
+            lo->col_type = RFX_I64;
+            lo->kind = RFX_AGG_SUM;
+            M->det_lo[a] = (signed char)idx;
+        }
     }
-    if (need_count) { /* the groups' row counts, once, behind the query's own aggregates */
-        rfx_agg_t *c = &M->aggs[M->nagg];
+    if (need_count) { /* the groups' row counts, once, behind everything else */
+        const int idx = M->nagg + M->nhidden++;
+        rfx_agg_t *c = &M->aggs[idx];
         memset(c, 0, sizeof(*c));
         for (int a = 0; a < M->nagg && !count_col; a++)
             if (M->det_on[a]) count_col = M->aggs[a].d_col; /* (a scratch image: i64) */
         c->d_col = count_col;
         c->col_type = count_type;
         c->kind = RFX_AGG_COUNT;
-        M->nhidden = 1;
+        M->det_cnt = idx;
     }
     return 0;
 }
@@ -403,7 +422,7 @@ static obj_p sel_build_groups(const rfx_groups_t *R, const sel_maps_t *M, const 
     const int nagg = M->nagg, nkeys = K->nkeys;
     obj_p ocols[RFX_MAX_AGGS] = {0}, okcols[RFX_MAX_KEYS] = {0};
     int ok = 1, enum_out = 0;
-    int64_t *hidden_cnt = NULL;
+    int64_t *hid[SEL_AGGS] = {0}; /* the hidden aggregates' result columns (second limbs, the row counts) */
     if (R->groups > 0) {
         /* every result vector first, then ONE read-back of all of them (every slice of a sliced result by the shard that holds it, over that
          * device's own link: the table construction of core/query.c:559-605 with N writers), then the 4-byte narrowing / enum decoding */
@@ -418,21 +437,24 @@ static obj_p sel_build_groups(const rfx_groups_t *R, const sel_maps_t *M, const 
                 ok = c8[a] && sel_fetch_add(&F, R->d_results[a], c8[a]);
             } else ok = sel_fetch_add(&F, R->d_results[a], RFX_AS_RAW(ocols[a]));
         }
-        if (ok && M->nhidden) {
-            hidden_cnt = (int64_t *)sel_fetch_tmp(&F, R->groups);
-            ok = hidden_cnt && sel_fetch_add(&F, R->d_results[nagg], hidden_cnt);
+        for (int j = nagg; j < nagg + M->nhidden && ok; j++) {
+            hid[j] = (int64_t *)sel_fetch_tmp(&F, R->groups);
+            ok = hid[j] && sel_fetch_add(&F, R->d_results[j], hid[j]);
         }
         if (ok) ok = rfx_exec_groups_fetch_all(g_x, R, F.n, F.src, F.dst) == RFX_OK;
         for (int a = 0; a < nagg && ok; a++) { /* reproducible sums: the integer sums back as f64 (an i64 sum's null cannot occur: no null went in, no sum leaves 63 bits) */
             if (!M->det_on[a]) continue;
             int64_t *raw = (int64_t *)RFX_AS_RAW(ocols[a]);
             double *out = (double *)RFX_AS_RAW(ocols[a]);
-            const double sc = ldexp(1.0, -M->det_k[a]); /* (a power of two: the product below is exact -- ldexp per cell cost 2.5 ms per 1e6 groups) */
-            if (M->det_avg[a]) {
-                for (int64_t g = 0; g < R->groups; g++) out[g] = hidden_cnt[g] ? ((double)raw[g] * sc) / (double)hidden_cnt[g] : NAN;
-            } else {
-                for (int64_t g = 0; g < R->groups; g++) out[g] = (double)raw[g] * sc;
-            }
+            /* (powers of two: the products below are exact -- ldexp per cell cost 2.5 ms per 1e6 groups; the second limb's scale may underflow to 0 for
+             * columns of tiny values: what it carries is below the subnormals then) */
+            const double sc = ldexp(1.0, -M->det_k[a]), sc2 = ldexp(1.0, -(M->det_k[a] + M->det_m[a]));
+            const int64_t *lo = M->det_lo[a] >= 0 ? hid[(int)M->det_lo[a]] : NULL, *cnt = M->det_cnt >= 0 ? hid[M->det_cnt] : NULL;
+            const int64_t ng = R->groups;
+            if (!lo && !M->det_avg[a]) for (int64_t g = 0; g < ng; g++) out[g] = (double)raw[g] * sc;
+            else if (!lo) for (int64_t g = 0; g < ng; g++) out[g] = cnt[g] ? ((double)raw[g] * sc) / (double)cnt[g] : NAN;
+            else if (!M->det_avg[a]) for (int64_t g = 0; g < ng; g++) out[g] = (double)raw[g] * sc + (double)lo[g] * sc2;
+            else for (int64_t g = 0; g < ng; g++) out[g] = cnt[g] ? ((double)raw[g] * sc + (double)lo[g] * sc2) / (double)cnt[g] : NAN;
         }
         if (ok) {
             enum_out = sel_key_columns_finish(K, R, okcols, k8) == SEL_OUT;
