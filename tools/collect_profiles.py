@@ -60,7 +60,12 @@ for w, pats in DOMINANT.items():
             tot += rd + wv
     traffic[w] = tot
     detail[w] = parts
-json.dump(traffic, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
+tpath = os.path.join(dst, "pmc_traffic.json")
+if os.path.exists(tpath):  # a partial round (profile_round.sh <tag> "c3w q7"): the other workloads keep their last figures
+    old = json.load(open(tpath))
+    old.update(traffic)
+    traffic = old
+json.dump(traffic, open(tpath, "w"), indent=1)
 json.dump({"tag": tag, "corrections": "FETCH_SIZE KiB x1024 x2 (gfx950 streaming-read undercount), WRITE_SIZE KiB x1024", "per_kernel": detail},
           open(os.path.join(dst, f"{tag}_pmc_detail.json"), "w"), indent=1)
 print(json.dumps(traffic, indent=1))

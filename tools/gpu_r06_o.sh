@@ -1,0 +1,8 @@
+#!/bin/bash
+# round 6, the final tree (make clean + build()): the whole GPU suite, smoke, the default bench line, rocprofv3 of the headline and of q7 (kernel stats + PMC)
+cd "$(dirname "$0")/.." || exit 1
+mkdir -p gpurun_out; export TMPDIR=/tmp
+( time timeout 3000 python -m pytest tests -q -m gpu -p no:cacheprovider ) > gpurun_out/r06o_suite.txt 2>&1; tail -8 gpurun_out/r06o_suite.txt
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
+timeout 900 python bench.py --steps 20 --warmup 5 > gpurun_out/r06o_bench.json 2> gpurun_out/r06o_bench.err; tail -1 gpurun_out/r06o_bench.err | cut -c1-1800
+timeout 1500 bash tools/profile_round.sh r06o "c3w q7" > gpurun_out/r06o_profile.log 2>&1; ls gpurun_out/prof_r06o | head -20
