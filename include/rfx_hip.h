@@ -587,6 +587,9 @@ int rfx_hip_absmax_f64(rfx_ctx_t *ctx, const double *d_in, int64_t n, double *ab
 int rfx_hip_fix_f64(rfx_ctx_t *ctx, const double *d_in, int64_t n, int k, int64_t *d_out);
 /* ... and the part of every cell that rfx_hip_fix_f64 rounded away, as a second limb: llrint((x * 2^k - rint(x * 2^k)) * 2^m), 0 <= m <= 62 (not in place) */
 int rfx_hip_fix_f64_low(rfx_ctx_t *ctx, const double *d_in, int64_t n, int k, int m, int64_t *d_out);
+/* ... and a result column of such integer sums back as f64, in place: (double)hi * sc + (double)lo * sc2 (d_lo may be NULL), divided by d_cnt[i] (may be NULL;
+ * a zero count gives NaN) */
+int rfx_hip_unfix_f64(rfx_ctx_t *ctx, int64_t *d_hi_io, const int64_t *d_lo, const int64_t *d_cnt, int64_t n, double sc, double sc2);
 
 /* ---- bucketed group keys: (xbar col width), XBARI64 core/ops.h:192-193 ----
  * d_out[r] = null for a null input, else the largest multiple of `width` (> 0) that is <= d_col[r].  Group on the result

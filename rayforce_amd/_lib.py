@@ -235,6 +235,7 @@ PROTOTYPES = {
     "rfx_hip_absmax_f64": (C.c_int, [_ctx, C.c_void_p, C.c_int64, _P(C.c_double), _P(C.c_int)]),
     "rfx_hip_fix_f64": (C.c_int, [_ctx, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
     "rfx_hip_fix_f64_low": (C.c_int, [_ctx, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]),
+    "rfx_hip_unfix_f64": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_double]),
     "rfx_hip_update_group": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, _P(Agg), _P(GroupTables)]),
     "rfx_dist_unique_id": (C.c_int, [C.c_void_p]),
     "rfx_dist_init": (C.c_int, [_ctx, C.c_int, C.c_int, C.c_void_p]),

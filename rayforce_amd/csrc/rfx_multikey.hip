@@ -343,6 +343,26 @@ extern "C" int rfx_hip_fix_f64_low(rfx_ctx_t *c, const double *d_in, int64_t n, 
     RFX_HIP_CHECK(hipGetLastError());
     return RFX_OK;
 }
+// ... and back: a result column of integer sums (hi, optionally lo) as f64 in place -- (double)hi * sc + (double)lo * sc2 (powers of two: the products are
+// exact), divided by the group's row count for an average.  No contraction (-ffp-contract=off): one rounding per operation, on every device alike.
+__global__ __launch_bounds__(RFX_BLOCK) void k_unfix_f64(i64 *hi_io, const i64 *lo, const i64 *cnt, i64 n, double sc, double sc2) {
+    for (i64 i = blockIdx.x * (i64)RFX_BLOCK + threadIdx.x; i < n; i += (i64)gridDim.x * RFX_BLOCK) {
+        double v = (double)hi_io[i] * sc;
+        if (lo) v = v + (double)lo[i] * sc2;
+        if (cnt) v = cnt[i] ? v / (double)cnt[i] : rfx_as_f64(RFX_NAN_BITS);
+        ((double *)hi_io)[i] = v;
+    }
+}
+extern "C" int rfx_hip_unfix_f64(rfx_ctx_t *c, int64_t *d_hi_io, const int64_t *d_lo, const int64_t *d_cnt, int64_t n, double sc, double sc2) {
+    RFX_REQUIRE(c, RFX_EINVAL, "NULL argument");
+    if (n <= 0) return RFX_OK;
+    RFX_REQUIRE(d_hi_io, RFX_EINVAL, "NULL argument");
+    const i64 blocks = (n + RFX_BLOCK - 1) / RFX_BLOCK;
+    hipLaunchKernelGGL(k_unfix_f64, dim3((unsigned)(blocks < (i64)c->num_cus * 8 ? blocks : (i64)c->num_cus * 8)), dim3(RFX_BLOCK), 0, c->stream, (i64 *)d_hi_io, (const i64 *)d_lo,
+                       (const i64 *)d_cnt, (i64)n, sc, sc2);
+    RFX_HIP_CHECK(hipGetLastError());
+    return RFX_OK;
+}
 extern "C" int rfx_hip_fix_f64(rfx_ctx_t *c, const double *d_in, int64_t n, int k, int64_t *d_out) {
     RFX_REQUIRE(c, RFX_EINVAL, "ctx is NULL");
     if (n <= 0) return RFX_OK;

@@ -437,12 +437,31 @@ static obj_p sel_build_groups(const rfx_groups_t *R, const sel_maps_t *M, const 
                 ok = c8[a] && sel_fetch_add(&F, R->d_results[a], c8[a]);
             } else ok = sel_fetch_add(&F, R->d_results[a], RFX_AS_RAW(ocols[a]));
         }
-        for (int j = nagg; j < nagg + M->nhidden && ok; j++) {
+        /* reproducible sums: the integer sums back as f64 (an i64 sum's null cannot occur: no null went in, no sum leaves 63 bits) -- ON THE DEVICE, in place,
+         * every slice where it lies (the hidden columns then never cross the link); a small dense result is mirrored on the host already: there below */
+        const int on_device = !R->h_block;
+        for (int a = 0; a < nagg && ok && on_device; a++) {
+            if (!M->det_on[a]) continue;
+            const double sc = ldexp(1.0, -M->det_k[a]), sc2 = ldexp(1.0, -(M->det_k[a] + M->det_m[a]));
+            const int lo = M->det_lo[a], cn = M->det_avg[a] ? M->det_cnt : -1;
+            if (R->nslices <= 1) ok = rfx_hip_unfix_f64(g_ctxs[R->nslices == 1 ? R->slice[0].shard : 0], (int64_t *)R->d_results[a], lo >= 0 ? (const int64_t *)R->d_results[lo] : NULL,
+                                                        cn >= 0 ? (const int64_t *)R->d_results[cn] : NULL, R->groups, sc, sc2) == RFX_OK;
+            else {
+                for (int i = 0; i < R->nslices && ok; i++) {
+                    const struct rfx_gslice *sl = &R->slice[i];
+                    rfx_hip_ctx_bind_thread(g_ctxs[sl->shard]);
+                    ok = rfx_hip_unfix_f64(g_ctxs[sl->shard], (int64_t *)sl->d_results[a], lo >= 0 ? (const int64_t *)sl->d_results[lo] : NULL,
+                                           cn >= 0 ? (const int64_t *)sl->d_results[cn] : NULL, sl->n, sc, sc2) == RFX_OK;
+                }
+                rfx_hip_ctx_bind_thread(g_ctx);
+            }
+        }
+        for (int j = nagg; j < nagg + M->nhidden && ok && !on_device; j++) {
             hid[j] = (int64_t *)sel_fetch_tmp(&F, R->groups);
             ok = hid[j] && sel_fetch_add(&F, R->d_results[j], hid[j]);
         }
         if (ok) ok = rfx_exec_groups_fetch_all(g_x, R, F.n, F.src, F.dst) == RFX_OK;
-        for (int a = 0; a < nagg && ok; a++) { /* reproducible sums: the integer sums back as f64 (an i64 sum's null cannot occur: no null went in, no sum leaves 63 bits) */
+        for (int a = 0; a < nagg && ok && !on_device; a++) {
             if (!M->det_on[a]) continue;
             int64_t *raw = (int64_t *)RFX_AS_RAW(ocols[a]);
             double *out = (double *)RFX_AS_RAW(ocols[a]);
