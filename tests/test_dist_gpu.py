@@ -167,6 +167,29 @@ def _worker(rank, world, port, q):
                     w = w[g0.value:g0.value + gn.value]
                     assert got[nm].shape == w.shape, (slices, det, nm, got[nm].shape, w.shape)
                     assert np.allclose(got[nm], w, rtol=1e-9, atol=1e-9) if w.dtype == np.float64 else np.array_equal(got[nm], w), (slices, det, nm)
+        # ... the hashed paths too (sparse keys; a key tuple beyond a 64-bit composite key): whole and sliced, default and two limbs
+        whole2 = dict(whole, k=whole["k"] * 1_000_003 - 5, k2=rfo.gen_i64(n, 44, 7) * (1 << 50), k3=rfo.gen_i64(n, 45, 5) * (1 << 45))
+        tab2 = H.table({c: np.ascontiguousarray(x[cut[rank]:cut[rank + 1]]) for c, x in whole2.items()})
+        for qd2 in ({"s": ("sum", "w"), "c": ("count", "a"), "by": "k"}, {"s": ("sum", "w"), "m": ("max", "a"), "by": {"k": "k", "k2": "k2", "k3": "k3"}}):
+            d2 = H.select_dict(qd2, tab2)
+            want2 = rfo.select({"from": whole2, **qd2})
+            for slices in (0, 1):
+                for det in (0, 2):
+                    assert ops.rfx_ops_set_rank_slices(slices) == 0 and ops.rfx_ops_set_deterministic(det) == 0
+                    r = ops.rfx_select(d2)
+                    assert r and not H.is_error(r), H.error_text(r)
+                    assert int(ops.rfx_last_select_on_gpu()) == 1, (qd2, slices, det)
+                    got = H.table_to_numpy(r)
+                    ops.rfx_host_drop(r)
+                    g0, gn = C.c_int64(0), C.c_int64(len(want2["k"]))
+                    if slices:
+                        ops.rfx_exec_split(len(want2["k"]), 2, rank, C.byref(g0), C.byref(gn))
+                    for nm, w in want2.items():
+                        w = w[g0.value:g0.value + gn.value]
+                        assert got[nm].shape == w.shape, (qd2, slices, det, nm, got[nm].shape, w.shape)
+                        assert np.allclose(got[nm], w, rtol=1e-9, atol=1e-9) if w.dtype == np.float64 else np.array_equal(got[nm], w), (qd2, slices, det, nm)
+            ops.rfx_host_drop(d2)
+        ops.rfx_host_drop(tab2)
         assert ncalls[0, 0] >= 3 and ncalls[1, 0] == ncalls[0, 0] and ncalls[0, 1] == ncalls[0, 0] + 2 == ncalls[1, 1], ncalls  # (one gather per rewritten aggregate ...)
         assert ncalls[0, 2] >= ncalls[0, 1] and ncalls[1, 2] == ncalls[0, 2], ncalls  # (... however many limbs; more aggregates may mean one more table exchange)
         ops.rfx_ops_set_rank_slices(0)
