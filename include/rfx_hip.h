@@ -431,6 +431,12 @@ typedef struct rfx_hash_tables {
 int rfx_hip_hash_tables_init(rfx_ctx_t *ctx, const rfx_agg_t *aggs, const rfx_hash_tables_t *t);
 int rfx_hip_group_hash_accumulate(rfx_ctx_t *ctx, const int64_t *d_key, const rfx_pred_t *preds, int npred, int logic,
                                   const rfx_agg_t *aggs, int64_t nrows, int64_t row0, const rfx_hash_tables_t *t);
+/* ... the same, and -- when the rows went straight into the device-wide table (about as many groups as rows: too large for the partitioned forms) -- every
+ * row's slot into d_row_slots[nrows] (-1: not selected) with *recorded = 1; the partitioned forms aggregate in LDS tables first, no row learns its slot there
+ * (*recorded = 0: rfx_hip_join_probe_hash_slots answers).  rfx_hip_hash_slot_first: d_ids[i] = the first row of row i's group, from its slot. */
+int rfx_hip_group_hash_accumulate_slots(rfx_ctx_t *ctx, const int64_t *d_key, const rfx_pred_t *preds, int npred, int logic, const rfx_agg_t *aggs, int64_t nrows,
+                                        int64_t row0, const rfx_hash_tables_t *t, int64_t *d_row_slots, int *recorded);
+int rfx_hip_hash_slot_first(rfx_ctx_t *ctx, const rfx_hash_tables_t *t, const int64_t *d_row_slots, int64_t nrows, int64_t *d_ids);
 /* Merge another GPU's table (same capacity) into ours: re-inserts its occupied slots. */
 int rfx_hip_hash_tables_merge(rfx_ctx_t *ctx, const rfx_agg_t *aggs, const rfx_hash_tables_t *into,
                               const rfx_hash_tables_t *from);

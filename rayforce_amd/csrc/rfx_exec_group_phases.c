@@ -193,7 +193,18 @@ static int ph_pass(void *arg, int s) {
         }
         if (rc != RFX_OK) return rc;
     } else {
-        rc = h->nrows == 0 ? RFX_OK : rfx_hip_group_hash_accumulate(c, (const int64_t *)h->key, h->preds, G->npred, G->q->logic, h->aggs, h->nrows, h->row0, &h->ht);
+        /* the row-hash route / a first-row probe on one shard will want every row's slot and group-first row: a table that takes the rows directly
+         * (about as many groups as rows) says the slots while it inserts -- the probe pass over all rows again is saved (gb_prove_tuples) */
+        const int want_slots = !G->multi && (G->rowhash || (G->q->flags & RFX_Q_PROBE_FIRST)) && h->nrows > 0 && !getenv("RFX_NO_INSERT_SLOTS");
+        h->slots_recorded = 0;
+        if (want_slots && !h->probe_slots) {
+            void *p = NULL;
+            if ((rc = rfx_hip_malloc(c, &p, (size_t)h->nrows * 8)) != RFX_OK) return rc;
+            h->probe_slots = (int64_t *)p;
+        }
+        rc = h->nrows == 0 ? RFX_OK
+                           : rfx_hip_group_hash_accumulate_slots(c, (const int64_t *)h->key, h->preds, G->npred, G->q->logic, h->aggs, h->nrows, h->row0, &h->ht,
+                                                                 want_slots ? h->probe_slots : NULL, want_slots ? &h->slots_recorded : NULL);
         if (rc == RFX_ELIMIT) {
             h->flag = 1;
             return RFX_OK;

@@ -326,9 +326,17 @@ static int gb_prove_tuples(gq_t *G) {
          * gather, a compare pass and a sync per key column); both arrays stay with the shard: a table that is large against the rows is emitted by
          * ROWS (ph_rank_emit) instead of by ranking its slots */
         void *ids = NULL, *slots = NULL;
+        const int recorded = h->slots_recorded && h->probe_slots; /* (the insert pass said every row's slot: only the groups' first rows are looked up) */
+        if (h->probe_slots && !recorded) { rfx_hip_free(c, h->probe_slots); h->probe_slots = NULL; }
         rc = rfx_hip_malloc(c, &ids, (size_t)(h->nrows ? h->nrows : 1) * 8);
-        if (rc == RFX_OK) rc = rfx_hip_malloc(c, &slots, (size_t)(h->nrows ? h->nrows : 1) * 8);
-        if (rc == RFX_OK) rc = rfx_hip_join_probe_hash_slots(c, (const int64_t *)h->key, h->nrows, &h->ht, (int64_t *)ids, (int64_t *)slots);
+        if (recorded) {
+            slots = h->probe_slots;
+            h->probe_slots = NULL;
+            if (rc == RFX_OK) rc = rfx_hip_hash_slot_first(c, &h->ht, (const int64_t *)slots, h->nrows, (int64_t *)ids);
+        } else {
+            if (rc == RFX_OK) rc = rfx_hip_malloc(c, &slots, (size_t)(h->nrows ? h->nrows : 1) * 8);
+            if (rc == RFX_OK) rc = rfx_hip_join_probe_hash_slots(c, (const int64_t *)h->key, h->nrows, &h->ht, (int64_t *)ids, (int64_t *)slots);
+        }
         int collision = 0;
         if (rc == RFX_OK && G->rowhash) {
             int64_t differ = 0;

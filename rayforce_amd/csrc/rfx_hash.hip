@@ -24,7 +24,7 @@ __device__ __host__ __forceinline__ u64 rfx_hash_fnv1a(u64 key) {
 
 
 template <int NC>
-__global__ __launch_bounds__(RFX_BLOCK) void k_group_hash(const Plan P, const HashArgs H, int *__restrict__ overflow) {
+__global__ __launch_bounds__(RFX_BLOCK) void k_group_hash(const Plan P, const HashArgs H, int *__restrict__ overflow, i64 *__restrict__ row_slot) {
     constexpr int U = (NC <= 2) ? 2 : 1;
     constexpr int E = 2 * U;
     constexpr int TILE = RFX_BLOCK * E;
@@ -48,7 +48,18 @@ __global__ __launch_bounds__(RFX_BLOCK) void k_group_hash(const Plan P, const Ha
             for (int c = 0; c < NC; c++) v[c][e] = in ? P.cols[c][row] : 0ULL;
         }
         const unsigned m = eval_preds<NC, E, RFX_MAX_PREDS>(S, v, valid);
-        if (__ballot(m != 0) == 0) continue; // wave-uniform: the slot count below is reduced across the wave
+        if (__ballot(m != 0) == 0) { // wave-uniform: the slot count below is reduced across the wave
+            if (row_slot) {
+#pragma unroll
+                for (int u = 0; u < U; u++)
+                    if ((valid >> (2 * u)) & 1u) {
+                        const i64 r = base + (i64)u * JSTRIDE;
+                        if ((valid >> (2 * u + 1)) & 1u) *(longlong2 *)(row_slot + r) = make_longlong2(-1, -1);
+                        else row_slot[r] = -1;
+                    }
+            }
+            continue;
+        }
         u64 key[E];
         sel_col<NC, E>(key, v, H.key_idx);
         i64 slot[E];
@@ -64,6 +75,16 @@ __global__ __launch_bounds__(RFX_BLOCK) void k_group_hash(const Plan P, const Ha
             }
             const u64 row = (u64)(P.row0 + base + (i64)(e >> 1) * JSTRIDE + (e & 1));
             if (row < H.first[slot[e]]) atomicMin((unsigned long long *)&H.first[slot[e]], (unsigned long long)row);
+        }
+        // every row's slot (-1: not selected), for the caller that wants it (the row-hash route: saves probing the table for all rows again)
+        if (row_slot) {
+#pragma unroll
+            for (int u = 0; u < U; u++)
+                if ((valid >> (2 * u)) & 1u) {
+                    const i64 r = base + (i64)u * JSTRIDE;
+                    if ((valid >> (2 * u + 1)) & 1u) *(longlong2 *)(row_slot + r) = make_longlong2(slot[2 * u], slot[2 * u + 1]);
+                    else row_slot[r] = slot[2 * u];
+                }
         }
         // load factor: one counter update per wave and tile that claimed slots; beyond 3/4 the launch is abandoned (grow and retry)
         for (int sft = 32; sft >= 1; sft >>= 1) fresh += __shfl_xor(fresh, sft, 64);
@@ -166,12 +187,20 @@ static int read_overflow(rfx_ctx *c, int *d_flag, const char *what) {
 }
 
 template <int NC>
-static void launch_hash(rfx_ctx *c, const Plan &P, const HashArgs &H, int grid, int *flag) {
-    hipLaunchKernelGGL((k_group_hash<NC>), dim3(grid), dim3(RFX_BLOCK), 0, c->stream, P, H, flag);
+static void launch_hash(rfx_ctx *c, const Plan &P, const HashArgs &H, int grid, int *flag, i64 *row_slot) {
+    hipLaunchKernelGGL((k_group_hash<NC>), dim3(grid), dim3(RFX_BLOCK), 0, c->stream, P, H, flag, row_slot);
 }
 
 extern "C" int rfx_hip_group_hash_accumulate(rfx_ctx_t *c, const int64_t *d_key, const rfx_pred_t *preds, int npred, int logic,
                                              const rfx_agg_t *aggs, int64_t nrows, int64_t row0, const rfx_hash_tables_t *t) {
+    return rfx_hip_group_hash_accumulate_slots(c, d_key, preds, npred, logic, aggs, nrows, row0, t, NULL, NULL);
+}
+// ... the same, and -- when the rows went straight into the device-wide table (a table too large for the partitioned forms: about as many groups as rows) --
+// every row's slot in d_row_slots[nrows] (-1: not selected), *recorded = 1.  The partitioned forms aggregate in LDS tables and merge: no row learns its slot
+// there (*recorded = 0: probe the table).
+extern "C" int rfx_hip_group_hash_accumulate_slots(rfx_ctx_t *c, const int64_t *d_key, const rfx_pred_t *preds, int npred, int logic, const rfx_agg_t *aggs, int64_t nrows,
+                                                   int64_t row0, const rfx_hash_tables_t *t, int64_t *d_row_slots, int *recorded) {
+    if (recorded) *recorded = 0;
     RFX_REQUIRE(c && d_key, RFX_EINVAL, "NULL argument");
     int rc = check_hash(aggs, t);
     if (rc != RFX_OK) return rc;
@@ -189,7 +218,7 @@ extern "C" int rfx_hip_group_hash_accumulate(rfx_ctx_t *c, const int64_t *d_key,
             t2.d_acc[a] = t->d_acc[h + a];
             t2.d_cnt[a] = t->d_cnt[h + a];
         }
-        rc = rfx_hip_group_hash_accumulate(c, d_key, preds, npred, logic, aggs, nrows, row0, &t1);
+        rc = rfx_hip_group_hash_accumulate_slots(c, d_key, preds, npred, logic, aggs, nrows, row0, &t1, d_row_slots, recorded); // (the same keys, the same slots: once)
         if (rc != RFX_OK) return rc;
         return rfx_hip_group_hash_accumulate(c, d_key, preds, npred, logic, aggs + h, nrows, row0, &t2);
     }
@@ -235,18 +264,37 @@ extern "C" int rfx_hip_group_hash_accumulate(rfx_ctx_t *c, const int64_t *d_key,
         return RFX_ELIMIT;
     }
     int grid = rfx_grid(c) * 4;
+    i64 *rs = (d_row_slots && recorded) ? (i64 *)d_row_slots : NULL;
     switch (P.ncols) {
-        case 1: launch_hash<1>(c, P, H, grid, flag); break;
-        case 2: launch_hash<2>(c, P, H, grid, flag); break;
-        case 3: launch_hash<3>(c, P, H, grid, flag); break;
-        case 4: launch_hash<4>(c, P, H, grid, flag); break;
-        case 5: launch_hash<5>(c, P, H, grid, flag); break;
-        case 6: launch_hash<6>(c, P, H, grid, flag); break;
-        case 7: launch_hash<7>(c, P, H, grid, flag); break;
-        default: launch_hash<8>(c, P, H, grid, flag); break;
+        case 1: launch_hash<1>(c, P, H, grid, flag, rs); break;
+        case 2: launch_hash<2>(c, P, H, grid, flag, rs); break;
+        case 3: launch_hash<3>(c, P, H, grid, flag, rs); break;
+        case 4: launch_hash<4>(c, P, H, grid, flag, rs); break;
+        case 5: launch_hash<5>(c, P, H, grid, flag, rs); break;
+        case 6: launch_hash<6>(c, P, H, grid, flag, rs); break;
+        case 7: launch_hash<7>(c, P, H, grid, flag, rs); break;
+        default: launch_hash<8>(c, P, H, grid, flag, rs); break;
     }
     RFX_HIP_CHECK(hipGetLastError());
-    return read_overflow(c, flag, "group_hash_accumulate");
+    rc = read_overflow(c, flag, "group_hash_accumulate");
+    if (rc == RFX_OK && rs) *recorded = 1;
+    return rc;
+}
+
+// every row's group-first row from its slot (what the probe answers beside the slot): ids[i] = first[slot[i]], the null for a row without one
+__global__ __launch_bounds__(RFX_BLOCK) void k_slot_first(const i64 *__restrict__ row_slot, const u64 *__restrict__ first, i64 n, i64 *__restrict__ ids) {
+    for (i64 i = blockIdx.x * (i64)RFX_BLOCK + threadIdx.x; i < n; i += (i64)gridDim.x * RFX_BLOCK) {
+        const i64 s = row_slot[i];
+        ids[i] = s < 0 ? RFX_NULL_I64_D : (i64)first[s];
+    }
+}
+extern "C" int rfx_hip_hash_slot_first(rfx_ctx_t *c, const rfx_hash_tables_t *t, const int64_t *d_row_slots, int64_t nrows, int64_t *d_ids) {
+    RFX_REQUIRE(c && t && t->d_first, RFX_EINVAL, "NULL argument");
+    if (nrows <= 0) return RFX_OK;
+    RFX_REQUIRE(d_row_slots && d_ids, RFX_EINVAL, "NULL argument");
+    hipLaunchKernelGGL(k_slot_first, dim3(rfx_grid(c) * 4), dim3(RFX_BLOCK), 0, c->stream, (const i64 *)d_row_slots, (const u64 *)t->d_first, (i64)nrows, (i64 *)d_ids);
+    RFX_HIP_CHECK(hipGetLastError());
+    return RFX_OK;
 }
 
 extern "C" int rfx_hip_hash_tables_merge(rfx_ctx_t *c, const rfx_agg_t *aggs, const rfx_hash_tables_t *into,

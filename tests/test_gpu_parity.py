@@ -476,6 +476,53 @@ def test_hash_primitives_pinned(eng):
     assert np.array_equal(out.cpu().numpy().view(np.uint64), want)
 
 
+@pytest.mark.parametrize("n, flags", [(5003, 0), (64_001, 0), (300_000, 2)])
+def test_insert_pass_says_every_rows_slot(eng, n, flags):
+    """rfx_hip_group_hash_accumulate_slots: when the rows go straight into the device-wide table (small inputs; RFX_TUNE_NO_PARTITION; about as many groups as
+    rows) the insert pass leaves every row's slot -- the same slots a probe of the finished table finds (-1 for rows the filter drops), and
+    rfx_hip_hash_slot_first turns them into the groups' first rows: what the row-hash route needs without probing all rows again."""
+    import ctypes as C
+    from rayforce_amd import _lib as L
+    k = rfo.gen_i64(n, 31, max(8, n // 2)) * 1_000_003 - 99
+    k[7::113] = NULL
+    a = rfo.gen_i64(n, 32, 1000)
+    dk, da = eng.column(k), eng.column(a)
+    cap = 1 << int(np.ceil(np.log2(2 * n)))
+    arr = [torch.empty(cap + 1, dtype=torch.int64, device=dk.device) for _ in range(4)]  # keys, first, acc, cnt
+    ht = L.HashTables()
+    ht.capacity, ht.nagg, ht.d_keys, ht.d_first = cap, 1, arr[0].data_ptr(), arr[1].data_ptr()
+    ht.d_acc[0], ht.d_cnt[0] = arr[2].data_ptr(), arr[3].data_ptr()
+    agg = L.Agg()
+    agg.d_col, agg.col_type, agg.kind = da.data_ptr(), L.RFX_I64, L.RFX_AGG_SUM
+    pred = L.Pred()
+    pred.d_col, pred.col_type, pred.rhs_type, pred.op, pred.rhs_i = da.data_ptr(), L.RFX_I64, L.RFX_I64, L.RFX_LT, 600
+    eng.tune(flags=flags)
+    try:
+        L.check(eng.lib.rfx_hip_hash_tables_init(eng._ctx, C.byref(agg), C.byref(ht)), "init")
+        slots = torch.full((n,), 12345, dtype=torch.int64, device=dk.device)
+        rec = C.c_int(-1)
+        L.check(eng.lib.rfx_hip_group_hash_accumulate_slots(eng._ctx, dk.data_ptr(), C.byref(pred), 1, L.RFX_AND, C.byref(agg), n, 0, C.byref(ht), slots.data_ptr(), C.byref(rec)),
+                "accumulate_slots")
+        eng.sync()
+        if n < 65_536 or flags == 2:
+            assert rec.value == 1  # (the partitioned forms decline: the device-wide kernel ran)
+        if rec.value == 1:
+            ids, pslots, mine = eng.empty(n), eng.empty(n), eng.empty(n)
+            L.check(eng.lib.rfx_hip_join_probe_hash_slots(eng._ctx, dk.data_ptr(), n, C.byref(ht), ids.data_ptr(), pslots.data_ptr()), "probe")
+            L.check(eng.lib.rfx_hip_hash_slot_first(eng._ctx, C.byref(ht), slots.data_ptr(), n, mine.data_ptr()), "slot_first")
+            eng.sync()
+            sel = torch.from_numpy(a < 600).to(dk.device)
+            assert torch.equal(slots[sel], pslots[sel]) and torch.equal(mine[sel], ids[sel])
+            assert bool((slots[~sel] == -1).all()) and bool((mine[~sel] == NULL).all())
+            first = mine[sel].cpu().numpy()
+            want_first = {}
+            for i in np.flatnonzero(a < 600):
+                want_first.setdefault(int(k[i]), int(i))
+            assert np.array_equal(first, np.array([want_first[int(x)] for x in k[a < 600]], np.int64))
+    finally:
+        eng.tune(flags=0)
+
+
 # ---------------------------------------------------------------- row-sharded driver on one rank (collectives are no-ops)
 def test_sharded_engine_single_rank(eng):
     from rayforce_amd.dist import ShardedEngine
