@@ -167,6 +167,7 @@ static int fn_id(obj_p o) {
 /* The operator layer by concern (round 5: one 3 100-line file before).  ONE translation unit -- the pieces share the lock, the residency cache and the
  * per-call scratch lists as file statics -- read in this order: */
 #include "rfx_ops_residency.c"
+#include "rfx_ops_repro.c"
 #include "rfx_ops_plan.c"
 #include "rfx_ops_select.c"
 #include "rfx_ops_update.c"
