@@ -656,7 +656,10 @@ def c_door(name, eng, rows, steps, warmup, device_columns=False):
                 same_bits = all(np.array_equal(np.ascontiguousarray(dgot[c]).view(np.uint8), np.ascontiguousarray(again[c]).view(np.uint8)) for c in dgot)
                 err = max([float(np.max(np.abs(dgot[c] - got[c]) / np.maximum(np.abs(got[c]), 1e-300))) for c in got if got[c].dtype == np.float64] + [0.0])
                 exact = all(bool(np.array_equal(dgot[c], got[c])) for c in got if got[c].dtype != np.float64)
-                if not (same_bits and exact and err <= 1e-9):
+                # (one limb rounds a cell to 2^(e + b - 62) ABSOLUTE: at the workload's full size that is far inside 1e-9 of every group's sum; a --rows run
+                #  with a handful of rows per group may hold a group of tiny values beyond it -- reported, not judged; two limbs are held to 1e-9 at any size)
+                judged = mode == 2 or rows >= 500_000_000
+                if not (same_bits and exact and (err <= 1e-9 or not judged)):
                     raise SystemExit(f"bench.py: rfx_select({name}) in reproducible mode {mode}: bit-identical between two calls {same_bits}, "
                                      f"largest relative distance from the default path {err:.3g}")
                 st = H.to_numpy(ops.rfx_stats(0))
@@ -668,7 +671,7 @@ def c_door(name, eng, rows, steps, warmup, device_columns=False):
                 det[label] = {"first_call_ms": first_ms, "kernels_ms": dk, "phases_ms": door_phases(ops, H, d),
                               "median_ms": dsteps["median"], "ms_per_step": ddt * 1e3 / min(steps, 10), "steps_ms_in_order": dsteps["in_order"],
                               "images_made": int(st[15] - st0[15]), "images_found_again": int(st[16] - st0[16]), "largest_relative_distance_from_the_default_path": err,
-                              "verified": "two calls bit-identical; every column within 1e-9 of the default path's"}
+                              "verified": "two calls bit-identical" + ("; every column within 1e-9 of the default path's" if judged else "")}
             finally:
                 ops.rfx_ops_set_deterministic(0)
     for o in ([pin, ops.rfx_unpin(tab)] if pin else []) + [d, tab]:
