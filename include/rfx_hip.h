@@ -437,6 +437,14 @@ int rfx_hip_group_hash_accumulate(rfx_ctx_t *ctx, const int64_t *d_key, const rf
 int rfx_hip_group_hash_accumulate_slots(rfx_ctx_t *ctx, const int64_t *d_key, const rfx_pred_t *preds, int npred, int logic, const rfx_agg_t *aggs, int64_t nrows,
                                         int64_t row0, const rfx_hash_tables_t *t, int64_t *d_row_slots, int *recorded);
 int rfx_hip_hash_slot_first(rfx_ctx_t *ctx, const rfx_hash_tables_t *t, const int64_t *d_row_slots, int64_t nrows, int64_t *d_ids);
+/* The PACKED form of a hashed table set (round 6; the row-hash route's device-wide table): ONE block of capacity + 1 entries of `stride` cells -- key, first
+ * row, accumulators, counts of a slot side by side, so that an insert touches one line -- described by the same struct: d_keys = the block, every other array
+ * pointer = another cell of the FIRST entry, and every index into the arrays is slot * stride.  rfx_hip_group_hash_accumulate_packed inserts the rows
+ * directly (no partitioned form) and leaves every row's SCALED slot in d_row_slots (-1: not selected); rfx_hip_hash_slot_first and rfx_hip_hash_rows_emit take
+ * such a table and such slots as they are.  RFX_ESTATE: a query this form does not carry (expression trees, too many columns for one launch). */
+int rfx_hip_hash_tables_init_packed(rfx_ctx_t *ctx, const rfx_agg_t *aggs, const rfx_hash_tables_t *t, int stride);
+int rfx_hip_group_hash_accumulate_packed(rfx_ctx_t *ctx, const int64_t *d_key, const rfx_pred_t *preds, int npred, int logic, const rfx_agg_t *aggs, int64_t nrows,
+                                         int64_t row0, const rfx_hash_tables_t *t, int stride, int64_t *d_row_slots);
 /* Merge another GPU's table (same capacity) into ours: re-inserts its occupied slots. */
 int rfx_hip_hash_tables_merge(rfx_ctx_t *ctx, const rfx_agg_t *aggs, const rfx_hash_tables_t *into,
                               const rfx_hash_tables_t *from);

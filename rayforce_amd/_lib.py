@@ -225,6 +225,8 @@ PROTOTYPES = {
     "rfx_hip_group_hash_accumulate": (C.c_int, [_ctx, C.c_void_p, _P(Pred), C.c_int, C.c_int, _P(Agg), C.c_int64, C.c_int64, _P(HashTables)]),
     "rfx_hip_group_hash_accumulate_slots": (C.c_int, [_ctx, C.c_void_p, _P(Pred), C.c_int, C.c_int, _P(Agg), C.c_int64, C.c_int64, _P(HashTables), C.c_void_p, _P(C.c_int)]),
     "rfx_hip_hash_slot_first": (C.c_int, [_ctx, _P(HashTables), C.c_void_p, C.c_int64, C.c_void_p]),
+    "rfx_hip_hash_tables_init_packed": (C.c_int, [_ctx, _P(Agg), _P(HashTables), C.c_int]),
+    "rfx_hip_group_hash_accumulate_packed": (C.c_int, [_ctx, C.c_void_p, _P(Pred), C.c_int, C.c_int, _P(Agg), C.c_int64, C.c_int64, _P(HashTables), C.c_int, C.c_void_p]),
     "rfx_hip_hash_tables_merge": (C.c_int, [_ctx, _P(Agg), _P(HashTables), _P(HashTables)]),
     "rfx_hip_hash_rank": (C.c_int, [_ctx, _P(HashTables), C.c_int64, _P(C.c_int64)]),
     "rfx_hip_hash_emit": (C.c_int, [_ctx, _P(Agg), _P(HashTables), C.c_void_p, C.c_void_p, _P(C.c_void_p)]),

@@ -135,15 +135,54 @@ static int ph_composite(void *arg, int s) {
     return RFX_OK;
 }
 
-/* tables of one shard: one block, arrays of `cells` 8-byte cells (what the exchanges and the merge kernel walk) */
+static int by_rows_env(void) { /* RFX_EMIT_BY_ROWS: 0 = the slot-ranking tail everywhere (A/B), 2 = the tail by rows wherever the probe arrays exist (tests) */
+    static int v = -1;
+    if (v < 0) v = getenv("RFX_EMIT_BY_ROWS") ? atoi(getenv("RFX_EMIT_BY_ROWS")) : 1;
+    return v;
+}
+/* the hashed pass on one shard that will want every row's slot and group-first row afterwards (the row-hash route's proof; RFX_Q_PROBE_FIRST) */
+static int want_row_slots(const gq_t *G, const shard_t *h) {
+    return !G->dense && !G->multi && (G->rowhash || (G->q->flags & RFX_Q_PROBE_FIRST)) && h->nrows > 0 && !getenv("RFX_NO_INSERT_SLOTS");
+}
+/* ... and whose table is so large against the rows that the tail will walk the ROWS (ph_rank_emit): nothing but the insert pass, the first-row look-up and
+ * the emit by rows ever reads that table -- it is laid out PACKED (one line per insert instead of one per field).  At least 2^24 slots: an estimate of 8M
+ * groups and more, where the partitioned forms of the insert decline anyway */
+static int want_packed(const gq_t *G, const shard_t *h) {
+    if (!want_row_slots(G, h) || !by_rows_env() || G->nsl != 1 || getenv("RFX_NO_PACKED_TABLE") || G->narr < 2 || G->narr > 2 + 2 * RFX_MAX_AGGS) return 0;
+    for (int a = 0; a < G->na; a++)
+        if (h->aggs[a].nxnodes > 0) return 0; /* (expression trees: the packed insert does not carry them) */
+    return by_rows_env() == 2 || (G->cap >= ((int64_t)1 << 24) && h->nrows <= 4 * (G->cap + 1));
+}
+/* tables of one shard: one block, arrays of `cells` 8-byte cells (what the exchanges and the merge kernel walk) -- or, packed, entries of narr cells */
+static int tables_layout(gq_t *G, int s, int packed) {
+    shard_t *h = &G->sh[s];
+    rfx_ctx_t *c = G->x->ctx[s];
+    const int64_t cells = G->dense ? (int64_t)G->range : G->cap + 1;
+    const int64_t step = packed ? 1 : cells;
+    int64_t *base = (int64_t *)h->store;
+    int k = 0;
+    h->packed = packed ? G->narr : 0;
+    memset(&h->ht, 0, sizeof(h->ht));
+    h->ht.capacity = G->cap;
+    h->ht.nagg = G->na;
+    h->ht.d_keys = base + (k++) * step;
+    h->ht.d_first = base + (k++) * step;
+    for (int a = 0; a < G->na; a++) {
+        h->ht.d_acc[a] = base + (k++) * step;
+        h->ht.d_cnt[a] = has_cnt(&h->aggs[a]) ? base + (k++) * step : NULL;
+    }
+    return packed ? rfx_hip_hash_tables_init_packed(c, h->aggs, &h->ht, G->narr) : rfx_hip_hash_tables_init(c, h->aggs, &h->ht);
+}
 static int tables_alloc(gq_t *G, int s) {
     shard_t *h = &G->sh[s];
     rfx_ctx_t *c = G->x->ctx[s];
     const int64_t cells = G->dense ? (int64_t)G->range : G->cap + 1;
     if (h->store) rfx_hip_free(c, h->store);
     h->store = NULL;
+    h->packed = 0;
     int rc = rfx_hip_malloc(c, &h->store, (size_t)G->narr * (size_t)cells * 8);
     if (rc != RFX_OK) return rc;
+    if (!G->dense) return tables_layout(G, s, want_packed(G, h));
     int64_t *base = (int64_t *)h->store;
     int k = 0;
     memset(&h->gt, 0, sizeof(h->gt));
@@ -195,16 +234,22 @@ static int ph_pass(void *arg, int s) {
     } else {
         /* the row-hash route / a first-row probe on one shard will want every row's slot and group-first row: a table that takes the rows directly
          * (about as many groups as rows) says the slots while it inserts -- the probe pass over all rows again is saved (gb_prove_tuples) */
-        const int want_slots = !G->multi && (G->rowhash || (G->q->flags & RFX_Q_PROBE_FIRST)) && h->nrows > 0 && !getenv("RFX_NO_INSERT_SLOTS");
+        const int want_slots = want_row_slots(G, h);
         h->slots_recorded = 0;
         if (want_slots && !h->probe_slots) {
             void *p = NULL;
             if ((rc = rfx_hip_malloc(c, &p, (size_t)h->nrows * 8)) != RFX_OK) return rc;
             h->probe_slots = (int64_t *)p;
         }
-        rc = h->nrows == 0 ? RFX_OK
-                           : rfx_hip_group_hash_accumulate_slots(c, (const int64_t *)h->key, h->preds, G->npred, G->q->logic, h->aggs, h->nrows, h->row0, &h->ht,
-                                                                 want_slots ? h->probe_slots : NULL, want_slots ? &h->slots_recorded : NULL);
+        if (h->packed) { /* (tables_alloc laid the table out packed: the rows go straight in, their scaled slots come back) */
+            rc = rfx_hip_group_hash_accumulate_packed(c, (const int64_t *)h->key, h->preds, G->npred, G->q->logic, h->aggs, h->nrows, h->row0, &h->ht, h->packed, h->probe_slots);
+            if (rc == RFX_OK) h->slots_recorded = 1;
+            else if (rc == RFX_ESTATE && (rc = tables_layout(G, s, 0)) != RFX_OK) return rc; /* a query the packed insert does not carry: field by field after all */
+        }
+        if (!h->packed)
+            rc = h->nrows == 0 ? RFX_OK
+                               : rfx_hip_group_hash_accumulate_slots(c, (const int64_t *)h->key, h->preds, G->npred, G->q->logic, h->aggs, h->nrows, h->row0, &h->ht,
+                                                                     want_slots ? h->probe_slots : NULL, want_slots ? &h->slots_recorded : NULL);
         if (rc == RFX_ELIMIT) {
             h->flag = 1;
             return RFX_OK;

@@ -154,10 +154,9 @@ static int ph_rank_emit(void *arg, int s) {
      *  8 aggregates over 4M slots would pin 300 MB for what may be a handful of groups -- the group count comes back first and the block is exact) */
     const int64_t bound0 = (slots < G->seen ? slots : G->seen) < 1 ? 1 : (slots < G->seen ? slots : G->seen);
     const int one_launch_fits = (size_t)(G->na + 1) * (size_t)(bound0 / (G->nsl > 1 ? G->nsl : 1) + 1) * 8 <= ((size_t)64 << 20);
-    static int by_rows_env = -1; /* RFX_EMIT_BY_ROWS=0: the slot-ranking form everywhere (A/B) */
-    if (by_rows_env < 0) by_rows_env = getenv("RFX_EMIT_BY_ROWS") ? atoi(getenv("RFX_EMIT_BY_ROWS")) : 1;
-    /* (RFX_EMIT_BY_ROWS=2: wherever the probe arrays exist, whatever the sizes -- how the small tests reach this path) */
-    if (by_rows_env && !G->dense && !multi && nsl == 1 && h->probe_ids && h->probe_slots && ((slots > RFX_RANK_EMIT_MAX && h->nrows <= 4 * slots) || by_rows_env == 2)) {
+    /* (RFX_EMIT_BY_ROWS=2: wherever the probe arrays exist, whatever the sizes -- how the small tests reach this path; a PACKED table has no other tail) */
+    if (h->packed && !(h->probe_ids && h->probe_slots && nsl == 1 && !multi)) { snprintf(x->err, sizeof(x->err), "rfx_exec: a packed table without its rows' slots"); return RFX_ESTATE; }
+    if (by_rows_env() && !G->dense && !multi && nsl == 1 && h->probe_ids && h->probe_slots && ((slots > RFX_RANK_EMIT_MAX && h->nrows <= 4 * slots) || by_rows_env() == 2 || h->packed)) {
         /* MANY groups in a table that is large against the rows (the row-hash route's 1e8 groups in 2.7e8 slots): the groups are the rows that head
          * their own group, in ascending order -- a compaction over the probe's first rows and one gather per table array at those rows' slots, instead
          * of five passes over the slots, a slot -> id array, an inverse permutation and a gather through it (rfx_hip_hash_rows_*) */

@@ -34,6 +34,7 @@ typedef struct {
     /* hashed path on one shard: per row the first row of its group and the table slot of its key (gb_prove_tuples' probe), kept for an emit by rows */
     int64_t *probe_ids, *probe_slots;
     int slots_recorded; /* probe_slots was written by the insert pass itself (rfx_hip_group_hash_accumulate_slots): no probe needed, only the first rows */
+    int packed;         /* > 0: the hashed table is PACKED (rfx_hip.h), this many cells per entry; probe_slots holds scaled slots */
     int probe_owned_by_result; /* (RFX_Q_PROBE_FIRST: the result took probe_ids over) */
 } shard_t;
 
@@ -98,6 +99,7 @@ static void sh_release(rfx_exec_t *x, shard_t *h, int s) {
     if (h->probe_slots) rfx_hip_free(x->ctx[s], h->probe_slots);
     h->probe_ids = h->probe_slots = NULL;
     h->slots_recorded = 0;
+    h->packed = 0;
 }
 
 /* how many of the aggregates from a0 on one pass carries: <= RFX_MAX_AGGS, <= RFX_MAX_EXPRS expressions and a handful of distinct argument

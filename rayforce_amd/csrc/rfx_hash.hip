@@ -23,8 +23,34 @@ __device__ __host__ __forceinline__ u64 rfx_hash_fnv1a(u64 key) {
 }
 
 
-template <int NC>
-__global__ __launch_bounds__(RFX_BLOCK) void k_group_hash(const Plan P, const HashArgs H, int *__restrict__ overflow, i64 *__restrict__ row_slot) {
+// A PACKED table (round 6, the row-hash route's device-wide table): entry e = the W cells [e * W, (e + 1) * W) of ONE block -- key, first row, accumulators,
+// counts side by side, so that an insert touches one line where the array-per-field layout touches one per field (four for `count, sum`: 44 GB moved for 1e8
+// inserts).  The table's array pointers are the block's first W cells' addresses and every index is e * W: find-or-insert answers that, the insert pass
+// records it as the row's "slot", and k_slot_first / k_emit_rows index the arrays with it as they always did.
+__device__ __forceinline__ i64 hash_slot_ins_packed(u64 *keys, i64 capacity, int W, u64 key, unsigned &inserted) {
+    if ((i64)key == RFX_NULL_I64_D) return capacity * W;
+    const u64 mask = (u64)capacity - 1;
+    u64 s = rfx_hash_index_u64(RFX_U64_HASH_SEED, key) & mask;
+    const i64 bound = capacity < RFX_HASH_MAX_PROBES ? capacity : RFX_HASH_MAX_PROBES;
+    for (i64 probe = 0; probe < bound; probe++) {
+        u64 *p = keys + s * (u64)W;
+        const u64 k = *p;
+        if (k == key) return (i64)(s * (u64)W);
+        if ((i64)k == RFX_NULL_I64_D) {
+            const u64 old = atomicCAS((unsigned long long *)p, (unsigned long long)RFX_NULL_I64_D, (unsigned long long)key);
+            if ((i64)old == RFX_NULL_I64_D) {
+                inserted++;
+                return (i64)(s * (u64)W);
+            }
+            if (old == key) return (i64)(s * (u64)W);
+        }
+        s = (s + 1) & mask;
+    }
+    return -1;
+}
+
+template <int NC, bool PACKED>
+__global__ __launch_bounds__(RFX_BLOCK) void k_group_hash(const Plan P, const HashArgs H, int *__restrict__ overflow, i64 *__restrict__ row_slot, int stride) {
     constexpr int U = (NC <= 2) ? 2 : 1;
     constexpr int E = 2 * U;
     constexpr int TILE = RFX_BLOCK * E;
@@ -68,7 +94,7 @@ __global__ __launch_bounds__(RFX_BLOCK) void k_group_hash(const Plan P, const Ha
         for (int e = 0; e < E; e++) {
             slot[e] = -1;
             if (!((m >> e) & 1u)) continue;
-            slot[e] = hash_slot_ins(H.keys, H.capacity, key[e], fresh);
+            slot[e] = PACKED ? hash_slot_ins_packed(H.keys, H.capacity, stride, key[e], fresh) : hash_slot_ins(H.keys, H.capacity, key[e], fresh);
             if (slot[e] < 0) {
                 atomicExch(overflow, 1);
                 continue;
@@ -187,8 +213,21 @@ static int read_overflow(rfx_ctx *c, int *d_flag, const char *what) {
 }
 
 template <int NC>
-static void launch_hash(rfx_ctx *c, const Plan &P, const HashArgs &H, int grid, int *flag, i64 *row_slot) {
-    hipLaunchKernelGGL((k_group_hash<NC>), dim3(grid), dim3(RFX_BLOCK), 0, c->stream, P, H, flag, row_slot);
+static void launch_hash(rfx_ctx *c, const Plan &P, const HashArgs &H, int grid, int *flag, i64 *row_slot, int stride = 1) {
+    if (stride > 1) hipLaunchKernelGGL((k_group_hash<NC, true>), dim3(grid), dim3(RFX_BLOCK), 0, c->stream, P, H, flag, row_slot, stride);
+    else hipLaunchKernelGGL((k_group_hash<NC, false>), dim3(grid), dim3(RFX_BLOCK), 0, c->stream, P, H, flag, row_slot, 1);
+}
+static void launch_hash_nc(rfx_ctx *c, const Plan &P, const HashArgs &H, int grid, int *flag, i64 *rs, int stride) {
+    switch (P.ncols) {
+        case 1: launch_hash<1>(c, P, H, grid, flag, rs, stride); break;
+        case 2: launch_hash<2>(c, P, H, grid, flag, rs, stride); break;
+        case 3: launch_hash<3>(c, P, H, grid, flag, rs, stride); break;
+        case 4: launch_hash<4>(c, P, H, grid, flag, rs, stride); break;
+        case 5: launch_hash<5>(c, P, H, grid, flag, rs, stride); break;
+        case 6: launch_hash<6>(c, P, H, grid, flag, rs, stride); break;
+        case 7: launch_hash<7>(c, P, H, grid, flag, rs, stride); break;
+        default: launch_hash<8>(c, P, H, grid, flag, rs, stride); break;
+    }
 }
 
 extern "C" int rfx_hip_group_hash_accumulate(rfx_ctx_t *c, const int64_t *d_key, const rfx_pred_t *preds, int npred, int logic,
@@ -265,20 +304,84 @@ extern "C" int rfx_hip_group_hash_accumulate_slots(rfx_ctx_t *c, const int64_t *
     }
     int grid = rfx_grid(c) * 4;
     i64 *rs = (d_row_slots && recorded) ? (i64 *)d_row_slots : NULL;
-    switch (P.ncols) {
-        case 1: launch_hash<1>(c, P, H, grid, flag, rs); break;
-        case 2: launch_hash<2>(c, P, H, grid, flag, rs); break;
-        case 3: launch_hash<3>(c, P, H, grid, flag, rs); break;
-        case 4: launch_hash<4>(c, P, H, grid, flag, rs); break;
-        case 5: launch_hash<5>(c, P, H, grid, flag, rs); break;
-        case 6: launch_hash<6>(c, P, H, grid, flag, rs); break;
-        case 7: launch_hash<7>(c, P, H, grid, flag, rs); break;
-        default: launch_hash<8>(c, P, H, grid, flag, rs); break;
-    }
+    launch_hash_nc(c, P, H, grid, flag, rs, 1);
     RFX_HIP_CHECK(hipGetLastError());
     rc = read_overflow(c, flag, "group_hash_accumulate");
     if (rc == RFX_OK && rs) *recorded = 1;
     return rc;
+}
+
+// ---- the packed form (see hash_slot_ins_packed): t's array pointers are the first entry's cells, `stride` the cells per entry ----
+struct PackedPat {
+    u64 v[2 + 2 * RFX_MAX_AGGS];
+};
+__global__ __launch_bounds__(RFX_BLOCK) void k_fill_packed(u64 *__restrict__ base, i64 cells, int W, const PackedPat pat) {
+    for (i64 i = blockIdx.x * (i64)RFX_BLOCK + threadIdx.x; i < cells; i += (i64)gridDim.x * RFX_BLOCK) base[i] = pat.v[i % W];
+}
+static int packed_offsets_ok(const rfx_hash_tables_t *t, int stride) { // every array one of the entry's cells, no two the same
+    unsigned seen = 0;
+    const char *b = (const char *)t->d_keys;
+    auto cell = [&](const void *p) -> int {
+        const ptrdiff_t o = (const char *)p - b;
+        if (o < 0 || (o & 7) || o / 8 >= stride || (seen & (1u << (o / 8)))) return -1;
+        seen |= 1u << (o / 8);
+        return (int)(o / 8);
+    };
+    if (cell(t->d_keys) != 0 || cell(t->d_first) < 0) return 0;
+    for (int a = 0; a < t->nagg; a++)
+        if (cell(t->d_acc[a]) < 0 || (t->d_cnt[a] && cell(t->d_cnt[a]) < 0)) return 0;
+    return 1;
+}
+extern "C" int rfx_hip_hash_tables_init_packed(rfx_ctx_t *c, const rfx_agg_t *aggs, const rfx_hash_tables_t *t, int stride) {
+    RFX_REQUIRE(c, RFX_EINVAL, "ctx is NULL");
+    int rc = check_hash(aggs, t);
+    if (rc != RFX_OK) return rc;
+    RFX_REQUIRE(stride >= 2 && stride <= 2 + 2 * RFX_MAX_AGGS && packed_offsets_ok(t, stride), RFX_EINVAL, "packed table: the arrays must be distinct cells of the first entry");
+    PackedPat pat;
+    for (int j = 0; j < stride; j++) pat.v[j] = 0; // (cells no array names: padding)
+    const u64 *b = (const u64 *)t->d_keys;
+    pat.v[0] = (u64)RFX_NULL_I64_D;
+    pat.v[(const u64 *)t->d_first - b] = (u64)RFX_INF_I64_D;
+    for (int a = 0; a < t->nagg; a++) {
+        pat.v[(const u64 *)t->d_acc[a] - b] = acc_identity(aggs[a].kind, rfx_agg_input_type(&aggs[a]) == RFX_F64);
+        if (t->d_cnt[a]) pat.v[(const u64 *)t->d_cnt[a] - b] = 0;
+    }
+    hipLaunchKernelGGL(k_fill_packed, dim3(rfx_grid(c) * 4), dim3(RFX_BLOCK), 0, c->stream, (u64 *)t->d_keys, (i64)(t->capacity + 1) * stride, stride, pat);
+    RFX_HIP_CHECK(hipGetLastError());
+    return RFX_OK;
+}
+// every row straight into the packed table, its scaled slot into d_row_slots[nrows] (-1: not selected).  RFX_ESTATE: a query this form does not carry
+// (expression trees; more columns than one launch reads): the caller lays the table out field by field and takes rfx_hip_group_hash_accumulate_slots
+extern "C" int rfx_hip_group_hash_accumulate_packed(rfx_ctx_t *c, const int64_t *d_key, const rfx_pred_t *preds, int npred, int logic, const rfx_agg_t *aggs, int64_t nrows,
+                                                    int64_t row0, const rfx_hash_tables_t *t, int stride, int64_t *d_row_slots) {
+    RFX_REQUIRE(c && d_key && d_row_slots, RFX_EINVAL, "NULL argument");
+    int rc = check_hash(aggs, t);
+    if (rc != RFX_OK) return rc;
+    RFX_REQUIRE(stride >= 2 && stride <= 2 + 2 * RFX_MAX_AGGS && packed_offsets_ok(t, stride), RFX_EINVAL, "packed table: the arrays must be distinct cells of the first entry");
+    if (nrows == 0) return RFX_OK;
+    Plan P;
+    int key_idx = 0;
+    rc = rfx_plan_build(&P, preds, npred, logic, aggs, t->nagg, d_key, &key_idx, nrows, row0);
+    if (rc == RFX_ELIMIT || (rc == RFX_OK && rfx_plan_has_deep_expr(P))) return RFX_ESTATE;
+    if (rc != RFX_OK) return rc;
+    HashArgs H;
+    memset(&H, 0, sizeof(H));
+    H.capacity = t->capacity;
+    H.key_idx = key_idx;
+    H.nagg = t->nagg;
+    H.keys = (u64 *)t->d_keys;
+    H.first = (u64 *)t->d_first;
+    for (int a = 0; a < t->nagg; a++) {
+        H.acc[a] = (u64 *)t->d_acc[a];
+        H.cnt[a] = (u64 *)t->d_cnt[a];
+    }
+    rc = rfx_ws_reserve(c, ((size_t)1 << 21) + 512);
+    if (rc != RFX_OK) return rc;
+    int *flag = (int *)c->d_ws;
+    RFX_HIP_CHECK(hipMemsetAsync(flag, 0, 16, c->stream));
+    launch_hash_nc(c, P, H, rfx_grid(c) * 4, flag, (i64 *)d_row_slots, stride);
+    RFX_HIP_CHECK(hipGetLastError());
+    return read_overflow(c, flag, "group_hash_accumulate_packed");
 }
 
 // every row's group-first row from its slot (what the probe answers beside the slot): ids[i] = first[slot[i]], the null for a row without one
