@@ -25,7 +25,7 @@ DOMINANT = {"c2": ["k_filter_aggr_plan"], "c2b": ["k_filter_aggr_plan"], "c5": [
             "q2": ["k_part_scope_hist", "k_group_dense", "k_composite", "k_mark_first", "k_group_emit", "k_slot_gid", "k_bitmap_counts", "k_fill_u64"],
             "k9": ["k_plane_", "k_part_scope_hist", "k_part_hist", "k_part_scatter", "k_part_hash_aggregate", "k_part_colscan", "k_group_hash", "k_distinct_sample", "k_mark_first", "k_group_emit",
                    "k_slot_gid", "k_bitmap_counts", "k_fill_u64"],
-            "q7": ["k_row_hash", "k_part_scope_hist", "k_part_hist", "k_part_scatter", "k_part_hash_aggregate", "k_part_colscan", "k_group_hash", "k_join_probe_hash", "k_slot_first", "k_tuple_check", "k_rep_mask", "k_gather_or", "k_gather8", "k_emit_perm", "k_group_emit_by_group", "k_rep_mask", "k_emit_rows", "k_tuple_check", "k_mask_bitmap", "k_emit_ids", "k_chunk_counts", "k_scan", "k_distinct_sample", "k_mark_first",
+            "q7": ["k_row_hash", "k_part_scope_hist", "k_part_hist", "k_part_scatter", "k_part_hash_aggregate", "k_part_colscan", "k_group_hash", "k_join_probe_hash", "k_fill_packed", "k_slot_first", "k_tuple_check", "k_rep_mask", "k_gather_or", "k_gather8", "k_emit_perm", "k_group_emit_by_group", "k_rep_mask", "k_emit_rows", "k_tuple_check", "k_mask_bitmap", "k_emit_ids", "k_chunk_counts", "k_scan", "k_distinct_sample", "k_mark_first",
                    "k_group_emit", "k_slot_gid", "k_bitmap_counts", "k_fill_u64", "k_replace_null"],
             "w2": ["k_where_once", "k_where_sample", "k_sel_bitmap", "k_chunk_counts", "k_emit_ids"], "m2": ["k_cmp_mask"]}
 
