@@ -784,6 +784,21 @@ def test_group_by_several_keys_overflow_takes_the_row_hash_path(eng):
     check_select(eng, host, {"by": {"y": "k2"}, "s": ("sum", "v")})
 
 
+def test_row_hash_path_with_more_columns_than_one_launch_reads(eng):
+    """The row-hash route with eight aggregates over eight distinct columns beside a filter column: more than one launch of the insert kernel reads
+    (RFX_MAX_COLS) -- the unpacked insert splits into two passes over the same slots; the PACKED insert (RFX_EMIT_BY_ROWS=2 takes it at this size) declines
+    (RFX_ESTATE) and the planner lays the same block out field by field and goes on (ph_pass)."""
+    n = 40_009
+    host = mk_table(n, (10, 10), (0, 0))
+    host["k2"][7::131] = NULL  # (a null key: the row-hash path)
+    for j in range(8):
+        host[f"c{j}"] = rfo.gen_f64(n, 90 + j) if j % 2 else rfo.gen_i64(n, 90 + j, 1000)
+    q = {"by": {"x": "k1", "y": "k2"}, "where": ("<", "a", 700_000)}
+    for j, fn in enumerate(("sum", "max", "sum", "min", "count", "avg", "max", "sum")):
+        q[f"o{j}"] = (fn, f"c{j}")
+    check_select(eng, host, q)
+
+
 def test_sharded_several_keys_single_rank(eng):
     from rayforce_amd.dist import ShardedEngine
     n = 200_003
@@ -1191,7 +1206,8 @@ def test_k1_plan_kernels_match_the_prebuilt_kernels(eng):
                 assert (x == y) or (isinstance(x, float) and math.isnan(x) and math.isnan(y)), (fn, col, x, y)
 
 
-@pytest.mark.parametrize("knob", ["RFX_EMIT_BY_ROWS=2", "RFX_EMIT_BY_ROWS=0", "RFX_PLH_VAR=0", "RFX_PLH_VAR=1"])
+@pytest.mark.parametrize("knob", ["RFX_EMIT_BY_ROWS=2", "RFX_EMIT_BY_ROWS=2,RFX_NO_PACKED_TABLE=1", "RFX_EMIT_BY_ROWS=2,RFX_NO_INSERT_SLOTS=1", "RFX_EMIT_BY_ROWS=0", "RFX_PLH_VAR=0",
+                                  "RFX_PLH_VAR=1"])
 def test_path_variants_in_a_process_of_their_own(built, knob):
     """Path choices that are read once per process: the hashed group-by's result emitted BY ROWS wherever the probe exists (RFX_EMIT_BY_ROWS=2: the
     route 1e8-group row-hash queries take, forced at test sizes) / by ranking the slots only (=0); the sparse-key aggregate's slot-by-slot probing forms
@@ -1201,8 +1217,8 @@ def test_path_variants_in_a_process_of_their_own(built, knob):
     import torch
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
-    name, val = knob.split("=")
-    env = dict(os.environ, **{name: val})
+    name, val = knob.split(",")[0].split("=")
+    env = dict(os.environ, **dict(kv.split("=") for kv in knob.split(",")))  # (=2 alone: the packed table with the insert pass's slots; then without either)
     here = os.path.dirname(os.path.abspath(__file__))
     sel = "row_hash or key_tuples or several_keys or join" if name == "RFX_EMIT_BY_ROWS" else "sparse or hash"
     p = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_parity.py"), os.path.join(here, "test_gpu_golden.py"), "-q", "-m", "gpu", "-x", "-p", "no:cacheprovider",
