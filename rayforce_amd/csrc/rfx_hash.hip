@@ -316,7 +316,15 @@ struct PackedPat {
     u64 v[2 + 2 * RFX_MAX_AGGS];
 };
 __global__ __launch_bounds__(RFX_BLOCK) void k_fill_packed(u64 *__restrict__ base, i64 cells, int W, const PackedPat pat) {
-    for (i64 i = blockIdx.x * (i64)RFX_BLOCK + threadIdx.x; i < cells; i += (i64)gridDim.x * RFX_BLOCK) base[i] = pat.v[i % W];
+    const i64 step = (i64)gridDim.x * RFX_BLOCK;
+    i64 i = blockIdx.x * (i64)RFX_BLOCK + threadIdx.x;
+    int r = (int)(i % W);
+    const int dr = (int)(step % W); // (the cell's place in its entry, carried along: no 64-bit division per cell)
+    for (; i < cells; i += step) {
+        base[i] = pat.v[r];
+        r += dr;
+        r -= r >= W ? W : 0;
+    }
 }
 static int packed_offsets_ok(const rfx_hash_tables_t *t, int stride) { // every array one of the entry's cells, no two the same
     unsigned seen = 0;
