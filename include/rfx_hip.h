@@ -326,6 +326,8 @@ int rfx_hip_where_once(rfx_ctx_t *ctx, const rfx_pred_t *preds, int npred, int l
 
 /* ---- K4: gather of 8-byte elements: d_out[i] = d_col[d_ids[i]] ---- */
 int rfx_hip_gather(rfx_ctx_t *ctx, const void *d_col, const int64_t *d_ids, int64_t m, void *d_out);
+/* ... up to RFX_MAX_KEYS 8-byte columns at the same ids in ONE launch (the ids are read once): d_outs[k][i] = d_cols[k][d_ids[i]] */
+int rfx_hip_gather_many(rfx_ctx_t *ctx, const void *const *d_cols, int ncols, const int64_t *d_ids, int64_t m, void *const *d_outs);
 /* The same for ids that come from OUTSIDE (the `at` operator, a MAPFILTER pair handed over by the host): an id that is null,
  * negative or >= col_len yields the typed null (NULL_I64 / NaN) as at_vec_*_by_i64 does (core/items.c:53-72) -- never a read
  * beyond the column.  rfx_hip_gather stays unchecked for ids the library produced itself. */

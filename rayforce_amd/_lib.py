@@ -202,6 +202,7 @@ PROTOTYPES = {
     "rfx_hip_where_estimate": (C.c_int, [_ctx, _P(Pred), C.c_int, C.c_int, C.c_int64, _P(C.c_int64)]),
     "rfx_hip_where_once": (C.c_int, [_ctx, _P(Pred), C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, _P(C.c_int64)]),
     "rfx_hip_gather": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "rfx_hip_gather_many": (C.c_int, [_ctx, _P(C.c_void_p), C.c_int, C.c_void_p, C.c_int64, _P(C.c_void_p)]),
     "rfx_hip_gather_checked": (C.c_int, [_ctx, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]),
     "rfx_hip_scope_i64": (C.c_int, [_ctx, C.c_void_p, _P(Pred), C.c_int, C.c_int, C.c_int64, _P(C.c_int64), _P(C.c_int64), _P(C.c_int64)]),
     "rfx_hip_group_scope": (C.c_int, [_ctx, C.c_void_p, _P(Pred), C.c_int, C.c_int, _P(Agg), C.c_int, C.c_int64, _P(C.c_int64), _P(C.c_int64), _P(C.c_int64)]),

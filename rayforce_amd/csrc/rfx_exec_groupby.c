@@ -485,9 +485,10 @@ static int gb_emit(gq_t *G) {
                     if (rc != RFX_OK) break;
                     own(x, out, cell);
                     out->d_keycols[k] = (int64_t *)cell;
-                    rc = G->rowhash ? rfx_hip_gather(c, h->keys[k], (const int64_t *)h->dfirst, g, cell)
-                                    : rfx_hip_composite_decode(c, (const int64_t *)h->dout, g, G->kmins[k], G->kmults[k], G->kmaxs[k] - G->kmins[k] + 1, (int64_t *)cell);
+                    if (!G->rowhash) rc = rfx_hip_composite_decode(c, (const int64_t *)h->dout, g, G->kmins[k], G->kmults[k], G->kmaxs[k] - G->kmins[k] + 1, (int64_t *)cell);
                 }
+                if (rc == RFX_OK && G->nkeys > 1 && G->rowhash && !G->multi) /* (every key column at the groups' first rows: ONE launch, the first rows read once) */
+                    rc = rfx_hip_gather_many(c, (const void *const *)h->keys, G->nkeys, (const int64_t *)h->dfirst, g, (void *const *)out->d_keycols);
                 if (rc == RFX_OK && q->d_mask && h->dfirst) { /* first rows among the SELECTED rows -> rows of the table */
                     void *tr = NULL;
                     rc = rfx_hip_malloc(c, &tr, (size_t)g * 8);

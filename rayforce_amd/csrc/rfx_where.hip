@@ -562,6 +562,48 @@ __global__ __launch_bounds__(RFX_BLOCK) void k_gather8(const u64 *__restrict__ c
     for (i64 i = blockIdx.x * (i64)RFX_BLOCK + threadIdx.x; i < m; i += (i64)gridDim.x * RFX_BLOCK) out[i] = col[ids[i]];
 }
 
+// ... several columns at the same ids in one launch: the ids are read once (the row-hash route's key columns at the groups' first rows: six gathers, five
+// of whose index reads were as large as the gathered column)
+struct GatherMany {
+    const u64 *col[RFX_MAX_KEYS];
+    u64 *out[RFX_MAX_KEYS];
+};
+template <int N>
+__global__ __launch_bounds__(RFX_BLOCK) void k_gather_many(const GatherMany A, const i64 *__restrict__ ids, i64 m) {
+    for (i64 i = blockIdx.x * (i64)RFX_BLOCK + threadIdx.x; i < m; i += (i64)gridDim.x * RFX_BLOCK) {
+        const i64 r = ids[i];
+        u64 v[N];
+#pragma unroll
+        for (int k = 0; k < N; k++) v[k] = A.col[k][r];
+#pragma unroll
+        for (int k = 0; k < N; k++) A.out[k][i] = v[k];
+    }
+}
+extern "C" int rfx_hip_gather_many(rfx_ctx_t *c, const void *const *d_cols, int ncols, const int64_t *d_ids, int64_t m, void *const *d_outs) {
+    RFX_REQUIRE(c, RFX_EINVAL, "ctx is NULL");
+    RFX_REQUIRE(ncols >= 1 && ncols <= RFX_MAX_KEYS && d_cols && d_outs, RFX_EINVAL, "1..RFX_MAX_KEYS columns");
+    if (m <= 0) return RFX_OK;
+    RFX_REQUIRE(d_ids, RFX_EINVAL, "NULL argument");
+    GatherMany A;
+    for (int k = 0; k < ncols; k++) {
+        RFX_REQUIRE(d_cols[k] && d_outs[k], RFX_EINVAL, "NULL column");
+        A.col[k] = (const u64 *)d_cols[k];
+        A.out[k] = (u64 *)d_outs[k];
+    }
+    for (int k = ncols; k < RFX_MAX_KEYS; k++) A.col[k] = NULL, A.out[k] = NULL;
+    const i64 blocks = (m + RFX_BLOCK - 1) / RFX_BLOCK;
+    int grid = rfx_grid(c) * 4;
+    if (blocks < grid) grid = (int)blocks;
+#define GM(N) case N: hipLaunchKernelGGL((k_gather_many<N>), dim3(grid), dim3(RFX_BLOCK), 0, c->stream, A, (const i64 *)d_ids, (i64)m); break;
+    switch (ncols) {
+        GM(1) GM(2) GM(3) GM(4) GM(5) GM(6) GM(7)
+        default: hipLaunchKernelGGL((k_gather_many<8>), dim3(grid), dim3(RFX_BLOCK), 0, c->stream, A, (const i64 *)d_ids, (i64)m); break;
+    }
+#undef GM
+    RFX_HIP_CHECK(hipGetLastError());
+    return RFX_OK;
+}
+
 extern "C" int rfx_hip_gather(rfx_ctx_t *c, const void *d_col, const int64_t *d_ids, int64_t m, void *d_out) {
     RFX_REQUIRE(c, RFX_EINVAL, "ctx is NULL");
     if (m <= 0) return RFX_OK;
