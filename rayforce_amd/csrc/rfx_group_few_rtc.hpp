@@ -21,7 +21,9 @@
 
 
 // one row folded into one group's register cells; `hit` = the row is selected and belongs to the group
-__device__ __forceinline__ void few_apply(u64 &acc, unsigned &cnt, int kind, int f64, int skip, u64 x, bool hit) {
+// (count_nulls: wave-uniform -- some lane of the wave holds a selected null in this tile; without one the null counter of an i64 sum is left alone.
+//  COUNT is not folded here: every group's selected rows are counted once per row for all aggregates, k_group_few's rsel[])
+__device__ __forceinline__ void few_apply(u64 &acc, unsigned &cnt, int kind, int f64, int skip, u64 x, bool hit, bool count_nulls) {
     switch (kind) {
         case RFX_AGG_SUM:
             if (f64) {
@@ -29,7 +31,7 @@ __device__ __forceinline__ void few_apply(u64 &acc, unsigned &cnt, int kind, int
                 acc = rfx_as_u64(rfx_as_f64(acc) + (on ? rfx_as_f64(x) : 0.0));
             } else {
                 const bool null = (i64)x == RFX_NULL_I64_D;
-                cnt += (hit && null) ? 1u : 0u;
+                if (count_nulls) cnt += (hit && null) ? 1u : 0u;
                 acc += (hit && !null) ? x : 0ULL;
             }
             break;
@@ -51,10 +53,7 @@ __device__ __forceinline__ void few_apply(u64 &acc, unsigned &cnt, int kind, int
             acc = (on && y > (i64)acc) ? (u64)y : acc;
             break;
         }
-        case RFX_AGG_COUNT:
-            acc += hit ? 1ULL : 0ULL;
-            break;
-        default: // FIRST is resolved at emit time from d_first
+        default: // COUNT: rsel[] (see above); FIRST is resolved at emit time from d_first
             break;
     }
 }
@@ -106,6 +105,12 @@ extern "C" __global__ __launch_bounds__(RFX_BLOCK) void k_group_few(const Plan P
     }
 #pragma unroll
     for (int g = 0; g < NG; g++) rfirst[g] = 0xffffffffu;
+    // Round 6: every group's selected rows, counted ONCE per row for all aggregates -- COUNT is that number, an average's divisor is that number less the
+    // nulls of its own column, and those (rcnt[a][g] under the masked fma) are only counted in tiles where some lane of the wave holds a selected null:
+    // three averages and a count beside five sums (the Q1 shape) spent 96 of ~420 vector instructions per tile on four identical counters
+    unsigned rsel[NG];
+#pragma unroll
+    for (int g = 0; g < NG; g++) rsel[g] = 0;
     if (tid < NG) {
         lfirst[tid] = 0xffffffffu;
 #pragma unroll
@@ -206,6 +211,7 @@ extern "C" __global__ __launch_bounds__(RFX_BLOCK) void k_group_few(const Plan P
             for (int g = 0; g < NG; g++) {
                 const bool hit = sel && key[e] == (u64)g;
                 hitd[e][g] = hit ? 1.0 : 0.0;
+                rsel[g] += hit ? 1u : 0u;
                 rfirst[g] = (hit && lrow < rfirst[g]) ? lrow : rfirst[g];
             }
         }
@@ -222,28 +228,40 @@ extern "C" __global__ __launch_bounds__(RFX_BLOCK) void k_group_few(const Plan P
                 // f64 accumulation: acc += x * (1.0 if the row is this group's else 0.0) -- one v_fma_f64 per (aggregate, group) where a
                 // select + add is three instructions.  x * 0.0 is only harmless for finite x, so nulls (NaN / null i64, skipped or
                 // poisoning by the aggregate's rule) and infinities are zeroed here and -- rare -- added for real on a side path.
+                bool selnul[E], anynul = false; // (an average's rcnt[a][g]: the group's selected NULLS of this column)
 #pragma unroll
                 for (int e = 0; e < E; e++) {
                     const bool sel = (m >> e) & 1u;
                     const bool nul = f64 ? rfx_isnan_bits(x[e]) : ((i64)x[e] == RFX_NULL_I64_D);
                     const bool inf = f64 && (x[e] & 0x7FFFFFFFFFFFFFFFULL) == RFX_PINF_BITS;
                     const double xd = f64 ? rfx_as_f64(x[e]) : (double)(i64)x[e];
-                    const bool valid = !nul;                                               // AVG: counted and added
                     const bool real_add = sel && (inf || (nul && kind == RFX_AGG_SUM && !skip)); // must reach the accumulator as it is
                     const double xz = (nul || inf) ? 0.0 : xd;
+                    selnul[e] = sel && nul;
+                    anynul |= selnul[e];
 #pragma unroll
-                    for (int g = 0; g < NG; g++) {
-                        racc[a][g] = rfx_as_u64(__builtin_fma(xz, hitd[e][g], rfx_as_f64(racc[a][g])));
-                        if (kind == RFX_AGG_AVG) rcnt[a][g] += (sel && valid && key[e] == (u64)g) ? 1u : 0u;
-                    }
+                    for (int g = 0; g < NG; g++) racc[a][g] = rfx_as_u64(__builtin_fma(xz, hitd[e][g], rfx_as_f64(racc[a][g])));
                     special |= real_add;
                 }
-            } else {
+                if (kind == RFX_AGG_AVG && __builtin_amdgcn_ballot_w64(anynul) != 0) { // wave-uniform: skipped by the tiles without a selected null
+#pragma unroll
+                    for (int e = 0; e < E; e++) {
+#pragma unroll
+                        for (int g = 0; g < NG; g++) rcnt[a][g] += (selnul[e] && key[e] == (u64)g) ? 1u : 0u;
+                    }
+                }
+            } else if (kind != RFX_AGG_COUNT) {
+                bool anynul = false;
+                if (kind == RFX_AGG_SUM && !f64) {
+#pragma unroll
+                    for (int e = 0; e < E; e++) anynul |= ((m >> e) & 1u) && (i64)x[e] == RFX_NULL_I64_D;
+                }
+                const bool count_nulls = __builtin_amdgcn_ballot_w64(anynul) != 0;
 #pragma unroll
                 for (int e = 0; e < E; e++) {
                     const bool sel = (m >> e) & 1u;
 #pragma unroll
-                    for (int g = 0; g < NG; g++) few_apply(racc[a][g], rcnt[a][g], kind, f64, skip, x[e], sel && key[e] == (u64)g);
+                    for (int g = 0; g < NG; g++) few_apply(racc[a][g], rcnt[a][g], kind, f64, skip, x[e], sel && key[e] == (u64)g, count_nulls);
                 }
             }
         }
@@ -278,7 +296,12 @@ extern "C" __global__ __launch_bounds__(RFX_BLOCK) void k_group_few(const Plan P
         if (rfirst[g] == 0xffffffffu) continue; // this lane saw no row of the group: its cells are identities
         atomicMin(&lfirst[g], rfirst[g]);
 #pragma unroll
-        for (int a = 0; a < NA; a++) few_merge_lds(&lacc[a][g], &lcnt[a][g], P.aggs[a].kind, P.aggs[a].f64, racc[a][g], rcnt[a][g]);
+        for (int a = 0; a < NA; a++) {
+            const int kind = P.aggs[a].kind;
+            // (COUNT: the shared counter; an average under the masked fma: the selected rows less its column's nulls)
+            few_merge_lds(&lacc[a][g], &lcnt[a][g], kind, P.aggs[a].f64, kind == RFX_AGG_COUNT ? (u64)rsel[g] : racc[a][g],
+                          (FEW_FMA && kind == RFX_AGG_AVG) ? rsel[g] - rcnt[a][g] : rcnt[a][g]);
+        }
     }
     __syncthreads();
     if (tid < NG) {
