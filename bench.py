@@ -556,6 +556,61 @@ def door_kernels(ops, H, d, steps=5):
     return [sum(col) / len(col) for col in zip(*runs)] if runs else []
 
 
+def door_clocks(ops, H, d, device_index, steps=10):
+    """What the part ran at while answering: shader clock and socket power of THIS device (hwmon: freq1_input, power1_input, power1_cap), polled by a thread
+    every millisecond over `steps` more calls, untimed by `value`.  Boxes of a pool differ most where kernels are bound by instruction issue:
+    a record that says 0.58 instead of 0.64 should also say what clock it was measured at.  None when the box does not show the files."""
+    import glob
+    import threading
+    try:
+        props = torch.cuda.get_device_properties(device_index)
+        want = f"{getattr(props, 'pci_domain_id', 0):04x}:{props.pci_bus_id:02x}:{getattr(props, 'pci_device_id', 0):02x}"
+        hw = None
+        for card in glob.glob("/sys/class/drm/card*/device"):
+            if os.path.basename(os.path.realpath(card)).lower().startswith(want):
+                hits = glob.glob(os.path.join(card, "hwmon", "hwmon*"))
+                hw = hits[0] if hits else None
+        if not hw or not os.path.exists(os.path.join(hw, "freq1_input")):
+            return None
+
+        def rd(name):
+            try:
+                with open(os.path.join(hw, name)) as f:
+                    return int(f.read().strip())
+            except (OSError, ValueError):
+                return None
+        freq, power, stop = [], [], threading.Event()
+
+        def poll():
+            while not stop.is_set():
+                a, b = rd("freq1_input"), rd("power1_input")
+                if a:
+                    freq.append(a / 1e6)
+                if b:
+                    power.append(b / 1e6)
+                time.sleep(0.001)
+        idle = rd("freq1_input")
+        th = threading.Thread(target=poll, daemon=True)
+        th.start()
+        for _ in range(steps):
+            r = ops.rfx_select(d)
+            assert r and not H.is_error(r), H.error_text(r)
+            ops.rfx_host_drop(r)
+        stop.set()
+        th.join(timeout=1.0)
+        if not freq:
+            return None
+        fs, ps = sorted(freq), sorted(power)
+        cap = rd("power1_cap")
+        return {"sclk_mhz": {"min": round(fs[0]), "median": round(fs[len(fs) // 2]), "max": round(fs[-1])},
+                "power_w": {"median": round(ps[len(ps) // 2]), "max": round(ps[-1])} if ps else None, "power_cap_w": round(cap / 1e6) if cap else None,
+                "sclk_mhz_before": round(idle / 1e6) if idle else None, "samples": len(fs), "device": want,
+                "how": f"hwmon freq1_input / power1_input of the device, one sample per millisecond over {steps} more calls after the timed loop"}
+    except Exception as e:  # noqa: BLE001  (a diagnostic: never the reason a bench line is missing)
+        log(f"[bench] door_clocks failed: {e}")
+        return None
+
+
 def door_phases(ops, H, d, steps=5):
     """The planner's per-phase wall time (rfx_exec_timing: a sync at every phase end, so the sum sits a little above the untimed step) of
     `steps` more calls, untimed by `value`: ms per step of scope / pass / merge / rank / emit / fetch and the step's total."""
@@ -623,6 +678,7 @@ def c_door(name, eng, rows, steps, warmup, device_columns=False):
     d = H.select_dict(q, tab)
     dt, got = door_run(ops, H, d, steps, warmup)
     steps_ms = dict(door_run.last_steps_ms)
+    clocks = door_clocks(ops, H, d, eng.device.index) if "by" in q and not device_columns else None  # (right after the timed loop: the state `value` was measured in)
     phases = door_phases(ops, H, d) if "by" in q else None
     try:
         kernels_ms = door_kernels(ops, H, d)
@@ -683,7 +739,7 @@ def c_door(name, eng, rows, steps, warmup, device_columns=False):
             "rows": rows, "steps": steps, "ms_per_step": dt * 1e3 / steps, "rows_per_s": rows / (dt / steps), "answered_on_gpu": 1,
             "median_ms": steps_ms["median"], "rows_per_s_median": rows / (steps_ms["median"] * 1e-3),
             "steps_ms": steps_ms, "phases_ms": phases, "kernels_ms": kernels_ms,
-            "pin_upload_s": pin_s, "deterministic_mode": det, "verified": "every result column equals Engine.select's on the same data (f64 within 1e-9)"}
+            "pin_upload_s": pin_s, "clocks": clocks, "deterministic_mode": det, "verified": "every result column equals Engine.select's on the same data (f64 within 1e-9)"}
 
 
 # ------------------------------------------------------------------------------------------------ the Amdahl budget of the sharded tail
@@ -1348,6 +1404,7 @@ def main():
                    "median_ms": r3(door["median_ms"]) if door else None, "frac_mean": r3(head.get("frac_mean")),
                    "steps": [r3(v) for v in door["steps_ms"]["in_order"]] if door else None,
                    "kernels_ms": [r3(v) for v in door.get("kernels_ms") or []] if door else None,
+                   "sclk_mhz": (door.get("clocks") or {}).get("sclk_mhz") if door else None, "power_w": (door.get("clocks") or {}).get("power_w") if door else None,
                    "phases_ms": {k: r3(v) for k, v in door["phases_ms"].items() if not isinstance(v, list)} if door and door.get("phases_ms") else None,
                    "also": {k: ([r3(v.get("ms_per_step")), r3(v.get("frac"))] + ([r3(v["rfx_select_ms_per_step"])] if "rfx_select_ms_per_step" in v else [])
                                 if "error" not in v else "error") for k, v in also.items()},
